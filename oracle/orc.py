@@ -1,0 +1,237 @@
+"""ORACLE — TEST INFRASTRUCTURE ONLY. ctypes binding of oracle/_build/liborc.so.
+
+Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may import this module; the
+product path (rustracer_amd/) never does.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB_PATH = os.path.join(_HERE, "_build", "liborc.so")
+_lib = None
+
+
+def build(force: bool = False) -> str:
+    if force or not os.path.exists(_LIB_PATH) or any(
+            os.path.getmtime(os.path.join(_HERE, f)) > os.path.getmtime(_LIB_PATH)
+            for f in os.listdir(_HERE) if f.endswith((".h", ".cpp"))):
+        subprocess.check_call(["make", "-C", _HERE, "-s"])
+    return _LIB_PATH
+
+
+class RenderParams(C.Structure):
+    _fields_ = [
+        ("xres", C.c_int32), ("yres", C.c_int32), ("crop", C.c_float * 4),
+        ("filter_kind", C.c_int32), ("filter_params", C.c_float * 4),
+        ("film_scale", C.c_float), ("max_sample_luminance", C.c_float),
+        ("cam_to_world", C.c_float * 16), ("cam_to_world_inv", C.c_float * 16),
+        ("fov", C.c_float), ("lens_radius", C.c_float), ("focal_distance", C.c_float),
+        ("spp", C.c_int32), ("sampler_dims", C.c_int32), ("sampler_mode", C.c_int32),
+        ("max_depth", C.c_int32), ("rr_threshold", C.c_float), ("light_strategy", C.c_int32),
+        ("pixel_bounds", C.c_int32 * 4), ("n_threads", C.c_int32), ("tile_size", C.c_int32),
+    ]
+
+
+class Stats(C.Structure):
+    _fields_ = [(n, C.c_uint64) for n in (
+        "camera_rays", "rays_closest", "rays_shadow", "rays_mis", "nodes_closest", "nodes_shadow", "nodes_mis",
+        "tris_closest", "tris_shadow", "tris_mis", "pdf_wi_tests", "zero_radiance", "nee_total", "path_len_sum", "scrubbed")] + [
+        ("seconds", C.c_double)]
+
+    def as_dict(self):
+        return {n: getattr(self, n) for n, _ in self._fields_}
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        build()
+        _lib = C.CDLL(_LIB_PATH)
+        L = _lib
+        L.orc_scene_new.restype = C.c_void_p
+        L.orc_scene_free.argtypes = [C.c_void_p]
+        for name in ("orc_scene_set_mesh", "orc_scene_add_mipmap", "orc_scene_add_texture", "orc_scene_add_material",
+                     "orc_scene_add_light", "orc_scene_commit", "orc_scene_bvh_sizes", "orc_scene_bvh_get", "orc_trace",
+                     "orc_render", "orc_light_distrib", "orc_li_keyed", "orc_camera_film_setup"):
+            getattr(L, name).restype = C.c_int
+        L.orc_radical_inverse.restype = C.c_float
+        L.orc_radical_inverse.argtypes = [C.c_int, C.c_uint64]
+        L.orc_next_float_up.restype = C.c_float
+        L.orc_next_float_up.argtypes = [C.c_float]
+        L.orc_next_float_down.restype = C.c_float
+        L.orc_next_float_down.argtypes = [C.c_float]
+        L.orc_gamma.restype = C.c_float
+        L.orc_rng_bounded.restype = C.c_uint32
+        L.orc_rng_bounded.argtypes = [C.c_int64, C.c_uint32, C.c_int]
+    return _lib
+
+
+def _p(a, t=C.c_float):
+    return None if a is None else a.ctypes.data_as(C.POINTER(t))
+
+
+def look_at(pos, look, up):
+    m = np.zeros((4, 4), np.float32)
+    mi = np.zeros((4, 4), np.float32)
+    lib().orc_look_at(_p(np.float32(pos)), _p(np.float32(look)), _p(np.float32(up)), _p(m), _p(mi))
+    return m, mi
+
+
+def render_params(desc, mode: int, n_threads: int = 0) -> RenderParams:
+    p = RenderParams()
+    f, c, s, it = desc.film, desc.camera, desc.sampler, desc.integrator
+    p.xres, p.yres = f.xres, f.yres
+    p.crop[:] = [float(x) for x in f.crop]
+    p.filter_kind = f.filter_kind
+    p.filter_params[:] = [float(x) for x in f.filter_params]
+    p.film_scale = f.scale
+    p.max_sample_luminance = f.max_sample_luminance
+    w2c, c2w = look_at(c.pos, c.look, c.up)  # CTM = LookAt; camera_to_world = CTM.inverse() (api.rs camera())
+    p.cam_to_world[:] = c2w.reshape(-1).tolist()
+    p.cam_to_world_inv[:] = w2c.reshape(-1).tolist()
+    p.fov, p.lens_radius, p.focal_distance = c.fov, c.lens_radius, c.focal_distance
+    p.spp, p.sampler_dims, p.sampler_mode = s.spp, s.dims, mode
+    p.max_depth, p.rr_threshold = it.max_depth, it.rr_threshold
+    p.light_strategy = 1 if it.light_strategy == "uniform" else 0
+    pb = it.pixel_bounds
+    p.pixel_bounds[:] = list(pb) if pb is not None else [0, 0, 0, 0]
+    p.n_threads = n_threads
+    p.tile_size = 16
+    return p
+
+
+class OracleScene:
+    """Oracle-side scene: builds its own SAH BVH from the unflattened description."""
+
+    def __init__(self, desc):
+        L = lib()
+        self.desc = desc
+        self.h = C.c_void_p(L.orc_scene_new())
+        P, idx, N, UV, S, mat, light, flags = desc.arrays()
+        self._keep = (P, idx, N, UV, S, mat, light, flags)
+        rc = L.orc_scene_set_mesh(self.h, _p(P), P.shape[0], _p(idx, C.c_int32), idx.shape[0], _p(N), _p(UV), _p(S),
+                                  _p(mat, C.c_int32), _p(light, C.c_int32), _p(flags, C.c_uint8))
+        assert rc == 0
+        for m in desc.mipmaps:
+            h, w = m.data.shape[:2]
+            assert L.orc_scene_add_mipmap(self.h, w, h, _p(m.data), int(m.trilinear), C.c_float(m.max_aniso), m.wrap) >= 0
+        for t in desc.textures:
+            v = np.float32(t.value)
+            mp = np.float32(t.mapping)
+            L.orc_scene_add_texture(self.h, t.kind, _p(v), t.tex1, t.tex2, t.amount, t.mip, _p(mp))
+        for m in desc.materials:
+            sl = m.slots()
+            L.orc_scene_add_material(self.h, m.kind, _p(sl, C.c_int32), int(m.remap_roughness))
+        for l in desc.lights:
+            rgb = np.float32(l.rgb)
+            vec = np.float32(l.vec)
+            l2w = None if l.l2w is None else np.ascontiguousarray(l.l2w, np.float32)
+            w2l = None if l.w2l is None else np.ascontiguousarray(l.w2l, np.float32)
+            assert L.orc_scene_add_light(self.h, l.kind, l.tri, _p(rgb), int(l.two_sided), _p(vec), l.mip, _p(l2w), _p(w2l)) >= 0
+        L.orc_scene_commit(self.h, desc.max_prims_per_node)
+
+    def __del__(self):
+        try:
+            lib().orc_scene_free(self.h)
+        except Exception:
+            pass
+
+    def bvh(self):
+        L = lib()
+        nn, npr = C.c_int(), C.c_int()
+        L.orc_scene_bvh_sizes(self.h, C.byref(nn), C.byref(npr))
+        bounds = np.zeros((nn.value, 6), np.float32)
+        offset = np.zeros(nn.value, np.uint32)
+        nprims = np.zeros(nn.value, np.uint16)
+        axis = np.zeros(nn.value, np.uint8)
+        ordered = np.zeros(npr.value, np.int32)
+        L.orc_scene_bvh_get(self.h, _p(bounds), _p(offset, C.c_uint32), _p(nprims, C.c_uint16), _p(axis, C.c_uint8), _p(ordered, C.c_int32))
+        return dict(bounds=bounds, offset=offset, n_prims=nprims, axis=axis, ordered=ordered)
+
+    def trace(self, rays: np.ndarray, any_hit: bool = False):
+        """rays (n,8) f32: o.xyz, tmax, d.xyz, pad -> dict(t, prim, b0, b1 | occluded), counters"""
+        rays = np.ascontiguousarray(rays, np.float32)
+        n = rays.shape[0]
+        out = np.zeros((n, 4), np.float32)
+        cnt = np.zeros(2, np.uint64)
+        lib().orc_trace(self.h, _p(rays), C.c_int64(n), int(any_hit), _p(out), _p(cnt, C.c_uint64))
+        if any_hit:
+            return dict(occluded=out[:, 0] > 0.5, nodes=int(cnt[0]), tris=int(cnt[1]))
+        return dict(t=out[:, 0].copy(), prim=out[:, 1].copy().view(np.int32), b0=out[:, 2].copy(), b1=out[:, 3].copy(),
+                    nodes=int(cnt[0]), tris=int(cnt[1]))
+
+    def setup(self, mode=1):
+        p = render_params(self.desc, mode)
+        r2c = np.zeros((4, 4), np.float32)
+        dxdy = np.zeros(6, np.float32)
+        table = np.zeros(256, np.float32)
+        sb = np.zeros(4, np.int32)
+        cr = np.zeros(4, np.int32)
+        lib().orc_camera_film_setup(C.byref(p), _p(r2c), _p(dxdy), _p(table), _p(sb, C.c_int32), _p(cr, C.c_int32))
+        return dict(raster_to_camera=r2c, dx_camera=dxdy[:3].copy(), dy_camera=dxdy[3:].copy(), filter_table=table,
+                    sample_bounds=sb, cropped=cr, params=p)
+
+    def render(self, mode: int = 1, n_threads: int = 0):
+        """Returns (film_xyzw (H,W,4) over the cropped pixel bounds, stats dict)."""
+        st = self.setup(mode)
+        p = st["params"]
+        p.n_threads = n_threads
+        cr = st["cropped"]
+        w, h = int(cr[2] - cr[0]), int(cr[3] - cr[1])
+        film = np.zeros((h, w, 4), np.float32)
+        stats = Stats()
+        rc = lib().orc_render(self.h, C.byref(p), _p(film), C.byref(stats))
+        assert rc == 0
+        return film, stats.as_dict()
+
+    def li_keyed(self, px, py, sample):
+        p = render_params(self.desc, 1)
+        out = np.zeros(3, np.float32)
+        lib().orc_li_keyed(self.h, C.byref(p), px, py, sample, _p(out))
+        return out
+
+    def light_distrib(self, max_voxels=None):
+        L = lib()
+        nv = np.zeros(3, np.int32)
+        strategy = 1 if self.desc.integrator.light_strategy == "uniform" else 0
+        L.orc_light_distrib(self.h, strategy, _p(nv, C.c_int32), None, None, None, C.c_int64(0))
+        total = int(nv[0]) * int(nv[1]) * int(nv[2])
+        if total == 0:
+            return dict(n_voxels=nv)
+        lim = total if max_voxels is None else min(total, max_voxels)
+        nl = len(self.desc.lights)
+        func = np.zeros((lim, nl), np.float32)
+        cdf = np.zeros((lim, nl + 1), np.float32)
+        fint = np.zeros(lim, np.float32)
+        L.orc_light_distrib(self.h, strategy, _p(nv, C.c_int32), _p(func), _p(cdf), _p(fint), C.c_int64(lim))
+        return dict(n_voxels=nv, func=func, cdf=cdf, func_int=fint)
+
+
+def film_to_rgb(film_xyzw: np.ndarray, scale: float = 1.0) -> np.ndarray:
+    f = np.ascontiguousarray(film_xyzw, np.float32)
+    out = np.zeros(f.shape[:-1] + (3,), np.float32)
+    lib().orc_film_to_rgb(_p(f), C.c_int64(f.size // 4), C.c_float(scale), _p(out))
+    return out
+
+
+def sampler_tables(spp, dims, mode, seed):
+    spp2 = 1
+    while spp2 < spp:
+        spp2 *= 2
+    o1 = np.zeros((dims, spp2), np.float32)
+    o2 = np.zeros((dims, spp2, 2), np.float32)
+    st = np.zeros(2, np.uint64)
+    lib().orc_sampler_tables(spp, dims, mode, C.c_uint64(seed), _p(o1), _p(o2), _p(st, C.c_uint64))
+    return o1, o2, st
+
+
+def rng_stream(seq, n):
+    u = np.zeros(n, np.uint32)
+    f = np.zeros(n, np.float32)
+    lib().orc_rng_stream(C.c_int64(seq), n, _p(u, C.c_uint32), _p(f))
+    return u, f

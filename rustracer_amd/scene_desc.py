@@ -1,0 +1,307 @@
+"""Host-level scene description shared by every backend binding.
+
+This is the *unflattened* input the reference's `RealApi` accumulates before `world_end`
+(rc/api.rs:174-176 `RenderOptions.primitives/lights`, :913-966 `shape()`): triangle meshes already
+in world space (rc/shapes/mesh.rs:61), one `DiffuseAreaLight` per emissive triangle in shape order
+(rc/api.rs:933-946), material/texture tables, the light list, and the Camera/Film/Sampler/Integrator
+parameters with the defaults of their `create()` functions.
+
+Pure numpy + dataclasses: no backend code is imported here.
+"""
+from __future__ import annotations
+
+from dataclasses import dataclass, field
+from typing import List, Optional, Sequence
+
+import numpy as np
+
+# --- enums shared (by value) with include/rtx_hip.h and oracle/ -------------------------------
+TEX_CONST, TEX_SCALE, TEX_MIX, TEX_IMAGE = 0, 1, 2, 3
+(MAT_MATTE, MAT_PLASTIC, MAT_METAL, MAT_MIRROR, MAT_GLASS, MAT_UBER, MAT_SUBSTRATE, MAT_MIX,
+ MAT_TRANSLUCENT) = range(9)
+LIGHT_DIFFUSE_AREA, LIGHT_POINT, LIGHT_DISTANT, LIGHT_INFINITE = 0, 1, 2, 3
+FILTER_BOX, FILTER_TRIANGLE, FILTER_GAUSSIAN, FILTER_MITCHELL = 0, 1, 2, 3
+WRAP_REPEAT, WRAP_BLACK, WRAP_CLAMP = 0, 1, 2
+SAMPLER_REF, SAMPLER_KEYED = 0, 1
+# tri_flags bits
+TRI_FLIP, TRI_HAS_N, TRI_HAS_UV, TRI_HAS_S = 1, 2, 4, 8
+# order of the 16 material parameter slots
+MAT_SLOTS = ("kd", "ks", "kr", "kt", "sigma", "roughness", "urough", "vrough", "eta", "k", "opacity",
+             "reflect", "transmit", "amount", "m1", "m2")
+
+# Metal's default eta/k come from Spectrum::from_sampled over measured copper data and the CIE
+# tables (rc/material/metal.rs:25-29, rc/cie.rs) - host-side data the build does not carry
+# (SURVEY.md §2 row 41). The widely published RGB values for copper are used as the defaults here;
+# they reach every backend as ordinary constant textures, so parity does not depend on them.
+COPPER_ETA = (0.200438, 0.924033, 1.102212)
+COPPER_K = (3.912949, 2.452848, 2.142188)
+
+
+@dataclass
+class Texture:
+    kind: int = TEX_CONST
+    value: Sequence[float] = (0.0, 0.0, 0.0)
+    tex1: int = -1
+    tex2: int = -1
+    amount: int = -1
+    mip: int = -1
+    mapping: Sequence[float] = (1.0, 1.0, 0.0, 0.0)  # su sv du dv (rc/texture/mod.rs:38-61)
+
+
+@dataclass
+class MipImage:
+    data: np.ndarray  # (h, w, 3) float32, already y-flipped / gamma-decoded / scaled (imagemap.rs:52-84)
+    trilinear: bool = False
+    max_aniso: float = 8.0
+    wrap: int = WRAP_REPEAT
+
+
+@dataclass
+class Material:
+    kind: int = MAT_MATTE
+    params: dict = field(default_factory=dict)  # slot name -> texture id (or material id for m1/m2)
+    remap_roughness: bool = True
+
+    def slots(self) -> np.ndarray:
+        return np.array([int(self.params.get(k, -1)) for k in MAT_SLOTS], dtype=np.int32)
+
+
+@dataclass
+class Light:
+    kind: int = LIGHT_DIFFUSE_AREA
+    tri: int = -1
+    rgb: Sequence[float] = (1.0, 1.0, 1.0)
+    two_sided: bool = False
+    vec: Sequence[float] = (0.0, 0.0, 0.0)  # point: position; distant: from - to
+    mip: int = -1
+    l2w: Optional[np.ndarray] = None  # 4x4 (infinite)
+    w2l: Optional[np.ndarray] = None
+
+
+@dataclass
+class Camera:
+    pos: Sequence[float] = (0.0, 0.0, 0.0)
+    look: Sequence[float] = (0.0, 0.0, 1.0)
+    up: Sequence[float] = (0.0, 1.0, 0.0)
+    fov: float = 90.0            # camera.rs:108
+    lens_radius: float = 0.0     # :84
+    focal_distance: float = 1e6  # :85
+
+
+@dataclass
+class Film:
+    xres: int = 1280  # film.rs:124-125
+    yres: int = 720
+    crop: Sequence[float] = (0.0, 1.0, 0.0, 1.0)
+    filter_kind: int = FILTER_BOX
+    filter_params: Sequence[float] = (0.5, 0.5, 0.0, 0.0)  # xwidth ywidth alpha|B C
+    scale: float = 1.0
+    max_sample_luminance: float = float("inf")
+
+
+@dataclass
+class Sampler:
+    spp: int = 16   # zerotwosequence.rs:59
+    dims: int = 4   # :60
+
+
+@dataclass
+class Integrator:
+    max_depth: int = 5           # path.rs:50
+    rr_threshold: float = 1.0    # :51
+    light_strategy: str = "spatial"  # :52
+    pixel_bounds: Optional[Sequence[int]] = None  # x0 x1 y0 y1
+
+
+class SceneDesc:
+    def __init__(self):
+        self._P: List[np.ndarray] = []
+        self._N: List[np.ndarray] = []
+        self._UV: List[np.ndarray] = []
+        self._S: List[np.ndarray] = []
+        self._idx: List[np.ndarray] = []
+        self._mat: List[np.ndarray] = []
+        self._light: List[np.ndarray] = []
+        self._flags: List[np.ndarray] = []
+        self._nv = 0
+        self._nt = 0
+        self.textures: List[Texture] = []
+        self.mipmaps: List[MipImage] = []
+        self.materials: List[Material] = []
+        self.lights: List[Light] = []
+        self.camera = Camera()
+        self.film = Film()
+        self.sampler = Sampler()
+        self.integrator = Integrator()
+        self.max_prims_per_node = 4  # bvh/mod.rs:76
+        self.name = "scene"
+
+    # ---- textures -----------------------------------------------------------------------
+    def const_tex(self, v) -> int:
+        if np.isscalar(v):
+            v = (float(v),) * 3
+        self.textures.append(Texture(TEX_CONST, tuple(float(x) for x in v)))
+        return len(self.textures) - 1
+
+    def scale_tex(self, t1: int, t2: int) -> int:
+        self.textures.append(Texture(TEX_SCALE, tex1=t1, tex2=t2))
+        return len(self.textures) - 1
+
+    def mix_tex(self, t1: int, t2: int, amount: int) -> int:
+        self.textures.append(Texture(TEX_MIX, tex1=t1, tex2=t2, amount=amount))
+        return len(self.textures) - 1
+
+    def add_mip(self, data, trilinear=False, max_aniso=8.0, wrap=WRAP_REPEAT) -> int:
+        data = np.ascontiguousarray(data, dtype=np.float32)
+        assert data.ndim == 3 and data.shape[2] == 3
+        h, w = data.shape[:2]
+        assert w & (w - 1) == 0 and h & (h - 1) == 0, "power-of-two images only (SURVEY §8(f)-2)"
+        self.mipmaps.append(MipImage(data, trilinear, max_aniso, wrap))
+        return len(self.mipmaps) - 1
+
+    def image_tex(self, mip: int, su=1.0, sv=1.0, du=0.0, dv=0.0) -> int:
+        self.textures.append(Texture(TEX_IMAGE, mip=mip, mapping=(su, sv, du, dv)))
+        return len(self.textures) - 1
+
+    def _t(self, v) -> int:
+        """int => existing texture id; number/tuple => new constant texture."""
+        if isinstance(v, (int, np.integer)) and not isinstance(v, bool):
+            return int(v)
+        return self.const_tex(v)
+
+    # ---- materials (defaults = the reference's create() functions) -----------------------
+    def matte(self, kd=0.5, sigma=0.0) -> int:  # matte.rs:22-34
+        self.materials.append(Material(MAT_MATTE, {"kd": self._t(_f(kd)), "sigma": self._t(float(sigma))}))
+        return len(self.materials) - 1
+
+    def plastic(self, kd=0.25, ks=0.25, roughness=0.1, remap=True) -> int:  # plastic.rs:25-41
+        self.materials.append(Material(MAT_PLASTIC, {"kd": self._t(_f(kd)), "ks": self._t(_f(ks)),
+                                                      "roughness": self._t(float(roughness))}, remap))
+        return len(self.materials) - 1
+
+    def metal(self, eta=COPPER_ETA, k=COPPER_K, roughness=0.01, urough=None, vrough=None, remap=True) -> int:  # metal.rs:23-47
+        p = {"eta": self._t(_f(eta)), "k": self._t(_f(k)), "roughness": self._t(float(roughness))}
+        if urough is not None:
+            p["urough"] = self._t(float(urough))
+        if vrough is not None:
+            p["vrough"] = self._t(float(vrough))
+        self.materials.append(Material(MAT_METAL, p, remap))
+        return len(self.materials) - 1
+
+    def mirror(self, kr=0.9) -> int:  # mirror.rs:22
+        self.materials.append(Material(MAT_MIRROR, {"kr": self._t(_f(kr))}))
+        return len(self.materials) - 1
+
+    def glass(self, kr=1.0, kt=1.0, index=1.5, urough=0.0, vrough=0.0, remap=True) -> int:  # glass.rs:30-38
+        self.materials.append(Material(MAT_GLASS, {"kr": self._t(_f(kr)), "kt": self._t(_f(kt)), "eta": self._t(float(index)),
+                                                    "urough": self._t(float(urough)), "vrough": self._t(float(vrough))}, remap))
+        return len(self.materials) - 1
+
+    def uber(self, kd=0.25, ks=0.25, kr=0.0, kt=0.0, roughness=0.1, urough=None, vrough=None, index=1.5,
+             opacity=1.0, remap=True) -> int:  # uber.rs:32-44
+        p = {"kd": self._t(_f(kd)), "ks": self._t(_f(ks)), "kr": self._t(_f(kr)), "kt": self._t(_f(kt)),
+             "roughness": self._t(float(roughness)), "eta": self._t(float(index)), "opacity": self._t(_f(opacity))}
+        if urough is not None:
+            p["urough"] = self._t(float(urough))
+        if vrough is not None:
+            p["vrough"] = self._t(float(vrough))
+        self.materials.append(Material(MAT_UBER, p, remap))
+        return len(self.materials) - 1
+
+    def substrate(self, kd=0.5, ks=0.5, urough=0.1, vrough=0.1, remap=True) -> int:  # substrate.rs:24-29
+        self.materials.append(Material(MAT_SUBSTRATE, {"kd": self._t(_f(kd)), "ks": self._t(_f(ks)),
+                                                        "urough": self._t(float(urough)), "vrough": self._t(float(vrough))}, remap))
+        return len(self.materials) - 1
+
+    def translucent(self, kd=0.25, ks=0.25, reflect=0.5, transmit=0.5, roughness=0.1, remap=True) -> int:  # translucent.rs:28-34
+        self.materials.append(Material(MAT_TRANSLUCENT, {"kd": self._t(_f(kd)), "ks": self._t(_f(ks)), "reflect": self._t(_f(reflect)),
+                                                          "transmit": self._t(_f(transmit)), "roughness": self._t(float(roughness))}, remap))
+        return len(self.materials) - 1
+
+    def mix(self, m1: int, m2: int, amount=0.5) -> int:  # mixmat.rs:22-30
+        self.materials.append(Material(MAT_MIX, {"m1": int(m1), "m2": int(m2), "amount": self._t(_f(amount))}))
+        return len(self.materials) - 1
+
+    # ---- geometry ------------------------------------------------------------------------
+    def add_mesh(self, P, idx, material: int, N=None, UV=None, S=None, reverse_orientation=False,
+                 emission=None, two_sided=False) -> int:
+        """Append a triangle mesh whose points are already in world space (identity CTM).
+        Returns the index of its first triangle. One DiffuseAreaLight per triangle when `emission`
+        is given (rc/api.rs:933-946), appended to the light list in triangle order."""
+        P = np.ascontiguousarray(P, dtype=np.float32).reshape(-1, 3)
+        idx = np.ascontiguousarray(idx, dtype=np.int32).reshape(-1, 3)
+        nv, nt = P.shape[0], idx.shape[0]
+        assert idx.min() >= 0 and idx.max() < nv
+        flags = (TRI_FLIP if reverse_orientation else 0)
+        self._P.append(P)
+        for lst, arr, w, bit in ((self._N, N, 3, TRI_HAS_N), (self._UV, UV, 2, TRI_HAS_UV), (self._S, S, 3, TRI_HAS_S)):
+            if arr is not None:
+                a = np.ascontiguousarray(arr, dtype=np.float32).reshape(-1, w)
+                assert a.shape[0] == nv
+                flags |= bit
+            else:
+                a = np.zeros((nv, w), dtype=np.float32)
+            lst.append(a)
+        self._idx.append(idx + self._nv)
+        self._mat.append(np.full(nt, material, dtype=np.int32))
+        self._flags.append(np.full(nt, flags, dtype=np.uint8))
+        first = self._nt
+        if emission is not None:
+            ids = np.arange(len(self.lights), len(self.lights) + nt, dtype=np.int32)
+            for t in range(nt):
+                self.lights.append(Light(LIGHT_DIFFUSE_AREA, tri=first + t, rgb=tuple(float(x) for x in emission), two_sided=two_sided))
+            self._light.append(ids)
+        else:
+            self._light.append(np.full(nt, -1, dtype=np.int32))
+        self._nv += nv
+        self._nt += nt
+        return first
+
+    def add_quad(self, p0, p1, p2, p3, material: int, **kw) -> int:
+        return self.add_mesh([p0, p1, p2, p3], [[0, 1, 2], [0, 2, 3]], material, **kw)
+
+    # ---- lights --------------------------------------------------------------------------
+    def point_light(self, pos, I=(1.0, 1.0, 1.0)) -> int:
+        self.lights.append(Light(LIGHT_POINT, rgb=tuple(I), vec=tuple(pos)))
+        return len(self.lights) - 1
+
+    def distant_light(self, frm, to, L=(1.0, 1.0, 1.0)) -> int:
+        d = np.float32(frm) - np.float32(to)
+        self.lights.append(Light(LIGHT_DISTANT, rgb=tuple(L), vec=tuple(float(x) for x in d)))
+        return len(self.lights) - 1
+
+    def infinite_light(self, mip: int, l2w=None) -> int:
+        l2w = np.eye(4, dtype=np.float32) if l2w is None else np.ascontiguousarray(l2w, dtype=np.float32)
+        w2l = np.linalg.inv(l2w.astype(np.float64)).astype(np.float32)
+        self.lights.append(Light(LIGHT_INFINITE, mip=mip, l2w=l2w, w2l=w2l))
+        return len(self.lights) - 1
+
+    # ---- flattened views -------------------------------------------------------------------
+    @property
+    def n_tris(self) -> int:
+        return self._nt
+
+    @property
+    def n_verts(self) -> int:
+        return self._nv
+
+    def arrays(self):
+        """(P, idx, N|None, UV|None, S|None, tri_material, tri_light, tri_flags) as contiguous arrays."""
+        P = np.ascontiguousarray(np.concatenate(self._P), dtype=np.float32)
+        idx = np.ascontiguousarray(np.concatenate(self._idx), dtype=np.int32)
+        flags = np.ascontiguousarray(np.concatenate(self._flags), dtype=np.uint8)
+        N = np.ascontiguousarray(np.concatenate(self._N)) if (flags & TRI_HAS_N).any() else None
+        UV = np.ascontiguousarray(np.concatenate(self._UV)) if (flags & TRI_HAS_UV).any() else None
+        S = np.ascontiguousarray(np.concatenate(self._S)) if (flags & TRI_HAS_S).any() else None
+        mat = np.ascontiguousarray(np.concatenate(self._mat), dtype=np.int32)
+        light = np.ascontiguousarray(np.concatenate(self._light), dtype=np.int32)
+        return P, idx, N, UV, S, mat, light, flags
+
+
+def _f(v):
+    """Normalise a python colour argument: texture ids (ints) pass through, numbers -> float."""
+    if isinstance(v, (int, np.integer)) and not isinstance(v, bool):
+        return int(v)
+    if np.isscalar(v):
+        return float(v)
+    return tuple(float(x) for x in v)
