@@ -1,0 +1,212 @@
+/* rtx_hip.h — C ABI of the MI355X (gfx950) wavefront path-tracing backend.
+ *
+ * This is the drop-in boundary for ONE path of abusch/rustracer: the call
+ *     renderer::render(scene, integrator, camera, num_threads, sampler, 16)
+ * made once per WorldEnd (rustracer-core/src/api.rs:1003-1010, implemented in
+ * rustracer-core/src/renderer.rs:22-143). A host (Rust in the reference; the C++ layer of
+ * include/rtx_host.h here) keeps scene parsing, the SAH BVH build and the Film; it flattens
+ * BVH nodes, triangles, material/texture tables and the light list into the plain arrays below
+ * and hands them over. Plain pointers and sizes only; nothing here knows about torch.
+ *
+ * `rc/` = rustracer-core/src/ of the reference.
+ */
+#ifndef RTX_HIP_H
+#define RTX_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define RT_OK 0
+#define RT_ERR_INVALID (-1)   /* bad argument / inconsistent description            */
+#define RT_ERR_NO_DEVICE (-2) /* no usable gfx950 device; there is NO CPU fallback  */
+#define RT_ERR_HIP (-3)       /* a HIP call failed; see rt_last_error()             */
+#define RT_ERR_OOM (-4)
+
+/* -- flattened BVH node, 32 B: replaces LinearBVHNode (rc/bvh/mod.rs:582-598) ------------ */
+typedef struct rt_bvh_node {
+  float bmin[3];
+  float bmax[3];
+  uint32_t offset;  /* leaf: first primitive (leaf order); interior: second child index */
+  uint16_t n_prims; /* 0 => interior                                                    */
+  uint8_t axis;     /* interior: split axis                                             */
+  uint8_t pad;
+} rt_bvh_node;
+
+/* -- per-triangle metadata: replaces GeometricPrimitive{shape,material,area_light}
+ *    (rc/primitive.rs:34-76) and Triangle{reverse_orientation,swaps_handedness}
+ *    (rc/shapes/mesh.rs:175-180) ---------------------------------------------------------- */
+#define RT_TRI_FLIP 1u   /* reverse_orientation ^ transform_swaps_handedness */
+#define RT_TRI_HAS_N 2u  /* mesh.n is Some                                   */
+#define RT_TRI_HAS_UV 4u /* mesh.uv is Some (else default uvs, mesh.rs:201-211) */
+#define RT_TRI_HAS_S 8u  /* mesh.s is Some                                   */
+typedef struct rt_tri_meta {
+  int32_t material; /* index into materials[]                 */
+  int32_t light;    /* index into lights[] (area light) or -1 */
+  uint32_t flags;
+  uint32_t source_index; /* triangle index before BVH re-ordering (diagnostics) */
+} rt_tri_meta;
+
+/* -- textures: replaces dyn Texture<T> (rc/texture/{constant,scale,mix,imagemap}.rs) ------ */
+enum { RT_TEX_CONST = 0, RT_TEX_SCALE = 1, RT_TEX_MIX = 2, RT_TEX_IMAGE = 3 };
+typedef struct rt_texture {
+  int32_t kind;
+  float value[3];             /* constant; float textures use value[0]                 */
+  int32_t tex1, tex2, amount; /* scale / mix operands                                  */
+  int32_t image;              /* imagemap: index into images[]                         */
+  float mapping[4];           /* UVMapping2D su sv du dv (rc/texture/mod.rs:38-61)      */
+} rt_texture;
+
+/* -- MIP pyramid built by the host: replaces MIPMap<Spectrum> (rc/mipmap.rs:46-53) --------- */
+enum { RT_WRAP_REPEAT = 0, RT_WRAP_BLACK = 1, RT_WRAP_CLAMP = 2 };
+#define RT_MAX_MIP_LEVELS 16
+typedef struct rt_image {
+  int32_t n_levels;
+  int32_t width[RT_MAX_MIP_LEVELS], height[RT_MAX_MIP_LEVELS];
+  uint64_t offset[RT_MAX_MIP_LEVELS]; /* texel offset of each level inside `texels` (RGB f32) */
+  const float* texels;                /* all levels, row-major, 3 floats per texel            */
+  uint64_t n_texels;
+  int32_t trilinear;
+  float max_anisotropy;
+  int32_t wrap;
+} rt_image;
+
+/* -- materials: replaces dyn Material (rc/material/*.rs) ----------------------------------- */
+enum { RT_MAT_MATTE = 0, RT_MAT_PLASTIC, RT_MAT_METAL, RT_MAT_MIRROR, RT_MAT_GLASS, RT_MAT_UBER, RT_MAT_SUBSTRATE, RT_MAT_MIX, RT_MAT_TRANSLUCENT };
+enum { RT_SLOT_KD = 0, RT_SLOT_KS, RT_SLOT_KR, RT_SLOT_KT, RT_SLOT_SIGMA, RT_SLOT_ROUGHNESS, RT_SLOT_UROUGH, RT_SLOT_VROUGH,
+       RT_SLOT_ETA, RT_SLOT_K, RT_SLOT_OPACITY, RT_SLOT_REFLECT, RT_SLOT_TRANSMIT, RT_SLOT_AMOUNT, RT_SLOT_M1, RT_SLOT_M2, RT_N_SLOTS };
+typedef struct rt_material {
+  int32_t kind;
+  int32_t slot[RT_N_SLOTS]; /* texture ids (material ids for M1/M2); -1 = absent */
+  int32_t remap_roughness;
+} rt_material;
+
+/* -- lights: replaces dyn Light (rc/light/{diffuse,point,distant,infinite}.rs) ------------- */
+enum { RT_LIGHT_DIFFUSE_AREA = 0, RT_LIGHT_POINT = 1, RT_LIGHT_DISTANT = 2, RT_LIGHT_INFINITE = 3 };
+typedef struct rt_light {
+  int32_t kind;
+  int32_t prim;      /* area: emitting triangle, LEAF-ORDER index          */
+  float rgb[3];      /* area: L_emit; point: I; distant: L                 */
+  int32_t two_sided;
+  float vec[3];      /* point: position; distant: normalised direction     */
+  float area;        /* area: Shape::area()                                */
+  float world_radius; /* distant / infinite: scene bounding-sphere radius  */
+  int32_t image;     /* infinite: Lmap pyramid                             */
+  float l2w[12], w2l[12]; /* infinite: 3x4 light<->world                   */
+  /* infinite: Distribution2D over (2*w) x (2*h) (rc/light/infinite.rs:80-101), host-built */
+  int32_t dist_nu, dist_nv;
+  const float* dist_func;     /* nv*nu                */
+  const float* dist_cdf;      /* nv*(nu+1)            */
+  const float* dist_func_int; /* nv                   */
+  const float* marg_func;     /* nv                   */
+  const float* marg_cdf;      /* nv+1                 */
+  float marg_func_int;
+} rt_light;
+
+/* -- the flattened scene handed over at WorldEnd -------------------------------------------- */
+typedef struct rt_scene_desc {
+  uint32_t n_nodes;
+  const rt_bvh_node* nodes; /* pre-order, left child = i+1 (rc/bvh/mod.rs:314-358)          */
+  uint32_t n_tris;
+  const float* tri_p;       /* n_tris*9, world space, LEAF ORDER (p0 p1 p2)                  */
+  const float* tri_n;       /* n_tris*9 or NULL                                              */
+  const float* tri_uv;      /* n_tris*6 or NULL                                              */
+  const float* tri_s;       /* n_tris*9 or NULL                                              */
+  const rt_tri_meta* tri_meta;
+  uint32_t n_textures; const rt_texture* textures;
+  uint32_t n_images; const rt_image* images;
+  uint32_t n_materials; const rt_material* materials;
+  uint32_t n_lights; const rt_light* lights; /* order = Scene::lights (rc/scene.rs:24)       */
+} rt_scene_desc;
+
+/* -- what renderer::render receives through &dyn Camera / Film / Sampler / Integrator ------- */
+typedef struct rt_camera {        /* PerspectiveCamera (rc/camera.rs:18-27)        */
+  float raster_to_camera[16];     /* 4x4 projective                                */
+  float camera_to_world[16];
+  float dx_camera[3], dy_camera[3];
+  float lens_radius, focal_distance;
+} rt_camera;
+typedef struct rt_film_desc {     /* Film (rc/film.rs:45-55)                       */
+  int32_t cropped_pixel_bounds[4]; /* x0 y0 x1 y1                                  */
+  int32_t sample_bounds[4];        /* Film::get_sample_bounds, x0 y0 x1 y1         */
+  float filter_radius[2];
+  float filter_table[256];         /* 16x16, film.rs:16-17,92-102                  */
+  float max_sample_luminance;
+} rt_film_desc;
+typedef struct rt_sampler_desc {  /* ZeroTwoSequence (rc/sampler/zerotwosequence.rs) */
+  int32_t spp;                    /* rounded up to a power of two by the callee    */
+  int32_t dimensions;             /* "dimensions", default 4                       */
+} rt_sampler_desc;
+typedef struct rt_path_desc {     /* PathIntegrator (rc/integrator/path.rs:25-31)  */
+  int32_t max_depth;
+  float rr_threshold;
+  int32_t light_strategy;         /* 0 "spatial" (voxel CDF, rc/lightdistrib.rs), 1 "uniform" */
+  int32_t pixel_bounds[4];        /* x0 y0 x1 y1                                    */
+} rt_path_desc;
+/* Film sharding for multi-GPU: this call renders the 16-pixel tile rows r with
+ * r % world_size == rank; pixels of other rows stay zero in the output. */
+typedef struct rt_shard { int32_t rank, world_size; } rt_shard;
+
+typedef struct rt_stats {
+  uint64_t camera_rays;
+  uint64_t rays_closest, rays_shadow, rays_mis;  /* ray casts by class            */
+  uint64_t nodes_closest, nodes_shadow, nodes_mis; /* BVH node visits (0 unless counting is on) */
+  uint64_t tris_closest, tris_shadow, tris_mis;    /* triangle tests                */
+  uint64_t paths_scrubbed;                       /* NaN / negative / inf samples set to black (renderer.rs:115-126) */
+  double ms_total;                               /* rt_render wall time, device-synchronised */
+  double ms_sampler, ms_raygen, ms_trace_closest, ms_trace_any, ms_trace_mis, ms_shade, ms_resolve, ms_film, ms_lightdist; /* HIP-event times */
+  uint64_t launches_trace_closest;               /* number of trace_closest launches (path + MIS) */
+  uint64_t n_passes;
+} rt_stats;
+
+#define RT_FLAG_COUNT_TRAVERSAL 1u /* fill nodes_ and tris_ counters (slower)                  */
+#define RT_FLAG_FILM_ON_DEVICE 2u  /* film_xyzw is a device pointer (HBM-resident output)      */
+#define RT_FLAG_TIME_KERNELS 4u    /* fill the per-kernel ms_ fields with HIP events           */
+
+typedef struct rt_scene rt_scene;
+
+/* Uploads the flattened scene (copies every array; the caller may free its own afterwards).
+ * device < 0 => the current HIP device. Replaces Scene::new + BVH ownership (rc/scene.rs:29-49). */
+int rt_scene_create(const rt_scene_desc* desc, int device, rt_scene** out);
+void rt_scene_destroy(rt_scene* scene);
+
+/* Renders one frame: the body of renderer::render (rc/renderer.rs:22-143) — preprocess (light
+ * distribution), per-pixel sampler tables, camera rays, PathIntegrator::li for every sample,
+ * radiance scrubbing and Film::add_sample/merge. Blocking. film_xyzw: W*H*4 floats over the
+ * cropped pixel bounds, (X, Y, Z, filter_weight_sum) per pixel as Film's Pixel (film.rs:38-43).
+ * `stream` is a hipStream_t (NULL = the null stream). */
+int rt_render(rt_scene* scene, const rt_camera* camera, const rt_film_desc* film, const rt_sampler_desc* sampler,
+              const rt_path_desc* path, const rt_shard* shard, uint32_t flags, void* stream, float* film_xyzw, rt_stats* stats);
+
+/* Kernel-level entry points used by the parity tests.
+ * rays: n*8 floats (o.xyz, t_max, d.xyz, unused). closest: hits n*4 floats (t, prim as int bits
+ * or -1, b0, b1) — BVH::intersect (rc/bvh/mod.rs:366-433). any: hits n uint32 0/1 —
+ * BVH::intersect_p (:435-501). counters (optional): {node visits, triangle tests}. Host pointers. */
+int rt_trace_closest(rt_scene* scene, const float* rays, uint64_t n, float* hits, uint64_t counters[2]);
+int rt_trace_any(rt_scene* scene, const float* rays, uint64_t n, uint32_t* occluded, uint64_t counters[2]);
+/* Same kernels on device-resident buffers, timed with HIP events on `stream` (bench): returns the
+ * average milliseconds per launch over `reps` launches in *ms_per_launch. */
+int rt_trace_closest_device(rt_scene* scene, const void* d_rays, uint64_t n, void* d_hits, int reps, void* stream, float* ms_per_launch);
+
+/* ZeroTwoSequence::start_pixel in the pixel-keyed mode: for pixels
+ * [pixel0, pixel0+n_pixels) returns the 12 scramble words and the post-shuffle sample index
+ * permutation of each of the 2*dimensions tables. scrambles: n_pixels*3*dimensions u32
+ * (1D dims first, then 2D pairs); perms: n_pixels*2*dimensions*spp u16. Host pointers. */
+int rt_sampler_tables(int32_t spp, int32_t dimensions, uint64_t pixel0, uint64_t n_pixels, uint32_t* scrambles, uint16_t* perms);
+
+/* Dense voxel light distribution of SpatialLightDistribution (rc/lightdistrib.rs:101-179):
+ * n_voxels[3]; func: nvox*n_lights, cdf: nvox*(n_lights+1), func_int: nvox (host pointers, may be NULL
+ * to query n_voxels only). */
+int rt_light_distribution(rt_scene* scene, int32_t n_voxels[3], float* func, float* cdf, float* func_int);
+
+const char* rt_last_error(void);
+/* 1 if a gfx950 device is visible to this process, else 0 (never falls back to a CPU path). */
+int rt_device_available(void);
+const char* rt_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* RTX_HIP_H */

@@ -1,0 +1,78 @@
+/* rtx_host.h — host-side layer above the C ABI of rtx_hip.h.
+ *
+ * In the reference this layer is Rust: `RealApi` accumulates shapes, materials and lights
+ * (rustracer-core/src/api.rs:913-966), `world_end` builds camera + film + sampler + integrator +
+ * Scene(BVH) (api.rs:977-1010) and calls `renderer::render`. No Rust toolchain exists in this
+ * image, so the same responsibilities are written in C++ here, with the reference's names and
+ * defaults, and everything device-side goes through rtx_hip.h:
+ *   - BVH::new / recursive_build (SAH, 12 buckets) / flatten_bvh      rc/bvh/mod.rs:80-358
+ *   - TriangleMesh world-space vertices, one DiffuseAreaLight per emissive triangle  rc/api.rs:933-946
+ *   - MIPMap pyramid construction (power-of-two images)                rc/mipmap.rs:158-187
+ *   - InfiniteAreaLight sampling distribution                          rc/light/infinite.rs:78-101
+ *   - PerspectiveCamera::new, Film::new (filter table, bounds), filters rc/camera.rs:30-72, rc/film.rs:58-115,249-257
+ *   - Scene::new light preprocess (world bounding sphere)              rc/scene.rs:29-49
+ * This library contains no rendering arithmetic of its own: radiance comes from the HIP kernels only.
+ */
+#ifndef RTX_HOST_H
+#define RTX_HOST_H
+#include <stdint.h>
+#include "rtx_hip.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct rtxh_scene rtxh_scene;
+
+typedef struct rtxh_render_params {
+  int32_t xres, yres;
+  float crop[4];           /* cropwindow xmin xmax ymin ymax                       film.rs:126-136 */
+  int32_t filter_kind;     /* 0 box 1 triangle 2 gaussian 3 mitchell               rc/filter       */
+  float filter_params[4];  /* xwidth ywidth alpha|B C                                             */
+  float film_scale, max_sample_luminance;
+  float cam_to_world[16], cam_to_world_inv[16]; /* Transform{m, m_inv} of CTM.inverse()            */
+  float fov, lens_radius, focal_distance;       /* camera.rs:84-113                                */
+  int32_t spp, sampler_dims;                    /* zerotwosequence.rs:58-63                        */
+  int32_t max_depth; float rr_threshold; int32_t light_strategy; /* path.rs:49-53                  */
+  int32_t pixel_bounds[4]; /* x0 x1 y0 y1; x1 <= x0 => film sample bounds                          */
+  int32_t rank, world_size; /* film sharding (tile rows interleaved over ranks)                    */
+  uint32_t flags;           /* RT_FLAG_*                                                           */
+} rtxh_render_params;
+
+rtxh_scene* rtxh_scene_new(void);
+void rtxh_scene_free(rtxh_scene*);
+/* Triangle soup of all `Shape "trianglemesh"` calls, world space; tri_light = index into the light
+ * list of that triangle's DiffuseAreaLight or -1; tri_flags = RT_TRI_* (per-mesh attributes). */
+int rtxh_scene_set_mesh(rtxh_scene*, const float* P, int32_t n_verts, const int32_t* indices, int32_t n_tris, const float* N, const float* UV,
+                        const float* S, const int32_t* tri_material, const int32_t* tri_light, const uint8_t* tri_flags);
+int rtxh_scene_add_mipmap(rtxh_scene*, int32_t width, int32_t height, const float* rgb, int32_t trilinear, float max_aniso, int32_t wrap);
+int rtxh_scene_add_texture(rtxh_scene*, int32_t kind, const float* value3, int32_t tex1, int32_t tex2, int32_t amount, int32_t mip, const float* mapping4);
+int rtxh_scene_add_material(rtxh_scene*, int32_t kind, const int32_t* slots16, int32_t remap_roughness);
+int rtxh_scene_add_light(rtxh_scene*, int32_t kind, int32_t tri, const float* rgb3, int32_t two_sided, const float* vec3, int32_t mip,
+                         const float* l2w16, const float* w2l16);
+/* BVH::create(prims, "sah", maxnodeprims) + Scene::new; flattens everything into an rt_scene_desc. */
+int rtxh_scene_commit(rtxh_scene*, int32_t max_prims_per_node);
+/* Uploads the flattened scene to the current HIP device (rt_scene_create). Fails without a GPU. */
+int rtxh_scene_upload(rtxh_scene*, int32_t device);
+
+/* Inspection of the host-side products (CPU only; used by the parity tests against the oracle). */
+int rtxh_scene_bvh_sizes(rtxh_scene*, int32_t* n_nodes, int32_t* n_prims);
+int rtxh_scene_bvh_get(rtxh_scene*, float* bounds6, uint32_t* offset, uint16_t* n_prims, uint8_t* axis, int32_t* ordered);
+int rtxh_camera_film_setup(const rtxh_render_params*, float* raster_to_camera16, float* dxdy6, float* filter_table256, int32_t* sample_bounds4,
+                           int32_t* cropped4);
+int rtxh_mip_level(rtxh_scene*, int32_t mip, int32_t level, int32_t* w, int32_t* h, float* rgb_out /* may be NULL */);
+int rtxh_look_at(const float* pos, const float* look, const float* up, float* m16, float* m_inv16);
+
+/* renderer::render through the HIP backend. film_xyzw: (y1-y0)*(x1-x0)*4 floats over the cropped pixel bounds
+ * (host pointer, or device pointer with RT_FLAG_FILM_ON_DEVICE). */
+int rtxh_render(rtxh_scene*, const rtxh_render_params*, void* hip_stream, float* film_xyzw, rt_stats* stats);
+/* Kernel-level pass-throughs on the uploaded scene (prim indices are leaf-order). */
+int rtxh_trace(rtxh_scene*, const float* rays, uint64_t n, int32_t any_hit, float* hits4_or_occ, uint64_t counters[2]);
+int rtxh_trace_device(rtxh_scene*, const void* d_rays, uint64_t n, void* d_hits, int32_t reps, void* hip_stream, float* ms_per_launch);
+int rtxh_light_distribution(rtxh_scene*, int32_t n_voxels[3], float* func, float* cdf, float* func_int);
+const char* rtxh_last_error(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,218 @@
+// rtx_dev_math.h — device-side f32 math substrate for the gfx950 path-tracing kernels.
+//
+// Arithmetic contract: every expression is evaluated in the operation order of the reference
+// (rc/ = rustracer-core/src/) with NO fused multiply-add (the .hip files are compiled with
+// -ffp-contract=off; f32 divide and sqrt are correctly rounded, HIP's default), so that traversal,
+// triangle tests, sampler tables and light tables are bit-identical to the CPU result.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#define RT_DEV __device__ __forceinline__
+#define RT_DEVN __device__ __noinline__
+
+namespace rtx {
+
+constexpr float kInf = __builtin_huge_valf();
+constexpr float kPi = 3.14159265358979323846f;
+constexpr float kInvPi = 0.318309886183790671538f;
+constexpr float kPiOver2 = 1.57079632679489661923f;
+constexpr float kPiOver4 = kPiOver2 / 2.0f;  // rc/sampling/mod.rs:11
+constexpr float kTau = 6.28318530717958647692f;
+constexpr float kMachineEpsilon = 1.1920929e-07f * 0.5f;  // rc/lib.rs:89
+constexpr float kOneMinusEpsilon = 0.99999994f;           // rc/lib.rs:95
+
+RT_DEV float gamma_n(int n) { return ((float)n * kMachineEpsilon) / (1.0f - (float)n * kMachineEpsilon); }  // rc/lib.rs:90-92
+RT_DEV float min_po(float a, float b) { return a < b ? a : b; }  // rc/lib.rs:192-198
+RT_DEV float max_po(float a, float b) { return a > b ? a : b; }  // rc/lib.rs:201-207
+RT_DEV float clampf(float v, float lo, float hi) { return v < lo ? lo : (v > hi ? hi : v); }  // rc/lib.rs:264-275
+RT_DEV int clampi(int v, int lo, int hi) { return v < lo ? lo : (v > hi ? hi : v); }
+RT_DEV float lerpf(float t, float a, float b) { return a * (1.0f - t) + b * t; }  // rc/lib.rs:107-117
+
+RT_DEV float next_float_up(float v) {  // rc/lib.rs:227-243
+  if (isinf(v) && v > 0.0f) return v;
+  if (v == -0.0f) v = 0.0f;
+  uint32_t ui = __float_as_uint(v);
+  if (v >= 0.0f) ui += 1; else ui -= 1;
+  return __uint_as_float(ui);
+}
+RT_DEV float next_float_down(float v) {  // rc/lib.rs:246-262
+  if (isinf(v) && v < 0.0f) return v;
+  if (v == 0.0f) v = -0.0f;
+  uint32_t ui = __float_as_uint(v);
+  if (v > 0.0f) ui -= 1; else ui += 1;
+  return __uint_as_float(ui);
+}
+// Rust `as i32` / `as usize` semantics (saturating, NaN -> 0)
+RT_DEV int f2i_sat(float f) {
+  if (f != f) return 0;
+  if (f >= 2147483648.0f) return 2147483647;
+  if (f <= -2147483648.0f) return -2147483647 - 1;
+  return (int)f;
+}
+RT_DEV uint32_t f2u_sat(float f) {
+  if (f != f || f <= 0.0f) return 0u;
+  if (f >= 4294967296.0f) return 0xffffffffu;
+  return (uint32_t)f;
+}
+
+// ---------------------------------------------------------------- 3-vectors (rc/geometry/vector.rs)
+struct f3 { float x, y, z; };
+RT_DEV f3 mk3(float x, float y, float z) { f3 r; r.x = x; r.y = y; r.z = z; return r; }
+RT_DEV f3 operator+(f3 a, f3 b) { return mk3(a.x + b.x, a.y + b.y, a.z + b.z); }
+RT_DEV f3 operator-(f3 a, f3 b) { return mk3(a.x - b.x, a.y - b.y, a.z - b.z); }
+RT_DEV f3 operator-(f3 a) { return mk3(-a.x, -a.y, -a.z); }
+RT_DEV f3 operator*(f3 a, float s) { return mk3(a.x * s, a.y * s, a.z * s); }
+RT_DEV f3 operator*(float s, f3 a) { return mk3(s * a.x, s * a.y, s * a.z); }
+RT_DEV f3 operator/(f3 a, float s) { return mk3(a.x / s, a.y / s, a.z / s); }
+RT_DEV float dot(f3 a, f3 b) { return a.x * b.x + a.y * b.y + a.z * b.z; }
+RT_DEV float len2(f3 a) { return a.x * a.x + a.y * a.y + a.z * a.z; }
+RT_DEV float len(f3 a) { return sqrtf(len2(a)); }
+RT_DEV f3 normalize(f3 a) { return a / len(a); }
+RT_DEV f3 cross(f3 a, f3 v) { return mk3((a.y * v.z) - (a.z * v.y), (a.z * v.x) - (a.x * v.z), (a.x * v.y) - (a.y * v.x)); }
+RT_DEV f3 abs3(f3 a) { return mk3(fabsf(a.x), fabsf(a.y), fabsf(a.z)); }
+RT_DEV float comp(f3 v, int i) { return i == 0 ? v.x : (i == 1 ? v.y : v.z); }
+RT_DEV int max_dimension(f3 v) { return v.x > v.y ? (v.x > v.z ? 0 : 2) : (v.y > v.z ? 1 : 2); }  // rc/lib.rs:120-135
+RT_DEV float max_component(f3 v) { return fmaxf(v.x, fmaxf(v.y, v.z)); }                           // rc/lib.rs:137-139
+RT_DEV f3 permute(f3 v, int x, int y, int z) { return mk3(comp(v, x), comp(v, y), comp(v, z)); }
+RT_DEV void coordinate_system(f3 v1, f3& v2, f3& v3) {  // rc/lib.rs:158-168
+  if (fabsf(v1.x) > fabsf(v1.y)) v2 = mk3(-v1.z, 0.0f, v1.x) / sqrtf(v1.x * v1.x + v1.z * v1.z);
+  else v2 = mk3(0.0f, v1.z, -v1.y) / sqrtf(v1.y * v1.y + v1.z * v1.z);
+  v3 = cross(v1, v2);
+}
+RT_DEV f3 face_forward(f3 v1, f3 v2) { return dot(v1, v2) < 0.0f ? -v1 : v1; }  // rc/geometry/mod.rs:129-144
+RT_DEV float distance_squared(f3 p1, f3 p2) { return len2(p2 - p1); }
+
+RT_DEV f3 offset_ray_origin(f3 p, f3 p_error, f3 n, f3 w) {  // rc/geometry/mod.rs:203-220
+  float d = dot(abs3(n), p_error);
+  f3 offset = d * n;
+  if (dot(w, n) < 0.0f) offset = -offset;
+  f3 po = p + offset;
+  if (offset.x > 0.0f) po.x = next_float_up(po.x); else if (offset.x < 0.0f) po.x = next_float_down(po.x);
+  if (offset.y > 0.0f) po.y = next_float_up(po.y); else if (offset.y < 0.0f) po.y = next_float_down(po.y);
+  if (offset.z > 0.0f) po.z = next_float_up(po.z); else if (offset.z < 0.0f) po.z = next_float_down(po.z);
+  return po;
+}
+
+// shading-frame trig (rc/geometry/mod.rs:15-109)
+RT_DEV float cos_theta(f3 w) { return w.z; }
+RT_DEV float cos2_theta(f3 w) { return w.z * w.z; }
+RT_DEV float abs_cos_theta(f3 w) { return fabsf(w.z); }
+RT_DEV float sin2_theta(f3 w) { return fmaxf(1.0f - cos2_theta(w), 0.0f); }
+RT_DEV float sin_theta(f3 w) { return sqrtf(sin2_theta(w)); }
+RT_DEV float tan_theta(f3 w) { return sin_theta(w) / cos_theta(w); }
+RT_DEV float tan2_theta(f3 w) { return sin2_theta(w) / cos2_theta(w); }
+RT_DEV float cos_phi(f3 w) { float s = sin_theta(w); return s == 0.0f ? 1.0f : clampf(w.x / s, -1.0f, 1.0f); }
+RT_DEV float sin_phi(f3 w) { float s = sin_theta(w); return s == 0.0f ? 0.0f : clampf(w.y / s, -1.0f, 1.0f); }
+RT_DEV float cos2_phi(f3 w) { return cos_phi(w) * cos_phi(w); }
+RT_DEV float sin2_phi(f3 w) { return sin_phi(w) * sin_phi(w); }
+RT_DEV bool same_hemisphere(f3 w, f3 wp) { return w.z * wp.z > 0.0f; }
+RT_DEV float spherical_theta(f3 v) { return acosf(clampf(v.z, -1.0f, 1.0f)); }
+RT_DEV float spherical_phi(f3 v) { float p = atan2f(v.y, v.x); return p < 0.0f ? p + 2.0f * kPi : p; }
+
+// ---------------------------------------------------------------- RGB (rc/spectrum.rs)
+struct rgb3 { float r, g, b; };
+RT_DEV rgb3 mkc(float r, float g, float b) { rgb3 c; c.r = r; c.g = g; c.b = b; return c; }
+RT_DEV rgb3 grey(float v) { return mkc(v, v, v); }
+RT_DEV rgb3 operator+(rgb3 a, rgb3 b) { return mkc(a.r + b.r, a.g + b.g, a.b + b.b); }
+RT_DEV rgb3 operator-(rgb3 a, rgb3 b) { return mkc(a.r - b.r, a.g - b.g, a.b - b.b); }
+RT_DEV rgb3 operator*(rgb3 a, rgb3 b) { return mkc(a.r * b.r, a.g * b.g, a.b * b.b); }
+RT_DEV rgb3 operator/(rgb3 a, rgb3 b) { return mkc(a.r / b.r, a.g / b.g, a.b / b.b); }
+RT_DEV rgb3 operator*(rgb3 a, float s) { return mkc(a.r * s, a.g * s, a.b * s); }
+RT_DEV rgb3 operator*(float s, rgb3 a) { return mkc(s * a.r, s * a.g, s * a.b); }
+RT_DEV rgb3 operator/(rgb3 a, float s) { return mkc(a.r / s, a.g / s, a.b / s); }
+RT_DEV rgb3 operator+(rgb3 a, float s) { return mkc(a.r + s, a.g + s, a.b + s); }
+RT_DEV rgb3 operator-(rgb3 a, float s) { return mkc(a.r - s, a.g - s, a.b - s); }
+RT_DEV bool is_black(rgb3 c) { return c.r == 0.0f && c.g == 0.0f && c.b == 0.0f; }
+RT_DEV bool has_nan(rgb3 c) { return c.r != c.r || c.g != c.g || c.b != c.b; }
+RT_DEV float lum_y(rgb3 c) { return 0.212671f * c.r + 0.715160f * c.g + 0.072169f * c.b; }  // :149-152
+RT_DEV float max_component_value(rgb3 c) { return fmaxf(fmaxf(c.r, c.g), c.b); }          // :154
+RT_DEV rgb3 clamp_pos(rgb3 c) { return mkc(clampf(c.r, 0.0f, kInf), clampf(c.g, 0.0f, kInf), clampf(c.b, 0.0f, kInf)); }  // :158-164
+RT_DEV rgb3 sqrt3(rgb3 c) { return mkc(sqrtf(c.r), sqrtf(c.g), sqrtf(c.b)); }
+
+struct f2 { float x, y; };
+RT_DEV f2 mk2(float x, float y) { f2 r; r.x = x; r.y = y; return r; }
+
+// ---------------------------------------------------------------- PCG32 (rc/rng.rs)
+struct Pcg32 {
+  uint64_t state, inc;
+  RT_DEV uint32_t next_u32() {  // :23-30
+    uint64_t old = state;
+    state = old * 0x5851f42d4c957f2dULL + inc;
+    uint32_t xorshifted = (uint32_t)(((old >> 18u) ^ old) >> 27u);
+    uint32_t rot = (uint32_t)(old >> 59u);
+    return (xorshifted >> rot) | (xorshifted << ((~rot + 1u) & 31u));
+  }
+  RT_DEV uint32_t bounded(uint32_t b) {  // :32-40 (threshold = (!b+1)&b, reference quirk)
+    uint32_t threshold = (~b + 1u) & b;
+    for (;;) {
+      uint32_t r = next_u32();
+      if (r >= threshold) return r % b;
+    }
+  }
+  RT_DEV float next_f32() { return fminf((float)next_u32() * 2.3283064365386963e-10f, kOneMinusEpsilon); }  // :42-44
+  RT_DEV void set_sequence(uint64_t seed) {  // :46-52
+    state = 0;
+    inc = (seed << 1u) | 1u;
+    (void)next_u32();
+    state += 0x853c49e6748fea9bULL;
+    (void)next_u32();
+  }
+};
+
+// Generator matrices of the (0,2)-sequence (rc/sampler/lowdiscrepancy.rs:126-174).
+// Column j of the van-der-Corput / first Sobol' matrix is 0x80000000 >> j, so the XOR over the
+// set bits of g is simply the 32-bit bit reversal of g.
+__device__ __constant__ const uint32_t kCSobol1[32] = {
+    0x80000000u, 0xc0000000u, 0xa0000000u, 0xf0000000u, 0x88000000u, 0xcc000000u, 0xaa000000u, 0xff000000u,
+    0x80800000u, 0xc0c00000u, 0xa0a00000u, 0xf0f00000u, 0x88880000u, 0xcccc0000u, 0xaaaa0000u, 0xffff0000u,
+    0x80008000u, 0xc000c000u, 0xa000a000u, 0xf000f000u, 0x88008800u, 0xcc00cc00u, 0xaa00aa00u, 0xff00ff00u,
+    0x80808080u, 0xc0c0c0c0u, 0xa0a0a0a0u, 0xf0f0f0f0u, 0x88888888u, 0xccccccccu, 0xaaaaaaaau, 0xffffffffu};
+// value of gray_code_sample at index k (rc/sampler/lowdiscrepancy.rs:96-102): the running XOR
+// v_k = scramble ^ XOR_{i<k} C[ctz(i+1)] equals scramble ^ C * gray(k), gray(k) = k ^ (k >> 1).
+RT_DEV uint32_t vdc_bits(uint32_t k) { return __brev(k ^ (k >> 1)); }
+RT_DEV uint32_t sobol1_bits(uint32_t k) {
+  uint32_t g = k ^ (k >> 1), v = 0;
+  while (g) { int j = __ffs(g) - 1; v ^= kCSobol1[j]; g &= g - 1; }
+  return v;
+}
+RT_DEV float u32_to_unit(uint32_t v) { return fminf((float)v * 2.3283064365386963e-10f, kOneMinusEpsilon); }
+
+// radical_inverse (rc/sampler/lowdiscrepancy.rs:52-94)
+RT_DEV float radical_inverse_specialized(uint32_t base, uint64_t a) {
+  float inv_base = 1.0f / (float)base;
+  uint64_t reversed = 0;
+  float inv_base_n = 1.0f;
+  while (a != 0) {
+    uint64_t next = a / base;
+    uint64_t digit = a - next * base;
+    reversed = reversed * base + digit;
+    inv_base_n *= inv_base;
+    a = next;
+  }
+  return fminf((float)reversed * inv_base_n, kOneMinusEpsilon);
+}
+RT_DEV float radical_inverse(int base_index, uint64_t a) {
+  switch (base_index) {
+    case 0: {
+      uint64_t r = ((uint64_t)__brev((uint32_t)a) << 32) | (uint64_t)__brev((uint32_t)(a >> 32));
+      return (float)r * 5.4210108624275222e-20f;
+    }
+    case 1: return radical_inverse_specialized(3, a);
+    case 2: return radical_inverse_specialized(5, a);
+    case 3: return radical_inverse_specialized(7, a);
+    default: return radical_inverse_specialized(11, a);
+  }
+}
+
+// rc/lib.rs:171-189 over a device array: pred(i) = (a[i] <= x)
+RT_DEV int find_interval_le(const float* a, int size, float x) {
+  int first = 0, len = size;
+  while (len > 0) {
+    int half = len >> 1, middle = first + half;
+    if (a[middle] <= x) { first = middle + 1; len -= half + 1; } else { len = half; }
+  }
+  return clampi(first - 1, 0, size - 2);
+}
+
+}  // namespace rtx

@@ -1,0 +1,277 @@
+// rtx_dev_scene.h — device scene layout in HBM, watertight triangle test, BVH traversal and
+// SurfaceInteraction construction. Restates rc/bvh/mod.rs:366-501, rc/bounds.rs:127-157,
+// rc/shapes/mesh.rs:215-426,428-586,610-634, rc/interaction.rs, rc/shapes/mod.rs:39-68.
+#pragma once
+#include "rtx_dev_math.h"
+
+namespace rtx {
+
+// ---- HBM layout (DESIGN.md "Data layout") -------------------------------------------------
+// nodes : n_nodes x 32 B  = 2 x float4 {bmin.xyz, bmax.x} {bmax.yz, offset, n_prims|axis<<16}
+// tri_p : n_tris  x 48 B  = 3 x float4 {p0.xyz, material} {p1.xyz, light} {p2.xyz, flags}   (leaf order;
+//         the w lanes carry rt_tri_meta so that shading needs no second gather; the algorithmic
+//         size of a triangle stays the 36 B of its nine coordinates)
+struct DTexture { int kind; float v[3]; int tex1, tex2, amount, image; float su, sv, du, dv; };
+struct DImage {
+  int n_levels; int w[16], h[16]; unsigned long long off[16];
+  const float* texels; int trilinear; float max_aniso; int wrap;
+};
+struct DMaterial { int kind; int slot[16]; int remap; };
+struct DLight {
+  int kind; int prim; float rgb[3]; int two_sided; float vec[3]; float area; float world_radius; int image;
+  float l2w[12], w2l[12];
+  int nu, nv; const float* func; const float* cdf; const float* func_int; const float* mfunc; const float* mcdf; float mfunc_int;
+};
+struct DScene {
+  const float4* nodes; unsigned n_nodes;
+  const float4* tri_p; unsigned n_tris;
+  const float* tri_n; const float* tri_uv; const float* tri_s;
+  const DTexture* textures; const DImage* images; const DMaterial* materials; const DLight* lights;
+  int n_lights; int n_infinite; int infinite_ids[4];
+  f3 wb_min, wb_max;
+  // light distribution (rc/lightdistrib.rs): dense voxel table or a single uniform distribution
+  int ld_uniform; int nvox[3];
+  const float* ld_func; const float* ld_cdf; const float* ld_int;  // [voxel][n_lights], [voxel][n_lights+1], [voxel]
+};
+
+struct Ray { f3 o, d; float t_max; };
+struct TriHit { float t, b0, b1, b2; };
+
+// Shared hit test of Triangle::intersect / intersect_p (mesh.rs:215-319, 428-532).
+RT_DEV bool tri_test(f3 p0, f3 p1, f3 p2, const Ray& ray, TriHit& h) {
+  f3 p0t = p0 - ray.o, p1t = p1 - ray.o, p2t = p2 - ray.o;
+  int kz = max_dimension(abs3(ray.d));
+  int kx = kz + 1; if (kx == 3) kx = 0;
+  int ky = kx + 1; if (ky == 3) ky = 0;
+  f3 d = permute(ray.d, kx, ky, kz);
+  p0t = permute(p0t, kx, ky, kz); p1t = permute(p1t, kx, ky, kz); p2t = permute(p2t, kx, ky, kz);
+  float sx = -d.x / d.z, sy = -d.y / d.z, sz = 1.0f / d.z;
+  p0t.x += sx * p0t.z; p0t.y += sy * p0t.z;
+  p1t.x += sx * p1t.z; p1t.y += sy * p1t.z;
+  p2t.x += sx * p2t.z; p2t.y += sy * p2t.z;
+  float e0 = p1t.x * p2t.y - p1t.y * p2t.x;
+  float e1 = p2t.x * p0t.y - p2t.y * p0t.x;
+  float e2 = p0t.x * p1t.y - p0t.y * p1t.x;
+  if (__builtin_expect(e0 == 0.0f || e1 == 0.0f || e2 == 0.0f, 0)) {  // cold f64 path, mesh.rs:260-270
+    double p2txp1ty = (double)p2t.x * (double)p1t.y, p2typ1tx = (double)p2t.y * (double)p1t.x;
+    e0 = (float)(p2typ1tx - p2txp1ty);
+    double p0txp2ty = (double)p0t.x * (double)p2t.y, p0typ2tx = (double)p0t.y * (double)p2t.x;
+    e1 = (float)(p0typ2tx - p0txp2ty);
+    double p1txp0ty = (double)p1t.x * (double)p0t.y, p1typ0tx = (double)p1t.y * (double)p0t.x;
+    e2 = (float)(p1typ0tx - p1txp0ty);
+  }
+  if ((e0 < 0.0f || e1 < 0.0f || e2 < 0.0f) && (e0 > 0.0f || e1 > 0.0f || e2 > 0.0f)) return false;
+  float det = e0 + e1 + e2;
+  if (det == 0.0f) return false;
+  p0t.z *= sz; p1t.z *= sz; p2t.z *= sz;
+  float t_scaled = e0 * p0t.z + e1 * p1t.z + e2 * p2t.z;
+  if ((det < 0.0f && (t_scaled >= 0.0f || t_scaled < ray.t_max * det)) || (det > 0.0f && (t_scaled <= 0.0f || t_scaled > ray.t_max * det)))
+    return false;
+  float inv_det = 1.0f / det;
+  float b0 = e0 * inv_det, b1 = e1 * inv_det, b2 = e2 * inv_det;
+  float t = t_scaled * inv_det;
+  float maxzt = max_component(abs3(mk3(p0t.z, p1t.z, p2t.z)));
+  float delta_z = gamma_n(3) * maxzt;
+  float maxxt = max_component(abs3(mk3(p0t.x, p1t.x, p2t.x)));
+  float maxyt = max_component(abs3(mk3(p0t.y, p1t.y, p2t.y)));
+  float delta_x = gamma_n(5) * (maxxt + maxzt);
+  float delta_y = gamma_n(5) * (maxyt + maxzt);
+  float delta_e = 2.0f * (gamma_n(2) * maxxt * maxyt + delta_y * maxxt + delta_x * maxyt);
+  float max_e = max_component(abs3(mk3(e0, e1, e2)));
+  float delta_t = 3.0f * (gamma_n(3) * max_e * maxzt + delta_e * maxzt + delta_z * max_e) * fabsf(inv_det);
+  if (t <= delta_t) return false;
+  h.t = t; h.b0 = b0; h.b1 = b1; h.b2 = b2;
+  return true;
+}
+
+RT_DEVN bool tri_test_call(f3 p0, f3 p1, f3 p2, const Ray& ray, TriHit& h) { return tri_test(p0, p1, p2, ray, h); }
+
+// Bounds3::intersect_p_fast (bounds.rs:127-157): no (1 + 2 gamma3) widening, as in the reference.
+RT_DEV bool slab_test(float4 n0, float4 n1, const Ray& ray, f3 inv_dir, int neg_x, int neg_y, int neg_z) {
+  // n0 = {min.x, min.y, min.z, max.x}, n1 = {max.y, max.z, ..}
+  float bx0 = neg_x ? n0.w : n0.x, bx1 = neg_x ? n0.x : n0.w;
+  float by0 = neg_y ? n1.x : n0.y, by1 = neg_y ? n0.y : n1.x;
+  float bz0 = neg_z ? n1.y : n0.z, bz1 = neg_z ? n0.z : n1.y;
+  float tmin = (bx0 - ray.o.x) * inv_dir.x;
+  float tmax = (bx1 - ray.o.x) * inv_dir.x;
+  float tymin = (by0 - ray.o.y) * inv_dir.y;
+  float tymax = (by1 - ray.o.y) * inv_dir.y;
+  if ((tmin > tymax) || (tymin > tmax)) return false;
+  if (tymin > tmin) tmin = tymin;
+  if (tymax < tmax) tmax = tymax;
+  float tzmin = (bz0 - ray.o.z) * inv_dir.z;
+  float tzmax = (bz1 - ray.o.z) * inv_dir.z;
+  if ((tmin > tzmax) || (tzmin > tmax)) return false;
+  if (tzmin > tmin) tmin = tzmin;
+  if (tzmax < tmax) tmax = tzmax;
+  return tmin < ray.t_max && tmax > 0.0f;
+}
+
+RT_DEV void load_tri(const float4* tri_p, int prim, f3& p0, f3& p1, f3& p2) {
+  float4 a = tri_p[3 * prim], b = tri_p[3 * prim + 1], c = tri_p[3 * prim + 2];
+  p0 = mk3(a.x, a.y, a.z); p1 = mk3(b.x, b.y, b.z); p2 = mk3(c.x, c.y, c.z);
+}
+RT_DEV int tri_material(const float4* tri_p, int prim) { return __float_as_int(tri_p[3 * prim].w); }
+RT_DEV int tri_light(const float4* tri_p, int prim) { return __float_as_int(tri_p[3 * prim + 1].w); }
+RT_DEV unsigned tri_flags(const float4* tri_p, int prim) { return __float_as_uint(tri_p[3 * prim + 2].w); }
+
+// ---------------------------------------------------------------- interactions (rc/interaction.rs)
+struct Interaction { f3 p, p_error, wo, n; };
+struct SurfaceInteraction {
+  Interaction hit;
+  f2 uv;
+  f3 dpdu, dpdv;
+  float dudx, dvdx, dudy, dvdy;
+  f3 sh_n, sh_dpdu, sh_dpdv;
+  int prim;
+};
+RT_DEV Ray spawn_ray(const Interaction& it, f3 dir) {  // :56-60
+  Ray r; r.o = offset_ray_origin(it.p, it.p_error, it.n, dir); r.d = dir; r.t_max = kInf; return r;
+}
+RT_DEV Ray spawn_ray_to_interaction(const Interaction& a, const Interaction& b) {  // :69-74
+  Ray r;
+  f3 origin = offset_ray_origin(a.p, a.p_error, a.n, b.p - a.p);
+  f3 target = offset_ray_origin(b.p, b.p_error, b.n, origin - b.p);
+  r.o = origin; r.d = target - origin; r.t_max = 1.0f - 1e-4f;
+  return r;
+}
+
+// Triangle::intersect tail, mesh.rs:321-425 (alpha masks: not carried by the flattened scene)
+RT_DEVN void tri_fill_interaction(const DScene& sc, int prim, f3 ray_d, const TriHit& h, SurfaceInteraction& si) {
+  f3 p0, p1, p2; load_tri(sc.tri_p, prim, p0, p1, p2);
+  const unsigned flags = tri_flags(sc.tri_p, prim);
+  const float b0 = h.b0, b1 = h.b1, b2 = h.b2;
+  f2 uv0 = mk2(0.0f, 0.0f), uv1 = mk2(1.0f, 0.0f), uv2 = mk2(1.0f, 1.0f);  // :201-211
+  if (flags & 4u) {
+    const float* u = sc.tri_uv + 6 * (size_t)prim;
+    uv0 = mk2(u[0], u[1]); uv1 = mk2(u[2], u[3]); uv2 = mk2(u[4], u[5]);
+  }
+  f3 dpdu = mk3(0, 0, 0), dpdv = mk3(0, 0, 0);
+  float duv02x = uv0.x - uv2.x, duv02y = uv0.y - uv2.y, duv12x = uv1.x - uv2.x, duv12y = uv1.y - uv2.y;
+  f3 dp02 = p0 - p2, dp12 = p1 - p2;
+  float determinant = duv02x * duv12y - duv02y * duv12x;
+  bool degenerate_uv = fabsf(determinant) < 1e-8f;
+  if (!degenerate_uv) {
+    float inv_det = 1.0f / determinant;
+    dpdu = (duv12y * dp02 - duv02y * dp12) * inv_det;
+    dpdv = (-duv12x * dp02 + duv02x * dp12) * inv_det;
+  }
+  if (degenerate_uv || len2(cross(dpdu, dpdv)) == 0.0f) coordinate_system(normalize(cross(p2 - p0, p1 - p0)), dpdu, dpdv);
+  float x_abs_sum = fabsf(b0 * p0.x) + fabsf(b1 * p1.x) + fabsf(b2 * p2.x);
+  float y_abs_sum = fabsf(b0 * p0.y) + fabsf(b1 * p1.y) + fabsf(b2 * p2.y);
+  float z_abs_sum = fabsf(b0 * p0.z) + fabsf(b1 * p1.z) + fabsf(b2 * p2.z);
+  si.hit.p_error = gamma_n(7) * mk3(x_abs_sum, y_abs_sum, z_abs_sum);
+  si.hit.p = p0 * b0 + p1 * b1 + p2 * b2;
+  si.uv = mk2(uv0.x * b0 + uv1.x * b1 + uv2.x * b2, uv0.y * b0 + uv1.y * b1 + uv2.y * b2);
+  si.hit.wo = normalize(normalize(-ray_d));  // SurfaceInteraction::new + Interaction::new both normalise (interaction.rs:42,123)
+  si.dpdu = dpdu; si.dpdv = dpdv;
+  f3 n = normalize(cross(dp02, dp12));  // :385
+  si.hit.n = n;
+  f3 ns = n;
+  if (flags & 2u) {
+    const float* q = sc.tri_n + 9 * (size_t)prim;
+    ns = normalize(mk3(q[0], q[1], q[2]) * b0 + mk3(q[3], q[4], q[5]) * b1 + mk3(q[6], q[7], q[8]) * b2);
+  }
+  f3 ss;
+  if (flags & 8u) {
+    const float* q = sc.tri_s + 9 * (size_t)prim;
+    ss = normalize(mk3(q[0], q[1], q[2]) * b0 + mk3(q[3], q[4], q[5]) * b1 + mk3(q[6], q[7], q[8]) * b2);
+  } else ss = normalize(dpdu);
+  f3 ts = cross(ss, ns);
+  if (len2(ts) > 0.0f) { ts = normalize(ts); ss = cross(ts, ns); }
+  else coordinate_system(ns, ss, ts);
+  si.sh_n = ns; si.sh_dpdu = ss; si.sh_dpdv = ts;
+  if (flags & 2u) si.hit.n = face_forward(si.hit.n, si.sh_n);  // :417-422
+  else if (flags & 1u) { si.hit.n = -si.hit.n; si.sh_n = si.hit.n; }
+  si.dudx = si.dvdx = si.dudy = si.dvdy = 0.0f;
+  si.prim = prim;
+}
+
+// Geometric normal + hit point of a known hit, enough for Light::l / pdf_wi (no shading frame).
+RT_DEVN void tri_hit_point_normal(const DScene& sc, int prim, const TriHit& h, f3& p, f3& n) {
+  f3 p0, p1, p2; load_tri(sc.tri_p, prim, p0, p1, p2);
+  const unsigned flags = tri_flags(sc.tri_p, prim);
+  p = p0 * h.b0 + p1 * h.b1 + p2 * h.b2;
+  n = normalize(cross(p0 - p2, p1 - p2));
+  if (flags & 2u) {
+    const float* q = sc.tri_n + 9 * (size_t)prim;
+    f3 ns = normalize(mk3(q[0], q[1], q[2]) * h.b0 + mk3(q[3], q[4], q[5]) * h.b1 + mk3(q[6], q[7], q[8]) * h.b2);
+    n = face_forward(n, ns);
+  } else if (flags & 1u) n = -n;
+}
+
+// compute_differential (interaction.rs:245-314) for a ray that carries differentials
+RT_DEVN void compute_differential(SurfaceInteraction& si, f3 rx_o, f3 ry_o, f3 rx_d, f3 ry_d) {
+  const f3 n = si.hit.n, p = si.hit.p;
+  float d = dot(n, mk3(p.x, p.y, p.z));
+  float tx = -(dot(n, rx_o) - d) / dot(n, rx_d);
+  float ty = -(dot(n, ry_o) - d) / dot(n, ry_d);
+  if (isinf(tx) || tx != tx || isinf(ty) || ty != ty) return;
+  f3 px = rx_o + tx * rx_d, py = ry_o + ty * ry_d;
+  int dim0, dim1;
+  if (fabsf(n.x) > fabsf(n.y) && fabsf(n.x) > fabsf(n.z)) { dim0 = 1; dim1 = 2; }
+  else if (fabsf(n.y) > fabsf(n.z)) { dim0 = 0; dim1 = 2; }
+  else { dim0 = 0; dim1 = 1; }
+  float A00 = comp(si.dpdu, dim0), A01 = comp(si.dpdv, dim0), A10 = comp(si.dpdu, dim1), A11 = comp(si.dpdv, dim1);
+  float Bx0 = comp(px, dim0) - comp(p, dim0), Bx1 = comp(px, dim1) - comp(p, dim1);
+  float By0 = comp(py, dim0) - comp(p, dim0), By1 = comp(py, dim1) - comp(p, dim1);
+  float det = A00 * A11 - A01 * A10;  // solve_linear_system2x2, transform.rs:382-394
+  if (fabsf(det) < 1e-10f) return;
+  float x0 = (A11 * Bx0 - A01 * Bx1) / det, x1 = (A00 * Bx1 - A10 * Bx0) / det;
+  if (!(x0 != x0 || x1 != x1)) { si.dudx = x0; si.dvdx = x1; }
+  float y0 = (A11 * By0 - A01 * By1) / det, y1 = (A00 * By1 - A10 * By0) / det;
+  if (!(y0 != y0 || y1 != y1)) { si.dudy = y0; si.dvdy = y1; }
+}
+
+// ---------------------------------------------------------------- BVH traversal
+// One lane = one ray. The to-visit stack (64 entries, bvh/mod.rs:374) lives in LDS, laid out
+// [depth][lane] so that a wave's push/pop of one depth touches 64 consecutive banks.
+// NodeSrc abstracts where node/triangle records come from: HBM, or an LDS copy of a small scene.
+struct GlobalSrc {
+  const float4* nodes; const float4* tri_p;
+  RT_DEV void node(int i, float4& a, float4& b) const { a = nodes[2 * i]; b = nodes[2 * i + 1]; }
+  RT_DEV void tri(int i, f3& p0, f3& p1, f3& p2) const { load_tri(tri_p, i, p0, p1, p2); }
+};
+
+template <bool ANY, bool COUNT, class Src>
+RT_DEV bool traverse(const Src& src, Ray ray, int* stack, int stack_stride, int& prim_out, TriHit& hit_out, unsigned& n_nodes, unsigned& n_tris) {
+  bool found = false;
+  int sp = 0, cur = 0;
+  f3 inv_dir = mk3(1.0f / ray.d.x, 1.0f / ray.d.y, 1.0f / ray.d.z);
+  const int neg_x = inv_dir.x < 0.0f, neg_y = inv_dir.y < 0.0f, neg_z = inv_dir.z < 0.0f;
+  for (;;) {
+    float4 n0, n1;
+    src.node(cur, n0, n1);
+    if (COUNT) n_nodes += 1;
+    if (slab_test(n0, n1, ray, inv_dir, neg_x, neg_y, neg_z)) {
+      const unsigned packed = __float_as_uint(n1.w);
+      const int n_prims = (int)(packed & 0xffffu);
+      const int offset = __float_as_int(n1.z);
+      if (n_prims > 0) {
+        for (int i = 0; i < n_prims; ++i) {
+          f3 p0, p1, p2;
+          src.tri(offset + i, p0, p1, p2);
+          if (COUNT) n_tris += 1;
+          TriHit h;
+          if (tri_test(p0, p1, p2, ray, h)) {
+            if (ANY) return true;
+            ray.t_max = h.t; found = true; prim_out = offset + i; hit_out = h;  // `.or(result)`: later accepted hits replace
+          }
+        }
+        if (sp == 0) break;
+        cur = stack[(--sp) * stack_stride];
+      } else {
+        const int axis = (int)((packed >> 16) & 0xffu);
+        const int neg = axis == 0 ? neg_x : (axis == 1 ? neg_y : neg_z);
+        if (neg) { stack[(sp++) * stack_stride] = cur + 1; cur = offset; }
+        else { stack[(sp++) * stack_stride] = offset; cur = cur + 1; }
+      }
+    } else {
+      if (sp == 0) break;
+      cur = stack[(--sp) * stack_stride];
+    }
+  }
+  return found;
+}
+
+}  // namespace rtx

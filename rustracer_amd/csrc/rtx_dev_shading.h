@@ -1,0 +1,433 @@
+// rtx_dev_shading.h — textures / MIP lookups, materials -> Bsdf, lights and light distributions.
+// Restates rc/texture/*.rs, rc/mipmap.rs:208-360, rc/material/*.rs, rc/light/*.rs,
+// rc/lightdistrib.rs, rc/sampling/distribution{1,2}d.rs.
+#pragma once
+#include "rtx_dev_bsdf.h"
+#include "rtx_dev_scene.h"
+
+namespace rtx {
+
+// ---------------------------------------------------------------- MIPMap lookups (rc/mipmap.rs)
+__device__ __constant__ float kEwaLut[128];  // filled by the host at start-up: exp(-2 r2) - exp(-2) (:33-44)
+
+RT_DEV long modl(long a, long b) { long r = a % b; return r < 0 ? r + b : r; }  // :428-435
+RT_DEV rgb3 mip_texel(const DImage& im, int level, long s, long t) {              // :208-225
+  long us = im.w[level], vs = im.h[level], ss, tt;
+  if (im.wrap == 0) { ss = modl(s, us); tt = modl(t, vs); }
+  else if (im.wrap == 2) { ss = s < 0 ? 0 : (s > us - 1 ? us - 1 : s); tt = t < 0 ? 0 : (t > vs - 1 ? vs - 1 : t); }
+  else { if (s < 0 || s >= us || t < 0 || t >= vs) return mkc(0, 0, 0); ss = s; tt = t; }
+  const float* p = im.texels + 3 * (im.off[level] + (unsigned long long)tt * (unsigned long long)us + (unsigned long long)ss);
+  return mkc(p[0], p[1], p[2]);
+}
+RT_DEVN rgb3 mip_triangle(const DImage& im, int level, f2 st) {  // :285-308
+  level = clampi(level, 0, im.n_levels - 1);
+  float s = st.x * (float)im.w[level] - 0.5f;
+  float t = st.y * (float)im.h[level] - 0.5f;
+  long s0 = f2i_sat(floorf(s)), t0 = f2i_sat(floorf(t));
+  float ds = s - (float)s0, dt = t - (float)t0;
+  return mip_texel(im, level, s0, t0) * (1.0f - ds) * (1.0f - dt) + mip_texel(im, level, s0, t0 + 1) * (1.0f - ds) * dt +
+         mip_texel(im, level, s0 + 1, t0) * ds * (1.0f - dt) + mip_texel(im, level, s0 + 1, t0 + 1) * ds * dt;
+}
+RT_DEV rgb3 lerp_rgb(float t, rgb3 a, rgb3 b) { return a * (1.0f - t) + b * t; }
+RT_DEVN rgb3 mip_lookup(const DImage& im, f2 st, float width) {  // :227-245
+  float level = (float)im.n_levels - 1.0f + log2f(fmaxf(width, 1e-8f));
+  if (level < 0.0f) return mip_triangle(im, 0, st);
+  if (level >= (float)im.n_levels - 1.0f) return mip_texel(im, im.n_levels - 1, 0, 0);
+  float i_level = floorf(level);
+  float delta = level - i_level;
+  int il = (int)f2u_sat(i_level);
+  return lerp_rgb(delta, mip_triangle(im, il, st), mip_triangle(im, il + 1, st));
+}
+RT_DEVN rgb3 mip_ewa(const DImage& im, int level, f2 st, f2 dst0, f2 dst1) {  // :310-360
+  if (level >= im.n_levels) return mip_texel(im, im.n_levels - 1, 0, 0);
+  float us = (float)im.w[level], vs = (float)im.h[level];
+  st.x = st.x * us - 0.5f; st.y = st.y * vs - 0.5f;
+  dst0.x *= us; dst0.y *= vs; dst1.x *= us; dst1.y *= vs;
+  float A = dst0.y * dst0.y + dst1.y * dst1.y + 1.0f;
+  float B = -2.0f * (dst0.x * dst0.y + dst1.x * dst1.y);
+  float C = dst0.x * dst0.x + dst1.x * dst1.x + 1.0f;
+  float invF = 1.0f / (A * C - B * B * 0.25f);
+  A *= invF; B *= invF; C *= invF;
+  float det = -B * B + 4.0f * A * C;
+  float invDet = 1.0f / det;
+  float uSqrt = sqrtf(det * C), vSqrt = sqrtf(A * det);
+  long s0 = f2i_sat(ceilf(st.x - 2.0f * invDet * uSqrt)), s1 = f2i_sat(floorf(st.x + 2.0f * invDet * uSqrt));
+  long t0 = f2i_sat(ceilf(st.y - 2.0f * invDet * vSqrt)), t1 = f2i_sat(floorf(st.y + 2.0f * invDet * vSqrt));
+  rgb3 sum = mkc(0, 0, 0); float sumWts = 0.0f;
+  for (long it = t0; it < t1 + 1; ++it) {
+    float tt = (float)it - st.y;
+    for (long is = s0; is < s1 + 1; ++is) {
+      float ss = (float)is - st.x;
+      float r2 = A * ss * ss + B * ss * tt + C * tt * tt;
+      if (r2 < 1.0f) {
+        unsigned index = f2u_sat(r2 * 128.0f); if (index > 127u) index = 127u;
+        float weight = kEwaLut[index];
+        sum = sum + mip_texel(im, level, is, it) * weight;
+        sumWts += weight;
+      }
+    }
+  }
+  return sum / sumWts;
+}
+RT_DEVN rgb3 mip_lookup_diff(const DImage& im, f2 st, f2 dst0, f2 dst1) {  // :247-283
+  if (im.trilinear) {
+    float width = fmaxf(fmaxf(fabsf(dst0.x), fabsf(dst0.y)), fmaxf(fabsf(dst1.x), fabsf(dst1.y)));
+    return mip_lookup(im, st, 2.0f * width);
+  }
+  float l0 = dst0.x * dst0.x + dst0.y * dst0.y, l1 = dst1.x * dst1.x + dst1.y * dst1.y;
+  if (l0 < l1) { f2 t = dst0; dst0 = dst1; dst1 = t; }
+  float major_length = sqrtf(dst0.x * dst0.x + dst0.y * dst0.y);
+  float minor_length = sqrtf(dst1.x * dst1.x + dst1.y * dst1.y);
+  if ((minor_length * im.max_aniso) < major_length && minor_length > 0.0f) {
+    float scale = major_length / (minor_length * im.max_aniso);
+    dst1.x *= scale; dst1.y *= scale;
+    minor_length *= scale;
+  }
+  if (minor_length == 0.0f) return mip_triangle(im, 0, st);
+  float lod = fmaxf(0.0f, (float)im.n_levels - 1.0f + log2f(minor_length));
+  int ilod = (int)f2u_sat(floorf(lod));
+  return lerp_rgb(lod - (float)ilod, mip_ewa(im, ilod, st, dst0, dst1), mip_ewa(im, ilod + 1, st, dst0, dst1));
+}
+
+// ---------------------------------------------------------------- textures (rc/texture/*.rs)
+// Scale/Mix operands are resolved iteratively with a tiny explicit stack (no device recursion).
+RT_DEV rgb3 tex_leaf(const DScene& sc, const DTexture& t, const SurfaceInteraction& si) {
+  if (t.kind == 0) return mkc(t.v[0], t.v[1], t.v[2]);  // constant.rs:35-38
+  // imagemap.rs:232-235 with UVMapping2D (texture/mod.rs:52-60)
+  f2 st = mk2(t.su * si.uv.x + t.du, t.sv * si.uv.y + t.dv);
+  f2 dstdx = mk2(t.su * si.dudx, t.sv * si.dvdx), dstdy = mk2(t.su * si.dudy, t.sv * si.dvdy);
+  return mip_lookup_diff(sc.images[t.image], st, dstdx, dstdy);
+}
+RT_DEVN rgb3 tex_eval(const DScene& sc, int id, const SurfaceInteraction& si) {
+  const DTexture& t = sc.textures[id];
+  if (t.kind == 0 || t.kind == 3) return tex_leaf(sc, t, si);
+  // one level of scale/mix whose operands may themselves be scale/mix of leaves (depth <= 2)
+  rgb3 a, b;
+  {
+    const DTexture& t1 = sc.textures[t.tex1];
+    if (t1.kind == 1) a = tex_leaf(sc, sc.textures[t1.tex1], si) * tex_leaf(sc, sc.textures[t1.tex2], si);
+    else if (t1.kind == 2) {
+      rgb3 x = tex_leaf(sc, sc.textures[t1.tex1], si), y = tex_leaf(sc, sc.textures[t1.tex2], si);
+      float amt = tex_leaf(sc, sc.textures[t1.amount], si).r;
+      a = x * (1.0f - amt) + y * amt;
+    } else a = tex_leaf(sc, t1, si);
+    const DTexture& t2 = sc.textures[t.tex2];
+    if (t2.kind == 1) b = tex_leaf(sc, sc.textures[t2.tex1], si) * tex_leaf(sc, sc.textures[t2.tex2], si);
+    else if (t2.kind == 2) {
+      rgb3 x = tex_leaf(sc, sc.textures[t2.tex1], si), y = tex_leaf(sc, sc.textures[t2.tex2], si);
+      float amt = tex_leaf(sc, sc.textures[t2.amount], si).r;
+      b = x * (1.0f - amt) + y * amt;
+    } else b = tex_leaf(sc, t2, si);
+  }
+  if (t.kind == 1) return a * b;  // scale.rs:23-25
+  float amt = tex_leaf(sc, sc.textures[t.amount], si).r;  // mix.rs:24
+  return a * (1.0f - amt) + b * amt;
+}
+RT_DEV float tex_eval_f(const DScene& sc, int id, const SurfaceInteraction& si) { return tex_eval(sc, id, si).r; }
+
+// ---------------------------------------------------------------- materials (rc/material/*.rs)
+RT_DEV Lobe lobe_zero(int kind) {
+  Lobe l; l.kind = kind; l.fr_kind = FR_NOOP; l.r = mkc(0, 0, 0); l.t = mkc(0, 0, 0); l.k = mkc(0, 0, 0);
+  l.ax = l.ay = 0.0f; l.eta_a = l.eta_b = 1.0f; l.fr_ei = l.fr_et = 1.0f; l.n_scales = 0; l.scale0 = l.scale1 = mkc(1, 1, 1);
+  return l;
+}
+RT_DEV void bsdf_add(Bsdf& b, const Lobe& l) { if (b.n < RT_MAX_LOBES) b.lobes[b.n++] = l; }
+RT_DEV Lobe mk_micro_r(rgb3 r, float ax, float ay, int fr_kind, float ei, float et) {
+  Lobe l = lobe_zero(LB_MICRO_R); l.r = r; l.ax = ax; l.ay = ay; l.fr_kind = fr_kind; l.fr_ei = ei; l.fr_et = et; return l;
+}
+RT_DEV Lobe mk_micro_t(rgb3 t, float ax, float ay, float ea, float eb) {
+  Lobe l = lobe_zero(LB_MICRO_T); l.r = t; l.ax = ax; l.ay = ay; l.eta_a = ea; l.eta_b = eb; l.fr_kind = FR_DIELECTRIC; l.fr_ei = ea; l.fr_et = eb; return l;
+}
+RT_DEV Lobe mk_spec_t(rgb3 t, float ea, float eb) {
+  Lobe l = lobe_zero(LB_SPEC_T); l.r = t; l.eta_a = ea; l.eta_b = eb; l.fr_kind = FR_DIELECTRIC; l.fr_ei = ea; l.fr_et = eb; return l;
+}
+RT_DEV Lobe mk_lambert(int kind, rgb3 r) { Lobe l = lobe_zero(kind); l.r = r; return l; }
+
+// Fills the lobes of one non-mix material; returns eta.
+RT_DEVN float material_lobes(const DScene& sc, const DMaterial& m, const SurfaceInteraction& si, Bsdf& b) {
+  float eta = 1.0f;
+  const int* s = m.slot;
+  switch (m.kind) {
+    case 0: {  // matte.rs:37-62
+      rgb3 r = clamp_pos(tex_eval(sc, s[0], si));
+      float sigma = clampf(tex_eval_f(sc, s[4], si), 0.0f, 1.0f);
+      if (!is_black(r)) {
+        if (sigma == 0.0f) bsdf_add(b, mk_lambert(LB_LAMBERT_R, r));
+        else {  // OrenNayar::new, oren_nayar.rs:17-27
+          Lobe l = lobe_zero(LB_OREN_NAYAR); l.r = r;
+          float sigma_rad = sigma * (kPi / 180.0f);
+          float sigma2 = sigma_rad * sigma_rad;
+          l.ax = 1.0f - (sigma2 / (2.0f * (sigma2 + 0.33f)));
+          l.ay = 0.45f * sigma2 / (sigma2 + 0.09f);
+          bsdf_add(b, l);
+        }
+      }
+      break;
+    }
+    case 1: {  // plastic.rs:45-75
+      rgb3 kd = tex_eval(sc, s[0], si), ks = tex_eval(sc, s[1], si);
+      if (!is_black(kd)) bsdf_add(b, mk_lambert(LB_LAMBERT_R, kd));
+      if (!is_black(ks)) {
+        float rough = tex_eval_f(sc, s[5], si);
+        if (m.remap) rough = tr_roughness_to_alpha(rough);
+        bsdf_add(b, mk_micro_r(ks, rough, rough, FR_DIELECTRIC, 1.5f, 1.0f));
+      }
+      break;
+    }
+    case 2: {  // metal.rs:50-82
+      float ur = tex_eval_f(sc, s[6] >= 0 ? s[6] : s[5], si), vr = tex_eval_f(sc, s[7] >= 0 ? s[7] : s[5], si);
+      if (m.remap) { ur = tr_roughness_to_alpha(ur); vr = tr_roughness_to_alpha(vr); }
+      Lobe l = mk_micro_r(mkc(1, 1, 1), ur, vr, FR_CONDUCTOR, 1.0f, 1.0f);
+      l.t = tex_eval(sc, s[8], si); l.k = tex_eval(sc, s[9], si);
+      bsdf_add(b, l);
+      break;
+    }
+    case 3: {  // mirror.rs:30-48
+      rgb3 R = clamp_pos(tex_eval(sc, s[2], si));
+      if (!is_black(R)) { Lobe l = lobe_zero(LB_SPEC_R); l.r = R; bsdf_add(b, l); }
+      break;
+    }
+    case 4: {  // glass.rs:53-106, allow_multiple_lobes = true (path.rs:145)
+      eta = tex_eval_f(sc, s[8], si);
+      float ur = tex_eval_f(sc, s[6], si), vr = tex_eval_f(sc, s[7], si);
+      rgb3 r = tex_eval(sc, s[2], si), t = tex_eval(sc, s[3], si);
+      if (!is_black(r) || !is_black(t)) {
+        if (ur == 0.0f && vr == 0.0f) {
+          Lobe l = lobe_zero(LB_FRESNEL_SPEC); l.r = r; l.t = t; l.eta_a = 1.0f; l.eta_b = eta; bsdf_add(b, l);
+        } else {
+          if (m.remap) { ur = tr_roughness_to_alpha(ur); vr = tr_roughness_to_alpha(vr); }
+          if (!is_black(r)) bsdf_add(b, mk_micro_r(r, ur, vr, FR_DIELECTRIC, 1.0f, eta));
+          if (!is_black(t)) bsdf_add(b, mk_micro_t(r, ur, vr, 1.0f, eta));  // passes `r` (glass.rs:97)
+        }
+      }
+      break;
+    }
+    case 5: {  // uber.rs:63-126
+      float e = tex_eval_f(sc, s[8], si);
+      rgb3 op = clamp_pos(tex_eval(sc, s[10], si));
+      rgb3 t = clamp_pos(mkc(1, 1, 1) - op);
+      eta = e;
+      if (!is_black(t)) { eta = 1.0f; bsdf_add(b, mk_spec_t(t, 1.0f, 1.0f)); }
+      rgb3 kd = op * clamp_pos(tex_eval(sc, s[0], si));
+      if (!is_black(kd)) bsdf_add(b, mk_lambert(LB_LAMBERT_R, kd));
+      rgb3 ks = op * clamp_pos(tex_eval(sc, s[1], si));
+      if (!is_black(ks)) {
+        float ru = tex_eval_f(sc, s[6] >= 0 ? s[6] : s[5], si), rv = tex_eval_f(sc, s[7] >= 0 ? s[7] : s[5], si);
+        if (m.remap) { ru = tr_roughness_to_alpha(ru); rv = tr_roughness_to_alpha(rv); }
+        bsdf_add(b, mk_micro_r(ks, ru, rv, FR_DIELECTRIC, 1.0f, e));
+      }
+      rgb3 kr = op * clamp_pos(tex_eval(sc, s[2], si));
+      if (!is_black(kr)) { Lobe l = lobe_zero(LB_SPEC_R); l.r = kr; l.fr_kind = FR_DIELECTRIC; l.fr_ei = 1.0f; l.fr_et = e; bsdf_add(b, l); }
+      rgb3 kt = op * clamp_pos(tex_eval(sc, s[3], si));
+      if (!is_black(kt)) bsdf_add(b, mk_spec_t(kt, 1.0f, e));
+      break;
+    }
+    case 6: {  // substrate.rs:43-71
+      rgb3 d = clamp_pos(tex_eval(sc, s[0], si)), sp = clamp_pos(tex_eval(sc, s[1], si));
+      float ru = tex_eval_f(sc, s[6], si), rv = tex_eval_f(sc, s[7], si);
+      if (!is_black(d) || !is_black(sp)) {
+        if (m.remap) { ru = tr_roughness_to_alpha(ru); rv = tr_roughness_to_alpha(rv); }
+        Lobe l = lobe_zero(LB_FRESNEL_BLEND); l.r = d; l.t = sp; l.ax = ru; l.ay = rv; bsdf_add(b, l);
+      }
+      break;
+    }
+    case 8: {  // translucent.rs:49-101
+      eta = 1.5f;
+      rgb3 r = clamp_pos(tex_eval(sc, s[11], si)), t = clamp_pos(tex_eval(sc, s[12], si));
+      if (!is_black(r) || !is_black(t)) {
+        rgb3 kd = clamp_pos(tex_eval(sc, s[0], si));
+        if (!is_black(kd)) {
+          if (!is_black(r)) bsdf_add(b, mk_lambert(LB_LAMBERT_R, r * kd));
+          if (!is_black(t)) bsdf_add(b, mk_lambert(LB_LAMBERT_T, t * kd));
+        }
+        rgb3 ks = clamp_pos(tex_eval(sc, s[1], si));
+        if (!is_black(ks) && (!is_black(r) || !is_black(t))) {
+          float rough = tex_eval_f(sc, s[5], si);
+          if (m.remap) rough = tr_roughness_to_alpha(rough);
+          if (!is_black(r)) bsdf_add(b, mk_micro_r(r * ks, rough, rough, FR_DIELECTRIC, 1.0f, eta));
+          if (!is_black(t)) bsdf_add(b, mk_micro_t(t * ks, rough, rough, 1.0f, eta));
+        }
+      }
+      break;
+    }
+    default: break;
+  }
+  return eta;
+}
+RT_DEV void scale_lobes(Bsdf& b, int first, int last, rgb3 s) {
+  for (int i = first; i < last; ++i) {
+    Lobe& l = b.lobes[i];
+    if (l.n_scales == 0) l.scale0 = s; else l.scale1 = s;
+    l.n_scales += 1;
+  }
+}
+// Material::compute_scattering_functions. MixMaterial (mixmat.rs:34-64) is expanded up to two
+// levels (a mix whose operands are plain materials or mixes of plain materials); the host rejects
+// deeper nesting at scene creation.
+RT_DEVN void build_bsdf(const DScene& sc, int mat, const SurfaceInteraction& si, Bsdf& b) {
+  b.n = 0;
+  const DMaterial& m = sc.materials[mat];
+  float eta;
+  if (m.kind != 7) eta = material_lobes(sc, m, si, b);
+  else {
+    rgb3 s1 = clamp_pos(tex_eval(sc, m.slot[13], si)), s2 = clamp_pos(mkc(1, 1, 1) - s1);
+    eta = 1.0f;
+    for (int side = 0; side < 2; ++side) {
+      const DMaterial& c = sc.materials[side == 0 ? m.slot[14] : m.slot[15]];
+      int first = b.n;
+      float e;
+      if (c.kind != 7) e = material_lobes(sc, c, si, b);
+      else {
+        rgb3 c1 = clamp_pos(tex_eval(sc, c.slot[13], si)), c2 = clamp_pos(mkc(1, 1, 1) - c1);
+        int f1 = b.n;
+        e = material_lobes(sc, sc.materials[c.slot[14]], si, b);
+        scale_lobes(b, f1, b.n, c1);
+        int f2_ = b.n;
+        (void)material_lobes(sc, sc.materials[c.slot[15]], si, b);
+        scale_lobes(b, f2_, b.n, c2);
+      }
+      scale_lobes(b, first, b.n, side == 0 ? s1 : s2);
+      if (side == 0) eta = e;  // the Bsdf (frame, eta) of mat1 is kept, only its lobe list is replaced
+    }
+  }
+  b.eta = eta;
+  bsdf_init_frame(b, si.sh_n, si.hit.n, si.sh_dpdu);
+}
+
+// ---------------------------------------------------------------- distributions
+RT_DEV void d1_sample_continuous(const float* func, const float* cdf, float func_int, int n, float u, float& x, float& pdf, int& off) {  // distribution1d.rs:48-68
+  int offset = find_interval_le(cdf, n + 1, u);
+  float du = u - cdf[offset];
+  if (cdf[offset + 1] - cdf[offset] > 0.0f) du /= cdf[offset + 1] - cdf[offset];
+  pdf = func_int > 0.0f ? func[offset] / func_int : 0.0f;
+  x = ((float)offset + du) / (float)n;
+  off = offset;
+}
+RT_DEV void d1_sample_discrete(const float* func, const float* cdf, float func_int, int n, float u, int& off, float& pdf) {  // :70-79
+  int offset = find_interval_le(cdf, n + 1, u);
+  pdf = func_int > 0.0f ? func[offset] / (func_int * (float)n) : 0.0f;
+  off = offset;
+}
+
+// ---------------------------------------------------------------- lights
+struct LiSample { rgb3 li; f3 wi; float pdf; Interaction p1; };
+
+RT_DEV float tri_area(const DScene& sc, int prim) {  // mesh.rs:588-594
+  f3 p0, p1, p2; load_tri(sc.tri_p, prim, p0, p1, p2);
+  return 0.5f * len(cross(p1 - p0, p2 - p0));
+}
+RT_DEV rgb3 area_light_l(const DLight& l, f3 n, f3 w) {  // diffuse.rs:91-97
+  if (l.two_sided || dot(n, w) > 0.0f) return mkc(l.rgb[0], l.rgb[1], l.rgb[2]);
+  return mkc(0, 0, 0);
+}
+RT_DEV f3 xf3x4(const float* m, f3 v) {  // Transform * Vector3f, transform.rs:288-303
+  return mk3(m[0] * v.x + m[1] * v.y + m[2] * v.z, m[4] * v.x + m[5] * v.y + m[6] * v.z, m[8] * v.x + m[9] * v.y + m[10] * v.z);
+}
+RT_DEVN rgb3 infinite_le(const DScene& sc, const DLight& l, f3 ray_d) {  // infinite.rs:211-219
+  f3 w = normalize(xf3x4(l.w2l, ray_d));
+  f2 st = mk2(spherical_phi(w) * kInvPi * 0.5f, spherical_theta(w) * kInvPi);
+  return mip_lookup(sc.images[l.image], st, 0.0f);
+}
+RT_DEVN LiSample light_sample_li(const DScene& sc, const DLight& l, const Interaction& ref, f2 u) {
+  LiSample s;
+  switch (l.kind) {
+    case 0: {  // DiffuseAreaLight::sample_li diffuse.rs:59-70 -> Shape::sample_si shapes/mod.rs:39-53 -> Triangle::sample mesh.rs:610-634
+      f2 b = uniform_sample_triangle(u);
+      f3 p0, p1, p2; load_tri(sc.tri_p, l.prim, p0, p1, p2);
+      const unsigned flags = tri_flags(sc.tri_p, l.prim);
+      float b2 = 1.0f - b.x - b.y;
+      f3 p = (b.x * p0) + (b.y * p1) + (b2 * p2);
+      f3 normal = normalize(cross(p1 - p0, p2 - p0));
+      if (flags & 2u) {
+        const float* q = sc.tri_n + 9 * (size_t)l.prim;
+        f3 ns = b.x * mk3(q[0], q[1], q[2]) + b.y * mk3(q[3], q[4], q[5]) + b2 * mk3(q[6], q[7], q[8]);
+        normal = face_forward(normal, ns);
+      } else if (flags & 1u) normal = normal * -1.0f;
+      f3 p_abs_sum = abs3(b.x * p0) + abs3(b.y * p1) + abs3(b2 * p2);
+      s.p1.p = p; s.p1.p_error = gamma_n(6) * p_abs_sum; s.p1.wo = mk3(0, 0, 0); s.p1.n = normal;
+      float pdf = 1.0f / l.area;
+      f3 wi = p - ref.p;
+      if (len2(wi) == 0.0f) pdf = 0.0f;
+      else {
+        wi = normalize(wi);
+        pdf *= distance_squared(ref.p, p) / fabsf(dot(normal, -wi));
+        if (isinf(pdf)) pdf = 0.0f;
+      }
+      s.wi = normalize(p - ref.p);
+      s.pdf = pdf;
+      s.li = area_light_l(l, normal, -s.wi);
+      return s;
+    }
+    case 1: {  // PointLight::sample_li point.rs:43-54 (I / (4 pi r^2), reference quirk)
+      f3 pos = mk3(l.vec[0], l.vec[1], l.vec[2]);
+      f3 wi = pos - ref.p;
+      float r2 = len2(wi);
+      s.li = mkc(l.rgb[0], l.rgb[1], l.rgb[2]) / (4.0f * kPi * r2);
+      s.wi = normalize(wi); s.pdf = 1.0f;
+      s.p1.p = pos; s.p1.p_error = mk3(0, 0, 0); s.p1.wo = mk3(0, 0, 0); s.p1.n = mk3(0, 0, 0);
+      return s;
+    }
+    case 2: {  // DistantLight::sample_li distant.rs:57-70
+      f3 dir = mk3(l.vec[0], l.vec[1], l.vec[2]);
+      s.li = mkc(l.rgb[0], l.rgb[1], l.rgb[2]); s.wi = dir; s.pdf = 1.0f;
+      s.p1.p = ref.p + dir * (2.0f * l.world_radius); s.p1.p_error = mk3(0, 0, 0); s.p1.wo = mk3(0, 0, 0); s.p1.n = mk3(0, 0, 0);
+      return s;
+    }
+    default: {  // InfiniteAreaLight::sample_li infinite.rs:143-181
+      float d1, pdf1, d0, pdf0; int v, dummy;
+      d1_sample_continuous(l.mfunc, l.mcdf, l.mfunc_int, l.nv, u.y, d1, pdf1, v);  // Distribution2D::sample_continuous
+      d1_sample_continuous(l.func + (size_t)v * l.nu, l.cdf + (size_t)v * (l.nu + 1), l.func_int[v], l.nu, u.x, d0, pdf0, dummy);
+      float map_pdf = pdf0 * pdf1;
+      s.p1.p_error = mk3(0, 0, 0); s.p1.wo = mk3(0, 0, 0); s.p1.n = mk3(0, 0, 0);
+      if (map_pdf == 0.0f) { s.li = mkc(0, 0, 0); s.wi = mk3(0, 0, 0); s.pdf = 0.0f; s.p1.p = mk3(0, 0, 0); return s; }
+      float theta = d1 * kPi, phi = d0 * 2.0f * kPi;
+      float cos_theta_ = cosf(theta), sin_theta_ = sinf(theta), cos_phi_ = cosf(phi), sin_phi_ = sinf(phi);
+      f3 wi = xf3x4(l.l2w, mk3(sin_theta_ * cos_phi_, sin_theta_ * sin_phi_, cos_theta_));
+      s.pdf = sin_theta_ == 0.0f ? 0.0f : map_pdf / (2.0f * kPi * kPi * sin_theta_);
+      s.p1.p = ref.p + wi * (2.0f * l.world_radius);
+      s.li = mip_lookup(sc.images[l.image], mk2(d0, d1), 0.0f); s.wi = wi;
+      return s;
+    }
+  }
+}
+// Light::pdf_li. Area lights: Shape::pdf_wi (shapes/mod.rs:59-68) re-intersects the emitter triangle.
+RT_DEVN float light_pdf_li(const DScene& sc, const DLight& l, const Interaction& ref, f3 wi) {
+  if (l.kind == 0) {
+    Ray ray = spawn_ray(ref, wi);
+    f3 p0, p1, p2; load_tri(sc.tri_p, l.prim, p0, p1, p2);
+    TriHit h;
+    if (!tri_test_call(p0, p1, p2, ray, h)) return 0.0f;
+    f3 p, n; tri_hit_point_normal(sc, l.prim, h, p, n);
+    return distance_squared(ref.p, p) / (fabsf(dot(n, -wi)) * l.area);
+  }
+  if (l.kind == 3) {  // infinite.rs:183-196
+    f3 w = xf3x4(l.w2l, wi);
+    float theta = spherical_theta(w), phi = spherical_phi(w);
+    float sin_theta_ = sinf(theta);
+    if (sin_theta_ == 0.0f) return 0.0f;
+    f2 p = mk2(phi * kInvPi * 0.5f, theta * kInvPi);  // Distribution2D::pdf, distribution2d.rs:36-49
+    int iu = clampi((int)f2u_sat(p.x * (float)l.nu), 0, l.nu - 1), iv = clampi((int)f2u_sat(p.y * (float)l.nv), 0, l.nv - 1);
+    return (l.func[(size_t)iv * l.nu + iu] / l.mfunc_int) / (2.0f * kPi * kPi * sin_theta_);
+  }
+  return 0.0f;
+}
+RT_DEV bool light_is_delta(const DLight& l) { return l.kind == 1 || l.kind == 2; }  // light/mod.rs:38-40
+
+// ---------------------------------------------------------------- light distribution (rc/lightdistrib.rs)
+RT_DEV f3 bounds_offset(f3 mn, f3 mx, f3 p) {  // bounds.rs:177-190
+  f3 o = p - mn;
+  if (mx.x > mn.x) o.x /= mx.x - mn.x;
+  if (mx.y > mn.y) o.y /= mx.y - mn.y;
+  if (mx.z > mn.z) o.z /= mx.z - mn.z;
+  return o;
+}
+RT_DEV f3 bounds_lerp(f3 mn, f3 mx, f3 t) { return mk3(lerpf(t.x, mn.x, mx.x), lerpf(t.y, mn.y, mx.y), lerpf(t.z, mn.z, mx.z)); }  // :160-166
+RT_DEV long voxel_of(const DScene& sc, f3 p) {  // lightdistrib.rs:187-198
+  f3 offset = bounds_offset(sc.wb_min, sc.wb_max, p);
+  int px = clampi(f2i_sat(offset.x * (float)sc.nvox[0]), 0, sc.nvox[0] - 1);
+  int py = clampi(f2i_sat(offset.y * (float)sc.nvox[1]), 0, sc.nvox[1] - 1);
+  int pz = clampi(f2i_sat(offset.z * (float)sc.nvox[2]), 0, sc.nvox[2] - 1);
+  return ((long)pz * sc.nvox[1] + py) * sc.nvox[0] + px;
+}
+
+}  // namespace rtx

@@ -1,0 +1,559 @@
+// rtx_hip.hip — C-ABI implementation (include/rtx_hip.h): scene upload, the per-frame launch
+// sequence of the wavefront kernels, and the kernel-level entry points used by the parity tests.
+// There is no CPU fallback anywhere in this file: without a gfx950 device every entry point fails.
+#include <hip/hip_runtime.h>
+#include <chrono>
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "../../include/rtx_hip.h"
+#include "rtx_kernels.h"
+
+using namespace rtx;
+
+static thread_local std::string g_err;
+static int fail(int code, const std::string& msg) { g_err = msg; return code; }
+#define HIP_TRY(expr)                                                                                        \
+  do {                                                                                                       \
+    hipError_t e_ = (expr);                                                                                  \
+    if (e_ != hipSuccess) return fail(RT_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(e_));        \
+  } while (0)
+
+struct DevBuf {
+  void* p = nullptr; size_t bytes = 0;
+  ~DevBuf() { if (p) (void)hipFree(p); }
+  hipError_t ensure(size_t n) {
+    if (n <= bytes && p) return hipSuccess;
+    if (p) { (void)hipFree(p); p = nullptr; bytes = 0; }
+    hipError_t e = hipMalloc(&p, n > 0 ? n : 16);
+    if (e == hipSuccess) bytes = n;
+    return e;
+  }
+  template <class T> T* as() const { return (T*)p; }
+};
+
+struct rt_scene {
+  int device = 0;
+  DScene d{};
+  bool small = false;
+  int stack_depth = 64;  // entries the to-visit stack needs for this tree (<= 64, rc/bvh/mod.rs:374)
+  unsigned n_nodes = 0, n_tris = 0; int n_lights = 0;
+  DevBuf nodes, tri_p, tri_n, tri_uv, tri_s, textures, images, materials, lights, texels, dist;
+  std::vector<DLight> h_lights;
+  // light distribution tables (built per render, rc/integrator/path.rs:86-94)
+  DevBuf ld_func, ld_cdf, ld_int;
+  int ld_strategy_built = -1;
+  // per-render workspace
+  DevBuf ws[32];
+  DevBuf film_acc, film_out, counters, stats, filter_table, scrambles, perms;
+  int n_cu = 256;
+};
+
+extern "C" const char* rt_last_error(void) { return g_err.c_str(); }
+extern "C" const char* rt_version(void) { return "rtx-mi355x 0.1 (gfx950 wavefront path tracer)"; }
+extern "C" int rt_device_available(void) {
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess || n <= 0) return 0;
+  return 1;
+}
+
+static int upload(DevBuf& b, const void* src, size_t bytes) {
+  HIP_TRY(b.ensure(bytes));
+  if (bytes) HIP_TRY(hipMemcpy(b.p, src, bytes, hipMemcpyHostToDevice));
+  return RT_OK;
+}
+
+static void fill_ewa_lut() {
+  float lut[128];
+  for (int i = 0; i < 128; ++i) {  // rc/mipmap.rs:33-44
+    float alpha = 2.0f;
+    float r2 = (float)i / (128.0f - 1.0f);
+    lut[i] = expf(-alpha * r2) - expf(-alpha);
+  }
+  (void)hipMemcpyToSymbol(HIP_SYMBOL(kEwaLut), lut, sizeof(lut));
+}
+
+extern "C" int rt_scene_create(const rt_scene_desc* desc, int device, rt_scene** out) {
+  if (!desc || !out) return fail(RT_ERR_INVALID, "null argument");
+  if (!rt_device_available()) return fail(RT_ERR_NO_DEVICE, "no HIP device visible; this backend has no CPU fallback");
+  if (desc->n_nodes == 0 || desc->n_tris == 0 || !desc->nodes || !desc->tri_p || !desc->tri_meta) return fail(RT_ERR_INVALID, "empty scene");
+  if (device >= 0) HIP_TRY(hipSetDevice(device));
+  int dev = 0; HIP_TRY(hipGetDevice(&dev));
+  rt_scene* s = new rt_scene();
+  s->device = dev;
+  hipDeviceProp_t prop; if (hipGetDeviceProperties(&prop, dev) == hipSuccess) s->n_cu = prop.multiProcessorCount;
+  s->n_nodes = desc->n_nodes; s->n_tris = desc->n_tris; s->n_lights = (int)desc->n_lights;
+  int rc;
+#define TRY_RC(x) do { rc = (x); if (rc != RT_OK) { delete s; return rc; } } while (0)
+  TRY_RC(upload(s->nodes, desc->nodes, sizeof(rt_bvh_node) * (size_t)desc->n_nodes));
+  // 48-byte triangle records: coordinates + meta in the w lanes
+  std::vector<float> tp((size_t)desc->n_tris * 12);
+  for (size_t i = 0; i < desc->n_tris; ++i) {
+    const float* p = desc->tri_p + 9 * i; const rt_tri_meta& m = desc->tri_meta[i];
+    float* q = &tp[12 * i];
+    q[0] = p[0]; q[1] = p[1]; q[2] = p[2]; memcpy(&q[3], &m.material, 4);
+    q[4] = p[3]; q[5] = p[4]; q[6] = p[5]; memcpy(&q[7], &m.light, 4);
+    q[8] = p[6]; q[9] = p[7]; q[10] = p[8]; memcpy(&q[11], &m.flags, 4);
+    if ((m.flags & RT_TRI_HAS_N) && !desc->tri_n) { delete s; return fail(RT_ERR_INVALID, "tri flags need tri_n"); }
+    if ((m.flags & RT_TRI_HAS_UV) && !desc->tri_uv) { delete s; return fail(RT_ERR_INVALID, "tri flags need tri_uv"); }
+    if ((m.flags & RT_TRI_HAS_S) && !desc->tri_s) { delete s; return fail(RT_ERR_INVALID, "tri flags need tri_s"); }
+    if (m.material < 0 || (uint32_t)m.material >= desc->n_materials) { delete s; return fail(RT_ERR_INVALID, "material index out of range"); }
+    if (m.light >= (int)desc->n_lights) { delete s; return fail(RT_ERR_INVALID, "light index out of range"); }
+  }
+  TRY_RC(upload(s->tri_p, tp.data(), tp.size() * 4));
+  if (desc->tri_n) TRY_RC(upload(s->tri_n, desc->tri_n, (size_t)desc->n_tris * 36));
+  if (desc->tri_uv) TRY_RC(upload(s->tri_uv, desc->tri_uv, (size_t)desc->n_tris * 24));
+  if (desc->tri_s) TRY_RC(upload(s->tri_s, desc->tri_s, (size_t)desc->n_tris * 36));
+  // images: one texel blob
+  std::vector<DImage> himg(desc->n_images);
+  {
+    size_t total = 0;
+    for (uint32_t i = 0; i < desc->n_images; ++i) total += desc->images[i].n_texels;
+    std::vector<float> blob(total * 3 + 4);
+    size_t base = 0;
+    for (uint32_t i = 0; i < desc->n_images; ++i) {
+      const rt_image& im = desc->images[i];
+      if (im.n_levels <= 0 || im.n_levels > RT_MAX_MIP_LEVELS) { delete s; return fail(RT_ERR_INVALID, "bad mip level count"); }
+      memcpy(&blob[base * 3], im.texels, im.n_texels * 12);
+      DImage& d = himg[i];
+      d.n_levels = im.n_levels; d.trilinear = im.trilinear; d.max_aniso = im.max_anisotropy; d.wrap = im.wrap;
+      for (int l = 0; l < 16; ++l) { d.w[l] = l < im.n_levels ? im.width[l] : 0; d.h[l] = l < im.n_levels ? im.height[l] : 0; d.off[l] = l < im.n_levels ? base + im.offset[l] : 0; }
+      base += im.n_texels;
+    }
+    TRY_RC(upload(s->texels, blob.data(), blob.size() * 4));
+    for (auto& d : himg) d.texels = s->texels.as<float>();
+    TRY_RC(upload(s->images, himg.data(), himg.size() * sizeof(DImage)));
+  }
+  std::vector<DTexture> htex(desc->n_textures);
+  for (uint32_t i = 0; i < desc->n_textures; ++i) {
+    const rt_texture& t = desc->textures[i]; DTexture& d = htex[i];
+    d.kind = t.kind; d.v[0] = t.value[0]; d.v[1] = t.value[1]; d.v[2] = t.value[2];
+    d.tex1 = t.tex1; d.tex2 = t.tex2; d.amount = t.amount; d.image = t.image;
+    d.su = t.mapping[0]; d.sv = t.mapping[1]; d.du = t.mapping[2]; d.dv = t.mapping[3];
+    auto ok = [&](int id) { return id >= 0 && (uint32_t)id < desc->n_textures; };
+    if ((t.kind == RT_TEX_SCALE || t.kind == RT_TEX_MIX) && (!ok(t.tex1) || !ok(t.tex2))) { delete s; return fail(RT_ERR_INVALID, "texture operand out of range"); }
+    if (t.kind == RT_TEX_MIX && !ok(t.amount)) { delete s; return fail(RT_ERR_INVALID, "mix amount out of range"); }
+    if (t.kind == RT_TEX_IMAGE && (t.image < 0 || (uint32_t)t.image >= desc->n_images)) { delete s; return fail(RT_ERR_INVALID, "image index out of range"); }
+  }
+  // scale/mix nesting deeper than two levels is not expanded on the device
+  for (uint32_t i = 0; i < desc->n_textures; ++i) {
+    const rt_texture& t = desc->textures[i];
+    if (t.kind != RT_TEX_SCALE && t.kind != RT_TEX_MIX) continue;
+    const int ops[3] = {t.tex1, t.tex2, t.kind == RT_TEX_MIX ? t.amount : -1};
+    for (int k = 0; k < 3; ++k) {
+      if (ops[k] < 0) continue;
+      const rt_texture& c = desc->textures[ops[k]];
+      if (c.kind != RT_TEX_SCALE && c.kind != RT_TEX_MIX) continue;
+      if (k == 2) { delete s; return fail(RT_ERR_INVALID, "mix amount must be a leaf texture"); }
+      const int cops[3] = {c.tex1, c.tex2, c.kind == RT_TEX_MIX ? c.amount : -1};
+      for (int q = 0; q < 3; ++q)
+        if (cops[q] >= 0) { int kk = desc->textures[cops[q]].kind; if (kk == RT_TEX_SCALE || kk == RT_TEX_MIX) { delete s; return fail(RT_ERR_INVALID, "texture nesting deeper than 2"); } }
+    }
+  }
+  TRY_RC(upload(s->textures, htex.data(), htex.size() * sizeof(DTexture)));
+  std::vector<DMaterial> hmat(desc->n_materials);
+  for (uint32_t i = 0; i < desc->n_materials; ++i) {
+    const rt_material& m = desc->materials[i];
+    hmat[i].kind = m.kind; hmat[i].remap = m.remap_roughness;
+    for (int k = 0; k < 16; ++k) hmat[i].slot[k] = m.slot[k];
+    if (m.kind == RT_MAT_MIX) {
+      for (int side = 0; side < 2; ++side) {
+        int c = m.slot[RT_SLOT_M1 + side];
+        if (c < 0 || (uint32_t)c >= desc->n_materials) { delete s; return fail(RT_ERR_INVALID, "mix operand out of range"); }
+        if (desc->materials[c].kind == RT_MAT_MIX)
+          for (int q = 0; q < 2; ++q) { int g = desc->materials[c].slot[RT_SLOT_M1 + q]; if (g < 0 || (uint32_t)g >= desc->n_materials || desc->materials[g].kind == RT_MAT_MIX) { delete s; return fail(RT_ERR_INVALID, "mix nesting deeper than 2"); } }
+      }
+    }
+  }
+  TRY_RC(upload(s->materials, hmat.data(), hmat.size() * sizeof(DMaterial)));
+  // lights (+ env distributions in one blob)
+  s->h_lights.resize(desc->n_lights);
+  {
+    size_t total = 0;
+    for (uint32_t i = 0; i < desc->n_lights; ++i) {
+      const rt_light& l = desc->lights[i];
+      if (l.kind == RT_LIGHT_INFINITE) total += (size_t)l.dist_nv * l.dist_nu + (size_t)l.dist_nv * (l.dist_nu + 1) + (size_t)l.dist_nv * 3 + 1;
+    }
+    std::vector<float> blob(total + 4);
+    TRY_RC([&]() { return s->dist.ensure(blob.size() * 4) == hipSuccess ? RT_OK : fail(RT_ERR_OOM, "dist alloc"); }());
+    size_t base = 0; int n_inf = 0;
+    for (uint32_t i = 0; i < desc->n_lights; ++i) {
+      const rt_light& l = desc->lights[i]; DLight& d = s->h_lights[i];
+      memset(&d, 0, sizeof(d));
+      d.kind = l.kind; d.prim = l.prim; d.rgb[0] = l.rgb[0]; d.rgb[1] = l.rgb[1]; d.rgb[2] = l.rgb[2]; d.two_sided = l.two_sided;
+      d.vec[0] = l.vec[0]; d.vec[1] = l.vec[1]; d.vec[2] = l.vec[2]; d.area = l.area; d.world_radius = l.world_radius; d.image = l.image;
+      memcpy(d.l2w, l.l2w, 48); memcpy(d.w2l, l.w2l, 48);
+      if (l.kind == RT_LIGHT_DIFFUSE_AREA && (l.prim < 0 || (uint32_t)l.prim >= desc->n_tris)) { delete s; return fail(RT_ERR_INVALID, "area light prim out of range"); }
+      if (l.kind == RT_LIGHT_INFINITE) {
+        if (n_inf >= 4) { delete s; return fail(RT_ERR_INVALID, "more than 4 infinite lights"); }
+        if (l.image < 0 || (uint32_t)l.image >= desc->n_images) { delete s; return fail(RT_ERR_INVALID, "infinite light image out of range"); }
+        s->d.infinite_ids[n_inf++] = (int)i;
+        d.nu = l.dist_nu; d.nv = l.dist_nv; d.mfunc_int = l.marg_func_int;
+        float* db = s->dist.as<float>();
+        size_t nfunc = (size_t)l.dist_nv * l.dist_nu, ncdf = (size_t)l.dist_nv * (l.dist_nu + 1);
+        memcpy(&blob[base], l.dist_func, nfunc * 4); d.func = db + base; base += nfunc;
+        memcpy(&blob[base], l.dist_cdf, ncdf * 4); d.cdf = db + base; base += ncdf;
+        memcpy(&blob[base], l.dist_func_int, (size_t)l.dist_nv * 4); d.func_int = db + base; base += l.dist_nv;
+        memcpy(&blob[base], l.marg_func, (size_t)l.dist_nv * 4); d.mfunc = db + base; base += l.dist_nv;
+        memcpy(&blob[base], l.marg_cdf, ((size_t)l.dist_nv + 1) * 4); d.mcdf = db + base; base += (size_t)l.dist_nv + 1;
+      }
+    }
+    s->d.n_infinite = n_inf;
+    if (hipMemcpy(s->dist.p, blob.data(), blob.size() * 4, hipMemcpyHostToDevice) != hipSuccess) { delete s; return fail(RT_ERR_HIP, "dist upload"); }
+    TRY_RC(upload(s->lights, s->h_lights.data(), s->h_lights.size() * sizeof(DLight)));
+  }
+#undef TRY_RC
+  DScene& d = s->d;
+  d.nodes = s->nodes.as<float4>(); d.n_nodes = desc->n_nodes;
+  d.tri_p = s->tri_p.as<float4>(); d.n_tris = desc->n_tris;
+  d.tri_n = s->tri_n.as<float>(); d.tri_uv = s->tri_uv.as<float>(); d.tri_s = s->tri_s.as<float>();
+  d.textures = s->textures.as<DTexture>(); d.images = s->images.as<DImage>(); d.materials = s->materials.as<DMaterial>(); d.lights = s->lights.as<DLight>();
+  d.n_lights = (int)desc->n_lights;
+  d.wb_min = f3{desc->nodes[0].bmin[0], desc->nodes[0].bmin[1], desc->nodes[0].bmin[2]};
+  d.wb_max = f3{desc->nodes[0].bmax[0], desc->nodes[0].bmax[1], desc->nodes[0].bmax[2]};
+  d.ld_uniform = 1; d.nvox[0] = d.nvox[1] = d.nvox[2] = 1;
+  s->small = desc->n_nodes <= RT_SMALL_NODES && desc->n_tris <= RT_SMALL_TRIS;
+  {  // tree height bounds the number of simultaneously pending stack entries
+    std::vector<int> depth(desc->n_nodes, 0); int maxd = 0;
+    for (uint32_t i = 0; i < desc->n_nodes; ++i) {
+      const rt_bvh_node& n = desc->nodes[i];
+      if (n.n_prims == 0) {
+        if (i + 1 >= desc->n_nodes || n.offset >= desc->n_nodes || n.offset <= i) { delete s; return fail(RT_ERR_INVALID, "malformed BVH"); }
+        depth[i + 1] = depth[i] + 1; depth[n.offset] = depth[i] + 1;
+      } else if ((uint64_t)n.offset + n.n_prims > desc->n_tris) { delete s; return fail(RT_ERR_INVALID, "leaf range out of bounds"); }
+      if (depth[i] > maxd) maxd = depth[i];
+    }
+    if (maxd + 1 > 64) { delete s; return fail(RT_ERR_INVALID, "BVH deeper than the 64-entry traversal stack"); }
+    s->stack_depth = maxd + 1;
+  }
+  fill_ewa_lut();
+  HIP_TRY(hipDeviceSynchronize());
+  *out = s;
+  return RT_OK;
+}
+
+extern "C" void rt_scene_destroy(rt_scene* s) {
+  if (!s) return;
+  (void)hipSetDevice(s->device);
+  delete s;
+}
+
+// ---------------------------------------------------------------------------------------------- light distribution
+// PathIntegrator::preprocess (rc/integrator/path.rs:86-94) + SpatialLightDistribution::new (rc/lightdistrib.rs:67-99)
+static int build_light_distribution(rt_scene* s, int strategy, hipStream_t stream) {
+  DScene& d = s->d;
+  const int nl = s->n_lights;
+  const bool uniform = strategy == 1 || nl == 1 || nl == 0;
+  if (uniform) {
+    const int n = nl > 0 ? nl : 1;
+    std::vector<float> func(n, 1.0f), cdf(n + 1, 0.0f);  // Distribution1D::new over [1.0; n]
+    for (int i = 1; i < n + 1; ++i) cdf[i] = cdf[i - 1] + func[i - 1] / (float)n;
+    float func_int = cdf[n];
+    if (func_int == 0.0f) for (int i = 1; i < n + 1; ++i) cdf[i] = (float)i / (float)n;
+    else for (int i = 1; i < n + 1; ++i) cdf[i] /= func_int;
+    int rc;
+    if ((rc = upload(s->ld_func, func.data(), func.size() * 4)) != RT_OK) return rc;
+    if ((rc = upload(s->ld_cdf, cdf.data(), cdf.size() * 4)) != RT_OK) return rc;
+    if ((rc = upload(s->ld_int, &func_int, 4)) != RT_OK) return rc;
+    d.ld_uniform = 1; d.nvox[0] = d.nvox[1] = d.nvox[2] = 1;
+  } else {
+    float diag[3] = {d.wb_max.x - d.wb_min.x, d.wb_max.y - d.wb_min.y, d.wb_max.z - d.wb_min.z};
+    int ext = diag[0] > diag[1] ? (diag[0] > diag[2] ? 0 : 2) : (diag[1] > diag[2] ? 1 : 2);
+    float b_max = diag[ext];
+    size_t total = 1;
+    for (int i = 0; i < 3; ++i) {
+      float r = roundf(diag[i] / b_max * 64.0f);
+      unsigned v = (r != r || r <= 0.0f) ? 0u : (unsigned)r;
+      d.nvox[i] = (int)(v > 1u ? v : 1u);
+      total *= (size_t)d.nvox[i];
+    }
+    HIP_TRY(s->ld_func.ensure(total * nl * 4)); HIP_TRY(s->ld_cdf.ensure(total * (nl + 1) * 4)); HIP_TRY(s->ld_int.ensure(total * 4));
+    d.ld_uniform = 0;
+    d.ld_func = s->ld_func.as<float>(); d.ld_cdf = s->ld_cdf.as<float>(); d.ld_int = s->ld_int.as<float>();
+    hipLaunchKernelGGL(k_lightdist_build, dim3((unsigned)((total + 127) / 128)), dim3(128), 0, stream, d, s->ld_func.as<float>(), s->ld_cdf.as<float>(), s->ld_int.as<float>());
+    HIP_TRY(hipGetLastError());
+  }
+  d.ld_func = s->ld_func.as<float>(); d.ld_cdf = s->ld_cdf.as<float>(); d.ld_int = s->ld_int.as<float>();
+  s->ld_strategy_built = strategy;
+  return RT_OK;
+}
+
+extern "C" int rt_light_distribution(rt_scene* s, int32_t n_voxels[3], float* func, float* cdf, float* func_int) {
+  if (!s) return fail(RT_ERR_INVALID, "null scene");
+  HIP_TRY(hipSetDevice(s->device));
+  int rc = build_light_distribution(s, 0, nullptr);
+  if (rc != RT_OK) return rc;
+  HIP_TRY(hipDeviceSynchronize());
+  if (s->d.ld_uniform) { n_voxels[0] = n_voxels[1] = n_voxels[2] = 0; return RT_OK; }
+  n_voxels[0] = s->d.nvox[0]; n_voxels[1] = s->d.nvox[1]; n_voxels[2] = s->d.nvox[2];
+  size_t total = (size_t)s->d.nvox[0] * s->d.nvox[1] * s->d.nvox[2];
+  if (func) HIP_TRY(hipMemcpy(func, s->ld_func.p, total * s->n_lights * 4, hipMemcpyDeviceToHost));
+  if (cdf) HIP_TRY(hipMemcpy(cdf, s->ld_cdf.p, total * (s->n_lights + 1) * 4, hipMemcpyDeviceToHost));
+  if (func_int) HIP_TRY(hipMemcpy(func_int, s->ld_int.p, total * 4, hipMemcpyDeviceToHost));
+  return RT_OK;
+}
+
+// ---------------------------------------------------------------------------------------------- trace launches
+template <bool ANY, bool COUNT, bool SMALL, int BLOCK, int DEPTH>
+static void launch_trace_v(rt_scene* s, const float4* ro, const float4* rd, const unsigned* queue, const unsigned* count_ptr, unsigned count_static,
+                           float4* hits, unsigned* occ, unsigned long long* stats, int st_rays, int st_nodes, int st_tris, hipStream_t stream) {
+  // persistent grid: enough workgroups to fill every CU at the kernel's LDS-limited residency
+  const unsigned lds = (unsigned)(DEPTH * BLOCK * 4 + (SMALL ? (2 * RT_SMALL_NODES + 3 * RT_SMALL_TRIS) * 16 : 32));
+  unsigned per_cu = (160u * 1024u) / lds; if (per_cu * BLOCK > 2048u) per_cu = 2048u / BLOCK; if (per_cu < 1) per_cu = 1;
+  hipLaunchKernelGGL((k_trace<ANY, COUNT, SMALL, BLOCK, DEPTH>), dim3((unsigned)s->n_cu * per_cu), dim3(BLOCK), 0, stream, s->d, ro, rd, queue, count_ptr,
+                     count_static, hits, occ, stats, st_rays, st_nodes, st_tris);
+}
+template <bool ANY, bool COUNT>
+static void launch_trace_c(rt_scene* s, const float4* ro, const float4* rd, const unsigned* queue, const unsigned* count_ptr, unsigned count_static,
+                           float4* hits, unsigned* occ, unsigned long long* stats, int st_rays, int st_nodes, int st_tris, hipStream_t stream) {
+#define RT_ARGS s, ro, rd, queue, count_ptr, count_static, hits, occ, stats, st_rays, st_nodes, st_tris, stream
+  if (s->small) {
+    if (s->stack_depth <= 16) launch_trace_v<ANY, COUNT, true, 256, 16>(RT_ARGS);
+    else if (s->stack_depth <= 32) launch_trace_v<ANY, COUNT, true, 256, 32>(RT_ARGS);
+    else launch_trace_v<ANY, COUNT, true, 128, 64>(RT_ARGS);
+  } else {
+    if (s->stack_depth <= 32) launch_trace_v<ANY, COUNT, false, 128, 32>(RT_ARGS);
+    else launch_trace_v<ANY, COUNT, false, 128, 64>(RT_ARGS);
+  }
+#undef RT_ARGS
+}
+template <bool ANY>
+static void launch_trace(rt_scene* s, bool count, const float4* ro, const float4* rd, const unsigned* queue, const unsigned* count_ptr, unsigned count_static,
+                         float4* hits, unsigned* occ, unsigned long long* stats, int st_rays, int st_nodes, int st_tris, hipStream_t stream) {
+  if (count) launch_trace_c<ANY, true>(s, ro, rd, queue, count_ptr, count_static, hits, occ, stats, st_rays, st_nodes, st_tris, stream);
+  else launch_trace_c<ANY, false>(s, ro, rd, queue, count_ptr, count_static, hits, occ, stats, st_rays, st_nodes, st_tris, stream);
+}
+
+static int trace_batch(rt_scene* s, const float* rays, uint64_t n, bool any, float* hits, uint32_t* occluded, uint64_t counters[2]) {
+  if (!s || !rays || n == 0 || n > 0x7fffffffull) return fail(RT_ERR_INVALID, "bad trace batch");
+  HIP_TRY(hipSetDevice(s->device));
+  DevBuf ro, rd, out, st;
+  HIP_TRY(ro.ensure(n * 16)); HIP_TRY(rd.ensure(n * 16)); HIP_TRY(out.ensure(n * 16)); HIP_TRY(st.ensure(ST_COUNT * 8));
+  std::vector<float> o(n * 4), d(n * 4);
+  for (uint64_t i = 0; i < n; ++i) {
+    const float* r = rays + 8 * i;
+    o[4 * i] = r[0]; o[4 * i + 1] = r[1]; o[4 * i + 2] = r[2]; o[4 * i + 3] = r[3];
+    d[4 * i] = r[4]; d[4 * i + 1] = r[5]; d[4 * i + 2] = r[6]; d[4 * i + 3] = 0.0f;
+  }
+  HIP_TRY(hipMemcpy(ro.p, o.data(), n * 16, hipMemcpyHostToDevice));
+  HIP_TRY(hipMemcpy(rd.p, d.data(), n * 16, hipMemcpyHostToDevice));
+  HIP_TRY(hipMemset(st.p, 0, ST_COUNT * 8));
+  if (any) launch_trace<true>(s, true, ro.as<float4>(), rd.as<float4>(), nullptr, nullptr, (unsigned)n, nullptr, out.as<unsigned>(), st.as<unsigned long long>(), ST_RAYS_SHADOW, ST_NODES_SHADOW, ST_TRIS_SHADOW, nullptr);
+  else launch_trace<false>(s, true, ro.as<float4>(), rd.as<float4>(), nullptr, nullptr, (unsigned)n, out.as<float4>(), nullptr, st.as<unsigned long long>(), ST_RAYS_CLOSEST, ST_NODES_CLOSEST, ST_TRIS_CLOSEST, nullptr);
+  HIP_TRY(hipGetLastError());
+  HIP_TRY(hipDeviceSynchronize());
+  if (any) HIP_TRY(hipMemcpy(occluded, out.p, n * 4, hipMemcpyDeviceToHost));
+  else HIP_TRY(hipMemcpy(hits, out.p, n * 16, hipMemcpyDeviceToHost));
+  if (counters) {
+    unsigned long long h[ST_COUNT];
+    HIP_TRY(hipMemcpy(h, st.p, sizeof(h), hipMemcpyDeviceToHost));
+    counters[0] = any ? h[ST_NODES_SHADOW] : h[ST_NODES_CLOSEST];
+    counters[1] = any ? h[ST_TRIS_SHADOW] : h[ST_TRIS_CLOSEST];
+  }
+  return RT_OK;
+}
+extern "C" int rt_trace_closest(rt_scene* s, const float* rays, uint64_t n, float* hits, uint64_t counters[2]) { return trace_batch(s, rays, n, false, hits, nullptr, counters); }
+extern "C" int rt_trace_any(rt_scene* s, const float* rays, uint64_t n, uint32_t* occluded, uint64_t counters[2]) { return trace_batch(s, rays, n, true, nullptr, occluded, counters); }
+
+extern "C" int rt_trace_closest_device(rt_scene* s, const void* d_rays, uint64_t n, void* d_hits, int reps, void* stream_, float* ms_per_launch) {
+  if (!s || !d_rays || !d_hits || n == 0 || reps <= 0) return fail(RT_ERR_INVALID, "bad arguments");
+  HIP_TRY(hipSetDevice(s->device));
+  hipStream_t stream = (hipStream_t)stream_;
+  // d_rays: n x (float4 o|tmax, float4 d) planar: first n float4 origins, then n float4 directions
+  const float4* ro = (const float4*)d_rays; const float4* rd = ro + n;
+  hipEvent_t e0, e1; HIP_TRY(hipEventCreate(&e0)); HIP_TRY(hipEventCreate(&e1));
+  HIP_TRY(hipEventRecord(e0, stream));
+  for (int i = 0; i < reps; ++i)
+    launch_trace<false>(s, false, ro, rd, nullptr, nullptr, (unsigned)n, (float4*)d_hits, nullptr, nullptr, 0, 0, 0, stream);
+  HIP_TRY(hipEventRecord(e1, stream));
+  HIP_TRY(hipEventSynchronize(e1));
+  float ms = 0; HIP_TRY(hipEventElapsedTime(&ms, e0, e1));
+  if (ms_per_launch) *ms_per_launch = ms / (float)reps;
+  (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
+  return RT_OK;
+}
+
+// ---------------------------------------------------------------------------------------------- sampler tables
+static unsigned next_pow2(unsigned v) { unsigned p = 1; while (p < v) p <<= 1; return p; }
+
+extern "C" int rt_sampler_tables(int32_t spp_, int32_t dims, uint64_t pixel0, uint64_t n_pixels, uint32_t* scrambles, uint16_t* perms) {
+  if (!rt_device_available()) return fail(RT_ERR_NO_DEVICE, "no HIP device visible; this backend has no CPU fallback");
+  if (spp_ <= 0 || dims <= 0 || dims > 8 || n_pixels == 0) return fail(RT_ERR_INVALID, "bad sampler arguments");
+  const unsigned spp = next_pow2((unsigned)spp_);
+  if (spp > 16384) return fail(RT_ERR_INVALID, "spp > 16384 unsupported");
+  DevBuf sc, pm;
+  HIP_TRY(sc.ensure(n_pixels * 3 * dims * 4)); HIP_TRY(pm.ensure(n_pixels * 2 * dims * spp * 2));
+  FrameParams fp{};
+  const size_t lds = 64 * (size_t)(spp + 2) * 2;
+  HIP_TRY(hipFuncSetAttribute((const void*)k_sampler_tables, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  hipLaunchKernelGGL(k_sampler_tables, dim3((unsigned)((n_pixels + 63) / 64)), dim3(64), lds, nullptr, fp, (unsigned)n_pixels, spp, (unsigned)dims, (unsigned long long)pixel0, 1,
+                     sc.as<unsigned>(), pm.as<unsigned short>());
+  HIP_TRY(hipGetLastError());
+  HIP_TRY(hipDeviceSynchronize());
+  HIP_TRY(hipMemcpy(scrambles, sc.p, n_pixels * 3 * dims * 4, hipMemcpyDeviceToHost));
+  HIP_TRY(hipMemcpy(perms, pm.p, n_pixels * 2 * dims * spp * 2, hipMemcpyDeviceToHost));
+  return RT_OK;
+}
+
+// ---------------------------------------------------------------------------------------------- render
+struct KTimer {
+  bool on; hipStream_t st; hipEvent_t a, b; double* acc;
+  std::vector<std::pair<hipEvent_t, hipEvent_t>> pending; std::vector<double*> dst;
+  void begin(double* where) { if (!on) return; hipEvent_t x, y; hipEventCreate(&x); hipEventCreate(&y); hipEventRecord(x, st); pending.push_back({x, y}); dst.push_back(where); }
+  void end() { if (!on) return; hipEventRecord(pending.back().second, st); }
+  void collect() {
+    for (size_t i = 0; i < pending.size(); ++i) {
+      float ms = 0; hipEventSynchronize(pending[i].second); hipEventElapsedTime(&ms, pending[i].first, pending[i].second);
+      *dst[i] += ms; hipEventDestroy(pending[i].first); hipEventDestroy(pending[i].second);
+    }
+    pending.clear(); dst.clear();
+  }
+};
+
+extern "C" int rt_render(rt_scene* s, const rt_camera* cam, const rt_film_desc* film, const rt_sampler_desc* smp, const rt_path_desc* path,
+                         const rt_shard* shard, uint32_t flags, void* stream_, float* film_xyzw, rt_stats* stats_out) {
+  if (!s || !cam || !film || !smp || !path || !film_xyzw) return fail(RT_ERR_INVALID, "null argument");
+  HIP_TRY(hipSetDevice(s->device));
+  hipStream_t stream = (hipStream_t)stream_;
+  const unsigned spp = next_pow2((unsigned)(smp->spp > 0 ? smp->spp : 1));
+  const unsigned dims = (unsigned)smp->dimensions;
+  if (dims < 2 || dims > 8) return fail(RT_ERR_INVALID, "sampler dimensions must be in [2, 8]");
+  if (spp > 16384) return fail(RT_ERR_INVALID, "spp > 16384 unsupported");
+  unsigned spp_log2 = 0; while ((1u << spp_log2) < spp) ++spp_log2;
+  const int rank = shard ? shard->rank : 0, world = shard ? shard->world_size : 1;
+  if (world < 1 || rank < 0 || rank >= world) return fail(RT_ERR_INVALID, "bad shard");
+  const int W = film->sample_bounds[2] - film->sample_bounds[0], H = film->sample_bounds[3] - film->sample_bounds[1];
+  const int cw = film->cropped_pixel_bounds[2] - film->cropped_pixel_bounds[0], ch = film->cropped_pixel_bounds[3] - film->cropped_pixel_bounds[1];
+  if (W <= 0 || H <= 0 || cw <= 0 || ch <= 0) return fail(RT_ERR_INVALID, "empty film");
+  if (film->filter_radius[0] > 8.0f || film->filter_radius[1] > 8.0f) return fail(RT_ERR_INVALID, "filter radius > 8");
+  auto t_begin = std::chrono::steady_clock::now();
+
+  FrameParams fp{};
+  memcpy(fp.r2c, cam->raster_to_camera, 64); memcpy(fp.c2w, cam->camera_to_world, 64);
+  fp.dx_camera = f3{cam->dx_camera[0], cam->dx_camera[1], cam->dx_camera[2]}; fp.dy_camera = f3{cam->dy_camera[0], cam->dy_camera[1], cam->dy_camera[2]};
+  fp.lens_radius = cam->lens_radius; fp.focal_distance = cam->focal_distance;
+  fp.crop_x0 = film->cropped_pixel_bounds[0]; fp.crop_y0 = film->cropped_pixel_bounds[1]; fp.crop_x1 = film->cropped_pixel_bounds[2]; fp.crop_y1 = film->cropped_pixel_bounds[3];
+  fp.sb_x0 = film->sample_bounds[0]; fp.sb_y0 = film->sample_bounds[1]; fp.sb_x1 = film->sample_bounds[2]; fp.sb_y1 = film->sample_bounds[3];
+  fp.radius_x = film->filter_radius[0]; fp.radius_y = film->filter_radius[1]; fp.max_sample_luminance = film->max_sample_luminance;
+  fp.max_depth = (int)(uint8_t)path->max_depth; fp.rr_threshold = path->rr_threshold;
+  fp.pb_x0 = path->pixel_bounds[0]; fp.pb_y0 = path->pixel_bounds[1]; fp.pb_x1 = path->pixel_bounds[2]; fp.pb_y1 = path->pixel_bounds[3];
+  fp.rank = rank; fp.world = world;
+
+  // owned sample rows (tile rows of 16, interleaved over ranks)
+  unsigned long long owned_rows = 0;
+  for (int row = 0; row < H; ++row) if (((row >> 4) % world) == rank) owned_rows++;
+  const unsigned long long owned_pixels = owned_rows * (unsigned long long)W;
+
+  rt_stats stats{};
+  KTimer tm{(flags & RT_FLAG_TIME_KERNELS) != 0, stream};
+
+  // integrator.preprocess (renderer.rs:30)
+  tm.begin(&stats.ms_lightdist);
+  int rc = build_light_distribution(s, path->light_strategy, stream);
+  if (rc != RT_OK) return rc;
+  tm.end();
+
+  // pass sizing: whole pixels x all spp, at most ~2^23 paths per pass
+  const unsigned long long target_paths = 1ull << 23;
+  unsigned long long chunk_pixels = target_paths / spp; if (chunk_pixels < 64) chunk_pixels = 64;
+  if (chunk_pixels > owned_pixels) chunk_pixels = owned_pixels;
+  const unsigned long long cap = chunk_pixels * spp;
+  if (cap > 0x7fffffffull) return fail(RT_ERR_INVALID, "pass too large");
+
+  // workspace
+  enum { B_RAYO, B_RAYD, B_HIT, B_BETA, B_LACC, B_RNG, B_PFILM, B_SHO, B_SHD, B_SHOCC, B_MIO, B_MID, B_MIHIT, B_PA, B_PB, B_PC, B_PF, B_QIN, B_QOUT, B_QSH, B_QMI };
+  const size_t sz16 = cap * 16, sz8 = cap * 8, sz4 = cap * 4;
+  const size_t sizes[] = {sz16, sz16, sz16, sz16, sz16, sz8, sz8, sz16, sz16, sz4, sz16, sz16, sz16, sz16, sz16, sz16, sz4, sz4, sz4, sz4, sz4};
+  for (int i = 0; i < 21; ++i) HIP_TRY(s->ws[i].ensure(sizes[i]));
+  HIP_TRY(s->counters.ensure(64)); HIP_TRY(s->stats.ensure(ST_COUNT * 8));
+  HIP_TRY(s->film_acc.ensure((size_t)cw * ch * 16));
+  HIP_TRY(s->filter_table.ensure(1024));
+  HIP_TRY(s->scrambles.ensure(chunk_pixels * 3 * dims * 4)); HIP_TRY(s->perms.ensure(chunk_pixels * 2 * dims * spp * 2));
+  float4* d_out = nullptr;
+  if (flags & RT_FLAG_FILM_ON_DEVICE) d_out = (float4*)film_xyzw;
+  else { HIP_TRY(s->film_out.ensure((size_t)cw * ch * 16)); d_out = s->film_out.as<float4>(); }
+  HIP_TRY(hipMemcpyAsync(s->filter_table.p, film->filter_table, 1024, hipMemcpyHostToDevice, stream));
+  HIP_TRY(hipMemsetAsync(s->film_acc.p, 0, (size_t)cw * ch * 16, stream));
+  HIP_TRY(hipMemsetAsync(s->stats.p, 0, ST_COUNT * 8, stream));
+
+  PassState ps{};
+  ps.spp = spp; ps.spp_log2 = spp_log2; ps.dims = dims;
+  ps.scrambles = s->scrambles.as<unsigned>(); ps.perms = s->perms.as<unsigned short>();
+  ps.ray_o = s->ws[B_RAYO].as<float4>(); ps.ray_d = s->ws[B_RAYD].as<float4>(); ps.hit = s->ws[B_HIT].as<float4>();
+  ps.beta = s->ws[B_BETA].as<float4>(); ps.lacc = s->ws[B_LACC].as<float4>(); ps.rng = s->ws[B_RNG].as<unsigned long long>();
+  ps.pfilm = s->ws[B_PFILM].as<float2>();
+  ps.sh_o = s->ws[B_SHO].as<float4>(); ps.sh_d = s->ws[B_SHD].as<float4>(); ps.sh_occ = s->ws[B_SHOCC].as<unsigned>();
+  ps.mi_o = s->ws[B_MIO].as<float4>(); ps.mi_d = s->ws[B_MID].as<float4>(); ps.mi_hit = s->ws[B_MIHIT].as<float4>();
+  ps.pend_a = s->ws[B_PA].as<float4>(); ps.pend_b = s->ws[B_PB].as<float4>(); ps.pend_c = s->ws[B_PC].as<float4>(); ps.pend_flags = s->ws[B_PF].as<unsigned>();
+  unsigned* q_a = s->ws[B_QIN].as<unsigned>(); unsigned* q_b = s->ws[B_QOUT].as<unsigned>();
+  ps.q_shadow = s->ws[B_QSH].as<unsigned>(); ps.q_mis = s->ws[B_QMI].as<unsigned>();
+  ps.counters = s->counters.as<unsigned>(); ps.stats = s->stats.as<unsigned long long>();
+
+  const size_t lds = 64 * (size_t)(spp + 2) * 2;
+  HIP_TRY(hipFuncSetAttribute((const void*)k_sampler_tables, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  const bool count = (flags & RT_FLAG_COUNT_TRAVERSAL) != 0;
+  const unsigned pgrid = (unsigned)s->n_cu * 8u;
+  unsigned long long* dstats = s->stats.as<unsigned long long>();
+
+  for (unsigned long long first = 0; first < owned_pixels; first += chunk_pixels) {
+    const unsigned long long npx = std::min(chunk_pixels, owned_pixels - first);
+    fp.chunk_first = first;
+    ps.n_pixels = (unsigned)npx; ps.cap = (unsigned)(npx * spp);
+    ps.q_in = q_a; ps.q_out = q_b;
+    HIP_TRY(hipMemsetAsync(s->counters.p, 0, 64, stream));
+    tm.begin(&stats.ms_sampler);
+    hipLaunchKernelGGL(k_sampler_tables, dim3((unsigned)((npx + 63) / 64)), dim3(64), lds, stream, fp, (unsigned)npx, spp, dims, 0ull, 0, s->scrambles.as<unsigned>(), s->perms.as<unsigned short>());
+    tm.end();
+    tm.begin(&stats.ms_raygen);
+    hipLaunchKernelGGL(k_raygen, dim3(pgrid), dim3(256), 0, stream, fp, ps);
+    tm.end();
+    for (int bounce = 0; bounce <= fp.max_depth; ++bounce) {
+      tm.begin(&stats.ms_trace_closest);
+      launch_trace<false>(s, count, ps.ray_o, ps.ray_d, ps.q_in, &ps.counters[0], 0, ps.hit, nullptr, dstats, ST_RAYS_CLOSEST, ST_NODES_CLOSEST, ST_TRIS_CLOSEST, stream);
+      tm.end();
+      tm.begin(&stats.ms_shade);
+      hipLaunchKernelGGL(k_shade, dim3(pgrid), dim3(256), 0, stream, s->d, fp, ps);
+      tm.end();
+      tm.begin(&stats.ms_trace_any);
+      launch_trace<true>(s, count, ps.sh_o, ps.sh_d, ps.q_shadow, &ps.counters[2], 0, nullptr, ps.sh_occ, dstats, ST_RAYS_SHADOW, ST_NODES_SHADOW, ST_TRIS_SHADOW, stream);
+      tm.end();
+      tm.begin(&stats.ms_trace_mis);
+      launch_trace<false>(s, count, ps.mi_o, ps.mi_d, ps.q_mis, &ps.counters[3], 0, ps.mi_hit, nullptr, dstats, ST_RAYS_MIS, ST_NODES_MIS, ST_TRIS_MIS, stream);
+      tm.end();
+      tm.begin(&stats.ms_resolve);
+      hipLaunchKernelGGL(k_resolve, dim3(pgrid), dim3(256), 0, stream, s->d, ps);
+      hipLaunchKernelGGL(k_next_bounce, dim3(1), dim3(64), 0, stream, ps.counters);
+      tm.end();
+      stats.launches_trace_closest += 2;
+      std::swap(ps.q_in, ps.q_out);
+    }
+    tm.begin(&stats.ms_film);
+    hipLaunchKernelGGL(k_film_accumulate, dim3(pgrid), dim3(256), 0, stream, fp, ps, s->filter_table.as<float>(), s->film_acc.as<float4>());
+    tm.end();
+    stats.n_passes += 1;
+    HIP_TRY(hipGetLastError());
+  }
+  tm.begin(&stats.ms_film);
+  {
+    unsigned long long n = (unsigned long long)cw * ch;
+    hipLaunchKernelGGL(k_film_finalize, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, s->film_acc.as<float4>(), d_out, n);
+  }
+  tm.end();
+  HIP_TRY(hipGetLastError());
+  if (!(flags & RT_FLAG_FILM_ON_DEVICE)) HIP_TRY(hipMemcpyAsync(film_xyzw, d_out, (size_t)cw * ch * 16, hipMemcpyDeviceToHost, stream));
+  HIP_TRY(hipStreamSynchronize(stream));
+  tm.collect();
+  unsigned long long h[ST_COUNT];
+  HIP_TRY(hipMemcpy(h, s->stats.p, sizeof(h), hipMemcpyDeviceToHost));
+  stats.camera_rays = owned_pixels * spp;
+  stats.rays_closest = h[ST_RAYS_CLOSEST]; stats.rays_shadow = h[ST_RAYS_SHADOW]; stats.rays_mis = h[ST_RAYS_MIS];
+  stats.nodes_closest = h[ST_NODES_CLOSEST]; stats.nodes_shadow = h[ST_NODES_SHADOW]; stats.nodes_mis = h[ST_NODES_MIS];
+  stats.tris_closest = h[ST_TRIS_CLOSEST]; stats.tris_shadow = h[ST_TRIS_SHADOW]; stats.tris_mis = h[ST_TRIS_MIS];
+  stats.paths_scrubbed = h[ST_SCRUBBED];
+  stats.ms_total = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_begin).count();
+  if (stats_out) *stats_out = stats;
+  return RT_OK;
+}

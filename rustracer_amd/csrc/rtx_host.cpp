@@ -1,0 +1,611 @@
+// rtx_host.cpp — host layer of include/rtx_host.h: the work rustracer's Rust host does before and
+// around `renderer::render` (scene assembly, SAH BVH, flattening, camera/film set-up), handing the
+// hot path to the HIP backend through the C ABI of include/rtx_hip.h. Compiled with g++
+// -ffp-contract=off: the BVH bounds, SAH costs and camera matrices must come out bit-identical to
+// an f32 evaluation in the reference's operation order (rc/ = rustracer-core/src/).
+#include "../../include/rtx_host.h"
+
+#include <algorithm>
+#include <cmath>
+#include <cstring>
+#include <limits>
+#include <string>
+#include <vector>
+
+namespace {
+
+thread_local std::string g_err;
+int fail(int code, const std::string& m) { g_err = m; return code; }
+
+struct Box { float lo[3], hi[3]; };
+const float kFmax = std::numeric_limits<float>::max();
+inline Box box_empty() { return Box{{kFmax, kFmax, kFmax}, {-kFmax, -kFmax, -kFmax}}; }  // Bounds3::new, rc/bounds.rs:25-32
+inline float pmin(float a, float b) { return a < b ? a : b; }                           // rc/lib.rs:192-207
+inline float pmax(float a, float b) { return a > b ? a : b; }
+inline Box box_union(const Box& a, const Box& b) {                                       // rc/bounds.rs:92-108
+  Box r;
+  for (int k = 0; k < 3; ++k) { r.lo[k] = pmin(a.lo[k], b.lo[k]); r.hi[k] = pmax(a.hi[k], b.hi[k]); }
+  return r;
+}
+inline void box_extend(Box& b, const float p[3]) {                                       // rc/bounds.rs:56-75
+  for (int k = 0; k < 3; ++k) { if (p[k] < b.lo[k]) b.lo[k] = p[k]; if (p[k] > b.hi[k]) b.hi[k] = p[k]; }
+}
+inline int box_max_extent(const Box& b) {                                                // rc/bounds.rs:77-90
+  float x = b.hi[0] - b.lo[0], y = b.hi[1] - b.lo[1], z = b.hi[2] - b.lo[2];
+  return x > y ? (x > z ? 0 : 2) : (y > z ? 1 : 2);
+}
+inline float box_area(const Box& b) {                                                    // rc/bounds.rs:214-217
+  float dx = b.hi[0] - b.lo[0], dy = b.hi[1] - b.lo[1], dz = b.hi[2] - b.lo[2];
+  return 2.0f * (dx * dy + dx * dz + dy * dz);
+}
+inline unsigned long f2usz(float f) { if (f != f || f <= 0.0f) return 0; return (unsigned long)f; }  // Rust `as usize`
+inline int f2i(float f) {                                                                           // Rust `as i32`
+  if (f != f) return 0;
+  if (f >= 2147483648.0f) return 2147483647;
+  if (f <= -2147483648.0f) return -2147483647 - 1;
+  return (int)f;
+}
+
+// ------------------------------------------------------------------ 4x4 matrices (rc/geometry/matrix.rs, rc/transform.rs)
+struct Mat { float a[4][4]; };
+Mat mat_identity() { Mat m; for (int i = 0; i < 4; ++i) for (int j = 0; j < 4; ++j) m.a[i][j] = i == j ? 1.0f : 0.0f; return m; }
+Mat mat_mul(const Mat& x, const Mat& y) {  // matrix.rs:157-168
+  Mat r;
+  for (int i = 0; i < 4; ++i)
+    for (int j = 0; j < 4; ++j) r.a[i][j] = x.a[i][0] * y.a[0][j] + x.a[i][1] * y.a[1][j] + x.a[i][2] * y.a[2][j] + x.a[i][3] * y.a[3][j];
+  return r;
+}
+Mat mat_inverse(const Mat& in) {  // Gauss-Jordan, matrix.rs:72-145
+  int indxc[4] = {0}, indxr[4] = {0}, ipiv[4] = {0};
+  Mat w = in;
+  for (int i = 0; i < 4; ++i) {
+    int irow = 0, icol = 0; float big = 0.0f;
+    for (int j = 0; j < 4; ++j)
+      if (ipiv[j] != 1)
+        for (int k = 0; k < 4; ++k)
+          if (ipiv[k] == 0 && std::fabs(w.a[j][k]) >= big) { big = std::fabs(w.a[j][k]); irow = j; icol = k; }
+    ipiv[icol] += 1;
+    if (irow != icol) for (int k = 0; k < 4; ++k) std::swap(w.a[irow][k], w.a[icol][k]);
+    indxr[i] = irow; indxc[i] = icol;
+    float pivinv = 1.0f / w.a[icol][icol];
+    w.a[icol][icol] = 1.0f;
+    for (int j = 0; j < 4; ++j) w.a[icol][j] *= pivinv;
+    for (int j = 0; j < 4; ++j)
+      if (j != icol) {
+        float save = w.a[j][icol];
+        w.a[j][icol] = 0.0f;
+        for (int k = 0; k < 4; ++k) w.a[j][k] -= w.a[icol][k] * save;
+      }
+  }
+  for (int j = 3; j >= 0; --j)
+    if (indxr[j] != indxc[j]) for (int k = 0; k < 4; ++k) std::swap(w.a[k][indxr[j]], w.a[k][indxc[j]]);
+  return w;
+}
+struct Xf { Mat m, inv; };
+Xf xf_mul(const Xf& x, const Xf& y) { return Xf{mat_mul(x.m, y.m), mat_mul(y.inv, x.inv)}; }  // transform.rs:320-340
+Xf xf_inverse(const Xf& x) { return Xf{x.inv, x.m}; }
+Xf xf_scale(float sx, float sy, float sz) {  // transform.rs:94-117
+  Xf t{mat_identity(), mat_identity()};
+  t.m.a[0][0] = sx; t.m.a[1][1] = sy; t.m.a[2][2] = sz;
+  t.inv.a[0][0] = 1.0f / sx; t.inv.a[1][1] = 1.0f / sy; t.inv.a[2][2] = 1.0f / sz;
+  return t;
+}
+Xf xf_translate(float x, float y, float z) {  // transform.rs:70-80
+  Xf t{mat_identity(), mat_identity()};
+  t.m.a[0][3] = x; t.m.a[1][3] = y; t.m.a[2][3] = z;
+  t.inv.a[0][3] = -x; t.inv.a[1][3] = -y; t.inv.a[2][3] = -z;
+  return t;
+}
+Xf xf_perspective(float fov, float n, float f) {  // transform.rs:157-164
+  Mat persp = mat_identity();
+  persp.a[2][2] = f / (f - n); persp.a[2][3] = -f * n / (f - n); persp.a[3][2] = 1.0f; persp.a[3][3] = 0.0f;
+  const float pi = 3.14159265358979323846f;
+  float inv_tan = 1.0f / std::tan((fov * (pi / 180.0f)) / 2.0f);
+  return xf_mul(xf_scale(inv_tan, inv_tan, 1.0f), Xf{persp, mat_inverse(persp)});
+}
+void xf_point(const Mat& m, const float p[3], float out[3]) {  // transform.rs:264-286
+  float x = p[0], y = p[1], z = p[2];
+  float xp = m.a[0][0] * x + m.a[0][1] * y + m.a[0][2] * z + m.a[0][3];
+  float yp = m.a[1][0] * x + m.a[1][1] * y + m.a[1][2] * z + m.a[1][3];
+  float zp = m.a[2][0] * x + m.a[2][1] * y + m.a[2][2] * z + m.a[2][3];
+  float wp = m.a[3][0] * x + m.a[3][1] * y + m.a[3][2] * z + m.a[3][3];
+  if (wp == 1.0f) { out[0] = xp; out[1] = yp; out[2] = zp; }
+  else { out[0] = xp / wp; out[1] = yp / wp; out[2] = zp / wp; }
+}
+
+// ------------------------------------------------------------------ filters (rc/filter/*.rs)
+float mitchell_1d(float x, float B, float C) {  // mitchell.rs:25-41
+  float fx = std::fabs(x) * 2.0f;
+  if (fx < 1.0f) return ((12.0f - 9.0f * B - 6.0f * C) * fx * fx * fx + (-18.0f + 12.0f * B + 6.0f * C) * fx * fx + (6.0f - 2.0f * B)) * (1.0f / 6.0f);
+  if (fx < 2.0f) return ((-B - 6.0f * C) * fx * fx * fx + (6.0f * B + 30.0f * C) * fx * fx + (-12.0f * B - 48.0f * C) * fx + (8.0f * B + 24.0f * C)) * (1.0f / 6.0f);
+  return 0.0f;
+}
+float filter_eval(int kind, const float prm[4], float x, float y) {
+  const float xw = prm[0], yw = prm[1];
+  switch (kind) {
+    case 0: return 1.0f;                                                                           // boxfilter.rs:26-28
+    case 1: return std::fmax(0.0f, xw - std::fabs(x)) * std::fmax(0.0f, yw - std::fabs(y));         // triangle.rs:29-31
+    case 2: {                                                                                      // gaussian.rs:15-38
+      float alpha = prm[2];
+      float ex = std::exp(-alpha * xw * xw), ey = std::exp(-alpha * yw * yw);
+      return std::fmax(std::exp(-alpha * x * x) - ex, 0.0f) * std::fmax(std::exp(-alpha * y * y) - ey, 0.0f);
+    }
+    default: return mitchell_1d(x * (1.0f / xw), prm[2], prm[3]) * mitchell_1d(y * (1.0f / yw), prm[2], prm[3]);  // mitchell.rs:54-56
+  }
+}
+
+struct MipLevels {
+  int trilinear, wrap; float max_aniso;
+  std::vector<int> w, h; std::vector<uint64_t> off; std::vector<float> texels;  // RGB
+};
+long modl(long a, long b) { long r = a % b; return r < 0 ? r + b : r; }
+// MIPMap::texel (mipmap.rs:208-225) on a finished level
+void mip_texel(const MipLevels& m, int level, long s, long t, float out[3]) {
+  long us = m.w[level], vs = m.h[level];
+  if (m.wrap == RT_WRAP_REPEAT) { s = modl(s, us); t = modl(t, vs); }
+  else if (m.wrap == RT_WRAP_CLAMP) { s = s < 0 ? 0 : (s > us - 1 ? us - 1 : s); t = t < 0 ? 0 : (t > vs - 1 ? vs - 1 : t); }
+  else if (s < 0 || s >= us || t < 0 || t >= vs) { out[0] = out[1] = out[2] = 0.0f; return; }
+  const float* p = &m.texels[3 * (m.off[level] + (uint64_t)t * us + s)];
+  out[0] = p[0]; out[1] = p[1]; out[2] = p[2];
+}
+void mip_triangle(const MipLevels& m, int level, float sx, float sy, float out[3]) {  // mipmap.rs:285-308
+  int nl = (int)m.w.size();
+  level = level < 0 ? 0 : (level > nl - 1 ? nl - 1 : level);
+  float s = sx * (float)m.w[level] - 0.5f, t = sy * (float)m.h[level] - 0.5f;
+  long s0 = f2i(std::floor(s)), t0 = f2i(std::floor(t));
+  float ds = s - (float)s0, dt = t - (float)t0;
+  float a[3], b[3], c[3], d[3];
+  mip_texel(m, level, s0, t0, a); mip_texel(m, level, s0, t0 + 1, b); mip_texel(m, level, s0 + 1, t0, c); mip_texel(m, level, s0 + 1, t0 + 1, d);
+  for (int k = 0; k < 3; ++k) out[k] = a[k] * (1.0f - ds) * (1.0f - dt) + b[k] * (1.0f - ds) * dt + c[k] * ds * (1.0f - dt) + d[k] * ds * dt;
+}
+void mip_lookup(const MipLevels& m, float sx, float sy, float width, float out[3]) {  // mipmap.rs:227-245
+  int nl = (int)m.w.size();
+  float level = (float)nl - 1.0f + std::log2(std::fmax(width, 1e-8f));
+  if (level < 0.0f) { mip_triangle(m, 0, sx, sy, out); return; }
+  if (level >= (float)nl - 1.0f) { mip_texel(m, nl - 1, 0, 0, out); return; }
+  float il = std::floor(level), delta = level - il;
+  float a[3], b[3];
+  mip_triangle(m, (int)f2usz(il), sx, sy, a); mip_triangle(m, (int)f2usz(il) + 1, sx, sy, b);
+  for (int k = 0; k < 3; ++k) out[k] = a[k] * (1.0f - delta) + b[k] * delta;
+}
+
+struct Dist1 { std::vector<float> func, cdf; float func_int; };
+void dist1_init(Dist1& d, const float* f, size_t n) {  // Distribution1D::new, distribution1d.rs:11-42
+  d.func.assign(f, f + n); d.cdf.assign(n + 1, 0.0f);
+  for (size_t i = 1; i < n + 1; ++i) d.cdf[i] = d.cdf[i - 1] + d.func[i - 1] / (float)n;
+  d.func_int = d.cdf[n];
+  if (d.func_int == 0.0f) for (size_t i = 1; i < n + 1; ++i) d.cdf[i] = (float)i / (float)n;
+  else for (size_t i = 1; i < n + 1; ++i) d.cdf[i] /= d.func_int;
+}
+
+struct HostLight {
+  rt_light l;
+  int tri_source = -1;  // input-order triangle (area lights)
+  std::vector<float> dfunc, dcdf, dint, mfunc, mcdf;
+};
+
+}  // namespace
+
+struct rtxh_scene {
+  // input soup
+  std::vector<float> P, N, UV, S; std::vector<int32_t> idx, tri_mat, tri_light; std::vector<uint8_t> tri_flags;
+  std::vector<rt_texture> textures; std::vector<rt_material> materials; std::vector<MipLevels> mips; std::vector<HostLight> lights;
+  // BVH products
+  std::vector<rt_bvh_node> nodes; std::vector<int32_t> ordered;
+  // flattened arrays (leaf order)
+  std::vector<float> f_p, f_n, f_uv, f_s; std::vector<rt_tri_meta> f_meta; std::vector<rt_light> f_lights; std::vector<rt_image> f_images;
+  bool committed = false;
+  rt_scene* dev = nullptr;
+  size_t n_tris() const { return idx.size() / 3; }
+};
+
+namespace {
+
+// ------------------------------------------------------------------ SAH BVH (rc/bvh/mod.rs:80-358)
+struct Builder {
+  // primitive_info as parallel arrays (BVHPrimitiveInfo, :522-536)
+  std::vector<int32_t> prim; std::vector<Box> pb; std::vector<float> cx, cy, cz;
+  struct BNode { Box b; int axis, first, count, left, right; };
+  std::vector<BNode> pool; std::vector<int32_t>* ordered; int max_prims;
+
+  float centroid(size_t i, int dim) const { return dim == 0 ? cx[i] : (dim == 1 ? cy[i] : cz[i]); }
+  void swap_info(size_t a, size_t b) { std::swap(prim[a], prim[b]); std::swap(pb[a], pb[b]); std::swap(cx[a], cx[b]); std::swap(cy[a], cy[b]); std::swap(cz[a], cz[b]); }
+  int make_leaf(size_t start, size_t end, const Box& b) {
+    BNode n{b, 0, (int)ordered->size(), (int)(end - start), -1, -1};
+    for (size_t i = start; i < end; ++i) ordered->push_back(prim[i]);
+    pool.push_back(n);
+    return (int)pool.size() - 1;
+  }
+  int bucket(const Box& cb, size_t i, int dim) const {  // (N_BUCKETS as f32 * centroids_bounds.offset(c)[dim]) as usize, :220-225
+    float o = centroid(i, dim) - cb.lo[dim];
+    if (cb.hi[dim] > cb.lo[dim]) o /= cb.hi[dim] - cb.lo[dim];  // Bounds3::offset, bounds.rs:177-190
+    int b = (int)f2usz(12.0f * o);
+    return b == 12 ? 11 : b;
+  }
+  int build(size_t start, size_t end) {
+    const size_t n = end - start;
+    Box bounds = box_empty();
+    for (size_t i = start; i < end; ++i) bounds = box_union(bounds, pb[i]);
+    if (n == 1) return make_leaf(start, end, bounds);
+    Box cb = box_empty();
+    for (size_t i = start; i < end; ++i) { float c[3] = {cx[i], cy[i], cz[i]}; box_extend(cb, c); }
+    const int dim = box_max_extent(cb);
+    if (cb.lo[dim] == cb.hi[dim]) return make_leaf(start, end, bounds);
+    size_t mid;
+    if (n <= 2) {
+      mid = (start + end) / 2;
+      if (start != end - 1 && centroid(end - 1, dim) < centroid(start, dim)) swap_info(start, end - 1);
+    } else {
+      int cnt[12] = {0}; Box bb[12];
+      for (int k = 0; k < 12; ++k) bb[k] = box_empty();
+      for (size_t i = start; i < end; ++i) { int b = bucket(cb, i, dim); cnt[b] += 1; bb[b] = box_union(bb[b], pb[i]); }
+      float best = 0.0f; int best_k = 0;
+      for (int k = 0; k < 11; ++k) {
+        Box b0 = box_empty(), b1 = box_empty(); int c0 = 0, c1 = 0;
+        for (int j = 0; j <= k; ++j) { b0 = box_union(b0, bb[j]); c0 += cnt[j]; }
+        for (int j = k + 1; j < 12; ++j) { b1 = box_union(b1, bb[j]); c1 += cnt[j]; }
+        float cost = 1.0f + ((float)c0 * box_area(b0) + (float)c1 * box_area(b1)) / box_area(bounds);
+        if (k == 0 || cost < best) { best = cost; best_k = k; }
+      }
+      if ((int)n > max_prims || best < (float)n) {
+        // itertools::partition (0.10.3): front cursor finds a failing element, back cursor the next passing one; swap
+        size_t split = 0, front = start, back = end;
+        bool done = false;
+        while (!done && front < back) {
+          size_t f = front++;
+          if (!(bucket(cb, f, dim) <= best_k)) {
+            bool found = false;
+            while (front < back) { size_t b = --back; if (bucket(cb, b, dim) <= best_k) { swap_info(f, b); found = true; break; } }
+            if (!found) { done = true; break; }
+          }
+          split += 1;
+        }
+        mid = start + split;
+      } else return make_leaf(start, end, bounds);
+    }
+    int right = build(mid, end);  // right child first (:290-299): its leaves come first in ordered_prims
+    int left = build(start, mid);
+    BNode nd{box_union(pool[left].b, pool[right].b), dim, 0, 0, left, right};
+    pool.push_back(nd);
+    return (int)pool.size() - 1;
+  }
+};
+
+int commit_scene(rtxh_scene* s, int max_prims_per_node) {
+  const size_t nt = s->n_tris();
+  if (nt == 0) return fail(RT_ERR_INVALID, "no triangles");
+  Builder b; b.ordered = &s->ordered; b.max_prims = max_prims_per_node > 255 ? 255 : max_prims_per_node;
+  b.prim.resize(nt); b.pb.resize(nt); b.cx.resize(nt); b.cy.resize(nt); b.cz.resize(nt);
+  for (size_t t = 0; t < nt; ++t) {  // Triangle::world_bounds, mesh.rs:603-608
+    const float* p0 = &s->P[3 * s->idx[3 * t]]; const float* p1 = &s->P[3 * s->idx[3 * t + 1]]; const float* p2 = &s->P[3 * s->idx[3 * t + 2]];
+    Box bb;
+    for (int k = 0; k < 3; ++k) { bb.lo[k] = pmin(p0[k], p1[k]); bb.hi[k] = pmax(p0[k], p1[k]); }
+    box_extend(bb, p2);
+    b.prim[t] = (int32_t)t; b.pb[t] = bb;
+    b.cx[t] = 0.5f * bb.lo[0] + 0.5f * bb.hi[0]; b.cy[t] = 0.5f * bb.lo[1] + 0.5f * bb.hi[1]; b.cz[t] = 0.5f * bb.lo[2] + 0.5f * bb.hi[2];  // :532
+  }
+  s->ordered.clear(); s->ordered.reserve(nt);
+  int root = b.build(0, nt);
+  // flatten_bvh (:314-358): pre-order, left child adjacent, second child offset patched afterwards
+  s->nodes.clear(); s->nodes.reserve(b.pool.size());
+  struct Item { int node; int parent_flat; };
+  std::vector<Item> st; st.push_back({root, -1});
+  while (!st.empty()) {
+    Item it = st.back(); st.pop_back();
+    const Builder::BNode& n = b.pool[it.node];
+    rt_bvh_node out{};
+    for (int k = 0; k < 3; ++k) { out.bmin[k] = n.b.lo[k]; out.bmax[k] = n.b.hi[k]; }
+    int me = (int)s->nodes.size();
+    if (it.parent_flat >= 0) s->nodes[it.parent_flat].offset = (uint32_t)me;  // this node is its parent's second child
+    if (n.count > 0) { out.offset = (uint32_t)n.first; out.n_prims = (uint16_t)n.count; out.axis = 0; }
+    else { out.offset = 0; out.n_prims = 0; out.axis = (uint8_t)n.axis; }
+    s->nodes.push_back(out);
+    if (n.count == 0) { st.push_back({n.right, me}); st.push_back({n.left, -1}); }
+  }
+  // world bounding sphere for distant / infinite lights (Scene::new -> Light::preprocess, scene.rs:29-49; bounds.rs:199-212)
+  const rt_bvh_node& r0 = s->nodes[0];
+  float c[3] = {(r0.bmin[0] + r0.bmax[0]) / 2.0f, (r0.bmin[1] + r0.bmax[1]) / 2.0f, (r0.bmin[2] + r0.bmax[2]) / 2.0f};
+  bool inside = c[0] >= r0.bmin[0] && c[0] <= r0.bmax[0] && c[1] >= r0.bmin[1] && c[1] <= r0.bmax[1] && c[2] >= r0.bmin[2] && c[2] <= r0.bmax[2];
+  float dx = r0.bmax[0] - c[0], dy = r0.bmax[1] - c[1], dz = r0.bmax[2] - c[2];
+  float world_radius = inside ? std::sqrt(dx * dx + dy * dy + dz * dz) : 0.0f;
+
+  // flatten geometry into leaf order
+  std::vector<int32_t> leaf_of(nt, -1);
+  for (size_t i = 0; i < nt; ++i) leaf_of[s->ordered[i]] = (int32_t)i;
+  const bool any_n = !s->N.empty(), any_uv = !s->UV.empty(), any_s = !s->S.empty();
+  s->f_p.assign(nt * 9, 0.0f); s->f_meta.assign(nt, rt_tri_meta{});
+  if (any_n) s->f_n.assign(nt * 9, 0.0f); if (any_uv) s->f_uv.assign(nt * 6, 0.0f); if (any_s) s->f_s.assign(nt * 9, 0.0f);
+  for (size_t i = 0; i < nt; ++i) {
+    const int32_t t = s->ordered[i];
+    for (int v = 0; v < 3; ++v) {
+      const int32_t vi = s->idx[3 * t + v];
+      for (int k = 0; k < 3; ++k) s->f_p[9 * i + 3 * v + k] = s->P[3 * vi + k];
+      if (any_n) for (int k = 0; k < 3; ++k) s->f_n[9 * i + 3 * v + k] = s->N[3 * vi + k];
+      if (any_s) for (int k = 0; k < 3; ++k) s->f_s[9 * i + 3 * v + k] = s->S[3 * vi + k];
+      if (any_uv) for (int k = 0; k < 2; ++k) s->f_uv[6 * i + 2 * v + k] = s->UV[2 * vi + k];
+    }
+    s->f_meta[i] = rt_tri_meta{s->tri_mat[t], s->tri_light[t], (uint32_t)s->tri_flags[t], (uint32_t)t};
+  }
+  // images
+  s->f_images.clear();
+  for (const MipLevels& m : s->mips) {
+    rt_image im{};
+    im.n_levels = (int32_t)m.w.size();
+    for (int l = 0; l < im.n_levels; ++l) { im.width[l] = m.w[l]; im.height[l] = m.h[l]; im.offset[l] = m.off[l]; }
+    im.texels = m.texels.data(); im.n_texels = m.texels.size() / 3; im.trilinear = m.trilinear; im.max_anisotropy = m.max_aniso; im.wrap = m.wrap;
+    s->f_images.push_back(im);
+  }
+  // lights
+  s->f_lights.clear();
+  for (HostLight& hl : s->lights) {
+    rt_light l = hl.l;
+    if (l.kind == RT_LIGHT_DIFFUSE_AREA) {
+      if (hl.tri_source < 0 || (size_t)hl.tri_source >= nt) return fail(RT_ERR_INVALID, "area light triangle out of range");
+      l.prim = leaf_of[hl.tri_source];
+      const float* p0 = &s->P[3 * s->idx[3 * hl.tri_source]]; const float* p1 = &s->P[3 * s->idx[3 * hl.tri_source + 1]]; const float* p2 = &s->P[3 * s->idx[3 * hl.tri_source + 2]];
+      float a[3] = {p1[0] - p0[0], p1[1] - p0[1], p1[2] - p0[2]}, bq[3] = {p2[0] - p0[0], p2[1] - p0[1], p2[2] - p0[2]};
+      float cxr[3] = {(a[1] * bq[2]) - (a[2] * bq[1]), (a[2] * bq[0]) - (a[0] * bq[2]), (a[0] * bq[1]) - (a[1] * bq[0])};
+      l.area = 0.5f * std::sqrt(cxr[0] * cxr[0] + cxr[1] * cxr[1] + cxr[2] * cxr[2]);  // Triangle::area, mesh.rs:588-594
+    }
+    if (l.kind == RT_LIGHT_DISTANT || l.kind == RT_LIGHT_INFINITE) l.world_radius = world_radius;
+    if (l.kind == RT_LIGHT_INFINITE) {
+      l.dist_func = hl.dfunc.data(); l.dist_cdf = hl.dcdf.data(); l.dist_func_int = hl.dint.data(); l.marg_func = hl.mfunc.data(); l.marg_cdf = hl.mcdf.data();
+    }
+    s->f_lights.push_back(l);
+  }
+  s->committed = true;
+  return RT_OK;
+}
+
+rt_scene_desc make_desc(rtxh_scene* s) {
+  rt_scene_desc d{};
+  d.n_nodes = (uint32_t)s->nodes.size(); d.nodes = s->nodes.data();
+  d.n_tris = (uint32_t)s->n_tris(); d.tri_p = s->f_p.data();
+  d.tri_n = s->f_n.empty() ? nullptr : s->f_n.data(); d.tri_uv = s->f_uv.empty() ? nullptr : s->f_uv.data(); d.tri_s = s->f_s.empty() ? nullptr : s->f_s.data();
+  d.tri_meta = s->f_meta.data();
+  d.n_textures = (uint32_t)s->textures.size(); d.textures = s->textures.data();
+  d.n_images = (uint32_t)s->f_images.size(); d.images = s->f_images.data();
+  d.n_materials = (uint32_t)s->materials.size(); d.materials = s->materials.data();
+  d.n_lights = (uint32_t)s->f_lights.size(); d.lights = s->f_lights.data();
+  return d;
+}
+
+struct CamFilm { rt_camera cam; rt_film_desc film; };
+// PerspectiveCamera::new (camera.rs:30-72) with create()'s default screen window (:86-97); Film::new (film.rs:58-115)
+int setup_camera_film(const rtxh_render_params* p, CamFilm& out) {
+  if (p->xres <= 0 || p->yres <= 0) return fail(RT_ERR_INVALID, "bad resolution");
+  float frame = (float)p->xres / (float)p->yres;
+  float sw[4];
+  if (frame > 1.0f) { sw[0] = -frame; sw[1] = frame; sw[2] = -1.0f; sw[3] = 1.0f; }
+  else { sw[0] = -1.0f; sw[1] = 1.0f; sw[2] = -1.0f / frame; sw[3] = 1.0f / frame; }
+  Xf camera_to_screen = xf_perspective(p->fov, 1e-2f, 1000.0f);
+  Xf screen_to_raster = xf_mul(xf_mul(xf_scale((float)p->xres, (float)p->yres, 1.0f), xf_scale(1.0f / (sw[1] - sw[0]), 1.0f / (sw[2] - sw[3]), 1.0f)),
+                               xf_translate(-sw[0], -sw[3], 0.0f));
+  Xf raster_to_camera = xf_mul(xf_inverse(camera_to_screen), xf_inverse(screen_to_raster));
+  memcpy(out.cam.raster_to_camera, raster_to_camera.m.a, 64);
+  memcpy(out.cam.camera_to_world, p->cam_to_world, 64);
+  const float o[3] = {0, 0, 0}, ex[3] = {1, 0, 0}, ey[3] = {0, 1, 0};
+  float po[3], px[3], py[3];
+  xf_point(raster_to_camera.m, o, po); xf_point(raster_to_camera.m, ex, px); xf_point(raster_to_camera.m, ey, py);
+  for (int k = 0; k < 3; ++k) { out.cam.dx_camera[k] = px[k] - po[k]; out.cam.dy_camera[k] = py[k] - po[k]; }
+  out.cam.lens_radius = p->lens_radius; out.cam.focal_distance = p->focal_distance;
+  // film
+  rt_film_desc& f = out.film;
+  int ax = f2i(std::ceil((float)p->xres * p->crop[0])), ay = f2i(std::ceil((float)p->yres * p->crop[2]));
+  int bx = f2i(std::ceil((float)p->xres * p->crop[1])), by = f2i(std::ceil((float)p->yres * p->crop[3]));
+  f.cropped_pixel_bounds[0] = std::min(ax, bx); f.cropped_pixel_bounds[1] = std::min(ay, by);
+  f.cropped_pixel_bounds[2] = std::max(ax, bx); f.cropped_pixel_bounds[3] = std::max(ay, by);
+  const float xw = p->filter_params[0], yw = p->filter_params[1];
+  f.filter_radius[0] = xw; f.filter_radius[1] = yw;
+  for (int y = 0; y < 16; ++y) {
+    float fy = ((float)y + 0.5f) * (yw / 16.0f);
+    for (int x = 0; x < 16; ++x) { float fx = ((float)x + 0.5f) * (xw / 16.0f); f.filter_table[y * 16 + x] = filter_eval(p->filter_kind, p->filter_params, fx, fy); }
+  }
+  f.max_sample_luminance = p->max_sample_luminance;
+  // Film::get_sample_bounds (film.rs:249-257)
+  float x0 = std::floor((float)f.cropped_pixel_bounds[0] + 0.5f - xw), y0 = std::floor((float)f.cropped_pixel_bounds[1] + 0.5f - yw);
+  float x1 = std::ceil((float)f.cropped_pixel_bounds[2] - 0.5f + xw), y1 = std::ceil((float)f.cropped_pixel_bounds[3] - 0.5f + yw);
+  f.sample_bounds[0] = f2i(pmin(x0, x1)); f.sample_bounds[1] = f2i(pmin(y0, y1)); f.sample_bounds[2] = f2i(pmax(x0, x1)); f.sample_bounds[3] = f2i(pmax(y0, y1));
+  return RT_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+const char* rtxh_last_error(void) { return g_err.empty() ? rt_last_error() : g_err.c_str(); }
+rtxh_scene* rtxh_scene_new(void) { return new rtxh_scene(); }
+void rtxh_scene_free(rtxh_scene* s) { if (!s) return; if (s->dev) rt_scene_destroy(s->dev); delete s; }
+
+int rtxh_scene_set_mesh(rtxh_scene* s, const float* P, int32_t nv, const int32_t* idx, int32_t nt, const float* N, const float* UV, const float* S,
+                        const int32_t* tri_material, const int32_t* tri_light, const uint8_t* tri_flags) {
+  if (!s || !P || !idx || nv <= 0 || nt <= 0 || !tri_material || !tri_light || !tri_flags) return fail(RT_ERR_INVALID, "bad mesh arguments");
+  s->P.assign(P, P + 3 * (size_t)nv);
+  s->N.clear(); s->UV.clear(); s->S.clear();
+  if (N) s->N.assign(N, N + 3 * (size_t)nv);
+  if (UV) s->UV.assign(UV, UV + 2 * (size_t)nv);
+  if (S) s->S.assign(S, S + 3 * (size_t)nv);
+  s->idx.assign(idx, idx + 3 * (size_t)nt);
+  for (int32_t v : s->idx) if (v < 0 || v >= nv) return fail(RT_ERR_INVALID, "vertex index out of range");
+  s->tri_mat.assign(tri_material, tri_material + nt); s->tri_light.assign(tri_light, tri_light + nt); s->tri_flags.assign(tri_flags, tri_flags + nt);
+  for (int32_t t = 0; t < nt; ++t) {
+    uint8_t f = tri_flags[t];
+    if (((f & RT_TRI_HAS_N) && !N) || ((f & RT_TRI_HAS_UV) && !UV) || ((f & RT_TRI_HAS_S) && !S)) return fail(RT_ERR_INVALID, "flags promise a missing attribute");
+  }
+  s->committed = false;
+  return RT_OK;
+}
+
+int rtxh_scene_add_mipmap(rtxh_scene* s, int32_t w, int32_t h, const float* rgb, int32_t trilinear, float max_aniso, int32_t wrap) {
+  if (!s || !rgb || w <= 0 || h <= 0 || (w & (w - 1)) || (h & (h - 1))) return fail(RT_ERR_INVALID, "images must have power-of-two sides");
+  MipLevels m; m.trilinear = trilinear; m.wrap = wrap; m.max_aniso = max_aniso;
+  // MIPMap::new (mipmap.rs:158-187): n_levels = 1 + log2(max(res)) as usize; each level = box filter of 4 texels of the finer one
+  int n_levels = 1 + (int)f2usz(std::log2((float)std::max(w, h)));
+  m.w.push_back(w); m.h.push_back(h); m.off.push_back(0);
+  m.texels.assign(rgb, rgb + 3 * (size_t)w * h);
+  for (int i = 1; i < n_levels; ++i) {
+    int sr = std::max(1, m.w[i - 1] / 2), tr = std::max(1, m.h[i - 1] / 2);
+    uint64_t off = m.texels.size() / 3;
+    std::vector<float> lvl((size_t)sr * tr * 3);
+    for (int t = 0; t < tr; ++t)
+      for (int sx = 0; sx < sr; ++sx) {
+        float a[3], b[3], c[3], d[3];
+        mip_texel(m, i - 1, 2 * sx, 2 * t, a); mip_texel(m, i - 1, 2 * sx + 1, 2 * t, b); mip_texel(m, i - 1, 2 * sx, 2 * t + 1, c); mip_texel(m, i - 1, 2 * sx + 1, 2 * t + 1, d);
+        for (int k = 0; k < 3; ++k) lvl[3 * ((size_t)t * sr + sx) + k] = (a[k] + b[k] + c[k] + d[k]) * 0.25f;
+      }
+    m.texels.insert(m.texels.end(), lvl.begin(), lvl.end());
+    m.w.push_back(sr); m.h.push_back(tr); m.off.push_back(off);
+  }
+  s->mips.push_back(std::move(m));
+  s->committed = false;
+  return (int)s->mips.size() - 1;
+}
+
+int rtxh_scene_add_texture(rtxh_scene* s, int32_t kind, const float* v, int32_t tex1, int32_t tex2, int32_t amount, int32_t mip, const float* mapping) {
+  if (!s || !v) return fail(RT_ERR_INVALID, "bad texture arguments");
+  rt_texture t{}; t.kind = kind; t.value[0] = v[0]; t.value[1] = v[1]; t.value[2] = v[2]; t.tex1 = tex1; t.tex2 = tex2; t.amount = amount; t.image = mip;
+  t.mapping[0] = mapping ? mapping[0] : 1.0f; t.mapping[1] = mapping ? mapping[1] : 1.0f; t.mapping[2] = mapping ? mapping[2] : 0.0f; t.mapping[3] = mapping ? mapping[3] : 0.0f;
+  s->textures.push_back(t);
+  return (int)s->textures.size() - 1;
+}
+int rtxh_scene_add_material(rtxh_scene* s, int32_t kind, const int32_t* slots, int32_t remap) {
+  if (!s || !slots) return fail(RT_ERR_INVALID, "bad material arguments");
+  rt_material m{}; m.kind = kind; m.remap_roughness = remap;
+  for (int k = 0; k < RT_N_SLOTS; ++k) m.slot[k] = slots[k];
+  s->materials.push_back(m);
+  return (int)s->materials.size() - 1;
+}
+int rtxh_scene_add_light(rtxh_scene* s, int32_t kind, int32_t tri, const float* rgb, int32_t two_sided, const float* vec, int32_t mip, const float* l2w, const float* w2l) {
+  if (!s || !rgb) return fail(RT_ERR_INVALID, "bad light arguments");
+  HostLight hl; memset(&hl.l, 0, sizeof(hl.l));
+  rt_light& l = hl.l;
+  l.kind = kind; l.prim = -1; hl.tri_source = tri; l.rgb[0] = rgb[0]; l.rgb[1] = rgb[1]; l.rgb[2] = rgb[2]; l.two_sided = two_sided; l.image = mip;
+  if (vec) { l.vec[0] = vec[0]; l.vec[1] = vec[1]; l.vec[2] = vec[2]; }
+  if (kind == RT_LIGHT_DISTANT) {  // DistantLight::new normalises the direction (distant.rs:27)
+    float len = std::sqrt(l.vec[0] * l.vec[0] + l.vec[1] * l.vec[1] + l.vec[2] * l.vec[2]);
+    l.vec[0] /= len; l.vec[1] /= len; l.vec[2] /= len;
+  }
+  for (int r = 0; r < 3; ++r) for (int c = 0; c < 4; ++c) { l.l2w[4 * r + c] = l2w ? l2w[4 * r + c] : (r == c ? 1.0f : 0.0f); l.w2l[4 * r + c] = w2l ? w2l[4 * r + c] : (r == c ? 1.0f : 0.0f); }
+  if (kind == RT_LIGHT_INFINITE) {
+    if (mip < 0 || (size_t)mip >= s->mips.size()) return fail(RT_ERR_INVALID, "infinite light needs an environment map");
+    // InfiniteAreaLight::new (infinite.rs:78-101): luminance * sin(theta) at twice the map resolution
+    const MipLevels& m = s->mips[mip];
+    const int width = 2 * m.w[0], height = 2 * m.h[0];
+    const float filter = 0.5f / std::fmin((float)width, (float)height);
+    const float pi = 3.14159265358979323846f;
+    std::vector<float> img((size_t)width * height);
+    for (int v = 0; v < height; ++v) {
+      float vp = ((float)v + 0.5f) / (float)height;
+      float sin_theta = std::sin(pi * ((float)v + 0.5f) / (float)height);
+      for (int u = 0; u < width; ++u) {
+        float up = ((float)u + 0.5f) / (float)width;
+        float c[3]; mip_lookup(m, up, vp, filter, c);
+        img[(size_t)v * width + u] = (0.212671f * c[0] + 0.715160f * c[1] + 0.072169f * c[2]) * sin_theta;
+      }
+    }
+    // Distribution2D::new (distribution2d.rs:11-27)
+    hl.dfunc = img; hl.dcdf.resize((size_t)height * (width + 1)); hl.dint.resize(height); hl.mfunc.resize(height);
+    for (int v = 0; v < height; ++v) {
+      Dist1 d; dist1_init(d, &img[(size_t)v * width], width);
+      memcpy(&hl.dcdf[(size_t)v * (width + 1)], d.cdf.data(), (size_t)(width + 1) * 4);
+      hl.dint[v] = d.func_int; hl.mfunc[v] = d.func_int;
+    }
+    Dist1 md; dist1_init(md, hl.mfunc.data(), height);
+    hl.mcdf = md.cdf; l.marg_func_int = md.func_int; l.dist_nu = width; l.dist_nv = height;
+  }
+  s->lights.push_back(std::move(hl));
+  s->committed = false;
+  return (int)s->lights.size() - 1;
+}
+
+int rtxh_scene_commit(rtxh_scene* s, int32_t max_prims_per_node) { if (!s) return fail(RT_ERR_INVALID, "null scene"); g_err.clear(); return commit_scene(s, max_prims_per_node); }
+
+int rtxh_scene_upload(rtxh_scene* s, int32_t device) {
+  if (!s || !s->committed) return fail(RT_ERR_INVALID, "scene not committed");
+  g_err.clear();
+  if (s->dev) { rt_scene_destroy(s->dev); s->dev = nullptr; }
+  rt_scene_desc d = make_desc(s);
+  return rt_scene_create(&d, device, &s->dev);
+}
+
+int rtxh_scene_bvh_sizes(rtxh_scene* s, int32_t* n_nodes, int32_t* n_prims) { *n_nodes = (int32_t)s->nodes.size(); *n_prims = (int32_t)s->ordered.size(); return RT_OK; }
+int rtxh_scene_bvh_get(rtxh_scene* s, float* bounds6, uint32_t* offset, uint16_t* n_prims, uint8_t* axis, int32_t* ordered) {
+  for (size_t i = 0; i < s->nodes.size(); ++i) {
+    const rt_bvh_node& n = s->nodes[i];
+    for (int k = 0; k < 3; ++k) { bounds6[6 * i + k] = n.bmin[k]; bounds6[6 * i + 3 + k] = n.bmax[k]; }
+    offset[i] = n.offset; n_prims[i] = n.n_prims; axis[i] = n.axis;
+  }
+  memcpy(ordered, s->ordered.data(), s->ordered.size() * 4);
+  return RT_OK;
+}
+int rtxh_camera_film_setup(const rtxh_render_params* p, float* r2c, float* dxdy, float* table, int32_t* sb, int32_t* cropped) {
+  CamFilm cf; int rc = setup_camera_film(p, cf); if (rc != RT_OK) return rc;
+  memcpy(r2c, cf.cam.raster_to_camera, 64);
+  for (int k = 0; k < 3; ++k) { dxdy[k] = cf.cam.dx_camera[k]; dxdy[3 + k] = cf.cam.dy_camera[k]; }
+  memcpy(table, cf.film.filter_table, 1024); memcpy(sb, cf.film.sample_bounds, 16); memcpy(cropped, cf.film.cropped_pixel_bounds, 16);
+  return RT_OK;
+}
+int rtxh_mip_level(rtxh_scene* s, int32_t mip, int32_t level, int32_t* w, int32_t* h, float* rgb_out) {
+  if (!s || mip < 0 || (size_t)mip >= s->mips.size()) return fail(RT_ERR_INVALID, "bad mip index");
+  const MipLevels& m = s->mips[mip];
+  if (level < 0 || (size_t)level >= m.w.size()) return fail(RT_ERR_INVALID, "bad level");
+  *w = m.w[level]; *h = m.h[level];
+  if (rgb_out) memcpy(rgb_out, &m.texels[3 * m.off[level]], (size_t)m.w[level] * m.h[level] * 12);
+  return (int)m.w.size();
+}
+// Transform::look_at (transform.rs:119-154): m = world->camera, m_inv = camera->world
+int rtxh_look_at(const float* pos, const float* look, const float* up, float* m16, float* minv16) {
+  auto norm = [](float v[3]) { float l = std::sqrt(v[0] * v[0] + v[1] * v[1] + v[2] * v[2]); v[0] /= l; v[1] /= l; v[2] /= l; };
+  auto cross = [](const float a[3], const float b[3], float o[3]) { o[0] = (a[1] * b[2]) - (a[2] * b[1]); o[1] = (a[2] * b[0]) - (a[0] * b[2]); o[2] = (a[0] * b[1]) - (a[1] * b[0]); };
+  Mat c2w = mat_identity();
+  c2w.a[0][3] = pos[0]; c2w.a[1][3] = pos[1]; c2w.a[2][3] = pos[2]; c2w.a[3][3] = 1.0f;
+  float dir[3] = {look[0] - pos[0], look[1] - pos[1], look[2] - pos[2]}; norm(dir);
+  float upn[3] = {up[0], up[1], up[2]}; norm(upn);
+  float left[3]; cross(upn, dir, left);
+  if (std::sqrt(left[0] * left[0] + left[1] * left[1] + left[2] * left[2]) == 0.0f) { Mat id = mat_identity(); memcpy(m16, id.a, 64); memcpy(minv16, id.a, 64); return RT_OK; }
+  norm(left);
+  float new_up[3]; cross(dir, left, new_up);
+  for (int r = 0; r < 3; ++r) { c2w.a[r][0] = left[r]; c2w.a[r][1] = new_up[r]; c2w.a[r][2] = dir[r]; }
+  c2w.a[3][0] = c2w.a[3][1] = c2w.a[3][2] = 0.0f;
+  Mat w2c = mat_inverse(c2w);
+  memcpy(m16, w2c.a, 64); memcpy(minv16, c2w.a, 64);
+  return RT_OK;
+}
+
+int rtxh_render(rtxh_scene* s, const rtxh_render_params* p, void* stream, float* film_xyzw, rt_stats* stats) {
+  if (!s || !p || !film_xyzw) return fail(RT_ERR_INVALID, "null argument");
+  g_err.clear();
+  if (!s->dev) { int rc = rtxh_scene_upload(s, -1); if (rc != RT_OK) return rc; }
+  CamFilm cf; int rc = setup_camera_film(p, cf); if (rc != RT_OK) return rc;
+  rt_sampler_desc smp{p->spp, p->sampler_dims};
+  rt_path_desc path{}; path.max_depth = p->max_depth; path.rr_threshold = p->rr_threshold; path.light_strategy = p->light_strategy;
+  // PathIntegrator::create (path.rs:53-69): pixel_bounds = sample bounds, optionally intersected with "pixelbounds"
+  int pb[4] = {cf.film.sample_bounds[0], cf.film.sample_bounds[1], cf.film.sample_bounds[2], cf.film.sample_bounds[3]};
+  if (p->pixel_bounds[1] > p->pixel_bounds[0]) {
+    pb[0] = std::max(pb[0], p->pixel_bounds[0]); pb[1] = std::max(pb[1], p->pixel_bounds[2]);
+    pb[2] = std::min(pb[2], p->pixel_bounds[1]); pb[3] = std::min(pb[3], p->pixel_bounds[3]);
+  }
+  memcpy(path.pixel_bounds, pb, 16);
+  rt_shard shard{p->rank, p->world_size > 0 ? p->world_size : 1};
+  return rt_render(s->dev, &cf.cam, &cf.film, &smp, &path, &shard, p->flags, stream, film_xyzw, stats);
+}
+int rtxh_trace(rtxh_scene* s, const float* rays, uint64_t n, int32_t any_hit, float* out, uint64_t counters[2]) {
+  if (!s) return fail(RT_ERR_INVALID, "null scene");
+  g_err.clear();
+  if (!s->dev) { int rc = rtxh_scene_upload(s, -1); if (rc != RT_OK) return rc; }
+  return any_hit ? rt_trace_any(s->dev, rays, n, (uint32_t*)out, counters) : rt_trace_closest(s->dev, rays, n, out, counters);
+}
+int rtxh_trace_device(rtxh_scene* s, const void* d_rays, uint64_t n, void* d_hits, int32_t reps, void* stream, float* ms) {
+  if (!s) return fail(RT_ERR_INVALID, "null scene");
+  g_err.clear();
+  if (!s->dev) { int rc = rtxh_scene_upload(s, -1); if (rc != RT_OK) return rc; }
+  return rt_trace_closest_device(s->dev, d_rays, n, d_hits, reps, stream, ms);
+}
+int rtxh_light_distribution(rtxh_scene* s, int32_t n_voxels[3], float* func, float* cdf, float* func_int) {
+  if (!s) return fail(RT_ERR_INVALID, "null scene");
+  g_err.clear();
+  if (!s->dev) { int rc = rtxh_scene_upload(s, -1); if (rc != RT_OK) return rc; }
+  return rt_light_distribution(s->dev, n_voxels, func, cdf, func_int);
+}
+
+}  // extern "C"

@@ -1,0 +1,586 @@
+// rtx_kernels.h — the wavefront kernels (gfx950). One frame = for each pass (a chunk of pixels x all
+// spp): sampler_tables -> raygen -> { trace_closest -> shade -> trace_any(shadow) ->
+// trace_closest(MIS) -> resolve } x (max_depth + 1) -> film_accumulate; then film_finalize.
+// Every kernel is launched with a fixed persistent grid and strides over a device-side queue
+// whose length is read from device memory, so a frame needs no host round trip.
+#pragma once
+#include "rtx_dev_shading.h"
+
+namespace rtx {
+
+
+// ---- per-pass path state in HBM (SoA, indexed by path id = chunk_pixel * spp + sample) --------
+struct PassState {
+  unsigned cap;            // paths in this pass
+  unsigned spp, spp_log2, dims;
+  unsigned n_pixels;       // chunk pixels
+  // sampler tables of the chunk
+  const unsigned* scrambles;        // [pixel][3*dims]
+  const unsigned short* perms;      // [pixel][2*dims][spp]
+  // rays / hits
+  float4* ray_o; float4* ray_d; float4* hit;
+  float4* beta;    // rgb, eta_scale
+  float4* lacc;    // rgb, packed state
+  unsigned long long* rng;
+  float2* pfilm;
+  float4* sh_o; float4* sh_d; unsigned* sh_occ;
+  float4* mi_o; float4* mi_d; float4* mi_hit;
+  float4* pend_a; float4* pend_b; float4* pend_c; unsigned* pend_flags;
+  // queues (path ids) + counters: [0]=active in, [1]=active out, [2]=shadow, [3]=mis
+  unsigned* q_in; unsigned* q_out; unsigned* q_shadow; unsigned* q_mis;
+  unsigned* counters;
+  unsigned long long* stats;  // device-side u64 counters, see ST_* below
+};
+enum { ST_CAMERA = 0, ST_RAYS_CLOSEST, ST_RAYS_SHADOW, ST_RAYS_MIS, ST_NODES_CLOSEST, ST_NODES_SHADOW, ST_NODES_MIS,
+       ST_TRIS_CLOSEST, ST_TRIS_SHADOW, ST_TRIS_MIS, ST_SCRUBBED, ST_COUNT };
+
+struct FrameParams {
+  // camera (rc/camera.rs)
+  float r2c[16]; float c2w[16]; f3 dx_camera, dy_camera; float lens_radius, focal_distance;
+  // film (rc/film.rs)
+  int crop_x0, crop_y0, crop_x1, crop_y1; int sb_x0, sb_y0, sb_x1, sb_y1;
+  float radius_x, radius_y, max_sample_luminance;
+  // integrator
+  int max_depth; float rr_threshold; int pb_x0, pb_y0, pb_x1, pb_y1;
+  // sharding: owned sample rows j -> y = sb_y0 + ((j >> 4) * world + rank) * 16 + (j & 15)
+  int rank, world;
+  // pass
+  unsigned long long chunk_first;  // first owned-pixel index of this pass
+};
+
+// packed per-path state in lacc.w: bits 0-7 bounces, bit 8 specular_bounce, bits 9-12 cur_1d, bits 13-16 cur_2d
+RT_DEV unsigned pack_state(int bounces, bool spec, int c1, int c2) { return (unsigned)bounces | ((unsigned)spec << 8) | ((unsigned)c1 << 9) | ((unsigned)c2 << 13); }
+
+RT_DEV unsigned wave_push(unsigned* counter, bool pred) {
+  unsigned long long mask = __ballot(pred);
+  if (mask == 0ull) return 0u;
+  unsigned lane = __lane_id();
+  int leader = __ffsll((long long)mask) - 1;
+  unsigned base = 0;
+  if ((int)lane == leader) base = atomicAdd(counter, (unsigned)__popcll(mask));
+  base = __shfl(base, leader);
+  return base + (unsigned)__popcll(mask & ((1ull << lane) - 1ull));
+}
+
+// owned-pixel index -> raster pixel (x, y) and keyed pixel index inside the sample bounds
+RT_DEV void owned_pixel(const FrameParams& fp, unsigned long long k, int& x, int& y, unsigned long long& pixel_index) {
+  const unsigned W = (unsigned)(fp.sb_x1 - fp.sb_x0);
+  unsigned long long j = k / W;
+  unsigned xi = (unsigned)(k - j * W);
+  unsigned long long row = ((j >> 4) * (unsigned long long)fp.world + (unsigned long long)fp.rank) * 16ull + (j & 15ull);
+  x = fp.sb_x0 + (int)xi;
+  y = fp.sb_y0 + (int)row;
+  pixel_index = row * W + xi;
+}
+
+// ================================================================================ K0 sampler tables
+// ZeroTwoSequence::start_pixel (rc/sampler/zerotwosequence.rs:67-108) in keyed mode: one lane per
+// pixel runs the sequential PCG32-driven Fisher-Yates shuffles (rc/sampler/lowdiscrepancy.rs:4-50,
+// 114-124) on a permutation of sample indices kept in LDS ([lane][spp+2] u16); the (0,2) values
+// themselves are a closed form of (scramble, index) and are evaluated by the consumers.
+// Output: scrambles[pixel][3*dims] and perms[pixel][2*dims][spp] written coalesced per pixel.
+__global__ void __launch_bounds__(64) k_sampler_tables(FrameParams fp, unsigned n_pixels, unsigned spp, unsigned dims,
+                                                       unsigned long long explicit_pixel0, int use_explicit,
+                                                       unsigned* scrambles, unsigned short* perms) {
+  extern __shared__ unsigned short lds_perm[];
+  const unsigned lane = threadIdx.x;
+  const unsigned stride = spp + 2;
+  unsigned short* mine = lds_perm + (size_t)lane * stride;
+  const unsigned pix = blockIdx.x * 64u + lane;
+  const bool live = pix < n_pixels;
+  unsigned long long pixel_index = 0;
+  if (live) {
+    if (use_explicit) pixel_index = explicit_pixel0 + pix;
+    else { int x, y; owned_pixel(fp, fp.chunk_first + pix, x, y, pixel_index); }
+  }
+  Pcg32 rng; rng.set_sequence(pixel_index);
+  const unsigned block_pix0 = blockIdx.x * 64u;
+  const unsigned block_n = min(64u, n_pixels - block_pix0);
+  for (unsigned t = 0; t < 2u * dims; ++t) {
+    if (live) {
+      if (t < dims) scrambles[(size_t)pix * 3u * dims + t] = rng.next_u32();  // van_der_corput scramble (:10)
+      else {  // sobol_2d scramble pair (:31)
+        unsigned s0 = rng.next_u32(), s1 = rng.next_u32();
+        scrambles[(size_t)pix * 3u * dims + dims + 2u * (t - dims)] = s0;
+        scrambles[(size_t)pix * 3u * dims + dims + 2u * (t - dims) + 1u] = s1;
+      }
+      for (unsigned i = 0; i < spp; ++i) mine[i] = (unsigned short)i;
+      // per-pixel-sample shuffles of n_samples_per_pixel_sample = 1 element: only consume RNG (:14-21)
+      for (unsigned i = 0; i < spp; ++i) (void)rng.bounded(1u);
+      // shuffle(samples, n_pixel_samples, 1) (:22, :114-124)
+      for (unsigned i = 0; i < spp; ++i) {
+        unsigned other = i + rng.bounded(spp - i);
+        unsigned short a = mine[i], b = mine[other];
+        mine[i] = b; mine[other] = a;
+      }
+    }
+    __syncthreads();
+    // cooperative coalesced copy-out: all 64 lanes stream pixel p's permutation
+    for (unsigned p = 0; p < block_n; ++p) {
+      const unsigned short* src = lds_perm + (size_t)p * stride;
+      unsigned short* dst = perms + ((size_t)(block_pix0 + p) * 2u * dims + t) * spp;
+      for (unsigned i = lane; i < spp; i += 64u) dst[i] = src[i];
+    }
+    __syncthreads();
+  }
+}
+
+// table look-ups used by raygen / shade: value of dimension d for sample s
+struct Tables { const unsigned* scrambles; const unsigned short* perms; unsigned spp, dims; };
+RT_DEV Tables tables_of(const PassState& ps) { Tables t; t.scrambles = ps.scrambles; t.perms = ps.perms; t.spp = ps.spp; t.dims = ps.dims; return t; }
+RT_DEV float table_1d(const Tables& tb, unsigned pix, unsigned d, unsigned s) {
+  unsigned k = tb.perms[((size_t)pix * 2u * tb.dims + d) * tb.spp + s];
+  return u32_to_unit(tb.scrambles[(size_t)pix * 3u * tb.dims + d] ^ vdc_bits(k));
+}
+RT_DEV f2 table_2d(const Tables& tb, unsigned pix, unsigned d, unsigned s) {
+  unsigned k = tb.perms[((size_t)pix * 2u * tb.dims + tb.dims + d) * tb.spp + s];
+  const unsigned* sc = tb.scrambles + (size_t)pix * 3u * tb.dims + tb.dims + 2u * d;
+  return mk2(u32_to_unit(sc[0] ^ vdc_bits(k)), u32_to_unit(sc[1] ^ sobol1_bits(k)));
+}
+
+// ================================================================================ K1 raygen
+RT_DEV f3 xf_point44(const float* m, f3 p) {  // transform.rs:264-286
+  float xp = m[0] * p.x + m[1] * p.y + m[2] * p.z + m[3];
+  float yp = m[4] * p.x + m[5] * p.y + m[6] * p.z + m[7];
+  float zp = m[8] * p.x + m[9] * p.y + m[10] * p.z + m[11];
+  float wp = m[12] * p.x + m[13] * p.y + m[14] * p.z + m[15];
+  if (wp == 1.0f) return mk3(xp, yp, zp);
+  return mk3(xp, yp, zp) / wp;
+}
+RT_DEV f3 xf_vector44(const float* m, f3 v) {
+  return mk3(m[0] * v.x + m[1] * v.y + m[2] * v.z, m[4] * v.x + m[5] * v.y + m[6] * v.z, m[8] * v.x + m[9] * v.y + m[10] * v.z);
+}
+struct CameraRay { f3 o, d, rx_o, ry_o, rx_d, ry_d; };
+// PerspectiveCamera::generate_ray_differential (camera.rs:150-202) + Ray::transform (ray.rs:46-71)
+// + scale_differentials (ray.rs:73-80)
+RT_DEVN CameraRay generate_camera_ray(const FrameParams& fp, f2 p_film, f2 p_lens, float diff_scale) {
+  CameraRay r;
+  f3 p_camera = xf_point44(fp.r2c, mk3(p_film.x, p_film.y, 0.0f));
+  f3 o = mk3(0, 0, 0), d = normalize(p_camera);
+  f3 rx_o, ry_o, rx_d, ry_d;
+  if (fp.lens_radius > 0.0f) {
+    f2 pl = concentric_sample_disk(p_lens); pl.x = fp.lens_radius * pl.x; pl.y = fp.lens_radius * pl.y;
+    float ft = fp.focal_distance / d.z;
+    f3 p_focus = o + ft * d;
+    o = mk3(pl.x, pl.y, 0.0f);
+    d = normalize(p_focus - o);
+    f3 origin = mk3(pl.x, pl.y, 0.0f);
+    f3 dx = normalize(p_camera + fp.dx_camera);
+    float ft_x = fp.focal_distance / dx.z;
+    f3 dy = normalize(p_camera + fp.dy_camera);
+    float ft_y = fp.focal_distance / dy.z;
+    rx_o = origin; ry_o = origin;
+    rx_d = normalize(ft_x * dx - origin); ry_d = normalize(ft_y * dy - origin);
+  } else {
+    rx_o = o; ry_o = o;
+    rx_d = normalize(p_camera + fp.dx_camera); ry_d = normalize(p_camera + fp.dy_camera);
+  }
+  // Ray::transform with the origin error nudge (transform.rs:175-188)
+  const float* m = fp.c2w;
+  f3 to = xf_point44(m, o);
+  f3 o_error = gamma_n(3) * mk3(fabsf(m[0] * o.x) + fabsf(m[1] * o.y) + fabsf(m[2] * o.z) + fabsf(m[3]),
+                                fabsf(m[4] * o.x) + fabsf(m[5] * o.y) + fabsf(m[6] * o.z) + fabsf(m[7]),
+                                fabsf(m[8] * o.x) + fabsf(m[9] * o.y) + fabsf(m[10] * o.z) + fabsf(m[11]));
+  f3 td = xf_vector44(m, d);
+  float l2 = len2(td);
+  if (l2 > 0.0f) { float dt = dot(abs3(td), o_error) / l2; to = to + td * dt; }
+  r.o = to; r.d = td;
+  r.rx_o = xf_point44(m, rx_o); r.ry_o = xf_point44(m, ry_o);
+  r.rx_d = xf_vector44(m, rx_d); r.ry_d = xf_vector44(m, ry_d);
+  r.rx_o = r.o + (r.rx_o - r.o) * diff_scale; r.ry_o = r.o + (r.ry_o - r.o) * diff_scale;
+  r.rx_d = r.d + (r.rx_d - r.d) * diff_scale; r.ry_d = r.d + (r.ry_d - r.d) * diff_scale;
+  return r;
+}
+
+__global__ void __launch_bounds__(256) k_raygen(FrameParams fp, PassState ps) {
+  const unsigned stride = gridDim.x * blockDim.x;
+  for (unsigned pid = blockIdx.x * blockDim.x + threadIdx.x; pid < ps.cap; pid += stride) {
+    const unsigned pix = pid >> ps.spp_log2, s = pid & (ps.spp - 1u);
+    int x, y; unsigned long long pixel_index;
+    owned_pixel(fp, fp.chunk_first + pix, x, y, pixel_index);
+    bool in_bounds = y < fp.sb_y1 && x >= fp.pb_x0 && x < fp.pb_x1 && y >= fp.pb_y0 && y < fp.pb_y1;  // renderer.rs:103
+    // get_camera_sample (zerotwosequence.rs:182-192): 2D#0 film, 1D#0 time, 2D#1 lens
+    const Tables tb = tables_of(ps);
+    f2 o = table_2d(tb, pix, 0, s);
+    f2 p_film = mk2((float)x + o.x, (float)y + o.y);
+    f2 p_lens = table_2d(tb, pix, 1, s);
+    ps.pfilm[pid] = make_float2(p_film.x, p_film.y);
+    CameraRay cr = generate_camera_ray(fp, p_film, p_lens, 1.0f / sqrtf((float)ps.spp));
+    ps.ray_o[pid] = make_float4(cr.o.x, cr.o.y, cr.o.z, kInf);
+    ps.ray_d[pid] = make_float4(cr.d.x, cr.d.y, cr.d.z, 0.0f);
+    ps.beta[pid] = make_float4(1.0f, 1.0f, 1.0f, 1.0f);
+    ps.lacc[pid] = make_float4(0.0f, 0.0f, 0.0f, __uint_as_float(pack_state(0, false, 1, 2)));
+    Pcg32 rng; rng.set_sequence(pixel_index * (unsigned long long)ps.spp + s + (1ull << 32));  // keyed per-sample stream
+    ps.rng[pid] = rng.state;
+    ps.pend_flags[pid] = in_bounds ? 0u : 0x80000000u;  // bit31: sample outside pixel_bounds, never traced
+    unsigned slot = wave_push(&ps.counters[0], in_bounds);
+    if (in_bounds) ps.q_in[slot] = pid;
+  }
+}
+
+// ================================================================================ K2/K4 trace
+// rays indexed through `queue` (NULL => identity). Small scenes are copied into LDS first
+// (SMALL): nodes and triangle records are then read from LDS for the whole kernel.
+struct LdsSrc {
+  const float4* nodes; const float4* tris;
+  RT_DEV void node(int i, float4& a, float4& b) const { a = nodes[2 * i]; b = nodes[2 * i + 1]; }
+  RT_DEV void tri(int i, f3& p0, f3& p1, f3& p2) const {
+    float4 a = tris[3 * i], b = tris[3 * i + 1], c = tris[3 * i + 2];
+    p0 = mk3(a.x, a.y, a.z); p1 = mk3(b.x, b.y, b.z); p2 = mk3(c.x, c.y, c.z);
+  }
+};
+#define RT_SMALL_NODES 256
+#define RT_SMALL_TRIS 128
+
+// BLOCK threads per workgroup, DEPTH = to-visit stack entries per lane (the host picks the
+// smallest of 16/32/64 that covers the tree height; the reference's fixed 64 is the maximum).
+template <bool ANY, bool COUNT, bool SMALL, int BLOCK, int DEPTH>
+__global__ void __launch_bounds__(BLOCK) k_trace(DScene sc, const float4* __restrict__ ray_o, const float4* __restrict__ ray_d,
+                                                 const unsigned* __restrict__ queue, const unsigned* __restrict__ count_ptr, unsigned count_static,
+                                                 float4* __restrict__ hits, unsigned* __restrict__ occluded, unsigned long long* stats,
+                                                 int st_rays, int st_nodes, int st_tris) {
+  __shared__ int stack[DEPTH * BLOCK];
+  __shared__ float4 s_nodes[SMALL ? 2 * RT_SMALL_NODES : 1];
+  __shared__ float4 s_tris[SMALL ? 3 * RT_SMALL_TRIS : 1];
+  if (SMALL) {
+    for (unsigned i = threadIdx.x; i < 2u * sc.n_nodes; i += BLOCK) s_nodes[i] = sc.nodes[i];
+    for (unsigned i = threadIdx.x; i < 3u * sc.n_tris; i += BLOCK) s_tris[i] = sc.tri_p[i];
+    __syncthreads();
+  }
+  const unsigned count = count_ptr ? *count_ptr : count_static;
+  const unsigned stride = gridDim.x * BLOCK;
+  unsigned n_nodes = 0, n_tris = 0, n_rays = 0;
+  for (unsigned i = blockIdx.x * BLOCK + threadIdx.x; i < count; i += stride) {
+    const unsigned pid = queue ? queue[i] : i;
+    float4 o4 = ray_o[pid], d4 = ray_d[pid];
+    Ray ray; ray.o = mk3(o4.x, o4.y, o4.z); ray.d = mk3(d4.x, d4.y, d4.z); ray.t_max = o4.w;
+    int prim = -1; TriHit h; h.t = kInf; h.b0 = h.b1 = h.b2 = 0.0f;
+    bool found;
+    if (SMALL) { LdsSrc src{s_nodes, s_tris}; found = traverse<ANY, COUNT>(src, ray, stack + threadIdx.x, BLOCK, prim, h, n_nodes, n_tris); }
+    else { GlobalSrc src{sc.nodes, sc.tri_p}; found = traverse<ANY, COUNT>(src, ray, stack + threadIdx.x, BLOCK, prim, h, n_nodes, n_tris); }
+    n_rays += 1;
+    if (ANY) occluded[pid] = found ? 1u : 0u;
+    else hits[pid] = make_float4(found ? h.t : kInf, __int_as_float(found ? prim : -1), h.b0, h.b1);
+  }
+  if (stats) {
+    // one atomic per wave and counter
+    for (int off = 32; off > 0; off >>= 1) { n_rays += __shfl_down(n_rays, off); if (COUNT) { n_nodes += __shfl_down(n_nodes, off); n_tris += __shfl_down(n_tris, off); } }
+    if ((threadIdx.x & 63u) == 0u) {
+      if (n_rays) atomicAdd(&stats[st_rays], (unsigned long long)n_rays);
+      if (COUNT) { atomicAdd(&stats[st_nodes], (unsigned long long)n_nodes); atomicAdd(&stats[st_tris], (unsigned long long)n_tris); }
+    }
+  }
+}
+
+// ================================================================================ K3 shade
+struct PathSampler {  // ZeroTwoSequence::get_1d / get_2d (zerotwosequence.rs:158-180) for one (pixel, sample)
+  Tables tb; unsigned pix, s; int c1, c2; Pcg32 rng;
+  RT_DEV float get_1d() {
+    if (c1 < (int)tb.dims) return table_1d(tb, pix, (unsigned)c1++, s);
+    return rng.next_f32();
+  }
+  RT_DEV f2 get_2d() {
+    if (c2 < (int)tb.dims) return table_2d(tb, pix, (unsigned)c2++, s);
+    float x = rng.next_f32();
+    float y = rng.next_f32();
+    return mk2(y, x);  // (second draw, first draw), :174-179
+  }
+};
+
+__global__ void __launch_bounds__(256) k_shade(DScene sc, FrameParams fp, PassState ps) {
+  const unsigned count = ps.counters[0];
+  const unsigned stride = gridDim.x * blockDim.x;
+  for (unsigned base = blockIdx.x * blockDim.x; base < count; base += stride) {
+    const unsigned i = base + threadIdx.x;
+    const bool lane_live = i < count;
+    bool cont = false, want_shadow = false, want_mis = false;
+    unsigned pid = 0;
+    if (lane_live) {
+      pid = ps.q_in[i];
+      const unsigned pix = pid >> ps.spp_log2, s = pid & (ps.spp - 1u);
+      float4 o4 = ps.ray_o[pid], d4 = ps.ray_d[pid], h4 = ps.hit[pid], b4 = ps.beta[pid], l4 = ps.lacc[pid];
+      f3 ray_o = mk3(o4.x, o4.y, o4.z), ray_d = mk3(d4.x, d4.y, d4.z);
+      rgb3 beta = mkc(b4.x, b4.y, b4.z), L = mkc(l4.x, l4.y, l4.z);
+      float eta_scale = b4.w;
+      unsigned st = __float_as_uint(l4.w);
+      int bounces = (int)(st & 0xffu); bool specular_bounce = (st >> 8) & 1u;
+      PathSampler smp; smp.tb = tables_of(ps); smp.pix = pix; smp.s = s; smp.c1 = (int)((st >> 9) & 15u); smp.c2 = (int)((st >> 13) & 15u);
+      int x, y; unsigned long long pixel_index; owned_pixel(fp, fp.chunk_first + pix, x, y, pixel_index);
+      smp.rng.state = ps.rng[pid];
+      smp.rng.inc = ((pixel_index * (unsigned long long)ps.spp + s + (1ull << 32)) << 1u) | 1ull;
+      const int prim = __float_as_int(h4.y);
+      const bool found = prim >= 0;
+      unsigned pend = 0u;
+      // rebuild the exact hit (t, b0, b1, b2) by re-running the accepted triangle test (t_max = inf)
+      SurfaceInteraction si; TriHit th;
+      if (found) {
+        f3 p0, p1, p2; load_tri(sc.tri_p, prim, p0, p1, p2);
+        Ray r; r.o = ray_o; r.d = ray_d; r.t_max = kInf;
+        (void)tri_test_call(p0, p1, p2, r, th);
+        tri_fill_interaction(sc, prim, ray_d, th, si);
+      }
+      // path.rs:127-136 emitted light at the vertex / from the environment
+      if (bounces == 0 || specular_bounce) {
+        if (found) {
+          int li = tri_light(sc.tri_p, prim);
+          if (li >= 0) L = L + beta * area_light_l(sc.lights[li], si.hit.n, -ray_d);
+        } else {
+          for (int k = 0; k < sc.n_infinite; ++k) L = L + beta * infinite_le(sc, sc.lights[sc.infinite_ids[k]], ray_d);
+        }
+      }
+      if (found && bounces < fp.max_depth) {  // path.rs:139
+        if (bounces == 0) {  // only the camera ray carries differentials (interaction.rs:245-314)
+          f2 pf; { float2 t = ps.pfilm[pid]; pf = mk2(t.x, t.y); }
+          f2 pl = table_2d(smp.tb, pix, 1, s);
+          CameraRay cr = generate_camera_ray(fp, pf, pl, 1.0f / sqrtf((float)ps.spp));
+          compute_differential(si, cr.rx_o, cr.ry_o, cr.rx_d, cr.ry_d);
+        }
+        Bsdf bsdf;
+        build_bsdf(sc, tri_material(sc.tri_p, prim), si, bsdf);
+        // light_distribution.lookup(p) (path.rs:154-158)
+        const float* ld_func; const float* ld_cdf; float ld_int;
+        if (sc.ld_uniform) { ld_func = sc.ld_func; ld_cdf = sc.ld_cdf; ld_int = sc.ld_int[0]; }
+        else { long v = voxel_of(sc, si.hit.p); ld_func = sc.ld_func + v * sc.n_lights; ld_cdf = sc.ld_cdf + v * (sc.n_lights + 1); ld_int = sc.ld_int[v]; }
+        const unsigned nonspec = BSDF_ALL & ~BSDF_SPECULAR;
+        if (bsdf_num_components(bsdf, nonspec) > 0 && sc.n_lights > 0) {  // uniform_sample_one_light, integrator/mod.rs:186-220
+          float su = smp.get_1d();
+          int light_num; float light_pdf;
+          d1_sample_discrete(ld_func, ld_cdf, ld_int, sc.n_lights, su, light_num, light_pdf);
+          if (light_pdf != 0.0f) {
+            f2 u_light = smp.get_2d();
+            f2 u_scattering = smp.get_2d();
+            const DLight& light = sc.lights[light_num];
+            // ---- estimate_direct (integrator/mod.rs:222-318), light-sampling half
+            rgb3 ld1 = mkc(0, 0, 0);
+            LiSample ls = light_sample_li(sc, light, si.hit, u_light);
+            if (ls.pdf > 0.0f && !is_black(ls.li)) {
+              rgb3 f = bsdf_f(bsdf, si.hit.wo, ls.wi, nonspec) * fabsf(dot(ls.wi, si.sh_n));
+              float scattering_pdf = bsdf_pdf(bsdf, si.hit.wo, ls.wi, nonspec);
+              if (!is_black(f)) {
+                Ray sr = spawn_ray_to_interaction(si.hit, ls.p1);  // VisibilityTester, light/mod.rs:52-55
+                ps.sh_o[pid] = make_float4(sr.o.x, sr.o.y, sr.o.z, sr.t_max);
+                ps.sh_d[pid] = make_float4(sr.d.x, sr.d.y, sr.d.z, 0.0f);
+                want_shadow = true; pend |= 1u;
+                if (light_is_delta(light)) ld1 = f * ls.li / ls.pdf;
+                else ld1 = f * ls.li * power_heuristic1(ls.pdf, scattering_pdf) / ls.pdf;
+              }
+            }
+            ps.pend_a[pid] = make_float4(ld1.r, ld1.g, ld1.b, light_pdf);
+            // ---- BSDF-sampling half
+            if (!light_is_delta(light)) {
+              LobeSample bs = bsdf_sample_f(bsdf, si.hit.wo, u_scattering, nonspec);
+              rgb3 f = bs.f * fabsf(dot(bs.wi, si.sh_n));
+              if (!is_black(f) && bs.pdf > 0.0f) {
+                float weight = 1.0f; bool go = true;
+                if (!(bs.type & BSDF_SPECULAR)) {
+                  float lp = light_pdf_li(sc, light, si.hit, bs.wi);
+                  if (lp == 0.0f) go = false;  // `return ld`
+                  else weight = power_heuristic1(bs.pdf, lp);
+                }
+                if (go) {
+                  Ray mr = spawn_ray(si.hit, bs.wi);
+                  ps.mi_o[pid] = make_float4(mr.o.x, mr.o.y, mr.o.z, kInf);
+                  ps.mi_d[pid] = make_float4(mr.d.x, mr.d.y, mr.d.z, 0.0f);
+                  ps.pend_b[pid] = make_float4(f.r, f.g, f.b, weight);
+                  want_mis = true; pend |= 2u | ((unsigned)light_num << 2);
+                  ps.pend_c[pid] = make_float4(beta.r, beta.g, beta.b, bs.pdf);
+                }
+              }
+            }
+            if ((pend & 2u) == 0u) ps.pend_c[pid] = make_float4(beta.r, beta.g, beta.b, 1.0f);
+            pend |= 0x40000000u;  // a direct-lighting estimate is pending for this vertex
+          }
+        }
+        // ---- sample the BSDF for the next direction (path.rs:172-196)
+        f3 wo = -ray_d;  // not normalised (reference quirk)
+        LobeSample bs = bsdf_sample_f(bsdf, wo, smp.get_2d(), BSDF_ALL);
+        if (!(is_black(bs.f) || bs.pdf <= 0.0f)) {
+          beta = beta * bs.f * fabsf(dot(bs.wi, si.sh_n)) / bs.pdf;
+          specular_bounce = (bs.type & BSDF_SPECULAR) != 0u;
+          if ((bs.type & BSDF_SPECULAR) && (bs.type & BSDF_TRANSMISSION)) {
+            float eta = bsdf.eta;
+            eta_scale *= dot(wo, si.hit.n) > 0.0f ? eta * eta : 1.0f / (eta * eta);
+          }
+          Ray nr = spawn_ray(si.hit, bs.wi);
+          cont = true;
+          rgb3 rr_beta = beta * eta_scale;  // path.rs:201-209
+          if (max_component_value(rr_beta) < fp.rr_threshold && bounces > 3) {
+            float q = fmaxf(1.0f - max_component_value(rr_beta), 0.05f);
+            if (smp.get_1d() < q) cont = false;
+            else beta = beta / (1.0f - q);
+          }
+          if (cont) {
+            bounces += 1;
+            ps.ray_o[pid] = make_float4(nr.o.x, nr.o.y, nr.o.z, kInf);
+            ps.ray_d[pid] = make_float4(nr.d.x, nr.d.y, nr.d.z, 0.0f);
+          }
+        }
+      }
+      ps.beta[pid] = make_float4(beta.r, beta.g, beta.b, eta_scale);
+      ps.lacc[pid] = make_float4(L.r, L.g, L.b, __uint_as_float(pack_state(bounces, specular_bounce, smp.c1, smp.c2)));
+      ps.rng[pid] = smp.rng.state;
+      ps.pend_flags[pid] = pend;
+    }
+    unsigned s0 = wave_push(&ps.counters[1], cont);
+    if (cont) ps.q_out[s0] = pid;
+    unsigned s1 = wave_push(&ps.counters[2], want_shadow);
+    if (want_shadow) ps.q_shadow[s1] = pid;
+    unsigned s2 = wave_push(&ps.counters[3], want_mis);
+    if (want_mis) ps.q_mis[s2] = pid;
+  }
+}
+
+// ================================================================================ K5 resolve
+// Completes estimate_direct for every path shaded this bounce: ld = [unoccluded] Ld1 + [MIS ray
+// reached the sampled light] f*Le*w/pdf; L += beta_at_vertex * (ld / light_pick_pdf).
+__global__ void __launch_bounds__(256) k_resolve(DScene sc, PassState ps) {
+  const unsigned count = ps.counters[0];
+  const unsigned stride = gridDim.x * blockDim.x;
+  for (unsigned i = blockIdx.x * blockDim.x + threadIdx.x; i < count; i += stride) {
+    const unsigned pid = ps.q_in[i];
+    const unsigned pend = ps.pend_flags[pid];
+    if (!(pend & 0x40000000u)) continue;
+    float4 a = ps.pend_a[pid], c = ps.pend_c[pid];
+    rgb3 ld = mkc(0, 0, 0);
+    if ((pend & 1u) && ps.sh_occ[pid] == 0u) ld = ld + mkc(a.x, a.y, a.z);
+    if (pend & 2u) {
+      float4 b = ps.pend_b[pid], h4 = ps.mi_hit[pid], d4 = ps.mi_d[pid];
+      const int light_num = (int)((pend >> 2) & 0x0fffffffu);
+      const DLight& light = sc.lights[light_num];
+      f3 wi = mk3(d4.x, d4.y, d4.z);
+      rgb3 li = mkc(0, 0, 0);
+      const int prim = __float_as_int(h4.y);
+      if (prim >= 0) {  // integrator/mod.rs:293-307: emitted radiance only if the hit emitter IS the sampled light
+        if (tri_light(sc.tri_p, prim) == light_num) {
+          float4 o4 = ps.mi_o[pid];
+          f3 p0, p1, p2; load_tri(sc.tri_p, prim, p0, p1, p2);
+          Ray r; r.o = mk3(o4.x, o4.y, o4.z); r.d = wi; r.t_max = kInf;
+          TriHit th; (void)tri_test_call(p0, p1, p2, r, th);
+          f3 p, n; tri_hit_point_normal(sc, prim, th, p, n);
+          li = area_light_l(light, n, -wi);
+        }
+      } else if (light.kind == 3) li = infinite_le(sc, light, wi);  // light.le(ray)
+      if (!is_black(li)) ld = ld + mkc(b.x, b.y, b.z) * li * b.w / c.w;
+    }
+    float4 l4 = ps.lacc[pid];
+    rgb3 add = mkc(c.x, c.y, c.z) * (ld / a.w);
+    ps.lacc[pid] = make_float4(l4.x + add.r, l4.y + add.g, l4.z + add.b, l4.w);
+  }
+}
+
+// queue hand-over between bounces: counters[0] <- counters[1]; others cleared (single thread)
+__global__ void k_next_bounce(unsigned* counters) {
+  if (threadIdx.x == 0 && blockIdx.x == 0) { counters[0] = counters[1]; counters[1] = 0; counters[2] = 0; counters[3] = 0; }
+}
+
+// ================================================================================ K6 film
+// FilmTile::add_sample (film.rs:298-361) + merge (:177-194). One lane per chunk pixel walks its
+// samples in order; its own pixel's sum stays in registers (sequential order = the reference's
+// per-tile order); splats onto other pixels (filter radius > 0.5, or a sample exactly on a pixel
+// edge) go through float atomics. film_acc: float4 (R, G, B sums, weight sum) per cropped pixel.
+__global__ void __launch_bounds__(256) k_film_accumulate(FrameParams fp, PassState ps, const float* __restrict__ filter_table, float4* film_acc) {
+  const unsigned stride = gridDim.x * blockDim.x;
+  const int cw = fp.crop_x1 - fp.crop_x0;
+  const float inv_rx = 1.0f / fp.radius_x, inv_ry = 1.0f / fp.radius_y;
+  for (unsigned pix = blockIdx.x * blockDim.x + threadIdx.x; pix < ps.n_pixels; pix += stride) {
+    int x, y; unsigned long long pixel_index;
+    owned_pixel(fp, fp.chunk_first + pix, x, y, pixel_index);
+    if (y >= fp.sb_y1) continue;
+    rgb3 own = mkc(0, 0, 0); float own_w = 0.0f; bool own_any = false;
+    unsigned scrubbed = 0;
+    for (unsigned s = 0; s < ps.spp; ++s) {
+      const unsigned pid = (pix << ps.spp_log2) | s;
+      if (ps.pend_flags[pid] & 0x80000000u) continue;
+      float4 l4 = ps.lacc[pid];
+      rgb3 c = mkc(l4.x, l4.y, l4.z);
+      bool bad = false;  // renderer.rs:115-126
+      if (has_nan(c)) { c = mkc(0, 0, 0); bad = true; }
+      if (lum_y(c) < -1e-5f) { c = mkc(0, 0, 0); bad = true; }
+      if (isinf(lum_y(c))) { c = mkc(0, 0, 0); bad = true; }
+      scrubbed += bad;
+      rgb3 Lc = lum_y(c) > fp.max_sample_luminance ? c * fp.max_sample_luminance / lum_y(c) : c;
+      float2 pf = ps.pfilm[pid];
+      float dx = pf.x - 0.5f, dy = pf.y - 0.5f;
+      float p0x = ceilf(dx - fp.radius_x), p0y = ceilf(dy - fp.radius_y);
+      float p1x = floorf(dx + fp.radius_x + 1.0f), p1y = floorf(dy + fp.radius_y + 1.0f);
+      int x0 = f2i_sat(max_po(p0x, (float)fp.crop_x0)), y0 = f2i_sat(max_po(p0y, (float)fp.crop_y0));
+      int x1 = f2i_sat(min_po(p1x, (float)fp.crop_x1)), y1 = f2i_sat(min_po(p1y, (float)fp.crop_y1));
+      for (int yy = y0; yy < y1; ++yy) {
+        float fy = fabsf(((float)yy - dy) * inv_ry * 16.0f);
+        int iy = (int)f2u_sat(fminf(floorf(fy), 15.0f));
+        for (int xx = x0; xx < x1; ++xx) {
+          float fx = fabsf(((float)xx - dx) * inv_rx * 16.0f);
+          int ix = (int)f2u_sat(fminf(floorf(fx), 15.0f));
+          float fw = filter_table[iy * 16 + ix];
+          if (xx == x && yy == y) { own = own + Lc * fw; own_w += fw; own_any = true; }
+          else {
+            float* dst = (float*)&film_acc[(size_t)(yy - fp.crop_y0) * cw + (xx - fp.crop_x0)];
+            rgb3 v = Lc * fw;
+            atomicAdd(dst + 0, v.r); atomicAdd(dst + 1, v.g); atomicAdd(dst + 2, v.b); atomicAdd(dst + 3, fw);
+          }
+        }
+      }
+    }
+    if (own_any && x >= fp.crop_x0 && x < fp.crop_x1 && y >= fp.crop_y0 && y < fp.crop_y1) {
+      float* dst = (float*)&film_acc[(size_t)(y - fp.crop_y0) * cw + (x - fp.crop_x0)];
+      atomicAdd(dst + 0, own.r); atomicAdd(dst + 1, own.g); atomicAdd(dst + 2, own.b); atomicAdd(dst + 3, own_w);
+    }
+    if (scrubbed) atomicAdd(&ps.stats[ST_SCRUBBED], (unsigned long long)scrubbed);
+  }
+}
+// merge_film_tile's RGB -> XYZ (spectrum.rs:98-106); output (X, Y, Z, filter_weight_sum)
+__global__ void k_film_finalize(const float4* film_acc, float4* film_xyzw, unsigned long long n) {
+  unsigned long long i = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  float4 a = film_acc[i];
+  float X = 0.412453f * a.x + 0.357580f * a.y + 0.180423f * a.z;
+  float Y = 0.212671f * a.x + 0.715160f * a.y + 0.072169f * a.z;
+  float Z = 0.019334f * a.x + 0.119193f * a.y + 0.950227f * a.z;
+  film_xyzw[i] = make_float4(X, Y, Z, a.w);
+}
+
+// ================================================================================ light distribution build
+// SpatialLightDistribution::compute_distribution (rc/lightdistrib.rs:101-179) for every voxel.
+// One lane per voxel; loops lights outermost so that each light's 128-term sum is accumulated in
+// the reference's order while needing no per-lane array. The five Halton coordinates of the 128
+// points are voxel-independent and staged once per block in LDS.
+__global__ void __launch_bounds__(128) k_lightdist_build(DScene sc, float* func, float* cdf, float* fint) {
+  __shared__ float halton[128 * 5];
+  for (unsigned i = threadIdx.x; i < 128u * 5u; i += blockDim.x) halton[i] = radical_inverse((int)(i % 5u), (unsigned long long)(i / 5u));
+  __syncthreads();
+  const long nvox = (long)sc.nvox[0] * sc.nvox[1] * sc.nvox[2];
+  const long v = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (v >= nvox) return;
+  const int px = (int)(v % sc.nvox[0]), py = (int)((v / sc.nvox[0]) % sc.nvox[1]), pz = (int)(v / ((long)sc.nvox[0] * sc.nvox[1]));
+  f3 p0 = mk3((float)px / (float)sc.nvox[0], (float)py / (float)sc.nvox[1], (float)pz / (float)sc.nvox[2]);
+  f3 p1 = mk3(((float)px + 1.0f) / (float)sc.nvox[0], ((float)py + 1.0f) / (float)sc.nvox[1], ((float)pz + 1.0f) / (float)sc.nvox[2]);
+  f3 a = bounds_lerp(sc.wb_min, sc.wb_max, p0), b = bounds_lerp(sc.wb_min, sc.wb_max, p1);
+  f3 vmn = mk3(min_po(a.x, b.x), min_po(a.y, b.y), min_po(a.z, b.z)), vmx = mk3(max_po(a.x, b.x), max_po(a.y, b.y), max_po(a.z, b.z));
+  const int nl = sc.n_lights;
+  float* fv = func + v * nl; float* cv = cdf + v * (nl + 1);
+  float sum = 0.0f;
+  for (int j = 0; j < nl; ++j) {
+    const DLight& light = sc.lights[j];
+    float contrib = 0.0f;
+    for (int i = 0; i < 128; ++i) {
+      Interaction intr;
+      intr.p = bounds_lerp(vmn, vmx, mk3(halton[5 * i], halton[5 * i + 1], halton[5 * i + 2]));
+      intr.p_error = mk3(0, 0, 0); intr.wo = mk3(1, 0, 0); intr.n = mk3(0, 0, 0);
+      LiSample s = light_sample_li(sc, light, intr, mk2(halton[5 * i + 3], halton[5 * i + 4]));
+      if (s.pdf > 0.0f) contrib += lum_y(s.li) / s.pdf;
+    }
+    fv[j] = contrib;
+    sum += contrib;
+  }
+  float avg = sum / (float)(128ull * (unsigned long long)nl);
+  float min_contrib = avg > 0.0f ? 0.001f * avg : 1.0f;
+  // Distribution1D::new (distribution1d.rs:11-42)
+  cv[0] = 0.0f;
+  for (int j = 0; j < nl; ++j) { float c = fmaxf(fv[j], min_contrib); fv[j] = c; cv[j + 1] = cv[j] + c / (float)nl; }
+  float func_int = cv[nl];
+  if (func_int == 0.0f) for (int j = 1; j < nl + 1; ++j) cv[j] = (float)j / (float)nl;
+  else for (int j = 1; j < nl + 1; ++j) cv[j] /= func_int;
+  fint[v] = func_int;
+}
+
+}  // namespace rtx

@@ -1,0 +1,279 @@
+"""ctypes binding of the product libraries (csrc/_build/librtx_host.so -> librtx_hip.so).
+
+`HostScene` plays the role of rustracer's `RealApi` + `world_end` (rc/api.rs:913-1010): it feeds the
+unflattened scene description to the C++ host layer (SAH BVH build, flattening, camera/film set-up)
+and renders through the HIP backend. Nothing here computes radiance and nothing falls back to a CPU
+path: without a GPU `render`/`trace` raise `BackendError`.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_CSRC = os.path.join(_HERE, "csrc")
+_BUILD = os.path.join(_CSRC, "_build")
+HOST_LIB = os.path.join(_BUILD, "librtx_host.so")
+HIP_LIB = os.path.join(_BUILD, "librtx_hip.so")
+
+RT_FLAG_COUNT_TRAVERSAL = 1
+RT_FLAG_FILM_ON_DEVICE = 2
+RT_FLAG_TIME_KERNELS = 4
+
+
+class BackendError(RuntimeError):
+    pass
+
+
+def build(force: bool = False) -> None:
+    """Compile both libraries for gfx950 (hipcc cross-compiles without a GPU)."""
+    srcs = [os.path.join(_CSRC, f) for f in os.listdir(_CSRC) if f.endswith((".h", ".hip", ".cpp"))]
+    srcs += [os.path.join(_HERE, "..", "include", f) for f in ("rtx_hip.h", "rtx_host.h")]
+    stale = force or not (os.path.exists(HOST_LIB) and os.path.exists(HIP_LIB))
+    if not stale:
+        newest = max(os.path.getmtime(s) for s in srcs)
+        stale = newest > min(os.path.getmtime(HOST_LIB), os.path.getmtime(HIP_LIB))
+    if stale:
+        subprocess.check_call(["make", "-C", _CSRC, "-s"])
+
+
+class RenderParams(C.Structure):
+    _fields_ = [
+        ("xres", C.c_int32), ("yres", C.c_int32), ("crop", C.c_float * 4),
+        ("filter_kind", C.c_int32), ("filter_params", C.c_float * 4),
+        ("film_scale", C.c_float), ("max_sample_luminance", C.c_float),
+        ("cam_to_world", C.c_float * 16), ("cam_to_world_inv", C.c_float * 16),
+        ("fov", C.c_float), ("lens_radius", C.c_float), ("focal_distance", C.c_float),
+        ("spp", C.c_int32), ("sampler_dims", C.c_int32),
+        ("max_depth", C.c_int32), ("rr_threshold", C.c_float), ("light_strategy", C.c_int32),
+        ("pixel_bounds", C.c_int32 * 4), ("rank", C.c_int32), ("world_size", C.c_int32), ("flags", C.c_uint32),
+    ]
+
+
+class Stats(C.Structure):
+    _fields_ = ([(n, C.c_uint64) for n in (
+        "camera_rays", "rays_closest", "rays_shadow", "rays_mis", "nodes_closest", "nodes_shadow", "nodes_mis",
+        "tris_closest", "tris_shadow", "tris_mis", "paths_scrubbed")] +
+        [(n, C.c_double) for n in ("ms_total", "ms_sampler", "ms_raygen", "ms_trace_closest", "ms_trace_any", "ms_trace_mis",
+                                   "ms_shade", "ms_resolve", "ms_film", "ms_lightdist")] +
+        [("launches_trace_closest", C.c_uint64), ("n_passes", C.c_uint64)])
+
+    def as_dict(self):
+        return {n: getattr(self, n) for n, _ in self._fields_}
+
+
+_lib = None
+_hip = None
+
+
+def lib():
+    global _lib, _hip
+    if _lib is None:
+        if not os.path.exists(HOST_LIB):
+            raise BackendError(f"{HOST_LIB} missing: run `python -c 'import __graft_entry__ as g; g.build()'`")
+        _hip = C.CDLL(HIP_LIB, mode=C.RTLD_GLOBAL)
+        _lib = C.CDLL(HOST_LIB)
+        L = _lib
+        L.rtxh_scene_new.restype = C.c_void_p
+        L.rtxh_scene_free.argtypes = [C.c_void_p]
+        L.rtxh_last_error.restype = C.c_char_p
+        _hip.rt_last_error.restype = C.c_char_p
+        _hip.rt_version.restype = C.c_char_p
+    return _lib
+
+
+def hip_lib():
+    lib()
+    return _hip
+
+
+def device_available() -> bool:
+    return bool(hip_lib().rt_device_available())
+
+
+def _p(a, t=C.c_float):
+    return None if a is None else a.ctypes.data_as(C.POINTER(t))
+
+
+def _check(rc, what):
+    if rc < 0:
+        msg = lib().rtxh_last_error()
+        raise BackendError(f"{what} failed ({rc}): {msg.decode() if msg else '?'}")
+    return rc
+
+
+def look_at(pos, look, up):
+    m = np.zeros((4, 4), np.float32)
+    mi = np.zeros((4, 4), np.float32)
+    lib().rtxh_look_at(_p(np.float32(pos)), _p(np.float32(look)), _p(np.float32(up)), _p(m), _p(mi))
+    return m, mi
+
+
+def render_params(desc, rank=0, world_size=1, flags=0) -> RenderParams:
+    p = RenderParams()
+    f, c, s, it = desc.film, desc.camera, desc.sampler, desc.integrator
+    p.xres, p.yres = f.xres, f.yres
+    p.crop[:] = [float(x) for x in f.crop]
+    p.filter_kind = f.filter_kind
+    p.filter_params[:] = [float(x) for x in f.filter_params]
+    p.film_scale = f.scale
+    p.max_sample_luminance = f.max_sample_luminance
+    w2c, c2w = look_at(c.pos, c.look, c.up)  # CTM = LookAt; camera_to_world = CTM.inverse()
+    p.cam_to_world[:] = c2w.reshape(-1).tolist()
+    p.cam_to_world_inv[:] = w2c.reshape(-1).tolist()
+    p.fov, p.lens_radius, p.focal_distance = c.fov, c.lens_radius, c.focal_distance
+    p.spp, p.sampler_dims = s.spp, s.dims
+    p.max_depth, p.rr_threshold = it.max_depth, it.rr_threshold
+    p.light_strategy = 1 if it.light_strategy == "uniform" else 0
+    pb = it.pixel_bounds
+    p.pixel_bounds[:] = list(pb) if pb is not None else [0, 0, 0, 0]
+    p.rank, p.world_size, p.flags = rank, world_size, flags
+    return p
+
+
+class HostScene:
+    def __init__(self, desc):
+        L = lib()
+        self.desc = desc
+        self.h = C.c_void_p(L.rtxh_scene_new())
+        P, idx, N, UV, S, mat, light, flags = desc.arrays()
+        self._keep = (P, idx, N, UV, S, mat, light, flags)
+        _check(L.rtxh_scene_set_mesh(self.h, _p(P), P.shape[0], _p(idx, C.c_int32), idx.shape[0], _p(N), _p(UV), _p(S),
+                                     _p(mat, C.c_int32), _p(light, C.c_int32), _p(flags, C.c_uint8)), "set_mesh")
+        for m in desc.mipmaps:
+            h, w = m.data.shape[:2]
+            _check(L.rtxh_scene_add_mipmap(self.h, w, h, _p(m.data), int(m.trilinear), C.c_float(m.max_aniso), m.wrap), "add_mipmap")
+        for t in desc.textures:
+            _check(L.rtxh_scene_add_texture(self.h, t.kind, _p(np.float32(t.value)), t.tex1, t.tex2, t.amount, t.mip, _p(np.float32(t.mapping))), "add_texture")
+        for m in desc.materials:
+            _check(L.rtxh_scene_add_material(self.h, m.kind, _p(m.slots(), C.c_int32), int(m.remap_roughness)), "add_material")
+        for l in desc.lights:
+            l2w = None if l.l2w is None else np.ascontiguousarray(l.l2w, np.float32)
+            w2l = None if l.w2l is None else np.ascontiguousarray(l.w2l, np.float32)
+            _check(L.rtxh_scene_add_light(self.h, l.kind, l.tri, _p(np.float32(l.rgb)), int(l.two_sided), _p(np.float32(l.vec)), l.mip, _p(l2w), _p(w2l)), "add_light")
+        _check(L.rtxh_scene_commit(self.h, desc.max_prims_per_node), "commit")
+
+    def __del__(self):
+        try:
+            lib().rtxh_scene_free(self.h)
+        except Exception:
+            pass
+
+    # ---- CPU-side products -----------------------------------------------------------------
+    def bvh(self):
+        L = lib()
+        nn, npr = C.c_int32(), C.c_int32()
+        L.rtxh_scene_bvh_sizes(self.h, C.byref(nn), C.byref(npr))
+        bounds = np.zeros((nn.value, 6), np.float32)
+        offset = np.zeros(nn.value, np.uint32)
+        nprims = np.zeros(nn.value, np.uint16)
+        axis = np.zeros(nn.value, np.uint8)
+        ordered = np.zeros(npr.value, np.int32)
+        L.rtxh_scene_bvh_get(self.h, _p(bounds), _p(offset, C.c_uint32), _p(nprims, C.c_uint16), _p(axis, C.c_uint8), _p(ordered, C.c_int32))
+        return dict(bounds=bounds, offset=offset, n_prims=nprims, axis=axis, ordered=ordered)
+
+    def setup(self, **kw):
+        p = render_params(self.desc, **kw)
+        r2c = np.zeros((4, 4), np.float32)
+        dxdy = np.zeros(6, np.float32)
+        table = np.zeros(256, np.float32)
+        sb = np.zeros(4, np.int32)
+        cr = np.zeros(4, np.int32)
+        _check(lib().rtxh_camera_film_setup(C.byref(p), _p(r2c), _p(dxdy), _p(table), _p(sb, C.c_int32), _p(cr, C.c_int32)), "camera_film_setup")
+        return dict(raster_to_camera=r2c, dx_camera=dxdy[:3].copy(), dy_camera=dxdy[3:].copy(), filter_table=table, sample_bounds=sb, cropped=cr, params=p)
+
+    def mip_levels(self, mip):
+        L = lib()
+        w, h = C.c_int32(), C.c_int32()
+        n = _check(L.rtxh_mip_level(self.h, mip, 0, C.byref(w), C.byref(h), None), "mip_level")
+        out = []
+        for lvl in range(n):
+            L.rtxh_mip_level(self.h, mip, lvl, C.byref(w), C.byref(h), None)
+            a = np.zeros((h.value, w.value, 3), np.float32)
+            L.rtxh_mip_level(self.h, mip, lvl, C.byref(w), C.byref(h), _p(a))
+            out.append(a)
+        return out
+
+    # ---- GPU ---------------------------------------------------------------------------------
+    def upload(self, device=-1):
+        _check(lib().rtxh_scene_upload(self.h, device), "upload")
+
+    def render(self, rank=0, world_size=1, count_traversal=False, time_kernels=False, device_out=None, stream=0):
+        """renderer::render on the GPU. Returns (film_xyzw (H,W,4) over the cropped bounds, stats dict).
+        `device_out`: optional torch CUDA tensor (H,W,4) float32 that receives the film in HBM."""
+        flags = (RT_FLAG_COUNT_TRAVERSAL if count_traversal else 0) | (RT_FLAG_TIME_KERNELS if time_kernels else 0)
+        st = self.setup(rank=rank, world_size=world_size)
+        cr = st["cropped"]
+        w, h = int(cr[2] - cr[0]), int(cr[3] - cr[1])
+        p = st["params"]
+        stats = Stats()
+        if device_out is not None:
+            assert tuple(device_out.shape) == (h, w, 4) and device_out.is_contiguous()
+            p.flags = flags | RT_FLAG_FILM_ON_DEVICE
+            _check(lib().rtxh_render(self.h, C.byref(p), C.c_void_p(stream), C.c_void_p(device_out.data_ptr()), C.byref(stats)), "render")
+            return device_out, stats.as_dict()
+        p.flags = flags
+        film = np.zeros((h, w, 4), np.float32)
+        _check(lib().rtxh_render(self.h, C.byref(p), C.c_void_p(stream), _p(film), C.byref(stats)), "render")
+        return film, stats.as_dict()
+
+    def trace(self, rays, any_hit=False):
+        rays = np.ascontiguousarray(rays, np.float32)
+        n = rays.shape[0]
+        cnt = np.zeros(2, np.uint64)
+        if any_hit:
+            occ = np.zeros(n, np.uint32)
+            _check(lib().rtxh_trace(self.h, _p(rays), C.c_uint64(n), 1, occ.ctypes.data_as(C.POINTER(C.c_float)), _p(cnt, C.c_uint64)), "trace_any")
+            return dict(occluded=occ > 0, nodes=int(cnt[0]), tris=int(cnt[1]))
+        out = np.zeros((n, 4), np.float32)
+        _check(lib().rtxh_trace(self.h, _p(rays), C.c_uint64(n), 0, _p(out), _p(cnt, C.c_uint64)), "trace_closest")
+        return dict(t=out[:, 0].copy(), prim=out[:, 1].copy().view(np.int32), b0=out[:, 2].copy(), b1=out[:, 3].copy(), nodes=int(cnt[0]), tris=int(cnt[1]))
+
+    def trace_device(self, d_rays_ptr, n, d_hits_ptr, reps=10, stream=0):
+        ms = C.c_float()
+        _check(lib().rtxh_trace_device(self.h, C.c_void_p(d_rays_ptr), C.c_uint64(n), C.c_void_p(d_hits_ptr), reps, C.c_void_p(stream), C.byref(ms)), "trace_device")
+        return ms.value
+
+    def light_distribution(self):
+        nv = np.zeros(3, np.int32)
+        _check(lib().rtxh_light_distribution(self.h, _p(nv, C.c_int32), None, None, None), "light_distribution")
+        total = int(nv[0]) * int(nv[1]) * int(nv[2])
+        if total == 0:
+            return dict(n_voxels=nv)
+        nl = len(self.desc.lights)
+        func = np.zeros((total, nl), np.float32)
+        cdf = np.zeros((total, nl + 1), np.float32)
+        fint = np.zeros(total, np.float32)
+        _check(lib().rtxh_light_distribution(self.h, _p(nv, C.c_int32), _p(func), _p(cdf), _p(fint)), "light_distribution")
+        return dict(n_voxels=nv, func=func, cdf=cdf, func_int=fint)
+
+
+def sampler_tables(spp, dims, pixel0, n_pixels):
+    """K0 on the GPU: (scrambles (n,3*dims) u32, perms (n, 2*dims, spp) u16)."""
+    spp2 = 1
+    while spp2 < spp:
+        spp2 *= 2
+    sc = np.zeros((n_pixels, 3 * dims), np.uint32)
+    pm = np.zeros((n_pixels, 2 * dims, spp2), np.uint16)
+    rc = hip_lib().rt_sampler_tables(spp, dims, C.c_uint64(pixel0), C.c_uint64(n_pixels), _p(sc, C.c_uint32), _p(pm, C.c_uint16))
+    if rc < 0:
+        raise BackendError(f"rt_sampler_tables failed ({rc}): {hip_lib().rt_last_error().decode()}")
+    return sc, pm
+
+
+def film_to_rgb(film_xyzw: np.ndarray, scale: float = 1.0) -> np.ndarray:
+    """Film::write_image's pixel maths (rc/film.rs:196-234) in float32 numpy: XYZ -> RGB, / weight, clamp, * scale."""
+    f = np.asarray(film_xyzw, np.float32)
+    X, Y, Z, Wt = f[..., 0], f[..., 1], f[..., 2], f[..., 3]
+    c = np.float32
+    r = c(3.240479) * X - c(1.537150) * Y - c(0.498535) * Z
+    g = c(-0.969256) * X + c(1.875991) * Y + c(0.041556) * Z
+    b = c(0.055648) * X - c(0.204043) * Y + c(1.057311) * Z
+    rgb = np.stack([r, g, b], -1)
+    nz = Wt != 0
+    inv = np.where(nz, c(1.0) / np.where(nz, Wt, c(1.0)), c(1.0)).astype(np.float32)
+    rgb = np.where(nz[..., None], np.maximum(c(0.0), rgb * inv[..., None]), rgb)
+    return (rgb * c(scale)).astype(np.float32)
