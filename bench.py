@@ -1,0 +1,157 @@
+#!/usr/bin/env python3
+"""bench.py — headline benchmark of the MI355X path-tracing backend (BASELINE.json configs[1]).
+
+A "step" is one full frame of the hot path: the synthetic Cornell box (S1) at
+1024x1024, PathIntegrator maxdepth=5, 1024 spp, scene already resident in HBM. With N > 1 the film is
+sharded by interleaved 16-row tile rows (one process per GPU, no collective on the data path) and
+merged by one end-of-frame sum-reduce to rank 0 over RCCL, which is inside the timed region.
+
+Prints ONE JSON line (rank 0). `roofline` is for the dominant kernel, trace_closest: algorithmic
+bytes (48 B per cast + 32 B per BVH node visited + 36 B per triangle tested, counted by
+an untimed counting frame of the same workload) / the kernel's HIP-event time measured in the timed
+frames. `cpu_baseline` is the C++ oracle in its reference-faithful tile-sequential sampler mode on all
+host cores, over a bounded sample of the same workload (reported, not the target).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--res", type=int, default=1024)
+    ap.add_argument("--spp", type=int, default=1024)
+    ap.add_argument("--cpu-spp", type=int, default=32, help="spp of the bounded CPU-baseline sample")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    import numpy as np
+    import torch
+    from rustracer_amd import host
+    from rustracer_amd.distributed import merge_film
+    from rustracer_amd.scenes import cornell_box
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    n_gpus = max(args.gpus, 1)
+    if world != n_gpus and world > 1:
+        n_gpus = world
+    if not host.device_available() or not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: the backend has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+
+    desc = cornell_box(args.res, args.res, args.spp)
+    scene = host.HostScene(desc)
+    scene.upload(local_rank)
+    st0 = scene.setup()
+    cr = st0["cropped"]
+    h, w = int(cr[3] - cr[1]), int(cr[2] - cr[0])
+    film = torch.zeros((h, w, 4), dtype=torch.float32, device=f"cuda:{local_rank}")
+    stream = torch.cuda.current_stream().cuda_stream
+
+    def barrier():
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    def step(timed):
+        _, st = scene.render(rank=rank, world_size=world, time_kernels=timed, device_out=film, stream=stream)
+        merge_film(film, dst=0)  # end-of-frame film merge (no-op at N = 1)
+        return st
+
+    for _ in range(args.warmup):
+        step(False)
+    barrier()
+    t0 = time.perf_counter()
+    kstats = []
+    for _ in range(args.steps):
+        kstats.append(step(True))
+    barrier()
+    dt = time.perf_counter() - t0
+    if dist is not None:
+        tt = torch.tensor([dt], dtype=torch.float64, device=f"cuda:{local_rank}")
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dt = float(tt.item())
+        cnt = torch.tensor([float(kstats[-1]["camera_rays"])], dtype=torch.float64, device=f"cuda:{local_rank}")
+        dist.all_reduce(cnt, op=dist.ReduceOp.SUM)
+        samples_per_step = float(cnt.item())
+    else:
+        samples_per_step = float(kstats[-1]["camera_rays"])
+
+    # untimed counting frame: per-ray BVH node visits / triangle tests for the algorithmic byte count
+    _, cst = scene.render(rank=rank, world_size=world, count_traversal=True, device_out=film, stream=stream)
+    torch.cuda.synchronize()
+
+    if rank == 0:
+        ms_step = dt / args.steps * 1e3
+        value = samples_per_step * args.steps / dt / 1e6
+        # --- roofline of trace_closest (path-continuation + MIS closest-hit launches share the kernel)
+        rays = cst["rays_closest"] + cst["rays_mis"]
+        algo_bytes = 48 * rays + 32 * (cst["nodes_closest"] + cst["nodes_mis"]) + 36 * (cst["tris_closest"] + cst["tris_mis"])
+        launches = kstats[-1]["launches_trace_closest"]
+        ms_kernel = float(np.mean([k["ms_trace_closest"] + k["ms_trace_mis"] for k in kstats]))
+        achieved = algo_bytes / (ms_kernel * 1e-3) / 1e9  # GB/s
+        traffic = None
+        pmc = os.path.join(ROOT, "profiles", "pmc_trace_closest.json")
+        if os.path.exists(pmc):
+            try:
+                traffic = json.load(open(pmc)).get("hbm_bytes_per_launch")
+            except Exception:
+                traffic = None
+        roofline = {"bound": "hbm", "kernel": "k_trace<closest>", "achieved": round(achieved, 1), "peak": 8000.0, "unit": "GB/s",
+                    "frac": round(achieved / 8000.0, 4), "traffic": traffic,
+                    "algorithmic_bytes_per_launch": round(algo_bytes / launches), "avg_launch_ms": round(ms_kernel / launches, 4),
+                    "launches_per_step": int(launches), "bytes_per_ray": round(algo_bytes / rays, 1)}
+        kernels_ms = {k[3:]: round(float(np.mean([s[k] for s in kstats])), 2) for k in kstats[-1] if k.startswith("ms_")}
+        out = {
+            "metric": "Msamples/s", "value": round(value, 2), "unit": "Msamples/s", "n_gpus": n_gpus, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(ms_step, 2), "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": f"cornell-box (synthetic S1, 32 triangles, 2 area lights) {args.res}x{args.res} PathIntegrator maxdepth=5 {args.spp}spp 02sequence box-filter",
+                       "sharding": "interleaved 16-row tile rows, end-of-frame sum-reduce to rank 0" if n_gpus > 1 else "single GPU",
+                       "sampler_mode": "pixel-keyed"},
+            "s_per_frame": round(ms_step / 1e3, 4),
+            "Mrays_per_s": round((kstats[-1]["rays_closest"] + kstats[-1]["rays_shadow"] + kstats[-1]["rays_mis"]) * (n_gpus if n_gpus > 1 else 1) / (ms_step * 1e-3) / 1e6, 1),
+            "kernel_ms_per_step": kernels_ms,
+            "roofline": roofline,
+        }
+        if n_gpus == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(desc, args)
+            out["speedup_vs_cpu_baseline"] = round(value / out["cpu_baseline"]["value"], 1)
+        print(json.dumps(out), flush=True)
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+def cpu_baseline(desc, args):
+    """The oracle (C++ restatement of rustracer's CPU path), reference-faithful tile-sequential sampler, all host cores."""
+    import copy
+    from oracle import orc  # noqa: the checker, timed as the CPU baseline only
+    d = copy.copy(desc)
+    d.sampler = copy.copy(desc.sampler)
+    d.sampler.spp = args.cpu_spp
+    o = orc.OracleScene(d)
+    cores = os.cpu_count() or 1
+    _, st = o.render(mode=0, n_threads=cores)
+    return {"value": round(st["camera_rays"] / st["seconds"] / 1e6, 3), "unit": "Msamples/s", "cores": cores, "kind": "port",
+            "sample": f"same scene and resolution at {args.cpu_spp} spp ({st['camera_rays']} camera samples, {round(st['seconds'], 1)} s); "
+                      "Msamples/s is spp-independent",
+            "Mrays_per_s": round((st["rays_closest"] + st["rays_shadow"] + st["rays_mis"]) / st["seconds"] / 1e6, 2)}
+
+
+if __name__ == "__main__":
+    main()

@@ -290,12 +290,66 @@ int orc_distribution1d_get(const float* f, int n, float* cdf_out, float* func_in
   Distribution1D d(f, (size_t)n); for (size_t i = 0; i < d.cdf.size(); ++i) cdf_out[i] = d.cdf[i]; *func_int = d.func_int; return 0;
 }
 int orc_find_interval_array(const float* a, int n, float x) { return (int)find_interval((size_t)n, [&](size_t i) { return a[i] <= x; }); }
-// Bounds2i iteration order (rc/bounds.rs:382-420): row-major, x fastest, degenerate => nothing
+// Bounds2i iteration order (rc/bounds.rs:382-420): the iterator's own state machine
 int orc_bounds2i_iter(int x0, int y0, int x1, int y1, int32_t* out_xy, int cap) {
   int n = 0;
-  if (x1 <= x0 || y1 <= y0) return 0;
-  for (int y = y0; y < y1; ++y) for (int x = x0; x < x1; ++x) { if (n < cap) { out_xy[2 * n] = x; out_xy[2 * n + 1] = y; } ++n; }
+  int px = x0 - 1, py = y0;  // into_iter(): "start 1 before p_min.x"
+  for (;;) {
+    if (x1 <= x0 || y1 <= y0) break;  // degenerate bounds yield nothing
+    px += 1;
+    if (px == x1) { px = x0; py += 1; }
+    if (py >= y1) break;
+    if (n < cap) { out_xy[2 * n] = px; out_xy[2 * n + 1] = py; }
+    ++n;
+  }
   return n;
+}
+// pcg32_srandom_r(initstate, initseq) + n draws with the generator step of rc/rng.rs:23-30. RNG::set_sequence(seq)
+// is pcg32_srandom_r(PCG32_DEFAULT_STATE, seq); the published PCG32 demo vector uses (42, 54).
+int orc_pcg32_srandom_stream(uint64_t initstate, uint64_t initseq, int n, uint32_t* out) {
+  Rng r; r.state = 0; r.inc = (initseq << 1u) | 1u;
+  (void)r.uniform_u32(); r.state += initstate; (void)r.uniform_u32();
+  for (int i = 0; i < n; ++i) out[i] = r.uniform_u32();
+  return 0;
+}
+// Single triangle test (tests): tri9 = p0 p1 p2, ray8 = o, tmax, d, pad -> out4 = t b0 b1 b2; returns 1 on hit
+int orc_tri_intersect(const float* tri9, const float* ray8, float* out4) {
+  Scene s; s.P = {v3(tri9[0], tri9[1], tri9[2]), v3(tri9[3], tri9[4], tri9[5]), v3(tri9[6], tri9[7], tri9[8])};
+  s.idx = {0, 1, 2}; s.tri_material = {0}; s.tri_light = {-1}; s.tri_flags = {0};
+  Ray ray = ray_segment(v3(ray8[0], ray8[1], ray8[2]), v3(ray8[4], ray8[5], ray8[6]), ray8[3]);
+  TriHit h;
+  if (!s.tri_test(0, ray, &h)) return 0;
+  out4[0] = h.t; out4[1] = h.b0; out4[2] = h.b1; out4[3] = h.b2;
+  return 1;
+}
+// The reference's sphere property test (rustracer-core/tests/shapes.rs:16-54) transplanted to triangles:
+// hit the triangle, spawn a ray from the hit in direction w and re-test. Returns -1 original miss, 0 no re-hit, 1 re-hit.
+int orc_tri_reintersect(const float* tri9, const float* ray8, const float* w3) {
+  Scene s; s.P = {v3(tri9[0], tri9[1], tri9[2]), v3(tri9[3], tri9[4], tri9[5]), v3(tri9[6], tri9[7], tri9[8])};
+  s.idx = {0, 1, 2}; s.tri_material = {0}; s.tri_light = {-1}; s.tri_flags = {0};
+  Ray ray = ray_segment(v3(ray8[0], ray8[1], ray8[2]), v3(ray8[4], ray8[5], ray8[6]), ray8[3]);
+  TriHit h;
+  if (!s.tri_test(0, ray, &h)) return -1;
+  SurfaceInteraction si; s.tri_fill_interaction(0, ray, h, &si);
+  V3 w = v3(w3[0], w3[1], w3[2]);
+  if (dot(w, si.hit.n) * dot(-ray.d, si.hit.n) < 0.0f) w = -w;  // leave on the side the ray came from
+  Ray r2 = spawn_ray(si.hit, w);
+  TriHit h2;
+  return s.tri_test(0, r2, &h2) ? 1 : 0;
+}
+// BSDF probes (tests): evaluates f / pdf / sample_f of the Bsdf a material builds at a canonical hit (n = +z)
+int orc_bsdf_probe(void* h, int material, const float* wo3, const float* wi3, const float* u2, float* f3_out, float* pdf_out, float* sample_out8) {
+  Scene* s = (Scene*)h;
+  SurfaceInteraction si; si.hit = Interaction{v3(0, 0, 0), v3(0, 0, 0), v3(0, 0, 1), v3(0, 0, 1)}; si.uv = P2{0.5f, 0.5f};
+  si.dpdu = v3(1, 0, 0); si.dpdv = v3(0, 1, 0); si.shading.n = v3(0, 0, 1); si.shading.dpdu = v3(1, 0, 0); si.shading.dpdv = v3(0, 1, 0);
+  Bsdf b; s->build_bsdf(material, si, &b);
+  V3 wo = v3(wo3[0], wo3[1], wo3[2]), wi = v3(wi3[0], wi3[1], wi3[2]);
+  RGB f = b.f(wo, wi, BSDF_ALL); f3_out[0] = f.r; f3_out[1] = f.g; f3_out[2] = f.b;
+  *pdf_out = b.pdf(wo, wi, BSDF_ALL);
+  SampleF sf = b.sample_f(wo, P2{u2[0], u2[1]}, BSDF_ALL);
+  sample_out8[0] = sf.f.r; sample_out8[1] = sf.f.g; sample_out8[2] = sf.f.b; sample_out8[3] = sf.wi.x; sample_out8[4] = sf.wi.y; sample_out8[5] = sf.wi.z;
+  sample_out8[6] = sf.pdf; sample_out8[7] = (float)sf.type;
+  return b.n;
 }
 float orc_next_float_up(float v) { return next_float_up(v); }
 float orc_next_float_down(float v) { return next_float_down(v); }
