@@ -137,6 +137,19 @@ def main():
         dist.destroy_process_group()
 
 
+def host_cores():
+    """Cores this process may actually use: affinity mask capped by the cgroup CPU quota (what Rust's
+    num_cpus::get(), the reference's default thread count (rc/api.rs:997-1001), reports as well)."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            n = min(n, max(1, int(int(quota) / int(period))))
+    except Exception:
+        pass
+    return n
+
+
 def cpu_baseline(desc, args):
     """The oracle (C++ restatement of rustracer's CPU path), reference-faithful tile-sequential sampler, all host cores."""
     import copy
@@ -145,7 +158,7 @@ def cpu_baseline(desc, args):
     d.sampler = copy.copy(desc.sampler)
     d.sampler.spp = args.cpu_spp
     o = orc.OracleScene(d)
-    cores = os.cpu_count() or 1
+    cores = host_cores()
     _, st = o.render(mode=0, n_threads=cores)
     return {"value": round(st["camera_rays"] / st["seconds"] / 1e6, 3), "unit": "Msamples/s", "cores": cores, "kind": "port",
             "sample": f"same scene and resolution at {args.cpu_spp} spp ({st['camera_rays']} camera samples, {round(st['seconds'], 1)} s); "

@@ -28,6 +28,7 @@ struct DScene {
   const float* tri_n; const float* tri_uv; const float* tri_s;
   const DTexture* textures; const DImage* images; const DMaterial* materials; const DLight* lights;
   int n_lights; int n_infinite; int infinite_ids[4];
+  int needs_differentials;  // some texture is an image map (the only consumer of dudx.. is MIPMap filtering)
   f3 wb_min, wb_max;
   // light distribution (rc/lightdistrib.rs): dense voxel table or a single uniform distribution
   int ld_uniform; int nvox[3];
@@ -137,7 +138,7 @@ RT_DEV Ray spawn_ray_to_interaction(const Interaction& a, const Interaction& b) 
 }
 
 // Triangle::intersect tail, mesh.rs:321-425 (alpha masks: not carried by the flattened scene)
-RT_DEVN void tri_fill_interaction(const DScene& sc, int prim, f3 ray_d, const TriHit& h, SurfaceInteraction& si) {
+RT_DEV void tri_fill_interaction_inl(const DScene& sc, int prim, f3 ray_d, const TriHit& h, SurfaceInteraction& si) {
   f3 p0, p1, p2; load_tri(sc.tri_p, prim, p0, p1, p2);
   const unsigned flags = tri_flags(sc.tri_p, prim);
   const float b0 = h.b0, b1 = h.b1, b2 = h.b2;
@@ -187,8 +188,10 @@ RT_DEVN void tri_fill_interaction(const DScene& sc, int prim, f3 ray_d, const Tr
   si.prim = prim;
 }
 
+RT_DEVN void tri_fill_interaction(const DScene& sc, int prim, f3 ray_d, const TriHit& h, SurfaceInteraction& si) { tri_fill_interaction_inl(sc, prim, ray_d, h, si); }
+
 // Geometric normal + hit point of a known hit, enough for Light::l / pdf_wi (no shading frame).
-RT_DEVN void tri_hit_point_normal(const DScene& sc, int prim, const TriHit& h, f3& p, f3& n) {
+RT_DEV void tri_hit_point_normal_inl(const DScene& sc, int prim, const TriHit& h, f3& p, f3& n) {
   f3 p0, p1, p2; load_tri(sc.tri_p, prim, p0, p1, p2);
   const unsigned flags = tri_flags(sc.tri_p, prim);
   p = p0 * h.b0 + p1 * h.b1 + p2 * h.b2;
@@ -199,6 +202,8 @@ RT_DEVN void tri_hit_point_normal(const DScene& sc, int prim, const TriHit& h, f
     n = face_forward(n, ns);
   } else if (flags & 1u) n = -n;
 }
+
+RT_DEVN void tri_hit_point_normal(const DScene& sc, int prim, const TriHit& h, f3& p, f3& n) { tri_hit_point_normal_inl(sc, prim, h, p, n); }
 
 // compute_differential (interaction.rs:245-314) for a ray that carries differentials
 RT_DEVN void compute_differential(SurfaceInteraction& si, f3 rx_o, f3 ry_o, f3 rx_d, f3 ry_d) {

@@ -328,36 +328,48 @@ RT_DEVN rgb3 infinite_le(const DScene& sc, const DLight& l, f3 ray_d) {  // infi
   f2 st = mk2(spherical_phi(w) * kInvPi * 0.5f, spherical_theta(w) * kInvPi);
   return mip_lookup(sc.images[l.image], st, 0.0f);
 }
+// DiffuseAreaLight::sample_li diffuse.rs:59-70 -> Shape::sample_si shapes/mod.rs:39-53 -> Triangle::sample mesh.rs:610-634
+RT_DEV LiSample area_light_sample_li(const DScene& sc, const DLight& l, const Interaction& ref, f2 u) {
+  LiSample s;
+  f2 b = uniform_sample_triangle(u);
+  f3 p0, p1, p2; load_tri(sc.tri_p, l.prim, p0, p1, p2);
+  const unsigned flags = tri_flags(sc.tri_p, l.prim);
+  float b2 = 1.0f - b.x - b.y;
+  f3 p = (b.x * p0) + (b.y * p1) + (b2 * p2);
+  f3 normal = normalize(cross(p1 - p0, p2 - p0));
+  if (flags & 2u) {
+    const float* q = sc.tri_n + 9 * (size_t)l.prim;
+    f3 ns = b.x * mk3(q[0], q[1], q[2]) + b.y * mk3(q[3], q[4], q[5]) + b2 * mk3(q[6], q[7], q[8]);
+    normal = face_forward(normal, ns);
+  } else if (flags & 1u) normal = normal * -1.0f;
+  f3 p_abs_sum = abs3(b.x * p0) + abs3(b.y * p1) + abs3(b2 * p2);
+  s.p1.p = p; s.p1.p_error = gamma_n(6) * p_abs_sum; s.p1.wo = mk3(0, 0, 0); s.p1.n = normal;
+  float pdf = 1.0f / l.area;
+  f3 wi = p - ref.p;
+  if (len2(wi) == 0.0f) pdf = 0.0f;
+  else {
+    wi = normalize(wi);
+    pdf *= distance_squared(ref.p, p) / fabsf(dot(normal, -wi));
+    if (isinf(pdf)) pdf = 0.0f;
+  }
+  s.wi = normalize(p - ref.p);
+  s.pdf = pdf;
+  s.li = area_light_l(l, normal, -s.wi);
+  return s;
+}
+// Shape::pdf_wi (shapes/mod.rs:59-68): re-intersects the emitter triangle
+RT_DEV float area_light_pdf_li(const DScene& sc, const DLight& l, const Interaction& ref, f3 wi) {
+  Ray ray = spawn_ray(ref, wi);
+  f3 p0, p1, p2; load_tri(sc.tri_p, l.prim, p0, p1, p2);
+  TriHit h;
+  if (!tri_test(p0, p1, p2, ray, h)) return 0.0f;
+  f3 p, n; tri_hit_point_normal_inl(sc, l.prim, h, p, n);
+  return distance_squared(ref.p, p) / (fabsf(dot(n, -wi)) * l.area);
+}
 RT_DEVN LiSample light_sample_li(const DScene& sc, const DLight& l, const Interaction& ref, f2 u) {
   LiSample s;
   switch (l.kind) {
-    case 0: {  // DiffuseAreaLight::sample_li diffuse.rs:59-70 -> Shape::sample_si shapes/mod.rs:39-53 -> Triangle::sample mesh.rs:610-634
-      f2 b = uniform_sample_triangle(u);
-      f3 p0, p1, p2; load_tri(sc.tri_p, l.prim, p0, p1, p2);
-      const unsigned flags = tri_flags(sc.tri_p, l.prim);
-      float b2 = 1.0f - b.x - b.y;
-      f3 p = (b.x * p0) + (b.y * p1) + (b2 * p2);
-      f3 normal = normalize(cross(p1 - p0, p2 - p0));
-      if (flags & 2u) {
-        const float* q = sc.tri_n + 9 * (size_t)l.prim;
-        f3 ns = b.x * mk3(q[0], q[1], q[2]) + b.y * mk3(q[3], q[4], q[5]) + b2 * mk3(q[6], q[7], q[8]);
-        normal = face_forward(normal, ns);
-      } else if (flags & 1u) normal = normal * -1.0f;
-      f3 p_abs_sum = abs3(b.x * p0) + abs3(b.y * p1) + abs3(b2 * p2);
-      s.p1.p = p; s.p1.p_error = gamma_n(6) * p_abs_sum; s.p1.wo = mk3(0, 0, 0); s.p1.n = normal;
-      float pdf = 1.0f / l.area;
-      f3 wi = p - ref.p;
-      if (len2(wi) == 0.0f) pdf = 0.0f;
-      else {
-        wi = normalize(wi);
-        pdf *= distance_squared(ref.p, p) / fabsf(dot(normal, -wi));
-        if (isinf(pdf)) pdf = 0.0f;
-      }
-      s.wi = normalize(p - ref.p);
-      s.pdf = pdf;
-      s.li = area_light_l(l, normal, -s.wi);
-      return s;
-    }
+    case 0: return area_light_sample_li(sc, l, ref, u);
     case 1: {  // PointLight::sample_li point.rs:43-54 (I / (4 pi r^2), reference quirk)
       f3 pos = mk3(l.vec[0], l.vec[1], l.vec[2]);
       f3 wi = pos - ref.p;
@@ -392,14 +404,7 @@ RT_DEVN LiSample light_sample_li(const DScene& sc, const DLight& l, const Intera
 }
 // Light::pdf_li. Area lights: Shape::pdf_wi (shapes/mod.rs:59-68) re-intersects the emitter triangle.
 RT_DEVN float light_pdf_li(const DScene& sc, const DLight& l, const Interaction& ref, f3 wi) {
-  if (l.kind == 0) {
-    Ray ray = spawn_ray(ref, wi);
-    f3 p0, p1, p2; load_tri(sc.tri_p, l.prim, p0, p1, p2);
-    TriHit h;
-    if (!tri_test_call(p0, p1, p2, ray, h)) return 0.0f;
-    f3 p, n; tri_hit_point_normal(sc, l.prim, h, p, n);
-    return distance_squared(ref.p, p) / (fabsf(dot(n, -wi)) * l.area);
-  }
+  if (l.kind == 0) return area_light_pdf_li(sc, l, ref, wi);
   if (l.kind == 3) {  // infinite.rs:183-196
     f3 w = xf3x4(l.w2l, wi);
     float theta = spherical_theta(w), phi = spherical_phi(w);

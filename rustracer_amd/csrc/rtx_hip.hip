@@ -39,6 +39,7 @@ struct rt_scene {
   int device = 0;
   DScene d{};
   bool small = false;
+  bool lambert_only = false;  // every material is matte{constant Kd, sigma == 0}: k_shade<1>
   int stack_depth = 64;  // entries the to-visit stack needs for this tree (<= 64, rc/bvh/mod.rs:374)
   unsigned n_nodes = 0, n_tris = 0; int n_lights = 0;
   DevBuf nodes, tri_p, tri_n, tri_uv, tri_s, textures, images, materials, lights, texels, dist;
@@ -50,6 +51,8 @@ struct rt_scene {
   DevBuf ws[32];
   DevBuf film_acc, film_out, counters, stats, filter_table, scrambles, perms;
   int n_cu = 256;
+  std::vector<hipEvent_t> event_pool;
+  ~rt_scene() { for (hipEvent_t e : event_pool) (void)hipEventDestroy(e); }
 };
 
 extern "C" const char* rt_last_error(void) { return g_err.c_str(); }
@@ -215,6 +218,16 @@ extern "C" int rt_scene_create(const rt_scene_desc* desc, int device, rt_scene**
   d.wb_min = f3{desc->nodes[0].bmin[0], desc->nodes[0].bmin[1], desc->nodes[0].bmin[2]};
   d.wb_max = f3{desc->nodes[0].bmax[0], desc->nodes[0].bmax[1], desc->nodes[0].bmax[2]};
   d.ld_uniform = 1; d.nvox[0] = d.nvox[1] = d.nvox[2] = 1;
+  d.needs_differentials = 0;
+  for (uint32_t i = 0; i < desc->n_textures; ++i) if (desc->textures[i].kind == RT_TEX_IMAGE) d.needs_differentials = 1;
+  s->lambert_only = true;
+  for (uint32_t i = 0; i < desc->n_materials; ++i) {
+    const rt_material& m = desc->materials[i];
+    auto is_const = [&](int id) { return id >= 0 && (uint32_t)id < desc->n_textures && desc->textures[id].kind == RT_TEX_CONST; };
+    if (m.kind != RT_MAT_MATTE || !is_const(m.slot[RT_SLOT_KD]) || !is_const(m.slot[RT_SLOT_SIGMA])) { s->lambert_only = false; break; }
+    const float sg = desc->textures[m.slot[RT_SLOT_SIGMA]].value[0];
+    if (!(sg <= 0.0f)) { s->lambert_only = false; break; }  // clamp(sigma, 0, 1) == 0 (matte.rs:51)
+  }
   s->small = desc->n_nodes <= RT_SMALL_NODES && desc->n_tris <= RT_SMALL_TRIS;
   {  // tree height bounds the number of simultaneously pending stack entries
     std::vector<int> depth(desc->n_nodes, 0); int maxd = 0;
@@ -378,6 +391,15 @@ extern "C" int rt_trace_closest_device(rt_scene* s, const void* d_rays, uint64_t
 
 // ---------------------------------------------------------------------------------------------- sampler tables
 static unsigned next_pow2(unsigned v) { unsigned p = 1; while (p < v) p <<= 1; return p; }
+// lanes per K0 block: the per-lane permutation (2 B * (spp + 2)) of a block should fill ~32 KB of LDS
+static unsigned sampler_lanes_per_block(unsigned spp) {
+  unsigned l = (32u * 1024u) / ((spp + 2u) * 2u);
+  if (l >= 64u) return 64u;
+  if (l >= 32u) return 32u;
+  if (l >= 16u) return 16u;
+  if (l >= 8u) return 8u;
+  return 4u;
+}
 
 extern "C" int rt_sampler_tables(int32_t spp_, int32_t dims, uint64_t pixel0, uint64_t n_pixels, uint32_t* scrambles, uint16_t* perms) {
   if (!rt_device_available()) return fail(RT_ERR_NO_DEVICE, "no HIP device visible; this backend has no CPU fallback");
@@ -387,29 +409,41 @@ extern "C" int rt_sampler_tables(int32_t spp_, int32_t dims, uint64_t pixel0, ui
   DevBuf sc, pm;
   HIP_TRY(sc.ensure(n_pixels * 3 * dims * 4)); HIP_TRY(pm.ensure(n_pixels * 2 * dims * spp * 2));
   FrameParams fp{};
-  const size_t lds = 64 * (size_t)(spp + 2) * 2;
+  const unsigned lpb = sampler_lanes_per_block(spp);
+  const size_t lds = (size_t)lpb * (spp + 2) * 2;
   HIP_TRY(hipFuncSetAttribute((const void*)k_sampler_tables, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-  hipLaunchKernelGGL(k_sampler_tables, dim3((unsigned)((n_pixels + 63) / 64)), dim3(64), lds, nullptr, fp, (unsigned)n_pixels, spp, (unsigned)dims, (unsigned long long)pixel0, 1,
+  hipLaunchKernelGGL(k_sampler_tables, dim3((unsigned)((n_pixels + lpb - 1) / lpb)), dim3(lpb), lds, nullptr, fp, (unsigned)n_pixels, spp, (unsigned)dims, (unsigned long long)pixel0, 1,
                      sc.as<unsigned>(), pm.as<unsigned short>());
   HIP_TRY(hipGetLastError());
   HIP_TRY(hipDeviceSynchronize());
-  HIP_TRY(hipMemcpy(scrambles, sc.p, n_pixels * 3 * dims * 4, hipMemcpyDeviceToHost));
-  HIP_TRY(hipMemcpy(perms, pm.p, n_pixels * 2 * dims * spp * 2, hipMemcpyDeviceToHost));
+  // device layout is pixel-minor ([k][pixel], [table][sample][pixel]); the ABI returns pixel-major
+  std::vector<uint32_t> hs(n_pixels * 3 * dims); std::vector<uint16_t> hp(n_pixels * 2 * dims * spp);
+  HIP_TRY(hipMemcpy(hs.data(), sc.p, hs.size() * 4, hipMemcpyDeviceToHost));
+  HIP_TRY(hipMemcpy(hp.data(), pm.p, hp.size() * 2, hipMemcpyDeviceToHost));
+  for (uint64_t p = 0; p < n_pixels; ++p) {
+    for (uint64_t k = 0; k < 3ull * dims; ++k) scrambles[p * 3 * dims + k] = hs[k * n_pixels + p];
+    for (uint64_t t = 0; t < 2ull * dims; ++t)
+      for (uint64_t i = 0; i < spp; ++i) perms[(p * 2 * dims + t) * spp + i] = hp[(t * spp + i) * n_pixels + p];
+  }
   return RT_OK;
 }
 
 // ---------------------------------------------------------------------------------------------- render
-struct KTimer {
-  bool on; hipStream_t st; hipEvent_t a, b; double* acc;
-  std::vector<std::pair<hipEvent_t, hipEvent_t>> pending; std::vector<double*> dst;
-  void begin(double* where) { if (!on) return; hipEvent_t x, y; hipEventCreate(&x); hipEventCreate(&y); hipEventRecord(x, st); pending.push_back({x, y}); dst.push_back(where); }
-  void end() { if (!on) return; hipEventRecord(pending.back().second, st); }
+struct KTimer {  // HIP-event kernel timing on the render stream; events come from a per-scene pool
+  bool on; hipStream_t st; std::vector<hipEvent_t>* pool; size_t used = 0;
+  std::vector<double*> dst;
+  hipEvent_t get() {
+    if (used == pool->size()) { hipEvent_t e; (void)hipEventCreate(&e); pool->push_back(e); }
+    return (*pool)[used++];
+  }
+  void begin(double* where) { if (!on) return; (void)hipEventRecord(get(), st); dst.push_back(where); }
+  void end() { if (!on) return; (void)hipEventRecord(get(), st); }
   void collect() {
-    for (size_t i = 0; i < pending.size(); ++i) {
-      float ms = 0; hipEventSynchronize(pending[i].second); hipEventElapsedTime(&ms, pending[i].first, pending[i].second);
-      *dst[i] += ms; hipEventDestroy(pending[i].first); hipEventDestroy(pending[i].second);
+    for (size_t i = 0; i < dst.size(); ++i) {
+      float ms = 0; (void)hipEventSynchronize((*pool)[2 * i + 1]); (void)hipEventElapsedTime(&ms, (*pool)[2 * i], (*pool)[2 * i + 1]);
+      *dst[i] += ms;
     }
-    pending.clear(); dst.clear();
+    dst.clear(); used = 0;
   }
 };
 
@@ -448,7 +482,7 @@ extern "C" int rt_render(rt_scene* s, const rt_camera* cam, const rt_film_desc* 
   const unsigned long long owned_pixels = owned_rows * (unsigned long long)W;
 
   rt_stats stats{};
-  KTimer tm{(flags & RT_FLAG_TIME_KERNELS) != 0, stream};
+  KTimer tm{(flags & RT_FLAG_TIME_KERNELS) != 0, stream, &s->event_pool};
 
   // integrator.preprocess (renderer.rs:30)
   tm.begin(&stats.ms_lightdist);
@@ -492,7 +526,8 @@ extern "C" int rt_render(rt_scene* s, const rt_camera* cam, const rt_film_desc* 
   ps.q_shadow = s->ws[B_QSH].as<unsigned>(); ps.q_mis = s->ws[B_QMI].as<unsigned>();
   ps.counters = s->counters.as<unsigned>(); ps.stats = s->stats.as<unsigned long long>();
 
-  const size_t lds = 64 * (size_t)(spp + 2) * 2;
+  const unsigned lpb = sampler_lanes_per_block(spp);
+  const size_t lds = (size_t)lpb * (spp + 2) * 2;
   HIP_TRY(hipFuncSetAttribute((const void*)k_sampler_tables, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
   const bool count = (flags & RT_FLAG_COUNT_TRAVERSAL) != 0;
   const unsigned pgrid = (unsigned)s->n_cu * 8u;
@@ -505,7 +540,7 @@ extern "C" int rt_render(rt_scene* s, const rt_camera* cam, const rt_film_desc* 
     ps.q_in = q_a; ps.q_out = q_b;
     HIP_TRY(hipMemsetAsync(s->counters.p, 0, 64, stream));
     tm.begin(&stats.ms_sampler);
-    hipLaunchKernelGGL(k_sampler_tables, dim3((unsigned)((npx + 63) / 64)), dim3(64), lds, stream, fp, (unsigned)npx, spp, dims, 0ull, 0, s->scrambles.as<unsigned>(), s->perms.as<unsigned short>());
+    hipLaunchKernelGGL(k_sampler_tables, dim3((unsigned)((npx + lpb - 1) / lpb)), dim3(lpb), lds, stream, fp, (unsigned)npx, spp, dims, 0ull, 0, s->scrambles.as<unsigned>(), s->perms.as<unsigned short>());
     tm.end();
     tm.begin(&stats.ms_raygen);
     hipLaunchKernelGGL(k_raygen, dim3(pgrid), dim3(256), 0, stream, fp, ps);
@@ -515,7 +550,8 @@ extern "C" int rt_render(rt_scene* s, const rt_camera* cam, const rt_film_desc* 
       launch_trace<false>(s, count, ps.ray_o, ps.ray_d, ps.q_in, &ps.counters[0], 0, ps.hit, nullptr, dstats, ST_RAYS_CLOSEST, ST_NODES_CLOSEST, ST_TRIS_CLOSEST, stream);
       tm.end();
       tm.begin(&stats.ms_shade);
-      hipLaunchKernelGGL(k_shade, dim3(pgrid), dim3(256), 0, stream, s->d, fp, ps);
+      if (s->lambert_only) hipLaunchKernelGGL(k_shade<1>, dim3(pgrid), dim3(256), 0, stream, s->d, fp, ps);
+      else hipLaunchKernelGGL(k_shade<0>, dim3(pgrid), dim3(256), 0, stream, s->d, fp, ps);
       tm.end();
       tm.begin(&stats.ms_trace_any);
       launch_trace<true>(s, count, ps.sh_o, ps.sh_d, ps.q_shadow, &ps.counters[2], 0, nullptr, ps.sh_occ, dstats, ST_RAYS_SHADOW, ST_NODES_SHADOW, ST_TRIS_SHADOW, stream);

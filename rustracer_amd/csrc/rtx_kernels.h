@@ -4,12 +4,14 @@
 // Every kernel is launched with a fixed persistent grid and strides over a device-side queue
 // whose length is read from device memory, so a frame needs no host round trip.
 #pragma once
+#include <type_traits>
 #include "rtx_dev_shading.h"
 
 namespace rtx {
 
 
-// ---- per-pass path state in HBM (SoA, indexed by path id = chunk_pixel * spp + sample) --------
+// ---- per-pass path state in HBM (SoA, indexed by path id = sample * n_pixels + chunk_pixel, so that
+//      the 64 lanes of a wave hold the same sample of 64 neighbouring pixels and every access coalesces)
 struct PassState {
   unsigned cap;            // paths in this pass
   unsigned spp, spp_log2, dims;
@@ -62,6 +64,32 @@ RT_DEV unsigned wave_push(unsigned* counter, bool pred) {
   return base + (unsigned)__popcll(mask & ((1ull << lane) - 1ull));
 }
 
+// Block-aggregated append to up to three device queues: one returning atomic per queue per 256-lane
+// iteration instead of one per wave (a single counter word sustains only ~88 returning atomics/us).
+// Must be reached by every thread of the block. Returns the slot for each queue (valid where pred).
+template <int NQ>
+RT_DEV void block_push(unsigned* counters, const int* counter_idx, const bool* pred, unsigned* slot) {
+  __shared__ unsigned s_cnt[NQ][16];
+  __shared__ unsigned s_base[NQ];
+  const unsigned lane = __lane_id(), wave = threadIdx.x >> 6, n_waves = (blockDim.x + 63u) >> 6;
+  unsigned long long mask[NQ];
+#pragma unroll
+  for (int q = 0; q < NQ; ++q) {
+    mask[q] = __ballot(pred[q]);
+    if (lane == 0) s_cnt[q][wave] = (unsigned)__popcll(mask[q]);
+  }
+  __syncthreads();
+  if (threadIdx.x < NQ) {
+    unsigned total = 0;
+    for (unsigned w = 0; w < n_waves; ++w) { unsigned c = s_cnt[threadIdx.x][w]; s_cnt[threadIdx.x][w] = total; total += c; }
+    s_base[threadIdx.x] = total ? atomicAdd(&counters[counter_idx[threadIdx.x]], total) : 0u;
+  }
+  __syncthreads();
+#pragma unroll
+  for (int q = 0; q < NQ; ++q) slot[q] = s_base[q] + s_cnt[q][wave] + (unsigned)__popcll(mask[q] & ((1ull << lane) - 1ull));
+  __syncthreads();
+}
+
 // owned-pixel index -> raster pixel (x, y) and keyed pixel index inside the sample bounds
 RT_DEV void owned_pixel(const FrameParams& fp, unsigned long long k, int& x, int& y, unsigned long long& pixel_index) {
   const unsigned W = (unsigned)(fp.sb_x1 - fp.sb_x0);
@@ -76,66 +104,57 @@ RT_DEV void owned_pixel(const FrameParams& fp, unsigned long long k, int& x, int
 // ================================================================================ K0 sampler tables
 // ZeroTwoSequence::start_pixel (rc/sampler/zerotwosequence.rs:67-108) in keyed mode: one lane per
 // pixel runs the sequential PCG32-driven Fisher-Yates shuffles (rc/sampler/lowdiscrepancy.rs:4-50,
-// 114-124) on a permutation of sample indices kept in LDS ([lane][spp+2] u16); the (0,2) values
-// themselves are a closed form of (scramble, index) and are evaluated by the consumers.
-// Output: scrambles[pixel][3*dims] and perms[pixel][2*dims][spp] written coalesced per pixel.
-__global__ void __launch_bounds__(64) k_sampler_tables(FrameParams fp, unsigned n_pixels, unsigned spp, unsigned dims,
-                                                       unsigned long long explicit_pixel0, int use_explicit,
-                                                       unsigned* scrambles, unsigned short* perms) {
+// 114-124) on a permutation of sample indices kept in LDS ([lane][spp+2] u16, odd word stride =>
+// conflict-free for equal-index accesses); the (0,2) values themselves are a closed form of
+// (scramble, index) and are evaluated by the consumers (table_1d/table_2d below).
+// The loop is a chain of dependent LDS accesses, i.e. latency-bound and capped by LDS capacity
+// (2 B * spp per lane), so blocks are kept SMALL (blockDim = lanes whose tables fill ~32 KB): that
+// puts a wave on every SIMD of a CU instead of one 64-lane wave on one SIMD.
+// Output, pixel-minor so that a wave's accesses coalesce: scrambles[k][pixel], perms[table][sample][pixel].
+__global__ void k_sampler_tables(FrameParams fp, unsigned n_pixels, unsigned spp, unsigned dims,
+                                 unsigned long long explicit_pixel0, int use_explicit, unsigned* scrambles, unsigned short* perms) {
   extern __shared__ unsigned short lds_perm[];
   const unsigned lane = threadIdx.x;
   const unsigned stride = spp + 2;
   unsigned short* mine = lds_perm + (size_t)lane * stride;
-  const unsigned pix = blockIdx.x * 64u + lane;
-  const bool live = pix < n_pixels;
-  unsigned long long pixel_index = 0;
-  if (live) {
-    if (use_explicit) pixel_index = explicit_pixel0 + pix;
-    else { int x, y; owned_pixel(fp, fp.chunk_first + pix, x, y, pixel_index); }
-  }
+  const unsigned pix = blockIdx.x * blockDim.x + lane;
+  if (pix >= n_pixels) return;
+  unsigned long long pixel_index;
+  if (use_explicit) pixel_index = explicit_pixel0 + pix;
+  else { int x, y; owned_pixel(fp, fp.chunk_first + pix, x, y, pixel_index); }
   Pcg32 rng; rng.set_sequence(pixel_index);
-  const unsigned block_pix0 = blockIdx.x * 64u;
-  const unsigned block_n = min(64u, n_pixels - block_pix0);
   for (unsigned t = 0; t < 2u * dims; ++t) {
-    if (live) {
-      if (t < dims) scrambles[(size_t)pix * 3u * dims + t] = rng.next_u32();  // van_der_corput scramble (:10)
-      else {  // sobol_2d scramble pair (:31)
-        unsigned s0 = rng.next_u32(), s1 = rng.next_u32();
-        scrambles[(size_t)pix * 3u * dims + dims + 2u * (t - dims)] = s0;
-        scrambles[(size_t)pix * 3u * dims + dims + 2u * (t - dims) + 1u] = s1;
-      }
-      for (unsigned i = 0; i < spp; ++i) mine[i] = (unsigned short)i;
-      // per-pixel-sample shuffles of n_samples_per_pixel_sample = 1 element: only consume RNG (:14-21)
-      for (unsigned i = 0; i < spp; ++i) (void)rng.bounded(1u);
-      // shuffle(samples, n_pixel_samples, 1) (:22, :114-124)
-      for (unsigned i = 0; i < spp; ++i) {
-        unsigned other = i + rng.bounded(spp - i);
-        unsigned short a = mine[i], b = mine[other];
-        mine[i] = b; mine[other] = a;
-      }
+    if (t < dims) scrambles[(size_t)t * n_pixels + pix] = rng.next_u32();  // van_der_corput scramble (:10)
+    else {  // sobol_2d scramble pair (:31)
+      unsigned s0 = rng.next_u32(), s1 = rng.next_u32();
+      scrambles[(size_t)(dims + 2u * (t - dims)) * n_pixels + pix] = s0;
+      scrambles[(size_t)(dims + 2u * (t - dims) + 1u) * n_pixels + pix] = s1;
     }
-    __syncthreads();
-    // cooperative coalesced copy-out: all 64 lanes stream pixel p's permutation
-    for (unsigned p = 0; p < block_n; ++p) {
-      const unsigned short* src = lds_perm + (size_t)p * stride;
-      unsigned short* dst = perms + ((size_t)(block_pix0 + p) * 2u * dims + t) * spp;
-      for (unsigned i = lane; i < spp; i += 64u) dst[i] = src[i];
+    for (unsigned i = 0; i < spp; ++i) mine[i] = (unsigned short)i;
+    // per-pixel-sample shuffles of n_samples_per_pixel_sample = 1 element only consume RNG draws (:14-21)
+    for (unsigned i = 0; i < spp; ++i) (void)rng.bounded(1u);
+    // shuffle(samples, n_pixel_samples, 1) (:22, :114-124)
+    for (unsigned i = 0; i < spp; ++i) {
+      unsigned other = i + rng.bounded(spp - i);
+      unsigned short a = mine[i], b = mine[other];
+      mine[i] = b; mine[other] = a;
     }
-    __syncthreads();
+    unsigned short* dst = perms + (size_t)t * spp * n_pixels + pix;
+    for (unsigned i = 0; i < spp; ++i) dst[(size_t)i * n_pixels] = mine[i];
   }
 }
 
-// table look-ups used by raygen / shade: value of dimension d for sample s
-struct Tables { const unsigned* scrambles; const unsigned short* perms; unsigned spp, dims; };
-RT_DEV Tables tables_of(const PassState& ps) { Tables t; t.scrambles = ps.scrambles; t.perms = ps.perms; t.spp = ps.spp; t.dims = ps.dims; return t; }
+// table look-ups used by raygen / shade: value of dimension d for sample s of chunk pixel pix
+struct Tables { const unsigned* scrambles; const unsigned short* perms; unsigned spp, dims, n_pixels; };
+RT_DEV Tables tables_of(const PassState& ps) { Tables t; t.scrambles = ps.scrambles; t.perms = ps.perms; t.spp = ps.spp; t.dims = ps.dims; t.n_pixels = ps.n_pixels; return t; }
 RT_DEV float table_1d(const Tables& tb, unsigned pix, unsigned d, unsigned s) {
-  unsigned k = tb.perms[((size_t)pix * 2u * tb.dims + d) * tb.spp + s];
-  return u32_to_unit(tb.scrambles[(size_t)pix * 3u * tb.dims + d] ^ vdc_bits(k));
+  unsigned k = tb.perms[((size_t)d * tb.spp + s) * tb.n_pixels + pix];
+  return u32_to_unit(tb.scrambles[(size_t)d * tb.n_pixels + pix] ^ vdc_bits(k));
 }
 RT_DEV f2 table_2d(const Tables& tb, unsigned pix, unsigned d, unsigned s) {
-  unsigned k = tb.perms[((size_t)pix * 2u * tb.dims + tb.dims + d) * tb.spp + s];
-  const unsigned* sc = tb.scrambles + (size_t)pix * 3u * tb.dims + tb.dims + 2u * d;
-  return mk2(u32_to_unit(sc[0] ^ vdc_bits(k)), u32_to_unit(sc[1] ^ sobol1_bits(k)));
+  unsigned k = tb.perms[((size_t)(tb.dims + d) * tb.spp + s) * tb.n_pixels + pix];
+  unsigned s0 = tb.scrambles[(size_t)(tb.dims + 2u * d) * tb.n_pixels + pix], s1 = tb.scrambles[(size_t)(tb.dims + 2u * d + 1u) * tb.n_pixels + pix];
+  return mk2(u32_to_unit(s0 ^ vdc_bits(k)), u32_to_unit(s1 ^ sobol1_bits(k)));
 }
 
 // ================================================================================ K1 raygen
@@ -153,7 +172,7 @@ RT_DEV f3 xf_vector44(const float* m, f3 v) {
 struct CameraRay { f3 o, d, rx_o, ry_o, rx_d, ry_d; };
 // PerspectiveCamera::generate_ray_differential (camera.rs:150-202) + Ray::transform (ray.rs:46-71)
 // + scale_differentials (ray.rs:73-80)
-RT_DEVN CameraRay generate_camera_ray(const FrameParams& fp, f2 p_film, f2 p_lens, float diff_scale) {
+RT_DEV CameraRay generate_camera_ray(const FrameParams& fp, f2 p_film, f2 p_lens, float diff_scale) {
   CameraRay r;
   f3 p_camera = xf_point44(fp.r2c, mk3(p_film.x, p_film.y, 0.0f));
   f3 o = mk3(0, 0, 0), d = normalize(p_camera);
@@ -194,27 +213,32 @@ RT_DEVN CameraRay generate_camera_ray(const FrameParams& fp, f2 p_film, f2 p_len
 
 __global__ void __launch_bounds__(256) k_raygen(FrameParams fp, PassState ps) {
   const unsigned stride = gridDim.x * blockDim.x;
-  for (unsigned pid = blockIdx.x * blockDim.x + threadIdx.x; pid < ps.cap; pid += stride) {
-    const unsigned pix = pid >> ps.spp_log2, s = pid & (ps.spp - 1u);
-    int x, y; unsigned long long pixel_index;
-    owned_pixel(fp, fp.chunk_first + pix, x, y, pixel_index);
-    bool in_bounds = y < fp.sb_y1 && x >= fp.pb_x0 && x < fp.pb_x1 && y >= fp.pb_y0 && y < fp.pb_y1;  // renderer.rs:103
-    // get_camera_sample (zerotwosequence.rs:182-192): 2D#0 film, 1D#0 time, 2D#1 lens
-    const Tables tb = tables_of(ps);
-    f2 o = table_2d(tb, pix, 0, s);
-    f2 p_film = mk2((float)x + o.x, (float)y + o.y);
-    f2 p_lens = table_2d(tb, pix, 1, s);
-    ps.pfilm[pid] = make_float2(p_film.x, p_film.y);
-    CameraRay cr = generate_camera_ray(fp, p_film, p_lens, 1.0f / sqrtf((float)ps.spp));
-    ps.ray_o[pid] = make_float4(cr.o.x, cr.o.y, cr.o.z, kInf);
-    ps.ray_d[pid] = make_float4(cr.d.x, cr.d.y, cr.d.z, 0.0f);
-    ps.beta[pid] = make_float4(1.0f, 1.0f, 1.0f, 1.0f);
-    ps.lacc[pid] = make_float4(0.0f, 0.0f, 0.0f, __uint_as_float(pack_state(0, false, 1, 2)));
-    Pcg32 rng; rng.set_sequence(pixel_index * (unsigned long long)ps.spp + s + (1ull << 32));  // keyed per-sample stream
-    ps.rng[pid] = rng.state;
-    ps.pend_flags[pid] = in_bounds ? 0u : 0x80000000u;  // bit31: sample outside pixel_bounds, never traced
-    unsigned slot = wave_push(&ps.counters[0], in_bounds);
-    if (in_bounds) ps.q_in[slot] = pid;
+  const Tables tb = tables_of(ps);
+  for (unsigned base = blockIdx.x * blockDim.x; base < ps.cap; base += stride) {
+    const unsigned pid = base + threadIdx.x;
+    bool in_bounds = false;
+    if (pid < ps.cap) {
+      const unsigned s = pid / ps.n_pixels, pix = pid - s * ps.n_pixels;
+      int x, y; unsigned long long pixel_index;
+      owned_pixel(fp, fp.chunk_first + pix, x, y, pixel_index);
+      in_bounds = y < fp.sb_y1 && x >= fp.pb_x0 && x < fp.pb_x1 && y >= fp.pb_y0 && y < fp.pb_y1;  // renderer.rs:103
+      // get_camera_sample (zerotwosequence.rs:182-192): 2D#0 film, 1D#0 time, 2D#1 lens
+      f2 o = table_2d(tb, pix, 0, s);
+      f2 p_film = mk2((float)x + o.x, (float)y + o.y);
+      f2 p_lens = table_2d(tb, pix, 1, s);
+      ps.pfilm[pid] = make_float2(p_film.x, p_film.y);
+      CameraRay cr = generate_camera_ray(fp, p_film, p_lens, 1.0f / sqrtf((float)ps.spp));
+      ps.ray_o[pid] = make_float4(cr.o.x, cr.o.y, cr.o.z, kInf);
+      ps.ray_d[pid] = make_float4(cr.d.x, cr.d.y, cr.d.z, 0.0f);
+      ps.beta[pid] = make_float4(1.0f, 1.0f, 1.0f, 1.0f);
+      ps.lacc[pid] = make_float4(0.0f, 0.0f, 0.0f, __uint_as_float(pack_state(0, false, 1, 2)));
+      Pcg32 rng; rng.set_sequence(pixel_index * (unsigned long long)ps.spp + s + (1ull << 32));  // keyed per-sample stream
+      ps.rng[pid] = rng.state;
+      ps.pend_flags[pid] = in_bounds ? 0u : 0x80000000u;  // bit31: sample outside pixel_bounds, never traced
+    }
+    const int ci[1] = {0}; const bool pr[1] = {in_bounds}; unsigned slot[1];
+    block_push<1>(ps.counters, ci, pr, slot);
+    if (in_bounds) ps.q_in[slot[0]] = pid;
   }
 }
 
@@ -287,7 +311,68 @@ struct PathSampler {  // ZeroTwoSequence::get_1d / get_2d (zerotwosequence.rs:15
   }
 };
 
-__global__ void __launch_bounds__(256) k_shade(DScene sc, FrameParams fp, PassState ps) {
+// ---- Bsdf front-ends. GenericBsdf is the tagged-lobe aggregate of rtx_dev_bsdf.h. SingleLambert is the
+// same arithmetic specialised for the Bsdf a constant-texture matte material builds (one
+// LambertianReflection lobe, or none when Kd is black): with one matching lobe the component choice,
+// the u remap (u*1-0), the pdf average (/1) and the lobe sums (0+x) of Bsdf::{f,pdf,sample_f} are
+// identities, so both front-ends return bit-identical values; the specialised one needs no lobe
+// array in scratch and a fraction of the registers.
+struct GenericBsdf {
+  Bsdf b;
+  RT_DEV void build(const DScene& sc, int mat, const SurfaceInteraction& si) { build_bsdf(sc, mat, si, b); }
+  RT_DEV int num_nonspecular() const { return bsdf_num_components(b, BSDF_ALL & ~BSDF_SPECULAR); }
+  RT_DEV rgb3 f(f3 wo, f3 wi, unsigned flags) const { return bsdf_f(b, wo, wi, flags); }
+  RT_DEV float pdf(f3 wo, f3 wi, unsigned flags) const { return bsdf_pdf(b, wo, wi, flags); }
+  RT_DEV LobeSample sample_f(f3 wo, f2 u, unsigned flags) const { return bsdf_sample_f(b, wo, u, flags); }
+  RT_DEV float eta() const { return b.eta; }
+};
+struct SingleLambert {
+  rgb3 r; bool has; f3 ns, ng, ss, ts;
+  RT_DEV void build(const DScene& sc, int mat, const SurfaceInteraction& si) {  // matte.rs:37-62 with constant Kd, sigma == 0
+    const DTexture& t = sc.textures[sc.materials[mat].slot[0]];
+    r = clamp_pos(mkc(t.v[0], t.v[1], t.v[2]));
+    has = !is_black(r);
+    ss = normalize(si.sh_dpdu); ns = si.sh_n; ng = si.hit.n; ts = cross(si.sh_n, ss);  // Bsdf::new, bsdf/mod.rs:77-91
+  }
+  RT_DEV f3 to_local(f3 v) const { return mk3(dot(v, ss), dot(v, ts), dot(v, ns)); }
+  RT_DEV int num_nonspecular() const { return has ? 1 : 0; }
+  RT_DEV rgb3 f(f3 wo_w, f3 wi_w, unsigned) const {
+    f3 wo = to_local(wo_w);
+    if (!has || wo.z == 0.0f) return mkc(0, 0, 0);
+    bool refl = dot(wi_w, ng) * dot(wo_w, ng) > 0.0f;
+    return refl ? r * kInvPi : mkc(0, 0, 0);
+  }
+  RT_DEV float pdf(f3 wo_w, f3 wi_w, unsigned) const {
+    if (!has) return 0.0f;
+    f3 wo = to_local(wo_w);
+    if (wo.z == 0.0f) return 0.0f;
+    f3 wi = to_local(wi_w);
+    return default_pdf(wo, wi);
+  }
+  RT_DEV LobeSample sample_f(f3 wo_w, f2 u, unsigned) const {
+    if (!has) return mk_ls(mkc(0, 0, 0), mk3(0, 0, 0), 0.0f, 0u);
+    f2 ur = mk2(fminf(u.x * 1.0f - 0.0f, kOneMinusEpsilon), u.y);
+    f3 wo = to_local(wo_w);
+    if (wo.z == 0.0f) return mk_ls(mkc(0, 0, 0), mk3(0, 0, 0), 0.0f, BSDF_DIFFUSE | BSDF_REFLECTION);
+    f3 wi = cosine_sample_hemisphere(ur);
+    if (wo.z < 0.0f) wi.z *= -1.0f;
+    float pdf = default_pdf(wo, wi);
+    if (pdf == 0.0f) return mk_ls(mkc(0, 0, 0), mk3(0, 0, 0), 0.0f, 0u);
+    f3 wi_w = mk3(ss.x * wi.x + ts.x * wi.y + ns.x * wi.z, ss.y * wi.x + ts.y * wi.y + ns.y * wi.z, ss.z * wi.x + ts.z * wi.y + ns.z * wi.z);
+    bool refl = dot(wi_w, ng) * dot(wo_w, ng) > 0.0f;
+    return mk_ls(refl ? r * kInvPi : mkc(0, 0, 0), wi_w, pdf, 0u);
+  }
+  RT_DEV float eta() const { return 1.0f; }
+};
+
+// MODE 0: any material / texture. MODE 1: every material is matte with constant Kd and sigma == 0
+// (decided by the host from the material table), which also means no texture ever reads the
+// camera-ray differentials.
+#ifndef RT_SHADE_MIN_WAVES
+#define RT_SHADE_MIN_WAVES 2
+#endif
+template <int MODE>
+__global__ void __launch_bounds__(256, RT_SHADE_MIN_WAVES) k_shade(DScene sc, FrameParams fp, PassState ps) {
   const unsigned count = ps.counters[0];
   const unsigned stride = gridDim.x * blockDim.x;
   for (unsigned base = blockIdx.x * blockDim.x; base < count; base += stride) {
@@ -297,7 +382,7 @@ __global__ void __launch_bounds__(256) k_shade(DScene sc, FrameParams fp, PassSt
     unsigned pid = 0;
     if (lane_live) {
       pid = ps.q_in[i];
-      const unsigned pix = pid >> ps.spp_log2, s = pid & (ps.spp - 1u);
+      const unsigned s = pid / ps.n_pixels, pix = pid - s * ps.n_pixels;
       float4 o4 = ps.ray_o[pid], d4 = ps.ray_d[pid], h4 = ps.hit[pid], b4 = ps.beta[pid], l4 = ps.lacc[pid];
       f3 ray_o = mk3(o4.x, o4.y, o4.z), ray_d = mk3(d4.x, d4.y, d4.z);
       rgb3 beta = mkc(b4.x, b4.y, b4.z), L = mkc(l4.x, l4.y, l4.z);
@@ -316,8 +401,8 @@ __global__ void __launch_bounds__(256) k_shade(DScene sc, FrameParams fp, PassSt
       if (found) {
         f3 p0, p1, p2; load_tri(sc.tri_p, prim, p0, p1, p2);
         Ray r; r.o = ray_o; r.d = ray_d; r.t_max = kInf;
-        (void)tri_test_call(p0, p1, p2, r, th);
-        tri_fill_interaction(sc, prim, ray_d, th, si);
+        if (MODE == 1) { (void)tri_test(p0, p1, p2, r, th); tri_fill_interaction_inl(sc, prim, ray_d, th, si); }
+        else { (void)tri_test_call(p0, p1, p2, r, th); tri_fill_interaction(sc, prim, ray_d, th, si); }
       }
       // path.rs:127-136 emitted light at the vertex / from the environment
       if (bounces == 0 || specular_bounce) {
@@ -329,20 +414,20 @@ __global__ void __launch_bounds__(256) k_shade(DScene sc, FrameParams fp, PassSt
         }
       }
       if (found && bounces < fp.max_depth) {  // path.rs:139
-        if (bounces == 0) {  // only the camera ray carries differentials (interaction.rs:245-314)
+        if (MODE == 0 && bounces == 0 && sc.needs_differentials) {  // only the camera ray carries differentials (interaction.rs:245-314)
           f2 pf; { float2 t = ps.pfilm[pid]; pf = mk2(t.x, t.y); }
           f2 pl = table_2d(smp.tb, pix, 1, s);
           CameraRay cr = generate_camera_ray(fp, pf, pl, 1.0f / sqrtf((float)ps.spp));
           compute_differential(si, cr.rx_o, cr.ry_o, cr.rx_d, cr.ry_d);
         }
-        Bsdf bsdf;
-        build_bsdf(sc, tri_material(sc.tri_p, prim), si, bsdf);
+        typename std::conditional<MODE == 1, SingleLambert, GenericBsdf>::type bsdf;
+        bsdf.build(sc, tri_material(sc.tri_p, prim), si);
         // light_distribution.lookup(p) (path.rs:154-158)
         const float* ld_func; const float* ld_cdf; float ld_int;
         if (sc.ld_uniform) { ld_func = sc.ld_func; ld_cdf = sc.ld_cdf; ld_int = sc.ld_int[0]; }
         else { long v = voxel_of(sc, si.hit.p); ld_func = sc.ld_func + v * sc.n_lights; ld_cdf = sc.ld_cdf + v * (sc.n_lights + 1); ld_int = sc.ld_int[v]; }
         const unsigned nonspec = BSDF_ALL & ~BSDF_SPECULAR;
-        if (bsdf_num_components(bsdf, nonspec) > 0 && sc.n_lights > 0) {  // uniform_sample_one_light, integrator/mod.rs:186-220
+        if (bsdf.num_nonspecular() > 0 && sc.n_lights > 0) {  // uniform_sample_one_light, integrator/mod.rs:186-220
           float su = smp.get_1d();
           int light_num; float light_pdf;
           d1_sample_discrete(ld_func, ld_cdf, ld_int, sc.n_lights, su, light_num, light_pdf);
@@ -352,10 +437,10 @@ __global__ void __launch_bounds__(256) k_shade(DScene sc, FrameParams fp, PassSt
             const DLight& light = sc.lights[light_num];
             // ---- estimate_direct (integrator/mod.rs:222-318), light-sampling half
             rgb3 ld1 = mkc(0, 0, 0);
-            LiSample ls = light_sample_li(sc, light, si.hit, u_light);
+            LiSample ls = (MODE == 1 && light.kind == 0) ? area_light_sample_li(sc, light, si.hit, u_light) : light_sample_li(sc, light, si.hit, u_light);
             if (ls.pdf > 0.0f && !is_black(ls.li)) {
-              rgb3 f = bsdf_f(bsdf, si.hit.wo, ls.wi, nonspec) * fabsf(dot(ls.wi, si.sh_n));
-              float scattering_pdf = bsdf_pdf(bsdf, si.hit.wo, ls.wi, nonspec);
+              rgb3 f = bsdf.f(si.hit.wo, ls.wi, nonspec) * fabsf(dot(ls.wi, si.sh_n));
+              float scattering_pdf = bsdf.pdf(si.hit.wo, ls.wi, nonspec);
               if (!is_black(f)) {
                 Ray sr = spawn_ray_to_interaction(si.hit, ls.p1);  // VisibilityTester, light/mod.rs:52-55
                 ps.sh_o[pid] = make_float4(sr.o.x, sr.o.y, sr.o.z, sr.t_max);
@@ -368,12 +453,12 @@ __global__ void __launch_bounds__(256) k_shade(DScene sc, FrameParams fp, PassSt
             ps.pend_a[pid] = make_float4(ld1.r, ld1.g, ld1.b, light_pdf);
             // ---- BSDF-sampling half
             if (!light_is_delta(light)) {
-              LobeSample bs = bsdf_sample_f(bsdf, si.hit.wo, u_scattering, nonspec);
+              LobeSample bs = bsdf.sample_f(si.hit.wo, u_scattering, nonspec);
               rgb3 f = bs.f * fabsf(dot(bs.wi, si.sh_n));
               if (!is_black(f) && bs.pdf > 0.0f) {
                 float weight = 1.0f; bool go = true;
                 if (!(bs.type & BSDF_SPECULAR)) {
-                  float lp = light_pdf_li(sc, light, si.hit, bs.wi);
+                  float lp = (MODE == 1 && light.kind == 0) ? area_light_pdf_li(sc, light, si.hit, bs.wi) : light_pdf_li(sc, light, si.hit, bs.wi);
                   if (lp == 0.0f) go = false;  // `return ld`
                   else weight = power_heuristic1(bs.pdf, lp);
                 }
@@ -393,12 +478,12 @@ __global__ void __launch_bounds__(256) k_shade(DScene sc, FrameParams fp, PassSt
         }
         // ---- sample the BSDF for the next direction (path.rs:172-196)
         f3 wo = -ray_d;  // not normalised (reference quirk)
-        LobeSample bs = bsdf_sample_f(bsdf, wo, smp.get_2d(), BSDF_ALL);
+        LobeSample bs = bsdf.sample_f(wo, smp.get_2d(), BSDF_ALL);
         if (!(is_black(bs.f) || bs.pdf <= 0.0f)) {
           beta = beta * bs.f * fabsf(dot(bs.wi, si.sh_n)) / bs.pdf;
           specular_bounce = (bs.type & BSDF_SPECULAR) != 0u;
           if ((bs.type & BSDF_SPECULAR) && (bs.type & BSDF_TRANSMISSION)) {
-            float eta = bsdf.eta;
+            float eta = bsdf.eta();
             eta_scale *= dot(wo, si.hit.n) > 0.0f ? eta * eta : 1.0f / (eta * eta);
           }
           Ray nr = spawn_ray(si.hit, bs.wi);
@@ -421,12 +506,11 @@ __global__ void __launch_bounds__(256) k_shade(DScene sc, FrameParams fp, PassSt
       ps.rng[pid] = smp.rng.state;
       ps.pend_flags[pid] = pend;
     }
-    unsigned s0 = wave_push(&ps.counters[1], cont);
-    if (cont) ps.q_out[s0] = pid;
-    unsigned s1 = wave_push(&ps.counters[2], want_shadow);
-    if (want_shadow) ps.q_shadow[s1] = pid;
-    unsigned s2 = wave_push(&ps.counters[3], want_mis);
-    if (want_mis) ps.q_mis[s2] = pid;
+    const int ci[3] = {1, 2, 3}; const bool pr[3] = {cont, want_shadow, want_mis}; unsigned slot[3];
+    block_push<3>(ps.counters, ci, pr, slot);
+    if (cont) ps.q_out[slot[0]] = pid;
+    if (want_shadow) ps.q_shadow[slot[1]] = pid;
+    if (want_mis) ps.q_mis[slot[2]] = pid;
   }
 }
 
@@ -489,7 +573,7 @@ __global__ void __launch_bounds__(256) k_film_accumulate(FrameParams fp, PassSta
     rgb3 own = mkc(0, 0, 0); float own_w = 0.0f; bool own_any = false;
     unsigned scrubbed = 0;
     for (unsigned s = 0; s < ps.spp; ++s) {
-      const unsigned pid = (pix << ps.spp_log2) | s;
+      const unsigned pid = s * ps.n_pixels + pix;
       if (ps.pend_flags[pid] & 0x80000000u) continue;
       float4 l4 = ps.lacc[pid];
       rgb3 c = mkc(l4.x, l4.y, l4.z);
