@@ -238,6 +238,9 @@ struct GlobalSrc {
   RT_DEV void tri(int i, f3& p0, f3& p1, f3& p2) const { load_tri(tri_p, i, p0, p1, p2); }
 };
 
+// "while-while" form: every lane first descends (slab tests, pushes) until it holds a leaf, then the
+// wave tests leaf triangles together. The per-ray sequence of node visits and triangle tests is exactly
+// the reference's single loop (so counts and tie-breaking are unchanged); only the SIMD interleaving differs.
 template <bool ANY, bool COUNT, class Src>
 RT_DEV bool traverse(const Src& src, Ray ray, int* stack, int stack_stride, int& prim_out, TriHit& hit_out, unsigned& n_nodes, unsigned& n_tris) {
   bool found = false;
@@ -245,36 +248,39 @@ RT_DEV bool traverse(const Src& src, Ray ray, int* stack, int stack_stride, int&
   f3 inv_dir = mk3(1.0f / ray.d.x, 1.0f / ray.d.y, 1.0f / ray.d.z);
   const int neg_x = inv_dir.x < 0.0f, neg_y = inv_dir.y < 0.0f, neg_z = inv_dir.z < 0.0f;
   for (;;) {
-    float4 n0, n1;
-    src.node(cur, n0, n1);
-    if (COUNT) n_nodes += 1;
-    if (slab_test(n0, n1, ray, inv_dir, neg_x, neg_y, neg_z)) {
-      const unsigned packed = __float_as_uint(n1.w);
-      const int n_prims = (int)(packed & 0xffffu);
-      const int offset = __float_as_int(n1.z);
-      if (n_prims > 0) {
-        for (int i = 0; i < n_prims; ++i) {
-          f3 p0, p1, p2;
-          src.tri(offset + i, p0, p1, p2);
-          if (COUNT) n_tris += 1;
-          TriHit h;
-          if (tri_test(p0, p1, p2, ray, h)) {
-            if (ANY) return true;
-            ray.t_max = h.t; found = true; prim_out = offset + i; hit_out = h;  // `.or(result)`: later accepted hits replace
-          }
-        }
-        if (sp == 0) break;
-        cur = stack[(--sp) * stack_stride];
-      } else {
+    int leaf_off = 0, leaf_n = 0;
+    bool done = false;
+    for (;;) {  // descend to the next leaf whose box the ray enters
+      float4 n0, n1;
+      src.node(cur, n0, n1);
+      if (COUNT) n_nodes += 1;
+      if (slab_test(n0, n1, ray, inv_dir, neg_x, neg_y, neg_z)) {
+        const unsigned packed = __float_as_uint(n1.w);
+        const int n_prims = (int)(packed & 0xffffu);
+        const int offset = __float_as_int(n1.z);
+        if (n_prims > 0) { leaf_off = offset; leaf_n = n_prims; break; }
         const int axis = (int)((packed >> 16) & 0xffu);
         const int neg = axis == 0 ? neg_x : (axis == 1 ? neg_y : neg_z);
         if (neg) { stack[(sp++) * stack_stride] = cur + 1; cur = offset; }
         else { stack[(sp++) * stack_stride] = offset; cur = cur + 1; }
+      } else {
+        if (sp == 0) { done = true; break; }
+        cur = stack[(--sp) * stack_stride];
       }
-    } else {
-      if (sp == 0) break;
-      cur = stack[(--sp) * stack_stride];
     }
+    if (done) break;
+    for (int i = 0; i < leaf_n; ++i) {
+      f3 p0, p1, p2;
+      src.tri(leaf_off + i, p0, p1, p2);
+      if (COUNT) n_tris += 1;
+      TriHit h;
+      if (tri_test(p0, p1, p2, ray, h)) {
+        if (ANY) return true;
+        ray.t_max = h.t; found = true; prim_out = leaf_off + i; hit_out = h;  // `.or(result)`: later accepted hits replace
+      }
+    }
+    if (sp == 0) break;
+    cur = stack[(--sp) * stack_stride];
   }
   return found;
 }

@@ -39,7 +39,7 @@ struct rt_scene {
   int device = 0;
   DScene d{};
   bool small = false;
-  bool lambert_only = false;  // every material is matte{constant Kd, sigma == 0}: k_shade<1>
+  bool lambert_only = false;  // every material is matte{constant Kd, sigma == 0} and every light an area light: k_shade<1>
   int stack_depth = 64;  // entries the to-visit stack needs for this tree (<= 64, rc/bvh/mod.rs:374)
   unsigned n_nodes = 0, n_tris = 0; int n_lights = 0;
   DevBuf nodes, tri_p, tri_n, tri_uv, tri_s, textures, images, materials, lights, texels, dist;
@@ -228,6 +228,7 @@ extern "C" int rt_scene_create(const rt_scene_desc* desc, int device, rt_scene**
     const float sg = desc->textures[m.slot[RT_SLOT_SIGMA]].value[0];
     if (!(sg <= 0.0f)) { s->lambert_only = false; break; }  // clamp(sigma, 0, 1) == 0 (matte.rs:51)
   }
+  for (uint32_t i = 0; i < desc->n_lights; ++i) if (desc->lights[i].kind != RT_LIGHT_DIFFUSE_AREA) s->lambert_only = false;
   s->small = desc->n_nodes <= RT_SMALL_NODES && desc->n_tris <= RT_SMALL_TRIS;
   {  // tree height bounds the number of simultaneously pending stack entries
     std::vector<int> depth(desc->n_nodes, 0); int maxd = 0;
@@ -311,18 +312,18 @@ extern "C" int rt_light_distribution(rt_scene* s, int32_t n_voxels[3], float* fu
 
 // ---------------------------------------------------------------------------------------------- trace launches
 template <bool ANY, bool COUNT, bool SMALL, int BLOCK, int DEPTH>
-static void launch_trace_v(rt_scene* s, const float4* ro, const float4* rd, const unsigned* queue, const unsigned* count_ptr, unsigned count_static,
+static void launch_trace_v(rt_scene* s, const float4* ro, const float4* rd, const unsigned* queue, const unsigned* count_ptr, unsigned shard_cap, unsigned count_static,
                            float4* hits, unsigned* occ, unsigned long long* stats, int st_rays, int st_nodes, int st_tris, hipStream_t stream) {
   // persistent grid: enough workgroups to fill every CU at the kernel's LDS-limited residency
   const unsigned lds = (unsigned)(DEPTH * BLOCK * 4 + (SMALL ? (2 * RT_SMALL_NODES + 3 * RT_SMALL_TRIS) * 16 : 32));
   unsigned per_cu = (160u * 1024u) / lds; if (per_cu * BLOCK > 2048u) per_cu = 2048u / BLOCK; if (per_cu < 1) per_cu = 1;
   hipLaunchKernelGGL((k_trace<ANY, COUNT, SMALL, BLOCK, DEPTH>), dim3((unsigned)s->n_cu * per_cu), dim3(BLOCK), 0, stream, s->d, ro, rd, queue, count_ptr,
-                     count_static, hits, occ, stats, st_rays, st_nodes, st_tris);
+                     shard_cap, count_static, hits, occ, stats, st_rays, st_nodes, st_tris);
 }
 template <bool ANY, bool COUNT>
-static void launch_trace_c(rt_scene* s, const float4* ro, const float4* rd, const unsigned* queue, const unsigned* count_ptr, unsigned count_static,
+static void launch_trace_c(rt_scene* s, const float4* ro, const float4* rd, const unsigned* queue, const unsigned* count_ptr, unsigned shard_cap, unsigned count_static,
                            float4* hits, unsigned* occ, unsigned long long* stats, int st_rays, int st_nodes, int st_tris, hipStream_t stream) {
-#define RT_ARGS s, ro, rd, queue, count_ptr, count_static, hits, occ, stats, st_rays, st_nodes, st_tris, stream
+#define RT_ARGS s, ro, rd, queue, count_ptr, shard_cap, count_static, hits, occ, stats, st_rays, st_nodes, st_tris, stream
   if (s->small) {
     if (s->stack_depth <= 16) launch_trace_v<ANY, COUNT, true, 256, 16>(RT_ARGS);
     else if (s->stack_depth <= 32) launch_trace_v<ANY, COUNT, true, 256, 32>(RT_ARGS);
@@ -334,10 +335,10 @@ static void launch_trace_c(rt_scene* s, const float4* ro, const float4* rd, cons
 #undef RT_ARGS
 }
 template <bool ANY>
-static void launch_trace(rt_scene* s, bool count, const float4* ro, const float4* rd, const unsigned* queue, const unsigned* count_ptr, unsigned count_static,
+static void launch_trace(rt_scene* s, bool count, const float4* ro, const float4* rd, const unsigned* queue, const unsigned* count_ptr, unsigned shard_cap, unsigned count_static,
                          float4* hits, unsigned* occ, unsigned long long* stats, int st_rays, int st_nodes, int st_tris, hipStream_t stream) {
-  if (count) launch_trace_c<ANY, true>(s, ro, rd, queue, count_ptr, count_static, hits, occ, stats, st_rays, st_nodes, st_tris, stream);
-  else launch_trace_c<ANY, false>(s, ro, rd, queue, count_ptr, count_static, hits, occ, stats, st_rays, st_nodes, st_tris, stream);
+  if (count) launch_trace_c<ANY, true>(s, ro, rd, queue, count_ptr, shard_cap, count_static, hits, occ, stats, st_rays, st_nodes, st_tris, stream);
+  else launch_trace_c<ANY, false>(s, ro, rd, queue, count_ptr, shard_cap, count_static, hits, occ, stats, st_rays, st_nodes, st_tris, stream);
 }
 
 static int trace_batch(rt_scene* s, const float* rays, uint64_t n, bool any, float* hits, uint32_t* occluded, uint64_t counters[2]) {
@@ -354,8 +355,8 @@ static int trace_batch(rt_scene* s, const float* rays, uint64_t n, bool any, flo
   HIP_TRY(hipMemcpy(ro.p, o.data(), n * 16, hipMemcpyHostToDevice));
   HIP_TRY(hipMemcpy(rd.p, d.data(), n * 16, hipMemcpyHostToDevice));
   HIP_TRY(hipMemset(st.p, 0, ST_COUNT * 8));
-  if (any) launch_trace<true>(s, true, ro.as<float4>(), rd.as<float4>(), nullptr, nullptr, (unsigned)n, nullptr, out.as<unsigned>(), st.as<unsigned long long>(), ST_RAYS_SHADOW, ST_NODES_SHADOW, ST_TRIS_SHADOW, nullptr);
-  else launch_trace<false>(s, true, ro.as<float4>(), rd.as<float4>(), nullptr, nullptr, (unsigned)n, out.as<float4>(), nullptr, st.as<unsigned long long>(), ST_RAYS_CLOSEST, ST_NODES_CLOSEST, ST_TRIS_CLOSEST, nullptr);
+  if (any) launch_trace<true>(s, true, ro.as<float4>(), rd.as<float4>(), nullptr, nullptr, 0, (unsigned)n, nullptr, out.as<unsigned>(), st.as<unsigned long long>(), ST_RAYS_SHADOW, ST_NODES_SHADOW, ST_TRIS_SHADOW, nullptr);
+  else launch_trace<false>(s, true, ro.as<float4>(), rd.as<float4>(), nullptr, nullptr, 0, (unsigned)n, out.as<float4>(), nullptr, st.as<unsigned long long>(), ST_RAYS_CLOSEST, ST_NODES_CLOSEST, ST_TRIS_CLOSEST, nullptr);
   HIP_TRY(hipGetLastError());
   HIP_TRY(hipDeviceSynchronize());
   if (any) HIP_TRY(hipMemcpy(occluded, out.p, n * 4, hipMemcpyDeviceToHost));
@@ -380,7 +381,7 @@ extern "C" int rt_trace_closest_device(rt_scene* s, const void* d_rays, uint64_t
   hipEvent_t e0, e1; HIP_TRY(hipEventCreate(&e0)); HIP_TRY(hipEventCreate(&e1));
   HIP_TRY(hipEventRecord(e0, stream));
   for (int i = 0; i < reps; ++i)
-    launch_trace<false>(s, false, ro, rd, nullptr, nullptr, (unsigned)n, (float4*)d_hits, nullptr, nullptr, 0, 0, 0, stream);
+    launch_trace<false>(s, false, ro, rd, nullptr, nullptr, 0, (unsigned)n, (float4*)d_hits, nullptr, nullptr, 0, 0, 0, stream);
   HIP_TRY(hipEventRecord(e1, stream));
   HIP_TRY(hipEventSynchronize(e1));
   float ms = 0; HIP_TRY(hipEventElapsedTime(&ms, e0, e1));
@@ -500,9 +501,14 @@ extern "C" int rt_render(rt_scene* s, const rt_camera* cam, const rt_film_desc* 
   // workspace
   enum { B_RAYO, B_RAYD, B_HIT, B_BETA, B_LACC, B_RNG, B_PFILM, B_SHO, B_SHD, B_SHOCC, B_MIO, B_MID, B_MIHIT, B_PA, B_PB, B_PC, B_PF, B_QIN, B_QOUT, B_QSH, B_QMI };
   const size_t sz16 = cap * 16, sz8 = cap * 8, sz4 = cap * 4;
-  const size_t sizes[] = {sz16, sz16, sz16, sz16, sz16, sz8, sz8, sz16, sz16, sz4, sz16, sz16, sz16, sz16, sz16, sz16, sz4, sz4, sz4, sz4, sz4};
+  // a shard receives the appends of the blocks with blockIdx % RT_QSHARDS == shard; a grid-stride loop hands
+  // each block at most ceil(n / (grid * 256)) iterations, so cap / RT_QSHARDS plus one iteration per block bounds it
+  const unsigned pgrid_q = (unsigned)s->n_cu * 8u;
+  const unsigned shard_cap = (unsigned)(cap / RT_QSHARDS) + 256u * (pgrid_q / RT_QSHARDS + 1u) + 256u;
+  const size_t szq = (size_t)shard_cap * RT_QSHARDS * 4;
+  const size_t sizes[] = {sz16, sz16, sz16, sz16, sz16, sz8, sz8, sz16, sz16, sz4, sz16, sz16, sz16, sz16, sz16, sz16, sz4, szq, szq, szq, szq};
   for (int i = 0; i < 21; ++i) HIP_TRY(s->ws[i].ensure(sizes[i]));
-  HIP_TRY(s->counters.ensure(64)); HIP_TRY(s->stats.ensure(ST_COUNT * 8));
+  HIP_TRY(s->counters.ensure(4 * RT_QSHARDS * 4)); HIP_TRY(s->stats.ensure(ST_COUNT * 8));
   HIP_TRY(s->film_acc.ensure((size_t)cw * ch * 16));
   HIP_TRY(s->filter_table.ensure(1024));
   HIP_TRY(s->scrambles.ensure(chunk_pixels * 3 * dims * 4)); HIP_TRY(s->perms.ensure(chunk_pixels * 2 * dims * spp * 2));
@@ -524,7 +530,7 @@ extern "C" int rt_render(rt_scene* s, const rt_camera* cam, const rt_film_desc* 
   ps.pend_a = s->ws[B_PA].as<float4>(); ps.pend_b = s->ws[B_PB].as<float4>(); ps.pend_c = s->ws[B_PC].as<float4>(); ps.pend_flags = s->ws[B_PF].as<unsigned>();
   unsigned* q_a = s->ws[B_QIN].as<unsigned>(); unsigned* q_b = s->ws[B_QOUT].as<unsigned>();
   ps.q_shadow = s->ws[B_QSH].as<unsigned>(); ps.q_mis = s->ws[B_QMI].as<unsigned>();
-  ps.counters = s->counters.as<unsigned>(); ps.stats = s->stats.as<unsigned long long>();
+  ps.counters = s->counters.as<unsigned>(); ps.shard_cap = shard_cap; ps.stats = s->stats.as<unsigned long long>();
 
   const unsigned lpb = sampler_lanes_per_block(spp);
   const size_t lds = (size_t)lpb * (spp + 2) * 2;
@@ -538,7 +544,7 @@ extern "C" int rt_render(rt_scene* s, const rt_camera* cam, const rt_film_desc* 
     fp.chunk_first = first;
     ps.n_pixels = (unsigned)npx; ps.cap = (unsigned)(npx * spp);
     ps.q_in = q_a; ps.q_out = q_b;
-    HIP_TRY(hipMemsetAsync(s->counters.p, 0, 64, stream));
+    HIP_TRY(hipMemsetAsync(s->counters.p, 0, 4 * RT_QSHARDS * 4, stream));
     tm.begin(&stats.ms_sampler);
     hipLaunchKernelGGL(k_sampler_tables, dim3((unsigned)((npx + lpb - 1) / lpb)), dim3(lpb), lds, stream, fp, (unsigned)npx, spp, dims, 0ull, 0, s->scrambles.as<unsigned>(), s->perms.as<unsigned short>());
     tm.end();
@@ -547,17 +553,17 @@ extern "C" int rt_render(rt_scene* s, const rt_camera* cam, const rt_film_desc* 
     tm.end();
     for (int bounce = 0; bounce <= fp.max_depth; ++bounce) {
       tm.begin(&stats.ms_trace_closest);
-      launch_trace<false>(s, count, ps.ray_o, ps.ray_d, ps.q_in, &ps.counters[0], 0, ps.hit, nullptr, dstats, ST_RAYS_CLOSEST, ST_NODES_CLOSEST, ST_TRIS_CLOSEST, stream);
+      launch_trace<false>(s, count, ps.ray_o, ps.ray_d, ps.q_in, &ps.counters[0], ps.shard_cap, 0, ps.hit, nullptr, dstats, ST_RAYS_CLOSEST, ST_NODES_CLOSEST, ST_TRIS_CLOSEST, stream);
       tm.end();
       tm.begin(&stats.ms_shade);
       if (s->lambert_only) hipLaunchKernelGGL(k_shade<1>, dim3(pgrid), dim3(256), 0, stream, s->d, fp, ps);
       else hipLaunchKernelGGL(k_shade<0>, dim3(pgrid), dim3(256), 0, stream, s->d, fp, ps);
       tm.end();
       tm.begin(&stats.ms_trace_any);
-      launch_trace<true>(s, count, ps.sh_o, ps.sh_d, ps.q_shadow, &ps.counters[2], 0, nullptr, ps.sh_occ, dstats, ST_RAYS_SHADOW, ST_NODES_SHADOW, ST_TRIS_SHADOW, stream);
+      launch_trace<true>(s, count, ps.sh_o, ps.sh_d, ps.q_shadow, &ps.counters[2 * RT_QSHARDS], ps.shard_cap, 0, nullptr, ps.sh_occ, dstats, ST_RAYS_SHADOW, ST_NODES_SHADOW, ST_TRIS_SHADOW, stream);
       tm.end();
       tm.begin(&stats.ms_trace_mis);
-      launch_trace<false>(s, count, ps.mi_o, ps.mi_d, ps.q_mis, &ps.counters[3], 0, ps.mi_hit, nullptr, dstats, ST_RAYS_MIS, ST_NODES_MIS, ST_TRIS_MIS, stream);
+      launch_trace<false>(s, count, ps.mi_o, ps.mi_d, ps.q_mis, &ps.counters[3 * RT_QSHARDS], ps.shard_cap, 0, ps.mi_hit, nullptr, dstats, ST_RAYS_MIS, ST_NODES_MIS, ST_TRIS_MIS, stream);
       tm.end();
       tm.begin(&stats.ms_resolve);
       hipLaunchKernelGGL(k_resolve, dim3(pgrid), dim3(256), 0, stream, s->d, ps);

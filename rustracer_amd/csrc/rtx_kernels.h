@@ -28,9 +28,11 @@ struct PassState {
   float4* sh_o; float4* sh_d; unsigned* sh_occ;
   float4* mi_o; float4* mi_d; float4* mi_hit;
   float4* pend_a; float4* pend_b; float4* pend_c; unsigned* pend_flags;
-  // queues (path ids) + counters: [0]=active in, [1]=active out, [2]=shadow, [3]=mis
+  // queues of path ids, each split into RT_QSHARDS shards (shard = blockIdx & 7 of the producer, region
+  // [shard * shard_cap, ...)) with its own counter word: a single word sustains only ~88 returning
+  // atomics per microsecond. counters[q * RT_QSHARDS + shard], q: 0 = active in, 1 = active out, 2 = shadow, 3 = mis
   unsigned* q_in; unsigned* q_out; unsigned* q_shadow; unsigned* q_mis;
-  unsigned* counters;
+  unsigned* counters; unsigned shard_cap;
   unsigned long long* stats;  // device-side u64 counters, see ST_* below
 };
 enum { ST_CAMERA = 0, ST_RAYS_CLOSEST, ST_RAYS_SHADOW, ST_RAYS_MIS, ST_NODES_CLOSEST, ST_NODES_SHADOW, ST_NODES_MIS,
@@ -64,14 +66,32 @@ RT_DEV unsigned wave_push(unsigned* counter, bool pred) {
   return base + (unsigned)__popcll(mask & ((1ull << lane) - 1ull));
 }
 
-// Block-aggregated append to up to three device queues: one returning atomic per queue per 256-lane
-// iteration instead of one per wave (a single counter word sustains only ~88 returning atomics/us).
-// Must be reached by every thread of the block. Returns the slot for each queue (valid where pred).
+#define RT_QSHARDS 8
+// Consumer view of a sharded queue: entry i of the concatenation of the shards' filled prefixes.
+struct QView {
+  const unsigned* ids; unsigned pre[RT_QSHARDS + 1]; unsigned shard_cap;
+  RT_DEV void init(const unsigned* ids_, const unsigned* counts, unsigned cap) {
+    ids = ids_; shard_cap = cap; pre[0] = 0;
+#pragma unroll
+    for (int k = 0; k < RT_QSHARDS; ++k) pre[k + 1] = pre[k] + counts[k];
+  }
+  RT_DEV unsigned total() const { return pre[RT_QSHARDS]; }
+  RT_DEV unsigned get(unsigned i) const {
+    unsigned k = 0;
+#pragma unroll
+    for (int j = 1; j < RT_QSHARDS; ++j) k += (i >= pre[j]) ? 1u : 0u;
+    return ids[k * shard_cap + (i - pre[k])];
+  }
+};
+// Block-aggregated append to up to three sharded device queues: one returning atomic per queue per
+// 256-lane iteration, on the counter word of this block's shard. Must be reached by every thread of
+// the block. Returns the absolute slot for each queue (valid where pred).
 template <int NQ>
-RT_DEV void block_push(unsigned* counters, const int* counter_idx, const bool* pred, unsigned* slot) {
+RT_DEV void block_push(unsigned* counters, unsigned shard_cap, const int* queue_idx, const bool* pred, unsigned* slot) {
   __shared__ unsigned s_cnt[NQ][16];
   __shared__ unsigned s_base[NQ];
   const unsigned lane = __lane_id(), wave = threadIdx.x >> 6, n_waves = (blockDim.x + 63u) >> 6;
+  const unsigned shard = blockIdx.x & (RT_QSHARDS - 1);
   unsigned long long mask[NQ];
 #pragma unroll
   for (int q = 0; q < NQ; ++q) {
@@ -82,7 +102,7 @@ RT_DEV void block_push(unsigned* counters, const int* counter_idx, const bool* p
   if (threadIdx.x < NQ) {
     unsigned total = 0;
     for (unsigned w = 0; w < n_waves; ++w) { unsigned c = s_cnt[threadIdx.x][w]; s_cnt[threadIdx.x][w] = total; total += c; }
-    s_base[threadIdx.x] = total ? atomicAdd(&counters[counter_idx[threadIdx.x]], total) : 0u;
+    s_base[threadIdx.x] = shard * shard_cap + (total ? atomicAdd(&counters[queue_idx[threadIdx.x] * RT_QSHARDS + shard], total) : 0u);
   }
   __syncthreads();
 #pragma unroll
@@ -237,7 +257,7 @@ __global__ void __launch_bounds__(256) k_raygen(FrameParams fp, PassState ps) {
       ps.pend_flags[pid] = in_bounds ? 0u : 0x80000000u;  // bit31: sample outside pixel_bounds, never traced
     }
     const int ci[1] = {0}; const bool pr[1] = {in_bounds}; unsigned slot[1];
-    block_push<1>(ps.counters, ci, pr, slot);
+    block_push<1>(ps.counters, ps.shard_cap, ci, pr, slot);
     if (in_bounds) ps.q_in[slot[0]] = pid;
   }
 }
@@ -260,7 +280,7 @@ struct LdsSrc {
 // smallest of 16/32/64 that covers the tree height; the reference's fixed 64 is the maximum).
 template <bool ANY, bool COUNT, bool SMALL, int BLOCK, int DEPTH>
 __global__ void __launch_bounds__(BLOCK) k_trace(DScene sc, const float4* __restrict__ ray_o, const float4* __restrict__ ray_d,
-                                                 const unsigned* __restrict__ queue, const unsigned* __restrict__ count_ptr, unsigned count_static,
+                                                 const unsigned* __restrict__ queue, const unsigned* __restrict__ shard_counts, unsigned shard_cap, unsigned count_static,
                                                  float4* __restrict__ hits, unsigned* __restrict__ occluded, unsigned long long* stats,
                                                  int st_rays, int st_nodes, int st_tris) {
   __shared__ int stack[DEPTH * BLOCK];
@@ -271,11 +291,12 @@ __global__ void __launch_bounds__(BLOCK) k_trace(DScene sc, const float4* __rest
     for (unsigned i = threadIdx.x; i < 3u * sc.n_tris; i += BLOCK) s_tris[i] = sc.tri_p[i];
     __syncthreads();
   }
-  const unsigned count = count_ptr ? *count_ptr : count_static;
+  QView qv; if (queue) qv.init(queue, shard_counts, shard_cap);
+  const unsigned count = queue ? qv.total() : count_static;
   const unsigned stride = gridDim.x * BLOCK;
   unsigned n_nodes = 0, n_tris = 0, n_rays = 0;
   for (unsigned i = blockIdx.x * BLOCK + threadIdx.x; i < count; i += stride) {
-    const unsigned pid = queue ? queue[i] : i;
+    const unsigned pid = queue ? qv.get(i) : i;
     float4 o4 = ray_o[pid], d4 = ray_d[pid];
     Ray ray; ray.o = mk3(o4.x, o4.y, o4.z); ray.d = mk3(d4.x, d4.y, d4.z); ray.t_max = o4.w;
     int prim = -1; TriHit h; h.t = kInf; h.b0 = h.b1 = h.b2 = 0.0f;
@@ -365,15 +386,16 @@ struct SingleLambert {
   RT_DEV float eta() const { return 1.0f; }
 };
 
-// MODE 0: any material / texture. MODE 1: every material is matte with constant Kd and sigma == 0
-// (decided by the host from the material table), which also means no texture ever reads the
-// camera-ray differentials.
+// MODE 0: any material / texture / light. MODE 1: every material is matte with constant Kd and
+// sigma == 0 and every light is a DiffuseAreaLight (decided by the host from the material and light
+// tables); no texture then reads the camera-ray differentials and the kernel makes no out-of-line call.
 #ifndef RT_SHADE_MIN_WAVES
 #define RT_SHADE_MIN_WAVES 2
 #endif
 template <int MODE>
 __global__ void __launch_bounds__(256, RT_SHADE_MIN_WAVES) k_shade(DScene sc, FrameParams fp, PassState ps) {
-  const unsigned count = ps.counters[0];
+  QView qv; qv.init(ps.q_in, ps.counters, ps.shard_cap);
+  const unsigned count = qv.total();
   const unsigned stride = gridDim.x * blockDim.x;
   for (unsigned base = blockIdx.x * blockDim.x; base < count; base += stride) {
     const unsigned i = base + threadIdx.x;
@@ -381,7 +403,7 @@ __global__ void __launch_bounds__(256, RT_SHADE_MIN_WAVES) k_shade(DScene sc, Fr
     bool cont = false, want_shadow = false, want_mis = false;
     unsigned pid = 0;
     if (lane_live) {
-      pid = ps.q_in[i];
+      pid = qv.get(i);
       const unsigned s = pid / ps.n_pixels, pix = pid - s * ps.n_pixels;
       float4 o4 = ps.ray_o[pid], d4 = ps.ray_d[pid], h4 = ps.hit[pid], b4 = ps.beta[pid], l4 = ps.lacc[pid];
       f3 ray_o = mk3(o4.x, o4.y, o4.z), ray_d = mk3(d4.x, d4.y, d4.z);
@@ -409,7 +431,7 @@ __global__ void __launch_bounds__(256, RT_SHADE_MIN_WAVES) k_shade(DScene sc, Fr
         if (found) {
           int li = tri_light(sc.tri_p, prim);
           if (li >= 0) L = L + beta * area_light_l(sc.lights[li], si.hit.n, -ray_d);
-        } else {
+        } else if (MODE == 0) {
           for (int k = 0; k < sc.n_infinite; ++k) L = L + beta * infinite_le(sc, sc.lights[sc.infinite_ids[k]], ray_d);
         }
       }
@@ -437,7 +459,7 @@ __global__ void __launch_bounds__(256, RT_SHADE_MIN_WAVES) k_shade(DScene sc, Fr
             const DLight& light = sc.lights[light_num];
             // ---- estimate_direct (integrator/mod.rs:222-318), light-sampling half
             rgb3 ld1 = mkc(0, 0, 0);
-            LiSample ls = (MODE == 1 && light.kind == 0) ? area_light_sample_li(sc, light, si.hit, u_light) : light_sample_li(sc, light, si.hit, u_light);
+            LiSample ls = (MODE == 1) ? area_light_sample_li(sc, light, si.hit, u_light) : light_sample_li(sc, light, si.hit, u_light);
             if (ls.pdf > 0.0f && !is_black(ls.li)) {
               rgb3 f = bsdf.f(si.hit.wo, ls.wi, nonspec) * fabsf(dot(ls.wi, si.sh_n));
               float scattering_pdf = bsdf.pdf(si.hit.wo, ls.wi, nonspec);
@@ -458,7 +480,7 @@ __global__ void __launch_bounds__(256, RT_SHADE_MIN_WAVES) k_shade(DScene sc, Fr
               if (!is_black(f) && bs.pdf > 0.0f) {
                 float weight = 1.0f; bool go = true;
                 if (!(bs.type & BSDF_SPECULAR)) {
-                  float lp = (MODE == 1 && light.kind == 0) ? area_light_pdf_li(sc, light, si.hit, bs.wi) : light_pdf_li(sc, light, si.hit, bs.wi);
+                  float lp = (MODE == 1) ? area_light_pdf_li(sc, light, si.hit, bs.wi) : light_pdf_li(sc, light, si.hit, bs.wi);
                   if (lp == 0.0f) go = false;  // `return ld`
                   else weight = power_heuristic1(bs.pdf, lp);
                 }
@@ -507,7 +529,7 @@ __global__ void __launch_bounds__(256, RT_SHADE_MIN_WAVES) k_shade(DScene sc, Fr
       ps.pend_flags[pid] = pend;
     }
     const int ci[3] = {1, 2, 3}; const bool pr[3] = {cont, want_shadow, want_mis}; unsigned slot[3];
-    block_push<3>(ps.counters, ci, pr, slot);
+    block_push<3>(ps.counters, ps.shard_cap, ci, pr, slot);
     if (cont) ps.q_out[slot[0]] = pid;
     if (want_shadow) ps.q_shadow[slot[1]] = pid;
     if (want_mis) ps.q_mis[slot[2]] = pid;
@@ -518,10 +540,11 @@ __global__ void __launch_bounds__(256, RT_SHADE_MIN_WAVES) k_shade(DScene sc, Fr
 // Completes estimate_direct for every path shaded this bounce: ld = [unoccluded] Ld1 + [MIS ray
 // reached the sampled light] f*Le*w/pdf; L += beta_at_vertex * (ld / light_pick_pdf).
 __global__ void __launch_bounds__(256) k_resolve(DScene sc, PassState ps) {
-  const unsigned count = ps.counters[0];
+  QView qv; qv.init(ps.q_in, ps.counters, ps.shard_cap);
+  const unsigned count = qv.total();
   const unsigned stride = gridDim.x * blockDim.x;
   for (unsigned i = blockIdx.x * blockDim.x + threadIdx.x; i < count; i += stride) {
-    const unsigned pid = ps.q_in[i];
+    const unsigned pid = qv.get(i);
     const unsigned pend = ps.pend_flags[pid];
     if (!(pend & 0x40000000u)) continue;
     float4 a = ps.pend_a[pid], c = ps.pend_c[pid];
@@ -554,7 +577,10 @@ __global__ void __launch_bounds__(256) k_resolve(DScene sc, PassState ps) {
 
 // queue hand-over between bounces: counters[0] <- counters[1]; others cleared (single thread)
 __global__ void k_next_bounce(unsigned* counters) {
-  if (threadIdx.x == 0 && blockIdx.x == 0) { counters[0] = counters[1]; counters[1] = 0; counters[2] = 0; counters[3] = 0; }
+  if (blockIdx.x == 0 && threadIdx.x < RT_QSHARDS) {
+    const unsigned k = threadIdx.x;
+    counters[k] = counters[RT_QSHARDS + k]; counters[RT_QSHARDS + k] = 0; counters[2 * RT_QSHARDS + k] = 0; counters[3 * RT_QSHARDS + k] = 0;
+  }
 }
 
 // ================================================================================ K6 film
