@@ -39,14 +39,24 @@ struct Ray { f3 o, d; float t_max; };
 struct TriHit { float t, b0, b1, b2; };
 
 // Shared hit test of Triangle::intersect / intersect_p (mesh.rs:215-319, 428-532).
-RT_DEV bool tri_test(f3 p0, f3 p1, f3 p2, const Ray& ray, TriHit& h) {
+RT_DEV bool tri_test(f3 p0, f3 p1, f3 p2, const Ray& ray, TriHit& h);
+
+// Ray-only part of the watertight test (mesh.rs:229-247): permutation and shear constants depend on the ray
+// alone, so the traversal computes them once per ray instead of once per triangle (same values, same order).
+struct RayPre { int kx, ky, kz; float sx, sy, sz; };
+RT_DEV RayPre ray_pre(const Ray& ray) {
+  RayPre r;
+  r.kz = max_dimension(abs3(ray.d));
+  r.kx = r.kz + 1; if (r.kx == 3) r.kx = 0;
+  r.ky = r.kx + 1; if (r.ky == 3) r.ky = 0;
+  f3 d = permute(ray.d, r.kx, r.ky, r.kz);
+  r.sx = -d.x / d.z; r.sy = -d.y / d.z; r.sz = 1.0f / d.z;
+  return r;
+}
+RT_DEV bool tri_test_pre(f3 p0, f3 p1, f3 p2, const Ray& ray, const RayPre& rp, TriHit& h) {
   f3 p0t = p0 - ray.o, p1t = p1 - ray.o, p2t = p2 - ray.o;
-  int kz = max_dimension(abs3(ray.d));
-  int kx = kz + 1; if (kx == 3) kx = 0;
-  int ky = kx + 1; if (ky == 3) ky = 0;
-  f3 d = permute(ray.d, kx, ky, kz);
-  p0t = permute(p0t, kx, ky, kz); p1t = permute(p1t, kx, ky, kz); p2t = permute(p2t, kx, ky, kz);
-  float sx = -d.x / d.z, sy = -d.y / d.z, sz = 1.0f / d.z;
+  p0t = permute(p0t, rp.kx, rp.ky, rp.kz); p1t = permute(p1t, rp.kx, rp.ky, rp.kz); p2t = permute(p2t, rp.kx, rp.ky, rp.kz);
+  const float sx = rp.sx, sy = rp.sy, sz = rp.sz;
   p0t.x += sx * p0t.z; p0t.y += sy * p0t.z;
   p1t.x += sx * p1t.z; p1t.y += sy * p1t.z;
   p2t.x += sx * p2t.z; p2t.y += sy * p2t.z;
@@ -85,6 +95,7 @@ RT_DEV bool tri_test(f3 p0, f3 p1, f3 p2, const Ray& ray, TriHit& h) {
   return true;
 }
 
+RT_DEV bool tri_test(f3 p0, f3 p1, f3 p2, const Ray& ray, TriHit& h) { RayPre rp = ray_pre(ray); return tri_test_pre(p0, p1, p2, ray, rp, h); }
 RT_DEVN bool tri_test_call(f3 p0, f3 p1, f3 p2, const Ray& ray, TriHit& h) { return tri_test(p0, p1, p2, ray, h); }
 
 // Bounds3::intersect_p_fast (bounds.rs:127-157): no (1 + 2 gamma3) widening, as in the reference.
@@ -238,15 +249,50 @@ struct GlobalSrc {
   RT_DEV void tri(int i, f3& p0, f3& p1, f3& p2) const { load_tri(tri_p, i, p0, p1, p2); }
 };
 
-// "while-while" form: every lane first descends (slab tests, pushes) until it holds a leaf, then the
-// wave tests leaf triangles together. The per-ray sequence of node visits and triangle tests is exactly
-// the reference's single loop (so counts and tie-breaking are unchanged); only the SIMD interleaving differs.
+// Closest-hit uses the "while-while" form: every lane first descends (slab tests, pushes) until it holds a
+// leaf, then the wave tests leaf triangles together. Any-hit keeps the reference's single loop (it leaves at
+// the first accepted triangle, so there is little leaf work to batch). In both, the per-ray sequence of node
+// visits and triangle tests is exactly the reference's (counts and tie-breaking unchanged); only the SIMD
+// interleaving differs.
 template <bool ANY, bool COUNT, class Src>
 RT_DEV bool traverse(const Src& src, Ray ray, int* stack, int stack_stride, int& prim_out, TriHit& hit_out, unsigned& n_nodes, unsigned& n_tris) {
   bool found = false;
   int sp = 0, cur = 0;
   f3 inv_dir = mk3(1.0f / ray.d.x, 1.0f / ray.d.y, 1.0f / ray.d.z);
   const int neg_x = inv_dir.x < 0.0f, neg_y = inv_dir.y < 0.0f, neg_z = inv_dir.z < 0.0f;
+  const RayPre rp = ray_pre(ray);
+  if (ANY) {
+    for (;;) {
+      float4 n0, n1;
+      src.node(cur, n0, n1);
+      if (COUNT) n_nodes += 1;
+      if (slab_test(n0, n1, ray, inv_dir, neg_x, neg_y, neg_z)) {
+        const unsigned packed = __float_as_uint(n1.w);
+        const int n_prims = (int)(packed & 0xffffu);
+        const int offset = __float_as_int(n1.z);
+        if (n_prims > 0) {
+          for (int i = 0; i < n_prims; ++i) {
+            f3 p0, p1, p2;
+            src.tri(offset + i, p0, p1, p2);
+            if (COUNT) n_tris += 1;
+            TriHit h;
+            if (tri_test_pre(p0, p1, p2, ray, rp, h)) return true;
+          }
+          if (sp == 0) break;
+          cur = stack[(--sp) * stack_stride];
+        } else {
+          const int axis = (int)((packed >> 16) & 0xffu);
+          const int neg = axis == 0 ? neg_x : (axis == 1 ? neg_y : neg_z);
+          if (neg) { stack[(sp++) * stack_stride] = cur + 1; cur = offset; }
+          else { stack[(sp++) * stack_stride] = offset; cur = cur + 1; }
+        }
+      } else {
+        if (sp == 0) break;
+        cur = stack[(--sp) * stack_stride];
+      }
+    }
+    return false;
+  }
   for (;;) {
     int leaf_off = 0, leaf_n = 0;
     bool done = false;
@@ -274,8 +320,7 @@ RT_DEV bool traverse(const Src& src, Ray ray, int* stack, int stack_stride, int&
       src.tri(leaf_off + i, p0, p1, p2);
       if (COUNT) n_tris += 1;
       TriHit h;
-      if (tri_test(p0, p1, p2, ray, h)) {
-        if (ANY) return true;
+      if (tri_test_pre(p0, p1, p2, ray, rp, h)) {
         ray.t_max = h.t; found = true; prim_out = leaf_off + i; hit_out = h;  // `.or(result)`: later accepted hits replace
       }
     }

@@ -313,17 +313,17 @@ extern "C" int rt_light_distribution(rt_scene* s, int32_t n_voxels[3], float* fu
 // ---------------------------------------------------------------------------------------------- trace launches
 template <bool ANY, bool COUNT, bool SMALL, int BLOCK, int DEPTH>
 static void launch_trace_v(rt_scene* s, const float4* ro, const float4* rd, const unsigned* queue, const unsigned* count_ptr, unsigned shard_cap, unsigned count_static,
-                           float4* hits, unsigned* occ, unsigned long long* stats, int st_rays, int st_nodes, int st_tris, hipStream_t stream) {
+                           float4* hits, unsigned* occ, unsigned long long* stats, int st_rays, int st_nodes, int st_tris, hipStream_t stream, float4* lacc = nullptr, const float4* direct_add = nullptr) {
   // persistent grid: enough workgroups to fill every CU at the kernel's LDS-limited residency
   const unsigned lds = (unsigned)(DEPTH * BLOCK * 4 + (SMALL ? (2 * RT_SMALL_NODES + 3 * RT_SMALL_TRIS) * 16 : 32));
   unsigned per_cu = (160u * 1024u) / lds; if (per_cu * BLOCK > 2048u) per_cu = 2048u / BLOCK; if (per_cu < 1) per_cu = 1;
   hipLaunchKernelGGL((k_trace<ANY, COUNT, SMALL, BLOCK, DEPTH>), dim3((unsigned)s->n_cu * per_cu), dim3(BLOCK), 0, stream, s->d, ro, rd, queue, count_ptr,
-                     shard_cap, count_static, hits, occ, stats, st_rays, st_nodes, st_tris);
+                     shard_cap, count_static, hits, occ, stats, st_rays, st_nodes, st_tris, lacc, direct_add);
 }
 template <bool ANY, bool COUNT>
 static void launch_trace_c(rt_scene* s, const float4* ro, const float4* rd, const unsigned* queue, const unsigned* count_ptr, unsigned shard_cap, unsigned count_static,
-                           float4* hits, unsigned* occ, unsigned long long* stats, int st_rays, int st_nodes, int st_tris, hipStream_t stream) {
-#define RT_ARGS s, ro, rd, queue, count_ptr, shard_cap, count_static, hits, occ, stats, st_rays, st_nodes, st_tris, stream
+                           float4* hits, unsigned* occ, unsigned long long* stats, int st_rays, int st_nodes, int st_tris, hipStream_t stream, float4* lacc = nullptr, const float4* direct_add = nullptr) {
+#define RT_ARGS s, ro, rd, queue, count_ptr, shard_cap, count_static, hits, occ, stats, st_rays, st_nodes, st_tris, stream, lacc, direct_add
   if (s->small) {
     if (s->stack_depth <= 16) launch_trace_v<ANY, COUNT, true, 256, 16>(RT_ARGS);
     else if (s->stack_depth <= 32) launch_trace_v<ANY, COUNT, true, 256, 32>(RT_ARGS);
@@ -336,9 +336,9 @@ static void launch_trace_c(rt_scene* s, const float4* ro, const float4* rd, cons
 }
 template <bool ANY>
 static void launch_trace(rt_scene* s, bool count, const float4* ro, const float4* rd, const unsigned* queue, const unsigned* count_ptr, unsigned shard_cap, unsigned count_static,
-                         float4* hits, unsigned* occ, unsigned long long* stats, int st_rays, int st_nodes, int st_tris, hipStream_t stream) {
-  if (count) launch_trace_c<ANY, true>(s, ro, rd, queue, count_ptr, shard_cap, count_static, hits, occ, stats, st_rays, st_nodes, st_tris, stream);
-  else launch_trace_c<ANY, false>(s, ro, rd, queue, count_ptr, shard_cap, count_static, hits, occ, stats, st_rays, st_nodes, st_tris, stream);
+                         float4* hits, unsigned* occ, unsigned long long* stats, int st_rays, int st_nodes, int st_tris, hipStream_t stream, float4* lacc = nullptr, const float4* direct_add = nullptr) {
+  if (count) launch_trace_c<ANY, true>(s, ro, rd, queue, count_ptr, shard_cap, count_static, hits, occ, stats, st_rays, st_nodes, st_tris, stream, lacc, direct_add);
+  else launch_trace_c<ANY, false>(s, ro, rd, queue, count_ptr, shard_cap, count_static, hits, occ, stats, st_rays, st_nodes, st_tris, stream, lacc, direct_add);
 }
 
 static int trace_batch(rt_scene* s, const float* rays, uint64_t n, bool any, float* hits, uint32_t* occluded, uint64_t counters[2]) {
@@ -560,7 +560,7 @@ extern "C" int rt_render(rt_scene* s, const rt_camera* cam, const rt_film_desc* 
       else hipLaunchKernelGGL(k_shade<0>, dim3(pgrid), dim3(256), 0, stream, s->d, fp, ps);
       tm.end();
       tm.begin(&stats.ms_trace_any);
-      launch_trace<true>(s, count, ps.sh_o, ps.sh_d, ps.q_shadow, &ps.counters[2 * RT_QSHARDS], ps.shard_cap, 0, nullptr, ps.sh_occ, dstats, ST_RAYS_SHADOW, ST_NODES_SHADOW, ST_TRIS_SHADOW, stream);
+      launch_trace<true>(s, count, ps.sh_o, ps.sh_d, ps.q_shadow, &ps.counters[2 * RT_QSHARDS], ps.shard_cap, 0, nullptr, ps.sh_occ, dstats, ST_RAYS_SHADOW, ST_NODES_SHADOW, ST_TRIS_SHADOW, stream, ps.lacc, ps.pend_a);
       tm.end();
       tm.begin(&stats.ms_trace_mis);
       launch_trace<false>(s, count, ps.mi_o, ps.mi_d, ps.q_mis, &ps.counters[3 * RT_QSHARDS], ps.shard_cap, 0, ps.mi_hit, nullptr, dstats, ST_RAYS_MIS, ST_NODES_MIS, ST_TRIS_MIS, stream);

@@ -282,7 +282,7 @@ template <bool ANY, bool COUNT, bool SMALL, int BLOCK, int DEPTH>
 __global__ void __launch_bounds__(BLOCK) k_trace(DScene sc, const float4* __restrict__ ray_o, const float4* __restrict__ ray_d,
                                                  const unsigned* __restrict__ queue, const unsigned* __restrict__ shard_counts, unsigned shard_cap, unsigned count_static,
                                                  float4* __restrict__ hits, unsigned* __restrict__ occluded, unsigned long long* stats,
-                                                 int st_rays, int st_nodes, int st_tris) {
+                                                 int st_rays, int st_nodes, int st_tris, float4* __restrict__ lacc, const float4* __restrict__ direct_add) {
   __shared__ int stack[DEPTH * BLOCK];
   __shared__ float4 s_nodes[SMALL ? 2 * RT_SMALL_NODES : 1];
   __shared__ float4 s_tris[SMALL ? 3 * RT_SMALL_TRIS : 1];
@@ -304,8 +304,14 @@ __global__ void __launch_bounds__(BLOCK) k_trace(DScene sc, const float4* __rest
     if (SMALL) { LdsSrc src{s_nodes, s_tris}; found = traverse<ANY, COUNT>(src, ray, stack + threadIdx.x, BLOCK, prim, h, n_nodes, n_tris); }
     else { GlobalSrc src{sc.nodes, sc.tri_p}; found = traverse<ANY, COUNT>(src, ray, stack + threadIdx.x, BLOCK, prim, h, n_nodes, n_tris); }
     n_rays += 1;
-    if (ANY) occluded[pid] = found ? 1u : 0u;
-    else hits[pid] = make_float4(found ? h.t : kInf, __int_as_float(found ? prim : -1), h.b0, h.b1);
+    if (ANY) {
+      // Shadow rays of the frame loop carry d.w = 1 when the vertex has no MIS ray in flight: the light-sampling
+      // term of estimate_direct is then complete and `L += beta * (Ld / pick_pdf)` (precomputed by k_shade into
+      // direct_add) is applied right here if the ray is unoccluded. Otherwise the flag is left for k_resolve.
+      if (lacc != nullptr && d4.w != 0.0f) {
+        if (!found) { float4 a = direct_add[pid]; float4 l = lacc[pid]; lacc[pid] = make_float4(l.x + a.x, l.y + a.y, l.z + a.z, l.w); }
+      } else occluded[pid] = found ? 1u : 0u;
+    } else hits[pid] = make_float4(found ? h.t : kInf, __int_as_float(found ? prim : -1), h.b0, h.b1);
   }
   if (stats) {
     // one atomic per wave and counter
@@ -417,7 +423,6 @@ __global__ void __launch_bounds__(256, RT_SHADE_MIN_WAVES) k_shade(DScene sc, Fr
       smp.rng.inc = ((pixel_index * (unsigned long long)ps.spp + s + (1ull << 32)) << 1u) | 1ull;
       const int prim = __float_as_int(h4.y);
       const bool found = prim >= 0;
-      unsigned pend = 0u;
       // rebuild the exact hit (t, b0, b1, b2) by re-running the accepted triangle test (t_max = inf)
       SurfaceInteraction si; TriHit th;
       if (found) {
@@ -458,7 +463,7 @@ __global__ void __launch_bounds__(256, RT_SHADE_MIN_WAVES) k_shade(DScene sc, Fr
             f2 u_scattering = smp.get_2d();
             const DLight& light = sc.lights[light_num];
             // ---- estimate_direct (integrator/mod.rs:222-318), light-sampling half
-            rgb3 ld1 = mkc(0, 0, 0);
+            rgb3 ld1 = mkc(0, 0, 0); f3 sh_dir = mk3(0, 0, 0);
             LiSample ls = (MODE == 1) ? area_light_sample_li(sc, light, si.hit, u_light) : light_sample_li(sc, light, si.hit, u_light);
             if (ls.pdf > 0.0f && !is_black(ls.li)) {
               rgb3 f = bsdf.f(si.hit.wo, ls.wi, nonspec) * fabsf(dot(ls.wi, si.sh_n));
@@ -466,14 +471,14 @@ __global__ void __launch_bounds__(256, RT_SHADE_MIN_WAVES) k_shade(DScene sc, Fr
               if (!is_black(f)) {
                 Ray sr = spawn_ray_to_interaction(si.hit, ls.p1);  // VisibilityTester, light/mod.rs:52-55
                 ps.sh_o[pid] = make_float4(sr.o.x, sr.o.y, sr.o.z, sr.t_max);
-                ps.sh_d[pid] = make_float4(sr.d.x, sr.d.y, sr.d.z, 0.0f);
-                want_shadow = true; pend |= 1u;
+                sh_dir = sr.d;
+                want_shadow = true;
                 if (light_is_delta(light)) ld1 = f * ls.li / ls.pdf;
                 else ld1 = f * ls.li * power_heuristic1(ls.pdf, scattering_pdf) / ls.pdf;
               }
             }
-            ps.pend_a[pid] = make_float4(ld1.r, ld1.g, ld1.b, light_pdf);
             // ---- BSDF-sampling half
+            rgb3 f2v = mkc(0, 0, 0); float w2 = 0.0f, spdf2 = 1.0f;
             if (!light_is_delta(light)) {
               LobeSample bs = bsdf.sample_f(si.hit.wo, u_scattering, nonspec);
               rgb3 f = bs.f * fabsf(dot(bs.wi, si.sh_n));
@@ -488,14 +493,20 @@ __global__ void __launch_bounds__(256, RT_SHADE_MIN_WAVES) k_shade(DScene sc, Fr
                   Ray mr = spawn_ray(si.hit, bs.wi);
                   ps.mi_o[pid] = make_float4(mr.o.x, mr.o.y, mr.o.z, kInf);
                   ps.mi_d[pid] = make_float4(mr.d.x, mr.d.y, mr.d.z, 0.0f);
-                  ps.pend_b[pid] = make_float4(f.r, f.g, f.b, weight);
-                  want_mis = true; pend |= 2u | ((unsigned)light_num << 2);
-                  ps.pend_c[pid] = make_float4(beta.r, beta.g, beta.b, bs.pdf);
+                  want_mis = true; f2v = f; w2 = weight; spdf2 = bs.pdf;
                 }
               }
             }
-            if ((pend & 2u) == 0u) ps.pend_c[pid] = make_float4(beta.r, beta.g, beta.b, 1.0f);
-            pend |= 0x40000000u;  // a direct-lighting estimate is pending for this vertex
+            if (want_mis) {  // rare: both halves are combined by k_resolve once both rays are back
+              ps.pend_a[pid] = make_float4(ld1.r, ld1.g, ld1.b, light_pdf);
+              ps.pend_b[pid] = make_float4(f2v.r, f2v.g, f2v.b, w2);
+              ps.pend_c[pid] = make_float4(beta.r, beta.g, beta.b, spdf2);
+              ps.pend_flags[pid] = (want_shadow ? 1u : 0u) | 2u | ((unsigned)light_num << 2);
+            } else if (want_shadow) {  // common: L += beta * ((0 + Ld1) / pick_pdf) if unoccluded, applied by the any-hit kernel
+              rgb3 add = beta * ((mkc(0, 0, 0) + ld1) / light_pdf);
+              ps.pend_a[pid] = make_float4(add.r, add.g, add.b, 0.0f);
+            }
+            if (want_shadow) ps.sh_d[pid] = make_float4(sh_dir.x, sh_dir.y, sh_dir.z, want_mis ? 0.0f : 1.0f);
           }
         }
         // ---- sample the BSDF for the next direction (path.rs:172-196)
@@ -526,7 +537,6 @@ __global__ void __launch_bounds__(256, RT_SHADE_MIN_WAVES) k_shade(DScene sc, Fr
       ps.beta[pid] = make_float4(beta.r, beta.g, beta.b, eta_scale);
       ps.lacc[pid] = make_float4(L.r, L.g, L.b, __uint_as_float(pack_state(bounces, specular_bounce, smp.c1, smp.c2)));
       ps.rng[pid] = smp.rng.state;
-      ps.pend_flags[pid] = pend;
     }
     const int ci[3] = {1, 2, 3}; const bool pr[3] = {cont, want_shadow, want_mis}; unsigned slot[3];
     block_push<3>(ps.counters, ps.shard_cap, ci, pr, slot);
@@ -537,20 +547,19 @@ __global__ void __launch_bounds__(256, RT_SHADE_MIN_WAVES) k_shade(DScene sc, Fr
 }
 
 // ================================================================================ K5 resolve
-// Completes estimate_direct for every path shaded this bounce: ld = [unoccluded] Ld1 + [MIS ray
-// reached the sampled light] f*Le*w/pdf; L += beta_at_vertex * (ld / light_pick_pdf).
+// estimate_direct for the (rare) vertices whose BSDF-sampled MIS ray was traced: ld = [unoccluded] Ld1 +
+// [the MIS ray reached the sampled light] f*Le*w/pdf; L += beta_at_vertex * (ld / light_pick_pdf).
 __global__ void __launch_bounds__(256) k_resolve(DScene sc, PassState ps) {
-  QView qv; qv.init(ps.q_in, ps.counters, ps.shard_cap);
+  QView qv; qv.init(ps.q_mis, ps.counters + 3 * RT_QSHARDS, ps.shard_cap);
   const unsigned count = qv.total();
   const unsigned stride = gridDim.x * blockDim.x;
   for (unsigned i = blockIdx.x * blockDim.x + threadIdx.x; i < count; i += stride) {
     const unsigned pid = qv.get(i);
     const unsigned pend = ps.pend_flags[pid];
-    if (!(pend & 0x40000000u)) continue;
     float4 a = ps.pend_a[pid], c = ps.pend_c[pid];
     rgb3 ld = mkc(0, 0, 0);
     if ((pend & 1u) && ps.sh_occ[pid] == 0u) ld = ld + mkc(a.x, a.y, a.z);
-    if (pend & 2u) {
+    {
       float4 b = ps.pend_b[pid], h4 = ps.mi_hit[pid], d4 = ps.mi_d[pid];
       const int light_num = (int)((pend >> 2) & 0x0fffffffu);
       const DLight& light = sc.lights[light_num];
