@@ -49,7 +49,7 @@ struct rt_scene {
   int ld_strategy_built = -1;
   // per-render workspace
   DevBuf ws[32];
-  DevBuf film_acc, film_out, counters, stats, filter_table, scrambles, perms;
+  DevBuf film_acc, own_acc, film_out, counters, stats, filter_table, scrambles, perms;
   int n_cu = 256;
   std::vector<hipEvent_t> event_pool;
   ~rt_scene() { for (hipEvent_t e : event_pool) (void)hipEventDestroy(e); }
@@ -491,11 +491,16 @@ extern "C" int rt_render(rt_scene* s, const rt_camera* cam, const rt_film_desc* 
   if (rc != RT_OK) return rc;
   tm.end();
 
-  // pass sizing: whole pixels x all spp, at most ~2^23 paths per pass
+  // batch / pass sizing. A batch is a range of owned pixels whose sampler tables (2*dims u16 per sample) are built
+  // at once; it is rendered in passes of n_samples consecutive samples of all its pixels, ~2^23 paths per pass.
   const unsigned long long target_paths = 1ull << 23;
-  unsigned long long chunk_pixels = target_paths / spp; if (chunk_pixels < 64) chunk_pixels = 64;
-  if (chunk_pixels > owned_pixels) chunk_pixels = owned_pixels;
-  const unsigned long long cap = chunk_pixels * spp;
+  unsigned long long batch_pixels = std::max<unsigned long long>(1, std::min<unsigned long long>(owned_pixels, 1ull << 17));  // a rank may own no rows
+  const unsigned long long table_bytes_per_pixel = 2ull * dims * spp * 2ull;
+  while (batch_pixels > 4096 && batch_pixels * table_bytes_per_pixel > (4ull << 30)) batch_pixels >>= 1;  // <= 4 GiB of tables
+  unsigned pass_samples = (unsigned)std::max<unsigned long long>(1, target_paths / batch_pixels);
+  if (pass_samples > spp) pass_samples = spp;
+  const unsigned long long chunk_pixels = batch_pixels;
+  const unsigned long long cap = batch_pixels * pass_samples;
   if (cap > 0x7fffffffull) return fail(RT_ERR_INVALID, "pass too large");
 
   // workspace
@@ -509,7 +514,7 @@ extern "C" int rt_render(rt_scene* s, const rt_camera* cam, const rt_film_desc* 
   const size_t sizes[] = {sz16, sz16, sz16, sz16, sz16, sz8, sz8, sz16, sz16, sz4, sz16, sz16, sz16, sz16, sz16, sz16, sz4, szq, szq, szq, szq};
   for (int i = 0; i < 21; ++i) HIP_TRY(s->ws[i].ensure(sizes[i]));
   HIP_TRY(s->counters.ensure(4 * RT_QSHARDS * 4)); HIP_TRY(s->stats.ensure(ST_COUNT * 8));
-  HIP_TRY(s->film_acc.ensure((size_t)cw * ch * 16));
+  HIP_TRY(s->film_acc.ensure((size_t)cw * ch * 16)); HIP_TRY(s->own_acc.ensure(chunk_pixels * 16));
   HIP_TRY(s->filter_table.ensure(1024));
   HIP_TRY(s->scrambles.ensure(chunk_pixels * 3 * dims * 4)); HIP_TRY(s->perms.ensure(chunk_pixels * 2 * dims * spp * 2));
   float4* d_out = nullptr;
@@ -530,7 +535,7 @@ extern "C" int rt_render(rt_scene* s, const rt_camera* cam, const rt_film_desc* 
   ps.pend_a = s->ws[B_PA].as<float4>(); ps.pend_b = s->ws[B_PB].as<float4>(); ps.pend_c = s->ws[B_PC].as<float4>(); ps.pend_flags = s->ws[B_PF].as<unsigned>();
   unsigned* q_a = s->ws[B_QIN].as<unsigned>(); unsigned* q_b = s->ws[B_QOUT].as<unsigned>();
   ps.q_shadow = s->ws[B_QSH].as<unsigned>(); ps.q_mis = s->ws[B_QMI].as<unsigned>();
-  ps.counters = s->counters.as<unsigned>(); ps.shard_cap = shard_cap; ps.stats = s->stats.as<unsigned long long>();
+  ps.own_acc = s->own_acc.as<float4>(); ps.counters = s->counters.as<unsigned>(); ps.shard_cap = shard_cap; ps.stats = s->stats.as<unsigned long long>();
 
   const unsigned lpb = sampler_lanes_per_block(spp);
   const size_t lds = (size_t)lpb * (spp + 2) * 2;
@@ -542,41 +547,44 @@ extern "C" int rt_render(rt_scene* s, const rt_camera* cam, const rt_film_desc* 
   for (unsigned long long first = 0; first < owned_pixels; first += chunk_pixels) {
     const unsigned long long npx = std::min(chunk_pixels, owned_pixels - first);
     fp.chunk_first = first;
-    ps.n_pixels = (unsigned)npx; ps.cap = (unsigned)(npx * spp);
-    ps.q_in = q_a; ps.q_out = q_b;
-    HIP_TRY(hipMemsetAsync(s->counters.p, 0, 4 * RT_QSHARDS * 4, stream));
+    ps.n_pixels = (unsigned)npx;
     tm.begin(&stats.ms_sampler);
     hipLaunchKernelGGL(k_sampler_tables, dim3((unsigned)((npx + lpb - 1) / lpb)), dim3(lpb), lds, stream, fp, (unsigned)npx, spp, dims, 0ull, 0, s->scrambles.as<unsigned>(), s->perms.as<unsigned short>());
     tm.end();
-    tm.begin(&stats.ms_raygen);
-    hipLaunchKernelGGL(k_raygen, dim3(pgrid), dim3(256), 0, stream, fp, ps);
-    tm.end();
-    for (int bounce = 0; bounce <= fp.max_depth; ++bounce) {
-      tm.begin(&stats.ms_trace_closest);
-      launch_trace<false>(s, count, ps.ray_o, ps.ray_d, ps.q_in, &ps.counters[0], ps.shard_cap, 0, ps.hit, nullptr, dstats, ST_RAYS_CLOSEST, ST_NODES_CLOSEST, ST_TRIS_CLOSEST, stream);
+    for (unsigned s0 = 0; s0 < spp; s0 += pass_samples) {
+      ps.s0 = s0; ps.n_samples = std::min(pass_samples, spp - s0); ps.cap = (unsigned)(npx * ps.n_samples);
+      ps.q_in = q_a; ps.q_out = q_b;
+      HIP_TRY(hipMemsetAsync(s->counters.p, 0, 4 * RT_QSHARDS * 4, stream));
+      tm.begin(&stats.ms_raygen);
+      hipLaunchKernelGGL(k_raygen, dim3(pgrid), dim3(256), 0, stream, fp, ps);
       tm.end();
-      tm.begin(&stats.ms_shade);
-      if (s->lambert_only) hipLaunchKernelGGL(k_shade<1>, dim3(pgrid), dim3(256), 0, stream, s->d, fp, ps);
-      else hipLaunchKernelGGL(k_shade<0>, dim3(pgrid), dim3(256), 0, stream, s->d, fp, ps);
+      for (int bounce = 0; bounce <= fp.max_depth; ++bounce) {
+        tm.begin(&stats.ms_trace_closest);
+        launch_trace<false>(s, count, ps.ray_o, ps.ray_d, ps.q_in, &ps.counters[0], ps.shard_cap, 0, ps.hit, nullptr, dstats, ST_RAYS_CLOSEST, ST_NODES_CLOSEST, ST_TRIS_CLOSEST, stream);
+        tm.end();
+        tm.begin(&stats.ms_shade);
+        if (s->lambert_only) hipLaunchKernelGGL(k_shade<1>, dim3(pgrid), dim3(256), 0, stream, s->d, fp, ps);
+        else hipLaunchKernelGGL(k_shade<0>, dim3(pgrid), dim3(256), 0, stream, s->d, fp, ps);
+        tm.end();
+        tm.begin(&stats.ms_trace_any);
+        launch_trace<true>(s, count, ps.sh_o, ps.sh_d, ps.q_shadow, &ps.counters[2 * RT_QSHARDS], ps.shard_cap, 0, nullptr, ps.sh_occ, dstats, ST_RAYS_SHADOW, ST_NODES_SHADOW, ST_TRIS_SHADOW, stream, ps.lacc, ps.pend_a);
+        tm.end();
+        tm.begin(&stats.ms_trace_mis);
+        launch_trace<false>(s, count, ps.mi_o, ps.mi_d, ps.q_mis, &ps.counters[3 * RT_QSHARDS], ps.shard_cap, 0, ps.mi_hit, nullptr, dstats, ST_RAYS_MIS, ST_NODES_MIS, ST_TRIS_MIS, stream);
+        tm.end();
+        tm.begin(&stats.ms_resolve);
+        hipLaunchKernelGGL(k_resolve, dim3(pgrid), dim3(256), 0, stream, s->d, ps);
+        hipLaunchKernelGGL(k_next_bounce, dim3(1), dim3(64), 0, stream, ps.counters);
+        tm.end();
+        stats.launches_trace_closest += 2;
+        std::swap(ps.q_in, ps.q_out);
+      }
+      tm.begin(&stats.ms_film);
+      hipLaunchKernelGGL(k_film_accumulate, dim3(pgrid), dim3(256), 0, stream, fp, ps, s->filter_table.as<float>(), s->film_acc.as<float4>());
       tm.end();
-      tm.begin(&stats.ms_trace_any);
-      launch_trace<true>(s, count, ps.sh_o, ps.sh_d, ps.q_shadow, &ps.counters[2 * RT_QSHARDS], ps.shard_cap, 0, nullptr, ps.sh_occ, dstats, ST_RAYS_SHADOW, ST_NODES_SHADOW, ST_TRIS_SHADOW, stream, ps.lacc, ps.pend_a);
-      tm.end();
-      tm.begin(&stats.ms_trace_mis);
-      launch_trace<false>(s, count, ps.mi_o, ps.mi_d, ps.q_mis, &ps.counters[3 * RT_QSHARDS], ps.shard_cap, 0, ps.mi_hit, nullptr, dstats, ST_RAYS_MIS, ST_NODES_MIS, ST_TRIS_MIS, stream);
-      tm.end();
-      tm.begin(&stats.ms_resolve);
-      hipLaunchKernelGGL(k_resolve, dim3(pgrid), dim3(256), 0, stream, s->d, ps);
-      hipLaunchKernelGGL(k_next_bounce, dim3(1), dim3(64), 0, stream, ps.counters);
-      tm.end();
-      stats.launches_trace_closest += 2;
-      std::swap(ps.q_in, ps.q_out);
+      stats.n_passes += 1;
+      HIP_TRY(hipGetLastError());
     }
-    tm.begin(&stats.ms_film);
-    hipLaunchKernelGGL(k_film_accumulate, dim3(pgrid), dim3(256), 0, stream, fp, ps, s->filter_table.as<float>(), s->film_acc.as<float4>());
-    tm.end();
-    stats.n_passes += 1;
-    HIP_TRY(hipGetLastError());
   }
   tm.begin(&stats.ms_film);
   {

@@ -10,12 +10,16 @@
 namespace rtx {
 
 
-// ---- per-pass path state in HBM (SoA, indexed by path id = sample * n_pixels + chunk_pixel, so that
-//      the 64 lanes of a wave hold the same sample of 64 neighbouring pixels and every access coalesces)
+// ---- per-pass path state in HBM. A frame is cut into pixel BATCHES (sampler tables are built once per batch
+//      for all spp) and each batch into PASSES of n_samples consecutive samples of every batch pixel.
+//      SoA arrays are indexed by path id = local_sample * n_pixels + batch_pixel, so that the 64 lanes of a
+//      wave hold the same sample of 64 neighbouring pixels and every access coalesces.
 struct PassState {
-  unsigned cap;            // paths in this pass
+  unsigned cap;            // paths in this pass = n_pixels * n_samples
   unsigned spp, spp_log2, dims;
-  unsigned n_pixels;       // chunk pixels
+  unsigned n_pixels;       // batch pixels
+  unsigned s0, n_samples;  // this pass renders samples [s0, s0 + n_samples) of every batch pixel
+  float4* own_acc;         // [batch pixel] running (R, G, B, weight) sum of the pixel's own samples across passes
   // sampler tables of the chunk
   const unsigned* scrambles;        // [pixel][3*dims]
   const unsigned short* perms;      // [pixel][2*dims][spp]
@@ -49,7 +53,7 @@ struct FrameParams {
   // sharding: owned sample rows j -> y = sb_y0 + ((j >> 4) * world + rank) * 16 + (j & 15)
   int rank, world;
   // pass
-  unsigned long long chunk_first;  // first owned-pixel index of this pass
+  unsigned long long chunk_first;  // first owned-pixel index of this batch
 };
 
 // packed per-path state in lacc.w: bits 0-7 bounces, bit 8 specular_bounce, bits 9-12 cur_1d, bits 13-16 cur_2d
@@ -238,7 +242,7 @@ __global__ void __launch_bounds__(256) k_raygen(FrameParams fp, PassState ps) {
     const unsigned pid = base + threadIdx.x;
     bool in_bounds = false;
     if (pid < ps.cap) {
-      const unsigned s = pid / ps.n_pixels, pix = pid - s * ps.n_pixels;
+      const unsigned sl = pid / ps.n_pixels, pix = pid - sl * ps.n_pixels, s = ps.s0 + sl;
       int x, y; unsigned long long pixel_index;
       owned_pixel(fp, fp.chunk_first + pix, x, y, pixel_index);
       in_bounds = y < fp.sb_y1 && x >= fp.pb_x0 && x < fp.pb_x1 && y >= fp.pb_y0 && y < fp.pb_y1;  // renderer.rs:103
@@ -410,7 +414,7 @@ __global__ void __launch_bounds__(256, RT_SHADE_MIN_WAVES) k_shade(DScene sc, Fr
     unsigned pid = 0;
     if (lane_live) {
       pid = qv.get(i);
-      const unsigned s = pid / ps.n_pixels, pix = pid - s * ps.n_pixels;
+      const unsigned sl = pid / ps.n_pixels, pix = pid - sl * ps.n_pixels, s = ps.s0 + sl;
       float4 o4 = ps.ray_o[pid], d4 = ps.ray_d[pid], h4 = ps.hit[pid], b4 = ps.beta[pid], l4 = ps.lacc[pid];
       f3 ray_o = mk3(o4.x, o4.y, o4.z), ray_d = mk3(d4.x, d4.y, d4.z);
       rgb3 beta = mkc(b4.x, b4.y, b4.z), L = mkc(l4.x, l4.y, l4.z);
@@ -593,22 +597,25 @@ __global__ void k_next_bounce(unsigned* counters) {
 }
 
 // ================================================================================ K6 film
-// FilmTile::add_sample (film.rs:298-361) + merge (:177-194). One lane per chunk pixel walks its
-// samples in order; its own pixel's sum stays in registers (sequential order = the reference's
-// per-tile order); splats onto other pixels (filter radius > 0.5, or a sample exactly on a pixel
-// edge) go through float atomics. film_acc: float4 (R, G, B sums, weight sum) per cropped pixel.
+// FilmTile::add_sample (film.rs:298-361) + merge (:177-194). One lane per batch pixel walks the pass's
+// samples in order; the pixel's own running sum (registers within a pass, own_acc between passes) is
+// therefore accumulated in exactly the reference's per-tile order and flushed once after the last pass;
+// splats onto other pixels (filter radius > 0.5, or a sample exactly on a pixel edge) go through float
+// atomics. film_acc: float4 (R, G, B sums, weight sum) per cropped pixel.
 __global__ void __launch_bounds__(256) k_film_accumulate(FrameParams fp, PassState ps, const float* __restrict__ filter_table, float4* film_acc) {
   const unsigned stride = gridDim.x * blockDim.x;
   const int cw = fp.crop_x1 - fp.crop_x0;
   const float inv_rx = 1.0f / fp.radius_x, inv_ry = 1.0f / fp.radius_y;
+  const bool first_pass = ps.s0 == 0u, last_pass = ps.s0 + ps.n_samples >= ps.spp;
   for (unsigned pix = blockIdx.x * blockDim.x + threadIdx.x; pix < ps.n_pixels; pix += stride) {
     int x, y; unsigned long long pixel_index;
     owned_pixel(fp, fp.chunk_first + pix, x, y, pixel_index);
     if (y >= fp.sb_y1) continue;
-    rgb3 own = mkc(0, 0, 0); float own_w = 0.0f; bool own_any = false;
+    rgb3 own = mkc(0, 0, 0); float own_w = 0.0f;
+    if (!first_pass) { float4 a = ps.own_acc[pix]; own = mkc(a.x, a.y, a.z); own_w = a.w; }
     unsigned scrubbed = 0;
-    for (unsigned s = 0; s < ps.spp; ++s) {
-      const unsigned pid = s * ps.n_pixels + pix;
+    for (unsigned sl = 0; sl < ps.n_samples; ++sl) {
+      const unsigned pid = sl * ps.n_pixels + pix;
       if (ps.pend_flags[pid] & 0x80000000u) continue;
       float4 l4 = ps.lacc[pid];
       rgb3 c = mkc(l4.x, l4.y, l4.z);
@@ -631,7 +638,7 @@ __global__ void __launch_bounds__(256) k_film_accumulate(FrameParams fp, PassSta
           float fx = fabsf(((float)xx - dx) * inv_rx * 16.0f);
           int ix = (int)f2u_sat(fminf(floorf(fx), 15.0f));
           float fw = filter_table[iy * 16 + ix];
-          if (xx == x && yy == y) { own = own + Lc * fw; own_w += fw; own_any = true; }
+          if (xx == x && yy == y) { own = own + Lc * fw; own_w += fw; }
           else {
             float* dst = (float*)&film_acc[(size_t)(yy - fp.crop_y0) * cw + (xx - fp.crop_x0)];
             rgb3 v = Lc * fw;
@@ -640,7 +647,8 @@ __global__ void __launch_bounds__(256) k_film_accumulate(FrameParams fp, PassSta
         }
       }
     }
-    if (own_any && x >= fp.crop_x0 && x < fp.crop_x1 && y >= fp.crop_y0 && y < fp.crop_y1) {
+    if (!last_pass) ps.own_acc[pix] = make_float4(own.r, own.g, own.b, own_w);
+    else if (x >= fp.crop_x0 && x < fp.crop_x1 && y >= fp.crop_y0 && y < fp.crop_y1) {
       float* dst = (float*)&film_acc[(size_t)(y - fp.crop_y0) * cw + (x - fp.crop_x0)];
       atomicAdd(dst + 0, own.r); atomicAdd(dst + 1, own.g); atomicAdd(dst + 2, own.b); atomicAdd(dst + 3, own_w);
     }
