@@ -254,8 +254,8 @@ struct GlobalSrc {
 // the first accepted triangle, so there is little leaf work to batch). In both, the per-ray sequence of node
 // visits and triangle tests is exactly the reference's (counts and tie-breaking unchanged); only the SIMD
 // interleaving differs.
-template <bool ANY, bool COUNT, class Src>
-RT_DEV bool traverse(const Src& src, Ray ray, int* stack, int stack_stride, int& prim_out, TriHit& hit_out, unsigned& n_nodes, unsigned& n_tris) {
+template <bool ANY, bool COUNT, class Src, class StackT>
+RT_DEV bool traverse(const Src& src, Ray ray, StackT* stack, int stack_stride, int& prim_out, TriHit& hit_out, unsigned& n_nodes, unsigned& n_tris) {
   bool found = false;
   int sp = 0, cur = 0;
   f3 inv_dir = mk3(1.0f / ray.d.x, 1.0f / ray.d.y, 1.0f / ray.d.z);
@@ -279,16 +279,16 @@ RT_DEV bool traverse(const Src& src, Ray ray, int* stack, int stack_stride, int&
             if (tri_test_pre(p0, p1, p2, ray, rp, h)) return true;
           }
           if (sp == 0) break;
-          cur = stack[(--sp) * stack_stride];
+          cur = (int)stack[(--sp) * stack_stride];
         } else {
           const int axis = (int)((packed >> 16) & 0xffu);
           const int neg = axis == 0 ? neg_x : (axis == 1 ? neg_y : neg_z);
-          if (neg) { stack[(sp++) * stack_stride] = cur + 1; cur = offset; }
-          else { stack[(sp++) * stack_stride] = offset; cur = cur + 1; }
+          if (neg) { stack[(sp++) * stack_stride] = (StackT)(cur + 1); cur = offset; }
+          else { stack[(sp++) * stack_stride] = (StackT)offset; cur = cur + 1; }
         }
       } else {
         if (sp == 0) break;
-        cur = stack[(--sp) * stack_stride];
+        cur = (int)stack[(--sp) * stack_stride];
       }
     }
     return false;
@@ -307,11 +307,11 @@ RT_DEV bool traverse(const Src& src, Ray ray, int* stack, int stack_stride, int&
         if (n_prims > 0) { leaf_off = offset; leaf_n = n_prims; break; }
         const int axis = (int)((packed >> 16) & 0xffu);
         const int neg = axis == 0 ? neg_x : (axis == 1 ? neg_y : neg_z);
-        if (neg) { stack[(sp++) * stack_stride] = cur + 1; cur = offset; }
-        else { stack[(sp++) * stack_stride] = offset; cur = cur + 1; }
+        if (neg) { stack[(sp++) * stack_stride] = (StackT)(cur + 1); cur = offset; }
+        else { stack[(sp++) * stack_stride] = (StackT)offset; cur = cur + 1; }
       } else {
         if (sp == 0) { done = true; break; }
-        cur = stack[(--sp) * stack_stride];
+        cur = (int)stack[(--sp) * stack_stride];
       }
     }
     if (done) break;
@@ -325,7 +325,7 @@ RT_DEV bool traverse(const Src& src, Ray ray, int* stack, int stack_stride, int&
       }
     }
     if (sp == 0) break;
-    cur = stack[(--sp) * stack_stride];
+    cur = (int)stack[(--sp) * stack_stride];
   }
   return found;
 }

@@ -315,7 +315,7 @@ template <bool ANY, bool COUNT, bool SMALL, int BLOCK, int DEPTH>
 static void launch_trace_v(rt_scene* s, const float4* ro, const float4* rd, const unsigned* queue, const unsigned* count_ptr, unsigned shard_cap, unsigned count_static,
                            float4* hits, unsigned* occ, unsigned long long* stats, int st_rays, int st_nodes, int st_tris, hipStream_t stream, float4* lacc = nullptr, const float4* direct_add = nullptr) {
   // persistent grid: enough workgroups to fill every CU at the kernel's LDS-limited residency
-  const unsigned lds = (unsigned)(DEPTH * BLOCK * 4 + (SMALL ? (2 * RT_SMALL_NODES + 3 * RT_SMALL_TRIS) * 16 : 32));
+  const unsigned lds = (unsigned)(DEPTH * BLOCK * ((SMALL && !ANY) ? 2 : 4) + (SMALL ? (2 * RT_SMALL_NODES + 3 * RT_SMALL_TRIS) * 16 : 32));
   unsigned per_cu = (160u * 1024u) / lds; if (per_cu * BLOCK > 2048u) per_cu = 2048u / BLOCK; if (per_cu < 1) per_cu = 1;
   hipLaunchKernelGGL((k_trace<ANY, COUNT, SMALL, BLOCK, DEPTH>), dim3((unsigned)s->n_cu * per_cu), dim3(BLOCK), 0, stream, s->d, ro, rd, queue, count_ptr,
                      shard_cap, count_static, hits, occ, stats, st_rays, st_nodes, st_tris, lacc, direct_add);
@@ -560,7 +560,7 @@ extern "C" int rt_render(rt_scene* s, const rt_camera* cam, const rt_film_desc* 
       tm.end();
       for (int bounce = 0; bounce <= fp.max_depth; ++bounce) {
         tm.begin(&stats.ms_trace_closest);
-        launch_trace<false>(s, count, ps.ray_o, ps.ray_d, ps.q_in, &ps.counters[0], ps.shard_cap, 0, ps.hit, nullptr, dstats, ST_RAYS_CLOSEST, ST_NODES_CLOSEST, ST_TRIS_CLOSEST, stream);
+        launch_trace<false>(s, count, ps.ray_o, ps.ray_d, ps.q_in, &ps.counters[0], ps.shard_cap, 0, ps.hit, nullptr, dstats, ST_RAYS_CLOSEST, ST_NODES_CLOSEST, ST_TRIS_CLOSEST, stream, ps.lacc, nullptr);
         tm.end();
         tm.begin(&stats.ms_shade);
         if (s->lambert_only) hipLaunchKernelGGL(k_shade<1>, dim3(pgrid), dim3(256), 0, stream, s->d, fp, ps);

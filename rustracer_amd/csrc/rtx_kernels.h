@@ -287,7 +287,9 @@ __global__ void __launch_bounds__(BLOCK) k_trace(DScene sc, const float4* __rest
                                                  const unsigned* __restrict__ queue, const unsigned* __restrict__ shard_counts, unsigned shard_cap, unsigned count_static,
                                                  float4* __restrict__ hits, unsigned* __restrict__ occluded, unsigned long long* stats,
                                                  int st_rays, int st_nodes, int st_tris, float4* __restrict__ lacc, const float4* __restrict__ direct_add) {
-  __shared__ int stack[DEPTH * BLOCK];
+  // node indices of a tiny scene fit 16 bits: half the stack bytes => more resident waves per CU
+  typedef typename std::conditional<SMALL && !ANY, unsigned short, int>::type StackT;
+  __shared__ StackT stack[DEPTH * BLOCK];
   __shared__ float4 s_nodes[SMALL ? 2 * RT_SMALL_NODES : 1];
   __shared__ float4 s_tris[SMALL ? 3 * RT_SMALL_TRIS : 1];
   if (SMALL) {
@@ -305,8 +307,8 @@ __global__ void __launch_bounds__(BLOCK) k_trace(DScene sc, const float4* __rest
     Ray ray; ray.o = mk3(o4.x, o4.y, o4.z); ray.d = mk3(d4.x, d4.y, d4.z); ray.t_max = o4.w;
     int prim = -1; TriHit h; h.t = kInf; h.b0 = h.b1 = h.b2 = 0.0f;
     bool found;
-    if (SMALL) { LdsSrc src{s_nodes, s_tris}; found = traverse<ANY, COUNT>(src, ray, stack + threadIdx.x, BLOCK, prim, h, n_nodes, n_tris); }
-    else { GlobalSrc src{sc.nodes, sc.tri_p}; found = traverse<ANY, COUNT>(src, ray, stack + threadIdx.x, BLOCK, prim, h, n_nodes, n_tris); }
+    if (SMALL) { LdsSrc src{s_nodes, s_tris}; found = traverse<ANY, COUNT, LdsSrc, StackT>(src, ray, stack + threadIdx.x, BLOCK, prim, h, n_nodes, n_tris); }
+    else { GlobalSrc src{sc.nodes, sc.tri_p}; found = traverse<ANY, COUNT, GlobalSrc, StackT>(src, ray, stack + threadIdx.x, BLOCK, prim, h, n_nodes, n_tris); }
     n_rays += 1;
     if (ANY) {
       // Shadow rays of the frame loop carry d.w = 1 when the vertex has no MIS ray in flight: the light-sampling
@@ -315,7 +317,7 @@ __global__ void __launch_bounds__(BLOCK) k_trace(DScene sc, const float4* __rest
       if (lacc != nullptr && d4.w != 0.0f) {
         if (!found) { float4 a = direct_add[pid]; float4 l = lacc[pid]; lacc[pid] = make_float4(l.x + a.x, l.y + a.y, l.z + a.z, l.w); }
       } else occluded[pid] = found ? 1u : 0u;
-    } else hits[pid] = make_float4(found ? h.t : kInf, __int_as_float(found ? prim : -1), h.b0, h.b1);
+    } else hits[pid] = make_float4(lacc != nullptr ? h.b2 : (found ? h.t : kInf), __int_as_float(found ? prim : -1), h.b0, h.b1);
   }
   if (stats) {
     // one atomic per wave and counter
@@ -415,8 +417,8 @@ __global__ void __launch_bounds__(256, RT_SHADE_MIN_WAVES) k_shade(DScene sc, Fr
     if (lane_live) {
       pid = qv.get(i);
       const unsigned sl = pid / ps.n_pixels, pix = pid - sl * ps.n_pixels, s = ps.s0 + sl;
-      float4 o4 = ps.ray_o[pid], d4 = ps.ray_d[pid], h4 = ps.hit[pid], b4 = ps.beta[pid], l4 = ps.lacc[pid];
-      f3 ray_o = mk3(o4.x, o4.y, o4.z), ray_d = mk3(d4.x, d4.y, d4.z);
+      float4 d4 = ps.ray_d[pid], h4 = ps.hit[pid], b4 = ps.beta[pid], l4 = ps.lacc[pid];
+      f3 ray_d = mk3(d4.x, d4.y, d4.z);
       rgb3 beta = mkc(b4.x, b4.y, b4.z), L = mkc(l4.x, l4.y, l4.z);
       float eta_scale = b4.w;
       unsigned st = __float_as_uint(l4.w);
@@ -427,13 +429,11 @@ __global__ void __launch_bounds__(256, RT_SHADE_MIN_WAVES) k_shade(DScene sc, Fr
       smp.rng.inc = ((pixel_index * (unsigned long long)ps.spp + s + (1ull << 32)) << 1u) | 1ull;
       const int prim = __float_as_int(h4.y);
       const bool found = prim >= 0;
-      // rebuild the exact hit (t, b0, b1, b2) by re-running the accepted triangle test (t_max = inf)
-      SurfaceInteraction si; TriHit th;
+      // the frame loop's hit record is (b2, prim, b0, b1): the three barycentrics of the accepted test
+      SurfaceInteraction si; TriHit th; th.t = 0.0f; th.b0 = h4.z; th.b1 = h4.w; th.b2 = h4.x;
       if (found) {
-        f3 p0, p1, p2; load_tri(sc.tri_p, prim, p0, p1, p2);
-        Ray r; r.o = ray_o; r.d = ray_d; r.t_max = kInf;
-        if (MODE == 1) { (void)tri_test(p0, p1, p2, r, th); tri_fill_interaction_inl(sc, prim, ray_d, th, si); }
-        else { (void)tri_test_call(p0, p1, p2, r, th); tri_fill_interaction(sc, prim, ray_d, th, si); }
+        if (MODE == 1) tri_fill_interaction_inl(sc, prim, ray_d, th, si);
+        else tri_fill_interaction(sc, prim, ray_d, th, si);
       }
       // path.rs:127-136 emitted light at the vertex / from the environment
       if (bounces == 0 || specular_bounce) {
