@@ -27,8 +27,10 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--res", type=int, default=1024)
-    ap.add_argument("--spp", type=int, default=1024)
+    ap.add_argument("--scene", default="cornell", choices=["cornell", "blob", "mis", "room"],
+                    help="cornell = BASELINE configs[1] (the headline); blob / mis / room = configs[2..4] (SURVEY.md §8d S2-S4)")
+    ap.add_argument("--res", type=int, default=1024, help="cornell only (the other scenes use their BASELINE resolution)")
+    ap.add_argument("--spp", type=int, default=0, help="0 = the BASELINE spp of the scene (cornell 1024, blob 256, mis 512, room 1024)")
     ap.add_argument("--cpu-spp", type=int, default=32, help="spp of the bounded CPU-baseline sample")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
@@ -37,7 +39,7 @@ def main():
     import torch
     from rustracer_amd import host
     from rustracer_amd.distributed import merge_film
-    from rustracer_amd.scenes import cornell_box
+    from rustracer_amd.scenes import blob_scene, cornell_box, mis_plates, room_env
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -54,7 +56,16 @@ def main():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
 
-    desc = cornell_box(args.res, args.res, args.spp)
+    if args.scene == "cornell":
+        args.spp = args.spp or 1024
+        desc = cornell_box(args.res, args.res, args.spp)
+        workload = f"cornell-box (synthetic S1, 32 triangles, 2 area lights) {args.res}x{args.res} PathIntegrator maxdepth=5 {args.spp}spp 02sequence box-filter"
+    else:
+        gen, spp0 = {"blob": (blob_scene, 256), "mis": (mis_plates, 512), "room": (room_env, 1024)}[args.scene]
+        args.spp = args.spp or spp0
+        desc = gen(spp=args.spp)
+        workload = (f"{desc.name} (synthetic, {desc.n_tris} triangles, {len(desc.lights)} lights) {desc.film.xres}x{desc.film.yres} "
+                    f"PathIntegrator maxdepth={desc.integrator.max_depth} {args.spp}spp 02sequence box-filter")
     scene = host.HostScene(desc)
     scene.upload(local_rank)
     st0 = scene.setup()
@@ -120,7 +131,7 @@ def main():
         out = {
             "metric": "Msamples/s", "value": round(value, 2), "unit": "Msamples/s", "n_gpus": n_gpus, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(ms_step, 2), "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": f"cornell-box (synthetic S1, 32 triangles, 2 area lights) {args.res}x{args.res} PathIntegrator maxdepth=5 {args.spp}spp 02sequence box-filter",
+            "config": {"workload": workload,
                        "sharding": "interleaved 16-row tile rows, end-of-frame sum-reduce to rank 0" if n_gpus > 1 else "single GPU",
                        "sampler_mode": "pixel-keyed"},
             "s_per_frame": round(ms_step / 1e3, 4),

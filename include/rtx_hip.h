@@ -195,6 +195,9 @@ int rt_trace_closest_device(rt_scene* scene, const void* d_rays, uint64_t n, voi
  * permutation of each of the 2*dimensions tables. scrambles: n_pixels*3*dimensions u32
  * (1D dims first, then 2D pairs); perms: n_pixels*2*dimensions*spp u16. Host pointers. */
 int rt_sampler_tables(int32_t spp, int32_t dimensions, uint64_t pixel0, uint64_t n_pixels, uint32_t* scrambles, uint16_t* perms);
+/* Same result from the single-kernel statement of the algorithm (one lane walks a pixel's whole RNG stream in
+ * order). Not used by rt_render; it is the on-device cross-check of the segmented sampler over large pixel ranges. */
+int rt_sampler_tables_plain(int32_t spp, int32_t dimensions, uint64_t pixel0, uint64_t n_pixels, uint32_t* scrambles, uint16_t* perms);
 
 /* Dense voxel light distribution of SpatialLightDistribution (rc/lightdistrib.rs:101-179):
  * n_voxels[3]; func: nvox*n_lights, cdf: nvox*(n_lights+1), func_int: nvox (host pointers, may be NULL

@@ -230,6 +230,13 @@ def sampler_tables(spp, dims, mode, seed):
     return o1, o2, st
 
 
+def sampler_retry_scan(spp, dims, pixel0, n, cap=64):
+    """Keyed pixel indices in [pixel0, pixel0+n) whose start_pixel stream contains a bounded-draw retry."""
+    out = np.zeros(cap, np.uint64)
+    k = lib().orc_sampler_retry_scan(spp, dims, C.c_uint64(pixel0), C.c_uint64(n), _p(out, C.c_uint64), cap)
+    return out[:k].copy()
+
+
 def rng_stream(seq, n):
     u = np.zeros(n, np.uint32)
     f = np.zeros(n, np.float32)

@@ -273,6 +273,28 @@ int orc_sampler_tables(int spp, int dims, int mode, uint64_t seed, float* out1d,
   if (rng_state_after) { rng_state_after[0] = z.rng.state; rng_state_after[1] = z.rng.inc; }
   return (int)z.spp;
 }
+// Keyed pixels in [pixel0, pixel0 + n) whose start_pixel stream hits at least one uniform_u32_bounded retry
+// (rc/rng.rs:32-40: r < (!b+1)&b). Found by replaying the draw sequence of start_pixel
+// (rc/sampler/zerotwosequence.rs:67-108 -> lowdiscrepancy.rs:4-50) without building the tables. Tests use these
+// rare pixels to exercise the GPU sampler's retry path.
+int orc_sampler_retry_scan(int spp_, int dims, uint64_t pixel0, uint64_t n, uint64_t* out, int cap) {
+  uint32_t spp = 1; while (spp < (uint32_t)spp_) spp <<= 1;
+  int found = 0;
+  for (uint64_t k = 0; k < n && found < cap; ++k) {
+    Rng r; r.set_sequence(pixel0 + k);
+    bool retried = false;
+    for (int t = 0; t < 2 * dims && !retried; ++t) {
+      r.uniform_u32(); if (t >= dims) r.uniform_u32();
+      for (int half = 0; half < 2; ++half)
+        for (uint32_t i = 0; i < spp; ++i) {
+          const uint32_t b = half == 0 ? 1u : spp - i, threshold = (~b + 1u) & b;
+          if (r.uniform_u32() < threshold) retried = true;  // the reference would draw again here: the stream shifts
+        }
+    }
+    if (retried) out[found++] = pixel0 + k;
+  }
+  return found;
+}
 // Raw PCG32 stream (tests): seq < 0 => default-constructed generator
 int orc_rng_stream(int64_t seq, int n, uint32_t* out_u32, float* out_f32) {
   Rng r; if (seq >= 0) r.set_sequence((uint64_t)seq);

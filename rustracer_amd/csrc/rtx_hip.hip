@@ -35,8 +35,14 @@ struct DevBuf {
   template <class T> T* as() const { return (T*)p; }
 };
 
+struct SamplerPlan {  // launch plan of K0 for one (spp, dims): stream segments, reciprocal table, retry list
+  unsigned spp = 0, dims = 0, seg_len = 0, n_segs = 0;
+  DevBuf segs, magic, dirty, partners;  // partners: the shuffle's swap partners of one batch, [table][pixel][spp] u16
+};
+
 struct rt_scene {
   int device = 0;
+  SamplerPlan sampler_plan;
   DScene d{};
   bool small = false;
   bool lambert_only = false;  // every material is matte{constant Kd, sigma == 0} and every light an area light: k_shade<1>
@@ -49,10 +55,19 @@ struct rt_scene {
   int ld_strategy_built = -1;
   // per-render workspace
   DevBuf ws[32];
-  DevBuf film_acc, own_acc, film_out, counters, stats, filter_table, scrambles, perms;
+  DevBuf film_acc, own_acc, film_out, counters, stats, filter_table;
+  // sampler tables are double-buffered: K0 of batch b+1 runs on aux_stream under the path kernels of batch b
+  DevBuf scrambles[2], perms[2];
+  hipStream_t aux_stream = nullptr;
+  hipEvent_t ev_tables[2] = {nullptr, nullptr}, ev_batch_done[2] = {nullptr, nullptr}, ev_frame_begin = nullptr;
   int n_cu = 256;
   std::vector<hipEvent_t> event_pool;
-  ~rt_scene() { for (hipEvent_t e : event_pool) (void)hipEventDestroy(e); }
+  ~rt_scene() {
+    for (hipEvent_t e : event_pool) (void)hipEventDestroy(e);
+    for (int i = 0; i < 2; ++i) { if (ev_tables[i]) (void)hipEventDestroy(ev_tables[i]); if (ev_batch_done[i]) (void)hipEventDestroy(ev_batch_done[i]); }
+    if (ev_frame_begin) (void)hipEventDestroy(ev_frame_begin);
+    if (aux_stream) (void)hipStreamDestroy(aux_stream);
+  }
 };
 
 extern "C" const char* rt_last_error(void) { return g_err.c_str(); }
@@ -402,7 +417,81 @@ static unsigned sampler_lanes_per_block(unsigned spp) {
   return 4u;
 }
 
-extern "C" int rt_sampler_tables(int32_t spp_, int32_t dims, uint64_t pixel0, uint64_t n_pixels, uint32_t* scrambles, uint16_t* perms) {
+// PCG32 jump-ahead constants: state_n = A^n * state_0 + S_n * inc with S_n = 1 + A + ... + A^(n-1) (mod 2^64)
+static void pcg_advance_constants(unsigned long long n, unsigned long long& mul, unsigned long long& sum) {
+  unsigned long long cur_mul = 0x5851f42d4c957f2dULL, cur_sum = 1ull;
+  mul = 1ull; sum = 0ull;
+  while (n) {
+    if (n & 1ull) { sum = sum * cur_mul + cur_sum; mul *= cur_mul; }
+    cur_sum = (cur_mul + 1ull) * cur_sum; cur_mul *= cur_mul;
+    n >>= 1;
+  }
+}
+// Launch plan of K0 for (spp, dims): stream segments for k_sampler_draws and the reciprocal table.
+static int sampler_plan_prepare(SamplerPlan& pl, unsigned spp_, unsigned dims_) {
+  unsigned &spp = pl.spp, &dims = pl.dims, &seg_len = pl.seg_len, &n_segs = pl.n_segs;
+  DevBuf &segs = pl.segs, &magic = pl.magic, &dirty = pl.dirty;
+  {
+    if (spp == spp_ && dims == dims_ && segs.p) return RT_OK;
+    seg_len = spp_ < 256u ? spp_ : 256u;
+    const unsigned per_half = spp_ / seg_len;
+    std::vector<SamplerSeg> h;
+    unsigned long long pos = 0;
+    for (unsigned t = 0; t < 2u * dims_; ++t) {
+      const unsigned n_scr = t < dims_ ? 1u : 2u;
+      for (unsigned half = 0; half < 2u; ++half)
+        for (unsigned g = 0; g < per_half; ++g) {
+          SamplerSeg sg{};
+          const bool first = half == 0u && g == 0u;
+          const unsigned long long start = first ? pos : pos + n_scr + (unsigned long long)half * spp_ + (unsigned long long)g * seg_len;
+          pcg_advance_constants(start, sg.mul, sg.sum);
+          sg.table = t; sg.half = half; sg.i0 = g * seg_len; sg.n_scr = first ? n_scr : 0u;
+          h.push_back(sg);
+        }
+      pos += n_scr + 2ull * spp_;
+    }
+    std::vector<unsigned> mg(spp_ + 1, 0u);
+    for (unsigned b = 2; b <= spp_; ++b) mg[b] = (unsigned)((1ull << 32) / b);
+    int rc;
+    if ((rc = upload(segs, h.data(), h.size() * sizeof(SamplerSeg))) != RT_OK) return rc;
+    if ((rc = upload(magic, mg.data(), mg.size() * 4)) != RT_OK) return rc;
+    HIP_TRY(dirty.ensure((2 + RT_DIRTY_CAP) * 4));
+    HIP_TRY(hipMemset(dirty.p, 0, (2 + RT_DIRTY_CAP) * 4));
+    spp = spp_; dims = dims_; n_segs = (unsigned)h.size();
+    return RT_OK;
+  }
+}
+// lanes per K0b block: 16384 / spp lanes hold 32 KB of permutations (one wave at most, four lanes at least)
+static unsigned shuffle_lanes_per_block(unsigned spp) { unsigned l = 65536u / spp; return l > 64u ? 64u : (l < 4u ? 4u : l); }
+static int launch_sampler_tables(SamplerPlan& pl, const FrameParams& fp, unsigned n_pixels, unsigned long long explicit_pixel0, int use_explicit,
+                                 unsigned* scrambles, unsigned short* perms, hipStream_t stream) {
+  const unsigned spp = pl.spp, dims = pl.dims;
+  const unsigned lpb = shuffle_lanes_per_block(spp);
+  const size_t lds = (size_t)lpb * spp * 2;
+  HIP_TRY(pl.partners.ensure((size_t)n_pixels * 2u * dims * spp * 2u));
+  unsigned short* partners = pl.partners.as<unsigned short>();
+  HIP_TRY(hipMemsetAsync(pl.dirty.p, 0, 4, stream));
+  hipLaunchKernelGGL(k_sampler_draws, dim3((n_pixels + 255u) / 256u, pl.n_segs), dim3(256), 0, stream, fp, n_pixels, spp, dims, pl.seg_len, explicit_pixel0, use_explicit,
+                     pl.segs.as<SamplerSeg>(), pl.magic.as<unsigned>(), scrambles, partners, pl.dirty.as<unsigned>());
+  hipLaunchKernelGGL(k_sampler_redo, dim3(RT_DIRTY_CAP / 64u), dim3(64), 0, stream, fp, n_pixels, spp, dims, explicit_pixel0, use_explicit, pl.dirty.as<unsigned>(), pl.magic.as<unsigned>(), scrambles, partners);
+  hipLaunchKernelGGL(k_sampler_shuffle, dim3((n_pixels + lpb - 1) / lpb, 2u * dims), dim3(lpb), lds, stream, n_pixels, spp, partners, perms);
+  return RT_OK;
+}
+static int sampler_set_lds_limits(unsigned spp) {
+  const size_t lds = (size_t)sampler_lanes_per_block(spp) * (spp + 2) * 2;
+  HIP_TRY(hipFuncSetAttribute((const void*)k_sampler_tables, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  HIP_TRY(hipFuncSetAttribute((const void*)k_sampler_shuffle, hipFuncAttributeMaxDynamicSharedMemorySize, (int)((size_t)shuffle_lanes_per_block(spp) * spp * 2)));
+  return RT_OK;
+}
+
+static int sampler_tables_host(int32_t spp_, int32_t dims, uint64_t pixel0, uint64_t n_pixels, uint32_t* scrambles, uint16_t* perms, bool plain);
+extern "C" int rt_sampler_tables(int32_t spp, int32_t dims, uint64_t pixel0, uint64_t n_pixels, uint32_t* scrambles, uint16_t* perms) {
+  return sampler_tables_host(spp, dims, pixel0, n_pixels, scrambles, perms, false);
+}
+extern "C" int rt_sampler_tables_plain(int32_t spp, int32_t dims, uint64_t pixel0, uint64_t n_pixels, uint32_t* scrambles, uint16_t* perms) {
+  return sampler_tables_host(spp, dims, pixel0, n_pixels, scrambles, perms, true);
+}
+static int sampler_tables_host(int32_t spp_, int32_t dims, uint64_t pixel0, uint64_t n_pixels, uint32_t* scrambles, uint16_t* perms, bool plain) {
   if (!rt_device_available()) return fail(RT_ERR_NO_DEVICE, "no HIP device visible; this backend has no CPU fallback");
   if (spp_ <= 0 || dims <= 0 || dims > 8 || n_pixels == 0) return fail(RT_ERR_INVALID, "bad sampler arguments");
   const unsigned spp = next_pow2((unsigned)spp_);
@@ -410,13 +499,17 @@ extern "C" int rt_sampler_tables(int32_t spp_, int32_t dims, uint64_t pixel0, ui
   DevBuf sc, pm;
   HIP_TRY(sc.ensure(n_pixels * 3 * dims * 4)); HIP_TRY(pm.ensure(n_pixels * 2 * dims * spp * 2));
   FrameParams fp{};
-  const unsigned lpb = sampler_lanes_per_block(spp);
-  const size_t lds = (size_t)lpb * (spp + 2) * 2;
-  HIP_TRY(hipFuncSetAttribute((const void*)k_sampler_tables, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-  hipLaunchKernelGGL(k_sampler_tables, dim3((unsigned)((n_pixels + lpb - 1) / lpb)), dim3(lpb), lds, nullptr, fp, (unsigned)n_pixels, spp, (unsigned)dims, (unsigned long long)pixel0, 1,
-                     sc.as<unsigned>(), pm.as<unsigned short>());
+  SamplerPlan plan; int rc;
+  if ((rc = sampler_plan_prepare(plan, spp, (unsigned)dims)) != RT_OK) return rc;
+  if ((rc = sampler_set_lds_limits(spp)) != RT_OK) return rc;
+  if (plain) {
+    const unsigned lpb = sampler_lanes_per_block(spp);
+    hipLaunchKernelGGL(k_sampler_tables, dim3((unsigned)((n_pixels + lpb - 1) / lpb)), dim3(lpb), (size_t)lpb * (spp + 2) * 2, nullptr, fp, (unsigned)n_pixels, spp, (unsigned)dims,
+                       (unsigned long long)pixel0, 1, sc.as<unsigned>(), pm.as<unsigned short>());
+  } else if ((rc = launch_sampler_tables(plan, fp, (unsigned)n_pixels, (unsigned long long)pixel0, 1, sc.as<unsigned>(), pm.as<unsigned short>(), nullptr)) != RT_OK) return rc;
   HIP_TRY(hipGetLastError());
   HIP_TRY(hipDeviceSynchronize());
+  { unsigned ovf = 0; HIP_TRY(hipMemcpy(&ovf, plan.dirty.as<unsigned>() + 1 + RT_DIRTY_CAP, 4, hipMemcpyDeviceToHost)); if (ovf) return fail(RT_ERR_INVALID, "sampler retry list overflow"); }
   // device layout is pixel-minor ([k][pixel], [table][sample][pixel]); the ABI returns pixel-major
   std::vector<uint32_t> hs(n_pixels * 3 * dims); std::vector<uint16_t> hp(n_pixels * 2 * dims * spp);
   HIP_TRY(hipMemcpy(hs.data(), sc.p, hs.size() * 4, hipMemcpyDeviceToHost));
@@ -437,8 +530,8 @@ struct KTimer {  // HIP-event kernel timing on the render stream; events come fr
     if (used == pool->size()) { hipEvent_t e; (void)hipEventCreate(&e); pool->push_back(e); }
     return (*pool)[used++];
   }
-  void begin(double* where) { if (!on) return; (void)hipEventRecord(get(), st); dst.push_back(where); }
-  void end() { if (!on) return; (void)hipEventRecord(get(), st); }
+  void begin(double* where, hipStream_t on_stream = nullptr) { if (!on) return; (void)hipEventRecord(get(), on_stream ? on_stream : st); dst.push_back(where); }
+  void end(hipStream_t on_stream = nullptr) { if (!on) return; (void)hipEventRecord(get(), on_stream ? on_stream : st); }
   void collect() {
     for (size_t i = 0; i < dst.size(); ++i) {
       float ms = 0; (void)hipEventSynchronize((*pool)[2 * i + 1]); (void)hipEventElapsedTime(&ms, (*pool)[2 * i], (*pool)[2 * i + 1]);
@@ -516,7 +609,14 @@ extern "C" int rt_render(rt_scene* s, const rt_camera* cam, const rt_film_desc* 
   HIP_TRY(s->counters.ensure(4 * RT_QSHARDS * 4)); HIP_TRY(s->stats.ensure(ST_COUNT * 8));
   HIP_TRY(s->film_acc.ensure((size_t)cw * ch * 16)); HIP_TRY(s->own_acc.ensure(chunk_pixels * 16));
   HIP_TRY(s->filter_table.ensure(1024));
-  HIP_TRY(s->scrambles.ensure(chunk_pixels * 3 * dims * 4)); HIP_TRY(s->perms.ensure(chunk_pixels * 2 * dims * spp * 2));
+  const bool multi_batch = owned_pixels > chunk_pixels;
+  for (int b = 0; b < (multi_batch ? 2 : 1); ++b) { HIP_TRY(s->scrambles[b].ensure(chunk_pixels * 3 * dims * 4)); HIP_TRY(s->perms[b].ensure(chunk_pixels * 2 * dims * spp * 2)); }
+  if (!s->aux_stream) {
+    int lo = 0, hi = 0; (void)hipDeviceGetStreamPriorityRange(&lo, &hi);  // lo = numerically greatest = lowest priority
+    HIP_TRY(hipStreamCreateWithPriority(&s->aux_stream, hipStreamNonBlocking, lo));
+    for (int i = 0; i < 2; ++i) { HIP_TRY(hipEventCreateWithFlags(&s->ev_tables[i], hipEventDisableTiming)); HIP_TRY(hipEventCreateWithFlags(&s->ev_batch_done[i], hipEventDisableTiming)); }
+    HIP_TRY(hipEventCreateWithFlags(&s->ev_frame_begin, hipEventDisableTiming));
+  }
   float4* d_out = nullptr;
   if (flags & RT_FLAG_FILM_ON_DEVICE) d_out = (float4*)film_xyzw;
   else { HIP_TRY(s->film_out.ensure((size_t)cw * ch * 16)); d_out = s->film_out.as<float4>(); }
@@ -526,7 +626,6 @@ extern "C" int rt_render(rt_scene* s, const rt_camera* cam, const rt_film_desc* 
 
   PassState ps{};
   ps.spp = spp; ps.spp_log2 = spp_log2; ps.dims = dims;
-  ps.scrambles = s->scrambles.as<unsigned>(); ps.perms = s->perms.as<unsigned short>();
   ps.ray_o = s->ws[B_RAYO].as<float4>(); ps.ray_d = s->ws[B_RAYD].as<float4>(); ps.hit = s->ws[B_HIT].as<float4>();
   ps.beta = s->ws[B_BETA].as<float4>(); ps.lacc = s->ws[B_LACC].as<float4>(); ps.rng = s->ws[B_RNG].as<unsigned long long>();
   ps.pfilm = s->ws[B_PFILM].as<float2>();
@@ -537,20 +636,41 @@ extern "C" int rt_render(rt_scene* s, const rt_camera* cam, const rt_film_desc* 
   ps.q_shadow = s->ws[B_QSH].as<unsigned>(); ps.q_mis = s->ws[B_QMI].as<unsigned>();
   ps.own_acc = s->own_acc.as<float4>(); ps.counters = s->counters.as<unsigned>(); ps.shard_cap = shard_cap; ps.stats = s->stats.as<unsigned long long>();
 
-  const unsigned lpb = sampler_lanes_per_block(spp);
-  const size_t lds = (size_t)lpb * (spp + 2) * 2;
-  HIP_TRY(hipFuncSetAttribute((const void*)k_sampler_tables, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  if ((rc = sampler_plan_prepare(s->sampler_plan, spp, dims)) != RT_OK) return rc;
+  if ((rc = sampler_set_lds_limits(spp)) != RT_OK) return rc;
   const bool count = (flags & RT_FLAG_COUNT_TRAVERSAL) != 0;
   const unsigned pgrid = (unsigned)s->n_cu * 8u;
   unsigned long long* dstats = s->stats.as<unsigned long long>();
 
-  for (unsigned long long first = 0; first < owned_pixels; first += chunk_pixels) {
+  // K0 of a batch goes to the low-priority aux stream: it is a latency-bound chain of LDS swaps that leaves the
+  // VALUs idle, so it runs underneath the previous batch's path kernels. ev_tables[k]: tables in buffer k are
+  // ready; ev_batch_done[k]: the path kernels that read buffer k have finished (it may be overwritten).
+  // RTX_K0_OVERLAP=0 (measurement knob) keeps K0 on the render stream
+  const char* ov = getenv("RTX_K0_OVERLAP");
+  hipStream_t aux = (ov && ov[0] == '0') ? stream : s->aux_stream;
+  HIP_TRY(hipEventRecord(s->ev_frame_begin, stream));
+  HIP_TRY(hipStreamWaitEvent(aux, s->ev_frame_begin, 0));
+  auto launch_tables = [&](unsigned long long first, int buf) {
     const unsigned long long npx = std::min(chunk_pixels, owned_pixels - first);
+    FrameParams f2 = fp; f2.chunk_first = first;
+    tm.begin(&stats.ms_sampler, aux);
+    (void)launch_sampler_tables(s->sampler_plan, f2, (unsigned)npx, 0ull, 0, s->scrambles[buf].as<unsigned>(), s->perms[buf].as<unsigned short>(), aux);
+    tm.end(aux);
+    (void)hipEventRecord(s->ev_tables[buf], aux);
+  };
+  if (owned_pixels > 0) launch_tables(0, 0);  // a rank may own no rows
+  unsigned long long batch_no = 0;
+  for (unsigned long long first = 0; first < owned_pixels; first += chunk_pixels, ++batch_no) {
+    const unsigned long long npx = std::min(chunk_pixels, owned_pixels - first);
+    const int buf = (int)(batch_no & 1ull);
     fp.chunk_first = first;
     ps.n_pixels = (unsigned)npx;
-    tm.begin(&stats.ms_sampler);
-    hipLaunchKernelGGL(k_sampler_tables, dim3((unsigned)((npx + lpb - 1) / lpb)), dim3(lpb), lds, stream, fp, (unsigned)npx, spp, dims, 0ull, 0, s->scrambles.as<unsigned>(), s->perms.as<unsigned short>());
-    tm.end();
+    ps.scrambles = s->scrambles[buf].as<unsigned>(); ps.perms = s->perms[buf].as<unsigned short>();
+    if (first + chunk_pixels < owned_pixels) {  // next batch's tables into the other buffer, once its previous readers are done
+      if (batch_no >= 1) HIP_TRY(hipStreamWaitEvent(aux, s->ev_batch_done[buf ^ 1], 0));
+      launch_tables(first + chunk_pixels, buf ^ 1);
+    }
+    HIP_TRY(hipStreamWaitEvent(stream, s->ev_tables[buf], 0));
     for (unsigned s0 = 0; s0 < spp; s0 += pass_samples) {
       ps.s0 = s0; ps.n_samples = std::min(pass_samples, spp - s0); ps.cap = (unsigned)(npx * ps.n_samples);
       ps.q_in = q_a; ps.q_out = q_b;
@@ -585,6 +705,7 @@ extern "C" int rt_render(rt_scene* s, const rt_camera* cam, const rt_film_desc* 
       stats.n_passes += 1;
       HIP_TRY(hipGetLastError());
     }
+    HIP_TRY(hipEventRecord(s->ev_batch_done[buf], stream));
   }
   tm.begin(&stats.ms_film);
   {
@@ -598,6 +719,8 @@ extern "C" int rt_render(rt_scene* s, const rt_camera* cam, const rt_film_desc* 
   tm.collect();
   unsigned long long h[ST_COUNT];
   HIP_TRY(hipMemcpy(h, s->stats.p, sizeof(h), hipMemcpyDeviceToHost));
+  { unsigned ovf = 0; HIP_TRY(hipMemcpy(&ovf, s->sampler_plan.dirty.as<unsigned>() + 1 + RT_DIRTY_CAP, 4, hipMemcpyDeviceToHost));
+    if (ovf) { (void)hipMemset(s->sampler_plan.dirty.p, 0, (2 + RT_DIRTY_CAP) * 4); return fail(RT_ERR_INVALID, "sampler retry list overflow"); } }
   stats.camera_rays = owned_pixels * spp;
   stats.rays_closest = h[ST_RAYS_CLOSEST]; stats.rays_shadow = h[ST_RAYS_SHADOW]; stats.rays_mis = h[ST_RAYS_MIS];
   stats.nodes_closest = h[ST_NODES_CLOSEST]; stats.nodes_shadow = h[ST_NODES_SHADOW]; stats.nodes_mis = h[ST_NODES_MIS];

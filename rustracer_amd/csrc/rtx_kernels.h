@@ -126,15 +126,204 @@ RT_DEV void owned_pixel(const FrameParams& fp, unsigned long long k, int& x, int
 }
 
 // ================================================================================ K0 sampler tables
-// ZeroTwoSequence::start_pixel (rc/sampler/zerotwosequence.rs:67-108) in keyed mode: one lane per
-// pixel runs the sequential PCG32-driven Fisher-Yates shuffles (rc/sampler/lowdiscrepancy.rs:4-50,
-// 114-124) on a permutation of sample indices kept in LDS ([lane][spp+2] u16, odd word stride =>
-// conflict-free for equal-index accesses); the (0,2) values themselves are a closed form of
-// (scramble, index) and are evaluated by the consumers (table_1d/table_2d below).
-// The loop is a chain of dependent LDS accesses, i.e. latency-bound and capped by LDS capacity
-// (2 B * spp per lane), so blocks are kept SMALL (blockDim = lanes whose tables fill ~32 KB): that
-// puts a wave on every SIMD of a CU instead of one 64-lane wave on one SIMD.
+// ZeroTwoSequence::start_pixel (rc/sampler/zerotwosequence.rs:67-108) in keyed mode. Per pixel the reference draws,
+// for each of the 2*dims tables in turn and from ONE PCG32 stream: 1 (van_der_corput, lowdiscrepancy.rs:10) or 2
+// (sobol_2d, :31) scrambles, spp draws uniform_u32_bounded(1) for the per-pixel-sample shuffles of one element
+// (:14-21), and spp draws bounded(spp - i) of the Fisher-Yates shuffle of the sample order (:22, :114-124). The
+// (0,2) values are a closed form of (scramble, shuffled index) and are evaluated by the consumers (table_1d/2d).
+//
+// The stream is cut at fixed positions: a bounded draw retries only when r < (!b+1)&b = lowest set bit of b
+// (rng.rs:32-40), which over a whole pixel happens with probability ~1e-5. So:
+//   K0a  one lane per (pixel, table, segment of <= 256 draws): PCG32 jump-ahead to the segment's nominal stream
+//        position (state = A^n * s0 + S_n * inc, (A^n, S_n) from a host-built table), then sequential draws;
+//        the shuffle's swap partners other_i = i + r % (spp - i) go to a scratch array [table][pixel][i]; any
+//        retry marks the pixel dirty. The divisor is wave-uniform: r % b by a multiply with floor(2^32 / b).
+//   K0c  the (rare) dirty pixels' draws are redone in stream order, one lane per pixel.
+//   K0b  one lane per (pixel, table) replays the swaps on a permutation kept in LDS ([lane][spp+2] u16, odd word
+//        stride => conflict-free); a dependent LDS chain, so blocks are small to put a wave on every SIMD.
 // Output, pixel-minor so that a wave's accesses coalesce: scrambles[k][pixel], perms[table][sample][pixel].
+struct SamplerSeg { unsigned long long mul, sum; unsigned table, half, i0, n_scr; };  // half 0: consume draws, 1: swap draws
+#define RT_DIRTY_CAP 1024u
+
+RT_DEV unsigned long long pixel_index_of(const FrameParams& fp, unsigned pix, unsigned long long explicit_pixel0, int use_explicit) {
+  if (use_explicit) return explicit_pixel0 + pix;
+  int x, y; unsigned long long pixel_index; owned_pixel(fp, fp.chunk_first + pix, x, y, pixel_index);
+  return pixel_index;
+}
+RT_DEV void mark_dirty(unsigned* dirty, unsigned pix) {  // dirty[0] = count, dirty[1..] = pixels (duplicates are harmless)
+  unsigned k = atomicAdd(&dirty[0], 1u);
+  if (k < RT_DIRTY_CAP) dirty[1 + k] = pix;
+}
+
+__global__ void __launch_bounds__(256) k_sampler_draws(FrameParams fp, unsigned n_pixels, unsigned spp, unsigned dims, unsigned seg_len,
+                                                       unsigned long long explicit_pixel0, int use_explicit, const SamplerSeg* __restrict__ segs,
+                                                       const unsigned* __restrict__ magic, unsigned* __restrict__ scrambles, unsigned short* __restrict__ partners,
+                                                       unsigned* dirty) {
+  const unsigned pix = blockIdx.x * blockDim.x + threadIdx.x;
+  if (pix >= n_pixels) return;
+  const SamplerSeg sg = segs[blockIdx.y];
+  const unsigned long long pixel_index = pixel_index_of(fp, pix, explicit_pixel0, use_explicit);
+  Pcg32 rng;
+  rng.inc = (pixel_index << 1u) | 1ull;
+  const unsigned long long s0 = (rng.inc + 0x853c49e6748fea9bULL) * 0x5851f42d4c957f2dULL + rng.inc;  // state after set_sequence
+  rng.state = sg.mul * s0 + sg.sum * rng.inc;
+  const unsigned t = sg.table;
+  if (sg.n_scr == 1u) scrambles[(size_t)t * n_pixels + pix] = rng.next_u32();
+  else if (sg.n_scr == 2u) {
+    unsigned a = rng.next_u32(), b = rng.next_u32();
+    scrambles[(size_t)(dims + 2u * (t - dims)) * n_pixels + pix] = a;
+    scrambles[(size_t)(dims + 2u * (t - dims) + 1u) * n_pixels + pix] = b;
+  }
+  bool retry = false;
+  if (sg.half == 0u) {
+    // bounded(1): threshold 1, retried iff the draw is 0; the output function maps exactly xorshifted == 0 to 0
+    for (unsigned i = 0; i < seg_len; ++i) {
+      unsigned long long old = rng.state;
+      rng.state = old * 0x5851f42d4c957f2dULL + rng.inc;
+      retry |= (unsigned)(((old >> 18u) ^ old) >> 27u) == 0u;
+    }
+  } else {
+    // partners[table][i][pixel]: a wave's stores coalesce
+    unsigned short* dst = partners + ((size_t)t * spp + sg.i0) * n_pixels + pix;
+    for (unsigned k = 0; k < seg_len; ++k) {
+      const unsigned i = sg.i0 + k, b = spp - i;  // wave-uniform
+      const unsigned r = rng.next_u32();
+      retry |= r < ((~b + 1u) & b);
+      unsigned rem = 0u;
+      if (b > 1u) {
+        const unsigned q = __umulhi(r, magic[b]);  // floor(r / b) or one less
+        rem = r - q * b;
+        rem = rem >= b ? rem - b : rem;
+      }
+      dst[(size_t)k * n_pixels] = (unsigned short)(i + rem);
+    }
+  }
+  if (retry) mark_dirty(dirty, pix);
+}
+
+// K0b. Step i of the shuffle: swap(a[i], a[other_i]). The LDS round trip of one step would serialise the chain,
+// so G steps are issued together: all 2G reads go out at once and the values are then corrected in registers for
+// the writes of the earlier steps of the same group (a later step may read a slot an earlier one has just
+// overwritten). a[i] is final after step i, so the permutation is flushed from LDS once at the end.
+// LDS layout of K0b: lane l keeps its permutation in [l * spp, (l + 1) * spp) u16 with the index XOR-ed by
+// (2 l) mod spp: equal indices of different lanes then fall into different banks although the lane stride is a
+// power of two, and a block of 16384 / spp lanes fills exactly 32 KB (five blocks per CU).
+struct PermLds {
+  unsigned short* base; unsigned swz;
+  RT_DEV unsigned get(unsigned i) const { return base[i ^ swz]; }
+  RT_DEV void set(unsigned i, unsigned v) const { base[i ^ swz] = (unsigned short)v; }
+};
+RT_DEV PermLds perm_lds(unsigned short* lds, unsigned lane, unsigned spp) { PermLds p; p.base = lds + (size_t)lane * spp; p.swz = (lane << 1) & (spp - 1u); return p; }
+
+template <int G>
+RT_DEV void shuffle_group(const PermLds& a, unsigned i, const unsigned* o) {
+  unsigned va[G], vb[G];  // 32-bit registers: 16-bit VALU operands cost pack/unpack instructions
+#pragma unroll
+  for (int k = 0; k < G; ++k) { va[k] = a.get(i + k); vb[k] = a.get(o[k]); }
+#pragma unroll
+  for (int k = 0; k < G; ++k) {
+#pragma unroll
+    for (int j = 0; j < k; ++j) {
+      if (o[j] == i + k) va[k] = va[j];
+      if (o[j] == o[k]) vb[k] = va[j];
+    }
+    a.set(o[k], va[k]);
+    a.set(i + k, vb[k]);  // after the write above: if other_k == i + k both hold the same value
+  }
+}
+RT_DEV void unpack8(uint4 v, unsigned* o) {
+  o[0] = v.x & 0xffffu; o[1] = v.x >> 16; o[2] = v.y & 0xffffu; o[3] = v.y >> 16;
+  o[4] = v.z & 0xffffu; o[5] = v.z >> 16; o[6] = v.w & 0xffffu; o[7] = v.w >> 16;
+}
+// blockDim.x = L lanes (one wave at most), blockIdx.y = table
+__global__ void __launch_bounds__(64) k_sampler_shuffle(unsigned n_pixels, unsigned spp, const unsigned short* __restrict__ partners, unsigned short* __restrict__ perms) {
+  extern __shared__ unsigned short lds_perm[];
+  const unsigned lane = threadIdx.x, L = blockDim.x;
+  const unsigned pix0 = blockIdx.x * L, pix = pix0 + lane;
+  const PermLds a = perm_lds(lds_perm, lane, spp);
+  if (pix < n_pixels) {
+    const unsigned short* in = partners + (size_t)blockIdx.y * spp * n_pixels + pix;
+    for (unsigned i = 0; i < spp; ++i) a.set(i, i);
+    constexpr int G = 8;
+    if (spp >= 4u * G) {
+      // partners are fetched three groups ahead (global latency >> one group) into a ring of four register
+      // buffers; the loop is unrolled over the ring so that it needs no register moves
+      unsigned b0[G], b1[G], b2[G], b3[G];
+      auto fetch = [&](unsigned* dst, unsigned first) {
+        const unsigned f = first < spp ? first : 0u;  // past the end: a harmless re-read
+#pragma unroll
+        for (int k = 0; k < G; ++k) dst[k] = in[(size_t)(f + k) * n_pixels];
+      };
+      fetch(b0, 0u); fetch(b1, G); fetch(b2, 2u * G);
+      for (unsigned i = 0; i < spp; i += 4u * G) {
+        fetch(b3, i + 3u * G); shuffle_group<G>(a, i, b0);
+        fetch(b0, i + 4u * G); shuffle_group<G>(a, i + G, b1);
+        fetch(b1, i + 5u * G); shuffle_group<G>(a, i + 2u * G, b2);
+        fetch(b2, i + 6u * G); shuffle_group<G>(a, i + 3u * G, b3);
+      }
+    } else {
+      for (unsigned i = 0; i < spp; ++i) {
+        unsigned o = in[(size_t)i * n_pixels];
+        unsigned va = a.get(i), vb = a.get(o);
+        a.set(i, vb); a.set(o, va);
+      }
+    }
+  }
+  __syncthreads();
+  // flush to perms[table][sample][pixel]. A vector memory instruction costs the same issue slot whatever it
+  // carries, so each lane gathers one sample of 8 neighbouring pixels from LDS and stores 16 bytes.
+  unsigned short* out = perms + (size_t)blockIdx.y * spp * n_pixels;
+  if ((n_pixels & 7u) == 0u && L >= 8u) {
+    const unsigned groups = L >> 3, g = lane % groups, r0 = lane / groups;  // 8 rows per pass
+    const unsigned gp = pix0 + 8u * g;
+    if (gp < n_pixels) {
+      PermLds c[8];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) c[j] = perm_lds(lds_perm, 8u * g + (unsigned)j, spp);
+      for (unsigned i = r0; i < spp; i += 8u) {
+        unsigned w[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) w[j] = c[2 * j].get(i) | (c[2 * j + 1].get(i) << 16);
+        *(uint4*)(out + (size_t)i * n_pixels + gp) = make_uint4(w[0], w[1], w[2], w[3]);
+      }
+    }
+  } else if (pix < n_pixels) {
+    for (unsigned i = 0; i < spp; ++i) out[(size_t)i * n_pixels + pix] = (unsigned short)a.get(i);
+  }
+}
+
+// K0c: the swap partners and scrambles of the (rare) pixels whose stream holds a retry, redone from the start of
+// the stream in order, one lane per pixel, before K0b consumes them.
+__global__ void __launch_bounds__(64) k_sampler_redo(FrameParams fp, unsigned n_pixels, unsigned spp, unsigned dims,
+                                                     unsigned long long explicit_pixel0, int use_explicit, unsigned* dirty,
+                                                     const unsigned* __restrict__ magic, unsigned* scrambles, unsigned short* partners) {
+  const unsigned k = blockIdx.x * blockDim.x + threadIdx.x;
+  if (k == 0 && dirty[0] > RT_DIRTY_CAP) dirty[1 + RT_DIRTY_CAP] = 1u;  // sticky: the host fails the frame
+  const unsigned n = dirty[0] < RT_DIRTY_CAP ? dirty[0] : RT_DIRTY_CAP;
+  if (k >= n) return;
+  const unsigned pix = dirty[1 + k];
+  Pcg32 rng; rng.set_sequence(pixel_index_of(fp, pix, explicit_pixel0, use_explicit));
+  for (unsigned t = 0; t < 2u * dims; ++t) {
+    if (t < dims) scrambles[(size_t)t * n_pixels + pix] = rng.next_u32();
+    else {
+      unsigned s0 = rng.next_u32(), s1 = rng.next_u32();
+      scrambles[(size_t)(dims + 2u * (t - dims)) * n_pixels + pix] = s0;
+      scrambles[(size_t)(dims + 2u * (t - dims) + 1u) * n_pixels + pix] = s1;
+    }
+    for (unsigned i = 0; i < spp; ++i) (void)rng.bounded(1u);
+    unsigned short* dst = partners + (size_t)t * spp * n_pixels + pix;
+    for (unsigned i = 0; i < spp; ++i) {
+      const unsigned b = spp - i, threshold = (~b + 1u) & b;
+      unsigned r; do { r = rng.next_u32(); } while (r < threshold);  // bounded(b), rng.rs:32-40
+      unsigned rem = 0u;
+      if (b > 1u) { const unsigned q = __umulhi(r, magic[b]); rem = r - q * b; rem = rem >= b ? rem - b : rem; }  // r % b
+      dst[(size_t)i * n_pixels] = (unsigned short)(i + rem);
+    }
+  }
+}
+
+// The plain statement of the whole algorithm, one lane per pixel (kept as the in-tree cross-check of K0a-c:
+// rt_sampler_tables(..., RT_SAMPLER_PLAIN)).
 __global__ void k_sampler_tables(FrameParams fp, unsigned n_pixels, unsigned spp, unsigned dims,
                                  unsigned long long explicit_pixel0, int use_explicit, unsigned* scrambles, unsigned short* perms) {
   extern __shared__ unsigned short lds_perm[];
@@ -143,9 +332,7 @@ __global__ void k_sampler_tables(FrameParams fp, unsigned n_pixels, unsigned spp
   unsigned short* mine = lds_perm + (size_t)lane * stride;
   const unsigned pix = blockIdx.x * blockDim.x + lane;
   if (pix >= n_pixels) return;
-  unsigned long long pixel_index;
-  if (use_explicit) pixel_index = explicit_pixel0 + pix;
-  else { int x, y; owned_pixel(fp, fp.chunk_first + pix, x, y, pixel_index); }
+  const unsigned long long pixel_index = pixel_index_of(fp, pix, explicit_pixel0, use_explicit);
   Pcg32 rng; rng.set_sequence(pixel_index);
   for (unsigned t = 0; t < 2u * dims; ++t) {
     if (t < dims) scrambles[(size_t)t * n_pixels + pix] = rng.next_u32();  // van_der_corput scramble (:10)

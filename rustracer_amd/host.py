@@ -251,14 +251,16 @@ class HostScene:
         return dict(n_voxels=nv, func=func, cdf=cdf, func_int=fint)
 
 
-def sampler_tables(spp, dims, pixel0, n_pixels):
-    """K0 on the GPU: (scrambles (n,3*dims) u32, perms (n, 2*dims, spp) u16)."""
+def sampler_tables(spp, dims, pixel0, n_pixels, plain=False):
+    """K0 on the GPU: (scrambles (n,3*dims) u32, perms (n, 2*dims, spp) u16). plain=True: the single-kernel
+    in-order statement of the algorithm (cross-check of the segmented sampler rt_render uses)."""
     spp2 = 1
     while spp2 < spp:
         spp2 *= 2
     sc = np.zeros((n_pixels, 3 * dims), np.uint32)
     pm = np.zeros((n_pixels, 2 * dims, spp2), np.uint16)
-    rc = hip_lib().rt_sampler_tables(spp, dims, C.c_uint64(pixel0), C.c_uint64(n_pixels), _p(sc, C.c_uint32), _p(pm, C.c_uint16))
+    fn = hip_lib().rt_sampler_tables_plain if plain else hip_lib().rt_sampler_tables
+    rc = fn(spp, dims, C.c_uint64(pixel0), C.c_uint64(n_pixels), _p(sc, C.c_uint32), _p(pm, C.c_uint16))
     if rc < 0:
         raise BackendError(f"rt_sampler_tables failed ({rc}): {hip_lib().rt_last_error().decode()}")
     return sc, pm

@@ -44,6 +44,10 @@ def main():
             tabs[f"t1_{spp}_{px}"] = t1
             tabs[f"t2_{spp}_{px}"] = t2
     np.savez_compressed(os.path.join(OUT, "sampler_tables_keyed.npz"), **tabs)
+    # Keyed pixels whose start_pixel stream contains a bounded-draw retry (rc/rng.rs:32-40): ~1e-5 of all pixels.
+    # The GPU sampler cuts the stream at fixed positions and must fall back for exactly these.
+    np.savez_compressed(os.path.join(OUT, "sampler_retry_pixels.npz"),
+                        spp1024=orc.sampler_retry_scan(1024, 4, 0, 300000), spp16384=orc.sampler_retry_scan(16384, 4, 0, 12000))
     print("wrote fixtures to", OUT)
 
 

@@ -97,6 +97,31 @@ def test_sampler_tables_match_golden(gpu_host):
             assert np.array_equal(bits(t1), bits(g[f"t1_{spp}_{px}"])) and np.array_equal(bits(t2), bits(g[f"t2_{spp}_{px}"]))
 
 
+@pytest.mark.parametrize("spp", [1024, 16384])
+def test_sampler_tables_retry_pixels(gpu_host, orc, spp):
+    """Pixels whose RNG stream holds a bounded-draw retry (found by the oracle, stored as a fixture): the segmented
+    jump-ahead sampler must detect them and fall back to the sequential stream."""
+    px = np.load(os.path.join(GOLD, "sampler_retry_pixels.npz"))[f"spp{spp}"]
+    assert len(px) >= 3
+    for p in px[:3]:
+        p = int(p)
+        assert len(orc.sampler_retry_scan(spp, 4, p, 1)) == 1  # the fixture still names a retry pixel
+        sc, pm = gpu_host.sampler_tables(spp, 4, p - 2, 5)     # two clean neighbours either side
+        for i in range(5):
+            t1, t2 = tables_from_perm(sc[i], pm[i], 4)
+            o1, o2, _ = orc.sampler_tables(spp, 4, 1, p - 2 + i)
+            assert np.array_equal(bits(t1), bits(o1)) and np.array_equal(bits(t2), bits(o2)), (spp, p, i)
+
+
+def test_sampler_segmented_equals_plain_over_a_large_range(gpu_host):
+    """The sampler rt_render uses (jump-ahead segments + pipelined shuffle + retry redo) against the single-kernel
+    in-order walk of the same stream, over a pixel range that holds retry pixels 8933 (spp 1024)."""
+    for spp, p0, n in ((1024, 8000, 2000), (256, 0, 5000), (8, 123456, 4097), (2, 7, 300)):
+        a = gpu_host.sampler_tables(spp, 4, p0, n)
+        b = gpu_host.sampler_tables(spp, 4, p0, n, plain=True)
+        assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1]), spp
+
+
 def test_light_distribution_matches_oracle_and_golden(gpu_host, orc, gold):
     d = _cornell(8, 8, 1)
     ldh = gpu_host.HostScene(d).light_distribution()
