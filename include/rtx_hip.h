@@ -183,7 +183,9 @@ int rt_render(rt_scene* scene, const rt_camera* camera, const rt_film_desc* film
 /* Kernel-level entry points used by the parity tests.
  * rays: n*8 floats (o.xyz, t_max, d.xyz, unused). closest: hits n*4 floats (t, prim as int bits
  * or -1, b0, b1) — BVH::intersect (rc/bvh/mod.rs:366-433). any: hits n uint32 0/1 —
- * BVH::intersect_p (:435-501). counters (optional): {node visits, triangle tests}. Host pointers. */
+ * BVH::intersect_p (:435-501). counters (optional): {node visits, triangle tests}; with counters the kernels
+ * that walk the tree one node per step (the reference's visit sequence) run, without them the kernels rt_render
+ * uses (same hits). Host pointers. */
 int rt_trace_closest(rt_scene* scene, const float* rays, uint64_t n, float* hits, uint64_t counters[2]);
 int rt_trace_any(rt_scene* scene, const float* rays, uint64_t n, uint32_t* occluded, uint64_t counters[2]);
 /* Same kernels on device-resident buffers, timed with HIP events on `stream` (bench): returns the

@@ -24,6 +24,7 @@ struct DLight {
 };
 struct DScene {
   const float4* nodes; unsigned n_nodes;
+  const float4* pairs;  // n_nodes x 64 B child-pair records of the interior nodes (NULL for LDS-resident scenes), see k_trace_pair
   const float4* tri_p; unsigned n_tris;
   const float* tri_n; const float* tri_uv; const float* tri_s;
   const DTexture* textures; const DImage* images; const DMaterial* materials; const DLight* lights;

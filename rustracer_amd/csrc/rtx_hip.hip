@@ -48,6 +48,8 @@ struct rt_scene {
   bool lambert_only = false;  // every material is matte{constant Kd, sigma == 0} and every light an area light: k_shade<1>
   int stack_depth = 64;  // entries the to-visit stack needs for this tree (<= 64, rc/bvh/mod.rs:374)
   unsigned n_nodes = 0, n_tris = 0; int n_lights = 0;
+  DevBuf pairs, tmin_stack;  // child-pair node records and the HBM half of the traversal stack (k_trace_pair)
+  bool use_pairs = false;
   DevBuf nodes, tri_p, tri_n, tri_uv, tri_s, textures, images, materials, lights, texels, dist;
   std::vector<DLight> h_lights;
   // light distribution tables (built per render, rc/integrator/path.rs:86-94)
@@ -258,6 +260,31 @@ extern "C" int rt_scene_create(const rt_scene_desc* desc, int device, rt_scene**
     if (maxd + 1 > 64) { delete s; return fail(RT_ERR_INVALID, "BVH deeper than the 64-entry traversal stack"); }
     s->stack_depth = maxd + 1;
   }
+  d.pairs = nullptr;
+  if (!s->small) {
+    // child-pair records for k_trace_pair: {A.min.xyz, A.max.x} {A.max.yz, code A, code B} {B.min.xyz, B.max.x} {B.max.yz, -, -}
+    bool ok = desc->n_nodes < (1u << 29) && desc->n_tris < (1u << 26);
+    auto code_of = [&](uint32_t c, bool& good) -> uint32_t {
+      const rt_bvh_node& n = desc->nodes[c];
+      if (n.n_prims > 0) { if (n.n_prims > 32) good = false; return 0x80000000u | n.offset | ((uint32_t)(n.n_prims - 1) << 26); }
+      return c | ((uint32_t)n.axis << 29);
+    };
+    std::vector<float> pr((size_t)desc->n_nodes * 16, 0.0f);
+    for (uint32_t i = 0; i < desc->n_nodes && ok; ++i) {
+      const rt_bvh_node& n = desc->nodes[i];
+      if (n.n_prims != 0) continue;
+      const rt_bvh_node& a = desc->nodes[i + 1]; const rt_bvh_node& b = desc->nodes[n.offset];
+      float* q = pr.data() + (size_t)i * 16;
+      uint32_t ca = code_of(i + 1, ok), cb = code_of(n.offset, ok);
+      q[0] = a.bmin[0]; q[1] = a.bmin[1]; q[2] = a.bmin[2]; q[3] = a.bmax[0]; q[4] = a.bmax[1]; q[5] = a.bmax[2]; memcpy(q + 6, &ca, 4); memcpy(q + 7, &cb, 4);
+      q[8] = b.bmin[0]; q[9] = b.bmin[1]; q[10] = b.bmin[2]; q[11] = b.bmax[0]; q[12] = b.bmax[1]; q[13] = b.bmax[2];
+    }
+    if (ok) {
+      int rc2 = upload(s->pairs, pr.data(), pr.size() * 4);
+      if (rc2 != RT_OK) { delete s; return rc2; }
+      d.pairs = s->pairs.as<float4>(); s->use_pairs = true;
+    }
+  }
   fill_ewa_lut();
   HIP_TRY(hipDeviceSynchronize());
   *out = s;
@@ -332,6 +359,26 @@ static void launch_trace_v(rt_scene* s, const float4* ro, const float4* rd, cons
   // persistent grid: enough workgroups to fill every CU at the kernel's LDS-limited residency
   const unsigned lds = (unsigned)(DEPTH * BLOCK * ((SMALL && !ANY) ? 2 : 4) + (SMALL ? (2 * RT_SMALL_NODES + 3 * RT_SMALL_TRIS) * 16 : 32));
   unsigned per_cu = (160u * 1024u) / lds; if (per_cu * BLOCK > 2048u) per_cu = 2048u / BLOCK; if (per_cu < 1) per_cu = 1;
+  if constexpr (!SMALL) {
+    // measurement knob RTX_TRACE: "plain" = one ray per lane per iteration, "refill" = persistent waves on the one-node-per-step
+    // loop, default = child-pair traversal (frames that count visits always use the one-node-per-step loops)
+    static const char* mode = getenv("RTX_TRACE");
+    const bool plain = mode && mode[0] == 'p', refill_only = mode && mode[0] == 'r';
+    if (!COUNT && !plain && !refill_only && s->use_pairs) {
+      const unsigned grid = (unsigned)s->n_cu * per_cu;
+      if (!ANY && s->tmin_stack.ensure((size_t)grid * BLOCK * DEPTH * 4) != hipSuccess) return;
+      static const bool ww = getenv("RTX_TRACE_WW") && getenv("RTX_TRACE_WW")[0] == '1';  // measurement knob; the single loop is faster
+      static const unsigned refill_min = getenv("RTX_REFILL_MIN") ? (unsigned)atoi(getenv("RTX_REFILL_MIN")) : (unsigned)RT_REFILL_MIN;
+      if (ww) hipLaunchKernelGGL((k_trace_pair<ANY, true, BLOCK, DEPTH>), dim3(grid), dim3(BLOCK), 0, stream, s->d, ro, rd, queue, count_ptr, shard_cap, count_static, hits, occ, stats, st_rays, lacc, direct_add, s->tmin_stack.as<float>(), refill_min);
+      else hipLaunchKernelGGL((k_trace_pair<ANY, false, BLOCK, DEPTH>), dim3(grid), dim3(BLOCK), 0, stream, s->d, ro, rd, queue, count_ptr, shard_cap, count_static, hits, occ, stats, st_rays, lacc, direct_add, s->tmin_stack.as<float>(), refill_min);
+      return;
+    }
+    if (!plain) {
+      hipLaunchKernelGGL((k_trace_big<ANY, COUNT, BLOCK, DEPTH>), dim3((unsigned)s->n_cu * per_cu), dim3(BLOCK), 0, stream, s->d, ro, rd, queue, count_ptr,
+                         shard_cap, count_static, hits, occ, stats, st_rays, st_nodes, st_tris, lacc, direct_add);
+      return;
+    }
+  }
   hipLaunchKernelGGL((k_trace<ANY, COUNT, SMALL, BLOCK, DEPTH>), dim3((unsigned)s->n_cu * per_cu), dim3(BLOCK), 0, stream, s->d, ro, rd, queue, count_ptr,
                      shard_cap, count_static, hits, occ, stats, st_rays, st_nodes, st_tris, lacc, direct_add);
 }
@@ -370,8 +417,8 @@ static int trace_batch(rt_scene* s, const float* rays, uint64_t n, bool any, flo
   HIP_TRY(hipMemcpy(ro.p, o.data(), n * 16, hipMemcpyHostToDevice));
   HIP_TRY(hipMemcpy(rd.p, d.data(), n * 16, hipMemcpyHostToDevice));
   HIP_TRY(hipMemset(st.p, 0, ST_COUNT * 8));
-  if (any) launch_trace<true>(s, true, ro.as<float4>(), rd.as<float4>(), nullptr, nullptr, 0, (unsigned)n, nullptr, out.as<unsigned>(), st.as<unsigned long long>(), ST_RAYS_SHADOW, ST_NODES_SHADOW, ST_TRIS_SHADOW, nullptr);
-  else launch_trace<false>(s, true, ro.as<float4>(), rd.as<float4>(), nullptr, nullptr, 0, (unsigned)n, out.as<float4>(), nullptr, st.as<unsigned long long>(), ST_RAYS_CLOSEST, ST_NODES_CLOSEST, ST_TRIS_CLOSEST, nullptr);
+  if (any) launch_trace<true>(s, counters != nullptr, ro.as<float4>(), rd.as<float4>(), nullptr, nullptr, 0, (unsigned)n, nullptr, out.as<unsigned>(), st.as<unsigned long long>(), ST_RAYS_SHADOW, ST_NODES_SHADOW, ST_TRIS_SHADOW, nullptr);
+  else launch_trace<false>(s, counters != nullptr, ro.as<float4>(), rd.as<float4>(), nullptr, nullptr, 0, (unsigned)n, out.as<float4>(), nullptr, st.as<unsigned long long>(), ST_RAYS_CLOSEST, ST_NODES_CLOSEST, ST_TRIS_CLOSEST, nullptr);
   HIP_TRY(hipGetLastError());
   HIP_TRY(hipDeviceSynchronize());
   if (any) HIP_TRY(hipMemcpy(occluded, out.p, n * 4, hipMemcpyDeviceToHost));

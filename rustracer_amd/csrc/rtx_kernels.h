@@ -516,6 +516,272 @@ __global__ void __launch_bounds__(BLOCK) k_trace(DScene sc, const float4* __rest
   }
 }
 
+// ---- K2/K4 for scenes that live in HBM. Ray lengths then vary by an order of magnitude (a camera ray that
+// misses the root box ends after one node, one that grazes a silhouette visits a hundred), and with one ray per
+// lane per grid-stride iteration a wave runs as long as its longest ray with most lanes idle (measured: 11 of 64
+// lanes active per VALU instruction on the 1M-triangle scene). Here a wave is persistent and keeps its lanes
+// fed: whenever RT_REFILL_MIN or more lanes have finished their ray, they take the next unclaimed rays of the
+// wave's share of the queue (64-entry blocks, interleaved over the waves of the grid so that every wave samples
+// the whole queue and the shares finish together; no atomics). The per-ray sequence of node visits and
+// triangle tests is unchanged (closest-hit: descend to a leaf, then test its triangles; results bit-identical).
+#ifndef RT_REFILL_MIN
+#define RT_REFILL_MIN 16
+#endif
+template <bool ANY, bool COUNT, int BLOCK, int DEPTH>
+__global__ void __launch_bounds__(BLOCK) k_trace_big(DScene sc, const float4* __restrict__ ray_o, const float4* __restrict__ ray_d,
+                                                     const unsigned* __restrict__ queue, const unsigned* __restrict__ shard_counts, unsigned shard_cap, unsigned count_static,
+                                                     float4* __restrict__ hits, unsigned* __restrict__ occluded, unsigned long long* stats,
+                                                     int st_rays, int st_nodes, int st_tris, float4* __restrict__ lacc, const float4* __restrict__ direct_add) {
+  __shared__ int stack_mem[DEPTH * BLOCK];
+  int* const stack = stack_mem + threadIdx.x;
+  QView qv; if (queue) qv.init(queue, shard_counts, shard_cap);
+  const unsigned count = queue ? qv.total() : count_static;
+  const unsigned lane = __lane_id();
+  const unsigned n_waves = gridDim.x * (BLOCK / 64), wave = blockIdx.x * (BLOCK / 64) + (threadIdx.x >> 6);
+  const GlobalSrc src{sc.nodes, sc.tri_p};
+  unsigned n_nodes = 0, n_tris = 0, n_rays = 0;
+  // wave-uniform cursor over the wave's share: virtual entry v -> queue entry ((v / 64) * n_waves + wave) * 64 + v % 64
+  unsigned cursor = 0;
+  bool exhausted = (unsigned long long)wave * 64ull >= count;
+  // per-lane ray state
+  bool active = false, found = false;
+  unsigned pid = 0; float dw = 0.0f;
+  Ray ray; ray.o = ray.d = mk3(0, 0, 0); ray.t_max = 0.0f;
+  f3 inv_dir = mk3(0, 0, 0); int neg_x = 0, neg_y = 0, neg_z = 0; RayPre rp = ray_pre(ray);
+  int sp = 0, cur = 0, prim = -1; TriHit hit; hit.t = kInf; hit.b0 = hit.b1 = hit.b2 = 0.0f;
+
+  auto finish = [&]() {  // the lane's ray is complete: write its result (same epilogue as k_trace)
+    if (ANY) {
+      if (lacc != nullptr && dw != 0.0f) {
+        if (!found) { float4 a = direct_add[pid]; float4 l = lacc[pid]; lacc[pid] = make_float4(l.x + a.x, l.y + a.y, l.z + a.z, l.w); }
+      } else occluded[pid] = found ? 1u : 0u;
+    } else hits[pid] = make_float4(lacc != nullptr ? hit.b2 : (found ? hit.t : kInf), __int_as_float(found ? prim : -1), hit.b0, hit.b1);
+    active = false;
+  };
+
+  for (;;) {
+    const unsigned long long idle = __ballot(!active);
+    if (!exhausted && (unsigned)__popcll(idle) >= (idle == ~0ull ? 1u : (unsigned)RT_REFILL_MIN)) {
+      const unsigned v = cursor + (unsigned)__popcll(idle & ((1ull << lane) - 1ull));
+      const unsigned long long e = ((unsigned long long)(v >> 6) * n_waves + wave) * 64ull + (v & 63u);
+      if (!active && e < count) {
+        pid = queue ? qv.get((unsigned)e) : (unsigned)e;
+        const float4 o4 = ray_o[pid], d4 = ray_d[pid];
+        ray.o = mk3(o4.x, o4.y, o4.z); ray.d = mk3(d4.x, d4.y, d4.z); ray.t_max = o4.w; dw = d4.w;
+        inv_dir = mk3(1.0f / ray.d.x, 1.0f / ray.d.y, 1.0f / ray.d.z);
+        neg_x = inv_dir.x < 0.0f; neg_y = inv_dir.y < 0.0f; neg_z = inv_dir.z < 0.0f;
+        rp = ray_pre(ray);
+        sp = 0; cur = 0; prim = -1; found = false; hit.t = kInf; hit.b0 = hit.b1 = hit.b2 = 0.0f;
+        active = true; n_rays += 1;
+      }
+      cursor += (unsigned)__popcll(idle);
+      exhausted = ((unsigned long long)(cursor >> 6) * n_waves + wave) * 64ull + (cursor & 63u) >= count;  // entries grow with the cursor
+    }
+    if (__ballot(active) == 0ull) { if (exhausted) break; else continue; }
+    // ---- descend to the next leaf whose box the ray enters
+    int leaf_off = 0, leaf_n = 0;
+    while (active && leaf_n == 0) {
+      float4 n0, n1;
+      src.node(cur, n0, n1);
+      if (COUNT) n_nodes += 1;
+      if (slab_test(n0, n1, ray, inv_dir, neg_x, neg_y, neg_z)) {
+        const unsigned packed = __float_as_uint(n1.w);
+        const int n_prims = (int)(packed & 0xffffu);
+        const int offset = __float_as_int(n1.z);
+        if (n_prims > 0) { leaf_off = offset; leaf_n = n_prims; break; }
+        const int axis = (int)((packed >> 16) & 0xffu);
+        const int neg = axis == 0 ? neg_x : (axis == 1 ? neg_y : neg_z);
+        if (neg) { stack[(sp++) * BLOCK] = cur + 1; cur = offset; }
+        else { stack[(sp++) * BLOCK] = offset; cur = cur + 1; }
+      } else {
+        if (sp == 0) { finish(); break; }
+        cur = stack[(--sp) * BLOCK];
+      }
+    }
+    // ---- test the leaf's triangles
+    if (active) {
+      for (int i = 0; i < leaf_n; ++i) {
+        f3 p0, p1, p2;
+        src.tri(leaf_off + i, p0, p1, p2);
+        if (COUNT) n_tris += 1;
+        TriHit h;
+        if (tri_test_pre(p0, p1, p2, ray, rp, h)) {
+          found = true;
+          if (ANY) break;
+          ray.t_max = h.t; prim = leaf_off + i; hit = h;  // `.or(result)`: later accepted hits replace
+        }
+      }
+      if ((ANY && found) || sp == 0) finish();
+      else cur = stack[(--sp) * BLOCK];
+    }
+  }
+  if (stats) {
+    for (int off = 32; off > 0; off >>= 1) { n_rays += __shfl_down(n_rays, off); if (COUNT) { n_nodes += __shfl_down(n_nodes, off); n_tris += __shfl_down(n_tris, off); } }
+    if (lane == 0u) {
+      if (n_rays) atomicAdd(&stats[st_rays], (unsigned long long)n_rays);
+      if (COUNT) { atomicAdd(&stats[st_nodes], (unsigned long long)n_nodes); atomicAdd(&stats[st_tris], (unsigned long long)n_tris); }
+    }
+  }
+}
+
+// ---- child-pair traversal (HBM scenes, frames that do not count visits). The reference visits one node per
+// step: fetch its box, test, then pop or descend (rc/bvh/mod.rs:381-425) - every step is a dependent round trip
+// to memory, and on a scene that does not fit the caches the kernel is bound by exactly that latency. Here an
+// interior node P is expanded in one step: a 64-byte record (DScene::pairs, built at rt_scene_create) holds the
+// boxes of both children and what each child is; the near child's test is the reference's test at that moment,
+// the far child's slab arithmetic is done now and its only ray-state-dependent clause, tmin < t_max, is
+// re-evaluated with the then-current t_max when the entry is popped (t_max only shrinks, so a far child that
+// fails now is never pushed). The decisions, the order of triangle tests and therefore the hit record are
+// identical to the reference's; the number of dependent fetches per ray roughly halves.
+//   child code: bit 31 clear: interior node, bits 0-28 node index, bits 29-30 split axis
+//               bit 31 set  : leaf, bits 0-25 first triangle, bits 26-30 triangle count - 1
+RT_DEV bool slab_geom(float4 n0, float4 n1, const Ray& ray, f3 inv_dir, int neg_x, int neg_y, int neg_z, float& tmin_out) {
+  // Bounds3::intersect_p_fast (bounds.rs:127-157) without its `tmin < ray.t_max` clause; same operations, same order
+  float bx0 = neg_x ? n0.w : n0.x, bx1 = neg_x ? n0.x : n0.w;
+  float by0 = neg_y ? n1.x : n0.y, by1 = neg_y ? n0.y : n1.x;
+  float bz0 = neg_z ? n1.y : n0.z, bz1 = neg_z ? n0.z : n1.y;
+  float tmin = (bx0 - ray.o.x) * inv_dir.x;
+  float tmax = (bx1 - ray.o.x) * inv_dir.x;
+  float tymin = (by0 - ray.o.y) * inv_dir.y;
+  float tymax = (by1 - ray.o.y) * inv_dir.y;
+  if ((tmin > tymax) || (tymin > tmax)) return false;
+  if (tymin > tmin) tmin = tymin;
+  if (tymax < tmax) tmax = tymax;
+  float tzmin = (bz0 - ray.o.z) * inv_dir.z;
+  float tzmax = (bz1 - ray.o.z) * inv_dir.z;
+  if ((tmin > tzmax) || (tzmin > tmax)) return false;
+  if (tzmin > tmin) tmin = tzmin;
+  if (tzmax < tmax) tmax = tzmax;
+  tmin_out = tmin;
+  return tmax > 0.0f;
+}
+#define RT_PAIR_LEAF 0x80000000u
+
+// per-lane traversal state and the output arrays a finished ray is written to
+struct PairLane {
+  bool active, found; unsigned pid; float dw;
+  Ray ray; f3 inv_dir; int neg_x, neg_y, neg_z; RayPre rp;
+  int sp, prim; unsigned cur; TriHit hit;
+};
+struct TraceOut { float4* hits; unsigned* occluded; float4* lacc; const float4* direct_add; };
+template <bool ANY>
+RT_DEV void pair_finish(PairLane& L, const TraceOut& o) {  // same epilogue as k_trace
+  if (ANY) {
+    if (o.lacc != nullptr && L.dw != 0.0f) {
+      if (!L.found) { float4 a = o.direct_add[L.pid]; float4 l = o.lacc[L.pid]; o.lacc[L.pid] = make_float4(l.x + a.x, l.y + a.y, l.z + a.z, l.w); }
+    } else o.occluded[L.pid] = L.found ? 1u : 0u;
+  } else o.hits[L.pid] = make_float4(o.lacc != nullptr ? L.hit.b2 : (L.found ? L.hit.t : kInf), __int_as_float(L.found ? L.prim : -1), L.hit.b0, L.hit.b1);
+  L.active = false;
+}
+// next pending entry that still passes tmin < t_max, or the ray is complete
+template <bool ANY, int BLOCK>
+RT_DEV void pair_pop(PairLane& L, const TraceOut& o, const unsigned* stack, const float* tstack, size_t grid_lanes) {
+  for (;;) {
+    if (L.sp == 0) { pair_finish<ANY>(L, o); return; }
+    --L.sp;
+    const unsigned c = stack[L.sp * BLOCK];
+    if (ANY) { L.cur = c; return; }  // t_max never changes: the test at push time stands
+    if (tstack[(size_t)L.sp * grid_lanes] < L.ray.t_max) { L.cur = c; return; }
+  }
+}
+template <bool ANY, int BLOCK>
+RT_DEV void pair_interior_step(PairLane& L, const TraceOut& o, const float4* __restrict__ pairs, unsigned* stack, float* tstack, size_t grid_lanes) {
+  const unsigned P = L.cur & 0x1fffffffu, axis = (L.cur >> 29) & 3u;
+  const float4 a0 = pairs[4 * (size_t)P], a1 = pairs[4 * (size_t)P + 1], b0 = pairs[4 * (size_t)P + 2], b1 = pairs[4 * (size_t)P + 3];
+  const bool neg = (axis == 0u ? L.neg_x : (axis == 1u ? L.neg_y : L.neg_z)) != 0;
+  // reference: negative direction along the split axis => second child first (bvh/mod.rs:411-417)
+  const float4 n0 = neg ? b0 : a0, n1 = neg ? b1 : a1, f0 = neg ? a0 : b0, f1 = neg ? a1 : b1;
+  const unsigned code_a = __float_as_uint(a1.z), code_b = __float_as_uint(a1.w);
+  const unsigned code_n = neg ? code_b : code_a, code_f = neg ? code_a : code_b;
+  float tmin_n = 0.0f, tmin_f = 0.0f;
+  const bool hit_n = slab_geom(n0, n1, L.ray, L.inv_dir, L.neg_x, L.neg_y, L.neg_z, tmin_n) && tmin_n < L.ray.t_max;
+  const bool keep_f = slab_geom(f0, f1, L.ray, L.inv_dir, L.neg_x, L.neg_y, L.neg_z, tmin_f) && tmin_f < L.ray.t_max;
+  if (hit_n) {
+    if (keep_f) { stack[L.sp * BLOCK] = code_f; if (!ANY) tstack[(size_t)L.sp * grid_lanes] = tmin_f; ++L.sp; }
+    L.cur = code_n;
+  } else if (keep_f) L.cur = code_f;
+  else pair_pop<ANY, BLOCK>(L, o, stack, tstack, grid_lanes);
+}
+template <bool ANY, int BLOCK>
+RT_DEV void pair_leaf_step(PairLane& L, const TraceOut& o, const float4* __restrict__ tri_p, const unsigned* stack, const float* tstack, size_t grid_lanes) {
+  const int off = (int)(L.cur & 0x03ffffffu), n = (int)((L.cur >> 26) & 31u) + 1;
+  for (int i = 0; i < n; ++i) {
+    f3 p0, p1, p2;
+    load_tri(tri_p, off + i, p0, p1, p2);
+    TriHit h;
+    if (tri_test_pre(p0, p1, p2, L.ray, L.rp, h)) {
+      L.found = true;
+      if (ANY) break;
+      L.ray.t_max = h.t; L.prim = off + i; L.hit = h;  // `.or(result)`: later accepted hits replace
+    }
+  }
+  if (ANY && L.found) pair_finish<ANY>(L, o); else pair_pop<ANY, BLOCK>(L, o, stack, tstack, grid_lanes);
+}
+
+template <bool ANY, bool WW, int BLOCK, int DEPTH>
+__global__ void __launch_bounds__(BLOCK) k_trace_pair(DScene sc, const float4* __restrict__ ray_o, const float4* __restrict__ ray_d,
+                                                      const unsigned* __restrict__ queue, const unsigned* __restrict__ shard_counts, unsigned shard_cap, unsigned count_static,
+                                                      float4* __restrict__ hits, unsigned* __restrict__ occluded, unsigned long long* stats, int st_rays,
+                                                      float4* __restrict__ lacc, const float4* __restrict__ direct_add, float* __restrict__ tmin_stack_mem, unsigned refill_min) {
+  __shared__ unsigned stack_mem[DEPTH * BLOCK];
+  unsigned* const stack = stack_mem + threadIdx.x;
+  // the deferred tmin of each stack entry lives in HBM, [depth][lane of the grid]: a push is a fire-and-forget
+  // store and a pop's load is the only extra latency
+  const size_t grid_lanes = (size_t)gridDim.x * BLOCK;
+  float* const tstack = tmin_stack_mem + (size_t)blockIdx.x * BLOCK + threadIdx.x;
+  QView qv; if (queue) qv.init(queue, shard_counts, shard_cap);
+  const unsigned count = queue ? qv.total() : count_static;
+  const unsigned lane = __lane_id();
+  const unsigned n_waves = gridDim.x * (BLOCK / 64), wave = blockIdx.x * (BLOCK / 64) + (threadIdx.x >> 6);
+  const float4* __restrict__ pairs = sc.pairs; const float4* __restrict__ tri_p = sc.tri_p; const float4* __restrict__ nodes = sc.nodes;
+  const TraceOut out{hits, occluded, lacc, direct_add};
+  unsigned n_rays = 0;
+  unsigned cursor = 0;
+  bool exhausted = (unsigned long long)wave * 64ull >= count;
+  PairLane L;
+  L.active = false; L.found = false; L.pid = 0; L.dw = 0.0f;
+  L.ray.o = L.ray.d = mk3(0, 0, 0); L.ray.t_max = 0.0f; L.inv_dir = mk3(0, 0, 0); L.neg_x = L.neg_y = L.neg_z = 0; L.rp = ray_pre(L.ray);
+  L.sp = 0; L.prim = -1; L.cur = 0; L.hit.t = kInf; L.hit.b0 = L.hit.b1 = L.hit.b2 = 0.0f;
+
+  for (;;) {
+    const unsigned long long idle = __ballot(!L.active);
+    if (!exhausted && (unsigned)__popcll(idle) >= (idle == ~0ull ? 1u : refill_min)) {
+      const unsigned v = cursor + (unsigned)__popcll(idle & ((1ull << lane) - 1ull));
+      const unsigned long long e = ((unsigned long long)(v >> 6) * n_waves + wave) * 64ull + (v & 63u);
+      if (!L.active && e < count) {
+        L.pid = queue ? qv.get((unsigned)e) : (unsigned)e;
+        const float4 o4 = ray_o[L.pid], d4 = ray_d[L.pid];
+        L.ray.o = mk3(o4.x, o4.y, o4.z); L.ray.d = mk3(d4.x, d4.y, d4.z); L.ray.t_max = o4.w; L.dw = d4.w;
+        L.inv_dir = mk3(1.0f / L.ray.d.x, 1.0f / L.ray.d.y, 1.0f / L.ray.d.z);
+        L.neg_x = L.inv_dir.x < 0.0f; L.neg_y = L.inv_dir.y < 0.0f; L.neg_z = L.inv_dir.z < 0.0f;
+        L.rp = ray_pre(L.ray);
+        L.sp = 0; L.prim = -1; L.found = false; L.hit.t = kInf; L.hit.b0 = L.hit.b1 = L.hit.b2 = 0.0f;
+        L.active = true; n_rays += 1;
+        // the root is the one node tested on its own
+        const float4 r0 = nodes[0], r1 = nodes[1];
+        if (slab_test(r0, r1, L.ray, L.inv_dir, L.neg_x, L.neg_y, L.neg_z)) {
+          const unsigned packed = __float_as_uint(r1.w), np = packed & 0xffffu;
+          L.cur = np > 0u ? (RT_PAIR_LEAF | (unsigned)__float_as_int(r1.z) | ((np - 1u) << 26)) : (((packed >> 16) & 0xffu) << 29);
+        } else pair_finish<ANY>(L, out);
+      }
+      cursor += (unsigned)__popcll(idle);
+      exhausted = ((unsigned long long)(cursor >> 6) * n_waves + wave) * 64ull + (cursor & 63u) >= count;
+    }
+    if (__ballot(L.active) == 0ull) { if (exhausted) break; else continue; }
+    if (WW) {
+      while (L.active && !(L.cur & RT_PAIR_LEAF)) pair_interior_step<ANY, BLOCK>(L, out, pairs, stack, tstack, grid_lanes);
+      if (L.active) pair_leaf_step<ANY, BLOCK>(L, out, tri_p, stack, tstack, grid_lanes);
+    } else if (L.active) {
+      if (L.cur & RT_PAIR_LEAF) pair_leaf_step<ANY, BLOCK>(L, out, tri_p, stack, tstack, grid_lanes);
+      else pair_interior_step<ANY, BLOCK>(L, out, pairs, stack, tstack, grid_lanes);
+    }
+  }
+  if (stats) {
+    for (int off = 32; off > 0; off >>= 1) n_rays += __shfl_down(n_rays, off);
+    if (lane == 0u && n_rays) atomicAdd(&stats[st_rays], (unsigned long long)n_rays);
+  }
+}
+
 // ================================================================================ K3 shade
 struct PathSampler {  // ZeroTwoSequence::get_1d / get_2d (zerotwosequence.rs:158-180) for one (pixel, sample)
   Tables tb; unsigned pix, s; int c1, c2; Pcg32 rng;

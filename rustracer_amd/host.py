@@ -220,16 +220,19 @@ class HostScene:
         _check(lib().rtxh_render(self.h, C.byref(p), C.c_void_p(stream), _p(film), C.byref(stats)), "render")
         return film, stats.as_dict()
 
-    def trace(self, rays, any_hit=False):
+    def trace(self, rays, any_hit=False, count=True):
+        """count=True: the visit-counting kernels (one node per step, the reference's sequence); count=False: the
+        kernels rt_render launches (same hit records, no counters)."""
         rays = np.ascontiguousarray(rays, np.float32)
         n = rays.shape[0]
         cnt = np.zeros(2, np.uint64)
+        pc = _p(cnt, C.c_uint64) if count else None
         if any_hit:
             occ = np.zeros(n, np.uint32)
-            _check(lib().rtxh_trace(self.h, _p(rays), C.c_uint64(n), 1, occ.ctypes.data_as(C.POINTER(C.c_float)), _p(cnt, C.c_uint64)), "trace_any")
+            _check(lib().rtxh_trace(self.h, _p(rays), C.c_uint64(n), 1, occ.ctypes.data_as(C.POINTER(C.c_float)), pc), "trace_any")
             return dict(occluded=occ > 0, nodes=int(cnt[0]), tris=int(cnt[1]))
         out = np.zeros((n, 4), np.float32)
-        _check(lib().rtxh_trace(self.h, _p(rays), C.c_uint64(n), 0, _p(out), _p(cnt, C.c_uint64)), "trace_closest")
+        _check(lib().rtxh_trace(self.h, _p(rays), C.c_uint64(n), 0, _p(out), pc), "trace_closest")
         return dict(t=out[:, 0].copy(), prim=out[:, 1].copy().view(np.int32), b0=out[:, 2].copy(), b1=out[:, 3].copy(), nodes=int(cnt[0]), tris=int(cnt[1]))
 
     def trace_device(self, d_rays_ptr, n, d_hits_ptr, reps=10, stream=0):

@@ -54,9 +54,12 @@ def test_trace_kernels_match_oracle_on_soups(gpu_host, orc, n_tris, max_prims):
         assert np.array_equal(bits(ro[k]), bits(rh[k])), k
     assert (ro["nodes"], ro["tris"]) == (rh["nodes"], rh["tris"])
     assert (ro["prim"] >= 0).mean() > 0.02
+    rr = h.trace(rays, count=False)  # the kernels rt_render launches
+    assert np.array_equal(ro["prim"], rr["prim"]) and all(np.array_equal(bits(ro[k]), bits(rr[k])) for k in ("t", "b0", "b1"))
     rays[:, 3] = np.random.default_rng(4).uniform(1, 150, len(rays)).astype(np.float32)
     ao, ah = o.trace(rays, True), h.trace(rays, True)
     assert np.array_equal(ao["occluded"], ah["occluded"]) and (ao["nodes"], ao["tris"]) == (ah["nodes"], ah["tris"])
+    assert np.array_equal(ao["occluded"], h.trace(rays, True, count=False)["occluded"])
 
 
 def test_trace_edge_cases(gpu_host, orc):

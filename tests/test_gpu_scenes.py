@@ -53,9 +53,14 @@ def test_scene_trace_bit_exact(gpu_host, orc, name):
         assert np.array_equal(bits(ro[k]), bits(rh[k])), k
     assert (ro["nodes"], ro["tris"]) == (rh["nodes"], rh["tris"])
     assert (ro["prim"] >= 0).mean() > 0.05
+    rr = h.trace(rays, count=False)  # the kernels rt_render launches (child-pair traversal for HBM scenes)
+    assert np.array_equal(ro["prim"], rr["prim"])
+    for k in ("t", "b0", "b1"):
+        assert np.array_equal(bits(ro[k]), bits(rr[k])), k
     rays[:, 3] = np.random.default_rng(4).uniform(0.1, float(np.linalg.norm(hi - lo)), len(rays)).astype(np.float32)
     ao, ah = o.trace(rays, True), h.trace(rays, True)
     assert np.array_equal(ao["occluded"], ah["occluded"]) and (ao["nodes"], ao["tris"]) == (ah["nodes"], ah["tris"])
+    assert np.array_equal(ao["occluded"], h.trace(rays, True, count=False)["occluded"])
 
 
 def test_scene_light_distribution_bit_exact(gpu_host, orc):
