@@ -261,7 +261,7 @@ extern "C" int rt_scene_create(const rt_scene_desc* desc, int device, rt_scene**
     s->stack_depth = maxd + 1;
   }
   d.pairs = nullptr;
-  if (!s->small) {
+  if (!s->small) {  // LDS-resident scenes keep the one-node-per-step loop: the pair form measured no faster there
     // child-pair records for k_trace_pair: {A.min.xyz, A.max.x} {A.max.yz, code A, code B} {B.min.xyz, B.max.x} {B.max.yz, -, -}
     bool ok = desc->n_nodes < (1u << 29) && desc->n_tris < (1u << 26);
     auto code_of = [&](uint32_t c, bool& good) -> uint32_t {
@@ -616,6 +616,7 @@ extern "C" int rt_render(rt_scene* s, const rt_camera* cam, const rt_film_desc* 
   fp.max_depth = (int)(uint8_t)path->max_depth; fp.rr_threshold = path->rr_threshold;
   fp.pb_x0 = path->pixel_bounds[0]; fp.pb_y0 = path->pixel_bounds[1]; fp.pb_x1 = path->pixel_bounds[2]; fp.pb_y1 = path->pixel_bounds[3];
   fp.rank = rank; fp.world = world;
+  fp.w_recip = W > 1 ? (unsigned)((1ull << 32) / (unsigned long long)W) : 0u;
 
   // owned sample rows (tile rows of 16, interleaved over ranks)
   unsigned long long owned_rows = 0;
@@ -631,6 +632,9 @@ extern "C" int rt_render(rt_scene* s, const rt_camera* cam, const rt_film_desc* 
   if (rc != RT_OK) return rc;
   tm.end();
 
+  // pixel_bounds (path.rs:30) that do not crop the sample bounds: every generated sample is traced
+  const bool all_in_bounds = path->pixel_bounds[0] <= film->sample_bounds[0] && path->pixel_bounds[2] >= film->sample_bounds[2] &&
+                             path->pixel_bounds[1] <= film->sample_bounds[1] && path->pixel_bounds[3] >= film->sample_bounds[3];
   // batch / pass sizing. A batch is a range of owned pixels whose sampler tables (2*dims u16 per sample) are built
   // at once; it is rendered in passes of n_samples consecutive samples of all its pixels, ~2^23 paths per pass.
   const unsigned long long target_paths = 1ull << 23;
@@ -653,7 +657,8 @@ extern "C" int rt_render(rt_scene* s, const rt_camera* cam, const rt_film_desc* 
   const size_t szq = (size_t)shard_cap * RT_QSHARDS * 4;
   const size_t sizes[] = {sz16, sz16, sz16, sz16, sz16, sz8, sz8, sz16, sz16, sz4, sz16, sz16, sz16, sz16, sz16, sz16, sz4, szq, szq, szq, szq};
   for (int i = 0; i < 21; ++i) HIP_TRY(s->ws[i].ensure(sizes[i]));
-  HIP_TRY(s->counters.ensure(4 * RT_QSHARDS * 4)); HIP_TRY(s->stats.ensure(ST_COUNT * 8));
+  const size_t counter_words = (size_t)(fp.max_depth + 2) * 3 * RT_QSHARDS;  // one block of {out, shadow, mis} shard counts per bounce + raygen's
+  HIP_TRY(s->counters.ensure(counter_words * 4)); HIP_TRY(s->stats.ensure(ST_COUNT * 8));
   HIP_TRY(s->film_acc.ensure((size_t)cw * ch * 16)); HIP_TRY(s->own_acc.ensure(chunk_pixels * 16));
   HIP_TRY(s->filter_table.ensure(1024));
   const bool multi_batch = owned_pixels > chunk_pixels;
@@ -681,7 +686,7 @@ extern "C" int rt_render(rt_scene* s, const rt_camera* cam, const rt_film_desc* 
   ps.pend_a = s->ws[B_PA].as<float4>(); ps.pend_b = s->ws[B_PB].as<float4>(); ps.pend_c = s->ws[B_PC].as<float4>(); ps.pend_flags = s->ws[B_PF].as<unsigned>();
   unsigned* q_a = s->ws[B_QIN].as<unsigned>(); unsigned* q_b = s->ws[B_QOUT].as<unsigned>();
   ps.q_shadow = s->ws[B_QSH].as<unsigned>(); ps.q_mis = s->ws[B_QMI].as<unsigned>();
-  ps.own_acc = s->own_acc.as<float4>(); ps.counters = s->counters.as<unsigned>(); ps.shard_cap = shard_cap; ps.stats = s->stats.as<unsigned long long>();
+  ps.own_acc = s->own_acc.as<float4>(); ps.shard_cap = shard_cap; ps.stats = s->stats.as<unsigned long long>();
 
   if ((rc = sampler_plan_prepare(s->sampler_plan, spp, dims)) != RT_OK) return rc;
   if ((rc = sampler_set_lds_limits(spp)) != RT_OK) return rc;
@@ -721,29 +726,35 @@ extern "C" int rt_render(rt_scene* s, const rt_camera* cam, const rt_film_desc* 
     for (unsigned s0 = 0; s0 < spp; s0 += pass_samples) {
       ps.s0 = s0; ps.n_samples = std::min(pass_samples, spp - s0); ps.cap = (unsigned)(npx * ps.n_samples);
       ps.q_in = q_a; ps.q_out = q_b;
-      HIP_TRY(hipMemsetAsync(s->counters.p, 0, 4 * RT_QSHARDS * 4, stream));
+      HIP_TRY(hipMemsetAsync(s->counters.p, 0, counter_words * 4, stream));
+      unsigned* const cb = s->counters.as<unsigned>();
+      ps.cnt_in = nullptr; ps.cnt_out = cb;  // raygen appends to block 0's `out` queue
+      ps.all_in_bounds = all_in_bounds ? 1 : 0;
       tm.begin(&stats.ms_raygen);
       hipLaunchKernelGGL(k_raygen, dim3(pgrid), dim3(256), 0, stream, fp, ps);
       tm.end();
       for (int bounce = 0; bounce <= fp.max_depth; ++bounce) {
+        ps.cnt_in = cb + (size_t)bounce * 3 * RT_QSHARDS; ps.cnt_out = cb + (size_t)(bounce + 1) * 3 * RT_QSHARDS;
+        unsigned* const q_first = ps.q_in;
+        if (bounce == 0 && all_in_bounds) ps.q_in = nullptr;  // identity: path i is entry i
         tm.begin(&stats.ms_trace_closest);
-        launch_trace<false>(s, count, ps.ray_o, ps.ray_d, ps.q_in, &ps.counters[0], ps.shard_cap, 0, ps.hit, nullptr, dstats, ST_RAYS_CLOSEST, ST_NODES_CLOSEST, ST_TRIS_CLOSEST, stream, ps.lacc, nullptr);
+        launch_trace<false>(s, count, ps.ray_o, ps.ray_d, ps.q_in, ps.cnt_in, ps.shard_cap, ps.cap, ps.hit, nullptr, dstats, ST_RAYS_CLOSEST, ST_NODES_CLOSEST, ST_TRIS_CLOSEST, stream, ps.lacc, nullptr);
         tm.end();
         tm.begin(&stats.ms_shade);
         if (s->lambert_only) hipLaunchKernelGGL(k_shade<1>, dim3(pgrid), dim3(256), 0, stream, s->d, fp, ps);
         else hipLaunchKernelGGL(k_shade<0>, dim3(pgrid), dim3(256), 0, stream, s->d, fp, ps);
         tm.end();
         tm.begin(&stats.ms_trace_any);
-        launch_trace<true>(s, count, ps.sh_o, ps.sh_d, ps.q_shadow, &ps.counters[2 * RT_QSHARDS], ps.shard_cap, 0, nullptr, ps.sh_occ, dstats, ST_RAYS_SHADOW, ST_NODES_SHADOW, ST_TRIS_SHADOW, stream, ps.lacc, ps.pend_a);
+        launch_trace<true>(s, count, ps.sh_o, ps.sh_d, ps.q_shadow, ps.cnt_out + RT_QSHARDS, ps.shard_cap, 0, nullptr, ps.sh_occ, dstats, ST_RAYS_SHADOW, ST_NODES_SHADOW, ST_TRIS_SHADOW, stream, ps.lacc, ps.pend_a);
         tm.end();
         tm.begin(&stats.ms_trace_mis);
-        launch_trace<false>(s, count, ps.mi_o, ps.mi_d, ps.q_mis, &ps.counters[3 * RT_QSHARDS], ps.shard_cap, 0, ps.mi_hit, nullptr, dstats, ST_RAYS_MIS, ST_NODES_MIS, ST_TRIS_MIS, stream);
+        launch_trace<false>(s, count, ps.mi_o, ps.mi_d, ps.q_mis, ps.cnt_out + 2 * RT_QSHARDS, ps.shard_cap, 0, ps.mi_hit, nullptr, dstats, ST_RAYS_MIS, ST_NODES_MIS, ST_TRIS_MIS, stream);
         tm.end();
         tm.begin(&stats.ms_resolve);
-        hipLaunchKernelGGL(k_resolve, dim3(pgrid), dim3(256), 0, stream, s->d, ps);
-        hipLaunchKernelGGL(k_next_bounce, dim3(1), dim3(64), 0, stream, ps.counters);
+        hipLaunchKernelGGL(k_resolve, dim3((unsigned)s->n_cu), dim3(256), 0, stream, s->d, ps);  // a short queue: one block per CU
         tm.end();
         stats.launches_trace_closest += 2;
+        ps.q_in = q_first;
         std::swap(ps.q_in, ps.q_out);
       }
       tm.begin(&stats.ms_film);

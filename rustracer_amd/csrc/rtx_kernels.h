@@ -34,9 +34,12 @@ struct PassState {
   float4* pend_a; float4* pend_b; float4* pend_c; unsigned* pend_flags;
   // queues of path ids, each split into RT_QSHARDS shards (shard = blockIdx & 7 of the producer, region
   // [shard * shard_cap, ...)) with its own counter word: a single word sustains only ~88 returning
-  // atomics per microsecond. counters[q * RT_QSHARDS + shard], q: 0 = active in, 1 = active out, 2 = shadow, 3 = mis
+  // atomics per microsecond. Every bounce has its own zero-initialised block of counters, so nothing has to be
+  // reset or rotated between bounces: cnt_in = the 8 shard counts of q_in (written by raygen / the previous
+  // bounce), cnt_out[q * RT_QSHARDS + shard] with q: 0 = continuing paths (q_out), 1 = shadow, 2 = mis.
   unsigned* q_in; unsigned* q_out; unsigned* q_shadow; unsigned* q_mis;
-  unsigned* counters; unsigned shard_cap;
+  const unsigned* cnt_in; unsigned* cnt_out; unsigned shard_cap;
+  int all_in_bounds;  // every sample of the pass is traced (no crop by pixel_bounds): bounce 0 needs no queue, path i is entry i
   unsigned long long* stats;  // device-side u64 counters, see ST_* below
 };
 enum { ST_CAMERA = 0, ST_RAYS_CLOSEST, ST_RAYS_SHADOW, ST_RAYS_MIS, ST_NODES_CLOSEST, ST_NODES_SHADOW, ST_NODES_MIS,
@@ -54,6 +57,7 @@ struct FrameParams {
   int rank, world;
   // pass
   unsigned long long chunk_first;  // first owned-pixel index of this batch
+  unsigned w_recip;                // floor(2^32 / W), W = sample-bounds width (0 when W == 1): division by W without a divide
 };
 
 // packed per-path state in lacc.w: bits 0-7 bounces, bit 8 specular_bounce, bits 9-12 cur_1d, bits 13-16 cur_2d
@@ -117,8 +121,14 @@ RT_DEV void block_push(unsigned* counters, unsigned shard_cap, const int* queue_
 // owned-pixel index -> raster pixel (x, y) and keyed pixel index inside the sample bounds
 RT_DEV void owned_pixel(const FrameParams& fp, unsigned long long k, int& x, int& y, unsigned long long& pixel_index) {
   const unsigned W = (unsigned)(fp.sb_x1 - fp.sb_x0);
-  unsigned long long j = k / W;
-  unsigned xi = (unsigned)(k - j * W);
+  unsigned long long j; unsigned xi;
+  if (k <= 0xffffffffull && fp.w_recip != 0u) {
+    // k / W by a multiply: q = mulhi(k, floor(2^32 / W)) is floor(k / W) or one less (k < 2^32), fixed by one compare
+    const unsigned k32 = (unsigned)k;
+    unsigned q = __umulhi(k32, fp.w_recip), r = k32 - q * W;
+    if (r >= W) { q += 1u; r -= W; }
+    j = q; xi = r;
+  } else { j = k / W; xi = (unsigned)(k - j * W); }
   unsigned long long row = ((j >> 4) * (unsigned long long)fp.world + (unsigned long long)fp.rank) * 16ull + (j & 15ull);
   x = fp.sb_x0 + (int)xi;
   y = fp.sb_y0 + (int)row;
@@ -447,9 +457,11 @@ __global__ void __launch_bounds__(256) k_raygen(FrameParams fp, PassState ps) {
       ps.rng[pid] = rng.state;
       ps.pend_flags[pid] = in_bounds ? 0u : 0x80000000u;  // bit31: sample outside pixel_bounds, never traced
     }
-    const int ci[1] = {0}; const bool pr[1] = {in_bounds}; unsigned slot[1];
-    block_push<1>(ps.counters, ps.shard_cap, ci, pr, slot);
-    if (in_bounds) ps.q_in[slot[0]] = pid;
+    if (!ps.all_in_bounds) {
+      const int ci[1] = {0}; const bool pr[1] = {in_bounds}; unsigned slot[1];
+      block_push<1>(ps.cnt_out, ps.shard_cap, ci, pr, slot);
+      if (in_bounds) ps.q_in[slot[0]] = pid;
+    }
   }
 }
 
@@ -479,13 +491,14 @@ __global__ void __launch_bounds__(BLOCK) k_trace(DScene sc, const float4* __rest
   __shared__ StackT stack[DEPTH * BLOCK];
   __shared__ float4 s_nodes[SMALL ? 2 * RT_SMALL_NODES : 1];
   __shared__ float4 s_tris[SMALL ? 3 * RT_SMALL_TRIS : 1];
+  QView qv; if (queue) qv.init(queue, shard_counts, shard_cap);
+  const unsigned count = queue ? qv.total() : count_static;
+  if (blockIdx.x * BLOCK >= count) return;  // short queues (MIS rays, late bounces): most blocks of the persistent grid have nothing to stage for
   if (SMALL) {
     for (unsigned i = threadIdx.x; i < 2u * sc.n_nodes; i += BLOCK) s_nodes[i] = sc.nodes[i];
     for (unsigned i = threadIdx.x; i < 3u * sc.n_tris; i += BLOCK) s_tris[i] = sc.tri_p[i];
     __syncthreads();
   }
-  QView qv; if (queue) qv.init(queue, shard_counts, shard_cap);
-  const unsigned count = queue ? qv.total() : count_static;
   const unsigned stride = gridDim.x * BLOCK;
   unsigned n_nodes = 0, n_tris = 0, n_rays = 0;
   for (unsigned i = blockIdx.x * BLOCK + threadIdx.x; i < count; i += stride) {
@@ -859,8 +872,8 @@ struct SingleLambert {
 #endif
 template <int MODE>
 __global__ void __launch_bounds__(256, RT_SHADE_MIN_WAVES) k_shade(DScene sc, FrameParams fp, PassState ps) {
-  QView qv; qv.init(ps.q_in, ps.counters, ps.shard_cap);
-  const unsigned count = qv.total();
+  QView qv; if (ps.q_in) qv.init(ps.q_in, ps.cnt_in, ps.shard_cap);
+  const unsigned count = ps.q_in ? qv.total() : ps.cap;  // no queue: bounce 0 of a pass whose samples are all traced
   const unsigned stride = gridDim.x * blockDim.x;
   for (unsigned base = blockIdx.x * blockDim.x; base < count; base += stride) {
     const unsigned i = base + threadIdx.x;
@@ -868,7 +881,7 @@ __global__ void __launch_bounds__(256, RT_SHADE_MIN_WAVES) k_shade(DScene sc, Fr
     bool cont = false, want_shadow = false, want_mis = false;
     unsigned pid = 0;
     if (lane_live) {
-      pid = qv.get(i);
+      pid = ps.q_in ? qv.get(i) : i;
       const unsigned sl = pid / ps.n_pixels, pix = pid - sl * ps.n_pixels, s = ps.s0 + sl;
       float4 d4 = ps.ray_d[pid], h4 = ps.hit[pid], b4 = ps.beta[pid], l4 = ps.lacc[pid];
       f3 ray_d = mk3(d4.x, d4.y, d4.z);
@@ -995,8 +1008,8 @@ __global__ void __launch_bounds__(256, RT_SHADE_MIN_WAVES) k_shade(DScene sc, Fr
       ps.lacc[pid] = make_float4(L.r, L.g, L.b, __uint_as_float(pack_state(bounces, specular_bounce, smp.c1, smp.c2)));
       ps.rng[pid] = smp.rng.state;
     }
-    const int ci[3] = {1, 2, 3}; const bool pr[3] = {cont, want_shadow, want_mis}; unsigned slot[3];
-    block_push<3>(ps.counters, ps.shard_cap, ci, pr, slot);
+    const int ci[3] = {0, 1, 2}; const bool pr[3] = {cont, want_shadow, want_mis}; unsigned slot[3];
+    block_push<3>(ps.cnt_out, ps.shard_cap, ci, pr, slot);
     if (cont) ps.q_out[slot[0]] = pid;
     if (want_shadow) ps.q_shadow[slot[1]] = pid;
     if (want_mis) ps.q_mis[slot[2]] = pid;
@@ -1007,7 +1020,7 @@ __global__ void __launch_bounds__(256, RT_SHADE_MIN_WAVES) k_shade(DScene sc, Fr
 // estimate_direct for the (rare) vertices whose BSDF-sampled MIS ray was traced: ld = [unoccluded] Ld1 +
 // [the MIS ray reached the sampled light] f*Le*w/pdf; L += beta_at_vertex * (ld / light_pick_pdf).
 __global__ void __launch_bounds__(256) k_resolve(DScene sc, PassState ps) {
-  QView qv; qv.init(ps.q_mis, ps.counters + 3 * RT_QSHARDS, ps.shard_cap);
+  QView qv; qv.init(ps.q_mis, ps.cnt_out + 2 * RT_QSHARDS, ps.shard_cap);
   const unsigned count = qv.total();
   const unsigned stride = gridDim.x * blockDim.x;
   for (unsigned i = blockIdx.x * blockDim.x + threadIdx.x; i < count; i += stride) {
@@ -1038,14 +1051,6 @@ __global__ void __launch_bounds__(256) k_resolve(DScene sc, PassState ps) {
     float4 l4 = ps.lacc[pid];
     rgb3 add = mkc(c.x, c.y, c.z) * (ld / a.w);
     ps.lacc[pid] = make_float4(l4.x + add.r, l4.y + add.g, l4.z + add.b, l4.w);
-  }
-}
-
-// queue hand-over between bounces: counters[0] <- counters[1]; others cleared (single thread)
-__global__ void k_next_bounce(unsigned* counters) {
-  if (blockIdx.x == 0 && threadIdx.x < RT_QSHARDS) {
-    const unsigned k = threadIdx.x;
-    counters[k] = counters[RT_QSHARDS + k]; counters[RT_QSHARDS + k] = 0; counters[2 * RT_QSHARDS + k] = 0; counters[3 * RT_QSHARDS + k] = 0;
   }
 }
 
