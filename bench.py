@@ -110,23 +110,31 @@ def main():
     if rank == 0:
         ms_step = dt / args.steps * 1e3
         value = samples_per_step * args.steps / dt / 1e6
-        # --- roofline of trace_closest (path-continuation + MIS closest-hit launches share the kernel)
-        rays = cst["rays_closest"] + cst["rays_mis"]
-        algo_bytes = 48 * rays + 32 * (cst["nodes_closest"] + cst["nodes_mis"]) + 36 * (cst["tris_closest"] + cst["tris_mis"])
-        launches = kstats[-1]["launches_trace_closest"]
-        ms_kernel = float(np.mean([k["ms_trace_closest"] + k["ms_trace_mis"] for k in kstats]))
+        # --- roofline of the dominant kernel. Algorithmic bytes follow SURVEY.md §8(d): a ray cast = 32 B ray record read + 16 B hit
+        # record written + 32 B per BVH node visited + 36 B per triangle tested (the reference algorithm's visit counts, from the
+        # counting frame); a shaded vertex = 64 B path state read + 64 B written + 32 B per ray it emits, + 48 B of sampler tables per path.
+        ms_tc = float(np.mean([k["ms_trace_closest"] + k["ms_trace_mis"] for k in kstats]))
+        ms_sh = float(np.mean([k["ms_shade"] for k in kstats]))
+        pmc = {}
+        try:
+            pmc = json.load(open(os.path.join(ROOT, "profiles", f"pmc_{args.scene}.json")))
+        except Exception:
+            pmc = {}
+        if ms_tc >= ms_sh:
+            rays = cst["rays_closest"] + cst["rays_mis"]
+            algo_bytes = 48 * rays + 32 * (cst["nodes_closest"] + cst["nodes_mis"]) + 36 * (cst["tris_closest"] + cst["tris_mis"])
+            launches, ms_kernel, kname, unit_n, unit = kstats[-1]["launches_trace_closest"], ms_tc, "trace_closest", rays, "ray"
+        else:
+            verts = cst["rays_closest"]
+            emitted = cst["rays_shadow"] + cst["rays_mis"] + (cst["rays_closest"] - cst["camera_rays"])
+            algo_bytes = 128 * verts + 32 * emitted + 48 * cst["camera_rays"]
+            launches, ms_kernel, kname, unit_n, unit = kstats[-1]["launches_trace_closest"] // 2, ms_sh, "shade", verts, "vertex"
         achieved = algo_bytes / (ms_kernel * 1e-3) / 1e9  # GB/s
-        traffic = None
-        pmc = os.path.join(ROOT, "profiles", "pmc_trace_closest.json")
-        if os.path.exists(pmc):
-            try:
-                traffic = json.load(open(pmc)).get("hbm_bytes_per_launch")
-            except Exception:
-                traffic = None
-        roofline = {"bound": "hbm", "kernel": "k_trace<closest>", "achieved": round(achieved, 1), "peak": 8000.0, "unit": "GB/s",
+        traffic = (pmc.get(kname) or {}).get("hbm_bytes_per_launch")
+        roofline = {"bound": "hbm", "kernel": "k_" + kname, "achieved": round(achieved, 1), "peak": 8000.0, "unit": "GB/s",
                     "frac": round(achieved / 8000.0, 4), "traffic": traffic,
                     "algorithmic_bytes_per_launch": round(algo_bytes / launches), "avg_launch_ms": round(ms_kernel / launches, 4),
-                    "launches_per_step": int(launches), "bytes_per_ray": round(algo_bytes / rays, 1)}
+                    "launches_per_step": int(launches), f"bytes_per_{unit}": round(algo_bytes / unit_n, 1)}
         kernels_ms = {k[3:]: round(float(np.mean([s[k] for s in kstats])), 2) for k in kstats[-1] if k.startswith("ms_")}
         out = {
             "metric": "Msamples/s", "value": round(value, 2), "unit": "Msamples/s", "n_gpus": n_gpus, "steps": args.steps, "warmup": args.warmup,

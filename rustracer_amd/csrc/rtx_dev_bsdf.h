@@ -328,7 +328,9 @@ RT_DEV float lobe_pdf(const Lobe& l, f3 wo, f3 wi) { return l.n_scales > 0 ? def
 RT_DEV LobeSample lobe_sample(const Lobe& l, f3 wo, f2 u) { LobeSample s = lobe_sample_inner(l, wo, u); s.f = apply_scales(l, s.f); return s; }
 
 // ---------------------------------------------------------------- Bsdf (bsdf/mod.rs:64-269)
+#ifndef RT_MAX_LOBES
 #define RT_MAX_LOBES 8
+#endif
 struct Bsdf {
   float eta;
   f3 ns, ng, ss, ts;

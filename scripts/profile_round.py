@@ -1,18 +1,19 @@
 """Post-process rocprofv3 output (run on the GPU box by scripts/profile_round.sh) into profiles/.
 
-Inputs under gpurun_out/<tag>/: stats/ (--kernel-trace --stats), fetch/ (--pmc FETCH_SIZE), write/ (--pmc WRITE_SIZE).
-Outputs: profiles/<tag>_kernel_stats.csv (verbatim rocprofv3 summary), profiles/<tag>_pmc_hbm.csv (per-kernel HBM
-bytes per launch with the MI355X guide's gfx950 correction: FETCH_SIZE is in KiB and reads of a 16-B-per-lane
-stream are reported at half their size), profiles/pmc_trace_closest.json (what bench.py reports as roofline.traffic).
+Inputs under gpurun_out/<tag>_<scene>/: stats/ (--kernel-trace --stats), fetch/ (--pmc FETCH_SIZE), write/ (--pmc WRITE_SIZE).
+Outputs: profiles/<tag>_<scene>_kernel_stats.csv (verbatim rocprofv3 summary), profiles/<tag>_<scene>_pmc_hbm.csv (per-kernel HBM
+bytes per launch with the MI355X guide's gfx950 correction: FETCH_SIZE is in KiB and reads of a 16-B-per-lane stream are
+reported at half their size), profiles/pmc_<scene>.json (what bench.py reports as roofline.traffic: HBM bytes per launch of
+the path-continuation closest-hit kernel and of the shade kernel, at the pass size of the full-spp run).
 """
 import collections, csv, glob, json, os, shutil, sys
 
-tag = sys.argv[1]
-base = os.path.join('gpurun_out', tag)
+tag, scene = sys.argv[1], (sys.argv[2] if len(sys.argv) > 2 else 'cornell')
+base = os.path.join('gpurun_out', f'{tag}_{scene}')
 os.makedirs('profiles', exist_ok=True)
 st = glob.glob(os.path.join(base, 'stats', '*', '*_kernel_stats.csv'))
 if st:
-    shutil.copy(st[0], os.path.join('profiles', f'{tag}_kernel_stats.csv'))
+    shutil.copy(st[0], os.path.join('profiles', f'{tag}_{scene}_kernel_stats.csv'))
 
 def per_kernel(sub, counter):
     files = glob.glob(os.path.join(base, sub, '*', '*_counter_collection.csv'))
@@ -36,15 +37,23 @@ for k in sorted(set(fetch) | set(write)):
     rd = fetch.get(k, 0.0) * 1024.0 * 2.0 / launches   # KiB -> B, x2: gfx950 reports wide streaming reads at half size
     wr = write.get(k, 0.0) * 1024.0 / launches
     rows.append((k.split('(')[0].replace('void ', ''), launches, rd, wr, rd + wr))
-with open(os.path.join('profiles', f'{tag}_pmc_hbm.csv'), 'w') as f:
+with open(os.path.join('profiles', f'{tag}_{scene}_pmc_hbm.csv'), 'w') as f:
     f.write('kernel,launches,read_bytes_per_launch(x2_corrected),write_bytes_per_launch,hbm_bytes_per_launch\n')
     for r in rows:
         f.write(f'"{r[0]}",{r[1]},{r[2]:.0f},{r[3]:.0f},{r[4]:.0f}\n')
-tc = [r for r in rows if r[0].startswith('rtx::k_trace<false')]
-if tc:
-    tot_l = sum(r[1] for r in tc)
-    val = sum(r[4] * r[1] for r in tc) / tot_l
-    json.dump({'kernel': 'k_trace<closest>', 'hbm_bytes_per_launch': round(val), 'launches_profiled': tot_l,
-               'method': 'rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate passes; KiB->B; reads x2 (gfx950 16-B/lane correction, MI355X guide)',
-               'source': f'profiles/{tag}_pmc_hbm.csv'}, open(os.path.join('profiles', 'pmc_trace_closest.json'), 'w'), indent=1)
-print(open(os.path.join('profiles', f'{tag}_pmc_hbm.csv')).read())
+
+def pick(prefixes, exclude=()):
+    sel = [r for r in rows if any(r[0].startswith(p) for p in prefixes) and not any(e in r[0] for e in exclude)]
+    if not sel:
+        return None
+    tot_l = sum(r[1] for r in sel)
+    return {'kernels': sorted({r[0] for r in sel}), 'hbm_bytes_per_launch': round(sum(r[4] * r[1] for r in sel) / tot_l), 'launches_profiled': tot_l}
+
+# closest-hit kernels of the timed frames: k_trace<false, false, ...> (LDS scenes) or k_trace_pair<false, ...> (HBM scenes)
+out = {'scene': scene,
+       'method': 'rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate passes; KiB->B; reads x2 (gfx950 16-B/lane correction, MI355X guide)',
+       'source': f'profiles/{tag}_{scene}_pmc_hbm.csv',
+       'trace_closest': pick(['rtx::k_trace<false, false', 'rtx::k_trace_pair<false']),
+       'shade': pick(['rtx::k_shade'])}
+json.dump(out, open(os.path.join('profiles', f'pmc_{scene}.json'), 'w'), indent=1)
+print(open(os.path.join('profiles', f'{tag}_{scene}_pmc_hbm.csv')).read())

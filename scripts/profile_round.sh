@@ -1,12 +1,14 @@
 #!/bin/bash
-# Usage (on the GPU box, from the repo root): bash scripts/profile_round.sh <tag>
+# Usage (on the GPU box, from the repo root): bash scripts/profile_round.sh <tag> [scene]
 # Kernel-trace summary of the benchmark command + two separate PMC passes (never combined with tracing).
 TAG=${1:-r01}
-OUT=gpurun_out/$TAG
+SCENE=${2:-cornell}
+OUT=gpurun_out/${TAG}_${SCENE}
 mkdir -p $OUT
 ROOT=$(pwd)
 cd /tmp && export TMPDIR=/tmp && cd $ROOT
-rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline > $OUT/stats.log 2>&1
-rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/fetch -- python3 bench.py --steps 1 --warmup 0 --spp 64 --no-cpu-baseline > $OUT/fetch.log 2>&1
-rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/write -- python3 bench.py --steps 1 --warmup 0 --spp 64 --no-cpu-baseline > $OUT/write.log 2>&1
-python3 scripts/profile_round.py $TAG
+case $SCENE in cornell) PSPP=64;; blob) PSPP=64;; mis) PSPP=64;; room) PSPP=64;; esac
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -- python3 bench.py --scene $SCENE --steps 2 --warmup 1 --no-cpu-baseline > $OUT/stats.log 2>&1
+rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/fetch -- python3 bench.py --scene $SCENE --steps 1 --warmup 0 --spp $PSPP --no-cpu-baseline > $OUT/fetch.log 2>&1
+rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/write -- python3 bench.py --scene $SCENE --steps 1 --warmup 0 --spp $PSPP --no-cpu-baseline > $OUT/write.log 2>&1
+python3 scripts/profile_round.py $TAG $SCENE
