@@ -165,7 +165,7 @@ RT_DEVN f3 tr_sample_wh(float ax, float ay, f3 wo, f2 u) {  // :495-514, 604-645
 RT_DEV float pow5(float v) { return (v * v) * (v * v) * v; }
 RT_DEV float default_pdf(f3 wo, f3 wi) { return same_hemisphere(wo, wi) ? abs_cos_theta(wi) * kInvPi : 0.0f; }  // bxdf.rs:38-44
 
-RT_DEVN rgb3 lobe_f_inner(const Lobe& l, f3 wo, f3 wi) {
+RT_DEV rgb3 lobe_f_inner(const Lobe& l, f3 wo, f3 wi) {
   switch (l.kind) {
     case LB_LAMBERT_R: case LB_LAMBERT_T: return l.r * kInvPi;
     case LB_OREN_NAYAR: {  // oren_nayar.rs:31-53
@@ -216,7 +216,7 @@ RT_DEVN rgb3 lobe_f_inner(const Lobe& l, f3 wo, f3 wi) {
     }
   }
 }
-RT_DEVN float lobe_pdf_inner(const Lobe& l, f3 wo, f3 wi) {
+RT_DEV float lobe_pdf_inner(const Lobe& l, f3 wo, f3 wi) {
   switch (l.kind) {
     case LB_SPEC_R: case LB_SPEC_T: case LB_FRESNEL_SPEC: return 0.0f;
     case LB_FRESNEL_BLEND: {  // fresnel.rs:376-384
@@ -243,7 +243,7 @@ RT_DEVN float lobe_pdf_inner(const Lobe& l, f3 wo, f3 wi) {
 }
 struct LobeSample { rgb3 f; f3 wi; float pdf; unsigned type; };
 RT_DEV LobeSample mk_ls(rgb3 f, f3 wi, float pdf, unsigned type) { LobeSample s; s.f = f; s.wi = wi; s.pdf = pdf; s.type = type; return s; }
-RT_DEVN LobeSample lobe_sample_inner(const Lobe& l, f3 wo, f2 u) {
+RT_DEV LobeSample lobe_sample_inner(const Lobe& l, f3 wo, f2 u) {
   const unsigned ty = lobe_type(l.kind);
   switch (l.kind) {
     case LB_SPEC_R: {  // fresnel.rs:158-163

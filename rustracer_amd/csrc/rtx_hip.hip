@@ -53,11 +53,13 @@ struct rt_scene {
   DevBuf nodes, tri_p, tri_n, tri_uv, tri_s, textures, images, materials, lights, texels, dist;
   std::vector<DLight> h_lights;
   // light distribution tables (built per render, rc/integrator/path.rs:86-94)
-  DevBuf ld_func, ld_cdf, ld_int;
+  DevBuf ld_func, ld_cdf, ld_int, ld_mark, ld_list;
   int ld_strategy_built = -1;
   // per-render workspace
   DevBuf ws[32];
   DevBuf film_acc, own_acc, film_out, counters, stats, filter_table;
+  DevBuf bin_words, bin_sorted;  // material binning of the shade queue (generic shade path)
+  unsigned n_materials = 0;
   // sampler tables are double-buffered: K0 of batch b+1 runs on aux_stream under the path kernels of batch b
   DevBuf scrambles[2], perms[2];
   hipStream_t aux_stream = nullptr;
@@ -246,6 +248,7 @@ extern "C" int rt_scene_create(const rt_scene_desc* desc, int device, rt_scene**
     if (!(sg <= 0.0f)) { s->lambert_only = false; break; }  // clamp(sigma, 0, 1) == 0 (matte.rs:51)
   }
   for (uint32_t i = 0; i < desc->n_lights; ++i) if (desc->lights[i].kind != RT_LIGHT_DIFFUSE_AREA) s->lambert_only = false;
+  s->n_materials = desc->n_materials;
   s->small = desc->n_nodes <= RT_SMALL_NODES && desc->n_tris <= RT_SMALL_TRIS;
   {  // tree height bounds the number of simultaneously pending stack entries
     std::vector<int> depth(desc->n_nodes, 0); int maxd = 0;
@@ -299,7 +302,7 @@ extern "C" void rt_scene_destroy(rt_scene* s) {
 
 // ---------------------------------------------------------------------------------------------- light distribution
 // PathIntegrator::preprocess (rc/integrator/path.rs:86-94) + SpatialLightDistribution::new (rc/lightdistrib.rs:67-99)
-static int build_light_distribution(rt_scene* s, int strategy, hipStream_t stream) {
+static int build_light_distribution(rt_scene* s, int strategy, hipStream_t stream, bool all_voxels = false) {
   DScene& d = s->d;
   const int nl = s->n_lights;
   const bool uniform = strategy == 1 || nl == 1 || nl == 0;
@@ -329,7 +332,18 @@ static int build_light_distribution(rt_scene* s, int strategy, hipStream_t strea
     HIP_TRY(s->ld_func.ensure(total * nl * 4)); HIP_TRY(s->ld_cdf.ensure(total * (nl + 1) * 4)); HIP_TRY(s->ld_int.ensure(total * 4));
     d.ld_uniform = 0;
     d.ld_func = s->ld_func.as<float>(); d.ld_cdf = s->ld_cdf.as<float>(); d.ld_int = s->ld_int.as<float>();
-    hipLaunchKernelGGL(k_lightdist_build, dim3((unsigned)((total + 127) / 128)), dim3(128), 0, stream, d, s->ld_func.as<float>(), s->ld_cdf.as<float>(), s->ld_int.as<float>());
+    // only voxels that can hold a surface point are built (k_lightdist_mark); the table API asks for all
+    HIP_TRY(s->ld_mark.ensure(total)); HIP_TRY(s->ld_list.ensure((total + 1) * 4));
+    unsigned* n_list = s->ld_list.as<unsigned>(); unsigned* list = n_list + 1;
+    HIP_TRY(hipMemsetAsync(s->ld_mark.p, 0, total, stream)); HIP_TRY(hipMemsetAsync(n_list, 0, 4, stream));
+    HIP_TRY(hipMemsetD32Async((hipDeviceptr_t)s->ld_int.p, (int)0xbf800000u, total, stream));  // -1.0f = not built
+    if (!all_voxels) hipLaunchKernelGGL(k_lightdist_mark, dim3((s->n_tris + 255u) / 256u), dim3(256), 0, stream, d, s->ld_mark.as<unsigned char>());
+    hipLaunchKernelGGL(k_lightdist_compact, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream, s->ld_mark.as<unsigned char>(), (unsigned)total, all_voxels ? 1 : 0, list, n_list);
+    unsigned lights_pad = 1; while (lights_pad < (unsigned)nl) lights_pad <<= 1;
+    const unsigned long long contrib_blocks = lights_pad <= 128u ? (total + 128u / lights_pad - 1) / (128u / lights_pad) : (unsigned long long)total * (unsigned)((nl + 127) / 128);
+    if (contrib_blocks > 0x7fffffffull) return fail(RT_ERR_INVALID, "light distribution grid too large");
+    hipLaunchKernelGGL(k_lightdist_contrib, dim3((unsigned)contrib_blocks), dim3(128), 0, stream, d, list, n_list, lights_pad, (unsigned)((nl + 127) / 128), s->ld_func.as<float>());
+    hipLaunchKernelGGL(k_lightdist_finish, dim3((unsigned)((total + 127) / 128)), dim3(128), 0, stream, d, list, n_list, s->ld_func.as<float>(), s->ld_cdf.as<float>(), s->ld_int.as<float>());
     HIP_TRY(hipGetLastError());
   }
   d.ld_func = s->ld_func.as<float>(); d.ld_cdf = s->ld_cdf.as<float>(); d.ld_int = s->ld_int.as<float>();
@@ -340,7 +354,7 @@ static int build_light_distribution(rt_scene* s, int strategy, hipStream_t strea
 extern "C" int rt_light_distribution(rt_scene* s, int32_t n_voxels[3], float* func, float* cdf, float* func_int) {
   if (!s) return fail(RT_ERR_INVALID, "null scene");
   HIP_TRY(hipSetDevice(s->device));
-  int rc = build_light_distribution(s, 0, nullptr);
+  int rc = build_light_distribution(s, 0, nullptr, true);
   if (rc != RT_OK) return rc;
   HIP_TRY(hipDeviceSynchronize());
   if (s->d.ld_uniform) { n_voxels[0] = n_voxels[1] = n_voxels[2] = 0; return RT_OK; }
@@ -659,6 +673,12 @@ extern "C" int rt_render(rt_scene* s, const rt_camera* cam, const rt_film_desc* 
   for (int i = 0; i < 21; ++i) HIP_TRY(s->ws[i].ensure(sizes[i]));
   const size_t counter_words = (size_t)(fp.max_depth + 2) * 3 * RT_QSHARDS;  // one block of {out, shadow, mis} shard counts per bounce + raygen's
   HIP_TRY(s->counters.ensure(counter_words * 4)); HIP_TRY(s->stats.ensure(ST_COUNT * 8));
+  // material binning before the generic shade kernel: per bounce {hist, cursor}[RT_BIN_MAX + 1] + the 8 count words of the sorted queue
+  static const bool bin_off = getenv("RTX_SHADE_BINS") && getenv("RTX_SHADE_BINS")[0] == '0';  // measurement knob
+  const bool use_bins = !s->lambert_only && s->n_materials > 1 && !bin_off;
+  const unsigned n_bins = std::min<unsigned>(s->n_materials, RT_BIN_MAX) + 1u;
+  const size_t bin_stride = 2 * (RT_BIN_MAX + 1) + RT_QSHARDS;
+  if (use_bins) { HIP_TRY(s->bin_words.ensure((size_t)(fp.max_depth + 1) * bin_stride * 4)); HIP_TRY(s->bin_sorted.ensure(cap * 4)); }
   HIP_TRY(s->film_acc.ensure((size_t)cw * ch * 16)); HIP_TRY(s->own_acc.ensure(chunk_pixels * 16));
   HIP_TRY(s->filter_table.ensure(1024));
   const bool multi_batch = owned_pixels > chunk_pixels;
@@ -727,6 +747,7 @@ extern "C" int rt_render(rt_scene* s, const rt_camera* cam, const rt_film_desc* 
       ps.s0 = s0; ps.n_samples = std::min(pass_samples, spp - s0); ps.cap = (unsigned)(npx * ps.n_samples);
       ps.q_in = q_a; ps.q_out = q_b;
       HIP_TRY(hipMemsetAsync(s->counters.p, 0, counter_words * 4, stream));
+      if (use_bins) HIP_TRY(hipMemsetAsync(s->bin_words.p, 0, (size_t)(fp.max_depth + 1) * bin_stride * 4, stream));
       unsigned* const cb = s->counters.as<unsigned>();
       ps.cnt_in = nullptr; ps.cnt_out = cb;  // raygen appends to block 0's `out` queue
       ps.all_in_bounds = all_in_bounds ? 1 : 0;
@@ -742,7 +763,15 @@ extern "C" int rt_render(rt_scene* s, const rt_camera* cam, const rt_film_desc* 
         tm.end();
         tm.begin(&stats.ms_shade);
         if (s->lambert_only) hipLaunchKernelGGL(k_shade<1>, dim3(pgrid), dim3(256), 0, stream, s->d, fp, ps);
-        else hipLaunchKernelGGL(k_shade<0>, dim3(pgrid), dim3(256), 0, stream, s->d, fp, ps);
+        else if (!use_bins) hipLaunchKernelGGL(k_shade<0>, dim3(pgrid), dim3(256), 0, stream, s->d, fp, ps);
+        else {
+          unsigned* bw = s->bin_words.as<unsigned>() + (size_t)bounce * bin_stride;
+          unsigned* hist = bw; unsigned* cursor = bw + (RT_BIN_MAX + 1); unsigned* sorted_cnt = bw + 2 * (RT_BIN_MAX + 1);
+          hipLaunchKernelGGL(k_bin_count, dim3(pgrid), dim3(256), 0, stream, s->d, ps, n_bins, hist);
+          hipLaunchKernelGGL(k_bin_scatter, dim3(pgrid), dim3(256), 0, stream, s->d, ps, n_bins, hist, cursor, s->bin_sorted.as<unsigned>(), sorted_cnt);
+          PassState pb = ps; pb.q_in = s->bin_sorted.as<unsigned>(); pb.cnt_in = sorted_cnt;  // all entries in shard 0: QView::get(i) = ids[i]
+          hipLaunchKernelGGL(k_shade<0>, dim3(pgrid), dim3(256), 0, stream, s->d, fp, pb);
+        }
         tm.end();
         tm.begin(&stats.ms_trace_any);
         launch_trace<true>(s, count, ps.sh_o, ps.sh_d, ps.q_shadow, ps.cnt_out + RT_QSHARDS, ps.shard_cap, 0, nullptr, ps.sh_occ, dstats, ST_RAYS_SHADOW, ST_NODES_SHADOW, ST_TRIS_SHADOW, stream, ps.lacc, ps.pend_a);
@@ -784,6 +813,7 @@ extern "C" int rt_render(rt_scene* s, const rt_camera* cam, const rt_film_desc* 
   stats.nodes_closest = h[ST_NODES_CLOSEST]; stats.nodes_shadow = h[ST_NODES_SHADOW]; stats.nodes_mis = h[ST_NODES_MIS];
   stats.tris_closest = h[ST_TRIS_CLOSEST]; stats.tris_shadow = h[ST_TRIS_SHADOW]; stats.tris_mis = h[ST_TRIS_MIS];
   stats.paths_scrubbed = h[ST_SCRUBBED];
+  if (h[ST_UNBUILT_VOXEL]) return fail(RT_ERR_INVALID, "a path looked up a light-distribution voxel that holds no surface (voxel marking bug)");
   stats.ms_total = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_begin).count();
   if (stats_out) *stats_out = stats;
   return RT_OK;

@@ -43,7 +43,7 @@ struct PassState {
   unsigned long long* stats;  // device-side u64 counters, see ST_* below
 };
 enum { ST_CAMERA = 0, ST_RAYS_CLOSEST, ST_RAYS_SHADOW, ST_RAYS_MIS, ST_NODES_CLOSEST, ST_NODES_SHADOW, ST_NODES_MIS,
-       ST_TRIS_CLOSEST, ST_TRIS_SHADOW, ST_TRIS_MIS, ST_SCRUBBED, ST_COUNT };
+       ST_TRIS_CLOSEST, ST_TRIS_SHADOW, ST_TRIS_MIS, ST_SCRUBBED, ST_UNBUILT_VOXEL, ST_COUNT };
 
 struct FrameParams {
   // camera (rc/camera.rs)
@@ -795,6 +795,60 @@ __global__ void __launch_bounds__(BLOCK) k_trace_pair(DScene sc, const float4* _
   }
 }
 
+// ================================================================================ K2b material binning
+// The generic shade kernel evaluates tagged lobes ("for each lobe: switch (kind)"); a wave whose 64 vertices carry
+// different materials executes the union of their code paths (measured on S4: 20 of 64 lanes active per VALU
+// instruction). Between closest hit and shade the vertex queue is therefore counting-sorted by the material of the
+// hit triangle (misses last), so that most waves shade one material. Order within a bin is arbitrary: paths are
+// independent and the film sums each pixel's samples in sample order. hist/cursor: RT_BIN_MAX + 1 zeroed words each.
+#define RT_BIN_MAX 256
+RT_DEV unsigned bin_of(const float4* __restrict__ tri_p, const float4* __restrict__ hit, unsigned pid, unsigned n_bins) {
+  const int prim = __float_as_int(hit[pid].y);
+  if (prim < 0) return n_bins - 1u;
+  const unsigned m = (unsigned)tri_material(tri_p, prim);
+  return m < n_bins - 1u ? m : n_bins - 2u;
+}
+__global__ void __launch_bounds__(256) k_bin_count(DScene sc, PassState ps, unsigned n_bins, unsigned* __restrict__ hist) {
+  __shared__ unsigned lh[RT_BIN_MAX + 1];
+  for (unsigned i = threadIdx.x; i <= RT_BIN_MAX; i += 256u) lh[i] = 0u;
+  __syncthreads();
+  QView qv; if (ps.q_in) qv.init(ps.q_in, ps.cnt_in, ps.shard_cap);
+  const unsigned count = ps.q_in ? qv.total() : ps.cap;
+  for (unsigned i = blockIdx.x * 256u + threadIdx.x; i < count; i += gridDim.x * 256u) {
+    const unsigned pid = ps.q_in ? qv.get(i) : i;
+    atomicAdd(&lh[bin_of(sc.tri_p, ps.hit, pid, n_bins)], 1u);
+  }
+  __syncthreads();
+  for (unsigned i = threadIdx.x; i < n_bins; i += 256u) if (lh[i]) atomicAdd(&hist[i], lh[i]);
+}
+// sorted: path ids grouped by bin; sorted_cnt[RT_QSHARDS]: {total, 0, ...} so that the result reads as a one-shard queue
+__global__ void __launch_bounds__(256) k_bin_scatter(DScene sc, PassState ps, unsigned n_bins, const unsigned* __restrict__ hist, unsigned* __restrict__ cursor,
+                                                     unsigned* __restrict__ sorted, unsigned* __restrict__ sorted_cnt) {
+  __shared__ unsigned base[RT_BIN_MAX + 1], lcount[RT_BIN_MAX + 1], lbase[RT_BIN_MAX + 1];
+  if (threadIdx.x == 0) {  // exclusive prefix of the histogram (<= 257 entries)
+    unsigned run = 0;
+    for (unsigned b = 0; b < n_bins; ++b) { base[b] = run; run += hist[b]; }
+    if (blockIdx.x == 0) { sorted_cnt[0] = run; for (int k = 1; k < RT_QSHARDS; ++k) sorted_cnt[k] = 0u; }
+  }
+  for (unsigned i = threadIdx.x; i <= RT_BIN_MAX; i += 256u) lcount[i] = 0u;
+  __syncthreads();
+  QView qv; if (ps.q_in) qv.init(ps.q_in, ps.cnt_in, ps.shard_cap);
+  const unsigned count = ps.q_in ? qv.total() : ps.cap;
+  for (unsigned start = blockIdx.x * 256u; start < count; start += gridDim.x * 256u) {
+    const unsigned i = start + threadIdx.x;
+    unsigned pid = 0, bin = 0, rank = 0;
+    const bool live = i < count;
+    if (live) { pid = ps.q_in ? qv.get(i) : i; bin = bin_of(sc.tri_p, ps.hit, pid, n_bins); rank = atomicAdd(&lcount[bin], 1u); }
+    __syncthreads();
+    for (unsigned b = threadIdx.x; b < n_bins; b += 256u) if (lcount[b]) lbase[b] = atomicAdd(&cursor[b], lcount[b]);  // one global atomic per bin per 256 entries
+    __syncthreads();
+    if (live) sorted[base[bin] + lbase[bin] + rank] = pid;
+    __syncthreads();
+    for (unsigned b = threadIdx.x; b < n_bins; b += 256u) lcount[b] = 0u;
+    __syncthreads();
+  }
+}
+
 // ================================================================================ K3 shade
 struct PathSampler {  // ZeroTwoSequence::get_1d / get_2d (zerotwosequence.rs:158-180) for one (pixel, sample)
   Tables tb; unsigned pix, s; int c1, c2; Pcg32 rng;
@@ -870,8 +924,11 @@ struct SingleLambert {
 #ifndef RT_SHADE_MIN_WAVES
 #define RT_SHADE_MIN_WAVES 2
 #endif
+#ifndef RT_SHADE0_MIN_WAVES
+#define RT_SHADE0_MIN_WAVES 2
+#endif
 template <int MODE>
-__global__ void __launch_bounds__(256, RT_SHADE_MIN_WAVES) k_shade(DScene sc, FrameParams fp, PassState ps) {
+__global__ void __launch_bounds__(256, MODE == 1 ? RT_SHADE_MIN_WAVES : RT_SHADE0_MIN_WAVES) k_shade(DScene sc, FrameParams fp, PassState ps) {
   QView qv; if (ps.q_in) qv.init(ps.q_in, ps.cnt_in, ps.shard_cap);
   const unsigned count = ps.q_in ? qv.total() : ps.cap;  // no queue: bounce 0 of a pass whose samples are all traced
   const unsigned stride = gridDim.x * blockDim.x;
@@ -924,7 +981,11 @@ __global__ void __launch_bounds__(256, RT_SHADE_MIN_WAVES) k_shade(DScene sc, Fr
         if (sc.ld_uniform) { ld_func = sc.ld_func; ld_cdf = sc.ld_cdf; ld_int = sc.ld_int[0]; }
         else { long v = voxel_of(sc, si.hit.p); ld_func = sc.ld_func + v * sc.n_lights; ld_cdf = sc.ld_cdf + v * (sc.n_lights + 1); ld_int = sc.ld_int[v]; }
         const unsigned nonspec = BSDF_ALL & ~BSDF_SPECULAR;
-        if (bsdf.num_nonspecular() > 0 && sc.n_lights > 0) {  // uniform_sample_one_light, integrator/mod.rs:186-220
+        // voxels are built eagerly for every cell a surface point can fall into (k_lightdist_mark); the rest carry -1.
+        // Looking one up would mean the marking missed a cell: count it (rt_render then fails the frame) and skip.
+        const bool voxel_ok = !(ld_int < 0.0f);
+        if (!voxel_ok) atomicAdd(&ps.stats[ST_UNBUILT_VOXEL], 1ull);
+        if (voxel_ok && bsdf.num_nonspecular() > 0 && sc.n_lights > 0) {  // uniform_sample_one_light, integrator/mod.rs:186-220
           float su = smp.get_1d();
           int light_num; float light_pdf;
           d1_sample_discrete(ld_func, ld_cdf, ld_int, sc.n_lights, su, light_num, light_pdf);
@@ -1125,38 +1186,90 @@ __global__ void k_film_finalize(const float4* film_acc, float4* film_xyzw, unsig
 }
 
 // ================================================================================ light distribution build
-// SpatialLightDistribution::compute_distribution (rc/lightdistrib.rs:101-179) for every voxel.
-// One lane per voxel; loops lights outermost so that each light's 128-term sum is accumulated in
-// the reference's order while needing no per-lane array. The five Halton coordinates of the 128
-// points are voxel-independent and staged once per block in LDS.
-__global__ void __launch_bounds__(128) k_lightdist_build(DScene sc, float* func, float* cdf, float* fint) {
-  __shared__ float halton[128 * 5];
-  for (unsigned i = threadIdx.x; i < 128u * 5u; i += blockDim.x) halton[i] = radical_inverse((int)(i % 5u), (unsigned long long)(i / 5u));
-  __syncthreads();
-  const long nvox = (long)sc.nvox[0] * sc.nvox[1] * sc.nvox[2];
-  const long v = (long)blockIdx.x * blockDim.x + threadIdx.x;
-  if (v >= nvox) return;
+// SpatialLightDistribution::compute_distribution (rc/lightdistrib.rs:101-179). Each light's 128-term sum is
+// accumulated in the reference's order. The five Halton coordinates of the 128 points are voxel-independent and
+// staged once per block in LDS.
+// Which voxels can PathIntegrator::li ever look up? Only those holding a surface point (path.rs:154 passes isect.p),
+// and isect.p = b0 p0 + b1 p1 + b2 p2 lies in its triangle's bounding box up to rounding. k_lightdist_mark marks,
+// per triangle, the voxels of its (slightly inflated) box that its plane crosses - a conservative superset; the
+// reference computes voxels lazily on first lookup (lightdistrib.rs:200-296), this is the eager equivalent.
+// Only marked voxels are built (list = compacted marks); rt_light_distribution() asks for all of them.
+__global__ void __launch_bounds__(256) k_lightdist_mark(DScene sc, unsigned char* __restrict__ mark) {
+  const unsigned t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= sc.n_tris) return;
+  f3 p0, p1, p2; load_tri(sc.tri_p, (int)t, p0, p1, p2);
+  const f3 mn = mk3(fminf(p0.x, fminf(p1.x, p2.x)), fminf(p0.y, fminf(p1.y, p2.y)), fminf(p0.z, fminf(p1.z, p2.z)));
+  const f3 mx = mk3(fmaxf(p0.x, fmaxf(p1.x, p2.x)), fmaxf(p0.y, fmaxf(p1.y, p2.y)), fmaxf(p0.z, fmaxf(p1.z, p2.z)));
+  const f3 o0 = bounds_offset(sc.wb_min, sc.wb_max, mn), o1 = bounds_offset(sc.wb_min, sc.wb_max, mx);
+  const float pad = 1e-4f;  // in units of the scene extent: >> the rounding of p and of voxel_of, << one voxel (1/64)
+  int lo[3], hi[3];
+  const float a0[3] = {o0.x, o0.y, o0.z}, a1[3] = {o1.x, o1.y, o1.z};
+  for (int k = 0; k < 3; ++k) {
+    lo[k] = clampi(f2i_sat(floorf((a0[k] - pad) * (float)sc.nvox[k])), 0, sc.nvox[k] - 1);
+    hi[k] = clampi(f2i_sat(floorf((a1[k] + pad) * (float)sc.nvox[k])), 0, sc.nvox[k] - 1);
+  }
+  const f3 n = cross(p1 - p0, p2 - p0);
+  const f3 ext = sc.wb_max - sc.wb_min;
+  const f3 h = mk3(0.51f * ext.x / (float)sc.nvox[0] + pad * ext.x, 0.51f * ext.y / (float)sc.nvox[1] + pad * ext.y, 0.51f * ext.z / (float)sc.nvox[2] + pad * ext.z);  // inflated half extents
+  const float r = fabsf(n.x) * h.x + fabsf(n.y) * h.y + fabsf(n.z) * h.z;
+  const bool flat = !(len2(n) > 0.0f);  // degenerate triangle: keep its whole box
+  for (int z = lo[2]; z <= hi[2]; ++z)
+    for (int y = lo[1]; y <= hi[1]; ++y)
+      for (int x = lo[0]; x <= hi[0]; ++x) {
+        const f3 c = mk3(sc.wb_min.x + ((float)x + 0.5f) * ext.x / (float)sc.nvox[0], sc.wb_min.y + ((float)y + 0.5f) * ext.y / (float)sc.nvox[1],
+                         sc.wb_min.z + ((float)z + 0.5f) * ext.z / (float)sc.nvox[2]);
+        if (flat || fabsf(dot(n, c - p0)) <= r * 1.01f) mark[((size_t)z * sc.nvox[1] + y) * sc.nvox[0] + x] = 1;
+      }
+}
+__global__ void __launch_bounds__(256) k_lightdist_compact(const unsigned char* __restrict__ mark, unsigned n_vox, int mark_all, unsigned* __restrict__ list, unsigned* __restrict__ n_list) {
+  const unsigned v = blockIdx.x * blockDim.x + threadIdx.x;
+  const bool take = v < n_vox && (mark_all || mark[v]);
+  const unsigned slot = wave_push(n_list, take);
+  if (take) list[slot] = v;
+}
+
+// Two kernels so that a scene with many lights fills the chip: k_lightdist_contrib has one lane per
+// (built voxel, light) and accumulates that light's 128-term sum in the reference's order; k_lightdist_finish has
+// one lane per built voxel and runs the voxel's sequential tail (sum over lights, floor, Distribution1D::new).
+RT_DEV void voxel_bounds(const DScene& sc, long v, f3& vmn, f3& vmx) {
   const int px = (int)(v % sc.nvox[0]), py = (int)((v / sc.nvox[0]) % sc.nvox[1]), pz = (int)(v / ((long)sc.nvox[0] * sc.nvox[1]));
   f3 p0 = mk3((float)px / (float)sc.nvox[0], (float)py / (float)sc.nvox[1], (float)pz / (float)sc.nvox[2]);
   f3 p1 = mk3(((float)px + 1.0f) / (float)sc.nvox[0], ((float)py + 1.0f) / (float)sc.nvox[1], ((float)pz + 1.0f) / (float)sc.nvox[2]);
   f3 a = bounds_lerp(sc.wb_min, sc.wb_max, p0), b = bounds_lerp(sc.wb_min, sc.wb_max, p1);
-  f3 vmn = mk3(min_po(a.x, b.x), min_po(a.y, b.y), min_po(a.z, b.z)), vmx = mk3(max_po(a.x, b.x), max_po(a.y, b.y), max_po(a.z, b.z));
+  vmn = mk3(min_po(a.x, b.x), min_po(a.y, b.y), min_po(a.z, b.z)); vmx = mk3(max_po(a.x, b.x), max_po(a.y, b.y), max_po(a.z, b.z));
+}
+// Lanes of a 128-lane block = (voxel slot, light): with lights_pad = n_lights rounded up to a power of two, a block
+// covers 128 / lights_pad list entries when lights_pad <= 128, else bpv = ceil(n_lights / 128) consecutive blocks cover one.
+__global__ void __launch_bounds__(128) k_lightdist_contrib(DScene sc, const unsigned* __restrict__ list, const unsigned* __restrict__ n_list, unsigned lights_pad, unsigned bpv, float* func) {
+  __shared__ float halton[128 * 5];
+  unsigned li; int j;
+  if (lights_pad <= 128u) { const unsigned vpb = 128u / lights_pad; li = blockIdx.x * vpb + threadIdx.x / lights_pad; j = (int)(threadIdx.x % lights_pad); }
+  else { li = blockIdx.x / bpv; j = (int)((blockIdx.x % bpv) * 128u + threadIdx.x); }  // bpv = ceil(n_lights / 128)
+  if ((lights_pad <= 128u ? blockIdx.x * (128u / lights_pad) : blockIdx.x / bpv) >= *n_list) return;  // whole block idle
+  for (unsigned i = threadIdx.x; i < 128u * 5u; i += blockDim.x) halton[i] = radical_inverse((int)(i % 5u), (unsigned long long)(i / 5u));
+  __syncthreads();
+  if (li >= *n_list || j >= sc.n_lights) return;
+  const long v = (long)list[li];
+  f3 vmn, vmx; voxel_bounds(sc, v, vmn, vmx);
+  const DLight& light = sc.lights[j];
+  float contrib = 0.0f;
+  for (int i = 0; i < 128; ++i) {
+    Interaction intr;
+    intr.p = bounds_lerp(vmn, vmx, mk3(halton[5 * i], halton[5 * i + 1], halton[5 * i + 2]));
+    intr.p_error = mk3(0, 0, 0); intr.wo = mk3(1, 0, 0); intr.n = mk3(0, 0, 0);
+    LiSample s = light_sample_li(sc, light, intr, mk2(halton[5 * i + 3], halton[5 * i + 4]));
+    if (s.pdf > 0.0f) contrib += lum_y(s.li) / s.pdf;
+  }
+  func[v * sc.n_lights + j] = contrib;
+}
+__global__ void __launch_bounds__(128) k_lightdist_finish(DScene sc, const unsigned* __restrict__ list, const unsigned* __restrict__ n_list, float* func, float* cdf, float* fint) {
+  const unsigned li = blockIdx.x * blockDim.x + threadIdx.x;
+  if (li >= *n_list) return;
+  const long v = (long)list[li];
   const int nl = sc.n_lights;
   float* fv = func + v * nl; float* cv = cdf + v * (nl + 1);
   float sum = 0.0f;
-  for (int j = 0; j < nl; ++j) {
-    const DLight& light = sc.lights[j];
-    float contrib = 0.0f;
-    for (int i = 0; i < 128; ++i) {
-      Interaction intr;
-      intr.p = bounds_lerp(vmn, vmx, mk3(halton[5 * i], halton[5 * i + 1], halton[5 * i + 2]));
-      intr.p_error = mk3(0, 0, 0); intr.wo = mk3(1, 0, 0); intr.n = mk3(0, 0, 0);
-      LiSample s = light_sample_li(sc, light, intr, mk2(halton[5 * i + 3], halton[5 * i + 4]));
-      if (s.pdf > 0.0f) contrib += lum_y(s.li) / s.pdf;
-    }
-    fv[j] = contrib;
-    sum += contrib;
-  }
+  for (int j = 0; j < nl; ++j) sum += fv[j];
   float avg = sum / (float)(128ull * (unsigned long long)nl);
   float min_contrib = avg > 0.0f ? 0.001f * avg : 1.0f;
   // Distribution1D::new (distribution1d.rs:11-42)
