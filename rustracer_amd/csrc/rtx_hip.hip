@@ -780,7 +780,7 @@ extern "C" int rt_render(rt_scene* s, const rt_camera* cam, const rt_film_desc* 
         launch_trace<false>(s, count, ps.mi_o, ps.mi_d, ps.q_mis, ps.cnt_out + 2 * RT_QSHARDS, ps.shard_cap, 0, ps.mi_hit, nullptr, dstats, ST_RAYS_MIS, ST_NODES_MIS, ST_TRIS_MIS, stream);
         tm.end();
         tm.begin(&stats.ms_resolve);
-        hipLaunchKernelGGL(k_resolve, dim3((unsigned)s->n_cu), dim3(256), 0, stream, s->d, ps);  // a short queue: one block per CU
+        hipLaunchKernelGGL(k_resolve, dim3(pgrid), dim3(256), 0, stream, s->d, ps);
         tm.end();
         stats.launches_trace_closest += 2;
         ps.q_in = q_first;
