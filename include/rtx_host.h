@@ -72,6 +72,29 @@ int rtxh_trace_device(rtxh_scene*, const void* d_rays, uint64_t n, void* d_hits,
 int rtxh_light_distribution(rtxh_scene*, int32_t n_voxels[3], float* func, float* cdf, float* func_int);
 const char* rtxh_last_error(void);
 
+/* ---- input formats on the caller's side of the path ------------------------------------
+ * plymesh::create (rc/shapes/plymesh.rs:18-186, parser = ply-rs 0.1.3): ascii, binary_little_endian and
+ * binary_big_endian PLY with elements `vertex` and `face`. As in the reference only `float` vertex properties are
+ * taken (x y z required; nx ny nz; u v | s t | texture_u texture_v | texture_s texture_t), other properties are
+ * parsed and ignored; `face.vertex_indices` must be a list of int or uint (any count type); triangles are kept, a
+ * quad (a b c d) becomes (a b c) (d a c) (:101-123), other faces are dropped; any other element is an error (the
+ * reference panics, :97). Returns arrays owned by the library until rtxh_ply_free. */
+typedef struct rtxh_ply {
+  int32_t n_verts, n_tris;
+  float* P;       /* n_verts x 3 */
+  float* N;       /* n_verts x 3 or NULL */
+  float* UV;      /* n_verts x 2 or NULL */
+  int32_t* idx;   /* n_tris x 3 */
+  int32_t n_dropped_faces;
+} rtxh_ply;
+int rtxh_ply_read(const char* path, rtxh_ply* out);
+void rtxh_ply_free(rtxh_ply* ply);
+/* read_image_pfm (rc/imageio.rs:179-246): "PF" (rgb) or "Pf" (grey, replicated) header, width, height, scale whose
+ * sign gives the byte order and whose magnitude multiplies the samples when != 1; rows are flipped so that row 0 is
+ * the top of the image. rgb: width*height*3 floats owned by the library until rtxh_free. */
+int rtxh_pfm_read(const char* path, int32_t* width, int32_t* height, float** rgb);
+void rtxh_free(void* p);
+
 #ifdef __cplusplus
 }
 #endif

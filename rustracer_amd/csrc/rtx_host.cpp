@@ -7,6 +7,8 @@
 
 #include <algorithm>
 #include <cmath>
+#include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <limits>
 #include <string>
@@ -608,4 +610,169 @@ int rtxh_light_distribution(rtxh_scene* s, int32_t n_voxels[3], float* func, flo
   return rt_light_distribution(s->dev, n_voxels, func, cdf, func_int);
 }
 
+
+// ---------------------------------------------------------------------------------------------- PLY / PFM readers
+namespace {
+struct PlyProp { std::string name; int type = -1; bool is_list = false; int count_type = -1; };  // type ids below
+struct PlyElem { std::string name; size_t count = 0; std::vector<PlyProp> props; };
+// scalar type ids: 0 char 1 uchar 2 short 3 ushort 4 int 5 uint 6 float 7 double
+int ply_type_id(const std::string& t) {
+  static const char* names[][2] = {{"char", "int8"}, {"uchar", "uint8"}, {"short", "int16"}, {"ushort", "uint16"}, {"int", "int32"}, {"uint", "uint32"}, {"float", "float32"}, {"double", "float64"}};
+  for (int i = 0; i < 8; ++i) if (t == names[i][0] || t == names[i][1]) return i;
+  return -1;
+}
+const int kPlySize[8] = {1, 1, 2, 2, 4, 4, 4, 8};
+struct PlyReader {
+  FILE* f = nullptr; int format = 0;  // 0 ascii, 1 little endian, 2 big endian
+  bool read_scalar(int type, double& out) {
+    if (format == 0) { return fscanf(f, "%lf", &out) == 1; }
+    unsigned char b[8]; const int n = kPlySize[type];
+    if (fread(b, 1, (size_t)n, f) != (size_t)n) return false;
+    if (format == 2) for (int i = 0; i < n / 2; ++i) std::swap(b[i], b[n - 1 - i]);
+    switch (type) {
+      case 0: { int8_t v; memcpy(&v, b, 1); out = v; break; }
+      case 1: { uint8_t v; memcpy(&v, b, 1); out = v; break; }
+      case 2: { int16_t v; memcpy(&v, b, 2); out = v; break; }
+      case 3: { uint16_t v; memcpy(&v, b, 2); out = v; break; }
+      case 4: { int32_t v; memcpy(&v, b, 4); out = v; break; }
+      case 5: { uint32_t v; memcpy(&v, b, 4); out = v; break; }
+      case 6: { float v; memcpy(&v, b, 4); out = v; break; }
+      default: { double v; memcpy(&v, b, 8); out = v; break; }
+    }
+    return true;
+  }
+};
+}  // namespace
+
+int rtxh_ply_read(const char* path, rtxh_ply* out) {
+  if (!path || !out) return fail(RT_ERR_INVALID, "null argument");
+  g_err.clear();
+  memset(out, 0, sizeof(*out));
+  PlyReader rd; rd.f = fopen(path, "rb");
+  if (!rd.f) return fail(RT_ERR_INVALID, std::string("cannot open ") + path);
+  struct Closer { FILE* f; ~Closer() { if (f) fclose(f); } } closer{rd.f};
+  char line[1024];
+  if (!fgets(line, sizeof line, rd.f) || strncmp(line, "ply", 3) != 0) return fail(RT_ERR_INVALID, "not a PLY file");
+  std::vector<PlyElem> elems; bool have_format = false, ended = false;
+  while (fgets(line, sizeof line, rd.f)) {
+    char a[256] = "", b[256] = "", c[256] = "", d[256] = "", e[256] = "";
+    const int n = sscanf(line, "%255s %255s %255s %255s %255s", a, b, c, d, e);
+    if (n <= 0) continue;
+    const std::string kw = a;
+    if (kw == "end_header") { ended = true; break; }
+    if (kw == "comment" || kw == "obj_info") continue;
+    if (kw == "format") {
+      const std::string fm = b;
+      if (fm == "ascii") rd.format = 0; else if (fm == "binary_little_endian") rd.format = 1; else if (fm == "binary_big_endian") rd.format = 2;
+      else return fail(RT_ERR_INVALID, "unknown PLY format " + fm);
+      have_format = true;
+    } else if (kw == "element" && n >= 3) { PlyElem el; el.name = b; el.count = (size_t)strtoull(c, nullptr, 10); elems.push_back(el); }
+    else if (kw == "property" && !elems.empty()) {
+      PlyProp p;
+      if (std::string(b) == "list" && n >= 5) { p.is_list = true; p.count_type = ply_type_id(c); p.type = ply_type_id(d); p.name = e; if (p.count_type < 0) return fail(RT_ERR_INVALID, "bad PLY list count type"); }
+      else if (n >= 3) { p.type = ply_type_id(b); p.name = c; }
+      if (p.type < 0) return fail(RT_ERR_INVALID, std::string("unknown PLY property type in: ") + line);
+      elems.back().props.push_back(p);
+    } else return fail(RT_ERR_INVALID, std::string("unexpected PLY header line: ") + line);
+  }
+  if (!ended || !have_format) return fail(RT_ERR_INVALID, "truncated PLY header");
+  size_t vertex_count = 0, face_count = 0; bool has_normals = false, has_texture = false;
+  for (const PlyElem& el : elems) {
+    auto has = [&](const char* k) { for (const PlyProp& p : el.props) if (p.name == k) return true; return false; };
+    if (el.name == "vertex") {
+      vertex_count = el.count;
+      if (!has("x") || !has("y") || !has("z")) return fail(RT_ERR_INVALID, "PLY: vertex coordinate property not found");  // plymesh.rs:42-51
+      has_normals = has("nx") && has("ny") && has("nz");
+      has_texture = (has("u") && has("v")) || (has("s") && has("t")) || (has("texture_u") && has("texture_v")) || (has("texture_s") && has("texture_t"));
+    } else if (el.name == "face") face_count = el.count;
+  }
+  if (vertex_count == 0 || face_count == 0) return fail(RT_ERR_INVALID, "PLY file is invalid: no face/vertex elements found");  // :73-79
+  if (vertex_count > 0x7fffffffull || face_count > 0x3fffffffull) return fail(RT_ERR_INVALID, "PLY too large");
+  std::vector<float> P(vertex_count * 3, 0.0f), N(has_normals ? vertex_count * 3 : 0, 0.0f), UV(has_texture ? vertex_count * 2 : 0, 0.0f);
+  std::vector<int32_t> idx; idx.reserve(face_count * 3);
+  int32_t dropped = 0;
+  for (const PlyElem& el : elems) {
+    if (el.name != "vertex" && el.name != "face") return fail(RT_ERR_INVALID, "unexpected PLY element \"" + el.name + "\"");  // panics in the reference (:97)
+    for (size_t i = 0; i < el.count; ++i) {
+      std::vector<int32_t> face;
+      for (const PlyProp& p : el.props) {
+        if (!p.is_list) {
+          double v;
+          if (!rd.read_scalar(p.type, v)) return fail(RT_ERR_INVALID, "truncated PLY payload");
+          if (el.name == "vertex" && p.type == 6) {  // only Property::Float is taken (plymesh.rs:196-214)
+            const float fv = (float)v; const std::string& k = p.name;
+            if (k == "x") P[3 * i] = fv; else if (k == "y") P[3 * i + 1] = fv; else if (k == "z") P[3 * i + 2] = fv;
+            else if (has_normals && k == "nx") N[3 * i] = fv; else if (has_normals && k == "ny") N[3 * i + 1] = fv; else if (has_normals && k == "nz") N[3 * i + 2] = fv;
+            else if (has_texture && (k == "u" || k == "texture_u" || k == "s" || k == "texture_s")) UV[2 * i] = fv;
+            else if (has_texture && (k == "v" || k == "t" || k == "texture_v" || k == "texture_t")) UV[2 * i + 1] = fv;
+          }
+        } else {
+          double cnt;
+          if (!rd.read_scalar(p.count_type, cnt) || cnt < 0 || cnt > 1e6) return fail(RT_ERR_INVALID, "bad PLY list");
+          const bool take = el.name == "face" && p.name == "vertex_indices" && (p.type == 4 || p.type == 5);  // ListInt / ListUInt only (:229-234)
+          for (int k = 0; k < (int)cnt; ++k) {
+            double v;
+            if (!rd.read_scalar(p.type, v)) return fail(RT_ERR_INVALID, "truncated PLY payload");
+            if (take) face.push_back((int32_t)(int64_t)v);
+          }
+        }
+      }
+      if (el.name == "face") {
+        const size_t L = face.size();
+        if (L != 3 && L != 4) { ++dropped; continue; }  // :104-107
+        for (size_t k = 0; k < L; ++k) if (face[k] < 0 || (size_t)face[k] >= vertex_count) return fail(RT_ERR_INVALID, "PLY face index out of range");
+        idx.push_back(face[0]); idx.push_back(face[1]); idx.push_back(face[2]);
+        if (L == 4) { idx.push_back(face[3]); idx.push_back(face[0]); idx.push_back(face[2]); }  // :113-118
+      }
+    }
+  }
+  auto dup = [](const void* src, size_t bytes) -> void* { void* p = malloc(bytes ? bytes : 1); if (p && bytes) memcpy(p, src, bytes); return p; };
+  out->n_verts = (int32_t)vertex_count; out->n_tris = (int32_t)(idx.size() / 3); out->n_dropped_faces = dropped;
+  out->P = (float*)dup(P.data(), P.size() * 4);
+  out->N = has_normals ? (float*)dup(N.data(), N.size() * 4) : nullptr;
+  out->UV = has_texture ? (float*)dup(UV.data(), UV.size() * 4) : nullptr;
+  out->idx = (int32_t*)dup(idx.data(), idx.size() * 4);
+  return RT_OK;
+}
+void rtxh_ply_free(rtxh_ply* p) { if (!p) return; free(p->P); free(p->N); free(p->UV); free(p->idx); memset(p, 0, sizeof(*p)); }
+void rtxh_free(void* p) { free(p); }
+
+int rtxh_pfm_read(const char* path, int32_t* width, int32_t* height, float** rgb) {
+  if (!path || !width || !height || !rgb) return fail(RT_ERR_INVALID, "null argument");
+  g_err.clear();
+  FILE* f = fopen(path, "rb");
+  if (!f) return fail(RT_ERR_INVALID, std::string("cannot open ") + path);
+  struct Closer { FILE* f; ~Closer() { fclose(f); } } closer{f};
+  auto read_word = [&]() {  // imageio.rs:166-177: bytes up to the next ' ', '\n' or '\t' (which is consumed)
+    std::string w; int c;
+    while ((c = fgetc(f)) != EOF) { if (c == ' ' || c == '\n' || c == '\t') break; w.push_back((char)c); }
+    return w;
+  };
+  const std::string magic = read_word();
+  const int nc = magic == "Pf" ? 1 : (magic == "PF" ? 3 : 0);
+  if (!nc) return fail(RT_ERR_INVALID, std::string("error reading PFM file ") + path);
+  char* end = nullptr;
+  std::string w = read_word(); const unsigned long long W = strtoull(w.c_str(), &end, 10); if (w.empty() || *end) return fail(RT_ERR_INVALID, "PFM: failed to parse width");
+  w = read_word(); const unsigned long long H = strtoull(w.c_str(), &end, 10); if (w.empty() || *end) return fail(RT_ERR_INVALID, "PFM: failed to parse height");
+  w = read_word(); const float scale = strtof(w.c_str(), &end); if (w.empty() || *end) return fail(RT_ERR_INVALID, "PFM: failed to parse scale");
+  if (W == 0 || H == 0 || W > 65536 || H > 65536) return fail(RT_ERR_INVALID, "PFM: bad dimensions");
+  const bool file_little = scale < 0.0f;
+  std::vector<float> row((size_t)W * nc);
+  float* out = (float*)malloc((size_t)W * H * 3 * sizeof(float));
+  if (!out) return fail(RT_ERR_INVALID, "out of memory");
+  for (long long y = (long long)H - 1; y >= 0; --y) {  // flip in Y: P*M has its origin at the lower left (:217)
+    if (fread(row.data(), 4, row.size(), f) != row.size()) { free(out); return fail(RT_ERR_INVALID, "PFM: truncated data"); }
+    for (size_t i = 0; i < row.size(); ++i) {
+      unsigned char b[4]; memcpy(b, &row[i], 4);
+      if (!file_little) { std::swap(b[0], b[3]); std::swap(b[1], b[2]); }
+      float v; memcpy(&v, b, 4);
+      if (fabsf(scale) != 1.0f) v *= fabsf(scale);
+      const size_t x = i / nc, ch = i % nc;
+      if (nc == 1) { float* o = out + ((size_t)y * W + x) * 3; o[0] = o[1] = o[2] = v; }
+      else out[((size_t)y * W + x) * 3 + ch] = v;
+    }
+  }
+  *width = (int32_t)W; *height = (int32_t)H; *rgb = out;
+  return RT_OK;
+}
 }  // extern "C"

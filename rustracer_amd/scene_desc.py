@@ -260,6 +260,17 @@ class SceneDesc:
     def add_quad(self, p0, p1, p2, p3, material: int, **kw) -> int:
         return self.add_mesh([p0, p1, p2, p3], [[0, 1, 2], [0, 2, 3]], material, **kw)
 
+    def add_ply(self, path, material: int, **kw) -> int:
+        """Shape "plymesh" (rc/shapes/plymesh.rs): vertices, normals, uvs and (split) faces from a PLY file."""
+        from .ingest import read_ply
+        m = read_ply(path)
+        return self.add_mesh(m["P"], m["idx"], material, N=m["N"], UV=m["UV"], **kw)
+
+    def add_pfm_mip(self, path, **kw) -> int:
+        """An image-map / environment MIP pyramid from a PFM file (rc/imageio.rs:179-246)."""
+        from .ingest import read_pfm
+        return self.add_mip(read_pfm(path), **kw)
+
     # ---- lights --------------------------------------------------------------------------
     def point_light(self, pos, I=(1.0, 1.0, 1.0)) -> int:
         self.lights.append(Light(LIGHT_POINT, rgb=tuple(I), vec=tuple(pos)))

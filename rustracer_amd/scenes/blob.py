@@ -7,14 +7,20 @@ from ..scene_desc import SceneDesc
 from .procedural import displaced_sphere
 
 
-def blob_scene(nu: int = 1024, nv: int = 512, xres: int = 1280, yres: int = 720, spp: int = 256, seed: int = 1234) -> SceneDesc:
+def blob_scene(nu: int = 1024, nv: int = 512, xres: int = 1280, yres: int = 720, spp: int = 256, seed: int = 1234, via_ply: str = None) -> SceneDesc:
+    """via_ply: path; the mesh is written there as binary little-endian PLY and read back through the host's PLY reader."""
     s = SceneDesc()
     s.name = f"blob-{2 * nu * nv}"
     body = s.matte((0.6, 0.6, 0.6))
     ground = s.matte((0.4, 0.38, 0.35))
     lm = s.matte((0.5, 0.5, 0.5))
     P, idx, N, UV = displaced_sphere(nu, nv, (0.0, 1.1, 0.0), 1.0, 0.18, seed)
-    s.add_mesh(P, idx, body, N=N, UV=UV)
+    if via_ply:
+        from ..ingest import write_ply
+        write_ply(via_ply, P, idx, N, UV)
+        s.add_ply(via_ply, body)
+    else:
+        s.add_mesh(P, idx, body, N=N, UV=UV)
     s.add_quad((-6.0, 0.0, -6.0), (-6.0, 0.0, 6.0), (6.0, 0.0, 6.0), (6.0, 0.0, -6.0), ground)
     # light above, facing down
     s.add_quad((-1.5, 4.5, -1.5), (1.5, 4.5, -1.5), (1.5, 4.5, 1.5), (-1.5, 4.5, 1.5), lm, emission=(18.0, 17.0, 15.0))
