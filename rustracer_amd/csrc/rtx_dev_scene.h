@@ -102,6 +102,8 @@ RT_DEVN bool tri_test_call(f3 p0, f3 p1, f3 p2, const Ray& ray, TriHit& h) { ret
 // Bounds3::intersect_p_fast (bounds.rs:127-157): no (1 + 2 gamma3) widening, as in the reference.
 RT_DEV bool slab_test(float4 n0, float4 n1, const Ray& ray, f3 inv_dir, int neg_x, int neg_y, int neg_z) {
   // n0 = {min.x, min.y, min.z, max.x}, n1 = {max.y, max.z, ..}
+  // The reference leaves at the first failing clause; every clause is a pure comparison, so evaluating all of them and
+  // combining the predicates gives the same answer without the divergent branches (which cost more than the arithmetic).
   float bx0 = neg_x ? n0.w : n0.x, bx1 = neg_x ? n0.x : n0.w;
   float by0 = neg_y ? n1.x : n0.y, by1 = neg_y ? n0.y : n1.x;
   float bz0 = neg_z ? n1.y : n0.z, bz1 = neg_z ? n0.z : n1.y;
@@ -109,15 +111,15 @@ RT_DEV bool slab_test(float4 n0, float4 n1, const Ray& ray, f3 inv_dir, int neg_
   float tmax = (bx1 - ray.o.x) * inv_dir.x;
   float tymin = (by0 - ray.o.y) * inv_dir.y;
   float tymax = (by1 - ray.o.y) * inv_dir.y;
-  if ((tmin > tymax) || (tymin > tmax)) return false;
-  if (tymin > tmin) tmin = tymin;
-  if (tymax < tmax) tmax = tymax;
+  const bool miss_xy = (tmin > tymax) | (tymin > tmax);
+  tmin = tymin > tmin ? tymin : tmin;
+  tmax = tymax < tmax ? tymax : tmax;
   float tzmin = (bz0 - ray.o.z) * inv_dir.z;
   float tzmax = (bz1 - ray.o.z) * inv_dir.z;
-  if ((tmin > tzmax) || (tzmin > tmax)) return false;
-  if (tzmin > tmin) tmin = tzmin;
-  if (tzmax < tmax) tmax = tzmax;
-  return tmin < ray.t_max && tmax > 0.0f;
+  const bool miss_z = (tmin > tzmax) | (tzmin > tmax);
+  tmin = tzmin > tmin ? tzmin : tmin;
+  tmax = tzmax < tmax ? tzmax : tmax;
+  return !miss_xy & !miss_z & (tmin < ray.t_max) & (tmax > 0.0f);
 }
 
 RT_DEV void load_tri(const float4* tri_p, int prim, f3& p0, f3& p1, f3& p2) {

@@ -649,7 +649,7 @@ __global__ void __launch_bounds__(BLOCK) k_trace_big(DScene sc, const float4* __
 //   child code: bit 31 clear: interior node, bits 0-28 node index, bits 29-30 split axis
 //               bit 31 set  : leaf, bits 0-25 first triangle, bits 26-30 triangle count - 1
 RT_DEV bool slab_geom(float4 n0, float4 n1, const Ray& ray, f3 inv_dir, int neg_x, int neg_y, int neg_z, float& tmin_out) {
-  // Bounds3::intersect_p_fast (bounds.rs:127-157) without its `tmin < ray.t_max` clause; same operations, same order
+  // Bounds3::intersect_p_fast (bounds.rs:127-157) without its `tmin < ray.t_max` clause; same operations, predicates combined (see slab_test)
   float bx0 = neg_x ? n0.w : n0.x, bx1 = neg_x ? n0.x : n0.w;
   float by0 = neg_y ? n1.x : n0.y, by1 = neg_y ? n0.y : n1.x;
   float bz0 = neg_z ? n1.y : n0.z, bz1 = neg_z ? n0.z : n1.y;
@@ -657,16 +657,16 @@ RT_DEV bool slab_geom(float4 n0, float4 n1, const Ray& ray, f3 inv_dir, int neg_
   float tmax = (bx1 - ray.o.x) * inv_dir.x;
   float tymin = (by0 - ray.o.y) * inv_dir.y;
   float tymax = (by1 - ray.o.y) * inv_dir.y;
-  if ((tmin > tymax) || (tymin > tmax)) return false;
-  if (tymin > tmin) tmin = tymin;
-  if (tymax < tmax) tmax = tymax;
+  const bool miss_xy = (tmin > tymax) | (tymin > tmax);
+  tmin = tymin > tmin ? tymin : tmin;
+  tmax = tymax < tmax ? tymax : tmax;
   float tzmin = (bz0 - ray.o.z) * inv_dir.z;
   float tzmax = (bz1 - ray.o.z) * inv_dir.z;
-  if ((tmin > tzmax) || (tzmin > tmax)) return false;
-  if (tzmin > tmin) tmin = tzmin;
-  if (tzmax < tmax) tmax = tzmax;
+  const bool miss_z = (tmin > tzmax) | (tzmin > tmax);
+  tmin = tzmin > tmin ? tzmin : tmin;
+  tmax = tzmax < tmax ? tzmax : tmax;
   tmin_out = tmin;
-  return tmax > 0.0f;
+  return !miss_xy & !miss_z & (tmax > 0.0f);
 }
 #define RT_PAIR_LEAF 0x80000000u
 
