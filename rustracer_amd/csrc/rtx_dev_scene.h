@@ -72,13 +72,15 @@ RT_DEV bool tri_test_pre(f3 p0, f3 p1, f3 p2, const Ray& ray, const RayPre& rp, 
     double p1txp0ty = (double)p1t.x * (double)p0t.y, p1typ0tx = (double)p1t.y * (double)p0t.x;
     e2 = (float)(p1typ0tx - p1txp0ty);
   }
-  if ((e0 < 0.0f || e1 < 0.0f || e2 < 0.0f) && (e0 > 0.0f || e1 > 0.0f || e2 > 0.0f)) return false;
+  // The reference's three rejection tests (edge signs, det == 0, t range; mesh.rs:272-296) are pure comparisons: they are
+  // evaluated together and leave through one branch instead of three.
+  const bool sign_fail = ((e0 < 0.0f) | (e1 < 0.0f) | (e2 < 0.0f)) & ((e0 > 0.0f) | (e1 > 0.0f) | (e2 > 0.0f));
   float det = e0 + e1 + e2;
-  if (det == 0.0f) return false;
   p0t.z *= sz; p1t.z *= sz; p2t.z *= sz;
   float t_scaled = e0 * p0t.z + e1 * p1t.z + e2 * p2t.z;
-  if ((det < 0.0f && (t_scaled >= 0.0f || t_scaled < ray.t_max * det)) || (det > 0.0f && (t_scaled <= 0.0f || t_scaled > ray.t_max * det)))
-    return false;
+  const float tmd = ray.t_max * det;
+  const bool range_fail = ((det < 0.0f) & ((t_scaled >= 0.0f) | (t_scaled < tmd))) | ((det > 0.0f) & ((t_scaled <= 0.0f) | (t_scaled > tmd)));
+  if (sign_fail | (det == 0.0f) | range_fail) return false;
   float inv_det = 1.0f / det;
   float b0 = e0 * inv_det, b1 = e1 * inv_det, b2 = e2 * inv_det;
   float t = t_scaled * inv_det;
