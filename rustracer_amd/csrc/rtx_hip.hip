@@ -650,11 +650,13 @@ extern "C" int rt_render(rt_scene* s, const rt_camera* cam, const rt_film_desc* 
   const bool all_in_bounds = path->pixel_bounds[0] <= film->sample_bounds[0] && path->pixel_bounds[2] >= film->sample_bounds[2] &&
                              path->pixel_bounds[1] <= film->sample_bounds[1] && path->pixel_bounds[3] >= film->sample_bounds[3];
   // batch / pass sizing. A batch is a range of owned pixels whose sampler tables (2*dims u16 per sample) are built
-  // at once; it is rendered in passes of n_samples consecutive samples of all its pixels, ~2^23 paths per pass.
-  const unsigned long long target_paths = 1ull << 23;
-  unsigned long long batch_pixels = std::max<unsigned long long>(1, std::min<unsigned long long>(owned_pixels, 1ull << 17));  // a rank may own no rows
+  // at once; it is rendered in passes of n_samples consecutive samples of all its pixels, ~2^26 paths (17 GB of path state) per pass.
+  static const int tp_log2 = getenv("RTX_PASS_LOG2") ? atoi(getenv("RTX_PASS_LOG2")) : 26;  // measurement knobs; 2^23 -> 2^26 paths per pass: -9 % (S1), -32 % (S2): fewer, larger launches
+  static const int bp_log2 = getenv("RTX_BATCH_LOG2") ? atoi(getenv("RTX_BATCH_LOG2")) : 18;
+  const unsigned long long target_paths = 1ull << tp_log2;
+  unsigned long long batch_pixels = std::max<unsigned long long>(1, std::min<unsigned long long>(owned_pixels, 1ull << bp_log2));  // a rank may own no rows
   const unsigned long long table_bytes_per_pixel = 2ull * dims * spp * 2ull;
-  while (batch_pixels > 4096 && batch_pixels * table_bytes_per_pixel > (4ull << 30)) batch_pixels >>= 1;  // <= 4 GiB of tables
+  while (batch_pixels > 4096 && batch_pixels * table_bytes_per_pixel > (16ull << 30)) batch_pixels >>= 1;  // <= 16 GiB of tables per buffer
   unsigned pass_samples = (unsigned)std::max<unsigned long long>(1, target_paths / batch_pixels);
   if (pass_samples > spp) pass_samples = spp;
   const unsigned long long chunk_pixels = batch_pixels;
