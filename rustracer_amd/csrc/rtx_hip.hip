@@ -655,6 +655,9 @@ extern "C" int rt_render(rt_scene* s, const rt_camera* cam, const rt_film_desc* 
   static const int bp_log2 = getenv("RTX_BATCH_LOG2") ? atoi(getenv("RTX_BATCH_LOG2")) : 18;
   const unsigned long long target_paths = 1ull << tp_log2;
   unsigned long long batch_pixels = std::max<unsigned long long>(1, std::min<unsigned long long>(owned_pixels, 1ull << bp_log2));  // a rank may own no rows
+  // a shard that fits one batch (e.g. 1/8 of a frame on an 8-GPU run) is still cut in two, so that the second half's sampler
+  // tables are built under the first half's path kernels; only worth it when the whole frame is more than two passes
+  if (owned_pixels <= batch_pixels && owned_pixels >= (1ull << 15) && owned_pixels * spp > 2 * target_paths) batch_pixels = (owned_pixels + 1) / 2;
   const unsigned long long table_bytes_per_pixel = 2ull * dims * spp * 2ull;
   while (batch_pixels > 4096 && batch_pixels * table_bytes_per_pixel > (16ull << 30)) batch_pixels >>= 1;  // <= 16 GiB of tables per buffer
   unsigned pass_samples = (unsigned)std::max<unsigned long long>(1, target_paths / batch_pixels);
