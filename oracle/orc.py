@@ -153,6 +153,19 @@ class OracleScene:
         L.orc_scene_bvh_get(self.h, _p(bounds), _p(offset, C.c_uint32), _p(nprims, C.c_uint16), _p(axis, C.c_uint8), _p(ordered, C.c_int32))
         return dict(bounds=bounds, offset=offset, n_prims=nprims, axis=axis, ordered=ordered)
 
+    def mip_levels(self, mip):
+        L = lib()
+        w, h = C.c_int32(), C.c_int32()
+        n = L.orc_mip_level(self.h, mip, 0, C.byref(w), C.byref(h), None)
+        assert n > 0
+        out = []
+        for lvl in range(n):
+            L.orc_mip_level(self.h, mip, lvl, C.byref(w), C.byref(h), None)
+            a = np.zeros((h.value, w.value, 3), np.float32)
+            L.orc_mip_level(self.h, mip, lvl, C.byref(w), C.byref(h), _p(a))
+            out.append(a)
+        return out
+
     def trace(self, rays: np.ndarray, any_hit: bool = False):
         """rays (n,8) f32: o.xyz, tmax, d.xyz, pad -> dict(t, prim, b0, b1 | occluded), counters"""
         rays = np.ascontiguousarray(rays, np.float32)
@@ -235,6 +248,10 @@ def sampler_retry_scan(spp, dims, pixel0, n, cap=64):
     out = np.zeros(cap, np.uint64)
     k = lib().orc_sampler_retry_scan(spp, dims, C.c_uint64(pixel0), C.c_uint64(n), _p(out, C.c_uint64), cap)
     return out[:k].copy()
+
+
+def round_up_pow2(v):
+    return int(lib().orc_round_up_pow2(int(v)))
 
 
 def rng_stream(seq, n):

@@ -176,7 +176,7 @@ int orc_scene_set_mesh(void* h, const float* P, int nv, const int32_t* idx, int 
 }
 int orc_scene_add_mipmap(void* h, int w, int hgt, const float* rgbdata, int trilinear, float max_aniso, int wrap) {
   Scene* s = (Scene*)h;
-  if (w <= 0 || hgt <= 0 || (w & (w - 1)) || (hgt & (hgt - 1))) return -1;
+  if (w <= 0 || hgt <= 0) return -1;
   auto m = std::make_shared<MipMap>();
   std::vector<RGB> img((size_t)w * hgt);
   for (size_t i = 0; i < img.size(); ++i) img[i] = rgb(rgbdata[3 * i], rgbdata[3 * i + 1], rgbdata[3 * i + 2]);
@@ -184,6 +184,18 @@ int orc_scene_add_mipmap(void* h, int w, int hgt, const float* rgbdata, int tril
   s->mips.push_back(m);
   return (int)s->mips.size() - 1;
 }
+// Inspection (tests): level `level` of MIP pyramid `mip`; returns the number of levels. rgb_out may be NULL.
+int orc_mip_level(void* h, int mip, int level, int* w, int* hgt, float* rgb_out) {
+  Scene* s = (Scene*)h;
+  if (mip < 0 || mip >= (int)s->mips.size()) return -1;
+  const MipMap& m = *s->mips[mip];
+  if (level < 0 || level >= m.levels()) return -1;
+  const MipLevel& l = m.pyramid[level];
+  *w = l.u; *hgt = l.v;
+  if (rgb_out) for (size_t i = 0; i < l.data.size(); ++i) { rgb_out[3 * i] = l.data[i].r; rgb_out[3 * i + 1] = l.data[i].g; rgb_out[3 * i + 2] = l.data[i].b; }
+  return m.levels();
+}
+int orc_round_up_pow2(int v) { return MipMap::round_up_pow2(v); }  // lib.rs:215-224 (reference KAT: lib.rs:341-345)
 int orc_scene_add_texture(void* h, int kind, const float* value, int tex1, int tex2, int amount, int mip, const float* mapping) {
   Scene* s = (Scene*)h;
   Texture t; t.kind = kind; t.value = rgb(value[0], value[1], value[2]); t.tex1 = tex1; t.tex2 = tex2; t.amount = amount; t.mip = mip;

@@ -2,8 +2,8 @@
 // MIPMap (rc/mipmap.rs; rc/blockedarray.rs is only a memory layout and is restated as plain
 // row-major storage), ImageTexture (rc/texture/imagemap.rs:232-235 + UVMapping2D rc/texture/mod.rs:52-60)
 // and InfiniteAreaLight (rc/light/infinite.rs).
-// Only power-of-two images are accepted: the Lanczos re-sampling of mipmap.rs:75-139 is an
-// ingest-side step that no synthetic config needs.
+// Images whose sides are not powers of two are first re-sampled with the reference's 4-tap Lanczos zoom
+// (mipmap.rs:75-139, 362-408).
 #pragma once
 #include <vector>
 #include "orc_scene.h"
@@ -33,9 +33,63 @@ struct MipMap {
   }
   int levels() const { return (int)pyramid.size(); }
 
-  // mipmap.rs:67-194, power-of-two path only. `img` is row-major, res.x * res.y texels.
-  void init(int rx, int ry, const RGB* img, bool trilinear, float max_aniso, int wrap_mode) {
-    do_trilinear = trilinear; max_anisotropy = max_aniso; wrap = wrap_mode; res_x = rx; res_y = ry;
+  static float lanczos(float f) {  // mipmap.rs:395-408
+    float tau = 2.0f, x = fabsf(f);
+    if (x < 1e-5f) return 1.0f;
+    if (x > 1.0f) return 0.0f;
+    x *= kPi;
+    float s = sinf(x * tau) / (x * tau);
+    float l = sinf(x) / x;
+    return s * l;
+  }
+  struct ResampleWeight { int first_texel; float w[4]; };
+  static std::vector<ResampleWeight> resample_weights(int old_res, int new_res) {  // mipmap.rs:362-393
+    std::vector<ResampleWeight> wt((size_t)new_res);
+    const float filter_width = 2.0f;
+    for (int i = 0; i < new_res; ++i) {
+      float center = ((float)i + 0.5f) * (float)old_res / (float)new_res;
+      float first = floorf((center - filter_width) + 0.5f);
+      float w[4];
+      for (int j = 0; j < 4; ++j) { float pos = first + (float)j + 0.5f; w[j] = lanczos((pos - center) / filter_width); }
+      float inv = 1.0f / (w[0] + w[1] + w[2] + w[3]);
+      wt[(size_t)i].first_texel = f2i_sat(first);
+      for (int j = 0; j < 4; ++j) wt[(size_t)i].w[j] = w[j] * inv;
+    }
+    return wt;
+  }
+  static int round_up_pow2(int v) { v -= 1; v |= v >> 1; v |= v >> 2; v |= v >> 4; v |= v >> 8; v |= v >> 16; return v + 1; }  // lib.rs:215-224
+  long wrap_index(long i, long n) const { return wrap == WRAP_REPEAT ? modulo(i, n) : (wrap == WRAP_CLAMP ? clamp_t<long>(i, 0, n - 1) : i); }
+
+  // mipmap.rs:67-194. `img` is row-major, res.x * res.y texels.
+  void init(int rx, int ry, const RGB* img_in, bool trilinear, float max_aniso, int wrap_mode) {
+    do_trilinear = trilinear; max_anisotropy = max_aniso; wrap = wrap_mode;
+    std::vector<RGB> resampled;
+    const RGB* img = img_in;
+    if ((rx & (rx - 1)) != 0 || (ry & (ry - 1)) != 0) {  // :75-139
+      const int px = round_up_pow2(rx), py = round_up_pow2(ry);
+      resampled.assign((size_t)px * py, rgb(0, 0, 0));
+      std::vector<ResampleWeight> sw = resample_weights(rx, px);
+      for (int t = 0; t < ry; ++t)  // zoom in s: only the first res.y rows are filled
+        for (int s = 0; s < px; ++s)
+          for (int j = 0; j < 4; ++j) {
+            long o = wrap_index((long)sw[(size_t)s].first_texel + j, rx);
+            if (o >= 0 && o < rx) resampled[(size_t)t * px + s] = resampled[(size_t)t * px + s] + img_in[(size_t)t * rx + o] * sw[(size_t)s].w[j];
+          }
+      std::vector<ResampleWeight> tw = resample_weights(ry, py);
+      std::vector<RGB> work((size_t)py);
+      for (int s = 0; s < px; ++s) {  // zoom in t, column by column
+        for (int t = 0; t < py; ++t) {
+          work[(size_t)t] = rgb(0, 0, 0);
+          for (int j = 0; j < 4; ++j) {
+            long o = wrap_index((long)tw[(size_t)t].first_texel + j, ry);
+            if (o >= 0 && o < ry) work[(size_t)t] = work[(size_t)t] + resampled[(size_t)o * px + s] * tw[(size_t)t].w[j];
+          }
+        }
+        for (int t = 0; t < py; ++t) resampled[(size_t)t * px + s] = clamp_pos(work[(size_t)t]);  // Clampable::clamp(0, inf), lib.rs:287-295
+      }
+      rx = px; ry = py; img = resampled.data();
+    }
+    res_x = rx; res_y = ry;
     for (int i = 0; i < 128; ++i) {  // :33-44
       float alpha = 2.0f;
       float r2 = (float)i / (128.0f - 1.0f);

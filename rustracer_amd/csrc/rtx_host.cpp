@@ -438,9 +438,72 @@ int rtxh_scene_set_mesh(rtxh_scene* s, const float* P, int32_t nv, const int32_t
   return RT_OK;
 }
 
-int rtxh_scene_add_mipmap(rtxh_scene* s, int32_t w, int32_t h, const float* rgb, int32_t trilinear, float max_aniso, int32_t wrap) {
-  if (!s || !rgb || w <= 0 || h <= 0 || (w & (w - 1)) || (h & (h - 1))) return fail(RT_ERR_INVALID, "images must have power-of-two sides");
+// MIPMap::resample_weights / lanczos (mipmap.rs:362-408)
+static float mip_lanczos(float f) {
+  float tau = 2.0f, x = std::fabs(f);
+  if (x < 1e-5f) return 1.0f;
+  if (x > 1.0f) return 0.0f;
+  x *= 3.14159265358979323846f;
+  float s = std::sin(x * tau) / (x * tau);
+  float l = std::sin(x) / x;
+  return s * l;
+}
+struct MipResampleWeight { int first_texel; float w[4]; };
+static std::vector<MipResampleWeight> mip_resample_weights(int old_res, int new_res) {
+  std::vector<MipResampleWeight> wt((size_t)new_res);
+  const float filter_width = 2.0f;
+  for (int i = 0; i < new_res; ++i) {
+    float center = ((float)i + 0.5f) * (float)old_res / (float)new_res;
+    float first = std::floor((center - filter_width) + 0.5f);
+    float w[4];
+    for (int j = 0; j < 4; ++j) { float pos = first + (float)j + 0.5f; w[j] = mip_lanczos((pos - center) / filter_width); }
+    float inv = 1.0f / (w[0] + w[1] + w[2] + w[3]);
+    wt[(size_t)i].first_texel = (int)first;  // |first| < 2^24: exact
+    for (int j = 0; j < 4; ++j) wt[(size_t)i].w[j] = w[j] * inv;
+  }
+  return wt;
+}
+static int round_up_pow2(int v) { v -= 1; v |= v >> 1; v |= v >> 2; v |= v >> 4; v |= v >> 8; v |= v >> 16; return v + 1; }  // lib.rs:215-224
+
+int rtxh_scene_add_mipmap(rtxh_scene* s, int32_t w, int32_t h, const float* rgb_in, int32_t trilinear, float max_aniso, int32_t wrap) {
+  if (!s || !rgb_in || w <= 0 || h <= 0 || w > 65536 || h > 65536) return fail(RT_ERR_INVALID, "bad image");
   MipLevels m; m.trilinear = trilinear; m.wrap = wrap; m.max_aniso = max_aniso;
+  std::vector<float> resampled;
+  const float* rgb = rgb_in;
+  if ((w & (w - 1)) || (h & (h - 1))) {
+    // MIPMap::new, mipmap.rs:75-139: 4-tap Lanczos zoom to the next powers of two, first along s (rows < h only), then along t
+    const int px = round_up_pow2(w), py = round_up_pow2(h);
+    auto wrap_index = [&](long i, long n) -> long {
+      if (wrap == 0) { long r = i % n; return r < 0 ? r + n : r; }   // Repeat
+      if (wrap == 2) return i < 0 ? 0 : (i > n - 1 ? n - 1 : i);      // Clamp
+      return i;                                                        // Black
+    };
+    resampled.assign((size_t)px * py * 3, 0.0f);
+    std::vector<MipResampleWeight> sw = mip_resample_weights(w, px);
+    for (int t = 0; t < h; ++t)
+      for (int sx = 0; sx < px; ++sx)
+        for (int j = 0; j < 4; ++j) {
+          long o = wrap_index((long)sw[(size_t)sx].first_texel + j, w);
+          if (o >= 0 && o < w)
+            for (int k = 0; k < 3; ++k) resampled[3 * ((size_t)t * px + sx) + k] += rgb_in[3 * ((size_t)t * w + o) + k] * sw[(size_t)sx].w[j];
+        }
+    std::vector<MipResampleWeight> tw = mip_resample_weights(h, py);
+    std::vector<float> work((size_t)py * 3);
+    for (int sx = 0; sx < px; ++sx) {
+      for (int t = 0; t < py; ++t) {
+        float acc[3] = {0.0f, 0.0f, 0.0f};
+        for (int j = 0; j < 4; ++j) {
+          long o = wrap_index((long)tw[(size_t)t].first_texel + j, h);
+          if (o >= 0 && o < h)
+            for (int k = 0; k < 3; ++k) acc[k] += resampled[3 * ((size_t)o * px + sx) + k] * tw[(size_t)t].w[j];
+        }
+        for (int k = 0; k < 3; ++k) work[3 * (size_t)t + k] = acc[k];
+      }
+      for (int t = 0; t < py; ++t)
+        for (int k = 0; k < 3; ++k) { float v = work[3 * (size_t)t + k]; resampled[3 * ((size_t)t * px + sx) + k] = v < 0.0f ? 0.0f : v; }  // clamp(0, inf), lib.rs:264-275
+    }
+    w = px; h = py; rgb = resampled.data();
+  }
   // MIPMap::new (mipmap.rs:158-187): n_levels = 1 + log2(max(res)) as usize; each level = box filter of 4 texels of the finer one
   int n_levels = 1 + (int)f2usz(std::log2((float)std::max(w, h)));
   m.w.push_back(w); m.h.push_back(h); m.off.push_back(0);

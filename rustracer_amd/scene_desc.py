@@ -155,7 +155,6 @@ class SceneDesc:
         data = np.ascontiguousarray(data, dtype=np.float32)
         assert data.ndim == 3 and data.shape[2] == 3
         h, w = data.shape[:2]
-        assert w & (w - 1) == 0 and h & (h - 1) == 0, "power-of-two images only (SURVEY §8(f)-2)"
         self.mipmaps.append(MipImage(data, trilinear, max_aniso, wrap))
         return len(self.mipmaps) - 1
 

@@ -20,13 +20,16 @@ def _zoo(material: str, light: str = "area", res=(40, 32), spp=8, max_depth=5):
     img = s.add_mip(checker_fbm_image(32, 5, (0.9, 0.3, 0.2), (0.2, 0.3, 0.9), 4), trilinear=False, max_aniso=8.0, wrap=WRAP_REPEAT)
     img_tri = s.add_mip(checker_fbm_image(16, 6), trilinear=True, wrap=WRAP_CLAMP)
     img_blk = s.add_mip(checker_fbm_image(16, 7), trilinear=False, max_aniso=2.0, wrap=WRAP_BLACK)
+    img_npot = s.add_mip(checker_fbm_image(32, 8)[:20, :24], trilinear=False, max_aniso=8.0, wrap=WRAP_REPEAT)  # 24 x 20: Lanczos-zoomed to 32 x 32 (mipmap.rs:75-139)
     t_img, t_tri, t_blk = s.image_tex(img, 3, 2, 0.1, 0.2), s.image_tex(img_tri, 2, 2), s.image_tex(img_blk, 1.5, 1.5, -0.2, 0.0)
+    t_npot = s.image_tex(img_npot, 2, 3)
     mats = {
         "matte": lambda: s.matte((0.6, 0.5, 0.4)),
         "oren_nayar": lambda: s.matte((0.6, 0.5, 0.4), sigma=30.0),
         "matte_image_ewa": lambda: s.matte(t_img),
         "matte_image_trilinear_clamp": lambda: s.matte(t_tri),
         "matte_image_black_wrap": lambda: s.matte(t_blk),
+        "matte_image_npot": lambda: s.matte(t_npot),
         "matte_scale_mix_tex": lambda: s.matte(s.mix_tex(s.scale_tex(t_img, s.const_tex((0.9, 0.8, 0.7))), s.const_tex((0.1, 0.6, 0.2)), s.const_tex(0.3))),
         "plastic": lambda: s.plastic((0.3, 0.1, 0.1), (0.5, 0.5, 0.5), 0.15),
         "plastic_noremap": lambda: s.plastic(t_img, (0.4, 0.4, 0.4), 0.2, remap=False),
@@ -83,7 +86,7 @@ def _check(gpu_host, orc, d):
     assert int(sh["paths_scrubbed"]) == int(so["scrubbed"]) if "scrubbed" in so else True
 
 
-MATERIALS = ["matte", "oren_nayar", "matte_image_ewa", "matte_image_trilinear_clamp", "matte_image_black_wrap", "matte_scale_mix_tex", "plastic",
+MATERIALS = ["matte", "oren_nayar", "matte_image_ewa", "matte_image_trilinear_clamp", "matte_image_black_wrap", "matte_image_npot", "matte_scale_mix_tex", "plastic",
              "plastic_noremap", "metal", "metal_aniso", "mirror", "glass", "glass_rough", "uber", "substrate", "translucent", "mix", "mix_nested"]
 
 

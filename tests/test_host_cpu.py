@@ -159,3 +159,29 @@ def test_product_does_not_import_the_oracle():
                 if re.search(r"(from|import)\s+oracle|#include\s+\"[^\"]*orc_|liborc", t):
                     bad.append(f)
     assert not bad, bad
+
+
+@pytest.mark.parametrize("shape,wrap", [((3, 5), 0), ((17, 33), 1), ((60, 100), 2), ((16, 12), 0), ((7, 8), 2)])
+def test_mip_of_a_non_power_of_two_image_is_resampled_like_the_reference(orc, host, shape, wrap):
+    """MIPMap::new's 4-tap Lanczos zoom (rc/mipmap.rs:75-139, 362-408): host == oracle bit for bit, sizes = next powers of two."""
+    from rustracer_amd.scene_desc import SceneDesc
+    rng = np.random.default_rng(shape[0] * 100 + shape[1])
+    img = rng.uniform(0, 1, shape + (3,)).astype(np.float32)
+    s = SceneDesc()
+    m = s.add_mip(img, wrap=wrap)
+    s.add_quad((0, 0, 0), (1, 0, 0), (1, 1, 0), (0, 1, 0), s.matte(s.image_tex(m)))
+    lo, lh = orc.OracleScene(s).mip_levels(0), host.HostScene(s).mip_levels(0)
+    p2 = lambda v: 1 << (int(v) - 1).bit_length()
+    assert lo[0].shape[:2] == (p2(shape[0]), p2(shape[1])) and len(lo) == len(lh)
+    for a, b in zip(lo, lh):
+        assert a.shape == b.shape and np.array_equal(bits(a), bits(b))
+    assert (lo[0] >= 0).all() and np.isfinite(lo[0]).all()  # clamped to [0, inf) after the t pass (:133)
+    # a constant image stays constant where the 4 taps see it whole (weights are normalised, :376-378)
+    c = SceneDesc(); c.add_mip(np.full(shape + (3,), 0.5, np.float32), wrap=0 if wrap == 1 else wrap)
+    c.add_quad((0, 0, 0), (1, 0, 0), (1, 1, 0), (0, 1, 0), c.matte(0.5))
+    assert np.allclose(host.HostScene(c).mip_levels(0)[0], 0.5, atol=1e-6)
+
+
+def test_round_up_pow2_reference_kat(orc):
+    assert orc.round_up_pow2(1023) == 1024 and orc.round_up_pow2(1024) == 1024  # rc/lib.rs:341-345
+    assert [orc.round_up_pow2(v) for v in (1, 2, 3, 5, 17, 1025)] == [1, 2, 4, 8, 32, 2048]
