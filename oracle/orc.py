@@ -250,6 +250,12 @@ def sampler_retry_scan(spp, dims, pixel0, n, cap=64):
     return out[:k].copy()
 
 
+def translate_apply(delta, v, is_vector=False):
+    out = np.zeros(3, np.float32)
+    lib().orc_translate_apply(_p(np.asarray(delta, np.float32)), _p(np.asarray(v, np.float32)), int(is_vector), _p(out))
+    return out
+
+
 def round_up_pow2(v):
     return int(lib().orc_round_up_pow2(int(v)))
 

@@ -195,6 +195,12 @@ int orc_mip_level(void* h, int mip, int level, int* w, int* hgt, float* rgb_out)
   if (rgb_out) for (size_t i = 0; i < l.data.size(); ++i) { rgb_out[3 * i] = l.data[i].r; rgb_out[3 * i + 1] = l.data[i].g; rgb_out[3 * i + 2] = l.data[i].b; }
   return m.levels();
 }
+// `&Transform * &Point3f` / `* &Vector3f` (transform.rs:264-303) for a translation (reference KAT: ray.rs:120-128)
+void orc_translate_apply(const float* delta3, const float* in3, int is_vector, float* out3) {
+  M44 m = xf_translate(v3(delta3[0], delta3[1], delta3[2])).m;
+  V3 r = is_vector ? xf_vector(m, v3(in3[0], in3[1], in3[2])) : xf_point(m, v3(in3[0], in3[1], in3[2]));
+  out3[0] = r.x; out3[1] = r.y; out3[2] = r.z;
+}
 int orc_round_up_pow2(int v) { return MipMap::round_up_pow2(v); }  // lib.rs:215-224 (reference KAT: lib.rs:341-345)
 int orc_scene_add_texture(void* h, int kind, const float* value, int tex1, int tex2, int amount, int mip, const float* mapping) {
   Scene* s = (Scene*)h;

@@ -57,6 +57,12 @@ def test_bounds2i_iteration_order_kat(orc):
     assert L.orc_bounds2i_iter(2**31 - 1, 2**31 - 1, -2**31, -2**31, p, 16) == 0  # Bounds2i::new()
 
 
+def test_transform_translation_kat(orc):
+    """rc/ray.rs:120-128 (test_translation): translate(1,1,1) * Ray{o=(1,0,0), d=(0,1,0)} == Ray{o=(2,1,1), d unchanged}."""
+    assert orc.translate_apply((1, 1, 1), (1, 0, 0)).tolist() == [2.0, 1.0, 1.0]
+    assert orc.translate_apply((1, 1, 1), (0, 1, 0), is_vector=True).tolist() == [0.0, 1.0, 0.0]
+
+
 def test_bxdf_flag_subset_kat():
     # rc/bsdf/mod.rs:271-278 with the bit values of :24-32
     refl, trans, spec = 1, 2, 16
