@@ -49,12 +49,14 @@ typedef struct rt_tri_meta {
   uint32_t source_index; /* triangle index before BVH re-ordering (diagnostics) */
 } rt_tri_meta;
 
-/* -- textures: replaces dyn Texture<T> (rc/texture/{constant,scale,mix,imagemap}.rs) ------ */
-enum { RT_TEX_CONST = 0, RT_TEX_SCALE = 1, RT_TEX_MIX = 2, RT_TEX_IMAGE = 3 };
+/* -- textures: replaces dyn Texture<T> (rc/texture/{constant,scale,mix,imagemap,checkerboard,uv,fbm}.rs) --
+ * checkerboard (2D): tex1, tex2, mapping, amount = AAMethod (0 none, 1 closedform); uv: mapping;
+ * fbm: value[0] = omega, amount = octaves (texture space = world space). */
+enum { RT_TEX_CONST = 0, RT_TEX_SCALE = 1, RT_TEX_MIX = 2, RT_TEX_IMAGE = 3, RT_TEX_CHECKER = 4, RT_TEX_UV = 5, RT_TEX_FBM = 6 };
 typedef struct rt_texture {
   int32_t kind;
   float value[3];             /* constant; float textures use value[0]                 */
-  int32_t tex1, tex2, amount; /* scale / mix operands                                  */
+  int32_t tex1, tex2, amount; /* scale / mix / checkerboard operands (see above)       */
   int32_t image;              /* imagemap: index into images[]                         */
   float mapping[4];           /* UVMapping2D su sv du dv (rc/texture/mod.rs:38-61)      */
 } rt_texture;

@@ -153,6 +153,12 @@ class OracleScene:
         L.orc_scene_bvh_get(self.h, _p(bounds), _p(offset, C.c_uint32), _p(nprims, C.c_uint16), _p(axis, C.c_uint8), _p(ordered, C.c_int32))
         return dict(bounds=bounds, offset=offset, n_prims=nprims, axis=axis, ordered=ordered)
 
+    def tex_probe(self, tex, uv=(0.0, 0.0), p=(0.0, 0.0, 0.0), duv=(0.0, 0.0, 0.0, 0.0), dpdx=(0.0, 0.0, 0.0), dpdy=(0.0, 0.0, 0.0)):
+        out = np.zeros(3, np.float32)
+        f = lambda v: _p(np.asarray(v, np.float32))
+        lib().orc_tex_probe(self.h, int(tex), f(uv), f(p), f(duv), f(dpdx), f(dpdy), _p(out))
+        return out
+
     def mip_levels(self, mip):
         L = lib()
         w, h = C.c_int32(), C.c_int32()
@@ -254,6 +260,12 @@ def translate_apply(delta, v, is_vector=False):
     out = np.zeros(3, np.float32)
     lib().orc_translate_apply(_p(np.asarray(delta, np.float32)), _p(np.asarray(v, np.float32)), int(is_vector), _p(out))
     return out
+
+
+def noise(x, y, z):
+    L = lib()
+    L.orc_noise.restype = C.c_float
+    return float(L.orc_noise(C.c_float(x), C.c_float(y), C.c_float(z)))
 
 
 def round_up_pow2(v):

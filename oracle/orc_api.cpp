@@ -184,6 +184,17 @@ int orc_scene_add_mipmap(void* h, int w, int hgt, const float* rgbdata, int tril
   s->mips.push_back(m);
   return (int)s->mips.size() - 1;
 }
+// Texture::evaluate at a hand-made SurfaceInteraction (tests): uv, p, (dudx, dvdx, dudy, dvdy), dpdx, dpdy.
+void orc_tex_probe(void* h, int tex, const float* uv2, const float* p3, const float* duv4, const float* dpdx3, const float* dpdy3, float* out3) {
+  Scene* s = (Scene*)h;
+  SurfaceInteraction si;
+  si.uv = P2{uv2[0], uv2[1]}; si.hit.p = v3(p3[0], p3[1], p3[2]);
+  si.dudx = duv4[0]; si.dvdx = duv4[1]; si.dudy = duv4[2]; si.dvdy = duv4[3];
+  si.dpdx = v3(dpdx3[0], dpdx3[1], dpdx3[2]); si.dpdy = v3(dpdy3[0], dpdy3[1], dpdy3[2]);
+  RGB c = s->tex_eval(tex, si);
+  out3[0] = c.r; out3[1] = c.g; out3[2] = c.b;
+}
+float orc_noise(float x, float y, float z) { return noise_perlin(x, y, z); }
 // Inspection (tests): level `level` of MIP pyramid `mip`; returns the number of levels. rgb_out may be NULL.
 int orc_mip_level(void* h, int mip, int level, int* w, int* hgt, float* rgb_out) {
   Scene* s = (Scene*)h;

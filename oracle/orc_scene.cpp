@@ -413,6 +413,62 @@ RGB Scene::light_le(const Light& l, const Ray& ray) const {
   return rgb(0, 0, 0);  // light/mod.rs:90-92
 }
 
+// ============================================================================ Perlin noise (rc/noise.rs)
+static const uint8_t kNoisePerm[512] = {
+    151, 160, 137, 91, 90, 15, 131, 13, 201, 95, 96, 53, 194, 233, 7, 225, 140, 36, 103, 30, 69, 142, 8, 99, 37, 240, 21, 10, 23, 190, 6, 148,
+    247, 120, 234, 75, 0, 26, 197, 62, 94, 252, 219, 203, 117, 35, 11, 32, 57, 177, 33, 88, 237, 149, 56, 87, 174, 20, 125, 136, 171, 168, 68, 175,
+    74, 165, 71, 134, 139, 48, 27, 166, 77, 146, 158, 231, 83, 111, 229, 122, 60, 211, 133, 230, 220, 105, 92, 41, 55, 46, 245, 40, 244, 102, 143, 54,
+    65, 25, 63, 161, 1, 216, 80, 73, 209, 76, 132, 187, 208, 89, 18, 169, 200, 196, 135, 130, 116, 188, 159, 86, 164, 100, 109, 198, 173, 186, 3, 64,
+    52, 217, 226, 250, 124, 123, 5, 202, 38, 147, 118, 126, 255, 82, 85, 212, 207, 206, 59, 227, 47, 16, 58, 17, 182, 189, 28, 42, 223, 183, 170, 213,
+    119, 248, 152, 2, 44, 154, 163, 70, 221, 153, 101, 155, 167, 43, 172, 9, 129, 22, 39, 253, 19, 98, 108, 110, 79, 113, 224, 232, 178, 185, 112, 104,
+    218, 246, 97, 228, 251, 34, 242, 193, 238, 210, 144, 12, 191, 179, 162, 241, 81, 51, 145, 235, 249, 14, 239, 107, 49, 192, 214, 31, 181, 199, 106, 157,
+    184, 84, 204, 176, 115, 121, 50, 45, 127, 4, 150, 254, 138, 236, 205, 93, 222, 114, 67, 29, 24, 72, 243, 141, 128, 195, 78, 66, 215, 61, 156, 180,
+    151, 160, 137, 91, 90, 15, 131, 13, 201, 95, 96, 53, 194, 233, 7, 225, 140, 36, 103, 30, 69, 142, 8, 99, 37, 240, 21, 10, 23, 190, 6, 148,
+    247, 120, 234, 75, 0, 26, 197, 62, 94, 252, 219, 203, 117, 35, 11, 32, 57, 177, 33, 88, 237, 149, 56, 87, 174, 20, 125, 136, 171, 168, 68, 175,
+    74, 165, 71, 134, 139, 48, 27, 166, 77, 146, 158, 231, 83, 111, 229, 122, 60, 211, 133, 230, 220, 105, 92, 41, 55, 46, 245, 40, 244, 102, 143, 54,
+    65, 25, 63, 161, 1, 216, 80, 73, 209, 76, 132, 187, 208, 89, 18, 169, 200, 196, 135, 130, 116, 188, 159, 86, 164, 100, 109, 198, 173, 186, 3, 64,
+    52, 217, 226, 250, 124, 123, 5, 202, 38, 147, 118, 126, 255, 82, 85, 212, 207, 206, 59, 227, 47, 16, 58, 17, 182, 189, 28, 42, 223, 183, 170, 213,
+    119, 248, 152, 2, 44, 154, 163, 70, 221, 153, 101, 155, 167, 43, 172, 9, 129, 22, 39, 253, 19, 98, 108, 110, 79, 113, 224, 232, 178, 185, 112, 104,
+    218, 246, 97, 228, 251, 34, 242, 193, 238, 210, 144, 12, 191, 179, 162, 241, 81, 51, 145, 235, 249, 14, 239, 107, 49, 192, 214, 31, 181, 199, 106, 157,
+    184, 84, 204, 176, 115, 121, 50, 45, 127, 4, 150, 254, 138, 236, 205, 93, 222, 114, 67, 29, 24, 72, 243, 141, 128, 195, 78, 66, 215, 61, 156, 180};
+static inline float noise_grad(int x, int y, int z, float dx, float dy, float dz) {  // noise.rs:68-76
+  int h = kNoisePerm[kNoisePerm[kNoisePerm[x] + y] + z];
+  h &= 15;
+  float u = (h < 8 || h == 12 || h == 13) ? dx : dy;
+  float v = (h < 4 || h == 12 || h == 13) ? dy : dz;
+  return ((h & 1) ? -u : u) + ((h & 2) ? -v : v);
+}
+static inline float noise_weight(float t) { float t3 = t * t * t, t4 = t3 * t; return 6.0f * t4 * t - 15.0f * t4 + 10.0f * t3; }  // :78-83
+
+float noise_perlin(float x, float y, float z) {  // noise.rs:8-43
+  int ix = f2i_sat(floorf(x)), iy = f2i_sat(floorf(y)), iz = f2i_sat(floorf(z));
+  float dx = x - (float)ix, dy = y - (float)iy, dz = z - (float)iz;
+  ix &= 255; iy &= 255; iz &= 255;
+  float w000 = noise_grad(ix, iy, iz, dx, dy, dz), w100 = noise_grad(ix + 1, iy, iz, dx - 1.0f, dy, dz);
+  float w010 = noise_grad(ix, iy + 1, iz, dx, dy - 1.0f, dz), w110 = noise_grad(ix + 1, iy + 1, iz, dx - 1.0f, dy - 1.0f, dz);
+  float w001 = noise_grad(ix, iy, iz + 1, dx, dy, dz - 1.0f), w101 = noise_grad(ix + 1, iy, iz + 1, dx - 1.0f, dy, dz - 1.0f);
+  float w011 = noise_grad(ix, iy + 1, iz + 1, dx, dy - 1.0f, dz - 1.0f), w111 = noise_grad(ix + 1, iy + 1, iz + 1, dx - 1.0f, dy - 1.0f, dz - 1.0f);
+  float wx = noise_weight(dx), wy = noise_weight(dy), wz = noise_weight(dz);
+  float x00 = lerp_f(wx, w000, w100), x10 = lerp_f(wx, w010, w110), x01 = lerp_f(wx, w001, w101), x11 = lerp_f(wx, w011, w111);
+  float y0 = lerp_f(wy, x00, x10), y1 = lerp_f(wy, x01, x11);
+  return lerp_f(wz, y0, y1);
+}
+float noise_fbm(V3 p, V3 dpdx, V3 dpdy, float omega, uint32_t max_octaves) {  // noise.rs:46-66
+  float len2 = fmaxf(dot(dpdx, dpdx), dot(dpdy, dpdy));
+  float n = clamp_t(-1.0f - 0.5f * log2f(len2), 0.0f, (float)max_octaves);
+  uint32_t n_int = f2u_sat(floorf(n));
+  float sum = 0.0f, lambda = 1.0f, o = 1.0f;
+  for (uint32_t i = 0; i < n_int; ++i) {
+    sum += o * noise_perlin(lambda * p.x, lambda * p.y, lambda * p.z);
+    lambda *= 1.99f;
+    o *= omega;
+  }
+  float n_partial = n - (float)n_int;
+  float v = clamp_t((n_partial - 0.3f) / (0.7f - 0.3f), 0.0f, 1.0f);  // smooth_step, :85-89
+  sum += o * (v * v * (-2.0f * v + 3.0f)) * noise_perlin(lambda * p.x, lambda * p.y, lambda * p.z);
+  return sum;
+}
+
 // ============================================================================ textures
 RGB Scene::tex_eval(int id, const SurfaceInteraction& si) const {
   const Texture& t = textures[id];
@@ -424,6 +480,32 @@ RGB Scene::tex_eval(int id, const SurfaceInteraction& si) const {
       float amt = tex_eval_f(t.amount, si);
       return t1 * (1.0f - amt) + t2 * amt;
     }
+    case TEX_CHECKER: {  // checkerboard.rs:102-143 (2D, UVMapping2D)
+      P2 st{t.su * si.uv.x + t.du, t.sv * si.uv.y + t.dv};
+      P2 dstdx{t.su * si.dudx, t.sv * si.dvdx}, dstdy{t.su * si.dudy, t.sv * si.dvdy};
+      if (t.amount == 0) {  // AAMethod::None: `floor() as u32` saturates negatives to 0, the u32 sum wraps
+        auto as_u32 = [](float f) { uint64_t v = f2u_sat(f); return (uint32_t)(v > 0xffffffffull ? 0xffffffffull : v); };
+        uint32_t a = as_u32(floorf(st.x)), b = as_u32(floorf(st.y));
+        return ((uint32_t)(a + b) % 2u == 0u) ? tex_eval(t.tex1, si) : tex_eval(t.tex2, si);
+      }
+      float ds = fmaxf(fabsf(dstdx.x), fabsf(dstdy.x)), dt = fmaxf(fabsf(dstdx.y), fabsf(dstdy.y));
+      float s0 = st.x - ds, s1 = st.x + ds, t0 = st.y - dt, t1 = st.y + dt;
+      if (floorf(s0) == floorf(s1) && floorf(t0) == floorf(t1)) {  // filter inside one check: point sample
+        int sum = (int)((int64_t)f2i_sat(floorf(st.x)) + (int64_t)f2i_sat(floorf(st.y)));  // i32 add (wraps only at 2^31)
+        return (sum % 2 == 0) ? tex_eval(t.tex1, si) : tex_eval(t.tex2, si);
+      }
+      auto bump_int = [](float x) { return floorf(x / 2.0f) + 2.0f * fmaxf(x / 2.0f - floorf(x / 2.0f) - 0.5f, 0.0f); };
+      float sint = (bump_int(s1) - bump_int(s0)) / (2.0f * ds);
+      float tint = (bump_int(t1) - bump_int(t0)) / (2.0f * dt);
+      float area2 = sint + tint - 2.0f * sint * tint;
+      if (ds > 1.0f || dt > 1.0f) area2 = 0.5f;
+      return tex_eval(t.tex1, si) * (1.0f - area2) + tex_eval(t.tex2, si) * area2;
+    }
+    case TEX_UV: {  // uv.rs:50-54
+      P2 st{t.su * si.uv.x + t.du, t.sv * si.uv.y + t.dv};
+      return rgb(st.x - floorf(st.x), st.y - floorf(st.y), 0.0f);
+    }
+    case TEX_FBM: return grey(noise_fbm(si.hit.p, si.dpdx, si.dpdy, t.value.r, (uint32_t)(t.amount < 0 ? 0 : t.amount)));  // fbm.rs:18-21, IdentityMapping3D with identity
     default: return image_tex_eval(*this, t, si);
   }
 }

@@ -74,15 +74,20 @@ inline void compute_differential(SurfaceInteraction& si, const Ray& ray) {
 
 // ---------------------------------------------------------------- textures
 struct MipMap;  // orc_mipmap.h
-enum TexKind { TEX_CONST = 0, TEX_SCALE = 1, TEX_MIX = 2, TEX_IMAGE = 3 };
+enum TexKind { TEX_CONST = 0, TEX_SCALE = 1, TEX_MIX = 2, TEX_IMAGE = 3, TEX_CHECKER = 4, TEX_UV = 5, TEX_FBM = 6 };
 struct Texture {
   int kind = TEX_CONST;
   RGB value{0, 0, 0};          // constant (float textures use .r)   rc/texture/constant.rs:35-38
   int tex1 = -1, tex2 = -1, amount = -1;  // scale / mix             rc/texture/scale.rs:23-25, mix.rs:24
   int mip = -1;                // imagemap                           rc/texture/imagemap.rs:232-235
   float su = 1, sv = 1, du = 0, dv = 0;   // UVMapping2D             rc/texture/mod.rs:38-61
+  // checkerboard (rc/texture/checkerboard.rs): tex1, tex2, UV mapping, amount = AAMethod (0 None, 1 ClosedForm)
+  // uv (rc/texture/uv.rs): UV mapping.  fbm (rc/texture/fbm.rs): value.r = omega, amount = octaves, identity texture space
   bool is_float = false;
 };
+
+float noise_perlin(float x, float y, float z);                                   // rc/noise.rs:8-43
+float noise_fbm(V3 p, V3 dpdx, V3 dpdy, float omega, uint32_t max_octaves);     // rc/noise.rs:46-66
 
 // ---------------------------------------------------------------- materials
 enum MatKind { MAT_MATTE = 0, MAT_PLASTIC, MAT_METAL, MAT_MIRROR, MAT_GLASS, MAT_UBER, MAT_SUBSTRATE, MAT_MIX, MAT_TRANSLUCENT, MAT_NONE };

@@ -29,7 +29,7 @@ struct DScene {
   const float* tri_n; const float* tri_uv; const float* tri_s;
   const DTexture* textures; const DImage* images; const DMaterial* materials; const DLight* lights;
   int n_lights; int n_infinite; int infinite_ids[4];
-  int needs_differentials;  // some texture is an image map (the only consumer of dudx.. is MIPMap filtering)
+  int needs_differentials;  // some texture reads dudx.. / dpdx.. (image maps, closed-form checkerboards, fbm)
   f3 wb_min, wb_max;
   // light distribution (rc/lightdistrib.rs): dense voxel table or a single uniform distribution
   int ld_uniform; int nvox[3];
@@ -139,6 +139,7 @@ struct SurfaceInteraction {
   f2 uv;
   f3 dpdu, dpdv;
   float dudx, dvdx, dudy, dvdy;
+  f3 dpdx, dpdy;
   f3 sh_n, sh_dpdu, sh_dpdv;
   int prim;
 };
@@ -201,6 +202,7 @@ RT_DEV void tri_fill_interaction_inl(const DScene& sc, int prim, f3 ray_d, const
   if (flags & 2u) si.hit.n = face_forward(si.hit.n, si.sh_n);  // :417-422
   else if (flags & 1u) { si.hit.n = -si.hit.n; si.sh_n = si.hit.n; }
   si.dudx = si.dvdx = si.dudy = si.dvdy = 0.0f;
+  si.dpdx = si.dpdy = mk3(0, 0, 0);
   si.prim = prim;
 }
 
@@ -229,6 +231,7 @@ RT_DEVN void compute_differential(SurfaceInteraction& si, f3 rx_o, f3 ry_o, f3 r
   float ty = -(dot(n, ry_o) - d) / dot(n, ry_d);
   if (isinf(tx) || tx != tx || isinf(ty) || ty != ty) return;
   f3 px = rx_o + tx * rx_d, py = ry_o + ty * ry_d;
+  si.dpdx = px - p; si.dpdy = py - p;  // interaction.rs:268-269
   int dim0, dim1;
   if (fabsf(n.x) > fabsf(n.y) && fabsf(n.x) > fabsf(n.z)) { dim0 = 1; dim1 = 2; }
   else if (fabsf(n.y) > fabsf(n.z)) { dim0 = 0; dim1 = 2; }

@@ -91,37 +91,112 @@ RT_DEVN rgb3 mip_lookup_diff(const DImage& im, f2 st, f2 dst0, f2 dst1) {  // :2
 
 // ---------------------------------------------------------------- textures (rc/texture/*.rs)
 // Scale/Mix operands are resolved iteratively with a tiny explicit stack (no device recursion).
+// ---- Perlin noise (rc/noise.rs)
+__device__ __constant__ const unsigned char kNoisePerm[512] = {
+    151, 160, 137, 91, 90, 15, 131, 13, 201, 95, 96, 53, 194, 233, 7, 225, 140, 36, 103, 30, 69, 142, 8, 99, 37, 240, 21, 10, 23, 190, 6, 148,
+    247, 120, 234, 75, 0, 26, 197, 62, 94, 252, 219, 203, 117, 35, 11, 32, 57, 177, 33, 88, 237, 149, 56, 87, 174, 20, 125, 136, 171, 168, 68, 175,
+    74, 165, 71, 134, 139, 48, 27, 166, 77, 146, 158, 231, 83, 111, 229, 122, 60, 211, 133, 230, 220, 105, 92, 41, 55, 46, 245, 40, 244, 102, 143, 54,
+    65, 25, 63, 161, 1, 216, 80, 73, 209, 76, 132, 187, 208, 89, 18, 169, 200, 196, 135, 130, 116, 188, 159, 86, 164, 100, 109, 198, 173, 186, 3, 64,
+    52, 217, 226, 250, 124, 123, 5, 202, 38, 147, 118, 126, 255, 82, 85, 212, 207, 206, 59, 227, 47, 16, 58, 17, 182, 189, 28, 42, 223, 183, 170, 213,
+    119, 248, 152, 2, 44, 154, 163, 70, 221, 153, 101, 155, 167, 43, 172, 9, 129, 22, 39, 253, 19, 98, 108, 110, 79, 113, 224, 232, 178, 185, 112, 104,
+    218, 246, 97, 228, 251, 34, 242, 193, 238, 210, 144, 12, 191, 179, 162, 241, 81, 51, 145, 235, 249, 14, 239, 107, 49, 192, 214, 31, 181, 199, 106, 157,
+    184, 84, 204, 176, 115, 121, 50, 45, 127, 4, 150, 254, 138, 236, 205, 93, 222, 114, 67, 29, 24, 72, 243, 141, 128, 195, 78, 66, 215, 61, 156, 180,
+    151, 160, 137, 91, 90, 15, 131, 13, 201, 95, 96, 53, 194, 233, 7, 225, 140, 36, 103, 30, 69, 142, 8, 99, 37, 240, 21, 10, 23, 190, 6, 148,
+    247, 120, 234, 75, 0, 26, 197, 62, 94, 252, 219, 203, 117, 35, 11, 32, 57, 177, 33, 88, 237, 149, 56, 87, 174, 20, 125, 136, 171, 168, 68, 175,
+    74, 165, 71, 134, 139, 48, 27, 166, 77, 146, 158, 231, 83, 111, 229, 122, 60, 211, 133, 230, 220, 105, 92, 41, 55, 46, 245, 40, 244, 102, 143, 54,
+    65, 25, 63, 161, 1, 216, 80, 73, 209, 76, 132, 187, 208, 89, 18, 169, 200, 196, 135, 130, 116, 188, 159, 86, 164, 100, 109, 198, 173, 186, 3, 64,
+    52, 217, 226, 250, 124, 123, 5, 202, 38, 147, 118, 126, 255, 82, 85, 212, 207, 206, 59, 227, 47, 16, 58, 17, 182, 189, 28, 42, 223, 183, 170, 213,
+    119, 248, 152, 2, 44, 154, 163, 70, 221, 153, 101, 155, 167, 43, 172, 9, 129, 22, 39, 253, 19, 98, 108, 110, 79, 113, 224, 232, 178, 185, 112, 104,
+    218, 246, 97, 228, 251, 34, 242, 193, 238, 210, 144, 12, 191, 179, 162, 241, 81, 51, 145, 235, 249, 14, 239, 107, 49, 192, 214, 31, 181, 199, 106, 157,
+    184, 84, 204, 176, 115, 121, 50, 45, 127, 4, 150, 254, 138, 236, 205, 93, 222, 114, 67, 29, 24, 72, 243, 141, 128, 195, 78, 66, 215, 61, 156, 180};
+RT_DEV float noise_grad(int x, int y, int z, float dx, float dy, float dz) {  // noise.rs:68-76
+  int h = kNoisePerm[kNoisePerm[kNoisePerm[x] + y] + z];
+  h &= 15;
+  float u = (h < 8 || h == 12 || h == 13) ? dx : dy;
+  float v = (h < 4 || h == 12 || h == 13) ? dy : dz;
+  return ((h & 1) ? -u : u) + ((h & 2) ? -v : v);
+}
+RT_DEV float noise_weight(float t) { float t3 = t * t * t, t4 = t3 * t; return 6.0f * t4 * t - 15.0f * t4 + 10.0f * t3; }  // :78-83
+RT_DEVN float noise_perlin(float x, float y, float z) {  // noise.rs:8-43
+  int ix = f2i_sat(floorf(x)), iy = f2i_sat(floorf(y)), iz = f2i_sat(floorf(z));
+  float dx = x - (float)ix, dy = y - (float)iy, dz = z - (float)iz;
+  ix &= 255; iy &= 255; iz &= 255;
+  float w000 = noise_grad(ix, iy, iz, dx, dy, dz), w100 = noise_grad(ix + 1, iy, iz, dx - 1.0f, dy, dz);
+  float w010 = noise_grad(ix, iy + 1, iz, dx, dy - 1.0f, dz), w110 = noise_grad(ix + 1, iy + 1, iz, dx - 1.0f, dy - 1.0f, dz);
+  float w001 = noise_grad(ix, iy, iz + 1, dx, dy, dz - 1.0f), w101 = noise_grad(ix + 1, iy, iz + 1, dx - 1.0f, dy, dz - 1.0f);
+  float w011 = noise_grad(ix, iy + 1, iz + 1, dx, dy - 1.0f, dz - 1.0f), w111 = noise_grad(ix + 1, iy + 1, iz + 1, dx - 1.0f, dy - 1.0f, dz - 1.0f);
+  float wx = noise_weight(dx), wy = noise_weight(dy), wz = noise_weight(dz);
+  float x00 = lerpf(wx, w000, w100), x10 = lerpf(wx, w010, w110), x01 = lerpf(wx, w001, w101), x11 = lerpf(wx, w011, w111);
+  float y0 = lerpf(wy, x00, x10), y1 = lerpf(wy, x01, x11);
+  return lerpf(wz, y0, y1);
+}
+RT_DEV float noise_fbm(f3 p, f3 dpdx, f3 dpdy, float omega, unsigned max_octaves) {  // noise.rs:46-66
+  float l2 = fmaxf(len2(dpdx), len2(dpdy));
+  float n = clampf(-1.0f - 0.5f * log2f(l2), 0.0f, (float)max_octaves);
+  unsigned n_int = f2u_sat(floorf(n));
+  float sum = 0.0f, lambda = 1.0f, o = 1.0f;
+  for (unsigned i = 0; i < n_int; ++i) {
+    sum += o * noise_perlin(lambda * p.x, lambda * p.y, lambda * p.z);
+    lambda *= 1.99f;
+    o *= omega;
+  }
+  float n_partial = n - (float)n_int;
+  float v = clampf((n_partial - 0.3f) / (0.7f - 0.3f), 0.0f, 1.0f);  // smooth_step, :85-89
+  sum += o * (v * v * (-2.0f * v + 3.0f)) * noise_perlin(lambda * p.x, lambda * p.y, lambda * p.z);
+  return sum;
+}
+
+// Leaves: constant, imagemap, uv, fbm. Combinators (operands = other textures): scale, mix, checkerboard.
+RT_DEV bool tex_is_leaf(int kind) { return kind == 0 || kind == 3 || kind == 5 || kind == 6; }
 RT_DEV rgb3 tex_leaf(const DScene& sc, const DTexture& t, const SurfaceInteraction& si) {
   if (t.kind == 0) return mkc(t.v[0], t.v[1], t.v[2]);  // constant.rs:35-38
-  // imagemap.rs:232-235 with UVMapping2D (texture/mod.rs:52-60)
-  f2 st = mk2(t.su * si.uv.x + t.du, t.sv * si.uv.y + t.dv);
+  if (t.kind == 6) { float f = noise_fbm(si.hit.p, si.dpdx, si.dpdy, t.v[0], (unsigned)(t.amount < 0 ? 0 : t.amount)); return mkc(f, f, f); }  // fbm.rs:18-21
+  f2 st = mk2(t.su * si.uv.x + t.du, t.sv * si.uv.y + t.dv);  // UVMapping2D (texture/mod.rs:52-60)
+  if (t.kind == 5) return mkc(st.x - floorf(st.x), st.y - floorf(st.y), 0.0f);  // uv.rs:50-54
+  // imagemap.rs:232-235
   f2 dstdx = mk2(t.su * si.dudx, t.sv * si.dvdx), dstdy = mk2(t.su * si.dudy, t.sv * si.dvdy);
   return mip_lookup_diff(sc.images[t.image], st, dstdx, dstdy);
 }
+// checkerboard.rs:102-143: which of the two operands, or the box-filtered blend. Returns 0 = tex1, 1 = tex2, 2 = blend with area2.
+RT_DEV int checker_select(const DTexture& t, const SurfaceInteraction& si, float& area2) {
+  f2 st = mk2(t.su * si.uv.x + t.du, t.sv * si.uv.y + t.dv);
+  if (t.amount == 0) {  // AAMethod::None: `floor() as u32` saturates negatives to 0, the u32 sum wraps
+    unsigned a = f2u_sat(floorf(st.x)), b = f2u_sat(floorf(st.y));
+    return ((a + b) % 2u == 0u) ? 0 : 1;
+  }
+  f2 dstdx = mk2(t.su * si.dudx, t.sv * si.dvdx), dstdy = mk2(t.su * si.dudy, t.sv * si.dvdy);
+  float ds = fmaxf(fabsf(dstdx.x), fabsf(dstdy.x)), dt = fmaxf(fabsf(dstdx.y), fabsf(dstdy.y));
+  float s0 = st.x - ds, s1 = st.x + ds, t0 = st.y - dt, t1 = st.y + dt;
+  if (floorf(s0) == floorf(s1) && floorf(t0) == floorf(t1)) {
+    int sum = (int)((long long)f2i_sat(floorf(st.x)) + (long long)f2i_sat(floorf(st.y)));
+    return (sum % 2 == 0) ? 0 : 1;
+  }
+  float b1 = floorf(s1 / 2.0f) + 2.0f * fmaxf(s1 / 2.0f - floorf(s1 / 2.0f) - 0.5f, 0.0f);
+  float b0 = floorf(s0 / 2.0f) + 2.0f * fmaxf(s0 / 2.0f - floorf(s0 / 2.0f) - 0.5f, 0.0f);
+  float c1 = floorf(t1 / 2.0f) + 2.0f * fmaxf(t1 / 2.0f - floorf(t1 / 2.0f) - 0.5f, 0.0f);
+  float c0 = floorf(t0 / 2.0f) + 2.0f * fmaxf(t0 / 2.0f - floorf(t0 / 2.0f) - 0.5f, 0.0f);
+  float sint = (b1 - b0) / (2.0f * ds), tint = (c1 - c0) / (2.0f * dt);
+  area2 = sint + tint - 2.0f * sint * tint;
+  if (ds > 1.0f || dt > 1.0f) area2 = 0.5f;
+  return 2;
+}
+RT_DEV rgb3 tex_combine(const DScene& sc, const DTexture& t, rgb3 a, rgb3 b, const SurfaceInteraction& si) {
+  if (t.kind == 1) return a * b;  // scale.rs:23-25
+  if (t.kind == 2) { float amt = tex_leaf(sc, sc.textures[t.amount], si).r; return a * (1.0f - amt) + b * amt; }  // mix.rs:24
+  float area2 = 0.0f;
+  const int sel = checker_select(t, si, area2);
+  return sel == 0 ? a : (sel == 1 ? b : a * (1.0f - area2) + b * area2);
+}
+// a texture whose operands are leaves
+RT_DEV rgb3 tex_depth1(const DScene& sc, const DTexture& t, const SurfaceInteraction& si) {
+  if (tex_is_leaf(t.kind)) return tex_leaf(sc, t, si);
+  return tex_combine(sc, t, tex_leaf(sc, sc.textures[t.tex1], si), tex_leaf(sc, sc.textures[t.tex2], si), si);
+}
+// combinators nest two deep at most (a combinator of combinators of leaves); the host rejects deeper scenes
 RT_DEVN rgb3 tex_eval(const DScene& sc, int id, const SurfaceInteraction& si) {
   const DTexture& t = sc.textures[id];
-  if (t.kind == 0 || t.kind == 3) return tex_leaf(sc, t, si);
-  // one level of scale/mix whose operands may themselves be scale/mix of leaves (depth <= 2)
-  rgb3 a, b;
-  {
-    const DTexture& t1 = sc.textures[t.tex1];
-    if (t1.kind == 1) a = tex_leaf(sc, sc.textures[t1.tex1], si) * tex_leaf(sc, sc.textures[t1.tex2], si);
-    else if (t1.kind == 2) {
-      rgb3 x = tex_leaf(sc, sc.textures[t1.tex1], si), y = tex_leaf(sc, sc.textures[t1.tex2], si);
-      float amt = tex_leaf(sc, sc.textures[t1.amount], si).r;
-      a = x * (1.0f - amt) + y * amt;
-    } else a = tex_leaf(sc, t1, si);
-    const DTexture& t2 = sc.textures[t.tex2];
-    if (t2.kind == 1) b = tex_leaf(sc, sc.textures[t2.tex1], si) * tex_leaf(sc, sc.textures[t2.tex2], si);
-    else if (t2.kind == 2) {
-      rgb3 x = tex_leaf(sc, sc.textures[t2.tex1], si), y = tex_leaf(sc, sc.textures[t2.tex2], si);
-      float amt = tex_leaf(sc, sc.textures[t2.amount], si).r;
-      b = x * (1.0f - amt) + y * amt;
-    } else b = tex_leaf(sc, t2, si);
-  }
-  if (t.kind == 1) return a * b;  // scale.rs:23-25
-  float amt = tex_leaf(sc, sc.textures[t.amount], si).r;  // mix.rs:24
-  return a * (1.0f - amt) + b * amt;
+  if (tex_is_leaf(t.kind)) return tex_leaf(sc, t, si);
+  return tex_combine(sc, t, tex_depth1(sc, sc.textures[t.tex1], si), tex_depth1(sc, sc.textures[t.tex2], si), si);
 }
 RT_DEV float tex_eval_f(const DScene& sc, int id, const SurfaceInteraction& si) { return tex_eval(sc, id, si).r; }
 

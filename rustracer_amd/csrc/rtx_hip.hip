@@ -156,23 +156,24 @@ extern "C" int rt_scene_create(const rt_scene_desc* desc, int device, rt_scene**
     d.tex1 = t.tex1; d.tex2 = t.tex2; d.amount = t.amount; d.image = t.image;
     d.su = t.mapping[0]; d.sv = t.mapping[1]; d.du = t.mapping[2]; d.dv = t.mapping[3];
     auto ok = [&](int id) { return id >= 0 && (uint32_t)id < desc->n_textures; };
-    if ((t.kind == RT_TEX_SCALE || t.kind == RT_TEX_MIX) && (!ok(t.tex1) || !ok(t.tex2))) { delete s; return fail(RT_ERR_INVALID, "texture operand out of range"); }
+    const bool comb = t.kind == RT_TEX_SCALE || t.kind == RT_TEX_MIX || t.kind == RT_TEX_CHECKER;
+    if (t.kind < RT_TEX_CONST || t.kind > RT_TEX_FBM) { delete s; return fail(RT_ERR_INVALID, "unknown texture kind"); }
+    if (comb && (!ok(t.tex1) || !ok(t.tex2))) { delete s; return fail(RT_ERR_INVALID, "texture operand out of range"); }
     if (t.kind == RT_TEX_MIX && !ok(t.amount)) { delete s; return fail(RT_ERR_INVALID, "mix amount out of range"); }
     if (t.kind == RT_TEX_IMAGE && (t.image < 0 || (uint32_t)t.image >= desc->n_images)) { delete s; return fail(RT_ERR_INVALID, "image index out of range"); }
   }
-  // scale/mix nesting deeper than two levels is not expanded on the device
+  // combinators (scale / mix / checkerboard) nested deeper than two levels are not expanded on the device
+  auto is_comb = [&](int id) { int k = desc->textures[id].kind; return k == RT_TEX_SCALE || k == RT_TEX_MIX || k == RT_TEX_CHECKER; };
   for (uint32_t i = 0; i < desc->n_textures; ++i) {
     const rt_texture& t = desc->textures[i];
-    if (t.kind != RT_TEX_SCALE && t.kind != RT_TEX_MIX) continue;
-    const int ops[3] = {t.tex1, t.tex2, t.kind == RT_TEX_MIX ? t.amount : -1};
-    for (int k = 0; k < 3; ++k) {
-      if (ops[k] < 0) continue;
+    if (!is_comb((int)i)) continue;
+    if (t.kind == RT_TEX_MIX && is_comb(t.amount)) { delete s; return fail(RT_ERR_INVALID, "mix amount must be a leaf texture"); }
+    const int ops[2] = {t.tex1, t.tex2};
+    for (int k = 0; k < 2; ++k) {
       const rt_texture& c = desc->textures[ops[k]];
-      if (c.kind != RT_TEX_SCALE && c.kind != RT_TEX_MIX) continue;
-      if (k == 2) { delete s; return fail(RT_ERR_INVALID, "mix amount must be a leaf texture"); }
-      const int cops[3] = {c.tex1, c.tex2, c.kind == RT_TEX_MIX ? c.amount : -1};
-      for (int q = 0; q < 3; ++q)
-        if (cops[q] >= 0) { int kk = desc->textures[cops[q]].kind; if (kk == RT_TEX_SCALE || kk == RT_TEX_MIX) { delete s; return fail(RT_ERR_INVALID, "texture nesting deeper than 2"); } }
+      if (!is_comb(ops[k])) continue;
+      if (c.kind == RT_TEX_MIX && is_comb(c.amount)) { delete s; return fail(RT_ERR_INVALID, "mix amount must be a leaf texture"); }
+      if (is_comb(c.tex1) || is_comb(c.tex2)) { delete s; return fail(RT_ERR_INVALID, "texture nesting deeper than 2"); }
     }
   }
   TRY_RC(upload(s->textures, htex.data(), htex.size() * sizeof(DTexture)));
@@ -238,7 +239,10 @@ extern "C" int rt_scene_create(const rt_scene_desc* desc, int device, rt_scene**
   d.wb_max = f3{desc->nodes[0].bmax[0], desc->nodes[0].bmax[1], desc->nodes[0].bmax[2]};
   d.ld_uniform = 1; d.nvox[0] = d.nvox[1] = d.nvox[2] = 1;
   d.needs_differentials = 0;
-  for (uint32_t i = 0; i < desc->n_textures; ++i) if (desc->textures[i].kind == RT_TEX_IMAGE) d.needs_differentials = 1;
+  for (uint32_t i = 0; i < desc->n_textures; ++i) {
+    const rt_texture& t = desc->textures[i];
+    if (t.kind == RT_TEX_IMAGE || t.kind == RT_TEX_FBM || (t.kind == RT_TEX_CHECKER && t.amount != 0)) d.needs_differentials = 1;
+  }
   s->lambert_only = true;
   for (uint32_t i = 0; i < desc->n_materials; ++i) {
     const rt_material& m = desc->materials[i];

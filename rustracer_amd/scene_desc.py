@@ -16,7 +16,7 @@ from typing import List, Optional, Sequence
 import numpy as np
 
 # --- enums shared (by value) with include/rtx_hip.h and oracle/ -------------------------------
-TEX_CONST, TEX_SCALE, TEX_MIX, TEX_IMAGE = 0, 1, 2, 3
+TEX_CONST, TEX_SCALE, TEX_MIX, TEX_IMAGE, TEX_CHECKER, TEX_UV, TEX_FBM = 0, 1, 2, 3, 4, 5, 6
 (MAT_MATTE, MAT_PLASTIC, MAT_METAL, MAT_MIRROR, MAT_GLASS, MAT_UBER, MAT_SUBSTRATE, MAT_MIX,
  MAT_TRANSLUCENT) = range(9)
 LIGHT_DIFFUSE_AREA, LIGHT_POINT, LIGHT_DISTANT, LIGHT_INFINITE = 0, 1, 2, 3
@@ -160,6 +160,18 @@ class SceneDesc:
 
     def image_tex(self, mip: int, su=1.0, sv=1.0, du=0.0, dv=0.0) -> int:
         self.textures.append(Texture(TEX_IMAGE, mip=mip, mapping=(su, sv, du, dv)))
+        return len(self.textures) - 1
+
+    def checker_tex(self, t1, t2, su=1.0, sv=1.0, du=0.0, dv=0.0, aa="closedform") -> int:  # checkerboard.rs:44-95 (dimension 2, "uv" mapping)
+        self.textures.append(Texture(TEX_CHECKER, tex1=self._t(_f(t1)), tex2=self._t(_f(t2)), amount=0 if aa == "none" else 1, mapping=(su, sv, du, dv)))
+        return len(self.textures) - 1
+
+    def uv_tex(self, su=1.0, sv=1.0, du=0.0, dv=0.0) -> int:  # uv.rs:21-40
+        self.textures.append(Texture(TEX_UV, mapping=(su, sv, du, dv)))
+        return len(self.textures) - 1
+
+    def fbm_tex(self, omega=0.5, octaves=8) -> int:  # fbm.rs:25-44 (identity texture-to-world)
+        self.textures.append(Texture(TEX_FBM, value=(float(omega), 0.0, 0.0), amount=int(octaves)))
         return len(self.textures) - 1
 
     def _t(self, v) -> int:

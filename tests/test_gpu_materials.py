@@ -30,6 +30,11 @@ def _zoo(material: str, light: str = "area", res=(40, 32), spp=8, max_depth=5):
         "matte_image_trilinear_clamp": lambda: s.matte(t_tri),
         "matte_image_black_wrap": lambda: s.matte(t_blk),
         "matte_image_npot": lambda: s.matte(t_npot),
+        "matte_checker_closedform": lambda: s.matte(s.checker_tex(t_img, (0.1, 0.1, 0.6), 6, 5, 0.1, 0.3)),
+        "matte_checker_none_nested": lambda: s.matte(s.scale_tex(s.checker_tex((0.9, 0.8, 0.2), t_tri, 7, 7, aa="none"), s.mix_tex(s.uv_tex(2, 2), s.const_tex((0.8, 0.8, 0.8)), s.const_tex(0.6)))),
+        "matte_uv": lambda: s.matte(s.uv_tex(3.0, 2.0, 0.2, 0.1)),
+        "matte_fbm": lambda: s.matte(s.scale_tex(s.fbm_tex(0.6, 6), s.const_tex((0.9, 0.7, 0.5)))),
+        "plastic_fbm_checker_roughness": lambda: s.plastic(s.checker_tex(s.fbm_tex(0.5, 4), (0.5, 0.2, 0.2), 3, 3), (0.4, 0.4, 0.4), 0.2),
         "matte_scale_mix_tex": lambda: s.matte(s.mix_tex(s.scale_tex(t_img, s.const_tex((0.9, 0.8, 0.7))), s.const_tex((0.1, 0.6, 0.2)), s.const_tex(0.3))),
         "plastic": lambda: s.plastic((0.3, 0.1, 0.1), (0.5, 0.5, 0.5), 0.15),
         "plastic_noremap": lambda: s.plastic(t_img, (0.4, 0.4, 0.4), 0.2, remap=False),
@@ -86,7 +91,8 @@ def _check(gpu_host, orc, d):
     assert int(sh["paths_scrubbed"]) == int(so["scrubbed"]) if "scrubbed" in so else True
 
 
-MATERIALS = ["matte", "oren_nayar", "matte_image_ewa", "matte_image_trilinear_clamp", "matte_image_black_wrap", "matte_image_npot", "matte_scale_mix_tex", "plastic",
+MATERIALS = ["matte", "oren_nayar", "matte_image_ewa", "matte_image_trilinear_clamp", "matte_image_black_wrap", "matte_image_npot", "matte_checker_closedform", "matte_checker_none_nested", "matte_uv", "matte_fbm",
+             "plastic_fbm_checker_roughness", "matte_scale_mix_tex", "plastic",
              "plastic_noremap", "metal", "metal_aniso", "mirror", "glass", "glass_rough", "uber", "substrate", "translucent", "mix", "mix_nested"]
 
 
