@@ -83,6 +83,7 @@ typedef struct rt_material {
   int32_t kind;
   int32_t slot[RT_N_SLOTS]; /* texture ids (material ids for M1/M2); -1 = absent */
   int32_t remap_roughness;
+  int32_t bump;             /* "bumpmap" float texture id or -1 (material::bump, rc/material/mod.rs:50-92); ignored by mix */
 } rt_material;
 
 /* -- lights: replaces dyn Light (rc/light/{diffuse,point,distant,infinite}.rs) ------------- */

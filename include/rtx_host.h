@@ -47,7 +47,7 @@ int rtxh_scene_set_mesh(rtxh_scene*, const float* P, int32_t n_verts, const int3
                         const float* S, const int32_t* tri_material, const int32_t* tri_light, const uint8_t* tri_flags);
 int rtxh_scene_add_mipmap(rtxh_scene*, int32_t width, int32_t height, const float* rgb, int32_t trilinear, float max_aniso, int32_t wrap);
 int rtxh_scene_add_texture(rtxh_scene*, int32_t kind, const float* value3, int32_t tex1, int32_t tex2, int32_t amount, int32_t mip, const float* mapping4);
-int rtxh_scene_add_material(rtxh_scene*, int32_t kind, const int32_t* slots16, int32_t remap_roughness);
+int rtxh_scene_add_material(rtxh_scene*, int32_t kind, const int32_t* slots16, int32_t remap_roughness, int32_t bump_texture /* or -1 */);
 int rtxh_scene_add_light(rtxh_scene*, int32_t kind, int32_t tri, const float* rgb3, int32_t two_sided, const float* vec3, int32_t mip,
                          const float* l2w16, const float* w2l16);
 /* BVH::create(prims, "sah", maxnodeprims) + Scene::new; flattens everything into an rt_scene_desc. */

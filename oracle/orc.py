@@ -126,7 +126,7 @@ class OracleScene:
             L.orc_scene_add_texture(self.h, t.kind, _p(v), t.tex1, t.tex2, t.amount, t.mip, _p(mp))
         for m in desc.materials:
             sl = m.slots()
-            L.orc_scene_add_material(self.h, m.kind, _p(sl, C.c_int32), int(m.remap_roughness))
+            L.orc_scene_add_material(self.h, m.kind, _p(sl, C.c_int32), int(m.remap_roughness), int(m.bump))
         for l in desc.lights:
             rgb = np.float32(l.rgb)
             vec = np.float32(l.vec)

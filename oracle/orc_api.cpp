@@ -221,12 +221,12 @@ int orc_scene_add_texture(void* h, int kind, const float* value, int tex1, int t
   return (int)s->textures.size() - 1;
 }
 // params: kd ks kr kt sigma roughness urough vrough eta k opacity reflect transmit amount m1 m2
-int orc_scene_add_material(void* h, int kind, const int32_t* p, int remap_roughness) {
+int orc_scene_add_material(void* h, int kind, const int32_t* p, int remap_roughness, int bump) {
   Scene* s = (Scene*)h;
   Material m; m.kind = kind;
   m.kd = p[0]; m.ks = p[1]; m.kr = p[2]; m.kt = p[3]; m.sigma = p[4]; m.roughness = p[5]; m.urough = p[6]; m.vrough = p[7];
   m.eta = p[8]; m.k = p[9]; m.opacity = p[10]; m.reflect = p[11]; m.transmit = p[12]; m.amount = p[13]; m.m1 = p[14]; m.m2 = p[15];
-  m.remap_roughness = remap_roughness != 0;
+  m.remap_roughness = remap_roughness != 0; m.bump = bump;
   s->materials.push_back(m);
   return (int)s->materials.size() - 1;
 }

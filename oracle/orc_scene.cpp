@@ -521,10 +521,37 @@ static Bxdf micro_t(RGB t, float ax, float ay, float ea, float eb) {
 static Bxdf spec_r(RGB r, Fresnel f) { Bxdf b; b.kind = BX_SPEC_R; b.r = r; b.fresnel = f; return b; }
 static Bxdf spec_t(RGB t, float ea, float eb) { Bxdf b; b.kind = BX_SPEC_T; b.r = t; b.eta_a = ea; b.eta_b = eb; b.fresnel = fr_diel(ea, eb); return b; }
 
-void Scene::build_bsdf(int mat, const SurfaceInteraction& si, Bsdf* bsdf, int depth) const {
+// material::bump (rc/material/mod.rs:50-92). Triangles carry dndu = dndv = 0 (mesh.rs:372-382 passes zero()), and so do
+// their shading.dndu / dndv (interaction.rs:118-160), which keeps the terms below in place with zero vectors.
+void Scene::bump(int tex, SurfaceInteraction& si) const {
+  const V3 dndu = v3(0, 0, 0), dndv = v3(0, 0, 0);
+  SurfaceInteraction si_eval = si;
+  float du = 0.5f * (fabsf(si.dudx) + fabsf(si.dudy));
+  if (du == 0.0f) du = 0.0005f;
+  si_eval.hit.p = si.hit.p + du * si.shading.dpdu;
+  si_eval.uv = P2{si.uv.x + du, si.uv.y + 0.0f};
+  si_eval.hit.n = normalize(cross(si.shading.dpdu, si.shading.dpdv) + du * dndu);
+  float u_displace = tex_eval_f(tex, si_eval);
+  float dv = 0.5f * (fabsf(si.dvdx) + fabsf(si.dvdy));
+  if (dv == 0.0f) dv = 0.0005f;
+  si_eval.hit.p = si.hit.p + dv * si.shading.dpdv;
+  si_eval.uv = P2{si.uv.x + 0.0f, si.uv.y + dv};
+  si_eval.hit.n = normalize(cross(si.shading.dpdu, si.shading.dpdv) + dv * dndv);
+  float v_displace = tex_eval_f(tex, si_eval);
+  float displace = tex_eval_f(tex, si);
+  V3 dpdu = si.shading.dpdu + (u_displace - displace) / du * si.shading.n + displace * dndu;
+  V3 dpdv = si.shading.dpdv + (v_displace - displace) / dv * si.shading.n + displace * dndv;
+  // set_shading_geometry(dpdu, dpdv, dndu, dndv, false), interaction.rs:218-242
+  si.shading.n = normalize(cross(dpdu, dpdv));
+  if (si.prim >= 0 && (tri_flags[ordered[si.prim]] & 1)) si.shading.n = si.shading.n * -1.0f;  // reverse_orientation ^ transform_swaps_handedness
+  si.shading.n = face_forward(si.shading.n, si.hit.n);
+  si.shading.dpdu = dpdu; si.shading.dpdv = dpdv;
+}
+void Scene::build_bsdf(int mat, SurfaceInteraction& si, Bsdf* bsdf, int depth) const {
   const Material& m = materials[mat];
   bsdf->n = 0;
   float eta = 1.0f;
+  if (m.kind != MAT_MIX && m.bump >= 0) bump(m.bump, si);  // first statement of every compute_scattering_functions but mix
   switch (m.kind) {
     case MAT_MATTE: {  // matte.rs:37-62
       RGB r = clamp_pos(tex_eval(m.kd, si));
@@ -624,7 +651,8 @@ void Scene::build_bsdf(int mat, const SurfaceInteraction& si, Bsdf* bsdf, int de
       RGB s1 = clamp_pos(tex_eval(m.amount, si));
       RGB s2 = clamp_pos(rgb(1, 1, 1) - s1);
       Bsdf b1, b2;
-      if (depth < 4) { build_bsdf(m.m1, si, &b1, depth + 1); build_bsdf(m.m2, si, &b2, depth + 1); }
+      SurfaceInteraction si2 = si;  // mat2 works on a clone taken before mat1 touches si (mixmat.rs:43)
+      if (depth < 4) { build_bsdf(m.m1, si, &b1, depth + 1); build_bsdf(m.m2, si2, &b2, depth + 1); }
       *bsdf = b1;  // frame + eta of mat1's Bsdf are kept, lobes replaced
       bsdf->n = 0;
       for (int i = 0; i < b1.n; ++i) { Bxdf b = b1.bxdfs[i]; b.wrap_scaled(s1); bsdf->add(b); }

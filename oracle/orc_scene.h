@@ -97,6 +97,7 @@ struct Material {
   int kd = -1, ks = -1, kr = -1, kt = -1, sigma = -1, roughness = -1, urough = -1, vrough = -1;
   int eta = -1, k = -1, opacity = -1, reflect = -1, transmit = -1, amount = -1;
   int m1 = -1, m2 = -1;  // mix
+  int bump = -1;         // "bumpmap" float texture (every material but mix), material/mod.rs:50-92
   bool remap_roughness = true;
 };
 
@@ -254,7 +255,8 @@ struct Scene {
   // ---- textures / materials
   RGB tex_eval(int id, const SurfaceInteraction& si) const;
   float tex_eval_f(int id, const SurfaceInteraction& si) const { return tex_eval(id, si).r; }
-  void build_bsdf(int mat, const SurfaceInteraction& si, Bsdf* bsdf, int depth = 0) const;
+  void build_bsdf(int mat, SurfaceInteraction& si, Bsdf* bsdf, int depth = 0) const;  // may bump-map si's shading geometry
+  void bump(int tex, SurfaceInteraction& si) const;
 };
 
 // ---------------------------------------------------------------- light distributions (rc/lightdistrib.rs)

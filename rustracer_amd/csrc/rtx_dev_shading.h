@@ -339,26 +339,60 @@ RT_DEV void scale_lobes(Bsdf& b, int first, int last, rgb3 s) {
 // Material::compute_scattering_functions. MixMaterial (mixmat.rs:34-64) is expanded up to two
 // levels (a mix whose operands are plain materials or mixes of plain materials); the host rejects
 // deeper nesting at scene creation.
-RT_DEVN void build_bsdf(const DScene& sc, int mat, const SurfaceInteraction& si, Bsdf& b) {
+// material::bump (rc/material/mod.rs:50-92). Triangles carry dndu = dndv = 0 (mesh.rs:372-382 passes zero()) and so do their
+// shading.dndu / dndv, which keeps the terms below in place with zero vectors.
+RT_DEVN void bump_map(const DScene& sc, int tex, SurfaceInteraction& si) {
+  const f3 dndu = mk3(0, 0, 0), dndv = mk3(0, 0, 0);
+  SurfaceInteraction e = si;
+  float du = 0.5f * (fabsf(si.dudx) + fabsf(si.dudy));
+  if (du == 0.0f) du = 0.0005f;
+  e.hit.p = si.hit.p + du * si.sh_dpdu;
+  e.uv = mk2(si.uv.x + du, si.uv.y + 0.0f);
+  e.hit.n = normalize(cross(si.sh_dpdu, si.sh_dpdv) + du * dndu);
+  const float u_displace = tex_eval(sc, tex, e).r;
+  float dv = 0.5f * (fabsf(si.dvdx) + fabsf(si.dvdy));
+  if (dv == 0.0f) dv = 0.0005f;
+  e.hit.p = si.hit.p + dv * si.sh_dpdv;
+  e.uv = mk2(si.uv.x + 0.0f, si.uv.y + dv);
+  e.hit.n = normalize(cross(si.sh_dpdu, si.sh_dpdv) + dv * dndv);
+  const float v_displace = tex_eval(sc, tex, e).r;
+  const float displace = tex_eval(sc, tex, si).r;
+  const f3 dpdu = si.sh_dpdu + (u_displace - displace) / du * si.sh_n + displace * dndu;
+  const f3 dpdv = si.sh_dpdv + (v_displace - displace) / dv * si.sh_n + displace * dndv;
+  // set_shading_geometry(dpdu, dpdv, dndu, dndv, false), interaction.rs:218-242
+  f3 n = normalize(cross(dpdu, dpdv));
+  if (tri_flags(sc.tri_p, si.prim) & 1u) n = n * -1.0f;  // reverse_orientation ^ transform_swaps_handedness
+  si.sh_n = face_forward(n, si.hit.n);
+  si.sh_dpdu = dpdu; si.sh_dpdv = dpdv;
+}
+// one non-mix material: its bump map first (the first statement of its compute_scattering_functions), then its lobes
+RT_DEV float material_apply(const DScene& sc, const DMaterial& m, SurfaceInteraction& si, Bsdf& b) {
+  if (m.bump >= 0) bump_map(sc, m.bump, si);
+  return material_lobes(sc, m, si, b);
+}
+RT_DEVN void build_bsdf(const DScene& sc, int mat, SurfaceInteraction& si, Bsdf& b) {
   b.n = 0;
   const DMaterial& m = sc.materials[mat];
   float eta;
-  if (m.kind != 7) eta = material_lobes(sc, m, si, b);
+  if (m.kind != 7) eta = material_apply(sc, m, si, b);
   else {
     rgb3 s1 = clamp_pos(tex_eval(sc, m.slot[13], si)), s2 = clamp_pos(mkc(1, 1, 1) - s1);
     eta = 1.0f;
+    SurfaceInteraction si2 = si;  // mat2 works on a clone taken before mat1 touches si (mixmat.rs:43); mat1's changes stay in si
     for (int side = 0; side < 2; ++side) {
       const DMaterial& c = sc.materials[side == 0 ? m.slot[14] : m.slot[15]];
+      SurfaceInteraction& cs = side == 0 ? si : si2;
       int first = b.n;
       float e;
-      if (c.kind != 7) e = material_lobes(sc, c, si, b);
+      if (c.kind != 7) e = material_apply(sc, c, cs, b);
       else {
-        rgb3 c1 = clamp_pos(tex_eval(sc, c.slot[13], si)), c2 = clamp_pos(mkc(1, 1, 1) - c1);
+        rgb3 c1 = clamp_pos(tex_eval(sc, c.slot[13], cs)), c2 = clamp_pos(mkc(1, 1, 1) - c1);
+        SurfaceInteraction cs2 = cs;
         int f1 = b.n;
-        e = material_lobes(sc, sc.materials[c.slot[14]], si, b);
+        e = material_apply(sc, sc.materials[c.slot[14]], cs, b);
         scale_lobes(b, f1, b.n, c1);
         int f2_ = b.n;
-        (void)material_lobes(sc, sc.materials[c.slot[15]], si, b);
+        (void)material_apply(sc, sc.materials[c.slot[15]], cs2, b);
         scale_lobes(b, f2_, b.n, c2);
       }
       scale_lobes(b, first, b.n, side == 0 ? s1 : s2);

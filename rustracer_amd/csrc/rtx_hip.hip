@@ -181,6 +181,8 @@ extern "C" int rt_scene_create(const rt_scene_desc* desc, int device, rt_scene**
   for (uint32_t i = 0; i < desc->n_materials; ++i) {
     const rt_material& m = desc->materials[i];
     hmat[i].kind = m.kind; hmat[i].remap = m.remap_roughness;
+    hmat[i].bump = (m.kind != RT_MAT_MIX && m.bump >= 0) ? m.bump : -1;
+    if (hmat[i].bump >= 0 && (uint32_t)hmat[i].bump >= desc->n_textures) { delete s; return fail(RT_ERR_INVALID, "bump texture out of range"); }
     for (int k = 0; k < 16; ++k) hmat[i].slot[k] = m.slot[k];
     if (m.kind == RT_MAT_MIX) {
       for (int side = 0; side < 2; ++side) {
@@ -243,11 +245,12 @@ extern "C" int rt_scene_create(const rt_scene_desc* desc, int device, rt_scene**
     const rt_texture& t = desc->textures[i];
     if (t.kind == RT_TEX_IMAGE || t.kind == RT_TEX_FBM || (t.kind == RT_TEX_CHECKER && t.amount != 0)) d.needs_differentials = 1;
   }
+  for (uint32_t i = 0; i < desc->n_materials; ++i) if (desc->materials[i].kind != RT_MAT_MIX && desc->materials[i].bump >= 0) d.needs_differentials = 1;  // bump() reads dudx..
   s->lambert_only = true;
   for (uint32_t i = 0; i < desc->n_materials; ++i) {
     const rt_material& m = desc->materials[i];
     auto is_const = [&](int id) { return id >= 0 && (uint32_t)id < desc->n_textures && desc->textures[id].kind == RT_TEX_CONST; };
-    if (m.kind != RT_MAT_MATTE || !is_const(m.slot[RT_SLOT_KD]) || !is_const(m.slot[RT_SLOT_SIGMA])) { s->lambert_only = false; break; }
+    if (m.kind != RT_MAT_MATTE || !is_const(m.slot[RT_SLOT_KD]) || !is_const(m.slot[RT_SLOT_SIGMA]) || m.bump >= 0) { s->lambert_only = false; break; }
     const float sg = desc->textures[m.slot[RT_SLOT_SIGMA]].value[0];
     if (!(sg <= 0.0f)) { s->lambert_only = false; break; }  // clamp(sigma, 0, 1) == 0 (matte.rs:51)
   }

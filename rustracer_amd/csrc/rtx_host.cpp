@@ -533,9 +533,9 @@ int rtxh_scene_add_texture(rtxh_scene* s, int32_t kind, const float* v, int32_t 
   s->textures.push_back(t);
   return (int)s->textures.size() - 1;
 }
-int rtxh_scene_add_material(rtxh_scene* s, int32_t kind, const int32_t* slots, int32_t remap) {
+int rtxh_scene_add_material(rtxh_scene* s, int32_t kind, const int32_t* slots, int32_t remap, int32_t bump) {
   if (!s || !slots) return fail(RT_ERR_INVALID, "bad material arguments");
-  rt_material m{}; m.kind = kind; m.remap_roughness = remap;
+  rt_material m{}; m.kind = kind; m.remap_roughness = remap; m.bump = bump;
   for (int k = 0; k < RT_N_SLOTS; ++k) m.slot[k] = slots[k];
   s->materials.push_back(m);
   return (int)s->materials.size() - 1;

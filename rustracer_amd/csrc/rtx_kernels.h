@@ -872,7 +872,7 @@ struct PathSampler {  // ZeroTwoSequence::get_1d / get_2d (zerotwosequence.rs:15
 // array in scratch and a fraction of the registers.
 struct GenericBsdf {
   Bsdf b;
-  RT_DEV void build(const DScene& sc, int mat, const SurfaceInteraction& si) { build_bsdf(sc, mat, si, b); }
+  RT_DEV void build(const DScene& sc, int mat, SurfaceInteraction& si) { build_bsdf(sc, mat, si, b); }  // a bump map rewrites si's shading geometry
   RT_DEV int num_nonspecular() const { return bsdf_num_components(b, BSDF_ALL & ~BSDF_SPECULAR); }
   RT_DEV rgb3 f(f3 wo, f3 wi, unsigned flags) const { return bsdf_f(b, wo, wi, flags); }
   RT_DEV float pdf(f3 wo, f3 wi, unsigned flags) const { return bsdf_pdf(b, wo, wi, flags); }
@@ -881,7 +881,7 @@ struct GenericBsdf {
 };
 struct SingleLambert {
   rgb3 r; bool has; f3 ns, ng, ss, ts;
-  RT_DEV void build(const DScene& sc, int mat, const SurfaceInteraction& si) {  // matte.rs:37-62 with constant Kd, sigma == 0
+  RT_DEV void build(const DScene& sc, int mat, SurfaceInteraction& si) {  // matte.rs:37-62 with constant Kd, sigma == 0, no bump map
     const DTexture& t = sc.textures[sc.materials[mat].slot[0]];
     r = clamp_pos(mkc(t.v[0], t.v[1], t.v[2]));
     has = !is_black(r);

@@ -149,7 +149,7 @@ class HostScene:
         for t in desc.textures:
             _check(L.rtxh_scene_add_texture(self.h, t.kind, _p(np.float32(t.value)), t.tex1, t.tex2, t.amount, t.mip, _p(np.float32(t.mapping))), "add_texture")
         for m in desc.materials:
-            _check(L.rtxh_scene_add_material(self.h, m.kind, _p(m.slots(), C.c_int32), int(m.remap_roughness)), "add_material")
+            _check(L.rtxh_scene_add_material(self.h, m.kind, _p(m.slots(), C.c_int32), int(m.remap_roughness), int(m.bump)), "add_material")
         for l in desc.lights:
             l2w = None if l.l2w is None else np.ascontiguousarray(l.l2w, np.float32)
             w2l = None if l.w2l is None else np.ascontiguousarray(l.w2l, np.float32)

@@ -61,6 +61,7 @@ class Material:
     kind: int = MAT_MATTE
     params: dict = field(default_factory=dict)  # slot name -> texture id (or material id for m1/m2)
     remap_roughness: bool = True
+    bump: int = -1  # "bumpmap" float texture id (rc/material/mod.rs:50-92)
 
     def slots(self) -> np.ndarray:
         return np.array([int(self.params.get(k, -1)) for k in MAT_SLOTS], dtype=np.int32)
@@ -228,6 +229,12 @@ class SceneDesc:
         self.materials.append(Material(MAT_TRANSLUCENT, {"kd": self._t(_f(kd)), "ks": self._t(_f(ks)), "reflect": self._t(_f(reflect)),
                                                           "transmit": self._t(_f(transmit)), "roughness": self._t(float(roughness))}, remap))
         return len(self.materials) - 1
+
+    def set_bump(self, material: int, tex) -> int:
+        """Attach a "bumpmap" float texture to a (non-mix) material; returns the material id."""
+        assert self.materials[material].kind != MAT_MIX
+        self.materials[material].bump = self._t(_f(tex))
+        return material
 
     def mix(self, m1: int, m2: int, amount=0.5) -> int:  # mixmat.rs:22-30
         self.materials.append(Material(MAT_MIX, {"m1": int(m1), "m2": int(m2), "amount": self._t(_f(amount))}))

@@ -35,6 +35,11 @@ def _zoo(material: str, light: str = "area", res=(40, 32), spp=8, max_depth=5):
         "matte_uv": lambda: s.matte(s.uv_tex(3.0, 2.0, 0.2, 0.1)),
         "matte_fbm": lambda: s.matte(s.scale_tex(s.fbm_tex(0.6, 6), s.const_tex((0.9, 0.7, 0.5)))),
         "plastic_fbm_checker_roughness": lambda: s.plastic(s.checker_tex(s.fbm_tex(0.5, 4), (0.5, 0.2, 0.2), 3, 3), (0.4, 0.4, 0.4), 0.2),
+        "matte_bump_fbm": lambda: s.set_bump(s.matte((0.6, 0.5, 0.4)), s.scale_tex(s.fbm_tex(0.6, 5), s.const_tex(0.05))),
+        "plastic_bump_image": lambda: s.set_bump(s.plastic((0.3, 0.3, 0.5), (0.4, 0.4, 0.4), 0.1), s.scale_tex(t_img, s.const_tex(0.02))),
+        "mirror_bump_checker": lambda: s.set_bump(s.mirror(0.9), s.checker_tex(0.0, 0.01, 8, 8)),
+        "mix_bump_both": lambda: s.mix(s.set_bump(s.matte((0.7, 0.2, 0.2)), s.scale_tex(s.fbm_tex(0.5, 4), s.const_tex(0.03))),
+                                       s.set_bump(s.metal(roughness=0.1), s.scale_tex(s.uv_tex(9, 9), s.const_tex(0.02))), 0.4),
         "matte_scale_mix_tex": lambda: s.matte(s.mix_tex(s.scale_tex(t_img, s.const_tex((0.9, 0.8, 0.7))), s.const_tex((0.1, 0.6, 0.2)), s.const_tex(0.3))),
         "plastic": lambda: s.plastic((0.3, 0.1, 0.1), (0.5, 0.5, 0.5), 0.15),
         "plastic_noremap": lambda: s.plastic(t_img, (0.4, 0.4, 0.4), 0.2, remap=False),
@@ -92,7 +97,7 @@ def _check(gpu_host, orc, d):
 
 
 MATERIALS = ["matte", "oren_nayar", "matte_image_ewa", "matte_image_trilinear_clamp", "matte_image_black_wrap", "matte_image_npot", "matte_checker_closedform", "matte_checker_none_nested", "matte_uv", "matte_fbm",
-             "plastic_fbm_checker_roughness", "matte_scale_mix_tex", "plastic",
+             "plastic_fbm_checker_roughness", "matte_bump_fbm", "plastic_bump_image", "mirror_bump_checker", "mix_bump_both", "matte_scale_mix_tex", "plastic",
              "plastic_noremap", "metal", "metal_aniso", "mirror", "glass", "glass_rough", "uber", "substrate", "translucent", "mix", "mix_nested"]
 
 
