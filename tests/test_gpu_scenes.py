@@ -82,3 +82,34 @@ def test_room_depth_and_strategy(gpu_host, orc, strategy):
     fo, _ = orc.OracleScene(d).render(mode=1)
     fh, _ = gpu_host.HostScene(d).render()
     assert rel_l2(gpu_host.film_to_rgb(fh), orc.film_to_rgb(fo)) < L2_GATE
+
+
+# ---------------------------------------------------------------- BASELINE-sized inputs against the oracle (low spp keeps the oracle to seconds)
+def test_full_resolution_cornell_matches_oracle(gpu_host, orc):
+    from rustracer_amd.scenes import cornell_box
+    d = cornell_box(1024, 1024, 4)
+    fo, so = orc.OracleScene(d).render(mode=1)
+    fh, sh = gpu_host.HostScene(d).render(count_traversal=True)
+    assert np.array_equal(fo[..., 3], fh[..., 3])
+    assert rel_l2(gpu_host.film_to_rgb(fh), orc.film_to_rgb(fo)) < L2_GATE
+    for k in ("rays_closest", "rays_shadow", "rays_mis", "nodes_closest", "tris_closest"):
+        assert abs(int(sh[k]) - int(so[k])) <= 1e-4 * int(so[k]) + 16, (k, sh[k], so[k])
+
+
+def test_million_triangle_mesh_matches_oracle(gpu_host, orc):
+    """S2 at its full triangle count: same BVH (2 M nodes), bit-identical hit records from the child-pair traversal, and the frame."""
+    from rustracer_amd.scenes import blob_scene
+    d = blob_scene(1024, 512, 320, 180, 4)
+    assert d.n_tris == 1048580
+    o, h = orc.OracleScene(d), gpu_host.HostScene(d)
+    bo, bh = o.bvh(), h.bvh()
+    assert all(np.array_equal(bo[k], bh[k]) for k in bo)
+    rays = random_rays(200000, np.float32([-2.5, -0.5, -2.5]), np.float32([2.5, 3.5, 2.5]), 11)
+    ro, rr = o.trace(rays), h.trace(rays, count=False)
+    assert np.array_equal(ro["prim"], rr["prim"]) and all(np.array_equal(bits(ro[k]), bits(rr[k])) for k in ("t", "b0", "b1"))
+    assert (ro["prim"] >= 0).mean() > 0.2
+    rc = h.trace(rays)  # counting kernels: the reference's visit sequence
+    assert (ro["nodes"], ro["tris"]) == (rc["nodes"], rc["tris"])
+    fo, _ = o.render(mode=1)
+    fh, _ = h.render()
+    assert np.array_equal(fo[..., 3], fh[..., 3]) and rel_l2(gpu_host.film_to_rgb(fh), orc.film_to_rgb(fo)) < L2_GATE
