@@ -76,7 +76,10 @@ typedef struct rt_image {
 } rt_image;
 
 /* -- materials: replaces dyn Material (rc/material/*.rs) ----------------------------------- */
-enum { RT_MAT_MATTE = 0, RT_MAT_PLASTIC, RT_MAT_METAL, RT_MAT_MIRROR, RT_MAT_GLASS, RT_MAT_UBER, RT_MAT_SUBSTRATE, RT_MAT_MIX, RT_MAT_TRANSLUCENT };
+enum { RT_MAT_MATTE = 0, RT_MAT_PLASTIC, RT_MAT_METAL, RT_MAT_MIRROR, RT_MAT_GLASS, RT_MAT_UBER, RT_MAT_SUBSTRATE, RT_MAT_MIX, RT_MAT_TRANSLUCENT,
+       RT_MAT_DISNEY /* rc/material/disney.rs; slots: KD color, KS metallic, ETA eta, ROUGHNESS roughness, KR speculartint, UROUGH anisotropic,
+                        KT sheen, SIGMA sheentint, VROUGH clearcoat, K clearcoatgloss, OPACITY spectrans, REFLECT scatterdistance,
+                        TRANSMIT flatness, AMOUNT difftrans, M1 = thin (0 / 1, not an id) */ };
 enum { RT_SLOT_KD = 0, RT_SLOT_KS, RT_SLOT_KR, RT_SLOT_KT, RT_SLOT_SIGMA, RT_SLOT_ROUGHNESS, RT_SLOT_UROUGH, RT_SLOT_VROUGH,
        RT_SLOT_ETA, RT_SLOT_K, RT_SLOT_OPACITY, RT_SLOT_REFLECT, RT_SLOT_TRANSMIT, RT_SLOT_AMOUNT, RT_SLOT_M1, RT_SLOT_M2, RT_N_SLOTS };
 typedef struct rt_material {

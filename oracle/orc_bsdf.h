@@ -74,14 +74,23 @@ inline RGB fr_conductor(float cos_theta_i, RGB eta_i, RGB eta_t, RGB k) {  // :6
   RGB r_p = r_s * (t3 - t4) / (t3 + t4);
   return 0.5f * (r_p + r_s);
 }
-enum FresnelKind { FR_NOOP = 0, FR_DIELECTRIC = 1, FR_CONDUCTOR = 2 };
+// Schlick helpers of rc/material/disney.rs:478-503
+inline float schlick_weight(float cos_theta) { float m = clamp_t(1.0f - cos_theta, 0.0f, 1.0f); return (m * m) * (m * m) * m; }
+inline float fr_schlick(float r0, float cos_theta) { return lerp_f(schlick_weight(cos_theta), r0, 1.0f); }
+inline RGB fr_schlick_rgb(RGB r0, float cos_theta) { float w = schlick_weight(cos_theta); return r0 * (1.0f - w) + rgb(1, 1, 1) * w; }
+enum FresnelKind { FR_NOOP = 0, FR_DIELECTRIC = 1, FR_CONDUCTOR = 2, FR_DISNEY = 3 };
 struct Fresnel {
   int kind = FR_NOOP;
   float eta_i = 1.0f, eta_t = 1.0f;  // dielectric
   RGB c_eta_i{1, 1, 1}, c_eta_t{1, 1, 1}, c_k{0, 0, 0};
+  RGB d_r0{0, 0, 0}; float d_metallic = 0.0f, d_eta = 1.5f;  // DisneyFresnel (disney.rs:420-442)
   RGB evaluate(float cos_theta_i) const {  // :110-136 (quirk 7: abs() before fr_dielectric)
     if (kind == FR_DIELECTRIC) return grey(fr_dielectric(fabsf(cos_theta_i), eta_i, eta_t));
     if (kind == FR_CONDUCTOR) return fr_conductor(fabsf(cos_theta_i), c_eta_i, c_eta_t, c_k);
+    if (kind == FR_DISNEY) {  // lerp(metallic, dielectric, schlick); no abs() here
+      RGB a = grey(fr_dielectric(cos_theta_i, 1.0f, d_eta)), b = fr_schlick_rgb(d_r0, cos_theta_i);
+      return a * (1.0f - d_metallic) + b * d_metallic;
+    }
     return rgb(1, 1, 1);
   }
 };
@@ -89,6 +98,7 @@ struct Fresnel {
 // ---------------------------------------------------------------- TrowbridgeReitz (bsdf/microfacet.rs:470-650)
 struct TRDist {
   float ax = 0.1f, ay = 0.1f;
+  bool separable_g = false;  // DisneyMicrofacetDistribution (disney.rs:444-476): g = g1(wi) * g1(wo)
   static float roughness_to_alpha(float roughness) {  // :485-493
     roughness = fmaxf(roughness, 1e-3f);
     float x = logf(roughness);
@@ -109,7 +119,7 @@ struct TRDist {
     return (-1.0f + sqrtf(1.0f + a2t2)) / 2.0f;
   }
   float g1(V3 w) const { return 1.0f / (1.0f + lambda(w)); }                        // :235-237
-  float g(V3 wi, V3 wo) const { return 1.0f / (1.0f + lambda(wi) + lambda(wo)); }   // :239-241
+  float g(V3 wi, V3 wo) const { return separable_g ? g1(wi) * g1(wo) : 1.0f / (1.0f + lambda(wi) + lambda(wo)); }   // :239-241
   float pdf(V3 wo, V3 wh) const { return d(wh) * g1(wo) * fabsf(dot(wo, wh)) / abs_cos_theta(wo); }  // :243-249 (visible area)
   static void sample11(float cos_theta_, float u1, float u2, float* sx, float* sy) {  // :517-572
     if (cos_theta_ > 0.9999f) {
@@ -157,8 +167,17 @@ struct TRDist {
 // ---------------------------------------------------------------- BxDF tagged union
 enum BxdfKind {
   BX_LAMBERT_R = 0, BX_LAMBERT_T, BX_OREN_NAYAR, BX_SPEC_R, BX_SPEC_T, BX_FRESNEL_SPEC,
-  BX_FRESNEL_BLEND, BX_MICRO_R, BX_MICRO_T
+  BX_FRESNEL_BLEND, BX_MICRO_R, BX_MICRO_T,
+  BX_DISNEY_DIFFUSE, BX_DISNEY_FAKESS, BX_DISNEY_RETRO, BX_DISNEY_SHEEN, BX_DISNEY_CLEARCOAT  // rc/material/disney.rs:215-418
 };
+inline float disney_gtr1(float cos_theta, float alpha) {  // disney.rs:505-511 (log10, as the reference has it)
+  float alpha2 = alpha * alpha;
+  return (alpha2 - 1.0f) / (kPi * log10f(alpha2) * (1.0f + (alpha2 - 1.0f) * cos_theta * cos_theta));
+}
+inline float disney_smith_g_ggx(float cos_theta, float alpha) {  // disney.rs:513-519
+  float alpha2 = alpha * alpha, cos_theta2 = cos_theta * cos_theta;
+  return 1.0f / (cos_theta + sqrtf(alpha2 + cos_theta2 - alpha2 * cos_theta2));
+}
 struct SampleF { RGB f; V3 wi; float pdf; uint32_t type; };
 
 inline float pow5(float v) { return (v * v) * (v * v) * v; }  // fresnel.rs:414-417
@@ -167,7 +186,7 @@ struct Bxdf {
   int kind = BX_LAMBERT_R;
   RGB r{0, 0, 0};   // R / T / (FresnelSpecular: R) / (FresnelBlend: Rd)
   RGB t{0, 0, 0};   // FresnelSpecular: T ; FresnelBlend: Rs
-  float a = 0, b = 0;          // OrenNayar A,B
+  float a = 0, b = 0;          // OrenNayar A,B; Disney FakeSS / Retro: a = roughness; ClearCoat: a = weight, b = gloss
   float eta_a = 1, eta_b = 1;  // transmission / FresnelSpecular
   Fresnel fresnel;             // SpecularReflection / MicrofacetReflection / (dielectric of *Transmission)
   TRDist dist;
@@ -185,6 +204,8 @@ struct Bxdf {
       case BX_FRESNEL_SPEC: return BSDF_SPECULAR | BSDF_REFLECTION | BSDF_TRANSMISSION;  // :331
       case BX_FRESNEL_BLEND: return BSDF_REFLECTION | BSDF_GLOSSY;                 // :410
       case BX_MICRO_R: return BSDF_REFLECTION | BSDF_GLOSSY;                       // microfacet.rs:56
+      case BX_DISNEY_DIFFUSE: case BX_DISNEY_FAKESS: case BX_DISNEY_RETRO: case BX_DISNEY_SHEEN: return BSDF_REFLECTION | BSDF_DIFFUSE;
+      case BX_DISNEY_CLEARCOAT: return BSDF_REFLECTION | BSDF_GLOSSY;              // disney.rs:415-417
       default: return BSDF_TRANSMISSION | BSDF_GLOSSY;                             // microfacet.rs:175
     }
   }
@@ -229,6 +250,32 @@ struct Bxdf {
         RGB fr = fresnel.evaluate(dot(wi, wh));
         return r * dist.d(wh) * dist.g(wo, wi) * fr / (4.0f * cos_theta_i * cos_theta_o);
       }
+      case BX_DISNEY_DIFFUSE: {  // disney.rs:228-236
+        float fo = schlick_weight(abs_cos_theta(wo)), fi = schlick_weight(abs_cos_theta(wi));
+        return r * kInvPi * (1.0f - fo / 2.0f) * (1.0f - fi / 2.0f);
+      }
+      case BX_DISNEY_FAKESS: case BX_DISNEY_RETRO: case BX_DISNEY_SHEEN: case BX_DISNEY_CLEARCOAT: {
+        V3 wh = wi + wo;
+        if (wh.x == 0.0f && wh.y == 0.0f && wh.z == 0.0f) return rgb(0, 0, 0);
+        wh = normalize(wh);
+        float cos_theta_d = dot(wi, wh);
+        if (kind == BX_DISNEY_SHEEN) return r * schlick_weight(cos_theta_d);  // :332-341
+        if (kind == BX_DISNEY_CLEARCOAT) {  // :363-378
+          float Dr = disney_gtr1(abs_cos_theta(wh), b);
+          float Fr = fr_schlick(0.04f, dot(wo, wh));
+          float Gr = disney_smith_g_ggx(abs_cos_theta(wo), 0.25f) * disney_smith_g_ggx(abs_cos_theta(wi), 0.25f);
+          return grey(a * Gr * Fr * Dr / 4.0f);
+        }
+        float fo = schlick_weight(abs_cos_theta(wo)), fi = schlick_weight(abs_cos_theta(wi));
+        if (kind == BX_DISNEY_FAKESS) {  // :258-274
+          float fss90 = cos_theta_d * cos_theta_d * a;
+          float fss = lerp_f(fo, 1.0f, fss90) * lerp_f(fi, 1.0f, fss90);
+          float ss = 1.25f * (fss * (1.0f / (abs_cos_theta(wo) + abs_cos_theta(wi)) - 0.5f) + 0.5f);
+          return r * kInvPi * ss;
+        }
+        float rr = 2.0f * a * cos_theta_d * cos_theta_d;  // DisneyRetro, :296-308
+        return r * kInvPi * rr * (fo + fi + fo * fi * (rr - 1.0f));
+      }
       default: {  // BX_MICRO_T microfacet.rs:127-172  (r = T)
         if (same_hemisphere(wo, wi)) return rgb(0, 0, 0);
         float cos_theta_o = cos_theta(wo), cos_theta_i = cos_theta(wi);
@@ -267,7 +314,15 @@ struct Bxdf {
         float dwh_dwi = fabsf((eta * eta * dot(wi, wh)) / (sqrt_denom * sqrt_denom));
         return dist.pdf(wo, wh) * dwh_dwi;
       }
-      default: return default_pdf(wo, wi);  // Lambertian R/T (quirk 6), OrenNayar
+      case BX_DISNEY_CLEARCOAT: {  // disney.rs:397-413
+        if (!same_hemisphere(wo, wi)) return 0.0f;
+        V3 wh = wo + wi;
+        if (wh.x == 0.0f && wh.y == 0.0f && wh.z == 0.0f) return 0.0f;
+        wh = normalize(wh);
+        float Dr = disney_gtr1(abs_cos_theta(wh), b);
+        return Dr * abs_cos_theta(wh) / (4.0f * dot(wo, wh));
+      }
+      default: return default_pdf(wo, wi);  // Lambertian R/T (quirk 6), OrenNayar, Disney diffuse lobes
     }
   }
   SampleF sample_inner(V3 wo, P2 u) const {
@@ -336,6 +391,19 @@ struct Bxdf {
           return {f_inner(wo, wi), wi, pdf, get_type()};
         }
         return {rgb(0, 0, 0), v3(0, 0, 0), 0.0f, get_type()};
+      }
+      case BX_DISNEY_CLEARCOAT: {  // disney.rs:380-395
+        if (wo.z == 0.0f) return {rgb(0, 0, 0), v3(0, 0, 0), 0.0f, get_type()};
+        float alpha2 = b * b;
+        float cos_theta_ = sqrtf(fmaxf(0.0f, (1.0f - powf(alpha2, 1.0f - u.x)) / (1.0f - alpha2)));
+        float sin_theta_ = sqrtf(fmaxf(0.0f, 1.0f - cos_theta_ * cos_theta_));
+        float phi = 2.0f * kPi * u.y;
+        V3 wh = v3(sin_theta_ * cosf(phi), sin_theta_ * sinf(phi), cos_theta_);  // spherical_direction, geometry/mod.rs:112-114
+        if (!same_hemisphere(wo, wh)) wh = -wh;
+        V3 wi = reflect(wo, wh);
+        if (!same_hemisphere(wo, wi)) return {rgb(0, 0, 0), v3(0, 0, 0), 0.0f, get_type()};
+        float pdf = pdf_inner(wo, wi);
+        return {f_inner(wo, wi), wi, pdf, get_type()};
       }
       default: {  // default trait sample_f, bxdf.rs:18-25 (quirk 5: returns empty type flags)
         V3 wi = cosine_sample_hemisphere(u);

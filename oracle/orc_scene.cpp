@@ -647,6 +647,56 @@ void Scene::build_bsdf(int mat, SurfaceInteraction& si, Bsdf* bsdf, int depth) c
       }
       break;
     }
+    case MAT_DISNEY: {  // disney.rs:82-213 (slot reuse: see MatKind)
+      auto disney = [](int kind, RGB r, float a = 0.0f, float b = 0.0f) { Bxdf x; x.kind = kind; x.r = r; x.a = a; x.b = b; return x; };
+      auto lerp_rgb = [](float t, RGB a, RGB b) { return a * (1.0f - t) + b * t; };
+      const bool thin = m.m1 != 0;
+      RGB c = clamp_pos(tex_eval(m.kd, si));
+      float metallic_weight = tex_eval_f(m.ks, si);
+      float e = tex_eval_f(m.eta, si);
+      float strans = tex_eval_f(m.opacity, si);
+      float diffuse_weight = (1.0f - metallic_weight) * (1.0f - strans);
+      float dt = tex_eval_f(m.amount, si) / 2.0f;
+      float rough = tex_eval_f(m.roughness, si);
+      float lum = lum_y(c);
+      RGB c_tint = lum > 0.0f ? c / lum : rgb(1, 1, 1);
+      float sheen_weight = tex_eval_f(m.kt, si);
+      RGB c_sheen = rgb(0, 0, 0);
+      if (sheen_weight > 0.0f) { float stint = tex_eval_f(m.sigma, si); c_sheen = lerp_rgb(stint, rgb(1, 1, 1), c_tint); }
+      if (diffuse_weight > 0.0f) {
+        if (thin) {
+          float flat = tex_eval_f(m.transmit, si);
+          bsdf->add(disney(BX_DISNEY_DIFFUSE, diffuse_weight * (1.0f - flat) * (1.0f - dt) * c));
+          bsdf->add(disney(BX_DISNEY_FAKESS, diffuse_weight * flat * (1.0f - dt) * c, rough));
+        } else {
+          RGB sd = tex_eval(m.reflect, si);
+          if (is_black(sd)) bsdf->add(disney(BX_DISNEY_DIFFUSE, diffuse_weight * c));
+          else bsdf->add(spec_t(grey(1.0f), 1.0f, e));  // stand-in of the missing BSSRDF (:137-144)
+        }
+        bsdf->add(disney(BX_DISNEY_RETRO, diffuse_weight * c, rough));
+        if (sheen_weight > 0.0f) bsdf->add(disney(BX_DISNEY_SHEEN, diffuse_weight * sheen_weight * c_sheen));
+      }
+      float aspect = sqrtf(1.0f - tex_eval_f(m.urough, si) * 0.9f);
+      float ax = fmaxf(0.001f, (rough * rough) / aspect), ay = fmaxf(0.001f, (rough * rough) * aspect);
+      float spec_tint = tex_eval_f(m.kr, si);
+      float r0eta = ((e - 1.0f) * (e - 1.0f)) / ((e + 1.0f) * (e + 1.0f));  // schlick_r0_from_eta, :497-503
+      RGB cspec0 = lerp_rgb(metallic_weight, r0eta * lerp_rgb(spec_tint, rgb(1, 1, 1), c_tint), c);
+      Fresnel f; f.kind = FR_DISNEY; f.d_r0 = cspec0; f.d_metallic = metallic_weight; f.d_eta = e;
+      { Bxdf x = micro_r(c, ax, ay, f); x.dist.separable_g = true; bsdf->add(x); }
+      float cc = tex_eval_f(m.vrough, si);
+      if (cc > 0.0f) bsdf->add(disney(BX_DISNEY_CLEARCOAT, rgb(0, 0, 0), cc, lerp_f(tex_eval_f(m.k, si), 0.1f, 0.001f)));
+      if (strans > 0.0f) {
+        RGB t = strans * rgb_sqrt(c);
+        if (thin) {
+          float rscaled = (0.65f * e - 0.35f) * rough;
+          float ax2 = fmaxf(0.001f, (rscaled * rscaled) / aspect), ay2 = fmaxf(0.001f, (rscaled * rscaled) * aspect);
+          bsdf->add(micro_t(t, ax2, ay2, 1.0f, e));
+        } else { Bxdf x = micro_t(t, ax, ay, 1.0f, e); x.dist.separable_g = true; bsdf->add(x); }
+      }
+      if (thin) bsdf->add(lambert_t(dt * c));
+      eta = 1.0f;  // Bsdf::new(si, 1.0, ..), :212
+      break;
+    }
     case MAT_MIX: {  // mixmat.rs:34-64
       RGB s1 = clamp_pos(tex_eval(m.amount, si));
       RGB s2 = clamp_pos(rgb(1, 1, 1) - s1);

@@ -90,7 +90,10 @@ float noise_perlin(float x, float y, float z);                                  
 float noise_fbm(V3 p, V3 dpdx, V3 dpdy, float omega, uint32_t max_octaves);     // rc/noise.rs:46-66
 
 // ---------------------------------------------------------------- materials
-enum MatKind { MAT_MATTE = 0, MAT_PLASTIC, MAT_METAL, MAT_MIRROR, MAT_GLASS, MAT_UBER, MAT_SUBSTRATE, MAT_MIX, MAT_TRANSLUCENT, MAT_NONE };
+enum MatKind { MAT_MATTE = 0, MAT_PLASTIC, MAT_METAL, MAT_MIRROR, MAT_GLASS, MAT_UBER, MAT_SUBSTRATE, MAT_MIX, MAT_TRANSLUCENT, MAT_DISNEY, MAT_NONE };
+// MAT_DISNEY (rc/material/disney.rs) reuses the slots: kd = color, ks = metallic, eta = eta, roughness = roughness, kr = speculartint,
+// urough = anisotropic, kt = sheen, sigma = sheentint, vrough = clearcoat, k = clearcoatgloss, opacity = spectrans,
+// reflect = scatterdistance, transmit = flatness, amount = difftrans, m1 = thin (0 / 1, not a texture id)
 struct Material {
   int kind = MAT_MATTE;
   // texture ids; meaning depends on kind (see build_bsdf)

@@ -69,16 +69,18 @@ RT_DEVN rgb3 fr_conductor(float cos_theta_i, rgb3 eta_i, rgb3 eta_t, rgb3 k) {  
 }
 
 // ---------------------------------------------------------------- lobes
-enum { LB_LAMBERT_R = 0, LB_LAMBERT_T, LB_OREN_NAYAR, LB_SPEC_R, LB_SPEC_T, LB_FRESNEL_SPEC, LB_FRESNEL_BLEND, LB_MICRO_R, LB_MICRO_T };
-enum { FR_NOOP = 0, FR_DIELECTRIC = 1, FR_CONDUCTOR = 2 };
+enum { LB_LAMBERT_R = 0, LB_LAMBERT_T, LB_OREN_NAYAR, LB_SPEC_R, LB_SPEC_T, LB_FRESNEL_SPEC, LB_FRESNEL_BLEND, LB_MICRO_R, LB_MICRO_T,
+       LB_DISNEY_DIFFUSE, LB_DISNEY_FAKESS, LB_DISNEY_RETRO, LB_DISNEY_SHEEN, LB_DISNEY_CLEARCOAT };  // rc/material/disney.rs:215-418
+// fr_kind: bits 0-1 = Fresnel kind; bit 2 = the microfacet distribution is Disney's (separable masking-shadowing, disney.rs:444-476)
+enum { FR_NOOP = 0, FR_DIELECTRIC = 1, FR_CONDUCTOR = 2, FR_DISNEY = 3, FR_SEPARABLE_G = 4 };
 struct Lobe {
   int kind, fr_kind;
   rgb3 r;        // R / T / FresnelSpecular R / FresnelBlend Rd
-  rgb3 t;        // FresnelSpecular T / FresnelBlend Rs / conductor eta_t
+  rgb3 t;        // FresnelSpecular T / FresnelBlend Rs / conductor eta_t / DisneyFresnel R0
   rgb3 k;        // conductor k
-  float ax, ay;  // Trowbridge-Reitz alphas, or Oren-Nayar A, B
+  float ax, ay;  // Trowbridge-Reitz alphas, or Oren-Nayar A, B; Disney FakeSS / Retro: ax = roughness; ClearCoat: ax = weight, ay = gloss
   float eta_a, eta_b;  // transmission lobes / FresnelSpecular; dielectric Fresnel uses (fr_ei, fr_et)
-  float fr_ei, fr_et;
+  float fr_ei, fr_et;  // DisneyFresnel: metallic, eta
   int n_scales; rgb3 scale0, scale1;  // ScaledBxDF nesting (bxdf.rs:48-71), innermost first
 };
 RT_DEV unsigned lobe_type(int kind) {
@@ -91,13 +93,24 @@ RT_DEV unsigned lobe_type(int kind) {
     case LB_FRESNEL_SPEC: return BSDF_SPECULAR | BSDF_REFLECTION | BSDF_TRANSMISSION;
     case LB_FRESNEL_BLEND: return BSDF_REFLECTION | BSDF_GLOSSY;
     case LB_MICRO_R: return BSDF_REFLECTION | BSDF_GLOSSY;
+    case LB_DISNEY_DIFFUSE: case LB_DISNEY_FAKESS: case LB_DISNEY_RETRO: case LB_DISNEY_SHEEN: return BSDF_REFLECTION | BSDF_DIFFUSE;
+    case LB_DISNEY_CLEARCOAT: return BSDF_REFLECTION | BSDF_GLOSSY;
     default: return BSDF_TRANSMISSION | BSDF_GLOSSY;
   }
 }
 RT_DEV bool lobe_matches(int kind, unsigned flags) { unsigned t = lobe_type(kind); return (t & flags) == t; }  // bxdf.rs:29-31
+// Schlick helpers of rc/material/disney.rs:478-503
+RT_DEV float schlick_weight(float cos_theta) { float m = clampf(1.0f - cos_theta, 0.0f, 1.0f); return (m * m) * (m * m) * m; }
+RT_DEV float fr_schlick(float r0, float cos_theta) { return lerpf(schlick_weight(cos_theta), r0, 1.0f); }
 RT_DEV rgb3 fresnel_eval(const Lobe& l, float cos_theta_i) {  // fresnel.rs:110-136 (abs() first: quirk 7)
-  if (l.fr_kind == FR_DIELECTRIC) return grey(fr_dielectric(fabsf(cos_theta_i), l.fr_ei, l.fr_et));
-  if (l.fr_kind == FR_CONDUCTOR) return fr_conductor(fabsf(cos_theta_i), mkc(1.0f, 1.0f, 1.0f), l.t, l.k);
+  const int k = l.fr_kind & 3;
+  if (k == FR_DIELECTRIC) return grey(fr_dielectric(fabsf(cos_theta_i), l.fr_ei, l.fr_et));
+  if (k == FR_CONDUCTOR) return fr_conductor(fabsf(cos_theta_i), mkc(1.0f, 1.0f, 1.0f), l.t, l.k);
+  if (k == FR_DISNEY) {  // DisneyFresnel::evaluate (disney.rs:434-442): lerp(metallic, dielectric, schlick); no abs() here
+    const float w = schlick_weight(cos_theta_i), m = l.fr_ei;
+    rgb3 a = grey(fr_dielectric(cos_theta_i, 1.0f, l.fr_et)), b = l.t * (1.0f - w) + mkc(1.0f, 1.0f, 1.0f) * w;
+    return a * (1.0f - m) + b * m;
+  }
   return mkc(1.0f, 1.0f, 1.0f);
 }
 
@@ -123,6 +136,7 @@ RT_DEV float tr_lambda(float ax, float ay, f3 w) {  // :590-602
 }
 RT_DEV float tr_g1(float ax, float ay, f3 w) { return 1.0f / (1.0f + tr_lambda(ax, ay, w)); }
 RT_DEV float tr_g(float ax, float ay, f3 wi, f3 wo) { return 1.0f / (1.0f + tr_lambda(ax, ay, wi) + tr_lambda(ax, ay, wo)); }
+RT_DEV float lobe_g(const Lobe& l, f3 wi, f3 wo) { return (l.fr_kind & FR_SEPARABLE_G) ? tr_g1(l.ax, l.ay, wi) * tr_g1(l.ax, l.ay, wo) : tr_g(l.ax, l.ay, wi, wo); }
 RT_DEV float tr_pdf(float ax, float ay, f3 wo, f3 wh) { return tr_d(ax, ay, wh) * tr_g1(ax, ay, wo) * fabsf(dot(wo, wh)) / abs_cos_theta(wo); }
 RT_DEV void tr_sample11(float cos_theta_, float u1, float u2, float& sx, float& sy) {  // :517-572
   if (cos_theta_ > 0.9999f) {
@@ -163,6 +177,14 @@ RT_DEVN f3 tr_sample_wh(float ax, float ay, f3 wo, f2 u) {  // :495-514, 604-645
 }
 
 RT_DEV float pow5(float v) { return (v * v) * (v * v) * v; }
+RT_DEV float disney_gtr1(float cos_theta, float alpha) {  // disney.rs:505-511 (log10, as the reference has it)
+  float alpha2 = alpha * alpha;
+  return (alpha2 - 1.0f) / (kPi * log10f(alpha2) * (1.0f + (alpha2 - 1.0f) * cos_theta * cos_theta));
+}
+RT_DEV float disney_smith_g_ggx(float cos_theta, float alpha) {  // disney.rs:513-519
+  float alpha2 = alpha * alpha, cos_theta2 = cos_theta * cos_theta;
+  return 1.0f / (cos_theta + sqrtf(alpha2 + cos_theta2 - alpha2 * cos_theta2));
+}
 RT_DEV float default_pdf(f3 wo, f3 wi) { return same_hemisphere(wo, wi) ? abs_cos_theta(wi) * kInvPi : 0.0f; }  // bxdf.rs:38-44
 
 RT_DEV rgb3 lobe_f_inner(const Lobe& l, f3 wo, f3 wi) {
@@ -198,7 +220,33 @@ RT_DEV rgb3 lobe_f_inner(const Lobe& l, f3 wo, f3 wi) {
       if (wh.x == 0.0f && wh.y == 0.0f && wh.z == 0.0f) return mkc(0, 0, 0);
       wh = normalize(wh);
       rgb3 fr = fresnel_eval(l, dot(wi, wh));
-      return l.r * tr_d(l.ax, l.ay, wh) * tr_g(l.ax, l.ay, wo, wi) * fr / (4.0f * cos_theta_i * cos_theta_o);
+      return l.r * tr_d(l.ax, l.ay, wh) * lobe_g(l, wo, wi) * fr / (4.0f * cos_theta_i * cos_theta_o);
+    }
+    case LB_DISNEY_DIFFUSE: {  // disney.rs:228-236
+      float fo = schlick_weight(abs_cos_theta(wo)), fi = schlick_weight(abs_cos_theta(wi));
+      return l.r * kInvPi * (1.0f - fo / 2.0f) * (1.0f - fi / 2.0f);
+    }
+    case LB_DISNEY_FAKESS: case LB_DISNEY_RETRO: case LB_DISNEY_SHEEN: case LB_DISNEY_CLEARCOAT: {
+      f3 wh = wi + wo;
+      if (wh.x == 0.0f && wh.y == 0.0f && wh.z == 0.0f) return mkc(0, 0, 0);
+      wh = normalize(wh);
+      float cos_theta_d = dot(wi, wh);
+      if (l.kind == LB_DISNEY_SHEEN) return l.r * schlick_weight(cos_theta_d);  // :332-341
+      if (l.kind == LB_DISNEY_CLEARCOAT) {  // :363-378
+        float Dr = disney_gtr1(abs_cos_theta(wh), l.ay);
+        float Fr = fr_schlick(0.04f, dot(wo, wh));
+        float Gr = disney_smith_g_ggx(abs_cos_theta(wo), 0.25f) * disney_smith_g_ggx(abs_cos_theta(wi), 0.25f);
+        return grey(l.ax * Gr * Fr * Dr / 4.0f);
+      }
+      float fo = schlick_weight(abs_cos_theta(wo)), fi = schlick_weight(abs_cos_theta(wi));
+      if (l.kind == LB_DISNEY_FAKESS) {  // :258-274
+        float fss90 = cos_theta_d * cos_theta_d * l.ax;
+        float fss = lerpf(fo, 1.0f, fss90) * lerpf(fi, 1.0f, fss90);
+        float ss = 1.25f * (fss * (1.0f / (abs_cos_theta(wo) + abs_cos_theta(wi)) - 0.5f) + 0.5f);
+        return l.r * kInvPi * ss;
+      }
+      float rr = 2.0f * l.ax * cos_theta_d * cos_theta_d;  // DisneyRetro, :296-308
+      return l.r * kInvPi * rr * (fo + fi + fo * fi * (rr - 1.0f));
     }
     default: {  // LB_MICRO_T, microfacet.rs:127-172 (mode == RADIANCE)
       if (same_hemisphere(wo, wi)) return mkc(0, 0, 0);
@@ -211,7 +259,7 @@ RT_DEV rgb3 lobe_f_inner(const Lobe& l, f3 wo, f3 wi) {
       float sqrt_denom = dot(wo, wh) + eta * dot(wi, wh);
       float factor = 1.0f / eta;
       return (mkc(1, 1, 1) - fr) * l.r *
-             fabsf(tr_d(l.ax, l.ay, wh) * tr_g(l.ax, l.ay, wo, wi) * eta * eta * fabsf(dot(wi, wh)) * fabsf(dot(wo, wh)) * factor * factor /
+             fabsf(tr_d(l.ax, l.ay, wh) * lobe_g(l, wo, wi) * eta * eta * fabsf(dot(wi, wh)) * fabsf(dot(wo, wh)) * factor * factor /
                    (cos_theta_i * cos_theta_o * sqrt_denom * sqrt_denom));
     }
   }
@@ -238,7 +286,15 @@ RT_DEV float lobe_pdf_inner(const Lobe& l, f3 wo, f3 wi) {
       float dwh_dwi = fabsf((eta * eta * dot(wi, wh)) / (sqrt_denom * sqrt_denom));
       return tr_pdf(l.ax, l.ay, wo, wh) * dwh_dwi;
     }
-    default: return default_pdf(wo, wi);  // Lambertian R and T (quirk 6), Oren-Nayar
+    case LB_DISNEY_CLEARCOAT: {  // disney.rs:397-413
+      if (!same_hemisphere(wo, wi)) return 0.0f;
+      f3 wh = wo + wi;
+      if (wh.x == 0.0f && wh.y == 0.0f && wh.z == 0.0f) return 0.0f;
+      wh = normalize(wh);
+      float Dr = disney_gtr1(abs_cos_theta(wh), l.ay);
+      return Dr * abs_cos_theta(wh) / (4.0f * dot(wo, wh));
+    }
+    default: return default_pdf(wo, wi);  // Lambertian R and T (quirk 6), Oren-Nayar, Disney diffuse lobes
   }
 }
 struct LobeSample { rgb3 f; f3 wi; float pdf; unsigned type; };
@@ -309,6 +365,19 @@ RT_DEV LobeSample lobe_sample_inner(const Lobe& l, f3 wo, f2 u) {
         return mk_ls(lobe_f_inner(l, wo, wi), wi, pdf, ty);
       }
       return mk_ls(mkc(0, 0, 0), mk3(0, 0, 0), 0.0f, ty);
+    }
+    case LB_DISNEY_CLEARCOAT: {  // disney.rs:380-395
+      if (wo.z == 0.0f) return mk_ls(mkc(0, 0, 0), mk3(0, 0, 0), 0.0f, ty);
+      float alpha2 = l.ay * l.ay;
+      float cos_theta_ = sqrtf(fmaxf(0.0f, (1.0f - powf(alpha2, 1.0f - u.x)) / (1.0f - alpha2)));
+      float sin_theta_ = sqrtf(fmaxf(0.0f, 1.0f - cos_theta_ * cos_theta_));
+      float phi = 2.0f * kPi * u.y;
+      f3 wh = mk3(sin_theta_ * cosf(phi), sin_theta_ * sinf(phi), cos_theta_);  // spherical_direction, geometry/mod.rs:112-114
+      if (!same_hemisphere(wo, wh)) wh = -wh;
+      f3 wi = reflect(wo, wh);
+      if (!same_hemisphere(wo, wi)) return mk_ls(mkc(0, 0, 0), mk3(0, 0, 0), 0.0f, ty);
+      float pdf = lobe_pdf_inner(l, wo, wi);
+      return mk_ls(lobe_f_inner(l, wo, wi), wi, pdf, ty);
     }
     default: {  // default BxDF::sample_f (bxdf.rs:18-25): cosine sampling, EMPTY sampled-type flags (quirk 5)
       f3 wi = cosine_sample_hemisphere(u);

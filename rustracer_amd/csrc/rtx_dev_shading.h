@@ -325,6 +325,54 @@ RT_DEVN float material_lobes(const DScene& sc, const DMaterial& m, const Surface
       }
       break;
     }
+    case 9: {  // disney.rs:82-213. Slots: 0 color, 1 metallic, 8 eta, 5 roughness, 2 speculartint, 6 anisotropic, 3 sheen, 4 sheentint,
+               // 7 clearcoat, 9 clearcoatgloss, 10 spectrans, 11 scatterdistance, 12 flatness, 13 difftrans, 14 thin (0 / 1)
+      const bool thin = s[14] != 0;
+      rgb3 c = clamp_pos(tex_eval(sc, s[0], si));
+      float metallic_weight = tex_eval_f(sc, s[1], si);
+      float e = tex_eval_f(sc, s[8], si);
+      float strans = tex_eval_f(sc, s[10], si);
+      float diffuse_weight = (1.0f - metallic_weight) * (1.0f - strans);
+      float dt = tex_eval_f(sc, s[13], si) / 2.0f;
+      float rough = tex_eval_f(sc, s[5], si);
+      float lum = lum_y(c);
+      rgb3 c_tint = lum > 0.0f ? c / lum : mkc(1, 1, 1);
+      float sheen_weight = tex_eval_f(sc, s[3], si);
+      rgb3 c_sheen = mkc(0, 0, 0);
+      if (sheen_weight > 0.0f) { float stint = tex_eval_f(sc, s[4], si); c_sheen = mkc(1, 1, 1) * (1.0f - stint) + c_tint * stint; }
+      if (diffuse_weight > 0.0f) {
+        if (thin) {
+          float flat = tex_eval_f(sc, s[12], si);
+          bsdf_add(b, mk_lambert(LB_DISNEY_DIFFUSE, diffuse_weight * (1.0f - flat) * (1.0f - dt) * c));
+          { Lobe l = mk_lambert(LB_DISNEY_FAKESS, diffuse_weight * flat * (1.0f - dt) * c); l.ax = rough; bsdf_add(b, l); }
+        } else {
+          rgb3 sd = tex_eval(sc, s[11], si);
+          if (is_black(sd)) bsdf_add(b, mk_lambert(LB_DISNEY_DIFFUSE, diffuse_weight * c));
+          else bsdf_add(b, mk_spec_t(mkc(1, 1, 1), 1.0f, e));  // stand-in of the missing BSSRDF (:137-144)
+        }
+        { Lobe l = mk_lambert(LB_DISNEY_RETRO, diffuse_weight * c); l.ax = rough; bsdf_add(b, l); }
+        if (sheen_weight > 0.0f) bsdf_add(b, mk_lambert(LB_DISNEY_SHEEN, diffuse_weight * sheen_weight * c_sheen));
+      }
+      float aspect = sqrtf(1.0f - tex_eval_f(sc, s[6], si) * 0.9f);
+      float ax = fmaxf(0.001f, (rough * rough) / aspect), ay = fmaxf(0.001f, (rough * rough) * aspect);
+      float spec_tint = tex_eval_f(sc, s[2], si);
+      float r0eta = ((e - 1.0f) * (e - 1.0f)) / ((e + 1.0f) * (e + 1.0f));  // schlick_r0_from_eta, :497-503
+      rgb3 tinted = r0eta * (mkc(1, 1, 1) * (1.0f - spec_tint) + c_tint * spec_tint);
+      rgb3 cspec0 = tinted * (1.0f - metallic_weight) + c * metallic_weight;
+      { Lobe l = mk_micro_r(c, ax, ay, FR_DISNEY | FR_SEPARABLE_G, metallic_weight, e); l.t = cspec0; bsdf_add(b, l); }
+      float cc = tex_eval_f(sc, s[7], si);
+      if (cc > 0.0f) { Lobe l = lobe_zero(LB_DISNEY_CLEARCOAT); l.ax = cc; l.ay = lerpf(tex_eval_f(sc, s[9], si), 0.1f, 0.001f); bsdf_add(b, l); }
+      if (strans > 0.0f) {
+        rgb3 t = strans * sqrt3(c);
+        if (thin) {
+          float rscaled = (0.65f * e - 0.35f) * rough;
+          bsdf_add(b, mk_micro_t(t, fmaxf(0.001f, (rscaled * rscaled) / aspect), fmaxf(0.001f, (rscaled * rscaled) * aspect), 1.0f, e));
+        } else { Lobe l = mk_micro_t(t, ax, ay, 1.0f, e); l.fr_kind |= FR_SEPARABLE_G; bsdf_add(b, l); }
+      }
+      if (thin) bsdf_add(b, mk_lambert(LB_LAMBERT_T, dt * c));
+      eta = 1.0f;  // Bsdf::new(si, 1.0, ..), :212
+      break;
+    }
     default: break;
   }
   return eta;

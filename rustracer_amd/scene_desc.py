@@ -18,7 +18,7 @@ import numpy as np
 # --- enums shared (by value) with include/rtx_hip.h and oracle/ -------------------------------
 TEX_CONST, TEX_SCALE, TEX_MIX, TEX_IMAGE, TEX_CHECKER, TEX_UV, TEX_FBM = 0, 1, 2, 3, 4, 5, 6
 (MAT_MATTE, MAT_PLASTIC, MAT_METAL, MAT_MIRROR, MAT_GLASS, MAT_UBER, MAT_SUBSTRATE, MAT_MIX,
- MAT_TRANSLUCENT) = range(9)
+ MAT_TRANSLUCENT, MAT_DISNEY) = range(10)
 LIGHT_DIFFUSE_AREA, LIGHT_POINT, LIGHT_DISTANT, LIGHT_INFINITE = 0, 1, 2, 3
 FILTER_BOX, FILTER_TRIANGLE, FILTER_GAUSSIAN, FILTER_MITCHELL = 0, 1, 2, 3
 WRAP_REPEAT, WRAP_BLACK, WRAP_CLAMP = 0, 1, 2
@@ -228,6 +228,15 @@ class SceneDesc:
     def translucent(self, kd=0.25, ks=0.25, reflect=0.5, transmit=0.5, roughness=0.1, remap=True) -> int:  # translucent.rs:28-34
         self.materials.append(Material(MAT_TRANSLUCENT, {"kd": self._t(_f(kd)), "ks": self._t(_f(ks)), "reflect": self._t(_f(reflect)),
                                                           "transmit": self._t(_f(transmit)), "roughness": self._t(float(roughness))}, remap))
+        return len(self.materials) - 1
+
+    def disney(self, color=0.5, metallic=0.0, eta=1.5, roughness=0.5, speculartint=0.0, anisotropic=0.0, sheen=0.0, sheentint=0.5,
+               clearcoat=0.0, clearcoatgloss=1.0, spectrans=0.0, scatterdistance=0.0, thin=False, flatness=0.0, difftrans=1.0) -> int:  # disney.rs:43-80
+        t = lambda v: self._t(_f(v))
+        self.materials.append(Material(MAT_DISNEY, {"kd": t(color), "ks": t(metallic),
+                                                    "eta": t(eta), "roughness": t(roughness), "kr": t(speculartint), "urough": t(anisotropic), "kt": t(sheen),
+                                                    "sigma": t(sheentint), "vrough": t(clearcoat), "k": t(clearcoatgloss), "opacity": t(spectrans),
+                                                    "reflect": t(scatterdistance), "transmit": t(flatness), "amount": t(difftrans), "m1": 1 if thin else 0}))
         return len(self.materials) - 1
 
     def set_bump(self, material: int, tex) -> int:

@@ -40,6 +40,13 @@ def _zoo(material: str, light: str = "area", res=(40, 32), spp=8, max_depth=5):
         "mirror_bump_checker": lambda: s.set_bump(s.mirror(0.9), s.checker_tex(0.0, 0.01, 8, 8)),
         "mix_bump_both": lambda: s.mix(s.set_bump(s.matte((0.7, 0.2, 0.2)), s.scale_tex(s.fbm_tex(0.5, 4), s.const_tex(0.03))),
                                        s.set_bump(s.metal(roughness=0.1), s.scale_tex(s.uv_tex(9, 9), s.const_tex(0.02))), 0.4),
+        "disney_default": lambda: s.disney((0.6, 0.3, 0.2)),
+        "disney_metal_aniso_clearcoat": lambda: s.disney((0.8, 0.6, 0.2), metallic=0.9, roughness=0.3, anisotropic=0.7, speculartint=0.5, clearcoat=0.8, clearcoatgloss=0.7),
+        "disney_sheen_textured": lambda: s.disney(t_img, roughness=0.6, sheen=1.0, sheentint=0.8, metallic=0.1),
+        "disney_spectrans": lambda: s.disney((0.7, 0.8, 0.9), spectrans=0.8, roughness=0.15, eta=1.4),
+        "disney_thin": lambda: s.disney((0.5, 0.7, 0.4), thin=True, flatness=0.4, difftrans=1.2, spectrans=0.3, roughness=0.4),
+        "disney_scatterdistance": lambda: s.disney((0.6, 0.5, 0.5), scatterdistance=(0.1, 0.1, 0.1), sheen=0.5),
+        "mix_disney_bump": lambda: s.mix(s.set_bump(s.disney((0.3, 0.5, 0.7), clearcoat=1.0), s.scale_tex(s.fbm_tex(0.5, 4), s.const_tex(0.02))), s.glass(), (0.6, 0.6, 0.6)),
         "matte_scale_mix_tex": lambda: s.matte(s.mix_tex(s.scale_tex(t_img, s.const_tex((0.9, 0.8, 0.7))), s.const_tex((0.1, 0.6, 0.2)), s.const_tex(0.3))),
         "plastic": lambda: s.plastic((0.3, 0.1, 0.1), (0.5, 0.5, 0.5), 0.15),
         "plastic_noremap": lambda: s.plastic(t_img, (0.4, 0.4, 0.4), 0.2, remap=False),
@@ -97,7 +104,8 @@ def _check(gpu_host, orc, d):
 
 
 MATERIALS = ["matte", "oren_nayar", "matte_image_ewa", "matte_image_trilinear_clamp", "matte_image_black_wrap", "matte_image_npot", "matte_checker_closedform", "matte_checker_none_nested", "matte_uv", "matte_fbm",
-             "plastic_fbm_checker_roughness", "matte_bump_fbm", "plastic_bump_image", "mirror_bump_checker", "mix_bump_both", "matte_scale_mix_tex", "plastic",
+             "plastic_fbm_checker_roughness", "matte_bump_fbm", "plastic_bump_image", "mirror_bump_checker", "mix_bump_both", "disney_default", "disney_metal_aniso_clearcoat", "disney_sheen_textured", "disney_spectrans",
+             "disney_thin", "disney_scatterdistance", "mix_disney_bump", "matte_scale_mix_tex", "plastic",
              "plastic_noremap", "metal", "metal_aniso", "mirror", "glass", "glass_rough", "uber", "substrate", "translucent", "mix", "mix_nested"]
 
 
