@@ -6,6 +6,8 @@
 #include "../../include/rtx_host.h"
 
 #include <algorithm>
+#include <atomic>
+#include <thread>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -205,16 +207,21 @@ namespace {
 
 // ------------------------------------------------------------------ SAH BVH (rc/bvh/mod.rs:80-358)
 struct Builder {
-  // primitive_info as parallel arrays (BVHPrimitiveInfo, :522-536)
-  std::vector<int32_t> prim; std::vector<Box> pb; std::vector<float> cx, cy, cz;
+  // primitive_info as parallel arrays (BVHPrimitiveInfo, :522-536), owned by the caller; a builder permutes them in place
+  int32_t* prim; Box* pb; float* cx; float* cy; float* cz;
   struct BNode { Box b; int axis, first, count, left, right; };
-  std::vector<BNode> pool; std::vector<int32_t>* ordered; int max_prims;
+  std::vector<BNode> pool; int32_t* ordered; int max_prims;  // ordered: n_tris entries, written at explicit offsets
+  // Subtrees of at most `task_size` primitives are not built by build() but recorded as tasks (placeholder node index
+  // -(task + 2)), so that they can be built concurrently: a subtree owns the index range [start, end) of the primitive arrays
+  // and the slice [obase, obase + end - start) of `ordered` (the right child's leaves come first, :290-299), nothing else.
+  struct Task { size_t start, end, obase; };
+  std::vector<Task>* tasks = nullptr; size_t task_size = 0;
 
   float centroid(size_t i, int dim) const { return dim == 0 ? cx[i] : (dim == 1 ? cy[i] : cz[i]); }
   void swap_info(size_t a, size_t b) { std::swap(prim[a], prim[b]); std::swap(pb[a], pb[b]); std::swap(cx[a], cx[b]); std::swap(cy[a], cy[b]); std::swap(cz[a], cz[b]); }
-  int make_leaf(size_t start, size_t end, const Box& b) {
-    BNode n{b, 0, (int)ordered->size(), (int)(end - start), -1, -1};
-    for (size_t i = start; i < end; ++i) ordered->push_back(prim[i]);
+  int make_leaf(size_t start, size_t end, size_t obase, const Box& b) {
+    BNode n{b, 0, (int)obase, (int)(end - start), -1, -1};
+    for (size_t i = start; i < end; ++i) ordered[obase + (i - start)] = prim[i];
     pool.push_back(n);
     return (int)pool.size() - 1;
   }
@@ -224,15 +231,16 @@ struct Builder {
     int b = (int)f2usz(12.0f * o);
     return b == 12 ? 11 : b;
   }
-  int build(size_t start, size_t end) {
+  int build(size_t start, size_t end, size_t obase) {
     const size_t n = end - start;
+    if (tasks && n <= task_size && n > 1) { tasks->push_back(Task{start, end, obase}); return -(int)tasks->size() - 1; }
     Box bounds = box_empty();
     for (size_t i = start; i < end; ++i) bounds = box_union(bounds, pb[i]);
-    if (n == 1) return make_leaf(start, end, bounds);
+    if (n == 1) return make_leaf(start, end, obase, bounds);
     Box cb = box_empty();
     for (size_t i = start; i < end; ++i) { float c[3] = {cx[i], cy[i], cz[i]}; box_extend(cb, c); }
     const int dim = box_max_extent(cb);
-    if (cb.lo[dim] == cb.hi[dim]) return make_leaf(start, end, bounds);
+    if (cb.lo[dim] == cb.hi[dim]) return make_leaf(start, end, obase, bounds);
     size_t mid;
     if (n <= 2) {
       mid = (start + end) / 2;
@@ -263,11 +271,12 @@ struct Builder {
           split += 1;
         }
         mid = start + split;
-      } else return make_leaf(start, end, bounds);
+      } else return make_leaf(start, end, obase, bounds);
     }
-    int right = build(mid, end);  // right child first (:290-299): its leaves come first in ordered_prims
-    int left = build(start, mid);
-    BNode nd{box_union(pool[left].b, pool[right].b), dim, 0, 0, left, right};
+    int right = build(mid, end, obase);  // right child first (:290-299): its leaves come first in ordered_prims
+    int left = build(start, mid, obase + (end - mid));
+    // BVHBuildNode::interior unions the children's bounds (:64-78), which are the unions of their primitives' boxes: `bounds`
+    BNode nd{bounds, dim, 0, 0, left, right};
     pool.push_back(nd);
     return (int)pool.size() - 1;
   }
@@ -276,8 +285,9 @@ struct Builder {
 int commit_scene(rtxh_scene* s, int max_prims_per_node) {
   const size_t nt = s->n_tris();
   if (nt == 0) return fail(RT_ERR_INVALID, "no triangles");
-  Builder b; b.ordered = &s->ordered; b.max_prims = max_prims_per_node > 255 ? 255 : max_prims_per_node;
-  b.prim.resize(nt); b.pb.resize(nt); b.cx.resize(nt); b.cy.resize(nt); b.cz.resize(nt);
+  Builder b; b.max_prims = max_prims_per_node > 255 ? 255 : max_prims_per_node;
+  std::vector<int32_t> a_prim(nt); std::vector<Box> a_pb(nt); std::vector<float> a_cx(nt), a_cy(nt), a_cz(nt);
+  b.prim = a_prim.data(); b.pb = a_pb.data(); b.cx = a_cx.data(); b.cy = a_cy.data(); b.cz = a_cz.data();
   for (size_t t = 0; t < nt; ++t) {  // Triangle::world_bounds, mesh.rs:603-608
     const float* p0 = &s->P[3 * s->idx[3 * t]]; const float* p1 = &s->P[3 * s->idx[3 * t + 1]]; const float* p2 = &s->P[3 * s->idx[3 * t + 2]];
     Box bb;
@@ -286,8 +296,44 @@ int commit_scene(rtxh_scene* s, int max_prims_per_node) {
     b.prim[t] = (int32_t)t; b.pb[t] = bb;
     b.cx[t] = 0.5f * bb.lo[0] + 0.5f * bb.hi[0]; b.cy[t] = 0.5f * bb.lo[1] + 0.5f * bb.hi[1]; b.cz[t] = 0.5f * bb.lo[2] + 0.5f * bb.hi[2];  // :532
   }
-  s->ordered.clear(); s->ordered.reserve(nt);
-  int root = b.build(0, nt);
+  s->ordered.assign(nt, -1);
+  b.ordered = s->ordered.data();
+  int root;
+  unsigned n_threads = std::thread::hardware_concurrency(); if (n_threads > 16) n_threads = 16; if (n_threads < 1) n_threads = 1;
+  if (nt < 65536 || n_threads == 1) root = b.build(0, nt, 0);
+  else {
+    // top of the tree serially (every level is one partition pass over its range), subtrees of <= nt / (8 threads) primitives concurrently
+    std::vector<Builder::Task> tasks;
+    b.tasks = &tasks; b.task_size = nt / (8 * (size_t)n_threads) + 1;
+    root = b.build(0, nt, 0);
+    b.tasks = nullptr;
+    std::vector<std::vector<Builder::BNode>> pools(tasks.size());
+    std::vector<int> roots(tasks.size(), -1);
+    std::atomic<size_t> next{0};
+    auto run = [&]() {
+      for (;;) {
+        const size_t k = next.fetch_add(1);
+        if (k >= tasks.size()) return;
+        Builder lb = b;  // same arrays, same `ordered`; its own node pool
+        lb.pool.clear(); lb.tasks = nullptr;
+        roots[k] = lb.build(tasks[k].start, tasks[k].end, tasks[k].obase);
+        pools[k].swap(lb.pool);
+      }
+    };
+    std::vector<std::thread> th;
+    for (unsigned t = 1; t < n_threads; ++t) th.emplace_back(run);
+    run();
+    for (auto& x : th) x.join();
+    std::vector<int> task_root(tasks.size());
+    for (size_t k = 0; k < tasks.size(); ++k) {
+      const int off = (int)b.pool.size();
+      for (Builder::BNode nd : pools[k]) { if (nd.count == 0) { nd.left += off; nd.right += off; } b.pool.push_back(nd); }
+      task_root[k] = off + roots[k];
+    }
+    auto fix = [&](int& c) { if (c < -1) c = task_root[(size_t)(-c - 2)]; };
+    for (auto& nd : b.pool) if (nd.count == 0) { fix(nd.left); fix(nd.right); }
+    if (root < -1) root = task_root[(size_t)(-root - 2)];
+  }
   // flatten_bvh (:314-358): pre-order, left child adjacent, second child offset patched afterwards
   s->nodes.clear(); s->nodes.reserve(b.pool.size());
   struct Item { int node; int parent_flat; };
