@@ -61,6 +61,13 @@ int rtxh_scene_bvh_get(rtxh_scene*, float* bounds6, uint32_t* offset, uint16_t* 
 int rtxh_camera_film_setup(const rtxh_render_params*, float* raster_to_camera16, float* dxdy6, float* filter_table256, int32_t* sample_bounds4,
                            int32_t* cropped4);
 int rtxh_mip_level(rtxh_scene*, int32_t mip, int32_t level, int32_t* w, int32_t* h, float* rgb_out /* may be NULL */);
+/* Copies of the unflattened tables (tests compare a parsed .pbrt scene with the same scene built call by call).
+ * out == NULL: only *n_items. Items: rt_texture, rt_material, rtxh_light_info, float[3] (P N S), float[2] (UV),
+ * int32[3] (indices), int32 (tri material / light), uint8 (tri flags). */
+enum { RTXH_TABLE_TEXTURES = 0, RTXH_TABLE_MATERIALS, RTXH_TABLE_LIGHTS, RTXH_TABLE_P, RTXH_TABLE_N, RTXH_TABLE_UV, RTXH_TABLE_S, RTXH_TABLE_INDICES,
+       RTXH_TABLE_TRI_MATERIAL, RTXH_TABLE_TRI_LIGHT, RTXH_TABLE_TRI_FLAGS };
+typedef struct rtxh_light_info { int32_t kind, tri; float rgb[3]; int32_t two_sided; float vec[3]; int32_t mip; float l2w[12], w2l[12]; } rtxh_light_info;
+int rtxh_scene_inspect(rtxh_scene*, int32_t table, void* out, uint64_t capacity_bytes, uint64_t* n_items);
 int rtxh_look_at(const float* pos, const float* look, const float* up, float* m16, float* m_inv16);
 
 /* renderer::render through the HIP backend. film_xyzw: (y1-y0)*(x1-x0)*4 floats over the cropped pixel bounds
@@ -94,6 +101,32 @@ void rtxh_ply_free(rtxh_ply* ply);
  * the top of the image. rgb: width*height*3 floats owned by the library until rtxh_free. */
 int rtxh_pfm_read(const char* path, int32_t* width, int32_t* height, float** rgb);
 void rtxh_free(void* p);
+
+/* ---- pbrt-v3 scene description ----------------------------------------------------------
+ * What `rustracer scene.pbrt` does before renderer::render: tokenise + parse (rc/pbrt/lexer.rs:185-275,
+ * rc/pbrt/parser.rs:20-320), run the directive state machine of RealApi (rc/api.rs:516-1010: CTM, named coordinate
+ * systems, attribute / transform stacks, GraphicsState with named textures and materials, RenderOptions) and build
+ * camera, film, filter, sampler, integrator, shapes, materials, textures and lights from their parameter lists
+ * (RenderOptions::make_* rc/api.rs:179-256, make_shapes / make_material / make_*_texture rc/api.rs:1093-1259,
+ * TextureParams rc/paramset.rs:356-470, and each module's create()). The result is a committed rtxh_scene (BVH
+ * built with the file's Accelerator parameters) plus the rtxh_render_params rtxh_render takes.
+ * Errors like the reference's (unknown Film / Filter / Sampler / Camera, options inside the world block, ...) and
+ * every directive or class this backend does not implement (non-triangle shapes, object instancing, integrators
+ * other than "path", spectral parameter types, alpha masks) fail with a message; nothing is skipped silently.
+ * n_warnings counts the conditions the reference only logs (missing named texture, unknown material -> matte, ...). */
+typedef struct rtxh_pbrt_result {
+  rtxh_scene* scene;            /* owned by the caller: rtxh_scene_free */
+  rtxh_render_params params;
+  int32_t max_prims_per_node;   /* Accelerator "integer maxnodeprims" (bvh/mod.rs:76), already applied */
+  int32_t n_warnings;
+  char film_filename[512];      /* Film::create naming: "rt-" + filename, or "image.png" (film.rs:118-123) */
+} rtxh_pbrt_result;
+int rtxh_pbrt_load(const char* path, rtxh_pbrt_result* out);
+/* Same from memory; relative file names (Include, plymesh, imagemap, mapname) resolve against base_dir. */
+int rtxh_pbrt_parse(const char* text, const char* base_dir, rtxh_pbrt_result* out);
+/* The lexer alone (rc/pbrt/lexer.rs:185-275; comments dropped as in rc/pbrt/mod.rs:39-43): one token per line,
+ * "K <word>", "N <number %.9g>", "S <string>", "[" or "]". Returns the token count or < 0. */
+int rtxh_pbrt_tokens(const char* text, char* out, uint64_t capacity);
 
 #ifdef __cplusplus
 }

@@ -91,7 +91,8 @@ def render_params(desc, mode: int, n_threads: int = 0) -> RenderParams:
     p.filter_params[:] = [float(x) for x in f.filter_params]
     p.film_scale = f.scale
     p.max_sample_luminance = f.max_sample_luminance
-    w2c, c2w = look_at(c.pos, c.look, c.up)  # CTM = LookAt; camera_to_world = CTM.inverse() (api.rs camera())
+    w2c, c2w = look_at(c.pos, c.look, c.up)  # CTM = identity * LookAt (api.rs:637); camera_to_world = CTM.inverse() (:726)
+    w2c, c2w = w2c + np.float32(0.0), c2w + np.float32(0.0)  # the product with the identity CTM turns a -0 entry into +0
     p.cam_to_world[:] = c2w.reshape(-1).tolist()
     p.cam_to_world_inv[:] = w2c.reshape(-1).tolist()
     p.fov, p.lens_radius, p.focal_distance = c.fov, c.lens_radius, c.focal_distance

@@ -6,6 +6,9 @@
 #include "../../include/rtx_host.h"
 
 #include <algorithm>
+#include <array>
+#include <initializer_list>
+#include <map>
 #include <atomic>
 #include <thread>
 #include <cmath>
@@ -665,6 +668,38 @@ int rtxh_mip_level(rtxh_scene* s, int32_t mip, int32_t level, int32_t* w, int32_
   return (int)m.w.size();
 }
 // Transform::look_at (transform.rs:119-154): m = world->camera, m_inv = camera->world
+int rtxh_scene_inspect(rtxh_scene* s, int32_t table, void* out, uint64_t capacity_bytes, uint64_t* n_items) {
+  if (!s || !n_items) return fail(RT_ERR_INVALID, "null argument");
+  const void* src = nullptr; size_t item = 0, n = 0;
+  std::vector<rtxh_light_info> li;
+  switch (table) {
+    case RTXH_TABLE_TEXTURES: src = s->textures.data(); item = sizeof(rt_texture); n = s->textures.size(); break;
+    case RTXH_TABLE_MATERIALS: src = s->materials.data(); item = sizeof(rt_material); n = s->materials.size(); break;
+    case RTXH_TABLE_LIGHTS:
+      for (const HostLight& h : s->lights) {
+        rtxh_light_info i; memset(&i, 0, sizeof i);
+        i.kind = h.l.kind; i.tri = h.tri_source; memcpy(i.rgb, h.l.rgb, 12); i.two_sided = h.l.two_sided; memcpy(i.vec, h.l.vec, 12); i.mip = h.l.image;
+        memcpy(i.l2w, h.l.l2w, 48); memcpy(i.w2l, h.l.w2l, 48);
+        li.push_back(i);
+      }
+      src = li.data(); item = sizeof(rtxh_light_info); n = li.size(); break;
+    case RTXH_TABLE_P: src = s->P.data(); item = 12; n = s->P.size() / 3; break;
+    case RTXH_TABLE_N: src = s->N.data(); item = 12; n = s->N.size() / 3; break;
+    case RTXH_TABLE_UV: src = s->UV.data(); item = 8; n = s->UV.size() / 2; break;
+    case RTXH_TABLE_S: src = s->S.data(); item = 12; n = s->S.size() / 3; break;
+    case RTXH_TABLE_INDICES: src = s->idx.data(); item = 12; n = s->idx.size() / 3; break;
+    case RTXH_TABLE_TRI_MATERIAL: src = s->tri_mat.data(); item = 4; n = s->tri_mat.size(); break;
+    case RTXH_TABLE_TRI_LIGHT: src = s->tri_light.data(); item = 4; n = s->tri_light.size(); break;
+    case RTXH_TABLE_TRI_FLAGS: src = s->tri_flags.data(); item = 1; n = s->tri_flags.size(); break;
+    default: return fail(RT_ERR_INVALID, "unknown table");
+  }
+  *n_items = n;
+  if (out) {
+    if (capacity_bytes < n * item) return fail(RT_ERR_INVALID, "buffer too small");
+    if (n) memcpy(out, src, n * item);
+  }
+  return RT_OK;
+}
 int rtxh_look_at(const float* pos, const float* look, const float* up, float* m16, float* minv16) {
   auto norm = [](float v[3]) { float l = std::sqrt(v[0] * v[0] + v[1] * v[1] + v[2] * v[2]); v[0] /= l; v[1] /= l; v[2] /= l; };
   auto cross = [](const float a[3], const float b[3], float o[3]) { o[0] = (a[1] * b[2]) - (a[2] * b[1]); o[1] = (a[2] * b[0]) - (a[0] * b[2]); o[2] = (a[0] * b[1]) - (a[1] * b[0]); };
@@ -885,3 +920,6 @@ int rtxh_pfm_read(const char* path, int32_t* width, int32_t* height, float** rgb
   return RT_OK;
 }
 }  // extern "C"
+
+// pbrt-v3 scene files -> rtxh_scene + rtxh_render_params
+#include "rtx_pbrt.inl"

@@ -121,7 +121,8 @@ def render_params(desc, rank=0, world_size=1, flags=0) -> RenderParams:
     p.filter_params[:] = [float(x) for x in f.filter_params]
     p.film_scale = f.scale
     p.max_sample_luminance = f.max_sample_luminance
-    w2c, c2w = look_at(c.pos, c.look, c.up)  # CTM = LookAt; camera_to_world = CTM.inverse()
+    w2c, c2w = look_at(c.pos, c.look, c.up)  # CTM = identity * LookAt (api.rs:637); camera_to_world = CTM.inverse() (:726)
+    w2c, c2w = w2c + np.float32(0.0), c2w + np.float32(0.0)  # the product with the identity CTM turns a -0 entry into +0
     p.cam_to_world[:] = c2w.reshape(-1).tolist()
     p.cam_to_world_inv[:] = w2c.reshape(-1).tolist()
     p.fov, p.lens_radius, p.focal_distance = c.fov, c.lens_radius, c.focal_distance
@@ -175,8 +176,17 @@ class HostScene:
         L.rtxh_scene_bvh_get(self.h, _p(bounds), _p(offset, C.c_uint32), _p(nprims, C.c_uint16), _p(axis, C.c_uint8), _p(ordered, C.c_int32))
         return dict(bounds=bounds, offset=offset, n_prims=nprims, axis=axis, ordered=ordered)
 
+    def _render_params(self, **kw):
+        return render_params(self.desc, **kw)
+
+    def n_lights(self):
+        return len(self.desc.lights)
+
+    def table(self, name):
+        return scene_table(self.h, name)
+
     def setup(self, **kw):
-        p = render_params(self.desc, **kw)
+        p = self._render_params(**kw)
         r2c = np.zeros((4, 4), np.float32)
         dxdy = np.zeros(6, np.float32)
         table = np.zeros(256, np.float32)
@@ -246,12 +256,78 @@ class HostScene:
         total = int(nv[0]) * int(nv[1]) * int(nv[2])
         if total == 0:
             return dict(n_voxels=nv)
-        nl = len(self.desc.lights)
+        nl = self.n_lights()
         func = np.zeros((total, nl), np.float32)
         cdf = np.zeros((total, nl + 1), np.float32)
         fint = np.zeros(total, np.float32)
         _check(lib().rtxh_light_distribution(self.h, _p(nv, C.c_int32), _p(func), _p(cdf), _p(fint)), "light_distribution")
         return dict(n_voxels=nv, func=func, cdf=cdf, func_int=fint)
+
+
+class PbrtResult(C.Structure):
+    _fields_ = [("scene", C.c_void_p), ("params", RenderParams), ("max_prims_per_node", C.c_int32), ("n_warnings", C.c_int32),
+                ("film_filename", C.c_char * 512)]
+
+
+_TEXTURE_DT = np.dtype([("kind", "<i4"), ("value", "<f4", 3), ("tex1", "<i4"), ("tex2", "<i4"), ("amount", "<i4"), ("image", "<i4"), ("mapping", "<f4", 4)])
+_MATERIAL_DT = np.dtype([("kind", "<i4"), ("slot", "<i4", 16), ("remap_roughness", "<i4"), ("bump", "<i4")])
+_LIGHT_DT = np.dtype([("kind", "<i4"), ("tri", "<i4"), ("rgb", "<f4", 3), ("two_sided", "<i4"), ("vec", "<f4", 3), ("mip", "<i4"), ("l2w", "<f4", 12), ("w2l", "<f4", 12)])
+_TABLES = {"textures": (0, _TEXTURE_DT), "materials": (1, _MATERIAL_DT), "lights": (2, _LIGHT_DT), "P": (3, np.dtype(("<f4", 3))), "N": (4, np.dtype(("<f4", 3))),
+           "UV": (5, np.dtype(("<f4", 2))), "S": (6, np.dtype(("<f4", 3))), "indices": (7, np.dtype(("<i4", 3))), "tri_material": (8, np.dtype("<i4")),
+           "tri_light": (9, np.dtype("<i4")), "tri_flags": (10, np.dtype("u1"))}
+
+
+def scene_table(handle, name):
+    """Copy of one unflattened table of an rtxh_scene (rtxh_scene_inspect)."""
+    which, dt = _TABLES[name]
+    n = C.c_uint64()
+    _check(lib().rtxh_scene_inspect(handle, which, None, C.c_uint64(0), C.byref(n)), "scene_inspect")
+    out = np.zeros(n.value, dt)
+    if n.value:
+        _check(lib().rtxh_scene_inspect(handle, which, out.ctypes.data_as(C.c_void_p), C.c_uint64(out.nbytes), C.byref(n)), "scene_inspect")
+    return out
+
+
+class PbrtScene(HostScene):
+    """A scene read from a pbrt-v3 file by the C++ host (rtxh_pbrt_load): what `rustracer scene.pbrt` builds up to
+    `renderer::render` (rc/pbrt/mod.rs:16-27, rc/api.rs:977-1010). Same methods as HostScene."""
+
+    def __init__(self, path=None, text=None, base_dir=""):
+        L = lib()
+        res = PbrtResult()
+        if path is not None:
+            _check(L.rtxh_pbrt_load(os.fsencode(path), C.byref(res)), "pbrt_load")
+        else:
+            _check(L.rtxh_pbrt_parse(text.encode(), os.fsencode(base_dir), C.byref(res)), "pbrt_parse")
+        self.h = C.c_void_p(res.scene)
+        self.desc = None
+        self.params = RenderParams.from_buffer_copy(res.params)
+        self.max_prims_per_node = res.max_prims_per_node
+        self.n_warnings = res.n_warnings
+        self.film_filename = res.film_filename.decode()
+
+    def _render_params(self, rank=0, world_size=1, flags=0):
+        p = RenderParams.from_buffer_copy(self.params)
+        p.rank, p.world_size, p.flags = rank, world_size, flags
+        return p
+
+    def n_lights(self):
+        return len(scene_table(self.h, "lights"))
+
+
+def pbrt_tokens(text: str):
+    """The host lexer's token list: [("K", word) | ("N", float) | ("S", string) | ("[", None) | ("]", None)]."""
+    buf = C.create_string_buffer(16 * len(text) + 64)
+    n = _check(lib().rtxh_pbrt_tokens(text.encode(), buf, C.c_uint64(len(buf))), "pbrt_tokens")
+    out = []
+    for line in buf.value.decode().split("\n")[:n]:
+        if line in ("[", "]"):
+            out.append((line, None))
+        elif line[0] == "N":
+            out.append(("N", float(line[2:])))
+        else:
+            out.append((line[0], line[2:]))
+    return out
 
 
 def sampler_tables(spp, dims, pixel0, n_pixels, plain=False):

@@ -1,0 +1,214 @@
+"""Write a SceneDesc as a pbrt-v3 scene file (+ PFM images) that rustracer - and this repository's C++ host
+(`rtxh_pbrt_load`, include/rtx_host.h) - reads back to the same scene.
+
+A caller-side tool: the scenes of `rustracer_amd.scenes` become files the reference's
+`rustracer-cli scene.pbrt` can render, and the parser tests use it for a full round trip
+(SceneDesc -> .pbrt -> C++ parser -> same tables, same BVH, same render parameters).
+
+Numbers are written with 9 significant digits, which identifies every float32 exactly.
+"""
+from __future__ import annotations
+
+import os
+
+import numpy as np
+
+from . import scene_desc as sd
+from .ingest import write_pfm
+
+_FILTER_NAMES = {sd.FILTER_BOX: "box", sd.FILTER_TRIANGLE: "triangle", sd.FILTER_GAUSSIAN: "gaussian", sd.FILTER_MITCHELL: "mitchell"}
+_WRAP_NAMES = {sd.WRAP_REPEAT: "repeat", sd.WRAP_BLACK: "black", sd.WRAP_CLAMP: "clamp"}
+_MAT_NAMES = {sd.MAT_MATTE: "matte", sd.MAT_PLASTIC: "plastic", sd.MAT_METAL: "metal", sd.MAT_MIRROR: "mirror", sd.MAT_GLASS: "glass", sd.MAT_UBER: "uber",
+              sd.MAT_SUBSTRATE: "substrate", sd.MAT_MIX: "mix", sd.MAT_TRANSLUCENT: "translucent", sd.MAT_DISNEY: "disney"}
+# material kind -> {slot: (pbrt parameter, "spectrum" | "float")}   (the create() of each rc/material/*.rs)
+_S, _F = "spectrum", "float"
+_SLOTS = {
+    sd.MAT_MATTE: {"kd": ("Kd", _S), "sigma": ("sigma", _F)},
+    sd.MAT_PLASTIC: {"kd": ("Kd", _S), "ks": ("Ks", _S), "roughness": ("roughness", _F)},
+    sd.MAT_METAL: {"eta": ("eta", _S), "k": ("k", _S), "roughness": ("roughness", _F), "urough": ("uroughness", _F), "vrough": ("vroughness", _F)},
+    sd.MAT_MIRROR: {"kr": ("Kr", _S)},
+    sd.MAT_GLASS: {"kr": ("Kr", _S), "kt": ("Kt", _S), "eta": ("index", _F), "urough": ("uroughness", _F), "vrough": ("vroughness", _F)},
+    sd.MAT_UBER: {"kd": ("Kd", _S), "ks": ("Ks", _S), "kr": ("Kr", _S), "kt": ("Kt", _S), "roughness": ("roughness", _F), "urough": ("uroughness", _F),
+                  "vrough": ("vroughness", _F), "eta": ("index", _F), "opacity": ("opacity", _S)},
+    sd.MAT_SUBSTRATE: {"kd": ("Kd", _S), "ks": ("Ks", _S), "urough": ("uroughness", _F), "vrough": ("vroughness", _F)},
+    sd.MAT_TRANSLUCENT: {"kd": ("Kd", _S), "ks": ("Ks", _S), "reflect": ("reflect", _S), "transmit": ("transmit", _S), "roughness": ("roughness", _F)},
+    sd.MAT_DISNEY: {"kd": ("color", _S), "ks": ("metallic", _F), "eta": ("eta", _F), "roughness": ("roughness", _F), "kr": ("speculartint", _F),
+                    "urough": ("anisotropic", _F), "kt": ("sheen", _F), "sigma": ("sheentint", _F), "vrough": ("clearcoat", _F), "k": ("clearcoatgloss", _F),
+                    "opacity": ("spectrans", _F), "reflect": ("scatterdistance", _S), "transmit": ("flatness", _F), "amount": ("difftrans", _F)},
+    sd.MAT_MIX: {"amount": ("amount", _S)},
+}
+
+
+def _n(x) -> str:
+    x = float(np.float32(x))
+    if x == float("inf"):
+        raise ValueError("infinite values have no pbrt spelling")
+    return "%.9g" % x
+
+
+def _nums(a) -> str:
+    return " ".join(_n(x) for x in np.asarray(a, np.float32).reshape(-1))
+
+
+class _Writer:
+    def __init__(self, desc: sd.SceneDesc, path: str):
+        self.d = desc
+        self.dir = os.path.dirname(os.path.abspath(path))
+        self.stem = os.path.splitext(os.path.basename(path))[0]
+        self.out = []
+        self.tex_names = {}   # (texture id, type) -> name
+        self.mat_names = {}
+        self.image_files = {}
+
+    # ---- textures -----------------------------------------------------------------------------------------------
+    def image_file(self, mip: int, flip: bool, grey: bool) -> str:
+        key = (mip, flip, grey)
+        if key not in self.image_files:
+            name = f"{self.stem}_img{mip}{'f' if flip else ''}{'g' if grey else ''}.pfm"
+            data = self.d.mipmaps[mip].data
+            if flip:
+                data = data[::-1]  # ImageTexture::new flips what it reads (imagemap.rs:52-60)
+            write_pfm(os.path.join(self.dir, name), data[..., 0] if grey else data)
+            self.image_files[key] = name
+        return self.image_files[key]
+
+    def param(self, pname: str, tex: int, typ: str) -> str:
+        """`"type name" value` for texture id `tex` used as a parameter of type typ."""
+        t = self.d.textures[tex]
+        if t.kind == sd.TEX_CONST:
+            return f'"float {pname}" [{_n(t.value[0])}]' if typ == _F else f'"rgb {pname}" [{_nums(t.value)}]'
+        return f'"texture {pname}" "{self.texture(tex, typ)}"'
+
+    def texture(self, tex: int, typ: str) -> str:
+        key = (tex, typ)
+        if key in self.tex_names:
+            return self.tex_names[key]
+        t = self.d.textures[tex]
+        name = f"t{tex}{'f' if typ == _F else 's'}"
+        mapping = f'"float uscale" [{_n(t.mapping[0])}] "float vscale" [{_n(t.mapping[1])}] "float udelta" [{_n(t.mapping[2])}] "float vdelta" [{_n(t.mapping[3])}]'
+        if t.kind == sd.TEX_CONST:
+            body = f'"constant" ' + (f'"float value" [{_n(t.value[0])}]' if typ == _F else f'"rgb value" [{_nums(t.value)}]')
+        elif t.kind == sd.TEX_SCALE:
+            body = f'"scale" {self.param("tex1", t.tex1, typ)} {self.param("tex2", t.tex2, typ)}'
+        elif t.kind == sd.TEX_MIX:
+            body = f'"mix" {self.param("tex1", t.tex1, typ)} {self.param("tex2", t.tex2, typ)} {self.param("amount", t.amount, _F)}'
+        elif t.kind == sd.TEX_IMAGE:
+            m = self.d.mipmaps[t.mip]
+            body = (f'"imagemap" "string filename" "{self.image_file(t.mip, True, typ == _F)}" "bool gamma" "false" "bool trilinear" "{"true" if m.trilinear else "false"}" '
+                    f'"float maxanisotropy" [{_n(m.max_aniso)}] "string wrap" "{_WRAP_NAMES[m.wrap]}" {mapping}')
+        elif t.kind == sd.TEX_CHECKER:
+            if typ == _F:
+                raise ValueError("the reference has no float checkerboard (api.rs:1201-1216)")
+            body = f'"checkerboard" {self.param("tex1", t.tex1, _S)} {self.param("tex2", t.tex2, _S)} "string aamode" "{"none" if t.amount == 0 else "closedform"}" {mapping}'
+        elif t.kind == sd.TEX_UV:
+            if typ == _F:
+                raise ValueError("the reference has no float uv texture")
+            body = f'"uv" {mapping}'
+        elif t.kind == sd.TEX_FBM:
+            body = f'"fbm" "float omega" [{_n(t.value[0])}] "integer octaves" [{int(t.amount)}]'
+        else:
+            raise ValueError(f"texture kind {t.kind}")
+        self.out.append(f'Texture "{name}" "{"float" if typ == _F else "spectrum"}" {body}')
+        self.tex_names[key] = name
+        return name
+
+    # ---- materials ----------------------------------------------------------------------------------------------
+    def material(self, mid: int) -> str:
+        if mid in self.mat_names:
+            return self.mat_names[mid]
+        m = self.d.materials[mid]
+        parts = [f'"string type" "{_MAT_NAMES[m.kind]}"']
+        for slot, (pname, typ) in _SLOTS[m.kind].items():
+            if slot in m.params and m.params[slot] >= 0:
+                parts.append(self.param(pname, m.params[slot], typ))
+        if m.kind == sd.MAT_MIX:
+            parts.append(f'"string namedmaterial1" "{self.material(m.params["m1"])}" "string namedmaterial2" "{self.material(m.params["m2"])}"')
+        else:
+            if m.kind == sd.MAT_DISNEY:
+                parts.append(f'"bool thin" "{"true" if m.params.get("m1", 0) else "false"}"')
+            else:
+                parts.append(f'"bool remaproughness" "{"true" if m.remap_roughness else "false"}"')
+            if m.bump >= 0:
+                parts.append(self.param("bumpmap", m.bump, _F))
+        name = f"m{mid}"
+        self.out.append(f'MakeNamedMaterial "{name}" ' + " ".join(parts))
+        self.mat_names[mid] = name
+        return name
+
+    # ---- lights ---------------------------------------------------------------------------------------------------
+    def light(self, l: sd.Light):
+        if l.kind == sd.LIGHT_POINT:
+            self.out.append(f'LightSource "point" "rgb I" [{_nums(l.rgb)}] "point from" [{_nums(l.vec)}]')
+        elif l.kind == sd.LIGHT_DISTANT:
+            self.out.append(f'LightSource "distant" "rgb L" [{_nums(l.rgb)}] "point from" [{_nums(l.vec)}] "point to" [0 0 0]')
+        elif l.kind == sd.LIGHT_INFINITE:
+            l2w = np.eye(4, dtype=np.float32) if l.l2w is None else np.asarray(l.l2w, np.float32)
+            self.out.append("AttributeBegin")
+            self.out.append(f"  Transform [{_nums(l2w.T)}]")  # column-major in the file (api.rs:596-600)
+            self.out.append(f'  LightSource "infinite" "string mapname" "{self.image_file(l.mip, False, False)}"')
+            self.out.append("AttributeEnd")
+        else:
+            raise ValueError("area lights are written with their shape")
+
+    def write(self):
+        d, o = self.d, self.out
+        c, f, s, it = d.camera, d.film, d.sampler, d.integrator
+        o.append(f"LookAt {_nums(c.pos)}  {_nums(c.look)}  {_nums(c.up)}")
+        o.append(f'Camera "perspective" "float fov" [{_n(c.fov)}] "float lensradius" [{_n(c.lens_radius)}] "float focaldistance" [{_n(c.focal_distance)}]')
+        film = f'Film "image" "integer xresolution" [{f.xres}] "integer yresolution" [{f.yres}] "float cropwindow" [{_nums(f.crop)}] "float scale" [{_n(f.scale)}] "string filename" "{d.name}.png"'
+        if np.isfinite(f.max_sample_luminance):
+            film += f' "float maxsampleluminance" [{_n(f.max_sample_luminance)}]'
+        o.append(film)
+        fp = f.filter_params
+        extra = {sd.FILTER_BOX: "", sd.FILTER_TRIANGLE: "", sd.FILTER_GAUSSIAN: f' "float alpha" [{_n(fp[2])}]', sd.FILTER_MITCHELL: f' "float B" [{_n(fp[2])}] "float C" [{_n(fp[3])}]'}[f.filter_kind]
+        o.append(f'PixelFilter "{_FILTER_NAMES[f.filter_kind]}" "float xwidth" [{_n(fp[0])}] "float ywidth" [{_n(fp[1])}]{extra}')
+        o.append(f'Sampler "02sequence" "integer pixelsamples" [{s.spp}] "integer dimensions" [{s.dims}]')
+        integ = f'Integrator "path" "integer maxdepth" [{it.max_depth}] "float rrthreshold" [{_n(it.rr_threshold)}] "string lightsamplestrategy" "{it.light_strategy}"'
+        if it.pixel_bounds is not None:
+            integ += f' "integer pixelbounds" [{" ".join(str(int(x)) for x in it.pixel_bounds)}]'
+        o.append(integ)
+        o.append(f'Accelerator "bvh" "integer maxnodeprims" [{d.max_prims_per_node}]')
+        o.append("WorldBegin")
+        other = [(i, l) for i, l in enumerate(d.lights) if l.kind != sd.LIGHT_DIFFUSE_AREA]
+        nv0 = 0
+        for m in range(len(d._idx)):
+            lights = d._light[m]
+            first = int(lights[0]) if lights.size and lights[0] >= 0 else None
+            while other and first is not None and other[0][0] < first:
+                self.light(other.pop(0)[1])
+            mats = np.unique(d._mat[m])
+            assert mats.size == 1
+            flags = int(d._flags[m][0])
+            name = self.material(int(mats[0]))
+            o.append("AttributeBegin")
+            o.append(f'  NamedMaterial "{name}"')
+            if flags & sd.TRI_FLIP:
+                o.append("  ReverseOrientation")
+            if first is not None:
+                l0 = d.lights[first]
+                assert all(tuple(d.lights[int(i)].rgb) == tuple(l0.rgb) for i in lights)
+                o.append(f'  AreaLightSource "diffuse" "rgb L" [{_nums(l0.rgb)}] "bool twosided" "{"true" if l0.two_sided else "false"}"')
+            nv = d._P[m].shape[0]
+            shape = f'  Shape "trianglemesh" "integer indices" [{" ".join(str(int(x)) for x in (d._idx[m] - nv0).reshape(-1))}] "point P" [{_nums(d._P[m])}]'
+            if flags & sd.TRI_HAS_N:
+                shape += f' "normal N" [{_nums(d._N[m])}]'
+            if flags & sd.TRI_HAS_UV:
+                shape += f' "float uv" [{_nums(d._UV[m])}]'
+            if flags & sd.TRI_HAS_S:
+                shape += f' "vector S" [{_nums(d._S[m])}]'
+            o.append(shape)
+            o.append("AttributeEnd")
+            nv0 += nv
+        for _, l in other:
+            self.light(l)
+        o.append("WorldEnd")
+        return "\n".join(o) + "\n"
+
+
+def write_pbrt(desc: sd.SceneDesc, path: str) -> str:
+    """Writes `path` (and the PFM images it names, next to it); returns the scene text."""
+    w = _Writer(desc, path)
+    text = w.write()
+    with open(path, "w") as fh:
+        fh.write(text)
+    return text

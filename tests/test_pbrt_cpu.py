@@ -1,0 +1,429 @@
+"""pbrt-v3 scene files through the C++ host (`rtxh_pbrt_load`) - CPU only.
+
+Two kinds of checks:
+  * round trips: a SceneDesc written by `rustracer_amd.pbrt_export` and read back by the C++ parser must give the same
+    triangle soup, BVH, render parameters, lights and (resolved) material / texture trees as the same SceneDesc handed to
+    the host call by call (`HostScene`), for the benchmark scenes and the whole material / texture / light zoo;
+  * directive semantics on hand-written files: the lexer's known answers (rc/pbrt/lexer.rs:277-337), CTM composition
+    order, attribute / transform stacks, named coordinate systems, Include, named materials, parameter defaults of every
+    create(), and the reference's error cases (rc/api.rs:179-256, 418-470).
+"""
+import os
+
+import numpy as np
+import pytest
+
+from rustracer_amd import host, scene_desc as sd
+from rustracer_amd.pbrt_export import write_pbrt
+
+F32 = np.float32
+
+
+# ------------------------------------------------------------------------------------------------ comparison helpers
+class _Cmp:
+    """Walks the material / texture tables of two host scenes side by side."""
+
+    def __init__(self, a, b):
+        self.a, self.b = a, b
+        self.ta, self.tb = a.table("textures"), b.table("textures")
+        self.ma, self.mb = a.table("materials"), b.table("materials")
+        self.mips_seen = {}
+
+    def mip(self, ia, ib, exact):
+        if (ia, ib) in self.mips_seen:
+            return
+        self.mips_seen[(ia, ib)] = True
+        la, lb = self.a.mip_levels(ia), self.b.mip_levels(ib)
+        assert len(la) == len(lb)
+        for x, y in zip(la, lb):
+            assert x.shape == y.shape
+            if exact:
+                assert np.array_equal(x, y)
+            else:  # float image maps go through Spectrum::y() when read (imagemap.rs:214-216)
+                assert np.allclose(x[..., 0], y[..., 0], rtol=2e-6, atol=1e-7)
+
+    def tex(self, ia, ib, exact=True):
+        assert (ia < 0) == (ib < 0), (ia, ib)
+        if ia < 0:
+            return
+        x, y = self.ta[ia], self.tb[ib]
+        assert x["kind"] == y["kind"], (x, y)
+        k = int(x["kind"])
+        if k == sd.TEX_CONST:
+            if exact:
+                assert np.array_equal(x["value"], y["value"]), (x, y)
+            else:
+                assert x["value"][0] == y["value"][0]
+        elif k in (sd.TEX_SCALE, sd.TEX_MIX):
+            self.tex(x["tex1"], y["tex1"], exact)
+            self.tex(x["tex2"], y["tex2"], exact)
+            if k == sd.TEX_MIX:
+                self.tex(x["amount"], y["amount"], False)
+        elif k == sd.TEX_IMAGE:
+            assert np.array_equal(x["mapping"], y["mapping"])
+            self.mip(int(x["image"]), int(y["image"]), exact)
+        elif k == sd.TEX_CHECKER:
+            assert np.array_equal(x["mapping"], y["mapping"]) and x["amount"] == y["amount"]
+            self.tex(x["tex1"], y["tex1"])
+            self.tex(x["tex2"], y["tex2"])
+        elif k == sd.TEX_UV:
+            assert np.array_equal(x["mapping"], y["mapping"])
+        elif k == sd.TEX_FBM:
+            assert x["value"][0] == y["value"][0] and x["amount"] == y["amount"]
+        else:
+            raise AssertionError(k)
+
+    FLOAT_SLOTS = {sd.MAT_MATTE: {4}, sd.MAT_PLASTIC: {5}, sd.MAT_METAL: {5, 6, 7}, sd.MAT_GLASS: {6, 7, 8}, sd.MAT_UBER: {5, 6, 7, 8}, sd.MAT_SUBSTRATE: {6, 7},
+                   sd.MAT_TRANSLUCENT: {5}, sd.MAT_DISNEY: {1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 12, 13}, sd.MAT_MIRROR: set(), sd.MAT_MIX: set()}
+
+    def mat(self, ia, ib):
+        x, y = self.ma[ia], self.mb[ib]
+        assert x["kind"] == y["kind"]
+        k = int(x["kind"])
+        if k != sd.MAT_MIX:
+            assert x["remap_roughness"] == y["remap_roughness"]
+            self.tex(int(x["bump"]), int(y["bump"]), False)
+        for slot in range(14):
+            self.tex(int(x["slot"][slot]), int(y["slot"][slot]), slot not in self.FLOAT_SLOTS[k])
+        if k == sd.MAT_MIX:
+            self.mat(int(x["slot"][14]), int(y["slot"][14]))
+            self.mat(int(x["slot"][15]), int(y["slot"][15]))
+        elif k == sd.MAT_DISNEY:
+            assert x["slot"][14] == y["slot"][14]
+
+
+def assert_same_scene(p, h):
+    """p: PbrtScene, h: HostScene of the SceneDesc the file was written from."""
+    for name in ("P", "N", "UV", "S", "indices", "tri_light", "tri_flags"):
+        assert np.array_equal(p.table(name), h.table(name)), name
+    bp, bh = p.bvh(), h.bvh()
+    for k in bp:
+        assert np.array_equal(bp[k], bh[k]), k
+    sp, sh = p.setup(), h.setup()
+    for name, _ in host.RenderParams._fields_:   # value equality: CTM = identity * LookAt turns a -0 of the LookAt matrix into +0 (api.rs:637)
+        x, y = getattr(sp["params"], name), getattr(sh["params"], name)
+        assert np.array_equal(np.array(x), np.array(y)), name
+    for k in ("raster_to_camera", "dx_camera", "dy_camera", "filter_table", "sample_bounds", "cropped"):
+        assert np.array_equal(sp[k], sh[k]), k
+    c = _Cmp(p, h)
+    tm_p, tm_h = p.table("tri_material"), h.table("tri_material")
+    for a, b in sorted(set(zip(tm_p.tolist(), tm_h.tolist()))):
+        c.mat(a, b)
+    lp, lh = p.table("lights"), h.table("lights")
+    assert len(lp) == len(lh)
+    for k in ("kind", "tri", "rgb", "two_sided", "vec", "l2w"):
+        assert np.array_equal(lp[k], lh[k]), k
+    assert np.allclose(lp["w2l"], lh["w2l"], rtol=1e-5, atol=1e-6)
+    for a, b in zip(lp, lh):
+        if a["kind"] == sd.LIGHT_INFINITE:
+            c.mip(int(a["mip"]), int(b["mip"]), True)
+
+
+def _round_trip(desc, tmp_path):
+    path = os.path.join(str(tmp_path), f"{desc.name}.pbrt")
+    write_pbrt(desc, path)
+    p = host.PbrtScene(path)
+    assert p.n_warnings == 0
+    assert p.max_prims_per_node == desc.max_prims_per_node
+    assert p.film_filename == f"rt-{desc.name}.png"
+    assert_same_scene(p, host.HostScene(desc))
+    return p
+
+
+# ------------------------------------------------------------------------------------------------ round trips
+def test_cornell_round_trip(tmp_path):
+    from rustracer_amd.scenes import cornell_box
+    _round_trip(cornell_box(96, 64, 32), tmp_path)
+
+
+def test_mis_plates_round_trip(tmp_path):
+    from rustracer_amd.scenes import mis_plates
+    _round_trip(mis_plates(64, 48, 8, sphere_level=1), tmp_path)
+
+
+def test_room_env_round_trip(tmp_path):
+    from rustracer_amd.scenes import room_env
+    _round_trip(room_env(64, 36, 4, detail=2, tex_size=32, env_size=32), tmp_path)
+
+
+def _zoo_cases():
+    from test_gpu_materials import MATERIALS
+    # float checkerboard / uv textures (bump maps of two zoo entries) do not exist in the reference's make_float_texture (api.rs:1201-1216)
+    return [m for m in MATERIALS if m not in ("mirror_bump_checker", "mix_bump_both")]
+
+
+@pytest.mark.parametrize("material", _zoo_cases())
+def test_material_zoo_round_trip(tmp_path, material):
+    from test_gpu_materials import _zoo
+    d = _zoo(material)
+    d.name = material
+    _round_trip(d, tmp_path)
+
+
+@pytest.mark.parametrize("light", ["area_two_sided", "point", "distant", "infinite"])
+def test_light_zoo_round_trip(tmp_path, light):
+    from test_gpu_materials import _zoo
+    d = _zoo("plastic", light)
+    d.film.filter_kind, d.film.filter_params = {"point": (sd.FILTER_GAUSSIAN, (1.5, 2.5, 1.7, 0.0)), "distant": (sd.FILTER_MITCHELL, (2.0, 3.0, 0.4, 0.3)),
+                                                 "infinite": (sd.FILTER_TRIANGLE, (1.5, 1.0, 0.0, 0.0))}.get(light, (sd.FILTER_BOX, (0.5, 0.5, 0.0, 0.0)))
+    d.film.crop = (0.1, 0.9, 0.25, 0.75)
+    d.film.scale, d.film.max_sample_luminance = 2.0, 50.0
+    d.camera.lens_radius, d.camera.focal_distance = 0.05, 5.0
+    d.integrator.light_strategy, d.integrator.rr_threshold, d.integrator.pixel_bounds = "uniform", 0.25, (2, 30, 3, 20)
+    d.max_prims_per_node = 2
+    d.name = light
+    _round_trip(d, tmp_path)
+
+
+# ------------------------------------------------------------------------------------------------ lexer known answers
+def test_lexer_known_answers():
+    # rc/pbrt/lexer.rs:316-337: float, string, keyword / bracket and comment parsers
+    assert host.pbrt_tokens("-1.23e2") == [("N", -123.0)]
+    assert host.pbrt_tokens('"this is a string"') == [("S", "this is a string")]
+    assert host.pbrt_tokens("Accelerator") == [("K", "Accelerator")]
+    assert host.pbrt_tokens("[") == [("[", None)]
+    assert host.pbrt_tokens("#foo\n") == []
+    toks = host.pbrt_tokens('LookAt 0 0 5 0 0 0 0 1 0\nCamera "perspective" "float fov" [50] # trailing\n  #whole line\nWorldBegin\nShape "sphere"\nWorldEnd')
+    assert toks[0] == ("K", "LookAt") and [t[1] for t in toks[1:10]] == [0, 0, 5, 0, 0, 0, 0, 1, 0]
+    assert toks[10:] == [("K", "Camera"), ("S", "perspective"), ("S", "float fov"), ("[", None), ("N", 50.0), ("]", None), ("K", "WorldBegin"), ("K", "Shape"),
+                         ("S", "sphere"), ("K", "WorldEnd")]
+    assert host.pbrt_tokens('"a""b"[1 2]') == [("S", "a"), ("S", "b"), ("[", None), ("N", 1.0), ("N", 2.0), ("]", None)]
+    with pytest.raises(host.BackendError, match="unterminated"):
+        host.pbrt_tokens('Shape "open')
+
+
+# ------------------------------------------------------------------------------------------------ directive semantics
+HEADER = 'Sampler "02sequence"\n'
+TRI = 'Shape "trianglemesh" "integer indices" [0 1 2] "point P" [0 0 0 1 0 0 0 1 0]\n'
+
+
+def _parse(text, base_dir=""):
+    return host.PbrtScene(text=text, base_dir=str(base_dir))
+
+
+def _mm(a, b):  # Matrix4x4 product in f32, the summation order of matrix.rs:157-168
+    r = np.zeros((4, 4), F32)
+    for i in range(4):
+        for j in range(4):
+            r[i, j] = F32(F32(F32(a[i, 0] * b[0, j]) + F32(a[i, 1] * b[1, j])) + F32(a[i, 2] * b[2, j])) + F32(a[i, 3] * b[3, j])
+    return r
+
+
+def _pt(m, p):  # Transform * Point3f (transform.rs:264-286), w == 1 here
+    x, y, z = (F32(v) for v in p)
+    return np.array([F32(F32(F32(m[r, 0] * x) + F32(m[r, 1] * y)) + F32(m[r, 2] * z)) + m[r, 3] for r in range(3)], F32)
+
+
+def _translate(x, y, z):
+    m = np.eye(4, dtype=F32)
+    m[:3, 3] = (x, y, z)
+    return m
+
+
+def _scale(x, y, z):
+    return np.diag(np.array([x, y, z, 1], F32))
+
+
+def test_defaults_of_every_create():
+    p = _parse(HEADER + "WorldBegin\n" + TRI + "WorldEnd\n")
+    q = p.params
+    assert (q.xres, q.yres) == (1280, 720) and list(q.crop) == [0, 1, 0, 1]                       # film.rs:124-126
+    assert q.filter_kind == 0 and list(q.filter_params)[:2] == [0.5, 0.5]                         # api.rs:283 + boxfilter.rs
+    assert q.film_scale == 1.0 and q.max_sample_luminance == float("inf")
+    assert q.fov == 90.0 and q.lens_radius == 0.0 and q.focal_distance == F32(1e6)                # camera.rs:84-108
+    assert (q.spp, q.sampler_dims) == (16, 4)                                                     # zerotwosequence.rs:58-63
+    assert (q.max_depth, q.rr_threshold, q.light_strategy) == (5, 1.0, 0)                         # path.rs:49-53
+    assert list(q.pixel_bounds) == [0, 0, 0, 0]
+    assert np.array_equal(np.array(q.cam_to_world), np.eye(4, dtype=F32).reshape(-1))
+    assert p.max_prims_per_node == 4 and p.film_filename == "image.png"                           # bvh/mod.rs:76, film.rs:118-123
+    m = p.table("materials")
+    t = p.table("textures")
+    assert len(m) == 1 and m[0]["kind"] == sd.MAT_MATTE                                           # api.rs:304 default material "matte"
+    assert np.array_equal(t[m[0]["slot"][0]]["value"], F32([0.5, 0.5, 0.5])) and t[m[0]["slot"][4]]["value"][0] == 0.0   # matte.rs:24-25
+    assert p.n_lights() == 0 and p.n_warnings == 0
+
+
+def test_halton_default_sampler_is_an_error_like_the_reference():
+    with pytest.raises(host.BackendError, match='Sampler "halton" unknown'):   # api.rs:285 default + :205-215
+        _parse("WorldBegin\n" + TRI + "WorldEnd\n")
+
+
+def test_ctm_composition_and_stacks():
+    text = HEADER + """WorldBegin
+Translate 1 2 3
+Scale 2 2 2
+""" + TRI + """AttributeBegin
+  Translate 10 0 0
+  TransformBegin
+    Scale -1 1 1
+""" + TRI + """  TransformEnd
+""" + TRI + """AttributeEnd
+""" + TRI + "WorldEnd\n"
+    p = _parse(text)
+    P = p.table("P")
+    base = np.array([[0, 0, 0], [1, 0, 0], [0, 1, 0]], F32)
+    ctm0 = _mm(_translate(1, 2, 3), _scale(2, 2, 2))          # cur_transform = cur_transform * t (api.rs:536-556)
+    ctm1 = _mm(ctm0, _translate(10, 0, 0))
+    ctm2 = _mm(ctm1, _scale(-1, 1, 1))
+    for k, m in enumerate((ctm0, ctm2, ctm1, ctm0)):
+        assert np.array_equal(P[3 * k:3 * k + 3], np.stack([_pt(m, v) for v in base])), k
+    flags = p.table("tri_flags")
+    assert [int(f) & sd.TRI_FLIP for f in flags] == [0, sd.TRI_FLIP, 0, 0]   # swaps_handedness of the mirrored CTM (transform.rs:255-261)
+
+
+def test_reverse_orientation_is_graphics_state():
+    p = _parse(HEADER + "WorldBegin\nAttributeBegin\nReverseOrientation\n" + TRI + "Scale 1 1 -1\n" + TRI + "AttributeEnd\n" + TRI + "WorldEnd\n")
+    assert [int(f) & sd.TRI_FLIP for f in p.table("tri_flags")] == [sd.TRI_FLIP, 0, 0]   # reverse ^ swaps_handedness (mesh.rs:175-180)
+
+
+def test_rotate_and_concat_transform_and_lookat_camera():
+    text = """LookAt 1 2 3  0 0 0  0 1 0
+Camera "perspective" "float fov" [40]
+""" + HEADER + """WorldBegin
+Rotate 90 0 0 1
+ConcatTransform [1 0 0 0  0 1 0 0  0 0 1 0  5 6 7 1]
+""" + TRI + """CoordSysTransform "camera"
+""" + TRI + "WorldEnd\n"
+    p = _parse(text)
+    P = p.table("P")
+    s, c = F32(np.sin(np.radians(F32(90)))), F32(np.cos(np.radians(F32(90))))
+    rot = np.eye(4, dtype=F32)
+    rot[0, 0], rot[0, 1], rot[1, 0], rot[1, 1] = c, -s, s, c     # Transform::rotate about z (transform.rs:30-56): m[0][0] = 0 + 1*cos
+    ctm = _mm(rot, _translate(5, 6, 7))                          # the file gives the matrix column-major (api.rs:596-600)
+    base = np.array([[0, 0, 0], [1, 0, 0], [0, 1, 0]], F32)
+    assert np.allclose(P[:3], np.stack([_pt(ctm, v) for v in base]), rtol=0, atol=1e-6)
+    w2c, c2w = host.look_at((1, 2, 3), (0, 0, 0), (0, 1, 0))
+    assert np.array_equal(np.array(p.params.cam_to_world, F32).reshape(4, 4), c2w)       # camera_to_world = CTM.inverse() (api.rs:726)
+    assert np.array_equal(P[3:6], np.stack([_pt(c2w, v) for v in base]))                 # named coordinate system "camera" (:728)
+    assert p.params.fov == 40.0
+
+
+def test_world_begin_resets_the_ctm_and_options_are_refused_in_the_world_block():
+    p = _parse("Translate 100 0 0\n" + HEADER + "WorldBegin\n" + TRI + "WorldEnd\n")
+    assert np.array_equal(p.table("P")[1], F32([1, 0, 0]))                               # api.rs:741
+    with pytest.raises(host.BackendError, match="Options cannot be set inside world block"):
+        _parse(HEADER + 'WorldBegin\nFilm "image"\n' + TRI + "WorldEnd\n")
+    with pytest.raises(host.BackendError, match="must be inside world block"):
+        _parse(HEADER + TRI + "WorldBegin\nWorldEnd\n")
+    with pytest.raises(host.BackendError, match="WorldEnd"):
+        _parse(HEADER + "WorldBegin\n" + TRI)
+
+
+def test_named_materials_textures_and_lookup_order():
+    text = HEADER + """WorldBegin
+Texture "grid" "spectrum" "checkerboard" "float uscale" [4] "float vscale" [6] "rgb tex1" [0.9 0.1 0.1] "rgb tex2" [0.1 0.1 0.9]
+Texture "bumps" "float" "scale" "float tex1" [0.25] "float tex2" [2]
+MakeNamedMaterial "a" "string type" "plastic" "texture Kd" "grid" "float roughness" [0.3] "bool remaproughness" "false" "texture bumpmap" "bumps"
+MakeNamedMaterial "b" "string type" "mirror"
+MakeNamedMaterial "ab" "string type" "mix" "string namedmaterial1" "a" "string namedmaterial2" "b" "rgb amount" [0.2 0.4 0.6]
+Material "matte" "rgb Kd" [0.1 0.2 0.3] "float sigma" [20]
+""" + TRI + TRI.replace('"point P"', '"rgb Kd" [0.7 0.8 0.9] "point P"') + """NamedMaterial "ab"
+""" + TRI + """Material "glass" "float eta" [1.7]
+""" + TRI + """NamedMaterial "missing"
+""" + TRI + "WorldEnd\n"
+    p = _parse(text)
+    m, t, tm = p.table("materials"), p.table("textures"), p.table("tri_material")
+    m0, m1, m2, m3, m4 = (m[i] for i in tm)
+    assert m0["kind"] == sd.MAT_MATTE and np.array_equal(t[m0["slot"][0]]["value"], F32([0.1, 0.2, 0.3])) and t[m0["slot"][4]]["value"][0] == 20.0
+    assert np.array_equal(t[m1["slot"][0]]["value"], F32([0.7, 0.8, 0.9]))       # shape parameters override the Material's (paramset.rs:421-424)
+    assert t[m1["slot"][4]]["value"][0] == 20.0
+    assert m2["kind"] == sd.MAT_MIX and np.array_equal(t[m2["slot"][13]]["value"], F32([0.2, 0.4, 0.6]))
+    a, b = m[m2["slot"][14]], m[m2["slot"][15]]
+    assert a["kind"] == sd.MAT_PLASTIC and a["remap_roughness"] == 0 and b["kind"] == sd.MAT_MIRROR
+    grid = t[a["slot"][0]]
+    assert grid["kind"] == sd.TEX_CHECKER and list(grid["mapping"]) == [4, 6, 0, 0] and grid["amount"] == 1
+    assert np.array_equal(t[a["slot"][1]]["value"], F32([0.25, 0.25, 0.25])) and t[a["slot"][5]]["value"][0] == F32(0.3)
+    bump = t[a["bump"]]
+    assert bump["kind"] == sd.TEX_SCALE and t[bump["tex1"]]["value"][0] == 0.25 and t[bump["tex2"]]["value"][0] == 2.0
+    assert np.array_equal(t[b["slot"][2]]["value"], F32([0.9, 0.9, 0.9]))        # mirror.rs:22
+    assert m3["kind"] == sd.MAT_GLASS and t[m3["slot"][8]]["value"][0] == F32(1.7)   # "eta" before "index" (glass.rs:32-34)
+    assert m4["kind"] == sd.MAT_MATTE and p.n_warnings == 1                     # api.rs:318-326: unknown named material -> matte, logged
+    # the Material directive cleared the named material (api.rs:890), then NamedMaterial took over again
+
+
+def test_attribute_end_restores_material_and_area_light():
+    text = HEADER + """WorldBegin
+AttributeBegin
+  Material "mirror"
+  AreaLightSource "diffuse" "rgb L" [2 3 4] "rgb scale" [0.5 0.5 2] "bool twosided" "true"
+""" + TRI + TRI + """AttributeEnd
+LightSource "point" "rgb I" [1 2 3] "point from" [1 1 1]
+""" + TRI + """AttributeBegin
+  Translate 0 0 5
+  LightSource "point" "point from" [1 1 1] "rgb scale" [2 2 2]
+  LightSource "distant" "point from" [0 0 0] "point to" [0 0 2]
+AttributeEnd
+WorldEnd
+"""
+    p = _parse(text)
+    l = p.table("lights")
+    assert list(l["kind"]) == [sd.LIGHT_DIFFUSE_AREA, sd.LIGHT_DIFFUSE_AREA, sd.LIGHT_POINT, sd.LIGHT_POINT, sd.LIGHT_DISTANT]   # appearance order (api.rs:904, 958-963)
+    assert list(l["tri"][:2]) == [0, 1] and np.array_equal(l["rgb"][0], F32([1, 1.5, 8])) and list(l["two_sided"][:2]) == [1, 1]  # L * scale (diffuse.rs:44-50)
+    assert list(p.table("tri_light")) == [0, 1, -1]
+    m, tm = p.table("materials"), p.table("tri_material")
+    assert m[tm[0]]["kind"] == sd.MAT_MIRROR and m[tm[2]]["kind"] == sd.MAT_MATTE
+    assert np.array_equal(l["vec"][2], F32([1, 1, 1])) and np.array_equal(l["rgb"][2], F32([1, 2, 3]))
+    assert np.array_equal(l["vec"][3], F32([1, 1, 6])) and np.array_equal(l["rgb"][3], F32([2, 2, 2]))     # translate(from) * l2w (point.rs:33-34)
+    assert np.array_equal(l["vec"][4], F32([0, 0, -1]))                                                     # l2w * (from - to), normalised (distant.rs:27,39-40)
+
+
+def test_include_and_plymesh_and_imagemap(tmp_path):
+    from rustracer_amd.ingest import write_pfm, write_ply
+    P = np.array([[0, 0, 0], [1, 0, 0], [1, 1, 0], [0, 1, 0]], F32)
+    write_ply(os.path.join(str(tmp_path), "quad.ply"), P, np.array([[0, 1, 2], [0, 2, 3]], np.int32), UV=P[:, :2].copy())
+    rng = np.random.default_rng(5)
+    img = rng.random((4, 8, 3), dtype=F32)
+    write_pfm(os.path.join(str(tmp_path), "tex.pfm"), img)
+    os.makedirs(os.path.join(str(tmp_path), "geo"))
+    with open(os.path.join(str(tmp_path), "geo", "inc.pbrt"), "w") as f:
+        f.write('Texture "img" "spectrum" "imagemap" "string filename" "tex.pfm" "float scale" [0.5] "string wrap" "clamp" "bool trilinear" "true"\n'
+                'Material "matte" "texture Kd" "img"\nShape "plymesh" "string filename" "quad.ply"\n')
+    main = os.path.join(str(tmp_path), "main.pbrt")
+    with open(main, "w") as f:
+        f.write(HEADER + 'WorldBegin\nTranslate 0 0 2\nInclude "geo/inc.pbrt"\n' + TRI + "WorldEnd\n")
+    p = host.PbrtScene(main)
+    assert len(p.table("indices")) == 3 and np.array_equal(p.table("P")[:4], P + F32([0, 0, 2]))
+    assert [int(f) for f in p.table("tri_flags")] == [sd.TRI_HAS_UV, sd.TRI_HAS_UV, 0]
+    t = p.table("textures")
+    kd = t[p.table("materials")[p.table("tri_material")[0]]["slot"][0]]
+    assert kd["kind"] == sd.TEX_IMAGE
+    lv = p.mip_levels(int(kd["image"]))
+    assert np.array_equal(lv[0], F32(0.5) * img[::-1])           # y flip + scale, no gamma for .pfm (imagemap.rs:52-84, 124-127)
+    # a missing image is a 1x1 grey texel, logged, as in the reference (imagemap.rs:62-69)
+    q = _parse(HEADER + 'WorldBegin\nTexture "img" "spectrum" "imagemap" "string filename" "nope.pfm"\nMaterial "matte" "texture Kd" "img"\n' + TRI + "WorldEnd\n", tmp_path)
+    assert q.n_warnings == 1 and np.array_equal(q.mip_levels(0)[0], np.full((1, 1, 3), 0.18, F32))
+
+
+def test_infinite_light_texels_carry_the_scale(tmp_path):
+    from rustracer_amd.ingest import write_pfm
+    img = np.random.default_rng(9).random((8, 16, 3), dtype=F32)
+    write_pfm(os.path.join(str(tmp_path), "env.pfm"), img)
+    p = _parse(HEADER + 'WorldBegin\nLightSource "infinite" "string mapname" "env.pfm" "rgb L" [2 1 0.5] "rgb scale" [0.5 1 2]\n' + TRI + "WorldEnd\n", tmp_path)
+    assert np.array_equal(p.mip_levels(0)[0], img * (F32([2, 1, 0.5]) * F32([0.5, 1, 2])))   # infinite.rs:60, 117-127: no flip, texel * (L * scale)
+    q = _parse(HEADER + 'WorldBegin\nLightSource "infinite" "rgb L" [3 2 1]\n' + TRI + "WorldEnd\n", tmp_path)
+    assert np.array_equal(q.mip_levels(0)[0], F32([[[3, 2, 1]]])) and q.n_lights() == 1       # no map: one texel of `power` (:62-69)
+
+
+@pytest.mark.parametrize("text, message", [
+    ('Film "other"\n' + HEADER + "WorldBegin\n" + TRI + "WorldEnd\n", 'Film "other" unknown'),
+    ('PixelFilter "sinc"\n' + HEADER + "WorldBegin\n" + TRI + "WorldEnd\n", 'Filter "sinc" unknown'),
+    ('Camera "orthographic"\n' + HEADER + "WorldBegin\n" + TRI + "WorldEnd\n", 'Camera "orthographic" unknown'),
+    ('Integrator "whitted"\n' + HEADER + "WorldBegin\n" + TRI + "WorldEnd\n", "not supported"),
+    (HEADER + 'WorldBegin\nShape "sphere"\nWorldEnd\n', "not supported"),
+    (HEADER + 'WorldBegin\nObjectBegin "x"\nObjectEnd\n' + TRI + "WorldEnd\n", "instancing"),
+    (HEADER + 'WorldBegin\nLightSource "spot"\n' + TRI + "WorldEnd\n", "not supported"),
+    (HEADER + 'WorldBegin\nAreaLightSource "sphere"\n' + TRI + "WorldEnd\n", "unknown"),
+    (HEADER + 'WorldBegin\nMakeNamedMaterial "m" "rgb Kd" [1 1 1]\n' + TRI + "WorldEnd\n", 'No parameter string "type"'),
+    (HEADER + 'WorldBegin\nMaterial "matte" "spectrum Kd" "file.spd"\n' + TRI + "WorldEnd\n", "not supported"),
+    (HEADER + "WorldBegin\nFrobnicate 1 2\nWorldEnd\n", "unknown directive"),
+    (HEADER + 'WorldBegin\nShape "trianglemesh" "integer indices" [0 1 5] "point P" [0 0 0 1 0 0 0 1 0]\nWorldEnd\n', "out of range"),
+    (HEADER + "WorldBegin\nWorldEnd\n", "no triangles"),
+])
+def test_errors(text, message):
+    with pytest.raises(host.BackendError, match=message):
+        _parse(text)
+
+
+def test_unknown_material_and_coordinate_system_are_logged_not_fatal():
+    p = _parse(HEADER + 'WorldBegin\nCoordSysTransform "nowhere"\nMaterial "velvet"\n' + TRI + "AttributeEnd\nTransformEnd\nWorldEnd\n")
+    assert p.n_warnings == 4 and p.table("materials")[0]["kind"] == sd.MAT_MATTE   # api.rs:663-667, 1178-1181, 757-760, 779-782
