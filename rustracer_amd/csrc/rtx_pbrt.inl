@@ -8,8 +8,9 @@
 // "perspective", Film "image", Sampler "02sequence"|"lowdiscrepancy", Integrator "path", PixelFilter box|triangle|gaussian|mitchell,
 // Accelerator "bvh", WorldBegin/End, Attribute/TransformBegin/End, ReverseOrientation, Shape trianglemesh|plymesh, Material,
 // MakeNamedMaterial, NamedMaterial, Texture (constant scale mix imagemap[pfm] checkerboard uv fbm), LightSource point|distant|infinite,
-// AreaLightSource diffuse|area, Include. Anything else the reference implements but this backend does not (other shapes, object
-// instancing, other integrators / samplers, spectral parameter types) is an error, never silently skipped.
+// AreaLightSource diffuse|area, ObjectBegin/End, ObjectInstance (written out as world-space triangles), Include. Anything else the
+// reference implements but this backend does not (other shapes, other integrators / samplers, spectral parameter types) is an
+// error, never silently skipped.
 
 namespace {
 
@@ -47,6 +48,23 @@ struct PbrtGraphicsState {  // rc/api.rs:300-311
   bool reverse_orientation = false;
 };
 
+struct PbrtSoup {  // triangle soup: world space for the scene, instance space for an ObjectBegin .. ObjectEnd block
+  std::vector<float> P, N, UV, S; std::vector<int32_t> idx, tri_mat, tri_light; std::vector<uint8_t> tri_flags;
+  bool any_n = false, any_uv = false, any_s = false;
+  size_t n_verts() const { return P.size() / 3; }
+  // appends nv vertices (attributes may be null: zero-filled once any mesh carries them); returns the first vertex index
+  size_t add_verts(size_t nv, const float* p, const float* n, const float* uv, const float* s) {
+    const size_t v0 = n_verts();
+    auto put = [&](std::vector<float>& a, size_t per, bool& any, const float* src) {
+      if (src) { if (!any) { a.assign(v0 * per, 0.0f); any = true; } a.insert(a.end(), src, src + nv * per); }
+      else if (any) a.resize(a.size() + nv * per, 0.0f);
+    };
+    P.insert(P.end(), p, p + 3 * nv);
+    put(N, 3, any_n, n); put(UV, 2, any_uv, uv); put(S, 3, any_s, s);
+    return v0;
+  }
+};
+
 struct PbrtLoader {
   rtxh_scene* scene = nullptr;
   rtxh_render_params* rp = nullptr;
@@ -62,9 +80,8 @@ struct PbrtLoader {
   std::map<std::string, Xf> named_cs;
   std::vector<Xf> pushed_transforms;
   PbrtGraphicsState gs; std::vector<PbrtGraphicsState> pushed_gs;
-  // triangle soup, world space
-  std::vector<float> P, N, UV, S; std::vector<int32_t> idx, tri_mat, tri_light; std::vector<uint8_t> tri_flags;
-  bool any_n = false, any_uv = false, any_s = false;
+  PbrtSoup world;
+  std::map<std::string, PbrtSoup> instances; std::string current_instance; bool in_instance = false;  // RenderOptions::instances / current_instance (api.rs:175-177)
   int n_lights = 0;
 
   bool fail_(const std::string& m) { if (err.empty()) err = m; return false; }
@@ -306,31 +323,65 @@ struct PbrtLoader {
     if (nt == 0) return true;
     const int mat = current_material(p);
     if (mat < 0) return fail_(err.empty() ? rtxh_last_error() : err);
-    // TriangleMesh::new (mesh.rs:47-74): points go to world space; normals and tangents are kept as given
-    const size_t v0 = P.size() / 3;
-    auto pad = [&](std::vector<float>& a, size_t per, bool& any) { if (!any) { a.assign(v0 * per, 0.0f); any = true; } };
-    for (size_t v = 0; v < nv; ++v) { float o[3]; xf_point(ctm.m, &vp[3 * v], o); P.insert(P.end(), o, o + 3); }
-    if (!vn.empty()) { pad(N, 3, any_n); N.insert(N.end(), vn.begin(), vn.end()); } else if (any_n) N.resize(N.size() + nv * 3, 0.0f);
-    if (!vuv.empty()) { pad(UV, 2, any_uv); UV.insert(UV.end(), vuv.begin(), vuv.begin() + nv * 2); } else if (any_uv) UV.resize(UV.size() + nv * 2, 0.0f);
-    if (!vs.empty()) { pad(S, 3, any_s); S.insert(S.end(), vs.begin(), vs.end()); } else if (any_s) S.resize(S.size() + nv * 3, 0.0f);
-    const Mat& m = ctm.m;  // Transform::swaps_handedness, transform.rs:255-261
-    const float det = m.a[0][0] * (m.a[1][1] * m.a[2][2] - m.a[1][2] * m.a[2][1]) - m.a[0][1] * (m.a[1][0] * m.a[2][2] - m.a[1][2] * m.a[2][0]) + m.a[0][2] * (m.a[1][0] * m.a[2][1] - m.a[1][1] * m.a[2][0]);
-    const uint8_t flags = (uint8_t)(((gs.reverse_orientation != (det < 0.0f)) ? RT_TRI_FLIP : 0) | (!vn.empty() ? RT_TRI_HAS_N : 0) | (!vuv.empty() ? RT_TRI_HAS_UV : 0) | (!vs.empty() ? RT_TRI_HAS_S : 0));
+    // TriangleMesh::new (mesh.rs:47-74): points go to world space (instance space inside an object definition); normals and tangents are kept as given
+    PbrtSoup& soup = in_instance ? instances[current_instance] : world;
+    std::vector<float> wp(vp.size());
+    for (size_t v = 0; v < nv; ++v) xf_point(ctm.m, &vp[3 * v], &wp[3 * v]);
+    const size_t v0 = soup.add_verts(nv, wp.data(), vn.empty() ? nullptr : vn.data(), vuv.empty() ? nullptr : vuv.data(), vs.empty() ? nullptr : vs.data());
+    const uint8_t flags = (uint8_t)(((gs.reverse_orientation != swaps_handedness(ctm.m)) ? RT_TRI_FLIP : 0) | (!vn.empty() ? RT_TRI_HAS_N : 0) | (!vuv.empty() ? RT_TRI_HAS_UV : 0) | (!vs.empty() ? RT_TRI_HAS_S : 0));
     // area light per triangle (make_area_light, api.rs:1185-1199; DiffuseAreaLight::create, light/diffuse.rs:39-51)
     float L[3] = {1, 1, 1}, sc[3] = {1, 1, 1}; bool emit = false, two_sided = false;
     if (!gs.area_light.empty()) {
       if (gs.area_light != "area" && gs.area_light != "diffuse") return fail_("area light \"" + gs.area_light + "\" unknown");
+      // the reference keeps such a light out of the scene's light list (api.rs:955-957): it would glow when seen and never be sampled
+      if (in_instance) return fail_("area lights inside an object definition are not supported");
       gs.area_light_params.one_rgb("L", L); gs.area_light_params.one_rgb("scale", sc); two_sided = gs.area_light_params.one_bool("twosided", false); emit = true;
       for (int k = 0; k < 3; ++k) L[k] *= sc[k];
     }
     for (size_t t = 0; t < nt; ++t) {
-      const int32_t tri_index = (int32_t)(idx.size() / 3);
-      for (int k = 0; k < 3; ++k) idx.push_back((int32_t)(v0 + vi[3 * t + k]));
-      tri_mat.push_back(mat); tri_flags.push_back(flags);
+      const int32_t tri_index = (int32_t)(soup.idx.size() / 3);
+      for (int k = 0; k < 3; ++k) soup.idx.push_back((int32_t)(v0 + vi[3 * t + k]));
+      soup.tri_mat.push_back(mat); soup.tri_flags.push_back(flags);
       if (emit) {
         if (rtxh_scene_add_light(scene, RT_LIGHT_DIFFUSE_AREA, tri_index, L, two_sided ? 1 : 0, nullptr, -1, nullptr, nullptr) < 0) return fail_(rtxh_last_error());
-        tri_light.push_back(n_lights++);
-      } else tri_light.push_back(-1);
+        soup.tri_light.push_back(n_lights++);
+      } else soup.tri_light.push_back(-1);
+    }
+    return true;
+  }
+  static bool swaps_handedness(const Mat& m) {  // transform.rs:255-261
+    const float det = m.a[0][0] * (m.a[1][1] * m.a[2][2] - m.a[1][2] * m.a[2][1]) - m.a[0][1] * (m.a[1][0] * m.a[2][2] - m.a[1][2] * m.a[2][0]) + m.a[0][2] * (m.a[1][0] * m.a[2][1] - m.a[1][1] * m.a[2][0]);
+    return det < 0.0f;
+  }
+
+  // ObjectInstance (api.rs:1053-1090 + TransformedPrimitive, primitive.rs:79-118). The reference keeps one BVH per object and sends each ray
+  // through instance_to_world^-1; here the instance is written out: with 288 GB of HBM the copies are cheap and every ray stays in the
+  // single-level traversal kernels. Points go through instance_to_world, normals through its inverse transpose and tangents through its
+  // linear part (SurfaceInteraction::transform, interaction.rs:156-190 - all linear, so transforming the vertex attributes commutes with
+  // the barycentric interpolation); a mirroring transform flips the winding-derived normal, hence the toggled RT_TRI_FLIP.
+  bool instantiate(const std::string& name) {
+    auto it = instances.find(name);
+    if (it == instances.end()) return fail_("Unable to find instance named " + name);
+    const PbrtSoup& o = it->second;
+    if (o.idx.empty()) return true;
+    const size_t nv = o.n_verts();
+    std::vector<float> p(3 * nv), n, sv;
+    for (size_t v = 0; v < nv; ++v) xf_point(ctm.m, &o.P[3 * v], &p[3 * v]);
+    if (o.any_n) {
+      n.resize(3 * nv); const Mat& i = ctm.inv;  // Transform::transform_normal: the transpose of the inverse (transform.rs:244-253)
+      for (size_t v = 0; v < nv; ++v) { const float* x = &o.N[3 * v];
+        for (int r = 0; r < 3; ++r) n[3 * v + r] = i.a[0][r] * x[0] + i.a[1][r] * x[1] + i.a[2][r] * x[2]; }
+    }
+    if (o.any_s) {
+      sv.resize(3 * nv); const Mat& m = ctm.m;
+      for (size_t v = 0; v < nv; ++v) { const float* x = &o.S[3 * v];
+        for (int r = 0; r < 3; ++r) sv[3 * v + r] = m.a[r][0] * x[0] + m.a[r][1] * x[1] + m.a[r][2] * x[2]; }
+    }
+    const size_t v0 = world.add_verts(nv, p.data(), o.any_n ? n.data() : nullptr, o.any_uv ? o.UV.data() : nullptr, o.any_s ? sv.data() : nullptr);
+    const uint8_t toggle = swaps_handedness(ctm.m) ? RT_TRI_FLIP : 0;
+    for (size_t t = 0; t < o.idx.size() / 3; ++t) {
+      for (int k = 0; k < 3; ++k) world.idx.push_back((int32_t)(v0 + o.idx[3 * t + k]));
+      world.tri_mat.push_back(o.tri_mat[t]); world.tri_light.push_back(-1); world.tri_flags.push_back((uint8_t)(o.tri_flags[t] ^ toggle));
     }
     return true;
   }
@@ -487,7 +538,22 @@ struct PbrtLoader {
         std::vector<Tok> sub; if (!tokenize(text, sub, err)) return false;
         if (!run(sub, depth + 1)) return false;
         if (world_ended) return true;
-      } else if (d == "ObjectBegin" || d == "ObjectEnd" || d == "ObjectInstance") return fail_("object instancing is not supported");
+      } else if (d == "ObjectBegin") {  // api.rs:1018-1032
+        if (!in_world) return fail_("Scene description must be inside world block.");
+        if (!str(a)) return fail_("ObjectBegin needs a name");
+        pushed_gs.push_back(gs); pushed_transforms.push_back(ctm);
+        if (in_instance) return fail_("ObjectBegin called inside of instance definition");
+        in_instance = true; current_instance = a; instances[a] = PbrtSoup();
+      } else if (d == "ObjectEnd") {  // api.rs:1034-1049
+        if (!in_instance) return fail_("ObjectEnd called outside of instance definition");
+        in_instance = false; current_instance.clear();
+        if (!pushed_gs.empty()) { gs = pushed_gs.back(); pushed_gs.pop_back(); ctm = pushed_transforms.back(); pushed_transforms.pop_back(); }
+      } else if (d == "ObjectInstance") {
+        if (!in_world) return fail_("Scene description must be inside world block.");
+        if (!str(a)) return fail_("ObjectInstance needs a name");
+        if (in_instance) return fail_("ObjectInstance called inside of instance definition");
+        if (!instantiate(a)) return false;
+      }
       else if (d == "MakeNamedMedium" || d == "MediumInterface" || d == "TransformTimes" || d == "ActiveTransform") return fail_("directive " + d + " is not supported");
       else return fail_("unknown directive \"" + d + "\"");
     }
@@ -510,11 +576,12 @@ int pbrt_load_text(const std::string& text, const std::string& base_dir, rtxh_pb
   bool ok = PbrtLoader::tokenize(text, toks, L.err) && L.run(toks, 0);
   if (ok && !L.world_ended) { L.err = "missing WorldEnd"; ok = false; }
   if (ok) ok = L.finish_options();
-  if (ok && L.idx.empty()) { L.err = "the scene holds no triangles"; ok = false; }
+  if (ok && L.world.idx.empty()) { L.err = "the scene holds no triangles"; ok = false; }
   if (ok) {
-    const int32_t nv = (int32_t)(L.P.size() / 3), nt = (int32_t)(L.idx.size() / 3);
-    if (rtxh_scene_set_mesh(L.scene, L.P.data(), nv, L.idx.data(), nt, L.any_n ? L.N.data() : nullptr, L.any_uv ? L.UV.data() : nullptr, L.any_s ? L.S.data() : nullptr,
-                            L.tri_mat.data(), L.tri_light.data(), L.tri_flags.data()) != RT_OK || rtxh_scene_commit(L.scene, L.max_prims) != RT_OK) { L.err = rtxh_last_error(); ok = false; }
+    const PbrtSoup& w = L.world;
+    const int32_t nv = (int32_t)w.n_verts(), nt = (int32_t)(w.idx.size() / 3);
+    if (rtxh_scene_set_mesh(L.scene, w.P.data(), nv, w.idx.data(), nt, w.any_n ? w.N.data() : nullptr, w.any_uv ? w.UV.data() : nullptr, w.any_s ? w.S.data() : nullptr,
+                            w.tri_mat.data(), w.tri_light.data(), w.tri_flags.data()) != RT_OK || rtxh_scene_commit(L.scene, L.max_prims) != RT_OK) { L.err = rtxh_last_error(); ok = false; }
   }
   if (!ok) { std::string m = L.err.empty() ? std::string("pbrt: parse error") : "pbrt: " + L.err; rtxh_scene_free(L.scene); return fail(RT_ERR_INVALID, m); }
   out->scene = L.scene; out->max_prims_per_node = L.max_prims; out->n_warnings = L.warnings;

@@ -42,3 +42,45 @@ def test_zoo_from_file_matches_direct(gpu_host, tmp_path, material, light):
     # material / texture ids differ between the two builds (the parser shares equal constants), values do not
     assert rel_l2(fp[..., :3], fh[..., :3]) < 1e-6
     assert sp["rays_closest"] == sh["rays_closest"]
+
+
+def test_object_instances_render_like_the_written_out_scene(gpu_host, orc):
+    """ObjectBegin / ObjectInstance (api.rs:1018-1090): three placements of one box, one of them mirrored."""
+    from rustracer_amd.scene_desc import SceneDesc
+    from rustracer_amd.scenes.procedural import box_mesh
+    from test_pbrt_cpu import _mm, _pt, _scale, _translate
+    bp, bi, _ = box_mesh((-0.5, 0.0, -0.5), (0.5, 1.0, 0.5))
+    bp, bi = np.asarray(bp, np.float32), np.asarray(bi, np.int32)
+    box = (f'Shape "trianglemesh" "integer indices" [{" ".join(str(int(x)) for x in bi.reshape(-1))}] '
+           f'"point P" [{" ".join("%.9g" % float(x) for x in bp.reshape(-1))}]\n')
+    room = ['Shape "trianglemesh" "integer indices" [0 1 2 0 2 3] "point P" [-4 0 -4 -4 0 4 4 0 4 4 0 -4]\n',
+            'Shape "trianglemesh" "integer indices" [0 1 2 0 2 3] "point P" [-4 0 4 -4 5 4 4 5 4 4 0 4]\n']
+    text = ('LookAt 0 3 -9  0 1 0  0 1 0\nCamera "perspective" "float fov" [45]\nSampler "02sequence" "integer pixelsamples" [16]\n'
+            'Film "image" "integer xresolution" [96] "integer yresolution" [64]\nWorldBegin\n'
+            'Material "matte" "rgb Kd" [0.7 0.7 0.7]\n' + room[0] + room[1] +
+            'AttributeBegin\nAreaLightSource "diffuse" "rgb L" [20 18 15]\n'
+            'Shape "trianglemesh" "integer indices" [0 1 2 0 2 3] "point P" [-1 4.9 -1 1 4.9 -1 1 4.9 1 -1 4.9 1]\nAttributeEnd\n'
+            'ObjectBegin "box"\nMaterial "plastic" "rgb Kd" [0.2 0.4 0.7] "float roughness" [0.2]\n' + box + 'ObjectEnd\n'
+            'AttributeBegin\nTranslate -2 0 0\nObjectInstance "box"\nAttributeEnd\n'
+            'AttributeBegin\nTranslate 2 0 1\nScale 1 2 1\nObjectInstance "box"\nAttributeEnd\n'
+            'AttributeBegin\nTranslate 0 0 -1\nScale -1.5 0.5 1.5\nObjectInstance "box"\nAttributeEnd\n'
+            'WorldEnd\n')
+    p = gpu_host.PbrtScene(text=text)
+    d = SceneDesc()
+    grey, blue = d.matte((0.7, 0.7, 0.7)), d.plastic((0.2, 0.4, 0.7), (0.25, 0.25, 0.25), 0.2)
+    d.add_quad((-4, 0, -4), (-4, 0, 4), (4, 0, 4), (4, 0, -4), grey)
+    d.add_quad((-4, 0, 4), (-4, 5, 4), (4, 5, 4), (4, 0, 4), grey)
+    d.add_quad((-1, 4.9, -1), (1, 4.9, -1), (1, 4.9, 1), (-1, 4.9, 1), grey, emission=(20.0, 18.0, 15.0))
+    for m, mirrored in ((_translate(-2, 0, 0), False), (_mm(_translate(2, 0, 1), _scale(1, 2, 1)), False), (_mm(_translate(0, 0, -1), _scale(-1.5, 0.5, 1.5)), True)):
+        d.add_mesh(np.stack([_pt(m, v) for v in bp]), bi, blue, reverse_orientation=mirrored)
+    d.camera.pos, d.camera.look, d.camera.fov = (0.0, 3.0, -9.0), (0.0, 1.0, 0.0), 45.0
+    d.film.xres, d.film.yres = 96, 64
+    d.sampler.spp = 16
+    h = gpu_host.HostScene(d)
+    for name in ("P", "indices", "tri_flags", "tri_light"):
+        assert np.array_equal(p.table(name), h.table(name)), name
+    fp, sp = p.render(count_traversal=True)
+    fh, sh = h.render(count_traversal=True)
+    assert np.array_equal(fp, fh)
+    fo, _ = orc.OracleScene(d).render(mode=1)
+    assert np.array_equal(fo[..., 3], fp[..., 3]) and rel_l2(gpu_host.film_to_rgb(fp), orc.film_to_rgb(fo)) < 1e-3

@@ -404,13 +404,59 @@ def test_infinite_light_texels_carry_the_scale(tmp_path):
     assert np.array_equal(q.mip_levels(0)[0], F32([[[3, 2, 1]]])) and q.n_lights() == 1       # no map: one texel of `power` (:62-69)
 
 
+def test_object_instances_are_written_out():
+    mesh = ('Shape "trianglemesh" "integer indices" [0 1 2 0 2 3] "point P" [0 0 0 1 0 0 1 1 0 0 1 0] "normal N" [0 0 1 0 0 1 0.6 0 0.8 0 0.6 0.8] '
+            '"vector S" [1 0 0 1 0 0 0.8 0 -0.6 1 0 0] "float uv" [0 0 1 0 1 1 0 1]\n')
+    text = HEADER + """WorldBegin
+Material "mirror"
+""" + TRI + """ObjectBegin "thing"
+  Material "plastic"
+  Translate 0 0 1
+""" + mesh + """  ReverseOrientation
+""" + TRI + """ObjectEnd
+ObjectBegin "empty"
+ObjectEnd
+""" + TRI + """AttributeBegin
+  Translate 5 0 0
+  Scale 2 1 1
+  ObjectInstance "thing"
+AttributeEnd
+ObjectInstance "empty"
+Scale 1 -3 1
+ObjectInstance "thing"
+WorldEnd
+"""
+    p = _parse(text)
+    P, N, S, UV = p.table("P"), p.table("N"), p.table("S"), p.table("UV")
+    idx, flags, tm, m = p.table("indices"), p.table("tri_flags"), p.table("tri_material"), p.table("materials")
+    assert len(idx) == 2 + 2 * 3 and len(P) == 3 + 3 + 2 * 7
+    assert [m[i]["kind"] for i in tm] == [sd.MAT_MIRROR, sd.MAT_MIRROR] + [sd.MAT_PLASTIC] * 6      # ObjectEnd restores the graphics state (api.rs:1046)
+    obj_p = np.array([[0, 0, 1], [1, 0, 1], [1, 1, 1], [0, 1, 1], [0, 0, 1], [1, 0, 1], [0, 1, 1]], F32)   # instance space: CTM inside the definition
+    obj_n = np.array([[0, 0, 1], [0, 0, 1], [0.6, 0, 0.8], [0, 0.6, 0.8]] + [[0, 0, 0]] * 3, F32)
+    obj_s = np.array([[1, 0, 0], [1, 0, 0], [0.8, 0, -0.6], [1, 0, 0]] + [[0, 0, 0]] * 3, F32)
+    m1 = _mm(_translate(5, 0, 0), _scale(2, 1, 1))
+    m2 = _scale(1, -3, 1)
+    for v0, mtx, inv_diag in ((6, m1, (0.5, 1, 1)), (13, m2, (1, F32(1) / F32(-3), 1))):
+        assert np.array_equal(P[v0:v0 + 7], np.stack([_pt(mtx, v) for v in obj_p]))
+        assert np.allclose(N[v0:v0 + 7], obj_n * F32(inv_diag), rtol=1e-6, atol=0)                 # inverse transpose (transform.rs:244-253)
+        assert np.array_equal(S[v0:v0 + 7], obj_s * np.diag(mtx)[:3])
+        assert np.array_equal(UV[v0:v0 + 4], F32([[0, 0], [1, 0], [1, 1], [0, 1]]))
+    base = sd.TRI_HAS_N | sd.TRI_HAS_UV | sd.TRI_HAS_S
+    assert [int(f) for f in flags] == [0, 0, base, base, sd.TRI_FLIP, base | sd.TRI_FLIP, base | sd.TRI_FLIP, 0]   # the mirrored instance toggles the flip
+    assert np.array_equal(idx[2:5], [[6, 7, 8], [6, 8, 9], [10, 11, 12]]) and np.array_equal(idx[5:], [[13, 14, 15], [13, 15, 16], [17, 18, 19]])
+    assert (p.table("tri_light") == -1).all()
+
+
 @pytest.mark.parametrize("text, message", [
+    (HEADER + 'WorldBegin\nObjectInstance "nothing"\n' + TRI + "WorldEnd\n", "Unable to find instance named nothing"),
+    (HEADER + 'WorldBegin\nObjectBegin "a"\nObjectBegin "b"\nObjectEnd\nObjectEnd\n' + TRI + "WorldEnd\n", "inside of instance definition"),
+    (HEADER + 'WorldBegin\nObjectEnd\n' + TRI + "WorldEnd\n", "outside of instance definition"),
+    (HEADER + 'WorldBegin\nObjectBegin "a"\nAreaLightSource "diffuse"\n' + TRI + "ObjectEnd\nWorldEnd\n", "area lights inside an object definition"),
     ('Film "other"\n' + HEADER + "WorldBegin\n" + TRI + "WorldEnd\n", 'Film "other" unknown'),
     ('PixelFilter "sinc"\n' + HEADER + "WorldBegin\n" + TRI + "WorldEnd\n", 'Filter "sinc" unknown'),
     ('Camera "orthographic"\n' + HEADER + "WorldBegin\n" + TRI + "WorldEnd\n", 'Camera "orthographic" unknown'),
     ('Integrator "whitted"\n' + HEADER + "WorldBegin\n" + TRI + "WorldEnd\n", "not supported"),
     (HEADER + 'WorldBegin\nShape "sphere"\nWorldEnd\n', "not supported"),
-    (HEADER + 'WorldBegin\nObjectBegin "x"\nObjectEnd\n' + TRI + "WorldEnd\n", "instancing"),
     (HEADER + 'WorldBegin\nLightSource "spot"\n' + TRI + "WorldEnd\n", "not supported"),
     (HEADER + 'WorldBegin\nAreaLightSource "sphere"\n' + TRI + "WorldEnd\n", "unknown"),
     (HEADER + 'WorldBegin\nMakeNamedMaterial "m" "rgb Kd" [1 1 1]\n' + TRI + "WorldEnd\n", 'No parameter string "type"'),
