@@ -24,6 +24,7 @@ extern "C" {
 #define RT_ERR_NO_DEVICE (-2) /* no usable gfx950 device; there is NO CPU fallback  */
 #define RT_ERR_HIP (-3)       /* a HIP call failed; see rt_last_error()             */
 #define RT_ERR_OOM (-4)
+#define RT_ERR_UNSUPPORTED (-5) /* input the reference accepts and this backend does not  */
 
 /* -- flattened BVH node, 32 B: replaces LinearBVHNode (rc/bvh/mod.rs:582-598) ------------ */
 typedef struct rt_bvh_node {

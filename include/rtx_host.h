@@ -101,6 +101,11 @@ void rtxh_ply_free(rtxh_ply* ply);
  * the top of the image. rgb: width*height*3 floats owned by the library until rtxh_free. */
 int rtxh_pfm_read(const char* path, int32_t* width, int32_t* height, float** rgb);
 void rtxh_free(void* p);
+/* read_image (rc/imageio.rs:16-33): decoder by extension - png PNG tga TGA (8-bit RGB / 255 after the `image` crate's
+ * to_rgb8: palette and grey expanded, alpha dropped, 16-bit samples (c + 128) / 257; imageio.rs:94-112), hdr (Radiance
+ * RGBE, c * 2^(e - 136); imageio.rs:114-132), pfm (above). exr is refused (RT_ERR_UNSUPPORTED): the `exr` crate's
+ * decoder is not restated. Any other extension: "Unsupported file format", as the reference. Row 0 = top of the image. */
+int rtxh_image_read(const char* path, int32_t* width, int32_t* height, float** rgb);
 
 /* ---- pbrt-v3 scene description ----------------------------------------------------------
  * What `rustracer scene.pbrt` does before renderer::render: tokenise + parse (rc/pbrt/lexer.rs:185-275,

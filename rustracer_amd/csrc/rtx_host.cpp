@@ -921,5 +921,8 @@ int rtxh_pfm_read(const char* path, int32_t* width, int32_t* height, float** rgb
 }
 }  // extern "C"
 
+// PNG / TGA / Radiance HDR decoding
+#include "rtx_images.inl"
+
 // pbrt-v3 scene files -> rtxh_scene + rtxh_render_params
 #include "rtx_pbrt.inl"

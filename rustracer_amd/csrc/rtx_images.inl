@@ -1,0 +1,353 @@
+// rtx_images.inl — image files for textures and environment maps. Included by rtx_host.cpp.
+//
+// read_image (rc/imageio.rs:16-33) picks the decoder by file extension: tga / TGA / png / PNG -> the `image` crate
+// (0.24.2, png 0.17.5; absent from /root/reference, pinned by Cargo.lock) followed by `to_rgb8()` and c / 255
+// (imageio.rs:94-112); hdr -> image's HdrDecoder (non-strict) and Rgbe8Pixel::to_hdr (imageio.rs:114-132); pfm ->
+// read_image_pfm (rtxh_pfm_read above); exr -> the `exr` crate (1.4.2), not decoded here. The formats' published
+// definitions are restated below: RFC 1950 / 1951 (zlib, DEFLATE), the PNG specification (filters, Adam7, sample
+// expansion as png's EXPAND transformation does it), Truevision TGA 2.0 (types 1 2 3 9 10 11) and the Radiance RGBE
+// picture format (flat and new-style run-length scanlines). Row 0 of every result is the top of the image.
+
+namespace {
+
+struct Bytes {
+  const uint8_t* p; size_t n, pos = 0;
+  bool need(size_t k) const { return pos + k <= n; }
+  uint8_t u8() { return p[pos++]; }
+  uint32_t be32() { uint32_t v = (uint32_t)p[pos] << 24 | (uint32_t)p[pos + 1] << 16 | (uint32_t)p[pos + 2] << 8 | p[pos + 3]; pos += 4; return v; }
+  uint16_t le16() { uint16_t v = (uint16_t)(p[pos] | p[pos + 1] << 8); pos += 2; return v; }
+};
+
+bool read_whole_file(const char* path, std::vector<uint8_t>& out) {
+  FILE* f = fopen(path, "rb"); if (!f) return false;
+  uint8_t buf[65536]; size_t n; out.clear();
+  while ((n = fread(buf, 1, sizeof buf, f)) > 0) out.insert(out.end(), buf, buf + n);
+  fclose(f); return true;
+}
+
+// ------------------------------------------------------------------ DEFLATE (RFC 1951) inside a zlib stream (RFC 1950)
+struct Inflater {
+  const uint8_t* in; size_t n, pos = 0; uint32_t bitbuf = 0; int bitcnt = 0; std::vector<uint8_t>& out; const char* err = nullptr;
+  Inflater(const uint8_t* i, size_t nn, std::vector<uint8_t>& o) : in(i), n(nn), out(o) {}
+  int bits(int need) {
+    uint32_t v = bitbuf;
+    while (bitcnt < need) { if (pos >= n) { err = "deflate: out of input"; return 0; } v |= (uint32_t)in[pos++] << bitcnt; bitcnt += 8; }
+    bitbuf = need == 32 ? 0 : v >> need; bitcnt -= need;
+    return (int)(v & ((need == 32 ? 0 : (1u << need)) - 1u));
+  }
+  struct Huff { uint16_t count[16]; uint16_t symbol[288]; };
+  static bool build(Huff& h, const uint8_t* len, int n) {  // canonical code from code lengths (RFC 1951 §3.2.2)
+    memset(h.count, 0, sizeof h.count);
+    for (int s = 0; s < n; ++s) h.count[len[s]]++;
+    if (h.count[0] == n) return true;
+    int left = 1;
+    for (int l = 1; l < 16; ++l) { left <<= 1; left -= h.count[l]; if (left < 0) return false; }
+    uint16_t offs[16]; offs[1] = 0;
+    for (int l = 1; l < 15; ++l) offs[l + 1] = (uint16_t)(offs[l] + h.count[l]);
+    for (int s = 0; s < n; ++s) if (len[s]) h.symbol[offs[len[s]]++] = (uint16_t)s;
+    return true;
+  }
+  int decode(const Huff& h) {
+    int code = 0, first = 0, index = 0;
+    for (int l = 1; l < 16; ++l) {
+      code |= bits(1); if (err) return -1;
+      int c = h.count[l];
+      if (code - c < first) return h.symbol[index + (code - first)];
+      index += c; first += c; first <<= 1; code <<= 1;
+    }
+    err = "deflate: bad code"; return -1;
+  }
+  bool codes(const Huff& lit, const Huff& dist) {
+    static const uint16_t lbase[29] = {3, 4, 5, 6, 7, 8, 9, 10, 11, 13, 15, 17, 19, 23, 27, 31, 35, 43, 51, 59, 67, 83, 99, 115, 131, 163, 195, 227, 258};
+    static const uint16_t lext[29] = {0, 0, 0, 0, 0, 0, 0, 0, 1, 1, 1, 1, 2, 2, 2, 2, 3, 3, 3, 3, 4, 4, 4, 4, 5, 5, 5, 5, 0};
+    static const uint16_t dbase[30] = {1, 2, 3, 4, 5, 7, 9, 13, 17, 25, 33, 49, 65, 97, 129, 193, 257, 385, 513, 769, 1025, 1537, 2049, 3073, 4097, 6145, 8193, 12289, 16385, 24577};
+    static const uint16_t dext[30] = {0, 0, 0, 0, 1, 1, 2, 2, 3, 3, 4, 4, 5, 5, 6, 6, 7, 7, 8, 8, 9, 9, 10, 10, 11, 11, 12, 12, 13, 13};
+    for (;;) {
+      int sym = decode(lit); if (err) return false;
+      if (sym < 256) out.push_back((uint8_t)sym);
+      else if (sym == 256) return true;
+      else {
+        sym -= 257; if (sym >= 29) { err = "deflate: bad length symbol"; return false; }
+        int len = lbase[sym] + bits(lext[sym]);
+        int ds = decode(dist); if (err) return false;
+        if (ds >= 30) { err = "deflate: bad distance symbol"; return false; }
+        size_t d = (size_t)dbase[ds] + (size_t)bits(dext[ds]); if (err) return false;
+        if (d > out.size()) { err = "deflate: distance too far back"; return false; }
+        size_t from = out.size() - d;
+        for (int k = 0; k < len; ++k) out.push_back(out[from + k]);
+      }
+    }
+  }
+  bool run() {
+    for (;;) {
+      int last = bits(1), type = bits(2); if (err) return false;
+      if (type == 0) {
+        bitbuf = 0; bitcnt = 0;
+        if (pos + 4 > n) { err = "deflate: out of input"; return false; }
+        unsigned len = in[pos] | in[pos + 1] << 8, nlen = in[pos + 2] | in[pos + 3] << 8; pos += 4;
+        if (len != (~nlen & 0xffffu)) { err = "deflate: stored block length mismatch"; return false; }
+        if (pos + len > n) { err = "deflate: out of input"; return false; }
+        out.insert(out.end(), in + pos, in + pos + len); pos += len;
+      } else if (type == 1) {
+        uint8_t l[320]; Huff lit, dist;
+        for (int s = 0; s < 144; ++s) l[s] = 8; for (int s = 144; s < 256; ++s) l[s] = 9; for (int s = 256; s < 280; ++s) l[s] = 7; for (int s = 280; s < 288; ++s) l[s] = 8;
+        build(lit, l, 288);
+        for (int s = 0; s < 30; ++s) l[s] = 5;
+        build(dist, l, 30);
+        if (!codes(lit, dist)) return false;
+      } else if (type == 2) {
+        static const uint8_t order[19] = {16, 17, 18, 0, 8, 7, 9, 6, 10, 5, 11, 4, 12, 3, 13, 2, 14, 1, 15};
+        int nlen = bits(5) + 257, ndist = bits(5) + 1, ncode = bits(4) + 4; if (err) return false;
+        if (nlen > 286 || ndist > 30) { err = "deflate: too many codes"; return false; }
+        uint8_t l[320]; memset(l, 0, sizeof l);
+        for (int i = 0; i < ncode; ++i) l[order[i]] = (uint8_t)bits(3);
+        if (err) return false;
+        Huff lencode; if (!build(lencode, l, 19)) { err = "deflate: bad code lengths"; return false; }
+        uint8_t ll[320]; int idx = 0;
+        while (idx < nlen + ndist) {
+          int sym = decode(lencode); if (err) return false;
+          if (sym < 16) ll[idx++] = (uint8_t)sym;
+          else {
+            int prev = 0, rep;
+            if (sym == 16) { if (idx == 0) { err = "deflate: repeat without a previous length"; return false; } prev = ll[idx - 1]; rep = 3 + bits(2); }
+            else if (sym == 17) rep = 3 + bits(3); else rep = 11 + bits(7);
+            if (err) return false;
+            if (idx + rep > nlen + ndist) { err = "deflate: too many lengths"; return false; }
+            while (rep--) ll[idx++] = (uint8_t)prev;
+          }
+        }
+        if (ll[256] == 0) { err = "deflate: no end-of-block code"; return false; }
+        Huff lit, dist;
+        if (!build(lit, ll, nlen) || !build(dist, ll + nlen, ndist)) { err = "deflate: over-subscribed code"; return false; }
+        if (!codes(lit, dist)) return false;
+      } else { err = "deflate: reserved block type"; return false; }
+      if (last) return true;
+    }
+  }
+};
+
+bool zlib_inflate(const uint8_t* src, size_t n, std::vector<uint8_t>& out, std::string& err) {
+  if (n < 6) { err = "zlib: stream too short"; return false; }
+  if ((src[0] & 0x0f) != 8 || ((src[0] << 8 | src[1]) % 31) != 0 || (src[1] & 0x20)) { err = "zlib: bad header"; return false; }
+  Inflater z(src + 2, n - 2, out);
+  if (!z.run()) { err = z.err ? z.err : "deflate: error"; return false; }
+  size_t end = 2 + z.pos;
+  if (end + 4 > n) { err = "zlib: missing checksum"; return false; }
+  uint32_t a = 1, b = 0;
+  for (uint8_t c : out) { a = (a + c) % 65521u; b = (b + a) % 65521u; }
+  const uint32_t want = (uint32_t)src[end] << 24 | (uint32_t)src[end + 1] << 16 | (uint32_t)src[end + 2] << 8 | src[end + 3];
+  if (((b << 16) | a) != want) { err = "zlib: Adler-32 mismatch"; return false; }
+  return true;
+}
+
+uint32_t crc32_of(const uint8_t* p, size_t n) {
+  static uint32_t table[256]; static bool init = false;
+  if (!init) { for (uint32_t i = 0; i < 256; ++i) { uint32_t c = i; for (int k = 0; k < 8; ++k) c = c & 1 ? 0xedb88320u ^ (c >> 1) : c >> 1; table[i] = c; } init = true; }
+  uint32_t c = 0xffffffffu;
+  for (size_t i = 0; i < n; ++i) c = table[(c ^ p[i]) & 0xff] ^ (c >> 8);
+  return c ^ 0xffffffffu;
+}
+
+// ------------------------------------------------------------------ PNG -> RGB8 (png's EXPAND + image's to_rgb8)
+inline uint8_t sample16_to_8(unsigned c) { return (uint8_t)((c + 128u) / 257u); }  // image 0.24 FromPrimitive<u16> for u8
+bool png_decode(const std::vector<uint8_t>& file, int& W, int& H, std::vector<uint8_t>& rgb, std::string& err) {
+  static const uint8_t sig[8] = {137, 80, 78, 71, 13, 10, 26, 10};
+  if (file.size() < 8 || memcmp(file.data(), sig, 8) != 0) { err = "PNG: bad signature"; return false; }
+  Bytes b{file.data(), file.size(), 8};
+  uint32_t w = 0, h = 0; int depth = 0, ctype = -1, interlace = 0; bool have_ihdr = false, have_end = false;
+  std::vector<uint8_t> idat, plte;
+  while (!have_end) {
+    if (!b.need(8)) { err = "PNG: truncated chunk header"; return false; }
+    uint32_t len = b.be32(); const uint8_t* type = b.p + b.pos; b.pos += 4;
+    if (!b.need((size_t)len + 4)) { err = "PNG: truncated chunk"; return false; }
+    const uint8_t* data = b.p + b.pos; b.pos += len;
+    const uint32_t crc = b.be32();
+    if (crc32_of(type, (size_t)len + 4) != crc) { err = "PNG: chunk CRC mismatch"; return false; }
+    if (!memcmp(type, "IHDR", 4)) {
+      if (len != 13) { err = "PNG: bad IHDR"; return false; }
+      Bytes d{data, 13}; w = d.be32(); h = d.be32(); depth = d.u8(); ctype = d.u8();
+      if (d.u8() != 0 || d.u8() != 0) { err = "PNG: unknown compression / filter method"; return false; }
+      interlace = d.u8(); have_ihdr = true;
+      if (w == 0 || h == 0 || w > 65536 || h > 65536 || interlace > 1) { err = "PNG: bad dimensions"; return false; }
+      const bool ok = (ctype == 0 && (depth == 1 || depth == 2 || depth == 4 || depth == 8 || depth == 16)) || (ctype == 3 && (depth == 1 || depth == 2 || depth == 4 || depth == 8)) ||
+                      ((ctype == 2 || ctype == 4 || ctype == 6) && (depth == 8 || depth == 16));
+      if (!ok) { err = "PNG: invalid colour type / bit depth"; return false; }
+    } else if (!memcmp(type, "PLTE", 4)) plte.assign(data, data + len);
+    else if (!memcmp(type, "IDAT", 4)) idat.insert(idat.end(), data, data + len);
+    else if (!memcmp(type, "IEND", 4)) have_end = true;
+    else if (!(type[0] & 0x20)) { err = "PNG: unknown critical chunk"; return false; }
+  }
+  if (!have_ihdr || idat.empty()) { err = "PNG: missing IHDR / IDAT"; return false; }
+  if (ctype == 3 && (plte.empty() || plte.size() % 3)) { err = "PNG: missing palette"; return false; }
+  std::vector<uint8_t> raw; raw.reserve((size_t)w * h * 4 + h);
+  if (!zlib_inflate(idat.data(), idat.size(), raw, err)) return false;
+  const int channels = ctype == 0 ? 1 : ctype == 2 ? 3 : ctype == 3 ? 1 : ctype == 4 ? 2 : 4;
+  const int bits_pp = channels * depth, bpp = bits_pp >= 8 ? bits_pp / 8 : 1;
+  W = (int)w; H = (int)h; rgb.assign((size_t)w * h * 3, 0);
+  auto put = [&](uint32_t x, uint32_t y, const uint8_t* line, uint32_t i) {  // i-th pixel of an unfiltered scanline -> rgb[x, y]
+    uint8_t* o = &rgb[((size_t)y * w + x) * 3];
+    auto s8 = [&](int c) -> uint8_t { return depth == 16 ? sample16_to_8((unsigned)line[(i * channels + c) * 2] << 8 | line[(i * channels + c) * 2 + 1]) : line[i * channels + c]; };
+    if (ctype == 2 || ctype == 6) { o[0] = s8(0); o[1] = s8(1); o[2] = s8(2); return; }
+    if (ctype == 4) { o[0] = o[1] = o[2] = s8(0); return; }
+    unsigned v;
+    if (depth >= 8) v = s8(0);
+    else { const unsigned per = 8 / depth, byte = line[i / per], shift = (per - 1 - i % per) * depth; v = (byte >> shift) & ((1u << depth) - 1u); }
+    if (ctype == 3) { if (3 * v + 2 >= plte.size()) { o[0] = o[1] = o[2] = 0; return; } o[0] = plte[3 * v]; o[1] = plte[3 * v + 1]; o[2] = plte[3 * v + 2]; return; }
+    if (depth < 8) v = v * (255u / ((1u << depth) - 1u));  // png expand_gray_u8
+    o[0] = o[1] = o[2] = (uint8_t)v;
+  };
+  static const int xs[7] = {0, 4, 0, 2, 0, 1, 0}, ys[7] = {0, 0, 4, 0, 2, 0, 1}, dx[7] = {8, 8, 4, 4, 2, 2, 1}, dy[7] = {8, 8, 8, 4, 4, 2, 2};
+  size_t pos = 0;
+  for (int pass = 0; pass < (interlace ? 7 : 1); ++pass) {
+    const uint32_t pw = interlace ? (w > (uint32_t)xs[pass] ? (w - xs[pass] + dx[pass] - 1) / dx[pass] : 0) : w;
+    const uint32_t ph = interlace ? (h > (uint32_t)ys[pass] ? (h - ys[pass] + dy[pass] - 1) / dy[pass] : 0) : h;
+    if (pw == 0 || ph == 0) continue;
+    const size_t stride = ((size_t)pw * bits_pp + 7) / 8;
+    std::vector<uint8_t> prev(stride, 0), cur(stride);
+    for (uint32_t r = 0; r < ph; ++r) {
+      if (pos + 1 + stride > raw.size()) { err = "PNG: not enough image data"; return false; }
+      const int ft = raw[pos++];
+      memcpy(cur.data(), &raw[pos], stride); pos += stride;
+      for (size_t i = 0; i < stride; ++i) {  // PNG specification, 9.2 filter types
+        const int a = i >= (size_t)bpp ? cur[i - bpp] : 0, up = prev[i], c = i >= (size_t)bpp ? prev[i - bpp] : 0;
+        int add;
+        switch (ft) {
+          case 0: add = 0; break;
+          case 1: add = a; break;
+          case 2: add = up; break;
+          case 3: add = (a + up) >> 1; break;
+          case 4: { int p = a + up - c, pa = std::abs(p - a), pb = std::abs(p - up), pc = std::abs(p - c); add = (pa <= pb && pa <= pc) ? a : (pb <= pc ? up : c); break; }
+          default: err = "PNG: bad filter type"; return false;
+        }
+        cur[i] = (uint8_t)(cur[i] + add);
+      }
+      for (uint32_t i = 0; i < pw; ++i) put(interlace ? xs[pass] + i * dx[pass] : i, interlace ? ys[pass] + r * dy[pass] : r, cur.data(), i);
+      prev.swap(cur);
+    }
+  }
+  return true;
+}
+
+// ------------------------------------------------------------------ TGA -> RGB8 (image's TgaDecoder + to_rgb8)
+bool tga_decode(const std::vector<uint8_t>& file, int& W, int& H, std::vector<uint8_t>& rgb, std::string& err) {
+  if (file.size() < 18) { err = "TGA: truncated header"; return false; }
+  Bytes b{file.data(), file.size()};
+  const int id_len = b.u8(), map_type = b.u8(), type = b.u8();
+  const int map_first = b.le16(), map_len = b.le16(), map_bits = b.u8();
+  b.le16(); b.le16();
+  const int w = b.le16(), h = b.le16(), bits = b.u8(), desc = b.u8();
+  const bool rle = type & 8; const int base = type & 7;
+  if (w == 0 || h == 0) { err = "TGA: bad dimensions"; return false; }
+  if (base < 1 || base > 3 || type > 11) { err = "TGA: unsupported image type"; return false; }
+  if (base == 1 && (map_type != 1 || bits != 8 || (map_bits != 24 && map_bits != 32))) { err = "TGA: unsupported colour map"; return false; }
+  if (base == 2 && bits != 24 && bits != 32) { err = "TGA: unsupported pixel depth"; return false; }
+  if (base == 3 && bits != 8 && bits != 16) { err = "TGA: unsupported pixel depth"; return false; }
+  b.pos += id_len;
+  const int map_bytes = map_type == 1 ? map_bits / 8 : 0;
+  if (!b.need((size_t)map_len * map_bytes)) { err = "TGA: truncated colour map"; return false; }
+  const uint8_t* cmap = b.p + b.pos; b.pos += (size_t)map_len * map_bytes;
+  const int bytes = bits / 8; const size_t npx = (size_t)w * h;
+  std::vector<uint8_t> px(npx * bytes);
+  if (!rle) {
+    if (!b.need(px.size())) { err = "TGA: truncated image data"; return false; }
+    memcpy(px.data(), b.p + b.pos, px.size());
+  } else {
+    size_t o = 0;
+    while (o < npx) {
+      if (!b.need(1)) { err = "TGA: truncated run-length data"; return false; }
+      const int hd = b.u8(); const size_t cnt = (size_t)(hd & 0x7f) + 1;
+      if (o + cnt > npx) { err = "TGA: run past the end of the image"; return false; }
+      if (hd & 0x80) { if (!b.need(bytes)) { err = "TGA: truncated run-length data"; return false; } for (size_t k = 0; k < cnt; ++k) memcpy(&px[(o + k) * bytes], b.p + b.pos, bytes); b.pos += bytes; }
+      else { if (!b.need(cnt * bytes)) { err = "TGA: truncated run-length data"; return false; } memcpy(&px[o * bytes], b.p + b.pos, cnt * bytes); b.pos += cnt * bytes; }
+      o += cnt;
+    }
+  }
+  W = w; H = h; rgb.resize(npx * 3);
+  const bool top_origin = desc & 0x20, right_origin = desc & 0x10;
+  for (int y = 0; y < h; ++y) for (int x = 0; x < w; ++x) {
+    const uint8_t* s = &px[((size_t)y * w + x) * bytes];
+    uint8_t* o = &rgb[((size_t)(top_origin ? y : h - 1 - y) * w + (right_origin ? w - 1 - x : x)) * 3];
+    if (base == 3) { o[0] = o[1] = o[2] = s[0]; }
+    else if (base == 2) { o[0] = s[2]; o[1] = s[1]; o[2] = s[0]; }  // stored B G R (A)
+    else { const int i = (int)s[0] - map_first; if (i < 0 || i >= map_len) { o[0] = o[1] = o[2] = 0; } else { const uint8_t* c = cmap + (size_t)i * map_bytes; o[0] = c[2]; o[1] = c[1]; o[2] = c[0]; } }
+  }
+  return true;
+}
+
+// ------------------------------------------------------------------ Radiance .hdr -> float RGB (image's HdrDecoder, non-strict)
+bool hdr_decode(const std::vector<uint8_t>& file, int& W, int& H, std::vector<float>& rgb, std::string& err) {
+  size_t pos = 0;
+  auto line = [&](std::string& out) -> bool { out.clear(); if (pos >= file.size()) return false; while (pos < file.size() && file[pos] != '\n') out += (char)file[pos++]; if (pos < file.size()) ++pos; return true; };
+  std::string l;
+  if (!line(l) || (l.compare(0, 10, "#?RADIANCE") != 0 && l.compare(0, 6, "#?RGBE") != 0)) { err = "HDR: missing #?RADIANCE signature"; return false; }
+  bool have_format = false;
+  for (;;) { if (!line(l)) { err = "HDR: truncated header"; return false; } if (l.empty()) break; if (l.compare(0, 7, "FORMAT=") == 0) { have_format = true; if (l != "FORMAT=32-bit_rle_rgbe") { err = "HDR: unsupported FORMAT"; return false; } } }
+  (void)have_format;
+  if (!line(l)) { err = "HDR: missing resolution line"; return false; }
+  int h = 0, w = 0;
+  if (sscanf(l.c_str(), "-Y %d +X %d", &h, &w) != 2 || w <= 0 || h <= 0) { err = "HDR: unsupported orientation / resolution \"" + l + "\""; return false; }
+  W = w; H = h; rgb.assign((size_t)w * h * 3, 0.0f);
+  std::vector<uint8_t> scan((size_t)w * 4);
+  for (int y = 0; y < h; ++y) {
+    if (pos + 4 > file.size()) { err = "HDR: truncated scanline"; return false; }
+    const uint8_t* s = &file[pos];
+    if (w >= 8 && w < 32768 && s[0] == 2 && s[1] == 2 && (s[2] << 8 | s[3]) == w) {  // new-style RLE: the four components separately
+      pos += 4;
+      for (int c = 0; c < 4; ++c) {
+        int x = 0;
+        while (x < w) {
+          if (pos >= file.size()) { err = "HDR: truncated run-length data"; return false; }
+          int cnt = file[pos++];
+          if (cnt > 128) { cnt -= 128; if (pos >= file.size() || x + cnt > w) { err = "HDR: bad run"; return false; } const uint8_t v = file[pos++]; for (int k = 0; k < cnt; ++k) scan[(size_t)(x++) * 4 + c] = v; }
+          else { if (cnt == 0 || pos + cnt > file.size() || x + cnt > w) { err = "HDR: bad run"; return false; } for (int k = 0; k < cnt; ++k) scan[(size_t)(x++) * 4 + c] = file[pos++]; }
+        }
+      }
+    } else {  // flat (or old-style run-length: a pixel (1,1,1,n) repeats the previous one n << shift times)
+      int x = 0, shift = 0;
+      while (x < w) {
+        if (pos + 4 > file.size()) { err = "HDR: truncated scanline"; return false; }
+        const uint8_t* q = &file[pos]; pos += 4;
+        if (q[0] == 1 && q[1] == 1 && q[2] == 1 && x > 0) { int cnt = (int)q[3] << shift; if (x + cnt > w) { err = "HDR: bad run"; return false; } for (int k = 0; k < cnt; ++k, ++x) memcpy(&scan[(size_t)x * 4], &scan[(size_t)(x - 1) * 4], 4); shift += 8; }
+        else { memcpy(&scan[(size_t)x * 4], q, 4); ++x; shift = 0; }
+      }
+    }
+    for (int x = 0; x < w; ++x) {  // Rgbe8Pixel::to_hdr: 0 for e == 0, else c * 2^(e - 136)
+      const uint8_t* q = &scan[(size_t)x * 4]; float* o = &rgb[((size_t)y * w + x) * 3];
+      if (q[3] == 0) { o[0] = o[1] = o[2] = 0.0f; continue; }
+      const float e = std::exp2((float)q[3] - (128.0f + 8.0f));
+      o[0] = e * (float)q[0]; o[1] = e * (float)q[1]; o[2] = e * (float)q[2];
+    }
+  }
+  return true;
+}
+
+}  // namespace
+
+extern "C" int rtxh_image_read(const char* path, int32_t* width, int32_t* height, float** rgb) {
+  if (!path || !width || !height || !rgb) return fail(RT_ERR_INVALID, "null argument");
+  g_err.clear();
+  const std::string p = path; const size_t dot = p.find_last_of('.'), slash = p.find_last_of('/');
+  if (dot == std::string::npos || (slash != std::string::npos && dot < slash)) return fail(RT_ERR_INVALID, "Texture filename doesn't have an extension");  // imageio.rs:19-21
+  const std::string ext = p.substr(dot + 1);
+  if (ext == "pfm") return rtxh_pfm_read(path, width, height, rgb);
+  if (ext == "exr" || ext == "EXR") return fail(RT_ERR_UNSUPPORTED, "OpenEXR images are not decoded by this host layer (convert to .pfm or .hdr)");
+  const bool ldr = ext == "tga" || ext == "TGA" || ext == "png" || ext == "PNG";
+  if (!ldr && ext != "hdr") return fail(RT_ERR_INVALID, "Unsupported file format");  // imageio.rs:30-32
+  std::vector<uint8_t> file;
+  if (!read_whole_file(path, file)) return fail(RT_ERR_INVALID, std::string("cannot open ") + path);
+  int w = 0, h = 0; std::string err; std::vector<float> f;
+  if (ldr) {
+    std::vector<uint8_t> px;
+    // image::open sniffs the content first and falls back on the extension (TGA has no signature)
+    static const uint8_t png_sig[4] = {137, 80, 78, 71};
+    const bool is_png = file.size() >= 4 && memcmp(file.data(), png_sig, 4) == 0;
+    if (!(is_png ? png_decode(file, w, h, px, err) : tga_decode(file, w, h, px, err))) return fail(RT_ERR_INVALID, err + " (" + p + ")");
+    f.resize(px.size());
+    for (size_t i = 0; i < px.size(); ++i) f[i] = (float)px[i] / 255.0f;  // imageio.rs:104-106
+  } else if (!hdr_decode(file, w, h, f, err)) return fail(RT_ERR_INVALID, err + " (" + p + ")");
+  float* out = (float*)malloc(f.size() * sizeof(float));
+  if (!out) return fail(RT_ERR_INVALID, "out of memory");
+  memcpy(out, f.data(), f.size() * sizeof(float));
+  *width = w; *height = h; *rgb = out;
+  return RT_OK;
+}

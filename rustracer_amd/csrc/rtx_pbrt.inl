@@ -7,7 +7,7 @@
 // Supported: Identity Translate Scale Rotate LookAt Transform ConcatTransform CoordinateSystem CoordSysTransform, Camera
 // "perspective", Film "image", Sampler "02sequence"|"lowdiscrepancy", Integrator "path", PixelFilter box|triangle|gaussian|mitchell,
 // Accelerator "bvh", WorldBegin/End, Attribute/TransformBegin/End, ReverseOrientation, Shape trianglemesh|plymesh, Material,
-// MakeNamedMaterial, NamedMaterial, Texture (constant scale mix imagemap[pfm] checkerboard uv fbm), LightSource point|distant|infinite,
+// MakeNamedMaterial, NamedMaterial, Texture (constant scale mix imagemap checkerboard uv fbm), LightSource point|distant|infinite,
 // AreaLightSource diffuse|area, ObjectBegin/End, ObjectInstance (written out as world-space triangles), Include. Anything else the
 // reference implements but this backend does not (other shapes, other integrators / samplers, spectral parameter types) is an
 // error, never silently skipped.
@@ -179,12 +179,12 @@ struct PbrtLoader {
   std::string base_dir;
   std::string resolve(const std::string& f) const { return (!f.empty() && f[0] != '/' && !base_dir.empty()) ? base_dir + "/" + f : f; }
 
-  // image file -> MIP pyramid id. Only PFM is decoded here; like the reference on a failed read, anything else becomes a 1x1 grey
-  // texel (imagemap.rs:50-72) - with a warning, so that callers can refuse.
+  // image file -> MIP pyramid id (read_image, imageio.rs:16-33: png tga hdr pfm by extension). Like the reference, a failed read gives
+  // a 1x1 texel (grey for textures, imagemap.rs:62-69; the radiance itself for environment maps, infinite.rs:62-69) - with a warning.
   int load_mip(const std::string& file, bool flip_y, float scale, bool gamma, const float mul[3], bool to_float, int trilinear, float max_aniso, int wrap, bool grey_on_failure) {
     int32_t w = 0, h = 0; float* rgb = nullptr;
     std::vector<float> px;
-    if (!file.empty() && rtxh_pfm_read(resolve(file).c_str(), &w, &h, &rgb) == RT_OK) { px.assign(rgb, rgb + (size_t)w * h * 3); rtxh_free(rgb); }
+    if (!file.empty() && rtxh_image_read(resolve(file).c_str(), &w, &h, &rgb) == RT_OK) { px.assign(rgb, rgb + (size_t)w * h * 3); rtxh_free(rgb); }
     else { warn("image not readable: " + file); w = h = 1; if (grey_on_failure) px = {0.18f, 0.18f, 0.18f}; else px = {1.0f, 1.0f, 1.0f}; g_err.clear(); }
     if (flip_y)
       for (int y = 0; y < h / 2; ++y) for (int x = 0; x < w * 3; ++x) std::swap(px[(size_t)y * w * 3 + x], px[(size_t)(h - 1 - y) * w * 3 + x]);

@@ -104,3 +104,105 @@ def test_scene_from_ply_and_pfm_equals_the_in_memory_scene(ingest, host, orc, tm
     s1, s2 = SceneDesc(), SceneDesc()
     s1.add_mip(img); s2.add_pfm_mip(str(tmp_path / "t.pfm"))
     assert np.array_equal(s1.mipmaps[0].data, s2.mipmaps[0].data)
+
+
+# ------------------------------------------------------------------------------------------------ PNG / TGA / HDR (rc/imageio.rs:16-132)
+def _u16_to_u8(c):   # image 0.24 FromPrimitive<u16> for u8
+    return ((c.astype(np.uint32) + 128) // 257).astype(np.uint8)
+
+
+@pytest.mark.parametrize("color_type, depth", [(0, 1), (0, 2), (0, 4), (0, 8), (0, 16), (2, 8), (2, 16), (3, 1), (3, 2), (3, 4), (3, 8), (4, 8), (4, 16), (6, 8), (6, 16)])
+@pytest.mark.parametrize("interlace", [False, True])
+def test_png_every_colour_type_depth_filter_and_interlace(ingest, tmp_path, color_type, depth, interlace):
+    rng = np.random.default_rng(100 * color_type + depth + (7 if interlace else 0))
+    h, w = 13, 19   # odd sizes: partial bytes at low bit depths, ragged Adam7 passes
+    ch = {0: 1, 2: 3, 3: 1, 4: 2, 6: 4}[color_type]
+    palette = rng.integers(0, 256, (1 << depth, 3)).astype(np.uint8) if color_type == 3 else None
+    a = rng.integers(0, 1 << depth, (h, w, ch))
+    a[3:9, 2:15] = a[3, 2]   # flat region: long matches for the DEFLATE back-references
+    path = str(tmp_path / "t.png")
+    ingest.write_png(path, a, color_type, depth, palette=palette, interlace=interlace, idat_split=97)
+    got = ingest.read_image(path)
+    if color_type == 3:
+        want8 = palette[a[..., 0]]
+    else:
+        s = _u16_to_u8(a) if depth == 16 else (a * (255 // ((1 << depth) - 1))).astype(np.uint8) if depth < 8 else a.astype(np.uint8)
+        want8 = s[..., :3] if ch >= 3 else np.repeat(s[..., :1], 3, -1)   # to_rgb8: grey replicated, alpha dropped
+    assert got.shape == (h, w, 3) and np.array_equal(got, want8.astype(np.float32) / np.float32(255.0))
+
+
+@pytest.mark.parametrize("level", [0, 1, 9])
+def test_png_stored_fixed_and_dynamic_deflate_blocks(ingest, tmp_path, level):
+    rng = np.random.default_rng(level)
+    a = rng.integers(0, 256, (64, 80, 3))
+    a[:, 40:] = a[:, :40]                      # level 0: stored blocks; 1: mostly fixed codes; 9: dynamic codes with long matches
+    if level == 1:
+        a = a[:2, :3]                          # tiny image: zlib emits a fixed-Huffman block
+    path = str(tmp_path / "t.png")
+    ingest.write_png(path, a, 2, 8, filters=(0,), level=level)
+    assert np.array_equal(ingest.read_image(path), a.astype(np.float32) / np.float32(255.0))
+
+
+def test_png_ancillary_chunks_are_skipped_and_damage_is_reported(ingest, host, tmp_path):
+    a = np.arange(5 * 4 * 3).reshape(5, 4, 3) % 256
+    path = str(tmp_path / "t.png")
+    ingest.write_png(path, a, 2, 8, extra_chunks=((b"gAMA", (45455).to_bytes(4, "big")), (b"tEXt", b"Comment\0hello")))
+    assert np.array_equal(ingest.read_image(path), a.astype(np.float32) / np.float32(255.0))   # gamma chunks do not touch the samples
+    raw = bytearray(open(path, "rb").read())
+    bad = bytearray(raw); bad[-20] ^= 0x55
+    open(path, "wb").write(bad)
+    with pytest.raises(host.BackendError, match="CRC|Adler|deflate"):
+        ingest.read_image(path)
+    open(path, "wb").write(raw[:40])
+    with pytest.raises(host.BackendError, match="truncated|missing"):
+        ingest.read_image(path)
+    ingest.write_png(path, a, 2, 8, extra_chunks=((b"ABCD", b"critical"),))
+    with pytest.raises(host.BackendError, match="critical"):
+        ingest.read_image(path)
+
+
+@pytest.mark.parametrize("kind", ["rgb", "rgba", "grey", "mapped"])
+@pytest.mark.parametrize("rle", [False, True])
+@pytest.mark.parametrize("top_origin", [False, True])
+def test_tga_types_origins_and_run_lengths(ingest, tmp_path, kind, rle, top_origin):
+    rng = np.random.default_rng(3)
+    h, w = 9, 14
+    palette = rng.integers(0, 256, (32, 3)).astype(np.uint8) if kind == "mapped" else None
+    if kind in ("rgb", "rgba"):
+        a = rng.integers(0, 256, (h, w, 3 if kind == "rgb" else 4)).astype(np.uint8)
+        a[2:5] = a[2, 0]          # runs that cross scanlines
+        want = a[..., :3]
+    else:
+        a = rng.integers(0, 32, (h, w)).astype(np.uint8)
+        a[2:5] = 7
+        want = palette[a] if kind == "mapped" else np.repeat(a[..., None], 3, -1)
+    path = str(tmp_path / "t.tga")
+    ingest.write_tga(path, a, kind, rle=rle, top_origin=top_origin, palette=palette, id_field=b"id!")
+    assert np.array_equal(ingest.read_image(path), want.astype(np.float32) / np.float32(255.0))
+
+
+@pytest.mark.parametrize("rle", [False, True])
+def test_radiance_hdr(ingest, tmp_path, rle):
+    rng = np.random.default_rng(11)
+    h, w = 6, 40
+    a = rng.integers(0, 256, (h, w, 4)).astype(np.uint8)
+    a[..., 3] = rng.integers(120, 140, (h, w))
+    a[2, 5:30] = a[2, 5]          # runs
+    a[4, 3] = (9, 9, 9, 0)        # exponent 0 -> black
+    path = str(tmp_path / "t.hdr")
+    ingest.write_hdr(path, a, rle=rle)
+    e = np.exp2(a[..., 3:].astype(np.float32) - np.float32(136.0))
+    want = np.where(a[..., 3:] == 0, np.float32(0), e * a[..., :3].astype(np.float32)).astype(np.float32)   # Rgbe8Pixel::to_hdr
+    assert np.array_equal(ingest.read_image(path), want)
+
+
+def test_read_image_extension_rules(ingest, host, tmp_path):
+    # imageio.rs:19-32: no extension / unknown extension are errors; exr is refused by this host layer, loudly
+    for name, msg in (("noext", "doesn't have an extension"), ("x.jpg", "Unsupported file format"), ("x.exr", "OpenEXR"), ("missing.png", "cannot open")):
+        with pytest.raises(host.BackendError, match=msg):
+            ingest.read_image(str(tmp_path / name))
+    a = np.full((2, 2, 3), 200, np.uint8)
+    ingest.write_png(str(tmp_path / "upper.PNG"), a, 2, 8)
+    assert ingest.read_image(str(tmp_path / "upper.PNG"))[0, 0, 0] == np.float32(200) / np.float32(255)
+    ingest.write_pfm(str(tmp_path / "f.pfm"), a.astype(np.float32))
+    assert np.array_equal(ingest.read_image(str(tmp_path / "f.pfm")), a.astype(np.float32))

@@ -394,6 +394,20 @@ def test_include_and_plymesh_and_imagemap(tmp_path):
     assert q.n_warnings == 1 and np.array_equal(q.mip_levels(0)[0], np.full((1, 1, 3), 0.18, F32))
 
 
+def test_png_imagemap_is_gamma_decoded_by_default(tmp_path):
+    from rustracer_amd.ingest import write_png
+    a = np.random.default_rng(2).integers(0, 256, (4, 4, 3))
+    write_png(os.path.join(str(tmp_path), "t.png"), a, 2, 8)
+    base = HEADER + 'WorldBegin\nTexture "img" "spectrum" "imagemap" "string filename" "t.png" %s\nMaterial "matte" "texture Kd" "img"\n' + TRI + "WorldEnd\n"
+    v = (a.astype(F32) / F32(255))[::-1]
+    lin = np.where(v <= F32(0.04045), v / F32(12.92), ((v + F32(0.055)) * F32(1.0) / F32(1.055)) ** F32(2.4)).astype(F32)   # spectrum.rs:379-385
+    assert np.allclose(_parse(base % "", tmp_path).mip_levels(0)[0], lin, rtol=3e-7, atol=0)          # gamma defaults to true for png / tga (imagemap.rs:124-127)
+    assert np.array_equal(_parse(base % '"bool gamma" "false"', tmp_path).mip_levels(0)[0], v)
+    f = _parse((base % '"float scale" [2]').replace('"spectrum"', '"float"').replace('"texture Kd" "img"', '"texture sigma" "img"'), tmp_path).mip_levels(0)[0]
+    y = F32(2) * lin
+    assert np.allclose(f[..., 0], F32(0.212671) * y[..., 0] + F32(0.715160) * y[..., 1] + F32(0.072169) * y[..., 2], rtol=1e-6)   # float maps keep y() (imagemap.rs:214-216)
+
+
 def test_infinite_light_texels_carry_the_scale(tmp_path):
     from rustracer_amd.ingest import write_pfm
     img = np.random.default_rng(9).random((8, 16, 3), dtype=F32)
