@@ -179,6 +179,16 @@ typedef struct rt_scene rt_scene;
 int rt_scene_create(const rt_scene_desc* desc, int device, rt_scene** out);
 void rt_scene_destroy(rt_scene* scene);
 
+/* BVH::new (rc/bvh/mod.rs:80-135) on the device, for callers that want the tree in milliseconds rather than the best
+ * tree: a linear BVH (63-bit Morton order of the centroids, one radix sort, boxes fitted bottom-up), leaves of up to
+ * max_prims_per_node triangles, written in the layout flatten_bvh gives (rc/bvh/mod.rs:314-358: pre-order, first child
+ * = i + 1, `offset` = second child, `axis` = the axis the children are ordered along). The SAH tree of the host layer
+ * traces faster and is what parity on node / triangle counts refers to; closest hits do not depend on the builder.
+ * tri_p: n_tris x 9 floats, world space, host memory. nodes: room for 2 * n_tris - 1 records. ordered: n_tris source
+ * triangle indices in leaf order. RT_ERR_UNSUPPORTED if the tree needs more than the 64-entry traversal stack. */
+int rt_bvh_build(const float* tri_p, uint32_t n_tris, int32_t max_prims_per_node, rt_bvh_node* nodes, uint32_t* n_nodes, int32_t* ordered,
+                 float* ms_device /* may be NULL */);
+
 /* Renders one frame: the body of renderer::render (rc/renderer.rs:22-143) — preprocess (light
  * distribution), per-pixel sampler tables, camera rays, PathIntegrator::li for every sample,
  * radiance scrubbing and Film::add_sample/merge. Blocking. film_xyzw: W*H*4 floats over the

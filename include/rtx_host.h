@@ -52,6 +52,9 @@ int rtxh_scene_add_light(rtxh_scene*, int32_t kind, int32_t tri, const float* rg
                          const float* l2w16, const float* w2l16);
 /* BVH::create(prims, "sah", maxnodeprims) + Scene::new; flattens everything into an rt_scene_desc. */
 int rtxh_scene_commit(rtxh_scene*, int32_t max_prims_per_node);
+/* Same, with the tree built on the GPU by rt_bvh_build (linear BVH: milliseconds instead of seconds for 10^6
+ * triangles, more node visits per ray afterwards; rtx_hip.h). Fails without a GPU. ms_device (may be NULL): kernel time. */
+int rtxh_scene_commit_device_bvh(rtxh_scene*, int32_t max_prims_per_node, float* ms_device);
 /* Uploads the flattened scene to the current HIP device (rt_scene_create). Fails without a GPU. */
 int rtxh_scene_upload(rtxh_scene*, int32_t device);
 

@@ -301,6 +301,8 @@ extern "C" int rt_scene_create(const rt_scene_desc* desc, int device, rt_scene**
   return RT_OK;
 }
 
+#include "rtx_bvh_build.h"
+
 extern "C" void rt_scene_destroy(rt_scene* s) {
   if (!s) return;
   (void)hipSetDevice(s->device);

@@ -285,6 +285,8 @@ struct Builder {
   }
 };
 
+int finish_commit(rtxh_scene* s);
+
 int commit_scene(rtxh_scene* s, int max_prims_per_node) {
   const size_t nt = s->n_tris();
   if (nt == 0) return fail(RT_ERR_INVALID, "no triangles");
@@ -353,6 +355,25 @@ int commit_scene(rtxh_scene* s, int max_prims_per_node) {
     s->nodes.push_back(out);
     if (n.count == 0) { st.push_back({n.right, me}); st.push_back({n.left, -1}); }
   }
+  return finish_commit(s);
+}
+
+// BVH by the device's linear builder (rt_bvh_build) instead of the SAH recursion above; everything after the tree is shared
+int commit_scene_device(rtxh_scene* s, int max_prims_per_node, float* ms_device) {
+  const size_t nt = s->n_tris();
+  if (nt == 0) return fail(RT_ERR_INVALID, "no triangles");
+  std::vector<float> tp(nt * 9);
+  for (size_t t = 0; t < nt; ++t) for (int v = 0; v < 3; ++v) for (int k = 0; k < 3; ++k) tp[9 * t + 3 * v + k] = s->P[3 * s->idx[3 * t + v] + k];
+  s->nodes.assign(2 * nt - 1, rt_bvh_node{}); s->ordered.assign(nt, -1);
+  uint32_t n_nodes = 0;
+  const int rc = rt_bvh_build(tp.data(), (uint32_t)nt, max_prims_per_node, s->nodes.data(), &n_nodes, s->ordered.data(), ms_device);
+  if (rc != RT_OK) { s->nodes.clear(); s->ordered.clear(); g_err.clear(); return rc; }
+  s->nodes.resize(n_nodes);
+  return finish_commit(s);
+}
+
+int finish_commit(rtxh_scene* s) {
+  const size_t nt = s->n_tris();
   // world bounding sphere for distant / infinite lights (Scene::new -> Light::preprocess, scene.rs:29-49; bounds.rs:199-212)
   const rt_bvh_node& r0 = s->nodes[0];
   float c[3] = {(r0.bmin[0] + r0.bmax[0]) / 2.0f, (r0.bmin[1] + r0.bmax[1]) / 2.0f, (r0.bmin[2] + r0.bmax[2]) / 2.0f};
@@ -633,6 +654,7 @@ int rtxh_scene_add_light(rtxh_scene* s, int32_t kind, int32_t tri, const float* 
 }
 
 int rtxh_scene_commit(rtxh_scene* s, int32_t max_prims_per_node) { if (!s) return fail(RT_ERR_INVALID, "null scene"); g_err.clear(); return commit_scene(s, max_prims_per_node); }
+int rtxh_scene_commit_device_bvh(rtxh_scene* s, int32_t max_prims_per_node, float* ms_device) { if (!s) return fail(RT_ERR_INVALID, "null scene"); g_err.clear(); return commit_scene_device(s, max_prims_per_node, ms_device); }
 
 int rtxh_scene_upload(rtxh_scene* s, int32_t device) {
   if (!s || !s->committed) return fail(RT_ERR_INVALID, "scene not committed");

@@ -136,7 +136,8 @@ def render_params(desc, rank=0, world_size=1, flags=0) -> RenderParams:
 
 
 class HostScene:
-    def __init__(self, desc):
+    def __init__(self, desc, device_bvh=False):
+        """device_bvh=True: the tree comes from the GPU's linear builder (rt_bvh_build) instead of the host SAH build."""
         L = lib()
         self.desc = desc
         self.h = C.c_void_p(L.rtxh_scene_new())
@@ -155,7 +156,13 @@ class HostScene:
             l2w = None if l.l2w is None else np.ascontiguousarray(l.l2w, np.float32)
             w2l = None if l.w2l is None else np.ascontiguousarray(l.w2l, np.float32)
             _check(L.rtxh_scene_add_light(self.h, l.kind, l.tri, _p(np.float32(l.rgb)), int(l.two_sided), _p(np.float32(l.vec)), l.mip, _p(l2w), _p(w2l)), "add_light")
-        _check(L.rtxh_scene_commit(self.h, desc.max_prims_per_node), "commit")
+        self.bvh_build_ms = None
+        if device_bvh:
+            ms = C.c_float()
+            _check(L.rtxh_scene_commit_device_bvh(self.h, desc.max_prims_per_node, C.byref(ms)), "commit_device_bvh")
+            self.bvh_build_ms = ms.value
+        else:
+            _check(L.rtxh_scene_commit(self.h, desc.max_prims_per_node), "commit")
 
     def __del__(self):
         try:
