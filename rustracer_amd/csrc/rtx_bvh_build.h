@@ -105,17 +105,18 @@ __global__ void k_lbvh_hierarchy(const unsigned long long* __restrict__ keys, in
 
 struct LbvhBox { float lo[3], hi[3]; };
 
-// bottom-up: boxes, and the size (node count) of each subtree once ranges of <= max_prims triangles are single leaves.
+// bottom-up: boxes, leaf-or-split decisions, and the size (node count) of each subtree after them.
 // The second thread to arrive at a node owns it (its sibling's results are visible after the fence).
 __global__ void k_lbvh_refit(const float* __restrict__ tri_p, const unsigned* __restrict__ order, int n, int max_prims, LbvhNode* __restrict__ nodes,
                              const int* __restrict__ leaf_parent, LbvhBox* __restrict__ boxes /* 2n-1: internal then leaves */, int* __restrict__ sizes /* n-1 */,
-                             unsigned char* __restrict__ axis /* n-1 */, unsigned* __restrict__ visits) {
+                             unsigned char* __restrict__ axis /* n-1: bits 0-1 axis, 4 = children swapped, 8 = collapsed into a leaf */, float* __restrict__ costs /* 2n-1 */,
+                             unsigned* __restrict__ visits) {
   const int t = blockIdx.x * blockDim.x + threadIdx.x;
   if (t >= n) return;
   const float* p = tri_p + 9ull * order[t];
   LbvhBox b;
   for (int a = 0; a < 3; ++a) { b.lo[a] = fminf(p[a], fminf(p[3 + a], p[6 + a])); b.hi[a] = fmaxf(p[a], fmaxf(p[3 + a], p[6 + a])); }
-  boxes[(n - 1) + t] = b;
+  boxes[(n - 1) + t] = b; costs[(n - 1) + t] = 1.0f;
   __threadfence();
   int node = leaf_parent[t];
   while (node >= 0) {
@@ -129,10 +130,16 @@ __global__ void k_lbvh_refit(const float* __restrict__ tri_p, const unsigned* __
     // traversal order: the axis along which the children's box centres are furthest apart; `swap` when the first child is the far one
     float best = -1.0f; int ax = 0; bool swap = false;
     for (int a = 0; a < 3; ++a) { const float dl = (l.lo[a] + l.hi[a]) - (r.lo[a] + r.hi[a]); if (fabsf(dl) > best) { best = fabsf(dl); ax = a; swap = dl > 0.0f; } }
-    axis[node] = (unsigned char)(ax | (swap ? 4 : 0));
+    // leaf or split by the reference's cost model (bvh/mod.rs:233-265): n against 1 + (A_l c_l + A_r c_r) / A, decided bottom-up
     const int count = nd.last - nd.first + 1;
+    auto area = [](const LbvhBox& x) { const float dx = x.hi[0] - x.lo[0], dy = x.hi[1] - x.lo[1], dz = x.hi[2] - x.lo[2]; return 2.0f * (dx * dy + dx * dz + dy * dz); };
+    const float au = area(u);
+    const float split_cost = au > 0.0f ? 1.0f + (area(l) * costs[nd.left] + area(r) * costs[nd.right]) / au : 3.402823466e38f;
+    const bool collapse = count <= max_prims && (float)count <= split_cost;
+    costs[node] = collapse ? (float)count : split_cost;
+    axis[node] = (unsigned char)(ax | (swap ? 4 : 0) | (collapse ? 8 : 0));
     const int sl = nd.left >= n - 1 ? 1 : sizes[nd.left], sr = nd.right >= n - 1 ? 1 : sizes[nd.right];
-    sizes[node] = count <= max_prims ? 1 : 1 + sl + sr;
+    sizes[node] = collapse ? 1 : 1 + sl + sr;
     __threadfence();
     node = nd.parent;
   }
@@ -146,10 +153,11 @@ __global__ void k_lbvh_emit(int n, int max_prims, const LbvhNode* __restrict__ n
   const bool is_leaf = t >= n - 1;
   const int parent = is_leaf ? leaf_parent[t - (n - 1)] : nodes[t].parent;
   const int count = is_leaf ? 1 : nodes[t].last - nodes[t].first + 1;
-  if (parent >= 0 && nodes[parent].last - nodes[parent].first + 1 <= max_prims) return;  // inside a collapsed range
+  const bool leaf_out = is_leaf || (axis[t] & 8);
   int slot = 0, depth = 0, child = t, p = parent;
   while (p >= 0) {
     const LbvhNode nd = nodes[p];
+    if (axis[p] & 8) return;  // inside a collapsed range
     const bool swap = axis[p] & 4;
     const int first = swap ? nd.right : nd.left;
     if (child == first) slot += 1;
@@ -160,7 +168,7 @@ __global__ void k_lbvh_emit(int n, int max_prims, const LbvhNode* __restrict__ n
   const LbvhBox b = boxes[t];
   for (int a = 0; a < 3; ++a) { o.bmin[a] = b.lo[a]; o.bmax[a] = b.hi[a]; }
   o.pad = 0;
-  if (count <= max_prims) { o.offset = (unsigned)(is_leaf ? t - (n - 1) : nodes[t].first); o.n_prims = (unsigned short)count; o.axis = 0; }
+  if (leaf_out) { o.offset = (unsigned)(is_leaf ? t - (n - 1) : nodes[t].first); o.n_prims = (unsigned short)count; o.axis = 0; }
   else {
     const bool swap = axis[t] & 4;
     const int first = swap ? nodes[t].right : nodes[t].left;
@@ -187,11 +195,11 @@ extern "C" int rt_bvh_build(const float* tri_p, uint32_t n_tris, int32_t max_pri
     o.n_prims = 1; nodes[0] = o; *n_nodes = 1; ordered[0] = 0; if (ms_device) *ms_device = 0.0f;
     return RT_OK;
   }
-  DevBuf d_p, d_cb, d_keys, d_vals, d_keys2, d_vals2, d_tmp, d_nodes, d_lpar, d_boxes, d_sizes, d_axis, d_visits, d_out, d_depth;
+  DevBuf d_p, d_cb, d_keys, d_vals, d_keys2, d_vals2, d_tmp, d_nodes, d_lpar, d_boxes, d_sizes, d_axis, d_costs, d_visits, d_out, d_depth;
   HIP_TRY(d_p.ensure((size_t)n * 36)); HIP_TRY(hipMemcpy(d_p.p, tri_p, (size_t)n * 36, hipMemcpyHostToDevice));
   HIP_TRY(d_cb.ensure(24)); HIP_TRY(d_keys.ensure((size_t)n * 8)); HIP_TRY(d_vals.ensure((size_t)n * 4)); HIP_TRY(d_keys2.ensure((size_t)n * 8)); HIP_TRY(d_vals2.ensure((size_t)n * 4));
   HIP_TRY(d_nodes.ensure((size_t)(n - 1) * sizeof(LbvhNode))); HIP_TRY(d_lpar.ensure((size_t)n * 4)); HIP_TRY(d_boxes.ensure((size_t)(2 * n - 1) * sizeof(LbvhBox)));
-  HIP_TRY(d_sizes.ensure((size_t)(n - 1) * 4)); HIP_TRY(d_axis.ensure((size_t)(n - 1))); HIP_TRY(d_visits.ensure((size_t)(n - 1) * 4));
+  HIP_TRY(d_sizes.ensure((size_t)(n - 1) * 4)); HIP_TRY(d_axis.ensure((size_t)(n - 1))); HIP_TRY(d_visits.ensure((size_t)(n - 1) * 4)); HIP_TRY(d_costs.ensure((size_t)(2 * n - 1) * 4));
   HIP_TRY(d_out.ensure((size_t)(2 * n - 1) * sizeof(rt_bvh_node))); HIP_TRY(d_depth.ensure(4));
   hipEvent_t e0, e1; HIP_TRY(hipEventCreate(&e0)); HIP_TRY(hipEventCreate(&e1));
   HIP_TRY(hipEventRecord(e0, 0));
@@ -207,7 +215,7 @@ extern "C" int rt_bvh_build(const float* tri_p, uint32_t n_tris, int32_t max_pri
   HIP_TRY(hipcub::DeviceRadixSort::SortPairs(d_tmp.p, tmp_bytes, d_keys.as<unsigned long long>(), d_keys2.as<unsigned long long>(), d_vals.as<unsigned>(), d_vals2.as<unsigned>(), n, 0, 63, 0));
   k_lbvh_hierarchy<<<blocks, 256, 0, 0>>>(d_keys2.as<unsigned long long>(), n, d_nodes.as<LbvhNode>(), d_lpar.as<int>());
   k_lbvh_refit<<<blocks, 256, 0, 0>>>(d_p.as<float>(), d_vals2.as<unsigned>(), n, max_prims, d_nodes.as<LbvhNode>(), d_lpar.as<int>(), d_boxes.as<LbvhBox>(), d_sizes.as<int>(),
-                                      d_axis.as<unsigned char>(), d_visits.as<unsigned>());
+                                      d_axis.as<unsigned char>(), d_costs.as<float>(), d_visits.as<unsigned>());
   k_lbvh_emit<<<(unsigned)((2 * n - 1 + 255) / 256), 256, 0, 0>>>(n, max_prims, d_nodes.as<LbvhNode>(), d_lpar.as<int>(), d_boxes.as<LbvhBox>(), d_sizes.as<int>(), d_axis.as<unsigned char>(),
                                                                    d_out.as<rt_bvh_node>(), d_depth.as<int>());
   HIP_TRY(hipEventRecord(e1, 0));
