@@ -365,3 +365,14 @@ def film_to_rgb(film_xyzw: np.ndarray, scale: float = 1.0) -> np.ndarray:
     inv = np.where(nz, c(1.0) / np.where(nz, Wt, c(1.0)), c(1.0)).astype(np.float32)
     rgb = np.where(nz[..., None], np.maximum(c(0.0), rgb * inv[..., None]), rgb)
     return (rgb * c(scale)).astype(np.float32)
+
+
+def rgb_to_png8(rgb: np.ndarray) -> np.ndarray:
+    """write_image_png's quantisation (rc/imageio.rs:52-63): clamp(255 * gamma_correct(v) + 0.5, 0, 255) as u8, sRGB curve of
+    rc/spectrum.rs:387-393."""
+    v = np.asarray(rgb, np.float32)
+    c = np.float32
+    with np.errstate(invalid="ignore"):
+        g = np.where(v <= c(0.0031308), c(12.92) * v, c(1.055) * np.power(np.maximum(v, c(0.0)), c(1.0) / c(2.4), dtype=np.float32) - c(0.055)).astype(np.float32)
+    q = np.clip(c(255.0) * g + c(0.5), c(0.0), c(255.0))
+    return np.nan_to_num(q, nan=0.0).astype(np.uint8)   # Rust's `as u8` maps NaN to 0

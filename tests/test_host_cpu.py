@@ -185,3 +185,16 @@ def test_mip_of_a_non_power_of_two_image_is_resampled_like_the_reference(orc, ho
 def test_round_up_pow2_reference_kat(orc):
     assert orc.round_up_pow2(1023) == 1024 and orc.round_up_pow2(1024) == 1024  # rc/lib.rs:341-345
     assert [orc.round_up_pow2(v) for v in (1, 2, 3, 5, 17, 1025)] == [1, 2, 4, 8, 32, 2048]
+
+
+def test_png8_quantisation_matches_write_image_png(host):
+    # rc/imageio.rs:59-62 with rc/spectrum.rs:387-393, value by value in Python floats rounded to f32 at each step
+    v = np.array([-1.0, 0.0, 0.001, 0.0031308, 0.0031309, 0.18, 0.5, 1.0, 1.5, np.nan, np.inf], np.float32)
+    want = []
+    for x in v:
+        if np.isnan(x):
+            want.append(0); continue
+        g = np.float32(12.92) * x if x <= np.float32(0.0031308) else np.float32(1.055) * np.float32(np.power(np.float32(x), np.float32(1.0) / np.float32(2.4))) - np.float32(0.055)
+        want.append(int(min(max(np.float32(255.0) * np.float32(g) + np.float32(0.5), 0.0), 255.0)))
+    assert host.rgb_to_png8(v).tolist() == want
+    assert want[:2] == [0, 0] and want[7:9] == [255, 255] and want[5] == 118
