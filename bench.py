@@ -33,6 +33,7 @@ def main():
     ap.add_argument("--spp", type=int, default=0, help="0 = the BASELINE spp of the scene (cornell 1024, blob 256, mis 512, room 1024)")
     ap.add_argument("--cpu-spp", type=int, default=32, help="spp of the bounded CPU-baseline sample")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--pbrt", default=None, help="render this pbrt-v3 scene file instead of a generated scene (read by the C++ host's parser; no CPU baseline)")
     args = ap.parse_args()
 
     import numpy as np
@@ -56,7 +57,15 @@ def main():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
 
-    if args.scene == "cornell":
+    desc = None
+    if args.pbrt:
+        scene = host.PbrtScene(args.pbrt)
+        if args.spp:
+            scene.params.spp = args.spp
+        args.spp, args.scene = scene.params.spp, "pbrt"
+        workload = (f"{os.path.basename(args.pbrt)} ({len(scene.table('indices'))} triangles, {scene.n_lights()} lights) {scene.params.xres}x{scene.params.yres} "
+                    f"PathIntegrator maxdepth={scene.params.max_depth} {args.spp}spp 02sequence")
+    elif args.scene == "cornell":
         args.spp = args.spp or 1024
         desc = cornell_box(args.res, args.res, args.spp)
         workload = f"cornell-box (synthetic S1, 32 triangles, 2 area lights) {args.res}x{args.res} PathIntegrator maxdepth=5 {args.spp}spp 02sequence box-filter"
@@ -66,7 +75,8 @@ def main():
         desc = gen(spp=args.spp)
         workload = (f"{desc.name} (synthetic, {desc.n_tris} triangles, {len(desc.lights)} lights) {desc.film.xres}x{desc.film.yres} "
                     f"PathIntegrator maxdepth={desc.integrator.max_depth} {args.spp}spp 02sequence box-filter")
-    scene = host.HostScene(desc)
+    if desc is not None:
+        scene = host.HostScene(desc)
     scene.upload(local_rank)
     st0 = scene.setup()
     cr = st0["cropped"]
@@ -151,7 +161,7 @@ def main():
             "roofline": roofline,
             "roofline_second_kernel": roofline_other,
         }
-        if n_gpus == 1 and not args.no_cpu_baseline:
+        if n_gpus == 1 and not args.no_cpu_baseline and desc is not None:
             out["cpu_baseline"] = cpu_baseline(desc, args)
             out["speedup_vs_cpu_baseline"] = round(value / out["cpu_baseline"]["value"], 1)
         print(json.dumps(out), flush=True)
