@@ -23,3 +23,15 @@ for t in d.textures:
     if t.kind == sd.TEX_IMAGE:
         t.kind = sd.TEX_CONST; t.value = (0.5, 0.4, 0.3); t.mip = -1
 run("const", d)
+for m in d.materials:
+    if m.kind != sd.MAT_MIX:
+        kd = m.params.get("kd", d.const_tex((0.5, 0.5, 0.5)))
+        m.kind, m.params, m.bump = sd.MAT_MATTE, {"kd": kd if d.textures[kd].kind == sd.TEX_CONST else d.const_tex((0.5, 0.5, 0.5)), "sigma": d.const_tex(0.0)}, -1
+for m in d.materials:
+    if m.kind == sd.MAT_MIX:
+        m.kind, m.params = sd.MAT_MATTE, {"kd": d.const_tex((0.5, 0.5, 0.5)), "sigma": d.const_tex(0.0)}
+run("all matte", d)
+for i, l in enumerate(d.lights):
+    if l.kind == sd.LIGHT_INFINITE:
+        d.lights[i] = sd.Light(sd.LIGHT_POINT, rgb=(30.0, 30.0, 30.0), vec=(0.5, 2.0, 0.5))
+run("matte+point", d)
