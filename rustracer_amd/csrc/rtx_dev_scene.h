@@ -16,7 +16,7 @@ struct DImage {
   int n_levels; int w[16], h[16]; unsigned long long off[16];
   const float* texels; int trilinear; float max_aniso; int wrap;
 };
-struct DMaterial { int kind; int slot[16]; int remap; int bump; };
+struct DMaterial { int kind; int slot[16]; int remap; int bump; int code_class; };  // code_class: materials that run the same shading code share one (host: material_code_classes)
 struct DLight {
   int kind; int prim; float rgb[3]; int two_sided; float vec[3]; float area; float world_radius; int image;
   float l2w[12], w2l[12];

@@ -8,6 +8,8 @@
 #include <cstring>
 #include <string>
 #include <vector>
+#include <functional>
+#include <map>
 
 #include "../../include/rtx_hip.h"
 #include "rtx_kernels.h"
@@ -59,7 +61,7 @@ struct rt_scene {
   DevBuf ws[32];
   DevBuf film_acc, own_acc, film_out, counters, stats, filter_table;
   DevBuf bin_words, bin_sorted;  // material binning of the shade queue (generic shade path)
-  unsigned n_materials = 0;
+  unsigned n_materials = 0, n_code_classes = 0;
   // sampler tables are double-buffered: K0 of batch b+1 runs on aux_stream under the path kernels of batch b
   DevBuf scrambles[2], perms[2];
   hipStream_t aux_stream = nullptr;
@@ -192,6 +194,35 @@ extern "C" int rt_scene_create(const rt_scene_desc* desc, int device, rt_scene**
           for (int q = 0; q < 2; ++q) { int g = desc->materials[c].slot[RT_SLOT_M1 + q]; if (g < 0 || (uint32_t)g >= desc->n_materials || desc->materials[g].kind == RT_MAT_MIX) { delete s; return fail(RT_ERR_INVALID, "mix nesting deeper than 2"); } }
       }
     }
+  }
+  {  // code classes: materials of one kind (and roughness remap / bump presence) whose slots hold textures of the same shape run the same code
+    std::map<std::vector<int>, int> classes;
+    std::function<void(int, int, std::vector<int>&)> tex_sig = [&](int id, int depth, std::vector<int>& sig) {
+      if (id < 0 || (uint32_t)id >= desc->n_textures) { sig.push_back(-1); return; }
+      const rt_texture& t = desc->textures[id];
+      sig.push_back(t.kind);
+      if (t.kind == RT_TEX_CONST) sig.push_back(t.value[0] == 0.0f ? 0 : 1);  // sigma == 0 (Lambert, not Oren-Nayar), roughness == 0 (specular lobes), ...
+      if (t.kind == RT_TEX_IMAGE) { const rt_image& im = desc->images[t.image]; sig.push_back(im.trilinear ? 1 : 0); }
+      if (t.kind == RT_TEX_CHECKER) sig.push_back(t.amount);
+      if ((t.kind == RT_TEX_SCALE || t.kind == RT_TEX_MIX || t.kind == RT_TEX_CHECKER) && depth < 3) {
+        tex_sig(t.tex1, depth + 1, sig); tex_sig(t.tex2, depth + 1, sig);
+        if (t.kind == RT_TEX_MIX) tex_sig(t.amount, depth + 1, sig);
+      }
+    };
+    std::function<void(int, int, std::vector<int>&)> mat_sig = [&](int id, int depth, std::vector<int>& sig) {
+      const rt_material& m = desc->materials[id];
+      sig.push_back(1000 + m.kind); sig.push_back(m.remap_roughness ? 1 : 0);
+      for (int k = 0; k < RT_SLOT_M1; ++k) tex_sig(m.slot[k], 0, sig);
+      if (m.kind == RT_MAT_MIX) { if (depth < 2) { mat_sig(m.slot[RT_SLOT_M1], depth + 1, sig); mat_sig(m.slot[RT_SLOT_M2], depth + 1, sig); } }
+      else { sig.push_back(m.kind == RT_MAT_DISNEY ? m.slot[RT_SLOT_M1] : 0); tex_sig(m.bump, 0, sig); }
+    };
+    for (uint32_t i = 0; i < desc->n_materials; ++i) {
+      std::vector<int> sig; mat_sig((int)i, 0, sig);
+      auto it = classes.find(sig);
+      if (it == classes.end()) it = classes.emplace(sig, (int)classes.size()).first;
+      hmat[i].code_class = it->second;
+    }
+    s->n_code_classes = (unsigned)classes.size();
   }
   TRY_RC(upload(s->materials, hmat.data(), hmat.size() * sizeof(DMaterial)));
   // lights (+ env distributions in one blob)
@@ -689,8 +720,8 @@ extern "C" int rt_render(rt_scene* s, const rt_camera* cam, const rt_film_desc* 
   HIP_TRY(s->counters.ensure(counter_words * 4)); HIP_TRY(s->stats.ensure(ST_COUNT * 8));
   // material binning before the generic shade kernel: per bounce {hist, cursor}[RT_BIN_MAX + 1] + the 8 count words of the sorted queue
   static const bool bin_off = getenv("RTX_SHADE_BINS") && getenv("RTX_SHADE_BINS")[0] == '0';  // measurement knob
-  const bool use_bins = !s->lambert_only && s->n_materials > 1 && !bin_off;
-  const unsigned n_bins = std::min<unsigned>(s->n_materials, RT_BIN_MAX) + 1u;
+  const bool use_bins = !s->lambert_only && s->n_code_classes > 1 && !bin_off;  // one class: every vertex runs the same code, the queue order is kept
+  const unsigned n_bins = std::min<unsigned>(s->n_code_classes, RT_BIN_MAX) + 1u;
   const size_t bin_stride = 2 * (RT_BIN_MAX + 1) + RT_QSHARDS;
   if (use_bins) { HIP_TRY(s->bin_words.ensure((size_t)(fp.max_depth + 1) * bin_stride * 4)); HIP_TRY(s->bin_sorted.ensure(cap * 4)); }
   HIP_TRY(s->film_acc.ensure((size_t)cw * ch * 16)); HIP_TRY(s->own_acc.ensure(chunk_pixels * 16));

@@ -798,14 +798,15 @@ __global__ void __launch_bounds__(BLOCK) k_trace_pair(DScene sc, const float4* _
 // ================================================================================ K2b material binning
 // The generic shade kernel evaluates tagged lobes ("for each lobe: switch (kind)"); a wave whose 64 vertices carry
 // different materials executes the union of their code paths (measured on S4: 20 of 64 lanes active per VALU
-// instruction). Between closest hit and shade the vertex queue is therefore counting-sorted by the material of the
-// hit triangle (misses last), so that most waves shade one material. Order within a bin is arbitrary: paths are
+// instruction). Between closest hit and shade the vertex queue is therefore counting-sorted by the code class of the hit
+// triangle's material (materials of one kind whose parameters are textures of the same kinds run the same code and share a
+// class; misses last), so that most waves run one code path. Order within a bin is arbitrary: paths are
 // independent and the film sums each pixel's samples in sample order. hist/cursor: RT_BIN_MAX + 1 zeroed words each.
 #define RT_BIN_MAX 256
-RT_DEV unsigned bin_of(const float4* __restrict__ tri_p, const float4* __restrict__ hit, unsigned pid, unsigned n_bins) {
+RT_DEV unsigned bin_of(const DMaterial* __restrict__ materials, const float4* __restrict__ tri_p, const float4* __restrict__ hit, unsigned pid, unsigned n_bins) {
   const int prim = __float_as_int(hit[pid].y);
   if (prim < 0) return n_bins - 1u;
-  const unsigned m = (unsigned)tri_material(tri_p, prim);
+  const unsigned m = (unsigned)materials[tri_material(tri_p, prim)].code_class;
   return m < n_bins - 1u ? m : n_bins - 2u;
 }
 __global__ void __launch_bounds__(256) k_bin_count(DScene sc, PassState ps, unsigned n_bins, unsigned* __restrict__ hist) {
@@ -816,7 +817,7 @@ __global__ void __launch_bounds__(256) k_bin_count(DScene sc, PassState ps, unsi
   const unsigned count = ps.q_in ? qv.total() : ps.cap;
   for (unsigned i = blockIdx.x * 256u + threadIdx.x; i < count; i += gridDim.x * 256u) {
     const unsigned pid = ps.q_in ? qv.get(i) : i;
-    atomicAdd(&lh[bin_of(sc.tri_p, ps.hit, pid, n_bins)], 1u);
+    atomicAdd(&lh[bin_of(sc.materials, sc.tri_p, ps.hit, pid, n_bins)], 1u);
   }
   __syncthreads();
   for (unsigned i = threadIdx.x; i < n_bins; i += 256u) if (lh[i]) atomicAdd(&hist[i], lh[i]);
@@ -838,7 +839,7 @@ __global__ void __launch_bounds__(256) k_bin_scatter(DScene sc, PassState ps, un
     const unsigned i = start + threadIdx.x;
     unsigned pid = 0, bin = 0, rank = 0;
     const bool live = i < count;
-    if (live) { pid = ps.q_in ? qv.get(i) : i; bin = bin_of(sc.tri_p, ps.hit, pid, n_bins); rank = atomicAdd(&lcount[bin], 1u); }
+    if (live) { pid = ps.q_in ? qv.get(i) : i; bin = bin_of(sc.materials, sc.tri_p, ps.hit, pid, n_bins); rank = atomicAdd(&lcount[bin], 1u); }
     __syncthreads();
     for (unsigned b = threadIdx.x; b < n_bins; b += 256u) if (lcount[b]) lbase[b] = atomicAdd(&cursor[b], lcount[b]);  // one global atomic per bin per 256 entries
     __syncthreads();
