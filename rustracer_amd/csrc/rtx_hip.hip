@@ -47,6 +47,7 @@ struct rt_scene {
   SamplerPlan sampler_plan;
   DScene d{};
   bool small = false;
+  bool lambert_materials = false;  // the material half of lambert_only: with other light kinds k_shade<3>
   bool lambert_only = false;  // every material is matte{constant Kd, sigma == 0} and every light an area light: k_shade<1>
   int stack_depth = 64;  // entries the to-visit stack needs for this tree (<= 64, rc/bvh/mod.rs:374)
   unsigned n_nodes = 0, n_tris = 0; int n_lights = 0;
@@ -285,6 +286,7 @@ extern "C" int rt_scene_create(const rt_scene_desc* desc, int device, rt_scene**
     const float sg = desc->textures[m.slot[RT_SLOT_SIGMA]].value[0];
     if (!(sg <= 0.0f)) { s->lambert_only = false; break; }  // clamp(sigma, 0, 1) == 0 (matte.rs:51)
   }
+  s->lambert_materials = s->lambert_only;
   for (uint32_t i = 0; i < desc->n_lights; ++i) if (desc->lights[i].kind != RT_LIGHT_DIFFUSE_AREA) s->lambert_only = false;
   s->n_materials = desc->n_materials;
   s->small = desc->n_nodes <= RT_SMALL_NODES && desc->n_tris <= RT_SMALL_TRIS;
@@ -720,7 +722,7 @@ extern "C" int rt_render(rt_scene* s, const rt_camera* cam, const rt_film_desc* 
   HIP_TRY(s->counters.ensure(counter_words * 4)); HIP_TRY(s->stats.ensure(ST_COUNT * 8));
   // material binning before the generic shade kernel: per bounce {hist, cursor}[RT_BIN_MAX + 1] + the 8 count words of the sorted queue
   static const bool bin_off = getenv("RTX_SHADE_BINS") && getenv("RTX_SHADE_BINS")[0] == '0';  // measurement knob
-  const bool use_bins = !s->lambert_only && s->n_code_classes > 1 && !bin_off;  // one class: every vertex runs the same code, the queue order is kept
+  const bool use_bins = !s->lambert_materials && s->n_code_classes > 1 && !bin_off;  // one class: every vertex runs the same code, the queue order is kept
   const unsigned n_bins = std::min<unsigned>(s->n_code_classes, RT_BIN_MAX) + 1u;
   const size_t bin_stride = 2 * (RT_BIN_MAX + 1) + RT_QSHARDS;
   if (use_bins) { HIP_TRY(s->bin_words.ensure((size_t)(fp.max_depth + 1) * bin_stride * 4)); HIP_TRY(s->bin_sorted.ensure(cap * 4)); }
@@ -808,6 +810,7 @@ extern "C" int rt_render(rt_scene* s, const rt_camera* cam, const rt_film_desc* 
         tm.end();
         tm.begin(&stats.ms_shade);
         if (s->lambert_only) hipLaunchKernelGGL(k_shade<1>, dim3(pgrid), dim3(256), 0, stream, s->d, fp, ps);
+        else if (s->lambert_materials) hipLaunchKernelGGL(k_shade<3>, dim3(pgrid), dim3(256), 0, stream, s->d, fp, ps);
         else if (!use_bins) hipLaunchKernelGGL(k_shade<0>, dim3(pgrid), dim3(256), 0, stream, s->d, fp, ps);
         else {
           unsigned* bw = s->bin_words.as<unsigned>() + (size_t)bounce * bin_stride;

@@ -922,6 +922,8 @@ struct SingleLambert {
 // MODE 0: any material / texture / light. MODE 1: every material is matte with constant Kd and
 // sigma == 0 and every light is a DiffuseAreaLight (decided by the host from the material and light
 // tables); no texture then reads the camera-ray differentials and the kernel makes no out-of-line call.
+// MODE 3: the materials of MODE 1 under any kind of light (environment, point, distant): the register-resident
+// front-end with the generic light functions.
 #ifndef RT_SHADE_MIN_WAVES
 #define RT_SHADE_MIN_WAVES 2
 #endif
@@ -956,7 +958,7 @@ __global__ void __launch_bounds__(256, MODE == 1 ? RT_SHADE_MIN_WAVES : RT_SHADE
       // the frame loop's hit record is (b2, prim, b0, b1): the three barycentrics of the accepted test
       SurfaceInteraction si; TriHit th; th.t = 0.0f; th.b0 = h4.z; th.b1 = h4.w; th.b2 = h4.x;
       if (found) {
-        if (MODE == 1) tri_fill_interaction_inl(sc, prim, ray_d, th, si);
+        if (MODE & 1) tri_fill_interaction_inl(sc, prim, ray_d, th, si);
         else tri_fill_interaction(sc, prim, ray_d, th, si);
       }
       // path.rs:127-136 emitted light at the vertex / from the environment
@@ -964,18 +966,18 @@ __global__ void __launch_bounds__(256, MODE == 1 ? RT_SHADE_MIN_WAVES : RT_SHADE
         if (found) {
           int li = tri_light(sc.tri_p, prim);
           if (li >= 0) L = L + beta * area_light_l(sc.lights[li], si.hit.n, -ray_d);
-        } else if (MODE == 0) {
+        } else if (MODE != 1) {
           for (int k = 0; k < sc.n_infinite; ++k) L = L + beta * infinite_le(sc, sc.lights[sc.infinite_ids[k]], ray_d);
         }
       }
       if (found && bounces < fp.max_depth) {  // path.rs:139
-        if (MODE == 0 && bounces == 0 && sc.needs_differentials) {  // only the camera ray carries differentials (interaction.rs:245-314)
+        if (MODE != 1 && bounces == 0 && sc.needs_differentials) {  // only the camera ray carries differentials (interaction.rs:245-314)
           f2 pf; { float2 t = ps.pfilm[pid]; pf = mk2(t.x, t.y); }
           f2 pl = table_2d(smp.tb, pix, 1, s);
           CameraRay cr = generate_camera_ray(fp, pf, pl, 1.0f / sqrtf((float)ps.spp));
           compute_differential(si, cr.rx_o, cr.ry_o, cr.rx_d, cr.ry_d);
         }
-        typename std::conditional<MODE == 1, SingleLambert, GenericBsdf>::type bsdf;
+        typename std::conditional<(MODE & 1) != 0, SingleLambert, GenericBsdf>::type bsdf;
         bsdf.build(sc, tri_material(sc.tri_p, prim), si);
         // light_distribution.lookup(p) (path.rs:154-158)
         const float* ld_func; const float* ld_cdf; float ld_int;

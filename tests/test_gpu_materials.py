@@ -125,3 +125,19 @@ def test_uniform_light_strategy_and_deep_paths(gpu_host, orc):
     d.integrator.light_strategy = "uniform"
     d.integrator.rr_threshold = 0.5
     _check(gpu_host, orc, d)
+
+
+@pytest.mark.parametrize("lights", ["point", "distant", "infinite", "all"])
+def test_constant_matte_scene_under_other_light_kinds(gpu_host, orc, lights):
+    """Constant-Kd matte materials with non-area lights: the register-resident front-end with the generic light code (k_shade<3>)."""
+    from rustracer_amd.scenes import cornell_box
+    from rustracer_amd.scenes.procedural import sky_image
+    d = cornell_box(72, 56, 16)
+    if lights in ("point", "all"):
+        d.point_light((278.0, 400.0, 200.0), (4e4, 3e4, 2e4))
+    if lights in ("distant", "all"):
+        d.distant_light((0.0, 0.0, 0.0), (0.1, 0.3, 1.0), (0.5, 0.6, 0.8))
+    if lights in ("infinite", "all"):
+        env = d.add_mip(sky_image(64, 32, (0.0, -0.3, -1.0), 30.0, 0.97), trilinear=False, max_aniso=0.0)
+        d.infinite_light(env, np.array([[1, 0, 0, 0], [0, 0, 1, 0], [0, 1, 0, 0], [0, 0, 0, 1]], np.float32))
+    _check(gpu_host, orc, d)
