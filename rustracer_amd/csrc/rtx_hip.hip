@@ -62,7 +62,7 @@ struct rt_scene {
   DevBuf ws[32];
   DevBuf film_acc, own_acc, film_out, counters, stats, filter_table;
   DevBuf bin_words, bin_sorted;  // material binning of the shade queue (generic shade path)
-  unsigned n_materials = 0, n_code_classes = 0;
+  unsigned n_materials = 0, n_code_classes = 0, n_lambert_classes = 0;
   // sampler tables are double-buffered: K0 of batch b+1 runs on aux_stream under the path kernels of batch b
   DevBuf scrambles[2], perms[2];
   hipStream_t aux_stream = nullptr;
@@ -224,6 +224,20 @@ extern "C" int rt_scene_create(const rt_scene_desc* desc, int device, rt_scene**
       hmat[i].code_class = it->second;
     }
     s->n_code_classes = (unsigned)classes.size();
+    // classes the register-resident front-end can shade (constant Kd, sigma == 0, no bump: SingleLambert) get the lowest ids, so that
+    // after binning they are one contiguous range of the queue
+    auto is_const = [&](int id) { return id >= 0 && (uint32_t)id < desc->n_textures && desc->textures[id].kind == RT_TEX_CONST; };
+    std::vector<int> lambert(classes.size(), 0), remap(classes.size(), -1);
+    for (uint32_t i = 0; i < desc->n_materials; ++i) {
+      const rt_material& m = desc->materials[i];
+      lambert[hmat[i].code_class] = m.kind == RT_MAT_MATTE && is_const(m.slot[RT_SLOT_KD]) && is_const(m.slot[RT_SLOT_SIGMA]) && m.bump < 0 &&
+                                    desc->textures[m.slot[RT_SLOT_SIGMA]].value[0] <= 0.0f;
+    }
+    int next = 0;
+    for (size_t c = 0; c < classes.size(); ++c) if (lambert[c]) remap[c] = next++;
+    s->n_lambert_classes = (unsigned)next;
+    for (size_t c = 0; c < classes.size(); ++c) if (!lambert[c]) remap[c] = next++;
+    for (uint32_t i = 0; i < desc->n_materials; ++i) hmat[i].code_class = remap[hmat[i].code_class];
   }
   TRY_RC(upload(s->materials, hmat.data(), hmat.size() * sizeof(DMaterial)));
   // lights (+ env distributions in one blob)
@@ -724,7 +738,9 @@ extern "C" int rt_render(rt_scene* s, const rt_camera* cam, const rt_film_desc* 
   static const bool bin_off = getenv("RTX_SHADE_BINS") && getenv("RTX_SHADE_BINS")[0] == '0';  // measurement knob
   const bool use_bins = !s->lambert_materials && s->n_code_classes > 1 && !bin_off;  // one class: every vertex runs the same code, the queue order is kept
   const unsigned n_bins = std::min<unsigned>(s->n_code_classes, RT_BIN_MAX) + 1u;
-  const size_t bin_stride = 2 * (RT_BIN_MAX + 1) + RT_QSHARDS;
+  const size_t bin_stride = 2 * (RT_BIN_MAX + 1) + RT_QSHARDS + 4;  // + {begin, end} of the two class ranges
+  static const bool split_off = getenv("RTX_SHADE_SPLIT") && getenv("RTX_SHADE_SPLIT")[0] == '0';  // measurement knob
+  const bool split_classes = use_bins && !split_off && s->n_lambert_classes > 0 && s->n_lambert_classes < RT_BIN_MAX;
   if (use_bins) { HIP_TRY(s->bin_words.ensure((size_t)(fp.max_depth + 1) * bin_stride * 4)); HIP_TRY(s->bin_sorted.ensure(cap * 4)); }
   HIP_TRY(s->film_acc.ensure((size_t)cw * ch * 16)); HIP_TRY(s->own_acc.ensure(chunk_pixels * 16));
   HIP_TRY(s->filter_table.ensure(1024));
@@ -816,9 +832,14 @@ extern "C" int rt_render(rt_scene* s, const rt_camera* cam, const rt_film_desc* 
           unsigned* bw = s->bin_words.as<unsigned>() + (size_t)bounce * bin_stride;
           unsigned* hist = bw; unsigned* cursor = bw + (RT_BIN_MAX + 1); unsigned* sorted_cnt = bw + 2 * (RT_BIN_MAX + 1);
           hipLaunchKernelGGL(k_bin_count, dim3(pgrid), dim3(256), 0, stream, s->d, ps, n_bins, hist);
-          hipLaunchKernelGGL(k_bin_scatter, dim3(pgrid), dim3(256), 0, stream, s->d, ps, n_bins, hist, cursor, s->bin_sorted.as<unsigned>(), sorted_cnt);
+          unsigned* ranges = sorted_cnt + RT_QSHARDS;
+          hipLaunchKernelGGL(k_bin_scatter, dim3(pgrid), dim3(256), 0, stream, s->d, ps, n_bins, hist, cursor, s->bin_sorted.as<unsigned>(), sorted_cnt,
+                             split_classes ? s->n_lambert_classes : 0u, ranges);
           PassState pb = ps; pb.q_in = s->bin_sorted.as<unsigned>(); pb.cnt_in = sorted_cnt;  // all entries in shard 0: QView::get(i) = ids[i]
-          hipLaunchKernelGGL(k_shade<0>, dim3(pgrid), dim3(256), 0, stream, s->d, fp, pb);
+          if (split_classes) {  // constant-matte classes through the register-resident front-end, the rest through the generic one
+            pb.range = ranges; hipLaunchKernelGGL(k_shade<3>, dim3(pgrid), dim3(256), 0, stream, s->d, fp, pb);
+            pb.range = ranges + 2; hipLaunchKernelGGL(k_shade<0>, dim3(pgrid), dim3(256), 0, stream, s->d, fp, pb);
+          } else hipLaunchKernelGGL(k_shade<0>, dim3(pgrid), dim3(256), 0, stream, s->d, fp, pb);
         }
         tm.end();
         tm.begin(&stats.ms_trace_any);

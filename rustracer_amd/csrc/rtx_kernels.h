@@ -40,6 +40,7 @@ struct PassState {
   unsigned* q_in; unsigned* q_out; unsigned* q_shadow; unsigned* q_mis;
   const unsigned* cnt_in; unsigned* cnt_out; unsigned shard_cap;
   int all_in_bounds;  // every sample of the pass is traced (no crop by pixel_bounds): bounce 0 needs no queue, path i is entry i
+  const unsigned* range;  // k_shade: shade entries [range[0], range[1]) of q_in only (NULL = all): class-wise dispatch over the binned queue
   unsigned long long* stats;  // device-side u64 counters, see ST_* below
 };
 enum { ST_CAMERA = 0, ST_RAYS_CLOSEST, ST_RAYS_SHADOW, ST_RAYS_MIS, ST_NODES_CLOSEST, ST_NODES_SHADOW, ST_NODES_MIS,
@@ -824,12 +825,16 @@ __global__ void __launch_bounds__(256) k_bin_count(DScene sc, PassState ps, unsi
 }
 // sorted: path ids grouped by bin; sorted_cnt[RT_QSHARDS]: {total, 0, ...} so that the result reads as a one-shard queue
 __global__ void __launch_bounds__(256) k_bin_scatter(DScene sc, PassState ps, unsigned n_bins, const unsigned* __restrict__ hist, unsigned* __restrict__ cursor,
-                                                     unsigned* __restrict__ sorted, unsigned* __restrict__ sorted_cnt) {
+                                                     unsigned* __restrict__ sorted, unsigned* __restrict__ sorted_cnt, unsigned split_bin, unsigned* __restrict__ ranges) {
   __shared__ unsigned base[RT_BIN_MAX + 1], lcount[RT_BIN_MAX + 1], lbase[RT_BIN_MAX + 1];
   if (threadIdx.x == 0) {  // exclusive prefix of the histogram (<= 257 entries)
     unsigned run = 0;
     for (unsigned b = 0; b < n_bins; ++b) { base[b] = run; run += hist[b]; }
-    if (blockIdx.x == 0) { sorted_cnt[0] = run; for (int k = 1; k < RT_QSHARDS; ++k) sorted_cnt[k] = 0u; }
+    if (blockIdx.x == 0) {
+      sorted_cnt[0] = run; for (int k = 1; k < RT_QSHARDS; ++k) sorted_cnt[k] = 0u;
+      const unsigned split = split_bin < n_bins ? base[split_bin] : run;  // bins [0, split_bin) are the classes the register-resident front-end shades
+      ranges[0] = 0u; ranges[1] = split; ranges[2] = split; ranges[3] = run;
+    }
   }
   for (unsigned i = threadIdx.x; i <= RT_BIN_MAX; i += 256u) lcount[i] = 0u;
   __syncthreads();
@@ -933,9 +938,10 @@ struct SingleLambert {
 template <int MODE>
 __global__ void __launch_bounds__(256, MODE == 1 ? RT_SHADE_MIN_WAVES : RT_SHADE0_MIN_WAVES) k_shade(DScene sc, FrameParams fp, PassState ps) {
   QView qv; if (ps.q_in) qv.init(ps.q_in, ps.cnt_in, ps.shard_cap);
-  const unsigned count = ps.q_in ? qv.total() : ps.cap;  // no queue: bounce 0 of a pass whose samples are all traced
+  unsigned first = 0, count = ps.q_in ? qv.total() : ps.cap;  // no queue: bounce 0 of a pass whose samples are all traced
+  if (MODE != 1 && ps.range) { first = ps.range[0]; count = ps.range[1]; }
   const unsigned stride = gridDim.x * blockDim.x;
-  for (unsigned base = blockIdx.x * blockDim.x; base < count; base += stride) {
+  for (unsigned base = first + blockIdx.x * blockDim.x; base < count; base += stride) {
     const unsigned i = base + threadIdx.x;
     const bool lane_live = i < count;
     bool cont = false, want_shadow = false, want_mis = false;
@@ -971,7 +977,7 @@ __global__ void __launch_bounds__(256, MODE == 1 ? RT_SHADE_MIN_WAVES : RT_SHADE
         }
       }
       if (found && bounces < fp.max_depth) {  // path.rs:139
-        if (MODE != 1 && bounces == 0 && sc.needs_differentials) {  // only the camera ray carries differentials (interaction.rs:245-314)
+        if ((MODE & 1) == 0 && bounces == 0 && sc.needs_differentials) {  // only the camera ray carries differentials (interaction.rs:245-314)
           f2 pf; { float2 t = ps.pfilm[pid]; pf = mk2(t.x, t.y); }
           f2 pl = table_2d(smp.tb, pix, 1, s);
           CameraRay cr = generate_camera_ray(fp, pf, pl, 1.0f / sqrtf((float)ps.spp));
