@@ -42,11 +42,13 @@ with open(os.path.join('profiles', f'{tag}_{scene}_pmc_hbm.csv'), 'w') as f:
     for r in rows:
         f.write(f'"{r[0]}",{r[1]},{r[2]:.0f},{r[3]:.0f},{r[4]:.0f}\n')
 
-def pick(prefixes, exclude=()):
+def pick(prefixes, exclude=(), per_stage=False):
     sel = [r for r in rows if any(r[0].startswith(p) for p in prefixes) and not any(e in r[0] for e in exclude)]
     if not sel:
         return None
-    tot_l = sum(r[1] for r in sel)
+    # several variants of one stage (k_shade<3> + k_shade<0> on a class-split queue, k_trace variants) run once per bounce each:
+    # bytes per launch = all their bytes / the launches of the most frequent variant
+    tot_l = max(r[1] for r in sel) if per_stage else sum(r[1] for r in sel)
     return {'kernels': sorted({r[0] for r in sel}), 'hbm_bytes_per_launch': round(sum(r[4] * r[1] for r in sel) / tot_l), 'launches_profiled': tot_l}
 
 # closest-hit kernels of the timed frames: k_trace<false, false, ...> (LDS scenes) or k_trace_pair<false, ...> (HBM scenes)
@@ -54,6 +56,6 @@ out = {'scene': scene,
        'method': 'rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate passes; KiB->B; reads x2 (gfx950 16-B/lane correction, MI355X guide)',
        'source': f'profiles/{tag}_{scene}_pmc_hbm.csv',
        'trace_closest': pick(['rtx::k_trace<false, false', 'rtx::k_trace_pair<false']),
-       'shade': pick(['rtx::k_shade'])}
+       'shade': pick(['rtx::k_shade'], per_stage=True)}
 json.dump(out, open(os.path.join('profiles', f'pmc_{scene}.json'), 'w'), indent=1)
 print(open(os.path.join('profiles', f'{tag}_{scene}_pmc_hbm.csv')).read())
