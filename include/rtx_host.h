@@ -106,8 +106,10 @@ int rtxh_pfm_read(const char* path, int32_t* width, int32_t* height, float** rgb
 void rtxh_free(void* p);
 /* read_image (rc/imageio.rs:16-33): decoder by extension - png PNG tga TGA (8-bit RGB / 255 after the `image` crate's
  * to_rgb8: palette and grey expanded, alpha dropped, 16-bit samples (c + 128) / 257; imageio.rs:94-112), hdr (Radiance
- * RGBE, c * 2^(e - 136); imageio.rs:114-132), pfm (above). exr is refused (RT_ERR_UNSUPPORTED): the `exr` crate's
- * decoder is not restated. Any other extension: "Unsupported file format", as the reference. Row 0 = top of the image. */
+ * RGBE, c * 2^(e - 136); imageio.rs:114-132), pfm (above), exr EXR (imageio.rs:134-160: first layer with R, G, B;
+ * scan-line files with NONE / RLE / ZIPS / ZIP compression and half / float / uint samples; PIZ, PXR24, B44, DWA, tiled and
+ * multi-part files fail with RT_ERR_UNSUPPORTED and a message naming the feature). Any other extension:
+ * "Unsupported file format", as the reference. Row 0 = top of the image. */
 int rtxh_image_read(const char* path, int32_t* width, int32_t* height, float** rgb);
 
 /* ---- pbrt-v3 scene description ----------------------------------------------------------

@@ -3,7 +3,7 @@
 // read_image (rc/imageio.rs:16-33) picks the decoder by file extension: tga / TGA / png / PNG -> the `image` crate
 // (0.24.2, png 0.17.5; absent from /root/reference, pinned by Cargo.lock) followed by `to_rgb8()` and c / 255
 // (imageio.rs:94-112); hdr -> image's HdrDecoder (non-strict) and Rgbe8Pixel::to_hdr (imageio.rs:114-132); pfm ->
-// read_image_pfm (rtxh_pfm_read above); exr -> the `exr` crate (1.4.2), not decoded here. The formats' published
+// read_image_pfm (rtxh_pfm_read above); exr -> the `exr` crate (1.4.2), scan-line files below. The formats' published
 // definitions are restated below: RFC 1950 / 1951 (zlib, DEFLATE), the PNG specification (filters, Adam7, sample
 // expansion as png's EXPAND transformation does it), Truevision TGA 2.0 (types 1 2 3 9 10 11) and the Radiance RGBE
 // picture format (flat and new-style run-length scanlines). Row 0 of every result is the top of the image.
@@ -323,6 +323,138 @@ bool hdr_decode(const std::vector<uint8_t>& file, int& W, int& H, std::vector<fl
 
 }  // namespace
 
+// ------------------------------------------------------------------ OpenEXR (scan-line, single part) -> float RGB
+// read_image_exr (rc/imageio.rs:134-160) calls exr 1.4.2's read_first_rgba_layer_from_file: the first layer that has R, G and B
+// channels, samples converted to f32, stored at their position inside the layer. Restated from the OpenEXR file layout
+// specification: magic + version, attribute list (channels, compression, dataWindow, displayWindow, lineOrder), offset table,
+// scan-line blocks of 1 (NONE, RLE, ZIPS) or 16 (ZIP) lines holding each line's channels in alphabetical order. ZIP / ZIPS / RLE
+// payloads are byte-delta coded and split into even / odd halves before compression. PIZ, PXR24, B44, DWA and tiled or multi-part
+// files are refused with a message. The reference takes the resolution from displayWindow and the pixels from the layer
+// (imageio.rs:153-159), which only agree when the two windows do: files where they differ are refused.
+namespace {
+
+inline float half_to_float(uint16_t h) {
+  const uint32_t sign = (uint32_t)(h & 0x8000u) << 16; uint32_t e = (h >> 10) & 0x1f, m = h & 0x3ff, bits;
+  if (e == 0) {
+    if (m == 0) bits = sign;
+    else { int sh = 0; while (!(m & 0x400)) { m <<= 1; ++sh; } m &= 0x3ff; bits = sign | (uint32_t)(127 - 15 - sh + 1) << 23 | m << 13; }
+  } else if (e == 31) bits = sign | 0x7f800000u | m << 13;
+  else bits = sign | (e + 112) << 23 | m << 13;
+  float f; memcpy(&f, &bits, 4); return f;
+}
+
+bool exr_unpredict(std::vector<uint8_t>& raw, size_t want, std::string& err) {  // undo the delta predictor, then re-interleave the two halves
+  if (raw.size() != want) { err = "EXR: block decompressed to the wrong size"; return false; }
+  for (size_t i = 1; i < raw.size(); ++i) raw[i] = (uint8_t)(raw[i - 1] + raw[i] - 128);
+  std::vector<uint8_t> out(raw.size());
+  const size_t half = (raw.size() + 1) / 2;
+  for (size_t i = 0; i < raw.size(); ++i) out[i] = (i & 1) ? raw[half + i / 2] : raw[i / 2];
+  raw.swap(out);
+  return true;
+}
+
+bool exr_decode(const std::vector<uint8_t>& file, int& W, int& H, std::vector<float>& rgb, std::string& err) {
+  Bytes b{file.data(), file.size()};
+  auto le32 = [&]() -> uint32_t { uint32_t v = (uint32_t)b.p[b.pos] | (uint32_t)b.p[b.pos + 1] << 8 | (uint32_t)b.p[b.pos + 2] << 16 | (uint32_t)b.p[b.pos + 3] << 24; b.pos += 4; return v; };
+  auto cstr = [&](std::string& out) -> bool { out.clear(); while (b.pos < b.n && b.p[b.pos]) out += (char)b.p[b.pos++]; if (b.pos >= b.n) return false; ++b.pos; return true; };
+  if (!b.need(8) || le32() != 20000630u) { err = "EXR: bad magic number"; return false; }
+  const uint32_t version = le32();
+  if ((version & 0xff) != 2) { err = "EXR: unsupported file version"; return false; }
+  if (version & 0x200) { err = "EXR: tiled images are not supported"; return false; }
+  if (version & 0x1800) { err = "EXR: deep / multi-part images are not supported"; return false; }
+  struct Chan { std::string name; int type, xs, ys; };
+  std::vector<Chan> chans; int compression = -1, line_order = 0; int32_t dw[4] = {0, 0, -1, -1}, disp[4] = {0, 0, -1, -1}; bool have_dw = false, have_disp = false;
+  for (;;) {
+    std::string name, type;
+    if (!cstr(name)) { err = "EXR: truncated header"; return false; }
+    if (name.empty()) break;
+    if (!cstr(type) || !b.need(4)) { err = "EXR: truncated header"; return false; }
+    const uint32_t size = le32();
+    if (!b.need(size)) { err = "EXR: truncated attribute"; return false; }
+    const size_t end = b.pos + size;
+    if (name == "channels") {
+      while (b.pos < end && b.p[b.pos]) {
+        Chan c; if (!cstr(c.name) || b.pos + 16 > end) { err = "EXR: bad channel list"; return false; }
+        c.type = (int)le32(); b.pos += 4; c.xs = (int)le32(); c.ys = (int)le32();
+        if (c.type < 0 || c.type > 2) { err = "EXR: unknown pixel type"; return false; }
+        if (c.xs != 1 || c.ys != 1) { err = "EXR: sub-sampled channels are not supported"; return false; }
+        chans.push_back(c);
+      }
+    } else if (name == "compression" && size >= 1) compression = b.p[b.pos];
+    else if (name == "lineOrder" && size >= 1) line_order = b.p[b.pos];
+    else if ((name == "dataWindow" || name == "displayWindow") && size == 16) {
+      int32_t* w = name == "dataWindow" ? dw : disp; (name == "dataWindow" ? have_dw : have_disp) = true;
+      for (int k = 0; k < 4; ++k) { uint32_t v = le32(); memcpy(&w[k], &v, 4); }
+    }
+    b.pos = end;
+  }
+  if (chans.empty() || compression < 0 || !have_dw || !have_disp) { err = "EXR: missing required attribute"; return false; }
+  if (compression > 3) { err = "EXR: only NONE, RLE, ZIPS and ZIP compression are supported (this file uses PIZ / PXR24 / B44 / DWA)"; return false; }
+  if (line_order > 1) { err = "EXR: unsupported line order"; return false; }
+  const long long w = (long long)dw[2] - dw[0] + 1, h = (long long)dw[3] - dw[1] + 1;
+  if (w <= 0 || h <= 0 || w > 65536 || h > 65536) { err = "EXR: bad data window"; return false; }
+  if (disp[2] - disp[0] != dw[2] - dw[0] || disp[3] - disp[1] != dw[3] - dw[1]) { err = "EXR: data window and display window differ in size"; return false; }
+  int ci[3] = {-1, -1, -1};  // first layer with R, G, B: the unnamed layer's channels, else the first "<layer>.R / .G / .B" triple
+  bool found = false;
+  auto triple = [&](const std::string& pre) {
+    int r = -1, g = -1, bl = -1;
+    for (size_t k = 0; k < chans.size(); ++k) { if (chans[k].name == pre + "R") r = (int)k; if (chans[k].name == pre + "G") g = (int)k; if (chans[k].name == pre + "B") bl = (int)k; }
+    if (r >= 0 && g >= 0 && bl >= 0) { ci[0] = r; ci[1] = g; ci[2] = bl; found = true; }
+  };
+  triple("");
+  for (size_t k = 0; k < chans.size() && !found; ++k) {
+    const std::string& nm = chans[k].name;
+    if (nm.size() >= 2 && nm.compare(nm.size() - 2, 2, ".R") == 0) triple(nm.substr(0, nm.size() - 1));
+  }
+  if (!found) { err = "EXR: no layer with R, G and B channels"; return false; }
+  std::vector<size_t> chan_off(chans.size()); size_t line_bytes = 0;
+  for (size_t k = 0; k < chans.size(); ++k) { chan_off[k] = line_bytes; line_bytes += (size_t)w * (chans[k].type == 1 ? 2 : 4); }
+  const int lines_per_block = compression == 3 ? 16 : 1;
+  const size_t n_blocks = ((size_t)h + lines_per_block - 1) / lines_per_block;
+  if (!b.need(n_blocks * 8)) { err = "EXR: truncated offset table"; return false; }
+  const size_t table = b.pos;
+  W = (int)w; H = (int)h; rgb.assign((size_t)w * h * 3, 0.0f);
+  std::vector<uint8_t> raw;
+  for (size_t blk = 0; blk < n_blocks; ++blk) {
+    uint64_t off = 0; for (int k = 7; k >= 0; --k) off = off << 8 | file[table + blk * 8 + k];
+    if (off + 8 > file.size()) { err = "EXR: block offset outside the file"; return false; }
+    b.pos = (size_t)off;
+    int32_t y0; { uint32_t v = le32(); memcpy(&y0, &v, 4); }
+    const uint32_t size = le32();
+    if (!b.need(size)) { err = "EXR: truncated block"; return false; }
+    if (y0 < dw[1] || y0 > dw[3]) { err = "EXR: block outside the data window"; return false; }
+    const size_t rows = std::min<long long>(lines_per_block, (long long)dw[3] - y0 + 1), want = rows * line_bytes;
+    const uint8_t* src = b.p + b.pos;
+    if (size == want) raw.assign(src, src + size);   // stored uncompressed (always for NONE; for the others when compression did not help)
+    else if (compression == 2 || compression == 3) { raw.clear(); if (!zlib_inflate(src, size, raw, err) || !exr_unpredict(raw, want, err)) return false; }
+    else if (compression == 1) {
+      raw.clear(); size_t i = 0;
+      while (i < size) {
+        const int c = (int8_t)src[i++];
+        if (c < 0) { const size_t n = (size_t)(-c); if (i + n > size) { err = "EXR: bad RLE run"; return false; } raw.insert(raw.end(), src + i, src + i + n); i += n; }
+        else { if (i >= size) { err = "EXR: bad RLE run"; return false; } raw.insert(raw.end(), (size_t)c + 1, src[i]); ++i; }
+      }
+      if (!exr_unpredict(raw, want, err)) return false;
+    } else { err = "EXR: compressed block in an uncompressed file"; return false; }
+    for (size_t r = 0; r < rows; ++r) {
+      const size_t y = (size_t)(y0 - dw[1]) + r;
+      for (int c = 0; c < 3; ++c) {
+        const Chan& ch = chans[ci[c]]; const uint8_t* q = raw.data() + r * line_bytes + chan_off[ci[c]];
+        for (size_t x = 0; x < (size_t)w; ++x) {
+          float v;
+          if (ch.type == 1) v = half_to_float((uint16_t)(q[2 * x] | q[2 * x + 1] << 8));
+          else if (ch.type == 2) memcpy(&v, q + 4 * x, 4);
+          else { uint32_t u; memcpy(&u, q + 4 * x, 4); v = (float)u; }
+          rgb[(y * (size_t)w + x) * 3 + c] = v;
+        }
+      }
+    }
+  }
+  return true;
+}
+
+}  // namespace
+
 extern "C" int rtxh_image_read(const char* path, int32_t* width, int32_t* height, float** rgb) {
   if (!path || !width || !height || !rgb) return fail(RT_ERR_INVALID, "null argument");
   g_err.clear();
@@ -330,9 +462,8 @@ extern "C" int rtxh_image_read(const char* path, int32_t* width, int32_t* height
   if (dot == std::string::npos || (slash != std::string::npos && dot < slash)) return fail(RT_ERR_INVALID, "Texture filename doesn't have an extension");  // imageio.rs:19-21
   const std::string ext = p.substr(dot + 1);
   if (ext == "pfm") return rtxh_pfm_read(path, width, height, rgb);
-  if (ext == "exr" || ext == "EXR") return fail(RT_ERR_UNSUPPORTED, "OpenEXR images are not decoded by this host layer (convert to .pfm or .hdr)");
-  const bool ldr = ext == "tga" || ext == "TGA" || ext == "png" || ext == "PNG";
-  if (!ldr && ext != "hdr") return fail(RT_ERR_INVALID, "Unsupported file format");  // imageio.rs:30-32
+  const bool ldr = ext == "tga" || ext == "TGA" || ext == "png" || ext == "PNG", exr = ext == "exr" || ext == "EXR";
+  if (!ldr && !exr && ext != "hdr") return fail(RT_ERR_INVALID, "Unsupported file format");  // imageio.rs:30-32
   std::vector<uint8_t> file;
   if (!read_whole_file(path, file)) return fail(RT_ERR_INVALID, std::string("cannot open ") + path);
   int w = 0, h = 0; std::string err; std::vector<float> f;
@@ -344,6 +475,8 @@ extern "C" int rtxh_image_read(const char* path, int32_t* width, int32_t* height
     if (!(is_png ? png_decode(file, w, h, px, err) : tga_decode(file, w, h, px, err))) return fail(RT_ERR_INVALID, err + " (" + p + ")");
     f.resize(px.size());
     for (size_t i = 0; i < px.size(); ++i) f[i] = (float)px[i] / 255.0f;  // imageio.rs:104-106
+  } else if (exr) {
+    if (!exr_decode(file, w, h, f, err)) return fail(err.find("not supported") != std::string::npos || err.find("only NONE") != std::string::npos ? RT_ERR_UNSUPPORTED : RT_ERR_INVALID, err + " (" + p + ")");
   } else if (!hdr_decode(file, w, h, f, err)) return fail(RT_ERR_INVALID, err + " (" + p + ")");
   float* out = (float*)malloc(f.size() * sizeof(float));
   if (!out) return fail(RT_ERR_INVALID, "out of memory");

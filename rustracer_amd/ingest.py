@@ -274,3 +274,73 @@ def write_hdr(path: str, rgbe, rle: bool = True) -> None:
                     i += lit
     with open(path, "wb") as f:
         f.write(bytes(out))
+
+
+def write_exr(path: str, img, compression: str = "zip", pixel_type: str = "half", layer: str = "", alpha: bool = False, origin=(0, 0), extra_channels=()) -> None:
+    """Scan-line OpenEXR file (OpenEXR file layout specification) of img (h, w, 3) float: channels <layer>B/G/R (+A, + extra names)
+    in alphabetical order, half or float samples, compression none | rle | zips | zip. Test writer: numpy + zlib only."""
+    import struct
+    import zlib
+    a = np.asarray(img, np.float32)
+    h, w = a.shape[:2]
+    comp = {"none": 0, "rle": 1, "zips": 2, "zip": 3}[compression]
+    ptype, dt = (1, "<f2") if pixel_type == "half" else (2, "<f4")
+    planes = {layer + "R": a[..., 0], layer + "G": a[..., 1], layer + "B": a[..., 2]}
+    if alpha:
+        planes[layer + "A"] = np.ones((h, w), np.float32)
+    for k, name in enumerate(extra_channels):
+        planes[name] = np.full((h, w), 0.25 * (k + 1), np.float32)
+    names = sorted(planes)
+
+    def attr(name, typ, data):
+        return name.encode() + b"\0" + typ.encode() + b"\0" + struct.pack("<I", len(data)) + data
+    chlist = b"".join(n.encode() + b"\0" + struct.pack("<iBxxxii", ptype, 0, 1, 1) for n in names) + b"\0"
+    x0, y0 = origin
+    box = struct.pack("<iiii", x0, y0, x0 + w - 1, y0 + h - 1)
+    hdr = (struct.pack("<II", 20000630, 2) + attr("channels", "chlist", chlist) + attr("compression", "compression", bytes([comp])) +
+           attr("dataWindow", "box2i", box) + attr("displayWindow", "box2i", box) + attr("lineOrder", "lineOrder", b"\0") +
+           attr("pixelAspectRatio", "float", struct.pack("<f", 1.0)) + attr("screenWindowCenter", "v2f", struct.pack("<ff", 0, 0)) +
+           attr("screenWindowWidth", "float", struct.pack("<f", 1.0)) + b"\0")
+    lines = 16 if comp == 3 else 1
+
+    def pack(block: bytes) -> bytes:
+        if comp == 0:
+            return block
+        b = np.frombuffer(block, np.uint8)
+        t = np.concatenate([b[0::2], b[1::2]]).astype(np.int16)          # even bytes, then odd bytes
+        d = t.copy()
+        d[1:] = (t[1:] - t[:-1] + 128 + 256) % 256                        # byte deltas, biased by 128
+        pre = d.astype(np.uint8).tobytes()
+        if comp in (2, 3):
+            out = zlib.compress(pre, 6)
+        else:
+            out = bytearray()
+            i, n = 0, len(pre)
+            while i < n:
+                run = 1
+                while i + run < n and run < 128 and pre[i + run] == pre[i]:
+                    run += 1
+                if run >= 3:
+                    out += bytes([run - 1, pre[i]])
+                    i += run
+                else:
+                    lit = 1
+                    while i + lit < n and lit < 127 and not (i + lit + 2 < n and pre[i + lit] == pre[i + lit + 1] == pre[i + lit + 2]):
+                        lit += 1
+                    out += bytes([(256 - lit) & 0xff]) + pre[i:i + lit]
+                    i += lit
+            out = bytes(out)
+        return out if len(out) < len(block) else block                    # a block that does not shrink is stored raw
+    blocks = []
+    for yb in range(0, h, lines):
+        rows = b"".join(b"".join(planes[n][y].astype(dt).tobytes() for n in names) for y in range(yb, min(h, yb + lines)))
+        data = pack(rows)
+        blocks.append(struct.pack("<iI", y0 + yb, len(data)) + data)
+    table_at = len(hdr)
+    pos = table_at + 8 * len(blocks)
+    table = b""
+    for blk in blocks:
+        table += struct.pack("<Q", pos)
+        pos += len(blk)
+    with open(path, "wb") as f:
+        f.write(hdr + table + b"".join(blocks))

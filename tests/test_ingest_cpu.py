@@ -198,7 +198,7 @@ def test_radiance_hdr(ingest, tmp_path, rle):
 
 def test_read_image_extension_rules(ingest, host, tmp_path):
     # imageio.rs:19-32: no extension / unknown extension are errors; exr is refused by this host layer, loudly
-    for name, msg in (("noext", "doesn't have an extension"), ("x.jpg", "Unsupported file format"), ("x.exr", "OpenEXR"), ("missing.png", "cannot open")):
+    for name, msg in (("noext", "doesn.t have an extension"), ("x.jpg", "Unsupported file format"), ("missing.exr", "cannot open"), ("missing.png", "cannot open")):
         with pytest.raises(host.BackendError, match=msg):
             ingest.read_image(str(tmp_path / name))
     a = np.full((2, 2, 3), 200, np.uint8)
@@ -206,3 +206,38 @@ def test_read_image_extension_rules(ingest, host, tmp_path):
     assert ingest.read_image(str(tmp_path / "upper.PNG"))[0, 0, 0] == np.float32(200) / np.float32(255)
     ingest.write_pfm(str(tmp_path / "f.pfm"), a.astype(np.float32))
     assert np.array_equal(ingest.read_image(str(tmp_path / "f.pfm")), a.astype(np.float32))
+
+
+@pytest.mark.parametrize("compression", ["none", "rle", "zips", "zip"])
+@pytest.mark.parametrize("pixel_type", ["half", "float"])
+def test_openexr_scanline_files(ingest, tmp_path, compression, pixel_type):
+    rng = np.random.default_rng(21)
+    h, w = 37, 29   # not a multiple of the 16-line ZIP block
+    a = (rng.random((h, w, 3), dtype=np.float32) * 4.0).astype(np.float32)
+    a[5:20, 3:25] = a[5, 3]                          # flat region: long runs after the delta predictor
+    a[0, 0] = (0.0, 6.1e-5, 3.0e-6)                  # smallest normal half and a subnormal half
+    a[1, 1] = (65504.0, np.inf, -2.5)
+    path = str(tmp_path / "t.exr")
+    ingest.write_exr(path, a, compression, pixel_type, alpha=True, origin=(-3, 7), extra_channels=("Z",))
+    want = a.astype(np.float16).astype(np.float32) if pixel_type == "half" else a
+    assert np.array_equal(ingest.read_image(path), want)
+
+
+def test_openexr_named_layer_and_refusals(ingest, host, tmp_path):
+    a = np.random.default_rng(3).random((8, 8, 3), dtype=np.float32)
+    path = str(tmp_path / "layer.exr")
+    ingest.write_exr(path, a, "zip", "float", layer="diffuse.")
+    assert np.array_equal(ingest.read_image(path), a)                              # first layer that has R, G and B
+    raw = bytearray(open(path, "rb").read())
+    i = raw.index(b"compression\0compression\0") + len(b"compression\0compression\0") + 4
+    raw[i] = 4                                                                      # PIZ
+    open(path, "wb").write(raw)
+    with pytest.raises(host.BackendError, match="PIZ"):
+        ingest.read_image(path)
+    raw[i] = 3; raw[4:8] = (2 | 0x200).to_bytes(4, "little")                       # tiled flag
+    open(path, "wb").write(raw)
+    with pytest.raises(host.BackendError, match="tiled"):
+        ingest.read_image(path)
+    open(path, "wb").write(b"not an exr file at all")
+    with pytest.raises(host.BackendError, match="magic"):
+        ingest.read_image(path)
