@@ -810,10 +810,16 @@ struct PlyReader {
 };
 }  // namespace
 
+static int ply_read_unguarded(const char* path, rtxh_ply* out);
 int rtxh_ply_read(const char* path, rtxh_ply* out) {
   if (!path || !out) return fail(RT_ERR_INVALID, "null argument");
   g_err.clear();
   memset(out, 0, sizeof(*out));
+  try { return ply_read_unguarded(path, out); }  // no C++ exception may cross the C ABI (a damaged header can ask for any amount of memory)
+  catch (const std::bad_alloc&) { rtxh_ply_free(out); return fail(RT_ERR_OOM, std::string("out of memory while reading ") + path); }
+  catch (const std::exception& e) { rtxh_ply_free(out); return fail(RT_ERR_INVALID, std::string(e.what()) + " (" + path + ")"); }
+}
+static int ply_read_unguarded(const char* path, rtxh_ply* out) {
   PlyReader rd; rd.f = fopen(path, "rb");
   if (!rd.f) return fail(RT_ERR_INVALID, std::string("cannot open ") + path);
   struct Closer { FILE* f; ~Closer() { if (f) fclose(f); } } closer{rd.f};

@@ -168,7 +168,7 @@ bool png_decode(const std::vector<uint8_t>& file, int& W, int& H, std::vector<ui
       Bytes d{data, 13}; w = d.be32(); h = d.be32(); depth = d.u8(); ctype = d.u8();
       if (d.u8() != 0 || d.u8() != 0) { err = "PNG: unknown compression / filter method"; return false; }
       interlace = d.u8(); have_ihdr = true;
-      if (w == 0 || h == 0 || w > 65536 || h > 65536 || interlace > 1) { err = "PNG: bad dimensions"; return false; }
+      if (w == 0 || h == 0 || w > 65536 || h > 65536 || (uint64_t)w * h > (1ull << 28) || interlace > 1) { err = "PNG: bad dimensions"; return false; }
       const bool ok = (ctype == 0 && (depth == 1 || depth == 2 || depth == 4 || depth == 8 || depth == 16)) || (ctype == 3 && (depth == 1 || depth == 2 || depth == 4 || depth == 8)) ||
                       ((ctype == 2 || ctype == 4 || ctype == 6) && (depth == 8 || depth == 16));
       if (!ok) { err = "PNG: invalid colour type / bit depth"; return false; }
@@ -237,7 +237,7 @@ bool tga_decode(const std::vector<uint8_t>& file, int& W, int& H, std::vector<ui
   b.le16(); b.le16();
   const int w = b.le16(), h = b.le16(), bits = b.u8(), desc = b.u8();
   const bool rle = type & 8; const int base = type & 7;
-  if (w == 0 || h == 0) { err = "TGA: bad dimensions"; return false; }
+  if (w == 0 || h == 0 || (uint64_t)w * h > (1ull << 28)) { err = "TGA: bad dimensions"; return false; }
   if (base < 1 || base > 3 || type > 11) { err = "TGA: unsupported image type"; return false; }
   if (base == 1 && (map_type != 1 || bits != 8 || (map_bits != 24 && map_bits != 32))) { err = "TGA: unsupported colour map"; return false; }
   if (base == 2 && bits != 24 && bits != 32) { err = "TGA: unsupported pixel depth"; return false; }
@@ -285,7 +285,7 @@ bool hdr_decode(const std::vector<uint8_t>& file, int& W, int& H, std::vector<fl
   (void)have_format;
   if (!line(l)) { err = "HDR: missing resolution line"; return false; }
   int h = 0, w = 0;
-  if (sscanf(l.c_str(), "-Y %d +X %d", &h, &w) != 2 || w <= 0 || h <= 0) { err = "HDR: unsupported orientation / resolution \"" + l + "\""; return false; }
+  if (sscanf(l.c_str(), "-Y %d +X %d", &h, &w) != 2 || w <= 0 || h <= 0 || (uint64_t)w * (uint64_t)h > (1ull << 28)) { err = "HDR: unsupported orientation / resolution \"" + l + "\""; return false; }
   W = w; H = h; rgb.assign((size_t)w * h * 3, 0.0f);
   std::vector<uint8_t> scan((size_t)w * 4);
   for (int y = 0; y < h; ++y) {
@@ -392,7 +392,7 @@ bool exr_decode(const std::vector<uint8_t>& file, int& W, int& H, std::vector<fl
   if (compression > 3) { err = "EXR: only NONE, RLE, ZIPS and ZIP compression are supported (this file uses PIZ / PXR24 / B44 / DWA)"; return false; }
   if (line_order > 1) { err = "EXR: unsupported line order"; return false; }
   const long long w = (long long)dw[2] - dw[0] + 1, h = (long long)dw[3] - dw[1] + 1;
-  if (w <= 0 || h <= 0 || w > 65536 || h > 65536) { err = "EXR: bad data window"; return false; }
+  if (w <= 0 || h <= 0 || w > 65536 || h > 65536 || w * h > (1ll << 28)) { err = "EXR: bad data window"; return false; }
   if (disp[2] - disp[0] != dw[2] - dw[0] || disp[3] - disp[1] != dw[3] - dw[1]) { err = "EXR: data window and display window differ in size"; return false; }
   int ci[3] = {-1, -1, -1};  // first layer with R, G, B: the unnamed layer's channels, else the first "<layer>.R / .G / .B" triple
   bool found = false;
@@ -455,9 +455,15 @@ bool exr_decode(const std::vector<uint8_t>& file, int& W, int& H, std::vector<fl
 
 }  // namespace
 
+static int image_read_unguarded(const char* path, int32_t* width, int32_t* height, float** rgb);
 extern "C" int rtxh_image_read(const char* path, int32_t* width, int32_t* height, float** rgb) {
   if (!path || !width || !height || !rgb) return fail(RT_ERR_INVALID, "null argument");
   g_err.clear();
+  try { return image_read_unguarded(path, width, height, rgb); }  // no C++ exception may cross the C ABI
+  catch (const std::bad_alloc&) { return fail(RT_ERR_OOM, std::string("out of memory while decoding ") + path); }
+  catch (const std::exception& e) { return fail(RT_ERR_INVALID, std::string(e.what()) + " (" + path + ")"); }
+}
+static int image_read_unguarded(const char* path, int32_t* width, int32_t* height, float** rgb) {
   const std::string p = path; const size_t dot = p.find_last_of('.'), slash = p.find_last_of('/');
   if (dot == std::string::npos || (slash != std::string::npos && dot < slash)) return fail(RT_ERR_INVALID, "Texture filename doesn't have an extension");  // imageio.rs:19-21
   const std::string ext = p.substr(dot + 1);

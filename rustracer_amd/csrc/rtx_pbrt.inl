@@ -66,7 +66,8 @@ struct PbrtSoup {  // triangle soup: world space for the scene, instance space f
 };
 
 struct PbrtLoader {
-  rtxh_scene* scene = nullptr;
+  rtxh_scene* scene = nullptr; bool scene_handed_over = false;
+  ~PbrtLoader() { if (scene && !scene_handed_over) rtxh_scene_free(scene); }
   rtxh_render_params* rp = nullptr;
   std::string film_filename, err;
   int max_prims = 4, warnings = 0;
@@ -93,7 +94,7 @@ struct PbrtLoader {
     size_t i = 0, n = src.size();
     while (i < n) {
       char c = src[i];
-      if (c == ' ' || c == '\t' || c == '\n' || c == '\r') { ++i; continue; }
+      if (c == ' ' || c == '\t' || c == '\n' || c == '\r' || c == '\0') { ++i; continue; }
       if (c == '#') { while (i < n && src[i] != '\n') ++i; continue; }
       if (c == '[') { out.push_back({2, "["}); ++i; continue; }
       if (c == ']') { out.push_back({3, "]"}); ++i; continue; }
@@ -104,7 +105,7 @@ struct PbrtLoader {
         out.push_back({1, src.substr(i + 1, j - i - 1)}); i = j + 1; continue;
       }
       size_t j = i;
-      while (j < n && !strchr(" \t\r\n[]\"#", src[j])) ++j;
+      while (j < n && src[j] != '\0' && !strchr(" \t\r\n[]\"#", src[j])) ++j;
       out.push_back({0, src.substr(i, j - i)}); i = j;
     }
     return true;
@@ -583,26 +584,32 @@ int pbrt_load_text(const std::string& text, const std::string& base_dir, rtxh_pb
     if (rtxh_scene_set_mesh(L.scene, w.P.data(), nv, w.idx.data(), nt, w.any_n ? w.N.data() : nullptr, w.any_uv ? w.UV.data() : nullptr, w.any_s ? w.S.data() : nullptr,
                             w.tri_mat.data(), w.tri_light.data(), w.tri_flags.data()) != RT_OK || rtxh_scene_commit(L.scene, L.max_prims) != RT_OK) { L.err = rtxh_last_error(); ok = false; }
   }
-  if (!ok) { std::string m = L.err.empty() ? std::string("pbrt: parse error") : "pbrt: " + L.err; rtxh_scene_free(L.scene); return fail(RT_ERR_INVALID, m); }
-  out->scene = L.scene; out->max_prims_per_node = L.max_prims; out->n_warnings = L.warnings;
+  if (!ok) { std::string m = L.err.empty() ? std::string("pbrt: parse error") : "pbrt: " + L.err; return fail(RT_ERR_INVALID, m); }
+  out->scene = L.scene; L.scene_handed_over = true; out->max_prims_per_node = L.max_prims; out->n_warnings = L.warnings;
   snprintf(out->film_filename, sizeof out->film_filename, "%s", L.film_filename.c_str());
   return RT_OK;
 }
 
 }  // namespace
 
+// no C++ exception may cross the C ABI: a damaged file can ask for any amount of memory
+static int pbrt_load_guarded(const std::string& text, const std::string& base_dir, rtxh_pbrt_result* out) {
+  try { return pbrt_load_text(text, base_dir, out); }
+  catch (const std::bad_alloc&) { memset(out, 0, sizeof *out); return fail(RT_ERR_OOM, "pbrt: out of memory while building the scene"); }
+  catch (const std::exception& e) { memset(out, 0, sizeof *out); return fail(RT_ERR_INVALID, std::string("pbrt: ") + e.what()); }
+}
 int rtxh_pbrt_load(const char* path, rtxh_pbrt_result* out) {
   if (!path || !out) return fail(RT_ERR_INVALID, "null argument");
   g_err.clear();
   std::string text;
   if (!PbrtLoader::read_file(path, text)) return fail(RT_ERR_INVALID, std::string("cannot open ") + path);
   std::string dir = path; size_t sl = dir.find_last_of('/'); dir = sl == std::string::npos ? std::string() : dir.substr(0, sl);
-  return pbrt_load_text(text, dir, out);
+  return pbrt_load_guarded(text, dir, out);
 }
 int rtxh_pbrt_parse(const char* text, const char* base_dir, rtxh_pbrt_result* out) {
   if (!text || !out) return fail(RT_ERR_INVALID, "null argument");
   g_err.clear();
-  return pbrt_load_text(text, base_dir ? base_dir : "", out);
+  return pbrt_load_guarded(text, base_dir ? base_dir : "", out);
 }
 int rtxh_pbrt_tokens(const char* text, char* out, uint64_t capacity) {
   if (!text) return fail(RT_ERR_INVALID, "null argument");

@@ -101,7 +101,7 @@ def _p(a, t=C.c_float):
 def _check(rc, what):
     if rc < 0:
         msg = lib().rtxh_last_error()
-        raise BackendError(f"{what} failed ({rc}): {msg.decode() if msg else '?'}")
+        raise BackendError(f"{what} failed ({rc}): {msg.decode(errors='replace') if msg else '?'}")
     return rc
 
 
@@ -311,7 +311,7 @@ class PbrtScene(HostScene):
         self.params = RenderParams.from_buffer_copy(res.params)
         self.max_prims_per_node = res.max_prims_per_node
         self.n_warnings = res.n_warnings
-        self.film_filename = res.film_filename.decode()
+        self.film_filename = res.film_filename.decode(errors='replace')
 
     def _render_params(self, rank=0, world_size=1, flags=0):
         p = RenderParams.from_buffer_copy(self.params)
@@ -348,7 +348,7 @@ def sampler_tables(spp, dims, pixel0, n_pixels, plain=False):
     fn = hip_lib().rt_sampler_tables_plain if plain else hip_lib().rt_sampler_tables
     rc = fn(spp, dims, C.c_uint64(pixel0), C.c_uint64(n_pixels), _p(sc, C.c_uint32), _p(pm, C.c_uint16))
     if rc < 0:
-        raise BackendError(f"rt_sampler_tables failed ({rc}): {hip_lib().rt_last_error().decode()}")
+        raise BackendError(f"rt_sampler_tables failed ({rc}): {hip_lib().rt_last_error().decode(errors='replace')}")
     return sc, pm
 
 

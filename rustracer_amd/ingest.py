@@ -28,7 +28,7 @@ def read_ply(path: str) -> dict:
     ply = _Ply()
     rc = L.rtxh_ply_read(str(path).encode(), C.byref(ply))
     if rc != 0:
-        raise host.BackendError(f"rtxh_ply_read failed ({rc}): {L.rtxh_last_error().decode()}")
+        raise host.BackendError(f"rtxh_ply_read failed ({rc}): {L.rtxh_last_error().decode(errors='replace')}")
     try:
         nv, nt = ply.n_verts, ply.n_tris
         out = dict(P=np.ctypeslib.as_array(ply.P, (nv, 3)).copy(), idx=np.ctypeslib.as_array(ply.idx, (nt, 3)).copy() if nt else np.zeros((0, 3), np.int32),
@@ -83,7 +83,7 @@ def read_pfm(path: str) -> np.ndarray:
     w, h, p = C.c_int32(), C.c_int32(), C.POINTER(C.c_float)()
     rc = L.rtxh_pfm_read(str(path).encode(), C.byref(w), C.byref(h), C.byref(p))
     if rc != 0:
-        raise host.BackendError(f"rtxh_pfm_read failed ({rc}): {L.rtxh_last_error().decode()}")
+        raise host.BackendError(f"rtxh_pfm_read failed ({rc}): {L.rtxh_last_error().decode(errors='replace')}")
     try:
         return np.ctypeslib.as_array(p, (h.value, w.value, 3)).copy()
     finally:
@@ -109,7 +109,7 @@ def read_image(path: str) -> np.ndarray:
     L.rtxh_free.restype = None
     rc = L.rtxh_image_read(str(path).encode(), C.byref(w), C.byref(h), C.byref(ptr))
     if rc != 0:
-        raise host.BackendError(f"rtxh_image_read failed ({rc}): {L.rtxh_last_error().decode()}")
+        raise host.BackendError(f"rtxh_image_read failed ({rc}): {L.rtxh_last_error().decode(errors='replace')}")
     try:
         return np.ctypeslib.as_array(ptr, (h.value, w.value, 3)).copy()
     finally:

@@ -241,3 +241,39 @@ def test_openexr_named_layer_and_refusals(ingest, host, tmp_path):
     open(path, "wb").write(b"not an exr file at all")
     with pytest.raises(host.BackendError, match="magic"):
         ingest.read_image(path)
+
+
+def test_damaged_image_and_mesh_files_fail_cleanly(ingest, host, tmp_path):
+    """Random damage and truncation of valid PNG / TGA / HDR / EXR / PFM / PLY files: an error or a decoded result, never a crash."""
+    import random
+    rng = np.random.default_rng(1)
+    a8 = rng.integers(0, 256, (9, 11, 3))
+    ingest.write_png(str(tmp_path / "a.png"), a8, 2, 8)
+    ingest.write_png(str(tmp_path / "b.png"), rng.integers(0, 4, (9, 11, 1)), 3, 2, palette=rng.integers(0, 256, (4, 3)), interlace=True)
+    ingest.write_tga(str(tmp_path / "a.tga"), a8.astype(np.uint8), "rgb", rle=True)
+    ingest.write_hdr(str(tmp_path / "a.hdr"), rng.integers(0, 256, (6, 40, 4)).astype(np.uint8), rle=True)
+    ingest.write_exr(str(tmp_path / "a.exr"), rng.random((20, 9, 3), dtype=np.float32), "zip", "half")
+    ingest.write_exr(str(tmp_path / "b.exr"), rng.random((5, 9, 3), dtype=np.float32), "rle", "float")
+    ingest.write_pfm(str(tmp_path / "a.pfm"), rng.random((4, 5, 3), dtype=np.float32))
+    ingest.write_ply(str(tmp_path / "a.ply"), rng.random((6, 3), dtype=np.float32), [[0, 1, 2], [3, 4, 5, 0]])
+    ingest.write_ply(str(tmp_path / "b.ply"), rng.random((6, 3), dtype=np.float32), [[0, 1, 2], [3, 4, 5]], fmt="ascii")
+    rnd = random.Random(7)
+    for name in sorted(p.name for p in tmp_path.iterdir()):
+        data = (tmp_path / name).read_bytes()
+        ext = name.split(".")[-1]
+        for _ in range(40):
+            b = bytearray(data)
+            if rnd.random() < 0.25:
+                b = b[: rnd.randrange(len(b))]
+            for _ in range(rnd.choice([1, 2, 4, 16])):
+                if b:
+                    b[rnd.randrange(len(b))] = rnd.randrange(256)
+            if rnd.random() < 0.2 and len(b) > 8:
+                i = rnd.randrange(len(b) - 4)
+                b[i:i + 4] = rnd.choice([b"\xff\xff\xff\xff", b"\x00\x00\x00\x00", b"\xff\xff\xff\x7f"])
+            p = str(tmp_path / ("fz." + ext))
+            open(p, "wb").write(b)
+            try:
+                ingest.read_ply(p) if ext == "ply" else ingest.read_image(p)
+            except host.BackendError:
+                pass

@@ -487,3 +487,25 @@ def test_errors(text, message):
 def test_unknown_material_and_coordinate_system_are_logged_not_fatal():
     p = _parse(HEADER + 'WorldBegin\nCoordSysTransform "nowhere"\nMaterial "velvet"\n' + TRI + "AttributeEnd\nTransformEnd\nWorldEnd\n")
     assert p.n_warnings == 4 and p.table("materials")[0]["kind"] == sd.MAT_MATTE   # api.rs:663-667, 1178-1181, 757-760, 779-782
+
+
+def test_damaged_files_fail_cleanly(tmp_path):
+    """NUL bytes, truncation and random damage end in BackendError (or a valid scene), never in a hang or a C++ exception."""
+    import random
+    from rustracer_amd.scenes import cornell_box
+    path = os.path.join(str(tmp_path), "c.pbrt")
+    text = write_pbrt(cornell_box(16, 16, 4), path).encode()
+    rnd = random.Random(5)
+    cases = [text.replace(b"[0 1 2 0 2 3]", b"[0 \0\0\0\0 0 2 3]", 1), text[: len(text) // 2], text.replace(b'"', b"", 1), b"\0" * 64, b"Shape " * 1000]
+    for _ in range(60):
+        b = bytearray(text)
+        for _ in range(rnd.choice([1, 2, 8])):
+            b[rnd.randrange(len(b))] = rnd.randrange(256)
+        cases.append(bytes(b))
+    for k, c in enumerate(cases):
+        p = os.path.join(str(tmp_path), f"d{k}.pbrt")
+        open(p, "wb").write(c)
+        try:
+            host.PbrtScene(p)
+        except host.BackendError:
+            pass
