@@ -814,6 +814,8 @@ extern "C" int rt_render(rt_scene* s, const rt_camera* cam, const rt_film_desc* 
       unsigned* const cb = s->counters.as<unsigned>();
       ps.cnt_in = nullptr; ps.cnt_out = cb;  // raygen appends to block 0's `out` queue
       ps.all_in_bounds = all_in_bounds ? 1 : 0;
+      ps.resolve_scan = use_bins ? 1 : 0;
+      if (use_bins) HIP_TRY(hipMemsetAsync(ps.pend_flags, 0, (size_t)ps.cap * 4, stream));
       tm.begin(&stats.ms_raygen);
       hipLaunchKernelGGL(k_raygen, dim3(pgrid), dim3(256), 0, stream, fp, ps);
       tm.end();

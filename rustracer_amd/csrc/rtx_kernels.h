@@ -40,6 +40,7 @@ struct PassState {
   unsigned* q_in; unsigned* q_out; unsigned* q_shadow; unsigned* q_mis;
   const unsigned* cnt_in; unsigned* cnt_out; unsigned shard_cap;
   int all_in_bounds;  // every sample of the pass is traced (no crop by pixel_bounds): bounce 0 needs no queue, path i is entry i
+  int resolve_scan;   // k_resolve walks pend_flags in path-id order instead of the MIS queue (set when the shade queue is binned)
   const unsigned* range;  // k_shade: shade entries [range[0], range[1]) of q_in only (NULL = all): class-wise dispatch over the binned queue
   unsigned long long* stats;  // device-side u64 counters, see ST_* below
 };
@@ -1089,13 +1090,18 @@ __global__ void __launch_bounds__(256, MODE == 1 ? RT_SHADE_MIN_WAVES : RT_SHADE
 // ================================================================================ K5 resolve
 // estimate_direct for the (rare) vertices whose BSDF-sampled MIS ray was traced: ld = [unoccluded] Ld1 +
 // [the MIS ray reached the sampled light] f*Le*w/pdf; L += beta_at_vertex * (ld / light_pick_pdf).
+// ps.resolve_scan: the MIS queue was filled in the binned shade order, i.e. scattered over the path ids; the vertices are then found
+// by scanning pend_flags in path-id order (flag bit 1 = an MIS ray is out, cleared here), which keeps every access below coalesced.
 __global__ void __launch_bounds__(256) k_resolve(DScene sc, PassState ps) {
   QView qv; qv.init(ps.q_mis, ps.cnt_out + 2 * RT_QSHARDS, ps.shard_cap);
-  const unsigned count = qv.total();
+  const bool scan = ps.resolve_scan && (unsigned long long)qv.total() * 16ull >= ps.cap;  // a sparse queue is cheaper to gather than the flags are to scan
+  const unsigned count = scan ? ps.cap : qv.total();
   const unsigned stride = gridDim.x * blockDim.x;
   for (unsigned i = blockIdx.x * blockDim.x + threadIdx.x; i < count; i += stride) {
-    const unsigned pid = qv.get(i);
-    const unsigned pend = ps.pend_flags[pid];
+    unsigned pid, pend;
+    if (scan) { pid = i; pend = ps.pend_flags[i]; if (!(pend & 2u)) continue; }
+    else { pid = qv.get(i); pend = ps.pend_flags[pid]; }
+    if (ps.resolve_scan) ps.pend_flags[pid] = 0u;
     float4 a = ps.pend_a[pid], c = ps.pend_c[pid];
     rgb3 ld = mkc(0, 0, 0);
     if ((pend & 1u) && ps.sh_occ[pid] == 0u) ld = ld + mkc(a.x, a.y, a.z);
