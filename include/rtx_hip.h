@@ -189,6 +189,18 @@ void rt_scene_destroy(rt_scene* scene);
 int rt_bvh_build(const float* tri_p, uint32_t n_tris, int32_t max_prims_per_node, rt_bvh_node* nodes, uint32_t* n_nodes, int32_t* ordered,
                  float* ms_device /* may be NULL */);
 
+/* MIPMap::new (rc/mipmap.rs:75-187) on the device: the Lanczos zoom of a non-power-of-two image (taps computed by the caller: first
+ * source texel + 4 weights per output texel and axis; NULL and px = width, py = height for power-of-two images) and the box-filtered
+ * levels. lvl_w / lvl_h / lvl_off: level geometry (texel offsets into texels_out, which receives every level). Host pointers. */
+int rt_mip_build(const float* rgb, int32_t width, int32_t height, int32_t px, int32_t py, const int32_t* s_first, const float* s_wts, const int32_t* t_first,
+                 const float* t_wts, int32_t wrap, int32_t n_levels, const int32_t* lvl_w, const int32_t* lvl_h, const uint64_t* lvl_off, float* texels_out);
+/* The sampling tables of InfiniteAreaLight::new (rc/light/infinite.rs:78-101) on the device: func = luminance of the filtered map
+ * lookup * sin(theta) at width x height (twice the map's resolution), one Distribution1D per row (rc/distribution1d.rs:11-42) and the
+ * marginal one over the row integrals. mode / il / delta: MIPMap::lookup's level choice for the constant filter width (0: level 0,
+ * 1: the last level's texel, 2: levels il and il + 1 blended by delta); sin_theta: height values. All pointers are host memory. */
+int rt_env_distribution(const rt_image* image, int32_t width, int32_t height, int32_t mode, int32_t il, float delta, const float* sin_theta,
+                        float* func, float* cdf, float* func_int, float* marg_cdf, float* marg_func_int);
+
 /* Renders one frame: the body of renderer::render (rc/renderer.rs:22-143) — preprocess (light
  * distribution), per-pixel sampler tables, camera rays, PathIntegrator::li for every sample,
  * radiance scrubbing and Film::add_sample/merge. Blocking. film_xyzw: W*H*4 floats over the

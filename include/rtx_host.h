@@ -45,6 +45,10 @@ void rtxh_scene_free(rtxh_scene*);
  * list of that triangle's DiffuseAreaLight or -1; tri_flags = RT_TRI_* (per-mesh attributes). */
 int rtxh_scene_set_mesh(rtxh_scene*, const float* P, int32_t n_verts, const int32_t* indices, int32_t n_tris, const float* N, const float* UV,
                         const float* S, const int32_t* tri_material, const int32_t* tri_light, const uint8_t* tri_flags);
+/* on != 0: MIP pyramids (rtxh_scene_add_mipmap) and environment-map sampling tables (rtxh_scene_add_light, infinite) are built
+ * by the GPU (rt_mip_build, rt_env_distribution in rtx_hip.h) - bit-identical tables, milliseconds instead of tenths of a second for
+ * a 2048 x 1024 map. Off by default: the host build needs no device. Process-wide. */
+void rtxh_set_device_ingest(int32_t on);
 int rtxh_scene_add_mipmap(rtxh_scene*, int32_t width, int32_t height, const float* rgb, int32_t trilinear, float max_aniso, int32_t wrap);
 int rtxh_scene_add_texture(rtxh_scene*, int32_t kind, const float* value3, int32_t tex1, int32_t tex2, int32_t amount, int32_t mip, const float* mapping4);
 int rtxh_scene_add_material(rtxh_scene*, int32_t kind, const int32_t* slots16, int32_t remap_roughness, int32_t bump_texture /* or -1 */);
@@ -68,7 +72,9 @@ int rtxh_mip_level(rtxh_scene*, int32_t mip, int32_t level, int32_t* w, int32_t*
  * out == NULL: only *n_items. Items: rt_texture, rt_material, rtxh_light_info, float[3] (P N S), float[2] (UV),
  * int32[3] (indices), int32 (tri material / light), uint8 (tri flags). */
 enum { RTXH_TABLE_TEXTURES = 0, RTXH_TABLE_MATERIALS, RTXH_TABLE_LIGHTS, RTXH_TABLE_P, RTXH_TABLE_N, RTXH_TABLE_UV, RTXH_TABLE_S, RTXH_TABLE_INDICES,
-       RTXH_TABLE_TRI_MATERIAL, RTXH_TABLE_TRI_LIGHT, RTXH_TABLE_TRI_FLAGS };
+       RTXH_TABLE_TRI_MATERIAL, RTXH_TABLE_TRI_LIGHT, RTXH_TABLE_TRI_FLAGS,
+       /* sampling tables of the first infinite light (floats): func, per-row cdf, row integrals, marginal cdf */
+       RTXH_TABLE_ENV_FUNC, RTXH_TABLE_ENV_CDF, RTXH_TABLE_ENV_ROW_INT, RTXH_TABLE_ENV_MARG_CDF };
 typedef struct rtxh_light_info { int32_t kind, tri; float rgb[3]; int32_t two_sided; float vec[3]; int32_t mip; float l2w[12], w2l[12]; } rtxh_light_info;
 int rtxh_scene_inspect(rtxh_scene*, int32_t table, void* out, uint64_t capacity_bytes, uint64_t* n_items);
 int rtxh_look_at(const float* pos, const float* look, const float* up, float* m16, float* m_inv16);

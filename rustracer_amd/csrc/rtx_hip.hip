@@ -349,6 +349,7 @@ extern "C" int rt_scene_create(const rt_scene_desc* desc, int device, rt_scene**
 }
 
 #include "rtx_bvh_build.h"
+#include "rtx_ingest_build.h"
 
 extern "C" void rt_scene_destroy(rt_scene* s) {
   if (!s) return;

@@ -535,8 +535,40 @@ static std::vector<MipResampleWeight> mip_resample_weights(int old_res, int new_
 }
 static int round_up_pow2(int v) { v -= 1; v |= v >> 1; v |= v >> 2; v |= v >> 4; v |= v >> 8; v |= v >> 16; return v + 1; }  // lib.rs:215-224
 
+static bool g_device_ingest = false;
+void rtxh_set_device_ingest(int32_t on) { g_device_ingest = on != 0; }
+
+// MIPMap::new with the arithmetic on the GPU (rt_mip_build): the host only supplies the Lanczos taps and the level geometry
+static int add_mipmap_device(rtxh_scene* s, int32_t w, int32_t h, const float* rgb_in, int32_t trilinear, float max_aniso, int32_t wrap) {
+  MipLevels m; m.trilinear = trilinear; m.wrap = wrap; m.max_aniso = max_aniso;
+  const int px = round_up_pow2(w), py = round_up_pow2(h);
+  std::vector<int32_t> sf, tf; std::vector<float> sw, tw;
+  if (px != w || py != h) {
+    auto taps = [](int old_res, int new_res, std::vector<int32_t>& first, std::vector<float>& wts) {
+      const std::vector<MipResampleWeight> wt = mip_resample_weights(old_res, new_res);
+      first.resize(wt.size()); wts.resize(wt.size() * 4);
+      for (size_t i = 0; i < wt.size(); ++i) { first[i] = wt[i].first_texel; for (int j = 0; j < 4; ++j) wts[4 * i + j] = wt[i].w[j]; }
+    };
+    taps(w, px, sf, sw); taps(h, py, tf, tw);
+  }
+  const int n_levels = 1 + (int)f2usz(std::log2((float)std::max(px, py)));
+  uint64_t off = 0;
+  for (int i = 0; i < n_levels; ++i) {
+    const int lw = i == 0 ? px : std::max(1, m.w[i - 1] / 2), lh = i == 0 ? py : std::max(1, m.h[i - 1] / 2);
+    m.w.push_back(lw); m.h.push_back(lh); m.off.push_back(off); off += (uint64_t)lw * lh;
+  }
+  m.texels.assign((size_t)off * 3, 0.0f);
+  const int rc = rt_mip_build(rgb_in, w, h, px, py, sf.empty() ? nullptr : sf.data(), sw.empty() ? nullptr : sw.data(), tf.empty() ? nullptr : tf.data(), tw.empty() ? nullptr : tw.data(),
+                              wrap, n_levels, m.w.data(), m.h.data(), m.off.data(), m.texels.data());
+  if (rc != RT_OK) { g_err.clear(); return rc; }
+  s->mips.push_back(std::move(m));
+  s->committed = false;
+  return (int)s->mips.size() - 1;
+}
+
 int rtxh_scene_add_mipmap(rtxh_scene* s, int32_t w, int32_t h, const float* rgb_in, int32_t trilinear, float max_aniso, int32_t wrap) {
   if (!s || !rgb_in || w <= 0 || h <= 0 || w > 65536 || h > 65536) return fail(RT_ERR_INVALID, "bad image");
+  if (g_device_ingest) return add_mipmap_device(s, w, h, rgb_in, trilinear, max_aniso, wrap);
   MipLevels m; m.trilinear = trilinear; m.wrap = wrap; m.max_aniso = max_aniso;
   std::vector<float> resampled;
   const float* rgb = rgb_in;
@@ -628,6 +660,25 @@ int rtxh_scene_add_light(rtxh_scene* s, int32_t kind, int32_t tri, const float* 
     const int width = 2 * m.w[0], height = 2 * m.h[0];
     const float filter = 0.5f / std::fmin((float)width, (float)height);
     const float pi = 3.14159265358979323846f;
+    if (g_device_ingest) {  // same tables from the GPU (rt_env_distribution); sin(theta) and the level choice of the constant filter width stay on the host
+      std::vector<float> sin_theta((size_t)height);
+      for (int v = 0; v < height; ++v) sin_theta[(size_t)v] = std::sin(pi * ((float)v + 0.5f) / (float)height);
+      const int nl = (int)m.w.size();
+      const float level = (float)nl - 1.0f + std::log2(std::fmax(filter, 1e-8f));
+      int mode, il = 0; float delta = 0.0f;
+      if (level < 0.0f) mode = 0; else if (level >= (float)nl - 1.0f) mode = 1; else { mode = 2; const float fl = std::floor(level); il = (int)f2usz(fl); delta = level - fl; }
+      rt_image im{}; im.n_levels = nl;
+      for (int lv = 0; lv < nl; ++lv) { im.width[lv] = m.w[lv]; im.height[lv] = m.h[lv]; im.offset[lv] = m.off[lv]; }
+      im.texels = m.texels.data(); im.n_texels = m.texels.size() / 3; im.trilinear = m.trilinear; im.max_anisotropy = m.max_aniso; im.wrap = m.wrap;
+      hl.dfunc.assign((size_t)width * height, 0.0f); hl.dcdf.assign((size_t)height * (width + 1), 0.0f); hl.dint.assign((size_t)height, 0.0f); hl.mcdf.assign((size_t)height + 1, 0.0f);
+      float mint = 0.0f;
+      const int rc = rt_env_distribution(&im, width, height, mode, il, delta, sin_theta.data(), hl.dfunc.data(), hl.dcdf.data(), hl.dint.data(), hl.mcdf.data(), &mint);
+      if (rc != RT_OK) { g_err.clear(); return rc; }
+      hl.mfunc = hl.dint; l.marg_func_int = mint; l.dist_nu = width; l.dist_nv = height;
+      s->lights.push_back(std::move(hl));
+      s->committed = false;
+      return (int)s->lights.size() - 1;
+    }
     std::vector<float> img((size_t)width * height);
     for (int v = 0; v < height; ++v) {
       float vp = ((float)v + 0.5f) / (float)height;
@@ -713,6 +764,13 @@ int rtxh_scene_inspect(rtxh_scene* s, int32_t table, void* out, uint64_t capacit
     case RTXH_TABLE_TRI_MATERIAL: src = s->tri_mat.data(); item = 4; n = s->tri_mat.size(); break;
     case RTXH_TABLE_TRI_LIGHT: src = s->tri_light.data(); item = 4; n = s->tri_light.size(); break;
     case RTXH_TABLE_TRI_FLAGS: src = s->tri_flags.data(); item = 1; n = s->tri_flags.size(); break;
+    case RTXH_TABLE_ENV_FUNC: case RTXH_TABLE_ENV_CDF: case RTXH_TABLE_ENV_ROW_INT: case RTXH_TABLE_ENV_MARG_CDF: {
+      const HostLight* e = nullptr;
+      for (const HostLight& h : s->lights) if (h.l.kind == RT_LIGHT_INFINITE) { e = &h; break; }
+      if (!e) { *n_items = 0; return RT_OK; }
+      const std::vector<float>& v = table == RTXH_TABLE_ENV_FUNC ? e->dfunc : table == RTXH_TABLE_ENV_CDF ? e->dcdf : table == RTXH_TABLE_ENV_ROW_INT ? e->dint : e->mcdf;
+      src = v.data(); item = 4; n = v.size(); break;
+    }
     default: return fail(RT_ERR_INVALID, "unknown table");
   }
   *n_items = n;

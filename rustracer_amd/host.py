@@ -136,8 +136,17 @@ def render_params(desc, rank=0, world_size=1, flags=0) -> RenderParams:
 
 
 class HostScene:
-    def __init__(self, desc, device_bvh=False):
-        """device_bvh=True: the tree comes from the GPU's linear builder (rt_bvh_build) instead of the host SAH build."""
+    def __init__(self, desc, device_bvh=False, device_ingest=False):
+        """device_bvh=True: the tree comes from the GPU's linear builder (rt_bvh_build) instead of the host SAH build.
+        device_ingest=True: MIP pyramids and environment-map sampling tables are built on the GPU (bit-identical tables)."""
+        L = lib()
+        L.rtxh_set_device_ingest(1 if device_ingest else 0)
+        try:
+            self._build(desc, device_bvh)
+        finally:
+            L.rtxh_set_device_ingest(0)
+
+    def _build(self, desc, device_bvh):
         L = lib()
         self.desc = desc
         self.h = C.c_void_p(L.rtxh_scene_new())
@@ -281,7 +290,8 @@ _MATERIAL_DT = np.dtype([("kind", "<i4"), ("slot", "<i4", 16), ("remap_roughness
 _LIGHT_DT = np.dtype([("kind", "<i4"), ("tri", "<i4"), ("rgb", "<f4", 3), ("two_sided", "<i4"), ("vec", "<f4", 3), ("mip", "<i4"), ("l2w", "<f4", 12), ("w2l", "<f4", 12)])
 _TABLES = {"textures": (0, _TEXTURE_DT), "materials": (1, _MATERIAL_DT), "lights": (2, _LIGHT_DT), "P": (3, np.dtype(("<f4", 3))), "N": (4, np.dtype(("<f4", 3))),
            "UV": (5, np.dtype(("<f4", 2))), "S": (6, np.dtype(("<f4", 3))), "indices": (7, np.dtype(("<i4", 3))), "tri_material": (8, np.dtype("<i4")),
-           "tri_light": (9, np.dtype("<i4")), "tri_flags": (10, np.dtype("u1"))}
+           "tri_light": (9, np.dtype("<i4")), "tri_flags": (10, np.dtype("u1")), "env_func": (11, np.dtype("<f4")), "env_cdf": (12, np.dtype("<f4")),
+           "env_row_int": (13, np.dtype("<f4")), "env_marg_cdf": (14, np.dtype("<f4"))}
 
 
 def scene_table(handle, name):
