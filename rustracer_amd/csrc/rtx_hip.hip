@@ -224,13 +224,13 @@ extern "C" int rt_scene_create(const rt_scene_desc* desc, int device, rt_scene**
       hmat[i].code_class = it->second;
     }
     s->n_code_classes = (unsigned)classes.size();
-    // classes the register-resident front-end can shade (constant Kd, sigma == 0, no bump: SingleLambert) get the lowest ids, so that
+    // classes the register-resident front-end can shade (matte, sigma == 0, no bump, Kd any texture: SingleLambertT) get the lowest ids, so that
     // after binning they are one contiguous range of the queue
     auto is_const = [&](int id) { return id >= 0 && (uint32_t)id < desc->n_textures && desc->textures[id].kind == RT_TEX_CONST; };
     std::vector<int> lambert(classes.size(), 0), remap(classes.size(), -1);
     for (uint32_t i = 0; i < desc->n_materials; ++i) {
       const rt_material& m = desc->materials[i];
-      lambert[hmat[i].code_class] = m.kind == RT_MAT_MATTE && is_const(m.slot[RT_SLOT_KD]) && is_const(m.slot[RT_SLOT_SIGMA]) && m.bump < 0 &&
+      lambert[hmat[i].code_class] = m.kind == RT_MAT_MATTE && m.slot[RT_SLOT_KD] >= 0 && is_const(m.slot[RT_SLOT_SIGMA]) && m.bump < 0 &&
                                     desc->textures[m.slot[RT_SLOT_SIGMA]].value[0] <= 0.0f;
     }
     int next = 0;
@@ -300,7 +300,13 @@ extern "C" int rt_scene_create(const rt_scene_desc* desc, int device, rt_scene**
     const float sg = desc->textures[m.slot[RT_SLOT_SIGMA]].value[0];
     if (!(sg <= 0.0f)) { s->lambert_only = false; break; }  // clamp(sigma, 0, 1) == 0 (matte.rs:51)
   }
-  s->lambert_materials = s->lambert_only;
+  s->lambert_materials = true;  // the same with Kd any texture: SingleLambertT<true>
+  for (uint32_t i = 0; i < desc->n_materials; ++i) {
+    const rt_material& m = desc->materials[i];
+    const bool sigma_zero = m.slot[RT_SLOT_SIGMA] >= 0 && (uint32_t)m.slot[RT_SLOT_SIGMA] < desc->n_textures && desc->textures[m.slot[RT_SLOT_SIGMA]].kind == RT_TEX_CONST &&
+                            desc->textures[m.slot[RT_SLOT_SIGMA]].value[0] <= 0.0f;
+    if (m.kind != RT_MAT_MATTE || m.slot[RT_SLOT_KD] < 0 || !sigma_zero || m.bump >= 0) { s->lambert_materials = false; break; }
+  }
   for (uint32_t i = 0; i < desc->n_lights; ++i) if (desc->lights[i].kind != RT_LIGHT_DIFFUSE_AREA) s->lambert_only = false;
   s->n_materials = desc->n_materials;
   s->small = desc->n_nodes <= RT_SMALL_NODES && desc->n_tris <= RT_SMALL_TRIS;

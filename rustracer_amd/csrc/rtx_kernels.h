@@ -886,11 +886,14 @@ struct GenericBsdf {
   RT_DEV LobeSample sample_f(f3 wo, f2 u, unsigned flags) const { return bsdf_sample_f(b, wo, u, flags); }
   RT_DEV float eta() const { return b.eta; }
 };
-struct SingleLambert {
+template <bool TEXTURED>  // TEXTURED: Kd may be any texture (evaluated out of line); false: constant Kd only, no call in the kernel
+struct SingleLambertT {
   rgb3 r; bool has; f3 ns, ng, ss, ts;
-  RT_DEV void build(const DScene& sc, int mat, SurfaceInteraction& si) {  // matte.rs:37-62 with constant Kd, sigma == 0, no bump map
-    const DTexture& t = sc.textures[sc.materials[mat].slot[0]];
-    r = clamp_pos(mkc(t.v[0], t.v[1], t.v[2]));
+  RT_DEV void build(const DScene& sc, int mat, SurfaceInteraction& si) {  // matte.rs:37-62 with sigma == 0 and no bump map
+    const int kd = sc.materials[mat].slot[0];
+    const DTexture& t = sc.textures[kd];
+    if (TEXTURED && t.kind != RT_TEX_CONST) r = clamp_pos(tex_eval(sc, kd, si));
+    else r = clamp_pos(mkc(t.v[0], t.v[1], t.v[2]));
     has = !is_black(r);
     ss = normalize(si.sh_dpdu); ns = si.sh_n; ng = si.hit.n; ts = cross(si.sh_n, ss);  // Bsdf::new, bsdf/mod.rs:77-91
   }
@@ -924,12 +927,13 @@ struct SingleLambert {
   }
   RT_DEV float eta() const { return 1.0f; }
 };
+typedef SingleLambertT<false> SingleLambert;
 
 // MODE 0: any material / texture / light. MODE 1: every material is matte with constant Kd and
 // sigma == 0 and every light is a DiffuseAreaLight (decided by the host from the material and light
 // tables); no texture then reads the camera-ray differentials and the kernel makes no out-of-line call.
-// MODE 3: the materials of MODE 1 under any kind of light (environment, point, distant): the register-resident
-// front-end with the generic light functions.
+// MODE 3: matte materials with sigma == 0 and no bump map - Kd any texture - under any kind of light: the register-resident
+// front-end with the generic light and texture functions.
 #ifndef RT_SHADE_MIN_WAVES
 #define RT_SHADE_MIN_WAVES 2
 #endif
@@ -978,13 +982,13 @@ __global__ void __launch_bounds__(256, MODE == 1 ? RT_SHADE_MIN_WAVES : RT_SHADE
         }
       }
       if (found && bounces < fp.max_depth) {  // path.rs:139
-        if ((MODE & 1) == 0 && bounces == 0 && sc.needs_differentials) {  // only the camera ray carries differentials (interaction.rs:245-314)
+        if (MODE != 1 && bounces == 0 && sc.needs_differentials) {  // only the camera ray carries differentials (interaction.rs:245-314)
           f2 pf; { float2 t = ps.pfilm[pid]; pf = mk2(t.x, t.y); }
           f2 pl = table_2d(smp.tb, pix, 1, s);
           CameraRay cr = generate_camera_ray(fp, pf, pl, 1.0f / sqrtf((float)ps.spp));
           compute_differential(si, cr.rx_o, cr.ry_o, cr.rx_d, cr.ry_d);
         }
-        typename std::conditional<(MODE & 1) != 0, SingleLambert, GenericBsdf>::type bsdf;
+        typename std::conditional<MODE == 1, SingleLambert, typename std::conditional<MODE == 3, SingleLambertT<true>, GenericBsdf>::type>::type bsdf;
         bsdf.build(sc, tri_material(sc.tri_p, prim), si);
         // light_distribution.lookup(p) (path.rs:154-158)
         const float* ld_func; const float* ld_cdf; float ld_int;
