@@ -62,7 +62,7 @@ struct rt_scene {
   DevBuf ws[32];
   DevBuf film_acc, own_acc, film_out, counters, stats, filter_table;
   DevBuf bin_words, bin_sorted;  // material binning of the shade queue (generic shade path)
-  unsigned n_materials = 0, n_code_classes = 0, n_lambert_classes = 0;
+  unsigned n_materials = 0, n_code_classes = 0, n_lambert_classes = 0, n_small_classes = 0;
   // sampler tables are double-buffered: K0 of batch b+1 runs on aux_stream under the path kernels of batch b
   DevBuf scrambles[2], perms[2];
   hipStream_t aux_stream = nullptr;
@@ -233,10 +233,18 @@ extern "C" int rt_scene_create(const rt_scene_desc* desc, int device, rt_scene**
       lambert[hmat[i].code_class] = m.kind == RT_MAT_MATTE && m.slot[RT_SLOT_KD] >= 0 && is_const(m.slot[RT_SLOT_SIGMA]) && m.bump < 0 &&
                                     desc->textures[m.slot[RT_SLOT_SIGMA]].value[0] <= 0.0f;
     }
+    // then the classes of the two-lobe front-end (SmallBsdf): matte with sigma > 0, plastic, metal, mirror, no bump map
+    std::vector<int> small(classes.size(), 0);
+    for (uint32_t i = 0; i < desc->n_materials; ++i) {
+      const rt_material& m = desc->materials[i];
+      small[hmat[i].code_class] = !lambert[hmat[i].code_class] && m.bump < 0 && (m.kind == RT_MAT_MATTE || m.kind == RT_MAT_PLASTIC || m.kind == RT_MAT_METAL || m.kind == RT_MAT_MIRROR);
+    }
     int next = 0;
     for (size_t c = 0; c < classes.size(); ++c) if (lambert[c]) remap[c] = next++;
     s->n_lambert_classes = (unsigned)next;
-    for (size_t c = 0; c < classes.size(); ++c) if (!lambert[c]) remap[c] = next++;
+    for (size_t c = 0; c < classes.size(); ++c) if (small[c]) remap[c] = next++;
+    s->n_small_classes = (unsigned)next - s->n_lambert_classes;
+    for (size_t c = 0; c < classes.size(); ++c) if (!lambert[c] && !small[c]) remap[c] = next++;
     for (uint32_t i = 0; i < desc->n_materials; ++i) hmat[i].code_class = remap[hmat[i].code_class];
   }
   TRY_RC(upload(s->materials, hmat.data(), hmat.size() * sizeof(DMaterial)));
@@ -745,9 +753,11 @@ extern "C" int rt_render(rt_scene* s, const rt_camera* cam, const rt_film_desc* 
   static const bool bin_off = getenv("RTX_SHADE_BINS") && getenv("RTX_SHADE_BINS")[0] == '0';  // measurement knob
   const bool use_bins = !s->lambert_materials && s->n_code_classes > 1 && !bin_off;  // one class: every vertex runs the same code, the queue order is kept
   const unsigned n_bins = std::min<unsigned>(s->n_code_classes, RT_BIN_MAX) + 1u;
-  const size_t bin_stride = 2 * (RT_BIN_MAX + 1) + RT_QSHARDS + 4;  // + {begin, end} of the two class ranges
-  static const bool split_off = getenv("RTX_SHADE_SPLIT") && getenv("RTX_SHADE_SPLIT")[0] == '0';  // measurement knob
-  const bool split_classes = use_bins && !split_off && s->n_lambert_classes > 0 && s->n_lambert_classes < RT_BIN_MAX;
+  const size_t bin_stride = 2 * (RT_BIN_MAX + 1) + RT_QSHARDS + 6;  // + {begin, end} of the three class ranges
+  // RTX_SHADE_SPLIT (measurement knob): 0 = every class through the generic front-end, 1 = Lambert classes apart, default = Lambert and two-lobe classes apart
+  const int split_mode = getenv("RTX_SHADE_SPLIT") ? atoi(getenv("RTX_SHADE_SPLIT")) : 2;
+  const unsigned n_first = split_mode >= 1 ? s->n_lambert_classes : 0u, n_second = split_mode >= 2 ? s->n_small_classes : 0u;
+  const bool split_classes = use_bins && (n_first + n_second) > 0 && n_first + n_second < RT_BIN_MAX;
   if (use_bins) { HIP_TRY(s->bin_words.ensure((size_t)(fp.max_depth + 1) * bin_stride * 4)); HIP_TRY(s->bin_sorted.ensure(cap * 4)); }
   HIP_TRY(s->film_acc.ensure((size_t)cw * ch * 16)); HIP_TRY(s->own_acc.ensure(chunk_pixels * 16));
   HIP_TRY(s->filter_table.ensure(1024));
@@ -843,11 +853,12 @@ extern "C" int rt_render(rt_scene* s, const rt_camera* cam, const rt_film_desc* 
           hipLaunchKernelGGL(k_bin_count, dim3(pgrid), dim3(256), 0, stream, s->d, ps, n_bins, hist);
           unsigned* ranges = sorted_cnt + RT_QSHARDS;
           hipLaunchKernelGGL(k_bin_scatter, dim3(pgrid), dim3(256), 0, stream, s->d, ps, n_bins, hist, cursor, s->bin_sorted.as<unsigned>(), sorted_cnt,
-                             split_classes ? s->n_lambert_classes : 0u, ranges);
+                             split_classes ? n_first : 0u, split_classes ? n_first + n_second : 0u, ranges);
           PassState pb = ps; pb.q_in = s->bin_sorted.as<unsigned>(); pb.cnt_in = sorted_cnt;  // all entries in shard 0: QView::get(i) = ids[i]
           if (split_classes) {  // constant-matte classes through the register-resident front-end, the rest through the generic one
-            pb.range = ranges; hipLaunchKernelGGL(k_shade<3>, dim3(pgrid), dim3(256), 0, stream, s->d, fp, pb);
-            pb.range = ranges + 2; hipLaunchKernelGGL(k_shade<0>, dim3(pgrid), dim3(256), 0, stream, s->d, fp, pb);
+            if (n_first) { pb.range = ranges; hipLaunchKernelGGL(k_shade<3>, dim3(pgrid), dim3(256), 0, stream, s->d, fp, pb); }
+            if (n_second) { pb.range = ranges + 2; hipLaunchKernelGGL(k_shade<5>, dim3(pgrid), dim3(256), 0, stream, s->d, fp, pb); }
+            pb.range = ranges + 4; hipLaunchKernelGGL(k_shade<0>, dim3(pgrid), dim3(256), 0, stream, s->d, fp, pb);
           } else hipLaunchKernelGGL(k_shade<0>, dim3(pgrid), dim3(256), 0, stream, s->d, fp, pb);
         }
         tm.end();

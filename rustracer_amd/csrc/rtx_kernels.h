@@ -826,15 +826,17 @@ __global__ void __launch_bounds__(256) k_bin_count(DScene sc, PassState ps, unsi
 }
 // sorted: path ids grouped by bin; sorted_cnt[RT_QSHARDS]: {total, 0, ...} so that the result reads as a one-shard queue
 __global__ void __launch_bounds__(256) k_bin_scatter(DScene sc, PassState ps, unsigned n_bins, const unsigned* __restrict__ hist, unsigned* __restrict__ cursor,
-                                                     unsigned* __restrict__ sorted, unsigned* __restrict__ sorted_cnt, unsigned split_bin, unsigned* __restrict__ ranges) {
+                                                     unsigned* __restrict__ sorted, unsigned* __restrict__ sorted_cnt, unsigned split_bin, unsigned split_bin2,
+                                                     unsigned* __restrict__ ranges) {
   __shared__ unsigned base[RT_BIN_MAX + 1], lcount[RT_BIN_MAX + 1], lbase[RT_BIN_MAX + 1];
   if (threadIdx.x == 0) {  // exclusive prefix of the histogram (<= 257 entries)
     unsigned run = 0;
     for (unsigned b = 0; b < n_bins; ++b) { base[b] = run; run += hist[b]; }
     if (blockIdx.x == 0) {
       sorted_cnt[0] = run; for (int k = 1; k < RT_QSHARDS; ++k) sorted_cnt[k] = 0u;
-      const unsigned split = split_bin < n_bins ? base[split_bin] : run;  // bins [0, split_bin) are the classes the register-resident front-end shades
-      ranges[0] = 0u; ranges[1] = split; ranges[2] = split; ranges[3] = run;
+      // bins [0, split_bin): classes of the Lambert front-end; [split_bin, split_bin2): of the two-lobe front-end; the rest: generic
+      const unsigned split = split_bin < n_bins ? base[split_bin] : run, split2 = split_bin2 < n_bins ? base[split_bin2] : run;
+      ranges[0] = 0u; ranges[1] = split; ranges[2] = split; ranges[3] = split2; ranges[4] = split2; ranges[5] = run;
     }
   }
   for (unsigned i = threadIdx.x; i <= RT_BIN_MAX; i += 256u) lcount[i] = 0u;
@@ -929,11 +931,127 @@ struct SingleLambertT {
 };
 typedef SingleLambertT<false> SingleLambert;
 
+// Register-resident front-end for the materials that build at most two lobes out of {Lambertian, Oren-Nayar, microfacet
+// reflection, specular reflection}: matte (any sigma), plastic, metal, mirror, without bump map. Bsdf::{f, pdf, sample_f}
+// (bsdf/mod.rs:94-251) restated over two named lobes; every lobe function is entered with its kind as a constant, so only that
+// kind's code is instantiated. Same operations in the same order as GenericBsdf (sums start from the same zero, the same component
+// choice and u remap), hence the same values.
+struct SmallBsdf {
+  f3 ns, ng, ss, ts; int n; Lobe l0, l1;
+  RT_DEV void add(const Lobe& l) { if (n == 0) l0 = l; else l1 = l; ++n; }
+  RT_DEV void build(const DScene& sc, int mat, SurfaceInteraction& si) {
+    const DMaterial& m = sc.materials[mat]; const int* s = m.slot;
+    n = 0; l0 = lobe_zero(LB_LAMBERT_R); l1 = l0;
+    if (m.kind == 0) {  // matte.rs:37-62
+      rgb3 r = clamp_pos(tex_eval(sc, s[0], si));
+      float sigma = clampf(tex_eval_f(sc, s[4], si), 0.0f, 1.0f);
+      if (!is_black(r)) {
+        if (sigma == 0.0f) add(mk_lambert(LB_LAMBERT_R, r));
+        else {  // OrenNayar::new, oren_nayar.rs:17-27
+          Lobe l = lobe_zero(LB_OREN_NAYAR); l.r = r;
+          float sigma_rad = sigma * (kPi / 180.0f);
+          float sigma2 = sigma_rad * sigma_rad;
+          l.ax = 1.0f - (sigma2 / (2.0f * (sigma2 + 0.33f)));
+          l.ay = 0.45f * sigma2 / (sigma2 + 0.09f);
+          add(l);
+        }
+      }
+    } else if (m.kind == 1) {  // plastic.rs:45-75
+      rgb3 kd = tex_eval(sc, s[0], si), ks = tex_eval(sc, s[1], si);
+      if (!is_black(kd)) add(mk_lambert(LB_LAMBERT_R, kd));
+      if (!is_black(ks)) {
+        float rough = tex_eval_f(sc, s[5], si);
+        if (m.remap) rough = tr_roughness_to_alpha(rough);
+        add(mk_micro_r(ks, rough, rough, FR_DIELECTRIC, 1.5f, 1.0f));
+      }
+    } else if (m.kind == 2) {  // metal.rs:50-82
+      float ur = tex_eval_f(sc, s[6] >= 0 ? s[6] : s[5], si), vr = tex_eval_f(sc, s[7] >= 0 ? s[7] : s[5], si);
+      if (m.remap) { ur = tr_roughness_to_alpha(ur); vr = tr_roughness_to_alpha(vr); }
+      Lobe l = mk_micro_r(mkc(1, 1, 1), ur, vr, FR_CONDUCTOR, 1.0f, 1.0f);
+      l.t = tex_eval(sc, s[8], si); l.k = tex_eval(sc, s[9], si);
+      add(l);
+    } else {  // mirror.rs:30-48
+      rgb3 R = clamp_pos(tex_eval(sc, s[2], si));
+      if (!is_black(R)) { Lobe l = lobe_zero(LB_SPEC_R); l.r = R; add(l); }
+    }
+    ss = normalize(si.sh_dpdu); ns = si.sh_n; ng = si.hit.n; ts = cross(si.sh_n, ss);  // Bsdf::new, bsdf/mod.rs:77-91
+  }
+  RT_DEV f3 to_local(f3 v) const { return mk3(dot(v, ss), dot(v, ts), dot(v, ns)); }
+  // one lobe function entered with its kind as a compile-time constant
+  template <class F> RT_DEV static auto with_kind(const Lobe& l, F fn) -> decltype(fn(l)) {
+    Lobe c = l;
+    switch (l.kind) {
+      case LB_OREN_NAYAR: c.kind = LB_OREN_NAYAR; return fn(c);
+      case LB_MICRO_R: c.kind = LB_MICRO_R; return fn(c);
+      case LB_SPEC_R: c.kind = LB_SPEC_R; return fn(c);
+      default: c.kind = LB_LAMBERT_R; return fn(c);
+    }
+  }
+  RT_DEV static rgb3 lf(const Lobe& l, f3 wo, f3 wi) { return with_kind(l, [&](const Lobe& c) { return lobe_f_inner(c, wo, wi); }); }
+  RT_DEV static float lp(const Lobe& l, f3 wo, f3 wi) { return with_kind(l, [&](const Lobe& c) { return lobe_pdf_inner(c, wo, wi); }); }
+  RT_DEV static LobeSample lsamp(const Lobe& l, f3 wo, f2 u) { return with_kind(l, [&](const Lobe& c) { return lobe_sample_inner(c, wo, u); }); }
+  RT_DEV int num(unsigned flags) const { return (n > 0 && lobe_matches(l0.kind, flags) ? 1 : 0) + (n > 1 && lobe_matches(l1.kind, flags) ? 1 : 0); }
+  RT_DEV int num_nonspecular() const { return num(BSDF_ALL & ~BSDF_SPECULAR); }
+  RT_DEV static bool admits(const Lobe& l, unsigned flags, bool refl) {
+    const unsigned ty = lobe_type(l.kind);
+    return ((ty & flags) == ty) && ((refl && (ty & BSDF_REFLECTION)) || (!refl && (ty & BSDF_TRANSMISSION)));
+  }
+  RT_DEV rgb3 f(f3 wo_w, f3 wi_w, unsigned flags) const {  // :94-111
+    f3 wi = to_local(wi_w), wo = to_local(wo_w);
+    if (wo.z == 0.0f) return mkc(0, 0, 0);
+    bool refl = dot(wi_w, ng) * dot(wo_w, ng) > 0.0f;
+    rgb3 c = mkc(0, 0, 0);
+    if (n > 0 && admits(l0, flags, refl)) c = c + lf(l0, wo, wi);
+    if (n > 1 && admits(l1, flags, refl)) c = c + lf(l1, wo, wi);
+    return c;
+  }
+  RT_DEV float pdf(f3 wo_w, f3 wi_w, unsigned flags) const {  // :113-136
+    if (n == 0) return 0.0f;
+    f3 wo = to_local(wo_w);
+    if (wo.z == 0.0f) return 0.0f;
+    f3 wi = to_local(wi_w);
+    int matched = 0; float p = 0.0f;
+    if (n > 0 && lobe_matches(l0.kind, flags)) { ++matched; p += lp(l0, wo, wi); }
+    if (n > 1 && lobe_matches(l1.kind, flags)) { ++matched; p += lp(l1, wo, wi); }
+    return matched == 0 ? 0.0f : p / (float)matched;
+  }
+  RT_DEV LobeSample sample_f(f3 wo_w, f2 u, unsigned flags) const {  // :138-251
+    const bool m0 = n > 0 && lobe_matches(l0.kind, flags), m1 = n > 1 && lobe_matches(l1.kind, flags);
+    const int m = (m0 ? 1 : 0) + (m1 ? 1 : 0);
+    if (m == 0) return mk_ls(mkc(0, 0, 0), mk3(0, 0, 0), 0.0f, 0u);
+    int comp_i = (int)f2u_sat(floorf(u.x * (float)m));
+    if (comp_i > m - 1) comp_i = m - 1;
+    const bool second = m0 ? (comp_i == 1) : true;  // the comp_i-th matching lobe
+    const Lobe bx = second ? l1 : l0;
+    const unsigned bty = lobe_type(bx.kind);
+    f2 ur = mk2(fminf(u.x * (float)m - (float)comp_i, kOneMinusEpsilon), u.y);
+    f3 wo = to_local(wo_w);
+    if (wo.z == 0.0f) return mk_ls(mkc(0, 0, 0), mk3(0, 0, 0), 0.0f, bty);
+    LobeSample s = lsamp(bx, wo, ur);
+    if (s.pdf == 0.0f) return mk_ls(mkc(0, 0, 0), mk3(0, 0, 0), 0.0f, 0u);
+    f3 wi = s.wi;
+    f3 wi_w = mk3(ss.x * wi.x + ts.x * wi.y + ns.x * wi.z, ss.y * wi.x + ts.y * wi.y + ns.y * wi.z, ss.z * wi.x + ts.z * wi.y + ns.z * wi.z);
+    float pdf = s.pdf;
+    if (!(bty & BSDF_SPECULAR) && m > 1) pdf += second ? lp(l0, wo, wi) : lp(l1, wo, wi);  // the other matching lobe
+    if (m > 1) pdf /= (float)m;
+    rgb3 fv = s.f;
+    if (!(bty & BSDF_SPECULAR)) {
+      bool refl = dot(wi_w, ng) * dot(wo_w, ng) > 0.0f;
+      fv = mkc(0, 0, 0);
+      if (n > 0 && admits(l0, flags, refl)) fv = fv + lf(l0, wo, wi);
+      if (n > 1 && admits(l1, flags, refl)) fv = fv + lf(l1, wo, wi);
+    }
+    return mk_ls(fv, wi_w, pdf, s.type);
+  }
+  RT_DEV float eta() const { return 1.0f; }
+};
+
 // MODE 0: any material / texture / light. MODE 1: every material is matte with constant Kd and
 // sigma == 0 and every light is a DiffuseAreaLight (decided by the host from the material and light
 // tables); no texture then reads the camera-ray differentials and the kernel makes no out-of-line call.
 // MODE 3: matte materials with sigma == 0 and no bump map - Kd any texture - under any kind of light: the register-resident
-// front-end with the generic light and texture functions.
+// front-end with the generic light and texture functions. MODE 5: matte (any sigma), plastic, metal and mirror without bump map
+// through SmallBsdf.
 #ifndef RT_SHADE_MIN_WAVES
 #define RT_SHADE_MIN_WAVES 2
 #endif
@@ -988,7 +1106,8 @@ __global__ void __launch_bounds__(256, MODE == 1 ? RT_SHADE_MIN_WAVES : RT_SHADE
           CameraRay cr = generate_camera_ray(fp, pf, pl, 1.0f / sqrtf((float)ps.spp));
           compute_differential(si, cr.rx_o, cr.ry_o, cr.rx_d, cr.ry_d);
         }
-        typename std::conditional<MODE == 1, SingleLambert, typename std::conditional<MODE == 3, SingleLambertT<true>, GenericBsdf>::type>::type bsdf;
+        typename std::conditional<MODE == 1, SingleLambert, typename std::conditional<MODE == 3, SingleLambertT<true>,
+                                  typename std::conditional<MODE == 5, SmallBsdf, GenericBsdf>::type>::type>::type bsdf;
         bsdf.build(sc, tri_material(sc.tri_p, prim), si);
         // light_distribution.lookup(p) (path.rs:154-158)
         const float* ld_func; const float* ld_cdf; float ld_int;

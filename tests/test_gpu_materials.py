@@ -141,3 +141,18 @@ def test_constant_matte_scene_under_other_light_kinds(gpu_host, orc, lights):
         env = d.add_mip(sky_image(64, 32, (0.0, -0.3, -1.0), 30.0, 0.97), trilinear=False, max_aniso=0.0)
         d.infinite_light(env, np.array([[1, 0, 0, 0], [0, 0, 1, 0], [0, 1, 0, 0], [0, 0, 0, 1]], np.float32))
     _check(gpu_host, orc, d)
+
+
+@pytest.mark.parametrize("material", ["matte", "oren_nayar", "matte_image_ewa", "plastic", "plastic_noremap", "metal", "metal_aniso", "mirror", "mix"])
+def test_register_resident_front_ends_equal_the_generic_one(gpu_host, material, monkeypatch):
+    """Class-wise dispatch (k_shade<3> / k_shade<5> / k_shade<0>) against every class through the generic lobe array."""
+    d = _zoo(material, "infinite")
+    h = gpu_host.HostScene(d)
+    monkeypatch.setenv("RTX_SHADE_SPLIT", "0")
+    f0, s0 = h.render()
+    monkeypatch.setenv("RTX_SHADE_SPLIT", "2")
+    f2, s2 = h.render()
+    assert np.array_equal(f0[..., 3], f2[..., 3])
+    assert rel_l2(f2[..., :3], f0[..., :3]) < 1e-6
+    for k in ("rays_closest", "rays_shadow", "rays_mis"):
+        assert abs(int(s0[k]) - int(s2[k])) <= 4, k
