@@ -143,7 +143,7 @@ def test_constant_matte_scene_under_other_light_kinds(gpu_host, orc, lights):
     _check(gpu_host, orc, d)
 
 
-@pytest.mark.parametrize("material", ["matte", "oren_nayar", "matte_image_ewa", "plastic", "plastic_noremap", "metal", "metal_aniso", "mirror", "mix"])
+@pytest.mark.parametrize("material", ["matte", "oren_nayar", "matte_image_ewa", "plastic", "plastic_noremap", "metal", "metal_aniso", "mirror", "glass", "glass_rough", "substrate", "matte_bump_fbm", "plastic_bump_image", "mirror_bump_checker", "mix", "uber"])
 def test_register_resident_front_ends_equal_the_generic_one(gpu_host, material, monkeypatch):
     """Class-wise dispatch (k_shade<3> / k_shade<5> / k_shade<0>) against every class through the generic lobe array."""
     d = _zoo(material, "infinite")
