@@ -25,6 +25,7 @@ struct DLight {
 struct DScene {
   const float4* nodes; unsigned n_nodes;
   const float4* pairs;  // n_nodes x 64 B child-pair records of the interior nodes (NULL for LDS-resident scenes), see k_trace_pair
+  const float4* quads;  // n_nodes x 128 B grandchild records of the interior nodes (NULL when not built), see k_trace_quad
   const float4* tri_p; unsigned n_tris;
   const float* tri_n; const float* tri_uv; const float* tri_s;
   const DTexture* textures; const DImage* images; const DMaterial* materials; const DLight* lights;

@@ -53,6 +53,7 @@ struct rt_scene {
   unsigned n_nodes = 0, n_tris = 0; int n_lights = 0;
   DevBuf pairs, tmin_stack;  // child-pair node records and the HBM half of the traversal stack (k_trace_pair)
   bool use_pairs = false;
+  DevBuf quads; bool use_quads = false; int quad_stack_depth = 0;  // four-wide records of the any-hit kernel (k_trace_quad)
   DevBuf nodes, tri_p, tri_n, tri_uv, tri_s, textures, images, materials, lights, texels, dist;
   std::vector<DLight> h_lights;
   // light distribution tables (built per render, rc/integrator/path.rs:86-94)
@@ -331,7 +332,7 @@ extern "C" int rt_scene_create(const rt_scene_desc* desc, int device, rt_scene**
     if (maxd + 1 > 64) { delete s; return fail(RT_ERR_INVALID, "BVH deeper than the 64-entry traversal stack"); }
     s->stack_depth = maxd + 1;
   }
-  d.pairs = nullptr;
+  d.pairs = nullptr; d.quads = nullptr;
   if (!s->small) {  // LDS-resident scenes keep the one-node-per-step loop: the pair form measured no faster there
     // child-pair records for k_trace_pair: {A.min.xyz, A.max.x} {A.max.yz, code A, code B} {B.min.xyz, B.max.x} {B.max.yz, -, -}
     bool ok = desc->n_nodes < (1u << 29) && desc->n_tris < (1u << 26);
@@ -354,6 +355,41 @@ extern "C" int rt_scene_create(const rt_scene_desc* desc, int device, rt_scene**
       int rc2 = upload(s->pairs, pr.data(), pr.size() * 4);
       if (rc2 != RT_OK) { delete s; return rc2; }
       d.pairs = s->pairs.as<float4>(); s->use_pairs = true;
+    }
+    // four-wide records for the any-hit kernel (k_trace_quad): an interior node's grandchildren (a leaf child stands for itself), 128 B
+    // per node: 24 floats = boxes of slots 0..3 (slots 0,1: first child's part, 2,3: second child's), 4 codes (0xffffffff = empty slot),
+    // {axis of the first child | axis of the second child << 2}.
+    if (ok) {
+      std::vector<float> qr((size_t)desc->n_nodes * 32, 0.0f);
+      std::vector<int> need(desc->n_nodes, 0);  // stack entries the four-wide walk can have pending below this node
+      for (uint32_t i = desc->n_nodes; i-- > 0;) {
+        const rt_bvh_node& n = desc->nodes[i];
+        if (n.n_prims != 0) continue;
+        float* q = qr.data() + (size_t)i * 32;
+        uint32_t codes[4] = {0xffffffffu, 0xffffffffu, 0xffffffffu, 0xffffffffu}, axes = 0; int n_entries = 0, deepest = 0;
+        const uint32_t child[2] = {i + 1, n.offset};
+        for (int side = 0; side < 2; ++side) {
+          const rt_bvh_node& c = desc->nodes[child[side]];
+          uint32_t ids[2]; int cnt;
+          if (c.n_prims != 0) { ids[0] = child[side]; cnt = 1; }
+          else { ids[0] = child[side] + 1; ids[1] = c.offset; cnt = 2; axes |= (uint32_t)c.axis << (2 * side); }
+          for (int k = 0; k < cnt; ++k) {
+            const rt_bvh_node& g = desc->nodes[ids[k]];
+            float* bq = q + 6 * (2 * side + k);
+            bq[0] = g.bmin[0]; bq[1] = g.bmin[1]; bq[2] = g.bmin[2]; bq[3] = g.bmax[0]; bq[4] = g.bmax[1]; bq[5] = g.bmax[2];
+            codes[2 * side + k] = code_of(ids[k], ok);
+            n_entries += 1; if (need[ids[k]] > deepest) deepest = need[ids[k]];
+          }
+        }
+        memcpy(q + 24, codes, 16); memcpy(q + 28, &axes, 4);
+        need[i] = deepest + n_entries - 1;
+      }
+      s->quad_stack_depth = need[0] + 1;
+      if (ok && s->quad_stack_depth <= 32) {  // beyond the 32-entry LDS stack the larger stack costs more residency than the wider step returns
+        int rc2 = upload(s->quads, qr.data(), qr.size() * 4);
+        if (rc2 != RT_OK) { delete s; return rc2; }
+        d.quads = s->quads.as<float4>(); s->use_quads = true;
+      }
     }
   }
   fill_ewa_lut();
@@ -449,6 +485,12 @@ static void launch_trace_v(rt_scene* s, const float4* ro, const float4* rd, cons
     // loop, default = child-pair traversal (frames that count visits always use the one-node-per-step loops)
     static const char* mode = getenv("RTX_TRACE");
     const bool plain = mode && mode[0] == 'p', refill_only = mode && mode[0] == 'r';
+    if (ANY && !COUNT && !plain && !refill_only && !(mode && mode[0] == 'c') && s->use_quads && s->quad_stack_depth <= DEPTH) {  // RTX_TRACE=childpair: two-wide only
+      const unsigned grid = (unsigned)s->n_cu * per_cu;
+      static const unsigned refill_min_q = getenv("RTX_REFILL_MIN") ? (unsigned)atoi(getenv("RTX_REFILL_MIN")) : (unsigned)RT_REFILL_MIN;
+      hipLaunchKernelGGL((k_trace_quad<ANY, BLOCK, DEPTH>), dim3(grid), dim3(BLOCK), 0, stream, s->d, ro, rd, queue, count_ptr, shard_cap, count_static, hits, occ, stats, st_rays, lacc, direct_add, s->tmin_stack.as<float>(), refill_min_q);
+      return;
+    }
     if (!COUNT && !plain && !refill_only && s->use_pairs) {
       const unsigned grid = (unsigned)s->n_cu * per_cu;
       if (!ANY && s->tmin_stack.ensure((size_t)grid * BLOCK * DEPTH * 4) != hipSuccess) return;
