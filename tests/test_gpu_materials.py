@@ -156,3 +156,15 @@ def test_register_resident_front_ends_equal_the_generic_one(gpu_host, material, 
     assert rel_l2(f2[..., :3], f0[..., :3]) < 1e-6
     for k in ("rays_closest", "rays_shadow", "rays_mis"):
         assert abs(int(s0[k]) - int(s2[k])) <= 4, k
+
+
+def test_cropped_film_and_pixel_bounds_with_the_class_wise_dispatch(gpu_host, orc):
+    """cropwindow + pixelbounds (samples outside are never traced) on a scene that is binned, class-dispatched and resolved by flag scan."""
+    d = _zoo("plastic", "infinite", res=(48, 40), spp=8)
+    d.film.crop = (0.1, 0.9, 0.2, 0.85)
+    d.integrator.pixel_bounds = (10, 40, 12, 30)
+    _check(gpu_host, orc, d)
+    d2 = _zoo("mix_nested", "point", res=(48, 40), spp=8)
+    d2.integrator.pixel_bounds = (0, 30, 5, 40)
+    d2.film.filter_kind, d2.film.filter_params = 1, (1.5, 1.5, 0.0, 0.0)   # triangle filter: samples splat onto neighbouring pixels
+    _check(gpu_host, orc, d2)
