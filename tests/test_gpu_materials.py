@@ -168,3 +168,21 @@ def test_cropped_film_and_pixel_bounds_with_the_class_wise_dispatch(gpu_host, or
     d2.integrator.pixel_bounds = (0, 30, 5, 40)
     d2.film.filter_kind, d2.film.filter_params = 1, (1.5, 1.5, 0.0, 0.0)   # triangle filter: samples splat onto neighbouring pixels
     _check(gpu_host, orc, d2)
+
+
+def test_sharded_render_of_a_class_dispatched_scene_sums_to_the_full_frame(gpu_host):
+    """Film shards (one process per GPU in production) of a scene that takes every shade kernel: their sum is the full frame, bit for bit."""
+    from rustracer_amd.distributed import owned_pixel_mask
+    from util import bits
+    d = _zoo("mix_nested", "infinite", res=(40, 70), spp=4)
+    h = gpu_host.HostScene(d)
+    full, _ = h.render()
+    st = h.setup()
+    for world in (2, 8):
+        acc = np.zeros_like(full)
+        for r in range(world):
+            part, _ = h.render(rank=r, world_size=world)
+            m = owned_pixel_mask(st["cropped"], st["sample_bounds"], r, world)
+            assert np.all(part[~m] == 0)
+            acc += part
+        assert np.array_equal(bits(acc), bits(full))
