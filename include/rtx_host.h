@@ -37,6 +37,7 @@ typedef struct rtxh_render_params {
   int32_t pixel_bounds[4]; /* x0 x1 y0 y1; x1 <= x0 => film sample bounds                          */
   int32_t rank, world_size; /* film sharding (tile rows interleaved over ranks)                    */
   uint32_t flags;           /* RT_FLAG_*                                                           */
+  float screen_window[4];   /* xmin xmax ymin ymax; xmax <= xmin => create()'s default from the aspect ratio, camera.rs:86-107 */
 } rtxh_render_params;
 
 rtxh_scene* rtxh_scene_new(void);

@@ -144,6 +144,7 @@ struct orc_render_params {
   int32_t light_strategy;  // 0 = "spatial", 1 = "uniform"
   int32_t pixel_bounds[4]; // x0 x1 y0 y1; x1 <= x0 => use the sample bounds (path.rs:53-69)
   int32_t n_threads, tile_size;
+  float screen_window[4];  // xmin xmax ymin ymax; xmax <= xmin => PerspectiveCamera::create's default from the aspect ratio (camera.rs:86-107)
 };
 struct orc_stats {
   uint64_t camera_rays, rays_closest, rays_shadow, rays_mis, nodes_closest, nodes_shadow, nodes_mis, tris_closest, tris_shadow, tris_mis;
@@ -418,6 +419,7 @@ int orc_camera_film_setup(const orc_render_params* p, float* r2c, float* dxdy, f
   Film film; film.init(p->xres, p->yres, p->crop, f, p->film_scale, p->max_sample_luminance);
   Camera cam; Transform c2w; memcpy(c2w.m.m, p->cam_to_world, 64); memcpy(c2w.m_inv.m, p->cam_to_world_inv, 64);
   float sw[4]; Camera::default_screen_window(p->xres, p->yres, sw);
+  if (p->screen_window[1] > p->screen_window[0]) memcpy(sw, p->screen_window, 16);
   cam.init(c2w, sw, p->lens_radius, p->focal_distance, p->fov, p->xres, p->yres);
   memcpy(r2c, cam.raster_to_camera.m.m, 64);
   dxdy[0] = cam.dx_camera.x; dxdy[1] = cam.dx_camera.y; dxdy[2] = cam.dx_camera.z; dxdy[3] = cam.dy_camera.x; dxdy[4] = cam.dy_camera.y; dxdy[5] = cam.dy_camera.z;
@@ -462,6 +464,7 @@ int orc_render(void* h, const orc_render_params* p, float* film_xyzw, orc_stats*
   Film film; film.init(p->xres, p->yres, p->crop, f, p->film_scale, p->max_sample_luminance);
   Camera cam; Transform c2w; memcpy(c2w.m.m, p->cam_to_world, 64); memcpy(c2w.m_inv.m, p->cam_to_world_inv, 64);
   float sw[4]; Camera::default_screen_window(p->xres, p->yres, sw);
+  if (p->screen_window[1] > p->screen_window[0]) memcpy(sw, p->screen_window, 16);
   cam.init(c2w, sw, p->lens_radius, p->focal_distance, p->fov, p->xres, p->yres);
 
   auto t0 = std::chrono::steady_clock::now();
@@ -563,6 +566,7 @@ int orc_li_keyed(void* h, const orc_render_params* p, int px, int py, int sample
   Film film; film.init(p->xres, p->yres, p->crop, f, p->film_scale, p->max_sample_luminance);
   Camera cam; Transform c2w; memcpy(c2w.m.m, p->cam_to_world, 64); memcpy(c2w.m_inv.m, p->cam_to_world_inv, 64);
   float sw[4]; Camera::default_screen_window(p->xres, p->yres, sw);
+  if (p->screen_window[1] > p->screen_window[0]) memcpy(sw, p->screen_window, 16);
   cam.init(c2w, sw, p->lens_radius, p->focal_distance, p->fov, p->xres, p->yres);
   LightDistribution distrib; distrib.init(s, p->light_strategy == 1 ? "uniform" : "spatial");
   PathIntegrator integ; integ.scene = s; integ.distrib = &distrib; integ.max_depth = (int)(uint8_t)p->max_depth; integ.rr_threshold = p->rr_threshold;

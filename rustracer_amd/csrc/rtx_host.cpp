@@ -450,6 +450,7 @@ int setup_camera_film(const rtxh_render_params* p, CamFilm& out) {
   float sw[4];
   if (frame > 1.0f) { sw[0] = -frame; sw[1] = frame; sw[2] = -1.0f; sw[3] = 1.0f; }
   else { sw[0] = -1.0f; sw[1] = 1.0f; sw[2] = -1.0f / frame; sw[3] = 1.0f / frame; }
+  if (p->screen_window[1] > p->screen_window[0]) memcpy(sw, p->screen_window, 16);  // "screenwindow" / "frameaspectratio" (camera.rs:86-107)
   Xf camera_to_screen = xf_perspective(p->fov, 1e-2f, 1000.0f);
   Xf screen_to_raster = xf_mul(xf_mul(xf_scale((float)p->xres, (float)p->yres, 1.0f), xf_scale(1.0f / (sw[1] - sw[0]), 1.0f / (sw[2] - sw[3]), 1.0f)),
                                xf_translate(-sw[0], -sw[3], 0.0f));

@@ -435,7 +435,17 @@ struct PbrtLoader {
     else if (filter_name == "mitchell") { o.filter_kind = 3; o.filter_params[0] = filter_p.one_float("xwidth", 2.0f); o.filter_params[1] = filter_p.one_float("ywidth", 2.0f); o.filter_params[2] = filter_p.one_float("B", 1.0f / 3.0f); o.filter_params[3] = filter_p.one_float("C", 1.0f / 3.0f); }
     else return fail_("Filter \"" + filter_name + "\" unknown.");
     if (camera_name != "perspective") return fail_("Camera \"" + camera_name + "\" unknown.");
-    if (camera_p.find("frameaspectratio", {"float"}) || camera_p.find("screenwindow", {"float"})) return fail_("Camera: frameaspectratio / screenwindow are not supported");
+    {  // PerspectiveCamera::create, camera.rs:86-107: "frameaspectratio" (default xres / yres) gives the screen window, "screenwindow" overrides it
+      const float frame = camera_p.one_float("frameaspectratio", (float)o.xres / (float)o.yres);
+      const bool explicit_frame = camera_p.find("frameaspectratio", {"float"}) != nullptr;
+      float sw[4];
+      if (frame > 1.0f) { sw[0] = -frame; sw[1] = frame; sw[2] = -1.0f; sw[3] = 1.0f; } else { sw[0] = -1.0f; sw[1] = 1.0f; sw[2] = -1.0f / frame; sw[3] = 1.0f / frame; }
+      bool explicit_window = false;
+      if (const std::vector<float>* w = camera_p.floats("screenwindow", {"float"})) {
+        if (w->size() == 4) { for (int k = 0; k < 4; ++k) sw[k] = (*w)[k]; explicit_window = true; } else warn("screenwindow should have 4 values");
+      }
+      if (explicit_frame || explicit_window) { if (!(sw[1] > sw[0])) return fail_("Camera: empty screen window"); memcpy(o.screen_window, sw, 16); }
+    }
     float fov = camera_p.one_float("fov", 90.0f); const float half = camera_p.one_float("halffov", -1.0f);  // camera.rs:108-112
     if (half > 0.0f) fov = 2.0f * half;
     o.fov = fov; o.lens_radius = camera_p.one_float("lensradius", 0.0f); o.focal_distance = camera_p.one_float("focaldistance", 1e6f);

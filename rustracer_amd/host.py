@@ -50,6 +50,7 @@ class RenderParams(C.Structure):
         ("spp", C.c_int32), ("sampler_dims", C.c_int32),
         ("max_depth", C.c_int32), ("rr_threshold", C.c_float), ("light_strategy", C.c_int32),
         ("pixel_bounds", C.c_int32 * 4), ("rank", C.c_int32), ("world_size", C.c_int32), ("flags", C.c_uint32),
+        ("screen_window", C.c_float * 4),
     ]
 
 
@@ -112,6 +113,17 @@ def look_at(pos, look, up):
     return m, mi
 
 
+def screen_window_of(camera):
+    """PerspectiveCamera::create (camera.rs:86-107): explicit "screenwindow", else from "frameaspectratio", else (0, 0, 0, 0) = the default."""
+    if getattr(camera, "screen_window", None) is not None:
+        return tuple(camera.screen_window)
+    fr = getattr(camera, "frame_aspect", None)
+    if fr is None:
+        return (0.0, 0.0, 0.0, 0.0)
+    fr = np.float32(fr)
+    return (-fr, fr, -1.0, 1.0) if fr > 1.0 else (-1.0, 1.0, np.float32(-1.0) / fr, np.float32(1.0) / fr)
+
+
 def render_params(desc, rank=0, world_size=1, flags=0) -> RenderParams:
     p = RenderParams()
     f, c, s, it = desc.film, desc.camera, desc.sampler, desc.integrator
@@ -126,6 +138,7 @@ def render_params(desc, rank=0, world_size=1, flags=0) -> RenderParams:
     p.cam_to_world[:] = c2w.reshape(-1).tolist()
     p.cam_to_world_inv[:] = w2c.reshape(-1).tolist()
     p.fov, p.lens_radius, p.focal_distance = c.fov, c.lens_radius, c.focal_distance
+    p.screen_window[:] = [float(x) for x in screen_window_of(c)]
     p.spp, p.sampler_dims = s.spp, s.dims
     p.max_depth, p.rr_threshold = it.max_depth, it.rr_threshold
     p.light_strategy = 1 if it.light_strategy == "uniform" else 0

@@ -154,7 +154,12 @@ class _Writer:
         d, o = self.d, self.out
         c, f, s, it = d.camera, d.film, d.sampler, d.integrator
         o.append(f"LookAt {_nums(c.pos)}  {_nums(c.look)}  {_nums(c.up)}")
-        o.append(f'Camera "perspective" "float fov" [{_n(c.fov)}] "float lensradius" [{_n(c.lens_radius)}] "float focaldistance" [{_n(c.focal_distance)}]')
+        cam = f'Camera "perspective" "float fov" [{_n(c.fov)}] "float lensradius" [{_n(c.lens_radius)}] "float focaldistance" [{_n(c.focal_distance)}]'
+        if c.frame_aspect is not None:
+            cam += f' "float frameaspectratio" [{_n(c.frame_aspect)}]'
+        if c.screen_window is not None:
+            cam += f' "float screenwindow" [{_nums(c.screen_window)}]'
+        o.append(cam)
         film = f'Film "image" "integer xresolution" [{f.xres}] "integer yresolution" [{f.yres}] "float cropwindow" [{_nums(f.crop)}] "float scale" [{_n(f.scale)}] "string filename" "{d.name}.png"'
         if np.isfinite(f.max_sample_luminance):
             film += f' "float maxsampleluminance" [{_n(f.max_sample_luminance)}]'

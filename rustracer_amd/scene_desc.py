@@ -87,6 +87,8 @@ class Camera:
     fov: float = 90.0            # camera.rs:108
     lens_radius: float = 0.0     # :84
     focal_distance: float = 1e6  # :85
+    frame_aspect: Optional[float] = None                 # "frameaspectratio" (:86-97); None = xres / yres
+    screen_window: Optional[Sequence[float]] = None      # "screenwindow" xmin xmax ymin ymax (:98-107); overrides the aspect ratio
 
 
 @dataclass

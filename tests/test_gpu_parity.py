@@ -248,3 +248,12 @@ def test_full_size_properties(gpu_host):
     assert plain.mean() > 0.99
     assert np.array_equal(bits(acc[plain]), bits(film2[plain]))
     assert np.allclose(acc, film2, rtol=1e-5, atol=1e-6)
+
+
+def test_screen_window_frame_matches_oracle(gpu_host, orc):
+    d = _cornell(48, 36, 8)
+    d.camera.screen_window = (-0.8, 1.1, -0.9, 0.6)   # off-centre window (camera.rs:98-107)
+    fo, _ = orc.OracleScene(d).render(mode=1, n_threads=1)
+    fh, _ = gpu_host.HostScene(d).render()
+    assert np.array_equal(fo[..., 3], fh[..., 3])
+    assert rel_l2(gpu_host.film_to_rgb(fh), orc.film_to_rgb(fo)) < 1e-3

@@ -198,3 +198,17 @@ def test_png8_quantisation_matches_write_image_png(host):
         want.append(int(min(max(np.float32(255.0) * np.float32(g) + np.float32(0.5), 0.0), 255.0)))
     assert host.rgb_to_png8(v).tolist() == want
     assert want[:2] == [0, 0] and want[7:9] == [255, 255] and want[5] == 118
+
+
+@pytest.mark.parametrize("camera", [dict(frame_aspect=2.0), dict(frame_aspect=0.5), dict(screen_window=(-0.5, 1.25, -0.75, 0.5)), dict(frame_aspect=3.0, screen_window=(-1.0, 1.0, -1.0, 1.0))])
+def test_screen_window_and_frame_aspect_match_the_oracle(host, orc, camera):
+    """PerspectiveCamera::create's "frameaspectratio" / "screenwindow" (camera.rs:86-107): same raster-to-camera matrix and differentials from both hosts."""
+    from rustracer_amd.scenes import cornell_box
+    d = cornell_box(48, 32, 4)
+    for k, v in camera.items():
+        setattr(d.camera, k, v)
+    a, b = host.HostScene(d).setup(), orc.OracleScene(d).setup()
+    for k in ("raster_to_camera", "dx_camera", "dy_camera"):
+        assert np.array_equal(a[k], b[k]), k
+    base = host.HostScene(cornell_box(48, 32, 4)).setup()
+    assert not np.array_equal(a["raster_to_camera"], base["raster_to_camera"]) or camera == dict(frame_aspect=1.5)

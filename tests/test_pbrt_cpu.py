@@ -298,6 +298,19 @@ ConcatTransform [1 0 0 0  0 1 0 0  0 0 1 0  5 6 7 1]
     assert p.params.fov == 40.0
 
 
+def test_camera_screen_window_parameters(tmp_path):
+    from rustracer_amd.scenes import cornell_box
+    p = _parse('Camera "perspective" "float frameaspectratio" [2]\n' + HEADER + "WorldBegin\n" + TRI + "WorldEnd\n")
+    assert list(p.params.screen_window) == [-2.0, 2.0, -1.0, 1.0]                                   # camera.rs:86-97
+    p = _parse('Camera "perspective" "float frameaspectratio" [0.5] "float screenwindow" [-1 2 -3 4]\n' + HEADER + "WorldBegin\n" + TRI + "WorldEnd\n")
+    assert list(p.params.screen_window) == [-1.0, 2.0, -3.0, 4.0]                                   # :98-107 overrides
+    p = _parse('Camera "perspective"\n' + HEADER + "WorldBegin\n" + TRI + "WorldEnd\n")
+    assert list(p.params.screen_window) == [0.0, 0.0, 0.0, 0.0]                                     # default: derived from the resolution at set-up
+    d = cornell_box(48, 32, 4)
+    d.camera.frame_aspect, d.camera.screen_window, d.name = 0.75, (-0.6, 0.9, -1.1, 0.8), "win"
+    _round_trip(d, tmp_path)
+
+
 def test_world_begin_resets_the_ctm_and_options_are_refused_in_the_world_block():
     p = _parse("Translate 100 0 0\n" + HEADER + "WorldBegin\n" + TRI + "WorldEnd\n")
     assert np.array_equal(p.table("P")[1], F32([1, 0, 0]))                               # api.rs:741
