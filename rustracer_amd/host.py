@@ -322,13 +322,17 @@ class PbrtScene(HostScene):
     """A scene read from a pbrt-v3 file by the C++ host (rtxh_pbrt_load): what `rustracer scene.pbrt` builds up to
     `renderer::render` (rc/pbrt/mod.rs:16-27, rc/api.rs:977-1010). Same methods as HostScene."""
 
-    def __init__(self, path=None, text=None, base_dir=""):
+    def __init__(self, path=None, text=None, base_dir="", device_ingest=False):
         L = lib()
         res = PbrtResult()
-        if path is not None:
-            _check(L.rtxh_pbrt_load(os.fsencode(path), C.byref(res)), "pbrt_load")
-        else:
-            _check(L.rtxh_pbrt_parse(text.encode(), os.fsencode(base_dir), C.byref(res)), "pbrt_parse")
+        L.rtxh_set_device_ingest(1 if device_ingest else 0)  # MIP pyramids / environment tables on the GPU (bit-identical)
+        try:
+            if path is not None:
+                _check(L.rtxh_pbrt_load(os.fsencode(path), C.byref(res)), "pbrt_load")
+            else:
+                _check(L.rtxh_pbrt_parse(text.encode(), os.fsencode(base_dir), C.byref(res)), "pbrt_parse")
+        finally:
+            L.rtxh_set_device_ingest(0)
         self.h = C.c_void_p(res.scene)
         self.desc = None
         self.params = RenderParams.from_buffer_copy(res.params)
