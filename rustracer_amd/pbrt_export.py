@@ -51,8 +51,9 @@ def _nums(a) -> str:
 
 
 class _Writer:
-    def __init__(self, desc: sd.SceneDesc, path: str):
+    def __init__(self, desc: sd.SceneDesc, path: str, ply_over: int = 1 << 62):
         self.d = desc
+        self.ply_over = ply_over
         self.dir = os.path.dirname(os.path.abspath(path))
         self.stem = os.path.splitext(os.path.basename(path))[0]
         self.out = []
@@ -194,13 +195,20 @@ class _Writer:
                 assert all(tuple(d.lights[int(i)].rgb) == tuple(l0.rgb) for i in lights)
                 o.append(f'  AreaLightSource "diffuse" "rgb L" [{_nums(l0.rgb)}] "bool twosided" "{"true" if l0.two_sided else "false"}"')
             nv = d._P[m].shape[0]
-            shape = f'  Shape "trianglemesh" "integer indices" [{" ".join(str(int(x)) for x in (d._idx[m] - nv0).reshape(-1))}] "point P" [{_nums(d._P[m])}]'
-            if flags & sd.TRI_HAS_N:
-                shape += f' "normal N" [{_nums(d._N[m])}]'
-            if flags & sd.TRI_HAS_UV:
-                shape += f' "float uv" [{_nums(d._UV[m])}]'
-            if flags & sd.TRI_HAS_S:
-                shape += f' "vector S" [{_nums(d._S[m])}]'
+            if d._idx[m].shape[0] > self.ply_over and not (flags & sd.TRI_HAS_S):
+                # a large mesh goes into a binary PLY next to the scene file (Shape "plymesh", rc/shapes/plymesh.rs); tangents have no PLY property
+                from .ingest import write_ply
+                name = f"{self.stem}_mesh{m}.ply"
+                write_ply(os.path.join(self.dir, name), d._P[m], d._idx[m] - nv0, N=d._N[m] if flags & sd.TRI_HAS_N else None, UV=d._UV[m] if flags & sd.TRI_HAS_UV else None)
+                shape = f'  Shape "plymesh" "string filename" "{name}"'
+            else:
+                shape = f'  Shape "trianglemesh" "integer indices" [{" ".join(str(int(x)) for x in (d._idx[m] - nv0).reshape(-1))}] "point P" [{_nums(d._P[m])}]'
+                if flags & sd.TRI_HAS_N:
+                    shape += f' "normal N" [{_nums(d._N[m])}]'
+                if flags & sd.TRI_HAS_UV:
+                    shape += f' "float uv" [{_nums(d._UV[m])}]'
+                if flags & sd.TRI_HAS_S:
+                    shape += f' "vector S" [{_nums(d._S[m])}]'
             o.append(shape)
             o.append("AttributeEnd")
             nv0 += nv
@@ -210,9 +218,10 @@ class _Writer:
         return "\n".join(o) + "\n"
 
 
-def write_pbrt(desc: sd.SceneDesc, path: str) -> str:
-    """Writes `path` (and the PFM images it names, next to it); returns the scene text."""
-    w = _Writer(desc, path)
+def write_pbrt(desc: sd.SceneDesc, path: str, ply_over: int = 1 << 62) -> str:
+    """Writes `path` (and the PFM images it names, next to it); returns the scene text. Meshes of more than `ply_over` triangles
+    are written as binary PLY files and referenced with Shape "plymesh"."""
+    w = _Writer(desc, path, ply_over)
     text = w.write()
     with open(path, "w") as fh:
         fh.write(text)

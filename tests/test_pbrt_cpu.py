@@ -146,6 +146,15 @@ def test_room_env_round_trip(tmp_path):
     _round_trip(room_env(64, 36, 4, detail=2, tex_size=32, env_size=32), tmp_path)
 
 
+def test_large_meshes_round_trip_through_plymesh(tmp_path):
+    from rustracer_amd.scenes import blob_scene
+    d = blob_scene(nu=48, nv=24, xres=32, yres=32, spp=4)
+    path = os.path.join(str(tmp_path), "blob.pbrt")
+    text = write_pbrt(d, path, ply_over=100)
+    assert 'Shape "plymesh"' in text and os.path.exists(os.path.join(str(tmp_path), "blob_mesh0.ply"))
+    assert_same_scene(host.PbrtScene(path), host.HostScene(d))
+
+
 def _zoo_cases():
     from test_gpu_materials import MATERIALS
     # float checkerboard / uv textures (bump maps of two zoo entries) do not exist in the reference's make_float_texture (api.rs:1201-1216)
