@@ -30,7 +30,7 @@ class BackendError(RuntimeError):
 
 def build(force: bool = False) -> None:
     """Compile both libraries for gfx950 (hipcc cross-compiles without a GPU)."""
-    srcs = [os.path.join(_CSRC, f) for f in os.listdir(_CSRC) if f.endswith((".h", ".hip", ".cpp"))]
+    srcs = [os.path.join(_CSRC, f) for f in os.listdir(_CSRC) if f.endswith((".h", ".hip", ".cpp", ".inl")) or f == "Makefile"]
     srcs += [os.path.join(_HERE, "..", "include", f) for f in ("rtx_hip.h", "rtx_host.h")]
     stale = force or not (os.path.exists(HOST_LIB) and os.path.exists(HIP_LIB))
     if not stale:
