@@ -795,7 +795,7 @@ extern "C" int rt_render(rt_scene* s, const rt_camera* cam, const rt_film_desc* 
   static const bool bin_off = getenv("RTX_SHADE_BINS") && getenv("RTX_SHADE_BINS")[0] == '0';  // measurement knob
   const bool use_bins = !s->lambert_materials && s->n_code_classes > 1 && !bin_off;  // one class: every vertex runs the same code, the queue order is kept
   const unsigned n_bins = std::min<unsigned>(s->n_code_classes, RT_BIN_MAX) + 1u;
-  const size_t bin_stride = 2 * (RT_BIN_MAX + 1) + RT_QSHARDS + 6;  // + {begin, end} of the three class ranges
+  const size_t bin_stride = 2 * (RT_BIN_MAX + 1) + RT_QSHARDS + 8;  // + {begin, end} of the three class ranges and of the miss bin
   // RTX_SHADE_SPLIT (measurement knob): 0 = every class through the generic front-end, 1 = Lambert classes apart, default = Lambert and two-lobe classes apart
   const int split_mode = getenv("RTX_SHADE_SPLIT") ? atoi(getenv("RTX_SHADE_SPLIT")) : 2;
   const unsigned n_first = split_mode >= 1 ? s->n_lambert_classes : 0u, n_second = split_mode >= 2 ? s->n_small_classes : 0u;
@@ -897,11 +897,11 @@ extern "C" int rt_render(rt_scene* s, const rt_camera* cam, const rt_film_desc* 
           hipLaunchKernelGGL(k_bin_scatter, dim3(pgrid), dim3(256), 0, stream, s->d, ps, n_bins, hist, cursor, s->bin_sorted.as<unsigned>(), sorted_cnt,
                              split_classes ? n_first : 0u, split_classes ? n_first + n_second : 0u, ranges);
           PassState pb = ps; pb.q_in = s->bin_sorted.as<unsigned>(); pb.cnt_in = sorted_cnt;  // all entries in shard 0: QView::get(i) = ids[i]
-          if (split_classes) {  // constant-matte classes through the register-resident front-end, the rest through the generic one
-            if (n_first) { pb.range = ranges; hipLaunchKernelGGL(k_shade<3>, dim3(pgrid), dim3(256), 0, stream, s->d, fp, pb); }
-            if (n_second) { pb.range = ranges + 2; hipLaunchKernelGGL(k_shade<5>, dim3(pgrid), dim3(256), 0, stream, s->d, fp, pb); }
-            pb.range = ranges + 4; hipLaunchKernelGGL(k_shade<0>, dim3(pgrid), dim3(256), 0, stream, s->d, fp, pb);
-          } else hipLaunchKernelGGL(k_shade<0>, dim3(pgrid), dim3(256), 0, stream, s->d, fp, pb);
+          // classes of the register-resident front-ends, then the generic one, then the rays that left the scene
+          if (split_classes && n_first) { pb.range = ranges; hipLaunchKernelGGL(k_shade<3>, dim3(pgrid), dim3(256), 0, stream, s->d, fp, pb); }
+          if (split_classes && n_second) { pb.range = ranges + 2; hipLaunchKernelGGL(k_shade<5>, dim3(pgrid), dim3(256), 0, stream, s->d, fp, pb); }
+          pb.range = ranges + 4; hipLaunchKernelGGL(k_shade<0>, dim3(pgrid), dim3(256), 0, stream, s->d, fp, pb);
+          pb.range = ranges + 6; hipLaunchKernelGGL(k_shade_miss, dim3(pgrid), dim3(256), 0, stream, s->d, pb);
         }
         tm.end();
         tm.begin(&stats.ms_trace_any);

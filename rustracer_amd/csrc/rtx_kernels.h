@@ -968,7 +968,8 @@ __global__ void __launch_bounds__(256) k_bin_scatter(DScene sc, PassState ps, un
       sorted_cnt[0] = run; for (int k = 1; k < RT_QSHARDS; ++k) sorted_cnt[k] = 0u;
       // bins [0, split_bin): classes of the Lambert front-end; [split_bin, split_bin2): of the two-lobe front-end; the rest: generic
       const unsigned split = split_bin < n_bins ? base[split_bin] : run, split2 = split_bin2 < n_bins ? base[split_bin2] : run;
-      ranges[0] = 0u; ranges[1] = split; ranges[2] = split; ranges[3] = split2; ranges[4] = split2; ranges[5] = run;
+      const unsigned miss = base[n_bins - 1u];  // the last bin: rays that left the scene
+      ranges[0] = 0u; ranges[1] = split; ranges[2] = split; ranges[3] = split2; ranges[4] = split2; ranges[5] = miss; ranges[6] = miss; ranges[7] = run;
     }
   }
   for (unsigned i = threadIdx.x; i <= RT_BIN_MAX; i += 256u) lcount[i] = 0u;
@@ -1339,6 +1340,27 @@ __global__ void __launch_bounds__(256, MODE == 1 ? RT_SHADE_MIN_WAVES : RT_SHADE
     if (cont) ps.q_out[slot[0]] = pid;
     if (want_shadow) ps.q_shadow[slot[1]] = pid;
     if (want_mis) ps.q_mis[slot[2]] = pid;
+  }
+}
+
+// The miss bin of a binned queue: a path whose ray left the scene. PathIntegrator::li adds the environment's radiance only for camera rays
+// and after specular bounces (path.rs:127-136, otherwise the light samples already account for it) and terminates the path; throughput,
+// RNG and sampler counters stay as they are. One load for most entries - instead of the generic shade kernel's whole prologue.
+__global__ void __launch_bounds__(256) k_shade_miss(DScene sc, PassState ps) {
+  const unsigned first = ps.range[0], count = ps.range[1];
+  const unsigned stride = gridDim.x * blockDim.x;
+  for (unsigned i = first + blockIdx.x * blockDim.x + threadIdx.x; i < count; i += stride) {
+    const unsigned pid = ps.q_in[i];
+    const float4 l4 = ps.lacc[pid];
+    const unsigned st = __float_as_uint(l4.w);
+    const int bounces = (int)(st & 0xffu); const bool specular_bounce = (st >> 8) & 1u;
+    if (!(bounces == 0 || specular_bounce) || sc.n_infinite == 0) continue;
+    const float4 d4 = ps.ray_d[pid], b4 = ps.beta[pid];
+    const f3 ray_d = mk3(d4.x, d4.y, d4.z);
+    const rgb3 beta = mkc(b4.x, b4.y, b4.z);
+    rgb3 L = mkc(l4.x, l4.y, l4.z);
+    for (int k = 0; k < sc.n_infinite; ++k) L = L + beta * infinite_le(sc, sc.lights[sc.infinite_ids[k]], ray_d);
+    ps.lacc[pid] = make_float4(L.r, L.g, L.b, l4.w);
   }
 }
 
