@@ -976,15 +976,22 @@ __global__ void __launch_bounds__(256) k_bin_scatter(DScene sc, PassState ps, un
   __syncthreads();
   QView qv; if (ps.q_in) qv.init(ps.q_in, ps.cnt_in, ps.shard_cap);
   const unsigned count = ps.q_in ? qv.total() : ps.cap;
-  for (unsigned start = blockIdx.x * 256u; start < count; start += gridDim.x * 256u) {
-    const unsigned i = start + threadIdx.x;
-    unsigned pid = 0, bin = 0, rank = 0;
-    const bool live = i < count;
-    if (live) { pid = ps.q_in ? qv.get(i) : i; bin = bin_of(sc.materials, sc.tri_p, ps.hit, pid, n_bins); rank = atomicAdd(&lcount[bin], 1u); }
+  constexpr unsigned E = 4;  // entries per lane per round: the barriers and the global atomics are per 1024 entries
+  for (unsigned start = blockIdx.x * (256u * E); start < count; start += gridDim.x * (256u * E)) {
+    unsigned pid[E], bin[E], rank[E]; bool live[E];
+#pragma unroll
+    for (unsigned k = 0; k < E; ++k) {  // rounds of 256 consecutive entries: a bin keeps the queue's order up to that granularity
+      const unsigned i = start + k * 256u + threadIdx.x;
+      live[k] = i < count; pid[k] = 0; bin[k] = 0; rank[k] = 0;
+      if (live[k]) { pid[k] = ps.q_in ? qv.get(i) : i; bin[k] = bin_of(sc.materials, sc.tri_p, ps.hit, pid[k], n_bins); }
+    }
+#pragma unroll
+    for (unsigned k = 0; k < E; ++k) if (live[k]) rank[k] = atomicAdd(&lcount[bin[k]], 1u);
     __syncthreads();
-    for (unsigned b = threadIdx.x; b < n_bins; b += 256u) if (lcount[b]) lbase[b] = atomicAdd(&cursor[b], lcount[b]);  // one global atomic per bin per 256 entries
+    for (unsigned b = threadIdx.x; b < n_bins; b += 256u) if (lcount[b]) lbase[b] = atomicAdd(&cursor[b], lcount[b]);  // one global atomic per bin per 1024 entries
     __syncthreads();
-    if (live) sorted[base[bin] + lbase[bin] + rank] = pid;
+#pragma unroll
+    for (unsigned k = 0; k < E; ++k) if (live[k]) sorted[base[bin[k]] + lbase[bin[k]] + rank[k]] = pid[k];
     __syncthreads();
     for (unsigned b = threadIdx.x; b < n_bins; b += 256u) lcount[b] = 0u;
     __syncthreads();
