@@ -976,7 +976,7 @@ __global__ void __launch_bounds__(256) k_bin_scatter(DScene sc, PassState ps, un
   __syncthreads();
   QView qv; if (ps.q_in) qv.init(ps.q_in, ps.cnt_in, ps.shard_cap);
   const unsigned count = ps.q_in ? qv.total() : ps.cap;
-  constexpr unsigned E = 4;  // entries per lane per round: the barriers and the global atomics are per 1024 entries
+  constexpr unsigned E = 8;  // entries per lane per round: the barriers and the global atomics are per 2048 entries
   for (unsigned start = blockIdx.x * (256u * E); start < count; start += gridDim.x * (256u * E)) {
     unsigned pid[E], bin[E], rank[E]; bool live[E];
 #pragma unroll
