@@ -199,6 +199,12 @@ RT_DEVN rgb3 tex_eval(const DScene& sc, int id, const SurfaceInteraction& si) {
   return tex_combine(sc, t, tex_depth1(sc, sc.textures[t.tex1], si), tex_depth1(sc, sc.textures[t.tex2], si), si);
 }
 RT_DEV float tex_eval_f(const DScene& sc, int id, const SurfaceInteraction& si) { return tex_eval(sc, id, si).r; }
+// the same values with the constant texture (the common parameter) answered in place instead of through the out-of-line evaluator
+RT_DEV rgb3 tex_eval_c(const DScene& sc, int id, const SurfaceInteraction& si) {
+  const DTexture& t = sc.textures[id];
+  return t.kind == 0 ? mkc(t.v[0], t.v[1], t.v[2]) : tex_eval(sc, id, si);
+}
+RT_DEV float tex_eval_cf(const DScene& sc, int id, const SurfaceInteraction& si) { return tex_eval_c(sc, id, si).r; }
 
 // ---------------------------------------------------------------- materials (rc/material/*.rs)
 RT_DEV Lobe lobe_zero(int kind) {

@@ -1083,8 +1083,8 @@ struct SmallBsdf {
     const DMaterial& m = sc.materials[mat]; const int* s = m.slot;
     n = 0; l0 = lobe_zero(LB_LAMBERT_R); l1 = l0;
     if (m.kind == 0) {  // matte.rs:37-62
-      rgb3 r = clamp_pos(tex_eval(sc, s[0], si));
-      float sigma = clampf(tex_eval_f(sc, s[4], si), 0.0f, 1.0f);
+      rgb3 r = clamp_pos(tex_eval_c(sc, s[0], si));
+      float sigma = clampf(tex_eval_cf(sc, s[4], si), 0.0f, 1.0f);
       if (!is_black(r)) {
         if (sigma == 0.0f) add(mk_lambert(LB_LAMBERT_R, r));
         else {  // OrenNayar::new, oren_nayar.rs:17-27
@@ -1097,21 +1097,21 @@ struct SmallBsdf {
         }
       }
     } else if (m.kind == 1) {  // plastic.rs:45-75
-      rgb3 kd = tex_eval(sc, s[0], si), ks = tex_eval(sc, s[1], si);
+      rgb3 kd = tex_eval_c(sc, s[0], si), ks = tex_eval_c(sc, s[1], si);
       if (!is_black(kd)) add(mk_lambert(LB_LAMBERT_R, kd));
       if (!is_black(ks)) {
-        float rough = tex_eval_f(sc, s[5], si);
+        float rough = tex_eval_cf(sc, s[5], si);
         if (m.remap) rough = tr_roughness_to_alpha(rough);
         add(mk_micro_r(ks, rough, rough, FR_DIELECTRIC, 1.5f, 1.0f));
       }
     } else if (m.kind == 2) {  // metal.rs:50-82
-      float ur = tex_eval_f(sc, s[6] >= 0 ? s[6] : s[5], si), vr = tex_eval_f(sc, s[7] >= 0 ? s[7] : s[5], si);
+      float ur = tex_eval_cf(sc, s[6] >= 0 ? s[6] : s[5], si), vr = tex_eval_cf(sc, s[7] >= 0 ? s[7] : s[5], si);
       if (m.remap) { ur = tr_roughness_to_alpha(ur); vr = tr_roughness_to_alpha(vr); }
       Lobe l = mk_micro_r(mkc(1, 1, 1), ur, vr, FR_CONDUCTOR, 1.0f, 1.0f);
-      l.t = tex_eval(sc, s[8], si); l.k = tex_eval(sc, s[9], si);
+      l.t = tex_eval_c(sc, s[8], si); l.k = tex_eval_c(sc, s[9], si);
       add(l);
     } else {  // mirror.rs:30-48
-      rgb3 R = clamp_pos(tex_eval(sc, s[2], si));
+      rgb3 R = clamp_pos(tex_eval_c(sc, s[2], si));
       if (!is_black(R)) { Lobe l = lobe_zero(LB_SPEC_R); l.r = R; add(l); }
     }
     ss = normalize(si.sh_dpdu); ns = si.sh_n; ng = si.hit.n; ts = cross(si.sh_n, ss);  // Bsdf::new, bsdf/mod.rs:77-91
