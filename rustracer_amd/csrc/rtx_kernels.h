@@ -675,7 +675,14 @@ RT_DEV bool slab_geom(float4 n0, float4 n1, const Ray& ray, f3 inv_dir, int neg_
 // per-lane traversal state and the output arrays a finished ray is written to
 struct PairLane {
   bool active, found; unsigned pid; float dw;
-  Ray ray; f3 inv_dir; int neg_x, neg_y, neg_z; RayPre rp;
+  // registers are the currency of this kernel (86 -> 80 VGPRs is one more wave per SIMD): the direction signs are read off inv_dir where
+  // they are used (a compare either way) and of the watertight test's permutation only kz is kept (kx, ky follow from it)
+  Ray ray; f3 inv_dir; int kz; float sx, sy, sz;
+  RT_DEV int neg_x() const { return inv_dir.x < 0.0f; }
+  RT_DEV int neg_y() const { return inv_dir.y < 0.0f; }
+  RT_DEV int neg_z() const { return inv_dir.z < 0.0f; }
+  RT_DEV RayPre rp() const { RayPre r; r.kz = kz; r.kx = kz + 1; if (r.kx == 3) r.kx = 0; r.ky = r.kx + 1; if (r.ky == 3) r.ky = 0; r.sx = sx; r.sy = sy; r.sz = sz; return r; }
+  RT_DEV void set_rp(const RayPre& r) { kz = r.kz; sx = r.sx; sy = r.sy; sz = r.sz; }
   int sp, prim; unsigned cur; TriHit hit;
 };
 struct TraceOut { float4* hits; unsigned* occluded; float4* lacc; const float4* direct_add; };
@@ -703,14 +710,14 @@ template <bool ANY, int BLOCK>
 RT_DEV void pair_interior_step(PairLane& L, const TraceOut& o, const float4* __restrict__ pairs, unsigned* stack, float* tstack, size_t grid_lanes) {
   const unsigned P = L.cur & 0x1fffffffu, axis = (L.cur >> 29) & 3u;
   const float4 a0 = pairs[4 * (size_t)P], a1 = pairs[4 * (size_t)P + 1], b0 = pairs[4 * (size_t)P + 2], b1 = pairs[4 * (size_t)P + 3];
-  const bool neg = (axis == 0u ? L.neg_x : (axis == 1u ? L.neg_y : L.neg_z)) != 0;
+  const bool neg = (axis == 0u ? L.neg_x() : (axis == 1u ? L.neg_y() : L.neg_z())) != 0;
   // reference: negative direction along the split axis => second child first (bvh/mod.rs:411-417)
   const float4 n0 = neg ? b0 : a0, n1 = neg ? b1 : a1, f0 = neg ? a0 : b0, f1 = neg ? a1 : b1;
   const unsigned code_a = __float_as_uint(a1.z), code_b = __float_as_uint(a1.w);
   const unsigned code_n = neg ? code_b : code_a, code_f = neg ? code_a : code_b;
   float tmin_n = 0.0f, tmin_f = 0.0f;
-  const bool hit_n = slab_geom(n0, n1, L.ray, L.inv_dir, L.neg_x, L.neg_y, L.neg_z, tmin_n) && tmin_n < L.ray.t_max;
-  const bool keep_f = slab_geom(f0, f1, L.ray, L.inv_dir, L.neg_x, L.neg_y, L.neg_z, tmin_f) && tmin_f < L.ray.t_max;
+  const bool hit_n = slab_geom(n0, n1, L.ray, L.inv_dir, L.neg_x(), L.neg_y(), L.neg_z(), tmin_n) && tmin_n < L.ray.t_max;
+  const bool keep_f = slab_geom(f0, f1, L.ray, L.inv_dir, L.neg_x(), L.neg_y(), L.neg_z(), tmin_f) && tmin_f < L.ray.t_max;
   if (hit_n) {
     if (keep_f) { stack[L.sp * BLOCK] = code_f; if (!ANY) tstack[(size_t)L.sp * grid_lanes] = tmin_f; ++L.sp; }
     L.cur = code_n;
@@ -724,7 +731,7 @@ RT_DEV void pair_leaf_step(PairLane& L, const TraceOut& o, const float4* __restr
     f3 p0, p1, p2;
     load_tri(tri_p, off + i, p0, p1, p2);
     TriHit h;
-    if (tri_test_pre(p0, p1, p2, L.ray, L.rp, h)) {
+    if (tri_test_pre(p0, p1, p2, L.ray, L.rp(), h)) {
       L.found = true;
       if (ANY) break;
       L.ray.t_max = h.t; L.prim = off + i; L.hit = h;  // `.or(result)`: later accepted hits replace
@@ -755,7 +762,7 @@ __global__ void __launch_bounds__(BLOCK) k_trace_pair(DScene sc, const float4* _
   bool exhausted = (unsigned long long)wave * 64ull >= count;
   PairLane L;
   L.active = false; L.found = false; L.pid = 0; L.dw = 0.0f;
-  L.ray.o = L.ray.d = mk3(0, 0, 0); L.ray.t_max = 0.0f; L.inv_dir = mk3(0, 0, 0); L.neg_x = L.neg_y = L.neg_z = 0; L.rp = ray_pre(L.ray);
+  L.ray.o = L.ray.d = mk3(0, 0, 0); L.ray.t_max = 0.0f; L.inv_dir = mk3(0, 0, 0); L.set_rp(ray_pre(L.ray));
   L.sp = 0; L.prim = -1; L.cur = 0; L.hit.t = kInf; L.hit.b0 = L.hit.b1 = L.hit.b2 = 0.0f;
 
   for (;;) {
@@ -768,13 +775,12 @@ __global__ void __launch_bounds__(BLOCK) k_trace_pair(DScene sc, const float4* _
         const float4 o4 = ray_o[L.pid], d4 = ray_d[L.pid];
         L.ray.o = mk3(o4.x, o4.y, o4.z); L.ray.d = mk3(d4.x, d4.y, d4.z); L.ray.t_max = o4.w; L.dw = d4.w;
         L.inv_dir = mk3(1.0f / L.ray.d.x, 1.0f / L.ray.d.y, 1.0f / L.ray.d.z);
-        L.neg_x = L.inv_dir.x < 0.0f; L.neg_y = L.inv_dir.y < 0.0f; L.neg_z = L.inv_dir.z < 0.0f;
-        L.rp = ray_pre(L.ray);
+        L.set_rp(ray_pre(L.ray));
         L.sp = 0; L.prim = -1; L.found = false; L.hit.t = kInf; L.hit.b0 = L.hit.b1 = L.hit.b2 = 0.0f;
         L.active = true; n_rays += 1;
         // the root is the one node tested on its own
         const float4 r0 = nodes[0], r1 = nodes[1];
-        if (slab_test(r0, r1, L.ray, L.inv_dir, L.neg_x, L.neg_y, L.neg_z)) {
+        if (slab_test(r0, r1, L.ray, L.inv_dir, L.neg_x(), L.neg_y(), L.neg_z())) {
           const unsigned packed = __float_as_uint(r1.w), np = packed & 0xffffu;
           L.cur = np > 0u ? (RT_PAIR_LEAF | (unsigned)__float_as_int(r1.z) | ((np - 1u) << 26)) : (((packed >> 16) & 0xffu) << 29);
         } else pair_finish<ANY>(L, out);
@@ -841,10 +847,10 @@ RT_DEV void quad_interior_step(PairLane& L, const TraceOut& o, const float4* __r
 #pragma unroll
   for (int k = 0; k < 4; ++k) {
     tmin[k] = 0.0f;
-    hit[k] = (code[k] != 0xffffffffu) & slab_geom6(bx + 6 * k, L.ray, L.inv_dir, L.neg_x, L.neg_y, L.neg_z, tmin[k]);
+    hit[k] = (code[k] != 0xffffffffu) & slab_geom6(bx + 6 * k, L.ray, L.inv_dir, L.neg_x(), L.neg_y(), L.neg_z(), tmin[k]);
     hit[k] = hit[k] & (tmin[k] < L.ray.t_max);
   }
-  auto neg_of = [&](unsigned ax) { return (ax == 0u ? L.neg_x : (ax == 1u ? L.neg_y : L.neg_z)) != 0; };
+  auto neg_of = [&](unsigned ax) { return (ax == 0u ? L.neg_x() : (ax == 1u ? L.neg_y() : L.neg_z())) != 0; };
   // negative direction along a split axis => that node's second child first (bvh/mod.rs:411-417), at all three nodes involved
   const bool sp = neg_of(axis_p), sa = neg_of(axes & 3u) & (code[1] != 0xffffffffu), sb = neg_of((axes >> 2) & 3u) & (code[3] != 0xffffffffu);
   const int a0 = sa ? 1 : 0, a1 = sa ? 0 : 1, b0 = sb ? 3 : 2, b1 = sb ? 2 : 3;
@@ -892,7 +898,7 @@ __global__ void __launch_bounds__(BLOCK) k_trace_quad(DScene sc, const float4* _
   bool exhausted = (unsigned long long)wave * 64ull >= count;
   PairLane L;
   L.active = false; L.found = false; L.pid = 0; L.dw = 0.0f;
-  L.ray.o = L.ray.d = mk3(0, 0, 0); L.ray.t_max = 0.0f; L.inv_dir = mk3(0, 0, 0); L.neg_x = L.neg_y = L.neg_z = 0; L.rp = ray_pre(L.ray);
+  L.ray.o = L.ray.d = mk3(0, 0, 0); L.ray.t_max = 0.0f; L.inv_dir = mk3(0, 0, 0); L.set_rp(ray_pre(L.ray));
   L.sp = 0; L.prim = -1; L.cur = 0; L.hit.t = kInf; L.hit.b0 = L.hit.b1 = L.hit.b2 = 0.0f;
   for (;;) {
     const unsigned long long idle = __ballot(!L.active);
@@ -904,12 +910,11 @@ __global__ void __launch_bounds__(BLOCK) k_trace_quad(DScene sc, const float4* _
         const float4 o4 = ray_o[L.pid], d4 = ray_d[L.pid];
         L.ray.o = mk3(o4.x, o4.y, o4.z); L.ray.d = mk3(d4.x, d4.y, d4.z); L.ray.t_max = o4.w; L.dw = d4.w;
         L.inv_dir = mk3(1.0f / L.ray.d.x, 1.0f / L.ray.d.y, 1.0f / L.ray.d.z);
-        L.neg_x = L.inv_dir.x < 0.0f; L.neg_y = L.inv_dir.y < 0.0f; L.neg_z = L.inv_dir.z < 0.0f;
-        L.rp = ray_pre(L.ray);
+        L.set_rp(ray_pre(L.ray));
         L.sp = 0; L.prim = -1; L.found = false; L.hit.t = kInf; L.hit.b0 = L.hit.b1 = L.hit.b2 = 0.0f;
         L.active = true; n_rays += 1;
         const float4 r0 = nodes[0], r1 = nodes[1];  // the root is the one node tested on its own
-        if (slab_test(r0, r1, L.ray, L.inv_dir, L.neg_x, L.neg_y, L.neg_z)) {
+        if (slab_test(r0, r1, L.ray, L.inv_dir, L.neg_x(), L.neg_y(), L.neg_z())) {
           const unsigned packed = __float_as_uint(r1.w), np = packed & 0xffffu;
           L.cur = np > 0u ? (RT_PAIR_LEAF | (unsigned)__float_as_int(r1.z) | ((np - 1u) << 26)) : (((packed >> 16) & 0xffu) << 29);
         } else pair_finish<ANY>(L, out);
