@@ -763,14 +763,16 @@ extern "C" int rt_render(rt_scene* s, const rt_camera* cam, const rt_film_desc* 
   const bool all_in_bounds = path->pixel_bounds[0] <= film->sample_bounds[0] && path->pixel_bounds[2] >= film->sample_bounds[2] &&
                              path->pixel_bounds[1] <= film->sample_bounds[1] && path->pixel_bounds[3] >= film->sample_bounds[3];
   // batch / pass sizing. A batch is a range of owned pixels whose sampler tables (2*dims u16 per sample) are built
-  // at once; it is rendered in passes of n_samples consecutive samples of all its pixels, ~2^26 paths (17 GB of path state) per pass.
-  static const int tp_log2 = getenv("RTX_PASS_LOG2") ? atoi(getenv("RTX_PASS_LOG2")) : 26;  // measurement knobs; 2^23 -> 2^26 paths per pass: -9 % (S1), -32 % (S2): fewer, larger launches
-  static const int bp_log2 = getenv("RTX_BATCH_LOG2") ? atoi(getenv("RTX_BATCH_LOG2")) : 18;
+  // at once; it is rendered in passes of n_samples consecutive samples of all its pixels, ~2^28 paths (70 GB of path state) per pass.
+  // measurement knobs; 2^23 -> 2^26 paths per pass: -9 % (S1), -32 % (S2); 2^26 -> 2^28 with 2^19-pixel batches: -1 % (S1), -7 % (S2), -1 % (S3):
+  // fewer, larger launches - late bounces hold few rays - and 288 GB of HBM hold the 70 GB of path state of such a pass with room to spare
+  static const int tp_log2 = getenv("RTX_PASS_LOG2") ? atoi(getenv("RTX_PASS_LOG2")) : 28;
+  static const int bp_log2 = getenv("RTX_BATCH_LOG2") ? atoi(getenv("RTX_BATCH_LOG2")) : 19;
   const unsigned long long target_paths = 1ull << tp_log2;
   unsigned long long batch_pixels = std::max<unsigned long long>(1, std::min<unsigned long long>(owned_pixels, 1ull << bp_log2));  // a rank may own no rows
   // a shard that fits one batch (e.g. 1/8 of a frame on an 8-GPU run) is still cut in two, so that the second half's sampler
-  // tables are built under the first half's path kernels; only worth it when the whole frame is more than two passes
-  if (owned_pixels <= batch_pixels && owned_pixels >= (1ull << 15) && owned_pixels * spp > 2 * target_paths) batch_pixels = (owned_pixels + 1) / 2;
+  // tables are built under the first half's path kernels; only worth it when there is enough work to hide them under
+  if (owned_pixels <= batch_pixels && owned_pixels >= (1ull << 15) && owned_pixels * spp >= (1ull << 27)) batch_pixels = (owned_pixels + 1) / 2;
   const unsigned long long table_bytes_per_pixel = 2ull * dims * spp * 2ull;
   while (batch_pixels > 4096 && batch_pixels * table_bytes_per_pixel > (16ull << 30)) batch_pixels >>= 1;  // <= 16 GiB of tables per buffer
   unsigned pass_samples = (unsigned)std::max<unsigned long long>(1, target_paths / batch_pixels);

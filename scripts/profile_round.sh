@@ -7,8 +7,8 @@ OUT=gpurun_out/${TAG}_${SCENE}
 mkdir -p $OUT
 ROOT=$(pwd)
 cd /tmp && export TMPDIR=/tmp && cd $ROOT
-# PMC passes run at the spp that gives the launch size of the full run (a pass holds 2^26 paths = 256 samples of a 2^18-pixel batch)
-PSPP=256
+# PMC passes run at the spp that gives the launch size of the full run (a pass holds 2^28 paths = 512 samples of a 2^19-pixel batch)
+PSPP=512
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -- python3 bench.py --scene $SCENE --steps 2 --warmup 1 --no-cpu-baseline > $OUT/stats.log 2>&1
 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/fetch -- python3 bench.py --scene $SCENE --steps 1 --warmup 0 --spp $PSPP --no-cpu-baseline > $OUT/fetch.log 2>&1
 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/write -- python3 bench.py --scene $SCENE --steps 1 --warmup 0 --spp $PSPP --no-cpu-baseline > $OUT/write.log 2>&1
