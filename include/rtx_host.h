@@ -34,10 +34,12 @@ typedef struct rtxh_render_params {
   float fov, lens_radius, focal_distance;       /* camera.rs:84-113                                */
   int32_t spp, sampler_dims;                    /* zerotwosequence.rs:58-63                        */
   int32_t max_depth; float rr_threshold; int32_t light_strategy; /* path.rs:49-53                  */
-  int32_t pixel_bounds[4]; /* x0 x1 y0 y1; x1 <= x0 => film sample bounds                          */
+  int32_t pixel_bounds[4]; /* "pixelbounds" x0 x1 y0 y1, used when has_pixel_bounds != 0                     */
   int32_t rank, world_size; /* film sharding (tile rows interleaved over ranks)                    */
   uint32_t flags;           /* RT_FLAG_*                                                           */
   float screen_window[4];   /* xmin xmax ymin ymax; xmax <= xmin => create()'s default from the aspect ratio, camera.rs:86-107 */
+  int32_t has_pixel_bounds; /* PathIntegrator::create (path.rs:53-69) intersects the sample bounds with "pixelbounds" whenever the
+                               parameter is given: a degenerate or non-overlapping window renders nothing, it is not ignored */
 } rtxh_render_params;
 
 rtxh_scene* rtxh_scene_new(void);
@@ -48,7 +50,8 @@ int rtxh_scene_set_mesh(rtxh_scene*, const float* P, int32_t n_verts, const int3
                         const float* S, const int32_t* tri_material, const int32_t* tri_light, const uint8_t* tri_flags);
 /* on != 0: MIP pyramids (rtxh_scene_add_mipmap) and environment-map sampling tables (rtxh_scene_add_light, infinite) are built
  * by the GPU (rt_mip_build, rt_env_distribution in rtx_hip.h) - bit-identical tables, milliseconds instead of tenths of a second for
- * a 2048 x 1024 map. Off by default: the host build needs no device. Process-wide. */
+ * a 2048 x 1024 map. Off by default: the host build needs no device. The setting belongs to the calling thread (scene builds on
+ * different threads do not affect each other) and applies to the scenes that thread builds afterwards, rtxh_pbrt_load included. */
 void rtxh_set_device_ingest(int32_t on);
 int rtxh_scene_add_mipmap(rtxh_scene*, int32_t width, int32_t height, const float* rgb, int32_t trilinear, float max_aniso, int32_t wrap);
 int rtxh_scene_add_texture(rtxh_scene*, int32_t kind, const float* value3, int32_t tex1, int32_t tex2, int32_t amount, int32_t mip, const float* mapping4);

@@ -34,7 +34,7 @@ class RenderParams(C.Structure):
         ("spp", C.c_int32), ("sampler_dims", C.c_int32), ("sampler_mode", C.c_int32),
         ("max_depth", C.c_int32), ("rr_threshold", C.c_float), ("light_strategy", C.c_int32),
         ("pixel_bounds", C.c_int32 * 4), ("n_threads", C.c_int32), ("tile_size", C.c_int32),
-        ("screen_window", C.c_float * 4),
+        ("screen_window", C.c_float * 4), ("has_pixel_bounds", C.c_int32),
     ]
 
 
@@ -114,6 +114,7 @@ def render_params(desc, mode: int, n_threads: int = 0) -> RenderParams:
     p.light_strategy = 1 if it.light_strategy == "uniform" else 0
     pb = it.pixel_bounds
     p.pixel_bounds[:] = list(pb) if pb is not None else [0, 0, 0, 0]
+    p.has_pixel_bounds = 1 if pb is not None else 0
     p.n_threads = n_threads
     p.tile_size = 16
     return p

@@ -142,9 +142,10 @@ struct orc_render_params {
   int32_t max_depth;
   float rr_threshold;
   int32_t light_strategy;  // 0 = "spatial", 1 = "uniform"
-  int32_t pixel_bounds[4]; // x0 x1 y0 y1; x1 <= x0 => use the sample bounds (path.rs:53-69)
+  int32_t pixel_bounds[4]; // "pixelbounds" x0 x1 y0 y1, intersected with the sample bounds when has_pixel_bounds (path.rs:53-69)
   int32_t n_threads, tile_size;
   float screen_window[4];  // xmin xmax ymin ymax; xmax <= xmin => PerspectiveCamera::create's default from the aspect ratio (camera.rs:86-107)
+  int32_t has_pixel_bounds; // the parameter was given: a degenerate intersection is kept (only logged, path.rs:66-68) and renders nothing
 };
 struct orc_stats {
   uint64_t camera_rays, rays_closest, rays_shadow, rays_mis, nodes_closest, nodes_shadow, nodes_mis, tris_closest, tris_shadow, tris_mis;
@@ -474,7 +475,7 @@ int orc_render(void* h, const orc_render_params* p, float* film_xyzw, orc_stats*
   integ.max_depth = (int)(uint8_t)p->max_depth; integ.rr_threshold = p->rr_threshold;
   const B2i sample_bounds = film.sample_bounds();
   B2i pixel_bounds = sample_bounds;  // path.rs:53-69
-  if (p->pixel_bounds[1] > p->pixel_bounds[0]) {
+  if (p->has_pixel_bounds) {
     B2i pb{p->pixel_bounds[0], p->pixel_bounds[2], p->pixel_bounds[1], p->pixel_bounds[3]};
     pixel_bounds = B2i{max_po(pixel_bounds.x0, pb.x0), max_po(pixel_bounds.y0, pb.y0), min_po(pixel_bounds.x1, pb.x1), min_po(pixel_bounds.y1, pb.y1)};
   }

@@ -12,9 +12,9 @@ namespace rtx {
 //         the w lanes carry rt_tri_meta so that shading needs no second gather; the algorithmic
 //         size of a triangle stays the 36 B of its nine coordinates)
 struct DTexture { int kind; float v[3]; int tex1, tex2, amount, image; float su, sv, du, dv; };
-struct DImage {
+struct DImage {  // levels of a MIPMap: float4 texels in tiles of 4 x 2 (one 128-byte line), 2^tshift tiles per tile row; off = first texel of a level
   int n_levels; int w[16], h[16]; unsigned long long off[16];
-  const float* texels; int trilinear; float max_aniso; int wrap;
+  const float4* texels; int trilinear; float max_aniso; int wrap; int tshift[16];
 };
 struct DMaterial { int kind; int slot[16]; int remap; int bump; int code_class; };  // code_class: materials that run the same shading code share one (host: material_code_classes)
 struct DLight {

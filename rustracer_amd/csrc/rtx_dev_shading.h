@@ -10,14 +10,16 @@ namespace rtx {
 // ---------------------------------------------------------------- MIPMap lookups (rc/mipmap.rs)
 __device__ __constant__ float kEwaLut[128];  // filled by the host at start-up: exp(-2 r2) - exp(-2) (:33-44)
 
-RT_DEV long modl(long a, long b) { long r = a % b; return r < 0 ? r + b : r; }  // :428-435
-RT_DEV rgb3 mip_texel(const DImage& im, int level, long s, long t) {              // :208-225
-  long us = im.w[level], vs = im.h[level], ss, tt;
-  if (im.wrap == 0) { ss = modl(s, us); tt = modl(t, vs); }
-  else if (im.wrap == 2) { ss = s < 0 ? 0 : (s > us - 1 ? us - 1 : s); tt = t < 0 ? 0 : (t > vs - 1 ? vs - 1 : t); }
-  else { if (s < 0 || s >= us || t < 0 || t >= vs) return mkc(0, 0, 0); ss = s; tt = t; }
-  const float* p = im.texels + 3 * (im.off[level] + (unsigned long long)tt * (unsigned long long)us + (unsigned long long)ss);
-  return mkc(p[0], p[1], p[2]);
+// MIPMap::texel (:208-225). Level sizes are powers of two (MIPMap::new resamples, :75-139; checked at rt_scene_create), so the Repeat wrap
+// `modulo(s, size)` (:428-435) is the low bits of s - for negative s too, in two's complement - instead of a 64-bit signed division per texel.
+RT_DEV rgb3 mip_texel(const DImage& im, int level, long s, long t) {
+  const int us = im.w[level], vs = im.h[level];
+  unsigned ss, tt;
+  if (im.wrap == 0) { ss = (unsigned)s & (unsigned)(us - 1); tt = (unsigned)t & (unsigned)(vs - 1); }
+  else if (im.wrap == 2) { ss = (unsigned)(s < 0 ? 0 : (s > us - 1 ? us - 1 : s)); tt = (unsigned)(t < 0 ? 0 : (t > vs - 1 ? vs - 1 : t)); }
+  else { if (s < 0 || s >= us || t < 0 || t >= vs) return mkc(0, 0, 0); ss = (unsigned)s; tt = (unsigned)t; }
+  const float4 v = im.texels[im.off[level] + ((((unsigned long long)(tt >> 1) << im.tshift[level]) + (ss >> 2)) << 3) + ((tt & 1u) << 2) + (ss & 3u)];
+  return mkc(v.x, v.y, v.z);
 }
 RT_DEVN rgb3 mip_triangle(const DImage& im, int level, f2 st) {  // :285-308
   level = clampi(level, 0, im.n_levels - 1);

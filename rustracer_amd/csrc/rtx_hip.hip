@@ -102,6 +102,7 @@ static void fill_ewa_lut() {
   (void)hipMemcpyToSymbol(HIP_SYMBOL(kEwaLut), lut, sizeof(lut));
 }
 
+static size_t tmin_stack_bytes(const rt_scene* s);
 extern "C" int rt_scene_create(const rt_scene_desc* desc, int device, rt_scene** out) {
   if (!desc || !out) return fail(RT_ERR_INVALID, "null argument");
   if (!rt_device_available()) return fail(RT_ERR_NO_DEVICE, "no HIP device visible; this backend has no CPU fallback");
@@ -133,24 +134,45 @@ extern "C" int rt_scene_create(const rt_scene_desc* desc, int device, rt_scene**
   if (desc->tri_n) TRY_RC(upload(s->tri_n, desc->tri_n, (size_t)desc->n_tris * 36));
   if (desc->tri_uv) TRY_RC(upload(s->tri_uv, desc->tri_uv, (size_t)desc->n_tris * 24));
   if (desc->tri_s) TRY_RC(upload(s->tri_s, desc->tri_s, (size_t)desc->n_tris * 36));
-  // images: one texel blob
+  // images: one blob of float4 texels, every level cut into tiles of 4 x 2 texels = one 128-byte line (mip_texel in rtx_dev_shading.h): a bilinear
+  // or EWA footprint then touches fewer lines than with 12-byte row-major texels, and a texel is one aligned 16-byte load. The layout changes no value.
   std::vector<DImage> himg(desc->n_images);
   {
-    size_t total = 0;
-    for (uint32_t i = 0; i < desc->n_images; ++i) total += desc->images[i].n_texels;
-    std::vector<float> blob(total * 3 + 4);
-    size_t base = 0;
+    auto is_pow2 = [](int v) { return v > 0 && (v & (v - 1)) == 0; };
+    size_t total = 0;  // in float4 texels, levels padded to whole tiles
     for (uint32_t i = 0; i < desc->n_images; ++i) {
       const rt_image& im = desc->images[i];
       if (im.n_levels <= 0 || im.n_levels > RT_MAX_MIP_LEVELS) { delete s; return fail(RT_ERR_INVALID, "bad mip level count"); }
-      memcpy(&blob[base * 3], im.texels, im.n_texels * 12);
+      for (int l = 0; l < im.n_levels; ++l) {
+        // MIPMap::new resamples to powers of two and halves from there (rc/mipmap.rs:75-139), which is what lets Repeat wrap by a mask
+        if (!is_pow2(im.width[l]) || !is_pow2(im.height[l])) { delete s; return fail(RT_ERR_INVALID, "MIP level sizes must be powers of two (rc/mipmap.rs:75-139)"); }
+        if ((uint64_t)im.offset[l] + (uint64_t)im.width[l] * im.height[l] > im.n_texels) { delete s; return fail(RT_ERR_INVALID, "MIP level outside the texel array"); }
+        total += (size_t)std::max(im.width[l], 4) * std::max(im.height[l], 2);
+      }
+    }
+    std::vector<float> blob((total + 1) * 4, 0.0f);
+    size_t base = 0;
+    for (uint32_t i = 0; i < desc->n_images; ++i) {
+      const rt_image& im = desc->images[i];
       DImage& d = himg[i];
       d.n_levels = im.n_levels; d.trilinear = im.trilinear; d.max_aniso = im.max_anisotropy; d.wrap = im.wrap;
-      for (int l = 0; l < 16; ++l) { d.w[l] = l < im.n_levels ? im.width[l] : 0; d.h[l] = l < im.n_levels ? im.height[l] : 0; d.off[l] = l < im.n_levels ? base + im.offset[l] : 0; }
-      base += im.n_texels;
+      for (int l = 0; l < 16; ++l) { d.w[l] = 0; d.h[l] = 0; d.off[l] = 0; d.tshift[l] = 0; }
+      for (int l = 0; l < im.n_levels; ++l) {
+        const int w = im.width[l], h = im.height[l], pw = std::max(w, 4), ph = std::max(h, 2);
+        int ts = 0; while ((4 << ts) < pw) ++ts;  // tiles per row = 2^ts
+        d.w[l] = w; d.h[l] = h; d.off[l] = base; d.tshift[l] = ts;
+        const float* src = im.texels + 3 * (size_t)im.offset[l];
+        for (int t = 0; t < h; ++t)
+          for (int x = 0; x < w; ++x) {
+            const size_t idx = base + ((((size_t)(t >> 1) << ts) + (size_t)(x >> 2)) << 3) + (size_t)((t & 1) << 2) + (size_t)(x & 3);
+            const float* q = src + 3 * ((size_t)t * w + x);
+            float* o = &blob[idx * 4]; o[0] = q[0]; o[1] = q[1]; o[2] = q[2];
+          }
+        base += (size_t)pw * ph;
+      }
     }
     TRY_RC(upload(s->texels, blob.data(), blob.size() * 4));
-    for (auto& d : himg) d.texels = s->texels.as<float>();
+    for (auto& d : himg) d.texels = s->texels.as<float4>();
     TRY_RC(upload(s->images, himg.data(), himg.size() * sizeof(DImage)));
   }
   std::vector<DTexture> htex(desc->n_textures);
@@ -335,7 +357,8 @@ extern "C" int rt_scene_create(const rt_scene_desc* desc, int device, rt_scene**
   d.pairs = nullptr; d.quads = nullptr;
   if (!s->small) {  // LDS-resident scenes keep the one-node-per-step loop: the pair form measured no faster there
     // child-pair records for k_trace_pair: {A.min.xyz, A.max.x} {A.max.yz, code A, code B} {B.min.xyz, B.max.x} {B.max.yz, -, -}
-    bool ok = desc->n_nodes < (1u << 29) && desc->n_tris < (1u << 26);
+    // (a root that is itself a leaf - every centroid coincides - is never seen by code_of(): its count must fit the 5-bit field too)
+    bool ok = desc->n_nodes < (1u << 29) && desc->n_tris < (1u << 26) && desc->nodes[0].n_prims <= 32;
     auto code_of = [&](uint32_t c, bool& good) -> uint32_t {
       const rt_bvh_node& n = desc->nodes[c];
       if (n.n_prims > 0) { if (n.n_prims > 32) good = false; return 0x80000000u | n.offset | ((uint32_t)(n.n_prims - 1) << 26); }
@@ -391,6 +414,9 @@ extern "C" int rt_scene_create(const rt_scene_desc* desc, int device, rt_scene**
         d.quads = s->quads.as<float4>(); s->use_quads = true;
       }
     }
+  }
+  if (const size_t nb = tmin_stack_bytes(s)) {
+    if (s->tmin_stack.ensure(nb) != hipSuccess) { delete s; return fail(RT_ERR_OOM, "traversal stack allocation failed"); }
   }
   fill_ewa_lut();
   HIP_TRY(hipDeviceSynchronize());
@@ -474,45 +500,50 @@ extern "C" int rt_light_distribution(rt_scene* s, int32_t n_voxels[3], float* fu
 }
 
 // ---------------------------------------------------------------------------------------------- trace launches
-template <bool ANY, bool COUNT, bool SMALL, int BLOCK, int DEPTH>
-static void launch_trace_v(rt_scene* s, const float4* ro, const float4* rd, const unsigned* queue, const unsigned* count_ptr, unsigned shard_cap, unsigned count_static,
-                           float4* hits, unsigned* occ, unsigned long long* stats, int st_rays, int st_nodes, int st_tris, hipStream_t stream, float4* lacc = nullptr, const float4* direct_add = nullptr) {
-  // persistent grid: enough workgroups to fill every CU at the kernel's LDS-limited residency
+// LDS a workgroup of the trace kernels declares, and the persistent grid that fills every CU at that residency
+template <bool ANY, bool SMALL, int BLOCK, int DEPTH>
+static unsigned trace_grid(const rt_scene* s) {
   const unsigned lds = (unsigned)(DEPTH * BLOCK * ((SMALL && !ANY) ? 2 : 4) + (SMALL ? (2 * RT_SMALL_NODES + 3 * RT_SMALL_TRIS) * 16 : 32));
   unsigned per_cu = (160u * 1024u) / lds; if (per_cu * BLOCK > 2048u) per_cu = 2048u / BLOCK; if (per_cu < 1) per_cu = 1;
+  return (unsigned)s->n_cu * per_cu;
+}
+// HBM half of the child-pair / four-wide kernels' traversal stack: [depth][lane of the grid]. Sized once per scene for the largest grid any
+// launch variant uses (rt_scene_create), so that no launch can fail on an allocation and leave stale hit records behind.
+static size_t tmin_stack_bytes(const rt_scene* s) {
+  if (s->small || !s->use_pairs) return 0;
+  return s->stack_depth <= 32 ? (size_t)trace_grid<false, false, 128, 32>(s) * 128 * 32 * 4 : (size_t)trace_grid<false, false, 128, 64>(s) * 128 * 64 * 4;
+}
+template <bool ANY, bool COUNT, bool SMALL, int BLOCK, int DEPTH>
+static void launch_trace_v(rt_scene* s, const TraceIO& io, const unsigned* queue, const unsigned* count_ptr, unsigned shard_cap, unsigned count_static,
+                           unsigned long long* stats, int st_rays, int st_nodes, int st_tris, hipStream_t stream) {
+  const unsigned grid = trace_grid<ANY, SMALL, BLOCK, DEPTH>(s);
   if constexpr (!SMALL) {
     // measurement knob RTX_TRACE: "plain" = one ray per lane per iteration, "refill" = persistent waves on the one-node-per-step
     // loop, default = child-pair traversal (frames that count visits always use the one-node-per-step loops)
     static const char* mode = getenv("RTX_TRACE");
     const bool plain = mode && mode[0] == 'p', refill_only = mode && mode[0] == 'r';
+    static const unsigned refill_min = getenv("RTX_REFILL_MIN") ? (unsigned)std::min(64, std::max(1, atoi(getenv("RTX_REFILL_MIN")))) : (unsigned)RT_REFILL_MIN;
     if (ANY && !COUNT && !plain && !refill_only && !(mode && mode[0] == 'c') && s->use_quads && s->quad_stack_depth <= DEPTH) {  // RTX_TRACE=childpair: two-wide only
-      const unsigned grid = (unsigned)s->n_cu * per_cu;
-      static const unsigned refill_min_q = getenv("RTX_REFILL_MIN") ? (unsigned)atoi(getenv("RTX_REFILL_MIN")) : (unsigned)RT_REFILL_MIN;
-      hipLaunchKernelGGL((k_trace_quad<ANY, BLOCK, DEPTH>), dim3(grid), dim3(BLOCK), 0, stream, s->d, ro, rd, queue, count_ptr, shard_cap, count_static, hits, occ, stats, st_rays, lacc, direct_add, s->tmin_stack.as<float>(), refill_min_q);
+      hipLaunchKernelGGL((k_trace_quad<ANY, BLOCK, DEPTH>), dim3(grid), dim3(BLOCK), 0, stream, s->d, io, queue, count_ptr, shard_cap, count_static, stats, st_rays, s->tmin_stack.as<float>(), refill_min);
       return;
     }
     if (!COUNT && !plain && !refill_only && s->use_pairs) {
-      const unsigned grid = (unsigned)s->n_cu * per_cu;
-      if (!ANY && s->tmin_stack.ensure((size_t)grid * BLOCK * DEPTH * 4) != hipSuccess) return;
       static const bool ww = getenv("RTX_TRACE_WW") && getenv("RTX_TRACE_WW")[0] == '1';  // measurement knob; the single loop is faster
-      static const unsigned refill_min = getenv("RTX_REFILL_MIN") ? (unsigned)atoi(getenv("RTX_REFILL_MIN")) : (unsigned)RT_REFILL_MIN;
-      if (ww) hipLaunchKernelGGL((k_trace_pair<ANY, true, BLOCK, DEPTH>), dim3(grid), dim3(BLOCK), 0, stream, s->d, ro, rd, queue, count_ptr, shard_cap, count_static, hits, occ, stats, st_rays, lacc, direct_add, s->tmin_stack.as<float>(), refill_min);
-      else hipLaunchKernelGGL((k_trace_pair<ANY, false, BLOCK, DEPTH>), dim3(grid), dim3(BLOCK), 0, stream, s->d, ro, rd, queue, count_ptr, shard_cap, count_static, hits, occ, stats, st_rays, lacc, direct_add, s->tmin_stack.as<float>(), refill_min);
+      if (ww) hipLaunchKernelGGL((k_trace_pair<ANY, true, BLOCK, DEPTH>), dim3(grid), dim3(BLOCK), 0, stream, s->d, io, queue, count_ptr, shard_cap, count_static, stats, st_rays, s->tmin_stack.as<float>(), refill_min);
+      else hipLaunchKernelGGL((k_trace_pair<ANY, false, BLOCK, DEPTH>), dim3(grid), dim3(BLOCK), 0, stream, s->d, io, queue, count_ptr, shard_cap, count_static, stats, st_rays, s->tmin_stack.as<float>(), refill_min);
       return;
     }
     if (!plain) {
-      hipLaunchKernelGGL((k_trace_big<ANY, COUNT, BLOCK, DEPTH>), dim3((unsigned)s->n_cu * per_cu), dim3(BLOCK), 0, stream, s->d, ro, rd, queue, count_ptr,
-                         shard_cap, count_static, hits, occ, stats, st_rays, st_nodes, st_tris, lacc, direct_add);
+      hipLaunchKernelGGL((k_trace_big<ANY, COUNT, BLOCK, DEPTH>), dim3(grid), dim3(BLOCK), 0, stream, s->d, io, queue, count_ptr, shard_cap, count_static, stats, st_rays, st_nodes, st_tris);
       return;
     }
   }
-  hipLaunchKernelGGL((k_trace<ANY, COUNT, SMALL, BLOCK, DEPTH>), dim3((unsigned)s->n_cu * per_cu), dim3(BLOCK), 0, stream, s->d, ro, rd, queue, count_ptr,
-                     shard_cap, count_static, hits, occ, stats, st_rays, st_nodes, st_tris, lacc, direct_add);
+  hipLaunchKernelGGL((k_trace<ANY, COUNT, SMALL, BLOCK, DEPTH>), dim3(grid), dim3(BLOCK), 0, stream, s->d, io, queue, count_ptr, shard_cap, count_static, stats, st_rays, st_nodes, st_tris);
 }
 template <bool ANY, bool COUNT>
-static void launch_trace_c(rt_scene* s, const float4* ro, const float4* rd, const unsigned* queue, const unsigned* count_ptr, unsigned shard_cap, unsigned count_static,
-                           float4* hits, unsigned* occ, unsigned long long* stats, int st_rays, int st_nodes, int st_tris, hipStream_t stream, float4* lacc = nullptr, const float4* direct_add = nullptr) {
-#define RT_ARGS s, ro, rd, queue, count_ptr, shard_cap, count_static, hits, occ, stats, st_rays, st_nodes, st_tris, stream, lacc, direct_add
+static void launch_trace_c(rt_scene* s, const TraceIO& io, const unsigned* queue, const unsigned* count_ptr, unsigned shard_cap, unsigned count_static,
+                           unsigned long long* stats, int st_rays, int st_nodes, int st_tris, hipStream_t stream) {
+#define RT_ARGS s, io, queue, count_ptr, shard_cap, count_static, stats, st_rays, st_nodes, st_tris, stream
   if (s->small) {
     if (s->stack_depth <= 16) launch_trace_v<ANY, COUNT, true, 256, 16>(RT_ARGS);
     else if (s->stack_depth <= 32) launch_trace_v<ANY, COUNT, true, 256, 32>(RT_ARGS);
@@ -524,10 +555,15 @@ static void launch_trace_c(rt_scene* s, const float4* ro, const float4* rd, cons
 #undef RT_ARGS
 }
 template <bool ANY>
-static void launch_trace(rt_scene* s, bool count, const float4* ro, const float4* rd, const unsigned* queue, const unsigned* count_ptr, unsigned shard_cap, unsigned count_static,
-                         float4* hits, unsigned* occ, unsigned long long* stats, int st_rays, int st_nodes, int st_tris, hipStream_t stream, float4* lacc = nullptr, const float4* direct_add = nullptr) {
-  if (count) launch_trace_c<ANY, true>(s, ro, rd, queue, count_ptr, shard_cap, count_static, hits, occ, stats, st_rays, st_nodes, st_tris, stream, lacc, direct_add);
-  else launch_trace_c<ANY, false>(s, ro, rd, queue, count_ptr, shard_cap, count_static, hits, occ, stats, st_rays, st_nodes, st_tris, stream, lacc, direct_add);
+static void launch_trace(rt_scene* s, bool count, const TraceIO& io, const unsigned* queue, const unsigned* count_ptr, unsigned shard_cap, unsigned count_static,
+                         unsigned long long* stats, int st_rays, int st_nodes, int st_tris, hipStream_t stream) {
+  if (count) launch_trace_c<ANY, true>(s, io, queue, count_ptr, shard_cap, count_static, stats, st_rays, st_nodes, st_tris, stream);
+  else launch_trace_c<ANY, false>(s, io, queue, count_ptr, shard_cap, count_static, stats, st_rays, st_nodes, st_tris, stream);
+}
+// planar arrays of the batch entry points
+static TraceIO trace_io_planar(const float4* ro, const float4* rd, float4* hits, unsigned* occ) {
+  TraceIO io{}; io.ray_o = ro; io.ray_d = rd; io.ray_stride = 1; io.hits = hits; io.hit_stride = 1; io.hit_b2 = 0; io.occluded = occ; io.occ_stride = 1;
+  return io;
 }
 
 static int trace_batch(rt_scene* s, const float* rays, uint64_t n, bool any, float* hits, uint32_t* occluded, uint64_t counters[2]) {
@@ -544,8 +580,9 @@ static int trace_batch(rt_scene* s, const float* rays, uint64_t n, bool any, flo
   HIP_TRY(hipMemcpy(ro.p, o.data(), n * 16, hipMemcpyHostToDevice));
   HIP_TRY(hipMemcpy(rd.p, d.data(), n * 16, hipMemcpyHostToDevice));
   HIP_TRY(hipMemset(st.p, 0, ST_COUNT * 8));
-  if (any) launch_trace<true>(s, counters != nullptr, ro.as<float4>(), rd.as<float4>(), nullptr, nullptr, 0, (unsigned)n, nullptr, out.as<unsigned>(), st.as<unsigned long long>(), ST_RAYS_SHADOW, ST_NODES_SHADOW, ST_TRIS_SHADOW, nullptr);
-  else launch_trace<false>(s, counters != nullptr, ro.as<float4>(), rd.as<float4>(), nullptr, nullptr, 0, (unsigned)n, out.as<float4>(), nullptr, st.as<unsigned long long>(), ST_RAYS_CLOSEST, ST_NODES_CLOSEST, ST_TRIS_CLOSEST, nullptr);
+  const TraceIO io = trace_io_planar(ro.as<float4>(), rd.as<float4>(), any ? nullptr : out.as<float4>(), any ? out.as<unsigned>() : nullptr);
+  if (any) launch_trace<true>(s, counters != nullptr, io, nullptr, nullptr, 0, (unsigned)n, st.as<unsigned long long>(), ST_RAYS_SHADOW, ST_NODES_SHADOW, ST_TRIS_SHADOW, nullptr);
+  else launch_trace<false>(s, counters != nullptr, io, nullptr, nullptr, 0, (unsigned)n, st.as<unsigned long long>(), ST_RAYS_CLOSEST, ST_NODES_CLOSEST, ST_TRIS_CLOSEST, nullptr);
   HIP_TRY(hipGetLastError());
   HIP_TRY(hipDeviceSynchronize());
   if (any) HIP_TRY(hipMemcpy(occluded, out.p, n * 4, hipMemcpyDeviceToHost));
@@ -569,8 +606,8 @@ extern "C" int rt_trace_closest_device(rt_scene* s, const void* d_rays, uint64_t
   const float4* ro = (const float4*)d_rays; const float4* rd = ro + n;
   hipEvent_t e0, e1; HIP_TRY(hipEventCreate(&e0)); HIP_TRY(hipEventCreate(&e1));
   HIP_TRY(hipEventRecord(e0, stream));
-  for (int i = 0; i < reps; ++i)
-    launch_trace<false>(s, false, ro, rd, nullptr, nullptr, 0, (unsigned)n, (float4*)d_hits, nullptr, nullptr, 0, 0, 0, stream);
+  const TraceIO io = trace_io_planar(ro, rd, (float4*)d_hits, nullptr);
+  for (int i = 0; i < reps; ++i) launch_trace<false>(s, false, io, nullptr, nullptr, 0, (unsigned)n, nullptr, 0, 0, 0, stream);
   HIP_TRY(hipEventRecord(e1, stream));
   HIP_TRY(hipEventSynchronize(e1));
   float ms = 0; HIP_TRY(hipEventElapsedTime(&ms, e0, e1));
@@ -763,36 +800,17 @@ extern "C" int rt_render(rt_scene* s, const rt_camera* cam, const rt_film_desc* 
   const bool all_in_bounds = path->pixel_bounds[0] <= film->sample_bounds[0] && path->pixel_bounds[2] >= film->sample_bounds[2] &&
                              path->pixel_bounds[1] <= film->sample_bounds[1] && path->pixel_bounds[3] >= film->sample_bounds[3];
   // batch / pass sizing. A batch is a range of owned pixels whose sampler tables (2*dims u16 per sample) are built
-  // at once; it is rendered in passes of n_samples consecutive samples of all its pixels, ~2^28 paths (70 GB of path state) per pass.
+  // at once; it is rendered in passes of n_samples consecutive samples of all its pixels, ~2^28 paths (83 GB of path state) per pass.
   // measurement knobs; 2^23 -> 2^26 paths per pass: -9 % (S1), -32 % (S2); 2^26 -> 2^28 with 2^19-pixel batches: -1 % (S1), -7 % (S2), -1 % (S3):
-  // fewer, larger launches - late bounces hold few rays - and 288 GB of HBM hold the 70 GB of path state of such a pass with room to spare
-  static const int tp_log2 = getenv("RTX_PASS_LOG2") ? atoi(getenv("RTX_PASS_LOG2")) : 28;
-  static const int bp_log2 = getenv("RTX_BATCH_LOG2") ? atoi(getenv("RTX_BATCH_LOG2")) : 19;
-  const unsigned long long target_paths = 1ull << tp_log2;
-  unsigned long long batch_pixels = std::max<unsigned long long>(1, std::min<unsigned long long>(owned_pixels, 1ull << bp_log2));  // a rank may own no rows
-  // a shard that fits one batch (e.g. 1/8 of a frame on an 8-GPU run) is still cut in two, so that the second half's sampler
-  // tables are built under the first half's path kernels; only worth it when there is enough work to hide them under
-  if (owned_pixels <= batch_pixels && owned_pixels >= (1ull << 15) && owned_pixels * spp >= (1ull << 27)) batch_pixels = (owned_pixels + 1) / 2;
-  const unsigned long long table_bytes_per_pixel = 2ull * dims * spp * 2ull;
-  while (batch_pixels > 4096 && batch_pixels * table_bytes_per_pixel > (16ull << 30)) batch_pixels >>= 1;  // <= 16 GiB of tables per buffer
-  unsigned pass_samples = (unsigned)std::max<unsigned long long>(1, target_paths / batch_pixels);
-  if (pass_samples > spp) pass_samples = spp;
-  const unsigned long long chunk_pixels = batch_pixels;
-  const unsigned long long cap = batch_pixels * pass_samples;
-  if (cap > 0x7fffffffull) return fail(RT_ERR_INVALID, "pass too large");
-
-  // workspace
-  enum { B_RAYO, B_RAYD, B_HIT, B_BETA, B_LACC, B_RNG, B_PFILM, B_SHO, B_SHD, B_SHOCC, B_MIO, B_MID, B_MIHIT, B_PA, B_PB, B_PC, B_PF, B_QIN, B_QOUT, B_QSH, B_QMI };
-  const size_t sz16 = cap * 16, sz8 = cap * 8, sz4 = cap * 4;
-  // a shard receives the appends of the blocks with blockIdx % RT_QSHARDS == shard; a grid-stride loop hands
-  // each block at most ceil(n / (grid * 256)) iterations, so cap / RT_QSHARDS plus one iteration per block bounds it
-  const unsigned pgrid_q = (unsigned)s->n_cu * 8u;
-  const unsigned shard_cap = (unsigned)(cap / RT_QSHARDS) + 256u * (pgrid_q / RT_QSHARDS + 1u) + 256u;
-  const size_t szq = (size_t)shard_cap * RT_QSHARDS * 4;
-  const size_t sizes[] = {sz16, sz16, sz16, sz16, sz16, sz8, sz8, sz16, sz16, sz4, sz16, sz16, sz16, sz16, sz16, sz16, sz4, szq, szq, szq, szq};
-  for (int i = 0; i < 21; ++i) HIP_TRY(s->ws[i].ensure(sizes[i]));
-  const size_t counter_words = (size_t)(fp.max_depth + 2) * 3 * RT_QSHARDS;  // one block of {out, shadow, mis} shard counts per bounce + raygen's
-  HIP_TRY(s->counters.ensure(counter_words * 4)); HIP_TRY(s->stats.ensure(ST_COUNT * 8));
+  // fewer, larger launches - late bounces hold few rays - and 288 GB of HBM hold the path state of such a pass with room to spare. On a
+  // device with less free memory (a busy GPU, several live scenes, a smaller part) the pass is halved until its workspace fits what
+  // hipMemGetInfo reports, and halved again if an allocation fails all the same.
+  auto env_log2 = [](const char* name, int dflt) { const char* e = getenv(name); return e ? std::min(30, std::max(16, atoi(e))) : dflt; };
+  static const int tp_log2 = env_log2("RTX_PASS_LOG2", 28);
+  static const int bp_log2 = env_log2("RTX_BATCH_LOG2", 19);
+  enum { B_PATH, B_ACC, B_SH, B_MI, B_QIN, B_QOUT, B_QSH, B_QMI, B_QMA, B_COUNT };  // grouped per-path records (rtx_kernels.h) and five queues of path ids
+  const bool has_infinite = s->d.n_infinite > 0;
+  const size_t counter_words = (size_t)(fp.max_depth + 2) * RT_NQ * RT_QSHARDS;  // one block of {out, shadow, mis, mis-any} shard counts per bounce + raygen's
   // material binning before the generic shade kernel: per bounce {hist, cursor}[RT_BIN_MAX + 1] + the 8 count words of the sorted queue
   static const bool bin_off = getenv("RTX_SHADE_BINS") && getenv("RTX_SHADE_BINS")[0] == '0';  // measurement knob
   const bool use_bins = !s->lambert_materials && s->n_code_classes > 1 && !bin_off;  // one class: every vertex runs the same code, the queue order is kept
@@ -802,38 +820,80 @@ extern "C" int rt_render(rt_scene* s, const rt_camera* cam, const rt_film_desc* 
   const int split_mode = getenv("RTX_SHADE_SPLIT") ? atoi(getenv("RTX_SHADE_SPLIT")) : 2;
   const unsigned n_first = split_mode >= 1 ? s->n_lambert_classes : 0u, n_second = split_mode >= 2 ? s->n_small_classes : 0u;
   const bool split_classes = use_bins && (n_first + n_second) > 0 && n_first + n_second < RT_BIN_MAX;
-  if (use_bins) { HIP_TRY(s->bin_words.ensure((size_t)(fp.max_depth + 1) * bin_stride * 4)); HIP_TRY(s->bin_sorted.ensure(cap * 4)); }
-  HIP_TRY(s->film_acc.ensure((size_t)cw * ch * 16)); HIP_TRY(s->own_acc.ensure(chunk_pixels * 16));
-  HIP_TRY(s->filter_table.ensure(1024));
-  const bool multi_batch = owned_pixels > chunk_pixels;
-  for (int b = 0; b < (multi_batch ? 2 : 1); ++b) { HIP_TRY(s->scrambles[b].ensure(chunk_pixels * 3 * dims * 4)); HIP_TRY(s->perms[b].ensure(chunk_pixels * 2 * dims * spp * 2)); }
+  const unsigned pgrid_q = (unsigned)s->n_cu * 8u;
+  const unsigned long long table_bytes_per_pixel = 2ull * dims * spp * 2ull;
+
+  unsigned long long batch_pixels = 0, chunk_pixels = 0, cap = 0; unsigned pass_samples = 0, shard_cap = 0; bool multi_batch = false;
+  for (int shrink = 0;; ++shrink) {
+    if (tp_log2 - shrink < 14) return fail(RT_ERR_OOM, "not enough free device memory for the smallest pass (2^14 paths)");
+    const unsigned long long target_paths = 1ull << (tp_log2 - shrink);
+    batch_pixels = std::max<unsigned long long>(1, std::min<unsigned long long>(owned_pixels, std::min(1ull << bp_log2, target_paths)));  // a rank may own no rows
+    // a shard that fits one batch (e.g. 1/8 of a frame on an 8-GPU run) is still cut in two, so that the second half's sampler
+    // tables are built under the first half's path kernels; only worth it when there is enough work to hide them under
+    if (owned_pixels <= batch_pixels && owned_pixels >= (1ull << 15) && owned_pixels * spp >= (1ull << 27)) batch_pixels = (owned_pixels + 1) / 2;
+    while (batch_pixels > 4096 && batch_pixels * table_bytes_per_pixel > (16ull << 30)) batch_pixels >>= 1;  // <= 16 GiB of tables per buffer
+    pass_samples = (unsigned)std::max<unsigned long long>(1, target_paths / batch_pixels);
+    if (pass_samples > spp) pass_samples = spp;
+    chunk_pixels = batch_pixels;
+    cap = batch_pixels * pass_samples;
+    if (cap > 0x7fffffffull) return fail(RT_ERR_INVALID, "pass too large");
+    // a shard receives the appends of the blocks with blockIdx % RT_QSHARDS == shard; a grid-stride loop hands
+    // each block at most ceil(n / (grid * 256)) iterations, so cap / RT_QSHARDS plus one iteration per block bounds it
+    shard_cap = (unsigned)(cap / RT_QSHARDS) + 256u * (pgrid_q / RT_QSHARDS + 1u) + 256u;
+    const size_t szq = (size_t)shard_cap * RT_QSHARDS * 4;
+    multi_batch = owned_pixels > chunk_pixels;
+    struct Want { DevBuf* buf; size_t bytes; };
+    std::vector<Want> want = {
+        {&s->ws[B_PATH], cap * sizeof(PathRec)}, {&s->ws[B_ACC], cap * sizeof(PathAcc)}, {&s->ws[B_SH], cap * sizeof(ShadowRec)}, {&s->ws[B_MI], cap * sizeof(MisRec)},
+        {&s->ws[B_QIN], szq}, {&s->ws[B_QOUT], szq}, {&s->ws[B_QSH], szq}, {&s->ws[B_QMI], szq}, {&s->ws[B_QMA], has_infinite ? szq : 16},
+        {&s->counters, counter_words * 4}, {&s->stats, (size_t)ST_COUNT * 8}, {&s->film_acc, (size_t)cw * ch * 16}, {&s->own_acc, (size_t)chunk_pixels * 16},
+        {&s->filter_table, 1024}, {&s->scrambles[0], (size_t)chunk_pixels * 3 * dims * 4}, {&s->perms[0], (size_t)(chunk_pixels * table_bytes_per_pixel)},
+        {&s->sampler_plan.partners, (size_t)(chunk_pixels * table_bytes_per_pixel)}};
+    if (use_bins) { want.push_back({&s->bin_words, (size_t)(fp.max_depth + 1) * bin_stride * 4}); want.push_back({&s->bin_sorted, (size_t)cap * 4}); }
+    if (multi_batch) { want.push_back({&s->scrambles[1], (size_t)chunk_pixels * 3 * dims * 4}); want.push_back({&s->perms[1], (size_t)(chunk_pixels * table_bytes_per_pixel)}); }
+    if (!(flags & RT_FLAG_FILM_ON_DEVICE)) want.push_back({&s->film_out, (size_t)cw * ch * 16});
+    size_t grow = 0;  // bytes the buffers have to grow by (a buffer that is too small is freed and allocated anew)
+    for (const Want& w : want) if (!w.buf->p || w.buf->bytes < w.bytes) grow += w.bytes;
+    size_t held = 0;
+    for (const Want& w : want) if (w.buf->p && w.buf->bytes < w.bytes) held += w.buf->bytes;
+    size_t mem_free = 0, mem_total = 0;
+    HIP_TRY(hipMemGetInfo(&mem_free, &mem_total));
+    if (grow > mem_free + held - std::min<size_t>(mem_free + held, (size_t)256 << 20)) continue;  // keep 256 MiB clear of the workspace
+    bool ok = true;
+    for (const Want& w : want) if (w.buf->ensure(w.bytes) != hipSuccess) { ok = false; break; }
+    if (ok) break;
+    (void)hipGetLastError();  // the failed hipMalloc; try again with half the pass
+  }
   if (!s->aux_stream) {
     int lo = 0, hi = 0; (void)hipDeviceGetStreamPriorityRange(&lo, &hi);  // lo = numerically greatest = lowest priority
     HIP_TRY(hipStreamCreateWithPriority(&s->aux_stream, hipStreamNonBlocking, lo));
     for (int i = 0; i < 2; ++i) { HIP_TRY(hipEventCreateWithFlags(&s->ev_tables[i], hipEventDisableTiming)); HIP_TRY(hipEventCreateWithFlags(&s->ev_batch_done[i], hipEventDisableTiming)); }
     HIP_TRY(hipEventCreateWithFlags(&s->ev_frame_begin, hipEventDisableTiming));
   }
-  float4* d_out = nullptr;
-  if (flags & RT_FLAG_FILM_ON_DEVICE) d_out = (float4*)film_xyzw;
-  else { HIP_TRY(s->film_out.ensure((size_t)cw * ch * 16)); d_out = s->film_out.as<float4>(); }
+  float4* const d_out = (flags & RT_FLAG_FILM_ON_DEVICE) ? (float4*)film_xyzw : s->film_out.as<float4>();
   HIP_TRY(hipMemcpyAsync(s->filter_table.p, film->filter_table, 1024, hipMemcpyHostToDevice, stream));
   HIP_TRY(hipMemsetAsync(s->film_acc.p, 0, (size_t)cw * ch * 16, stream));
   HIP_TRY(hipMemsetAsync(s->stats.p, 0, ST_COUNT * 8, stream));
 
   PassState ps{};
   ps.spp = spp; ps.spp_log2 = spp_log2; ps.dims = dims;
-  ps.ray_o = s->ws[B_RAYO].as<float4>(); ps.ray_d = s->ws[B_RAYD].as<float4>(); ps.hit = s->ws[B_HIT].as<float4>();
-  ps.beta = s->ws[B_BETA].as<float4>(); ps.lacc = s->ws[B_LACC].as<float4>(); ps.rng = s->ws[B_RNG].as<unsigned long long>();
-  ps.pfilm = s->ws[B_PFILM].as<float2>();
-  ps.sh_o = s->ws[B_SHO].as<float4>(); ps.sh_d = s->ws[B_SHD].as<float4>(); ps.sh_occ = s->ws[B_SHOCC].as<unsigned>();
-  ps.mi_o = s->ws[B_MIO].as<float4>(); ps.mi_d = s->ws[B_MID].as<float4>(); ps.mi_hit = s->ws[B_MIHIT].as<float4>();
-  ps.pend_a = s->ws[B_PA].as<float4>(); ps.pend_b = s->ws[B_PB].as<float4>(); ps.pend_c = s->ws[B_PC].as<float4>(); ps.pend_flags = s->ws[B_PF].as<unsigned>();
+  ps.path = s->ws[B_PATH].as<PathRec>(); ps.acc = s->ws[B_ACC].as<PathAcc>(); ps.sh = s->ws[B_SH].as<ShadowRec>(); ps.mi = s->ws[B_MI].as<MisRec>();
   unsigned* q_a = s->ws[B_QIN].as<unsigned>(); unsigned* q_b = s->ws[B_QOUT].as<unsigned>();
-  ps.q_shadow = s->ws[B_QSH].as<unsigned>(); ps.q_mis = s->ws[B_QMI].as<unsigned>();
+  ps.q_shadow = s->ws[B_QSH].as<unsigned>(); ps.q_mis = s->ws[B_QMI].as<unsigned>(); ps.q_misany = s->ws[B_QMA].as<unsigned>();
   ps.own_acc = s->own_acc.as<float4>(); ps.shard_cap = shard_cap; ps.stats = s->stats.as<unsigned long long>();
 
   if ((rc = sampler_plan_prepare(s->sampler_plan, spp, dims)) != RT_OK) return rc;
   if ((rc = sampler_set_lds_limits(spp)) != RT_OK) return rc;
+  // the four kinds of trace launch of a bounce, on the records of the pass
+  TraceIO io_path{}, io_shadow{}, io_mis{}, io_mis_any{};
+  {
+    constexpr unsigned PR = sizeof(PathRec) / 16, SR = sizeof(ShadowRec) / 16, MR = sizeof(MisRec) / 16;
+    io_path.ray_o = &ps.path->o; io_path.ray_d = &ps.path->d; io_path.ray_stride = PR; io_path.hits = &ps.path->hit; io_path.hit_stride = PR; io_path.hit_b2 = 1;
+    io_shadow.ray_o = &ps.sh->o; io_shadow.ray_d = &ps.sh->d; io_shadow.ray_stride = SR; io_shadow.occluded = &ps.mi->occ; io_shadow.occ_stride = sizeof(MisRec) / 4;
+    io_shadow.lacc = &ps.acc->lacc; io_shadow.lacc_stride = sizeof(PathAcc) / 16; io_shadow.direct_add = &ps.sh->add; io_shadow.add_stride = SR;
+    io_mis.ray_o = &ps.mi->o; io_mis.ray_d = &ps.mi->d; io_mis.ray_stride = MR; io_mis.hits = &ps.mi->hit; io_mis.hit_stride = MR; io_mis.hit_b2 = 0;
+    io_mis_any = io_mis; io_mis_any.hits = nullptr; io_mis_any.occluded = (unsigned*)&ps.mi->hit.y; io_mis_any.occ_stride = sizeof(MisRec) / 4;
+  }
   const bool count = (flags & RT_FLAG_COUNT_TRAVERSAL) != 0;
   const unsigned pgrid = (unsigned)s->n_cu * 8u;
   unsigned long long* dstats = s->stats.as<unsigned long long>();
@@ -846,11 +906,13 @@ extern "C" int rt_render(rt_scene* s, const rt_camera* cam, const rt_film_desc* 
   hipStream_t aux = (ov && ov[0] == '0') ? stream : s->aux_stream;
   HIP_TRY(hipEventRecord(s->ev_frame_begin, stream));
   HIP_TRY(hipStreamWaitEvent(aux, s->ev_frame_begin, 0));
+  int tables_rc = RT_OK;
   auto launch_tables = [&](unsigned long long first, int buf) {
     const unsigned long long npx = std::min(chunk_pixels, owned_pixels - first);
     FrameParams f2 = fp; f2.chunk_first = first;
     tm.begin(&stats.ms_sampler, aux);
-    (void)launch_sampler_tables(s->sampler_plan, f2, (unsigned)npx, 0ull, 0, s->scrambles[buf].as<unsigned>(), s->perms[buf].as<unsigned short>(), aux);
+    const int trc = launch_sampler_tables(s->sampler_plan, f2, (unsigned)npx, 0ull, 0, s->scrambles[buf].as<unsigned>(), s->perms[buf].as<unsigned short>(), aux);
+    if (trc != RT_OK && tables_rc == RT_OK) tables_rc = trc;
     tm.end(aux);
     (void)hipEventRecord(s->ev_tables[buf], aux);
   };
@@ -866,6 +928,7 @@ extern "C" int rt_render(rt_scene* s, const rt_camera* cam, const rt_film_desc* 
       if (batch_no >= 1) HIP_TRY(hipStreamWaitEvent(aux, s->ev_batch_done[buf ^ 1], 0));
       launch_tables(first + chunk_pixels, buf ^ 1);
     }
+    if (tables_rc != RT_OK) { (void)hipDeviceSynchronize(); return tables_rc; }
     HIP_TRY(hipStreamWaitEvent(stream, s->ev_tables[buf], 0));
     for (unsigned s0 = 0; s0 < spp; s0 += pass_samples) {
       ps.s0 = s0; ps.n_samples = std::min(pass_samples, spp - s0); ps.cap = (unsigned)(npx * ps.n_samples);
@@ -875,17 +938,16 @@ extern "C" int rt_render(rt_scene* s, const rt_camera* cam, const rt_film_desc* 
       unsigned* const cb = s->counters.as<unsigned>();
       ps.cnt_in = nullptr; ps.cnt_out = cb;  // raygen appends to block 0's `out` queue
       ps.all_in_bounds = all_in_bounds ? 1 : 0;
-      ps.resolve_scan = use_bins ? 1 : 0;
-      if (use_bins) HIP_TRY(hipMemsetAsync(ps.pend_flags, 0, (size_t)ps.cap * 4, stream));
+      ps.mis_any = (has_infinite && !count) ? 1 : 0;  // a frame that counts node visits keeps the reference's closest-hit walk for every MIS ray
       tm.begin(&stats.ms_raygen);
       hipLaunchKernelGGL(k_raygen, dim3(pgrid), dim3(256), 0, stream, fp, ps);
       tm.end();
       for (int bounce = 0; bounce <= fp.max_depth; ++bounce) {
-        ps.cnt_in = cb + (size_t)bounce * 3 * RT_QSHARDS; ps.cnt_out = cb + (size_t)(bounce + 1) * 3 * RT_QSHARDS;
+        ps.cnt_in = cb + (size_t)bounce * RT_NQ * RT_QSHARDS; ps.cnt_out = cb + (size_t)(bounce + 1) * RT_NQ * RT_QSHARDS;
         unsigned* const q_first = ps.q_in;
         if (bounce == 0 && all_in_bounds) ps.q_in = nullptr;  // identity: path i is entry i
         tm.begin(&stats.ms_trace_closest);
-        launch_trace<false>(s, count, ps.ray_o, ps.ray_d, ps.q_in, ps.cnt_in, ps.shard_cap, ps.cap, ps.hit, nullptr, dstats, ST_RAYS_CLOSEST, ST_NODES_CLOSEST, ST_TRIS_CLOSEST, stream, ps.lacc, nullptr);
+        launch_trace<false>(s, count, io_path, ps.q_in, ps.cnt_in, ps.shard_cap, ps.cap, dstats, ST_RAYS_CLOSEST, ST_NODES_CLOSEST, ST_TRIS_CLOSEST, stream);
         tm.end();
         tm.begin(&stats.ms_shade);
         if (s->lambert_only) hipLaunchKernelGGL(k_shade<1>, dim3(pgrid), dim3(256), 0, stream, s->d, fp, ps);
@@ -907,10 +969,11 @@ extern "C" int rt_render(rt_scene* s, const rt_camera* cam, const rt_film_desc* 
         }
         tm.end();
         tm.begin(&stats.ms_trace_any);
-        launch_trace<true>(s, count, ps.sh_o, ps.sh_d, ps.q_shadow, ps.cnt_out + RT_QSHARDS, ps.shard_cap, 0, nullptr, ps.sh_occ, dstats, ST_RAYS_SHADOW, ST_NODES_SHADOW, ST_TRIS_SHADOW, stream, ps.lacc, ps.pend_a);
+        launch_trace<true>(s, count, io_shadow, ps.q_shadow, ps.cnt_out + RT_QSHARDS, ps.shard_cap, 0, dstats, ST_RAYS_SHADOW, ST_NODES_SHADOW, ST_TRIS_SHADOW, stream);
         tm.end();
         tm.begin(&stats.ms_trace_mis);
-        launch_trace<false>(s, count, ps.mi_o, ps.mi_d, ps.q_mis, ps.cnt_out + 2 * RT_QSHARDS, ps.shard_cap, 0, ps.mi_hit, nullptr, dstats, ST_RAYS_MIS, ST_NODES_MIS, ST_TRIS_MIS, stream);
+        launch_trace<false>(s, count, io_mis, ps.q_mis, ps.cnt_out + 2 * RT_QSHARDS, ps.shard_cap, 0, dstats, ST_RAYS_MIS, ST_NODES_MIS, ST_TRIS_MIS, stream);
+        if (ps.mis_any) launch_trace<true>(s, false, io_mis_any, ps.q_misany, ps.cnt_out + 3 * RT_QSHARDS, ps.shard_cap, 0, dstats, ST_RAYS_MIS, ST_NODES_MIS, ST_TRIS_MIS, stream);
         tm.end();
         tm.begin(&stats.ms_resolve);
         hipLaunchKernelGGL(k_resolve, dim3(pgrid), dim3(256), 0, stream, s->d, ps);

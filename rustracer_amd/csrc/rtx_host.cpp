@@ -536,7 +536,7 @@ static std::vector<MipResampleWeight> mip_resample_weights(int old_res, int new_
 }
 static int round_up_pow2(int v) { v -= 1; v |= v >> 1; v |= v >> 2; v |= v >> 4; v |= v >> 8; v |= v >> 16; return v + 1; }  // lib.rs:215-224
 
-static bool g_device_ingest = false;
+static thread_local bool g_device_ingest = false;  // per calling thread: two threads building scenes do not see each other's choice
 void rtxh_set_device_ingest(int32_t on) { g_device_ingest = on != 0; }
 
 // MIPMap::new with the arithmetic on the GPU (rt_mip_build): the host only supplies the Lanczos taps and the level geometry
@@ -808,7 +808,7 @@ int rtxh_render(rtxh_scene* s, const rtxh_render_params* p, void* stream, float*
   rt_path_desc path{}; path.max_depth = p->max_depth; path.rr_threshold = p->rr_threshold; path.light_strategy = p->light_strategy;
   // PathIntegrator::create (path.rs:53-69): pixel_bounds = sample bounds, optionally intersected with "pixelbounds"
   int pb[4] = {cf.film.sample_bounds[0], cf.film.sample_bounds[1], cf.film.sample_bounds[2], cf.film.sample_bounds[3]};
-  if (p->pixel_bounds[1] > p->pixel_bounds[0]) {
+  if (p->has_pixel_bounds) {  // Bounds2i::intersect (bounds.rs): max of the mins, min of the maxes; an empty result is kept and renders nothing
     pb[0] = std::max(pb[0], p->pixel_bounds[0]); pb[1] = std::max(pb[1], p->pixel_bounds[2]);
     pb[2] = std::min(pb[2], p->pixel_bounds[1]); pb[3] = std::min(pb[3], p->pixel_bounds[3]);
   }

@@ -307,7 +307,7 @@ bool hdr_decode(const std::vector<uint8_t>& file, int& W, int& H, std::vector<fl
       while (x < w) {
         if (pos + 4 > file.size()) { err = "HDR: truncated scanline"; return false; }
         const uint8_t* q = &file[pos]; pos += 4;
-        if (q[0] == 1 && q[1] == 1 && q[2] == 1 && x > 0) { int cnt = (int)q[3] << shift; if (x + cnt > w) { err = "HDR: bad run"; return false; } for (int k = 0; k < cnt; ++k, ++x) memcpy(&scan[(size_t)x * 4], &scan[(size_t)(x - 1) * 4], 4); shift += 8; }
+        if (q[0] == 1 && q[1] == 1 && q[2] == 1 && x > 0) { if (shift > 24) { err = "HDR: bad run"; return false; } const uint64_t cnt = (uint64_t)q[3] << shift; if ((uint64_t)x + cnt > (uint64_t)w) { err = "HDR: bad run"; return false; } for (uint64_t k = 0; k < cnt; ++k, ++x) memcpy(&scan[(size_t)x * 4], &scan[(size_t)(x - 1) * 4], 4); shift += 8; }
         else { memcpy(&scan[(size_t)x * 4], q, 4); ++x; shift = 0; }
       }
     }
@@ -417,7 +417,7 @@ bool exr_decode(const std::vector<uint8_t>& file, int& W, int& H, std::vector<fl
   std::vector<uint8_t> raw;
   for (size_t blk = 0; blk < n_blocks; ++blk) {
     uint64_t off = 0; for (int k = 7; k >= 0; --k) off = off << 8 | file[table + blk * 8 + k];
-    if (off + 8 > file.size()) { err = "EXR: block offset outside the file"; return false; }
+    if (file.size() < 8 || off > file.size() - 8) { err = "EXR: block offset outside the file"; return false; }  // (off + 8 would wrap for offsets near 2^64)
     b.pos = (size_t)off;
     int32_t y0; { uint32_t v = le32(); memcpy(&y0, &v, 4); }
     const uint32_t size = le32();

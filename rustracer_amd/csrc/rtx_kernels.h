@@ -14,6 +14,17 @@ namespace rtx {
 //      for all spp) and each batch into PASSES of n_samples consecutive samples of every batch pixel.
 //      SoA arrays are indexed by path id = local_sample * n_pixels + batch_pixel, so that the 64 lanes of a
 //      wave hold the same sample of 64 neighbouring pixels and every access coalesces.
+// Per-path records are grouped by the kernels that touch them together, so that a vertex shaded out of path-id order (the shade queue
+// is counting-sorted by material class on scenes with several) touches four cache lines instead of twenty 16-byte slots of
+// twenty arrays - a scattered 16-byte access moves a whole 128-byte line. In path-id order the records stream like the arrays did.
+struct PathRec { float4 o, d, hit, beta; };  // 64 B: ray (o | t_max, d), hit (b2 | t, prim, b0, b1), throughput (rgb, eta_scale). trace: R o d, W hit; shade: R d hit beta, W o d beta
+struct PathAcc { float4 lacc; unsigned long long rng; float2 pfilm; };  // 32 B: radiance (rgb, packed state), RNG state, film position
+struct ShadowRec { float4 o, d, add, pad; };  // 64 B: shadow ray (d.w = 1: no MIS ray pending, `add` is applied by the any-hit kernel) and beta * Ld / pick_pdf
+// 128 B, one line: everything k_resolve needs of a vertex with a BSDF-sampled MIS ray. hit.y = prim of the closest hit, or - for rays that only
+// need occlusion (sampled light infinite) - 1 / 0 from the any-hit kernel
+struct MisRec { float4 o, d, hit, a, b, c; unsigned occ, flags, pad[6]; };
+#define RT_PEND_SHADOW 1u           // MisRec::flags: a shadow ray is out (its result is in occ)
+#define RT_PEND_MIS_ANY 0x40000000u // the MIS ray was traced for occlusion only; bits 2-29: index of the sampled light
 struct PassState {
   unsigned cap;            // paths in this pass = n_pixels * n_samples
   unsigned spp, spp_log2, dims;
@@ -23,27 +34,21 @@ struct PassState {
   // sampler tables of the chunk
   const unsigned* scrambles;        // [pixel][3*dims]
   const unsigned short* perms;      // [pixel][2*dims][spp]
-  // rays / hits
-  float4* ray_o; float4* ray_d; float4* hit;
-  float4* beta;    // rgb, eta_scale
-  float4* lacc;    // rgb, packed state
-  unsigned long long* rng;
-  float2* pfilm;
-  float4* sh_o; float4* sh_d; unsigned* sh_occ;
-  float4* mi_o; float4* mi_d; float4* mi_hit;
-  float4* pend_a; float4* pend_b; float4* pend_c; unsigned* pend_flags;
+  PathRec* path; PathAcc* acc; ShadowRec* sh; MisRec* mi;
   // queues of path ids, each split into RT_QSHARDS shards (shard = blockIdx & 7 of the producer, region
   // [shard * shard_cap, ...)) with its own counter word: a single word sustains only ~88 returning
   // atomics per microsecond. Every bounce has its own zero-initialised block of counters, so nothing has to be
   // reset or rotated between bounces: cnt_in = the 8 shard counts of q_in (written by raygen / the previous
-  // bounce), cnt_out[q * RT_QSHARDS + shard] with q: 0 = continuing paths (q_out), 1 = shadow, 2 = mis.
-  unsigned* q_in; unsigned* q_out; unsigned* q_shadow; unsigned* q_mis;
+  // bounce), cnt_out[q * RT_QSHARDS + shard] with q: 0 = continuing paths (q_out), 1 = shadow, 2 = mis (closest hit),
+  // 3 = mis rays that only need occlusion.
+  unsigned* q_in; unsigned* q_out; unsigned* q_shadow; unsigned* q_mis; unsigned* q_misany;
   const unsigned* cnt_in; unsigned* cnt_out; unsigned shard_cap;
   int all_in_bounds;  // every sample of the pass is traced (no crop by pixel_bounds): bounce 0 needs no queue, path i is entry i
-  int resolve_scan;   // k_resolve walks pend_flags in path-id order instead of the MIS queue (set when the shade queue is binned)
+  int mis_any;        // BSDF-sampled MIS rays toward an infinite light go to q_misany (off on frames that count node visits: reference walk)
   const unsigned* range;  // k_shade: shade entries [range[0], range[1]) of q_in only (NULL = all): class-wise dispatch over the binned queue
   unsigned long long* stats;  // device-side u64 counters, see ST_* below
 };
+#define RT_NQ 4  // queues a bounce fills
 enum { ST_CAMERA = 0, ST_RAYS_CLOSEST, ST_RAYS_SHADOW, ST_RAYS_MIS, ST_NODES_CLOSEST, ST_NODES_SHADOW, ST_NODES_MIS,
        ST_TRIS_CLOSEST, ST_TRIS_SHADOW, ST_TRIS_MIS, ST_SCRUBBED, ST_UNBUILT_VOXEL, ST_COUNT };
 
@@ -62,7 +67,9 @@ struct FrameParams {
   unsigned w_recip;                // floor(2^32 / W), W = sample-bounds width (0 when W == 1): division by W without a divide
 };
 
-// packed per-path state in lacc.w: bits 0-7 bounces, bit 8 specular_bounce, bits 9-12 cur_1d, bits 13-16 cur_2d
+// packed per-path state in lacc.w: bits 0-7 bounces, bit 8 specular_bounce, bits 9-12 cur_1d, bits 13-16 cur_2d, bit 17: sample outside
+// pixel_bounds (never traced, skipped by the film)
+#define RT_STATE_OUT_OF_BOUNDS (1u << 17)
 RT_DEV unsigned pack_state(int bounces, bool spec, int c1, int c2) { return (unsigned)bounces | ((unsigned)spec << 8) | ((unsigned)c1 << 9) | ((unsigned)c2 << 13); }
 
 RT_DEV unsigned wave_push(unsigned* counter, bool pred) {
@@ -449,15 +456,16 @@ __global__ void __launch_bounds__(256) k_raygen(FrameParams fp, PassState ps) {
       f2 o = table_2d(tb, pix, 0, s);
       f2 p_film = mk2((float)x + o.x, (float)y + o.y);
       f2 p_lens = table_2d(tb, pix, 1, s);
-      ps.pfilm[pid] = make_float2(p_film.x, p_film.y);
       CameraRay cr = generate_camera_ray(fp, p_film, p_lens, 1.0f / sqrtf((float)ps.spp));
-      ps.ray_o[pid] = make_float4(cr.o.x, cr.o.y, cr.o.z, kInf);
-      ps.ray_d[pid] = make_float4(cr.d.x, cr.d.y, cr.d.z, 0.0f);
-      ps.beta[pid] = make_float4(1.0f, 1.0f, 1.0f, 1.0f);
-      ps.lacc[pid] = make_float4(0.0f, 0.0f, 0.0f, __uint_as_float(pack_state(0, false, 1, 2)));
+      PathRec* pr = ps.path + pid;
+      pr->o = make_float4(cr.o.x, cr.o.y, cr.o.z, kInf);
+      pr->d = make_float4(cr.d.x, cr.d.y, cr.d.z, 0.0f);
+      pr->beta = make_float4(1.0f, 1.0f, 1.0f, 1.0f);
       Pcg32 rng; rng.set_sequence(pixel_index * (unsigned long long)ps.spp + s + (1ull << 32));  // keyed per-sample stream
-      ps.rng[pid] = rng.state;
-      ps.pend_flags[pid] = in_bounds ? 0u : 0x80000000u;  // bit31: sample outside pixel_bounds, never traced
+      PathAcc* pa = ps.acc + pid;
+      pa->lacc = make_float4(0.0f, 0.0f, 0.0f, __uint_as_float(pack_state(0, false, 1, 2) | (in_bounds ? 0u : RT_STATE_OUT_OF_BOUNDS)));
+      pa->rng = rng.state;
+      pa->pfilm = make_float2(p_film.x, p_film.y);
     }
     if (!ps.all_in_bounds) {
       const int ci[1] = {0}; const bool pr[1] = {in_bounds}; unsigned slot[1];
@@ -481,13 +489,34 @@ struct LdsSrc {
 #define RT_SMALL_NODES 256
 #define RT_SMALL_TRIS 128
 
+// Where a trace launch reads its rays and writes its results: element [pid * stride] of each pointer (strides in elements of the pointer's
+// type), so that the same kernels serve the records of a frame (PathRec / ShadowRec / MisRec) and the planar arrays of the batch entry points.
+struct TraceIO {
+  const float4* ray_o; const float4* ray_d; unsigned ray_stride;  // (o | t_max), (d | flag)
+  float4* hits; unsigned hit_stride; int hit_b2;  // closest hit: (t, prim, b0, b1), or (b2, prim, b0, b1) inside a frame (shade needs the three barycentrics, not t)
+  unsigned* occluded; unsigned occ_stride;        // any hit: 1 / 0
+  // any hit inside a frame: a shadow ray with d.w != 0 belongs to a vertex without MIS ray - its `direct_add` goes into lacc right here if unoccluded
+  float4* lacc; unsigned lacc_stride; const float4* direct_add; unsigned add_stride;
+};
+RT_DEV void trace_write_any(float4* __restrict__ lacc, size_t ls, const float4* __restrict__ direct_add, size_t as, unsigned* __restrict__ occluded, size_t os,
+                            unsigned pid, float dw, bool found) {
+  // Shadow rays of the frame loop carry d.w = 1 when the vertex has no MIS ray in flight: the light-sampling
+  // term of estimate_direct is then complete and `L += beta * (Ld / pick_pdf)` (precomputed by k_shade into
+  // direct_add) is applied right here if the ray is unoccluded. Otherwise the flag is left for k_resolve.
+  if (lacc != nullptr && dw != 0.0f) {
+    if (!found) { float4 a = direct_add[pid * as]; float4 l = lacc[pid * ls]; lacc[pid * ls] = make_float4(l.x + a.x, l.y + a.y, l.z + a.z, l.w); }
+  } else occluded[pid * os] = found ? 1u : 0u;
+}
+
 // BLOCK threads per workgroup, DEPTH = to-visit stack entries per lane (the host picks the
 // smallest of 16/32/64 that covers the tree height; the reference's fixed 64 is the maximum).
 template <bool ANY, bool COUNT, bool SMALL, int BLOCK, int DEPTH>
-__global__ void __launch_bounds__(BLOCK) k_trace(DScene sc, const float4* __restrict__ ray_o, const float4* __restrict__ ray_d,
-                                                 const unsigned* __restrict__ queue, const unsigned* __restrict__ shard_counts, unsigned shard_cap, unsigned count_static,
-                                                 float4* __restrict__ hits, unsigned* __restrict__ occluded, unsigned long long* stats,
-                                                 int st_rays, int st_nodes, int st_tris, float4* __restrict__ lacc, const float4* __restrict__ direct_add) {
+__global__ void __launch_bounds__(BLOCK) k_trace(DScene sc, TraceIO io, const unsigned* __restrict__ queue, const unsigned* __restrict__ shard_counts, unsigned shard_cap,
+                                                 unsigned count_static, unsigned long long* stats, int st_rays, int st_nodes, int st_tris) {
+  const float4* __restrict__ ray_o = io.ray_o; const float4* __restrict__ ray_d = io.ray_d; const size_t rs = io.ray_stride;
+  float4* __restrict__ hits = io.hits; const size_t hs = io.hit_stride; const bool hit_b2 = io.hit_b2 != 0;
+  unsigned* __restrict__ occluded = io.occluded; const size_t os = io.occ_stride;
+  float4* __restrict__ lacc = io.lacc; const size_t ls = io.lacc_stride; const float4* __restrict__ direct_add = io.direct_add; const size_t as = io.add_stride;
   // node indices of a tiny scene fit 16 bits: half the stack bytes => more resident waves per CU
   typedef typename std::conditional<SMALL && !ANY, unsigned short, int>::type StackT;
   __shared__ StackT stack[DEPTH * BLOCK];
@@ -505,21 +534,15 @@ __global__ void __launch_bounds__(BLOCK) k_trace(DScene sc, const float4* __rest
   unsigned n_nodes = 0, n_tris = 0, n_rays = 0;
   for (unsigned i = blockIdx.x * BLOCK + threadIdx.x; i < count; i += stride) {
     const unsigned pid = queue ? qv.get(i) : i;
-    float4 o4 = ray_o[pid], d4 = ray_d[pid];
+    float4 o4 = ray_o[pid * rs], d4 = ray_d[pid * rs];
     Ray ray; ray.o = mk3(o4.x, o4.y, o4.z); ray.d = mk3(d4.x, d4.y, d4.z); ray.t_max = o4.w;
     int prim = -1; TriHit h; h.t = kInf; h.b0 = h.b1 = h.b2 = 0.0f;
     bool found;
     if (SMALL) { LdsSrc src{s_nodes, s_tris}; found = traverse<ANY, COUNT, LdsSrc, StackT>(src, ray, stack + threadIdx.x, BLOCK, prim, h, n_nodes, n_tris); }
     else { GlobalSrc src{sc.nodes, sc.tri_p}; found = traverse<ANY, COUNT, GlobalSrc, StackT>(src, ray, stack + threadIdx.x, BLOCK, prim, h, n_nodes, n_tris); }
     n_rays += 1;
-    if (ANY) {
-      // Shadow rays of the frame loop carry d.w = 1 when the vertex has no MIS ray in flight: the light-sampling
-      // term of estimate_direct is then complete and `L += beta * (Ld / pick_pdf)` (precomputed by k_shade into
-      // direct_add) is applied right here if the ray is unoccluded. Otherwise the flag is left for k_resolve.
-      if (lacc != nullptr && d4.w != 0.0f) {
-        if (!found) { float4 a = direct_add[pid]; float4 l = lacc[pid]; lacc[pid] = make_float4(l.x + a.x, l.y + a.y, l.z + a.z, l.w); }
-      } else occluded[pid] = found ? 1u : 0u;
-    } else hits[pid] = make_float4(lacc != nullptr ? h.b2 : (found ? h.t : kInf), __int_as_float(found ? prim : -1), h.b0, h.b1);
+    if (ANY) trace_write_any(lacc, ls, direct_add, as, occluded, os, pid, d4.w, found);
+    else hits[pid * hs] = make_float4(hit_b2 ? h.b2 : (found ? h.t : kInf), __int_as_float(found ? prim : -1), h.b0, h.b1);
   }
   if (stats) {
     // one atomic per wave and counter
@@ -543,10 +566,12 @@ __global__ void __launch_bounds__(BLOCK) k_trace(DScene sc, const float4* __rest
 #define RT_REFILL_MIN 16
 #endif
 template <bool ANY, bool COUNT, int BLOCK, int DEPTH>
-__global__ void __launch_bounds__(BLOCK) k_trace_big(DScene sc, const float4* __restrict__ ray_o, const float4* __restrict__ ray_d,
-                                                     const unsigned* __restrict__ queue, const unsigned* __restrict__ shard_counts, unsigned shard_cap, unsigned count_static,
-                                                     float4* __restrict__ hits, unsigned* __restrict__ occluded, unsigned long long* stats,
-                                                     int st_rays, int st_nodes, int st_tris, float4* __restrict__ lacc, const float4* __restrict__ direct_add) {
+__global__ void __launch_bounds__(BLOCK) k_trace_big(DScene sc, TraceIO io, const unsigned* __restrict__ queue, const unsigned* __restrict__ shard_counts, unsigned shard_cap,
+                                                     unsigned count_static, unsigned long long* stats, int st_rays, int st_nodes, int st_tris) {
+  const float4* __restrict__ ray_o = io.ray_o; const float4* __restrict__ ray_d = io.ray_d; const size_t rs = io.ray_stride;
+  float4* __restrict__ hits = io.hits; const size_t hs = io.hit_stride; const bool hit_b2 = io.hit_b2 != 0;
+  unsigned* __restrict__ occluded = io.occluded; const size_t os = io.occ_stride;
+  float4* __restrict__ lacc = io.lacc; const size_t ls = io.lacc_stride; const float4* __restrict__ direct_add = io.direct_add; const size_t as = io.add_stride;
   __shared__ int stack_mem[DEPTH * BLOCK];
   int* const stack = stack_mem + threadIdx.x;
   QView qv; if (queue) qv.init(queue, shard_counts, shard_cap);
@@ -566,11 +591,8 @@ __global__ void __launch_bounds__(BLOCK) k_trace_big(DScene sc, const float4* __
   int sp = 0, cur = 0, prim = -1; TriHit hit; hit.t = kInf; hit.b0 = hit.b1 = hit.b2 = 0.0f;
 
   auto finish = [&]() {  // the lane's ray is complete: write its result (same epilogue as k_trace)
-    if (ANY) {
-      if (lacc != nullptr && dw != 0.0f) {
-        if (!found) { float4 a = direct_add[pid]; float4 l = lacc[pid]; lacc[pid] = make_float4(l.x + a.x, l.y + a.y, l.z + a.z, l.w); }
-      } else occluded[pid] = found ? 1u : 0u;
-    } else hits[pid] = make_float4(lacc != nullptr ? hit.b2 : (found ? hit.t : kInf), __int_as_float(found ? prim : -1), hit.b0, hit.b1);
+    if (ANY) trace_write_any(lacc, ls, direct_add, as, occluded, os, pid, dw, found);
+    else hits[pid * hs] = make_float4(hit_b2 ? hit.b2 : (found ? hit.t : kInf), __int_as_float(found ? prim : -1), hit.b0, hit.b1);
     active = false;
   };
 
@@ -581,7 +603,7 @@ __global__ void __launch_bounds__(BLOCK) k_trace_big(DScene sc, const float4* __
       const unsigned long long e = ((unsigned long long)(v >> 6) * n_waves + wave) * 64ull + (v & 63u);
       if (!active && e < count) {
         pid = queue ? qv.get((unsigned)e) : (unsigned)e;
-        const float4 o4 = ray_o[pid], d4 = ray_d[pid];
+        const float4 o4 = ray_o[pid * rs], d4 = ray_d[pid * rs];
         ray.o = mk3(o4.x, o4.y, o4.z); ray.d = mk3(d4.x, d4.y, d4.z); ray.t_max = o4.w; dw = d4.w;
         inv_dir = mk3(1.0f / ray.d.x, 1.0f / ray.d.y, 1.0f / ray.d.z);
         neg_x = inv_dir.x < 0.0f; neg_y = inv_dir.y < 0.0f; neg_z = inv_dir.z < 0.0f;
@@ -685,14 +707,15 @@ struct PairLane {
   RT_DEV void set_rp(const RayPre& r) { kz = r.kz; sx = r.sx; sy = r.sy; sz = r.sz; }
   int sp, prim; unsigned cur; TriHit hit;
 };
-struct TraceOut { float4* hits; unsigned* occluded; float4* lacc; const float4* direct_add; };
+struct TraceOut { float4* hits; size_t hs; bool hit_b2; unsigned* occluded; size_t os; float4* lacc; size_t ls; const float4* direct_add; size_t as; };
+RT_DEV TraceOut trace_out_of(const TraceIO& io) {
+  TraceOut o; o.hits = io.hits; o.hs = io.hit_stride; o.hit_b2 = io.hit_b2 != 0; o.occluded = io.occluded; o.os = io.occ_stride;
+  o.lacc = io.lacc; o.ls = io.lacc_stride; o.direct_add = io.direct_add; o.as = io.add_stride; return o;
+}
 template <bool ANY>
 RT_DEV void pair_finish(PairLane& L, const TraceOut& o) {  // same epilogue as k_trace
-  if (ANY) {
-    if (o.lacc != nullptr && L.dw != 0.0f) {
-      if (!L.found) { float4 a = o.direct_add[L.pid]; float4 l = o.lacc[L.pid]; o.lacc[L.pid] = make_float4(l.x + a.x, l.y + a.y, l.z + a.z, l.w); }
-    } else o.occluded[L.pid] = L.found ? 1u : 0u;
-  } else o.hits[L.pid] = make_float4(o.lacc != nullptr ? L.hit.b2 : (L.found ? L.hit.t : kInf), __int_as_float(L.found ? L.prim : -1), L.hit.b0, L.hit.b1);
+  if (ANY) trace_write_any(o.lacc, o.ls, o.direct_add, o.as, o.occluded, o.os, L.pid, L.dw, L.found);
+  else o.hits[L.pid * o.hs] = make_float4(o.hit_b2 ? L.hit.b2 : (L.found ? L.hit.t : kInf), __int_as_float(L.found ? L.prim : -1), L.hit.b0, L.hit.b1);
   L.active = false;
 }
 // next pending entry that still passes tmin < t_max, or the ray is complete
@@ -741,10 +764,9 @@ RT_DEV void pair_leaf_step(PairLane& L, const TraceOut& o, const float4* __restr
 }
 
 template <bool ANY, bool WW, int BLOCK, int DEPTH>
-__global__ void __launch_bounds__(BLOCK) k_trace_pair(DScene sc, const float4* __restrict__ ray_o, const float4* __restrict__ ray_d,
-                                                      const unsigned* __restrict__ queue, const unsigned* __restrict__ shard_counts, unsigned shard_cap, unsigned count_static,
-                                                      float4* __restrict__ hits, unsigned* __restrict__ occluded, unsigned long long* stats, int st_rays,
-                                                      float4* __restrict__ lacc, const float4* __restrict__ direct_add, float* __restrict__ tmin_stack_mem, unsigned refill_min) {
+__global__ void __launch_bounds__(BLOCK) k_trace_pair(DScene sc, TraceIO io, const unsigned* __restrict__ queue, const unsigned* __restrict__ shard_counts, unsigned shard_cap,
+                                                      unsigned count_static, unsigned long long* stats, int st_rays, float* __restrict__ tmin_stack_mem, unsigned refill_min) {
+  const float4* __restrict__ ray_o = io.ray_o; const float4* __restrict__ ray_d = io.ray_d; const size_t rs = io.ray_stride;
   __shared__ unsigned stack_mem[DEPTH * BLOCK];
   unsigned* const stack = stack_mem + threadIdx.x;
   // the deferred tmin of each stack entry lives in HBM, [depth][lane of the grid]: a push is a fire-and-forget
@@ -756,7 +778,7 @@ __global__ void __launch_bounds__(BLOCK) k_trace_pair(DScene sc, const float4* _
   const unsigned lane = __lane_id();
   const unsigned n_waves = gridDim.x * (BLOCK / 64), wave = blockIdx.x * (BLOCK / 64) + (threadIdx.x >> 6);
   const float4* __restrict__ pairs = sc.pairs; const float4* __restrict__ tri_p = sc.tri_p; const float4* __restrict__ nodes = sc.nodes;
-  const TraceOut out{hits, occluded, lacc, direct_add};
+  const TraceOut out = trace_out_of(io);
   unsigned n_rays = 0;
   unsigned cursor = 0;
   bool exhausted = (unsigned long long)wave * 64ull >= count;
@@ -772,7 +794,7 @@ __global__ void __launch_bounds__(BLOCK) k_trace_pair(DScene sc, const float4* _
       const unsigned long long e = ((unsigned long long)(v >> 6) * n_waves + wave) * 64ull + (v & 63u);
       if (!L.active && e < count) {
         L.pid = queue ? qv.get((unsigned)e) : (unsigned)e;
-        const float4 o4 = ray_o[L.pid], d4 = ray_d[L.pid];
+        const float4 o4 = ray_o[L.pid * rs], d4 = ray_d[L.pid * rs];
         L.ray.o = mk3(o4.x, o4.y, o4.z); L.ray.d = mk3(d4.x, d4.y, d4.z); L.ray.t_max = o4.w; L.dw = d4.w;
         L.inv_dir = mk3(1.0f / L.ray.d.x, 1.0f / L.ray.d.y, 1.0f / L.ray.d.z);
         L.set_rp(ray_pre(L.ray));
@@ -879,10 +901,9 @@ RT_DEV void quad_interior_step(PairLane& L, const TraceOut& o, const float4* __r
 }
 
 template <bool ANY, int BLOCK, int DEPTH>
-__global__ void __launch_bounds__(BLOCK) k_trace_quad(DScene sc, const float4* __restrict__ ray_o, const float4* __restrict__ ray_d,
-                                                      const unsigned* __restrict__ queue, const unsigned* __restrict__ shard_counts, unsigned shard_cap, unsigned count_static,
-                                                      float4* __restrict__ hits, unsigned* __restrict__ occluded, unsigned long long* stats, int st_rays,
-                                                      float4* __restrict__ lacc, const float4* __restrict__ direct_add, float* __restrict__ tmin_stack_mem, unsigned refill_min) {
+__global__ void __launch_bounds__(BLOCK) k_trace_quad(DScene sc, TraceIO io, const unsigned* __restrict__ queue, const unsigned* __restrict__ shard_counts, unsigned shard_cap,
+                                                      unsigned count_static, unsigned long long* stats, int st_rays, float* __restrict__ tmin_stack_mem, unsigned refill_min) {
+  const float4* __restrict__ ray_o = io.ray_o; const float4* __restrict__ ray_d = io.ray_d; const size_t rs = io.ray_stride;
   __shared__ unsigned stack_mem[DEPTH * BLOCK];
   unsigned* const stack = stack_mem + threadIdx.x;
   const size_t grid_lanes = (size_t)gridDim.x * BLOCK;
@@ -892,7 +913,7 @@ __global__ void __launch_bounds__(BLOCK) k_trace_quad(DScene sc, const float4* _
   const unsigned lane = __lane_id();
   const unsigned n_waves = gridDim.x * (BLOCK / 64), wave = blockIdx.x * (BLOCK / 64) + (threadIdx.x >> 6);
   const float4* __restrict__ quads = sc.quads; const float4* __restrict__ tri_p = sc.tri_p; const float4* __restrict__ nodes = sc.nodes;
-  const TraceOut out{hits, occluded, lacc, direct_add};
+  const TraceOut out = trace_out_of(io);
   unsigned n_rays = 0;
   unsigned cursor = 0;
   bool exhausted = (unsigned long long)wave * 64ull >= count;
@@ -907,7 +928,7 @@ __global__ void __launch_bounds__(BLOCK) k_trace_quad(DScene sc, const float4* _
       const unsigned long long e = ((unsigned long long)(v >> 6) * n_waves + wave) * 64ull + (v & 63u);
       if (!L.active && e < count) {
         L.pid = queue ? qv.get((unsigned)e) : (unsigned)e;
-        const float4 o4 = ray_o[L.pid], d4 = ray_d[L.pid];
+        const float4 o4 = ray_o[L.pid * rs], d4 = ray_d[L.pid * rs];
         L.ray.o = mk3(o4.x, o4.y, o4.z); L.ray.d = mk3(d4.x, d4.y, d4.z); L.ray.t_max = o4.w; L.dw = d4.w;
         L.inv_dir = mk3(1.0f / L.ray.d.x, 1.0f / L.ray.d.y, 1.0f / L.ray.d.z);
         L.set_rp(ray_pre(L.ray));
@@ -942,8 +963,8 @@ __global__ void __launch_bounds__(BLOCK) k_trace_quad(DScene sc, const float4* _
 // class; misses last), so that most waves run one code path. Order within a bin is arbitrary: paths are
 // independent and the film sums each pixel's samples in sample order. hist/cursor: RT_BIN_MAX + 1 zeroed words each.
 #define RT_BIN_MAX 256
-RT_DEV unsigned bin_of(const DMaterial* __restrict__ materials, const float4* __restrict__ tri_p, const float4* __restrict__ hit, unsigned pid, unsigned n_bins) {
-  const int prim = __float_as_int(hit[pid].y);
+RT_DEV unsigned bin_of(const DMaterial* __restrict__ materials, const float4* __restrict__ tri_p, const PathRec* __restrict__ path, unsigned pid, unsigned n_bins) {
+  const int prim = __float_as_int(path[pid].hit.y);
   if (prim < 0) return n_bins - 1u;
   const unsigned m = (unsigned)materials[tri_material(tri_p, prim)].code_class;
   return m < n_bins - 1u ? m : n_bins - 2u;
@@ -956,7 +977,7 @@ __global__ void __launch_bounds__(256) k_bin_count(DScene sc, PassState ps, unsi
   const unsigned count = ps.q_in ? qv.total() : ps.cap;
   for (unsigned i = blockIdx.x * 256u + threadIdx.x; i < count; i += gridDim.x * 256u) {
     const unsigned pid = ps.q_in ? qv.get(i) : i;
-    atomicAdd(&lh[bin_of(sc.materials, sc.tri_p, ps.hit, pid, n_bins)], 1u);
+    atomicAdd(&lh[bin_of(sc.materials, sc.tri_p, ps.path, pid, n_bins)], 1u);
   }
   __syncthreads();
   for (unsigned i = threadIdx.x; i < n_bins; i += 256u) if (lh[i]) atomicAdd(&hist[i], lh[i]);
@@ -988,7 +1009,7 @@ __global__ void __launch_bounds__(256) k_bin_scatter(DScene sc, PassState ps, un
     for (unsigned k = 0; k < E; ++k) {  // rounds of 256 consecutive entries: a bin keeps the queue's order up to that granularity
       const unsigned i = start + k * 256u + threadIdx.x;
       live[k] = i < count; pid[k] = 0; bin[k] = 0; rank[k] = 0;
-      if (live[k]) { pid[k] = ps.q_in ? qv.get(i) : i; bin[k] = bin_of(sc.materials, sc.tri_p, ps.hit, pid[k], n_bins); }
+      if (live[k]) { pid[k] = ps.q_in ? qv.get(i) : i; bin[k] = bin_of(sc.materials, sc.tri_p, ps.path, pid[k], n_bins); }
     }
 #pragma unroll
     for (unsigned k = 0; k < E; ++k) if (live[k]) rank[k] = atomicAdd(&lcount[bin[k]], 1u);
@@ -1212,12 +1233,13 @@ __global__ void __launch_bounds__(256, MODE == 1 ? RT_SHADE_MIN_WAVES : RT_SHADE
   for (unsigned base = first + blockIdx.x * blockDim.x; base < count; base += stride) {
     const unsigned i = base + threadIdx.x;
     const bool lane_live = i < count;
-    bool cont = false, want_shadow = false, want_mis = false;
+    bool cont = false, want_shadow = false, want_mis = false, mis_occlusion_only = false;
     unsigned pid = 0;
     if (lane_live) {
       pid = ps.q_in ? qv.get(i) : i;
       const unsigned sl = pid / ps.n_pixels, pix = pid - sl * ps.n_pixels, s = ps.s0 + sl;
-      float4 d4 = ps.ray_d[pid], h4 = ps.hit[pid], b4 = ps.beta[pid], l4 = ps.lacc[pid];
+      PathRec* const prec = ps.path + pid; PathAcc* const pacc = ps.acc + pid;
+      float4 d4 = prec->d, h4 = prec->hit, b4 = prec->beta, l4 = pacc->lacc;
       f3 ray_d = mk3(d4.x, d4.y, d4.z);
       rgb3 beta = mkc(b4.x, b4.y, b4.z), L = mkc(l4.x, l4.y, l4.z);
       float eta_scale = b4.w;
@@ -1225,7 +1247,7 @@ __global__ void __launch_bounds__(256, MODE == 1 ? RT_SHADE_MIN_WAVES : RT_SHADE
       int bounces = (int)(st & 0xffu); bool specular_bounce = (st >> 8) & 1u;
       PathSampler smp; smp.tb = tables_of(ps); smp.pix = pix; smp.s = s; smp.c1 = (int)((st >> 9) & 15u); smp.c2 = (int)((st >> 13) & 15u);
       int x, y; unsigned long long pixel_index; owned_pixel(fp, fp.chunk_first + pix, x, y, pixel_index);
-      smp.rng.state = ps.rng[pid];
+      smp.rng.state = pacc->rng;
       smp.rng.inc = ((pixel_index * (unsigned long long)ps.spp + s + (1ull << 32)) << 1u) | 1ull;
       const int prim = __float_as_int(h4.y);
       const bool found = prim >= 0;
@@ -1246,7 +1268,7 @@ __global__ void __launch_bounds__(256, MODE == 1 ? RT_SHADE_MIN_WAVES : RT_SHADE
       }
       if (found && bounces < fp.max_depth) {  // path.rs:139
         if (MODE != 1 && bounces == 0 && sc.needs_differentials) {  // only the camera ray carries differentials (interaction.rs:245-314)
-          f2 pf; { float2 t = ps.pfilm[pid]; pf = mk2(t.x, t.y); }
+          f2 pf; { float2 t = pacc->pfilm; pf = mk2(t.x, t.y); }
           f2 pl = table_2d(smp.tb, pix, 1, s);
           CameraRay cr = generate_camera_ray(fp, pf, pl, 1.0f / sqrtf((float)ps.spp));
           compute_differential(si, cr.rx_o, cr.ry_o, cr.rx_d, cr.ry_d);
@@ -1279,7 +1301,7 @@ __global__ void __launch_bounds__(256, MODE == 1 ? RT_SHADE_MIN_WAVES : RT_SHADE
               float scattering_pdf = bsdf.pdf(si.hit.wo, ls.wi, nonspec);
               if (!is_black(f)) {
                 Ray sr = spawn_ray_to_interaction(si.hit, ls.p1);  // VisibilityTester, light/mod.rs:52-55
-                ps.sh_o[pid] = make_float4(sr.o.x, sr.o.y, sr.o.z, sr.t_max);
+                ps.sh[pid].o = make_float4(sr.o.x, sr.o.y, sr.o.z, sr.t_max);
                 sh_dir = sr.d;
                 want_shadow = true;
                 if (light_is_delta(light)) ld1 = f * ls.li / ls.pdf;
@@ -1300,22 +1322,26 @@ __global__ void __launch_bounds__(256, MODE == 1 ? RT_SHADE_MIN_WAVES : RT_SHADE
                 }
                 if (go) {
                   Ray mr = spawn_ray(si.hit, bs.wi);
-                  ps.mi_o[pid] = make_float4(mr.o.x, mr.o.y, mr.o.z, kInf);
-                  ps.mi_d[pid] = make_float4(mr.d.x, mr.d.y, mr.d.z, 0.0f);
+                  ps.mi[pid].o = make_float4(mr.o.x, mr.o.y, mr.o.z, kInf);
+                  ps.mi[pid].d = make_float4(mr.d.x, mr.d.y, mr.d.z, 0.0f);
                   want_mis = true; f2v = f; w2 = weight; spdf2 = bs.pdf;
+                  // An infinite light is never the emitter a ray hits (integrator/mod.rs:291-309): the term is `Le(ray)` if the ray leaves the
+                  // scene and nothing otherwise, so occlusion is all this ray has to report.
+                  mis_occlusion_only = MODE != 1 && ps.mis_any && light.kind == 3;
                 }
               }
             }
-            if (want_mis) {  // rare: both halves are combined by k_resolve once both rays are back
-              ps.pend_a[pid] = make_float4(ld1.r, ld1.g, ld1.b, light_pdf);
-              ps.pend_b[pid] = make_float4(f2v.r, f2v.g, f2v.b, w2);
-              ps.pend_c[pid] = make_float4(beta.r, beta.g, beta.b, spdf2);
-              ps.pend_flags[pid] = (want_shadow ? 1u : 0u) | 2u | ((unsigned)light_num << 2);
-            } else if (want_shadow) {  // common: L += beta * ((0 + Ld1) / pick_pdf) if unoccluded, applied by the any-hit kernel
+            if (want_mis) {  // both halves are combined by k_resolve once both rays are back
+              MisRec* const m = ps.mi + pid;
+              m->a = make_float4(ld1.r, ld1.g, ld1.b, light_pdf);
+              m->b = make_float4(f2v.r, f2v.g, f2v.b, w2);
+              m->c = make_float4(beta.r, beta.g, beta.b, spdf2);
+              m->flags = (want_shadow ? RT_PEND_SHADOW : 0u) | 2u | ((unsigned)light_num << 2) | (mis_occlusion_only ? RT_PEND_MIS_ANY : 0u);
+            } else if (want_shadow) {  // L += beta * ((0 + Ld1) / pick_pdf) if unoccluded, applied by the any-hit kernel
               rgb3 add = beta * ((mkc(0, 0, 0) + ld1) / light_pdf);
-              ps.pend_a[pid] = make_float4(add.r, add.g, add.b, 0.0f);
+              ps.sh[pid].add = make_float4(add.r, add.g, add.b, 0.0f);
             }
-            if (want_shadow) ps.sh_d[pid] = make_float4(sh_dir.x, sh_dir.y, sh_dir.z, want_mis ? 0.0f : 1.0f);
+            if (want_shadow) ps.sh[pid].d = make_float4(sh_dir.x, sh_dir.y, sh_dir.z, want_mis ? 0.0f : 1.0f);
           }
         }
         // ---- sample the BSDF for the next direction (path.rs:172-196)
@@ -1338,20 +1364,22 @@ __global__ void __launch_bounds__(256, MODE == 1 ? RT_SHADE_MIN_WAVES : RT_SHADE
           }
           if (cont) {
             bounces += 1;
-            ps.ray_o[pid] = make_float4(nr.o.x, nr.o.y, nr.o.z, kInf);
-            ps.ray_d[pid] = make_float4(nr.d.x, nr.d.y, nr.d.z, 0.0f);
+            prec->o = make_float4(nr.o.x, nr.o.y, nr.o.z, kInf);
+            prec->d = make_float4(nr.d.x, nr.d.y, nr.d.z, 0.0f);
           }
         }
       }
-      ps.beta[pid] = make_float4(beta.r, beta.g, beta.b, eta_scale);
-      ps.lacc[pid] = make_float4(L.r, L.g, L.b, __uint_as_float(pack_state(bounces, specular_bounce, smp.c1, smp.c2)));
-      ps.rng[pid] = smp.rng.state;
+      prec->beta = make_float4(beta.r, beta.g, beta.b, eta_scale);
+      pacc->lacc = make_float4(L.r, L.g, L.b, __uint_as_float(pack_state(bounces, specular_bounce, smp.c1, smp.c2)));
+      pacc->rng = smp.rng.state;
     }
-    const int ci[3] = {0, 1, 2}; const bool pr[3] = {cont, want_shadow, want_mis}; unsigned slot[3];
-    block_push<3>(ps.cnt_out, ps.shard_cap, ci, pr, slot);
+    constexpr int NQ = MODE == 1 ? 3 : 4;  // area lights only: every MIS ray needs its closest hit
+    const int ci[4] = {0, 1, 2, 3}; const bool pr[4] = {cont, want_shadow, want_mis && !mis_occlusion_only, want_mis && mis_occlusion_only}; unsigned slot[4];
+    block_push<NQ>(ps.cnt_out, ps.shard_cap, ci, pr, slot);
     if (cont) ps.q_out[slot[0]] = pid;
     if (want_shadow) ps.q_shadow[slot[1]] = pid;
-    if (want_mis) ps.q_mis[slot[2]] = pid;
+    if (pr[2]) ps.q_mis[slot[2]] = pid;
+    if (NQ == 4 && pr[3]) ps.q_misany[slot[3]] = pid;
   }
 }
 
@@ -1363,59 +1391,62 @@ __global__ void __launch_bounds__(256) k_shade_miss(DScene sc, PassState ps) {
   const unsigned stride = gridDim.x * blockDim.x;
   for (unsigned i = first + blockIdx.x * blockDim.x + threadIdx.x; i < count; i += stride) {
     const unsigned pid = ps.q_in[i];
-    const float4 l4 = ps.lacc[pid];
+    const float4 l4 = ps.acc[pid].lacc;
     const unsigned st = __float_as_uint(l4.w);
     const int bounces = (int)(st & 0xffu); const bool specular_bounce = (st >> 8) & 1u;
     if (!(bounces == 0 || specular_bounce) || sc.n_infinite == 0) continue;
-    const float4 d4 = ps.ray_d[pid], b4 = ps.beta[pid];
+    const float4 d4 = ps.path[pid].d, b4 = ps.path[pid].beta;
     const f3 ray_d = mk3(d4.x, d4.y, d4.z);
     const rgb3 beta = mkc(b4.x, b4.y, b4.z);
     rgb3 L = mkc(l4.x, l4.y, l4.z);
     for (int k = 0; k < sc.n_infinite; ++k) L = L + beta * infinite_le(sc, sc.lights[sc.infinite_ids[k]], ray_d);
-    ps.lacc[pid] = make_float4(L.r, L.g, L.b, l4.w);
+    ps.acc[pid].lacc = make_float4(L.r, L.g, L.b, l4.w);
   }
 }
 
 // ================================================================================ K5 resolve
-// estimate_direct for the (rare) vertices whose BSDF-sampled MIS ray was traced: ld = [unoccluded] Ld1 +
+// estimate_direct for the vertices whose BSDF-sampled MIS ray was traced: ld = [unoccluded] Ld1 +
 // [the MIS ray reached the sampled light] f*Le*w/pdf; L += beta_at_vertex * (ld / light_pick_pdf).
-// ps.resolve_scan: the MIS queue was filled in the binned shade order, i.e. scattered over the path ids; the vertices are then found
-// by scanning pend_flags in path-id order (flag bit 1 = an MIS ray is out, cleared here), which keeps every access below coalesced.
+// Everything about the vertex sits in its 128-byte MisRec, so the entries are gathered through the two MIS queues (closest-hit rays, then
+// occlusion-only rays) at one line per vertex whatever order the shade kernel filled them in.
 __global__ void __launch_bounds__(256) k_resolve(DScene sc, PassState ps) {
   QView qv; qv.init(ps.q_mis, ps.cnt_out + 2 * RT_QSHARDS, ps.shard_cap);
-  const bool scan = ps.resolve_scan && (unsigned long long)qv.total() * 16ull >= ps.cap;  // a sparse queue is cheaper to gather than the flags are to scan
-  const unsigned count = scan ? ps.cap : qv.total();
+  QView qa; qa.init(ps.q_misany, ps.cnt_out + 3 * RT_QSHARDS, ps.shard_cap);
+  const unsigned n_closest = qv.total(), count = n_closest + qa.total();
   const unsigned stride = gridDim.x * blockDim.x;
   for (unsigned i = blockIdx.x * blockDim.x + threadIdx.x; i < count; i += stride) {
-    unsigned pid, pend;
-    if (scan) { pid = i; pend = ps.pend_flags[i]; if (!(pend & 2u)) continue; }
-    else { pid = qv.get(i); pend = ps.pend_flags[pid]; }
-    if (ps.resolve_scan) ps.pend_flags[pid] = 0u;
-    float4 a = ps.pend_a[pid], c = ps.pend_c[pid];
+    const unsigned pid = i < n_closest ? qv.get(i) : qa.get(i - n_closest);
+    const MisRec* const m = ps.mi + pid;
+    const unsigned pend = m->flags;
+    float4 a = m->a, c = m->c;
     rgb3 ld = mkc(0, 0, 0);
-    if ((pend & 1u) && ps.sh_occ[pid] == 0u) ld = ld + mkc(a.x, a.y, a.z);
+    if ((pend & RT_PEND_SHADOW) && m->occ == 0u) ld = ld + mkc(a.x, a.y, a.z);
     {
-      float4 b = ps.pend_b[pid], h4 = ps.mi_hit[pid], d4 = ps.mi_d[pid];
+      float4 b = m->b, h4 = m->hit, d4 = m->d;
       const int light_num = (int)((pend >> 2) & 0x0fffffffu);
       const DLight& light = sc.lights[light_num];
       f3 wi = mk3(d4.x, d4.y, d4.z);
       rgb3 li = mkc(0, 0, 0);
-      const int prim = __float_as_int(h4.y);
-      if (prim >= 0) {  // integrator/mod.rs:293-307: emitted radiance only if the hit emitter IS the sampled light
-        if (tri_light(sc.tri_p, prim) == light_num) {
-          float4 o4 = ps.mi_o[pid];
-          f3 p0, p1, p2; load_tri(sc.tri_p, prim, p0, p1, p2);
-          Ray r; r.o = mk3(o4.x, o4.y, o4.z); r.d = wi; r.t_max = kInf;
-          TriHit th; (void)tri_test_call(p0, p1, p2, r, th);
-          f3 p, n; tri_hit_point_normal(sc, prim, th, p, n);
-          li = area_light_l(light, n, -wi);
-        }
-      } else if (light.kind == 3) li = infinite_le(sc, light, wi);  // light.le(ray)
+      if (pend & RT_PEND_MIS_ANY) {  // infinite light, occlusion only: hit.y = 1 / 0 (integrator/mod.rs:291-309: a hit surface is never this light)
+        if (__float_as_uint(h4.y) == 0u) li = infinite_le(sc, light, wi);
+      } else {
+        const int prim = __float_as_int(h4.y);
+        if (prim >= 0) {  // integrator/mod.rs:293-307: emitted radiance only if the hit emitter IS the sampled light
+          if (tri_light(sc.tri_p, prim) == light_num) {
+            float4 o4 = m->o;
+            f3 p0, p1, p2; load_tri(sc.tri_p, prim, p0, p1, p2);
+            Ray r; r.o = mk3(o4.x, o4.y, o4.z); r.d = wi; r.t_max = kInf;
+            TriHit th; (void)tri_test_call(p0, p1, p2, r, th);
+            f3 p, n; tri_hit_point_normal(sc, prim, th, p, n);
+            li = area_light_l(light, n, -wi);
+          }
+        } else if (light.kind == 3) li = infinite_le(sc, light, wi);  // light.le(ray)
+      }
       if (!is_black(li)) ld = ld + mkc(b.x, b.y, b.z) * li * b.w / c.w;
     }
-    float4 l4 = ps.lacc[pid];
+    float4 l4 = ps.acc[pid].lacc;
     rgb3 add = mkc(c.x, c.y, c.z) * (ld / a.w);
-    ps.lacc[pid] = make_float4(l4.x + add.r, l4.y + add.g, l4.z + add.b, l4.w);
+    ps.acc[pid].lacc = make_float4(l4.x + add.r, l4.y + add.g, l4.z + add.b, l4.w);
   }
 }
 
@@ -1439,8 +1470,9 @@ __global__ void __launch_bounds__(256) k_film_accumulate(FrameParams fp, PassSta
     unsigned scrubbed = 0;
     for (unsigned sl = 0; sl < ps.n_samples; ++sl) {
       const unsigned pid = sl * ps.n_pixels + pix;
-      if (ps.pend_flags[pid] & 0x80000000u) continue;
-      float4 l4 = ps.lacc[pid];
+      const PathAcc* const pa = ps.acc + pid;
+      float4 l4 = pa->lacc;
+      if (__float_as_uint(l4.w) & RT_STATE_OUT_OF_BOUNDS) continue;
       rgb3 c = mkc(l4.x, l4.y, l4.z);
       bool bad = false;  // renderer.rs:115-126
       if (has_nan(c)) { c = mkc(0, 0, 0); bad = true; }
@@ -1448,7 +1480,7 @@ __global__ void __launch_bounds__(256) k_film_accumulate(FrameParams fp, PassSta
       if (isinf(lum_y(c))) { c = mkc(0, 0, 0); bad = true; }
       scrubbed += bad;
       rgb3 Lc = lum_y(c) > fp.max_sample_luminance ? c * fp.max_sample_luminance / lum_y(c) : c;
-      float2 pf = ps.pfilm[pid];
+      float2 pf = pa->pfilm;
       float dx = pf.x - 0.5f, dy = pf.y - 0.5f;
       float p0x = ceilf(dx - fp.radius_x), p0y = ceilf(dy - fp.radius_y);
       float p1x = floorf(dx + fp.radius_x + 1.0f), p1y = floorf(dy + fp.radius_y + 1.0f);

@@ -457,7 +457,7 @@ struct PbrtLoader {
     const std::string ls = integrator_p.one_string("lightsamplestrategy", "spatial");
     if (ls == "spatial") o.light_strategy = 0; else if (ls == "uniform") o.light_strategy = 1; else return fail_("lightsamplestrategy \"" + ls + "\" is not supported");
     if (const std::vector<float>* pb = integrator_p.floats("pixelbounds", {"integer"})) {
-      if (pb->size() == 4) for (int k = 0; k < 4; ++k) o.pixel_bounds[k] = (int32_t)(*pb)[k];
+      if (pb->size() == 4) { for (int k = 0; k < 4; ++k) o.pixel_bounds[k] = (int32_t)(*pb)[k]; o.has_pixel_bounds = 1; }
       else warn("pixelbounds expects 4 values");
     }
     if (accel_name == "kdtree") return fail_("Accelerator \"kdtree\" is not implemented (nor in the reference, api.rs:262-263)");

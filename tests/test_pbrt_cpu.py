@@ -242,7 +242,7 @@ def test_defaults_of_every_create():
     assert q.fov == 90.0 and q.lens_radius == 0.0 and q.focal_distance == F32(1e6)                # camera.rs:84-108
     assert (q.spp, q.sampler_dims) == (16, 4)                                                     # zerotwosequence.rs:58-63
     assert (q.max_depth, q.rr_threshold, q.light_strategy) == (5, 1.0, 0)                         # path.rs:49-53
-    assert list(q.pixel_bounds) == [0, 0, 0, 0]
+    assert list(q.pixel_bounds) == [0, 0, 0, 0] and q.has_pixel_bounds == 0
     assert np.array_equal(np.array(q.cam_to_world), np.eye(4, dtype=F32).reshape(-1))
     assert p.max_prims_per_node == 4 and p.film_filename == "image.png"                           # bvh/mod.rs:76, film.rs:118-123
     m = p.table("materials")
