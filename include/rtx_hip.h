@@ -166,6 +166,11 @@ typedef struct rt_stats {
   double ms_sampler, ms_raygen, ms_trace_closest, ms_trace_any, ms_trace_mis, ms_shade, ms_resolve, ms_film, ms_lightdist; /* HIP-event times */
   uint64_t launches_trace_closest;               /* number of trace_closest launches (path + MIS) */
   uint64_t n_passes;
+  /* path vertices by the shade front-end that served them: constant-Kd matte under area lights, Lambert under any light,
+   * two-lobe materials (matte with sigma, plastic, metal, mirror), everything else */
+  uint64_t vertices_lambert_const, vertices_lambert, vertices_two_lobe, vertices_generic;
+  /* ms_shade split (RT_FLAG_TIME_KERNELS): the shade launches of each front-end, the queue binning, the miss bin */
+  double ms_shade_lambert_const, ms_shade_lambert, ms_shade_two_lobe, ms_shade_generic, ms_shade_bin, ms_shade_miss;
 } rt_stats;
 
 #define RT_FLAG_COUNT_TRAVERSAL 1u /* fill nodes_ and tris_ counters (slower)                  */

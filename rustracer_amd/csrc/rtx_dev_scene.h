@@ -35,7 +35,15 @@ struct DScene {
   // light distribution (rc/lightdistrib.rs): dense voxel table or a single uniform distribution
   int ld_uniform; int nvox[3];
   const float* ld_func; const float* ld_cdf; const float* ld_int;  // [voxel][n_lights], [voxel][n_lights+1], [voxel]
+#ifdef RT_ABLATE
+  int dbg;  // measurement builds only (make ABLATE=1): bits switch parts of the shade kernel off to see what they cost; images are wrong
+#endif
 };
+#ifdef RT_ABLATE
+#define RT_DBG(sc, bit) (((sc).dbg & (bit)) != 0)
+#else
+#define RT_DBG(sc, bit) false
+#endif
 
 struct Ray { f3 o, d; float t_max; };
 struct TriHit { float t, b0, b1, b2; };

@@ -552,8 +552,10 @@ RT_DEVN LiSample light_sample_li(const DScene& sc, const DLight& l, const Intera
     }
     default: {  // InfiniteAreaLight::sample_li infinite.rs:143-181
       float d1, pdf1, d0, pdf0; int v, dummy;
+      if (RT_DBG(sc, 2)) { d1 = u.y; d0 = u.x; pdf0 = pdf1 = 1.0f; } else {
       d1_sample_continuous(l.mfunc, l.mcdf, l.mfunc_int, l.nv, u.y, d1, pdf1, v);  // Distribution2D::sample_continuous
       d1_sample_continuous(l.func + (size_t)v * l.nu, l.cdf + (size_t)v * (l.nu + 1), l.func_int[v], l.nu, u.x, d0, pdf0, dummy);
+      }
       float map_pdf = pdf0 * pdf1;
       s.p1.p_error = mk3(0, 0, 0); s.p1.wo = mk3(0, 0, 0); s.p1.n = mk3(0, 0, 0);
       if (map_pdf == 0.0f) { s.li = mkc(0, 0, 0); s.wi = mk3(0, 0, 0); s.pdf = 0.0f; s.p1.p = mk3(0, 0, 0); return s; }
@@ -562,7 +564,7 @@ RT_DEVN LiSample light_sample_li(const DScene& sc, const DLight& l, const Intera
       f3 wi = xf3x4(l.l2w, mk3(sin_theta_ * cos_phi_, sin_theta_ * sin_phi_, cos_theta_));
       s.pdf = sin_theta_ == 0.0f ? 0.0f : map_pdf / (2.0f * kPi * kPi * sin_theta_);
       s.p1.p = ref.p + wi * (2.0f * l.world_radius);
-      s.li = mip_lookup(sc.images[l.image], mk2(d0, d1), 0.0f); s.wi = wi;
+      s.li = RT_DBG(sc, 4) ? mkc(1, 1, 1) : mip_lookup(sc.images[l.image], mk2(d0, d1), 0.0f); s.wi = wi;
       return s;
     }
   }

@@ -318,6 +318,9 @@ extern "C" int rt_scene_create(const rt_scene_desc* desc, int device, rt_scene**
   d.wb_max = f3{desc->nodes[0].bmax[0], desc->nodes[0].bmax[1], desc->nodes[0].bmax[2]};
   d.ld_uniform = 1; d.nvox[0] = d.nvox[1] = d.nvox[2] = 1;
   d.needs_differentials = 0;
+#ifdef RT_ABLATE
+  d.dbg = getenv("RTX_DBG") ? atoi(getenv("RTX_DBG")) : 0;
+#endif
   for (uint32_t i = 0; i < desc->n_textures; ++i) {
     const rt_texture& t = desc->textures[i];
     if (t.kind == RT_TEX_IMAGE || t.kind == RT_TEX_FBM || (t.kind == RT_TEX_CHECKER && t.amount != 0)) d.needs_differentials = 1;
@@ -949,25 +952,25 @@ extern "C" int rt_render(rt_scene* s, const rt_camera* cam, const rt_film_desc* 
         tm.begin(&stats.ms_trace_closest);
         launch_trace<false>(s, count, io_path, ps.q_in, ps.cnt_in, ps.shard_cap, ps.cap, dstats, ST_RAYS_CLOSEST, ST_NODES_CLOSEST, ST_TRIS_CLOSEST, stream);
         tm.end();
-        tm.begin(&stats.ms_shade);
-        if (s->lambert_only) hipLaunchKernelGGL(k_shade<1>, dim3(pgrid), dim3(256), 0, stream, s->d, fp, ps);
-        else if (s->lambert_materials) hipLaunchKernelGGL(k_shade<3>, dim3(pgrid), dim3(256), 0, stream, s->d, fp, ps);
-        else if (!use_bins) hipLaunchKernelGGL(k_shade<0>, dim3(pgrid), dim3(256), 0, stream, s->d, fp, ps);
+        if (s->lambert_only) { tm.begin(&stats.ms_shade_lambert_const); hipLaunchKernelGGL(k_shade<1>, dim3(pgrid), dim3(256), 0, stream, s->d, fp, ps); tm.end(); }
+        else if (s->lambert_materials) { tm.begin(&stats.ms_shade_lambert); hipLaunchKernelGGL(k_shade<3>, dim3(pgrid), dim3(256), 0, stream, s->d, fp, ps); tm.end(); }
+        else if (!use_bins) { tm.begin(&stats.ms_shade_generic); hipLaunchKernelGGL(k_shade<0>, dim3(pgrid), dim3(256), 0, stream, s->d, fp, ps); tm.end(); }
         else {
+          tm.begin(&stats.ms_shade_bin);
           unsigned* bw = s->bin_words.as<unsigned>() + (size_t)bounce * bin_stride;
           unsigned* hist = bw; unsigned* cursor = bw + (RT_BIN_MAX + 1); unsigned* sorted_cnt = bw + 2 * (RT_BIN_MAX + 1);
           hipLaunchKernelGGL(k_bin_count, dim3(pgrid), dim3(256), 0, stream, s->d, ps, n_bins, hist);
           unsigned* ranges = sorted_cnt + RT_QSHARDS;
           hipLaunchKernelGGL(k_bin_scatter, dim3(pgrid), dim3(256), 0, stream, s->d, ps, n_bins, hist, cursor, s->bin_sorted.as<unsigned>(), sorted_cnt,
                              split_classes ? n_first : 0u, split_classes ? n_first + n_second : 0u, ranges);
+          tm.end();
           PassState pb = ps; pb.q_in = s->bin_sorted.as<unsigned>(); pb.cnt_in = sorted_cnt;  // all entries in shard 0: QView::get(i) = ids[i]
           // classes of the register-resident front-ends, then the generic one, then the rays that left the scene
-          if (split_classes && n_first) { pb.range = ranges; hipLaunchKernelGGL(k_shade<3>, dim3(pgrid), dim3(256), 0, stream, s->d, fp, pb); }
-          if (split_classes && n_second) { pb.range = ranges + 2; hipLaunchKernelGGL(k_shade<5>, dim3(pgrid), dim3(256), 0, stream, s->d, fp, pb); }
-          pb.range = ranges + 4; hipLaunchKernelGGL(k_shade<0>, dim3(pgrid), dim3(256), 0, stream, s->d, fp, pb);
-          pb.range = ranges + 6; hipLaunchKernelGGL(k_shade_miss, dim3(pgrid), dim3(256), 0, stream, s->d, pb);
+          if (split_classes && n_first) { pb.range = ranges; tm.begin(&stats.ms_shade_lambert); hipLaunchKernelGGL(k_shade<3>, dim3(pgrid), dim3(256), 0, stream, s->d, fp, pb); tm.end(); }
+          if (split_classes && n_second) { pb.range = ranges + 2; tm.begin(&stats.ms_shade_two_lobe); hipLaunchKernelGGL(k_shade<5>, dim3(pgrid), dim3(256), 0, stream, s->d, fp, pb); tm.end(); }
+          pb.range = ranges + 4; tm.begin(&stats.ms_shade_generic); hipLaunchKernelGGL(k_shade<0>, dim3(pgrid), dim3(256), 0, stream, s->d, fp, pb); tm.end();
+          pb.range = ranges + 6; tm.begin(&stats.ms_shade_miss); hipLaunchKernelGGL(k_shade_miss, dim3(pgrid), dim3(256), 0, stream, s->d, pb); tm.end();
         }
-        tm.end();
         tm.begin(&stats.ms_trace_any);
         launch_trace<true>(s, count, io_shadow, ps.q_shadow, ps.cnt_out + RT_QSHARDS, ps.shard_cap, 0, dstats, ST_RAYS_SHADOW, ST_NODES_SHADOW, ST_TRIS_SHADOW, stream);
         tm.end();
@@ -1000,6 +1003,7 @@ extern "C" int rt_render(rt_scene* s, const rt_camera* cam, const rt_film_desc* 
   if (!(flags & RT_FLAG_FILM_ON_DEVICE)) HIP_TRY(hipMemcpyAsync(film_xyzw, d_out, (size_t)cw * ch * 16, hipMemcpyDeviceToHost, stream));
   HIP_TRY(hipStreamSynchronize(stream));
   tm.collect();
+  stats.ms_shade = stats.ms_shade_lambert_const + stats.ms_shade_lambert + stats.ms_shade_two_lobe + stats.ms_shade_generic + stats.ms_shade_bin + stats.ms_shade_miss;
   unsigned long long h[ST_COUNT];
   HIP_TRY(hipMemcpy(h, s->stats.p, sizeof(h), hipMemcpyDeviceToHost));
   { unsigned ovf = 0; HIP_TRY(hipMemcpy(&ovf, s->sampler_plan.dirty.as<unsigned>() + 1 + RT_DIRTY_CAP, 4, hipMemcpyDeviceToHost));
@@ -1009,6 +1013,7 @@ extern "C" int rt_render(rt_scene* s, const rt_camera* cam, const rt_film_desc* 
   stats.nodes_closest = h[ST_NODES_CLOSEST]; stats.nodes_shadow = h[ST_NODES_SHADOW]; stats.nodes_mis = h[ST_NODES_MIS];
   stats.tris_closest = h[ST_TRIS_CLOSEST]; stats.tris_shadow = h[ST_TRIS_SHADOW]; stats.tris_mis = h[ST_TRIS_MIS];
   stats.paths_scrubbed = h[ST_SCRUBBED];
+  stats.vertices_lambert_const = h[ST_SHADED]; stats.vertices_lambert = h[ST_SHADED + 1]; stats.vertices_two_lobe = h[ST_SHADED + 2]; stats.vertices_generic = h[ST_SHADED + 3];
   if (h[ST_UNBUILT_VOXEL]) return fail(RT_ERR_INVALID, "a path looked up a light-distribution voxel that holds no surface (voxel marking bug)");
   stats.ms_total = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_begin).count();
   if (stats_out) *stats_out = stats;

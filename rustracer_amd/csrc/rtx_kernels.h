@@ -50,7 +50,9 @@ struct PassState {
 };
 #define RT_NQ 4  // queues a bounce fills
 enum { ST_CAMERA = 0, ST_RAYS_CLOSEST, ST_RAYS_SHADOW, ST_RAYS_MIS, ST_NODES_CLOSEST, ST_NODES_SHADOW, ST_NODES_MIS,
-       ST_TRIS_CLOSEST, ST_TRIS_SHADOW, ST_TRIS_MIS, ST_SCRUBBED, ST_UNBUILT_VOXEL, ST_COUNT };
+       ST_TRIS_CLOSEST, ST_TRIS_SHADOW, ST_TRIS_MIS, ST_SCRUBBED, ST_UNBUILT_VOXEL,
+       ST_SHADED,  // + {0: k_shade<1>, 1: k_shade<3>, 2: k_shade<5>, 3: k_shade<0>}: path vertices shaded by each front-end (misses included)
+       ST_COUNT = ST_SHADED + 4 };
 
 struct FrameParams {
   // camera (rc/camera.rs)
@@ -1060,8 +1062,8 @@ struct SingleLambertT {
   RT_DEV void build(const DScene& sc, int mat, SurfaceInteraction& si) {  // matte.rs:37-62 with sigma == 0 and no bump map
     const int kd = sc.materials[mat].slot[0];
     const DTexture& t = sc.textures[kd];
-    if (TEXTURED && t.kind != RT_TEX_CONST) r = clamp_pos(tex_eval(sc, kd, si));
-    else r = clamp_pos(mkc(t.v[0], t.v[1], t.v[2]));
+    if (TEXTURED && t.kind != RT_TEX_CONST && !RT_DBG(sc, 1)) r = clamp_pos(tex_eval(sc, kd, si));
+    else r = (TEXTURED && t.kind != RT_TEX_CONST) ? mkc(0.75f, 0.75f, 0.75f) : clamp_pos(mkc(t.v[0], t.v[1], t.v[2]));
     has = !is_black(r);
     ss = normalize(si.sh_dpdu); ns = si.sh_n; ng = si.hit.n; ts = cross(si.sh_n, ss);  // Bsdf::new, bsdf/mod.rs:77-91
   }
@@ -1230,9 +1232,11 @@ __global__ void __launch_bounds__(256, MODE == 1 ? RT_SHADE_MIN_WAVES : RT_SHADE
   unsigned first = 0, count = ps.q_in ? qv.total() : ps.cap;  // no queue: bounce 0 of a pass whose samples are all traced
   if (MODE != 1 && ps.range) { first = ps.range[0]; count = ps.range[1]; }
   const unsigned stride = gridDim.x * blockDim.x;
+  unsigned n_shaded = 0;
   for (unsigned base = first + blockIdx.x * blockDim.x; base < count; base += stride) {
     const unsigned i = base + threadIdx.x;
     const bool lane_live = i < count;
+    n_shaded += lane_live ? 1u : 0u;
     bool cont = false, want_shadow = false, want_mis = false, mis_occlusion_only = false;
     unsigned pid = 0;
     if (lane_live) {
@@ -1267,7 +1271,7 @@ __global__ void __launch_bounds__(256, MODE == 1 ? RT_SHADE_MIN_WAVES : RT_SHADE
         }
       }
       if (found && bounces < fp.max_depth) {  // path.rs:139
-        if (MODE != 1 && bounces == 0 && sc.needs_differentials) {  // only the camera ray carries differentials (interaction.rs:245-314)
+        if (MODE != 1 && bounces == 0 && sc.needs_differentials && !RT_DBG(sc, 16)) {  // only the camera ray carries differentials (interaction.rs:245-314)
           f2 pf; { float2 t = pacc->pfilm; pf = mk2(t.x, t.y); }
           f2 pl = table_2d(smp.tb, pix, 1, s);
           CameraRay cr = generate_camera_ray(fp, pf, pl, 1.0f / sqrtf((float)ps.spp));
@@ -1310,7 +1314,7 @@ __global__ void __launch_bounds__(256, MODE == 1 ? RT_SHADE_MIN_WAVES : RT_SHADE
             }
             // ---- BSDF-sampling half
             rgb3 f2v = mkc(0, 0, 0); float w2 = 0.0f, spdf2 = 1.0f;
-            if (!light_is_delta(light)) {
+            if (!light_is_delta(light) && !RT_DBG(sc, 8)) {
               LobeSample bs = bsdf.sample_f(si.hit.wo, u_scattering, nonspec);
               rgb3 f = bs.f * fabsf(dot(bs.wi, si.sh_n));
               if (!is_black(f) && bs.pdf > 0.0f) {
@@ -1381,6 +1385,8 @@ __global__ void __launch_bounds__(256, MODE == 1 ? RT_SHADE_MIN_WAVES : RT_SHADE
     if (pr[2]) ps.q_mis[slot[2]] = pid;
     if (NQ == 4 && pr[3]) ps.q_misany[slot[3]] = pid;
   }
+  for (int off = 32; off > 0; off >>= 1) n_shaded += __shfl_down(n_shaded, off);
+  if ((threadIdx.x & 63u) == 0u && n_shaded) atomicAdd(&ps.stats[ST_SHADED + (MODE == 1 ? 0 : (MODE == 3 ? 1 : (MODE == 5 ? 2 : 3)))], (unsigned long long)n_shaded);
 }
 
 // The miss bin of a binned queue: a path whose ray left the scene. PathIntegrator::li adds the environment's radiance only for camera rays
