@@ -503,6 +503,9 @@ int orc_render(void* h, const orc_render_params* p, float* film_xyzw, orc_stats*
       for (int y = y0; y < y1; ++y)
         for (int x = x0; x < x1; ++x) {
           uint64_t pixel_index = (uint64_t)(y - sample_bounds.y0) * (uint64_t)ext_x + (uint64_t)(x - sample_bounds.x0);
+          // renderer.rs:96-104 starts every pixel and then skips those outside pixel_bounds: in the tile-sequential mode the skipped pixel's draws
+          // advance the tile's RNG stream; in the pixel-keyed mode the next pixel re-keys it, so the tables of a skipped pixel are never observed
+          if (sampler.mode != SAMPLER_REF && !b2i_inside_exclusive(pixel_bounds, x, y)) continue;
           sampler.start_pixel(pixel_index);
           if (!b2i_inside_exclusive(pixel_bounds, x, y)) continue;
           for (;;) {

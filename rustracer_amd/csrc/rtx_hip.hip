@@ -1008,7 +1008,7 @@ extern "C" int rt_render(rt_scene* s, const rt_camera* cam, const rt_film_desc* 
   HIP_TRY(hipMemcpy(h, s->stats.p, sizeof(h), hipMemcpyDeviceToHost));
   { unsigned ovf = 0; HIP_TRY(hipMemcpy(&ovf, s->sampler_plan.dirty.as<unsigned>() + 1 + RT_DIRTY_CAP, 4, hipMemcpyDeviceToHost));
     if (ovf) { (void)hipMemset(s->sampler_plan.dirty.p, 0, (2 + RT_DIRTY_CAP) * 4); return fail(RT_ERR_INVALID, "sampler retry list overflow"); } }
-  stats.camera_rays = owned_pixels * spp;
+  stats.camera_rays = h[ST_CAMERA];  // counted by k_raygen: samples inside pixel_bounds and the film's sample rows
   stats.rays_closest = h[ST_RAYS_CLOSEST]; stats.rays_shadow = h[ST_RAYS_SHADOW]; stats.rays_mis = h[ST_RAYS_MIS];
   stats.nodes_closest = h[ST_NODES_CLOSEST]; stats.nodes_shadow = h[ST_NODES_SHADOW]; stats.nodes_mis = h[ST_NODES_MIS];
   stats.tris_closest = h[ST_TRIS_CLOSEST]; stats.tris_shadow = h[ST_TRIS_SHADOW]; stats.tris_mis = h[ST_TRIS_MIS];

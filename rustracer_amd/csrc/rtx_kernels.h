@@ -446,6 +446,7 @@ RT_DEV CameraRay generate_camera_ray(const FrameParams& fp, f2 p_film, f2 p_lens
 __global__ void __launch_bounds__(256) k_raygen(FrameParams fp, PassState ps) {
   const unsigned stride = gridDim.x * blockDim.x;
   const Tables tb = tables_of(ps);
+  unsigned n_camera = 0;
   for (unsigned base = blockIdx.x * blockDim.x; base < ps.cap; base += stride) {
     const unsigned pid = base + threadIdx.x;
     bool in_bounds = false;
@@ -469,12 +470,16 @@ __global__ void __launch_bounds__(256) k_raygen(FrameParams fp, PassState ps) {
       pa->rng = rng.state;
       pa->pfilm = make_float2(p_film.x, p_film.y);
     }
+    n_camera += in_bounds ? 1u : 0u;
     if (!ps.all_in_bounds) {
       const int ci[1] = {0}; const bool pr[1] = {in_bounds}; unsigned slot[1];
       block_push<1>(ps.cnt_out, ps.shard_cap, ci, pr, slot);
       if (in_bounds) ps.q_in[slot[0]] = pid;
     }
   }
+  // camera samples actually generated: calls of PathIntegrator::li (samples outside pixel_bounds are skipped, renderer.rs:103)
+  for (int off = 32; off > 0; off >>= 1) n_camera += __shfl_down(n_camera, off);
+  if ((threadIdx.x & 63u) == 0u && n_camera) atomicAdd(&ps.stats[ST_CAMERA], (unsigned long long)n_camera);
 }
 
 // ================================================================================ K2/K4 trace

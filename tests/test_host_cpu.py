@@ -58,6 +58,25 @@ def test_oracle_ref_and_keyed_modes_agree_statistically(orc):
     assert np.linalg.norm(a - b) / np.linalg.norm(b) < 0.25
 
 
+def test_c1_config_on_the_cpu_port(orc):
+    """BASELINE.json configs[0] exactly - cornell-box 400x400, PathIntegrator maxdepth 5, 64 spp, on the CPU (the reference's own runnable case):
+    the oracle in the reference's tile-sequential sampler mode on every host thread, and the pixel-keyed mode the GPU parity is defined on. Both are
+    unbiased estimators of the same image; the frame is independent of the thread count because a tile's stream is seeded by its index."""
+    from rustracer_amd.scenes import cornell_box
+    d = cornell_box(400, 400, 64)
+    assert (d.integrator.max_depth, d.sampler.spp, d.film.xres, d.film.yres) == (5, 64, 400, 400)
+    o = orc.OracleScene(d)
+    ref, st = o.render(mode=0)
+    # 64 unit weights per pixel, except where a sample fell exactly on a pixel edge and went to both neighbours (film.rs:313-321)
+    assert st["camera_rays"] == 400 * 400 * 64 and ref[..., 3].sum() >= 400 * 400 * 64 and (np.abs(ref[..., 3] - 64) <= 4).all() and (ref[..., 3] == 64).mean() > 0.99
+    ref1, _ = o.render(mode=0, n_threads=3)
+    assert np.array_equal(ref[..., 3], ref1[..., 3]) and np.allclose(ref, ref1, rtol=1e-5)  # only such edge splats cross tiles: the merge order barely matters
+    key, _ = o.render(mode=1)
+    a, b = orc.film_to_rgb(ref), orc.film_to_rgb(key)
+    assert abs(a.mean() - b.mean()) / b.mean() < 0.01
+    assert np.linalg.norm(a - b) / np.linalg.norm(b) < 0.2
+
+
 def test_oracle_single_path_probe_matches_film(orc):
     from rustracer_amd.scenes import cornell_box
     d = cornell_box(8, 8, 4)
