@@ -122,6 +122,14 @@ void rtxh_free(void* p);
  * "Unsupported file format", as the reference. Row 0 = top of the image. */
 int rtxh_image_read(const char* path, int32_t* width, int32_t* height, float** rgb);
 
+/* ---- sampled spectra (rc/spectrum.rs:108-126,168-211, rc/cie.rs): the reference's Spectrum is RGB; spectral data is converted once, when the
+ * scene is described. from_sampled: n (wavelength nm, value) samples, increasing wavelengths, -> RGB through the CIE 1931 observer. blackbody:
+ * `scale * from_sampled(normalised Planck curve at T)` as a "blackbody" parameter gives (paramset.rs:291-310). copper: the default eta and k of
+ * Material "metal" (Metal::create, rc/material/metal.rs:25-29 over the measured tables :84-200). */
+int rtxh_spectrum_from_sampled(const float* lambda_nm, const float* values, int32_t n, float rgb[3]);
+int rtxh_spectrum_blackbody(float temperature_kelvin, float scale, float rgb[3]);
+void rtxh_copper(float eta_rgb[3], float k_rgb[3]);
+
 /* ---- pbrt-v3 scene description ----------------------------------------------------------
  * What `rustracer scene.pbrt` does before renderer::render: tokenise + parse (rc/pbrt/lexer.rs:185-275,
  * rc/pbrt/parser.rs:20-320), run the directive state machine of RealApi (rc/api.rs:516-1010: CTM, named coordinate

@@ -16,6 +16,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <limits>
+#include <sstream>
 #include <string>
 #include <vector>
 
@@ -967,6 +968,59 @@ static int ply_read_unguarded(const char* path, rtxh_ply* out) {
 }
 void rtxh_ply_free(rtxh_ply* p) { if (!p) return; free(p->P); free(p->N); free(p->UV); free(p->idx); memset(p, 0, sizeof(*p)); }
 void rtxh_free(void* p) { free(p); }
+
+// ---------------------------------------------------------------- sampled spectra -> RGB (rc/spectrum.rs, rc/cie.rs)
+// Spectrum is RGB in the reference (spectrum.rs:12-17); spectral data enters it at scene-description time only: Metal::create's copper
+// default (metal.rs:25-29), `spectrum` parameters naming SPD files and `blackbody` parameters (paramset.rs:141-152, 254-310).
+#include "rtx_spectrum_tables.inl"
+static float spd_interpolate(const float* lambda, const float* vals, size_t n, float l) {  // interpolate_spectrum_samples, spectrum.rs:196-211
+  if (l <= lambda[0]) return vals[0];
+  if (l >= lambda[n - 1]) return vals[n - 1];
+  size_t first = 0, len = n;  // find_interval(n, |i| lambda[i] <= l), lib.rs:171-189
+  while (len > 0) {
+    const size_t half = len >> 1, middle = first + half;
+    if (lambda[middle] <= l) { first = middle + 1; len -= half + 1; } else len = half;
+  }
+  long off = (long)first - 1; if (off < 0) off = 0; if (off > (long)n - 2) off = (long)n - 2;
+  const float t = (l - lambda[off]) / (lambda[off + 1] - lambda[off]);
+  return vals[off] * (1.0f - t) + vals[off + 1] * t;  // lerp, lib.rs:107-117
+}
+int rtxh_spectrum_from_sampled(const float* lambda, const float* v, int32_t n, float rgb[3]) {  // Spectrum::from_sampled, spectrum.rs:108-126
+  if (!lambda || !v || !rgb || n < 1) return fail(RT_ERR_INVALID, "bad spectrum samples");
+  for (int i = 0; i + 1 < n; ++i) if (!(lambda[i + 1] > lambda[i])) return fail(RT_ERR_INVALID, "spectrum wavelengths must increase (the reference asserts it, spectrum.rs:197-199)");
+  float xyz[3] = {0.0f, 0.0f, 0.0f};
+  for (int i = 0; i < kNCieSamples; ++i) {
+    const float val = n == 1 ? v[0] : spd_interpolate(lambda, v, (size_t)n, 360.0f + (float)i);
+    xyz[0] += val * kCieX[i]; xyz[1] += val * kCieY[i]; xyz[2] += val * kCieZ[i];
+  }
+  const float scale = ((360.0f + (float)(kNCieSamples - 1)) - 360.0f) / (kCieYIntegral * (float)kNCieSamples);
+  xyz[0] *= scale; xyz[1] *= scale; xyz[2] *= scale;
+  rgb[0] = 3.240479f * xyz[0] - 1.537150f * xyz[1] - 0.498535f * xyz[2];  // from_xyz, spectrum.rs:91-96
+  rgb[1] = -0.969256f * xyz[0] + 1.875991f * xyz[1] + 0.041556f * xyz[2];
+  rgb[2] = 0.055648f * xyz[0] - 0.204043f * xyz[1] + 1.057311f * xyz[2];
+  return RT_OK;
+}
+static float blackbody_le(float lambda_nm, float temp) {  // blackbody, spectrum.rs:168-185
+  const float c = 299792458.0f, h = 6.62606957e-34f, kb = 1.3806488e-23f;
+  const float l = lambda_nm * 1e-9f;
+  const float lambda5 = (l * l) * (l * l) * l;
+  return (2.0f * h * c * c) / (lambda5 * (std::exp((h * c) / (l * kb * temp)) - 1.0f));
+}
+int rtxh_spectrum_blackbody(float temperature, float scale, float rgb[3]) {  // add_blackbody_spectrum, paramset.rs:291-310 + blackbody_normalized, spectrum.rs:187-194
+  if (!rgb || !(temperature > 0.0f)) return fail(RT_ERR_INVALID, "blackbody temperature must be positive (the reference asserts it, spectrum.rs:169)");
+  std::vector<float> lam((size_t)kNCieSamples), le((size_t)kNCieSamples);
+  const float lambda_max = 2.8977721e-3f / temperature * 1e9f;
+  const float max_l = blackbody_le(lambda_max, temperature);
+  for (int i = 0; i < kNCieSamples; ++i) { lam[(size_t)i] = 360.0f + (float)i; le[(size_t)i] = blackbody_le(lam[(size_t)i], temperature) / max_l; }
+  const int rc = rtxh_spectrum_from_sampled(lam.data(), le.data(), kNCieSamples, rgb);
+  if (rc != RT_OK) return rc;
+  for (int k = 0; k < 3; ++k) rgb[k] = scale * rgb[k];
+  return RT_OK;
+}
+void rtxh_copper(float eta_rgb[3], float k_rgb[3]) {  // the defaults of Metal::create, metal.rs:25-29
+  (void)rtxh_spectrum_from_sampled(kCopperWavelengths, kCopperN, kCopperSamples, eta_rgb);
+  (void)rtxh_spectrum_from_sampled(kCopperWavelengths, kCopperK, kCopperSamples, k_rgb);
+}
 
 int rtxh_pfm_read(const char* path, int32_t* width, int32_t* height, float** rgb) {
   if (!path || !width || !height || !rgb) return fail(RT_ERR_INVALID, "null argument");

@@ -133,9 +133,41 @@ struct PbrtLoader {
         if (i >= t.size()) return fail_("unterminated parameter array " + p.name);
         ++i;
       } else { if (!take(t[i])) return fail_("bad value of parameter " + p.name); ++i; }
+      // ParamSet::init (paramset.rs:141-152): "spectrum" values are SPD file names, one Spectrum::from_sampled each (an unreadable file is a
+      // warning and gives black, :257-266; inline samples are a TODO in the reference and an error here); "blackbody" values are
+      // (temperature, scale) pairs. Both land in the same `spectra` list as rgb / color values, so they become "rgb" here.
+      if (p.type == "spectrum") {
+        if (p.strs.empty()) return fail_("inline samples in spectrum parameter \"" + p.name + "\" are not supported (nor by the reference, paramset.rs:144)");
+        p.nums.clear();
+        for (const std::string& f : p.strs) {
+          float rgb[3] = {0.0f, 0.0f, 0.0f}; std::string text;
+          if (!read_file(resolve(f), text)) warn("unable to read SPD file, using black");
+          else {
+            std::vector<float> wl, vals, all; std::istringstream lines(text); std::string line;
+            while (std::getline(lines, line)) {  // read_float_file, floatfile.rs:8-35
+              if (!line.empty() && line[0] == '#') continue;
+              std::istringstream toks(line); std::string tok;
+              while (toks >> tok) { float v; if (is_number(tok, v)) all.push_back(v); else warn("unexpected text in float file"); }
+            }
+            for (size_t k = 0; k + 1 < all.size(); k += 2) { wl.push_back(all[k]); vals.push_back(all[k + 1]); }
+            if (all.size() % 2) warn("extra value in spectrum file");
+            if (wl.empty() || rtxh_spectrum_from_sampled(wl.data(), vals.data(), (int32_t)wl.size(), rgb) != RT_OK) return fail_("bad SPD file " + f + ": " + rtxh_last_error());
+          }
+          p.nums.insert(p.nums.end(), rgb, rgb + 3);
+        }
+        p.strs.clear(); p.type = "rgb";
+      } else if (p.type == "blackbody") {
+        std::vector<float> out_rgb;
+        for (size_t k = 0; k + 1 < p.nums.size(); k += 2) {
+          float rgb[3];
+          if (rtxh_spectrum_blackbody(p.nums[k], p.nums[k + 1], rgb) != RT_OK) return fail_(rtxh_last_error());
+          out_rgb.insert(out_rgb.end(), rgb, rgb + 3);
+        }
+        p.nums = out_rgb; p.type = "rgb";
+      }
       static const char* known[] = {"integer", "float", "bool", "string", "texture", "rgb", "color", "point", "point2", "point3", "vector", "vector2", "vector3", "normal", "normal3"};
       bool ok = false; for (const char* k : known) if (p.type == k) ok = true;
-      if (!ok) return fail_("parameter type \"" + p.type + "\" is not supported by this backend (spectrum / blackbody / xyz data)");
+      if (!ok) return fail_("parameter type \"" + p.type + "\" is not supported (xyz: \"not implemented yet\" in the reference too, paramset.rs:157-160)");
       out.v.push_back(std::move(p));
     }
     return true;
@@ -250,8 +282,9 @@ struct PbrtLoader {
     auto F = [&](int slot, const char* n, float d) { slots[slot] = float_texture(gp, mp, n, d); };
     auto eta_or_index = [&]() { const int e = float_texture_or_none(gp, mp, "eta"); slots[RT_SLOT_ETA] = e >= 0 ? e : float_texture(gp, mp, "index", 1.5f); };  // glass.rs:32-34, uber.rs:39-41
     if (name == "plastic") { kind = RT_MAT_PLASTIC; S(RT_SLOT_KD, "Kd", .25f, .25f, .25f); S(RT_SLOT_KS, "Ks", .25f, .25f, .25f); F(RT_SLOT_ROUGHNESS, "roughness", 0.1f); }
-    else if (name == "metal") {  // metal.rs:23-47; default eta / k: the published RGB values of copper (see scene_desc.py)
-      kind = RT_MAT_METAL; S(RT_SLOT_ETA, "eta", 0.200438f, 0.924033f, 1.102212f); S(RT_SLOT_K, "k", 3.912949f, 2.452848f, 2.142188f); F(RT_SLOT_ROUGHNESS, "roughness", 0.01f);
+    else if (name == "metal") {  // metal.rs:23-47; default eta / k = Spectrum::from_sampled over the measured copper tables (:25-29)
+      float ce[3], ck[3]; rtxh_copper(ce, ck);
+      kind = RT_MAT_METAL; S(RT_SLOT_ETA, "eta", ce[0], ce[1], ce[2]); S(RT_SLOT_K, "k", ck[0], ck[1], ck[2]); F(RT_SLOT_ROUGHNESS, "roughness", 0.01f);
       slots[RT_SLOT_UROUGH] = float_texture_or_none(gp, mp, "uroughness"); slots[RT_SLOT_VROUGH] = float_texture_or_none(gp, mp, "vroughness");
     } else if (name == "mirror") { kind = RT_MAT_MIRROR; S(RT_SLOT_KR, "Kr", .9f, .9f, .9f); }
     else if (name == "glass") { kind = RT_MAT_GLASS; S(RT_SLOT_KR, "Kr", 1, 1, 1); S(RT_SLOT_KT, "Kt", 1, 1, 1); eta_or_index(); F(RT_SLOT_UROUGH, "uroughness", 0.0f); F(RT_SLOT_VROUGH, "vroughness", 0.0f); }

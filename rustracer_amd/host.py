@@ -295,6 +295,28 @@ class HostScene:
         return dict(n_voxels=nv, func=func, cdf=cdf, func_int=fint)
 
 
+def copper():
+    """(eta rgb, k rgb): the defaults of Material "metal" (Metal::create, rc/material/metal.rs:25-29)."""
+    e, k = (C.c_float * 3)(), (C.c_float * 3)()
+    lib().rtxh_copper(e, k)
+    return np.float32(list(e)), np.float32(list(k))
+
+
+def spectrum_from_sampled(wavelengths_nm, values):
+    """Spectrum::from_sampled (rc/spectrum.rs:108-126) -> RGB."""
+    lam, v = np.ascontiguousarray(wavelengths_nm, np.float32), np.ascontiguousarray(values, np.float32)
+    out = (C.c_float * 3)()
+    _check(lib().rtxh_spectrum_from_sampled(_p(lam), _p(v), len(lam), out), "spectrum_from_sampled")
+    return np.float32(list(out))
+
+
+def spectrum_blackbody(temperature, scale=1.0):
+    """A "blackbody" parameter's value (rc/paramset.rs:291-310) -> RGB."""
+    out = (C.c_float * 3)()
+    _check(lib().rtxh_spectrum_blackbody(C.c_float(temperature), C.c_float(scale), out), "spectrum_blackbody")
+    return np.float32(list(out))
+
+
 class PbrtResult(C.Structure):
     _fields_ = [("scene", C.c_void_p), ("params", RenderParams), ("max_prims_per_node", C.c_int32), ("n_warnings", C.c_int32),
                 ("film_filename", C.c_char * 512)]

@@ -29,12 +29,11 @@ TRI_FLIP, TRI_HAS_N, TRI_HAS_UV, TRI_HAS_S = 1, 2, 4, 8
 MAT_SLOTS = ("kd", "ks", "kr", "kt", "sigma", "roughness", "urough", "vrough", "eta", "k", "opacity",
              "reflect", "transmit", "amount", "m1", "m2")
 
-# Metal's default eta/k come from Spectrum::from_sampled over measured copper data and the CIE
-# tables (rc/material/metal.rs:25-29, rc/cie.rs) - host-side data the build does not carry
-# (SURVEY.md §2 row 41). The widely published RGB values for copper are used as the defaults here;
-# they reach every backend as ordinary constant textures, so parity does not depend on them.
-COPPER_ETA = (0.200438, 0.924033, 1.102212)
-COPPER_K = (3.912949, 2.452848, 2.142188)
+# Metal's default eta / k: Spectrum::from_sampled over the measured copper tables and the CIE 1931 observer (rc/material/metal.rs:25-29,
+# 84-200; rc/spectrum.rs:108-126; rc/cie.rs). These are the f32 values that arithmetic gives - the C++ host computes them (rtxh_copper in
+# rtx_host.cpp, used by the .pbrt loader) and tests/test_pbrt_cpu.py checks these constants against it and against a numpy restatement.
+COPPER_ETA = (0.19999069, 0.9220846, 1.0998759)
+COPPER_K = (3.9046354, 2.4476333, 2.1376526)
 
 
 @dataclass

@@ -496,7 +496,8 @@ WorldEnd
     (HEADER + 'WorldBegin\nLightSource "spot"\n' + TRI + "WorldEnd\n", "not supported"),
     (HEADER + 'WorldBegin\nAreaLightSource "sphere"\n' + TRI + "WorldEnd\n", "unknown"),
     (HEADER + 'WorldBegin\nMakeNamedMaterial "m" "rgb Kd" [1 1 1]\n' + TRI + "WorldEnd\n", 'No parameter string "type"'),
-    (HEADER + 'WorldBegin\nMaterial "matte" "spectrum Kd" "file.spd"\n' + TRI + "WorldEnd\n", "not supported"),
+    (HEADER + 'WorldBegin\nMaterial "matte" "spectrum Kd" [400 1 700 1]\n' + TRI + "WorldEnd\n", "inline samples"),
+    (HEADER + 'WorldBegin\nMaterial "matte" "xyz Kd" [1 1 1]\n' + TRI + "WorldEnd\n", "not supported"),
     (HEADER + "WorldBegin\nFrobnicate 1 2\nWorldEnd\n", "unknown directive"),
     (HEADER + 'WorldBegin\nShape "trianglemesh" "integer indices" [0 1 5] "point P" [0 0 0 1 0 0 0 1 0]\nWorldEnd\n', "out of range"),
     (HEADER + "WorldBegin\nWorldEnd\n", "no triangles"),
@@ -531,3 +532,97 @@ def test_damaged_files_fail_cleanly(tmp_path):
             host.PbrtScene(p)
         except host.BackendError:
             pass
+
+
+# ------------------------------------------------------------------------------------------------ sampled spectra (rc/spectrum.rs, rc/cie.rs)
+def _spectrum_tables():
+    """The data tables of rtx_spectrum_tables.inl, parsed from the file the C++ host compiles."""
+    import re
+    text = open(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "rustracer_amd", "csrc", "rtx_spectrum_tables.inl")).read()
+    t = {m.group(1): np.array([float(x.rstrip("f")) for x in re.findall(r"[-+0-9.e]+f", m.group(2))], F32)
+         for m in re.finditer(r"static const float (\w+)\[\d+\] = \{(.*?)\};", text, re.S)}
+    t["y_int"] = F32(re.search(r"kCieYIntegral = ([0-9.]+)f", text).group(1))
+    return t
+
+
+def _from_sampled_numpy(t, lam, v):
+    """Spectrum::from_sampled (rc/spectrum.rs:108-126) + interpolate_spectrum_samples (:196-211) + from_xyz (:91-96), in f32, operation by operation."""
+    lam, v = np.asarray(lam, F32), np.asarray(v, F32)
+    xyz = [F32(0), F32(0), F32(0)]
+    for i in range(471):
+        l = F32(360 + i)
+        if l <= lam[0]:
+            val = v[0]
+        elif l >= lam[-1]:
+            val = v[-1]
+        else:
+            off = min(max(int(np.searchsorted(lam, l, side="right")) - 1, 0), len(lam) - 2)  # find_interval(n, |i| lambda[i] <= l)
+            tt = F32(l - lam[off]) / F32(lam[off + 1] - lam[off])
+            val = F32(v[off] * F32(F32(1) - tt)) + F32(v[off + 1] * tt)
+        for k, tab in enumerate(("kCieX", "kCieY", "kCieZ")):
+            xyz[k] = F32(xyz[k] + F32(val * t[tab][i]))
+    scale = F32(F32(830) - F32(360)) / F32(t["y_int"] * F32(471))
+    x, y, z = (F32(c * scale) for c in xyz)
+    m = [(3.240479, -1.537150, -0.498535), (-0.969256, 1.875991, 0.041556), (0.055648, -0.204043, 1.057311)]
+    return np.array([F32(F32(F32(F32(a) * x) + F32(F32(b) * y)) + F32(F32(c) * z)) for a, b, c in m], F32)
+
+
+def test_cie_tables_are_the_1931_standard_observer():
+    """Pins the DATA independently of the reference: published properties of the CIE 1931 2-degree colour matching functions."""
+    t = _spectrum_tables()
+    x, y, z = t["kCieX"], t["kCieY"], t["kCieZ"]
+    assert len(x) == len(y) == len(z) == 471
+    assert y.max() == 1.0 and 360 + int(y.argmax()) == 555                      # photopic peak V(555 nm) = 1
+    assert 360 + int(x.argmax()) == 599 and abs(float(x.max()) - 1.0622) < 1e-3  # x-bar: main lobe 1.0622 at 599 nm ...
+    assert 360 + int(x[:140].argmax()) == 442 and abs(float(x[:140].max()) - 0.3501) < 1e-3  # ... secondary lobe 0.3501 at 442 nm
+    assert 360 + int(z.argmax()) == 446 and abs(float(z.max()) - 1.7826) < 1e-3  # z-bar: 1.7826 at 446 nm
+    assert abs(float(y.astype(np.float64).sum()) - float(t["y_int"])) < 1e-3      # CIE_Y_INTEGRAL = sum of y-bar = 106.8569
+    # equal-energy white has x = y = 1/3: the three integrals agree to 5e-4
+    sx, sy, sz = (float(a.astype(np.float64).sum()) for a in (x, y, z))
+    assert abs(sx / sy - 1) < 5e-4 and abs(sz / sy - 1) < 5e-4
+    cw, cn, ck = t["kCopperWavelengths"], t["kCopperN"], t["kCopperK"]
+    assert len(cw) == 56 and np.all(np.diff(cw) > 0) and cw[0] < 300 and cw[-1] > 880
+    # copper is red because its reflectance edge sits near 560-600 nm: n drops below 0.5 and k rises past it in the red
+    red, blue = cw > 620, (cw > 420) & (cw < 480)
+    assert cn[red].max() < 0.5 and cn[blue].min() > 1.0 and ck[red].min() > 3.0
+
+
+def test_from_sampled_matches_a_numpy_restatement_and_physics():
+    t = _spectrum_tables()
+    eta, k = host.copper()
+    assert np.array_equal(eta, F32(sd.COPPER_ETA)) and np.array_equal(k, F32(sd.COPPER_K))  # scene_desc's defaults ARE the reference arithmetic's values
+    assert np.array_equal(eta, _from_sampled_numpy(t, t["kCopperWavelengths"], t["kCopperN"]))
+    assert np.array_equal(k, _from_sampled_numpy(t, t["kCopperWavelengths"], t["kCopperK"]))
+    assert np.allclose(eta, (0.200438, 0.924033, 1.102212), rtol=5e-3) and np.allclose(k, (3.912949, 2.452848, 2.142188), rtol=5e-3)  # the values in the literature
+    rng = np.random.default_rng(5)
+    lam = np.sort(rng.uniform(300, 900, 40)).astype(F32)
+    v = rng.uniform(0, 2, 40).astype(F32)
+    assert np.array_equal(host.spectrum_from_sampled(lam, v), _from_sampled_numpy(t, lam, v))
+    flat = host.spectrum_from_sampled(F32([400, 700]), F32([1, 1]))   # a constant SPD: Y = (830 - 360) / 471, the Riemann-sum scale of spectrum.rs:119-120
+    assert abs(float(0.212671 * flat[0] + 0.715160 * flat[1] + 0.072169 * flat[2]) - 470.0 / 471.0) < 1e-5
+    with pytest.raises(host.BackendError, match="increase"):
+        host.spectrum_from_sampled(F32([500, 400]), F32([1, 1]))
+    # blackbody: Planck locus chromaticities (x, y): 6500 K -> (0.3135, 0.3237), 2856 K (illuminant A) -> (0.4476, 0.4074)
+    for temp, (cx, cy) in [(6500.0, (0.3135, 0.3237)), (2856.0, (0.4476, 0.4074))]:
+        r, g, b = (float(c) for c in host.spectrum_blackbody(temp, 1.0))
+        X = 0.412453 * r + 0.357580 * g + 0.180423 * b; Y = 0.212671 * r + 0.715160 * g + 0.072169 * b; Z = 0.019334 * r + 0.119193 * g + 0.950227 * b
+        assert abs(X / (X + Y + Z) - cx) < 2e-3 and abs(Y / (X + Y + Z) - cy) < 2e-3, (temp, X / (X + Y + Z), Y / (X + Y + Z))
+    assert np.allclose(host.spectrum_blackbody(5000.0, 3.0), 3.0 * host.spectrum_blackbody(5000.0, 1.0), rtol=1e-6)
+
+
+def test_metal_default_spectrum_files_and_blackbody_parameters(tmp_path):
+    spd = tmp_path / "green.spd"
+    spd.write_text("# wavelength value\n400 0.1\n500 0.2 550 0.9\n600 0.2\n700 0.1\n")
+    p = _parse(HEADER + 'WorldBegin\nMaterial "metal"\n' + TRI + 'Material "matte" "spectrum Kd" "green.spd"\n' + TRI
+               + 'AreaLightSource "diffuse" "blackbody L" [6500 2]\n' + TRI + "WorldEnd\n", base_dir=str(tmp_path))
+    m, t = p.table("materials"), p.table("textures")
+    metal = [x for x in m if x["kind"] == sd.MAT_METAL][0]
+    eta, k = host.copper()
+    assert np.array_equal(t[metal["slot"][sd.MAT_SLOTS.index("eta")]]["value"], eta) and np.array_equal(t[metal["slot"][sd.MAT_SLOTS.index("k")]]["value"], k)
+    matte_kd = [t[x["slot"][0]]["value"] for x in m if x["kind"] == sd.MAT_MATTE]
+    want = host.spectrum_from_sampled(F32([400, 500, 550, 600, 700]), F32([0.1, 0.2, 0.9, 0.2, 0.1]))
+    assert any(np.array_equal(v, want) for v in matte_kd) and want[1] > want[0] and want[1] > want[2]
+    lights = p.table("lights")
+    assert np.array_equal(F32(lights[0]["rgb"]), host.spectrum_blackbody(6500.0, 2.0))
+    q = _parse(HEADER + 'WorldBegin\nMaterial "matte" "spectrum Kd" "missing.spd"\n' + TRI + "WorldEnd\n", base_dir=str(tmp_path))
+    assert q.n_warnings >= 1 and np.array_equal(q.table("textures")[q.table("materials")[0]["slot"][0]]["value"], F32([0, 0, 0]))  # paramset.rs:257-266: black
