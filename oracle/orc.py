@@ -34,7 +34,7 @@ class RenderParams(C.Structure):
         ("spp", C.c_int32), ("sampler_dims", C.c_int32), ("sampler_mode", C.c_int32),
         ("max_depth", C.c_int32), ("rr_threshold", C.c_float), ("light_strategy", C.c_int32),
         ("pixel_bounds", C.c_int32 * 4), ("n_threads", C.c_int32), ("tile_size", C.c_int32),
-        ("screen_window", C.c_float * 4), ("has_pixel_bounds", C.c_int32),
+        ("screen_window", C.c_float * 4), ("has_pixel_bounds", C.c_int32), ("mis_mode", C.c_int32),
     ]
 
 
@@ -210,11 +210,13 @@ class OracleScene:
         return dict(raster_to_camera=r2c, dx_camera=dxdy[:3].copy(), dy_camera=dxdy[3:].copy(), filter_table=table,
                     sample_bounds=sb, cropped=cr, params=p)
 
-    def render(self, mode: int = 1, n_threads: int = 0):
-        """Returns (film_xyzw (H,W,4) over the cropped pixel bounds, stats dict)."""
+    def render(self, mode: int = 1, n_threads: int = 0, mis_mode: int = 0):
+        """Returns (film_xyzw (H,W,4) over the cropped pixel bounds, stats dict). mis_mode != 0: test hook (light sampling alone / BSDF sampling
+        alone in estimate_direct), see PathIntegrator::mis_mode in orc_render.h."""
         st = self.setup(mode)
         p = st["params"]
         p.n_threads = n_threads
+        p.mis_mode = mis_mode
         cr = st["cropped"]
         w, h = int(cr[2] - cr[0]), int(cr[3] - cr[1])
         film = np.zeros((h, w, 4), np.float32)

@@ -18,6 +18,7 @@ RGB PathIntegrator::estimate_direct(const SurfaceInteraction& it, const Bsdf& bs
   RGB ld = rgb(0, 0, 0);
   Scene::LiSample ls = scene->light_sample_li(light, it.hit, u_light);
   RGB li = ls.li;
+  if (mis_mode == 2 && !Scene::is_delta(light)) li = rgb(0, 0, 0);  // test hook: BSDF sampling alone
   if (ls.pdf > 0.0f && !is_black(li)) {
     RGB f = bsdf.f(it.hit.wo, ls.wi, bsdf_flags) * fabsf(dot(ls.wi, it.shading.n));
     float scattering_pdf = bsdf.pdf(it.hit.wo, ls.wi, bsdf_flags);
@@ -28,12 +29,13 @@ RGB PathIntegrator::estimate_direct(const SurfaceInteraction& it, const Bsdf& bs
         if (Scene::is_delta(light)) ld = ld + f * li / ls.pdf;
         else {
           float weight = power_heuristic(1, ls.pdf, 1, scattering_pdf);
+          if (mis_mode == 1) weight = 1.0f;  // test hook: light sampling alone
           ld = ld + f * li * weight / ls.pdf;
         }
       }
     }
   }
-  if (!Scene::is_delta(light)) {
+  if (!Scene::is_delta(light) && mis_mode != 1) {
     SampleF bs = bsdf.sample_f(it.hit.wo, u_scattering, bsdf_flags);
     RGB f = bs.f * fabsf(dot(bs.wi, it.shading.n));
     bool sampled_specular = (bs.type & BSDF_SPECULAR) != 0;
@@ -44,6 +46,7 @@ RGB PathIntegrator::estimate_direct(const SurfaceInteraction& it, const Bsdf& bs
         float light_pdf = scene->light_pdf_li(light, it.hit, bs.wi, nullptr);
         if (light_pdf == 0.0f) return ld;
         weight = power_heuristic(1, bs.pdf, 1, light_pdf);
+        if (mis_mode == 2) weight = 1.0f;  // test hook: BSDF sampling alone
       }
       Ray ray = spawn_ray(it.hit, bs.wi);
       SurfaceInteraction light_isect;
@@ -146,6 +149,7 @@ struct orc_render_params {
   int32_t n_threads, tile_size;
   float screen_window[4];  // xmin xmax ymin ymax; xmax <= xmin => PerspectiveCamera::create's default from the aspect ratio (camera.rs:86-107)
   int32_t has_pixel_bounds; // the parameter was given: a degenerate intersection is kept (only logged, path.rs:66-68) and renders nothing
+  int32_t mis_mode;         // test hook, see PathIntegrator::mis_mode (0 = the reference)
 };
 struct orc_stats {
   uint64_t camera_rays, rays_closest, rays_shadow, rays_mis, nodes_closest, nodes_shadow, nodes_mis, tris_closest, tris_shadow, tris_mis;
@@ -472,7 +476,7 @@ int orc_render(void* h, const orc_render_params* p, float* film_xyzw, orc_stats*
   LightDistribution distrib;  // integrator.preprocess, renderer.rs:30
   distrib.init(s, p->light_strategy == 1 ? "uniform" : "spatial");
   PathIntegrator integ; integ.scene = s; integ.distrib = &distrib;
-  integ.max_depth = (int)(uint8_t)p->max_depth; integ.rr_threshold = p->rr_threshold;
+  integ.max_depth = (int)(uint8_t)p->max_depth; integ.rr_threshold = p->rr_threshold; integ.mis_mode = p->mis_mode;
   const B2i sample_bounds = film.sample_bounds();
   B2i pixel_bounds = sample_bounds;  // path.rs:53-69
   if (p->has_pixel_bounds) {

@@ -229,6 +229,10 @@ struct PathIntegrator {
   const Scene* scene = nullptr;
   LightDistribution* distrib = nullptr;
   int max_depth = 5;       // stored as u8 in the reference (path.rs:27)
+  // NOT in the reference - a test hook for the MIS-invariance check (tests/test_invariants_cpu.py): 0 = the reference's estimate_direct (both
+  // strategies, power heuristic); 1 = light sampling alone with weight 1; 2 = BSDF sampling alone with weight 1. All three are unbiased estimators
+  // of the same direct lighting; they agree in the mean only if f, Li and BOTH pdfs (Light::pdf_li, Bsdf::pdf) are mutually consistent.
+  int mis_mode = 0;
   float rr_threshold = 1.0f;
   B2i pixel_bounds{0, 0, 0, 0};
   RGB estimate_direct(const SurfaceInteraction& it, const Bsdf& bsdf, P2 u_scattering, const Light& light, int light_index, P2 u_light, PathStats& st) const;
