@@ -43,6 +43,8 @@ typedef struct rt_bvh_node {
 #define RT_TRI_HAS_N 2u  /* mesh.n is Some                                   */
 #define RT_TRI_HAS_UV 4u /* mesh.uv is Some (else default uvs, mesh.rs:201-211) */
 #define RT_TRI_HAS_S 8u  /* mesh.s is Some                                   */
+#define RT_TRI_HAS_ALPHA 16u        /* mesh.alpha_mask is Some: tri_alpha[2 i] is its float texture (rc/shapes/mesh.rs:38,134-144)          */
+#define RT_TRI_HAS_SHADOW_ALPHA 32u /* mesh.shadow_alpha_mask is Some: tri_alpha[2 i + 1] (mesh.rs:39,146-156); shadow rays only (:577-581) */
 typedef struct rt_tri_meta {
   int32_t material; /* index into materials[]                 */
   int32_t light;    /* index into lights[] (area light) or -1 */
@@ -122,6 +124,9 @@ typedef struct rt_scene_desc {
   const float* tri_uv;      /* n_tris*6 or NULL                                              */
   const float* tri_s;       /* n_tris*9 or NULL                                              */
   const rt_tri_meta* tri_meta;
+  const int32_t* tri_alpha; /* n_tris*2 {alpha, shadowalpha} float-texture ids, read where the RT_TRI_HAS_*ALPHA flags are set; NULL if no
+                               mesh carries a mask. A hit whose mask evaluates to 0 is no hit (Triangle::intersect mesh.rs:353-370,
+                               intersect_p :534-582) - in BVH traversal and in Shape::pdf_wi's re-intersection alike */
   uint32_t n_textures; const rt_texture* textures;
   uint32_t n_images; const rt_image* images;
   uint32_t n_materials; const rt_material* materials;

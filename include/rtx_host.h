@@ -48,6 +48,9 @@ void rtxh_scene_free(rtxh_scene*);
  * list of that triangle's DiffuseAreaLight or -1; tri_flags = RT_TRI_* (per-mesh attributes). */
 int rtxh_scene_set_mesh(rtxh_scene*, const float* P, int32_t n_verts, const int32_t* indices, int32_t n_tris, const float* N, const float* UV,
                         const float* S, const int32_t* tri_material, const int32_t* tri_light, const uint8_t* tri_flags);
+/* Alpha masks of the meshes, after rtxh_scene_set_mesh: per triangle {alpha, shadowalpha} float-texture ids or -1 (TriangleMesh::create,
+ * rc/shapes/mesh.rs:134-156: a named float texture, or the constant 0 when the float parameter is 0). NULL removes all masks. */
+int rtxh_scene_set_alpha(rtxh_scene*, const int32_t* tri_alpha2);
 /* on != 0: MIP pyramids (rtxh_scene_add_mipmap) and environment-map sampling tables (rtxh_scene_add_light, infinite) are built
  * by the GPU (rt_mip_build, rt_env_distribution in rtx_hip.h) - bit-identical tables, milliseconds instead of tenths of a second for
  * a 2048 x 1024 map. Off by default: the host build needs no device. The setting belongs to the calling thread (scene builds on

@@ -132,6 +132,10 @@ class OracleScene:
         rc = L.orc_scene_set_mesh(self.h, _p(P), P.shape[0], _p(idx, C.c_int32), idx.shape[0], _p(N), _p(UV), _p(S),
                                   _p(mat, C.c_int32), _p(light, C.c_int32), _p(flags, C.c_uint8))
         assert rc == 0
+        alpha = desc.alpha_ids() if hasattr(desc, "alpha_ids") else None
+        if alpha is not None:
+            self._keep += (alpha,)
+            assert L.orc_scene_set_alpha(self.h, _p(alpha, C.c_int32)) == 0
         for m in desc.mipmaps:
             h, w = m.data.shape[:2]
             assert L.orc_scene_add_mipmap(self.h, w, h, _p(m.data), int(m.trilinear), C.c_float(m.max_aniso), m.wrap) >= 0

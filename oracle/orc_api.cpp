@@ -180,6 +180,11 @@ int orc_scene_set_mesh(void* h, const float* P, int nv, const int32_t* idx, int 
   }
   return 0;
 }
+int orc_scene_set_alpha(void* h, const int32_t* tri_alpha2) {  // after orc_scene_set_mesh: per triangle {alpha, shadowalpha} float-texture ids or -1
+  Scene* s = (Scene*)h;
+  if (!tri_alpha2) s->tri_alpha.clear(); else s->tri_alpha.assign(tri_alpha2, tri_alpha2 + 2 * s->n_tris());
+  return 0;
+}
 int orc_scene_add_mipmap(void* h, int w, int hgt, const float* rgbdata, int trilinear, float max_aniso, int wrap) {
   Scene* s = (Scene*)h;
   if (w <= 0 || hgt <= 0) return -1;

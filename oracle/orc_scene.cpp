@@ -183,7 +183,42 @@ bool Scene::tri_test(int tri, const Ray& ray, TriHit* h) const {
   return true;
 }
 
-// mesh.rs:321-425 (no alpha masks: the build's scenes carry none; documented in DESIGN.md)
+// The alpha tests of Triangle::intersect (mesh.rs:353-370: alpha_mask) and Triangle::intersect_p (:534-582: alpha_mask, then shadow_alpha_mask): the
+// float texture is evaluated on a local SurfaceInteraction::new(p_hit, zero error, uv_hit, -ray.d, dpdu, dpdv, ...) that carries no ray differentials;
+// a value of exactly 0 turns the accepted hit test into a miss.
+bool Scene::tri_alpha_rejects(int tri, const Ray& ray, const TriHit& h, bool shadow_ray) const {
+  if (tri_alpha.empty()) return false;
+  const int alpha = tri_alpha[2 * (size_t)tri], shadow_alpha = tri_alpha[2 * (size_t)tri + 1];
+  if (alpha < 0 && !(shadow_ray && shadow_alpha >= 0)) return false;
+  V3 p0, p1, p2; tri_verts(tri, &p0, &p1, &p2);
+  P2 uv[3]; tri_uvs(tri, uv);
+  V3 dpdu = v3(0, 0, 0), dpdv = v3(0, 0, 0);
+  float duv02x = uv[0].x - uv[2].x, duv02y = uv[0].y - uv[2].y, duv12x = uv[1].x - uv[2].x, duv12y = uv[1].y - uv[2].y;
+  V3 dp02 = p0 - p2, dp12 = p1 - p2;
+  float determinant = duv02x * duv12y - duv02y * duv12x;
+  bool degenerate_uv = fabsf(determinant) < 1e-8f;
+  if (!degenerate_uv) {
+    float inv_det = 1.0f / determinant;
+    if (shadow_ray) {  // intersect_p DIVIDES by inv_det (mesh.rs:549-550) where intersect multiplies (:331-332): a reference quirk, kept.
+      dpdu = (duv12y * dp02 - duv02y * dp12) / inv_det;   // No texture class reads dpdu / dpdv or the normal built from them, so it cannot
+      dpdv = (-duv12x * dp02 + duv02x * dp12) / inv_det;  // change a mask value - which is why the device does not form them at all.
+    } else {
+      dpdu = (duv12y * dp02 - duv02y * dp12) * inv_det;
+      dpdv = (-duv12x * dp02 + duv02x * dp12) * inv_det;
+    }
+  }
+  if (degenerate_uv || length_squared(cross(dpdu, dpdv)) == 0.0f) coordinate_system(normalize(cross(p2 - p0, p1 - p0)), &dpdu, &dpdv);
+  SurfaceInteraction si;
+  V3 p_hit = p0 * h.b0 + p1 * h.b1 + p2 * h.b2;
+  si.hit = interaction_new(p_hit, v3(0, 0, 0), normalize(-ray.d), v3(0, 0, 0));
+  si.uv = P2{uv[0].x * h.b0 + uv[1].x * h.b1 + uv[2].x * h.b2, uv[0].y * h.b0 + uv[1].y * h.b1 + uv[2].y * h.b2};
+  si.dpdu = dpdu; si.dpdv = dpdv;
+  if (alpha >= 0 && tex_eval_f(alpha, si) == 0.0f) return true;
+  if (shadow_ray && shadow_alpha >= 0 && tex_eval_f(shadow_alpha, si) == 0.0f) return true;
+  return false;
+}
+
+// mesh.rs:321-425 (the alpha test of :353-370 is tri_alpha_rejects above, applied by the callers right after the hit test)
 void Scene::tri_fill_interaction(int tri, const Ray& ray, const TriHit& h, SurfaceInteraction* out) const {
   V3 p0, p1, p2; tri_verts(tri, &p0, &p1, &p2);
   const float b0 = h.b0, b1 = h.b1, b2 = h.b2;
@@ -263,7 +298,7 @@ bool Scene::intersect_raw(Ray& ray, int* prim_out, TriHit* hit_out, TraceCounter
           TriHit h;
           // `result = prim.intersect(ray).or(result)`: every accepted test replaces the result and
           // shrinks ray.t_max (GeometricPrimitive::intersect, primitive.rs:45-51)
-          if (tri_test(ordered[prim], ray, &h)) {
+          if (tri_test(ordered[prim], ray, &h) && !tri_alpha_rejects(ordered[prim], ray, h, false)) {
             if (tc) tc->tri_hits += 1;
             ray.t_max = h.t; found = true; best_prim = prim; best = h;
           }
@@ -306,7 +341,7 @@ bool Scene::intersect_p(const Ray& ray, TraceCounters* tc) const {  // bvh/mod.r
         for (int i = 0; i < node.n_prims; ++i) {
           if (tc) tc->tris += 1;
           TriHit h;
-          if (tri_test(ordered[node.offset + i], ray, &h)) { if (tc) tc->tri_hits += 1; return true; }
+          if (tri_test(ordered[node.offset + i], ray, &h) && !tri_alpha_rejects(ordered[node.offset + i], ray, h, true)) { if (tc) tc->tri_hits += 1; return true; }
         }
         if (to_visit == 0) break;
         cur = stack[--to_visit];
@@ -357,7 +392,7 @@ float Scene::shape_pdf_wi(int tri, const Interaction& ref, V3 wi, TraceCounters*
   Ray ray = spawn_ray(ref, wi);
   TriHit h;
   if (tc) tc->tris += 1;
-  if (!tri_test(tri, ray, &h)) return 0.0f;
+  if (!tri_test(tri, ray, &h) || tri_alpha_rejects(tri, ray, h, false)) return 0.0f;  // Shape::pdf_wi calls self.intersect (shapes/mod.rs:61)
   SurfaceInteraction li; tri_fill_interaction(tri, ray, h, &li);
   return distance_squared(ref.p, li.hit.p) / (fabsf(dot(li.hit.n, -wi)) * tri_area(tri));
 }

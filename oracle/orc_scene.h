@@ -201,6 +201,7 @@ struct Scene {
   std::vector<int32_t> tri_material;
   std::vector<int32_t> tri_light;   // index into lights or -1
   std::vector<uint8_t> tri_flags;   // bit0: reverse_orientation ^ swaps_handedness; bit1: mesh has N; bit2: has UV; bit3: has S
+  std::vector<int32_t> tri_alpha;   // 2 per triangle: float-texture ids of mesh.alpha_mask / mesh.shadow_alpha_mask or -1 (mesh.rs:38-39); empty = none
   std::vector<Texture> textures;
   std::vector<std::shared_ptr<MipMap>> mips;
   std::vector<Material> materials;
@@ -230,6 +231,7 @@ struct Scene {
   // ---- build / traversal (orc_scene.cpp)
   void build_bvh();
   bool tri_test(int tri, const Ray& ray, TriHit* h) const;          // mesh.rs:215-319 / 428-532 (shared hit test)
+  bool tri_alpha_rejects(int tri, const Ray& ray, const TriHit& h, bool shadow_ray) const;  // mesh.rs:353-370 (intersect), 534-582 (intersect_p)
   void tri_fill_interaction(int tri, const Ray& ray, const TriHit& h, SurfaceInteraction* si) const;  // mesh.rs:321-425
   bool intersect_raw(Ray& ray, int* prim_out, TriHit* hit_out, TraceCounters* tc) const;  // bvh/mod.rs:366-433
   bool intersect(Ray& ray, SurfaceInteraction* si, TraceCounters* tc) const;

@@ -28,6 +28,7 @@ struct DScene {
   const float4* quads;  // n_nodes x 128 B grandchild records of the interior nodes (NULL when not built), see k_trace_quad
   const float4* tri_p; unsigned n_tris;
   const float* tri_n; const float* tri_uv; const float* tri_s;
+  const int2* tri_alpha;  // {alpha, shadowalpha} texture ids of the triangles whose flags carry bit 4 / bit 5 (NULL: no mask in the scene)
   const DTexture* textures; const DImage* images; const DMaterial* materials; const DLight* lights;
   int n_lights; int n_infinite; int infinite_ids[4];
   int needs_differentials;  // some texture reads dudx.. / dpdx.. (image maps, closed-form checkerboards, fbm)

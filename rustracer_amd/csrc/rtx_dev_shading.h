@@ -208,6 +208,29 @@ RT_DEV rgb3 tex_eval_c(const DScene& sc, int id, const SurfaceInteraction& si) {
 }
 RT_DEV float tex_eval_cf(const DScene& sc, int id, const SurfaceInteraction& si) { return tex_eval_c(sc, id, si).r; }
 
+// ---------------------------------------------------------------- alpha masks (rc/shapes/mesh.rs:353-370, 534-582)
+// An accepted hit test is no hit when the mesh's "alpha" float texture evaluates to 0 at the hit (and, for intersect_p, its "shadowalpha"
+// texture). The reference evaluates the texture on a local SurfaceInteraction(p_hit, uv_hit, -ray.d, dpdu, dpdv) without ray differentials
+// (dudx .. = 0, dpdx = dpdy = 0: an image map then takes its bilinear level-0 lookup). No texture class reads dpdu / dpdv or the normal, so the
+// reference's `/ inv_det` in intersect_p's dpdu (mesh.rs:549-550, where intersect multiplies) cannot change an outcome; they are not formed here.
+RT_DEVN bool tri_alpha_rejects(const DScene& sc, int prim, const TriHit& h, bool shadow_ray) {
+  const unsigned flags = tri_flags(sc.tri_p, prim);
+  const unsigned want = shadow_ray ? 48u : 16u;
+  if (!(flags & want)) return false;
+  f3 p0, p1, p2; load_tri(sc.tri_p, prim, p0, p1, p2);
+  f2 uv0 = mk2(0.0f, 0.0f), uv1 = mk2(1.0f, 0.0f), uv2 = mk2(1.0f, 1.0f);  // mesh.rs:201-211
+  if (flags & 4u) { const float* u = sc.tri_uv + 6 * (size_t)prim; uv0 = mk2(u[0], u[1]); uv1 = mk2(u[2], u[3]); uv2 = mk2(u[4], u[5]); }
+  SurfaceInteraction si;
+  si.hit.p = p0 * h.b0 + p1 * h.b1 + p2 * h.b2;
+  si.uv = mk2(uv0.x * h.b0 + uv1.x * h.b1 + uv2.x * h.b2, uv0.y * h.b0 + uv1.y * h.b1 + uv2.y * h.b2);
+  si.dudx = si.dvdx = si.dudy = si.dvdy = 0.0f; si.dpdx = si.dpdy = mk3(0, 0, 0);
+  si.hit.p_error = si.hit.wo = si.hit.n = si.dpdu = si.dpdv = si.sh_n = si.sh_dpdu = si.sh_dpdv = mk3(0, 0, 0); si.prim = prim;
+  const int2 ids = sc.tri_alpha[prim];
+  if ((flags & 16u) && tex_eval(sc, ids.x, si).r == 0.0f) return true;
+  if (shadow_ray && (flags & 32u) && tex_eval(sc, ids.y, si).r == 0.0f) return true;
+  return false;
+}
+
 // ---------------------------------------------------------------- materials (rc/material/*.rs)
 RT_DEV Lobe lobe_zero(int kind) {
   Lobe l; l.kind = kind; l.fr_kind = FR_NOOP; l.r = mkc(0, 0, 0); l.t = mkc(0, 0, 0); l.k = mkc(0, 0, 0);
@@ -522,12 +545,14 @@ RT_DEV LiSample area_light_sample_li(const DScene& sc, const DLight& l, const In
   s.li = area_light_l(l, normal, -s.wi);
   return s;
 }
-// Shape::pdf_wi (shapes/mod.rs:59-68): re-intersects the emitter triangle
+// Shape::pdf_wi (shapes/mod.rs:59-68): re-intersects the emitter triangle (Triangle::intersect, alpha mask included)
+template <bool GENERAL = true>  // false: the scene is known to hold no masked triangle (k_shade<1>: no out-of-line call in the kernel)
 RT_DEV float area_light_pdf_li(const DScene& sc, const DLight& l, const Interaction& ref, f3 wi) {
   Ray ray = spawn_ray(ref, wi);
   f3 p0, p1, p2; load_tri(sc.tri_p, l.prim, p0, p1, p2);
   TriHit h;
   if (!tri_test(p0, p1, p2, ray, h)) return 0.0f;
+  if (GENERAL && sc.tri_alpha != nullptr && tri_alpha_rejects(sc, l.prim, h, false)) return 0.0f;
   f3 p, n; tri_hit_point_normal_inl(sc, l.prim, h, p, n);
   return distance_squared(ref.p, p) / (fabsf(dot(n, -wi)) * l.area);
 }

@@ -54,7 +54,8 @@ struct rt_scene {
   DevBuf pairs, tmin_stack;  // child-pair node records and the HBM half of the traversal stack (k_trace_pair)
   bool use_pairs = false;
   DevBuf quads; bool use_quads = false; int quad_stack_depth = 0;  // four-wide records of the any-hit kernel (k_trace_quad)
-  DevBuf nodes, tri_p, tri_n, tri_uv, tri_s, textures, images, materials, lights, texels, dist;
+  DevBuf nodes, tri_p, tri_n, tri_uv, tri_s, tri_alpha, textures, images, materials, lights, texels, dist;
+  bool general_prims = false;  // alpha-masked triangles: traced by k_trace_big<.., GENERAL> only
   std::vector<DLight> h_lights;
   // light distribution tables (built per render, rc/integrator/path.rs:86-94)
   DevBuf ld_func, ld_cdf, ld_int, ld_mark, ld_list;
@@ -129,7 +130,16 @@ extern "C" int rt_scene_create(const rt_scene_desc* desc, int device, rt_scene**
     if ((m.flags & RT_TRI_HAS_S) && !desc->tri_s) { delete s; return fail(RT_ERR_INVALID, "tri flags need tri_s"); }
     if (m.material < 0 || (uint32_t)m.material >= desc->n_materials) { delete s; return fail(RT_ERR_INVALID, "material index out of range"); }
     if (m.light >= (int)desc->n_lights) { delete s; return fail(RT_ERR_INVALID, "light index out of range"); }
+    if (m.flags & (RT_TRI_HAS_ALPHA | RT_TRI_HAS_SHADOW_ALPHA)) {
+      if (!desc->tri_alpha) { delete s; return fail(RT_ERR_INVALID, "tri flags need tri_alpha"); }
+      for (int k = 0; k < 2; ++k)
+        if ((m.flags & (k == 0 ? RT_TRI_HAS_ALPHA : RT_TRI_HAS_SHADOW_ALPHA)) && (desc->tri_alpha[2 * i + k] < 0 || (uint32_t)desc->tri_alpha[2 * i + k] >= desc->n_textures)) {
+          delete s; return fail(RT_ERR_INVALID, "alpha texture out of range");
+        }
+      s->general_prims = true;
+    }
   }
+  if (s->general_prims) TRY_RC(upload(s->tri_alpha, desc->tri_alpha, (size_t)desc->n_tris * 8));
   TRY_RC(upload(s->tri_p, tp.data(), tp.size() * 4));
   if (desc->tri_n) TRY_RC(upload(s->tri_n, desc->tri_n, (size_t)desc->n_tris * 36));
   if (desc->tri_uv) TRY_RC(upload(s->tri_uv, desc->tri_uv, (size_t)desc->n_tris * 24));
@@ -312,6 +322,7 @@ extern "C" int rt_scene_create(const rt_scene_desc* desc, int device, rt_scene**
   d.nodes = s->nodes.as<float4>(); d.n_nodes = desc->n_nodes;
   d.tri_p = s->tri_p.as<float4>(); d.n_tris = desc->n_tris;
   d.tri_n = s->tri_n.as<float>(); d.tri_uv = s->tri_uv.as<float>(); d.tri_s = s->tri_s.as<float>();
+  d.tri_alpha = s->general_prims ? s->tri_alpha.as<int2>() : nullptr;
   d.textures = s->textures.as<DTexture>(); d.images = s->images.as<DImage>(); d.materials = s->materials.as<DMaterial>(); d.lights = s->lights.as<DLight>();
   d.n_lights = (int)desc->n_lights;
   d.wb_min = f3{desc->nodes[0].bmin[0], desc->nodes[0].bmin[1], desc->nodes[0].bmin[2]};
@@ -342,8 +353,9 @@ extern "C" int rt_scene_create(const rt_scene_desc* desc, int device, rt_scene**
     if (m.kind != RT_MAT_MATTE || m.slot[RT_SLOT_KD] < 0 || !sigma_zero || m.bump >= 0) { s->lambert_materials = false; break; }
   }
   for (uint32_t i = 0; i < desc->n_lights; ++i) if (desc->lights[i].kind != RT_LIGHT_DIFFUSE_AREA) s->lambert_only = false;
+  if (s->general_prims) s->lambert_only = false;  // k_shade<1> re-intersects emitters without the mask test
   s->n_materials = desc->n_materials;
-  s->small = desc->n_nodes <= RT_SMALL_NODES && desc->n_tris <= RT_SMALL_TRIS;
+  s->small = desc->n_nodes <= RT_SMALL_NODES && desc->n_tris <= RT_SMALL_TRIS && !s->general_prims;
   {  // tree height bounds the number of simultaneously pending stack entries
     std::vector<int> depth(desc->n_nodes, 0); int maxd = 0;
     for (uint32_t i = 0; i < desc->n_nodes; ++i) {
@@ -358,7 +370,7 @@ extern "C" int rt_scene_create(const rt_scene_desc* desc, int device, rt_scene**
     s->stack_depth = maxd + 1;
   }
   d.pairs = nullptr; d.quads = nullptr;
-  if (!s->small) {  // LDS-resident scenes keep the one-node-per-step loop: the pair form measured no faster there
+  if (!s->small && !s->general_prims) {  // LDS-resident scenes keep the one-node-per-step loop: the pair form measured no faster there
     // child-pair records for k_trace_pair: {A.min.xyz, A.max.x} {A.max.yz, code A, code B} {B.min.xyz, B.max.x} {B.max.yz, -, -}
     // (a root that is itself a leaf - every centroid coincides - is never seen by code_of(): its count must fit the 5-bit field too)
     bool ok = desc->n_nodes < (1u << 29) && desc->n_tris < (1u << 26) && desc->nodes[0].n_prims <= 32;
@@ -547,6 +559,11 @@ template <bool ANY, bool COUNT>
 static void launch_trace_c(rt_scene* s, const TraceIO& io, const unsigned* queue, const unsigned* count_ptr, unsigned shard_cap, unsigned count_static,
                            unsigned long long* stats, int st_rays, int st_nodes, int st_tris, hipStream_t stream) {
 #define RT_ARGS s, io, queue, count_ptr, shard_cap, count_static, stats, st_rays, st_nodes, st_tris, stream
+  if (s->general_prims) {  // alpha-masked triangles: the one kernel whose leaf loop evaluates masks
+    if (s->stack_depth <= 32) hipLaunchKernelGGL((k_trace_big<ANY, COUNT, 128, 32, true>), dim3(trace_grid<ANY, false, 128, 32>(s)), dim3(128), 0, stream, s->d, io, queue, count_ptr, shard_cap, count_static, stats, st_rays, st_nodes, st_tris);
+    else hipLaunchKernelGGL((k_trace_big<ANY, COUNT, 128, 64, true>), dim3(trace_grid<ANY, false, 128, 64>(s)), dim3(128), 0, stream, s->d, io, queue, count_ptr, shard_cap, count_static, stats, st_rays, st_nodes, st_tris);
+    return;
+  }
   if (s->small) {
     if (s->stack_depth <= 16) launch_trace_v<ANY, COUNT, true, 256, 16>(RT_ARGS);
     else if (s->stack_depth <= 32) launch_trace_v<ANY, COUNT, true, 256, 32>(RT_ARGS);

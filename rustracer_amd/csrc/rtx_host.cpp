@@ -197,11 +197,12 @@ struct HostLight {
 struct rtxh_scene {
   // input soup
   std::vector<float> P, N, UV, S; std::vector<int32_t> idx, tri_mat, tri_light; std::vector<uint8_t> tri_flags;
+  std::vector<int32_t> tri_alpha;  // 2 per triangle {alpha, shadowalpha} float-texture ids or -1 (empty: no mesh carries a mask)
   std::vector<rt_texture> textures; std::vector<rt_material> materials; std::vector<MipLevels> mips; std::vector<HostLight> lights;
   // BVH products
   std::vector<rt_bvh_node> nodes; std::vector<int32_t> ordered;
   // flattened arrays (leaf order)
-  std::vector<float> f_p, f_n, f_uv, f_s; std::vector<rt_tri_meta> f_meta; std::vector<rt_light> f_lights; std::vector<rt_image> f_images;
+  std::vector<float> f_p, f_n, f_uv, f_s; std::vector<rt_tri_meta> f_meta; std::vector<int32_t> f_alpha; std::vector<rt_light> f_lights; std::vector<rt_image> f_images;
   bool committed = false;
   rt_scene* dev = nullptr;
   size_t n_tris() const { return idx.size() / 3; }
@@ -399,6 +400,18 @@ int finish_commit(rtxh_scene* s) {
     }
     s->f_meta[i] = rt_tri_meta{s->tri_mat[t], s->tri_light[t], (uint32_t)s->tri_flags[t], (uint32_t)t};
   }
+  s->f_alpha.clear();
+  if (!s->tri_alpha.empty()) {
+    s->f_alpha.assign(nt * 2, -1);
+    for (size_t i = 0; i < nt; ++i) {
+      const int32_t t = s->ordered[i];
+      for (int k = 0; k < 2; ++k) {
+        const int32_t id = s->tri_alpha[2 * (size_t)t + k];
+        if (id >= (int32_t)s->textures.size()) return fail(RT_ERR_INVALID, "alpha texture out of range");
+        if (id >= 0) { s->f_alpha[2 * i + k] = id; s->f_meta[i].flags |= (k == 0 ? RT_TRI_HAS_ALPHA : RT_TRI_HAS_SHADOW_ALPHA); }
+      }
+    }
+  }
   // images
   s->f_images.clear();
   for (const MipLevels& m : s->mips) {
@@ -435,7 +448,7 @@ rt_scene_desc make_desc(rtxh_scene* s) {
   d.n_nodes = (uint32_t)s->nodes.size(); d.nodes = s->nodes.data();
   d.n_tris = (uint32_t)s->n_tris(); d.tri_p = s->f_p.data();
   d.tri_n = s->f_n.empty() ? nullptr : s->f_n.data(); d.tri_uv = s->f_uv.empty() ? nullptr : s->f_uv.data(); d.tri_s = s->f_s.empty() ? nullptr : s->f_s.data();
-  d.tri_meta = s->f_meta.data();
+  d.tri_meta = s->f_meta.data(); d.tri_alpha = s->f_alpha.empty() ? nullptr : s->f_alpha.data();
   d.n_textures = (uint32_t)s->textures.size(); d.textures = s->textures.data();
   d.n_images = (uint32_t)s->f_images.size(); d.images = s->f_images.data();
   d.n_materials = (uint32_t)s->materials.size(); d.materials = s->materials.data();
@@ -506,6 +519,13 @@ int rtxh_scene_set_mesh(rtxh_scene* s, const float* P, int32_t nv, const int32_t
     uint8_t f = tri_flags[t];
     if (((f & RT_TRI_HAS_N) && !N) || ((f & RT_TRI_HAS_UV) && !UV) || ((f & RT_TRI_HAS_S) && !S)) return fail(RT_ERR_INVALID, "flags promise a missing attribute");
   }
+  s->committed = false;
+  return RT_OK;
+}
+
+int rtxh_scene_set_alpha(rtxh_scene* s, const int32_t* tri_alpha2) {
+  if (!s) return fail(RT_ERR_INVALID, "null scene");
+  if (!tri_alpha2) s->tri_alpha.clear(); else s->tri_alpha.assign(tri_alpha2, tri_alpha2 + 2 * s->n_tris());
   s->committed = false;
   return RT_OK;
 }

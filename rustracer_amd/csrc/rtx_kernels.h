@@ -572,7 +572,10 @@ __global__ void __launch_bounds__(BLOCK) k_trace(DScene sc, TraceIO io, const un
 #ifndef RT_REFILL_MIN
 #define RT_REFILL_MIN 16
 #endif
-template <bool ANY, bool COUNT, int BLOCK, int DEPTH>
+// GENERAL: the scene holds primitives whose hit test is more than the watertight triangle test - alpha-masked triangles (an accepted hit is
+// dropped when its mask texture evaluates to 0, mesh.rs:353-370 / 534-582). Such scenes trace through this kernel only; every other kernel
+// keeps the bare triangle loop.
+template <bool ANY, bool COUNT, int BLOCK, int DEPTH, bool GENERAL = false>
 __global__ void __launch_bounds__(BLOCK) k_trace_big(DScene sc, TraceIO io, const unsigned* __restrict__ queue, const unsigned* __restrict__ shard_counts, unsigned shard_cap,
                                                      unsigned count_static, unsigned long long* stats, int st_rays, int st_nodes, int st_tris) {
   const float4* __restrict__ ray_o = io.ray_o; const float4* __restrict__ ray_d = io.ray_d; const size_t rs = io.ray_stride;
@@ -650,6 +653,7 @@ __global__ void __launch_bounds__(BLOCK) k_trace_big(DScene sc, TraceIO io, cons
         if (COUNT) n_tris += 1;
         TriHit h;
         if (tri_test_pre(p0, p1, p2, ray, rp, h)) {
+          if (GENERAL && tri_alpha_rejects(sc, leaf_off + i, h, ANY)) continue;
           found = true;
           if (ANY) break;
           ray.t_max = h.t; prim = leaf_off + i; hit = h;  // `.or(result)`: later accepted hits replace
@@ -1325,7 +1329,7 @@ __global__ void __launch_bounds__(256, MODE == 1 ? RT_SHADE_MIN_WAVES : RT_SHADE
               if (!is_black(f) && bs.pdf > 0.0f) {
                 float weight = 1.0f; bool go = true;
                 if (!(bs.type & BSDF_SPECULAR)) {
-                  float lp = (MODE == 1) ? area_light_pdf_li(sc, light, si.hit, bs.wi) : light_pdf_li(sc, light, si.hit, bs.wi);
+                  float lp = (MODE == 1) ? area_light_pdf_li<false>(sc, light, si.hit, bs.wi) : light_pdf_li(sc, light, si.hit, bs.wi);
                   if (lp == 0.0f) go = false;  // `return ld`
                   else weight = power_heuristic1(bs.pdf, lp);
                 }

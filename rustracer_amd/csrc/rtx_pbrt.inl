@@ -49,7 +49,7 @@ struct PbrtGraphicsState {  // rc/api.rs:300-311
 };
 
 struct PbrtSoup {  // triangle soup: world space for the scene, instance space for an ObjectBegin .. ObjectEnd block
-  std::vector<float> P, N, UV, S; std::vector<int32_t> idx, tri_mat, tri_light; std::vector<uint8_t> tri_flags;
+  std::vector<float> P, N, UV, S; std::vector<int32_t> idx, tri_mat, tri_light, tri_alpha /* 2 per triangle */; std::vector<uint8_t> tri_flags;
   bool any_n = false, any_uv = false, any_s = false;
   size_t n_verts() const { return P.size() / 3; }
   // appends nv vertices (attributes may be null: zero-filled once any mesh carries them); returns the first vertex index
@@ -351,7 +351,15 @@ struct PbrtLoader {
       if (ply.UV) vuv.assign(ply.UV, ply.UV + (size_t)ply.n_verts * 2);
       rtxh_ply_free(&ply);
     } else return fail_("shape \"" + name + "\" is not supported (triangle meshes only)");
-    if (p.find("alpha", {"texture", "float"}) || p.find("shadowalpha", {"texture", "float"})) return fail_("alpha masks are not supported");
+    // "alpha" / "shadowalpha" (TriangleMesh::create mesh.rs:134-156, plymesh.rs:143-165): a named float texture (unknown name: logged, no mask),
+    // else the constant-0 texture when the float parameter is exactly 0
+    auto mask = [&](const char* n) -> int {
+      const std::string tn = p.texture(n);
+      if (!tn.empty()) { auto it = gs.float_textures.find(tn); if (it != gs.float_textures.end()) return it->second; warn("alpha texture not found"); return -1; }
+      if (p.one_float(n, 1.0f) == 0.0f) { const float z[3] = {0.0f, 0.0f, 0.0f}; return const_tex(z); }
+      return -1;
+    };
+    const int alpha_tex = mask("alpha"), shadow_alpha_tex = mask("shadowalpha");
     const size_t nv = vp.size() / 3, nt = vi.size() / 3;
     for (int32_t i : vi) if (i < 0 || (size_t)i >= nv) return fail_("triangle index out of range");
     if (nt == 0) return true;
@@ -375,7 +383,7 @@ struct PbrtLoader {
     for (size_t t = 0; t < nt; ++t) {
       const int32_t tri_index = (int32_t)(soup.idx.size() / 3);
       for (int k = 0; k < 3; ++k) soup.idx.push_back((int32_t)(v0 + vi[3 * t + k]));
-      soup.tri_mat.push_back(mat); soup.tri_flags.push_back(flags);
+      soup.tri_mat.push_back(mat); soup.tri_flags.push_back(flags); soup.tri_alpha.push_back(alpha_tex); soup.tri_alpha.push_back(shadow_alpha_tex);
       if (emit) {
         if (rtxh_scene_add_light(scene, RT_LIGHT_DIFFUSE_AREA, tri_index, L, two_sided ? 1 : 0, nullptr, -1, nullptr, nullptr) < 0) return fail_(rtxh_last_error());
         soup.tri_light.push_back(n_lights++);
@@ -416,6 +424,7 @@ struct PbrtLoader {
     for (size_t t = 0; t < o.idx.size() / 3; ++t) {
       for (int k = 0; k < 3; ++k) world.idx.push_back((int32_t)(v0 + o.idx[3 * t + k]));
       world.tri_mat.push_back(o.tri_mat[t]); world.tri_light.push_back(-1); world.tri_flags.push_back((uint8_t)(o.tri_flags[t] ^ toggle));
+      world.tri_alpha.push_back(o.tri_alpha[2 * t]); world.tri_alpha.push_back(o.tri_alpha[2 * t + 1]);
     }
     return true;
   }
@@ -625,7 +634,10 @@ int pbrt_load_text(const std::string& text, const std::string& base_dir, rtxh_pb
     const PbrtSoup& w = L.world;
     const int32_t nv = (int32_t)w.n_verts(), nt = (int32_t)(w.idx.size() / 3);
     if (rtxh_scene_set_mesh(L.scene, w.P.data(), nv, w.idx.data(), nt, w.any_n ? w.N.data() : nullptr, w.any_uv ? w.UV.data() : nullptr, w.any_s ? w.S.data() : nullptr,
-                            w.tri_mat.data(), w.tri_light.data(), w.tri_flags.data()) != RT_OK || rtxh_scene_commit(L.scene, L.max_prims) != RT_OK) { L.err = rtxh_last_error(); ok = false; }
+                            w.tri_mat.data(), w.tri_light.data(), w.tri_flags.data()) != RT_OK) { L.err = rtxh_last_error(); ok = false; }
+    bool any_mask = false; for (int32_t a : w.tri_alpha) any_mask |= a >= 0;
+    if (ok && any_mask && rtxh_scene_set_alpha(L.scene, w.tri_alpha.data()) != RT_OK) { L.err = rtxh_last_error(); ok = false; }
+    if (ok && rtxh_scene_commit(L.scene, L.max_prims) != RT_OK) { L.err = rtxh_last_error(); ok = false; }
   }
   if (!ok) { std::string m = L.err.empty() ? std::string("pbrt: parse error") : "pbrt: " + L.err; return fail(RT_ERR_INVALID, m); }
   out->scene = L.scene; L.scene_handed_over = true; out->max_prims_per_node = L.max_prims; out->n_warnings = L.warnings;

@@ -169,6 +169,10 @@ class HostScene:
         self._keep = (P, idx, N, UV, S, mat, light, flags)
         _check(L.rtxh_scene_set_mesh(self.h, _p(P), P.shape[0], _p(idx, C.c_int32), idx.shape[0], _p(N), _p(UV), _p(S),
                                      _p(mat, C.c_int32), _p(light, C.c_int32), _p(flags, C.c_uint8)), "set_mesh")
+        alpha = desc.alpha_ids() if hasattr(desc, "alpha_ids") else None
+        if alpha is not None:
+            self._keep += (alpha,)
+            _check(L.rtxh_scene_set_alpha(self.h, _p(alpha, C.c_int32)), "set_alpha")
         for m in desc.mipmaps:
             h, w = m.data.shape[:2]
             _check(L.rtxh_scene_add_mipmap(self.h, w, h, _p(m.data), int(m.trilinear), C.c_float(m.max_aniso), m.wrap), "add_mipmap")

@@ -186,6 +186,11 @@ class _Writer:
             assert mats.size == 1
             flags = int(d._flags[m][0])
             name = self.material(int(mats[0]))
+            masks = ""  # "alpha" / "shadowalpha" of the mesh (mesh.rs:134-156): a float texture, or the float 0
+            if getattr(d, "_alpha", None):
+                for pname, tid in zip(("alpha", "shadowalpha"), (int(x) for x in d._alpha[m][0])):
+                    if tid >= 0:
+                        masks += " " + self.param(pname, tid, _F)
             o.append("AttributeBegin")
             o.append(f'  NamedMaterial "{name}"')
             if flags & sd.TRI_FLIP:
@@ -200,7 +205,7 @@ class _Writer:
                 from .ingest import write_ply
                 name = f"{self.stem}_mesh{m}.ply"
                 write_ply(os.path.join(self.dir, name), d._P[m], d._idx[m] - nv0, N=d._N[m] if flags & sd.TRI_HAS_N else None, UV=d._UV[m] if flags & sd.TRI_HAS_UV else None)
-                shape = f'  Shape "plymesh" "string filename" "{name}"'
+                shape = f'  Shape "plymesh" "string filename" "{name}"' + masks
             else:
                 shape = f'  Shape "trianglemesh" "integer indices" [{" ".join(str(int(x)) for x in (d._idx[m] - nv0).reshape(-1))}] "point P" [{_nums(d._P[m])}]'
                 if flags & sd.TRI_HAS_N:
@@ -209,6 +214,7 @@ class _Writer:
                     shape += f' "float uv" [{_nums(d._UV[m])}]'
                 if flags & sd.TRI_HAS_S:
                     shape += f' "vector S" [{_nums(d._S[m])}]'
+                shape += masks
             o.append(shape)
             o.append("AttributeEnd")
             nv0 += nv

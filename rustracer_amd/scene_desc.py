@@ -125,6 +125,7 @@ class SceneDesc:
         self._mat: List[np.ndarray] = []
         self._light: List[np.ndarray] = []
         self._flags: List[np.ndarray] = []
+        self._alpha: List[np.ndarray] = []  # per triangle (alpha, shadowalpha) float-texture ids or -1 (mesh.rs:134-156)
         self._nv = 0
         self._nt = 0
         self.textures: List[Texture] = []
@@ -252,7 +253,7 @@ class SceneDesc:
 
     # ---- geometry ------------------------------------------------------------------------
     def add_mesh(self, P, idx, material: int, N=None, UV=None, S=None, reverse_orientation=False,
-                 emission=None, two_sided=False) -> int:
+                 emission=None, two_sided=False, alpha=None, shadow_alpha=None) -> int:
         """Append a triangle mesh whose points are already in world space (identity CTM).
         Returns the index of its first triangle. One DiffuseAreaLight per triangle when `emission`
         is given (rc/api.rs:933-946), appended to the light list in triangle order."""
@@ -273,6 +274,10 @@ class SceneDesc:
         self._idx.append(idx + self._nv)
         self._mat.append(np.full(nt, material, dtype=np.int32))
         self._flags.append(np.full(nt, flags, dtype=np.uint8))
+        # "alpha" / "shadowalpha": a float texture id, or a number (only 0 makes a mask: the constant-0 texture, mesh.rs:142-144, 154-156)
+        am = [(-1 if a is None else (int(a) if isinstance(a, (int, np.integer)) and not isinstance(a, bool) else (self.const_tex(0.0) if float(a) == 0.0 else -1)))
+              for a in (alpha, shadow_alpha)]
+        self._alpha.append(np.tile(np.int32(am), (nt, 1)))
         first = self._nt
         if emission is not None:
             ids = np.arange(len(self.lights), len(self.lights) + nt, dtype=np.int32)
@@ -335,6 +340,11 @@ class SceneDesc:
         mat = np.ascontiguousarray(np.concatenate(self._mat), dtype=np.int32)
         light = np.ascontiguousarray(np.concatenate(self._light), dtype=np.int32)
         return P, idx, N, UV, S, mat, light, flags
+
+    def alpha_ids(self):
+        """(n_tris, 2) int32 {alpha, shadowalpha} texture ids, or None when no mesh carries a mask."""
+        a = np.ascontiguousarray(np.concatenate(self._alpha), dtype=np.int32) if self._alpha else None
+        return a if a is not None and (a >= 0).any() else None
 
 
 def _f(v):
