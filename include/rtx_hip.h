@@ -213,11 +213,28 @@ int rt_env_distribution(const rt_image* image, int32_t width, int32_t height, in
 
 /* Renders one frame: the body of renderer::render (rc/renderer.rs:22-143) — preprocess (light
  * distribution), per-pixel sampler tables, camera rays, PathIntegrator::li for every sample,
- * radiance scrubbing and Film::add_sample/merge. Blocking. film_xyzw: W*H*4 floats over the
+ * radiance scrubbing and Film::add_sample/merge. Blocking; calls on one rt_scene from several threads are safe and take turns (they share the
+ * scene's workspace), calls on different rt_scene objects run concurrently. The light distribution is built by the first frame that needs it
+ * and kept (the scene is immutable). film_xyzw: W*H*4 floats over the
  * cropped pixel bounds, (X, Y, Z, filter_weight_sum) per pixel as Film's Pixel (film.rs:38-43).
  * `stream` is a hipStream_t (NULL = the null stream). */
 int rt_render(rt_scene* scene, const rt_camera* camera, const rt_film_desc* film, const rt_sampler_desc* sampler,
               const rt_path_desc* path, const rt_shard* shard, uint32_t flags, void* stream, float* film_xyzw, rt_stats* stats);
+
+/* Several GPUs of one node from one process (north_star: "partition the film across the 8 GPUs of one node"). The reference's
+ * render loop hands 16 x 16 tiles to worker threads from a shared queue and merges finished tiles into the film (rc/renderer.rs:47-71,
+ * rc/film.rs:177-194); here the workers are GPUs. rt_multi_create replicates the scene on every listed device (a device may be listed more than
+ * once). rt_multi_render cuts the frame into n_devices * chunks_per_device chunks of interleaved 16-row tile rows, lets one host thread per
+ * device pull chunks from a shared counter (chunks_per_device = 1: the static split; > 1: the dynamic queue for frames whose rows differ in
+ * cost), and sends only the film rows a chunk can have touched to devices[0] over xGMI (hipMemcpyPeerAsync), where they are summed in chunk
+ * order - the gather that replaces Film::merge_film_tile. No collective while paths are traced. film_xyzw: host memory, or memory of
+ * devices[0] with RT_FLAG_FILM_ON_DEVICE. total / per_device (n_devices entries) may be NULL; total->ms_total is the wall time of the call.
+ * One process per GPU (torch.distributed / RCCL harness) uses rt_render with rt_shard instead. */
+typedef struct rt_multi rt_multi;
+int rt_multi_create(const rt_scene_desc* desc, const int32_t* devices, int32_t n_devices, rt_multi** out);
+void rt_multi_destroy(rt_multi* multi);
+int rt_multi_render(rt_multi* multi, const rt_camera* camera, const rt_film_desc* film, const rt_sampler_desc* sampler, const rt_path_desc* path,
+                    int32_t chunks_per_device, uint32_t flags, float* film_xyzw, rt_stats* total, rt_stats* per_device);
 
 /* Kernel-level entry points used by the parity tests.
  * rays: n*8 floats (o.xyz, t_max, d.xyz, unused). closest: hits n*4 floats (t, prim as int bits

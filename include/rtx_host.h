@@ -89,6 +89,11 @@ int rtxh_look_at(const float* pos, const float* look, const float* up, float* m1
 /* renderer::render through the HIP backend. film_xyzw: (y1-y0)*(x1-x0)*4 floats over the cropped pixel bounds
  * (host pointer, or device pointer with RT_FLAG_FILM_ON_DEVICE). */
 int rtxh_render(rtxh_scene*, const rtxh_render_params*, void* hip_stream, float* film_xyzw, rt_stats* stats);
+/* The same frame on several GPUs of this process (rt_multi_* in rtx_hip.h): the scene is replicated on `devices` (kept for later calls with the
+ * same list), host threads pull chunks of tile rows, the film is gathered on devices[0] and returned in host memory (or in memory of devices[0]
+ * with RT_FLAG_FILM_ON_DEVICE). rank / world_size of the parameters are ignored. */
+int rtxh_render_multi(rtxh_scene*, const rtxh_render_params*, const int32_t* devices, int32_t n_devices, int32_t chunks_per_device, float* film_xyzw,
+                      rt_stats* total, rt_stats* per_device /* n_devices entries or NULL */);
 /* Kernel-level pass-throughs on the uploaded scene (prim indices are leaf-order). */
 int rtxh_trace(rtxh_scene*, const float* rays, uint64_t n, int32_t any_hit, float* hits4_or_occ, uint64_t counters[2]);
 int rtxh_trace_device(rtxh_scene*, const void* d_rays, uint64_t n, void* d_hits, int32_t reps, void* hip_stream, float* ms_per_launch);

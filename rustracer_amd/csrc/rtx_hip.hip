@@ -10,6 +10,9 @@
 #include <vector>
 #include <functional>
 #include <map>
+#include <atomic>
+#include <mutex>
+#include <thread>
 
 #include "../../include/rtx_hip.h"
 #include "rtx_kernels.h"
@@ -59,7 +62,8 @@ struct rt_scene {
   std::vector<DLight> h_lights;
   // light distribution tables (built per render, rc/integrator/path.rs:86-94)
   DevBuf ld_func, ld_cdf, ld_int, ld_mark, ld_list;
-  int ld_strategy_built = -1;
+  int ld_strategy_built = -1; bool ld_all_voxels = false;  // the tables are a function of the scene alone: built once per strategy, kept across frames
+  std::mutex render_mutex;  // rt_render shares the workspace below: concurrent calls on one rt_scene take turns
   // per-render workspace
   DevBuf ws[32];
   DevBuf film_acc, own_acc, film_out, counters, stats, filter_table;
@@ -452,6 +456,9 @@ extern "C" void rt_scene_destroy(rt_scene* s) {
 // PathIntegrator::preprocess (rc/integrator/path.rs:86-94) + SpatialLightDistribution::new (rc/lightdistrib.rs:67-99)
 static int build_light_distribution(rt_scene* s, int strategy, hipStream_t stream, bool all_voxels = false) {
   DScene& d = s->d;
+  // PathIntegrator::preprocess runs once per render in the reference (renderer.rs:30) - on an immutable scene it builds the same tables every
+  // time, so they are kept (a table built for every voxel serves a frame as well: the frame only reads voxels that hold a surface point)
+  if (s->ld_strategy_built == strategy && (s->ld_all_voxels || !all_voxels)) return RT_OK;
   const int nl = s->n_lights;
   const bool uniform = strategy == 1 || nl == 1 || nl == 0;
   if (uniform) {
@@ -495,7 +502,7 @@ static int build_light_distribution(rt_scene* s, int strategy, hipStream_t strea
     HIP_TRY(hipGetLastError());
   }
   d.ld_func = s->ld_func.as<float>(); d.ld_cdf = s->ld_cdf.as<float>(); d.ld_int = s->ld_int.as<float>();
-  s->ld_strategy_built = strategy;
+  s->ld_strategy_built = strategy; s->ld_all_voxels = all_voxels;
   return RT_OK;
 }
 
@@ -775,6 +782,7 @@ struct KTimer {  // HIP-event kernel timing on the render stream; events come fr
 extern "C" int rt_render(rt_scene* s, const rt_camera* cam, const rt_film_desc* film, const rt_sampler_desc* smp, const rt_path_desc* path,
                          const rt_shard* shard, uint32_t flags, void* stream_, float* film_xyzw, rt_stats* stats_out) {
   if (!s || !cam || !film || !smp || !path || !film_xyzw) return fail(RT_ERR_INVALID, "null argument");
+  std::lock_guard<std::mutex> render_lock(s->render_mutex);
   HIP_TRY(hipSetDevice(s->device));
   hipStream_t stream = (hipStream_t)stream_;
   const unsigned spp = next_pow2((unsigned)(smp->spp > 0 ? smp->spp : 1));
@@ -1034,5 +1042,149 @@ extern "C" int rt_render(rt_scene* s, const rt_camera* cam, const rt_film_desc* 
   if (h[ST_UNBUILT_VOXEL]) return fail(RT_ERR_INVALID, "a path looked up a light-distribution voxel that holds no surface (voxel marking bug)");
   stats.ms_total = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_begin).count();
   if (stats_out) *stats_out = stats;
+  return RT_OK;
+}
+
+// ---------------------------------------------------------------------------------------------- several GPUs, one process
+// renderer::render hands tiles to worker threads from a shared queue and merges each finished tile into the film (rc/renderer.rs:47-71,
+// rc/film.rs:177-194). Here the workers are GPUs: the scene is replicated, the frame is cut into chunks of interleaved 16-row tile rows
+// (rt_shard), one host thread per device takes chunks from a shared counter, renders each with rt_render into a film on its own device and sends
+// the rows that chunk can have touched - its tile rows plus the filter's reach - to the first device over xGMI (hipMemcpyPeerAsync), where they are
+// added into the frame in chunk order. Only those rows cross the links; nothing is exchanged while paths are traced.
+__global__ void k_film_add(float4* __restrict__ dst, const float4* __restrict__ src, unsigned long long n) {
+  const unsigned long long i = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const float4 a = dst[i], b = src[i];
+  dst[i] = make_float4(a.x + b.x, a.y + b.y, a.z + b.z, a.w + b.w);
+}
+struct rt_multi {
+  std::vector<int> devices; std::vector<rt_scene*> replicas; std::vector<hipStream_t> streams; std::vector<DevBuf*> chunk_film;
+  DevBuf acc; std::vector<DevBuf*> staging;  // on devices[0]: the frame, and one buffer of rows per chunk
+  ~rt_multi() {
+    for (size_t i = 0; i < replicas.size(); ++i) {
+      (void)hipSetDevice(devices[i]);
+      if (i < streams.size() && streams[i]) (void)hipStreamDestroy(streams[i]);
+      if (i < chunk_film.size()) delete chunk_film[i];
+      if (replicas[i]) rt_scene_destroy(replicas[i]);
+    }
+    if (!devices.empty()) (void)hipSetDevice(devices[0]);
+    for (DevBuf* b : staging) delete b;
+  }
+};
+extern "C" int rt_multi_create(const rt_scene_desc* desc, const int32_t* devices, int32_t n_devices, rt_multi** out) {
+  if (!desc || !devices || n_devices < 1 || !out) return fail(RT_ERR_INVALID, "bad rt_multi_create arguments");
+  int n_visible = 0;
+  if (hipGetDeviceCount(&n_visible) != hipSuccess || n_visible <= 0) return fail(RT_ERR_NO_DEVICE, "no HIP device visible; this backend has no CPU fallback");
+  rt_multi* m = new rt_multi();
+  for (int i = 0; i < n_devices; ++i) {
+    if (devices[i] < 0 || devices[i] >= n_visible) { delete m; return fail(RT_ERR_INVALID, "device index out of range"); }
+    m->devices.push_back(devices[i]); m->replicas.push_back(nullptr); m->streams.push_back(nullptr); m->chunk_film.push_back(new DevBuf());
+  }
+  for (int i = 0; i < n_devices; ++i) {  // a device may be named more than once (several workers on one GPU, each with its own replica)
+    const int rc = rt_scene_create(desc, devices[i], &m->replicas[i]);
+    if (rc != RT_OK) { const std::string e = g_err; delete m; return fail(rc, e); }
+    if (hipStreamCreateWithFlags(&m->streams[i], hipStreamNonBlocking) != hipSuccess) { delete m; return fail(RT_ERR_HIP, "stream creation failed"); }
+    if (devices[i] != devices[0]) {  // let the workers write into the first device's memory directly where the fabric allows it (else the copy is staged by the runtime)
+      int can = 0; (void)hipDeviceCanAccessPeer(&can, devices[i], devices[0]);
+      if (can) { hipError_t e = hipDeviceEnablePeerAccess(devices[0], 0); if (e != hipSuccess) (void)hipGetLastError(); }
+    }
+  }
+  *out = m;
+  return RT_OK;
+}
+extern "C" void rt_multi_destroy(rt_multi* m) { delete m; }
+
+extern "C" int rt_multi_render(rt_multi* m, const rt_camera* cam, const rt_film_desc* film, const rt_sampler_desc* smp, const rt_path_desc* path,
+                               int32_t chunks_per_device, uint32_t flags, float* film_xyzw, rt_stats* total, rt_stats* per_device) {
+  if (!m || !cam || !film || !smp || !path || !film_xyzw) return fail(RT_ERR_INVALID, "null argument");
+  const int n_dev = (int)m->devices.size();
+  const int n_chunks = n_dev * std::max(1, std::min(64, (int)chunks_per_device));
+  const int cw = film->cropped_pixel_bounds[2] - film->cropped_pixel_bounds[0], ch = film->cropped_pixel_bounds[3] - film->cropped_pixel_bounds[1];
+  const int H = film->sample_bounds[3] - film->sample_bounds[1];
+  if (cw <= 0 || ch <= 0 || H <= 0) return fail(RT_ERR_INVALID, "empty film");
+  const auto t_begin = std::chrono::steady_clock::now();
+  // film rows chunk c can have written: its tile rows, widened by the filter's reach (FilmTile::add_sample splats ceil(y - 0.5 - r) .. floor(y - 0.5 + r),
+  // film.rs:303-321; with the box filter that is the sample's own pixel, plus the one above when the sample sits exactly on the edge)
+  const int halo = (int)std::ceil(film->filter_radius[1] - 0.5f) + 1;
+  const int n_tile_rows = (H + 15) / 16;
+  auto bands = [&](int c) {
+    std::vector<std::pair<int, int>> b;  // [first, end) film rows, merged
+    for (int t = c; t < n_tile_rows; t += n_chunks) {
+      const int y0 = film->sample_bounds[1] + 16 * t - halo - film->cropped_pixel_bounds[1], y1 = film->sample_bounds[1] + std::min(16 * t + 16, H) + halo - film->cropped_pixel_bounds[1];
+      const int a = std::max(0, y0), e = std::min(ch, y1);
+      if (a >= e) continue;
+      if (!b.empty() && a <= b.back().second) b.back().second = std::max(b.back().second, e); else b.push_back({a, e});
+    }
+    return b;
+  };
+  const size_t frame_bytes = (size_t)cw * ch * 16;
+  HIP_TRY(hipSetDevice(m->devices[0]));
+  HIP_TRY(m->acc.ensure(frame_bytes));
+  HIP_TRY(hipMemset(m->acc.p, 0, frame_bytes));
+  while ((int)m->staging.size() < n_chunks) m->staging.push_back(new DevBuf());
+  std::vector<std::vector<std::pair<int, int>>> chunk_bands(n_chunks);
+  for (int c = 0; c < n_chunks; ++c) {
+    chunk_bands[c] = bands(c);
+    size_t rows = 0; for (auto& b : chunk_bands[c]) rows += (size_t)(b.second - b.first);
+    HIP_TRY(m->staging[c]->ensure(std::max<size_t>(rows * cw * 16, 16)));
+  }
+  std::atomic<int> next{0}; std::mutex err_mtx; int first_rc = RT_OK; std::string first_err;
+  std::vector<rt_stats> dev_stats(n_dev, rt_stats{});
+  auto worker = [&](int k) {
+    auto bail = [&](int rc, const std::string& msg) { std::lock_guard<std::mutex> g(err_mtx); if (first_rc == RT_OK) { first_rc = rc; first_err = msg; } };
+    if (hipSetDevice(m->devices[k]) != hipSuccess || m->chunk_film[k]->ensure(frame_bytes) != hipSuccess) { bail(RT_ERR_HIP, "device set-up failed"); return; }
+    for (;;) {  // the tile queue of renderer.rs:68-71, in chunks
+      const int c = next.fetch_add(1);
+      if (c >= n_chunks) break;
+      { std::lock_guard<std::mutex> g(err_mtx); if (first_rc != RT_OK) break; }
+      const rt_shard sh{c, n_chunks}; rt_stats st{};
+      const int rc = rt_render(m->replicas[k], cam, film, smp, path, &sh, (flags & ~RT_FLAG_FILM_ON_DEVICE) | RT_FLAG_FILM_ON_DEVICE, m->streams[k], m->chunk_film[k]->as<float>(), &st);
+      if (rc != RT_OK) { bail(rc, g_err); break; }
+      size_t off = 0;
+      for (auto& b : chunk_bands[c]) {
+        const size_t bytes = (size_t)(b.second - b.first) * cw * 16;
+        if (hipMemcpyPeerAsync((char*)m->staging[c]->p + off, m->devices[0], m->chunk_film[k]->as<char>() + (size_t)b.first * cw * 16, m->devices[k], bytes, m->streams[k]) != hipSuccess) { bail(RT_ERR_HIP, "peer copy failed"); break; }
+        off += bytes;
+      }
+      if (hipStreamSynchronize(m->streams[k]) != hipSuccess) { bail(RT_ERR_HIP, "peer copy failed"); break; }
+      rt_stats& a = dev_stats[k];
+      a.camera_rays += st.camera_rays; a.rays_closest += st.rays_closest; a.rays_shadow += st.rays_shadow; a.rays_mis += st.rays_mis;
+      a.nodes_closest += st.nodes_closest; a.nodes_shadow += st.nodes_shadow; a.nodes_mis += st.nodes_mis;
+      a.tris_closest += st.tris_closest; a.tris_shadow += st.tris_shadow; a.tris_mis += st.tris_mis; a.paths_scrubbed += st.paths_scrubbed;
+      a.ms_total += st.ms_total; a.ms_sampler += st.ms_sampler; a.ms_raygen += st.ms_raygen; a.ms_trace_closest += st.ms_trace_closest; a.ms_trace_any += st.ms_trace_any;
+      a.ms_trace_mis += st.ms_trace_mis; a.ms_shade += st.ms_shade; a.ms_resolve += st.ms_resolve; a.ms_film += st.ms_film; a.ms_lightdist += st.ms_lightdist;
+      a.launches_trace_closest += st.launches_trace_closest; a.n_passes += st.n_passes;
+      a.vertices_lambert_const += st.vertices_lambert_const; a.vertices_lambert += st.vertices_lambert; a.vertices_two_lobe += st.vertices_two_lobe; a.vertices_generic += st.vertices_generic;
+    }
+  };
+  std::vector<std::thread> threads;
+  for (int k = 0; k < n_dev; ++k) threads.emplace_back(worker, k);
+  for (auto& t : threads) t.join();
+  if (first_rc != RT_OK) return fail(first_rc, first_err);
+  // Film::merge_film_tile on the first device: every chunk's rows are added into the frame, in chunk order (a pixel two chunks touched - a filter
+  // wider than a pixel, or a sample exactly on an edge - then sums in a fixed order)
+  HIP_TRY(hipSetDevice(m->devices[0]));
+  for (int c = 0; c < n_chunks; ++c) {
+    size_t off = 0;
+    for (auto& b : chunk_bands[c]) {
+      const unsigned long long n = (unsigned long long)(b.second - b.first) * cw;
+      hipLaunchKernelGGL(k_film_add, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, nullptr, m->acc.as<float4>() + (size_t)b.first * cw, (const float4*)((char*)m->staging[c]->p + off), n);
+      off += n * 16;
+    }
+  }
+  HIP_TRY(hipGetLastError());
+  HIP_TRY(hipMemcpy(film_xyzw, m->acc.p, frame_bytes, (flags & RT_FLAG_FILM_ON_DEVICE) ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost));
+  if (per_device) for (int k = 0; k < n_dev; ++k) per_device[k] = dev_stats[k];
+  if (total) {
+    rt_stats t{};
+    for (const rt_stats& a : dev_stats) {
+      t.camera_rays += a.camera_rays; t.rays_closest += a.rays_closest; t.rays_shadow += a.rays_shadow; t.rays_mis += a.rays_mis;
+      t.nodes_closest += a.nodes_closest; t.nodes_shadow += a.nodes_shadow; t.nodes_mis += a.nodes_mis; t.tris_closest += a.tris_closest; t.tris_shadow += a.tris_shadow; t.tris_mis += a.tris_mis;
+      t.paths_scrubbed += a.paths_scrubbed; t.launches_trace_closest += a.launches_trace_closest; t.n_passes += a.n_passes;
+      t.vertices_lambert_const += a.vertices_lambert_const; t.vertices_lambert += a.vertices_lambert; t.vertices_two_lobe += a.vertices_two_lobe; t.vertices_generic += a.vertices_generic;
+    }
+    t.ms_total = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_begin).count();
+    *total = t;
+  }
   return RT_OK;
 }

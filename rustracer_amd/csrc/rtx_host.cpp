@@ -205,6 +205,7 @@ struct rtxh_scene {
   std::vector<float> f_p, f_n, f_uv, f_s; std::vector<rt_tri_meta> f_meta; std::vector<int32_t> f_alpha; std::vector<rt_light> f_lights; std::vector<rt_image> f_images;
   bool committed = false;
   rt_scene* dev = nullptr;
+  rt_multi* multi = nullptr; std::vector<int32_t> multi_devices;  // replicas for rtxh_render_multi, kept while the device list stays the same
   size_t n_tris() const { return idx.size() / 3; }
 };
 
@@ -502,7 +503,7 @@ extern "C" {
 
 const char* rtxh_last_error(void) { return g_err.empty() ? rt_last_error() : g_err.c_str(); }
 rtxh_scene* rtxh_scene_new(void) { return new rtxh_scene(); }
-void rtxh_scene_free(rtxh_scene* s) { if (!s) return; if (s->dev) rt_scene_destroy(s->dev); delete s; }
+void rtxh_scene_free(rtxh_scene* s) { if (!s) return; if (s->dev) rt_scene_destroy(s->dev); if (s->multi) rt_multi_destroy(s->multi); delete s; }
 
 int rtxh_scene_set_mesh(rtxh_scene* s, const float* P, int32_t nv, const int32_t* idx, int32_t nt, const float* N, const float* UV, const float* S,
                         const int32_t* tri_material, const int32_t* tri_light, const uint8_t* tri_flags) {
@@ -836,6 +837,30 @@ int rtxh_render(rtxh_scene* s, const rtxh_render_params* p, void* stream, float*
   memcpy(path.pixel_bounds, pb, 16);
   rt_shard shard{p->rank, p->world_size > 0 ? p->world_size : 1};
   return rt_render(s->dev, &cf.cam, &cf.film, &smp, &path, &shard, p->flags, stream, film_xyzw, stats);
+}
+int rtxh_render_multi(rtxh_scene* s, const rtxh_render_params* p, const int32_t* devices, int32_t n_devices, int32_t chunks_per_device, float* film_xyzw,
+                      rt_stats* total, rt_stats* per_device) {
+  if (!s || !p || !film_xyzw || !devices || n_devices < 1) return fail(RT_ERR_INVALID, "null argument");
+  if (!s->committed) return fail(RT_ERR_INVALID, "scene not committed");
+  g_err.clear();
+  const std::vector<int32_t> want(devices, devices + n_devices);
+  if (!s->multi || s->multi_devices != want) {
+    if (s->multi) { rt_multi_destroy(s->multi); s->multi = nullptr; }
+    rt_scene_desc d = make_desc(s);
+    const int rc = rt_multi_create(&d, devices, n_devices, &s->multi);
+    if (rc != RT_OK) return rc;
+    s->multi_devices = want;
+  }
+  CamFilm cf; int rc = setup_camera_film(p, cf); if (rc != RT_OK) return rc;
+  rt_sampler_desc smp{p->spp, p->sampler_dims};
+  rt_path_desc path{}; path.max_depth = p->max_depth; path.rr_threshold = p->rr_threshold; path.light_strategy = p->light_strategy;
+  int pb[4] = {cf.film.sample_bounds[0], cf.film.sample_bounds[1], cf.film.sample_bounds[2], cf.film.sample_bounds[3]};
+  if (p->has_pixel_bounds) {
+    pb[0] = std::max(pb[0], p->pixel_bounds[0]); pb[1] = std::max(pb[1], p->pixel_bounds[2]);
+    pb[2] = std::min(pb[2], p->pixel_bounds[1]); pb[3] = std::min(pb[3], p->pixel_bounds[3]);
+  }
+  memcpy(path.pixel_bounds, pb, 16);
+  return rt_multi_render(s->multi, &cf.cam, &cf.film, &smp, &path, chunks_per_device, p->flags, film_xyzw, total, per_device);
 }
 int rtxh_trace(rtxh_scene* s, const float* rays, uint64_t n, int32_t any_hit, float* out, uint64_t counters[2]) {
   if (!s) return fail(RT_ERR_INVALID, "null scene");

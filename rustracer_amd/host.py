@@ -265,6 +265,21 @@ class HostScene:
         _check(lib().rtxh_render(self.h, C.byref(p), C.c_void_p(stream), _p(film), C.byref(stats)), "render")
         return film, stats.as_dict()
 
+    def render_multi(self, devices, chunks_per_device=1, count_traversal=False, time_kernels=False):
+        """The frame on several GPUs of this process (rt_multi_render): one host thread per entry of `devices`, chunks of tile rows pulled from a
+        shared queue, rows gathered on devices[0]. Returns (film, total stats, [per-device stats])."""
+        flags = (RT_FLAG_COUNT_TRAVERSAL if count_traversal else 0) | (RT_FLAG_TIME_KERNELS if time_kernels else 0)
+        st = self.setup()
+        cr = st["cropped"]
+        w, h = int(cr[2] - cr[0]), int(cr[3] - cr[1])
+        p = st["params"]
+        p.flags = flags
+        dev = np.ascontiguousarray(devices, np.int32)
+        film = np.zeros((h, w, 4), np.float32)
+        total, per = Stats(), (Stats * len(dev))()
+        _check(lib().rtxh_render_multi(self.h, C.byref(p), _p(dev, C.c_int32), len(dev), int(chunks_per_device), _p(film), C.byref(total), per), "render_multi")
+        return film, total.as_dict(), [s.as_dict() for s in per]
+
     def trace(self, rays, any_hit=False, count=True):
         """count=True: the visit-counting kernels (one node per step, the reference's sequence); count=False: the
         kernels rt_render launches (same hit records, no counters)."""

@@ -257,3 +257,31 @@ def test_screen_window_frame_matches_oracle(gpu_host, orc):
     fh, _ = gpu_host.HostScene(d).render()
     assert np.array_equal(fo[..., 3], fh[..., 3])
     assert rel_l2(gpu_host.film_to_rgb(fh), orc.film_to_rgb(fo)) < 1e-3
+
+
+@pytest.mark.parametrize("chunks_per_device", [1, 3])
+def test_multi_device_entry_point_on_one_gpu(gpu_host, chunks_per_device):
+    """rt_multi_render with two workers that both sit on device 0 (each with its own scene replica, host thread and stream): chunks of tile rows
+    from the shared queue, rows gathered by peer copies and summed on the first device - the same film as one rt_render call."""
+    d = _cornell(72, 70, 8)  # 70 rows: 5 tile rows, the last one partial
+    h = gpu_host.HostScene(d)
+    full, sf = h.render()
+    film, total, per = h.render_multi([0, 0], chunks_per_device=chunks_per_device)
+    assert np.array_equal(film[..., 3], full[..., 3])
+    # a pixel two chunks touched (a sample exactly on a row edge) sums in chunk order instead of sample order
+    assert np.allclose(film, full, rtol=1e-6, atol=0) and (film != full).mean() < 1e-3
+    assert total["camera_rays"] == sf["camera_rays"] == sum(p["camera_rays"] for p in per)
+    for k in ("rays_closest", "rays_shadow", "rays_mis"):
+        assert total[k] == sf[k]
+    assert all(p["camera_rays"] > 0 for p in per) or chunks_per_device > 1  # both workers rendered (a dynamic queue may starve one on a tiny frame)
+    film2, _, _ = h.render_multi([0, 0], chunks_per_device=chunks_per_device)  # replicas and light distributions are reused
+    assert np.array_equal(film2, film)
+
+
+def test_multi_device_wide_filter_rows_are_summed(gpu_host):
+    d = _cornell(48, 64, 4)
+    d.film.filter_kind, d.film.filter_params = 2, (2.0, 2.0, 2.0, 0.0)  # gaussian radius 2: every tile row splats into its neighbours
+    h = gpu_host.HostScene(d)
+    full, _ = h.render()
+    film, _, _ = h.render_multi([0, 0, 0], chunks_per_device=1)
+    assert np.allclose(film, full, rtol=2e-5, atol=1e-6)
