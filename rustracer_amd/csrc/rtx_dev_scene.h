@@ -35,7 +35,9 @@ struct DScene {
   f3 wb_min, wb_max;
   // light distribution (rc/lightdistrib.rs): dense voxel table or a single uniform distribution
   int ld_uniform; int nvox[3];
-  const float* ld_func; const float* ld_cdf; const float* ld_int;  // [voxel][n_lights], [voxel][n_lights+1], [voxel]
+  // tables of the BUILT voxels only (those that can hold a surface point): [slot][n_lights], [slot][n_lights+1], [slot]; ld_slot[voxel] = slot or -1.
+  // Memory is O(built voxels x lights) - a dense 64^3 table of 10^5 emitters would not fit any GPU
+  const float* ld_func; const float* ld_cdf; const float* ld_int; const int* ld_slot;
 #ifdef RT_ABLATE
   int dbg;  // measurement builds only (make ABLATE=1): bits switch parts of the shade kernel off to see what they cost; images are wrong
 #endif

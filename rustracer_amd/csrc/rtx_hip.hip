@@ -61,7 +61,7 @@ struct rt_scene {
   bool general_prims = false;  // alpha-masked triangles: traced by k_trace_big<.., GENERAL> only
   std::vector<DLight> h_lights;
   // light distribution tables (built per render, rc/integrator/path.rs:86-94)
-  DevBuf ld_func, ld_cdf, ld_int, ld_mark, ld_list;
+  DevBuf ld_func, ld_cdf, ld_int, ld_mark, ld_list, ld_slot;
   int ld_strategy_built = -1; bool ld_all_voxels = false;  // the tables are a function of the scene alone: built once per strategy, kept across frames
   std::mutex render_mutex;  // rt_render shares the workspace below: concurrent calls on one rt_scene take turns
   // per-render workspace
@@ -484,24 +484,31 @@ static int build_light_distribution(rt_scene* s, int strategy, hipStream_t strea
       d.nvox[i] = (int)(v > 1u ? v : 1u);
       total *= (size_t)d.nvox[i];
     }
-    HIP_TRY(s->ld_func.ensure(total * nl * 4)); HIP_TRY(s->ld_cdf.ensure(total * (nl + 1) * 4)); HIP_TRY(s->ld_int.ensure(total * 4));
     d.ld_uniform = 0;
-    d.ld_func = s->ld_func.as<float>(); d.ld_cdf = s->ld_cdf.as<float>(); d.ld_int = s->ld_int.as<float>();
-    // only voxels that can hold a surface point are built (k_lightdist_mark); the table API asks for all
-    HIP_TRY(s->ld_mark.ensure(total)); HIP_TRY(s->ld_list.ensure((total + 1) * 4));
+    // only voxels that can hold a surface point are built (k_lightdist_mark) and only they get table rows; the table API asks for all
+    HIP_TRY(s->ld_mark.ensure(total)); HIP_TRY(s->ld_list.ensure((total + 1) * 4)); HIP_TRY(s->ld_slot.ensure(total * 4));
     unsigned* n_list = s->ld_list.as<unsigned>(); unsigned* list = n_list + 1;
-    HIP_TRY(hipMemsetAsync(s->ld_mark.p, 0, total, stream)); HIP_TRY(hipMemsetAsync(n_list, 0, 4, stream));
-    HIP_TRY(hipMemsetD32Async((hipDeviceptr_t)s->ld_int.p, (int)0xbf800000u, total, stream));  // -1.0f = not built
-    if (!all_voxels) hipLaunchKernelGGL(k_lightdist_mark, dim3((s->n_tris + 255u) / 256u), dim3(256), 0, stream, d, s->ld_mark.as<unsigned char>());
-    hipLaunchKernelGGL(k_lightdist_compact, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream, s->ld_mark.as<unsigned char>(), (unsigned)total, all_voxels ? 1 : 0, list, n_list);
+    HIP_TRY(hipMemsetAsync(s->ld_slot.p, 0xff, total * 4, stream));  // -1 = not built
+    if (all_voxels) hipLaunchKernelGGL(k_lightdist_iota, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream, (unsigned)total, list, n_list);
+    else {
+      HIP_TRY(hipMemsetAsync(s->ld_mark.p, 0, total, stream)); HIP_TRY(hipMemsetAsync(n_list, 0, 4, stream));
+      hipLaunchKernelGGL(k_lightdist_mark, dim3((s->n_tris + 255u) / 256u), dim3(256), 0, stream, d, s->ld_mark.as<unsigned char>());
+      hipLaunchKernelGGL(k_lightdist_compact, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream, s->ld_mark.as<unsigned char>(), (unsigned)total, 0, list, n_list);
+    }
+    unsigned n_built = 0;  // once per scene and strategy (the tables are kept): a host round trip here is off every frame's path
+    HIP_TRY(hipMemcpyAsync(&n_built, n_list, 4, hipMemcpyDeviceToHost, stream)); HIP_TRY(hipStreamSynchronize(stream));
+    const size_t rows = std::max<size_t>(n_built, 1);
+    if (s->ld_func.ensure(rows * nl * 4) != hipSuccess || s->ld_cdf.ensure(rows * (nl + 1) * 4) != hipSuccess || s->ld_int.ensure(rows * 4) != hipSuccess)
+      return fail(RT_ERR_OOM, "light distribution tables do not fit (built voxels x lights)");
+    d.ld_func = s->ld_func.as<float>(); d.ld_cdf = s->ld_cdf.as<float>(); d.ld_int = s->ld_int.as<float>(); d.ld_slot = s->ld_slot.as<int>();
     unsigned lights_pad = 1; while (lights_pad < (unsigned)nl) lights_pad <<= 1;
-    const unsigned long long contrib_blocks = lights_pad <= 128u ? (total + 128u / lights_pad - 1) / (128u / lights_pad) : (unsigned long long)total * (unsigned)((nl + 127) / 128);
+    const unsigned long long contrib_blocks = lights_pad <= 128u ? (rows + 128u / lights_pad - 1) / (128u / lights_pad) : (unsigned long long)rows * (unsigned)((nl + 127) / 128);
     if (contrib_blocks > 0x7fffffffull) return fail(RT_ERR_INVALID, "light distribution grid too large");
     hipLaunchKernelGGL(k_lightdist_contrib, dim3((unsigned)contrib_blocks), dim3(128), 0, stream, d, list, n_list, lights_pad, (unsigned)((nl + 127) / 128), s->ld_func.as<float>());
-    hipLaunchKernelGGL(k_lightdist_finish, dim3((unsigned)((total + 127) / 128)), dim3(128), 0, stream, d, list, n_list, s->ld_func.as<float>(), s->ld_cdf.as<float>(), s->ld_int.as<float>());
+    hipLaunchKernelGGL(k_lightdist_finish, dim3((unsigned)((rows + 127) / 128)), dim3(128), 0, stream, d, list, n_list, s->ld_func.as<float>(), s->ld_cdf.as<float>(), s->ld_int.as<float>(), s->ld_slot.as<int>());
     HIP_TRY(hipGetLastError());
   }
-  d.ld_func = s->ld_func.as<float>(); d.ld_cdf = s->ld_cdf.as<float>(); d.ld_int = s->ld_int.as<float>();
+  d.ld_func = s->ld_func.as<float>(); d.ld_cdf = s->ld_cdf.as<float>(); d.ld_int = s->ld_int.as<float>(); d.ld_slot = s->ld_slot.as<int>();
   s->ld_strategy_built = strategy; s->ld_all_voxels = all_voxels;
   return RT_OK;
 }

@@ -1292,7 +1292,11 @@ __global__ void __launch_bounds__(256, MODE == 1 ? RT_SHADE_MIN_WAVES : RT_SHADE
         // light_distribution.lookup(p) (path.rs:154-158)
         const float* ld_func; const float* ld_cdf; float ld_int;
         if (sc.ld_uniform) { ld_func = sc.ld_func; ld_cdf = sc.ld_cdf; ld_int = sc.ld_int[0]; }
-        else { long v = voxel_of(sc, si.hit.p); ld_func = sc.ld_func + v * sc.n_lights; ld_cdf = sc.ld_cdf + v * (sc.n_lights + 1); ld_int = sc.ld_int[v]; }
+        else {
+          const long slot = sc.ld_slot[voxel_of(sc, si.hit.p)];
+          if (slot >= 0) { ld_func = sc.ld_func + slot * sc.n_lights; ld_cdf = sc.ld_cdf + slot * (sc.n_lights + 1); ld_int = sc.ld_int[slot]; }
+          else { ld_func = sc.ld_func; ld_cdf = sc.ld_cdf; ld_int = -1.0f; }
+        }
         const unsigned nonspec = BSDF_ALL & ~BSDF_SPECULAR;
         // voxels are built eagerly for every cell a surface point can fall into (k_lightdist_mark); the rest carry -1.
         // Looking one up would mean the marking missed a cell: count it (rt_render then fails the frame) and skip.
@@ -1641,14 +1645,15 @@ __global__ void __launch_bounds__(128) k_lightdist_contrib(DScene sc, const unsi
       if (s.pdf > 0.0f) contrib += lum_y(s.li) / s.pdf;
     }
   }
-  func[v * sc.n_lights + j] = contrib;
+  func[(size_t)li * sc.n_lights + j] = contrib;
 }
-__global__ void __launch_bounds__(128) k_lightdist_finish(DScene sc, const unsigned* __restrict__ list, const unsigned* __restrict__ n_list, float* func, float* cdf, float* fint) {
+__global__ void __launch_bounds__(128) k_lightdist_finish(DScene sc, const unsigned* __restrict__ list, const unsigned* __restrict__ n_list, float* func, float* cdf, float* fint, int* slot_of) {
   const unsigned li = blockIdx.x * blockDim.x + threadIdx.x;
   if (li >= *n_list) return;
   const long v = (long)list[li];
+  slot_of[v] = (int)li;
   const int nl = sc.n_lights;
-  float* fv = func + v * nl; float* cv = cdf + v * (nl + 1);
+  float* fv = func + (size_t)li * nl; float* cv = cdf + (size_t)li * (nl + 1);
   float sum = 0.0f;
   for (int j = 0; j < nl; ++j) sum += fv[j];
   float avg = sum / (float)(128ull * (unsigned long long)nl);
@@ -1659,7 +1664,12 @@ __global__ void __launch_bounds__(128) k_lightdist_finish(DScene sc, const unsig
   float func_int = cv[nl];
   if (func_int == 0.0f) for (int j = 1; j < nl + 1; ++j) cv[j] = (float)j / (float)nl;
   else for (int j = 1; j < nl + 1; ++j) cv[j] /= func_int;
-  fint[v] = func_int;
+  fint[li] = func_int;
+}
+__global__ void k_lightdist_iota(unsigned n, unsigned* __restrict__ list, unsigned* __restrict__ n_list) {  // every voxel, in order: slot == voxel
+  const unsigned v = blockIdx.x * blockDim.x + threadIdx.x;
+  if (v < n) list[v] = v;
+  if (v == 0) *n_list = n;
 }
 
 }  // namespace rtx
