@@ -546,7 +546,7 @@ RT_DEV LiSample area_light_sample_li(const DScene& sc, const DLight& l, const In
   return s;
 }
 // Shape::pdf_wi (shapes/mod.rs:59-68): re-intersects the emitter triangle (Triangle::intersect, alpha mask included)
-template <bool GENERAL = true>  // false: the scene is known to hold no masked triangle (k_shade<1>: no out-of-line call in the kernel)
+template <bool GENERAL>  // true only in the shade kernel of scenes with alpha-masked EMITTERS: the mask evaluator is a large out-of-line function
 RT_DEV float area_light_pdf_li(const DScene& sc, const DLight& l, const Interaction& ref, f3 wi) {
   Ray ray = spawn_ray(ref, wi);
   f3 p0, p1, p2; load_tri(sc.tri_p, l.prim, p0, p1, p2);
@@ -595,8 +595,9 @@ RT_DEVN LiSample light_sample_li(const DScene& sc, const DLight& l, const Intera
   }
 }
 // Light::pdf_li. Area lights: Shape::pdf_wi (shapes/mod.rs:59-68) re-intersects the emitter triangle.
+template <bool GENERAL>
 RT_DEVN float light_pdf_li(const DScene& sc, const DLight& l, const Interaction& ref, f3 wi) {
-  if (l.kind == 0) return area_light_pdf_li(sc, l, ref, wi);
+  if (l.kind == 0) return area_light_pdf_li<GENERAL>(sc, l, ref, wi);
   if (l.kind == 3) {  // infinite.rs:183-196
     f3 w = xf3x4(l.w2l, wi);
     float theta = spherical_theta(w), phi = spherical_phi(w);

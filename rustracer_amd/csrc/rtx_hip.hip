@@ -59,6 +59,7 @@ struct rt_scene {
   DevBuf quads; bool use_quads = false; int quad_stack_depth = 0;  // four-wide records of the any-hit kernel (k_trace_quad)
   DevBuf nodes, tri_p, tri_n, tri_uv, tri_s, tri_alpha, textures, images, materials, lights, texels, dist;
   bool general_prims = false;  // alpha-masked triangles: traced by k_trace_big<.., GENERAL> only
+  bool masked_emitters = false;  // ... and some of them emit: every vertex is shaded by k_shade<0, true> (Shape::pdf_wi evaluates the mask)
   std::vector<DLight> h_lights;
   // light distribution tables (built per render, rc/integrator/path.rs:86-94)
   DevBuf ld_func, ld_cdf, ld_int, ld_mark, ld_list, ld_slot;
@@ -357,7 +358,9 @@ extern "C" int rt_scene_create(const rt_scene_desc* desc, int device, rt_scene**
     if (m.kind != RT_MAT_MATTE || m.slot[RT_SLOT_KD] < 0 || !sigma_zero || m.bump >= 0) { s->lambert_materials = false; break; }
   }
   for (uint32_t i = 0; i < desc->n_lights; ++i) if (desc->lights[i].kind != RT_LIGHT_DIFFUSE_AREA) s->lambert_only = false;
-  if (s->general_prims) s->lambert_only = false;  // k_shade<1> re-intersects emitters without the mask test
+  for (uint32_t i = 0; i < desc->n_lights; ++i)
+    if (desc->lights[i].kind == RT_LIGHT_DIFFUSE_AREA && (desc->tri_meta[desc->lights[i].prim].flags & RT_TRI_HAS_ALPHA)) s->masked_emitters = true;
+  if (s->masked_emitters) { s->lambert_only = false; s->lambert_materials = false; }  // only the generic kernel re-intersects emitters with the mask test
   s->n_materials = desc->n_materials;
   s->small = desc->n_nodes <= RT_SMALL_NODES && desc->n_tris <= RT_SMALL_TRIS && !s->general_prims;
   {  // tree height bounds the number of simultaneously pending stack entries
@@ -848,7 +851,7 @@ extern "C" int rt_render(rt_scene* s, const rt_camera* cam, const rt_film_desc* 
   const size_t counter_words = (size_t)(fp.max_depth + 2) * RT_NQ * RT_QSHARDS;  // one block of {out, shadow, mis, mis-any} shard counts per bounce + raygen's
   // material binning before the generic shade kernel: per bounce {hist, cursor}[RT_BIN_MAX + 1] + the 8 count words of the sorted queue
   static const bool bin_off = getenv("RTX_SHADE_BINS") && getenv("RTX_SHADE_BINS")[0] == '0';  // measurement knob
-  const bool use_bins = !s->lambert_materials && s->n_code_classes > 1 && !bin_off;  // one class: every vertex runs the same code, the queue order is kept
+  const bool use_bins = !s->lambert_materials && s->n_code_classes > 1 && !bin_off && !s->masked_emitters;  // one class: every vertex runs the same code, the queue order is kept
   const unsigned n_bins = std::min<unsigned>(s->n_code_classes, RT_BIN_MAX) + 1u;
   const size_t bin_stride = 2 * (RT_BIN_MAX + 1) + RT_QSHARDS + 8;  // + {begin, end} of the three class ranges and of the miss bin
   // RTX_SHADE_SPLIT (measurement knob): 0 = every class through the generic front-end, 1 = Lambert classes apart, default = Lambert and two-lobe classes apart
@@ -986,7 +989,12 @@ extern "C" int rt_render(rt_scene* s, const rt_camera* cam, const rt_film_desc* 
         tm.end();
         if (s->lambert_only) { tm.begin(&stats.ms_shade_lambert_const); hipLaunchKernelGGL(k_shade<1>, dim3(pgrid), dim3(256), 0, stream, s->d, fp, ps); tm.end(); }
         else if (s->lambert_materials) { tm.begin(&stats.ms_shade_lambert); hipLaunchKernelGGL(k_shade<3>, dim3(pgrid), dim3(256), 0, stream, s->d, fp, ps); tm.end(); }
-        else if (!use_bins) { tm.begin(&stats.ms_shade_generic); hipLaunchKernelGGL(k_shade<0>, dim3(pgrid), dim3(256), 0, stream, s->d, fp, ps); tm.end(); }
+        else if (!use_bins) {
+          tm.begin(&stats.ms_shade_generic);
+          if (s->masked_emitters) hipLaunchKernelGGL((k_shade<0, true>), dim3(pgrid), dim3(256), 0, stream, s->d, fp, ps);
+          else hipLaunchKernelGGL(k_shade<0>, dim3(pgrid), dim3(256), 0, stream, s->d, fp, ps);
+          tm.end();
+        }
         else {
           tm.begin(&stats.ms_shade_bin);
           unsigned* bw = s->bin_words.as<unsigned>() + (size_t)bounce * bin_stride;

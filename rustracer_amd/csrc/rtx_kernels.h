@@ -1235,7 +1235,9 @@ struct SmallBsdf {
 #ifndef RT_SHADE0_MIN_WAVES
 #define RT_SHADE0_MIN_WAVES 2
 #endif
-template <int MODE>
+// GENERAL (generic front-end only): some emitter triangle carries an alpha mask, so Shape::pdf_wi's re-intersection evaluates it; such scenes shade
+// every vertex through k_shade<0, true>, every other scene never instantiates the mask evaluator in a shade kernel.
+template <int MODE, bool GENERAL = false>
 __global__ void __launch_bounds__(256, MODE == 1 ? RT_SHADE_MIN_WAVES : RT_SHADE0_MIN_WAVES) k_shade(DScene sc, FrameParams fp, PassState ps) {
   QView qv; if (ps.q_in) qv.init(ps.q_in, ps.cnt_in, ps.shard_cap);
   unsigned first = 0, count = ps.q_in ? qv.total() : ps.cap;  // no queue: bounce 0 of a pass whose samples are all traced
@@ -1333,7 +1335,7 @@ __global__ void __launch_bounds__(256, MODE == 1 ? RT_SHADE_MIN_WAVES : RT_SHADE
               if (!is_black(f) && bs.pdf > 0.0f) {
                 float weight = 1.0f; bool go = true;
                 if (!(bs.type & BSDF_SPECULAR)) {
-                  float lp = (MODE == 1) ? area_light_pdf_li<false>(sc, light, si.hit, bs.wi) : light_pdf_li(sc, light, si.hit, bs.wi);
+                  float lp = (MODE == 1) ? area_light_pdf_li<false>(sc, light, si.hit, bs.wi) : light_pdf_li<GENERAL>(sc, light, si.hit, bs.wi);
                   if (lp == 0.0f) go = false;  // `return ld`
                   else weight = power_heuristic1(bs.pdf, lp);
                 }

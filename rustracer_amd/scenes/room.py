@@ -1,7 +1,8 @@
 """S4 "room-env" (BASELINE config 5, living-room-class): a box room lit through a window opening by an
 InfiniteAreaLight with a procedural lat-long HDR (sun + sky), imagemap-textured matte/plastic/uber/substrate
 surfaces (EWA filtered, power-of-two procedural images standing in for decoded PNGs), a glass pane, a mirror,
-subdivided noise-displaced furniture blocks. `detail` scales the triangle count (detail=1 ~ 3 K, detail=8 ~ 200 K)."""
+subdivided noise-displaced furniture blocks. `detail` scales the triangle count: 5 blocks x 6 faces x (4 detail)^2 x 2 triangles
+(detail=1: 504, detail=8: 61 K, the default 14.5: 201,864 - the ~200 K of SURVEY.md §8d)."""
 from __future__ import annotations
 
 import numpy as np
@@ -10,7 +11,7 @@ from ..scene_desc import SceneDesc, WRAP_REPEAT
 from .procedural import box_mesh, checker_fbm_image, sky_image
 
 
-def room_env(xres: int = 1920, yres: int = 1080, spp: int = 1024, detail: int = 8, tex_size: int = 1024, env_size: int = 2048) -> SceneDesc:
+def room_env(xres: int = 1920, yres: int = 1080, spp: int = 1024, detail: float = 14.5, tex_size: int = 1024, env_size: int = 2048) -> SceneDesc:
     s = SceneDesc()
     s.name = "room-env"
     imgs = [s.add_mip(checker_fbm_image(tex_size, 42 + i, c0, c1, cells), max_aniso=8.0, wrap=WRAP_REPEAT)
@@ -46,7 +47,7 @@ def room_env(xres: int = 1920, yres: int = 1080, spp: int = 1024, detail: int = 
     quad((W - 0.02, y0, z0), (W - 0.02, y1, z0), (W - 0.02, y1, z1), (W - 0.02, y0, z1), glass)  # pane
     quad((0.01, 0.8, 2.0), (0.01, 0.8, 4.0), (0.01, 2.4, 4.0), (0.01, 2.4, 2.0), mirror)
     quad((2.0, 0.005, 1.5), (6.0, 0.005, 1.5), (6.0, 0.005, 4.5), (2.0, 0.005, 4.5), rug)
-    sub = max(1, 4 * detail)
+    sub = max(1, int(round(4 * detail)))
     for lo, hi, m, amp, sd in [((1.0, 0.0, 4.6), (5.0, 0.9, 5.8), sofa, 0.04, 1), ((1.0, 0.9, 5.4), (5.0, 1.6, 5.8), sofa, 0.05, 2),
                                ((3.0, 0.0, 2.4), (5.0, 0.45, 3.6), table, 0.0, 3), ((6.4, 0.0, 4.8), (7.2, 1.8, 5.6), mixm, 0.02, 4),
                                ((3.7, 0.45, 2.8), (4.3, 0.9, 3.2), rough_lamp, 0.03, 5)]:

@@ -11,7 +11,7 @@ for SET in "FETCH_SIZE" "WRITE_SIZE" \
   "TCC_HIT_sum TCC_MISS_sum TCP_TCC_READ_REQ_sum TCP_TOTAL_CACHE_ACCESSES_sum TCC_EA0_RDREQ_sum" \
   "SQ_INSTS_LDS SQ_WAIT_INST_LDS SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT SQ_INSTS_SALU SQ_INSTS_VMEM_WR SQ_WAIT_ANY SQ_ACTIVE_INST_ANY"; do
   i=$((i+1))
-  rocprofv3 --pmc $SET --output-format csv -d $OUT/p$i -- python3 bench.py --scene $SCENE --spp $SPP --steps 1 --warmup 0 --no-cpu-baseline > $OUT/p$i.log 2>&1
+  rocprofv3 --pmc $SET --output-format csv -d $OUT/p$i -- python3 bench.py --scene $SCENE --spp $SPP --steps 1 --warmup 0 --no-cpu-baseline --headline-only > $OUT/p$i.log 2>&1
   python3 scripts/pmc_summary.py $OUT/p$i > $OUT/p$i.txt 2>&1
 done
 cat $OUT/p*.txt

@@ -19,6 +19,23 @@ def test_owned_rows_partition_the_frame():
     assert np.all(m[0] ^ m[1])
 
 
+def test_touched_rows_cover_the_owned_rows_and_the_filter_reach():
+    from rustracer_amd.distributed import owned_sample_rows, touched_rows
+    for (cy0, cy1), (sy0, sy1), radius in (((0, 70), (0, 70), 0.5), ((0, 1080), (-2, 1082), 2.0), ((10, 50), (8, 52), 1.5)):
+        for world in (1, 2, 3, 8):
+            seen = np.zeros(cy1 - cy0, int)
+            for r in range(world):
+                t = touched_rows((0, cy0, 40, cy1), (0, sy0, 40, sy1), r, world, radius)
+                own = owned_sample_rows(sy0, sy1, r, world)
+                own = own[(own >= cy0) & (own < cy1)] - cy0
+                assert np.isin(own, t).all()                       # a rank's own rows
+                reach = int(np.ceil(radius - 0.5)) + 1
+                grown = np.unique(np.clip(np.add.outer(own, np.arange(-reach, reach + 1)).ravel(), 0, cy1 - cy0 - 1))
+                assert np.array_equal(np.sort(t), grown)           # ... widened by the filter's reach, nothing more
+                seen[t] += 1
+            assert (seen >= 1).all()
+
+
 def _free_port():
     s = socket.socket()
     s.bind(("127.0.0.1", 0))
@@ -37,17 +54,22 @@ def _worker(rank, world, port, q):
         rng = np.random.default_rng(0)  # same "full frame" on every rank
         full = rng.uniform(0, 4, (70, 40, 4)).astype(np.float32)
         mask = owned_pixel_mask((0, 0, 40, 70), (0, 0, 40, 70), rank, world)
-        mine = torch.from_numpy(np.where(mask[..., None], full, np.float32(0)))
+        mine = np.where(mask[..., None], full, np.float32(0))
+        if rank == 1:
+            mine[15] = np.float32(0.25)  # a sample of rank 1 that sat exactly on the edge of row 16 splats into row 15, which rank 0 owns
+        mine = torch.from_numpy(mine)
         merge_film(mine, dst=0)
         dist.barrier()
         if rank == 0:
-            q.put(bool(np.array_equal(mine.numpy().view(np.uint32), full.view(np.uint32))))
+            want = full.copy()
+            want[15] += np.float32(0.25)
+            q.put(bool(np.array_equal(mine.numpy().view(np.uint32), want.view(np.uint32))))
     finally:
         dist.destroy_process_group()
 
 
 @pytest.mark.parametrize("world", [2])
-def test_film_merge_over_gloo_is_a_bit_exact_gather(world):
+def test_film_merge_over_gloo_gathers_the_touched_rows(world):
     import torch.multiprocessing as mp
     ctx = mp.get_context("spawn")
     q = ctx.Queue()

@@ -231,3 +231,28 @@ def test_screen_window_and_frame_aspect_match_the_oracle(host, orc, camera):
         assert np.array_equal(a[k], b[k]), k
     base = host.HostScene(cornell_box(48, 32, 4)).setup()
     assert not np.array_equal(a["raster_to_camera"], base["raster_to_camera"]) or camera == dict(frame_aspect=1.5)
+
+
+def test_kernel_register_and_scratch_budgets(host):
+    """Occupancy is decided by registers on this chip (waves per SIMD = 512 / allocated VGPRs, 8-register granules; MI355X guide) and a change
+    in one device function can move a kernel across a step without any test failing: alpha masks once took k_shade<5> from 218 to 258 VGPRs (2 -> 1
+    wave per SIMD) because their texture evaluator became reachable from every shade kernel. The budgets below are read from the BUILT library."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("kernel_budget", os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "scripts", "kernel_budget.py"))
+    kb = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(kb)
+    res = kb.kernel_resources(host.HIP_LIB)
+    budget = {  # kernel prefix -> (max VGPRs, max scratch bytes)
+        "rtx::k_shade<1, false>": (168, 0),        # 3 waves per SIMD, no scratch, no out-of-line call
+        "rtx::k_shade<3, false>": (200, 640),      # 2 waves
+        "rtx::k_shade<5, false>": (224, 640),
+        "rtx::k_shade<0, false>": (256, 2048),
+        "rtx::k_trace<false, false, true, 256, 16>": (72, 64),   # the LDS-resident closest-hit kernel of the headline: 7 waves
+        "rtx::k_trace<true, false, true, 256, 16>": (64, 64),    # ... and its shadow-ray twin: 8 waves
+        "rtx::k_trace_pair<false, false, 128, 32>": (80, 160),   # HBM scenes: 6 waves
+        "rtx::k_trace_quad<true, 128, 32>": (64, 160),
+        "rtx::k_resolve": (88, 256), "rtx::k_raygen": (72, 0), "rtx::k_film_accumulate": (48, 0),
+    }
+    for name, (vg, sc) in budget.items():
+        r = res[name]
+        assert r["vgpr"] <= vg and r["scratch"] <= sc and r["vgpr_spills"] == 0, (name, r)
