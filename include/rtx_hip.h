@@ -45,12 +45,23 @@ typedef struct rt_bvh_node {
 #define RT_TRI_HAS_S 8u  /* mesh.s is Some                                   */
 #define RT_TRI_HAS_ALPHA 16u        /* mesh.alpha_mask is Some: tri_alpha[2 i] is its float texture (rc/shapes/mesh.rs:38,134-144)          */
 #define RT_TRI_HAS_SHADOW_ALPHA 32u /* mesh.shadow_alpha_mask is Some: tri_alpha[2 i + 1] (mesh.rs:39,146-156); shadow rays only (:577-581) */
+#define RT_PRIM_SPHERE 64u /* this primitive is an analytic sphere (rc/shapes/sphere.rs), not a triangle: its tri_p slot holds the world bounding
+                              box (p0 = min, p1 = max) and, as the bits of p2.x, its index into rt_scene_desc::spheres                          */
 typedef struct rt_tri_meta {
   int32_t material; /* index into materials[]                 */
   int32_t light;    /* index into lights[] (area light) or -1 */
   uint32_t flags;
   uint32_t source_index; /* triangle index before BVH re-ordering (diagnostics) */
 } rt_tri_meta;
+
+/* -- Shape "sphere": replaces Sphere (rc/shapes/sphere.rs:15-68). o2w / w2o: the object-to-world matrix and its inverse, row-major 4x4
+ *    (Transform{m, m_inv}: the inverse as the host computed it - a Gauss-Jordan inverse in f32 need not have an exact last row, and
+ *    Transform * Point divides by w whenever w != 1, transform.rs:264-286); z_min .. phi_max as Sphere::new leaves them. -------------------- */
+typedef struct rt_sphere {
+  float o2w[16], w2o[16];
+  float radius, z_min, z_max, theta_min, theta_max, phi_max;
+  int32_t reverse_orientation, swaps_handedness;
+} rt_sphere;
 
 /* -- textures: replaces dyn Texture<T> (rc/texture/{constant,scale,mix,imagemap,checkerboard,uv,fbm}.rs) --
  * checkerboard (2D): tex1, tex2, mapping, amount = AAMethod (0 none, 1 closedform); uv: mapping;
@@ -118,7 +129,7 @@ typedef struct rt_light {
 typedef struct rt_scene_desc {
   uint32_t n_nodes;
   const rt_bvh_node* nodes; /* pre-order, left child = i+1 (rc/bvh/mod.rs:314-358)          */
-  uint32_t n_tris;
+  uint32_t n_tris;          /* primitives in leaf order: triangles, and spheres where tri_meta[i].flags has RT_PRIM_SPHERE      */
   const float* tri_p;       /* n_tris*9, world space, LEAF ORDER (p0 p1 p2)                  */
   const float* tri_n;       /* n_tris*9 or NULL                                              */
   const float* tri_uv;      /* n_tris*6 or NULL                                              */
@@ -127,6 +138,7 @@ typedef struct rt_scene_desc {
   const int32_t* tri_alpha; /* n_tris*2 {alpha, shadowalpha} float-texture ids, read where the RT_TRI_HAS_*ALPHA flags are set; NULL if no
                                mesh carries a mask. A hit whose mask evaluates to 0 is no hit (Triangle::intersect mesh.rs:353-370,
                                intersect_p :534-582) - in BVH traversal and in Shape::pdf_wi's re-intersection alike */
+  uint32_t n_spheres; const rt_sphere* spheres; /* the analytic spheres among the n_tris primitives (RT_PRIM_SPHERE); an area light's `prim` may name one */
   uint32_t n_textures; const rt_texture* textures;
   uint32_t n_images; const rt_image* images;
   uint32_t n_materials; const rt_material* materials;

@@ -48,6 +48,11 @@ void rtxh_scene_free(rtxh_scene*);
  * list of that triangle's DiffuseAreaLight or -1; tri_flags = RT_TRI_* (per-mesh attributes). */
 int rtxh_scene_set_mesh(rtxh_scene*, const float* P, int32_t n_verts, const int32_t* indices, int32_t n_tris, const float* N, const float* UV,
                         const float* S, const int32_t* tri_material, const int32_t* tri_light, const uint8_t* tri_flags);
+/* Shape "sphere" (rc/shapes/sphere.rs:53-68): radius, zmin, zmax, phimax (degrees) as the parameters give them (Sphere::new clamps and converts),
+ * under the object-to-world transform o2w (row-major 4x4, with its inverse as Transform{m, m_inv} holds it). `light`: index of its DiffuseAreaLight in the light list or -1;
+ * that light is added by rtxh_scene_add_light(RT_LIGHT_DIFFUSE_AREA, tri = -2 - k, ...) for sphere k. Returns k. */
+int rtxh_scene_add_sphere(rtxh_scene*, const float* o2w16, const float* w2o16, float radius, float z_min, float z_max, float phi_max, int32_t reverse_orientation,
+                          int32_t material, int32_t light);
 /* Alpha masks of the meshes, after rtxh_scene_set_mesh: per triangle {alpha, shadowalpha} float-texture ids or -1 (TriangleMesh::create,
  * rc/shapes/mesh.rs:134-156: a named float texture, or the constant 0 when the float parameter is 0). NULL removes all masks. */
 int rtxh_scene_set_alpha(rtxh_scene*, const int32_t* tri_alpha2);

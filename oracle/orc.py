@@ -146,12 +146,16 @@ class OracleScene:
         for m in desc.materials:
             sl = m.slots()
             L.orc_scene_add_material(self.h, m.kind, _p(sl, C.c_int32), int(m.remap_roughness), int(m.bump))
+        for sp in getattr(desc, "spheres", []):
+            L.orc_scene_add_sphere(self.h, _p(sp.o2w), _p(sp.w2o), C.c_float(sp.radius), C.c_float(sp.z_min), C.c_float(sp.z_max), C.c_float(sp.phi_max),
+                                   int(sp.reverse_orientation), sp.material, sp.light)
         for l in desc.lights:
             rgb = np.float32(l.rgb)
             vec = np.float32(l.vec)
             l2w = None if l.l2w is None else np.ascontiguousarray(l.l2w, np.float32)
             w2l = None if l.w2l is None else np.ascontiguousarray(l.w2l, np.float32)
-            assert L.orc_scene_add_light(self.h, l.kind, l.tri, _p(rgb), int(l.two_sided), _p(vec), l.mip, _p(l2w), _p(w2l)) >= 0
+            tri = l.tri if getattr(l, "sphere", -1) < 0 else -2 - l.sphere  # -2 - k: the area light sits on sphere k
+            assert L.orc_scene_add_light(self.h, l.kind, tri, _p(rgb), int(l.two_sided), _p(vec), l.mip, _p(l2w), _p(w2l)) >= 0
         L.orc_scene_commit(self.h, desc.max_prims_per_node)
 
     def __del__(self):

@@ -185,6 +185,17 @@ int orc_scene_set_alpha(void* h, const int32_t* tri_alpha2) {  // after orc_scen
   if (!tri_alpha2) s->tri_alpha.clear(); else s->tri_alpha.assign(tri_alpha2, tri_alpha2 + 2 * s->n_tris());
   return 0;
 }
+// Shape "sphere" (Sphere::create, sphere.rs:53-68), after orc_scene_set_mesh. Returns its primitive id (n_tris + index): what an area light's `tri` names.
+int orc_scene_add_sphere(void* h, const float* o2w16, const float* w2o16, float radius, float z_min, float z_max, float phi_max, int reverse_orientation,
+                         int material, int light) {
+  Scene* s = (Scene*)h;
+  Transform t; memcpy(t.m.m, o2w16, 64); memcpy(t.m_inv.m, w2o16, 64);
+  Sphere sp = sphere_new(t, radius, z_min, z_max, phi_max, reverse_orientation != 0);
+  s->spheres.push_back(sp);
+  s->tri_material.push_back(material); s->tri_light.push_back(light);
+  s->tri_flags.push_back((uint8_t)((sp.reverse_orientation != sp.swaps_handedness) ? 1 : 0));
+  return (int)(s->n_prims() - 1);
+}
 int orc_scene_add_mipmap(void* h, int w, int hgt, const float* rgbdata, int trilinear, float max_aniso, int wrap) {
   Scene* s = (Scene*)h;
   if (w <= 0 || hgt <= 0) return -1;
@@ -244,6 +255,7 @@ int orc_scene_add_material(void* h, int kind, const int32_t* p, int remap_roughn
 // kind: LightKind. rgbv: L / I. vec: point position or distant direction (w_light = from - to, already in world space).
 int orc_scene_add_light(void* h, int kind, int tri, const float* rgbv, int two_sided, const float* vec, int mip, const float* l2w, const float* w2l) {
   Scene* s = (Scene*)h;
+  if (tri <= -2) tri = (int)s->n_tris() + (-2 - tri);  // -2 - k: sphere k (primitive ids of spheres follow the triangles')
   Light l; l.kind = kind; l.tri = tri; l.two_sided = two_sided != 0;
   l.l_emit = rgb(rgbv[0], rgbv[1], rgbv[2]); l.intensity = l.l_emit;
   if (vec) l.pos = v3(vec[0], vec[1], vec[2]);

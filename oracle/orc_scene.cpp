@@ -118,11 +118,11 @@ size_t flatten(const BuildNode* node, std::vector<LinearNode>& out) {  // :314-3
 
 void Scene::build_bvh() {
   nodes.clear(); ordered.clear();
-  size_t n = n_tris();
+  size_t n = n_prims();
   if (n == 0) return;
   std::vector<PrimInfo> info(n);
   for (size_t i = 0; i < n; ++i) {
-    B3 bb = tri_world_bounds((int)i);
+    B3 bb = is_sphere((int)i) ? sphere_world_bounds(sphere_of((int)i)) : tri_world_bounds((int)i);
     info[i].prim_number = (int)i;
     info[i].bounds = bb;
     info[i].centroid = 0.5f * bb.mn + 0.5f * bb.mx;  // :532
@@ -187,7 +187,7 @@ bool Scene::tri_test(int tri, const Ray& ray, TriHit* h) const {
 // float texture is evaluated on a local SurfaceInteraction::new(p_hit, zero error, uv_hit, -ray.d, dpdu, dpdv, ...) that carries no ray differentials;
 // a value of exactly 0 turns the accepted hit test into a miss.
 bool Scene::tri_alpha_rejects(int tri, const Ray& ray, const TriHit& h, bool shadow_ray) const {
-  if (tri_alpha.empty()) return false;
+  if (tri_alpha.empty() || is_sphere(tri)) return false;  // (Sphere has no alpha mask in the reference)
   const int alpha = tri_alpha[2 * (size_t)tri], shadow_alpha = tri_alpha[2 * (size_t)tri + 1];
   if (alpha < 0 && !(shadow_ray && shadow_alpha >= 0)) return false;
   V3 p0, p1, p2; tri_verts(tri, &p0, &p1, &p2);
@@ -298,7 +298,7 @@ bool Scene::intersect_raw(Ray& ray, int* prim_out, TriHit* hit_out, TraceCounter
           TriHit h;
           // `result = prim.intersect(ray).or(result)`: every accepted test replaces the result and
           // shrinks ray.t_max (GeometricPrimitive::intersect, primitive.rs:45-51)
-          if (tri_test(ordered[prim], ray, &h) && !tri_alpha_rejects(ordered[prim], ray, h, false)) {
+          if (prim_test(ordered[prim], ray, &h) && !tri_alpha_rejects(ordered[prim], ray, h, false)) {
             if (tc) tc->tri_hits += 1;
             ray.t_max = h.t; found = true; best_prim = prim; best = h;
           }
@@ -322,9 +322,21 @@ bool Scene::intersect(Ray& ray, SurfaceInteraction* si, TraceCounters* tc) const
   if (!intersect_raw(ray, &prim, &h, tc)) return false;
   // The reference builds the full SurfaceInteraction for every accepted candidate (mesh.rs:321-425);
   // only the last one survives, so building it once for the final hit gives the same value.
-  tri_fill_interaction(ordered[prim], ray, h, si);
+  prim_fill_interaction(ordered[prim], ray, h, si);
   si->prim = prim;
   return true;
+}
+void Scene::prim_fill_interaction(int prim, const Ray& ray, const TriHit& h, SurfaceInteraction* si) const {
+  if (!is_sphere(prim)) { tri_fill_interaction(prim, ray, h, si); return; }
+  // Sphere::intersect builds its interaction inside the hit test; it is rebuilt here for the accepted hit. The roots, the clipping retry and
+  // therefore p_hit do not depend on ray.t_max (it only rejects), so t_max = infinity reproduces the accepted test's decisions.
+  Ray r = ray; r.t_max = kInf;
+  SphereHit sh; bool ok = sphere_intersect(sphere_of(prim), r, true, &sh); (void)ok;
+  SurfaceInteraction s;
+  s.hit.p = sh.p; s.hit.p_error = sh.p_error; s.hit.wo = sh.wo; s.hit.n = sh.n;
+  s.uv = sh.uv; s.dpdu = sh.dpdu; s.dpdv = sh.dpdv;
+  s.shading.n = sh.sh_n; s.shading.dpdu = sh.dpdu; s.shading.dpdv = sh.dpdv;
+  *si = s;
 }
 
 bool Scene::intersect_p(const Ray& ray, TraceCounters* tc) const {  // bvh/mod.rs:435-501
@@ -341,7 +353,7 @@ bool Scene::intersect_p(const Ray& ray, TraceCounters* tc) const {  // bvh/mod.r
         for (int i = 0; i < node.n_prims; ++i) {
           if (tc) tc->tris += 1;
           TriHit h;
-          if (tri_test(ordered[node.offset + i], ray, &h) && !tri_alpha_rejects(ordered[node.offset + i], ray, h, true)) { if (tc) tc->tri_hits += 1; return true; }
+          if (prim_test(ordered[node.offset + i], ray, &h) && !tri_alpha_rejects(ordered[node.offset + i], ray, h, true)) { if (tc) tc->tri_hits += 1; return true; }
         }
         if (to_visit == 0) break;
         cur = stack[--to_visit];
@@ -378,6 +390,11 @@ void Scene::tri_sample(int tri, P2 u, Interaction* it, float* pdf) const {  // m
   *pdf = 1.0f / tri_area(tri);
 }
 void Scene::shape_sample_si(int tri, const Interaction& ref, P2 u, Interaction* it, float* pdf_out) const {  // shapes/mod.rs:39-53
+  if (is_sphere(tri)) {  // Sphere overrides sample_si (sphere.rs:246-308)
+    SpherePoint sp = sphere_sample_si(sphere_of(tri), ref, u, pdf_out);
+    it->p = sp.p; it->p_error = sp.p_error; it->wo = v3(0, 0, 0); it->n = sp.n;
+    return;
+  }
   float pdf; tri_sample(tri, u, it, &pdf);
   V3 wi = it->p - ref.p;
   if (length_squared(wi) == 0.0f) pdf = 0.0f;
@@ -389,6 +406,7 @@ void Scene::shape_sample_si(int tri, const Interaction& ref, P2 u, Interaction* 
   *pdf_out = pdf;
 }
 float Scene::shape_pdf_wi(int tri, const Interaction& ref, V3 wi, TraceCounters* tc) const {  // shapes/mod.rs:59-68
+  if (is_sphere(tri)) return sphere_pdf_wi(sphere_of(tri), ref, wi, tc ? &tc->tris : nullptr);  // sphere.rs:310-334
   Ray ray = spawn_ray(ref, wi);
   TriHit h;
   if (tc) tc->tris += 1;
@@ -403,7 +421,7 @@ void Scene::preprocess_lights() {  // scene.rs:29-49: light.preprocess runs whil
   B3 wb = world_bounds();
   for (size_t i = 0; i < lights.size(); ++i) {
     Light& l = lights[i];
-    if (l.kind == LIGHT_DIFFUSE_AREA) l.area = tri_area(l.tri);
+    if (l.kind == LIGHT_DIFFUSE_AREA) l.area = shape_area(l.tri);
     if (l.kind == LIGHT_DISTANT || l.kind == LIGHT_INFINITE) b3_bounding_sphere(wb, &l.w_center, &l.w_radius);
     if (l.kind == LIGHT_INFINITE) infinite_lights.push_back((int)i);
   }

@@ -35,6 +35,9 @@ inline Ray spawn_ray_to_interaction(const Interaction& a, const Interaction& b) 
   V3 d = target - origin;
   return ray_segment(origin, d, 1.0f - 1e-4f);
 }
+}  // namespace orc
+#include "orc_sphere.h"  // needs Ray and Interaction
+namespace orc {
 
 struct SurfaceInteraction {  // rc/interaction.rs:78-104
   Interaction hit;
@@ -202,6 +205,22 @@ struct Scene {
   std::vector<int32_t> tri_light;   // index into lights or -1
   std::vector<uint8_t> tri_flags;   // bit0: reverse_orientation ^ swaps_handedness; bit1: mesh has N; bit2: has UV; bit3: has S
   std::vector<int32_t> tri_alpha;   // 2 per triangle: float-texture ids of mesh.alpha_mask / mesh.shadow_alpha_mask or -1 (mesh.rs:38-39); empty = none
+  // ---- analytic spheres (rc/shapes/sphere.rs): primitive ids n_tris() .. n_prims() - 1; tri_material / tri_light / tri_flags carry their entries too
+  // (bit0 of the flags: reverse_orientation ^ swaps_handedness, as for triangles)
+  std::vector<Sphere> spheres;
+  size_t n_prims() const { return n_tris() + spheres.size(); }
+  bool is_sphere(int prim) const { return (size_t)prim >= n_tris(); }
+  const Sphere& sphere_of(int prim) const { return spheres[(size_t)prim - n_tris()]; }
+  float shape_area(int prim) const { return is_sphere(prim) ? sphere_area(sphere_of(prim)) : tri_area(prim); }
+  // Shape::intersect of primitive `prim`, hit test only: triangles give barycentrics, spheres t alone
+  bool prim_test(int prim, const Ray& ray, TriHit* h) const {
+    if (!is_sphere(prim)) return tri_test(prim, ray, h);
+    SphereHit sh;
+    if (!sphere_intersect(sphere_of(prim), ray, false, &sh)) return false;
+    h->t = sh.t; h->b0 = h->b1 = h->b2 = 0.0f;
+    return true;
+  }
+  void prim_fill_interaction(int prim, const Ray& ray, const TriHit& h, SurfaceInteraction* si) const;
   std::vector<Texture> textures;
   std::vector<std::shared_ptr<MipMap>> mips;
   std::vector<Material> materials;

@@ -22,6 +22,7 @@ struct DLight {
   float l2w[12], w2l[12];
   int nu, nv; const float* func; const float* cdf; const float* func_int; const float* mfunc; const float* mcdf; float mfunc_int;
 };
+struct DSphere;  // rtx_dev_sphere.h
 struct DScene {
   const float4* nodes; unsigned n_nodes;
   const float4* pairs;  // n_nodes x 64 B child-pair records of the interior nodes (NULL for LDS-resident scenes), see k_trace_pair
@@ -29,6 +30,7 @@ struct DScene {
   const float4* tri_p; unsigned n_tris;
   const float* tri_n; const float* tri_uv; const float* tri_s;
   const int2* tri_alpha;  // {alpha, shadowalpha} texture ids of the triangles whose flags carry bit 4 / bit 5 (NULL: no mask in the scene)
+  const DSphere* spheres; // analytic spheres: a primitive whose flags carry bit 6 (RT_PRIM_SPHERE) holds its world box in p0 / p1 and its index as the bits of p2.x
   const DTexture* textures; const DImage* images; const DMaterial* materials; const DLight* lights;
   int n_lights; int n_infinite; int infinite_ids[4];
   int needs_differentials;  // some texture reads dudx.. / dpdx.. (image maps, closed-form checkerboards, fbm)
@@ -143,6 +145,8 @@ RT_DEV void load_tri(const float4* tri_p, int prim, f3& p0, f3& p1, f3& p2) {
 RT_DEV int tri_material(const float4* tri_p, int prim) { return __float_as_int(tri_p[3 * prim].w); }
 RT_DEV int tri_light(const float4* tri_p, int prim) { return __float_as_int(tri_p[3 * prim + 1].w); }
 RT_DEV unsigned tri_flags(const float4* tri_p, int prim) { return __float_as_uint(tri_p[3 * prim + 2].w); }
+#define RT_FLAG_SPHERE 64u
+RT_DEV unsigned prim_sphere_index(const float4* tri_p, int prim) { return __float_as_uint(tri_p[3 * prim + 2].x); }
 
 // ---------------------------------------------------------------- interactions (rc/interaction.rs)
 struct Interaction { f3 p, p_error, wo, n; };

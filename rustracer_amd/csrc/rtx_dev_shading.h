@@ -4,6 +4,7 @@
 #pragma once
 #include "rtx_dev_bsdf.h"
 #include "rtx_dev_scene.h"
+#include "rtx_dev_sphere.h"
 
 namespace rtx {
 
@@ -548,6 +549,7 @@ RT_DEV LiSample area_light_sample_li(const DScene& sc, const DLight& l, const In
 // Shape::pdf_wi (shapes/mod.rs:59-68): re-intersects the emitter triangle (Triangle::intersect, alpha mask included)
 template <bool GENERAL>  // true only in the shade kernel of scenes with alpha-masked EMITTERS: the mask evaluator is a large out-of-line function
 RT_DEV float area_light_pdf_li(const DScene& sc, const DLight& l, const Interaction& ref, f3 wi) {
+  if (GENERAL && (tri_flags(sc.tri_p, l.prim) & RT_FLAG_SPHERE)) return sphere_pdf_wi(sc.spheres[prim_sphere_index(sc.tri_p, l.prim)], ref, wi);  // Sphere overrides pdf_wi
   Ray ray = spawn_ray(ref, wi);
   f3 p0, p1, p2; load_tri(sc.tri_p, l.prim, p0, p1, p2);
   TriHit h;
@@ -556,10 +558,18 @@ RT_DEV float area_light_pdf_li(const DScene& sc, const DLight& l, const Interact
   f3 p, n; tri_hit_point_normal_inl(sc, l.prim, h, p, n);
   return distance_squared(ref.p, p) / (fabsf(dot(n, -wi)) * l.area);
 }
+template <bool GENERAL>
 RT_DEVN LiSample light_sample_li(const DScene& sc, const DLight& l, const Interaction& ref, f2 u) {
   LiSample s;
   switch (l.kind) {
-    case 0: return area_light_sample_li(sc, l, ref, u);
+    case 0:
+      if (GENERAL && (tri_flags(sc.tri_p, l.prim) & RT_FLAG_SPHERE)) {  // DiffuseAreaLight::sample_li (diffuse.rs:59-70) over Sphere::sample_si
+        float pdf; const SpherePoint sp = sphere_sample_si(sc.spheres[prim_sphere_index(sc.tri_p, l.prim)], ref, u, pdf);
+        s.p1.p = sp.p; s.p1.p_error = sp.p_error; s.p1.wo = mk3(0, 0, 0); s.p1.n = sp.n;
+        s.wi = normalize(sp.p - ref.p); s.pdf = pdf; s.li = area_light_l(l, sp.n, -s.wi);
+        return s;
+      }
+      return area_light_sample_li(sc, l, ref, u);
     case 1: {  // PointLight::sample_li point.rs:43-54 (I / (4 pi r^2), reference quirk)
       f3 pos = mk3(l.vec[0], l.vec[1], l.vec[2]);
       f3 wi = pos - ref.p;

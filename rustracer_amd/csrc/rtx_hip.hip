@@ -57,7 +57,8 @@ struct rt_scene {
   DevBuf pairs, tmin_stack;  // child-pair node records and the HBM half of the traversal stack (k_trace_pair)
   bool use_pairs = false;
   DevBuf quads; bool use_quads = false; int quad_stack_depth = 0;  // four-wide records of the any-hit kernel (k_trace_quad)
-  DevBuf nodes, tri_p, tri_n, tri_uv, tri_s, tri_alpha, textures, images, materials, lights, texels, dist;
+  DevBuf nodes, tri_p, tri_n, tri_uv, tri_s, tri_alpha, spheres, textures, images, materials, lights, texels, dist;
+  bool has_spheres = false;
   bool general_prims = false;  // alpha-masked triangles: traced by k_trace_big<.., GENERAL> only
   bool masked_emitters = false;  // ... and some of them emit: every vertex is shaded by k_shade<0, true> (Shape::pdf_wi evaluates the mask)
   std::vector<DLight> h_lights;
@@ -145,6 +146,15 @@ extern "C" int rt_scene_create(const rt_scene_desc* desc, int device, rt_scene**
     }
   }
   if (s->general_prims) TRY_RC(upload(s->tri_alpha, desc->tri_alpha, (size_t)desc->n_tris * 8));
+  static_assert(sizeof(rt_sphere) == sizeof(DSphere), "rt_sphere and DSphere are the same record");
+  for (size_t i = 0; i < desc->n_tris; ++i)
+    if (desc->tri_meta[i].flags & RT_PRIM_SPHERE) {
+      uint32_t k; memcpy(&k, desc->tri_p + 9 * i + 6, 4);
+      if (!desc->spheres || k >= desc->n_spheres) { delete s; return fail(RT_ERR_INVALID, "sphere index out of range"); }
+      if (desc->tri_meta[i].flags & (RT_TRI_HAS_N | RT_TRI_HAS_UV | RT_TRI_HAS_S | RT_TRI_HAS_ALPHA | RT_TRI_HAS_SHADOW_ALPHA)) { delete s; return fail(RT_ERR_INVALID, "a sphere primitive carries triangle attributes"); }
+      s->has_spheres = true;
+    }
+  if (s->has_spheres) { TRY_RC(upload(s->spheres, desc->spheres, (size_t)desc->n_spheres * sizeof(rt_sphere))); s->general_prims = true; }
   TRY_RC(upload(s->tri_p, tp.data(), tp.size() * 4));
   if (desc->tri_n) TRY_RC(upload(s->tri_n, desc->tri_n, (size_t)desc->n_tris * 36));
   if (desc->tri_uv) TRY_RC(upload(s->tri_uv, desc->tri_uv, (size_t)desc->n_tris * 24));
@@ -327,7 +337,8 @@ extern "C" int rt_scene_create(const rt_scene_desc* desc, int device, rt_scene**
   d.nodes = s->nodes.as<float4>(); d.n_nodes = desc->n_nodes;
   d.tri_p = s->tri_p.as<float4>(); d.n_tris = desc->n_tris;
   d.tri_n = s->tri_n.as<float>(); d.tri_uv = s->tri_uv.as<float>(); d.tri_s = s->tri_s.as<float>();
-  d.tri_alpha = s->general_prims ? s->tri_alpha.as<int2>() : nullptr;
+  d.tri_alpha = s->tri_alpha.p ? s->tri_alpha.as<int2>() : nullptr;
+  d.spheres = s->has_spheres ? s->spheres.as<DSphere>() : nullptr;
   d.textures = s->textures.as<DTexture>(); d.images = s->images.as<DImage>(); d.materials = s->materials.as<DMaterial>(); d.lights = s->lights.as<DLight>();
   d.n_lights = (int)desc->n_lights;
   d.wb_min = f3{desc->nodes[0].bmin[0], desc->nodes[0].bmin[1], desc->nodes[0].bmin[2]};
@@ -360,6 +371,7 @@ extern "C" int rt_scene_create(const rt_scene_desc* desc, int device, rt_scene**
   for (uint32_t i = 0; i < desc->n_lights; ++i) if (desc->lights[i].kind != RT_LIGHT_DIFFUSE_AREA) s->lambert_only = false;
   for (uint32_t i = 0; i < desc->n_lights; ++i)
     if (desc->lights[i].kind == RT_LIGHT_DIFFUSE_AREA && (desc->tri_meta[desc->lights[i].prim].flags & RT_TRI_HAS_ALPHA)) s->masked_emitters = true;
+  if (s->has_spheres) s->masked_emitters = true;  // sphere hits, sphere emitters: the generic shade kernel and its GENERAL light functions
   if (s->masked_emitters) { s->lambert_only = false; s->lambert_materials = false; }  // only the generic kernel re-intersects emitters with the mask test
   s->n_materials = desc->n_materials;
   s->small = desc->n_nodes <= RT_SMALL_NODES && desc->n_tris <= RT_SMALL_TRIS && !s->general_prims;
@@ -507,7 +519,8 @@ static int build_light_distribution(rt_scene* s, int strategy, hipStream_t strea
     unsigned lights_pad = 1; while (lights_pad < (unsigned)nl) lights_pad <<= 1;
     const unsigned long long contrib_blocks = lights_pad <= 128u ? (rows + 128u / lights_pad - 1) / (128u / lights_pad) : (unsigned long long)rows * (unsigned)((nl + 127) / 128);
     if (contrib_blocks > 0x7fffffffull) return fail(RT_ERR_INVALID, "light distribution grid too large");
-    hipLaunchKernelGGL(k_lightdist_contrib, dim3((unsigned)contrib_blocks), dim3(128), 0, stream, d, list, n_list, lights_pad, (unsigned)((nl + 127) / 128), s->ld_func.as<float>());
+    if (s->has_spheres) hipLaunchKernelGGL(k_lightdist_contrib<true>, dim3((unsigned)contrib_blocks), dim3(128), 0, stream, d, list, n_list, lights_pad, (unsigned)((nl + 127) / 128), s->ld_func.as<float>());
+    else hipLaunchKernelGGL(k_lightdist_contrib<false>, dim3((unsigned)contrib_blocks), dim3(128), 0, stream, d, list, n_list, lights_pad, (unsigned)((nl + 127) / 128), s->ld_func.as<float>());
     hipLaunchKernelGGL(k_lightdist_finish, dim3((unsigned)((rows + 127) / 128)), dim3(128), 0, stream, d, list, n_list, s->ld_func.as<float>(), s->ld_cdf.as<float>(), s->ld_int.as<float>(), s->ld_slot.as<int>());
     HIP_TRY(hipGetLastError());
   }
@@ -1019,7 +1032,8 @@ extern "C" int rt_render(rt_scene* s, const rt_camera* cam, const rt_film_desc* 
         if (ps.mis_any) launch_trace<true>(s, false, io_mis_any, ps.q_misany, ps.cnt_out + 3 * RT_QSHARDS, ps.shard_cap, 0, dstats, ST_RAYS_MIS, ST_NODES_MIS, ST_TRIS_MIS, stream);
         tm.end();
         tm.begin(&stats.ms_resolve);
-        hipLaunchKernelGGL(k_resolve, dim3(pgrid), dim3(256), 0, stream, s->d, ps);
+        if (s->has_spheres) hipLaunchKernelGGL(k_resolve<true>, dim3(pgrid), dim3(256), 0, stream, s->d, ps);
+        else hipLaunchKernelGGL(k_resolve<false>, dim3(pgrid), dim3(256), 0, stream, s->d, ps);
         tm.end();
         stats.launches_trace_closest += 2;
         ps.q_in = q_first;

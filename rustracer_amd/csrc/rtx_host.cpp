@@ -198,6 +198,10 @@ struct rtxh_scene {
   // input soup
   std::vector<float> P, N, UV, S; std::vector<int32_t> idx, tri_mat, tri_light; std::vector<uint8_t> tri_flags;
   std::vector<int32_t> tri_alpha;  // 2 per triangle {alpha, shadowalpha} float-texture ids or -1 (empty: no mesh carries a mask)
+  // Shape "sphere": primitive ids n_tris() .. n_prims() - 1
+  struct HostSphere { rt_sphere s; int32_t material, light; };
+  std::vector<HostSphere> spheres; std::vector<rt_sphere> f_spheres;
+  size_t n_prims() const { return n_tris() + spheres.size(); }
   std::vector<rt_texture> textures; std::vector<rt_material> materials; std::vector<MipLevels> mips; std::vector<HostLight> lights;
   // BVH products
   std::vector<rt_bvh_node> nodes; std::vector<int32_t> ordered;
@@ -290,17 +294,38 @@ struct Builder {
 
 int finish_commit(rtxh_scene* s);
 
+// Sphere::world_bounds (sphere.rs:212-225): the 8 corners of the object-space box through object_to_world, in the reference's order
+static Box sphere_world_box(const rt_sphere& sp) {
+  const float lo[3] = {-sp.radius, -sp.radius, sp.z_min}, hi[3] = {sp.radius, sp.radius, sp.z_max};
+  const int order[8][3] = {{0, 0, 0}, {1, 0, 0}, {0, 1, 0}, {0, 0, 1}, {1, 1, 0}, {1, 0, 1}, {0, 1, 1}, {1, 1, 1}};
+  Box bb; const float M = std::numeric_limits<float>::max();
+  for (int k = 0; k < 3; ++k) { bb.lo[k] = M; bb.hi[k] = -M; }  // Bounds3f::new, bounds.rs:25-32
+  for (int c = 0; c < 8; ++c) {
+    const float x = order[c][0] ? hi[0] : lo[0], y = order[c][1] ? hi[1] : lo[1], z = order[c][2] ? hi[2] : lo[2];
+    float p[3];
+    for (int r = 0; r < 3; ++r) p[r] = sp.o2w[4 * r] * x + sp.o2w[4 * r + 1] * y + sp.o2w[4 * r + 2] * z + sp.o2w[4 * r + 3];
+    const float wp = sp.o2w[12] * x + sp.o2w[13] * y + sp.o2w[14] * z + sp.o2w[15];  // Transform * Point3f, transform.rs:264-286
+    if (wp != 1.0f) for (int r = 0; r < 3; ++r) p[r] = p[r] / wp;
+    box_extend(bb, p);
+  }
+  return bb;
+}
+
 int commit_scene(rtxh_scene* s, int max_prims_per_node) {
-  const size_t nt = s->n_tris();
+  const size_t n_triangles = s->n_tris();
+  const size_t nt = s->n_prims();  // every primitive: the triangles, then the spheres
   if (nt == 0) return fail(RT_ERR_INVALID, "no triangles");
   Builder b; b.max_prims = max_prims_per_node > 255 ? 255 : max_prims_per_node;
   std::vector<int32_t> a_prim(nt); std::vector<Box> a_pb(nt); std::vector<float> a_cx(nt), a_cy(nt), a_cz(nt);
   b.prim = a_prim.data(); b.pb = a_pb.data(); b.cx = a_cx.data(); b.cy = a_cy.data(); b.cz = a_cz.data();
   for (size_t t = 0; t < nt; ++t) {  // Triangle::world_bounds, mesh.rs:603-608
-    const float* p0 = &s->P[3 * s->idx[3 * t]]; const float* p1 = &s->P[3 * s->idx[3 * t + 1]]; const float* p2 = &s->P[3 * s->idx[3 * t + 2]];
     Box bb;
-    for (int k = 0; k < 3; ++k) { bb.lo[k] = pmin(p0[k], p1[k]); bb.hi[k] = pmax(p0[k], p1[k]); }
-    box_extend(bb, p2);
+    if (t >= n_triangles) bb = sphere_world_box(s->spheres[t - n_triangles].s);
+    else {
+      const float* p0 = &s->P[3 * s->idx[3 * t]]; const float* p1 = &s->P[3 * s->idx[3 * t + 1]]; const float* p2 = &s->P[3 * s->idx[3 * t + 2]];
+      for (int k = 0; k < 3; ++k) { bb.lo[k] = pmin(p0[k], p1[k]); bb.hi[k] = pmax(p0[k], p1[k]); }
+      box_extend(bb, p2);
+    }
     b.prim[t] = (int32_t)t; b.pb[t] = bb;
     b.cx[t] = 0.5f * bb.lo[0] + 0.5f * bb.hi[0]; b.cy[t] = 0.5f * bb.lo[1] + 0.5f * bb.hi[1]; b.cz[t] = 0.5f * bb.lo[2] + 0.5f * bb.hi[2];  // :532
   }
@@ -365,6 +390,7 @@ int commit_scene(rtxh_scene* s, int max_prims_per_node) {
 int commit_scene_device(rtxh_scene* s, int max_prims_per_node, float* ms_device) {
   const size_t nt = s->n_tris();
   if (nt == 0) return fail(RT_ERR_INVALID, "no triangles");
+  if (!s->spheres.empty()) return fail(RT_ERR_UNSUPPORTED, "the device BVH builder takes triangles only: a scene with analytic spheres is built by the host");
   std::vector<float> tp(nt * 9);
   for (size_t t = 0; t < nt; ++t) for (int v = 0; v < 3; ++v) for (int k = 0; k < 3; ++k) tp[9 * t + 3 * v + k] = s->P[3 * s->idx[3 * t + v] + k];
   s->nodes.assign(2 * nt - 1, rt_bvh_node{}); s->ordered.assign(nt, -1);
@@ -376,7 +402,8 @@ int commit_scene_device(rtxh_scene* s, int max_prims_per_node, float* ms_device)
 }
 
 int finish_commit(rtxh_scene* s) {
-  const size_t nt = s->n_tris();
+  const size_t n_triangles = s->n_tris();
+  const size_t nt = s->n_prims();
   // world bounding sphere for distant / infinite lights (Scene::new -> Light::preprocess, scene.rs:29-49; bounds.rs:199-212)
   const rt_bvh_node& r0 = s->nodes[0];
   float c[3] = {(r0.bmin[0] + r0.bmax[0]) / 2.0f, (r0.bmin[1] + r0.bmax[1]) / 2.0f, (r0.bmin[2] + r0.bmax[2]) / 2.0f};
@@ -390,8 +417,19 @@ int finish_commit(rtxh_scene* s) {
   const bool any_n = !s->N.empty(), any_uv = !s->UV.empty(), any_s = !s->S.empty();
   s->f_p.assign(nt * 9, 0.0f); s->f_meta.assign(nt, rt_tri_meta{});
   if (any_n) s->f_n.assign(nt * 9, 0.0f); if (any_uv) s->f_uv.assign(nt * 6, 0.0f); if (any_s) s->f_s.assign(nt * 9, 0.0f);
+  s->f_spheres.clear();
+  for (const auto& hs : s->spheres) s->f_spheres.push_back(hs.s);
   for (size_t i = 0; i < nt; ++i) {
     const int32_t t = s->ordered[i];
+    if ((size_t)t >= n_triangles) {  // a sphere: world box in p0 / p1, its index as the bits of p2.x
+      const auto& hs = s->spheres[(size_t)t - n_triangles];
+      const Box bb = sphere_world_box(hs.s);
+      for (int k = 0; k < 3; ++k) { s->f_p[9 * i + k] = bb.lo[k]; s->f_p[9 * i + 3 + k] = bb.hi[k]; }
+      const uint32_t si = (uint32_t)((size_t)t - n_triangles); memcpy(&s->f_p[9 * i + 6], &si, 4);
+      const uint32_t flip = (hs.s.reverse_orientation != 0) != (hs.s.swaps_handedness != 0) ? RT_TRI_FLIP : 0u;
+      s->f_meta[i] = rt_tri_meta{hs.material, hs.light, RT_PRIM_SPHERE | flip, (uint32_t)t};
+      continue;
+    }
     for (int v = 0; v < 3; ++v) {
       const int32_t vi = s->idx[3 * t + v];
       for (int k = 0; k < 3; ++k) s->f_p[9 * i + 3 * v + k] = s->P[3 * vi + k];
@@ -406,6 +444,7 @@ int finish_commit(rtxh_scene* s) {
     s->f_alpha.assign(nt * 2, -1);
     for (size_t i = 0; i < nt; ++i) {
       const int32_t t = s->ordered[i];
+      if ((size_t)t >= n_triangles) continue;  // spheres carry no mask
       for (int k = 0; k < 2; ++k) {
         const int32_t id = s->tri_alpha[2 * (size_t)t + k];
         if (id >= (int32_t)s->textures.size()) return fail(RT_ERR_INVALID, "alpha texture out of range");
@@ -427,8 +466,16 @@ int finish_commit(rtxh_scene* s) {
   for (HostLight& hl : s->lights) {
     rt_light l = hl.l;
     if (l.kind == RT_LIGHT_DIFFUSE_AREA) {
+      if (hl.tri_source <= -2) hl.tri_source = (int)(n_triangles + (size_t)(-2 - hl.tri_source));  // -2 - k: the light sits on sphere k
       if (hl.tri_source < 0 || (size_t)hl.tri_source >= nt) return fail(RT_ERR_INVALID, "area light triangle out of range");
       l.prim = leaf_of[hl.tri_source];
+      if ((size_t)hl.tri_source >= n_triangles) {
+        const rt_sphere& sp = s->spheres[(size_t)hl.tri_source - n_triangles].s;
+        l.area = sp.phi_max * sp.radius * (sp.z_max - sp.z_min);  // Sphere::area, sphere.rs:336-338
+        if (l.kind == RT_LIGHT_DISTANT || l.kind == RT_LIGHT_INFINITE) l.world_radius = world_radius;
+        s->f_lights.push_back(l);
+        continue;
+      }
       const float* p0 = &s->P[3 * s->idx[3 * hl.tri_source]]; const float* p1 = &s->P[3 * s->idx[3 * hl.tri_source + 1]]; const float* p2 = &s->P[3 * s->idx[3 * hl.tri_source + 2]];
       float a[3] = {p1[0] - p0[0], p1[1] - p0[1], p1[2] - p0[2]}, bq[3] = {p2[0] - p0[0], p2[1] - p0[1], p2[2] - p0[2]};
       float cxr[3] = {(a[1] * bq[2]) - (a[2] * bq[1]), (a[2] * bq[0]) - (a[0] * bq[2]), (a[0] * bq[1]) - (a[1] * bq[0])};
@@ -450,6 +497,7 @@ rt_scene_desc make_desc(rtxh_scene* s) {
   d.n_tris = (uint32_t)s->n_tris(); d.tri_p = s->f_p.data();
   d.tri_n = s->f_n.empty() ? nullptr : s->f_n.data(); d.tri_uv = s->f_uv.empty() ? nullptr : s->f_uv.data(); d.tri_s = s->f_s.empty() ? nullptr : s->f_s.data();
   d.tri_meta = s->f_meta.data(); d.tri_alpha = s->f_alpha.empty() ? nullptr : s->f_alpha.data();
+  d.n_tris = (uint32_t)s->n_prims(); d.n_spheres = (uint32_t)s->f_spheres.size(); d.spheres = s->f_spheres.empty() ? nullptr : s->f_spheres.data();
   d.n_textures = (uint32_t)s->textures.size(); d.textures = s->textures.data();
   d.n_images = (uint32_t)s->f_images.size(); d.images = s->f_images.data();
   d.n_materials = (uint32_t)s->materials.size(); d.materials = s->materials.data();
@@ -522,6 +570,27 @@ int rtxh_scene_set_mesh(rtxh_scene* s, const float* P, int32_t nv, const int32_t
   }
   s->committed = false;
   return RT_OK;
+}
+
+// Shape "sphere" (Sphere::create sphere.rs:53-68 + Sphere::new :29-51). Returns the sphere's index k; an area light on it is added with tri = -2 - k.
+int rtxh_scene_add_sphere(rtxh_scene* s, const float* o2w16, const float* w2o16, float radius, float z_min, float z_max, float phi_max, int32_t reverse_orientation,
+                          int32_t material, int32_t light) {
+  if (!s || !o2w16 || !w2o16) return fail(RT_ERR_INVALID, "bad sphere arguments");
+  rtxh_scene::HostSphere hs{}; rt_sphere& sp = hs.s;
+  memcpy(sp.o2w, o2w16, 64); memcpy(sp.w2o, w2o16, 64);
+  auto clampf = [](float v, float lo, float hi) { return v < lo ? lo : (v > hi ? hi : v); };  // lib.rs:264-275
+  sp.radius = radius;
+  sp.z_min = clampf(std::fmin(z_min, z_max), -radius, radius); sp.z_max = clampf(std::fmax(z_min, z_max), -radius, radius);
+  sp.theta_min = std::acos(clampf(std::fmin(z_min, z_max) / radius, -1.0f, 1.0f)); sp.theta_max = std::acos(clampf(std::fmax(z_min, z_max) / radius, -1.0f, 1.0f));
+  sp.phi_max = clampf(phi_max, 0.0f, 360.0f) * (3.14159265358979323846f / 180.0f);  // f32::to_radians
+  sp.reverse_orientation = reverse_orientation ? 1 : 0;
+  const float* m = o2w16;  // Transform::swaps_handedness, transform.rs:255-261
+  const float det = m[0] * (m[5] * m[10] - m[6] * m[9]) - m[1] * (m[4] * m[10] - m[6] * m[8]) + m[2] * (m[4] * m[9] - m[5] * m[8]);
+  sp.swaps_handedness = det < 0.0f ? 1 : 0;
+  hs.material = material; hs.light = light;
+  s->spheres.push_back(hs);
+  s->committed = false;
+  return (int)s->spheres.size() - 1;
 }
 
 int rtxh_scene_set_alpha(rtxh_scene* s, const int32_t* tri_alpha2) {

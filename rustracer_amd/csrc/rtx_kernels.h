@@ -652,6 +652,15 @@ __global__ void __launch_bounds__(BLOCK) k_trace_big(DScene sc, TraceIO io, cons
         src.tri(leaf_off + i, p0, p1, p2);
         if (COUNT) n_tris += 1;
         TriHit h;
+        if (GENERAL && (tri_flags(sc.tri_p, leaf_off + i) & RT_FLAG_SPHERE)) {  // Sphere::intersect; the hit record carries t where a triangle's carries b2
+          float ts;
+          if (!sphere_test(sc.spheres[__float_as_uint(p2.x)], ray.o, ray.d, ray.t_max, ts)) continue;
+          h.t = ts; h.b0 = h.b1 = 0.0f; h.b2 = ts;
+          found = true;
+          if (ANY) break;
+          ray.t_max = ts; prim = leaf_off + i; hit = h;
+          continue;
+        }
         if (tri_test_pre(p0, p1, p2, ray, rp, h)) {
           if (GENERAL && tri_alpha_rejects(sc, leaf_off + i, h, ANY)) continue;
           found = true;
@@ -1269,7 +1278,12 @@ __global__ void __launch_bounds__(256, MODE == 1 ? RT_SHADE_MIN_WAVES : RT_SHADE
       // the frame loop's hit record is (b2, prim, b0, b1): the three barycentrics of the accepted test
       SurfaceInteraction si; TriHit th; th.t = 0.0f; th.b0 = h4.z; th.b1 = h4.w; th.b2 = h4.x;
       if (found) {
-        if (MODE & 1) tri_fill_interaction_inl(sc, prim, ray_d, th, si);
+        if (GENERAL && (tri_flags(sc.tri_p, prim) & RT_FLAG_SPHERE)) {  // Sphere::intersect builds its interaction from the ray: origin and direction of the path's ray
+          const float4 o4 = prec->o;
+          (void)sphere_fill_interaction(sc.spheres[prim_sphere_index(sc.tri_p, prim)], mk3(o4.x, o4.y, o4.z), ray_d, si);
+          si.prim = prim;
+        }
+        else if (MODE & 1) tri_fill_interaction_inl(sc, prim, ray_d, th, si);
         else tri_fill_interaction(sc, prim, ray_d, th, si);
       }
       // path.rs:127-136 emitted light at the vertex / from the environment
@@ -1314,7 +1328,7 @@ __global__ void __launch_bounds__(256, MODE == 1 ? RT_SHADE_MIN_WAVES : RT_SHADE
             const DLight& light = sc.lights[light_num];
             // ---- estimate_direct (integrator/mod.rs:222-318), light-sampling half
             rgb3 ld1 = mkc(0, 0, 0); f3 sh_dir = mk3(0, 0, 0);
-            LiSample ls = (MODE == 1) ? area_light_sample_li(sc, light, si.hit, u_light) : light_sample_li(sc, light, si.hit, u_light);
+            LiSample ls = (MODE == 1) ? area_light_sample_li(sc, light, si.hit, u_light) : light_sample_li<GENERAL>(sc, light, si.hit, u_light);
             if (ls.pdf > 0.0f && !is_black(ls.li)) {
               rgb3 f = bsdf.f(si.hit.wo, ls.wi, nonspec) * fabsf(dot(ls.wi, si.sh_n));
               float scattering_pdf = bsdf.pdf(si.hit.wo, ls.wi, nonspec);
@@ -1430,6 +1444,7 @@ __global__ void __launch_bounds__(256) k_shade_miss(DScene sc, PassState ps) {
 // [the MIS ray reached the sampled light] f*Le*w/pdf; L += beta_at_vertex * (ld / light_pick_pdf).
 // Everything about the vertex sits in its 128-byte MisRec, so the entries are gathered through the two MIS queues (closest-hit rays, then
 // occlusion-only rays) at one line per vertex whatever order the shade kernel filled them in.
+template <bool GENERAL>  // GENERAL: the emitter a MIS ray reached may be an analytic sphere
 __global__ void __launch_bounds__(256) k_resolve(DScene sc, PassState ps) {
   QView qv; qv.init(ps.q_mis, ps.cnt_out + 2 * RT_QSHARDS, ps.shard_cap);
   QView qa; qa.init(ps.q_misany, ps.cnt_out + 3 * RT_QSHARDS, ps.shard_cap);
@@ -1453,7 +1468,11 @@ __global__ void __launch_bounds__(256) k_resolve(DScene sc, PassState ps) {
       } else {
         const int prim = __float_as_int(h4.y);
         if (prim >= 0) {  // integrator/mod.rs:293-307: emitted radiance only if the hit emitter IS the sampled light
-          if (tri_light(sc.tri_p, prim) == light_num) {
+          if (GENERAL && tri_light(sc.tri_p, prim) == light_num && (tri_flags(sc.tri_p, prim) & RT_FLAG_SPHERE)) {
+            float4 o4 = m->o;
+            SurfaceInteraction lsi; (void)sphere_fill_interaction(sc.spheres[prim_sphere_index(sc.tri_p, prim)], mk3(o4.x, o4.y, o4.z), wi, lsi);
+            li = area_light_l(light, lsi.hit.n, -wi);
+          } else if (tri_light(sc.tri_p, prim) == light_num) {
             float4 o4 = m->o;
             f3 p0, p1, p2; load_tri(sc.tri_p, prim, p0, p1, p2);
             Ray r; r.o = mk3(o4.x, o4.y, o4.z); r.d = wi; r.t_max = kInf;
@@ -1555,8 +1574,9 @@ __global__ void __launch_bounds__(256) k_lightdist_mark(DScene sc, unsigned char
   const unsigned t = blockIdx.x * blockDim.x + threadIdx.x;
   if (t >= sc.n_tris) return;
   f3 p0, p1, p2; load_tri(sc.tri_p, (int)t, p0, p1, p2);
-  const f3 mn = mk3(fminf(p0.x, fminf(p1.x, p2.x)), fminf(p0.y, fminf(p1.y, p2.y)), fminf(p0.z, fminf(p1.z, p2.z)));
-  const f3 mx = mk3(fmaxf(p0.x, fmaxf(p1.x, p2.x)), fmaxf(p0.y, fmaxf(p1.y, p2.y)), fmaxf(p0.z, fmaxf(p1.z, p2.z)));
+  const bool is_sphere = (tri_flags(sc.tri_p, (int)t) & RT_FLAG_SPHERE) != 0u;  // its slot holds the world box: every voxel of the box is kept
+  const f3 mn = is_sphere ? p0 : mk3(fminf(p0.x, fminf(p1.x, p2.x)), fminf(p0.y, fminf(p1.y, p2.y)), fminf(p0.z, fminf(p1.z, p2.z)));
+  const f3 mx = is_sphere ? p1 : mk3(fmaxf(p0.x, fmaxf(p1.x, p2.x)), fmaxf(p0.y, fmaxf(p1.y, p2.y)), fmaxf(p0.z, fmaxf(p1.z, p2.z)));
   const f3 o0 = bounds_offset(sc.wb_min, sc.wb_max, mn), o1 = bounds_offset(sc.wb_min, sc.wb_max, mx);
   const float pad = 1e-4f;  // in units of the scene extent: >> the rounding of p and of voxel_of, << one voxel (1/64)
   int lo[3], hi[3];
@@ -1569,7 +1589,7 @@ __global__ void __launch_bounds__(256) k_lightdist_mark(DScene sc, unsigned char
   const f3 ext = sc.wb_max - sc.wb_min;
   const f3 h = mk3(0.51f * ext.x / (float)sc.nvox[0] + pad * ext.x, 0.51f * ext.y / (float)sc.nvox[1] + pad * ext.y, 0.51f * ext.z / (float)sc.nvox[2] + pad * ext.z);  // inflated half extents
   const float r = fabsf(n.x) * h.x + fabsf(n.y) * h.y + fabsf(n.z) * h.z;
-  const bool flat = !(len2(n) > 0.0f);  // degenerate triangle: keep its whole box
+  const bool flat = is_sphere || !(len2(n) > 0.0f);  // degenerate triangle: keep its whole box
   for (int z = lo[2]; z <= hi[2]; ++z)
     for (int y = lo[1]; y <= hi[1]; ++y)
       for (int x = lo[0]; x <= hi[0]; ++x) {
@@ -1597,6 +1617,7 @@ RT_DEV void voxel_bounds(const DScene& sc, long v, f3& vmn, f3& vmx) {
 }
 // Lanes of a 128-lane block = (voxel slot, light): with lights_pad = n_lights rounded up to a power of two, a block
 // covers 128 / lights_pad list entries when lights_pad <= 128, else bpv = ceil(n_lights / 128) consecutive blocks cover one.
+template <bool GENERAL>  // GENERAL: an emitter may be an analytic sphere
 __global__ void __launch_bounds__(128) k_lightdist_contrib(DScene sc, const unsigned* __restrict__ list, const unsigned* __restrict__ n_list, unsigned lights_pad, unsigned bpv, float* func) {
   __shared__ float halton[128 * 5];
   unsigned li; int j;
@@ -1610,7 +1631,7 @@ __global__ void __launch_bounds__(128) k_lightdist_contrib(DScene sc, const unsi
   f3 vmn, vmx; voxel_bounds(sc, v, vmn, vmx);
   const DLight& light = sc.lights[j];
   float contrib = 0.0f;
-  if (light.kind == 0) {
+  if (light.kind == 0 && !(GENERAL && (tri_flags(sc.tri_p, light.prim) & RT_FLAG_SPHERE))) {
     // DiffuseAreaLight::sample_li (area_light_sample_li) with what does not depend on the sample taken out of the 128-sample loop:
     // the emitter's vertices, its normal when the mesh carries no per-vertex normals, 1 / area. Same operations per sample, same sums.
     f3 p0, p1, p2; load_tri(sc.tri_p, light.prim, p0, p1, p2);
@@ -1643,7 +1664,7 @@ __global__ void __launch_bounds__(128) k_lightdist_contrib(DScene sc, const unsi
       Interaction intr;
       intr.p = bounds_lerp(vmn, vmx, mk3(halton[5 * i], halton[5 * i + 1], halton[5 * i + 2]));
       intr.p_error = mk3(0, 0, 0); intr.wo = mk3(1, 0, 0); intr.n = mk3(0, 0, 0);
-      LiSample s = light_sample_li(sc, light, intr, mk2(halton[5 * i + 3], halton[5 * i + 4]));
+      LiSample s = light_sample_li<GENERAL>(sc, light, intr, mk2(halton[5 * i + 3], halton[5 * i + 4]));
       if (s.pdf > 0.0f) contrib += lum_y(s.li) / s.pdf;
     }
   }

@@ -83,7 +83,7 @@ struct PbrtLoader {
   PbrtGraphicsState gs; std::vector<PbrtGraphicsState> pushed_gs;
   PbrtSoup world;
   std::map<std::string, PbrtSoup> instances; std::string current_instance; bool in_instance = false;  // RenderOptions::instances / current_instance (api.rs:175-177)
-  int n_lights = 0;
+  int n_lights = 0, n_spheres = 0;
 
   bool fail_(const std::string& m) { if (err.empty()) err = m; return false; }
   void warn(const std::string&) { warnings += 1; }
@@ -333,6 +333,29 @@ struct PbrtLoader {
   // ------------------------------------------------------------------ shapes (make_shapes api.rs:1093-1139; mesh.rs:76-179; plymesh.rs)
   bool add_shape(const std::string& name, const PbrtParams& p) {
     std::vector<float> vp, vn, vuv, vs; std::vector<int32_t> vi;
+    if (name == "sphere") {  // Sphere::create (sphere.rs:53-68): an analytic primitive under the CTM, with one DiffuseAreaLight if an area light is active (api.rs:933-946)
+      if (in_instance) return fail_("a sphere inside an object definition is not supported (instances are written out as triangles)");
+      const float radius = p.one_float("radius", 1.0f);
+      const float zmin = p.one_float("zmin", -radius), zmax = p.one_float("zmax", radius), phimax = p.one_float("phimax", 360.0f);
+      const int mat = current_material(p);
+      if (mat < 0) return fail_(err.empty() ? rtxh_last_error() : err);
+      int light = -1;
+      if (!gs.area_light.empty()) {
+        if (gs.area_light != "area" && gs.area_light != "diffuse") return fail_("area light \"" + gs.area_light + "\" unknown");
+        light = n_lights;
+      }
+      const int k = rtxh_scene_add_sphere(scene, &ctm.m.a[0][0], &ctm.inv.a[0][0], radius, zmin, zmax, phimax, gs.reverse_orientation ? 1 : 0, mat, light);
+      if (k < 0) return fail_(rtxh_last_error());
+      if (light >= 0) {
+        float L[3] = {1, 1, 1}, sc[3] = {1, 1, 1};
+        gs.area_light_params.one_rgb("L", L); gs.area_light_params.one_rgb("scale", sc);
+        for (int c = 0; c < 3; ++c) L[c] *= sc[c];
+        if (rtxh_scene_add_light(scene, RT_LIGHT_DIFFUSE_AREA, -2 - k, L, gs.area_light_params.one_bool("twosided", false) ? 1 : 0, nullptr, -1, nullptr, nullptr) < 0) return fail_(rtxh_last_error());
+        n_lights++;
+      }
+      n_spheres++;
+      return true;
+    }
     if (name == "trianglemesh") {
       const std::vector<float>* ind = p.floats("indices", {"integer"});
       const std::vector<float>* pts = p.floats("P", {"point3", "point"});
@@ -350,7 +373,7 @@ struct PbrtLoader {
       if (ply.N) vn.assign(ply.N, ply.N + (size_t)ply.n_verts * 3);
       if (ply.UV) vuv.assign(ply.UV, ply.UV + (size_t)ply.n_verts * 2);
       rtxh_ply_free(&ply);
-    } else return fail_("shape \"" + name + "\" is not supported (triangle meshes only)");
+    } else return fail_("shape \"" + name + "\" is not supported (triangle meshes and spheres only)");
     // "alpha" / "shadowalpha" (TriangleMesh::create mesh.rs:134-156, plymesh.rs:143-165): a named float texture (unknown name: logged, no mask),
     // else the constant-0 texture when the float parameter is exactly 0
     auto mask = [&](const char* n) -> int {
@@ -629,11 +652,11 @@ int pbrt_load_text(const std::string& text, const std::string& base_dir, rtxh_pb
   bool ok = PbrtLoader::tokenize(text, toks, L.err) && L.run(toks, 0);
   if (ok && !L.world_ended) { L.err = "missing WorldEnd"; ok = false; }
   if (ok) ok = L.finish_options();
-  if (ok && L.world.idx.empty()) { L.err = "the scene holds no triangles"; ok = false; }
+  if (ok && L.world.idx.empty() && L.n_spheres == 0) { L.err = "the scene holds no triangles"; ok = false; }
   if (ok) {
     const PbrtSoup& w = L.world;
     const int32_t nv = (int32_t)w.n_verts(), nt = (int32_t)(w.idx.size() / 3);
-    if (rtxh_scene_set_mesh(L.scene, w.P.data(), nv, w.idx.data(), nt, w.any_n ? w.N.data() : nullptr, w.any_uv ? w.UV.data() : nullptr, w.any_s ? w.S.data() : nullptr,
+    if (nt > 0 && rtxh_scene_set_mesh(L.scene, w.P.data(), nv, w.idx.data(), nt, w.any_n ? w.N.data() : nullptr, w.any_uv ? w.UV.data() : nullptr, w.any_s ? w.S.data() : nullptr,
                             w.tri_mat.data(), w.tri_light.data(), w.tri_flags.data()) != RT_OK) { L.err = rtxh_last_error(); ok = false; }
     bool any_mask = false; for (int32_t a : w.tri_alpha) any_mask |= a >= 0;
     if (ok && any_mask && rtxh_scene_set_alpha(L.scene, w.tri_alpha.data()) != RT_OK) { L.err = rtxh_last_error(); ok = false; }

@@ -180,10 +180,14 @@ class HostScene:
             _check(L.rtxh_scene_add_texture(self.h, t.kind, _p(np.float32(t.value)), t.tex1, t.tex2, t.amount, t.mip, _p(np.float32(t.mapping))), "add_texture")
         for m in desc.materials:
             _check(L.rtxh_scene_add_material(self.h, m.kind, _p(m.slots(), C.c_int32), int(m.remap_roughness), int(m.bump)), "add_material")
+        for sp in getattr(desc, "spheres", []):
+            _check(L.rtxh_scene_add_sphere(self.h, _p(sp.o2w), _p(sp.w2o), C.c_float(sp.radius), C.c_float(sp.z_min), C.c_float(sp.z_max), C.c_float(sp.phi_max),
+                                           int(sp.reverse_orientation), sp.material, sp.light), "add_sphere")
         for l in desc.lights:
             l2w = None if l.l2w is None else np.ascontiguousarray(l.l2w, np.float32)
             w2l = None if l.w2l is None else np.ascontiguousarray(l.w2l, np.float32)
-            _check(L.rtxh_scene_add_light(self.h, l.kind, l.tri, _p(np.float32(l.rgb)), int(l.two_sided), _p(np.float32(l.vec)), l.mip, _p(l2w), _p(w2l)), "add_light")
+            tri = l.tri if getattr(l, "sphere", -1) < 0 else -2 - l.sphere  # -2 - k: the area light sits on sphere k
+            _check(L.rtxh_scene_add_light(self.h, l.kind, tri, _p(np.float32(l.rgb)), int(l.two_sided), _p(np.float32(l.vec)), l.mip, _p(l2w), _p(w2l)), "add_light")
         self.bvh_build_ms = None
         if device_bvh:
             ms = C.c_float()

@@ -218,6 +218,18 @@ class _Writer:
             o.append(shape)
             o.append("AttributeEnd")
             nv0 += nv
+        for k, sp in enumerate(getattr(d, "spheres", [])):  # Shape "sphere" under its object-to-world transform, with its area light if it has one
+            name = self.material(sp.material)
+            o.append("AttributeBegin")
+            o.append(f'  NamedMaterial "{name}"')
+            o.append(f"  Transform [{_nums(np.asarray(sp.o2w, np.float32).T)}]")
+            if sp.reverse_orientation:
+                o.append("  ReverseOrientation")
+            if sp.light >= 0:
+                l = d.lights[sp.light]
+                o.append(f'  AreaLightSource "diffuse" "rgb L" [{_nums(l.rgb)}] "bool twosided" "{"true" if l.two_sided else "false"}"')
+            o.append(f'  Shape "sphere" "float radius" [{_n(sp.radius)}] "float zmin" [{_n(sp.z_min)}] "float zmax" [{_n(sp.z_max)}] "float phimax" [{_n(sp.phi_max)}]')
+            o.append("AttributeEnd")
         for _, l in other:
             self.light(l)
         o.append("WorldEnd")

@@ -70,12 +70,26 @@ class Material:
 class Light:
     kind: int = LIGHT_DIFFUSE_AREA
     tri: int = -1
+    sphere: int = -1  # area light on analytic sphere number `sphere` instead of on a triangle
     rgb: Sequence[float] = (1.0, 1.0, 1.0)
     two_sided: bool = False
     vec: Sequence[float] = (0.0, 0.0, 0.0)  # point: position; distant: from - to
     mip: int = -1
     l2w: Optional[np.ndarray] = None  # 4x4 (infinite)
     w2l: Optional[np.ndarray] = None
+
+
+@dataclass
+class SphereShape:  # Shape "sphere" (rc/shapes/sphere.rs:53-68)
+    o2w: np.ndarray  # 4x4 object-to-world, float32
+    w2o: np.ndarray
+    radius: float = 1.0
+    z_min: float = -1.0
+    z_max: float = 1.0
+    phi_max: float = 360.0
+    reverse_orientation: bool = False
+    material: int = 0
+    light: int = -1  # index into the light list of its DiffuseAreaLight, or -1
 
 
 @dataclass
@@ -130,6 +144,7 @@ class SceneDesc:
         self._nt = 0
         self.textures: List[Texture] = []
         self.mipmaps: List[MipImage] = []
+        self.spheres: List[SphereShape] = []
         self.materials: List[Material] = []
         self.lights: List[Light] = []
         self.camera = Camera()
@@ -289,6 +304,23 @@ class SceneDesc:
         self._nv += nv
         self._nt += nt
         return first
+
+    def add_sphere(self, center=(0.0, 0.0, 0.0), radius=1.0, material: int = 0, o2w=None, z_min=None, z_max=None, phi_max=360.0,
+                   reverse_orientation=False, emission=None, two_sided=False) -> int:
+        """Shape "sphere" (rc/shapes/sphere.rs): an analytic sphere - optionally clipped in z and phi - under `o2w` (default: a translation to
+        `center`). With `emission` it carries one DiffuseAreaLight (one light per Shape, rc/api.rs:933-946). Returns the sphere's index."""
+        if o2w is None:
+            o2w = np.eye(4, dtype=np.float32)
+            o2w[:3, 3] = np.float32(center)
+        o2w = np.ascontiguousarray(o2w, np.float32)
+        w2o = np.ascontiguousarray(np.linalg.inv(o2w.astype(np.float64)), np.float32)
+        light = -1
+        if emission is not None:
+            self.lights.append(Light(LIGHT_DIFFUSE_AREA, tri=-1, sphere=len(self.spheres), rgb=tuple(float(x) for x in emission), two_sided=two_sided))
+            light = len(self.lights) - 1
+        self.spheres.append(SphereShape(o2w, w2o, float(radius), float(-radius if z_min is None else z_min), float(radius if z_max is None else z_max),
+                                        float(phi_max), bool(reverse_orientation), int(material), light))
+        return len(self.spheres) - 1
 
     def add_quad(self, p0, p1, p2, p3, material: int, **kw) -> int:
         return self.add_mesh([p0, p1, p2, p3], [[0, 1, 2], [0, 2, 3]], material, **kw)

@@ -1,7 +1,8 @@
 """S3 "mis-plates" (BASELINE config 4, veach-mis-class): four tilted plates with Trowbridge-Reitz roughness
-0.005 / 0.02 / 0.05 / 0.1 (metal and plastic), four emitters of radius 0.03 / 0.1 / 0.3 / 0.9 tessellated as
-icospheres with equal power (the reference's sphere emitters are analytic; tessellation is a documented deviation,
-SURVEY.md §8a-22), a dim floor light. Exercises microfacet BSDFs, MIS and the spatial light distribution."""
+0.005 / 0.02 / 0.05 / 0.1 (metal and plastic), four emitters of radius 0.03 / 0.1 / 0.3 / 0.9 with equal power - tessellated as
+icospheres (1280 emitter triangles: the many-lights workload the BASELINE config is benchmarked on) or, with `analytic_spheres=True`, as four
+Shape "sphere" emitters the way veach-mis.pbrt has them - and a dim ceiling light. Exercises microfacet BSDFs, MIS and the
+spatial light distribution."""
 from __future__ import annotations
 
 import numpy as np
@@ -10,7 +11,7 @@ from ..scene_desc import SceneDesc
 from .procedural import icosphere
 
 
-def mis_plates(xres: int = 1280, yres: int = 720, spp: int = 512, sphere_level: int = 2) -> SceneDesc:
+def mis_plates(xres: int = 1280, yres: int = 720, spp: int = 512, sphere_level: int = 2, analytic_spheres: bool = False) -> SceneDesc:
     s = SceneDesc()
     s.name = "mis-plates"
     floor = s.matte((0.4, 0.4, 0.4))
@@ -29,9 +30,13 @@ def mis_plates(xres: int = 1280, yres: int = 720, spp: int = 512, sphere_level: 
     xs = [-3.6, -1.3, 1.0, 3.6]
     n_em = 0
     for r, x in zip(radii, xs):
-        P, F = icosphere(sphere_level, (x, 6.0, 6.0), r)
         power = 800.0  # equal power: L = P / (pi * area), area ~ 4 pi r^2
         L = power / (np.pi * 4 * np.pi * r * r)
+        if analytic_spheres:
+            s.add_sphere((x, 6.0, 6.0), r, lm, emission=(L, L * 0.9, L * 0.8))
+            n_em += 1
+            continue
+        P, F = icosphere(sphere_level, (x, 6.0, 6.0), r)
         s.add_mesh(P, F, lm, emission=(L, L * 0.9, L * 0.8))
         n_em += F.shape[0]
     s.add_quad((-10, 10.0, 0), (10, 10.0, 0), (10, 10.0, 10), (-10, 10.0, 10), lm, emission=(0.4, 0.4, 0.45))

@@ -1,0 +1,147 @@
+"""Analytic spheres (Shape "sphere", rc/shapes/sphere.rs) on the HIP path: hit records bit-for-bit against the oracle, frames within the image gate,
+and closed forms that owe nothing to either (a Lambertian sphere in a furnace; the irradiance of a spherical emitter)."""
+import numpy as np
+import pytest
+
+from util import bits, random_rays, rel_l2
+
+pytestmark = pytest.mark.gpu
+
+
+def _rot(axis, deg):
+    a = np.radians(deg); c, s = np.cos(a), np.sin(a)
+    x, y, z = np.asarray(axis, np.float64) / np.linalg.norm(axis)
+    m = np.eye(4)
+    m[:3, :3] = [[c + x * x * (1 - c), x * y * (1 - c) - z * s, x * z * (1 - c) + y * s],
+                 [y * x * (1 - c) + z * s, c + y * y * (1 - c), y * z * (1 - c) - x * s],
+                 [z * x * (1 - c) - y * s, z * y * (1 - c) + x * s, c + z * z * (1 - c)]]
+    return m
+
+
+def _xf(center, scale=(1, 1, 1), rot=None):
+    m = np.eye(4)
+    m[:3, 3] = center
+    if rot is not None:
+        m = m @ rot
+    return (m @ np.diag(list(scale) + [1])).astype(np.float32)
+
+
+def _sphere_zoo(res=48, spp=16):
+    from rustracer_amd.scenes import cornell_box
+    d = cornell_box(res, res, spp)
+    d.add_sphere((150, 100, 200), 70.0, d.plastic((0.2, 0.4, 0.7), (0.5, 0.5, 0.5), 0.1))                              # whole sphere
+    d.add_sphere(radius=60.0, material=d.matte((0.8, 0.3, 0.2)), o2w=_xf((400, 380, 300), rot=_rot((1, 0.3, 0), 40)), z_min=-25.0, z_max=45.0)   # a clipped band
+    d.add_sphere(radius=50.0, material=d.metal(roughness=0.1), o2w=_xf((300, 120, 120), (1.0, 0.6, 1.4), _rot((0, 1, 0), 30)), phi_max=250.0)  # an ellipsoid wedge
+    d.add_sphere(radius=40.0, material=d.matte((0.3, 0.8, 0.3)), o2w=_xf((120, 330, 380), (1, 1, -1)), reverse_orientation=True)              # mirrored + reversed
+    d.add_sphere((420, 150, 100), 35.0, d.glass())
+    d.add_sphere((278, 450, 250), 30.0, d.matte((0.0,) * 3), emission=(30.0, 25.0, 20.0))                                                    # a sphere light
+    return d
+
+
+def test_sphere_hits_match_the_oracle_bit_for_bit(gpu_host, orc):
+    d = _sphere_zoo()
+    o, h = orc.OracleScene(d), gpu_host.HostScene(d)
+    bo, bh = o.bvh(), h.bvh()
+    assert all(np.array_equal(bo[k], bh[k]) for k in bo)  # the same tree over triangles and sphere boxes
+    rays = random_rays(60000, np.float32([0, 0, 0]), np.float32([555, 555, 555]), 9)
+    ro, rh = o.trace(rays), h.trace(rays)
+    assert np.array_equal(ro["prim"], rh["prim"]) and np.array_equal(bits(ro["t"]), bits(rh["t"]))
+    assert (ro["nodes"], ro["tris"]) == (rh["nodes"], rh["tris"])
+    n_tri = d.n_tris
+    on_sphere = bo["ordered"][np.maximum(ro["prim"], 0)] >= n_tri
+    assert (on_sphere & (ro["prim"] >= 0)).sum() > 2000
+    rr = h.trace(rays, count=False)
+    assert np.array_equal(ro["prim"], rr["prim"]) and np.array_equal(bits(ro["t"]), bits(rr["t"]))
+    rays[:, 3] = np.random.default_rng(4).uniform(20, 700, len(rays)).astype(np.float32)
+    ao, ah = o.trace(rays, True), h.trace(rays, True)
+    assert np.array_equal(ao["occluded"], ah["occluded"]) and (ao["nodes"], ao["tris"]) == (ah["nodes"], ah["tris"])
+    # rays that start inside spheres, graze them, or are shorter than the far root
+    inside = random_rays(20000, np.float32([100, 50, 150]), np.float32([200, 150, 250]), 5)
+    io, ih = o.trace(inside), h.trace(inside)
+    assert np.array_equal(io["prim"], ih["prim"]) and np.array_equal(bits(io["t"]), bits(ih["t"]))
+
+
+def test_sphere_zoo_render_matches_oracle(gpu_host, orc):
+    d = _sphere_zoo(64, 32)
+    fo, so = orc.OracleScene(d).render(mode=1)
+    fh, sh = gpu_host.HostScene(d).render(count_traversal=True)
+    assert np.array_equal(fo[..., 3], fh[..., 3])
+    assert rel_l2(gpu_host.film_to_rgb(fh), orc.film_to_rgb(fo)) < 1e-3
+    for k in ("rays_closest", "rays_shadow", "rays_mis", "nodes_closest", "tris_closest"):
+        assert abs(int(sh[k]) - int(so[k])) <= 2e-3 * int(so[k]) + 16, (k, sh[k], so[k])
+    fh2, _ = gpu_host.HostScene(d).render()
+    assert rel_l2(gpu_host.film_to_rgb(fh2), orc.film_to_rgb(fo)) < 1e-3
+
+
+def test_veach_style_plates_with_four_sphere_lights(gpu_host, orc):
+    from rustracer_amd.scenes import mis_plates
+    d = mis_plates(160, 96, 32, analytic_spheres=True)
+    assert len(d.lights) == 4 + 2 and len(d.spheres) == 4
+    fo, so = orc.OracleScene(d).render(mode=1)
+    fh, sh = gpu_host.HostScene(d).render()
+    assert np.array_equal(fo[..., 3], fh[..., 3]) and rel_l2(gpu_host.film_to_rgb(fh), orc.film_to_rgb(fo)) < 1e-3
+    for k in ("rays_closest", "rays_shadow", "rays_mis"):
+        assert abs(int(sh[k]) - int(so[k])) <= 2e-3 * int(so[k]) + 16, (k, sh[k], so[k])
+
+
+def _furnace_sphere(rho, depth, res=64, spp=64):
+    from rustracer_amd.scene_desc import SceneDesc
+    s = SceneDesc()
+    s.add_sphere((0, 0, 0), 0.6, s.matte((rho,) * 3))
+    s.add_quad((40, 40, 40), (40.01, 40, 40), (40.01, 40.01, 40), (40, 40.01, 40), s.matte((0.0,) * 3))  # (the soup must hold a triangle: a speck, far away)
+    s.infinite_light(s.add_mip(np.ones((4, 8, 3), np.float32)))
+    s.camera.pos, s.camera.look, s.camera.up, s.camera.fov = (0.0, -2.2, 1.2), (0, 0, 0), (0, 0, 1), 30.0
+    s.film.xres = s.film.yres = res
+    s.sampler.spp = spp
+    s.integrator.max_depth = depth
+    return s
+
+
+@pytest.mark.parametrize("who", ["gpu", "oracle"])
+@pytest.mark.parametrize("rho,depth", [(0.5, 1), (0.8, 4)])
+def test_lambertian_sphere_in_a_furnace(gpu_host, orc, who, rho, depth):
+    """A convex body of albedo rho in a constant environment of radiance 1 shows L = rho at any depth (tests/invariants.py)."""
+    import invariants as inv
+    d = _furnace_sphere(rho, depth)
+    img = gpu_host.film_to_rgb(gpu_host.HostScene(d).render()[0]) if who == "gpu" else orc.film_to_rgb(orc.OracleScene(d).render(mode=1)[0])
+    body = inv.furnace_body_mask(img, rho, depth)
+    assert body.sum() > 400
+    assert np.allclose(img[body].mean(axis=0), rho, rtol=0.005), img[body].mean(axis=0)
+
+
+@pytest.mark.parametrize("who", ["gpu", "oracle"])
+def test_irradiance_of_a_spherical_emitter(gpu_host, orc, who):
+    """A Lambertian floor under an emitting sphere, direct light only: L = rho * Le * (r / D)^2 * cos(theta) (the whole sphere is above the horizon),
+    whether the sphere is sampled inside its cone (Sphere::sample_si), found by the BSDF-sampled ray (Sphere::pdf_wi) or both (MIS)."""
+    from rustracer_amd.scene_desc import SceneDesc
+    rho, le, r, hz, cam = 0.6, 20.0, 0.5, 3.0, 2.0
+    s = SceneDesc()
+    s.add_quad((-6, -6, 0), (6, -6, 0), (6, 6, 0), (-6, 6, 0), s.matte((rho,) * 3))
+    s.add_sphere((0, 0, hz), r, s.matte((0.0,) * 3), emission=(le,) * 3)
+    s.camera.pos, s.camera.look, s.camera.up, s.camera.fov = (0.0, 0.0, cam), (0, 0, 0), (0, 1, 0), 60.0
+    s.film.xres = s.film.yres = 64
+    s.sampler.spp = 256
+    s.integrator.max_depth = 1
+    img = (gpu_host.film_to_rgb(gpu_host.HostScene(s).render()[0]) if who == "gpu" else orc.film_to_rgb(orc.OracleScene(s).render(mode=1)[0]))[..., 0]
+    t = np.tan(np.radians(60.0) / 2) * cam
+    c = (2 * (np.arange(64) + 0.5) / 64 - 1) * t
+    x, y = np.meshgrid(c, c)
+    D2 = x * x + y * y + hz * hz
+    want = rho * le * (r * r / D2) * (hz / np.sqrt(D2))
+    assert abs(img.mean() / want.mean() - 1) < 0.004, (img.mean(), want.mean())
+    gm, wm = img.reshape(8, 8, 8, 8).mean(axis=(1, 3)), want.reshape(8, 8, 8, 8).mean(axis=(1, 3))
+    assert np.allclose(gm, wm, rtol=0.03), gm / wm
+
+
+def test_spheres_through_a_pbrt_file(gpu_host, tmp_path):
+    """Shape "sphere" in the .pbrt loader: same primitives, same film as the scene built call by call. (In a file a shape's lights follow it in order of
+    appearance; the exporter writes spheres after the meshes, so the zoo's light order - mesh lights, then the sphere light - is the file's too.)"""
+    from rustracer_amd.pbrt_export import write_pbrt
+    d = _sphere_zoo(40, 8)
+    path = str(tmp_path / "spheres.pbrt")
+    write_pbrt(d, path)
+    a, sa = gpu_host.HostScene(d).render()
+    p = gpu_host.PbrtScene(path)
+    b, sb = p.render()
+    assert np.array_equal(a[..., 3], b[..., 3]) and rel_l2(gpu_host.film_to_rgb(b), gpu_host.film_to_rgb(a)) < 2e-4
+    assert sa["rays_closest"] == sb["rays_closest"] or abs(int(sa["rays_closest"]) - int(sb["rays_closest"])) < 1e-3 * sa["rays_closest"]

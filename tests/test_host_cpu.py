@@ -251,7 +251,7 @@ def test_kernel_register_and_scratch_budgets(host):
         "rtx::k_trace<true, false, true, 256, 16>": (64, 64),    # ... and its shadow-ray twin: 8 waves
         "rtx::k_trace_pair<false, false, 128, 32>": (80, 160),   # HBM scenes: 6 waves
         "rtx::k_trace_quad<true, 128, 32>": (64, 160),
-        "rtx::k_resolve": (88, 256), "rtx::k_raygen": (72, 0), "rtx::k_film_accumulate": (48, 0),
+        "rtx::k_resolve<false>": (88, 256), "rtx::k_raygen": (72, 0), "rtx::k_film_accumulate": (48, 0),
     }
     for name, (vg, sc) in budget.items():
         r = res[name]
