@@ -17,7 +17,26 @@ namespace rtx {
 // Per-path records are grouped by the kernels that touch them together, so that a vertex shaded out of path-id order (the shade queue
 // is counting-sorted by material class on scenes with several) touches four cache lines instead of twenty 16-byte slots of
 // twenty arrays - a scattered 16-byte access moves a whole 128-byte line. In path-id order the records stream like the arrays did.
-struct PathRec { float4 o, d, hit, beta; };  // 64 B: ray (o | t_max, d), hit (b2 | t, prim, b0, b1), throughput (rgb, eta_scale). trace: R o d, W hit; shade: R d hit beta, W o d beta
+// The ray (o | t_max, d) and the vertex record (hit (b2 | t, prim, b0, b1), throughput (rgb, eta_scale)) of a path. RT_PATHREC_SPLIT = 1 (default):
+// two 32-byte records - the trace kernels stream rays and nothing else, shade reads one more line per vertex. Measured on one box (scripts/ab_bench.sh):
+// 0, one 64-byte record: S1 -2.9 %, S2 -3.3 %, S3 -4.3 %, S4 -0.5 % (closest hit +3 .. +9 %: twice the lines per wave of rays; S4's binned shade
+// did not get faster); 2, hit and throughput in 16-byte arrays of their own: within 0.4 % of 1 everywhere.
+#ifndef RT_PATHREC_SPLIT
+#define RT_PATHREC_SPLIT 1
+#endif
+#if RT_PATHREC_SPLIT == 2
+struct RayRec { float4 o, d; };
+struct VertRec { float4 hit; };
+struct BetaRec { float4 beta; };
+#elif RT_PATHREC_SPLIT
+struct RayRec { float4 o, d; };
+struct VertRec { float4 hit, beta; };
+typedef VertRec BetaRec;
+#else
+struct RayRec { float4 o, d, hit, beta; };
+typedef RayRec VertRec;  // the same array
+typedef RayRec BetaRec;
+#endif
 struct PathAcc { float4 lacc; unsigned long long rng; float2 pfilm; };  // 32 B: radiance (rgb, packed state), RNG state, film position
 struct ShadowRec { float4 o, d, add, pad; };  // 64 B: shadow ray (d.w = 1: no MIS ray pending, `add` is applied by the any-hit kernel) and beta * Ld / pick_pdf
 // 128 B, one line: everything k_resolve needs of a vertex with a BSDF-sampled MIS ray. hit.y = prim of the closest hit, or - for rays that only
@@ -34,7 +53,7 @@ struct PassState {
   // sampler tables of the chunk
   const unsigned* scrambles;        // [pixel][3*dims]
   const unsigned short* perms;      // [pixel][2*dims][spp]
-  PathRec* path; PathAcc* acc; ShadowRec* sh; MisRec* mi;
+  RayRec* ray; VertRec* vert; BetaRec* bet; PathAcc* acc; ShadowRec* sh; MisRec* mi;
   // queues of path ids, each split into RT_QSHARDS shards (shard = blockIdx & 7 of the producer, region
   // [shard * shard_cap, ...)) with its own counter word: a single word sustains only ~88 returning
   // atomics per microsecond. Every bounce has its own zero-initialised block of counters, so nothing has to be
@@ -460,10 +479,10 @@ __global__ void __launch_bounds__(256) k_raygen(FrameParams fp, PassState ps) {
       f2 p_film = mk2((float)x + o.x, (float)y + o.y);
       f2 p_lens = table_2d(tb, pix, 1, s);
       CameraRay cr = generate_camera_ray(fp, p_film, p_lens, 1.0f / sqrtf((float)ps.spp));
-      PathRec* pr = ps.path + pid;
+      RayRec* pr = ps.ray + pid;
       pr->o = make_float4(cr.o.x, cr.o.y, cr.o.z, kInf);
       pr->d = make_float4(cr.d.x, cr.d.y, cr.d.z, 0.0f);
-      pr->beta = make_float4(1.0f, 1.0f, 1.0f, 1.0f);
+      ps.bet[pid].beta = make_float4(1.0f, 1.0f, 1.0f, 1.0f);
       Pcg32 rng; rng.set_sequence(pixel_index * (unsigned long long)ps.spp + s + (1ull << 32));  // keyed per-sample stream
       PathAcc* pa = ps.acc + pid;
       pa->lacc = make_float4(0.0f, 0.0f, 0.0f, __uint_as_float(pack_state(0, false, 1, 2) | (in_bounds ? 0u : RT_STATE_OUT_OF_BOUNDS)));
@@ -497,7 +516,7 @@ struct LdsSrc {
 #define RT_SMALL_TRIS 128
 
 // Where a trace launch reads its rays and writes its results: element [pid * stride] of each pointer (strides in elements of the pointer's
-// type), so that the same kernels serve the records of a frame (PathRec / ShadowRec / MisRec) and the planar arrays of the batch entry points.
+// type), so that the same kernels serve the records of a frame (RayRec / VertRec / ShadowRec / MisRec) and the planar arrays of the batch entry points.
 struct TraceIO {
   const float4* ray_o; const float4* ray_d; unsigned ray_stride;  // (o | t_max), (d | flag)
   float4* hits; unsigned hit_stride; int hit_b2;  // closest hit: (t, prim, b0, b1), or (b2, prim, b0, b1) inside a frame (shade needs the three barycentrics, not t)
@@ -983,7 +1002,7 @@ __global__ void __launch_bounds__(BLOCK) k_trace_quad(DScene sc, TraceIO io, con
 // class; misses last), so that most waves run one code path. Order within a bin is arbitrary: paths are
 // independent and the film sums each pixel's samples in sample order. hist/cursor: RT_BIN_MAX + 1 zeroed words each.
 #define RT_BIN_MAX 256
-RT_DEV unsigned bin_of(const DMaterial* __restrict__ materials, const float4* __restrict__ tri_p, const PathRec* __restrict__ path, unsigned pid, unsigned n_bins) {
+RT_DEV unsigned bin_of(const DMaterial* __restrict__ materials, const float4* __restrict__ tri_p, const VertRec* __restrict__ path, unsigned pid, unsigned n_bins) {
   const int prim = __float_as_int(path[pid].hit.y);
   if (prim < 0) return n_bins - 1u;
   const unsigned m = (unsigned)materials[tri_material(tri_p, prim)].code_class;
@@ -997,7 +1016,7 @@ __global__ void __launch_bounds__(256) k_bin_count(DScene sc, PassState ps, unsi
   const unsigned count = ps.q_in ? qv.total() : ps.cap;
   for (unsigned i = blockIdx.x * 256u + threadIdx.x; i < count; i += gridDim.x * 256u) {
     const unsigned pid = ps.q_in ? qv.get(i) : i;
-    atomicAdd(&lh[bin_of(sc.materials, sc.tri_p, ps.path, pid, n_bins)], 1u);
+    atomicAdd(&lh[bin_of(sc.materials, sc.tri_p, ps.vert, pid, n_bins)], 1u);
   }
   __syncthreads();
   for (unsigned i = threadIdx.x; i < n_bins; i += 256u) if (lh[i]) atomicAdd(&hist[i], lh[i]);
@@ -1029,7 +1048,7 @@ __global__ void __launch_bounds__(256) k_bin_scatter(DScene sc, PassState ps, un
     for (unsigned k = 0; k < E; ++k) {  // rounds of 256 consecutive entries: a bin keeps the queue's order up to that granularity
       const unsigned i = start + k * 256u + threadIdx.x;
       live[k] = i < count; pid[k] = 0; bin[k] = 0; rank[k] = 0;
-      if (live[k]) { pid[k] = ps.q_in ? qv.get(i) : i; bin[k] = bin_of(sc.materials, sc.tri_p, ps.path, pid[k], n_bins); }
+      if (live[k]) { pid[k] = ps.q_in ? qv.get(i) : i; bin[k] = bin_of(sc.materials, sc.tri_p, ps.vert, pid[k], n_bins); }
     }
 #pragma unroll
     for (unsigned k = 0; k < E; ++k) if (live[k]) rank[k] = atomicAdd(&lcount[bin[k]], 1u);
@@ -1262,8 +1281,8 @@ __global__ void __launch_bounds__(256, MODE == 1 ? RT_SHADE_MIN_WAVES : RT_SHADE
     if (lane_live) {
       pid = ps.q_in ? qv.get(i) : i;
       const unsigned sl = pid / ps.n_pixels, pix = pid - sl * ps.n_pixels, s = ps.s0 + sl;
-      PathRec* const prec = ps.path + pid; PathAcc* const pacc = ps.acc + pid;
-      float4 d4 = prec->d, h4 = prec->hit, b4 = prec->beta, l4 = pacc->lacc;
+      RayRec* const prec = ps.ray + pid; VertRec* const pvert = ps.vert + pid; PathAcc* const pacc = ps.acc + pid;
+      float4 d4 = prec->d, h4 = pvert->hit, b4 = ps.bet[pid].beta, l4 = pacc->lacc;
       f3 ray_d = mk3(d4.x, d4.y, d4.z);
       rgb3 beta = mkc(b4.x, b4.y, b4.z), L = mkc(l4.x, l4.y, l4.z);
       float eta_scale = b4.w;
@@ -1402,7 +1421,7 @@ __global__ void __launch_bounds__(256, MODE == 1 ? RT_SHADE_MIN_WAVES : RT_SHADE
           }
         }
       }
-      prec->beta = make_float4(beta.r, beta.g, beta.b, eta_scale);
+      ps.bet[pid].beta = make_float4(beta.r, beta.g, beta.b, eta_scale);
       pacc->lacc = make_float4(L.r, L.g, L.b, __uint_as_float(pack_state(bounces, specular_bounce, smp.c1, smp.c2)));
       pacc->rng = smp.rng.state;
     }
@@ -1430,7 +1449,7 @@ __global__ void __launch_bounds__(256) k_shade_miss(DScene sc, PassState ps) {
     const unsigned st = __float_as_uint(l4.w);
     const int bounces = (int)(st & 0xffu); const bool specular_bounce = (st >> 8) & 1u;
     if (!(bounces == 0 || specular_bounce) || sc.n_infinite == 0) continue;
-    const float4 d4 = ps.path[pid].d, b4 = ps.path[pid].beta;
+    const float4 d4 = ps.ray[pid].d, b4 = ps.bet[pid].beta;
     const f3 ray_d = mk3(d4.x, d4.y, d4.z);
     const rgb3 beta = mkc(b4.x, b4.y, b4.z);
     rgb3 L = mkc(l4.x, l4.y, l4.z);
