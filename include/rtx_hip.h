@@ -61,6 +61,10 @@ typedef struct rt_sphere {
   float o2w[16], w2o[16];
   float radius, z_min, z_max, theta_min, theta_max, phi_max;
   int32_t reverse_orientation, swaps_handedness;
+  /* the same record carries the reference's two other quadrics: kind 1 = Disk (rc/shapes/disk.rs: height, radius, inner_radius, phi_max),
+   * kind 2 = Cylinder (rc/shapes/cylinder.rs: radius, z_min, z_max, phi_max); kind 0 = Sphere */
+  int32_t kind;
+  float height, inner_radius;
 } rt_sphere;
 
 /* -- textures: replaces dyn Texture<T> (rc/texture/{constant,scale,mix,imagemap,checkerboard,uv,fbm}.rs) --

@@ -53,6 +53,10 @@ int rtxh_scene_set_mesh(rtxh_scene*, const float* P, int32_t n_verts, const int3
  * that light is added by rtxh_scene_add_light(RT_LIGHT_DIFFUSE_AREA, tri = -2 - k, ...) for sphere k. Returns k. */
 int rtxh_scene_add_sphere(rtxh_scene*, const float* o2w16, const float* w2o16, float radius, float z_min, float z_max, float phi_max, int32_t reverse_orientation,
                           int32_t material, int32_t light);
+/* The reference's other quadrics through the same record: kind 0 = sphere (as above), 1 = Shape "disk" (z_min := height, z_max := innerradius;
+ * rc/shapes/disk.rs:48-62), 2 = Shape "cylinder" (z_min, z_max as given; rc/shapes/cylinder.rs:26-46). Area lights as for spheres (tri = -2 - k). */
+int rtxh_scene_add_quadric(rtxh_scene*, int32_t kind, const float* o2w16, const float* w2o16, float radius, float z_min, float z_max, float phi_max,
+                           int32_t reverse_orientation, int32_t material, int32_t light);
 /* Alpha masks of the meshes, after rtxh_scene_set_mesh: per triangle {alpha, shadowalpha} float-texture ids or -1 (TriangleMesh::create,
  * rc/shapes/mesh.rs:134-156: a named float texture, or the constant 0 when the float parameter is 0). NULL removes all masks. */
 int rtxh_scene_set_alpha(rtxh_scene*, const int32_t* tri_alpha2);

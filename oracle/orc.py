@@ -148,7 +148,7 @@ class OracleScene:
             L.orc_scene_add_material(self.h, m.kind, _p(sl, C.c_int32), int(m.remap_roughness), int(m.bump))
         for sp in getattr(desc, "spheres", []):
             L.orc_scene_add_sphere(self.h, _p(sp.o2w), _p(sp.w2o), C.c_float(sp.radius), C.c_float(sp.z_min), C.c_float(sp.z_max), C.c_float(sp.phi_max),
-                                   int(sp.reverse_orientation), sp.material, sp.light)
+                                   int(sp.reverse_orientation), sp.material, sp.light, int(getattr(sp, "kind", 0)))
         for l in desc.lights:
             rgb = np.float32(l.rgb)
             vec = np.float32(l.vec)

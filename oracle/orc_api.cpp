@@ -186,11 +186,13 @@ int orc_scene_set_alpha(void* h, const int32_t* tri_alpha2) {  // after orc_scen
   return 0;
 }
 // Shape "sphere" (Sphere::create, sphere.rs:53-68), after orc_scene_set_mesh. Returns its primitive id (n_tris + index): what an area light's `tri` names.
-int orc_scene_add_sphere(void* h, const float* o2w16, const float* w2o16, float radius, float z_min, float z_max, float phi_max, int reverse_orientation,
-                         int material, int light) {
+// kind: 0 sphere (a = zmin, b = zmax), 1 disk (a = height, b = innerradius; disk.rs:48-62), 2 cylinder (a = z_min, b = z_max; cylinder.rs:26-46)
+int orc_scene_add_sphere(void* h, const float* o2w16, const float* w2o16, float radius, float a, float b, float phi_max, int reverse_orientation,
+                         int material, int light, int kind) {
   Scene* s = (Scene*)h;
   Transform t; memcpy(t.m.m, o2w16, 64); memcpy(t.m_inv.m, w2o16, 64);
-  Sphere sp = sphere_new(t, radius, z_min, z_max, phi_max, reverse_orientation != 0);
+  Sphere sp = kind == QUADRIC_DISK ? disk_new(t, a, radius, b, phi_max, reverse_orientation != 0)
+            : kind == QUADRIC_CYLINDER ? cylinder_new(t, radius, a, b, phi_max, reverse_orientation != 0) : sphere_new(t, radius, a, b, phi_max, reverse_orientation != 0);
   s->spheres.push_back(sp);
   s->tri_material.push_back(material); s->tri_light.push_back(light);
   s->tri_flags.push_back((uint8_t)((sp.reverse_orientation != sp.swaps_handedness) ? 1 : 0));

@@ -122,7 +122,7 @@ void Scene::build_bvh() {
   if (n == 0) return;
   std::vector<PrimInfo> info(n);
   for (size_t i = 0; i < n; ++i) {
-    B3 bb = is_sphere((int)i) ? sphere_world_bounds(sphere_of((int)i)) : tri_world_bounds((int)i);
+    B3 bb = is_sphere((int)i) ? quadric_world_bounds(sphere_of((int)i)) : tri_world_bounds((int)i);
     info[i].prim_number = (int)i;
     info[i].bounds = bb;
     info[i].centroid = 0.5f * bb.mn + 0.5f * bb.mx;  // :532
@@ -331,7 +331,7 @@ void Scene::prim_fill_interaction(int prim, const Ray& ray, const TriHit& h, Sur
   // Sphere::intersect builds its interaction inside the hit test; it is rebuilt here for the accepted hit. The roots, the clipping retry and
   // therefore p_hit do not depend on ray.t_max (it only rejects), so t_max = infinity reproduces the accepted test's decisions.
   Ray r = ray; r.t_max = kInf;
-  SphereHit sh; bool ok = sphere_intersect(sphere_of(prim), r, true, &sh); (void)ok;
+  SphereHit sh; bool ok = quadric_intersect(sphere_of(prim), r, true, &sh); (void)ok;
   SurfaceInteraction s;
   s.hit.p = sh.p; s.hit.p_error = sh.p_error; s.hit.wo = sh.wo; s.hit.n = sh.n;
   s.uv = sh.uv; s.dpdu = sh.dpdu; s.dpdv = sh.dpdv;
@@ -391,7 +391,7 @@ void Scene::tri_sample(int tri, P2 u, Interaction* it, float* pdf) const {  // m
 }
 void Scene::shape_sample_si(int tri, const Interaction& ref, P2 u, Interaction* it, float* pdf_out) const {  // shapes/mod.rs:39-53
   if (is_sphere(tri)) {  // Sphere overrides sample_si (sphere.rs:246-308)
-    SpherePoint sp = sphere_sample_si(sphere_of(tri), ref, u, pdf_out);
+    SpherePoint sp = quadric_sample_si(sphere_of(tri), ref, u, pdf_out);
     it->p = sp.p; it->p_error = sp.p_error; it->wo = v3(0, 0, 0); it->n = sp.n;
     return;
   }
@@ -406,7 +406,7 @@ void Scene::shape_sample_si(int tri, const Interaction& ref, P2 u, Interaction* 
   *pdf_out = pdf;
 }
 float Scene::shape_pdf_wi(int tri, const Interaction& ref, V3 wi, TraceCounters* tc) const {  // shapes/mod.rs:59-68
-  if (is_sphere(tri)) return sphere_pdf_wi(sphere_of(tri), ref, wi, tc ? &tc->tris : nullptr);  // sphere.rs:310-334
+  if (is_sphere(tri)) return quadric_pdf_wi(sphere_of(tri), ref, wi, tc ? &tc->tris : nullptr);  // sphere.rs:310-334 / the trait default
   Ray ray = spawn_ray(ref, wi);
   TriHit h;
   if (tc) tc->tris += 1;

@@ -211,12 +211,12 @@ struct Scene {
   size_t n_prims() const { return n_tris() + spheres.size(); }
   bool is_sphere(int prim) const { return (size_t)prim >= n_tris(); }
   const Sphere& sphere_of(int prim) const { return spheres[(size_t)prim - n_tris()]; }
-  float shape_area(int prim) const { return is_sphere(prim) ? sphere_area(sphere_of(prim)) : tri_area(prim); }
+  float shape_area(int prim) const { return is_sphere(prim) ? quadric_area(sphere_of(prim)) : tri_area(prim); }
   // Shape::intersect of primitive `prim`, hit test only: triangles give barycentrics, spheres t alone
   bool prim_test(int prim, const Ray& ray, TriHit* h) const {
     if (!is_sphere(prim)) return tri_test(prim, ray, h);
     SphereHit sh;
-    if (!sphere_intersect(sphere_of(prim), ray, false, &sh)) return false;
+    if (!quadric_intersect(sphere_of(prim), ray, false, &sh)) return false;
     h->t = sh.t; h->b0 = h->b1 = h->b2 = 0.0f;
     return true;
   }

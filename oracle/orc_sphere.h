@@ -74,11 +74,14 @@ inline V3 xf_point_with_error(const M44& m, V3 p, V3 pe, V3* err) {  // transfor
   return xf_point(m, p);
 }
 
-// ---------------------------------------------------------------- Sphere
+// ---------------------------------------------------------------- Sphere (and, by `kind`, the two other quadrics of the reference: Disk, Cylinder)
+enum { QUADRIC_SPHERE = 0, QUADRIC_DISK = 1, QUADRIC_CYLINDER = 2 };
 struct Sphere {
   Transform o2w;  // object_to_world (m) / world_to_object (m_inv)
   float radius, z_min, z_max, theta_min, theta_max, phi_max;
   bool reverse_orientation, swaps_handedness;
+  int kind = QUADRIC_SPHERE;
+  float height = 0, inner_radius = 0;  // Disk (rc/shapes/disk.rs:13-22)
 };
 inline Sphere sphere_new(const Transform& o2w, float radius, float z_min, float z_max, float phi_max, bool reverse_orientation) {  // Sphere::new, :29-51
   Sphere s;
@@ -235,6 +238,181 @@ inline float sphere_pdf_wi(const Sphere& s, const Interaction& si, V3 wi, uint64
   float sin_theta_max_2 = s.radius * s.radius / distance_squared(si.p, p_center);
   float cos_theta_max = sqrtf(fmaxf(0.0f, 1.0f - sin_theta_max_2));
   return 1.0f / (2.0f * kPi * (1.0f - cos_theta_max));  // uniform_cone_pdf, sampling/mod.rs:54-56
+}
+
+
+// ---------------------------------------------------------------- Disk (rc/shapes/disk.rs) and Cylinder (rc/shapes/cylinder.rs)
+inline Sphere disk_new(const Transform& o2w, float height, float radius, float inner_radius, float phi_max, bool reverse_orientation) {  // Disk::new, disk.rs:25-46
+  Sphere s{};
+  s.kind = QUADRIC_DISK; s.o2w = o2w; s.height = height; s.radius = radius; s.inner_radius = inner_radius;
+  s.phi_max = to_radians(clamp_t(phi_max, 0.0f, 360.0f));
+  s.z_min = s.z_max = height; s.theta_min = s.theta_max = 0.0f;
+  s.reverse_orientation = reverse_orientation; s.swaps_handedness = xf_swaps_handedness(o2w.m);
+  return s;
+}
+inline Sphere cylinder_new(const Transform& o2w, float radius, float z_min, float z_max, float phi_max, bool reverse_orientation) {  // Cylinder::create, cylinder.rs:26-46
+  Sphere s{};
+  s.kind = QUADRIC_CYLINDER; s.o2w = o2w; s.radius = radius; s.z_min = z_min; s.z_max = z_max;  // (not sorted, not clamped: as the reference)
+  s.phi_max = to_radians(clamp_t(phi_max, 0.0f, 360.0f));
+  s.theta_min = s.theta_max = 0.0f;
+  s.reverse_orientation = reverse_orientation; s.swaps_handedness = xf_swaps_handedness(o2w.m);
+  return s;
+}
+inline float quadric_area(const Sphere& s) {
+  if (s.kind == QUADRIC_DISK) return s.phi_max * 0.5f * (s.radius * s.radius - s.inner_radius * s.inner_radius);  // disk.rs:153-155
+  if (s.kind == QUADRIC_CYLINDER) return (s.z_max - s.z_min) * s.radius * s.phi_max;                             // cylinder.rs:252-254
+  return sphere_area(s);
+}
+inline B3 quadric_world_bounds(const Sphere& s) {
+  if (s.kind == QUADRIC_DISK) {  // Disk::world_bounds (disk.rs:127-134) maps only two corners of the object box: wrong under a rotation, kept (reference quirk)
+    V3 p1 = xf_point(s.o2w.m, v3(-s.radius, -s.radius, s.height)), p2 = xf_point(s.o2w.m, v3(s.radius, s.radius, s.height));
+    return b3_from_points(v3(fminf(p1.x, p2.x), fminf(p1.y, p2.y), fminf(p1.z, p2.z)), v3(fmaxf(p1.x, p2.x), fmaxf(p1.y, p2.y), fmaxf(p1.z, p2.z)));
+  }
+  if (s.kind == QUADRIC_CYLINDER) {  // &object_to_world * &object_bounds (transform.rs:342-380): the union of the 8 mapped corners of from_points(..)
+    const B3 ob = b3_from_points(v3(-s.radius, -s.radius, s.z_min), v3(s.radius, s.radius, s.z_max));
+    B3 b = b3_empty();
+    for (int i = 0; i < 8; ++i) b = b3_union_p(b, xf_point(s.o2w.m, v3(i & 1 ? ob.mx.x : ob.mn.x, i & 2 ? ob.mx.y : ob.mn.y, i & 4 ? ob.mx.z : ob.mn.z)));
+    return b;
+  }
+  return sphere_world_bounds(s);
+}
+// the tail shared by the three intersect(): SurfaceInteraction::new(p_hit, p_error, uv, -ray.d, dpdu, dpdv, ..) then .transform(object_to_world)
+inline void quadric_finish(const Sphere& s, V3 p_hit, V3 p_error, P2 uv, V3 d_obj, V3 dpdu, V3 dpdv, SphereHit* out) {
+  V3 n = normalize(cross(dpdu, dpdv));
+  if (s.reverse_orientation != s.swaps_handedness) n = n * -1.0f;
+  V3 wo = normalize(normalize(-d_obj));
+  out->p = xf_point_with_error(s.o2w.m, p_hit, p_error, &out->p_error);
+  out->wo = normalize(normalize(xf_vector(s.o2w.m, wo)));
+  out->n = normalize(xf_normal(s.o2w.m_inv, n));
+  out->uv = uv;
+  out->dpdu = xf_vector(s.o2w.m, dpdu); out->dpdv = xf_vector(s.o2w.m, dpdv);
+  V3 sn = normalize(xf_normal(s.o2w.m_inv, n));
+  out->sh_n = dot(sn, out->n) < 0.0f ? -sn : sn;
+}
+inline bool disk_intersect(const Sphere& s, const Ray& ray, bool fill, SphereHit* out) {  // Disk::intersect, disk.rs:65-118
+  V3 o_err, d_err;
+  V3 o = xf_point_err(s.o2w.m_inv, ray.o, &o_err);
+  V3 d = xf_vector_err(s.o2w.m_inv, ray.d, &d_err);
+  float l2 = length_squared(d);
+  if (l2 > 0.0f) { float dt = dot(vabs(d), o_err) / l2; o = o + d * dt; }
+  if (d.z == 0.0f) return false;
+  float t_shape_hit = (s.height - o.z) / d.z;
+  if (t_shape_hit <= 0.0f || t_shape_hit > ray.t_max) return false;
+  V3 p_hit = o + t_shape_hit * d;
+  float dist2 = p_hit.x * p_hit.x + p_hit.y * p_hit.y;
+  if (dist2 > s.radius * s.radius || dist2 < s.inner_radius * s.inner_radius) return false;
+  float phi = atan2f(p_hit.y, p_hit.x);
+  if (phi < 0.0f) phi += 2.0f * kPi;
+  if (phi > s.phi_max) return false;
+  out->t = t_shape_hit;
+  if (!fill) return true;
+  float u = phi / s.phi_max;
+  float r_hit = sqrtf(dist2);
+  float one_minus_v = (r_hit - s.inner_radius) / (s.radius - s.inner_radius);
+  float v = 1.0f - one_minus_v;
+  V3 dpdu = v3(-s.phi_max * p_hit.y, s.phi_max * p_hit.x, 0.0f);
+  V3 dpdv = v3(p_hit.x, p_hit.y, 0.0f) * (s.radius - s.inner_radius) / r_hit;
+  p_hit.z = s.height;
+  quadric_finish(s, p_hit, v3(0, 0, 0), P2{u, v}, d, dpdu, dpdv, out);
+  return true;
+}
+inline bool cylinder_intersect(const Sphere& s, const Ray& ray, bool fill, SphereHit* out) {  // Cylinder::intersect, cylinder.rs:62-172 (intersect_p :174-250: the same decisions)
+  V3 o_err, d_err;
+  V3 o = xf_point_err(s.o2w.m_inv, ray.o, &o_err);
+  V3 d = xf_vector_err(s.o2w.m_inv, ray.d, &d_err);
+  float l2 = length_squared(d);
+  if (l2 > 0.0f) { float dt = dot(vabs(d), o_err) / l2; o = o + d * dt; }
+  const float t_max = ray.t_max;
+  EFloat ox = ef_new(o.x, o_err.x), oy = ef_new(o.y, o_err.y);
+  EFloat dx = ef_new(d.x, d_err.x), dy = ef_new(d.y, d_err.y);
+  EFloat a = dx * dx + dy * dy;
+  EFloat b = 2.0f * (dx * ox + dy * oy);
+  EFloat c = ox * ox + oy * oy - ef(s.radius) * ef(s.radius);
+  EFloat t0, t1;
+  if (!ef_solve_quadratic(a, b, c, &t0, &t1)) return false;
+  if (t0.upper_bound() > t_max || t1.lower_bound() <= 0.0f) return false;
+  EFloat ts = t0; bool is_t1 = false;
+  if (ts.lower_bound() <= 0.0f) { ts = t1; is_t1 = true; if (ts.upper_bound() > t_max) return false; }
+  V3 p_hit = o + ts.v * d;
+  float hit_rad = sqrtf(p_hit.x * p_hit.x + p_hit.y * p_hit.y);
+  p_hit.x *= s.radius / hit_rad; p_hit.y *= s.radius / hit_rad;
+  float phi = atan2f(p_hit.y, p_hit.x);
+  if (phi < 0.0f) phi += 2.0f * kPi;
+  if (p_hit.z < s.z_min || p_hit.z > s.z_max || phi > s.phi_max) {
+    if (is_t1 || ts.v == t1.v) return false;
+    ts = t1;
+    if (t1.upper_bound() > t_max) return false;
+    p_hit = o + ts.v * d;
+    hit_rad = sqrtf(p_hit.x * p_hit.x + p_hit.y * p_hit.y);
+    p_hit.x *= s.radius / hit_rad; p_hit.y *= s.radius / hit_rad;
+    phi = atan2f(p_hit.y, p_hit.x);
+    if (phi < 0.0f) phi += 2.0f * kPi;
+    if (p_hit.z < s.z_min || p_hit.z > s.z_max || phi > s.phi_max) return false;
+  }
+  out->t = ts.v;
+  if (!fill) return true;
+  float u = phi / s.phi_max;
+  float v = (p_hit.z - s.z_min) / (s.z_max / s.z_min);  // a division where pbrt subtracts (cylinder.rs:121): kept
+  V3 dpdu = v3(-s.phi_max * p_hit.y, s.phi_max * p_hit.x, 0.0f);
+  V3 dpdv = v3(0.0f, 0.0f, s.z_max - s.z_min);
+  V3 p_error = gamma_n(3) * v3(fabsf(p_hit.x), fabsf(p_hit.y), 0.0f);
+  quadric_finish(s, p_hit, p_error, P2{u, v}, d, dpdu, dpdv, out);
+  return true;
+}
+inline bool quadric_intersect(const Sphere& s, const Ray& ray, bool fill, SphereHit* out) {
+  if (s.kind == QUADRIC_DISK) return disk_intersect(s, ray, fill, out);
+  if (s.kind == QUADRIC_CYLINDER) return cylinder_intersect(s, ray, fill, out);
+  return sphere_intersect(s, ray, fill, out);
+}
+inline P2 concentric_sample_disk_q(P2 u) {  // sampling/mod.rs:29-47
+  float ox = 2.0f * u.x - 1.0f, oy = 2.0f * u.y - 1.0f;
+  if (ox == 0.0f && oy == 0.0f) return P2{0.0f, 0.0f};
+  float r, theta;
+  if (fabsf(ox) > fabsf(oy)) { r = ox; theta = (kPi / 4.0f) * (oy / ox); }
+  else { r = oy; theta = (kPi / 2.0f) - (kPi / 4.0f) * (ox / oy); }
+  return P2{r * cosf(theta), r * sinf(theta)};
+}
+// Shape::sample of a disk / cylinder (disk.rs:136-151, cylinder.rs:256-278): a point by area
+inline SpherePoint quadric_sample(const Sphere& s, P2 u, float* pdf) {
+  SpherePoint it;
+  if (s.kind == QUADRIC_DISK) {
+    P2 pd = concentric_sample_disk_q(u);
+    V3 p_obj = v3(pd.x * s.radius, pd.y * s.radius, s.height);
+    it.n = normalize(xf_normal(s.o2w.m_inv, v3(0.0f, 0.0f, 1.0f)));
+    if (s.reverse_orientation) it.n = -it.n;
+    it.p = xf_point_with_error(s.o2w.m, p_obj, v3(0, 0, 0), &it.p_error);
+  } else {
+    float z = lerp_f(u.x, s.z_min, s.z_max);
+    float phi = u.y * s.phi_max;
+    V3 p_obj = v3(s.radius * cosf(phi), s.radius * sinf(phi), z);
+    V3 n = normalize(xf_normal(s.o2w.m_inv, v3(p_obj.x, p_obj.y, 0.0f)));
+    if (s.reverse_orientation) n = n * -1.0f;
+    float hit_rad = sqrtf(p_obj.x * p_obj.x + p_obj.y * p_obj.y);
+    p_obj.x *= s.radius / hit_rad; p_obj.y *= s.radius / hit_rad;
+    V3 p_obj_error = gamma_n(3) * v3(fabsf(p_obj.x), fabsf(p_obj.y), 0.0f);
+    it.p = xf_point_with_error(s.o2w.m, p_obj, p_obj_error, &it.p_error);
+    it.n = n;
+  }
+  *pdf = 1.0f / quadric_area(s);
+  return it;
+}
+// Shape::sample_si / pdf_wi: Sphere's overrides, or the trait defaults (shapes/mod.rs:39-68) over sample() / intersect()
+inline SpherePoint quadric_sample_si(const Sphere& s, const Interaction& ref, P2 u, float* pdf_out) {
+  if (s.kind == QUADRIC_SPHERE) return sphere_sample_si(s, ref, u, pdf_out);
+  float pdf; SpherePoint intr = quadric_sample(s, u, &pdf);
+  V3 wi = intr.p - ref.p;
+  if (length_squared(wi) == 0.0f) pdf = 0.0f;
+  else { wi = normalize(wi); pdf *= distance_squared(ref.p, intr.p) / fabsf(dot(intr.n, -wi)); if (std::isinf(pdf)) pdf = 0.0f; }
+  *pdf_out = pdf;
+  return intr;
+}
+inline float quadric_pdf_wi(const Sphere& s, const Interaction& ref, V3 wi, uint64_t* n_tests) {
+  if (s.kind == QUADRIC_SPHERE) return sphere_pdf_wi(s, ref, wi, n_tests);
+  Ray ray = spawn_ray(ref, wi);
+  SphereHit h;
+  if (n_tests) *n_tests += 1;
+  if (!quadric_intersect(s, ray, true, &h)) return 0.0f;
+  return distance_squared(ref.p, h.p) / (fabsf(dot(h.n, -wi)) * quadric_area(s));
 }
 
 }  // namespace orc

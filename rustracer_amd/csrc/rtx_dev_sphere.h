@@ -3,6 +3,7 @@
 // rc/transform.rs:175-253. Same operations in the same order as the reference; the CPU restatement the tests compare with is oracle/orc_sphere.h.
 // Only the kernels of scenes that hold a sphere (k_trace_big<.., GENERAL>, k_shade<0, true>, k_resolve<true>) reach this code.
 #pragma once
+#include "rtx_dev_bsdf.h"
 #include "rtx_dev_scene.h"
 
 namespace rtx {
@@ -11,6 +12,8 @@ struct DSphere {  // Sphere (sphere.rs:15-27); o2w / w2o: object-to-world matrix
   float o2w[16], w2o[16];
   float radius, z_min, z_max, theta_min, theta_max, phi_max;
   int reverse_orientation, swaps_handedness;
+  int kind;                    // 0 sphere, 1 disk (rc/shapes/disk.rs), 2 cylinder (rc/shapes/cylinder.rs)
+  float height, inner_radius;  // disk
 };
 
 // ---------------------------------------------------------------- EFloat (rc/efloat.rs)
@@ -75,12 +78,105 @@ RT_DEV f3 xf34_point_with_error(const float* m, f3 p, f3 pe, f3& err) {  // tran
   return xf34_point(m, p);
 }
 
-RT_DEV float sphere_area(const DSphere& s) { return s.phi_max * s.radius * (s.z_max - s.z_min); }  // :336-338
+RT_DEV float sphere_area(const DSphere& s) {
+  if (s.kind == 1) return s.phi_max * 0.5f * (s.radius * s.radius - s.inner_radius * s.inner_radius);  // Disk::area, disk.rs:153-155
+  if (s.kind == 2) return (s.z_max - s.z_min) * s.radius * s.phi_max;                                 // Cylinder::area, cylinder.rs:252-254
+  return s.phi_max * s.radius * (s.z_max - s.z_min);                                                  // Sphere::area, sphere.rs:336-338
+}
+// the tail the three intersect() share: SurfaceInteraction::new(p_hit, p_error, uv, -ray.d, dpdu, dpdv, ..) then .transform(object_to_world)
+// (interaction.rs:107-190; dndu / dndv are zeroed by that transform, so they are not formed)
+RT_DEV void quadric_finish(const DSphere& s, f3 p_hit, f3 p_error, f2 uv, f3 d_obj, f3 dpdu, f3 dpdv, SurfaceInteraction* si) {
+  f3 n = normalize(cross(dpdu, dpdv));
+  if ((s.reverse_orientation != 0) != (s.swaps_handedness != 0)) n = n * -1.0f;
+  const f3 wo = normalize(normalize(-d_obj));
+  f3 pe_w;
+  si->hit.p = xf34_point_with_error(s.o2w, p_hit, p_error, pe_w);
+  si->hit.p_error = pe_w;
+  si->hit.wo = normalize(normalize(xf34_vector(s.o2w, wo)));
+  si->hit.n = normalize(xf34_normal(s.w2o, n));
+  si->uv = uv;
+  si->dpdu = xf34_vector(s.o2w, dpdu); si->dpdv = xf34_vector(s.o2w, dpdv);
+  const f3 sn = normalize(xf34_normal(s.w2o, n));
+  si->sh_n = dot(sn, si->hit.n) < 0.0f ? -sn : sn;  // face_forward_n(shading.n, hit.n)
+  si->sh_dpdu = si->dpdu; si->sh_dpdv = si->dpdv;
+  si->dudx = si->dvdx = si->dudy = si->dvdy = 0.0f; si->dpdx = si->dpdy = mk3(0, 0, 0);
+}
+// Ray::transform(world_to_object), ray.rs:46-71
+RT_DEV void ray_to_object(const DSphere& s, f3 ray_o, f3 ray_d, f3& o, f3& d, f3& o_err, f3& d_err) {
+  o = xf34_point(s.w2o, ray_o);
+  o_err = gamma_n(3) * xf34_abs_sum(s.w2o, ray_o);
+  d = xf34_vector(s.w2o, ray_d);
+  d_err = gamma_n(3) * xf34_abs_sum(s.w2o, ray_d);
+  const float l2 = len2(d);
+  if (l2 > 0.0f) { const float dt = dot(abs3(d), o_err) / l2; o = o + d * dt; }
+}
+template <bool FILL>
+RT_DEV bool disk_intersect(const DSphere& s, f3 ray_o, f3 ray_d, float t_max, float& t_hit, SurfaceInteraction* si) {  // Disk::intersect, disk.rs:65-118
+  f3 o, d, o_err, d_err; ray_to_object(s, ray_o, ray_d, o, d, o_err, d_err);
+  if (d.z == 0.0f) return false;
+  const float ts = (s.height - o.z) / d.z;
+  if (ts <= 0.0f || ts > t_max) return false;
+  f3 p_hit = o + ts * d;
+  const float dist2 = p_hit.x * p_hit.x + p_hit.y * p_hit.y;
+  if (dist2 > s.radius * s.radius || dist2 < s.inner_radius * s.inner_radius) return false;
+  float phi = atan2f(p_hit.y, p_hit.x);
+  if (phi < 0.0f) phi += 2.0f * kPi;
+  if (phi > s.phi_max) return false;
+  t_hit = ts;
+  if (!FILL) return true;
+  const float u = phi / s.phi_max;
+  const float r_hit = sqrtf(dist2);
+  const float one_minus_v = (r_hit - s.inner_radius) / (s.radius - s.inner_radius);
+  const f3 dpdu = mk3(-s.phi_max * p_hit.y, s.phi_max * p_hit.x, 0.0f);
+  const f3 dpdv = mk3(p_hit.x, p_hit.y, 0.0f) * (s.radius - s.inner_radius) / r_hit;
+  p_hit.z = s.height;
+  quadric_finish(s, p_hit, mk3(0, 0, 0), mk2(u, 1.0f - one_minus_v), d, dpdu, dpdv, si);
+  return true;
+}
+template <bool FILL>
+RT_DEV bool cylinder_intersect(const DSphere& s, f3 ray_o, f3 ray_d, float t_max, float& t_hit, SurfaceInteraction* si) {  // Cylinder::intersect / intersect_p, cylinder.rs:62-250
+  f3 o, d, o_err, d_err; ray_to_object(s, ray_o, ray_d, o, d, o_err, d_err);
+  const EFloat ox = ef_new(o.x, o_err.x), oy = ef_new(o.y, o_err.y);
+  const EFloat dx = ef_new(d.x, d_err.x), dy = ef_new(d.y, d_err.y);
+  const EFloat a = dx * dx + dy * dy;
+  const EFloat b = ef(2.0f) * (dx * ox + dy * oy);
+  const EFloat c = ox * ox + oy * oy - ef(s.radius) * ef(s.radius);
+  EFloat t0, t1;
+  if (!ef_solve_quadratic(a, b, c, t0, t1)) return false;
+  if (t0.high > t_max || t1.low <= 0.0f) return false;
+  EFloat ts = t0; bool is_t1 = false;
+  if (ts.low <= 0.0f) { ts = t1; is_t1 = true; if (ts.high > t_max) return false; }
+  f3 p_hit = o + ts.v * d;
+  float hit_rad = sqrtf(p_hit.x * p_hit.x + p_hit.y * p_hit.y);
+  p_hit.x *= s.radius / hit_rad; p_hit.y *= s.radius / hit_rad;
+  float phi = atan2f(p_hit.y, p_hit.x);
+  if (phi < 0.0f) phi += 2.0f * kPi;
+  if (p_hit.z < s.z_min || p_hit.z > s.z_max || phi > s.phi_max) {
+    if (is_t1 || ts.v == t1.v) return false;
+    ts = t1;
+    if (t1.high > t_max) return false;
+    p_hit = o + ts.v * d;
+    hit_rad = sqrtf(p_hit.x * p_hit.x + p_hit.y * p_hit.y);
+    p_hit.x *= s.radius / hit_rad; p_hit.y *= s.radius / hit_rad;
+    phi = atan2f(p_hit.y, p_hit.x);
+    if (phi < 0.0f) phi += 2.0f * kPi;
+    if (p_hit.z < s.z_min || p_hit.z > s.z_max || phi > s.phi_max) return false;
+  }
+  t_hit = ts.v;
+  if (!FILL) return true;
+  const float u = phi / s.phi_max;
+  const float v = (p_hit.z - s.z_min) / (s.z_max / s.z_min);  // a division where pbrt subtracts (cylinder.rs:121): kept
+  const f3 dpdu = mk3(-s.phi_max * p_hit.y, s.phi_max * p_hit.x, 0.0f);
+  const f3 dpdv = mk3(0.0f, 0.0f, s.z_max - s.z_min);
+  const f3 p_error = gamma_n(3) * mk3(fabsf(p_hit.x), fabsf(p_hit.y), 0.0f);
+  quadric_finish(s, p_hit, p_error, mk2(u, v), d, dpdu, dpdv, si);
+  return true;
+}
 
 // Sphere::intersect (:71-203). FILL: also the world-space SurfaceInteraction that SurfaceInteraction::new + .transform(object_to_world) leave
 // (interaction.rs:107-190; dndu / dndv are zeroed by that transform, so they are not formed).
 template <bool FILL>
-RT_DEV bool sphere_intersect(const DSphere& s, f3 ray_o, f3 ray_d, float t_max, float& t_hit, SurfaceInteraction* si) {
+RT_DEV bool sphere_only_intersect(const DSphere& s, f3 ray_o, f3 ray_d, float t_max, float& t_hit, SurfaceInteraction* si) {
   // Ray::transform(world_to_object), ray.rs:46-71
   f3 o = xf34_point(s.w2o, ray_o);
   const f3 o_err = gamma_n(3) * xf34_abs_sum(s.w2o, ray_o);
@@ -141,6 +237,12 @@ RT_DEV bool sphere_intersect(const DSphere& s, f3 ray_o, f3 ray_d, float t_max, 
   si->dudx = si->dvdx = si->dudy = si->dvdy = 0.0f; si->dpdx = si->dpdy = mk3(0, 0, 0);
   return true;
 }
+template <bool FILL>
+RT_DEV bool sphere_intersect(const DSphere& s, f3 ray_o, f3 ray_d, float t_max, float& t_hit, SurfaceInteraction* si) {  // Shape::intersect of a quadric
+  if (s.kind == 1) return disk_intersect<FILL>(s, ray_o, ray_d, t_max, t_hit, si);
+  if (s.kind == 2) return cylinder_intersect<FILL>(s, ray_o, ray_d, t_max, t_hit, si);
+  return sphere_only_intersect<FILL>(s, ray_o, ray_d, t_max, t_hit, si);
+}
 // out-of-line entry points: the hit test of the traversal leaf loop, and the interaction of an accepted hit (t_max = infinity: the roots, the clipping
 // retry and p_hit do not depend on t_max, which only rejects - the accepted test's decisions are reproduced)
 RT_DEVN bool sphere_test(const DSphere& s, f3 o, f3 d, float t_max, float& t_hit) { return sphere_intersect<false>(s, o, d, t_max, t_hit, nullptr); }
@@ -160,7 +262,36 @@ RT_DEV SpherePoint sphere_sample(const DSphere& s, f2 u, float& pdf) {  // Spher
   pdf = 1.0f / sphere_area(s);
   return it;
 }
+// Shape::sample of a disk / cylinder (disk.rs:136-151, cylinder.rs:256-278) and the trait's default sample_si over it (shapes/mod.rs:39-53)
+RT_DEV SpherePoint quadric_default_sample_si(const DSphere& s, const Interaction& ref, f2 u, float& pdf_out) {
+  SpherePoint it;
+  if (s.kind == 1) {
+    const f2 pd = concentric_sample_disk(u);
+    const f3 p_obj = mk3(pd.x * s.radius, pd.y * s.radius, s.height);
+    it.n = normalize(xf34_normal(s.w2o, mk3(0.0f, 0.0f, 1.0f)));
+    if (s.reverse_orientation) it.n = -it.n;
+    it.p = xf34_point_with_error(s.o2w, p_obj, mk3(0, 0, 0), it.p_error);
+  } else {
+    const float z = lerpf(u.x, s.z_min, s.z_max);
+    const float phi = u.y * s.phi_max;
+    f3 p_obj = mk3(s.radius * cosf(phi), s.radius * sinf(phi), z);
+    f3 n = normalize(xf34_normal(s.w2o, mk3(p_obj.x, p_obj.y, 0.0f)));
+    if (s.reverse_orientation) n = n * -1.0f;
+    const float hit_rad = sqrtf(p_obj.x * p_obj.x + p_obj.y * p_obj.y);
+    p_obj.x *= s.radius / hit_rad; p_obj.y *= s.radius / hit_rad;
+    const f3 p_obj_error = gamma_n(3) * mk3(fabsf(p_obj.x), fabsf(p_obj.y), 0.0f);
+    it.p = xf34_point_with_error(s.o2w, p_obj, p_obj_error, it.p_error);
+    it.n = n;
+  }
+  float pdf = 1.0f / sphere_area(s);
+  f3 wi = it.p - ref.p;
+  if (len2(wi) == 0.0f) pdf = 0.0f;
+  else { wi = normalize(wi); pdf *= distance_squared(ref.p, it.p) / fabsf(dot(it.n, -wi)); if (isinf(pdf)) pdf = 0.0f; }
+  pdf_out = pdf;
+  return it;
+}
 RT_DEVN SpherePoint sphere_sample_si(const DSphere& s, const Interaction& ref, f2 u, float& pdf_out) {  // Sphere::sample_si, :246-308
+  if (s.kind != 0) return quadric_default_sample_si(s, ref, u, pdf_out);
   const f3 p_center = xf34_point(s.o2w, mk3(0, 0, 0));
   const f3 p_origin = offset_ray_origin(ref.p, ref.p_error, ref.n, p_center - ref.p);
   if (distance_squared(p_origin, p_center) <= s.radius * s.radius) {
@@ -192,10 +323,10 @@ RT_DEVN SpherePoint sphere_sample_si(const DSphere& s, const Interaction& ref, f
   pdf_out = 1.0f / (2.0f * kPi * (1.0f - cos_theta_max));  // uniform cone pdf
   return it;
 }
-RT_DEVN float sphere_pdf_wi(const DSphere& s, const Interaction& ref, f3 wi) {  // Sphere::pdf_wi, :310-334
+RT_DEVN float sphere_pdf_wi(const DSphere& s, const Interaction& ref, f3 wi) {  // Sphere::pdf_wi, :310-334; disk / cylinder: the trait default, shapes/mod.rs:59-68
   const f3 p_center = xf34_point(s.o2w, mk3(0, 0, 0));
   const f3 p_origin = offset_ray_origin(ref.p, ref.p_error, ref.n, p_center - ref.p);
-  if (distance_squared(p_origin, p_center) <= s.radius * s.radius) {
+  if (s.kind != 0 || distance_squared(p_origin, p_center) <= s.radius * s.radius) {
     const f3 ro = offset_ray_origin(ref.p, ref.p_error, ref.n, wi);  // Interaction::spawn_ray
     SurfaceInteraction li; float t;
     if (!sphere_intersect<true>(s, ro, wi, kInf, t, &li)) return 0.0f;

@@ -296,7 +296,19 @@ int finish_commit(rtxh_scene* s);
 
 // Sphere::world_bounds (sphere.rs:212-225): the 8 corners of the object-space box through object_to_world, in the reference's order
 static Box sphere_world_box(const rt_sphere& sp) {
-  const float lo[3] = {-sp.radius, -sp.radius, sp.z_min}, hi[3] = {sp.radius, sp.radius, sp.z_max};
+  auto map = [&](float x, float y, float z, float* p) {  // Transform * Point3f, transform.rs:264-286
+    for (int r = 0; r < 3; ++r) p[r] = sp.o2w[4 * r] * x + sp.o2w[4 * r + 1] * y + sp.o2w[4 * r + 2] * z + sp.o2w[4 * r + 3];
+    const float wp = sp.o2w[12] * x + sp.o2w[13] * y + sp.o2w[14] * z + sp.o2w[15];
+    if (wp != 1.0f) for (int r = 0; r < 3; ++r) p[r] = p[r] / wp;
+  };
+  if (sp.kind == 1) {  // Disk::world_bounds (disk.rs:127-134) maps two corners of the object box only - wrong under a rotation, kept as it is
+    float p1[3], p2[3]; map(-sp.radius, -sp.radius, sp.height, p1); map(sp.radius, sp.radius, sp.height, p2);
+    Box bb; for (int k = 0; k < 3; ++k) { bb.lo[k] = std::fmin(p1[k], p2[k]); bb.hi[k] = std::fmax(p1[k], p2[k]); }
+    return bb;
+  }
+  // Sphere: the 8 corners in the order of sphere.rs:212-225; Cylinder: &object_to_world * &object_bounds (transform.rs:342-380) - the same 8 corners of
+  // from_points((-r, -r, z_min), (r, r, z_max)), whose min / max do not depend on the order
+  const float lo[3] = {-sp.radius, -sp.radius, sp.kind == 2 ? std::fmin(sp.z_min, sp.z_max) : sp.z_min}, hi[3] = {sp.radius, sp.radius, sp.kind == 2 ? std::fmax(sp.z_min, sp.z_max) : sp.z_max};
   const int order[8][3] = {{0, 0, 0}, {1, 0, 0}, {0, 1, 0}, {0, 0, 1}, {1, 1, 0}, {1, 0, 1}, {0, 1, 1}, {1, 1, 1}};
   Box bb; const float M = std::numeric_limits<float>::max();
   for (int k = 0; k < 3; ++k) { bb.lo[k] = M; bb.hi[k] = -M; }  // Bounds3f::new, bounds.rs:25-32
@@ -471,7 +483,9 @@ int finish_commit(rtxh_scene* s) {
       l.prim = leaf_of[hl.tri_source];
       if ((size_t)hl.tri_source >= n_triangles) {
         const rt_sphere& sp = s->spheres[(size_t)hl.tri_source - n_triangles].s;
-        l.area = sp.phi_max * sp.radius * (sp.z_max - sp.z_min);  // Sphere::area, sphere.rs:336-338
+        l.area = sp.kind == 1 ? sp.phi_max * 0.5f * (sp.radius * sp.radius - sp.inner_radius * sp.inner_radius)  // Disk::area, disk.rs:153-155
+                 : sp.kind == 2 ? (sp.z_max - sp.z_min) * sp.radius * sp.phi_max                              // Cylinder::area, cylinder.rs:252-254
+                                : sp.phi_max * sp.radius * (sp.z_max - sp.z_min);                             // Sphere::area, sphere.rs:336-338
         if (l.kind == RT_LIGHT_DISTANT || l.kind == RT_LIGHT_INFINITE) l.world_radius = world_radius;
         s->f_lights.push_back(l);
         continue;
@@ -575,13 +589,23 @@ int rtxh_scene_set_mesh(rtxh_scene* s, const float* P, int32_t nv, const int32_t
 // Shape "sphere" (Sphere::create sphere.rs:53-68 + Sphere::new :29-51). Returns the sphere's index k; an area light on it is added with tri = -2 - k.
 int rtxh_scene_add_sphere(rtxh_scene* s, const float* o2w16, const float* w2o16, float radius, float z_min, float z_max, float phi_max, int32_t reverse_orientation,
                           int32_t material, int32_t light) {
+  return rtxh_scene_add_quadric(s, 0, o2w16, w2o16, radius, z_min, z_max, phi_max, reverse_orientation, material, light);
+}
+int rtxh_scene_add_quadric(rtxh_scene* s, int32_t kind, const float* o2w16, const float* w2o16, float radius, float z_min, float z_max, float phi_max,
+                           int32_t reverse_orientation, int32_t material, int32_t light) {
+  if (kind < 0 || kind > 2) return fail(RT_ERR_INVALID, "unknown quadric kind");
   if (!s || !o2w16 || !w2o16) return fail(RT_ERR_INVALID, "bad sphere arguments");
   rtxh_scene::HostSphere hs{}; rt_sphere& sp = hs.s;
   memcpy(sp.o2w, o2w16, 64); memcpy(sp.w2o, w2o16, 64);
   auto clampf = [](float v, float lo, float hi) { return v < lo ? lo : (v > hi ? hi : v); };  // lib.rs:264-275
-  sp.radius = radius;
-  sp.z_min = clampf(std::fmin(z_min, z_max), -radius, radius); sp.z_max = clampf(std::fmax(z_min, z_max), -radius, radius);
-  sp.theta_min = std::acos(clampf(std::fmin(z_min, z_max) / radius, -1.0f, 1.0f)); sp.theta_max = std::acos(clampf(std::fmax(z_min, z_max) / radius, -1.0f, 1.0f));
+  sp.radius = radius; sp.kind = kind;
+  if (kind == 0) {  // Sphere::new, sphere.rs:29-51
+    sp.z_min = clampf(std::fmin(z_min, z_max), -radius, radius); sp.z_max = clampf(std::fmax(z_min, z_max), -radius, radius);
+    sp.theta_min = std::acos(clampf(std::fmin(z_min, z_max) / radius, -1.0f, 1.0f)); sp.theta_max = std::acos(clampf(std::fmax(z_min, z_max) / radius, -1.0f, 1.0f));
+  } else if (kind == 1) {  // Disk::new(height = z_min, inner_radius = z_max), disk.rs:25-46 (it asserts radius > 0, inner_radius >= 0, phi_max > 0)
+    if (!(radius > 0.0f) || !(z_max >= 0.0f) || !(phi_max > 0.0f)) return fail(RT_ERR_INVALID, "disk needs radius > 0, innerradius >= 0, phimax > 0 (the reference asserts it)");
+    sp.height = z_min; sp.inner_radius = z_max; sp.z_min = sp.z_max = z_min;
+  } else { sp.z_min = z_min; sp.z_max = z_max; }  // Cylinder::create keeps z_min / z_max as given, cylinder.rs:26-46
   sp.phi_max = clampf(phi_max, 0.0f, 360.0f) * (3.14159265358979323846f / 180.0f);  // f32::to_radians
   sp.reverse_orientation = reverse_orientation ? 1 : 0;
   const float* m = o2w16;  // Transform::swaps_handedness, transform.rs:255-261

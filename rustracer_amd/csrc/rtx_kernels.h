@@ -1593,9 +1593,20 @@ __global__ void __launch_bounds__(256) k_lightdist_mark(DScene sc, unsigned char
   const unsigned t = blockIdx.x * blockDim.x + threadIdx.x;
   if (t >= sc.n_tris) return;
   f3 p0, p1, p2; load_tri(sc.tri_p, (int)t, p0, p1, p2);
-  const bool is_sphere = (tri_flags(sc.tri_p, (int)t) & RT_FLAG_SPHERE) != 0u;  // its slot holds the world box: every voxel of the box is kept
-  const f3 mn = is_sphere ? p0 : mk3(fminf(p0.x, fminf(p1.x, p2.x)), fminf(p0.y, fminf(p1.y, p2.y)), fminf(p0.z, fminf(p1.z, p2.z)));
-  const f3 mx = is_sphere ? p1 : mk3(fmaxf(p0.x, fmaxf(p1.x, p2.x)), fmaxf(p0.y, fmaxf(p1.y, p2.y)), fmaxf(p0.z, fmaxf(p1.z, p2.z)));
+  const bool is_sphere = (tri_flags(sc.tri_p, (int)t) & RT_FLAG_SPHERE) != 0u;  // a quadric: every voxel of its box is kept
+  f3 mn = mk3(fminf(p0.x, fminf(p1.x, p2.x)), fminf(p0.y, fminf(p1.y, p2.y)), fminf(p0.z, fminf(p1.z, p2.z)));
+  f3 mx = mk3(fmaxf(p0.x, fmaxf(p1.x, p2.x)), fmaxf(p0.y, fmaxf(p1.y, p2.y)), fmaxf(p0.z, fmaxf(p1.z, p2.z)));
+  if (is_sphere) {
+    // The box in the slot is the one the reference's BVH uses, and Disk::world_bounds is wrong under a rotation (disk.rs:127-134): surface points of a
+    // disk can lie outside it. Marking needs a box that truly holds the surface: the 8 mapped corners of the object-space box.
+    const DSphere& q = sc.spheres[__float_as_uint(p2.x)];
+    const float zlo = q.kind == 1 ? q.height : fminf(q.z_min, q.z_max), zhi = q.kind == 1 ? q.height : fmaxf(q.z_min, q.z_max);
+    mn = mk3(kInf, kInf, kInf); mx = mk3(-kInf, -kInf, -kInf);
+    for (int c = 0; c < 8; ++c) {
+      const f3 w = xf34_point(q.o2w, mk3(c & 1 ? q.radius : -q.radius, c & 2 ? q.radius : -q.radius, c & 4 ? zhi : zlo));
+      mn = mk3(fminf(mn.x, w.x), fminf(mn.y, w.y), fminf(mn.z, w.z)); mx = mk3(fmaxf(mx.x, w.x), fmaxf(mx.y, w.y), fmaxf(mx.z, w.z));
+    }
+  }
   const f3 o0 = bounds_offset(sc.wb_min, sc.wb_max, mn), o1 = bounds_offset(sc.wb_min, sc.wb_max, mx);
   const float pad = 1e-4f;  // in units of the scene extent: >> the rounding of p and of voxel_of, << one voxel (1/64)
   int lo[3], hi[3];

@@ -333,10 +333,15 @@ struct PbrtLoader {
   // ------------------------------------------------------------------ shapes (make_shapes api.rs:1093-1139; mesh.rs:76-179; plymesh.rs)
   bool add_shape(const std::string& name, const PbrtParams& p) {
     std::vector<float> vp, vn, vuv, vs; std::vector<int32_t> vi;
-    if (name == "sphere") {  // Sphere::create (sphere.rs:53-68): an analytic primitive under the CTM, with one DiffuseAreaLight if an area light is active (api.rs:933-946)
-      if (in_instance) return fail_("a sphere inside an object definition is not supported (instances are written out as triangles)");
+    if (name == "sphere" || name == "disk" || name == "cylinder") {  // an analytic primitive under the CTM, with one DiffuseAreaLight if an area light is active (api.rs:933-946)
+      if (in_instance) return fail_("a " + name + " inside an object definition is not supported (instances are written out as triangles)");
+      const int kind = name == "sphere" ? 0 : (name == "disk" ? 1 : 2);
       const float radius = p.one_float("radius", 1.0f);
-      const float zmin = p.one_float("zmin", -radius), zmax = p.one_float("zmax", radius), phimax = p.one_float("phimax", 360.0f);
+      // Sphere::create (sphere.rs:53-68): zmin zmax phimax; Disk::create (disk.rs:48-62): height innerradius phimax; Cylinder::create
+      // (cylinder.rs:26-46) reads "z_min" "z_max" "phi_max" - not pbrt's names: a reference quirk, kept
+      const float zmin = kind == 0 ? p.one_float("zmin", -radius) : (kind == 1 ? p.one_float("height", 0.0f) : p.one_float("z_min", -1.0f));
+      const float zmax = kind == 0 ? p.one_float("zmax", radius) : (kind == 1 ? p.one_float("innerradius", 0.0f) : p.one_float("z_max", 1.0f));
+      const float phimax = kind == 2 ? p.one_float("phi_max", 360.0f) : p.one_float("phimax", 360.0f);
       const int mat = current_material(p);
       if (mat < 0) return fail_(err.empty() ? rtxh_last_error() : err);
       int light = -1;
@@ -344,7 +349,7 @@ struct PbrtLoader {
         if (gs.area_light != "area" && gs.area_light != "diffuse") return fail_("area light \"" + gs.area_light + "\" unknown");
         light = n_lights;
       }
-      const int k = rtxh_scene_add_sphere(scene, &ctm.m.a[0][0], &ctm.inv.a[0][0], radius, zmin, zmax, phimax, gs.reverse_orientation ? 1 : 0, mat, light);
+      const int k = rtxh_scene_add_quadric(scene, kind, &ctm.m.a[0][0], &ctm.inv.a[0][0], radius, zmin, zmax, phimax, gs.reverse_orientation ? 1 : 0, mat, light);
       if (k < 0) return fail_(rtxh_last_error());
       if (light >= 0) {
         float L[3] = {1, 1, 1}, sc[3] = {1, 1, 1};
@@ -373,7 +378,7 @@ struct PbrtLoader {
       if (ply.N) vn.assign(ply.N, ply.N + (size_t)ply.n_verts * 3);
       if (ply.UV) vuv.assign(ply.UV, ply.UV + (size_t)ply.n_verts * 2);
       rtxh_ply_free(&ply);
-    } else return fail_("shape \"" + name + "\" is not supported (triangle meshes and spheres only)");
+    } else return fail_("shape \"" + name + "\" is not supported (triangle meshes, spheres, disks and cylinders; cone / paraboloid / hyperboloid / curve are unimplemented!() in the reference too)");
     // "alpha" / "shadowalpha" (TriangleMesh::create mesh.rs:134-156, plymesh.rs:143-165): a named float texture (unknown name: logged, no mask),
     // else the constant-0 texture when the float parameter is exactly 0
     auto mask = [&](const char* n) -> int {

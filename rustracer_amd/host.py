@@ -181,8 +181,8 @@ class HostScene:
         for m in desc.materials:
             _check(L.rtxh_scene_add_material(self.h, m.kind, _p(m.slots(), C.c_int32), int(m.remap_roughness), int(m.bump)), "add_material")
         for sp in getattr(desc, "spheres", []):
-            _check(L.rtxh_scene_add_sphere(self.h, _p(sp.o2w), _p(sp.w2o), C.c_float(sp.radius), C.c_float(sp.z_min), C.c_float(sp.z_max), C.c_float(sp.phi_max),
-                                           int(sp.reverse_orientation), sp.material, sp.light), "add_sphere")
+            _check(L.rtxh_scene_add_quadric(self.h, int(getattr(sp, "kind", 0)), _p(sp.o2w), _p(sp.w2o), C.c_float(sp.radius), C.c_float(sp.z_min), C.c_float(sp.z_max),
+                                            C.c_float(sp.phi_max), int(sp.reverse_orientation), sp.material, sp.light), "add_quadric")
         for l in desc.lights:
             l2w = None if l.l2w is None else np.ascontiguousarray(l.l2w, np.float32)
             w2l = None if l.w2l is None else np.ascontiguousarray(l.w2l, np.float32)

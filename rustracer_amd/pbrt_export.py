@@ -228,7 +228,13 @@ class _Writer:
             if sp.light >= 0:
                 l = d.lights[sp.light]
                 o.append(f'  AreaLightSource "diffuse" "rgb L" [{_nums(l.rgb)}] "bool twosided" "{"true" if l.two_sided else "false"}"')
-            o.append(f'  Shape "sphere" "float radius" [{_n(sp.radius)}] "float zmin" [{_n(sp.z_min)}] "float zmax" [{_n(sp.z_max)}] "float phimax" [{_n(sp.phi_max)}]')
+            kind = getattr(sp, "kind", 0)
+            if kind == 0:
+                o.append(f'  Shape "sphere" "float radius" [{_n(sp.radius)}] "float zmin" [{_n(sp.z_min)}] "float zmax" [{_n(sp.z_max)}] "float phimax" [{_n(sp.phi_max)}]')
+            elif kind == 1:
+                o.append(f'  Shape "disk" "float radius" [{_n(sp.radius)}] "float height" [{_n(sp.z_min)}] "float innerradius" [{_n(sp.z_max)}] "float phimax" [{_n(sp.phi_max)}]')
+            else:  # the reference's Cylinder::create reads z_min / z_max / phi_max (cylinder.rs:31-34)
+                o.append(f'  Shape "cylinder" "float radius" [{_n(sp.radius)}] "float z_min" [{_n(sp.z_min)}] "float z_max" [{_n(sp.z_max)}] "float phi_max" [{_n(sp.phi_max)}]')
             o.append("AttributeEnd")
         for _, l in other:
             self.light(l)

@@ -90,6 +90,7 @@ class SphereShape:  # Shape "sphere" (rc/shapes/sphere.rs:53-68)
     reverse_orientation: bool = False
     material: int = 0
     light: int = -1  # index into the light list of its DiffuseAreaLight, or -1
+    kind: int = 0    # 0 sphere, 1 disk (z_min = height, z_max = inner radius; rc/shapes/disk.rs), 2 cylinder (rc/shapes/cylinder.rs)
 
 
 @dataclass
@@ -321,6 +322,24 @@ class SceneDesc:
         self.spheres.append(SphereShape(o2w, w2o, float(radius), float(-radius if z_min is None else z_min), float(radius if z_max is None else z_max),
                                         float(phi_max), bool(reverse_orientation), int(material), light))
         return len(self.spheres) - 1
+
+    def _add_quadric(self, kind, o2w, radius, a, b, phi_max, material, reverse_orientation, emission, two_sided) -> int:
+        o2w = np.ascontiguousarray(o2w, np.float32)
+        w2o = np.ascontiguousarray(np.linalg.inv(o2w.astype(np.float64)), np.float32)
+        light = -1
+        if emission is not None:
+            self.lights.append(Light(LIGHT_DIFFUSE_AREA, tri=-1, sphere=len(self.spheres), rgb=tuple(float(x) for x in emission), two_sided=two_sided))
+            light = len(self.lights) - 1
+        self.spheres.append(SphereShape(o2w, w2o, float(radius), float(a), float(b), float(phi_max), bool(reverse_orientation), int(material), light, kind))
+        return len(self.spheres) - 1
+
+    def add_disk(self, o2w, radius=1.0, material: int = 0, height=0.0, inner_radius=0.0, phi_max=360.0, reverse_orientation=False, emission=None, two_sided=False) -> int:
+        """Shape "disk" (rc/shapes/disk.rs): the annulus inner_radius <= r <= radius of the plane z = height of object space."""
+        return self._add_quadric(1, o2w, radius, height, inner_radius, phi_max, material, reverse_orientation, emission, two_sided)
+
+    def add_cylinder(self, o2w, radius=1.0, material: int = 0, z_min=-1.0, z_max=1.0, phi_max=360.0, reverse_orientation=False, emission=None, two_sided=False) -> int:
+        """Shape "cylinder" (rc/shapes/cylinder.rs): the open cylinder of `radius` around the object-space z axis between z_min and z_max."""
+        return self._add_quadric(2, o2w, radius, z_min, z_max, phi_max, material, reverse_orientation, emission, two_sided)
 
     def add_quad(self, p0, p1, p2, p3, material: int, **kw) -> int:
         return self.add_mesh([p0, p1, p2, p3], [[0, 1, 2], [0, 2, 3]], material, **kw)

@@ -35,6 +35,10 @@ def _sphere_zoo(res=48, spp=16):
     d.add_sphere(radius=40.0, material=d.matte((0.3, 0.8, 0.3)), o2w=_xf((120, 330, 380), (1, 1, -1)), reverse_orientation=True)              # mirrored + reversed
     d.add_sphere((420, 150, 100), 35.0, d.glass())
     d.add_sphere((278, 450, 250), 30.0, d.matte((0.0,) * 3), emission=(30.0, 25.0, 20.0))                                                    # a sphere light
+    # the reference's other quadrics: a tilted ring (disk with a hole, partial sweep), a leaning cylinder, and a disk light under the ceiling
+    d.add_disk(_xf((430, 60, 330), rot=_rot((1, 0, 0.2), -70)), 55.0, d.matte((0.7, 0.7, 0.2)), height=5.0, inner_radius=20.0, phi_max=300.0)
+    d.add_cylinder(_xf((230, 0, 420), rot=_rot((1, 0, 0), -90) @ _rot((0, 1, 0), 12)), 35.0, d.plastic((0.6, 0.2, 0.5), (0.3, 0.3, 0.3), 0.2), z_min=5.0, z_max=210.0)
+    d.add_disk(_xf((120, 520, 150), rot=_rot((1, 0, 0), 90)), 45.0, d.matte((0.0,) * 3), emission=(12.0, 14.0, 18.0))
     return d
 
 
@@ -145,3 +149,29 @@ def test_spheres_through_a_pbrt_file(gpu_host, tmp_path):
     b, sb = p.render()
     assert np.array_equal(a[..., 3], b[..., 3]) and rel_l2(gpu_host.film_to_rgb(b), gpu_host.film_to_rgb(a)) < 2e-4
     assert sa["rays_closest"] == sb["rays_closest"] or abs(int(sa["rays_closest"]) - int(sb["rays_closest"])) < 1e-3 * sa["rays_closest"]
+
+
+@pytest.mark.parametrize("who", ["gpu", "oracle"])
+def test_irradiance_of_a_disk_emitter(gpu_host, orc, who):
+    """A Lambertian floor under a parallel emitting disk of radius R at height h, direct light only: at distance a from the axis
+    E = pi L / 2 * (1 - (h^2 + a^2 - R^2) / sqrt((h^2 + a^2 + R^2)^2 - 4 R^2 a^2)) (the classic disk-to-element form factor); L_floor = rho / pi * E.
+    Disk::sample + the trait's default sample_si / pdf_wi (area measure converted to solid angle) and MIS against the BSDF-sampled ray."""
+    from rustracer_amd.scene_desc import SceneDesc
+    rho, le, rad, hz, cam = 0.6, 8.0, 0.7, 3.0, 2.0
+    s = SceneDesc()
+    s.add_quad((-6, -6, 0), (6, -6, 0), (6, 6, 0), (-6, 6, 0), s.matte((rho,) * 3))
+    o2w = np.eye(4, dtype=np.float32); o2w[2, 3] = hz
+    s.add_disk(o2w, rad, s.matte((0.0,) * 3), emission=(le,) * 3, reverse_orientation=True)  # its normal is +z: reversed, it emits downwards
+    s.camera.pos, s.camera.look, s.camera.up, s.camera.fov = (0.0, 0.0, cam), (0, 0, 0), (0, 1, 0), 60.0
+    s.film.xres = s.film.yres = 64
+    s.sampler.spp = 256
+    s.integrator.max_depth = 1
+    img = (gpu_host.film_to_rgb(gpu_host.HostScene(s).render()[0]) if who == "gpu" else orc.film_to_rgb(orc.OracleScene(s).render(mode=1)[0]))[..., 0]
+    t = np.tan(np.radians(60.0) / 2) * cam
+    c = (2 * (np.arange(64) + 0.5) / 64 - 1) * t
+    x, y = np.meshgrid(c, c)
+    a2 = x * x + y * y
+    want = rho / np.pi * (np.pi * le / 2) * (1 - (hz * hz + a2 - rad * rad) / np.sqrt((hz * hz + a2 + rad * rad) ** 2 - 4 * rad * rad * a2))
+    assert abs(img.mean() / want.mean() - 1) < 0.004, (img.mean(), want.mean())
+    gm, wm = img.reshape(8, 8, 8, 8).mean(axis=(1, 3)), want.reshape(8, 8, 8, 8).mean(axis=(1, 3))
+    assert np.allclose(gm, wm, rtol=0.03), gm / wm

@@ -492,7 +492,7 @@ WorldEnd
     ('PixelFilter "sinc"\n' + HEADER + "WorldBegin\n" + TRI + "WorldEnd\n", 'Filter "sinc" unknown'),
     ('Camera "orthographic"\n' + HEADER + "WorldBegin\n" + TRI + "WorldEnd\n", 'Camera "orthographic" unknown'),
     ('Integrator "whitted"\n' + HEADER + "WorldBegin\n" + TRI + "WorldEnd\n", "not supported"),
-    (HEADER + 'WorldBegin\nShape "cylinder"\nWorldEnd\n', "not supported"),
+    (HEADER + 'WorldBegin\nShape "cone"\nWorldEnd\n', "not supported"),
     (HEADER + 'WorldBegin\nObjectBegin "o"\nShape "sphere"\nObjectEnd\n' + TRI + "WorldEnd\n", "object definition"),
     (HEADER + 'WorldBegin\nLightSource "spot"\n' + TRI + "WorldEnd\n", "not supported"),
     (HEADER + 'WorldBegin\nAreaLightSource "sphere"\n' + TRI + "WorldEnd\n", "unknown"),
