@@ -83,7 +83,7 @@ struct PbrtLoader {
   PbrtGraphicsState gs; std::vector<PbrtGraphicsState> pushed_gs;
   PbrtSoup world;
   std::map<std::string, PbrtSoup> instances; std::string current_instance; bool in_instance = false;  // RenderOptions::instances / current_instance (api.rs:175-177)
-  int n_lights = 0, n_spheres = 0;
+  int n_lights = 0, n_spheres = 0; size_t instanced_triangles = 0;
 
   bool fail_(const std::string& m) { if (err.empty()) err = m; return false; }
   void warn(const std::string&) { warnings += 1; }
@@ -434,6 +434,14 @@ struct PbrtLoader {
     if (it == instances.end()) return fail_("Unable to find instance named " + name);
     const PbrtSoup& o = it->second;
     if (o.idx.empty()) return true;
+    // Written-out instances cost memory in proportion to instances x mesh size, where the reference's TransformedPrimitive shares one BVH. A scene
+    // that instantiates its way past the budget is refused with a message instead of exhausting the host (RTX_INSTANCE_TRIANGLE_BUDGET, default 2^28
+    // triangles ~ 40 GB of device geometry and BVH - a fraction of the 288 GB the design counts on).
+    static const size_t budget = getenv("RTX_INSTANCE_TRIANGLE_BUDGET") ? (size_t)strtoull(getenv("RTX_INSTANCE_TRIANGLE_BUDGET"), nullptr, 10) : ((size_t)1 << 28);
+    instanced_triangles += o.idx.size() / 3;
+    if (world.idx.size() / 3 + o.idx.size() / 3 > budget)
+      return fail_("ObjectInstance \"" + name + "\": writing the instances out would exceed " + std::to_string(budget) + " triangles (" + std::to_string(instanced_triangles) +
+                   " instanced so far); this backend has no two-level traversal (RTX_INSTANCE_TRIANGLE_BUDGET raises the limit)");
     const size_t nv = o.n_verts();
     std::vector<float> p(3 * nv), n, sv;
     for (size_t v = 0; v < nv; ++v) xf_point(ctm.m, &o.P[3 * v], &p[3 * v]);

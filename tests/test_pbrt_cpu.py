@@ -627,3 +627,20 @@ def test_metal_default_spectrum_files_and_blackbody_parameters(tmp_path):
     assert np.array_equal(F32(lights[0]["rgb"]), host.spectrum_blackbody(6500.0, 2.0))
     q = _parse(HEADER + 'WorldBegin\nMaterial "matte" "spectrum Kd" "missing.spd"\n' + TRI + "WorldEnd\n", base_dir=str(tmp_path))
     assert q.n_warnings >= 1 and np.array_equal(q.table("textures")[q.table("materials")[0]["slot"][0]]["value"], F32([0, 0, 0]))  # paramset.rs:257-266: black
+
+
+def test_instancing_past_the_triangle_budget_is_refused(monkeypatch):
+    """ObjectInstance is written out (no two-level traversal): a file that instantiates its way past the budget fails with a message naming it."""
+    body = 'WorldBegin\nObjectBegin "o"\n' + TRI * 3 + "ObjectEnd\n" + "".join(f'AttributeBegin\nTranslate {i} 0 0\nObjectInstance "o"\nAttributeEnd\n' for i in range(8)) + "WorldEnd\n"
+    assert len(_parse(HEADER + body).table("indices")) == 24
+    import subprocess, sys, textwrap
+    code = textwrap.dedent(f"""
+        import sys; sys.path.insert(0, {os.path.dirname(os.path.dirname(os.path.abspath(__file__)))!r})
+        from rustracer_amd import host
+        try:
+            host.PbrtScene(text={HEADER + body!r})
+        except host.BackendError as e:
+            print("REFUSED", e)
+    """)
+    out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, env=dict(os.environ, RTX_INSTANCE_TRIANGLE_BUDGET="10")).stdout
+    assert "REFUSED" in out and "exceed 10 triangles" in out
