@@ -26,6 +26,7 @@ struct DSphere;  // rtx_dev_sphere.h
 struct DScene {
   const float4* nodes; unsigned n_nodes;
   const float4* pairs;  // n_nodes x 64 B child-pair records of the interior nodes (NULL for LDS-resident scenes), see k_trace_pair
+  const float4* top_pairs; unsigned n_top;  // pair records of the first levels of the tree, child codes re-pointed at LDS slots (k_trace_top); n_top <= RT_TOP_MAX
   const float4* quads;  // n_nodes x 128 B grandchild records of the interior nodes (NULL when not built), see k_trace_quad
   const float4* tri_p; unsigned n_tris;
   const float* tri_n; const float* tri_uv; const float* tri_s;

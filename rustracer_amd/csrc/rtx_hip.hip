@@ -55,6 +55,8 @@ struct rt_scene {
   int stack_depth = 64;  // entries the to-visit stack needs for this tree (<= 64, rc/bvh/mod.rs:374)
   unsigned n_nodes = 0, n_tris = 0; int n_lights = 0;
   DevBuf pairs, tmin_stack;  // child-pair node records and the HBM half of the traversal stack (k_trace_pair)
+  DevBuf top_pairs, deep_stack; bool use_top = false;  // k_trace_top: LDS-resident top of the tree, HBM spill of stack entries beyond the LDS ones
+  bool top_for_closest = false;  // closest-hit rays through k_trace_top as well (shadow rays always, when no four-wide records exist)
   bool use_pairs = false;
   DevBuf quads; bool use_quads = false; int quad_stack_depth = 0;  // four-wide records of the any-hit kernel (k_trace_quad)
   DevBuf nodes, tri_p, tri_n, tri_uv, tri_s, tri_alpha, spheres, textures, images, materials, lights, texels, dist;
@@ -110,6 +112,7 @@ static void fill_ewa_lut() {
 }
 
 static size_t tmin_stack_bytes(const rt_scene* s);
+static size_t deep_stack_bytes(const rt_scene* s);
 extern "C" int rt_scene_create(const rt_scene_desc* desc, int device, rt_scene** out) {
   if (!desc || !out) return fail(RT_ERR_INVALID, "null argument");
   if (!rt_device_available()) return fail(RT_ERR_NO_DEVICE, "no HIP device visible; this backend has no CPU fallback");
@@ -413,6 +416,34 @@ extern "C" int rt_scene_create(const rt_scene_desc* desc, int device, rt_scene**
       if (rc2 != RT_OK) { delete s; return rc2; }
       d.pairs = s->pairs.as<float4>(); s->use_pairs = true;
     }
+    d.top_pairs = nullptr; d.n_top = 0;
+    if (ok && desc->n_nodes < (1u << 28) && desc->nodes[0].n_prims == 0) {
+      // the first levels of the tree, breadth first, for k_trace_top: up to RT_TOP_MAX interior nodes; a child that is itself one of them is named by its slot
+      std::vector<uint32_t> top; std::vector<int> slot_of(desc->n_nodes, -1);
+      top.push_back(0); slot_of[0] = 0;
+      for (size_t head = 0; head < top.size(); ++head) {
+        const uint32_t P = top[head]; const uint32_t kids[2] = {P + 1, desc->nodes[P].offset};
+        for (uint32_t c : kids)
+          if (desc->nodes[c].n_prims == 0 && top.size() < RT_TOP_MAX) { slot_of[c] = (int)top.size(); top.push_back(c); }
+      }
+      std::vector<float> tp(top.size() * 16);
+      for (size_t k = 0; k < top.size(); ++k) {
+        float* q = tp.data() + 16 * k; memcpy(q, pr.data() + (size_t)top[k] * 16, 64);
+        for (int side = 0; side < 2; ++side) {
+          uint32_t code; memcpy(&code, q + 6 + side, 4);
+          if (!(code & 0x80000000u) && slot_of[code & 0x0fffffffu] >= 0) { code = (code & 0x60000000u) | RT_PAIR_TOP | (uint32_t)slot_of[code & 0x0fffffffu]; memcpy(q + 6 + side, &code, 4); }
+        }
+      }
+      int rc2 = upload(s->top_pairs, tp.data(), tp.size() * 4);
+      if (rc2 != RT_OK) { delete s; return rc2; }
+      d.top_pairs = s->top_pairs.as<float4>(); d.n_top = (unsigned)top.size(); s->use_top = true;
+      // Measured (scripts/ab_bench.sh, one box; k_trace_top vs k_trace_pair): shadow rays -9 % (S2) .. -12 % (S4); closest-hit rays -8 % on S4 (25 MB of
+      // pair records), +2 % on S3 (83 KB: L1-resident either way) and +6 % on S2 (128 MB: a sixth wave per SIMD evicts more of the tree from L2 than
+      // it hides). 64, 128 or 256 LDS-resident nodes measured the same: the top of the tree was already served by the CU's L1 - what the kernel
+      // gains is its sixth wave per SIMD, and that pays where the tree fits the 32 MB of L2 without fitting an L1.
+      const size_t pair_bytes = (size_t)desc->n_nodes * 64;
+      s->top_for_closest = pair_bytes >= ((size_t)1 << 20) && pair_bytes <= ((size_t)64 << 20);
+    }
     // four-wide records for the any-hit kernel (k_trace_quad): an interior node's grandchildren (a leaf child stands for itself), 128 B
     // per node: 24 floats = boxes of slots 0..3 (slots 0,1: first child's part, 2,3: second child's), 4 codes (0xffffffff = empty slot),
     // {axis of the first child | axis of the second child << 2}.
@@ -451,6 +482,9 @@ extern "C" int rt_scene_create(const rt_scene_desc* desc, int device, rt_scene**
   }
   if (const size_t nb = tmin_stack_bytes(s)) {
     if (s->tmin_stack.ensure(nb) != hipSuccess) { delete s; return fail(RT_ERR_OOM, "traversal stack allocation failed"); }
+  }
+  if (const size_t nb = deep_stack_bytes(s)) {
+    if (s->deep_stack.ensure(nb) != hipSuccess) { delete s; return fail(RT_ERR_OOM, "traversal stack allocation failed"); }
   }
   fill_ewa_lut();
   HIP_TRY(hipDeviceSynchronize());
@@ -554,9 +588,17 @@ static unsigned trace_grid(const rt_scene* s) {
 }
 // HBM half of the child-pair / four-wide kernels' traversal stack: [depth][lane of the grid]. Sized once per scene for the largest grid any
 // launch variant uses (rt_scene_create), so that no launch can fail on an allocation and leave stale hit records behind.
+#define RT_TOP_BLOCK 512
+static unsigned top_grid(const rt_scene* s) { return (unsigned)s->n_cu * 3u; }  // 48 KB of LDS per workgroup: three per CU, six waves per SIMD
 static size_t tmin_stack_bytes(const rt_scene* s) {
   if (s->small || !s->use_pairs) return 0;
-  return s->stack_depth <= 32 ? (size_t)trace_grid<false, false, 128, 32>(s) * 128 * 32 * 4 : (size_t)trace_grid<false, false, 128, 64>(s) * 128 * 64 * 4;
+  const size_t a = s->stack_depth <= 32 ? (size_t)trace_grid<false, false, 128, 32>(s) * 128 * 32 * 4 : (size_t)trace_grid<false, false, 128, 64>(s) * 128 * 64 * 4;
+  const size_t b = s->use_top ? (size_t)top_grid(s) * RT_TOP_BLOCK * (size_t)s->stack_depth * 4 : 0;
+  return std::max(a, b);
+}
+static size_t deep_stack_bytes(const rt_scene* s) {
+  if (!s->use_top) return 0;
+  return (size_t)top_grid(s) * RT_TOP_BLOCK * (size_t)std::max(1, s->stack_depth - RT_TOP_LDS_DEPTH) * 4;
 }
 template <bool ANY, bool COUNT, bool SMALL, int BLOCK, int DEPTH>
 static void launch_trace_v(rt_scene* s, const TraceIO& io, const unsigned* queue, const unsigned* count_ptr, unsigned shard_cap, unsigned count_static,
@@ -570,6 +612,12 @@ static void launch_trace_v(rt_scene* s, const TraceIO& io, const unsigned* queue
     static const unsigned refill_min = getenv("RTX_REFILL_MIN") ? (unsigned)std::min(64, std::max(1, atoi(getenv("RTX_REFILL_MIN")))) : (unsigned)RT_REFILL_MIN;
     if (ANY && !COUNT && !plain && !refill_only && !(mode && mode[0] == 'c') && s->use_quads && s->quad_stack_depth <= DEPTH) {  // RTX_TRACE=childpair: two-wide only
       hipLaunchKernelGGL((k_trace_quad<ANY, BLOCK, DEPTH>), dim3(grid), dim3(BLOCK), 0, stream, s->d, io, queue, count_ptr, shard_cap, count_static, stats, st_rays, s->tmin_stack.as<float>(), refill_min);
+      return;
+    }
+    // RTX_TRACE=top0: the child-pair kernel without the LDS-resident top of the tree (measurement knob)
+    if (!COUNT && !plain && !refill_only && s->use_pairs && s->use_top && (ANY || s->top_for_closest) && !(mode && mode[0] == 't')) {
+      hipLaunchKernelGGL((k_trace_top<ANY, RT_TOP_BLOCK>), dim3(top_grid(s)), dim3(RT_TOP_BLOCK), 0, stream, s->d, io, queue, count_ptr, shard_cap, count_static, stats, st_rays,
+                         s->tmin_stack.as<float>(), s->deep_stack.as<unsigned>(), refill_min);
       return;
     }
     if (!COUNT && !plain && !refill_only && s->use_pairs) {

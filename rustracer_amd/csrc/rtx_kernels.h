@@ -864,6 +864,130 @@ __global__ void __launch_bounds__(BLOCK) k_trace_pair(DScene sc, TraceIO io, con
   }
 }
 
+// ---- child-pair traversal with the top of the tree in LDS. k_trace_pair waits on memory two thirds of its wave cycles: every step is a dependent
+// fetch of a 64-byte record from L2 (or beyond), and every ray starts at the root. Here the pair records of the first levels of the tree (up to
+// RT_TOP_MAX interior nodes, breadth first; rt_scene_create) are copied into LDS once per workgroup and the steps that touch them never leave the
+// CU; deeper nodes are fetched as before. To pay for the 16 KB the to-visit stack keeps only its first RT_TOP_LDS_DEPTH entries in LDS and spills
+// deeper ones to an HBM array (rare: the stack is that deep only below the LDS levels of a path that kept its far children), and a workgroup is 512
+// lanes so that three of them (48 KB each) fill a CU at six waves per SIMD. Records, steps and decisions are those of k_trace_pair: same hit records.
+//   interior code with RT_PAIR_TOP set: bits 0-7 = LDS slot of the node's record (bits 29-30 split axis as before)
+#ifndef RT_TOP_MAX
+#define RT_TOP_MAX 256
+#endif
+#ifndef RT_TOP_LDS_DEPTH
+#define RT_TOP_LDS_DEPTH 16
+#endif
+#define RT_PAIR_TOP 0x10000000u
+template <int BLOCK>
+struct SplitStack {  // lds: this lane's column of [RT_TOP_LDS_DEPTH][BLOCK]; hbm: this lane's column of [deeper][grid lanes]
+  unsigned* lds; unsigned* hbm; size_t grid_lanes;
+  RT_DEV void put(int sp, unsigned v) const { if (sp < RT_TOP_LDS_DEPTH) lds[sp * BLOCK] = v; else hbm[(size_t)(sp - RT_TOP_LDS_DEPTH) * grid_lanes] = v; }
+  RT_DEV unsigned get(int sp) const { return sp < RT_TOP_LDS_DEPTH ? lds[sp * BLOCK] : hbm[(size_t)(sp - RT_TOP_LDS_DEPTH) * grid_lanes]; }
+};
+template <bool ANY, int BLOCK>
+RT_DEV void top_pop(PairLane& L, const TraceOut& o, const SplitStack<BLOCK>& stk, const float* tstack, size_t grid_lanes) {
+  for (;;) {
+    if (L.sp == 0) { pair_finish<ANY>(L, o); return; }
+    --L.sp;
+    const unsigned c = stk.get(L.sp);
+    if (ANY) { L.cur = c; return; }
+    if (tstack[(size_t)L.sp * grid_lanes] < L.ray.t_max) { L.cur = c; return; }
+  }
+}
+template <bool ANY, int BLOCK>
+RT_DEV void top_interior_step(PairLane& L, const TraceOut& o, const float4* __restrict__ pairs, const float4* s_top, const SplitStack<BLOCK>& stk, float* tstack, size_t grid_lanes) {
+  const unsigned axis = (L.cur >> 29) & 3u;
+  float4 a0, a1, b0, b1;
+  if (L.cur & RT_PAIR_TOP) { const unsigned k = L.cur & 0xffu; a0 = s_top[4 * k]; a1 = s_top[4 * k + 1]; b0 = s_top[4 * k + 2]; b1 = s_top[4 * k + 3]; }
+  else { const size_t P = L.cur & 0x0fffffffu; a0 = pairs[4 * P]; a1 = pairs[4 * P + 1]; b0 = pairs[4 * P + 2]; b1 = pairs[4 * P + 3]; }
+  const bool neg = (axis == 0u ? L.neg_x() : (axis == 1u ? L.neg_y() : L.neg_z())) != 0;
+  const float4 n0 = neg ? b0 : a0, n1 = neg ? b1 : a1, f0 = neg ? a0 : b0, f1 = neg ? a1 : b1;
+  const unsigned code_a = __float_as_uint(a1.z), code_b = __float_as_uint(a1.w);
+  const unsigned code_n = neg ? code_b : code_a, code_f = neg ? code_a : code_b;
+  float tmin_n = 0.0f, tmin_f = 0.0f;
+  const bool hit_n = slab_geom(n0, n1, L.ray, L.inv_dir, L.neg_x(), L.neg_y(), L.neg_z(), tmin_n) && tmin_n < L.ray.t_max;
+  const bool keep_f = slab_geom(f0, f1, L.ray, L.inv_dir, L.neg_x(), L.neg_y(), L.neg_z(), tmin_f) && tmin_f < L.ray.t_max;
+  if (hit_n) {
+    if (keep_f) { stk.put(L.sp, code_f); if (!ANY) tstack[(size_t)L.sp * grid_lanes] = tmin_f; ++L.sp; }
+    L.cur = code_n;
+  } else if (keep_f) L.cur = code_f;
+  else top_pop<ANY, BLOCK>(L, o, stk, tstack, grid_lanes);
+}
+template <bool ANY, int BLOCK>
+RT_DEV void top_leaf_step(PairLane& L, const TraceOut& o, const float4* __restrict__ tri_p, const SplitStack<BLOCK>& stk, const float* tstack, size_t grid_lanes) {
+  const int off = (int)(L.cur & 0x03ffffffu), n = (int)((L.cur >> 26) & 31u) + 1;
+  for (int i = 0; i < n; ++i) {
+    f3 p0, p1, p2;
+    load_tri(tri_p, off + i, p0, p1, p2);
+    TriHit h;
+    if (tri_test_pre(p0, p1, p2, L.ray, L.rp(), h)) {
+      L.found = true;
+      if (ANY) break;
+      L.ray.t_max = h.t; L.prim = off + i; L.hit = h;
+    }
+  }
+  if (ANY && L.found) pair_finish<ANY>(L, o); else top_pop<ANY, BLOCK>(L, o, stk, tstack, grid_lanes);
+}
+template <bool ANY, int BLOCK>
+__global__ void __launch_bounds__(BLOCK) k_trace_top(DScene sc, TraceIO io, const unsigned* __restrict__ queue, const unsigned* __restrict__ shard_counts, unsigned shard_cap,
+                                                     unsigned count_static, unsigned long long* stats, int st_rays, float* __restrict__ tmin_stack_mem, unsigned* __restrict__ deep_stack_mem,
+                                                     unsigned refill_min) {
+  __shared__ unsigned stack_mem[RT_TOP_LDS_DEPTH * BLOCK];
+  __shared__ float4 s_top[4 * RT_TOP_MAX];
+  const float4* __restrict__ ray_o = io.ray_o; const float4* __restrict__ ray_d = io.ray_d; const size_t rs = io.ray_stride;
+  QView qv; if (queue) qv.init(queue, shard_counts, shard_cap);
+  const unsigned count = queue ? qv.total() : count_static;
+  if ((unsigned long long)blockIdx.x * BLOCK >= count) return;  // (uniform per workgroup: nothing to stage the top of the tree for)
+  for (unsigned i = threadIdx.x; i < 4u * sc.n_top; i += BLOCK) s_top[i] = sc.top_pairs[i];
+  __syncthreads();
+  const size_t grid_lanes = (size_t)gridDim.x * BLOCK;
+  const size_t my_lane = (size_t)blockIdx.x * BLOCK + threadIdx.x;
+  float* const tstack = tmin_stack_mem + my_lane;
+  const SplitStack<BLOCK> stk{stack_mem + threadIdx.x, deep_stack_mem + my_lane, grid_lanes};
+  const unsigned lane = __lane_id();
+  const unsigned n_waves = gridDim.x * (BLOCK / 64), wave = blockIdx.x * (BLOCK / 64) + (threadIdx.x >> 6);
+  const float4* __restrict__ pairs = sc.pairs; const float4* __restrict__ tri_p = sc.tri_p; const float4* __restrict__ nodes = sc.nodes;
+  const TraceOut out = trace_out_of(io);
+  unsigned n_rays = 0, cursor = 0;
+  bool exhausted = (unsigned long long)wave * 64ull >= count;
+  PairLane L;
+  L.active = false; L.found = false; L.pid = 0; L.dw = 0.0f;
+  L.ray.o = L.ray.d = mk3(0, 0, 0); L.ray.t_max = 0.0f; L.inv_dir = mk3(0, 0, 0); L.set_rp(ray_pre(L.ray));
+  L.sp = 0; L.prim = -1; L.cur = 0; L.hit.t = kInf; L.hit.b0 = L.hit.b1 = L.hit.b2 = 0.0f;
+  for (;;) {
+    const unsigned long long idle = __ballot(!L.active);
+    if (!exhausted && (unsigned)__popcll(idle) >= (idle == ~0ull ? 1u : refill_min)) {  // the refill scheme of k_trace_pair
+      const unsigned v = cursor + (unsigned)__popcll(idle & ((1ull << lane) - 1ull));
+      const unsigned long long e = ((unsigned long long)(v >> 6) * n_waves + wave) * 64ull + (v & 63u);
+      if (!L.active && e < count) {
+        L.pid = queue ? qv.get((unsigned)e) : (unsigned)e;
+        const float4 o4 = ray_o[L.pid * rs], d4 = ray_d[L.pid * rs];
+        L.ray.o = mk3(o4.x, o4.y, o4.z); L.ray.d = mk3(d4.x, d4.y, d4.z); L.ray.t_max = o4.w; L.dw = d4.w;
+        L.inv_dir = mk3(1.0f / L.ray.d.x, 1.0f / L.ray.d.y, 1.0f / L.ray.d.z);
+        L.set_rp(ray_pre(L.ray));
+        L.sp = 0; L.prim = -1; L.found = false; L.hit.t = kInf; L.hit.b0 = L.hit.b1 = L.hit.b2 = 0.0f;
+        L.active = true; n_rays += 1;
+        const float4 r0 = nodes[0], r1 = nodes[1];  // the root is the one node tested on its own
+        if (slab_test(r0, r1, L.ray, L.inv_dir, L.neg_x(), L.neg_y(), L.neg_z())) {
+          const unsigned packed = __float_as_uint(r1.w), np = packed & 0xffffu;
+          L.cur = np > 0u ? (RT_PAIR_LEAF | (unsigned)__float_as_int(r1.z) | ((np - 1u) << 26)) : ((((packed >> 16) & 0xffu) << 29) | (sc.n_top ? RT_PAIR_TOP : 0u));  // root = slot 0
+        } else pair_finish<ANY>(L, out);
+      }
+      cursor += (unsigned)__popcll(idle);
+      exhausted = ((unsigned long long)(cursor >> 6) * n_waves + wave) * 64ull + (cursor & 63u) >= count;
+    }
+    if (__ballot(L.active) == 0ull) { if (exhausted) break; else continue; }
+    if (L.active) {
+      if (L.cur & RT_PAIR_LEAF) top_leaf_step<ANY, BLOCK>(L, out, tri_p, stk, tstack, grid_lanes);
+      else top_interior_step<ANY, BLOCK>(L, out, pairs, s_top, stk, tstack, grid_lanes);
+    }
+  }
+  if (stats) {
+    for (int off = 32; off > 0; off >>= 1) n_rays += __shfl_down(n_rays, off);
+    if (lane == 0u && n_rays) atomicAdd(&stats[st_rays], (unsigned long long)n_rays);
+  }
+}
+
 // ---- four-wide any-hit traversal (HBM scenes). The tree is the reference's binary tree; a quad record holds, for an interior node,
 // the boxes of its grandchildren (a child that is a leaf stands for itself), so one 128-byte fetch decides two binary levels and the
 // chain of dependent node fetches per ray halves. Entries are entered in the order the signs of the ray direction along the three
