@@ -192,6 +192,9 @@ typedef struct rt_stats {
   uint64_t vertices_lambert_const, vertices_lambert, vertices_two_lobe, vertices_generic;
   /* ms_shade split (RT_FLAG_TIME_KERNELS): the shade launches of each front-end, the queue binning, the miss bin */
   double ms_shade_lambert_const, ms_shade_lambert, ms_shade_two_lobe, ms_shade_generic, ms_shade_bin, ms_shade_miss;
+  /* measurement builds only (make ABLATE=1; zero otherwise): wave cycles per section of the shade kernel, [front-end 0..3][section 0..7] =
+   * state + interaction, emission + differentials, material, light pick, light-sampling half, BSDF-sampling half, continuation + stores, loop tail */
+  uint64_t shade_section_cycles[32];
 } rt_stats;
 
 #define RT_FLAG_COUNT_TRAVERSAL 1u /* fill nodes_ and tris_ counters (slower)                  */

@@ -72,7 +72,7 @@ struct rt_scene {
   DevBuf ws[32];
   DevBuf film_acc, own_acc, film_out, counters, stats, filter_table;
   DevBuf bin_words, bin_sorted;  // material binning of the shade queue (generic shade path)
-  unsigned n_materials = 0, n_code_classes = 0, n_lambert_classes = 0, n_small_classes = 0;
+  unsigned n_materials = 0, n_code_classes = 0, n_lambert_classes = 0, n_small_classes = 0, n_wide_classes = 0;
   // sampler tables are double-buffered: K0 of batch b+1 runs on aux_stream under the path kernels of batch b
   DevBuf scrambles[2], perms[2];
   hipStream_t aux_stream = nullptr;
@@ -261,12 +261,24 @@ extern "C" int rt_scene_create(const rt_scene_desc* desc, int device, rt_scene**
         if (t.kind == RT_TEX_MIX) tex_sig(t.amount, depth + 1, sig);
       }
     };
+    // an uber material whose opacity, Kr and Kt are constants with 1 - opacity, Kr and Kt black builds Lambert + microfacet reflection only (uber.rs:76-121)
+    auto uber_two_lobes = [&](const rt_material& m) {
+      auto konst = [&](int id) -> const rt_texture* { return id >= 0 && (uint32_t)id < desc->n_textures && desc->textures[id].kind == RT_TEX_CONST ? &desc->textures[id] : nullptr; };
+      const rt_texture *op = konst(m.slot[RT_SLOT_OPACITY]), *kr = konst(m.slot[RT_SLOT_KR]), *kt = konst(m.slot[RT_SLOT_KT]);
+      if (!op || !kr || !kt) return false;
+      for (int c = 0; c < 3; ++c) {
+        const float o = std::max(op->value[c], 0.0f);
+        if (!(std::max(1.0f - o, 0.0f) == 0.0f) || !std::isfinite(o) || !(std::max(kr->value[c], 0.0f) == 0.0f) || !(std::max(kt->value[c], 0.0f) == 0.0f)) return false;
+      }
+      return true;
+    };
     std::function<void(int, int, std::vector<int>&)> mat_sig = [&](int id, int depth, std::vector<int>& sig) {
       const rt_material& m = desc->materials[id];
       sig.push_back(1000 + m.kind); sig.push_back(m.remap_roughness ? 1 : 0);
       for (int k = 0; k < RT_SLOT_M1; ++k) tex_sig(m.slot[k], 0, sig);
       if (m.kind == RT_MAT_MIX) { if (depth < 2) { mat_sig(m.slot[RT_SLOT_M1], depth + 1, sig); mat_sig(m.slot[RT_SLOT_M2], depth + 1, sig); } }
       else { sig.push_back(m.kind == RT_MAT_DISNEY ? m.slot[RT_SLOT_M1] : 0); tex_sig(m.bump, 0, sig); }
+      if (m.kind == RT_MAT_UBER) sig.push_back(uber_two_lobes(m) ? 1 : 0);
     };
     for (uint32_t i = 0; i < desc->n_materials; ++i) {
       std::vector<int> sig; mat_sig((int)i, 0, sig);
@@ -284,18 +296,22 @@ extern "C" int rt_scene_create(const rt_scene_desc* desc, int device, rt_scene**
       lambert[hmat[i].code_class] = m.kind == RT_MAT_MATTE && m.slot[RT_SLOT_KD] >= 0 && is_const(m.slot[RT_SLOT_SIGMA]) && m.bump < 0 &&
                                     desc->textures[m.slot[RT_SLOT_SIGMA]].value[0] <= 0.0f;
     }
-    // then the classes of the two-lobe front-end (SmallBsdf): matte with sigma > 0, plastic, metal, mirror, no bump map
-    std::vector<int> small(classes.size(), 0);
+    // then the classes of the two-lobe front-end (SmallBsdfT<false>): matte with sigma > 0, plastic, metal, mirror; then of its wide form: glass,
+    // substrate, opaque uber; no bump map
+    std::vector<int> small(classes.size(), 0), wide(classes.size(), 0);
     for (uint32_t i = 0; i < desc->n_materials; ++i) {
       const rt_material& m = desc->materials[i];
       small[hmat[i].code_class] = !lambert[hmat[i].code_class] && m.bump < 0 && (m.kind == RT_MAT_MATTE || m.kind == RT_MAT_PLASTIC || m.kind == RT_MAT_METAL || m.kind == RT_MAT_MIRROR);
+      wide[hmat[i].code_class] = m.bump < 0 && (m.kind == RT_MAT_GLASS || m.kind == RT_MAT_SUBSTRATE || (m.kind == RT_MAT_UBER && uber_two_lobes(m)));
     }
     int next = 0;
     for (size_t c = 0; c < classes.size(); ++c) if (lambert[c]) remap[c] = next++;
     s->n_lambert_classes = (unsigned)next;
     for (size_t c = 0; c < classes.size(); ++c) if (small[c]) remap[c] = next++;
     s->n_small_classes = (unsigned)next - s->n_lambert_classes;
-    for (size_t c = 0; c < classes.size(); ++c) if (!lambert[c] && !small[c]) remap[c] = next++;
+    for (size_t c = 0; c < classes.size(); ++c) if (wide[c]) remap[c] = next++;
+    s->n_wide_classes = (unsigned)next - s->n_lambert_classes - s->n_small_classes;
+    for (size_t c = 0; c < classes.size(); ++c) if (!lambert[c] && !small[c] && !wide[c]) remap[c] = next++;
     for (uint32_t i = 0; i < desc->n_materials; ++i) hmat[i].code_class = remap[hmat[i].code_class];
   }
   TRY_RC(upload(s->materials, hmat.data(), hmat.size() * sizeof(DMaterial)));
@@ -914,11 +930,12 @@ extern "C" int rt_render(rt_scene* s, const rt_camera* cam, const rt_film_desc* 
   static const bool bin_off = getenv("RTX_SHADE_BINS") && getenv("RTX_SHADE_BINS")[0] == '0';  // measurement knob
   const bool use_bins = !s->lambert_materials && s->n_code_classes > 1 && !bin_off && !s->masked_emitters;  // one class: every vertex runs the same code, the queue order is kept
   const unsigned n_bins = std::min<unsigned>(s->n_code_classes, RT_BIN_MAX) + 1u;
-  const size_t bin_stride = 2 * (RT_BIN_MAX + 1) + RT_QSHARDS + 8;  // + {begin, end} of the three class ranges and of the miss bin
+  const size_t bin_stride = 2 * (RT_BIN_MAX + 1) + RT_QSHARDS + 10;  // + {begin, end} of the four class ranges and of the miss bin
   // RTX_SHADE_SPLIT (measurement knob): 0 = every class through the generic front-end, 1 = Lambert classes apart, default = Lambert and two-lobe classes apart
   const int split_mode = getenv("RTX_SHADE_SPLIT") ? atoi(getenv("RTX_SHADE_SPLIT")) : 2;
   const unsigned n_first = split_mode >= 1 ? s->n_lambert_classes : 0u, n_second = split_mode >= 2 ? s->n_small_classes : 0u;
-  const bool split_classes = use_bins && (n_first + n_second) > 0 && n_first + n_second < RT_BIN_MAX;
+  const unsigned n_third = split_mode >= 2 ? s->n_wide_classes : 0u;
+  const bool split_classes = use_bins && (n_first + n_second + n_third) > 0 && n_first + n_second + n_third < RT_BIN_MAX;
   const unsigned pgrid_q = (unsigned)s->n_cu * 8u;
   const unsigned long long table_bytes_per_pixel = 2ull * dims * spp * 2ull;
 
@@ -1064,12 +1081,13 @@ extern "C" int rt_render(rt_scene* s, const rt_camera* cam, const rt_film_desc* 
           hipLaunchKernelGGL(k_bin_count, dim3(pgrid), dim3(256), 0, stream, s->d, ps, n_bins, hist);
           unsigned* ranges = sorted_cnt + RT_QSHARDS;
           hipLaunchKernelGGL(k_bin_scatter, dim3(pgrid), dim3(256), 0, stream, s->d, ps, n_bins, hist, cursor, s->bin_sorted.as<unsigned>(), sorted_cnt,
-                             split_classes ? n_first : 0u, split_classes ? n_first + n_second : 0u, ranges);
+                             split_classes ? n_first : 0u, split_classes ? n_first + n_second : 0u, split_classes ? n_first + n_second + n_third : 0u, ranges);
           tm.end();
           PassState pb = ps; pb.q_in = s->bin_sorted.as<unsigned>(); pb.cnt_in = sorted_cnt;  // all entries in shard 0: QView::get(i) = ids[i]
           // classes of the register-resident front-ends, then the generic one, then the rays that left the scene
           if (split_classes && n_first) { pb.range = ranges; tm.begin(&stats.ms_shade_lambert); hipLaunchKernelGGL(k_shade<3>, dim3(pgrid), dim3(256), 0, stream, s->d, fp, pb); tm.end(); }
           if (split_classes && n_second) { pb.range = ranges + 2; tm.begin(&stats.ms_shade_two_lobe); hipLaunchKernelGGL(k_shade<5>, dim3(pgrid), dim3(256), 0, stream, s->d, fp, pb); tm.end(); }
+          if (split_classes && n_third) { pb.range = ranges + 8; tm.begin(&stats.ms_shade_two_lobe); hipLaunchKernelGGL(k_shade<6>, dim3(pgrid), dim3(256), 0, stream, s->d, fp, pb); tm.end(); }
           pb.range = ranges + 4; tm.begin(&stats.ms_shade_generic); hipLaunchKernelGGL(k_shade<0>, dim3(pgrid), dim3(256), 0, stream, s->d, fp, pb); tm.end();
           pb.range = ranges + 6; tm.begin(&stats.ms_shade_miss); hipLaunchKernelGGL(k_shade_miss, dim3(pgrid), dim3(256), 0, stream, s->d, pb); tm.end();
         }
@@ -1116,6 +1134,7 @@ extern "C" int rt_render(rt_scene* s, const rt_camera* cam, const rt_film_desc* 
   stats.nodes_closest = h[ST_NODES_CLOSEST]; stats.nodes_shadow = h[ST_NODES_SHADOW]; stats.nodes_mis = h[ST_NODES_MIS];
   stats.tris_closest = h[ST_TRIS_CLOSEST]; stats.tris_shadow = h[ST_TRIS_SHADOW]; stats.tris_mis = h[ST_TRIS_MIS];
   stats.paths_scrubbed = h[ST_SCRUBBED];
+  for (int k = 0; k < 32; ++k) stats.shade_section_cycles[k] = h[ST_STAMP + k];
   stats.vertices_lambert_const = h[ST_SHADED]; stats.vertices_lambert = h[ST_SHADED + 1]; stats.vertices_two_lobe = h[ST_SHADED + 2]; stats.vertices_generic = h[ST_SHADED + 3];
   if (h[ST_UNBUILT_VOXEL]) return fail(RT_ERR_INVALID, "a path looked up a light-distribution voxel that holds no surface (voxel marking bug)");
   stats.ms_total = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_begin).count();

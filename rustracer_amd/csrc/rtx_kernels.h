@@ -71,7 +71,13 @@ struct PassState {
 enum { ST_CAMERA = 0, ST_RAYS_CLOSEST, ST_RAYS_SHADOW, ST_RAYS_MIS, ST_NODES_CLOSEST, ST_NODES_SHADOW, ST_NODES_MIS,
        ST_TRIS_CLOSEST, ST_TRIS_SHADOW, ST_TRIS_MIS, ST_SCRUBBED, ST_UNBUILT_VOXEL,
        ST_SHADED,  // + {0: k_shade<1>, 1: k_shade<3>, 2: k_shade<5>, 3: k_shade<0>}: path vertices shaded by each front-end (misses included)
-       ST_COUNT = ST_SHADED + 4 };
+       ST_STAMP = ST_SHADED + 4,  // + 8 * front-end + section: wave cycles of the sections of k_shade (measurement builds only, make ABLATE=1)
+       ST_COUNT = ST_STAMP + 32 };
+#ifdef RT_ABLATE
+#define RT_STAMP(k) do { const unsigned long long t_ = clock64(); stamp_acc[k] += t_ - stamp_last; stamp_last = t_; } while (0)
+#else
+#define RT_STAMP(k) do { } while (0)
+#endif
 
 struct FrameParams {
   // camera (rc/camera.rs)
@@ -1148,17 +1154,20 @@ __global__ void __launch_bounds__(256) k_bin_count(DScene sc, PassState ps, unsi
 // sorted: path ids grouped by bin; sorted_cnt[RT_QSHARDS]: {total, 0, ...} so that the result reads as a one-shard queue
 __global__ void __launch_bounds__(256) k_bin_scatter(DScene sc, PassState ps, unsigned n_bins, const unsigned* __restrict__ hist, unsigned* __restrict__ cursor,
                                                      unsigned* __restrict__ sorted, unsigned* __restrict__ sorted_cnt, unsigned split_bin, unsigned split_bin2,
-                                                     unsigned* __restrict__ ranges) {
+                                                     unsigned split_bin3, unsigned* __restrict__ ranges) {
   __shared__ unsigned base[RT_BIN_MAX + 1], lcount[RT_BIN_MAX + 1], lbase[RT_BIN_MAX + 1];
   if (threadIdx.x == 0) {  // exclusive prefix of the histogram (<= 257 entries)
     unsigned run = 0;
     for (unsigned b = 0; b < n_bins; ++b) { base[b] = run; run += hist[b]; }
     if (blockIdx.x == 0) {
       sorted_cnt[0] = run; for (int k = 1; k < RT_QSHARDS; ++k) sorted_cnt[k] = 0u;
-      // bins [0, split_bin): classes of the Lambert front-end; [split_bin, split_bin2): of the two-lobe front-end; the rest: generic
+      // bins [0, split_bin): classes of the Lambert front-end; [split_bin, split_bin2): of the two-lobe front-end; [split_bin2, split_bin3): of its wide form;
+      // the rest: generic
       const unsigned split = split_bin < n_bins ? base[split_bin] : run, split2 = split_bin2 < n_bins ? base[split_bin2] : run;
+      const unsigned split3 = split_bin3 < n_bins ? base[split_bin3] : run;
       const unsigned miss = base[n_bins - 1u];  // the last bin: rays that left the scene
-      ranges[0] = 0u; ranges[1] = split; ranges[2] = split; ranges[3] = split2; ranges[4] = split2; ranges[5] = miss; ranges[6] = miss; ranges[7] = run;
+      ranges[0] = 0u; ranges[1] = split; ranges[2] = split; ranges[3] = split2; ranges[4] = split3; ranges[5] = miss; ranges[6] = miss; ranges[7] = run;
+      ranges[8] = split2; ranges[9] = split3;
     }
   }
   for (unsigned i = threadIdx.x; i <= RT_BIN_MAX; i += 256u) lcount[i] = 0u;
@@ -1265,13 +1274,46 @@ typedef SingleLambertT<false> SingleLambert;
 // (bsdf/mod.rs:94-251) restated over two named lobes; every lobe function is entered with its kind as a constant, so only that
 // kind's code is instantiated. Same operations in the same order as GenericBsdf (sums start from the same zero, the same component
 // choice and u remap), hence the same values.
-struct SmallBsdf {
-  f3 ns, ng, ss, ts; int n; Lobe l0, l1;
+template <bool WIDE>  // WIDE: + glass, substrate and the opaque uber form (FresnelSpecular, FresnelBlend, microfacet transmission; a Bsdf eta)
+struct SmallBsdfT {
+  f3 ns, ng, ss, ts; int n; Lobe l0, l1; float eta_;
   RT_DEV void add(const Lobe& l) { if (n == 0) l0 = l; else l1 = l; ++n; }
   RT_DEV void build(const DScene& sc, int mat, SurfaceInteraction& si) {
     const DMaterial& m = sc.materials[mat]; const int* s = m.slot;
-    n = 0; l0 = lobe_zero(LB_LAMBERT_R); l1 = l0;
-    if (m.kind == 0) {  // matte.rs:37-62
+    n = 0; l0 = lobe_zero(LB_LAMBERT_R); l1 = l0; eta_ = 1.0f;
+    if (WIDE && m.kind == 4) {  // glass.rs:53-106, allow_multiple_lobes = true (path.rs:145): one FresnelSpecular lobe, or microfacet reflection + transmission
+      eta_ = tex_eval_cf(sc, s[8], si);
+      float ur = tex_eval_cf(sc, s[6], si), vr = tex_eval_cf(sc, s[7], si);
+      rgb3 r = tex_eval_c(sc, s[2], si), t = tex_eval_c(sc, s[3], si);
+      if (!is_black(r) || !is_black(t)) {
+        if (ur == 0.0f && vr == 0.0f) {
+          Lobe l = lobe_zero(LB_FRESNEL_SPEC); l.r = r; l.t = t; l.eta_a = 1.0f; l.eta_b = eta_; add(l);
+        } else {
+          if (m.remap) { ur = tr_roughness_to_alpha(ur); vr = tr_roughness_to_alpha(vr); }
+          if (!is_black(r)) add(mk_micro_r(r, ur, vr, FR_DIELECTRIC, 1.0f, eta_));
+          if (!is_black(t)) add(mk_micro_t(r, ur, vr, 1.0f, eta_));  // passes `r` (glass.rs:97)
+        }
+      }
+    } else if (WIDE && m.kind == 5) {  // uber.rs:63-126 where the host found opacity, Kr and Kt constant with 1 - opacity, Kr and Kt black: no specular lobe
+      float e = tex_eval_cf(sc, s[8], si);
+      rgb3 op = clamp_pos(tex_eval_c(sc, s[10], si));
+      eta_ = e;
+      rgb3 kd = op * clamp_pos(tex_eval_c(sc, s[0], si));
+      if (!is_black(kd)) add(mk_lambert(LB_LAMBERT_R, kd));
+      rgb3 ks = op * clamp_pos(tex_eval_c(sc, s[1], si));
+      if (!is_black(ks)) {
+        float ru = tex_eval_cf(sc, s[6] >= 0 ? s[6] : s[5], si), rv = tex_eval_cf(sc, s[7] >= 0 ? s[7] : s[5], si);
+        if (m.remap) { ru = tr_roughness_to_alpha(ru); rv = tr_roughness_to_alpha(rv); }
+        add(mk_micro_r(ks, ru, rv, FR_DIELECTRIC, 1.0f, e));
+      }
+    } else if (WIDE && m.kind == 6) {  // substrate.rs:43-71
+      rgb3 d = clamp_pos(tex_eval_c(sc, s[0], si)), sp = clamp_pos(tex_eval_c(sc, s[1], si));
+      float ru = tex_eval_cf(sc, s[6], si), rv = tex_eval_cf(sc, s[7], si);
+      if (!is_black(d) || !is_black(sp)) {
+        if (m.remap) { ru = tr_roughness_to_alpha(ru); rv = tr_roughness_to_alpha(rv); }
+        Lobe l = lobe_zero(LB_FRESNEL_BLEND); l.r = d; l.t = sp; l.ax = ru; l.ay = rv; add(l);
+      }
+    } else if (m.kind == 0) {  // matte.rs:37-62
       rgb3 r = clamp_pos(tex_eval_c(sc, s[0], si));
       float sigma = clampf(tex_eval_cf(sc, s[4], si), 0.0f, 1.0f);
       if (!is_black(r)) {
@@ -1313,8 +1355,12 @@ struct SmallBsdf {
       case LB_OREN_NAYAR: c.kind = LB_OREN_NAYAR; return fn(c);
       case LB_MICRO_R: c.kind = LB_MICRO_R; return fn(c);
       case LB_SPEC_R: c.kind = LB_SPEC_R; return fn(c);
-      default: c.kind = LB_LAMBERT_R; return fn(c);
+      case LB_FRESNEL_SPEC: if (WIDE) { c.kind = LB_FRESNEL_SPEC; return fn(c); } break;
+      case LB_FRESNEL_BLEND: if (WIDE) { c.kind = LB_FRESNEL_BLEND; return fn(c); } break;
+      case LB_MICRO_T: if (WIDE) { c.kind = LB_MICRO_T; return fn(c); } break;
+      default: break;
     }
+    c.kind = LB_LAMBERT_R; return fn(c);
   }
   RT_DEV static rgb3 lf(const Lobe& l, f3 wo, f3 wi) { return with_kind(l, [&](const Lobe& c) { return lobe_f_inner(c, wo, wi); }); }
   RT_DEV static float lp(const Lobe& l, f3 wo, f3 wi) { return with_kind(l, [&](const Lobe& c) { return lobe_pdf_inner(c, wo, wi); }); }
@@ -1372,7 +1418,7 @@ struct SmallBsdf {
     }
     return mk_ls(fv, wi_w, pdf, s.type);
   }
-  RT_DEV float eta() const { return 1.0f; }
+  RT_DEV float eta() const { return WIDE ? eta_ : 1.0f; }
 };
 
 // MODE 0: any material / texture / light. MODE 1: every material is matte with constant Kd and
@@ -1380,7 +1426,7 @@ struct SmallBsdf {
 // tables); no texture then reads the camera-ray differentials and the kernel makes no out-of-line call.
 // MODE 3: matte materials with sigma == 0 and no bump map - Kd any texture - under any kind of light: the register-resident
 // front-end with the generic light and texture functions. MODE 5: matte (any sigma), plastic, metal and mirror without bump map
-// through SmallBsdf.
+// through SmallBsdfT<false>; MODE 6: glass, substrate and opaque uber as well, through SmallBsdfT<true> (the narrow kernel is 5 % faster on its classes).
 #ifndef RT_SHADE_MIN_WAVES
 #define RT_SHADE_MIN_WAVES 2
 #endif
@@ -1396,10 +1442,14 @@ __global__ void __launch_bounds__(256, MODE == 1 ? RT_SHADE_MIN_WAVES : RT_SHADE
   if (MODE != 1 && ps.range) { first = ps.range[0]; count = ps.range[1]; }
   const unsigned stride = gridDim.x * blockDim.x;
   unsigned n_shaded = 0;
+#ifdef RT_ABLATE
+  unsigned long long stamp_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, stamp_last = clock64();
+#endif
   for (unsigned base = first + blockIdx.x * blockDim.x; base < count; base += stride) {
     const unsigned i = base + threadIdx.x;
     const bool lane_live = i < count;
     n_shaded += lane_live ? 1u : 0u;
+    RT_STAMP(7);  // loop overhead / previous iteration's tail
     bool cont = false, want_shadow = false, want_mis = false, mis_occlusion_only = false;
     unsigned pid = 0;
     if (lane_live) {
@@ -1429,6 +1479,7 @@ __global__ void __launch_bounds__(256, MODE == 1 ? RT_SHADE_MIN_WAVES : RT_SHADE
         else if (MODE & 1) tri_fill_interaction_inl(sc, prim, ray_d, th, si);
         else tri_fill_interaction(sc, prim, ray_d, th, si);
       }
+      RT_STAMP(0);  // path state loads + SurfaceInteraction
       // path.rs:127-136 emitted light at the vertex / from the environment
       if (bounces == 0 || specular_bounce) {
         if (found) {
@@ -1446,8 +1497,10 @@ __global__ void __launch_bounds__(256, MODE == 1 ? RT_SHADE_MIN_WAVES : RT_SHADE
           compute_differential(si, cr.rx_o, cr.ry_o, cr.rx_d, cr.ry_d);
         }
         typename std::conditional<MODE == 1, SingleLambert, typename std::conditional<MODE == 3, SingleLambertT<true>,
-                                  typename std::conditional<MODE == 5, SmallBsdf, GenericBsdf>::type>::type>::type bsdf;
+                                  typename std::conditional<MODE == 5, SmallBsdfT<false>, typename std::conditional<MODE == 6, SmallBsdfT<true>, GenericBsdf>::type>::type>::type>::type bsdf;
+        RT_STAMP(1);  // emission + differentials
         bsdf.build(sc, tri_material(sc.tri_p, prim), si);
+        RT_STAMP(2);  // material: textures + lobes
         // light_distribution.lookup(p) (path.rs:154-158)
         const float* ld_func; const float* ld_cdf; float ld_int;
         if (sc.ld_uniform) { ld_func = sc.ld_func; ld_cdf = sc.ld_cdf; ld_int = sc.ld_int[0]; }
@@ -1465,6 +1518,7 @@ __global__ void __launch_bounds__(256, MODE == 1 ? RT_SHADE_MIN_WAVES : RT_SHADE
           float su = smp.get_1d();
           int light_num; float light_pdf;
           d1_sample_discrete(ld_func, ld_cdf, ld_int, sc.n_lights, su, light_num, light_pdf);
+          RT_STAMP(3);  // light pick: voxel row + discrete search
           if (light_pdf != 0.0f) {
             f2 u_light = smp.get_2d();
             f2 u_scattering = smp.get_2d();
@@ -1484,6 +1538,7 @@ __global__ void __launch_bounds__(256, MODE == 1 ? RT_SHADE_MIN_WAVES : RT_SHADE
                 else ld1 = f * ls.li * power_heuristic1(ls.pdf, scattering_pdf) / ls.pdf;
               }
             }
+            RT_STAMP(4);  // light-sampling half: sample_li, f, pdf, shadow ray
             // ---- BSDF-sampling half
             rgb3 f2v = mkc(0, 0, 0); float w2 = 0.0f, spdf2 = 1.0f;
             if (!light_is_delta(light) && !RT_DBG(sc, 8)) {
@@ -1520,6 +1575,7 @@ __global__ void __launch_bounds__(256, MODE == 1 ? RT_SHADE_MIN_WAVES : RT_SHADE
             if (want_shadow) ps.sh[pid].d = make_float4(sh_dir.x, sh_dir.y, sh_dir.z, want_mis ? 0.0f : 1.0f);
           }
         }
+        RT_STAMP(5);  // BSDF-sampling half + records
         // ---- sample the BSDF for the next direction (path.rs:172-196)
         f3 wo = -ray_d;  // not normalised (reference quirk)
         LobeSample bs = bsdf.sample_f(wo, smp.get_2d(), BSDF_ALL);
@@ -1549,6 +1605,7 @@ __global__ void __launch_bounds__(256, MODE == 1 ? RT_SHADE_MIN_WAVES : RT_SHADE
       pacc->lacc = make_float4(L.r, L.g, L.b, __uint_as_float(pack_state(bounces, specular_bounce, smp.c1, smp.c2)));
       pacc->rng = smp.rng.state;
     }
+    RT_STAMP(6);  // continuation sample, spawn, state stores
     constexpr int NQ = MODE == 1 ? 3 : 4;  // area lights only: every MIS ray needs its closest hit
     const int ci[4] = {0, 1, 2, 3}; const bool pr[4] = {cont, want_shadow, want_mis && !mis_occlusion_only, want_mis && mis_occlusion_only}; unsigned slot[4];
     block_push<NQ>(ps.cnt_out, ps.shard_cap, ci, pr, slot);
@@ -1558,7 +1615,10 @@ __global__ void __launch_bounds__(256, MODE == 1 ? RT_SHADE_MIN_WAVES : RT_SHADE
     if (NQ == 4 && pr[3]) ps.q_misany[slot[3]] = pid;
   }
   for (int off = 32; off > 0; off >>= 1) n_shaded += __shfl_down(n_shaded, off);
-  if ((threadIdx.x & 63u) == 0u && n_shaded) atomicAdd(&ps.stats[ST_SHADED + (MODE == 1 ? 0 : (MODE == 3 ? 1 : (MODE == 5 ? 2 : 3)))], (unsigned long long)n_shaded);
+  if ((threadIdx.x & 63u) == 0u && n_shaded) atomicAdd(&ps.stats[ST_SHADED + (MODE == 1 ? 0 : (MODE == 3 ? 1 : (MODE == 5 || MODE == 6 ? 2 : 3)))], (unsigned long long)n_shaded);
+#ifdef RT_ABLATE
+  if ((threadIdx.x & 63u) == 0u) for (int k = 0; k < 8; ++k) atomicAdd(&ps.stats[ST_STAMP + 8 * (MODE == 1 ? 0 : (MODE == 3 ? 1 : (MODE == 5 || MODE == 6 ? 2 : 3))) + k], stamp_acc[k]);
+#endif
 }
 
 // The miss bin of a binned queue: a path whose ray left the scene. PathIntegrator::li adds the environment's radiance only for camera rays

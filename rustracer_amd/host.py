@@ -61,10 +61,11 @@ class Stats(C.Structure):
         [(n, C.c_double) for n in ("ms_total", "ms_sampler", "ms_raygen", "ms_trace_closest", "ms_trace_any", "ms_trace_mis",
                                    "ms_shade", "ms_resolve", "ms_film", "ms_lightdist")] +
         [(n, C.c_uint64) for n in ("launches_trace_closest", "n_passes", "vertices_lambert_const", "vertices_lambert", "vertices_two_lobe", "vertices_generic")] +
-        [(n, C.c_double) for n in ("ms_shade_lambert_const", "ms_shade_lambert", "ms_shade_two_lobe", "ms_shade_generic", "ms_shade_bin", "ms_shade_miss")])
+        [(n, C.c_double) for n in ("ms_shade_lambert_const", "ms_shade_lambert", "ms_shade_two_lobe", "ms_shade_generic", "ms_shade_bin", "ms_shade_miss")] +
+        [("shade_section_cycles", C.c_uint64 * 32)])
 
     def as_dict(self):
-        return {n: getattr(self, n) for n, _ in self._fields_}
+        return {n: (list(getattr(self, n)) if n == "shade_section_cycles" else getattr(self, n)) for n, _ in self._fields_}
 
 
 _lib = None

@@ -10,6 +10,13 @@ if len(sys.argv) > 3 and sys.argv[3] == "child":
     h = host.HostScene(d); h.upload(); h.render(time_kernels=True)
     _, st = h.render(time_kernels=True)
     v = [st[k] for k in ("vertices_lambert_const", "vertices_lambert", "vertices_two_lobe", "vertices_generic")]
+    sec = st["shade_section_cycles"]
+    if any(sec):
+        names = ["state+si", "emit+diff", "material", "lightpick", "light half", "bsdf half", "cont+store", "tail"]
+        for fe, fname in enumerate(("lambert_const", "lambert", "two_lobe", "generic")):
+            row = sec[8 * fe:8 * fe + 8]
+            if sum(row):
+                print(f"   {fname:14s} " + "  ".join(f"{n} {100.0 * c / sum(row):4.1f}%" for n, c in zip(names, row)), flush=True)
     print(f"dbg={os.environ.get('RTX_DBG', '0'):>3s} total {st['ms_total']:8.1f} shade {st['ms_shade']:8.1f} (L {st['ms_shade_lambert']:.0f} 2 {st['ms_shade_two_lobe']:.0f} G {st['ms_shade_generic']:.0f} bin {st['ms_shade_bin']:.0f} miss {st['ms_shade_miss']:.0f}) closest {st['ms_trace_closest']:7.1f} any {st['ms_trace_any']:6.1f} "
           f"mis {st['ms_trace_mis']:6.1f} resolve {st['ms_resolve']:6.1f} | vertices {v} rays c/s/m {st['rays_closest']} {st['rays_shadow']} {st['rays_mis']}", flush=True)
 else:

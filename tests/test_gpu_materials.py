@@ -56,6 +56,7 @@ def _zoo(material: str, light: str = "area", res=(40, 32), spp=8, max_depth=5):
         "glass": lambda: s.glass(index=1.5),
         "glass_rough": lambda: s.glass(kr=0.9, kt=0.8, index=1.33, urough=0.1, vrough=0.2),
         "uber": lambda: s.uber(kd=(0.3, 0.4, 0.2), ks=(0.3, 0.3, 0.3), kr=(0.1, 0.1, 0.1), kt=(0.2, 0.2, 0.2), roughness=0.1, opacity=(0.8, 0.7, 0.9)),
+        "uber_opaque": lambda: s.uber(kd=t_img, ks=(0.25, 0.25, 0.25), roughness=0.2),  # opacity 1, Kr = Kt = 0: Lambert + microfacet reflection only
         "substrate": lambda: s.substrate(kd=(0.5, 0.2, 0.2), ks=(0.3, 0.3, 0.3), urough=0.05, vrough=0.2),
         "translucent": lambda: s.translucent(kd=(0.4, 0.4, 0.3), ks=(0.2, 0.2, 0.2), reflect=0.4, transmit=0.6, roughness=0.2),
         "mix": lambda: s.mix(s.plastic((0.1, 0.3, 0.1), (0.4, 0.4, 0.4), 0.1), s.metal(roughness=0.1), 0.35),
@@ -106,7 +107,7 @@ def _check(gpu_host, orc, d):
 MATERIALS = ["matte", "oren_nayar", "matte_image_ewa", "matte_image_trilinear_clamp", "matte_image_black_wrap", "matte_image_npot", "matte_checker_closedform", "matte_checker_none_nested", "matte_uv", "matte_fbm",
              "plastic_fbm_checker_roughness", "matte_bump_fbm", "plastic_bump_image", "mirror_bump_checker", "mix_bump_both", "disney_default", "disney_metal_aniso_clearcoat", "disney_sheen_textured", "disney_spectrans",
              "disney_thin", "disney_scatterdistance", "mix_disney_bump", "matte_scale_mix_tex", "plastic",
-             "plastic_noremap", "metal", "metal_aniso", "mirror", "glass", "glass_rough", "uber", "substrate", "translucent", "mix", "mix_nested"]
+             "plastic_noremap", "metal", "metal_aniso", "mirror", "glass", "glass_rough", "uber", "uber_opaque", "substrate", "translucent", "mix", "mix_nested"]
 
 
 @pytest.mark.parametrize("material", MATERIALS)
@@ -143,9 +144,9 @@ def test_constant_matte_scene_under_other_light_kinds(gpu_host, orc, lights):
     _check(gpu_host, orc, d)
 
 
-@pytest.mark.parametrize("material", ["matte", "oren_nayar", "matte_image_ewa", "plastic", "plastic_noremap", "metal", "metal_aniso", "mirror", "glass", "glass_rough", "substrate", "matte_bump_fbm", "plastic_bump_image", "mirror_bump_checker", "mix", "uber"])
+@pytest.mark.parametrize("material", ["matte", "oren_nayar", "matte_image_ewa", "plastic", "plastic_noremap", "metal", "metal_aniso", "mirror", "glass", "glass_rough", "substrate", "matte_bump_fbm", "plastic_bump_image", "mirror_bump_checker", "mix", "uber", "uber_opaque"])
 def test_register_resident_front_ends_equal_the_generic_one(gpu_host, material, monkeypatch):
-    """Class-wise dispatch (k_shade<3> / k_shade<5> / k_shade<0>) against every class through the generic lobe array."""
+    """Class-wise dispatch (k_shade<3> / k_shade<5> / k_shade<6> / k_shade<0>) against every class through the generic lobe array."""
     d = _zoo(material, "infinite")
     h = gpu_host.HostScene(d)
     monkeypatch.setenv("RTX_SHADE_SPLIT", "0")

@@ -246,6 +246,7 @@ def test_kernel_register_and_scratch_budgets(host):
         "rtx::k_shade<1, false>": (168, 0),        # 3 waves per SIMD, no scratch, no out-of-line call
         "rtx::k_shade<3, false>": (200, 640),      # 2 waves
         "rtx::k_shade<5, false>": (224, 640),
+        "rtx::k_shade<6, false>": (224, 640),
         "rtx::k_shade<0, false>": (256, 2048),
         "rtx::k_trace<false, false, true, 256, 16>": (72, 64),   # the LDS-resident closest-hit kernel of the headline: 7 waves
         "rtx::k_trace<true, false, true, 256, 16>": (64, 64),    # ... and its shadow-ray twin: 8 waves
