@@ -41,6 +41,10 @@ struct DScene {
   // tables of the BUILT voxels only (those that can hold a surface point): [slot][n_lights], [slot][n_lights+1], [slot]; ld_slot[voxel] = slot or -1.
   // Memory is O(built voxels x lights) - a dense 64^3 table of 10^5 emitters would not fit any GPU
   const float* ld_func; const float* ld_cdf; const float* ld_int; const int* ld_slot;
+  // This record in device memory. A kernel takes its DScene by value (fields in SGPRs); an out-of-line device function that wants the scene is handed
+  // `*sc.self` instead of `sc`: a reference to the kernel argument would force a 300-byte private copy of it into every lane's scratch, read back
+  // lane by lane at each use (k_shade<3> on S4 moved 4 KB per vertex between L2 and memory, most of it scratch).
+  const DScene* self;
 #ifdef RT_ABLATE
   int dbg;  // measurement builds only (make ABLATE=1): bits switch parts of the shade kernel off to see what they cost; images are wrong
 #endif
@@ -151,6 +155,7 @@ RT_DEV unsigned prim_sphere_index(const float4* tri_p, int prim) { return __floa
 
 // ---------------------------------------------------------------- interactions (rc/interaction.rs)
 struct Interaction { f3 p, p_error, wo, n; };
+struct LightPoint { f3 p, p_error, n; };  // the Interaction a light sample returns, without the fields nothing reads (wo, time): LiSample stays within the 16 registers a call returns
 struct SurfaceInteraction {
   Interaction hit;
   f2 uv;
@@ -163,7 +168,8 @@ struct SurfaceInteraction {
 RT_DEV Ray spawn_ray(const Interaction& it, f3 dir) {  // :56-60
   Ray r; r.o = offset_ray_origin(it.p, it.p_error, it.n, dir); r.d = dir; r.t_max = kInf; return r;
 }
-RT_DEV Ray spawn_ray_to_interaction(const Interaction& a, const Interaction& b) {  // :69-74
+template <class Target>
+RT_DEV Ray spawn_ray_to_interaction(const Interaction& a, const Target& b) {  // :69-74
   Ray r;
   f3 origin = offset_ray_origin(a.p, a.p_error, a.n, b.p - a.p);
   f3 target = offset_ray_origin(b.p, b.p_error, b.n, origin - b.p);
@@ -240,8 +246,8 @@ RT_DEV void tri_hit_point_normal_inl(const DScene& sc, int prim, const TriHit& h
 
 RT_DEVN void tri_hit_point_normal(const DScene& sc, int prim, const TriHit& h, f3& p, f3& n) { tri_hit_point_normal_inl(sc, prim, h, p, n); }
 
-// compute_differential (interaction.rs:245-314) for a ray that carries differentials
-RT_DEVN void compute_differential(SurfaceInteraction& si, f3 rx_o, f3 ry_o, f3 rx_d, f3 ry_d) {
+// compute_differential (interaction.rs:245-314) for a ray that carries differentials. Inline: called out of line, `si` would have to live in scratch.
+RT_DEV void compute_differential(SurfaceInteraction& si, f3 rx_o, f3 ry_o, f3 rx_d, f3 ry_d) {
   const f3 n = si.hit.n, p = si.hit.p;
   float d = dot(n, mk3(p.x, p.y, p.z));
   float tx = -(dot(n, rx_o) - d) / dot(n, rx_d);

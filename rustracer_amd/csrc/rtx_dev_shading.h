@@ -149,19 +149,25 @@ RT_DEV float noise_fbm(f3 p, f3 dpdx, f3 dpdy, float omega, unsigned max_octaves
   return sum;
 }
 
+// What a texture reads of the SurfaceInteraction (texture/mod.rs:52-60 UVMapping2D, noise.rs): 15 dwords, handed to the out-of-line evaluator by value in
+// registers - a reference would pin the caller's whole SurfaceInteraction in scratch.
+struct TexIn { f2 uv; float dudx, dvdx, dudy, dvdy; f3 p, dpdx, dpdy; };
+RT_DEV TexIn tex_in(const SurfaceInteraction& si) {
+  TexIn q; q.uv = si.uv; q.dudx = si.dudx; q.dvdx = si.dvdx; q.dudy = si.dudy; q.dvdy = si.dvdy; q.p = si.hit.p; q.dpdx = si.dpdx; q.dpdy = si.dpdy; return q;
+}
 // Leaves: constant, imagemap, uv, fbm. Combinators (operands = other textures): scale, mix, checkerboard.
 RT_DEV bool tex_is_leaf(int kind) { return kind == 0 || kind == 3 || kind == 5 || kind == 6; }
-RT_DEV rgb3 tex_leaf(const DScene& sc, const DTexture& t, const SurfaceInteraction& si) {
+RT_DEV rgb3 tex_leaf(const DImage* images, const DTexture& t, const TexIn& si) {
   if (t.kind == 0) return mkc(t.v[0], t.v[1], t.v[2]);  // constant.rs:35-38
-  if (t.kind == 6) { float f = noise_fbm(si.hit.p, si.dpdx, si.dpdy, t.v[0], (unsigned)(t.amount < 0 ? 0 : t.amount)); return mkc(f, f, f); }  // fbm.rs:18-21
+  if (t.kind == 6) { float f = noise_fbm(si.p, si.dpdx, si.dpdy, t.v[0], (unsigned)(t.amount < 0 ? 0 : t.amount)); return mkc(f, f, f); }  // fbm.rs:18-21
   f2 st = mk2(t.su * si.uv.x + t.du, t.sv * si.uv.y + t.dv);  // UVMapping2D (texture/mod.rs:52-60)
   if (t.kind == 5) return mkc(st.x - floorf(st.x), st.y - floorf(st.y), 0.0f);  // uv.rs:50-54
   // imagemap.rs:232-235
   f2 dstdx = mk2(t.su * si.dudx, t.sv * si.dvdx), dstdy = mk2(t.su * si.dudy, t.sv * si.dvdy);
-  return mip_lookup_diff(sc.images[t.image], st, dstdx, dstdy);
+  return mip_lookup_diff(images[t.image], st, dstdx, dstdy);
 }
 // checkerboard.rs:102-143: which of the two operands, or the box-filtered blend. Returns 0 = tex1, 1 = tex2, 2 = blend with area2.
-RT_DEV int checker_select(const DTexture& t, const SurfaceInteraction& si, float& area2) {
+RT_DEV int checker_select(const DTexture& t, const TexIn& si, float& area2) {
   f2 st = mk2(t.su * si.uv.x + t.du, t.sv * si.uv.y + t.dv);
   if (t.amount == 0) {  // AAMethod::None: `floor() as u32` saturates negatives to 0, the u32 sum wraps
     unsigned a = f2u_sat(floorf(st.x)), b = f2u_sat(floorf(st.y));
@@ -183,23 +189,29 @@ RT_DEV int checker_select(const DTexture& t, const SurfaceInteraction& si, float
   if (ds > 1.0f || dt > 1.0f) area2 = 0.5f;
   return 2;
 }
-RT_DEV rgb3 tex_combine(const DScene& sc, const DTexture& t, rgb3 a, rgb3 b, const SurfaceInteraction& si) {
+RT_DEV rgb3 tex_combine(const DTexture* textures, const DImage* images, const DTexture& t, rgb3 a, rgb3 b, const TexIn& si) {
   if (t.kind == 1) return a * b;  // scale.rs:23-25
-  if (t.kind == 2) { float amt = tex_leaf(sc, sc.textures[t.amount], si).r; return a * (1.0f - amt) + b * amt; }  // mix.rs:24
+  if (t.kind == 2) { float amt = tex_leaf(images, textures[t.amount], si).r; return a * (1.0f - amt) + b * amt; }  // mix.rs:24
   float area2 = 0.0f;
   const int sel = checker_select(t, si, area2);
   return sel == 0 ? a : (sel == 1 ? b : a * (1.0f - area2) + b * area2);
 }
 // a texture whose operands are leaves
-RT_DEV rgb3 tex_depth1(const DScene& sc, const DTexture& t, const SurfaceInteraction& si) {
-  if (tex_is_leaf(t.kind)) return tex_leaf(sc, t, si);
-  return tex_combine(sc, t, tex_leaf(sc, sc.textures[t.tex1], si), tex_leaf(sc, sc.textures[t.tex2], si), si);
+RT_DEV rgb3 tex_depth1(const DTexture* textures, const DImage* images, const DTexture& t, const TexIn& si) {
+  if (tex_is_leaf(t.kind)) return tex_leaf(images, t, si);
+  return tex_combine(textures, images, t, tex_leaf(images, textures[t.tex1], si), tex_leaf(images, textures[t.tex2], si), si);
 }
 // combinators nest two deep at most (a combinator of combinators of leaves); the host rejects deeper scenes
-RT_DEVN rgb3 tex_eval(const DScene& sc, int id, const SurfaceInteraction& si) {
-  const DTexture& t = sc.textures[id];
-  if (tex_is_leaf(t.kind)) return tex_leaf(sc, t, si);
-  return tex_combine(sc, t, tex_depth1(sc, sc.textures[t.tex1], si), tex_depth1(sc, sc.textures[t.tex2], si), si);
+// The register budget of a call's aggregate arguments is 16 dwords, pointers included; scalars always travel in registers - hence the nine floats.
+RT_DEVN rgb3 tex_eval_q(const DTexture* textures, const DImage* images, int id, f2 uv, float dudx, float dvdx, float dudy, float dvdy, float px, float py, float pz,
+                        float dpdx_x, float dpdx_y, float dpdx_z, float dpdy_x, float dpdy_y, float dpdy_z) {
+  TexIn si; si.uv = uv; si.dudx = dudx; si.dvdx = dvdx; si.dudy = dudy; si.dvdy = dvdy; si.p = mk3(px, py, pz); si.dpdx = mk3(dpdx_x, dpdx_y, dpdx_z); si.dpdy = mk3(dpdy_x, dpdy_y, dpdy_z);
+  const DTexture& t = textures[id];
+  if (tex_is_leaf(t.kind)) return tex_leaf(images, t, si);
+  return tex_combine(textures, images, t, tex_depth1(textures, images, textures[t.tex1], si), tex_depth1(textures, images, textures[t.tex2], si), si);
+}
+RT_DEV rgb3 tex_eval(const DScene& sc, int id, const SurfaceInteraction& si) {
+  return tex_eval_q(sc.textures, sc.images, id, si.uv, si.dudx, si.dvdx, si.dudy, si.dvdy, si.hit.p.x, si.hit.p.y, si.hit.p.z, si.dpdx.x, si.dpdx.y, si.dpdx.z, si.dpdy.x, si.dpdy.y, si.dpdy.z);
 }
 RT_DEV float tex_eval_f(const DScene& sc, int id, const SurfaceInteraction& si) { return tex_eval(sc, id, si).r; }
 // the same values with the constant texture (the common parameter) answered in place instead of through the out-of-line evaluator
@@ -499,7 +511,7 @@ RT_DEV void d1_sample_discrete(const float* func, const float* cdf, float func_i
 }
 
 // ---------------------------------------------------------------- lights
-struct LiSample { rgb3 li; f3 wi; float pdf; Interaction p1; };
+struct LiSample { rgb3 li; f3 wi; float pdf; LightPoint p1; };  // 16 dwords: returned in registers
 
 RT_DEV float tri_area(const DScene& sc, int prim) {  // mesh.rs:588-594
   f3 p0, p1, p2; load_tri(sc.tri_p, prim, p0, p1, p2);
@@ -512,11 +524,12 @@ RT_DEV rgb3 area_light_l(const DLight& l, f3 n, f3 w) {  // diffuse.rs:91-97
 RT_DEV f3 xf3x4(const float* m, f3 v) {  // Transform * Vector3f, transform.rs:288-303
   return mk3(m[0] * v.x + m[1] * v.y + m[2] * v.z, m[4] * v.x + m[5] * v.y + m[6] * v.z, m[8] * v.x + m[9] * v.y + m[10] * v.z);
 }
-RT_DEVN rgb3 infinite_le(const DScene& sc, const DLight& l, f3 ray_d) {  // infinite.rs:211-219
+RT_DEVN rgb3 infinite_le_q(const DImage* images, const DLight& l, f3 ray_d) {  // infinite.rs:211-219
   f3 w = normalize(xf3x4(l.w2l, ray_d));
   f2 st = mk2(spherical_phi(w) * kInvPi * 0.5f, spherical_theta(w) * kInvPi);
-  return mip_lookup(sc.images[l.image], st, 0.0f);
+  return mip_lookup(images[l.image], st, 0.0f);
 }
+RT_DEV rgb3 infinite_le(const DScene& sc, const DLight& l, f3 ray_d) { return infinite_le_q(sc.images, l, ray_d); }
 // DiffuseAreaLight::sample_li diffuse.rs:59-70 -> Shape::sample_si shapes/mod.rs:39-53 -> Triangle::sample mesh.rs:610-634
 RT_DEV LiSample area_light_sample_li(const DScene& sc, const DLight& l, const Interaction& ref, f2 u) {
   LiSample s;
@@ -532,7 +545,7 @@ RT_DEV LiSample area_light_sample_li(const DScene& sc, const DLight& l, const In
     normal = face_forward(normal, ns);
   } else if (flags & 1u) normal = normal * -1.0f;
   f3 p_abs_sum = abs3(b.x * p0) + abs3(b.y * p1) + abs3(b2 * p2);
-  s.p1.p = p; s.p1.p_error = gamma_n(6) * p_abs_sum; s.p1.wo = mk3(0, 0, 0); s.p1.n = normal;
+  s.p1.p = p; s.p1.p_error = gamma_n(6) * p_abs_sum; s.p1.n = normal;
   float pdf = 1.0f / l.area;
   f3 wi = p - ref.p;
   if (len2(wi) == 0.0f) pdf = 0.0f;
@@ -559,13 +572,13 @@ RT_DEV float area_light_pdf_li(const DScene& sc, const DLight& l, const Interact
   return distance_squared(ref.p, p) / (fabsf(dot(n, -wi)) * l.area);
 }
 template <bool GENERAL>
-RT_DEVN LiSample light_sample_li(const DScene& sc, const DLight& l, const Interaction& ref, f2 u) {
+RT_DEVN LiSample light_sample_li(const DScene& sc, const DLight& l, Interaction ref, f2 u) {  // sc: a DScene in device memory (*sc.self); ref by value, in registers
   LiSample s;
   switch (l.kind) {
     case 0:
       if (GENERAL && (tri_flags(sc.tri_p, l.prim) & RT_FLAG_SPHERE)) {  // DiffuseAreaLight::sample_li (diffuse.rs:59-70) over Sphere::sample_si
         float pdf; const SpherePoint sp = sphere_sample_si(sc.spheres[prim_sphere_index(sc.tri_p, l.prim)], ref, u, pdf);
-        s.p1.p = sp.p; s.p1.p_error = sp.p_error; s.p1.wo = mk3(0, 0, 0); s.p1.n = sp.n;
+        s.p1.p = sp.p; s.p1.p_error = sp.p_error; s.p1.n = sp.n;
         s.wi = normalize(sp.p - ref.p); s.pdf = pdf; s.li = area_light_l(l, sp.n, -s.wi);
         return s;
       }
@@ -576,13 +589,13 @@ RT_DEVN LiSample light_sample_li(const DScene& sc, const DLight& l, const Intera
       float r2 = len2(wi);
       s.li = mkc(l.rgb[0], l.rgb[1], l.rgb[2]) / (4.0f * kPi * r2);
       s.wi = normalize(wi); s.pdf = 1.0f;
-      s.p1.p = pos; s.p1.p_error = mk3(0, 0, 0); s.p1.wo = mk3(0, 0, 0); s.p1.n = mk3(0, 0, 0);
+      s.p1.p = pos; s.p1.p_error = mk3(0, 0, 0); s.p1.n = mk3(0, 0, 0);
       return s;
     }
     case 2: {  // DistantLight::sample_li distant.rs:57-70
       f3 dir = mk3(l.vec[0], l.vec[1], l.vec[2]);
       s.li = mkc(l.rgb[0], l.rgb[1], l.rgb[2]); s.wi = dir; s.pdf = 1.0f;
-      s.p1.p = ref.p + dir * (2.0f * l.world_radius); s.p1.p_error = mk3(0, 0, 0); s.p1.wo = mk3(0, 0, 0); s.p1.n = mk3(0, 0, 0);
+      s.p1.p = ref.p + dir * (2.0f * l.world_radius); s.p1.p_error = mk3(0, 0, 0); s.p1.n = mk3(0, 0, 0);
       return s;
     }
     default: {  // InfiniteAreaLight::sample_li infinite.rs:143-181
@@ -592,7 +605,7 @@ RT_DEVN LiSample light_sample_li(const DScene& sc, const DLight& l, const Intera
       d1_sample_continuous(l.func + (size_t)v * l.nu, l.cdf + (size_t)v * (l.nu + 1), l.func_int[v], l.nu, u.x, d0, pdf0, dummy);
       }
       float map_pdf = pdf0 * pdf1;
-      s.p1.p_error = mk3(0, 0, 0); s.p1.wo = mk3(0, 0, 0); s.p1.n = mk3(0, 0, 0);
+      s.p1.p_error = mk3(0, 0, 0); s.p1.n = mk3(0, 0, 0);
       if (map_pdf == 0.0f) { s.li = mkc(0, 0, 0); s.wi = mk3(0, 0, 0); s.pdf = 0.0f; s.p1.p = mk3(0, 0, 0); return s; }
       float theta = d1 * kPi, phi = d0 * 2.0f * kPi;
       float cos_theta_ = cosf(theta), sin_theta_ = sinf(theta), cos_phi_ = cosf(phi), sin_phi_ = sinf(phi);
@@ -606,7 +619,8 @@ RT_DEVN LiSample light_sample_li(const DScene& sc, const DLight& l, const Intera
 }
 // Light::pdf_li. Area lights: Shape::pdf_wi (shapes/mod.rs:59-68) re-intersects the emitter triangle.
 template <bool GENERAL>
-RT_DEVN float light_pdf_li(const DScene& sc, const DLight& l, const Interaction& ref, f3 wi) {
+RT_DEVN float light_pdf_li_q(const DScene& sc, const DLight& l, Interaction ref, float wi_x, float wi_y, float wi_z) {
+  const f3 wi = mk3(wi_x, wi_y, wi_z);
   if (l.kind == 0) return area_light_pdf_li<GENERAL>(sc, l, ref, wi);
   if (l.kind == 3) {  // infinite.rs:183-196
     f3 w = xf3x4(l.w2l, wi);
@@ -619,6 +633,8 @@ RT_DEVN float light_pdf_li(const DScene& sc, const DLight& l, const Interaction&
   }
   return 0.0f;
 }
+template <bool GENERAL>
+RT_DEV float light_pdf_li(const DScene& sc, const DLight& l, const Interaction& ref, f3 wi) { return light_pdf_li_q<GENERAL>(sc, l, ref, wi.x, wi.y, wi.z); }
 RT_DEV bool light_is_delta(const DLight& l) { return l.kind == 1 || l.kind == 2; }  // light/mod.rs:38-40
 
 // ---------------------------------------------------------------- light distribution (rc/lightdistrib.rs)

@@ -66,6 +66,7 @@ struct rt_scene {
   std::vector<DLight> h_lights;
   // light distribution tables (built per render, rc/integrator/path.rs:86-94)
   DevBuf ld_func, ld_cdf, ld_int, ld_mark, ld_list, ld_slot;
+  DevBuf self;  // `d` in device memory (DScene::self), rewritten whenever `d` changes
   int ld_strategy_built = -1; bool ld_all_voxels = false;  // the tables are a function of the scene alone: built once per strategy, kept across frames
   std::mutex render_mutex;  // rt_render shares the workspace below: concurrent calls on one rt_scene take turns
   // per-render workspace
@@ -503,6 +504,9 @@ extern "C" int rt_scene_create(const rt_scene_desc* desc, int device, rt_scene**
     if (s->deep_stack.ensure(nb) != hipSuccess) { delete s; return fail(RT_ERR_OOM, "traversal stack allocation failed"); }
   }
   fill_ewa_lut();
+  if (s->self.ensure(sizeof(DScene)) != hipSuccess) { delete s; return fail(RT_ERR_OOM, "scene record allocation failed"); }
+  d.self = s->self.as<DScene>();
+  HIP_TRY(hipMemcpy(s->self.p, &d, sizeof(DScene), hipMemcpyHostToDevice));
   HIP_TRY(hipDeviceSynchronize());
   *out = s;
   return RT_OK;
@@ -576,6 +580,7 @@ static int build_light_distribution(rt_scene* s, int strategy, hipStream_t strea
   }
   d.ld_func = s->ld_func.as<float>(); d.ld_cdf = s->ld_cdf.as<float>(); d.ld_int = s->ld_int.as<float>(); d.ld_slot = s->ld_slot.as<int>();
   s->ld_strategy_built = strategy; s->ld_all_voxels = all_voxels;
+  HIP_TRY(hipMemcpyAsync(s->self.p, &s->d, sizeof(DScene), hipMemcpyHostToDevice, stream));
   return RT_OK;
 }
 

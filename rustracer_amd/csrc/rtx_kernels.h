@@ -687,7 +687,7 @@ __global__ void __launch_bounds__(BLOCK) k_trace_big(DScene sc, TraceIO io, cons
           continue;
         }
         if (tri_test_pre(p0, p1, p2, ray, rp, h)) {
-          if (GENERAL && tri_alpha_rejects(sc, leaf_off + i, h, ANY)) continue;
+          if (GENERAL && tri_alpha_rejects(*sc.self, leaf_off + i, h, ANY)) continue;
           found = true;
           if (ANY) break;
           ray.t_max = h.t; prim = leaf_off + i; hit = h;  // `.or(result)`: later accepted hits replace
@@ -1442,6 +1442,7 @@ __global__ void __launch_bounds__(256, MODE == 1 ? RT_SHADE_MIN_WAVES : RT_SHADE
   if (MODE != 1 && ps.range) { first = ps.range[0]; count = ps.range[1]; }
   const unsigned stride = gridDim.x * blockDim.x;
   unsigned n_shaded = 0;
+  const DScene& gsc = *sc.self;  // what out-of-line functions get: the scene record in device memory, not a private copy of the kernel argument
 #ifdef RT_ABLATE
   unsigned long long stamp_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, stamp_last = clock64();
 #endif
@@ -1476,8 +1477,8 @@ __global__ void __launch_bounds__(256, MODE == 1 ? RT_SHADE_MIN_WAVES : RT_SHADE
           (void)sphere_fill_interaction(sc.spheres[prim_sphere_index(sc.tri_p, prim)], mk3(o4.x, o4.y, o4.z), ray_d, si);
           si.prim = prim;
         }
-        else if (MODE & 1) tri_fill_interaction_inl(sc, prim, ray_d, th, si);
-        else tri_fill_interaction(sc, prim, ray_d, th, si);
+        else if (MODE != 0) tri_fill_interaction_inl(sc, prim, ray_d, th, si);
+        else tri_fill_interaction(gsc, prim, ray_d, th, si);
       }
       RT_STAMP(0);  // path state loads + SurfaceInteraction
       // path.rs:127-136 emitted light at the vertex / from the environment
@@ -1499,7 +1500,7 @@ __global__ void __launch_bounds__(256, MODE == 1 ? RT_SHADE_MIN_WAVES : RT_SHADE
         typename std::conditional<MODE == 1, SingleLambert, typename std::conditional<MODE == 3, SingleLambertT<true>,
                                   typename std::conditional<MODE == 5, SmallBsdfT<false>, typename std::conditional<MODE == 6, SmallBsdfT<true>, GenericBsdf>::type>::type>::type>::type bsdf;
         RT_STAMP(1);  // emission + differentials
-        bsdf.build(sc, tri_material(sc.tri_p, prim), si);
+        if (MODE == 0) bsdf.build(gsc, tri_material(sc.tri_p, prim), si); else bsdf.build(sc, tri_material(sc.tri_p, prim), si);
         RT_STAMP(2);  // material: textures + lobes
         // light_distribution.lookup(p) (path.rs:154-158)
         const float* ld_func; const float* ld_cdf; float ld_int;
@@ -1525,7 +1526,7 @@ __global__ void __launch_bounds__(256, MODE == 1 ? RT_SHADE_MIN_WAVES : RT_SHADE
             const DLight& light = sc.lights[light_num];
             // ---- estimate_direct (integrator/mod.rs:222-318), light-sampling half
             rgb3 ld1 = mkc(0, 0, 0); f3 sh_dir = mk3(0, 0, 0);
-            LiSample ls = (MODE == 1) ? area_light_sample_li(sc, light, si.hit, u_light) : light_sample_li<GENERAL>(sc, light, si.hit, u_light);
+            LiSample ls = (MODE == 1) ? area_light_sample_li(sc, light, si.hit, u_light) : light_sample_li<GENERAL>(gsc, light, si.hit, u_light);
             if (ls.pdf > 0.0f && !is_black(ls.li)) {
               rgb3 f = bsdf.f(si.hit.wo, ls.wi, nonspec) * fabsf(dot(ls.wi, si.sh_n));
               float scattering_pdf = bsdf.pdf(si.hit.wo, ls.wi, nonspec);
@@ -1547,7 +1548,7 @@ __global__ void __launch_bounds__(256, MODE == 1 ? RT_SHADE_MIN_WAVES : RT_SHADE
               if (!is_black(f) && bs.pdf > 0.0f) {
                 float weight = 1.0f; bool go = true;
                 if (!(bs.type & BSDF_SPECULAR)) {
-                  float lp = (MODE == 1) ? area_light_pdf_li<false>(sc, light, si.hit, bs.wi) : light_pdf_li<GENERAL>(sc, light, si.hit, bs.wi);
+                  float lp = (MODE == 1) ? area_light_pdf_li<false>(sc, light, si.hit, bs.wi) : light_pdf_li<GENERAL>(gsc, light, si.hit, bs.wi);
                   if (lp == 0.0f) go = false;  // `return ld`
                   else weight = power_heuristic1(bs.pdf, lp);
                 }
@@ -1680,7 +1681,7 @@ __global__ void __launch_bounds__(256) k_resolve(DScene sc, PassState ps) {
             f3 p0, p1, p2; load_tri(sc.tri_p, prim, p0, p1, p2);
             Ray r; r.o = mk3(o4.x, o4.y, o4.z); r.d = wi; r.t_max = kInf;
             TriHit th; (void)tri_test_call(p0, p1, p2, r, th);
-            f3 p, n; tri_hit_point_normal(sc, prim, th, p, n);
+            f3 p, n; tri_hit_point_normal(*sc.self, prim, th, p, n);
             li = area_light_l(light, n, -wi);
           }
         } else if (light.kind == 3) li = infinite_le(sc, light, wi);  // light.le(ray)
@@ -1878,7 +1879,7 @@ __global__ void __launch_bounds__(128) k_lightdist_contrib(DScene sc, const unsi
       Interaction intr;
       intr.p = bounds_lerp(vmn, vmx, mk3(halton[5 * i], halton[5 * i + 1], halton[5 * i + 2]));
       intr.p_error = mk3(0, 0, 0); intr.wo = mk3(1, 0, 0); intr.n = mk3(0, 0, 0);
-      LiSample s = light_sample_li<GENERAL>(sc, light, intr, mk2(halton[5 * i + 3], halton[5 * i + 4]));
+      LiSample s = light_sample_li<GENERAL>(*sc.self, light, intr, mk2(halton[5 * i + 3], halton[5 * i + 4]));
       if (s.pdf > 0.0f) contrib += lum_y(s.li) / s.pdf;
     }
   }
