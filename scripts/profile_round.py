@@ -13,14 +13,14 @@ base = os.path.join('gpurun_out', f'{tag}_{scene}')
 os.makedirs('profiles', exist_ok=True)
 st = glob.glob(os.path.join(base, 'stats', '*', '*_kernel_stats.csv'))
 if st:
-    shutil.copy(st[0], os.path.join('profiles', f'{tag}_{scene}_kernel_stats.csv'))
+    shutil.copy(max(st, key=os.path.getmtime), os.path.join('profiles', f'{tag}_{scene}_kernel_stats.csv'))  # the latest run
 
 def per_kernel(sub, counter):
     files = glob.glob(os.path.join(base, sub, '*', '*_counter_collection.csv'))
     agg = collections.defaultdict(float); n = collections.Counter()
     if not files:
         return agg, n
-    for r in csv.DictReader(open(files[0])):
+    for r in csv.DictReader(open(max(files, key=os.path.getmtime))):
         if r['Counter_Name'] != counter:
             continue
         k = r['Kernel_Name']
@@ -51,7 +51,7 @@ def pick(prefixes, exclude=(), per_stage=False):
     tot_l = max(r[1] for r in sel) if per_stage else sum(r[1] for r in sel)
     return {'kernels': sorted({r[0] for r in sel}), 'hbm_bytes_per_launch': round(sum(r[4] * r[1] for r in sel) / tot_l), 'launches_profiled': tot_l}
 
-# closest-hit kernels of the timed frames: k_trace<false, false, ...> (LDS scenes) or k_trace_pair<false, ...> (HBM scenes)
+# closest-hit kernels of the timed frames: k_trace<false, false, ...> (LDS scenes), k_trace_pair<false, ...> or k_trace_top<false, ...> (HBM scenes)
 import datetime, subprocess
 try:
     commit = subprocess.run(['git', 'rev-parse', '--short', 'HEAD'], capture_output=True, text=True).stdout.strip() or None
@@ -60,7 +60,7 @@ except Exception:
 out = {'scene': scene, 'collected': f'{tag}, {datetime.date.today().isoformat()}' + (f', tree {commit}' if commit else ''),
        'method': 'rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate passes; KiB->B; reads x2 (gfx950 16-B/lane correction, MI355X guide)',
        'source': f'profiles/{tag}_{scene}_pmc_hbm.csv',
-       'trace_closest': pick(['rtx::k_trace<false, false', 'rtx::k_trace_pair<false']),
+       'trace_closest': pick(['rtx::k_trace<false, false', 'rtx::k_trace_pair<false', 'rtx::k_trace_top<false']),
        'shade': pick(['rtx::k_shade'], per_stage=True)}
 json.dump(out, open(os.path.join('profiles', f'pmc_{scene}.json'), 'w'), indent=1)
 print(open(os.path.join('profiles', f'{tag}_{scene}_pmc_hbm.csv')).read())
