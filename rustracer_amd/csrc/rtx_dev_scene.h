@@ -270,6 +270,8 @@ RT_DEV void compute_differential(SurfaceInteraction& si, f3 rx_o, f3 ry_o, f3 rx
   if (!(y0 != y0 || y1 != y1)) { si.dudy = y0; si.dvdy = y1; }
 }
 
+RT_DEVN void compute_differential_call(SurfaceInteraction& si, f3 rx_o, f3 ry_o, f3 rx_d, f3 ry_d) { compute_differential(si, rx_o, ry_o, rx_d, ry_d); }  // generic shade kernel: its SurfaceInteraction lives in scratch anyway
+
 // ---------------------------------------------------------------- BVH traversal
 // One lane = one ray. The to-visit stack (64 entries, bvh/mod.rs:374) lives in LDS, laid out
 // [depth][lane] so that a wave's push/pop of one depth touches 64 consecutive banks.

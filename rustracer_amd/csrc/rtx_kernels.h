@@ -1495,7 +1495,7 @@ __global__ void __launch_bounds__(256, MODE == 1 ? RT_SHADE_MIN_WAVES : RT_SHADE
           f2 pf; { float2 t = pacc->pfilm; pf = mk2(t.x, t.y); }
           f2 pl = table_2d(smp.tb, pix, 1, s);
           CameraRay cr = generate_camera_ray(fp, pf, pl, 1.0f / sqrtf((float)ps.spp));
-          compute_differential(si, cr.rx_o, cr.ry_o, cr.rx_d, cr.ry_d);
+          if (MODE == 0) compute_differential_call(si, cr.rx_o, cr.ry_o, cr.rx_d, cr.ry_d); else compute_differential(si, cr.rx_o, cr.ry_o, cr.rx_d, cr.ry_d);
         }
         typename std::conditional<MODE == 1, SingleLambert, typename std::conditional<MODE == 3, SingleLambertT<true>,
                                   typename std::conditional<MODE == 5, SmallBsdfT<false>, typename std::conditional<MODE == 6, SmallBsdfT<true>, GenericBsdf>::type>::type>::type>::type bsdf;
