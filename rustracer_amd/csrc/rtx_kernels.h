@@ -748,6 +748,9 @@ struct PairLane {
   RT_DEV int neg_x() const { return inv_dir.x < 0.0f; }
   RT_DEV int neg_y() const { return inv_dir.y < 0.0f; }
   RT_DEV int neg_z() const { return inv_dir.z < 0.0f; }
+  // the sign along a node's split axis as arithmetic on the three compares: written as a select between the components, the optimiser turns it into
+  // an indexed load from a private copy of inv_dir - one scratch access per node visit
+  RT_DEV bool neg_axis(unsigned axis) const { return ((((inv_dir.x < 0.0f) ? 1u : 0u) | ((inv_dir.y < 0.0f) ? 2u : 0u) | ((inv_dir.z < 0.0f) ? 4u : 0u)) >> axis) & 1u; }
   RT_DEV RayPre rp() const { RayPre r; r.kz = kz; r.kx = kz + 1; if (r.kx == 3) r.kx = 0; r.ky = r.kx + 1; if (r.ky == 3) r.ky = 0; r.sx = sx; r.sy = sy; r.sz = sz; return r; }
   RT_DEV void set_rp(const RayPre& r) { kz = r.kz; sx = r.sx; sy = r.sy; sz = r.sz; }
   int sp, prim; unsigned cur; TriHit hit;
@@ -778,7 +781,7 @@ template <bool ANY, int BLOCK>
 RT_DEV void pair_interior_step(PairLane& L, const TraceOut& o, const float4* __restrict__ pairs, unsigned* stack, float* tstack, size_t grid_lanes) {
   const unsigned P = L.cur & 0x1fffffffu, axis = (L.cur >> 29) & 3u;
   const float4 a0 = pairs[4 * (size_t)P], a1 = pairs[4 * (size_t)P + 1], b0 = pairs[4 * (size_t)P + 2], b1 = pairs[4 * (size_t)P + 3];
-  const bool neg = (axis == 0u ? L.neg_x() : (axis == 1u ? L.neg_y() : L.neg_z())) != 0;
+  const bool neg = L.neg_axis(axis);
   // reference: negative direction along the split axis => second child first (bvh/mod.rs:411-417)
   const float4 n0 = neg ? b0 : a0, n1 = neg ? b1 : a1, f0 = neg ? a0 : b0, f1 = neg ? a1 : b1;
   const unsigned code_a = __float_as_uint(a1.z), code_b = __float_as_uint(a1.w);
@@ -906,7 +909,7 @@ RT_DEV void top_interior_step(PairLane& L, const TraceOut& o, const float4* __re
   float4 a0, a1, b0, b1;
   if (L.cur & RT_PAIR_TOP) { const unsigned k = L.cur & 0xffu; a0 = s_top[4 * k]; a1 = s_top[4 * k + 1]; b0 = s_top[4 * k + 2]; b1 = s_top[4 * k + 3]; }
   else { const size_t P = L.cur & 0x0fffffffu; a0 = pairs[4 * P]; a1 = pairs[4 * P + 1]; b0 = pairs[4 * P + 2]; b1 = pairs[4 * P + 3]; }
-  const bool neg = (axis == 0u ? L.neg_x() : (axis == 1u ? L.neg_y() : L.neg_z())) != 0;
+  const bool neg = L.neg_axis(axis);
   const float4 n0 = neg ? b0 : a0, n1 = neg ? b1 : a1, f0 = neg ? a0 : b0, f1 = neg ? a1 : b1;
   const unsigned code_a = __float_as_uint(a1.z), code_b = __float_as_uint(a1.w);
   const unsigned code_n = neg ? code_b : code_a, code_f = neg ? code_a : code_b;
@@ -935,7 +938,7 @@ RT_DEV void top_leaf_step(PairLane& L, const TraceOut& o, const float4* __restri
   if (ANY && L.found) pair_finish<ANY>(L, o); else top_pop<ANY, BLOCK>(L, o, stk, tstack, grid_lanes);
 }
 template <bool ANY, int BLOCK>
-__global__ void __launch_bounds__(BLOCK) k_trace_top(DScene sc, TraceIO io, const unsigned* __restrict__ queue, const unsigned* __restrict__ shard_counts, unsigned shard_cap,
+__global__ void __launch_bounds__(BLOCK, 6) k_trace_top(DScene sc, TraceIO io, const unsigned* __restrict__ queue, const unsigned* __restrict__ shard_counts, unsigned shard_cap,
                                                      unsigned count_static, unsigned long long* stats, int st_rays, float* __restrict__ tmin_stack_mem, unsigned* __restrict__ deep_stack_mem,
                                                      unsigned refill_min) {
   __shared__ unsigned stack_mem[RT_TOP_LDS_DEPTH * BLOCK];
@@ -1041,7 +1044,7 @@ RT_DEV void quad_interior_step(PairLane& L, const TraceOut& o, const float4* __r
     hit[k] = (code[k] != 0xffffffffu) & slab_geom6(bx + 6 * k, L.ray, L.inv_dir, L.neg_x(), L.neg_y(), L.neg_z(), tmin[k]);
     hit[k] = hit[k] & (tmin[k] < L.ray.t_max);
   }
-  auto neg_of = [&](unsigned ax) { return (ax == 0u ? L.neg_x() : (ax == 1u ? L.neg_y() : L.neg_z())) != 0; };
+  auto neg_of = [&](unsigned ax) { return L.neg_axis(ax); };
   // negative direction along a split axis => that node's second child first (bvh/mod.rs:411-417), at all three nodes involved
   const bool sp = neg_of(axis_p), sa = neg_of(axes & 3u) & (code[1] != 0xffffffffu), sb = neg_of((axes >> 2) & 3u) & (code[3] != 0xffffffffu);
   const int a0 = sa ? 1 : 0, a1 = sa ? 0 : 1, b0 = sb ? 3 : 2, b1 = sb ? 2 : 3;
