@@ -22,7 +22,7 @@ RT_DEV rgb3 mip_texel(const DImage& im, int level, long s, long t) {
   const float4 v = im.texels[im.off[level] + ((((unsigned long long)(tt >> 1) << im.tshift[level]) + (ss >> 2)) << 3) + ((tt & 1u) << 2) + (ss & 3u)];
   return mkc(v.x, v.y, v.z);
 }
-RT_DEVN rgb3 mip_triangle(const DImage& im, int level, f2 st) {  // :285-308
+RT_DEV rgb3 mip_triangle(const DImage& im, int level, f2 st) {  // :285-308
   level = clampi(level, 0, im.n_levels - 1);
   float s = st.x * (float)im.w[level] - 0.5f;
   float t = st.y * (float)im.h[level] - 0.5f;
@@ -32,16 +32,18 @@ RT_DEVN rgb3 mip_triangle(const DImage& im, int level, f2 st) {  // :285-308
          mip_texel(im, level, s0 + 1, t0) * ds * (1.0f - dt) + mip_texel(im, level, s0 + 1, t0 + 1) * ds * dt;
 }
 RT_DEV rgb3 lerp_rgb(float t, rgb3 a, rgb3 b) { return a * (1.0f - t) + b * t; }
-RT_DEVN rgb3 mip_lookup(const DImage& im, f2 st, float width) {  // :227-245
+RT_DEV rgb3 mip_lookup(const DImage& im, f2 st, float width) {  // :227-245
   float level = (float)im.n_levels - 1.0f + log2f(fmaxf(width, 1e-8f));
   if (level < 0.0f) return mip_triangle(im, 0, st);
   if (level >= (float)im.n_levels - 1.0f) return mip_texel(im, im.n_levels - 1, 0, 0);
   float i_level = floorf(level);
   float delta = level - i_level;
   int il = (int)f2u_sat(i_level);
-  return lerp_rgb(delta, mip_triangle(im, il, st), mip_triangle(im, il + 1, st));
+  rgb3 v[2];
+  for (int k = 0; k < 2; ++k) v[k] = mip_triangle(im, il + k, st);  // a loop: one copy of the inlined lookup
+  return lerp_rgb(delta, v[0], v[1]);
 }
-RT_DEVN rgb3 mip_ewa(const DImage& im, int level, f2 st, f2 dst0, f2 dst1) {  // :310-360
+RT_DEV rgb3 mip_ewa(const DImage& im, int level, f2 st, f2 dst0, f2 dst1) {  // :310-360
   if (level >= im.n_levels) return mip_texel(im, im.n_levels - 1, 0, 0);
   float us = (float)im.w[level], vs = (float)im.h[level];
   st.x = st.x * us - 0.5f; st.y = st.y * vs - 0.5f;
@@ -72,7 +74,7 @@ RT_DEVN rgb3 mip_ewa(const DImage& im, int level, f2 st, f2 dst0, f2 dst1) {  //
   }
   return sum / sumWts;
 }
-RT_DEVN rgb3 mip_lookup_diff(const DImage& im, f2 st, f2 dst0, f2 dst1) {  // :247-283
+RT_DEV rgb3 mip_lookup_diff(const DImage& im, f2 st, f2 dst0, f2 dst1) {  // :247-283
   if (im.trilinear) {
     float width = fmaxf(fmaxf(fabsf(dst0.x), fabsf(dst0.y)), fmaxf(fabsf(dst1.x), fabsf(dst1.y)));
     return mip_lookup(im, st, 2.0f * width);
@@ -89,7 +91,9 @@ RT_DEVN rgb3 mip_lookup_diff(const DImage& im, f2 st, f2 dst0, f2 dst1) {  // :2
   if (minor_length == 0.0f) return mip_triangle(im, 0, st);
   float lod = fmaxf(0.0f, (float)im.n_levels - 1.0f + log2f(minor_length));
   int ilod = (int)f2u_sat(floorf(lod));
-  return lerp_rgb(lod - (float)ilod, mip_ewa(im, ilod, st, dst0, dst1), mip_ewa(im, ilod + 1, st, dst0, dst1));
+  rgb3 v[2];
+  for (int k = 0; k < 2; ++k) v[k] = mip_ewa(im, ilod + k, st, dst0, dst1);  // a loop: one copy of the inlined filter
+  return lerp_rgb(lod - (float)ilod, v[0], v[1]);
 }
 
 // ---------------------------------------------------------------- textures (rc/texture/*.rs)

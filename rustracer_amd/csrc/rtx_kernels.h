@@ -121,10 +121,10 @@ struct QView {
   }
   RT_DEV unsigned total() const { return pre[RT_QSHARDS]; }
   RT_DEV unsigned get(unsigned i) const {
-    unsigned k = 0;
+    unsigned k = 0, base = 0;  // pre[k] selected on the way: indexed afterwards, the prefix array would live in scratch
 #pragma unroll
-    for (int j = 1; j < RT_QSHARDS; ++j) k += (i >= pre[j]) ? 1u : 0u;
-    return ids[k * shard_cap + (i - pre[k])];
+    for (int j = 1; j < RT_QSHARDS; ++j) { const bool ge = i >= pre[j]; k += ge ? 1u : 0u; base = ge ? pre[j] : base; }
+    return ids[k * shard_cap + (i - base)];
   }
 };
 // Block-aggregated append to up to three sharded device queues: one returning atomic per queue per
@@ -1490,7 +1490,7 @@ __global__ void __launch_bounds__(256, MODE == 1 ? RT_SHADE_MIN_WAVES : RT_SHADE
           int li = tri_light(sc.tri_p, prim);
           if (li >= 0) L = L + beta * area_light_l(sc.lights[li], si.hit.n, -ray_d);
         } else if (MODE != 1) {
-          for (int k = 0; k < sc.n_infinite; ++k) L = L + beta * infinite_le(sc, sc.lights[sc.infinite_ids[k]], ray_d);
+          for (int k = 0; k < sc.n_infinite; ++k) L = L + beta * infinite_le(sc, sc.lights[k == 0 ? sc.infinite_ids[0] : (k == 1 ? sc.infinite_ids[1] : (k == 2 ? sc.infinite_ids[2] : sc.infinite_ids[3]))], ray_d);  // constant indices: the kernel argument stays in SGPRs
         }
       }
       if (found && bounces < fp.max_depth) {  // path.rs:139
@@ -1641,7 +1641,7 @@ __global__ void __launch_bounds__(256) k_shade_miss(DScene sc, PassState ps) {
     const f3 ray_d = mk3(d4.x, d4.y, d4.z);
     const rgb3 beta = mkc(b4.x, b4.y, b4.z);
     rgb3 L = mkc(l4.x, l4.y, l4.z);
-    for (int k = 0; k < sc.n_infinite; ++k) L = L + beta * infinite_le(sc, sc.lights[sc.infinite_ids[k]], ray_d);
+    for (int k = 0; k < sc.n_infinite; ++k) L = L + beta * infinite_le(sc, sc.lights[k == 0 ? sc.infinite_ids[0] : (k == 1 ? sc.infinite_ids[1] : (k == 2 ? sc.infinite_ids[2] : sc.infinite_ids[3]))], ray_d);  // constant indices: the kernel argument stays in SGPRs
     ps.acc[pid].lacc = make_float4(L.r, L.g, L.b, l4.w);
   }
 }
