@@ -47,6 +47,8 @@ typedef struct rt_bvh_node {
 #define RT_TRI_HAS_SHADOW_ALPHA 32u /* mesh.shadow_alpha_mask is Some: tri_alpha[2 i + 1] (mesh.rs:39,146-156); shadow rays only (:577-581) */
 #define RT_PRIM_SPHERE 64u /* this primitive is an analytic sphere (rc/shapes/sphere.rs), not a triangle: its tri_p slot holds the world bounding
                               box (p0 = min, p1 = max) and, as the bits of p2.x, its index into rt_scene_desc::spheres                          */
+#define RT_PRIM_INSTANCE 128u /* this primitive is an object instance (TransformedPrimitive, rc/primitive.rs:79-118): its tri_p slot holds the world
+                                 bounding box (p0 = min, p1 = max) and, as the bits of p2.x, its index into rt_scene_desc::instances              */
 typedef struct rt_tri_meta {
   int32_t material; /* index into materials[]                 */
   int32_t light;    /* index into lights[] (area light) or -1 */
@@ -66,6 +68,16 @@ typedef struct rt_sphere {
   int32_t kind;
   float height, inner_radius;
 } rt_sphere;
+
+/* -- ObjectInstance: replaces TransformedPrimitive{primitive, primitive_to_world} (rc/primitive.rs:79-118, rc/api.rs:1053-1090). The object is what
+ *    object_instance wraps: the BVH aggregate over the object's primitives - n_nodes nodes from nodes[node_base], child / primitive offsets relative to
+ *    the object's own first node / first primitive - or, for an object of exactly one primitive, that primitive itself (n_nodes = 0). Its n_prims
+ *    primitives (triangles in OBJECT space, leaf order) sit in the tri_* arrays from prim_base on, after the n_top_prims primitives of the top level.
+ *    A hit inside instance k carries the id n_tris + (n_prims of instances 0 .. k-1) + its leaf-order index in the object (rt_trace_closest). ------ */
+typedef struct rt_instance {
+  float o2w[16], w2o[16]; /* primitive_to_world and its inverse as the host holds them, row-major */
+  uint32_t node_base, n_nodes, prim_base, n_prims;
+} rt_instance;
 
 /* -- textures: replaces dyn Texture<T> (rc/texture/{constant,scale,mix,imagemap,checkerboard,uv,fbm}.rs) --
  * checkerboard (2D): tex1, tex2, mapping, amount = AAMethod (0 none, 1 closedform); uv: mapping;
@@ -147,6 +159,11 @@ typedef struct rt_scene_desc {
   uint32_t n_images; const rt_image* images;
   uint32_t n_materials; const rt_material* materials;
   uint32_t n_lights; const rt_light* lights; /* order = Scene::lights (rc/scene.rs:24)       */
+  /* object instances (two-level traversal). With n_instances > 0: nodes[0 .. n_top_nodes) is the top-level tree and tri_*[0 .. n_top_prims) its
+   * primitives (some of them RT_PRIM_INSTANCE); the objects' trees and primitives follow in the same arrays (n_nodes, n_tris count everything).
+   * Without instances the three fields are 0 / NULL. */
+  uint32_t n_instances; const rt_instance* instances;
+  uint32_t n_top_nodes, n_top_prims;
 } rt_scene_desc;
 
 /* -- what renderer::render receives through &dyn Camera / Film / Sampler / Integrator ------- */

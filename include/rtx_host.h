@@ -57,6 +57,14 @@ int rtxh_scene_add_sphere(rtxh_scene*, const float* o2w16, const float* w2o16, f
  * rc/shapes/disk.rs:48-62), 2 = Shape "cylinder" (z_min, z_max as given; rc/shapes/cylinder.rs:26-46). Area lights as for spheres (tri = -2 - k). */
 int rtxh_scene_add_quadric(rtxh_scene*, int32_t kind, const float* o2w16, const float* w2o16, float radius, float z_min, float z_max, float phi_max,
                            int32_t reverse_orientation, int32_t material, int32_t light);
+/* ObjectBegin ... ObjectEnd (rc/api.rs:1019-1051): a triangle mesh in OBJECT space (vertices as the shapes' own CTMs leave them), arrays as for
+ * rtxh_scene_set_mesh without lights (area lights inside object definitions are refused; the reference shows but never samples them, api.rs:955-957).
+ * Returns the object's index; nothing is rendered until an instance places it. */
+int rtxh_scene_add_object(rtxh_scene*, const float* P, int32_t nv, const int32_t* idx, int32_t nt, const float* N, const float* UV, const float* S,
+                          const int32_t* tri_material, const uint8_t* tri_flags);
+/* ObjectInstance (rc/api.rs:1053-1090): a TransformedPrimitive over `object` with primitive_to_world = o2w (and its inverse w2o, row-major 4x4). The
+ * object's tree is traversed in object space (rc/primitive.rs:90-101) - nothing is copied. Returns the instance's index. */
+int rtxh_scene_add_instance(rtxh_scene*, int32_t object, const float* o2w16, const float* w2o16);
 /* Alpha masks of the meshes, after rtxh_scene_set_mesh: per triangle {alpha, shadowalpha} float-texture ids or -1 (TriangleMesh::create,
  * rc/shapes/mesh.rs:134-156: a named float texture, or the constant 0 when the float parameter is 0). NULL removes all masks. */
 int rtxh_scene_set_alpha(rtxh_scene*, const int32_t* tri_alpha2);

@@ -54,7 +54,7 @@ RGB PathIntegrator::estimate_direct(const SurfaceInteraction& it, const Bsdf& bs
       if (scene->intersect(ray, &light_isect, &st.mis)) {
         int tri = scene->ordered[light_isect.prim];
         // area_light.id() == light.id()  (mod.rs:295-304): ids are indices into scene.lights here
-        if (scene->tri_light[tri] >= 0 && scene->tri_light[tri] == light_index) li2 = scene->isect_le(light_isect, -bs.wi);
+        if (!scene->is_instance(tri) && scene->tri_light[tri] >= 0 && scene->tri_light[tri] == light_index) li2 = scene->isect_le(light_isect, -bs.wi);
         else li2 = rgb(0, 0, 0);
       } else {
         li2 = scene->light_le(light, ray);
@@ -95,8 +95,7 @@ RGB PathIntegrator::li(Ray ray, ZeroTwoSequence& sampler, PathStats& st) const {
     if (!found || bounces >= max_depth) break;
     compute_differential(isect, ray);  // interaction.rs:192-203
     Bsdf bsdf;
-    int tri = scene->ordered[isect.prim];
-    scene->build_bsdf(scene->tri_material[tri], isect, &bsdf);
+    scene->build_bsdf(scene->material_of(isect), isect, &bsdf);
     const Distribution1D* d = distrib->lookup(isect.hit.p);
     if (bsdf.num_components(BSDF_ALL & ~BSDF_SPECULAR) > 0) {
       st.nee_total += 1;
@@ -190,12 +189,33 @@ int orc_scene_set_alpha(void* h, const int32_t* tri_alpha2) {  // after orc_scen
 int orc_scene_add_sphere(void* h, const float* o2w16, const float* w2o16, float radius, float a, float b, float phi_max, int reverse_orientation,
                          int material, int light, int kind) {
   Scene* s = (Scene*)h;
+  if (!s->instances.empty()) return -1;  // primitive ids: triangles, spheres, instances - in this order
   Transform t; memcpy(t.m.m, o2w16, 64); memcpy(t.m_inv.m, w2o16, 64);
   Sphere sp = kind == QUADRIC_DISK ? disk_new(t, a, radius, b, phi_max, reverse_orientation != 0)
             : kind == QUADRIC_CYLINDER ? cylinder_new(t, radius, a, b, phi_max, reverse_orientation != 0) : sphere_new(t, radius, a, b, phi_max, reverse_orientation != 0);
   s->spheres.push_back(sp);
   s->tri_material.push_back(material); s->tri_light.push_back(light);
   s->tri_flags.push_back((uint8_t)((sp.reverse_orientation != sp.swaps_handedness) ? 1 : 0));
+  return (int)(s->n_prims() - 1);
+}
+// ObjectBegin ... ObjectEnd (api.rs:1019-1051): a triangle mesh in object space (vertices as the shapes' own CTMs leave them); tri_material indexes the
+// scene's materials. Returns the object's index.
+int orc_scene_add_object(void* h, const float* P, int nv, const int32_t* idx, int nt, const float* N, const float* UV, const float* S,
+                         const int32_t* tri_material, const uint8_t* tri_flags) {
+  Scene* s = (Scene*)h;
+  auto o = std::make_shared<Scene>();
+  std::vector<int32_t> no_light((size_t)nt, -1);
+  if (nt <= 0 || orc_scene_set_mesh(o.get(), P, nv, idx, nt, N, UV, S, tri_material, no_light.data(), tri_flags) != 0) return -1;
+  s->objects.push_back(o);
+  return (int)s->objects.size() - 1;
+}
+// ObjectInstance (api.rs:1053-1090): TransformedPrimitive{object, primitive_to_world = the CTM}. Returns the primitive id. After every sphere.
+int orc_scene_add_instance(void* h, int object, const float* o2w16, const float* w2o16) {
+  Scene* s = (Scene*)h;
+  if (object < 0 || (size_t)object >= s->objects.size()) return -1;
+  Scene::Instance in; in.object = object; memcpy(in.o2w.m, o2w16, 64); memcpy(in.w2o.m, w2o16, 64);
+  s->instances.push_back(in);
+  s->tri_material.push_back(-1); s->tri_light.push_back(-1); s->tri_flags.push_back(0);
   return (int)(s->n_prims() - 1);
 }
 int orc_scene_add_mipmap(void* h, int w, int hgt, const float* rgbdata, int trilinear, float max_aniso, int wrap) {
@@ -305,8 +325,8 @@ int orc_trace(void* h, const float* rays, int64_t n, int any_hit, float* out_hit
     if (any_hit) {
       o[0] = s->intersect_p(ray, &tc) ? 1.0f : 0.0f; o[1] = o[2] = o[3] = 0.0f;
     } else {
-      int prim; TriHit th;
-      if (s->intersect_raw(ray, &prim, &th, &tc)) { o[0] = th.t; o[1] = bits2f((uint32_t)prim); o[2] = th.b0; o[3] = th.b1; }
+      int prim, osub = -1; TriHit th;
+      if (s->intersect_raw(ray, &prim, &th, &tc, &osub)) { o[0] = th.t; o[1] = bits2f((uint32_t)s->hit_id(prim, osub)); o[2] = th.b0; o[3] = th.b1; }
       else { o[0] = kInf; o[1] = bits2f(0xffffffffu); o[2] = o[3] = 0.0f; }
     }
   }

@@ -122,7 +122,20 @@ void Scene::build_bvh() {
   if (n == 0) return;
   std::vector<PrimInfo> info(n);
   for (size_t i = 0; i < n; ++i) {
-    B3 bb = is_sphere((int)i) ? quadric_world_bounds(sphere_of((int)i)) : tri_world_bounds((int)i);
+    B3 bb;
+    if (is_instance((int)i)) {  // TransformedPrimitive::world_bounds (primitive.rs:86-88): Transform * Bounds3f, the 8 corners (transform.rs:342-378)
+      const Instance& in = instance_of((int)i);
+      Scene& o = *objects[in.object];
+      if (o.nodes.empty()) { o.max_prims_per_node = max_prims_per_node; o.build_bvh(); }
+      const B3 ob = o.n_prims() == 1 ? (o.is_sphere(0) ? quadric_world_bounds(o.sphere_of(0)) : o.tri_world_bounds(0)) : o.nodes[0].bounds;
+      bb = b3_from_points(xf_point(in.o2w, v3(ob.mn.x, ob.mn.y, ob.mn.z)), xf_point(in.o2w, v3(ob.mx.x, ob.mn.y, ob.mn.z)));
+      bb = b3_union_p(bb, xf_point(in.o2w, v3(ob.mn.x, ob.mx.y, ob.mn.z)));
+      bb = b3_union_p(bb, xf_point(in.o2w, v3(ob.mn.x, ob.mn.y, ob.mx.z)));
+      bb = b3_union_p(bb, xf_point(in.o2w, v3(ob.mn.x, ob.mx.y, ob.mx.z)));
+      bb = b3_union_p(bb, xf_point(in.o2w, v3(ob.mx.x, ob.mx.y, ob.mn.z)));
+      bb = b3_union_p(bb, xf_point(in.o2w, v3(ob.mx.x, ob.mn.y, ob.mx.z)));
+      bb = b3_union_p(bb, xf_point(in.o2w, v3(ob.mx.x, ob.mx.y, ob.mx.z)));
+    } else bb = is_sphere((int)i) ? quadric_world_bounds(sphere_of((int)i)) : tri_world_bounds((int)i);
     info[i].prim_number = (int)i;
     info[i].bounds = bb;
     info[i].centroid = 0.5f * bb.mn + 0.5f * bb.mx;  // :532
@@ -280,10 +293,41 @@ static inline bool slab_test(const B3& b, const Ray& ray, V3 inv_dir, const int 
   return tmin < ray.t_max && tmax > 0.0f;
 }
 
-bool Scene::intersect_raw(Ray& ray, int* prim_out, TriHit* hit_out, TraceCounters* tc) const {  // bvh/mod.rs:366-433
+// What object_instance wraps in a TransformedPrimitive (api.rs:1073-1086): the aggregate built over the object's primitives, or - for exactly one - that primitive itself
+bool Scene::object_intersect_raw(Ray& ray, int* prim_out, TriHit* hit_out, TraceCounters* tc) const {
+  if (n_prims() == 1) {
+    if (tc) tc->tris += 1;
+    TriHit h;
+    if (!prim_test(0, ray, &h)) return false;
+    if (tc) tc->tri_hits += 1;
+    ray.t_max = h.t; *prim_out = 0; *hit_out = h;
+    return true;
+  }
+  const uint64_t rays = tc ? tc->rays_closest : 0;
+  const bool r = intersect_raw(ray, prim_out, hit_out, tc);
+  if (tc) tc->rays_closest = rays;  // the nested walk is part of the outer ray
+  return r;
+}
+bool Scene::object_intersect_p(const Ray& ray, TraceCounters* tc) const {
+  if (n_prims() == 1) {
+    if (tc) tc->tris += 1;
+    TriHit h;
+    const bool r = prim_test(0, ray, &h);
+    if (r && tc) tc->tri_hits += 1;
+    return r;
+  }
+  const uint64_t rays = tc ? tc->rays_any : 0;
+  const bool r = intersect_p(ray, tc);
+  if (tc) tc->rays_any = rays;
+  return r;
+}
+// Transform * Ray (ray.rs:83-93): origin as a point, direction as a vector, t_max kept - no error offset (unlike Ray::transform)
+static inline Ray ray_to_object(const M44& w2o, const Ray& ray) { Ray r = ray; r.o = xf_point(w2o, ray.o); r.d = xf_vector(w2o, ray.d); return r; }
+
+bool Scene::intersect_raw(Ray& ray, int* prim_out, TriHit* hit_out, TraceCounters* tc, int* sub_out) const {  // bvh/mod.rs:366-433
   if (tc) tc->rays_closest += 1;
   if (nodes.empty()) return false;
-  bool found = false; int best_prim = -1; TriHit best{};
+  bool found = false; int best_prim = -1, best_sub = -1; TriHit best{};
   int to_visit = 0, cur = 0; int stack[64];
   V3 inv_dir = v3(1.0f / ray.d.x, 1.0f / ray.d.y, 1.0f / ray.d.z);
   int neg[3] = {inv_dir.x < 0.0f, inv_dir.y < 0.0f, inv_dir.z < 0.0f};
@@ -296,11 +340,18 @@ bool Scene::intersect_raw(Ray& ray, int* prim_out, TriHit* hit_out, TraceCounter
           int prim = (int)node.offset + i;
           if (tc) tc->tris += 1;
           TriHit h;
+          if (is_instance(ordered[prim])) {  // TransformedPrimitive::intersect (primitive.rs:90-96)
+            const Instance& in = instance_of(ordered[prim]);
+            Ray r = ray_to_object(in.w2o, ray);
+            int oprim;
+            if (objects[in.object]->object_intersect_raw(r, &oprim, &h, tc)) { ray.t_max = r.t_max; found = true; best_prim = prim; best_sub = oprim; best = h; }
+            continue;
+          }
           // `result = prim.intersect(ray).or(result)`: every accepted test replaces the result and
           // shrinks ray.t_max (GeometricPrimitive::intersect, primitive.rs:45-51)
           if (prim_test(ordered[prim], ray, &h) && !tri_alpha_rejects(ordered[prim], ray, h, false)) {
             if (tc) tc->tri_hits += 1;
-            ray.t_max = h.t; found = true; best_prim = prim; best = h;
+            ray.t_max = h.t; found = true; best_prim = prim; best_sub = -1; best = h;
           }
         }
         if (to_visit == 0) break;
@@ -314,12 +365,32 @@ bool Scene::intersect_raw(Ray& ray, int* prim_out, TriHit* hit_out, TraceCounter
       cur = stack[--to_visit];
     }
   }
-  if (found) { *prim_out = best_prim; *hit_out = best; }
+  if (found) { *prim_out = best_prim; *hit_out = best; if (sub_out) *sub_out = best_sub; }
   return found;
 }
 bool Scene::intersect(Ray& ray, SurfaceInteraction* si, TraceCounters* tc) const {
-  int prim; TriHit h;
-  if (!intersect_raw(ray, &prim, &h, tc)) return false;
+  int prim, osub = -1; TriHit h;
+  if (!intersect_raw(ray, &prim, &h, tc, &osub)) return false;
+  if (is_instance(ordered[prim])) {  // the object's interaction, then SurfaceInteraction::transform(primitive_to_world) (interaction.rs:156-190)
+    const Instance& in = instance_of(ordered[prim]);
+    const Scene& o = *objects[in.object];
+    const Ray r = ray_to_object(in.w2o, ray);
+    SurfaceInteraction s;
+    o.prim_fill_interaction(o.ordered[osub], r, h, &s);
+    SurfaceInteraction t;
+    V3 perr;
+    t.hit.p = xf_point_with_error(in.o2w, s.hit.p, s.hit.p_error, &perr); t.hit.p_error = perr;
+    t.hit.wo = normalize(xf_vector(in.o2w, s.hit.wo));
+    t.hit.n = normalize(xf_normal(in.w2o, s.hit.n));
+    t.uv = s.uv;
+    t.dpdu = xf_vector(in.o2w, s.dpdu); t.dpdv = xf_vector(in.o2w, s.dpdv);
+    t.shading.n = normalize(xf_normal(in.w2o, s.shading.n));
+    t.shading.dpdu = xf_vector(in.o2w, s.shading.dpdu); t.shading.dpdv = xf_vector(in.o2w, s.shading.dpdv);
+    t.shading.n = face_forward(t.shading.n, t.hit.n);
+    t.prim = prim; t.sub = osub;
+    *si = t;
+    return true;
+  }
   // The reference builds the full SurfaceInteraction for every accepted candidate (mesh.rs:321-425);
   // only the last one survives, so building it once for the final hit gives the same value.
   prim_fill_interaction(ordered[prim], ray, h, si);
@@ -353,6 +424,11 @@ bool Scene::intersect_p(const Ray& ray, TraceCounters* tc) const {  // bvh/mod.r
         for (int i = 0; i < node.n_prims; ++i) {
           if (tc) tc->tris += 1;
           TriHit h;
+          if (is_instance(ordered[node.offset + i])) {  // TransformedPrimitive::intersect_p (primitive.rs:98-101)
+            const Instance& in = instance_of(ordered[node.offset + i]);
+            if (objects[in.object]->object_intersect_p(ray_to_object(in.w2o, ray), tc)) return true;
+            continue;
+          }
           if (prim_test(ordered[node.offset + i], ray, &h) && !tri_alpha_rejects(ordered[node.offset + i], ray, h, true)) { if (tc) tc->tri_hits += 1; return true; }
         }
         if (to_visit == 0) break;
@@ -596,7 +672,10 @@ void Scene::bump(int tex, SurfaceInteraction& si) const {
   V3 dpdv = si.shading.dpdv + (v_displace - displace) / dv * si.shading.n + displace * dndv;
   // set_shading_geometry(dpdu, dpdv, dndu, dndv, false), interaction.rs:218-242
   si.shading.n = normalize(cross(dpdu, dpdv));
-  if (si.prim >= 0 && (tri_flags[ordered[si.prim]] & 1)) si.shading.n = si.shading.n * -1.0f;  // reverse_orientation ^ transform_swaps_handedness
+  if (si.prim >= 0) {  // reverse_orientation ^ transform_swaps_handedness of si.shape: the object's shape for a hit inside an instance
+    int tri; const Scene& o = owner_of(si, &tri);
+    if (o.tri_flags[tri] & 1) si.shading.n = si.shading.n * -1.0f;
+  }
   si.shading.n = face_forward(si.shading.n, si.hit.n);
   si.shading.dpdu = dpdu; si.shading.dpdv = dpdv;
 }

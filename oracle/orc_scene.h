@@ -46,6 +46,7 @@ struct SurfaceInteraction {  // rc/interaction.rs:78-104
   V3 dpdx{0, 0, 0}, dpdy{0, 0, 0};
   float dudx = 0, dvdx = 0, dudy = 0, dvdy = 0;
   int prim = -1;  // index into ordered primitive list
+  int sub = -1;   // hit inside an object instance (prim names the TransformedPrimitive): index into the OBJECT's ordered primitive list
   struct { V3 n, dpdu, dpdv; } shading;
 };
 
@@ -208,8 +209,35 @@ struct Scene {
   // ---- analytic spheres (rc/shapes/sphere.rs): primitive ids n_tris() .. n_prims() - 1; tri_material / tri_light / tri_flags carry their entries too
   // (bit0 of the flags: reverse_orientation ^ swaps_handedness, as for triangles)
   std::vector<Sphere> spheres;
-  size_t n_prims() const { return n_tris() + spheres.size(); }
-  bool is_sphere(int prim) const { return (size_t)prim >= n_tris(); }
+  // ---- object instances (TransformedPrimitive, rc/primitive.rs:79-118; api.rs:1053-1090): primitive ids after the spheres. An object is a triangle
+  // mesh in OBJECT space with its own BVH (the aggregate object_instance builds over more than one primitive; a single primitive is wrapped as it is);
+  // its tri_material entries index THIS scene's materials, it holds no lights (area lights inside object definitions are refused by the host layer).
+  struct Instance { int object; M44 o2w, w2o; };
+  std::vector<std::shared_ptr<Scene>> objects;
+  std::vector<Instance> instances;
+  size_t n_prims() const { return n_tris() + spheres.size() + instances.size(); }
+  bool is_sphere(int prim) const { return (size_t)prim >= n_tris() && (size_t)prim < n_tris() + spheres.size(); }
+  bool is_instance(int prim) const { return (size_t)prim >= n_tris() + spheres.size(); }
+  const Instance& instance_of(int prim) const { return instances[(size_t)prim - n_tris() - spheres.size()]; }
+  // the scene and input-order primitive id that carry a hit's material / flags: the object's for a hit inside an instance
+  const Scene& owner_of(const SurfaceInteraction& si, int* tri) const {
+    const int top = ordered[si.prim];
+    if (!is_instance(top)) { *tri = top; return *this; }
+    const Scene& o = *objects[instance_of(top).object];
+    *tri = o.ordered[si.sub];
+    return o;
+  }
+  int material_of(const SurfaceInteraction& si) const { int tri; const Scene& o = owner_of(si, &tri); return o.tri_material[tri]; }
+  // The id a hit record carries (rt_trace_closest, include/rtx_hip.h): the leaf-order index of a top-level primitive, or - inside instance k (in
+  // add_instance order) - n_prims() + (primitives of the objects of instances 0 .. k-1) + the object's leaf-order index
+  int64_t hit_id(int prim, int sub_) const {
+    const int top = ordered[prim];
+    if (!is_instance(top)) return prim;
+    const size_t k = (size_t)top - n_tris() - spheres.size();
+    int64_t base = (int64_t)n_prims();
+    for (size_t j = 0; j < k; ++j) base += (int64_t)objects[instances[j].object]->n_prims();
+    return base + sub_;
+  }
   const Sphere& sphere_of(int prim) const { return spheres[(size_t)prim - n_tris()]; }
   float shape_area(int prim) const { return is_sphere(prim) ? quadric_area(sphere_of(prim)) : tri_area(prim); }
   // Shape::intersect of primitive `prim`, hit test only: triangles give barycentrics, spheres t alone
@@ -252,7 +280,9 @@ struct Scene {
   bool tri_test(int tri, const Ray& ray, TriHit* h) const;          // mesh.rs:215-319 / 428-532 (shared hit test)
   bool tri_alpha_rejects(int tri, const Ray& ray, const TriHit& h, bool shadow_ray) const;  // mesh.rs:353-370 (intersect), 534-582 (intersect_p)
   void tri_fill_interaction(int tri, const Ray& ray, const TriHit& h, SurfaceInteraction* si) const;  // mesh.rs:321-425
-  bool intersect_raw(Ray& ray, int* prim_out, TriHit* hit_out, TraceCounters* tc) const;  // bvh/mod.rs:366-433
+  bool intersect_raw(Ray& ray, int* prim_out, TriHit* hit_out, TraceCounters* tc, int* sub_out = nullptr) const;  // bvh/mod.rs:366-433
+  bool object_intersect_raw(Ray& ray, int* prim_out, TriHit* hit_out, TraceCounters* tc) const;  // the primitive a TransformedPrimitive wraps: the BVH, or the single primitive
+  bool object_intersect_p(const Ray& ray, TraceCounters* tc) const;
   bool intersect(Ray& ray, SurfaceInteraction* si, TraceCounters* tc) const;
   bool intersect_p(const Ray& ray, TraceCounters* tc) const;        // bvh/mod.rs:435-501
   // ---- lights
@@ -263,6 +293,7 @@ struct Scene {
   }
   RGB isect_le(const SurfaceInteraction& si, V3 w) const {  // interaction.rs:149-154
     int tri = ordered[si.prim];
+    if (is_instance(tri)) return rgb(0, 0, 0);  // objects hold no emitters here
     int li = tri_light[tri];
     if (li < 0) return rgb(0, 0, 0);
     return area_light_l(lights[li], si.hit, w);

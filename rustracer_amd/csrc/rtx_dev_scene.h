@@ -23,6 +23,9 @@ struct DLight {
   int nu, nv; const float* func; const float* cdf; const float* func_int; const float* mfunc; const float* mcdf; float mfunc_int;
 };
 struct DSphere;  // rtx_dev_sphere.h
+// An object instance (rt_instance): primitive_to_world and its inverse, where the object's tree and primitives sit in the scene's arrays, and the first
+// hit id of this instance (n_top_prims + the primitives of the instances before it)
+struct DInstance { float o2w[16], w2o[16]; unsigned node_base, n_nodes, prim_base, n_prims, id_base, pad[3]; };
 struct DScene {
   const float4* nodes; unsigned n_nodes;
   const float4* pairs;  // n_nodes x 64 B child-pair records of the interior nodes (NULL for LDS-resident scenes), see k_trace_pair
@@ -31,6 +34,7 @@ struct DScene {
   const float4* tri_p; unsigned n_tris;
   const float* tri_n; const float* tri_uv; const float* tri_s;
   const int2* tri_alpha;  // {alpha, shadowalpha} texture ids of the triangles whose flags carry bit 4 / bit 5 (NULL: no mask in the scene)
+  const DInstance* instances; unsigned n_instances, n_top_prims;  // object instances (RT_FLAG_INSTANCE primitives); primitives [0, n_top_prims) are the top level's
   const DSphere* spheres; // analytic spheres: a primitive whose flags carry bit 6 (RT_PRIM_SPHERE) holds its world box in p0 / p1 and its index as the bits of p2.x
   const DTexture* textures; const DImage* images; const DMaterial* materials; const DLight* lights;
   int n_lights; int n_infinite; int infinite_ids[4];
@@ -151,6 +155,7 @@ RT_DEV int tri_material(const float4* tri_p, int prim) { return __float_as_int(t
 RT_DEV int tri_light(const float4* tri_p, int prim) { return __float_as_int(tri_p[3 * prim + 1].w); }
 RT_DEV unsigned tri_flags(const float4* tri_p, int prim) { return __float_as_uint(tri_p[3 * prim + 2].w); }
 #define RT_FLAG_SPHERE 64u
+#define RT_FLAG_INSTANCE 128u
 RT_DEV unsigned prim_sphere_index(const float4* tri_p, int prim) { return __float_as_uint(tri_p[3 * prim + 2].x); }
 
 // ---------------------------------------------------------------- interactions (rc/interaction.rs)

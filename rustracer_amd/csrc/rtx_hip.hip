@@ -61,6 +61,8 @@ struct rt_scene {
   DevBuf quads; bool use_quads = false; int quad_stack_depth = 0;  // four-wide records of the any-hit kernel (k_trace_quad)
   DevBuf nodes, tri_p, tri_n, tri_uv, tri_s, tri_alpha, spheres, textures, images, materials, lights, texels, dist;
   bool has_spheres = false;
+  bool has_instances = false;  // object instances: two-level traversal in k_trace_big<.., GENERAL>, every vertex shaded by k_shade<0, true>
+  DevBuf instances;
   bool general_prims = false;  // alpha-masked triangles: traced by k_trace_big<.., GENERAL> only
   bool masked_emitters = false;  // ... and some of them emit: every vertex is shaded by k_shade<0, true> (Shape::pdf_wi evaluates the mask)
   std::vector<DLight> h_lights;
@@ -138,6 +140,12 @@ extern "C" int rt_scene_create(const rt_scene_desc* desc, int device, rt_scene**
     if ((m.flags & RT_TRI_HAS_N) && !desc->tri_n) { delete s; return fail(RT_ERR_INVALID, "tri flags need tri_n"); }
     if ((m.flags & RT_TRI_HAS_UV) && !desc->tri_uv) { delete s; return fail(RT_ERR_INVALID, "tri flags need tri_uv"); }
     if ((m.flags & RT_TRI_HAS_S) && !desc->tri_s) { delete s; return fail(RT_ERR_INVALID, "tri flags need tri_s"); }
+    if (m.flags & RT_PRIM_INSTANCE) {
+      uint32_t k; memcpy(&k, p + 6, 4);
+      if (!desc->instances || k >= desc->n_instances || i >= desc->n_top_prims) { delete s; return fail(RT_ERR_INVALID, "instance index out of range"); }
+      if (m.flags != RT_PRIM_INSTANCE || m.light >= 0) { delete s; return fail(RT_ERR_INVALID, "an instance primitive carries triangle attributes or a light"); }
+      continue;
+    }
     if (m.material < 0 || (uint32_t)m.material >= desc->n_materials) { delete s; return fail(RT_ERR_INVALID, "material index out of range"); }
     if (m.light >= (int)desc->n_lights) { delete s; return fail(RT_ERR_INVALID, "light index out of range"); }
     if (m.flags & (RT_TRI_HAS_ALPHA | RT_TRI_HAS_SHADOW_ALPHA)) {
@@ -159,6 +167,27 @@ extern "C" int rt_scene_create(const rt_scene_desc* desc, int device, rt_scene**
       s->has_spheres = true;
     }
   if (s->has_spheres) { TRY_RC(upload(s->spheres, desc->spheres, (size_t)desc->n_spheres * sizeof(rt_sphere))); s->general_prims = true; }
+  const uint32_t n_top_nodes = desc->n_instances ? desc->n_top_nodes : desc->n_nodes, n_top_prims = desc->n_instances ? desc->n_top_prims : desc->n_tris;
+  if (desc->n_instances) {  // rt_instance -> DInstance: + the first hit id of each instance
+    if (!desc->instances || n_top_nodes == 0 || n_top_nodes > desc->n_nodes || n_top_prims == 0 || n_top_prims > desc->n_tris) { delete s; return fail(RT_ERR_INVALID, "bad instance tables"); }
+    std::vector<DInstance> di(desc->n_instances);
+    uint64_t id = n_top_prims;
+    for (uint32_t k = 0; k < desc->n_instances; ++k) {
+      const rt_instance& in = desc->instances[k];
+      if (in.n_prims == 0 || (uint64_t)in.prim_base + in.n_prims > desc->n_tris || in.prim_base < n_top_prims || (in.n_nodes == 0 && in.n_prims != 1) ||
+          (in.n_nodes != 0 && ((uint64_t)in.node_base + in.n_nodes > desc->n_nodes || in.node_base < n_top_nodes))) { delete s; return fail(RT_ERR_INVALID, "instance ranges out of bounds"); }
+      for (uint32_t t = in.prim_base; t < in.prim_base + in.n_prims; ++t)
+        if (desc->tri_meta[t].flags & (RT_PRIM_SPHERE | RT_PRIM_INSTANCE | RT_TRI_HAS_ALPHA | RT_TRI_HAS_SHADOW_ALPHA) || desc->tri_meta[t].light >= 0) {
+          delete s; return fail(RT_ERR_UNSUPPORTED, "an instanced object holds triangles without masks and without area lights only");
+        }
+      memcpy(di[k].o2w, in.o2w, 64); memcpy(di[k].w2o, in.w2o, 64);
+      di[k].node_base = in.node_base; di[k].n_nodes = in.n_nodes; di[k].prim_base = in.prim_base; di[k].n_prims = in.n_prims; di[k].id_base = (unsigned)id;
+      id += in.n_prims;
+      if (id >= (1ull << 31)) { delete s; return fail(RT_ERR_UNSUPPORTED, "more than 2^31 instanced primitives"); }
+    }
+    TRY_RC(upload(s->instances, di.data(), di.size() * sizeof(DInstance)));
+    s->has_instances = true; s->general_prims = true;
+  }
   TRY_RC(upload(s->tri_p, tp.data(), tp.size() * 4));
   if (desc->tri_n) TRY_RC(upload(s->tri_n, desc->tri_n, (size_t)desc->n_tris * 36));
   if (desc->tri_uv) TRY_RC(upload(s->tri_uv, desc->tri_uv, (size_t)desc->n_tris * 24));
@@ -359,6 +388,7 @@ extern "C" int rt_scene_create(const rt_scene_desc* desc, int device, rt_scene**
   d.tri_n = s->tri_n.as<float>(); d.tri_uv = s->tri_uv.as<float>(); d.tri_s = s->tri_s.as<float>();
   d.tri_alpha = s->tri_alpha.p ? s->tri_alpha.as<int2>() : nullptr;
   d.spheres = s->has_spheres ? s->spheres.as<DSphere>() : nullptr;
+  d.instances = s->has_instances ? s->instances.as<DInstance>() : nullptr; d.n_instances = s->has_instances ? desc->n_instances : 0u; d.n_top_prims = n_top_prims;
   d.textures = s->textures.as<DTexture>(); d.images = s->images.as<DImage>(); d.materials = s->materials.as<DMaterial>(); d.lights = s->lights.as<DLight>();
   d.n_lights = (int)desc->n_lights;
   d.wb_min = f3{desc->nodes[0].bmin[0], desc->nodes[0].bmin[1], desc->nodes[0].bmin[2]};
@@ -391,22 +421,33 @@ extern "C" int rt_scene_create(const rt_scene_desc* desc, int device, rt_scene**
   for (uint32_t i = 0; i < desc->n_lights; ++i) if (desc->lights[i].kind != RT_LIGHT_DIFFUSE_AREA) s->lambert_only = false;
   for (uint32_t i = 0; i < desc->n_lights; ++i)
     if (desc->lights[i].kind == RT_LIGHT_DIFFUSE_AREA && (desc->tri_meta[desc->lights[i].prim].flags & RT_TRI_HAS_ALPHA)) s->masked_emitters = true;
-  if (s->has_spheres) s->masked_emitters = true;  // sphere hits, sphere emitters: the generic shade kernel and its GENERAL light functions
+  if (s->has_spheres || s->has_instances) s->masked_emitters = true;  // sphere / instance hits, sphere emitters: the generic shade kernel and its GENERAL functions
   if (s->masked_emitters) { s->lambert_only = false; s->lambert_materials = false; }  // only the generic kernel re-intersects emitters with the mask test
   s->n_materials = desc->n_materials;
   s->small = desc->n_nodes <= RT_SMALL_NODES && desc->n_tris <= RT_SMALL_TRIS && !s->general_prims;
   {  // tree height bounds the number of simultaneously pending stack entries
-    std::vector<int> depth(desc->n_nodes, 0); int maxd = 0;
-    for (uint32_t i = 0; i < desc->n_nodes; ++i) {
-      const rt_bvh_node& n = desc->nodes[i];
-      if (n.n_prims == 0) {
-        if (i + 1 >= desc->n_nodes || n.offset >= desc->n_nodes || n.offset <= i) { delete s; return fail(RT_ERR_INVALID, "malformed BVH"); }
-        depth[i + 1] = depth[i] + 1; depth[n.offset] = depth[i] + 1;
-      } else if ((uint64_t)n.offset + n.n_prims > desc->n_tris) { delete s; return fail(RT_ERR_INVALID, "leaf range out of bounds"); }
-      if (depth[i] > maxd) maxd = depth[i];
-    }
+    // one tree: nodes [base, base + nn), child offsets relative to base, leaf ranges within its np primitives
+    auto tree_depth = [&](uint32_t base, uint32_t nn, uint32_t np, int& maxd) -> bool {
+      std::vector<int> depth(nn, 0); maxd = 0;
+      for (uint32_t i = 0; i < nn; ++i) {
+        const rt_bvh_node& n = desc->nodes[base + i];
+        if (n.n_prims == 0) {
+          if (i + 1 >= nn || n.offset >= nn || n.offset <= i) return false;
+          depth[i + 1] = depth[i] + 1; depth[n.offset] = depth[i] + 1;
+        } else if ((uint64_t)n.offset + n.n_prims > np) return false;
+        if (depth[i] > maxd) maxd = depth[i];
+      }
+      return true;
+    };
+    int maxd = 0;
+    if (!tree_depth(0, n_top_nodes, n_top_prims, maxd)) { delete s; return fail(RT_ERR_INVALID, "malformed BVH"); }
     if (maxd + 1 > 64) { delete s; return fail(RT_ERR_INVALID, "BVH deeper than the 64-entry traversal stack"); }
     s->stack_depth = maxd + 1;
+    for (uint32_t k = 0; k < desc->n_instances; ++k) {
+      const rt_instance& in = desc->instances[k];
+      int od = 0;
+      if (in.n_nodes && (!tree_depth(in.node_base, in.n_nodes, in.n_prims, od) || od + 1 > 64)) { delete s; return fail(RT_ERR_INVALID, "malformed or too deep object BVH"); }
+    }
   }
   d.pairs = nullptr; d.quads = nullptr;
   if (!s->small && !s->general_prims) {  // LDS-resident scenes keep the one-node-per-step loop: the pair form measured no faster there

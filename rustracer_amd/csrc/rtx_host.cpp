@@ -201,7 +201,17 @@ struct rtxh_scene {
   // Shape "sphere": primitive ids n_tris() .. n_prims() - 1
   struct HostSphere { rt_sphere s; int32_t material, light; };
   std::vector<HostSphere> spheres; std::vector<rt_sphere> f_spheres;
-  size_t n_prims() const { return n_tris() + spheres.size(); }
+  // ObjectBegin / ObjectInstance: primitive ids after the spheres. An object keeps its own soup (object space), tree and leaf order.
+  struct HostObject {
+    std::vector<float> P, N, UV, S; std::vector<int32_t> idx, tri_mat; std::vector<uint8_t> tri_flags;
+    std::vector<rt_bvh_node> nodes; std::vector<int32_t> ordered;
+    size_t n_tris() const { return idx.size() / 3; }
+  };
+  struct HostInstance { int32_t object; float o2w[16], w2o[16]; };
+  std::vector<HostObject> objects; std::vector<HostInstance> instances; std::vector<rt_instance> f_instances;
+  std::vector<rt_bvh_node> f_nodes;  // with instances: the top-level tree followed by the objects' trees (what rt_scene_desc::nodes points at)
+  size_t n_top_prims = 0;            // ... and the top-level primitives' share of the flattened arrays
+  size_t n_prims() const { return n_tris() + spheres.size() + instances.size(); }
   std::vector<rt_texture> textures; std::vector<rt_material> materials; std::vector<MipLevels> mips; std::vector<HostLight> lights;
   // BVH products
   std::vector<rt_bvh_node> nodes; std::vector<int32_t> ordered;
@@ -323,26 +333,18 @@ static Box sphere_world_box(const rt_sphere& sp) {
   return bb;
 }
 
-int commit_scene(rtxh_scene* s, int max_prims_per_node) {
-  const size_t n_triangles = s->n_tris();
-  const size_t nt = s->n_prims();  // every primitive: the triangles, then the spheres
-  if (nt == 0) return fail(RT_ERR_INVALID, "no triangles");
+// BVH::new + flatten_bvh over `nt` primitives given by their world boxes (rc/bvh/mod.rs:80-358): nodes in pre-order, `ordered` = leaf order -> primitive
+static void build_tree(size_t nt, const std::vector<Box>& boxes, int max_prims_per_node, std::vector<rt_bvh_node>& nodes, std::vector<int32_t>& ordered) {
   Builder b; b.max_prims = max_prims_per_node > 255 ? 255 : max_prims_per_node;
-  std::vector<int32_t> a_prim(nt); std::vector<Box> a_pb(nt); std::vector<float> a_cx(nt), a_cy(nt), a_cz(nt);
+  std::vector<int32_t> a_prim(nt); std::vector<Box> a_pb(boxes); std::vector<float> a_cx(nt), a_cy(nt), a_cz(nt);
   b.prim = a_prim.data(); b.pb = a_pb.data(); b.cx = a_cx.data(); b.cy = a_cy.data(); b.cz = a_cz.data();
-  for (size_t t = 0; t < nt; ++t) {  // Triangle::world_bounds, mesh.rs:603-608
-    Box bb;
-    if (t >= n_triangles) bb = sphere_world_box(s->spheres[t - n_triangles].s);
-    else {
-      const float* p0 = &s->P[3 * s->idx[3 * t]]; const float* p1 = &s->P[3 * s->idx[3 * t + 1]]; const float* p2 = &s->P[3 * s->idx[3 * t + 2]];
-      for (int k = 0; k < 3; ++k) { bb.lo[k] = pmin(p0[k], p1[k]); bb.hi[k] = pmax(p0[k], p1[k]); }
-      box_extend(bb, p2);
-    }
-    b.prim[t] = (int32_t)t; b.pb[t] = bb;
+  for (size_t t = 0; t < nt; ++t) {
+    const Box& bb = boxes[t];
+    b.prim[t] = (int32_t)t;
     b.cx[t] = 0.5f * bb.lo[0] + 0.5f * bb.hi[0]; b.cy[t] = 0.5f * bb.lo[1] + 0.5f * bb.hi[1]; b.cz[t] = 0.5f * bb.lo[2] + 0.5f * bb.hi[2];  // :532
   }
-  s->ordered.assign(nt, -1);
-  b.ordered = s->ordered.data();
+  ordered.assign(nt, -1);
+  b.ordered = ordered.data();
   int root;
   unsigned n_threads = std::thread::hardware_concurrency(); if (n_threads > 16) n_threads = 16; if (n_threads < 1) n_threads = 1;
   if (nt < 65536 || n_threads == 1) root = b.build(0, nt, 0);
@@ -380,7 +382,7 @@ int commit_scene(rtxh_scene* s, int max_prims_per_node) {
     if (root < -1) root = task_root[(size_t)(-root - 2)];
   }
   // flatten_bvh (:314-358): pre-order, left child adjacent, second child offset patched afterwards
-  s->nodes.clear(); s->nodes.reserve(b.pool.size());
+  nodes.clear(); nodes.reserve(b.pool.size());
   struct Item { int node; int parent_flat; };
   std::vector<Item> st; st.push_back({root, -1});
   while (!st.empty()) {
@@ -388,13 +390,57 @@ int commit_scene(rtxh_scene* s, int max_prims_per_node) {
     const Builder::BNode& n = b.pool[it.node];
     rt_bvh_node out{};
     for (int k = 0; k < 3; ++k) { out.bmin[k] = n.b.lo[k]; out.bmax[k] = n.b.hi[k]; }
-    int me = (int)s->nodes.size();
-    if (it.parent_flat >= 0) s->nodes[it.parent_flat].offset = (uint32_t)me;  // this node is its parent's second child
+    int me = (int)nodes.size();
+    if (it.parent_flat >= 0) nodes[it.parent_flat].offset = (uint32_t)me;  // this node is its parent's second child
     if (n.count > 0) { out.offset = (uint32_t)n.first; out.n_prims = (uint16_t)n.count; out.axis = 0; }
     else { out.offset = 0; out.n_prims = 0; out.axis = (uint8_t)n.axis; }
-    s->nodes.push_back(out);
+    nodes.push_back(out);
     if (n.count == 0) { st.push_back({n.right, me}); st.push_back({n.left, -1}); }
   }
+}
+static Box triangle_box(const std::vector<float>& P, const std::vector<int32_t>& idx, size_t t) {  // Triangle::world_bounds, mesh.rs:603-608
+  const float* p0 = &P[3 * idx[3 * t]]; const float* p1 = &P[3 * idx[3 * t + 1]]; const float* p2 = &P[3 * idx[3 * t + 2]];
+  Box bb;
+  for (int k = 0; k < 3; ++k) { bb.lo[k] = pmin(p0[k], p1[k]); bb.hi[k] = pmax(p0[k], p1[k]); }
+  box_extend(bb, p2);
+  return bb;
+}
+// TransformedPrimitive::world_bounds (primitive.rs:86-88): Transform * Bounds3f - the 8 corners of the object's bounds (transform.rs:342-378)
+static Box instance_world_box(const rtxh_scene::HostObject& o, const float* o2w) {
+  Box ob;
+  if (o.n_tris() == 1) ob = triangle_box(o.P, o.idx, 0);  // a single primitive is wrapped as it is (api.rs:1073-1082)
+  else { for (int k = 0; k < 3; ++k) { ob.lo[k] = o.nodes[0].bmin[k]; ob.hi[k] = o.nodes[0].bmax[k]; } }
+  const int order[8][3] = {{0, 0, 0}, {1, 0, 0}, {0, 1, 0}, {0, 0, 1}, {0, 1, 1}, {1, 1, 0}, {1, 0, 1}, {1, 1, 1}};
+  Box bb;
+  for (int c = 0; c < 8; ++c) {
+    const float x = order[c][0] ? ob.hi[0] : ob.lo[0], y = order[c][1] ? ob.hi[1] : ob.lo[1], z = order[c][2] ? ob.hi[2] : ob.lo[2];
+    float p[3];
+    for (int r = 0; r < 3; ++r) p[r] = o2w[4 * r] * x + o2w[4 * r + 1] * y + o2w[4 * r + 2] * z + o2w[4 * r + 3];
+    const float wp = o2w[12] * x + o2w[13] * y + o2w[14] * z + o2w[15];  // Transform * Point3f, transform.rs:264-286
+    if (wp != 1.0f) for (int r = 0; r < 3; ++r) p[r] = p[r] / wp;
+    if (c == 0) { for (int k = 0; k < 3; ++k) bb.lo[k] = bb.hi[k] = p[k]; }  // Bounds3f::from_point
+    else box_extend(bb, p);
+  }
+  return bb;
+}
+
+int commit_scene(rtxh_scene* s, int max_prims_per_node) {
+  const size_t n_triangles = s->n_tris(), n_geom = n_triangles + s->spheres.size();
+  const size_t nt = s->n_prims();  // every primitive: the triangles, then the spheres, then the object instances
+  if (nt == 0) return fail(RT_ERR_INVALID, "no triangles");
+  for (auto& o : s->objects) {  // make_accelerator over the object's primitives, with the scene's accelerator parameters (api.rs:1073-1080)
+    const size_t on = o.n_tris();
+    std::vector<Box> ob(on);
+    for (size_t t = 0; t < on; ++t) ob[t] = triangle_box(o.P, o.idx, t);
+    build_tree(on, ob, max_prims_per_node, o.nodes, o.ordered);
+  }
+  std::vector<Box> boxes(nt);
+  for (size_t t = 0; t < nt; ++t) {
+    if (t >= n_geom) { const auto& in = s->instances[t - n_geom]; boxes[t] = instance_world_box(s->objects[(size_t)in.object], in.o2w); }
+    else if (t >= n_triangles) boxes[t] = sphere_world_box(s->spheres[t - n_triangles].s);
+    else boxes[t] = triangle_box(s->P, s->idx, t);
+  }
+  build_tree(nt, boxes, max_prims_per_node, s->nodes, s->ordered);
   return finish_commit(s);
 }
 
@@ -402,7 +448,7 @@ int commit_scene(rtxh_scene* s, int max_prims_per_node) {
 int commit_scene_device(rtxh_scene* s, int max_prims_per_node, float* ms_device) {
   const size_t nt = s->n_tris();
   if (nt == 0) return fail(RT_ERR_INVALID, "no triangles");
-  if (!s->spheres.empty()) return fail(RT_ERR_UNSUPPORTED, "the device BVH builder takes triangles only: a scene with analytic spheres is built by the host");
+  if (!s->spheres.empty() || !s->instances.empty()) return fail(RT_ERR_UNSUPPORTED, "the device BVH builder takes triangles only: a scene with analytic spheres or object instances is built by the host");
   std::vector<float> tp(nt * 9);
   for (size_t t = 0; t < nt; ++t) for (int v = 0; v < 3; ++v) for (int k = 0; k < 3; ++k) tp[9 * t + 3 * v + k] = s->P[3 * s->idx[3 * t + v] + k];
   s->nodes.assign(2 * nt - 1, rt_bvh_node{}); s->ordered.assign(nt, -1);
@@ -426,13 +472,63 @@ int finish_commit(rtxh_scene* s) {
   // flatten geometry into leaf order
   std::vector<int32_t> leaf_of(nt, -1);
   for (size_t i = 0; i < nt; ++i) leaf_of[s->ordered[i]] = (int32_t)i;
-  const bool any_n = !s->N.empty(), any_uv = !s->UV.empty(), any_s = !s->S.empty();
-  s->f_p.assign(nt * 9, 0.0f); s->f_meta.assign(nt, rt_tri_meta{});
-  if (any_n) s->f_n.assign(nt * 9, 0.0f); if (any_uv) s->f_uv.assign(nt * 6, 0.0f); if (any_s) s->f_s.assign(nt * 9, 0.0f);
+  bool any_n = !s->N.empty(), any_uv = !s->UV.empty(), any_s = !s->S.empty();
+  const size_t n_geom = n_triangles + s->spheres.size();
+  // object primitives follow the top level's in the same arrays: every INSTANCED object once, in the order of its first instance
+  std::vector<int64_t> obj_prim_base(s->objects.size(), -1), obj_node_base(s->objects.size(), -1);
+  size_t n_all = nt, n_all_nodes = s->nodes.size();
+  for (const auto& in : s->instances) {
+    const size_t o = (size_t)in.object;
+    if (obj_prim_base[o] >= 0) continue;
+    obj_prim_base[o] = (int64_t)n_all; obj_node_base[o] = (int64_t)n_all_nodes;
+    n_all += s->objects[o].n_tris(); n_all_nodes += s->objects[o].nodes.size();
+    any_n = any_n || !s->objects[o].N.empty(); any_uv = any_uv || !s->objects[o].UV.empty(); any_s = any_s || !s->objects[o].S.empty();
+  }
+  s->n_top_prims = nt;
+  s->f_p.assign(n_all * 9, 0.0f); s->f_meta.assign(n_all, rt_tri_meta{});
+  s->f_n.clear(); s->f_uv.clear(); s->f_s.clear();
+  if (any_n) s->f_n.assign(n_all * 9, 0.0f); if (any_uv) s->f_uv.assign(n_all * 6, 0.0f); if (any_s) s->f_s.assign(n_all * 9, 0.0f);
+  s->f_instances.clear(); s->f_nodes.clear();
+  if (!s->instances.empty()) {
+    s->f_nodes = s->nodes; s->f_nodes.resize(n_all_nodes);
+    for (size_t o = 0; o < s->objects.size(); ++o) {
+      if (obj_prim_base[o] < 0) continue;
+      const auto& ob = s->objects[o];
+      std::copy(ob.nodes.begin(), ob.nodes.end(), s->f_nodes.begin() + obj_node_base[o]);
+      const bool on = !ob.N.empty(), ouv = !ob.UV.empty(), os = !ob.S.empty();
+      for (size_t i = 0; i < ob.n_tris(); ++i) {
+        const size_t g = (size_t)obj_prim_base[o] + i; const int32_t t = ob.ordered[i];
+        for (int v = 0; v < 3; ++v) {
+          const int32_t vi = ob.idx[3 * t + v];
+          for (int k = 0; k < 3; ++k) s->f_p[9 * g + 3 * v + k] = ob.P[3 * vi + k];
+          if (on) for (int k = 0; k < 3; ++k) s->f_n[9 * g + 3 * v + k] = ob.N[3 * vi + k];
+          if (os) for (int k = 0; k < 3; ++k) s->f_s[9 * g + 3 * v + k] = ob.S[3 * vi + k];
+          if (ouv) for (int k = 0; k < 2; ++k) s->f_uv[6 * g + 2 * v + k] = ob.UV[2 * vi + k];
+        }
+        s->f_meta[g] = rt_tri_meta{ob.tri_mat[t], -1, (uint32_t)ob.tri_flags[t], (uint32_t)t};
+      }
+    }
+    for (const auto& in : s->instances) {
+      const auto& ob = s->objects[(size_t)in.object];
+      rt_instance ri{};
+      memcpy(ri.o2w, in.o2w, 64); memcpy(ri.w2o, in.w2o, 64);
+      ri.node_base = (uint32_t)obj_node_base[(size_t)in.object]; ri.n_nodes = ob.n_tris() == 1 ? 0u : (uint32_t)ob.nodes.size();
+      ri.prim_base = (uint32_t)obj_prim_base[(size_t)in.object]; ri.n_prims = (uint32_t)ob.n_tris();
+      s->f_instances.push_back(ri);
+    }
+  }
   s->f_spheres.clear();
   for (const auto& hs : s->spheres) s->f_spheres.push_back(hs.s);
   for (size_t i = 0; i < nt; ++i) {
     const int32_t t = s->ordered[i];
+    if ((size_t)t >= n_geom) {  // an object instance: world box in p0 / p1, its index as the bits of p2.x
+      const auto& in = s->instances[(size_t)t - n_geom];
+      const Box bb = instance_world_box(s->objects[(size_t)in.object], in.o2w);
+      for (int k = 0; k < 3; ++k) { s->f_p[9 * i + k] = bb.lo[k]; s->f_p[9 * i + 3 + k] = bb.hi[k]; }
+      const uint32_t ii = (uint32_t)((size_t)t - n_geom); memcpy(&s->f_p[9 * i + 6], &ii, 4);
+      s->f_meta[i] = rt_tri_meta{-1, -1, RT_PRIM_INSTANCE, (uint32_t)t};
+      continue;
+    }
     if ((size_t)t >= n_triangles) {  // a sphere: world box in p0 / p1, its index as the bits of p2.x
       const auto& hs = s->spheres[(size_t)t - n_triangles];
       const Box bb = sphere_world_box(hs.s);
@@ -445,18 +541,18 @@ int finish_commit(rtxh_scene* s) {
     for (int v = 0; v < 3; ++v) {
       const int32_t vi = s->idx[3 * t + v];
       for (int k = 0; k < 3; ++k) s->f_p[9 * i + 3 * v + k] = s->P[3 * vi + k];
-      if (any_n) for (int k = 0; k < 3; ++k) s->f_n[9 * i + 3 * v + k] = s->N[3 * vi + k];
-      if (any_s) for (int k = 0; k < 3; ++k) s->f_s[9 * i + 3 * v + k] = s->S[3 * vi + k];
-      if (any_uv) for (int k = 0; k < 2; ++k) s->f_uv[6 * i + 2 * v + k] = s->UV[2 * vi + k];
+      if (!s->N.empty()) for (int k = 0; k < 3; ++k) s->f_n[9 * i + 3 * v + k] = s->N[3 * vi + k];
+      if (!s->S.empty()) for (int k = 0; k < 3; ++k) s->f_s[9 * i + 3 * v + k] = s->S[3 * vi + k];
+      if (!s->UV.empty()) for (int k = 0; k < 2; ++k) s->f_uv[6 * i + 2 * v + k] = s->UV[2 * vi + k];
     }
     s->f_meta[i] = rt_tri_meta{s->tri_mat[t], s->tri_light[t], (uint32_t)s->tri_flags[t], (uint32_t)t};
   }
   s->f_alpha.clear();
   if (!s->tri_alpha.empty()) {
-    s->f_alpha.assign(nt * 2, -1);
+    s->f_alpha.assign(n_all * 2, -1);
     for (size_t i = 0; i < nt; ++i) {
       const int32_t t = s->ordered[i];
-      if ((size_t)t >= n_triangles) continue;  // spheres carry no mask
+      if ((size_t)t >= n_triangles) continue;  // spheres and instances carry no mask
       for (int k = 0; k < 2; ++k) {
         const int32_t id = s->tri_alpha[2 * (size_t)t + k];
         if (id >= (int32_t)s->textures.size()) return fail(RT_ERR_INVALID, "alpha texture out of range");
@@ -479,7 +575,7 @@ int finish_commit(rtxh_scene* s) {
     rt_light l = hl.l;
     if (l.kind == RT_LIGHT_DIFFUSE_AREA) {
       if (hl.tri_source <= -2) hl.tri_source = (int)(n_triangles + (size_t)(-2 - hl.tri_source));  // -2 - k: the light sits on sphere k
-      if (hl.tri_source < 0 || (size_t)hl.tri_source >= nt) return fail(RT_ERR_INVALID, "area light triangle out of range");
+      if (hl.tri_source < 0 || (size_t)hl.tri_source >= n_geom) return fail(RT_ERR_INVALID, "area light triangle out of range");
       l.prim = leaf_of[hl.tri_source];
       if ((size_t)hl.tri_source >= n_triangles) {
         const rt_sphere& sp = s->spheres[(size_t)hl.tri_source - n_triangles].s;
@@ -508,10 +604,15 @@ int finish_commit(rtxh_scene* s) {
 rt_scene_desc make_desc(rtxh_scene* s) {
   rt_scene_desc d{};
   d.n_nodes = (uint32_t)s->nodes.size(); d.nodes = s->nodes.data();
+  if (!s->f_instances.empty()) {
+    d.n_top_nodes = d.n_nodes; d.n_nodes = (uint32_t)s->f_nodes.size(); d.nodes = s->f_nodes.data();
+    d.n_instances = (uint32_t)s->f_instances.size(); d.instances = s->f_instances.data();
+  }
   d.n_tris = (uint32_t)s->n_tris(); d.tri_p = s->f_p.data();
   d.tri_n = s->f_n.empty() ? nullptr : s->f_n.data(); d.tri_uv = s->f_uv.empty() ? nullptr : s->f_uv.data(); d.tri_s = s->f_s.empty() ? nullptr : s->f_s.data();
   d.tri_meta = s->f_meta.data(); d.tri_alpha = s->f_alpha.empty() ? nullptr : s->f_alpha.data();
-  d.n_tris = (uint32_t)s->n_prims(); d.n_spheres = (uint32_t)s->f_spheres.size(); d.spheres = s->f_spheres.empty() ? nullptr : s->f_spheres.data();
+  d.n_tris = (uint32_t)s->n_prims(); d.n_spheres = (uint32_t)s->f_spheres.size();
+  if (!s->f_instances.empty()) { d.n_top_prims = d.n_tris; d.n_tris = (uint32_t)(s->f_meta.size()); } d.spheres = s->f_spheres.empty() ? nullptr : s->f_spheres.data();
   d.n_textures = (uint32_t)s->textures.size(); d.textures = s->textures.data();
   d.n_images = (uint32_t)s->f_images.size(); d.images = s->f_images.data();
   d.n_materials = (uint32_t)s->materials.size(); d.materials = s->materials.data();
@@ -617,6 +718,27 @@ int rtxh_scene_add_quadric(rtxh_scene* s, int32_t kind, const float* o2w16, cons
   return (int)s->spheres.size() - 1;
 }
 
+int rtxh_scene_add_object(rtxh_scene* s, const float* P, int32_t nv, const int32_t* idx, int32_t nt, const float* N, const float* UV, const float* S,
+                          const int32_t* tri_material, const uint8_t* tri_flags) {
+  if (!s || !P || !idx || !tri_material || !tri_flags || nv <= 0 || nt <= 0) return fail(RT_ERR_INVALID, "bad object mesh");
+  rtxh_scene::HostObject o;
+  o.P.assign(P, P + 3 * (size_t)nv); o.idx.assign(idx, idx + 3 * (size_t)nt);
+  if (N) o.N.assign(N, N + 3 * (size_t)nv); if (UV) o.UV.assign(UV, UV + 2 * (size_t)nv); if (S) o.S.assign(S, S + 3 * (size_t)nv);
+  o.tri_mat.assign(tri_material, tri_material + nt); o.tri_flags.assign(tri_flags, tri_flags + nt);
+  for (int32_t i = 0; i < 3 * nt; ++i) if (idx[i] < 0 || idx[i] >= nv) return fail(RT_ERR_INVALID, "object vertex index out of range");
+  for (int32_t i = 0; i < nt; ++i) {
+    const uint8_t f = tri_flags[i];
+    if (((f & RT_TRI_HAS_N) && !N) || ((f & RT_TRI_HAS_UV) && !UV) || ((f & RT_TRI_HAS_S) && !S)) return fail(RT_ERR_INVALID, "object triangle flags name a missing attribute array");
+  }
+  s->objects.push_back(std::move(o)); s->committed = false;
+  return (int)s->objects.size() - 1;
+}
+int rtxh_scene_add_instance(rtxh_scene* s, int32_t object, const float* o2w16, const float* w2o16) {
+  if (!s || !o2w16 || !w2o16 || object < 0 || (size_t)object >= s->objects.size()) return fail(RT_ERR_INVALID, "bad object instance");
+  rtxh_scene::HostInstance in; in.object = object; memcpy(in.o2w, o2w16, 64); memcpy(in.w2o, w2o16, 64);
+  s->instances.push_back(in); s->committed = false;
+  return (int)s->instances.size() - 1;
+}
 int rtxh_scene_set_alpha(rtxh_scene* s, const int32_t* tri_alpha2) {
   if (!s) return fail(RT_ERR_INVALID, "null scene");
   if (!tri_alpha2) s->tri_alpha.clear(); else s->tri_alpha.assign(tri_alpha2, tri_alpha2 + 2 * s->n_tris());

@@ -600,6 +600,31 @@ __global__ void __launch_bounds__(BLOCK) k_trace(DScene sc, TraceIO io, const un
 // GENERAL: the scene holds primitives whose hit test is more than the watertight triangle test - alpha-masked triangles (an accepted hit is
 // dropped when its mask texture evaluates to 0, mesh.rs:353-370 / 534-582). Such scenes trace through this kernel only; every other kernel
 // keeps the bare triangle loop.
+// TransformedPrimitive::intersect / intersect_p (rc/primitive.rs:90-101): the ray goes to object space as `Transform * Ray` does (origin as a point,
+// direction as a vector, t_max kept - rc/ray.rs:83-93), the object - its tree, or its single primitive - is intersected there; t is the same parameter
+// in both spaces. The nested walk keeps its stack in private memory: this is the general path, not the fast one.
+template <bool ANY, bool COUNT>
+RT_DEVN bool instance_intersect(const DScene& sc, unsigned inst, float ox, float oy, float oz, float dx, float dy, float dz, float& t_max, int& prim_out, TriHit& hit_out,
+                                unsigned& n_nodes, unsigned& n_tris) {
+  const DInstance& in = sc.instances[inst];
+  Ray r; r.o = xf34_point(in.w2o, mk3(ox, oy, oz)); r.d = xf34_vector(in.w2o, mk3(dx, dy, dz)); r.t_max = t_max;
+  bool found;
+  if (in.n_nodes == 0u) {  // an object of one primitive is wrapped as it is (api.rs:1073-1082): no node test
+    f3 p0, p1, p2; load_tri(sc.tri_p, (int)in.prim_base, p0, p1, p2);
+    if (COUNT) n_tris += 1;
+    TriHit h;
+    found = tri_test(p0, p1, p2, r, h);
+    if (found) { prim_out = 0; hit_out = h; r.t_max = h.t; }
+  } else {
+    const GlobalSrc src{sc.nodes + 2 * (size_t)in.node_base, sc.tri_p + 3 * (size_t)in.prim_base};
+    int stack[64];
+    found = traverse<ANY, COUNT>(src, r, stack, 1, prim_out, hit_out, n_nodes, n_tris);
+    if (found && !ANY) r.t_max = hit_out.t;
+  }
+  if (found) t_max = r.t_max;
+  return found;
+}
+
 template <bool ANY, bool COUNT, int BLOCK, int DEPTH, bool GENERAL = false>
 __global__ void __launch_bounds__(BLOCK) k_trace_big(DScene sc, TraceIO io, const unsigned* __restrict__ queue, const unsigned* __restrict__ shard_counts, unsigned shard_cap,
                                                      unsigned count_static, unsigned long long* stats, int st_rays, int st_nodes, int st_tris) {
@@ -677,6 +702,16 @@ __global__ void __launch_bounds__(BLOCK) k_trace_big(DScene sc, TraceIO io, cons
         src.tri(leaf_off + i, p0, p1, p2);
         if (COUNT) n_tris += 1;
         TriHit h;
+        if (GENERAL && (tri_flags(sc.tri_p, leaf_off + i) & RT_FLAG_INSTANCE)) {  // an object instance: the hit id names (instance, the object's primitive)
+          const unsigned k = __float_as_uint(p2.x);
+          int oprim = 0; float tm = ray.t_max; unsigned nn = 0, ntt = 0;
+          if (!instance_intersect<ANY, COUNT>(*sc.self, k, ray.o.x, ray.o.y, ray.o.z, ray.d.x, ray.d.y, ray.d.z, tm, oprim, h, nn, ntt)) { if (COUNT) { n_nodes += nn; n_tris += ntt; } continue; }
+          if (COUNT) { n_nodes += nn; n_tris += ntt; }
+          found = true;
+          if (ANY) break;
+          ray.t_max = tm; prim = (int)(sc.instances[k].id_base + (unsigned)oprim); hit = h;
+          continue;
+        }
         if (GENERAL && (tri_flags(sc.tri_p, leaf_off + i) & RT_FLAG_SPHERE)) {  // Sphere::intersect; the hit record carries t where a triangle's carries b2
           float ts;
           if (!sphere_test(sc.spheres[__float_as_uint(p2.x)], ray.o, ray.d, ray.t_max, ts)) continue;
@@ -1424,6 +1459,33 @@ struct SmallBsdfT {
   RT_DEV float eta() const { return WIDE ? eta_ : 1.0f; }
 };
 
+// The SurfaceInteraction of a hit inside an object instance: the object-space interaction of the object's primitive, then SurfaceInteraction::transform
+// (primitive_to_world), rc/interaction.rs:156-190. Returns the primitive's index in the scene's arrays (material, flags).
+RT_DEVN int instance_fill_interaction(const DScene& sc, unsigned hit_id, float ox, float oy, float oz, float dx, float dy, float dz, float b0, float b1, float b2,
+                                      SurfaceInteraction& si) {
+  unsigned lo = 0, hi = sc.n_instances;  // the last instance whose id_base <= hit_id
+  while (hi - lo > 1u) { const unsigned mid = (lo + hi) >> 1; if (sc.instances[mid].id_base <= hit_id) lo = mid; else hi = mid; }
+  const DInstance& in = sc.instances[lo];
+  const int gprim = (int)(in.prim_base + (hit_id - in.id_base));
+  const f3 d_obj = xf34_vector(in.w2o, mk3(dx, dy, dz));  // Transform * Ray: the direction as a vector (the origin does not enter a triangle's interaction)
+  (void)ox; (void)oy; (void)oz;
+  TriHit th; th.t = 0.0f; th.b0 = b0; th.b1 = b1; th.b2 = b2;
+  SurfaceInteraction s;
+  tri_fill_interaction_inl(sc, gprim, d_obj, th, s);
+  f3 perr;
+  si.hit.p = xf34_point_with_error(in.o2w, s.hit.p, s.hit.p_error, perr); si.hit.p_error = perr;
+  si.hit.wo = normalize(xf34_vector(in.o2w, s.hit.wo));
+  si.hit.n = normalize(xf34_normal(in.w2o, s.hit.n));
+  si.uv = s.uv;
+  si.dpdu = xf34_vector(in.o2w, s.dpdu); si.dpdv = xf34_vector(in.o2w, s.dpdv);
+  si.dudx = si.dvdx = si.dudy = si.dvdy = 0.0f; si.dpdx = si.dpdy = mk3(0, 0, 0);
+  si.sh_n = normalize(xf34_normal(in.w2o, s.sh_n));
+  si.sh_dpdu = xf34_vector(in.o2w, s.sh_dpdu); si.sh_dpdv = xf34_vector(in.o2w, s.sh_dpdv);
+  si.sh_n = face_forward(si.sh_n, si.hit.n);
+  si.prim = gprim;
+  return gprim;
+}
+
 // MODE 0: any material / texture / light. MODE 1: every material is matte with constant Kd and
 // sigma == 0 and every light is a DiffuseAreaLight (decided by the host from the material and light
 // tables); no texture then reads the camera-ray differentials and the kernel makes no out-of-line call.
@@ -1470,12 +1532,16 @@ __global__ void __launch_bounds__(256, MODE == 1 ? RT_SHADE_MIN_WAVES : RT_SHADE
       int x, y; unsigned long long pixel_index; owned_pixel(fp, fp.chunk_first + pix, x, y, pixel_index);
       smp.rng.state = pacc->rng;
       smp.rng.inc = ((pixel_index * (unsigned long long)ps.spp + s + (1ull << 32)) << 1u) | 1ull;
-      const int prim = __float_as_int(h4.y);
+      int prim = __float_as_int(h4.y);
       const bool found = prim >= 0;
       // the frame loop's hit record is (b2, prim, b0, b1): the three barycentrics of the accepted test
       SurfaceInteraction si; TriHit th; th.t = 0.0f; th.b0 = h4.z; th.b1 = h4.w; th.b2 = h4.x;
       if (found) {
-        if (GENERAL && (tri_flags(sc.tri_p, prim) & RT_FLAG_SPHERE)) {  // Sphere::intersect builds its interaction from the ray: origin and direction of the path's ray
+        if (GENERAL && sc.n_instances != 0u && (unsigned)prim >= sc.n_top_prims) {  // a hit inside an object instance: from here on `prim` is the object's primitive
+          const float4 o4 = prec->o;
+          prim = instance_fill_interaction(gsc, (unsigned)prim, o4.x, o4.y, o4.z, ray_d.x, ray_d.y, ray_d.z, th.b0, th.b1, th.b2, si);
+        }
+        else if (GENERAL && (tri_flags(sc.tri_p, prim) & RT_FLAG_SPHERE)) {  // Sphere::intersect builds its interaction from the ray: origin and direction of the path's ray
           const float4 o4 = prec->o;
           (void)sphere_fill_interaction(sc.spheres[prim_sphere_index(sc.tri_p, prim)], mk3(o4.x, o4.y, o4.z), ray_d, si);
           si.prim = prim;
@@ -1674,7 +1740,8 @@ __global__ void __launch_bounds__(256) k_resolve(DScene sc, PassState ps) {
         if (__float_as_uint(h4.y) == 0u) li = infinite_le(sc, light, wi);
       } else {
         const int prim = __float_as_int(h4.y);
-        if (prim >= 0) {  // integrator/mod.rs:293-307: emitted radiance only if the hit emitter IS the sampled light
+        if (GENERAL && sc.n_instances != 0u && prim >= 0 && (unsigned)prim >= sc.n_top_prims) {  // a hit inside an object instance: objects hold no emitters
+        } else if (prim >= 0) {  // integrator/mod.rs:293-307: emitted radiance only if the hit emitter IS the sampled light
           if (GENERAL && tri_light(sc.tri_p, prim) == light_num && (tri_flags(sc.tri_p, prim) & RT_FLAG_SPHERE)) {
             float4 o4 = m->o;
             SurfaceInteraction lsi; (void)sphere_fill_interaction(sc.spheres[prim_sphere_index(sc.tri_p, prim)], mk3(o4.x, o4.y, o4.z), wi, lsi);
@@ -1779,9 +1846,12 @@ __global__ void k_film_finalize(const float4* film_acc, float4* film_xyzw, unsig
 // Only marked voxels are built (list = compacted marks); rt_light_distribution() asks for all of them.
 __global__ void __launch_bounds__(256) k_lightdist_mark(DScene sc, unsigned char* __restrict__ mark) {
   const unsigned t = blockIdx.x * blockDim.x + threadIdx.x;
-  if (t >= sc.n_tris) return;
+  if (t >= (sc.n_instances != 0u ? sc.n_top_prims : sc.n_tris)) return;  // object-space primitives follow the top level's: they are reached through their instances
   f3 p0, p1, p2; load_tri(sc.tri_p, (int)t, p0, p1, p2);
-  const bool is_sphere = (tri_flags(sc.tri_p, (int)t) & RT_FLAG_SPHERE) != 0u;  // a quadric: every voxel of its box is kept
+  // a quadric or an object instance: every voxel of its box is kept (the instance's slot holds its world box in p0 / p1: min and max below are that box)
+  const bool is_instance = (tri_flags(sc.tri_p, (int)t) & RT_FLAG_INSTANCE) != 0u;
+  if (is_instance) p2 = p0;
+  const bool is_sphere = (tri_flags(sc.tri_p, (int)t) & RT_FLAG_SPHERE) != 0u;
   f3 mn = mk3(fminf(p0.x, fminf(p1.x, p2.x)), fminf(p0.y, fminf(p1.y, p2.y)), fminf(p0.z, fminf(p1.z, p2.z)));
   f3 mx = mk3(fmaxf(p0.x, fmaxf(p1.x, p2.x)), fmaxf(p0.y, fmaxf(p1.y, p2.y)), fmaxf(p0.z, fmaxf(p1.z, p2.z)));
   if (is_sphere) {

@@ -184,6 +184,12 @@ class HostScene:
         for sp in getattr(desc, "spheres", []):
             _check(L.rtxh_scene_add_quadric(self.h, int(getattr(sp, "kind", 0)), _p(sp.o2w), _p(sp.w2o), C.c_float(sp.radius), C.c_float(sp.z_min), C.c_float(sp.z_max),
                                             C.c_float(sp.phi_max), int(sp.reverse_orientation), sp.material, sp.light), "add_quadric")
+        for o in getattr(desc, "objects", []):
+            self._keep += (o,)
+            _check(L.rtxh_scene_add_object(self.h, _p(o.P), o.P.shape[0], _p(o.idx, C.c_int32), o.idx.shape[0], _p(o.N), _p(o.UV), _p(o.S),
+                                           _p(o.mat, C.c_int32), _p(o.flags, C.c_uint8)), "add_object")
+        for i in getattr(desc, "instances", []):
+            _check(L.rtxh_scene_add_instance(self.h, i.obj, _p(i.o2w), _p(i.w2o)), "add_instance")
         for l in desc.lights:
             l2w = None if l.l2w is None else np.ascontiguousarray(l.l2w, np.float32)
             w2l = None if l.w2l is None else np.ascontiguousarray(l.w2l, np.float32)

@@ -130,6 +130,25 @@ class Integrator:
     pixel_bounds: Optional[Sequence[int]] = None  # x0 x1 y0 y1
 
 
+@dataclass
+class ObjectDef:
+    """An object definition: a triangle soup in object space (vertices as the shapes' own CTMs leave them) and per-triangle material / flags."""
+    P: np.ndarray
+    idx: np.ndarray
+    N: Optional[np.ndarray]
+    UV: Optional[np.ndarray]
+    S: Optional[np.ndarray]
+    mat: np.ndarray
+    flags: np.ndarray
+
+
+@dataclass
+class InstanceDef:
+    obj: int
+    o2w: np.ndarray
+    w2o: np.ndarray
+
+
 class SceneDesc:
     def __init__(self):
         self._P: List[np.ndarray] = []
@@ -146,6 +165,8 @@ class SceneDesc:
         self.textures: List[Texture] = []
         self.mipmaps: List[MipImage] = []
         self.spheres: List[SphereShape] = []
+        self.objects: List[ObjectDef] = []
+        self.instances: List[InstanceDef] = []
         self.materials: List[Material] = []
         self.lights: List[Light] = []
         self.camera = Camera()
@@ -340,6 +361,49 @@ class SceneDesc:
     def add_cylinder(self, o2w, radius=1.0, material: int = 0, z_min=-1.0, z_max=1.0, phi_max=360.0, reverse_orientation=False, emission=None, two_sided=False) -> int:
         """Shape "cylinder" (rc/shapes/cylinder.rs): the open cylinder of `radius` around the object-space z axis between z_min and z_max."""
         return self._add_quadric(2, o2w, radius, z_min, z_max, phi_max, material, reverse_orientation, emission, two_sided)
+
+    def add_object(self, meshes) -> int:
+        """ObjectBegin ... ObjectEnd (rc/api.rs:1019-1051): triangle meshes in OBJECT space - an iterable of dicts with the keys of `add_mesh`
+        (P, idx, material, N, UV, S, reverse_orientation; no emission, no alpha masks). Returns the object's index; nothing is rendered until
+        `add_instance` places it."""
+        Ps, Is, Ns, UVs, Ss, mats, flags, nv0 = [], [], [], [], [], [], [], 0
+        for m in meshes:
+            P = np.ascontiguousarray(m["P"], dtype=np.float32).reshape(-1, 3)
+            idx = np.ascontiguousarray(m["idx"], dtype=np.int32).reshape(-1, 3)
+            nv, nt = P.shape[0], idx.shape[0]
+            assert idx.min() >= 0 and idx.max() < nv
+            f = TRI_FLIP if m.get("reverse_orientation", False) else 0
+            Ps.append(P)
+            for lst, key, w, bit in ((Ns, "N", 3, TRI_HAS_N), (UVs, "UV", 2, TRI_HAS_UV), (Ss, "S", 3, TRI_HAS_S)):
+                a = m.get(key)
+                if a is not None:
+                    a = np.ascontiguousarray(a, dtype=np.float32).reshape(-1, w)
+                    assert a.shape[0] == nv
+                    f |= bit
+                else:
+                    a = np.zeros((nv, w), dtype=np.float32)
+                lst.append(a)
+            Is.append(idx + nv0)
+            mats.append(np.full(nt, int(m["material"]), dtype=np.int32))
+            flags.append(np.full(nt, f, dtype=np.uint8))
+            nv0 += nv
+        fl = np.ascontiguousarray(np.concatenate(flags), dtype=np.uint8)
+        self.objects.append(ObjectDef(
+            np.ascontiguousarray(np.concatenate(Ps)), np.ascontiguousarray(np.concatenate(Is)),
+            np.ascontiguousarray(np.concatenate(Ns)) if (fl & TRI_HAS_N).any() else None,
+            np.ascontiguousarray(np.concatenate(UVs)) if (fl & TRI_HAS_UV).any() else None,
+            np.ascontiguousarray(np.concatenate(Ss)) if (fl & TRI_HAS_S).any() else None,
+            np.ascontiguousarray(np.concatenate(mats)), fl))
+        return len(self.objects) - 1
+
+    def add_instance(self, obj: int, o2w) -> int:
+        """ObjectInstance (rc/api.rs:1053-1090): a TransformedPrimitive over object `obj` with primitive_to_world = `o2w` (rc/primitive.rs:79-118).
+        The object's BVH is traversed in object space; nothing is copied. Returns the instance's index."""
+        assert 0 <= obj < len(self.objects)
+        o2w = np.ascontiguousarray(o2w, np.float32).reshape(4, 4)
+        w2o = np.ascontiguousarray(np.linalg.inv(o2w.astype(np.float64)), np.float32)
+        self.instances.append(InstanceDef(int(obj), o2w, w2o))
+        return len(self.instances) - 1
 
     def add_quad(self, p0, p1, p2, p3, material: int, **kw) -> int:
         return self.add_mesh([p0, p1, p2, p3], [[0, 1, 2], [0, 2, 3]], material, **kw)
