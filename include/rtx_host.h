@@ -57,6 +57,10 @@ int rtxh_scene_add_sphere(rtxh_scene*, const float* o2w16, const float* w2o16, f
  * rc/shapes/disk.rs:48-62), 2 = Shape "cylinder" (z_min, z_max as given; rc/shapes/cylinder.rs:26-46). Area lights as for spheres (tri = -2 - k). */
 int rtxh_scene_add_quadric(rtxh_scene*, int32_t kind, const float* o2w16, const float* w2o16, float radius, float z_min, float z_max, float phi_max,
                            int32_t reverse_orientation, int32_t material, int32_t light);
+/* Scene files (rtxh_pbrt_load / rtxh_pbrt_parse), per calling thread: on != 0 writes every ObjectInstance out as world-space triangles (memory in
+ * proportion to instances x mesh, but every ray stays in the single-level traversal kernels); 0 - the default - keeps the reference's form, one tree per
+ * object and a TransformedPrimitive per instance (objects whose meshes carry alpha masks are written out either way). */
+void rtxh_set_flatten_instances(int32_t on);
 /* ObjectBegin ... ObjectEnd (rc/api.rs:1019-1051): a triangle mesh in OBJECT space (vertices as the shapes' own CTMs leave them), arrays as for
  * rtxh_scene_set_mesh without lights (area lights inside object definitions are refused; the reference shows but never samples them, api.rs:955-957).
  * Returns the object's index; nothing is rendered until an instance places it. */
@@ -98,7 +102,10 @@ int rtxh_mip_level(rtxh_scene*, int32_t mip, int32_t level, int32_t* w, int32_t*
 enum { RTXH_TABLE_TEXTURES = 0, RTXH_TABLE_MATERIALS, RTXH_TABLE_LIGHTS, RTXH_TABLE_P, RTXH_TABLE_N, RTXH_TABLE_UV, RTXH_TABLE_S, RTXH_TABLE_INDICES,
        RTXH_TABLE_TRI_MATERIAL, RTXH_TABLE_TRI_LIGHT, RTXH_TABLE_TRI_FLAGS,
        /* sampling tables of the first infinite light (floats): func, per-row cdf, row integrals, marginal cdf */
-       RTXH_TABLE_ENV_FUNC, RTXH_TABLE_ENV_CDF, RTXH_TABLE_ENV_ROW_INT, RTXH_TABLE_ENV_MARG_CDF };
+       RTXH_TABLE_ENV_FUNC, RTXH_TABLE_ENV_CDF, RTXH_TABLE_ENV_ROW_INT, RTXH_TABLE_ENV_MARG_CDF,
+       RTXH_TABLE_INSTANCES,         /* rtxh_instance_info per ObjectInstance, in order */
+       RTXH_TABLE_OBJECT_BASE = 1000 /* + 8 * object + {0 P, 1 N, 2 UV, 3 S, 4 indices, 5 tri material, 6 tri flags}: the object-space soup of one object */ };
+typedef struct rtxh_instance_info { int32_t object; float o2w[16], w2o[16]; } rtxh_instance_info;
 typedef struct rtxh_light_info { int32_t kind, tri; float rgb[3]; int32_t two_sided; float vec[3]; int32_t mip; float l2w[12], w2l[12]; } rtxh_light_info;
 int rtxh_scene_inspect(rtxh_scene*, int32_t table, void* out, uint64_t capacity_bytes, uint64_t* n_items);
 int rtxh_look_at(const float* pos, const float* look, const float* up, float* m16, float* m_inv16);

@@ -982,8 +982,28 @@ int rtxh_mip_level(rtxh_scene* s, int32_t mip, int32_t level, int32_t* w, int32_
 int rtxh_scene_inspect(rtxh_scene* s, int32_t table, void* out, uint64_t capacity_bytes, uint64_t* n_items) {
   if (!s || !n_items) return fail(RT_ERR_INVALID, "null argument");
   const void* src = nullptr; size_t item = 0, n = 0;
-  std::vector<rtxh_light_info> li;
+  std::vector<rtxh_light_info> li; std::vector<rtxh_instance_info> ii;
+  if (table >= RTXH_TABLE_OBJECT_BASE) {
+    const size_t k = (size_t)(table - RTXH_TABLE_OBJECT_BASE) / 8; const int j = (table - RTXH_TABLE_OBJECT_BASE) % 8;
+    if (k >= s->objects.size() || j > 6) return fail(RT_ERR_INVALID, "unknown object table");
+    const auto& o = s->objects[k];
+    switch (j) {
+      case 0: src = o.P.data(); item = 12; n = o.P.size() / 3; break;
+      case 1: src = o.N.data(); item = 12; n = o.N.size() / 3; break;
+      case 2: src = o.UV.data(); item = 8; n = o.UV.size() / 2; break;
+      case 3: src = o.S.data(); item = 12; n = o.S.size() / 3; break;
+      case 4: src = o.idx.data(); item = 12; n = o.idx.size() / 3; break;
+      case 5: src = o.tri_mat.data(); item = 4; n = o.tri_mat.size(); break;
+      default: src = o.tri_flags.data(); item = 1; n = o.tri_flags.size(); break;
+    }
+    *n_items = n;
+    if (out) { if (capacity_bytes < n * item) return fail(RT_ERR_INVALID, "buffer too small"); if (n) memcpy(out, src, n * item); }
+    return RT_OK;
+  }
   switch (table) {
+    case RTXH_TABLE_INSTANCES:
+      for (const auto& in : s->instances) { rtxh_instance_info i; i.object = in.object; memcpy(i.o2w, in.o2w, 64); memcpy(i.w2o, in.w2o, 64); ii.push_back(i); }
+      src = ii.data(); item = sizeof(rtxh_instance_info); n = ii.size(); break;
     case RTXH_TABLE_TEXTURES: src = s->textures.data(); item = sizeof(rt_texture); n = s->textures.size(); break;
     case RTXH_TABLE_MATERIALS: src = s->materials.data(); item = sizeof(rt_material); n = s->materials.size(); break;
     case RTXH_TABLE_LIGHTS:

@@ -48,6 +48,7 @@ struct PbrtGraphicsState {  // rc/api.rs:300-311
   bool reverse_orientation = false;
 };
 
+static thread_local bool g_flatten_instances = false;  // rtxh_set_flatten_instances, per calling thread
 struct PbrtSoup {  // triangle soup: world space for the scene, instance space for an ObjectBegin .. ObjectEnd block
   std::vector<float> P, N, UV, S; std::vector<int32_t> idx, tri_mat, tri_light, tri_alpha /* 2 per triangle */; std::vector<uint8_t> tri_flags;
   bool any_n = false, any_uv = false, any_s = false;
@@ -83,6 +84,7 @@ struct PbrtLoader {
   PbrtGraphicsState gs; std::vector<PbrtGraphicsState> pushed_gs;
   PbrtSoup world;
   std::map<std::string, PbrtSoup> instances; std::string current_instance; bool in_instance = false;  // RenderOptions::instances / current_instance (api.rs:175-177)
+  std::map<std::string, int> object_ids; size_t n_instances = 0;  // objects already handed to the host layer, instances placed (two-level instancing)
   int n_lights = 0, n_spheres = 0; size_t instanced_triangles = 0;
 
   bool fail_(const std::string& m) { if (err.empty()) err = m; return false; }
@@ -434,6 +436,23 @@ struct PbrtLoader {
     if (it == instances.end()) return fail_("Unable to find instance named " + name);
     const PbrtSoup& o = it->second;
     if (o.idx.empty()) return true;
+    // The reference's form (the default): one tree per object, a TransformedPrimitive per instance - rtxh_scene_add_object once, rtxh_scene_add_instance
+    // per use, nothing copied, traversed in object space by the general kernels. Objects whose meshes carry alpha masks are written out (below), and so
+    // is everything when the caller asked for it (rtxh_set_flatten_instances: every ray then stays in the single-level kernels).
+    bool plain = !g_flatten_instances;
+    for (int32_t a : o.tri_alpha) if (a >= 0) plain = false;
+    if (plain) {
+      auto id = object_ids.find(name);
+      if (id == object_ids.end()) {
+        const int k = rtxh_scene_add_object(scene, o.P.data(), (int32_t)o.n_verts(), o.idx.data(), (int32_t)(o.idx.size() / 3), o.any_n ? o.N.data() : nullptr,
+                                            o.any_uv ? o.UV.data() : nullptr, o.any_s ? o.S.data() : nullptr, o.tri_mat.data(), o.tri_flags.data());
+        if (k < 0) return fail_(rtxh_last_error());
+        id = object_ids.emplace(name, k).first;
+      }
+      if (rtxh_scene_add_instance(scene, id->second, &ctm.m.a[0][0], &ctm.inv.a[0][0]) < 0) return fail_(rtxh_last_error());
+      n_instances += 1;
+      return true;
+    }
     // Written-out instances cost memory in proportion to instances x mesh size, where the reference's TransformedPrimitive shares one BVH. A scene
     // that instantiates its way past the budget is refused with a message instead of exhausting the host (RTX_INSTANCE_TRIANGLE_BUDGET, default 2^28
     // triangles ~ 40 GB of device geometry and BVH - a fraction of the 288 GB the design counts on).
@@ -441,7 +460,7 @@ struct PbrtLoader {
     instanced_triangles += o.idx.size() / 3;
     if (world.idx.size() / 3 + o.idx.size() / 3 > budget)
       return fail_("ObjectInstance \"" + name + "\": writing the instances out would exceed " + std::to_string(budget) + " triangles (" + std::to_string(instanced_triangles) +
-                   " instanced so far); this backend has no two-level traversal (RTX_INSTANCE_TRIANGLE_BUDGET raises the limit)");
+                   " instanced so far; RTX_INSTANCE_TRIANGLE_BUDGET raises the limit, two-level instancing - the default - copies nothing)");
     const size_t nv = o.n_verts();
     std::vector<float> p(3 * nv), n, sv;
     for (size_t v = 0; v < nv; ++v) xf_point(ctm.m, &o.P[3 * v], &p[3 * v]);
@@ -665,7 +684,7 @@ int pbrt_load_text(const std::string& text, const std::string& base_dir, rtxh_pb
   bool ok = PbrtLoader::tokenize(text, toks, L.err) && L.run(toks, 0);
   if (ok && !L.world_ended) { L.err = "missing WorldEnd"; ok = false; }
   if (ok) ok = L.finish_options();
-  if (ok && L.world.idx.empty() && L.n_spheres == 0) { L.err = "the scene holds no triangles"; ok = false; }
+  if (ok && L.world.idx.empty() && L.n_spheres == 0 && L.n_instances == 0) { L.err = "the scene holds no triangles"; ok = false; }
   if (ok) {
     const PbrtSoup& w = L.world;
     const int32_t nv = (int32_t)w.n_verts(), nt = (int32_t)(w.idx.size() / 3);
@@ -689,6 +708,7 @@ static int pbrt_load_guarded(const std::string& text, const std::string& base_di
   catch (const std::bad_alloc&) { memset(out, 0, sizeof *out); return fail(RT_ERR_OOM, "pbrt: out of memory while building the scene"); }
   catch (const std::exception& e) { memset(out, 0, sizeof *out); return fail(RT_ERR_INVALID, std::string("pbrt: ") + e.what()); }
 }
+void rtxh_set_flatten_instances(int32_t on) { g_flatten_instances = on != 0; }
 int rtxh_pbrt_load(const char* path, rtxh_pbrt_result* out) {
   if (!path || !out) return fail(RT_ERR_INVALID, "null argument");
   g_err.clear();

@@ -358,12 +358,19 @@ _LIGHT_DT = np.dtype([("kind", "<i4"), ("tri", "<i4"), ("rgb", "<f4", 3), ("two_
 _TABLES = {"textures": (0, _TEXTURE_DT), "materials": (1, _MATERIAL_DT), "lights": (2, _LIGHT_DT), "P": (3, np.dtype(("<f4", 3))), "N": (4, np.dtype(("<f4", 3))),
            "UV": (5, np.dtype(("<f4", 2))), "S": (6, np.dtype(("<f4", 3))), "indices": (7, np.dtype(("<i4", 3))), "tri_material": (8, np.dtype("<i4")),
            "tri_light": (9, np.dtype("<i4")), "tri_flags": (10, np.dtype("u1")), "env_func": (11, np.dtype("<f4")), "env_cdf": (12, np.dtype("<f4")),
-           "env_row_int": (13, np.dtype("<f4")), "env_marg_cdf": (14, np.dtype("<f4"))}
+           "env_row_int": (13, np.dtype("<f4")), "env_marg_cdf": (14, np.dtype("<f4")),
+           "instances": (15, np.dtype([("object", "<i4"), ("o2w", "<f4", (4, 4)), ("w2o", "<f4", (4, 4))]))}
+_OBJECT_TABLES = {"P": (0, np.dtype(("<f4", 3))), "N": (1, np.dtype(("<f4", 3))), "UV": (2, np.dtype(("<f4", 2))), "S": (3, np.dtype(("<f4", 3))),
+                  "indices": (4, np.dtype(("<i4", 3))), "tri_material": (5, np.dtype("<i4")), "tri_flags": (6, np.dtype("u1"))}
 
 
 def scene_table(handle, name):
     """Copy of one unflattened table of an rtxh_scene (rtxh_scene_inspect)."""
-    which, dt = _TABLES[name]
+    if isinstance(name, tuple):  # (object index, table): the object-space soup of one ObjectBegin block
+        j, dt = _OBJECT_TABLES[name[1]]
+        which = 1000 + 8 * int(name[0]) + j
+    else:
+        which, dt = _TABLES[name]
     n = C.c_uint64()
     _check(lib().rtxh_scene_inspect(handle, which, None, C.c_uint64(0), C.byref(n)), "scene_inspect")
     out = np.zeros(n.value, dt)
@@ -376,10 +383,13 @@ class PbrtScene(HostScene):
     """A scene read from a pbrt-v3 file by the C++ host (rtxh_pbrt_load): what `rustracer scene.pbrt` builds up to
     `renderer::render` (rc/pbrt/mod.rs:16-27, rc/api.rs:977-1010). Same methods as HostScene."""
 
-    def __init__(self, path=None, text=None, base_dir="", device_ingest=False):
+    def __init__(self, path=None, text=None, base_dir="", device_ingest=False, flatten_instances=False):
+        """flatten_instances=True: every ObjectInstance is written out as world-space triangles (single-level traversal kernels) instead of the
+        reference's one tree per object (rc/primitive.rs:79-118), which is the default."""
         L = lib()
         res = PbrtResult()
         L.rtxh_set_device_ingest(1 if device_ingest else 0)  # MIP pyramids / environment tables on the GPU (bit-identical)
+        L.rtxh_set_flatten_instances(1 if flatten_instances else 0)
         try:
             if path is not None:
                 _check(L.rtxh_pbrt_load(os.fsencode(path), C.byref(res)), "pbrt_load")
@@ -387,6 +397,7 @@ class PbrtScene(HostScene):
                 _check(L.rtxh_pbrt_parse(text.encode(), os.fsencode(base_dir), C.byref(res)), "pbrt_parse")
         finally:
             L.rtxh_set_device_ingest(0)
+            L.rtxh_set_flatten_instances(0)
         self.h = C.c_void_p(res.scene)
         self.desc = None
         self.params = RenderParams.from_buffer_copy(res.params)

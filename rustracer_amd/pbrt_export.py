@@ -236,6 +236,39 @@ class _Writer:
             else:  # the reference's Cylinder::create reads z_min / z_max / phi_max (cylinder.rs:31-34)
                 o.append(f'  Shape "cylinder" "float radius" [{_n(sp.radius)}] "float z_min" [{_n(sp.z_min)}] "float z_max" [{_n(sp.z_max)}] "float phi_max" [{_n(sp.phi_max)}]')
             o.append("AttributeEnd")
+        # ObjectBegin .. ObjectEnd per object (one Shape per run of triangles that share material and flags: the meshes add_object was given), then
+        # one ObjectInstance per placement under its primitive-to-world matrix
+        for k, ob in enumerate(getattr(d, "objects", [])):
+            o.append(f'ObjectBegin "object{k}"')
+            nt = ob.idx.shape[0]
+            t0 = 0
+            while t0 < nt:
+                t1 = t0
+                while t1 + 1 < nt and ob.mat[t1 + 1] == ob.mat[t0] and ob.flags[t1 + 1] == ob.flags[t0] and ob.idx[t1 + 1].min() >= ob.idx[t0:t1 + 1].min():
+                    t1 += 1
+                tri = ob.idx[t0:t1 + 1]
+                v0, v1 = int(tri.min()), int(tri.max()) + 1
+                flags = int(ob.flags[t0])
+                o.append("  AttributeBegin")
+                o.append(f'    NamedMaterial "{self.material(int(ob.mat[t0]))}"')
+                if flags & sd.TRI_FLIP:
+                    o.append("    ReverseOrientation")
+                shape = f'    Shape "trianglemesh" "integer indices" [{" ".join(str(int(x)) for x in (tri - v0).reshape(-1))}] "point P" [{_nums(ob.P[v0:v1])}]'
+                if flags & sd.TRI_HAS_N:
+                    shape += f' "normal N" [{_nums(ob.N[v0:v1])}]'
+                if flags & sd.TRI_HAS_UV:
+                    shape += f' "float uv" [{_nums(ob.UV[v0:v1])}]'
+                if flags & sd.TRI_HAS_S:
+                    shape += f' "vector S" [{_nums(ob.S[v0:v1])}]'
+                o.append(shape)
+                o.append("  AttributeEnd")
+                t0 = t1 + 1
+            o.append("ObjectEnd")
+        for i in getattr(d, "instances", []):
+            o.append("AttributeBegin")
+            o.append(f"  Transform [{_nums(np.asarray(i.o2w, np.float32).T)}]")
+            o.append(f'  ObjectInstance "object{i.obj}"')
+            o.append("AttributeEnd")
         for _, l in other:
             self.light(l)
         o.append("WorldEnd")

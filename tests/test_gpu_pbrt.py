@@ -65,7 +65,7 @@ def test_object_instances_render_like_the_written_out_scene(gpu_host, orc):
             'AttributeBegin\nTranslate 2 0 1\nScale 1 2 1\nObjectInstance "box"\nAttributeEnd\n'
             'AttributeBegin\nTranslate 0 0 -1\nScale -1.5 0.5 1.5\nObjectInstance "box"\nAttributeEnd\n'
             'WorldEnd\n')
-    p = gpu_host.PbrtScene(text=text)
+    p = gpu_host.PbrtScene(text=text, flatten_instances=True)
     d = SceneDesc()
     grey, blue = d.matte((0.7, 0.7, 0.7)), d.plastic((0.2, 0.4, 0.7), (0.25, 0.25, 0.25), 0.2)
     d.add_quad((-4, 0, -4), (-4, 0, 4), (4, 0, 4), (4, 0, -4), grey)
@@ -84,3 +84,22 @@ def test_object_instances_render_like_the_written_out_scene(gpu_host, orc):
     assert np.array_equal(fp, fh)
     fo, _ = orc.OracleScene(d).render(mode=1)
     assert np.array_equal(fo[..., 3], fp[..., 3]) and rel_l2(gpu_host.film_to_rgb(fp), orc.film_to_rgb(fo)) < 1e-3
+    # the default: the reference's own form - one tree for the box, three TransformedPrimitives - against the same scene built by calls, and the oracle
+    p2 = gpu_host.PbrtScene(text=text)
+    d2 = SceneDesc()
+    grey, blue = d2.matte((0.7, 0.7, 0.7)), d2.plastic((0.2, 0.4, 0.7), (0.25, 0.25, 0.25), 0.2)
+    d2.add_quad((-4, 0, -4), (-4, 0, 4), (4, 0, 4), (4, 0, -4), grey)
+    d2.add_quad((-4, 0, 4), (-4, 5, 4), (4, 5, 4), (4, 0, 4), grey)
+    d2.add_quad((-1, 4.9, -1), (1, 4.9, -1), (1, 4.9, 1), (-1, 4.9, 1), grey, emission=(20.0, 18.0, 15.0))
+    o = d2.add_object([dict(P=bp, idx=bi, material=blue)])
+    for m in (_translate(-2, 0, 0), _mm(_translate(2, 0, 1), _scale(1, 2, 1)), _mm(_translate(0, 0, -1), _scale(-1.5, 0.5, 1.5))):
+        d2.add_instance(o, m)
+    d2.camera.pos, d2.camera.look, d2.camera.fov = (0.0, 3.0, -9.0), (0.0, 1.0, 0.0), 45.0
+    d2.film.xres, d2.film.yres = 96, 64
+    d2.sampler.spp = 16
+    assert len(p2.table("instances")) == 3 and np.array_equal(p2.table((0, "P")), bp) and len(p2.table("indices")) == 6
+    assert np.array_equal(p2.table("instances")["o2w"], np.stack([i.o2w for i in d2.instances]))
+    f2, _ = p2.render()
+    fo2, _ = orc.OracleScene(d2).render(mode=1)
+    assert np.array_equal(fo2[..., 3], f2[..., 3]) and rel_l2(gpu_host.film_to_rgb(f2), orc.film_to_rgb(fo2)) < 1e-3
+    assert rel_l2(gpu_host.film_to_rgb(f2), gpu_host.film_to_rgb(fp)) < 5e-3   # two roundings of one scene

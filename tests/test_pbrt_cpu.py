@@ -462,7 +462,7 @@ Scale 1 -3 1
 ObjectInstance "thing"
 WorldEnd
 """
-    p = _parse(text)
+    p = host.PbrtScene(text=text, flatten_instances=True)
     P, N, S, UV = p.table("P"), p.table("N"), p.table("S"), p.table("UV")
     idx, flags, tm, m = p.table("indices"), p.table("tri_flags"), p.table("tri_material"), p.table("materials")
     assert len(idx) == 2 + 2 * 3 and len(P) == 3 + 3 + 2 * 7
@@ -481,6 +481,49 @@ WorldEnd
     assert [int(f) for f in flags] == [0, 0, base, base, sd.TRI_FLIP, base | sd.TRI_FLIP, base | sd.TRI_FLIP, 0]   # the mirrored instance toggles the flip
     assert np.array_equal(idx[2:5], [[6, 7, 8], [6, 8, 9], [10, 11, 12]]) and np.array_equal(idx[5:], [[13, 14, 15], [13, 15, 16], [17, 18, 19]])
     assert (p.table("tri_light") == -1).all()
+
+
+def test_object_instances_keep_the_references_form_by_default():
+    """ObjectBegin / ObjectInstance as the reference holds them (rc/api.rs:1019-1090, rc/primitive.rs:79-118): the object's soup stays in object space - one
+    copy however often it is used -, each instance is the CTM at its ObjectInstance with the inverse the Transform carries; an object that is never
+    instantiated (or is empty) leaves nothing behind."""
+    text = HEADER + """WorldBegin
+Material "mirror"
+""" + TRI + """ObjectBegin "thing"
+  Material "plastic"
+  Translate 0 0 1
+""" + TRI + """  ReverseOrientation
+""" + TRI + """ObjectEnd
+ObjectBegin "unused"
+""" + TRI + """ObjectEnd
+ObjectBegin "empty"
+ObjectEnd
+AttributeBegin
+  Translate 5 0 0
+  Scale 2 1 1
+  ObjectInstance "thing"
+AttributeEnd
+ObjectInstance "empty"
+Scale 1 -3 1
+ObjectInstance "thing"
+WorldEnd
+"""
+    p = _parse(text)
+    assert len(p.table("indices")) == 1 and len(p.table("P")) == 3                       # the top level holds its own triangle only
+    inst = p.table("instances")
+    assert len(inst) == 2 and list(inst["object"]) == [0, 0]                               # both uses share object 0; "unused" and "empty" were never handed over
+    m1 = _mm(_translate(5, 0, 0), _scale(2, 1, 1))
+    assert np.array_equal(inst["o2w"][0], m1) and np.array_equal(inst["o2w"][1], _scale(1, -3, 1))
+    assert np.allclose(inst["w2o"][0] @ inst["o2w"][0], np.eye(4), atol=1e-6) and np.allclose(inst["w2o"][1] @ inst["o2w"][1], np.eye(4), atol=1e-6)
+    oP, oi, of, om = p.table((0, "P")), p.table((0, "indices")), p.table((0, "tri_flags")), p.table((0, "tri_material"))
+    assert np.array_equal(oP, F32([[0, 0, 1], [1, 0, 1], [0, 1, 1]] * 2)) and np.array_equal(oi, [[0, 1, 2], [3, 4, 5]])   # the CTM inside the definition applied, the instance's not
+    assert [int(f) for f in of] == [0, sd.TRI_FLIP]
+    m = p.table("materials")
+    assert [m[i]["kind"] for i in om] == [sd.MAT_PLASTIC] * 2 and m[p.table("tri_material")[0]]["kind"] == sd.MAT_MIRROR
+    b = p.bvh()
+    assert len(b["ordered"]) == 3 and sorted(b["ordered"]) == [0, 1, 2]                   # one triangle and two instance boxes in the top-level tree
+    with pytest.raises(host.BackendError, match="Unable to find instance"):
+        _parse(text.replace('ObjectInstance "empty"', 'ObjectInstance "nope"'))
 
 
 @pytest.mark.parametrize("text, message", [
@@ -630,17 +673,51 @@ def test_metal_default_spectrum_files_and_blackbody_parameters(tmp_path):
 
 
 def test_instancing_past_the_triangle_budget_is_refused(monkeypatch):
-    """ObjectInstance is written out (no two-level traversal): a file that instantiates its way past the budget fails with a message naming it."""
+    """ObjectInstance written out on request: a file that instantiates its way past the budget fails with a message naming it (the two-level default copies nothing)."""
     body = 'WorldBegin\nObjectBegin "o"\n' + TRI * 3 + "ObjectEnd\n" + "".join(f'AttributeBegin\nTranslate {i} 0 0\nObjectInstance "o"\nAttributeEnd\n' for i in range(8)) + "WorldEnd\n"
-    assert len(_parse(HEADER + body).table("indices")) == 24
+    assert len(host.PbrtScene(text=HEADER + body, flatten_instances=True).table("indices")) == 24
+    two_level = _parse(HEADER + body)
+    assert len(two_level.table("indices")) == 0 and len(two_level.table("instances")) == 8 and len(two_level.table((0, "indices"))) == 3
     import subprocess, sys, textwrap
     code = textwrap.dedent(f"""
         import sys; sys.path.insert(0, {os.path.dirname(os.path.dirname(os.path.abspath(__file__)))!r})
         from rustracer_amd import host
         try:
-            host.PbrtScene(text={HEADER + body!r})
+            host.PbrtScene(text={HEADER + body!r}, flatten_instances=True)
         except host.BackendError as e:
             print("REFUSED", e)
     """)
     out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, env=dict(os.environ, RTX_INSTANCE_TRIANGLE_BUDGET="10")).stdout
     assert "REFUSED" in out and "exceed 10 triangles" in out
+
+
+def test_instanced_scene_round_trips_through_a_file(tmp_path):
+    """SceneDesc objects / instances -> ObjectBegin .. ObjectEnd / ObjectInstance -> the loader's two-level form: the object-space soups come back array for
+    array, each instance with its matrix (the inverse is the loader's own f32 Gauss-Jordan, equal to the description's to rounding), the same top-level tree."""
+    from rustracer_amd.scene_desc import SceneDesc
+    from rustracer_amd.scenes.procedural import icosphere
+    d = SceneDesc()
+    a, b = d.matte((0.5, 0.5, 0.5)), d.plastic((0.2, 0.3, 0.6), (0.3, 0.3, 0.3), 0.1)
+    d.add_quad((-5, 0, -5), (-5, 0, 5), (5, 0, 5), (5, 0, -5), a)
+    P, F = icosphere(1, (0, 0, 0), 0.5)
+    n = (P / F32(0.5)).astype(F32)
+    o0 = d.add_object([dict(P=P, idx=F, material=b, N=n), dict(P=F32([[0, 1, 0], [1, 1, 0], [0, 1, 1]]), idx=[[0, 1, 2]], material=a, reverse_orientation=True)])
+    o1 = d.add_object([dict(P=F32([[0, 0, 0], [1, 0, 0], [0, 1, 0]]), idx=[[0, 1, 2]], material=a)])
+    for k, obj in enumerate((o0, o1, o0)):
+        m = np.eye(4, dtype=F32); m[:3, 3] = (2.0 * k - 2.0, 0.7, 0.5 * k); m[0, 0] = -1.5 if k == 2 else 1.0
+        d.add_instance(obj, m)
+    d.add_quad((-1, 4, -1), (1, 4, -1), (1, 4, 1), (-1, 4, 1), d.matte((0, 0, 0)), emission=(10, 10, 10))
+    path = os.path.join(str(tmp_path), "inst.pbrt")
+    write_pbrt(d, path)
+    p, h = host.PbrtScene(path=path), host.HostScene(d)
+    inst = p.table("instances")
+    assert list(inst["object"]) == [0, 1, 0] and np.array_equal(inst["o2w"], np.stack([i.o2w for i in d.instances]))
+    assert np.allclose(inst["w2o"], np.stack([i.w2o for i in d.instances]), rtol=0, atol=1e-6)
+    for k, ob in enumerate(d.objects):
+        for name, want in (("P", ob.P), ("indices", ob.idx), ("tri_flags", ob.flags), ("N", ob.N)):
+            got = p.table((k, name))
+            assert (len(got) == 0) if want is None else np.array_equal(got, want), (k, name)
+    bp, bh = p.bvh(), h.bvh()
+    assert all(np.array_equal(bp[k], bh[k]) for k in bp)
+    for name in ("P", "indices", "tri_flags", "tri_light"):
+        assert np.array_equal(p.table(name), h.table(name)), name
