@@ -299,6 +299,9 @@ RT_DEV float lobe_pdf_inner(const Lobe& l, f3 wo, f3 wi) {
 }
 struct LobeSample { rgb3 f; f3 wi; float pdf; unsigned type; };
 RT_DEV LobeSample mk_ls(rgb3 f, f3 wi, float pdf, unsigned type) { LobeSample s; s.f = f; s.wi = wi; s.pdf = pdf; s.type = type; return s; }
+// WANT_F = false: the value of a NON-specular lobe is left out (zero). Bsdf::sample_f discards it - for a non-specular sample f is recomputed as the sum over
+// every matching lobe (bsdf/mod.rs:228-247) - and with it goes one full microfacet evaluation (D, G, Fresnel) per sample. Specular lobes always return theirs.
+template <bool WANT_F = true>
 RT_DEV LobeSample lobe_sample_inner(const Lobe& l, f3 wo, f2 u) {
   const unsigned ty = lobe_type(l.kind);
   switch (l.kind) {
@@ -345,7 +348,7 @@ RT_DEV LobeSample lobe_sample_inner(const Lobe& l, f3 wo, f2 u) {
         wi = reflect(wo, wh);
         if (!same_hemisphere(wo, wi)) return mk_ls(mkc(0, 0, 0), wi, 0.0f, ty);
       }
-      return mk_ls(lobe_f_inner(l, wo, wi), wi, lobe_pdf_inner(l, wo, wi), ty);
+      return mk_ls(WANT_F ? lobe_f_inner(l, wo, wi) : mkc(0, 0, 0), wi, lobe_pdf_inner(l, wo, wi), ty);
     }
     case LB_MICRO_R: {  // microfacet.rs:61-84 (no wo.wh < 0 rejection: quirk 8)
       if (wo.z == 0.0f) return mk_ls(mkc(0, 0, 0), mk3(0, 0, 0), 0.0f, ty);
@@ -353,7 +356,7 @@ RT_DEV LobeSample lobe_sample_inner(const Lobe& l, f3 wo, f2 u) {
       f3 wi = reflect(wo, wh);
       if (!same_hemisphere(wo, wi)) return mk_ls(mkc(0, 0, 0), mk3(0, 0, 0), 0.0f, ty);
       float pdf = tr_pdf(l.ax, l.ay, wo, wh) / (4.0f * dot(wo, wh));
-      return mk_ls(lobe_f_inner(l, wo, wi), wi, pdf, ty);
+      return mk_ls(WANT_F ? lobe_f_inner(l, wo, wi) : mkc(0, 0, 0), wi, pdf, ty);
     }
     case LB_MICRO_T: {  // microfacet.rs:180-208
       if (wo.z == 0.0f) return mk_ls(mkc(0, 0, 0), mk3(0, 0, 0), 0.0f, ty);
@@ -362,7 +365,7 @@ RT_DEV LobeSample lobe_sample_inner(const Lobe& l, f3 wo, f2 u) {
       f3 wi;
       if (refract(wo, wh, eta, wi)) {
         float pdf = lobe_pdf_inner(l, wo, wi);
-        return mk_ls(lobe_f_inner(l, wo, wi), wi, pdf, ty);
+        return mk_ls(WANT_F ? lobe_f_inner(l, wo, wi) : mkc(0, 0, 0), wi, pdf, ty);
       }
       return mk_ls(mkc(0, 0, 0), mk3(0, 0, 0), 0.0f, ty);
     }
@@ -377,13 +380,13 @@ RT_DEV LobeSample lobe_sample_inner(const Lobe& l, f3 wo, f2 u) {
       f3 wi = reflect(wo, wh);
       if (!same_hemisphere(wo, wi)) return mk_ls(mkc(0, 0, 0), mk3(0, 0, 0), 0.0f, ty);
       float pdf = lobe_pdf_inner(l, wo, wi);
-      return mk_ls(lobe_f_inner(l, wo, wi), wi, pdf, ty);
+      return mk_ls(WANT_F ? lobe_f_inner(l, wo, wi) : mkc(0, 0, 0), wi, pdf, ty);
     }
     default: {  // default BxDF::sample_f (bxdf.rs:18-25): cosine sampling, EMPTY sampled-type flags (quirk 5)
       f3 wi = cosine_sample_hemisphere(u);
       if (wo.z < 0.0f) wi.z *= -1.0f;
       float pdf = lobe_pdf_inner(l, wo, wi);
-      return mk_ls(lobe_f_inner(l, wo, wi), wi, pdf, 0u);
+      return mk_ls(WANT_F ? lobe_f_inner(l, wo, wi) : mkc(0, 0, 0), wi, pdf, 0u);
     }
   }
 }
@@ -394,7 +397,7 @@ RT_DEV rgb3 apply_scales(const Lobe& l, rgb3 v) {
 }
 RT_DEV rgb3 lobe_f(const Lobe& l, f3 wo, f3 wi) { return apply_scales(l, lobe_f_inner(l, wo, wi)); }
 RT_DEV float lobe_pdf(const Lobe& l, f3 wo, f3 wi) { return l.n_scales > 0 ? default_pdf(wo, wi) : lobe_pdf_inner(l, wo, wi); }  // quirk 10
-RT_DEV LobeSample lobe_sample(const Lobe& l, f3 wo, f2 u) { LobeSample s = lobe_sample_inner(l, wo, u); s.f = apply_scales(l, s.f); return s; }
+RT_DEV LobeSample lobe_sample(const Lobe& l, f3 wo, f2 u) { LobeSample s = lobe_sample_inner<false>(l, wo, u); s.f = apply_scales(l, s.f); return s; }  // only Bsdf::sample_f samples lobes
 
 // ---------------------------------------------------------------- Bsdf (bsdf/mod.rs:64-269)
 #ifndef RT_MAX_LOBES

@@ -1402,7 +1402,7 @@ struct SmallBsdfT {
   }
   RT_DEV static rgb3 lf(const Lobe& l, f3 wo, f3 wi) { return with_kind(l, [&](const Lobe& c) { return lobe_f_inner(c, wo, wi); }); }
   RT_DEV static float lp(const Lobe& l, f3 wo, f3 wi) { return with_kind(l, [&](const Lobe& c) { return lobe_pdf_inner(c, wo, wi); }); }
-  RT_DEV static LobeSample lsamp(const Lobe& l, f3 wo, f2 u) { return with_kind(l, [&](const Lobe& c) { return lobe_sample_inner(c, wo, u); }); }
+  RT_DEV static LobeSample lsamp(const Lobe& l, f3 wo, f2 u) { return with_kind(l, [&](const Lobe& c) { return lobe_sample_inner<false>(c, wo, u); }); }
   RT_DEV int num(unsigned flags) const { return (n > 0 && lobe_matches(l0.kind, flags) ? 1 : 0) + (n > 1 && lobe_matches(l1.kind, flags) ? 1 : 0); }
   RT_DEV int num_nonspecular() const { return num(BSDF_ALL & ~BSDF_SPECULAR); }
   RT_DEV static bool admits(const Lobe& l, unsigned flags, bool refl) {
