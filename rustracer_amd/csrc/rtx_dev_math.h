@@ -163,18 +163,23 @@ struct Pcg32 {
 // Generator matrices of the (0,2)-sequence (rc/sampler/lowdiscrepancy.rs:126-174).
 // Column j of the van-der-Corput / first Sobol' matrix is 0x80000000 >> j, so the XOR over the
 // set bits of g is simply the 32-bit bit reversal of g.
-__device__ __constant__ const uint32_t kCSobol1[32] = {
-    0x80000000u, 0xc0000000u, 0xa0000000u, 0xf0000000u, 0x88000000u, 0xcc000000u, 0xaa000000u, 0xff000000u,
-    0x80800000u, 0xc0c00000u, 0xa0a00000u, 0xf0f00000u, 0x88880000u, 0xcccc0000u, 0xaaaa0000u, 0xffff0000u,
-    0x80008000u, 0xc000c000u, 0xa000a000u, 0xf000f000u, 0x88008800u, 0xcc00cc00u, 0xaa00aa00u, 0xff00ff00u,
-    0x80808080u, 0xc0c0c0c0u, 0xa0a0a0a0u, 0xf0f0f0f0u, 0x88888888u, 0xccccccccu, 0xaaaaaaaau, 0xffffffffu};
 // value of gray_code_sample at index k (rc/sampler/lowdiscrepancy.rs:96-102): the running XOR
 // v_k = scramble ^ XOR_{i<k} C[ctz(i+1)] equals scramble ^ C * gray(k), gray(k) = k ^ (k >> 1).
 RT_DEV uint32_t vdc_bits(uint32_t k) { return __brev(k ^ (k >> 1)); }
+// Column j of the second matrix (0x80000000, 0xc0000000, 0xa0000000, 0xf0000000, 0x88000000, ...: what sobol_2d's loop `v ^= v >> 1` walks,
+// lowdiscrepancy.rs:104-112) is the bit reversal of row j of
+// Pascal's triangle mod 2, i.e. of the coefficients of (1 + x)^j over GF(2). The XOR over the set bits of g is therefore the reversal of G(1 + x) for
+// G(y) = sum g_j y^j: a Taylor shift, which over GF(2) takes five steps because (1 + x)^(2^s) = 1 + x^(2^s) - the high half of every block of 2^(s+1)
+// coefficients is added into the low half. 16 bit operations, no loop over the set bits, no table loads (the identity: tests/test_host_cpu.py; the values on
+// the device: test_sampler_tables_* against the oracle's loop).
 RT_DEV uint32_t sobol1_bits(uint32_t k) {
-  uint32_t g = k ^ (k >> 1), v = 0;
-  while (g) { int j = __ffs(g) - 1; v ^= kCSobol1[j]; g &= g - 1; }
-  return v;
+  uint32_t n = k ^ (k >> 1);
+  n ^= (n & 0xffff0000u) >> 16;
+  n ^= (n & 0xff00ff00u) >> 8;
+  n ^= (n & 0xf0f0f0f0u) >> 4;
+  n ^= (n & 0xccccccccu) >> 2;
+  n ^= (n & 0xaaaaaaaau) >> 1;
+  return __brev(n);
 }
 RT_DEV float u32_to_unit(uint32_t v) { return fminf((float)v * 2.3283064365386963e-10f, kOneMinusEpsilon); }
 

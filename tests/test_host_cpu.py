@@ -257,3 +257,33 @@ def test_kernel_register_and_scratch_budgets(host):
     for name, (vg, sc) in budget.items():
         r = res[name]
         assert r["vgpr"] <= vg and r["scratch"] <= sc and r["vgpr_spills"] == 0, (name, r)
+
+
+def test_second_sobol_matrix_is_a_taylor_shift_over_gf2():
+    """The device evaluates the (0,2)-sequence's second dimension without the generator-matrix loop (rtx_dev_math.h sobol1_bits): the XOR of the matrix columns
+    over the set bits of the Gray code equals the bit reversal of a five-step Taylor shift. Checked against the loop (`v ^= v >> 1`,
+    rc/sampler/lowdiscrepancy.rs:104-112) for every index a 65536-spp table can hold and for random 32-bit arguments."""
+    def loop(n):  # sobol_2d's inner loop on the index itself (no Gray code): v starts at 1 << 31
+        v, out = np.uint32(1 << 31), np.zeros_like(n)
+        n = n.copy()
+        for _ in range(32):
+            out ^= np.where(n & np.uint32(1), v, np.uint32(0))
+            n >>= np.uint32(1)
+            v ^= v >> np.uint32(1)
+        return out
+
+    def brev(x):
+        x = ((x >> np.uint32(1)) & np.uint32(0x55555555)) | ((x & np.uint32(0x55555555)) << np.uint32(1))
+        x = ((x >> np.uint32(2)) & np.uint32(0x33333333)) | ((x & np.uint32(0x33333333)) << np.uint32(2))
+        x = ((x >> np.uint32(4)) & np.uint32(0x0f0f0f0f)) | ((x & np.uint32(0x0f0f0f0f)) << np.uint32(4))
+        x = ((x >> np.uint32(8)) & np.uint32(0x00ff00ff)) | ((x & np.uint32(0x00ff00ff)) << np.uint32(8))
+        return (x >> np.uint32(16)) | (x << np.uint32(16))
+
+    def shift(n):
+        n = n.copy()
+        for s, m in ((16, 0xffff0000), (8, 0xff00ff00), (4, 0xf0f0f0f0), (2, 0xcccccccc), (1, 0xaaaaaaaa)):
+            n ^= (n & np.uint32(m)) >> np.uint32(s)
+        return brev(n)
+
+    g = np.concatenate([np.arange(1 << 17, dtype=np.uint32), np.random.default_rng(7).integers(0, 1 << 32, 200000, dtype=np.uint64).astype(np.uint32)])
+    assert np.array_equal(loop(g), shift(g))
