@@ -1598,7 +1598,7 @@ __global__ void __launch_bounds__(256, MODE == 1 ? RT_SHADE_MIN_WAVES : RT_SHADE
             LiSample ls = (MODE == 1) ? area_light_sample_li(sc, light, si.hit, u_light) : light_sample_li<GENERAL>(gsc, light, si.hit, u_light);
             if (ls.pdf > 0.0f && !is_black(ls.li)) {
               rgb3 f = bsdf.f(si.hit.wo, ls.wi, nonspec) * fabsf(dot(ls.wi, si.sh_n));
-              float scattering_pdf = bsdf.pdf(si.hit.wo, ls.wi, nonspec);
+              float scattering_pdf = (MODE != 1 && light_is_delta(light)) ? 0.0f : bsdf.pdf(si.hit.wo, ls.wi, nonspec);  // read by the power heuristic only: a delta light has none
               if (!is_black(f)) {
                 Ray sr = spawn_ray_to_interaction(si.hit, ls.p1);  // VisibilityTester, light/mod.rs:52-55
                 ps.sh[pid].o = make_float4(sr.o.x, sr.o.y, sr.o.z, sr.t_max);
@@ -1758,8 +1758,9 @@ __global__ void __launch_bounds__(256) k_resolve(DScene sc, PassState ps) {
       }
       if (!is_black(li)) ld = ld + mkc(b.x, b.y, b.z) * li * b.w / c.w;
     }
-    float4 l4 = ps.acc[pid].lacc;
     rgb3 add = mkc(c.x, c.y, c.z) * (ld / a.w);
+    if (add.r == 0.0f && add.g == 0.0f && add.b == 0.0f) continue;  // both rays blocked (most vertices of an interior): L + 0 = L, the scattered read-modify-write is skipped (a NaN is not 0)
+    float4 l4 = ps.acc[pid].lacc;
     ps.acc[pid].lacc = make_float4(l4.x + add.r, l4.y + add.g, l4.z + add.b, l4.w);
   }
 }
