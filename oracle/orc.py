@@ -129,8 +129,8 @@ class OracleScene:
         self.h = C.c_void_p(L.orc_scene_new())
         P, idx, N, UV, S, mat, light, flags = desc.arrays()
         self._keep = (P, idx, N, UV, S, mat, light, flags)
-        rc = L.orc_scene_set_mesh(self.h, _p(P), P.shape[0], _p(idx, C.c_int32), idx.shape[0], _p(N), _p(UV), _p(S),
-                                  _p(mat, C.c_int32), _p(light, C.c_int32), _p(flags, C.c_uint8))
+        rc = 0 if idx.shape[0] == 0 else L.orc_scene_set_mesh(self.h, _p(P), P.shape[0], _p(idx, C.c_int32), idx.shape[0], _p(N), _p(UV), _p(S),
+                                                             _p(mat, C.c_int32), _p(light, C.c_int32), _p(flags, C.c_uint8))
         assert rc == 0
         alpha = desc.alpha_ids() if hasattr(desc, "alpha_ids") else None
         if alpha is not None:

@@ -168,8 +168,9 @@ class HostScene:
         self.h = C.c_void_p(L.rtxh_scene_new())
         P, idx, N, UV, S, mat, light, flags = desc.arrays()
         self._keep = (P, idx, N, UV, S, mat, light, flags)
-        _check(L.rtxh_scene_set_mesh(self.h, _p(P), P.shape[0], _p(idx, C.c_int32), idx.shape[0], _p(N), _p(UV), _p(S),
-                                     _p(mat, C.c_int32), _p(light, C.c_int32), _p(flags, C.c_uint8)), "set_mesh")
+        if idx.shape[0]:  # (a scene may hold spheres / object instances only)
+            _check(L.rtxh_scene_set_mesh(self.h, _p(P), P.shape[0], _p(idx, C.c_int32), idx.shape[0], _p(N), _p(UV), _p(S),
+                                         _p(mat, C.c_int32), _p(light, C.c_int32), _p(flags, C.c_uint8)), "set_mesh")
         alpha = desc.alpha_ids() if hasattr(desc, "alpha_ids") else None
         if alpha is not None:
             self._keep += (alpha,)

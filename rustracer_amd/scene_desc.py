@@ -446,6 +446,9 @@ class SceneDesc:
 
     def arrays(self):
         """(P, idx, N|None, UV|None, S|None, tri_material, tri_light, tri_flags) as contiguous arrays."""
+        if not self._P:  # a scene of spheres / object instances only: no top-level triangle
+            z = lambda w, dt: np.zeros((0, w) if w else (0,), dt)
+            return z(3, np.float32), z(3, np.int32), None, None, None, z(0, np.int32), z(0, np.int32), z(0, np.uint8)
         P = np.ascontiguousarray(np.concatenate(self._P), dtype=np.float32)
         idx = np.ascontiguousarray(np.concatenate(self._idx), dtype=np.int32)
         flags = np.ascontiguousarray(np.concatenate(self._flags), dtype=np.uint8)

@@ -118,3 +118,23 @@ def test_instances_render_through_the_multi_device_entry_point(gpu_host):
     one, _ = h.render()
     two = h.render_multi(devices=[0, 0], chunks_per_device=2)[0]
     assert np.array_equal(bits(one), bits(two))
+
+
+def test_a_scene_of_instances_only(gpu_host, orc):
+    """No top-level triangle at all: one two-triangle object placed twice and a single-triangle object (wrapped without a tree) under a point light."""
+    from rustracer_amd.scene_desc import SceneDesc
+    s = SceneDesc()
+    m = s.matte((0.5, 0.6, 0.4))
+    quad = s.add_object([dict(P=np.float32([[0, 0, 0], [1, 0, 0], [0, 1, 0], [1, 1, 0]]), idx=[[0, 1, 2], [1, 3, 2]], material=m)])
+    tri = s.add_object([dict(P=np.float32([[0, 0, 0], [1, 0, 0], [0, 1, 0]]), idx=[[0, 1, 2]], material=m)])
+    for obj, t, sc in ((quad, (0.0, 0.0, 3.0), 2.0), (quad, (-2.5, -0.5, 4.0), 1.0), (tri, (1.0, -1.0, 2.5), 1.5)):
+        mtx = np.diag([sc, sc, sc, 1.0]).astype(np.float32); mtx[:3, 3] = t
+        s.add_instance(obj, mtx)
+    s.point_light((0.5, 0.5, 0.0), (8.0, 8.0, 8.0))
+    s.camera.pos, s.camera.look = (0.5, 0.5, -3.0), (0.5, 0.5, 3.0)
+    s.film.xres, s.film.yres = 32, 24
+    s.sampler.spp = 4
+    fo, _ = orc.OracleScene(s).render(mode=1)
+    fh, _ = gpu_host.HostScene(s).render()
+    assert np.array_equal(fo[..., 3], fh[..., 3]) and orc.film_to_rgb(fo).mean() > 0
+    assert rel_l2(gpu_host.film_to_rgb(fh), orc.film_to_rgb(fo)) < 1e-3
