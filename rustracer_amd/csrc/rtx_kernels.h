@@ -790,6 +790,7 @@ struct PairLane {
   RT_DEV void set_rp(const RayPre& r) { kz = r.kz; sx = r.sx; sy = r.sy; sz = r.sz; }
   int sp, prim; unsigned cur; TriHit hit;
 };
+// (the leaf phase of these loops is held back until enough lanes wait at a leaf: leaf_phase_now, rtx_dev_scene.h)
 struct TraceOut { float4* hits; size_t hs; bool hit_b2; unsigned* occluded; size_t os; float4* lacc; size_t ls; const float4* direct_add; size_t as; };
 RT_DEV TraceOut trace_out_of(const TraceIO& io) {
   TraceOut o; o.hits = io.hits; o.hs = io.hit_stride; o.hit_b2 = io.hit_b2 != 0; o.occluded = io.occluded; o.os = io.occ_stride;
@@ -897,9 +898,13 @@ __global__ void __launch_bounds__(BLOCK) k_trace_pair(DScene sc, TraceIO io, con
     if (WW) {
       while (L.active && !(L.cur & RT_PAIR_LEAF)) pair_interior_step<ANY, BLOCK>(L, out, pairs, stack, tstack, grid_lanes);
       if (L.active) pair_leaf_step<ANY, BLOCK>(L, out, tri_p, stack, tstack, grid_lanes);
-    } else if (L.active) {
-      if (L.cur & RT_PAIR_LEAF) pair_leaf_step<ANY, BLOCK>(L, out, tri_p, stack, tstack, grid_lanes);
-      else pair_interior_step<ANY, BLOCK>(L, out, pairs, stack, tstack, grid_lanes);
+    } else {
+      const bool at_leaf = L.active && (L.cur & RT_PAIR_LEAF) != 0u;
+      const bool leaves_now = leaf_phase_now(L.active, at_leaf);
+      if (L.active) {
+        if (at_leaf) { if (leaves_now) pair_leaf_step<ANY, BLOCK>(L, out, tri_p, stack, tstack, grid_lanes); }
+        else pair_interior_step<ANY, BLOCK>(L, out, pairs, stack, tstack, grid_lanes);
+      }
     }
   }
   if (stats) {
@@ -1021,9 +1026,13 @@ __global__ void __launch_bounds__(BLOCK, 6) k_trace_top(DScene sc, TraceIO io, c
       exhausted = ((unsigned long long)(cursor >> 6) * n_waves + wave) * 64ull + (cursor & 63u) >= count;
     }
     if (__ballot(L.active) == 0ull) { if (exhausted) break; else continue; }
-    if (L.active) {
-      if (L.cur & RT_PAIR_LEAF) top_leaf_step<ANY, BLOCK>(L, out, tri_p, stk, tstack, grid_lanes);
-      else top_interior_step<ANY, BLOCK>(L, out, pairs, s_top, stk, tstack, grid_lanes);
+    {
+      const bool at_leaf = L.active && (L.cur & RT_PAIR_LEAF) != 0u;
+      const bool leaves_now = leaf_phase_now(L.active, at_leaf);
+      if (L.active) {
+        if (at_leaf) { if (leaves_now) top_leaf_step<ANY, BLOCK>(L, out, tri_p, stk, tstack, grid_lanes); }
+        else top_interior_step<ANY, BLOCK>(L, out, pairs, s_top, stk, tstack, grid_lanes);
+      }
     }
   }
   if (stats) {
@@ -1151,9 +1160,13 @@ __global__ void __launch_bounds__(BLOCK) k_trace_quad(DScene sc, TraceIO io, con
       exhausted = ((unsigned long long)(cursor >> 6) * n_waves + wave) * 64ull + (cursor & 63u) >= count;
     }
     if (__ballot(L.active) == 0ull) { if (exhausted) break; else continue; }
-    if (L.active) {
-      if (L.cur & RT_PAIR_LEAF) pair_leaf_step<ANY, BLOCK>(L, out, tri_p, stack, tstack, grid_lanes);
-      else quad_interior_step<ANY, BLOCK>(L, out, quads, stack, tstack, grid_lanes);
+    {
+      const bool at_leaf = L.active && (L.cur & RT_PAIR_LEAF) != 0u;
+      const bool leaves_now = leaf_phase_now(L.active, at_leaf);
+      if (L.active) {
+        if (at_leaf) { if (leaves_now) pair_leaf_step<ANY, BLOCK>(L, out, tri_p, stack, tstack, grid_lanes); }
+        else quad_interior_step<ANY, BLOCK>(L, out, quads, stack, tstack, grid_lanes);
+      }
     }
   }
   if (stats) {
