@@ -425,6 +425,7 @@ extern "C" int rt_scene_create(const rt_scene_desc* desc, int device, rt_scene**
   if (s->masked_emitters) { s->lambert_only = false; s->lambert_materials = false; }  // only the generic kernel re-intersects emitters with the mask test
   s->n_materials = desc->n_materials;
   s->small = desc->n_nodes <= RT_SMALL_NODES && desc->n_tris <= RT_SMALL_TRIS && !s->general_prims;
+  if (getenv("RTX_SMALL") && getenv("RTX_SMALL")[0] == '0') s->small = false;  // measurement knob: an LDS-sized scene through the kernels of the large ones
   {  // tree height bounds the number of simultaneously pending stack entries
     // one tree: nodes [base, base + nn), child offsets relative to base, leaf ranges within its np primitives
     auto tree_depth = [&](uint32_t base, uint32_t nn, uint32_t np, int& maxd) -> bool {
@@ -501,6 +502,7 @@ extern "C" int rt_scene_create(const rt_scene_desc* desc, int device, rt_scene**
       // gains is its sixth wave per SIMD, and that pays where the tree fits the 32 MB of L2 without fitting an L1.
       const size_t pair_bytes = (size_t)desc->n_nodes * 64;
       s->top_for_closest = pair_bytes >= ((size_t)1 << 20) && pair_bytes <= ((size_t)64 << 20);
+      if (getenv("RTX_TOP_CLOSEST")) s->top_for_closest = getenv("RTX_TOP_CLOSEST")[0] == '1';  // measurement knob
     }
     // four-wide records for the any-hit kernel (k_trace_quad): an interior node's grandchildren (a leaf child stands for itself), 128 B
     // per node: 24 floats = boxes of slots 0..3 (slots 0,1: first child's part, 2,3: second child's), 4 codes (0xffffffff = empty slot),
