@@ -336,7 +336,7 @@ struct PbrtLoader {
   bool add_shape(const std::string& name, const PbrtParams& p) {
     std::vector<float> vp, vn, vuv, vs; std::vector<int32_t> vi;
     if (name == "sphere" || name == "disk" || name == "cylinder") {  // an analytic primitive under the CTM, with one DiffuseAreaLight if an area light is active (api.rs:933-946)
-      if (in_instance) return fail_("a " + name + " inside an object definition is not supported (instances are written out as triangles)");
+      if (in_instance) return fail_("a " + name + " inside an object definition is not supported (an object holds triangle meshes only)");
       const int kind = name == "sphere" ? 0 : (name == "disk" ? 1 : 2);
       const float radius = p.one_float("radius", 1.0f);
       // Sphere::create (sphere.rs:53-68): zmin zmax phimax; Disk::create (disk.rs:48-62): height innerradius phimax; Cylinder::create
