@@ -570,7 +570,9 @@ __global__ void __launch_bounds__(BLOCK) k_trace(DScene sc, TraceIO io, const un
     Ray ray; ray.o = mk3(o4.x, o4.y, o4.z); ray.d = mk3(d4.x, d4.y, d4.z); ray.t_max = o4.w;
     int prim = -1; TriHit h; h.t = kInf; h.b0 = h.b1 = h.b2 = 0.0f;
     bool found;
-    if (SMALL) { LdsSrc src{s_nodes, s_tris}; found = traverse<ANY, COUNT, LdsSrc, StackT>(src, ray, stack + threadIdx.x, BLOCK, prim, h, n_nodes, n_tris); }
+    constexpr int LM = ANY ? RT_LDS_LEAF_MIN_ANY : RT_LDS_LEAF_MIN_CLOSEST;
+    if (SMALL && LM > 1 && LM < 64 && !COUNT) { LdsSrc src{s_nodes, s_tris}; found = traverse_rounds<ANY, COUNT, LM, LdsSrc, StackT>(src, ray, stack + threadIdx.x, BLOCK, prim, h, n_nodes, n_tris); }
+    else if (SMALL) { LdsSrc src{s_nodes, s_tris}; found = traverse<ANY, COUNT, LdsSrc, StackT>(src, ray, stack + threadIdx.x, BLOCK, prim, h, n_nodes, n_tris); }
     else { GlobalSrc src{sc.nodes, sc.tri_p}; found = traverse<ANY, COUNT, GlobalSrc, StackT>(src, ray, stack + threadIdx.x, BLOCK, prim, h, n_nodes, n_tris); }
     n_rays += 1;
     if (ANY) trace_write_any(lacc, ls, direct_add, as, occluded, os, pid, d4.w, found);
