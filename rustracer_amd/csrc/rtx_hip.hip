@@ -74,7 +74,7 @@ struct rt_scene {
   // per-render workspace
   DevBuf ws[32];
   DevBuf film_acc, own_acc, film_out, counters, stats, filter_table;
-  DevBuf bin_words, bin_sorted;  // material binning of the shade queue (generic shade path)
+  DevBuf bin_words, bin_sorted, bin_at;  // material binning of the shade queue (generic shade path); bin_at: u16 per queue entry
   unsigned n_materials = 0, n_code_classes = 0, n_lambert_classes = 0, n_small_classes = 0, n_wide_classes = 0;
   // sampler tables are double-buffered: K0 of batch b+1 runs on aux_stream under the path kernels of batch b
   DevBuf scrambles[2], perms[2];
@@ -1013,7 +1013,7 @@ extern "C" int rt_render(rt_scene* s, const rt_camera* cam, const rt_film_desc* 
         {&s->counters, counter_words * 4}, {&s->stats, (size_t)ST_COUNT * 8}, {&s->film_acc, (size_t)cw * ch * 16}, {&s->own_acc, (size_t)chunk_pixels * 16},
         {&s->filter_table, 1024}, {&s->scrambles[0], (size_t)chunk_pixels * 3 * dims * 4}, {&s->perms[0], (size_t)(chunk_pixels * table_bytes_per_pixel)},
         {&s->sampler_plan.partners, (size_t)(chunk_pixels * table_bytes_per_pixel)}};
-    if (use_bins) { want.push_back({&s->bin_words, (size_t)(fp.max_depth + 1) * bin_stride * 4}); want.push_back({&s->bin_sorted, (size_t)cap * 4}); }
+    if (use_bins) { want.push_back({&s->bin_words, (size_t)(fp.max_depth + 1) * bin_stride * 4}); want.push_back({&s->bin_sorted, (size_t)cap * 4}); want.push_back({&s->bin_at, (size_t)cap * 2}); }
     if (multi_batch) { want.push_back({&s->scrambles[1], (size_t)chunk_pixels * 3 * dims * 4}); want.push_back({&s->perms[1], (size_t)(chunk_pixels * table_bytes_per_pixel)}); }
     if (!(flags & RT_FLAG_FILM_ON_DEVICE)) want.push_back({&s->film_out, (size_t)cw * ch * 16});
     size_t grow = 0;  // bytes the buffers have to grow by (a buffer that is too small is freed and allocated anew)
@@ -1126,10 +1126,10 @@ extern "C" int rt_render(rt_scene* s, const rt_camera* cam, const rt_film_desc* 
           tm.begin(&stats.ms_shade_bin);
           unsigned* bw = s->bin_words.as<unsigned>() + (size_t)bounce * bin_stride;
           unsigned* hist = bw; unsigned* cursor = bw + (RT_BIN_MAX + 1); unsigned* sorted_cnt = bw + 2 * (RT_BIN_MAX + 1);
-          hipLaunchKernelGGL(k_bin_count, dim3(pgrid), dim3(256), 0, stream, s->d, ps, n_bins, hist);
+          hipLaunchKernelGGL(k_bin_count, dim3(pgrid), dim3(256), 0, stream, s->d, ps, n_bins, hist, s->bin_at.as<unsigned short>());
           unsigned* ranges = sorted_cnt + RT_QSHARDS;
           hipLaunchKernelGGL(k_bin_scatter, dim3(pgrid), dim3(256), 0, stream, s->d, ps, n_bins, hist, cursor, s->bin_sorted.as<unsigned>(), sorted_cnt,
-                             split_classes ? n_first : 0u, split_classes ? n_first + n_second : 0u, split_classes ? n_first + n_second + n_third : 0u, ranges);
+                             split_classes ? n_first : 0u, split_classes ? n_first + n_second : 0u, split_classes ? n_first + n_second + n_third : 0u, ranges, s->bin_at.as<unsigned short>());
           tm.end();
           PassState pb = ps; pb.q_in = s->bin_sorted.as<unsigned>(); pb.cnt_in = sorted_cnt;  // all entries in shard 0: QView::get(i) = ids[i]
           // classes of the register-resident front-ends, then the generic one, then the rays that left the scene

@@ -1191,7 +1191,8 @@ RT_DEV unsigned bin_of(const DMaterial* __restrict__ materials, const float4* __
   const unsigned m = (unsigned)materials[tri_material(tri_p, prim)].code_class;
   return m < n_bins - 1u ? m : n_bins - 2u;
 }
-__global__ void __launch_bounds__(256) k_bin_count(DScene sc, PassState ps, unsigned n_bins, unsigned* __restrict__ hist) {
+// bin_at[i]: the bin of queue entry i, kept for k_bin_scatter - finding it takes two dependent gathers (hit record -> triangle -> material) that need not be repeated
+__global__ void __launch_bounds__(256) k_bin_count(DScene sc, PassState ps, unsigned n_bins, unsigned* __restrict__ hist, unsigned short* __restrict__ bin_at) {
   __shared__ unsigned lh[RT_BIN_MAX + 1];
   for (unsigned i = threadIdx.x; i <= RT_BIN_MAX; i += 256u) lh[i] = 0u;
   __syncthreads();
@@ -1199,7 +1200,9 @@ __global__ void __launch_bounds__(256) k_bin_count(DScene sc, PassState ps, unsi
   const unsigned count = ps.q_in ? qv.total() : ps.cap;
   for (unsigned i = blockIdx.x * 256u + threadIdx.x; i < count; i += gridDim.x * 256u) {
     const unsigned pid = ps.q_in ? qv.get(i) : i;
-    atomicAdd(&lh[bin_of(sc.materials, sc.tri_p, ps.vert, pid, n_bins)], 1u);
+    const unsigned b = bin_of(sc.materials, sc.tri_p, ps.vert, pid, n_bins);
+    bin_at[i] = (unsigned short)b;
+    atomicAdd(&lh[b], 1u);
   }
   __syncthreads();
   for (unsigned i = threadIdx.x; i < n_bins; i += 256u) if (lh[i]) atomicAdd(&hist[i], lh[i]);
@@ -1207,7 +1210,7 @@ __global__ void __launch_bounds__(256) k_bin_count(DScene sc, PassState ps, unsi
 // sorted: path ids grouped by bin; sorted_cnt[RT_QSHARDS]: {total, 0, ...} so that the result reads as a one-shard queue
 __global__ void __launch_bounds__(256) k_bin_scatter(DScene sc, PassState ps, unsigned n_bins, const unsigned* __restrict__ hist, unsigned* __restrict__ cursor,
                                                      unsigned* __restrict__ sorted, unsigned* __restrict__ sorted_cnt, unsigned split_bin, unsigned split_bin2,
-                                                     unsigned split_bin3, unsigned* __restrict__ ranges) {
+                                                     unsigned split_bin3, unsigned* __restrict__ ranges, const unsigned short* __restrict__ bin_at) {
   __shared__ unsigned base[RT_BIN_MAX + 1], lcount[RT_BIN_MAX + 1], lbase[RT_BIN_MAX + 1];
   if (threadIdx.x == 0) {  // exclusive prefix of the histogram (<= 257 entries)
     unsigned run = 0;
@@ -1234,7 +1237,7 @@ __global__ void __launch_bounds__(256) k_bin_scatter(DScene sc, PassState ps, un
     for (unsigned k = 0; k < E; ++k) {  // rounds of 256 consecutive entries: a bin keeps the queue's order up to that granularity
       const unsigned i = start + k * 256u + threadIdx.x;
       live[k] = i < count; pid[k] = 0; bin[k] = 0; rank[k] = 0;
-      if (live[k]) { pid[k] = ps.q_in ? qv.get(i) : i; bin[k] = bin_of(sc.materials, sc.tri_p, ps.vert, pid[k], n_bins); }
+      if (live[k]) { pid[k] = ps.q_in ? qv.get(i) : i; bin[k] = bin_at[i]; }
     }
 #pragma unroll
     for (unsigned k = 0; k < E; ++k) if (live[k]) rank[k] = atomicAdd(&lcount[bin[k]], 1u);
