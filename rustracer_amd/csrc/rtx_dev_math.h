@@ -211,6 +211,14 @@ RT_DEV float radical_inverse(int base_index, uint64_t a) {
 }
 
 // rc/lib.rs:171-189 over a device array: pred(i) = (a[i] <= x)
+// the same bisection started inside a bracket known to hold the partition point (guide tables of the environment map, DLight::guide)
+RT_DEV int find_interval_le_from(const float* a, int size, float x, int first, int len) {
+  while (len > 0) {
+    int half = len >> 1, middle = first + half;
+    if (a[middle] <= x) { first = middle + 1; len -= half + 1; } else { len = half; }
+  }
+  return clampi(first - 1, 0, size - 2);
+}
 RT_DEV int find_interval_le(const float* a, int size, float x) {
   int first = 0, len = size;
   while (len > 0) {

@@ -21,6 +21,9 @@ struct DLight {
   int kind; int prim; float rgb[3]; int two_sided; float vec[3]; float area; float world_radius; int image;
   float l2w[12], w2l[12];
   int nu, nv; const float* func; const float* cdf; const float* func_int; const float* mfunc; const float* mcdf; float mfunc_int;
+  // guide tables of the CDF searches (rt_scene_create): guide[row][k] = the number of entries of the row's CDF that are <= k / 2^glog, k = 0 .. 2^glog - so
+  // the bisection for u starts inside [guide[k], guide[k + 1]], k = floor(u 2^glog), ~16 entries instead of 2049 (same answer: the CDF is non-decreasing)
+  const unsigned short* guide; const unsigned short* mguide; int glog, mglog;
 };
 struct DSphere;  // rtx_dev_sphere.h
 // An object instance (rt_instance): primitive_to_world and its inverse, where the object's tree and primitives sit in the scene's arrays, and the first
@@ -45,6 +48,7 @@ struct DScene {
   // tables of the BUILT voxels only (those that can hold a surface point): [slot][n_lights], [slot][n_lights+1], [slot]; ld_slot[voxel] = slot or -1.
   // Memory is O(built voxels x lights) - a dense 64^3 table of 10^5 emitters would not fit any GPU
   const float* ld_func; const float* ld_cdf; const float* ld_int; const int* ld_slot;
+  const unsigned short* ld_guide; int ld_glog;  // guide tables of the rows' CDF searches, [slot][2^ld_glog + 1] (see DLight::guide); ld_glog < 0: none (few lights)
   // This record in device memory. A kernel takes its DScene by value (fields in SGPRs); an out-of-line device function that wants the scene is handed
   // `*sc.self` instead of `sc`: a reference to the kernel argument would force a 300-byte private copy of it into every lane's scratch, read back
   // lane by lane at each use (k_shade<3> on S4 moved 4 KB per vertex between L2 and memory, most of it scratch).

@@ -508,6 +508,25 @@ RT_DEV void d1_sample_continuous(const float* func, const float* cdf, float func
   x = ((float)offset + du) / (float)n;
   off = offset;
 }
+RT_DEV void d1_sample_continuous_guided(const float* func, const float* cdf, float func_int, int n, float u, const unsigned short* guide, int glog, float& x, float& pdf, int& off) {
+  const int G = 1 << glog;
+  const int k = clampi((int)(u * (float)G), 0, G - 1);  // u 2^glog is exact
+  const int g0 = (int)guide[k], g1 = (int)guide[k + 1];
+  int offset = find_interval_le_from(cdf, n + 1, u, g0, g1 - g0);
+  float du = u - cdf[offset];
+  if (cdf[offset + 1] - cdf[offset] > 0.0f) du /= cdf[offset + 1] - cdf[offset];
+  pdf = func_int > 0.0f ? func[offset] / func_int : 0.0f;
+  x = ((float)offset + du) / (float)n;
+  off = offset;
+}
+RT_DEV void d1_sample_discrete_guided(const float* func, const float* cdf, float func_int, int n, float u, const unsigned short* guide, int glog, int& off, float& pdf) {
+  const int G = 1 << glog;
+  const int k = clampi((int)(u * (float)G), 0, G - 1);
+  const int g0 = (int)guide[k], g1 = (int)guide[k + 1];
+  int offset = find_interval_le_from(cdf, n + 1, u, g0, g1 - g0);
+  pdf = func_int > 0.0f ? func[offset] / (func_int * (float)n) : 0.0f;
+  off = offset;
+}
 RT_DEV void d1_sample_discrete(const float* func, const float* cdf, float func_int, int n, float u, int& off, float& pdf) {  // :70-79
   int offset = find_interval_le(cdf, n + 1, u);
   pdf = func_int > 0.0f ? func[offset] / (func_int * (float)n) : 0.0f;
@@ -605,8 +624,8 @@ RT_DEVN LiSample light_sample_li(const DScene& sc, const DLight& l, Interaction 
     default: {  // InfiniteAreaLight::sample_li infinite.rs:143-181
       float d1, pdf1, d0, pdf0; int v, dummy;
       if (RT_DBG(sc, 2)) { d1 = u.y; d0 = u.x; pdf0 = pdf1 = 1.0f; } else {
-      d1_sample_continuous(l.mfunc, l.mcdf, l.mfunc_int, l.nv, u.y, d1, pdf1, v);  // Distribution2D::sample_continuous
-      d1_sample_continuous(l.func + (size_t)v * l.nu, l.cdf + (size_t)v * (l.nu + 1), l.func_int[v], l.nu, u.x, d0, pdf0, dummy);
+      d1_sample_continuous_guided(l.mfunc, l.mcdf, l.mfunc_int, l.nv, u.y, l.mguide, l.mglog, d1, pdf1, v);  // Distribution2D::sample_continuous
+      d1_sample_continuous_guided(l.func + (size_t)v * l.nu, l.cdf + (size_t)v * (l.nu + 1), l.func_int[v], l.nu, u.x, l.guide + ((size_t)v << l.glog) + (size_t)v, l.glog, d0, pdf0, dummy);
       }
       float map_pdf = pdf0 * pdf1;
       s.p1.p_error = mk3(0, 0, 0); s.p1.n = mk3(0, 0, 0);

@@ -59,7 +59,7 @@ struct rt_scene {
   bool top_for_closest = false;  // closest-hit rays through k_trace_top as well (shadow rays always, when no four-wide records exist)
   bool use_pairs = false;
   DevBuf quads; bool use_quads = false; int quad_stack_depth = 0;  // four-wide records of the any-hit kernel (k_trace_quad)
-  DevBuf nodes, tri_p, tri_n, tri_uv, tri_s, tri_alpha, spheres, textures, images, materials, lights, texels, dist;
+  DevBuf nodes, tri_p, tri_n, tri_uv, tri_s, tri_alpha, spheres, textures, images, materials, lights, texels, dist, guides;
   bool has_spheres = false;
   bool has_instances = false;  // object instances: two-level traversal in k_trace_big<.., GENERAL>, every vertex shaded by k_shade<0, true>
   DevBuf instances;
@@ -67,7 +67,7 @@ struct rt_scene {
   bool masked_emitters = false;  // ... and some of them emit: every vertex is shaded by k_shade<0, true> (Shape::pdf_wi evaluates the mask)
   std::vector<DLight> h_lights;
   // light distribution tables (built per render, rc/integrator/path.rs:86-94)
-  DevBuf ld_func, ld_cdf, ld_int, ld_mark, ld_list, ld_slot;
+  DevBuf ld_func, ld_cdf, ld_int, ld_mark, ld_list, ld_slot, ld_guide;
   DevBuf self;  // `d` in device memory (DScene::self), rewritten whenever `d` changes
   int ld_strategy_built = -1; bool ld_all_voxels = false;  // the tables are a function of the scene alone: built once per strategy, kept across frames
   std::mutex render_mutex;  // rt_render shares the workspace below: concurrent calls on one rt_scene take turns
@@ -355,6 +355,23 @@ extern "C" int rt_scene_create(const rt_scene_desc* desc, int device, rt_scene**
     }
     std::vector<float> blob(total + 4);
     TRY_RC([&]() { return s->dist.ensure(blob.size() * 4) == hipSuccess ? RT_OK : fail(RT_ERR_OOM, "dist alloc"); }());
+    // guide tables of the environment maps' CDF searches (DLight::guide): 2^glog buckets of ~16 entries per row
+    auto guide_log = [](int n) { int g = 0; while ((2 << g) * 16 <= n) ++g; return g; };
+    auto guide_row = [](const float* cdf, int n, int glog, unsigned short* out) {  // out[k] = #{i in [0, n] : cdf[i] <= k / 2^glog}
+      const int G = 1 << glog; int i = 0;
+      for (int k = 0; k <= G; ++k) { const float x = (float)k / (float)G; while (i <= n && cdf[i] <= x) ++i; out[k] = (unsigned short)i; }
+    };
+    size_t guide_total = 0;
+    for (uint32_t i = 0; i < desc->n_lights; ++i) {
+      const rt_light& l = desc->lights[i];
+      if (l.kind == RT_LIGHT_INFINITE) {
+        if (l.dist_nu < 1 || l.dist_nv < 1 || l.dist_nu > 65534 || l.dist_nv > 65534 || !l.dist_cdf || !l.marg_cdf) { delete s; return fail(RT_ERR_INVALID, "infinite light tables missing or larger than 65534 entries per row"); }
+        guide_total += (size_t)l.dist_nv * ((1u << guide_log(l.dist_nu)) + 1) + ((1u << guide_log(l.dist_nv)) + 1);
+      }
+    }
+    std::vector<unsigned short> gblob(guide_total + 1);
+    TRY_RC([&]() { return s->guides.ensure(gblob.size() * 2) == hipSuccess ? RT_OK : fail(RT_ERR_OOM, "guide alloc"); }());
+    size_t gbase = 0;
     size_t base = 0; int n_inf = 0;
     for (uint32_t i = 0; i < desc->n_lights; ++i) {
       const rt_light& l = desc->lights[i]; DLight& d = s->h_lights[i];
@@ -375,10 +392,19 @@ extern "C" int rt_scene_create(const rt_scene_desc* desc, int device, rt_scene**
         memcpy(&blob[base], l.dist_func_int, (size_t)l.dist_nv * 4); d.func_int = db + base; base += l.dist_nv;
         memcpy(&blob[base], l.marg_func, (size_t)l.dist_nv * 4); d.mfunc = db + base; base += l.dist_nv;
         memcpy(&blob[base], l.marg_cdf, ((size_t)l.dist_nv + 1) * 4); d.mcdf = db + base; base += (size_t)l.dist_nv + 1;
+        d.glog = guide_log(l.dist_nu); d.mglog = guide_log(l.dist_nv);
+        const size_t gw = ((size_t)1 << d.glog) + 1;
+        d.guide = s->guides.as<unsigned short>() + gbase;
+        for (int r = 0; r < l.dist_nv; ++r) guide_row(l.dist_cdf + (size_t)r * (l.dist_nu + 1), l.dist_nu, d.glog, &gblob[gbase + (size_t)r * gw]);
+        gbase += (size_t)l.dist_nv * gw;
+        d.mguide = s->guides.as<unsigned short>() + gbase;
+        guide_row(l.marg_cdf, l.dist_nv, d.mglog, &gblob[gbase]);
+        gbase += ((size_t)1 << d.mglog) + 1;
       }
     }
     s->d.n_infinite = n_inf;
     if (hipMemcpy(s->dist.p, blob.data(), blob.size() * 4, hipMemcpyHostToDevice) != hipSuccess) { delete s; return fail(RT_ERR_HIP, "dist upload"); }
+    if (hipMemcpy(s->guides.p, gblob.data(), gblob.size() * 2, hipMemcpyHostToDevice) != hipSuccess) { delete s; return fail(RT_ERR_HIP, "guide upload"); }
     TRY_RC(upload(s->lights, s->h_lights.data(), s->h_lights.size() * sizeof(DLight)));
   }
 #undef TRY_RC
@@ -393,7 +419,7 @@ extern "C" int rt_scene_create(const rt_scene_desc* desc, int device, rt_scene**
   d.n_lights = (int)desc->n_lights;
   d.wb_min = f3{desc->nodes[0].bmin[0], desc->nodes[0].bmin[1], desc->nodes[0].bmin[2]};
   d.wb_max = f3{desc->nodes[0].bmax[0], desc->nodes[0].bmax[1], desc->nodes[0].bmax[2]};
-  d.ld_uniform = 1; d.nvox[0] = d.nvox[1] = d.nvox[2] = 1;
+  d.ld_uniform = 1; d.nvox[0] = d.nvox[1] = d.nvox[2] = 1; d.ld_glog = -1; d.ld_guide = nullptr;
   d.needs_differentials = 0;
 #ifdef RT_ABLATE
   d.dbg = getenv("RTX_DBG") ? atoi(getenv("RTX_DBG")) : 0;
@@ -573,6 +599,10 @@ static int build_light_distribution(rt_scene* s, int strategy, hipStream_t strea
   if (s->ld_strategy_built == strategy && (s->ld_all_voxels || !all_voxels)) return RT_OK;
   const int nl = s->n_lights;
   const bool uniform = strategy == 1 || nl == 1 || nl == 0;
+  // guide tables for the rows' CDF searches (DScene::ld_guide) where a search is long enough to gain from one: >= 64 lights, <= 65534 (u16 entries)
+  int glog = -1;
+  if (nl >= 64 && nl <= 65534) { glog = 0; while ((2 << glog) * 16 <= nl) ++glog; }
+  d.ld_glog = glog; d.ld_guide = nullptr;
   if (uniform) {
     const int n = nl > 0 ? nl : 1;
     std::vector<float> func(n, 1.0f), cdf(n + 1, 0.0f);  // Distribution1D::new over [1.0; n]
@@ -584,6 +614,11 @@ static int build_light_distribution(rt_scene* s, int strategy, hipStream_t strea
     if ((rc = upload(s->ld_func, func.data(), func.size() * 4)) != RT_OK) return rc;
     if ((rc = upload(s->ld_cdf, cdf.data(), cdf.size() * 4)) != RT_OK) return rc;
     if ((rc = upload(s->ld_int, &func_int, 4)) != RT_OK) return rc;
+    if (glog >= 0) {
+      const int G = 1 << glog; std::vector<unsigned short> g((size_t)G + 1); int i = 0;
+      for (int k = 0; k <= G; ++k) { const float x = (float)k / (float)G; while (i <= n && cdf[i] <= x) ++i; g[k] = (unsigned short)i; }
+      if ((rc = upload(s->ld_guide, g.data(), g.size() * 2)) != RT_OK) return rc;
+    }
     d.ld_uniform = 1; d.nvox[0] = d.nvox[1] = d.nvox[2] = 1;
   } else {
     float diag[3] = {d.wb_max.x - d.wb_min.x, d.wb_max.y - d.wb_min.y, d.wb_max.z - d.wb_min.z};
@@ -612,16 +647,19 @@ static int build_light_distribution(rt_scene* s, int strategy, hipStream_t strea
     const size_t rows = std::max<size_t>(n_built, 1);
     if (s->ld_func.ensure(rows * nl * 4) != hipSuccess || s->ld_cdf.ensure(rows * (nl + 1) * 4) != hipSuccess || s->ld_int.ensure(rows * 4) != hipSuccess)
       return fail(RT_ERR_OOM, "light distribution tables do not fit (built voxels x lights)");
+    if (glog >= 0 && s->ld_guide.ensure(rows * (((size_t)1 << glog) + 1) * 2) != hipSuccess) return fail(RT_ERR_OOM, "light distribution guide tables do not fit");
     d.ld_func = s->ld_func.as<float>(); d.ld_cdf = s->ld_cdf.as<float>(); d.ld_int = s->ld_int.as<float>(); d.ld_slot = s->ld_slot.as<int>();
     unsigned lights_pad = 1; while (lights_pad < (unsigned)nl) lights_pad <<= 1;
     const unsigned long long contrib_blocks = lights_pad <= 128u ? (rows + 128u / lights_pad - 1) / (128u / lights_pad) : (unsigned long long)rows * (unsigned)((nl + 127) / 128);
     if (contrib_blocks > 0x7fffffffull) return fail(RT_ERR_INVALID, "light distribution grid too large");
     if (s->has_spheres) hipLaunchKernelGGL(k_lightdist_contrib<true>, dim3((unsigned)contrib_blocks), dim3(128), 0, stream, d, list, n_list, lights_pad, (unsigned)((nl + 127) / 128), s->ld_func.as<float>());
     else hipLaunchKernelGGL(k_lightdist_contrib<false>, dim3((unsigned)contrib_blocks), dim3(128), 0, stream, d, list, n_list, lights_pad, (unsigned)((nl + 127) / 128), s->ld_func.as<float>());
-    hipLaunchKernelGGL(k_lightdist_finish, dim3((unsigned)((rows + 127) / 128)), dim3(128), 0, stream, d, list, n_list, s->ld_func.as<float>(), s->ld_cdf.as<float>(), s->ld_int.as<float>(), s->ld_slot.as<int>());
+    hipLaunchKernelGGL(k_lightdist_finish, dim3((unsigned)((rows + 127) / 128)), dim3(128), 0, stream, d, list, n_list, s->ld_func.as<float>(), s->ld_cdf.as<float>(), s->ld_int.as<float>(), s->ld_slot.as<int>(),
+                       glog >= 0 ? s->ld_guide.as<unsigned short>() : nullptr, glog);
     HIP_TRY(hipGetLastError());
   }
   d.ld_func = s->ld_func.as<float>(); d.ld_cdf = s->ld_cdf.as<float>(); d.ld_int = s->ld_int.as<float>(); d.ld_slot = s->ld_slot.as<int>();
+  d.ld_guide = glog >= 0 ? s->ld_guide.as<unsigned short>() : nullptr;
   s->ld_strategy_built = strategy; s->ld_all_voxels = all_voxels;
   HIP_TRY(hipMemcpyAsync(s->self.p, &s->d, sizeof(DScene), hipMemcpyHostToDevice, stream));
   return RT_OK;

@@ -1590,11 +1590,11 @@ __global__ void __launch_bounds__(256, MODE == 1 ? RT_SHADE_MIN_WAVES : RT_SHADE
         if (MODE == 0) bsdf.build(gsc, tri_material(sc.tri_p, prim), si); else bsdf.build(sc, tri_material(sc.tri_p, prim), si);
         RT_STAMP(2);  // material: textures + lobes
         // light_distribution.lookup(p) (path.rs:154-158)
-        const float* ld_func; const float* ld_cdf; float ld_int;
+        const float* ld_func; const float* ld_cdf; float ld_int; long ld_row = 0;
         if (sc.ld_uniform) { ld_func = sc.ld_func; ld_cdf = sc.ld_cdf; ld_int = sc.ld_int[0]; }
         else {
           const long slot = sc.ld_slot[voxel_of(sc, si.hit.p)];
-          if (slot >= 0) { ld_func = sc.ld_func + slot * sc.n_lights; ld_cdf = sc.ld_cdf + slot * (sc.n_lights + 1); ld_int = sc.ld_int[slot]; }
+          if (slot >= 0) { ld_func = sc.ld_func + slot * sc.n_lights; ld_cdf = sc.ld_cdf + slot * (sc.n_lights + 1); ld_int = sc.ld_int[slot]; ld_row = slot; }
           else { ld_func = sc.ld_func; ld_cdf = sc.ld_cdf; ld_int = -1.0f; }
         }
         const unsigned nonspec = BSDF_ALL & ~BSDF_SPECULAR;
@@ -1605,7 +1605,8 @@ __global__ void __launch_bounds__(256, MODE == 1 ? RT_SHADE_MIN_WAVES : RT_SHADE
         if (voxel_ok && bsdf.num_nonspecular() > 0 && sc.n_lights > 0) {  // uniform_sample_one_light, integrator/mod.rs:186-220
           float su = smp.get_1d();
           int light_num; float light_pdf;
-          d1_sample_discrete(ld_func, ld_cdf, ld_int, sc.n_lights, su, light_num, light_pdf);
+          if (MODE != 1 && sc.ld_glog >= 0) d1_sample_discrete_guided(ld_func, ld_cdf, ld_int, sc.n_lights, su, sc.ld_guide + ld_row * ((1 << sc.ld_glog) + 1), sc.ld_glog, light_num, light_pdf);
+          else d1_sample_discrete(ld_func, ld_cdf, ld_int, sc.n_lights, su, light_num, light_pdf);
           RT_STAMP(3);  // light pick: voxel row + discrete search
           if (light_pdf != 0.0f) {
             f2 u_light = smp.get_2d();
@@ -1977,7 +1978,8 @@ __global__ void __launch_bounds__(128) k_lightdist_contrib(DScene sc, const unsi
   }
   func[(size_t)li * sc.n_lights + j] = contrib;
 }
-__global__ void __launch_bounds__(128) k_lightdist_finish(DScene sc, const unsigned* __restrict__ list, const unsigned* __restrict__ n_list, float* func, float* cdf, float* fint, int* slot_of) {
+__global__ void __launch_bounds__(128) k_lightdist_finish(DScene sc, const unsigned* __restrict__ list, const unsigned* __restrict__ n_list, float* func, float* cdf, float* fint, int* slot_of,
+                                                          unsigned short* guide, int glog) {
   const unsigned li = blockIdx.x * blockDim.x + threadIdx.x;
   if (li >= *n_list) return;
   const long v = (long)list[li];
@@ -1995,6 +1997,10 @@ __global__ void __launch_bounds__(128) k_lightdist_finish(DScene sc, const unsig
   if (func_int == 0.0f) for (int j = 1; j < nl + 1; ++j) cv[j] = (float)j / (float)nl;
   else for (int j = 1; j < nl + 1; ++j) cv[j] /= func_int;
   fint[li] = func_int;
+  if (glog >= 0) {  // guide[k] = the number of CDF entries <= k / 2^glog (DScene::ld_guide)
+    const int G = 1 << glog; unsigned short* gv = guide + (size_t)li * (G + 1); int i = 0;
+    for (int k = 0; k <= G; ++k) { const float x = (float)k / (float)G; while (i <= nl && cv[i] <= x) ++i; gv[k] = (unsigned short)i; }
+  }
 }
 __global__ void k_lightdist_iota(unsigned n, unsigned* __restrict__ list, unsigned* __restrict__ n_list) {  // every voxel, in order: slot == voxel
   const unsigned v = blockIdx.x * blockDim.x + threadIdx.x;
