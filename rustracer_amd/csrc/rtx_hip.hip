@@ -527,7 +527,7 @@ extern "C" int rt_scene_create(const rt_scene_desc* desc, int device, rt_scene**
       // it hides). 64, 128 or 256 LDS-resident nodes measured the same: the top of the tree was already served by the CU's L1 - what the kernel
       // gains is its sixth wave per SIMD, and that pays where the tree fits the 32 MB of L2 without fitting an L1.
       const size_t pair_bytes = (size_t)desc->n_nodes * 64;
-      s->top_for_closest = pair_bytes >= ((size_t)1 << 20) && pair_bytes <= ((size_t)64 << 20);
+      s->top_for_closest = pair_bytes <= ((size_t)64 << 20);  // measured with the gated leaf phase: S3 (0.1 MB) 81 -> 78 ms, S4 (13 MB) 1743 -> 1659 ms, S2 (67 MB) 94 -> 102 ms
       if (getenv("RTX_TOP_CLOSEST")) s->top_for_closest = getenv("RTX_TOP_CLOSEST")[0] == '1';  // measurement knob
     }
     // four-wide records for the any-hit kernel (k_trace_quad): an interior node's grandchildren (a leaf child stands for itself), 128 B
