@@ -73,7 +73,8 @@ typedef struct rt_sphere {
  *    object_instance wraps: the BVH aggregate over the object's primitives - n_nodes nodes from nodes[node_base], child / primitive offsets relative to
  *    the object's own first node / first primitive - or, for an object of exactly one primitive, that primitive itself (n_nodes = 0). Its n_prims
  *    primitives (triangles in OBJECT space, leaf order) sit in the tri_* arrays from prim_base on, after the n_top_prims primitives of the top level.
- *    A hit inside instance k carries the id n_tris + (n_prims of instances 0 .. k-1) + its leaf-order index in the object (rt_trace_closest). ------ */
+ *    A hit inside instance k carries the id n_top_prims + (n_prims of instances 0 .. k-1) + its leaf-order index in the object (rt_trace_closest):
+ *    ids below n_top_prims name top-level primitives, as before. ------------------------------------------------------------------------------ */
 typedef struct rt_instance {
   float o2w[16], w2o[16]; /* primitive_to_world and its inverse as the host holds them, row-major */
   uint32_t node_base, n_nodes, prim_base, n_prims;
