@@ -597,6 +597,7 @@ static int build_light_distribution(rt_scene* s, int strategy, hipStream_t strea
   // PathIntegrator::preprocess runs once per render in the reference (renderer.rs:30) - on an immutable scene it builds the same tables every
   // time, so they are kept (a table built for every voxel serves a frame as well: the frame only reads voxels that hold a surface point)
   if (s->ld_strategy_built == strategy && (s->ld_all_voxels || !all_voxels)) return RT_OK;
+  s->ld_strategy_built = -1;  // a rebuild that fails half way leaves no table that a later frame could take for valid
   const int nl = s->n_lights;
   const bool uniform = strategy == 1 || nl == 1 || nl == 0;
   // guide tables for the rows' CDF searches (DScene::ld_guide) where a search is long enough to gain from one: >= 64 lights, <= 65534 (u16 entries)
@@ -763,6 +764,7 @@ static void launch_trace(rt_scene* s, bool count, const TraceIO& io, const unsig
 // planar arrays of the batch entry points
 static TraceIO trace_io_planar(const float4* ro, const float4* rd, float4* hits, unsigned* occ) {
   TraceIO io{}; io.ray_o = ro; io.ray_d = rd; io.ray_stride = 1; io.hits = hits; io.hit_stride = 1; io.hit_b2 = 0; io.occluded = occ; io.occ_stride = 1;
+  io.shadow_masks = 1;  // rt_trace_any is Scene::intersect_p
   return io;
 }
 
@@ -1093,9 +1095,9 @@ extern "C" int rt_render(rt_scene* s, const rt_camera* cam, const rt_film_desc* 
     constexpr unsigned PR = sizeof(RayRec) / 16, VR = sizeof(VertRec) / 16, SR = sizeof(ShadowRec) / 16, MR = sizeof(MisRec) / 16;
     io_path.ray_o = &ps.ray->o; io_path.ray_d = &ps.ray->d; io_path.ray_stride = PR; io_path.hits = &ps.vert->hit; io_path.hit_stride = VR; io_path.hit_b2 = 1;
     io_shadow.ray_o = &ps.sh->o; io_shadow.ray_d = &ps.sh->d; io_shadow.ray_stride = SR; io_shadow.occluded = &ps.mi->occ; io_shadow.occ_stride = sizeof(MisRec) / 4;
-    io_shadow.lacc = &ps.acc->lacc; io_shadow.lacc_stride = sizeof(PathAcc) / 16; io_shadow.direct_add = &ps.sh->add; io_shadow.add_stride = SR;
+    io_shadow.shadow_masks = 1; io_shadow.lacc = &ps.acc->lacc; io_shadow.lacc_stride = sizeof(PathAcc) / 16; io_shadow.direct_add = &ps.sh->add; io_shadow.add_stride = SR;
     io_mis.ray_o = &ps.mi->o; io_mis.ray_d = &ps.mi->d; io_mis.ray_stride = MR; io_mis.hits = &ps.mi->hit; io_mis.hit_stride = MR; io_mis.hit_b2 = 0;
-    io_mis_any = io_mis; io_mis_any.hits = nullptr; io_mis_any.occluded = (unsigned*)&ps.mi->hit.y; io_mis_any.occ_stride = sizeof(MisRec) / 4;
+    io_mis_any = io_mis; io_mis_any.shadow_masks = 0; io_mis_any.hits = nullptr; io_mis_any.occluded = (unsigned*)&ps.mi->hit.y; io_mis_any.occ_stride = sizeof(MisRec) / 4;
   }
   const bool count = (flags & RT_FLAG_COUNT_TRAVERSAL) != 0;
   const unsigned pgrid = (unsigned)s->n_cu * 8u;

@@ -217,7 +217,7 @@ struct rtxh_scene {
   std::vector<rt_bvh_node> nodes; std::vector<int32_t> ordered;
   // flattened arrays (leaf order)
   std::vector<float> f_p, f_n, f_uv, f_s; std::vector<rt_tri_meta> f_meta; std::vector<int32_t> f_alpha; std::vector<rt_light> f_lights; std::vector<rt_image> f_images;
-  bool committed = false;
+  bool committed = false; unsigned commit_gen = 0, multi_gen = 0;  // multi_gen: the commit the replicas of `multi` were made from
   rt_scene* dev = nullptr;
   rt_multi* multi = nullptr; std::vector<int32_t> multi_devices;  // replicas for rtxh_render_multi, kept while the device list stays the same
   size_t n_tris() const { return idx.size() / 3; }
@@ -597,7 +597,7 @@ int finish_commit(rtxh_scene* s) {
     }
     s->f_lights.push_back(l);
   }
-  s->committed = true;
+  s->committed = true; s->commit_gen += 1;
   return RT_OK;
 }
 
@@ -1079,12 +1079,12 @@ int rtxh_render_multi(rtxh_scene* s, const rtxh_render_params* p, const int32_t*
   if (!s->committed) return fail(RT_ERR_INVALID, "scene not committed");
   g_err.clear();
   const std::vector<int32_t> want(devices, devices + n_devices);
-  if (!s->multi || s->multi_devices != want) {
+  if (!s->multi || s->multi_devices != want || s->multi_gen != s->commit_gen) {  // a re-committed scene gets new replicas
     if (s->multi) { rt_multi_destroy(s->multi); s->multi = nullptr; }
     rt_scene_desc d = make_desc(s);
     const int rc = rt_multi_create(&d, devices, n_devices, &s->multi);
     if (rc != RT_OK) return rc;
-    s->multi_devices = want;
+    s->multi_devices = want; s->multi_gen = s->commit_gen;
   }
   CamFilm cf; int rc = setup_camera_film(p, cf); if (rc != RT_OK) return rc;
   rt_sampler_desc smp{p->spp, p->sampler_dims};

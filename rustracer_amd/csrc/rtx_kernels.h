@@ -529,6 +529,10 @@ struct TraceIO {
   unsigned* occluded; unsigned occ_stride;        // any hit: 1 / 0
   // any hit inside a frame: a shadow ray with d.w != 0 belongs to a vertex without MIS ray - its `direct_add` goes into lacc right here if unoccluded
   float4* lacc; unsigned lacc_stride; const float4* direct_add; unsigned add_stride;
+  // any hit on scenes with masked meshes: 1 = Triangle::intersect_p's test (alpha and shadowalpha, mesh.rs:534-582: shadow rays), 0 = Triangle::intersect's
+  // (alpha only, mesh.rs:353-370): a BSDF-sampled MIS ray toward an infinite light is traced by scene.intersect (integrator/mod.rs:291-309) although only
+  // its occlusion is read
+  int shadow_masks;
 };
 RT_DEV void trace_write_any(float4* __restrict__ lacc, size_t ls, const float4* __restrict__ direct_add, size_t as, unsigned* __restrict__ occluded, size_t os,
                             unsigned pid, float dw, bool found) {
@@ -724,7 +728,7 @@ __global__ void __launch_bounds__(BLOCK) k_trace_big(DScene sc, TraceIO io, cons
           continue;
         }
         if (tri_test_pre(p0, p1, p2, ray, rp, h)) {
-          if (GENERAL && tri_alpha_rejects(*sc.self, leaf_off + i, h, ANY)) continue;
+          if (GENERAL && tri_alpha_rejects(*sc.self, leaf_off + i, h, ANY && io.shadow_masks != 0)) continue;
           found = true;
           if (ANY) break;
           ray.t_max = h.t; prim = leaf_off + i; hit = h;  // `.or(result)`: later accepted hits replace

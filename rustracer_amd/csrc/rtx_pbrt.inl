@@ -652,6 +652,7 @@ struct PbrtLoader {
         pushed_gs.push_back(gs); pushed_transforms.push_back(ctm);
         if (in_instance) return fail_("ObjectBegin called inside of instance definition");
         in_instance = true; current_instance = a; instances[a] = PbrtSoup();
+        object_ids.erase(a);  // a name defined again: later ObjectInstance calls place the new definition (instances.insert(name, Vec::new()), api.rs:1030)
       } else if (d == "ObjectEnd") {  // api.rs:1034-1049
         if (!in_instance) return fail_("ObjectEnd called outside of instance definition");
         in_instance = false; current_instance.clear();

@@ -526,6 +526,22 @@ WorldEnd
         _parse(text.replace('ObjectInstance "empty"', 'ObjectInstance "nope"'))
 
 
+def test_a_redefined_object_is_what_later_instances_place():
+    """ObjectBegin on a name already in use replaces the definition (instances.insert(name, Vec::new()), rc/api.rs:1030): instances placed afterwards use
+    the new one, in the two-level form as in the written-out form."""
+    tri2 = TRI.replace("Shape", "Translate 0 0 7\nShape")
+    text = HEADER + 'WorldBegin\n' + TRI + 'ObjectBegin "a"\n' + TRI + 'ObjectEnd\nObjectInstance "a"\nObjectBegin "a"\n' + tri2 + TRI + 'ObjectEnd\nTranslate 1 0 0\nObjectInstance "a"\nWorldEnd\n'
+    p = _parse(text)
+    inst = p.table("instances")
+    assert len(inst) == 2 and list(inst["object"]) == [0, 1]
+    assert len(p.table((0, "indices"))) == 1 and len(p.table((1, "indices"))) == 2
+    assert p.table((1, "P"))[0, 2] == 7.0
+    q = host.PbrtScene(text=text, flatten_instances=True)
+    assert len(q.table("indices")) == 1 + 1 + 2
+    zs = sorted(float(z) for z in q.table("P")[:, 2])
+    assert zs.count(7.0) == 6  # both triangles of the second definition (the Translate stays in force inside it), none of the first
+
+
 @pytest.mark.parametrize("text, message", [
     (HEADER + 'WorldBegin\nObjectInstance "nothing"\n' + TRI + "WorldEnd\n", "Unable to find instance named nothing"),
     (HEADER + 'WorldBegin\nObjectBegin "a"\nObjectBegin "b"\nObjectEnd\nObjectEnd\n' + TRI + "WorldEnd\n", "inside of instance definition"),
