@@ -12,6 +12,11 @@ Prints ONE JSON line (rank 0). `roofline` is for the dominant kernel stage of th
 `cpu_baseline` is the C++ oracle in its reference-faithful tile-sequential sampler mode on all host cores, built on this box with
 -march=native, over a bounded sample of the same workload (reported, not the target).
 
+`--gpus N` with N > 1: under torchrun (WORLD_SIZE = N, what the driver launches) every rank renders its rows with rt_render and rank 0 gathers them over RCCL;
+started as a plain `python bench.py --gpus N` the ONE process drives N devices itself through rt_multi_render (one host thread per device, tile-row chunks from
+a shared queue, touched rows peer-copied to device 0) - renderer::render's worker pool with GPUs as the workers (rc/renderer.rs:22-29, 47-71). Either way the
+run fails when fewer than N devices are visible; `n_gpus` in the line is the number of devices that actually traced camera rays.
+
 At N = 1 the line also carries, under "other_configs", the same measurement for BASELINE configs[2..4] (S2 blob-1M, S3 mis-plates, S4 room-env;
 2 timed frames each whatever --steps says) and, under "config_c1", configs[0] exactly (cornell 400x400, 64 spp) on the GPU and on the CPU port.
 `--headline-only` skips those; `--scene X` makes X the headline instead.
@@ -26,7 +31,8 @@ import time
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-SCENE_SPP = {"cornell": 1024, "blob": 256, "mis": 512, "room": 1024}
+SCENE_SPP = {"cornell": 1024, "blob": 256, "mis": 512, "room": 1024, "mis-spheres": 512, "instances-10k": 64}
+EXTRA_SCENES = ("mis-spheres", "instances-10k")  # general-primitive workloads measured under other_configs (no CPU baseline: they are not BASELINE configs)
 
 
 def host_cores():
@@ -86,104 +92,235 @@ def make_desc(scene, spp, res=1024):
     if scene == "cornell":
         d = cornell_box(res, res, spp)
         return d, f"cornell-box (synthetic S1, 32 triangles, 2 area lights) {res}x{res} PathIntegrator maxdepth=5 {spp}spp 02sequence box-filter"
-    d = {"blob": blob_scene, "mis": mis_plates, "room": room_env}[scene](spp=spp)
-    return d, (f"{d.name} (synthetic, {d.n_tris} triangles, {len(d.lights)} lights) {d.film.xres}x{d.film.yres} "
+    if scene == "mis-spheres":  # S3 with its four emitters as Shape "sphere" - what veach-mis.pbrt is
+        d = mis_plates(spp=spp, analytic_spheres=True)
+        d.name = "mis-plates, analytic sphere lights"
+    elif scene == "instances-10k":  # 10 000 placements of a 1280-triangle object kept two-level (TransformedPrimitive, rc/primitive.rs:79-118)
+        from rustracer_amd.scenes import forest
+        d = forest(100, 3, spp)
+    else:
+        d = {"blob": blob_scene, "mis": mis_plates, "room": room_env}[scene](spp=spp)
+    extra = ""
+    if getattr(d, "spheres", None):
+        extra += f" + {len(d.spheres)} analytic quadrics"
+    if getattr(d, "instances", None):
+        extra += f" + {len(d.instances)} instances of {len(d.objects)} object(s) ({sum(int(o.idx.shape[0]) for o in d.objects)} triangles in their definitions)"
+    return d, (f"{d.name} (synthetic, {d.n_tris} triangles{extra}, {len(d.lights)} lights) {d.film.xres}x{d.film.yres} "
                f"PathIntegrator maxdepth={d.integrator.max_depth} {spp}spp 02sequence box-filter")
 
 
-def pmc_traffic(scene, kname):
+def source_sha():
+    """sha256 over the device sources: ties a PMC traffic file to the kernels it was collected from (the GPU box has no .git)."""
+    import hashlib
+    h = hashlib.sha256()
+    d = os.path.join(ROOT, "rustracer_amd", "csrc")
+    for f in sorted(os.listdir(d)):
+        if f.endswith((".h", ".hip", ".inl")):
+            h.update(open(os.path.join(d, f), "rb").read())
+    return h.hexdigest()[:16]
+
+
+def pmc_entry(scene, kname):
     try:
         j = json.load(open(os.path.join(ROOT, "profiles", f"pmc_{scene}.json")))
         e = j.get(kname) or {}
-        return e.get("hbm_bytes_per_launch"), {"file": f"profiles/pmc_{scene}.json", "from": j.get("source"), "collected": j.get("collected"), "method": j.get("method")}
+        prov = {"file": f"profiles/pmc_{scene}.json", "from": j.get("source"), "collected": j.get("collected"), "method": j.get("method"),
+                "kernel_source_sha": j.get("kernel_source_sha")}
+        # the traffic file is a measurement of the tree it names, not of this run: say when the kernels have changed since
+        prov["stale"] = (j.get("kernel_source_sha") != source_sha())
+        return e, prov
     except Exception:
-        return None, None
+        return {}, None
 
 
-def run_workload(scene_name, scene, workload, steps, warmup, rank, world, local_rank, dist):
+def occupancy_of(kernel_substr):
+    """Registers and waves per SIMD of the built kernels whose name contains the string (read from the .so that is about to run)."""
+    try:
+        sys.path.insert(0, os.path.join(ROOT, "scripts"))
+        from kernel_budget import kernel_resources
+        out = {}
+        for k, v in kernel_resources().items():
+            if kernel_substr in k:
+                alloc = -(-max(v["vgpr"] + v["agpr"], 1) // 8) * 8
+                out[k.replace("rtx::", "")] = {"vgpr": v["vgpr"], "waves_per_simd": min(8, 512 // alloc), "scratch": v["scratch"], "lds": v["lds"]}
+        return out
+    except Exception:
+        return None
+
+
+class Runner:
+    """One of the three ways a frame is rendered: 'single' (rt_render on one device), 'dist' (one process per GPU, rows gathered over RCCL),
+    'multi' (this process drives several devices through rt_multi_render)."""
+
+    def __init__(self, mode, scene, rank=0, world=1, local_rank=0, dist=None, devices=None, chunks=1):
+        import torch
+        self.mode, self.scene, self.rank, self.world, self.local_rank, self.dist, self.devices, self.chunks = mode, scene, rank, world, local_rank, dist, devices, chunks
+        self.torch = torch
+        dev0 = devices[0] if mode == "multi" else local_rank
+        if mode != "multi":
+            scene.upload(local_rank)
+        st0 = scene.setup()
+        self.cr, self.sb = st0["cropped"], st0["sample_bounds"]
+        h, w = int(self.cr[3] - self.cr[1]), int(self.cr[2] - self.cr[0])
+        self.radius_y = float(st0["params"].filter_params[1])
+        self.film = torch.zeros((h, w, 4), dtype=torch.float32, device=f"cuda:{dev0}")
+        with torch.cuda.device(dev0):
+            self.stream = torch.cuda.current_stream().cuda_stream
+        self.per_device = None
+
+    def barrier(self):
+        if self.dist is not None:
+            self.dist.barrier()
+        if self.mode == "multi":
+            for d in sorted(set(self.devices)):
+                self.torch.cuda.synchronize(d)
+        else:
+            self.torch.cuda.synchronize()
+
+    def step(self, timed):
+        if self.mode == "multi":
+            _, st, per = self.scene.render_multi(self.devices, chunks_per_device=self.chunks, time_kernels=timed, device_out=self.film)
+            st["ms_total_max_device"] = max(p["ms_total"] for p in per)
+            self.per_device = per
+            return st
+        from rustracer_amd.distributed import merge_film
+        _, st = self.scene.render(rank=self.rank, world_size=self.world, time_kernels=timed, device_out=self.film, stream=self.stream)
+        merge_film(self.film, dst=0, cropped=self.cr, sample_bounds=self.sb, filter_radius_y=self.radius_y)  # end-of-frame gather of the touched rows (no-op at N = 1)
+        return st
+
+    def count(self):
+        """untimed counting frame: per-ray BVH node visits / triangle tests of the walks the timed frames run"""
+        if self.mode == "multi":
+            _, st, _ = self.scene.render_multi(self.devices, chunks_per_device=self.chunks, count_traversal=True, count_as_rendered=True, device_out=self.film)
+        else:
+            _, st = self.scene.render(rank=self.rank, world_size=self.world, count_traversal=True, count_as_rendered=True, device_out=self.film, stream=self.stream)
+        return st
+
+
+def run_workload(scene_name, runner, workload, steps, warmup):
     """Times `steps` frames of one workload; returns the result dict (rank 0) or None."""
     import numpy as np
     import torch
-    from rustracer_amd.distributed import merge_film
-    scene.upload(local_rank)
-    st0 = scene.setup()
-    cr, sb = st0["cropped"], st0["sample_bounds"]
-    h, w = int(cr[3] - cr[1]), int(cr[2] - cr[0])
-    radius_y = float(st0["params"].filter_params[1])
-    film = torch.zeros((h, w, 4), dtype=torch.float32, device=f"cuda:{local_rank}")
-    stream = torch.cuda.current_stream().cuda_stream
-    n_gpus = max(world, 1)
-
-    def barrier():
-        if dist is not None:
-            dist.barrier()
-        torch.cuda.synchronize()
-
-    def step(timed):
-        _, st = scene.render(rank=rank, world_size=world, time_kernels=timed, device_out=film, stream=stream)
-        merge_film(film, dst=0, cropped=cr, sample_bounds=sb, filter_radius_y=radius_y)  # end-of-frame gather of the touched rows (no-op at N = 1)
-        return st
-
+    rank, world, dist = runner.rank, runner.world, runner.dist
     for _ in range(warmup):
-        step(False)
-    barrier()
+        runner.step(False)
+    runner.barrier()
     t0 = time.perf_counter()
     kstats = []
     for _ in range(steps):
-        kstats.append(step(True))
-    barrier()
+        kstats.append(runner.step(True))
+    runner.barrier()
     dt = time.perf_counter() - t0
+    cst = runner.count()
     if dist is not None:
-        tt = torch.tensor([dt], dtype=torch.float64, device=f"cuda:{local_rank}")
+        tt = torch.tensor([dt], dtype=torch.float64, device=f"cuda:{runner.local_rank}")
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
-        cnt = torch.tensor([float(kstats[-1]["camera_rays"])], dtype=torch.float64, device=f"cuda:{local_rank}")
-        dist.all_reduce(cnt, op=dist.ReduceOp.SUM)
-        samples_per_step = float(cnt.item())
+        # whole-frame counters: every rank's share summed; stage times: the slowest rank's
+        keys_sum = [k for k, v in cst.items() if isinstance(v, int)]
+        v = torch.tensor([float(kstats[-1]["camera_rays"])] + [float(cst[k]) for k in keys_sum], dtype=torch.float64, device=f"cuda:{runner.local_rank}")
+        dist.all_reduce(v, op=dist.ReduceOp.SUM)
+        samples_per_step = float(v[0].item())
+        for k, x in zip(keys_sum, v[1:].tolist()):
+            cst[k] = int(x)
+        mine = torch.tensor([float(kstats[-1]["camera_rays"] > 0)], dtype=torch.float64, device=f"cuda:{runner.local_rank}")
+        dist.all_reduce(mine, op=dist.ReduceOp.SUM)
+        n_active = int(mine.item())
+        ms_keys = [k for k in kstats[-1] if k.startswith("ms_")]
+        m = torch.tensor([[ks[k] for k in ms_keys] for ks in kstats], dtype=torch.float64, device=f"cuda:{runner.local_rank}").mean(0)
+        gathered = [torch.zeros_like(m) for _ in range(world)]
+        dist.all_gather(gathered, m)
+        per_rank_ms = [float(g[ms_keys.index("ms_total")].item()) for g in gathered]
+        mmax = torch.stack(gathered).max(0).values.tolist()
+        ms_mean = dict(zip(ms_keys, mmax))
+        n_gpus_asked = world
     else:
         samples_per_step = float(kstats[-1]["camera_rays"])
-    # untimed counting frame: per-ray BVH node visits / triangle tests for the algorithmic byte count
-    _, cst = scene.render(rank=rank, world_size=world, count_traversal=True, device_out=film, stream=stream)
-    torch.cuda.synchronize()
+        ms_keys = [k for k in kstats[-1] if k.startswith("ms_")]
+        ms_mean = {k: float(np.mean([ks[k] for ks in kstats])) for k in ms_keys}
+        if runner.mode == "multi":
+            nd = len(runner.devices)
+            n_active = sum(1 for p in runner.per_device if p["camera_rays"] > 0)
+            per_rank_ms = [round(p["ms_total"], 2) for p in runner.per_device]
+            # stage timers of rt_multi_render's total are device-milliseconds summed over the devices: per-device mean for the roofline
+            for k in ms_keys:
+                if k not in ("ms_total", "ms_gather", "ms_total_max_device"):
+                    ms_mean[k] /= nd
+            n_gpus_asked = nd
+        else:
+            n_active, per_rank_ms, n_gpus_asked = 1, [round(ms_mean["ms_total"], 2)], 1
     if rank != 0:
         return None
     ms_step = dt / steps * 1e3
     value = samples_per_step * steps / dt / 1e6
-    ms_tc = float(np.mean([k["ms_trace_closest"] + k["ms_trace_mis"] for k in kstats]))
-    ms_sh = float(np.mean([k["ms_shade"] for k in kstats]))
+    n_gpus = n_active  # devices that traced camera rays in the last timed frame
+    launches = kstats[-1]["launches_trace_closest"] // (n_gpus_asked if runner.mode == "multi" else 1)
+
+    # SURVEY §8d bytes of the three ray classes, each divided by the time of ITS launches. The counting frame walks what the timed frames walk
+    # (RT_FLAG_COUNT_AS_RENDERED): path rays and MIS rays toward area lights closest-hit, shadow rays and MIS rays toward the environment any-hit.
+    def ray_class(rays, nodes, tris, ms, per_ray):
+        b = per_ray * rays + 32 * nodes + 36 * tris
+        return {"rays": int(rays), "algorithmic_bytes": int(b), "ms": round(ms, 3), "GB_per_s": round(b / max(ms, 1e-9) / 1e6, 1), "frac_of_8TBs": round(b / max(ms, 1e-9) / 1e6 / 8000.0, 4),
+                "nodes_per_ray": round(nodes / max(rays, 1), 2), "tris_per_ray": round(tris / max(rays, 1), 2)}
+    ms_mis_any = ms_mean.get("ms_trace_mis_any", 0.0)
+    nd_div = n_gpus_asked if runner.mode != "single" else 1  # whole-frame bytes against per-device (mean / slowest-rank) stage time: bytes per device
+    classes = {
+        "path_closest": ray_class(cst["rays_closest"] / nd_div, cst["nodes_closest"] / nd_div, cst["tris_closest"] / nd_div, ms_mean["ms_trace_closest"], 48),
+        "shadow_any": ray_class(cst["rays_shadow"] / nd_div, cst["nodes_shadow"] / nd_div, cst["tris_shadow"] / nd_div, ms_mean["ms_trace_any"], 36),
+        "mis_closest": ray_class((cst["rays_mis"] - cst["rays_mis_any"]) / nd_div, (cst["nodes_mis"] - cst["nodes_mis_any"]) / nd_div, (cst["tris_mis"] - cst["tris_mis_any"]) / nd_div,
+                                 ms_mean["ms_trace_mis"] - ms_mis_any, 48),
+        "mis_any": ray_class(cst["rays_mis_any"] / nd_div, cst["nodes_mis_any"] / nd_div, cst["tris_mis_any"] / nd_div, ms_mis_any, 36),
+    }
+    ms_tc = ms_mean["ms_trace_closest"]
+    ms_sh = ms_mean["ms_shade"]
 
     def trace_roofline():
-        rays = cst["rays_closest"] + cst["rays_mis"]
-        algo = 48 * rays + 32 * (cst["nodes_closest"] + cst["nodes_mis"]) + 36 * (cst["tris_closest"] + cst["tris_mis"])
-        return algo, kstats[-1]["launches_trace_closest"], ms_tc, "trace_closest", rays, "ray"
+        c = classes["path_closest"]
+        return c["algorithmic_bytes"], launches // 2, ms_tc, "trace_closest", c["rays"], "ray"
 
     def shade_roofline():
-        verts = cst["rays_closest"]
-        emitted = cst["rays_shadow"] + cst["rays_mis"] + (cst["rays_closest"] - cst["camera_rays"])
-        return 128 * verts + 32 * emitted + 48 * cst["camera_rays"], kstats[-1]["launches_trace_closest"] // 2, ms_sh, "shade", verts, "vertex"
+        verts = cst["rays_closest"] / nd_div
+        emitted = (cst["rays_shadow"] + cst["rays_mis"] + (cst["rays_closest"] - cst["camera_rays"])) / nd_div
+        return 128 * verts + 32 * emitted + 48 * cst["camera_rays"] / nd_div, launches // 2, ms_sh, "shade", verts, "vertex"
 
-    def roof(algo_bytes, launches, ms_kernel, kname, unit_n, unit):
-        achieved = algo_bytes / (ms_kernel * 1e-3) / 1e9  # GB/s
-        traffic, prov = pmc_traffic(scene_name, kname)
-        return {"bound": "hbm", "kernel": "k_" + kname, "achieved": round(achieved, 1), "peak": 8000.0, "unit": "GB/s",
-                "frac": round(achieved / 8000.0, 4), "traffic": traffic, "traffic_provenance": prov,
-                "algorithmic_bytes_per_launch": round(algo_bytes / max(launches, 1)), "avg_launch_ms": round(ms_kernel / max(launches, 1), 4),
-                "launches_per_step": int(launches), f"bytes_per_{unit}": round(algo_bytes / max(unit_n, 1), 1)}
+    def roof(algo_bytes, n_launch, ms_kernel, kname, unit_n, unit):
+        achieved = algo_bytes / (ms_kernel * 1e-3) / 1e9  # GB/s per device
+        e, prov = pmc_entry(scene_name, kname)
+        r = {"bound": "hbm", "kernel": "k_" + kname, "achieved": round(achieved, 1), "peak": 8000.0, "unit": "GB/s",
+             "frac": round(achieved / 8000.0, 4), "traffic": e.get("hbm_bytes_per_launch"), "traffic_raw_reads": e.get("hbm_bytes_per_launch_raw"),
+             "traffic_provenance": prov,
+             "algorithmic_bytes_per_launch": round(algo_bytes / max(n_launch, 1)), "avg_launch_ms": round(ms_kernel / max(n_launch, 1), 4),
+             "launches_per_step": int(n_launch), f"bytes_per_{unit}": round(algo_bytes / max(unit_n, 1), 1),
+             "lanes_per_valu_instruction": e.get("lanes_per_valu"), "occupancy": occupancy_of("k_shade" if kname == "shade" else "k_trace")}
+        if prov and prov.get("stale"):
+            r["warning"] = "roofline.traffic was collected on other kernel sources than the ones that ran (profiles/pmc_*.json: kernel_source_sha differs)"
+        return r
     roofline = roof(*(trace_roofline() if ms_tc >= ms_sh else shade_roofline()))
     roofline_other = roof(*(shade_roofline() if ms_tc >= ms_sh else trace_roofline()))  # the runner-up of the two heavy stages
-    kernels_ms = {k[3:]: round(float(np.mean([s[k] for s in kstats])), 2) for k in kstats[-1] if k.startswith("ms_")}
+    kernels_ms = {k[3:]: round(v, 2) for k, v in ms_mean.items()}
     verts = {k[9:]: int(kstats[-1][k]) for k in kstats[-1] if k.startswith("vertices_") and kstats[-1][k]}
-    return {
+    sharding = {"single": "single GPU",
+                "dist": "interleaved 16-row tile rows, one process per GPU, end-of-frame gather of the touched rows to rank 0 (RCCL send/recv)",
+                "multi": f"one process, rt_multi_render: {runner.chunks} chunk(s) of interleaved 16-row tile rows per device from a shared queue, touched rows peer-copied to device 0 and added there"}[runner.mode]
+    out = {
         "metric": "Msamples/s", "value": round(value, 2), "unit": "Msamples/s", "n_gpus": n_gpus, "steps": steps, "warmup": warmup,
         "ms_per_step": round(ms_step, 2), "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-        "config": {"workload": workload,
-                   "sharding": "interleaved 16-row tile rows, end-of-frame gather of the touched rows to rank 0 (RCCL send/recv)" if n_gpus > 1 else "single GPU",
-                   "sampler_mode": "pixel-keyed"},
+        "config": {"workload": workload, "sharding": sharding, "sampler_mode": "pixel-keyed"},
         "s_per_frame": round(ms_step / 1e3, 4),
-        "Mrays_per_s": round((kstats[-1]["rays_closest"] + kstats[-1]["rays_shadow"] + kstats[-1]["rays_mis"]) * (n_gpus if n_gpus > 1 else 1) / (ms_step * 1e-3) / 1e6, 1),
+        "Mrays_per_s": round((cst["rays_closest"] + cst["rays_shadow"] + cst["rays_mis"]) / (ms_step * 1e-3) / 1e6, 1),
         "kernel_ms_per_step": kernels_ms, "vertices_by_shade_front_end": verts,
-        "roofline": roofline, "roofline_second_kernel": roofline_other,
+        "roofline": roofline, "roofline_second_kernel": roofline_other, "traversal_by_ray_class": classes,
     }
+    if n_gpus_asked > 1:
+        out["n_gpus_requested"] = n_gpus_asked
+        out["per_device_ms"] = per_rank_ms
+        out["imbalance_max_over_mean"] = round(max(per_rank_ms) / max(float(np.mean(per_rank_ms)), 1e-9), 3)
+        if runner.mode == "multi":
+            out["gather_ms"] = round(ms_mean.get("ms_gather", 0.0), 3)
+            out["devices"] = [int(d) for d in runner.devices]
+        else:
+            out["rccl_world_size"] = world
+    return out
 
 
 def main():
@@ -191,7 +328,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--scene", default="cornell", choices=["cornell", "blob", "mis", "room"],
+    ap.add_argument("--scene", default="cornell", choices=["cornell", "blob", "mis", "room", "mis-spheres", "instances-10k"],
                     help="the headline workload: cornell = BASELINE configs[1]; blob / mis / room = configs[2..4] (SURVEY.md §8d S2-S4)")
     ap.add_argument("--res", type=int, default=1024, help="cornell only (the other scenes use their BASELINE resolution)")
     ap.add_argument("--spp", type=int, default=0, help="0 = the BASELINE spp of the scene (cornell 1024, blob 256, mis 512, room 1024)")
@@ -199,22 +336,47 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--headline-only", action="store_true", help="skip configs[0] and configs[2..4] (they run only at N = 1 anyway)")
     ap.add_argument("--pbrt", default=None, help="render this pbrt-v3 scene file instead of a generated scene (read by the C++ host's parser; no CPU baseline)")
+    ap.add_argument("--devices", default=None, help="in-process multi-GPU mode: comma-separated device ordinals, one worker each (default 0..N-1). Naming an ordinal "
+                                                    "twice puts two workers with their own scene replicas on one GPU - a way to exercise the N > 1 path on a 1-GPU box, not a measurement")
+    ap.add_argument("--chunks-per-device", type=int, default=1, help="in-process multi-GPU mode: tile-row chunks per device on the shared queue (1 = static interleaved split)")
     args = ap.parse_args()
 
     import torch
-    from rustracer_amd import host
-
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    # How many GPUs the run was asked for, and how it gets them - decided before anything touches a device (device_count() does not initialise one)
+    n_visible = torch.cuda.device_count()
+    devices = None
+    if args.gpus < 1:
+        raise SystemExit("bench.py: --gpus must be >= 1")
+    if world > 1:
+        mode = "dist"
+        if args.gpus != world:
+            raise SystemExit(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}: launch with --nproc-per-node equal to --gpus")
+        if local_rank >= n_visible:
+            raise SystemExit(f"bench.py: rank {rank} wants device {local_rank} but only {n_visible} GPU(s) are visible")
+    elif args.gpus > 1 or args.devices:
+        mode = "multi"
+        devices = [int(x) for x in args.devices.split(",")] if args.devices else list(range(args.gpus))
+        if len(devices) != args.gpus:
+            raise SystemExit(f"bench.py: --gpus {args.gpus} but --devices names {len(devices)} device(s)")
+        if min(devices) < 0 or max(devices) >= n_visible:
+            raise SystemExit(f"bench.py: asked for {args.gpus} GPUs (devices {devices}) but only {n_visible} are visible; not measuring fewer under the same label")
+    else:
+        mode = "single"
+    from rustracer_amd import host
     if not host.device_available() or not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the backend has no CPU fallback")
-    torch.cuda.set_device(local_rank)
+    torch.cuda.set_device(devices[0] if mode == "multi" else local_rank)
     dist = None
-    if world > 1:
+    if mode == "dist":
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+
+    def runner_for(scene):
+        return Runner(mode, scene, rank=rank, world=world, local_rank=local_rank, dist=dist, devices=devices, chunks=max(1, args.chunks_per_device))
 
     desc = None
     if args.pbrt:
@@ -228,31 +390,32 @@ def main():
         args.spp = args.spp or SCENE_SPP[args.scene]
         desc, workload = make_desc(args.scene, args.spp, args.res)
         scene = host.HostScene(desc)
-    out = run_workload(args.scene, scene, workload, args.steps, args.warmup, rank, world, local_rank, dist)
-    del scene
-    if rank == 0 and world == 1:
+    r0 = runner_for(scene)
+    out = run_workload(args.scene, r0, workload, args.steps, args.warmup)
+    del r0, scene
+    if rank == 0 and mode == "single":
         if not args.no_cpu_baseline and desc is not None:
             cpu_spp = args.cpu_spp if args.scene != "room" else max(8, args.cpu_spp // 2)
             out["cpu_baseline"] = cpu_baseline(desc, cpu_spp)
             out["speedup_vs_cpu_baseline"] = round(out["value"] / out["cpu_baseline"]["value"], 1)
         if not args.headline_only and not args.pbrt:
-            # BASELINE configs[2..4] next to the headline, measured the same way by the same run (2 timed frames each)
+            # BASELINE configs[2..4] next to the headline, measured the same way by the same run (2 timed frames each), then the general-primitive scenes
             others = {}
-            for name in ("cornell", "blob", "mis", "room"):
+            for name in ("cornell", "blob", "mis", "room") + tuple(EXTRA_SCENES):
                 if name == args.scene:
                     continue
                 torch.cuda.empty_cache()
                 d, wl = make_desc(name, SCENE_SPP[name])
-                r = run_workload(name, host.HostScene(d), wl, 2, 1, 0, 1, local_rank, None)
-                if not args.no_cpu_baseline:
+                r = run_workload(name, runner_for(host.HostScene(d)), wl, 2, 1)
+                if not args.no_cpu_baseline and name not in EXTRA_SCENES:
                     r["cpu_baseline"] = cpu_baseline(d, args.cpu_spp if name != "room" else max(8, args.cpu_spp // 2))
                     r["speedup_vs_cpu_baseline"] = round(r["value"] / r["cpu_baseline"]["value"], 1)
                 others[name] = {k: r[k] for k in ("value", "unit", "steps", "ms_per_step", "config", "Mrays_per_s", "kernel_ms_per_step", "vertices_by_shade_front_end",
-                                                  "roofline", "roofline_second_kernel", "cpu_baseline", "speedup_vs_cpu_baseline") if k in r}
+                                                  "roofline", "roofline_second_kernel", "traversal_by_ray_class", "cpu_baseline", "speedup_vs_cpu_baseline") if k in r}
             out["other_configs"] = others
             # BASELINE configs[0] exactly: cornell 400x400, 64 spp - the reference's own CPU-runnable case, on the GPU and on the CPU port
             d, wl = make_desc("cornell", 64, 400)
-            r = run_workload("cornell", host.HostScene(d), wl, 5, 1, 0, 1, local_rank, None)
+            r = run_workload("cornell", runner_for(host.HostScene(d)), wl, 5, 1)
             c1 = {"workload": wl, "gpu": {"value": r["value"], "unit": "Msamples/s", "ms_per_step": r["ms_per_step"]}}
             if not args.no_cpu_baseline:
                 c1["cpu_port"] = cpu_baseline(d, 64, what="whole")

@@ -213,11 +213,22 @@ typedef struct rt_stats {
   /* measurement builds only (make ABLATE=1; zero otherwise): wave cycles per section of the shade kernel, [front-end 0..3][section 0..7] =
    * state + interaction, emission + differentials, material, light pick, light-sampling half, BSDF-sampling half, continuation + stores, loop tail */
   uint64_t shade_section_cycles[32];
+  /* BSDF-sampled MIS rays toward an infinite light are traced for occlusion only (their own launch of the any-hit kernel): of rays_mis / nodes_mis /
+   * tris_mis, the part that belongs to those rays, and of ms_trace_mis the time of their launches. nodes_ / tris_mis_any are filled by frames rendered with
+   * RT_FLAG_COUNT_TRAVERSAL | RT_FLAG_COUNT_AS_RENDERED (plain RT_FLAG_COUNT_TRAVERSAL walks every MIS ray as the reference does: closest hit). */
+  uint64_t rays_mis_any, nodes_mis_any, tris_mis_any;
+  double ms_trace_mis_any;
+  /* rt_multi_render, `total` only: wall time from the moment the last device finished its chunks to the merged frame being in place (the additions on
+   * devices[0] and the final copy); per-device wall times are per_device[k].ms_total */
+  double ms_gather;
 } rt_stats;
 
 #define RT_FLAG_COUNT_TRAVERSAL 1u /* fill nodes_ and tris_ counters (slower)                  */
 #define RT_FLAG_FILM_ON_DEVICE 2u  /* film_xyzw is a device pointer (HBM-resident output)      */
 #define RT_FLAG_TIME_KERNELS 4u    /* fill the per-kernel ms_ fields with HIP events           */
+#define RT_FLAG_COUNT_AS_RENDERED 8u /* with RT_FLAG_COUNT_TRAVERSAL: count the walks an uncounted frame runs (occlusion-only MIS rays walk as
+                                        intersect_p does) instead of the reference's (every MIS ray a closest-hit walk): what a roofline figure divides by
+                                        the time of */
 
 typedef struct rt_scene rt_scene;
 

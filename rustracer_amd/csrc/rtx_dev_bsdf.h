@@ -24,7 +24,7 @@ RT_DEV f3 cosine_sample_hemisphere(f2 u) {  // :22-26
 RT_DEV f2 uniform_sample_triangle(f2 u) { float su0 = sqrtf(u.x); return mk2(1.0f - su0, u.y * su0); }  // :49-52
 RT_DEV float power_heuristic1(float f_pdf, float g_pdf) {  // :59-63 with nf = ng = 1
   float f = 1.0f * f_pdf, g = 1.0f * g_pdf;
-  return (f * f) / (f * f + g * g);
+  return vdiv(f * f, f * f + g * g);
 }
 
 enum : unsigned { BSDF_REFLECTION = 1, BSDF_TRANSMISSION = 2, BSDF_DIFFUSE = 4, BSDF_GLOSSY = 8, BSDF_SPECULAR = 16, BSDF_ALL = 31 };

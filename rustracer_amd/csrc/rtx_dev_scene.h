@@ -24,6 +24,9 @@ struct DLight {
   // guide tables of the CDF searches (rt_scene_create): guide[row][k] = the number of entries of the row's CDF that are <= k / 2^glog, k = 0 .. 2^glog - so
   // the bisection for u starts inside [guide[k], guide[k + 1]], k = floor(u 2^glog), ~16 entries instead of 2049 (same answer: the CDF is non-decreasing)
   const unsigned short* guide; const unsigned short* mguide; int glog, mglog;
+  // constants of a triangle emitter, evaluated once on the device (k_light_consts) by the expressions DiffuseAreaLight::sample_li's call chain uses per sample:
+  // normalize(cross(p1 - p0, p2 - p0)) (Triangle::sample, mesh.rs:617, before orientation) and 1 / area (shapes/mod.rs:45)
+  float nrm[3]; float inv_area;
 };
 struct DSphere;  // rtx_dev_sphere.h
 // An object instance (rt_instance): primitive_to_world and its inverse, where the object's tree and primitives sit in the scene's arrays, and the first
@@ -35,6 +38,7 @@ struct DScene {
   const float4* top_pairs; unsigned n_top;  // pair records of the first levels of the tree, child codes re-pointed at LDS slots (k_trace_top); n_top <= RT_TOP_MAX
   const float4* quads;  // n_nodes x 128 B grandchild records of the interior nodes (NULL when not built), see k_trace_quad
   const float4* tri_p; unsigned n_tris;
+  const float4* tri_rec;  // per-triangle shade records (8 x float4, see tri_fill_interaction_inl), built on the device at rt_scene_create
   const float* tri_n; const float* tri_uv; const float* tri_s;
   const int2* tri_alpha;  // {alpha, shadowalpha} texture ids of the triangles whose flags carry bit 4 / bit 5 (NULL: no mask in the scene)
   const DInstance* instances; unsigned n_instances, n_top_prims;  // object instances (RT_FLAG_INSTANCE primitives); primitives [0, n_top_prims) are the top level's
@@ -155,11 +159,19 @@ RT_DEV void load_tri(const float4* tri_p, int prim, f3& p0, f3& p1, f3& p2) {
   float4 a = tri_p[3 * prim], b = tri_p[3 * prim + 1], c = tri_p[3 * prim + 2];
   p0 = mk3(a.x, a.y, a.z); p1 = mk3(b.x, b.y, b.z); p2 = mk3(c.x, c.y, c.z);
 }
+RT_DEV void load_tri_rec(const float4* tri_rec, int prim, f3& p0, f3& p1, f3& p2) {
+  float4 a = tri_rec[8 * (size_t)prim], b = tri_rec[8 * (size_t)prim + 1], c = tri_rec[8 * (size_t)prim + 2];
+  p0 = mk3(a.x, a.y, a.z); p1 = mk3(b.x, b.y, b.z); p2 = mk3(c.x, c.y, c.z);
+}
 RT_DEV int tri_material(const float4* tri_p, int prim) { return __float_as_int(tri_p[3 * prim].w); }
 RT_DEV int tri_light(const float4* tri_p, int prim) { return __float_as_int(tri_p[3 * prim + 1].w); }
 RT_DEV unsigned tri_flags(const float4* tri_p, int prim) { return __float_as_uint(tri_p[3 * prim + 2].w); }
 #define RT_FLAG_SPHERE 64u
 #define RT_FLAG_INSTANCE 128u
+// the same three words read from the shade record (one line with everything else a vertex needs of its triangle)
+RT_DEV int rec_material(const float4* tri_rec, int prim) { return __float_as_int(tri_rec[8 * (size_t)prim].w); }
+RT_DEV int rec_light(const float4* tri_rec, int prim) { return __float_as_int(tri_rec[8 * (size_t)prim + 1].w); }
+RT_DEV unsigned rec_flags(const float4* tri_rec, int prim) { return __float_as_uint(tri_rec[8 * (size_t)prim + 2].w); }
 RT_DEV unsigned prim_sphere_index(const float4* tri_p, int prim) { return __float_as_uint(tri_p[3 * prim + 2].x); }
 
 // ---------------------------------------------------------------- interactions (rc/interaction.rs)
@@ -172,6 +184,7 @@ struct SurfaceInteraction {
   float dudx, dvdx, dudy, dvdy;
   f3 dpdx, dpdy;
   f3 sh_n, sh_dpdu, sh_dpdv;
+  f3 ssb;  // normalize(sh_dpdu): the first axis of Bsdf::new's frame (bsdf/mod.rs:77-91), set by the triangle fill (a constant of most triangles: tri_rec); the generic front-end recomputes it (bump maps rewrite sh_dpdu)
   int prim;
 };
 RT_DEV Ray spawn_ray(const Interaction& it, f3 dir) {  // :56-60
@@ -186,16 +199,12 @@ RT_DEV Ray spawn_ray_to_interaction(const Interaction& a, const Target& b) {  //
   return r;
 }
 
-// Triangle::intersect tail, mesh.rs:321-425 (alpha masks: not carried by the flattened scene)
-RT_DEV void tri_fill_interaction_inl(const DScene& sc, int prim, f3 ray_d, const TriHit& h, SurfaceInteraction& si) {
-  f3 p0, p1, p2; load_tri(sc.tri_p, prim, p0, p1, p2);
-  const unsigned flags = tri_flags(sc.tri_p, prim);
-  const float b0 = h.b0, b1 = h.b1, b2 = h.b2;
-  f2 uv0 = mk2(0.0f, 0.0f), uv1 = mk2(1.0f, 0.0f), uv2 = mk2(1.0f, 1.0f);  // :201-211
-  if (flags & 4u) {
-    const float* u = sc.tri_uv + 6 * (size_t)prim;
-    uv0 = mk2(u[0], u[1]); uv1 = mk2(u[2], u[3]); uv2 = mk2(u[4], u[5]);
-  }
+// Triangle::intersect tail, mesh.rs:321-425, in three parts: what depends on the triangle alone (tri_geo), the shading frame (tri_frame: also a constant of
+// the triangle unless the mesh carries per-vertex normals or tangents) and what depends on the hit (point, error bounds, uv, wo). The first two are evaluated
+// once per triangle by k_tri_records into DScene::tri_rec - by these same functions, so a vertex shaded from the record sees the bits it would compute itself.
+struct TriGeo { f3 dpdu, dpdv, n; };  // n = normalize(cross(dp02, dp12)), before orientation
+RT_DEV TriGeo tri_geo(f3 p0, f3 p1, f3 p2, f2 uv0, f2 uv1, f2 uv2) {
+  TriGeo g;
   f3 dpdu = mk3(0, 0, 0), dpdv = mk3(0, 0, 0);
   float duv02x = uv0.x - uv2.x, duv02y = uv0.y - uv2.y, duv12x = uv1.x - uv2.x, duv12y = uv1.y - uv2.y;
   f3 dp02 = p0 - p2, dp12 = p1 - p2;
@@ -207,6 +216,41 @@ RT_DEV void tri_fill_interaction_inl(const DScene& sc, int prim, f3 ray_d, const
     dpdv = (-duv12x * dp02 + duv02x * dp12) * inv_det;
   }
   if (degenerate_uv || len2(cross(dpdu, dpdv)) == 0.0f) coordinate_system(normalize(cross(p2 - p0, p1 - p0)), dpdu, dpdv);
+  g.dpdu = dpdu; g.dpdv = dpdv;
+  g.n = normalize(cross(dp02, dp12));  // :385
+  return g;
+}
+struct TriFrame { f3 n, sh_n, ss, ts; };  // hit.n, shading.n, shading.dpdu, shading.dpdv
+// ns / ss_in: the interpolated, normalised vertex normal / tangent where the mesh has them (flags & 2, flags & 8)
+RT_DEV TriFrame tri_frame(const TriGeo& g, unsigned flags, f3 ns_in, f3 ss_in) {
+  TriFrame f;
+  f.n = g.n;
+  f3 ns = (flags & 2u) ? ns_in : g.n;
+  f3 ss = (flags & 8u) ? ss_in : normalize(g.dpdu);
+  f3 ts = cross(ss, ns);
+  if (len2(ts) > 0.0f) { ts = normalize(ts); ss = cross(ts, ns); }
+  else coordinate_system(ns, ss, ts);
+  f.sh_n = ns; f.ss = ss; f.ts = ts;
+  if (flags & 2u) f.n = face_forward(f.n, f.sh_n);  // :417-422
+  else if (flags & 1u) { f.n = -f.n; f.sh_n = f.n; }
+  return f;
+}
+// Per-triangle shade record (DScene::tri_rec, 8 x float4 = one 128-byte line): {p0 | material} {p1 | light} {p2 | flags} - the traversal record - then
+// {hit.n | ssb.x} {shading.dpdu | ssb.y} {shading.dpdv | ssb.z} {dpdu | 0} {dpdv | 0}; ssb = normalize(shading.dpdu), the first axis of Bsdf::new's frame
+// (bsdf/mod.rs:77-91). The frame entries are those of a triangle WITHOUT per-vertex normals and tangents (RT_REC_CONST_FRAME); with them only dpdu / dpdv
+// and n (row 3: g.n before orientation) are constants.
+#define RT_REC_CONST_FRAME(flags) (((flags) & (2u | 8u)) == 0u)
+RT_DEV void tri_fill_interaction_inl(const DScene& sc, int prim, f3 ray_d, const TriHit& h, SurfaceInteraction& si) {
+  const float4* __restrict__ rec = sc.tri_rec + 8 * (size_t)prim;
+  const float4 r0 = rec[0], r1 = rec[1], r2 = rec[2], r3 = rec[3];
+  const f3 p0 = mk3(r0.x, r0.y, r0.z), p1 = mk3(r1.x, r1.y, r1.z), p2 = mk3(r2.x, r2.y, r2.z);
+  const unsigned flags = __float_as_uint(r2.w);
+  const float b0 = h.b0, b1 = h.b1, b2 = h.b2;
+  f2 uv0 = mk2(0.0f, 0.0f), uv1 = mk2(1.0f, 0.0f), uv2 = mk2(1.0f, 1.0f);  // :201-211
+  if (flags & 4u) {
+    const float* u = sc.tri_uv + 6 * (size_t)prim;
+    uv0 = mk2(u[0], u[1]); uv1 = mk2(u[2], u[3]); uv2 = mk2(u[4], u[5]);
+  }
   float x_abs_sum = fabsf(b0 * p0.x) + fabsf(b1 * p1.x) + fabsf(b2 * p2.x);
   float y_abs_sum = fabsf(b0 * p0.y) + fabsf(b1 * p1.y) + fabsf(b2 * p2.y);
   float z_abs_sum = fabsf(b0 * p0.z) + fabsf(b1 * p1.z) + fabsf(b2 * p2.z);
@@ -214,25 +258,28 @@ RT_DEV void tri_fill_interaction_inl(const DScene& sc, int prim, f3 ray_d, const
   si.hit.p = p0 * b0 + p1 * b1 + p2 * b2;
   si.uv = mk2(uv0.x * b0 + uv1.x * b1 + uv2.x * b2, uv0.y * b0 + uv1.y * b1 + uv2.y * b2);
   si.hit.wo = normalize(normalize(-ray_d));  // SurfaceInteraction::new + Interaction::new both normalise (interaction.rs:42,123)
-  si.dpdu = dpdu; si.dpdv = dpdv;
-  f3 n = normalize(cross(dp02, dp12));  // :385
-  si.hit.n = n;
-  f3 ns = n;
-  if (flags & 2u) {
-    const float* q = sc.tri_n + 9 * (size_t)prim;
-    ns = normalize(mk3(q[0], q[1], q[2]) * b0 + mk3(q[3], q[4], q[5]) * b1 + mk3(q[6], q[7], q[8]) * b2);
+  const float4 r6 = rec[6], r7 = rec[7];
+  si.dpdu = mk3(r6.x, r6.y, r6.z); si.dpdv = mk3(r7.x, r7.y, r7.z);
+  if (RT_REC_CONST_FRAME(flags)) {
+    const float4 r4 = rec[4], r5 = rec[5];
+    si.hit.n = mk3(r3.x, r3.y, r3.z); si.sh_n = si.hit.n;
+    si.sh_dpdu = mk3(r4.x, r4.y, r4.z); si.sh_dpdv = mk3(r5.x, r5.y, r5.z);
+    si.ssb = mk3(r3.w, r4.w, r5.w);
+  } else {
+    TriGeo g; g.dpdu = si.dpdu; g.dpdv = si.dpdv; g.n = mk3(r3.x, r3.y, r3.z);
+    f3 ns = g.n, ss = g.n;
+    if (flags & 2u) {
+      const float* q = sc.tri_n + 9 * (size_t)prim;
+      ns = normalize(mk3(q[0], q[1], q[2]) * b0 + mk3(q[3], q[4], q[5]) * b1 + mk3(q[6], q[7], q[8]) * b2);
+    }
+    if (flags & 8u) {
+      const float* q = sc.tri_s + 9 * (size_t)prim;
+      ss = normalize(mk3(q[0], q[1], q[2]) * b0 + mk3(q[3], q[4], q[5]) * b1 + mk3(q[6], q[7], q[8]) * b2);
+    }
+    const TriFrame f = tri_frame(g, flags, ns, ss);
+    si.hit.n = f.n; si.sh_n = f.sh_n; si.sh_dpdu = f.ss; si.sh_dpdv = f.ts;
+    si.ssb = normalize(si.sh_dpdu);
   }
-  f3 ss;
-  if (flags & 8u) {
-    const float* q = sc.tri_s + 9 * (size_t)prim;
-    ss = normalize(mk3(q[0], q[1], q[2]) * b0 + mk3(q[3], q[4], q[5]) * b1 + mk3(q[6], q[7], q[8]) * b2);
-  } else ss = normalize(dpdu);
-  f3 ts = cross(ss, ns);
-  if (len2(ts) > 0.0f) { ts = normalize(ts); ss = cross(ts, ns); }
-  else coordinate_system(ns, ss, ts);
-  si.sh_n = ns; si.sh_dpdu = ss; si.sh_dpdv = ts;
-  if (flags & 2u) si.hit.n = face_forward(si.hit.n, si.sh_n);  // :417-422
-  else if (flags & 1u) { si.hit.n = -si.hit.n; si.sh_n = si.hit.n; }
   si.dudx = si.dvdx = si.dudy = si.dvdy = 0.0f;
   si.dpdx = si.dpdy = mk3(0, 0, 0);
   si.prim = prim;
@@ -242,15 +289,16 @@ RT_DEVN void tri_fill_interaction(const DScene& sc, int prim, f3 ray_d, const Tr
 
 // Geometric normal + hit point of a known hit, enough for Light::l / pdf_wi (no shading frame).
 RT_DEV void tri_hit_point_normal_inl(const DScene& sc, int prim, const TriHit& h, f3& p, f3& n) {
-  f3 p0, p1, p2; load_tri(sc.tri_p, prim, p0, p1, p2);
-  const unsigned flags = tri_flags(sc.tri_p, prim);
-  p = p0 * h.b0 + p1 * h.b1 + p2 * h.b2;
-  n = normalize(cross(p0 - p2, p1 - p2));
+  const float4* __restrict__ rec = sc.tri_rec + 8 * (size_t)prim;
+  const float4 r0 = rec[0], r1 = rec[1], r2 = rec[2], r3 = rec[3];
+  const unsigned flags = __float_as_uint(r2.w);
+  p = mk3(r0.x, r0.y, r0.z) * h.b0 + mk3(r1.x, r1.y, r1.z) * h.b1 + mk3(r2.x, r2.y, r2.z) * h.b2;
+  n = mk3(r3.x, r3.y, r3.z);  // normalize(cross(p0 - p2, p1 - p2)); already oriented (flags & 1) when the mesh has no vertex normals
   if (flags & 2u) {
     const float* q = sc.tri_n + 9 * (size_t)prim;
     f3 ns = normalize(mk3(q[0], q[1], q[2]) * h.b0 + mk3(q[3], q[4], q[5]) * h.b1 + mk3(q[6], q[7], q[8]) * h.b2);
     n = face_forward(n, ns);
-  } else if (flags & 1u) n = -n;
+  } else if (!RT_REC_CONST_FRAME(flags) && (flags & 1u)) n = -n;  // tangents without normals: row 3 holds the unoriented normal
 }
 
 RT_DEVN void tri_hit_point_normal(const DScene& sc, int prim, const TriHit& h, f3& p, f3& n) { tri_hit_point_normal_inl(sc, prim, h, p, n); }
@@ -289,6 +337,10 @@ struct GlobalSrc {
   const float4* nodes; const float4* tri_p;
   RT_DEV void node(int i, float4& a, float4& b) const { a = nodes[2 * i]; b = nodes[2 * i + 1]; }
   RT_DEV void tri(int i, f3& p0, f3& p1, f3& p2) const { load_tri(tri_p, i, p0, p1, p2); }
+  RT_DEV void tri_flags(int i, f3& p0, f3& p1, f3& p2, unsigned& flags) const {
+    float4 a = tri_p[3 * i], b = tri_p[3 * i + 1], c = tri_p[3 * i + 2];
+    p0 = mk3(a.x, a.y, a.z); p1 = mk3(b.x, b.y, b.z); p2 = mk3(c.x, c.y, c.z); flags = __float_as_uint(c.w);
+  }
 };
 
 // Closest-hit uses the "while-while" form: every lane first descends (slab tests, pushes) until it holds a
@@ -296,8 +348,30 @@ struct GlobalSrc {
 // the first accepted triangle, so there is little leaf work to batch). In both, the per-ray sequence of node
 // visits and triangle tests is exactly the reference's (counts and tie-breaking unchanged); only the SIMD
 // interleaving differs.
-template <bool ANY, bool COUNT, class Src, class StackT>
-RT_DEV bool traverse(const Src& src, Ray ray, StackT* stack, int stack_stride, int& prim_out, TriHit& hit_out, unsigned& n_nodes, unsigned& n_tris) {
+// A primitive of a GENERAL scene that is not a plain triangle test: an analytic quadric (Sphere::intersect / intersect_p, the hit record carries t where a
+// triangle's carries b2) or a triangle whose mesh has an alpha / shadow-alpha mask (an accepted test is dropped where the mask is 0, mesh.rs:353-370,
+// 534-582). Object instances are not handled here (they need a stack: general_leaf in rtx_kernels.h). c2 = the third float4 of the primitive's record
+// (p2 | flags). Defined in rtx_dev_shading.h; returns whether the ray hits, h filled.
+struct DScene;
+RT_DEV bool general_prim_test(const DScene& sc_self, int prim, f3 p0, f3 p1, f3 p2, unsigned flags, const Ray& ray, const RayPre& rp, bool shadow_masks, TriHit& h);
+#define RT_FLAG_GENERAL_TRI 48u  // alpha (16) | shadow alpha (32)
+
+// GENERAL: leaves may hold quadrics and alpha-masked triangles (gen = the scene record in device memory and whether shadowalpha masks apply); the plain
+// instantiation is the code it was.
+struct GeneralCtx { const DScene* self; bool shadow_masks; };
+template <bool GENERAL, class Src>
+RT_DEV bool leaf_prim_test(const Src& src, const GeneralCtx& gen, int prim, const Ray& ray, const RayPre& rp, TriHit& h) {
+  f3 p0, p1, p2;
+  if (GENERAL) {
+    unsigned flags; src.tri_flags(prim, p0, p1, p2, flags);
+    if (flags & (RT_FLAG_SPHERE | RT_FLAG_GENERAL_TRI)) return general_prim_test(*gen.self, prim, p0, p1, p2, flags, ray, rp, gen.shadow_masks, h);
+    return tri_test_pre(p0, p1, p2, ray, rp, h);
+  }
+  src.tri(prim, p0, p1, p2);
+  return tri_test_pre(p0, p1, p2, ray, rp, h);
+}
+template <bool ANY, bool COUNT, class Src, class StackT, bool GENERAL = false>
+RT_DEV bool traverse(const Src& src, Ray ray, StackT* stack, int stack_stride, int& prim_out, TriHit& hit_out, unsigned& n_nodes, unsigned& n_tris, GeneralCtx gen = GeneralCtx{nullptr, false}) {
   bool found = false;
   int sp = 0, cur = 0;
   f3 inv_dir = mk3(1.0f / ray.d.x, 1.0f / ray.d.y, 1.0f / ray.d.z);
@@ -314,11 +388,9 @@ RT_DEV bool traverse(const Src& src, Ray ray, StackT* stack, int stack_stride, i
         const int offset = __float_as_int(n1.z);
         if (n_prims > 0) {
           for (int i = 0; i < n_prims; ++i) {
-            f3 p0, p1, p2;
-            src.tri(offset + i, p0, p1, p2);
             if (COUNT) n_tris += 1;
             TriHit h;
-            if (tri_test_pre(p0, p1, p2, ray, rp, h)) return true;
+            if (leaf_prim_test<GENERAL>(src, gen, offset + i, ray, rp, h)) return true;
           }
           if (sp == 0) break;
           cur = (int)stack[(--sp) * stack_stride];
@@ -358,11 +430,9 @@ RT_DEV bool traverse(const Src& src, Ray ray, StackT* stack, int stack_stride, i
     }
     if (done) break;
     for (int i = 0; i < leaf_n; ++i) {
-      f3 p0, p1, p2;
-      src.tri(leaf_off + i, p0, p1, p2);
       if (COUNT) n_tris += 1;
       TriHit h;
-      if (tri_test_pre(p0, p1, p2, ray, rp, h)) {
+      if (leaf_prim_test<GENERAL>(src, gen, leaf_off + i, ray, rp, h)) {
         ray.t_max = h.t; found = true; prim_out = leaf_off + i; hit_out = h;  // `.or(result)`: later accepted hits replace
       }
     }
@@ -382,10 +452,10 @@ RT_DEV bool traverse(const Src& src, Ray ray, StackT* stack, int stack_stride, i
 #ifndef RT_LEAF_MIN
 #define RT_LEAF_MIN 20
 #endif
-RT_DEV bool leaf_phase_now(bool active, bool at_leaf) {  // called by every executing lane of the wave; wave-uniform answer
-  if (RT_LEAF_MIN <= 1) return true;
+RT_DEV bool leaf_phase_now(bool active, bool at_leaf, unsigned leaf_min) {  // called by every executing lane of the wave; wave-uniform answer. leaf_min: a launch parameter (rt_render picks it per ray class and scene)
+  if (leaf_min <= 1u) return true;
   const unsigned nl = (unsigned)__popcll(__ballot(active && at_leaf)), ni = (unsigned)__popcll(__ballot(active && !at_leaf));
-  return nl >= (unsigned)RT_LEAF_MIN || ni == 0u;
+  return nl >= leaf_min || ni == 0u;
 }
 
 // traverse() with the wave-level exit of its descend loop made explicit: the lanes walk down one node per round until LEAF_MIN of them hold a leaf or none
@@ -398,8 +468,8 @@ RT_DEV bool leaf_phase_now(bool active, bool at_leaf) {  // called by every exec
 #ifndef RT_LDS_LEAF_MIN_ANY
 #define RT_LDS_LEAF_MIN_ANY 1
 #endif
-template <bool ANY, bool COUNT, int LEAF_MIN, class Src, class StackT>
-RT_DEV bool traverse_rounds(const Src& src, Ray ray, StackT* stack, int stack_stride, int& prim_out, TriHit& hit_out, unsigned& n_nodes, unsigned& n_tris) {
+template <bool ANY, bool COUNT, int LEAF_MIN, class Src, class StackT, bool GENERAL = false>
+RT_DEV bool traverse_rounds(const Src& src, Ray ray, StackT* stack, int stack_stride, int& prim_out, TriHit& hit_out, unsigned& n_nodes, unsigned& n_tris, GeneralCtx gen = GeneralCtx{nullptr, false}) {
   bool found = false, done = false;
   int sp = 0, cur = 0, leaf_off = 0, leaf_n = 0;
   f3 inv_dir = mk3(1.0f / ray.d.x, 1.0f / ray.d.y, 1.0f / ray.d.z);
@@ -434,11 +504,9 @@ RT_DEV bool traverse_rounds(const Src& src, Ray ray, StackT* stack, int stack_st
     if ((holders | walkers) == 0ull) break;
     if (!done && leaf_n > 0) {
       for (int i = 0; i < leaf_n; ++i) {
-        f3 p0, p1, p2;
-        src.tri(leaf_off + i, p0, p1, p2);
         if (COUNT) n_tris += 1;
         TriHit h;
-        if (tri_test_pre(p0, p1, p2, ray, rp, h)) {
+        if (leaf_prim_test<GENERAL>(src, gen, leaf_off + i, ray, rp, h)) {
           found = true;
           if (ANY) break;
           ray.t_max = h.t; prim_out = leaf_off + i; hit_out = h;  // `.or(result)`: later accepted hits replace

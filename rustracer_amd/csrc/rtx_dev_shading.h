@@ -248,6 +248,18 @@ RT_DEVN bool tri_alpha_rejects(const DScene& sc, int prim, const TriHit& h, bool
   return false;
 }
 
+// leaf_prim_test's handler (rtx_dev_scene.h): a quadric, or a triangle of a masked mesh
+RT_DEV bool general_prim_test(const DScene& sc_self, int prim, f3 p0, f3 p1, f3 p2, unsigned flags, const Ray& ray, const RayPre& rp, bool shadow_masks, TriHit& h) {
+  if (flags & RT_FLAG_SPHERE) {
+    float ts;
+    if (!sphere_test(sc_self.spheres[__float_as_uint(p2.x)], ray.o, ray.d, ray.t_max, ts)) return false;
+    h.t = ts; h.b0 = h.b1 = 0.0f; h.b2 = ts;
+    return true;
+  }
+  if (!tri_test_pre(p0, p1, p2, ray, rp, h)) return false;
+  return !tri_alpha_rejects(sc_self, prim, h, shadow_masks);
+}
+
 // ---------------------------------------------------------------- materials (rc/material/*.rs)
 RT_DEV Lobe lobe_zero(int kind) {
   Lobe l; l.kind = kind; l.fr_kind = FR_NOOP; l.r = mkc(0, 0, 0); l.t = mkc(0, 0, 0); l.k = mkc(0, 0, 0);
@@ -504,7 +516,7 @@ RT_DEV void d1_sample_continuous(const float* func, const float* cdf, float func
   int offset = find_interval_le(cdf, n + 1, u);
   float du = u - cdf[offset];
   if (cdf[offset + 1] - cdf[offset] > 0.0f) du /= cdf[offset + 1] - cdf[offset];
-  pdf = func_int > 0.0f ? func[offset] / func_int : 0.0f;
+  pdf = func_int > 0.0f ? vdiv(func[offset], func_int) : 0.0f;
   x = ((float)offset + du) / (float)n;
   off = offset;
 }
@@ -515,7 +527,7 @@ RT_DEV void d1_sample_continuous_guided(const float* func, const float* cdf, flo
   int offset = find_interval_le_from(cdf, n + 1, u, g0, g1 - g0);
   float du = u - cdf[offset];
   if (cdf[offset + 1] - cdf[offset] > 0.0f) du /= cdf[offset + 1] - cdf[offset];
-  pdf = func_int > 0.0f ? func[offset] / func_int : 0.0f;
+  pdf = func_int > 0.0f ? vdiv(func[offset], func_int) : 0.0f;
   x = ((float)offset + du) / (float)n;
   off = offset;
 }
@@ -524,12 +536,12 @@ RT_DEV void d1_sample_discrete_guided(const float* func, const float* cdf, float
   const int k = clampi((int)(u * (float)G), 0, G - 1);
   const int g0 = (int)guide[k], g1 = (int)guide[k + 1];
   int offset = find_interval_le_from(cdf, n + 1, u, g0, g1 - g0);
-  pdf = func_int > 0.0f ? func[offset] / (func_int * (float)n) : 0.0f;
+  pdf = func_int > 0.0f ? vdiv(func[offset], func_int * (float)n) : 0.0f;
   off = offset;
 }
 RT_DEV void d1_sample_discrete(const float* func, const float* cdf, float func_int, int n, float u, int& off, float& pdf) {  // :70-79
   int offset = find_interval_le(cdf, n + 1, u);
-  pdf = func_int > 0.0f ? func[offset] / (func_int * (float)n) : 0.0f;
+  pdf = func_int > 0.0f ? vdiv(func[offset], func_int * (float)n) : 0.0f;
   off = offset;
 }
 
@@ -561,7 +573,7 @@ RT_DEV LiSample area_light_sample_li(const DScene& sc, const DLight& l, const In
   const unsigned flags = tri_flags(sc.tri_p, l.prim);
   float b2 = 1.0f - b.x - b.y;
   f3 p = (b.x * p0) + (b.y * p1) + (b2 * p2);
-  f3 normal = normalize(cross(p1 - p0, p2 - p0));
+  f3 normal = mk3(l.nrm[0], l.nrm[1], l.nrm[2]);  // normalize(cross(p1 - p0, p2 - p0)), k_light_consts
   if (flags & 2u) {
     const float* q = sc.tri_n + 9 * (size_t)l.prim;
     f3 ns = b.x * mk3(q[0], q[1], q[2]) + b.y * mk3(q[3], q[4], q[5]) + b2 * mk3(q[6], q[7], q[8]);
@@ -569,15 +581,15 @@ RT_DEV LiSample area_light_sample_li(const DScene& sc, const DLight& l, const In
   } else if (flags & 1u) normal = normal * -1.0f;
   f3 p_abs_sum = abs3(b.x * p0) + abs3(b.y * p1) + abs3(b2 * p2);
   s.p1.p = p; s.p1.p_error = gamma_n(6) * p_abs_sum; s.p1.n = normal;
-  float pdf = 1.0f / l.area;
+  float pdf = l.inv_area;  // 1.0 / area
   f3 wi = p - ref.p;
   if (len2(wi) == 0.0f) pdf = 0.0f;
   else {
-    wi = normalize(wi);
-    pdf *= distance_squared(ref.p, p) / fabsf(dot(normal, -wi));
+    wi = vnormalize(wi);  // the direction only enters BxDF values and this pdf; the shadow ray is spawned between the two points
+    pdf *= vdiv(distance_squared(ref.p, p), fabsf(dot(normal, -wi)));
     if (isinf(pdf)) pdf = 0.0f;
   }
-  s.wi = normalize(p - ref.p);
+  s.wi = vnormalize(p - ref.p);
   s.pdf = pdf;
   s.li = area_light_l(l, normal, -s.wi);
   return s;
@@ -587,12 +599,12 @@ template <bool GENERAL>  // true only in the shade kernel of scenes with alpha-m
 RT_DEV float area_light_pdf_li(const DScene& sc, const DLight& l, const Interaction& ref, f3 wi) {
   if (GENERAL && (tri_flags(sc.tri_p, l.prim) & RT_FLAG_SPHERE)) return sphere_pdf_wi(sc.spheres[prim_sphere_index(sc.tri_p, l.prim)], ref, wi);  // Sphere overrides pdf_wi
   Ray ray = spawn_ray(ref, wi);
-  f3 p0, p1, p2; load_tri(sc.tri_p, l.prim, p0, p1, p2);
+  f3 p0, p1, p2; load_tri_rec(sc.tri_rec, l.prim, p0, p1, p2);  // the line tri_hit_point_normal_inl reads as well
   TriHit h;
   if (!tri_test(p0, p1, p2, ray, h)) return 0.0f;
   if (GENERAL && sc.tri_alpha != nullptr && tri_alpha_rejects(sc, l.prim, h, false)) return 0.0f;
   f3 p, n; tri_hit_point_normal_inl(sc, l.prim, h, p, n);
-  return distance_squared(ref.p, p) / (fabsf(dot(n, -wi)) * l.area);
+  return vdiv(distance_squared(ref.p, p), fabsf(dot(n, -wi)) * l.area);
 }
 template <bool GENERAL>
 RT_DEVN LiSample light_sample_li(const DScene& sc, const DLight& l, Interaction ref, f2 u) {  // sc: a DScene in device memory (*sc.self); ref by value, in registers
@@ -633,7 +645,7 @@ RT_DEVN LiSample light_sample_li(const DScene& sc, const DLight& l, Interaction 
       float theta = d1 * kPi, phi = d0 * 2.0f * kPi;
       float cos_theta_ = cosf(theta), sin_theta_ = sinf(theta), cos_phi_ = cosf(phi), sin_phi_ = sinf(phi);
       f3 wi = xf3x4(l.l2w, mk3(sin_theta_ * cos_phi_, sin_theta_ * sin_phi_, cos_theta_));
-      s.pdf = sin_theta_ == 0.0f ? 0.0f : map_pdf / (2.0f * kPi * kPi * sin_theta_);
+      s.pdf = sin_theta_ == 0.0f ? 0.0f : vdiv(map_pdf, 2.0f * kPi * kPi * sin_theta_);
       s.p1.p = ref.p + wi * (2.0f * l.world_radius);
       s.li = RT_DBG(sc, 4) ? mkc(1, 1, 1) : mip_lookup(sc.images[l.image], mk2(d0, d1), 0.0f); s.wi = wi;
       return s;
@@ -652,7 +664,7 @@ RT_DEVN float light_pdf_li_q(const DScene& sc, const DLight& l, Interaction ref,
     if (sin_theta_ == 0.0f) return 0.0f;
     f2 p = mk2(phi * kInvPi * 0.5f, theta * kInvPi);  // Distribution2D::pdf, distribution2d.rs:36-49
     int iu = clampi((int)f2u_sat(p.x * (float)l.nu), 0, l.nu - 1), iv = clampi((int)f2u_sat(p.y * (float)l.nv), 0, l.nv - 1);
-    return (l.func[(size_t)iv * l.nu + iu] / l.mfunc_int) / (2.0f * kPi * kPi * sin_theta_);
+    return vdiv(vdiv(l.func[(size_t)iv * l.nu + iu], l.mfunc_int), 2.0f * kPi * kPi * sin_theta_);
   }
   return 0.0f;
 }

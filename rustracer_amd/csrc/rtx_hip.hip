@@ -59,6 +59,7 @@ struct rt_scene {
   bool top_for_closest = false;  // closest-hit rays through k_trace_top as well (shadow rays always, when no four-wide records exist)
   bool use_pairs = false;
   DevBuf quads; bool use_quads = false; int quad_stack_depth = 0;  // four-wide records of the any-hit kernel (k_trace_quad)
+  DevBuf tri_rec;  // per-triangle shade records (k_tri_records)
   DevBuf nodes, tri_p, tri_n, tri_uv, tri_s, tri_alpha, spheres, textures, images, materials, lights, texels, dist, guides;
   bool has_spheres = false;
   bool has_instances = false;  // object instances: two-level traversal in k_trace_big<.., GENERAL>, every vertex shaded by k_shade<0, true>
@@ -447,11 +448,12 @@ extern "C" int rt_scene_create(const rt_scene_desc* desc, int device, rt_scene**
   for (uint32_t i = 0; i < desc->n_lights; ++i) if (desc->lights[i].kind != RT_LIGHT_DIFFUSE_AREA) s->lambert_only = false;
   for (uint32_t i = 0; i < desc->n_lights; ++i)
     if (desc->lights[i].kind == RT_LIGHT_DIFFUSE_AREA && (desc->tri_meta[desc->lights[i].prim].flags & RT_TRI_HAS_ALPHA)) s->masked_emitters = true;
-  if (s->has_spheres || s->has_instances) s->masked_emitters = true;  // sphere / instance hits, sphere emitters: the generic shade kernel and its GENERAL functions
-  if (s->masked_emitters) { s->lambert_only = false; s->lambert_materials = false; }  // only the generic kernel re-intersects emitters with the mask test
+  if (s->has_spheres || s->has_instances) s->masked_emitters = true;  // quadric / instance hits, quadric emitters, masked emitters: the GENERAL instantiations of the shade kernels
+  if (s->masked_emitters) s->lambert_only = false;  // (the constant-matte kernel has no GENERAL form: such scenes shade through the Lambert front-end k_shade<3, true>)
   s->n_materials = desc->n_materials;
-  s->small = desc->n_nodes <= RT_SMALL_NODES && desc->n_tris <= RT_SMALL_TRIS && !s->general_prims;
+  s->small = desc->n_nodes <= RT_SMALL_NODES && desc->n_tris <= RT_SMALL_TRIS && !s->has_instances;  // quadrics and masked triangles: the GENERAL form of the LDS kernel
   if (getenv("RTX_SMALL") && getenv("RTX_SMALL")[0] == '0') s->small = false;  // measurement knob: an LDS-sized scene through the kernels of the large ones
+  int max_obj_depth = 0;
   {  // tree height bounds the number of simultaneously pending stack entries
     // one tree: nodes [base, base + nn), child offsets relative to base, leaf ranges within its np primitives
     auto tree_depth = [&](uint32_t base, uint32_t nn, uint32_t np, int& maxd) -> bool {
@@ -470,24 +472,38 @@ extern "C" int rt_scene_create(const rt_scene_desc* desc, int device, rt_scene**
     if (!tree_depth(0, n_top_nodes, n_top_prims, maxd)) { delete s; return fail(RT_ERR_INVALID, "malformed BVH"); }
     if (maxd + 1 > 64) { delete s; return fail(RT_ERR_INVALID, "BVH deeper than the 64-entry traversal stack"); }
     s->stack_depth = maxd + 1;
+    int max_obj = 0;
     for (uint32_t k = 0; k < desc->n_instances; ++k) {
       const rt_instance& in = desc->instances[k];
       int od = 0;
       if (in.n_nodes && (!tree_depth(in.node_base, in.n_nodes, in.n_prims, od) || od + 1 > 64)) { delete s; return fail(RT_ERR_INVALID, "malformed or too deep object BVH"); }
+      if (in.n_nodes) max_obj = std::max(max_obj, od + 1);
     }
+    // an object's walk uses the entries of the lane's stack column above the top level's pending ones: the column holds both
+    if (s->stack_depth + max_obj > 64) { delete s; return fail(RT_ERR_INVALID, "top-level BVH plus the deepest object BVH exceed the 64-entry traversal stack"); }
+    s->stack_depth += max_obj; max_obj_depth = max_obj;
   }
   d.pairs = nullptr; d.quads = nullptr;
-  if (!s->small && !s->general_prims) {  // LDS-resident scenes keep the one-node-per-step loop: the pair form measured no faster there
+  if (!s->small) {  // LDS-resident scenes keep the one-node-per-step loop: the pair form measured no faster there
+    // With object instances the records cover the top-level tree (objects are walked one node per step, their child offsets are relative to the object).
+    // A leaf of a GENERAL scene that holds anything but plain triangles carries RT_PAIR_GENERAL.
+    const uint32_t n_pair_nodes = n_top_nodes;
+    const bool gen = s->general_prims;
+    auto general_leaf = [&](const rt_bvh_node& n) {
+      for (uint32_t t = n.offset; t < n.offset + n.n_prims; ++t)
+        if (desc->tri_meta[t].flags & (RT_TRI_HAS_ALPHA | RT_TRI_HAS_SHADOW_ALPHA | RT_PRIM_SPHERE | RT_PRIM_INSTANCE)) return true;
+      return false;
+    };
     // child-pair records for k_trace_pair: {A.min.xyz, A.max.x} {A.max.yz, code A, code B} {B.min.xyz, B.max.x} {B.max.yz, -, -}
     // (a root that is itself a leaf - every centroid coincides - is never seen by code_of(): its count must fit the 5-bit field too)
-    bool ok = desc->n_nodes < (1u << 29) && desc->n_tris < (1u << 26) && desc->nodes[0].n_prims <= 32;
+    bool ok = n_pair_nodes < (1u << 29) && n_top_prims < (gen ? (1u << 25) : (1u << 26)) && desc->nodes[0].n_prims <= 32;
     auto code_of = [&](uint32_t c, bool& good) -> uint32_t {
       const rt_bvh_node& n = desc->nodes[c];
-      if (n.n_prims > 0) { if (n.n_prims > 32) good = false; return 0x80000000u | n.offset | ((uint32_t)(n.n_prims - 1) << 26); }
+      if (n.n_prims > 0) { if (n.n_prims > 32) good = false; return 0x80000000u | n.offset | ((uint32_t)(n.n_prims - 1) << 26) | (gen && general_leaf(n) ? RT_PAIR_GENERAL : 0u); }
       return c | ((uint32_t)n.axis << 29);
     };
-    std::vector<float> pr((size_t)desc->n_nodes * 16, 0.0f);
-    for (uint32_t i = 0; i < desc->n_nodes && ok; ++i) {
+    std::vector<float> pr((size_t)n_pair_nodes * 16, 0.0f);
+    for (uint32_t i = 0; i < n_pair_nodes && ok; ++i) {
       const rt_bvh_node& n = desc->nodes[i];
       if (n.n_prims != 0) continue;
       const rt_bvh_node& a = desc->nodes[i + 1]; const rt_bvh_node& b = desc->nodes[n.offset];
@@ -502,9 +518,9 @@ extern "C" int rt_scene_create(const rt_scene_desc* desc, int device, rt_scene**
       d.pairs = s->pairs.as<float4>(); s->use_pairs = true;
     }
     d.top_pairs = nullptr; d.n_top = 0;
-    if (ok && desc->n_nodes < (1u << 28) && desc->nodes[0].n_prims == 0) {
+    if (ok && n_pair_nodes < (1u << 28) && desc->nodes[0].n_prims == 0 && !s->has_instances) {  // (an object's walk needs a contiguous stack column: k_trace_pair)
       // the first levels of the tree, breadth first, for k_trace_top: up to RT_TOP_MAX interior nodes; a child that is itself one of them is named by its slot
-      std::vector<uint32_t> top; std::vector<int> slot_of(desc->n_nodes, -1);
+      std::vector<uint32_t> top; std::vector<int> slot_of(n_pair_nodes, -1);
       top.push_back(0); slot_of[0] = 0;
       for (size_t head = 0; head < top.size(); ++head) {
         const uint32_t P = top[head]; const uint32_t kids[2] = {P + 1, desc->nodes[P].offset};
@@ -526,7 +542,7 @@ extern "C" int rt_scene_create(const rt_scene_desc* desc, int device, rt_scene**
       // pair records), +2 % on S3 (83 KB: L1-resident either way) and +6 % on S2 (128 MB: a sixth wave per SIMD evicts more of the tree from L2 than
       // it hides). 64, 128 or 256 LDS-resident nodes measured the same: the top of the tree was already served by the CU's L1 - what the kernel
       // gains is its sixth wave per SIMD, and that pays where the tree fits the 32 MB of L2 without fitting an L1.
-      const size_t pair_bytes = (size_t)desc->n_nodes * 64;
+      const size_t pair_bytes = (size_t)n_pair_nodes * 64;
       s->top_for_closest = pair_bytes <= ((size_t)64 << 20);  // measured with the gated leaf phase: S3 (0.1 MB) 81 -> 78 ms, S4 (13 MB) 1743 -> 1659 ms, S2 (67 MB) 94 -> 102 ms
       if (getenv("RTX_TOP_CLOSEST")) s->top_for_closest = getenv("RTX_TOP_CLOSEST")[0] == '1';  // measurement knob
     }
@@ -534,9 +550,9 @@ extern "C" int rt_scene_create(const rt_scene_desc* desc, int device, rt_scene**
     // per node: 24 floats = boxes of slots 0..3 (slots 0,1: first child's part, 2,3: second child's), 4 codes (0xffffffff = empty slot),
     // {axis of the first child | axis of the second child << 2}.
     if (ok) {
-      std::vector<float> qr((size_t)desc->n_nodes * 32, 0.0f);
-      std::vector<int> need(desc->n_nodes, 0);  // stack entries the four-wide walk can have pending below this node
-      for (uint32_t i = desc->n_nodes; i-- > 0;) {
+      std::vector<float> qr((size_t)n_pair_nodes * 32, 0.0f);
+      std::vector<int> need(n_pair_nodes, 0);  // stack entries the four-wide walk can have pending below this node
+      for (uint32_t i = n_pair_nodes; i-- > 0;) {
         const rt_bvh_node& n = desc->nodes[i];
         if (n.n_prims != 0) continue;
         float* q = qr.data() + (size_t)i * 32;
@@ -558,7 +574,7 @@ extern "C" int rt_scene_create(const rt_scene_desc* desc, int device, rt_scene**
         memcpy(q + 24, codes, 16); memcpy(q + 28, &axes, 4);
         need[i] = deepest + n_entries - 1;
       }
-      s->quad_stack_depth = need[0] + 1;
+      s->quad_stack_depth = need[0] + 1 + max_obj_depth;  // (+ the deepest object's walk above the pending entries)
       if (ok && s->quad_stack_depth <= 32) {  // beyond the 32-entry LDS stack the larger stack costs more residency than the wider step returns
         int rc2 = upload(s->quads, qr.data(), qr.size() * 4);
         if (rc2 != RT_OK) { delete s; return rc2; }
@@ -573,6 +589,12 @@ extern "C" int rt_scene_create(const rt_scene_desc* desc, int device, rt_scene**
     if (s->deep_stack.ensure(nb) != hipSuccess) { delete s; return fail(RT_ERR_OOM, "traversal stack allocation failed"); }
   }
   fill_ewa_lut();
+  // per-triangle shade records and per-emitter constants, computed on the device by the per-vertex path's own expressions
+  if (s->tri_rec.ensure((size_t)desc->n_tris * 128) != hipSuccess) { delete s; return fail(RT_ERR_OOM, "shade record allocation failed"); }
+  d.tri_rec = s->tri_rec.as<float4>();
+  hipLaunchKernelGGL(k_tri_records, dim3((desc->n_tris + 255u) / 256u), dim3(256), 0, nullptr, d, s->tri_rec.as<float4>());
+  if (desc->n_lights) hipLaunchKernelGGL(k_light_consts, dim3((desc->n_lights + 255u) / 256u), dim3(256), 0, nullptr, d, s->lights.as<DLight>());
+  if (hipGetLastError() != hipSuccess) { delete s; return fail(RT_ERR_HIP, "constant precomputation launch failed"); }
   if (s->self.ensure(sizeof(DScene)) != hipSuccess) { delete s; return fail(RT_ERR_OOM, "scene record allocation failed"); }
   d.self = s->self.as<DScene>();
   HIP_TRY(hipMemcpy(s->self.p, &d, sizeof(DScene), hipMemcpyHostToDevice));
@@ -703,6 +725,18 @@ static size_t deep_stack_bytes(const rt_scene* s) {
   if (!s->use_top) return 0;
   return (size_t)top_grid(s) * RT_TOP_BLOCK * (size_t)std::max(1, s->stack_depth - RT_TOP_LDS_DEPTH) * 4;
 }
+// the two knobs of the persistent traversal loops in one launch argument: lanes that must be idle before a wave refills (bits 0-7) and lanes that must wait at
+// a leaf before the leaf phase runs (bits 8-15; RT_LEAF_MIN, see leaf_phase_now). A leaf of an instanced scene is a whole nested walk: no gating there.
+static unsigned trace_knobs(const rt_scene* s, bool any) {
+  static const int env_refill = getenv("RTX_REFILL_MIN") ? std::min(64, std::max(1, atoi(getenv("RTX_REFILL_MIN")))) : -1;
+  static const int env_leaf = getenv("RTX_LEAF_MIN") ? std::min(64, std::max(1, atoi(getenv("RTX_LEAF_MIN")))) : -1;
+  static const int env_leaf_any = getenv("RTX_LEAF_MIN_ANY") ? std::min(64, std::max(1, atoi(getenv("RTX_LEAF_MIN_ANY")))) : -1;
+  const unsigned refill = env_refill > 0 ? (unsigned)env_refill : (unsigned)RT_REFILL_MIN;
+  unsigned leaf = s->has_instances ? 1u : (unsigned)RT_LEAF_MIN;
+  if (env_leaf > 0) leaf = (unsigned)env_leaf;
+  if (any && env_leaf_any > 0) leaf = (unsigned)env_leaf_any;
+  return refill | (leaf << 8);
+}
 template <bool ANY, bool COUNT, bool SMALL, int BLOCK, int DEPTH>
 static void launch_trace_v(rt_scene* s, const TraceIO& io, const unsigned* queue, const unsigned* count_ptr, unsigned shard_cap, unsigned count_static,
                            unsigned long long* stats, int st_rays, int st_nodes, int st_tris, hipStream_t stream) {
@@ -712,7 +746,7 @@ static void launch_trace_v(rt_scene* s, const TraceIO& io, const unsigned* queue
     // loop, default = child-pair traversal (frames that count visits always use the one-node-per-step loops)
     static const char* mode = getenv("RTX_TRACE");
     const bool plain = mode && mode[0] == 'p', refill_only = mode && mode[0] == 'r';
-    static const unsigned refill_min = getenv("RTX_REFILL_MIN") ? (unsigned)std::min(64, std::max(1, atoi(getenv("RTX_REFILL_MIN")))) : (unsigned)RT_REFILL_MIN;
+    const unsigned refill_min = trace_knobs(s, ANY);
     if (ANY && !COUNT && !plain && !refill_only && !(mode && mode[0] == 'c') && s->use_quads && s->quad_stack_depth <= DEPTH) {  // RTX_TRACE=childpair: two-wide only
       hipLaunchKernelGGL((k_trace_quad<ANY, BLOCK, DEPTH>), dim3(grid), dim3(BLOCK), 0, stream, s->d, io, queue, count_ptr, shard_cap, count_static, stats, st_rays, s->tmin_stack.as<float>(), refill_min);
       return;
@@ -740,7 +774,32 @@ template <bool ANY, bool COUNT>
 static void launch_trace_c(rt_scene* s, const TraceIO& io, const unsigned* queue, const unsigned* count_ptr, unsigned shard_cap, unsigned count_static,
                            unsigned long long* stats, int st_rays, int st_nodes, int st_tris, hipStream_t stream) {
 #define RT_ARGS s, io, queue, count_ptr, shard_cap, count_static, stats, st_rays, st_nodes, st_tris, stream
-  if (s->general_prims) {  // alpha-masked triangles: the one kernel whose leaf loop evaluates masks
+  if (s->general_prims) {  // quadrics, masked triangles, object instances: the GENERAL instantiations (plain leaves of such a scene still run the bare triangle loop)
+    static const char* gmode = getenv("RTX_TRACE_GENERAL");  // measurement knob: "big" = the one-node-per-step kernel for every ray (round 2's path)
+    const bool big_only = gmode && gmode[0] == 'b';
+    if constexpr (!COUNT) {
+      const unsigned refill_min = trace_knobs(s, ANY);
+      if (!big_only && s->small) {
+        if (s->stack_depth <= 16) hipLaunchKernelGGL((k_trace<ANY, false, true, 256, 16, true>), dim3(trace_grid<ANY, true, 256, 16>(s)), dim3(256), 0, stream, s->d, io, queue, count_ptr, shard_cap, count_static, stats, st_rays, st_nodes, st_tris);
+        else if (s->stack_depth <= 32) hipLaunchKernelGGL((k_trace<ANY, false, true, 256, 32, true>), dim3(trace_grid<ANY, true, 256, 32>(s)), dim3(256), 0, stream, s->d, io, queue, count_ptr, shard_cap, count_static, stats, st_rays, st_nodes, st_tris);
+        else hipLaunchKernelGGL((k_trace<ANY, false, true, 128, 64, true>), dim3(trace_grid<ANY, true, 128, 64>(s)), dim3(128), 0, stream, s->d, io, queue, count_ptr, shard_cap, count_static, stats, st_rays, st_nodes, st_tris);
+        return;
+      }
+      if (!big_only && ANY && s->use_quads && s->quad_stack_depth <= 32) {
+        hipLaunchKernelGGL((k_trace_quad<ANY, 128, 32, true>), dim3(trace_grid<ANY, false, 128, 32>(s)), dim3(128), 0, stream, s->d, io, queue, count_ptr, shard_cap, count_static, stats, st_rays, s->tmin_stack.as<float>(), refill_min);
+        return;
+      }
+      if (!big_only && s->use_pairs && s->use_top && (ANY || s->top_for_closest)) {
+        hipLaunchKernelGGL((k_trace_top<ANY, RT_TOP_BLOCK, true>), dim3(top_grid(s)), dim3(RT_TOP_BLOCK), 0, stream, s->d, io, queue, count_ptr, shard_cap, count_static, stats, st_rays,
+                           s->tmin_stack.as<float>(), s->deep_stack.as<unsigned>(), refill_min);
+        return;
+      }
+      if (!big_only && s->use_pairs) {
+        if (s->stack_depth <= 32) hipLaunchKernelGGL((k_trace_pair<ANY, false, 128, 32, true>), dim3(trace_grid<ANY, false, 128, 32>(s)), dim3(128), 0, stream, s->d, io, queue, count_ptr, shard_cap, count_static, stats, st_rays, s->tmin_stack.as<float>(), refill_min);
+        else hipLaunchKernelGGL((k_trace_pair<ANY, false, 128, 64, true>), dim3(trace_grid<ANY, false, 128, 64>(s)), dim3(128), 0, stream, s->d, io, queue, count_ptr, shard_cap, count_static, stats, st_rays, s->tmin_stack.as<float>(), refill_min);
+        return;
+      }
+    }
     if (s->stack_depth <= 32) hipLaunchKernelGGL((k_trace_big<ANY, COUNT, 128, 32, true>), dim3(trace_grid<ANY, false, 128, 32>(s)), dim3(128), 0, stream, s->d, io, queue, count_ptr, shard_cap, count_static, stats, st_rays, st_nodes, st_tris);
     else hipLaunchKernelGGL((k_trace_big<ANY, COUNT, 128, 64, true>), dim3(trace_grid<ANY, false, 128, 64>(s)), dim3(128), 0, stream, s->d, io, queue, count_ptr, shard_cap, count_static, stats, st_rays, st_nodes, st_tris);
     return;
@@ -1013,12 +1072,13 @@ extern "C" int rt_render(rt_scene* s, const rt_camera* cam, const rt_film_desc* 
   static const int bp_log2 = env_log2("RTX_BATCH_LOG2", 19);
   enum { B_PATH, B_VERT, B_BETA, B_ACC, B_SH, B_MI, B_QIN, B_QOUT, B_QSH, B_QMI, B_QMA, B_COUNT };  // grouped per-path records (rtx_kernels.h) and five queues of path ids
   const bool has_infinite = s->d.n_infinite > 0;
-  const size_t counter_words = (size_t)(fp.max_depth + 2) * RT_NQ * RT_QSHARDS;  // one block of {out, shadow, mis, mis-any} shard counts per bounce + raygen's
+  const size_t counter_words = (size_t)(fp.max_depth + 2) * RT_NQ * RT_QSHARDS * RT_CNT_STRIDE;  // one block of {out, shadow, mis, mis-any} shard counts per bounce + raygen's
   // material binning before the generic shade kernel: per bounce {hist, cursor}[RT_BIN_MAX + 1] + the 8 count words of the sorted queue
   static const bool bin_off = getenv("RTX_SHADE_BINS") && getenv("RTX_SHADE_BINS")[0] == '0';  // measurement knob
-  const bool use_bins = !s->lambert_materials && s->n_code_classes > 1 && !bin_off && !s->masked_emitters;  // one class: every vertex runs the same code, the queue order is kept
+  const bool use_bins = !s->lambert_materials && s->n_code_classes > 1 && !bin_off;  // one class: every vertex runs the same code, the queue order is kept
+  const bool gshade = s->masked_emitters;  // quadric / instance hits, quadric or masked emitters: the GENERAL instantiations of the shade kernels
   const unsigned n_bins = std::min<unsigned>(s->n_code_classes, RT_BIN_MAX) + 1u;
-  const size_t bin_stride = 2 * (RT_BIN_MAX + 1) + RT_QSHARDS + 10;  // + {begin, end} of the four class ranges and of the miss bin
+  const size_t bin_stride = (RT_BIN_MAX + 1) + (size_t)(RT_BIN_MAX + 1) * RT_CNT_STRIDE + (size_t)RT_QSHARDS * RT_CNT_STRIDE + 10;  // hist, cursors (spread), the sorted queue's counts (laid out as shard counters)  // + {begin, end} of the four class ranges and of the miss bin
   // RTX_SHADE_SPLIT (measurement knob): 0 = every class through the generic front-end, 1 = Lambert classes apart, default = Lambert and two-lobe classes apart
   const int split_mode = getenv("RTX_SHADE_SPLIT") ? atoi(getenv("RTX_SHADE_SPLIT")) : 2;
   const unsigned n_first = split_mode >= 1 ? s->n_lambert_classes : 0u, n_second = split_mode >= 2 ? s->n_small_classes : 0u;
@@ -1101,6 +1161,10 @@ extern "C" int rt_render(rt_scene* s, const rt_camera* cam, const rt_film_desc* 
   }
   const bool count = (flags & RT_FLAG_COUNT_TRAVERSAL) != 0;
   const unsigned pgrid = (unsigned)s->n_cu * 8u;
+  // workgroup size of the shade launches (measurement knob RTX_SHADE_BLOCK = 64 | 128 | 256): the queue appends of a workgroup meet at three barriers per
+  // iteration, so its waves run in lockstep; smaller workgroups trade that for more atomics on the shard counters. Same number of lanes in the grid.
+  static const unsigned sblock = [] { const char* e = getenv("RTX_SHADE_BLOCK"); const int v = e ? atoi(e) : 256; return (unsigned)(v == 64 || v == 128 ? v : 256); }();
+  const unsigned sgrid = pgrid * (256u / sblock);
   unsigned long long* dstats = s->stats.as<unsigned long long>();
 
   // K0 of a batch goes to the low-priority aux stream: it is a latency-bound chain of LDS swaps that leaves the
@@ -1143,51 +1207,54 @@ extern "C" int rt_render(rt_scene* s, const rt_camera* cam, const rt_film_desc* 
       unsigned* const cb = s->counters.as<unsigned>();
       ps.cnt_in = nullptr; ps.cnt_out = cb;  // raygen appends to block 0's `out` queue
       ps.all_in_bounds = all_in_bounds ? 1 : 0;
-      ps.mis_any = (has_infinite && !count) ? 1 : 0;  // a frame that counts node visits keeps the reference's closest-hit walk for every MIS ray
+      // a frame that counts node visits keeps the reference's closest-hit walk for every MIS ray, unless it is asked to count what a production frame walks
+      ps.mis_any = (has_infinite && (!count || (flags & RT_FLAG_COUNT_AS_RENDERED))) ? 1 : 0;
       tm.begin(&stats.ms_raygen);
       hipLaunchKernelGGL(k_raygen, dim3(pgrid), dim3(256), 0, stream, fp, ps);
       tm.end();
       for (int bounce = 0; bounce <= fp.max_depth; ++bounce) {
-        ps.cnt_in = cb + (size_t)bounce * RT_NQ * RT_QSHARDS; ps.cnt_out = cb + (size_t)(bounce + 1) * RT_NQ * RT_QSHARDS;
+        ps.cnt_in = cb + (size_t)bounce * RT_NQ * RT_QSHARDS * RT_CNT_STRIDE; ps.cnt_out = cb + (size_t)(bounce + 1) * RT_NQ * RT_QSHARDS * RT_CNT_STRIDE;
         unsigned* const q_first = ps.q_in;
         if (bounce == 0 && all_in_bounds) ps.q_in = nullptr;  // identity: path i is entry i
         tm.begin(&stats.ms_trace_closest);
         launch_trace<false>(s, count, io_path, ps.q_in, ps.cnt_in, ps.shard_cap, ps.cap, dstats, ST_RAYS_CLOSEST, ST_NODES_CLOSEST, ST_TRIS_CLOSEST, stream);
         tm.end();
-        if (s->lambert_only) { tm.begin(&stats.ms_shade_lambert_const); hipLaunchKernelGGL(k_shade<1>, dim3(pgrid), dim3(256), 0, stream, s->d, fp, ps); tm.end(); }
-        else if (s->lambert_materials) { tm.begin(&stats.ms_shade_lambert); hipLaunchKernelGGL(k_shade<3>, dim3(pgrid), dim3(256), 0, stream, s->d, fp, ps); tm.end(); }
-        else if (!use_bins) {
-          tm.begin(&stats.ms_shade_generic);
-          if (s->masked_emitters) hipLaunchKernelGGL((k_shade<0, true>), dim3(pgrid), dim3(256), 0, stream, s->d, fp, ps);
-          else hipLaunchKernelGGL(k_shade<0>, dim3(pgrid), dim3(256), 0, stream, s->d, fp, ps);
-          tm.end();
-        }
+#define RT_SHADE(MODE, P) do { if (gshade) hipLaunchKernelGGL((k_shade<MODE, true>), dim3(sgrid), dim3(sblock), 0, stream, s->d, fp, P); \
+                               else hipLaunchKernelGGL((k_shade<MODE, false>), dim3(sgrid), dim3(sblock), 0, stream, s->d, fp, P); } while (0)
+        if (s->lambert_only) { tm.begin(&stats.ms_shade_lambert_const); hipLaunchKernelGGL(k_shade<1>, dim3(sgrid), dim3(sblock), 0, stream, s->d, fp, ps); tm.end(); }
+        else if (s->lambert_materials) { tm.begin(&stats.ms_shade_lambert); RT_SHADE(3, ps); tm.end(); }
+        else if (!use_bins) { tm.begin(&stats.ms_shade_generic); RT_SHADE(0, ps); tm.end(); }
         else {
           tm.begin(&stats.ms_shade_bin);
           unsigned* bw = s->bin_words.as<unsigned>() + (size_t)bounce * bin_stride;
-          unsigned* hist = bw; unsigned* cursor = bw + (RT_BIN_MAX + 1); unsigned* sorted_cnt = bw + 2 * (RT_BIN_MAX + 1);
+          unsigned* hist = bw; unsigned* cursor = bw + (RT_BIN_MAX + 1); unsigned* sorted_cnt = cursor + (size_t)(RT_BIN_MAX + 1) * RT_CNT_STRIDE;
           hipLaunchKernelGGL(k_bin_count, dim3(pgrid), dim3(256), 0, stream, s->d, ps, n_bins, hist, s->bin_at.as<unsigned short>());
-          unsigned* ranges = sorted_cnt + RT_QSHARDS;
+          unsigned* ranges = sorted_cnt + (size_t)RT_QSHARDS * RT_CNT_STRIDE;
           hipLaunchKernelGGL(k_bin_scatter, dim3(pgrid), dim3(256), 0, stream, s->d, ps, n_bins, hist, cursor, s->bin_sorted.as<unsigned>(), sorted_cnt,
                              split_classes ? n_first : 0u, split_classes ? n_first + n_second : 0u, split_classes ? n_first + n_second + n_third : 0u, ranges, s->bin_at.as<unsigned short>());
           tm.end();
           PassState pb = ps; pb.q_in = s->bin_sorted.as<unsigned>(); pb.cnt_in = sorted_cnt;  // all entries in shard 0: QView::get(i) = ids[i]
           // classes of the register-resident front-ends, then the generic one, then the rays that left the scene
-          if (split_classes && n_first) { pb.range = ranges; tm.begin(&stats.ms_shade_lambert); hipLaunchKernelGGL(k_shade<3>, dim3(pgrid), dim3(256), 0, stream, s->d, fp, pb); tm.end(); }
-          if (split_classes && n_second) { pb.range = ranges + 2; tm.begin(&stats.ms_shade_two_lobe); hipLaunchKernelGGL(k_shade<5>, dim3(pgrid), dim3(256), 0, stream, s->d, fp, pb); tm.end(); }
-          if (split_classes && n_third) { pb.range = ranges + 8; tm.begin(&stats.ms_shade_two_lobe); hipLaunchKernelGGL(k_shade<6>, dim3(pgrid), dim3(256), 0, stream, s->d, fp, pb); tm.end(); }
-          pb.range = ranges + 4; tm.begin(&stats.ms_shade_generic); hipLaunchKernelGGL(k_shade<0>, dim3(pgrid), dim3(256), 0, stream, s->d, fp, pb); tm.end();
+          if (split_classes && n_first) { pb.range = ranges; tm.begin(&stats.ms_shade_lambert); RT_SHADE(3, pb); tm.end(); }
+          if (split_classes && n_second) { pb.range = ranges + 2; tm.begin(&stats.ms_shade_two_lobe); RT_SHADE(5, pb); tm.end(); }
+          if (split_classes && n_third) { pb.range = ranges + 8; tm.begin(&stats.ms_shade_two_lobe); RT_SHADE(6, pb); tm.end(); }
+          pb.range = ranges + 4; tm.begin(&stats.ms_shade_generic); RT_SHADE(0, pb); tm.end();
           pb.range = ranges + 6; tm.begin(&stats.ms_shade_miss); hipLaunchKernelGGL(k_shade_miss, dim3(pgrid), dim3(256), 0, stream, s->d, pb); tm.end();
         }
+#undef RT_SHADE
         tm.begin(&stats.ms_trace_any);
-        launch_trace<true>(s, count, io_shadow, ps.q_shadow, ps.cnt_out + RT_QSHARDS, ps.shard_cap, 0, dstats, ST_RAYS_SHADOW, ST_NODES_SHADOW, ST_TRIS_SHADOW, stream);
+        launch_trace<true>(s, count, io_shadow, ps.q_shadow, ps.cnt_out + RT_QSHARDS * RT_CNT_STRIDE, ps.shard_cap, 0, dstats, ST_RAYS_SHADOW, ST_NODES_SHADOW, ST_TRIS_SHADOW, stream);
         tm.end();
         tm.begin(&stats.ms_trace_mis);
-        launch_trace<false>(s, count, io_mis, ps.q_mis, ps.cnt_out + 2 * RT_QSHARDS, ps.shard_cap, 0, dstats, ST_RAYS_MIS, ST_NODES_MIS, ST_TRIS_MIS, stream);
-        if (ps.mis_any) launch_trace<true>(s, false, io_mis_any, ps.q_misany, ps.cnt_out + 3 * RT_QSHARDS, ps.shard_cap, 0, dstats, ST_RAYS_MIS, ST_NODES_MIS, ST_TRIS_MIS, stream);
+        launch_trace<false>(s, count, io_mis, ps.q_mis, ps.cnt_out + 2 * RT_QSHARDS * RT_CNT_STRIDE, ps.shard_cap, 0, dstats, ST_RAYS_MIS, ST_NODES_MIS, ST_TRIS_MIS, stream);
         tm.end();
+        if (ps.mis_any) {
+          tm.begin(&stats.ms_trace_mis_any);
+          launch_trace<true>(s, count, io_mis_any, ps.q_misany, ps.cnt_out + 3 * RT_QSHARDS * RT_CNT_STRIDE, ps.shard_cap, 0, dstats, ST_RAYS_MISANY, ST_NODES_MISANY, ST_TRIS_MISANY, stream);
+          tm.end();
+        }
         tm.begin(&stats.ms_resolve);
-        if (s->has_spheres) hipLaunchKernelGGL(k_resolve<true>, dim3(pgrid), dim3(256), 0, stream, s->d, ps);
+        if (s->has_spheres || s->has_instances) hipLaunchKernelGGL(k_resolve<true>, dim3(pgrid), dim3(256), 0, stream, s->d, ps);  // (a hit id inside an instance is not a primitive index)
         else hipLaunchKernelGGL(k_resolve<false>, dim3(pgrid), dim3(256), 0, stream, s->d, ps);
         tm.end();
         stats.launches_trace_closest += 2;
@@ -1218,9 +1285,11 @@ extern "C" int rt_render(rt_scene* s, const rt_camera* cam, const rt_film_desc* 
   { unsigned ovf = 0; HIP_TRY(hipMemcpy(&ovf, s->sampler_plan.dirty.as<unsigned>() + 1 + RT_DIRTY_CAP, 4, hipMemcpyDeviceToHost));
     if (ovf) { (void)hipMemset(s->sampler_plan.dirty.p, 0, (2 + RT_DIRTY_CAP) * 4); return fail(RT_ERR_INVALID, "sampler retry list overflow"); } }
   stats.camera_rays = h[ST_CAMERA];  // counted by k_raygen: samples inside pixel_bounds and the film's sample rows
-  stats.rays_closest = h[ST_RAYS_CLOSEST]; stats.rays_shadow = h[ST_RAYS_SHADOW]; stats.rays_mis = h[ST_RAYS_MIS];
-  stats.nodes_closest = h[ST_NODES_CLOSEST]; stats.nodes_shadow = h[ST_NODES_SHADOW]; stats.nodes_mis = h[ST_NODES_MIS];
-  stats.tris_closest = h[ST_TRIS_CLOSEST]; stats.tris_shadow = h[ST_TRIS_SHADOW]; stats.tris_mis = h[ST_TRIS_MIS];
+  stats.rays_mis_any = h[ST_RAYS_MISANY]; stats.nodes_mis_any = h[ST_NODES_MISANY]; stats.tris_mis_any = h[ST_TRIS_MISANY];
+  stats.rays_closest = h[ST_RAYS_CLOSEST]; stats.rays_shadow = h[ST_RAYS_SHADOW]; stats.rays_mis = h[ST_RAYS_MIS] + h[ST_RAYS_MISANY];
+  stats.nodes_closest = h[ST_NODES_CLOSEST]; stats.nodes_shadow = h[ST_NODES_SHADOW]; stats.nodes_mis = h[ST_NODES_MIS] + h[ST_NODES_MISANY];
+  stats.tris_closest = h[ST_TRIS_CLOSEST]; stats.tris_shadow = h[ST_TRIS_SHADOW]; stats.tris_mis = h[ST_TRIS_MIS] + h[ST_TRIS_MISANY];
+  stats.ms_trace_mis += stats.ms_trace_mis_any;  // ms_trace_mis stays the time of all MIS launches
   stats.paths_scrubbed = h[ST_SCRUBBED];
   for (int k = 0; k < 32; ++k) stats.shade_section_cycles[k] = h[ST_STAMP + k];
   stats.vertices_lambert_const = h[ST_SHADED]; stats.vertices_lambert = h[ST_SHADED + 1]; stats.vertices_two_lobe = h[ST_SHADED + 2]; stats.vertices_generic = h[ST_SHADED + 3];
@@ -1242,9 +1311,24 @@ __global__ void k_film_add(float4* __restrict__ dst, const float4* __restrict__ 
   const float4 a = dst[i], b = src[i];
   dst[i] = make_float4(a.x + b.x, a.y + b.y, a.z + b.z, a.w + b.w);
 }
+// every counter and every timer of b added into a
+static void stats_add(rt_stats& a, const rt_stats& b) {
+  a.camera_rays += b.camera_rays; a.rays_closest += b.rays_closest; a.rays_shadow += b.rays_shadow; a.rays_mis += b.rays_mis;
+  a.nodes_closest += b.nodes_closest; a.nodes_shadow += b.nodes_shadow; a.nodes_mis += b.nodes_mis;
+  a.tris_closest += b.tris_closest; a.tris_shadow += b.tris_shadow; a.tris_mis += b.tris_mis; a.paths_scrubbed += b.paths_scrubbed;
+  a.ms_total += b.ms_total; a.ms_sampler += b.ms_sampler; a.ms_raygen += b.ms_raygen; a.ms_trace_closest += b.ms_trace_closest; a.ms_trace_any += b.ms_trace_any;
+  a.ms_trace_mis += b.ms_trace_mis; a.ms_shade += b.ms_shade; a.ms_resolve += b.ms_resolve; a.ms_film += b.ms_film; a.ms_lightdist += b.ms_lightdist;
+  a.launches_trace_closest += b.launches_trace_closest; a.n_passes += b.n_passes;
+  a.vertices_lambert_const += b.vertices_lambert_const; a.vertices_lambert += b.vertices_lambert; a.vertices_two_lobe += b.vertices_two_lobe; a.vertices_generic += b.vertices_generic;
+  a.ms_shade_lambert_const += b.ms_shade_lambert_const; a.ms_shade_lambert += b.ms_shade_lambert; a.ms_shade_two_lobe += b.ms_shade_two_lobe;
+  a.ms_shade_generic += b.ms_shade_generic; a.ms_shade_bin += b.ms_shade_bin; a.ms_shade_miss += b.ms_shade_miss;
+  for (int k = 0; k < 32; ++k) a.shade_section_cycles[k] += b.shade_section_cycles[k];
+  a.rays_mis_any += b.rays_mis_any; a.nodes_mis_any += b.nodes_mis_any; a.tris_mis_any += b.tris_mis_any; a.ms_trace_mis_any += b.ms_trace_mis_any;
+}
 struct rt_multi {
   std::vector<int> devices; std::vector<rt_scene*> replicas; std::vector<hipStream_t> streams; std::vector<DevBuf*> chunk_film;
   DevBuf acc; std::vector<DevBuf*> staging;  // on devices[0]: the frame, and one buffer of rows per chunk
+  std::string warnings;  // conditions that do not fail a call but are worth a line (left in rt_last_error by rt_multi_create)
   ~rt_multi() {
     for (size_t i = 0; i < replicas.size(); ++i) {
       (void)hipSetDevice(devices[i]);
@@ -1271,9 +1355,13 @@ extern "C" int rt_multi_create(const rt_scene_desc* desc, const int32_t* devices
     if (hipStreamCreateWithFlags(&m->streams[i], hipStreamNonBlocking) != hipSuccess) { delete m; return fail(RT_ERR_HIP, "stream creation failed"); }
     if (devices[i] != devices[0]) {  // let the workers write into the first device's memory directly where the fabric allows it (else the copy is staged by the runtime)
       int can = 0; (void)hipDeviceCanAccessPeer(&can, devices[i], devices[0]);
-      if (can) { hipError_t e = hipDeviceEnablePeerAccess(devices[0], 0); if (e != hipSuccess) (void)hipGetLastError(); }
+      hipError_t e = can ? hipDeviceEnablePeerAccess(devices[0], 0) : hipErrorPeerAccessUnsupported;
+      if (e != hipSuccess) (void)hipGetLastError();
+      if (e != hipSuccess && e != hipErrorPeerAccessAlreadyEnabled)  // not fatal - hipMemcpyPeerAsync then stages through the host - but slow: say so (rt_last_error after a successful create)
+        m->warnings += "device " + std::to_string(devices[i]) + " cannot write into device " + std::to_string(devices[0]) + " directly (" + hipGetErrorString(e) + "): film rows are staged by the runtime; ";
     }
   }
+  g_err = m->warnings;
   *out = m;
   return RT_OK;
 }
@@ -1332,20 +1420,14 @@ extern "C" int rt_multi_render(rt_multi* m, const rt_camera* cam, const rt_film_
         off += bytes;
       }
       if (hipStreamSynchronize(m->streams[k]) != hipSuccess) { bail(RT_ERR_HIP, "peer copy failed"); break; }
-      rt_stats& a = dev_stats[k];
-      a.camera_rays += st.camera_rays; a.rays_closest += st.rays_closest; a.rays_shadow += st.rays_shadow; a.rays_mis += st.rays_mis;
-      a.nodes_closest += st.nodes_closest; a.nodes_shadow += st.nodes_shadow; a.nodes_mis += st.nodes_mis;
-      a.tris_closest += st.tris_closest; a.tris_shadow += st.tris_shadow; a.tris_mis += st.tris_mis; a.paths_scrubbed += st.paths_scrubbed;
-      a.ms_total += st.ms_total; a.ms_sampler += st.ms_sampler; a.ms_raygen += st.ms_raygen; a.ms_trace_closest += st.ms_trace_closest; a.ms_trace_any += st.ms_trace_any;
-      a.ms_trace_mis += st.ms_trace_mis; a.ms_shade += st.ms_shade; a.ms_resolve += st.ms_resolve; a.ms_film += st.ms_film; a.ms_lightdist += st.ms_lightdist;
-      a.launches_trace_closest += st.launches_trace_closest; a.n_passes += st.n_passes;
-      a.vertices_lambert_const += st.vertices_lambert_const; a.vertices_lambert += st.vertices_lambert; a.vertices_two_lobe += st.vertices_two_lobe; a.vertices_generic += st.vertices_generic;
+      stats_add(dev_stats[k], st);
     }
   };
   std::vector<std::thread> threads;
   for (int k = 0; k < n_dev; ++k) threads.emplace_back(worker, k);
   for (auto& t : threads) t.join();
   if (first_rc != RT_OK) return fail(first_rc, first_err);
+  const auto t_gather = std::chrono::steady_clock::now();
   // Film::merge_film_tile on the first device: every chunk's rows are added into the frame, in chunk order (a pixel two chunks touched - a filter
   // wider than a pixel, or a sample exactly on an edge - then sums in a fixed order)
   HIP_TRY(hipSetDevice(m->devices[0]));
@@ -1362,13 +1444,9 @@ extern "C" int rt_multi_render(rt_multi* m, const rt_camera* cam, const rt_film_
   if (per_device) for (int k = 0; k < n_dev; ++k) per_device[k] = dev_stats[k];
   if (total) {
     rt_stats t{};
-    for (const rt_stats& a : dev_stats) {
-      t.camera_rays += a.camera_rays; t.rays_closest += a.rays_closest; t.rays_shadow += a.rays_shadow; t.rays_mis += a.rays_mis;
-      t.nodes_closest += a.nodes_closest; t.nodes_shadow += a.nodes_shadow; t.nodes_mis += a.nodes_mis; t.tris_closest += a.tris_closest; t.tris_shadow += a.tris_shadow; t.tris_mis += a.tris_mis;
-      t.paths_scrubbed += a.paths_scrubbed; t.launches_trace_closest += a.launches_trace_closest; t.n_passes += a.n_passes;
-      t.vertices_lambert_const += a.vertices_lambert_const; t.vertices_lambert += a.vertices_lambert; t.vertices_two_lobe += a.vertices_two_lobe; t.vertices_generic += a.vertices_generic;
-    }
+    for (const rt_stats& a : dev_stats) stats_add(t, a);  // times are summed over devices (device-milliseconds), ms_total below is the call's wall time
     t.ms_total = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_begin).count();
+    t.ms_gather = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_gather).count();
     *total = t;
   }
   return RT_OK;

@@ -327,9 +327,10 @@ bool hdr_decode(const std::vector<uint8_t>& file, int& W, int& H, std::vector<fl
 // read_image_exr (rc/imageio.rs:134-160) calls exr 1.4.2's read_first_rgba_layer_from_file: the first layer that has R, G and B
 // channels, samples converted to f32, stored at their position inside the layer. Restated from the OpenEXR file layout
 // specification: magic + version, attribute list (channels, compression, dataWindow, displayWindow, lineOrder), offset table,
-// scan-line blocks of 1 (NONE, RLE, ZIPS) or 16 (ZIP) lines holding each line's channels in alphabetical order. ZIP / ZIPS / RLE
-// payloads are byte-delta coded and split into even / odd halves before compression. PIZ, PXR24, B44, DWA and tiled or multi-part
-// files are refused with a message. The reference takes the resolution from displayWindow and the pixels from the layer
+// scan-line blocks of 1 (NONE, RLE, ZIPS), 16 (ZIP, PXR24) or 32 (PIZ) lines - or tiles - holding each line's channels in alphabetical order. ZIP / ZIPS / RLE
+// payloads are byte-delta coded and split into even / odd halves before compression; PIZ and PXR24 are described at their decoders. Tiled files give their
+// full-resolution level (what exr 1.4.2 calls the largest resolution level), multi-part files their first flat part with R, G and B. The lossy B44 / B44A and
+// DWAA / DWAB compressions and deep data are refused with a message. The reference takes the resolution from displayWindow and the pixels from the layer
 // (imageio.rs:153-159), which only agree when the two windows do: files where they differ are refused.
 namespace {
 
@@ -353,6 +354,167 @@ bool exr_unpredict(std::vector<uint8_t>& raw, size_t want, std::string& err) {  
   return true;
 }
 
+// ---- PIZ (compression 4): per block a bitmap of the 16-bit values in use (-> a lookup table that packs them), a Haar-like 2-D wavelet transform of each
+// channel's 16-bit planes, and a canonical Huffman code over the result with a run-length symbol. Restated from the format's published description
+// (OpenEXR "ImfPizCompressor / ImfHuf / ImfWav": technical introduction + file layout documents).
+struct ExrBits {  // MSB-first bit reader over [p, end)
+  const uint8_t* p; const uint8_t* end; uint64_t c = 0; int lc = 0; bool ok = true;
+  uint32_t get(int n) {
+    while (lc < n) { if (p >= end) { ok = false; return 0; } c = (c << 8) | *p++; lc += 8; }
+    lc -= n; return (uint32_t)((c >> lc) & ((1ull << n) - 1ull));
+  }
+};
+bool piz_huf_uncompress(const uint8_t* src, size_t n_src, std::vector<uint16_t>& out, size_t n_out, std::string& err) {
+  out.assign(n_out, 0);
+  if (n_src == 0) { if (n_out) { err = "EXR: empty PIZ Huffman block"; return false; } return true; }
+  if (n_src < 20) { err = "EXR: truncated PIZ Huffman header"; return false; }
+  auto u32 = [&](size_t o) { return (uint32_t)src[o] | (uint32_t)src[o + 1] << 8 | (uint32_t)src[o + 2] << 16 | (uint32_t)src[o + 3] << 24; };
+  const uint32_t im = u32(0), iM = u32(4), n_bits = u32(12);
+  constexpr uint32_t ENC = 65537;  // 2^16 values + the run-length symbol
+  if (im >= ENC || iM >= ENC || im > iM) { err = "EXR: bad PIZ Huffman table range"; return false; }
+  // packed code lengths: 6 bits each; 59..62 = a run of 2..5 zero lengths, 63 = a run of 6 + (8 more bits) zeros
+  std::vector<uint8_t> len(ENC, 0);
+  ExrBits tb{src + 20, src + n_src};
+  for (uint32_t i = im; i <= iM; ++i) {
+    const uint32_t l = tb.get(6);
+    if (!tb.ok) { err = "EXR: truncated PIZ Huffman table"; return false; }
+    if (l == 63u || l >= 59u) {
+      uint32_t run = l == 63u ? tb.get(8) + 6u : l - 59u + 2u;
+      if (!tb.ok || i + run > iM + 1u) { err = "EXR: bad zero run in PIZ Huffman table"; return false; }
+      i += run - 1u;  // (the lengths stay 0)
+    } else len[i] = (uint8_t)l;
+  }
+  // canonical codes: within a length consecutive in symbol order, the longest lengths take the smallest code values
+  uint64_t count[59] = {0}, first[59] = {0};
+  for (uint32_t i = 0; i < ENC; ++i) count[len[i]] += 1;
+  { uint64_t c = 0; for (int l = 58; l > 0; --l) { const uint64_t nc = (c + count[l]) >> 1; first[l] = c; c = nc; } }
+  std::vector<uint32_t> sorted; sorted.reserve(ENC); size_t base[59] = {0};
+  for (int l = 1; l < 59; ++l) { base[l] = sorted.size(); for (uint32_t i = 0; i < ENC; ++i) if (len[i] == l) sorted.push_back(i); }
+  // the code data starts at the next byte after the table
+  const uint8_t* data = tb.p;
+  if ((uint64_t)(src + n_src - data) * 8ull < n_bits) { err = "EXR: truncated PIZ Huffman data"; return false; }
+  ExrBits db{data, src + n_src};
+  uint64_t used = 0; size_t o = 0;
+  while (used < n_bits && o < n_out) {
+    uint64_t v = 0; int l = 0; uint32_t sym = 0; bool hit = false;
+    while (l < 58 && used < n_bits) {
+      v = (v << 1) | db.get(1); ++l; ++used;
+      if (count[l] && v >= first[l] && v - first[l] < count[l]) { sym = sorted[base[l] + (size_t)(v - first[l])]; hit = true; break; }
+    }
+    if (!hit || !db.ok) { err = "EXR: bad PIZ Huffman code"; return false; }
+    if (sym == iM) {  // run-length symbol: repeat the previous value
+      if (used + 8 > n_bits || o == 0) { err = "EXR: bad PIZ run"; return false; }
+      const uint32_t run = db.get(8); used += 8;
+      if (o + run > n_out) { err = "EXR: PIZ run past the end of the block"; return false; }
+      const uint16_t prev = out[o - 1];
+      for (uint32_t k = 0; k < run; ++k) out[o++] = prev;
+    } else out[o++] = (uint16_t)sym;
+  }
+  if (o != n_out) { err = "EXR: PIZ block decodes to the wrong size"; return false; }
+  return true;
+}
+inline void piz_wdec14(uint16_t l, uint16_t h, uint16_t& a, uint16_t& b) {
+  const int ls = (int16_t)l, hs = (int16_t)h;
+  const int ai = ls + (hs & 1) + (hs >> 1);
+  a = (uint16_t)(int16_t)ai; b = (uint16_t)(int16_t)(ai - hs);
+}
+inline void piz_wdec16(uint16_t l, uint16_t h, uint16_t& a, uint16_t& b) {
+  const int m = l, d = h;
+  const int bb = (m - (d >> 1)) & 0xffff;
+  const int aa = (d + bb - 0x8000) & 0xffff;
+  b = (uint16_t)bb; a = (uint16_t)aa;
+}
+void piz_wav_decode(uint16_t* in, int nx, int ox, int ny, int oy, uint16_t mx) {
+  const bool w14 = mx < (1u << 14);
+  const int n = nx > ny ? ny : nx;
+  int p = 1; while (p <= n) p <<= 1;
+  p >>= 1; int p2 = p; p >>= 1;
+  auto dec = [&](uint16_t l, uint16_t h, uint16_t& a, uint16_t& b) { if (w14) piz_wdec14(l, h, a, b); else piz_wdec16(l, h, a, b); };
+  while (p >= 1) {
+    uint16_t* py = in; uint16_t* const ey = in + (ptrdiff_t)oy * (ny - p2);
+    const ptrdiff_t oy1 = (ptrdiff_t)oy * p, oy2 = (ptrdiff_t)oy * p2, ox1 = (ptrdiff_t)ox * p, ox2 = (ptrdiff_t)ox * p2;
+    for (; py <= ey; py += oy2) {
+      uint16_t* px = py; uint16_t* const ex = py + (ptrdiff_t)ox * (nx - p2);
+      for (; px <= ex; px += ox2) {
+        uint16_t* p01 = px + ox1; uint16_t* p10 = px + oy1; uint16_t* p11 = p10 + ox1;
+        uint16_t i00, i01, i10, i11;
+        dec(*px, *p10, i00, i10); dec(*p01, *p11, i01, i11);
+        dec(i00, i01, *px, *p01); dec(i10, i11, *p10, *p11);
+      }
+      if (nx & p) { uint16_t* p10 = px + oy1; uint16_t i00; dec(*px, *p10, i00, *p10); *px = i00; }
+    }
+    if (ny & p) {
+      uint16_t* px = py; uint16_t* const ex = py + (ptrdiff_t)ox * (nx - p2);
+      for (; px <= ex; px += ox2) { uint16_t* p01 = px + ox1; uint16_t i00; dec(*px, *p01, i00, *p01); *px = i00; }
+    }
+    p2 = p; p >>= 1;
+  }
+}
+struct ExrChan { std::string name; int type, xs, ys; };
+// one block (rows x w pixels, every channel) of PIZ data -> the uncompressed block layout (per row, per channel, little-endian samples)
+bool piz_uncompress(const uint8_t* src, size_t size, const std::vector<ExrChan>& chans, size_t w, size_t rows, std::vector<uint8_t>& raw, std::string& err) {
+  if (size < 4) { err = "EXR: truncated PIZ block"; return false; }
+  const unsigned min_nz = src[0] | src[1] << 8, max_nz = src[2] | src[3] << 8;
+  size_t pos = 4;
+  std::vector<uint8_t> bitmap(8192, 0);
+  if (min_nz <= max_nz) {
+    if (max_nz >= 8192 || pos + (max_nz - min_nz + 1) > size) { err = "EXR: bad PIZ bitmap"; return false; }
+    memcpy(bitmap.data() + min_nz, src + pos, max_nz - min_nz + 1); pos += max_nz - min_nz + 1;
+  }
+  std::vector<uint16_t> lut(65536, 0); unsigned k = 0;
+  for (unsigned i = 0; i < 65536; ++i) if (i == 0 || (bitmap[i >> 3] & (1u << (i & 7)))) lut[k++] = (uint16_t)i;
+  const uint16_t max_value = (uint16_t)(k - 1);
+  if (pos + 4 > size) { err = "EXR: truncated PIZ block"; return false; }
+  const uint32_t hlen = (uint32_t)src[pos] | (uint32_t)src[pos + 1] << 8 | (uint32_t)src[pos + 2] << 16 | (uint32_t)src[pos + 3] << 24; pos += 4;
+  if (hlen > size - pos) { err = "EXR: PIZ Huffman data longer than the block"; return false; }
+  size_t total = 0; std::vector<size_t> start(chans.size());
+  for (size_t c = 0; c < chans.size(); ++c) { start[c] = total; total += w * rows * (chans[c].type == 1 ? 1 : 2); }
+  std::vector<uint16_t> tmp;
+  if (!piz_huf_uncompress(src + pos, hlen, tmp, total, err)) return false;
+  for (size_t c = 0; c < chans.size(); ++c) {
+    const int sz = chans[c].type == 1 ? 1 : 2;
+    for (int j = 0; j < sz; ++j) piz_wav_decode(tmp.data() + start[c] + j, (int)w, sz, (int)rows, (int)w * sz, max_value);
+  }
+  for (uint16_t& v : tmp) v = lut[v];
+  raw.clear(); raw.reserve(total * 2);
+  std::vector<size_t> cur = start;
+  for (size_t r = 0; r < rows; ++r)
+    for (size_t c = 0; c < chans.size(); ++c) {
+      const size_t n = w * (chans[c].type == 1 ? 1 : 2);
+      for (size_t i = 0; i < n; ++i) { const uint16_t v = tmp[cur[c] + i]; raw.push_back((uint8_t)(v & 0xff)); raw.push_back((uint8_t)(v >> 8)); }
+      cur[c] += n;
+    }
+  return true;
+}
+// PXR24 (compression 5): zlib over, per row and channel, the byte planes (most significant first) of the differences between neighbouring samples;
+// 32-bit floats keep their upper 24 bits
+bool pxr24_uncompress(const uint8_t* src, size_t size, const std::vector<ExrChan>& chans, size_t w, size_t rows, std::vector<uint8_t>& raw, std::string& err) {
+  std::vector<uint8_t> z;
+  if (!zlib_inflate(src, size, z, err)) return false;
+  size_t want = 0; for (const ExrChan& c : chans) want += w * rows * (c.type == 1 ? 2 : (c.type == 2 ? 3 : 4));
+  if (z.size() != want) { err = "EXR: PXR24 block decompressed to the wrong size"; return false; }
+  raw.clear(); size_t p = 0;
+  for (size_t r = 0; r < rows; ++r)
+    for (const ExrChan& c : chans) {
+      const int planes = c.type == 1 ? 2 : (c.type == 2 ? 3 : 4);
+      uint32_t pixel = 0;
+      for (size_t x = 0; x < w; ++x) {
+        uint32_t diff = 0;
+        for (int k = 0; k < planes; ++k) diff = (diff << 8) | z[p + (size_t)k * w + x];
+        if (c.type == 2) diff <<= 8;
+        pixel += diff;
+        if (c.type == 1) { raw.push_back((uint8_t)(pixel & 0xff)); raw.push_back((uint8_t)((pixel >> 8) & 0xff)); }
+        else { raw.push_back((uint8_t)(pixel & 0xff)); raw.push_back((uint8_t)((pixel >> 8) & 0xff)); raw.push_back((uint8_t)((pixel >> 16) & 0xff)); raw.push_back((uint8_t)(pixel >> 24)); }
+      }
+      p += (size_t)planes * w;
+    }
+  return true;
+}
+
+struct ExrPart {
+  std::vector<ExrChan> chans; int compression = -1, line_order = 0; int32_t dw[4] = {0, 0, -1, -1}, disp[4] = {0, 0, -1, -1}; bool have_dw = false, have_disp = false;
+  bool tiled = false, deep = false; uint32_t tile_w = 0, tile_h = 0; int level_mode = 0, rounding = 0; long long chunk_count = -1; std::string type;
+};
 bool exr_decode(const std::vector<uint8_t>& file, int& W, int& H, std::vector<float>& rgb, std::string& err) {
   Bytes b{file.data(), file.size()};
   auto le32 = [&]() -> uint32_t { uint32_t v = (uint32_t)b.p[b.pos] | (uint32_t)b.p[b.pos + 1] << 8 | (uint32_t)b.p[b.pos + 2] << 16 | (uint32_t)b.p[b.pos + 3] << 24; b.pos += 4; return v; };
@@ -360,70 +522,126 @@ bool exr_decode(const std::vector<uint8_t>& file, int& W, int& H, std::vector<fl
   if (!b.need(8) || le32() != 20000630u) { err = "EXR: bad magic number"; return false; }
   const uint32_t version = le32();
   if ((version & 0xff) != 2) { err = "EXR: unsupported file version"; return false; }
-  if (version & 0x200) { err = "EXR: tiled images are not supported"; return false; }
-  if (version & 0x1800) { err = "EXR: deep / multi-part images are not supported"; return false; }
-  struct Chan { std::string name; int type, xs, ys; };
-  std::vector<Chan> chans; int compression = -1, line_order = 0; int32_t dw[4] = {0, 0, -1, -1}, disp[4] = {0, 0, -1, -1}; bool have_dw = false, have_disp = false;
+  const bool multipart = (version & 0x1000) != 0;
+  if (version & 0x800) { err = "EXR: deep images are not supported"; return false; }
+  // headers: one, or (multi-part) several, each ended by an empty attribute name, the list by an empty header
+  std::vector<ExrPart> parts;
   for (;;) {
-    std::string name, type;
-    if (!cstr(name)) { err = "EXR: truncated header"; return false; }
-    if (name.empty()) break;
-    if (!cstr(type) || !b.need(4)) { err = "EXR: truncated header"; return false; }
-    const uint32_t size = le32();
-    if (!b.need(size)) { err = "EXR: truncated attribute"; return false; }
-    const size_t end = b.pos + size;
-    if (name == "channels") {
-      while (b.pos < end && b.p[b.pos]) {
-        Chan c; if (!cstr(c.name) || b.pos + 16 > end) { err = "EXR: bad channel list"; return false; }
-        c.type = (int)le32(); b.pos += 4; c.xs = (int)le32(); c.ys = (int)le32();
-        if (c.type < 0 || c.type > 2) { err = "EXR: unknown pixel type"; return false; }
-        if (c.xs != 1 || c.ys != 1) { err = "EXR: sub-sampled channels are not supported"; return false; }
-        chans.push_back(c);
-      }
-    } else if (name == "compression" && size >= 1) compression = b.p[b.pos];
-    else if (name == "lineOrder" && size >= 1) line_order = b.p[b.pos];
-    else if ((name == "dataWindow" || name == "displayWindow") && size == 16) {
-      int32_t* w = name == "dataWindow" ? dw : disp; (name == "dataWindow" ? have_dw : have_disp) = true;
-      for (int k = 0; k < 4; ++k) { uint32_t v = le32(); memcpy(&w[k], &v, 4); }
+    ExrPart pt; pt.tiled = !multipart && (version & 0x200) != 0;
+    bool any = false;
+    for (;;) {
+      std::string name, type;
+      if (!cstr(name)) { err = "EXR: truncated header"; return false; }
+      if (name.empty()) break;
+      any = true;
+      if (!cstr(type) || !b.need(4)) { err = "EXR: truncated header"; return false; }
+      const uint32_t size = le32();
+      if (!b.need(size)) { err = "EXR: truncated attribute"; return false; }
+      const size_t end = b.pos + size;
+      if (name == "channels") {
+        while (b.pos < end && b.p[b.pos]) {
+          ExrChan c; if (!cstr(c.name) || b.pos + 16 > end) { err = "EXR: bad channel list"; return false; }
+          c.type = (int)le32(); b.pos += 4; c.xs = (int)le32(); c.ys = (int)le32();
+          if (c.type < 0 || c.type > 2) { err = "EXR: unknown pixel type"; return false; }
+          if (c.xs != 1 || c.ys != 1) { err = "EXR: sub-sampled channels are not supported"; return false; }
+          pt.chans.push_back(c);
+        }
+      } else if (name == "compression" && size >= 1) pt.compression = b.p[b.pos];
+      else if (name == "lineOrder" && size >= 1) pt.line_order = b.p[b.pos];
+      else if ((name == "dataWindow" || name == "displayWindow") && size == 16) {
+        int32_t* w = name == "dataWindow" ? pt.dw : pt.disp; (name == "dataWindow" ? pt.have_dw : pt.have_disp) = true;
+        for (int k = 0; k < 4; ++k) { uint32_t v = le32(); memcpy(&w[k], &v, 4); }
+      } else if (name == "tiles" && size == 9) { pt.tile_w = le32(); pt.tile_h = le32(); pt.level_mode = b.p[b.pos] & 0xf; pt.rounding = b.p[b.pos] >> 4; }
+      else if (name == "type" && type == "string") { pt.type.assign((const char*)b.p + b.pos, size); pt.tiled = pt.type == "tiledimage"; pt.deep = pt.type.compare(0, 4, "deep") == 0; }
+      else if (name == "chunkCount" && size == 4) { pt.chunk_count = (int32_t)le32(); }
+      b.pos = end;
     }
-    b.pos = end;
+    if (!any) { if (!multipart || parts.empty()) { err = "EXR: empty header"; return false; } break; }
+    parts.push_back(pt);
+    if (!multipart) break;
   }
-  if (chans.empty() || compression < 0 || !have_dw || !have_disp) { err = "EXR: missing required attribute"; return false; }
-  if (compression > 3) { err = "EXR: only NONE, RLE, ZIPS and ZIP compression are supported (this file uses PIZ / PXR24 / B44 / DWA)"; return false; }
-  if (line_order > 1) { err = "EXR: unsupported line order"; return false; }
+  // chunks per part: what its offset table holds
+  auto levels = [](long long n, int rounding) { int l = 1; while (n > 1) { n = rounding ? (n + 1) / 2 : n / 2; ++l; } return l; };
+  auto level_size = [](long long n, int l, int rounding) { for (int k = 0; k < l; ++k) n = std::max<long long>(1, rounding ? (n + 1) / 2 : n / 2); return n; };
+  auto lines_of = [](int c) { return c == 3 || c == 5 ? 16 : (c == 4 || c == 6 || c == 7 ? 32 : (c == 8 ? 32 : (c == 9 ? 256 : 1))); };
+  std::vector<long long> n_chunks(parts.size(), 0);
+  for (size_t k = 0; k < parts.size(); ++k) {
+    const ExrPart& pt = parts[k];
+    if (pt.chans.empty() || pt.compression < 0 || !pt.have_dw || !pt.have_disp) { err = "EXR: missing required attribute"; return false; }
+    const long long w = (long long)pt.dw[2] - pt.dw[0] + 1, h = (long long)pt.dw[3] - pt.dw[1] + 1;
+    if (w <= 0 || h <= 0 || w > 65536 || h > 65536 || w * h > (1ll << 28)) { err = "EXR: bad data window"; return false; }
+    if (pt.tiled) {
+      if (pt.tile_w == 0 || pt.tile_h == 0 || pt.tile_w > 65536 || pt.tile_h > 65536) { err = "EXR: bad tile description"; return false; }
+      if (pt.level_mode > 2) { err = "EXR: unknown level mode"; return false; }
+      long long total = 0;
+      const int nlx = pt.level_mode == 0 ? 1 : levels(pt.level_mode == 1 ? std::max(w, h) : w, pt.rounding), nly = pt.level_mode == 2 ? levels(h, pt.rounding) : nlx;
+      if (pt.level_mode == 2) { for (int ly = 0; ly < nly; ++ly) for (int lx = 0; lx < nlx; ++lx) total += ((level_size(w, lx, pt.rounding) + pt.tile_w - 1) / pt.tile_w) * ((level_size(h, ly, pt.rounding) + pt.tile_h - 1) / pt.tile_h); }
+      else for (int l = 0; l < nlx; ++l) total += ((level_size(w, l, pt.rounding) + pt.tile_w - 1) / pt.tile_w) * ((level_size(h, l, pt.rounding) + pt.tile_h - 1) / pt.tile_h);
+      n_chunks[k] = total;
+    } else n_chunks[k] = (h + lines_of(pt.compression) - 1) / lines_of(pt.compression);
+    if (multipart) { if (pt.chunk_count < 0) { err = "EXR: a part of a multi-part file lacks chunkCount"; return false; } n_chunks[k] = pt.chunk_count; }
+  }
+  // the first part (exr 1.4.2 read_first_rgba_layer_from_file: the first flat layer) that has R, G and B channels
+  int ci[3] = {-1, -1, -1}; int part = -1;
+  for (size_t k = 0; k < parts.size() && part < 0; ++k) {
+    if (parts[k].deep) continue;
+    const std::vector<ExrChan>& chans = parts[k].chans; bool found = false;
+    auto triple = [&](const std::string& pre) {
+      int r = -1, g = -1, bl = -1;
+      for (size_t q = 0; q < chans.size(); ++q) { if (chans[q].name == pre + "R") r = (int)q; if (chans[q].name == pre + "G") g = (int)q; if (chans[q].name == pre + "B") bl = (int)q; }
+      if (r >= 0 && g >= 0 && bl >= 0) { ci[0] = r; ci[1] = g; ci[2] = bl; found = true; }
+    };
+    triple("");
+    for (size_t q = 0; q < chans.size() && !found; ++q) {
+      const std::string& nm = chans[q].name;
+      if (nm.size() >= 2 && nm.compare(nm.size() - 2, 2, ".R") == 0) triple(nm.substr(0, nm.size() - 1));
+    }
+    if (found) part = (int)k;
+  }
+  if (part < 0) { err = "EXR: no layer with R, G and B channels"; return false; }
+  const ExrPart& pt = parts[part];
+  const std::vector<ExrChan>& chans = pt.chans; const int compression = pt.compression; const int32_t* dw = pt.dw; const int32_t* disp = pt.disp;
+  if (compression == 6 || compression == 7) { err = "EXR: B44 / B44A compression is not supported"; return false; }
+  if (compression > 5) { err = "EXR: DWAA / DWAB compression is not supported"; return false; }
+  if (pt.line_order > 2) { err = "EXR: unsupported line order"; return false; }
   const long long w = (long long)dw[2] - dw[0] + 1, h = (long long)dw[3] - dw[1] + 1;
-  if (w <= 0 || h <= 0 || w > 65536 || h > 65536 || w * h > (1ll << 28)) { err = "EXR: bad data window"; return false; }
   if (disp[2] - disp[0] != dw[2] - dw[0] || disp[3] - disp[1] != dw[3] - dw[1]) { err = "EXR: data window and display window differ in size"; return false; }
-  int ci[3] = {-1, -1, -1};  // first layer with R, G, B: the unnamed layer's channels, else the first "<layer>.R / .G / .B" triple
-  bool found = false;
-  auto triple = [&](const std::string& pre) {
-    int r = -1, g = -1, bl = -1;
-    for (size_t k = 0; k < chans.size(); ++k) { if (chans[k].name == pre + "R") r = (int)k; if (chans[k].name == pre + "G") g = (int)k; if (chans[k].name == pre + "B") bl = (int)k; }
-    if (r >= 0 && g >= 0 && bl >= 0) { ci[0] = r; ci[1] = g; ci[2] = bl; found = true; }
-  };
-  triple("");
-  for (size_t k = 0; k < chans.size() && !found; ++k) {
-    const std::string& nm = chans[k].name;
-    if (nm.size() >= 2 && nm.compare(nm.size() - 2, 2, ".R") == 0) triple(nm.substr(0, nm.size() - 1));
+  // offset tables: one per part, in header order
+  size_t table = b.pos, all = 0;
+  for (size_t k = 0; k < parts.size(); ++k) {
+    if (n_chunks[k] < 0 || (unsigned long long)n_chunks[k] > file.size() / 8) { err = "EXR: truncated offset table"; return false; }
+    all += (size_t)n_chunks[k] * 8;
+    if ((int)k < part) table += (size_t)n_chunks[k] * 8;
   }
-  if (!found) { err = "EXR: no layer with R, G and B channels"; return false; }
-  std::vector<size_t> chan_off(chans.size()); size_t line_bytes = 0;
-  for (size_t k = 0; k < chans.size(); ++k) { chan_off[k] = line_bytes; line_bytes += (size_t)w * (chans[k].type == 1 ? 2 : 4); }
-  const int lines_per_block = compression == 3 ? 16 : 1;
-  const size_t n_blocks = ((size_t)h + lines_per_block - 1) / lines_per_block;
-  if (!b.need(n_blocks * 8)) { err = "EXR: truncated offset table"; return false; }
-  const size_t table = b.pos;
+  if (b.pos + all > file.size()) { err = "EXR: truncated offset table"; return false; }
   W = (int)w; H = (int)h; rgb.assign((size_t)w * h * 3, 0.0f);
+  // chunks that hold full-resolution pixels: every scan-line block, or the tiles of level (0, 0) - which the offset table lists first
+  const long long tiles_x = pt.tiled ? (w + pt.tile_w - 1) / pt.tile_w : 1, tiles_y = pt.tiled ? (h + pt.tile_h - 1) / pt.tile_h : 0;
+  const size_t n_read = pt.tiled ? (size_t)(tiles_x * tiles_y) : (size_t)n_chunks[part];
+  const int lines_per_block = lines_of(compression);
   std::vector<uint8_t> raw;
-  for (size_t blk = 0; blk < n_blocks; ++blk) {
+  for (size_t blk = 0; blk < n_read; ++blk) {
     uint64_t off = 0; for (int k = 7; k >= 0; --k) off = off << 8 | file[table + blk * 8 + k];
-    if (file.size() < 8 || off > file.size() - 8) { err = "EXR: block offset outside the file"; return false; }  // (off + 8 would wrap for offsets near 2^64)
+    const size_t head = (multipart ? 4u : 0u) + (pt.tiled ? 20u : 8u);
+    if (file.size() < head || off > file.size() - head) { err = "EXR: block offset outside the file"; return false; }  // (off + head would wrap for offsets near 2^64)
     b.pos = (size_t)off;
-    int32_t y0; { uint32_t v = le32(); memcpy(&y0, &v, 4); }
+    if (multipart) { const uint32_t pn = le32(); if ((int)pn != part) { err = "EXR: chunk of another part in this part's offset table"; return false; } }
+    long long x0 = 0, y0, cols = w, rows;
+    if (pt.tiled) {
+      const uint32_t tx = le32(), ty = le32(), lx = le32(), ly = le32();
+      if (lx != 0 || ly != 0 || (long long)tx >= tiles_x || (long long)ty >= tiles_y) { err = "EXR: unexpected tile in the full-resolution level"; return false; }
+      x0 = (long long)tx * pt.tile_w; y0 = (long long)ty * pt.tile_h;
+      cols = std::min<long long>(pt.tile_w, w - x0); rows = std::min<long long>(pt.tile_h, h - y0);
+    } else {
+      int32_t yy; { uint32_t v = le32(); memcpy(&yy, &v, 4); }
+      if (yy < dw[1] || yy > dw[3]) { err = "EXR: block outside the data window"; return false; }
+      y0 = (long long)yy - dw[1]; rows = std::min<long long>(lines_per_block, h - y0);
+    }
     const uint32_t size = le32();
     if (!b.need(size)) { err = "EXR: truncated block"; return false; }
-    if (y0 < dw[1] || y0 > dw[3]) { err = "EXR: block outside the data window"; return false; }
-    const size_t rows = std::min<long long>(lines_per_block, (long long)dw[3] - y0 + 1), want = rows * line_bytes;
+    std::vector<size_t> chan_off(chans.size()); size_t line_bytes = 0;
+    for (size_t k = 0; k < chans.size(); ++k) { chan_off[k] = line_bytes; line_bytes += (size_t)cols * (chans[k].type == 1 ? 2 : 4); }
+    const size_t want = (size_t)rows * line_bytes;
     const uint8_t* src = b.p + b.pos;
     if (size == want) raw.assign(src, src + size);   // stored uncompressed (always for NONE; for the others when compression did not help)
     else if (compression == 2 || compression == 3) { raw.clear(); if (!zlib_inflate(src, size, raw, err) || !exr_unpredict(raw, want, err)) return false; }
@@ -435,17 +653,20 @@ bool exr_decode(const std::vector<uint8_t>& file, int& W, int& H, std::vector<fl
         else { if (i >= size) { err = "EXR: bad RLE run"; return false; } raw.insert(raw.end(), (size_t)c + 1, src[i]); ++i; }
       }
       if (!exr_unpredict(raw, want, err)) return false;
-    } else { err = "EXR: compressed block in an uncompressed file"; return false; }
-    for (size_t r = 0; r < rows; ++r) {
-      const size_t y = (size_t)(y0 - dw[1]) + r;
+    } else if (compression == 4) { if (!piz_uncompress(src, size, chans, (size_t)cols, (size_t)rows, raw, err)) return false; }
+    else if (compression == 5) { if (!pxr24_uncompress(src, size, chans, (size_t)cols, (size_t)rows, raw, err)) return false; }
+    else { err = "EXR: compressed block in an uncompressed file"; return false; }
+    if (raw.size() != want) { err = "EXR: block decompressed to the wrong size"; return false; }
+    for (size_t r = 0; r < (size_t)rows; ++r) {
+      const size_t y = (size_t)y0 + r;
       for (int c = 0; c < 3; ++c) {
-        const Chan& ch = chans[ci[c]]; const uint8_t* q = raw.data() + r * line_bytes + chan_off[ci[c]];
-        for (size_t x = 0; x < (size_t)w; ++x) {
+        const ExrChan& ch = chans[ci[c]]; const uint8_t* q = raw.data() + r * line_bytes + chan_off[ci[c]];
+        for (size_t x = 0; x < (size_t)cols; ++x) {
           float v;
           if (ch.type == 1) v = half_to_float((uint16_t)(q[2 * x] | q[2 * x + 1] << 8));
           else if (ch.type == 2) memcpy(&v, q + 4 * x, 4);
           else { uint32_t u; memcpy(&u, q + 4 * x, 4); v = (float)u; }
-          rgb[(y * (size_t)w + x) * 3 + c] = v;
+          rgb[(y * (size_t)w + (size_t)x0 + x) * 3 + c] = v;
         }
       }
     }
@@ -482,7 +703,7 @@ static int image_read_unguarded(const char* path, int32_t* width, int32_t* heigh
     f.resize(px.size());
     for (size_t i = 0; i < px.size(); ++i) f[i] = (float)px[i] / 255.0f;  // imageio.rs:104-106
   } else if (exr) {
-    if (!exr_decode(file, w, h, f, err)) return fail(err.find("not supported") != std::string::npos || err.find("only NONE") != std::string::npos ? RT_ERR_UNSUPPORTED : RT_ERR_INVALID, err + " (" + p + ")");
+    if (!exr_decode(file, w, h, f, err)) return fail(err.find("not supported") != std::string::npos ? RT_ERR_UNSUPPORTED : RT_ERR_INVALID, err + " (" + p + ")");
   } else if (!hdr_decode(file, w, h, f, err)) return fail(RT_ERR_INVALID, err + " (" + p + ")");
   float* out = (float*)malloc(f.size() * sizeof(float));
   if (!out) return fail(RT_ERR_INVALID, "out of memory");

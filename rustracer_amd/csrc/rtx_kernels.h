@@ -70,6 +70,7 @@ struct PassState {
 #define RT_NQ 4  // queues a bounce fills
 enum { ST_CAMERA = 0, ST_RAYS_CLOSEST, ST_RAYS_SHADOW, ST_RAYS_MIS, ST_NODES_CLOSEST, ST_NODES_SHADOW, ST_NODES_MIS,
        ST_TRIS_CLOSEST, ST_TRIS_SHADOW, ST_TRIS_MIS, ST_SCRUBBED, ST_UNBUILT_VOXEL,
+       ST_RAYS_MISANY, ST_NODES_MISANY, ST_TRIS_MISANY,  // the occlusion-only MIS rays (also counted in the _MIS entries)
        ST_SHADED,  // + {0: k_shade<1>, 1: k_shade<3>, 2: k_shade<5>, 3: k_shade<0>}: path vertices shaded by each front-end (misses included)
        ST_STAMP = ST_SHADED + 4,  // + 8 * front-end + section: wave cycles of the sections of k_shade (measurement builds only, make ABLATE=1)
        ST_COUNT = ST_STAMP + 32 };
@@ -111,13 +112,20 @@ RT_DEV unsigned wave_push(unsigned* counter, bool pred) {
 }
 
 #define RT_QSHARDS 8
+// Words between two counters that receive atomics (the shard counters of a queue, the bin cursors of the counting sort). Packed (1), the 24 - 32 shard counters
+// a bounce adds to sit in ONE 128-byte line, and atomics on one line are serviced one after the other whichever word they name: every workgroup of a shade
+// launch waits on that line three times per iteration (measured: 64-lane workgroups, four times the atomics, made S1's shade launch 1.9x slower). 64 words =
+// 256 bytes puts every counter on a line - and a memory channel - of its own.
+#ifndef RT_CNT_STRIDE
+#define RT_CNT_STRIDE 64
+#endif
 // Consumer view of a sharded queue: entry i of the concatenation of the shards' filled prefixes.
 struct QView {
   const unsigned* ids; unsigned pre[RT_QSHARDS + 1]; unsigned shard_cap;
   RT_DEV void init(const unsigned* ids_, const unsigned* counts, unsigned cap) {
     ids = ids_; shard_cap = cap; pre[0] = 0;
 #pragma unroll
-    for (int k = 0; k < RT_QSHARDS; ++k) pre[k + 1] = pre[k] + counts[k];
+    for (int k = 0; k < RT_QSHARDS; ++k) pre[k + 1] = pre[k] + counts[k * RT_CNT_STRIDE];
   }
   RT_DEV unsigned total() const { return pre[RT_QSHARDS]; }
   RT_DEV unsigned get(unsigned i) const {
@@ -146,7 +154,7 @@ RT_DEV void block_push(unsigned* counters, unsigned shard_cap, const int* queue_
   if (threadIdx.x < NQ) {
     unsigned total = 0;
     for (unsigned w = 0; w < n_waves; ++w) { unsigned c = s_cnt[threadIdx.x][w]; s_cnt[threadIdx.x][w] = total; total += c; }
-    s_base[threadIdx.x] = shard * shard_cap + (total ? atomicAdd(&counters[queue_idx[threadIdx.x] * RT_QSHARDS + shard], total) : 0u);
+    s_base[threadIdx.x] = shard * shard_cap + (total ? atomicAdd(&counters[(queue_idx[threadIdx.x] * RT_QSHARDS + shard) * RT_CNT_STRIDE], total) : 0u);
   }
   __syncthreads();
 #pragma unroll
@@ -517,6 +525,10 @@ struct LdsSrc {
     float4 a = tris[3 * i], b = tris[3 * i + 1], c = tris[3 * i + 2];
     p0 = mk3(a.x, a.y, a.z); p1 = mk3(b.x, b.y, b.z); p2 = mk3(c.x, c.y, c.z);
   }
+  RT_DEV void tri_flags(int i, f3& p0, f3& p1, f3& p2, unsigned& flags) const {
+    float4 a = tris[3 * i], b = tris[3 * i + 1], c = tris[3 * i + 2];
+    p0 = mk3(a.x, a.y, a.z); p1 = mk3(b.x, b.y, b.z); p2 = mk3(c.x, c.y, c.z); flags = __float_as_uint(c.w);
+  }
 };
 #define RT_SMALL_NODES 256
 #define RT_SMALL_TRIS 128
@@ -546,7 +558,7 @@ RT_DEV void trace_write_any(float4* __restrict__ lacc, size_t ls, const float4* 
 
 // BLOCK threads per workgroup, DEPTH = to-visit stack entries per lane (the host picks the
 // smallest of 16/32/64 that covers the tree height; the reference's fixed 64 is the maximum).
-template <bool ANY, bool COUNT, bool SMALL, int BLOCK, int DEPTH>
+template <bool ANY, bool COUNT, bool SMALL, int BLOCK, int DEPTH, bool GENERAL = false>  // GENERAL: quadrics / alpha-masked triangles in the leaves (no object instances)
 __global__ void __launch_bounds__(BLOCK) k_trace(DScene sc, TraceIO io, const unsigned* __restrict__ queue, const unsigned* __restrict__ shard_counts, unsigned shard_cap,
                                                  unsigned count_static, unsigned long long* stats, int st_rays, int st_nodes, int st_tris) {
   const float4* __restrict__ ray_o = io.ray_o; const float4* __restrict__ ray_d = io.ray_d; const size_t rs = io.ray_stride;
@@ -575,9 +587,10 @@ __global__ void __launch_bounds__(BLOCK) k_trace(DScene sc, TraceIO io, const un
     int prim = -1; TriHit h; h.t = kInf; h.b0 = h.b1 = h.b2 = 0.0f;
     bool found;
     constexpr int LM = ANY ? RT_LDS_LEAF_MIN_ANY : RT_LDS_LEAF_MIN_CLOSEST;
-    if (SMALL && LM > 1 && LM < 64 && !COUNT) { LdsSrc src{s_nodes, s_tris}; found = traverse_rounds<ANY, COUNT, LM, LdsSrc, StackT>(src, ray, stack + threadIdx.x, BLOCK, prim, h, n_nodes, n_tris); }
-    else if (SMALL) { LdsSrc src{s_nodes, s_tris}; found = traverse<ANY, COUNT, LdsSrc, StackT>(src, ray, stack + threadIdx.x, BLOCK, prim, h, n_nodes, n_tris); }
-    else { GlobalSrc src{sc.nodes, sc.tri_p}; found = traverse<ANY, COUNT, GlobalSrc, StackT>(src, ray, stack + threadIdx.x, BLOCK, prim, h, n_nodes, n_tris); }
+    const GeneralCtx gen{sc.self, ANY && io.shadow_masks != 0};
+    if (SMALL && LM > 1 && LM < 64 && !COUNT) { LdsSrc src{s_nodes, s_tris}; found = traverse_rounds<ANY, COUNT, LM, LdsSrc, StackT, GENERAL>(src, ray, stack + threadIdx.x, BLOCK, prim, h, n_nodes, n_tris, gen); }
+    else if (SMALL) { LdsSrc src{s_nodes, s_tris}; found = traverse<ANY, COUNT, LdsSrc, StackT, GENERAL>(src, ray, stack + threadIdx.x, BLOCK, prim, h, n_nodes, n_tris, gen); }
+    else { GlobalSrc src{sc.nodes, sc.tri_p}; found = traverse<ANY, COUNT, GlobalSrc, StackT, GENERAL>(src, ray, stack + threadIdx.x, BLOCK, prim, h, n_nodes, n_tris, gen); }
     n_rays += 1;
     if (ANY) trace_write_any(lacc, ls, direct_add, as, occluded, os, pid, d4.w, found);
     else hits[pid * hs] = make_float4(hit_b2 ? h.b2 : (found ? h.t : kInf), __int_as_float(found ? prim : -1), h.b0, h.b1);
@@ -609,11 +622,11 @@ __global__ void __launch_bounds__(BLOCK) k_trace(DScene sc, TraceIO io, const un
 // TransformedPrimitive::intersect / intersect_p (rc/primitive.rs:90-101): the ray goes to object space as `Transform * Ray` does (origin as a point,
 // direction as a vector, t_max kept - rc/ray.rs:83-93), the object - its tree, or its single primitive - is intersected there; t is the same parameter
 // in both spaces. The nested walk keeps its stack in private memory: this is the general path, not the fast one.
-template <bool ANY, bool COUNT>
-RT_DEVN bool instance_intersect(const DScene& sc, unsigned inst, float ox, float oy, float oz, float dx, float dy, float dz, float& t_max, int& prim_out, TriHit& hit_out,
-                                unsigned& n_nodes, unsigned& n_tris) {
+template <bool ANY, bool COUNT, class StackT>
+RT_DEV bool instance_intersect(const DScene& sc, unsigned inst, f3 o, f3 d, float& t_max, int& prim_out, TriHit& hit_out, unsigned& n_nodes, unsigned& n_tris,
+                               StackT* stack, int stack_stride) {
   const DInstance& in = sc.instances[inst];
-  Ray r; r.o = xf34_point(in.w2o, mk3(ox, oy, oz)); r.d = xf34_vector(in.w2o, mk3(dx, dy, dz)); r.t_max = t_max;
+  Ray r; r.o = xf34_point(in.w2o, o); r.d = xf34_vector(in.w2o, d); r.t_max = t_max;
   bool found;
   if (in.n_nodes == 0u) {  // an object of one primitive is wrapped as it is (api.rs:1073-1082): no node test
     f3 p0, p1, p2; load_tri(sc.tri_p, (int)in.prim_base, p0, p1, p2);
@@ -622,13 +635,35 @@ RT_DEVN bool instance_intersect(const DScene& sc, unsigned inst, float ox, float
     found = tri_test(p0, p1, p2, r, h);
     if (found) { prim_out = 0; hit_out = h; r.t_max = h.t; }
   } else {
+    // the object's walk takes the entries of this lane's stack column above the caller's pending ones (rt_scene_create sizes the column for the
+    // deepest top-level path plus the deepest object)
     const GlobalSrc src{sc.nodes + 2 * (size_t)in.node_base, sc.tri_p + 3 * (size_t)in.prim_base};
-    int stack[64];
-    found = traverse<ANY, COUNT>(src, r, stack, 1, prim_out, hit_out, n_nodes, n_tris);
+    found = traverse<ANY, COUNT, GlobalSrc, StackT>(src, r, stack, stack_stride, prim_out, hit_out, n_nodes, n_tris);
     if (found && !ANY) r.t_max = hit_out.t;
   }
   if (found) t_max = r.t_max;
   return found;
+}
+// One primitive of a leaf of a GENERAL scene, for the persistent kernels: an object instance (the hit id then names (instance, the object's primitive)), a
+// quadric, a masked triangle or a plain one. Returns whether the ray hits; for a closest-hit ray prim / hit / t_max are updated by the caller's rule.
+template <bool ANY, bool COUNT, class StackT>
+RT_DEV bool general_leaf_prim(const DScene& sc, const float4* __restrict__ tri_p, int prim, const Ray& ray, const RayPre& rp, bool shadow_masks, StackT* nested_stack, int stack_stride,
+                              TriHit& h, int& hit_prim, float& t_hit, unsigned& n_nodes, unsigned& n_tris) {
+  const float4 a = tri_p[3 * prim], b = tri_p[3 * prim + 1], c = tri_p[3 * prim + 2];
+  const f3 p0 = mk3(a.x, a.y, a.z), p1 = mk3(b.x, b.y, b.z), p2 = mk3(c.x, c.y, c.z);
+  const unsigned flags = __float_as_uint(c.w);
+  if (flags & RT_FLAG_INSTANCE) {
+    const unsigned k = __float_as_uint(c.x);
+    int oprim = 0; float tm = ray.t_max;
+    if (!instance_intersect<ANY, COUNT, StackT>(sc, k, ray.o, ray.d, tm, oprim, h, n_nodes, n_tris, nested_stack, stack_stride)) return false;
+    hit_prim = (int)(sc.instances[k].id_base + (unsigned)oprim); t_hit = tm;
+    return true;
+  }
+  hit_prim = prim;
+  if (flags & (RT_FLAG_SPHERE | RT_FLAG_GENERAL_TRI)) { if (!general_prim_test(*sc.self, prim, p0, p1, p2, flags, ray, rp, shadow_masks, h)) return false; }
+  else if (!tri_test_pre(p0, p1, p2, ray, rp, h)) return false;
+  t_hit = h.t;
+  return true;
 }
 
 template <bool ANY, bool COUNT, int BLOCK, int DEPTH, bool GENERAL = false>
@@ -704,31 +739,21 @@ __global__ void __launch_bounds__(BLOCK) k_trace_big(DScene sc, TraceIO io, cons
     // ---- test the leaf's triangles
     if (active) {
       for (int i = 0; i < leaf_n; ++i) {
-        f3 p0, p1, p2;
-        src.tri(leaf_off + i, p0, p1, p2);
         if (COUNT) n_tris += 1;
         TriHit h;
-        if (GENERAL && (tri_flags(sc.tri_p, leaf_off + i) & RT_FLAG_INSTANCE)) {  // an object instance: the hit id names (instance, the object's primitive)
-          const unsigned k = __float_as_uint(p2.x);
-          int oprim = 0; float tm = ray.t_max; unsigned nn = 0, ntt = 0;
-          if (!instance_intersect<ANY, COUNT>(*sc.self, k, ray.o.x, ray.o.y, ray.o.z, ray.d.x, ray.d.y, ray.d.z, tm, oprim, h, nn, ntt)) { if (COUNT) { n_nodes += nn; n_tris += ntt; } continue; }
+        if (GENERAL) {
+          int hp = 0; float th = 0.0f; unsigned nn = 0, ntt = 0;
+          const bool hitp = general_leaf_prim<ANY, COUNT, int>(sc, sc.tri_p, leaf_off + i, ray, rp, ANY && io.shadow_masks != 0, stack + sp * BLOCK, BLOCK, h, hp, th, nn, ntt);
           if (COUNT) { n_nodes += nn; n_tris += ntt; }
+          if (!hitp) continue;
           found = true;
           if (ANY) break;
-          ray.t_max = tm; prim = (int)(sc.instances[k].id_base + (unsigned)oprim); hit = h;
+          ray.t_max = th; prim = hp; hit = h;
           continue;
         }
-        if (GENERAL && (tri_flags(sc.tri_p, leaf_off + i) & RT_FLAG_SPHERE)) {  // Sphere::intersect; the hit record carries t where a triangle's carries b2
-          float ts;
-          if (!sphere_test(sc.spheres[__float_as_uint(p2.x)], ray.o, ray.d, ray.t_max, ts)) continue;
-          h.t = ts; h.b0 = h.b1 = 0.0f; h.b2 = ts;
-          found = true;
-          if (ANY) break;
-          ray.t_max = ts; prim = leaf_off + i; hit = h;
-          continue;
-        }
+        f3 p0, p1, p2;
+        src.tri(leaf_off + i, p0, p1, p2);
         if (tri_test_pre(p0, p1, p2, ray, rp, h)) {
-          if (GENERAL && tri_alpha_rejects(*sc.self, leaf_off + i, h, ANY && io.shadow_masks != 0)) continue;
           found = true;
           if (ANY) break;
           ray.t_max = h.t; prim = leaf_off + i; hit = h;  // `.or(result)`: later accepted hits replace
@@ -837,9 +862,22 @@ RT_DEV void pair_interior_step(PairLane& L, const TraceOut& o, const float4* __r
   } else if (keep_f) L.cur = code_f;
   else pair_pop<ANY, BLOCK>(L, o, stack, tstack, grid_lanes);
 }
-template <bool ANY, int BLOCK>
-RT_DEV void pair_leaf_step(PairLane& L, const TraceOut& o, const float4* __restrict__ tri_p, const unsigned* stack, const float* tstack, size_t grid_lanes) {
-  const int off = (int)(L.cur & 0x03ffffffu), n = (int)((L.cur >> 26) & 31u) + 1;
+// GENERAL scenes: a leaf that holds anything but plain triangles carries RT_PAIR_GENERAL in its code (first primitive then in bits 0-24) and walks its
+// primitives through general_leaf_prim; every other leaf of such a scene, and every leaf of a plain scene, runs the bare triangle loop.
+#define RT_PAIR_GENERAL 0x02000000u
+template <bool ANY, bool GENERAL>
+RT_DEV bool pair_leaf_prims(PairLane& L, const DScene& sc, const float4* __restrict__ tri_p, bool shadow_masks, unsigned* nested_stack, int stack_stride) {
+  const int off = (int)(L.cur & (GENERAL ? 0x01ffffffu : 0x03ffffffu)), n = (int)((L.cur >> 26) & 31u) + 1;
+  if (GENERAL && (L.cur & RT_PAIR_GENERAL)) {
+    for (int i = 0; i < n; ++i) {
+      TriHit h; int hp = 0; float th = 0.0f; unsigned nn = 0, ntt = 0;
+      if (!general_leaf_prim<ANY, false, unsigned>(sc, tri_p, off + i, L.ray, L.rp(), shadow_masks, nested_stack, stack_stride, h, hp, th, nn, ntt)) continue;
+      L.found = true;
+      if (ANY) break;
+      L.ray.t_max = th; L.prim = hp; L.hit = h;
+    }
+    return L.found;
+  }
   for (int i = 0; i < n; ++i) {
     f3 p0, p1, p2;
     load_tri(tri_p, off + i, p0, p1, p2);
@@ -850,10 +888,15 @@ RT_DEV void pair_leaf_step(PairLane& L, const TraceOut& o, const float4* __restr
       L.ray.t_max = h.t; L.prim = off + i; L.hit = h;  // `.or(result)`: later accepted hits replace
     }
   }
+  return L.found;
+}
+template <bool ANY, int BLOCK, bool GENERAL = false>
+RT_DEV void pair_leaf_step(PairLane& L, const TraceOut& o, const DScene& sc, const float4* __restrict__ tri_p, unsigned* stack, const float* tstack, size_t grid_lanes, bool shadow_masks) {
+  (void)pair_leaf_prims<ANY, GENERAL>(L, sc, tri_p, shadow_masks, stack + L.sp * BLOCK, BLOCK);
   if (ANY && L.found) pair_finish<ANY>(L, o); else pair_pop<ANY, BLOCK>(L, o, stack, tstack, grid_lanes);
 }
 
-template <bool ANY, bool WW, int BLOCK, int DEPTH>
+template <bool ANY, bool WW, int BLOCK, int DEPTH, bool GENERAL = false>
 __global__ void __launch_bounds__(BLOCK) k_trace_pair(DScene sc, TraceIO io, const unsigned* __restrict__ queue, const unsigned* __restrict__ shard_counts, unsigned shard_cap,
                                                       unsigned count_static, unsigned long long* stats, int st_rays, float* __restrict__ tmin_stack_mem, unsigned refill_min) {
   const float4* __restrict__ ray_o = io.ray_o; const float4* __restrict__ ray_d = io.ray_d; const size_t rs = io.ray_stride;
@@ -869,6 +912,7 @@ __global__ void __launch_bounds__(BLOCK) k_trace_pair(DScene sc, TraceIO io, con
   const unsigned n_waves = gridDim.x * (BLOCK / 64), wave = blockIdx.x * (BLOCK / 64) + (threadIdx.x >> 6);
   const float4* __restrict__ pairs = sc.pairs; const float4* __restrict__ tri_p = sc.tri_p; const float4* __restrict__ nodes = sc.nodes;
   const TraceOut out = trace_out_of(io);
+  const unsigned leaf_min = refill_min >> 8; refill_min &= 0xffu;  // the launch's two knobs travel in one word
   unsigned n_rays = 0;
   unsigned cursor = 0;
   bool exhausted = (unsigned long long)wave * 64ull >= count;
@@ -894,21 +938,22 @@ __global__ void __launch_bounds__(BLOCK) k_trace_pair(DScene sc, TraceIO io, con
         const float4 r0 = nodes[0], r1 = nodes[1];
         if (slab_test(r0, r1, L.ray, L.inv_dir, L.neg_x(), L.neg_y(), L.neg_z())) {
           const unsigned packed = __float_as_uint(r1.w), np = packed & 0xffffu;
-          L.cur = np > 0u ? (RT_PAIR_LEAF | (unsigned)__float_as_int(r1.z) | ((np - 1u) << 26)) : (((packed >> 16) & 0xffu) << 29);
+          L.cur = np > 0u ? (RT_PAIR_LEAF | (GENERAL ? RT_PAIR_GENERAL : 0u) | (unsigned)__float_as_int(r1.z) | ((np - 1u) << 26)) : (((packed >> 16) & 0xffu) << 29);
         } else pair_finish<ANY>(L, out);
       }
       cursor += (unsigned)__popcll(idle);
       exhausted = ((unsigned long long)(cursor >> 6) * n_waves + wave) * 64ull + (cursor & 63u) >= count;
     }
     if (__ballot(L.active) == 0ull) { if (exhausted) break; else continue; }
+    const bool shadow_masks = ANY && io.shadow_masks != 0;
     if (WW) {
       while (L.active && !(L.cur & RT_PAIR_LEAF)) pair_interior_step<ANY, BLOCK>(L, out, pairs, stack, tstack, grid_lanes);
-      if (L.active) pair_leaf_step<ANY, BLOCK>(L, out, tri_p, stack, tstack, grid_lanes);
+      if (L.active) pair_leaf_step<ANY, BLOCK, GENERAL>(L, out, sc, tri_p, stack, tstack, grid_lanes, shadow_masks);
     } else {
       const bool at_leaf = L.active && (L.cur & RT_PAIR_LEAF) != 0u;
-      const bool leaves_now = leaf_phase_now(L.active, at_leaf);
+      const bool leaves_now = leaf_phase_now(L.active, at_leaf, leaf_min);
       if (L.active) {
-        if (at_leaf) { if (leaves_now) pair_leaf_step<ANY, BLOCK>(L, out, tri_p, stack, tstack, grid_lanes); }
+        if (at_leaf) { if (leaves_now) pair_leaf_step<ANY, BLOCK, GENERAL>(L, out, sc, tri_p, stack, tstack, grid_lanes, shadow_masks); }
         else pair_interior_step<ANY, BLOCK>(L, out, pairs, stack, tstack, grid_lanes);
       }
     }
@@ -968,23 +1013,13 @@ RT_DEV void top_interior_step(PairLane& L, const TraceOut& o, const float4* __re
   } else if (keep_f) L.cur = code_f;
   else top_pop<ANY, BLOCK>(L, o, stk, tstack, grid_lanes);
 }
-template <bool ANY, int BLOCK>
-RT_DEV void top_leaf_step(PairLane& L, const TraceOut& o, const float4* __restrict__ tri_p, const SplitStack<BLOCK>& stk, const float* tstack, size_t grid_lanes) {
-  const int off = (int)(L.cur & 0x03ffffffu), n = (int)((L.cur >> 26) & 31u) + 1;
-  for (int i = 0; i < n; ++i) {
-    f3 p0, p1, p2;
-    load_tri(tri_p, off + i, p0, p1, p2);
-    TriHit h;
-    if (tri_test_pre(p0, p1, p2, L.ray, L.rp(), h)) {
-      L.found = true;
-      if (ANY) break;
-      L.ray.t_max = h.t; L.prim = off + i; L.hit = h;
-    }
-  }
+template <bool ANY, int BLOCK, bool GENERAL = false>  // GENERAL here: quadrics and masked triangles (an instanced scene needs a contiguous stack column: k_trace_pair)
+RT_DEV void top_leaf_step(PairLane& L, const TraceOut& o, const DScene& sc, const float4* __restrict__ tri_p, const SplitStack<BLOCK>& stk, const float* tstack, size_t grid_lanes, bool shadow_masks) {
+  (void)pair_leaf_prims<ANY, GENERAL>(L, sc, tri_p, shadow_masks, nullptr, 0);
   if (ANY && L.found) pair_finish<ANY>(L, o); else top_pop<ANY, BLOCK>(L, o, stk, tstack, grid_lanes);
 }
-template <bool ANY, int BLOCK>
-__global__ void __launch_bounds__(BLOCK, 6) k_trace_top(DScene sc, TraceIO io, const unsigned* __restrict__ queue, const unsigned* __restrict__ shard_counts, unsigned shard_cap,
+template <bool ANY, int BLOCK, bool GENERAL = false>
+__global__ void __launch_bounds__(BLOCK, GENERAL ? 4 : 6) k_trace_top(DScene sc, TraceIO io, const unsigned* __restrict__ queue, const unsigned* __restrict__ shard_counts, unsigned shard_cap,
                                                      unsigned count_static, unsigned long long* stats, int st_rays, float* __restrict__ tmin_stack_mem, unsigned* __restrict__ deep_stack_mem,
                                                      unsigned refill_min) {
   __shared__ unsigned stack_mem[RT_TOP_LDS_DEPTH * BLOCK];
@@ -1003,6 +1038,7 @@ __global__ void __launch_bounds__(BLOCK, 6) k_trace_top(DScene sc, TraceIO io, c
   const unsigned n_waves = gridDim.x * (BLOCK / 64), wave = blockIdx.x * (BLOCK / 64) + (threadIdx.x >> 6);
   const float4* __restrict__ pairs = sc.pairs; const float4* __restrict__ tri_p = sc.tri_p; const float4* __restrict__ nodes = sc.nodes;
   const TraceOut out = trace_out_of(io);
+  const unsigned leaf_min = refill_min >> 8; refill_min &= 0xffu;  // the launch's two knobs travel in one word
   unsigned n_rays = 0, cursor = 0;
   bool exhausted = (unsigned long long)wave * 64ull >= count;
   PairLane L;
@@ -1025,7 +1061,7 @@ __global__ void __launch_bounds__(BLOCK, 6) k_trace_top(DScene sc, TraceIO io, c
         const float4 r0 = nodes[0], r1 = nodes[1];  // the root is the one node tested on its own
         if (slab_test(r0, r1, L.ray, L.inv_dir, L.neg_x(), L.neg_y(), L.neg_z())) {
           const unsigned packed = __float_as_uint(r1.w), np = packed & 0xffffu;
-          L.cur = np > 0u ? (RT_PAIR_LEAF | (unsigned)__float_as_int(r1.z) | ((np - 1u) << 26)) : ((((packed >> 16) & 0xffu) << 29) | (sc.n_top ? RT_PAIR_TOP : 0u));  // root = slot 0
+          L.cur = np > 0u ? (RT_PAIR_LEAF | (GENERAL ? RT_PAIR_GENERAL : 0u) | (unsigned)__float_as_int(r1.z) | ((np - 1u) << 26)) : ((((packed >> 16) & 0xffu) << 29) | (sc.n_top ? RT_PAIR_TOP : 0u));  // root = slot 0
         } else pair_finish<ANY>(L, out);
       }
       cursor += (unsigned)__popcll(idle);
@@ -1034,9 +1070,9 @@ __global__ void __launch_bounds__(BLOCK, 6) k_trace_top(DScene sc, TraceIO io, c
     if (__ballot(L.active) == 0ull) { if (exhausted) break; else continue; }
     {
       const bool at_leaf = L.active && (L.cur & RT_PAIR_LEAF) != 0u;
-      const bool leaves_now = leaf_phase_now(L.active, at_leaf);
+      const bool leaves_now = leaf_phase_now(L.active, at_leaf, leaf_min);
       if (L.active) {
-        if (at_leaf) { if (leaves_now) top_leaf_step<ANY, BLOCK>(L, out, tri_p, stk, tstack, grid_lanes); }
+        if (at_leaf) { if (leaves_now) top_leaf_step<ANY, BLOCK, GENERAL>(L, out, sc, tri_p, stk, tstack, grid_lanes, ANY && io.shadow_masks != 0); }
         else top_interior_step<ANY, BLOCK>(L, out, pairs, s_top, stk, tstack, grid_lanes);
       }
     }
@@ -1122,7 +1158,7 @@ RT_DEV void quad_interior_step(PairLane& L, const TraceOut& o, const float4* __r
   if (entered) L.cur = next; else pair_pop<ANY, BLOCK>(L, o, stack, tstack, grid_lanes);
 }
 
-template <bool ANY, int BLOCK, int DEPTH>
+template <bool ANY, int BLOCK, int DEPTH, bool GENERAL = false>
 __global__ void __launch_bounds__(BLOCK) k_trace_quad(DScene sc, TraceIO io, const unsigned* __restrict__ queue, const unsigned* __restrict__ shard_counts, unsigned shard_cap,
                                                       unsigned count_static, unsigned long long* stats, int st_rays, float* __restrict__ tmin_stack_mem, unsigned refill_min) {
   const float4* __restrict__ ray_o = io.ray_o; const float4* __restrict__ ray_d = io.ray_d; const size_t rs = io.ray_stride;
@@ -1136,6 +1172,7 @@ __global__ void __launch_bounds__(BLOCK) k_trace_quad(DScene sc, TraceIO io, con
   const unsigned n_waves = gridDim.x * (BLOCK / 64), wave = blockIdx.x * (BLOCK / 64) + (threadIdx.x >> 6);
   const float4* __restrict__ quads = sc.quads; const float4* __restrict__ tri_p = sc.tri_p; const float4* __restrict__ nodes = sc.nodes;
   const TraceOut out = trace_out_of(io);
+  const unsigned leaf_min = refill_min >> 8; refill_min &= 0xffu;  // the launch's two knobs travel in one word
   unsigned n_rays = 0;
   unsigned cursor = 0;
   bool exhausted = (unsigned long long)wave * 64ull >= count;
@@ -1159,7 +1196,7 @@ __global__ void __launch_bounds__(BLOCK) k_trace_quad(DScene sc, TraceIO io, con
         const float4 r0 = nodes[0], r1 = nodes[1];  // the root is the one node tested on its own
         if (slab_test(r0, r1, L.ray, L.inv_dir, L.neg_x(), L.neg_y(), L.neg_z())) {
           const unsigned packed = __float_as_uint(r1.w), np = packed & 0xffffu;
-          L.cur = np > 0u ? (RT_PAIR_LEAF | (unsigned)__float_as_int(r1.z) | ((np - 1u) << 26)) : (((packed >> 16) & 0xffu) << 29);
+          L.cur = np > 0u ? (RT_PAIR_LEAF | (GENERAL ? RT_PAIR_GENERAL : 0u) | (unsigned)__float_as_int(r1.z) | ((np - 1u) << 26)) : (((packed >> 16) & 0xffu) << 29);
         } else pair_finish<ANY>(L, out);
       }
       cursor += (unsigned)__popcll(idle);
@@ -1168,9 +1205,9 @@ __global__ void __launch_bounds__(BLOCK) k_trace_quad(DScene sc, TraceIO io, con
     if (__ballot(L.active) == 0ull) { if (exhausted) break; else continue; }
     {
       const bool at_leaf = L.active && (L.cur & RT_PAIR_LEAF) != 0u;
-      const bool leaves_now = leaf_phase_now(L.active, at_leaf);
+      const bool leaves_now = leaf_phase_now(L.active, at_leaf, leaf_min);
       if (L.active) {
-        if (at_leaf) { if (leaves_now) pair_leaf_step<ANY, BLOCK>(L, out, tri_p, stack, tstack, grid_lanes); }
+        if (at_leaf) { if (leaves_now) pair_leaf_step<ANY, BLOCK, GENERAL>(L, out, sc, tri_p, stack, tstack, grid_lanes, ANY && io.shadow_masks != 0); }
         else quad_interior_step<ANY, BLOCK>(L, out, quads, stack, tstack, grid_lanes);
       }
     }
@@ -1189,10 +1226,18 @@ __global__ void __launch_bounds__(BLOCK) k_trace_quad(DScene sc, TraceIO io, con
 // class; misses last), so that most waves run one code path. Order within a bin is arbitrary: paths are
 // independent and the film sums each pixel's samples in sample order. hist/cursor: RT_BIN_MAX + 1 zeroed words each.
 #define RT_BIN_MAX 256
-RT_DEV unsigned bin_of(const DMaterial* __restrict__ materials, const float4* __restrict__ tri_p, const VertRec* __restrict__ path, unsigned pid, unsigned n_bins) {
-  const int prim = __float_as_int(path[pid].hit.y);
+// hit id -> index of the primitive in the scene's arrays (an id past the top level's primitives names (instance, the object's primitive))
+RT_DEV int hit_primitive(const DInstance* __restrict__ instances, unsigned n_instances, unsigned n_top_prims, int hit_id) {
+  if (n_instances == 0u || (unsigned)hit_id < n_top_prims) return hit_id;
+  unsigned lo = 0, hi = n_instances;
+  while (hi - lo > 1u) { const unsigned mid = (lo + hi) >> 1; if (instances[mid].id_base <= (unsigned)hit_id) lo = mid; else hi = mid; }
+  return (int)(instances[lo].prim_base + ((unsigned)hit_id - instances[lo].id_base));
+}
+RT_DEV unsigned bin_of(const DScene& sc, const DMaterial* __restrict__ materials, const float4* __restrict__ tri_p /* the shade records */, const VertRec* __restrict__ path, unsigned pid, unsigned n_bins) {
+  int prim = __float_as_int(path[pid].hit.y);
   if (prim < 0) return n_bins - 1u;
-  const unsigned m = (unsigned)materials[tri_material(tri_p, prim)].code_class;
+  prim = hit_primitive(sc.instances, sc.n_instances, sc.n_top_prims, prim);
+  const unsigned m = (unsigned)materials[rec_material(tri_p, prim)].code_class;
   return m < n_bins - 1u ? m : n_bins - 2u;
 }
 // bin_at[i]: the bin of queue entry i, kept for k_bin_scatter - finding it takes two dependent gathers (hit record -> triangle -> material) that need not be repeated
@@ -1204,7 +1249,7 @@ __global__ void __launch_bounds__(256) k_bin_count(DScene sc, PassState ps, unsi
   const unsigned count = ps.q_in ? qv.total() : ps.cap;
   for (unsigned i = blockIdx.x * 256u + threadIdx.x; i < count; i += gridDim.x * 256u) {
     const unsigned pid = ps.q_in ? qv.get(i) : i;
-    const unsigned b = bin_of(sc.materials, sc.tri_p, ps.vert, pid, n_bins);
+    const unsigned b = bin_of(sc, sc.materials, sc.tri_rec, ps.vert, pid, n_bins);
     bin_at[i] = (unsigned short)b;
     atomicAdd(&lh[b], 1u);
   }
@@ -1220,7 +1265,7 @@ __global__ void __launch_bounds__(256) k_bin_scatter(DScene sc, PassState ps, un
     unsigned run = 0;
     for (unsigned b = 0; b < n_bins; ++b) { base[b] = run; run += hist[b]; }
     if (blockIdx.x == 0) {
-      sorted_cnt[0] = run; for (int k = 1; k < RT_QSHARDS; ++k) sorted_cnt[k] = 0u;
+      sorted_cnt[0] = run; for (int k = 1; k < RT_QSHARDS; ++k) sorted_cnt[k * RT_CNT_STRIDE] = 0u;
       // bins [0, split_bin): classes of the Lambert front-end; [split_bin, split_bin2): of the two-lobe front-end; [split_bin2, split_bin3): of its wide form;
       // the rest: generic
       const unsigned split = split_bin < n_bins ? base[split_bin] : run, split2 = split_bin2 < n_bins ? base[split_bin2] : run;
@@ -1246,7 +1291,7 @@ __global__ void __launch_bounds__(256) k_bin_scatter(DScene sc, PassState ps, un
 #pragma unroll
     for (unsigned k = 0; k < E; ++k) if (live[k]) rank[k] = atomicAdd(&lcount[bin[k]], 1u);
     __syncthreads();
-    for (unsigned b = threadIdx.x; b < n_bins; b += 256u) if (lcount[b]) lbase[b] = atomicAdd(&cursor[b], lcount[b]);  // one global atomic per bin per 1024 entries
+    for (unsigned b = threadIdx.x; b < n_bins; b += 256u) if (lcount[b]) lbase[b] = atomicAdd(&cursor[b * RT_CNT_STRIDE], lcount[b]);  // one global atomic per bin per 1024 entries
     __syncthreads();
 #pragma unroll
     for (unsigned k = 0; k < E; ++k) if (live[k]) sorted[base[bin[k]] + lbase[bin[k]] + rank[k]] = pid[k];
@@ -1295,7 +1340,7 @@ struct SingleLambertT {
     if (TEXTURED && t.kind != RT_TEX_CONST && !RT_DBG(sc, 1)) r = clamp_pos(tex_eval(sc, kd, si));
     else r = (TEXTURED && t.kind != RT_TEX_CONST) ? mkc(0.75f, 0.75f, 0.75f) : clamp_pos(mkc(t.v[0], t.v[1], t.v[2]));
     has = !is_black(r);
-    ss = normalize(si.sh_dpdu); ns = si.sh_n; ng = si.hit.n; ts = cross(si.sh_n, ss);  // Bsdf::new, bsdf/mod.rs:77-91
+    ss = si.ssb; ns = si.sh_n; ng = si.hit.n; ts = cross(si.sh_n, ss);  // Bsdf::new, bsdf/mod.rs:77-91 (ssb = normalize(si.sh_dpdu))
   }
   RT_DEV f3 to_local(f3 v) const { return mk3(dot(v, ss), dot(v, ts), dot(v, ns)); }
   RT_DEV int num_nonspecular() const { return has ? 1 : 0; }
@@ -1405,7 +1450,7 @@ struct SmallBsdfT {
       rgb3 R = clamp_pos(tex_eval_c(sc, s[2], si));
       if (!is_black(R)) { Lobe l = lobe_zero(LB_SPEC_R); l.r = R; add(l); }
     }
-    ss = normalize(si.sh_dpdu); ns = si.sh_n; ng = si.hit.n; ts = cross(si.sh_n, ss);  // Bsdf::new, bsdf/mod.rs:77-91
+    ss = si.ssb; ns = si.sh_n; ng = si.hit.n; ts = cross(si.sh_n, ss);  // Bsdf::new, bsdf/mod.rs:77-91 (ssb = normalize(si.sh_dpdu))
   }
   RT_DEV f3 to_local(f3 v) const { return mk3(dot(v, ss), dot(v, ts), dot(v, ns)); }
   // one lobe function entered with its kind as a compile-time constant
@@ -1504,6 +1549,7 @@ RT_DEVN int instance_fill_interaction(const DScene& sc, unsigned hit_id, float o
   si.sh_n = normalize(xf34_normal(in.w2o, s.sh_n));
   si.sh_dpdu = xf34_vector(in.o2w, s.sh_dpdu); si.sh_dpdv = xf34_vector(in.o2w, s.sh_dpdv);
   si.sh_n = face_forward(si.sh_n, si.hit.n);
+  si.ssb = normalize(si.sh_dpdu);
   si.prim = gprim;
   return gprim;
 }
@@ -1566,6 +1612,7 @@ __global__ void __launch_bounds__(256, MODE == 1 ? RT_SHADE_MIN_WAVES : RT_SHADE
         else if (GENERAL && (tri_flags(sc.tri_p, prim) & RT_FLAG_SPHERE)) {  // Sphere::intersect builds its interaction from the ray: origin and direction of the path's ray
           const float4 o4 = prec->o;
           (void)sphere_fill_interaction(sc.spheres[prim_sphere_index(sc.tri_p, prim)], mk3(o4.x, o4.y, o4.z), ray_d, si);
+          si.ssb = normalize(si.sh_dpdu);
           si.prim = prim;
         }
         else if (MODE != 0) tri_fill_interaction_inl(sc, prim, ray_d, th, si);
@@ -1575,7 +1622,7 @@ __global__ void __launch_bounds__(256, MODE == 1 ? RT_SHADE_MIN_WAVES : RT_SHADE
       // path.rs:127-136 emitted light at the vertex / from the environment
       if (bounces == 0 || specular_bounce) {
         if (found) {
-          int li = tri_light(sc.tri_p, prim);
+          int li = rec_light(sc.tri_rec, prim);
           if (li >= 0) L = L + beta * area_light_l(sc.lights[li], si.hit.n, -ray_d);
         } else if (MODE != 1) {
           for (int k = 0; k < sc.n_infinite; ++k) L = L + beta * infinite_le(sc, sc.lights[k == 0 ? sc.infinite_ids[0] : (k == 1 ? sc.infinite_ids[1] : (k == 2 ? sc.infinite_ids[2] : sc.infinite_ids[3]))], ray_d);  // constant indices: the kernel argument stays in SGPRs
@@ -1591,7 +1638,7 @@ __global__ void __launch_bounds__(256, MODE == 1 ? RT_SHADE_MIN_WAVES : RT_SHADE
         typename std::conditional<MODE == 1, SingleLambert, typename std::conditional<MODE == 3, SingleLambertT<true>,
                                   typename std::conditional<MODE == 5, SmallBsdfT<false>, typename std::conditional<MODE == 6, SmallBsdfT<true>, GenericBsdf>::type>::type>::type>::type bsdf;
         RT_STAMP(1);  // emission + differentials
-        if (MODE == 0) bsdf.build(gsc, tri_material(sc.tri_p, prim), si); else bsdf.build(sc, tri_material(sc.tri_p, prim), si);
+        if (MODE == 0) bsdf.build(gsc, rec_material(sc.tri_rec, prim), si); else bsdf.build(sc, rec_material(sc.tri_rec, prim), si);
         RT_STAMP(2);  // material: textures + lobes
         // light_distribution.lookup(p) (path.rs:154-158)
         const float* ld_func; const float* ld_cdf; float ld_int; long ld_row = 0;
@@ -1627,8 +1674,8 @@ __global__ void __launch_bounds__(256, MODE == 1 ? RT_SHADE_MIN_WAVES : RT_SHADE
                 ps.sh[pid].o = make_float4(sr.o.x, sr.o.y, sr.o.z, sr.t_max);
                 sh_dir = sr.d;
                 want_shadow = true;
-                if (light_is_delta(light)) ld1 = f * ls.li / ls.pdf;
-                else ld1 = f * ls.li * power_heuristic1(ls.pdf, scattering_pdf) / ls.pdf;
+                if (light_is_delta(light)) ld1 = vdiv(f * ls.li, ls.pdf);
+                else ld1 = vdiv(f * ls.li * power_heuristic1(ls.pdf, scattering_pdf), ls.pdf);
               }
             }
             RT_STAMP(4);  // light-sampling half: sample_li, f, pdf, shadow ray
@@ -1662,7 +1709,7 @@ __global__ void __launch_bounds__(256, MODE == 1 ? RT_SHADE_MIN_WAVES : RT_SHADE
               m->c = make_float4(beta.r, beta.g, beta.b, spdf2);
               m->flags = (want_shadow ? RT_PEND_SHADOW : 0u) | 2u | ((unsigned)light_num << 2) | (mis_occlusion_only ? RT_PEND_MIS_ANY : 0u);
             } else if (want_shadow) {  // L += beta * ((0 + Ld1) / pick_pdf) if unoccluded, applied by the any-hit kernel
-              rgb3 add = beta * ((mkc(0, 0, 0) + ld1) / light_pdf);
+              rgb3 add = beta * vdiv(mkc(0, 0, 0) + ld1, light_pdf);
               ps.sh[pid].add = make_float4(add.r, add.g, add.b, 0.0f);
             }
             if (want_shadow) ps.sh[pid].d = make_float4(sh_dir.x, sh_dir.y, sh_dir.z, want_mis ? 0.0f : 1.0f);
@@ -1673,11 +1720,11 @@ __global__ void __launch_bounds__(256, MODE == 1 ? RT_SHADE_MIN_WAVES : RT_SHADE
         f3 wo = -ray_d;  // not normalised (reference quirk)
         LobeSample bs = bsdf.sample_f(wo, smp.get_2d(), BSDF_ALL);
         if (!(is_black(bs.f) || bs.pdf <= 0.0f)) {
-          beta = beta * bs.f * fabsf(dot(bs.wi, si.sh_n)) / bs.pdf;
+          beta = vdiv(beta * bs.f * fabsf(dot(bs.wi, si.sh_n)), bs.pdf);
           specular_bounce = (bs.type & BSDF_SPECULAR) != 0u;
           if ((bs.type & BSDF_SPECULAR) && (bs.type & BSDF_TRANSMISSION)) {
             float eta = bsdf.eta();
-            eta_scale *= dot(wo, si.hit.n) > 0.0f ? eta * eta : 1.0f / (eta * eta);
+            eta_scale *= dot(wo, si.hit.n) > 0.0f ? eta * eta : vdiv(1.0f, eta * eta);
           }
           Ray nr = spawn_ray(si.hit, bs.wi);
           cont = true;
@@ -1685,7 +1732,7 @@ __global__ void __launch_bounds__(256, MODE == 1 ? RT_SHADE_MIN_WAVES : RT_SHADE
           if (max_component_value(rr_beta) < fp.rr_threshold && bounces > 3) {
             float q = fmaxf(1.0f - max_component_value(rr_beta), 0.05f);
             if (smp.get_1d() < q) cont = false;
-            else beta = beta / (1.0f - q);
+            else beta = vdiv(beta, 1.0f - q);
           }
           if (cont) {
             bounces += 1;
@@ -1742,8 +1789,8 @@ __global__ void __launch_bounds__(256) k_shade_miss(DScene sc, PassState ps) {
 // occlusion-only rays) at one line per vertex whatever order the shade kernel filled them in.
 template <bool GENERAL>  // GENERAL: the emitter a MIS ray reached may be an analytic sphere
 __global__ void __launch_bounds__(256) k_resolve(DScene sc, PassState ps) {
-  QView qv; qv.init(ps.q_mis, ps.cnt_out + 2 * RT_QSHARDS, ps.shard_cap);
-  QView qa; qa.init(ps.q_misany, ps.cnt_out + 3 * RT_QSHARDS, ps.shard_cap);
+  QView qv; qv.init(ps.q_mis, ps.cnt_out + 2 * RT_QSHARDS * RT_CNT_STRIDE, ps.shard_cap);
+  QView qa; qa.init(ps.q_misany, ps.cnt_out + 3 * RT_QSHARDS * RT_CNT_STRIDE, ps.shard_cap);
   const unsigned n_closest = qv.total(), count = n_closest + qa.total();
   const unsigned stride = gridDim.x * blockDim.x;
   for (unsigned i = blockIdx.x * blockDim.x + threadIdx.x; i < count; i += stride) {
@@ -1779,9 +1826,9 @@ __global__ void __launch_bounds__(256) k_resolve(DScene sc, PassState ps) {
           }
         } else if (light.kind == 3) li = infinite_le(sc, light, wi);  // light.le(ray)
       }
-      if (!is_black(li)) ld = ld + mkc(b.x, b.y, b.z) * li * b.w / c.w;
+      if (!is_black(li)) ld = ld + vdiv(mkc(b.x, b.y, b.z) * li * b.w, c.w);
     }
-    rgb3 add = mkc(c.x, c.y, c.z) * (ld / a.w);
+    rgb3 add = mkc(c.x, c.y, c.z) * vdiv(ld, a.w);
     if (add.r == 0.0f && add.g == 0.0f && add.b == 0.0f) continue;  // both rays blocked (most vertices of an interior): L + 0 = L, the scattered read-modify-write is skipped (a NaN is not 0)
     float4 l4 = ps.acc[pid].lacc;
     ps.acc[pid].lacc = make_float4(l4.x + add.r, l4.y + add.g, l4.z + add.b, l4.w);
@@ -1857,6 +1904,43 @@ __global__ void k_film_finalize(const float4* film_acc, float4* film_xyzw, unsig
   float Y = 0.212671f * a.x + 0.715160f * a.y + 0.072169f * a.z;
   float Z = 0.019334f * a.x + 0.119193f * a.y + 0.950227f * a.z;
   film_xyzw[i] = make_float4(X, Y, Z, a.w);
+}
+
+// ================================================================================ per-triangle / per-light constants (rt_scene_create)
+// What Triangle::intersect computes of the triangle alone (dpdu, dpdv, the geometric normal and - without per-vertex normals or tangents - the whole shading
+// frame and the first axis of Bsdf::new's frame) is evaluated once here, by the functions the per-vertex path uses (tri_geo, tri_frame: IEEE + - * / sqrt
+// without contraction give the same bits wherever they run), and kept in one 128-byte record per triangle together with the traversal record.
+__global__ void __launch_bounds__(256) k_tri_records(DScene sc, float4* __restrict__ out) {
+  const unsigned t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= sc.n_tris) return;
+  const float4 a = sc.tri_p[3 * (size_t)t], b = sc.tri_p[3 * (size_t)t + 1], c = sc.tri_p[3 * (size_t)t + 2];
+  float4* r = out + 8 * (size_t)t;
+  r[0] = a; r[1] = b; r[2] = c;
+  const unsigned flags = __float_as_uint(c.w);
+  const float4 z = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+  if (flags & (RT_FLAG_SPHERE | RT_FLAG_INSTANCE)) { r[3] = z; r[4] = z; r[5] = z; r[6] = z; r[7] = z; return; }
+  const f3 p0 = mk3(a.x, a.y, a.z), p1 = mk3(b.x, b.y, b.z), p2 = mk3(c.x, c.y, c.z);
+  f2 uv0 = mk2(0.0f, 0.0f), uv1 = mk2(1.0f, 0.0f), uv2 = mk2(1.0f, 1.0f);
+  if (flags & 4u) { const float* u = sc.tri_uv + 6 * (size_t)t; uv0 = mk2(u[0], u[1]); uv1 = mk2(u[2], u[3]); uv2 = mk2(u[4], u[5]); }
+  const TriGeo g = tri_geo(p0, p1, p2, uv0, uv1, uv2);
+  if (RT_REC_CONST_FRAME(flags)) {
+    const TriFrame f = tri_frame(g, flags, g.n, g.n);
+    const f3 ssb = normalize(f.ss);
+    r[3] = make_float4(f.n.x, f.n.y, f.n.z, ssb.x); r[4] = make_float4(f.ss.x, f.ss.y, f.ss.z, ssb.y); r[5] = make_float4(f.ts.x, f.ts.y, f.ts.z, ssb.z);
+  } else { r[3] = make_float4(g.n.x, g.n.y, g.n.z, 0.0f); r[4] = z; r[5] = z; }
+  r[6] = make_float4(g.dpdu.x, g.dpdu.y, g.dpdu.z, 0.0f); r[7] = make_float4(g.dpdv.x, g.dpdv.y, g.dpdv.z, 0.0f);
+}
+__global__ void __launch_bounds__(256) k_light_consts(DScene sc, DLight* __restrict__ lights) {
+  const int j = (int)(blockIdx.x * blockDim.x + threadIdx.x);
+  if (j >= sc.n_lights) return;
+  DLight& l = lights[j];
+  l.nrm[0] = l.nrm[1] = l.nrm[2] = 0.0f; l.inv_area = 0.0f;
+  if (l.kind != 0) return;
+  l.inv_area = 1.0f / l.area;
+  if (tri_flags(sc.tri_p, l.prim) & RT_FLAG_SPHERE) return;
+  f3 p0, p1, p2; load_tri(sc.tri_p, l.prim, p0, p1, p2);
+  const f3 n = normalize(cross(p1 - p0, p2 - p0));
+  l.nrm[0] = n.x; l.nrm[1] = n.y; l.nrm[2] = n.z;
 }
 
 // ================================================================================ light distribution build

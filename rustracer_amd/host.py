@@ -22,6 +22,7 @@ HIP_LIB = os.path.join(_BUILD, "librtx_hip.so")
 RT_FLAG_COUNT_TRAVERSAL = 1
 RT_FLAG_FILM_ON_DEVICE = 2
 RT_FLAG_TIME_KERNELS = 4
+RT_FLAG_COUNT_AS_RENDERED = 8
 
 
 class BackendError(RuntimeError):
@@ -62,7 +63,8 @@ class Stats(C.Structure):
                                    "ms_shade", "ms_resolve", "ms_film", "ms_lightdist")] +
         [(n, C.c_uint64) for n in ("launches_trace_closest", "n_passes", "vertices_lambert_const", "vertices_lambert", "vertices_two_lobe", "vertices_generic")] +
         [(n, C.c_double) for n in ("ms_shade_lambert_const", "ms_shade_lambert", "ms_shade_two_lobe", "ms_shade_generic", "ms_shade_bin", "ms_shade_miss")] +
-        [("shade_section_cycles", C.c_uint64 * 32)])
+        [("shade_section_cycles", C.c_uint64 * 32)] +
+        [(n, C.c_uint64) for n in ("rays_mis_any", "nodes_mis_any", "tris_mis_any")] + [("ms_trace_mis_any", C.c_double), ("ms_gather", C.c_double)])
 
     def as_dict(self):
         return {n: (list(getattr(self, n)) if n == "shade_section_cycles" else getattr(self, n)) for n, _ in self._fields_}
@@ -258,10 +260,11 @@ class HostScene:
     def upload(self, device=-1):
         _check(lib().rtxh_scene_upload(self.h, device), "upload")
 
-    def render(self, rank=0, world_size=1, count_traversal=False, time_kernels=False, device_out=None, stream=0):
+    def render(self, rank=0, world_size=1, count_traversal=False, time_kernels=False, device_out=None, stream=0, count_as_rendered=False):
         """renderer::render on the GPU. Returns (film_xyzw (H,W,4) over the cropped bounds, stats dict).
         `device_out`: optional torch CUDA tensor (H,W,4) float32 that receives the film in HBM."""
-        flags = (RT_FLAG_COUNT_TRAVERSAL if count_traversal else 0) | (RT_FLAG_TIME_KERNELS if time_kernels else 0)
+        flags = ((RT_FLAG_COUNT_TRAVERSAL if count_traversal else 0) | (RT_FLAG_TIME_KERNELS if time_kernels else 0) |
+                 (RT_FLAG_COUNT_AS_RENDERED if count_as_rendered else 0))
         st = self.setup(rank=rank, world_size=world_size)
         cr = st["cropped"]
         w, h = int(cr[2] - cr[0]), int(cr[3] - cr[1])
@@ -277,18 +280,25 @@ class HostScene:
         _check(lib().rtxh_render(self.h, C.byref(p), C.c_void_p(stream), _p(film), C.byref(stats)), "render")
         return film, stats.as_dict()
 
-    def render_multi(self, devices, chunks_per_device=1, count_traversal=False, time_kernels=False):
+    def render_multi(self, devices, chunks_per_device=1, count_traversal=False, time_kernels=False, count_as_rendered=False, device_out=None):
         """The frame on several GPUs of this process (rt_multi_render): one host thread per entry of `devices`, chunks of tile rows pulled from a
-        shared queue, rows gathered on devices[0]. Returns (film, total stats, [per-device stats])."""
-        flags = (RT_FLAG_COUNT_TRAVERSAL if count_traversal else 0) | (RT_FLAG_TIME_KERNELS if time_kernels else 0)
+        shared queue, rows gathered on devices[0]. Returns (film, total stats, [per-device stats]).
+        `device_out`: optional torch CUDA tensor (H,W,4) float32 on devices[0] that receives the merged film in HBM."""
+        flags = ((RT_FLAG_COUNT_TRAVERSAL if count_traversal else 0) | (RT_FLAG_TIME_KERNELS if time_kernels else 0) |
+                 (RT_FLAG_COUNT_AS_RENDERED if count_as_rendered else 0))
         st = self.setup()
         cr = st["cropped"]
         w, h = int(cr[2] - cr[0]), int(cr[3] - cr[1])
         p = st["params"]
-        p.flags = flags
         dev = np.ascontiguousarray(devices, np.int32)
-        film = np.zeros((h, w, 4), np.float32)
         total, per = Stats(), (Stats * len(dev))()
+        if device_out is not None:
+            assert tuple(device_out.shape) == (h, w, 4) and device_out.is_contiguous()
+            p.flags = flags | RT_FLAG_FILM_ON_DEVICE
+            _check(lib().rtxh_render_multi(self.h, C.byref(p), _p(dev, C.c_int32), len(dev), int(chunks_per_device), C.c_void_p(device_out.data_ptr()), C.byref(total), per), "render_multi")
+            return device_out, total.as_dict(), [s.as_dict() for s in per]
+        p.flags = flags
+        film = np.zeros((h, w, 4), np.float32)
         _check(lib().rtxh_render_multi(self.h, C.byref(p), _p(dev, C.c_int32), len(dev), int(chunks_per_device), _p(film), C.byref(total), per), "render_multi")
         return film, total.as_dict(), [s.as_dict() for s in per]
 

@@ -276,36 +276,228 @@ def write_hdr(path: str, rgbe, rle: bool = True) -> None:
         f.write(bytes(out))
 
 
-def write_exr(path: str, img, compression: str = "zip", pixel_type: str = "half", layer: str = "", alpha: bool = False, origin=(0, 0), extra_channels=()) -> None:
-    """Scan-line OpenEXR file (OpenEXR file layout specification) of img (h, w, 3) float: channels <layer>B/G/R (+A, + extra names)
-    in alphabetical order, half or float samples, compression none | rle | zips | zip. Test writer: numpy + zlib only."""
+def _piz_wenc(a, b, w14):
+    if w14:
+        a_s = a - 65536 if a >= 32768 else a
+        b_s = b - 65536 if b >= 32768 else b
+        return ((a_s + b_s) >> 1) & 0xffff, (a_s - b_s) & 0xffff
+    ao = (a + 0x8000) & 0xffff
+    m = (ao + b) >> 1
+    d = ao - b
+    if d < 0:
+        m = (m + 0x8000) & 0xffff
+    return m, d & 0xffff
+
+
+def _piz_wav_encode(v, base, nx, ox, ny, oy, mx):
+    """2-D wavelet transform of the nx x ny words at v[base + x * ox + y * oy] (the PIZ description's wav2Encode), in place on the Python list v."""
+    w14 = mx < (1 << 14)
+    n = min(nx, ny)
+    p, p2 = 1, 2
+    while p2 <= n:
+        oy1, oy2, ox1, ox2 = oy * p, oy * p2, ox * p, ox * p2
+        py = base
+        ey = base + oy * (ny - p2)
+        while py <= ey:
+            px = py
+            ex = py + ox * (nx - p2)
+            while px <= ex:
+                p01, p10 = px + ox1, px + oy1
+                p11 = p10 + ox1
+                i00, i01 = _piz_wenc(v[px], v[p01], w14)
+                i10, i11 = _piz_wenc(v[p10], v[p11], w14)
+                v[px], v[p10] = _piz_wenc(i00, i10, w14)
+                v[p01], v[p11] = _piz_wenc(i01, i11, w14)
+                px += ox2
+            if nx & p:
+                p10 = px + oy1
+                i00, v[p10] = _piz_wenc(v[px], v[p10], w14)
+                v[px] = i00
+            py += oy2
+        if ny & p:
+            px = py
+            ex = py + ox * (nx - p2)
+            while px <= ex:
+                p01 = px + ox1
+                i00, v[p01] = _piz_wenc(v[px], v[p01], w14)
+                v[px] = i00
+                px += ox2
+        p, p2 = p2, p2 << 1
+
+
+def _piz_huffman(symbols, use_runs=True):
+    """Canonical Huffman coding of 16-bit symbols with the run-length pseudo-symbol (the PIZ description's hufCompress): header + packed table + bits."""
+    import heapq
+    import struct
+    freq = {}
+    for s_ in symbols:
+        freq[s_] = freq.get(s_, 0) + 1
+    im, iM = min(freq), max(freq) + 1
+    freq[iM] = 1                                    # the run-length symbol
+    heap = [(f, i, (i,)) for i, f in freq.items()]
+    heapq.heapify(heap)
+    length = {i: 0 for i in freq}
+    if len(heap) == 1:
+        length[heap[0][1]] = 1
+    while len(heap) > 1:
+        f1, k1, m1 = heapq.heappop(heap)
+        f2, k2, m2 = heapq.heappop(heap)
+        for i in m1 + m2:
+            length[i] += 1
+        heapq.heappush(heap, (f1 + f2, min(k1, k2), m1 + m2))
+    assert max(length.values()) <= 58
+    n = [0] * 59
+    for l in length.values():
+        n[l] += 1
+    c = 0
+    for l in range(58, 0, -1):
+        nc = (c + n[l]) >> 1
+        n[l] = c
+        c = nc
+    code = {}
+    for i in sorted(length):                        # consecutive codes in symbol order within a length
+        l = length[i]
+        code[i] = (n[l], l)
+        n[l] += 1
+    bits = []
+
+    def put(value, nbits):
+        bits.append((value, nbits))
+    i = im
+    while i <= iM:                                  # packed code lengths
+        l = length.get(i, 0)
+        if l == 0:
+            run = 1
+            while i + run <= iM and length.get(i + run, 0) == 0 and run < 255 + 6:
+                run += 1
+            if run >= 2:
+                if run >= 6:
+                    put(63, 6)
+                    put(run - 6, 8)
+                else:
+                    put(59 + run - 2, 6)
+                i += run
+                continue
+        put(l, 6)
+        i += 1
+
+    def pack(items):
+        acc, nacc, out = 0, 0, bytearray()
+        total = 0
+        for v, nb in items:
+            acc = (acc << nb) | v
+            nacc += nb
+            total += nb
+            while nacc >= 8:
+                out.append((acc >> (nacc - 8)) & 0xff)
+                nacc -= 8
+            acc &= (1 << nacc) - 1
+        if nacc:
+            out.append((acc << (8 - nacc)) & 0xff)
+        return bytes(out), total
+    table, _ = pack(bits)
+    bits = []
+    k = 0
+    while k < len(symbols):
+        s_ = symbols[k]
+        run = 0
+        while use_runs and k + 1 + run < len(symbols) and symbols[k + 1 + run] == s_ and run < 255:
+            run += 1
+        cs, ls = code[s_]
+        cr, lr = code[iM]
+        if run and ls + lr + 8 < ls * run:
+            put(cs, ls)
+            put(cr, lr)
+            put(run, 8)
+        else:
+            for _ in range(run + 1):
+                put(cs, ls)
+        k += run + 1
+    data, n_bits = pack(bits)
+    return struct.pack("<IIIII", im, iM, len(table), n_bits, 0) + table + data
+
+
+def _piz_block(chan_words, w, rows, use_runs=True):
+    """chan_words: per channel (in file order) a (rows, w * size) uint16 array of the samples' little-endian 16-bit words."""
+    import struct
+    tmp, starts = [], []
+    for cw in chan_words:
+        starts.append(len(tmp))
+        tmp.extend(int(x) for x in np.asarray(cw, np.uint16).reshape(-1))
+    bitmap = bytearray(8192)
+    for v in set(tmp):
+        bitmap[v >> 3] |= 1 << (v & 7)
+    bitmap[0] &= 0xfe                                # zero is always in the table
+    nz = [i for i, b in enumerate(bitmap) if b]
+    mn, mx_ = (nz[0], nz[-1]) if nz else (8191, 0)
+    lut, k = {}, 0
+    for i in range(65536):
+        if i == 0 or bitmap[i >> 3] & (1 << (i & 7)):
+            lut[i] = k
+            k += 1
+    max_value = k - 1
+    tmp = [lut[v] for v in tmp]
+    for cw, st in zip(chan_words, starts):
+        size = cw.shape[1] // w
+        for j in range(size):
+            _piz_wav_encode(tmp, st + j, w, size, rows, w * size, max_value)
+    huf = _piz_huffman(tmp, use_runs)
+    return struct.pack("<HH", mn, mx_) + (bytes(bitmap[mn:mx_ + 1]) if mn <= mx_ else b"") + struct.pack("<i", len(huf)) + huf
+
+
+def write_exr(path: str, img, compression: str = "zip", pixel_type: str = "half", layer: str = "", alpha: bool = False, origin=(0, 0), extra_channels=(),
+              tiles=None, level_mode: str = "one", parts_before=(), piz_runs: bool = True) -> None:
+    """OpenEXR file (OpenEXR file layout specification) of img (h, w, 3) float: channels <layer>B/G/R (+A, + extra names) in alphabetical order, half, float
+    or uint samples, compression none | rle | zips | zip | piz | pxr24; scan-line blocks, or tiles=(tw, th) with level_mode one | mipmap (lower levels hold
+    a constant: a reader must take level 0); parts_before: channel-name tuples of parts written in front of the image's (a multi-part file).
+    Test writer: numpy + zlib + the format description only."""
     import struct
     import zlib
     a = np.asarray(img, np.float32)
     h, w = a.shape[:2]
-    comp = {"none": 0, "rle": 1, "zips": 2, "zip": 3}[compression]
-    ptype, dt = (1, "<f2") if pixel_type == "half" else (2, "<f4")
+    comp = {"none": 0, "rle": 1, "zips": 2, "zip": 3, "piz": 4, "pxr24": 5}[compression]
+    ptype, dt = {"half": (1, "<f2"), "float": (2, "<f4"), "uint": (0, "<u4")}[pixel_type]
     planes = {layer + "R": a[..., 0], layer + "G": a[..., 1], layer + "B": a[..., 2]}
     if alpha:
         planes[layer + "A"] = np.ones((h, w), np.float32)
     for k, name in enumerate(extra_channels):
         planes[name] = np.full((h, w), 0.25 * (k + 1), np.float32)
-    names = sorted(planes)
+    multipart = len(parts_before) > 0
 
     def attr(name, typ, data):
         return name.encode() + b"\0" + typ.encode() + b"\0" + struct.pack("<I", len(data)) + data
-    chlist = b"".join(n.encode() + b"\0" + struct.pack("<iBxxxii", ptype, 0, 1, 1) for n in names) + b"\0"
-    x0, y0 = origin
-    box = struct.pack("<iiii", x0, y0, x0 + w - 1, y0 + h - 1)
-    hdr = (struct.pack("<II", 20000630, 2) + attr("channels", "chlist", chlist) + attr("compression", "compression", bytes([comp])) +
-           attr("dataWindow", "box2i", box) + attr("displayWindow", "box2i", box) + attr("lineOrder", "lineOrder", b"\0") +
-           attr("pixelAspectRatio", "float", struct.pack("<f", 1.0)) + attr("screenWindowCenter", "v2f", struct.pack("<ff", 0, 0)) +
-           attr("screenWindowWidth", "float", struct.pack("<f", 1.0)) + b"\0")
-    lines = 16 if comp == 3 else 1
 
-    def pack(block: bytes) -> bytes:
+    def pack_block(rows_of, names_, wb, nrows):
+        """rows_of[name]: (nrows, wb) sample array in the file's sample type"""
+        block = b"".join(b"".join(rows_of[n][y].tobytes() for n in names_) for y in range(nrows))
         if comp == 0:
             return block
+        if comp == 4:
+            chan_words = [np.ascontiguousarray(rows_of[n]).view("<u2").reshape(nrows, -1) for n in names_]
+            out = _piz_block(chan_words, wb, nrows, piz_runs)
+            return out if len(out) < len(block) else block
+        if comp == 5:
+            pre = bytearray()
+            for y in range(nrows):
+                for n in names_:
+                    v = np.ascontiguousarray(rows_of[n][y])
+                    if ptype == 1:
+                        u = v.view("<u2").astype(np.uint32)
+                        nplanes, shift = 2, 0
+                    else:
+                        u = v.view("<u4").astype(np.uint32)
+                        nplanes, shift = (3, 8) if ptype == 2 else (4, 0)
+                        if ptype == 2:
+                            u = u & np.uint32(0xffffff00)            # (a real encoder rounds to 24 bits; the test image is exactly representable)
+                    mod = 1 << (16 if ptype == 1 else 32)
+                    d = np.empty_like(u)
+                    d[0] = u[0]
+                    d[1:] = (u[1:].astype(np.int64) - u[:-1].astype(np.int64)) % mod
+                    d = d.astype(np.uint64) >> shift
+                    for k in range(nplanes - 1, -1, -1):
+                        pre += ((d >> (8 * k)) & 0xff).astype(np.uint8).tobytes()
+            out = zlib.compress(bytes(pre), 6)
+            return out if len(out) < len(block) else block
         b = np.frombuffer(block, np.uint8)
         t = np.concatenate([b[0::2], b[1::2]]).astype(np.int16)          # even bytes, then odd bytes
         d = t.copy()
@@ -331,16 +523,53 @@ def write_exr(path: str, img, compression: str = "zip", pixel_type: str = "half"
                     i += lit
             out = bytes(out)
         return out if len(out) < len(block) else block                    # a block that does not shrink is stored raw
-    blocks = []
-    for yb in range(0, h, lines):
-        rows = b"".join(b"".join(planes[n][y].astype(dt).tobytes() for n in names) for y in range(yb, min(h, yb + lines)))
-        data = pack(rows)
-        blocks.append(struct.pack("<iI", y0 + yb, len(data)) + data)
-    table_at = len(hdr)
-    pos = table_at + 8 * len(blocks)
+
+    def part(planes_, part_no, name):
+        names_ = sorted(planes_)
+        typed = {n: planes_[n].astype(dt) for n in names_}
+        chlist = b"".join(n.encode() + b"\0" + struct.pack("<iBxxxii", ptype, 0, 1, 1) for n in names_) + b"\0"
+        x0, y0 = origin
+        box = struct.pack("<iiii", x0, y0, x0 + w - 1, y0 + h - 1)
+        hdr = (attr("channels", "chlist", chlist) + attr("compression", "compression", bytes([comp])) +
+               attr("dataWindow", "box2i", box) + attr("displayWindow", "box2i", box) + attr("lineOrder", "lineOrder", b"\0") +
+               attr("pixelAspectRatio", "float", struct.pack("<f", 1.0)) + attr("screenWindowCenter", "v2f", struct.pack("<ff", 0, 0)) +
+               attr("screenWindowWidth", "float", struct.pack("<f", 1.0)))
+        chunks = []
+        pre = struct.pack("<i", part_no) if multipart else b""
+        if tiles:
+            tw, th = tiles
+            hdr += attr("tiles", "tiledesc", struct.pack("<IIB", tw, th, {"one": 0, "mipmap": 1}[level_mode]))
+            levels = [(w, h)]
+            if level_mode == "mipmap":
+                while levels[-1] != (1, 1):
+                    levels.append((max(1, levels[-1][0] // 2), max(1, levels[-1][1] // 2)))
+            for lv, (lw, lh) in enumerate(levels):
+                src = typed if lv == 0 else {n: np.full((lh, lw), 7, dt) for n in names_}
+                for ty in range((lh + th - 1) // th):
+                    for tx in range((lw + tw - 1) // tw):
+                        sub = {n: src[n][ty * th:min(lh, ty * th + th), tx * tw:min(lw, tx * tw + tw)] for n in names_}
+                        nrows, wb = next(iter(sub.values())).shape
+                        data = pack_block(sub, names_, wb, nrows)
+                        chunks.append(pre + struct.pack("<iiiiI", tx, ty, lv, lv, len(data)) + data)
+        else:
+            lines = {3: 16, 5: 16, 4: 32}.get(comp, 1)
+            for yb in range(0, h, lines):
+                sub = {n: typed[n][yb:min(h, yb + lines)] for n in names_}
+                data = pack_block(sub, names_, w, min(h, yb + lines) - yb)
+                chunks.append(pre + struct.pack("<iI", y0 + yb, len(data)) + data)
+        if multipart:
+            hdr += (attr("name", "string", name.encode()) + attr("type", "string", b"tiledimage" if tiles else b"scanlineimage") +
+                    attr("chunkCount", "int", struct.pack("<i", len(chunks))))
+        return hdr + b"\0", chunks
+    all_parts = [part({c: np.full((h, w), 0.5, np.float32) for c in chans}, k, f"aux{k}") for k, chans in enumerate(parts_before)]
+    all_parts.append(part(planes, len(parts_before), "image"))
+    version = 2 | (0x200 if (tiles and not multipart) else 0) | (0x1000 if multipart else 0)
+    head = struct.pack("<II", 20000630, version) + b"".join(p[0] for p in all_parts) + (b"\0" if multipart else b"")
+    pos = len(head) + 8 * sum(len(p[1]) for p in all_parts)
     table = b""
-    for blk in blocks:
-        table += struct.pack("<Q", pos)
-        pos += len(blk)
+    for _, chunks in all_parts:
+        for blk in chunks:
+            table += struct.pack("<Q", pos)
+            pos += len(blk)
     with open(path, "wb") as f:
-        f.write(hdr + table + b"".join(blocks))
+        f.write(head + table + b"".join(b"".join(p[1]) for p in all_parts))

@@ -5,3 +5,4 @@ from .soup import random_soup  # noqa: F401
 from .blob import blob_scene  # noqa: F401
 from .mis import mis_plates  # noqa: F401
 from .room import room_env  # noqa: F401
+from .forest import forest  # noqa: F401

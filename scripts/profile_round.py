@@ -36,11 +36,11 @@ for k in sorted(set(fetch) | set(write)):
     launches = max(nf.get(k, 0), nw.get(k, 0), 1)
     rd = fetch.get(k, 0.0) * 1024.0 * 2.0 / launches   # KiB -> B, x2: gfx950 reports wide streaming reads at half size
     wr = write.get(k, 0.0) * 1024.0 / launches
-    rows.append((k.split('(')[0].replace('void ', ''), launches, rd, wr, rd + wr))
+    rows.append((k.split('(')[0].replace('void ', ''), launches, rd, wr, rd + wr, rd / 2.0 + wr))
 with open(os.path.join('profiles', f'{tag}_{scene}_pmc_hbm.csv'), 'w') as f:
-    f.write('kernel,launches,read_bytes_per_launch(x2_corrected),write_bytes_per_launch,hbm_bytes_per_launch\n')
+    f.write('kernel,launches,read_bytes_per_launch(x2_corrected),write_bytes_per_launch,hbm_bytes_per_launch,hbm_bytes_per_launch_raw_reads\n')
     for r in rows:
-        f.write(f'"{r[0]}",{r[1]},{r[2]:.0f},{r[3]:.0f},{r[4]:.0f}\n')
+        f.write(f'"{r[0]}",{r[1]},{r[2]:.0f},{r[3]:.0f},{r[4]:.0f},{r[5]:.0f}\n')
 
 def pick(prefixes, exclude=(), per_stage=False):
     sel = [r for r in rows if any(r[0].startswith(p) for p in prefixes) and not any(e in r[0] for e in exclude)]
@@ -49,7 +49,30 @@ def pick(prefixes, exclude=(), per_stage=False):
     # several variants of one stage (k_shade<3> + k_shade<0> on a class-split queue, k_trace variants) run once per bounce each:
     # bytes per launch = all their bytes / the launches of the most frequent variant
     tot_l = max(r[1] for r in sel) if per_stage else sum(r[1] for r in sel)
-    return {'kernels': sorted({r[0] for r in sel}), 'hbm_bytes_per_launch': round(sum(r[4] * r[1] for r in sel) / tot_l), 'launches_profiled': tot_l}
+    lanes = None
+    if valu:
+        tc = sum(valu[k][0] for k in valu if any(k.split('(')[0].replace('void ', '').startswith(p) for p in prefixes) and not any(e in k for e in exclude))
+        ni = sum(valu[k][1] for k in valu if any(k.split('(')[0].replace('void ', '').startswith(p) for p in prefixes) and not any(e in k for e in exclude))
+        lanes = round(tc / ni, 1) if ni else None
+    # the x2 of the guide holds for wide coalesced 16-B-per-lane streams; kernels that gather lie between the raw and the doubled figure: both are kept
+    return {'kernels': sorted({r[0] for r in sel}), 'hbm_bytes_per_launch': round(sum(r[4] * r[1] for r in sel) / tot_l),
+            'hbm_bytes_per_launch_raw': round(sum(r[5] * r[1] for r in sel) / tot_l), 'launches_profiled': tot_l, 'lanes_per_valu': lanes}
+
+# lanes per VALU instruction (SQ_THREAD_CYCLES_VALU / SQ_INSTS_VALU), when the SQ pass was collected
+valu = {}
+tcv, _ = per_kernel('sq', 'SQ_THREAD_CYCLES_VALU')
+niv, _ = per_kernel('sq', 'SQ_INSTS_VALU')
+for k in set(tcv) & set(niv):
+    valu[k] = (tcv[k], niv[k])
+
+def source_sha():
+    import hashlib
+    h = hashlib.sha256()
+    d = os.path.join('rustracer_amd', 'csrc')
+    for f in sorted(os.listdir(d)):
+        if f.endswith(('.h', '.hip', '.inl')):
+            h.update(open(os.path.join(d, f), 'rb').read())
+    return h.hexdigest()[:16]
 
 # closest-hit kernels of the timed frames: k_trace<false, false, ...> (LDS scenes), k_trace_pair<false, ...> or k_trace_top<false, ...> (HBM scenes)
 import datetime, subprocess
@@ -59,7 +82,7 @@ except Exception:
     commit = None
 out = {'scene': scene, 'collected': f'{tag}, {datetime.date.today().isoformat()}' + (f', tree {commit}' if commit else ''),
        'method': 'rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate passes; KiB->B; reads x2 (gfx950 16-B/lane correction, MI355X guide)',
-       'source': f'profiles/{tag}_{scene}_pmc_hbm.csv',
+       'source': f'profiles/{tag}_{scene}_pmc_hbm.csv', 'kernel_source_sha': source_sha(),
        'trace_closest': pick(['rtx::k_trace<false, false', 'rtx::k_trace_pair<false', 'rtx::k_trace_top<false']),
        'shade': pick(['rtx::k_shade'], per_stage=True)}
 json.dump(out, open(os.path.join('profiles', f'pmc_{scene}.json'), 'w'), indent=1)

@@ -208,19 +208,61 @@ def test_read_image_extension_rules(ingest, host, tmp_path):
     assert np.array_equal(ingest.read_image(str(tmp_path / "f.pfm")), a.astype(np.float32))
 
 
-@pytest.mark.parametrize("compression", ["none", "rle", "zips", "zip"])
+@pytest.mark.parametrize("compression", ["none", "rle", "zips", "zip", "piz", "pxr24"])
 @pytest.mark.parametrize("pixel_type", ["half", "float"])
 def test_openexr_scanline_files(ingest, tmp_path, compression, pixel_type):
     rng = np.random.default_rng(21)
-    h, w = 37, 29   # not a multiple of the 16-line ZIP block
+    h, w = 37, 29   # not a multiple of the 16-line ZIP / 32-line PIZ block
     a = (rng.random((h, w, 3), dtype=np.float32) * 4.0).astype(np.float32)
-    a[5:20, 3:25] = a[5, 3]                          # flat region: long runs after the delta predictor
+    a[5:20, 3:25] = a[5, 3]                          # flat region: long runs after the delta predictor / zero wavelet coefficients
     a[0, 0] = (0.0, 6.1e-5, 3.0e-6)                  # smallest normal half and a subnormal half
     a[1, 1] = (65504.0, np.inf, -2.5)
+    if compression == "pxr24":
+        a = (a.view(np.uint32) & np.uint32(0xffffff00)).view(np.float32)   # PXR24 keeps 24 bits of a float: the test image is representable in them
     path = str(tmp_path / "t.exr")
     ingest.write_exr(path, a, compression, pixel_type, alpha=True, origin=(-3, 7), extra_channels=("Z",))
     want = a.astype(np.float16).astype(np.float32) if pixel_type == "half" else a
     assert np.array_equal(ingest.read_image(path), want)
+
+
+def test_openexr_piz_details(ingest, tmp_path):
+    """PIZ on images that take its separate paths: few distinct values (14-bit wavelet), all 65536 half patterns' worth of values (16-bit wavelet),
+    run-length symbols on and off, uint samples, an all-zero block, one pixel, one row, one column."""
+    rng = np.random.default_rng(5)
+    few = rng.integers(0, 7, (40, 33, 3)).astype(np.float32) * 0.25
+    for runs in (True, False):
+        ingest.write_exr(str(tmp_path / "few.exr"), few, "piz", "half", piz_runs=runs)
+        assert np.array_equal(ingest.read_image(str(tmp_path / "few.exr")), few)
+    many = rng.integers(0, 0x7c00, (64, 70, 3)).astype(np.uint16).view(np.float16).astype(np.float32)   # > 2^14 distinct half patterns in one block
+    ingest.write_exr(str(tmp_path / "many.exr"), many, "piz", "half")
+    assert np.array_equal(ingest.read_image(str(tmp_path / "many.exr")), many)
+    ints = rng.integers(0, 100000, (35, 18, 3)).astype(np.float32)
+    ingest.write_exr(str(tmp_path / "u.exr"), ints, "piz", "uint", extra_channels=("id",))
+    assert np.array_equal(ingest.read_image(str(tmp_path / "u.exr")), ints)
+    for shape in ((33, 20), (1, 1), (1, 50), (45, 1)):
+        z = np.zeros(shape + (3,), np.float32)
+        ingest.write_exr(str(tmp_path / "z.exr"), z, "piz", "float")
+        assert np.array_equal(ingest.read_image(str(tmp_path / "z.exr")), z)
+        r = rng.random(shape + (3,), dtype=np.float32)
+        ingest.write_exr(str(tmp_path / "r.exr"), r, "piz", "float")
+        assert np.array_equal(ingest.read_image(str(tmp_path / "r.exr")), r)
+
+
+@pytest.mark.parametrize("compression", ["none", "zip", "piz", "rle"])
+@pytest.mark.parametrize("level_mode", ["one", "mipmap"])
+def test_openexr_tiled_files(ingest, tmp_path, compression, level_mode):
+    a = np.random.default_rng(8).random((45, 70, 3), dtype=np.float32)
+    path = str(tmp_path / "tiled.exr")
+    ingest.write_exr(path, a, compression, "half", tiles=(32, 16), level_mode=level_mode, alpha=True, origin=(5, -2))   # edge tiles are clipped; lower levels hold other values
+    assert np.array_equal(ingest.read_image(path), a.astype(np.float16).astype(np.float32))
+
+
+def test_openexr_multi_part_files(ingest, tmp_path):
+    a = np.random.default_rng(9).random((21, 17, 3), dtype=np.float32)
+    for tiles in (None, (8, 8)):
+        path = str(tmp_path / "parts.exr")
+        ingest.write_exr(path, a, "zip", "float", parts_before=(("Z",), ("A", "Y")), tiles=tiles)   # the first part WITH R, G and B is the third one
+        assert np.array_equal(ingest.read_image(path), a)
 
 
 def test_openexr_named_layer_and_refusals(ingest, host, tmp_path):
@@ -230,13 +272,18 @@ def test_openexr_named_layer_and_refusals(ingest, host, tmp_path):
     assert np.array_equal(ingest.read_image(path), a)                              # first layer that has R, G and B
     raw = bytearray(open(path, "rb").read())
     i = raw.index(b"compression\0compression\0") + len(b"compression\0compression\0") + 4
-    raw[i] = 4                                                                      # PIZ
+    for code, word in ((6, "B44"), (7, "B44"), (8, "DWA"), (9, "DWA")):           # the lossy compressions are refused by name
+        raw[i] = code
+        open(path, "wb").write(raw)
+        with pytest.raises(host.BackendError, match=word):
+            ingest.read_image(path)
+    raw[i] = 3; raw[4:8] = (2 | 0x800).to_bytes(4, "little")                       # deep data flag
     open(path, "wb").write(raw)
-    with pytest.raises(host.BackendError, match="PIZ"):
+    with pytest.raises(host.BackendError, match="deep"):
         ingest.read_image(path)
-    raw[i] = 3; raw[4:8] = (2 | 0x200).to_bytes(4, "little")                       # tiled flag
+    raw[4:8] = (2 | 0x200).to_bytes(4, "little")                                   # tiled flag without a tile description
     open(path, "wb").write(raw)
-    with pytest.raises(host.BackendError, match="tiled"):
+    with pytest.raises(host.BackendError, match="tile"):
         ingest.read_image(path)
     open(path, "wb").write(b"not an exr file at all")
     with pytest.raises(host.BackendError, match="magic"):
@@ -254,6 +301,8 @@ def test_damaged_image_and_mesh_files_fail_cleanly(ingest, host, tmp_path):
     ingest.write_hdr(str(tmp_path / "a.hdr"), rng.integers(0, 256, (6, 40, 4)).astype(np.uint8), rle=True)
     ingest.write_exr(str(tmp_path / "a.exr"), rng.random((20, 9, 3), dtype=np.float32), "zip", "half")
     ingest.write_exr(str(tmp_path / "b.exr"), rng.random((5, 9, 3), dtype=np.float32), "rle", "float")
+    ingest.write_exr(str(tmp_path / "c.exr"), rng.integers(0, 9, (34, 12, 3)).astype(np.float32), "piz", "half")
+    ingest.write_exr(str(tmp_path / "d.exr"), rng.random((20, 20, 3), dtype=np.float32), "pxr24", "half", tiles=(8, 8), parts_before=(("Z",),))
     ingest.write_pfm(str(tmp_path / "a.pfm"), rng.random((4, 5, 3), dtype=np.float32))
     ingest.write_ply(str(tmp_path / "a.ply"), rng.random((6, 3), dtype=np.float32), [[0, 1, 2], [3, 4, 5, 0]])
     ingest.write_ply(str(tmp_path / "b.ply"), rng.random((6, 3), dtype=np.float32), [[0, 1, 2], [3, 4, 5]], fmt="ascii")
