@@ -165,6 +165,11 @@ typedef struct rt_scene_desc {
    * Without instances the three fields are 0 / NULL. */
   uint32_t n_instances; const rt_instance* instances;
   uint32_t n_top_nodes, n_top_prims;
+  /* Emitters that are no lights: lights[n_lights .. n_lights + n_unlisted_lights) are DiffuseAreaLight records (rgb, two_sided) a primitive's `light`
+   * may name although Scene::lights does not hold them - a shape with an AreaLightSource inside an ObjectBegin block keeps its area light (it glows when a
+   * camera ray or a specular bounce hits it) while the light itself never reaches the scene's list (rc/api.rs:954-964): it is never sampled, has no entry in
+   * the light distribution, and a BSDF-sampled ray that reaches it contributes nothing (no sampled light is this one, rc/integrator/mod.rs:293-307). */
+  uint32_t n_unlisted_lights;
 } rt_scene_desc;
 
 /* -- what renderer::render receives through &dyn Camera / Film / Sampler / Integrator ------- */

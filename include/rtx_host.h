@@ -61,8 +61,14 @@ int rtxh_scene_add_quadric(rtxh_scene*, int32_t kind, const float* o2w16, const 
  * proportion to instances x mesh, but every ray stays in the single-level traversal kernels); 0 - the default - keeps the reference's form, one tree per
  * object and a TransformedPrimitive per instance (objects whose meshes carry alpha masks are written out either way). */
 void rtxh_set_flatten_instances(int32_t on);
+/* An emitter that is in no light list: a shape with an AreaLightSource inside an ObjectBegin block keeps its DiffuseAreaLight - it glows when a camera ray
+ * or a specular bounce reaches it - but the light never enters Scene::lights (rc/api.rs:954-964). rtxh_scene_add_emitter returns its index k;
+ * rtxh_scene_object_emitters gives every triangle of an object its emitter (k or -1); a top-level triangle names emitter k as light -2 - k in
+ * rtxh_scene_set_mesh's tri_light (what a written-out instance of such an object becomes). */
+int rtxh_scene_add_emitter(rtxh_scene*, const float* rgb3, int32_t two_sided);
+int rtxh_scene_object_emitters(rtxh_scene*, int32_t object, const int32_t* tri_emitter /* one per triangle of the object */);
 /* ObjectBegin ... ObjectEnd (rc/api.rs:1019-1051): a triangle mesh in OBJECT space (vertices as the shapes' own CTMs leave them), arrays as for
- * rtxh_scene_set_mesh without lights (area lights inside object definitions are refused; the reference shows but never samples them, api.rs:955-957).
+ * rtxh_scene_set_mesh without lights (an emitting shape inside an object definition is an unlisted emitter: rtxh_scene_object_emitters above).
  * Returns the object's index; nothing is rendered until an instance places it. */
 int rtxh_scene_add_object(rtxh_scene*, const float* P, int32_t nv, const int32_t* idx, int32_t nt, const float* N, const float* UV, const float* S,
                           const int32_t* tri_material, const uint8_t* tri_flags);
@@ -104,7 +110,10 @@ enum { RTXH_TABLE_TEXTURES = 0, RTXH_TABLE_MATERIALS, RTXH_TABLE_LIGHTS, RTXH_TA
        /* sampling tables of the first infinite light (floats): func, per-row cdf, row integrals, marginal cdf */
        RTXH_TABLE_ENV_FUNC, RTXH_TABLE_ENV_CDF, RTXH_TABLE_ENV_ROW_INT, RTXH_TABLE_ENV_MARG_CDF,
        RTXH_TABLE_INSTANCES,         /* rtxh_instance_info per ObjectInstance, in order */
-       RTXH_TABLE_OBJECT_BASE = 1000 /* + 8 * object + {0 P, 1 N, 2 UV, 3 S, 4 indices, 5 tri material, 6 tri flags}: the object-space soup of one object */ };
+       RTXH_TABLE_EMITTERS,          /* rtxh_emitter_info per emitter that is in no light list (rtxh_scene_add_emitter) */
+       RTXH_TABLE_OBJECT_BASE = 1000 /* + 8 * object + {0 P, 1 N, 2 UV, 3 S, 4 indices, 5 tri material, 6 tri flags, 7 tri emitter (k or -1; empty when no
+                                        triangle of the object emits)}: the object-space soup of one object */ };
+typedef struct rtxh_emitter_info { float rgb[3]; int32_t two_sided; } rtxh_emitter_info;
 typedef struct rtxh_instance_info { int32_t object; float o2w[16], w2o[16]; } rtxh_instance_info;
 typedef struct rtxh_light_info { int32_t kind, tri; float rgb[3]; int32_t two_sided; float vec[3]; int32_t mip; float l2w[12], w2l[12]; } rtxh_light_info;
 int rtxh_scene_inspect(rtxh_scene*, int32_t table, void* out, uint64_t capacity_bytes, uint64_t* n_items);

@@ -57,7 +57,7 @@ def lib():
         L.orc_scene_new.restype = C.c_void_p
         L.orc_scene_free.argtypes = [C.c_void_p]
         for name in ("orc_scene_set_mesh", "orc_scene_add_mipmap", "orc_scene_add_texture", "orc_scene_add_material",
-                     "orc_scene_add_light", "orc_scene_add_object", "orc_scene_add_instance", "orc_scene_commit", "orc_scene_bvh_sizes", "orc_scene_bvh_get", "orc_trace",
+                     "orc_scene_add_light", "orc_scene_add_object", "orc_scene_object_emitter", "orc_scene_add_instance", "orc_scene_commit", "orc_scene_bvh_sizes", "orc_scene_bvh_get", "orc_trace",
                      "orc_render", "orc_light_distrib", "orc_li_keyed", "orc_camera_film_setup"):
             getattr(L, name).restype = C.c_int
         L.orc_radical_inverse.restype = C.c_float
@@ -149,10 +149,15 @@ class OracleScene:
         for sp in getattr(desc, "spheres", []):
             L.orc_scene_add_sphere(self.h, _p(sp.o2w), _p(sp.w2o), C.c_float(sp.radius), C.c_float(sp.z_min), C.c_float(sp.z_max), C.c_float(sp.phi_max),
                                    int(sp.reverse_orientation), sp.material, sp.light, int(getattr(sp, "kind", 0)))
-        for o in getattr(desc, "objects", []):
+        for k, o in enumerate(getattr(desc, "objects", [])):
             self._keep += (o,)
             assert L.orc_scene_add_object(self.h, _p(o.P), o.P.shape[0], _p(o.idx, C.c_int32), o.idx.shape[0], _p(o.N), _p(o.UV), _p(o.S),
                                           _p(o.mat, C.c_int32), _p(o.flags, C.c_uint8)) >= 0
+            if getattr(o, "emit", None) is not None:  # emitting meshes inside the object: area lights that are in no light list (api.rs:954-964)
+                for t in range(o.emit.shape[0]):
+                    if o.emit[t] >= 0:
+                        rgb, two_sided = desc.emitters[int(o.emit[t])]
+                        assert L.orc_scene_object_emitter(self.h, k, t, _p(np.float32(rgb)), int(two_sided)) >= 0
         for i in getattr(desc, "instances", []):
             assert L.orc_scene_add_instance(self.h, i.obj, _p(i.o2w), _p(i.w2o)) >= 0
         for l in desc.lights:

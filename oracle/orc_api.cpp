@@ -209,6 +209,18 @@ int orc_scene_add_object(void* h, const float* P, int nv, const int32_t* idx, in
   s->objects.push_back(o);
   return (int)s->objects.size() - 1;
 }
+// A triangle of an object that sits under an AreaLightSource: GeometricPrimitive::area_light is set (api.rs:934-945), the light itself is dropped with
+// `area_lights` when there is a current instance (api.rs:954-964) - it is in the OBJECT's light table here, which nothing samples.
+int orc_scene_object_emitter(void* h, int object, int tri, const float* rgbv, int two_sided) {
+  Scene* s = (Scene*)h;
+  if (object < 0 || (size_t)object >= s->objects.size()) return -1;
+  Scene& o = *s->objects[(size_t)object];
+  if (tri < 0 || (size_t)tri >= o.tri_light.size()) return -1;
+  Light l{}; l.kind = LIGHT_DIFFUSE_AREA; l.l_emit = rgb(rgbv[0], rgbv[1], rgbv[2]); l.two_sided = two_sided != 0; l.tri = tri;
+  o.lights.push_back(l);
+  o.tri_light[(size_t)tri] = (int32_t)o.lights.size() - 1;
+  return 0;
+}
 // ObjectInstance (api.rs:1053-1090): TransformedPrimitive{object, primitive_to_world = the CTM}. Returns the primitive id. After every sphere.
 int orc_scene_add_instance(void* h, int object, const float* o2w16, const float* w2o16) {
   Scene* s = (Scene*)h;

@@ -211,7 +211,8 @@ struct Scene {
   std::vector<Sphere> spheres;
   // ---- object instances (TransformedPrimitive, rc/primitive.rs:79-118; api.rs:1053-1090): primitive ids after the spheres. An object is a triangle
   // mesh in OBJECT space with its own BVH (the aggregate object_instance builds over more than one primitive; a single primitive is wrapped as it is);
-  // its tri_material entries index THIS scene's materials, it holds no lights (area lights inside object definitions are refused by the host layer).
+  // its tri_material entries index THIS scene's materials; its `lights` are the area lights of emitting shapes inside the definition, which no light list
+  // holds (api.rs:954-964): looked up by isect_le, never sampled.
   struct Instance { int object; M44 o2w, w2o; };
   std::vector<std::shared_ptr<Scene>> objects;
   std::vector<Instance> instances;
@@ -293,7 +294,11 @@ struct Scene {
   }
   RGB isect_le(const SurfaceInteraction& si, V3 w) const {  // interaction.rs:149-154
     int tri = ordered[si.prim];
-    if (is_instance(tri)) return rgb(0, 0, 0);  // objects hold no emitters here
+    if (is_instance(tri)) {  // TransformedPrimitive hands the object's hit on: its primitive's area light, if any (never one of THIS scene's lights)
+      const Scene& o = *objects[instance_of(tri).object];
+      const int oli = o.tri_light[o.ordered[si.sub]];
+      return oli < 0 ? rgb(0, 0, 0) : area_light_l(o.lights[oli], si.hit, w);
+    }
     int li = tri_light[tri];
     if (li < 0) return rgb(0, 0, 0);
     return area_light_l(lights[li], si.hit, w);

@@ -218,11 +218,21 @@ RT_DEV rgb3 tex_eval(const DScene& sc, int id, const SurfaceInteraction& si) {
   return tex_eval_q(sc.textures, sc.images, id, si.uv, si.dudx, si.dvdx, si.dudy, si.dvdy, si.hit.p.x, si.hit.p.y, si.hit.p.z, si.dpdx.x, si.dpdx.y, si.dpdx.z, si.dpdy.x, si.dpdy.y, si.dpdy.z);
 }
 RT_DEV float tex_eval_f(const DScene& sc, int id, const SurfaceInteraction& si) { return tex_eval(sc, id, si).r; }
-// the same values with the constant texture (the common parameter) answered in place instead of through the out-of-line evaluator
-RT_DEV rgb3 tex_eval_c(const DScene& sc, int id, const SurfaceInteraction& si) {
-  const DTexture& t = sc.textures[id];
-  return t.kind == 0 ? mkc(t.v[0], t.v[1], t.v[2]) : tex_eval(sc, id, si);
+// The image-map leaf alone (imagemap.rs:232-235), out of line: what the register-resident shade front-ends call. Their material classes hold constant and
+// image-map parameters only (rt_scene_create sends every other texture shape to the generic kernel), so the general evaluator above - combinators two deep,
+// four inlined MIP lookups, Perlin noise: 163 VGPRs - is not reachable from them and does not set their register allocation.
+RT_DEVN rgb3 tex_image_q(const DTexture* textures, const DImage* images, int id, f2 uv, float dudx, float dvdx, float dudy, float dvdy) {
+  const DTexture& t = textures[id];
+  f2 st = mk2(t.su * uv.x + t.du, t.sv * uv.y + t.dv);  // UVMapping2D (texture/mod.rs:52-60)
+  f2 dstdx = mk2(t.su * dudx, t.sv * dvdx), dstdy = mk2(t.su * dudy, t.sv * dvdy);
+  return mip_lookup_diff(images[t.image], st, dstdx, dstdy);
 }
+RT_DEV rgb3 tex_eval_leaf(const DScene& sc, int id, const SurfaceInteraction& si) {  // constant or image map
+  const DTexture& t = sc.textures[id];
+  return t.kind == 0 ? mkc(t.v[0], t.v[1], t.v[2]) : tex_image_q(sc.textures, sc.images, id, si.uv, si.dudx, si.dvdx, si.dudy, si.dvdy);
+}
+// the same values with the constant texture (the common parameter) answered in place instead of through the out-of-line evaluator
+RT_DEV rgb3 tex_eval_c(const DScene& sc, int id, const SurfaceInteraction& si) { return tex_eval_leaf(sc, id, si); }  // (front-end classes: constants and image maps)
 RT_DEV float tex_eval_cf(const DScene& sc, int id, const SurfaceInteraction& si) { return tex_eval_c(sc, id, si).r; }
 
 // ---------------------------------------------------------------- alpha masks (rc/shapes/mesh.rs:353-370, 534-582)
@@ -647,10 +657,21 @@ RT_DEVN LiSample light_sample_li(const DScene& sc, const DLight& l, Interaction 
       f3 wi = xf3x4(l.l2w, mk3(sin_theta_ * cos_phi_, sin_theta_ * sin_phi_, cos_theta_));
       s.pdf = sin_theta_ == 0.0f ? 0.0f : vdiv(map_pdf, 2.0f * kPi * kPi * sin_theta_);
       s.p1.p = ref.p + wi * (2.0f * l.world_radius);
-      s.li = RT_DBG(sc, 4) ? mkc(1, 1, 1) : mip_lookup(sc.images[l.image], mk2(d0, d1), 0.0f); s.wi = wi;
+      // the radiance lookup `lmap.lookup(uv)` (infinite.rs:176) is left to the caller (light_sample_li_finish: a call of its own instead of 50 more registers
+      // in this function): li carries the map coordinates until then
+      s.li = mkc(d0, d1, 0.0f); s.wi = wi;
       return s;
     }
   }
+}
+// The environment map's radiance at map coordinates st (mipmap.rs:227-245 with width 0: the level-0 bilinear lookup), out of line
+RT_DEVN rgb3 infinite_li_q(const DImage* images, int image, float s0, float s1) { return mip_lookup(images[image], mk2(s0, s1), 0.0f); }
+// completes a light sample: an infinite light's radiance is looked up here (light_sample_li returns the map coordinates in li)
+template <bool GENERAL>
+RT_DEV LiSample light_sample_li_full(const DScene& sc, const DLight& l, const Interaction& ref, f2 u) {
+  LiSample s = light_sample_li<GENERAL>(sc, l, ref, u);
+  if (l.kind == 3 && s.pdf != 0.0f) s.li = RT_DBG(sc, 4) ? mkc(1, 1, 1) : infinite_li_q(sc.images, l.image, s.li.r, s.li.g);
+  return s;
 }
 // Light::pdf_li. Area lights: Shape::pdf_wi (shapes/mod.rs:59-68) re-intersects the emitter triangle.
 template <bool GENERAL>

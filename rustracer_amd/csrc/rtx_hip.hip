@@ -148,7 +148,7 @@ extern "C" int rt_scene_create(const rt_scene_desc* desc, int device, rt_scene**
       continue;
     }
     if (m.material < 0 || (uint32_t)m.material >= desc->n_materials) { delete s; return fail(RT_ERR_INVALID, "material index out of range"); }
-    if (m.light >= (int)desc->n_lights) { delete s; return fail(RT_ERR_INVALID, "light index out of range"); }
+    if (m.light >= (int)(desc->n_lights + desc->n_unlisted_lights)) { delete s; return fail(RT_ERR_INVALID, "light index out of range"); }
     if (m.flags & (RT_TRI_HAS_ALPHA | RT_TRI_HAS_SHADOW_ALPHA)) {
       if (!desc->tri_alpha) { delete s; return fail(RT_ERR_INVALID, "tri flags need tri_alpha"); }
       for (int k = 0; k < 2; ++k)
@@ -178,8 +178,9 @@ extern "C" int rt_scene_create(const rt_scene_desc* desc, int device, rt_scene**
       if (in.n_prims == 0 || (uint64_t)in.prim_base + in.n_prims > desc->n_tris || in.prim_base < n_top_prims || (in.n_nodes == 0 && in.n_prims != 1) ||
           (in.n_nodes != 0 && ((uint64_t)in.node_base + in.n_nodes > desc->n_nodes || in.node_base < n_top_nodes))) { delete s; return fail(RT_ERR_INVALID, "instance ranges out of bounds"); }
       for (uint32_t t = in.prim_base; t < in.prim_base + in.n_prims; ++t)
-        if (desc->tri_meta[t].flags & (RT_PRIM_SPHERE | RT_PRIM_INSTANCE | RT_TRI_HAS_ALPHA | RT_TRI_HAS_SHADOW_ALPHA) || desc->tri_meta[t].light >= 0) {
-          delete s; return fail(RT_ERR_UNSUPPORTED, "an instanced object holds triangles without masks and without area lights only");
+        if (desc->tri_meta[t].flags & (RT_PRIM_SPHERE | RT_PRIM_INSTANCE | RT_TRI_HAS_ALPHA | RT_TRI_HAS_SHADOW_ALPHA) ||
+            (desc->tri_meta[t].light >= 0 && (uint32_t)desc->tri_meta[t].light < desc->n_lights)) {  // (an emitter inside an object is never a listed light, api.rs:954-964)
+          delete s; return fail(RT_ERR_UNSUPPORTED, "an instanced object holds triangles without masks only, and no light of the scene's list");
         }
       memcpy(di[k].o2w, in.o2w, 64); memcpy(di[k].w2o, in.w2o, 64);
       di[k].node_base = in.node_base; di[k].n_nodes = in.n_nodes; di[k].prim_base = in.prim_base; di[k].n_prims = in.n_prims; di[k].id_base = (unsigned)id;
@@ -321,19 +322,29 @@ extern "C" int rt_scene_create(const rt_scene_desc* desc, int device, rt_scene**
     // classes the register-resident front-end can shade (matte, sigma == 0, no bump, Kd any texture: SingleLambertT) get the lowest ids, so that
     // after binning they are one contiguous range of the queue
     auto is_const = [&](int id) { return id >= 0 && (uint32_t)id < desc->n_textures && desc->textures[id].kind == RT_TEX_CONST; };
+    // the register-resident front-ends evaluate constants in place and image maps through tex_image_q; a material with any other texture shape in a slot
+    // (scale / mix / checkerboard / uv / fbm) is shaded by the generic kernel, whose evaluator handles them all
+    auto leaf_slots = [&](const rt_material& m) {
+      for (int k = 0; k < RT_SLOT_M1; ++k) {
+        const int id = m.slot[k];
+        if (id < 0 || (uint32_t)id >= desc->n_textures) continue;
+        if (desc->textures[id].kind != RT_TEX_CONST && desc->textures[id].kind != RT_TEX_IMAGE) return false;
+      }
+      return true;
+    };
     std::vector<int> lambert(classes.size(), 0), remap(classes.size(), -1);
     for (uint32_t i = 0; i < desc->n_materials; ++i) {
       const rt_material& m = desc->materials[i];
       lambert[hmat[i].code_class] = m.kind == RT_MAT_MATTE && m.slot[RT_SLOT_KD] >= 0 && is_const(m.slot[RT_SLOT_SIGMA]) && m.bump < 0 &&
-                                    desc->textures[m.slot[RT_SLOT_SIGMA]].value[0] <= 0.0f;
+                                    desc->textures[m.slot[RT_SLOT_SIGMA]].value[0] <= 0.0f && leaf_slots(m);
     }
     // then the classes of the two-lobe front-end (SmallBsdfT<false>): matte with sigma > 0, plastic, metal, mirror; then of its wide form: glass,
     // substrate, opaque uber; no bump map
     std::vector<int> small(classes.size(), 0), wide(classes.size(), 0);
     for (uint32_t i = 0; i < desc->n_materials; ++i) {
       const rt_material& m = desc->materials[i];
-      small[hmat[i].code_class] = !lambert[hmat[i].code_class] && m.bump < 0 && (m.kind == RT_MAT_MATTE || m.kind == RT_MAT_PLASTIC || m.kind == RT_MAT_METAL || m.kind == RT_MAT_MIRROR);
-      wide[hmat[i].code_class] = m.bump < 0 && (m.kind == RT_MAT_GLASS || m.kind == RT_MAT_SUBSTRATE || (m.kind == RT_MAT_UBER && uber_two_lobes(m)));
+      small[hmat[i].code_class] = !lambert[hmat[i].code_class] && m.bump < 0 && leaf_slots(m) && (m.kind == RT_MAT_MATTE || m.kind == RT_MAT_PLASTIC || m.kind == RT_MAT_METAL || m.kind == RT_MAT_MIRROR);
+      wide[hmat[i].code_class] = m.bump < 0 && leaf_slots(m) && (m.kind == RT_MAT_GLASS || m.kind == RT_MAT_SUBSTRATE || (m.kind == RT_MAT_UBER && uber_two_lobes(m)));
     }
     int next = 0;
     for (size_t c = 0; c < classes.size(); ++c) if (lambert[c]) remap[c] = next++;
@@ -347,10 +358,11 @@ extern "C" int rt_scene_create(const rt_scene_desc* desc, int device, rt_scene**
   }
   TRY_RC(upload(s->materials, hmat.data(), hmat.size() * sizeof(DMaterial)));
   // lights (+ env distributions in one blob)
-  s->h_lights.resize(desc->n_lights);
+  const uint32_t n_all_lights = desc->n_lights + desc->n_unlisted_lights;  // sampled lights, then the emitters no light list holds
+  s->h_lights.resize(n_all_lights);
   {
     size_t total = 0;
-    for (uint32_t i = 0; i < desc->n_lights; ++i) {
+    for (uint32_t i = 0; i < n_all_lights; ++i) {
       const rt_light& l = desc->lights[i];
       if (l.kind == RT_LIGHT_INFINITE) total += (size_t)l.dist_nv * l.dist_nu + (size_t)l.dist_nv * (l.dist_nu + 1) + (size_t)l.dist_nv * 3 + 1;
     }
@@ -363,7 +375,7 @@ extern "C" int rt_scene_create(const rt_scene_desc* desc, int device, rt_scene**
       for (int k = 0; k <= G; ++k) { const float x = (float)k / (float)G; while (i <= n && cdf[i] <= x) ++i; out[k] = (unsigned short)i; }
     };
     size_t guide_total = 0;
-    for (uint32_t i = 0; i < desc->n_lights; ++i) {
+    for (uint32_t i = 0; i < n_all_lights; ++i) {
       const rt_light& l = desc->lights[i];
       if (l.kind == RT_LIGHT_INFINITE) {
         if (l.dist_nu < 1 || l.dist_nv < 1 || l.dist_nu > 65534 || l.dist_nv > 65534 || !l.dist_cdf || !l.marg_cdf) { delete s; return fail(RT_ERR_INVALID, "infinite light tables missing or larger than 65534 entries per row"); }
@@ -374,13 +386,14 @@ extern "C" int rt_scene_create(const rt_scene_desc* desc, int device, rt_scene**
     TRY_RC([&]() { return s->guides.ensure(gblob.size() * 2) == hipSuccess ? RT_OK : fail(RT_ERR_OOM, "guide alloc"); }());
     size_t gbase = 0;
     size_t base = 0; int n_inf = 0;
-    for (uint32_t i = 0; i < desc->n_lights; ++i) {
+    for (uint32_t i = 0; i < n_all_lights; ++i) {
       const rt_light& l = desc->lights[i]; DLight& d = s->h_lights[i];
       memset(&d, 0, sizeof(d));
       d.kind = l.kind; d.prim = l.prim; d.rgb[0] = l.rgb[0]; d.rgb[1] = l.rgb[1]; d.rgb[2] = l.rgb[2]; d.two_sided = l.two_sided;
       d.vec[0] = l.vec[0]; d.vec[1] = l.vec[1]; d.vec[2] = l.vec[2]; d.area = l.area; d.world_radius = l.world_radius; d.image = l.image;
       memcpy(d.l2w, l.l2w, 48); memcpy(d.w2l, l.w2l, 48);
       if (l.kind == RT_LIGHT_DIFFUSE_AREA && (l.prim < 0 || (uint32_t)l.prim >= desc->n_tris)) { delete s; return fail(RT_ERR_INVALID, "area light prim out of range"); }
+      if (i >= desc->n_lights && l.kind != RT_LIGHT_DIFFUSE_AREA) { delete s; return fail(RT_ERR_INVALID, "an unlisted emitter must be a diffuse area light"); }
       if (l.kind == RT_LIGHT_INFINITE) {
         if (n_inf >= 4) { delete s; return fail(RT_ERR_INVALID, "more than 4 infinite lights"); }
         if (l.image < 0 || (uint32_t)l.image >= desc->n_images) { delete s; return fail(RT_ERR_INVALID, "infinite light image out of range"); }
@@ -443,7 +456,9 @@ extern "C" int rt_scene_create(const rt_scene_desc* desc, int device, rt_scene**
     const rt_material& m = desc->materials[i];
     const bool sigma_zero = m.slot[RT_SLOT_SIGMA] >= 0 && (uint32_t)m.slot[RT_SLOT_SIGMA] < desc->n_textures && desc->textures[m.slot[RT_SLOT_SIGMA]].kind == RT_TEX_CONST &&
                             desc->textures[m.slot[RT_SLOT_SIGMA]].value[0] <= 0.0f;
-    if (m.kind != RT_MAT_MATTE || m.slot[RT_SLOT_KD] < 0 || !sigma_zero || m.bump >= 0) { s->lambert_materials = false; break; }
+    const int kd = m.slot[RT_SLOT_KD];
+    const bool kd_leaf = kd >= 0 && (uint32_t)kd < desc->n_textures && (desc->textures[kd].kind == RT_TEX_CONST || desc->textures[kd].kind == RT_TEX_IMAGE);  // what k_shade<3> evaluates (tex_eval_leaf)
+    if (m.kind != RT_MAT_MATTE || !kd_leaf || !sigma_zero || m.bump >= 0) { s->lambert_materials = false; break; }
   }
   for (uint32_t i = 0; i < desc->n_lights; ++i) if (desc->lights[i].kind != RT_LIGHT_DIFFUSE_AREA) s->lambert_only = false;
   for (uint32_t i = 0; i < desc->n_lights; ++i)
@@ -593,7 +608,7 @@ extern "C" int rt_scene_create(const rt_scene_desc* desc, int device, rt_scene**
   if (s->tri_rec.ensure((size_t)desc->n_tris * 128) != hipSuccess) { delete s; return fail(RT_ERR_OOM, "shade record allocation failed"); }
   d.tri_rec = s->tri_rec.as<float4>();
   hipLaunchKernelGGL(k_tri_records, dim3((desc->n_tris + 255u) / 256u), dim3(256), 0, nullptr, d, s->tri_rec.as<float4>());
-  if (desc->n_lights) hipLaunchKernelGGL(k_light_consts, dim3((desc->n_lights + 255u) / 256u), dim3(256), 0, nullptr, d, s->lights.as<DLight>());
+  if (n_all_lights) hipLaunchKernelGGL(k_light_consts, dim3((n_all_lights + 255u) / 256u), dim3(256), 0, nullptr, d, s->lights.as<DLight>(), (int)n_all_lights);
   if (hipGetLastError() != hipSuccess) { delete s; return fail(RT_ERR_HIP, "constant precomputation launch failed"); }
   if (s->self.ensure(sizeof(DScene)) != hipSuccess) { delete s; return fail(RT_ERR_OOM, "scene record allocation failed"); }
   d.self = s->self.as<DScene>();
@@ -726,13 +741,14 @@ static size_t deep_stack_bytes(const rt_scene* s) {
   return (size_t)top_grid(s) * RT_TOP_BLOCK * (size_t)std::max(1, s->stack_depth - RT_TOP_LDS_DEPTH) * 4;
 }
 // the two knobs of the persistent traversal loops in one launch argument: lanes that must be idle before a wave refills (bits 0-7) and lanes that must wait at
-// a leaf before the leaf phase runs (bits 8-15; RT_LEAF_MIN, see leaf_phase_now). A leaf of an instanced scene is a whole nested walk: no gating there.
+// a leaf before the leaf phase runs (bits 8-15; RT_LEAF_MIN, see leaf_phase_now; measurement knobs RTX_LEAF_MIN / RTX_LEAF_MIN_ANY). On an instanced scene a
+// leaf is a whole nested walk and gating pays even more (10 000 placements, closest hit: 310 / 227 / 166 / 140 / 125 / 122 ms at 1 / 8 / 20 / 32 / 48 / 64).
 static unsigned trace_knobs(const rt_scene* s, bool any) {
   static const int env_refill = getenv("RTX_REFILL_MIN") ? std::min(64, std::max(1, atoi(getenv("RTX_REFILL_MIN")))) : -1;
   static const int env_leaf = getenv("RTX_LEAF_MIN") ? std::min(64, std::max(1, atoi(getenv("RTX_LEAF_MIN")))) : -1;
   static const int env_leaf_any = getenv("RTX_LEAF_MIN_ANY") ? std::min(64, std::max(1, atoi(getenv("RTX_LEAF_MIN_ANY")))) : -1;
   const unsigned refill = env_refill > 0 ? (unsigned)env_refill : (unsigned)RT_REFILL_MIN;
-  unsigned leaf = s->has_instances ? 1u : (unsigned)RT_LEAF_MIN;
+  unsigned leaf = s->has_instances ? 64u : (unsigned)RT_LEAF_MIN;  // (an instance leaf is a whole nested walk: the holders wait for every walker)
   if (env_leaf > 0) leaf = (unsigned)env_leaf;
   if (any && env_leaf_any > 0) leaf = (unsigned)env_leaf_any;
   return refill | (leaf << 8);

@@ -204,13 +204,18 @@ struct rtxh_scene {
   // ObjectBegin / ObjectInstance: primitive ids after the spheres. An object keeps its own soup (object space), tree and leaf order.
   struct HostObject {
     std::vector<float> P, N, UV, S; std::vector<int32_t> idx, tri_mat; std::vector<uint8_t> tri_flags;
+    std::vector<int32_t> tri_emit;  // per triangle: an unlisted emitter (rtxh_scene_add_emitter) or -1; empty = none
     std::vector<rt_bvh_node> nodes; std::vector<int32_t> ordered;
     size_t n_tris() const { return idx.size() / 3; }
   };
   struct HostInstance { int32_t object; float o2w[16], w2o[16]; };
   std::vector<HostObject> objects; std::vector<HostInstance> instances; std::vector<rt_instance> f_instances;
+  // emitters that are in no light list (a shape with an AreaLightSource inside an object definition, rc/api.rs:954-964): DiffuseAreaLight parameters
+  typedef rtxh_emitter_info Emitter;
+  std::vector<Emitter> emitters;
   std::vector<rt_bvh_node> f_nodes;  // with instances: the top-level tree followed by the objects' trees (what rt_scene_desc::nodes points at)
   size_t n_top_prims = 0;            // ... and the top-level primitives' share of the flattened arrays
+  size_t n_listed_lights = 0;        // f_lights: the scene's lights first, then `emitters`
   size_t n_prims() const { return n_tris() + spheres.size() + instances.size(); }
   std::vector<rt_texture> textures; std::vector<rt_material> materials; std::vector<MipLevels> mips; std::vector<HostLight> lights;
   // BVH products
@@ -485,6 +490,7 @@ int finish_commit(rtxh_scene* s) {
     any_n = any_n || !s->objects[o].N.empty(); any_uv = any_uv || !s->objects[o].UV.empty(); any_s = any_s || !s->objects[o].S.empty();
   }
   s->n_top_prims = nt;
+  std::vector<int64_t> emitter_prim(s->emitters.size(), -1);  // a primitive that carries each unlisted emitter (its DLight names one; nothing samples it)
   s->f_p.assign(n_all * 9, 0.0f); s->f_meta.assign(n_all, rt_tri_meta{});
   s->f_n.clear(); s->f_uv.clear(); s->f_s.clear();
   if (any_n) s->f_n.assign(n_all * 9, 0.0f); if (any_uv) s->f_uv.assign(n_all * 6, 0.0f); if (any_s) s->f_s.assign(n_all * 9, 0.0f);
@@ -505,7 +511,9 @@ int finish_commit(rtxh_scene* s) {
           if (os) for (int k = 0; k < 3; ++k) s->f_s[9 * g + 3 * v + k] = ob.S[3 * vi + k];
           if (ouv) for (int k = 0; k < 2; ++k) s->f_uv[6 * g + 2 * v + k] = ob.UV[2 * vi + k];
         }
-        s->f_meta[g] = rt_tri_meta{ob.tri_mat[t], -1, (uint32_t)ob.tri_flags[t], (uint32_t)t};
+        const int32_t em = ob.tri_emit.empty() ? -1 : ob.tri_emit[t];
+        s->f_meta[g] = rt_tri_meta{ob.tri_mat[t], em < 0 ? -1 : (int32_t)(s->lights.size() + (size_t)em), (uint32_t)ob.tri_flags[t], (uint32_t)t};
+        if (em >= 0 && emitter_prim[(size_t)em] < 0) emitter_prim[(size_t)em] = (int64_t)g;
       }
     }
     for (const auto& in : s->instances) {
@@ -545,7 +553,14 @@ int finish_commit(rtxh_scene* s) {
       if (!s->S.empty()) for (int k = 0; k < 3; ++k) s->f_s[9 * i + 3 * v + k] = s->S[3 * vi + k];
       if (!s->UV.empty()) for (int k = 0; k < 2; ++k) s->f_uv[6 * i + 2 * v + k] = s->UV[2 * vi + k];
     }
-    s->f_meta[i] = rt_tri_meta{s->tri_mat[t], s->tri_light[t], (uint32_t)s->tri_flags[t], (uint32_t)t};
+    int32_t tl = s->tri_light[t];
+    if (tl <= -2) {  // -2 - k: unlisted emitter k (a written-out instance of an object that holds an AreaLightSource)
+      const size_t k = (size_t)(-2 - (int64_t)tl);
+      if (k >= s->emitters.size()) return fail(RT_ERR_INVALID, "emitter index out of range");
+      tl = (int32_t)(s->lights.size() + k);
+      if (emitter_prim[k] < 0) emitter_prim[k] = (int64_t)i;
+    }
+    s->f_meta[i] = rt_tri_meta{s->tri_mat[t], tl, (uint32_t)s->tri_flags[t], (uint32_t)t};
   }
   s->f_alpha.clear();
   if (!s->tri_alpha.empty()) {
@@ -597,6 +612,12 @@ int finish_commit(rtxh_scene* s) {
     }
     s->f_lights.push_back(l);
   }
+  s->n_listed_lights = s->f_lights.size();
+  for (size_t k = 0; k < s->emitters.size(); ++k) {  // the emitters no list holds follow the scene's lights
+    rt_light l{}; l.kind = RT_LIGHT_DIFFUSE_AREA; l.prim = (int32_t)std::max<int64_t>(emitter_prim[k], 0); l.two_sided = s->emitters[k].two_sided; l.area = 1.0f; l.image = -1;
+    for (int c = 0; c < 3; ++c) l.rgb[c] = s->emitters[k].rgb[c];
+    s->f_lights.push_back(l);
+  }
   s->committed = true; s->commit_gen += 1;
   return RT_OK;
 }
@@ -616,7 +637,7 @@ rt_scene_desc make_desc(rtxh_scene* s) {
   d.n_textures = (uint32_t)s->textures.size(); d.textures = s->textures.data();
   d.n_images = (uint32_t)s->f_images.size(); d.images = s->f_images.data();
   d.n_materials = (uint32_t)s->materials.size(); d.materials = s->materials.data();
-  d.n_lights = (uint32_t)s->f_lights.size(); d.lights = s->f_lights.data();
+  d.n_lights = (uint32_t)s->n_listed_lights; d.n_unlisted_lights = (uint32_t)(s->f_lights.size() - s->n_listed_lights); d.lights = s->f_lights.data();
   return d;
 }
 
@@ -732,6 +753,19 @@ int rtxh_scene_add_object(rtxh_scene* s, const float* P, int32_t nv, const int32
   }
   s->objects.push_back(std::move(o)); s->committed = false;
   return (int)s->objects.size() - 1;
+}
+int rtxh_scene_add_emitter(rtxh_scene* s, const float* rgb, int32_t two_sided) {
+  if (!s || !rgb) return fail(RT_ERR_INVALID, "bad emitter");
+  rtxh_scene::Emitter e; e.rgb[0] = rgb[0]; e.rgb[1] = rgb[1]; e.rgb[2] = rgb[2]; e.two_sided = two_sided ? 1 : 0;
+  s->emitters.push_back(e); s->committed = false;
+  return (int)s->emitters.size() - 1;
+}
+int rtxh_scene_object_emitters(rtxh_scene* s, int32_t object, const int32_t* tri_emitter) {
+  if (!s || !tri_emitter || object < 0 || (size_t)object >= s->objects.size()) return fail(RT_ERR_INVALID, "bad object emitters");
+  auto& o = s->objects[(size_t)object];
+  for (size_t t = 0; t < o.n_tris(); ++t) if (tri_emitter[t] >= (int32_t)s->emitters.size()) return fail(RT_ERR_INVALID, "emitter index out of range");
+  o.tri_emit.assign(tri_emitter, tri_emitter + o.n_tris()); s->committed = false;
+  return RT_OK;
 }
 int rtxh_scene_add_instance(rtxh_scene* s, int32_t object, const float* o2w16, const float* w2o16) {
   if (!s || !o2w16 || !w2o16 || object < 0 || (size_t)object >= s->objects.size()) return fail(RT_ERR_INVALID, "bad object instance");
@@ -985,7 +1019,7 @@ int rtxh_scene_inspect(rtxh_scene* s, int32_t table, void* out, uint64_t capacit
   std::vector<rtxh_light_info> li; std::vector<rtxh_instance_info> ii;
   if (table >= RTXH_TABLE_OBJECT_BASE) {
     const size_t k = (size_t)(table - RTXH_TABLE_OBJECT_BASE) / 8; const int j = (table - RTXH_TABLE_OBJECT_BASE) % 8;
-    if (k >= s->objects.size() || j > 6) return fail(RT_ERR_INVALID, "unknown object table");
+    if (k >= s->objects.size() || j > 7) return fail(RT_ERR_INVALID, "unknown object table");
     const auto& o = s->objects[k];
     switch (j) {
       case 0: src = o.P.data(); item = 12; n = o.P.size() / 3; break;
@@ -994,6 +1028,7 @@ int rtxh_scene_inspect(rtxh_scene* s, int32_t table, void* out, uint64_t capacit
       case 3: src = o.S.data(); item = 12; n = o.S.size() / 3; break;
       case 4: src = o.idx.data(); item = 12; n = o.idx.size() / 3; break;
       case 5: src = o.tri_mat.data(); item = 4; n = o.tri_mat.size(); break;
+      case 7: src = o.tri_emit.data(); item = 4; n = o.tri_emit.size(); break;
       default: src = o.tri_flags.data(); item = 1; n = o.tri_flags.size(); break;
     }
     *n_items = n;
@@ -1004,6 +1039,7 @@ int rtxh_scene_inspect(rtxh_scene* s, int32_t table, void* out, uint64_t capacit
     case RTXH_TABLE_INSTANCES:
       for (const auto& in : s->instances) { rtxh_instance_info i; i.object = in.object; memcpy(i.o2w, in.o2w, 64); memcpy(i.w2o, in.w2o, 64); ii.push_back(i); }
       src = ii.data(); item = sizeof(rtxh_instance_info); n = ii.size(); break;
+    case RTXH_TABLE_EMITTERS: src = s->emitters.data(); item = sizeof(rtxh_emitter_info); n = s->emitters.size(); break;
     case RTXH_TABLE_TEXTURES: src = s->textures.data(); item = sizeof(rt_texture); n = s->textures.size(); break;
     case RTXH_TABLE_MATERIALS: src = s->materials.data(); item = sizeof(rt_material); n = s->materials.size(); break;
     case RTXH_TABLE_LIGHTS:

@@ -162,6 +162,49 @@ RT_DEV void block_push(unsigned* counters, unsigned shard_cap, const int* queue_
   __syncthreads();
 }
 
+// Wave-private staging of queue appends (the shade kernels). block_push costs three workgroup barriers and a returning atomic per iteration, with every
+// wave of the workgroup waiting for the slowest one and then for the atomic. Here a wave collects the ids it appends in its own LDS window (no barrier: the
+// window is the wave's), and whenever a queue's window holds 64 of them it reserves 64 slots with one atomic and writes them out as one coalesced store.
+// The order of ids inside a queue changes (it is arbitrary anyway: paths are independent), the ids and their number do not.
+#ifndef RT_WAVE_QUEUES
+#define RT_WAVE_QUEUES 1
+#endif
+template <int NQ>
+struct WaveQueues {
+  unsigned* win;        // this wave's NQ windows of 128 ids in LDS
+  unsigned fill[NQ];    // ids waiting in each window (wave-uniform)
+  unsigned* counters; unsigned shard_cap, shard;
+  RT_DEV void init(unsigned* lds, unsigned* counters_, unsigned shard_cap_) {
+    win = lds + (threadIdx.x >> 6) * (NQ * 128u);
+#pragma unroll
+    for (int q = 0; q < NQ; ++q) fill[q] = 0u;
+    counters = counters_; shard_cap = shard_cap_; shard = blockIdx.x & (RT_QSHARDS - 1);
+  }
+  RT_DEV void flush(int q, int qidx, unsigned* __restrict__ ids, unsigned n) {  // the first n (<= 64) ids of window q
+    const unsigned lane = __lane_id();
+    unsigned base = 0;
+    if (lane == 0u) base = atomicAdd(&counters[(qidx * RT_QSHARDS + shard) * RT_CNT_STRIDE], n);
+    base = __shfl(base, 0);
+    if (lane < n) ids[(size_t)shard * shard_cap + base + lane] = win[q * 128 + lane];
+  }
+  // must be reached by every lane of the wave
+  RT_DEV void push(int q, int qidx, unsigned* __restrict__ ids, bool pred, unsigned id) {
+    const unsigned long long mask = __ballot(pred);
+    if (mask == 0ull) return;
+    const unsigned lane = __lane_id();
+    if (pred) win[q * 128 + fill[q] + (unsigned)__popcll(mask & ((1ull << lane) - 1ull))] = id;
+    fill[q] += (unsigned)__popcll(mask);
+    if (fill[q] >= 64u) {
+      flush(q, qidx, ids, 64u);
+      const unsigned rest = fill[q] - 64u;  // < 64: move them to the front of the window
+      const unsigned v = lane < rest ? win[q * 128 + 64 + lane] : 0u;
+      if (lane < rest) win[q * 128 + lane] = v;
+      fill[q] = rest;
+    }
+  }
+  RT_DEV void finish(int q, int qidx, unsigned* __restrict__ ids) { if (fill[q]) { flush(q, qidx, ids, fill[q]); fill[q] = 0u; } }
+};
+
 // owned-pixel index -> raster pixel (x, y) and keyed pixel index inside the sample bounds
 RT_DEV void owned_pixel(const FrameParams& fp, unsigned long long k, int& x, int& y, unsigned long long& pixel_index) {
   const unsigned W = (unsigned)(fp.sb_x1 - fp.sb_x0);
@@ -1337,7 +1380,7 @@ struct SingleLambertT {
   RT_DEV void build(const DScene& sc, int mat, SurfaceInteraction& si) {  // matte.rs:37-62 with sigma == 0 and no bump map
     const int kd = sc.materials[mat].slot[0];
     const DTexture& t = sc.textures[kd];
-    if (TEXTURED && t.kind != RT_TEX_CONST && !RT_DBG(sc, 1)) r = clamp_pos(tex_eval(sc, kd, si));
+    if (TEXTURED && t.kind != RT_TEX_CONST && !RT_DBG(sc, 1)) r = clamp_pos(tex_eval_leaf(sc, kd, si));
     else r = (TEXTURED && t.kind != RT_TEX_CONST) ? mkc(0.75f, 0.75f, 0.75f) : clamp_pos(mkc(t.v[0], t.v[1], t.v[2]));
     has = !is_black(r);
     ss = si.ssb; ns = si.sh_n; ng = si.hit.n; ts = cross(si.sh_n, ss);  // Bsdf::new, bsdf/mod.rs:77-91 (ssb = normalize(si.sh_dpdu))
@@ -1566,16 +1609,23 @@ RT_DEVN int instance_fill_interaction(const DScene& sc, unsigned hit_id, float o
 #ifndef RT_SHADE0_MIN_WAVES
 #define RT_SHADE0_MIN_WAVES 2
 #endif
+#ifndef RT_SHADE3_MIN_WAVES  // the Lambert front-end under any light (k_shade<3>)
+#define RT_SHADE3_MIN_WAVES 2
+#endif
 // GENERAL (generic front-end only): some emitter triangle carries an alpha mask, so Shape::pdf_wi's re-intersection evaluates it; such scenes shade
 // every vertex through k_shade<0, true>, every other scene never instantiates the mask evaluator in a shade kernel.
 template <int MODE, bool GENERAL = false>
-__global__ void __launch_bounds__(256, MODE == 1 ? RT_SHADE_MIN_WAVES : RT_SHADE0_MIN_WAVES) k_shade(DScene sc, FrameParams fp, PassState ps) {
+__global__ void __launch_bounds__(256, MODE == 1 ? RT_SHADE_MIN_WAVES : (MODE == 3 && !GENERAL ? RT_SHADE3_MIN_WAVES : RT_SHADE0_MIN_WAVES)) k_shade(DScene sc, FrameParams fp, PassState ps) {
   QView qv; if (ps.q_in) qv.init(ps.q_in, ps.cnt_in, ps.shard_cap);
   unsigned first = 0, count = ps.q_in ? qv.total() : ps.cap;  // no queue: bounce 0 of a pass whose samples are all traced
   if (MODE != 1 && ps.range) { first = ps.range[0]; count = ps.range[1]; }
   const unsigned stride = gridDim.x * blockDim.x;
   unsigned n_shaded = 0;
   const DScene& gsc = *sc.self;  // what out-of-line functions get: the scene record in device memory, not a private copy of the kernel argument
+#if RT_WAVE_QUEUES
+  __shared__ unsigned s_win[4 * (MODE == 1 ? 3 : 4) * 128];  // (256 lanes = 4 waves)
+  WaveQueues<(MODE == 1 ? 3 : 4)> wq; wq.init(s_win, ps.cnt_out, ps.shard_cap);
+#endif
 #ifdef RT_ABLATE
   unsigned long long stamp_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, stamp_last = clock64();
 #endif
@@ -1665,7 +1715,7 @@ __global__ void __launch_bounds__(256, MODE == 1 ? RT_SHADE_MIN_WAVES : RT_SHADE
             const DLight& light = sc.lights[light_num];
             // ---- estimate_direct (integrator/mod.rs:222-318), light-sampling half
             rgb3 ld1 = mkc(0, 0, 0); f3 sh_dir = mk3(0, 0, 0);
-            LiSample ls = (MODE == 1) ? area_light_sample_li(sc, light, si.hit, u_light) : light_sample_li<GENERAL>(gsc, light, si.hit, u_light);
+            LiSample ls = (MODE == 1) ? area_light_sample_li(sc, light, si.hit, u_light) : light_sample_li_full<GENERAL>(gsc, light, si.hit, u_light);
             if (ls.pdf > 0.0f && !is_black(ls.li)) {
               rgb3 f = bsdf.f(si.hit.wo, ls.wi, nonspec) * fabsf(dot(ls.wi, si.sh_n));
               float scattering_pdf = (MODE != 1 && light_is_delta(light)) ? 0.0f : bsdf.pdf(si.hit.wo, ls.wi, nonspec);  // read by the power heuristic only: a delta light has none
@@ -1747,6 +1797,15 @@ __global__ void __launch_bounds__(256, MODE == 1 ? RT_SHADE_MIN_WAVES : RT_SHADE
     }
     RT_STAMP(6);  // continuation sample, spawn, state stores
     constexpr int NQ = MODE == 1 ? 3 : 4;  // area lights only: every MIS ray needs its closest hit
+#if RT_WAVE_QUEUES
+    wq.push(0, 0, ps.q_out, cont, pid);
+    wq.push(1, 1, ps.q_shadow, want_shadow, pid);
+    wq.push(2, 2, ps.q_mis, want_mis && !mis_occlusion_only, pid);
+    if (NQ == 4) wq.push(3, 3, ps.q_misany, want_mis && mis_occlusion_only, pid);
+  }
+  wq.finish(0, 0, ps.q_out); wq.finish(1, 1, ps.q_shadow); wq.finish(2, 2, ps.q_mis);
+  if (MODE != 1) wq.finish(3, 3, ps.q_misany);
+#else
     const int ci[4] = {0, 1, 2, 3}; const bool pr[4] = {cont, want_shadow, want_mis && !mis_occlusion_only, want_mis && mis_occlusion_only}; unsigned slot[4];
     block_push<NQ>(ps.cnt_out, ps.shard_cap, ci, pr, slot);
     if (cont) ps.q_out[slot[0]] = pid;
@@ -1754,6 +1813,7 @@ __global__ void __launch_bounds__(256, MODE == 1 ? RT_SHADE_MIN_WAVES : RT_SHADE
     if (pr[2]) ps.q_mis[slot[2]] = pid;
     if (NQ == 4 && pr[3]) ps.q_misany[slot[3]] = pid;
   }
+#endif
   for (int off = 32; off > 0; off >>= 1) n_shaded += __shfl_down(n_shaded, off);
   if ((threadIdx.x & 63u) == 0u && n_shaded) atomicAdd(&ps.stats[ST_SHADED + (MODE == 1 ? 0 : (MODE == 3 ? 1 : (MODE == 5 || MODE == 6 ? 2 : 3)))], (unsigned long long)n_shaded);
 #ifdef RT_ABLATE
@@ -1810,7 +1870,7 @@ __global__ void __launch_bounds__(256) k_resolve(DScene sc, PassState ps) {
         if (__float_as_uint(h4.y) == 0u) li = infinite_le(sc, light, wi);
       } else {
         const int prim = __float_as_int(h4.y);
-        if (GENERAL && sc.n_instances != 0u && prim >= 0 && (unsigned)prim >= sc.n_top_prims) {  // a hit inside an object instance: objects hold no emitters
+        if (GENERAL && sc.n_instances != 0u && prim >= 0 && (unsigned)prim >= sc.n_top_prims) {  // a hit inside an object instance: an emitter there is in no light list (api.rs:954-964), so it is never the sampled light
         } else if (prim >= 0) {  // integrator/mod.rs:293-307: emitted radiance only if the hit emitter IS the sampled light
           if (GENERAL && tri_light(sc.tri_p, prim) == light_num && (tri_flags(sc.tri_p, prim) & RT_FLAG_SPHERE)) {
             float4 o4 = m->o;
@@ -1930,9 +1990,9 @@ __global__ void __launch_bounds__(256) k_tri_records(DScene sc, float4* __restri
   } else { r[3] = make_float4(g.n.x, g.n.y, g.n.z, 0.0f); r[4] = z; r[5] = z; }
   r[6] = make_float4(g.dpdu.x, g.dpdu.y, g.dpdu.z, 0.0f); r[7] = make_float4(g.dpdv.x, g.dpdv.y, g.dpdv.z, 0.0f);
 }
-__global__ void __launch_bounds__(256) k_light_consts(DScene sc, DLight* __restrict__ lights) {
+__global__ void __launch_bounds__(256) k_light_consts(DScene sc, DLight* __restrict__ lights, int n_all /* sampled lights + unlisted emitters */) {
   const int j = (int)(blockIdx.x * blockDim.x + threadIdx.x);
-  if (j >= sc.n_lights) return;
+  if (j >= n_all) return;
   DLight& l = lights[j];
   l.nrm[0] = l.nrm[1] = l.nrm[2] = 0.0f; l.inv_area = 0.0f;
   if (l.kind != 0) return;
@@ -2060,7 +2120,7 @@ __global__ void __launch_bounds__(128) k_lightdist_contrib(DScene sc, const unsi
       Interaction intr;
       intr.p = bounds_lerp(vmn, vmx, mk3(halton[5 * i], halton[5 * i + 1], halton[5 * i + 2]));
       intr.p_error = mk3(0, 0, 0); intr.wo = mk3(1, 0, 0); intr.n = mk3(0, 0, 0);
-      LiSample s = light_sample_li<GENERAL>(*sc.self, light, intr, mk2(halton[5 * i + 3], halton[5 * i + 4]));
+      LiSample s = light_sample_li_full<GENERAL>(*sc.self, light, intr, mk2(halton[5 * i + 3], halton[5 * i + 4]));
       if (s.pdf > 0.0f) contrib += lum_y(s.li) / s.pdf;
     }
   }

@@ -405,16 +405,22 @@ struct PbrtLoader {
     float L[3] = {1, 1, 1}, sc[3] = {1, 1, 1}; bool emit = false, two_sided = false;
     if (!gs.area_light.empty()) {
       if (gs.area_light != "area" && gs.area_light != "diffuse") return fail_("area light \"" + gs.area_light + "\" unknown");
-      // the reference keeps such a light out of the scene's light list (api.rs:955-957): it would glow when seen and never be sampled
-      if (in_instance) return fail_("area lights inside an object definition are not supported");
       gs.area_light_params.one_rgb("L", L); gs.area_light_params.one_rgb("scale", sc); two_sided = gs.area_light_params.one_bool("twosided", false); emit = true;
       for (int k = 0; k < 3; ++k) L[k] *= sc[k];
+    }
+    // Inside an object definition the shapes keep their area light - they glow when a camera ray or a specular bounce reaches them - but the light never
+    // enters the scene's list (api.rs:954-964: `area_lights` is dropped when there is a current instance): an emitter that nothing samples
+    int32_t unlisted = -1;
+    if (emit && in_instance) {
+      unlisted = rtxh_scene_add_emitter(scene, L, two_sided ? 1 : 0);
+      if (unlisted < 0) return fail_(rtxh_last_error());
     }
     for (size_t t = 0; t < nt; ++t) {
       const int32_t tri_index = (int32_t)(soup.idx.size() / 3);
       for (int k = 0; k < 3; ++k) soup.idx.push_back((int32_t)(v0 + vi[3 * t + k]));
       soup.tri_mat.push_back(mat); soup.tri_flags.push_back(flags); soup.tri_alpha.push_back(alpha_tex); soup.tri_alpha.push_back(shadow_alpha_tex);
-      if (emit) {
+      if (unlisted >= 0) soup.tri_light.push_back(-2 - unlisted);
+      else if (emit) {
         if (rtxh_scene_add_light(scene, RT_LIGHT_DIFFUSE_AREA, tri_index, L, two_sided ? 1 : 0, nullptr, -1, nullptr, nullptr) < 0) return fail_(rtxh_last_error());
         soup.tri_light.push_back(n_lights++);
       } else soup.tri_light.push_back(-1);
@@ -447,6 +453,13 @@ struct PbrtLoader {
         const int k = rtxh_scene_add_object(scene, o.P.data(), (int32_t)o.n_verts(), o.idx.data(), (int32_t)(o.idx.size() / 3), o.any_n ? o.N.data() : nullptr,
                                             o.any_uv ? o.UV.data() : nullptr, o.any_s ? o.S.data() : nullptr, o.tri_mat.data(), o.tri_flags.data());
         if (k < 0) return fail_(rtxh_last_error());
+        bool emits = false;
+        for (int32_t l : o.tri_light) emits = emits || l <= -2;
+        if (emits) {
+          std::vector<int32_t> em(o.tri_light.size());
+          for (size_t t = 0; t < em.size(); ++t) em[t] = o.tri_light[t] <= -2 ? -2 - o.tri_light[t] : -1;
+          if (rtxh_scene_object_emitters(scene, k, em.data()) != RT_OK) return fail_(rtxh_last_error());
+        }
         id = object_ids.emplace(name, k).first;
       }
       if (rtxh_scene_add_instance(scene, id->second, &ctm.m.a[0][0], &ctm.inv.a[0][0]) < 0) return fail_(rtxh_last_error());
@@ -478,7 +491,7 @@ struct PbrtLoader {
     const uint8_t toggle = swaps_handedness(ctm.m) ? RT_TRI_FLIP : 0;
     for (size_t t = 0; t < o.idx.size() / 3; ++t) {
       for (int k = 0; k < 3; ++k) world.idx.push_back((int32_t)(v0 + o.idx[3 * t + k]));
-      world.tri_mat.push_back(o.tri_mat[t]); world.tri_light.push_back(-1); world.tri_flags.push_back((uint8_t)(o.tri_flags[t] ^ toggle));
+      world.tri_mat.push_back(o.tri_mat[t]); world.tri_light.push_back(o.tri_light[t]); world.tri_flags.push_back((uint8_t)(o.tri_flags[t] ^ toggle));  // (an emitter of the object stays unlisted: -2 - k)
       world.tri_alpha.push_back(o.tri_alpha[2 * t]); world.tri_alpha.push_back(o.tri_alpha[2 * t + 1]);
     }
     return true;

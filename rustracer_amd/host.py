@@ -187,10 +187,14 @@ class HostScene:
         for sp in getattr(desc, "spheres", []):
             _check(L.rtxh_scene_add_quadric(self.h, int(getattr(sp, "kind", 0)), _p(sp.o2w), _p(sp.w2o), C.c_float(sp.radius), C.c_float(sp.z_min), C.c_float(sp.z_max),
                                             C.c_float(sp.phi_max), int(sp.reverse_orientation), sp.material, sp.light), "add_quadric")
-        for o in getattr(desc, "objects", []):
+        for rgb, two_sided in getattr(desc, "emitters", []):
+            _check(L.rtxh_scene_add_emitter(self.h, _p(np.float32(rgb)), int(two_sided)), "add_emitter")
+        for k, o in enumerate(getattr(desc, "objects", [])):
             self._keep += (o,)
             _check(L.rtxh_scene_add_object(self.h, _p(o.P), o.P.shape[0], _p(o.idx, C.c_int32), o.idx.shape[0], _p(o.N), _p(o.UV), _p(o.S),
                                            _p(o.mat, C.c_int32), _p(o.flags, C.c_uint8)), "add_object")
+            if getattr(o, "emit", None) is not None:
+                _check(L.rtxh_scene_object_emitters(self.h, k, _p(o.emit, C.c_int32)), "object_emitters")
         for i in getattr(desc, "instances", []):
             _check(L.rtxh_scene_add_instance(self.h, i.obj, _p(i.o2w), _p(i.w2o)), "add_instance")
         for l in desc.lights:
@@ -370,9 +374,10 @@ _TABLES = {"textures": (0, _TEXTURE_DT), "materials": (1, _MATERIAL_DT), "lights
            "UV": (5, np.dtype(("<f4", 2))), "S": (6, np.dtype(("<f4", 3))), "indices": (7, np.dtype(("<i4", 3))), "tri_material": (8, np.dtype("<i4")),
            "tri_light": (9, np.dtype("<i4")), "tri_flags": (10, np.dtype("u1")), "env_func": (11, np.dtype("<f4")), "env_cdf": (12, np.dtype("<f4")),
            "env_row_int": (13, np.dtype("<f4")), "env_marg_cdf": (14, np.dtype("<f4")),
-           "instances": (15, np.dtype([("object", "<i4"), ("o2w", "<f4", (4, 4)), ("w2o", "<f4", (4, 4))]))}
+           "instances": (15, np.dtype([("object", "<i4"), ("o2w", "<f4", (4, 4)), ("w2o", "<f4", (4, 4))])),
+           "emitters": (16, np.dtype([("rgb", "<f4", (3,)), ("two_sided", "<i4")]))}
 _OBJECT_TABLES = {"P": (0, np.dtype(("<f4", 3))), "N": (1, np.dtype(("<f4", 3))), "UV": (2, np.dtype(("<f4", 2))), "S": (3, np.dtype(("<f4", 3))),
-                  "indices": (4, np.dtype(("<i4", 3))), "tri_material": (5, np.dtype("<i4")), "tri_flags": (6, np.dtype("u1"))}
+                  "indices": (4, np.dtype(("<i4", 3))), "tri_material": (5, np.dtype("<i4")), "tri_flags": (6, np.dtype("u1")), "tri_emitter": (7, np.dtype("<i4"))}
 
 
 def scene_table(handle, name):

@@ -244,7 +244,9 @@ class _Writer:
             t0 = 0
             while t0 < nt:
                 t1 = t0
-                while t1 + 1 < nt and ob.mat[t1 + 1] == ob.mat[t0] and ob.flags[t1 + 1] == ob.flags[t0] and ob.idx[t1 + 1].min() >= ob.idx[t0:t1 + 1].min():
+                emit = getattr(ob, "emit", None)
+                while (t1 + 1 < nt and ob.mat[t1 + 1] == ob.mat[t0] and ob.flags[t1 + 1] == ob.flags[t0] and ob.idx[t1 + 1].min() >= ob.idx[t0:t1 + 1].min()
+                       and (emit is None or emit[t1 + 1] == emit[t0])):
                     t1 += 1
                 tri = ob.idx[t0:t1 + 1]
                 v0, v1 = int(tri.min()), int(tri.max()) + 1
@@ -253,6 +255,9 @@ class _Writer:
                 o.append(f'    NamedMaterial "{self.material(int(ob.mat[t0]))}"')
                 if flags & sd.TRI_FLIP:
                     o.append("    ReverseOrientation")
+                if emit is not None and emit[t0] >= 0:  # an area light inside an object definition: shown, never sampled (rc/api.rs:954-964)
+                    rgb, two_sided = d.emitters[int(emit[t0])]
+                    o.append(f'    AreaLightSource "diffuse" "rgb L" [{_nums(rgb)}] "bool twosided" "{"true" if two_sided else "false"}"')
                 shape = f'    Shape "trianglemesh" "integer indices" [{" ".join(str(int(x)) for x in (tri - v0).reshape(-1))}] "point P" [{_nums(ob.P[v0:v1])}]'
                 if flags & sd.TRI_HAS_N:
                     shape += f' "normal N" [{_nums(ob.N[v0:v1])}]'

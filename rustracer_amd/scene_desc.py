@@ -140,6 +140,7 @@ class ObjectDef:
     S: Optional[np.ndarray]
     mat: np.ndarray
     flags: np.ndarray
+    emit: Optional[np.ndarray] = None  # per triangle: index into SceneDesc.emitters or -1 (None: no triangle of the object emits)
 
 
 @dataclass
@@ -166,6 +167,7 @@ class SceneDesc:
         self.mipmaps: List[MipImage] = []
         self.spheres: List[SphereShape] = []
         self.objects: List[ObjectDef] = []
+        self.emitters = []  # (rgb, two_sided) of emitters that are in no light list (emitting meshes inside object definitions)
         self.instances: List[InstanceDef] = []
         self.materials: List[Material] = []
         self.lights: List[Light] = []
@@ -364,9 +366,11 @@ class SceneDesc:
 
     def add_object(self, meshes) -> int:
         """ObjectBegin ... ObjectEnd (rc/api.rs:1019-1051): triangle meshes in OBJECT space - an iterable of dicts with the keys of `add_mesh`
-        (P, idx, material, N, UV, S, reverse_orientation; no emission, no alpha masks). Returns the object's index; nothing is rendered until
+        (P, idx, material, N, UV, S, reverse_orientation, emission, two_sided; no alpha masks). A mesh with `emission` is a shape under an AreaLightSource
+        inside the object definition: it keeps its DiffuseAreaLight (it glows when a camera ray or a specular bounce reaches it) but the light never enters
+        the scene's list (rc/api.rs:954-964) - an entry of `self.emitters`, not of `self.lights`. Returns the object's index; nothing is rendered until
         `add_instance` places it."""
-        Ps, Is, Ns, UVs, Ss, mats, flags, nv0 = [], [], [], [], [], [], [], 0
+        Ps, Is, Ns, UVs, Ss, mats, flags, emits, nv0 = [], [], [], [], [], [], [], [], 0
         for m in meshes:
             P = np.ascontiguousarray(m["P"], dtype=np.float32).reshape(-1, 3)
             idx = np.ascontiguousarray(m["idx"], dtype=np.int32).reshape(-1, 3)
@@ -386,6 +390,11 @@ class SceneDesc:
             Is.append(idx + nv0)
             mats.append(np.full(nt, int(m["material"]), dtype=np.int32))
             flags.append(np.full(nt, f, dtype=np.uint8))
+            em = -1
+            if m.get("emission") is not None:
+                self.emitters.append((tuple(float(x) for x in m["emission"]), bool(m.get("two_sided", False))))
+                em = len(self.emitters) - 1
+            emits.append(np.full(nt, em, dtype=np.int32))
             nv0 += nv
         fl = np.ascontiguousarray(np.concatenate(flags), dtype=np.uint8)
         self.objects.append(ObjectDef(
@@ -393,7 +402,8 @@ class SceneDesc:
             np.ascontiguousarray(np.concatenate(Ns)) if (fl & TRI_HAS_N).any() else None,
             np.ascontiguousarray(np.concatenate(UVs)) if (fl & TRI_HAS_UV).any() else None,
             np.ascontiguousarray(np.concatenate(Ss)) if (fl & TRI_HAS_S).any() else None,
-            np.ascontiguousarray(np.concatenate(mats)), fl))
+            np.ascontiguousarray(np.concatenate(mats)), fl,
+            np.ascontiguousarray(np.concatenate(emits)) if any((e >= 0).any() for e in emits) else None))
         return len(self.objects) - 1
 
     def add_instance(self, obj: int, o2w) -> int:
