@@ -1086,7 +1086,7 @@ extern "C" int rt_render(rt_scene* s, const rt_camera* cam, const rt_film_desc* 
   auto env_log2 = [](const char* name, int dflt) { const char* e = getenv(name); return e ? std::min(30, std::max(16, atoi(e))) : dflt; };
   static const int tp_log2 = env_log2("RTX_PASS_LOG2", 28);
   static const int bp_log2 = env_log2("RTX_BATCH_LOG2", 19);
-  enum { B_PATH, B_VERT, B_BETA, B_ACC, B_SH, B_MI, B_QIN, B_QOUT, B_QSH, B_QMI, B_QMA, B_COUNT };  // grouped per-path records (rtx_kernels.h) and five queues of path ids
+  enum { B_PATH, B_VERT, B_BETA, B_ACC, B_SH, B_MI, B_QIN, B_QOUT, B_QSH, B_QMI, B_QMA, B_OCCSH, B_OCCMI, B_COUNT };  // grouped per-path records (rtx_kernels.h) and five queues of path ids
   const bool has_infinite = s->d.n_infinite > 0;
   const size_t counter_words = (size_t)(fp.max_depth + 2) * RT_NQ * RT_QSHARDS * RT_CNT_STRIDE;  // one block of {out, shadow, mis, mis-any} shard counts per bounce + raygen's
   // material binning before the generic shade kernel: per bounce {hist, cursor}[RT_BIN_MAX + 1] + the 8 count words of the sorted queue
@@ -1124,7 +1124,7 @@ extern "C" int rt_render(rt_scene* s, const rt_camera* cam, const rt_film_desc* 
     multi_batch = owned_pixels > chunk_pixels;
     struct Want { DevBuf* buf; size_t bytes; };
     std::vector<Want> want = {
-        {&s->ws[B_PATH], cap * sizeof(RayRec)}, {&s->ws[B_VERT], RT_PATHREC_SPLIT ? cap * sizeof(VertRec) : 16}, {&s->ws[B_BETA], RT_PATHREC_SPLIT == 2 ? cap * sizeof(BetaRec) : 16}, {&s->ws[B_ACC], cap * sizeof(PathAcc)}, {&s->ws[B_SH], cap * sizeof(ShadowRec)}, {&s->ws[B_MI], cap * sizeof(MisRec)},
+        {&s->ws[B_PATH], cap * sizeof(RayRec)}, {&s->ws[B_VERT], RT_PATHREC_SPLIT ? cap * sizeof(VertRec) : 16}, {&s->ws[B_BETA], RT_PATHREC_SPLIT == 2 ? cap * sizeof(BetaRec) : 16}, {&s->ws[B_ACC], cap * sizeof(PathAcc)}, {&s->ws[B_SH], cap * sizeof(ShadowRec)}, {&s->ws[B_MI], cap * sizeof(MisRec)}, {&s->ws[B_OCCSH], cap}, {&s->ws[B_OCCMI], cap},
         {&s->ws[B_QIN], szq}, {&s->ws[B_QOUT], szq}, {&s->ws[B_QSH], szq}, {&s->ws[B_QMI], szq}, {&s->ws[B_QMA], has_infinite ? szq : 16},
         {&s->counters, counter_words * 4}, {&s->stats, (size_t)ST_COUNT * 8}, {&s->film_acc, (size_t)cw * ch * 16}, {&s->own_acc, (size_t)chunk_pixels * 16},
         {&s->filter_table, 1024}, {&s->scrambles[0], (size_t)chunk_pixels * 3 * dims * 4}, {&s->perms[0], (size_t)(chunk_pixels * table_bytes_per_pixel)},
@@ -1159,6 +1159,7 @@ extern "C" int rt_render(rt_scene* s, const rt_camera* cam, const rt_film_desc* 
   ps.spp = spp; ps.spp_log2 = spp_log2; ps.dims = dims;
   ps.ray = s->ws[B_PATH].as<RayRec>(); ps.vert = RT_PATHREC_SPLIT ? s->ws[B_VERT].as<VertRec>() : (VertRec*)s->ws[B_PATH].p;
   ps.bet = RT_PATHREC_SPLIT == 2 ? s->ws[B_BETA].as<BetaRec>() : (BetaRec*)ps.vert; ps.acc = s->ws[B_ACC].as<PathAcc>(); ps.sh = s->ws[B_SH].as<ShadowRec>(); ps.mi = s->ws[B_MI].as<MisRec>();
+  ps.occ_sh = s->ws[B_OCCSH].as<unsigned char>(); ps.occ_mi = s->ws[B_OCCMI].as<unsigned char>();
   unsigned* q_a = s->ws[B_QIN].as<unsigned>(); unsigned* q_b = s->ws[B_QOUT].as<unsigned>();
   ps.q_shadow = s->ws[B_QSH].as<unsigned>(); ps.q_mis = s->ws[B_QMI].as<unsigned>(); ps.q_misany = s->ws[B_QMA].as<unsigned>();
   ps.own_acc = s->own_acc.as<float4>(); ps.shard_cap = shard_cap; ps.stats = s->stats.as<unsigned long long>();
@@ -1170,10 +1171,10 @@ extern "C" int rt_render(rt_scene* s, const rt_camera* cam, const rt_film_desc* 
   {
     constexpr unsigned PR = sizeof(RayRec) / 16, VR = sizeof(VertRec) / 16, SR = sizeof(ShadowRec) / 16, MR = sizeof(MisRec) / 16;
     io_path.ray_o = &ps.ray->o; io_path.ray_d = &ps.ray->d; io_path.ray_stride = PR; io_path.hits = &ps.vert->hit; io_path.hit_stride = VR; io_path.hit_b2 = 1;
-    io_shadow.ray_o = &ps.sh->o; io_shadow.ray_d = &ps.sh->d; io_shadow.ray_stride = SR; io_shadow.occluded = &ps.mi->occ; io_shadow.occ_stride = sizeof(MisRec) / 4;
+    io_shadow.ray_o = &ps.sh->o; io_shadow.ray_d = &ps.sh->d; io_shadow.ray_stride = SR; io_shadow.occluded = (unsigned*)ps.occ_sh; io_shadow.occ_stride = 0;
     io_shadow.shadow_masks = 1; io_shadow.lacc = &ps.acc->lacc; io_shadow.lacc_stride = sizeof(PathAcc) / 16; io_shadow.direct_add = &ps.sh->add; io_shadow.add_stride = SR;
     io_mis.ray_o = &ps.mi->o; io_mis.ray_d = &ps.mi->d; io_mis.ray_stride = MR; io_mis.hits = &ps.mi->hit; io_mis.hit_stride = MR; io_mis.hit_b2 = 0;
-    io_mis_any = io_mis; io_mis_any.shadow_masks = 0; io_mis_any.hits = nullptr; io_mis_any.occluded = (unsigned*)&ps.mi->hit.y; io_mis_any.occ_stride = sizeof(MisRec) / 4;
+    io_mis_any = io_mis; io_mis_any.shadow_masks = 0; io_mis_any.hits = nullptr; io_mis_any.occluded = (unsigned*)ps.occ_mi; io_mis_any.occ_stride = 0;
   }
   const bool count = (flags & RT_FLAG_COUNT_TRAVERSAL) != 0;
   const unsigned pgrid = (unsigned)s->n_cu * 8u;

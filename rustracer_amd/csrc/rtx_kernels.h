@@ -54,6 +54,9 @@ struct PassState {
   const unsigned* scrambles;        // [pixel][3*dims]
   const unsigned short* perms;      // [pixel][2*dims][spp]
   RayRec* ray; VertRec* vert; BetaRec* bet; PathAcc* acc; ShadowRec* sh; MisRec* mi;
+  // one byte per path each: the shadow ray of a vertex that also has an MIS ray in flight was blocked / its occlusion-only MIS ray was blocked. Dense, so
+  // that k_resolve learns from two bytes that a vertex contributes nothing (most vertices of an interior) without touching its 128-byte MisRec
+  unsigned char* occ_sh; unsigned char* occ_mi;
   // queues of path ids, each split into RT_QSHARDS shards (shard = blockIdx & 7 of the producer, region
   // [shard * shard_cap, ...)) with its own counter word: a single word sustains only ~88 returning
   // atomics per microsecond. Every bounce has its own zero-initialised block of counters, so nothing has to be
@@ -166,8 +169,10 @@ RT_DEV void block_push(unsigned* counters, unsigned shard_cap, const int* queue_
 // wave of the workgroup waiting for the slowest one and then for the atomic. Here a wave collects the ids it appends in its own LDS window (no barrier: the
 // window is the wave's), and whenever a queue's window holds 64 of them it reserves 64 slots with one atomic and writes them out as one coalesced store.
 // The order of ids inside a queue changes (it is arbitrary anyway: paths are independent), the ids and their number do not.
+// Measured (one box, interleaved A/B, S1 / S3 / S4 shade ms): block_push 381 / 192 / 4109, wave windows 431 / 196 / 4178 - the LDS round trip of every id and the
+// compaction cost more than the barriers they remove; with 64- or 128-lane workgroups on top 411 / 416 (S1). Kept as a build option (-DRT_WAVE_QUEUES=1), off.
 #ifndef RT_WAVE_QUEUES
-#define RT_WAVE_QUEUES 1
+#define RT_WAVE_QUEUES 0
 #endif
 template <int NQ>
 struct WaveQueues {
@@ -581,7 +586,7 @@ struct LdsSrc {
 struct TraceIO {
   const float4* ray_o; const float4* ray_d; unsigned ray_stride;  // (o | t_max), (d | flag)
   float4* hits; unsigned hit_stride; int hit_b2;  // closest hit: (t, prim, b0, b1), or (b2, prim, b0, b1) inside a frame (shade needs the three barycentrics, not t)
-  unsigned* occluded; unsigned occ_stride;        // any hit: 1 / 0
+  unsigned* occluded; unsigned occ_stride;        // any hit: 1 / 0 (occ_stride 0: one BYTE per ray at ((unsigned char*)occluded)[pid] - the frame's dense result arrays, PassState::occ_sh / occ_mi)
   // any hit inside a frame: a shadow ray with d.w != 0 belongs to a vertex without MIS ray - its `direct_add` goes into lacc right here if unoccluded
   float4* lacc; unsigned lacc_stride; const float4* direct_add; unsigned add_stride;
   // any hit on scenes with masked meshes: 1 = Triangle::intersect_p's test (alpha and shadowalpha, mesh.rs:534-582: shadow rays), 0 = Triangle::intersect's
@@ -596,7 +601,8 @@ RT_DEV void trace_write_any(float4* __restrict__ lacc, size_t ls, const float4* 
   // direct_add) is applied right here if the ray is unoccluded. Otherwise the flag is left for k_resolve.
   if (lacc != nullptr && dw != 0.0f) {
     if (!found) { float4 a = direct_add[pid * as]; float4 l = lacc[pid * ls]; lacc[pid * ls] = make_float4(l.x + a.x, l.y + a.y, l.z + a.z, l.w); }
-  } else occluded[pid * os] = found ? 1u : 0u;
+  } else if (os == 0) ((unsigned char*)occluded)[pid] = found ? (unsigned char)1 : (unsigned char)0;
+  else occluded[pid * os] = found ? 1u : 0u;
 }
 
 // BLOCK threads per workgroup, DEPTH = to-visit stack entries per lane (the host picks the
@@ -1609,6 +1615,11 @@ RT_DEVN int instance_fill_interaction(const DScene& sc, unsigned hit_id, float o
 #ifndef RT_SHADE0_MIN_WAVES
 #define RT_SHADE0_MIN_WAVES 2
 #endif
+// k_shade<1>: the next vertex's records requested one iteration ahead (needs -DRT_SHADE_MIN_WAVES=3: 167 VGPRs, two spilled values). Measured, interleaved A/B
+// on S1: shade 380 -> 398 ms. The waves are not short of loads in flight; the extra registers and the longer loop head cost more. Off.
+#ifndef RT_SHADE_PREFETCH
+#define RT_SHADE_PREFETCH 0
+#endif
 #ifndef RT_SHADE3_MIN_WAVES  // the Lambert front-end under any light (k_shade<3>)
 #define RT_SHADE3_MIN_WAVES 2
 #endif
@@ -1629,6 +1640,19 @@ __global__ void __launch_bounds__(256, MODE == 1 ? RT_SHADE_MIN_WAVES : (MODE ==
 #ifdef RT_ABLATE
   unsigned long long stamp_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, stamp_last = clock64();
 #endif
+  // Software pipelining of the vertex records (MODE 1, where 17 more registers still fit three waves per SIMD): the path id of the vertex two iterations
+  // ahead and the records of the next one are requested at the top of an iteration, so the two dependent round trips queue -> id -> records overlap the
+  // shading of the current vertex instead of opening the next iteration. Paths are distinct, so nothing the current vertex stores is among them.
+  constexpr bool PREFETCH = MODE == 1 && RT_SHADE_PREFETCH != 0;
+  unsigned pf_pid = 0, pf_pid2 = 0; float4 pf_d4 = make_float4(0, 0, 0, 0), pf_h4 = pf_d4, pf_b4 = pf_d4, pf_l4 = pf_d4; 
+  if (PREFETCH) {
+    const unsigned i0 = first + blockIdx.x * blockDim.x + threadIdx.x, i1 = i0 + stride;
+    if (i0 < count) {
+      pf_pid = ps.q_in ? qv.get(i0) : i0;
+      pf_d4 = ps.ray[pf_pid].d; pf_h4 = ps.vert[pf_pid].hit; pf_b4 = ps.bet[pf_pid].beta; pf_l4 = ps.acc[pf_pid].lacc;
+    }
+    if (i1 < count) pf_pid2 = ps.q_in ? qv.get(i1) : i1;
+  }
   for (unsigned base = first + blockIdx.x * blockDim.x; base < count; base += stride) {
     const unsigned i = base + threadIdx.x;
     const bool lane_live = i < count;
@@ -1636,11 +1660,20 @@ __global__ void __launch_bounds__(256, MODE == 1 ? RT_SHADE_MIN_WAVES : (MODE ==
     RT_STAMP(7);  // loop overhead / previous iteration's tail
     bool cont = false, want_shadow = false, want_mis = false, mis_occlusion_only = false;
     unsigned pid = 0;
+    float4 c_d4 = pf_d4, c_h4 = pf_h4, c_b4 = pf_b4, c_l4 = pf_l4; const unsigned c_pid = pf_pid;
+    if (PREFETCH) {  // next vertex's records (its id arrived an iteration ago), and the id of the one after
+      const unsigned i1 = i + stride, i2 = i1 + stride;
+      pf_pid = pf_pid2;
+      if (i1 < count) { pf_d4 = ps.ray[pf_pid].d; pf_h4 = ps.vert[pf_pid].hit; pf_b4 = ps.bet[pf_pid].beta; pf_l4 = ps.acc[pf_pid].lacc; }
+      if (i2 < count) pf_pid2 = ps.q_in ? qv.get(i2) : i2;
+    }
     if (lane_live) {
-      pid = ps.q_in ? qv.get(i) : i;
+      pid = PREFETCH ? c_pid : (ps.q_in ? qv.get(i) : i);
       const unsigned sl = pid / ps.n_pixels, pix = pid - sl * ps.n_pixels, s = ps.s0 + sl;
       RayRec* const prec = ps.ray + pid; VertRec* const pvert = ps.vert + pid; PathAcc* const pacc = ps.acc + pid;
-      float4 d4 = prec->d, h4 = pvert->hit, b4 = ps.bet[pid].beta, l4 = pacc->lacc;
+      float4 d4, h4, b4, l4;
+      if (PREFETCH) { d4 = c_d4; h4 = c_h4; b4 = c_b4; l4 = c_l4; }
+      else { d4 = prec->d; h4 = pvert->hit; b4 = ps.bet[pid].beta; l4 = pacc->lacc; }
       f3 ray_d = mk3(d4.x, d4.y, d4.z);
       rgb3 beta = mkc(b4.x, b4.y, b4.z), L = mkc(l4.x, l4.y, l4.z);
       float eta_scale = b4.w;
@@ -1648,7 +1681,7 @@ __global__ void __launch_bounds__(256, MODE == 1 ? RT_SHADE_MIN_WAVES : (MODE ==
       int bounces = (int)(st & 0xffu); bool specular_bounce = (st >> 8) & 1u;
       PathSampler smp; smp.tb = tables_of(ps); smp.pix = pix; smp.s = s; smp.c1 = (int)((st >> 9) & 15u); smp.c2 = (int)((st >> 13) & 15u);
       int x, y; unsigned long long pixel_index; owned_pixel(fp, fp.chunk_first + pix, x, y, pixel_index);
-      smp.rng.state = pacc->rng;
+      smp.rng.state = pacc->rng;  // (not prefetched: its two registers would cost the kernel its third wave; it is read late)
       smp.rng.inc = ((pixel_index * (unsigned long long)ps.spp + s + (1ull << 32)) << 1u) | 1ull;
       int prim = __float_as_int(h4.y);
       const bool found = prim >= 0;
@@ -1758,6 +1791,7 @@ __global__ void __launch_bounds__(256, MODE == 1 ? RT_SHADE_MIN_WAVES : (MODE ==
               m->b = make_float4(f2v.r, f2v.g, f2v.b, w2);
               m->c = make_float4(beta.r, beta.g, beta.b, spdf2);
               m->flags = (want_shadow ? RT_PEND_SHADOW : 0u) | 2u | ((unsigned)light_num << 2) | (mis_occlusion_only ? RT_PEND_MIS_ANY : 0u);
+              if (!want_shadow) ps.occ_sh[pid] = (unsigned char)1;  // no light-sampling term: as good as blocked (the any-hit kernel writes the byte of every other vertex)
             } else if (want_shadow) {  // L += beta * ((0 + Ld1) / pick_pdf) if unoccluded, applied by the any-hit kernel
               rgb3 add = beta * vdiv(mkc(0, 0, 0) + ld1, light_pdf);
               ps.sh[pid].add = make_float4(add.r, add.g, add.b, 0.0f);
@@ -1855,19 +1889,22 @@ __global__ void __launch_bounds__(256) k_resolve(DScene sc, PassState ps) {
   const unsigned stride = gridDim.x * blockDim.x;
   for (unsigned i = blockIdx.x * blockDim.x + threadIdx.x; i < count; i += stride) {
     const unsigned pid = i < n_closest ? qv.get(i) : qa.get(i - n_closest);
+    const bool shadow_blocked = ps.occ_sh[pid] != 0;
+    const bool mis_blocked = i >= n_closest && ps.occ_mi[pid] != 0;  // (an occlusion-only MIS ray)
+    if (shadow_blocked && mis_blocked) continue;  // ld = 0: L + beta * (0 / pick_pdf) = L
     const MisRec* const m = ps.mi + pid;
     const unsigned pend = m->flags;
     float4 a = m->a, c = m->c;
     rgb3 ld = mkc(0, 0, 0);
-    if ((pend & RT_PEND_SHADOW) && m->occ == 0u) ld = ld + mkc(a.x, a.y, a.z);
+    if ((pend & RT_PEND_SHADOW) && !shadow_blocked) ld = ld + mkc(a.x, a.y, a.z);
     {
       float4 b = m->b, h4 = m->hit, d4 = m->d;
       const int light_num = (int)((pend >> 2) & 0x0fffffffu);
       const DLight& light = sc.lights[light_num];
       f3 wi = mk3(d4.x, d4.y, d4.z);
       rgb3 li = mkc(0, 0, 0);
-      if (pend & RT_PEND_MIS_ANY) {  // infinite light, occlusion only: hit.y = 1 / 0 (integrator/mod.rs:291-309: a hit surface is never this light)
-        if (__float_as_uint(h4.y) == 0u) li = infinite_le(sc, light, wi);
+      if (pend & RT_PEND_MIS_ANY) {  // infinite light, occlusion only (integrator/mod.rs:291-309: a hit surface is never this light)
+        if (!mis_blocked) li = infinite_le(sc, light, wi);
       } else {
         const int prim = __float_as_int(h4.y);
         if (GENERAL && sc.n_instances != 0u && prim >= 0 && (unsigned)prim >= sc.n_top_prims) {  // a hit inside an object instance: an emitter there is in no light list (api.rs:954-964), so it is never the sampled light

@@ -285,3 +285,4 @@ def test_multi_device_wide_filter_rows_are_summed(gpu_host):
     full, _ = h.render()
     film, _, _ = h.render_multi([0, 0, 0], chunks_per_device=1)
     assert np.allclose(film, full, rtol=2e-5, atol=1e-6)
+
