@@ -51,9 +51,21 @@ RT_DEV float fr_dielectric(float cos_theta_i, float eta_i, float eta_t) {  // :3
   float r_perp = ((eta_i * cos_theta_i) - (eta_t * cos_theta_t)) / ((eta_i * cos_theta_i) + (eta_t * cos_theta_t));
   return 0.5f * (r_parl * r_parl + r_perp * r_perp);
 }
+// the same for callers that only scale radiance by it (fresnel_eval); FresnelSpecular::sample_f, which picks reflection or transmission by it, keeps the one above
+RT_DEV float fr_dielectric_v(float cos_theta_i, float eta_i, float eta_t) {
+  cos_theta_i = clampf(cos_theta_i, -1.0f, 1.0f);
+  if (cos_theta_i <= 0.0f) { float t = eta_i; eta_i = eta_t; eta_t = t; cos_theta_i = fabsf(cos_theta_i); }
+  float sin_theta_i = sqrtf(fmaxf(1.0f - cos_theta_i * cos_theta_i, 0.0f));
+  float sin_theta_t = vdiv(eta_i, eta_t) * sin_theta_i;
+  if (sin_theta_t >= 1.0f) return 1.0f;
+  float cos_theta_t = sqrtf(fmaxf(1.0f - sin_theta_t * sin_theta_t, 0.0f));
+  float r_parl = vdiv((eta_t * cos_theta_i) - (eta_i * cos_theta_t), (eta_t * cos_theta_i) + (eta_i * cos_theta_t));
+  float r_perp = vdiv((eta_i * cos_theta_i) - (eta_t * cos_theta_t), (eta_i * cos_theta_i) + (eta_t * cos_theta_t));
+  return 0.5f * (r_parl * r_parl + r_perp * r_perp);
+}
 RT_DEVN rgb3 fr_conductor(float cos_theta_i, rgb3 eta_i, rgb3 eta_t, rgb3 k) {  // :60-82
   cos_theta_i = clampf(cos_theta_i, -1.0f, 1.0f);
-  rgb3 eta = eta_t / eta_i, eta_k = k / eta_i;
+  rgb3 eta = vdiv(eta_t, eta_i), eta_k = vdiv(k, eta_i);
   float cos2 = cos_theta_i * cos_theta_i, sin2 = 1.0f - cos2;
   rgb3 eta2 = eta * eta, eta_k2 = eta_k * eta_k;
   rgb3 t0 = eta2 - eta_k2 - sin2;
@@ -61,10 +73,10 @@ RT_DEVN rgb3 fr_conductor(float cos_theta_i, rgb3 eta_i, rgb3 eta_t, rgb3 k) {  
   rgb3 t1 = a2plusb2 + cos2;
   rgb3 a = sqrt3(0.5f * (a2plusb2 + t0));
   rgb3 t2 = 2.0f * cos_theta_i * a;
-  rgb3 r_s = (t1 - t2) / (t1 + t2);
+  rgb3 r_s = vdiv(t1 - t2, t1 + t2);
   rgb3 t3 = cos2 * a2plusb2 + sin2 * sin2;
   rgb3 t4 = t2 * sin2;
-  rgb3 r_p = r_s * (t3 - t4) / (t3 + t4);
+  rgb3 r_p = vdiv(r_s * (t3 - t4), t3 + t4);
   return 0.5f * (r_p + r_s);
 }
 
@@ -104,11 +116,11 @@ RT_DEV float schlick_weight(float cos_theta) { float m = clampf(1.0f - cos_theta
 RT_DEV float fr_schlick(float r0, float cos_theta) { return lerpf(schlick_weight(cos_theta), r0, 1.0f); }
 RT_DEV rgb3 fresnel_eval(const Lobe& l, float cos_theta_i) {  // fresnel.rs:110-136 (abs() first: quirk 7)
   const int k = l.fr_kind & 3;
-  if (k == FR_DIELECTRIC) return grey(fr_dielectric(fabsf(cos_theta_i), l.fr_ei, l.fr_et));
+  if (k == FR_DIELECTRIC) return grey(fr_dielectric_v(fabsf(cos_theta_i), l.fr_ei, l.fr_et));
   if (k == FR_CONDUCTOR) return fr_conductor(fabsf(cos_theta_i), mkc(1.0f, 1.0f, 1.0f), l.t, l.k);
   if (k == FR_DISNEY) {  // DisneyFresnel::evaluate (disney.rs:434-442): lerp(metallic, dielectric, schlick); no abs() here
     const float w = schlick_weight(cos_theta_i), m = l.fr_ei;
-    rgb3 a = grey(fr_dielectric(cos_theta_i, 1.0f, l.fr_et)), b = l.t * (1.0f - w) + mkc(1.0f, 1.0f, 1.0f) * w;
+    rgb3 a = grey(fr_dielectric_v(cos_theta_i, 1.0f, l.fr_et)), b = l.t * (1.0f - w) + mkc(1.0f, 1.0f, 1.0f) * w;
     return a * (1.0f - m) + b * m;
   }
   return mkc(1.0f, 1.0f, 1.0f);
@@ -124,8 +136,8 @@ RT_DEV float tr_d(float ax, float ay, f3 wh) {  // :576-588
   float tan2theta = tan2_theta(wh);
   if (isinf(tan2theta)) return 0.0f;
   float cos4theta = cos2_theta(wh) * cos2_theta(wh);
-  float e = (cos2_phi(wh) / (ax * ax) + sin2_phi(wh) / (ay * ay)) * tan2theta;
-  return 1.0f / (kPi * ax * ay * cos4theta * (1.0f + e) * (1.0f + e));
+  float e = (vdiv(cos2_phi(wh), ax * ax) + vdiv(sin2_phi(wh), ay * ay)) * tan2theta;
+  return vdiv(1.0f, kPi * ax * ay * cos4theta * (1.0f + e) * (1.0f + e));
 }
 RT_DEV float tr_lambda(float ax, float ay, f3 w) {  // :590-602
   float abs_tan_theta = fabsf(tan_theta(w));
@@ -134,10 +146,10 @@ RT_DEV float tr_lambda(float ax, float ay, f3 w) {  // :590-602
   float a2t2 = (alpha * abs_tan_theta) * (alpha * abs_tan_theta);
   return (-1.0f + sqrtf(1.0f + a2t2)) / 2.0f;
 }
-RT_DEV float tr_g1(float ax, float ay, f3 w) { return 1.0f / (1.0f + tr_lambda(ax, ay, w)); }
-RT_DEV float tr_g(float ax, float ay, f3 wi, f3 wo) { return 1.0f / (1.0f + tr_lambda(ax, ay, wi) + tr_lambda(ax, ay, wo)); }
+RT_DEV float tr_g1(float ax, float ay, f3 w) { return vdiv(1.0f, 1.0f + tr_lambda(ax, ay, w)); }
+RT_DEV float tr_g(float ax, float ay, f3 wi, f3 wo) { return vdiv(1.0f, 1.0f + tr_lambda(ax, ay, wi) + tr_lambda(ax, ay, wo)); }
 RT_DEV float lobe_g(const Lobe& l, f3 wi, f3 wo) { return (l.fr_kind & FR_SEPARABLE_G) ? tr_g1(l.ax, l.ay, wi) * tr_g1(l.ax, l.ay, wo) : tr_g(l.ax, l.ay, wi, wo); }
-RT_DEV float tr_pdf(float ax, float ay, f3 wo, f3 wh) { return tr_d(ax, ay, wh) * tr_g1(ax, ay, wo) * fabsf(dot(wo, wh)) / abs_cos_theta(wo); }
+RT_DEV float tr_pdf(float ax, float ay, f3 wo, f3 wh) { return vdiv(tr_d(ax, ay, wh) * tr_g1(ax, ay, wo) * fabsf(dot(wo, wh)), abs_cos_theta(wo)); }
 RT_DEV void tr_sample11(float cos_theta_, float u1, float u2, float& sx, float& sy) {  // :517-572
   if (cos_theta_ > 0.9999f) {
     float r = sqrtf(u1 / (1.0f - u1));
@@ -218,9 +230,9 @@ RT_DEV rgb3 lobe_f_inner(const Lobe& l, f3 wo, f3 wi) {
       f3 wh = wi + wo;
       if (cos_theta_o == 0.0f || cos_theta_i == 0.0f) return mkc(0, 0, 0);
       if (wh.x == 0.0f && wh.y == 0.0f && wh.z == 0.0f) return mkc(0, 0, 0);
-      wh = normalize(wh);
+      wh = vnormalize(wh);
       rgb3 fr = fresnel_eval(l, dot(wi, wh));
-      return l.r * tr_d(l.ax, l.ay, wh) * lobe_g(l, wo, wi) * fr / (4.0f * cos_theta_i * cos_theta_o);
+      return vdiv(l.r * tr_d(l.ax, l.ay, wh) * lobe_g(l, wo, wi) * fr, 4.0f * cos_theta_i * cos_theta_o);
     }
     case LB_DISNEY_DIFFUSE: {  // disney.rs:228-236
       float fo = schlick_weight(abs_cos_theta(wo)), fi = schlick_weight(abs_cos_theta(wi));
@@ -275,8 +287,8 @@ RT_DEV float lobe_pdf_inner(const Lobe& l, f3 wo, f3 wi) {
     }
     case LB_MICRO_R: {  // microfacet.rs:86-93
       if (!same_hemisphere(wo, wi)) return 0.0f;
-      f3 wh = normalize(wo + wi);
-      return tr_pdf(l.ax, l.ay, wo, wh) / (4.0f * dot(wo, wh));
+      f3 wh = vnormalize(wo + wi);
+      return vdiv(tr_pdf(l.ax, l.ay, wo, wh), 4.0f * dot(wo, wh));
     }
     case LB_MICRO_T: {  // microfacet.rs:210-226
       if (same_hemisphere(wo, wi)) return 0.0f;

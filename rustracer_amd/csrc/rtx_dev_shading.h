@@ -530,6 +530,7 @@ RT_DEV void d1_sample_continuous(const float* func, const float* cdf, float func
   x = ((float)offset + du) / (float)n;
   off = offset;
 }
+template <bool EXACT = false>
 RT_DEV void d1_sample_continuous_guided(const float* func, const float* cdf, float func_int, int n, float u, const unsigned short* guide, int glog, float& x, float& pdf, int& off) {
   const int G = 1 << glog;
   const int k = clampi((int)(u * (float)G), 0, G - 1);  // u 2^glog is exact
@@ -537,7 +538,7 @@ RT_DEV void d1_sample_continuous_guided(const float* func, const float* cdf, flo
   int offset = find_interval_le_from(cdf, n + 1, u, g0, g1 - g0);
   float du = u - cdf[offset];
   if (cdf[offset + 1] - cdf[offset] > 0.0f) du /= cdf[offset + 1] - cdf[offset];
-  pdf = func_int > 0.0f ? vdiv(func[offset], func_int) : 0.0f;
+  pdf = func_int > 0.0f ? vdiv_e<EXACT>(func[offset], func_int) : 0.0f;
   x = ((float)offset + du) / (float)n;
   off = offset;
 }
@@ -616,7 +617,7 @@ RT_DEV float area_light_pdf_li(const DScene& sc, const DLight& l, const Interact
   f3 p, n; tri_hit_point_normal_inl(sc, l.prim, h, p, n);
   return vdiv(distance_squared(ref.p, p), fabsf(dot(n, -wi)) * l.area);
 }
-template <bool GENERAL>
+template <bool GENERAL, bool EXACT = false>  // EXACT: the light-distribution build (k_lightdist_contrib), whose tables are bit-exact: correctly rounded quotients
 RT_DEVN LiSample light_sample_li(const DScene& sc, const DLight& l, Interaction ref, f2 u) {  // sc: a DScene in device memory (*sc.self); ref by value, in registers
   LiSample s;
   switch (l.kind) {
@@ -646,8 +647,8 @@ RT_DEVN LiSample light_sample_li(const DScene& sc, const DLight& l, Interaction 
     default: {  // InfiniteAreaLight::sample_li infinite.rs:143-181
       float d1, pdf1, d0, pdf0; int v, dummy;
       if (RT_DBG(sc, 2)) { d1 = u.y; d0 = u.x; pdf0 = pdf1 = 1.0f; } else {
-      d1_sample_continuous_guided(l.mfunc, l.mcdf, l.mfunc_int, l.nv, u.y, l.mguide, l.mglog, d1, pdf1, v);  // Distribution2D::sample_continuous
-      d1_sample_continuous_guided(l.func + (size_t)v * l.nu, l.cdf + (size_t)v * (l.nu + 1), l.func_int[v], l.nu, u.x, l.guide + ((size_t)v << l.glog) + (size_t)v, l.glog, d0, pdf0, dummy);
+      d1_sample_continuous_guided<EXACT>(l.mfunc, l.mcdf, l.mfunc_int, l.nv, u.y, l.mguide, l.mglog, d1, pdf1, v);  // Distribution2D::sample_continuous
+      d1_sample_continuous_guided<EXACT>(l.func + (size_t)v * l.nu, l.cdf + (size_t)v * (l.nu + 1), l.func_int[v], l.nu, u.x, l.guide + ((size_t)v << l.glog) + (size_t)v, l.glog, d0, pdf0, dummy);
       }
       float map_pdf = pdf0 * pdf1;
       s.p1.p_error = mk3(0, 0, 0); s.p1.n = mk3(0, 0, 0);
@@ -655,7 +656,7 @@ RT_DEVN LiSample light_sample_li(const DScene& sc, const DLight& l, Interaction 
       float theta = d1 * kPi, phi = d0 * 2.0f * kPi;
       float cos_theta_ = cosf(theta), sin_theta_ = sinf(theta), cos_phi_ = cosf(phi), sin_phi_ = sinf(phi);
       f3 wi = xf3x4(l.l2w, mk3(sin_theta_ * cos_phi_, sin_theta_ * sin_phi_, cos_theta_));
-      s.pdf = sin_theta_ == 0.0f ? 0.0f : vdiv(map_pdf, 2.0f * kPi * kPi * sin_theta_);
+      s.pdf = sin_theta_ == 0.0f ? 0.0f : vdiv_e<EXACT>(map_pdf, 2.0f * kPi * kPi * sin_theta_);
       s.p1.p = ref.p + wi * (2.0f * l.world_radius);
       // the radiance lookup `lmap.lookup(uv)` (infinite.rs:176) is left to the caller (light_sample_li_finish: a call of its own instead of 50 more registers
       // in this function): li carries the map coordinates until then
@@ -667,9 +668,9 @@ RT_DEVN LiSample light_sample_li(const DScene& sc, const DLight& l, Interaction 
 // The environment map's radiance at map coordinates st (mipmap.rs:227-245 with width 0: the level-0 bilinear lookup), out of line
 RT_DEVN rgb3 infinite_li_q(const DImage* images, int image, float s0, float s1) { return mip_lookup(images[image], mk2(s0, s1), 0.0f); }
 // completes a light sample: an infinite light's radiance is looked up here (light_sample_li returns the map coordinates in li)
-template <bool GENERAL>
+template <bool GENERAL, bool EXACT = false>
 RT_DEV LiSample light_sample_li_full(const DScene& sc, const DLight& l, const Interaction& ref, f2 u) {
-  LiSample s = light_sample_li<GENERAL>(sc, l, ref, u);
+  LiSample s = light_sample_li<GENERAL, EXACT>(sc, l, ref, u);
   if (l.kind == 3 && s.pdf != 0.0f) s.li = RT_DBG(sc, 4) ? mkc(1, 1, 1) : infinite_li_q(sc.images, l.image, s.li.r, s.li.g);
   return s;
 }

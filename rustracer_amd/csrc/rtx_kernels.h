@@ -2157,7 +2157,7 @@ __global__ void __launch_bounds__(128) k_lightdist_contrib(DScene sc, const unsi
       Interaction intr;
       intr.p = bounds_lerp(vmn, vmx, mk3(halton[5 * i], halton[5 * i + 1], halton[5 * i + 2]));
       intr.p_error = mk3(0, 0, 0); intr.wo = mk3(1, 0, 0); intr.n = mk3(0, 0, 0);
-      LiSample s = light_sample_li_full<GENERAL>(*sc.self, light, intr, mk2(halton[5 * i + 3], halton[5 * i + 4]));
+      LiSample s = light_sample_li_full<GENERAL, true>(*sc.self, light, intr, mk2(halton[5 * i + 3], halton[5 * i + 4]));  // (exact quotients: these tables are bit-equal to the oracle's)
       if (s.pdf > 0.0f) contrib += lum_y(s.li) / s.pdf;
     }
   }

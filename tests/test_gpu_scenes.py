@@ -113,3 +113,27 @@ def test_million_triangle_mesh_matches_oracle(gpu_host, orc):
     fo, _ = o.render(mode=1)
     fh, _ = h.render()
     assert np.array_equal(fo[..., 3], fh[..., 3]) and rel_l2(gpu_host.film_to_rgb(fh), orc.film_to_rgb(fo)) < L2_GATE
+
+
+def test_room_light_distribution_bit_exact_with_every_light_kind(gpu_host, orc):
+    """The light-distribution build keeps correctly rounded quotients although the radiance-only arithmetic of a frame does not (rtx_dev_math.h, vdiv):
+    the room's tables - an infinite, a point and a distant light - are the oracle's bit for bit."""
+    d = _scenes()["room"]()
+    lo = orc.OracleScene(d).light_distrib(max_voxels=2000)
+    lh = gpu_host.HostScene(d).light_distribution()
+    k = lo["func"].shape[0]
+    assert lo["n_voxels"].tolist() == lh["n_voxels"].tolist() and k > 100
+    assert np.array_equal(bits(lo["func"]), bits(lh["func"][:k])) and np.array_equal(bits(lo["cdf"]), bits(lh["cdf"][:k]))
+
+
+def test_radiance_only_arithmetic_stays_ten_times_inside_the_image_gate(gpu_host, orc):
+    """Quotients that only scale radiance are one v_rcp_f32 and a multiply (rtx_dev_math.h): the frames stay within 1e-4 relative L2 of the oracle - a tenth
+    of north_star's gate -, the filter weights exact and the ray counts within 1e-3, on every benchmark scene."""
+    for name, mk in _scenes().items():
+        d = mk()
+        fo, so = orc.OracleScene(d).render(mode=1)
+        fh, sh = gpu_host.HostScene(d).render()
+        assert np.array_equal(fo[..., 3], fh[..., 3]), name
+        assert rel_l2(gpu_host.film_to_rgb(fh), orc.film_to_rgb(fo)) < 1e-4, name
+        for k in ("rays_closest", "rays_shadow", "rays_mis"):
+            assert abs(int(sh[k]) - int(so[k])) <= 1e-3 * int(so[k]) + 4, (name, k, sh[k], so[k])
