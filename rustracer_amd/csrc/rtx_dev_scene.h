@@ -35,6 +35,7 @@ struct DInstance { float o2w[16], w2o[16]; unsigned node_base, n_nodes, prim_bas
 struct DScene {
   const float4* nodes; unsigned n_nodes;
   const float4* pairs;  // n_nodes x 64 B child-pair records of the interior nodes (NULL for LDS-resident scenes), see k_trace_pair
+  int obj_pairs;        // ... the objects' trees have records too (behind the top level's, child codes local to the object): nested_pair_walk
   const float4* top_pairs; unsigned n_top;  // pair records of the first levels of the tree, child codes re-pointed at LDS slots (k_trace_top); n_top <= RT_TOP_MAX
   const float4* quads;  // n_nodes x 128 B grandchild records of the interior nodes (NULL when not built), see k_trace_quad
   const float4* tri_p; unsigned n_tris;

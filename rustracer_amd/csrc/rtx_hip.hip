@@ -498,7 +498,7 @@ extern "C" int rt_scene_create(const rt_scene_desc* desc, int device, rt_scene**
     if (s->stack_depth + max_obj > 64) { delete s; return fail(RT_ERR_INVALID, "top-level BVH plus the deepest object BVH exceed the 64-entry traversal stack"); }
     s->stack_depth += max_obj; max_obj_depth = max_obj;
   }
-  d.pairs = nullptr; d.quads = nullptr;
+  d.pairs = nullptr; d.quads = nullptr; d.obj_pairs = 0;
   if (!s->small) {  // LDS-resident scenes keep the one-node-per-step loop: the pair form measured no faster there
     // With object instances the records cover the top-level tree (objects are walked one node per step, their child offsets are relative to the object).
     // A leaf of a GENERAL scene that holds anything but plain triangles carries RT_PAIR_GENERAL.
@@ -517,7 +517,7 @@ extern "C" int rt_scene_create(const rt_scene_desc* desc, int device, rt_scene**
       if (n.n_prims > 0) { if (n.n_prims > 32) good = false; return 0x80000000u | n.offset | ((uint32_t)(n.n_prims - 1) << 26) | (gen && general_leaf(n) ? RT_PAIR_GENERAL : 0u); }
       return c | ((uint32_t)n.axis << 29);
     };
-    std::vector<float> pr((size_t)n_pair_nodes * 16, 0.0f);
+    std::vector<float> pr((size_t)(s->has_instances ? desc->n_nodes : n_pair_nodes) * 16, 0.0f);  // (with instances: the objects' records behind the top level's)
     for (uint32_t i = 0; i < n_pair_nodes && ok; ++i) {
       const rt_bvh_node& n = desc->nodes[i];
       if (n.n_prims != 0) continue;
@@ -527,10 +527,39 @@ extern "C" int rt_scene_create(const rt_scene_desc* desc, int device, rt_scene**
       q[0] = a.bmin[0]; q[1] = a.bmin[1]; q[2] = a.bmin[2]; q[3] = a.bmax[0]; q[4] = a.bmax[1]; q[5] = a.bmax[2]; memcpy(q + 6, &ca, 4); memcpy(q + 7, &cb, 4);
       q[8] = b.bmin[0]; q[9] = b.bmin[1]; q[10] = b.bmin[2]; q[11] = b.bmax[0]; q[12] = b.bmax[1]; q[13] = b.bmax[2];
     }
+    // the objects' trees as child pairs as well (nested_pair_walk): records at the nodes' global indices, child codes LOCAL to the object - node indices and leaf
+    // ranges are relative to the object's bases in its flattened tree already. Objects hold plain triangles (checked above).
+    bool obj_ok = ok && s->has_instances;
+    if (obj_ok) {
+      std::vector<char> done(desc->n_nodes, 0);
+      for (uint32_t k = 0; k < desc->n_instances && obj_ok; ++k) {
+        const rt_instance& in = desc->instances[k];
+        if (in.n_nodes == 0 || done[in.node_base]) continue;
+        done[in.node_base] = 1;
+        if (in.n_nodes >= (1u << 29) || in.n_prims >= (1u << 26)) { obj_ok = false; break; }
+        auto local_code = [&](uint32_t c) -> uint32_t {
+          const rt_bvh_node& n = desc->nodes[in.node_base + c];
+          if (n.n_prims > 0) { if (n.n_prims > 32) obj_ok = false; return 0x80000000u | n.offset | ((uint32_t)(n.n_prims - 1) << 26); }
+          return c | ((uint32_t)n.axis << 29);
+        };
+        if (desc->nodes[in.node_base].n_prims > 32) obj_ok = false;
+        for (uint32_t i = 0; i < in.n_nodes && obj_ok; ++i) {
+          const rt_bvh_node& n = desc->nodes[in.node_base + i];
+          if (n.n_prims != 0) continue;
+          const rt_bvh_node& a = desc->nodes[in.node_base + i + 1]; const rt_bvh_node& b = desc->nodes[in.node_base + n.offset];
+          float* q = pr.data() + (size_t)(in.node_base + i) * 16;
+          const uint32_t ca = local_code(i + 1), cb = local_code(n.offset);
+          q[0] = a.bmin[0]; q[1] = a.bmin[1]; q[2] = a.bmin[2]; q[3] = a.bmax[0]; q[4] = a.bmax[1]; q[5] = a.bmax[2]; memcpy(q + 6, &ca, 4); memcpy(q + 7, &cb, 4);
+          q[8] = b.bmin[0]; q[9] = b.bmin[1]; q[10] = b.bmin[2]; q[11] = b.bmax[0]; q[12] = b.bmax[1]; q[13] = b.bmax[2];
+        }
+      }
+    }
     if (ok) {
       int rc2 = upload(s->pairs, pr.data(), pr.size() * 4);
       if (rc2 != RT_OK) { delete s; return rc2; }
       d.pairs = s->pairs.as<float4>(); s->use_pairs = true;
+      d.obj_pairs = obj_ok ? 1 : 0;
+      if (getenv("RTX_OBJ_PAIRS") && getenv("RTX_OBJ_PAIRS")[0] == '0') d.obj_pairs = 0;  // measurement knob: objects walked one node per step
     }
     d.top_pairs = nullptr; d.n_top = 0;
     if (ok && n_pair_nodes < (1u << 28) && desc->nodes[0].n_prims == 0 && !s->has_instances) {  // (an object's walk needs a contiguous stack column: k_trace_pair)

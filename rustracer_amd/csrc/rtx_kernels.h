@@ -671,9 +671,16 @@ __global__ void __launch_bounds__(BLOCK) k_trace(DScene sc, TraceIO io, const un
 // TransformedPrimitive::intersect / intersect_p (rc/primitive.rs:90-101): the ray goes to object space as `Transform * Ray` does (origin as a point,
 // direction as a vector, t_max kept - rc/ray.rs:83-93), the object - its tree, or its single primitive - is intersected there; t is the same parameter
 // in both spaces. The nested walk keeps its stack in private memory: this is the general path, not the fast one.
+// What an object's walk needs when it runs as child pairs (nested_pair_walk, below the top level's pair steps): the pair records (DScene::pairs holds the
+// objects' records behind the top level's, child codes local to the object) and this lane's column of the deferred-tmin array above its pending entries.
+// pairs == NULL: the one-node-per-step walk (frames that count visits; scenes whose objects have no records).
+struct NestedCtx { const float4* pairs; float* tstack; size_t grid_lanes; };
+template <bool ANY, class StackT>
+RT_DEV bool nested_pair_walk(const float4* __restrict__ pairs, const float4* __restrict__ nodes, const float4* __restrict__ tri_p, Ray& r, StackT* stack, int stack_stride,
+                             float* tstack, size_t grid_lanes, int& prim_out, TriHit& hit_out);
 template <bool ANY, bool COUNT, class StackT>
 RT_DEV bool instance_intersect(const DScene& sc, unsigned inst, f3 o, f3 d, float& t_max, int& prim_out, TriHit& hit_out, unsigned& n_nodes, unsigned& n_tris,
-                               StackT* stack, int stack_stride) {
+                               StackT* stack, int stack_stride, NestedCtx nc = NestedCtx{nullptr, nullptr, 0}) {
   const DInstance& in = sc.instances[inst];
   Ray r; r.o = xf34_point(in.w2o, o); r.d = xf34_vector(in.w2o, d); r.t_max = t_max;
   bool found;
@@ -686,9 +693,14 @@ RT_DEV bool instance_intersect(const DScene& sc, unsigned inst, f3 o, f3 d, floa
   } else {
     // the object's walk takes the entries of this lane's stack column above the caller's pending ones (rt_scene_create sizes the column for the
     // deepest top-level path plus the deepest object)
-    const GlobalSrc src{sc.nodes + 2 * (size_t)in.node_base, sc.tri_p + 3 * (size_t)in.prim_base};
-    found = traverse<ANY, COUNT, GlobalSrc, StackT>(src, r, stack, stack_stride, prim_out, hit_out, n_nodes, n_tris);
-    if (found && !ANY) r.t_max = hit_out.t;
+    if (!COUNT && nc.pairs != nullptr) {
+      found = nested_pair_walk<ANY, StackT>(nc.pairs + 4 * (size_t)in.node_base, sc.nodes + 2 * (size_t)in.node_base, sc.tri_p + 3 * (size_t)in.prim_base, r, stack, stack_stride,
+                                            nc.tstack, nc.grid_lanes, prim_out, hit_out);
+    } else {
+      const GlobalSrc src{sc.nodes + 2 * (size_t)in.node_base, sc.tri_p + 3 * (size_t)in.prim_base};
+      found = traverse<ANY, COUNT, GlobalSrc, StackT>(src, r, stack, stack_stride, prim_out, hit_out, n_nodes, n_tris);
+      if (found && !ANY) r.t_max = hit_out.t;
+    }
   }
   if (found) t_max = r.t_max;
   return found;
@@ -697,14 +709,14 @@ RT_DEV bool instance_intersect(const DScene& sc, unsigned inst, f3 o, f3 d, floa
 // quadric, a masked triangle or a plain one. Returns whether the ray hits; for a closest-hit ray prim / hit / t_max are updated by the caller's rule.
 template <bool ANY, bool COUNT, class StackT>
 RT_DEV bool general_leaf_prim(const DScene& sc, const float4* __restrict__ tri_p, int prim, const Ray& ray, const RayPre& rp, bool shadow_masks, StackT* nested_stack, int stack_stride,
-                              TriHit& h, int& hit_prim, float& t_hit, unsigned& n_nodes, unsigned& n_tris) {
+                              TriHit& h, int& hit_prim, float& t_hit, unsigned& n_nodes, unsigned& n_tris, NestedCtx nc = NestedCtx{nullptr, nullptr, 0}) {
   const float4 a = tri_p[3 * prim], b = tri_p[3 * prim + 1], c = tri_p[3 * prim + 2];
   const f3 p0 = mk3(a.x, a.y, a.z), p1 = mk3(b.x, b.y, b.z), p2 = mk3(c.x, c.y, c.z);
   const unsigned flags = __float_as_uint(c.w);
   if (flags & RT_FLAG_INSTANCE) {
     const unsigned k = __float_as_uint(c.x);
     int oprim = 0; float tm = ray.t_max;
-    if (!instance_intersect<ANY, COUNT, StackT>(sc, k, ray.o, ray.d, tm, oprim, h, n_nodes, n_tris, nested_stack, stack_stride)) return false;
+    if (!instance_intersect<ANY, COUNT, StackT>(sc, k, ray.o, ray.d, tm, oprim, h, n_nodes, n_tris, nested_stack, stack_stride, nc)) return false;
     hit_prim = (int)(sc.instances[k].id_base + (unsigned)oprim); t_hit = tm;
     return true;
   }
@@ -854,6 +866,64 @@ RT_DEV bool slab_geom(float4 n0, float4 n1, const Ray& ray, f3 inv_dir, int neg_
 }
 #define RT_PAIR_LEAF 0x80000000u
 
+// An object's tree (TransformedPrimitive::intersect / intersect_p -> the object's BVH, rc/primitive.rs:90-101) walked as child pairs: the steps of
+// pair_interior_step / pair_leaf_step / pair_pop for ONE ray, run to completion inside the top level's leaf step. Objects hold plain triangles. r.t_max shrinks
+// with every accepted hit (closest hit); the far child's deferred tmin goes to this lane's column of the tmin array, above the top level's pending entries.
+template <bool ANY, class StackT>
+RT_DEV bool nested_pair_walk(const float4* __restrict__ pairs, const float4* __restrict__ nodes, const float4* __restrict__ tri_p, Ray& r, StackT* stack, int stack_stride,
+                             float* tstack, size_t grid_lanes, int& prim_out, TriHit& hit_out) {
+  const f3 inv_dir = mk3(1.0f / r.d.x, 1.0f / r.d.y, 1.0f / r.d.z);
+  const int neg_x = inv_dir.x < 0.0f, neg_y = inv_dir.y < 0.0f, neg_z = inv_dir.z < 0.0f;
+  const RayPre rp = ray_pre(r);
+  unsigned cur;
+  {
+    const float4 r0 = nodes[0], r1 = nodes[1];  // the root is the one node tested on its own
+    if (!slab_test(r0, r1, r, inv_dir, neg_x, neg_y, neg_z)) return false;
+    const unsigned packed = __float_as_uint(r1.w), np = packed & 0xffffu;
+    cur = np > 0u ? (0x80000000u | (unsigned)__float_as_int(r1.z) | ((np - 1u) << 26)) : (((packed >> 16) & 0xffu) << 29);
+  }
+  int sp = 0; bool found = false;
+  for (;;) {
+    bool pop = false;
+    if (cur & 0x80000000u) {
+      const int off = (int)(cur & 0x03ffffffu), n = (int)((cur >> 26) & 31u) + 1;
+      for (int i = 0; i < n; ++i) {
+        f3 p0, p1, p2; load_tri(tri_p, off + i, p0, p1, p2);
+        TriHit h;
+        if (tri_test_pre(p0, p1, p2, r, rp, h)) {
+          found = true;
+          if (ANY) return true;
+          r.t_max = h.t; prim_out = off + i; hit_out = h;  // `.or(result)`: later accepted hits replace
+        }
+      }
+      pop = true;
+    } else {
+      const unsigned P = cur & 0x1fffffffu, axis = (cur >> 29) & 3u;
+      const float4 a0 = pairs[4 * (size_t)P], a1 = pairs[4 * (size_t)P + 1], b0 = pairs[4 * (size_t)P + 2], b1 = pairs[4 * (size_t)P + 3];
+      const bool neg = (((neg_x ? 1u : 0u) | (neg_y ? 2u : 0u) | (neg_z ? 4u : 0u)) >> axis) & 1u;
+      const float4 n0 = neg ? b0 : a0, n1 = neg ? b1 : a1, f0 = neg ? a0 : b0, f1 = neg ? a1 : b1;
+      const unsigned code_a = __float_as_uint(a1.z), code_b = __float_as_uint(a1.w);
+      const unsigned code_n = neg ? code_b : code_a, code_f = neg ? code_a : code_b;
+      float tmin_n = 0.0f, tmin_f = 0.0f;
+      const bool hit_n = slab_geom(n0, n1, r, inv_dir, neg_x, neg_y, neg_z, tmin_n) && tmin_n < r.t_max;
+      const bool keep_f = slab_geom(f0, f1, r, inv_dir, neg_x, neg_y, neg_z, tmin_f) && tmin_f < r.t_max;
+      if (hit_n) {
+        if (keep_f) { stack[sp * stack_stride] = (StackT)code_f; if (!ANY) tstack[(size_t)sp * grid_lanes] = tmin_f; ++sp; }
+        cur = code_n;
+      } else if (keep_f) cur = code_f;
+      else pop = true;
+    }
+    if (pop) {
+      for (;;) {
+        if (sp == 0) return found;
+        --sp;
+        const unsigned c = (unsigned)stack[sp * stack_stride];
+        if (ANY || tstack[(size_t)sp * grid_lanes] < r.t_max) { cur = c; break; }
+      }
+    }
+  }
+}
+
 // per-lane traversal state and the output arrays a finished ray is written to
 struct PairLane {
   bool active, found; unsigned pid; float dw;
@@ -915,12 +985,12 @@ RT_DEV void pair_interior_step(PairLane& L, const TraceOut& o, const float4* __r
 // primitives through general_leaf_prim; every other leaf of such a scene, and every leaf of a plain scene, runs the bare triangle loop.
 #define RT_PAIR_GENERAL 0x02000000u
 template <bool ANY, bool GENERAL>
-RT_DEV bool pair_leaf_prims(PairLane& L, const DScene& sc, const float4* __restrict__ tri_p, bool shadow_masks, unsigned* nested_stack, int stack_stride) {
+RT_DEV bool pair_leaf_prims(PairLane& L, const DScene& sc, const float4* __restrict__ tri_p, bool shadow_masks, unsigned* nested_stack, int stack_stride, NestedCtx nc = NestedCtx{nullptr, nullptr, 0}) {
   const int off = (int)(L.cur & (GENERAL ? 0x01ffffffu : 0x03ffffffu)), n = (int)((L.cur >> 26) & 31u) + 1;
   if (GENERAL && (L.cur & RT_PAIR_GENERAL)) {
     for (int i = 0; i < n; ++i) {
       TriHit h; int hp = 0; float th = 0.0f; unsigned nn = 0, ntt = 0;
-      if (!general_leaf_prim<ANY, false, unsigned>(sc, tri_p, off + i, L.ray, L.rp(), shadow_masks, nested_stack, stack_stride, h, hp, th, nn, ntt)) continue;
+      if (!general_leaf_prim<ANY, false, unsigned>(sc, tri_p, off + i, L.ray, L.rp(), shadow_masks, nested_stack, stack_stride, h, hp, th, nn, ntt, nc)) continue;
       L.found = true;
       if (ANY) break;
       L.ray.t_max = th; L.prim = hp; L.hit = h;
@@ -941,7 +1011,8 @@ RT_DEV bool pair_leaf_prims(PairLane& L, const DScene& sc, const float4* __restr
 }
 template <bool ANY, int BLOCK, bool GENERAL = false>
 RT_DEV void pair_leaf_step(PairLane& L, const TraceOut& o, const DScene& sc, const float4* __restrict__ tri_p, unsigned* stack, const float* tstack, size_t grid_lanes, bool shadow_masks) {
-  (void)pair_leaf_prims<ANY, GENERAL>(L, sc, tri_p, shadow_masks, stack + L.sp * BLOCK, BLOCK);
+  (void)pair_leaf_prims<ANY, GENERAL>(L, sc, tri_p, shadow_masks, stack + L.sp * BLOCK, BLOCK,
+                                      NestedCtx{sc.obj_pairs ? sc.pairs : nullptr, const_cast<float*>(tstack) + (size_t)L.sp * grid_lanes, grid_lanes});
   if (ANY && L.found) pair_finish<ANY>(L, o); else pair_pop<ANY, BLOCK>(L, o, stack, tstack, grid_lanes);
 }
 
