@@ -235,6 +235,12 @@ RT_DEV float radical_inverse(int base_index, uint64_t a) {
 // rc/lib.rs:171-189 over a device array: pred(i) = (a[i] <= x)
 // the same bisection started inside a bracket known to hold the partition point (guide tables of the environment map, DLight::guide)
 RT_DEV int find_interval_le_from(const float* a, int size, float x, int first, int len) {
+  if (len <= 3) {  // the usual bracket of a dense guide table: the partition point of a monotone predicate is first + #{true}, from three loads in flight together
+    const int last = size - 1;
+    const float c0 = a[first < last ? first : last], c1 = a[first + 1 < last ? first + 1 : last], c2 = a[first + 2 < last ? first + 2 : last];
+    first += (len > 0 && c0 <= x ? 1 : 0) + (len > 1 && c1 <= x ? 1 : 0) + (len > 2 && c2 <= x ? 1 : 0);
+    return clampi(first - 1, 0, size - 2);
+  }
   while (len > 0) {
     int half = len >> 1, middle = first + half;
     if (a[middle] <= x) { first = middle + 1; len -= half + 1; } else { len = half; }

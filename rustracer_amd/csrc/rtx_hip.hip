@@ -21,6 +21,10 @@ using namespace rtx;
 
 static thread_local std::string g_err;
 static int fail(int code, const std::string& msg) { g_err = msg; return code; }
+// Guide tables (environment-map rows, light-distribution rows) bracket a CDF search: bucket k of 2^glog holds the entries whose cdf lies in [k, k+1) / 2^glog.
+// Density in quarters of an entry per bucket on average: 4 = as many buckets as entries (the search that follows is 0-2 dependent loads instead of the 4-5 of
+// round 2's 16 entries per bucket; a 2048 x 1024 map's tables grow from 0.3 to 4 MB). Measurement knob RTX_GUIDE_QUARTERS (64 = round 2).
+static long guide_quarters() { static const long q = getenv("RTX_GUIDE_QUARTERS") ? std::min(4096, std::max(1, atoi(getenv("RTX_GUIDE_QUARTERS")))) : 4; return q; }
 #define HIP_TRY(expr)                                                                                        \
   do {                                                                                                       \
     hipError_t e_ = (expr);                                                                                  \
@@ -368,8 +372,8 @@ extern "C" int rt_scene_create(const rt_scene_desc* desc, int device, rt_scene**
     }
     std::vector<float> blob(total + 4);
     TRY_RC([&]() { return s->dist.ensure(blob.size() * 4) == hipSuccess ? RT_OK : fail(RT_ERR_OOM, "dist alloc"); }());
-    // guide tables of the environment maps' CDF searches (DLight::guide): 2^glog buckets of ~16 entries per row
-    auto guide_log = [](int n) { int g = 0; while ((2 << g) * 16 <= n) ++g; return g; };
+    // guide tables of the environment maps' CDF searches (DLight::guide): 2^glog buckets per row (guide_quarters)
+    auto guide_log = [](int n) { const long q = guide_quarters(); int g = 0; while (g < 16 && (long)(2 << g) * q <= 4l * n) ++g; return g; };
     auto guide_row = [](const float* cdf, int n, int glog, unsigned short* out) {  // out[k] = #{i in [0, n] : cdf[i] <= k / 2^glog}
       const int G = 1 << glog; int i = 0;
       for (int k = 0; k <= G; ++k) { const float x = (float)k / (float)G; while (i <= n && cdf[i] <= x) ++i; out[k] = (unsigned short)i; }
@@ -668,7 +672,7 @@ static int build_light_distribution(rt_scene* s, int strategy, hipStream_t strea
   const bool uniform = strategy == 1 || nl == 1 || nl == 0;
   // guide tables for the rows' CDF searches (DScene::ld_guide) where a search is long enough to gain from one: >= 64 lights, <= 65534 (u16 entries)
   int glog = -1;
-  if (nl >= 64 && nl <= 65534) { glog = 0; while ((2 << glog) * 16 <= nl) ++glog; }
+  if (nl >= 64 && nl <= 65534) { const long q = guide_quarters(); glog = 0; while (glog < 16 && (long)(2 << glog) * q <= 4l * nl) ++glog; }
   d.ld_glog = glog; d.ld_guide = nullptr;
   if (uniform) {
     const int n = nl > 0 ? nl : 1;

@@ -175,3 +175,44 @@ def test_irradiance_of_a_disk_emitter(gpu_host, orc, who):
     assert abs(img.mean() / want.mean() - 1) < 0.004, (img.mean(), want.mean())
     gm, wm = img.reshape(8, 8, 8, 8).mean(axis=(1, 3)), want.reshape(8, 8, 8, 8).mean(axis=(1, 3))
     assert np.allclose(gm, wm, rtol=0.03), gm / wm
+
+
+def _quadrics_among_many_triangles(res=40, spp=8):
+    """Too many primitives for the LDS-resident kernel: the child-pair / quad-leaf / top-of-tree kernels' GENERAL instantiations take the scene."""
+    from rustracer_amd.scenes import cornell_box
+    from rustracer_amd.scenes.procedural import icosphere
+    d = cornell_box(res, res, spp)
+    P, F = icosphere(3, (300, 250, 300), 120.0)  # 1280 triangles
+    d.add_mesh(P, F, d.plastic((0.5, 0.5, 0.2), (0.3, 0.3, 0.3), 0.2))
+    img = np.zeros((16, 16, 3), np.float32)
+    img[(np.add.outer(np.arange(16) // 4, np.arange(16) // 4) % 2) == 0] = 1.0
+    mask = d.image_tex(d.add_mip(img, trilinear=True), su=3.0, sv=3.0)
+    d.add_mesh([(60, 60, 120), (260, 60, 100), (260, 300, 140), (60, 300, 160)], [[0, 1, 2], [0, 2, 3]], d.matte((0.2, 0.5, 0.9)), UV=[(0, 0), (1, 0), (1, 1), (0, 1)], alpha=mask)
+    d.add_sphere((120, 90, 380), 80.0, d.glass())
+    d.add_sphere(radius=55.0, material=d.matte((0.8, 0.3, 0.2)), o2w=_xf((450, 400, 200), (1.0, 0.7, 1.3), _rot((1, 0.3, 0), 40)), z_min=-25.0, z_max=45.0)
+    d.add_sphere((300, 250, 300), 90.0, d.metal(roughness=0.1))  # inside the mesh: reached only through its gaps - none - and by rays that start inside
+    d.add_cylinder(_xf((480, 0, 450), rot=_rot((1, 0, 0), -90)), 30.0, d.matte((0.6, 0.2, 0.5)), z_min=5.0, z_max=300.0)
+    d.add_sphere((100, 470, 100), 25.0, d.matte((0.0,) * 3), emission=(40.0, 35.0, 30.0))
+    return d
+
+
+def test_quadrics_and_masks_among_many_triangles_take_the_fast_kernels(gpu_host, orc):
+    d = _quadrics_among_many_triangles()
+    o, h = orc.OracleScene(d), gpu_host.HostScene(d)
+    assert len(o.bvh()["ordered"]) > 1280  # (the LDS-resident kernel holds 128 primitives)
+    rays = random_rays(80000, np.float32([0, 0, 0]), np.float32([555, 555, 555]), 21)
+    ro = o.trace(rays)
+    for count in (True, False):  # the counting kernel, then the kernels rt_render launches
+        rh = h.trace(rays, count=count)
+        assert np.array_equal(ro["prim"], rh["prim"]) and all(np.array_equal(bits(ro[k]), bits(rh[k])) for k in ("t", "b0", "b1"))
+    kinds = np.asarray(o.bvh()["ordered"])[np.maximum(ro["prim"], 0)]
+    assert ((kinds >= d.n_tris) & (ro["prim"] >= 0)).sum() > 3000  # quadrics were hit
+    rays[:, 3] = np.random.default_rng(4).uniform(20, 700, len(rays)).astype(np.float32)
+    ao = o.trace(rays, True)
+    assert np.array_equal(ao["occluded"], h.trace(rays, True)["occluded"]) and np.array_equal(ao["occluded"], h.trace(rays, True, count=False)["occluded"])
+    assert 0.2 < ao["occluded"].mean() < 0.95
+    fo, so = o.render(mode=1)
+    fh, sh = h.render()
+    assert np.array_equal(fo[..., 3], fh[..., 3]) and rel_l2(gpu_host.film_to_rgb(fh), orc.film_to_rgb(fo)) < 1e-3
+    for k in ("rays_closest", "rays_shadow", "rays_mis"):
+        assert abs(int(sh[k]) - int(so[k])) <= 2e-3 * int(so[k]) + 16, (k, sh[k], so[k])
