@@ -762,16 +762,24 @@ static unsigned trace_grid(const rt_scene* s) {
 // HBM half of the child-pair / four-wide kernels' traversal stack: [depth][lane of the grid]. Sized once per scene for the largest grid any
 // launch variant uses (rt_scene_create), so that no launch can fail on an allocation and leave stale hit records behind.
 #define RT_TOP_BLOCK 512
-static unsigned top_grid(const rt_scene* s) { return (unsigned)s->n_cu * 3u; }  // 48 KB of LDS per workgroup: three per CU, six waves per SIMD
+static unsigned top_grid(const rt_scene* s, bool any = false) {
+  static const int env_top = getenv("RTX_TOP_BLOCKS_PER_CU") ? atoi(getenv("RTX_TOP_BLOCKS_PER_CU")) : 0;  // measurement knobs
+  static const int env_any = getenv("RTX_TOP_BLOCKS_ANY") ? atoi(getenv("RTX_TOP_BLOCKS_ANY")) : 0;
+  const unsigned fit = (160u * 1024u) / (16384u + (unsigned)RT_TOP_LDS_DEPTH * RT_TOP_BLOCK * 4u);
+  unsigned n = 3u;
+  if (env_top > 0) n = (unsigned)env_top;
+  if (any && env_any > 0) n = (unsigned)env_any;
+  return (unsigned)s->n_cu * std::max(1u, std::min(n, fit));
+}  // 48 KB of LDS per workgroup: three per CU, six waves per SIMD
 static size_t tmin_stack_bytes(const rt_scene* s) {
   if (s->small || !s->use_pairs) return 0;
   const size_t a = s->stack_depth <= 32 ? (size_t)trace_grid<false, false, 128, 32>(s) * 128 * 32 * 4 : (size_t)trace_grid<false, false, 128, 64>(s) * 128 * 64 * 4;
-  const size_t b = s->use_top ? (size_t)top_grid(s) * RT_TOP_BLOCK * (size_t)s->stack_depth * 4 : 0;
+  const size_t b = s->use_top ? (size_t)std::max(top_grid(s), top_grid(s, true)) * RT_TOP_BLOCK * (size_t)s->stack_depth * 4 : 0;
   return std::max(a, b);
 }
 static size_t deep_stack_bytes(const rt_scene* s) {
   if (!s->use_top) return 0;
-  return (size_t)top_grid(s) * RT_TOP_BLOCK * (size_t)std::max(1, s->stack_depth - RT_TOP_LDS_DEPTH) * 4;
+  return (size_t)std::max(top_grid(s), top_grid(s, true)) * RT_TOP_BLOCK * (size_t)std::max(1, s->stack_depth - RT_TOP_LDS_DEPTH) * 4;
 }
 // the two knobs of the persistent traversal loops in one launch argument: lanes that must be idle before a wave refills (bits 0-7) and lanes that must wait at
 // a leaf before the leaf phase runs (bits 8-15; RT_LEAF_MIN, see leaf_phase_now; measurement knobs RTX_LEAF_MIN / RTX_LEAF_MIN_ANY). On an instanced scene a
@@ -802,7 +810,7 @@ static void launch_trace_v(rt_scene* s, const TraceIO& io, const unsigned* queue
     }
     // RTX_TRACE=top0: the child-pair kernel without the LDS-resident top of the tree (measurement knob)
     if (!COUNT && !plain && !refill_only && s->use_pairs && s->use_top && (ANY || s->top_for_closest) && !(mode && mode[0] == 't')) {
-      hipLaunchKernelGGL((k_trace_top<ANY, RT_TOP_BLOCK>), dim3(top_grid(s)), dim3(RT_TOP_BLOCK), 0, stream, s->d, io, queue, count_ptr, shard_cap, count_static, stats, st_rays,
+      hipLaunchKernelGGL((k_trace_top<ANY, RT_TOP_BLOCK>), dim3(top_grid(s, ANY)), dim3(RT_TOP_BLOCK), 0, stream, s->d, io, queue, count_ptr, shard_cap, count_static, stats, st_rays,
                          s->tmin_stack.as<float>(), s->deep_stack.as<unsigned>(), refill_min);
       return;
     }
@@ -839,7 +847,7 @@ static void launch_trace_c(rt_scene* s, const TraceIO& io, const unsigned* queue
         return;
       }
       if (!big_only && s->use_pairs && s->use_top && (ANY || s->top_for_closest)) {
-        hipLaunchKernelGGL((k_trace_top<ANY, RT_TOP_BLOCK, true>), dim3(top_grid(s)), dim3(RT_TOP_BLOCK), 0, stream, s->d, io, queue, count_ptr, shard_cap, count_static, stats, st_rays,
+        hipLaunchKernelGGL((k_trace_top<ANY, RT_TOP_BLOCK, true>), dim3(top_grid(s, ANY)), dim3(RT_TOP_BLOCK), 0, stream, s->d, io, queue, count_ptr, shard_cap, count_static, stats, st_rays,
                            s->tmin_stack.as<float>(), s->deep_stack.as<unsigned>(), refill_min);
         return;
       }
