@@ -110,12 +110,13 @@ def make_desc(scene, spp, res=1024):
 
 
 def source_sha():
-    """sha256 over the device sources: ties a PMC traffic file to the kernels it was collected from (the GPU box has no .git)."""
+    """sha256 over the sources librtx_hip.so is built from: ties a PMC traffic file to the kernels it was collected from (the GPU box has no .git)."""
     import hashlib
     h = hashlib.sha256()
     d = os.path.join(ROOT, "rustracer_amd", "csrc")
+    host_only = ("rtx_pbrt.inl", "rtx_images.inl", "rtx_spectrum_tables.inl")  # parts of librtx_host.so: no kernel is built from them
     for f in sorted(os.listdir(d)):
-        if f.endswith((".h", ".hip", ".inl")):
+        if f.endswith((".h", ".hip", ".inl")) and f not in host_only:
             h.update(open(os.path.join(d, f), "rb").read())
     return h.hexdigest()[:16]
 

@@ -111,6 +111,7 @@ enum { RTXH_TABLE_TEXTURES = 0, RTXH_TABLE_MATERIALS, RTXH_TABLE_LIGHTS, RTXH_TA
        RTXH_TABLE_ENV_FUNC, RTXH_TABLE_ENV_CDF, RTXH_TABLE_ENV_ROW_INT, RTXH_TABLE_ENV_MARG_CDF,
        RTXH_TABLE_INSTANCES,         /* rtxh_instance_info per ObjectInstance, in order */
        RTXH_TABLE_EMITTERS,          /* rtxh_emitter_info per emitter that is in no light list (rtxh_scene_add_emitter) */
+       RTXH_TABLE_QUADRICS,          /* per quadric (rtxh_scene_add_quadric): rt_sphere, then int32 material, int32 light (>= 0 a listed light, -2 - k unlisted emitter k, -1 none) */
        RTXH_TABLE_OBJECT_BASE = 1000 /* + 8 * object + {0 P, 1 N, 2 UV, 3 S, 4 indices, 5 tri material, 6 tri flags, 7 tri emitter (k or -1; empty when no
                                         triangle of the object emits)}: the object-space soup of one object */ };
 typedef struct rtxh_emitter_info { float rgb[3]; int32_t two_sided; } rtxh_emitter_info;

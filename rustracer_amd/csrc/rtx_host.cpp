@@ -543,7 +543,14 @@ int finish_commit(rtxh_scene* s) {
       for (int k = 0; k < 3; ++k) { s->f_p[9 * i + k] = bb.lo[k]; s->f_p[9 * i + 3 + k] = bb.hi[k]; }
       const uint32_t si = (uint32_t)((size_t)t - n_triangles); memcpy(&s->f_p[9 * i + 6], &si, 4);
       const uint32_t flip = (hs.s.reverse_orientation != 0) != (hs.s.swaps_handedness != 0) ? RT_TRI_FLIP : 0u;
-      s->f_meta[i] = rt_tri_meta{hs.material, hs.light, RT_PRIM_SPHERE | flip, (uint32_t)t};
+      int32_t sl = hs.light;
+      if (sl <= -2) {  // -2 - k: unlisted emitter k (a quadric of an object definition, placed by an instance)
+        const size_t k = (size_t)(-2 - (int64_t)sl);
+        if (k >= s->emitters.size()) return fail(RT_ERR_INVALID, "emitter index out of range");
+        sl = (int32_t)(s->lights.size() + k);
+        if (emitter_prim[k] < 0) emitter_prim[k] = (int64_t)i;
+      }
+      s->f_meta[i] = rt_tri_meta{hs.material, sl, RT_PRIM_SPHERE | flip, (uint32_t)t};
       continue;
     }
     for (int v = 0; v < 3; ++v) {
@@ -1040,6 +1047,7 @@ int rtxh_scene_inspect(rtxh_scene* s, int32_t table, void* out, uint64_t capacit
       for (const auto& in : s->instances) { rtxh_instance_info i; i.object = in.object; memcpy(i.o2w, in.o2w, 64); memcpy(i.w2o, in.w2o, 64); ii.push_back(i); }
       src = ii.data(); item = sizeof(rtxh_instance_info); n = ii.size(); break;
     case RTXH_TABLE_EMITTERS: src = s->emitters.data(); item = sizeof(rtxh_emitter_info); n = s->emitters.size(); break;
+    case RTXH_TABLE_QUADRICS: src = s->spheres.data(); item = sizeof(rtxh_scene::HostSphere); n = s->spheres.size(); break;
     case RTXH_TABLE_TEXTURES: src = s->textures.data(); item = sizeof(rt_texture); n = s->textures.size(); break;
     case RTXH_TABLE_MATERIALS: src = s->materials.data(); item = sizeof(rt_material); n = s->materials.size(); break;
     case RTXH_TABLE_LIGHTS:

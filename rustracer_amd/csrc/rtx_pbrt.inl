@@ -49,8 +49,10 @@ struct PbrtGraphicsState {  // rc/api.rs:300-311
 };
 
 static thread_local bool g_flatten_instances = false;  // rtxh_set_flatten_instances, per calling thread
+struct PbrtObjQuadric { int kind; Xf xf; float radius, zmin, zmax, phimax; int reverse, mat, emitter /* unlisted emitter id or -1 */; };
 struct PbrtSoup {  // triangle soup: world space for the scene, instance space for an ObjectBegin .. ObjectEnd block
   std::vector<float> P, N, UV, S; std::vector<int32_t> idx, tri_mat, tri_light, tri_alpha /* 2 per triangle */; std::vector<uint8_t> tri_flags;
+  std::vector<PbrtObjQuadric> quadrics;  // Shape "sphere" / "disk" / "cylinder" inside an object definition (instance space)
   bool any_n = false, any_uv = false, any_s = false;
   size_t n_verts() const { return P.size() / 3; }
   // appends nv vertices (attributes may be null: zero-filled once any mesh carries them); returns the first vertex index
@@ -336,7 +338,6 @@ struct PbrtLoader {
   bool add_shape(const std::string& name, const PbrtParams& p) {
     std::vector<float> vp, vn, vuv, vs; std::vector<int32_t> vi;
     if (name == "sphere" || name == "disk" || name == "cylinder") {  // an analytic primitive under the CTM, with one DiffuseAreaLight if an area light is active (api.rs:933-946)
-      if (in_instance) return fail_("a " + name + " inside an object definition is not supported (an object holds triangle meshes only)");
       const int kind = name == "sphere" ? 0 : (name == "disk" ? 1 : 2);
       const float radius = p.one_float("radius", 1.0f);
       // Sphere::create (sphere.rs:53-68): zmin zmax phimax; Disk::create (disk.rs:48-62): height innerradius phimax; Cylinder::create
@@ -350,6 +351,22 @@ struct PbrtLoader {
       if (!gs.area_light.empty()) {
         if (gs.area_light != "area" && gs.area_light != "diffuse") return fail_("area light \"" + gs.area_light + "\" unknown");
         light = n_lights;
+      }
+      if (in_instance) {
+        // Inside an object definition: kept in instance space and placed by every ObjectInstance (instantiate). The reference wraps the object's aggregate in a
+        // TransformedPrimitive (api.rs:1053-1090) whatever it holds; a quadric carries its own object-to-world transform, so an instance of it is the same
+        // quadric under instance_to_world * object_to_world - written out, like a masked mesh, with rounding as the only difference. Its area light stays
+        // with the primitive and out of the light list (api.rs:954-964): an unlisted emitter.
+        int emitter = -1;
+        if (light >= 0) {
+          float L[3] = {1, 1, 1}, sc[3] = {1, 1, 1};
+          gs.area_light_params.one_rgb("L", L); gs.area_light_params.one_rgb("scale", sc);
+          for (int c = 0; c < 3; ++c) L[c] *= sc[c];
+          emitter = rtxh_scene_add_emitter(scene, L, gs.area_light_params.one_bool("twosided", false) ? 1 : 0);
+          if (emitter < 0) return fail_(rtxh_last_error());
+        }
+        instances[current_instance].quadrics.push_back(PbrtObjQuadric{kind, ctm, radius, zmin, zmax, phimax, gs.reverse_orientation ? 1 : 0, mat, emitter});
+        return true;
       }
       const int k = rtxh_scene_add_quadric(scene, kind, &ctm.m.a[0][0], &ctm.inv.a[0][0], radius, zmin, zmax, phimax, gs.reverse_orientation ? 1 : 0, mat, light);
       if (k < 0) return fail_(rtxh_last_error());
@@ -441,6 +458,11 @@ struct PbrtLoader {
     auto it = instances.find(name);
     if (it == instances.end()) return fail_("Unable to find instance named " + name);
     const PbrtSoup& o = it->second;
+    for (const PbrtObjQuadric& q : o.quadrics) {  // the object's quadrics under instance_to_world * object_to_world
+      const Xf w = xf_mul(ctm, q.xf);
+      if (rtxh_scene_add_quadric(scene, q.kind, &w.m.a[0][0], &w.inv.a[0][0], q.radius, q.zmin, q.zmax, q.phimax, q.reverse, q.mat, q.emitter >= 0 ? -2 - q.emitter : -1) < 0) return fail_(rtxh_last_error());
+      n_spheres++;
+    }
     if (o.idx.empty()) return true;
     // The reference's form (the default): one tree per object, a TransformedPrimitive per instance - rtxh_scene_add_object once, rtxh_scene_add_instance
     // per use, nothing copied, traversed in object space by the general kernels. Objects whose meshes carry alpha masks are written out (below), and so

@@ -375,7 +375,10 @@ _TABLES = {"textures": (0, _TEXTURE_DT), "materials": (1, _MATERIAL_DT), "lights
            "tri_light": (9, np.dtype("<i4")), "tri_flags": (10, np.dtype("u1")), "env_func": (11, np.dtype("<f4")), "env_cdf": (12, np.dtype("<f4")),
            "env_row_int": (13, np.dtype("<f4")), "env_marg_cdf": (14, np.dtype("<f4")),
            "instances": (15, np.dtype([("object", "<i4"), ("o2w", "<f4", (4, 4)), ("w2o", "<f4", (4, 4))])),
-           "emitters": (16, np.dtype([("rgb", "<f4", (3,)), ("two_sided", "<i4")]))}
+           "emitters": (16, np.dtype([("rgb", "<f4", (3,)), ("two_sided", "<i4")])),
+           "quadrics": (17, np.dtype([("o2w", "<f4", (4, 4)), ("w2o", "<f4", (4, 4)), ("radius", "<f4"), ("z_min", "<f4"), ("z_max", "<f4"), ("theta_min", "<f4"), ("theta_max", "<f4"),
+                                      ("phi_max", "<f4"), ("reverse_orientation", "<i4"), ("swaps_handedness", "<i4"), ("kind", "<i4"), ("height", "<f4"), ("inner_radius", "<f4"),
+                                      ("material", "<i4"), ("light", "<i4")]))}
 _OBJECT_TABLES = {"P": (0, np.dtype(("<f4", 3))), "N": (1, np.dtype(("<f4", 3))), "UV": (2, np.dtype(("<f4", 2))), "S": (3, np.dtype(("<f4", 3))),
                   "indices": (4, np.dtype(("<i4", 3))), "tri_material": (5, np.dtype("<i4")), "tri_flags": (6, np.dtype("u1")), "tri_emitter": (7, np.dtype("<i4"))}
 

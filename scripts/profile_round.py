@@ -69,8 +69,9 @@ def source_sha():
     import hashlib
     h = hashlib.sha256()
     d = os.path.join('rustracer_amd', 'csrc')
+    host_only = ('rtx_pbrt.inl', 'rtx_images.inl', 'rtx_spectrum_tables.inl')  # (bench.py source_sha: what librtx_hip.so is built from)
     for f in sorted(os.listdir(d)):
-        if f.endswith(('.h', '.hip', '.inl')):
+        if f.endswith(('.h', '.hip', '.inl')) and f not in host_only:
             h.update(open(os.path.join(d, f), 'rb').read())
     return h.hexdigest()[:16]
 

@@ -542,6 +542,34 @@ def test_area_lights_inside_object_definitions_stay_out_of_the_light_list():
     assert len(q.table("emitters")) == 2
 
 
+def test_quadrics_inside_object_definitions_are_placed_by_every_instance():
+    """The reference wraps whatever an object holds in a TransformedPrimitive (rc/api.rs:1053-1090). A quadric has an object-to-world transform of its own, so
+    an instance of it is the same quadric under instance_to_world * object_to_world: the same tables as the scene with the quadrics written at the top level
+    under the composed transforms; an area light on it stays out of the light list (api.rs:954-964)."""
+    obj = ('ObjectBegin "o"\n' + TRI + 'AttributeBegin\nTranslate 0 1 0\nScale 1 2 1\nShape "sphere" "float radius" 0.5 "float zmax" 0.25\nAttributeEnd\n'
+           'Rotate 30 0 0 1\nShape "cylinder" "float radius" 0.2\nObjectEnd\n')
+    text = HEADER + 'WorldBegin\nLightSource "point" "rgb I" [1 1 1]\n' + TRI + obj + 'Translate 3 0 0\nObjectInstance "o"\nRotate 45 0 1 0\nTranslate 0 0 2\nObjectInstance "o"\nWorldEnd\n'
+    flat = (HEADER + 'WorldBegin\nLightSource "point" "rgb I" [1 1 1]\n' + TRI +
+            'AttributeBegin\nTranslate 3 0 0\nAttributeBegin\nTranslate 0 1 0\nScale 1 2 1\nShape "sphere" "float radius" 0.5 "float zmax" 0.25\nAttributeEnd\n'
+            'Rotate 30 0 0 1\nShape "cylinder" "float radius" 0.2\nAttributeEnd\n'
+            'AttributeBegin\nTranslate 3 0 0\nRotate 45 0 1 0\nTranslate 0 0 2\nAttributeBegin\nTranslate 0 1 0\nScale 1 2 1\nShape "sphere" "float radius" 0.5 "float zmax" 0.25\nAttributeEnd\n'
+            'Rotate 30 0 0 1\nShape "cylinder" "float radius" 0.2\nAttributeEnd\nWorldEnd\n')
+    p, q = _parse(text), _parse(flat)
+    assert len(p.table("instances")) == 2 and len(p.table((0, "indices"))) == 1   # the object's triangle stays two-level
+    sp, sq = p.table("quadrics"), q.table("quadrics")
+    assert len(sp) == 4 and list(sp["kind"]) == [0, 2, 0, 2]
+    for k in sp.dtype.names:
+        if k in ("o2w", "w2o"):
+            assert np.allclose(sp[k], sq[k], rtol=0, atol=1e-6), k   # (the file spells the product out statement by statement: the same matrices up to the order of the roundings)
+        else:
+            assert np.array_equal(sp[k], sq[k]), k
+    # an emitting quadric of an object: unlisted, one emitter per Shape statement, shared by its placements
+    text_e = text.replace('Shape "sphere"', 'AreaLightSource "diffuse" "rgb L" [5 4 3]\nShape "sphere"')
+    e = _parse(text_e)
+    assert e.n_lights() == 1 and len(e.table("emitters")) == 1 and np.array_equal(e.table("emitters")["rgb"][0], F32([5, 4, 3]))
+    assert list(e.table("quadrics")["light"]) == [-2, -1, -2, -1]  # -2 - k: unlisted emitter k; the cylinders emit nothing
+
+
 def test_a_redefined_object_is_what_later_instances_place():
     """ObjectBegin on a name already in use replaces the definition (instances.insert(name, Vec::new()), rc/api.rs:1030): instances placed afterwards use
     the new one, in the two-level form as in the written-out form."""
@@ -567,7 +595,6 @@ def test_a_redefined_object_is_what_later_instances_place():
     ('Camera "orthographic"\n' + HEADER + "WorldBegin\n" + TRI + "WorldEnd\n", 'Camera "orthographic" unknown'),
     ('Integrator "whitted"\n' + HEADER + "WorldBegin\n" + TRI + "WorldEnd\n", "not supported"),
     (HEADER + 'WorldBegin\nShape "cone"\nWorldEnd\n', "not supported"),
-    (HEADER + 'WorldBegin\nObjectBegin "o"\nShape "sphere"\nObjectEnd\n' + TRI + "WorldEnd\n", "object definition"),
     (HEADER + 'WorldBegin\nLightSource "spot"\n' + TRI + "WorldEnd\n", "not supported"),
     (HEADER + 'WorldBegin\nAreaLightSource "sphere"\n' + TRI + "WorldEnd\n", "unknown"),
     (HEADER + 'WorldBegin\nMakeNamedMaterial "m" "rgb Kd" [1 1 1]\n' + TRI + "WorldEnd\n", 'No parameter string "type"'),
