@@ -226,6 +226,9 @@ typedef struct rt_stats {
   /* rt_multi_render, `total` only: wall time from the moment the last device finished its chunks to the merged frame being in place (the additions on
    * devices[0] and the final copy); per-device wall times are per_device[k].ms_total */
   double ms_gather;
+  /* of rays_mis: BSDF-sampled rays toward a sphere light that miss the sphere's world box and were therefore not cast (Sphere::pdf_wi is non-zero for any
+   * direction, sphere.rs:310-334; such a ray's term is zero whatever it hits). Zero on frames that count the reference's walk. */
+  uint64_t rays_mis_not_cast;
 } rt_stats;
 
 #define RT_FLAG_COUNT_TRAVERSAL 1u /* fill nodes_ and tris_ counters (slower)                  */

@@ -67,6 +67,11 @@ struct PassState {
   const unsigned* cnt_in; unsigned* cnt_out; unsigned shard_cap;
   int all_in_bounds;  // every sample of the pass is traced (no crop by pixel_bounds): bounce 0 needs no queue, path i is entry i
   int mis_any;        // BSDF-sampled MIS rays toward an infinite light go to q_misany (off on frames that count node visits: reference walk)
+  // Sphere::pdf_wi answers with the cone's uniform density for ANY direction (sphere.rs:310-334 never tests wi against the cone), so estimate_direct casts the
+  // BSDF-sampled ray of every vertex whose picked light is a sphere - 150x the MIS rays of the tessellated S3 - and drops all that do not end on the sphere. A ray
+  // that misses the sphere's (slightly widened) world box cannot end on it: with this flag such a ray is not cast (its term is the zero it would have been);
+  // it is counted in ST_MIS_UNREACHED and stays in rt_stats::rays_mis. Off on frames that count the reference's walk.
+  int skip_unreachable_mis;
   const unsigned* range;  // k_shade: shade entries [range[0], range[1]) of q_in only (NULL = all): class-wise dispatch over the binned queue
   unsigned long long* stats;  // device-side u64 counters, see ST_* below
 };
@@ -74,6 +79,7 @@ struct PassState {
 enum { ST_CAMERA = 0, ST_RAYS_CLOSEST, ST_RAYS_SHADOW, ST_RAYS_MIS, ST_NODES_CLOSEST, ST_NODES_SHADOW, ST_NODES_MIS,
        ST_TRIS_CLOSEST, ST_TRIS_SHADOW, ST_TRIS_MIS, ST_SCRUBBED, ST_UNBUILT_VOXEL,
        ST_RAYS_MISANY, ST_NODES_MISANY, ST_TRIS_MISANY,  // the occlusion-only MIS rays (also counted in the _MIS entries)
+       ST_MIS_UNREACHED,  // MIS rays toward a quadric light that miss its box: not cast (PassState::skip_unreachable_mis)
        ST_SHADED,  // + {0: k_shade<1>, 1: k_shade<3>, 2: k_shade<5>, 3: k_shade<0>}: path vertices shaded by each front-end (misses included)
        ST_STAMP = ST_SHADED + 4,  // + 8 * front-end + section: wave cycles of the sections of k_shade (measurement builds only, make ABLATE=1)
        ST_COUNT = ST_STAMP + 32 };
@@ -1421,6 +1427,19 @@ __global__ void __launch_bounds__(256) k_bin_scatter(DScene sc, PassState ps, un
   }
 }
 
+// Can a ray from o along d (any t >= 0) pass through the box [lo, hi] widened by 1e-3 of its largest extent? Conservative on purpose (the widening is orders
+// above what Sphere::intersect's error bounds can add to the surface; a zero direction component tests the origin against the slab): `false` is a proof.
+RT_DEV bool ray_may_reach_box(f3 lo, f3 hi, f3 o, f3 d) {
+  const float m = 1e-3f * fmaxf(fmaxf(hi.x - lo.x, hi.y - lo.y), hi.z - lo.z) + 1e-6f * fmaxf(fmaxf(fabsf(o.x), fabsf(o.y)), fabsf(o.z));
+  float t0 = 0.0f, t1 = kInf;
+#define RT_SLAB(a) do { const float l_ = lo.a - m - o.a, h_ = hi.a + m - o.a; \
+    if (d.a != 0.0f) { const float i_ = 1.0f / d.a; const float n_ = l_ * i_, f_ = h_ * i_; t0 = fmaxf(t0, fminf(n_, f_)); t1 = fminf(t1, fmaxf(n_, f_)); } \
+    else if (l_ > 0.0f || h_ < 0.0f) return false; } while (0)
+  RT_SLAB(x); RT_SLAB(y); RT_SLAB(z);
+#undef RT_SLAB
+  return t0 <= t1;
+}
+
 // ================================================================================ K3 shade
 struct PathSampler {  // ZeroTwoSequence::get_1d / get_2d (zerotwosequence.rs:158-180) for one (pixel, sample)
   Tables tb; unsigned pix, s; int c1, c2; Pcg32 rng;
@@ -1702,7 +1721,7 @@ __global__ void __launch_bounds__(256, MODE == 1 ? RT_SHADE_MIN_WAVES : (MODE ==
   unsigned first = 0, count = ps.q_in ? qv.total() : ps.cap;  // no queue: bounce 0 of a pass whose samples are all traced
   if (MODE != 1 && ps.range) { first = ps.range[0]; count = ps.range[1]; }
   const unsigned stride = gridDim.x * blockDim.x;
-  unsigned n_shaded = 0;
+  unsigned n_shaded = 0, n_unreached = 0;
   const DScene& gsc = *sc.self;  // what out-of-line functions get: the scene record in device memory, not a private copy of the kernel argument
 #if RT_WAVE_QUEUES
   __shared__ unsigned s_win[4 * (MODE == 1 ? 3 : 4) * 128];  // (256 lanes = 4 waves)
@@ -1844,6 +1863,10 @@ __global__ void __launch_bounds__(256, MODE == 1 ? RT_SHADE_MIN_WAVES : (MODE ==
                   float lp = (MODE == 1) ? area_light_pdf_li<false>(sc, light, si.hit, bs.wi) : light_pdf_li<GENERAL>(gsc, light, si.hit, bs.wi);
                   if (lp == 0.0f) go = false;  // `return ld`
                   else weight = power_heuristic1(bs.pdf, lp);
+                  if (GENERAL && go && ps.skip_unreachable_mis && light.kind == 0 && (tri_flags(sc.tri_p, light.prim) & RT_FLAG_SPHERE)) {
+                    const float4 b0 = sc.tri_p[3 * (size_t)light.prim], b1 = sc.tri_p[3 * (size_t)light.prim + 1];  // a quadric's leaf record: its world box
+                    if (!ray_may_reach_box(mk3(b0.x, b0.y, b0.z), mk3(b1.x, b1.y, b1.z), si.hit.p, bs.wi)) { go = false; n_unreached += 1u; }
+                  }
                 }
                 if (go) {
                   Ray mr = spawn_ray(si.hit, bs.wi);
@@ -1919,6 +1942,10 @@ __global__ void __launch_bounds__(256, MODE == 1 ? RT_SHADE_MIN_WAVES : (MODE ==
     if (NQ == 4 && pr[3]) ps.q_misany[slot[3]] = pid;
   }
 #endif
+  if (GENERAL) {
+    for (int off = 32; off > 0; off >>= 1) n_unreached += __shfl_down(n_unreached, off);
+    if ((threadIdx.x & 63u) == 0u && n_unreached) atomicAdd(&ps.stats[ST_MIS_UNREACHED], (unsigned long long)n_unreached);
+  }
   for (int off = 32; off > 0; off >>= 1) n_shaded += __shfl_down(n_shaded, off);
   if ((threadIdx.x & 63u) == 0u && n_shaded) atomicAdd(&ps.stats[ST_SHADED + (MODE == 1 ? 0 : (MODE == 3 ? 1 : (MODE == 5 || MODE == 6 ? 2 : 3)))], (unsigned long long)n_shaded);
 #ifdef RT_ABLATE

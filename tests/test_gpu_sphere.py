@@ -86,6 +86,12 @@ def test_veach_style_plates_with_four_sphere_lights(gpu_host, orc):
     assert np.array_equal(fo[..., 3], fh[..., 3]) and rel_l2(gpu_host.film_to_rgb(fh), orc.film_to_rgb(fo)) < 1e-3
     for k in ("rays_closest", "rays_shadow", "rays_mis"):
         assert abs(int(sh[k]) - int(so[k])) <= 2e-3 * int(so[k]) + 16, (k, sh[k], so[k])
+    # Sphere::pdf_wi is non-zero for every direction, so the reference casts a BSDF-sampled ray per vertex that picked a sphere light; the ones that miss the
+    # sphere's box are counted, not cast - and change nothing: the frame that walks every ray as the reference does (counting kernels) is the same frame
+    assert int(sh["rays_mis_not_cast"]) > 0.5 * int(sh["rays_mis"])
+    fc, sc = gpu_host.HostScene(d).render(count_traversal=True)
+    assert int(sc["rays_mis_not_cast"]) == 0 and abs(int(sc["rays_mis"]) - int(sh["rays_mis"])) <= 2e-3 * int(sh["rays_mis"]) + 16
+    assert np.array_equal(fc[..., 3], fh[..., 3]) and rel_l2(gpu_host.film_to_rgb(fh), gpu_host.film_to_rgb(fc)) < 1e-6
 
 
 def _furnace_sphere(rho, depth, res=64, spp=64):
