@@ -354,24 +354,28 @@ struct GlobalSrc {
 // 534-582). Object instances are not handled here (they need a stack: general_leaf in rtx_kernels.h). c2 = the third float4 of the primitive's record
 // (p2 | flags). Defined in rtx_dev_shading.h; returns whether the ray hits, h filled.
 struct DScene;
-RT_DEV bool general_prim_test(const DScene& sc_self, int prim, f3 p0, f3 p1, f3 p2, unsigned flags, const Ray& ray, const RayPre& rp, bool shadow_masks, TriHit& h);
+// GENERAL of the trace templates: 0 = plain triangles; 1 = every general primitive; 2 = general primitives of a scene WITHOUT alpha masks - the mask evaluator
+// (a texture evaluation: 179 VGPRs) is then not instantiated and the kernels keep the quadric test's 134 (three waves per SIMD instead of two).
+#define RT_GEN_ALL 1
+#define RT_GEN_NO_MASKS 2
+template <bool MASKS> RT_DEV bool general_prim_test(const DScene& sc_self, int prim, f3 p0, f3 p1, f3 p2, unsigned flags, const Ray& ray, const RayPre& rp, bool shadow_masks, TriHit& h);
 #define RT_FLAG_GENERAL_TRI 48u  // alpha (16) | shadow alpha (32)
 
 // GENERAL: leaves may hold quadrics and alpha-masked triangles (gen = the scene record in device memory and whether shadowalpha masks apply); the plain
 // instantiation is the code it was.
 struct GeneralCtx { const DScene* self; bool shadow_masks; };
-template <bool GENERAL, class Src>
+template <int GENERAL, class Src>
 RT_DEV bool leaf_prim_test(const Src& src, const GeneralCtx& gen, int prim, const Ray& ray, const RayPre& rp, TriHit& h) {
   f3 p0, p1, p2;
   if (GENERAL) {
     unsigned flags; src.tri_flags(prim, p0, p1, p2, flags);
-    if (flags & (RT_FLAG_SPHERE | RT_FLAG_GENERAL_TRI)) return general_prim_test(*gen.self, prim, p0, p1, p2, flags, ray, rp, gen.shadow_masks, h);
+    if (flags & (RT_FLAG_SPHERE | RT_FLAG_GENERAL_TRI)) return general_prim_test<GENERAL == RT_GEN_ALL>(*gen.self, prim, p0, p1, p2, flags, ray, rp, gen.shadow_masks, h);
     return tri_test_pre(p0, p1, p2, ray, rp, h);
   }
   src.tri(prim, p0, p1, p2);
   return tri_test_pre(p0, p1, p2, ray, rp, h);
 }
-template <bool ANY, bool COUNT, class Src, class StackT, bool GENERAL = false>
+template <bool ANY, bool COUNT, class Src, class StackT, int GENERAL = 0>
 RT_DEV bool traverse(const Src& src, Ray ray, StackT* stack, int stack_stride, int& prim_out, TriHit& hit_out, unsigned& n_nodes, unsigned& n_tris, GeneralCtx gen = GeneralCtx{nullptr, false}) {
   bool found = false;
   int sp = 0, cur = 0;
@@ -469,7 +473,7 @@ RT_DEV bool leaf_phase_now(bool active, bool at_leaf, unsigned leaf_min) {  // c
 #ifndef RT_LDS_LEAF_MIN_ANY
 #define RT_LDS_LEAF_MIN_ANY 1
 #endif
-template <bool ANY, bool COUNT, int LEAF_MIN, class Src, class StackT, bool GENERAL = false>
+template <bool ANY, bool COUNT, int LEAF_MIN, class Src, class StackT, int GENERAL = 0>
 RT_DEV bool traverse_rounds(const Src& src, Ray ray, StackT* stack, int stack_stride, int& prim_out, TriHit& hit_out, unsigned& n_nodes, unsigned& n_tris, GeneralCtx gen = GeneralCtx{nullptr, false}) {
   bool found = false, done = false;
   int sp = 0, cur = 0, leaf_off = 0, leaf_n = 0;

@@ -259,6 +259,7 @@ RT_DEVN bool tri_alpha_rejects(const DScene& sc, int prim, const TriHit& h, bool
 }
 
 // leaf_prim_test's handler (rtx_dev_scene.h): a quadric, or a triangle of a masked mesh
+template <bool MASKS>
 RT_DEV bool general_prim_test(const DScene& sc_self, int prim, f3 p0, f3 p1, f3 p2, unsigned flags, const Ray& ray, const RayPre& rp, bool shadow_masks, TriHit& h) {
   if (flags & RT_FLAG_SPHERE) {
     float ts;
@@ -267,6 +268,7 @@ RT_DEV bool general_prim_test(const DScene& sc_self, int prim, f3 p0, f3 p1, f3 
     return true;
   }
   if (!tri_test_pre(p0, p1, p2, ray, rp, h)) return false;
+  if (!MASKS) return true;  // (no mesh of the scene carries a mask: rt_scene_create picked this instantiation)
   return !tri_alpha_rejects(sc_self, prim, h, shadow_masks);
 }
 

@@ -68,7 +68,8 @@ struct rt_scene {
   bool has_spheres = false;
   bool has_instances = false;  // object instances: two-level traversal in k_trace_big<.., GENERAL>, every vertex shaded by k_shade<0, true>
   DevBuf instances;
-  bool general_prims = false;  // alpha-masked triangles: traced by k_trace_big<.., GENERAL> only
+  bool general_prims = false;  // alpha-masked triangles, quadrics, object instances: the GENERAL instantiations of the trace kernels
+  bool has_masks = false;      // some triangle carries an alpha / shadow-alpha mask (RT_GEN_ALL; without: RT_GEN_NO_MASKS, 134 instead of 179 VGPRs)
   bool masked_emitters = false;  // ... and some of them emit: every vertex is shaded by k_shade<0, true> (Shape::pdf_wi evaluates the mask)
   std::vector<DLight> h_lights;
   // light distribution tables (built per render, rc/integrator/path.rs:86-94)
@@ -159,7 +160,7 @@ extern "C" int rt_scene_create(const rt_scene_desc* desc, int device, rt_scene**
         if ((m.flags & (k == 0 ? RT_TRI_HAS_ALPHA : RT_TRI_HAS_SHADOW_ALPHA)) && (desc->tri_alpha[2 * i + k] < 0 || (uint32_t)desc->tri_alpha[2 * i + k] >= desc->n_textures)) {
           delete s; return fail(RT_ERR_INVALID, "alpha texture out of range");
         }
-      s->general_prims = true;
+      s->general_prims = true; s->has_masks = true;
     }
   }
   if (s->general_prims) TRY_RC(upload(s->tri_alpha, desc->tri_alpha, (size_t)desc->n_tris * 8));
@@ -836,26 +837,31 @@ static void launch_trace_c(rt_scene* s, const TraceIO& io, const unsigned* queue
     const bool big_only = gmode && gmode[0] == 'b';
     if constexpr (!COUNT) {
       const unsigned refill_min = trace_knobs(s, ANY);
+      static const bool masks_always = getenv("RTX_GEN_MASKS") && getenv("RTX_GEN_MASKS")[0] == '1';  // measurement knob: every general scene through the RT_GEN_ALL kernels
+      const bool all = s->has_masks || masks_always;
+#define RT_GEN_LAUNCH(KERNEL_ALL, KERNEL_NOMASK, GRID, BLK, ...) do { if (all) hipLaunchKernelGGL(KERNEL_ALL, dim3(GRID), dim3(BLK), 0, stream, __VA_ARGS__); \
+                                                                      else hipLaunchKernelGGL(KERNEL_NOMASK, dim3(GRID), dim3(BLK), 0, stream, __VA_ARGS__); } while (0)
       if (!big_only && s->small) {
-        if (s->stack_depth <= 16) hipLaunchKernelGGL((k_trace<ANY, false, true, 256, 16, true>), dim3(trace_grid<ANY, true, 256, 16>(s)), dim3(256), 0, stream, s->d, io, queue, count_ptr, shard_cap, count_static, stats, st_rays, st_nodes, st_tris);
-        else if (s->stack_depth <= 32) hipLaunchKernelGGL((k_trace<ANY, false, true, 256, 32, true>), dim3(trace_grid<ANY, true, 256, 32>(s)), dim3(256), 0, stream, s->d, io, queue, count_ptr, shard_cap, count_static, stats, st_rays, st_nodes, st_tris);
-        else hipLaunchKernelGGL((k_trace<ANY, false, true, 128, 64, true>), dim3(trace_grid<ANY, true, 128, 64>(s)), dim3(128), 0, stream, s->d, io, queue, count_ptr, shard_cap, count_static, stats, st_rays, st_nodes, st_tris);
+        if (s->stack_depth <= 16) RT_GEN_LAUNCH((k_trace<ANY, false, true, 256, 16, RT_GEN_ALL>), (k_trace<ANY, false, true, 256, 16, RT_GEN_NO_MASKS>), (trace_grid<ANY, true, 256, 16>(s)), 256, s->d, io, queue, count_ptr, shard_cap, count_static, stats, st_rays, st_nodes, st_tris);
+        else if (s->stack_depth <= 32) RT_GEN_LAUNCH((k_trace<ANY, false, true, 256, 32, RT_GEN_ALL>), (k_trace<ANY, false, true, 256, 32, RT_GEN_NO_MASKS>), (trace_grid<ANY, true, 256, 32>(s)), 256, s->d, io, queue, count_ptr, shard_cap, count_static, stats, st_rays, st_nodes, st_tris);
+        else RT_GEN_LAUNCH((k_trace<ANY, false, true, 128, 64, RT_GEN_ALL>), (k_trace<ANY, false, true, 128, 64, RT_GEN_NO_MASKS>), (trace_grid<ANY, true, 128, 64>(s)), 128, s->d, io, queue, count_ptr, shard_cap, count_static, stats, st_rays, st_nodes, st_tris);
         return;
       }
       if (!big_only && ANY && s->use_quads && s->quad_stack_depth <= 32) {
-        hipLaunchKernelGGL((k_trace_quad<ANY, 128, 32, true>), dim3(trace_grid<ANY, false, 128, 32>(s)), dim3(128), 0, stream, s->d, io, queue, count_ptr, shard_cap, count_static, stats, st_rays, s->tmin_stack.as<float>(), refill_min);
+        RT_GEN_LAUNCH((k_trace_quad<ANY, 128, 32, RT_GEN_ALL>), (k_trace_quad<ANY, 128, 32, RT_GEN_NO_MASKS>), (trace_grid<ANY, false, 128, 32>(s)), 128, s->d, io, queue, count_ptr, shard_cap, count_static, stats, st_rays, s->tmin_stack.as<float>(), refill_min);
         return;
       }
       if (!big_only && s->use_pairs && s->use_top && (ANY || s->top_for_closest)) {
-        hipLaunchKernelGGL((k_trace_top<ANY, RT_TOP_BLOCK, true>), dim3(top_grid(s, ANY)), dim3(RT_TOP_BLOCK), 0, stream, s->d, io, queue, count_ptr, shard_cap, count_static, stats, st_rays,
-                           s->tmin_stack.as<float>(), s->deep_stack.as<unsigned>(), refill_min);
+        RT_GEN_LAUNCH((k_trace_top<ANY, RT_TOP_BLOCK, RT_GEN_ALL>), (k_trace_top<ANY, RT_TOP_BLOCK, RT_GEN_NO_MASKS>), (top_grid(s, ANY)), RT_TOP_BLOCK, s->d, io, queue, count_ptr, shard_cap, count_static, stats, st_rays,
+                      s->tmin_stack.as<float>(), s->deep_stack.as<unsigned>(), refill_min);
         return;
       }
       if (!big_only && s->use_pairs) {
-        if (s->stack_depth <= 32) hipLaunchKernelGGL((k_trace_pair<ANY, false, 128, 32, true>), dim3(trace_grid<ANY, false, 128, 32>(s)), dim3(128), 0, stream, s->d, io, queue, count_ptr, shard_cap, count_static, stats, st_rays, s->tmin_stack.as<float>(), refill_min);
-        else hipLaunchKernelGGL((k_trace_pair<ANY, false, 128, 64, true>), dim3(trace_grid<ANY, false, 128, 64>(s)), dim3(128), 0, stream, s->d, io, queue, count_ptr, shard_cap, count_static, stats, st_rays, s->tmin_stack.as<float>(), refill_min);
+        if (s->stack_depth <= 32) RT_GEN_LAUNCH((k_trace_pair<ANY, false, 128, 32, RT_GEN_ALL>), (k_trace_pair<ANY, false, 128, 32, RT_GEN_NO_MASKS>), (trace_grid<ANY, false, 128, 32>(s)), 128, s->d, io, queue, count_ptr, shard_cap, count_static, stats, st_rays, s->tmin_stack.as<float>(), refill_min);
+        else RT_GEN_LAUNCH((k_trace_pair<ANY, false, 128, 64, RT_GEN_ALL>), (k_trace_pair<ANY, false, 128, 64, RT_GEN_NO_MASKS>), (trace_grid<ANY, false, 128, 64>(s)), 128, s->d, io, queue, count_ptr, shard_cap, count_static, stats, st_rays, s->tmin_stack.as<float>(), refill_min);
         return;
       }
+#undef RT_GEN_LAUNCH
     }
     if (s->stack_depth <= 32) hipLaunchKernelGGL((k_trace_big<ANY, COUNT, 128, 32, true>), dim3(trace_grid<ANY, false, 128, 32>(s)), dim3(128), 0, stream, s->d, io, queue, count_ptr, shard_cap, count_static, stats, st_rays, st_nodes, st_tris);
     else hipLaunchKernelGGL((k_trace_big<ANY, COUNT, 128, 64, true>), dim3(trace_grid<ANY, false, 128, 64>(s)), dim3(128), 0, stream, s->d, io, queue, count_ptr, shard_cap, count_static, stats, st_rays, st_nodes, st_tris);

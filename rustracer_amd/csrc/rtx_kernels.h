@@ -613,7 +613,7 @@ RT_DEV void trace_write_any(float4* __restrict__ lacc, size_t ls, const float4* 
 
 // BLOCK threads per workgroup, DEPTH = to-visit stack entries per lane (the host picks the
 // smallest of 16/32/64 that covers the tree height; the reference's fixed 64 is the maximum).
-template <bool ANY, bool COUNT, bool SMALL, int BLOCK, int DEPTH, bool GENERAL = false>  // GENERAL: quadrics / alpha-masked triangles in the leaves (no object instances)
+template <bool ANY, bool COUNT, bool SMALL, int BLOCK, int DEPTH, int GENERAL = 0>  // GENERAL: quadrics / alpha-masked triangles in the leaves (no object instances)
 __global__ void __launch_bounds__(BLOCK) k_trace(DScene sc, TraceIO io, const unsigned* __restrict__ queue, const unsigned* __restrict__ shard_counts, unsigned shard_cap,
                                                  unsigned count_static, unsigned long long* stats, int st_rays, int st_nodes, int st_tris) {
   const float4* __restrict__ ray_o = io.ray_o; const float4* __restrict__ ray_d = io.ray_d; const size_t rs = io.ray_stride;
@@ -713,7 +713,7 @@ RT_DEV bool instance_intersect(const DScene& sc, unsigned inst, f3 o, f3 d, floa
 }
 // One primitive of a leaf of a GENERAL scene, for the persistent kernels: an object instance (the hit id then names (instance, the object's primitive)), a
 // quadric, a masked triangle or a plain one. Returns whether the ray hits; for a closest-hit ray prim / hit / t_max are updated by the caller's rule.
-template <bool ANY, bool COUNT, class StackT>
+template <bool ANY, bool COUNT, class StackT, bool MASKS = true>
 RT_DEV bool general_leaf_prim(const DScene& sc, const float4* __restrict__ tri_p, int prim, const Ray& ray, const RayPre& rp, bool shadow_masks, StackT* nested_stack, int stack_stride,
                               TriHit& h, int& hit_prim, float& t_hit, unsigned& n_nodes, unsigned& n_tris, NestedCtx nc = NestedCtx{nullptr, nullptr, 0}) {
   const float4 a = tri_p[3 * prim], b = tri_p[3 * prim + 1], c = tri_p[3 * prim + 2];
@@ -727,13 +727,13 @@ RT_DEV bool general_leaf_prim(const DScene& sc, const float4* __restrict__ tri_p
     return true;
   }
   hit_prim = prim;
-  if (flags & (RT_FLAG_SPHERE | RT_FLAG_GENERAL_TRI)) { if (!general_prim_test(*sc.self, prim, p0, p1, p2, flags, ray, rp, shadow_masks, h)) return false; }
+  if (flags & (RT_FLAG_SPHERE | RT_FLAG_GENERAL_TRI)) { if (!general_prim_test<MASKS>(*sc.self, prim, p0, p1, p2, flags, ray, rp, shadow_masks, h)) return false; }
   else if (!tri_test_pre(p0, p1, p2, ray, rp, h)) return false;
   t_hit = h.t;
   return true;
 }
 
-template <bool ANY, bool COUNT, int BLOCK, int DEPTH, bool GENERAL = false>
+template <bool ANY, bool COUNT, int BLOCK, int DEPTH, int GENERAL = 0>
 __global__ void __launch_bounds__(BLOCK) k_trace_big(DScene sc, TraceIO io, const unsigned* __restrict__ queue, const unsigned* __restrict__ shard_counts, unsigned shard_cap,
                                                      unsigned count_static, unsigned long long* stats, int st_rays, int st_nodes, int st_tris) {
   const float4* __restrict__ ray_o = io.ray_o; const float4* __restrict__ ray_d = io.ray_d; const size_t rs = io.ray_stride;
@@ -990,13 +990,13 @@ RT_DEV void pair_interior_step(PairLane& L, const TraceOut& o, const float4* __r
 // GENERAL scenes: a leaf that holds anything but plain triangles carries RT_PAIR_GENERAL in its code (first primitive then in bits 0-24) and walks its
 // primitives through general_leaf_prim; every other leaf of such a scene, and every leaf of a plain scene, runs the bare triangle loop.
 #define RT_PAIR_GENERAL 0x02000000u
-template <bool ANY, bool GENERAL>
+template <bool ANY, int GENERAL>
 RT_DEV bool pair_leaf_prims(PairLane& L, const DScene& sc, const float4* __restrict__ tri_p, bool shadow_masks, unsigned* nested_stack, int stack_stride, NestedCtx nc = NestedCtx{nullptr, nullptr, 0}) {
   const int off = (int)(L.cur & (GENERAL ? 0x01ffffffu : 0x03ffffffu)), n = (int)((L.cur >> 26) & 31u) + 1;
   if (GENERAL && (L.cur & RT_PAIR_GENERAL)) {
     for (int i = 0; i < n; ++i) {
       TriHit h; int hp = 0; float th = 0.0f; unsigned nn = 0, ntt = 0;
-      if (!general_leaf_prim<ANY, false, unsigned>(sc, tri_p, off + i, L.ray, L.rp(), shadow_masks, nested_stack, stack_stride, h, hp, th, nn, ntt, nc)) continue;
+      if (!general_leaf_prim<ANY, false, unsigned, GENERAL == RT_GEN_ALL>(sc, tri_p, off + i, L.ray, L.rp(), shadow_masks, nested_stack, stack_stride, h, hp, th, nn, ntt, nc)) continue;
       L.found = true;
       if (ANY) break;
       L.ray.t_max = th; L.prim = hp; L.hit = h;
@@ -1015,14 +1015,14 @@ RT_DEV bool pair_leaf_prims(PairLane& L, const DScene& sc, const float4* __restr
   }
   return L.found;
 }
-template <bool ANY, int BLOCK, bool GENERAL = false>
+template <bool ANY, int BLOCK, int GENERAL = 0>
 RT_DEV void pair_leaf_step(PairLane& L, const TraceOut& o, const DScene& sc, const float4* __restrict__ tri_p, unsigned* stack, const float* tstack, size_t grid_lanes, bool shadow_masks) {
   (void)pair_leaf_prims<ANY, GENERAL>(L, sc, tri_p, shadow_masks, stack + L.sp * BLOCK, BLOCK,
                                       NestedCtx{sc.obj_pairs ? sc.pairs : nullptr, const_cast<float*>(tstack) + (size_t)L.sp * grid_lanes, grid_lanes});
   if (ANY && L.found) pair_finish<ANY>(L, o); else pair_pop<ANY, BLOCK>(L, o, stack, tstack, grid_lanes);
 }
 
-template <bool ANY, bool WW, int BLOCK, int DEPTH, bool GENERAL = false>
+template <bool ANY, bool WW, int BLOCK, int DEPTH, int GENERAL = 0>
 __global__ void __launch_bounds__(BLOCK) k_trace_pair(DScene sc, TraceIO io, const unsigned* __restrict__ queue, const unsigned* __restrict__ shard_counts, unsigned shard_cap,
                                                       unsigned count_static, unsigned long long* stats, int st_rays, float* __restrict__ tmin_stack_mem, unsigned refill_min) {
   const float4* __restrict__ ray_o = io.ray_o; const float4* __restrict__ ray_d = io.ray_d; const size_t rs = io.ray_stride;
@@ -1139,12 +1139,12 @@ RT_DEV void top_interior_step(PairLane& L, const TraceOut& o, const float4* __re
   } else if (keep_f) L.cur = code_f;
   else top_pop<ANY, BLOCK>(L, o, stk, tstack, grid_lanes);
 }
-template <bool ANY, int BLOCK, bool GENERAL = false>  // GENERAL here: quadrics and masked triangles (an instanced scene needs a contiguous stack column: k_trace_pair)
+template <bool ANY, int BLOCK, int GENERAL = 0>  // GENERAL here: quadrics and masked triangles (an instanced scene needs a contiguous stack column: k_trace_pair)
 RT_DEV void top_leaf_step(PairLane& L, const TraceOut& o, const DScene& sc, const float4* __restrict__ tri_p, const SplitStack<BLOCK>& stk, const float* tstack, size_t grid_lanes, bool shadow_masks) {
   (void)pair_leaf_prims<ANY, GENERAL>(L, sc, tri_p, shadow_masks, nullptr, 0);
   if (ANY && L.found) pair_finish<ANY>(L, o); else top_pop<ANY, BLOCK>(L, o, stk, tstack, grid_lanes);
 }
-template <bool ANY, int BLOCK, bool GENERAL = false>
+template <bool ANY, int BLOCK, int GENERAL = 0>
 __global__ void __launch_bounds__(BLOCK, GENERAL ? 4 : 6) k_trace_top(DScene sc, TraceIO io, const unsigned* __restrict__ queue, const unsigned* __restrict__ shard_counts, unsigned shard_cap,
                                                      unsigned count_static, unsigned long long* stats, int st_rays, float* __restrict__ tmin_stack_mem, unsigned* __restrict__ deep_stack_mem,
                                                      unsigned refill_min) {
@@ -1284,7 +1284,7 @@ RT_DEV void quad_interior_step(PairLane& L, const TraceOut& o, const float4* __r
   if (entered) L.cur = next; else pair_pop<ANY, BLOCK>(L, o, stack, tstack, grid_lanes);
 }
 
-template <bool ANY, int BLOCK, int DEPTH, bool GENERAL = false>
+template <bool ANY, int BLOCK, int DEPTH, int GENERAL = 0>
 __global__ void __launch_bounds__(BLOCK) k_trace_quad(DScene sc, TraceIO io, const unsigned* __restrict__ queue, const unsigned* __restrict__ shard_counts, unsigned shard_cap,
                                                       unsigned count_static, unsigned long long* stats, int st_rays, float* __restrict__ tmin_stack_mem, unsigned refill_min) {
   const float4* __restrict__ ray_o = io.ray_o; const float4* __restrict__ ray_d = io.ray_d; const size_t rs = io.ray_stride;

@@ -248,14 +248,16 @@ def test_kernel_register_and_scratch_budgets(host):
         "rtx::k_shade<5, false>": (256, 64),
         "rtx::k_shade<6, false>": (256, 64),
         "rtx::k_shade<0, false>": (256, 2048),     # 257 (one accumulation register added by a callee) is ONE wave per SIMD
-        "rtx::k_trace<false, false, true, 256, 16, false>": (72, 0),    # the LDS-resident closest-hit kernel of the headline: 7 waves
-        "rtx::k_trace<true, false, true, 256, 16, false>": (64, 0),     # ... and its shadow-ray twin: 8 waves
-        "rtx::k_trace_pair<false, false, 128, 32, false>": (80, 0),     # HBM scenes: 6 waves; no scratch (an indexed load per node visit once hid here)
-        "rtx::k_trace_quad<true, 128, 32, false>": (64, 0),
-        "rtx::k_trace_top<false, 512, false>": (80, 0), "rtx::k_trace_top<true, 512, false>": (80, 0),   # 512 lanes per workgroup: 6 waves
+        "rtx::k_trace<false, false, true, 256, 16, 0>": (72, 0),    # the LDS-resident closest-hit kernel of the headline: 7 waves
+        "rtx::k_trace<true, false, true, 256, 16, 0>": (64, 0),     # ... and its shadow-ray twin: 8 waves
+        "rtx::k_trace_pair<false, false, 128, 32, 0>": (80, 0),     # HBM scenes: 6 waves; no scratch (an indexed load per node visit once hid here)
+        "rtx::k_trace_quad<true, 128, 32, 0>": (64, 0),
+        "rtx::k_trace_top<false, 512, 0>": (80, 0), "rtx::k_trace_top<true, 512, 0>": (80, 0),   # 512 lanes per workgroup: 6 waves
         # GENERAL instantiations (quadrics, masked triangles, object instances): the out-of-line quadric / mask evaluators cost them the waves (2 per SIMD),
         # the plain instantiations above must not notice that these exist
-        "rtx::k_trace_pair<false, false, 128, 32, true>": (192, 128), "rtx::k_trace_quad<true, 128, 32, true>": (192, 128),
+        "rtx::k_trace_pair<false, false, 128, 32, 1>": (192, 128), "rtx::k_trace_quad<true, 128, 32, 1>": (192, 128),
+        # ... and without the mask evaluator (scenes whose meshes carry no alpha mask): three waves
+        "rtx::k_trace_pair<false, false, 128, 32, 2>": (168, 32), "rtx::k_trace_quad<true, 128, 32, 2>": (168, 32), "rtx::k_trace<false, false, true, 256, 16, 2>": (168, 32),
         "rtx::k_shade<3, true>": (256, 512), "rtx::k_shade<5, true>": (256, 512), "rtx::k_shade<6, true>": (256, 512),   # (they spill some: still one wave more than the generic kernel's code)
         "rtx::k_resolve<false>": (88, 256), "rtx::k_raygen": (72, 0), "rtx::k_film_accumulate": (48, 0),
     }
