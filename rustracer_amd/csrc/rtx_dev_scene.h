@@ -358,7 +358,8 @@ struct DScene;
 // (a texture evaluation: 179 VGPRs) is then not instantiated and the kernels keep the quadric test's 134 (three waves per SIMD instead of two).
 #define RT_GEN_ALL 1
 #define RT_GEN_NO_MASKS 2
-template <bool MASKS> RT_DEV bool general_prim_test(const DScene& sc_self, int prim, f3 p0, f3 p1, f3 p2, unsigned flags, const Ray& ray, const RayPre& rp, bool shadow_masks, TriHit& h);
+#define RT_GEN_INSTANCES_ONLY 3  // neither masks nor quadrics: object instances over plain triangles (133 / 99 VGPRs: the quadric test's 134 is not instantiated either)
+template <bool MASKS, bool QUADRICS> RT_DEV bool general_prim_test(const DScene& sc_self, int prim, f3 p0, f3 p1, f3 p2, unsigned flags, const Ray& ray, const RayPre& rp, bool shadow_masks, TriHit& h);
 #define RT_FLAG_GENERAL_TRI 48u  // alpha (16) | shadow alpha (32)
 
 // GENERAL: leaves may hold quadrics and alpha-masked triangles (gen = the scene record in device memory and whether shadowalpha masks apply); the plain
@@ -369,7 +370,7 @@ RT_DEV bool leaf_prim_test(const Src& src, const GeneralCtx& gen, int prim, cons
   f3 p0, p1, p2;
   if (GENERAL) {
     unsigned flags; src.tri_flags(prim, p0, p1, p2, flags);
-    if (flags & (RT_FLAG_SPHERE | RT_FLAG_GENERAL_TRI)) return general_prim_test<GENERAL == RT_GEN_ALL>(*gen.self, prim, p0, p1, p2, flags, ray, rp, gen.shadow_masks, h);
+    if (flags & (RT_FLAG_SPHERE | RT_FLAG_GENERAL_TRI)) return general_prim_test<GENERAL == RT_GEN_ALL, GENERAL != RT_GEN_INSTANCES_ONLY>(*gen.self, prim, p0, p1, p2, flags, ray, rp, gen.shadow_masks, h);
     return tri_test_pre(p0, p1, p2, ray, rp, h);
   }
   src.tri(prim, p0, p1, p2);

@@ -259,11 +259,11 @@ RT_DEVN bool tri_alpha_rejects(const DScene& sc, int prim, const TriHit& h, bool
 }
 
 // leaf_prim_test's handler (rtx_dev_scene.h): a quadric, or a triangle of a masked mesh
-template <bool MASKS>
+template <bool MASKS, bool QUADRICS>
 RT_DEV bool general_prim_test(const DScene& sc_self, int prim, f3 p0, f3 p1, f3 p2, unsigned flags, const Ray& ray, const RayPre& rp, bool shadow_masks, TriHit& h) {
-  if (flags & RT_FLAG_SPHERE) {
+  if (QUADRICS && (flags & RT_FLAG_SPHERE)) {
     float ts;
-    if (!sphere_test(sc_self.spheres[__float_as_uint(p2.x)], ray.o, ray.d, ray.t_max, ts)) return false;
+    if (!(MASKS ? sphere_test(sc_self.spheres[__float_as_uint(p2.x)], ray.o, ray.d, ray.t_max, ts) : sphere_test_inl(sc_self.spheres[__float_as_uint(p2.x)], ray.o, ray.d, ray.t_max, ts))) return false;
     h.t = ts; h.b0 = h.b1 = 0.0f; h.b2 = ts;
     return true;
   }

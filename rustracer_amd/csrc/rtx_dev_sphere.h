@@ -246,6 +246,8 @@ RT_DEV bool sphere_intersect(const DSphere& s, f3 ray_o, f3 ray_d, float t_max, 
 // out-of-line entry points: the hit test of the traversal leaf loop, and the interaction of an accepted hit (t_max = infinity: the roots, the clipping
 // retry and p_hit do not depend on t_max, which only rejects - the accepted test's decisions are reproduced)
 RT_DEVN bool sphere_test(const DSphere& s, f3 o, f3 d, float t_max, float& t_hit) { return sphere_intersect<false>(s, o, d, t_max, t_hit, nullptr); }
+// the same inline: for the kernels whose only large callee it would be (RT_GEN_NO_MASKS) - inside the kernel it falls under the kernel's register bound
+RT_DEV bool sphere_test_inl(const DSphere& s, f3 o, f3 d, float t_max, float& t_hit) { return sphere_intersect<false>(s, o, d, t_max, t_hit, nullptr); }
 RT_DEVN bool sphere_fill_interaction(const DSphere& s, f3 o, f3 d, SurfaceInteraction& si) { float t; return sphere_intersect<true>(s, o, d, kInf, t, &si); }
 
 struct SpherePoint { f3 p, p_error, n; };

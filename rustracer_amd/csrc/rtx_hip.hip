@@ -841,6 +841,9 @@ static void launch_trace_c(rt_scene* s, const TraceIO& io, const unsigned* queue
       const bool all = s->has_masks || masks_always;
 #define RT_GEN_LAUNCH(KERNEL_ALL, KERNEL_NOMASK, GRID, BLK, ...) do { if (all) hipLaunchKernelGGL(KERNEL_ALL, dim3(GRID), dim3(BLK), 0, stream, __VA_ARGS__); \
                                                                       else hipLaunchKernelGGL(KERNEL_NOMASK, dim3(GRID), dim3(BLK), 0, stream, __VA_ARGS__); } while (0)
+      // ... and neither masks nor quadrics (instances over plain triangles): the pair / four-wide kernels without the quadric test as well
+#define RT_GEN_LAUNCH3(KERNEL_ALL, KERNEL_NOMASK, KERNEL_INST, GRID, BLK, ...) do { if (!all && !s->has_spheres) hipLaunchKernelGGL(KERNEL_INST, dim3(GRID), dim3(BLK), 0, stream, __VA_ARGS__); \
+                                                                                   else RT_GEN_LAUNCH(KERNEL_ALL, KERNEL_NOMASK, GRID, BLK, __VA_ARGS__); } while (0)
       if (!big_only && s->small) {
         if (s->stack_depth <= 16) RT_GEN_LAUNCH((k_trace<ANY, false, true, 256, 16, RT_GEN_ALL>), (k_trace<ANY, false, true, 256, 16, RT_GEN_NO_MASKS>), (trace_grid<ANY, true, 256, 16>(s)), 256, s->d, io, queue, count_ptr, shard_cap, count_static, stats, st_rays, st_nodes, st_tris);
         else if (s->stack_depth <= 32) RT_GEN_LAUNCH((k_trace<ANY, false, true, 256, 32, RT_GEN_ALL>), (k_trace<ANY, false, true, 256, 32, RT_GEN_NO_MASKS>), (trace_grid<ANY, true, 256, 32>(s)), 256, s->d, io, queue, count_ptr, shard_cap, count_static, stats, st_rays, st_nodes, st_tris);
@@ -848,7 +851,7 @@ static void launch_trace_c(rt_scene* s, const TraceIO& io, const unsigned* queue
         return;
       }
       if (!big_only && ANY && s->use_quads && s->quad_stack_depth <= 32) {
-        RT_GEN_LAUNCH((k_trace_quad<ANY, 128, 32, RT_GEN_ALL>), (k_trace_quad<ANY, 128, 32, RT_GEN_NO_MASKS>), (trace_grid<ANY, false, 128, 32>(s)), 128, s->d, io, queue, count_ptr, shard_cap, count_static, stats, st_rays, s->tmin_stack.as<float>(), refill_min);
+        RT_GEN_LAUNCH3((k_trace_quad<ANY, 128, 32, RT_GEN_ALL>), (k_trace_quad<ANY, 128, 32, RT_GEN_NO_MASKS>), (k_trace_quad<ANY, 128, 32, RT_GEN_INSTANCES_ONLY>), (trace_grid<ANY, false, 128, 32>(s)), 128, s->d, io, queue, count_ptr, shard_cap, count_static, stats, st_rays, s->tmin_stack.as<float>(), refill_min);
         return;
       }
       if (!big_only && s->use_pairs && s->use_top && (ANY || s->top_for_closest)) {
@@ -857,10 +860,11 @@ static void launch_trace_c(rt_scene* s, const TraceIO& io, const unsigned* queue
         return;
       }
       if (!big_only && s->use_pairs) {
-        if (s->stack_depth <= 32) RT_GEN_LAUNCH((k_trace_pair<ANY, false, 128, 32, RT_GEN_ALL>), (k_trace_pair<ANY, false, 128, 32, RT_GEN_NO_MASKS>), (trace_grid<ANY, false, 128, 32>(s)), 128, s->d, io, queue, count_ptr, shard_cap, count_static, stats, st_rays, s->tmin_stack.as<float>(), refill_min);
-        else RT_GEN_LAUNCH((k_trace_pair<ANY, false, 128, 64, RT_GEN_ALL>), (k_trace_pair<ANY, false, 128, 64, RT_GEN_NO_MASKS>), (trace_grid<ANY, false, 128, 64>(s)), 128, s->d, io, queue, count_ptr, shard_cap, count_static, stats, st_rays, s->tmin_stack.as<float>(), refill_min);
+        if (s->stack_depth <= 32) RT_GEN_LAUNCH3((k_trace_pair<ANY, false, 128, 32, RT_GEN_ALL>), (k_trace_pair<ANY, false, 128, 32, RT_GEN_NO_MASKS>), (k_trace_pair<ANY, false, 128, 32, RT_GEN_INSTANCES_ONLY>), (trace_grid<ANY, false, 128, 32>(s)), 128, s->d, io, queue, count_ptr, shard_cap, count_static, stats, st_rays, s->tmin_stack.as<float>(), refill_min);
+        else RT_GEN_LAUNCH3((k_trace_pair<ANY, false, 128, 64, RT_GEN_ALL>), (k_trace_pair<ANY, false, 128, 64, RT_GEN_NO_MASKS>), (k_trace_pair<ANY, false, 128, 64, RT_GEN_INSTANCES_ONLY>), (trace_grid<ANY, false, 128, 64>(s)), 128, s->d, io, queue, count_ptr, shard_cap, count_static, stats, st_rays, s->tmin_stack.as<float>(), refill_min);
         return;
       }
+#undef RT_GEN_LAUNCH3
 #undef RT_GEN_LAUNCH
     }
     if (s->stack_depth <= 32) hipLaunchKernelGGL((k_trace_big<ANY, COUNT, 128, 32, true>), dim3(trace_grid<ANY, false, 128, 32>(s)), dim3(128), 0, stream, s->d, io, queue, count_ptr, shard_cap, count_static, stats, st_rays, st_nodes, st_tris);

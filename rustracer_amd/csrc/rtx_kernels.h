@@ -569,6 +569,9 @@ __global__ void __launch_bounds__(256) k_raygen(FrameParams fp, PassState ps) {
   if ((threadIdx.x & 63u) == 0u && n_camera) atomicAdd(&ps.stats[ST_CAMERA], (unsigned long long)n_camera);
 }
 
+// Without the mask evaluator a GENERAL trace kernel's largest part is the quadric test (134 VGPRs inline) or the nested instance walk (133): bound to four
+// waves per SIMD they take 128 / 127 with at most two spilled dwords (measured: three waves instead of two were worth 13 % / 27 % on mis-spheres / instances-10k).
+#define RT_GEN_MIN_WAVES(G) ((G) >= RT_GEN_NO_MASKS ? 4 : 1)
 // ================================================================================ K2/K4 trace
 // rays indexed through `queue` (NULL => identity). Small scenes are copied into LDS first
 // (SMALL): nodes and triangle records are then read from LDS for the whole kernel.
@@ -614,7 +617,7 @@ RT_DEV void trace_write_any(float4* __restrict__ lacc, size_t ls, const float4* 
 // BLOCK threads per workgroup, DEPTH = to-visit stack entries per lane (the host picks the
 // smallest of 16/32/64 that covers the tree height; the reference's fixed 64 is the maximum).
 template <bool ANY, bool COUNT, bool SMALL, int BLOCK, int DEPTH, int GENERAL = 0>  // GENERAL: quadrics / alpha-masked triangles in the leaves (no object instances)
-__global__ void __launch_bounds__(BLOCK) k_trace(DScene sc, TraceIO io, const unsigned* __restrict__ queue, const unsigned* __restrict__ shard_counts, unsigned shard_cap,
+__global__ void __launch_bounds__(BLOCK, RT_GEN_MIN_WAVES(GENERAL)) k_trace(DScene sc, TraceIO io, const unsigned* __restrict__ queue, const unsigned* __restrict__ shard_counts, unsigned shard_cap,
                                                  unsigned count_static, unsigned long long* stats, int st_rays, int st_nodes, int st_tris) {
   const float4* __restrict__ ray_o = io.ray_o; const float4* __restrict__ ray_d = io.ray_d; const size_t rs = io.ray_stride;
   float4* __restrict__ hits = io.hits; const size_t hs = io.hit_stride; const bool hit_b2 = io.hit_b2 != 0;
@@ -713,7 +716,7 @@ RT_DEV bool instance_intersect(const DScene& sc, unsigned inst, f3 o, f3 d, floa
 }
 // One primitive of a leaf of a GENERAL scene, for the persistent kernels: an object instance (the hit id then names (instance, the object's primitive)), a
 // quadric, a masked triangle or a plain one. Returns whether the ray hits; for a closest-hit ray prim / hit / t_max are updated by the caller's rule.
-template <bool ANY, bool COUNT, class StackT, bool MASKS = true>
+template <bool ANY, bool COUNT, class StackT, bool MASKS = true, bool QUADRICS = true>
 RT_DEV bool general_leaf_prim(const DScene& sc, const float4* __restrict__ tri_p, int prim, const Ray& ray, const RayPre& rp, bool shadow_masks, StackT* nested_stack, int stack_stride,
                               TriHit& h, int& hit_prim, float& t_hit, unsigned& n_nodes, unsigned& n_tris, NestedCtx nc = NestedCtx{nullptr, nullptr, 0}) {
   const float4 a = tri_p[3 * prim], b = tri_p[3 * prim + 1], c = tri_p[3 * prim + 2];
@@ -727,7 +730,7 @@ RT_DEV bool general_leaf_prim(const DScene& sc, const float4* __restrict__ tri_p
     return true;
   }
   hit_prim = prim;
-  if (flags & (RT_FLAG_SPHERE | RT_FLAG_GENERAL_TRI)) { if (!general_prim_test<MASKS>(*sc.self, prim, p0, p1, p2, flags, ray, rp, shadow_masks, h)) return false; }
+  if ((MASKS || QUADRICS) && (flags & (RT_FLAG_SPHERE | RT_FLAG_GENERAL_TRI))) { if (!general_prim_test<MASKS, QUADRICS>(*sc.self, prim, p0, p1, p2, flags, ray, rp, shadow_masks, h)) return false; }
   else if (!tri_test_pre(p0, p1, p2, ray, rp, h)) return false;
   t_hit = h.t;
   return true;
@@ -996,7 +999,7 @@ RT_DEV bool pair_leaf_prims(PairLane& L, const DScene& sc, const float4* __restr
   if (GENERAL && (L.cur & RT_PAIR_GENERAL)) {
     for (int i = 0; i < n; ++i) {
       TriHit h; int hp = 0; float th = 0.0f; unsigned nn = 0, ntt = 0;
-      if (!general_leaf_prim<ANY, false, unsigned, GENERAL == RT_GEN_ALL>(sc, tri_p, off + i, L.ray, L.rp(), shadow_masks, nested_stack, stack_stride, h, hp, th, nn, ntt, nc)) continue;
+      if (!general_leaf_prim<ANY, false, unsigned, GENERAL == RT_GEN_ALL, GENERAL != RT_GEN_INSTANCES_ONLY>(sc, tri_p, off + i, L.ray, L.rp(), shadow_masks, nested_stack, stack_stride, h, hp, th, nn, ntt, nc)) continue;
       L.found = true;
       if (ANY) break;
       L.ray.t_max = th; L.prim = hp; L.hit = h;
@@ -1022,8 +1025,9 @@ RT_DEV void pair_leaf_step(PairLane& L, const TraceOut& o, const DScene& sc, con
   if (ANY && L.found) pair_finish<ANY>(L, o); else pair_pop<ANY, BLOCK>(L, o, stack, tstack, grid_lanes);
 }
 
+// (closest hit with quadrics AND the nested walk: 154 VGPRs at three waves; bound to four it would spill 24 dwords)
 template <bool ANY, bool WW, int BLOCK, int DEPTH, int GENERAL = 0>
-__global__ void __launch_bounds__(BLOCK) k_trace_pair(DScene sc, TraceIO io, const unsigned* __restrict__ queue, const unsigned* __restrict__ shard_counts, unsigned shard_cap,
+__global__ void __launch_bounds__(BLOCK, (GENERAL == RT_GEN_NO_MASKS && !ANY) ? 3 : RT_GEN_MIN_WAVES(GENERAL)) k_trace_pair(DScene sc, TraceIO io, const unsigned* __restrict__ queue, const unsigned* __restrict__ shard_counts, unsigned shard_cap,
                                                       unsigned count_static, unsigned long long* stats, int st_rays, float* __restrict__ tmin_stack_mem, unsigned refill_min) {
   const float4* __restrict__ ray_o = io.ray_o; const float4* __restrict__ ray_d = io.ray_d; const size_t rs = io.ray_stride;
   __shared__ unsigned stack_mem[DEPTH * BLOCK];
@@ -1285,7 +1289,7 @@ RT_DEV void quad_interior_step(PairLane& L, const TraceOut& o, const float4* __r
 }
 
 template <bool ANY, int BLOCK, int DEPTH, int GENERAL = 0>
-__global__ void __launch_bounds__(BLOCK) k_trace_quad(DScene sc, TraceIO io, const unsigned* __restrict__ queue, const unsigned* __restrict__ shard_counts, unsigned shard_cap,
+__global__ void __launch_bounds__(BLOCK, RT_GEN_MIN_WAVES(GENERAL)) k_trace_quad(DScene sc, TraceIO io, const unsigned* __restrict__ queue, const unsigned* __restrict__ shard_counts, unsigned shard_cap,
                                                       unsigned count_static, unsigned long long* stats, int st_rays, float* __restrict__ tmin_stack_mem, unsigned refill_min) {
   const float4* __restrict__ ray_o = io.ray_o; const float4* __restrict__ ray_d = io.ray_d; const size_t rs = io.ray_stride;
   __shared__ unsigned stack_mem[DEPTH * BLOCK];

@@ -257,13 +257,15 @@ def test_kernel_register_and_scratch_budgets(host):
         # the plain instantiations above must not notice that these exist
         "rtx::k_trace_pair<false, false, 128, 32, 1>": (192, 128), "rtx::k_trace_quad<true, 128, 32, 1>": (192, 128),
         # ... and without the mask evaluator (scenes whose meshes carry no alpha mask): three waves
-        "rtx::k_trace_pair<false, false, 128, 32, 2>": (168, 32), "rtx::k_trace_quad<true, 128, 32, 2>": (168, 32), "rtx::k_trace<false, false, true, 256, 16, 2>": (168, 32),
+        "rtx::k_trace_pair<false, false, 128, 32, 2>": (168, 32), "rtx::k_trace_quad<true, 128, 32, 2>": (128, 32), "rtx::k_trace<false, false, true, 256, 16, 2>": (128, 32),
+        # ... and with neither masks nor quadrics (instances over plain triangles): four waves, nothing spilled
+        "rtx::k_trace_pair<false, false, 128, 32, 3>": (128, 0), "rtx::k_trace_quad<true, 128, 32, 3>": (128, 0),
         "rtx::k_shade<3, true>": (256, 512), "rtx::k_shade<5, true>": (256, 512), "rtx::k_shade<6, true>": (256, 512),   # (they spill some: still one wave more than the generic kernel's code)
         "rtx::k_resolve<false>": (88, 256), "rtx::k_raygen": (72, 0), "rtx::k_film_accumulate": (48, 0),
     }
     for name, (vg, sc) in budget.items():
         r = res[name]
-        spills_allowed = 32 if name.startswith("rtx::k_shade<0") else (64 if name.startswith("rtx::k_shade<") and name.endswith("true>") else 0)  # the generic kernel fills its 256 registers: a few spilled values, never a second wave lost
+        spills_allowed = 32 if name.startswith("rtx::k_shade<0") else (64 if name.startswith("rtx::k_shade<") and name.endswith("true>") else (2 if name.endswith(", 2>") else 0))  # the generic kernel fills its 256 registers: a few spilled values, never a second wave lost
         assert r["vgpr"] <= vg and r["scratch"] <= sc and r["vgpr_spills"] <= spills_allowed, (name, r)
 
 
