@@ -1,5 +1,5 @@
 #!/bin/bash
-# final measurements of the round: per-scene rocprofv3 stats + PMC passes -> profiles/r03_*, the default bench line, SQ counter sets
+# Final measurements of a round (GPU box, repo root): per-scene rocprofv3 stats + PMC passes -> profiles/<tag>_*, the default bench line, the two extra workloads, SQ counter sets. Usage: bash scripts/round_profiles.sh r03
 TAG=${1:-r03}
 mkdir -p gpurun_out/final
 for sc in cornell room blob mis; do
