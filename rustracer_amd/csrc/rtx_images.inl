@@ -329,7 +329,7 @@ bool hdr_decode(const std::vector<uint8_t>& file, int& W, int& H, std::vector<fl
 // specification: magic + version, attribute list (channels, compression, dataWindow, displayWindow, lineOrder), offset table,
 // scan-line blocks of 1 (NONE, RLE, ZIPS), 16 (ZIP, PXR24) or 32 (PIZ) lines - or tiles - holding each line's channels in alphabetical order. ZIP / ZIPS / RLE
 // payloads are byte-delta coded and split into even / odd halves before compression; PIZ and PXR24 are described at their decoders. Tiled files give their
-// full-resolution level (what exr 1.4.2 calls the largest resolution level), multi-part files their first flat part with R, G and B. The lossy B44 / B44A and
+// full-resolution level (what exr 1.4.2 calls the largest resolution level), multi-part files their first flat part with R, G and B. B44 / B44A are decoded (below); the lossy
 // DWAA / DWAB compressions and deep data are refused with a message. The reference takes the resolution from displayWindow and the pixels from the layer
 // (imageio.rs:153-159), which only agree when the two windows do: files where they differ are refused.
 namespace {
@@ -450,7 +450,7 @@ void piz_wav_decode(uint16_t* in, int nx, int ox, int ny, int oy, uint16_t mx) {
     p2 = p; p >>= 1;
   }
 }
-struct ExrChan { std::string name; int type, xs, ys; };
+struct ExrChan { std::string name; int type, xs, ys; int plinear = 0; };
 // one block (rows x w pixels, every channel) of PIZ data -> the uncompressed block layout (per row, per channel, little-endian samples)
 bool piz_uncompress(const uint8_t* src, size_t size, const std::vector<ExrChan>& chans, size_t w, size_t rows, std::vector<uint8_t>& raw, std::string& err) {
   if (size < 4) { err = "EXR: truncated PIZ block"; return false; }
@@ -511,6 +511,91 @@ bool pxr24_uncompress(const uint8_t* src, size_t size, const std::vector<ExrChan
   return true;
 }
 
+// B44 / B44A (compression 6 / 7): lossy, fixed rate. The block's channels are stored one after the other (not interleaved by row). A HALF channel is cut into
+// 4 x 4 pixel cells (rows and columns past the edge repeat the last one when packing; only the part inside is kept here), each cell packed into 14 bytes: the
+// first value as 16 bits, a 6-bit shift, and fifteen 6-bit running differences - down the first column, then along each row - in units of 2^shift, biased by 32;
+// B44A writes a cell whose sixteen values are equal as 3 bytes (value, then 0xfc where the shift would be). Values travel in an order-preserving 16-bit form
+// (sign bit flipped for positives, all bits for negatives). Channels flagged pLinear are stored as exp(x / 8) and come back through 8 ln(x). FLOAT and UINT
+// channels are stored raw. After the OpenEXR library's ImfB44Compressor, which exr 1.4.2's b44 module restates.
+inline uint16_t float_to_half_rne(float f) {
+  uint32_t x; memcpy(&x, &f, 4);
+  const uint32_t sign = (x >> 16) & 0x8000u; x &= 0x7fffffffu;
+  if (x >= 0x7f800000u) return (uint16_t)(sign | 0x7c00u | (x > 0x7f800000u ? 0x200u | ((x >> 13) & 0x3ffu) : 0u));
+  if (x >= 0x477ff000u) return (uint16_t)(sign | 0x7c00u);                 // rounds to infinity
+  if (x < 0x33000001u) return (uint16_t)sign;                               // rounds to zero
+  if (x < 0x38800000u) {                                                    // subnormal half
+    const int e = (int)(x >> 23); const uint32_t m = (x & 0x7fffffu) | 0x800000u; const int sh = 126 - e;   // value = m * 2^(e - 150); half ulp 2^-24
+    const uint32_t q = m >> sh, rem = m & ((1u << sh) - 1u), half = 1u << (sh - 1);
+    return (uint16_t)(sign | (q + ((rem > half || (rem == half && (q & 1u))) ? 1u : 0u)));
+  }
+  const uint32_t m = x & 0x1fffu, base = (x - 0x38000000u) >> 13;
+  return (uint16_t)(sign | (base + ((m > 0x1000u || (m == 0x1000u && (base & 1u))) ? 1u : 0u)));
+}
+inline void b44_unpack14(const uint8_t* b, uint16_t* s) {
+  s[0] = (uint16_t)((b[0] << 8) | b[1]);
+  const unsigned shift = b[2] >> 2; const unsigned bias = 0x20u << shift;
+  s[4] = (uint16_t)(s[0] + ((((b[2] << 4) | (b[3] >> 4)) & 0x3fu) << shift) - bias);
+  s[8] = (uint16_t)(s[4] + ((((b[3] << 2) | (b[4] >> 6)) & 0x3fu) << shift) - bias);
+  s[12] = (uint16_t)(s[8] + ((b[4] & 0x3fu) << shift) - bias);
+  s[1] = (uint16_t)(s[0] + ((unsigned)(b[5] >> 2) << shift) - bias);
+  s[5] = (uint16_t)(s[4] + ((((b[5] << 4) | (b[6] >> 4)) & 0x3fu) << shift) - bias);
+  s[9] = (uint16_t)(s[8] + ((((b[6] << 2) | (b[7] >> 6)) & 0x3fu) << shift) - bias);
+  s[13] = (uint16_t)(s[12] + ((b[7] & 0x3fu) << shift) - bias);
+  s[2] = (uint16_t)(s[1] + ((unsigned)(b[8] >> 2) << shift) - bias);
+  s[6] = (uint16_t)(s[5] + ((((b[8] << 4) | (b[9] >> 4)) & 0x3fu) << shift) - bias);
+  s[10] = (uint16_t)(s[9] + ((((b[9] << 2) | (b[10] >> 6)) & 0x3fu) << shift) - bias);
+  s[14] = (uint16_t)(s[13] + ((b[10] & 0x3fu) << shift) - bias);
+  s[3] = (uint16_t)(s[2] + ((unsigned)(b[11] >> 2) << shift) - bias);
+  s[7] = (uint16_t)(s[6] + ((((b[11] << 4) | (b[12] >> 4)) & 0x3fu) << shift) - bias);
+  s[11] = (uint16_t)(s[10] + ((((b[12] << 2) | (b[13] >> 6)) & 0x3fu) << shift) - bias);
+  s[15] = (uint16_t)(s[14] + ((b[13] & 0x3fu) << shift) - bias);
+  for (int i = 0; i < 16; ++i) s[i] = (s[i] & 0x8000u) ? (uint16_t)(s[i] & 0x7fffu) : (uint16_t)~s[i];
+}
+bool b44_uncompress(const uint8_t* src, size_t size, const std::vector<ExrChan>& chans, size_t w, size_t rows, std::vector<uint8_t>& raw, std::string& err) {
+  size_t line_bytes = 0; std::vector<size_t> chan_off(chans.size());
+  for (size_t k = 0; k < chans.size(); ++k) { chan_off[k] = line_bytes; line_bytes += w * (chans[k].type == 1 ? 2 : 4); }
+  raw.assign(rows * line_bytes, 0);
+  static std::vector<uint16_t> log_table;  // 8 ln(x) per half bit pattern (negative / non-finite -> 0): built on first use
+  size_t p = 0;
+  for (size_t k = 0; k < chans.size(); ++k) {
+    const ExrChan& c = chans[k];
+    if (c.type != 1) {  // FLOAT / UINT: the channel's rows, raw
+      const size_t n = w * 4;
+      if (p + rows * n > size) { err = "EXR: truncated B44 block"; return false; }
+      for (size_t r = 0; r < rows; ++r) { memcpy(&raw[r * line_bytes + chan_off[k]], src + p, n); p += n; }
+      continue;
+    }
+    if (c.plinear && log_table.empty()) {
+      log_table.resize(65536);
+      for (uint32_t i = 0; i < 65536; ++i) {
+        const bool finite = (i & 0x7c00u) != 0x7c00u; const float h = half_to_float((uint16_t)i);
+        log_table[i] = (!finite || h < 0.0f) ? (uint16_t)0 : float_to_half_rne((float)(8.0 * std::log((double)h)));
+      }
+    }
+    for (size_t y = 0; y < rows; y += 4)
+      for (size_t x = 0; x < w; x += 4) {
+        uint16_t s[16];
+        if (p + 3 > size) { err = "EXR: truncated B44 block"; return false; }
+        if (src[p + 2] == 0xfc) {
+          uint16_t v = (uint16_t)((src[p] << 8) | src[p + 1]); v = (v & 0x8000u) ? (uint16_t)(v & 0x7fffu) : (uint16_t)~v;
+          for (int i = 0; i < 16; ++i) s[i] = v;
+          p += 3;
+        } else {
+          if (p + 14 > size) { err = "EXR: truncated B44 block"; return false; }
+          b44_unpack14(src + p, s); p += 14;
+        }
+        if (c.plinear) for (int i = 0; i < 16; ++i) s[i] = log_table[s[i]];
+        for (size_t dy = 0; dy < 4 && y + dy < rows; ++dy)
+          for (size_t dx = 0; dx < 4 && x + dx < w; ++dx) {
+            uint8_t* q = &raw[(y + dy) * line_bytes + chan_off[k] + 2 * (x + dx)];
+            q[0] = (uint8_t)(s[4 * dy + dx] & 0xff); q[1] = (uint8_t)(s[4 * dy + dx] >> 8);
+          }
+      }
+  }
+  if (p != size) { err = "EXR: B44 block longer than its cells"; return false; }
+  return true;
+}
+
 struct ExrPart {
   std::vector<ExrChan> chans; int compression = -1, line_order = 0; int32_t dw[4] = {0, 0, -1, -1}, disp[4] = {0, 0, -1, -1}; bool have_dw = false, have_disp = false;
   bool tiled = false, deep = false; uint32_t tile_w = 0, tile_h = 0; int level_mode = 0, rounding = 0; long long chunk_count = -1; std::string type;
@@ -541,7 +626,7 @@ bool exr_decode(const std::vector<uint8_t>& file, int& W, int& H, std::vector<fl
       if (name == "channels") {
         while (b.pos < end && b.p[b.pos]) {
           ExrChan c; if (!cstr(c.name) || b.pos + 16 > end) { err = "EXR: bad channel list"; return false; }
-          c.type = (int)le32(); b.pos += 4; c.xs = (int)le32(); c.ys = (int)le32();
+          c.type = (int)le32(); c.plinear = b.p[b.pos] != 0; b.pos += 4; c.xs = (int)le32(); c.ys = (int)le32();
           if (c.type < 0 || c.type > 2) { err = "EXR: unknown pixel type"; return false; }
           if (c.xs != 1 || c.ys != 1) { err = "EXR: sub-sampled channels are not supported"; return false; }
           pt.chans.push_back(c);
@@ -601,8 +686,7 @@ bool exr_decode(const std::vector<uint8_t>& file, int& W, int& H, std::vector<fl
   if (part < 0) { err = "EXR: no layer with R, G and B channels"; return false; }
   const ExrPart& pt = parts[part];
   const std::vector<ExrChan>& chans = pt.chans; const int compression = pt.compression; const int32_t* dw = pt.dw; const int32_t* disp = pt.disp;
-  if (compression == 6 || compression == 7) { err = "EXR: B44 / B44A compression is not supported"; return false; }
-  if (compression > 5) { err = "EXR: DWAA / DWAB compression is not supported"; return false; }
+  if (compression > 7) { err = "EXR: DWAA / DWAB compression is not supported"; return false; }
   if (pt.line_order > 2) { err = "EXR: unsupported line order"; return false; }
   const long long w = (long long)dw[2] - dw[0] + 1, h = (long long)dw[3] - dw[1] + 1;
   if (disp[2] - disp[0] != dw[2] - dw[0] || disp[3] - disp[1] != dw[3] - dw[1]) { err = "EXR: data window and display window differ in size"; return false; }
@@ -655,6 +739,7 @@ bool exr_decode(const std::vector<uint8_t>& file, int& W, int& H, std::vector<fl
       if (!exr_unpredict(raw, want, err)) return false;
     } else if (compression == 4) { if (!piz_uncompress(src, size, chans, (size_t)cols, (size_t)rows, raw, err)) return false; }
     else if (compression == 5) { if (!pxr24_uncompress(src, size, chans, (size_t)cols, (size_t)rows, raw, err)) return false; }
+    else if (compression == 6 || compression == 7) { if (!b44_uncompress(src, size, chans, (size_t)cols, (size_t)rows, raw, err)) return false; }
     else { err = "EXR: compressed block in an uncompressed file"; return false; }
     if (raw.size() != want) { err = "EXR: block decompressed to the wrong size"; return false; }
     for (size_t r = 0; r < (size_t)rows; ++r) {

@@ -445,17 +445,71 @@ def _piz_block(chan_words, w, rows, use_runs=True):
     return struct.pack("<HH", mn, mx_) + (bytes(bitmap[mn:mx_ + 1]) if mn <= mx_ else b"") + struct.pack("<i", len(huf)) + huf
 
 
+def _b44_to_ordered(s):
+    """half bit patterns -> the order-preserving 16-bit form B44 packs (NaN / infinity become the smallest value)"""
+    s = np.asarray(s, np.uint16).astype(np.int64)
+    return np.where((s & 0x7c00) == 0x7c00, 0x8000, np.where(s & 0x8000, (~s) & 0xffff, s | 0x8000)).astype(np.int64)
+
+
+def _b44_pack(s, flat_ok: bool) -> bytes:
+    """One 4 x 4 cell (16 half bit patterns, row by row) -> 14 bytes, or 3 when all values are equal and flat_ok (B44A). After the description of the B44
+    format: the first value, a shift, fifteen 6-bit differences (down the first column, then along the rows) in units of 2^shift biased by 32; the shift is the
+    smallest one for which every difference fits."""
+    t = _b44_to_ordered(s)
+    tmax = int(t.max())
+    shift = -1
+    while True:
+        shift += 1
+        x = (tmax - t) << 1
+        a = (1 << shift) - 1
+        b = (x >> (shift + 1)) & 1
+        d = (x + a + b) >> (shift + 1)                                   # (tmax - t) / 2^shift, rounded half to even
+        pairs = [(0, 4), (4, 8), (8, 12), (0, 1), (4, 5), (8, 9), (12, 13), (1, 2), (5, 6), (9, 10), (13, 14), (2, 3), (6, 7), (10, 11), (14, 15)]
+        r = [int(d[i] - d[j]) + 0x20 for i, j in pairs]
+        if min(r) >= 0 and max(r) <= 0x3f:
+            break
+    t0 = int(t[0])
+    if flat_ok and min(r) == 0x20 and max(r) == 0x20:
+        return bytes([t0 >> 8, t0 & 0xff, 0xfc])
+    t0 = (tmax - (int(d[0]) << shift)) & 0xffff                          # the first value as the decoder will rebuild the others from it
+    return bytes([t0 >> 8, t0 & 0xff,
+                  ((shift << 2) | (r[0] >> 4)) & 0xff, ((r[0] << 4) | (r[1] >> 2)) & 0xff, ((r[1] << 6) | r[2]) & 0xff,
+                  ((r[3] << 2) | (r[4] >> 4)) & 0xff, ((r[4] << 4) | (r[5] >> 2)) & 0xff, ((r[5] << 6) | r[6]) & 0xff,
+                  ((r[7] << 2) | (r[8] >> 4)) & 0xff, ((r[8] << 4) | (r[9] >> 2)) & 0xff, ((r[9] << 6) | r[10]) & 0xff,
+                  ((r[11] << 2) | (r[12] >> 4)) & 0xff, ((r[12] << 4) | (r[13] >> 2)) & 0xff, ((r[13] << 6) | r[14]) & 0xff])
+
+
+def b44_unpack(cell: bytes) -> np.ndarray:
+    """The sixteen half bit patterns a B44 cell (14 bytes, or 3 for a flat B44A cell) decodes to: the model the decoder's tests compare with."""
+    b = list(cell)
+    s = [0] * 16
+    s[0] = (b[0] << 8) | b[1]
+    if len(b) == 3:
+        s = [s[0]] * 16
+    else:
+        sh = b[2] >> 2
+        bias = 0x20 << sh
+        six = [((b[2] << 4) | (b[3] >> 4)) & 0x3f, ((b[3] << 2) | (b[4] >> 6)) & 0x3f, b[4] & 0x3f,
+               b[5] >> 2, ((b[5] << 4) | (b[6] >> 4)) & 0x3f, ((b[6] << 2) | (b[7] >> 6)) & 0x3f, b[7] & 0x3f,
+               b[8] >> 2, ((b[8] << 4) | (b[9] >> 4)) & 0x3f, ((b[9] << 2) | (b[10] >> 6)) & 0x3f, b[10] & 0x3f,
+               b[11] >> 2, ((b[11] << 4) | (b[12] >> 4)) & 0x3f, ((b[12] << 2) | (b[13] >> 6)) & 0x3f, b[13] & 0x3f]
+        order = [(4, 0), (8, 4), (12, 8), (1, 0), (5, 4), (9, 8), (13, 12), (2, 1), (6, 5), (10, 9), (14, 13), (3, 2), (7, 6), (11, 10), (15, 14)]
+        for (dst, frm), v in zip(order, six):
+            s[dst] = (s[frm] + (v << sh) - bias) & 0xffff
+    return np.array([(v & 0x7fff) if (v & 0x8000) else ((~v) & 0xffff) for v in s], np.uint16)
+
+
 def write_exr(path: str, img, compression: str = "zip", pixel_type: str = "half", layer: str = "", alpha: bool = False, origin=(0, 0), extra_channels=(),
-              tiles=None, level_mode: str = "one", parts_before=(), piz_runs: bool = True) -> None:
+              tiles=None, level_mode: str = "one", parts_before=(), piz_runs: bool = True, plinear=()) -> None:
     """OpenEXR file (OpenEXR file layout specification) of img (h, w, 3) float: channels <layer>B/G/R (+A, + extra names) in alphabetical order, half, float
-    or uint samples, compression none | rle | zips | zip | piz | pxr24; scan-line blocks, or tiles=(tw, th) with level_mode one | mipmap (lower levels hold
+    or uint samples, compression none | rle | zips | zip | piz | pxr24 | b44 | b44a (plinear: names of channels flagged pLinear); scan-line blocks, or tiles=(tw, th) with level_mode one | mipmap (lower levels hold
     a constant: a reader must take level 0); parts_before: channel-name tuples of parts written in front of the image's (a multi-part file).
     Test writer: numpy + zlib + the format description only."""
     import struct
     import zlib
     a = np.asarray(img, np.float32)
     h, w = a.shape[:2]
-    comp = {"none": 0, "rle": 1, "zips": 2, "zip": 3, "piz": 4, "pxr24": 5}[compression]
+    comp = {"none": 0, "rle": 1, "zips": 2, "zip": 3, "piz": 4, "pxr24": 5, "b44": 6, "b44a": 7}[compression]
     ptype, dt = {"half": (1, "<f2"), "float": (2, "<f4"), "uint": (0, "<u4")}[pixel_type]
     planes = {layer + "R": a[..., 0], layer + "G": a[..., 1], layer + "B": a[..., 2]}
     if alpha:
@@ -475,6 +529,25 @@ def write_exr(path: str, img, compression: str = "zip", pixel_type: str = "half"
         if comp == 4:
             chan_words = [np.ascontiguousarray(rows_of[n]).view("<u2").reshape(nrows, -1) for n in names_]
             out = _piz_block(chan_words, wb, nrows, piz_runs)
+            return out if len(out) < len(block) else block
+        if comp in (6, 7):  # per channel: half samples in 4 x 4 cells (edge cells repeat the last row / column), other sample types raw
+            out = bytearray()
+            for n in names_:
+                v = np.ascontiguousarray(rows_of[n])
+                if ptype != 1:
+                    out += v.tobytes()
+                    continue
+                hb = v.view("<u2").reshape(nrows, wb)
+                if n in plinear:  # stored as exp(x / 8)
+                    f = hb.view("<f2").astype(np.float64)
+                    e = np.where(np.isfinite(f), np.where(f >= 8 * np.log(65504.0), 65504.0, np.exp(np.minimum(f, 100.0) / 8)), 0.0)
+                    hb = e.astype("<f2").view("<u2")
+                for y in range(0, nrows, 4):
+                    ys = [min(y + k, nrows - 1) for k in range(4)]
+                    for x in range(0, wb, 4):
+                        xs = [min(x + k, wb - 1) for k in range(4)]
+                        out += _b44_pack(hb[np.ix_(ys, xs)].reshape(-1), comp == 7)
+            out = bytes(out)
             return out if len(out) < len(block) else block
         if comp == 5:
             pre = bytearray()
@@ -527,7 +600,7 @@ def write_exr(path: str, img, compression: str = "zip", pixel_type: str = "half"
     def part(planes_, part_no, name):
         names_ = sorted(planes_)
         typed = {n: planes_[n].astype(dt) for n in names_}
-        chlist = b"".join(n.encode() + b"\0" + struct.pack("<iBxxxii", ptype, 0, 1, 1) for n in names_) + b"\0"
+        chlist = b"".join(n.encode() + b"\0" + struct.pack("<iBxxxii", ptype, 1 if n in plinear else 0, 1, 1) for n in names_) + b"\0"
         x0, y0 = origin
         box = struct.pack("<iiii", x0, y0, x0 + w - 1, y0 + h - 1)
         hdr = (attr("channels", "chlist", chlist) + attr("compression", "compression", bytes([comp])) +
@@ -552,7 +625,7 @@ def write_exr(path: str, img, compression: str = "zip", pixel_type: str = "half"
                         data = pack_block(sub, names_, wb, nrows)
                         chunks.append(pre + struct.pack("<iiiiI", tx, ty, lv, lv, len(data)) + data)
         else:
-            lines = {3: 16, 5: 16, 4: 32}.get(comp, 1)
+            lines = {3: 16, 5: 16, 4: 32, 6: 32, 7: 32}.get(comp, 1)
             for yb in range(0, h, lines):
                 sub = {n: typed[n][yb:min(h, yb + lines)] for n in names_}
                 data = pack_block(sub, names_, w, min(h, yb + lines) - yb)

@@ -248,6 +248,74 @@ def test_openexr_piz_details(ingest, tmp_path):
         assert np.array_equal(ingest.read_image(str(tmp_path / "r.exr")), r)
 
 
+def _b44_model(a, flat_ok, plinear=False):
+    """What a B44 file of the half image `a` (h, w, 3) decodes to, cell by cell through the test writer's packer and the model unpacker (rustracer_amd.ingest):
+    32-line blocks, 4 x 4 cells whose missing rows / columns repeat the last one; pLinear channels go through exp(x / 8) and come back through 8 ln(x)."""
+    from rustracer_amd.ingest import _b44_pack, b44_unpack
+    hb = a.astype(np.float16).view(np.uint16)
+    h, w = hb.shape[:2]
+    out = np.zeros_like(hb)
+    for c in range(3):
+        for by in range(0, h, 32):
+            nrows = min(32, h - by)
+            for y in range(0, nrows, 4):
+                ys = [by + min(y + k, nrows - 1) for k in range(4)]
+                for x in range(0, w, 4):
+                    xs = [min(x + k, w - 1) for k in range(4)]
+                    cell = hb[np.ix_(ys, xs, [c])].reshape(-1)
+                    if plinear:
+                        f = cell.view(np.float16).astype(np.float64)
+                        cell = np.where(np.isfinite(f), np.where(f >= 8 * np.log(65504.0), 65504.0, np.exp(np.minimum(f, 100.0) / 8)), 0.0).astype(np.float16).view(np.uint16)
+                    dec = b44_unpack(_b44_pack(cell, flat_ok))
+                    if plinear:
+                        f = dec.view(np.float16).astype(np.float64)
+                        with np.errstate(divide="ignore", invalid="ignore"):
+                            dec = np.where(np.isfinite(f) & (f >= 0), 8.0 * np.log(f), 0.0).astype(np.float32).astype(np.float16).view(np.uint16)
+                    for k, yy in enumerate(ys):
+                        for j, xx in enumerate(xs):
+                            out[yy, xx, c] = dec[4 * k + j]
+    return out.view(np.float16).astype(np.float32)
+
+
+@pytest.mark.parametrize("compression", ["b44", "b44a"])
+def test_openexr_b44_files(ingest, tmp_path, compression):
+    """B44 / B44A (lossy, fixed rate: exr 1.4.2 reads them, rc/imageio.rs:134-177). The decoder against the model of the format: the same half bit patterns,
+    and those within the format's error of the original - smooth cells, noisy cells (large shifts), negative values, a flat region (3-byte cells in B44A),
+    edge cells, a FLOAT channel beside the half ones (stored raw), tiles."""
+    rng = np.random.default_rng(44)
+    h, w = 45, 38                                                          # two 32-line blocks, clipped cells on both edges
+    yy, xx = np.mgrid[0:h, 0:w]
+    a = np.stack([0.5 + 0.4 * np.sin(xx / 5.0) * np.cos(yy / 7.0), rng.random((h, w)) * 100.0, -2.0 + 0.01 * xx - 0.02 * yy], -1).astype(np.float32)
+    a[8:24, 4:20] = (0.25, 3.0, -1.0)                                      # flat cells
+    a[30, 30] = (0.0, 65504.0, 1e-7)
+    path = str(tmp_path / "b.exr")
+    ingest.write_exr(path, a, compression, "half", alpha=True, origin=(2, -5))
+    got = ingest.read_image(path)
+    want = _b44_model(a, compression == "b44a")
+    assert np.array_equal(got.view(np.uint32), want.view(np.uint32))
+    err0 = np.abs(got[..., 0] - a[..., 0]); err0[28:32, 28:32] = 0                # (the cell of the planted 0.0 spans 0 .. 0.5: a coarse shift)
+    assert err0.max() < 4e-3 and np.array_equal(got[8:24, 4:20], np.broadcast_to(np.float32([0.25, 3.0, -1.0]), (16, 16, 3)))
+    size_a = len(open(path, "rb").read())
+    if compression == "b44a":
+        ingest.write_exr(str(tmp_path / "b0.exr"), a, "b44", "half", alpha=True, origin=(2, -5))
+        assert size_a < len(open(str(tmp_path / "b0.exr"), "rb").read())   # the flat cells took 3 bytes
+    # pLinear channels
+    pos = np.abs(a) + 0.01
+    ingest.write_exr(path, pos, compression, "half", plinear=("R", "G", "B"))
+    got = ingest.read_image(path)
+    assert np.array_equal(got.view(np.uint32), _b44_model(pos, compression == "b44a", plinear=True).view(np.uint32))
+    ep = np.abs(got[..., 0] - pos[..., 0]); ep[28:32, 28:32] = 0                  # exp(x / 8) as a half near 1 resolves x to 8 * 2^-10: an absolute error
+    assert ep.max() < 0.012
+    # float samples are stored raw by B44; tiles hold cells of their own
+    ingest.write_exr(path, a, compression, "float")
+    assert np.array_equal(ingest.read_image(path), a)
+    ingest.write_exr(path, a, compression, "half", tiles=(16, 12))
+    t = ingest.read_image(path)
+    e0 = np.abs(t[..., 0] - a[..., 0]); e0[24:36, 16:32] = 0                     # (the tile cell that holds the planted 0.0)
+    e2 = np.abs(t[..., 2] - a[..., 2]); e2[24:36, 16:32] = 0
+    assert e0.max() < 4e-3 and e2.max() < 8e-3
+
+
 @pytest.mark.parametrize("compression", ["none", "zip", "piz", "rle"])
 @pytest.mark.parametrize("level_mode", ["one", "mipmap"])
 def test_openexr_tiled_files(ingest, tmp_path, compression, level_mode):
@@ -272,7 +340,7 @@ def test_openexr_named_layer_and_refusals(ingest, host, tmp_path):
     assert np.array_equal(ingest.read_image(path), a)                              # first layer that has R, G and B
     raw = bytearray(open(path, "rb").read())
     i = raw.index(b"compression\0compression\0") + len(b"compression\0compression\0") + 4
-    for code, word in ((6, "B44"), (7, "B44"), (8, "DWA"), (9, "DWA")):           # the lossy compressions are refused by name
+    for code, word in ((8, "DWA"), (9, "DWA")):                                   # the DCT compressions are refused by name
         raw[i] = code
         open(path, "wb").write(raw)
         with pytest.raises(host.BackendError, match=word):
