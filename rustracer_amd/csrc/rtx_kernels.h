@@ -53,7 +53,13 @@ struct PassState {
   // sampler tables of the chunk
   const unsigned* scrambles;        // [pixel][3*dims]
   const unsigned short* perms;      // [pixel][2*dims][spp]
-  RayRec* ray; VertRec* vert; BetaRec* bet; PathAcc* acc; ShadowRec* sh; MisRec* mi;
+  RayRec* ray; VertRec* vert; BetaRec* bet; PathAcc* acc;  // indexed by path id
+  // The records of a vertex's shadow ray and BSDF-sampled MIS ray are indexed by the vertex's POSITION IN THE SHADE LAUNCH'S QUEUE (entry i of the - possibly
+  // material-sorted - queue; distinct for every vertex of a bounce), not by its path id: the 64 lanes of a shade wave then write 64 neighbouring records, the
+  // ray queues (which hold these indices) list them in nearly ascending order for the trace kernels and k_resolve, and occ_sh / occ_mi below are indexed the
+  // same way. On a material-sorted queue path ids are scattered; 192 B of records per vertex written and re-read by id were a quarter of S4's memory traffic.
+  // Each record carries its path: ShadowRec::d.w = (no MIS ray in flight: complete at the any-hit epilogue) << 31 | path id, MisRec::d.w = path id.
+  ShadowRec* sh; MisRec* mi;
   // one byte per path each: the shadow ray of a vertex that also has an MIS ray in flight was blocked / its occlusion-only MIS ray was blocked. Dense, so
   // that k_resolve learns from two bytes that a vertex contributes nothing (most vertices of an interior) without touching its 128-byte MisRec
   unsigned char* occ_sh; unsigned char* occ_mi;
@@ -608,8 +614,9 @@ RT_DEV void trace_write_any(float4* __restrict__ lacc, size_t ls, const float4* 
   // Shadow rays of the frame loop carry d.w = 1 when the vertex has no MIS ray in flight: the light-sampling
   // term of estimate_direct is then complete and `L += beta * (Ld / pick_pdf)` (precomputed by k_shade into
   // direct_add) is applied right here if the ray is unoccluded. Otherwise the flag is left for k_resolve.
-  if (lacc != nullptr && dw != 0.0f) {
-    if (!found) { float4 a = direct_add[pid * as]; float4 l = lacc[pid * ls]; lacc[pid * ls] = make_float4(l.x + a.x, l.y + a.y, l.z + a.z, l.w); }
+  // Inside a frame (lacc != nullptr) `pid` is the shadow RECORD's index and d.w carries (complete-here flag << 31) | path id.
+  if (lacc != nullptr && (__float_as_uint(dw) >> 31) != 0u) {
+    if (!found) { const size_t path = __float_as_uint(dw) & 0x7fffffffu; float4 a = direct_add[pid * as]; float4 l = lacc[path * ls]; lacc[path * ls] = make_float4(l.x + a.x, l.y + a.y, l.z + a.z, l.w); }
   } else if (os == 0) ((unsigned char*)occluded)[pid] = found ? (unsigned char)1 : (unsigned char)0;
   else occluded[pid * os] = found ? 1u : 0u;
 }
@@ -1848,7 +1855,7 @@ __global__ void __launch_bounds__(256, MODE == 1 ? RT_SHADE_MIN_WAVES : (MODE ==
               float scattering_pdf = (MODE != 1 && light_is_delta(light)) ? 0.0f : bsdf.pdf(si.hit.wo, ls.wi, nonspec);  // read by the power heuristic only: a delta light has none
               if (!is_black(f)) {
                 Ray sr = spawn_ray_to_interaction(si.hit, ls.p1);  // VisibilityTester, light/mod.rs:52-55
-                ps.sh[pid].o = make_float4(sr.o.x, sr.o.y, sr.o.z, sr.t_max);
+                ps.sh[i].o = make_float4(sr.o.x, sr.o.y, sr.o.z, sr.t_max);  // (shadow and MIS records sit at the vertex's position in THIS launch's queue, see PassState::sh)
                 sh_dir = sr.d;
                 want_shadow = true;
                 if (light_is_delta(light)) ld1 = vdiv(f * ls.li, ls.pdf);
@@ -1874,8 +1881,8 @@ __global__ void __launch_bounds__(256, MODE == 1 ? RT_SHADE_MIN_WAVES : (MODE ==
                 }
                 if (go) {
                   Ray mr = spawn_ray(si.hit, bs.wi);
-                  ps.mi[pid].o = make_float4(mr.o.x, mr.o.y, mr.o.z, kInf);
-                  ps.mi[pid].d = make_float4(mr.d.x, mr.d.y, mr.d.z, 0.0f);
+                  ps.mi[i].o = make_float4(mr.o.x, mr.o.y, mr.o.z, kInf);
+                  ps.mi[i].d = make_float4(mr.d.x, mr.d.y, mr.d.z, __uint_as_float(pid));  // the path the record belongs to
                   want_mis = true; f2v = f; w2 = weight; spdf2 = bs.pdf;
                   // An infinite light is never the emitter a ray hits (integrator/mod.rs:291-309): the term is `Le(ray)` if the ray leaves the
                   // scene and nothing otherwise, so occlusion is all this ray has to report.
@@ -1884,17 +1891,17 @@ __global__ void __launch_bounds__(256, MODE == 1 ? RT_SHADE_MIN_WAVES : (MODE ==
               }
             }
             if (want_mis) {  // both halves are combined by k_resolve once both rays are back
-              MisRec* const m = ps.mi + pid;
+              MisRec* const m = ps.mi + i;
               m->a = make_float4(ld1.r, ld1.g, ld1.b, light_pdf);
               m->b = make_float4(f2v.r, f2v.g, f2v.b, w2);
               m->c = make_float4(beta.r, beta.g, beta.b, spdf2);
               m->flags = (want_shadow ? RT_PEND_SHADOW : 0u) | 2u | ((unsigned)light_num << 2) | (mis_occlusion_only ? RT_PEND_MIS_ANY : 0u);
-              if (!want_shadow) ps.occ_sh[pid] = (unsigned char)1;  // no light-sampling term: as good as blocked (the any-hit kernel writes the byte of every other vertex)
+              if (!want_shadow) ps.occ_sh[i] = (unsigned char)1;  // no light-sampling term: as good as blocked (the any-hit kernel writes the byte of every other vertex)
             } else if (want_shadow) {  // L += beta * ((0 + Ld1) / pick_pdf) if unoccluded, applied by the any-hit kernel
               rgb3 add = beta * vdiv(mkc(0, 0, 0) + ld1, light_pdf);
-              ps.sh[pid].add = make_float4(add.r, add.g, add.b, 0.0f);
+              ps.sh[i].add = make_float4(add.r, add.g, add.b, 0.0f);
             }
-            if (want_shadow) ps.sh[pid].d = make_float4(sh_dir.x, sh_dir.y, sh_dir.z, want_mis ? 0.0f : 1.0f);
+            if (want_shadow) ps.sh[i].d = make_float4(sh_dir.x, sh_dir.y, sh_dir.z, __uint_as_float((want_mis ? 0u : 0x80000000u) | pid));  // bit 31: complete here (no MIS ray), bits 0-30: the path
           }
         }
         RT_STAMP(5);  // BSDF-sampling half + records
@@ -1941,9 +1948,9 @@ __global__ void __launch_bounds__(256, MODE == 1 ? RT_SHADE_MIN_WAVES : (MODE ==
     const int ci[4] = {0, 1, 2, 3}; const bool pr[4] = {cont, want_shadow, want_mis && !mis_occlusion_only, want_mis && mis_occlusion_only}; unsigned slot[4];
     block_push<NQ>(ps.cnt_out, ps.shard_cap, ci, pr, slot);
     if (cont) ps.q_out[slot[0]] = pid;
-    if (want_shadow) ps.q_shadow[slot[1]] = pid;
-    if (pr[2]) ps.q_mis[slot[2]] = pid;
-    if (NQ == 4 && pr[3]) ps.q_misany[slot[3]] = pid;
+    if (want_shadow) ps.q_shadow[slot[1]] = i;  // the ray queues name RECORDS (= this launch's queue positions), the path queue names paths
+    if (pr[2]) ps.q_mis[slot[2]] = i;
+    if (NQ == 4 && pr[3]) ps.q_misany[slot[3]] = i;
   }
 #endif
   if (GENERAL) {
@@ -1990,11 +1997,11 @@ __global__ void __launch_bounds__(256) k_resolve(DScene sc, PassState ps) {
   const unsigned n_closest = qv.total(), count = n_closest + qa.total();
   const unsigned stride = gridDim.x * blockDim.x;
   for (unsigned i = blockIdx.x * blockDim.x + threadIdx.x; i < count; i += stride) {
-    const unsigned pid = i < n_closest ? qv.get(i) : qa.get(i - n_closest);
-    const bool shadow_blocked = ps.occ_sh[pid] != 0;
-    const bool mis_blocked = i >= n_closest && ps.occ_mi[pid] != 0;  // (an occlusion-only MIS ray)
+    const unsigned rec = i < n_closest ? qv.get(i) : qa.get(i - n_closest);  // the vertex's record index (its position in the shade launch's queue)
+    const bool shadow_blocked = ps.occ_sh[rec] != 0;
+    const bool mis_blocked = i >= n_closest && ps.occ_mi[rec] != 0;  // (an occlusion-only MIS ray)
     if (shadow_blocked && mis_blocked) continue;  // ld = 0: L + beta * (0 / pick_pdf) = L
-    const MisRec* const m = ps.mi + pid;
+    const MisRec* const m = ps.mi + rec;
     const unsigned pend = m->flags;
     float4 a = m->a, c = m->c;
     rgb3 ld = mkc(0, 0, 0);
@@ -2029,6 +2036,7 @@ __global__ void __launch_bounds__(256) k_resolve(DScene sc, PassState ps) {
     }
     rgb3 add = mkc(c.x, c.y, c.z) * vdiv(ld, a.w);
     if (add.r == 0.0f && add.g == 0.0f && add.b == 0.0f) continue;  // both rays blocked (most vertices of an interior): L + 0 = L, the scattered read-modify-write is skipped (a NaN is not 0)
+    const unsigned pid = __float_as_uint(m->d.w);  // the path the vertex belongs to
     float4 l4 = ps.acc[pid].lacc;
     ps.acc[pid].lacc = make_float4(l4.x + add.r, l4.y + add.g, l4.z + add.b, l4.w);
   }
