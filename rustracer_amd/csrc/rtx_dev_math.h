@@ -247,6 +247,20 @@ RT_DEV int find_interval_le_from(const float* a, int size, float x, int first, i
   }
   return clampi(first - 1, 0, size - 2);
 }
+// the same over the first members of (cdf, func) pairs (DLight::cf)
+RT_DEV int find_interval_le_from_pairs(const float* a, int size, float x, int first, int len) {
+  if (len <= 3) {
+    const int last = size - 1;
+    const float c0 = a[2 * (first < last ? first : last)], c1 = a[2 * (first + 1 < last ? first + 1 : last)], c2 = a[2 * (first + 2 < last ? first + 2 : last)];
+    first += (len > 0 && c0 <= x ? 1 : 0) + (len > 1 && c1 <= x ? 1 : 0) + (len > 2 && c2 <= x ? 1 : 0);
+    return clampi(first - 1, 0, size - 2);
+  }
+  while (len > 0) {
+    int half = len >> 1, middle = first + half;
+    if (a[2 * middle] <= x) { first = middle + 1; len -= half + 1; } else { len = half; }
+  }
+  return clampi(first - 1, 0, size - 2);
+}
 RT_DEV int find_interval_le(const float* a, int size, float x) {
   int first = 0, len = size;
   while (len > 0) {

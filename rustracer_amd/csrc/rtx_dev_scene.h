@@ -20,7 +20,10 @@ struct DMaterial { int kind; int slot[16]; int remap; int bump; int code_class; 
 struct DLight {
   int kind; int prim; float rgb[3]; int two_sided; float vec[3]; float area; float world_radius; int image;
   float l2w[12], w2l[12];
-  int nu, nv; const float* func; const float* cdf; const float* func_int; const float* mfunc; const float* mcdf; float mfunc_int;
+  // Distribution2D of an infinite light (distribution2d.rs:11-50). The conditional rows are stored as (cdf[i], func[i]) PAIRS, nu + 1 per row (the last
+  // func is padding): the entries sample_continuous reads last - cdf[o], cdf[o + 1], func[o] - and the func[v][u] of Distribution2D::pdf sit in the sector the
+  // bracketed search has just fetched, one dependent round trip to a random row less per sample.
+  int nu, nv; const float* cf; const float* func_int; const float* mfunc; const float* mcdf; float mfunc_int;
   // guide tables of the CDF searches (rt_scene_create): guide[row][k] = the number of entries of the row's CDF that are <= k / 2^glog, k = 0 .. 2^glog - so
   // the bisection for u starts inside [guide[k], guide[k + 1]], k = floor(u 2^glog), ~16 entries instead of 2049 (same answer: the CDF is non-decreasing)
   const unsigned short* guide; const unsigned short* mguide; int glog, mglog;

@@ -544,6 +544,20 @@ RT_DEV void d1_sample_continuous_guided(const float* func, const float* cdf, flo
   x = ((float)offset + du) / (float)n;
   off = offset;
 }
+// ... over a row of (cdf, func) pairs
+template <bool EXACT = false>
+RT_DEV void d1_sample_continuous_pairs(const float* cf, float func_int, int n, float u, const unsigned short* guide, int glog, float& x, float& pdf, int& off) {
+  const int G = 1 << glog;
+  const int k = clampi((int)(u * (float)G), 0, G - 1);
+  const int g0 = (int)guide[k], g1 = (int)guide[k + 1];
+  const int offset = find_interval_le_from_pairs(cf, n + 1, u, g0, g1 - g0);
+  const float c0 = cf[2 * offset], f0 = cf[2 * offset + 1], c1 = cf[2 * offset + 2];
+  float du = u - c0;
+  if (c1 - c0 > 0.0f) du /= c1 - c0;
+  pdf = func_int > 0.0f ? vdiv_e<EXACT>(f0, func_int) : 0.0f;
+  x = ((float)offset + du) / (float)n;
+  off = offset;
+}
 RT_DEV void d1_sample_discrete_guided(const float* func, const float* cdf, float func_int, int n, float u, const unsigned short* guide, int glog, int& off, float& pdf) {
   const int G = 1 << glog;
   const int k = clampi((int)(u * (float)G), 0, G - 1);
@@ -650,7 +664,7 @@ RT_DEVN LiSample light_sample_li(const DScene& sc, const DLight& l, Interaction 
       float d1, pdf1, d0, pdf0; int v, dummy;
       if (RT_DBG(sc, 2)) { d1 = u.y; d0 = u.x; pdf0 = pdf1 = 1.0f; } else {
       d1_sample_continuous_guided<EXACT>(l.mfunc, l.mcdf, l.mfunc_int, l.nv, u.y, l.mguide, l.mglog, d1, pdf1, v);  // Distribution2D::sample_continuous
-      d1_sample_continuous_guided<EXACT>(l.func + (size_t)v * l.nu, l.cdf + (size_t)v * (l.nu + 1), l.func_int[v], l.nu, u.x, l.guide + ((size_t)v << l.glog) + (size_t)v, l.glog, d0, pdf0, dummy);
+      d1_sample_continuous_pairs<EXACT>(l.cf + (size_t)v * (l.nu + 1) * 2, l.func_int[v], l.nu, u.x, l.guide + ((size_t)v << l.glog) + (size_t)v, l.glog, d0, pdf0, dummy);
       }
       float map_pdf = pdf0 * pdf1;
       s.p1.p_error = mk3(0, 0, 0); s.p1.n = mk3(0, 0, 0);
@@ -688,7 +702,7 @@ RT_DEVN float light_pdf_li_q(const DScene& sc, const DLight& l, Interaction ref,
     if (sin_theta_ == 0.0f) return 0.0f;
     f2 p = mk2(phi * kInvPi * 0.5f, theta * kInvPi);  // Distribution2D::pdf, distribution2d.rs:36-49
     int iu = clampi((int)f2u_sat(p.x * (float)l.nu), 0, l.nu - 1), iv = clampi((int)f2u_sat(p.y * (float)l.nv), 0, l.nv - 1);
-    return vdiv(vdiv(l.func[(size_t)iv * l.nu + iu], l.mfunc_int), 2.0f * kPi * kPi * sin_theta_);
+    return vdiv(vdiv(l.cf[((size_t)iv * (l.nu + 1) + iu) * 2 + 1], l.mfunc_int), 2.0f * kPi * kPi * sin_theta_);
   }
   return 0.0f;
 }

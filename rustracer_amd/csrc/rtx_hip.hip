@@ -369,7 +369,7 @@ extern "C" int rt_scene_create(const rt_scene_desc* desc, int device, rt_scene**
     size_t total = 0;
     for (uint32_t i = 0; i < n_all_lights; ++i) {
       const rt_light& l = desc->lights[i];
-      if (l.kind == RT_LIGHT_INFINITE) total += (size_t)l.dist_nv * l.dist_nu + (size_t)l.dist_nv * (l.dist_nu + 1) + (size_t)l.dist_nv * 3 + 1;
+      if (l.kind == RT_LIGHT_INFINITE) total += 2 * (size_t)l.dist_nv * (l.dist_nu + 1) + (size_t)l.dist_nv * 3 + 1;
     }
     std::vector<float> blob(total + 4);
     TRY_RC([&]() { return s->dist.ensure(blob.size() * 4) == hipSuccess ? RT_OK : fail(RT_ERR_OOM, "dist alloc"); }());
@@ -406,8 +406,13 @@ extern "C" int rt_scene_create(const rt_scene_desc* desc, int device, rt_scene**
         d.nu = l.dist_nu; d.nv = l.dist_nv; d.mfunc_int = l.marg_func_int;
         float* db = s->dist.as<float>();
         size_t nfunc = (size_t)l.dist_nv * l.dist_nu, ncdf = (size_t)l.dist_nv * (l.dist_nu + 1);
-        memcpy(&blob[base], l.dist_func, nfunc * 4); d.func = db + base; base += nfunc;
-        memcpy(&blob[base], l.dist_cdf, ncdf * 4); d.cdf = db + base; base += ncdf;
+        d.cf = db + base;  // (cdf, func) pairs, nu + 1 per row
+        for (int r = 0; r < l.dist_nv; ++r)
+          for (int i = 0; i <= l.dist_nu; ++i) {
+            blob[base++] = l.dist_cdf[(size_t)r * (l.dist_nu + 1) + i];
+            blob[base++] = i < l.dist_nu ? l.dist_func[(size_t)r * l.dist_nu + i] : 0.0f;
+          }
+        (void)nfunc;
         memcpy(&blob[base], l.dist_func_int, (size_t)l.dist_nv * 4); d.func_int = db + base; base += l.dist_nv;
         memcpy(&blob[base], l.marg_func, (size_t)l.dist_nv * 4); d.mfunc = db + base; base += l.dist_nv;
         memcpy(&blob[base], l.marg_cdf, ((size_t)l.dist_nv + 1) * 4); d.mcdf = db + base; base += (size_t)l.dist_nv + 1;
