@@ -191,3 +191,33 @@ def test_emitters_inside_objects_glow_and_light_nothing(gpu_host, orc, tmp_path)
     ff, _ = flat.render()
     assert rel_l2(gpu_host.film_to_rgb(ft), rh) < 1e-5
     assert rel_l2(gpu_host.film_to_rgb(ff), ro) < 5e-3   # (two roundings of one scene, see test_two_level_and_written_out_instances_agree)
+
+
+@pytest.mark.parametrize("extra", ["quadrics", "masks", "both"])
+def test_instances_beside_quadrics_and_masked_meshes(gpu_host, orc, extra):
+    """The trace kernels come in three general forms (instances only / + quadrics / + alpha masks, rtx_dev_scene.h RT_GEN_*): an instanced scene that also
+    holds top-level quadrics and / or a masked mesh takes the other two; hit records of the production kernels and of the counting kernels equal the oracle's."""
+    d = _scene(True)
+    if extra in ("quadrics", "both"):
+        d.add_sphere((2.5, 0.8, 1.0), 0.8, d.glass())
+        d.add_sphere((-3.0, 0.5, 2.0), 0.5, d.matte((0.0,) * 3), emission=(6.0, 5.0, 4.0))
+        m = np.eye(4, dtype=np.float32); m[:3, 3] = (0.0, 0.0, 3.0)
+        d.add_cylinder(m, 0.3, d.matte((0.2, 0.7, 0.3)), z_min=0.0, z_max=1.5)
+    if extra in ("masks", "both"):
+        img = np.zeros((8, 8, 3), np.float32); img[::2, ::2] = 1.0; img[1::2, 1::2] = 1.0
+        mask = d.image_tex(d.add_mip(img, trilinear=True), su=3.0, sv=3.0)
+        d.add_mesh([(-4, 0.1, -1), (-1, 0.1, -1), (-1, 2.5, -0.5), (-4, 2.5, -0.5)], [[0, 1, 2], [0, 2, 3]], d.matte((0.9, 0.8, 0.1)), UV=[(0, 0), (1, 0), (1, 1), (0, 1)], alpha=mask)
+    o, h = orc.OracleScene(d), gpu_host.HostScene(d)
+    rays = random_rays(60000, np.float32([-4, 0, -4]), np.float32([4, 3, 4]), 33)
+    ro = o.trace(rays)
+    for count in (True, False):
+        rh = h.trace(rays, count=count)
+        assert np.array_equal(ro["prim"], rh["prim"]) and all(np.array_equal(bits(ro[k]), bits(rh[k])) for k in ("t", "b0", "b1"))
+    rays[:, 3] = np.random.default_rng(6).uniform(0.3, 9.0, len(rays)).astype(np.float32)
+    ao = o.trace(rays, True)
+    assert np.array_equal(ao["occluded"], h.trace(rays, True)["occluded"]) and np.array_equal(ao["occluded"], h.trace(rays, True, count=False)["occluded"])
+    fo, so = o.render(mode=1)
+    fh, sh = h.render()
+    assert np.array_equal(fo[..., 3], fh[..., 3]) and rel_l2(gpu_host.film_to_rgb(fh), orc.film_to_rgb(fo)) < 1e-3
+    for k in ("rays_closest", "rays_shadow", "rays_mis"):
+        assert abs(int(sh[k]) - int(so[k])) <= 2e-3 * int(so[k]) + 16, (k, sh[k], so[k])
