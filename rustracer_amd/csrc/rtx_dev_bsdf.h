@@ -14,7 +14,8 @@ RT_DEV f2 concentric_sample_disk(f2 u) {  // :28-47
   float r, theta;
   if (fabsf(ox) > fabsf(oy)) { r = ox; theta = kPiOver4 * (oy / ox); }
   else { r = oy; theta = kPiOver2 - kPiOver4 * (ox / oy); }
-  return mk2(r * cosf(theta), r * sinf(theta));
+  float sn, cs; sincosf(theta, &sn, &cs);  // one argument reduction and one pair of polynomials instead of two (k_shade<1>: 4537 -> 4294 instructions)
+  return mk2(r * cs, r * sn);
 }
 RT_DEV f3 cosine_sample_hemisphere(f2 u) {  // :22-26
   f2 d = concentric_sample_disk(u);
@@ -154,7 +155,7 @@ RT_DEV void tr_sample11(float cos_theta_, float u1, float u2, float& sx, float& 
   if (cos_theta_ > 0.9999f) {
     float r = sqrtf(u1 / (1.0f - u1));
     float phi = kTau * u2;
-    sx = r * cosf(phi); sy = r * sinf(phi);
+    float sn, cs; sincosf(phi, &sn, &cs); sx = r * cs; sy = r * sn;
     return;
   }
   float sin_theta_ = sqrtf(fmaxf(1.0f - cos_theta_ * cos_theta_, 0.0f));
@@ -387,7 +388,8 @@ RT_DEV LobeSample lobe_sample_inner(const Lobe& l, f3 wo, f2 u) {
       float cos_theta_ = sqrtf(fmaxf(0.0f, (1.0f - powf(alpha2, 1.0f - u.x)) / (1.0f - alpha2)));
       float sin_theta_ = sqrtf(fmaxf(0.0f, 1.0f - cos_theta_ * cos_theta_));
       float phi = 2.0f * kPi * u.y;
-      f3 wh = mk3(sin_theta_ * cosf(phi), sin_theta_ * sinf(phi), cos_theta_);  // spherical_direction, geometry/mod.rs:112-114
+      float sn_phi, cs_phi; sincosf(phi, &sn_phi, &cs_phi);
+      f3 wh = mk3(sin_theta_ * cs_phi, sin_theta_ * sn_phi, cos_theta_);  // spherical_direction, geometry/mod.rs:112-114
       if (!same_hemisphere(wo, wh)) wh = -wh;
       f3 wi = reflect(wo, wh);
       if (!same_hemisphere(wo, wi)) return mk_ls(mkc(0, 0, 0), mk3(0, 0, 0), 0.0f, ty);

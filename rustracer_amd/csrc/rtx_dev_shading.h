@@ -670,7 +670,7 @@ RT_DEVN LiSample light_sample_li(const DScene& sc, const DLight& l, Interaction 
       s.p1.p_error = mk3(0, 0, 0); s.p1.n = mk3(0, 0, 0);
       if (map_pdf == 0.0f) { s.li = mkc(0, 0, 0); s.wi = mk3(0, 0, 0); s.pdf = 0.0f; s.p1.p = mk3(0, 0, 0); return s; }
       float theta = d1 * kPi, phi = d0 * 2.0f * kPi;
-      float cos_theta_ = cosf(theta), sin_theta_ = sinf(theta), cos_phi_ = cosf(phi), sin_phi_ = sinf(phi);
+      float cos_theta_, sin_theta_, cos_phi_, sin_phi_; sincosf(theta, &sin_theta_, &cos_theta_); sincosf(phi, &sin_phi_, &cos_phi_);
       f3 wi = xf3x4(l.l2w, mk3(sin_theta_ * cos_phi_, sin_theta_ * sin_phi_, cos_theta_));
       s.pdf = sin_theta_ == 0.0f ? 0.0f : vdiv_e<EXACT>(map_pdf, 2.0f * kPi * kPi * sin_theta_);
       s.p1.p = ref.p + wi * (2.0f * l.world_radius);

@@ -255,7 +255,8 @@ RT_DEV SpherePoint sphere_sample(const DSphere& s, f2 u, float& pdf) {  // Spher
   const float z = 1.0f - 2.0f * u.x;  // uniform_sample_sphere, sampling/mod.rs:14-20
   const float r = sqrtf(fmaxf(1.0f - z * z, 0.0f));
   const float phi = 2.0f * kPi * u.y;
-  f3 p_obj = mk3(0, 0, 0) + s.radius * mk3(r * cosf(phi), r * sinf(phi), z);
+  float sn_phi, cs_phi; sincosf(phi, &sn_phi, &cs_phi);
+  f3 p_obj = mk3(0, 0, 0) + s.radius * mk3(r * cs_phi, r * sn_phi, z);
   SpherePoint it;
   it.n = normalize(xf34_normal(s.w2o, p_obj));
   p_obj = p_obj * s.radius / sqrtf(distance_squared(p_obj, mk3(0, 0, 0)));
@@ -276,7 +277,8 @@ RT_DEV SpherePoint quadric_default_sample_si(const DSphere& s, const Interaction
   } else {
     const float z = lerpf(u.x, s.z_min, s.z_max);
     const float phi = u.y * s.phi_max;
-    f3 p_obj = mk3(s.radius * cosf(phi), s.radius * sinf(phi), z);
+    float sn_phi, cs_phi; sincosf(phi, &sn_phi, &cs_phi);
+    f3 p_obj = mk3(s.radius * cs_phi, s.radius * sn_phi, z);
     f3 n = normalize(xf34_normal(s.w2o, mk3(p_obj.x, p_obj.y, 0.0f)));
     if (s.reverse_orientation) n = n * -1.0f;
     const float hit_rad = sqrtf(p_obj.x * p_obj.x + p_obj.y * p_obj.y);
@@ -316,7 +318,8 @@ RT_DEVN SpherePoint sphere_sample_si(const DSphere& s, const Interaction& ref, f
   const float ds = dc * cos_theta_ - sqrtf(fmaxf(0.0f, s.radius * s.radius - dc * dc * sin_theta_ * sin_theta_));
   const float cos_alpha = (dc * dc + s.radius * s.radius - ds * ds) / (2.0f * dc * s.radius);
   const float sin_alpha = sqrtf(fmaxf(0.0f, 1.0f - cos_alpha * cos_alpha));
-  const f3 n_world = sin_alpha * cosf(phi) * (-wc_x) + sin_alpha * sinf(phi) * (-wc_y) + cos_alpha * (-wc);  // spherical_direction_vec, geometry/mod.rs:117-126
+  float sn_phi, cs_phi; sincosf(phi, &sn_phi, &cs_phi);
+  const f3 n_world = sin_alpha * cs_phi * (-wc_x) + sin_alpha * sn_phi * (-wc_y) + cos_alpha * (-wc);  // spherical_direction_vec, geometry/mod.rs:117-126
   SpherePoint it;
   it.p = p_center + s.radius * mk3(n_world.x, n_world.y, n_world.z);
   it.p_error = gamma_n(5) * abs3(it.p);
