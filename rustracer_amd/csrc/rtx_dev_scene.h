@@ -244,6 +244,9 @@ RT_DEV TriFrame tri_frame(const TriGeo& g, unsigned flags, f3 ns_in, f3 ss_in) {
 // (bsdf/mod.rs:77-91). The frame entries are those of a triangle WITHOUT per-vertex normals and tangents (RT_REC_CONST_FRAME); with them only dpdu / dpdv
 // and n (row 3: g.n before orientation) are constants.
 #define RT_REC_CONST_FRAME(flags) (((flags) & (2u | 8u)) == 0u)
+// WO_SIGNS_ONLY: the caller's BSDF reads wo only through sign and zero tests of its dot products (the Lambert front-ends: same_hemisphere, the reflect /
+// transmit side, wo.z == 0) - positive scaling does not change those, so the two normalisations of -ray_d (2 square roots, 6 divisions per vertex) are left out.
+template <bool WO_SIGNS_ONLY = false>
 RT_DEV void tri_fill_interaction_inl(const DScene& sc, int prim, f3 ray_d, const TriHit& h, SurfaceInteraction& si) {
   const float4* __restrict__ rec = sc.tri_rec + 8 * (size_t)prim;
   const float4 r0 = rec[0], r1 = rec[1], r2 = rec[2], r3 = rec[3];
@@ -261,7 +264,7 @@ RT_DEV void tri_fill_interaction_inl(const DScene& sc, int prim, f3 ray_d, const
   si.hit.p_error = gamma_n(7) * mk3(x_abs_sum, y_abs_sum, z_abs_sum);
   si.hit.p = p0 * b0 + p1 * b1 + p2 * b2;
   si.uv = mk2(uv0.x * b0 + uv1.x * b1 + uv2.x * b2, uv0.y * b0 + uv1.y * b1 + uv2.y * b2);
-  si.hit.wo = normalize(normalize(-ray_d));  // SurfaceInteraction::new + Interaction::new both normalise (interaction.rs:42,123)
+  si.hit.wo = WO_SIGNS_ONLY ? -ray_d : normalize(normalize(-ray_d));  // SurfaceInteraction::new + Interaction::new both normalise (interaction.rs:42,123)
   const float4 r6 = rec[6], r7 = rec[7];
   si.dpdu = mk3(r6.x, r6.y, r6.z); si.dpdv = mk3(r7.x, r7.y, r7.z);
   if (RT_REC_CONST_FRAME(flags)) {

@@ -1799,7 +1799,7 @@ __global__ void __launch_bounds__(256, MODE == 1 ? RT_SHADE_MIN_WAVES : (MODE ==
           si.ssb = normalize(si.sh_dpdu);
           si.prim = prim;
         }
-        else if (MODE != 0) tri_fill_interaction_inl(sc, prim, ray_d, th, si);
+        else if (MODE != 0) tri_fill_interaction_inl<MODE == 1 || MODE == 3>(sc, prim, ray_d, th, si);
         else tri_fill_interaction(gsc, prim, ray_d, th, si);
       }
       RT_STAMP(0);  // path state loads + SurfaceInteraction
