@@ -1264,7 +1264,7 @@ extern "C" int rt_render(rt_scene* s, const rt_camera* cam, const rt_film_desc* 
     const unsigned long long npx = std::min(chunk_pixels, owned_pixels - first);
     const int buf = (int)(batch_no & 1ull);
     fp.chunk_first = first;
-    ps.n_pixels = (unsigned)npx;
+    ps.n_pixels = (unsigned)npx; ps.n_pixels_recip = npx > 1 ? (unsigned)((1ull << 32) / npx) : 0xffffffffu;
     ps.scrambles = s->scrambles[buf].as<unsigned>(); ps.perms = s->perms[buf].as<unsigned short>();
     if (first + chunk_pixels < owned_pixels) {  // next batch's tables into the other buffer, once its previous readers are done
       if (batch_no >= 1) HIP_TRY(hipStreamWaitEvent(aux, s->ev_batch_done[buf ^ 1], 0));

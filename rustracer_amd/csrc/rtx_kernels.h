@@ -48,6 +48,7 @@ struct PassState {
   unsigned cap;            // paths in this pass = n_pixels * n_samples
   unsigned spp, spp_log2, dims;
   unsigned n_pixels;       // batch pixels
+  unsigned n_pixels_recip; // floor(2^32 / n_pixels) (2^32 - 1 for one pixel): path id -> (sample, pixel) by a multiply (split_path_id)
   unsigned s0, n_samples;  // this pass renders samples [s0, s0 + n_samples) of every batch pixel
   float4* own_acc;         // [batch pixel] running (R, G, B, weight) sum of the pixel's own samples across passes
   // sampler tables of the chunk
@@ -94,6 +95,14 @@ enum { ST_CAMERA = 0, ST_RAYS_CLOSEST, ST_RAYS_SHADOW, ST_RAYS_MIS, ST_NODES_CLO
 #else
 #define RT_STAMP(k) do { } while (0)
 #endif
+
+// path id = local sample * n_pixels + batch pixel. q = mulhi(pid, floor(2^32 / n)) is floor(pid / n) or one less: one compare fixes it (an integer division is
+// ~30 instructions, twice per path vertex otherwise).
+RT_DEV void split_path_id(const PassState& ps, unsigned pid, unsigned& sl, unsigned& pix) {
+  unsigned q = __umulhi(pid, ps.n_pixels_recip), r = pid - q * ps.n_pixels;
+  if (r >= ps.n_pixels) { q += 1u; r -= ps.n_pixels; }
+  sl = q; pix = r;
+}
 
 struct FrameParams {
   // camera (rc/camera.rs)
@@ -544,7 +553,7 @@ __global__ void __launch_bounds__(256) k_raygen(FrameParams fp, PassState ps) {
     const unsigned pid = base + threadIdx.x;
     bool in_bounds = false;
     if (pid < ps.cap) {
-      const unsigned sl = pid / ps.n_pixels, pix = pid - sl * ps.n_pixels, s = ps.s0 + sl;
+      unsigned sl, pix; split_path_id(ps, pid, sl, pix); const unsigned s = ps.s0 + sl;
       int x, y; unsigned long long pixel_index;
       owned_pixel(fp, fp.chunk_first + pix, x, y, pixel_index);
       in_bounds = y < fp.sb_y1 && x >= fp.pb_x0 && x < fp.pb_x1 && y >= fp.pb_y0 && y < fp.pb_y1;  // renderer.rs:103
@@ -1770,7 +1779,7 @@ __global__ void __launch_bounds__(256, MODE == 1 ? RT_SHADE_MIN_WAVES : (MODE ==
     }
     if (lane_live) {
       pid = PREFETCH ? c_pid : (ps.q_in ? qv.get(i) : i);
-      const unsigned sl = pid / ps.n_pixels, pix = pid - sl * ps.n_pixels, s = ps.s0 + sl;
+      unsigned sl, pix; split_path_id(ps, pid, sl, pix); const unsigned s = ps.s0 + sl;
       RayRec* const prec = ps.ray + pid; VertRec* const pvert = ps.vert + pid; PathAcc* const pacc = ps.acc + pid;
       float4 d4, h4, b4, l4;
       if (PREFETCH) { d4 = c_d4; h4 = c_h4; b4 = c_b4; l4 = c_l4; }
