@@ -551,11 +551,22 @@ inline void b44_unpack14(const uint8_t* b, uint16_t* s) {
   s[15] = (uint16_t)(s[14] + ((b[13] & 0x3fu) << shift) - bias);
   for (int i = 0; i < 16; ++i) s[i] = (s[i] & 0x8000u) ? (uint16_t)(s[i] & 0x7fffu) : (uint16_t)~s[i];
 }
+// 8 ln(x) per half bit pattern (negative / non-finite -> 0): what a pLinear channel comes back through. Built on first use (a function-local static: once, thread-safe)
+inline const std::vector<uint16_t>& b44_log_table() {
+  static const std::vector<uint16_t> table = [] {
+    std::vector<uint16_t> t(65536);
+    for (uint32_t i = 0; i < 65536; ++i) {
+      const bool finite = (i & 0x7c00u) != 0x7c00u; const float h = half_to_float((uint16_t)i);
+      t[i] = (!finite || h < 0.0f) ? (uint16_t)0 : float_to_half_rne((float)(8.0 * std::log((double)h)));
+    }
+    return t;
+  }();
+  return table;
+}
 bool b44_uncompress(const uint8_t* src, size_t size, const std::vector<ExrChan>& chans, size_t w, size_t rows, std::vector<uint8_t>& raw, std::string& err) {
   size_t line_bytes = 0; std::vector<size_t> chan_off(chans.size());
   for (size_t k = 0; k < chans.size(); ++k) { chan_off[k] = line_bytes; line_bytes += w * (chans[k].type == 1 ? 2 : 4); }
   raw.assign(rows * line_bytes, 0);
-  static std::vector<uint16_t> log_table;  // 8 ln(x) per half bit pattern (negative / non-finite -> 0): built on first use
   size_t p = 0;
   for (size_t k = 0; k < chans.size(); ++k) {
     const ExrChan& c = chans[k];
@@ -564,13 +575,6 @@ bool b44_uncompress(const uint8_t* src, size_t size, const std::vector<ExrChan>&
       if (p + rows * n > size) { err = "EXR: truncated B44 block"; return false; }
       for (size_t r = 0; r < rows; ++r) { memcpy(&raw[r * line_bytes + chan_off[k]], src + p, n); p += n; }
       continue;
-    }
-    if (c.plinear && log_table.empty()) {
-      log_table.resize(65536);
-      for (uint32_t i = 0; i < 65536; ++i) {
-        const bool finite = (i & 0x7c00u) != 0x7c00u; const float h = half_to_float((uint16_t)i);
-        log_table[i] = (!finite || h < 0.0f) ? (uint16_t)0 : float_to_half_rne((float)(8.0 * std::log((double)h)));
-      }
     }
     for (size_t y = 0; y < rows; y += 4)
       for (size_t x = 0; x < w; x += 4) {
@@ -584,7 +588,7 @@ bool b44_uncompress(const uint8_t* src, size_t size, const std::vector<ExrChan>&
           if (p + 14 > size) { err = "EXR: truncated B44 block"; return false; }
           b44_unpack14(src + p, s); p += 14;
         }
-        if (c.plinear) for (int i = 0; i < 16; ++i) s[i] = log_table[s[i]];
+        if (c.plinear) { const std::vector<uint16_t>& log_table = b44_log_table(); for (int i = 0; i < 16; ++i) s[i] = log_table[s[i]]; }
         for (size_t dy = 0; dy < 4 && y + dy < rows; ++dy)
           for (size_t dx = 0; dx < 4 && x + dx < w; ++dx) {
             uint8_t* q = &raw[(y + dy) * line_bytes + chan_off[k] + 2 * (x + dx)];
