@@ -56,6 +56,7 @@ struct rt_scene {
   bool small = false;
   bool lambert_materials = false;  // the material half of lambert_only: with other light kinds k_shade<3>
   bool lambert_only = false;  // every material is matte{constant Kd, sigma == 0} and every light an area light: k_shade<1>
+  bool lean_shade = false;    // every light an area light on a triangle and every texture a constant: the LEAN forms of k_shade<3 | 5 | 6> (no out-of-line evaluator, three waves)
   int stack_depth = 64;  // entries the to-visit stack needs for this tree (<= 64, rc/bvh/mod.rs:374)
   unsigned n_nodes = 0, n_tris = 0; int n_lights = 0;
   DevBuf pairs, tmin_stack;  // child-pair node records and the HBM half of the traversal stack (k_trace_pair)
@@ -474,6 +475,9 @@ extern "C" int rt_scene_create(const rt_scene_desc* desc, int device, rt_scene**
   for (uint32_t i = 0; i < desc->n_lights; ++i)
     if (desc->lights[i].kind == RT_LIGHT_DIFFUSE_AREA && (desc->tri_meta[desc->lights[i].prim].flags & RT_TRI_HAS_ALPHA)) s->masked_emitters = true;
   if (s->has_spheres || s->has_instances) s->masked_emitters = true;  // quadric / instance hits, quadric emitters, masked emitters: the GENERAL instantiations of the shade kernels
+  s->lean_shade = !s->masked_emitters;
+  for (uint32_t i = 0; i < desc->n_lights; ++i) if (desc->lights[i].kind != RT_LIGHT_DIFFUSE_AREA) s->lean_shade = false;
+  for (uint32_t i = 0; i < desc->n_textures; ++i) if (desc->textures[i].kind != RT_TEX_CONST) s->lean_shade = false;
   if (s->masked_emitters) s->lambert_only = false;  // (the constant-matte kernel has no GENERAL form: such scenes shade through the Lambert front-end k_shade<3, true>)
   s->n_materials = desc->n_materials;
   s->small = desc->n_nodes <= RT_SMALL_NODES && desc->n_tris <= RT_SMALL_TRIS && !s->has_instances;  // quadrics and masked triangles: the GENERAL form of the LDS kernel
@@ -1085,6 +1089,15 @@ struct KTimer {  // HIP-event kernel timing on the render stream; events come fr
   }
 };
 
+// one shade launch of front-end MODE: the GENERAL form (quadric / instance hits, masked emitters), the LEAN form (area lights and constant textures only;
+// front-ends 3 / 5 / 6), or the plain one
+template <int MODE>
+static void launch_shade(bool general, bool lean, unsigned grid, unsigned block, hipStream_t stream, const DScene& d, const FrameParams& fp, const PassState& p) {
+  if (general) { hipLaunchKernelGGL((k_shade<MODE, true>), dim3(grid), dim3(block), 0, stream, d, fp, p); return; }
+  if constexpr (MODE != 0) { if (lean) { hipLaunchKernelGGL((k_shade<MODE, false, true>), dim3(grid), dim3(block), 0, stream, d, fp, p); return; } }
+  hipLaunchKernelGGL((k_shade<MODE, false>), dim3(grid), dim3(block), 0, stream, d, fp, p);
+}
+
 extern "C" int rt_render(rt_scene* s, const rt_camera* cam, const rt_film_desc* film, const rt_sampler_desc* smp, const rt_path_desc* path,
                          const rt_shard* shard, uint32_t flags, void* stream_, float* film_xyzw, rt_stats* stats_out) {
   if (!s || !cam || !film || !smp || !path || !film_xyzw) return fail(RT_ERR_INVALID, "null argument");
@@ -1149,6 +1162,8 @@ extern "C" int rt_render(rt_scene* s, const rt_camera* cam, const rt_film_desc* 
   static const bool bin_off = getenv("RTX_SHADE_BINS") && getenv("RTX_SHADE_BINS")[0] == '0';  // measurement knob
   const bool use_bins = !s->lambert_materials && s->n_code_classes > 1 && !bin_off;  // one class: every vertex runs the same code, the queue order is kept
   const bool gshade = s->masked_emitters;  // quadric / instance hits, quadric or masked emitters: the GENERAL instantiations of the shade kernels
+  static const bool lean_off = getenv("RTX_SHADE_LEAN") && getenv("RTX_SHADE_LEAN")[0] == '0';  // measurement knob
+  const bool lean_shade = s->lean_shade && !lean_off;
   const unsigned n_bins = std::min<unsigned>(s->n_code_classes, RT_BIN_MAX) + 1u;
   const size_t bin_stride = (RT_BIN_MAX + 1) + (size_t)(RT_BIN_MAX + 1) * RT_CNT_STRIDE + (size_t)RT_QSHARDS * RT_CNT_STRIDE + 10;  // hist, cursors (spread), the sorted queue's counts (laid out as shard counters)  // + {begin, end} of the four class ranges and of the miss bin
   // RTX_SHADE_SPLIT (measurement knob): 0 = every class through the generic front-end, 1 = Lambert classes apart, default = Lambert and two-lobe classes apart
@@ -1294,8 +1309,7 @@ extern "C" int rt_render(rt_scene* s, const rt_camera* cam, const rt_film_desc* 
         tm.begin(&stats.ms_trace_closest);
         launch_trace<false>(s, count, io_path, ps.q_in, ps.cnt_in, ps.shard_cap, ps.cap, dstats, ST_RAYS_CLOSEST, ST_NODES_CLOSEST, ST_TRIS_CLOSEST, stream);
         tm.end();
-#define RT_SHADE(MODE, P) do { if (gshade) hipLaunchKernelGGL((k_shade<MODE, true>), dim3(sgrid), dim3(sblock), 0, stream, s->d, fp, P); \
-                               else hipLaunchKernelGGL((k_shade<MODE, false>), dim3(sgrid), dim3(sblock), 0, stream, s->d, fp, P); } while (0)
+#define RT_SHADE(MODE, P) launch_shade<MODE>(gshade, lean_shade, sgrid, sblock, stream, s->d, fp, P)
         if (s->lambert_only) { tm.begin(&stats.ms_shade_lambert_const); hipLaunchKernelGGL(k_shade<1>, dim3(sgrid), dim3(sblock), 0, stream, s->d, fp, ps); tm.end(); }
         else if (s->lambert_materials) { tm.begin(&stats.ms_shade_lambert); RT_SHADE(3, ps); tm.end(); }
         else if (!use_bins) { tm.begin(&stats.ms_shade_generic); RT_SHADE(0, ps); tm.end(); }

@@ -1538,17 +1538,19 @@ typedef SingleLambertT<false> SingleLambert;
 // (bsdf/mod.rs:94-251) restated over two named lobes; every lobe function is entered with its kind as a constant, so only that
 // kind's code is instantiated. Same operations in the same order as GenericBsdf (sums start from the same zero, the same component
 // choice and u remap), hence the same values.
-template <bool WIDE>  // WIDE: + glass, substrate and the opaque uber form (FresnelSpecular, FresnelBlend, microfacet transmission; a Bsdf eta)
+template <bool WIDE, bool CONST_TEX = false>  // WIDE: + glass, substrate and the opaque uber form (FresnelSpecular, FresnelBlend, microfacet transmission; a Bsdf eta); CONST_TEX: every texture parameter is a constant (no out-of-line image lookup is instantiated)
 struct SmallBsdfT {
+  static RT_DEV rgb3 tc(const DScene& sc, int id, const SurfaceInteraction& si) { if (CONST_TEX) { const DTexture& t = sc.textures[id]; return mkc(t.v[0], t.v[1], t.v[2]); } return tex_eval_c(sc, id, si); }
+  static RT_DEV float tcf(const DScene& sc, int id, const SurfaceInteraction& si) { return tc(sc, id, si).r; }
   f3 ns, ng, ss, ts; int n; Lobe l0, l1; float eta_;
   RT_DEV void add(const Lobe& l) { if (n == 0) l0 = l; else l1 = l; ++n; }
   RT_DEV void build(const DScene& sc, int mat, SurfaceInteraction& si) {
     const DMaterial& m = sc.materials[mat]; const int* s = m.slot;
     n = 0; l0 = lobe_zero(LB_LAMBERT_R); l1 = l0; eta_ = 1.0f;
     if (WIDE && m.kind == 4) {  // glass.rs:53-106, allow_multiple_lobes = true (path.rs:145): one FresnelSpecular lobe, or microfacet reflection + transmission
-      eta_ = tex_eval_cf(sc, s[8], si);
-      float ur = tex_eval_cf(sc, s[6], si), vr = tex_eval_cf(sc, s[7], si);
-      rgb3 r = tex_eval_c(sc, s[2], si), t = tex_eval_c(sc, s[3], si);
+      eta_ = tcf(sc, s[8], si);
+      float ur = tcf(sc, s[6], si), vr = tcf(sc, s[7], si);
+      rgb3 r = tc(sc, s[2], si), t = tc(sc, s[3], si);
       if (!is_black(r) || !is_black(t)) {
         if (ur == 0.0f && vr == 0.0f) {
           Lobe l = lobe_zero(LB_FRESNEL_SPEC); l.r = r; l.t = t; l.eta_a = 1.0f; l.eta_b = eta_; add(l);
@@ -1559,27 +1561,27 @@ struct SmallBsdfT {
         }
       }
     } else if (WIDE && m.kind == 5) {  // uber.rs:63-126 where the host found opacity, Kr and Kt constant with 1 - opacity, Kr and Kt black: no specular lobe
-      float e = tex_eval_cf(sc, s[8], si);
-      rgb3 op = clamp_pos(tex_eval_c(sc, s[10], si));
+      float e = tcf(sc, s[8], si);
+      rgb3 op = clamp_pos(tc(sc, s[10], si));
       eta_ = e;
-      rgb3 kd = op * clamp_pos(tex_eval_c(sc, s[0], si));
+      rgb3 kd = op * clamp_pos(tc(sc, s[0], si));
       if (!is_black(kd)) add(mk_lambert(LB_LAMBERT_R, kd));
-      rgb3 ks = op * clamp_pos(tex_eval_c(sc, s[1], si));
+      rgb3 ks = op * clamp_pos(tc(sc, s[1], si));
       if (!is_black(ks)) {
-        float ru = tex_eval_cf(sc, s[6] >= 0 ? s[6] : s[5], si), rv = tex_eval_cf(sc, s[7] >= 0 ? s[7] : s[5], si);
+        float ru = tcf(sc, s[6] >= 0 ? s[6] : s[5], si), rv = tcf(sc, s[7] >= 0 ? s[7] : s[5], si);
         if (m.remap) { ru = tr_roughness_to_alpha(ru); rv = tr_roughness_to_alpha(rv); }
         add(mk_micro_r(ks, ru, rv, FR_DIELECTRIC, 1.0f, e));
       }
     } else if (WIDE && m.kind == 6) {  // substrate.rs:43-71
-      rgb3 d = clamp_pos(tex_eval_c(sc, s[0], si)), sp = clamp_pos(tex_eval_c(sc, s[1], si));
-      float ru = tex_eval_cf(sc, s[6], si), rv = tex_eval_cf(sc, s[7], si);
+      rgb3 d = clamp_pos(tc(sc, s[0], si)), sp = clamp_pos(tc(sc, s[1], si));
+      float ru = tcf(sc, s[6], si), rv = tcf(sc, s[7], si);
       if (!is_black(d) || !is_black(sp)) {
         if (m.remap) { ru = tr_roughness_to_alpha(ru); rv = tr_roughness_to_alpha(rv); }
         Lobe l = lobe_zero(LB_FRESNEL_BLEND); l.r = d; l.t = sp; l.ax = ru; l.ay = rv; add(l);
       }
     } else if (m.kind == 0) {  // matte.rs:37-62
-      rgb3 r = clamp_pos(tex_eval_c(sc, s[0], si));
-      float sigma = clampf(tex_eval_cf(sc, s[4], si), 0.0f, 1.0f);
+      rgb3 r = clamp_pos(tc(sc, s[0], si));
+      float sigma = clampf(tcf(sc, s[4], si), 0.0f, 1.0f);
       if (!is_black(r)) {
         if (sigma == 0.0f) add(mk_lambert(LB_LAMBERT_R, r));
         else {  // OrenNayar::new, oren_nayar.rs:17-27
@@ -1592,21 +1594,21 @@ struct SmallBsdfT {
         }
       }
     } else if (m.kind == 1) {  // plastic.rs:45-75
-      rgb3 kd = tex_eval_c(sc, s[0], si), ks = tex_eval_c(sc, s[1], si);
+      rgb3 kd = tc(sc, s[0], si), ks = tc(sc, s[1], si);
       if (!is_black(kd)) add(mk_lambert(LB_LAMBERT_R, kd));
       if (!is_black(ks)) {
-        float rough = tex_eval_cf(sc, s[5], si);
+        float rough = tcf(sc, s[5], si);
         if (m.remap) rough = tr_roughness_to_alpha(rough);
         add(mk_micro_r(ks, rough, rough, FR_DIELECTRIC, 1.5f, 1.0f));
       }
     } else if (m.kind == 2) {  // metal.rs:50-82
-      float ur = tex_eval_cf(sc, s[6] >= 0 ? s[6] : s[5], si), vr = tex_eval_cf(sc, s[7] >= 0 ? s[7] : s[5], si);
+      float ur = tcf(sc, s[6] >= 0 ? s[6] : s[5], si), vr = tcf(sc, s[7] >= 0 ? s[7] : s[5], si);
       if (m.remap) { ur = tr_roughness_to_alpha(ur); vr = tr_roughness_to_alpha(vr); }
       Lobe l = mk_micro_r(mkc(1, 1, 1), ur, vr, FR_CONDUCTOR, 1.0f, 1.0f);
-      l.t = tex_eval_c(sc, s[8], si); l.k = tex_eval_c(sc, s[9], si);
+      l.t = tc(sc, s[8], si); l.k = tc(sc, s[9], si);
       add(l);
     } else {  // mirror.rs:30-48
-      rgb3 R = clamp_pos(tex_eval_c(sc, s[2], si));
+      rgb3 R = clamp_pos(tc(sc, s[2], si));
       if (!is_black(R)) { Lobe l = lobe_zero(LB_SPEC_R); l.r = R; add(l); }
     }
     ss = si.ssb; ns = si.sh_n; ng = si.hit.n; ts = cross(si.sh_n, ss);  // Bsdf::new, bsdf/mod.rs:77-91 (ssb = normalize(si.sh_dpdu))
@@ -1735,8 +1737,11 @@ RT_DEVN int instance_fill_interaction(const DScene& sc, unsigned hit_id, float o
 #endif
 // GENERAL (generic front-end only): some emitter triangle carries an alpha mask, so Shape::pdf_wi's re-intersection evaluates it; such scenes shade
 // every vertex through k_shade<0, true>, every other scene never instantiates the mask evaluator in a shade kernel.
-template <int MODE, bool GENERAL = false>
-__global__ void __launch_bounds__(256, MODE == 1 ? RT_SHADE_MIN_WAVES : (MODE == 3 && !GENERAL ? RT_SHADE3_MIN_WAVES : RT_SHADE0_MIN_WAVES)) k_shade(DScene sc, FrameParams fp, PassState ps) {
+// LEAN (front-ends 3 / 5 / 6): every light is a diffuse area light on a triangle and every texture a constant - what MODE 1 assumes, for the other material
+// classes. No out-of-line light or texture evaluator is instantiated, so the kernel's allocation is its own: 155 / 168 / 168 VGPRs under a three-wave bound
+// (4 / 12 spilled dwords in the two-lobe forms) instead of 208 / 230 / 236 at two waves.
+template <int MODE, bool GENERAL = false, bool LEAN = false>
+__global__ void __launch_bounds__(256, (MODE == 1 || LEAN) ? (LEAN ? 3 : RT_SHADE_MIN_WAVES) : (MODE == 3 && !GENERAL ? RT_SHADE3_MIN_WAVES : RT_SHADE0_MIN_WAVES)) k_shade(DScene sc, FrameParams fp, PassState ps) {
   QView qv; if (ps.q_in) qv.init(ps.q_in, ps.cnt_in, ps.shard_cap);
   unsigned first = 0, count = ps.q_in ? qv.total() : ps.cap;  // no queue: bounce 0 of a pass whose samples are all traced
   if (MODE != 1 && ps.range) { first = ps.range[0]; count = ps.range[1]; }
@@ -1817,19 +1822,19 @@ __global__ void __launch_bounds__(256, MODE == 1 ? RT_SHADE_MIN_WAVES : (MODE ==
         if (found) {
           int li = rec_light(sc.tri_rec, prim);
           if (li >= 0) L = L + beta * area_light_l(sc.lights[li], si.hit.n, -ray_d);
-        } else if (MODE != 1) {
+        } else if ((MODE != 1 && !LEAN)) {
           for (int k = 0; k < sc.n_infinite; ++k) L = L + beta * infinite_le(sc, sc.lights[k == 0 ? sc.infinite_ids[0] : (k == 1 ? sc.infinite_ids[1] : (k == 2 ? sc.infinite_ids[2] : sc.infinite_ids[3]))], ray_d);  // constant indices: the kernel argument stays in SGPRs
         }
       }
       if (found && bounces < fp.max_depth) {  // path.rs:139
-        if (MODE != 1 && bounces == 0 && sc.needs_differentials && !RT_DBG(sc, 16)) {  // only the camera ray carries differentials (interaction.rs:245-314)
+        if ((MODE != 1 && !LEAN) && bounces == 0 && sc.needs_differentials && !RT_DBG(sc, 16)) {  // only the camera ray carries differentials (interaction.rs:245-314)
           f2 pf; { float2 t = pacc->pfilm; pf = mk2(t.x, t.y); }
           f2 pl = table_2d(smp.tb, pix, 1, s);
           CameraRay cr = generate_camera_ray(fp, pf, pl, 1.0f / sqrtf((float)ps.spp));
           if (MODE == 0) compute_differential_call(si, cr.rx_o, cr.ry_o, cr.rx_d, cr.ry_d); else compute_differential(si, cr.rx_o, cr.ry_o, cr.rx_d, cr.ry_d);
         }
-        typename std::conditional<MODE == 1, SingleLambert, typename std::conditional<MODE == 3, SingleLambertT<true>,
-                                  typename std::conditional<MODE == 5, SmallBsdfT<false>, typename std::conditional<MODE == 6, SmallBsdfT<true>, GenericBsdf>::type>::type>::type>::type bsdf;
+        typename std::conditional<MODE == 1, SingleLambert, typename std::conditional<MODE == 3, SingleLambertT<!LEAN>,
+                                  typename std::conditional<MODE == 5, SmallBsdfT<false, LEAN>, typename std::conditional<MODE == 6, SmallBsdfT<true, LEAN>, GenericBsdf>::type>::type>::type>::type bsdf;
         RT_STAMP(1);  // emission + differentials
         if (MODE == 0) bsdf.build(gsc, rec_material(sc.tri_rec, prim), si); else bsdf.build(sc, rec_material(sc.tri_rec, prim), si);
         RT_STAMP(2);  // material: textures + lobes
@@ -1858,10 +1863,10 @@ __global__ void __launch_bounds__(256, MODE == 1 ? RT_SHADE_MIN_WAVES : (MODE ==
             const DLight& light = sc.lights[light_num];
             // ---- estimate_direct (integrator/mod.rs:222-318), light-sampling half
             rgb3 ld1 = mkc(0, 0, 0); f3 sh_dir = mk3(0, 0, 0);
-            LiSample ls = (MODE == 1) ? area_light_sample_li(sc, light, si.hit, u_light) : light_sample_li_full<GENERAL>(gsc, light, si.hit, u_light);
+            LiSample ls = (MODE == 1 || LEAN) ? area_light_sample_li(sc, light, si.hit, u_light) : light_sample_li_full<GENERAL>(gsc, light, si.hit, u_light);
             if (ls.pdf > 0.0f && !is_black(ls.li)) {
               rgb3 f = bsdf.f(si.hit.wo, ls.wi, nonspec) * fabsf(dot(ls.wi, si.sh_n));
-              float scattering_pdf = (MODE != 1 && light_is_delta(light)) ? 0.0f : bsdf.pdf(si.hit.wo, ls.wi, nonspec);  // read by the power heuristic only: a delta light has none
+              float scattering_pdf = ((MODE != 1 && !LEAN) && light_is_delta(light)) ? 0.0f : bsdf.pdf(si.hit.wo, ls.wi, nonspec);  // read by the power heuristic only: a delta light has none
               if (!is_black(f)) {
                 Ray sr = spawn_ray_to_interaction(si.hit, ls.p1);  // VisibilityTester, light/mod.rs:52-55
                 ps.sh[i].o = make_float4(sr.o.x, sr.o.y, sr.o.z, sr.t_max);  // (shadow and MIS records sit at the vertex's position in THIS launch's queue, see PassState::sh)
@@ -1880,7 +1885,7 @@ __global__ void __launch_bounds__(256, MODE == 1 ? RT_SHADE_MIN_WAVES : (MODE ==
               if (!is_black(f) && bs.pdf > 0.0f) {
                 float weight = 1.0f; bool go = true;
                 if (!(bs.type & BSDF_SPECULAR)) {
-                  float lp = (MODE == 1) ? area_light_pdf_li<false>(sc, light, si.hit, bs.wi) : light_pdf_li<GENERAL>(gsc, light, si.hit, bs.wi);
+                  float lp = (MODE == 1 || LEAN) ? area_light_pdf_li<false>(sc, light, si.hit, bs.wi) : light_pdf_li<GENERAL>(gsc, light, si.hit, bs.wi);
                   if (lp == 0.0f) go = false;  // `return ld`
                   else weight = power_heuristic1(bs.pdf, lp);
                   if (GENERAL && go && ps.skip_unreachable_mis && light.kind == 0 && (tri_flags(sc.tri_p, light.prim) & RT_FLAG_SPHERE)) {
@@ -1895,7 +1900,7 @@ __global__ void __launch_bounds__(256, MODE == 1 ? RT_SHADE_MIN_WAVES : (MODE ==
                   want_mis = true; f2v = f; w2 = weight; spdf2 = bs.pdf;
                   // An infinite light is never the emitter a ray hits (integrator/mod.rs:291-309): the term is `Le(ray)` if the ray leaves the
                   // scene and nothing otherwise, so occlusion is all this ray has to report.
-                  mis_occlusion_only = MODE != 1 && ps.mis_any && light.kind == 3;
+                  mis_occlusion_only = (MODE != 1 && !LEAN) && ps.mis_any && light.kind == 3;
                 }
               }
             }
@@ -1944,7 +1949,7 @@ __global__ void __launch_bounds__(256, MODE == 1 ? RT_SHADE_MIN_WAVES : (MODE ==
       pacc->rng = smp.rng.state;
     }
     RT_STAMP(6);  // continuation sample, spawn, state stores
-    constexpr int NQ = MODE == 1 ? 3 : 4;  // area lights only: every MIS ray needs its closest hit
+    constexpr int NQ = (MODE == 1 || LEAN) ? 3 : 4;  // area lights only: every MIS ray needs its closest hit
 #if RT_WAVE_QUEUES
     wq.push(0, 0, ps.q_out, cont, pid);
     wq.push(1, 1, ps.q_shadow, want_shadow, pid);
@@ -1952,7 +1957,7 @@ __global__ void __launch_bounds__(256, MODE == 1 ? RT_SHADE_MIN_WAVES : (MODE ==
     if (NQ == 4) wq.push(3, 3, ps.q_misany, want_mis && mis_occlusion_only, pid);
   }
   wq.finish(0, 0, ps.q_out); wq.finish(1, 1, ps.q_shadow); wq.finish(2, 2, ps.q_mis);
-  if (MODE != 1) wq.finish(3, 3, ps.q_misany);
+  if ((MODE != 1 && !LEAN)) wq.finish(3, 3, ps.q_misany);
 #else
     const int ci[4] = {0, 1, 2, 3}; const bool pr[4] = {cont, want_shadow, want_mis && !mis_occlusion_only, want_mis && mis_occlusion_only}; unsigned slot[4];
     block_push<NQ>(ps.cnt_out, ps.shard_cap, ci, pr, slot);
