@@ -231,6 +231,13 @@ RT_DEV rgb3 tex_eval_leaf(const DScene& sc, int id, const SurfaceInteraction& si
   const DTexture& t = sc.textures[id];
   return t.kind == 0 ? mkc(t.v[0], t.v[1], t.v[2]) : tex_image_q(sc.textures, sc.images, id, si.uv, si.dudx, si.dvdx, si.dudy, si.dvdy);
 }
+// A vertex past the camera ray has no differentials (interaction.rs:245-314: only camera rays carry them), and an image map under zero differentials is
+// `triangle(0, st)` whichever filter it was built for (mipmap.rs:227-283: EWA with a zero minor axis, trilinear with width 0): the level-0 bilinear lookup, inline
+RT_DEV rgb3 tex_eval_leaf_bounced(const DScene& sc, int id, const SurfaceInteraction& si) {
+  const DTexture& t = sc.textures[id];
+  if (t.kind == 0) return mkc(t.v[0], t.v[1], t.v[2]);
+  return mip_triangle(sc.images[t.image], 0, mk2(t.su * si.uv.x + t.du, t.sv * si.uv.y + t.dv));  // UVMapping2D (texture/mod.rs:52-60), then what mip_lookup_diff returns for zero derivatives
+}
 // the same values with the constant texture (the common parameter) answered in place instead of through the out-of-line evaluator
 RT_DEV rgb3 tex_eval_c(const DScene& sc, int id, const SurfaceInteraction& si) { return tex_eval_leaf(sc, id, si); }  // (front-end classes: constants and image maps)
 RT_DEV float tex_eval_cf(const DScene& sc, int id, const SurfaceInteraction& si) { return tex_eval_c(sc, id, si).r; }
@@ -586,12 +593,15 @@ RT_DEV rgb3 area_light_l(const DLight& l, f3 n, f3 w) {  // diffuse.rs:91-97
 RT_DEV f3 xf3x4(const float* m, f3 v) {  // Transform * Vector3f, transform.rs:288-303
   return mk3(m[0] * v.x + m[1] * v.y + m[2] * v.z, m[4] * v.x + m[5] * v.y + m[6] * v.z, m[8] * v.x + m[9] * v.y + m[10] * v.z);
 }
-RT_DEVN rgb3 infinite_le_q(const DImage* images, const DLight& l, f3 ray_d) {  // infinite.rs:211-219
+RT_DEV rgb3 infinite_le_inl(const DImage* images, const DLight& l, f3 ray_d) {  // infinite.rs:211-219
   f3 w = normalize(xf3x4(l.w2l, ray_d));
   f2 st = mk2(spherical_phi(w) * kInvPi * 0.5f, spherical_theta(w) * kInvPi);
   return mip_lookup(images[l.image], st, 0.0f);
 }
-RT_DEV rgb3 infinite_le(const DScene& sc, const DLight& l, f3 ray_d) { return infinite_le_q(sc.images, l, ray_d); }
+RT_DEVN rgb3 infinite_le_q(const DImage* images, const DLight& l, f3 ray_d) { return infinite_le_inl(images, l, ray_d); }
+// INL: the evaluator inline (the BOUNCED form of k_shade<3>, whose register bound then covers it); otherwise the out-of-line copy
+template <bool INL = false>
+RT_DEV rgb3 infinite_le(const DScene& sc, const DLight& l, f3 ray_d) { return INL ? infinite_le_inl(sc.images, l, ray_d) : infinite_le_q(sc.images, l, ray_d); }
 // DiffuseAreaLight::sample_li diffuse.rs:59-70 -> Shape::sample_si shapes/mod.rs:39-53 -> Triangle::sample mesh.rs:610-634
 RT_DEV LiSample area_light_sample_li(const DScene& sc, const DLight& l, const Interaction& ref, f2 u) {
   LiSample s;
@@ -634,7 +644,7 @@ RT_DEV float area_light_pdf_li(const DScene& sc, const DLight& l, const Interact
   return vdiv(distance_squared(ref.p, p), fabsf(dot(n, -wi)) * l.area);
 }
 template <bool GENERAL, bool EXACT = false>  // EXACT: the light-distribution build (k_lightdist_contrib), whose tables are bit-exact: correctly rounded quotients
-RT_DEVN LiSample light_sample_li(const DScene& sc, const DLight& l, Interaction ref, f2 u) {  // sc: a DScene in device memory (*sc.self); ref by value, in registers
+RT_DEV LiSample light_sample_li_inl(const DScene& sc, const DLight& l, Interaction ref, f2 u) {  // sc: a DScene in device memory (*sc.self); ref by value, in registers
   LiSample s;
   switch (l.kind) {
     case 0:
@@ -682,18 +692,19 @@ RT_DEVN LiSample light_sample_li(const DScene& sc, const DLight& l, Interaction 
   }
 }
 // The environment map's radiance at map coordinates st (mipmap.rs:227-245 with width 0: the level-0 bilinear lookup), out of line
+template <bool GENERAL, bool EXACT = false>
+RT_DEVN LiSample light_sample_li(const DScene& sc, const DLight& l, Interaction ref, f2 u) { return light_sample_li_inl<GENERAL, EXACT>(sc, l, ref, u); }
 RT_DEVN rgb3 infinite_li_q(const DImage* images, int image, float s0, float s1) { return mip_lookup(images[image], mk2(s0, s1), 0.0f); }
 // completes a light sample: an infinite light's radiance is looked up here (light_sample_li returns the map coordinates in li)
-template <bool GENERAL, bool EXACT = false>
+template <bool GENERAL, bool EXACT = false, bool INL = false>
 RT_DEV LiSample light_sample_li_full(const DScene& sc, const DLight& l, const Interaction& ref, f2 u) {
-  LiSample s = light_sample_li<GENERAL, EXACT>(sc, l, ref, u);
-  if (l.kind == 3 && s.pdf != 0.0f) s.li = RT_DBG(sc, 4) ? mkc(1, 1, 1) : infinite_li_q(sc.images, l.image, s.li.r, s.li.g);
+  LiSample s = INL ? light_sample_li_inl<GENERAL, EXACT>(sc, l, ref, u) : light_sample_li<GENERAL, EXACT>(sc, l, ref, u);
+  if (l.kind == 3 && s.pdf != 0.0f) s.li = RT_DBG(sc, 4) ? mkc(1, 1, 1) : (INL ? mip_lookup(sc.images[l.image], mk2(s.li.r, s.li.g), 0.0f) : infinite_li_q(sc.images, l.image, s.li.r, s.li.g));
   return s;
 }
 // Light::pdf_li. Area lights: Shape::pdf_wi (shapes/mod.rs:59-68) re-intersects the emitter triangle.
 template <bool GENERAL>
-RT_DEVN float light_pdf_li_q(const DScene& sc, const DLight& l, Interaction ref, float wi_x, float wi_y, float wi_z) {
-  const f3 wi = mk3(wi_x, wi_y, wi_z);
+RT_DEV float light_pdf_li_inl(const DScene& sc, const DLight& l, const Interaction& ref, f3 wi) {
   if (l.kind == 0) return area_light_pdf_li<GENERAL>(sc, l, ref, wi);
   if (l.kind == 3) {  // infinite.rs:183-196
     f3 w = xf3x4(l.w2l, wi);
@@ -707,7 +718,9 @@ RT_DEVN float light_pdf_li_q(const DScene& sc, const DLight& l, Interaction ref,
   return 0.0f;
 }
 template <bool GENERAL>
-RT_DEV float light_pdf_li(const DScene& sc, const DLight& l, const Interaction& ref, f3 wi) { return light_pdf_li_q<GENERAL>(sc, l, ref, wi.x, wi.y, wi.z); }
+RT_DEVN float light_pdf_li_q(const DScene& sc, const DLight& l, Interaction ref, float wi_x, float wi_y, float wi_z) { return light_pdf_li_inl<GENERAL>(sc, l, ref, mk3(wi_x, wi_y, wi_z)); }
+template <bool GENERAL, bool INL = false>
+RT_DEV float light_pdf_li(const DScene& sc, const DLight& l, const Interaction& ref, f3 wi) { return INL ? light_pdf_li_inl<GENERAL>(sc, l, ref, wi) : light_pdf_li_q<GENERAL>(sc, l, ref, wi.x, wi.y, wi.z); }
 RT_DEV bool light_is_delta(const DLight& l) { return l.kind == 1 || l.kind == 2; }  // light/mod.rs:38-40
 
 // ---------------------------------------------------------------- light distribution (rc/lightdistrib.rs)

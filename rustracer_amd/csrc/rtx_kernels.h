@@ -1490,13 +1490,13 @@ struct GenericBsdf {
   RT_DEV LobeSample sample_f(f3 wo, f2 u, unsigned flags) const { return bsdf_sample_f(b, wo, u, flags); }
   RT_DEV float eta() const { return b.eta; }
 };
-template <bool TEXTURED>  // TEXTURED: Kd may be any texture (evaluated out of line); false: constant Kd only, no call in the kernel
+template <bool TEXTURED, bool BOUNCED = false>  // TEXTURED: Kd may be any texture (evaluated out of line); false: constant Kd only, no call in the kernel; BOUNCED: the vertex is past the camera ray (no differentials: the inline level-0 bilinear lookup)
 struct SingleLambertT {
   rgb3 r; bool has; f3 ns, ng, ss, ts;
   RT_DEV void build(const DScene& sc, int mat, SurfaceInteraction& si) {  // matte.rs:37-62 with sigma == 0 and no bump map
     const int kd = sc.materials[mat].slot[0];
     const DTexture& t = sc.textures[kd];
-    if (TEXTURED && t.kind != RT_TEX_CONST && !RT_DBG(sc, 1)) r = clamp_pos(tex_eval_leaf(sc, kd, si));
+    if (TEXTURED && t.kind != RT_TEX_CONST && !RT_DBG(sc, 1)) r = clamp_pos(BOUNCED ? tex_eval_leaf_bounced(sc, kd, si) : tex_eval_leaf(sc, kd, si));
     else r = (TEXTURED && t.kind != RT_TEX_CONST) ? mkc(0.75f, 0.75f, 0.75f) : clamp_pos(mkc(t.v[0], t.v[1], t.v[2]));
     has = !is_black(r);
     ss = si.ssb; ns = si.sh_n; ng = si.hit.n; ts = cross(si.sh_n, ss);  // Bsdf::new, bsdf/mod.rs:77-91 (ssb = normalize(si.sh_dpdu))
@@ -1740,8 +1740,10 @@ RT_DEVN int instance_fill_interaction(const DScene& sc, unsigned hit_id, float o
 // LEAN (front-ends 3 / 5 / 6): every light is a diffuse area light on a triangle and every texture a constant - what MODE 1 assumes, for the other material
 // classes. No out-of-line light or texture evaluator is instantiated, so the kernel's allocation is its own: 155 / 168 / 168 VGPRs under a three-wave bound
 // (4 / 12 spilled dwords in the two-lobe forms) instead of 208 / 230 / 236 at two waves.
-template <int MODE, bool GENERAL = false, bool LEAN = false>
-__global__ void __launch_bounds__(256, (MODE == 1 || LEAN) ? (LEAN ? 3 : RT_SHADE_MIN_WAVES) : (MODE == 3 && !GENERAL ? RT_SHADE3_MIN_WAVES : RT_SHADE0_MIN_WAVES)) k_shade(DScene sc, FrameParams fp, PassState ps) {
+// BOUNCED (front-end 3, launches of bounces >= 1): no vertex of the launch is a camera vertex, so no differentials exist, image maps are level-0 bilinear lookups
+// (inline) and the light evaluators are taken inline too: 183 VGPRs of its own, 168 under the three-wave bound with 5 spilled dwords.
+template <int MODE, bool GENERAL = false, bool LEAN = false, bool BOUNCED = false>
+__global__ void __launch_bounds__(256, (MODE == 1 || LEAN || BOUNCED) ? ((LEAN || BOUNCED) ? 3 : RT_SHADE_MIN_WAVES) : (MODE == 3 && !GENERAL ? RT_SHADE3_MIN_WAVES : RT_SHADE0_MIN_WAVES)) k_shade(DScene sc, FrameParams fp, PassState ps) {
   QView qv; if (ps.q_in) qv.init(ps.q_in, ps.cnt_in, ps.shard_cap);
   unsigned first = 0, count = ps.q_in ? qv.total() : ps.cap;  // no queue: bounce 0 of a pass whose samples are all traced
   if (MODE != 1 && ps.range) { first = ps.range[0]; count = ps.range[1]; }
@@ -1823,17 +1825,17 @@ __global__ void __launch_bounds__(256, (MODE == 1 || LEAN) ? (LEAN ? 3 : RT_SHAD
           int li = rec_light(sc.tri_rec, prim);
           if (li >= 0) L = L + beta * area_light_l(sc.lights[li], si.hit.n, -ray_d);
         } else if ((MODE != 1 && !LEAN)) {
-          for (int k = 0; k < sc.n_infinite; ++k) L = L + beta * infinite_le(sc, sc.lights[k == 0 ? sc.infinite_ids[0] : (k == 1 ? sc.infinite_ids[1] : (k == 2 ? sc.infinite_ids[2] : sc.infinite_ids[3]))], ray_d);  // constant indices: the kernel argument stays in SGPRs
+          for (int k = 0; k < sc.n_infinite; ++k) L = L + beta * infinite_le<BOUNCED>(sc, sc.lights[k == 0 ? sc.infinite_ids[0] : (k == 1 ? sc.infinite_ids[1] : (k == 2 ? sc.infinite_ids[2] : sc.infinite_ids[3]))], ray_d);  // constant indices: the kernel argument stays in SGPRs
         }
       }
       if (found && bounces < fp.max_depth) {  // path.rs:139
-        if ((MODE != 1 && !LEAN) && bounces == 0 && sc.needs_differentials && !RT_DBG(sc, 16)) {  // only the camera ray carries differentials (interaction.rs:245-314)
+        if ((MODE != 1 && !LEAN && !BOUNCED) && bounces == 0 && sc.needs_differentials && !RT_DBG(sc, 16)) {  // only the camera ray carries differentials (interaction.rs:245-314)
           f2 pf; { float2 t = pacc->pfilm; pf = mk2(t.x, t.y); }
           f2 pl = table_2d(smp.tb, pix, 1, s);
           CameraRay cr = generate_camera_ray(fp, pf, pl, 1.0f / sqrtf((float)ps.spp));
           if (MODE == 0) compute_differential_call(si, cr.rx_o, cr.ry_o, cr.rx_d, cr.ry_d); else compute_differential(si, cr.rx_o, cr.ry_o, cr.rx_d, cr.ry_d);
         }
-        typename std::conditional<MODE == 1, SingleLambert, typename std::conditional<MODE == 3, SingleLambertT<!LEAN>,
+        typename std::conditional<MODE == 1, SingleLambert, typename std::conditional<MODE == 3, SingleLambertT<!LEAN, BOUNCED>,
                                   typename std::conditional<MODE == 5, SmallBsdfT<false, LEAN>, typename std::conditional<MODE == 6, SmallBsdfT<true, LEAN>, GenericBsdf>::type>::type>::type>::type bsdf;
         RT_STAMP(1);  // emission + differentials
         if (MODE == 0) bsdf.build(gsc, rec_material(sc.tri_rec, prim), si); else bsdf.build(sc, rec_material(sc.tri_rec, prim), si);
@@ -1863,7 +1865,7 @@ __global__ void __launch_bounds__(256, (MODE == 1 || LEAN) ? (LEAN ? 3 : RT_SHAD
             const DLight& light = sc.lights[light_num];
             // ---- estimate_direct (integrator/mod.rs:222-318), light-sampling half
             rgb3 ld1 = mkc(0, 0, 0); f3 sh_dir = mk3(0, 0, 0);
-            LiSample ls = (MODE == 1 || LEAN) ? area_light_sample_li(sc, light, si.hit, u_light) : light_sample_li_full<GENERAL>(gsc, light, si.hit, u_light);
+            LiSample ls = (MODE == 1 || LEAN) ? area_light_sample_li(sc, light, si.hit, u_light) : light_sample_li_full<GENERAL, false, BOUNCED>(gsc, light, si.hit, u_light);
             if (ls.pdf > 0.0f && !is_black(ls.li)) {
               rgb3 f = bsdf.f(si.hit.wo, ls.wi, nonspec) * fabsf(dot(ls.wi, si.sh_n));
               float scattering_pdf = ((MODE != 1 && !LEAN) && light_is_delta(light)) ? 0.0f : bsdf.pdf(si.hit.wo, ls.wi, nonspec);  // read by the power heuristic only: a delta light has none
@@ -1885,7 +1887,7 @@ __global__ void __launch_bounds__(256, (MODE == 1 || LEAN) ? (LEAN ? 3 : RT_SHAD
               if (!is_black(f) && bs.pdf > 0.0f) {
                 float weight = 1.0f; bool go = true;
                 if (!(bs.type & BSDF_SPECULAR)) {
-                  float lp = (MODE == 1 || LEAN) ? area_light_pdf_li<false>(sc, light, si.hit, bs.wi) : light_pdf_li<GENERAL>(gsc, light, si.hit, bs.wi);
+                  float lp = (MODE == 1 || LEAN) ? area_light_pdf_li<false>(sc, light, si.hit, bs.wi) : light_pdf_li<GENERAL, BOUNCED>(gsc, light, si.hit, bs.wi);
                   if (lp == 0.0f) go = false;  // `return ld`
                   else weight = power_heuristic1(bs.pdf, lp);
                   if (GENERAL && go && ps.skip_unreachable_mis && light.kind == 0 && (tri_flags(sc.tri_p, light.prim) & RT_FLAG_SPHERE)) {
