@@ -261,7 +261,11 @@ def run_workload(scene_name, runner, workload, steps, warmup):
     # (RT_FLAG_COUNT_AS_RENDERED): path rays and MIS rays toward area lights closest-hit, shadow rays and MIS rays toward the environment any-hit.
     def ray_class(rays, nodes, tris, ms, per_ray):
         b = per_ray * rays + 32 * nodes + 36 * tris
-        return {"rays": int(rays), "algorithmic_bytes": int(b), "ms": round(ms, 3), "GB_per_s": round(b / max(ms, 1e-9) / 1e6, 1), "frac_of_8TBs": round(b / max(ms, 1e-9) / 1e6 / 8000.0, 4),
+        # `reference_walk_rate`: the bytes the REFERENCE's node-at-a-time walk would move for these rays / the time of the launches that traced them, over 8 TB/s.
+        # A rate in the reference's currency, not a share of this GPU's bandwidth: a four-wide kernel fetches fewer bytes than that for the same
+        # walk and a tree top held in LDS none, so it can exceed 1. The share of the bandwidth is `hbm_frac` of the kernel group below (PMC bytes / time / 8 TB/s).
+        return {"rays": int(rays), "algorithmic_bytes": int(b), "ms": round(ms, 3), "reference_walk_GB_per_s": round(b / max(ms, 1e-9) / 1e6, 1),
+                "reference_walk_rate": round(b / max(ms, 1e-9) / 1e6 / 8000.0, 4),
                 "nodes_per_ray": round(nodes / max(rays, 1), 2), "tris_per_ray": round(tris / max(rays, 1), 2)}
     ms_mis_any = ms_mean.get("ms_trace_mis_any", 0.0)
     not_cast = cst.get("rays_mis_not_cast", 0)  # of rays_mis: rays toward a sphere light that cannot reach it (rt_stats::rays_mis_not_cast): in no launch, no bytes
@@ -273,6 +277,18 @@ def run_workload(scene_name, runner, workload, steps, warmup):
                                  ms_mean["ms_trace_mis"] - ms_mis_any, 48),
         "mis_any": ray_class(cst["rays_mis_any"] / nd_div, cst["nodes_mis_any"] / nd_div, cst["tris_mis_any"] / nd_div, ms_mis_any, 36),
     }
+    # What the traversal kernels really take from HBM: PMC bytes per camera sample of each kernel group (profiles/pmc_<scene>.json, collected at this pass size)
+    # x this frame's samples / the group's launches' time / 8 TB/s. PMC counters are per kernel name, so the path and MIS launches of one kernel are one group.
+    def hbm_frac(group, ms):
+        e, prov = pmc_entry(scene_name, group)
+        bps = e.get("hbm_bytes_per_camera_sample")
+        if not bps or ms <= 0:
+            return None
+        n = cst["camera_rays"] / nd_div
+        return {"hbm_frac": round(bps * n / (ms * 1e-3) / 8e12, 4), "hbm_frac_raw_reads": round(e.get("hbm_bytes_per_camera_sample_raw", 0.0) * n / (ms * 1e-3) / 8e12, 4),
+                "hbm_GB": round(bps * n / 1e9, 2), "ms": round(ms, 3), "stale": bool(prov and prov.get("stale"))}
+    groups = {"closest_hit_kernels": hbm_frac("trace_closest_all", ms_mean["ms_trace_closest"] + ms_mean["ms_trace_mis"] - ms_mis_any),
+              "any_hit_kernels": hbm_frac("trace_any_all", ms_mean["ms_trace_any"] + ms_mis_any)}
     ms_tc = ms_mean["ms_trace_closest"]
     ms_sh = ms_mean["ms_shade"]
 
@@ -293,7 +309,7 @@ def run_workload(scene_name, runner, workload, steps, warmup):
              "traffic_provenance": prov,
              "algorithmic_bytes_per_launch": round(algo_bytes / max(n_launch, 1)), "avg_launch_ms": round(ms_kernel / max(n_launch, 1), 4),
              "launches_per_step": int(n_launch), f"bytes_per_{unit}": round(algo_bytes / max(unit_n, 1), 1),
-             "lanes_per_valu_instruction": e.get("lanes_per_valu"), "occupancy": occupancy_of("k_shade" if kname == "shade" else "k_trace")}
+             "lanes": e.get("lanes_per_valu")}
         if prov and prov.get("stale"):
             r["warning"] = "roofline.traffic was collected on other kernel sources than the ones that ran (profiles/pmc_*.json: kernel_source_sha differs)"
         return r
@@ -302,8 +318,8 @@ def run_workload(scene_name, runner, workload, steps, warmup):
     kernels_ms = {k[3:]: round(v, 2) for k, v in ms_mean.items()}
     verts = {k[9:]: int(kstats[-1][k]) for k in kstats[-1] if k.startswith("vertices_") and kstats[-1][k]}
     sharding = {"single": "single GPU",
-                "dist": "interleaved 16-row tile rows, one process per GPU, end-of-frame gather of the touched rows to rank 0 (RCCL send/recv)",
-                "multi": f"one process, rt_multi_render: {runner.chunks} chunk(s) of interleaved 16-row tile rows per device from a shared queue, touched rows peer-copied to device 0 and added there"}[runner.mode]
+                "dist": "interleaved tile rows, one process per GPU, touched rows gathered on rank 0 (RCCL send/recv)",
+                "multi": f"one process (rt_multi_render), {runner.chunks} chunk(s) of interleaved tile rows per device, touched rows peer-copied to device 0"}[runner.mode]
     out = {
         "metric": "Msamples/s", "value": round(value, 2), "unit": "Msamples/s", "n_gpus": n_gpus, "steps": steps, "warmup": warmup,
         "ms_per_step": round(ms_step, 2), "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
@@ -312,7 +328,8 @@ def run_workload(scene_name, runner, workload, steps, warmup):
         "Mrays_per_s": round((cst["rays_closest"] + cst["rays_shadow"] + cst["rays_mis"] - not_cast) / (ms_step * 1e-3) / 1e6, 1),
         "mis_rays_not_cast": int(not_cast),
         "kernel_ms_per_step": kernels_ms, "vertices_by_shade_front_end": verts,
-        "roofline": roofline, "roofline_second_kernel": roofline_other, "traversal_by_ray_class": classes,
+        "roofline": roofline, "roofline_second_kernel": roofline_other, "traversal_by_ray_class": classes, "traversal_hbm_share": groups,
+        "camera_samples_per_step": int(samples_per_step),
     }
     if n_gpus_asked > 1:
         out["n_gpus_requested"] = n_gpus_asked
@@ -324,6 +341,69 @@ def run_workload(scene_name, runner, workload, steps, warmup):
         else:
             out["rccl_world_size"] = world
     return out
+
+
+LINE_LIMIT = 4096  # bytes of the ONE printed line (a 78 KB line was not parsed by the driver); tests/test_bench_cpu.py holds it there
+
+ROOF_KEYS = ("bound", "kernel", "achieved", "peak", "unit", "frac", "traffic", "traffic_raw_reads", "algorithmic_bytes_per_launch", "avg_launch_ms", "launches_per_step", "lanes")
+CPU_KEYS = ("value", "unit", "cores", "kind", "sample")
+TOP_KEYS = ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data", "config",
+            "n_gpus_requested", "per_device_ms", "gather_ms", "imbalance_max_over_mean")
+
+
+def _roof(r):
+    return {k: r[k] for k in ROOF_KEYS if k in r}
+
+
+def _traffic_ratio(r):
+    return round(r["traffic"] / r["algorithmic_bytes_per_launch"], 2) if r.get("traffic") and r.get("algorithmic_bytes_per_launch") else None
+
+
+def compact_line(full):
+    """The ONE line bench.py prints: BASELINE's metric, `roofline` of the dominant kernel, `cpu_baseline`, and per other workload the six numbers that say
+    where it stands. Everything else a run measures (per-class traversal rates, stage times, register tables, provenance) is in the detail file."""
+    out = {k: full[k] for k in TOP_KEYS if k in full}
+    out["config"] = {k: v for k, v in full["config"].items() if k in ("workload", "sharding", "sampler_mode")}
+    out["roofline"] = _roof(full["roofline"])
+    if full["roofline"].get("warning"):
+        out["roofline"]["traffic_stale"] = True
+    if "cpu_baseline" in full:
+        out["cpu_baseline"] = {k: full["cpu_baseline"][k] for k in CPU_KEYS}
+        out["speedup"] = full.get("speedup_vs_cpu_baseline")
+    oc = {}
+    for name, r in (full.get("other_configs") or {}).items():
+        oc[name] = {"value": r["value"], "ms_per_step": r["ms_per_step"], "kernel": r["roofline"]["kernel"], "frac": r["roofline"]["frac"],
+                    "traffic_ratio": _traffic_ratio(r["roofline"]), "cpu": (r.get("cpu_baseline") or {}).get("value")}
+    if oc:
+        out["other_configs"] = oc
+    c1 = full.get("config_c1")
+    if c1:
+        out["config_c1"] = {"gpu": c1["gpu"]["value"], "cpu": (c1.get("cpu_port") or {}).get("value")}
+    if full.get("detail"):
+        out["detail"] = full["detail"]
+    line = json.dumps(out, separators=(",", ":"))
+    if len(line) > LINE_LIMIT:  # never let a long workload name or device list push the line past what the driver reads
+        out["config"]["workload"] = out["config"]["workload"][:160]
+        for k in ("per_device_ms", "detail"):
+            out.pop(k, None)
+        line = json.dumps(out, separators=(",", ":"))
+    assert len(line) <= LINE_LIMIT, len(line)
+    return line
+
+
+def write_detail(full, path=None):
+    """Everything the run measured, next to the line: gpurun_out/bench_detail.json (scratch on the GPU box; scripts/profile_round.sh copies it under profiles/)."""
+    path = path or os.path.join(ROOT, "gpurun_out", "bench_detail.json")
+    try:
+        os.makedirs(os.path.dirname(path), exist_ok=True)
+        full = dict(full)
+        full["kernel_resources"] = {"k_trace": occupancy_of("k_trace"), "k_shade": occupancy_of("k_shade")}
+        full["kernel_source_sha"] = source_sha()
+        with open(path, "w") as f:
+            json.dump(full, f, indent=1)
+        return os.path.relpath(path, ROOT)
+    except OSError:
+        return None
 
 
 def main():
@@ -342,6 +422,7 @@ def main():
     ap.add_argument("--devices", default=None, help="in-process multi-GPU mode: comma-separated device ordinals, one worker each (default 0..N-1). Naming an ordinal "
                                                     "twice puts two workers with their own scene replicas on one GPU - a way to exercise the N > 1 path on a 1-GPU box, not a measurement")
     ap.add_argument("--chunks-per-device", type=int, default=1, help="in-process multi-GPU mode: tile-row chunks per device on the shared queue (1 = static interleaved split)")
+    ap.add_argument("--detail", default=None, help="where the full measurement goes (default gpurun_out/bench_detail.json); the printed line stays under 4 KB")
     args = ap.parse_args()
 
     import torch
@@ -414,7 +495,7 @@ def main():
                     r["cpu_baseline"] = cpu_baseline(d, args.cpu_spp if name != "room" else max(8, args.cpu_spp // 2))
                     r["speedup_vs_cpu_baseline"] = round(r["value"] / r["cpu_baseline"]["value"], 1)
                 others[name] = {k: r[k] for k in ("value", "unit", "steps", "ms_per_step", "config", "Mrays_per_s", "kernel_ms_per_step", "vertices_by_shade_front_end",
-                                                  "roofline", "roofline_second_kernel", "traversal_by_ray_class", "cpu_baseline", "speedup_vs_cpu_baseline") if k in r}
+                                                  "roofline", "roofline_second_kernel", "traversal_by_ray_class", "traversal_hbm_share", "cpu_baseline", "speedup_vs_cpu_baseline") if k in r}
             out["other_configs"] = others
             # BASELINE configs[0] exactly: cornell 400x400, 64 spp - the reference's own CPU-runnable case, on the GPU and on the CPU port
             d, wl = make_desc("cornell", 64, 400)
@@ -424,7 +505,8 @@ def main():
                 c1["cpu_port"] = cpu_baseline(d, 64, what="whole")
             out["config_c1"] = c1
     if rank == 0:
-        print(json.dumps(out), flush=True)
+        out["detail"] = write_detail(out, args.detail)
+        print(compact_line(out), flush=True)
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()

@@ -86,5 +86,21 @@ out = {'scene': scene, 'collected': f'{tag}, {datetime.date.today().isoformat()}
        'source': f'profiles/{tag}_{scene}_pmc_hbm.csv', 'kernel_source_sha': source_sha(),
        'trace_closest': pick(['rtx::k_trace<false, false', 'rtx::k_trace_pair<false', 'rtx::k_trace_top<false']),
        'shade': pick(['rtx::k_shade'], per_stage=True)}
+
+def per_sample(prefixes):
+    """All launches of a kernel group (path and MIS rays alike: the counters are per kernel name) as HBM bytes per camera sample of the profiled run."""
+    sel = [r for r in rows if any(r[0].startswith(p) for p in prefixes)]
+    if not sel or not samples:
+        return None
+    return {'kernels': sorted({r[0] for r in sel}), 'hbm_bytes_per_camera_sample': sum(r[4] * r[1] for r in sel) / samples,
+            'hbm_bytes_per_camera_sample_raw': sum(r[5] * r[1] for r in sel) / samples, 'camera_samples_profiled': samples}
+
+samples = None
+try:  # the PMC runs write their full measurement next to their counters (bench.py --detail)
+    samples = json.load(open(os.path.join(base, 'fetch_detail.json')))['camera_samples_per_step']
+except Exception:
+    pass
+out['trace_closest_all'] = per_sample(['rtx::k_trace<false', 'rtx::k_trace_pair<false', 'rtx::k_trace_top<false'])  # k_trace_big is the visit-counting frame's kernel: not a timed launch
+out['trace_any_all'] = per_sample(['rtx::k_trace<true', 'rtx::k_trace_pair<true', 'rtx::k_trace_top<true', 'rtx::k_trace_quad'])
 json.dump(out, open(os.path.join('profiles', f'pmc_{scene}.json'), 'w'), indent=1)
 print(open(os.path.join('profiles', f'{tag}_{scene}_pmc_hbm.csv')).read())

@@ -10,10 +10,10 @@ cd /tmp && export TMPDIR=/tmp && cd $ROOT
 # PMC passes run at the spp that gives the launch size of the full run (a pass holds 2^28 paths = 512 samples of a 2^19-pixel batch)
 PSPP=512
 if [ "$SCENE" = "blob" ]; then PSPP=256; fi   # S2 renders 256 spp: its passes hold 256 samples
-rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/fetch -- python3 bench.py --scene $SCENE --steps 1 --warmup 0 --spp $PSPP --no-cpu-baseline --headline-only > $OUT/fetch.log 2>&1
-rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/write -- python3 bench.py --scene $SCENE --steps 1 --warmup 0 --spp $PSPP --no-cpu-baseline --headline-only > $OUT/write.log 2>&1
-rocprofv3 --pmc SQ_INSTS_VALU SQ_THREAD_CYCLES_VALU --output-format csv -d $OUT/sq -- python3 bench.py --scene $SCENE --steps 1 --warmup 0 --spp $PSPP --no-cpu-baseline --headline-only > $OUT/sq.log 2>&1
+rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/fetch -- python3 bench.py --scene $SCENE --steps 1 --warmup 0 --spp $PSPP --no-cpu-baseline --headline-only --detail $OUT/fetch_detail.json > $OUT/fetch.log 2>&1
+rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/write -- python3 bench.py --scene $SCENE --steps 1 --warmup 0 --spp $PSPP --no-cpu-baseline --headline-only --detail $OUT/write_detail.json > $OUT/write.log 2>&1
+rocprofv3 --pmc SQ_INSTS_VALU SQ_THREAD_CYCLES_VALU --output-format csv -d $OUT/sq -- python3 bench.py --scene $SCENE --steps 1 --warmup 0 --spp $PSPP --no-cpu-baseline --headline-only --detail $OUT/sq_detail.json > $OUT/sq.log 2>&1
 python3 scripts/profile_round.py $TAG $SCENE
 # the traced bench line last: it then compares with the PMC file of these very kernels (no stale-traffic warning in it)
-rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -- python3 bench.py --scene $SCENE --steps 2 --warmup 1 --no-cpu-baseline --headline-only > $OUT/stats.log 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -- python3 bench.py --scene $SCENE --steps 2 --warmup 1 --no-cpu-baseline --headline-only --detail $OUT/stats_detail.json > $OUT/stats.log 2>&1
 python3 scripts/profile_round.py $TAG $SCENE

@@ -6,7 +6,7 @@ for sc in cornell room blob mis; do
   timeout 1500 bash scripts/profile_round.sh $TAG $sc > gpurun_out/final/profile_$sc.log 2>&1
   cp gpurun_out/${TAG}_$sc/stats.log gpurun_out/final/bench_$sc.log 2>/dev/null
 done
-timeout 900 python bench.py > gpurun_out/final/bench_default.json 2> gpurun_out/final/bench_default.err
+timeout 900 python bench.py --detail gpurun_out/final/bench_default_detail.json > gpurun_out/final/bench_default.json 2> gpurun_out/final/bench_default.err
 for sc in mis-spheres instances-10k; do
   timeout 300 python bench.py --scene $sc --steps 3 --warmup 1 --no-cpu-baseline --headline-only > gpurun_out/final/bench_$sc.json 2> gpurun_out/final/bench_$sc.err
 done

@@ -30,15 +30,33 @@ def test_in_process_multi_gpu_runner_renders_the_single_gpu_film(gpu_host):
         assert c1[k] == c2[k], k
 
 
-def test_bench_line_of_the_in_process_multi_gpu_mode():
+def test_bench_line_of_the_in_process_multi_gpu_mode(tmp_path):
+    detail = str(tmp_path / "detail.json")
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--devices", "0,0", "--res", "128", "--spp", "16", "--steps", "1", "--warmup", "1",
-                        "--headline-only", "--no-cpu-baseline"], capture_output=True, text=True, timeout=600,
+                        "--headline-only", "--no-cpu-baseline", "--detail", detail], capture_output=True, text=True, timeout=600,
                        env={k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE")})
     assert r.returncode == 0, r.stderr[-2000:]
-    j = json.loads(r.stdout.strip().splitlines()[-1])
-    assert j["n_gpus"] == 2 and j["n_gpus_requested"] == 2 and j["devices"] == [0, 0] and len(j["per_device_ms"]) == 2
+    lines = r.stdout.strip().splitlines()
+    assert len(lines) == 1 and len(lines[0]) < 4096  # ONE line the driver can parse (78 KB were not)
+    j = json.loads(lines[0])
+    assert j["n_gpus"] == 2 and j["n_gpus_requested"] == 2 and len(j["per_device_ms"]) == 2
     assert j["value"] > 0 and j["roofline"]["frac"] > 0 and "gather_ms" in j and j["imbalance_max_over_mean"] >= 1.0
-    assert set(j["traversal_by_ray_class"]) == {"path_closest", "shadow_any", "mis_closest", "mis_any"}
+    d = json.load(open(detail))  # the rest of the measurement
+    assert d["devices"] == [0, 0] and set(d["traversal_by_ray_class"]) == {"path_closest", "shadow_any", "mis_closest", "mis_any"}
+    assert any("k_shade" in k for k in d["kernel_resources"]["k_shade"])
+
+
+def test_default_bench_line_parses_and_is_short(tmp_path):
+    """The command the driver runs, at a size that takes seconds: one line < 4 KB with roofline, cpu_baseline and the other configs' summary."""
+    detail = str(tmp_path / "detail.json")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--res", "128", "--spp", "16", "--steps", "1", "--warmup", "0", "--cpu-spp", "1", "--headline-only",
+                        "--detail", detail], capture_output=True, text=True, timeout=900, env={k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE")})
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = r.stdout.strip().splitlines()
+    assert len(lines) == 1 and len(lines[0]) < 4096
+    j = json.loads(lines[0])
+    assert j["n_gpus"] == 1 and j["roofline"]["bound"] == "hbm" and 0 < j["roofline"]["frac"] < 1 and j["roofline"]["peak"] == 8000.0
+    assert j["cpu_baseline"]["kind"] == "port" and j["cpu_baseline"]["value"] > 0 and j["cpu_baseline"]["cores"] >= 1 and j["speedup"] > 0
 
 
 def test_counting_as_rendered_walks_environment_mis_rays_as_occlusion_rays(gpu_host):
