@@ -1157,7 +1157,7 @@ extern "C" int rt_render(rt_scene* s, const rt_camera* cam, const rt_film_desc* 
   auto env_log2 = [](const char* name, int dflt) { const char* e = getenv(name); return e ? std::min(30, std::max(16, atoi(e))) : dflt; };
   static const int tp_log2 = env_log2("RTX_PASS_LOG2", 28);
   static const int bp_log2 = env_log2("RTX_BATCH_LOG2", 19);
-  enum { B_PATH, B_VERT, B_BETA, B_ACC, B_SH, B_MI, B_QIN, B_QOUT, B_QSH, B_QMI, B_QMA, B_OCCSH, B_OCCMI, B_COUNT };  // grouped per-path records (rtx_kernels.h) and five queues of path ids
+  enum { B_GEN0, B_GEN1, B_HIT, B_LACC, B_PFILM, B_SH, B_MI, B_QSH, B_QMI, B_QMA, B_OCCSH, B_OCCMI, B_COUNT };  // two generations of travelling path records + their hits (by queue slot), radiance and film position (by path id), ray records and the three ray queues
   const bool has_infinite = s->d.n_infinite > 0;
   const size_t counter_words = (size_t)(fp.max_depth + 2) * RT_NQ * RT_QSHARDS * RT_CNT_STRIDE;  // one block of {out, shadow, mis, mis-any} shard counts per bounce + raygen's
   // material binning before the generic shade kernel: per bounce {hist, cursor}[RT_BIN_MAX + 1] + the 8 count words of the sorted queue
@@ -1177,7 +1177,7 @@ extern "C" int rt_render(rt_scene* s, const rt_camera* cam, const rt_film_desc* 
   const unsigned pgrid_q = (unsigned)s->n_cu * 8u;
   const unsigned long long table_bytes_per_pixel = 2ull * dims * spp * 2ull;
 
-  unsigned long long batch_pixels = 0, chunk_pixels = 0, cap = 0; unsigned pass_samples = 0, shard_cap = 0; bool multi_batch = false;
+  unsigned long long batch_pixels = 0, chunk_pixels = 0, cap = 0; unsigned pass_samples = 0, shard_cap = 0; bool multi_batch = false; size_t n_slots = 0;
   for (int shrink = 0;; ++shrink) {
     if (tp_log2 - shrink < 14) return fail(RT_ERR_OOM, "not enough free device memory for the smallest pass (2^14 paths)");
     const unsigned long long target_paths = 1ull << (tp_log2 - shrink);
@@ -1195,11 +1195,13 @@ extern "C" int rt_render(rt_scene* s, const rt_camera* cam, const rt_film_desc* 
     // each block at most ceil(n / (grid * 256)) iterations, so cap / RT_QSHARDS plus one iteration per block bounds it
     shard_cap = (unsigned)(cap / RT_QSHARDS) + 256u * (pgrid_q / RT_QSHARDS + 1u) + 256u;
     const size_t szq = (size_t)shard_cap * RT_QSHARDS * 4;
+    n_slots = (size_t)shard_cap * RT_QSHARDS;  // slots of a sharded queue (>= cap: bounce 0 of a fully traced pass uses slot = path id)
     multi_batch = owned_pixels > chunk_pixels;
     struct Want { DevBuf* buf; size_t bytes; };
     std::vector<Want> want = {
-        {&s->ws[B_PATH], cap * sizeof(RayRec)}, {&s->ws[B_VERT], RT_PATHREC_SPLIT ? cap * sizeof(VertRec) : 16}, {&s->ws[B_BETA], RT_PATHREC_SPLIT == 2 ? cap * sizeof(BetaRec) : 16}, {&s->ws[B_ACC], cap * sizeof(PathAcc)}, {&s->ws[B_SH], cap * sizeof(ShadowRec)}, {&s->ws[B_MI], cap * sizeof(MisRec)}, {&s->ws[B_OCCSH], cap}, {&s->ws[B_OCCMI], cap},
-        {&s->ws[B_QIN], szq}, {&s->ws[B_QOUT], szq}, {&s->ws[B_QSH], szq}, {&s->ws[B_QMI], szq}, {&s->ws[B_QMA], has_infinite ? szq : 16},
+        {&s->ws[B_GEN0], n_slots * 64}, {&s->ws[B_GEN1], n_slots * 64}, {&s->ws[B_HIT], n_slots * 16}, {&s->ws[B_LACC], cap * 16}, {&s->ws[B_PFILM], cap * 8},
+        {&s->ws[B_SH], cap * sizeof(ShadowRec)}, {&s->ws[B_MI], cap * sizeof(MisRec)}, {&s->ws[B_OCCSH], cap}, {&s->ws[B_OCCMI], cap},
+        {&s->ws[B_QSH], szq}, {&s->ws[B_QMI], szq}, {&s->ws[B_QMA], has_infinite ? szq : 16},
         {&s->counters, counter_words * 4}, {&s->stats, (size_t)ST_COUNT * 8}, {&s->film_acc, (size_t)cw * ch * 16}, {&s->own_acc, (size_t)chunk_pixels * 16},
         {&s->filter_table, 1024}, {&s->scrambles[0], (size_t)chunk_pixels * 3 * dims * 4}, {&s->perms[0], (size_t)(chunk_pixels * table_bytes_per_pixel)},
         {&s->sampler_plan.partners, (size_t)(chunk_pixels * table_bytes_per_pixel)}};
@@ -1231,10 +1233,11 @@ extern "C" int rt_render(rt_scene* s, const rt_camera* cam, const rt_film_desc* 
 
   PassState ps{};
   ps.spp = spp; ps.spp_log2 = spp_log2; ps.dims = dims;
-  ps.ray = s->ws[B_PATH].as<RayRec>(); ps.vert = RT_PATHREC_SPLIT ? s->ws[B_VERT].as<VertRec>() : (VertRec*)s->ws[B_PATH].p;
-  ps.bet = RT_PATHREC_SPLIT == 2 ? s->ws[B_BETA].as<BetaRec>() : (BetaRec*)ps.vert; ps.acc = s->ws[B_ACC].as<PathAcc>(); ps.sh = s->ws[B_SH].as<ShadowRec>(); ps.mi = s->ws[B_MI].as<MisRec>();
+  auto gen_of = [&](int b) { PathGen g; char* p = (char*)s->ws[b].p; g.o = (float4*)p; g.d = (float4*)(p + n_slots * 16); g.beta = (float4*)(p + n_slots * 32); g.st = (uint4*)(p + n_slots * 48); return g; };
+  const PathGen gen0 = gen_of(B_GEN0), gen1 = gen_of(B_GEN1);
+  ps.hit = s->ws[B_HIT].as<float4>(); ps.lacc = s->ws[B_LACC].as<float4>(); ps.pfilm = s->ws[B_PFILM].as<float2>();
+  ps.sh = s->ws[B_SH].as<ShadowRec>(); ps.mi = s->ws[B_MI].as<MisRec>();
   ps.occ_sh = s->ws[B_OCCSH].as<unsigned char>(); ps.occ_mi = s->ws[B_OCCMI].as<unsigned char>();
-  unsigned* q_a = s->ws[B_QIN].as<unsigned>(); unsigned* q_b = s->ws[B_QOUT].as<unsigned>();
   ps.q_shadow = s->ws[B_QSH].as<unsigned>(); ps.q_mis = s->ws[B_QMI].as<unsigned>(); ps.q_misany = s->ws[B_QMA].as<unsigned>();
   ps.own_acc = s->own_acc.as<float4>(); ps.shard_cap = shard_cap; ps.stats = s->stats.as<unsigned long long>();
 
@@ -1243,10 +1246,10 @@ extern "C" int rt_render(rt_scene* s, const rt_camera* cam, const rt_film_desc* 
   // the four kinds of trace launch of a bounce, on the records of the pass
   TraceIO io_path{}, io_shadow{}, io_mis{}, io_mis_any{};
   {
-    constexpr unsigned PR = sizeof(RayRec) / 16, VR = sizeof(VertRec) / 16, SR = sizeof(ShadowRec) / 16, MR = sizeof(MisRec) / 16;
-    io_path.ray_o = &ps.ray->o; io_path.ray_d = &ps.ray->d; io_path.ray_stride = PR; io_path.hits = &ps.vert->hit; io_path.hit_stride = VR; io_path.hit_b2 = 1;
+    constexpr unsigned SR = sizeof(ShadowRec) / 16, MR = sizeof(MisRec) / 16;
+    io_path.ray_stride = 1; io_path.hits = ps.hit; io_path.hit_stride = 1; io_path.hit_b2 = 1; io_path.queue_is_slots = 1;  // (ray_o / ray_d: the bounce's generation)
     io_shadow.ray_o = &ps.sh->o; io_shadow.ray_d = &ps.sh->d; io_shadow.ray_stride = SR; io_shadow.occluded = (unsigned*)ps.occ_sh; io_shadow.occ_stride = 0;
-    io_shadow.shadow_masks = 1; io_shadow.lacc = &ps.acc->lacc; io_shadow.lacc_stride = sizeof(PathAcc) / 16; io_shadow.direct_add = &ps.sh->add; io_shadow.add_stride = SR;
+    io_shadow.shadow_masks = 1; io_shadow.lacc = ps.lacc; io_shadow.lacc_stride = 1; io_shadow.direct_add = &ps.sh->add; io_shadow.add_stride = SR;
     io_mis.ray_o = &ps.mi->o; io_mis.ray_d = &ps.mi->d; io_mis.ray_stride = MR; io_mis.hits = &ps.mi->hit; io_mis.hit_stride = MR; io_mis.hit_b2 = 0;
     io_mis_any = io_mis; io_mis_any.shadow_masks = 0; io_mis_any.hits = nullptr; io_mis_any.occluded = (unsigned*)ps.occ_mi; io_mis_any.occ_stride = 0;
   }
@@ -1292,7 +1295,7 @@ extern "C" int rt_render(rt_scene* s, const rt_camera* cam, const rt_film_desc* 
     HIP_TRY(hipStreamWaitEvent(stream, s->ev_tables[buf], 0));
     for (unsigned s0 = 0; s0 < spp; s0 += pass_samples) {
       ps.s0 = s0; ps.n_samples = std::min(pass_samples, spp - s0); ps.cap = (unsigned)(npx * ps.n_samples);
-      ps.q_in = q_a; ps.q_out = q_b;
+      ps.q_in = nullptr; ps.in = gen1; ps.out = gen0;  // raygen writes bounce 0's records
       HIP_TRY(hipMemsetAsync(s->counters.p, 0, counter_words * 4, stream));
       if (use_bins) HIP_TRY(hipMemsetAsync(s->bin_words.p, 0, (size_t)(fp.max_depth + 1) * bin_stride * 4, stream));
       unsigned* const cb = s->counters.as<unsigned>();
@@ -1307,10 +1310,12 @@ extern "C" int rt_render(rt_scene* s, const rt_camera* cam, const rt_film_desc* 
       tm.end();
       for (int bounce = 0; bounce <= fp.max_depth; ++bounce) {
         ps.cnt_in = cb + (size_t)bounce * RT_NQ * RT_QSHARDS * RT_CNT_STRIDE; ps.cnt_out = cb + (size_t)(bounce + 1) * RT_NQ * RT_QSHARDS * RT_CNT_STRIDE;
-        unsigned* const q_first = ps.q_in;
-        if (bounce == 0 && all_in_bounds) ps.q_in = nullptr;  // identity: path i is entry i
+        std::swap(ps.in, ps.out);  // what the previous stage appended is this bounce's input
+        if (bounce == 0 && all_in_bounds) ps.cnt_in = nullptr;  // identity: entry i is slot i is path i
+        io_path.ray_o = ps.in.o; io_path.ray_d = ps.in.d;
         tm.begin(&stats.ms_trace_closest);
-        launch_trace<false>(s, count, io_path, ps.q_in, ps.cnt_in, ps.shard_cap, ps.cap, dstats, ST_RAYS_CLOSEST, ST_NODES_CLOSEST, ST_TRIS_CLOSEST, stream);
+        // the rays of the bounce sit at their queue slots: the kernels walk the entries by the shard counts alone (a non-NULL `queue` only says "sharded")
+        launch_trace<false>(s, count, io_path, ps.cnt_in, ps.cnt_in, ps.shard_cap, ps.cap, dstats, ST_RAYS_CLOSEST, ST_NODES_CLOSEST, ST_TRIS_CLOSEST, stream);
         tm.end();
 #define RT_SHADE(MODE, P) launch_shade<MODE>(gshade, lean_shade, bounce >= 1 && !bounced_off, sgrid, sblock, stream, s->d, fp, P)
         if (s->lambert_only) { tm.begin(&stats.ms_shade_lambert_const); hipLaunchKernelGGL(k_shade<1>, dim3(sgrid), dim3(sblock), 0, stream, s->d, fp, ps); tm.end(); }
@@ -1350,8 +1355,6 @@ extern "C" int rt_render(rt_scene* s, const rt_camera* cam, const rt_film_desc* 
         else hipLaunchKernelGGL(k_resolve<false>, dim3(pgrid), dim3(256), 0, stream, s->d, ps);
         tm.end();
         stats.launches_trace_closest += 2;
-        ps.q_in = q_first;
-        std::swap(ps.q_in, ps.q_out);
       }
       tm.begin(&stats.ms_film);
       hipLaunchKernelGGL(k_film_accumulate, dim3(pgrid), dim3(256), 0, stream, fp, ps, s->filter_table.as<float>(), s->film_acc.as<float4>());

@@ -14,30 +14,15 @@ namespace rtx {
 //      for all spp) and each batch into PASSES of n_samples consecutive samples of every batch pixel.
 //      SoA arrays are indexed by path id = local_sample * n_pixels + batch_pixel, so that the 64 lanes of a
 //      wave hold the same sample of 64 neighbouring pixels and every access coalesces.
-// Per-path records are grouped by the kernels that touch them together, so that a vertex shaded out of path-id order (the shade queue
-// is counting-sorted by material class on scenes with several) touches four cache lines instead of twenty 16-byte slots of
-// twenty arrays - a scattered 16-byte access moves a whole 128-byte line. In path-id order the records stream like the arrays did.
-// The ray (o | t_max, d) and the vertex record (hit (b2 | t, prim, b0, b1), throughput (rgb, eta_scale)) of a path. RT_PATHREC_SPLIT = 1 (default):
-// two 32-byte records - the trace kernels stream rays and nothing else, shade reads one more line per vertex. Measured on one box (scripts/ab_bench.sh):
-// 0, one 64-byte record: S1 -2.9 %, S2 -3.3 %, S3 -4.3 %, S4 -0.5 % (closest hit +3 .. +9 %: twice the lines per wave of rays; S4's binned shade
-// did not get faster); 2, hit and throughput in 16-byte arrays of their own: within 0.4 % of 1 everywhere.
-#ifndef RT_PATHREC_SPLIT
-#define RT_PATHREC_SPLIT 1
-#endif
-#if RT_PATHREC_SPLIT == 2
-struct RayRec { float4 o, d; };
-struct VertRec { float4 hit; };
-struct BetaRec { float4 beta; };
-#elif RT_PATHREC_SPLIT
-struct RayRec { float4 o, d; };
-struct VertRec { float4 hit, beta; };
-typedef VertRec BetaRec;
-#else
-struct RayRec { float4 o, d, hit, beta; };
-typedef RayRec VertRec;  // the same array
-typedef RayRec BetaRec;
-#endif
-struct PathAcc { float4 lacc; unsigned long long rng; float2 pfilm; };  // 32 B: radiance (rgb, packed state), RNG state, film position
+// Round 4: the records of a path TRAVEL WITH ITS QUEUE ENTRY. A bounce's producer (k_raygen, or k_shade of the previous bounce) writes the ray, the throughput and
+// the packed state of every path it appends at the path's SLOT in the sharded queue (slot = shard * shard_cap + position in the shard), into planar 16-byte
+// arrays; the bounce's consumers - the closest-hit kernel, k_shade - walk the queue's entries in order and read slot after slot: every load of a wave is one
+// contiguous 1 KB stream issued without a dependent id fetch, paths that ended leave no holes, and the order rays are appended in (e.g. by direction octant)
+// costs the next shade launch nothing. Two generations (PathGen) alternate between bounces. What is addressed by PATH ID is only what outlives the bounce:
+// the radiance sum `lacc` (added to by the any-hit epilogue, k_resolve and - for emitters seen directly - k_shade) and the film position `pfilm`.
+// Before: RayRec / VertRec / PathAcc arrays indexed by path id and queues of ids, so a consumer's loads were a gather through the id (two dependent round
+// trips, lines shared with dead paths; S1 k_shade<1> moved 1.7x its algorithmic bytes at 0.68 wait cycles per wave cycle - VERDICT r03 weak #3).
+struct PathGen { float4* o; float4* d; float4* beta; uint4* st; };  // [slot]: ray (o | t_max), (d | -), throughput (rgb | eta_scale), (packed state, path id, RNG state lo, hi)
 struct ShadowRec { float4 o, d, add, pad; };  // 64 B: shadow ray (d.w = 1: no MIS ray pending, `add` is applied by the any-hit kernel) and beta * Ld / pick_pdf
 // 128 B, one line: everything k_resolve needs of a vertex with a BSDF-sampled MIS ray. hit.y = prim of the closest hit, or - for rays that only
 // need occlusion (sampled light infinite) - 1 / 0 from the any-hit kernel
@@ -54,7 +39,10 @@ struct PassState {
   // sampler tables of the chunk
   const unsigned* scrambles;        // [pixel][3*dims]
   const unsigned short* perms;      // [pixel][2*dims][spp]
-  RayRec* ray; VertRec* vert; BetaRec* bet; PathAcc* acc;  // indexed by path id
+  PathGen in, out;         // records of the paths of this bounce (read) and of the next (written), by queue slot
+  float4* hit;             // [slot] closest hit of the bounce's ray: (b2, prim, b0, b1)
+  float4* lacc;            // [path id] (L rgb | flags: RT_STATE_OUT_OF_BOUNDS)
+  float2* pfilm;           // [path id] film position of the camera sample
   // The records of a vertex's shadow ray and BSDF-sampled MIS ray are indexed by the vertex's POSITION IN THE SHADE LAUNCH'S QUEUE (entry i of the - possibly
   // material-sorted - queue; distinct for every vertex of a bounce), not by its path id: the 64 lanes of a shade wave then write 64 neighbouring records, the
   // ray queues (which hold these indices) list them in nearly ascending order for the trace kernels and k_resolve, and occ_sh / occ_mi below are indexed the
@@ -64,13 +52,15 @@ struct PassState {
   // one byte per path each: the shadow ray of a vertex that also has an MIS ray in flight was blocked / its occlusion-only MIS ray was blocked. Dense, so
   // that k_resolve learns from two bytes that a vertex contributes nothing (most vertices of an interior) without touching its 128-byte MisRec
   unsigned char* occ_sh; unsigned char* occ_mi;
-  // queues of path ids, each split into RT_QSHARDS shards (shard = blockIdx & 7 of the producer, region
+  // q_in: NULL = the bounce's entries are the slots of the sharded queue themselves (cnt_in: shard counts; also NULL: bounce 0 of a pass whose samples are all
+  // traced - entry i is slot i is path i), or the material-sorted list of slots (k_bin_scatter) as a one-shard queue. q_out is gone: the out records ARE the queue.
+  // Ray queues (shadow, mis, mis-any) hold record indices = positions in the shade launch's queue, each split into RT_QSHARDS shards (shard = blockIdx & 7 of the producer, region
   // [shard * shard_cap, ...)) with its own counter word: a single word sustains only ~88 returning
   // atomics per microsecond. Every bounce has its own zero-initialised block of counters, so nothing has to be
   // reset or rotated between bounces: cnt_in = the 8 shard counts of q_in (written by raygen / the previous
   // bounce), cnt_out[q * RT_QSHARDS + shard] with q: 0 = continuing paths (q_out), 1 = shadow, 2 = mis (closest hit),
   // 3 = mis rays that only need occlusion.
-  unsigned* q_in; unsigned* q_out; unsigned* q_shadow; unsigned* q_mis; unsigned* q_misany;
+  const unsigned* q_in; unsigned* q_shadow; unsigned* q_mis; unsigned* q_misany;
   const unsigned* cnt_in; unsigned* cnt_out; unsigned shard_cap;
   int all_in_bounds;  // every sample of the pass is traced (no crop by pixel_bounds): bounce 0 needs no queue, path i is entry i
   int mis_any;        // BSDF-sampled MIS rays toward an infinite light go to q_misany (off on frames that count node visits: reference walk)
@@ -119,7 +109,7 @@ struct FrameParams {
   unsigned w_recip;                // floor(2^32 / W), W = sample-bounds width (0 when W == 1): division by W without a divide
 };
 
-// packed per-path state in lacc.w: bits 0-7 bounces, bit 8 specular_bounce, bits 9-12 cur_1d, bits 13-16 cur_2d, bit 17: sample outside
+// packed per-path state (PathGen::st.x): bits 0-7 bounces, bit 8 specular_bounce, bits 9-12 cur_1d, bits 13-16 cur_2d. lacc.w, bit 17: sample outside
 // pixel_bounds (never traced, skipped by the film)
 #define RT_STATE_OUT_OF_BOUNDS (1u << 17)
 RT_DEV unsigned pack_state(int bounces, bool spec, int c1, int c2) { return (unsigned)bounces | ((unsigned)spec << 8) | ((unsigned)c1 << 9) | ((unsigned)c2 << 13); }
@@ -143,7 +133,8 @@ RT_DEV unsigned wave_push(unsigned* counter, bool pred) {
 #ifndef RT_CNT_STRIDE
 #define RT_CNT_STRIDE 64
 #endif
-// Consumer view of a sharded queue: entry i of the concatenation of the shards' filled prefixes.
+// Consumer view of a sharded queue: entry i of the concatenation of the shards' filled prefixes. ids == NULL: the entries are the queue's SLOTS
+// themselves (the travelling path records live at their slot, PassState::in) - get(i) is then arithmetic on the eight counts, no load.
 struct QView {
   const unsigned* ids; unsigned pre[RT_QSHARDS + 1]; unsigned shard_cap;
   RT_DEV void init(const unsigned* ids_, const unsigned* counts, unsigned cap) {
@@ -156,7 +147,8 @@ struct QView {
     unsigned k = 0, base = 0;  // pre[k] selected on the way: indexed afterwards, the prefix array would live in scratch
 #pragma unroll
     for (int j = 1; j < RT_QSHARDS; ++j) { const bool ge = i >= pre[j]; k += ge ? 1u : 0u; base = ge ? pre[j] : base; }
-    return ids[k * shard_cap + (i - base)];
+    const unsigned slot = k * shard_cap + (i - base);
+    return ids ? ids[slot] : slot;
   }
 };
 // Block-aggregated append to up to three sharded device queues: one returning atomic per queue per
@@ -185,51 +177,6 @@ RT_DEV void block_push(unsigned* counters, unsigned shard_cap, const int* queue_
   for (int q = 0; q < NQ; ++q) slot[q] = s_base[q] + s_cnt[q][wave] + (unsigned)__popcll(mask[q] & ((1ull << lane) - 1ull));
   __syncthreads();
 }
-
-// Wave-private staging of queue appends (the shade kernels). block_push costs three workgroup barriers and a returning atomic per iteration, with every
-// wave of the workgroup waiting for the slowest one and then for the atomic. Here a wave collects the ids it appends in its own LDS window (no barrier: the
-// window is the wave's), and whenever a queue's window holds 64 of them it reserves 64 slots with one atomic and writes them out as one coalesced store.
-// The order of ids inside a queue changes (it is arbitrary anyway: paths are independent), the ids and their number do not.
-// Measured (one box, interleaved A/B, S1 / S3 / S4 shade ms): block_push 381 / 192 / 4109, wave windows 431 / 196 / 4178 - the LDS round trip of every id and the
-// compaction cost more than the barriers they remove; with 64- or 128-lane workgroups on top 411 / 416 (S1). Kept as a build option (-DRT_WAVE_QUEUES=1), off.
-#ifndef RT_WAVE_QUEUES
-#define RT_WAVE_QUEUES 0
-#endif
-template <int NQ>
-struct WaveQueues {
-  unsigned* win;        // this wave's NQ windows of 128 ids in LDS
-  unsigned fill[NQ];    // ids waiting in each window (wave-uniform)
-  unsigned* counters; unsigned shard_cap, shard;
-  RT_DEV void init(unsigned* lds, unsigned* counters_, unsigned shard_cap_) {
-    win = lds + (threadIdx.x >> 6) * (NQ * 128u);
-#pragma unroll
-    for (int q = 0; q < NQ; ++q) fill[q] = 0u;
-    counters = counters_; shard_cap = shard_cap_; shard = blockIdx.x & (RT_QSHARDS - 1);
-  }
-  RT_DEV void flush(int q, int qidx, unsigned* __restrict__ ids, unsigned n) {  // the first n (<= 64) ids of window q
-    const unsigned lane = __lane_id();
-    unsigned base = 0;
-    if (lane == 0u) base = atomicAdd(&counters[(qidx * RT_QSHARDS + shard) * RT_CNT_STRIDE], n);
-    base = __shfl(base, 0);
-    if (lane < n) ids[(size_t)shard * shard_cap + base + lane] = win[q * 128 + lane];
-  }
-  // must be reached by every lane of the wave
-  RT_DEV void push(int q, int qidx, unsigned* __restrict__ ids, bool pred, unsigned id) {
-    const unsigned long long mask = __ballot(pred);
-    if (mask == 0ull) return;
-    const unsigned lane = __lane_id();
-    if (pred) win[q * 128 + fill[q] + (unsigned)__popcll(mask & ((1ull << lane) - 1ull))] = id;
-    fill[q] += (unsigned)__popcll(mask);
-    if (fill[q] >= 64u) {
-      flush(q, qidx, ids, 64u);
-      const unsigned rest = fill[q] - 64u;  // < 64: move them to the front of the window
-      const unsigned v = lane < rest ? win[q * 128 + 64 + lane] : 0u;
-      if (lane < rest) win[q * 128 + lane] = v;
-      fill[q] = rest;
-    }
-  }
-  RT_DEV void finish(int q, int qidx, unsigned* __restrict__ ids) { if (fill[q]) { flush(q, qidx, ids, fill[q]); fill[q] = 0u; } }
-};
 
 // owned-pixel index -> raster pixel (x, y) and keyed pixel index inside the sample bounds
 RT_DEV void owned_pixel(const FrameParams& fp, unsigned long long k, int& x, int& y, unsigned long long& pixel_index) {
@@ -552,6 +499,7 @@ __global__ void __launch_bounds__(256) k_raygen(FrameParams fp, PassState ps) {
   for (unsigned base = blockIdx.x * blockDim.x; base < ps.cap; base += stride) {
     const unsigned pid = base + threadIdx.x;
     bool in_bounds = false;
+    CameraRay cr; unsigned long long rng_state = 0ull;
     if (pid < ps.cap) {
       unsigned sl, pix; split_path_id(ps, pid, sl, pix); const unsigned s = ps.s0 + sl;
       int x, y; unsigned long long pixel_index;
@@ -561,22 +509,24 @@ __global__ void __launch_bounds__(256) k_raygen(FrameParams fp, PassState ps) {
       f2 o = table_2d(tb, pix, 0, s);
       f2 p_film = mk2((float)x + o.x, (float)y + o.y);
       f2 p_lens = table_2d(tb, pix, 1, s);
-      CameraRay cr = generate_camera_ray(fp, p_film, p_lens, 1.0f / sqrtf((float)ps.spp));
-      RayRec* pr = ps.ray + pid;
-      pr->o = make_float4(cr.o.x, cr.o.y, cr.o.z, kInf);
-      pr->d = make_float4(cr.d.x, cr.d.y, cr.d.z, 0.0f);
-      ps.bet[pid].beta = make_float4(1.0f, 1.0f, 1.0f, 1.0f);
+      cr = generate_camera_ray(fp, p_film, p_lens, 1.0f / sqrtf((float)ps.spp));
       Pcg32 rng; rng.set_sequence(pixel_index * (unsigned long long)ps.spp + s + (1ull << 32));  // keyed per-sample stream
-      PathAcc* pa = ps.acc + pid;
-      pa->lacc = make_float4(0.0f, 0.0f, 0.0f, __uint_as_float(pack_state(0, false, 1, 2) | (in_bounds ? 0u : RT_STATE_OUT_OF_BOUNDS)));
-      pa->rng = rng.state;
-      pa->pfilm = make_float2(p_film.x, p_film.y);
+      rng_state = rng.state;
+      ps.lacc[pid] = make_float4(0.0f, 0.0f, 0.0f, __uint_as_float(in_bounds ? 0u : RT_STATE_OUT_OF_BOUNDS));
+      ps.pfilm[pid] = make_float2(p_film.x, p_film.y);
     }
     n_camera += in_bounds ? 1u : 0u;
+    unsigned slot = pid;  // every sample traced: path i is entry i is slot i
     if (!ps.all_in_bounds) {
-      const int ci[1] = {0}; const bool pr[1] = {in_bounds}; unsigned slot[1];
-      block_push<1>(ps.cnt_out, ps.shard_cap, ci, pr, slot);
-      if (in_bounds) ps.q_in[slot[0]] = pid;
+      const int ci[1] = {0}; const bool pr[1] = {in_bounds}; unsigned sl_[1];
+      block_push<1>(ps.cnt_out, ps.shard_cap, ci, pr, sl_);
+      slot = sl_[0];
+    }
+    if (in_bounds) {  // the path's travelling records, at its slot of bounce 0's queue
+      ps.out.o[slot] = make_float4(cr.o.x, cr.o.y, cr.o.z, kInf);
+      ps.out.d[slot] = make_float4(cr.d.x, cr.d.y, cr.d.z, 0.0f);
+      ps.out.beta[slot] = make_float4(1.0f, 1.0f, 1.0f, 1.0f);
+      ps.out.st[slot] = make_uint4(pack_state(0, false, 1, 2), pid, (unsigned)rng_state, (unsigned)(rng_state >> 32));
     }
   }
   // camera samples actually generated: calls of PathIntegrator::li (samples outside pixel_bounds are skipped, renderer.rs:103)
@@ -617,6 +567,9 @@ struct TraceIO {
   // (alpha only, mesh.rs:353-370): a BSDF-sampled MIS ray toward an infinite light is traced by scene.intersect (integrator/mod.rs:291-309) although only
   // its occlusion is read
   int shadow_masks;
+  // the launch's rays are the entries of a sharded queue whose records sit at their slots (the path rays of a bounce, PassState::in): entry i -> slot by the
+  // shard counts alone, `queue` is then only a non-NULL marker
+  int queue_is_slots;
 };
 RT_DEV void trace_write_any(float4* __restrict__ lacc, size_t ls, const float4* __restrict__ direct_add, size_t as, unsigned* __restrict__ occluded, size_t os,
                             unsigned pid, float dw, bool found) {
@@ -644,7 +597,7 @@ __global__ void __launch_bounds__(BLOCK, RT_GEN_MIN_WAVES(GENERAL)) k_trace(DSce
   __shared__ StackT stack[DEPTH * BLOCK];
   __shared__ float4 s_nodes[SMALL ? 2 * RT_SMALL_NODES : 1];
   __shared__ float4 s_tris[SMALL ? 3 * RT_SMALL_TRIS : 1];
-  QView qv; if (queue) qv.init(queue, shard_counts, shard_cap);
+  QView qv; if (queue) qv.init(io.queue_is_slots ? nullptr : queue, shard_counts, shard_cap);
   const unsigned count = queue ? qv.total() : count_static;
   if (blockIdx.x * BLOCK >= count) return;  // short queues (MIS rays, late bounces): most blocks of the persistent grid have nothing to stage for
   if (SMALL) {
@@ -761,7 +714,7 @@ __global__ void __launch_bounds__(BLOCK) k_trace_big(DScene sc, TraceIO io, cons
   float4* __restrict__ lacc = io.lacc; const size_t ls = io.lacc_stride; const float4* __restrict__ direct_add = io.direct_add; const size_t as = io.add_stride;
   __shared__ int stack_mem[DEPTH * BLOCK];
   int* const stack = stack_mem + threadIdx.x;
-  QView qv; if (queue) qv.init(queue, shard_counts, shard_cap);
+  QView qv; if (queue) qv.init(io.queue_is_slots ? nullptr : queue, shard_counts, shard_cap);
   const unsigned count = queue ? qv.total() : count_static;
   const unsigned lane = __lane_id();
   const unsigned n_waves = gridDim.x * (BLOCK / 64), wave = blockIdx.x * (BLOCK / 64) + (threadIdx.x >> 6);
@@ -1052,7 +1005,7 @@ __global__ void __launch_bounds__(BLOCK, (GENERAL == RT_GEN_NO_MASKS && !ANY) ? 
   // store and a pop's load is the only extra latency
   const size_t grid_lanes = (size_t)gridDim.x * BLOCK;
   float* const tstack = tmin_stack_mem + (size_t)blockIdx.x * BLOCK + threadIdx.x;
-  QView qv; if (queue) qv.init(queue, shard_counts, shard_cap);
+  QView qv; if (queue) qv.init(io.queue_is_slots ? nullptr : queue, shard_counts, shard_cap);
   const unsigned count = queue ? qv.total() : count_static;
   const unsigned lane = __lane_id();
   const unsigned n_waves = gridDim.x * (BLOCK / 64), wave = blockIdx.x * (BLOCK / 64) + (threadIdx.x >> 6);
@@ -1171,7 +1124,7 @@ __global__ void __launch_bounds__(BLOCK, GENERAL ? 4 : 6) k_trace_top(DScene sc,
   __shared__ unsigned stack_mem[RT_TOP_LDS_DEPTH * BLOCK];
   __shared__ float4 s_top[4 * RT_TOP_MAX];
   const float4* __restrict__ ray_o = io.ray_o; const float4* __restrict__ ray_d = io.ray_d; const size_t rs = io.ray_stride;
-  QView qv; if (queue) qv.init(queue, shard_counts, shard_cap);
+  QView qv; if (queue) qv.init(io.queue_is_slots ? nullptr : queue, shard_counts, shard_cap);
   const unsigned count = queue ? qv.total() : count_static;
   if ((unsigned long long)blockIdx.x * BLOCK >= count) return;  // (uniform per workgroup: nothing to stage the top of the tree for)
   for (unsigned i = threadIdx.x; i < 4u * sc.n_top; i += BLOCK) s_top[i] = sc.top_pairs[i];
@@ -1312,7 +1265,7 @@ __global__ void __launch_bounds__(BLOCK, RT_GEN_MIN_WAVES(GENERAL)) k_trace_quad
   unsigned* const stack = stack_mem + threadIdx.x;
   const size_t grid_lanes = (size_t)gridDim.x * BLOCK;
   float* const tstack = tmin_stack_mem + (size_t)blockIdx.x * BLOCK + threadIdx.x;
-  QView qv; if (queue) qv.init(queue, shard_counts, shard_cap);
+  QView qv; if (queue) qv.init(io.queue_is_slots ? nullptr : queue, shard_counts, shard_cap);
   const unsigned count = queue ? qv.total() : count_static;
   const unsigned lane = __lane_id();
   const unsigned n_waves = gridDim.x * (BLOCK / 64), wave = blockIdx.x * (BLOCK / 64) + (threadIdx.x >> 6);
@@ -1379,8 +1332,8 @@ RT_DEV int hit_primitive(const DInstance* __restrict__ instances, unsigned n_ins
   while (hi - lo > 1u) { const unsigned mid = (lo + hi) >> 1; if (instances[mid].id_base <= (unsigned)hit_id) lo = mid; else hi = mid; }
   return (int)(instances[lo].prim_base + ((unsigned)hit_id - instances[lo].id_base));
 }
-RT_DEV unsigned bin_of(const DScene& sc, const DMaterial* __restrict__ materials, const float4* __restrict__ tri_p /* the shade records */, const VertRec* __restrict__ path, unsigned pid, unsigned n_bins) {
-  int prim = __float_as_int(path[pid].hit.y);
+RT_DEV unsigned bin_of(const DScene& sc, const DMaterial* __restrict__ materials, const float4* __restrict__ tri_p /* the shade records */, const float4* __restrict__ hit, unsigned slot, unsigned n_bins) {
+  int prim = __float_as_int(hit[slot].y);
   if (prim < 0) return n_bins - 1u;
   prim = hit_primitive(sc.instances, sc.n_instances, sc.n_top_prims, prim);
   const unsigned m = (unsigned)materials[rec_material(tri_p, prim)].code_class;
@@ -1391,18 +1344,18 @@ __global__ void __launch_bounds__(256) k_bin_count(DScene sc, PassState ps, unsi
   __shared__ unsigned lh[RT_BIN_MAX + 1];
   for (unsigned i = threadIdx.x; i <= RT_BIN_MAX; i += 256u) lh[i] = 0u;
   __syncthreads();
-  QView qv; if (ps.q_in) qv.init(ps.q_in, ps.cnt_in, ps.shard_cap);
-  const unsigned count = ps.q_in ? qv.total() : ps.cap;
+  QView qv; if (ps.cnt_in) qv.init(ps.q_in, ps.cnt_in, ps.shard_cap);
+  const unsigned count = ps.cnt_in ? qv.total() : ps.cap;
   for (unsigned i = blockIdx.x * 256u + threadIdx.x; i < count; i += gridDim.x * 256u) {
-    const unsigned pid = ps.q_in ? qv.get(i) : i;
-    const unsigned b = bin_of(sc, sc.materials, sc.tri_rec, ps.vert, pid, n_bins);
+    const unsigned slot = ps.cnt_in ? qv.get(i) : i;
+    const unsigned b = bin_of(sc, sc.materials, sc.tri_rec, ps.hit, slot, n_bins);
     bin_at[i] = (unsigned short)b;
     atomicAdd(&lh[b], 1u);
   }
   __syncthreads();
   for (unsigned i = threadIdx.x; i < n_bins; i += 256u) if (lh[i]) atomicAdd(&hist[i], lh[i]);
 }
-// sorted: path ids grouped by bin; sorted_cnt[RT_QSHARDS]: {total, 0, ...} so that the result reads as a one-shard queue
+// sorted: the slots of the bounce's paths grouped by bin; sorted_cnt[RT_QSHARDS]: {total, 0, ...} so that the result reads as a one-shard queue
 __global__ void __launch_bounds__(256) k_bin_scatter(DScene sc, PassState ps, unsigned n_bins, const unsigned* __restrict__ hist, unsigned* __restrict__ cursor,
                                                      unsigned* __restrict__ sorted, unsigned* __restrict__ sorted_cnt, unsigned split_bin, unsigned split_bin2,
                                                      unsigned split_bin3, unsigned* __restrict__ ranges, const unsigned short* __restrict__ bin_at) {
@@ -1423,8 +1376,8 @@ __global__ void __launch_bounds__(256) k_bin_scatter(DScene sc, PassState ps, un
   }
   for (unsigned i = threadIdx.x; i <= RT_BIN_MAX; i += 256u) lcount[i] = 0u;
   __syncthreads();
-  QView qv; if (ps.q_in) qv.init(ps.q_in, ps.cnt_in, ps.shard_cap);
-  const unsigned count = ps.q_in ? qv.total() : ps.cap;
+  QView qv; if (ps.cnt_in) qv.init(ps.q_in, ps.cnt_in, ps.shard_cap);
+  const unsigned count = ps.cnt_in ? qv.total() : ps.cap;
   constexpr unsigned E = 8;  // entries per lane per round: the barriers and the global atomics are per 2048 entries
   for (unsigned start = blockIdx.x * (256u * E); start < count; start += gridDim.x * (256u * E)) {
     unsigned pid[E], bin[E], rank[E]; bool live[E];
@@ -1432,7 +1385,7 @@ __global__ void __launch_bounds__(256) k_bin_scatter(DScene sc, PassState ps, un
     for (unsigned k = 0; k < E; ++k) {  // rounds of 256 consecutive entries: a bin keeps the queue's order up to that granularity
       const unsigned i = start + k * 256u + threadIdx.x;
       live[k] = i < count; pid[k] = 0; bin[k] = 0; rank[k] = 0;
-      if (live[k]) { pid[k] = ps.q_in ? qv.get(i) : i; bin[k] = bin_at[i]; }
+      if (live[k]) { pid[k] = ps.cnt_in ? qv.get(i) : i; bin[k] = bin_at[i]; }
     }
 #pragma unroll
     for (unsigned k = 0; k < E; ++k) if (live[k]) rank[k] = atomicAdd(&lcount[bin[k]], 1u);
@@ -1727,11 +1680,6 @@ RT_DEVN int instance_fill_interaction(const DScene& sc, unsigned hit_id, float o
 #ifndef RT_SHADE0_MIN_WAVES
 #define RT_SHADE0_MIN_WAVES 2
 #endif
-// k_shade<1>: the next vertex's records requested one iteration ahead (needs -DRT_SHADE_MIN_WAVES=3: 167 VGPRs, two spilled values). Measured, interleaved A/B
-// on S1: shade 380 -> 398 ms. The waves are not short of loads in flight; the extra registers and the longer loop head cost more. Off.
-#ifndef RT_SHADE_PREFETCH
-#define RT_SHADE_PREFETCH 0
-#endif
 #ifndef RT_SHADE3_MIN_WAVES  // the Lambert front-end under any light (k_shade<3>)
 #define RT_SHADE3_MIN_WAVES 2
 #endif
@@ -1744,61 +1692,37 @@ RT_DEVN int instance_fill_interaction(const DScene& sc, unsigned hit_id, float o
 // (inline) and the light evaluators are taken inline too: 183 VGPRs of its own, 168 under the three-wave bound with 5 spilled dwords.
 template <int MODE, bool GENERAL = false, bool LEAN = false, bool BOUNCED = false>
 __global__ void __launch_bounds__(256, (MODE == 1 || LEAN || BOUNCED) ? ((LEAN || BOUNCED) ? 3 : RT_SHADE_MIN_WAVES) : (MODE == 3 && !GENERAL ? RT_SHADE3_MIN_WAVES : RT_SHADE0_MIN_WAVES)) k_shade(DScene sc, FrameParams fp, PassState ps) {
-  QView qv; if (ps.q_in) qv.init(ps.q_in, ps.cnt_in, ps.shard_cap);
-  unsigned first = 0, count = ps.q_in ? qv.total() : ps.cap;  // no queue: bounce 0 of a pass whose samples are all traced
+  QView qv; if (ps.cnt_in) qv.init(ps.q_in, ps.cnt_in, ps.shard_cap);
+  unsigned first = 0, count = ps.cnt_in ? qv.total() : ps.cap;  // no counts: bounce 0 of a pass whose samples are all traced (entry i = slot i = path i)
   if (MODE != 1 && ps.range) { first = ps.range[0]; count = ps.range[1]; }
   const unsigned stride = gridDim.x * blockDim.x;
   unsigned n_shaded = 0, n_unreached = 0;
   const DScene& gsc = *sc.self;  // what out-of-line functions get: the scene record in device memory, not a private copy of the kernel argument
-#if RT_WAVE_QUEUES
-  __shared__ unsigned s_win[4 * (MODE == 1 ? 3 : 4) * 128];  // (256 lanes = 4 waves)
-  WaveQueues<(MODE == 1 ? 3 : 4)> wq; wq.init(s_win, ps.cnt_out, ps.shard_cap);
-#endif
 #ifdef RT_ABLATE
   unsigned long long stamp_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, stamp_last = clock64();
 #endif
-  // Software pipelining of the vertex records (MODE 1, where 17 more registers still fit three waves per SIMD): the path id of the vertex two iterations
-  // ahead and the records of the next one are requested at the top of an iteration, so the two dependent round trips queue -> id -> records overlap the
-  // shading of the current vertex instead of opening the next iteration. Paths are distinct, so nothing the current vertex stores is among them.
-  constexpr bool PREFETCH = MODE == 1 && RT_SHADE_PREFETCH != 0;
-  unsigned pf_pid = 0, pf_pid2 = 0; float4 pf_d4 = make_float4(0, 0, 0, 0), pf_h4 = pf_d4, pf_b4 = pf_d4, pf_l4 = pf_d4; 
-  if (PREFETCH) {
-    const unsigned i0 = first + blockIdx.x * blockDim.x + threadIdx.x, i1 = i0 + stride;
-    if (i0 < count) {
-      pf_pid = ps.q_in ? qv.get(i0) : i0;
-      pf_d4 = ps.ray[pf_pid].d; pf_h4 = ps.vert[pf_pid].hit; pf_b4 = ps.bet[pf_pid].beta; pf_l4 = ps.acc[pf_pid].lacc;
-    }
-    if (i1 < count) pf_pid2 = ps.q_in ? qv.get(i1) : i1;
-  }
   for (unsigned base = first + blockIdx.x * blockDim.x; base < count; base += stride) {
     const unsigned i = base + threadIdx.x;
     const bool lane_live = i < count;
     n_shaded += lane_live ? 1u : 0u;
     RT_STAMP(7);  // loop overhead / previous iteration's tail
     bool cont = false, want_shadow = false, want_mis = false, mis_occlusion_only = false;
-    unsigned pid = 0;
-    float4 c_d4 = pf_d4, c_h4 = pf_h4, c_b4 = pf_b4, c_l4 = pf_l4; const unsigned c_pid = pf_pid;
-    if (PREFETCH) {  // next vertex's records (its id arrived an iteration ago), and the id of the one after
-      const unsigned i1 = i + stride, i2 = i1 + stride;
-      pf_pid = pf_pid2;
-      if (i1 < count) { pf_d4 = ps.ray[pf_pid].d; pf_h4 = ps.vert[pf_pid].hit; pf_b4 = ps.bet[pf_pid].beta; pf_l4 = ps.acc[pf_pid].lacc; }
-      if (i2 < count) pf_pid2 = ps.q_in ? qv.get(i2) : i2;
-    }
+    // what a continuing path takes to its slot in the next bounce's queue (stored after the append below has named the slot)
+    f3 nr_o = mk3(0, 0, 0), nr_d = mk3(0, 0, 0); rgb3 beta = mkc(0, 0, 0); float eta_scale = 1.0f; unsigned st_out = 0u, pid = 0u; unsigned long long rng_out = 0ull;
     if (lane_live) {
-      pid = PREFETCH ? c_pid : (ps.q_in ? qv.get(i) : i);
+      // the vertex's records: four 16-byte loads at consecutive slots of consecutive lanes, requested together (slot = entry i of the sharded queue by the shard
+      // counts alone; on a material-sorted queue the sorted list names the slot)
+      const unsigned rslot = ps.cnt_in ? qv.get(i) : i;
+      const float4 d4 = ps.in.d[rslot], h4 = ps.hit[rslot], b4 = ps.in.beta[rslot]; const uint4 s4 = ps.in.st[rslot];
+      pid = s4.y;
       unsigned sl, pix; split_path_id(ps, pid, sl, pix); const unsigned s = ps.s0 + sl;
-      RayRec* const prec = ps.ray + pid; VertRec* const pvert = ps.vert + pid; PathAcc* const pacc = ps.acc + pid;
-      float4 d4, h4, b4, l4;
-      if (PREFETCH) { d4 = c_d4; h4 = c_h4; b4 = c_b4; l4 = c_l4; }
-      else { d4 = prec->d; h4 = pvert->hit; b4 = ps.bet[pid].beta; l4 = pacc->lacc; }
       f3 ray_d = mk3(d4.x, d4.y, d4.z);
-      rgb3 beta = mkc(b4.x, b4.y, b4.z), L = mkc(l4.x, l4.y, l4.z);
-      float eta_scale = b4.w;
-      unsigned st = __float_as_uint(l4.w);
+      beta = mkc(b4.x, b4.y, b4.z); eta_scale = b4.w;
+      const unsigned st = s4.x;
       int bounces = (int)(st & 0xffu); bool specular_bounce = (st >> 8) & 1u;
       PathSampler smp; smp.tb = tables_of(ps); smp.pix = pix; smp.s = s; smp.c1 = (int)((st >> 9) & 15u); smp.c2 = (int)((st >> 13) & 15u);
       int x, y; unsigned long long pixel_index; owned_pixel(fp, fp.chunk_first + pix, x, y, pixel_index);
-      smp.rng.state = pacc->rng;  // (not prefetched: its two registers would cost the kernel its third wave; it is read late)
+      smp.rng.state = (unsigned long long)s4.z | ((unsigned long long)s4.w << 32);
       smp.rng.inc = ((pixel_index * (unsigned long long)ps.spp + s + (1ull << 32)) << 1u) | 1ull;
       int prim = __float_as_int(h4.y);
       const bool found = prim >= 0;
@@ -1806,11 +1730,11 @@ __global__ void __launch_bounds__(256, (MODE == 1 || LEAN || BOUNCED) ? ((LEAN |
       SurfaceInteraction si; TriHit th; th.t = 0.0f; th.b0 = h4.z; th.b1 = h4.w; th.b2 = h4.x;
       if (found) {
         if (GENERAL && sc.n_instances != 0u && (unsigned)prim >= sc.n_top_prims) {  // a hit inside an object instance: from here on `prim` is the object's primitive
-          const float4 o4 = prec->o;
+          const float4 o4 = ps.in.o[rslot];
           prim = instance_fill_interaction(gsc, (unsigned)prim, o4.x, o4.y, o4.z, ray_d.x, ray_d.y, ray_d.z, th.b0, th.b1, th.b2, si);
         }
         else if (GENERAL && (tri_flags(sc.tri_p, prim) & RT_FLAG_SPHERE)) {  // Sphere::intersect builds its interaction from the ray: origin and direction of the path's ray
-          const float4 o4 = prec->o;
+          const float4 o4 = ps.in.o[rslot];
           (void)sphere_fill_interaction(sc.spheres[prim_sphere_index(sc.tri_p, prim)], mk3(o4.x, o4.y, o4.z), ray_d, si);
           si.ssb = normalize(si.sh_dpdu);
           si.prim = prim;
@@ -1823,14 +1747,19 @@ __global__ void __launch_bounds__(256, (MODE == 1 || LEAN || BOUNCED) ? ((LEAN |
       if (bounces == 0 || specular_bounce) {
         if (found) {
           int li = rec_light(sc.tri_rec, prim);
-          if (li >= 0) L = L + beta * area_light_l(sc.lights[li], si.hit.n, -ray_d);
-        } else if ((MODE != 1 && !LEAN)) {
+          // The path's radiance so far is not this kernel's business (round 4): it only adds what the vertex emits towards the path, where there is something to
+          // add (rare), as a read-modify-write of lacc[pid] right here. The reference's order of a path's terms is kept: this one reaches lacc before the bounce's
+          // direct-light terms (any-hit epilogue, k_resolve), after the previous bounce's.
+          if (li >= 0) { const float4 l4 = ps.lacc[pid]; const rgb3 L = mkc(l4.x, l4.y, l4.z) + beta * area_light_l(sc.lights[li], si.hit.n, -ray_d); ps.lacc[pid] = make_float4(L.r, L.g, L.b, l4.w); }
+        } else if ((MODE != 1 && !LEAN) && sc.n_infinite > 0) {
+          const float4 l4 = ps.lacc[pid]; rgb3 L = mkc(l4.x, l4.y, l4.z);
           for (int k = 0; k < sc.n_infinite; ++k) L = L + beta * infinite_le<BOUNCED>(sc, sc.lights[k == 0 ? sc.infinite_ids[0] : (k == 1 ? sc.infinite_ids[1] : (k == 2 ? sc.infinite_ids[2] : sc.infinite_ids[3]))], ray_d);  // constant indices: the kernel argument stays in SGPRs
+          ps.lacc[pid] = make_float4(L.r, L.g, L.b, l4.w);
         }
       }
       if (found && bounces < fp.max_depth) {  // path.rs:139
         if ((MODE != 1 && !LEAN && !BOUNCED) && bounces == 0 && sc.needs_differentials && !RT_DBG(sc, 16)) {  // only the camera ray carries differentials (interaction.rs:245-314)
-          f2 pf; { float2 t = pacc->pfilm; pf = mk2(t.x, t.y); }
+          f2 pf; { float2 t = ps.pfilm[pid]; pf = mk2(t.x, t.y); }
           f2 pl = table_2d(smp.tb, pix, 1, s);
           CameraRay cr = generate_camera_ray(fp, pf, pl, 1.0f / sqrtf((float)ps.spp));
           if (MODE == 0) compute_differential_call(si, cr.rx_o, cr.ry_o, cr.rx_d, cr.ry_d); else compute_differential(si, cr.rx_o, cr.ry_o, cr.rx_d, cr.ry_d);
@@ -1932,6 +1861,7 @@ __global__ void __launch_bounds__(256, (MODE == 1 || LEAN || BOUNCED) ? ((LEAN |
             eta_scale *= dot(wo, si.hit.n) > 0.0f ? eta * eta : vdiv(1.0f, eta * eta);
           }
           Ray nr = spawn_ray(si.hit, bs.wi);
+          nr_o = nr.o; nr_d = nr.d;
           cont = true;
           rgb3 rr_beta = beta * eta_scale;  // path.rs:201-209
           if (max_component_value(rr_beta) < fp.rr_threshold && bounces > 3) {
@@ -1939,36 +1869,25 @@ __global__ void __launch_bounds__(256, (MODE == 1 || LEAN || BOUNCED) ? ((LEAN |
             if (smp.get_1d() < q) cont = false;
             else beta = vdiv(beta, 1.0f - q);
           }
-          if (cont) {
-            bounces += 1;
-            prec->o = make_float4(nr.o.x, nr.o.y, nr.o.z, kInf);
-            prec->d = make_float4(nr.d.x, nr.d.y, nr.d.z, 0.0f);
-          }
+          if (cont) bounces += 1;
         }
       }
-      ps.bet[pid].beta = make_float4(beta.r, beta.g, beta.b, eta_scale);
-      pacc->lacc = make_float4(L.r, L.g, L.b, __uint_as_float(pack_state(bounces, specular_bounce, smp.c1, smp.c2)));
-      pacc->rng = smp.rng.state;
+      st_out = pack_state(bounces, specular_bounce, smp.c1, smp.c2); rng_out = smp.rng.state;
     }
     RT_STAMP(6);  // continuation sample, spawn, state stores
     constexpr int NQ = (MODE == 1 || LEAN) ? 3 : 4;  // area lights only: every MIS ray needs its closest hit
-#if RT_WAVE_QUEUES
-    wq.push(0, 0, ps.q_out, cont, pid);
-    wq.push(1, 1, ps.q_shadow, want_shadow, pid);
-    wq.push(2, 2, ps.q_mis, want_mis && !mis_occlusion_only, pid);
-    if (NQ == 4) wq.push(3, 3, ps.q_misany, want_mis && mis_occlusion_only, pid);
-  }
-  wq.finish(0, 0, ps.q_out); wq.finish(1, 1, ps.q_shadow); wq.finish(2, 2, ps.q_mis);
-  if ((MODE != 1 && !LEAN)) wq.finish(3, 3, ps.q_misany);
-#else
     const int ci[4] = {0, 1, 2, 3}; const bool pr[4] = {cont, want_shadow, want_mis && !mis_occlusion_only, want_mis && mis_occlusion_only}; unsigned slot[4];
     block_push<NQ>(ps.cnt_out, ps.shard_cap, ci, pr, slot);
-    if (cont) ps.q_out[slot[0]] = pid;
-    if (want_shadow) ps.q_shadow[slot[1]] = i;  // the ray queues name RECORDS (= this launch's queue positions), the path queue names paths
+    if (cont) {  // the path's records for the next bounce, at its slot of that bounce's queue: a wave's stores are runs of consecutive slots
+      ps.out.o[slot[0]] = make_float4(nr_o.x, nr_o.y, nr_o.z, kInf);
+      ps.out.d[slot[0]] = make_float4(nr_d.x, nr_d.y, nr_d.z, 0.0f);
+      ps.out.beta[slot[0]] = make_float4(beta.r, beta.g, beta.b, eta_scale);
+      ps.out.st[slot[0]] = make_uint4(st_out, pid, (unsigned)rng_out, (unsigned)(rng_out >> 32));
+    }
+    if (want_shadow) ps.q_shadow[slot[1]] = i;  // the ray queues name RECORDS (= this launch's queue positions)
     if (pr[2]) ps.q_mis[slot[2]] = i;
     if (NQ == 4 && pr[3]) ps.q_misany[slot[3]] = i;
   }
-#endif
   if (GENERAL) {
     for (int off = 32; off > 0; off >>= 1) n_unreached += __shfl_down(n_unreached, off);
     if ((threadIdx.x & 63u) == 0u && n_unreached) atomicAdd(&ps.stats[ST_MIS_UNREACHED], (unsigned long long)n_unreached);
@@ -1987,17 +1906,17 @@ __global__ void __launch_bounds__(256) k_shade_miss(DScene sc, PassState ps) {
   const unsigned first = ps.range[0], count = ps.range[1];
   const unsigned stride = gridDim.x * blockDim.x;
   for (unsigned i = first + blockIdx.x * blockDim.x + threadIdx.x; i < count; i += stride) {
-    const unsigned pid = ps.q_in[i];
-    const float4 l4 = ps.acc[pid].lacc;
-    const unsigned st = __float_as_uint(l4.w);
+    const unsigned slot = ps.q_in[i];  // (a binned queue: the sorted list of slots)
+    const uint4 s4 = ps.in.st[slot];
+    const unsigned st = s4.x, pid = s4.y;
     const int bounces = (int)(st & 0xffu); const bool specular_bounce = (st >> 8) & 1u;
     if (!(bounces == 0 || specular_bounce) || sc.n_infinite == 0) continue;
-    const float4 d4 = ps.ray[pid].d, b4 = ps.bet[pid].beta;
+    const float4 d4 = ps.in.d[slot], b4 = ps.in.beta[slot], l4 = ps.lacc[pid];
     const f3 ray_d = mk3(d4.x, d4.y, d4.z);
     const rgb3 beta = mkc(b4.x, b4.y, b4.z);
     rgb3 L = mkc(l4.x, l4.y, l4.z);
     for (int k = 0; k < sc.n_infinite; ++k) L = L + beta * infinite_le(sc, sc.lights[k == 0 ? sc.infinite_ids[0] : (k == 1 ? sc.infinite_ids[1] : (k == 2 ? sc.infinite_ids[2] : sc.infinite_ids[3]))], ray_d);  // constant indices: the kernel argument stays in SGPRs
-    ps.acc[pid].lacc = make_float4(L.r, L.g, L.b, l4.w);
+    ps.lacc[pid] = make_float4(L.r, L.g, L.b, l4.w);
   }
 }
 
@@ -2053,8 +1972,8 @@ __global__ void __launch_bounds__(256) k_resolve(DScene sc, PassState ps) {
     rgb3 add = mkc(c.x, c.y, c.z) * vdiv(ld, a.w);
     if (add.r == 0.0f && add.g == 0.0f && add.b == 0.0f) continue;  // both rays blocked (most vertices of an interior): L + 0 = L, the scattered read-modify-write is skipped (a NaN is not 0)
     const unsigned pid = __float_as_uint(m->d.w);  // the path the vertex belongs to
-    float4 l4 = ps.acc[pid].lacc;
-    ps.acc[pid].lacc = make_float4(l4.x + add.r, l4.y + add.g, l4.z + add.b, l4.w);
+    float4 l4 = ps.lacc[pid];
+    ps.lacc[pid] = make_float4(l4.x + add.r, l4.y + add.g, l4.z + add.b, l4.w);
   }
 }
 
@@ -2078,8 +1997,7 @@ __global__ void __launch_bounds__(256) k_film_accumulate(FrameParams fp, PassSta
     unsigned scrubbed = 0;
     for (unsigned sl = 0; sl < ps.n_samples; ++sl) {
       const unsigned pid = sl * ps.n_pixels + pix;
-      const PathAcc* const pa = ps.acc + pid;
-      float4 l4 = pa->lacc;
+      float4 l4 = ps.lacc[pid];
       if (__float_as_uint(l4.w) & RT_STATE_OUT_OF_BOUNDS) continue;
       rgb3 c = mkc(l4.x, l4.y, l4.z);
       bool bad = false;  // renderer.rs:115-126
@@ -2088,7 +2006,7 @@ __global__ void __launch_bounds__(256) k_film_accumulate(FrameParams fp, PassSta
       if (isinf(lum_y(c))) { c = mkc(0, 0, 0); bad = true; }
       scrubbed += bad;
       rgb3 Lc = lum_y(c) > fp.max_sample_luminance ? c * fp.max_sample_luminance / lum_y(c) : c;
-      float2 pf = pa->pfilm;
+      float2 pf = ps.pfilm[pid];
       float dx = pf.x - 0.5f, dy = pf.y - 0.5f;
       float p0x = ceilf(dx - fp.radius_x), p0y = ceilf(dy - fp.radius_y);
       float p1x = floorf(dx + fp.radius_x + 1.0f), p1y = floorf(dy + fp.radius_y + 1.0f);
