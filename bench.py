@@ -149,6 +149,70 @@ def occupancy_of(kernel_substr):
         return None
 
 
+class ClockSampler:
+    """sclk / mclk / socket power of the GPU read from sysfs every 50 ms while frames are timed (one binary's k_shade<1> took 370 - 421 ms "depending on
+    the box and the hour" with no clock reading beside it). Best effort: a box without the files yields None."""
+
+    def __init__(self, card=None):
+        import glob
+        self.rows, self.stop, self.thread = [], False, None
+        cards = sorted(glob.glob("/sys/class/drm/card*/device/pp_dpm_sclk"))
+        self.dev = os.path.dirname(cards[card or 0]) if cards else None
+        try:  # the card whose PCI address is the current HIP device's (a box may expose more cards in sysfs than it lets the process use)
+            import torch
+            pr = torch.cuda.get_device_properties(torch.cuda.current_device())
+            want = f"{pr.pci_domain_id:04x}:{pr.pci_bus_id:02x}:{pr.pci_device_id:02x}"
+            for c in cards:
+                if want in os.path.realpath(os.path.dirname(c)):
+                    self.dev = os.path.dirname(c)
+            self.pci = want
+        except Exception:
+            self.pci = None
+        pw = glob.glob(os.path.join(self.dev, "hwmon/hwmon*/power1_average")) + glob.glob(os.path.join(self.dev, "hwmon/hwmon*/power1_input")) if self.dev else []
+        self.power = pw[0] if pw else None
+
+    @staticmethod
+    def _active(path):
+        try:
+            for ln in open(path):
+                if "*" in ln:
+                    return int(float(ln.split(":")[1].strip().split("M")[0]))
+        except Exception:
+            pass
+        return None
+
+    def _run(self):
+        while not self.stop:
+            p = None
+            try:
+                p = int(open(self.power).read()) / 1e6 if self.power else None
+            except Exception:
+                pass
+            self.rows.append((self._active(os.path.join(self.dev, "pp_dpm_sclk")), self._active(os.path.join(self.dev, "pp_dpm_mclk")), p))
+            time.sleep(0.05)
+
+    def __enter__(self):
+        if self.dev:
+            import threading
+            self.thread = threading.Thread(target=self._run, daemon=True)
+            self.thread.start()
+        return self
+
+    def __exit__(self, *a):
+        self.stop = True
+        if self.thread:
+            self.thread.join(timeout=1.0)
+
+    def summary(self):
+        import numpy as np
+        out = {}
+        for k, name in enumerate(("sclk_MHz", "mclk_MHz", "power_W")):
+            v = [r[k] for r in self.rows if r[k] is not None]
+            if v:
+                out[name] = {"min": round(float(min(v)), 1), "median": round(float(np.median(v)), 1), "max": round(float(max(v)), 1)}
+        return dict(out, samples=len(self.rows), pci=self.pci) if out else None
+
+
 class Runner:
     """One of the three ways a frame is rendered: 'single' (rt_render on one device), 'dist' (one process per GPU, rows gathered over RCCL),
     'multi' (this process drives several devices through rt_multi_render)."""
@@ -208,9 +272,10 @@ def run_workload(scene_name, runner, workload, steps, warmup):
     runner.barrier()
     t0 = time.perf_counter()
     kstats = []
-    for _ in range(steps):
-        kstats.append(runner.step(True))
-    runner.barrier()
+    with ClockSampler() as clocks:
+        for _ in range(steps):
+            kstats.append(runner.step(True))
+        runner.barrier()
     dt = time.perf_counter() - t0
     cst = runner.count()
     if dist is not None:
@@ -329,7 +394,7 @@ def run_workload(scene_name, runner, workload, steps, warmup):
         "mis_rays_not_cast": int(not_cast),
         "kernel_ms_per_step": kernels_ms, "vertices_by_shade_front_end": verts,
         "roofline": roofline, "roofline_second_kernel": roofline_other, "traversal_by_ray_class": classes, "traversal_hbm_share": groups,
-        "camera_samples_per_step": int(samples_per_step),
+        "camera_samples_per_step": int(samples_per_step), "gpu_clocks_while_timed": clocks.summary(),
     }
     if n_gpus_asked > 1:
         out["n_gpus_requested"] = n_gpus_asked

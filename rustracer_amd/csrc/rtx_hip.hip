@@ -1157,12 +1157,17 @@ extern "C" int rt_render(rt_scene* s, const rt_camera* cam, const rt_film_desc* 
   auto env_log2 = [](const char* name, int dflt) { const char* e = getenv(name); return e ? std::min(30, std::max(16, atoi(e))) : dflt; };
   static const int tp_log2 = env_log2("RTX_PASS_LOG2", 28);
   static const int bp_log2 = env_log2("RTX_BATCH_LOG2", 19);
-  enum { B_GEN0, B_GEN1, B_HIT, B_LACC, B_PFILM, B_SH, B_MI, B_QSH, B_QMI, B_QMA, B_OCCSH, B_OCCMI, B_COUNT };  // two generations of travelling path records + their hits (by queue slot), radiance and film position (by path id), ray records and the three ray queues
+  enum { B_GEN0, B_GEN1, B_GENS, B_HIT, B_HITS, B_LACC, B_PFILM, B_SH, B_MI, B_QSH, B_QMI, B_QMA, B_OCCSH, B_OCCMI, B_COUNT };  // two generations of travelling path records + their hits (by queue slot), radiance and film position (by path id), ray records and the three ray queues
   const bool has_infinite = s->d.n_infinite > 0;
   const size_t counter_words = (size_t)(fp.max_depth + 2) * RT_NQ * RT_QSHARDS * RT_CNT_STRIDE;  // one block of {out, shadow, mis, mis-any} shard counts per bounce + raygen's
   // material binning before the generic shade kernel: per bounce {hist, cursor}[RT_BIN_MAX + 1] + the 8 count words of the sorted queue
   static const bool bin_off = getenv("RTX_SHADE_BINS") && getenv("RTX_SHADE_BINS")[0] == '0';  // measurement knob
   const bool use_bins = !s->lambert_materials && s->n_code_classes > 1 && !bin_off;  // one class: every vertex runs the same code, the queue order is kept
+  // RTX_BIN_MOVE=1 (measurement knob): k_bin_scatter copies the travelling records into sorted order so that the shade launches stream them. Measured (one box,
+  // back to back): S3 shade 121.6 -> 135.5 ms, S4 3158 -> 3235, mis-spheres 224 -> 244 - a bin keeps the queue's order in rounds of 256 entries, so the gather
+  // through the sorted list already reads runs of neighbouring slots, and the copy (128-160 B per vertex) costs more than the rest of the gather. Off.
+  static const bool bin_move_on = getenv("RTX_BIN_MOVE") && getenv("RTX_BIN_MOVE")[0] == '1';
+  const bool bin_move = use_bins && bin_move_on;
   const bool gshade = s->masked_emitters;  // quadric / instance hits, quadric or masked emitters: the GENERAL instantiations of the shade kernels
   static const bool lean_off = getenv("RTX_SHADE_LEAN") && getenv("RTX_SHADE_LEAN")[0] == '0';  // measurement knob
   const bool lean_shade = s->lean_shade && !lean_off;
@@ -1199,13 +1204,13 @@ extern "C" int rt_render(rt_scene* s, const rt_camera* cam, const rt_film_desc* 
     multi_batch = owned_pixels > chunk_pixels;
     struct Want { DevBuf* buf; size_t bytes; };
     std::vector<Want> want = {
-        {&s->ws[B_GEN0], n_slots * 64}, {&s->ws[B_GEN1], n_slots * 64}, {&s->ws[B_HIT], n_slots * 16}, {&s->ws[B_LACC], cap * 16}, {&s->ws[B_PFILM], cap * 8},
+        {&s->ws[B_GEN0], n_slots * 64}, {&s->ws[B_GEN1], n_slots * 64}, {&s->ws[B_HIT], n_slots * 16}, {&s->ws[B_GENS], bin_move ? n_slots * 64 : 16}, {&s->ws[B_HITS], bin_move ? n_slots * 16 : 16}, {&s->ws[B_LACC], cap * 16}, {&s->ws[B_PFILM], cap * 8},
         {&s->ws[B_SH], cap * sizeof(ShadowRec)}, {&s->ws[B_MI], cap * sizeof(MisRec)}, {&s->ws[B_OCCSH], cap}, {&s->ws[B_OCCMI], cap},
         {&s->ws[B_QSH], szq}, {&s->ws[B_QMI], szq}, {&s->ws[B_QMA], has_infinite ? szq : 16},
         {&s->counters, counter_words * 4}, {&s->stats, (size_t)ST_COUNT * 8}, {&s->film_acc, (size_t)cw * ch * 16}, {&s->own_acc, (size_t)chunk_pixels * 16},
         {&s->filter_table, 1024}, {&s->scrambles[0], (size_t)chunk_pixels * 3 * dims * 4}, {&s->perms[0], (size_t)(chunk_pixels * table_bytes_per_pixel)},
         {&s->sampler_plan.partners, (size_t)(chunk_pixels * table_bytes_per_pixel)}};
-    if (use_bins) { want.push_back({&s->bin_words, (size_t)(fp.max_depth + 1) * bin_stride * 4}); want.push_back({&s->bin_sorted, (size_t)cap * 4}); want.push_back({&s->bin_at, (size_t)cap * 2}); }
+    if (use_bins) { want.push_back({&s->bin_words, (size_t)(fp.max_depth + 1) * bin_stride * 4}); want.push_back({&s->bin_sorted, bin_move ? 16 : (size_t)cap * 4}); want.push_back({&s->bin_at, (size_t)cap * 2}); }
     if (multi_batch) { want.push_back({&s->scrambles[1], (size_t)chunk_pixels * 3 * dims * 4}); want.push_back({&s->perms[1], (size_t)(chunk_pixels * table_bytes_per_pixel)}); }
     if (!(flags & RT_FLAG_FILM_ON_DEVICE)) want.push_back({&s->film_out, (size_t)cw * ch * 16});
     size_t grow = 0;  // bytes the buffers have to grow by (a buffer that is too small is freed and allocated anew)
@@ -1234,7 +1239,7 @@ extern "C" int rt_render(rt_scene* s, const rt_camera* cam, const rt_film_desc* 
   PassState ps{};
   ps.spp = spp; ps.spp_log2 = spp_log2; ps.dims = dims;
   auto gen_of = [&](int b) { PathGen g; char* p = (char*)s->ws[b].p; g.o = (float4*)p; g.d = (float4*)(p + n_slots * 16); g.beta = (float4*)(p + n_slots * 32); g.st = (uint4*)(p + n_slots * 48); return g; };
-  const PathGen gen0 = gen_of(B_GEN0), gen1 = gen_of(B_GEN1);
+  const PathGen gen0 = gen_of(B_GEN0), gen1 = gen_of(B_GEN1), gen_sorted = gen_of(B_GENS);
   ps.hit = s->ws[B_HIT].as<float4>(); ps.lacc = s->ws[B_LACC].as<float4>(); ps.pfilm = s->ws[B_PFILM].as<float2>();
   ps.sh = s->ws[B_SH].as<ShadowRec>(); ps.mi = s->ws[B_MI].as<MisRec>();
   ps.occ_sh = s->ws[B_OCCSH].as<unsigned char>(); ps.occ_mi = s->ws[B_OCCMI].as<unsigned char>();
@@ -1327,10 +1332,13 @@ extern "C" int rt_render(rt_scene* s, const rt_camera* cam, const rt_film_desc* 
           unsigned* hist = bw; unsigned* cursor = bw + (RT_BIN_MAX + 1); unsigned* sorted_cnt = cursor + (size_t)(RT_BIN_MAX + 1) * RT_CNT_STRIDE;
           hipLaunchKernelGGL(k_bin_count, dim3(pgrid), dim3(256), 0, stream, s->d, ps, n_bins, hist, s->bin_at.as<unsigned short>());
           unsigned* ranges = sorted_cnt + (size_t)RT_QSHARDS * RT_CNT_STRIDE;
-          hipLaunchKernelGGL(k_bin_scatter, dim3(pgrid), dim3(256), 0, stream, s->d, ps, n_bins, hist, cursor, s->bin_sorted.as<unsigned>(), sorted_cnt,
-                             split_classes ? n_first : 0u, split_classes ? n_first + n_second : 0u, split_classes ? n_first + n_second + n_third : 0u, ranges, s->bin_at.as<unsigned short>());
+#define RT_BIN_ARGS dim3(pgrid), dim3(256), 0, stream, s->d, ps, n_bins, hist, cursor, s->bin_sorted.as<unsigned>(), sorted_cnt, split_classes ? n_first : 0u, split_classes ? n_first + n_second : 0u, \
+                    split_classes ? n_first + n_second + n_third : 0u, ranges, s->bin_at.as<unsigned short>(), gen_sorted, s->ws[B_HITS].as<float4>(), (s->has_spheres || s->has_instances) ? 1 : 0
+          if (bin_move) hipLaunchKernelGGL(k_bin_scatter<true>, RT_BIN_ARGS); else hipLaunchKernelGGL(k_bin_scatter<false>, RT_BIN_ARGS);
+#undef RT_BIN_ARGS
           tm.end();
           PassState pb = ps; pb.q_in = s->bin_sorted.as<unsigned>(); pb.cnt_in = sorted_cnt;  // all entries in shard 0: QView::get(i) = ids[i]
+          if (bin_move) { pb.q_in = nullptr; pb.in = gen_sorted; pb.hit = s->ws[B_HITS].as<float4>(); }  // the records were moved: entry i is slot i
           // classes of the register-resident front-ends, then the generic one, then the rays that left the scene
           if (split_classes && n_first) { pb.range = ranges; tm.begin(&stats.ms_shade_lambert); RT_SHADE(3, pb); tm.end(); }
           if (split_classes && n_second) { pb.range = ranges + 2; tm.begin(&stats.ms_shade_two_lobe); RT_SHADE(5, pb); tm.end(); }

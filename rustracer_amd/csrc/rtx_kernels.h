@@ -1355,10 +1355,16 @@ __global__ void __launch_bounds__(256) k_bin_count(DScene sc, PassState ps, unsi
   __syncthreads();
   for (unsigned i = threadIdx.x; i < n_bins; i += 256u) if (lh[i]) atomicAdd(&hist[i], lh[i]);
 }
-// sorted: the slots of the bounce's paths grouped by bin; sorted_cnt[RT_QSHARDS]: {total, 0, ...} so that the result reads as a one-shard queue
+// The bounce's paths grouped by bin; sorted_cnt[RT_QSHARDS]: {total, 0, ...} so that the result reads as a one-shard queue. MOVE: the travelling records themselves
+// (ray direction - and origin where the scene has quadrics or instances, whose interactions need it -, hit, throughput, state) are copied to the sorted
+// position into the generation `to` / `to_hit`, so that the shade launches STREAM them (entry i = slot i) instead of gathering 4 x 16 bytes per vertex through
+// the sorted list from lines they share with vertices of other bins; the copy itself reads a stream and writes runs (a round's entries of one bin are
+// consecutive). !MOVE: `sorted` receives the slots and the shade kernels gather.
+template <bool MOVE>
 __global__ void __launch_bounds__(256) k_bin_scatter(DScene sc, PassState ps, unsigned n_bins, const unsigned* __restrict__ hist, unsigned* __restrict__ cursor,
                                                      unsigned* __restrict__ sorted, unsigned* __restrict__ sorted_cnt, unsigned split_bin, unsigned split_bin2,
-                                                     unsigned split_bin3, unsigned* __restrict__ ranges, const unsigned short* __restrict__ bin_at) {
+                                                     unsigned split_bin3, unsigned* __restrict__ ranges, const unsigned short* __restrict__ bin_at,
+                                                     PathGen to, float4* __restrict__ to_hit, int with_origin) {
   __shared__ unsigned base[RT_BIN_MAX + 1], lcount[RT_BIN_MAX + 1], lbase[RT_BIN_MAX + 1];
   if (threadIdx.x == 0) {  // exclusive prefix of the histogram (<= 257 entries)
     unsigned run = 0;
@@ -1393,7 +1399,14 @@ __global__ void __launch_bounds__(256) k_bin_scatter(DScene sc, PassState ps, un
     for (unsigned b = threadIdx.x; b < n_bins; b += 256u) if (lcount[b]) lbase[b] = atomicAdd(&cursor[b * RT_CNT_STRIDE], lcount[b]);  // one global atomic per bin per 1024 entries
     __syncthreads();
 #pragma unroll
-    for (unsigned k = 0; k < E; ++k) if (live[k]) sorted[base[bin[k]] + lbase[bin[k]] + rank[k]] = pid[k];
+    for (unsigned k = 0; k < E; ++k) if (live[k]) {
+      const unsigned p = base[bin[k]] + lbase[bin[k]] + rank[k], from = pid[k];
+      if (MOVE) {
+        const float4 d4 = ps.in.d[from], h4 = ps.hit[from], b4 = ps.in.beta[from]; const uint4 s4 = ps.in.st[from];
+        to.d[p] = d4; to_hit[p] = h4; to.beta[p] = b4; to.st[p] = s4;
+        if (with_origin) to.o[p] = ps.in.o[from];
+      } else sorted[p] = from;
+    }
     __syncthreads();
     for (unsigned b = threadIdx.x; b < n_bins; b += 256u) lcount[b] = 0u;
     __syncthreads();
@@ -1906,7 +1919,7 @@ __global__ void __launch_bounds__(256) k_shade_miss(DScene sc, PassState ps) {
   const unsigned first = ps.range[0], count = ps.range[1];
   const unsigned stride = gridDim.x * blockDim.x;
   for (unsigned i = first + blockIdx.x * blockDim.x + threadIdx.x; i < count; i += stride) {
-    const unsigned slot = ps.q_in[i];  // (a binned queue: the sorted list of slots)
+    const unsigned slot = ps.q_in ? ps.q_in[i] : i;  // (a binned queue: the sorted list of slots, or the moved records themselves)
     const uint4 s4 = ps.in.st[slot];
     const unsigned st = s4.x, pid = s4.y;
     const int bounces = (int)(st & 0xffu); const bool specular_bounce = (st >> 8) & 1u;

@@ -14,7 +14,7 @@ for v in rustracer_amd/csrc/_build/ab/*.so; do
   name=$(basename $v .so)
   cp $v $LIB
   for sc in $SCENES; do
-    python bench.py --scene $sc --steps $STEPS --warmup 1 --no-cpu-baseline --headline-only > gpurun_out/ab/${name}_${sc}_$rep.json 2> gpurun_out/ab/${name}_${sc}_$rep.err
+    python bench.py --scene $sc --steps $STEPS --warmup 1 --no-cpu-baseline --headline-only --detail gpurun_out/ab/${name}_${sc}_$rep.json > gpurun_out/ab/${name}_${sc}_$rep.line 2> gpurun_out/ab/${name}_${sc}_$rep.err
     python scripts/ab_line.py $name $sc gpurun_out/ab/${name}_${sc}_$rep.json
   done
 done

@@ -5,7 +5,7 @@ rows = collections.defaultdict(list)
 for f in sorted(glob.glob("gpurun_out/ab/*_*_*.json")):
     m = re.match(r"(.+)_([a-z0-9-]+)_(\d+)\.json$", os.path.basename(f))
     try:
-        j = json.loads(open(f).read().strip().splitlines()[-1])
+        j = json.load(open(f))
     except Exception:
         continue
     rows[(m.group(2), m.group(1))].append(j)
