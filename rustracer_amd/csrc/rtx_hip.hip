@@ -765,7 +765,7 @@ extern "C" int rt_light_distribution(rt_scene* s, int32_t n_voxels[3], float* fu
 // LDS a workgroup of the trace kernels declares, and the persistent grid that fills every CU at that residency
 template <bool ANY, bool SMALL, int BLOCK, int DEPTH>
 static unsigned trace_grid(const rt_scene* s) {
-  const unsigned lds = (unsigned)(DEPTH * BLOCK * ((SMALL && !ANY) ? 2 : 4) + (SMALL ? (2 * RT_SMALL_NODES + 3 * RT_SMALL_TRIS) * 16 : 32));
+  const unsigned lds = (unsigned)(DEPTH * BLOCK * ((SMALL && !ANY) ? 2 : 4) + (SMALL ? (8 * RT_SMALL_NODES + 10 * RT_SMALL_TRIS) * 4 : 32));
   unsigned per_cu = (160u * 1024u) / lds; if (per_cu * BLOCK > 2048u) per_cu = 2048u / BLOCK; if (per_cu < 1) per_cu = 1;
   return (unsigned)s->n_cu * per_cu;
 }
@@ -832,6 +832,18 @@ static void launch_trace_v(rt_scene* s, const TraceIO& io, const unsigned* queue
     }
     if (!plain) {
       hipLaunchKernelGGL((k_trace_big<ANY, COUNT, BLOCK, DEPTH>), dim3(grid), dim3(BLOCK), 0, stream, s->d, io, queue, count_ptr, shard_cap, count_static, stats, st_rays, st_nodes, st_tris);
+      return;
+    }
+  }
+  if constexpr (SMALL && !COUNT) {
+    // LDS-resident scene: persistent waves with refill (k_trace_lds). RTX_LDS_REFILL=0 (measurement knob): one ray per lane per iteration (k_trace)
+    static const bool refill_off = getenv("RTX_LDS_REFILL") && getenv("RTX_LDS_REFILL")[0] == '0';
+    static const int env_lm = getenv("RTX_LDS_LEAF_MIN") ? atoi(getenv("RTX_LDS_LEAF_MIN")) : 0, env_lma = getenv("RTX_LDS_LEAF_MIN_ANY") ? atoi(getenv("RTX_LDS_LEAF_MIN_ANY")) : 0;
+    static const int env_rf = getenv("RTX_LDS_REFILL_MIN") ? atoi(getenv("RTX_LDS_REFILL_MIN")) : 0;
+    if (!refill_off) {
+      const unsigned leaf = ANY ? (env_lma > 0 ? (unsigned)env_lma : (unsigned)RT_LDS_LEAF_MIN_ANY) : (env_lm > 0 ? (unsigned)env_lm : (unsigned)RT_LDS_LEAF_MIN_CLOSEST);
+      const unsigned knobs = (unsigned)std::min(64, std::max(1, env_rf > 0 ? env_rf : RT_REFILL_MIN)) | (std::min(64u, std::max(1u, leaf)) << 8);
+      hipLaunchKernelGGL((k_trace_lds<ANY, BLOCK, DEPTH>), dim3(grid), dim3(BLOCK), 0, stream, s->d, io, queue, count_ptr, shard_cap, count_static, stats, st_rays, knobs);
       return;
     }
   }

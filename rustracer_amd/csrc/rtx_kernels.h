@@ -540,20 +540,40 @@ __global__ void __launch_bounds__(256) k_raygen(FrameParams fp, PassState ps) {
 // ================================================================================ K2/K4 trace
 // rays indexed through `queue` (NULL => identity). Small scenes are copied into LDS first
 // (SMALL): nodes and triangle records are then read from LDS for the whole kernel.
-struct LdsSrc {
-  const float4* nodes; const float4* tris;
-  RT_DEV void node(int i, float4& a, float4& b) const { a = nodes[2 * i]; b = nodes[2 * i + 1]; }
-  RT_DEV void tri(int i, f3& p0, f3& p1, f3& p2) const {
-    float4 a = tris[3 * i], b = tris[3 * i + 1], c = tris[3 * i + 2];
-    p0 = mk3(a.x, a.y, a.z); p1 = mk3(b.x, b.y, b.z); p2 = mk3(c.x, c.y, c.z);
-  }
-  RT_DEV void tri_flags(int i, f3& p0, f3& p1, f3& p2, unsigned& flags) const {
-    float4 a = tris[3 * i], b = tris[3 * i + 1], c = tris[3 * i + 2];
-    p0 = mk3(a.x, a.y, a.z); p1 = mk3(b.x, b.y, b.z); p2 = mk3(c.x, c.y, c.z); flags = __float_as_uint(c.w);
-  }
-};
 #define RT_SMALL_NODES 256
 #define RT_SMALL_TRIS 128
+// Planar in LDS: plane k of the nodes holds dword k of every 32-byte node, plane k of the triangles coordinate k of every triangle (plane 9: its flags word).
+// A lane reads node `cur`; the 64 lanes of a wave sit at different nodes. As 32-byte records two b128 reads per node hit the banks (cur * 8 + k) mod 32: only
+// FOUR distinct bank groups, so the ~20 distinct nodes a wave of bounced rays holds were served one after the other, eight to a group - the kernel was bound
+// by LDS bank conflicts (SQ_LDS_BANK_CONFLICT 1.26e10 > SQ_ACTIVE_INST_LDS 8.4e9 cycles on S1, round 3). Planar, the dword k of node cur sits in bank cur mod 32:
+// distinct nodes of a small scene fall into distinct banks, equal nodes are a broadcast.
+struct LdsSrc {
+  const float* nodes; const float* tris;
+  RT_DEV void node(int i, float4& a, float4& b) const {
+    constexpr int N = RT_SMALL_NODES;
+    a = make_float4(nodes[i], nodes[N + i], nodes[2 * N + i], nodes[3 * N + i]);
+    b = make_float4(nodes[4 * N + i], nodes[5 * N + i], nodes[6 * N + i], nodes[7 * N + i]);
+  }
+  RT_DEV void tri(int i, f3& p0, f3& p1, f3& p2) const {
+    constexpr int T = RT_SMALL_TRIS;
+    p0 = mk3(tris[i], tris[T + i], tris[2 * T + i]); p1 = mk3(tris[3 * T + i], tris[4 * T + i], tris[5 * T + i]); p2 = mk3(tris[6 * T + i], tris[7 * T + i], tris[8 * T + i]);
+  }
+  RT_DEV void tri_flags(int i, f3& p0, f3& p1, f3& p2, unsigned& flags) const { tri(i, p0, p1, p2); flags = __float_as_uint(tris[9 * RT_SMALL_TRIS + i]); }
+};
+// copies the scene's nodes and leaf-ordered triangle records into the planar LDS arrays (every thread of the workgroup; followed by a barrier at the caller)
+template <int BLOCK>
+RT_DEV void stage_small_scene(const DScene& sc, float* s_nodes, float* s_tris) {
+  constexpr int N = RT_SMALL_NODES, T = RT_SMALL_TRIS;
+  for (unsigned i = threadIdx.x; i < 2u * sc.n_nodes; i += BLOCK) {
+    const float4 v = sc.nodes[i]; const unsigned n = i >> 1, h = (i & 1u) * 4u;
+    s_nodes[h * N + n] = v.x; s_nodes[(h + 1u) * N + n] = v.y; s_nodes[(h + 2u) * N + n] = v.z; s_nodes[(h + 3u) * N + n] = v.w;
+  }
+  for (unsigned i = threadIdx.x; i < 3u * sc.n_tris; i += BLOCK) {
+    const float4 v = sc.tri_p[i]; const unsigned t = i / 3u, r = i - 3u * t;
+    s_tris[(3u * r) * T + t] = v.x; s_tris[(3u * r + 1u) * T + t] = v.y; s_tris[(3u * r + 2u) * T + t] = v.z;
+    if (r == 2u) s_tris[9 * T + t] = v.w;
+  }
+}
 
 // Where a trace launch reads its rays and writes its results: element [pid * stride] of each pointer (strides in elements of the pointer's
 // type), so that the same kernels serve the records of a frame (RayRec / VertRec / ShadowRec / MisRec) and the planar arrays of the batch entry points.
@@ -595,20 +615,15 @@ __global__ void __launch_bounds__(BLOCK, RT_GEN_MIN_WAVES(GENERAL)) k_trace(DSce
   // node indices of a tiny scene fit 16 bits: half the stack bytes => more resident waves per CU
   typedef typename std::conditional<SMALL && !ANY, unsigned short, int>::type StackT;
   __shared__ StackT stack[DEPTH * BLOCK];
-  __shared__ float4 s_nodes[SMALL ? 2 * RT_SMALL_NODES : 1];
-  __shared__ float4 s_tris[SMALL ? 3 * RT_SMALL_TRIS : 1];
+  __shared__ float s_nodes[SMALL ? 8 * RT_SMALL_NODES : 1];
+  __shared__ float s_tris[SMALL ? 10 * RT_SMALL_TRIS : 1];
   QView qv; if (queue) qv.init(io.queue_is_slots ? nullptr : queue, shard_counts, shard_cap);
   const unsigned count = queue ? qv.total() : count_static;
   if (blockIdx.x * BLOCK >= count) return;  // short queues (MIS rays, late bounces): most blocks of the persistent grid have nothing to stage for
-  if (SMALL) {
-    for (unsigned i = threadIdx.x; i < 2u * sc.n_nodes; i += BLOCK) s_nodes[i] = sc.nodes[i];
-    for (unsigned i = threadIdx.x; i < 3u * sc.n_tris; i += BLOCK) s_tris[i] = sc.tri_p[i];
-    __syncthreads();
-  }
+  if (SMALL) { stage_small_scene<BLOCK>(sc, s_nodes, s_tris); __syncthreads(); }
   const unsigned stride = gridDim.x * BLOCK;
   unsigned n_nodes = 0, n_tris = 0, n_rays = 0;
-  for (unsigned i = blockIdx.x * BLOCK + threadIdx.x; i < count; i += stride) {
-    const unsigned pid = queue ? qv.get(i) : i;
+  auto trace_one = [&](unsigned pid) {
     float4 o4 = ray_o[pid * rs], d4 = ray_d[pid * rs];
     Ray ray; ray.o = mk3(o4.x, o4.y, o4.z); ray.d = mk3(d4.x, d4.y, d4.z); ray.t_max = o4.w;
     int prim = -1; TriHit h; h.t = kInf; h.b0 = h.b1 = h.b2 = 0.0f;
@@ -621,7 +636,8 @@ __global__ void __launch_bounds__(BLOCK, RT_GEN_MIN_WAVES(GENERAL)) k_trace(DSce
     n_rays += 1;
     if (ANY) trace_write_any(lacc, ls, direct_add, as, occluded, os, pid, d4.w, found);
     else hits[pid * hs] = make_float4(hit_b2 ? h.b2 : (found ? h.t : kInf), __int_as_float(found ? prim : -1), h.b0, h.b1);
-  }
+  };
+  for (unsigned i = blockIdx.x * BLOCK + threadIdx.x; i < count; i += stride) trace_one(queue ? qv.get(i) : i);
   if (stats) {
     // one atomic per wave and counter
     for (int off = 32; off > 0; off >>= 1) { n_rays += __shfl_down(n_rays, off); if (COUNT) { n_nodes += __shfl_down(n_nodes, off); n_tris += __shfl_down(n_tris, off); } }
@@ -629,6 +645,117 @@ __global__ void __launch_bounds__(BLOCK, RT_GEN_MIN_WAVES(GENERAL)) k_trace(DSce
       if (n_rays) atomicAdd(&stats[st_rays], (unsigned long long)n_rays);
       if (COUNT) { atomicAdd(&stats[st_nodes], (unsigned long long)n_nodes); atomicAdd(&stats[st_tris], (unsigned long long)n_tris); }
     }
+  }
+}
+
+// ---- K2/K4 for LDS-resident scenes with persistent waves (round 4). In k_trace a wave takes 64 rays and walks them in lockstep until the LAST one is done: on
+// S1 a ray visits 17 nodes on average and the longest of 64 about twice that, so 28 of 64 lanes were active per VALU instruction - the tail, not the order of the
+// rays (a tile-local counting sort of the rays by direction octant and origin cell, which makes the 64 rays of a wave neighbours in both, bought 2 % and cost
+// the LDS of two resident workgroups: removed). Here a wave keeps its lanes fed as the HBM kernels below do: whenever `refill_min` lanes have finished, they take
+// the next rays of the wave's share of the queue; the loads' latency is covered by the other waves of the SIMD (the walk itself never leaves the CU). Per ray
+// the node visits, triangle tests and their order are traverse_rounds' (one 32-byte node per step from LDS, the leaf phase held back until `leaf_min` lanes
+// wait at a leaf): hit records and occlusion results are bit-identical.
+struct LdsLane {
+  bool active, found; unsigned pid; float dw;
+  Ray ray; f3 inv_dir; int kz; float sx, sy, sz;
+  int sp, prim, cur, leaf_off, leaf_n; TriHit hit;
+  RT_DEV RayPre rp() const { RayPre r; r.kz = kz; r.kx = kz + 1; if (r.kx == 3) r.kx = 0; r.ky = r.kx + 1; if (r.ky == 3) r.ky = 0; r.sx = sx; r.sy = sy; r.sz = sz; return r; }
+  RT_DEV void set_rp(const RayPre& r) { kz = r.kz; sx = r.sx; sy = r.sy; sz = r.sz; }
+};
+struct TraceOut { float4* hits; size_t hs; bool hit_b2; unsigned* occluded; size_t os; float4* lacc; size_t ls; const float4* direct_add; size_t as; };
+RT_DEV TraceOut trace_out_of(const TraceIO& io) {
+  TraceOut o; o.hits = io.hits; o.hs = io.hit_stride; o.hit_b2 = io.hit_b2 != 0; o.occluded = io.occluded; o.os = io.occ_stride;
+  o.lacc = io.lacc; o.ls = io.lacc_stride; o.direct_add = io.direct_add; o.as = io.add_stride; return o;
+}
+template <bool ANY, int BLOCK, int DEPTH>
+__global__ void __launch_bounds__(BLOCK) k_trace_lds(DScene sc, TraceIO io, const unsigned* __restrict__ queue, const unsigned* __restrict__ shard_counts, unsigned shard_cap,
+                                                     unsigned count_static, unsigned long long* stats, int st_rays, unsigned knobs) {
+  const float4* __restrict__ ray_o = io.ray_o; const float4* __restrict__ ray_d = io.ray_d; const size_t rs = io.ray_stride;
+  typedef typename std::conditional<!ANY, unsigned short, int>::type StackT;  // (as k_trace: node indices of a tiny scene fit 16 bits)
+  __shared__ StackT stack_mem[DEPTH * BLOCK];
+  __shared__ float s_nodes[8 * RT_SMALL_NODES];
+  __shared__ float s_tris[10 * RT_SMALL_TRIS];
+  StackT* const stack = stack_mem + threadIdx.x;
+  QView qv; if (queue) qv.init(io.queue_is_slots ? nullptr : queue, shard_counts, shard_cap);
+  const unsigned count = queue ? qv.total() : count_static;
+  if (blockIdx.x * BLOCK >= count) return;
+  stage_small_scene<BLOCK>(sc, s_nodes, s_tris);
+  __syncthreads();
+  const LdsSrc src{s_nodes, s_tris};
+  const unsigned lane = __lane_id();
+  const unsigned n_waves = gridDim.x * (BLOCK / 64), wave = blockIdx.x * (BLOCK / 64) + (threadIdx.x >> 6);
+  const TraceOut out = trace_out_of(io);
+  const unsigned leaf_min = knobs >> 8, refill_min = knobs & 0xffu;
+  unsigned n_rays = 0, cursor = 0;
+  bool exhausted = (unsigned long long)wave * 64ull >= count;
+  LdsLane L;
+  L.active = false; L.found = false; L.pid = 0; L.dw = 0.0f;
+  L.ray.o = L.ray.d = mk3(0, 0, 0); L.ray.t_max = 0.0f; L.inv_dir = mk3(0, 0, 0); L.set_rp(ray_pre(L.ray));
+  L.sp = 0; L.prim = -1; L.cur = 0; L.leaf_off = 0; L.leaf_n = 0; L.hit.t = kInf; L.hit.b0 = L.hit.b1 = L.hit.b2 = 0.0f;
+  auto finish = [&]() {
+    if (ANY) trace_write_any(out.lacc, out.ls, out.direct_add, out.as, out.occluded, out.os, L.pid, L.dw, L.found);
+    else out.hits[L.pid * out.hs] = make_float4(out.hit_b2 ? L.hit.b2 : (L.found ? L.hit.t : kInf), __int_as_float(L.found ? L.prim : -1), L.hit.b0, L.hit.b1);
+    L.active = false;
+  };
+  for (;;) {
+    const unsigned long long idle = __ballot(!L.active);
+    if (!exhausted && (unsigned)__popcll(idle) >= (idle == ~0ull ? 1u : refill_min)) {
+      const unsigned v = cursor + (unsigned)__popcll(idle & ((1ull << lane) - 1ull));
+      const unsigned long long e = ((unsigned long long)(v >> 6) * n_waves + wave) * 64ull + (v & 63u);
+      if (!L.active && e < count) {
+        L.pid = queue ? qv.get((unsigned)e) : (unsigned)e;
+        const float4 o4 = ray_o[L.pid * rs], d4 = ray_d[L.pid * rs];
+        L.ray.o = mk3(o4.x, o4.y, o4.z); L.ray.d = mk3(d4.x, d4.y, d4.z); L.ray.t_max = o4.w; L.dw = d4.w;
+        L.inv_dir = mk3(1.0f / L.ray.d.x, 1.0f / L.ray.d.y, 1.0f / L.ray.d.z);
+        L.set_rp(ray_pre(L.ray));
+        L.sp = 0; L.prim = -1; L.found = false; L.cur = 0; L.leaf_n = 0; L.hit.t = kInf; L.hit.b0 = L.hit.b1 = L.hit.b2 = 0.0f;
+        L.active = true; n_rays += 1;
+      }
+      cursor += (unsigned)__popcll(idle);
+      exhausted = ((unsigned long long)(cursor >> 6) * n_waves + wave) * 64ull + (cursor & 63u) >= count;
+    }
+    const unsigned long long holders = __ballot(L.active && L.leaf_n > 0), walkers = __ballot(L.active && L.leaf_n == 0);
+    if ((holders | walkers) == 0ull) { if (exhausted) break; else continue; }
+    if (walkers != 0ull && (unsigned)__popcll(holders) < leaf_min) {
+      if (L.active && L.leaf_n == 0) {  // one node (traverse_rounds' step)
+        const int neg_x = L.inv_dir.x < 0.0f, neg_y = L.inv_dir.y < 0.0f, neg_z = L.inv_dir.z < 0.0f;
+        float4 n0, n1;
+        src.node(L.cur, n0, n1);
+        if (slab_test(n0, n1, L.ray, L.inv_dir, neg_x, neg_y, neg_z)) {
+          const unsigned packed = __float_as_uint(n1.w);
+          const int n_prims = (int)(packed & 0xffffu);
+          const int offset = __float_as_int(n1.z);
+          if (n_prims > 0) { L.leaf_off = offset; L.leaf_n = n_prims; }
+          else {
+            const int axis = (int)((packed >> 16) & 0xffu);
+            const int neg = axis == 0 ? neg_x : (axis == 1 ? neg_y : neg_z);
+            if (neg) { stack[(L.sp++) * BLOCK] = (StackT)(L.cur + 1); L.cur = offset; }
+            else { stack[(L.sp++) * BLOCK] = (StackT)offset; L.cur = L.cur + 1; }
+          }
+        } else {
+          if (L.sp == 0) finish();
+          else L.cur = (int)stack[(--L.sp) * BLOCK];
+        }
+      }
+    } else if (L.active && L.leaf_n > 0) {
+      const RayPre rp = L.rp();
+      for (int i = 0; i < L.leaf_n; ++i) {
+        f3 p0, p1, p2; src.tri(L.leaf_off + i, p0, p1, p2);
+        TriHit h;
+        if (tri_test_pre(p0, p1, p2, L.ray, rp, h)) {
+          L.found = true;
+          if (ANY) break;
+          L.ray.t_max = h.t; L.prim = L.leaf_off + i; L.hit = h;  // `.or(result)`: later accepted hits replace
+        }
+      }
+      L.leaf_n = 0;
+      if ((ANY && L.found) || L.sp == 0) finish();
+      else L.cur = (int)stack[(--L.sp) * BLOCK];
+    }
+  }
+  if (stats) {
+    for (int off = 32; off > 0; off >>= 1) n_rays += __shfl_down(n_rays, off);
+    if (lane == 0u && n_rays) atomicAdd(&stats[st_rays], (unsigned long long)n_rays);
   }
 }
 
@@ -919,11 +1046,6 @@ struct PairLane {
   int sp, prim; unsigned cur; TriHit hit;
 };
 // (the leaf phase of these loops is held back until enough lanes wait at a leaf: leaf_phase_now, rtx_dev_scene.h)
-struct TraceOut { float4* hits; size_t hs; bool hit_b2; unsigned* occluded; size_t os; float4* lacc; size_t ls; const float4* direct_add; size_t as; };
-RT_DEV TraceOut trace_out_of(const TraceIO& io) {
-  TraceOut o; o.hits = io.hits; o.hs = io.hit_stride; o.hit_b2 = io.hit_b2 != 0; o.occluded = io.occluded; o.os = io.occ_stride;
-  o.lacc = io.lacc; o.ls = io.lacc_stride; o.direct_add = io.direct_add; o.as = io.add_stride; return o;
-}
 template <bool ANY>
 RT_DEV void pair_finish(PairLane& L, const TraceOut& o) {  // same epilogue as k_trace
   if (ANY) trace_write_any(o.lacc, o.ls, o.direct_add, o.as, o.occluded, o.os, L.pid, L.dw, L.found);
