@@ -835,18 +835,6 @@ static void launch_trace_v(rt_scene* s, const TraceIO& io, const unsigned* queue
       return;
     }
   }
-  if constexpr (SMALL && !COUNT) {
-    // LDS-resident scene: persistent waves with refill (k_trace_lds). RTX_LDS_REFILL=0 (measurement knob): one ray per lane per iteration (k_trace)
-    static const bool refill_off = getenv("RTX_LDS_REFILL") && getenv("RTX_LDS_REFILL")[0] == '0';
-    static const int env_lm = getenv("RTX_LDS_LEAF_MIN") ? atoi(getenv("RTX_LDS_LEAF_MIN")) : 0, env_lma = getenv("RTX_LDS_LEAF_MIN_ANY") ? atoi(getenv("RTX_LDS_LEAF_MIN_ANY")) : 0;
-    static const int env_rf = getenv("RTX_LDS_REFILL_MIN") ? atoi(getenv("RTX_LDS_REFILL_MIN")) : 0;
-    if (!refill_off) {
-      const unsigned leaf = ANY ? (env_lma > 0 ? (unsigned)env_lma : (unsigned)RT_LDS_LEAF_MIN_ANY) : (env_lm > 0 ? (unsigned)env_lm : (unsigned)RT_LDS_LEAF_MIN_CLOSEST);
-      const unsigned knobs = (unsigned)std::min(64, std::max(1, env_rf > 0 ? env_rf : RT_REFILL_MIN)) | (std::min(64u, std::max(1u, leaf)) << 8);
-      hipLaunchKernelGGL((k_trace_lds<ANY, BLOCK, DEPTH>), dim3(grid), dim3(BLOCK), 0, stream, s->d, io, queue, count_ptr, shard_cap, count_static, stats, st_rays, knobs);
-      return;
-    }
-  }
   hipLaunchKernelGGL((k_trace<ANY, COUNT, SMALL, BLOCK, DEPTH>), dim3(grid), dim3(BLOCK), 0, stream, s->d, io, queue, count_ptr, shard_cap, count_static, stats, st_rays, st_nodes, st_tris);
 }
 template <bool ANY, bool COUNT>

@@ -648,117 +648,21 @@ __global__ void __launch_bounds__(BLOCK, RT_GEN_MIN_WAVES(GENERAL)) k_trace(DSce
   }
 }
 
-// ---- K2/K4 for LDS-resident scenes with persistent waves (round 4). In k_trace a wave takes 64 rays and walks them in lockstep until the LAST one is done: on
-// S1 a ray visits 17 nodes on average and the longest of 64 about twice that, so 28 of 64 lanes were active per VALU instruction - the tail, not the order of the
-// rays (a tile-local counting sort of the rays by direction octant and origin cell, which makes the 64 rays of a wave neighbours in both, bought 2 % and cost
-// the LDS of two resident workgroups: removed). Here a wave keeps its lanes fed as the HBM kernels below do: whenever `refill_min` lanes have finished, they take
-// the next rays of the wave's share of the queue; the loads' latency is covered by the other waves of the SIMD (the walk itself never leaves the CU). Per ray
-// the node visits, triangle tests and their order are traverse_rounds' (one 32-byte node per step from LDS, the leaf phase held back until `leaf_min` lanes
-// wait at a leaf): hit records and occlusion results are bit-identical.
-struct LdsLane {
-  bool active, found; unsigned pid; float dw;
-  Ray ray; f3 inv_dir; int kz; float sx, sy, sz;
-  int sp, prim, cur, leaf_off, leaf_n; TriHit hit;
-  RT_DEV RayPre rp() const { RayPre r; r.kz = kz; r.kx = kz + 1; if (r.kx == 3) r.kx = 0; r.ky = r.kx + 1; if (r.ky == 3) r.ky = 0; r.sx = sx; r.sy = sy; r.sz = sz; return r; }
-  RT_DEV void set_rp(const RayPre& r) { kz = r.kz; sx = r.sx; sy = r.sy; sz = r.sz; }
-};
+// ---- Measured on the LDS-resident kernel in round 4 and not kept (S1, one box, closest hit / shadow rays per frame; k_trace as it stands: 336 / 168 ms):
+//  * tile-local ray ordering - the workgroup counting-sorts tiles of 2048 queue entries in LDS by direction octant (+ the 2 x 2 x 2 cell of the origin) so that
+//    the 64 rays of a wave are neighbours in both: 371 -> 364 / 228 -> 210 ms against 371 / 228 for the same kernel unsorted - the 4 KB of LDS it needs cost two
+//    resident workgroups per CU, which is worth more than the order (a wave's cost is its LONGEST ray: 17 nodes on average, about twice that for the slowest
+//    of 64, whatever their order);
+//  * persistent waves with refill as in k_trace_pair (a lane that finishes takes the next ray of the wave's share once 16 are idle; same per-ray steps):
+//    413 / 275 ms. The walk itself gains lanes, but a ray's set-up - six IEEE divisions for 1 / d and the watertight test's shear, the queue lookup - then
+//    runs for the 16-24 refilled lanes instead of all 64: ~200 instructions at a quarter of the lanes per ~1250 of walk. Refill thresholds 8 / 24 / 32 and
+//    leaf thresholds 8 / 24 / 32 all lose;
+//  * (kept) the scene planar in LDS (LdsSrc): 336 -> 329 ms; bank conflicts were real (round 3's counters) but not what the kernel waits for.
 struct TraceOut { float4* hits; size_t hs; bool hit_b2; unsigned* occluded; size_t os; float4* lacc; size_t ls; const float4* direct_add; size_t as; };
 RT_DEV TraceOut trace_out_of(const TraceIO& io) {
   TraceOut o; o.hits = io.hits; o.hs = io.hit_stride; o.hit_b2 = io.hit_b2 != 0; o.occluded = io.occluded; o.os = io.occ_stride;
   o.lacc = io.lacc; o.ls = io.lacc_stride; o.direct_add = io.direct_add; o.as = io.add_stride; return o;
 }
-template <bool ANY, int BLOCK, int DEPTH>
-__global__ void __launch_bounds__(BLOCK) k_trace_lds(DScene sc, TraceIO io, const unsigned* __restrict__ queue, const unsigned* __restrict__ shard_counts, unsigned shard_cap,
-                                                     unsigned count_static, unsigned long long* stats, int st_rays, unsigned knobs) {
-  const float4* __restrict__ ray_o = io.ray_o; const float4* __restrict__ ray_d = io.ray_d; const size_t rs = io.ray_stride;
-  typedef typename std::conditional<!ANY, unsigned short, int>::type StackT;  // (as k_trace: node indices of a tiny scene fit 16 bits)
-  __shared__ StackT stack_mem[DEPTH * BLOCK];
-  __shared__ float s_nodes[8 * RT_SMALL_NODES];
-  __shared__ float s_tris[10 * RT_SMALL_TRIS];
-  StackT* const stack = stack_mem + threadIdx.x;
-  QView qv; if (queue) qv.init(io.queue_is_slots ? nullptr : queue, shard_counts, shard_cap);
-  const unsigned count = queue ? qv.total() : count_static;
-  if (blockIdx.x * BLOCK >= count) return;
-  stage_small_scene<BLOCK>(sc, s_nodes, s_tris);
-  __syncthreads();
-  const LdsSrc src{s_nodes, s_tris};
-  const unsigned lane = __lane_id();
-  const unsigned n_waves = gridDim.x * (BLOCK / 64), wave = blockIdx.x * (BLOCK / 64) + (threadIdx.x >> 6);
-  const TraceOut out = trace_out_of(io);
-  const unsigned leaf_min = knobs >> 8, refill_min = knobs & 0xffu;
-  unsigned n_rays = 0, cursor = 0;
-  bool exhausted = (unsigned long long)wave * 64ull >= count;
-  LdsLane L;
-  L.active = false; L.found = false; L.pid = 0; L.dw = 0.0f;
-  L.ray.o = L.ray.d = mk3(0, 0, 0); L.ray.t_max = 0.0f; L.inv_dir = mk3(0, 0, 0); L.set_rp(ray_pre(L.ray));
-  L.sp = 0; L.prim = -1; L.cur = 0; L.leaf_off = 0; L.leaf_n = 0; L.hit.t = kInf; L.hit.b0 = L.hit.b1 = L.hit.b2 = 0.0f;
-  auto finish = [&]() {
-    if (ANY) trace_write_any(out.lacc, out.ls, out.direct_add, out.as, out.occluded, out.os, L.pid, L.dw, L.found);
-    else out.hits[L.pid * out.hs] = make_float4(out.hit_b2 ? L.hit.b2 : (L.found ? L.hit.t : kInf), __int_as_float(L.found ? L.prim : -1), L.hit.b0, L.hit.b1);
-    L.active = false;
-  };
-  for (;;) {
-    const unsigned long long idle = __ballot(!L.active);
-    if (!exhausted && (unsigned)__popcll(idle) >= (idle == ~0ull ? 1u : refill_min)) {
-      const unsigned v = cursor + (unsigned)__popcll(idle & ((1ull << lane) - 1ull));
-      const unsigned long long e = ((unsigned long long)(v >> 6) * n_waves + wave) * 64ull + (v & 63u);
-      if (!L.active && e < count) {
-        L.pid = queue ? qv.get((unsigned)e) : (unsigned)e;
-        const float4 o4 = ray_o[L.pid * rs], d4 = ray_d[L.pid * rs];
-        L.ray.o = mk3(o4.x, o4.y, o4.z); L.ray.d = mk3(d4.x, d4.y, d4.z); L.ray.t_max = o4.w; L.dw = d4.w;
-        L.inv_dir = mk3(1.0f / L.ray.d.x, 1.0f / L.ray.d.y, 1.0f / L.ray.d.z);
-        L.set_rp(ray_pre(L.ray));
-        L.sp = 0; L.prim = -1; L.found = false; L.cur = 0; L.leaf_n = 0; L.hit.t = kInf; L.hit.b0 = L.hit.b1 = L.hit.b2 = 0.0f;
-        L.active = true; n_rays += 1;
-      }
-      cursor += (unsigned)__popcll(idle);
-      exhausted = ((unsigned long long)(cursor >> 6) * n_waves + wave) * 64ull + (cursor & 63u) >= count;
-    }
-    const unsigned long long holders = __ballot(L.active && L.leaf_n > 0), walkers = __ballot(L.active && L.leaf_n == 0);
-    if ((holders | walkers) == 0ull) { if (exhausted) break; else continue; }
-    if (walkers != 0ull && (unsigned)__popcll(holders) < leaf_min) {
-      if (L.active && L.leaf_n == 0) {  // one node (traverse_rounds' step)
-        const int neg_x = L.inv_dir.x < 0.0f, neg_y = L.inv_dir.y < 0.0f, neg_z = L.inv_dir.z < 0.0f;
-        float4 n0, n1;
-        src.node(L.cur, n0, n1);
-        if (slab_test(n0, n1, L.ray, L.inv_dir, neg_x, neg_y, neg_z)) {
-          const unsigned packed = __float_as_uint(n1.w);
-          const int n_prims = (int)(packed & 0xffffu);
-          const int offset = __float_as_int(n1.z);
-          if (n_prims > 0) { L.leaf_off = offset; L.leaf_n = n_prims; }
-          else {
-            const int axis = (int)((packed >> 16) & 0xffu);
-            const int neg = axis == 0 ? neg_x : (axis == 1 ? neg_y : neg_z);
-            if (neg) { stack[(L.sp++) * BLOCK] = (StackT)(L.cur + 1); L.cur = offset; }
-            else { stack[(L.sp++) * BLOCK] = (StackT)offset; L.cur = L.cur + 1; }
-          }
-        } else {
-          if (L.sp == 0) finish();
-          else L.cur = (int)stack[(--L.sp) * BLOCK];
-        }
-      }
-    } else if (L.active && L.leaf_n > 0) {
-      const RayPre rp = L.rp();
-      for (int i = 0; i < L.leaf_n; ++i) {
-        f3 p0, p1, p2; src.tri(L.leaf_off + i, p0, p1, p2);
-        TriHit h;
-        if (tri_test_pre(p0, p1, p2, L.ray, rp, h)) {
-          L.found = true;
-          if (ANY) break;
-          L.ray.t_max = h.t; L.prim = L.leaf_off + i; L.hit = h;  // `.or(result)`: later accepted hits replace
-        }
-      }
-      L.leaf_n = 0;
-      if ((ANY && L.found) || L.sp == 0) finish();
-      else L.cur = (int)stack[(--L.sp) * BLOCK];
-    }
-  }
-  if (stats) {
-    for (int off = 32; off > 0; off >>= 1) n_rays += __shfl_down(n_rays, off);
-    if (lane == 0u && n_rays) atomicAdd(&stats[st_rays], (unsigned long long)n_rays);
-  }
-}
-
 // ---- K2/K4 for scenes that live in HBM. Ray lengths then vary by an order of magnitude (a camera ray that
 // misses the root box ends after one node, one that grazes a silhouette visits a hundred), and with one ray per
 // lane per grid-stride iteration a wave runs as long as its longest ray with most lanes idle (measured: 11 of 64
