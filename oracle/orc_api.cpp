@@ -445,6 +445,37 @@ int orc_tri_reintersect(const float* tri9, const float* ray8, const float* w3) {
   TriHit h2;
   return s.tri_test(0, r2, &h2) ? 1 : 0;
 }
+// The reference's own quadric property test, rustracer-core/tests/shapes.rs:16-54 (`full_sphere_reintersect` -> `test_reintersection_convex`), on the oracle's
+// Sphere: a full sphere of `radius` at the origin (Transform::default), the ray ray8 = (o, t_max, d, -); if it hits, `n` rays leave the hit point in the
+// directions uniform_sample_sphere(u[i]) flipped into the hemisphere of the hit's normal (isect.spawn_ray(&w)) and neither intersect_p nor intersect may find
+// the sphere again. Returns -1 when the first ray misses, else the number of re-hits (intersect_p + intersect); the spawned rays go to rays_out (n x 8) when given.
+int orc_sphere_reintersect(float radius, const float* ray8, const float* u2, int n, float* rays_out) {
+  const Sphere s = sphere_new(Transform{m44_identity(), m44_identity()}, radius, -radius, radius, 360.0f, false);
+  const Ray ray = ray_segment(v3(ray8[0], ray8[1], ray8[2]), v3(ray8[4], ray8[5], ray8[6]), ray8[3]);
+  SphereHit h;
+  if (!sphere_intersect(s, ray, true, &h)) return -1;
+  Interaction it; it.p = h.p; it.p_error = h.p_error; it.n = h.n; it.wo = h.wo;
+  int rehits = 0;
+  for (int i = 0; i < n; ++i) {
+    V3 w = uniform_sample_sphere(P2{u2[2 * i], u2[2 * i + 1]});
+    if (dot(w, h.n) < 0.0f) w = -w;
+    const Ray out = spawn_ray(it, w);
+    if (rays_out) { float* r = rays_out + 8 * (size_t)i; r[0] = out.o.x; r[1] = out.o.y; r[2] = out.o.z; r[3] = out.t_max; r[4] = out.d.x; r[5] = out.d.y; r[6] = out.d.z; r[7] = 0.0f; }
+    SphereHit h2;
+    if (sphere_intersect(s, out, false, &h2)) rehits += 1;  // intersect_p
+    if (sphere_intersect(s, out, true, &h2)) rehits += 1;   // intersect
+  }
+  return rehits;
+}
+// EFloat arithmetic for rustracer-core/tests/efloat.rs:51-154: op 0 abs, 1 sqrt, 2 add, 3 sub, 4 mul, 5 div on EFloat::new(av, aerr) (and EFloat::new(bv, berr));
+// out3 = (v, lower_bound, upper_bound); in_bounds4 = the operands' own (low, high) pairs, which the test draws its exact values from
+void orc_efloat_op(int op, float av, float aerr, float bv, float berr, float* out3, float* in_bounds4) {
+  const EFloat a = ef_new(av, aerr), b = ef_new(bv, berr);
+  EFloat r = a;
+  switch (op) { case 0: r = ef_abs(a); break; case 1: r = ef_sqrt(a); break; case 2: r = a + b; break; case 3: r = a - b; break; case 4: r = a * b; break; default: r = a / b; }
+  out3[0] = r.v; out3[1] = r.low; out3[2] = r.high;
+  in_bounds4[0] = a.low; in_bounds4[1] = a.high; in_bounds4[2] = b.low; in_bounds4[3] = b.high;
+}
 // BSDF probes (tests): evaluates f / pdf / sample_f of the Bsdf a material builds at a canonical hit (n = +z)
 int orc_bsdf_probe(void* h, int material, const float* wo3, const float* wi3, const float* u2, float* f3_out, float* pdf_out, float* sample_out8) {
   Scene* s = (Scene*)h;

@@ -34,6 +34,12 @@ inline EFloat operator/(EFloat a, EFloat f) {  // :190-220
   return {a.v / f.v, lo, hi};
 }
 inline EFloat operator*(float s, EFloat f) { return ef(s) * f; }
+inline EFloat ef_sqrt(EFloat a) { return {sqrtf(a.v), next_float_down(sqrtf(a.low)), next_float_up(sqrtf(a.high))}; }  // EFloat::sqrt, :39-47 (not on the sphere's path; replayed by the reference's property tests)
+inline EFloat ef_abs(EFloat a) {  // EFloat::abs, :49-70
+  if (a.low >= 0.0f) return a;
+  if (a.high <= 0.0f) return {-a.v, -a.high, -a.low};
+  return {fabsf(a.v), 0.0f, fmaxf(-a.low, a.high)};
+}
 inline bool ef_solve_quadratic(EFloat a, EFloat b, EFloat c, EFloat* t0, EFloat* t1) {  // solve_quadratic, :96-120
   double discrim = (double)b.v * (double)b.v - 4.0 * (double)a.v * (double)c.v;
   if (discrim < 0.0) return false;

@@ -222,3 +222,35 @@ def test_quadrics_and_masks_among_many_triangles_take_the_fast_kernels(gpu_host,
     assert np.array_equal(fo[..., 3], fh[..., 3]) and rel_l2(gpu_host.film_to_rgb(fh), orc.film_to_rgb(fo)) < 1e-3
     for k in ("rays_closest", "rays_shadow", "rays_mis"):
         assert abs(int(sh[k]) - int(so[k])) <= 2e-3 * int(so[k]) + 16, (k, sh[k], so[k])
+
+
+def test_reference_sphere_reintersection_property_holds_on_the_device(gpu_host, orc):
+    """rustracer-core/tests/shapes.rs:16-54 through the C ABI (rt_trace_closest / rt_trace_any): for seeded full spheres with radii 10^+-4 and ray origins up to
+    1e8 away, the device finds the first hit exactly where the oracle does, and none of the 1000 rays spawned from it into the normal's hemisphere finds the
+    sphere again - as occlusion query (Shape::intersect_p) or as closest hit (Shape::intersect). The spawned rays are the oracle's (offset_ray_origin on the
+    oracle's interaction: the device returns hit records, not interactions); cases as in tests/test_oracle_kat.py."""
+    import ctypes as C
+    from rustracer_amd.scene_desc import SceneDesc
+    from test_oracle_kat import sphere_reintersect_case
+    L = orc.lib()
+    L.orc_sphere_reintersect.restype = C.c_int
+    L.orc_sphere_reintersect.argtypes = [C.c_float, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]
+    tested = 0
+    for i in range(0, 1000, 4):  # every fourth of the reference's 1000 spheres: a scene is created per sphere
+        radius, ray, u = sphere_reintersect_case(i)
+        out = np.zeros((len(u), 8), np.float32)
+        r = L.orc_sphere_reintersect(radius, ray.ctypes.data_as(C.c_void_p), u.ctypes.data_as(C.c_void_p), len(u), out.ctypes.data_as(C.c_void_p))
+        d = SceneDesc()
+        d.add_sphere((0.0, 0.0, 0.0), radius, d.matte((0.5, 0.5, 0.5)))
+        h = gpu_host.HostScene(d)
+        first = h.trace(ray[None, :], count=False)
+        assert (first["prim"][0] >= 0) == (r >= 0), (i, radius, ray)
+        if r < 0:
+            continue
+        ro = orc.OracleScene(d).trace(ray[None, :])
+        assert np.array_equal(bits(ro["t"]), bits(first["t"]))
+        assert r == 0
+        assert not h.trace(out, True, count=False)["occluded"].any(), (i, radius)
+        assert (h.trace(out, count=False)["prim"] < 0).all(), (i, radius)
+        tested += 1
+    assert tested > 150

@@ -395,3 +395,95 @@ def test_disney_lobes(orc, material_scene):
     o = orc.OracleScene(s)
     f, pdf, _, n = _probe(orc, o, m0, wo, wo, u)
     assert n == 3 and pdf > 0 and np.all(f > np.float32([0.7, 0.4, 0.3]) / np.pi - 1e-6)
+
+
+# ---------------------------------------------------------------- the reference's own quadric / EFloat property tests, replayed on the oracle
+def _pexp(rng, e):
+    return np.float32(10.0) ** np.float32(rng.uniform(-e, e))  # shapes.rs:9-14
+
+
+def sphere_reintersect_case(i, n_out=1000):
+    """One iteration of rustracer-core/tests/shapes.rs:16-54 (`full_sphere_reintersect`): the radius (10^+-4), the ray toward a point of the sphere's box from an
+    origin with coordinates 10^+-8, normalised half of the time, and the n_out random points u that give the outward directions. Rust's StdRng stream is not
+    reproducible here (no Rust in this image), so the draws come from numpy's default_rng(i) - the same distributions in the same order, other values."""
+    rng = np.random.default_rng(i)
+    radius = _pexp(rng, 4.0)
+    o = np.array([_pexp(rng, 8.0), _pexp(rng, 8.0), _pexp(rng, 8.0)], np.float32)
+    t = rng.random(3, dtype=np.float32)
+    lo, hi = np.float32(-radius), np.float32(radius)
+    p = (np.float32(1.0) - t) * lo + t * hi  # Bounds3::lerp of the full sphere's world box [-r, r]^3
+    d = (p - o).astype(np.float32)
+    if rng.random(dtype=np.float32) < 0.5:
+        d = (d / np.sqrt(np.float32(d[0] * d[0] + d[1] * d[1] + d[2] * d[2]))).astype(np.float32)
+    ray = np.array([o[0], o[1], o[2], np.inf, d[0], d[1], d[2], 0], np.float32)
+    u = rng.random((n_out, 2), dtype=np.float32)
+    return float(radius), ray, u
+
+
+def test_reference_sphere_reintersection_property_holds_on_the_oracle(orc):
+    """tests/shapes.rs:16-54: 1000 spheres, 1000 rays spawned from each hit into the normal's hemisphere; none may find the sphere again (intersect_p and intersect)."""
+    L = orc.lib()
+    L.orc_sphere_reintersect.restype = C.c_int
+    L.orc_sphere_reintersect.argtypes = [C.c_float, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]
+    hit = 0
+    for i in range(1000):
+        radius, ray, u = sphere_reintersect_case(i)
+        r = L.orc_sphere_reintersect(radius, _f(ray), _f(u), len(u), None)
+        assert r <= 0, (i, radius, ray, r)  # -1: the first ray missed ("we usually, but not always, get an intersection")
+        hit += r == 0
+    assert hit > 600
+
+
+def _efloat_draw(rng, min_exp=-6.0, max_exp=6.0):
+    """get_float, tests/efloat.rs:9-31: an exponentially distributed value with one of four kinds of error."""
+    val = np.float32(10.0) ** np.float32(rng.uniform(min_exp, max_exp))
+    kind = int(rng.integers(0, 4))
+    if kind == 0:
+        err = np.float32(0.0)
+    elif kind in (1, 2):
+        ulp = int(rng.integers(0, 1024 if kind == 1 else 1024 * 1024))
+        off = (np.array([val], np.float32).view(np.uint32) + np.uint32(ulp)).view(np.float32)[0]
+        err = np.abs(off - val)
+    else:
+        err = np.float32(4.0 * rng.random(dtype=np.float32)) * np.abs(val)
+    sign = np.float32(-1.0 if rng.random(dtype=np.float32) < 0.5 else 1.0)
+    return np.float32(sign * val), np.float32(err)
+
+
+def _precise(rng, lo, hi):
+    """get_precise, tests/efloat.rs:33-49: an exact value inside the interval (an end point, or a clamped blend), in f64."""
+    k = int(rng.integers(0, 3))
+    if k == 0:
+        return float(lo)
+    if k == 1:
+        return float(hi)
+    t = rng.random()
+    return min(max((1.0 - t) * float(lo) + t * float(hi), float(lo)), float(hi))
+
+
+@pytest.mark.parametrize("op", ["abs", "sqrt", "add", "sub", "mul", "div"])
+def test_reference_efloat_bounds_contain_the_exact_result(orc, op):
+    """tests/efloat.rs:51-154: for 10 000 seeded trials per operation the interval of the EFloat result contains the f64 result of exact operands drawn from the
+    operands' intervals. (`test_efloat_sqrt` of the reference checks abs() again - :66-79 - so here sqrt is checked for what it is, on |a|.)"""
+    L = orc.lib()
+    L.orc_efloat_op.restype = None
+    L.orc_efloat_op.argtypes = [C.c_int, C.c_float, C.c_float, C.c_float, C.c_float, C.c_void_p, C.c_void_p]
+    code = ["abs", "sqrt", "add", "sub", "mul", "div"].index(op)
+    out, inb = np.zeros(3, np.float32), np.zeros(4, np.float32)
+    for trial in range(10000):
+        rng = np.random.default_rng(trial)
+        av, ae = _efloat_draw(rng)
+        bv, be = _efloat_draw(rng) if code >= 2 else (np.float32(1.0), np.float32(0.0))
+        if op == "sqrt":  # the square root of an interval that reaches below zero is NaN in the reference too (its own test never calls sqrt): positive operands
+            av = np.abs(av); ae = min(ae, np.float32(0.5) * av)
+        L.orc_efloat_op(code, float(av), float(ae), float(bv), float(be), _f(out), _f(inb))
+        ap = _precise(rng, inb[0], inb[1])
+        bp = _precise(rng, inb[2], inb[3]) if code >= 2 else 1.0
+        if op == "div" and inb[2] < 0 < inb[3]:
+            assert out[1] == -np.inf and out[2] == np.inf  # a divisor interval that straddles zero: the whole line (efloat.rs:196-199)
+            continue
+        if op == "div" and bp == 0:
+            continue
+        exact = {"abs": lambda: abs(ap), "sqrt": lambda: float(np.sqrt(ap)), "add": lambda: ap + bp, "sub": lambda: ap - bp, "mul": lambda: ap * bp, "div": lambda: ap / bp}[op]()
+        assert float(out[1]) <= exact <= float(out[2]), (trial, av, ae, bv, be, out, exact)
+        assert out[1] <= out[0] <= out[2]  # EFloat::check
