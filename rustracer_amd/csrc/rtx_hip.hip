@@ -63,6 +63,7 @@ struct rt_scene {
   DevBuf top_pairs, deep_stack; bool use_top = false;  // k_trace_top: LDS-resident top of the tree, HBM spill of stack entries beyond the LDS ones
   bool top_for_closest = false;  // closest-hit rays through k_trace_top as well (shadow rays always, when no four-wide records exist)
   bool use_pairs = false;
+  bool deep_column = false;  // top level + deepest object need more than 64 stack entries in one column: k_trace_big with 128
   DevBuf quads; bool use_quads = false; int quad_stack_depth = 0;  // four-wide records of the any-hit kernel (k_trace_quad)
   DevBuf tri_rec;  // per-triangle shade records (k_tri_records)
   DevBuf nodes, tri_p, tri_n, tri_uv, tri_s, tri_alpha, spheres, textures, images, materials, lights, texels, dist, guides;
@@ -509,11 +510,13 @@ extern "C" int rt_scene_create(const rt_scene_desc* desc, int device, rt_scene**
       if (in.n_nodes) max_obj = std::max(max_obj, od + 1);
     }
     // an object's walk uses the entries of the lane's stack column above the top level's pending ones: the column holds both
-    if (s->stack_depth + max_obj > 64) { delete s; return fail(RT_ERR_INVALID, "top-level BVH plus the deepest object BVH exceed the 64-entry traversal stack"); }
+    // The reference gives each BVH a 64-entry stack of its own (bvh/mod.rs:374), so a 36-deep top level over a 30-deep object is a valid scene: past 64 entries
+    // in one column the scene is traced by the one-node-per-step kernel with a 128-entry column (k_trace_big<.., 64, 128>; no pair / four-wide records)
     s->stack_depth += max_obj; max_obj_depth = max_obj;
+    s->deep_column = s->stack_depth > 64;
   }
   d.pairs = nullptr; d.quads = nullptr; d.obj_pairs = 0;
-  if (!s->small) {  // LDS-resident scenes keep the one-node-per-step loop: the pair form measured no faster there
+  if (!s->small && !s->deep_column) {  // LDS-resident scenes keep the one-node-per-step loop: the pair form measured no faster there
     // With object instances the records cover the top-level tree (objects are walked one node per step, their child offsets are relative to the object).
     // A leaf of a GENERAL scene that holds anything but plain triangles carries RT_PAIR_GENERAL.
     const uint32_t n_pair_nodes = n_top_nodes;
@@ -876,7 +879,8 @@ static void launch_trace_c(rt_scene* s, const TraceIO& io, const unsigned* queue
 #undef RT_GEN_LAUNCH3
 #undef RT_GEN_LAUNCH
     }
-    if (s->stack_depth <= 32) hipLaunchKernelGGL((k_trace_big<ANY, COUNT, 128, 32, true>), dim3(trace_grid<ANY, false, 128, 32>(s)), dim3(128), 0, stream, s->d, io, queue, count_ptr, shard_cap, count_static, stats, st_rays, st_nodes, st_tris);
+    if (s->stack_depth > 64) hipLaunchKernelGGL((k_trace_big<ANY, COUNT, 64, 128, true>), dim3(trace_grid<ANY, false, 64, 128>(s)), dim3(64), 0, stream, s->d, io, queue, count_ptr, shard_cap, count_static, stats, st_rays, st_nodes, st_tris);
+    else if (s->stack_depth <= 32) hipLaunchKernelGGL((k_trace_big<ANY, COUNT, 128, 32, true>), dim3(trace_grid<ANY, false, 128, 32>(s)), dim3(128), 0, stream, s->d, io, queue, count_ptr, shard_cap, count_static, stats, st_rays, st_nodes, st_tris);
     else hipLaunchKernelGGL((k_trace_big<ANY, COUNT, 128, 64, true>), dim3(trace_grid<ANY, false, 128, 64>(s)), dim3(128), 0, stream, s->d, io, queue, count_ptr, shard_cap, count_static, stats, st_rays, st_nodes, st_tris);
     return;
   }

@@ -580,7 +580,7 @@ bool b44_uncompress(const uint8_t* src, size_t size, const std::vector<ExrChan>&
       for (size_t x = 0; x < w; x += 4) {
         uint16_t s[16];
         if (p + 3 > size) { err = "EXR: truncated B44 block"; return false; }
-        if (src[p + 2] == 0xfc) {
+        if (src[p + 2] >= (13 << 2)) {  // a shift field >= 13 marks a 3-byte flat cell (ImfB44Compressor: the encoder writes 0xfc, any such value decodes as flat)
           uint16_t v = (uint16_t)((src[p] << 8) | src[p + 1]); v = (v & 0x8000u) ? (uint16_t)(v & 0x7fffu) : (uint16_t)~v;
           for (int i = 0; i < 16; ++i) s[i] = v;
           p += 3;
@@ -706,6 +706,10 @@ bool exr_decode(const std::vector<uint8_t>& file, int& W, int& H, std::vector<fl
   // chunks that hold full-resolution pixels: every scan-line block, or the tiles of level (0, 0) - which the offset table lists first
   const long long tiles_x = pt.tiled ? (w + pt.tile_w - 1) / pt.tile_w : 1, tiles_y = pt.tiled ? (h + pt.tile_h - 1) / pt.tile_h : 0;
   const size_t n_read = pt.tiled ? (size_t)(tiles_x * tiles_y) : (size_t)n_chunks[part];
+  // the part's own table must hold every chunk that is read (a multi-part file states its chunkCount; a patched one could name fewer entries than the data
+  // window needs and the loop below would index past the table - and past the file); a scan-line part has exactly ceil(h / lines per block) blocks
+  if ((unsigned long long)n_chunks[part] < (unsigned long long)n_read ||
+      (!pt.tiled && (long long)n_chunks[part] != (h + lines_of(compression) - 1) / lines_of(compression))) { err = "EXR: truncated offset table"; return false; }
   const int lines_per_block = lines_of(compression);
   std::vector<uint8_t> raw;
   for (size_t blk = 0; blk < n_read; ++blk) {

@@ -221,3 +221,60 @@ def test_instances_beside_quadrics_and_masked_meshes(gpu_host, orc, extra):
     assert np.array_equal(fo[..., 3], fh[..., 3]) and rel_l2(gpu_host.film_to_rgb(fh), orc.film_to_rgb(fo)) < 1e-3
     for k in ("rays_closest", "rays_shadow", "rays_mis"):
         assert abs(int(sh[k]) - int(so[k])) <= 2e-3 * int(so[k]) + 16, (k, sh[k], so[k])
+
+
+def _chain_mesh(n, material, base=13.0):
+    """n triangles at x = 13^k, each as large as its x: of the SAH's 12 buckets the last holds the largest triangle alone and the first all the others
+    (13^(n-1) / 13^n < 1 / 12), so every split peels one triangle off and the tree is a chain n - 1 deep."""
+    P, idx = [], []
+    for k in range(n):
+        x = float(base ** k)
+        P += [[x, 0.0, 0.0], [x, x, 0.0], [x, 0.0, x]]
+        idx.append([3 * k, 3 * k + 1, 3 * k + 2])
+    return dict(P=np.float32(P), idx=idx, material=material)
+
+
+def _depth(b, first, n_nodes):
+    d = np.zeros(n_nodes, int)
+    for i in range(n_nodes):
+        if b["n_prims"][first + i] == 0:
+            d[i + 1] = d[i] + 1; d[int(b["offset"][first + i])] = d[i] + 1
+    return int(d.max())
+
+
+def test_top_level_plus_object_deeper_than_one_64_entry_stack(gpu_host, orc):
+    """the reference gives each BVH its own 64-entry stack (bvh/mod.rs:374), so a deep top level over a deep object is a valid scene even when the
+    two depths add up to more than 64 (round 3 refused it). It is traced by the one-node-per-step kernel with a 128-entry column; hit records equal the oracle's."""
+    from rustracer_amd.scene_desc import SceneDesc
+    s = SceneDesc()
+    m = s.matte((0.5, 0.5, 0.5))
+    top = _chain_mesh(35, m)
+    s.add_mesh(top["P"], top["idx"], m)
+    o = s.add_object([_chain_mesh(35, m)])
+    xf = np.eye(4, dtype=np.float32); xf[:3, 3] = (0.0, 0.0, 0.0); xf[0, 0] = 0.5  # the object's triangles at x = 13^k / 2
+    s.add_instance(o, xf)
+    oc = orc.OracleScene(s)
+    alone = SceneDesc(); alone.add_mesh(top["P"], top["idx"], alone.matte((0.5, 0.5, 0.5)))
+    ba = orc.OracleScene(alone).bvh()
+    assert 2 * (_depth(ba, 0, len(ba["offset"])) + 1) > 64   # each of the two trees needs 35 entries
+    h = gpu_host.HostScene(s)
+    bo, bh = oc.bvh(), h.bvh()
+    assert all(np.array_equal(bo[k], bh[k]) for k in bo)
+    rng = np.random.default_rng(21)
+    n = 20000
+    rays = np.zeros((n, 8), np.float32)
+    k = rng.integers(0, 35, n)
+    x = 13.0 ** k * np.where(rng.random(n) < 0.5, 1.0, 0.5)
+    a = rng.uniform(0.05, 0.45, n); b = rng.uniform(0.05, 0.45, n)
+    target = np.stack([x, a * 13.0 ** k, b * 13.0 ** k], -1)
+    origin = target + np.stack([rng.choice([-1.0, 1.0], n) * 13.0 ** np.minimum(rng.uniform(k - 2, k + 2), 33.5), rng.normal(0, 0.3, n) * 13.0 ** k, rng.normal(0, 0.3, n) * 13.0 ** k], -1)
+    rays[:, 0:3] = origin; rays[:, 3] = np.inf; rays[:, 4:7] = target - origin
+    ro = oc.trace(rays)
+    assert (ro["prim"] >= 0).mean() > 0.5 and len(np.unique(ro["prim"])) > 40
+    for count in (True, False):
+        rh = h.trace(rays, count=count)
+        assert np.array_equal(ro["prim"], rh["prim"]) and np.array_equal(bits(ro["t"]), bits(rh["t"]))
+    rh = h.trace(rays)
+    assert (ro["nodes"], ro["tris"]) == (rh["nodes"], rh["tris"])
+    ao, ah = oc.trace(rays, True), h.trace(rays, True, count=False)
+    assert np.array_equal(ao["occluded"], ah["occluded"])

@@ -235,7 +235,7 @@ def test_reference_sphere_reintersection_property_holds_on_the_device(gpu_host, 
     L = orc.lib()
     L.orc_sphere_reintersect.restype = C.c_int
     L.orc_sphere_reintersect.argtypes = [C.c_float, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]
-    tested = 0
+    tested = missed_box = 0
     for i in range(0, 1000, 4):  # every fourth of the reference's 1000 spheres: a scene is created per sphere
         radius, ray, u = sphere_reintersect_case(i)
         out = np.zeros((len(u), 8), np.float32)
@@ -244,13 +244,16 @@ def test_reference_sphere_reintersection_property_holds_on_the_device(gpu_host, 
         d.add_sphere((0.0, 0.0, 0.0), radius, d.matte((0.5, 0.5, 0.5)))
         h = gpu_host.HostScene(d)
         first = h.trace(ray[None, :], count=False)
-        assert (first["prim"][0] >= 0) == (r >= 0), (i, radius, ray)
+        ro = orc.OracleScene(d).trace(ray[None, :])   # the same query on the oracle: Scene::intersect, i.e. the sphere behind its box in a one-leaf BVH
+        assert np.array_equal(ro["prim"], first["prim"]) and np.array_equal(bits(ro["t"]), bits(first["t"])), (i, radius, ray)
         if r < 0:
+            assert first["prim"][0] < 0
             continue
-        ro = orc.OracleScene(d).trace(ray[None, :])
-        assert np.array_equal(bits(ro["t"]), bits(first["t"]))
+        if first["prim"][0] < 0:  # the shape is hit but its box is not: Bounds3::intersect_p_fast without the 1 + 2 gamma(3) widening (reference quirk 3) on a
+            missed_box += 1       # sphere of radius 1e-4 seen from 1e7 away. Oracle and device agree (asserted above); the property below needs a hit.
+            continue
         assert r == 0
         assert not h.trace(out, True, count=False)["occluded"].any(), (i, radius)
         assert (h.trace(out, count=False)["prim"] < 0).all(), (i, radius)
         tested += 1
-    assert tested > 150
+    assert tested > 150 and missed_box < 10

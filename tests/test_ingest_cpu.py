@@ -333,6 +333,41 @@ def test_openexr_multi_part_files(ingest, tmp_path):
         assert np.array_equal(ingest.read_image(path), a)
 
 
+def test_openexr_patched_chunk_count_is_refused(ingest, host, tmp_path):
+    """a multi-part file states each part's chunkCount; one that names fewer chunks than the data window needs must fail as a truncated offset
+    table, not index past the table (tiled parts) or leave rows black (scan-line parts)."""
+    a = np.random.default_rng(10).random((21, 17, 3), dtype=np.float32)
+    for tiles in (None, (8, 8)):
+        path = str(tmp_path / "patched.exr")
+        ingest.write_exr(path, a, "none", "float", parts_before=(("Z",),), tiles=tiles)
+        raw = bytearray(open(path, "rb").read())
+        key = b"chunkCount\0int\0" + (4).to_bytes(4, "little")
+        i = raw.index(key, raw.index(key) + 1) + len(key)          # the second part's (the RGB part's) chunkCount
+        n = int.from_bytes(raw[i:i + 4], "little")
+        assert n == (21 if tiles is None else 9)
+        raw[i:i + 4] = (1).to_bytes(4, "little")
+        open(path, "wb").write(raw)
+        with pytest.raises(host.BackendError, match="truncated offset table"):
+            ingest.read_image(path)
+
+
+def test_openexr_b44_flat_cell_is_any_shift_of_13_or_more(ingest, tmp_path):
+    """a B44 cell whose third byte is >= 13 << 2 is a 3-byte flat cell whatever its low bits; this writer emits 0xfc, other encoders need not."""
+    a = np.full((8, 8, 3), 0.25, np.float32)
+    path = str(tmp_path / "flat.exr")
+    ingest.write_exr(path, a, "b44a", "half")
+    want = ingest.read_image(path)
+    raw = bytearray(open(path, "rb").read())
+    hits = [i for i in range(len(raw) - 2) if raw[i + 2] == 0xfc and raw[i:i + 2] == raw[i + 3:i + 5] and i + 5 < len(raw) and raw[i + 5] == 0xfc]
+    assert hits, "no run of flat cells found in the block"
+    k = hits[0]
+    while k + 2 < len(raw) and raw[k + 2] == 0xfc and raw[k:k + 2] == raw[hits[0]:hits[0] + 2]:
+        raw[k + 2] = 0x34 | (k & 3)   # shift 13 with arbitrary low bits
+        k += 3
+    open(path, "wb").write(raw)
+    assert np.array_equal(ingest.read_image(path), want)
+
+
 def test_openexr_named_layer_and_refusals(ingest, host, tmp_path):
     a = np.random.default_rng(3).random((8, 8, 3), dtype=np.float32)
     path = str(tmp_path / "layer.exr")
