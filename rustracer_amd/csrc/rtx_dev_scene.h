@@ -60,6 +60,7 @@ struct DScene {
   // This record in device memory. A kernel takes its DScene by value (fields in SGPRs); an out-of-line device function that wants the scene is handed
   // `*sc.self` instead of `sc`: a reference to the kernel argument would force a 300-byte private copy of it into every lane's scratch, read back
   // lane by lane at each use (k_shade<3> on S4 moved 4 KB per vertex between L2 and memory, most of it scratch).
+  int route_quadric_hits;  // k_bin_count: vertices on analytic quadrics go to a bin of their own in the generic range (scenes shaded by the QLIGHTS forms of k_shade)
   const DScene* self;
 #ifdef RT_ABLATE
   int dbg;  // measurement builds only (make ABLATE=1): bits switch parts of the shade kernel off to see what they cost; images are wrong

@@ -294,19 +294,8 @@ RT_DEV SpherePoint quadric_default_sample_si(const DSphere& s, const Interaction
   pdf_out = pdf;
   return it;
 }
-RT_DEVN SpherePoint sphere_sample_si(const DSphere& s, const Interaction& ref, f2 u, float& pdf_out) {  // Sphere::sample_si, :246-308
-  if (s.kind != 0) return quadric_default_sample_si(s, ref, u, pdf_out);
-  const f3 p_center = xf34_point(s.o2w, mk3(0, 0, 0));
-  const f3 p_origin = offset_ray_origin(ref.p, ref.p_error, ref.n, p_center - ref.p);
-  if (distance_squared(p_origin, p_center) <= s.radius * s.radius) {
-    float pdf; SpherePoint intr = sphere_sample(s, u, pdf);
-    f3 wi = intr.p - ref.p;
-    if (len2(wi) == 0.0f) pdf = 0.0f;
-    else { wi = normalize(wi); pdf *= distance_squared(ref.p, intr.p) / fabsf(dot(intr.n, -wi)); }
-    if (isinf(pdf)) pdf = 0.0f;
-    pdf_out = pdf;
-    return intr;
-  }
+// The branch of Sphere::sample_si for a reference point OUTSIDE the sphere (sphere.rs:264-308): uniform sampling of the cone the sphere subtends.
+RT_DEV SpherePoint sphere_cone_sample_si(const DSphere& s, f3 p_center, const Interaction& ref, f2 u, float& pdf_out) {
   const f3 wc = normalize(p_center - ref.p); f3 wc_x, wc_y;
   coordinate_system(wc, wc_x, wc_y);
   const float sin_theta_max_2 = s.radius * s.radius / distance_squared(ref.p, p_center);
@@ -328,6 +317,27 @@ RT_DEVN SpherePoint sphere_sample_si(const DSphere& s, const Interaction& ref, f
   pdf_out = 1.0f / (2.0f * kPi * (1.0f - cos_theta_max));  // uniform cone pdf
   return it;
 }
+// ... and of Sphere::pdf_wi (sphere.rs:325-333): the cone's uniform density, whatever wi is
+RT_DEV float sphere_cone_pdf_wi(const DSphere& s, f3 p_center, const Interaction& ref) {
+  const float sin_theta_max_2 = s.radius * s.radius / distance_squared(ref.p, p_center);
+  const float cos_theta_max = sqrtf(fmaxf(0.0f, 1.0f - sin_theta_max_2));
+  return 1.0f / (2.0f * kPi * (1.0f - cos_theta_max));  // uniform_cone_pdf, sampling/mod.rs:54-56
+}
+RT_DEVN SpherePoint sphere_sample_si(const DSphere& s, const Interaction& ref, f2 u, float& pdf_out) {  // Sphere::sample_si, :246-308
+  if (s.kind != 0) return quadric_default_sample_si(s, ref, u, pdf_out);
+  const f3 p_center = xf34_point(s.o2w, mk3(0, 0, 0));
+  const f3 p_origin = offset_ray_origin(ref.p, ref.p_error, ref.n, p_center - ref.p);
+  if (distance_squared(p_origin, p_center) <= s.radius * s.radius) {
+    float pdf; SpherePoint intr = sphere_sample(s, u, pdf);
+    f3 wi = intr.p - ref.p;
+    if (len2(wi) == 0.0f) pdf = 0.0f;
+    else { wi = normalize(wi); pdf *= distance_squared(ref.p, intr.p) / fabsf(dot(intr.n, -wi)); }
+    if (isinf(pdf)) pdf = 0.0f;
+    pdf_out = pdf;
+    return intr;
+  }
+  return sphere_cone_sample_si(s, p_center, ref, u, pdf_out);
+}
 RT_DEVN float sphere_pdf_wi(const DSphere& s, const Interaction& ref, f3 wi) {  // Sphere::pdf_wi, :310-334; disk / cylinder: the trait default, shapes/mod.rs:59-68
   const f3 p_center = xf34_point(s.o2w, mk3(0, 0, 0));
   const f3 p_origin = offset_ray_origin(ref.p, ref.p_error, ref.n, p_center - ref.p);
@@ -337,9 +347,7 @@ RT_DEVN float sphere_pdf_wi(const DSphere& s, const Interaction& ref, f3 wi) {  
     if (!sphere_intersect<true>(s, ro, wi, kInf, t, &li)) return 0.0f;
     return distance_squared(ref.p, li.hit.p) / (fabsf(dot(li.hit.n, -wi)) * sphere_area(s));
   }
-  const float sin_theta_max_2 = s.radius * s.radius / distance_squared(ref.p, p_center);
-  const float cos_theta_max = sqrtf(fmaxf(0.0f, 1.0f - sin_theta_max_2));
-  return 1.0f / (2.0f * kPi * (1.0f - cos_theta_max));  // uniform_cone_pdf, sampling/mod.rs:54-56
+  return sphere_cone_pdf_wi(s, p_center, ref);
 }
 
 }  // namespace rtx

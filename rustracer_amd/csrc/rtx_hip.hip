@@ -56,6 +56,7 @@ struct rt_scene {
   bool small = false;
   bool lambert_materials = false;  // the material half of lambert_only: with other light kinds k_shade<3>
   bool lambert_only = false;  // every material is matte{constant Kd, sigma == 0} and every light an area light: k_shade<1>
+  bool lean_qlights = false;  // LEAN with sphere lights: the QLIGHTS forms of k_shade<3 | 5 | 6>, quadric hits routed to the generic kernel
   bool lean_shade = false;    // every light an area light on a triangle and every texture a constant: the LEAN forms of k_shade<3 | 5 | 6> (no out-of-line evaluator, three waves)
   int stack_depth = 64;  // entries the to-visit stack needs for this tree (<= 64, rc/bvh/mod.rs:374)
   unsigned n_nodes = 0, n_tris = 0; int n_lights = 0;
@@ -124,6 +125,50 @@ static void fill_ewa_lut() {
 
 static size_t tmin_stack_bytes(const rt_scene* s);
 static size_t deep_stack_bytes(const rt_scene* s);
+// Is every quadric that carries an area light a Sphere (kind 0) that no triangle of the scene reaches into? Then a path vertex on a triangle lies outside
+// every emitter sphere, and Sphere::sample_si / Sphere::pdf_wi (rc/shapes/sphere.rs:246-334) take their cone branches for it: `distance_squared(p_origin,
+// p_center) <= radius^2` - the reference's own inside test, world-space distance against the object-space radius - is false with a margin of 1e-3 radius
+// (p_origin is the vertex moved by its error bounds, orders of magnitude less). Exact point-triangle distances in double; gives up (false) beyond 2e8 pairs.
+static bool sphere_lights_clear(const rt_scene_desc* desc) {
+  std::vector<uint32_t> emitters;
+  for (uint32_t i = 0; i < desc->n_lights; ++i) {
+    const rt_light& l = desc->lights[i];
+    if (l.kind != RT_LIGHT_DIFFUSE_AREA || l.prim < 0 || (uint32_t)l.prim >= desc->n_tris) continue;
+    if (!(desc->tri_meta[l.prim].flags & RT_PRIM_SPHERE)) continue;
+    uint32_t k; memcpy(&k, &desc->tri_p[9 * (size_t)l.prim + 6], 4);  // a quadric's leaf record: its index in p2.x
+    if (k >= desc->n_spheres || desc->spheres[k].kind != 0) return false;
+    emitters.push_back(k);
+  }
+  if ((double)emitters.size() * (double)desc->n_tris > 2e8) return false;
+  for (uint32_t k : emitters) {
+    const rt_sphere& sp = desc->spheres[k];
+    const double c[3] = {sp.o2w[3], sp.o2w[7], sp.o2w[11]};
+    const double r = (double)sp.radius * 1.001 + 1e-6 * std::max(std::max(fabs(c[0]), fabs(c[1])), fabs(c[2])), r2 = r * r;
+    for (uint32_t t = 0; t < desc->n_tris; ++t) {
+      if (desc->tri_meta[t].flags & (RT_PRIM_SPHERE | RT_PRIM_INSTANCE)) continue;
+      const float* q = desc->tri_p + 9 * (size_t)t;
+      // closest point of triangle (a, b, c) to p (Ericson, Real-Time Collision Detection 5.1.5), relative to p
+      double a[3], b[3], cc[3];
+      for (int j = 0; j < 3; ++j) { a[j] = q[j] - c[j]; b[j] = q[3 + j] - c[j]; cc[j] = q[6 + j] - c[j]; }
+      auto dot3 = [](const double* x, const double* y) { return x[0] * y[0] + x[1] * y[1] + x[2] * y[2]; };
+      double ab[3], ac[3]; for (int j = 0; j < 3; ++j) { ab[j] = b[j] - a[j]; ac[j] = cc[j] - a[j]; }
+      double best[3];
+      const double d1 = -dot3(ab, a), d2 = -dot3(ac, a);
+      const double d3 = -dot3(ab, b), d4 = -dot3(ac, b), d5 = -dot3(ab, cc), d6 = -dot3(ac, cc);
+      const double vc = d1 * d4 - d3 * d2, vb = d5 * d2 - d1 * d6, va = d3 * d6 - d5 * d4;
+      if (d1 <= 0 && d2 <= 0) { for (int j = 0; j < 3; ++j) best[j] = a[j]; }
+      else if (d3 >= 0 && d4 <= d3) { for (int j = 0; j < 3; ++j) best[j] = b[j]; }
+      else if (vc <= 0 && d1 >= 0 && d3 <= 0) { const double v = d1 / (d1 - d3); for (int j = 0; j < 3; ++j) best[j] = a[j] + v * ab[j]; }
+      else if (d6 >= 0 && d5 <= d6) { for (int j = 0; j < 3; ++j) best[j] = cc[j]; }
+      else if (vb <= 0 && d2 >= 0 && d6 <= 0) { const double w = d2 / (d2 - d6); for (int j = 0; j < 3; ++j) best[j] = a[j] + w * ac[j]; }
+      else if (va <= 0 && (d4 - d3) >= 0 && (d5 - d6) >= 0) { const double w = (d4 - d3) / ((d4 - d3) + (d5 - d6)); for (int j = 0; j < 3; ++j) best[j] = b[j] + w * (cc[j] - b[j]); }
+      else { const double den = 1.0 / (va + vb + vc), v = vb * den, w = vc * den; for (int j = 0; j < 3; ++j) best[j] = a[j] + ab[j] * v + ac[j] * w; }
+      if (!(dot3(best, best) > r2)) return false;  // (a NaN vertex fails too)
+    }
+  }
+  return true;
+}
+
 extern "C" int rt_scene_create(const rt_scene_desc* desc, int device, rt_scene** out) {
   if (!desc || !out) return fail(RT_ERR_INVALID, "null argument");
   if (!rt_device_available()) return fail(RT_ERR_NO_DEVICE, "no HIP device visible; this backend has no CPU fallback");
@@ -479,6 +524,17 @@ extern "C" int rt_scene_create(const rt_scene_desc* desc, int device, rt_scene**
   s->lean_shade = !s->masked_emitters;
   for (uint32_t i = 0; i < desc->n_lights; ++i) if (desc->lights[i].kind != RT_LIGHT_DIFFUSE_AREA) s->lean_shade = false;
   for (uint32_t i = 0; i < desc->n_textures; ++i) if (desc->textures[i].kind != RT_TEX_CONST) s->lean_shade = false;
+  // The LEAN forms with sphere lights (QLIGHTS): constant textures, every light a diffuse area light on a triangle or on a Sphere that no triangle reaches
+  // into, no masks, no instances. Vertices on quadrics are binned apart and shaded by the generic GENERAL kernel (route_quadric_hits), so the scene must be
+  // one whose shade queue is binned (several material classes - rt_render checks that).
+  s->lean_qlights = false;
+  if (s->has_spheres && !s->has_instances && !s->has_masks) {
+    bool ok = true;
+    for (uint32_t i = 0; i < desc->n_lights; ++i) if (desc->lights[i].kind != RT_LIGHT_DIFFUSE_AREA) ok = false;
+    for (uint32_t i = 0; i < desc->n_textures; ++i) if (desc->textures[i].kind != RT_TEX_CONST) ok = false;
+    static const bool off = getenv("RTX_SHADE_QLIGHTS") && getenv("RTX_SHADE_QLIGHTS")[0] == '0';  // measurement knob: the GENERAL forms as in round 3
+    s->lean_qlights = ok && !off && sphere_lights_clear(desc);
+  }
   if (s->masked_emitters) s->lambert_only = false;  // (the constant-matte kernel has no GENERAL form: such scenes shade through the Lambert front-end k_shade<3, true>)
   s->n_materials = desc->n_materials;
   s->small = desc->n_nodes <= RT_SMALL_NODES && desc->n_tris <= RT_SMALL_TRIS && !s->has_instances;  // quadrics and masked triangles: the GENERAL form of the LDS kernel
@@ -657,6 +713,7 @@ extern "C" int rt_scene_create(const rt_scene_desc* desc, int device, rt_scene**
   if (n_all_lights) hipLaunchKernelGGL(k_light_consts, dim3((n_all_lights + 255u) / 256u), dim3(256), 0, nullptr, d, s->lights.as<DLight>(), (int)n_all_lights);
   if (hipGetLastError() != hipSuccess) { delete s; return fail(RT_ERR_HIP, "constant precomputation launch failed"); }
   if (s->self.ensure(sizeof(DScene)) != hipSuccess) { delete s; return fail(RT_ERR_OOM, "scene record allocation failed"); }
+  d.route_quadric_hits = (s->lean_qlights && s->n_code_classes > 1 && !s->lambert_materials) ? 1 : 0;  // (the condition of rt_render's use_bins)
   d.self = s->self.as<DScene>();
   HIP_TRY(hipMemcpy(s->self.p, &d, sizeof(DScene), hipMemcpyHostToDevice));
   HIP_TRY(hipDeviceSynchronize());
@@ -1096,7 +1153,9 @@ struct KTimer {  // HIP-event kernel timing on the render stream; events come fr
 // one shade launch of front-end MODE: the GENERAL form (quadric / instance hits, masked emitters), the LEAN form (area lights and constant textures only;
 // front-ends 3 / 5 / 6), or the plain one
 template <int MODE>
-static void launch_shade(bool general, bool lean, bool bounced, unsigned grid, unsigned block, hipStream_t stream, const DScene& d, const FrameParams& fp, const PassState& p) {
+static void launch_shade(bool general, bool lean, bool bounced, unsigned grid, unsigned block, hipStream_t stream, const DScene& d, const FrameParams& fp, const PassState& p, bool qlights = false) {
+  // sphere lights over constant textures: the front-end ranges hold triangle vertices only (quadric hits are binned into the generic range)
+  if constexpr (MODE != 0) { if (qlights) { hipLaunchKernelGGL((k_shade<MODE, false, true, false, true>), dim3(grid), dim3(block), 0, stream, d, fp, p); return; } }
   if (general) { hipLaunchKernelGGL((k_shade<MODE, true>), dim3(grid), dim3(block), 0, stream, d, fp, p); return; }
   if constexpr (MODE != 0) { if (lean) { hipLaunchKernelGGL((k_shade<MODE, false, true>), dim3(grid), dim3(block), 0, stream, d, fp, p); return; } }
   // the Lambert front-end past the camera vertices: no differentials, bilinear image lookups, everything inline under a three-wave bound
@@ -1176,7 +1235,8 @@ extern "C" int rt_render(rt_scene* s, const rt_camera* cam, const rt_film_desc* 
   static const bool lean_off = getenv("RTX_SHADE_LEAN") && getenv("RTX_SHADE_LEAN")[0] == '0';  // measurement knob
   const bool lean_shade = s->lean_shade && !lean_off;
   static const bool bounced_off = getenv("RTX_SHADE_BOUNCED") && getenv("RTX_SHADE_BOUNCED")[0] == '0';  // measurement knob
-  const unsigned n_bins = std::min<unsigned>(s->n_code_classes, RT_BIN_MAX) + 1u;
+  const bool qlights = s->d.route_quadric_hits != 0 && use_bins;  // QLIGHTS forms on the front-end ranges, quadric hits in a generic bin of their own
+  const unsigned n_bins = std::min<unsigned>(s->n_code_classes, RT_BIN_MAX - 1) + 1u + (qlights ? 1u : 0u);
   const size_t bin_stride = (RT_BIN_MAX + 1) + (size_t)(RT_BIN_MAX + 1) * RT_CNT_STRIDE + (size_t)RT_QSHARDS * RT_CNT_STRIDE + 10;  // hist, cursors (spread), the sorted queue's counts (laid out as shard counters)  // + {begin, end} of the four class ranges and of the miss bin
   // RTX_SHADE_SPLIT (measurement knob): 0 = every class through the generic front-end, 1 = Lambert classes apart, default = Lambert and two-lobe classes apart
   const int split_mode = getenv("RTX_SHADE_SPLIT") ? atoi(getenv("RTX_SHADE_SPLIT")) : 2;
@@ -1326,7 +1386,7 @@ extern "C" int rt_render(rt_scene* s, const rt_camera* cam, const rt_film_desc* 
         // the rays of the bounce sit at their queue slots: the kernels walk the entries by the shard counts alone (a non-NULL `queue` only says "sharded")
         launch_trace<false>(s, count, io_path, ps.cnt_in, ps.cnt_in, ps.shard_cap, ps.cap, dstats, ST_RAYS_CLOSEST, ST_NODES_CLOSEST, ST_TRIS_CLOSEST, stream);
         tm.end();
-#define RT_SHADE(MODE, P) launch_shade<MODE>(gshade, lean_shade, bounce >= 1 && !bounced_off, sgrid, sblock, stream, s->d, fp, P)
+#define RT_SHADE(MODE, P) launch_shade<MODE>(gshade, lean_shade, bounce >= 1 && !bounced_off, sgrid, sblock, stream, s->d, fp, P, qlights)
         if (s->lambert_only) { tm.begin(&stats.ms_shade_lambert_const); hipLaunchKernelGGL(k_shade<1>, dim3(sgrid), dim3(sblock), 0, stream, s->d, fp, ps); tm.end(); }
         else if (s->lambert_materials) { tm.begin(&stats.ms_shade_lambert); RT_SHADE(3, ps); tm.end(); }
         else if (!use_bins) { tm.begin(&stats.ms_shade_generic); RT_SHADE(0, ps); tm.end(); }

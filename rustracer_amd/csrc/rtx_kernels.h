@@ -1362,6 +1362,13 @@ RT_DEV unsigned bin_of(const DScene& sc, const DMaterial* __restrict__ materials
   int prim = __float_as_int(hit[slot].y);
   if (prim < 0) return n_bins - 1u;
   prim = hit_primitive(sc.instances, sc.n_instances, sc.n_top_prims, prim);
+  // route_quadric_hits: the bin before the miss bin collects the vertices on analytic quadrics, whatever their material - it lies in the generic range, so the
+  // register-resident front-ends of such a scene (QLIGHTS forms) see triangles only and need no Sphere::intersect to rebuild an interaction
+  if (sc.route_quadric_hits) {
+    if (rec_flags(tri_p, prim) & RT_FLAG_SPHERE) return n_bins - 2u;
+    const unsigned m = (unsigned)materials[rec_material(tri_p, prim)].code_class;
+    return m < n_bins - 2u ? m : n_bins - 3u;
+  }
   const unsigned m = (unsigned)materials[rec_material(tri_p, prim)].code_class;
   return m < n_bins - 1u ? m : n_bins - 2u;
 }
@@ -1729,7 +1736,12 @@ RT_DEVN int instance_fill_interaction(const DScene& sc, unsigned hit_id, float o
 // (4 / 12 spilled dwords in the two-lobe forms) instead of 208 / 230 / 236 at two waves.
 // BOUNCED (front-end 3, launches of bounces >= 1): no vertex of the launch is a camera vertex, so no differentials exist, image maps are level-0 bilinear lookups
 // (inline) and the light evaluators are taken inline too: 183 VGPRs of its own, 168 under the three-wave bound with 5 spilled dwords.
-template <int MODE, bool GENERAL = false, bool LEAN = false, bool BOUNCED = false>
+// QLIGHTS (with LEAN, round 4): the LEAN form for scenes whose area lights may sit on analytic spheres - what veach-mis.pbrt is. The launch holds vertices on
+// TRIANGLES only (k_bin_count sends every quadric hit to the generic bin, DScene::route_quadric_hits) and the host has checked that no triangle reaches into
+// an emitter sphere (rt_scene_create: sphere_lights_clear), so Sphere::sample_si and Sphere::pdf_wi only ever take their cone branches (sphere.rs:264-308,
+// 325-333) - inlined here, no out-of-line evaluator, three waves per SIMD like the other LEAN forms. Round 3 shaded such scenes through the GENERAL forms:
+// 256 VGPRs and 352 - 448 B of scratch.
+template <int MODE, bool GENERAL = false, bool LEAN = false, bool BOUNCED = false, bool QLIGHTS = false>
 __global__ void __launch_bounds__(256, (MODE == 1 || LEAN || BOUNCED) ? ((LEAN || BOUNCED) ? 3 : RT_SHADE_MIN_WAVES) : (MODE == 3 && !GENERAL ? RT_SHADE3_MIN_WAVES : RT_SHADE0_MIN_WAVES)) k_shade(DScene sc, FrameParams fp, PassState ps) {
   QView qv; if (ps.cnt_in) qv.init(ps.q_in, ps.cnt_in, ps.shard_cap);
   unsigned first = 0, count = ps.cnt_in ? qv.total() : ps.cap;  // no counts: bounce 0 of a pass whose samples are all traced (entry i = slot i = path i)
@@ -1833,7 +1845,16 @@ __global__ void __launch_bounds__(256, (MODE == 1 || LEAN || BOUNCED) ? ((LEAN |
             const DLight& light = sc.lights[light_num];
             // ---- estimate_direct (integrator/mod.rs:222-318), light-sampling half
             rgb3 ld1 = mkc(0, 0, 0); f3 sh_dir = mk3(0, 0, 0);
-            LiSample ls = (MODE == 1 || LEAN) ? area_light_sample_li(sc, light, si.hit, u_light) : light_sample_li_full<GENERAL, false, BOUNCED>(gsc, light, si.hit, u_light);
+            const bool q_light = QLIGHTS && (tri_flags(sc.tri_p, light.prim) & RT_FLAG_SPHERE) != 0u;  // the picked light sits on a sphere
+            f3 q_center = mk3(0, 0, 0);
+            LiSample ls;
+            if (q_light) {  // DiffuseAreaLight::sample_li (diffuse.rs:59-70) over the cone branch of Sphere::sample_si, as light_sample_li_inl<true> assembles it
+              const DSphere& sp = sc.spheres[prim_sphere_index(sc.tri_p, light.prim)];
+              q_center = xf34_point(sp.o2w, mk3(0, 0, 0));
+              float pdf; const SpherePoint pt = sphere_cone_sample_si(sp, q_center, si.hit, u_light, pdf);
+              ls.p1.p = pt.p; ls.p1.p_error = pt.p_error; ls.p1.n = pt.n;
+              ls.wi = normalize(pt.p - si.hit.p); ls.pdf = pdf; ls.li = area_light_l(light, pt.n, -ls.wi);
+            } else ls = (MODE == 1 || LEAN) ? area_light_sample_li(sc, light, si.hit, u_light) : light_sample_li_full<GENERAL, false, BOUNCED>(gsc, light, si.hit, u_light);
             if (ls.pdf > 0.0f && !is_black(ls.li)) {
               rgb3 f = bsdf.f(si.hit.wo, ls.wi, nonspec) * fabsf(dot(ls.wi, si.sh_n));
               float scattering_pdf = ((MODE != 1 && !LEAN) && light_is_delta(light)) ? 0.0f : bsdf.pdf(si.hit.wo, ls.wi, nonspec);  // read by the power heuristic only: a delta light has none
@@ -1855,10 +1876,12 @@ __global__ void __launch_bounds__(256, (MODE == 1 || LEAN || BOUNCED) ? ((LEAN |
               if (!is_black(f) && bs.pdf > 0.0f) {
                 float weight = 1.0f; bool go = true;
                 if (!(bs.type & BSDF_SPECULAR)) {
-                  float lp = (MODE == 1 || LEAN) ? area_light_pdf_li<false>(sc, light, si.hit, bs.wi) : light_pdf_li<GENERAL, BOUNCED>(gsc, light, si.hit, bs.wi);
+                  float lp;
+                  if (q_light) lp = sphere_cone_pdf_wi(sc.spheres[prim_sphere_index(sc.tri_p, light.prim)], q_center, si.hit);
+                  else lp = (MODE == 1 || LEAN) ? area_light_pdf_li<false>(sc, light, si.hit, bs.wi) : light_pdf_li<GENERAL, BOUNCED>(gsc, light, si.hit, bs.wi);
                   if (lp == 0.0f) go = false;  // `return ld`
                   else weight = power_heuristic1(bs.pdf, lp);
-                  if (GENERAL && go && ps.skip_unreachable_mis && light.kind == 0 && (tri_flags(sc.tri_p, light.prim) & RT_FLAG_SPHERE)) {
+                  if ((GENERAL || QLIGHTS) && go && ps.skip_unreachable_mis && light.kind == 0 && (tri_flags(sc.tri_p, light.prim) & RT_FLAG_SPHERE)) {
                     const float4 b0 = sc.tri_p[3 * (size_t)light.prim], b1 = sc.tri_p[3 * (size_t)light.prim + 1];  // a quadric's leaf record: its world box
                     if (!ray_may_reach_box(mk3(b0.x, b0.y, b0.z), mk3(b1.x, b1.y, b1.z), si.hit.p, bs.wi)) { go = false; n_unreached += 1u; }
                   }
@@ -1927,7 +1950,7 @@ __global__ void __launch_bounds__(256, (MODE == 1 || LEAN || BOUNCED) ? ((LEAN |
     if (pr[2]) ps.q_mis[slot[2]] = i;
     if (NQ == 4 && pr[3]) ps.q_misany[slot[3]] = i;
   }
-  if (GENERAL) {
+  if (GENERAL || QLIGHTS) {
     for (int off = 32; off > 0; off >>= 1) n_unreached += __shfl_down(n_unreached, off);
     if ((threadIdx.x & 63u) == 0u && n_unreached) atomicAdd(&ps.stats[ST_MIS_UNREACHED], (unsigned long long)n_unreached);
   }

@@ -257,3 +257,28 @@ def test_reference_sphere_reintersection_property_holds_on_the_device(gpu_host, 
         assert (h.trace(out, count=False)["prim"] < 0).all(), (i, radius)
         tested += 1
     assert tested > 150 and missed_box < 10
+
+
+def test_sphere_light_scenes_shade_triangle_vertices_on_the_three_wave_forms(gpu_host, orc):
+    """Round 4: with constant textures and sphere lights that no triangle reaches into, vertices on triangles are shaded by the QLIGHTS
+    forms of the register-resident front-ends (cone branches of Sphere::sample_si / pdf_wi inline) and only the vertices ON quadrics by the generic GENERAL
+    kernel. Observable: the generic front-end's vertex count is exactly the number of path vertices on quadrics - non-zero although no material of the
+    scene belongs to a generic class -; the frame is the oracle's. A triangle poking into an emitter sphere switches the scene back to the GENERAL forms
+    (a vertex may then lie inside the sphere: the other branch of sample_si), where quadric hits are shaded by their material's own front-end."""
+    from rustracer_amd.scenes import mis_plates
+    d = mis_plates(96, 54, 16, analytic_spheres=True)
+    fo, so = orc.OracleScene(d).render(mode=1)
+    fh, sh = gpu_host.HostScene(d).render()
+    assert np.array_equal(fo[..., 3], fh[..., 3]) and rel_l2(gpu_host.film_to_rgb(fh), orc.film_to_rgb(fo)) < 1e-4
+    for k in ("rays_closest", "rays_shadow", "rays_mis"):
+        assert abs(int(sh[k]) - int(so[k])) <= 1e-3 * int(so[k]) + 4, (k, sh[k], so[k])
+    assert 0 < sh["vertices_generic"] < 0.2 * (sh["vertices_lambert"] + sh["vertices_two_lobe"])
+    # the same scene with a sliver of a triangle inside the first sphere light: no QLIGHTS forms, same agreement with the oracle
+    d2 = mis_plates(96, 54, 16, analytic_spheres=True)
+    sp = d2.spheres[0]
+    c = np.float32(sp.o2w)[:3, 3]
+    d2.add_mesh(np.float32([c, c + np.float32([0.01, 0, 0]), c + np.float32([0, 0.01, 0])]), [[0, 1, 2]], d2.matte((0.5, 0.5, 0.5)))
+    fo2, so2 = orc.OracleScene(d2).render(mode=1)
+    fh2, sh2 = gpu_host.HostScene(d2).render()
+    assert np.array_equal(fo2[..., 3], fh2[..., 3]) and rel_l2(gpu_host.film_to_rgb(fh2), orc.film_to_rgb(fo2)) < 1e-4
+    assert sh2["vertices_generic"] == 0
