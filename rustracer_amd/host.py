@@ -229,6 +229,16 @@ class HostScene:
         L.rtxh_scene_bvh_get(self.h, _p(bounds), _p(offset, C.c_uint32), _p(nprims, C.c_uint16), _p(axis, C.c_uint8), _p(ordered, C.c_int32))
         return dict(bounds=bounds, offset=offset, n_prims=nprims, axis=axis, ordered=ordered)
 
+    def bvh_sizes(self):
+        nn, npr = C.c_int32(), C.c_int32()
+        lib().rtxh_scene_bvh_sizes(self.h, C.byref(nn), C.byref(npr))
+        return nn.value, npr.value
+
+    def lds_resident(self):
+        """Does the traversal kernel keep this scene's nodes and primitives in LDS (rt_scene_create: RT_SMALL_NODES = 256, RT_SMALL_TRIS = 128, no object instances)?"""
+        nn, npr = self.bvh_sizes()
+        return nn <= 256 and npr <= 128 and not getattr(self.desc, "instances", None)
+
     def _render_params(self, **kw):
         return render_params(self.desc, **kw)
 

@@ -100,7 +100,7 @@ try:  # the PMC runs write their full measurement next to their counters (bench.
     samples = json.load(open(os.path.join(base, 'fetch_detail.json')))['camera_samples_per_step']
 except Exception:
     pass
-out['trace_closest_all'] = per_sample(['rtx::k_trace<false', 'rtx::k_trace_pair<false', 'rtx::k_trace_top<false'])  # k_trace_big is the visit-counting frame's kernel: not a timed launch
-out['trace_any_all'] = per_sample(['rtx::k_trace<true', 'rtx::k_trace_pair<true', 'rtx::k_trace_top<true', 'rtx::k_trace_quad'])
+out['trace_closest_all'] = per_sample(['rtx::k_trace<false, false', 'rtx::k_trace_pair<false', 'rtx::k_trace_top<false'])  # k_trace_big is the visit-counting frame's kernel: not a timed launch
+out['trace_any_all'] = per_sample(['rtx::k_trace<true, false', 'rtx::k_trace_pair<true', 'rtx::k_trace_top<true', 'rtx::k_trace_quad'])  # (<ANY, COUNT = false, ...>: the counting frame's kernels are not timed launches)
 json.dump(out, open(os.path.join('profiles', f'pmc_{scene}.json'), 'w'), indent=1)
 print(open(os.path.join('profiles', f'{tag}_{scene}_pmc_hbm.csv')).read())
