@@ -657,6 +657,10 @@ __global__ void __launch_bounds__(BLOCK, RT_GEN_MIN_WAVES(GENERAL)) k_trace(DSce
 //    413 / 275 ms. The walk itself gains lanes, but a ray's set-up - six IEEE divisions for 1 / d and the watertight test's shear, the queue lookup - then
 //    runs for the 16-24 refilled lanes instead of all 64: ~200 instructions at a quarter of the lanes per ~1250 of walk. Refill thresholds 8 / 24 / 32 and
 //    leaf thresholds 8 / 24 / 32 all lose;
+//  * two rays per lane (both loaded and set up with all lanes active, the second taken out of registers when the first is done, batched over 8 / 16 / 32
+//    ready lanes): 374 -> 632 - 668 / 171 -> 296 - 312 ms - 1.75x SLOWER per ray at 93 / 82 VGPRs. Together with the refill result this refutes the "tail"
+//    reading of the 28-of-64 lanes: the lanes of a wave do not finish at very different times; they are idle INSIDE a round - the holders of a leaf while the
+//    others step nodes, the walkers while the leaf phase tests triangles, and either side of every branch of the node step (hit / miss, push / pop);
 //  * (kept) the scene planar in LDS (LdsSrc): 336 -> 329 ms; bank conflicts were real (round 3's counters) but not what the kernel waits for.
 struct TraceOut { float4* hits; size_t hs; bool hit_b2; unsigned* occluded; size_t os; float4* lacc; size_t ls; const float4* direct_add; size_t as; };
 RT_DEV TraceOut trace_out_of(const TraceIO& io) {
