@@ -228,7 +228,7 @@ RT_DEV void mark_dirty(unsigned* dirty, unsigned pix) {  // dirty[0] = count, di
 __global__ void __launch_bounds__(256) k_sampler_draws(FrameParams fp, unsigned n_pixels, unsigned spp, unsigned dims, unsigned seg_len,
                                                        unsigned long long explicit_pixel0, int use_explicit, const SamplerSeg* __restrict__ segs,
                                                        const unsigned* __restrict__ magic, unsigned* __restrict__ scrambles, unsigned short* __restrict__ partners,
-                                                       unsigned* dirty) {
+                                                       unsigned* dirty, int chain_major) {
   const unsigned pix = blockIdx.x * blockDim.x + threadIdx.x;
   if (pix >= n_pixels) return;
   const SamplerSeg sg = segs[blockIdx.y];
@@ -253,8 +253,10 @@ __global__ void __launch_bounds__(256) k_sampler_draws(FrameParams fp, unsigned 
       retry |= (unsigned)(((old >> 18u) ^ old) >> 27u) == 0u;
     }
   } else {
-    // partners[table][i][pixel]: a wave's stores coalesce
-    unsigned short* dst = partners + ((size_t)t * spp + sg.i0) * n_pixels + pix;
+    // partners[table][i][pixel]: a wave's stores coalesce. chain_major (the parallel replay, k_sampler_shuffle_par): partners[table][pixel][i] - a lane
+    // writes its segment as 16-byte stores of eight partners each; a wave's lanes work on 64 lines of their own for the whole segment, which L2 merges
+    unsigned short* dst = chain_major ? partners + ((size_t)t * n_pixels + pix) * spp + sg.i0 : partners + ((size_t)t * spp + sg.i0) * n_pixels + pix;
+    unsigned w8[4] = {0u, 0u, 0u, 0u};
     for (unsigned k = 0; k < seg_len; ++k) {
       const unsigned i = sg.i0 + k, b = spp - i;  // wave-uniform
       const unsigned r = rng.next_u32();
@@ -265,7 +267,13 @@ __global__ void __launch_bounds__(256) k_sampler_draws(FrameParams fp, unsigned 
         rem = r - q * b;
         rem = rem >= b ? rem - b : rem;
       }
-      dst[(size_t)k * n_pixels] = (unsigned short)(i + rem);
+      if (!chain_major) dst[(size_t)k * n_pixels] = (unsigned short)(i + rem);
+      else {  // (seg_len is a multiple of 8 wherever chain_major is used: spp >= 64)
+        const unsigned v = i + rem, h = (k & 7u) >> 1;
+        const unsigned add = (k & 1u) ? (v << 16) : v;
+        w8[0] = h == 0u ? (w8[0] | add) : w8[0]; w8[1] = h == 1u ? (w8[1] | add) : w8[1]; w8[2] = h == 2u ? (w8[2] | add) : w8[2]; w8[3] = h == 3u ? (w8[3] | add) : w8[3];
+        if ((k & 7u) == 7u) { *(uint4*)(dst + (k - 7u)) = make_uint4(w8[0], w8[1], w8[2], w8[3]); w8[0] = w8[1] = w8[2] = w8[3] = 0u; }
+      }
     }
   }
   if (retry) mark_dirty(dirty, pix);
@@ -362,11 +370,193 @@ __global__ void __launch_bounds__(64) k_sampler_shuffle(unsigned n_pixels, unsig
   }
 }
 
+// K0b', the exact PARALLEL replay of the Fisher-Yates chain (round 4). k_sampler_shuffle walks a chain of spp dependent swaps with one
+// lane and a 2 * spp-byte permutation in LDS: 64 chains fill 128 KB, so a CU holds one such wave and runs it at the latency of one LDS round trip per eight
+// swaps - 57 ms per S1 frame alone, and while it overlaps path kernels its 128 KB workgroups evict theirs. Here ONE WAVE replays ONE chain, 64 steps at a time:
+//   step i does swap(a[i], a[o_i]), o_i >= i. Position p only changes when a step w < p with o_w = p (a "writer" of p) puts there what a[w] held before step w,
+//   R(w); at step p itself a[p] becomes final. So, with p's writers in order w_1 < w_2 < ... < w_k (the self-swap w = p, if any, last):
+//       perm[w_1] = p,   perm[w_{m+1}] = R(w_m),   R(j) = j if j has no writer below j, else R(L(j)) with L(j) = the last writer of j below j.
+//   Every step is a writer of exactly one position, so this names every perm[i] once. The writers are grouped by target with a counting sort in LDS (packed
+//   16-bit counters, one atomic per step; the groups come out in ascending order, which is checked), L is read off the groups and R is found by pointer
+//   jumping (a chain of L links is ~2 long: 3 - 5 rounds). Everything is straight-line code over the lane's E steps: a dozen dependent LDS round trips per
+//   chain instead of 1024. (A first version with per-target loops - insertion sort, pointer chase - took 131 ms per S1 frame: loops of dependent LDS reads.) The result goes through an LDS tile so that 16 chains leave as 32-byte runs of perms[table][sample][pixel].
+// MEASURED (S1's batches, 524 288 pixels x 8 tables, alone on the GPU): 15.4 ms against the chain kernel's 23.2 - and 4.4 ms more in k_sampler_draws for the
+// chain-major partner layout it needs; under path kernels, where a frame builds all tables but the first batch's, it costs the frame more than the chain
+// kernel does (rtx_hip.hip, launch_sampler_tables). Built as two verdicts asked, kept exact and tested, OFF by default (RTX_K0_PARALLEL=1).
+// Exact: the same permutation as the sequential replay for every partner sequence (tests: the sampler tables stay bit-equal to the oracle's, retry pixels
+// included). E = spp / 64 steps per lane: instantiated for spp 64 ... 1024; other sample counts keep k_sampler_shuffle.
+#define RT_SHUF_PIX 16
+RT_DEV void wave_sync_lds() { __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup"); __builtin_amdgcn_wave_barrier(); }
+#ifdef RT_K0_STAMP
+#define K0S(k) do { const unsigned long long t_ = clock64(); if (lane == 0u) atomicAdd(&((unsigned long long*)(n_resorted + 2))[k], t_ - t_last); t_last = clock64(); } while (0)
+#else
+#define K0S(k) do { } while (0)
+#endif
+template <int E>
+__global__ void __launch_bounds__(256) k_sampler_shuffle_par(unsigned n_pixels, const unsigned short* __restrict__ partners, unsigned short* __restrict__ perms, unsigned* __restrict__ n_resorted) {
+  constexpr unsigned N = 64u * E, NONE = 0xffffu;
+  __shared__ unsigned short tile[RT_SHUF_PIX][N + 2];  // (+2: rows an odd number of words apart, the transposed read-out is conflict-free)
+  __shared__ unsigned short s_o[4][N];                 // per wave: R (the pointer-jumping array)
+  __shared__ unsigned s_cnt[4][N / 2 + 64 + 1];        // per wave: packed 16-bit counters per target (target p at index CI(p) = p + 2 * (p / E)), then exclusive bases
+  __shared__ unsigned short s_wl[4][N];                // per wave: writers grouped by target
+  const unsigned lane = threadIdx.x & 63u, wv = threadIdx.x >> 6, t = blockIdx.y, pix0 = blockIdx.x * RT_SHUF_PIX;
+  unsigned short* const o = s_o[wv]; unsigned* const cnt = s_cnt[wv]; unsigned short* const wl = s_wl[wv];
+  const unsigned short* const cnt16 = (const unsigned short*)cnt;
+#ifdef RT_K0_STAMP
+  unsigned long long t_last = clock64();
+#endif
+  // the partners of the workgroup's 16 chains, all requested at once (one memory latency per workgroup, not one per chain): each chain's row of the tile holds
+  // its partners until the chain is replayed and its permutation afterwards
+  {  // 16-byte loads, all of a thread's in flight together: thread tid takes 16-byte piece tid, tid + 256, ... of the workgroup's 16 x 2 N bytes
+    constexpr unsigned PIECES = RT_SHUF_PIX * N * 2u / 16u / 256u;  // per thread (N >= 64: at least 1... N = 64: 128 pieces for 256 threads)
+    constexpr unsigned NP = PIECES ? PIECES : 1u;
+    uint4 v[NP];
+#pragma unroll
+    for (unsigned k = 0; k < NP; ++k) {
+      const unsigned piece = threadIdx.x + 256u * k, c = piece / (N / 8u), w = piece - c * (N / 8u);
+      v[k] = make_uint4(0u, 0u, 0u, 0u);
+      if (piece < RT_SHUF_PIX * (N / 8u) && pix0 + c < n_pixels) v[k] = ((const uint4*)(partners + ((size_t)t * n_pixels + pix0 + c) * N))[w];
+    }
+#pragma unroll
+    for (unsigned k = 0; k < NP; ++k) {
+      const unsigned piece = threadIdx.x + 256u * k, c = piece / (N / 8u), w = piece - c * (N / 8u);
+      if (piece < RT_SHUF_PIX * (N / 8u)) { unsigned* d = (unsigned*)tile[c] + 4u * w; d[0] = v[k].x; d[1] = v[k].y; d[2] = v[k].z; d[3] = v[k].w; }
+    }
+  }
+  __syncthreads();
+  K0S(0);
+  for (unsigned c = wv; c < RT_SHUF_PIX; c += 4u) {
+    const unsigned pix = pix0 + c;
+    if (pix >= n_pixels) break;  // (wave-uniform)
+    for (unsigned k = lane; k < N / 2u + 64u; k += 64u) cnt[k] = 0u;
+    wave_sync_lds();
+    // Step i = 64 m + lane. Its rank among the writers of its target is the value its atomic returns: iterations run in order of m, and the lanes of ONE
+    // atomic instruction that name the same counter are served in lane order on this hardware - so the rank is the writer's position in ascending order and
+    // the groups come out sorted. That order is not architected: it is CHECKED below (every writer against its predecessor) and a wave that finds it broken
+    // sorts its groups the slow way.
+    // Every phase below is written in STAGES over the lane's E steps - all loads of a stage first, then what depends on them - so that a stage costs one LDS
+    // round trip, not E of them (written step by step the compiler kept the steps' dependent reads in order: 19 500 cycles per chain, all of it LDS latency
+    // at the two waves per SIMD the workgroup's 57 KB allow).
+    unsigned pk[E], rk[E];
+#pragma unroll
+    for (int m = 0; m < E; ++m) pk[m] = tile[c][64u * (unsigned)m + lane];
+#pragma unroll
+    for (int m = 0; m < E; ++m) {
+      const unsigned ci = pk[m] + 2u * (pk[m] / (unsigned)E);
+      rk[m] = atomicAdd(&cnt[ci >> 1], (pk[m] & 1u) ? 0x10000u : 1u);
+    }
+#pragma unroll
+    for (int m = 0; m < E; ++m) rk[m] = (pk[m] & 1u) ? (rk[m] >> 16) : (rk[m] & 0xffffu);
+    wave_sync_lds();
+    K0S(1);
+    {  // exclusive scan of the counts over the targets: lane l scans its targets [l * E, (l + 1) * E) (CI skews the counters by one word per E targets, so
+       // that the 64 lanes' chunks start in different banks), one wave scan joins the lanes' sums
+      unsigned x[E], local[E]; unsigned sum = 0u;
+#pragma unroll
+      for (int m = 0; m < E; ++m) x[m] = cnt16[lane * (E + 2u) + (unsigned)m];
+#pragma unroll
+      for (int m = 0; m < E; ++m) { local[m] = sum; sum += x[m]; }
+      unsigned incl = sum;
+#pragma unroll
+      for (int off = 1; off < 64; off <<= 1) { const unsigned v = __shfl_up(incl, off); if ((int)lane >= off) incl += v; }
+      const unsigned excl = incl - sum;
+      wave_sync_lds();  // every lane has read its counts
+#pragma unroll
+      for (int m = 0; m < E; ++m) ((unsigned short*)cnt)[lane * (E + 2u) + (unsigned)m] = (unsigned short)(excl + local[m]);
+    }
+    wave_sync_lds();
+    K0S(2);
+    unsigned bs[E];
+#pragma unroll
+    for (int m = 0; m < E; ++m) bs[m] = cnt16[pk[m] + 2u * (pk[m] / (unsigned)E)];
+#pragma unroll
+    for (int m = 0; m < E; ++m) wl[bs[m] + rk[m]] = (unsigned short)(64u * (unsigned)m + lane);
+    wave_sync_lds();
+    K0S(3);
+    unsigned pred[E];  // the writer before step i in its group (sorted: its predecessor in arrival order), NONE for the first
+#pragma unroll
+    for (int m = 0; m < E; ++m) pred[m] = wl[bs[m] + (rk[m] > 0u ? rk[m] - 1u : 0u)];
+    bool unsorted = false;
+#pragma unroll
+    for (int m = 0; m < E; ++m) { if (rk[m] == 0u) pred[m] = NONE; else unsorted |= pred[m] >= 64u * (unsigned)m + lane; }
+    if (__ballot(unsorted) != 0ull) {  // never seen; kept exact: sort every group, then every step finds its place
+      if (lane == 0u && n_resorted) atomicAdd(n_resorted, 1u);
+#pragma unroll 1
+      for (int m = 0; m < E; ++m) {
+        const unsigned p = 64u * (unsigned)m + lane, g = cnt16[p + 2u * (p / (unsigned)E)], k = (p + 1u < N ? (unsigned)cnt16[p + 1u + 2u * ((p + 1u) / (unsigned)E)] : N) - g;
+        for (unsigned a = 1; a < k; ++a) {
+          const unsigned v = wl[g + a]; unsigned b = a;
+          while (b > 0u && wl[g + b - 1u] > v) { wl[g + b] = wl[g + b - 1u]; --b; }
+          wl[g + b] = (unsigned short)v;
+        }
+      }
+      wave_sync_lds();
+#pragma unroll 1
+      for (int m = 0; m < E; ++m) { unsigned a = 0; while (wl[bs[m] + a] != 64u * (unsigned)m + lane) ++a; pred[m] = a > 0u ? (unsigned)wl[bs[m] + a - 1u] : NONE; }
+    }
+    {  // R, first as "the last writer of j below j, or j itself" (its array: o, free once the partners are in registers)
+      unsigned g[E], gn[E], last[E], prev[E];
+#pragma unroll
+      for (int m = 0; m < E; ++m) { const unsigned p = 64u * (unsigned)m + lane; g[m] = cnt16[p + 2u * (p / (unsigned)E)]; gn[m] = p + 1u < N ? (unsigned)cnt16[p + 1u + 2u * ((p + 1u) / (unsigned)E)] : N; }
+#pragma unroll
+      for (int m = 0; m < E; ++m) { const unsigned k = gn[m] - g[m]; last[m] = wl[k > 0u ? gn[m] - 1u : 0u]; prev[m] = wl[k > 1u ? gn[m] - 2u : 0u]; }
+#pragma unroll
+      for (int m = 0; m < E; ++m) {
+        const unsigned p = 64u * (unsigned)m + lane, k = gn[m] - g[m];
+        const unsigned L = (k > 0u && last[m] < p) ? last[m] : ((k > 1u) ? prev[m] : NONE);  // (last == p: the self-swap; the writer before it)
+        o[p] = (unsigned short)(L == NONE ? p : L);
+      }
+    }
+    wave_sync_lds();
+    K0S(4);
+    // ... then by pointer jumping (in place: an entry only ever moves to an ancestor) until every entry names the start of its chain
+    for (;;) {
+      unsigned r[E], rr[E];
+#pragma unroll
+      for (int m = 0; m < E; ++m) r[m] = o[64u * (unsigned)m + lane];
+#pragma unroll
+      for (int m = 0; m < E; ++m) rr[m] = o[r[m]];
+      bool changed = false;
+#pragma unroll
+      for (int m = 0; m < E; ++m) { changed |= rr[m] != r[m]; o[64u * (unsigned)m + lane] = (unsigned short)rr[m]; }
+      wave_sync_lds();
+      if (__ballot(changed) == 0ull) break;
+    }
+    K0S(5);
+    {  // perm[i]: the target's own index for its first writer, else what the writer before it moved there
+      unsigned val[E];
+#pragma unroll
+      for (int m = 0; m < E; ++m) val[m] = o[pred[m] != NONE ? pred[m] : 0u];
+#pragma unroll
+      for (int m = 0; m < E; ++m) tile[c][64u * (unsigned)m + lane] = (unsigned short)(pred[m] != NONE ? val[m] : pk[m]);
+    }
+    wave_sync_lds();
+    K0S(6);
+  }
+  __syncthreads();
+  K0S(7);
+  // perms[table][sample][pixel]: a thread gathers sample i of the 16 chains (neighbouring lanes read neighbouring entries of a row) and stores 32 contiguous bytes
+  unsigned short* const out = perms + (size_t)t * N * n_pixels;
+  if ((n_pixels & 7u) == 0u && pix0 + RT_SHUF_PIX <= n_pixels) {
+    for (unsigned i = threadIdx.x; i < N; i += 256u) {
+      unsigned w[8];
+#pragma unroll
+      for (int q = 0; q < 8; ++q) w[q] = (unsigned)tile[2 * q][i] | ((unsigned)tile[2 * q + 1][i] << 16);
+      uint4* dst = (uint4*)(out + (size_t)i * n_pixels + pix0);
+      dst[0] = make_uint4(w[0], w[1], w[2], w[3]); dst[1] = make_uint4(w[4], w[5], w[6], w[7]);
+    }
+  } else {
+    for (unsigned i = threadIdx.x; i < N; i += 256u)
+      for (unsigned c = 0; c < RT_SHUF_PIX; ++c) if (pix0 + c < n_pixels) out[(size_t)i * n_pixels + pix0 + c] = tile[c][i];
+  }
+  K0S(8);
+}
+
 // K0c: the swap partners and scrambles of the (rare) pixels whose stream holds a retry, redone from the start of
 // the stream in order, one lane per pixel, before K0b consumes them.
 __global__ void __launch_bounds__(64) k_sampler_redo(FrameParams fp, unsigned n_pixels, unsigned spp, unsigned dims,
                                                      unsigned long long explicit_pixel0, int use_explicit, unsigned* dirty,
-                                                     const unsigned* __restrict__ magic, unsigned* scrambles, unsigned short* partners) {
+                                                     const unsigned* __restrict__ magic, unsigned* scrambles, unsigned short* partners, int chain_major) {
   const unsigned k = blockIdx.x * blockDim.x + threadIdx.x;
   if (k == 0 && dirty[0] > RT_DIRTY_CAP) dirty[1 + RT_DIRTY_CAP] = 1u;  // sticky: the host fails the frame
   const unsigned n = dirty[0] < RT_DIRTY_CAP ? dirty[0] : RT_DIRTY_CAP;
@@ -381,13 +571,14 @@ __global__ void __launch_bounds__(64) k_sampler_redo(FrameParams fp, unsigned n_
       scrambles[(size_t)(dims + 2u * (t - dims) + 1u) * n_pixels + pix] = s1;
     }
     for (unsigned i = 0; i < spp; ++i) (void)rng.bounded(1u);
-    unsigned short* dst = partners + (size_t)t * spp * n_pixels + pix;
+    unsigned short* dst = chain_major ? partners + ((size_t)t * n_pixels + pix) * spp : partners + (size_t)t * spp * n_pixels + pix;
+    const size_t step = chain_major ? 1 : n_pixels;
     for (unsigned i = 0; i < spp; ++i) {
       const unsigned b = spp - i, threshold = (~b + 1u) & b;
       unsigned r; do { r = rng.next_u32(); } while (r < threshold);  // bounded(b), rng.rs:32-40
       unsigned rem = 0u;
       if (b > 1u) { const unsigned q = __umulhi(r, magic[b]); rem = r - q * b; rem = rem >= b ? rem - b : rem; }  // r % b
-      dst[(size_t)i * n_pixels] = (unsigned short)(i + rem);
+      dst[(size_t)i * step] = (unsigned short)(i + rem);
     }
   }
 }

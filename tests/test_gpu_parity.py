@@ -119,7 +119,8 @@ def test_sampler_tables_retry_pixels(gpu_host, orc, spp):
 def test_sampler_segmented_equals_plain_over_a_large_range(gpu_host):
     """The sampler rt_render uses (jump-ahead segments + pipelined shuffle + retry redo) against the single-kernel
     in-order walk of the same stream, over a pixel range that holds retry pixels 8933 (spp 1024)."""
-    for spp, p0, n in ((1024, 8000, 2000), (256, 0, 5000), (8, 123456, 4097), (2, 7, 300)):
+    # (64 ... 1024 spp: the parallel replay of the shuffle, k_sampler_shuffle_par - odd pixel counts and ragged last workgroups included; others: the chain kernel)
+    for spp, p0, n in ((1024, 8000, 2000), (256, 0, 5000), (8, 123456, 4097), (2, 7, 300), (512, 100, 1000), (128, 5, 777), (64, 0, 1031), (2048, 3, 40)):
         a = gpu_host.sampler_tables(spp, 4, p0, n)
         b = gpu_host.sampler_tables(spp, 4, p0, n, plain=True)
         assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1]), spp
@@ -286,3 +287,16 @@ def test_multi_device_wide_filter_rows_are_summed(gpu_host):
     film, _, _ = h.render_multi([0, 0, 0], chunks_per_device=1)
     assert np.allclose(film, full, rtol=2e-5, atol=1e-6)
 
+
+
+def test_parallel_replay_of_the_shuffle_is_exact():
+    """k_sampler_shuffle_par (RTX_K0_PARALLEL=1; built in round 4, off by default - see rtx_hip.hip) replays a Fisher-Yates chain with one wave instead of one
+    lane. The knob is read once per process, so the sampler parity tests of this file run again in a child process with it set: tables bit-equal to the
+    oracle's (spp 64 and 1024), to the single-kernel in-order walk (64 ... 1024 spp, odd pixel counts, ragged workgroups) and on the retry pixels."""
+    import subprocess, sys
+    env = dict(os.environ, RTX_K0_PARALLEL="1", RTX_K0_REPORT="1")
+    r = subprocess.run([sys.executable, "-m", "pytest", os.path.abspath(__file__), "-x", "-q", "-m", "gpu", "-s", "-k",
+                        "sampler_tables_match_oracle or sampler_tables_retry_pixels or sampler_segmented_equals_plain"], capture_output=True, text=True, env=env, timeout=900,
+                       cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
+    assert "passed" in r.stdout and "k_sampler_shuffle_par: 0 wave(s) re-sorted" in r.stderr + r.stdout  # the parallel kernel ran, its groups came out sorted
