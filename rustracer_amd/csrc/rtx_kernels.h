@@ -126,6 +126,10 @@ RT_DEV unsigned wave_push(unsigned* counter, bool pred) {
 }
 
 #define RT_QSHARDS 8
+// Measured in round 4 and not kept: an XCD-aware chunk order (workgroups are dealt round-robin over the 8 XCDs, each with its own 4 MB L2; with chunk =
+// (b % 8) * (grid / 8) + b / 8 the blocks of one XCD take one contiguous eighth of a launch's queue instead of every eighth chunk) for k_shade and for the waves of
+// the persistent trace kernels: S4 shade 3136 -> 3155 / 3161 ms, closest hit 1521 -> 1514; S3, S2, S1 within noise. The shade kernels' misses go to tables of
+// 16 - 64 MB (environment rows, texels, triangle records) that no 4 MB L2 holds however its blocks are chosen.
 // Words between two counters that receive atomics (the shard counters of a queue, the bin cursors of the counting sort). Packed (1), the 24 - 32 shard counters
 // a bounce adds to sit in ONE 128-byte line, and atomics on one line are serviced one after the other whichever word they name: every workgroup of a shade
 // launch waits on that line three times per iteration (measured: 64-lane workgroups, four times the atomics, made S1's shade launch 1.9x slower). 64 words =
