@@ -150,12 +150,14 @@ def occupancy_of(kernel_substr):
 
 
 class ClockSampler:
-    """sclk / mclk / socket power of the GPU read from sysfs every 50 ms while frames are timed (one binary's k_shade<1> took 370 - 421 ms "depending on
-    the box and the hour" with no clock reading beside it). Best effort: a box without the files yields None."""
+    """sclk / mclk / socket power of the GPU read from sysfs right before and right after the timed frames (one binary's k_shade<1> took 370 - 421 ms
+    "depending on the box and the hour" with no clock reading beside it). NOT while they run: reading pp_dpm_sclk / power1_average makes the driver query the
+    SMU, and a thread doing that every 50 ms cost short frames 15 - 25 ms each on some runs (S2 177 / 202 ms, S3 328 / 353, instances 85 / 101 - found in round 4
+    when the stage times of a run no longer added up to its wall time). Best effort: a box without the files yields None."""
 
     def __init__(self, card=None):
         import glob
-        self.rows, self.stop, self.thread = [], False, None
+        self.rows = []
         cards = sorted(glob.glob("/sys/class/drm/card*/device/pp_dpm_sclk"))
         self.dev = os.path.dirname(cards[card or 0]) if cards else None
         try:  # the card whose PCI address is the current HIP device's (a box may expose more cards in sysfs than it lets the process use)
@@ -181,36 +183,30 @@ class ClockSampler:
             pass
         return None
 
-    def _run(self):
-        while not self.stop:
-            p = None
-            try:
-                p = int(open(self.power).read()) / 1e6 if self.power else None
-            except Exception:
-                pass
-            self.rows.append((self._active(os.path.join(self.dev, "pp_dpm_sclk")), self._active(os.path.join(self.dev, "pp_dpm_mclk")), p))
-            time.sleep(0.05)
+    def sample(self):
+        if not self.dev:
+            return
+        p = None
+        try:
+            p = int(open(self.power).read()) / 1e6 if self.power else None
+        except Exception:
+            pass
+        self.rows.append((self._active(os.path.join(self.dev, "pp_dpm_sclk")), self._active(os.path.join(self.dev, "pp_dpm_mclk")), p))
 
     def __enter__(self):
-        if self.dev:
-            import threading
-            self.thread = threading.Thread(target=self._run, daemon=True)
-            self.thread.start()
+        self.sample()
         return self
 
     def __exit__(self, *a):
-        self.stop = True
-        if self.thread:
-            self.thread.join(timeout=1.0)
+        self.sample()
 
     def summary(self):
-        import numpy as np
         out = {}
         for k, name in enumerate(("sclk_MHz", "mclk_MHz", "power_W")):
             v = [r[k] for r in self.rows if r[k] is not None]
             if v:
-                out[name] = {"min": round(float(min(v)), 1), "median": round(float(np.median(v)), 1), "max": round(float(max(v)), 1)}
-        return dict(out, samples=len(self.rows), pci=self.pci) if out else None
+                out[name] = {"before": v[0], "after": v[-1]}
+        return dict(out, pci=self.pci) if out else None
 
 
 class Runner:
@@ -269,14 +265,16 @@ def run_workload(scene_name, runner, workload, steps, warmup):
     rank, world, dist = runner.rank, runner.world, runner.dist
     for _ in range(warmup):
         runner.step(False)
+    kstats = []
+    clocks = ClockSampler()
+    clocks.sample()  # (before the opening barrier: the sysfs reads are outside the timed region)
     runner.barrier()
     t0 = time.perf_counter()
-    kstats = []
-    with ClockSampler() as clocks:
-        for _ in range(steps):
-            kstats.append(runner.step(True))
-        runner.barrier()
+    for _ in range(steps):
+        kstats.append(runner.step(True))
+    runner.barrier()
     dt = time.perf_counter() - t0
+    clocks.sample()
     cst = runner.count()
     if dist is not None:
         tt = torch.tensor([dt], dtype=torch.float64, device=f"cuda:{runner.local_rank}")
@@ -404,7 +402,7 @@ def run_workload(scene_name, runner, workload, steps, warmup):
         "mis_rays_not_cast": int(not_cast),
         "kernel_ms_per_step": kernels_ms, "vertices_by_shade_front_end": verts,
         "roofline": roofline, "roofline_second_kernel": roofline_other, "traversal_by_ray_class": classes, "traversal_hbm_share": groups,
-        "camera_samples_per_step": int(samples_per_step), "gpu_clocks_while_timed": clocks.summary(),
+        "camera_samples_per_step": int(samples_per_step), "gpu_clocks": clocks.summary(),
     }
     if n_gpus_asked > 1:
         out["n_gpus_requested"] = n_gpus_asked

@@ -919,6 +919,18 @@ static void launch_trace_c(rt_scene* s, const TraceIO& io, const unsigned* queue
         else RT_GEN_LAUNCH((k_trace<ANY, false, true, 128, 64, RT_GEN_ALL>), (k_trace<ANY, false, true, 128, 64, RT_GEN_NO_MASKS>), (trace_grid<ANY, true, 128, 64>(s)), 128, s->d, io, queue, count_ptr, shard_cap, count_static, stats, st_rays, st_nodes, st_tris);
         return;
       }
+      // object instances over plain triangles: the two-level walk as one loop (k_trace_inst). RTX_INST_LOOP (measurement knob): bit 0 closest hit, bit 1 any hit; 0 = the nested walks
+      static const int inst_loop = getenv("RTX_INST_LOOP") ? atoi(getenv("RTX_INST_LOOP")) : 3;
+      if (!big_only && s->has_instances && !all && !s->has_spheres && s->use_pairs && s->d.obj_pairs && ((ANY ? 2 : 1) & inst_loop)) {
+        const unsigned depth = s->stack_depth <= 32 ? 32u : 64u;
+        const unsigned lds = depth * 128u * 4u + 13u * 128u * 4u;
+        const unsigned grid_i = (unsigned)s->n_cu * std::max(1u, std::min(16u, (160u * 1024u) / lds));
+        const unsigned grid_cap = depth == 32u ? trace_grid<ANY, false, 128, 32>(s) : trace_grid<ANY, false, 128, 64>(s);  // (the deferred-tmin array is sized for this grid)
+        const unsigned g = std::min(grid_i, grid_cap);
+        if (depth == 32u) hipLaunchKernelGGL((k_trace_inst<ANY, 128, 32>), dim3(g), dim3(128), 0, stream, s->d, io, queue, count_ptr, shard_cap, count_static, stats, st_rays, s->tmin_stack.as<float>(), refill_min);
+        else hipLaunchKernelGGL((k_trace_inst<ANY, 128, 64>), dim3(g), dim3(128), 0, stream, s->d, io, queue, count_ptr, shard_cap, count_static, stats, st_rays, s->tmin_stack.as<float>(), refill_min);
+        return;
+      }
       if (!big_only && ANY && s->use_quads && s->quad_stack_depth <= 32) {
         RT_GEN_LAUNCH3((k_trace_quad<ANY, 128, 32, RT_GEN_ALL>), (k_trace_quad<ANY, 128, 32, RT_GEN_NO_MASKS>), (k_trace_quad<ANY, 128, 32, RT_GEN_INSTANCES_ONLY>), (trace_grid<ANY, false, 128, 32>(s)), 128, s->d, io, queue, count_ptr, shard_cap, count_static, stats, st_rays, s->tmin_stack.as<float>(), refill_min);
         return;

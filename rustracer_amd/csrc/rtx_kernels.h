@@ -1288,6 +1288,172 @@ __global__ void __launch_bounds__(BLOCK, (GENERAL == RT_GEN_NO_MASKS && !ANY) ? 
   }
 }
 
+// ---- two-level traversal as ONE loop (round 4). In k_trace_pair<.., RT_GEN_INSTANCES_ONLY> an object instance is a primitive of a top-level
+// leaf and its whole walk (nested_pair_walk) runs inside that lane's leaf step: the wave waits until every lane holds a leaf, then until the LONGEST of up to
+// 4 x 64 nested walks is over - 10 000 placements of a 1280-triangle object traced at 600 Msamples/s against 729 for the same triangles written out. Here a
+// lane that reaches an instance ENTERS it: the ray goes to object space (Transform * Ray, rc/ray.rs:83-93), the world ray waits in LDS, the rest of the
+// top-level leaf waits on the lane's stack as one more entry, and the lane carries on in the main loop - its interior steps are the same instructions as a
+// top-level lane's (other record base), so lanes on different levels share the wave's steps. When the object's entries are used up the lane restores its world
+// ray and pops on. Per ray the sequence of box tests, triangle tests and t_max updates is TransformedPrimitive::intersect's (primitive.rs:90-101) inside
+// BVH::intersect's: hit records and occlusion results bit-equal to the nested form (tests/test_gpu_instances.py).
+// Scenes: object instances over plain triangles, objects with pair records (DScene::obj_pairs) - the other general scenes keep k_trace_pair / k_trace_quad.
+#define RT_INST_NONE 0xffffffffu
+template <bool ANY, int BLOCK, int DEPTH>
+__global__ void __launch_bounds__(BLOCK, 4) k_trace_inst(DScene sc, TraceIO io, const unsigned* __restrict__ queue, const unsigned* __restrict__ shard_counts, unsigned shard_cap,
+                                                         unsigned count_static, unsigned long long* stats, int st_rays, float* __restrict__ tmin_stack_mem, unsigned refill_min) {
+  const float4* __restrict__ ray_o = io.ray_o; const float4* __restrict__ ray_d = io.ray_d; const size_t rs = io.ray_stride;
+  __shared__ unsigned stack_mem[DEPTH * BLOCK];
+  __shared__ float s_world[13 * BLOCK];  // the world-space ray of a lane that is inside an instance: o, d, 1 / d, the watertight test's shear
+  unsigned* const stack = stack_mem + threadIdx.x;
+  float* const wsave = s_world + threadIdx.x;
+  const size_t grid_lanes = (size_t)gridDim.x * BLOCK;
+  float* const tstack = tmin_stack_mem + (size_t)blockIdx.x * BLOCK + threadIdx.x;
+  QView qv; if (queue) qv.init(io.queue_is_slots ? nullptr : queue, shard_counts, shard_cap);
+  const unsigned count = queue ? qv.total() : count_static;
+  const unsigned lane = __lane_id();
+  const unsigned n_waves = gridDim.x * (BLOCK / 64), wave = blockIdx.x * (BLOCK / 64) + (threadIdx.x >> 6);
+  const float4* __restrict__ pairs = sc.pairs; const float4* __restrict__ tri_p = sc.tri_p; const float4* __restrict__ nodes = sc.nodes;
+  const TraceOut out = trace_out_of(io);
+  const unsigned leaf_min = refill_min >> 8; refill_min &= 0xffu;
+  unsigned n_rays = 0, cursor = 0;
+  bool exhausted = (unsigned long long)wave * 64ull >= count;
+  PairLane L;
+  L.active = false; L.found = false; L.pid = 0; L.dw = 0.0f;
+  L.ray.o = L.ray.d = mk3(0, 0, 0); L.ray.t_max = 0.0f; L.inv_dir = mk3(0, 0, 0); L.set_rp(ray_pre(L.ray));
+  L.sp = 0; L.prim = -1; L.cur = 0; L.hit.t = kInf; L.hit.b0 = L.hit.b1 = L.hit.b2 = 0.0f;
+  unsigned inst = RT_INST_NONE, node_base = 0u, prim_base = 0u, id_base = 0u; int sp_base = -1;  // the instance the lane is inside, its records, the stack height it was entered at
+
+  // next pending entry that still passes tmin < t_max; an object whose entries are used up is left first; no entry left: the ray is complete
+  auto pop = [&]() {
+    for (;;) {
+      if (inst != RT_INST_NONE && L.sp == sp_base) {
+        L.ray.o = mk3(wsave[0], wsave[BLOCK], wsave[2 * BLOCK]); L.ray.d = mk3(wsave[3 * BLOCK], wsave[4 * BLOCK], wsave[5 * BLOCK]);
+        L.inv_dir = mk3(wsave[6 * BLOCK], wsave[7 * BLOCK], wsave[8 * BLOCK]);
+        L.kz = __float_as_int(wsave[9 * BLOCK]); L.sx = wsave[10 * BLOCK]; L.sy = wsave[11 * BLOCK]; L.sz = wsave[12 * BLOCK];
+        inst = RT_INST_NONE; node_base = prim_base = id_base = 0u; sp_base = -1;
+      }
+      if (L.sp == 0) { pair_finish<ANY>(L, out); return; }
+      --L.sp;
+      const unsigned c = stack[L.sp * BLOCK];
+      if (ANY) { L.cur = c; return; }
+      if (tstack[(size_t)L.sp * grid_lanes] < L.ray.t_max) { L.cur = c; return; }
+    }
+  };
+  for (;;) {
+    const unsigned long long idle = __ballot(!L.active);
+    if (!exhausted && (unsigned)__popcll(idle) >= (idle == ~0ull ? 1u : refill_min)) {
+      const unsigned v = cursor + (unsigned)__popcll(idle & ((1ull << lane) - 1ull));
+      const unsigned long long e = ((unsigned long long)(v >> 6) * n_waves + wave) * 64ull + (v & 63u);
+      if (!L.active && e < count) {
+        L.pid = queue ? qv.get((unsigned)e) : (unsigned)e;
+        const float4 o4 = ray_o[L.pid * rs], d4 = ray_d[L.pid * rs];
+        L.ray.o = mk3(o4.x, o4.y, o4.z); L.ray.d = mk3(d4.x, d4.y, d4.z); L.ray.t_max = o4.w; L.dw = d4.w;
+        L.inv_dir = mk3(1.0f / L.ray.d.x, 1.0f / L.ray.d.y, 1.0f / L.ray.d.z);
+        L.set_rp(ray_pre(L.ray));
+        L.sp = 0; L.prim = -1; L.found = false; L.hit.t = kInf; L.hit.b0 = L.hit.b1 = L.hit.b2 = 0.0f;
+        inst = RT_INST_NONE; node_base = prim_base = id_base = 0u; sp_base = -1;
+        L.active = true; n_rays += 1;
+        const float4 r0 = nodes[0], r1 = nodes[1];  // the root is the one node tested on its own
+        if (slab_test(r0, r1, L.ray, L.inv_dir, L.neg_x(), L.neg_y(), L.neg_z())) {
+          const unsigned packed = __float_as_uint(r1.w), np = packed & 0xffffu;
+          L.cur = np > 0u ? (RT_PAIR_LEAF | RT_PAIR_GENERAL | (unsigned)__float_as_int(r1.z) | ((np - 1u) << 26)) : (((packed >> 16) & 0xffu) << 29);
+        } else pair_finish<ANY>(L, out);
+      }
+      cursor += (unsigned)__popcll(idle);
+      exhausted = ((unsigned long long)(cursor >> 6) * n_waves + wave) * 64ull + (cursor & 63u) >= count;
+    }
+    if (__ballot(L.active) == 0ull) { if (exhausted) break; else continue; }
+    const bool at_leaf = L.active && (L.cur & RT_PAIR_LEAF) != 0u;
+    const bool leaves_now = leaf_phase_now(L.active, at_leaf, leaf_min);
+    if (!L.active) continue;
+    if (!at_leaf) {  // one child pair, at either level (pair_interior_step; an object's records sit behind the top level's, codes local to the object)
+      const unsigned P = L.cur & 0x1fffffffu, axis = (L.cur >> 29) & 3u;
+      const float4* __restrict__ rec = pairs + 4 * ((size_t)node_base + P);
+      const float4 a0 = rec[0], a1 = rec[1], b0 = rec[2], b1 = rec[3];
+      const bool neg = L.neg_axis(axis);
+      const float4 n0 = neg ? b0 : a0, n1 = neg ? b1 : a1, f0 = neg ? a0 : b0, f1 = neg ? a1 : b1;
+      const unsigned code_a = __float_as_uint(a1.z), code_b = __float_as_uint(a1.w);
+      const unsigned code_n = neg ? code_b : code_a, code_f = neg ? code_a : code_b;
+      float tmin_n = 0.0f, tmin_f = 0.0f;
+      const bool hit_n = slab_geom(n0, n1, L.ray, L.inv_dir, L.neg_x(), L.neg_y(), L.neg_z(), tmin_n) && tmin_n < L.ray.t_max;
+      const bool keep_f = slab_geom(f0, f1, L.ray, L.inv_dir, L.neg_x(), L.neg_y(), L.neg_z(), tmin_f) && tmin_f < L.ray.t_max;
+      if (hit_n) {
+        if (keep_f) { stack[L.sp * BLOCK] = code_f; if (!ANY) tstack[(size_t)L.sp * grid_lanes] = tmin_f; ++L.sp; }
+        L.cur = code_n;
+      } else if (keep_f) L.cur = code_f;
+      else pop();
+      continue;
+    }
+    if (!leaves_now) continue;
+    if (inst != RT_INST_NONE) {  // a leaf of the object: plain triangles, in object space
+      const int off = (int)(L.cur & 0x03ffffffu), n = (int)((L.cur >> 26) & 31u) + 1;
+      const RayPre rp = L.rp();
+      for (int i = 0; i < n; ++i) {
+        f3 p0, p1, p2; load_tri(tri_p + 3 * (size_t)prim_base, off + i, p0, p1, p2);
+        TriHit h;
+        if (tri_test_pre(p0, p1, p2, L.ray, rp, h)) {
+          L.found = true;
+          if (ANY) break;
+          L.ray.t_max = h.t; L.prim = (int)(id_base + (unsigned)(off + i)); L.hit = h;  // `.or(result)`: later accepted hits replace
+        }
+      }
+      if (ANY && L.found) pair_finish<ANY>(L, out); else pop();
+      continue;
+    }
+    {  // a leaf of the top level: triangles and instances, in order; entering an instance leaves the rest of the leaf on the stack
+      const int off = (int)(L.cur & 0x01ffffffu), n = (int)((L.cur >> 26) & 31u) + 1;
+      bool entered = false;
+      for (int i = 0; i < n && !entered; ++i) {
+        const float4 a = tri_p[3 * (size_t)(off + i)], b = tri_p[3 * (size_t)(off + i) + 1], c = tri_p[3 * (size_t)(off + i) + 2];
+        if (!(__float_as_uint(c.w) & RT_FLAG_INSTANCE)) {
+          TriHit h;
+          if (tri_test_pre(mk3(a.x, a.y, a.z), mk3(b.x, b.y, b.z), mk3(c.x, c.y, c.z), L.ray, L.rp(), h)) {
+            L.found = true;
+            if (ANY) break;
+            L.ray.t_max = h.t; L.prim = off + i; L.hit = h;
+          }
+          continue;
+        }
+        const unsigned k = __float_as_uint(c.x);
+        const DInstance& in = sc.instances[k];
+        Ray r; r.o = xf34_point(in.w2o, L.ray.o); r.d = xf34_vector(in.w2o, L.ray.d); r.t_max = L.ray.t_max;
+        if (in.n_nodes == 0u) {  // an object of one primitive is wrapped as it is (api.rs:1073-1082): no node test, no walk
+          f3 p0, p1, p2; load_tri(tri_p, (int)in.prim_base, p0, p1, p2);
+          TriHit h;
+          if (tri_test(p0, p1, p2, r, h)) {
+            L.found = true;
+            if (ANY) break;
+            L.ray.t_max = h.t; L.prim = (int)in.id_base; L.hit = h;
+          }
+          continue;
+        }
+        const f3 inv = mk3(1.0f / r.d.x, 1.0f / r.d.y, 1.0f / r.d.z);
+        const float4 r0 = nodes[2 * (size_t)in.node_base], r1 = nodes[2 * (size_t)in.node_base + 1];  // the object's root: the one node tested on its own
+        if (!slab_test(r0, r1, r, inv, inv.x < 0.0f, inv.y < 0.0f, inv.z < 0.0f)) continue;
+        if (i + 1 < n) {  // the rest of this leaf: an entry that no t_max can discard (the reference's loop over the leaf's primitives goes on whatever was hit)
+          stack[L.sp * BLOCK] = RT_PAIR_LEAF | RT_PAIR_GENERAL | (unsigned)(off + i + 1) | ((unsigned)(n - i - 2) << 26);
+          if (!ANY) tstack[(size_t)L.sp * grid_lanes] = -kInf;
+          ++L.sp;
+        }
+        wsave[0] = L.ray.o.x; wsave[BLOCK] = L.ray.o.y; wsave[2 * BLOCK] = L.ray.o.z; wsave[3 * BLOCK] = L.ray.d.x; wsave[4 * BLOCK] = L.ray.d.y; wsave[5 * BLOCK] = L.ray.d.z;
+        wsave[6 * BLOCK] = L.inv_dir.x; wsave[7 * BLOCK] = L.inv_dir.y; wsave[8 * BLOCK] = L.inv_dir.z;
+        wsave[9 * BLOCK] = __int_as_float(L.kz); wsave[10 * BLOCK] = L.sx; wsave[11 * BLOCK] = L.sy; wsave[12 * BLOCK] = L.sz;
+        L.ray.o = r.o; L.ray.d = r.d; L.inv_dir = inv; L.set_rp(ray_pre(r));
+        inst = k; node_base = in.node_base; prim_base = in.prim_base; id_base = in.id_base; sp_base = L.sp;
+        const unsigned packed = __float_as_uint(r1.w), np = packed & 0xffffu;
+        L.cur = np > 0u ? (RT_PAIR_LEAF | (unsigned)__float_as_int(r1.z) | ((np - 1u) << 26)) : (((packed >> 16) & 0xffu) << 29);
+        entered = true;
+      }
+      if (entered) continue;
+      if (ANY && L.found) pair_finish<ANY>(L, out); else pop();
+    }
+  }
+  if (stats) {
+    for (int off = 32; off > 0; off >>= 1) n_rays += __shfl_down(n_rays, off);
+    if (lane == 0u && n_rays) atomicAdd(&stats[st_rays], (unsigned long long)n_rays);
+  }
+}
+
 // ---- child-pair traversal with the top of the tree in LDS. k_trace_pair waits on memory two thirds of its wave cycles: every step is a dependent
 // fetch of a 64-byte record from L2 (or beyond), and every ray starts at the root. Here the pair records of the first levels of the tree (up to
 // RT_TOP_MAX interior nodes, breadth first; rt_scene_create) are copied into LDS once per workgroup and the steps that touch them never leave the
