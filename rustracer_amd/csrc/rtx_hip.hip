@@ -854,12 +854,17 @@ static size_t deep_stack_bytes(const rt_scene* s) {
 // the two knobs of the persistent traversal loops in one launch argument: lanes that must be idle before a wave refills (bits 0-7) and lanes that must wait at
 // a leaf before the leaf phase runs (bits 8-15; RT_LEAF_MIN, see leaf_phase_now; measurement knobs RTX_LEAF_MIN / RTX_LEAF_MIN_ANY). On an instanced scene a
 // leaf is a whole nested walk and gating pays even more (10 000 placements, closest hit: 310 / 227 / 166 / 140 / 125 / 122 ms at 1 / 8 / 20 / 32 / 48 / 64).
+// does the scene trace through k_trace_inst (object instances over plain triangles, objects with pair records; RTX_INST_LOOP=0: the nested walks)?
+static int inst_loop_bits() { static const int v = getenv("RTX_INST_LOOP") ? atoi(getenv("RTX_INST_LOOP")) : 3; return v; }
+static bool inst_loop_kernel(const rt_scene* s) { return inst_loop_bits() != 0 && s->has_instances && !s->has_masks && !s->has_spheres && s->use_pairs && s->d.obj_pairs; }
 static unsigned trace_knobs(const rt_scene* s, bool any) {
   static const int env_refill = getenv("RTX_REFILL_MIN") ? std::min(64, std::max(1, atoi(getenv("RTX_REFILL_MIN")))) : -1;
   static const int env_leaf = getenv("RTX_LEAF_MIN") ? std::min(64, std::max(1, atoi(getenv("RTX_LEAF_MIN")))) : -1;
   static const int env_leaf_any = getenv("RTX_LEAF_MIN_ANY") ? std::min(64, std::max(1, atoi(getenv("RTX_LEAF_MIN_ANY")))) : -1;
   const unsigned refill = env_refill > 0 ? (unsigned)env_refill : (unsigned)RT_REFILL_MIN;
-  unsigned leaf = s->has_instances ? 64u : (unsigned)RT_LEAF_MIN;  // (an instance leaf is a whole nested walk: the holders wait for every walker)
+  // (an instance leaf of the nested form is a whole walk: the holders wait for every walker. In k_trace_inst a leaf is a leaf again: 20 / 24 / 32 / 40 / 48 / 64 lanes
+  // gave 780 / 779 / 781 / 764 / 739 / 684 Msamples/s on 10 000 placements of a 1280-triangle object)
+  unsigned leaf = s->has_instances ? (inst_loop_kernel(s) ? 32u : 64u) : (unsigned)RT_LEAF_MIN;
   if (env_leaf > 0) leaf = (unsigned)env_leaf;
   if (any && env_leaf_any > 0) leaf = (unsigned)env_leaf_any;
   return refill | (leaf << 8);
@@ -920,7 +925,7 @@ static void launch_trace_c(rt_scene* s, const TraceIO& io, const unsigned* queue
         return;
       }
       // object instances over plain triangles: the two-level walk as one loop (k_trace_inst). RTX_INST_LOOP (measurement knob): bit 0 closest hit, bit 1 any hit; 0 = the nested walks
-      static const int inst_loop = getenv("RTX_INST_LOOP") ? atoi(getenv("RTX_INST_LOOP")) : 3;
+      const int inst_loop = inst_loop_bits();
       if (!big_only && s->has_instances && !all && !s->has_spheres && s->use_pairs && s->d.obj_pairs && ((ANY ? 2 : 1) & inst_loop)) {
         const unsigned depth = s->stack_depth <= 32 ? 32u : 64u;
         const unsigned lds = depth * 128u * 4u + 13u * 128u * 4u;
