@@ -357,6 +357,12 @@ bool exr_unpredict(std::vector<uint8_t>& raw, size_t want, std::string& err) {  
 // ---- PIZ (compression 4): per block a bitmap of the 16-bit values in use (-> a lookup table that packs them), a Haar-like 2-D wavelet transform of each
 // channel's 16-bit planes, and a canonical Huffman code over the result with a run-length symbol. Restated from the format's published description
 // (OpenEXR "ImfPizCompressor / ImfHuf / ImfWav": technical introduction + file layout documents).
+// Attribution: the wavelet decode below - piz_wdec14, piz_wdec16, piz_wav_decode - follows OpenEXR's ImfWav.cpp (wdec14 / wdec16 / wav2Decode)
+// step for step, loop nest and variable roles included; the lifting steps ARE the format, so a decoder cannot do anything else, but the shape of the code is
+// theirs. OpenEXR is Copyright (c) Contributors to the OpenEXR Project / Industrial Light & Magic, distributed under the BSD-3-Clause licence: redistribution
+// and use in source and binary forms, with or without modification, are permitted provided that the copyright notice, the list of conditions and the
+// disclaimer of the licence are retained ("THIS SOFTWARE IS PROVIDED BY THE COPYRIGHT HOLDERS AND CONTRIBUTORS "AS IS" AND ANY EXPRESS OR IMPLIED
+// WARRANTIES ... ARE DISCLAIMED"). Not part of /root/reference (which calls the `exr` crate); off the hot path.
 struct ExrBits {  // MSB-first bit reader over [p, end)
   const uint8_t* p; const uint8_t* end; uint64_t c = 0; int lc = 0; bool ok = true;
   uint32_t get(int n) {
