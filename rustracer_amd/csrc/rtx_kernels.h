@@ -2117,18 +2117,15 @@ __global__ void __launch_bounds__(256, (MODE == 1 || LEAN || BOUNCED) ? ((LEAN |
 #ifdef RT_ABLATE
   unsigned long long stamp_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, stamp_last = clock64();
 #endif
-  for (unsigned base = first + blockIdx.x * blockDim.x; base < count; base += stride) {
-    const unsigned i = base + threadIdx.x;
-    const bool lane_live = i < count;
-    n_shaded += lane_live ? 1u : 0u;
+  // one vertex per lane: entry i of the launch's queue, its records at slot rslot. Must be reached by every thread of the workgroup (the queue appends at its
+  // end are workgroup-wide).
+  auto shade_vertex = [&](const bool lane_live, const unsigned i, const unsigned rslot) {
     RT_STAMP(7);  // loop overhead / previous iteration's tail
     bool cont = false, want_shadow = false, want_mis = false, mis_occlusion_only = false;
     // what a continuing path takes to its slot in the next bounce's queue (stored after the append below has named the slot)
     f3 nr_o = mk3(0, 0, 0), nr_d = mk3(0, 0, 0); rgb3 beta = mkc(0, 0, 0); float eta_scale = 1.0f; unsigned st_out = 0u, pid = 0u; unsigned long long rng_out = 0ull;
     if (lane_live) {
-      // the vertex's records: four 16-byte loads at consecutive slots of consecutive lanes, requested together (slot = entry i of the sharded queue by the shard
-      // counts alone; on a material-sorted queue the sorted list names the slot)
-      const unsigned rslot = ps.cnt_in ? qv.get(i) : i;
+      // the vertex's records: four 16-byte loads at consecutive slots of consecutive lanes, requested together
       const float4 d4 = ps.in.d[rslot], h4 = ps.hit[rslot], b4 = ps.in.beta[rslot]; const uint4 s4 = ps.in.st[rslot];
       pid = s4.y;
       unsigned sl, pix; split_path_id(ps, pid, sl, pix); const unsigned s = ps.s0 + sl;
@@ -2314,6 +2311,50 @@ __global__ void __launch_bounds__(256, (MODE == 1 || LEAN || BOUNCED) ? ((LEAN |
     if (want_shadow) ps.q_shadow[slot[1]] = i;  // the ray queues name RECORDS (= this launch's queue positions)
     if (pr[2]) ps.q_mis[slot[2]] = i;
     if (NQ == 4 && pr[3]) ps.q_misany[slot[3]] = i;
+  };
+  // slot = entry i of the sharded queue by the shard counts alone; on a material-sorted queue the sorted list names the slot
+  if (MODE != 1) {
+    for (unsigned base = first + blockIdx.x * blockDim.x; base < count; base += stride) {
+      const unsigned i = base + threadIdx.x;
+      const bool lane_live = i < count;
+      n_shaded += lane_live ? 1u : 0u;
+      shade_vertex(lane_live, i, lane_live ? (ps.cnt_in ? qv.get(i) : i) : 0u);
+    }
+  } else {
+    // MODE 1 (area lights only: a ray that left the scene adds nothing and ends its path): the workgroup COMPACTS its entries before it shades them. A fifth of
+    // S1's vertices are such misses (the box is open towards the camera) and their lanes sat through the ~4000 instructions of the others: 44 of 64 lanes per
+    // VALU instruction. Each iteration the 256 threads look at the hit records of 256 entries, append the (entry, slot) pairs of the hits to a ring in LDS, and
+    // whenever the ring holds 256 of them a full workgroup of vertices is shaded; the remainder at the end. Which lane shades a vertex is irrelevant (paths are
+    // independent; a vertex's shadow / MIS records sit at its own entry number whoever writes them): same film, same counters.
+    __shared__ unsigned s_ring_slot[512], s_ring_i[512], s_wave_hits[4];
+    unsigned head = 0, n_pend = 0;  // (workgroup-uniform)
+    const unsigned lane = threadIdx.x & 63u, wv = threadIdx.x >> 6;
+    for (unsigned base = first + blockIdx.x * blockDim.x; base < count; base += stride) {
+      const unsigned i = base + threadIdx.x;
+      const bool lane_live = i < count;
+      n_shaded += lane_live ? 1u : 0u;
+      const unsigned rslot = lane_live ? (ps.cnt_in ? qv.get(i) : i) : 0u;
+      const bool hit = lane_live && __float_as_int(ps.hit[rslot].y) >= 0;
+      const unsigned long long m = __ballot(hit);
+      if (lane == 0u) s_wave_hits[wv] = (unsigned)__popcll(m);
+      __syncthreads();
+      unsigned before = 0, total = 0;
+#pragma unroll
+      for (unsigned w = 0; w < 4u; ++w) { const unsigned c = w < (blockDim.x >> 6) ? s_wave_hits[w] : 0u; before += w < wv ? c : 0u; total += c; }
+      if (hit) { const unsigned pos = (head + n_pend + before + (unsigned)__popcll(m & ((1ull << lane) - 1ull))) & 511u; s_ring_slot[pos] = rslot; s_ring_i[pos] = i; }
+      n_pend += total;
+      __syncthreads();
+      if (n_pend >= blockDim.x) {
+        const unsigned pos = (head + threadIdx.x) & 511u;
+        shade_vertex(true, s_ring_i[pos], s_ring_slot[pos]);
+        head = (head + blockDim.x) & 511u; n_pend -= blockDim.x;
+      }
+    }
+    if (n_pend > 0u) {
+      const unsigned pos = (head + threadIdx.x) & 511u;
+      const bool lv = threadIdx.x < n_pend;
+      shade_vertex(lv, lv ? s_ring_i[pos] : 0u, lv ? s_ring_slot[pos] : 0u);
+    }
   }
   if (GENERAL || QLIGHTS) {
     for (int off = 32; off > 0; off >>= 1) n_unreached += __shfl_down(n_unreached, off);
