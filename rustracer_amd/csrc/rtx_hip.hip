@@ -1316,7 +1316,7 @@ extern "C" int rt_render(rt_scene* s, const rt_camera* cam, const rt_film_desc* 
     struct Want { DevBuf* buf; size_t bytes; };
     std::vector<Want> want = {
         {&s->ws[B_GEN0], n_slots * 64}, {&s->ws[B_GEN1], n_slots * 64}, {&s->ws[B_HIT], n_slots * 16}, {&s->ws[B_GENS], bin_move ? n_slots * 64 : 16}, {&s->ws[B_HITS], bin_move ? n_slots * 16 : 16}, {&s->ws[B_LACC], cap * 16}, {&s->ws[B_PFILM], cap * 8},
-        {&s->ws[B_SH], cap * sizeof(ShadowRec)}, {&s->ws[B_MI], cap * sizeof(MisRec)}, {&s->ws[B_OCCSH], cap}, {&s->ws[B_OCCMI], cap},
+        {&s->ws[B_SH], cap * 48}, {&s->ws[B_MI], cap * 100}, {&s->ws[B_OCCSH], cap}, {&s->ws[B_OCCMI], cap},
         {&s->ws[B_QSH], szq}, {&s->ws[B_QMI], szq}, {&s->ws[B_QMA], has_infinite ? szq : 16},
         {&s->counters, counter_words * 4}, {&s->stats, (size_t)ST_COUNT * 8}, {&s->film_acc, (size_t)cw * ch * 16}, {&s->own_acc, (size_t)chunk_pixels * 16},
         {&s->filter_table, 1024}, {&s->scrambles[0], (size_t)chunk_pixels * 3 * dims * 4}, {&s->perms[0], (size_t)(chunk_pixels * table_bytes_per_pixel)},
@@ -1352,7 +1352,9 @@ extern "C" int rt_render(rt_scene* s, const rt_camera* cam, const rt_film_desc* 
   auto gen_of = [&](int b) { PathGen g; char* p = (char*)s->ws[b].p; g.o = (float4*)p; g.d = (float4*)(p + n_slots * 16); g.beta = (float4*)(p + n_slots * 32); g.st = (uint4*)(p + n_slots * 48); return g; };
   const PathGen gen0 = gen_of(B_GEN0), gen1 = gen_of(B_GEN1), gen_sorted = gen_of(B_GENS);
   ps.hit = s->ws[B_HIT].as<float4>(); ps.lacc = s->ws[B_LACC].as<float4>(); ps.pfilm = s->ws[B_PFILM].as<float2>();
-  ps.sh = s->ws[B_SH].as<ShadowRec>(); ps.mi = s->ws[B_MI].as<MisRec>();
+  { char* p = (char*)s->ws[B_SH].p; ps.sh.o = (float4*)p; ps.sh.d = (float4*)(p + cap * 16); ps.sh.add = (float4*)(p + cap * 32);
+    char* q = (char*)s->ws[B_MI].p; ps.mi.o = (float4*)q; ps.mi.d = (float4*)(q + cap * 16); ps.mi.hit = (float4*)(q + cap * 32); ps.mi.a = (float4*)(q + cap * 48);
+    ps.mi.b = (float4*)(q + cap * 64); ps.mi.c = (float4*)(q + cap * 80); ps.mi.flags = (unsigned*)(q + cap * 96); }
   ps.occ_sh = s->ws[B_OCCSH].as<unsigned char>(); ps.occ_mi = s->ws[B_OCCMI].as<unsigned char>();
   ps.q_shadow = s->ws[B_QSH].as<unsigned>(); ps.q_mis = s->ws[B_QMI].as<unsigned>(); ps.q_misany = s->ws[B_QMA].as<unsigned>();
   ps.own_acc = s->own_acc.as<float4>(); ps.shard_cap = shard_cap; ps.stats = s->stats.as<unsigned long long>();
@@ -1362,11 +1364,10 @@ extern "C" int rt_render(rt_scene* s, const rt_camera* cam, const rt_film_desc* 
   // the four kinds of trace launch of a bounce, on the records of the pass
   TraceIO io_path{}, io_shadow{}, io_mis{}, io_mis_any{};
   {
-    constexpr unsigned SR = sizeof(ShadowRec) / 16, MR = sizeof(MisRec) / 16;
     io_path.ray_stride = 1; io_path.hits = ps.hit; io_path.hit_stride = 1; io_path.hit_b2 = 1; io_path.queue_is_slots = 1;  // (ray_o / ray_d: the bounce's generation)
-    io_shadow.ray_o = &ps.sh->o; io_shadow.ray_d = &ps.sh->d; io_shadow.ray_stride = SR; io_shadow.occluded = (unsigned*)ps.occ_sh; io_shadow.occ_stride = 0;
-    io_shadow.shadow_masks = 1; io_shadow.lacc = ps.lacc; io_shadow.lacc_stride = 1; io_shadow.direct_add = &ps.sh->add; io_shadow.add_stride = SR;
-    io_mis.ray_o = &ps.mi->o; io_mis.ray_d = &ps.mi->d; io_mis.ray_stride = MR; io_mis.hits = &ps.mi->hit; io_mis.hit_stride = MR; io_mis.hit_b2 = 0;
+    io_shadow.ray_o = ps.sh.o; io_shadow.ray_d = ps.sh.d; io_shadow.ray_stride = 1; io_shadow.occluded = (unsigned*)ps.occ_sh; io_shadow.occ_stride = 0;
+    io_shadow.shadow_masks = 1; io_shadow.lacc = ps.lacc; io_shadow.lacc_stride = 1; io_shadow.direct_add = ps.sh.add; io_shadow.add_stride = 1;
+    io_mis.ray_o = ps.mi.o; io_mis.ray_d = ps.mi.d; io_mis.ray_stride = 1; io_mis.hits = ps.mi.hit; io_mis.hit_stride = 1; io_mis.hit_b2 = 0;
     io_mis_any = io_mis; io_mis_any.shadow_masks = 0; io_mis_any.hits = nullptr; io_mis_any.occluded = (unsigned*)ps.occ_mi; io_mis_any.occ_stride = 0;
   }
   const bool count = (flags & RT_FLAG_COUNT_TRAVERSAL) != 0;

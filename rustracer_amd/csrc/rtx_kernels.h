@@ -23,11 +23,14 @@ namespace rtx {
 // Before: RayRec / VertRec / PathAcc arrays indexed by path id and queues of ids, so a consumer's loads were a gather through the id (two dependent round
 // trips, lines shared with dead paths; S1 k_shade<1> moved 1.7x its algorithmic bytes at 0.68 wait cycles per wave cycle - VERDICT r03 weak #3).
 struct PathGen { float4* o; float4* d; float4* beta; uint4* st; };  // [slot]: ray (o | t_max), (d | -), throughput (rgb | eta_scale), (packed state, path id, RNG state lo, hi)
-struct ShadowRec { float4 o, d, add, pad; };  // 64 B: shadow ray (d.w = 1: no MIS ray pending, `add` is applied by the any-hit kernel) and beta * Ld / pick_pdf
+// The records of a vertex's shadow ray and BSDF-sampled MIS ray, PLANAR (round 4; 64- and 128-byte structs with 16 + 44 unused bytes before): a shade wave's
+// stores are contiguous 1 KB runs per field, the trace kernels read the two ray fields and nothing else, k_resolve reads what it needs of a vertex that
+// contributes. 48 B per shadow ray, 100 B per MIS ray.
+struct ShadowPlanes { float4* o; float4* d; float4* add; };  // (o | t_max), (d | complete-here flag << 31 | path id), beta * Ld / pick_pdf
+struct MisPlanes { float4* o; float4* d; float4* hit; float4* a; float4* b; float4* c; unsigned* flags; };  // d.w = path id; hit: of closest-hit MIS rays
 // 128 B, one line: everything k_resolve needs of a vertex with a BSDF-sampled MIS ray. hit.y = prim of the closest hit, or - for rays that only
 // need occlusion (sampled light infinite) - 1 / 0 from the any-hit kernel
-struct MisRec { float4 o, d, hit, a, b, c; unsigned occ, flags, pad[6]; };
-#define RT_PEND_SHADOW 1u           // MisRec::flags: a shadow ray is out (its result is in occ)
+#define RT_PEND_SHADOW 1u           // MisPlanes::flags: a shadow ray is out (its result is in occ_sh)
 #define RT_PEND_MIS_ANY 0x40000000u // the MIS ray was traced for occlusion only; bits 2-29: index of the sampled light
 struct PassState {
   unsigned cap;            // paths in this pass = n_pixels * n_samples
@@ -48,7 +51,7 @@ struct PassState {
   // ray queues (which hold these indices) list them in nearly ascending order for the trace kernels and k_resolve, and occ_sh / occ_mi below are indexed the
   // same way. On a material-sorted queue path ids are scattered; 192 B of records per vertex written and re-read by id were a quarter of S4's memory traffic.
   // Each record carries its path: ShadowRec::d.w = (no MIS ray in flight: complete at the any-hit epilogue) << 31 | path id, MisRec::d.w = path id.
-  ShadowRec* sh; MisRec* mi;
+  ShadowPlanes sh; MisPlanes mi;
   // one byte per path each: the shadow ray of a vertex that also has an MIS ray in flight was blocked / its occlusion-only MIS ray was blocked. Dense, so
   // that k_resolve learns from two bytes that a vertex contributes nothing (most vertices of an interior) without touching its 128-byte MisRec
   unsigned char* occ_sh; unsigned char* occ_mi;
@@ -2222,7 +2225,7 @@ __global__ void __launch_bounds__(256, (MODE == 1 || LEAN || BOUNCED) ? ((LEAN |
               float scattering_pdf = ((MODE != 1 && !LEAN) && light_is_delta(light)) ? 0.0f : bsdf.pdf(si.hit.wo, ls.wi, nonspec);  // read by the power heuristic only: a delta light has none
               if (!is_black(f)) {
                 Ray sr = spawn_ray_to_interaction(si.hit, ls.p1);  // VisibilityTester, light/mod.rs:52-55
-                ps.sh[i].o = make_float4(sr.o.x, sr.o.y, sr.o.z, sr.t_max);  // (shadow and MIS records sit at the vertex's position in THIS launch's queue, see PassState::sh)
+                ps.sh.o[i] = make_float4(sr.o.x, sr.o.y, sr.o.z, sr.t_max);  // (shadow and MIS records sit at the vertex's position in THIS launch's queue, see PassState::sh)
                 sh_dir = sr.d;
                 want_shadow = true;
                 if (light_is_delta(light)) ld1 = vdiv(f * ls.li, ls.pdf);
@@ -2250,8 +2253,8 @@ __global__ void __launch_bounds__(256, (MODE == 1 || LEAN || BOUNCED) ? ((LEAN |
                 }
                 if (go) {
                   Ray mr = spawn_ray(si.hit, bs.wi);
-                  ps.mi[i].o = make_float4(mr.o.x, mr.o.y, mr.o.z, kInf);
-                  ps.mi[i].d = make_float4(mr.d.x, mr.d.y, mr.d.z, __uint_as_float(pid));  // the path the record belongs to
+                  ps.mi.o[i] = make_float4(mr.o.x, mr.o.y, mr.o.z, kInf);
+                  ps.mi.d[i] = make_float4(mr.d.x, mr.d.y, mr.d.z, __uint_as_float(pid));  // the path the record belongs to
                   want_mis = true; f2v = f; w2 = weight; spdf2 = bs.pdf;
                   // An infinite light is never the emitter a ray hits (integrator/mod.rs:291-309): the term is `Le(ray)` if the ray leaves the
                   // scene and nothing otherwise, so occlusion is all this ray has to report.
@@ -2260,17 +2263,16 @@ __global__ void __launch_bounds__(256, (MODE == 1 || LEAN || BOUNCED) ? ((LEAN |
               }
             }
             if (want_mis) {  // both halves are combined by k_resolve once both rays are back
-              MisRec* const m = ps.mi + i;
-              m->a = make_float4(ld1.r, ld1.g, ld1.b, light_pdf);
-              m->b = make_float4(f2v.r, f2v.g, f2v.b, w2);
-              m->c = make_float4(beta.r, beta.g, beta.b, spdf2);
-              m->flags = (want_shadow ? RT_PEND_SHADOW : 0u) | 2u | ((unsigned)light_num << 2) | (mis_occlusion_only ? RT_PEND_MIS_ANY : 0u);
+              ps.mi.a[i] = make_float4(ld1.r, ld1.g, ld1.b, light_pdf);
+              ps.mi.b[i] = make_float4(f2v.r, f2v.g, f2v.b, w2);
+              ps.mi.c[i] = make_float4(beta.r, beta.g, beta.b, spdf2);
+              ps.mi.flags[i] = (want_shadow ? RT_PEND_SHADOW : 0u) | 2u | ((unsigned)light_num << 2) | (mis_occlusion_only ? RT_PEND_MIS_ANY : 0u);
               if (!want_shadow) ps.occ_sh[i] = (unsigned char)1;  // no light-sampling term: as good as blocked (the any-hit kernel writes the byte of every other vertex)
             } else if (want_shadow) {  // L += beta * ((0 + Ld1) / pick_pdf) if unoccluded, applied by the any-hit kernel
               rgb3 add = beta * vdiv(mkc(0, 0, 0) + ld1, light_pdf);
-              ps.sh[i].add = make_float4(add.r, add.g, add.b, 0.0f);
+              ps.sh.add[i] = make_float4(add.r, add.g, add.b, 0.0f);
             }
-            if (want_shadow) ps.sh[i].d = make_float4(sh_dir.x, sh_dir.y, sh_dir.z, __uint_as_float((want_mis ? 0u : 0x80000000u) | pid));  // bit 31: complete here (no MIS ray), bits 0-30: the path
+            if (want_shadow) ps.sh.d[i] = make_float4(sh_dir.x, sh_dir.y, sh_dir.z, __uint_as_float((want_mis ? 0u : 0x80000000u) | pid));  // bit 31: complete here (no MIS ray), bits 0-30: the path
           }
         }
         RT_STAMP(5);  // BSDF-sampling half + records
@@ -2404,13 +2406,12 @@ __global__ void __launch_bounds__(256) k_resolve(DScene sc, PassState ps) {
     const bool shadow_blocked = ps.occ_sh[rec] != 0;
     const bool mis_blocked = i >= n_closest && ps.occ_mi[rec] != 0;  // (an occlusion-only MIS ray)
     if (shadow_blocked && mis_blocked) continue;  // ld = 0: L + beta * (0 / pick_pdf) = L
-    const MisRec* const m = ps.mi + rec;
-    const unsigned pend = m->flags;
-    float4 a = m->a, c = m->c;
+    const unsigned pend = ps.mi.flags[rec];
+    float4 a = ps.mi.a[rec], c = ps.mi.c[rec];
     rgb3 ld = mkc(0, 0, 0);
     if ((pend & RT_PEND_SHADOW) && !shadow_blocked) ld = ld + mkc(a.x, a.y, a.z);
     {
-      float4 b = m->b, h4 = m->hit, d4 = m->d;
+      float4 b = ps.mi.b[rec], d4 = ps.mi.d[rec]; const float4 h4 = (pend & RT_PEND_MIS_ANY) ? make_float4(0, 0, 0, 0) : ps.mi.hit[rec];
       const int light_num = (int)((pend >> 2) & 0x0fffffffu);
       const DLight& light = sc.lights[light_num];
       f3 wi = mk3(d4.x, d4.y, d4.z);
@@ -2422,11 +2423,11 @@ __global__ void __launch_bounds__(256) k_resolve(DScene sc, PassState ps) {
         if (GENERAL && sc.n_instances != 0u && prim >= 0 && (unsigned)prim >= sc.n_top_prims) {  // a hit inside an object instance: an emitter there is in no light list (api.rs:954-964), so it is never the sampled light
         } else if (prim >= 0) {  // integrator/mod.rs:293-307: emitted radiance only if the hit emitter IS the sampled light
           if (GENERAL && tri_light(sc.tri_p, prim) == light_num && (tri_flags(sc.tri_p, prim) & RT_FLAG_SPHERE)) {
-            float4 o4 = m->o;
+            float4 o4 = ps.mi.o[rec];
             SurfaceInteraction lsi; (void)sphere_fill_interaction(sc.spheres[prim_sphere_index(sc.tri_p, prim)], mk3(o4.x, o4.y, o4.z), wi, lsi);
             li = area_light_l(light, lsi.hit.n, -wi);
           } else if (tri_light(sc.tri_p, prim) == light_num) {
-            float4 o4 = m->o;
+            float4 o4 = ps.mi.o[rec];
             f3 p0, p1, p2; load_tri(sc.tri_p, prim, p0, p1, p2);
             Ray r; r.o = mk3(o4.x, o4.y, o4.z); r.d = wi; r.t_max = kInf;
             TriHit th; (void)tri_test_call(p0, p1, p2, r, th);
@@ -2439,7 +2440,7 @@ __global__ void __launch_bounds__(256) k_resolve(DScene sc, PassState ps) {
     }
     rgb3 add = mkc(c.x, c.y, c.z) * vdiv(ld, a.w);
     if (add.r == 0.0f && add.g == 0.0f && add.b == 0.0f) continue;  // both rays blocked (most vertices of an interior): L + 0 = L, the scattered read-modify-write is skipped (a NaN is not 0)
-    const unsigned pid = __float_as_uint(m->d.w);  // the path the vertex belongs to
+    const unsigned pid = __float_as_uint(ps.mi.d[rec].w);  // the path the vertex belongs to
     float4 l4 = ps.lacc[pid];
     ps.lacc[pid] = make_float4(l4.x + add.r, l4.y + add.g, l4.z + add.b, l4.w);
   }
