@@ -1090,7 +1090,7 @@ static int sampler_plan_prepare(SamplerPlan& pl, unsigned spp_, unsigned dims_) 
 // lanes per K0b block: 16384 / spp lanes hold 32 KB of permutations (one wave at most, four lanes at least)
 static unsigned shuffle_lanes_per_block(unsigned spp) { unsigned l = 65536u / spp; return l > 64u ? 64u : (l < 4u ? 4u : l); }
 static int launch_sampler_tables(SamplerPlan& pl, const FrameParams& fp, unsigned n_pixels, unsigned long long explicit_pixel0, int use_explicit,
-                                 unsigned* scrambles, unsigned short* perms, hipStream_t stream) {
+                                 unsigned* scrambles, unsigned short* perms, hipStream_t stream, bool alone = false) {
   const unsigned spp = pl.spp, dims = pl.dims;
   const unsigned lpb = shuffle_lanes_per_block(spp);
   const size_t lds = (size_t)lpb * spp * 2;
@@ -1103,7 +1103,10 @@ static int launch_sampler_tables(SamplerPlan& pl, const FrameParams& fp, unsigne
   // kernels, where the sequential kernel - one latency-bound wave per CU - takes almost nothing from them and the parallel one competes for issue slots and
   // LDS: S1 883 = 883 ms, S4 6178 = 6183, S3 328 -> 353, S2 177 -> 202. What the frame did gain from is making the un-overlapped batch short (lead_pixels).
   static const bool par_on = getenv("RTX_K0_PARALLEL") && getenv("RTX_K0_PARALLEL")[0] == '1';
-  const bool par = par_on && spp >= 64u && spp <= 1024u;  // (2048: 112 KB of LDS per workgroup, past the 64 KB a kernel may declare statically)
+  // ... except for a frame's FIRST batch at 1024 spp, which no path kernel runs beside (`alone`): there the parallel replay is what it measures alone, 25.0 against
+  // 28.6 ms (S1 862 -> 857 ms over three interleaved pairs; at 256 / 512 spp, where a lane replays 4 / 8 steps, it loses: S2 167.3 -> 169.5, S3 323.5 -> 324.6)
+  static const bool par_never = getenv("RTX_K0_PARALLEL") && getenv("RTX_K0_PARALLEL")[0] == '0';
+  const bool par = (par_on || (alone && !par_never && spp == 1024u)) && spp >= 64u && spp <= 1024u;  // (2048: 112 KB of LDS per workgroup, past the 64 KB a kernel may declare statically)
   hipLaunchKernelGGL(k_sampler_draws, dim3((n_pixels + 255u) / 256u, pl.n_segs), dim3(256), 0, stream, fp, n_pixels, spp, dims, pl.seg_len, explicit_pixel0, use_explicit,
                      pl.segs.as<SamplerSeg>(), pl.magic.as<unsigned>(), scrambles, partners, pl.dirty.as<unsigned>(), par ? 1 : 0);
   hipLaunchKernelGGL(k_sampler_redo, dim3(RT_DIRTY_CAP / 64u), dim3(64), 0, stream, fp, n_pixels, spp, dims, explicit_pixel0, use_explicit, pl.dirty.as<unsigned>(), pl.magic.as<unsigned>(), scrambles, partners, par ? 1 : 0);
@@ -1395,7 +1398,7 @@ extern "C" int rt_render(rt_scene* s, const rt_camera* cam, const rt_film_desc* 
   auto launch_tables = [&](size_t b, int buf) {
     FrameParams f2 = fp; f2.chunk_first = batches[b].first;
     tm.begin(&stats.ms_sampler, aux);
-    const int trc = launch_sampler_tables(s->sampler_plan, f2, (unsigned)batches[b].second, 0ull, 0, s->scrambles[buf].as<unsigned>(), s->perms[buf].as<unsigned short>(), aux);
+    const int trc = launch_sampler_tables(s->sampler_plan, f2, (unsigned)batches[b].second, 0ull, 0, s->scrambles[buf].as<unsigned>(), s->perms[buf].as<unsigned short>(), aux, b == 0);
     if (trc != RT_OK && tables_rc == RT_OK) tables_rc = trc;
     tm.end(aux);
     (void)hipEventRecord(s->ev_tables[buf], aux);
