@@ -2088,14 +2088,29 @@ RT_DEVN int instance_fill_interaction(const DScene& sc, unsigned hit_id, float o
 // MODE 3: matte materials with sigma == 0 and no bump map - Kd any texture - under any kind of light: the register-resident
 // front-end with the generic light and texture functions. MODE 5: matte (any sigma), plastic, metal and mirror without bump map
 // through SmallBsdfT<false>; MODE 6: glass, substrate and opaque uber as well, through SmallBsdfT<true> (the narrow kernel is 5 % faster on its classes).
+// k_shade<1> is bound to FOUR waves per SIMD (round 4): with the vertex body a function of (entry, slot) it fits 128 VGPRs with nothing spilled (round 3: 84 B of
+// scratch at four, 381 -> 404 ms). S1 shade 299 -> 264 ms, 1248 -> 1300 Msamples/s; S2 1403 -> 1432 (two interleaved rounds).
 #ifndef RT_SHADE_MIN_WAVES
-#define RT_SHADE_MIN_WAVES 2
+#define RT_SHADE_MIN_WAVES 4
 #endif
 #ifndef RT_SHADE0_MIN_WAVES
 #define RT_SHADE0_MIN_WAVES 2
 #endif
+// Round 4: the plain forms of the textured front-ends are bound to THREE waves per SIMD. Round 3 measured that as a loss (k_shade<3> 207 -> 168 VGPRs with 40
+// spilled: S4 shade 4074 -> 4166 ms); since the vertex body became a function of (entry, slot) the kernels need 187 / 207 / 214 VGPRs, and at 168 with 24 / 46 /
+// 59 spilled dwords (48 / 112 / 128 B of scratch) the third wave now pays: S4 shade 3027 -> 2972 ms (k_shade<3>) and -> 2854 ms (k_shade<5 | 6>), 353.0 -> 356.3 /
+// 363.1 Msamples/s, two interleaved rounds on one box (scripts/ab_bench.sh).
+#ifndef RT_SHADE_BOUNCED_MIN_WAVES
+#define RT_SHADE_BOUNCED_MIN_WAVES 3
+#endif
+#ifndef RT_SHADE_LEAN_MIN_WAVES
+#define RT_SHADE_LEAN_MIN_WAVES 3
+#endif
+#ifndef RT_SHADE56_MIN_WAVES  // the two-lobe front-ends under any light / texture (k_shade<5 | 6>, plain form)
+#define RT_SHADE56_MIN_WAVES 3
+#endif
 #ifndef RT_SHADE3_MIN_WAVES  // the Lambert front-end under any light (k_shade<3>)
-#define RT_SHADE3_MIN_WAVES 2
+#define RT_SHADE3_MIN_WAVES 3
 #endif
 // GENERAL (generic front-end only): some emitter triangle carries an alpha mask, so Shape::pdf_wi's re-intersection evaluates it; such scenes shade
 // every vertex through k_shade<0, true>, every other scene never instantiates the mask evaluator in a shade kernel.
@@ -2110,7 +2125,7 @@ RT_DEVN int instance_fill_interaction(const DScene& sc, unsigned hit_id, float o
 // 325-333) - inlined here, no out-of-line evaluator, three waves per SIMD like the other LEAN forms. Round 3 shaded such scenes through the GENERAL forms:
 // 256 VGPRs and 352 - 448 B of scratch.
 template <int MODE, bool GENERAL = false, bool LEAN = false, bool BOUNCED = false, bool QLIGHTS = false>
-__global__ void __launch_bounds__(256, (MODE == 1 || LEAN || BOUNCED) ? ((LEAN || BOUNCED) ? 3 : RT_SHADE_MIN_WAVES) : (MODE == 3 && !GENERAL ? RT_SHADE3_MIN_WAVES : RT_SHADE0_MIN_WAVES)) k_shade(DScene sc, FrameParams fp, PassState ps) {
+__global__ void __launch_bounds__(256, (MODE == 1 || LEAN || BOUNCED) ? ((LEAN || BOUNCED) ? (BOUNCED ? RT_SHADE_BOUNCED_MIN_WAVES : RT_SHADE_LEAN_MIN_WAVES) : RT_SHADE_MIN_WAVES) : (MODE == 3 && !GENERAL ? RT_SHADE3_MIN_WAVES : ((MODE == 5 || MODE == 6) && !GENERAL ? RT_SHADE56_MIN_WAVES : RT_SHADE0_MIN_WAVES))) k_shade(DScene sc, FrameParams fp, PassState ps) {
   QView qv; if (ps.cnt_in) qv.init(ps.q_in, ps.cnt_in, ps.shard_cap);
   unsigned first = 0, count = ps.cnt_in ? qv.total() : ps.cap;  // no counts: bounce 0 of a pass whose samples are all traced (entry i = slot i = path i)
   if (MODE != 1 && ps.range) { first = ps.range[0]; count = ps.range[1]; }

@@ -243,10 +243,11 @@ def test_kernel_register_and_scratch_budgets(host):
     spec.loader.exec_module(kb)
     res = kb.kernel_resources(host.HIP_LIB)
     budget = {  # kernel prefix -> (max VGPRs, max scratch bytes)
-        "rtx::k_shade<1, false, false, false, false>": (168, 0),        # 3 waves per SIMD, no scratch, no out-of-line call
-        "rtx::k_shade<3, false, false, false, false>": (256, 64),       # 2 waves; no scratch beyond a dynamically indexed kernel-argument array (scratch there was 4 KB of memory traffic per vertex)
-        "rtx::k_shade<5, false, false, false, false>": (256, 64),
-        "rtx::k_shade<6, false, false, false, false>": (256, 64),
+        "rtx::k_shade<1, false, false, false, false>": (128, 0),        # FOUR waves per SIMD (round 4), no scratch, no out-of-line call
+        # the textured front-ends bound to three waves (round 4): a few dozen spilled dwords buy the third wave (S4 shade 3027 -> 2801 ms)
+        "rtx::k_shade<3, false, false, false, false>": (168, 64),
+        "rtx::k_shade<5, false, false, false, false>": (168, 128),
+        "rtx::k_shade<6, false, false, false, false>": (168, 128),
         "rtx::k_shade<0, false, false, false, false>": (256, 2048),     # 257 (one accumulation register added by a callee) is ONE wave per SIMD
         "rtx::k_trace<false, false, true, 256, 16, 0>": (72, 0),    # the LDS-resident closest-hit kernel of the headline: 7 waves
         "rtx::k_trace<true, false, true, 256, 16, 0>": (64, 0),     # ... and its shadow-ray twin: 8 waves
@@ -272,7 +273,7 @@ def test_kernel_register_and_scratch_budgets(host):
     }
     for name, (vg, sc) in budget.items():
         r = res[name]
-        spills_allowed = 32 if name.startswith("rtx::k_shade<0") else (64 if name.startswith("rtx::k_shade<") and (name.endswith("true, false, false, false>") or name.endswith("false, true, false, false>") or name.endswith("false, false, true>")) else (2 if name.endswith(", 2>") else 0))  # the generic kernel fills its 256 registers: a few spilled values, never a second wave lost
+        spills_allowed = 32 if name.startswith("rtx::k_shade<0") else (64 if name.startswith("rtx::k_shade<") and name[13] in "356" and name.endswith("false, false, false, false>") else 64 if name.startswith("rtx::k_shade<") and (name.endswith("true, false, false, false>") or name.endswith("false, true, false, false>") or name.endswith("false, false, true>")) else (2 if name.endswith(", 2>") else 0))  # the generic kernel fills its 256 registers: a few spilled values, never a second wave lost
         assert r["vgpr"] <= vg and r["scratch"] <= sc and r["vgpr_spills"] <= spills_allowed, (name, r)
 
 
