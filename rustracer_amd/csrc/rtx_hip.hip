@@ -825,7 +825,7 @@ extern "C" int rt_light_distribution(rt_scene* s, int32_t n_voxels[3], float* fu
 // LDS a workgroup of the trace kernels declares, and the persistent grid that fills every CU at that residency
 template <bool ANY, bool SMALL, int BLOCK, int DEPTH>
 static unsigned trace_grid(const rt_scene* s) {
-  const unsigned lds = (unsigned)(DEPTH * BLOCK * ((SMALL && !ANY) ? 2 : 4) + (SMALL ? (8 * RT_SMALL_NODES + 10 * RT_SMALL_TRIS) * 4 : 32));
+  const unsigned lds = (unsigned)(DEPTH * BLOCK * ((SMALL && (!ANY || RT_ANY_STACK16)) ? 2 : 4) + (SMALL ? (8 * RT_SMALL_NODES + 10 * RT_SMALL_TRIS) * 4 : 32));
   unsigned per_cu = (160u * 1024u) / lds; if (per_cu * BLOCK > 2048u) per_cu = 2048u / BLOCK; if (per_cu < 1) per_cu = 1;
   return (unsigned)s->n_cu * per_cu;
 }

@@ -745,23 +745,24 @@ __global__ void __launch_bounds__(256) k_raygen(FrameParams fp, PassState ps) {
 // FOUR distinct bank groups, so the ~20 distinct nodes a wave of bounced rays holds were served one after the other, eight to a group - the kernel was bound
 // by LDS bank conflicts (SQ_LDS_BANK_CONFLICT 1.26e10 > SQ_ACTIVE_INST_LDS 8.4e9 cycles on S1, round 3). Planar, the dword k of node cur sits in bank cur mod 32:
 // distinct nodes of a small scene fall into distinct banks, equal nodes are a broadcast.
-struct LdsSrc {
+template <int N, int T>
+struct LdsSrcT {
   const float* nodes; const float* tris;
   RT_DEV void node(int i, float4& a, float4& b) const {
-    constexpr int N = RT_SMALL_NODES;
     a = make_float4(nodes[i], nodes[N + i], nodes[2 * N + i], nodes[3 * N + i]);
     b = make_float4(nodes[4 * N + i], nodes[5 * N + i], nodes[6 * N + i], nodes[7 * N + i]);
   }
   RT_DEV void tri(int i, f3& p0, f3& p1, f3& p2) const {
-    constexpr int T = RT_SMALL_TRIS;
     p0 = mk3(tris[i], tris[T + i], tris[2 * T + i]); p1 = mk3(tris[3 * T + i], tris[4 * T + i], tris[5 * T + i]); p2 = mk3(tris[6 * T + i], tris[7 * T + i], tris[8 * T + i]);
   }
-  RT_DEV void tri_flags(int i, f3& p0, f3& p1, f3& p2, unsigned& flags) const { tri(i, p0, p1, p2); flags = __float_as_uint(tris[9 * RT_SMALL_TRIS + i]); }
+  RT_DEV void tri_flags(int i, f3& p0, f3& p1, f3& p2, unsigned& flags) const { tri(i, p0, p1, p2); flags = __float_as_uint(tris[9 * T + i]); }
 };
+typedef LdsSrcT<RT_SMALL_NODES, RT_SMALL_TRIS> LdsSrc;
+// (LDS arrays sized for S1's 63 nodes / 32 triangles - 11.5 KB per workgroup, eight resident instead of seven, 62 VGPRs - were measured in round 4: closest hit
+// 328 -> 341 ms, shadow rays 155 -> 166. Seven waves per SIMD is this kernel's optimum.)
 // copies the scene's nodes and leaf-ordered triangle records into the planar LDS arrays (every thread of the workgroup; followed by a barrier at the caller)
-template <int BLOCK>
+template <int BLOCK, int N = RT_SMALL_NODES, int T = RT_SMALL_TRIS>
 RT_DEV void stage_small_scene(const DScene& sc, float* s_nodes, float* s_tris) {
-  constexpr int N = RT_SMALL_NODES, T = RT_SMALL_TRIS;
   for (unsigned i = threadIdx.x; i < 2u * sc.n_nodes; i += BLOCK) {
     const float4 v = sc.nodes[i]; const unsigned n = i >> 1, h = (i & 1u) * 4u;
     s_nodes[h * N + n] = v.x; s_nodes[(h + 1u) * N + n] = v.y; s_nodes[(h + 2u) * N + n] = v.z; s_nodes[(h + 3u) * N + n] = v.w;
@@ -811,14 +812,20 @@ __global__ void __launch_bounds__(BLOCK, RT_GEN_MIN_WAVES(GENERAL)) k_trace(DSce
   unsigned* __restrict__ occluded = io.occluded; const size_t os = io.occ_stride;
   float4* __restrict__ lacc = io.lacc; const size_t ls = io.lacc_stride; const float4* __restrict__ direct_add = io.direct_add; const size_t as = io.add_stride;
   // node indices of a tiny scene fit 16 bits: half the stack bytes => more resident waves per CU
-  typedef typename std::conditional<SMALL && !ANY, unsigned short, int>::type StackT;
+// (round 4: 16-bit stack entries for the occlusion kernel too - 30 -> 21.5 KB of LDS per workgroup, 5 -> 7 resident: S1 shadow rays 169 -> 154.5 ms)
+#ifndef RT_ANY_STACK16
+#define RT_ANY_STACK16 1
+#endif
+  typedef typename std::conditional<SMALL && (!ANY || RT_ANY_STACK16), unsigned short, int>::type StackT;
   __shared__ StackT stack[DEPTH * BLOCK];
-  __shared__ float s_nodes[SMALL ? 8 * RT_SMALL_NODES : 1];
-  __shared__ float s_tris[SMALL ? 10 * RT_SMALL_TRIS : 1];
+  constexpr int NN = RT_SMALL_NODES, NT = RT_SMALL_TRIS;
+  typedef LdsSrcT<NN, NT> LdsS;
+  __shared__ float s_nodes[SMALL ? 8 * NN : 1];
+  __shared__ float s_tris[SMALL ? 10 * NT : 1];
   QView qv; if (queue) qv.init(io.queue_is_slots ? nullptr : queue, shard_counts, shard_cap);
   const unsigned count = queue ? qv.total() : count_static;
   if (blockIdx.x * BLOCK >= count) return;  // short queues (MIS rays, late bounces): most blocks of the persistent grid have nothing to stage for
-  if (SMALL) { stage_small_scene<BLOCK>(sc, s_nodes, s_tris); __syncthreads(); }
+  if (SMALL) { stage_small_scene<BLOCK, NN, NT>(sc, s_nodes, s_tris); __syncthreads(); }
   const unsigned stride = gridDim.x * BLOCK;
   unsigned n_nodes = 0, n_tris = 0, n_rays = 0;
   auto trace_one = [&](unsigned pid) {
@@ -828,8 +835,8 @@ __global__ void __launch_bounds__(BLOCK, RT_GEN_MIN_WAVES(GENERAL)) k_trace(DSce
     bool found;
     constexpr int LM = ANY ? RT_LDS_LEAF_MIN_ANY : RT_LDS_LEAF_MIN_CLOSEST;
     const GeneralCtx gen{sc.self, ANY && io.shadow_masks != 0};
-    if (SMALL && LM > 1 && LM < 64 && !COUNT) { LdsSrc src{s_nodes, s_tris}; found = traverse_rounds<ANY, COUNT, LM, LdsSrc, StackT, GENERAL>(src, ray, stack + threadIdx.x, BLOCK, prim, h, n_nodes, n_tris, gen); }
-    else if (SMALL) { LdsSrc src{s_nodes, s_tris}; found = traverse<ANY, COUNT, LdsSrc, StackT, GENERAL>(src, ray, stack + threadIdx.x, BLOCK, prim, h, n_nodes, n_tris, gen); }
+    if (SMALL && LM > 1 && LM < 64 && !COUNT) { LdsS src{s_nodes, s_tris}; found = traverse_rounds<ANY, COUNT, LM, LdsS, StackT, GENERAL>(src, ray, stack + threadIdx.x, BLOCK, prim, h, n_nodes, n_tris, gen); }
+    else if (SMALL) { LdsS src{s_nodes, s_tris}; found = traverse<ANY, COUNT, LdsS, StackT, GENERAL>(src, ray, stack + threadIdx.x, BLOCK, prim, h, n_nodes, n_tris, gen); }
     else { GlobalSrc src{sc.nodes, sc.tri_p}; found = traverse<ANY, COUNT, GlobalSrc, StackT, GENERAL>(src, ray, stack + threadIdx.x, BLOCK, prim, h, n_nodes, n_tris, gen); }
     n_rays += 1;
     if (ANY) trace_write_any(lacc, ls, direct_add, as, occluded, os, pid, d4.w, found);
