@@ -2107,6 +2107,9 @@ RT_DEVN int instance_fill_interaction(const DScene& sc, unsigned hit_id, float o
 // spilled: S4 shade 4074 -> 4166 ms); since the vertex body became a function of (entry, slot) the kernels need 187 / 207 / 214 VGPRs, and at 168 with 24 / 46 /
 // 59 spilled dwords (48 / 112 / 128 B of scratch) the third wave now pays: S4 shade 3027 -> 2972 ms (k_shade<3>) and -> 2854 ms (k_shade<5 | 6>), 353.0 -> 356.3 /
 // 363.1 Msamples/s, two interleaved rounds on one box (scripts/ab_bench.sh).
+#ifndef RT_SHADE_GEN_MIN_WAVES  // the GENERAL forms of the register-resident front-ends (quadric / instance hits, masked emitters)
+#define RT_SHADE_GEN_MIN_WAVES 2
+#endif
 #ifndef RT_SHADE_BOUNCED_MIN_WAVES
 #define RT_SHADE_BOUNCED_MIN_WAVES 3
 #endif
@@ -2132,7 +2135,7 @@ RT_DEVN int instance_fill_interaction(const DScene& sc, unsigned hit_id, float o
 // 325-333) - inlined here, no out-of-line evaluator, three waves per SIMD like the other LEAN forms. Round 3 shaded such scenes through the GENERAL forms:
 // 256 VGPRs and 352 - 448 B of scratch.
 template <int MODE, bool GENERAL = false, bool LEAN = false, bool BOUNCED = false, bool QLIGHTS = false>
-__global__ void __launch_bounds__(256, (MODE == 1 || LEAN || BOUNCED) ? ((LEAN || BOUNCED) ? (BOUNCED ? RT_SHADE_BOUNCED_MIN_WAVES : RT_SHADE_LEAN_MIN_WAVES) : RT_SHADE_MIN_WAVES) : (MODE == 3 && !GENERAL ? RT_SHADE3_MIN_WAVES : ((MODE == 5 || MODE == 6) && !GENERAL ? RT_SHADE56_MIN_WAVES : RT_SHADE0_MIN_WAVES))) k_shade(DScene sc, FrameParams fp, PassState ps) {
+__global__ void __launch_bounds__(256, (MODE == 1 || LEAN || BOUNCED) ? ((LEAN || BOUNCED) ? (BOUNCED ? RT_SHADE_BOUNCED_MIN_WAVES : RT_SHADE_LEAN_MIN_WAVES) : RT_SHADE_MIN_WAVES) : (MODE == 3 && !GENERAL ? RT_SHADE3_MIN_WAVES : ((MODE == 5 || MODE == 6) && !GENERAL ? RT_SHADE56_MIN_WAVES : (MODE != 0 && GENERAL ? RT_SHADE_GEN_MIN_WAVES : RT_SHADE0_MIN_WAVES)))) k_shade(DScene sc, FrameParams fp, PassState ps) {
   QView qv; if (ps.cnt_in) qv.init(ps.q_in, ps.cnt_in, ps.shard_cap);
   unsigned first = 0, count = ps.cnt_in ? qv.total() : ps.cap;  // no counts: bounce 0 of a pass whose samples are all traced (entry i = slot i = path i)
   if (MODE != 1 && ps.range) { first = ps.range[0]; count = ps.range[1]; }
