@@ -88,12 +88,12 @@ struct rt_scene {
   // sampler tables are double-buffered: K0 of batch b+1 runs on aux_stream under the path kernels of batch b
   DevBuf scrambles[2], perms[2];
   hipStream_t aux_stream = nullptr;
-  hipEvent_t ev_tables[2] = {nullptr, nullptr}, ev_batch_done[2] = {nullptr, nullptr}, ev_frame_begin = nullptr;
+  hipEvent_t ev_tables[2][3] = {{nullptr, nullptr, nullptr}, {nullptr, nullptr, nullptr}}, ev_batch_done[2] = {nullptr, nullptr}, ev_frame_begin = nullptr;  // ev_tables[buffer][table group]
   int n_cu = 256;
   std::vector<hipEvent_t> event_pool;
   ~rt_scene() {
     for (hipEvent_t e : event_pool) (void)hipEventDestroy(e);
-    for (int i = 0; i < 2; ++i) { if (ev_tables[i]) (void)hipEventDestroy(ev_tables[i]); if (ev_batch_done[i]) (void)hipEventDestroy(ev_batch_done[i]); }
+    for (int i = 0; i < 2; ++i) { for (int g = 0; g < 3; ++g) if (ev_tables[i][g]) (void)hipEventDestroy(ev_tables[i][g]); if (ev_batch_done[i]) (void)hipEventDestroy(ev_batch_done[i]); }
     if (ev_frame_begin) (void)hipEventDestroy(ev_frame_begin);
     if (aux_stream) (void)hipStreamDestroy(aux_stream);
   }
@@ -1089,8 +1089,30 @@ static int sampler_plan_prepare(SamplerPlan& pl, unsigned spp_, unsigned dims_) 
 }
 // lanes per K0b block: 16384 / spp lanes hold 32 KB of permutations (one wave at most, four lanes at least)
 static unsigned shuffle_lanes_per_block(unsigned spp) { unsigned l = 65536u / spp; return l > 64u ? 64u : (l < 4u ? 4u : l); }
+// The tables of a batch in the ORDER A FRAME NEEDS THEM (round 4). ZeroTwoSequence hands out dimension after dimension: the camera sample takes 2-D tables 0 and 1
+// (film, lens) and 1-D table 0 (time - which this camera never reads); bounce 0 takes 1-D table 1 (light pick) and the remaining 2-D tables (light point,
+// scattering direction); bounces 1, 2, ... the remaining 1-D tables; everything after comes from the per-sample RNG. One PCG32 stream runs through all tables
+// of a pixel, so the DRAWS of all tables are made first (k_sampler_draws finds the retries that shift later tables; 3.8 ms of a 28.6 ms batch) - but the
+// shuffles, the expensive part, are independent per table: group 0 = what k_raygen reads, group 1 = what bounce 0's shade reads, group 2 = the rest; an event after
+// each group lets the frame's first batch start its camera rays after 11 ms instead of 28.6, with the other shuffles under its first kernels. 1-D table 0 is not
+// shuffled at all inside a frame (nothing reads it); rt_sampler_tables builds every table.
+struct TableGroups { unsigned packed[3], n[3]; int n_groups; };
+static TableGroups table_groups_all(unsigned dims) {
+  TableGroups g{}; g.n_groups = 1;
+  for (unsigned t = 0; t < 2u * dims; ++t) { g.packed[0] |= t << (4u * g.n[0]); g.n[0] += 1; }
+  return g;
+}
+static TableGroups table_groups_frame(unsigned dims) {
+  TableGroups g{}; g.n_groups = 3;
+  auto add = [&](int k, unsigned t) { g.packed[k] |= t << (4u * g.n[k]); g.n[k] += 1; };
+  add(0, dims); add(0, dims + 1u);                                   // 2-D tables 0, 1: the camera sample
+  if (dims > 1u) add(1, 1u);                                         // 1-D table 1: bounce 0's light pick
+  for (unsigned d = 2; d < dims; ++d) add(1, dims + d);              // 2-D tables 2 ...: bounce 0's light point and scattering direction
+  for (unsigned d = 2; d < dims; ++d) add(2, d);                     // 1-D tables 2 ...: the light picks of bounces 1, 2, ...
+  return g;
+}
 static int launch_sampler_tables(SamplerPlan& pl, const FrameParams& fp, unsigned n_pixels, unsigned long long explicit_pixel0, int use_explicit,
-                                 unsigned* scrambles, unsigned short* perms, hipStream_t stream, bool alone = false) {
+                                 unsigned* scrambles, unsigned short* perms, hipStream_t stream, bool alone, const TableGroups& groups, hipEvent_t* group_done) {
   const unsigned spp = pl.spp, dims = pl.dims;
   const unsigned lpb = shuffle_lanes_per_block(spp);
   const size_t lds = (size_t)lpb * spp * 2;
@@ -1106,23 +1128,27 @@ static int launch_sampler_tables(SamplerPlan& pl, const FrameParams& fp, unsigne
   // ... except for a frame's FIRST batch at 1024 spp, which no path kernel runs beside (`alone`): there the parallel replay is what it measures alone, 25.0 against
   // 28.6 ms (S1 862 -> 857 ms over three interleaved pairs; at 256 / 512 spp, where a lane replays 4 / 8 steps, it loses: S2 167.3 -> 169.5, S3 323.5 -> 324.6)
   static const bool par_never = getenv("RTX_K0_PARALLEL") && getenv("RTX_K0_PARALLEL")[0] == '0';
-  const bool par = (par_on || (alone && !par_never && spp == 1024u)) && spp >= 64u && spp <= 1024u;  // (2048: 112 KB of LDS per workgroup, past the 64 KB a kernel may declare statically)
+  const bool par = (par_on || (alone && !par_never && spp == 1024u)) && spp >= 64u && spp <= 1024u;
   hipLaunchKernelGGL(k_sampler_draws, dim3((n_pixels + 255u) / 256u, pl.n_segs), dim3(256), 0, stream, fp, n_pixels, spp, dims, pl.seg_len, explicit_pixel0, use_explicit,
                      pl.segs.as<SamplerSeg>(), pl.magic.as<unsigned>(), scrambles, partners, pl.dirty.as<unsigned>(), par ? 1 : 0);
   hipLaunchKernelGGL(k_sampler_redo, dim3(RT_DIRTY_CAP / 64u), dim3(64), 0, stream, fp, n_pixels, spp, dims, explicit_pixel0, use_explicit, pl.dirty.as<unsigned>(), pl.magic.as<unsigned>(), scrambles, partners, par ? 1 : 0);
-  if (par) {
-    const dim3 grid((n_pixels + RT_SHUF_PIX - 1) / RT_SHUF_PIX, 2u * dims);
-    unsigned* const resorted = pl.dirty.as<unsigned>() + 1 + RT_DIRTY_CAP + 1;  // waves whose groups did not come out sorted (diagnostic; the result is exact either way)
-    switch (spp) {
-      case 64: hipLaunchKernelGGL(k_sampler_shuffle_par<1>, grid, dim3(256), 0, stream, n_pixels, partners, perms, resorted); break;
-      case 128: hipLaunchKernelGGL(k_sampler_shuffle_par<2>, grid, dim3(256), 0, stream, n_pixels, partners, perms, resorted); break;
-      case 256: hipLaunchKernelGGL(k_sampler_shuffle_par<4>, grid, dim3(256), 0, stream, n_pixels, partners, perms, resorted); break;
-      case 512: hipLaunchKernelGGL(k_sampler_shuffle_par<8>, grid, dim3(256), 0, stream, n_pixels, partners, perms, resorted); break;
-      default: hipLaunchKernelGGL(k_sampler_shuffle_par<16>, grid, dim3(256), 0, stream, n_pixels, partners, perms, resorted); break;
+  unsigned* const resorted = pl.dirty.as<unsigned>() + 1 + RT_DIRTY_CAP + 1;  // waves whose groups did not come out sorted (diagnostic; the result is exact either way)
+  for (int g = 0; g < groups.n_groups; ++g) {
+    const unsigned tables = groups.packed[g], nt = groups.n[g];
+    if (nt) {
+      if (par) {
+        const dim3 grid((n_pixels + RT_SHUF_PIX - 1) / RT_SHUF_PIX, nt);
+        switch (spp) {
+          case 64: hipLaunchKernelGGL(k_sampler_shuffle_par<1>, grid, dim3(256), 0, stream, n_pixels, partners, perms, resorted, tables); break;
+          case 128: hipLaunchKernelGGL(k_sampler_shuffle_par<2>, grid, dim3(256), 0, stream, n_pixels, partners, perms, resorted, tables); break;
+          case 256: hipLaunchKernelGGL(k_sampler_shuffle_par<4>, grid, dim3(256), 0, stream, n_pixels, partners, perms, resorted, tables); break;
+          case 512: hipLaunchKernelGGL(k_sampler_shuffle_par<8>, grid, dim3(256), 0, stream, n_pixels, partners, perms, resorted, tables); break;
+          default: hipLaunchKernelGGL(k_sampler_shuffle_par<16>, grid, dim3(256), 0, stream, n_pixels, partners, perms, resorted, tables); break;
+        }
+      } else hipLaunchKernelGGL(k_sampler_shuffle, dim3((n_pixels + lpb - 1) / lpb, nt), dim3(lpb), lds, stream, n_pixels, spp, partners, perms, tables);
     }
-    return RT_OK;
+    if (group_done) (void)hipEventRecord(group_done[g], stream);
   }
-  hipLaunchKernelGGL(k_sampler_shuffle, dim3((n_pixels + lpb - 1) / lpb, 2u * dims), dim3(lpb), lds, stream, n_pixels, spp, partners, perms);
   return RT_OK;
 }
 static int sampler_set_lds_limits(unsigned spp) {
@@ -1154,7 +1180,7 @@ static int sampler_tables_host(int32_t spp_, int32_t dims, uint64_t pixel0, uint
     const unsigned lpb = sampler_lanes_per_block(spp);
     hipLaunchKernelGGL(k_sampler_tables, dim3((unsigned)((n_pixels + lpb - 1) / lpb)), dim3(lpb), (size_t)lpb * (spp + 2) * 2, nullptr, fp, (unsigned)n_pixels, spp, (unsigned)dims,
                        (unsigned long long)pixel0, 1, sc.as<unsigned>(), pm.as<unsigned short>());
-  } else if ((rc = launch_sampler_tables(plan, fp, (unsigned)n_pixels, (unsigned long long)pixel0, 1, sc.as<unsigned>(), pm.as<unsigned short>(), nullptr)) != RT_OK) return rc;
+  } else if ((rc = launch_sampler_tables(plan, fp, (unsigned)n_pixels, (unsigned long long)pixel0, 1, sc.as<unsigned>(), pm.as<unsigned short>(), nullptr, false, table_groups_all((unsigned)dims), nullptr)) != RT_OK) return rc;
   HIP_TRY(hipGetLastError());
   HIP_TRY(hipDeviceSynchronize());
   { unsigned ovf[2] = {0, 0}; HIP_TRY(hipMemcpy(ovf, plan.dirty.as<unsigned>() + 1 + RT_DIRTY_CAP, 8, hipMemcpyDeviceToHost)); if (ovf[0]) return fail(RT_ERR_INVALID, "sampler retry list overflow");
@@ -1342,7 +1368,7 @@ extern "C" int rt_render(rt_scene* s, const rt_camera* cam, const rt_film_desc* 
   if (!s->aux_stream) {
     int lo = 0, hi = 0; (void)hipDeviceGetStreamPriorityRange(&lo, &hi);  // lo = numerically greatest = lowest priority
     HIP_TRY(hipStreamCreateWithPriority(&s->aux_stream, hipStreamNonBlocking, lo));
-    for (int i = 0; i < 2; ++i) { HIP_TRY(hipEventCreateWithFlags(&s->ev_tables[i], hipEventDisableTiming)); HIP_TRY(hipEventCreateWithFlags(&s->ev_batch_done[i], hipEventDisableTiming)); }
+    for (int i = 0; i < 2; ++i) { for (int g = 0; g < 3; ++g) HIP_TRY(hipEventCreateWithFlags(&s->ev_tables[i][g], hipEventDisableTiming)); HIP_TRY(hipEventCreateWithFlags(&s->ev_batch_done[i], hipEventDisableTiming)); }
     HIP_TRY(hipEventCreateWithFlags(&s->ev_frame_begin, hipEventDisableTiming));
   }
   float4* const d_out = (flags & RT_FLAG_FILM_ON_DEVICE) ? (float4*)film_xyzw : s->film_out.as<float4>();
@@ -1395,13 +1421,16 @@ extern "C" int rt_render(rt_scene* s, const rt_camera* cam, const rt_film_desc* 
     const unsigned long long npx = (first == 0 && lead_pixels) ? lead_pixels : std::min(chunk_pixels, owned_pixels - first);
     batches.push_back({first, npx}); first += npx;
   }
+  static const bool groups_off = getenv("RTX_K0_GROUPS") && getenv("RTX_K0_GROUPS")[0] == '0';  // measurement knob: every table before the batch's first kernel
+  TableGroups tgroups = groups_off ? table_groups_all(dims) : table_groups_frame(dims);
+  if (groups_off) { tgroups.n_groups = 3; }  // (groups 1 and 2 empty: their events follow group 0's at once)
   auto launch_tables = [&](size_t b, int buf) {
     FrameParams f2 = fp; f2.chunk_first = batches[b].first;
     tm.begin(&stats.ms_sampler, aux);
-    const int trc = launch_sampler_tables(s->sampler_plan, f2, (unsigned)batches[b].second, 0ull, 0, s->scrambles[buf].as<unsigned>(), s->perms[buf].as<unsigned short>(), aux, b == 0);
+    const int trc = launch_sampler_tables(s->sampler_plan, f2, (unsigned)batches[b].second, 0ull, 0, s->scrambles[buf].as<unsigned>(), s->perms[buf].as<unsigned short>(), aux, b == 0,
+                                          tgroups, s->ev_tables[buf]);
     if (trc != RT_OK && tables_rc == RT_OK) tables_rc = trc;
     tm.end(aux);
-    (void)hipEventRecord(s->ev_tables[buf], aux);
   };
   if (!batches.empty()) launch_tables(0, 0);  // a rank may own no rows
   for (size_t batch_no = 0; batch_no < batches.size(); ++batch_no) {
@@ -1416,7 +1445,7 @@ extern "C" int rt_render(rt_scene* s, const rt_camera* cam, const rt_film_desc* 
     }
     const unsigned batch_pass_samples = (unsigned)std::min<unsigned long long>(spp, std::max<unsigned long long>(pass_samples, cap / npx));  // (a short batch: more samples per pass, same paths)
     if (tables_rc != RT_OK) { (void)hipDeviceSynchronize(); return tables_rc; }
-    HIP_TRY(hipStreamWaitEvent(stream, s->ev_tables[buf], 0));
+    HIP_TRY(hipStreamWaitEvent(stream, s->ev_tables[buf][0], 0));  // the tables the camera samples read; the others are waited for where they are first read
     for (unsigned s0 = 0; s0 < spp; s0 += batch_pass_samples) {
       ps.s0 = s0; ps.n_samples = std::min(batch_pass_samples, spp - s0); ps.cap = (unsigned)(npx * ps.n_samples);
       ps.q_in = nullptr; ps.in = gen1; ps.out = gen0;  // raygen writes bounce 0's records
@@ -1441,6 +1470,7 @@ extern "C" int rt_render(rt_scene* s, const rt_camera* cam, const rt_film_desc* 
         // the rays of the bounce sit at their queue slots: the kernels walk the entries by the shard counts alone (a non-NULL `queue` only says "sharded")
         launch_trace<false>(s, count, io_path, ps.cnt_in, ps.cnt_in, ps.shard_cap, ps.cap, dstats, ST_RAYS_CLOSEST, ST_NODES_CLOSEST, ST_TRIS_CLOSEST, stream);
         tm.end();
+        if (bounce <= 1) HIP_TRY(hipStreamWaitEvent(stream, s->ev_tables[buf][bounce + 1], 0));  // table groups 1 / 2: first read by the shade launches of bounce 0 / 1
 #define RT_SHADE(MODE, P) launch_shade<MODE>(gshade, lean_shade, bounce >= 1 && !bounced_off, sgrid, sblock, stream, s->d, fp, P, qlights)
         if (s->lambert_only) { tm.begin(&stats.ms_shade_lambert_const); hipLaunchKernelGGL(k_shade<1>, dim3(sgrid), dim3(sblock), 0, stream, s->d, fp, ps); tm.end(); }
         else if (s->lambert_materials) { tm.begin(&stats.ms_shade_lambert); RT_SHADE(3, ps); tm.end(); }

@@ -321,13 +321,15 @@ RT_DEV void unpack8(uint4 v, unsigned* o) {
   o[4] = v.z & 0xffffu; o[5] = v.z >> 16; o[6] = v.w & 0xffffu; o[7] = v.w >> 16;
 }
 // blockDim.x = L lanes (one wave at most), blockIdx.y = table
-__global__ void __launch_bounds__(64) k_sampler_shuffle(unsigned n_pixels, unsigned spp, const unsigned short* __restrict__ partners, unsigned short* __restrict__ perms) {
+// `tables`: the launch's tables, 4 bits each (blockIdx.y-th nibble): a frame builds its tables in the order it needs them (rt_render)
+__global__ void __launch_bounds__(64) k_sampler_shuffle(unsigned n_pixels, unsigned spp, const unsigned short* __restrict__ partners, unsigned short* __restrict__ perms, unsigned tables) {
+  const unsigned table = (tables >> (4u * blockIdx.y)) & 15u;
   extern __shared__ unsigned short lds_perm[];
   const unsigned lane = threadIdx.x, L = blockDim.x;
   const unsigned pix0 = blockIdx.x * L, pix = pix0 + lane;
   const PermLds a = perm_lds(lds_perm, lane, spp);
   if (pix < n_pixels) {
-    const unsigned short* in = partners + (size_t)blockIdx.y * spp * n_pixels + pix;
+    const unsigned short* in = partners + (size_t)table * spp * n_pixels + pix;
     for (unsigned i = 0; i < spp; ++i) a.set(i, i);
     constexpr int G = 8;
     if (spp >= 4u * G) {
@@ -357,7 +359,7 @@ __global__ void __launch_bounds__(64) k_sampler_shuffle(unsigned n_pixels, unsig
   __syncthreads();
   // flush to perms[table][sample][pixel]. A vector memory instruction costs the same issue slot whatever it
   // carries, so each lane gathers one sample of 8 neighbouring pixels from LDS and stores 16 bytes.
-  unsigned short* out = perms + (size_t)blockIdx.y * spp * n_pixels;
+  unsigned short* out = perms + (size_t)table * spp * n_pixels;
   if ((n_pixels & 7u) == 0u && L >= 8u) {
     const unsigned groups = L >> 3, g = lane % groups, r0 = lane / groups;  // 8 rows per pass
     const unsigned gp = pix0 + 8u * g;
@@ -400,13 +402,13 @@ RT_DEV void wave_sync_lds() { __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgrou
 #define K0S(k) do { } while (0)
 #endif
 template <int E>
-__global__ void __launch_bounds__(256) k_sampler_shuffle_par(unsigned n_pixels, const unsigned short* __restrict__ partners, unsigned short* __restrict__ perms, unsigned* __restrict__ n_resorted) {
+__global__ void __launch_bounds__(256) k_sampler_shuffle_par(unsigned n_pixels, const unsigned short* __restrict__ partners, unsigned short* __restrict__ perms, unsigned* __restrict__ n_resorted, unsigned tables) {
   constexpr unsigned N = 64u * E, NONE = 0xffffu;
   __shared__ unsigned short tile[RT_SHUF_PIX][N + 2];  // (+2: rows an odd number of words apart, the transposed read-out is conflict-free)
   __shared__ unsigned short s_o[4][N];                 // per wave: R (the pointer-jumping array)
   __shared__ unsigned s_cnt[4][N / 2 + 64 + 1];        // per wave: packed 16-bit counters per target (target p at index CI(p) = p + 2 * (p / E)), then exclusive bases
   __shared__ unsigned short s_wl[4][N];                // per wave: writers grouped by target
-  const unsigned lane = threadIdx.x & 63u, wv = threadIdx.x >> 6, t = blockIdx.y, pix0 = blockIdx.x * RT_SHUF_PIX;
+  const unsigned lane = threadIdx.x & 63u, wv = threadIdx.x >> 6, t = (tables >> (4u * blockIdx.y)) & 15u, pix0 = blockIdx.x * RT_SHUF_PIX;
   unsigned short* const o = s_o[wv]; unsigned* const cnt = s_cnt[wv]; unsigned short* const wl = s_wl[wv];
   const unsigned short* const cnt16 = (const unsigned short*)cnt;
 #ifdef RT_K0_STAMP
