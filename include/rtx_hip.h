@@ -196,9 +196,13 @@ typedef struct rt_path_desc {     /* PathIntegrator (rc/integrator/path.rs:25-31
   int32_t light_strategy;         /* 0 "spatial" (voxel CDF, rc/lightdistrib.rs), 1 "uniform" */
   int32_t pixel_bounds[4];        /* x0 y0 x1 y1                                    */
 } rt_path_desc;
-/* Film sharding for multi-GPU: this call renders the 16-pixel tile rows r with
- * r % world_size == rank; pixels of other rows stay zero in the output. */
+/* Film sharding for multi-GPU: this call renders the bands r of the sample rows with r % world_size == rank; pixels of
+ * other rows stay zero in the output. A band is RT_SHARD_ROWS(H, world_size) rows high, H = the sample bounds' height: the reference's 16-row tile
+ * rows - or 8 rows when the number of 16-row bands is not a multiple of world_size (1080 rows on 8 devices: 68 bands would be 9 for four devices and
+ * 8 for the others, 1.059 of the mean by construction; 135 bands of 8 rows are 17 at most against 16.9). Which samples a device renders changes nothing
+ * in the film: every pixel's sampler is keyed by the pixel (pixel-keyed mode). */
 typedef struct rt_shard { int32_t rank, world_size; } rt_shard;
+#define RT_SHARD_ROWS(H, world_size) (((world_size) > 1 && ((((H) + 15) / 16) % (world_size)) != 0) ? 8 : 16)
 
 typedef struct rt_stats {
   uint64_t camera_rays;

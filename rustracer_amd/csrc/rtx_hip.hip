@@ -1260,11 +1260,13 @@ extern "C" int rt_render(rt_scene* s, const rt_camera* cam, const rt_film_desc* 
   fp.max_depth = (int)(uint8_t)path->max_depth; fp.rr_threshold = path->rr_threshold;
   fp.pb_x0 = path->pixel_bounds[0]; fp.pb_y0 = path->pixel_bounds[1]; fp.pb_x1 = path->pixel_bounds[2]; fp.pb_y1 = path->pixel_bounds[3];
   fp.rank = rank; fp.world = world;
+  const int band = RT_SHARD_ROWS(H, world);  // rows per shard band: 16, or 8 where the 16-row bands do not divide over the ranks
+  fp.shard_log2 = band == 16 ? 4 : 3;
   fp.w_recip = W > 1 ? (unsigned)((1ull << 32) / (unsigned long long)W) : 0u;
 
   // owned sample rows (tile rows of 16, interleaved over ranks)
   unsigned long long owned_rows = 0;
-  for (int row = 0; row < H; ++row) if (((row >> 4) % world) == rank) owned_rows++;
+  for (int row = 0; row < H; ++row) if (((row >> fp.shard_log2) % world) == rank) owned_rows++;
   const unsigned long long owned_pixels = owned_rows * (unsigned long long)W;
 
   rt_stats stats{};
@@ -1632,11 +1634,11 @@ extern "C" int rt_multi_render(rt_multi* m, const rt_camera* cam, const rt_film_
   // film rows chunk c can have written: its tile rows, widened by the filter's reach (FilmTile::add_sample splats ceil(y - 0.5 - r) .. floor(y - 0.5 + r),
   // film.rs:303-321; with the box filter that is the sample's own pixel, plus the one above when the sample sits exactly on the edge)
   const int halo = (int)std::ceil(film->filter_radius[1] - 0.5f) + 1;
-  const int n_tile_rows = (H + 15) / 16;
+  const int band = RT_SHARD_ROWS(H, n_chunks), n_tile_rows = (H + band - 1) / band;  // (the bands rt_render cuts for world_size = n_chunks)
   auto bands = [&](int c) {
     std::vector<std::pair<int, int>> b;  // [first, end) film rows, merged
     for (int t = c; t < n_tile_rows; t += n_chunks) {
-      const int y0 = film->sample_bounds[1] + 16 * t - halo - film->cropped_pixel_bounds[1], y1 = film->sample_bounds[1] + std::min(16 * t + 16, H) + halo - film->cropped_pixel_bounds[1];
+      const int y0 = film->sample_bounds[1] + band * t - halo - film->cropped_pixel_bounds[1], y1 = film->sample_bounds[1] + std::min(band * t + band, H) + halo - film->cropped_pixel_bounds[1];
       const int a = std::max(0, y0), e = std::min(ch, y1);
       if (a >= e) continue;
       if (!b.empty() && a <= b.back().second) b.back().second = std::max(b.back().second, e); else b.push_back({a, e});

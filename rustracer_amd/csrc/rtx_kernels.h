@@ -105,8 +105,8 @@ struct FrameParams {
   float radius_x, radius_y, max_sample_luminance;
   // integrator
   int max_depth; float rr_threshold; int pb_x0, pb_y0, pb_x1, pb_y1;
-  // sharding: owned sample rows j -> y = sb_y0 + ((j >> 4) * world + rank) * 16 + (j & 15)
-  int rank, world;
+  // sharding: owned sample rows j -> y = sb_y0 + (((j >> L) * world + rank) << L) + (j & (2^L - 1)), L = shard_log2 (bands of 16 rows, or 8: RT_SHARD_ROWS)
+  int rank, world, shard_log2;
   // pass
   unsigned long long chunk_first;  // first owned-pixel index of this batch
   unsigned w_recip;                // floor(2^32 / W), W = sample-bounds width (0 when W == 1): division by W without a divide
@@ -196,7 +196,8 @@ RT_DEV void owned_pixel(const FrameParams& fp, unsigned long long k, int& x, int
     if (r >= W) { q += 1u; r -= W; }
     j = q; xi = r;
   } else { j = k / W; xi = (unsigned)(k - j * W); }
-  unsigned long long row = ((j >> 4) * (unsigned long long)fp.world + (unsigned long long)fp.rank) * 16ull + (j & 15ull);
+  const unsigned L = (unsigned)fp.shard_log2;
+  unsigned long long row = (((j >> L) * (unsigned long long)fp.world + (unsigned long long)fp.rank) << L) + (j & ((1ull << L) - 1ull));
   x = fp.sb_x0 + (int)xi;
   y = fp.sb_y0 + (int)row;
   pixel_index = row * W + xi;

@@ -20,10 +20,16 @@ import numpy as np
 TILE = 16  # block_size passed by rc/api.rs:1009
 
 
+def shard_rows(n_sample_rows: int, world: int) -> int:
+    """Rows per shard band - RT_SHARD_ROWS of include/rtx_hip.h: the reference's 16-row tile rows, or 8 rows when the number of 16-row bands is not a
+    multiple of `world` (1080 rows on 8 devices: 68 bands = 9 for four devices and 8 for the others; 135 bands of 8 rows = 17 at most against 16.9)."""
+    return 8 if world > 1 and ((n_sample_rows + 15) // 16) % world != 0 else 16
+
+
 def owned_sample_rows(sample_y0: int, sample_y1: int, rank: int, world: int) -> np.ndarray:
     """Sample-bounds rows (absolute y) rendered by `rank`; mirrors owned_pixel() in csrc/rtx_kernels.h."""
     rows = np.arange(sample_y0, sample_y1)
-    return rows[((rows - sample_y0) // TILE) % world == rank]
+    return rows[((rows - sample_y0) // shard_rows(sample_y1 - sample_y0, world)) % world == rank]
 
 
 def owned_pixel_mask(cropped, sample_bounds, rank: int, world: int) -> np.ndarray:
@@ -43,10 +49,11 @@ def touched_rows(cropped, sample_bounds, rank: int, world: int, filter_radius_y:
     sy0, sy1 = int(sample_bounds[1]), int(sample_bounds[3])
     halo = int(np.ceil(filter_radius_y - 0.5)) + 1
     hit = np.zeros(y1 - y0, bool)
-    n_tile_rows = (sy1 - sy0 + TILE - 1) // TILE
+    band = shard_rows(sy1 - sy0, world)
+    n_tile_rows = (sy1 - sy0 + band - 1) // band
     for t in range(rank, n_tile_rows, world):
-        a = max(0, sy0 + TILE * t - halo - y0)
-        b = min(y1 - y0, sy0 + min(TILE * t + TILE, sy1 - sy0) + halo - y0)
+        a = max(0, sy0 + band * t - halo - y0)
+        b = min(y1 - y0, sy0 + min(band * t + band, sy1 - sy0) + halo - y0)
         if a < b:
             hit[a:b] = True
     return np.nonzero(hit)[0]
