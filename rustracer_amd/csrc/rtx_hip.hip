@@ -1282,13 +1282,13 @@ extern "C" int rt_render(rt_scene* s, const rt_camera* cam, const rt_film_desc* 
   const bool all_in_bounds = path->pixel_bounds[0] <= film->sample_bounds[0] && path->pixel_bounds[2] >= film->sample_bounds[2] &&
                              path->pixel_bounds[1] <= film->sample_bounds[1] && path->pixel_bounds[3] >= film->sample_bounds[3];
   // batch / pass sizing. A batch is a range of owned pixels whose sampler tables (2*dims u16 per sample) are built
-  // at once; it is rendered in passes of n_samples consecutive samples of all its pixels, ~2^28 paths (83 GB of path state) per pass.
+  // at once; it is rendered in passes of n_samples consecutive samples of all its pixels, ~2^29 paths (211 GB of path state) per pass.
   // measurement knobs; 2^23 -> 2^26 paths per pass: -9 % (S1), -32 % (S2); 2^26 -> 2^28 with 2^19-pixel batches: -1 % (S1), -7 % (S2), -1 % (S3):
   // fewer, larger launches - late bounces hold few rays - and 288 GB of HBM hold the path state of such a pass with room to spare. On a
   // device with less free memory (a busy GPU, several live scenes, a smaller part) the pass is halved until its workspace fits what
   // hipMemGetInfo reports, and halved again if an allocation fails all the same.
   auto env_log2 = [](const char* name, int dflt) { const char* e = getenv(name); return e ? std::min(30, std::max(16, atoi(e))) : dflt; };
-  static const int tp_log2 = env_log2("RTX_PASS_LOG2", 28);
+  static const int tp_log2 = env_log2("RTX_PASS_LOG2", 29);  // (round 4: 2^28 -> 2^29 paths per pass, 211 GB of workspace: S1 815.9 -> 808.5 ms, S4 5764 -> 5728, S2 167.4 -> 164.9)
   static const int bp_log2 = env_log2("RTX_BATCH_LOG2", 19);
   enum { B_GEN0, B_GEN1, B_GENS, B_HIT, B_HITS, B_LACC, B_PFILM, B_SH, B_MI, B_QSH, B_QMI, B_QMA, B_OCCSH, B_OCCMI, B_COUNT };  // two generations of travelling path records + their hits (by queue slot), radiance and film position (by path id), ray records and the three ray queues
   const bool has_infinite = s->d.n_infinite > 0;

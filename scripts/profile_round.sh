@@ -7,9 +7,11 @@ OUT=gpurun_out/${TAG}_${SCENE}
 mkdir -p $OUT
 ROOT=$(pwd)
 cd /tmp && export TMPDIR=/tmp && cd $ROOT
-# PMC passes run at the spp that gives the launch size of the full run (a pass holds 2^28 paths = 512 samples of a 2^19-pixel batch)
-PSPP=512
-if [ "$SCENE" = "blob" ]; then PSPP=256; fi   # S2 renders 256 spp: its passes hold 256 samples
+# PMC passes run at the scene's full spp: a pass holds 2^29 paths = all 1024 samples of a 2^19-pixel batch, so only the full sample count gives the launch size of
+# the timed run (roofline.traffic is bytes PER LAUNCH)
+PSPP=1024
+if [ "$SCENE" = "blob" ]; then PSPP=256; fi
+if [ "$SCENE" = "mis" ]; then PSPP=512; fi
 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/fetch -- python3 bench.py --scene $SCENE --steps 1 --warmup 0 --spp $PSPP --no-cpu-baseline --headline-only --detail $OUT/fetch_detail.json > $OUT/fetch.log 2>&1
 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/write -- python3 bench.py --scene $SCENE --steps 1 --warmup 0 --spp $PSPP --no-cpu-baseline --headline-only --detail $OUT/write_detail.json > $OUT/write.log 2>&1
 rocprofv3 --pmc SQ_INSTS_VALU SQ_THREAD_CYCLES_VALU --output-format csv -d $OUT/sq -- python3 bench.py --scene $SCENE --steps 1 --warmup 0 --spp $PSPP --no-cpu-baseline --headline-only --detail $OUT/sq_detail.json > $OUT/sq.log 2>&1

@@ -10,9 +10,9 @@ timeout 900 python bench.py --detail gpurun_out/final/bench_default_detail.json 
 for sc in mis-spheres instances-10k; do
   timeout 300 python bench.py --scene $sc --steps 3 --warmup 1 --no-cpu-baseline --headline-only > gpurun_out/final/bench_$sc.json 2> gpurun_out/final/bench_$sc.err
 done
-timeout 600 bash scripts/pmc_scene.sh cornell 512 ${TAG}_sq_cornell > gpurun_out/final/sq_cornell.txt 2>&1
+timeout 600 bash scripts/pmc_scene.sh cornell 1024 ${TAG}_sq_cornell > gpurun_out/final/sq_cornell.txt 2>&1
 timeout 600 bash scripts/pmc_scene.sh blob 256 ${TAG}_sq_blob > gpurun_out/final/sq_blob.txt 2>&1
-timeout 900 bash scripts/pmc_scene.sh room 512 ${TAG}_sq_room > gpurun_out/final/sq_room.txt 2>&1
+timeout 900 bash scripts/pmc_scene.sh room 1024 ${TAG}_sq_room > gpurun_out/final/sq_room.txt 2>&1
 mkdir -p gpurun_out/final/profiles && cp profiles/${TAG}_* profiles/pmc_*.json gpurun_out/final/profiles/ 2>/dev/null
 ls gpurun_out/final gpurun_out/final/profiles
 tail -c 600 gpurun_out/final/bench_default.json
