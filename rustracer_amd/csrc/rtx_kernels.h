@@ -748,12 +748,17 @@ __global__ void __launch_bounds__(256) k_raygen(FrameParams fp, PassState ps) {
 // FOUR distinct bank groups, so the ~20 distinct nodes a wave of bounced rays holds were served one after the other, eight to a group - the kernel was bound
 // by LDS bank conflicts (SQ_LDS_BANK_CONFLICT 1.26e10 > SQ_ACTIVE_INST_LDS 8.4e9 cycles on S1, round 3). Planar, the dword k of node cur sits in bank cur mod 32:
 // distinct nodes of a small scene fall into distinct banks, equal nodes are a broadcast.
+// Plane 7 holds a node's control word in the form the finite-ray walks read it (lds_node_ctl): a leaf's primitive count in bits 0-15, an interior node's split
+// axis as ONE bit, 1 << (16 + axis) - `ctl & sign mask of the ray` is then the reference's "direction negative along the split axis" in two instructions
+// instead of six. LdsSrcT::node hands the other walks the node record as it is in HBM (n_prims | axis << 16).
+RT_DEV unsigned lds_node_ctl(unsigned packed) { const unsigned n = packed & 0xffffu; return n != 0u ? n : (1u << (16u + ((packed >> 16) & 0xffu))); }
 template <int N, int T>
 struct LdsSrcT {
   const float* nodes; const float* tris;
-  RT_DEV void node(int i, float4& a, float4& b) const {
-    a = make_float4(nodes[i], nodes[N + i], nodes[2 * N + i], nodes[3 * N + i]);
-    b = make_float4(nodes[4 * N + i], nodes[5 * N + i], nodes[6 * N + i], nodes[7 * N + i]);
+  RT_DEV void node(int i, float4& a, float4& b) const {  // node planes: min.x max.x min.y max.y min.z max.z offset ctl (an axis' two bounds in neighbouring planes: one two-register read feeds one packed subtraction)
+    a = make_float4(nodes[i], nodes[2 * N + i], nodes[4 * N + i], nodes[N + i]);
+    const unsigned ctl = __float_as_uint(nodes[7 * N + i]);
+    b = make_float4(nodes[3 * N + i], nodes[5 * N + i], nodes[6 * N + i], __uint_as_float((ctl & 0xffffu) | (((ctl >> 17) & 3u) << 16)));
   }
   RT_DEV void tri(int i, f3& p0, f3& p1, f3& p2) const {
     p0 = mk3(tris[i], tris[T + i], tris[2 * T + i]); p1 = mk3(tris[3 * T + i], tris[4 * T + i], tris[5 * T + i]); p2 = mk3(tris[6 * T + i], tris[7 * T + i], tris[8 * T + i]);
@@ -768,13 +773,72 @@ template <int BLOCK, int N = RT_SMALL_NODES, int T = RT_SMALL_TRIS>
 RT_DEV void stage_small_scene(const DScene& sc, float* s_nodes, float* s_tris) {
   for (unsigned i = threadIdx.x; i < 2u * sc.n_nodes; i += BLOCK) {
     const float4 v = sc.nodes[i]; const unsigned n = i >> 1, h = (i & 1u) * 4u;
-    s_nodes[h * N + n] = v.x; s_nodes[(h + 1u) * N + n] = v.y; s_nodes[(h + 2u) * N + n] = v.z; s_nodes[(h + 3u) * N + n] = v.w;
+    if (h == 0u) { s_nodes[n] = v.x; s_nodes[2 * N + n] = v.y; s_nodes[4 * N + n] = v.z; s_nodes[N + n] = v.w; }
+    else { s_nodes[3 * N + n] = v.x; s_nodes[5 * N + n] = v.y; s_nodes[6 * N + n] = v.z; s_nodes[7 * N + n] = __uint_as_float(lds_node_ctl(__float_as_uint(v.w))); }
   }
   for (unsigned i = threadIdx.x; i < 3u * sc.n_tris; i += BLOCK) {
     const float4 v = sc.tri_p[i]; const unsigned t = i / 3u, r = i - 3u * t;
     s_tris[(3u * r) * T + t] = v.x; s_tris[(3u * r + 1u) * T + t] = v.y; s_tris[(3u * r + 2u) * T + t] = v.z;
     if (r == 2u) s_tris[9 * T + t] = v.w;
   }
+}
+
+// ---- The walks of a finite ray (inv_dir_finite) through an LDS-resident scene of plain triangles: traverse_rounds / traverse of rtx_dev_scene.h with the
+// min / max node test, the control word of lds_node_ctl and the lane's state in ONE register (leaf_n > 0: holds a leaf of that many primitives, 0: walking,
+// < 0: done - the two ballots of a round are two compares). Per ray the sequence of node tests, triangle tests and t_max updates is the reference's.
+template <bool ANY, int LEAF_MIN, class StackT, int N, int T>
+RT_DEV bool traverse_small_finite(const float* __restrict__ s_nodes, const float* __restrict__ s_tris, Ray ray, StackT* stack, int stack_stride, int& prim_out, TriHit& hit_out) {
+  const f3 inv_dir = mk3(1.0f / ray.d.x, 1.0f / ray.d.y, 1.0f / ray.d.z);
+  const unsigned negmask = (inv_dir.x < 0.0f ? 0x10000u : 0u) | (inv_dir.y < 0.0f ? 0x20000u : 0u) | (inv_dir.z < 0.0f ? 0x40000u : 0u);
+  const RayPre rp = ray_pre(ray);
+  const LdsSrcT<N, T> src{s_nodes, s_tris};
+  bool found = false;
+  // the to-visit stack as the ADDRESS of its top entry (the lane's column, stack_stride entries apart): a push is a store at top + one entry and an add, a pop
+  // a load at top and an add - no index-to-address arithmetic per node
+  typedef __attribute__((address_space(3))) StackT LdsEntry;
+  const unsigned step = (unsigned)stack_stride * (unsigned)sizeof(StackT);
+  const unsigned bottom = (unsigned)(uintptr_t)(LdsEntry*)stack - step; unsigned top = bottom;
+  int cur = 0, leaf_off = 0, leaf_n = 0;
+  for (;;) {
+    unsigned long long holders = 0ull;
+    for (;;) {
+      if (leaf_n == 0) {
+        const float* nd = s_nodes + cur;
+        const float4 n0 = make_float4(nd[0], nd[2 * N], nd[4 * N], nd[N]), n1 = make_float4(nd[3 * N], nd[5 * N], 0.0f, 0.0f);
+        const int offset = __float_as_int(nd[6 * N]); const unsigned ctl = __float_as_uint(nd[7 * N]);
+        if (slab_test_finite(n0, n1, ray.o, ray.t_max, inv_dir)) {
+          const int n_prims = (int)(ctl & 0xffffu);
+          if (n_prims != 0) { leaf_off = offset; leaf_n = n_prims; }
+          else {
+            const bool neg = (ctl & negmask) != 0u;
+            top += step; *(LdsEntry*)(uintptr_t)top = (StackT)(neg ? cur + 1 : offset);
+            cur = neg ? offset : cur + 1;
+          }
+        } else if (top == bottom) leaf_n = -1;
+        else { cur = (int)*(const LdsEntry*)(uintptr_t)top; top -= step; }
+      }
+      if (LEAF_MIN <= 1) break;  // the single loop of the any-hit walk: one node step, then the lanes that hold a leaf test it
+      holders = __ballot(leaf_n > 0);
+      if (__ballot(leaf_n == 0) == 0ull) break;
+      if (__builtin_popcount((unsigned)holders) + __builtin_popcount((unsigned)(holders >> 32)) >= LEAF_MIN) break;  // (two 32-bit counts: the 64-bit count's compare is compiled as a VECTOR compare)
+    }
+    if (LEAF_MIN > 1 && holders == 0ull) break;
+    if (leaf_n > 0) {
+      for (int i = 0; i < leaf_n; ++i) {
+        f3 p0, p1, p2; src.tri(leaf_off + i, p0, p1, p2);
+        TriHit h;
+        if (tri_test_pre(p0, p1, p2, ray, rp, h)) {
+          found = true;
+          if (ANY) break;
+          ray.t_max = h.t; prim_out = leaf_off + i; hit_out = h;  // `.or(result)`: later accepted hits replace
+        }
+      }
+      if ((ANY && found) || top == bottom) leaf_n = -1;
+      else { leaf_n = 0; cur = (int)*(const LdsEntry*)(uintptr_t)top; top -= step; }
+    }
+    if (LEAF_MIN <= 1 && __ballot(leaf_n == 0) == 0ull) break;
+  }
+  return found;
 }
 
 // Where a trace launch reads its rays and writes its results: element [pid * stride] of each pointer (strides in elements of the pointer's
@@ -838,9 +902,25 @@ __global__ void __launch_bounds__(BLOCK, RT_GEN_MIN_WAVES(GENERAL)) k_trace(DSce
     bool found;
     constexpr int LM = ANY ? RT_LDS_LEAF_MIN_ANY : RT_LDS_LEAF_MIN_CLOSEST;
     const GeneralCtx gen{sc.self, ANY && io.shadow_masks != 0};
-    if (SMALL && LM > 1 && LM < 64 && !COUNT) { LdsS src{s_nodes, s_tris}; found = traverse_rounds<ANY, COUNT, LM, LdsS, StackT, GENERAL>(src, ray, stack + threadIdx.x, BLOCK, prim, h, n_nodes, n_tris, gen); }
-    else if (SMALL) { LdsS src{s_nodes, s_tris}; found = traverse<ANY, COUNT, LdsS, StackT, GENERAL>(src, ray, stack + threadIdx.x, BLOCK, prim, h, n_nodes, n_tris, gen); }
-    else { GlobalSrc src{sc.nodes, sc.tri_p}; found = traverse<ANY, COUNT, GlobalSrc, StackT, GENERAL>(src, ray, stack + threadIdx.x, BLOCK, prim, h, n_nodes, n_tris, gen); }
+    // Plain-triangle launches that do not count visits take the min / max node test (slab_test_finite) when every ray of the wave has a finite reciprocal
+    // direction - all but a few hundred waves of a frame; a wave that holds one ray with a zero direction component walks with the reference's selects.
+    constexpr bool FIN_FORMS = !COUNT && GENERAL == 0;
+    const bool fin = FIN_FORMS && __ballot(!inv_dir_finite(mk3(1.0f / ray.d.x, 1.0f / ray.d.y, 1.0f / ray.d.z))) == 0ull;
+    if (SMALL && LM > 1 && LM < 64 && !COUNT) {
+      LdsS src{s_nodes, s_tris};
+      if (FIN_FORMS && fin) found = traverse_small_finite<ANY, LM, StackT, NN, NT>(s_nodes, s_tris, ray, stack + threadIdx.x, BLOCK, prim, h);
+      else found = traverse_rounds<ANY, COUNT, LM, LdsS, StackT, GENERAL>(src, ray, stack + threadIdx.x, BLOCK, prim, h, n_nodes, n_tris, gen);
+    }
+    else if (SMALL) {
+      LdsS src{s_nodes, s_tris};
+      if (FIN_FORMS && fin) found = traverse_small_finite<ANY, (ANY ? 1 : 64), StackT, NN, NT>(s_nodes, s_tris, ray, stack + threadIdx.x, BLOCK, prim, h);
+      else found = traverse<ANY, COUNT, LdsS, StackT, GENERAL>(src, ray, stack + threadIdx.x, BLOCK, prim, h, n_nodes, n_tris, gen);
+    }
+    else {
+      GlobalSrc src{sc.nodes, sc.tri_p};
+      if (FIN_FORMS && fin) found = traverse<ANY, COUNT, GlobalSrc, StackT, GENERAL, FIN_FORMS>(src, ray, stack + threadIdx.x, BLOCK, prim, h, n_nodes, n_tris, gen);
+      else found = traverse<ANY, COUNT, GlobalSrc, StackT, GENERAL>(src, ray, stack + threadIdx.x, BLOCK, prim, h, n_nodes, n_tris, gen);
+    }
     n_rays += 1;
     if (ANY) trace_write_any(lacc, ls, direct_add, as, occluded, os, pid, d4.w, found);
     else hits[pid * hs] = make_float4(hit_b2 ? h.b2 : (found ? h.t : kInf), __int_as_float(found ? prim : -1), h.b0, h.b1);
@@ -1150,17 +1230,44 @@ struct PairLane {
   bool active, found; unsigned pid; float dw;
   // registers are the currency of this kernel (86 -> 80 VGPRs is one more wave per SIMD): the direction signs are read off inv_dir where
   // they are used (a compare either way) and of the watertight test's permutation only kz is kept (kx, ky follow from it)
-  Ray ray; f3 inv_dir; int kz; float sx, sy, sz;
+  Ray ray; f3 inv_dir; float sx, sy, sz;
+  // finite(): the ray's reciprocal direction has no infinite component (inv_dir_finite) - its node tests are minima / maxima (pair_slabs). Kept as bit 2 of
+  // kz (set: NOT finite), no register of its own; set_inv goes before set_rp.
+  RT_DEV bool finite() const { return kz < 4; }
+  RT_DEV void set_inv(f3 v) { inv_dir = v; kz = inv_dir_finite(v) ? 0 : 4; }
   RT_DEV int neg_x() const { return inv_dir.x < 0.0f; }
   RT_DEV int neg_y() const { return inv_dir.y < 0.0f; }
   RT_DEV int neg_z() const { return inv_dir.z < 0.0f; }
   // the sign along a node's split axis as arithmetic on the three compares: written as a select between the components, the optimiser turns it into
   // an indexed load from a private copy of inv_dir - one scratch access per node visit
   RT_DEV bool neg_axis(unsigned axis) const { return ((((inv_dir.x < 0.0f) ? 1u : 0u) | ((inv_dir.y < 0.0f) ? 2u : 0u) | ((inv_dir.z < 0.0f) ? 4u : 0u)) >> axis) & 1u; }
-  RT_DEV RayPre rp() const { RayPre r; r.kz = kz; r.kx = kz + 1; if (r.kx == 3) r.kx = 0; r.ky = r.kx + 1; if (r.ky == 3) r.ky = 0; r.sx = sx; r.sy = sy; r.sz = sz; return r; }
-  RT_DEV void set_rp(const RayPre& r) { kz = r.kz; sx = r.sx; sy = r.sy; sz = r.sz; }
+  RT_DEV RayPre rp() const { RayPre r; r.kz = kz & 3; r.kx = r.kz + 1; if (r.kx == 3) r.kx = 0; r.ky = r.kx + 1; if (r.ky == 3) r.ky = 0; r.sx = sx; r.sy = sy; r.sz = sz; return r; }
+  RT_DEV void set_rp(const RayPre& r) { kz = (kz & 4) | r.kz; sx = r.sx; sy = r.sy; sz = r.sz; }
   int sp, prim; unsigned cur; TriHit hit;
+  int kz;  // (apart from inv_dir: written together as neighbours, the two become one 16-byte store to a private copy of the lane's state - 24 bytes of scratch per lane)
 };
+// The two children of a pair record against the lane's ray: slab_geom && tmin < t_max for each. A finite ray (all but a few hundred of a frame) takes the
+// min / max form of the node test (slab_interval_finite: 14 instructions per box instead of 30, no sign selects); the branch is skipped by waves without
+// the other kind.
+RT_DEV void pair_slabs(const bool finite, const f3 o, const float t_max, const f3 inv_dir, float4 n0, float4 n1, float4 f0, float4 f1, bool& hit_n, bool& keep_f, float& tmin_n, float& tmin_f) {
+  if (__builtin_expect(finite, 1)) {
+    float tmax_n, tmax_f;
+    slab_interval_finite(n0, n1, o, inv_dir, tmin_n, tmax_n);
+    slab_interval_finite(f0, f1, o, inv_dir, tmin_f, tmax_f);
+    hit_n = (tmin_n <= tmax_n) & (tmax_n > 0.0f) & (tmin_n < t_max);
+    keep_f = (tmin_f <= tmax_f) & (tmax_f > 0.0f) & (tmin_f < t_max);
+  } else {
+    Ray ray; ray.o = o; ray.d = mk3(0, 0, 0); ray.t_max = t_max;  // (the node test reads the origin and t_max)
+    const int neg_x = inv_dir.x < 0.0f, neg_y = inv_dir.y < 0.0f, neg_z = inv_dir.z < 0.0f;
+    hit_n = slab_geom(n0, n1, ray, inv_dir, neg_x, neg_y, neg_z, tmin_n) && tmin_n < t_max;
+    keep_f = slab_geom(f0, f1, ray, inv_dir, neg_x, neg_y, neg_z, tmin_f) && tmin_f < t_max;
+  }
+}
+RT_DEV bool lane_slab_test(const bool finite, const f3 o, const float t_max, const f3 inv_dir, float4 n0, float4 n1) {  // slab_test for the lane's ray (the root)
+  if (__builtin_expect(finite, 1)) return slab_test_finite(n0, n1, o, t_max, inv_dir);
+  Ray ray; ray.o = o; ray.d = mk3(0, 0, 0); ray.t_max = t_max;
+  return slab_test(n0, n1, ray, inv_dir, inv_dir.x < 0.0f, inv_dir.y < 0.0f, inv_dir.z < 0.0f);
+}
 // (the leaf phase of these loops is held back until enough lanes wait at a leaf: leaf_phase_now, rtx_dev_scene.h)
 template <bool ANY>
 RT_DEV void pair_finish(PairLane& L, const TraceOut& o) {  // same epilogue as k_trace
@@ -1188,9 +1295,8 @@ RT_DEV void pair_interior_step(PairLane& L, const TraceOut& o, const float4* __r
   const float4 n0 = neg ? b0 : a0, n1 = neg ? b1 : a1, f0 = neg ? a0 : b0, f1 = neg ? a1 : b1;
   const unsigned code_a = __float_as_uint(a1.z), code_b = __float_as_uint(a1.w);
   const unsigned code_n = neg ? code_b : code_a, code_f = neg ? code_a : code_b;
-  float tmin_n = 0.0f, tmin_f = 0.0f;
-  const bool hit_n = slab_geom(n0, n1, L.ray, L.inv_dir, L.neg_x(), L.neg_y(), L.neg_z(), tmin_n) && tmin_n < L.ray.t_max;
-  const bool keep_f = slab_geom(f0, f1, L.ray, L.inv_dir, L.neg_x(), L.neg_y(), L.neg_z(), tmin_f) && tmin_f < L.ray.t_max;
+  float tmin_n = 0.0f, tmin_f = 0.0f; bool hit_n, keep_f;
+  pair_slabs(L.finite(), L.ray.o, L.ray.t_max, L.inv_dir, n0, n1, f0, f1, hit_n, keep_f, tmin_n, tmin_f);
   if (hit_n) {
     if (keep_f) { stack[L.sp * BLOCK] = code_f; if (!ANY) tstack[(size_t)L.sp * grid_lanes] = tmin_f; ++L.sp; }
     L.cur = code_n;
@@ -1255,7 +1361,7 @@ __global__ void __launch_bounds__(BLOCK, (GENERAL == RT_GEN_NO_MASKS && !ANY) ? 
   bool exhausted = (unsigned long long)wave * 64ull >= count;
   PairLane L;
   L.active = false; L.found = false; L.pid = 0; L.dw = 0.0f;
-  L.ray.o = L.ray.d = mk3(0, 0, 0); L.ray.t_max = 0.0f; L.inv_dir = mk3(0, 0, 0); L.set_rp(ray_pre(L.ray));
+  L.ray.o = L.ray.d = mk3(0, 0, 0); L.ray.t_max = 0.0f; L.set_inv(mk3(0, 0, 0)); L.set_rp(ray_pre(L.ray));
   L.sp = 0; L.prim = -1; L.cur = 0; L.hit.t = kInf; L.hit.b0 = L.hit.b1 = L.hit.b2 = 0.0f;
 
   for (;;) {
@@ -1267,13 +1373,13 @@ __global__ void __launch_bounds__(BLOCK, (GENERAL == RT_GEN_NO_MASKS && !ANY) ? 
         L.pid = queue ? qv.get((unsigned)e) : (unsigned)e;
         const float4 o4 = ray_o[L.pid * rs], d4 = ray_d[L.pid * rs];
         L.ray.o = mk3(o4.x, o4.y, o4.z); L.ray.d = mk3(d4.x, d4.y, d4.z); L.ray.t_max = o4.w; L.dw = d4.w;
-        L.inv_dir = mk3(1.0f / L.ray.d.x, 1.0f / L.ray.d.y, 1.0f / L.ray.d.z);
+        L.set_inv(mk3(1.0f / L.ray.d.x, 1.0f / L.ray.d.y, 1.0f / L.ray.d.z));
         L.set_rp(ray_pre(L.ray));
         L.sp = 0; L.prim = -1; L.found = false; L.hit.t = kInf; L.hit.b0 = L.hit.b1 = L.hit.b2 = 0.0f;
         L.active = true; n_rays += 1;
         // the root is the one node tested on its own
         const float4 r0 = nodes[0], r1 = nodes[1];
-        if (slab_test(r0, r1, L.ray, L.inv_dir, L.neg_x(), L.neg_y(), L.neg_z())) {
+        if (lane_slab_test(L.finite(), L.ray.o, L.ray.t_max, L.inv_dir, r0, r1)) {
           const unsigned packed = __float_as_uint(r1.w), np = packed & 0xffffu;
           L.cur = np > 0u ? (RT_PAIR_LEAF | (GENERAL ? RT_PAIR_GENERAL : 0u) | (unsigned)__float_as_int(r1.z) | ((np - 1u) << 26)) : (((packed >> 16) & 0xffu) << 29);
         } else pair_finish<ANY>(L, out);
@@ -1332,7 +1438,7 @@ __global__ void __launch_bounds__(BLOCK, 4) k_trace_inst(DScene sc, TraceIO io, 
   bool exhausted = (unsigned long long)wave * 64ull >= count;
   PairLane L;
   L.active = false; L.found = false; L.pid = 0; L.dw = 0.0f;
-  L.ray.o = L.ray.d = mk3(0, 0, 0); L.ray.t_max = 0.0f; L.inv_dir = mk3(0, 0, 0); L.set_rp(ray_pre(L.ray));
+  L.ray.o = L.ray.d = mk3(0, 0, 0); L.ray.t_max = 0.0f; L.set_inv(mk3(0, 0, 0)); L.set_rp(ray_pre(L.ray));
   L.sp = 0; L.prim = -1; L.cur = 0; L.hit.t = kInf; L.hit.b0 = L.hit.b1 = L.hit.b2 = 0.0f;
   unsigned inst = RT_INST_NONE, node_base = 0u, prim_base = 0u, id_base = 0u; int sp_base = -1;  // the instance the lane is inside, its records, the stack height it was entered at
 
@@ -1341,7 +1447,7 @@ __global__ void __launch_bounds__(BLOCK, 4) k_trace_inst(DScene sc, TraceIO io, 
     for (;;) {
       if (inst != RT_INST_NONE && L.sp == sp_base) {
         L.ray.o = mk3(wsave[0], wsave[BLOCK], wsave[2 * BLOCK]); L.ray.d = mk3(wsave[3 * BLOCK], wsave[4 * BLOCK], wsave[5 * BLOCK]);
-        L.inv_dir = mk3(wsave[6 * BLOCK], wsave[7 * BLOCK], wsave[8 * BLOCK]);
+        L.set_inv(mk3(wsave[6 * BLOCK], wsave[7 * BLOCK], wsave[8 * BLOCK]));
         L.kz = __float_as_int(wsave[9 * BLOCK]); L.sx = wsave[10 * BLOCK]; L.sy = wsave[11 * BLOCK]; L.sz = wsave[12 * BLOCK];
         inst = RT_INST_NONE; node_base = prim_base = id_base = 0u; sp_base = -1;
       }
@@ -1361,13 +1467,13 @@ __global__ void __launch_bounds__(BLOCK, 4) k_trace_inst(DScene sc, TraceIO io, 
         L.pid = queue ? qv.get((unsigned)e) : (unsigned)e;
         const float4 o4 = ray_o[L.pid * rs], d4 = ray_d[L.pid * rs];
         L.ray.o = mk3(o4.x, o4.y, o4.z); L.ray.d = mk3(d4.x, d4.y, d4.z); L.ray.t_max = o4.w; L.dw = d4.w;
-        L.inv_dir = mk3(1.0f / L.ray.d.x, 1.0f / L.ray.d.y, 1.0f / L.ray.d.z);
+        L.set_inv(mk3(1.0f / L.ray.d.x, 1.0f / L.ray.d.y, 1.0f / L.ray.d.z));
         L.set_rp(ray_pre(L.ray));
         L.sp = 0; L.prim = -1; L.found = false; L.hit.t = kInf; L.hit.b0 = L.hit.b1 = L.hit.b2 = 0.0f;
         inst = RT_INST_NONE; node_base = prim_base = id_base = 0u; sp_base = -1;
         L.active = true; n_rays += 1;
         const float4 r0 = nodes[0], r1 = nodes[1];  // the root is the one node tested on its own
-        if (slab_test(r0, r1, L.ray, L.inv_dir, L.neg_x(), L.neg_y(), L.neg_z())) {
+        if (lane_slab_test(L.finite(), L.ray.o, L.ray.t_max, L.inv_dir, r0, r1)) {
           const unsigned packed = __float_as_uint(r1.w), np = packed & 0xffffu;
           L.cur = np > 0u ? (RT_PAIR_LEAF | RT_PAIR_GENERAL | (unsigned)__float_as_int(r1.z) | ((np - 1u) << 26)) : (((packed >> 16) & 0xffu) << 29);
         } else pair_finish<ANY>(L, out);
@@ -1387,9 +1493,8 @@ __global__ void __launch_bounds__(BLOCK, 4) k_trace_inst(DScene sc, TraceIO io, 
       const float4 n0 = neg ? b0 : a0, n1 = neg ? b1 : a1, f0 = neg ? a0 : b0, f1 = neg ? a1 : b1;
       const unsigned code_a = __float_as_uint(a1.z), code_b = __float_as_uint(a1.w);
       const unsigned code_n = neg ? code_b : code_a, code_f = neg ? code_a : code_b;
-      float tmin_n = 0.0f, tmin_f = 0.0f;
-      const bool hit_n = slab_geom(n0, n1, L.ray, L.inv_dir, L.neg_x(), L.neg_y(), L.neg_z(), tmin_n) && tmin_n < L.ray.t_max;
-      const bool keep_f = slab_geom(f0, f1, L.ray, L.inv_dir, L.neg_x(), L.neg_y(), L.neg_z(), tmin_f) && tmin_f < L.ray.t_max;
+      float tmin_n = 0.0f, tmin_f = 0.0f; bool hit_n, keep_f;
+      pair_slabs(L.finite(), L.ray.o, L.ray.t_max, L.inv_dir, n0, n1, f0, f1, hit_n, keep_f, tmin_n, tmin_f);
       if (hit_n) {
         if (keep_f) { stack[L.sp * BLOCK] = code_f; if (!ANY) tstack[(size_t)L.sp * grid_lanes] = tmin_f; ++L.sp; }
         L.cur = code_n;
@@ -1451,7 +1556,7 @@ __global__ void __launch_bounds__(BLOCK, 4) k_trace_inst(DScene sc, TraceIO io, 
         wsave[0] = L.ray.o.x; wsave[BLOCK] = L.ray.o.y; wsave[2 * BLOCK] = L.ray.o.z; wsave[3 * BLOCK] = L.ray.d.x; wsave[4 * BLOCK] = L.ray.d.y; wsave[5 * BLOCK] = L.ray.d.z;
         wsave[6 * BLOCK] = L.inv_dir.x; wsave[7 * BLOCK] = L.inv_dir.y; wsave[8 * BLOCK] = L.inv_dir.z;
         wsave[9 * BLOCK] = __int_as_float(L.kz); wsave[10 * BLOCK] = L.sx; wsave[11 * BLOCK] = L.sy; wsave[12 * BLOCK] = L.sz;
-        L.ray.o = r.o; L.ray.d = r.d; L.inv_dir = inv; L.set_rp(ray_pre(r));
+        L.ray.o = r.o; L.ray.d = r.d; L.set_inv(inv); L.set_rp(ray_pre(r));
         inst = k; node_base = in.node_base; prim_base = in.prim_base; id_base = in.id_base; sp_base = L.sp;
         const unsigned packed = __float_as_uint(r1.w), np = packed & 0xffffu;
         L.cur = np > 0u ? (RT_PAIR_LEAF | (unsigned)__float_as_int(r1.z) | ((np - 1u) << 26)) : (((packed >> 16) & 0xffu) << 29);
@@ -1507,9 +1612,8 @@ RT_DEV void top_interior_step(PairLane& L, const TraceOut& o, const float4* __re
   const float4 n0 = neg ? b0 : a0, n1 = neg ? b1 : a1, f0 = neg ? a0 : b0, f1 = neg ? a1 : b1;
   const unsigned code_a = __float_as_uint(a1.z), code_b = __float_as_uint(a1.w);
   const unsigned code_n = neg ? code_b : code_a, code_f = neg ? code_a : code_b;
-  float tmin_n = 0.0f, tmin_f = 0.0f;
-  const bool hit_n = slab_geom(n0, n1, L.ray, L.inv_dir, L.neg_x(), L.neg_y(), L.neg_z(), tmin_n) && tmin_n < L.ray.t_max;
-  const bool keep_f = slab_geom(f0, f1, L.ray, L.inv_dir, L.neg_x(), L.neg_y(), L.neg_z(), tmin_f) && tmin_f < L.ray.t_max;
+  float tmin_n = 0.0f, tmin_f = 0.0f; bool hit_n, keep_f;
+  pair_slabs(L.finite(), L.ray.o, L.ray.t_max, L.inv_dir, n0, n1, f0, f1, hit_n, keep_f, tmin_n, tmin_f);
   if (hit_n) {
     if (keep_f) { stk.put(L.sp, code_f); if (!ANY) tstack[(size_t)L.sp * grid_lanes] = tmin_f; ++L.sp; }
     L.cur = code_n;
@@ -1546,7 +1650,7 @@ __global__ void __launch_bounds__(BLOCK, GENERAL ? 4 : 6) k_trace_top(DScene sc,
   bool exhausted = (unsigned long long)wave * 64ull >= count;
   PairLane L;
   L.active = false; L.found = false; L.pid = 0; L.dw = 0.0f;
-  L.ray.o = L.ray.d = mk3(0, 0, 0); L.ray.t_max = 0.0f; L.inv_dir = mk3(0, 0, 0); L.set_rp(ray_pre(L.ray));
+  L.ray.o = L.ray.d = mk3(0, 0, 0); L.ray.t_max = 0.0f; L.set_inv(mk3(0, 0, 0)); L.set_rp(ray_pre(L.ray));
   L.sp = 0; L.prim = -1; L.cur = 0; L.hit.t = kInf; L.hit.b0 = L.hit.b1 = L.hit.b2 = 0.0f;
   for (;;) {
     const unsigned long long idle = __ballot(!L.active);
@@ -1557,12 +1661,12 @@ __global__ void __launch_bounds__(BLOCK, GENERAL ? 4 : 6) k_trace_top(DScene sc,
         L.pid = queue ? qv.get((unsigned)e) : (unsigned)e;
         const float4 o4 = ray_o[L.pid * rs], d4 = ray_d[L.pid * rs];
         L.ray.o = mk3(o4.x, o4.y, o4.z); L.ray.d = mk3(d4.x, d4.y, d4.z); L.ray.t_max = o4.w; L.dw = d4.w;
-        L.inv_dir = mk3(1.0f / L.ray.d.x, 1.0f / L.ray.d.y, 1.0f / L.ray.d.z);
+        L.set_inv(mk3(1.0f / L.ray.d.x, 1.0f / L.ray.d.y, 1.0f / L.ray.d.z));
         L.set_rp(ray_pre(L.ray));
         L.sp = 0; L.prim = -1; L.found = false; L.hit.t = kInf; L.hit.b0 = L.hit.b1 = L.hit.b2 = 0.0f;
         L.active = true; n_rays += 1;
         const float4 r0 = nodes[0], r1 = nodes[1];  // the root is the one node tested on its own
-        if (slab_test(r0, r1, L.ray, L.inv_dir, L.neg_x(), L.neg_y(), L.neg_z())) {
+        if (lane_slab_test(L.finite(), L.ray.o, L.ray.t_max, L.inv_dir, r0, r1)) {
           const unsigned packed = __float_as_uint(r1.w), np = packed & 0xffffu;
           L.cur = np > 0u ? (RT_PAIR_LEAF | (GENERAL ? RT_PAIR_GENERAL : 0u) | (unsigned)__float_as_int(r1.z) | ((np - 1u) << 26)) : ((((packed >> 16) & 0xffu) << 29) | (sc.n_top ? RT_PAIR_TOP : 0u));  // root = slot 0
         } else pair_finish<ANY>(L, out);
@@ -1617,8 +1721,8 @@ RT_DEV void quad_interior_step(PairLane& L, const TraceOut& o, const float4* __r
   const unsigned P = L.cur & 0x1fffffffu, axis_p = (L.cur >> 29) & 3u;
   const float4* __restrict__ rec = quads + 8 * (size_t)P;
   float bx[24];
+  const float4 q0 = rec[0], q1 = rec[1], q2 = rec[2], q3 = rec[3], q4 = rec[4], q5 = rec[5];
   {
-    const float4 q0 = rec[0], q1 = rec[1], q2 = rec[2], q3 = rec[3], q4 = rec[4], q5 = rec[5];
     bx[0] = q0.x; bx[1] = q0.y; bx[2] = q0.z; bx[3] = q0.w; bx[4] = q1.x; bx[5] = q1.y; bx[6] = q1.z; bx[7] = q1.w;
     bx[8] = q2.x; bx[9] = q2.y; bx[10] = q2.z; bx[11] = q2.w; bx[12] = q3.x; bx[13] = q3.y; bx[14] = q3.z; bx[15] = q3.w;
     bx[16] = q4.x; bx[17] = q4.y; bx[18] = q4.z; bx[19] = q4.w; bx[20] = q5.x; bx[21] = q5.y; bx[22] = q5.z; bx[23] = q5.w;
@@ -1627,11 +1731,22 @@ RT_DEV void quad_interior_step(PairLane& L, const TraceOut& o, const float4* __r
   const unsigned code[4] = {__float_as_uint(qc.x), __float_as_uint(qc.y), __float_as_uint(qc.z), __float_as_uint(qc.w)};
   const unsigned axes = __float_as_uint(rec[7].x);
   bool hit[4]; float tmin[4];
+  if (__builtin_expect(L.finite(), 1)) {  // the min / max node test of a finite ray (slab_interval_finite)
+    const f3 qo = mk3(L.ray.o.x, L.ray.o.y, L.ray.o.z), qinv = mk3(L.inv_dir.x, L.inv_dir.y, L.inv_dir.z); const float qt = L.ray.t_max;
+    float tmax[4];
+    slab_interval_finite_scalar(q0, q1, qo, qinv, tmin[0], tmax[0]);
+    slab_interval_finite_scalar(make_float4(q1.z, q1.w, q2.x, q2.y), make_float4(q2.z, q2.w, 0.0f, 0.0f), qo, qinv, tmin[1], tmax[1]);
+    slab_interval_finite_scalar(q3, q4, qo, qinv, tmin[2], tmax[2]);
+    slab_interval_finite_scalar(make_float4(q4.z, q4.w, q5.x, q5.y), make_float4(q5.z, q5.w, 0.0f, 0.0f), qo, qinv, tmin[3], tmax[3]);
 #pragma unroll
-  for (int k = 0; k < 4; ++k) {
-    tmin[k] = 0.0f;
-    hit[k] = (code[k] != 0xffffffffu) & slab_geom6(bx + 6 * k, L.ray, L.inv_dir, L.neg_x(), L.neg_y(), L.neg_z(), tmin[k]);
-    hit[k] = hit[k] & (tmin[k] < L.ray.t_max);
+    for (int k = 0; k < 4; ++k) hit[k] = (code[k] != 0xffffffffu) & (tmin[k] <= tmax[k]) & (tmax[k] > 0.0f) & (tmin[k] < qt);
+  } else {
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      tmin[k] = 0.0f;
+      hit[k] = (code[k] != 0xffffffffu) & slab_geom6(bx + 6 * k, L.ray, L.inv_dir, L.neg_x(), L.neg_y(), L.neg_z(), tmin[k]);
+      hit[k] = hit[k] & (tmin[k] < L.ray.t_max);
+    }
   }
   auto neg_of = [&](unsigned ax) { return L.neg_axis(ax); };
   // negative direction along a split axis => that node's second child first (bvh/mod.rs:411-417), at all three nodes involved
@@ -1681,7 +1796,7 @@ __global__ void __launch_bounds__(BLOCK, RT_GEN_MIN_WAVES(GENERAL)) k_trace_quad
   bool exhausted = (unsigned long long)wave * 64ull >= count;
   PairLane L;
   L.active = false; L.found = false; L.pid = 0; L.dw = 0.0f;
-  L.ray.o = L.ray.d = mk3(0, 0, 0); L.ray.t_max = 0.0f; L.inv_dir = mk3(0, 0, 0); L.set_rp(ray_pre(L.ray));
+  L.ray.o = L.ray.d = mk3(0, 0, 0); L.ray.t_max = 0.0f; L.set_inv(mk3(0, 0, 0)); L.set_rp(ray_pre(L.ray));
   L.sp = 0; L.prim = -1; L.cur = 0; L.hit.t = kInf; L.hit.b0 = L.hit.b1 = L.hit.b2 = 0.0f;
   for (;;) {
     const unsigned long long idle = __ballot(!L.active);
@@ -1692,12 +1807,12 @@ __global__ void __launch_bounds__(BLOCK, RT_GEN_MIN_WAVES(GENERAL)) k_trace_quad
         L.pid = queue ? qv.get((unsigned)e) : (unsigned)e;
         const float4 o4 = ray_o[L.pid * rs], d4 = ray_d[L.pid * rs];
         L.ray.o = mk3(o4.x, o4.y, o4.z); L.ray.d = mk3(d4.x, d4.y, d4.z); L.ray.t_max = o4.w; L.dw = d4.w;
-        L.inv_dir = mk3(1.0f / L.ray.d.x, 1.0f / L.ray.d.y, 1.0f / L.ray.d.z);
+        L.set_inv(mk3(1.0f / L.ray.d.x, 1.0f / L.ray.d.y, 1.0f / L.ray.d.z));
         L.set_rp(ray_pre(L.ray));
         L.sp = 0; L.prim = -1; L.found = false; L.hit.t = kInf; L.hit.b0 = L.hit.b1 = L.hit.b2 = 0.0f;
         L.active = true; n_rays += 1;
         const float4 r0 = nodes[0], r1 = nodes[1];  // the root is the one node tested on its own
-        if (slab_test(r0, r1, L.ray, L.inv_dir, L.neg_x(), L.neg_y(), L.neg_z())) {
+        if (lane_slab_test(L.finite(), L.ray.o, L.ray.t_max, L.inv_dir, r0, r1)) {
           const unsigned packed = __float_as_uint(r1.w), np = packed & 0xffffu;
           L.cur = np > 0u ? (RT_PAIR_LEAF | (GENERAL ? RT_PAIR_GENERAL : 0u) | (unsigned)__float_as_int(r1.z) | ((np - 1u) << 26)) : (((packed >> 16) & 0xffu) << 29);
         } else pair_finish<ANY>(L, out);

@@ -80,6 +80,41 @@ def test_trace_edge_cases(gpu_host, orc):
     assert np.array_equal(ao["occluded"], ah["occluded"])
 
 
+@pytest.mark.parametrize("scene", ["cornell", "soup3000", "soup100000"])
+def test_rays_with_zero_direction_components_take_the_reference_selects(gpu_host, orc, scene):
+    """The kernels a frame launches test a node with minima / maxima when a ray's reciprocal direction is finite and with the reference's selects when it is
+    not (0 * inf = NaN on a box bound). Waves of finite rays, waves of axis-parallel rays whose origins sit EXACTLY on box bounds (vertex coordinates), denormal
+    components whose reciprocal overflows, and waves that mix the kinds: hit records and occlusion bit-equal to the oracle."""
+    from rustracer_amd.scenes import random_soup
+    d = _cornell(8, 8, 1) if scene == "cornell" else random_soup(int(scene[4:]), seed=11, max_prims=4)
+    o, h = orc.OracleScene(d), gpu_host.HostScene(d)
+    rng = np.random.default_rng(21)
+    verts = d.arrays()[0]
+    lo, hi = ([0, 0, -800], [556, 549, 560]) if scene == "cornell" else ([-20, -20, -20], [120, 140, 120])
+    n = 64 * 96
+    rays = random_rays(n, lo, hi, seed=5)
+    k = np.arange(n)
+    special = (k // 64) % 3 == 1            # every third wave: all lanes special
+    special |= ((k // 64) % 3 == 2) & (k % 7 == 0)  # the wave after it: a few special lanes among finite rays
+    idx = np.nonzero(special)[0]
+    pick = verts[rng.integers(0, len(verts), len(idx))]
+    rays[idx, 0:3] = pick                                       # origin exactly on box bounds (a vertex lies on the bounds of every node above it)
+    kind = rng.integers(0, 4, len(idx))
+    dirs = rays[idx, 4:7].copy()
+    ax = rng.integers(0, 3, len(idx))
+    dirs[np.arange(len(idx)), ax] = np.where(kind == 0, 0.0, np.where(kind == 1, -0.0, np.where(kind == 2, 1e-39, -1e-42))).astype(np.float32)
+    two = rng.random(len(idx)) < 0.3                            # two zero components: an axis-parallel ray
+    dirs[np.arange(len(idx))[two], (ax[two] + 1) % 3] = 0.0
+    rays[idx, 4:7] = dirs
+    ro, rh = o.trace(rays), h.trace(rays, count=False)
+    assert np.array_equal(ro["prim"], rh["prim"])
+    for f in ("t", "b0", "b1"):
+        assert np.array_equal(bits(ro[f]), bits(rh[f])), f
+    assert (ro["prim"] >= 0).mean() > 0.02
+    rays[:, 3] = rng.uniform(1, 600, n).astype(np.float32)
+    assert np.array_equal(o.trace(rays, True)["occluded"], h.trace(rays, True, count=False)["occluded"])
+
+
 @pytest.mark.parametrize("spp", [1, 16, 64, 1024])
 def test_sampler_tables_match_oracle(gpu_host, orc, spp):
     n = 130 if spp <= 64 else 66  # more than one 64-lane block, ragged tail
