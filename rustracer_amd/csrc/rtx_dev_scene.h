@@ -90,10 +90,14 @@ RT_DEV RayPre ray_pre(const Ray& ray) {
   r.sx = -d.x / d.z; r.sy = -d.y / d.z; r.sz = 1.0f / d.z;
   return r;
 }
+// ... from the translated, permuted vertices on (mesh.rs:248-319): shear, edge functions, the rejection tests, t and the barycentrics, the error bound on t
+RT_DEV bool tri_test_permuted(f3 p0t, f3 p1t, f3 p2t, float sx, float sy, float sz, float t_max, TriHit& h);
 RT_DEV bool tri_test_pre(f3 p0, f3 p1, f3 p2, const Ray& ray, const RayPre& rp, TriHit& h) {
   f3 p0t = p0 - ray.o, p1t = p1 - ray.o, p2t = p2 - ray.o;
   p0t = permute(p0t, rp.kx, rp.ky, rp.kz); p1t = permute(p1t, rp.kx, rp.ky, rp.kz); p2t = permute(p2t, rp.kx, rp.ky, rp.kz);
-  const float sx = rp.sx, sy = rp.sy, sz = rp.sz;
+  return tri_test_permuted(p0t, p1t, p2t, rp.sx, rp.sy, rp.sz, ray.t_max, h);
+}
+RT_DEV bool tri_test_permuted(f3 p0t, f3 p1t, f3 p2t, const float sx, const float sy, const float sz, const float t_max, TriHit& h) {
   p0t.x += sx * p0t.z; p0t.y += sy * p0t.z;
   p1t.x += sx * p1t.z; p1t.y += sy * p1t.z;
   p2t.x += sx * p2t.z; p2t.y += sy * p2t.z;
@@ -114,7 +118,7 @@ RT_DEV bool tri_test_pre(f3 p0, f3 p1, f3 p2, const Ray& ray, const RayPre& rp, 
   float det = e0 + e1 + e2;
   p0t.z *= sz; p1t.z *= sz; p2t.z *= sz;
   float t_scaled = e0 * p0t.z + e1 * p1t.z + e2 * p2t.z;
-  const float tmd = ray.t_max * det;
+  const float tmd = t_max * det;
   const bool range_fail = ((det < 0.0f) & ((t_scaled >= 0.0f) | (t_scaled < tmd))) | ((det > 0.0f) & ((t_scaled <= 0.0f) | (t_scaled > tmd)));
   if (sign_fail | (det == 0.0f) | range_fail) return false;
   float inv_det = 1.0f / det;

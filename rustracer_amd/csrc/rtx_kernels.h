@@ -791,7 +791,11 @@ RT_DEV bool traverse_small_finite(const float* __restrict__ s_nodes, const float
   const f3 inv_dir = mk3(1.0f / ray.d.x, 1.0f / ray.d.y, 1.0f / ray.d.z);
   const unsigned negmask = (inv_dir.x < 0.0f ? 0x10000u : 0u) | (inv_dir.y < 0.0f ? 0x20000u : 0u) | (inv_dir.z < 0.0f ? 0x40000u : 0u);
   const RayPre rp = ray_pre(ray);
-  const LdsSrcT<N, T> src{s_nodes, s_tris};
+  // The watertight test's permutation (mesh.rs:233-240) by ADDRESS: the triangles are planar in LDS (plane 3 v + c = coordinate c of vertex v), so a lane reads
+  // coordinate kx / ky / kz of a vertex from the plane its own permutation names - three base addresses per ray - and subtracts the equally permuted origin
+  // (p[k] - o[k]: the same subtraction): no selects per vertex (18 per test before).
+  const float* const tpx = s_tris + rp.kx * T; const float* const tpy = s_tris + rp.ky * T; const float* const tpz = s_tris + rp.kz * T;
+  const f3 op = permute(ray.o, rp.kx, rp.ky, rp.kz);
   bool found = false;
   // the to-visit stack as the ADDRESS of its top entry (the lane's column, stack_stride entries apart): a push is a store at top + one entry and an add, a pop
   // a load at top and an add - no index-to-address arithmetic per node
@@ -825,12 +829,14 @@ RT_DEV bool traverse_small_finite(const float* __restrict__ s_nodes, const float
     if (LEAF_MIN > 1 && holders == 0ull) break;
     if (leaf_n > 0) {
       for (int i = 0; i < leaf_n; ++i) {
-        f3 p0, p1, p2; src.tri(leaf_off + i, p0, p1, p2);
+        const int t = leaf_off + i;
+        const f3 p0t = mk3(tpx[t] - op.x, tpy[t] - op.y, tpz[t] - op.z), p1t = mk3(tpx[3 * T + t] - op.x, tpy[3 * T + t] - op.y, tpz[3 * T + t] - op.z),
+                 p2t = mk3(tpx[6 * T + t] - op.x, tpy[6 * T + t] - op.y, tpz[6 * T + t] - op.z);
         TriHit h;
-        if (tri_test_pre(p0, p1, p2, ray, rp, h)) {
+        if (tri_test_permuted(p0t, p1t, p2t, rp.sx, rp.sy, rp.sz, ray.t_max, h)) {
           found = true;
           if (ANY) break;
-          ray.t_max = h.t; prim_out = leaf_off + i; hit_out = h;  // `.or(result)`: later accepted hits replace
+          ray.t_max = h.t; prim_out = t; hit_out = h;  // `.or(result)`: later accepted hits replace
         }
       }
       if ((ANY && found) || top == bottom) leaf_n = -1;
@@ -871,8 +877,11 @@ RT_DEV void trace_write_any(float4* __restrict__ lacc, size_t ls, const float4* 
 
 // BLOCK threads per workgroup, DEPTH = to-visit stack entries per lane (the host picks the
 // smallest of 16/32/64 that covers the tree height; the reference's fixed 64 is the maximum).
+#ifndef RT_LDS_TRACE_WAVES  // the LDS-resident kernels' register bound in waves per SIMD: their LDS (21.5 KB per 256 lanes) lets seven workgroups share a CU
+#define RT_LDS_TRACE_WAVES 7
+#endif
 template <bool ANY, bool COUNT, bool SMALL, int BLOCK, int DEPTH, int GENERAL = 0>  // GENERAL: quadrics / alpha-masked triangles in the leaves (no object instances)
-__global__ void __launch_bounds__(BLOCK, RT_GEN_MIN_WAVES(GENERAL)) k_trace(DScene sc, TraceIO io, const unsigned* __restrict__ queue, const unsigned* __restrict__ shard_counts, unsigned shard_cap,
+__global__ void __launch_bounds__(BLOCK, (SMALL && GENERAL == 0 && !COUNT) ? RT_LDS_TRACE_WAVES : RT_GEN_MIN_WAVES(GENERAL)) k_trace(DScene sc, TraceIO io, const unsigned* __restrict__ queue, const unsigned* __restrict__ shard_counts, unsigned shard_cap,
                                                  unsigned count_static, unsigned long long* stats, int st_rays, int st_nodes, int st_tris) {
   const float4* __restrict__ ray_o = io.ray_o; const float4* __restrict__ ray_d = io.ray_d; const size_t rs = io.ray_stride;
   float4* __restrict__ hits = io.hits; const size_t hs = io.hit_stride; const bool hit_b2 = io.hit_b2 != 0;
