@@ -824,9 +824,11 @@ extern "C" int rt_light_distribution(rt_scene* s, int32_t n_voxels[3], float* fu
 // ---------------------------------------------------------------------------------------------- trace launches
 // LDS a workgroup of the trace kernels declares, and the persistent grid that fills every CU at that residency
 template <bool ANY, bool SMALL, int BLOCK, int DEPTH>
-static unsigned trace_grid(const rt_scene* s) {
-  const unsigned lds = (unsigned)(DEPTH * BLOCK * ((SMALL && (!ANY || RT_ANY_STACK16)) ? 2 : 4) + (SMALL ? (8 * RT_SMALL_NODES + 10 * RT_SMALL_TRIS) * 4 : 32));
-  unsigned per_cu = (160u * 1024u) / lds; if (per_cu * BLOCK > 2048u) per_cu = 2048u / BLOCK; if (per_cu < 1) per_cu = 1;
+static unsigned trace_grid(const rt_scene* s, bool stackless = false) {  // stackless: the plain-triangle occlusion kernel of an LDS-resident scene (occluded_small: skip links instead of a stack)
+  unsigned lds = (unsigned)(DEPTH * BLOCK * ((SMALL && (!ANY || RT_ANY_STACK16)) ? 2 : 4) + (SMALL ? (8 * RT_SMALL_NODES + 10 * RT_SMALL_TRIS) * 4 : 32));
+  unsigned waves = 8;
+  if (SMALL && stackless) { lds = (unsigned)((8 * RT_SMALL_NODES + 10 * RT_SMALL_TRIS) * 4 + RT_SMALL_NODES * 2 + DEPTH * 2); waves = RT_LDS_ANY_WAVES; }
+  unsigned per_cu = (160u * 1024u) / lds; if (per_cu * BLOCK > waves * 256u) per_cu = waves * 256u / BLOCK; if (per_cu < 1) per_cu = 1;
   return (unsigned)s->n_cu * per_cu;
 }
 // HBM half of the child-pair / four-wide kernels' traversal stack: [depth][lane of the grid]. Sized once per scene for the largest grid any
@@ -872,7 +874,7 @@ static unsigned trace_knobs(const rt_scene* s, bool any) {
 template <bool ANY, bool COUNT, bool SMALL, int BLOCK, int DEPTH>
 static void launch_trace_v(rt_scene* s, const TraceIO& io, const unsigned* queue, const unsigned* count_ptr, unsigned shard_cap, unsigned count_static,
                            unsigned long long* stats, int st_rays, int st_nodes, int st_tris, hipStream_t stream) {
-  const unsigned grid = trace_grid<ANY, SMALL, BLOCK, DEPTH>(s);
+  const unsigned grid = trace_grid<ANY, SMALL, BLOCK, DEPTH>(s, RT_LDS_ANY_STACKLESS && ANY && SMALL && !COUNT);
   if constexpr (!SMALL) {
     // measurement knob RTX_TRACE: "plain" = one ray per lane per iteration, "refill" = persistent waves on the one-node-per-step
     // loop, default = child-pair traversal (frames that count visits always use the one-node-per-step loops)

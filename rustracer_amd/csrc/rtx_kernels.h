@@ -155,6 +155,7 @@ struct QView {
 #pragma unroll
     for (int j = 1; j < RT_QSHARDS; ++j) { const bool ge = i >= pre[j]; k += ge ? 1u : 0u; base = ge ? pre[j] : base; }
     const unsigned slot = k * shard_cap + (i - base);
+    // (measured, no effect on any stage: the shard of the wave's first entry found on the scalar unit and shared by the lanes inside it)
     return ids ? ids[slot] : slot;
   }
 };
@@ -827,6 +828,24 @@ RT_DEV bool traverse_small_finite(const float* __restrict__ s_nodes, const float
       if (__builtin_popcount((unsigned)holders) + __builtin_popcount((unsigned)(holders >> 32)) >= LEAF_MIN) break;  // (two 32-bit counts: the 64-bit count's compare is compiled as a VECTOR compare)
     }
     if (LEAF_MIN > 1 && holders == 0ull) break;
+#ifndef RT_LDS_LEAF_ONE
+#define RT_LDS_LEAF_ONE 1
+#endif
+    if (RT_LDS_LEAF_ONE && !ANY) {
+      // one primitive per leaf phase: a holder with more stays a holder (and counts towards the next phase) - no lane waits for another's longer leaf
+      if (leaf_n > 0) {
+        const int t = leaf_off;
+        const f3 p0t = mk3(tpx[t] - op.x, tpy[t] - op.y, tpz[t] - op.z), p1t = mk3(tpx[3 * T + t] - op.x, tpy[3 * T + t] - op.y, tpz[3 * T + t] - op.z),
+                 p2t = mk3(tpx[6 * T + t] - op.x, tpy[6 * T + t] - op.y, tpz[6 * T + t] - op.z);
+        TriHit h;
+        if (tri_test_permuted(p0t, p1t, p2t, rp.sx, rp.sy, rp.sz, ray.t_max, h)) { found = true; ray.t_max = h.t; prim_out = t; hit_out = h; }
+        leaf_off += 1; leaf_n -= 1;
+        if (leaf_n == 0) {
+          if (top == bottom) leaf_n = -1;
+          else { cur = (int)*(const LdsEntry*)(uintptr_t)top; top -= step; }
+        }
+      }
+    } else
     if (leaf_n > 0) {
       for (int i = 0; i < leaf_n; ++i) {
         const int t = leaf_off + i;
@@ -843,6 +862,58 @@ RT_DEV bool traverse_small_finite(const float* __restrict__ s_nodes, const float
       else { leaf_n = 0; cur = (int)*(const LdsEntry*)(uintptr_t)top; top -= step; }
     }
     if (LEAF_MIN <= 1 && __ballot(leaf_n == 0) == 0ull) break;
+  }
+  return found;
+}
+
+// ---- Occlusion in an LDS-resident scene WITHOUT a stack (FINITE: the node test of a finite ray, slab_test_finite; otherwise the reference's selects). intersect_p's answer is a property of the tree and the ray alone - "some primitive
+// passes its test and every box above it passes the node test" - because nothing the walk learns changes a later test (t_max never shrinks; bvh/mod.rs:443-500
+// returns at the first accepted primitive). Any order that skips exactly the subtrees of failed boxes gives the reference's answer, so the lane walks the
+// nodes in their array order (pre-order: the first child follows its parent) and on a failed box jumps to the node after the subtree (s_skip, built per
+// workgroup by lds_build_skip): no to-visit stack, no direction signs - a node step is the box test and one select.
+template <int N>
+RT_DEV void lds_build_skip(const float* __restrict__ s_nodes, unsigned short* __restrict__ s_skip, unsigned n_nodes, unsigned short* pending /* n_nodes entries of scratch in LDS */) {
+  // one thread, in array order: skip[i] = the pending second child on top when i is reached (the node that follows i's subtree), n_nodes at the end
+  unsigned sp = 0;
+  for (unsigned i = 0; i < n_nodes; ++i) {
+    if (sp > 0u && pending[sp - 1u] == i) --sp;
+    s_skip[i] = sp > 0u ? pending[sp - 1u] : (unsigned short)n_nodes;
+    const unsigned ctl = __float_as_uint(s_nodes[7 * N + i]);
+    if ((ctl & 0xffffu) == 0u) pending[sp++] = (unsigned short)__float_as_uint(s_nodes[6 * N + i]);
+  }
+}
+// (Measured and not kept: holding a reached leaf until 4 / 8 / 12 / 16 lanes of the wave hold one, one primitive per phase - shadow rays 124 -> 130 / 135.5 / 140 /
+// 144 ms per S1 frame. A holder's wait costs more node rounds than the fuller triangle tests return.)
+template <int N, int T, bool FINITE>
+RT_DEV bool occluded_small(const float* __restrict__ s_nodes, const float* __restrict__ s_tris, const unsigned short* __restrict__ s_skip, const int n_nodes, const Ray ray) {
+  const f3 inv_dir = mk3(1.0f / ray.d.x, 1.0f / ray.d.y, 1.0f / ray.d.z);
+  const RayPre rp = ray_pre(ray);
+  const float* const tpx = s_tris + rp.kx * T; const float* const tpy = s_tris + rp.ky * T; const float* const tpz = s_tris + rp.kz * T;
+  const f3 op = permute(ray.o, rp.kx, rp.ky, rp.kz);
+  bool found = false;
+  int cur = 0;  // n_nodes: done
+  for (;;) {
+    if (cur < n_nodes) {
+      const float* nd = s_nodes + cur;
+      const float4 n0 = make_float4(nd[0], nd[2 * N], nd[4 * N], nd[N]), n1 = make_float4(nd[3 * N], nd[5 * N], 0.0f, 0.0f);
+      const bool hit = slab_test_t<FINITE>(n0, n1, ray, inv_dir, inv_dir.x < 0.0f, inv_dir.y < 0.0f, inv_dir.z < 0.0f);
+      int next = hit ? cur + 1 : (int)s_skip[cur];
+      if (hit) {
+        const int n_prims = (int)(__float_as_uint(nd[7 * N]) & 0xffffu);
+        if (n_prims != 0) {
+          const int off = __float_as_int(nd[6 * N]);
+          for (int i = 0; i < n_prims; ++i) {
+            const int t = off + i;
+            const f3 p0t = mk3(tpx[t] - op.x, tpy[t] - op.y, tpz[t] - op.z), p1t = mk3(tpx[3 * T + t] - op.x, tpy[3 * T + t] - op.y, tpz[3 * T + t] - op.z),
+                     p2t = mk3(tpx[6 * T + t] - op.x, tpy[6 * T + t] - op.y, tpz[6 * T + t] - op.z);
+            TriHit h;
+            if (tri_test_permuted(p0t, p1t, p2t, rp.sx, rp.sy, rp.sz, ray.t_max, h)) { found = true; next = n_nodes; break; }
+          }
+        }
+      }
+      cur = next;
+    }
+    if (__ballot(cur < n_nodes) == 0ull) break;
   }
   return found;
 }
@@ -880,8 +951,14 @@ RT_DEV void trace_write_any(float4* __restrict__ lacc, size_t ls, const float4* 
 #ifndef RT_LDS_TRACE_WAVES  // the LDS-resident kernels' register bound in waves per SIMD: their LDS (21.5 KB per 256 lanes) lets seven workgroups share a CU
 #define RT_LDS_TRACE_WAVES 7
 #endif
+#ifndef RT_LDS_ANY_STACKLESS  // plain-triangle occlusion rays of an LDS-resident scene walk without a stack (occluded_small)
+#define RT_LDS_ANY_STACKLESS 1
+#endif
+#ifndef RT_LDS_ANY_WAVES      // ... and their kernel, 13.6 KB of LDS per 256 lanes, is bound by its registers
+#define RT_LDS_ANY_WAVES 8
+#endif
 template <bool ANY, bool COUNT, bool SMALL, int BLOCK, int DEPTH, int GENERAL = 0>  // GENERAL: quadrics / alpha-masked triangles in the leaves (no object instances)
-__global__ void __launch_bounds__(BLOCK, (SMALL && GENERAL == 0 && !COUNT) ? RT_LDS_TRACE_WAVES : RT_GEN_MIN_WAVES(GENERAL)) k_trace(DScene sc, TraceIO io, const unsigned* __restrict__ queue, const unsigned* __restrict__ shard_counts, unsigned shard_cap,
+__global__ void __launch_bounds__(BLOCK, (SMALL && GENERAL == 0 && !COUNT) ? ((ANY && RT_LDS_ANY_STACKLESS) ? RT_LDS_ANY_WAVES : RT_LDS_TRACE_WAVES) : RT_GEN_MIN_WAVES(GENERAL)) k_trace(DScene sc, TraceIO io, const unsigned* __restrict__ queue, const unsigned* __restrict__ shard_counts, unsigned shard_cap,
                                                  unsigned count_static, unsigned long long* stats, int st_rays, int st_nodes, int st_tris) {
   const float4* __restrict__ ray_o = io.ray_o; const float4* __restrict__ ray_d = io.ray_d; const size_t rs = io.ray_stride;
   float4* __restrict__ hits = io.hits; const size_t hs = io.hit_stride; const bool hit_b2 = io.hit_b2 != 0;
@@ -893,7 +970,8 @@ __global__ void __launch_bounds__(BLOCK, (SMALL && GENERAL == 0 && !COUNT) ? RT_
 #define RT_ANY_STACK16 1
 #endif
   typedef typename std::conditional<SMALL && (!ANY || RT_ANY_STACK16), unsigned short, int>::type StackT;
-  __shared__ StackT stack[DEPTH * BLOCK];
+  constexpr bool STACKLESS = RT_LDS_ANY_STACKLESS && ANY && SMALL && !COUNT && GENERAL == 0;  // occluded_small: no to-visit stack at all (13.6 KB of LDS per workgroup instead of 21.5)
+  __shared__ StackT stack[STACKLESS ? 1 : DEPTH * BLOCK];
   constexpr int NN = RT_SMALL_NODES, NT = RT_SMALL_TRIS;
   typedef LdsSrcT<NN, NT> LdsS;
   __shared__ float s_nodes[SMALL ? 8 * NN : 1];
@@ -901,7 +979,12 @@ __global__ void __launch_bounds__(BLOCK, (SMALL && GENERAL == 0 && !COUNT) ? RT_
   QView qv; if (queue) qv.init(io.queue_is_slots ? nullptr : queue, shard_counts, shard_cap);
   const unsigned count = queue ? qv.total() : count_static;
   if (blockIdx.x * BLOCK >= count) return;  // short queues (MIS rays, late bounces): most blocks of the persistent grid have nothing to stage for
+  __shared__ unsigned short s_skip[STACKLESS ? NN : 1], s_pending[STACKLESS ? DEPTH : 1];
   if (SMALL) { stage_small_scene<BLOCK, NN, NT>(sc, s_nodes, s_tris); __syncthreads(); }
+  if (STACKLESS) {
+    if (threadIdx.x == 0u) lds_build_skip<NN>(s_nodes, s_skip, sc.n_nodes, s_pending);  // (pending second children: at most the tree's height <= DEPTH)
+    __syncthreads();
+  }
   const unsigned stride = gridDim.x * BLOCK;
   unsigned n_nodes = 0, n_tris = 0, n_rays = 0;
   auto trace_one = [&](unsigned pid) {
@@ -922,7 +1005,8 @@ __global__ void __launch_bounds__(BLOCK, (SMALL && GENERAL == 0 && !COUNT) ? RT_
     }
     else if (SMALL) {
       LdsS src{s_nodes, s_tris};
-      if (FIN_FORMS && fin) found = traverse_small_finite<ANY, (ANY ? 1 : 64), StackT, NN, NT>(s_nodes, s_tris, ray, stack + threadIdx.x, BLOCK, prim, h);
+      if (STACKLESS) found = fin ? occluded_small<NN, NT, true>(s_nodes, s_tris, s_skip, (int)sc.n_nodes, ray) : occluded_small<NN, NT, false>(s_nodes, s_tris, s_skip, (int)sc.n_nodes, ray);
+      else if (FIN_FORMS && fin) found = traverse_small_finite<ANY, (ANY ? 1 : 64), StackT, NN, NT>(s_nodes, s_tris, ray, stack + threadIdx.x, BLOCK, prim, h);
       else found = traverse<ANY, COUNT, LdsS, StackT, GENERAL>(src, ray, stack + threadIdx.x, BLOCK, prim, h, n_nodes, n_tris, gen);
     }
     else {
