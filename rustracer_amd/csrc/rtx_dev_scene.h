@@ -41,6 +41,10 @@ struct DScene {
   int obj_pairs;        // ... the objects' trees have records too (behind the top level's, child codes local to the object): nested_pair_walk
   const float4* top_pairs; unsigned n_top;  // pair records of the first levels of the tree, child codes re-pointed at LDS slots (k_trace_top); n_top <= RT_TOP_MAX
   const float4* quads;  // n_nodes x 128 B grandchild records of the interior nodes (NULL when not built), see k_trace_quad
+  // LDS-resident scenes of plain triangles: [8][n_nodes] u16 - for each sign octant of a ray's direction (bit 0 / 1 / 2: d.x / d.y / d.z negative) the node the
+  // reference's walk takes up once it is done with node i and everything below it (n_nodes: the walk is over). With these links the walk needs no stack
+  // (closest_small, occluded_small in rtx_kernels.h); built by rt_scene_create from the nodes
+  const unsigned short* skip8;
   const float4* tri_p; unsigned n_tris;
   const float4* tri_rec;  // per-triangle shade records (8 x float4, see tri_fill_interaction_inl), built on the device at rt_scene_create
   const float* tri_n; const float* tri_uv; const float* tri_s;

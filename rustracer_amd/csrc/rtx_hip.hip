@@ -65,6 +65,7 @@ struct rt_scene {
   bool top_for_closest = false;  // closest-hit rays through k_trace_top as well (shadow rays always, when no four-wide records exist)
   bool use_pairs = false;
   bool deep_column = false;  // top level + deepest object need more than 64 stack entries in one column: k_trace_big with 128
+  DevBuf skip8;  // DScene::skip8 (LDS-resident scenes)
   DevBuf quads; bool use_quads = false; int quad_stack_depth = 0;  // four-wide records of the any-hit kernel (k_trace_quad)
   DevBuf tri_rec;  // per-triangle shade records (k_tri_records)
   DevBuf nodes, tri_p, tri_n, tri_uv, tri_s, tri_alpha, spheres, textures, images, materials, lights, texels, dist, guides;
@@ -571,7 +572,32 @@ extern "C" int rt_scene_create(const rt_scene_desc* desc, int device, rt_scene**
     s->stack_depth += max_obj; max_obj_depth = max_obj;
     s->deep_column = s->stack_depth > 64;
   }
-  d.pairs = nullptr; d.quads = nullptr; d.obj_pairs = 0;
+  d.pairs = nullptr; d.quads = nullptr; d.obj_pairs = 0; d.skip8 = nullptr;
+  if (s->small) {
+    // The order in which BVH::intersect (bvh/mod.rs:381-425) reaches the nodes depends on the ray only through the signs of its direction (at an interior node
+    // the child on the ray's side of the split axis first, the other one pushed): one fixed order per octant. skip[o][i] = the entry on top of the to-visit stack
+    // when that walk reaches node i = where it carries on once i's subtree is done; n_nodes when nothing is pending.
+    const uint32_t nn = desc->n_nodes;
+    std::vector<uint16_t> skip((size_t)8 * nn, (uint16_t)nn);
+    std::vector<uint32_t> st; st.reserve(64);
+    for (uint32_t o = 0; o < 8; ++o) {
+      st.clear();
+      uint32_t cur = 0;
+      for (;;) {
+        skip[(size_t)o * nn + cur] = (uint16_t)(st.empty() ? nn : st.back());
+        const rt_bvh_node& n = desc->nodes[cur];
+        if (n.n_prims == 0) {
+          const bool neg = ((o >> (n.axis < 2 ? n.axis : 2)) & 1u) != 0u;  // (the walks read an axis other than 0 / 1 as z)
+          if (neg) { st.push_back(cur + 1); cur = n.offset; } else { st.push_back(n.offset); cur = cur + 1; }
+        } else {
+          if (st.empty()) break;
+          cur = st.back(); st.pop_back();
+        }
+      }
+    }
+    { const int rc8 = upload(s->skip8, skip.data(), skip.size() * sizeof(uint16_t)); if (rc8 != RT_OK) { delete s; return rc8; } }
+    d.skip8 = s->skip8.as<unsigned short>();
+  }
   if (!s->small && !s->deep_column) {  // LDS-resident scenes keep the one-node-per-step loop: the pair form measured no faster there
     // With object instances the records cover the top-level tree (objects are walked one node per step, their child offsets are relative to the object).
     // A leaf of a GENERAL scene that holds anything but plain triangles carries RT_PAIR_GENERAL.
@@ -824,10 +850,10 @@ extern "C" int rt_light_distribution(rt_scene* s, int32_t n_voxels[3], float* fu
 // ---------------------------------------------------------------------------------------------- trace launches
 // LDS a workgroup of the trace kernels declares, and the persistent grid that fills every CU at that residency
 template <bool ANY, bool SMALL, int BLOCK, int DEPTH>
-static unsigned trace_grid(const rt_scene* s, bool stackless = false) {  // stackless: the plain-triangle occlusion kernel of an LDS-resident scene (occluded_small: skip links instead of a stack)
+static unsigned trace_grid(const rt_scene* s, bool threaded = false) {  // threaded: the plain-triangle kernels of an LDS-resident scene (closest_small / occluded_small: skip links instead of a stack)
   unsigned lds = (unsigned)(DEPTH * BLOCK * ((SMALL && (!ANY || RT_ANY_STACK16)) ? 2 : 4) + (SMALL ? (8 * RT_SMALL_NODES + 10 * RT_SMALL_TRIS) * 4 : 32));
   unsigned waves = 8;
-  if (SMALL && stackless) { lds = (unsigned)((8 * RT_SMALL_NODES + 10 * RT_SMALL_TRIS) * 4 + RT_SMALL_NODES * 2 + DEPTH * 2); waves = RT_LDS_ANY_WAVES; }
+  if (SMALL && threaded) { lds = (unsigned)((8 * RT_SMALL_NODES + 10 * RT_SMALL_TRIS) * 4 + (ANY ? 1 : 8) * RT_SMALL_NODES * 2); waves = ANY ? RT_LDS_ANY_WAVES : RT_LDS_TRACE_WAVES; }
   unsigned per_cu = (160u * 1024u) / lds; if (per_cu * BLOCK > waves * 256u) per_cu = waves * 256u / BLOCK; if (per_cu < 1) per_cu = 1;
   return (unsigned)s->n_cu * per_cu;
 }
@@ -874,7 +900,7 @@ static unsigned trace_knobs(const rt_scene* s, bool any) {
 template <bool ANY, bool COUNT, bool SMALL, int BLOCK, int DEPTH>
 static void launch_trace_v(rt_scene* s, const TraceIO& io, const unsigned* queue, const unsigned* count_ptr, unsigned shard_cap, unsigned count_static,
                            unsigned long long* stats, int st_rays, int st_nodes, int st_tris, hipStream_t stream) {
-  const unsigned grid = trace_grid<ANY, SMALL, BLOCK, DEPTH>(s, RT_LDS_ANY_STACKLESS && ANY && SMALL && !COUNT);
+  const unsigned grid = trace_grid<ANY, SMALL, BLOCK, DEPTH>(s, RT_LDS_THREADED && SMALL && !COUNT);
   if constexpr (!SMALL) {
     // measurement knob RTX_TRACE: "plain" = one ray per lane per iteration, "refill" = persistent waves on the one-node-per-step
     // loop, default = child-pair traversal (frames that count visits always use the one-node-per-step loops)

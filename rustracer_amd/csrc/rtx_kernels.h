@@ -752,7 +752,7 @@ __global__ void __launch_bounds__(256) k_raygen(FrameParams fp, PassState ps) {
 // Plane 7 holds a node's control word in the form the finite-ray walks read it (lds_node_ctl): a leaf's primitive count in bits 0-15, an interior node's split
 // axis as ONE bit, 1 << (16 + axis) - `ctl & sign mask of the ray` is then the reference's "direction negative along the split axis" in two instructions
 // instead of six. LdsSrcT::node hands the other walks the node record as it is in HBM (n_prims | axis << 16).
-RT_DEV unsigned lds_node_ctl(unsigned packed) { const unsigned n = packed & 0xffffu; return n != 0u ? n : (1u << (16u + ((packed >> 16) & 0xffu))); }
+RT_DEV unsigned lds_node_ctl(unsigned packed) { const unsigned n = packed & 0xffffu, axis = (packed >> 16) & 0xffu; return n != 0u ? n : (1u << (16u + (axis < 2u ? axis : 2u))); }  // (an axis other than 0 / 1 reads as z, as in traverse())
 template <int N, int T>
 struct LdsSrcT {
   const float* nodes; const float* tris;
@@ -784,106 +784,15 @@ RT_DEV void stage_small_scene(const DScene& sc, float* s_nodes, float* s_tris) {
   }
 }
 
-// ---- The walks of a finite ray (inv_dir_finite) through an LDS-resident scene of plain triangles: traverse_rounds / traverse of rtx_dev_scene.h with the
-// min / max node test, the control word of lds_node_ctl and the lane's state in ONE register (leaf_n > 0: holds a leaf of that many primitives, 0: walking,
-// < 0: done - the two ballots of a round are two compares). Per ray the sequence of node tests, triangle tests and t_max updates is the reference's.
-template <bool ANY, int LEAF_MIN, class StackT, int N, int T>
-RT_DEV bool traverse_small_finite(const float* __restrict__ s_nodes, const float* __restrict__ s_tris, Ray ray, StackT* stack, int stack_stride, int& prim_out, TriHit& hit_out) {
-  const f3 inv_dir = mk3(1.0f / ray.d.x, 1.0f / ray.d.y, 1.0f / ray.d.z);
-  const unsigned negmask = (inv_dir.x < 0.0f ? 0x10000u : 0u) | (inv_dir.y < 0.0f ? 0x20000u : 0u) | (inv_dir.z < 0.0f ? 0x40000u : 0u);
-  const RayPre rp = ray_pre(ray);
-  // The watertight test's permutation (mesh.rs:233-240) by ADDRESS: the triangles are planar in LDS (plane 3 v + c = coordinate c of vertex v), so a lane reads
-  // coordinate kx / ky / kz of a vertex from the plane its own permutation names - three base addresses per ray - and subtracts the equally permuted origin
-  // (p[k] - o[k]: the same subtraction): no selects per vertex (18 per test before).
-  const float* const tpx = s_tris + rp.kx * T; const float* const tpy = s_tris + rp.ky * T; const float* const tpz = s_tris + rp.kz * T;
-  const f3 op = permute(ray.o, rp.kx, rp.ky, rp.kz);
-  bool found = false;
-  // the to-visit stack as the ADDRESS of its top entry (the lane's column, stack_stride entries apart): a push is a store at top + one entry and an add, a pop
-  // a load at top and an add - no index-to-address arithmetic per node
-  typedef __attribute__((address_space(3))) StackT LdsEntry;
-  const unsigned step = (unsigned)stack_stride * (unsigned)sizeof(StackT);
-  const unsigned bottom = (unsigned)(uintptr_t)(LdsEntry*)stack - step; unsigned top = bottom;
-  int cur = 0, leaf_off = 0, leaf_n = 0;
-  for (;;) {
-    unsigned long long holders = 0ull;
-    for (;;) {
-      if (leaf_n == 0) {
-        const float* nd = s_nodes + cur;
-        const float4 n0 = make_float4(nd[0], nd[2 * N], nd[4 * N], nd[N]), n1 = make_float4(nd[3 * N], nd[5 * N], 0.0f, 0.0f);
-        const int offset = __float_as_int(nd[6 * N]); const unsigned ctl = __float_as_uint(nd[7 * N]);
-        if (slab_test_finite(n0, n1, ray.o, ray.t_max, inv_dir)) {
-          const int n_prims = (int)(ctl & 0xffffu);
-          if (n_prims != 0) { leaf_off = offset; leaf_n = n_prims; }
-          else {
-            const bool neg = (ctl & negmask) != 0u;
-            top += step; *(LdsEntry*)(uintptr_t)top = (StackT)(neg ? cur + 1 : offset);
-            cur = neg ? offset : cur + 1;
-          }
-        } else if (top == bottom) leaf_n = -1;
-        else { cur = (int)*(const LdsEntry*)(uintptr_t)top; top -= step; }
-      }
-      if (LEAF_MIN <= 1) break;  // the single loop of the any-hit walk: one node step, then the lanes that hold a leaf test it
-      holders = __ballot(leaf_n > 0);
-      if (__ballot(leaf_n == 0) == 0ull) break;
-      if (__builtin_popcount((unsigned)holders) + __builtin_popcount((unsigned)(holders >> 32)) >= LEAF_MIN) break;  // (two 32-bit counts: the 64-bit count's compare is compiled as a VECTOR compare)
-    }
-    if (LEAF_MIN > 1 && holders == 0ull) break;
-#ifndef RT_LDS_LEAF_ONE
-#define RT_LDS_LEAF_ONE 1
-#endif
-    if (RT_LDS_LEAF_ONE && !ANY) {
-      // one primitive per leaf phase: a holder with more stays a holder (and counts towards the next phase) - no lane waits for another's longer leaf
-      if (leaf_n > 0) {
-        const int t = leaf_off;
-        const f3 p0t = mk3(tpx[t] - op.x, tpy[t] - op.y, tpz[t] - op.z), p1t = mk3(tpx[3 * T + t] - op.x, tpy[3 * T + t] - op.y, tpz[3 * T + t] - op.z),
-                 p2t = mk3(tpx[6 * T + t] - op.x, tpy[6 * T + t] - op.y, tpz[6 * T + t] - op.z);
-        TriHit h;
-        if (tri_test_permuted(p0t, p1t, p2t, rp.sx, rp.sy, rp.sz, ray.t_max, h)) { found = true; ray.t_max = h.t; prim_out = t; hit_out = h; }
-        leaf_off += 1; leaf_n -= 1;
-        if (leaf_n == 0) {
-          if (top == bottom) leaf_n = -1;
-          else { cur = (int)*(const LdsEntry*)(uintptr_t)top; top -= step; }
-        }
-      }
-    } else
-    if (leaf_n > 0) {
-      for (int i = 0; i < leaf_n; ++i) {
-        const int t = leaf_off + i;
-        const f3 p0t = mk3(tpx[t] - op.x, tpy[t] - op.y, tpz[t] - op.z), p1t = mk3(tpx[3 * T + t] - op.x, tpy[3 * T + t] - op.y, tpz[3 * T + t] - op.z),
-                 p2t = mk3(tpx[6 * T + t] - op.x, tpy[6 * T + t] - op.y, tpz[6 * T + t] - op.z);
-        TriHit h;
-        if (tri_test_permuted(p0t, p1t, p2t, rp.sx, rp.sy, rp.sz, ray.t_max, h)) {
-          found = true;
-          if (ANY) break;
-          ray.t_max = h.t; prim_out = t; hit_out = h;  // `.or(result)`: later accepted hits replace
-        }
-      }
-      if ((ANY && found) || top == bottom) leaf_n = -1;
-      else { leaf_n = 0; cur = (int)*(const LdsEntry*)(uintptr_t)top; top -= step; }
-    }
-    if (LEAF_MIN <= 1 && __ballot(leaf_n == 0) == 0ull) break;
-  }
-  return found;
-}
-
-// ---- Occlusion in an LDS-resident scene WITHOUT a stack (FINITE: the node test of a finite ray, slab_test_finite; otherwise the reference's selects). intersect_p's answer is a property of the tree and the ray alone - "some primitive
-// passes its test and every box above it passes the node test" - because nothing the walk learns changes a later test (t_max never shrinks; bvh/mod.rs:443-500
-// returns at the first accepted primitive). Any order that skips exactly the subtrees of failed boxes gives the reference's answer, so the lane walks the
-// nodes in their array order (pre-order: the first child follows its parent) and on a failed box jumps to the node after the subtree (s_skip, built per
-// workgroup by lds_build_skip): no to-visit stack, no direction signs - a node step is the box test and one select.
-template <int N>
-RT_DEV void lds_build_skip(const float* __restrict__ s_nodes, unsigned short* __restrict__ s_skip, unsigned n_nodes, unsigned short* pending /* n_nodes entries of scratch in LDS */) {
-  // one thread, in array order: skip[i] = the pending second child on top when i is reached (the node that follows i's subtree), n_nodes at the end
-  unsigned sp = 0;
-  for (unsigned i = 0; i < n_nodes; ++i) {
-    if (sp > 0u && pending[sp - 1u] == i) --sp;
-    s_skip[i] = sp > 0u ? pending[sp - 1u] : (unsigned short)n_nodes;
-    const unsigned ctl = __float_as_uint(s_nodes[7 * N + i]);
-    if ((ctl & 0xffffu) == 0u) pending[sp++] = (unsigned short)__float_as_uint(s_nodes[6 * N + i]);
-  }
-}
-// (Measured and not kept: holding a reached leaf until 4 / 8 / 12 / 16 lanes of the wave hold one, one primitive per phase - shadow rays 124 -> 130 / 135.5 / 140 /
-// 144 ms per S1 frame. A holder's wait costs more node rounds than the fuller triangle tests return.)
+// ---- The walks of an LDS-resident scene of plain triangles WITHOUT a stack (FINITE: the node test of a finite ray, slab_test_finite; otherwise the reference's
+// selects). The order in which BVH::intersect reaches the nodes depends on the ray only through the signs of its direction, so "the entry on top of the
+// to-visit stack when the walk reaches node i" is a constant of (octant, i): DScene::skip8, staged into LDS. A node step is then the box test and a select
+// between the near child and the link - no push, no pop, no stack memory (the closest-hit kernel: 17.5 KB of LDS per 256 lanes instead of 21.5, 13.9 for
+// occlusion rays). Per ray the sequence of node tests, primitive tests and t_max updates is the reference's: a far child is tested when the reference pops
+// it, with the t_max of that moment.
+// Occlusion rays: intersect_p's answer is a property of the tree and the ray alone - "some primitive passes its test and every box above it passes the node
+// test" (t_max never shrinks; bvh/mod.rs:443-500 returns at the first accepted primitive) - so they all walk in ONE order, octant 0's = array order, and
+// the kernel stages one row of links.
 template <int N, int T, bool FINITE>
 RT_DEV bool occluded_small(const float* __restrict__ s_nodes, const float* __restrict__ s_tris, const unsigned short* __restrict__ s_skip, const int n_nodes, const Ray ray) {
   const f3 inv_dir = mk3(1.0f / ray.d.x, 1.0f / ray.d.y, 1.0f / ray.d.z);
@@ -914,6 +823,52 @@ RT_DEV bool occluded_small(const float* __restrict__ s_nodes, const float* __res
       cur = next;
     }
     if (__ballot(cur < n_nodes) == 0ull) break;
+  }
+  return found;
+}
+// (Measured and not kept: holding a reached leaf until 4 / 8 / 12 / 16 lanes of the wave hold one, one primitive per phase - shadow rays 124 -> 130 / 135.5 / 140 /
+// 144 ms per S1 frame. A holder's wait costs more node rounds than the fuller triangle tests return.)
+// Closest hit: rounds (every walking lane takes one node; when LEAF_MIN lanes hold a leaf, or none walks, every holder tests ONE primitive - a holder with more
+// stays a holder; whole leaves per phase: closest hit 256 ms per S1 frame against 248).
+template <int N, int T, bool FINITE, int LEAF_MIN>
+RT_DEV bool closest_small(const float* __restrict__ s_nodes, const float* __restrict__ s_tris, const unsigned short* __restrict__ s_skip8, const int n_nodes, Ray ray, int& prim_out, TriHit& hit_out) {
+  const f3 inv_dir = mk3(1.0f / ray.d.x, 1.0f / ray.d.y, 1.0f / ray.d.z);
+  const int neg_x = inv_dir.x < 0.0f, neg_y = inv_dir.y < 0.0f, neg_z = inv_dir.z < 0.0f;
+  const unsigned oct = (neg_x ? 1u : 0u) | (neg_y ? 2u : 0u) | (neg_z ? 4u : 0u), negmask = oct << 16;
+  const unsigned short* const skip = s_skip8 + oct * N;
+  const RayPre rp = ray_pre(ray);
+  const float* const tpx = s_tris + rp.kx * T; const float* const tpy = s_tris + rp.ky * T; const float* const tpz = s_tris + rp.kz * T;
+  const f3 op = permute(ray.o, rp.kx, rp.ky, rp.kz);
+  bool found = false;
+  int cur = 0, leaf_off = 0, leaf_n = 0;  // cur == n_nodes: nothing left to visit; leaf_n > 0: the lane holds that many untested primitives from leaf_off on (cur already names what follows the leaf)
+  for (;;) {
+    unsigned long long holders = 0ull;
+    for (;;) {
+      if (leaf_n == 0 && cur < n_nodes) {
+        const float* nd = s_nodes + cur;
+        const float4 n0 = make_float4(nd[0], nd[2 * N], nd[4 * N], nd[N]), n1 = make_float4(nd[3 * N], nd[5 * N], 0.0f, 0.0f);
+        const int offset = __float_as_int(nd[6 * N]); const unsigned ctl = __float_as_uint(nd[7 * N]);
+        int next = (int)skip[cur];
+        if (slab_test_t<FINITE>(n0, n1, ray, inv_dir, neg_x, neg_y, neg_z)) {
+          const int n_prims = (int)(ctl & 0xffffu);
+          if (n_prims != 0) { leaf_off = offset; leaf_n = n_prims; }
+          else next = (ctl & negmask) != 0u ? offset : cur + 1;
+        }
+        cur = next;
+      }
+      holders = __ballot(leaf_n > 0);
+      if (__ballot(leaf_n == 0 && cur < n_nodes) == 0ull) break;
+      if (__builtin_popcount((unsigned)holders) + __builtin_popcount((unsigned)(holders >> 32)) >= LEAF_MIN) break;  // (two 32-bit counts: the 64-bit count's compare is compiled as a VECTOR compare)
+    }
+    if (holders == 0ull) break;
+    if (leaf_n > 0) {
+      const int t = leaf_off;
+      const f3 p0t = mk3(tpx[t] - op.x, tpy[t] - op.y, tpz[t] - op.z), p1t = mk3(tpx[3 * T + t] - op.x, tpy[3 * T + t] - op.y, tpz[3 * T + t] - op.z),
+               p2t = mk3(tpx[6 * T + t] - op.x, tpy[6 * T + t] - op.y, tpz[6 * T + t] - op.z);
+      TriHit h;
+      if (tri_test_permuted(p0t, p1t, p2t, rp.sx, rp.sy, rp.sz, ray.t_max, h)) { found = true; ray.t_max = h.t; prim_out = t; hit_out = h; }  // `.or(result)`: later accepted hits replace
+      leaf_off += 1; leaf_n -= 1;
+    }
   }
   return found;
 }
@@ -951,14 +906,14 @@ RT_DEV void trace_write_any(float4* __restrict__ lacc, size_t ls, const float4* 
 #ifndef RT_LDS_TRACE_WAVES  // the LDS-resident kernels' register bound in waves per SIMD: their LDS (21.5 KB per 256 lanes) lets seven workgroups share a CU
 #define RT_LDS_TRACE_WAVES 7
 #endif
-#ifndef RT_LDS_ANY_STACKLESS  // plain-triangle occlusion rays of an LDS-resident scene walk without a stack (occluded_small)
-#define RT_LDS_ANY_STACKLESS 1
+#ifndef RT_LDS_THREADED      // the plain-triangle kernels of an LDS-resident scene walk without a stack (closest_small, occluded_small)
+#define RT_LDS_THREADED 1
 #endif
-#ifndef RT_LDS_ANY_WAVES      // ... and their kernel, 13.6 KB of LDS per 256 lanes, is bound by its registers
+#ifndef RT_LDS_ANY_WAVES      // ... the occlusion kernel, 13.9 KB of LDS per 256 lanes, is bound by its registers
 #define RT_LDS_ANY_WAVES 8
 #endif
 template <bool ANY, bool COUNT, bool SMALL, int BLOCK, int DEPTH, int GENERAL = 0>  // GENERAL: quadrics / alpha-masked triangles in the leaves (no object instances)
-__global__ void __launch_bounds__(BLOCK, (SMALL && GENERAL == 0 && !COUNT) ? ((ANY && RT_LDS_ANY_STACKLESS) ? RT_LDS_ANY_WAVES : RT_LDS_TRACE_WAVES) : RT_GEN_MIN_WAVES(GENERAL)) k_trace(DScene sc, TraceIO io, const unsigned* __restrict__ queue, const unsigned* __restrict__ shard_counts, unsigned shard_cap,
+__global__ void __launch_bounds__(BLOCK, (SMALL && GENERAL == 0 && !COUNT) ? ((ANY && RT_LDS_THREADED) ? RT_LDS_ANY_WAVES : RT_LDS_TRACE_WAVES) : RT_GEN_MIN_WAVES(GENERAL)) k_trace(DScene sc, TraceIO io, const unsigned* __restrict__ queue, const unsigned* __restrict__ shard_counts, unsigned shard_cap,
                                                  unsigned count_static, unsigned long long* stats, int st_rays, int st_nodes, int st_tris) {
   const float4* __restrict__ ray_o = io.ray_o; const float4* __restrict__ ray_d = io.ray_d; const size_t rs = io.ray_stride;
   float4* __restrict__ hits = io.hits; const size_t hs = io.hit_stride; const bool hit_b2 = io.hit_b2 != 0;
@@ -970,7 +925,7 @@ __global__ void __launch_bounds__(BLOCK, (SMALL && GENERAL == 0 && !COUNT) ? ((A
 #define RT_ANY_STACK16 1
 #endif
   typedef typename std::conditional<SMALL && (!ANY || RT_ANY_STACK16), unsigned short, int>::type StackT;
-  constexpr bool STACKLESS = RT_LDS_ANY_STACKLESS && ANY && SMALL && !COUNT && GENERAL == 0;  // occluded_small: no to-visit stack at all (13.6 KB of LDS per workgroup instead of 21.5)
+  constexpr bool STACKLESS = RT_LDS_THREADED && SMALL && !COUNT && GENERAL == 0;  // closest_small / occluded_small: no to-visit stack at all
   __shared__ StackT stack[STACKLESS ? 1 : DEPTH * BLOCK];
   constexpr int NN = RT_SMALL_NODES, NT = RT_SMALL_TRIS;
   typedef LdsSrcT<NN, NT> LdsS;
@@ -979,10 +934,10 @@ __global__ void __launch_bounds__(BLOCK, (SMALL && GENERAL == 0 && !COUNT) ? ((A
   QView qv; if (queue) qv.init(io.queue_is_slots ? nullptr : queue, shard_counts, shard_cap);
   const unsigned count = queue ? qv.total() : count_static;
   if (blockIdx.x * BLOCK >= count) return;  // short queues (MIS rays, late bounces): most blocks of the persistent grid have nothing to stage for
-  __shared__ unsigned short s_skip[STACKLESS ? NN : 1], s_pending[STACKLESS ? DEPTH : 1];
+  __shared__ unsigned short s_skip[STACKLESS ? (ANY ? 1 : 8) * NN : 1];  // the links of the walk order(s): DScene::skip8, rows NN apart
   if (SMALL) { stage_small_scene<BLOCK, NN, NT>(sc, s_nodes, s_tris); __syncthreads(); }
   if (STACKLESS) {
-    if (threadIdx.x == 0u) lds_build_skip<NN>(s_nodes, s_skip, sc.n_nodes, s_pending);  // (pending second children: at most the tree's height <= DEPTH)
+    for (unsigned i = threadIdx.x; i < (ANY ? 1u : 8u) * sc.n_nodes; i += BLOCK) { const unsigned o = i / sc.n_nodes, k = i - o * sc.n_nodes; s_skip[o * NN + k] = sc.skip8[i]; }
     __syncthreads();
   }
   const unsigned stride = gridDim.x * BLOCK;
@@ -1000,13 +955,12 @@ __global__ void __launch_bounds__(BLOCK, (SMALL && GENERAL == 0 && !COUNT) ? ((A
     const bool fin = FIN_FORMS && __ballot(!inv_dir_finite(mk3(1.0f / ray.d.x, 1.0f / ray.d.y, 1.0f / ray.d.z))) == 0ull;
     if (SMALL && LM > 1 && LM < 64 && !COUNT) {
       LdsS src{s_nodes, s_tris};
-      if (FIN_FORMS && fin) found = traverse_small_finite<ANY, LM, StackT, NN, NT>(s_nodes, s_tris, ray, stack + threadIdx.x, BLOCK, prim, h);
+      if (STACKLESS && !ANY) found = fin ? closest_small<NN, NT, true, LM>(s_nodes, s_tris, s_skip, (int)sc.n_nodes, ray, prim, h) : closest_small<NN, NT, false, LM>(s_nodes, s_tris, s_skip, (int)sc.n_nodes, ray, prim, h);
       else found = traverse_rounds<ANY, COUNT, LM, LdsS, StackT, GENERAL>(src, ray, stack + threadIdx.x, BLOCK, prim, h, n_nodes, n_tris, gen);
     }
     else if (SMALL) {
       LdsS src{s_nodes, s_tris};
       if (STACKLESS) found = fin ? occluded_small<NN, NT, true>(s_nodes, s_tris, s_skip, (int)sc.n_nodes, ray) : occluded_small<NN, NT, false>(s_nodes, s_tris, s_skip, (int)sc.n_nodes, ray);
-      else if (FIN_FORMS && fin) found = traverse_small_finite<ANY, (ANY ? 1 : 64), StackT, NN, NT>(s_nodes, s_tris, ray, stack + threadIdx.x, BLOCK, prim, h);
       else found = traverse<ANY, COUNT, LdsS, StackT, GENERAL>(src, ray, stack + threadIdx.x, BLOCK, prim, h, n_nodes, n_tris, gen);
     }
     else {
