@@ -332,9 +332,10 @@ def run_workload(scene_name, runner, workload, steps, warmup):
                 "nodes_per_ray": round(nodes / max(rays, 1), 2), "tris_per_ray": round(tris / max(rays, 1), 2)}
     ms_mis_any = ms_mean.get("ms_trace_mis_any", 0.0)
     not_cast = cst.get("rays_mis_not_cast", 0)  # of rays_mis: rays toward a sphere light that cannot reach it (rt_stats::rays_mis_not_cast): in no launch, no bytes
+    tail_nc = cst.get("rays_tail_not_cast", 0)  # of rays_closest: path rays at the depth limit after a non-specular bounce (nothing reads their hit): in no launch, no vertex, no bytes
     nd_div = n_gpus_asked if runner.mode != "single" else 1  # whole-frame bytes against per-device (mean / slowest-rank) stage time: bytes per device
     classes = {
-        "path_closest": ray_class(cst["rays_closest"] / nd_div, cst["nodes_closest"] / nd_div, cst["tris_closest"] / nd_div, ms_mean["ms_trace_closest"], 48),
+        "path_closest": ray_class((cst["rays_closest"] - tail_nc) / nd_div, cst["nodes_closest"] / nd_div, cst["tris_closest"] / nd_div, ms_mean["ms_trace_closest"], 48),
         "shadow_any": ray_class(cst["rays_shadow"] / nd_div, cst["nodes_shadow"] / nd_div, cst["tris_shadow"] / nd_div, ms_mean["ms_trace_any"], 36),
         "mis_closest": ray_class((cst["rays_mis"] - cst["rays_mis_any"] - not_cast) / nd_div, (cst["nodes_mis"] - cst["nodes_mis_any"]) / nd_div, (cst["tris_mis"] - cst["tris_mis_any"]) / nd_div,
                                  ms_mean["ms_trace_mis"] - ms_mis_any, 48),
@@ -368,8 +369,8 @@ def run_workload(scene_name, runner, workload, steps, warmup):
         return c["algorithmic_bytes"], launches // 2, ms_tc, "trace_closest", c["rays"], "ray"
 
     def shade_roofline():
-        verts = cst["rays_closest"] / nd_div
-        emitted = (cst["rays_shadow"] + cst["rays_mis"] - not_cast + (cst["rays_closest"] - cst["camera_rays"])) / nd_div
+        verts = (cst["rays_closest"] - tail_nc) / nd_div
+        emitted = (cst["rays_shadow"] + cst["rays_mis"] - not_cast + (cst["rays_closest"] - tail_nc - cst["camera_rays"])) / nd_div
         return 128 * verts + 32 * emitted + 48 * cst["camera_rays"] / nd_div, launches // 2, ms_sh, "shade", verts, "vertex"
 
     def roof(algo_bytes, n_launch, ms_kernel, kname, unit_n, unit):
@@ -398,8 +399,8 @@ def run_workload(scene_name, runner, workload, steps, warmup):
         "ms_per_step": round(ms_step, 2), "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
         "config": {"workload": workload, "sharding": sharding, "sampler_mode": "pixel-keyed"},
         "s_per_frame": round(ms_step / 1e3, 4),
-        "Mrays_per_s": round((cst["rays_closest"] + cst["rays_shadow"] + cst["rays_mis"] - not_cast) / (ms_step * 1e-3) / 1e6, 1),
-        "mis_rays_not_cast": int(not_cast),
+        "Mrays_per_s": round((cst["rays_closest"] + cst["rays_shadow"] + cst["rays_mis"] - not_cast - tail_nc) / (ms_step * 1e-3) / 1e6, 1),
+        "mis_rays_not_cast": int(not_cast), "tail_rays_not_cast": int(tail_nc),
         "kernel_ms_per_step": kernels_ms, "vertices_by_shade_front_end": verts,
         "roofline": roofline, "roofline_second_kernel": roofline_other, "traversal_by_ray_class": classes, "traversal_hbm_share": groups,
         "camera_samples_per_step": int(samples_per_step), "gpu_clocks": clocks.summary(),

@@ -233,6 +233,10 @@ typedef struct rt_stats {
   /* of rays_mis: BSDF-sampled rays toward a sphere light that miss the sphere's world box and were therefore not cast (Sphere::pdf_wi is non-zero for any
    * direction, sphere.rs:310-334; such a ray's term is zero whatever it hits). Zero on frames that count the reference's walk. */
   uint64_t rays_mis_not_cast;
+  /* of rays_closest: path rays that follow a NON-specular bounce at the depth limit and were therefore not cast. PathIntegrator::li traces the next ray
+   * before it tests the depth (path.rs:100-137) and reads the hit only to add emitted light after a specular bounce: after any other bounce the ray at
+   * bounces == max_depth is never read. The film is the one the cast rays give; zero on frames that count the reference's walk. */
+  uint64_t rays_tail_not_cast;
 } rt_stats;
 
 #define RT_FLAG_COUNT_TRAVERSAL 1u /* fill nodes_ and tris_ counters (slower)                  */

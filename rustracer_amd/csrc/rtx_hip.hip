@@ -1488,6 +1488,8 @@ extern "C" int rt_render(rt_scene* s, const rt_camera* cam, const rt_film_desc* 
       ps.mis_any = (has_infinite && (!count || (flags & RT_FLAG_COUNT_AS_RENDERED))) ? 1 : 0;
       static const bool reach_off = getenv("RTX_MIS_REACH") && getenv("RTX_MIS_REACH")[0] == '0';  // measurement knob
       ps.skip_unreachable_mis = (!reach_off && (!count || (flags & RT_FLAG_COUNT_AS_RENDERED))) ? 1 : 0;
+      static const bool tail_off = getenv("RTX_DEAD_TAIL") && getenv("RTX_DEAD_TAIL")[0] == '0';  // measurement knob: cast the rays nothing reads as well
+      ps.skip_dead_tail = (!tail_off && (!count || (flags & RT_FLAG_COUNT_AS_RENDERED))) ? 1 : 0;
       tm.begin(&stats.ms_raygen);
       hipLaunchKernelGGL(k_raygen, dim3(pgrid), dim3(256), 0, stream, fp, ps);
       tm.end();
@@ -1568,7 +1570,7 @@ extern "C" int rt_render(rt_scene* s, const rt_camera* cam, const rt_film_desc* 
     if (ovf) { (void)hipMemset(s->sampler_plan.dirty.p, 0, (2 + RT_DIRTY_CAP) * 4); return fail(RT_ERR_INVALID, "sampler retry list overflow"); } }
   stats.camera_rays = h[ST_CAMERA];  // counted by k_raygen: samples inside pixel_bounds and the film's sample rows
   stats.rays_mis_any = h[ST_RAYS_MISANY]; stats.nodes_mis_any = h[ST_NODES_MISANY]; stats.tris_mis_any = h[ST_TRIS_MISANY];
-  stats.rays_closest = h[ST_RAYS_CLOSEST]; stats.rays_shadow = h[ST_RAYS_SHADOW]; stats.rays_mis = h[ST_RAYS_MIS] + h[ST_RAYS_MISANY] + h[ST_MIS_UNREACHED];
+  stats.rays_closest = h[ST_RAYS_CLOSEST] + h[ST_TAIL_UNCAST]; stats.rays_tail_not_cast = h[ST_TAIL_UNCAST]; stats.rays_shadow = h[ST_RAYS_SHADOW]; stats.rays_mis = h[ST_RAYS_MIS] + h[ST_RAYS_MISANY] + h[ST_MIS_UNREACHED];
   stats.rays_mis_not_cast = h[ST_MIS_UNREACHED];
   stats.nodes_closest = h[ST_NODES_CLOSEST]; stats.nodes_shadow = h[ST_NODES_SHADOW]; stats.nodes_mis = h[ST_NODES_MIS] + h[ST_NODES_MISANY];
   stats.tris_closest = h[ST_TRIS_CLOSEST]; stats.tris_shadow = h[ST_TRIS_SHADOW]; stats.tris_mis = h[ST_TRIS_MIS] + h[ST_TRIS_MISANY];
@@ -1596,7 +1598,7 @@ __global__ void k_film_add(float4* __restrict__ dst, const float4* __restrict__ 
 }
 // every counter and every timer of b added into a
 static void stats_add(rt_stats& a, const rt_stats& b) {
-  a.camera_rays += b.camera_rays; a.rays_closest += b.rays_closest; a.rays_shadow += b.rays_shadow; a.rays_mis += b.rays_mis; a.rays_mis_not_cast += b.rays_mis_not_cast;
+  a.camera_rays += b.camera_rays; a.rays_closest += b.rays_closest; a.rays_shadow += b.rays_shadow; a.rays_mis += b.rays_mis; a.rays_mis_not_cast += b.rays_mis_not_cast; a.rays_tail_not_cast += b.rays_tail_not_cast;
   a.nodes_closest += b.nodes_closest; a.nodes_shadow += b.nodes_shadow; a.nodes_mis += b.nodes_mis;
   a.tris_closest += b.tris_closest; a.tris_shadow += b.tris_shadow; a.tris_mis += b.tris_mis; a.paths_scrubbed += b.paths_scrubbed;
   a.ms_total += b.ms_total; a.ms_sampler += b.ms_sampler; a.ms_raygen += b.ms_raygen; a.ms_trace_closest += b.ms_trace_closest; a.ms_trace_any += b.ms_trace_any;

@@ -72,6 +72,11 @@ struct PassState {
   // that misses the sphere's (slightly widened) world box cannot end on it: with this flag such a ray is not cast (its term is the zero it would have been);
   // it is counted in ST_MIS_UNREACHED and stays in rt_stats::rays_mis. Off on frames that count the reference's walk.
   int skip_unreachable_mis;
+  // PathIntegrator::li traces a path's next ray BEFORE it tests the depth (path.rs:100-137: intersect, emitted light if bounces == 0 or after a specular
+  // bounce, then `if !found || bounces >= max_depth { break }`): the ray cast at bounces == max_depth is read only after a specular bounce. With this flag a
+  // path whose last bounce was not specular ends there (counted in ST_TAIL_UNCAST, part of rt_stats::rays_closest): same film, no trace, no vertex. Off on
+  // frames that count the reference's walk.
+  int skip_dead_tail;
   const unsigned* range;  // k_shade: shade entries [range[0], range[1]) of q_in only (NULL = all): class-wise dispatch over the binned queue
   unsigned long long* stats;  // device-side u64 counters, see ST_* below
 };
@@ -80,6 +85,7 @@ enum { ST_CAMERA = 0, ST_RAYS_CLOSEST, ST_RAYS_SHADOW, ST_RAYS_MIS, ST_NODES_CLO
        ST_TRIS_CLOSEST, ST_TRIS_SHADOW, ST_TRIS_MIS, ST_SCRUBBED, ST_UNBUILT_VOXEL,
        ST_RAYS_MISANY, ST_NODES_MISANY, ST_TRIS_MISANY,  // the occlusion-only MIS rays (also counted in the _MIS entries)
        ST_MIS_UNREACHED,  // MIS rays toward a quadric light that miss its box: not cast (PassState::skip_unreachable_mis)
+       ST_TAIL_UNCAST,    // path rays at the depth limit after a non-specular bounce: not cast (PassState::skip_dead_tail)
        ST_SHADED,  // + {0: k_shade<1>, 1: k_shade<3>, 2: k_shade<5>, 3: k_shade<0>}: path vertices shaded by each front-end (misses included)
        ST_STAMP = ST_SHADED + 4,  // + 8 * front-end + section: wave cycles of the sections of k_shade (measurement builds only, make ABLATE=1)
        ST_COUNT = ST_STAMP + 32 };
@@ -2305,7 +2311,7 @@ __global__ void __launch_bounds__(256, (MODE == 1 || LEAN || BOUNCED) ? ((LEAN |
   unsigned first = 0, count = ps.cnt_in ? qv.total() : ps.cap;  // no counts: bounce 0 of a pass whose samples are all traced (entry i = slot i = path i)
   if (MODE != 1 && ps.range) { first = ps.range[0]; count = ps.range[1]; }
   const unsigned stride = gridDim.x * blockDim.x;
-  unsigned n_shaded = 0, n_unreached = 0;
+  unsigned n_shaded = 0, n_unreached = 0, n_tail = 0;
   const DScene& gsc = *sc.self;  // what out-of-line functions get: the scene record in device memory, not a private copy of the kernel argument
 #ifdef RT_ABLATE
   unsigned long long stamp_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, stamp_last = clock64();
@@ -2476,8 +2482,6 @@ __global__ void __launch_bounds__(256, (MODE == 1 || LEAN || BOUNCED) ? ((LEAN |
             float eta = bsdf.eta();
             eta_scale *= dot(wo, si.hit.n) > 0.0f ? eta * eta : vdiv(1.0f, eta * eta);
           }
-          Ray nr = spawn_ray(si.hit, bs.wi);
-          nr_o = nr.o; nr_d = nr.d;
           cont = true;
           rgb3 rr_beta = beta * eta_scale;  // path.rs:201-209
           if (max_component_value(rr_beta) < fp.rr_threshold && bounces > 3) {
@@ -2486,6 +2490,9 @@ __global__ void __launch_bounds__(256, (MODE == 1 || LEAN || BOUNCED) ? ((LEAN |
             else beta = vdiv(beta, 1.0f - q);
           }
           if (cont) bounces += 1;
+          // the next iteration would trace this ray, add what it reaches only after a specular bounce, and leave at bounces >= max_depth (path.rs:127-139)
+          if (cont && ps.skip_dead_tail && bounces >= fp.max_depth && !specular_bounce) { cont = false; n_tail += 1u; }
+          if (cont) { const Ray nr = spawn_ray(si.hit, bs.wi); nr_o = nr.o; nr_d = nr.d; }
         }
       }
       st_out = pack_state(bounces, specular_bounce, smp.c1, smp.c2); rng_out = smp.rng.state;
@@ -2552,6 +2559,8 @@ __global__ void __launch_bounds__(256, (MODE == 1 || LEAN || BOUNCED) ? ((LEAN |
     for (int off = 32; off > 0; off >>= 1) n_unreached += __shfl_down(n_unreached, off);
     if ((threadIdx.x & 63u) == 0u && n_unreached) atomicAdd(&ps.stats[ST_MIS_UNREACHED], (unsigned long long)n_unreached);
   }
+  for (int off = 32; off > 0; off >>= 1) n_tail += __shfl_down(n_tail, off);
+  if ((threadIdx.x & 63u) == 0u && n_tail) atomicAdd(&ps.stats[ST_TAIL_UNCAST], (unsigned long long)n_tail);
   for (int off = 32; off > 0; off >>= 1) n_shaded += __shfl_down(n_shaded, off);
   if ((threadIdx.x & 63u) == 0u && n_shaded) atomicAdd(&ps.stats[ST_SHADED + (MODE == 1 ? 0 : (MODE == 3 ? 1 : (MODE == 5 || MODE == 6 ? 2 : 3)))], (unsigned long long)n_shaded);
 #ifdef RT_ABLATE

@@ -64,7 +64,7 @@ class Stats(C.Structure):
         [(n, C.c_uint64) for n in ("launches_trace_closest", "n_passes", "vertices_lambert_const", "vertices_lambert", "vertices_two_lobe", "vertices_generic")] +
         [(n, C.c_double) for n in ("ms_shade_lambert_const", "ms_shade_lambert", "ms_shade_two_lobe", "ms_shade_generic", "ms_shade_bin", "ms_shade_miss")] +
         [("shade_section_cycles", C.c_uint64 * 32)] +
-        [(n, C.c_uint64) for n in ("rays_mis_any", "nodes_mis_any", "tris_mis_any")] + [("ms_trace_mis_any", C.c_double), ("ms_gather", C.c_double), ("rays_mis_not_cast", C.c_uint64)])
+        [(n, C.c_uint64) for n in ("rays_mis_any", "nodes_mis_any", "tris_mis_any")] + [("ms_trace_mis_any", C.c_double), ("ms_gather", C.c_double), ("rays_mis_not_cast", C.c_uint64), ("rays_tail_not_cast", C.c_uint64)])
 
     def as_dict(self):
         return {n: (list(getattr(self, n)) if n == "shade_section_cycles" else getattr(self, n)) for n, _ in self._fields_}

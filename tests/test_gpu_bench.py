@@ -68,4 +68,7 @@ def test_counting_as_rendered_walks_environment_mis_rays_as_occlusion_rays(gpu_h
     assert ref["rays_mis_any"] == 0 and asr["rays_mis_any"] > 0
     assert asr["rays_mis"] == ref["rays_mis"] and asr["rays_closest"] == ref["rays_closest"]
     assert asr["nodes_mis"] < ref["nodes_mis"]                        # an any-hit walk leaves at the first hit
-    assert asr["nodes_closest"] == ref["nodes_closest"] and asr["nodes_shadow"] == ref["nodes_shadow"]
+    assert asr["nodes_shadow"] == ref["nodes_shadow"]
+    # ... and does not cast the path rays at the depth limit that nothing reads (rays_tail_not_cast, still part of rays_closest): their node visits are the difference
+    assert asr["rays_tail_not_cast"] > 0 and ref["rays_tail_not_cast"] == 0 and asr["nodes_closest"] < ref["nodes_closest"]
+    assert (ref["nodes_closest"] - asr["nodes_closest"]) < 4 * ref["nodes_closest"] * asr["rays_tail_not_cast"] / ref["rays_closest"]

@@ -197,6 +197,26 @@ def test_render_matches_oracle(gpu_host, orc, res, spp):
         assert abs(int(sh[k]) - int(so[k])) <= 1e-3 * int(so[k]) + 8, k
 
 
+def test_rays_nothing_reads_are_not_cast_and_the_film_is_the_same(gpu_host, orc):
+    """PathIntegrator::li traces the next ray before it tests the depth (path.rs:100-139) and reads the hit at bounces == max_depth only after a specular
+    bounce. A production frame does not cast the others (rt_stats::rays_tail_not_cast, part of rays_closest); a frame that counts the reference's walk casts
+    every ray the reference casts. Same film bit for bit, same ray counts - also with a mirror in the scene, where the rays behind a specular bounce at the
+    limit are read (emitted light) and therefore cast."""
+    for mirror in (False, True):
+        d = _cornell(40, 36, 16)
+        if mirror:
+            d.materials[1] = d.materials[d.mirror(0.9)]  # one wall becomes a mirror
+        h = gpu_host.HostScene(d)
+        plain, sp = h.render()
+        ref, sr = h.render(count_traversal=True)
+        assert np.array_equal(bits(plain), bits(ref))
+        assert sp["rays_tail_not_cast"] > 0 and sr["rays_tail_not_cast"] == 0
+        for k in ("camera_rays", "rays_closest", "rays_shadow", "rays_mis"):
+            assert sp[k] == sr[k], k
+        fo, so = orc.OracleScene(d).render(mode=1, n_threads=1)
+        assert abs(int(sp["rays_closest"]) - int(so["rays_closest"])) <= 8 and rel_l2(gpu_host.film_to_rgb(plain), orc.film_to_rgb(fo)) < L2_GATE
+
+
 def test_render_is_deterministic_and_reentrant(gpu_host):
     h = gpu_host.HostScene(_cornell(48, 48, 16))
     a, _ = h.render()
