@@ -95,12 +95,16 @@ RT_DEV RayPre ray_pre(const Ray& ray) {
   return r;
 }
 // ... from the translated, permuted vertices on (mesh.rs:248-319): shear, edge functions, the rejection tests, t and the barycentrics, the error bound on t
+// EARLY_SIGN: leave at the edge-sign test when every lane that runs the test fails it (the occlusion walk of an LDS-resident scene tests a primitive for the
+// two or three lanes that hold a leaf in a given step; most of them miss the triangle outright)
+template <bool EARLY_SIGN = false>
 RT_DEV bool tri_test_permuted(f3 p0t, f3 p1t, f3 p2t, float sx, float sy, float sz, float t_max, TriHit& h);
 RT_DEV bool tri_test_pre(f3 p0, f3 p1, f3 p2, const Ray& ray, const RayPre& rp, TriHit& h) {
   f3 p0t = p0 - ray.o, p1t = p1 - ray.o, p2t = p2 - ray.o;
   p0t = permute(p0t, rp.kx, rp.ky, rp.kz); p1t = permute(p1t, rp.kx, rp.ky, rp.kz); p2t = permute(p2t, rp.kx, rp.ky, rp.kz);
   return tri_test_permuted(p0t, p1t, p2t, rp.sx, rp.sy, rp.sz, ray.t_max, h);
 }
+template <bool EARLY_SIGN>
 RT_DEV bool tri_test_permuted(f3 p0t, f3 p1t, f3 p2t, const float sx, const float sy, const float sz, const float t_max, TriHit& h) {
   p0t.x += sx * p0t.z; p0t.y += sy * p0t.z;
   p1t.x += sx * p1t.z; p1t.y += sy * p1t.z;
@@ -119,6 +123,7 @@ RT_DEV bool tri_test_permuted(f3 p0t, f3 p1t, f3 p2t, const float sx, const floa
   // The reference's three rejection tests (edge signs, det == 0, t range; mesh.rs:272-296) are pure comparisons: they are
   // evaluated together and leave through one branch instead of three.
   const bool sign_fail = ((e0 < 0.0f) | (e1 < 0.0f) | (e2 < 0.0f)) & ((e0 > 0.0f) | (e1 > 0.0f) | (e2 > 0.0f));
+  if (EARLY_SIGN && sign_fail) return false;
   float det = e0 + e1 + e2;
   p0t.z *= sz; p1t.z *= sz; p2t.z *= sz;
   float t_scaled = e0 * p0t.z + e1 * p1t.z + e2 * p2t.z;

@@ -799,6 +799,9 @@ RT_DEV void stage_small_scene(const DScene& sc, float* s_nodes, float* s_tris) {
 // Occlusion rays: intersect_p's answer is a property of the tree and the ray alone - "some primitive passes its test and every box above it passes the node
 // test" (t_max never shrinks; bvh/mod.rs:443-500 returns at the first accepted primitive) - so they all walk in ONE order, octant 0's = array order, and
 // the kernel stages one row of links.
+#ifndef RT_ANY_EARLY_SIGN
+#define RT_ANY_EARLY_SIGN 1
+#endif
 template <int N, int T, bool FINITE>
 RT_DEV bool occluded_small(const float* __restrict__ s_nodes, const float* __restrict__ s_tris, const unsigned short* __restrict__ s_skip, const int n_nodes, const Ray ray) {
   const f3 inv_dir = mk3(1.0f / ray.d.x, 1.0f / ray.d.y, 1.0f / ray.d.z);
@@ -822,7 +825,7 @@ RT_DEV bool occluded_small(const float* __restrict__ s_nodes, const float* __res
             const f3 p0t = mk3(tpx[t] - op.x, tpy[t] - op.y, tpz[t] - op.z), p1t = mk3(tpx[3 * T + t] - op.x, tpy[3 * T + t] - op.y, tpz[3 * T + t] - op.z),
                      p2t = mk3(tpx[6 * T + t] - op.x, tpy[6 * T + t] - op.y, tpz[6 * T + t] - op.z);
             TriHit h;
-            if (tri_test_permuted(p0t, p1t, p2t, rp.sx, rp.sy, rp.sz, ray.t_max, h)) { found = true; next = n_nodes; break; }
+            if (tri_test_permuted<RT_ANY_EARLY_SIGN != 0>(p0t, p1t, p2t, rp.sx, rp.sy, rp.sz, ray.t_max, h)) { found = true; next = n_nodes; break; }
           }
         }
       }
