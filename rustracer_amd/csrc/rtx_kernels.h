@@ -2314,7 +2314,7 @@ __global__ void __launch_bounds__(256, (MODE == 1 || LEAN || BOUNCED) ? ((LEAN |
   unsigned first = 0, count = ps.cnt_in ? qv.total() : ps.cap;  // no counts: bounce 0 of a pass whose samples are all traced (entry i = slot i = path i)
   if (MODE != 1 && ps.range) { first = ps.range[0]; count = ps.range[1]; }
   const unsigned stride = gridDim.x * blockDim.x;
-  unsigned n_shaded = 0, n_unreached = 0, n_tail = 0;
+  unsigned n_shaded = 0, n_unreached = 0;
   const DScene& gsc = *sc.self;  // what out-of-line functions get: the scene record in device memory, not a private copy of the kernel argument
 #ifdef RT_ABLATE
   unsigned long long stamp_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, stamp_last = clock64();
@@ -2494,7 +2494,12 @@ __global__ void __launch_bounds__(256, (MODE == 1 || LEAN || BOUNCED) ? ((LEAN |
           }
           if (cont) bounces += 1;
           // the next iteration would trace this ray, add what it reaches only after a specular bounce, and leave at bounces >= max_depth (path.rs:127-139)
-          if (cont && ps.skip_dead_tail && bounces >= fp.max_depth && !specular_bounce) { cont = false; n_tail += 1u; }
+          if (cont && ps.skip_dead_tail && bounces >= fp.max_depth && !specular_bounce) {
+            cont = false;
+            // counted here, one atomic per wave that has such paths (the last bounce's launch only): a per-lane counter would be one more live register in every form
+            const unsigned long long m = __ballot(true);
+            if (__lane_id() == (unsigned)(__ffsll((long long)m) - 1)) atomicAdd(&ps.stats[ST_TAIL_UNCAST], (unsigned long long)__popcll(m));
+          }
           if (cont) { const Ray nr = spawn_ray(si.hit, bs.wi); nr_o = nr.o; nr_d = nr.d; }
         }
       }
@@ -2562,8 +2567,6 @@ __global__ void __launch_bounds__(256, (MODE == 1 || LEAN || BOUNCED) ? ((LEAN |
     for (int off = 32; off > 0; off >>= 1) n_unreached += __shfl_down(n_unreached, off);
     if ((threadIdx.x & 63u) == 0u && n_unreached) atomicAdd(&ps.stats[ST_MIS_UNREACHED], (unsigned long long)n_unreached);
   }
-  for (int off = 32; off > 0; off >>= 1) n_tail += __shfl_down(n_tail, off);
-  if ((threadIdx.x & 63u) == 0u && n_tail) atomicAdd(&ps.stats[ST_TAIL_UNCAST], (unsigned long long)n_tail);
   for (int off = 32; off > 0; off >>= 1) n_shaded += __shfl_down(n_shaded, off);
   if ((threadIdx.x & 63u) == 0u && n_shaded) atomicAdd(&ps.stats[ST_SHADED + (MODE == 1 ? 0 : (MODE == 3 ? 1 : (MODE == 5 || MODE == 6 ? 2 : 3)))], (unsigned long long)n_shaded);
 #ifdef RT_ABLATE
