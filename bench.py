@@ -172,6 +172,14 @@ class ClockSampler:
             self.pci = None
         pw = glob.glob(os.path.join(self.dev, "hwmon/hwmon*/power1_average")) + glob.glob(os.path.join(self.dev, "hwmon/hwmon*/power1_input")) if self.dev else []
         self.power = pw[0] if pw else None
+        # the socket power limit of this GPU (boxes of one pool differ: k_shade<1>, the one stage that loads both the VALUs and HBM, took 271 ms per S1 frame on
+        # GPUs that drew 950 - 1000 W in it and 328 ms on one that stayed at 850 W, every other stage equal)
+        self.power_cap = None
+        try:
+            cap = glob.glob(os.path.join(self.dev, "hwmon/hwmon*/power1_cap")) if self.dev else []
+            self.power_cap = int(open(cap[0]).read()) / 1e6 if cap else None
+        except Exception:
+            pass
 
     @staticmethod
     def _active(path):
@@ -206,7 +214,7 @@ class ClockSampler:
             v = [r[k] for r in self.rows if r[k] is not None]
             if v:
                 out[name] = {"before": v[0], "after": v[-1]}
-        return dict(out, pci=self.pci) if out else None
+        return dict(out, pci=self.pci, power_cap_W=self.power_cap) if out else None
 
 
 class Runner:

@@ -2314,7 +2314,7 @@ __global__ void __launch_bounds__(256, (MODE == 1 || LEAN || BOUNCED) ? ((LEAN |
   unsigned first = 0, count = ps.cnt_in ? qv.total() : ps.cap;  // no counts: bounce 0 of a pass whose samples are all traced (entry i = slot i = path i)
   if (MODE != 1 && ps.range) { first = ps.range[0]; count = ps.range[1]; }
   const unsigned stride = gridDim.x * blockDim.x;
-  unsigned n_shaded = 0, n_unreached = 0;
+  unsigned n_shaded = 0, n_unreached = 0, n_tail = 0;
   const DScene& gsc = *sc.self;  // what out-of-line functions get: the scene record in device memory, not a private copy of the kernel argument
 #ifdef RT_ABLATE
   unsigned long long stamp_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, stamp_last = clock64();
@@ -2323,7 +2323,7 @@ __global__ void __launch_bounds__(256, (MODE == 1 || LEAN || BOUNCED) ? ((LEAN |
   // end are workgroup-wide).
   auto shade_vertex = [&](const bool lane_live, const unsigned i, const unsigned rslot) {
     RT_STAMP(7);  // loop overhead / previous iteration's tail
-    bool cont = false, want_shadow = false, want_mis = false, mis_occlusion_only = false;
+    bool cont = false, want_shadow = false, want_mis = false, mis_occlusion_only = false, tail = false;
     // what a continuing path takes to its slot in the next bounce's queue (stored after the append below has named the slot)
     f3 nr_o = mk3(0, 0, 0), nr_d = mk3(0, 0, 0); rgb3 beta = mkc(0, 0, 0); float eta_scale = 1.0f; unsigned st_out = 0u, pid = 0u; unsigned long long rng_out = 0ull;
     if (lane_live) {
@@ -2494,18 +2494,16 @@ __global__ void __launch_bounds__(256, (MODE == 1 || LEAN || BOUNCED) ? ((LEAN |
           }
           if (cont) bounces += 1;
           // the next iteration would trace this ray, add what it reaches only after a specular bounce, and leave at bounces >= max_depth (path.rs:127-139)
-          if (cont && ps.skip_dead_tail && bounces >= fp.max_depth && !specular_bounce) {
-            cont = false;
-            // counted here, one atomic per wave that has such paths (the last bounce's launch only): a per-lane counter would be one more live register in every form
-            const unsigned long long m = __ballot(true);
-            if (__lane_id() == (unsigned)(__ffsll((long long)m) - 1)) atomicAdd(&ps.stats[ST_TAIL_UNCAST], (unsigned long long)__popcll(m));
-          }
+          if (cont && ps.skip_dead_tail && bounces >= fp.max_depth && !specular_bounce) { cont = false; tail = true; }
           if (cont) { const Ray nr = spawn_ray(si.hit, bs.wi); nr_o = nr.o; nr_d = nr.d; }
         }
       }
       st_out = pack_state(bounces, specular_bounce, smp.c1, smp.c2); rng_out = smp.rng.state;
     }
     RT_STAMP(6);  // continuation sample, spawn, state stores
+    // (a wave-uniform count, kept in a scalar register: a per-lane counter is one more live vector register in every form, and an atomic where the paths end
+    // is ~7 M atomics on one word in the launch at the depth limit - k_shade<1> 271 -> 329 ms per S1 frame, measured)
+    n_tail += (unsigned)__popcll(__ballot(tail));
     constexpr int NQ = (MODE == 1 || LEAN) ? 3 : 4;  // area lights only: every MIS ray needs its closest hit
     const int ci[4] = {0, 1, 2, 3}; const bool pr[4] = {cont, want_shadow, want_mis && !mis_occlusion_only, want_mis && mis_occlusion_only}; unsigned slot[4];
     block_push<NQ>(ps.cnt_out, ps.shard_cap, ci, pr, slot);
@@ -2567,6 +2565,7 @@ __global__ void __launch_bounds__(256, (MODE == 1 || LEAN || BOUNCED) ? ((LEAN |
     for (int off = 32; off > 0; off >>= 1) n_unreached += __shfl_down(n_unreached, off);
     if ((threadIdx.x & 63u) == 0u && n_unreached) atomicAdd(&ps.stats[ST_MIS_UNREACHED], (unsigned long long)n_unreached);
   }
+  if ((threadIdx.x & 63u) == 0u && n_tail) atomicAdd(&ps.stats[ST_TAIL_UNCAST], (unsigned long long)n_tail);  // (the wave's count, the same in every lane)
   for (int off = 32; off > 0; off >>= 1) n_shaded += __shfl_down(n_shaded, off);
   if ((threadIdx.x & 63u) == 0u && n_shaded) atomicAdd(&ps.stats[ST_SHADED + (MODE == 1 ? 0 : (MODE == 3 ? 1 : (MODE == 5 || MODE == 6 ? 2 : 3)))], (unsigned long long)n_shaded);
 #ifdef RT_ABLATE

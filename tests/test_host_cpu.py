@@ -247,7 +247,7 @@ def test_kernel_register_and_scratch_budgets(host):
         # the textured front-ends bound to three waves (round 4): a few dozen spilled dwords buy the third wave (S4 shade 3027 -> 2801 ms)
         "rtx::k_shade<3, false, false, false, false>": (168, 64),
         "rtx::k_shade<5, false, false, false, false>": (168, 128),
-        "rtx::k_shade<6, false, false, false, false>": (168, 192),
+        "rtx::k_shade<6, false, false, false, false>": (168, 224),
         "rtx::k_shade<0, false, false, false, false>": (256, 2048),     # 257 (one accumulation register added by a callee) is ONE wave per SIMD
         "rtx::k_trace<false, false, true, 256, 16, 0>": (72, 0),    # the LDS-resident closest-hit kernel of the headline: 7 waves
         "rtx::k_trace<true, false, true, 256, 16, 0>": (64, 0),     # ... and its shadow-ray twin: 8 waves
