@@ -1307,12 +1307,18 @@ struct PairLane {
 // the other kind.
 // RT_ANY_ORDER (occlusion rays only: intersect_p's answer - "some primitive passes its test and every box above it passes the node test" - does not depend on
 // the order of the walk, and the kernels of HBM scenes wait for memory, so a walk that reaches an occluder after fewer fetches is a faster one): which of two
-// children that are both hit is entered first - 0 the reference's (the one on the ray's side of the split), 1 the one whose box the ray crosses for the longer
-// stretch of [0, t_max], 2 the one entered earlier, 3 a leaf before an interior node, otherwise as 1. S4 per frame, shadow / environment MIS rays:
-// 478 / 799 ms (0), 391 / 729 (1), 431 / 784 (2), 379 / 722 (3). The four-wide kernel keeps the reference's order: its children sorted by stretch made S3's
-// shadow rays slower (100.8 -> 112.2 ms), and so did its leaves first (108.1); "the box that holds the origin first" on top of 3: 391 / 745.
+// children that are both hit is entered first. S4 per frame, shadow / environment MIS rays:
+//   0 the reference's order (the child on the ray's side of the split)               478 / 799 ms
+//   2 the box entered earlier                                                         431 / 784
+//   5 a leaf before an interior node, otherwise the box entered LATER                 434 / 760
+//   1 the box the ray crosses for the longer stretch of [0, t_max]                    391 / 729
+//   3 a leaf before an interior node, otherwise as 1                                  379 / 722   (+ "the box that holds the origin" before that: 391 / 745)
+//   6 a leaf before an interior node, otherwise the box the ray LEAVES later          367 / 701
+//   8 the box the ray leaves later (min(tmax, t_max))                                 361 / 690   <- default: what ends a ray inside a scene lies far along it
+// The four-wide kernel keeps the reference's order: its children sorted by stretch made S3's shadow rays slower (100.8 -> 112.2 ms), its leaves first too
+// (108.1), and sorted by where the ray leaves them as well (114.8).
 #ifndef RT_ANY_ORDER
-#define RT_ANY_ORDER 3
+#define RT_ANY_ORDER 8
 #endif
 struct PairTest { bool hit_n, keep_f, far_first; float tmin_n, tmin_f; };  // (by value: as reference parameters the three flags became a byte array in scratch, indexed by one of them)
 RT_DEV PairTest pair_slabs(const bool finite, const f3 o, const float t_max, const f3 inv_dir, float4 n0, float4 n1, float4 f0, float4 f1, const bool want_order) {
@@ -1326,6 +1332,8 @@ RT_DEV PairTest pair_slabs(const bool finite, const f3 o, const float t_max, con
     if (want_order) {
       if (RT_ANY_ORDER == 1 || RT_ANY_ORDER == 3) r.far_first = (fminf(tmax_f, t_max) - fmaxf(r.tmin_f, 0.0f)) > (fminf(tmax_n, t_max) - fmaxf(r.tmin_n, 0.0f));
       else if (RT_ANY_ORDER == 2) r.far_first = r.tmin_f < r.tmin_n;
+      else if (RT_ANY_ORDER == 5) r.far_first = r.tmin_f > r.tmin_n;                                                 // (leaf first, then) the box entered LATER
+      else if (RT_ANY_ORDER == 6 || RT_ANY_ORDER == 8) r.far_first = fminf(tmax_f, t_max) > fminf(tmax_n, t_max);  // (6: leaf first, then) the box left later
     }
   } else {
     Ray ray; ray.o = o; ray.d = mk3(0, 0, 0); ray.t_max = t_max;  // (the node test reads the origin and t_max)
@@ -1369,7 +1377,7 @@ RT_DEV void pair_interior_step(PairLane& L, const TraceOut& o, const float4* __r
   const unsigned code_n = neg ? code_b : code_a, code_f = neg ? code_a : code_b;
   const PairTest r = pair_slabs(L.finite(), L.ray.o, L.ray.t_max, L.inv_dir, n0, n1, f0, f1, ANY && RT_ANY_ORDER != 0);
   bool ff = ANY && r.far_first;
-  if (ANY && RT_ANY_ORDER == 3 && ((code_n ^ code_f) & RT_PAIR_LEAF) != 0u) ff = (code_f & RT_PAIR_LEAF) != 0u;  // exactly one child is a leaf: its primitives first
+  if (ANY && RT_ANY_ORDER >= 3 && RT_ANY_ORDER != 8 && ((code_n ^ code_f) & RT_PAIR_LEAF) != 0u) ff = (code_f & RT_PAIR_LEAF) != 0u;  // exactly one child is a leaf: its primitives first
   const unsigned first = ff ? code_f : code_n, second = ff ? code_n : code_f;  // (closest hit: always near, far)
   if (r.hit_n & r.keep_f) { stack[L.sp * BLOCK] = second; if (!ANY) tstack[(size_t)L.sp * grid_lanes] = r.tmin_f; ++L.sp; L.cur = first; }
   else if (r.hit_n) L.cur = code_n;
@@ -1687,7 +1695,7 @@ RT_DEV void top_interior_step(PairLane& L, const TraceOut& o, const float4* __re
   const unsigned code_n = neg ? code_b : code_a, code_f = neg ? code_a : code_b;
   const PairTest r = pair_slabs(L.finite(), L.ray.o, L.ray.t_max, L.inv_dir, n0, n1, f0, f1, ANY && RT_ANY_ORDER != 0);
   bool ff = ANY && r.far_first;
-  if (ANY && RT_ANY_ORDER == 3 && ((code_n ^ code_f) & RT_PAIR_LEAF) != 0u) ff = (code_f & RT_PAIR_LEAF) != 0u;
+  if (ANY && RT_ANY_ORDER >= 3 && RT_ANY_ORDER != 8 && ((code_n ^ code_f) & RT_PAIR_LEAF) != 0u) ff = (code_f & RT_PAIR_LEAF) != 0u;
   const unsigned first = ff ? code_f : code_n, second = ff ? code_n : code_f;
   if (r.hit_n & r.keep_f) { stk.put(L.sp, second); if (!ANY) tstack[(size_t)L.sp * grid_lanes] = r.tmin_f; ++L.sp; L.cur = first; }
   else if (r.hit_n) L.cur = code_n;
