@@ -893,6 +893,10 @@ static unsigned trace_knobs(const rt_scene* s, bool any) {
   // (an instance leaf of the nested form is a whole walk: the holders wait for every walker. In k_trace_inst a leaf is a leaf again: 20 / 24 / 32 / 40 / 48 / 64 lanes
   // gave 780 / 779 / 781 / 764 / 739 / 684 Msamples/s on 10 000 placements of a 1280-triangle object)
   unsigned leaf = s->has_instances ? (inst_loop_kernel(s) ? 32u : 64u) : (unsigned)RT_LEAF_MIN;
+  // Occlusion rays under an environment light are unbounded (t_max = inf) and long: with the order of RT_ANY_ORDER their leaf phases pay at 48 waiting lanes
+  // (S4 shadow / environment MIS rays 360 / 686 ms at 20, 335 / 637 at 28 - 32, 321 / 606 at 48), where the bounded shadow rays of area-light scenes lose
+  // (S2 31 -> 45 ms, S3 101 -> 112)
+  if (any && s->d.n_infinite > 0 && !s->has_instances) leaf = 48u;
   if (env_leaf > 0) leaf = (unsigned)env_leaf;
   if (any && env_leaf_any > 0) leaf = (unsigned)env_leaf_any;
   return refill | (leaf << 8);
