@@ -1160,7 +1160,10 @@ static int launch_sampler_tables(SamplerPlan& pl, const FrameParams& fp, unsigne
   // ... except for a frame's FIRST batch at 1024 spp, which no path kernel runs beside (`alone`): there the parallel replay is what it measures alone, 25.0 against
   // 28.6 ms (S1 862 -> 857 ms over three interleaved pairs; at 256 / 512 spp, where a lane replays 4 / 8 steps, it loses: S2 167.3 -> 169.5, S3 323.5 -> 324.6)
   static const bool par_never = getenv("RTX_K0_PARALLEL") && getenv("RTX_K0_PARALLEL")[0] == '0';
-  const bool par = (par_on || (alone && !par_never && spp == 1024u)) && spp >= 64u && spp <= 1024u;
+  // Late in round 4 (the path kernels of a batch had become a fifth shorter): at 1024 spp a short leading batch (lead_pixels) WITH the parallel replay for every batch -
+  // the next batch's tables are then ready when the short batch's kernels are done - S1 679.5 -> 670.7 ms, S4 5280 -> 5242 (each knob alone: S1 674 / 672 ms).
+  (void)alone;
+  const bool par = (par_on || (!par_never && spp == 1024u)) && spp >= 64u && spp <= 1024u;
   hipLaunchKernelGGL(k_sampler_draws, dim3((n_pixels + 255u) / 256u, pl.n_segs), dim3(256), 0, stream, fp, n_pixels, spp, dims, pl.seg_len, explicit_pixel0, use_explicit,
                      pl.segs.as<SamplerSeg>(), pl.magic.as<unsigned>(), scrambles, partners, pl.dirty.as<unsigned>(), par ? 1 : 0);
   hipLaunchKernelGGL(k_sampler_redo, dim3(RT_DIRTY_CAP / 64u), dim3(64), 0, stream, fp, n_pixels, spp, dims, explicit_pixel0, use_explicit, pl.dirty.as<unsigned>(), pl.magic.as<unsigned>(), scrambles, partners, par ? 1 : 0);
@@ -1349,7 +1352,8 @@ extern "C" int rt_render(rt_scene* s, const rt_camera* cam, const rt_film_desc* 
   const unsigned long long table_bytes_per_pixel = 2ull * dims * spp * 2ull;
 
   unsigned long long batch_pixels = 0, chunk_pixels = 0, cap = 0, lead_pixels = 0; unsigned pass_samples = 0, shard_cap = 0; bool multi_batch = false; size_t n_slots = 0;
-  static const bool lead_on = getenv("RTX_LEAD_BATCH") && getenv("RTX_LEAD_BATCH")[0] == '1';  // measurement knob (round 4), see lead_pixels below
+  static const char* lead_env = getenv("RTX_LEAD_BATCH");  // measurement knob (round 4), see lead_pixels below: 1 always, 0 never, unset: at 1024 spp
+  const bool lead_on = lead_env ? lead_env[0] == '1' : spp == 1024u;
   for (int shrink = 0;; ++shrink) {
     if (tp_log2 - shrink < 14) return fail(RT_ERR_OOM, "not enough free device memory for the smallest pass (2^14 paths)");
     const unsigned long long target_paths = 1ull << (tp_log2 - shrink);
