@@ -237,6 +237,10 @@ typedef struct rt_stats {
    * before it tests the depth (path.rs:100-137) and reads the hit only to add emitted light after a specular bounce: after any other bounce the ray at
    * bounces == max_depth is never read. The film is the one the cast rays give; zero on frames that count the reference's walk. */
   uint64_t rays_tail_not_cast;
+  /* launches per stage of this frame, as issued (round 5; launches_trace_closest above = launches_trace_path + launches_trace_mis): the closest-hit launches of
+   * the path rays, the any-hit launches of the shadow rays, the closest-hit launches of the BSDF-sampled MIS rays, the any-hit launches of the MIS rays toward
+   * an infinite light, and the k_shade launches of all front-ends together (binning and the miss bin not counted). What a per-launch average divides by. */
+  uint64_t launches_trace_path, launches_trace_shadow, launches_trace_mis, launches_trace_mis_any, launches_shade;
 } rt_stats;
 
 #define RT_FLAG_COUNT_TRAVERSAL 1u /* fill nodes_ and tris_ counters (slower)                  */
@@ -325,6 +329,14 @@ int rt_sampler_tables_plain(int32_t spp, int32_t dimensions, uint64_t pixel0, ui
  * n_voxels[3]; func: nvox*n_lights, cdf: nvox*(n_lights+1), func_int: nvox (host pointers, may be NULL
  * to query n_voxels only). */
 int rt_light_distribution(rt_scene* scene, int32_t n_voxels[3], float* func, float* cdf, float* func_int);
+
+/* What rt_scene_create decided about a scene (measurement / tests): RT_QUERY_LDS_RESIDENT - 1 if the traversal kernels keep the whole tree and its
+ * primitives in LDS (k_trace; the roofline of such a scene's traversal is VALU issue, its HBM bytes are ray records only), else 0. < 0: bad argument. */
+enum { RT_QUERY_LDS_RESIDENT = 0 };
+int rt_scene_query(rt_scene* scene, int32_t what);
+/* sizeof() of an ABI struct by its C name ("rt_stats", "rt_scene_desc", ...), or -1: lets a binding in another language check its mirror of the
+ * header against the library it actually loaded (rustracer_amd/host.py does at load time; tests/test_abi_cpu.py checks every struct). */
+int rt_sizeof(const char* struct_name);
 
 const char* rt_last_error(void);
 /* 1 if a gfx950 device is visible to this process, else 0 (never falls back to a CPU path). */

@@ -132,6 +132,10 @@ int rtxh_render_multi(rtxh_scene*, const rtxh_render_params*, const int32_t* dev
 int rtxh_trace(rtxh_scene*, const float* rays, uint64_t n, int32_t any_hit, float* hits4_or_occ, uint64_t counters[2]);
 int rtxh_trace_device(rtxh_scene*, const void* d_rays, uint64_t n, void* d_hits, int32_t reps, void* hip_stream, float* ms_per_launch);
 int rtxh_light_distribution(rtxh_scene*, int32_t n_voxels[3], float* func, float* cdf, float* func_int);
+/* rt_scene_query on the uploaded scene (uploads it first if need be; rtx_hip.h: RT_QUERY_*). */
+int rtxh_scene_query(rtxh_scene*, int32_t what);
+/* sizeof() of a struct of this header or of rtx_hip.h by its C name, or -1 (a binding checks its mirrors against the library it loaded). */
+int rtxh_sizeof(const char* struct_name);
 const char* rtxh_last_error(void);
 
 /* ---- input formats on the caller's side of the path ------------------------------------

@@ -101,7 +101,15 @@ struct rt_scene {
 };
 
 extern "C" const char* rt_last_error(void) { return g_err.c_str(); }
-extern "C" const char* rt_version(void) { return "rtx-mi355x 0.1 (gfx950 wavefront path tracer)"; }
+extern "C" const char* rt_version(void) { return "rtx-mi355x 0.5 (gfx950 wavefront path tracer)"; }
+extern "C" int rt_sizeof(const char* name) {
+  if (!name) return -1;
+#define RT_SZ(T) if (!strcmp(name, #T)) return (int)sizeof(T);
+  RT_SZ(rt_bvh_node) RT_SZ(rt_tri_meta) RT_SZ(rt_sphere) RT_SZ(rt_instance) RT_SZ(rt_texture) RT_SZ(rt_image) RT_SZ(rt_material) RT_SZ(rt_light) RT_SZ(rt_scene_desc)
+  RT_SZ(rt_camera) RT_SZ(rt_film_desc) RT_SZ(rt_sampler_desc) RT_SZ(rt_path_desc) RT_SZ(rt_shard) RT_SZ(rt_stats)
+#undef RT_SZ
+  return -1;
+}
 extern "C" int rt_device_available(void) {
   int n = 0;
   if (hipGetDeviceCount(&n) != hipSuccess || n <= 0) return 0;
@@ -755,6 +763,11 @@ extern "C" void rt_scene_destroy(rt_scene* s) {
   (void)hipSetDevice(s->device);
   delete s;
 }
+extern "C" int rt_scene_query(rt_scene* s, int32_t what) {
+  if (!s) return fail(RT_ERR_INVALID, "null scene");
+  if (what == RT_QUERY_LDS_RESIDENT) return s->small ? 1 : 0;
+  return fail(RT_ERR_INVALID, "unknown rt_scene_query item");
+}
 
 // ---------------------------------------------------------------------------------------------- light distribution
 // PathIntegrator::preprocess (rc/integrator/path.rs:86-94) + SpatialLightDistribution::new (rc/lightdistrib.rs:67-99)
@@ -1128,15 +1141,15 @@ static unsigned shuffle_lanes_per_block(unsigned spp) { unsigned l = 65536u / sp
 // shuffles, the expensive part, are independent per table: group 0 = what k_raygen reads, group 1 = what bounce 0's shade reads, group 2 = the rest; an event after
 // each group lets the frame's first batch start its camera rays after 11 ms instead of 28.6, with the other shuffles under its first kernels. 1-D table 0 is not
 // shuffled at all inside a frame (nothing reads it); rt_sampler_tables builds every table.
-struct TableGroups { unsigned packed[3], n[3]; int n_groups; };
+struct TableGroups { unsigned long long packed[3]; unsigned n[3]; int n_groups; };  // a group's table ids, 4 bits each: 2 * dims <= 16 tables fill 64 bits (32 bits held 8)
 static TableGroups table_groups_all(unsigned dims) {
   TableGroups g{}; g.n_groups = 1;
-  for (unsigned t = 0; t < 2u * dims; ++t) { g.packed[0] |= t << (4u * g.n[0]); g.n[0] += 1; }
+  for (unsigned t = 0; t < 2u * dims; ++t) { g.packed[0] |= (unsigned long long)t << (4u * g.n[0]); g.n[0] += 1; }
   return g;
 }
 static TableGroups table_groups_frame(unsigned dims) {
   TableGroups g{}; g.n_groups = 3;
-  auto add = [&](int k, unsigned t) { g.packed[k] |= t << (4u * g.n[k]); g.n[k] += 1; };
+  auto add = [&](int k, unsigned t) { g.packed[k] |= (unsigned long long)t << (4u * g.n[k]); g.n[k] += 1; };
   add(0, dims); add(0, dims + 1u);                                   // 2-D tables 0, 1: the camera sample
   if (dims > 1u) add(1, 1u);                                         // 1-D table 1: bounce 0's light pick
   for (unsigned d = 2; d < dims; ++d) add(1, dims + d);              // 2-D tables 2 ...: bounce 0's light point and scattering direction
@@ -1144,41 +1157,39 @@ static TableGroups table_groups_frame(unsigned dims) {
   return g;
 }
 static int launch_sampler_tables(SamplerPlan& pl, const FrameParams& fp, unsigned n_pixels, unsigned long long explicit_pixel0, int use_explicit,
-                                 unsigned* scrambles, unsigned short* perms, hipStream_t stream, bool alone, const TableGroups& groups, hipEvent_t* group_done) {
+                                 unsigned* scrambles, unsigned short* perms, hipStream_t stream, const TableGroups& groups, hipEvent_t* group_done) {
   const unsigned spp = pl.spp, dims = pl.dims;
   const unsigned lpb = shuffle_lanes_per_block(spp);
   const size_t lds = (size_t)lpb * spp * 2;
   HIP_TRY(pl.partners.ensure((size_t)n_pixels * 2u * dims * spp * 2u));
   unsigned short* partners = pl.partners.as<unsigned short>();
   HIP_TRY(hipMemsetAsync(pl.dirty.p, 0, 4, stream));
-  // RTX_K0_PARALLEL=1: the exact parallel replay (one wave per chain, k_sampler_shuffle_par) for 64 <= spp <= 1024. Built in round 4 as VERDICT r02 / r03 asked,
-  // measured, and left OFF: on its own a batch of S1's tables (524 288 pixels x 8 tables) takes 25.0 ms against 28.6 ms (the replay itself 15.4 against 23.2 ms;
-  // the draws kernel pays 4.4 ms for the chain-major partner layout the replay needs), but a frame builds all tables except the first batch's UNDER path
-  // kernels, where the sequential kernel - one latency-bound wave per CU - takes almost nothing from them and the parallel one competes for issue slots and
-  // LDS: S1 883 = 883 ms, S4 6178 = 6183, S3 328 -> 353, S2 177 -> 202. What the frame did gain from is making the un-overlapped batch short (lead_pixels).
+  // Which kernel replays the shuffles. k_sampler_shuffle_par (one wave per chain, exact; 64 <= spp <= 1024) takes 25.0 ms for a batch of S1's tables (524 288 pixels x 8
+  // tables) on its own against the chain kernel's 28.6 (the replay 15.4 against 23.2 ms; the draws kernel pays 4.4 ms for the chain-major partner layout it needs) -
+  // but a frame builds all tables except its first batch's UNDER path kernels, where the chain kernel (one latency-bound wave per CU) takes almost nothing from them
+  // and the parallel one competes for issue slots and LDS. Measured in round 4, frame times: at 256 / 512 spp the parallel replay loses (S2 167.3 -> 169.5 ms, S3 323.5 ->
+  // 324.6); at 1024 spp, with a short leading batch (lead_pixels in rt_render), it wins for EVERY batch (S1 679.5 -> 667.5 ms, S4 5280 -> 5242).
+  // DEFAULT therefore: parallel replay at spp == 1024, chain kernel otherwise. RTX_K0_PARALLEL=1 forces the parallel replay (64 <= spp <= 1024), =0 the chain kernel.
   static const bool par_on = getenv("RTX_K0_PARALLEL") && getenv("RTX_K0_PARALLEL")[0] == '1';
-  // ... except for a frame's FIRST batch at 1024 spp, which no path kernel runs beside (`alone`): there the parallel replay is what it measures alone, 25.0 against
-  // 28.6 ms (S1 862 -> 857 ms over three interleaved pairs; at 256 / 512 spp, where a lane replays 4 / 8 steps, it loses: S2 167.3 -> 169.5, S3 323.5 -> 324.6)
   static const bool par_never = getenv("RTX_K0_PARALLEL") && getenv("RTX_K0_PARALLEL")[0] == '0';
-  // Late in round 4 (the path kernels of a batch had become a fifth shorter): at 1024 spp a short leading batch (lead_pixels) WITH the parallel replay for every batch -
-  // the next batch's tables are then ready when the short batch's kernels are done - S1 679.5 -> 670.7 ms, S4 5280 -> 5242 (each knob alone: S1 674 / 672 ms).
-  (void)alone;
+  // RTX_K0_FORCE_RESORT=1 (test knob, read per call): the parallel replay is handed descending ranks, so every wave takes the branch that re-sorts its groups
+  const unsigned force_resort = (getenv("RTX_K0_FORCE_RESORT") && getenv("RTX_K0_FORCE_RESORT")[0] == '1') ? 1u : 0u;
   const bool par = (par_on || (!par_never && spp == 1024u)) && spp >= 64u && spp <= 1024u;
   hipLaunchKernelGGL(k_sampler_draws, dim3((n_pixels + 255u) / 256u, pl.n_segs), dim3(256), 0, stream, fp, n_pixels, spp, dims, pl.seg_len, explicit_pixel0, use_explicit,
                      pl.segs.as<SamplerSeg>(), pl.magic.as<unsigned>(), scrambles, partners, pl.dirty.as<unsigned>(), par ? 1 : 0);
   hipLaunchKernelGGL(k_sampler_redo, dim3(RT_DIRTY_CAP / 64u), dim3(64), 0, stream, fp, n_pixels, spp, dims, explicit_pixel0, use_explicit, pl.dirty.as<unsigned>(), pl.magic.as<unsigned>(), scrambles, partners, par ? 1 : 0);
   unsigned* const resorted = pl.dirty.as<unsigned>() + 1 + RT_DIRTY_CAP + 1;  // waves whose groups did not come out sorted (diagnostic; the result is exact either way)
   for (int g = 0; g < groups.n_groups; ++g) {
-    const unsigned tables = groups.packed[g], nt = groups.n[g];
+    const unsigned long long tables = groups.packed[g]; const unsigned nt = groups.n[g];
     if (nt) {
       if (par) {
         const dim3 grid((n_pixels + RT_SHUF_PIX - 1) / RT_SHUF_PIX, nt);
         switch (spp) {
-          case 64: hipLaunchKernelGGL(k_sampler_shuffle_par<1>, grid, dim3(256), 0, stream, n_pixels, partners, perms, resorted, tables); break;
-          case 128: hipLaunchKernelGGL(k_sampler_shuffle_par<2>, grid, dim3(256), 0, stream, n_pixels, partners, perms, resorted, tables); break;
-          case 256: hipLaunchKernelGGL(k_sampler_shuffle_par<4>, grid, dim3(256), 0, stream, n_pixels, partners, perms, resorted, tables); break;
-          case 512: hipLaunchKernelGGL(k_sampler_shuffle_par<8>, grid, dim3(256), 0, stream, n_pixels, partners, perms, resorted, tables); break;
-          default: hipLaunchKernelGGL(k_sampler_shuffle_par<16>, grid, dim3(256), 0, stream, n_pixels, partners, perms, resorted, tables); break;
+          case 64: hipLaunchKernelGGL(k_sampler_shuffle_par<1>, grid, dim3(256), 0, stream, n_pixels, partners, perms, resorted, tables, force_resort); break;
+          case 128: hipLaunchKernelGGL(k_sampler_shuffle_par<2>, grid, dim3(256), 0, stream, n_pixels, partners, perms, resorted, tables, force_resort); break;
+          case 256: hipLaunchKernelGGL(k_sampler_shuffle_par<4>, grid, dim3(256), 0, stream, n_pixels, partners, perms, resorted, tables, force_resort); break;
+          case 512: hipLaunchKernelGGL(k_sampler_shuffle_par<8>, grid, dim3(256), 0, stream, n_pixels, partners, perms, resorted, tables, force_resort); break;
+          default: hipLaunchKernelGGL(k_sampler_shuffle_par<16>, grid, dim3(256), 0, stream, n_pixels, partners, perms, resorted, tables, force_resort); break;
         }
       } else hipLaunchKernelGGL(k_sampler_shuffle, dim3((n_pixels + lpb - 1) / lpb, nt), dim3(lpb), lds, stream, n_pixels, spp, partners, perms, tables);
     }
@@ -1215,7 +1226,7 @@ static int sampler_tables_host(int32_t spp_, int32_t dims, uint64_t pixel0, uint
     const unsigned lpb = sampler_lanes_per_block(spp);
     hipLaunchKernelGGL(k_sampler_tables, dim3((unsigned)((n_pixels + lpb - 1) / lpb)), dim3(lpb), (size_t)lpb * (spp + 2) * 2, nullptr, fp, (unsigned)n_pixels, spp, (unsigned)dims,
                        (unsigned long long)pixel0, 1, sc.as<unsigned>(), pm.as<unsigned short>());
-  } else if ((rc = launch_sampler_tables(plan, fp, (unsigned)n_pixels, (unsigned long long)pixel0, 1, sc.as<unsigned>(), pm.as<unsigned short>(), nullptr, false, table_groups_all((unsigned)dims), nullptr)) != RT_OK) return rc;
+  } else if ((rc = launch_sampler_tables(plan, fp, (unsigned)n_pixels, (unsigned long long)pixel0, 1, sc.as<unsigned>(), pm.as<unsigned short>(), nullptr, table_groups_all((unsigned)dims), nullptr)) != RT_OK) return rc;
   HIP_TRY(hipGetLastError());
   HIP_TRY(hipDeviceSynchronize());
   { unsigned ovf[2] = {0, 0}; HIP_TRY(hipMemcpy(ovf, plan.dirty.as<unsigned>() + 1 + RT_DIRTY_CAP, 8, hipMemcpyDeviceToHost)); if (ovf[0]) return fail(RT_ERR_INVALID, "sampler retry list overflow");
@@ -1358,10 +1369,18 @@ extern "C" int rt_render(rt_scene* s, const rt_camera* cam, const rt_film_desc* 
     if (tp_log2 - shrink < 14) return fail(RT_ERR_OOM, "not enough free device memory for the smallest pass (2^14 paths)");
     const unsigned long long target_paths = 1ull << (tp_log2 - shrink);
     batch_pixels = std::max<unsigned long long>(1, std::min<unsigned long long>(owned_pixels, std::min(1ull << bp_log2, target_paths)));  // a rank may own no rows
-    // a shard that fits one batch (e.g. 1/8 of a frame on an 8-GPU run) is still cut in two, so that the second half's sampler
-    // tables are built under the first half's path kernels; only worth it when there is enough work to hide them under
-    if (!lead_on && owned_pixels <= batch_pixels && owned_pixels >= (1ull << 15) && owned_pixels * spp >= (1ull << 27)) batch_pixels = (owned_pixels + 1) / 2;
     while (batch_pixels > 4096 && batch_pixels * table_bytes_per_pixel > (16ull << 30)) batch_pixels >>= 1;  // <= 16 GiB of tables per buffer
+    // A short LEADING batch (RTX_LEAD_BATCH; on at 1024 spp since the end of round 4): the first batch's sampler tables are the only ones no path kernel runs over, so a
+    // first batch of an eighth of the others lets the path kernels start early. Measured alone it gained nothing (the NEXT batch's tables are then built under that
+    // short batch's kernels on the low-priority stream, where they take 3 - 4x their time alone: S1 883 -> 881 ms, S3 328 -> 353); together with the parallel replay
+    // of the shuffles at 1024 spp it does (S1 679.5 -> 667.5 ms, S4 5280 -> 5242).
+    lead_pixels = 0;
+    if (lead_on && owned_pixels >= (1ull << 16) && owned_pixels * spp >= (1ull << 27)) lead_pixels = std::max<unsigned long long>(1ull << 15, (batch_pixels / 8) & ~4095ull);
+    if (lead_pixels >= owned_pixels || lead_pixels >= batch_pixels) lead_pixels = 0;
+    // a shard without a leading batch that fits one batch (a 256 x 256 window; 1/8 of a frame on an 8-GPU run) is still cut in two, so that the second half's
+    // sampler tables are built under the first half's path kernels; only worth it when there is enough work to hide them under (the rule used to test
+    // lead_on instead of lead_pixels, so 2^15 <= owned_pixels < 2^16 at 1024 spp rendered as one batch)
+    if (lead_pixels == 0 && owned_pixels <= batch_pixels && owned_pixels >= (1ull << 15) && owned_pixels * spp >= (1ull << 27)) batch_pixels = (owned_pixels + 1) / 2;
     pass_samples = (unsigned)std::max<unsigned long long>(1, target_paths / batch_pixels);
     if (pass_samples > spp) pass_samples = spp;
     chunk_pixels = batch_pixels;
@@ -1372,13 +1391,6 @@ extern "C" int rt_render(rt_scene* s, const rt_camera* cam, const rt_film_desc* 
     shard_cap = (unsigned)(cap / RT_QSHARDS) + 256u * (pgrid_q / RT_QSHARDS + 1u) + 256u;
     const size_t szq = (size_t)shard_cap * RT_QSHARDS * 4;
     n_slots = (size_t)shard_cap * RT_QSHARDS;  // slots of a sharded queue (>= cap: bounce 0 of a fully traced pass uses slot = path id)
-    // A short LEADING batch (RTX_LEAD_BATCH=1; measured in round 4, off): the first batch's sampler tables are the only ones no path kernel runs over - 28 ms of
-    // S1's frame with two equal batches - so a first batch of an eighth of the others lets the path kernels start after ~4 ms. But the NEXT batch's tables are
-    // then built under that short batch's kernels, on the low-priority stream, where they take 3 - 4x their time alone (100 ms on S1): the frame waits for them
-    // instead. S1 883 -> 881 ms, S4 6183 -> 6161, S3 328 -> 353, S2 177 -> 177 / 202.
-    lead_pixels = 0;
-    if (lead_on && owned_pixels >= (1ull << 16) && owned_pixels * spp >= (1ull << 27)) lead_pixels = std::max<unsigned long long>(1ull << 15, (batch_pixels / 8) & ~4095ull);
-    if (lead_pixels >= owned_pixels || lead_pixels >= batch_pixels) lead_pixels = 0;
     multi_batch = owned_pixels > chunk_pixels || lead_pixels > 0;
     struct Want { DevBuf* buf; size_t bytes; };
     std::vector<Want> want = {
@@ -1465,8 +1477,7 @@ extern "C" int rt_render(rt_scene* s, const rt_camera* cam, const rt_film_desc* 
   auto launch_tables = [&](size_t b, int buf) {
     FrameParams f2 = fp; f2.chunk_first = batches[b].first;
     tm.begin(&stats.ms_sampler, aux);
-    const int trc = launch_sampler_tables(s->sampler_plan, f2, (unsigned)batches[b].second, 0ull, 0, s->scrambles[buf].as<unsigned>(), s->perms[buf].as<unsigned short>(), aux, b == 0,
-                                          tgroups, s->ev_tables[buf]);
+    const int trc = launch_sampler_tables(s->sampler_plan, f2, (unsigned)batches[b].second, 0ull, 0, s->scrambles[buf].as<unsigned>(), s->perms[buf].as<unsigned short>(), aux, tgroups, s->ev_tables[buf]);
     if (trc != RT_OK && tables_rc == RT_OK) tables_rc = trc;
     tm.end(aux);
   };
@@ -1511,8 +1522,8 @@ extern "C" int rt_render(rt_scene* s, const rt_camera* cam, const rt_film_desc* 
         launch_trace<false>(s, count, io_path, ps.cnt_in, ps.cnt_in, ps.shard_cap, ps.cap, dstats, ST_RAYS_CLOSEST, ST_NODES_CLOSEST, ST_TRIS_CLOSEST, stream);
         tm.end();
         if (bounce <= 1) HIP_TRY(hipStreamWaitEvent(stream, s->ev_tables[buf][bounce + 1], 0));  // table groups 1 / 2: first read by the shade launches of bounce 0 / 1
-#define RT_SHADE(MODE, P) launch_shade<MODE>(gshade, lean_shade, bounce >= 1 && !bounced_off, sgrid, sblock, stream, s->d, fp, P, qlights)
-        if (s->lambert_only) { tm.begin(&stats.ms_shade_lambert_const); hipLaunchKernelGGL(k_shade<1>, dim3(sgrid), dim3(sblock), 0, stream, s->d, fp, ps); tm.end(); }
+#define RT_SHADE(MODE, P) stats.launches_shade += 1, launch_shade<MODE>(gshade, lean_shade, bounce >= 1 && !bounced_off, sgrid, sblock, stream, s->d, fp, P, qlights)
+        if (s->lambert_only) { tm.begin(&stats.ms_shade_lambert_const); hipLaunchKernelGGL(k_shade<1>, dim3(sgrid), dim3(sblock), 0, stream, s->d, fp, ps); tm.end(); stats.launches_shade += 1; }
         else if (s->lambert_materials) { tm.begin(&stats.ms_shade_lambert); RT_SHADE(3, ps); tm.end(); }
         else if (!use_bins) { tm.begin(&stats.ms_shade_generic); RT_SHADE(0, ps); tm.end(); }
         else {
@@ -1551,7 +1562,7 @@ extern "C" int rt_render(rt_scene* s, const rt_camera* cam, const rt_film_desc* 
         if (s->has_spheres || s->has_instances) hipLaunchKernelGGL(k_resolve<true>, dim3(pgrid), dim3(256), 0, stream, s->d, ps);  // (a hit id inside an instance is not a primitive index)
         else hipLaunchKernelGGL(k_resolve<false>, dim3(pgrid), dim3(256), 0, stream, s->d, ps);
         tm.end();
-        stats.launches_trace_closest += 2;
+        stats.launches_trace_closest += 2; stats.launches_trace_path += 1; stats.launches_trace_mis += 1; stats.launches_trace_shadow += 1; stats.launches_trace_mis_any += ps.mis_any ? 1 : 0;
       }
       tm.begin(&stats.ms_film);
       hipLaunchKernelGGL(k_film_accumulate, dim3(pgrid), dim3(256), 0, stream, fp, ps, s->filter_table.as<float>(), s->film_acc.as<float4>());
@@ -1612,6 +1623,7 @@ static void stats_add(rt_stats& a, const rt_stats& b) {
   a.ms_total += b.ms_total; a.ms_sampler += b.ms_sampler; a.ms_raygen += b.ms_raygen; a.ms_trace_closest += b.ms_trace_closest; a.ms_trace_any += b.ms_trace_any;
   a.ms_trace_mis += b.ms_trace_mis; a.ms_shade += b.ms_shade; a.ms_resolve += b.ms_resolve; a.ms_film += b.ms_film; a.ms_lightdist += b.ms_lightdist;
   a.launches_trace_closest += b.launches_trace_closest; a.n_passes += b.n_passes;
+  a.launches_trace_path += b.launches_trace_path; a.launches_trace_shadow += b.launches_trace_shadow; a.launches_trace_mis += b.launches_trace_mis; a.launches_trace_mis_any += b.launches_trace_mis_any; a.launches_shade += b.launches_shade;
   a.vertices_lambert_const += b.vertices_lambert_const; a.vertices_lambert += b.vertices_lambert; a.vertices_two_lobe += b.vertices_two_lobe; a.vertices_generic += b.vertices_generic;
   a.ms_shade_lambert_const += b.ms_shade_lambert_const; a.ms_shade_lambert += b.ms_shade_lambert; a.ms_shade_two_lobe += b.ms_shade_two_lobe;
   a.ms_shade_generic += b.ms_shade_generic; a.ms_shade_bin += b.ms_shade_bin; a.ms_shade_miss += b.ms_shade_miss;

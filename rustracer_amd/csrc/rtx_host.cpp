@@ -1159,6 +1159,19 @@ int rtxh_light_distribution(rtxh_scene* s, int32_t n_voxels[3], float* func, flo
   if (!s->dev) { int rc = rtxh_scene_upload(s, -1); if (rc != RT_OK) return rc; }
   return rt_light_distribution(s->dev, n_voxels, func, cdf, func_int);
 }
+int rtxh_scene_query(rtxh_scene* s, int32_t what) {
+  if (!s) return fail(RT_ERR_INVALID, "null scene");
+  g_err.clear();
+  if (!s->dev) { int rc = rtxh_scene_upload(s, -1); if (rc != RT_OK) return rc; }
+  return rt_scene_query(s->dev, what);
+}
+int rtxh_sizeof(const char* name) {
+  if (!name) return -1;
+#define RTXH_SZ(T) if (!strcmp(name, #T)) return (int)sizeof(T);
+  RTXH_SZ(rtxh_render_params) RTXH_SZ(rtxh_emitter_info) RTXH_SZ(rtxh_instance_info) RTXH_SZ(rtxh_light_info) RTXH_SZ(rtxh_ply) RTXH_SZ(rtxh_pbrt_result)
+#undef RTXH_SZ
+  return rt_sizeof(name);
+}
 
 
 // ---------------------------------------------------------------------------------------------- PLY / PFM readers

@@ -330,8 +330,8 @@ RT_DEV void unpack8(uint4 v, unsigned* o) {
 }
 // blockDim.x = L lanes (one wave at most), blockIdx.y = table
 // `tables`: the launch's tables, 4 bits each (blockIdx.y-th nibble): a frame builds its tables in the order it needs them (rt_render)
-__global__ void __launch_bounds__(64) k_sampler_shuffle(unsigned n_pixels, unsigned spp, const unsigned short* __restrict__ partners, unsigned short* __restrict__ perms, unsigned tables) {
-  const unsigned table = (tables >> (4u * blockIdx.y)) & 15u;
+__global__ void __launch_bounds__(64) k_sampler_shuffle(unsigned n_pixels, unsigned spp, const unsigned short* __restrict__ partners, unsigned short* __restrict__ perms, unsigned long long tables) {
+  const unsigned table = (unsigned)(tables >> (4u * blockIdx.y)) & 15u;
   extern __shared__ unsigned short lds_perm[];
   const unsigned lane = threadIdx.x, L = blockDim.x;
   const unsigned pix0 = blockIdx.x * L, pix = pix0 + lane;
@@ -399,7 +399,8 @@ __global__ void __launch_bounds__(64) k_sampler_shuffle(unsigned n_pixels, unsig
 //   chain instead of 1024. (A first version with per-target loops - insertion sort, pointer chase - took 131 ms per S1 frame: loops of dependent LDS reads.) The result goes through an LDS tile so that 16 chains leave as 32-byte runs of perms[table][sample][pixel].
 // MEASURED (S1's batches, 524 288 pixels x 8 tables, alone on the GPU): 15.4 ms against the chain kernel's 23.2 - and 4.4 ms more in k_sampler_draws for the
 // chain-major partner layout it needs; under path kernels, where a frame builds all tables but the first batch's, it costs the frame more than the chain
-// kernel does (rtx_hip.hip, launch_sampler_tables). Built as two verdicts asked, kept exact and tested, OFF by default (RTX_K0_PARALLEL=1).
+// kernel does at 64 ... 512 spp (rtx_hip.hip, launch_sampler_tables). DEFAULT: used for every batch of a 1024-spp frame (together with a short leading batch: S1 679.5 ->
+// 667.5 ms, end of round 4), not used at other sample counts; RTX_K0_PARALLEL=1 forces it on for 64 <= spp <= 1024, =0 forces the chain kernel everywhere.
 // Exact: the same permutation as the sequential replay for every partner sequence (tests: the sampler tables stay bit-equal to the oracle's, retry pixels
 // included). E = spp / 64 steps per lane: instantiated for spp 64 ... 1024; other sample counts keep k_sampler_shuffle.
 #define RT_SHUF_PIX 16
@@ -410,13 +411,13 @@ RT_DEV void wave_sync_lds() { __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgrou
 #define K0S(k) do { } while (0)
 #endif
 template <int E>
-__global__ void __launch_bounds__(256) k_sampler_shuffle_par(unsigned n_pixels, const unsigned short* __restrict__ partners, unsigned short* __restrict__ perms, unsigned* __restrict__ n_resorted, unsigned tables) {
+__global__ void __launch_bounds__(256) k_sampler_shuffle_par(unsigned n_pixels, const unsigned short* __restrict__ partners, unsigned short* __restrict__ perms, unsigned* __restrict__ n_resorted, unsigned long long tables, unsigned force_resort) {
   constexpr unsigned N = 64u * E, NONE = 0xffffu;
   __shared__ unsigned short tile[RT_SHUF_PIX][N + 2];  // (+2: rows an odd number of words apart, the transposed read-out is conflict-free)
   __shared__ unsigned short s_o[4][N];                 // per wave: R (the pointer-jumping array)
   __shared__ unsigned s_cnt[4][N / 2 + 64 + 1];        // per wave: packed 16-bit counters per target (target p at index CI(p) = p + 2 * (p / E)), then exclusive bases
   __shared__ unsigned short s_wl[4][N];                // per wave: writers grouped by target
-  const unsigned lane = threadIdx.x & 63u, wv = threadIdx.x >> 6, t = (tables >> (4u * blockIdx.y)) & 15u, pix0 = blockIdx.x * RT_SHUF_PIX;
+  const unsigned lane = threadIdx.x & 63u, wv = threadIdx.x >> 6, t = (unsigned)(tables >> (4u * blockIdx.y)) & 15u, pix0 = blockIdx.x * RT_SHUF_PIX;
   unsigned short* const o = s_o[wv]; unsigned* const cnt = s_cnt[wv]; unsigned short* const wl = s_wl[wv];
   const unsigned short* const cnt16 = (const unsigned short*)cnt;
 #ifdef RT_K0_STAMP
@@ -466,6 +467,12 @@ __global__ void __launch_bounds__(256) k_sampler_shuffle_par(unsigned n_pixels, 
     for (int m = 0; m < E; ++m) rk[m] = (pk[m] & 1u) ? (rk[m] >> 16) : (rk[m] & 0xffffu);
     wave_sync_lds();
     K0S(1);
+    if (force_resort) {  // test knob (RTX_K0_FORCE_RESORT=1): hand every group its ranks in DESCENDING order, what an atomic unit that served lanes the other way round would
+                         // return - the check below then fails for every group of two or more writers and the wave takes the re-sort branch (that branch is
+                         // "never seen" on this hardware and would otherwise never be exercised)
+#pragma unroll
+      for (int m = 0; m < E; ++m) rk[m] = (unsigned)cnt16[pk[m] + 2u * (pk[m] / (unsigned)E)] - 1u - rk[m];
+    }
     {  // exclusive scan of the counts over the targets: lane l scans its targets [l * E, (l + 1) * E) (CI skews the counters by one word per E targets, so
        // that the 64 lanes' chunks start in different banks), one wave scan joins the lanes' sums
       unsigned x[E], local[E]; unsigned sum = 0u;

@@ -587,7 +587,9 @@ struct PbrtLoader {
     if (integrator_name != "path") return fail_("Integrator \"" + integrator_name + "\" is not supported (this backend is the path integrator)");
     o.max_depth = integrator_p.one_int("maxdepth", 5); o.rr_threshold = integrator_p.one_float("rrthreshold", 1.0f);
     const std::string ls = integrator_p.one_string("lightsamplestrategy", "spatial");
-    if (ls == "spatial") o.light_strategy = 0; else if (ls == "uniform") o.light_strategy = 1; else return fail_("lightsamplestrategy \"" + ls + "\" is not supported");
+    // PathIntegrator::preprocess (path.rs:86-94) compares the string with "uniform" only: every other value - "spatial", pbrt's "power", a typo -
+    // gets the SpatialLightDistribution
+    o.light_strategy = ls == "uniform" ? 1 : 0;
     if (const std::vector<float>* pb = integrator_p.floats("pixelbounds", {"integer"})) {
       if (pb->size() == 4) { for (int k = 0; k < 4; ++k) o.pixel_bounds[k] = (int32_t)(*pb)[k]; o.has_pixel_bounds = 1; }
       else warn("pixelbounds expects 4 values");

@@ -64,7 +64,8 @@ class Stats(C.Structure):
         [(n, C.c_uint64) for n in ("launches_trace_closest", "n_passes", "vertices_lambert_const", "vertices_lambert", "vertices_two_lobe", "vertices_generic")] +
         [(n, C.c_double) for n in ("ms_shade_lambert_const", "ms_shade_lambert", "ms_shade_two_lobe", "ms_shade_generic", "ms_shade_bin", "ms_shade_miss")] +
         [("shade_section_cycles", C.c_uint64 * 32)] +
-        [(n, C.c_uint64) for n in ("rays_mis_any", "nodes_mis_any", "tris_mis_any")] + [("ms_trace_mis_any", C.c_double), ("ms_gather", C.c_double), ("rays_mis_not_cast", C.c_uint64), ("rays_tail_not_cast", C.c_uint64)])
+        [(n, C.c_uint64) for n in ("rays_mis_any", "nodes_mis_any", "tris_mis_any")] + [("ms_trace_mis_any", C.c_double), ("ms_gather", C.c_double), ("rays_mis_not_cast", C.c_uint64), ("rays_tail_not_cast", C.c_uint64)] +
+        [(n, C.c_uint64) for n in ("launches_trace_path", "launches_trace_shadow", "launches_trace_mis", "launches_trace_mis_any", "launches_shade")])
 
     def as_dict(self):
         return {n: (list(getattr(self, n)) if n == "shade_section_cycles" else getattr(self, n)) for n, _ in self._fields_}
@@ -87,6 +88,12 @@ def lib():
         L.rtxh_last_error.restype = C.c_char_p
         _hip.rt_last_error.restype = C.c_char_p
         _hip.rt_version.restype = C.c_char_p
+        # the mirrors below are positional: a stale library (or a stale mirror) must not be used at all
+        for name, mirror in (("rt_stats", Stats), ("rtxh_render_params", RenderParams), ("rtxh_pbrt_result", PbrtResult)):
+            n = L.rtxh_sizeof(name.encode())
+            if n != C.sizeof(mirror):
+                _lib = _hip = None
+                raise BackendError(f"{HOST_LIB}: sizeof({name}) = {n}, the ctypes mirror {mirror.__name__} has {C.sizeof(mirror)} bytes - rebuild (make -C rustracer_amd/csrc)")
     return _lib
 
 
@@ -235,9 +242,9 @@ class HostScene:
         return nn.value, npr.value
 
     def lds_resident(self):
-        """Does the traversal kernel keep this scene's nodes and primitives in LDS (rt_scene_create: RT_SMALL_NODES = 256, RT_SMALL_TRIS = 128, no object instances)?"""
-        nn, npr = self.bvh_sizes()
-        return nn <= 256 and npr <= 128 and not getattr(self.desc, "instances", None)
+        """Does the traversal kernel keep this scene's nodes and primitives in LDS? Asked of the uploaded scene (rt_scene_query: what rt_scene_create decided,
+        the RTX_SMALL knob included), not re-derived here."""
+        return bool(_check(lib().rtxh_scene_query(self.h, 0), "scene_query"))
 
     def _render_params(self, **kw):
         return render_params(self.desc, **kw)

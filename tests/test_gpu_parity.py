@@ -161,6 +161,54 @@ def test_sampler_segmented_equals_plain_over_a_large_range(gpu_host):
         assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1]), spp
 
 
+@pytest.mark.parametrize("dims", [2, 5, 8])
+def test_sampler_tables_of_other_dimension_counts(gpu_host, orc, dims):
+    """ "dimensions" other than 4 (zerotwosequence.rs:58-63; the C ABI takes 2 ... 8): 2 * dims tables per pixel, up to 16 - ADVICE r04: the launch's table ids were
+    packed four bits each into 32 bits, so for dims >= 5 some tables were never shuffled and others twice. Segmented == plain == the oracle, both shuffle kernels."""
+    for spp, n in ((64, 130), (1024, 40), (16, 300)):   # (64, 1024: the parallel replay; 16: the chain kernel)
+        a = gpu_host.sampler_tables(spp, dims, 777, n)
+        b = gpu_host.sampler_tables(spp, dims, 777, n, plain=True)
+        assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1]), (dims, spp)
+        for t in range(2 * dims):
+            assert sorted(a[1][0, t].tolist()) == list(range(a[1].shape[2])), (dims, spp, t)   # every table is a permutation: none skipped, none shuffled twice
+        for i in (0, n - 1):
+            t1, t2 = tables_from_perm(a[0][i], a[1][i], dims)
+            o1, o2, _ = orc.sampler_tables(spp, dims, 1, 777 + i)
+            assert np.array_equal(bits(t1), bits(o1)) and np.array_equal(bits(t2), bits(o2)), (dims, spp, i)
+
+
+@pytest.mark.parametrize("dims", [2, 8])
+def test_frame_with_other_dimension_counts_matches_oracle(gpu_host, orc, dims):
+    """A whole frame at "dimensions" 2 / 8: the frame's table groups (which tables bounce 0 / 1 / later read) at the extremes."""
+    d = _cornell(24, 24, 16)
+    d.sampler.dims = dims
+    film, st = gpu_host.HostScene(d).render()
+    ref, ost = orc.OracleScene(d).render(mode=1)
+    assert np.array_equal(film[..., 3], ref[..., 3])
+    assert rel_l2(gpu_host.film_to_rgb(film), orc.film_to_rgb(ref)) < L2_GATE
+    assert st["camera_rays"] == 24 * 24 * 16
+
+
+def test_parallel_replay_survives_an_atomic_unit_that_serves_lanes_in_another_order(gpu_host, capfd):
+    """k_sampler_shuffle_par reads a writer's rank inside its group off an LDS atomic's return value and CHECKS that the groups came out ascending - lane order
+    within one atomic instruction is not architected. RTX_K0_FORCE_RESORT=1 hands every group its ranks reversed: every wave must notice, re-sort, and still produce
+    the sequential replay's tables (the fallback was 'never seen', so never run)."""
+    import re
+    os.environ["RTX_K0_FORCE_RESORT"] = "1"
+    os.environ["RTX_K0_REPORT"] = "1"
+    try:
+        capfd.readouterr()
+        a = gpu_host.sampler_tables(1024, 4, 8900, 70)   # (1024 spp uses the parallel replay by default; pixel 8933 holds a retry)
+        err = capfd.readouterr().err
+        m = re.search(r"k_sampler_shuffle_par: (\d+) wave", err)
+        assert m and int(m.group(1)) >= 70 * 8 // 16, err[-300:]   # every workgroup's waves took the re-sort branch
+    finally:
+        del os.environ["RTX_K0_FORCE_RESORT"]
+        del os.environ["RTX_K0_REPORT"]
+    b = gpu_host.sampler_tables(1024, 4, 8900, 70, plain=True)
+    assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1])
+
+
 def test_light_distribution_matches_oracle_and_golden(gpu_host, orc, gold):
     d = _cornell(8, 8, 1)
     ldh = gpu_host.HostScene(d).light_distribution()
@@ -345,9 +393,10 @@ def test_multi_device_wide_filter_rows_are_summed(gpu_host):
 
 
 def test_parallel_replay_of_the_shuffle_is_exact():
-    """k_sampler_shuffle_par (RTX_K0_PARALLEL=1; built in round 4, off by default - see rtx_hip.hip) replays a Fisher-Yates chain with one wave instead of one
-    lane. The knob is read once per process, so the sampler parity tests of this file run again in a child process with it set: tables bit-equal to the
-    oracle's (spp 64 and 1024), to the single-kernel in-order walk (64 ... 1024 spp, odd pixel counts, ragged workgroups) and on the retry pixels."""
+    """k_sampler_shuffle_par replays a Fisher-Yates chain with one wave instead of one lane. By default it serves 1024-spp frames only (rtx_hip.hip,
+    launch_sampler_tables); RTX_K0_PARALLEL=1 turns it on for 64 <= spp <= 1024. The knob is read once per process, so the sampler parity tests of this file run
+    again in a child process with it set: tables bit-equal to the oracle's (spp 64 and 1024), to the single-kernel in-order walk (64 ... 1024 spp, odd pixel
+    counts, ragged workgroups) and on the retry pixels - and every wave's groups came out sorted (the re-sort branch has its own test above)."""
     import subprocess, sys
     env = dict(os.environ, RTX_K0_PARALLEL="1", RTX_K0_REPORT="1")
     r = subprocess.run([sys.executable, "-m", "pytest", os.path.abspath(__file__), "-x", "-q", "-m", "gpu", "-s", "-k",

@@ -252,6 +252,13 @@ def test_defaults_of_every_create():
     assert p.n_lights() == 0 and p.n_warnings == 0
 
 
+@pytest.mark.parametrize("name, strategy", [("uniform", 1), ("spatial", 0), ("power", 0), ("anything-else", 0)])
+def test_every_light_sample_strategy_but_uniform_is_spatial(name, strategy):
+    # PathIntegrator::preprocess (path.rs:86-94) compares the string with "uniform" only; pbrt scene files carry "power"
+    p = _parse(f'Integrator "path" "string lightsamplestrategy" "{name}"\n' + HEADER + "WorldBegin\n" + TRI + "WorldEnd\n")
+    assert p.params.light_strategy == strategy and p.n_warnings == 0
+
+
 def test_halton_default_sampler_is_an_error_like_the_reference():
     with pytest.raises(host.BackendError, match='Sampler "halton" unknown'):   # api.rs:285 default + :205-215
         _parse("WorldBegin\n" + TRI + "WorldEnd\n")
