@@ -50,41 +50,82 @@ def _free_port():
     return p
 
 
-def _worker(rank, world, port, q):
+CASES = {
+    # name: (cropped x0 y0 x1 y1, sample bounds x0 y0 x1 y1, filter radius y)
+    "box-70-rows": ((0, 0, 40, 70), (0, 0, 40, 70), 0.5),          # 5 tile rows: bands of 8 rows for every world that does not divide 5
+    "wide-filter-cropped": ((3, 10, 43, 90), (1, 8, 45, 92), 2.0),  # Film::get_sample_bounds grows the cropped window by the radius (film.rs:249-257): rows nobody owns inside the film
+    "triangle-1080": ((0, 0, 8, 1080), (0, -1, 8, 1081), 1.5),      # C5's height: 68 tile rows -> 8-row bands on 8 ranks (RT_SHARD_ROWS)
+}
+
+
+def _rank_film(case, rank, world, edge=True):
+    """What rank `rank` renders of a synthetic frame: every sample row y it owns splats a row pattern f(y, dy) into the film rows within the filter's reach
+    (FilmTile::add_sample, film.rs:303-321), plus - under the box filter - one sample exactly on its first row's upper edge, which lands in the row above."""
+    from rustracer_amd.distributed import owned_sample_rows
+    (cx0, cy0, cx1, cy1), (sx0, sy0, sx1, sy1), radius = CASES[case]
+    h, w = cy1 - cy0, cx1 - cx0
+    film = np.zeros((h, w, 4), np.float32)
+    reach = int(np.ceil(radius - 0.5))
+    rng = np.random.default_rng(1234)
+    pattern = rng.uniform(0.1, 4.0, (sy1 - sy0, 2 * reach + 1, w, 4)).astype(np.float32)  # the same on every rank
+    rows = owned_sample_rows(sy0, sy1, rank, world)
+    for y in rows:
+        for dy in range(-reach, reach + 1):
+            r = y + dy - cy0
+            if 0 <= r < h:
+                film[r] += pattern[y - sy0, dy + reach]
+    if edge and len(rows) and 0 <= rows[0] - 1 - cy0 < h:
+        film[rows[0] - 1 - cy0] += np.float32(0.25)  # a sample exactly on a pixel edge (film.rs:313-321): one row beyond the filter's nominal reach
+    return film
+
+
+def _worker(rank, world, port, q, case):
     import torch
     import torch.distributed as dist
-    from rustracer_amd.distributed import merge_film, owned_pixel_mask, owned_sample_rows
+    from rustracer_amd.distributed import merge_film, touched_rows
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
-        rng = np.random.default_rng(0)  # same "full frame" on every rank
-        full = rng.uniform(0, 4, (70, 40, 4)).astype(np.float32)
-        mask = owned_pixel_mask((0, 0, 40, 70), (0, 0, 40, 70), rank, world)
-        mine = np.where(mask[..., None], full, np.float32(0))
-        edge = int(owned_sample_rows(0, 70, 1, world)[0]) - 1  # the row above rank 1's first band: rank 0's (70 rows on 2 ranks: 5 tile rows do not divide, bands of 8)
-        if rank == 1:
-            mine[edge] = np.float32(0.25)  # a sample of rank 1 that sat exactly on the edge of its first row splats into the row above, which rank 0 owns
+        cropped, sb, radius = CASES[case]
+        mine = _rank_film(case, rank, world)
+        t = touched_rows(cropped, sb, rank, world, radius)
+        untouched = np.setdiff1d(np.arange(mine.shape[0]), t)
+        ok = not mine[untouched].any()  # the gather's premise: a rank writes nothing outside the rows it reports as touched
         mine = torch.from_numpy(mine)
-        merge_film(mine, dst=0)
+        merge_film(mine, dst=0, cropped=cropped, sample_bounds=sb, filter_radius_y=radius)
         dist.barrier()
         if rank == 0:
-            want = full.copy()
-            want[edge] += np.float32(0.25)
-            q.put(bool(np.array_equal(mine.numpy().view(np.uint32), want.view(np.uint32))))
+            want = _rank_film(case, 0, world)
+            parts = _rank_film(case, 0, world, edge=False)
+            for r in range(1, world):  # rank 0 adds the others' rows in rank order: bit-equal to this sum
+                want = want + _rank_film(case, r, world)
+                parts = parts + _rank_film(case, r, world, edge=False)
+            whole = _rank_film(case, 0, 1, edge=False)   # the frame one rank renders: every sample row exactly once, up to the order of the additions
+            q.put((0, ok, bool(np.array_equal(mine.numpy().view(np.uint32), want.view(np.uint32))), bool(np.allclose(parts, whole, rtol=1e-6, atol=0))))
+        else:
+            q.put((rank, ok, True, True))
     finally:
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world", [2])
-def test_film_merge_over_gloo_gathers_the_touched_rows(world):
+@pytest.mark.parametrize("world, case", [(2, "box-70-rows"), (3, "box-70-rows"), (8, "box-70-rows"), (2, "wide-filter-cropped"), (3, "wide-filter-cropped"),
+                                         (8, "wide-filter-cropped"), (8, "triangle-1080")])
+def test_film_merge_over_gloo_gathers_the_touched_rows(world, case):
+    """The N > 1 data path on CPU (gloo): worlds 2, 3 and 8 - a world that divides the tile rows and ones that do not (8-row bands) -, the box filter, a wide
+    filter on a cropped film, C5's 1080 rows on 8 ranks. Rank 0's merged film equals the rank films summed in rank order bit for bit, and the whole frame
+    rendered by one rank up to the order of additions."""
     import torch.multiprocessing as mp
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(r, world, port, q)) for r in range(world)]
+    procs = [ctx.Process(target=_worker, args=(r, world, port, q, case)) for r in range(world)]
     for p in procs:
         p.start()
     for p in procs:
-        p.join(120)
+        p.join(180)
         assert p.exitcode == 0
-    assert q.get(timeout=10) is True
+    results = sorted(q.get(timeout=30) for _ in range(world))
+    assert [r[0] for r in results] == list(range(world))
+    assert all(r[1] for r in results), "a rank wrote outside the rows it reports as touched"
+    assert results[0][2], "rank 0's merged film is not the rank films summed in rank order"
+    assert results[0][3], "the shards do not add up to the whole frame"
