@@ -254,7 +254,11 @@ class Runner:
             return st
         from rustracer_amd.distributed import merge_film
         _, st = self.scene.render(rank=self.rank, world_size=self.world, time_kernels=timed, device_out=self.film, stream=self.stream)
+        t0 = time.perf_counter()
         merge_film(self.film, dst=0, cropped=self.cr, sample_bounds=self.sb, filter_radius_y=self.radius_y)  # end-of-frame gather of the touched rows (no-op at N = 1)
+        if self.dist is not None:  # this rank's share of the gather: its send (or, on rank 0, the receives and the additions) done
+            self.torch.cuda.synchronize()
+            st["ms_gather"] = (time.perf_counter() - t0) * 1e3
         return st
 
     def count(self):
@@ -271,8 +275,13 @@ def run_workload(scene_name, runner, workload, steps, warmup):
     import numpy as np
     import torch
     rank, world, dist = runner.rank, runner.world, runner.dist
-    for _ in range(warmup):
-        runner.step(False)
+    # integrator.preprocess runs inside renderer::render (rc/renderer.rs:30); rt_render builds the light-distribution tables in the FIRST frame of a scene and keeps
+    # them, so the timed frames (after a warm-up) do not contain it: the first frame's build time is reported beside them (config.light_distribution)
+    lightdist_first_ms = None
+    for k in range(warmup):
+        st = runner.step(k == 0)
+        if k == 0:
+            lightdist_first_ms = st.get("ms_lightdist")
     kstats = []
     clocks = ClockSampler()
     clocks.sample()  # (before the opening barrier: the sysfs reads are outside the timed region)
@@ -326,7 +335,11 @@ def run_workload(scene_name, runner, workload, steps, warmup):
     ms_step = dt / steps * 1e3
     value = samples_per_step * steps / dt / 1e6
     n_gpus = n_active  # devices that traced camera rays in the last timed frame
-    launches = kstats[-1]["launches_trace_closest"] // (n_gpus_asked if runner.mode == "multi" else 1)
+    ldiv = n_gpus_asked if runner.mode == "multi" else 1
+    launches_path = kstats[-1]["launches_trace_path"] // ldiv   # per-stage launch counts as rt_render issued them (rt_stats, round 5; round 4 derived them as launches_trace_closest // 2)
+    launches_shade = kstats[-1]["launches_shade"] // ldiv
+    if lightdist_first_ms is None:  # no warm-up: the first timed frame built the tables, its time is inside the timed region
+        lightdist_first_ms = kstats[0].get("ms_lightdist")
 
     # SURVEY §8d bytes of the three ray classes, each divided by the time of ITS launches. The counting frame walks what the timed frames walk
     # (RT_FLAG_COUNT_AS_RENDERED): path rays and MIS rays toward area lights closest-hit, shadow rays and MIS rays toward the environment any-hit.
@@ -358,7 +371,7 @@ def run_workload(scene_name, runner, workload, steps, warmup):
             return None
         n = cst["camera_rays"] / nd_div
         return {"hbm_frac": round(bps * n / (ms * 1e-3) / 8e12, 4), "hbm_frac_raw_reads": round(e.get("hbm_bytes_per_camera_sample_raw", 0.0) * n / (ms * 1e-3) / 8e12, 4),
-                "hbm_GB": round(bps * n / 1e9, 2), "ms": round(ms, 3), "stale": bool(prov and prov.get("stale"))}
+                "hbm_GB": round(bps * n / 1e9, 2), "ms": round(ms, 3), "bytes_from": "stored profile (profiles/pmc_%s.json), not this run" % scene_name, "stale": bool(prov and prov.get("stale"))}
     groups = {"closest_hit_kernels": hbm_frac("trace_closest_all", ms_mean["ms_trace_closest"] + ms_mean["ms_trace_mis"] - ms_mis_any),
               "any_hit_kernels": hbm_frac("trace_any_all", ms_mean["ms_trace_any"] + ms_mis_any)}
     ms_tc = ms_mean["ms_trace_closest"]
@@ -373,13 +386,13 @@ def run_workload(scene_name, runner, workload, steps, warmup):
     def trace_roofline():
         c = classes["path_closest"]
         if lds_scene:
-            return 48 * c["rays"], launches // 2, ms_tc, "trace_closest", c["rays"], "ray"
-        return c["algorithmic_bytes"], launches // 2, ms_tc, "trace_closest", c["rays"], "ray"
+            return 48 * c["rays"], launches_path, ms_tc, "trace_closest", c["rays"], "ray"
+        return c["algorithmic_bytes"], launches_path, ms_tc, "trace_closest", c["rays"], "ray"
 
     def shade_roofline():
         verts = (cst["rays_closest"] - tail_nc) / nd_div
         emitted = (cst["rays_shadow"] + cst["rays_mis"] - not_cast + (cst["rays_closest"] - tail_nc - cst["camera_rays"])) / nd_div
-        return 128 * verts + 32 * emitted + 48 * cst["camera_rays"] / nd_div, launches // 2, ms_sh, "shade", verts, "vertex"
+        return 128 * verts + 32 * emitted + 48 * cst["camera_rays"] / nd_div, launches_shade, ms_sh, "shade", verts, "vertex"
 
     def roof(algo_bytes, n_launch, ms_kernel, kname, unit_n, unit):
         achieved = algo_bytes / (ms_kernel * 1e-3) / 1e9  # GB/s per device
@@ -405,7 +418,9 @@ def run_workload(scene_name, runner, workload, steps, warmup):
     out = {
         "metric": "Msamples/s", "value": round(value, 2), "unit": "Msamples/s", "n_gpus": n_gpus, "steps": steps, "warmup": warmup,
         "ms_per_step": round(ms_step, 2), "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-        "config": {"workload": workload, "sharding": sharding, "sampler_mode": "pixel-keyed"},
+        "config": {"workload": workload, "sharding": sharding, "sampler_mode": "pixel-keyed",
+                   "light_distribution": ("cached across frames; first-frame build %.1f ms%s" % (lightdist_first_ms, "" if warmup else " (inside the first timed frame)")) if lightdist_first_ms is not None else "cached across frames"},
+        "lightdist_ms_first_frame": lightdist_first_ms,
         "s_per_frame": round(ms_step / 1e3, 4),
         "Mrays_per_s": round((cst["rays_closest"] + cst["rays_shadow"] + cst["rays_mis"] - not_cast - tail_nc) / (ms_step * 1e-3) / 1e6, 1),
         "mis_rays_not_cast": int(not_cast), "tail_rays_not_cast": int(tail_nc),
@@ -417,8 +432,8 @@ def run_workload(scene_name, runner, workload, steps, warmup):
         out["n_gpus_requested"] = n_gpus_asked
         out["per_device_ms"] = per_rank_ms
         out["imbalance_max_over_mean"] = round(max(per_rank_ms) / max(float(np.mean(per_rank_ms)), 1e-9), 3)
+        out["gather_ms"] = round(ms_mean.get("ms_gather", 0.0), 3)  # multi: last device done -> merged frame in place; dist: the slowest rank's share of the RCCL gather (rank 0: receives + additions)
         if runner.mode == "multi":
-            out["gather_ms"] = round(ms_mean.get("ms_gather", 0.0), 3)
             out["devices"] = [int(d) for d in runner.devices]
         else:
             out["rccl_world_size"] = world
@@ -445,7 +460,7 @@ def compact_line(full):
     """The ONE line bench.py prints: BASELINE's metric, `roofline` of the dominant kernel, `cpu_baseline`, and per other workload the six numbers that say
     where it stands. Everything else a run measures (per-class traversal rates, stage times, register tables, provenance) is in the detail file."""
     out = {k: full[k] for k in TOP_KEYS if k in full}
-    out["config"] = {k: v for k, v in full["config"].items() if k in ("workload", "sharding", "sampler_mode")}
+    out["config"] = {k: v for k, v in full["config"].items() if k in ("workload", "sharding", "sampler_mode", "light_distribution")}
     out["roofline"] = _roof(full["roofline"])
     r2 = full.get("roofline_second_kernel")
     if r2:  # the runner-up of the two heavy stages, in four numbers

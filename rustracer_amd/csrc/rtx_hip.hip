@@ -1633,6 +1633,9 @@ static void stats_add(rt_stats& a, const rt_stats& b) {
 struct rt_multi {
   std::vector<int> devices; std::vector<rt_scene*> replicas; std::vector<hipStream_t> streams; std::vector<DevBuf*> chunk_film;
   DevBuf acc; std::vector<DevBuf*> staging;  // on devices[0]: the frame, and one buffer of rows per chunk
+  hipStream_t add_stream = nullptr;          // on devices[0]: the additions into the frame, in chunk order, each behind its chunk's copy event only
+  std::vector<hipEvent_t> chunk_done;        // per chunk: its rows have arrived in staging (recorded on the worker's stream, on the worker's device)
+  std::vector<int> chunk_done_dev;
   std::string warnings;  // conditions that do not fail a call but are worth a line (left in rt_last_error by rt_multi_create)
   ~rt_multi() {
     for (size_t i = 0; i < replicas.size(); ++i) {
@@ -1641,7 +1644,9 @@ struct rt_multi {
       if (i < chunk_film.size()) delete chunk_film[i];
       if (replicas[i]) rt_scene_destroy(replicas[i]);
     }
+    for (size_t c = 0; c < chunk_done.size(); ++c) { (void)hipSetDevice(chunk_done_dev[c]); (void)hipEventDestroy(chunk_done[c]); }
     if (!devices.empty()) (void)hipSetDevice(devices[0]);
+    if (add_stream) (void)hipStreamDestroy(add_stream);
     for (DevBuf* b : staging) delete b;
   }
 };
@@ -1706,44 +1711,63 @@ extern "C" int rt_multi_render(rt_multi* m, const rt_camera* cam, const rt_film_
     size_t rows = 0; for (auto& b : chunk_bands[c]) rows += (size_t)(b.second - b.first);
     HIP_TRY(m->staging[c]->ensure(std::max<size_t>(rows * cw * 16, 16)));
   }
+  if (!m->add_stream) HIP_TRY(hipStreamCreateWithFlags(&m->add_stream, hipStreamNonBlocking));
   std::atomic<int> next{0}; std::mutex err_mtx; int first_rc = RT_OK; std::string first_err;
   std::vector<rt_stats> dev_stats(n_dev, rt_stats{});
+  // Film::merge_film_tile without a mutex and without a barrier: chunk c's rows are added into the frame on devices[0] by a stream of their own (not the null
+  // stream: round 4 added everything there after the LAST device had finished) that waits for chunk c's copy event only - so a chunk's addition runs while the
+  // other devices still trace. The additions are ISSUED in chunk order by this thread (a pixel two chunks touched - a filter wider than a pixel, a sample exactly
+  // on an edge - sums in a fixed order, whatever order the devices finish in); chunk_state[c]: 0 not yet, 1 rows on their way (event recorded), -1 failed.
+  std::vector<std::atomic<int>> chunk_state(n_chunks);
+  for (auto& a : chunk_state) a.store(0);
+  while ((int)m->chunk_done.size() < n_chunks) { m->chunk_done.push_back(nullptr); m->chunk_done_dev.push_back(-1); }
   auto worker = [&](int k) {
     auto bail = [&](int rc, const std::string& msg) { std::lock_guard<std::mutex> g(err_mtx); if (first_rc == RT_OK) { first_rc = rc; first_err = msg; } };
-    if (hipSetDevice(m->devices[k]) != hipSuccess || m->chunk_film[k]->ensure(frame_bytes) != hipSuccess) { bail(RT_ERR_HIP, "device set-up failed"); return; }
+    if (hipSetDevice(m->devices[k]) != hipSuccess || m->chunk_film[k]->ensure(frame_bytes) != hipSuccess) bail(RT_ERR_HIP, "device set-up failed");
     for (;;) {  // the tile queue of renderer.rs:68-71, in chunks
       const int c = next.fetch_add(1);
       if (c >= n_chunks) break;
-      { std::lock_guard<std::mutex> g(err_mtx); if (first_rc != RT_OK) break; }
+      bool failed; { std::lock_guard<std::mutex> g(err_mtx); failed = first_rc != RT_OK; }
+      if (failed) { chunk_state[c].store(-1); continue; }  // (every chunk's state is set, so the issuing thread never waits for a chunk nobody renders)
       const rt_shard sh{c, n_chunks}; rt_stats st{};
       const int rc = rt_render(m->replicas[k], cam, film, smp, path, &sh, (flags & ~RT_FLAG_FILM_ON_DEVICE) | RT_FLAG_FILM_ON_DEVICE, m->streams[k], m->chunk_film[k]->as<float>(), &st);
-      if (rc != RT_OK) { bail(rc, g_err); break; }
-      size_t off = 0;
+      if (rc != RT_OK) { bail(rc, g_err); chunk_state[c].store(-1); continue; }
+      size_t off = 0; bool ok = true;
       for (auto& b : chunk_bands[c]) {
         const size_t bytes = (size_t)(b.second - b.first) * cw * 16;
-        if (hipMemcpyPeerAsync((char*)m->staging[c]->p + off, m->devices[0], m->chunk_film[k]->as<char>() + (size_t)b.first * cw * 16, m->devices[k], bytes, m->streams[k]) != hipSuccess) { bail(RT_ERR_HIP, "peer copy failed"); break; }
+        if (hipMemcpyPeerAsync((char*)m->staging[c]->p + off, m->devices[0], m->chunk_film[k]->as<char>() + (size_t)b.first * cw * 16, m->devices[k], bytes, m->streams[k]) != hipSuccess) { ok = false; break; }
         off += bytes;
       }
-      if (hipStreamSynchronize(m->streams[k]) != hipSuccess) { bail(RT_ERR_HIP, "peer copy failed"); break; }
+      if (ok && (m->chunk_done[c] == nullptr || m->chunk_done_dev[c] != m->devices[k])) {  // an event lives on the device it was created on: chunk c's on the device that renders it this frame
+        if (m->chunk_done[c]) { (void)hipSetDevice(m->chunk_done_dev[c]); (void)hipEventDestroy(m->chunk_done[c]); (void)hipSetDevice(m->devices[k]); m->chunk_done[c] = nullptr; }
+        ok = hipEventCreateWithFlags(&m->chunk_done[c], hipEventDisableTiming) == hipSuccess; m->chunk_done_dev[c] = m->devices[k];
+      }
+      if (ok) ok = hipEventRecord(m->chunk_done[c], m->streams[k]) == hipSuccess;
+      if (!ok) { bail(RT_ERR_HIP, "peer copy failed"); chunk_state[c].store(-1); continue; }
+      chunk_state[c].store(1);  // (the next chunk's kernels on this stream are ordered behind the copies: chunk_film[k] is not overwritten under them)
       stats_add(dev_stats[k], st);
     }
+    if (hipStreamSynchronize(m->streams[k]) != hipSuccess) bail(RT_ERR_HIP, "peer copy failed");
   };
   std::vector<std::thread> threads;
   for (int k = 0; k < n_dev; ++k) threads.emplace_back(worker, k);
-  for (auto& t : threads) t.join();
-  if (first_rc != RT_OK) return fail(first_rc, first_err);
-  const auto t_gather = std::chrono::steady_clock::now();
-  // Film::merge_film_tile on the first device: every chunk's rows are added into the frame, in chunk order (a pixel two chunks touched - a filter
-  // wider than a pixel, or a sample exactly on an edge - then sums in a fixed order)
-  HIP_TRY(hipSetDevice(m->devices[0]));
+  bool add_failed = hipSetDevice(m->devices[0]) != hipSuccess;  // (no early return while the workers run)
   for (int c = 0; c < n_chunks; ++c) {
+    int stt; while ((stt = chunk_state[c].load()) == 0) std::this_thread::sleep_for(std::chrono::microseconds(50));
+    if (stt < 0 || add_failed) continue;
+    if (hipStreamWaitEvent(m->add_stream, m->chunk_done[c], 0) != hipSuccess) { add_failed = true; continue; }
     size_t off = 0;
     for (auto& b : chunk_bands[c]) {
       const unsigned long long n = (unsigned long long)(b.second - b.first) * cw;
-      hipLaunchKernelGGL(k_film_add, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, nullptr, m->acc.as<float4>() + (size_t)b.first * cw, (const float4*)((char*)m->staging[c]->p + off), n);
+      hipLaunchKernelGGL(k_film_add, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, m->add_stream, m->acc.as<float4>() + (size_t)b.first * cw, (const float4*)((char*)m->staging[c]->p + off), n);
       off += n * 16;
     }
   }
+  for (auto& t : threads) t.join();
+  const auto t_gather = std::chrono::steady_clock::now();  // the last device has finished (its rows are in staging): what is left is the tail of the additions
+  if (first_rc != RT_OK) { (void)hipStreamSynchronize(m->add_stream); return fail(first_rc, first_err); }
+  if (add_failed) return fail(RT_ERR_HIP, "waiting for a chunk's rows failed");
+  HIP_TRY(hipStreamSynchronize(m->add_stream));
   HIP_TRY(hipGetLastError());
   HIP_TRY(hipMemcpy(film_xyzw, m->acc.p, frame_bytes, (flags & RT_FLAG_FILM_ON_DEVICE) ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost));
   if (per_device) for (int k = 0; k < n_dev; ++k) per_device[k] = dev_stats[k];

@@ -102,5 +102,48 @@ except Exception:
     pass
 out['trace_closest_all'] = per_sample(['rtx::k_trace<false, false', 'rtx::k_trace_pair<false', 'rtx::k_trace_top<false'])  # k_trace_big is the visit-counting frame's kernel: not a timed launch
 out['trace_any_all'] = per_sample(['rtx::k_trace<true, false', 'rtx::k_trace_pair<true', 'rtx::k_trace_top<true', 'rtx::k_trace_quad'])  # (<ANY, COUNT = false, ...>: the counting frame's kernels are not timed launches)
+
+# Per shade front-end: HBM bytes per VERTEX of the class the form serves ("kernel: k_shade" hid which form wastes the bytes). Vertex counts by
+# front-end class come from the PMC run's own detail file; the plain and BOUNCED / LEAN / QLIGHTS forms of one front-end share its count.
+verts = {}
+try:
+    verts = json.load(open(os.path.join(base, 'fetch_detail.json'))).get('vertices_by_shade_front_end') or {}
+except Exception:
+    pass
+CLASS_OF = {'1': 'lambert_const', '3': 'lambert', '5': 'two_lobe', '6': 'two_lobe', '0': 'generic'}
+forms = collections.defaultdict(lambda: [0.0, 0.0, 0, []])
+for r in rows:
+    if r[0].startswith('rtx::k_shade<'):
+        cls = CLASS_OF.get(r[0][len('rtx::k_shade<')], None)
+        if cls:
+            f = forms[cls]; f[0] += r[4] * r[1]; f[1] += r[5] * r[1]; f[2] += r[1]; f[3].append(r[0])
+out['shade_by_front_end'] = {cls: {'kernels': sorted(f[3]), 'launches': f[2], 'hbm_bytes': round(f[0]), 'hbm_bytes_raw_reads': round(f[1]), 'vertices': verts.get(cls),
+                                   'hbm_bytes_per_vertex': round(f[0] / verts[cls], 1) if verts.get(cls) else None,
+                                   'hbm_bytes_per_vertex_raw_reads': round(f[1] / verts[cls], 1) if verts.get(cls) else None} for cls, f in forms.items()}
 json.dump(out, open(os.path.join('profiles', f'pmc_{scene}.json'), 'w'), indent=1)
+
+# The SQ pass, summarised per kernel next to the traffic files and under the same kernel_source_sha (the r04 SQ summaries predated the final kernels)
+sq_files = glob.glob(os.path.join(base, 'sq', '*', '*_counter_collection.csv'))
+if sq_files:
+    agg = collections.defaultdict(lambda: collections.defaultdict(float)); disp = collections.Counter()
+    for r in csv.DictReader(open(max(sq_files, key=os.path.getmtime))):
+        k = r['Kernel_Name'].split('(')[0].replace('void ', '')
+        if k.startswith('__amd'):
+            continue
+        agg[k][r['Counter_Name']] += float(r['Counter_Value']); disp[(k, r['Counter_Name'])] += 1
+    unit_of = {'rtx::k_shade<1': ('lambert_const', 'vertex'), 'rtx::k_shade<3': ('lambert', 'vertex'), 'rtx::k_shade<5': ('two_lobe', 'vertex'), 'rtx::k_shade<6': ('two_lobe', 'vertex'),
+               'rtx::k_shade<0': ('generic', 'vertex')}
+    with open(os.path.join('profiles', f'{tag}_{scene}_pmc_sq.txt'), 'w') as f:
+        f.write(f'# rocprofv3 --pmc SQ_* (one pass, scripts/profile_round.sh {tag} {scene}); kernel_source_sha {source_sha()}; sums over all dispatches of the run\n')
+        f.write('# lanes = SQ_THREAD_CYCLES_VALU / SQ_INSTS_VALU (active lanes per VALU instruction, of 64); wait = SQ_WAIT_ANY / SQ_WAVE_CYCLES; issue = SQ_ACTIVE_INST_ANY / SQ_WAVE_CYCLES (x waves per SIMD = share of cycles a SIMD issues);\n')
+        f.write('# valu_per_unit = SQ_INSTS_VALU (wave instructions) x 64 / units = VALU lane-slots per vertex (shade kernels; units from the run\'s vertices_by_shade_front_end)\n')
+        for k, v in sorted(agg.items()):
+            iv, tc, wc = v.get('SQ_INSTS_VALU', 0.0), v.get('SQ_THREAD_CYCLES_VALU', 0.0), v.get('SQ_WAVE_CYCLES', 0.0)
+            extra = ''
+            for pre, (cls, unit) in unit_of.items():
+                if k.startswith(pre) and verts.get(cls):
+                    extra = f' valu_per_{unit}={iv * 64.0 / verts[cls]:.0f}'
+            f.write(f"{k} dispatches={max(disp[(k, c)] for c in v)} lanes={tc / iv if iv else 0:.1f} wait={v.get('SQ_WAIT_ANY', 0.0) / wc if wc else 0:.3f} "
+                    f"issue={v.get('SQ_ACTIVE_INST_ANY', 0.0) / wc if wc else 0:.3f}{extra} " + ' '.join(f'{a}={b:.4g}' for a, b in sorted(v.items())) + '\n')
+
 print(open(os.path.join('profiles', f'{tag}_{scene}_pmc_hbm.csv')).read())

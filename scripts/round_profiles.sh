@@ -10,9 +10,10 @@ timeout 900 python bench.py --detail gpurun_out/final/bench_default_detail.json 
 for sc in mis-spheres instances-10k; do
   timeout 300 python bench.py --scene $sc --steps 3 --warmup 1 --no-cpu-baseline --headline-only > gpurun_out/final/bench_$sc.json 2> gpurun_out/final/bench_$sc.err
 done
-timeout 600 bash scripts/pmc_scene.sh cornell 1024 ${TAG}_sq_cornell > gpurun_out/final/sq_cornell.txt 2>&1
-timeout 600 bash scripts/pmc_scene.sh blob 256 ${TAG}_sq_blob > gpurun_out/final/sq_blob.txt 2>&1
-timeout 900 bash scripts/pmc_scene.sh room 1024 ${TAG}_sq_room > gpurun_out/final/sq_room.txt 2>&1
+# (the SQ counter summaries are part of profile_round.sh since round 5: profiles/<tag>_<scene>_pmc_sq.txt carries the same kernel_source_sha as the traffic files)
+# the 8-way static split of C5 and of the headline replayed on this one GPU: per-rank ms / mean (what the 8-GPU target will be measured on)
+timeout 600 python scripts/shard_replay.py room 8 profiles/${TAG}_shard_replay_room_8.json > gpurun_out/final/shard_room.log 2>&1
+timeout 300 python scripts/shard_replay.py cornell 8 profiles/${TAG}_shard_replay_cornell_8.json > gpurun_out/final/shard_cornell.log 2>&1
 mkdir -p gpurun_out/final/profiles && cp profiles/${TAG}_* profiles/pmc_*.json gpurun_out/final/profiles/ 2>/dev/null
 ls gpurun_out/final gpurun_out/final/profiles
 tail -c 600 gpurun_out/final/bench_default.json
