@@ -307,7 +307,7 @@ RT_DEV void tri_fill_interaction_inl(const DScene& sc, int prim, f3 ray_d, const
   const unsigned flags = __float_as_uint(r2.w);
   const float b0 = h.b0, b1 = h.b1, b2 = h.b2;
   f2 uv0 = mk2(0.0f, 0.0f), uv1 = mk2(1.0f, 0.0f), uv2 = mk2(1.0f, 1.0f);  // :201-211
-  if (flags & 4u) {
+  if ((flags & 4u) && !RT_DBG(sc, 32)) {  // (RT_DBG 32, measurement builds: what the shade stage would gain if the uvs came with the record's line)
     const float* u = sc.tri_uv + 6 * (size_t)prim;
     uv0 = mk2(u[0], u[1]); uv1 = mk2(u[2], u[3]); uv2 = mk2(u[4], u[5]);
   }
@@ -318,10 +318,11 @@ RT_DEV void tri_fill_interaction_inl(const DScene& sc, int prim, f3 ray_d, const
   si.hit.p = p0 * b0 + p1 * b1 + p2 * b2;
   si.uv = mk2(uv0.x * b0 + uv1.x * b1 + uv2.x * b2, uv0.y * b0 + uv1.y * b1 + uv2.y * b2);
   si.hit.wo = WO_SIGNS_ONLY ? -ray_d : normalize(normalize(-ray_d));  // SurfaceInteraction::new + Interaction::new both normalise (interaction.rs:42,123)
-  const float4 r6 = rec[6], r7 = rec[7];
+  const bool half_rec = RT_DBG(sc, 64);  // (RT_DBG 64, measurement builds: only the first 64 bytes of the record are read - what a 64-byte record would cost in traffic)
+  const float4 r6 = half_rec ? r0 : rec[6], r7 = half_rec ? r1 : rec[7];
   si.dpdu = mk3(r6.x, r6.y, r6.z); si.dpdv = mk3(r7.x, r7.y, r7.z);
   if (RT_REC_CONST_FRAME(flags)) {
-    const float4 r4 = rec[4], r5 = rec[5];
+    const float4 r4 = half_rec ? make_float4(r3.y, r3.z, r3.x, r3.y) : rec[4], r5 = half_rec ? make_float4(r3.z, r3.x, r3.y, r3.z) : rec[5];
     si.hit.n = mk3(r3.x, r3.y, r3.z); si.sh_n = si.hit.n;
     si.sh_dpdu = mk3(r4.x, r4.y, r4.z); si.sh_dpdv = mk3(r5.x, r5.y, r5.z);
     si.ssb = mk3(r3.w, r4.w, r5.w);

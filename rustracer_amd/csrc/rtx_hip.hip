@@ -66,7 +66,7 @@ struct rt_scene {
   bool use_pairs = false;
   bool deep_column = false;  // top level + deepest object need more than 64 stack entries in one column: k_trace_big with 128
   DevBuf skip8;  // DScene::skip8 (LDS-resident scenes)
-  DevBuf quads; bool use_quads = false; int quad_stack_depth = 0;  // four-wide records of the any-hit kernel (k_trace_quad)
+  DevBuf quads; bool use_quads = false, use_quads_closest = false; int quad_stack_depth = 0;  // four-wide records of the any-hit kernel (k_trace_quad)
   DevBuf tri_rec;  // per-triangle shade records (k_tri_records)
   DevBuf nodes, tri_p, tri_n, tri_uv, tri_s, tri_alpha, spheres, textures, images, materials, lights, texels, dist, guides;
   bool has_spheres = false;
@@ -723,13 +723,21 @@ extern "C" int rt_scene_create(const rt_scene_desc* desc, int device, rt_scene**
           }
         }
         memcpy(q + 24, codes, 16); memcpy(q + 28, &axes, 4);
+        { const uint32_t ca = code_of(child[0], ok), cb = code_of(child[1], ok); memcpy(q + 29, &ca, 4); memcpy(q + 30, &cb, 4); }  // the children themselves: what the closest-hit step pushes for the far side
         need[i] = deepest + n_entries - 1;
       }
       s->quad_stack_depth = need[0] + 1 + max_obj_depth;  // (+ the deepest object's walk above the pending entries)
-      if (ok && s->quad_stack_depth <= 32) {  // beyond the 32-entry LDS stack the larger stack costs more residency than the wider step returns
+      // closest-hit rays through the same records (quad_near_first_step pushes at most one entry per level: the binary walk's stack need). Plain scenes only.
+      // MEASURED (round 5, one box, interleaved with the two-wide kernels): S2 closest hit 91.0 -> 95.9 ms (k_trace_pair), S4 1371 -> 1554 ms (k_trace_top), S3 71.2 = 71.2;
+      // hit records bit-equal (tests). OFF: RTX_QUAD_CLOSEST=1 turns it on. A pair record shares its 128-byte line with the record of its first child (pre-order:
+      // node i + 1), so half of the two-wide walk's steps are served by the line the step before fetched - the four-wide record has no such neighbour and spends half of
+      // its line on the far side, which a closest-hit ray mostly discards.
+      static const char* qc_env = getenv("RTX_QUAD_CLOSEST");
+      s->use_quads_closest = ok && !s->general_prims && qc_env && qc_env[0] == '1';
+      if (ok && (s->quad_stack_depth <= 32 || s->use_quads_closest)) {  // (any hit: beyond the 32-entry LDS stack the larger stack costs more residency than the wider step returns)
         int rc2 = upload(s->quads, qr.data(), qr.size() * 4);
         if (rc2 != RT_OK) { delete s; return rc2; }
-        d.quads = s->quads.as<float4>(); s->use_quads = true;
+        d.quads = s->quads.as<float4>(); s->use_quads = s->quad_stack_depth <= 32;
       }
     }
   }
@@ -860,6 +868,15 @@ extern "C" int rt_light_distribution(rt_scene* s, int32_t n_voxels[3], float* fu
   return RT_OK;
 }
 
+// k_trace_pool (round 5), MEASURED on S1 (one box, same run): closest hit 238.6 -> 351 ms, occlusion rays 118.1 -> 219 ms. OFF (RTX_LDS_POOL=3 turns it on). The finished
+// lanes do get new rays at a dozen LDS reads each - and the kernel still loses a third: its 13 KB of pools leave five waves per SIMD instead of seven / eight, and
+// the refill bookkeeping (three more ballots and their scalar chain) sits in every round. Together with the deferred walks (closest_small_deferred, occluded_small_deferred:
+// more lanes per instruction, same or more time) this says what these kernels wait for: not VALU issue slots - a wave's round is a chain of dependent steps (LDS read ->
+// box test -> select -> ballot -> branch) and the SIMD is busy 62 % of the time with seven such chains interleaved; anything that lengthens the chain or removes a wave costs
+// more than the lanes it fills return.
+#ifndef RT_LDS_POOL_DEFAULT
+#define RT_LDS_POOL_DEFAULT 0
+#endif
 // ---------------------------------------------------------------------------------------------- trace launches
 // LDS a workgroup of the trace kernels declares, and the persistent grid that fills every CU at that residency
 template <bool ANY, bool SMALL, int BLOCK, int DEPTH>
@@ -928,6 +945,10 @@ static void launch_trace_v(rt_scene* s, const TraceIO& io, const unsigned* queue
       hipLaunchKernelGGL((k_trace_quad<ANY, BLOCK, DEPTH>), dim3(grid), dim3(BLOCK), 0, stream, s->d, io, queue, count_ptr, shard_cap, count_static, stats, st_rays, s->tmin_stack.as<float>(), refill_min);
       return;
     }
+    if (!ANY && !COUNT && !plain && !refill_only && !(mode && mode[0] == 'c') && s->use_quads_closest && s->stack_depth <= DEPTH) {  // closest hit four-wide, near side first (round 5)
+      hipLaunchKernelGGL((k_trace_quad<ANY, BLOCK, DEPTH>), dim3(grid), dim3(BLOCK), 0, stream, s->d, io, queue, count_ptr, shard_cap, count_static, stats, st_rays, s->tmin_stack.as<float>(), refill_min);
+      return;
+    }
     // RTX_TRACE=top0: the child-pair kernel without the LDS-resident top of the tree (measurement knob)
     if (!COUNT && !plain && !refill_only && s->use_pairs && s->use_top && (ANY || s->top_for_closest) && !(mode && mode[0] == 't')) {
       hipLaunchKernelGGL((k_trace_top<ANY, RT_TOP_BLOCK>), dim3(top_grid(s, ANY)), dim3(RT_TOP_BLOCK), 0, stream, s->d, io, queue, count_ptr, shard_cap, count_static, stats, st_rays,
@@ -942,6 +963,15 @@ static void launch_trace_v(rt_scene* s, const TraceIO& io, const unsigned* queue
     }
     if (!plain) {
       hipLaunchKernelGGL((k_trace_big<ANY, COUNT, BLOCK, DEPTH>), dim3(grid), dim3(BLOCK), 0, stream, s->d, io, queue, count_ptr, shard_cap, count_static, stats, st_rays, st_nodes, st_tris);
+      return;
+    }
+  }
+  if constexpr (SMALL && !COUNT && RT_LDS_THREADED) {  // the LDS-resident walks with a pool of set-up rays (k_trace_pool, round 5); RTX_LDS_POOL: bit 0 closest hit, bit 1 occlusion rays
+    static const int pool_bits = getenv("RTX_LDS_POOL") ? atoi(getenv("RTX_LDS_POOL")) : RT_LDS_POOL_DEFAULT;
+    if (pool_bits & (ANY ? 2 : 1)) {
+      const unsigned lds = (unsigned)((8 * RT_SMALL_NODES + 10 * RT_SMALL_TRIS) * 4 + (ANY ? 1 : 8) * RT_SMALL_NODES * 2 + 4 * RT_POOL_FIELDS * 64 * 4);
+      const unsigned per_cu = std::max(1u, std::min((unsigned)RT_POOL_WAVES, (160u * 1024u) / lds));
+      hipLaunchKernelGGL((k_trace_pool<ANY, 256>), dim3((unsigned)s->n_cu * per_cu), dim3(256), 0, stream, s->d, io, queue, count_ptr, shard_cap, count_static, stats, st_rays);
       return;
     }
   }
@@ -1599,6 +1629,14 @@ extern "C" int rt_render(rt_scene* s, const rt_camera* cam, const rt_film_desc* 
   stats.vertices_lambert_const = h[ST_SHADED]; stats.vertices_lambert = h[ST_SHADED + 1]; stats.vertices_two_lobe = h[ST_SHADED + 2]; stats.vertices_generic = h[ST_SHADED + 3];
   if (h[ST_UNBUILT_VOXEL]) return fail(RT_ERR_INVALID, "a path looked up a light-distribution voxel that holds no surface (voxel marking bug)");
   stats.ms_total = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_begin).count();
+#ifdef RT_TRACE_PROBE
+  if (getenv("RTX_PROBE")) {
+    unsigned long long pr[16]; HIP_TRY(hipMemcpyFromSymbol(pr, HIP_SYMBOL(g_probe), sizeof(pr))); unsigned long long z[16] = {0}; HIP_TRY(hipMemcpyToSymbol(HIP_SYMBOL(g_probe), z, sizeof(z)));
+    auto f = [](unsigned long long a, unsigned long long b) { return b ? (double)a / (double)b : 0.0; };
+    fprintf(stderr, "probe: occlusion walk lanes stepping %.3f of rounds | closest: node rounds %.3f, leaf phases %.3f (node : leaf slots %.2f : 1) | tail: all lanes' steps / (64 x longest lane) %.3f\n",
+            f(pr[1], pr[0]), f(pr[3], pr[2]), f(pr[5], pr[4]), f(pr[2], pr[4]), f(pr[7], pr[6]));
+  }
+#endif
   if (stats_out) *stats_out = stats;
   return RT_OK;
 }

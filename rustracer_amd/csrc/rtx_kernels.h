@@ -809,6 +809,15 @@ RT_DEV void stage_small_scene(const DScene& sc, float* s_nodes, float* s_tris) {
 #ifndef RT_ANY_EARLY_SIGN
 #define RT_ANY_EARLY_SIGN 1
 #endif
+// Measurement builds (EXTRA=-DRT_TRACE_PROBE): how the lanes of a wave spend the rounds of the LDS walks. g_probe[0 / 1]: occlusion walk, rounds x 64 and lanes
+// that stepped; [2 / 3]: closest-hit node rounds x 64 and lanes that stepped; [4 / 5]: its leaf phases x 64 and lanes that tested; [6 / 7]: per wave the LONGEST
+// lane's steps x 64 against all lanes' steps (the tail: what a wave that could hand finished lanes new work would save). Printed by rt_render (RTX_PROBE=1).
+#ifdef RT_TRACE_PROBE
+__device__ unsigned long long g_probe[16];
+#define RT_PROBE_ADD(k, v) do { if ((threadIdx.x & 63u) == 0u) atomicAdd(&g_probe[k], (unsigned long long)(v)); } while (0)
+#else
+#define RT_PROBE_ADD(k, v) do { } while (0)
+#endif
 template <int N, int T, bool FINITE>
 RT_DEV bool occluded_small(const float* __restrict__ s_nodes, const float* __restrict__ s_tris, const unsigned short* __restrict__ s_skip, const int n_nodes, const Ray ray) {
   const f3 inv_dir = mk3(1.0f / ray.d.x, 1.0f / ray.d.y, 1.0f / ray.d.z);
@@ -817,7 +826,13 @@ RT_DEV bool occluded_small(const float* __restrict__ s_nodes, const float* __res
   const f3 op = permute(ray.o, rp.kx, rp.ky, rp.kz);
   bool found = false;
   int cur = 0;  // n_nodes: done
+#ifdef RT_TRACE_PROBE
+  unsigned pr_rounds = 0, pr_mine = 0;
+#endif
   for (;;) {
+#ifdef RT_TRACE_PROBE
+    pr_rounds += 1; pr_mine += cur < n_nodes ? 1u : 0u;
+#endif
     if (cur < n_nodes) {
       const float* nd = s_nodes + cur;
       const float4 n0 = make_float4(nd[0], nd[2 * N], nd[4 * N], nd[N]), n1 = make_float4(nd[3 * N], nd[5 * N], 0.0f, 0.0f);
@@ -840,10 +855,63 @@ RT_DEV bool occluded_small(const float* __restrict__ s_nodes, const float* __res
     }
     if (__ballot(cur < n_nodes) == 0ull) break;
   }
+#ifdef RT_TRACE_PROBE
+  { unsigned tot = pr_mine; for (int off = 32; off > 0; off >>= 1) tot += __shfl_down(tot, off); RT_PROBE_ADD(0, 64u * pr_rounds); RT_PROBE_ADD(1, tot); }
+#endif
   return found;
 }
 // (Measured and not kept: holding a reached leaf until 4 / 8 / 12 / 16 lanes of the wave hold one, one primitive per phase - shadow rays 124 -> 130 / 135.5 / 140 /
 // 144 ms per S1 frame. A holder's wait costs more node rounds than the fuller triangle tests return.)
+//
+// Round 5: the occlusion walk with its primitive tests DEFERRED. occluded_small tests a leaf's primitives inside the node step, so in almost every round of the
+// wave two or three lanes run a triangle test (~100 instructions) while the others wait: 34 % of the lanes busy over the kernel, worse than the closest-hit
+// walk. But intersect_p's answer does not depend on WHEN a primitive is tested (t_max never shrinks), so a lane that reaches a leaf only notes it - up to six
+// pending leaves, ten bits each, in one 64-bit register - and walks on; nobody waits. Whenever LEAF_MIN lanes have something pending (or nobody can walk), every
+// lane with pending work tests ONE primitive: the triangle tests run at half the wave or more instead of at 3 - 5 lanes. A lane whose list is full stops
+// walking until a phase has taken an entry. Same answer: the set of (leaf box passes, primitive passes) pairs examined is a superset-until-found of the
+// reference's, and found = any of them.
+#ifndef RT_LDS_ANY_DEFER_MIN
+#define RT_LDS_ANY_DEFER_MIN 0  // measured (S1, two interleaved rounds): shadow rays 116.8 ms without, 117.6 / 115.2 / 117.7 at 16 / 32 / 48 - nothing: the occlusion kernel does not wait for its VALUs
+#endif
+template <int N, int T, bool FINITE, int LEAF_MIN>
+RT_DEV bool occluded_small_deferred(const float* __restrict__ s_nodes, const float* __restrict__ s_tris, const unsigned short* __restrict__ s_skip, const int n_nodes, const Ray ray) {
+  const f3 inv_dir = mk3(1.0f / ray.d.x, 1.0f / ray.d.y, 1.0f / ray.d.z);
+  const RayPre rp = ray_pre(ray);
+  const float* const tpx = s_tris + rp.kx * T; const float* const tpy = s_tris + rp.ky * T; const float* const tpz = s_tris + rp.kz * T;
+  const f3 op = permute(ray.o, rp.kx, rp.ky, rp.kz);
+  bool found = false;
+  int cur = 0;                     // n_nodes: nothing left to visit
+  unsigned long long pend = 0ull;  // pending leaves, (node index + 1) in ten bits each, the latest in bits 0-9
+  int leaf_off = 0, leaf_n = 0;    // the leaf being tested: leaf_n primitives from leaf_off on are still untested
+  for (;;) {
+    if (cur < n_nodes && (pend >> 50) == 0ull) {
+      const float* nd = s_nodes + cur;
+      const float4 n0 = make_float4(nd[0], nd[2 * N], nd[4 * N], nd[N]), n1 = make_float4(nd[3 * N], nd[5 * N], 0.0f, 0.0f);
+      const bool hit = slab_test_t<FINITE>(n0, n1, ray, inv_dir, inv_dir.x < 0.0f, inv_dir.y < 0.0f, inv_dir.z < 0.0f);
+      const int next = hit ? cur + 1 : (int)s_skip[cur];
+      if (hit && (__float_as_uint(nd[7 * N]) & 0xffffu) != 0u) pend = (pend << 10) | (unsigned long long)(cur + 1);
+      cur = next;
+    }
+    const bool has = (pend != 0ull) | (leaf_n > 0);
+    const unsigned long long walkers = __ballot(cur < n_nodes && (pend >> 50) == 0ull), havers = __ballot(has);
+    if ((walkers | havers) == 0ull) break;
+    if (walkers == 0ull || __builtin_popcount((unsigned)havers) + __builtin_popcount((unsigned)(havers >> 32)) >= LEAF_MIN) {
+      if (has) {
+        if (leaf_n == 0) {
+          const int node = (int)(pend & 1023ull) - 1; pend >>= 10;
+          leaf_off = __float_as_int(s_nodes[6 * N + node]); leaf_n = (int)(__float_as_uint(s_nodes[7 * N + node]) & 0xffffu);
+        }
+        const int t = leaf_off;
+        const f3 p0t = mk3(tpx[t] - op.x, tpy[t] - op.y, tpz[t] - op.z), p1t = mk3(tpx[3 * T + t] - op.x, tpy[3 * T + t] - op.y, tpz[3 * T + t] - op.z),
+                 p2t = mk3(tpx[6 * T + t] - op.x, tpy[6 * T + t] - op.y, tpz[6 * T + t] - op.z);
+        TriHit h;
+        if (tri_test_permuted<RT_ANY_EARLY_SIGN != 0>(p0t, p1t, p2t, rp.sx, rp.sy, rp.sz, ray.t_max, h)) { found = true; cur = n_nodes; pend = 0ull; leaf_n = 0; }
+        else { leaf_off += 1; leaf_n -= 1; }
+      }
+    }
+  }
+  return found;
+}
 // Closest hit: rounds (every walking lane takes one node; when LEAF_MIN lanes hold a leaf, or none walks, every holder tests ONE primitive - a holder with more
 // stays a holder; whole leaves per phase: closest hit 256 ms per S1 frame against 248).
 template <int N, int T, bool FINITE, int LEAF_MIN>
@@ -857,9 +925,15 @@ RT_DEV bool closest_small(const float* __restrict__ s_nodes, const float* __rest
   const f3 op = permute(ray.o, rp.kx, rp.ky, rp.kz);
   bool found = false;
   int cur = 0, leaf_off = 0, leaf_n = 0;  // cur == n_nodes: nothing left to visit; leaf_n > 0: the lane holds that many untested primitives from leaf_off on (cur already names what follows the leaf)
+#ifdef RT_TRACE_PROBE
+  unsigned pr_w = 0, pr_wm = 0, pr_l = 0, pr_lm = 0;
+#endif
   for (;;) {
     unsigned long long holders = 0ull;
     for (;;) {
+#ifdef RT_TRACE_PROBE
+      pr_w += 1; pr_wm += (leaf_n == 0 && cur < n_nodes) ? 1u : 0u;
+#endif
       if (leaf_n == 0 && cur < n_nodes) {
         const float* nd = s_nodes + cur;
         const float4 n0 = make_float4(nd[0], nd[2 * N], nd[4 * N], nd[N]), n1 = make_float4(nd[3 * N], nd[5 * N], 0.0f, 0.0f);
@@ -877,6 +951,9 @@ RT_DEV bool closest_small(const float* __restrict__ s_nodes, const float* __rest
       if (__builtin_popcount((unsigned)holders) + __builtin_popcount((unsigned)(holders >> 32)) >= LEAF_MIN) break;  // (two 32-bit counts: the 64-bit count's compare is compiled as a VECTOR compare)
     }
     if (holders == 0ull) break;
+#ifdef RT_TRACE_PROBE
+    pr_l += 1; pr_lm += leaf_n > 0 ? 1u : 0u;
+#endif
     if (leaf_n > 0) {
       const int t = leaf_off;
       const f3 p0t = mk3(tpx[t] - op.x, tpy[t] - op.y, tpz[t] - op.z), p1t = mk3(tpx[3 * T + t] - op.x, tpy[3 * T + t] - op.y, tpz[3 * T + t] - op.z),
@@ -884,6 +961,70 @@ RT_DEV bool closest_small(const float* __restrict__ s_nodes, const float* __rest
       TriHit h;
       if (tri_test_permuted(p0t, p1t, p2t, rp.sx, rp.sy, rp.sz, ray.t_max, h)) { found = true; ray.t_max = h.t; prim_out = t; hit_out = h; }  // `.or(result)`: later accepted hits replace
       leaf_off += 1; leaf_n -= 1;
+    }
+  }
+#ifdef RT_TRACE_PROBE
+  { unsigned a = pr_wm, b = pr_lm, mx = pr_wm + pr_lm, sm = pr_wm + pr_lm;
+    for (int off = 32; off > 0; off >>= 1) { a += __shfl_down(a, off); b += __shfl_down(b, off); sm += __shfl_down(sm, off); const unsigned o = __shfl_down(mx, off); mx = o > mx ? o : mx; }
+    RT_PROBE_ADD(2, 64u * pr_w); RT_PROBE_ADD(3, a); RT_PROBE_ADD(4, 64u * pr_l); RT_PROBE_ADD(5, b); RT_PROBE_ADD(6, 64u * mx); RT_PROBE_ADD(7, sm); }
+#endif
+  return found;
+}
+
+// Round 5: the closest-hit walk of an LDS-resident scene in which NOBODY WAITS. In closest_small a lane that reaches a leaf holds it until
+// LEAF_MIN lanes hold one - 48.6 % of the lanes step in a node round, 29.2 % test in a leaf phase (probe build, S1). It has to wait because what follows the leaf
+// is tested against the t_max the leaf leaves behind. Here the lane notes the leaf (FIFO of up to six node ids in one 64-bit register) and WALKS ON with the t_max
+// it has - a stale, larger t_max only lets more boxes pass, so what it notes is a superset, in the reference's order, of the leaves BVH::intersect visits. When a
+// leaf phase comes the lane takes its OLDEST noted leaf and tests that leaf's box again with the t_max of the moment: that test - same ray, same box, the t_max
+// left by every earlier leaf - IS the reference's test of that node at that point of its walk, and a leaf whose ancestor the reference culled fails it (a box
+// contains its children's boxes and tmin is monotone in the box: tmin(leaf) >= tmin(ancestor) >= t_max then >= t_max now). Leaves that pass have their primitives
+// tested in order, one per phase. The sequence of primitive tests and t_max updates per ray is BVH::intersect's; hit records bit-equal.
+#ifndef RT_LDS_CLOSEST_DEFER_MIN
+#define RT_LDS_CLOSEST_DEFER_MIN 0
+#endif
+template <int N, int T, bool FINITE, int LEAF_MIN>
+RT_DEV bool closest_small_deferred(const float* __restrict__ s_nodes, const float* __restrict__ s_tris, const unsigned short* __restrict__ s_skip8, const int n_nodes, Ray ray, int& prim_out, TriHit& hit_out) {
+  const f3 inv_dir = mk3(1.0f / ray.d.x, 1.0f / ray.d.y, 1.0f / ray.d.z);
+  const int neg_x = inv_dir.x < 0.0f, neg_y = inv_dir.y < 0.0f, neg_z = inv_dir.z < 0.0f;
+  const unsigned oct = (neg_x ? 1u : 0u) | (neg_y ? 2u : 0u) | (neg_z ? 4u : 0u), negmask = oct << 16;
+  const unsigned short* const skip = s_skip8 + oct * N;
+  const RayPre rp = ray_pre(ray);
+  const float* const tpx = s_tris + rp.kx * T; const float* const tpy = s_tris + rp.ky * T; const float* const tpz = s_tris + rp.kz * T;
+  const f3 op = permute(ray.o, rp.kx, rp.ky, rp.kz);
+  bool found = false;
+  int cur = 0, leaf_off = 0, leaf_n = 0;
+  unsigned long long pend = 0ull;  // noted leaves, (node index + 1) in ten bits each: the OLDEST in the highest occupied field
+  for (;;) {
+    if (cur < n_nodes && (pend >> 50) == 0ull) {
+      const float* nd = s_nodes + cur;
+      const float4 n0 = make_float4(nd[0], nd[2 * N], nd[4 * N], nd[N]), n1 = make_float4(nd[3 * N], nd[5 * N], 0.0f, 0.0f);
+      const int offset = __float_as_int(nd[6 * N]); const unsigned ctl = __float_as_uint(nd[7 * N]);
+      int next = (int)skip[cur];
+      if (slab_test_t<FINITE>(n0, n1, ray, inv_dir, neg_x, neg_y, neg_z)) {
+        if ((ctl & 0xffffu) != 0u) pend = (pend << 10) | (unsigned long long)(cur + 1);
+        else next = (ctl & negmask) != 0u ? offset : cur + 1;
+      }
+      cur = next;
+    }
+    const bool has = (pend != 0ull) | (leaf_n > 0);
+    const unsigned long long walkers = __ballot(cur < n_nodes && (pend >> 50) == 0ull), havers = __ballot(has);
+    if ((walkers | havers) == 0ull) break;
+    if (walkers == 0ull || __builtin_popcount((unsigned)havers) + __builtin_popcount((unsigned)(havers >> 32)) >= LEAF_MIN) {
+      while (leaf_n == 0 && pend != 0ull) {  // the oldest noted leaf that still passes its node test
+        const int field = (63 - __builtin_clzll(pend)) / 10, shift = 10 * field;
+        const int node = (int)((pend >> shift) & 1023ull) - 1; pend &= (1ull << shift) - 1ull;
+        const float* nd = s_nodes + node;
+        const float4 n0 = make_float4(nd[0], nd[2 * N], nd[4 * N], nd[N]), n1 = make_float4(nd[3 * N], nd[5 * N], 0.0f, 0.0f);
+        if (slab_test_t<FINITE>(n0, n1, ray, inv_dir, neg_x, neg_y, neg_z)) { leaf_off = __float_as_int(nd[6 * N]); leaf_n = (int)(__float_as_uint(nd[7 * N]) & 0xffffu); }
+      }
+      if (leaf_n > 0) {
+        const int t = leaf_off;
+        const f3 p0t = mk3(tpx[t] - op.x, tpy[t] - op.y, tpz[t] - op.z), p1t = mk3(tpx[3 * T + t] - op.x, tpy[3 * T + t] - op.y, tpz[3 * T + t] - op.z),
+                 p2t = mk3(tpx[6 * T + t] - op.x, tpy[6 * T + t] - op.y, tpz[6 * T + t] - op.z);
+        TriHit h;
+        if (tri_test_permuted(p0t, p1t, p2t, rp.sx, rp.sy, rp.sz, ray.t_max, h)) { found = true; ray.t_max = h.t; prim_out = t; hit_out = h; }
+        leaf_off += 1; leaf_n -= 1;
+      }
     }
   }
   return found;
@@ -971,12 +1112,14 @@ __global__ void __launch_bounds__(BLOCK, (SMALL && GENERAL == 0 && !COUNT) ? ((A
     const bool fin = FIN_FORMS && __ballot(!inv_dir_finite(mk3(1.0f / ray.d.x, 1.0f / ray.d.y, 1.0f / ray.d.z))) == 0ull;
     if (SMALL && LM > 1 && LM < 64 && !COUNT) {
       LdsS src{s_nodes, s_tris};
-      if (STACKLESS && !ANY) found = fin ? closest_small<NN, NT, true, LM>(s_nodes, s_tris, s_skip, (int)sc.n_nodes, ray, prim, h) : closest_small<NN, NT, false, LM>(s_nodes, s_tris, s_skip, (int)sc.n_nodes, ray, prim, h);
+      if (STACKLESS && !ANY && RT_LDS_CLOSEST_DEFER_MIN > 0) found = fin ? closest_small_deferred<NN, NT, true, RT_LDS_CLOSEST_DEFER_MIN>(s_nodes, s_tris, s_skip, (int)sc.n_nodes, ray, prim, h) : closest_small_deferred<NN, NT, false, RT_LDS_CLOSEST_DEFER_MIN>(s_nodes, s_tris, s_skip, (int)sc.n_nodes, ray, prim, h);
+      else if (STACKLESS && !ANY) found = fin ? closest_small<NN, NT, true, LM>(s_nodes, s_tris, s_skip, (int)sc.n_nodes, ray, prim, h) : closest_small<NN, NT, false, LM>(s_nodes, s_tris, s_skip, (int)sc.n_nodes, ray, prim, h);
       else found = traverse_rounds<ANY, COUNT, LM, LdsS, StackT, GENERAL>(src, ray, stack + threadIdx.x, BLOCK, prim, h, n_nodes, n_tris, gen);
     }
     else if (SMALL) {
       LdsS src{s_nodes, s_tris};
-      if (STACKLESS) found = fin ? occluded_small<NN, NT, true>(s_nodes, s_tris, s_skip, (int)sc.n_nodes, ray) : occluded_small<NN, NT, false>(s_nodes, s_tris, s_skip, (int)sc.n_nodes, ray);
+      if (STACKLESS && RT_LDS_ANY_DEFER_MIN > 0) found = fin ? occluded_small_deferred<NN, NT, true, RT_LDS_ANY_DEFER_MIN>(s_nodes, s_tris, s_skip, (int)sc.n_nodes, ray) : occluded_small_deferred<NN, NT, false, RT_LDS_ANY_DEFER_MIN>(s_nodes, s_tris, s_skip, (int)sc.n_nodes, ray);
+      else if (STACKLESS) found = fin ? occluded_small<NN, NT, true>(s_nodes, s_tris, s_skip, (int)sc.n_nodes, ray) : occluded_small<NN, NT, false>(s_nodes, s_tris, s_skip, (int)sc.n_nodes, ray);
       else found = traverse<ANY, COUNT, LdsS, StackT, GENERAL>(src, ray, stack + threadIdx.x, BLOCK, prim, h, n_nodes, n_tris, gen);
     }
     else {
@@ -1018,6 +1161,167 @@ RT_DEV TraceOut trace_out_of(const TraceIO& io) {
   TraceOut o; o.hits = io.hits; o.hs = io.hit_stride; o.hit_b2 = io.hit_b2 != 0; o.occluded = io.occluded; o.os = io.occ_stride;
   o.lacc = io.lacc; o.ls = io.lacc_stride; o.direct_add = io.direct_add; o.as = io.add_stride; return o;
 }
+// ---- Round 5: the LDS-resident walks with a POOL of set-up rays (k_trace_pool). The probe build says where the lanes of k_trace's waves go (S1): a closest-hit
+// wave steps nodes with 48.6 % of its lanes and tests primitives with 29.2 %; of that, the TAIL - lanes whose ray is done while the wave's longest ray walks on -
+// costs a third (all lanes' steps / (64 x the longest lane's) = 0.674; occlusion rays 0.645). Round 4 tried to hand finished lanes new rays (persistent waves
+// with refill: 413 / 275 ms against 329 / 168) and lost, because a ray's set-up - its record from HBM, six IEEE divisions for 1 / d and the watertight test's
+// shear - then ran for the 16 - 24 refilled lanes only. Here set-up and refill are two things: whenever the pool is empty ALL 64 lanes of the wave - walking or
+// not - set up the wave's next 64 rays (one record each, full width, the loads of the whole wave in flight together) and park them in LDS, 13 words a ray; a lane
+// whose ray is done takes the next parked ray: a dozen LDS reads, no division, no HBM. Per ray nothing changes: closest_small's / occluded_small's steps, the
+// reference's sequence of node tests, primitive tests and t_max updates; hit records bit-equal.
+#ifndef RT_POOL_REFILL_MIN
+#define RT_POOL_REFILL_MIN 8
+#endif
+#ifndef RT_POOL_WAVES  // register bound in waves per SIMD (LDS: 13.9 / 17.4 KB of scene + 13 KB of pools per 256 lanes)
+#define RT_POOL_WAVES 5
+#endif
+#define RT_POOL_FIELDS 13
+template <bool ANY, int BLOCK>
+__global__ void __launch_bounds__(BLOCK, RT_POOL_WAVES) k_trace_pool(DScene sc, TraceIO io, const unsigned* __restrict__ queue, const unsigned* __restrict__ shard_counts, unsigned shard_cap,
+                                                                    unsigned count_static, unsigned long long* stats, int st_rays) {
+  constexpr int N = RT_SMALL_NODES, T = RT_SMALL_TRIS, LEAF_MIN = RT_LDS_LEAF_MIN_CLOSEST;
+  const float4* __restrict__ ray_o = io.ray_o; const float4* __restrict__ ray_d = io.ray_d; const size_t rs = io.ray_stride;
+  __shared__ float s_nodes[8 * N];
+  __shared__ float s_tris[10 * T];
+  __shared__ unsigned short s_skip[(ANY ? 1 : 8) * N];
+  __shared__ float s_pool[BLOCK / 64][RT_POOL_FIELDS][64];
+  QView qv; if (queue) qv.init(io.queue_is_slots ? nullptr : queue, shard_counts, shard_cap);
+  const unsigned count = queue ? qv.total() : count_static;
+  if ((unsigned long long)blockIdx.x * BLOCK >= count) return;
+  stage_small_scene<BLOCK, N, T>(sc, s_nodes, s_tris);
+  for (unsigned i = threadIdx.x; i < (ANY ? 1u : 8u) * sc.n_nodes; i += BLOCK) { const unsigned o = i / sc.n_nodes, k = i - o * sc.n_nodes; s_skip[o * N + k] = sc.skip8[i]; }
+  __syncthreads();
+  const TraceOut out = trace_out_of(io);
+  const int n_nodes = (int)sc.n_nodes;
+  const unsigned lane = __lane_id(), wv = threadIdx.x >> 6;
+  const unsigned n_waves = gridDim.x * (BLOCK / 64), wave = blockIdx.x * (BLOCK / 64) + wv;
+  float (* const pool)[64] = s_pool[wv];
+  unsigned cursor = 0, pool_n = 0, pool_head = 0, n_rays = 0;  // (wave-uniform) rays of the wave's share that went into pools; parked rays left; the next one to hand out
+  bool exhausted = (unsigned long long)wave * 64ull >= count;
+  // the lane's ray
+  bool active = false, found = false, fin = true;
+  unsigned pid = 0; float dw = 0.0f;
+  Ray ray; ray.o = ray.d = mk3(0, 0, 0); ray.t_max = 0.0f;
+  f3 inv_dir = mk3(0, 0, 0), op = mk3(0, 0, 0); float sx = 0.0f, sy = 0.0f, sz = 0.0f;
+  unsigned ox = 0u, oy = 0u, oz = 0u, skip_off = 0u, negmask = 0u;  // (LDS offsets, not pointers: the planes of the permuted coordinates, the octant's row of links)
+  int cur = 0, leaf_off = 0, leaf_n = 0, prim = -1; TriHit h; h.t = kInf; h.b0 = h.b1 = h.b2 = 0.0f;
+  for (;;) {
+    const unsigned long long idle = __ballot(!active);
+    const unsigned n_idle = (unsigned)__popcll(idle);
+    if (n_idle >= (idle == ~0ull ? 1u : (unsigned)RT_POOL_REFILL_MIN)) {
+      if (pool_n == 0u && !exhausted) {  // every lane sets up one ray of the wave's next 64 and parks it
+        const unsigned long long e = ((unsigned long long)(cursor >> 6) * n_waves + wave) * 64ull + lane;
+        const bool valid = e < count;
+        if (valid) {
+          const unsigned p = queue ? qv.get((unsigned)e) : (unsigned)e;
+          const float4 o4 = ray_o[p * rs], d4 = ray_d[p * rs];
+          Ray r; r.o = mk3(o4.x, o4.y, o4.z); r.d = mk3(d4.x, d4.y, d4.z); r.t_max = o4.w;
+          const f3 inv = mk3(1.0f / r.d.x, 1.0f / r.d.y, 1.0f / r.d.z);
+          const RayPre rp = ray_pre(r);
+          pool[0][lane] = o4.x; pool[1][lane] = o4.y; pool[2][lane] = o4.z; pool[3][lane] = o4.w;
+          pool[4][lane] = inv.x; pool[5][lane] = inv.y; pool[6][lane] = inv.z;
+          pool[7][lane] = rp.sx; pool[8][lane] = rp.sy; pool[9][lane] = rp.sz;
+          pool[10][lane] = __int_as_float(rp.kz | (inv_dir_finite(inv) ? 0 : 4));
+          pool[11][lane] = __uint_as_float(p); pool[12][lane] = d4.w;
+        }
+        pool_n = (unsigned)__popcll(__ballot(valid)); pool_head = 0u;
+        cursor += 64u;
+        exhausted = ((unsigned long long)(cursor >> 6) * n_waves + wave) * 64ull >= count;
+        wave_sync_lds();
+      }
+      if (pool_n > 0u) {
+        const unsigned rank = (unsigned)__popcll(idle & ((1ull << lane) - 1ull));
+        if (!active && rank < pool_n) {
+          const unsigned k = pool_head + rank;
+          ray.o = mk3(pool[0][k], pool[1][k], pool[2][k]); ray.t_max = pool[3][k];
+          inv_dir = mk3(pool[4][k], pool[5][k], pool[6][k]);
+          sx = pool[7][k]; sy = pool[8][k]; sz = pool[9][k];
+          const int kzf = __float_as_int(pool[10][k]); const int kz = kzf & 3; fin = (kzf & 4) == 0;
+          int kx = kz + 1; if (kx == 3) kx = 0; int ky = kx + 1; if (ky == 3) ky = 0;
+          pid = __float_as_uint(pool[11][k]); dw = pool[12][k];
+          ox = (unsigned)(kx * T); oy = (unsigned)(ky * T); oz = (unsigned)(kz * T);
+          op = permute(ray.o, kx, ky, kz);
+          const unsigned oct = (inv_dir.x < 0.0f ? 1u : 0u) | (inv_dir.y < 0.0f ? 2u : 0u) | (inv_dir.z < 0.0f ? 4u : 0u);
+          negmask = oct << 16; skip_off = ANY ? 0u : oct * N;
+          cur = 0; leaf_off = 0; leaf_n = 0; prim = -1; found = false; h.t = kInf; h.b0 = h.b1 = h.b2 = 0.0f;
+          active = true; n_rays += 1u;
+        }
+        const unsigned taken = n_idle < pool_n ? n_idle : pool_n;
+        pool_head += taken; pool_n -= taken;
+        wave_sync_lds();  // (the parked rays are read before the next fill overwrites them)
+      }
+    }
+    if (__ballot(active) == 0ull) { if (exhausted && pool_n == 0u) break; else continue; }
+    const bool all_fin = __ballot(active && !fin) == 0ull;  // a wave that holds a ray with a zero direction component tests nodes with the reference's selects
+    const int neg_x = inv_dir.x < 0.0f, neg_y = inv_dir.y < 0.0f, neg_z = inv_dir.z < 0.0f;
+    if (ANY) {  // occluded_small's step
+      if (active) {
+        if (cur < n_nodes) {
+          const float* nd = s_nodes + cur;
+          const float4 n0 = make_float4(nd[0], nd[2 * N], nd[4 * N], nd[N]), n1 = make_float4(nd[3 * N], nd[5 * N], 0.0f, 0.0f);
+          const bool hit = all_fin ? slab_test_finite(n0, n1, ray.o, ray.t_max, inv_dir) : slab_test(n0, n1, ray, inv_dir, neg_x, neg_y, neg_z);
+          int next = hit ? cur + 1 : (int)s_skip[skip_off + cur];
+          if (hit) {
+            const int n_prims = (int)(__float_as_uint(nd[7 * N]) & 0xffffu);
+            if (n_prims != 0) {
+              const int off = __float_as_int(nd[6 * N]);
+              for (int i = 0; i < n_prims; ++i) {
+                const int t = off + i;
+                const f3 p0t = mk3(s_tris[ox + t] - op.x, s_tris[oy + t] - op.y, s_tris[oz + t] - op.z), p1t = mk3(s_tris[ox + 3 * T + t] - op.x, s_tris[oy + 3 * T + t] - op.y, s_tris[oz + 3 * T + t] - op.z),
+                         p2t = mk3(s_tris[ox + 6 * T + t] - op.x, s_tris[oy + 6 * T + t] - op.y, s_tris[oz + 6 * T + t] - op.z);
+                TriHit hh;
+                if (tri_test_permuted<RT_ANY_EARLY_SIGN != 0>(p0t, p1t, p2t, sx, sy, sz, ray.t_max, hh)) { found = true; next = n_nodes; break; }
+              }
+            }
+          }
+          cur = next;
+        }
+        if (cur >= n_nodes) { trace_write_any(out.lacc, out.ls, out.direct_add, out.as, out.occluded, out.os, pid, dw, found); active = false; }
+      }
+    } else {  // closest_small's rounds: node steps until LEAF_MIN lanes hold a leaf (or nobody walks), then one primitive per holder
+      unsigned long long holders = 0ull;
+      for (;;) {
+        if (active && leaf_n == 0 && cur < n_nodes) {
+          const float* nd = s_nodes + cur;
+          const float4 n0 = make_float4(nd[0], nd[2 * N], nd[4 * N], nd[N]), n1 = make_float4(nd[3 * N], nd[5 * N], 0.0f, 0.0f);
+          const int offset = __float_as_int(nd[6 * N]); const unsigned ctl = __float_as_uint(nd[7 * N]);
+          int next = (int)s_skip[skip_off + cur];
+          if (all_fin ? slab_test_finite(n0, n1, ray.o, ray.t_max, inv_dir) : slab_test(n0, n1, ray, inv_dir, neg_x, neg_y, neg_z)) {
+            const int n_prims = (int)(ctl & 0xffffu);
+            if (n_prims != 0) { leaf_off = offset; leaf_n = n_prims; }
+            else next = (ctl & negmask) != 0u ? offset : cur + 1;
+          }
+          cur = next;
+        }
+        holders = __ballot(active && leaf_n > 0);
+        const unsigned long long walkers = __ballot(active && leaf_n == 0 && cur < n_nodes);
+        if (walkers == 0ull) break;
+        if (__builtin_popcount((unsigned)holders) + __builtin_popcount((unsigned)(holders >> 32)) >= LEAF_MIN) break;
+        // a round after which enough lanes have run out of nodes goes back for new rays (the holders keep their leaves)
+        if ((pool_n > 0u || !exhausted) && (unsigned)__popcll(__ballot(!active || (leaf_n == 0 && cur >= n_nodes))) >= (unsigned)RT_POOL_REFILL_MIN) break;
+      }
+      const bool run_leaf = holders != 0ull && (__ballot(active && leaf_n == 0 && cur < n_nodes) == 0ull ||
+                                                __builtin_popcount((unsigned)holders) + __builtin_popcount((unsigned)(holders >> 32)) >= LEAF_MIN);  // (wave-uniform)
+      if (run_leaf && active && leaf_n > 0) {
+        const int t = leaf_off;
+        const f3 p0t = mk3(s_tris[ox + t] - op.x, s_tris[oy + t] - op.y, s_tris[oz + t] - op.z), p1t = mk3(s_tris[ox + 3 * T + t] - op.x, s_tris[oy + 3 * T + t] - op.y, s_tris[oz + 3 * T + t] - op.z),
+                 p2t = mk3(s_tris[ox + 6 * T + t] - op.x, s_tris[oy + 6 * T + t] - op.y, s_tris[oz + 6 * T + t] - op.z);
+        TriHit hh;
+        if (tri_test_permuted(p0t, p1t, p2t, sx, sy, sz, ray.t_max, hh)) { found = true; ray.t_max = hh.t; prim = t; h = hh; }
+        leaf_off += 1; leaf_n -= 1;
+      }
+      if (active && leaf_n == 0 && cur >= n_nodes) {
+        out.hits[pid * out.hs] = make_float4(out.hit_b2 ? h.b2 : (found ? h.t : kInf), __int_as_float(found ? prim : -1), h.b0, h.b1);
+        active = false;
+      }
+    }
+  }
+  if (stats) {
+    for (int off = 32; off > 0; off >>= 1) n_rays += __shfl_down(n_rays, off);
+    if (lane == 0u && n_rays) atomicAdd(&stats[st_rays], (unsigned long long)n_rays);
+  }
+}
+
 // ---- K2/K4 for scenes that live in HBM. Ray lengths then vary by an order of magnitude (a camera ray that
 // misses the root box ends after one node, one that grazes a silhouette visits a hundred), and with one ray per
 // lane per grid-stride iteration a wave runs as long as its longest ray with most lanes idle (measured: 11 of 64
@@ -1289,6 +1593,12 @@ RT_DEV bool nested_pair_walk(const float4* __restrict__ pairs, const float4* __r
 }
 
 // per-lane traversal state and the output arrays a finished ray is written to
+// RT_TTOP (round 5): a closest-hit pop has to compare the entry's deferred tmin with the t_max of the moment. The tmins live in HBM ([depth][lane of the grid]:
+// LDS holds the codes), so every pop - most of them dead: the far subtree behind a hit - waited one memory round trip before it could even ask for its node.
+// Now the top entry's tmin is ALSO kept in a register: a pop compares the register and requests the new top's tmin at once, which the next pop finds arrived.
+#ifndef RT_TTOP
+#define RT_TTOP 1
+#endif
 struct PairLane {
   bool active, found; unsigned pid; float dw;
   // registers are the currency of this kernel (86 -> 80 VGPRs is one more wave per SIMD): the direction signs are read off inv_dir where
@@ -1307,6 +1617,7 @@ struct PairLane {
   RT_DEV RayPre rp() const { RayPre r; r.kz = kz & 3; r.kx = r.kz + 1; if (r.kx == 3) r.kx = 0; r.ky = r.kx + 1; if (r.ky == 3) r.ky = 0; r.sx = sx; r.sy = sy; r.sz = sz; return r; }
   RT_DEV void set_rp(const RayPre& r) { kz = (kz & 4) | r.kz; sx = r.sx; sy = r.sy; sz = r.sz; }
   int sp, prim; unsigned cur; TriHit hit;
+  float ttop;  // closest hit: the deferred tmin of the entry on TOP of the to-visit stack (RT_TTOP), so that a pop compares a register and the load of the next entry's tmin is in flight long before the next pop
   int kz;  // (apart from inv_dir: written together as neighbours, the two become one 16-byte store to a private copy of the lane's state - 24 bytes of scratch per lane)
 };
 // The two children of a pair record against the lane's ray: slab_geom && tmin < t_max for each. A finite ray (all but a few hundred of a frame) takes the
@@ -1370,7 +1681,11 @@ RT_DEV void pair_pop(PairLane& L, const TraceOut& o, const unsigned* stack, cons
     --L.sp;
     const unsigned c = stack[L.sp * BLOCK];
     if (ANY) { L.cur = c; return; }  // t_max never changes: the test at push time stands
-    if (tstack[(size_t)L.sp * grid_lanes] < L.ray.t_max) { L.cur = c; return; }
+    if (RT_TTOP) {
+      const float t = L.ttop;
+      if (L.sp > 0) L.ttop = tstack[(size_t)(L.sp - 1) * grid_lanes];
+      if (t < L.ray.t_max) { L.cur = c; return; }
+    } else if (tstack[(size_t)L.sp * grid_lanes] < L.ray.t_max) { L.cur = c; return; }
   }
 }
 template <bool ANY, int BLOCK>
@@ -1386,7 +1701,7 @@ RT_DEV void pair_interior_step(PairLane& L, const TraceOut& o, const float4* __r
   bool ff = ANY && r.far_first;
   if (ANY && RT_ANY_ORDER >= 3 && RT_ANY_ORDER != 8 && ((code_n ^ code_f) & RT_PAIR_LEAF) != 0u) ff = (code_f & RT_PAIR_LEAF) != 0u;  // exactly one child is a leaf: its primitives first
   const unsigned first = ff ? code_f : code_n, second = ff ? code_n : code_f;  // (closest hit: always near, far)
-  if (r.hit_n & r.keep_f) { stack[L.sp * BLOCK] = second; if (!ANY) tstack[(size_t)L.sp * grid_lanes] = r.tmin_f; ++L.sp; L.cur = first; }
+  if (r.hit_n & r.keep_f) { stack[L.sp * BLOCK] = second; if (!ANY) { tstack[(size_t)L.sp * grid_lanes] = r.tmin_f; L.ttop = r.tmin_f; } ++L.sp; L.cur = first; }
   else if (r.hit_n) L.cur = code_n;
   else if (r.keep_f) L.cur = code_f;
   else pair_pop<ANY, BLOCK>(L, o, stack, tstack, grid_lanes);
@@ -1450,7 +1765,7 @@ __global__ void __launch_bounds__(BLOCK, (GENERAL == RT_GEN_NO_MASKS && !ANY) ? 
   PairLane L;
   L.active = false; L.found = false; L.pid = 0; L.dw = 0.0f;
   L.ray.o = L.ray.d = mk3(0, 0, 0); L.ray.t_max = 0.0f; L.set_inv(mk3(0, 0, 0)); L.set_rp(ray_pre(L.ray));
-  L.sp = 0; L.prim = -1; L.cur = 0; L.hit.t = kInf; L.hit.b0 = L.hit.b1 = L.hit.b2 = 0.0f;
+  L.sp = 0; L.prim = -1; L.cur = 0; L.ttop = 0.0f; L.hit.t = kInf; L.hit.b0 = L.hit.b1 = L.hit.b2 = 0.0f;
 
   for (;;) {
     const unsigned long long idle = __ballot(!L.active);
@@ -1527,7 +1842,7 @@ __global__ void __launch_bounds__(BLOCK, 4) k_trace_inst(DScene sc, TraceIO io, 
   PairLane L;
   L.active = false; L.found = false; L.pid = 0; L.dw = 0.0f;
   L.ray.o = L.ray.d = mk3(0, 0, 0); L.ray.t_max = 0.0f; L.set_inv(mk3(0, 0, 0)); L.set_rp(ray_pre(L.ray));
-  L.sp = 0; L.prim = -1; L.cur = 0; L.hit.t = kInf; L.hit.b0 = L.hit.b1 = L.hit.b2 = 0.0f;
+  L.sp = 0; L.prim = -1; L.cur = 0; L.ttop = 0.0f; L.hit.t = kInf; L.hit.b0 = L.hit.b1 = L.hit.b2 = 0.0f;
   unsigned inst = RT_INST_NONE, node_base = 0u, prim_base = 0u, id_base = 0u; int sp_base = -1;  // the instance the lane is inside, its records, the stack height it was entered at
 
   // next pending entry that still passes tmin < t_max; an object whose entries are used up is left first; no entry left: the ray is complete
@@ -1543,6 +1858,11 @@ __global__ void __launch_bounds__(BLOCK, 4) k_trace_inst(DScene sc, TraceIO io, 
       --L.sp;
       const unsigned c = stack[L.sp * BLOCK];
       if (ANY) { L.cur = c; return; }
+      if (RT_TTOP) {
+        const float t = L.ttop;
+        if (L.sp > 0) L.ttop = tstack[(size_t)(L.sp - 1) * grid_lanes];
+        if (t < L.ray.t_max) { L.cur = c; return; }
+      } else
       if (tstack[(size_t)L.sp * grid_lanes] < L.ray.t_max) { L.cur = c; return; }
     }
   };
@@ -1584,7 +1904,7 @@ __global__ void __launch_bounds__(BLOCK, 4) k_trace_inst(DScene sc, TraceIO io, 
       const PairTest pt = pair_slabs(L.finite(), L.ray.o, L.ray.t_max, L.inv_dir, n0, n1, f0, f1, false);
       const bool hit_n = pt.hit_n, keep_f = pt.keep_f; const float tmin_f = pt.tmin_f;
       if (hit_n) {
-        if (keep_f) { stack[L.sp * BLOCK] = code_f; if (!ANY) tstack[(size_t)L.sp * grid_lanes] = tmin_f; ++L.sp; }
+        if (keep_f) { stack[L.sp * BLOCK] = code_f; if (!ANY) { tstack[(size_t)L.sp * grid_lanes] = tmin_f; L.ttop = tmin_f; } ++L.sp; }
         L.cur = code_n;
       } else if (keep_f) L.cur = code_f;
       else pop();
@@ -1638,7 +1958,7 @@ __global__ void __launch_bounds__(BLOCK, 4) k_trace_inst(DScene sc, TraceIO io, 
         if (!slab_test(r0, r1, r, inv, inv.x < 0.0f, inv.y < 0.0f, inv.z < 0.0f)) continue;
         if (i + 1 < n) {  // the rest of this leaf: an entry that no t_max can discard (the reference's loop over the leaf's primitives goes on whatever was hit)
           stack[L.sp * BLOCK] = RT_PAIR_LEAF | RT_PAIR_GENERAL | (unsigned)(off + i + 1) | ((unsigned)(n - i - 2) << 26);
-          if (!ANY) tstack[(size_t)L.sp * grid_lanes] = -kInf;
+          if (!ANY) { tstack[(size_t)L.sp * grid_lanes] = -kInf; L.ttop = -kInf; }
           ++L.sp;
         }
         wsave[0] = L.ray.o.x; wsave[BLOCK] = L.ray.o.y; wsave[2 * BLOCK] = L.ray.o.z; wsave[3 * BLOCK] = L.ray.d.x; wsave[4 * BLOCK] = L.ray.d.y; wsave[5 * BLOCK] = L.ray.d.z;
@@ -1687,6 +2007,11 @@ RT_DEV void top_pop(PairLane& L, const TraceOut& o, const SplitStack<BLOCK>& stk
     --L.sp;
     const unsigned c = stk.get(L.sp);
     if (ANY) { L.cur = c; return; }
+    if (RT_TTOP) {
+      const float t = L.ttop;
+      if (L.sp > 0) L.ttop = tstack[(size_t)(L.sp - 1) * grid_lanes];
+      if (t < L.ray.t_max) { L.cur = c; return; }
+    } else
     if (tstack[(size_t)L.sp * grid_lanes] < L.ray.t_max) { L.cur = c; return; }
   }
 }
@@ -1704,7 +2029,7 @@ RT_DEV void top_interior_step(PairLane& L, const TraceOut& o, const float4* __re
   bool ff = ANY && r.far_first;
   if (ANY && RT_ANY_ORDER >= 3 && RT_ANY_ORDER != 8 && ((code_n ^ code_f) & RT_PAIR_LEAF) != 0u) ff = (code_f & RT_PAIR_LEAF) != 0u;
   const unsigned first = ff ? code_f : code_n, second = ff ? code_n : code_f;
-  if (r.hit_n & r.keep_f) { stk.put(L.sp, second); if (!ANY) tstack[(size_t)L.sp * grid_lanes] = r.tmin_f; ++L.sp; L.cur = first; }
+  if (r.hit_n & r.keep_f) { stk.put(L.sp, second); if (!ANY) { tstack[(size_t)L.sp * grid_lanes] = r.tmin_f; L.ttop = r.tmin_f; } ++L.sp; L.cur = first; }
   else if (r.hit_n) L.cur = code_n;
   else if (r.keep_f) L.cur = code_f;
   else top_pop<ANY, BLOCK>(L, o, stk, tstack, grid_lanes);
@@ -1740,7 +2065,7 @@ __global__ void __launch_bounds__(BLOCK, GENERAL ? 4 : 6) k_trace_top(DScene sc,
   PairLane L;
   L.active = false; L.found = false; L.pid = 0; L.dw = 0.0f;
   L.ray.o = L.ray.d = mk3(0, 0, 0); L.ray.t_max = 0.0f; L.set_inv(mk3(0, 0, 0)); L.set_rp(ray_pre(L.ray));
-  L.sp = 0; L.prim = -1; L.cur = 0; L.hit.t = kInf; L.hit.b0 = L.hit.b1 = L.hit.b2 = 0.0f;
+  L.sp = 0; L.prim = -1; L.cur = 0; L.ttop = 0.0f; L.hit.t = kInf; L.hit.b0 = L.hit.b1 = L.hit.b2 = 0.0f;
   for (;;) {
     const unsigned long long idle = __ballot(!L.active);
     if (!exhausted && (unsigned)__popcll(idle) >= (idle == ~0ull ? 1u : refill_min)) {  // the refill scheme of k_trace_pair
@@ -1858,11 +2183,68 @@ RT_DEV void quad_interior_step(PairLane& L, const TraceOut& o, const float4* __r
 #pragma unroll
     for (int e = 0; e < j; ++e) earlier |= h[e];
     if (h[j]) {
-      if (earlier) { stack[L.sp * BLOCK] = c[j]; if (!ANY) tstack[(size_t)L.sp * grid_lanes] = t[j]; ++L.sp; }
+      if (earlier) { stack[L.sp * BLOCK] = c[j]; if (!ANY) { tstack[(size_t)L.sp * grid_lanes] = t[j]; L.ttop = t[j]; } ++L.sp; }
       else { entered = true; next = c[j]; }
     }
   }
   if (entered) L.cur = next; else pair_pop<ANY, BLOCK>(L, o, stack, tstack, grid_lanes);
+}
+
+// ---- The four-wide step of a CLOSEST-HIT ray (round 5). quad_interior_step pushes both halves of the far child and every dead pop of
+// them waited for its tmin - rounds 2 / 3 measured that as a loss and kept closest hit two-wide. This step reads the same 128-byte record and spends it
+// differently: the NEAR child N of the node (the side BVH::intersect enters first, bvh/mod.rs:411-417) is resolved two levels deep - its two children in N's
+// own order, or N itself where it is a leaf - and the FAR child F is tested AS A WHOLE: its box is the union of its children's boxes in the record (interior
+// bounds are exactly that union, bvh/mod.rs:279-287, so the products (bound - o) * inv_dir are F's own, bit for bit). Entries in the reference's order:
+// N's first, N's second, F. The first that is hit is entered, the others wait on the stack with their tmin, re-tested against the t_max of the moment they are
+// popped (pair_pop) - which is when the reference tests them. Not testing N itself changes nothing: a box contains its children's, so N fails exactly when both
+// of its children fail and passes whenever one of them does (finite rays: minima / maxima are monotone; rays with a zero direction component: the literal test
+// rejects a NaN on x and ignores one on y / z for parent and child alike - the argument k_trace_pair's far-child re-test and the any-hit quad kernel rest on).
+// Per ray the leaves visited, their order and every t_max update are BVH::intersect's; at most two entries are pushed per step (two levels), so the stack
+// need is the binary walk's. One dependent fetch per two levels on the near side, where a closest-hit ray finds its hit.
+template <int BLOCK>
+RT_DEV void quad_near_first_step(PairLane& L, const TraceOut& o, const float4* __restrict__ quads, unsigned* stack, float* tstack, size_t grid_lanes) {
+  const unsigned P = L.cur & 0x1fffffffu, axis_p = (L.cur >> 29) & 3u;
+  const float4* __restrict__ rec = quads + 8 * (size_t)P;
+  const float4 q0 = rec[0], q1 = rec[1], q2 = rec[2], q3 = rec[3], q4 = rec[4], q5 = rec[5], qc = rec[6], qx = rec[7];
+  const bool far_is_a = L.neg_axis(axis_p);  // negative along the node's split axis: the second child (slots 2, 3) is near
+  // near side's two slots (n0x: first slot of the side), far side's two slots
+  const float4 na0 = far_is_a ? q3 : q0, na1 = far_is_a ? q4 : q1, na2 = far_is_a ? q5 : q2;  // 12 floats: boxes of the near side's slots
+  const float4 fa0 = far_is_a ? q0 : q3, fa1 = far_is_a ? q1 : q4, fa2 = far_is_a ? q2 : q5;  // ... of the far side's
+  const unsigned cn0 = far_is_a ? __float_as_uint(qc.z) : __float_as_uint(qc.x), cn1 = far_is_a ? __float_as_uint(qc.w) : __float_as_uint(qc.y);
+  const unsigned cf1 = far_is_a ? __float_as_uint(qc.y) : __float_as_uint(qc.w);
+  const unsigned axes = __float_as_uint(qx.x);
+  const unsigned code_f = far_is_a ? __float_as_uint(qx.y) : __float_as_uint(qx.z);  // the far child itself (an interior node's index | axis, or its leaf code)
+  const unsigned axis_n = far_is_a ? ((axes >> 2) & 3u) : (axes & 3u);
+  // far child's box: the union of its two slots (slot 1 empty: the far child is a leaf and slot 0 is its own box)
+  const bool f_two = cf1 != 0xffffffffu;
+  const float4 fb0 = make_float4(f_two ? fminf(fa0.x, fa1.z) : fa0.x, f_two ? fminf(fa0.y, fa1.w) : fa0.y, f_two ? fminf(fa0.z, fa2.x) : fa0.z, f_two ? fmaxf(fa0.w, fa2.y) : fa0.w);
+  const float4 fb1 = make_float4(f_two ? fmaxf(fa1.x, fa2.z) : fa1.x, f_two ? fmaxf(fa1.y, fa2.w) : fa1.y, 0.0f, 0.0f);
+  // boxes as (min.xyz, max.x) (max.yz): slot 0 of a side = floats 0-5, slot 1 = floats 6-11
+  const float4 n0a = na0, n0b = na1, n1a = make_float4(na1.z, na1.w, na2.x, na2.y), n1b = make_float4(na2.z, na2.w, 0.0f, 0.0f);
+  bool h0, h1, hf; float t0, t1, tf;
+  if (__builtin_expect(L.finite(), 1)) {
+    const f3 qo = mk3(L.ray.o.x, L.ray.o.y, L.ray.o.z), qinv = mk3(L.inv_dir.x, L.inv_dir.y, L.inv_dir.z); const float qt = L.ray.t_max;
+    float m0, m1, mf;
+    slab_interval_finite_scalar(n0a, n0b, qo, qinv, t0, m0);
+    slab_interval_finite_scalar(n1a, n1b, qo, qinv, t1, m1);
+    slab_interval_finite_scalar(fb0, fb1, qo, qinv, tf, mf);
+    h0 = (t0 <= m0) & (m0 > 0.0f) & (t0 < qt);
+    h1 = (cn1 != 0xffffffffu) & (t1 <= m1) & (m1 > 0.0f) & (t1 < qt);
+    hf = (tf <= mf) & (mf > 0.0f) & (tf < qt);
+  } else {
+    const int nx = L.neg_x(), ny = L.neg_y(), nz = L.neg_z();
+    t0 = t1 = tf = 0.0f;
+    h0 = slab_geom(n0a, n0b, L.ray, L.inv_dir, nx, ny, nz, t0) && t0 < L.ray.t_max;
+    h1 = cn1 != 0xffffffffu && slab_geom(n1a, n1b, L.ray, L.inv_dir, nx, ny, nz, t1) && t1 < L.ray.t_max;
+    hf = slab_geom(fb0, fb1, L.ray, L.inv_dir, nx, ny, nz, tf) && tf < L.ray.t_max;
+  }
+  // the near child's own order: negative along ITS split axis => its second child first (a leaf near child has one slot)
+  const bool swap_n = (cn1 != 0xffffffffu) & L.neg_axis(axis_n);
+  const bool ha = swap_n ? h1 : h0, hb = swap_n ? h0 : h1; const float ta = swap_n ? t1 : t0, tb = swap_n ? t0 : t1; const unsigned ca = swap_n ? cn1 : cn0, cb = swap_n ? cn0 : cn1;
+  // entries in order: a, b, F. Push the later ones (F deepest), enter the first that is hit.
+  if (hf & (ha | hb)) { stack[L.sp * BLOCK] = code_f; tstack[(size_t)L.sp * grid_lanes] = tf; L.ttop = tf; ++L.sp; }
+  if (hb & ha) { stack[L.sp * BLOCK] = cb; tstack[(size_t)L.sp * grid_lanes] = tb; L.ttop = tb; ++L.sp; }
+  if (ha) L.cur = ca; else if (hb) L.cur = cb; else if (hf) L.cur = code_f; else pair_pop<false, BLOCK>(L, o, stack, tstack, grid_lanes);
 }
 
 template <bool ANY, int BLOCK, int DEPTH, int GENERAL = 0>
@@ -1886,7 +2268,7 @@ __global__ void __launch_bounds__(BLOCK, RT_GEN_MIN_WAVES(GENERAL)) k_trace_quad
   PairLane L;
   L.active = false; L.found = false; L.pid = 0; L.dw = 0.0f;
   L.ray.o = L.ray.d = mk3(0, 0, 0); L.ray.t_max = 0.0f; L.set_inv(mk3(0, 0, 0)); L.set_rp(ray_pre(L.ray));
-  L.sp = 0; L.prim = -1; L.cur = 0; L.hit.t = kInf; L.hit.b0 = L.hit.b1 = L.hit.b2 = 0.0f;
+  L.sp = 0; L.prim = -1; L.cur = 0; L.ttop = 0.0f; L.hit.t = kInf; L.hit.b0 = L.hit.b1 = L.hit.b2 = 0.0f;
   for (;;) {
     const unsigned long long idle = __ballot(!L.active);
     if (!exhausted && (unsigned)__popcll(idle) >= (idle == ~0ull ? 1u : refill_min)) {  // same refill scheme as k_trace_pair
@@ -1915,7 +2297,8 @@ __global__ void __launch_bounds__(BLOCK, RT_GEN_MIN_WAVES(GENERAL)) k_trace_quad
       const bool leaves_now = leaf_phase_now(L.active, at_leaf, leaf_min);
       if (L.active) {
         if (at_leaf) { if (leaves_now) pair_leaf_step<ANY, BLOCK, GENERAL>(L, out, sc, tri_p, stack, tstack, grid_lanes, ANY && io.shadow_masks != 0); }
-        else quad_interior_step<ANY, BLOCK>(L, out, quads, stack, tstack, grid_lanes);
+        else if constexpr (ANY) quad_interior_step<ANY, BLOCK>(L, out, quads, stack, tstack, grid_lanes);
+        else quad_near_first_step<BLOCK>(L, out, quads, stack, tstack, grid_lanes);
       }
     }
   }
