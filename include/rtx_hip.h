@@ -325,6 +325,11 @@ int rt_sampler_tables(int32_t spp, int32_t dimensions, uint64_t pixel0, uint64_t
  * order). Not used by rt_render; it is the on-device cross-check of the segmented sampler over large pixel ranges. */
 int rt_sampler_tables_plain(int32_t spp, int32_t dimensions, uint64_t pixel0, uint64_t n_pixels, uint32_t* scrambles, uint16_t* perms);
 
+/* offset_ray_origin (rc/geometry/mod.rs:203-220) with its next_float_up / next_float_down steps (rc/lib.rs:227-262) on n points: p, p_error, normal and
+ * direction w as n x 3 floats each, out n x 3. The device function every spawned ray goes through (Interaction::spawn_ray / spawn_ray_to, rc/interaction.rs:
+ * 56-74), exposed for the parity tests (zeros of both signs, infinities, denormals, NaN). Host pointers. */
+int rt_offset_ray_origin(const float* p, const float* p_error, const float* n, const float* w, uint64_t count, float* out);
+
 /* Dense voxel light distribution of SpatialLightDistribution (rc/lightdistrib.rs:101-179):
  * n_voxels[3]; func: nvox*n_lights, cdf: nvox*(n_lights+1), func_int: nvox (host pointers, may be NULL
  * to query n_voxels only). */

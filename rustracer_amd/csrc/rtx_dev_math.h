@@ -83,14 +83,28 @@ RT_DEV void coordinate_system(f3 v1, f3& v2, f3& v3) {  // rc/lib.rs:158-168
 RT_DEV f3 face_forward(f3 v1, f3 v2) { return dot(v1, v2) < 0.0f ? -v1 : v1; }  // rc/geometry/mod.rs:129-144
 RT_DEV float distance_squared(f3 p1, f3 p2) { return len2(p2 - p1); }
 
+// next_float_up(v) where `up`, next_float_down(v) otherwise, as ONE sequence (round 5). offset_ray_origin picks one of the two per coordinate by the sign of the
+// offset; written as `if (> 0) up else if (< 0) down` both were evaluated under a select: 28 instructions per coordinate, 84 per call, two to three calls per
+// vertex - 170 of k_shade<1>'s ~2000 instructions per vertex. Same results for every input, NaN included (its comparisons are false in both forms): a zero takes the
+// direction's sign (up: -0 -> +0, down: +0 -> -0, lib.rs:231-233, 250-252); the bit pattern moves away from zero where `v >= 0` (up) or `!(v > 0)` (down) holds;
+// an infinity in the direction of travel stays.
+RT_DEV float next_float_toward(float v, bool up) {
+  const uint32_t zero = up ? 0u : 0x80000000u;
+  const uint32_t bits = v == 0.0f ? zero : __float_as_uint(v);
+  const float v0 = __uint_as_float(bits);
+  const bool inc = up ? (v0 >= 0.0f) : !(v0 > 0.0f);
+  const uint32_t r = bits + (inc ? 1u : 0xffffffffu);
+  const bool stays = up ? (v == kInf) : (v == -kInf);
+  return stays ? v : __uint_as_float(r);
+}
 RT_DEV f3 offset_ray_origin(f3 p, f3 p_error, f3 n, f3 w) {  // rc/geometry/mod.rs:203-220
   float d = dot(abs3(n), p_error);
   f3 offset = d * n;
   if (dot(w, n) < 0.0f) offset = -offset;
   f3 po = p + offset;
-  if (offset.x > 0.0f) po.x = next_float_up(po.x); else if (offset.x < 0.0f) po.x = next_float_down(po.x);
-  if (offset.y > 0.0f) po.y = next_float_up(po.y); else if (offset.y < 0.0f) po.y = next_float_down(po.y);
-  if (offset.z > 0.0f) po.z = next_float_up(po.z); else if (offset.z < 0.0f) po.z = next_float_down(po.z);
+  if ((offset.x > 0.0f) | (offset.x < 0.0f)) po.x = next_float_toward(po.x, offset.x > 0.0f);
+  if ((offset.y > 0.0f) | (offset.y < 0.0f)) po.y = next_float_toward(po.y, offset.y > 0.0f);
+  if ((offset.z > 0.0f) | (offset.z < 0.0f)) po.z = next_float_toward(po.z, offset.z > 0.0f);
   return po;
 }
 

@@ -771,6 +771,25 @@ extern "C" void rt_scene_destroy(rt_scene* s) {
   (void)hipSetDevice(s->device);
   delete s;
 }
+__global__ void k_offset_ray_origin(const float* __restrict__ p, const float* __restrict__ pe, const float* __restrict__ n, const float* __restrict__ w, unsigned long long count, float* __restrict__ out) {
+  const unsigned long long i = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= count) return;
+  const f3 r = offset_ray_origin(mk3(p[3 * i], p[3 * i + 1], p[3 * i + 2]), mk3(pe[3 * i], pe[3 * i + 1], pe[3 * i + 2]), mk3(n[3 * i], n[3 * i + 1], n[3 * i + 2]), mk3(w[3 * i], w[3 * i + 1], w[3 * i + 2]));
+  out[3 * i] = r.x; out[3 * i + 1] = r.y; out[3 * i + 2] = r.z;
+}
+extern "C" int rt_offset_ray_origin(const float* p, const float* p_error, const float* n, const float* w, uint64_t count, float* out) {
+  if (!rt_device_available()) return fail(RT_ERR_NO_DEVICE, "no HIP device visible; this backend has no CPU fallback");
+  if (!p || !p_error || !n || !w || !out || count == 0) return fail(RT_ERR_INVALID, "bad rt_offset_ray_origin arguments");
+  DevBuf b[5];
+  const size_t bytes = (size_t)count * 12;
+  const float* src[4] = {p, p_error, n, w};
+  for (int k = 0; k < 5; ++k) HIP_TRY(b[k].ensure(bytes));
+  for (int k = 0; k < 4; ++k) HIP_TRY(hipMemcpy(b[k].p, src[k], bytes, hipMemcpyHostToDevice));
+  hipLaunchKernelGGL(k_offset_ray_origin, dim3((unsigned)((count + 255) / 256)), dim3(256), 0, nullptr, b[0].as<float>(), b[1].as<float>(), b[2].as<float>(), b[3].as<float>(), (unsigned long long)count, b[4].as<float>());
+  HIP_TRY(hipGetLastError());
+  HIP_TRY(hipMemcpy(out, b[4].p, bytes, hipMemcpyDeviceToHost));
+  return RT_OK;
+}
 extern "C" int rt_scene_query(rt_scene* s, int32_t what) {
   if (!s) return fail(RT_ERR_INVALID, "null scene");
   if (what == RT_QUERY_LDS_RESIDENT) return s->small ? 1 : 0;

@@ -1533,6 +1533,7 @@ RT_DEV bool slab_geom(float4 n0, float4 n1, const Ray& ray, f3 inv_dir, int neg_
   return !miss_xy & !miss_z & (tmax > 0.0f);
 }
 #define RT_PAIR_LEAF 0x80000000u
+#define RT_PAIR_TOP 0x10000000u  // (k_trace_top: the child is one of the LDS-resident top records, named by its slot)
 
 // An object's tree (TransformedPrimitive::intersect / intersect_p -> the object's BVH, rc/primitive.rs:90-101) walked as child pairs: the steps of
 // pair_interior_step / pair_leaf_step / pair_pop for ONE ray, run to completion inside the top level's leaf step. Objects hold plain triangles. r.t_max shrinks
@@ -1599,6 +1600,16 @@ RT_DEV bool nested_pair_walk(const float4* __restrict__ pairs, const float4* __r
 #ifndef RT_TTOP
 #define RT_TTOP 1
 #endif
+// RT_PUSH_PREFETCH (round 5, measurement knob): these kernels wait for memory with a seventh of the bandwidth in use, and an entry that is pushed is usually
+// popped a few steps later from HBM. Pushing an interior entry therefore also REQUESTS one word of its record (a load whose value nothing needs: it is folded
+// into a register at the next push, when it has long arrived, and that register reaches memory only if it equals a constant it cannot equal by design of the
+// sink - the lane's own dead stack slot), so the pop finds the line in L2.
+#ifndef RT_PUSH_PREFETCH
+#define RT_PUSH_PREFETCH 0
+#endif
+#define RT_PF_PAIR(L, base, code) do { if (RT_PUSH_PREFETCH && !((code) & (RT_PAIR_LEAF | RT_PAIR_TOP))) { (L).pf_acc ^= (L).pf; (L).pf = __float_as_uint((base)[4 * (size_t)((code) & 0x0fffffffu)].x); } } while (0)
+#define RT_PF_QUAD(L, base, code) do { if (RT_PUSH_PREFETCH && (code) != 0xffffffffu && !((code) & RT_PAIR_LEAF)) { (L).pf_acc ^= (L).pf; (L).pf = __float_as_uint((base)[8 * (size_t)((code) & 0x1fffffffu)].x); } } while (0)
+#define RT_PF_SINK(L, tstack) do { if (RT_PUSH_PREFETCH && ((L).pf_acc ^ (L).pf) == 0x7fc1a5a5u && (L).sp == 0x40000000) (tstack)[0] = 0.0f; } while (0)
 struct PairLane {
   bool active, found; unsigned pid; float dw;
   // registers are the currency of this kernel (86 -> 80 VGPRs is one more wave per SIMD): the direction signs are read off inv_dir where
@@ -1617,6 +1628,7 @@ struct PairLane {
   RT_DEV RayPre rp() const { RayPre r; r.kz = kz & 3; r.kx = r.kz + 1; if (r.kx == 3) r.kx = 0; r.ky = r.kx + 1; if (r.ky == 3) r.ky = 0; r.sx = sx; r.sy = sy; r.sz = sz; return r; }
   RT_DEV void set_rp(const RayPre& r) { kz = (kz & 4) | r.kz; sx = r.sx; sy = r.sy; sz = r.sz; }
   int sp, prim; unsigned cur; TriHit hit;
+  unsigned pf, pf_acc;  // RT_PUSH_PREFETCH: the word requested from the record of the entry pushed last, folded into pf_acc at the next push (never read for its value)
   float ttop;  // closest hit: the deferred tmin of the entry on TOP of the to-visit stack (RT_TTOP), so that a pop compares a register and the load of the next entry's tmin is in flight long before the next pop
   int kz;  // (apart from inv_dir: written together as neighbours, the two become one 16-byte store to a private copy of the lane's state - 24 bytes of scratch per lane)
 };
@@ -1701,7 +1713,7 @@ RT_DEV void pair_interior_step(PairLane& L, const TraceOut& o, const float4* __r
   bool ff = ANY && r.far_first;
   if (ANY && RT_ANY_ORDER >= 3 && RT_ANY_ORDER != 8 && ((code_n ^ code_f) & RT_PAIR_LEAF) != 0u) ff = (code_f & RT_PAIR_LEAF) != 0u;  // exactly one child is a leaf: its primitives first
   const unsigned first = ff ? code_f : code_n, second = ff ? code_n : code_f;  // (closest hit: always near, far)
-  if (r.hit_n & r.keep_f) { stack[L.sp * BLOCK] = second; if (!ANY) { tstack[(size_t)L.sp * grid_lanes] = r.tmin_f; L.ttop = r.tmin_f; } ++L.sp; L.cur = first; }
+  if (r.hit_n & r.keep_f) { stack[L.sp * BLOCK] = second; if (!ANY) { tstack[(size_t)L.sp * grid_lanes] = r.tmin_f; L.ttop = r.tmin_f; } ++L.sp; L.cur = first; RT_PF_PAIR(L, pairs, second); }
   else if (r.hit_n) L.cur = code_n;
   else if (r.keep_f) L.cur = code_f;
   else pair_pop<ANY, BLOCK>(L, o, stack, tstack, grid_lanes);
@@ -1765,7 +1777,7 @@ __global__ void __launch_bounds__(BLOCK, (GENERAL == RT_GEN_NO_MASKS && !ANY) ? 
   PairLane L;
   L.active = false; L.found = false; L.pid = 0; L.dw = 0.0f;
   L.ray.o = L.ray.d = mk3(0, 0, 0); L.ray.t_max = 0.0f; L.set_inv(mk3(0, 0, 0)); L.set_rp(ray_pre(L.ray));
-  L.sp = 0; L.prim = -1; L.cur = 0; L.ttop = 0.0f; L.hit.t = kInf; L.hit.b0 = L.hit.b1 = L.hit.b2 = 0.0f;
+  L.sp = 0; L.prim = -1; L.cur = 0; L.ttop = 0.0f; L.pf = L.pf_acc = 0u; L.hit.t = kInf; L.hit.b0 = L.hit.b1 = L.hit.b2 = 0.0f;
 
   for (;;) {
     const unsigned long long idle = __ballot(!L.active);
@@ -1804,6 +1816,7 @@ __global__ void __launch_bounds__(BLOCK, (GENERAL == RT_GEN_NO_MASKS && !ANY) ? 
       }
     }
   }
+  RT_PF_SINK(L, tstack);
   if (stats) {
     for (int off = 32; off > 0; off >>= 1) n_rays += __shfl_down(n_rays, off);
     if (lane == 0u && n_rays) atomicAdd(&stats[st_rays], (unsigned long long)n_rays);
@@ -1842,7 +1855,7 @@ __global__ void __launch_bounds__(BLOCK, 4) k_trace_inst(DScene sc, TraceIO io, 
   PairLane L;
   L.active = false; L.found = false; L.pid = 0; L.dw = 0.0f;
   L.ray.o = L.ray.d = mk3(0, 0, 0); L.ray.t_max = 0.0f; L.set_inv(mk3(0, 0, 0)); L.set_rp(ray_pre(L.ray));
-  L.sp = 0; L.prim = -1; L.cur = 0; L.ttop = 0.0f; L.hit.t = kInf; L.hit.b0 = L.hit.b1 = L.hit.b2 = 0.0f;
+  L.sp = 0; L.prim = -1; L.cur = 0; L.ttop = 0.0f; L.pf = L.pf_acc = 0u; L.hit.t = kInf; L.hit.b0 = L.hit.b1 = L.hit.b2 = 0.0f;
   unsigned inst = RT_INST_NONE, node_base = 0u, prim_base = 0u, id_base = 0u; int sp_base = -1;  // the instance the lane is inside, its records, the stack height it was entered at
 
   // next pending entry that still passes tmin < t_max; an object whose entries are used up is left first; no entry left: the ray is complete
@@ -1993,7 +2006,7 @@ __global__ void __launch_bounds__(BLOCK, 4) k_trace_inst(DScene sc, TraceIO io, 
 #ifndef RT_TOP_LDS_DEPTH
 #define RT_TOP_LDS_DEPTH 16
 #endif
-#define RT_PAIR_TOP 0x10000000u
+
 template <int BLOCK>
 struct SplitStack {  // lds: this lane's column of [RT_TOP_LDS_DEPTH][BLOCK]; hbm: this lane's column of [deeper][grid lanes]
   unsigned* lds; unsigned* hbm; size_t grid_lanes;
@@ -2029,7 +2042,7 @@ RT_DEV void top_interior_step(PairLane& L, const TraceOut& o, const float4* __re
   bool ff = ANY && r.far_first;
   if (ANY && RT_ANY_ORDER >= 3 && RT_ANY_ORDER != 8 && ((code_n ^ code_f) & RT_PAIR_LEAF) != 0u) ff = (code_f & RT_PAIR_LEAF) != 0u;
   const unsigned first = ff ? code_f : code_n, second = ff ? code_n : code_f;
-  if (r.hit_n & r.keep_f) { stk.put(L.sp, second); if (!ANY) { tstack[(size_t)L.sp * grid_lanes] = r.tmin_f; L.ttop = r.tmin_f; } ++L.sp; L.cur = first; }
+  if (r.hit_n & r.keep_f) { stk.put(L.sp, second); if (!ANY) { tstack[(size_t)L.sp * grid_lanes] = r.tmin_f; L.ttop = r.tmin_f; } ++L.sp; L.cur = first; RT_PF_PAIR(L, pairs, second); }
   else if (r.hit_n) L.cur = code_n;
   else if (r.keep_f) L.cur = code_f;
   else top_pop<ANY, BLOCK>(L, o, stk, tstack, grid_lanes);
@@ -2065,7 +2078,7 @@ __global__ void __launch_bounds__(BLOCK, GENERAL ? 4 : 6) k_trace_top(DScene sc,
   PairLane L;
   L.active = false; L.found = false; L.pid = 0; L.dw = 0.0f;
   L.ray.o = L.ray.d = mk3(0, 0, 0); L.ray.t_max = 0.0f; L.set_inv(mk3(0, 0, 0)); L.set_rp(ray_pre(L.ray));
-  L.sp = 0; L.prim = -1; L.cur = 0; L.ttop = 0.0f; L.hit.t = kInf; L.hit.b0 = L.hit.b1 = L.hit.b2 = 0.0f;
+  L.sp = 0; L.prim = -1; L.cur = 0; L.ttop = 0.0f; L.pf = L.pf_acc = 0u; L.hit.t = kInf; L.hit.b0 = L.hit.b1 = L.hit.b2 = 0.0f;
   for (;;) {
     const unsigned long long idle = __ballot(!L.active);
     if (!exhausted && (unsigned)__popcll(idle) >= (idle == ~0ull ? 1u : refill_min)) {  // the refill scheme of k_trace_pair
@@ -2098,6 +2111,7 @@ __global__ void __launch_bounds__(BLOCK, GENERAL ? 4 : 6) k_trace_top(DScene sc,
       }
     }
   }
+  RT_PF_SINK(L, tstack);
   if (stats) {
     for (int off = 32; off > 0; off >>= 1) n_rays += __shfl_down(n_rays, off);
     if (lane == 0u && n_rays) atomicAdd(&stats[st_rays], (unsigned long long)n_rays);
@@ -2183,7 +2197,7 @@ RT_DEV void quad_interior_step(PairLane& L, const TraceOut& o, const float4* __r
 #pragma unroll
     for (int e = 0; e < j; ++e) earlier |= h[e];
     if (h[j]) {
-      if (earlier) { stack[L.sp * BLOCK] = c[j]; if (!ANY) { tstack[(size_t)L.sp * grid_lanes] = t[j]; L.ttop = t[j]; } ++L.sp; }
+      if (earlier) { stack[L.sp * BLOCK] = c[j]; if (!ANY) { tstack[(size_t)L.sp * grid_lanes] = t[j]; L.ttop = t[j]; } ++L.sp; RT_PF_QUAD(L, quads, c[j]); }
       else { entered = true; next = c[j]; }
     }
   }
@@ -2268,7 +2282,7 @@ __global__ void __launch_bounds__(BLOCK, RT_GEN_MIN_WAVES(GENERAL)) k_trace_quad
   PairLane L;
   L.active = false; L.found = false; L.pid = 0; L.dw = 0.0f;
   L.ray.o = L.ray.d = mk3(0, 0, 0); L.ray.t_max = 0.0f; L.set_inv(mk3(0, 0, 0)); L.set_rp(ray_pre(L.ray));
-  L.sp = 0; L.prim = -1; L.cur = 0; L.ttop = 0.0f; L.hit.t = kInf; L.hit.b0 = L.hit.b1 = L.hit.b2 = 0.0f;
+  L.sp = 0; L.prim = -1; L.cur = 0; L.ttop = 0.0f; L.pf = L.pf_acc = 0u; L.hit.t = kInf; L.hit.b0 = L.hit.b1 = L.hit.b2 = 0.0f;
   for (;;) {
     const unsigned long long idle = __ballot(!L.active);
     if (!exhausted && (unsigned)__popcll(idle) >= (idle == ~0ull ? 1u : refill_min)) {  // same refill scheme as k_trace_pair
@@ -2302,6 +2316,7 @@ __global__ void __launch_bounds__(BLOCK, RT_GEN_MIN_WAVES(GENERAL)) k_trace_quad
       }
     }
   }
+  RT_PF_SINK(L, tstack);
   if (stats) {
     for (int off = 32; off > 0; off >>= 1) n_rays += __shfl_down(n_rays, off);
     if (lane == 0u && n_rays) atomicAdd(&stats[st_rays], (unsigned long long)n_rays);

@@ -480,6 +480,16 @@ def sampler_tables(spp, dims, pixel0, n_pixels, plain=False):
     return sc, pm
 
 
+def offset_ray_origin(p, p_error, n, w):
+    """offset_ray_origin (rc/geometry/mod.rs:203-220) on the device for (k, 3) float32 arrays: the parity hook of the ulp stepping every spawned ray goes through."""
+    a = [np.ascontiguousarray(x, np.float32).reshape(-1, 3) for x in (p, p_error, n, w)]
+    out = np.zeros_like(a[0])
+    rc = hip_lib().rt_offset_ray_origin(_p(a[0]), _p(a[1]), _p(a[2]), _p(a[3]), C.c_uint64(a[0].shape[0]), _p(out))
+    if rc < 0:
+        raise BackendError(f"rt_offset_ray_origin failed ({rc}): {hip_lib().rt_last_error().decode(errors='replace')}")
+    return out
+
+
 def film_to_rgb(film_xyzw: np.ndarray, scale: float = 1.0) -> np.ndarray:
     """Film::write_image's pixel maths (rc/film.rs:196-234) in float32 numpy: XYZ -> RGB, / weight, clamp, * scale."""
     f = np.asarray(film_xyzw, np.float32)

@@ -115,6 +115,45 @@ def test_rays_with_zero_direction_components_take_the_reference_selects(gpu_host
     assert np.array_equal(o.trace(rays, True)["occluded"], h.trace(rays, True, count=False)["occluded"])
 
 
+def test_offset_ray_origin_steps_ulps_like_the_reference(gpu_host, orc):
+    """offset_ray_origin (geometry/mod.rs:203-220): the device steps a coordinate up or down with ONE fused sequence (next_float_toward, round 5); the reference has
+    next_float_up / next_float_down (lib.rs:227-262). Bit-equal on ordinary points and on every special value: zeros of both signs, denormals, the largest floats,
+    infinities, NaN, zero offsets (no step), normals of both orientations."""
+    rng = np.random.default_rng(11)
+    n = 20000
+    specials = np.array([0.0, -0.0, 1e-45, -1e-45, 1.1754944e-38, -1.1754944e-38, 3.4028235e38, -3.4028235e38, np.inf, -np.inf, np.nan, 1.0, -1.0, 555.0], np.float32)
+    p = rng.uniform(-600, 600, (n, 3)).astype(np.float32)
+    k = rng.integers(0, n, 3000)
+    p[k, rng.integers(0, 3, 3000)] = specials[rng.integers(0, len(specials), 3000)]
+    pe = (np.abs(p) * np.float32(4e-7)).astype(np.float32)
+    pe[~np.isfinite(pe)] = 0.0
+    nn = rng.normal(size=(n, 3)).astype(np.float32)
+    nn[rng.integers(0, n, 2000), rng.integers(0, 3, 2000)] = 0.0      # zero offset components: that coordinate is not stepped
+    nn[rng.integers(0, n, 500)] = 0.0                                # a zero normal: nothing moves
+    nn = (nn / np.maximum(np.linalg.norm(nn, axis=1, keepdims=True), np.float32(1e-20))).astype(np.float32)
+    w = rng.normal(size=(n, 3)).astype(np.float32)
+    got = gpu_host.offset_ray_origin(p, pe, nn, w)
+    # the reference's arithmetic in float32, its two stepping functions from the oracle
+    f = np.float32
+    an = np.abs(nn)
+    d = ((an[:, 0] * pe[:, 0]).astype(f) + (an[:, 1] * pe[:, 1]).astype(f)).astype(f) + (an[:, 2] * pe[:, 2]).astype(f)
+    off = (d[:, None] * nn).astype(f)
+    dwn = ((w[:, 0] * nn[:, 0]).astype(f) + (w[:, 1] * nn[:, 1]).astype(f)).astype(f) + (w[:, 2] * nn[:, 2]).astype(f)
+    off = np.where((dwn < 0)[:, None], -off, off).astype(f)
+    with np.errstate(invalid="ignore"):
+        po = (p + off).astype(f)
+    L = orc.lib()
+    want = po.copy()
+    for i, c in zip(*np.nonzero(off > 0)):
+        want[i, c] = L.orc_next_float_up(float(po[i, c])) if not np.isnan(po[i, c]) else np.float32(np.uint32(po[i, c].view(np.uint32) - np.uint32(1)).view(np.float32))
+    for i, c in zip(*np.nonzero(off < 0)):
+        want[i, c] = L.orc_next_float_down(float(po[i, c])) if not np.isnan(po[i, c]) else np.float32(np.uint32(po[i, c].view(np.uint32) + np.uint32(1)).view(np.float32))
+    fin = ~np.isnan(want)
+    assert np.array_equal(bits(got)[fin], bits(want)[fin])
+    assert np.array_equal(np.isnan(got), np.isnan(want))
+    assert (off > 0).sum() > 10000 and (off < 0).sum() > 10000 and (off == 0).sum() > 1000
+
+
 @pytest.mark.parametrize("spp", [1, 16, 64, 1024])
 def test_sampler_tables_match_oracle(gpu_host, orc, spp):
     n = 130 if spp <= 64 else 66  # more than one 64-lane block, ragged tail
