@@ -53,6 +53,7 @@ struct DScene {
   const DSphere* spheres; // analytic spheres: a primitive whose flags carry bit 6 (RT_PRIM_SPHERE) holds its world box in p0 / p1 and its index as the bits of p2.x
   const DTexture* textures; const DImage* images; const DMaterial* materials; const DLight* lights;
   int n_lights; int n_infinite; int infinite_ids[4];
+  int n_lights_all;  // sampled lights + the emitters no light list holds: records in `lights`
   int needs_differentials;  // some texture reads dudx.. / dpdx.. (image maps, closed-form checkerboards, fbm)
   f3 wb_min, wb_max;
   // light distribution (rc/lightdistrib.rs): dense voxel table or a single uniform distribution

@@ -55,6 +55,7 @@ struct rt_scene {
   DScene d{};
   bool small = false;
   bool lambert_materials = false;  // the material half of lambert_only: with other light kinds k_shade<3>
+  bool lds_records = false;   // the scene's shade / traversal records and its light table fit the shade kernel's LDS (k_shade<1, .., LDSREC>)
   bool lambert_only = false;  // every material is matte{constant Kd, sigma == 0} and every light an area light: k_shade<1>
   bool lean_qlights = false;  // LEAN with sphere lights: the QLIGHTS forms of k_shade<3 | 5 | 6>, quadric hits routed to the generic kernel
   bool lean_shade = false;    // every light an area light on a triangle and every texture a constant: the LEAN forms of k_shade<3 | 5 | 6> (no out-of-line evaluator, three waves)
@@ -752,6 +753,8 @@ extern "C" int rt_scene_create(const rt_scene_desc* desc, int device, rt_scene**
   if (s->tri_rec.ensure((size_t)desc->n_tris * 128) != hipSuccess) { delete s; return fail(RT_ERR_OOM, "shade record allocation failed"); }
   d.tri_rec = s->tri_rec.as<float4>();
   hipLaunchKernelGGL(k_tri_records, dim3((desc->n_tris + 255u) / 256u), dim3(256), 0, nullptr, d, s->tri_rec.as<float4>());
+  d.n_lights_all = (int)n_all_lights;
+  s->lds_records = s->small && !s->has_instances && !s->has_spheres && desc->n_tris <= RT_SMALL_TRIS && n_all_lights <= RT_LDS_LIGHTS && !(getenv("RTX_SHADE_LDSREC") && getenv("RTX_SHADE_LDSREC")[0] == '0');  // k_shade<1, .., LDSREC> (RTX_SHADE_LDSREC=0: measurement knob)
   if (n_all_lights) hipLaunchKernelGGL(k_light_consts, dim3((n_all_lights + 255u) / 256u), dim3(256), 0, nullptr, d, s->lights.as<DLight>(), (int)n_all_lights);
   if (hipGetLastError() != hipSuccess) { delete s; return fail(RT_ERR_HIP, "constant precomputation launch failed"); }
   if (s->self.ensure(sizeof(DScene)) != hipSuccess) { delete s; return fail(RT_ERR_OOM, "scene record allocation failed"); }
@@ -1572,7 +1575,12 @@ extern "C" int rt_render(rt_scene* s, const rt_camera* cam, const rt_film_desc* 
         tm.end();
         if (bounce <= 1) HIP_TRY(hipStreamWaitEvent(stream, s->ev_tables[buf][bounce + 1], 0));  // table groups 1 / 2: first read by the shade launches of bounce 0 / 1
 #define RT_SHADE(MODE, P) stats.launches_shade += 1, launch_shade<MODE>(gshade, lean_shade, bounce >= 1 && !bounced_off, sgrid, sblock, stream, s->d, fp, P, qlights)
-        if (s->lambert_only) { tm.begin(&stats.ms_shade_lambert_const); hipLaunchKernelGGL(k_shade<1>, dim3(sgrid), dim3(sblock), 0, stream, s->d, fp, ps); tm.end(); stats.launches_shade += 1; }
+        if (s->lambert_only) {
+          tm.begin(&stats.ms_shade_lambert_const);
+          if (s->lds_records) hipLaunchKernelGGL((k_shade<1, false, false, false, false, true>), dim3(sgrid), dim3(sblock), 0, stream, s->d, fp, ps);
+          else hipLaunchKernelGGL(k_shade<1>, dim3(sgrid), dim3(sblock), 0, stream, s->d, fp, ps);
+          tm.end(); stats.launches_shade += 1;
+        }
         else if (s->lambert_materials) { tm.begin(&stats.ms_shade_lambert); RT_SHADE(3, ps); tm.end(); }
         else if (!use_bins) { tm.begin(&stats.ms_shade_generic); RT_SHADE(0, ps); tm.end(); }
         else {

@@ -2739,8 +2739,25 @@ RT_DEVN int instance_fill_interaction(const DScene& sc, unsigned hit_id, float o
 // an emitter sphere (rt_scene_create: sphere_lights_clear), so Sphere::sample_si and Sphere::pdf_wi only ever take their cone branches (sphere.rs:264-308,
 // 325-333) - inlined here, no out-of-line evaluator, three waves per SIMD like the other LEAN forms. Round 3 shaded such scenes through the GENERAL forms:
 // 256 VGPRs and 352 - 448 B of scratch.
-template <int MODE, bool GENERAL = false, bool LEAN = false, bool BOUNCED = false, bool QLIGHTS = false>
+#define RT_LDS_LIGHTS 8
+template <int MODE, bool GENERAL = false, bool LEAN = false, bool BOUNCED = false, bool QLIGHTS = false, bool LDSREC = false>
 __global__ void __launch_bounds__(256, (MODE == 1 || LEAN || BOUNCED) ? ((LEAN || BOUNCED) ? (BOUNCED ? RT_SHADE_BOUNCED_MIN_WAVES : RT_SHADE_LEAN_MIN_WAVES) : RT_SHADE_MIN_WAVES) : (MODE == 3 && !GENERAL ? RT_SHADE3_MIN_WAVES : ((MODE == 5 || MODE == 6) && !GENERAL ? RT_SHADE56_MIN_WAVES : (MODE != 0 && GENERAL ? RT_SHADE_GEN_MIN_WAVES : RT_SHADE0_MIN_WAVES)))) k_shade(DScene sc, FrameParams fp, PassState ps) {
+  // LDSREC (MODE 1, round 5): a scene of <= RT_SMALL_TRIS triangles and <= RT_LDS_LIGHTS emitters keeps its shade records, traversal records and light table in LDS
+  // for the launch. k_shade<1> is busy issuing VALU instructions half of the time and waits for memory two thirds of a wave's life (SQ counters), yet neither ~10 % fewer
+  // instructions nor an earlier scan load moved it - what it waits for is the texture path's address processing: ~40 vector memory instructions per vertex, the
+  // gathers among them (a vertex's triangle, the picked light, the light's triangle: every lane its own address) served a few lanes per clock. Read from LDS they
+  // do not go there at all. Same values, same arithmetic.
+  __shared__ float4 s_rec[LDSREC ? 8 * RT_SMALL_TRIS : 1];
+  __shared__ float4 s_trip[LDSREC ? 3 * RT_SMALL_TRIS : 1];
+  __shared__ unsigned s_lights[LDSREC ? RT_LDS_LIGHTS * (sizeof(DLight) / 4) : 1];
+  if (LDSREC) {
+    for (unsigned k = threadIdx.x; k < 8u * sc.n_tris; k += blockDim.x) s_rec[k] = sc.tri_rec[k];
+    for (unsigned k = threadIdx.x; k < 3u * sc.n_tris; k += blockDim.x) s_trip[k] = sc.tri_p[k];
+    const unsigned nl = (unsigned)sc.n_lights_all * (unsigned)(sizeof(DLight) / 4);
+    for (unsigned k = threadIdx.x; k < nl; k += blockDim.x) s_lights[k] = ((const unsigned*)sc.lights)[k];
+    __syncthreads();
+    sc.tri_rec = (const float4*)s_rec; sc.tri_p = (const float4*)s_trip; sc.lights = (const DLight*)s_lights;
+  }
   QView qv; if (ps.cnt_in) qv.init(ps.q_in, ps.cnt_in, ps.shard_cap);
   unsigned first = 0, count = ps.cnt_in ? qv.total() : ps.cap;  // no counts: bounce 0 of a pass whose samples are all traced (entry i = slot i = path i)
   if (MODE != 1 && ps.range) { first = ps.range[0]; count = ps.range[1]; }
