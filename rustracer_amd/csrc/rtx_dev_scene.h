@@ -54,6 +54,7 @@ struct DScene {
   const DTexture* textures; const DImage* images; const DMaterial* materials; const DLight* lights;
   int n_lights; int n_infinite; int infinite_ids[4];
   int n_lights_all;  // sampled lights + the emitters no light list holds: records in `lights`
+  int n_materials, n_textures;
   int needs_differentials;  // some texture reads dudx.. / dpdx.. (image maps, closed-form checkerboards, fbm)
   f3 wb_min, wb_max;
   // light distribution (rc/lightdistrib.rs): dense voxel table or a single uniform distribution
@@ -61,6 +62,8 @@ struct DScene {
   // tables of the BUILT voxels only (those that can hold a surface point): [slot][n_lights], [slot][n_lights+1], [slot]; ld_slot[voxel] = slot or -1.
   // Memory is O(built voxels x lights) - a dense 64^3 table of 10^5 emitters would not fit any GPU
   const float* ld_func; const float* ld_cdf; const float* ld_int; const int* ld_slot;
+  const float4* ld_dense8;  // ... the same records indexed by VOXEL (an unbuilt voxel: func_int = -1): no slot to fetch first; NULL where the grid is too large for it
+  const float4* ld_rows8;  // n_lights <= 3: [slot] {func_int, func[0..2]} {cdf[0..3]} - a voxel's whole distribution in two 16-byte loads in flight together (round 5); else NULL
   const unsigned short* ld_guide; int ld_glog;  // guide tables of the rows' CDF searches, [slot][2^ld_glog + 1] (see DLight::guide); ld_glog < 0: none (few lights)
   // This record in device memory. A kernel takes its DScene by value (fields in SGPRs); an out-of-line device function that wants the scene is handed
   // `*sc.self` instead of `sc`: a reference to the kernel argument would force a 300-byte private copy of it into every lane's scratch, read back

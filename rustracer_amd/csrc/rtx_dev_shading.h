@@ -573,6 +573,15 @@ RT_DEV void d1_sample_discrete_guided(const float* func, const float* cdf, float
   pdf = func_int > 0.0f ? vdiv(func[offset], func_int * (float)n) : 0.0f;
   off = offset;
 }
+// Distribution1D::sample_discrete (distribution1d.rs:70-79) of a distribution of n <= 3 entries held in registers: r0 = {func_int, func[0..2]}, r1 = {cdf[0..3]}
+// (DScene::ld_rows8). find_interval over a non-decreasing array is (the number of entries <= u) - 1, clamped: the same index the bisection returns; same quotient.
+RT_DEV void d1_sample_discrete_row8(float4 r0, float4 r1, int n, float u, int& off, float& pdf) {
+  const int cnt = (r1.x <= u ? 1 : 0) + ((n >= 1 && r1.y <= u) ? 1 : 0) + ((n >= 2 && r1.z <= u) ? 1 : 0) + ((n >= 3 && r1.w <= u) ? 1 : 0);
+  const int offset = clampi(cnt - 1, 0, n - 1);
+  const float f = offset == 0 ? r0.y : (offset == 1 ? r0.z : r0.w);
+  pdf = r0.x > 0.0f ? vdiv(f, r0.x * (float)n) : 0.0f;
+  off = offset;
+}
 RT_DEV void d1_sample_discrete(const float* func, const float* cdf, float func_int, int n, float u, int& off, float& pdf) {  // :70-79
   int offset = find_interval_le(cdf, n + 1, u);
   pdf = func_int > 0.0f ? vdiv(func[offset], func_int * (float)n) : 0.0f;

@@ -78,7 +78,7 @@ struct rt_scene {
   bool masked_emitters = false;  // ... and some of them emit: every vertex is shaded by k_shade<0, true> (Shape::pdf_wi evaluates the mask)
   std::vector<DLight> h_lights;
   // light distribution tables (built per render, rc/integrator/path.rs:86-94)
-  DevBuf ld_func, ld_cdf, ld_int, ld_mark, ld_list, ld_slot, ld_guide;
+  DevBuf ld_func, ld_cdf, ld_int, ld_mark, ld_list, ld_slot, ld_guide, ld_rows8, ld_dense8;
   DevBuf self;  // `d` in device memory (DScene::self), rewritten whenever `d` changes
   int ld_strategy_built = -1; bool ld_all_voxels = false;  // the tables are a function of the scene alone: built once per strategy, kept across frames
   std::mutex render_mutex;  // rt_render shares the workspace below: concurrent calls on one rt_scene take turns
@@ -497,6 +497,7 @@ extern "C" int rt_scene_create(const rt_scene_desc* desc, int device, rt_scene**
   d.spheres = s->has_spheres ? s->spheres.as<DSphere>() : nullptr;
   d.instances = s->has_instances ? s->instances.as<DInstance>() : nullptr; d.n_instances = s->has_instances ? desc->n_instances : 0u; d.n_top_prims = n_top_prims;
   d.textures = s->textures.as<DTexture>(); d.images = s->images.as<DImage>(); d.materials = s->materials.as<DMaterial>(); d.lights = s->lights.as<DLight>();
+  d.n_materials = (int)desc->n_materials; d.n_textures = (int)desc->n_textures;
   d.n_lights = (int)desc->n_lights;
   d.wb_min = f3{desc->nodes[0].bmin[0], desc->nodes[0].bmin[1], desc->nodes[0].bmin[2]};
   d.wb_max = f3{desc->nodes[0].bmax[0], desc->nodes[0].bmax[1], desc->nodes[0].bmax[2]};
@@ -754,7 +755,7 @@ extern "C" int rt_scene_create(const rt_scene_desc* desc, int device, rt_scene**
   d.tri_rec = s->tri_rec.as<float4>();
   hipLaunchKernelGGL(k_tri_records, dim3((desc->n_tris + 255u) / 256u), dim3(256), 0, nullptr, d, s->tri_rec.as<float4>());
   d.n_lights_all = (int)n_all_lights;
-  s->lds_records = s->small && !s->has_instances && !s->has_spheres && desc->n_tris <= RT_SMALL_TRIS && n_all_lights <= RT_LDS_LIGHTS && !(getenv("RTX_SHADE_LDSREC") && getenv("RTX_SHADE_LDSREC")[0] == '0');  // k_shade<1, .., LDSREC> (RTX_SHADE_LDSREC=0: measurement knob)
+  s->lds_records = s->small && !s->has_instances && !s->has_spheres && desc->n_tris <= RT_SMALL_TRIS && n_all_lights <= RT_LDS_LIGHTS && desc->n_materials <= RT_LDS_MATERIALS && desc->n_textures <= RT_LDS_MATERIALS && !(getenv("RTX_SHADE_LDSREC") && getenv("RTX_SHADE_LDSREC")[0] == '0');  // k_shade<1, .., LDSREC> (RTX_SHADE_LDSREC=0: measurement knob)
   if (n_all_lights) hipLaunchKernelGGL(k_light_consts, dim3((n_all_lights + 255u) / 256u), dim3(256), 0, nullptr, d, s->lights.as<DLight>(), (int)n_all_lights);
   if (hipGetLastError() != hipSuccess) { delete s; return fail(RT_ERR_HIP, "constant precomputation launch failed"); }
   if (s->self.ensure(sizeof(DScene)) != hipSuccess) { delete s; return fail(RT_ERR_OOM, "scene record allocation failed"); }
@@ -808,6 +809,7 @@ static int build_light_distribution(rt_scene* s, int strategy, hipStream_t strea
   if (s->ld_strategy_built == strategy && (s->ld_all_voxels || !all_voxels)) return RT_OK;
   s->ld_strategy_built = -1;  // a rebuild that fails half way leaves no table that a later frame could take for valid
   const int nl = s->n_lights;
+  size_t ld_rows_built = 1;  // rows of the tables: one (uniform) or one per built voxel
   const bool uniform = strategy == 1 || nl == 1 || nl == 0;
   // guide tables for the rows' CDF searches (DScene::ld_guide) where a search is long enough to gain from one: >= 64 lights, <= 65534 (u16 entries)
   int glog = -1;
@@ -855,6 +857,7 @@ static int build_light_distribution(rt_scene* s, int strategy, hipStream_t strea
     unsigned n_built = 0;  // once per scene and strategy (the tables are kept): a host round trip here is off every frame's path
     HIP_TRY(hipMemcpyAsync(&n_built, n_list, 4, hipMemcpyDeviceToHost, stream)); HIP_TRY(hipStreamSynchronize(stream));
     const size_t rows = std::max<size_t>(n_built, 1);
+    ld_rows_built = rows;
     if (s->ld_func.ensure(rows * nl * 4) != hipSuccess || s->ld_cdf.ensure(rows * (nl + 1) * 4) != hipSuccess || s->ld_int.ensure(rows * 4) != hipSuccess)
       return fail(RT_ERR_OOM, "light distribution tables do not fit (built voxels x lights)");
     if (glog >= 0 && s->ld_guide.ensure(rows * (((size_t)1 << glog) + 1) * 2) != hipSuccess) return fail(RT_ERR_OOM, "light distribution guide tables do not fit");
@@ -870,6 +873,22 @@ static int build_light_distribution(rt_scene* s, int strategy, hipStream_t strea
   }
   d.ld_func = s->ld_func.as<float>(); d.ld_cdf = s->ld_cdf.as<float>(); d.ld_int = s->ld_int.as<float>(); d.ld_slot = s->ld_slot.as<int>();
   d.ld_guide = glog >= 0 ? s->ld_guide.as<unsigned short>() : nullptr;
+  d.ld_rows8 = nullptr; d.ld_dense8 = nullptr;
+  if (nl >= 1 && nl <= 3 && !(getenv("RTX_LD_ROWS8") && getenv("RTX_LD_ROWS8")[0] == '0')) {  // (measurement knob: 0 = the three separate tables)
+    const size_t n_rows = ld_rows_built;
+    HIP_TRY(s->ld_rows8.ensure(n_rows * 32));
+    hipLaunchKernelGGL(k_lightdist_rows8, dim3((unsigned)((n_rows + 255) / 256)), dim3(256), 0, stream, s->ld_func.as<float>(), s->ld_cdf.as<float>(), s->ld_int.as<float>(), (int)nl, (unsigned)n_rows, s->ld_rows8.as<float4>());
+    HIP_TRY(hipGetLastError());
+    d.ld_rows8 = s->ld_rows8.as<float4>();
+    const unsigned long long n_vox = (unsigned long long)d.nvox[0] * d.nvox[1] * d.nvox[2];
+    static const int dense_mb = getenv("RTX_LD_DENSE_MB") ? atoi(getenv("RTX_LD_DENSE_MB")) : 16;  // (measurement knob: 0 = never)
+    if (!uniform && n_vox * 32ull <= (unsigned long long)dense_mb << 20) {
+      HIP_TRY(s->ld_dense8.ensure((size_t)n_vox * 32));
+      hipLaunchKernelGGL(k_lightdist_dense8, dim3((unsigned)((n_vox + 255) / 256)), dim3(256), 0, stream, s->ld_rows8.as<float4>(), s->ld_slot.as<int>(), n_vox, s->ld_dense8.as<float4>());
+      HIP_TRY(hipGetLastError());
+      d.ld_dense8 = s->ld_dense8.as<float4>();
+    }
+  }
   s->ld_strategy_built = strategy; s->ld_all_voxels = all_voxels;
   HIP_TRY(hipMemcpyAsync(s->self.p, &s->d, sizeof(DScene), hipMemcpyHostToDevice, stream));
   return RT_OK;

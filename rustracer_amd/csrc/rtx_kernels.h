@@ -2740,6 +2740,7 @@ RT_DEVN int instance_fill_interaction(const DScene& sc, unsigned hit_id, float o
 // 325-333) - inlined here, no out-of-line evaluator, three waves per SIMD like the other LEAN forms. Round 3 shaded such scenes through the GENERAL forms:
 // 256 VGPRs and 352 - 448 B of scratch.
 #define RT_LDS_LIGHTS 8
+#define RT_LDS_MATERIALS 16
 template <int MODE, bool GENERAL = false, bool LEAN = false, bool BOUNCED = false, bool QLIGHTS = false, bool LDSREC = false>
 __global__ void __launch_bounds__(256, (MODE == 1 || LEAN || BOUNCED) ? ((LEAN || BOUNCED) ? (BOUNCED ? RT_SHADE_BOUNCED_MIN_WAVES : RT_SHADE_LEAN_MIN_WAVES) : RT_SHADE_MIN_WAVES) : (MODE == 3 && !GENERAL ? RT_SHADE3_MIN_WAVES : ((MODE == 5 || MODE == 6) && !GENERAL ? RT_SHADE56_MIN_WAVES : (MODE != 0 && GENERAL ? RT_SHADE_GEN_MIN_WAVES : RT_SHADE0_MIN_WAVES)))) k_shade(DScene sc, FrameParams fp, PassState ps) {
   // LDSREC (MODE 1, round 5): a scene of <= RT_SMALL_TRIS triangles and <= RT_LDS_LIGHTS emitters keeps its shade records, traversal records and light table in LDS
@@ -2750,13 +2751,18 @@ __global__ void __launch_bounds__(256, (MODE == 1 || LEAN || BOUNCED) ? ((LEAN |
   __shared__ float4 s_rec[LDSREC ? 8 * RT_SMALL_TRIS : 1];
   __shared__ float4 s_trip[LDSREC ? 3 * RT_SMALL_TRIS : 1];
   __shared__ unsigned s_lights[LDSREC ? RT_LDS_LIGHTS * (sizeof(DLight) / 4) : 1];
+  __shared__ unsigned s_mats[LDSREC ? RT_LDS_MATERIALS * (sizeof(DMaterial) / 4) : 1];
+  __shared__ unsigned s_texs[LDSREC ? RT_LDS_MATERIALS * (sizeof(DTexture) / 4) : 1];
   if (LDSREC) {
     for (unsigned k = threadIdx.x; k < 8u * sc.n_tris; k += blockDim.x) s_rec[k] = sc.tri_rec[k];
     for (unsigned k = threadIdx.x; k < 3u * sc.n_tris; k += blockDim.x) s_trip[k] = sc.tri_p[k];
     const unsigned nl = (unsigned)sc.n_lights_all * (unsigned)(sizeof(DLight) / 4);
     for (unsigned k = threadIdx.x; k < nl; k += blockDim.x) s_lights[k] = ((const unsigned*)sc.lights)[k];
+    for (unsigned k = threadIdx.x; k < (unsigned)sc.n_materials * (unsigned)(sizeof(DMaterial) / 4); k += blockDim.x) s_mats[k] = ((const unsigned*)sc.materials)[k];
+    for (unsigned k = threadIdx.x; k < (unsigned)sc.n_textures * (unsigned)(sizeof(DTexture) / 4); k += blockDim.x) s_texs[k] = ((const unsigned*)sc.textures)[k];
     __syncthreads();
     sc.tri_rec = (const float4*)s_rec; sc.tri_p = (const float4*)s_trip; sc.lights = (const DLight*)s_lights;
+    sc.materials = (const DMaterial*)s_mats; sc.textures = (const DTexture*)s_texs;
   }
   QView qv; if (ps.cnt_in) qv.init(ps.q_in, ps.cnt_in, ps.shard_cap);
   unsigned first = 0, count = ps.cnt_in ? qv.total() : ps.cap;  // no counts: bounce 0 of a pass whose samples are all traced (entry i = slot i = path i)
@@ -2834,10 +2840,19 @@ __global__ void __launch_bounds__(256, (MODE == 1 || LEAN || BOUNCED) ? ((LEAN |
         RT_STAMP(2);  // material: textures + lobes
         // light_distribution.lookup(p) (path.rs:154-158)
         const float* ld_func; const float* ld_cdf; float ld_int; long ld_row = 0;
-        if (sc.ld_uniform) { ld_func = sc.ld_func; ld_cdf = sc.ld_cdf; ld_int = sc.ld_int[0]; }
+        float4 ld_r0 = make_float4(0, 0, 0, 0), ld_r1 = ld_r0;  // (DScene::ld_rows8: the voxel's whole distribution, scenes of <= 3 lights)
+        const bool rows8 = sc.ld_rows8 != nullptr;
+        if (sc.ld_uniform) { ld_func = sc.ld_func; ld_cdf = sc.ld_cdf; if (rows8) { ld_r0 = sc.ld_rows8[0]; ld_r1 = sc.ld_rows8[1]; ld_int = ld_r0.x; } else ld_int = sc.ld_int[0]; }
+        else if (sc.ld_dense8 != nullptr) {  // (<= 3 lights, a grid of moderate size: the voxel's record directly, two loads in flight together and no slot before them)
+          const long v = voxel_of(sc, si.hit.p);
+          ld_r0 = sc.ld_dense8[2 * v]; ld_r1 = sc.ld_dense8[2 * v + 1]; ld_int = ld_r0.x; ld_func = sc.ld_func; ld_cdf = sc.ld_cdf;
+        }
         else {
           const long slot = sc.ld_slot[voxel_of(sc, si.hit.p)];
-          if (slot >= 0) { ld_func = sc.ld_func + slot * sc.n_lights; ld_cdf = sc.ld_cdf + slot * (sc.n_lights + 1); ld_int = sc.ld_int[slot]; ld_row = slot; }
+          if (slot >= 0) {
+            ld_func = sc.ld_func + slot * sc.n_lights; ld_cdf = sc.ld_cdf + slot * (sc.n_lights + 1); ld_row = slot;
+            if (rows8) { ld_r0 = sc.ld_rows8[2 * slot]; ld_r1 = sc.ld_rows8[2 * slot + 1]; ld_int = ld_r0.x; } else ld_int = sc.ld_int[slot];
+          }
           else { ld_func = sc.ld_func; ld_cdf = sc.ld_cdf; ld_int = -1.0f; }
         }
         const unsigned nonspec = BSDF_ALL & ~BSDF_SPECULAR;
@@ -2848,7 +2863,8 @@ __global__ void __launch_bounds__(256, (MODE == 1 || LEAN || BOUNCED) ? ((LEAN |
         if (voxel_ok && bsdf.num_nonspecular() > 0 && sc.n_lights > 0) {  // uniform_sample_one_light, integrator/mod.rs:186-220
           float su = smp.get_1d();
           int light_num; float light_pdf;
-          if (MODE != 1 && sc.ld_glog >= 0) d1_sample_discrete_guided(ld_func, ld_cdf, ld_int, sc.n_lights, su, sc.ld_guide + ld_row * ((1 << sc.ld_glog) + 1), sc.ld_glog, light_num, light_pdf);
+          if (rows8) d1_sample_discrete_row8(ld_r0, ld_r1, sc.n_lights, su, light_num, light_pdf);
+          else if (MODE != 1 && sc.ld_glog >= 0) d1_sample_discrete_guided(ld_func, ld_cdf, ld_int, sc.n_lights, su, sc.ld_guide + ld_row * ((1 << sc.ld_glog) + 1), sc.ld_glog, light_num, light_pdf);
           else d1_sample_discrete(ld_func, ld_cdf, ld_int, sc.n_lights, su, light_num, light_pdf);
           RT_STAMP(3);  // light pick: voxel row + discrete search
           if (light_pdf != 0.0f) {
@@ -3191,6 +3207,21 @@ __global__ void __launch_bounds__(256) k_tri_records(DScene sc, float4* __restri
     r[3] = make_float4(f.n.x, f.n.y, f.n.z, ssb.x); r[4] = make_float4(f.ss.x, f.ss.y, f.ss.z, ssb.y); r[5] = make_float4(f.ts.x, f.ts.y, f.ts.z, ssb.z);
   } else { r[3] = make_float4(g.n.x, g.n.y, g.n.z, 0.0f); r[4] = z; r[5] = z; }
   r[6] = make_float4(g.dpdu.x, g.dpdu.y, g.dpdu.z, 0.0f); r[7] = make_float4(g.dpdv.x, g.dpdv.y, g.dpdv.z, 0.0f);
+}
+// DScene::ld_rows8: the tables of a scene with <= 3 lights repacked, one 32-byte record per built voxel
+__global__ void __launch_bounds__(256) k_lightdist_rows8(const float* __restrict__ func, const float* __restrict__ cdf, const float* __restrict__ fint, int n_lights, unsigned rows, float4* __restrict__ out) {
+  const unsigned r = blockIdx.x * blockDim.x + threadIdx.x;
+  if (r >= rows) return;
+  const float* f = func + (size_t)r * n_lights; const float* c = cdf + (size_t)r * (n_lights + 1);
+  out[2 * (size_t)r] = make_float4(fint[r], f[0], n_lights > 1 ? f[1] : 0.0f, n_lights > 2 ? f[2] : 0.0f);
+  out[2 * (size_t)r + 1] = make_float4(c[0], c[1], n_lights > 1 ? c[2] : 0.0f, n_lights > 2 ? c[3] : 0.0f);
+}
+__global__ void __launch_bounds__(256) k_lightdist_dense8(const float4* __restrict__ rows8, const int* __restrict__ slot_of, unsigned long long n_voxels, float4* __restrict__ out) {
+  const unsigned long long v = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (v >= n_voxels) return;
+  const int slot = slot_of[v];
+  out[2 * v] = slot >= 0 ? rows8[2 * (size_t)slot] : make_float4(-1.0f, 0.0f, 0.0f, 0.0f);
+  out[2 * v + 1] = slot >= 0 ? rows8[2 * (size_t)slot + 1] : make_float4(0.0f, 0.0f, 0.0f, 0.0f);
 }
 __global__ void __launch_bounds__(256) k_light_consts(DScene sc, DLight* __restrict__ lights, int n_all /* sampled lights + unlisted emitters */) {
   const int j = (int)(blockIdx.x * blockDim.x + threadIdx.x);
