@@ -392,7 +392,9 @@ def run_workload(scene_name, runner, workload, steps, warmup):
     def shade_roofline():
         verts = (cst["rays_closest"] - tail_nc) / nd_div
         emitted = (cst["rays_shadow"] + cst["rays_mis"] - not_cast + (cst["rays_closest"] - tail_nc - cst["camera_rays"])) / nd_div
-        return 128 * verts + 32 * emitted + 48 * cst["camera_rays"] / nd_div, launches_shade, ms_sh, "shade", verts, "vertex"
+        # one shade STAGE per bounce and pass (= per path-ray trace launch, counted by rt_render); on a class-split queue a stage is several k_shade launches
+        # (rt_stats::launches_shade, in the detail file) - `traffic` (PMC) is per stage as well
+        return 128 * verts + 32 * emitted + 48 * cst["camera_rays"] / nd_div, launches_path, ms_sh, "shade", verts, "vertex"
 
     def roof(algo_bytes, n_launch, ms_kernel, kname, unit_n, unit):
         achieved = algo_bytes / (ms_kernel * 1e-3) / 1e9  # GB/s per device
@@ -424,7 +426,7 @@ def run_workload(scene_name, runner, workload, steps, warmup):
         "s_per_frame": round(ms_step / 1e3, 4),
         "Mrays_per_s": round((cst["rays_closest"] + cst["rays_shadow"] + cst["rays_mis"] - not_cast - tail_nc) / (ms_step * 1e-3) / 1e6, 1),
         "mis_rays_not_cast": int(not_cast), "tail_rays_not_cast": int(tail_nc),
-        "kernel_ms_per_step": kernels_ms, "vertices_by_shade_front_end": verts,
+        "kernel_ms_per_step": kernels_ms, "vertices_by_shade_front_end": verts, "shade_kernel_launches_per_step": int(launches_shade),
         "roofline": roofline, "roofline_second_kernel": roofline_other, "traversal_by_ray_class": classes, "traversal_hbm_share": groups,
         "camera_samples_per_step": int(samples_per_step), "gpu_clocks": clocks.summary(),
     }
