@@ -55,6 +55,8 @@ struct rt_scene {
   DScene d{};
   bool small = false;
   bool lambert_materials = false;  // the material half of lambert_only: with other light kinds k_shade<3>
+  bool lds_records_q = false; // a scene of quadric emitters whose triangles, lights, materials and textures all fit (QLIGHTS forms with LDSREC = 1)
+  bool lds_mats = false;      // ... at least its material and texture tables do (the LEAN forms of the other front-ends)
   bool lds_records = false;   // the scene's shade / traversal records and its light table fit the shade kernel's LDS (k_shade<1, .., LDSREC>)
   bool lambert_only = false;  // every material is matte{constant Kd, sigma == 0} and every light an area light: k_shade<1>
   bool lean_qlights = false;  // LEAN with sphere lights: the QLIGHTS forms of k_shade<3 | 5 | 6>, quadric hits routed to the generic kernel
@@ -755,7 +757,9 @@ extern "C" int rt_scene_create(const rt_scene_desc* desc, int device, rt_scene**
   d.tri_rec = s->tri_rec.as<float4>();
   hipLaunchKernelGGL(k_tri_records, dim3((desc->n_tris + 255u) / 256u), dim3(256), 0, nullptr, d, s->tri_rec.as<float4>());
   d.n_lights_all = (int)n_all_lights;
-  s->lds_records = s->small && !s->has_instances && !s->has_spheres && desc->n_tris <= RT_SMALL_TRIS && n_all_lights <= RT_LDS_LIGHTS && desc->n_materials <= RT_LDS_MATERIALS && desc->n_textures <= RT_LDS_MATERIALS && !(getenv("RTX_SHADE_LDSREC") && getenv("RTX_SHADE_LDSREC")[0] == '0');  // k_shade<1, .., LDSREC> (RTX_SHADE_LDSREC=0: measurement knob)
+  s->lds_records = s->small && !s->has_instances && !s->has_spheres && desc->n_tris <= RT_SMALL_TRIS && n_all_lights <= RT_LDS_LIGHTS && desc->n_materials <= RT_LDS_MATERIALS && desc->n_textures <= RT_LDS_TEXTURES && !(getenv("RTX_SHADE_LDSREC") && getenv("RTX_SHADE_LDSREC")[0] == '0');  // k_shade<1, .., LDSREC> (RTX_SHADE_LDSREC=0: measurement knob)
+  s->lds_records_q = desc->n_tris <= RT_SMALL_TRIS && !s->has_instances && n_all_lights <= RT_LDS_LIGHTS && desc->n_materials <= RT_LDS_MATERIALS && desc->n_textures <= RT_LDS_TEXTURES && !(getenv("RTX_SHADE_LDSREC") && getenv("RTX_SHADE_LDSREC")[0] == '0');
+  s->lds_mats = desc->n_materials <= RT_LDS_MATERIALS && desc->n_textures <= RT_LDS_TEXTURES && !(getenv("RTX_SHADE_LDSREC") && getenv("RTX_SHADE_LDSREC")[0] == '0');  // the LEAN forms: material and texture tables in LDS
   if (n_all_lights) hipLaunchKernelGGL(k_light_consts, dim3((n_all_lights + 255u) / 256u), dim3(256), 0, nullptr, d, s->lights.as<DLight>(), (int)n_all_lights);
   if (hipGetLastError() != hipSuccess) { delete s; return fail(RT_ERR_HIP, "constant precomputation launch failed"); }
   if (s->self.ensure(sizeof(DScene)) != hipSuccess) { delete s; return fail(RT_ERR_OOM, "scene record allocation failed"); }
@@ -1338,11 +1342,25 @@ struct KTimer {  // HIP-event kernel timing on the render stream; events come fr
 // one shade launch of front-end MODE: the GENERAL form (quadric / instance hits, masked emitters), the LEAN form (area lights and constant textures only;
 // front-ends 3 / 5 / 6), or the plain one
 template <int MODE>
-static void launch_shade(bool general, bool lean, bool bounced, unsigned grid, unsigned block, hipStream_t stream, const DScene& d, const FrameParams& fp, const PassState& p, bool qlights = false) {
+static void launch_shade(bool general, bool lean, bool bounced, unsigned grid, unsigned block, hipStream_t stream, const DScene& d, const FrameParams& fp, const PassState& p, bool qlights = false, int lds = 0) {
   // sphere lights over constant textures: the front-end ranges hold triangle vertices only (quadric hits are binned into the generic range)
-  if constexpr (MODE != 0) { if (qlights) { hipLaunchKernelGGL((k_shade<MODE, false, true, false, true>), dim3(grid), dim3(block), 0, stream, d, fp, p); return; } }
+  // lds (LEAN / QLIGHTS forms): 1 = the scene's records, lights, materials and textures fit the kernel's LDS, 2 = its materials and textures do (k_shade's LDSREC)
+  if constexpr (MODE != 0) {
+    if (qlights) {
+      if (lds == 1) hipLaunchKernelGGL((k_shade<MODE, false, true, false, true, 1>), dim3(grid), dim3(block), 0, stream, d, fp, p);
+      else if (lds == 2) hipLaunchKernelGGL((k_shade<MODE, false, true, false, true, 2>), dim3(grid), dim3(block), 0, stream, d, fp, p);
+      else hipLaunchKernelGGL((k_shade<MODE, false, true, false, true>), dim3(grid), dim3(block), 0, stream, d, fp, p);
+      return;
+    }
+  }
   if (general) { hipLaunchKernelGGL((k_shade<MODE, true>), dim3(grid), dim3(block), 0, stream, d, fp, p); return; }
-  if constexpr (MODE != 0) { if (lean) { hipLaunchKernelGGL((k_shade<MODE, false, true>), dim3(grid), dim3(block), 0, stream, d, fp, p); return; } }
+  if constexpr (MODE != 0) {
+    if (lean) {
+      if (lds == 2) hipLaunchKernelGGL((k_shade<MODE, false, true, false, false, 2>), dim3(grid), dim3(block), 0, stream, d, fp, p);
+      else hipLaunchKernelGGL((k_shade<MODE, false, true>), dim3(grid), dim3(block), 0, stream, d, fp, p);
+      return;
+    }
+  }
   // the Lambert front-end past the camera vertices: no differentials, bilinear image lookups, everything inline under a three-wave bound
   if constexpr (MODE == 3) { if (bounced) { hipLaunchKernelGGL((k_shade<3, false, false, true>), dim3(grid), dim3(block), 0, stream, d, fp, p); return; } }
   hipLaunchKernelGGL((k_shade<MODE, false>), dim3(grid), dim3(block), 0, stream, d, fp, p);
@@ -1422,6 +1440,7 @@ extern "C" int rt_render(rt_scene* s, const rt_camera* cam, const rt_film_desc* 
   static const bool lean_off = getenv("RTX_SHADE_LEAN") && getenv("RTX_SHADE_LEAN")[0] == '0';  // measurement knob
   const bool lean_shade = s->lean_shade && !lean_off;
   static const bool bounced_off = getenv("RTX_SHADE_BOUNCED") && getenv("RTX_SHADE_BOUNCED")[0] == '0';  // measurement knob
+  const int lds_shade = (s->lds_records_q && s->d.route_quadric_hits != 0) ? 1 : (s->lds_mats ? 2 : 0);  // the LEAN / QLIGHTS forms' tables in LDS
   const bool qlights = s->d.route_quadric_hits != 0 && use_bins;  // QLIGHTS forms on the front-end ranges, quadric hits in a generic bin of their own
   const unsigned n_bins = std::min<unsigned>(s->n_code_classes, RT_BIN_MAX - 1) + 1u + (qlights ? 1u : 0u);
   const size_t bin_stride = (RT_BIN_MAX + 1) + (size_t)(RT_BIN_MAX + 1) * RT_CNT_STRIDE + (size_t)RT_QSHARDS * RT_CNT_STRIDE + 10;  // hist, cursors (spread), the sorted queue's counts (laid out as shard counters)  // + {begin, end} of the four class ranges and of the miss bin
@@ -1593,10 +1612,10 @@ extern "C" int rt_render(rt_scene* s, const rt_camera* cam, const rt_film_desc* 
         launch_trace<false>(s, count, io_path, ps.cnt_in, ps.cnt_in, ps.shard_cap, ps.cap, dstats, ST_RAYS_CLOSEST, ST_NODES_CLOSEST, ST_TRIS_CLOSEST, stream);
         tm.end();
         if (bounce <= 1) HIP_TRY(hipStreamWaitEvent(stream, s->ev_tables[buf][bounce + 1], 0));  // table groups 1 / 2: first read by the shade launches of bounce 0 / 1
-#define RT_SHADE(MODE, P) stats.launches_shade += 1, launch_shade<MODE>(gshade, lean_shade, bounce >= 1 && !bounced_off, sgrid, sblock, stream, s->d, fp, P, qlights)
+#define RT_SHADE(MODE, P) stats.launches_shade += 1, launch_shade<MODE>(gshade, lean_shade, bounce >= 1 && !bounced_off, sgrid, sblock, stream, s->d, fp, P, qlights, lds_shade)
         if (s->lambert_only) {
           tm.begin(&stats.ms_shade_lambert_const);
-          if (s->lds_records) hipLaunchKernelGGL((k_shade<1, false, false, false, false, true>), dim3(sgrid), dim3(sblock), 0, stream, s->d, fp, ps);
+          if (s->lds_records) hipLaunchKernelGGL((k_shade<1, false, false, false, false, 1>), dim3(sgrid), dim3(sblock), 0, stream, s->d, fp, ps);
           else hipLaunchKernelGGL(k_shade<1>, dim3(sgrid), dim3(sblock), 0, stream, s->d, fp, ps);
           tm.end(); stats.launches_shade += 1;
         }

@@ -2741,27 +2741,31 @@ RT_DEVN int instance_fill_interaction(const DScene& sc, unsigned hit_id, float o
 // 256 VGPRs and 352 - 448 B of scratch.
 #define RT_LDS_LIGHTS 8
 #define RT_LDS_MATERIALS 16
-template <int MODE, bool GENERAL = false, bool LEAN = false, bool BOUNCED = false, bool QLIGHTS = false, bool LDSREC = false>
+#define RT_LDS_TEXTURES 32
+// LDSREC: 0 = every table in HBM; 1 = the scene's shade / traversal records, lights, materials and textures in LDS (small scenes); 2 = materials and textures only
+template <int MODE, bool GENERAL = false, bool LEAN = false, bool BOUNCED = false, bool QLIGHTS = false, int LDSREC = 0>
 __global__ void __launch_bounds__(256, (MODE == 1 || LEAN || BOUNCED) ? ((LEAN || BOUNCED) ? (BOUNCED ? RT_SHADE_BOUNCED_MIN_WAVES : RT_SHADE_LEAN_MIN_WAVES) : RT_SHADE_MIN_WAVES) : (MODE == 3 && !GENERAL ? RT_SHADE3_MIN_WAVES : ((MODE == 5 || MODE == 6) && !GENERAL ? RT_SHADE56_MIN_WAVES : (MODE != 0 && GENERAL ? RT_SHADE_GEN_MIN_WAVES : RT_SHADE0_MIN_WAVES)))) k_shade(DScene sc, FrameParams fp, PassState ps) {
   // LDSREC (MODE 1, round 5): a scene of <= RT_SMALL_TRIS triangles and <= RT_LDS_LIGHTS emitters keeps its shade records, traversal records and light table in LDS
   // for the launch. k_shade<1> is busy issuing VALU instructions half of the time and waits for memory two thirds of a wave's life (SQ counters), yet neither ~10 % fewer
   // instructions nor an earlier scan load moved it - what it waits for is the texture path's address processing: ~40 vector memory instructions per vertex, the
   // gathers among them (a vertex's triangle, the picked light, the light's triangle: every lane its own address) served a few lanes per clock. Read from LDS they
   // do not go there at all. Same values, same arithmetic.
-  __shared__ float4 s_rec[LDSREC ? 8 * RT_SMALL_TRIS : 1];
-  __shared__ float4 s_trip[LDSREC ? 3 * RT_SMALL_TRIS : 1];
-  __shared__ unsigned s_lights[LDSREC ? RT_LDS_LIGHTS * (sizeof(DLight) / 4) : 1];
+  __shared__ float4 s_rec[LDSREC == 1 ? 8 * RT_SMALL_TRIS : 1];
+  __shared__ float4 s_trip[LDSREC == 1 ? 3 * RT_SMALL_TRIS : 1];
+  __shared__ unsigned s_lights[LDSREC == 1 ? RT_LDS_LIGHTS * (sizeof(DLight) / 4) : 1];
   __shared__ unsigned s_mats[LDSREC ? RT_LDS_MATERIALS * (sizeof(DMaterial) / 4) : 1];
-  __shared__ unsigned s_texs[LDSREC ? RT_LDS_MATERIALS * (sizeof(DTexture) / 4) : 1];
+  __shared__ unsigned s_texs[LDSREC ? RT_LDS_TEXTURES * (sizeof(DTexture) / 4) : 1];
   if (LDSREC) {
-    for (unsigned k = threadIdx.x; k < 8u * sc.n_tris; k += blockDim.x) s_rec[k] = sc.tri_rec[k];
-    for (unsigned k = threadIdx.x; k < 3u * sc.n_tris; k += blockDim.x) s_trip[k] = sc.tri_p[k];
-    const unsigned nl = (unsigned)sc.n_lights_all * (unsigned)(sizeof(DLight) / 4);
-    for (unsigned k = threadIdx.x; k < nl; k += blockDim.x) s_lights[k] = ((const unsigned*)sc.lights)[k];
+    if (LDSREC == 1) {
+      for (unsigned k = threadIdx.x; k < 8u * sc.n_tris; k += blockDim.x) s_rec[k] = sc.tri_rec[k];
+      for (unsigned k = threadIdx.x; k < 3u * sc.n_tris; k += blockDim.x) s_trip[k] = sc.tri_p[k];
+      const unsigned nl = (unsigned)sc.n_lights_all * (unsigned)(sizeof(DLight) / 4);
+      for (unsigned k = threadIdx.x; k < nl; k += blockDim.x) s_lights[k] = ((const unsigned*)sc.lights)[k];
+    }
     for (unsigned k = threadIdx.x; k < (unsigned)sc.n_materials * (unsigned)(sizeof(DMaterial) / 4); k += blockDim.x) s_mats[k] = ((const unsigned*)sc.materials)[k];
     for (unsigned k = threadIdx.x; k < (unsigned)sc.n_textures * (unsigned)(sizeof(DTexture) / 4); k += blockDim.x) s_texs[k] = ((const unsigned*)sc.textures)[k];
     __syncthreads();
-    sc.tri_rec = (const float4*)s_rec; sc.tri_p = (const float4*)s_trip; sc.lights = (const DLight*)s_lights;
+    if (LDSREC == 1) { sc.tri_rec = (const float4*)s_rec; sc.tri_p = (const float4*)s_trip; sc.lights = (const DLight*)s_lights; }
     sc.materials = (const DMaterial*)s_mats; sc.textures = (const DTexture*)s_texs;
   }
   QView qv; if (ps.cnt_in) qv.init(ps.q_in, ps.cnt_in, ps.shard_cap);
