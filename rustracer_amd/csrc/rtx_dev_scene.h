@@ -54,7 +54,7 @@ struct DScene {
   const DTexture* textures; const DImage* images; const DMaterial* materials; const DLight* lights;
   int n_lights; int n_infinite; int infinite_ids[4];
   int n_lights_all;  // sampled lights + the emitters no light list holds: records in `lights`
-  int n_materials, n_textures;
+  int n_materials, n_textures, n_images;
   int needs_differentials;  // some texture reads dudx.. / dpdx.. (image maps, closed-form checkerboards, fbm)
   f3 wb_min, wb_max;
   // light distribution (rc/lightdistrib.rs): dense voxel table or a single uniform distribution

@@ -56,6 +56,7 @@ struct rt_scene {
   bool small = false;
   bool lambert_materials = false;  // the material half of lambert_only: with other light kinds k_shade<3>
   bool lds_records_q = false; // a scene of quadric emitters whose triangles, lights, materials and textures all fit (QLIGHTS forms with LDSREC = 1)
+  bool lds_tables = false;    // ... its lights, materials, textures and image headers do (the plain forms)
   bool lds_mats = false;      // ... at least its material and texture tables do (the LEAN forms of the other front-ends)
   bool lds_records = false;   // the scene's shade / traversal records and its light table fit the shade kernel's LDS (k_shade<1, .., LDSREC>)
   bool lambert_only = false;  // every material is matte{constant Kd, sigma == 0} and every light an area light: k_shade<1>
@@ -499,7 +500,7 @@ extern "C" int rt_scene_create(const rt_scene_desc* desc, int device, rt_scene**
   d.spheres = s->has_spheres ? s->spheres.as<DSphere>() : nullptr;
   d.instances = s->has_instances ? s->instances.as<DInstance>() : nullptr; d.n_instances = s->has_instances ? desc->n_instances : 0u; d.n_top_prims = n_top_prims;
   d.textures = s->textures.as<DTexture>(); d.images = s->images.as<DImage>(); d.materials = s->materials.as<DMaterial>(); d.lights = s->lights.as<DLight>();
-  d.n_materials = (int)desc->n_materials; d.n_textures = (int)desc->n_textures;
+  d.n_materials = (int)desc->n_materials; d.n_textures = (int)desc->n_textures; d.n_images = (int)desc->n_images;
   d.n_lights = (int)desc->n_lights;
   d.wb_min = f3{desc->nodes[0].bmin[0], desc->nodes[0].bmin[1], desc->nodes[0].bmin[2]};
   d.wb_max = f3{desc->nodes[0].bmax[0], desc->nodes[0].bmax[1], desc->nodes[0].bmax[2]};
@@ -759,6 +760,7 @@ extern "C" int rt_scene_create(const rt_scene_desc* desc, int device, rt_scene**
   d.n_lights_all = (int)n_all_lights;
   s->lds_records = s->small && !s->has_instances && !s->has_spheres && desc->n_tris <= RT_SMALL_TRIS && n_all_lights <= RT_LDS_LIGHTS && desc->n_materials <= RT_LDS_MATERIALS && desc->n_textures <= RT_LDS_TEXTURES && !(getenv("RTX_SHADE_LDSREC") && getenv("RTX_SHADE_LDSREC")[0] == '0');  // k_shade<1, .., LDSREC> (RTX_SHADE_LDSREC=0: measurement knob)
   s->lds_records_q = desc->n_tris <= RT_SMALL_TRIS && !s->has_instances && n_all_lights <= RT_LDS_LIGHTS && desc->n_materials <= RT_LDS_MATERIALS && desc->n_textures <= RT_LDS_TEXTURES && !(getenv("RTX_SHADE_LDSREC") && getenv("RTX_SHADE_LDSREC")[0] == '0');
+  s->lds_tables = n_all_lights <= RT_LDS_LIGHTS && desc->n_materials <= RT_LDS_MATERIALS && desc->n_textures <= RT_LDS_TEXTURES && desc->n_images <= RT_LDS_IMAGES && !(getenv("RTX_SHADE_LDSREC") && getenv("RTX_SHADE_LDSREC")[0] == '0');
   s->lds_mats = desc->n_materials <= RT_LDS_MATERIALS && desc->n_textures <= RT_LDS_TEXTURES && !(getenv("RTX_SHADE_LDSREC") && getenv("RTX_SHADE_LDSREC")[0] == '0');  // the LEAN forms: material and texture tables in LDS
   if (n_all_lights) hipLaunchKernelGGL(k_light_consts, dim3((n_all_lights + 255u) / 256u), dim3(256), 0, nullptr, d, s->lights.as<DLight>(), (int)n_all_lights);
   if (hipGetLastError() != hipSuccess) { delete s; return fail(RT_ERR_HIP, "constant precomputation launch failed"); }
@@ -1362,7 +1364,14 @@ static void launch_shade(bool general, bool lean, bool bounced, unsigned grid, u
     }
   }
   // the Lambert front-end past the camera vertices: no differentials, bilinear image lookups, everything inline under a three-wave bound
-  if constexpr (MODE == 3) { if (bounced) { hipLaunchKernelGGL((k_shade<3, false, false, true>), dim3(grid), dim3(block), 0, stream, d, fp, p); return; } }
+  if constexpr (MODE == 3) {
+    if (bounced) {
+      if (lds == 3) hipLaunchKernelGGL((k_shade<3, false, false, true, false, 3>), dim3(grid), dim3(block), 0, stream, d, fp, p);
+      else hipLaunchKernelGGL((k_shade<3, false, false, true>), dim3(grid), dim3(block), 0, stream, d, fp, p);
+      return;
+    }
+  }
+  if constexpr (MODE == 3 || MODE == 5 || MODE == 6) { if (lds == 3) { hipLaunchKernelGGL((k_shade<MODE, false, false, false, false, 3>), dim3(grid), dim3(block), 0, stream, d, fp, p); return; } }
   hipLaunchKernelGGL((k_shade<MODE, false>), dim3(grid), dim3(block), 0, stream, d, fp, p);
 }
 
@@ -1440,7 +1449,7 @@ extern "C" int rt_render(rt_scene* s, const rt_camera* cam, const rt_film_desc* 
   static const bool lean_off = getenv("RTX_SHADE_LEAN") && getenv("RTX_SHADE_LEAN")[0] == '0';  // measurement knob
   const bool lean_shade = s->lean_shade && !lean_off;
   static const bool bounced_off = getenv("RTX_SHADE_BOUNCED") && getenv("RTX_SHADE_BOUNCED")[0] == '0';  // measurement knob
-  const int lds_shade = (s->lds_records_q && s->d.route_quadric_hits != 0) ? 1 : (s->lds_mats ? 2 : 0);  // the LEAN / QLIGHTS forms' tables in LDS
+  const int lds_shade = (s->lds_records_q && s->d.route_quadric_hits != 0) ? 1 : ((lean_shade || gshade) ? (s->lds_mats ? 2 : 0) : (s->lds_tables ? 3 : 0));  // the LEAN / QLIGHTS forms' tables in LDS
   const bool qlights = s->d.route_quadric_hits != 0 && use_bins;  // QLIGHTS forms on the front-end ranges, quadric hits in a generic bin of their own
   const unsigned n_bins = std::min<unsigned>(s->n_code_classes, RT_BIN_MAX - 1) + 1u + (qlights ? 1u : 0u);
   const size_t bin_stride = (RT_BIN_MAX + 1) + (size_t)(RT_BIN_MAX + 1) * RT_CNT_STRIDE + (size_t)RT_QSHARDS * RT_CNT_STRIDE + 10;  // hist, cursors (spread), the sorted queue's counts (laid out as shard counters)  // + {begin, end} of the four class ranges and of the miss bin

@@ -2741,8 +2741,10 @@ RT_DEVN int instance_fill_interaction(const DScene& sc, unsigned hit_id, float o
 // 256 VGPRs and 352 - 448 B of scratch.
 #define RT_LDS_LIGHTS 8
 #define RT_LDS_MATERIALS 16
-#define RT_LDS_TEXTURES 32
-// LDSREC: 0 = every table in HBM; 1 = the scene's shade / traversal records, lights, materials and textures in LDS (small scenes); 2 = materials and textures only
+#define RT_LDS_TEXTURES 64
+#define RT_LDS_IMAGES 8
+// LDSREC: 0 = every table in HBM; 1 = the scene's shade / traversal records, lights, materials and textures in LDS (small scenes); 2 = materials and textures only;
+// 3 = lights, materials, textures and image headers (the plain forms of scenes with few of each)
 template <int MODE, bool GENERAL = false, bool LEAN = false, bool BOUNCED = false, bool QLIGHTS = false, int LDSREC = 0>
 __global__ void __launch_bounds__(256, (MODE == 1 || LEAN || BOUNCED) ? ((LEAN || BOUNCED) ? (BOUNCED ? RT_SHADE_BOUNCED_MIN_WAVES : RT_SHADE_LEAN_MIN_WAVES) : RT_SHADE_MIN_WAVES) : (MODE == 3 && !GENERAL ? RT_SHADE3_MIN_WAVES : ((MODE == 5 || MODE == 6) && !GENERAL ? RT_SHADE56_MIN_WAVES : (MODE != 0 && GENERAL ? RT_SHADE_GEN_MIN_WAVES : RT_SHADE0_MIN_WAVES)))) k_shade(DScene sc, FrameParams fp, PassState ps) {
   // LDSREC (MODE 1, round 5): a scene of <= RT_SMALL_TRIS triangles and <= RT_LDS_LIGHTS emitters keeps its shade records, traversal records and light table in LDS
@@ -2752,20 +2754,26 @@ __global__ void __launch_bounds__(256, (MODE == 1 || LEAN || BOUNCED) ? ((LEAN |
   // do not go there at all. Same values, same arithmetic.
   __shared__ float4 s_rec[LDSREC == 1 ? 8 * RT_SMALL_TRIS : 1];
   __shared__ float4 s_trip[LDSREC == 1 ? 3 * RT_SMALL_TRIS : 1];
-  __shared__ unsigned s_lights[LDSREC == 1 ? RT_LDS_LIGHTS * (sizeof(DLight) / 4) : 1];
+  __shared__ unsigned s_lights[(LDSREC == 1 || LDSREC == 3) ? RT_LDS_LIGHTS * (sizeof(DLight) / 4) : 1];
+  __shared__ unsigned s_imgs[LDSREC == 3 ? RT_LDS_IMAGES * (sizeof(DImage) / 4) : 1];
   __shared__ unsigned s_mats[LDSREC ? RT_LDS_MATERIALS * (sizeof(DMaterial) / 4) : 1];
   __shared__ unsigned s_texs[LDSREC ? RT_LDS_TEXTURES * (sizeof(DTexture) / 4) : 1];
   if (LDSREC) {
     if (LDSREC == 1) {
       for (unsigned k = threadIdx.x; k < 8u * sc.n_tris; k += blockDim.x) s_rec[k] = sc.tri_rec[k];
       for (unsigned k = threadIdx.x; k < 3u * sc.n_tris; k += blockDim.x) s_trip[k] = sc.tri_p[k];
+    }
+    if (LDSREC == 1 || LDSREC == 3) {
       const unsigned nl = (unsigned)sc.n_lights_all * (unsigned)(sizeof(DLight) / 4);
       for (unsigned k = threadIdx.x; k < nl; k += blockDim.x) s_lights[k] = ((const unsigned*)sc.lights)[k];
     }
+    if (LDSREC == 3) for (unsigned k = threadIdx.x; k < (unsigned)sc.n_images * (unsigned)(sizeof(DImage) / 4); k += blockDim.x) s_imgs[k] = ((const unsigned*)sc.images)[k];
     for (unsigned k = threadIdx.x; k < (unsigned)sc.n_materials * (unsigned)(sizeof(DMaterial) / 4); k += blockDim.x) s_mats[k] = ((const unsigned*)sc.materials)[k];
     for (unsigned k = threadIdx.x; k < (unsigned)sc.n_textures * (unsigned)(sizeof(DTexture) / 4); k += blockDim.x) s_texs[k] = ((const unsigned*)sc.textures)[k];
     __syncthreads();
-    if (LDSREC == 1) { sc.tri_rec = (const float4*)s_rec; sc.tri_p = (const float4*)s_trip; sc.lights = (const DLight*)s_lights; }
+    if (LDSREC == 1) { sc.tri_rec = (const float4*)s_rec; sc.tri_p = (const float4*)s_trip; }
+    if (LDSREC == 1 || LDSREC == 3) sc.lights = (const DLight*)s_lights;
+    if (LDSREC == 3) sc.images = (const DImage*)s_imgs;
     sc.materials = (const DMaterial*)s_mats; sc.textures = (const DTexture*)s_texs;
   }
   QView qv; if (ps.cnt_in) qv.init(ps.q_in, ps.cnt_in, ps.shard_cap);
