@@ -107,7 +107,10 @@ out['trace_any_all'] = per_sample(['rtx::k_trace<true, false', 'rtx::k_trace_pai
 # front-end class come from the PMC run's own detail file; the plain and BOUNCED / LEAN / QLIGHTS forms of one front-end share its count.
 verts = {}
 try:
-    verts = json.load(open(os.path.join(base, 'fetch_detail.json'))).get('vertices_by_shade_front_end') or {}
+    _fd = json.load(open(os.path.join(base, 'fetch_detail.json')))
+    # the detail file counts the vertices of ONE frame; a PMC run renders steps + warmup timed frames and the counting frame, all through the same shade kernels
+    _frames = int(_fd.get('steps', 1)) + int(_fd.get('warmup', 0)) + 1
+    verts = {k: v * _frames for k, v in (_fd.get('vertices_by_shade_front_end') or {}).items()}
 except Exception:
     pass
 CLASS_OF = {'1': 'lambert_const', '3': 'lambert', '5': 'two_lobe', '6': 'two_lobe', '0': 'generic'}
