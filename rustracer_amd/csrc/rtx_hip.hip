@@ -887,7 +887,7 @@ static int build_light_distribution(rt_scene* s, int strategy, hipStream_t strea
     HIP_TRY(hipGetLastError());
     d.ld_rows8 = s->ld_rows8.as<float4>();
     const unsigned long long n_vox = (unsigned long long)d.nvox[0] * d.nvox[1] * d.nvox[2];
-    static const int dense_mb = getenv("RTX_LD_DENSE_MB") ? atoi(getenv("RTX_LD_DENSE_MB")) : 16;  // (measurement knob: 0 = never)
+    const int dense_mb = getenv("RTX_LD_DENSE_MB") ? atoi(getenv("RTX_LD_DENSE_MB")) : 16;  // (measurement knob, read per build: 0 = never)
     if (!uniform && n_vox * 32ull <= (unsigned long long)dense_mb << 20) {
       HIP_TRY(s->ld_dense8.ensure((size_t)n_vox * 32));
       hipLaunchKernelGGL(k_lightdist_dense8, dim3((unsigned)((n_vox + 255) / 256)), dim3(256), 0, stream, s->ld_rows8.as<float4>(), s->ld_slot.as<int>(), n_vox, s->ld_dense8.as<float4>());

@@ -144,6 +144,41 @@ def test_constant_matte_scene_under_other_light_kinds(gpu_host, orc, lights):
     _check(gpu_host, orc, d)
 
 
+@pytest.mark.parametrize("scene", ["cornell", "mis-spheres", "zoo-plastic-infinite", "zoo-matte-image", "mis-plates-small"])
+def test_tables_in_lds_change_no_bit_of_the_film(gpu_host, scene, monkeypatch):
+    """Round 5: the shade kernels read the small tables of a scene - triangle records, lights, materials, textures, image headers (k_shade's LDSREC forms) - from LDS,
+    and the light distribution of a scene with <= 3 lights as one 32-byte record per voxel (ld_rows8 / ld_dense8). Same values through the same arithmetic: the film
+    with every one of these switched off (tables in HBM, the three separate distribution tables) is the same film bit for bit."""
+    from rustracer_amd.scenes import cornell_box, mis_plates
+    if scene == "cornell":
+        d = cornell_box(96, 80, 16)                          # k_shade<1, .., LDSREC = 1>, ld_dense8
+    elif scene == "mis-spheres":
+        d = mis_plates(spp=8, analytic_spheres=True)          # QLIGHTS forms with every table in LDS
+        d.film.xres, d.film.yres = 160, 90
+    elif scene == "mis-plates-small":
+        d = mis_plates(spp=4)                                 # LEAN forms: materials + textures in LDS (1282 lights stay in HBM)
+        d.film.xres, d.film.yres = 160, 90
+    elif scene == "zoo-plastic-infinite":
+        d = _zoo("plastic", "infinite", res=(64, 48))         # plain forms: lights + materials + textures + image headers (LDSREC = 3); rows8 with one area light + environment
+    else:
+        d = _zoo("matte_image_ewa", "area", res=(64, 48))
+    films = []
+    for off in (False, True):
+        for k in ("RTX_SHADE_LDSREC", "RTX_LD_ROWS8", "RTX_LD_DENSE_MB"):
+            if off:
+                monkeypatch.setenv(k, "0")
+            else:
+                monkeypatch.delenv(k, raising=False)
+        h = gpu_host.HostScene(d)                             # the knobs are read when the scene and its light distribution are built
+        f, st = h.render()
+        films.append((f, st))
+    (f0, s0), (f1, s1) = films
+    assert np.array_equal(f0.view(np.uint32), f1.view(np.uint32))
+    for k in ("rays_closest", "rays_shadow", "rays_mis", "camera_rays"):
+        assert s0[k] == s1[k], k
+    assert np.isfinite(f0).all() and f0[..., :3].max() > 0
+
+
 @pytest.mark.parametrize("material", ["matte", "oren_nayar", "matte_image_ewa", "plastic", "plastic_noremap", "metal", "metal_aniso", "mirror", "glass", "glass_rough", "substrate", "matte_bump_fbm", "plastic_bump_image", "mirror_bump_checker", "mix", "uber", "uber_opaque"])
 def test_register_resident_front_ends_equal_the_generic_one(gpu_host, material, monkeypatch):
     """Class-wise dispatch (k_shade<3> / k_shade<5> / k_shade<6> / k_shade<0>) against every class through the generic lobe array."""
