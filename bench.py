@@ -404,7 +404,7 @@ def run_workload(scene_name, runner, workload, steps, warmup):
              "traffic_provenance": prov,
              "algorithmic_bytes_per_launch": round(algo_bytes / max(n_launch, 1)), "avg_launch_ms": round(ms_kernel / max(n_launch, 1), 4),
              "launches_per_step": int(n_launch), f"bytes_per_{unit}": round(algo_bytes / max(unit_n, 1), 1),
-             "lanes": e.get("lanes_per_valu")}
+             "lanes": e.get("lanes_per_valu"), "valu_busy": e.get("valu_busy")}  # lanes / valu_busy: SQ counters of the stored profile (share of the SIMDs' cycles that issue a vector instruction)
         if kname == "trace_closest" and lds_scene:
             r["limiter"] = "VALU issue: the scene is LDS-resident, a ray's HBM bytes are its record in and its hit out"
         if prov and prov.get("stale"):
@@ -444,7 +444,7 @@ def run_workload(scene_name, runner, workload, steps, warmup):
 
 LINE_LIMIT = 4096  # bytes of the ONE printed line (a 78 KB line was not parsed by the driver); tests/test_bench_cpu.py holds it there
 
-ROOF_KEYS = ("bound", "kernel", "achieved", "peak", "unit", "frac", "traffic", "traffic_raw_reads", "algorithmic_bytes_per_launch", "avg_launch_ms", "launches_per_step", "lanes", "limiter")
+ROOF_KEYS = ("bound", "kernel", "achieved", "peak", "unit", "frac", "traffic", "traffic_raw_reads", "algorithmic_bytes_per_launch", "avg_launch_ms", "launches_per_step", "lanes", "valu_busy", "limiter")
 CPU_KEYS = ("value", "unit", "cores", "kind", "sample")
 TOP_KEYS = ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data", "config",
             "n_gpus_requested", "per_device_ms", "gather_ms", "imbalance_max_over_mean")

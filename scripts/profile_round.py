@@ -123,6 +123,29 @@ for r in rows:
 out['shade_by_front_end'] = {cls: {'kernels': sorted(f[3]), 'launches': f[2], 'hbm_bytes': round(f[0]), 'hbm_bytes_raw_reads': round(f[1]), 'vertices': verts.get(cls),
                                    'hbm_bytes_per_vertex': round(f[0] / verts[cls], 1) if verts.get(cls) else None,
                                    'hbm_bytes_per_vertex_raw_reads': round(f[1] / verts[cls], 1) if verts.get(cls) else None} for cls, f in forms.items()}
+# How busy the SIMDs' vector ALUs are in the two heavy stages: SQ_INSTS_VALU (wave instructions, 4 cycles each on a 16-lane SIMD) of the SQ run / (1024 SIMDs x the kernels' time x
+# sclk); the time of the SQ run's dispatches is estimated from the traced run's average per dispatch (same kernels, same launch sizes), sclk from the detail file's reading after the frames
+def valu_busy(prefixes):
+    try:
+        sclk = (_fd.get('gpu_clocks') or {}).get('sclk_MHz', {}).get('after') or 2300
+        stats_files = glob.glob(os.path.join(base, 'stats', '*', '*_kernel_stats.csv'))
+        avg = {}
+        for r in csv.DictReader(open(max(stats_files, key=os.path.getmtime))):
+            avg[r['Name'].split('(')[0].replace('void ', '')] = float(r['AverageNs'])
+        insts = cyc = 0.0
+        for k, (tc, ni) in valu.items():
+            kk = k.split('(')[0].replace('void ', '')
+            if any(kk.startswith(p_) for p_ in prefixes) and kk in avg:
+                nd = [n_ for (kn, c), n_ in sq_disp.items() if kn == k and c == 'SQ_INSTS_VALU']
+                insts += ni; cyc += avg[kk] * 1e-9 * (nd[0] if nd else 0) * sclk * 1e6 * 1024.0
+        return round(insts * 4.0 / cyc, 3) if cyc else None
+    except Exception:
+        return None
+_, sq_disp_n = per_kernel('sq', 'SQ_INSTS_VALU')
+sq_disp = {(k, 'SQ_INSTS_VALU'): v for k, v in sq_disp_n.items()}
+for grp, pre in (('trace_closest', ['rtx::k_trace<false, false', 'rtx::k_trace_pair<false', 'rtx::k_trace_top<false']), ('shade', ['rtx::k_shade'])):
+    if out.get(grp):
+        out[grp]['valu_busy'] = valu_busy(pre)
 json.dump(out, open(os.path.join('profiles', f'pmc_{scene}.json'), 'w'), indent=1)
 
 # The SQ pass, summarised per kernel next to the traffic files and under the same kernel_source_sha (the r04 SQ summaries predated the final kernels)
