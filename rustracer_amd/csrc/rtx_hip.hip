@@ -1625,6 +1625,7 @@ extern "C" int rt_render(rt_scene* s, const rt_camera* cam, const rt_film_desc* 
         if (s->lambert_only) {
           tm.begin(&stats.ms_shade_lambert_const);
           if (s->lds_records) hipLaunchKernelGGL((k_shade<1, false, false, false, false, 1>), dim3(sgrid), dim3(sblock), 0, stream, s->d, fp, ps);
+          else if (s->lds_tables) hipLaunchKernelGGL((k_shade<1, false, false, false, false, 3>), dim3(sgrid), dim3(sblock), 0, stream, s->d, fp, ps);  // a large mesh with few lights / materials (S2)
           else hipLaunchKernelGGL(k_shade<1>, dim3(sgrid), dim3(sblock), 0, stream, s->d, fp, ps);
           tm.end(); stats.launches_shade += 1;
         }
