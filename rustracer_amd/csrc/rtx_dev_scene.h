@@ -45,6 +45,9 @@ struct DScene {
   // reference's walk takes up once it is done with node i and everything below it (n_nodes: the walk is over). With these links the walk needs no stack
   // (closest_small, occluded_small in rtx_kernels.h); built by rt_scene_create from the nodes
   const unsigned short* skip8;
+  // round 5: the walks' links as one word per (octant, node): (where the walk goes when the node's box passes and it is interior) << 16 | (where it carries on after the node and
+  // everything below it), then 8 start nodes. link8: over the nodes the walks TEST (interior nodes whose test rarely fails are passed over, rt_scene_create); link8_full: over all nodes
+  const unsigned* link8; const unsigned* link8_full;
   const float4* tri_p; unsigned n_tris;
   const float4* tri_rec;  // per-triangle shade records (8 x float4, see tri_fill_interaction_inl), built on the device at rt_scene_create
   const float* tri_n; const float* tri_uv; const float* tri_s;

@@ -64,6 +64,7 @@ struct rt_scene {
   bool lean_shade = false;    // every light an area light on a triangle and every texture a constant: the LEAN forms of k_shade<3 | 5 | 6> (no out-of-line evaluator, three waves)
   int stack_depth = 64;  // entries the to-visit stack needs for this tree (<= 64, rc/bvh/mod.rs:374)
   unsigned n_nodes = 0, n_tris = 0; int n_lights = 0;
+  DevBuf link8, link8_full; unsigned lds_nodes_tested = 0;  // link tables of the stackless LDS walks; nodes they test (of n_nodes)
   DevBuf pairs, tmin_stack;  // child-pair node records and the HBM half of the traversal stack (k_trace_pair)
   DevBuf top_pairs, deep_stack; bool use_top = false;  // k_trace_top: LDS-resident top of the tree, HBM spill of stack entries beyond the LDS ones
   bool top_for_closest = false;  // closest-hit rays through k_trace_top as well (shadow rays always, when no four-wide records exist)
@@ -585,7 +586,7 @@ extern "C" int rt_scene_create(const rt_scene_desc* desc, int device, rt_scene**
     s->stack_depth += max_obj; max_obj_depth = max_obj;
     s->deep_column = s->stack_depth > 64;
   }
-  d.pairs = nullptr; d.quads = nullptr; d.obj_pairs = 0; d.skip8 = nullptr;
+  d.pairs = nullptr; d.quads = nullptr; d.obj_pairs = 0; d.skip8 = nullptr; d.link8 = nullptr; d.link8_full = nullptr;
   if (s->small) {
     // The order in which BVH::intersect (bvh/mod.rs:381-425) reaches the nodes depends on the ray only through the signs of its direction (at an interior node
     // the child on the ray's side of the split axis first, the other one pushed): one fixed order per octant. skip[o][i] = the entry on top of the to-visit stack
@@ -610,6 +611,153 @@ extern "C" int rt_scene_create(const rt_scene_desc* desc, int device, rt_scene**
     }
     { const int rc8 = upload(s->skip8, skip.data(), skip.size() * sizeof(uint16_t)); if (rc8 != RT_OK) { delete s; return rc8; } }
     d.skip8 = s->skip8.as<unsigned short>();
+    // ---- round 5: link tables of the stackless walks (rtx_kernels.h, closest_small_links), over all nodes and over the nodes worth testing.
+    // A box contains its children's boxes, so an interior node's test decides nothing - it saves its subtree's tests when it fails and costs one test when it does not. Which
+    // interior nodes earn their test is measured here on synthetic rays of the kind a path tracer casts (origins on the surfaces, cosine-distributed directions): a greedy pass
+    // drops a node when the walk without it tests fewer nodes. Leaves always stay (a leaf's own test is what decides whether its primitives are tested). The choice only moves time.
+    std::vector<char> kept(nn, 1);
+    bool nested = !s->general_prims && nn >= 3;
+    for (uint32_t i = 0; i < nn && nested; ++i) {
+      const rt_bvh_node& n = desc->nodes[i];
+      if (n.n_prims != 0) continue;
+      const uint32_t kids[2] = {i + 1, n.offset};
+      for (uint32_t c : kids) for (int k = 0; k < 3; ++k) if (!(desc->nodes[c].bmin[k] >= n.bmin[k] && desc->nodes[c].bmax[k] <= n.bmax[k])) nested = false;  // (NaN bounds: no)
+    }
+    const char* prune_env = getenv("RTX_LDS_PRUNE");  // measurement / test knob, read per scene: 0 = every node is tested
+    s->lds_nodes_tested = nn;
+    if (nested && !(prune_env && prune_env[0] == '0')) {
+      const uint32_t K = nn <= 64 ? 2048u : 512u;  // (the greedy pass costs interior nodes x rays x visits: milliseconds for S1's 39 nodes, under a tenth of a second for 255)
+      struct CalRay { double o[3], d[3]; };
+      std::vector<CalRay> rays; rays.reserve(K);
+      std::vector<double> cum(desc->n_tris + 1, 0.0);
+      auto P = [&](uint32_t t, int v, int k) { return (double)desc->tri_p[9 * (size_t)t + 3 * v + k]; };
+      for (uint32_t t = 0; t < desc->n_tris; ++t) {
+        const double e1[3] = {P(t, 1, 0) - P(t, 0, 0), P(t, 1, 1) - P(t, 0, 1), P(t, 1, 2) - P(t, 0, 2)}, e2[3] = {P(t, 2, 0) - P(t, 0, 0), P(t, 2, 1) - P(t, 0, 1), P(t, 2, 2) - P(t, 0, 2)};
+        const double cx = e1[1] * e2[2] - e1[2] * e2[1], cy = e1[2] * e2[0] - e1[0] * e2[2], cz = e1[0] * e2[1] - e1[1] * e2[0];
+        cum[t + 1] = cum[t] + 0.5 * std::sqrt(cx * cx + cy * cy + cz * cz);
+      }
+      unsigned long long rs = 0x9e3779b97f4a7c15ull;  // splitmix64: a fixed stream, the same tables for the same scene
+      auto rnd = [&]() { rs += 0x9e3779b97f4a7c15ull; unsigned long long z = rs; z = (z ^ (z >> 30)) * 0xbf58476d1ce4e5b9ull; z = (z ^ (z >> 27)) * 0x94d049bb133111ebull; z ^= z >> 31; return (double)(z >> 11) * (1.0 / 9007199254740992.0); };
+      const rt_bvh_node& root = desc->nodes[0];
+      const double ctr[3] = {0.5 * ((double)root.bmin[0] + root.bmax[0]), 0.5 * ((double)root.bmin[1] + root.bmax[1]), 0.5 * ((double)root.bmin[2] + root.bmax[2])};
+      for (uint32_t r = 0; r < K && cum[desc->n_tris] > 0.0; ++r) {
+        const double x = rnd() * cum[desc->n_tris];
+        const uint32_t t = (uint32_t)std::min<size_t>(desc->n_tris - 1, (size_t)(std::upper_bound(cum.begin(), cum.end(), x) - cum.begin()) - 1);
+        const double su = std::sqrt(rnd()), b0 = 1.0 - su, b1 = rnd() * su, b2 = 1.0 - b0 - b1;
+        CalRay cr;
+        for (int k = 0; k < 3; ++k) cr.o[k] = b0 * P(t, 0, k) + b1 * P(t, 1, k) + b2 * P(t, 2, k);
+        const double e1[3] = {P(t, 1, 0) - P(t, 0, 0), P(t, 1, 1) - P(t, 0, 1), P(t, 1, 2) - P(t, 0, 2)}, e2[3] = {P(t, 2, 0) - P(t, 0, 0), P(t, 2, 1) - P(t, 0, 1), P(t, 2, 2) - P(t, 0, 2)};
+        double n[3] = {e1[1] * e2[2] - e1[2] * e2[1], e1[2] * e2[0] - e1[0] * e2[2], e1[0] * e2[1] - e1[1] * e2[0]};
+        const double nl = std::sqrt(n[0] * n[0] + n[1] * n[1] + n[2] * n[2]);
+        if (!(nl > 0.0)) continue;
+        for (int k = 0; k < 3; ++k) n[k] /= nl;
+        // three of four rays leave towards the middle of the scene (where a path's next vertex usually lies), one the other way
+        const double side = ((ctr[0] - cr.o[0]) * n[0] + (ctr[1] - cr.o[1]) * n[1] + (ctr[2] - cr.o[2]) * n[2]) < 0.0 ? -1.0 : 1.0;
+        const double flip = (rnd() < 0.25 ? -1.0 : 1.0) * side;
+        for (int k = 0; k < 3; ++k) n[k] *= flip;
+        const double a[3] = {std::fabs(n[0]) > 0.9 ? 0.0 : 1.0, std::fabs(n[0]) > 0.9 ? 1.0 : 0.0, 0.0};
+        double tx[3] = {n[1] * a[2] - n[2] * a[1], n[2] * a[0] - n[0] * a[2], n[0] * a[1] - n[1] * a[0]};
+        const double tl = std::sqrt(tx[0] * tx[0] + tx[1] * tx[1] + tx[2] * tx[2]);
+        for (int k = 0; k < 3; ++k) tx[k] /= tl;
+        const double ty[3] = {n[1] * tx[2] - n[2] * tx[1], n[2] * tx[0] - n[0] * tx[2], n[0] * tx[1] - n[1] * tx[0]};
+        const double r1 = rnd(), ph = 6.283185307179586 * rnd(), rr = std::sqrt(r1), cz = std::sqrt(1.0 - r1);
+        for (int k = 0; k < 3; ++k) { cr.d[k] = tx[k] * rr * std::cos(ph) + ty[k] * rr * std::sin(ph) + n[k] * cz; cr.o[k] += 1e-4 * nl * 0.0 + n[k] * 1e-6 * (std::fabs(cr.o[k]) + 1.0); }
+        if (cr.d[0] == 0.0 || cr.d[1] == 0.0 || cr.d[2] == 0.0) continue;
+        rays.push_back(cr);
+      }
+      // node tests of BVH::intersect's walk over the rays when only `kept` nodes are tested (a node that is not tested counts as passed)
+      auto cost = [&]() {
+        unsigned long long tests = 0;
+        std::vector<uint32_t> stk; stk.reserve(64);
+        for (const CalRay& cr : rays) {
+          const double inv[3] = {1.0 / cr.d[0], 1.0 / cr.d[1], 1.0 / cr.d[2]};
+          double t_max = 1e300; stk.clear(); uint32_t cur = 0;
+          for (;;) {
+            const rt_bvh_node& n = desc->nodes[cur];
+            bool hit = true;
+            if (kept[cur]) {
+              tests += 1;
+              double tn = -1e300, tf = 1e300;
+              for (int k = 0; k < 3; ++k) { double a0 = ((double)n.bmin[k] - cr.o[k]) * inv[k], a1 = ((double)n.bmax[k] - cr.o[k]) * inv[k]; if (a0 > a1) std::swap(a0, a1); tn = std::max(tn, a0); tf = std::min(tf, a1); }
+              hit = tn <= tf && tf > 0.0 && tn < t_max;
+            }
+            if (hit && n.n_prims != 0) {
+              for (uint32_t t = n.offset; t < n.offset + n.n_prims; ++t) {  // Moeller-Trumbore in double: the t_max a hit leaves behind
+                const double e1[3] = {P(t, 1, 0) - P(t, 0, 0), P(t, 1, 1) - P(t, 0, 1), P(t, 1, 2) - P(t, 0, 2)}, e2[3] = {P(t, 2, 0) - P(t, 0, 0), P(t, 2, 1) - P(t, 0, 1), P(t, 2, 2) - P(t, 0, 2)};
+                const double pv[3] = {cr.d[1] * e2[2] - cr.d[2] * e2[1], cr.d[2] * e2[0] - cr.d[0] * e2[2], cr.d[0] * e2[1] - cr.d[1] * e2[0]};
+                const double det = pv[0] * e1[0] + pv[1] * e1[1] + pv[2] * e1[2];
+                if (det == 0.0) continue;
+                const double tv[3] = {cr.o[0] - P(t, 0, 0), cr.o[1] - P(t, 0, 1), cr.o[2] - P(t, 0, 2)};
+                const double u = (tv[0] * pv[0] + tv[1] * pv[1] + tv[2] * pv[2]) / det;
+                if (u < 0.0 || u > 1.0) continue;
+                const double qv[3] = {tv[1] * e1[2] - tv[2] * e1[1], tv[2] * e1[0] - tv[0] * e1[2], tv[0] * e1[1] - tv[1] * e1[0]};
+                const double v = (cr.d[0] * qv[0] + cr.d[1] * qv[1] + cr.d[2] * qv[2]) / det;
+                if (v < 0.0 || u + v > 1.0) continue;
+                const double tt = (e2[0] * qv[0] + e2[1] * qv[1] + e2[2] * qv[2]) / det;
+                if (tt > 1e-9 && tt < t_max) t_max = tt;
+              }
+            }
+            if (hit && n.n_prims == 0) {
+              const bool neg = inv[n.axis < 2 ? n.axis : 2] < 0.0;
+              if (neg) { stk.push_back(cur + 1); cur = n.offset; } else { stk.push_back(n.offset); cur = cur + 1; }
+            } else { if (stk.empty()) break; cur = stk.back(); stk.pop_back(); }
+          }
+        }
+        return tests;
+      };
+      if (rays.size() >= K / 2) {
+        unsigned long long best = cost();
+        for (int pass = 0; pass < 3; ++pass) {
+          bool changed = false;
+          for (uint32_t i = 0; i < nn; ++i) {
+            if (desc->nodes[i].n_prims != 0 || !kept[i]) continue;
+            kept[i] = 0;
+            const unsigned long long c = cost();
+            if (c < best) { best = c; changed = true; } else kept[i] = 1;
+          }
+          if (!changed) break;
+        }
+      }
+      uint32_t nt = 0; for (uint32_t i = 0; i < nn; ++i) nt += kept[i] ? 1u : 0u;
+      s->lds_nodes_tested = nt;
+    }
+    {
+      // the octant's order over ALL nodes (pos), each node's subtree as a range of it; then per node: the first TESTED node inside its subtree (enter) and the first after it (skip)
+      std::vector<uint32_t> link_full((size_t)8 * nn + 8, 0u), link_kept((size_t)8 * nn + 8, 0u);
+      std::vector<uint32_t> order; std::vector<uint32_t> pos(nn), end_(nn);
+      for (uint32_t o = 0; o < 8; ++o) {
+        order.clear(); st.clear();
+        uint32_t cur = 0;
+        for (;;) {
+          pos[cur] = (uint32_t)order.size(); order.push_back(cur);
+          const rt_bvh_node& n = desc->nodes[cur];
+          if (n.n_prims == 0) {
+            const bool neg = ((o >> (n.axis < 2 ? n.axis : 2)) & 1u) != 0u;
+            if (neg) { st.push_back(cur + 1); cur = n.offset; } else { st.push_back(n.offset); cur = cur + 1; }
+          } else { if (st.empty()) break; cur = st.back(); st.pop_back(); }
+        }
+        // subtree end in the octant's order: a node's subtree is contiguous in any depth-first order; its length is its node count
+        std::vector<uint32_t> size(nn, 1u);
+        for (uint32_t i = nn; i-- > 0;) if (desc->nodes[i].n_prims == 0) size[i] = 1u + size[i + 1] + size[desc->nodes[i].offset];
+        for (uint32_t i = 0; i < nn; ++i) end_[i] = pos[i] + size[i];
+        for (int which = 0; which < 2; ++which) {
+          std::vector<uint32_t>& L = which == 0 ? link_full : link_kept;
+          auto tested = [&](uint32_t i) { return which == 0 || kept[i] != 0; };
+          std::vector<uint32_t> next_tested(nn + 1, nn);  // by position: the first tested node at or after it
+          for (uint32_t p_ = nn; p_-- > 0;) next_tested[p_] = tested(order[p_]) ? order[p_] : next_tested[p_ + 1];
+          for (uint32_t i = 0; i < nn; ++i) {
+            const uint32_t enter = pos[i] + 1 < end_[i] ? next_tested[pos[i] + 1] : nn;  // (inside the subtree a tested node always exists: its leaves)
+            const uint32_t skp = end_[i] < nn ? next_tested[end_[i]] : nn;
+            L[(size_t)o * nn + i] = (enter << 16) | skp;
+          }
+          L[(size_t)8 * nn + o] = next_tested[0];
+        }
+      }
+      int rcl = upload(s->link8_full, link_full.data(), link_full.size() * 4);
+      if (rcl == RT_OK) rcl = upload(s->link8, link_kept.data(), link_kept.size() * 4);
+      if (rcl != RT_OK) { delete s; return rcl; }
+      d.link8_full = s->link8_full.as<unsigned>(); d.link8 = s->link8.as<unsigned>();
+    }
   }
   if (!s->small && !s->deep_column) {  // LDS-resident scenes keep the one-node-per-step loop: the pair form measured no faster there
     // With object instances the records cover the top-level tree (objects are walked one node per step, their child offsets are relative to the object).
@@ -803,6 +951,7 @@ extern "C" int rt_offset_ray_origin(const float* p, const float* p_error, const 
 extern "C" int rt_scene_query(rt_scene* s, int32_t what) {
   if (!s) return fail(RT_ERR_INVALID, "null scene");
   if (what == RT_QUERY_LDS_RESIDENT) return s->small ? 1 : 0;
+  if (what == RT_QUERY_LDS_NODES_TESTED) return s->small ? (int)s->lds_nodes_tested : 0;
   return fail(RT_ERR_INVALID, "unknown rt_scene_query item");
 }
 
@@ -930,7 +1079,7 @@ template <bool ANY, bool SMALL, int BLOCK, int DEPTH>
 static unsigned trace_grid(const rt_scene* s, bool threaded = false) {  // threaded: the plain-triangle kernels of an LDS-resident scene (closest_small / occluded_small: skip links instead of a stack)
   unsigned lds = (unsigned)(DEPTH * BLOCK * ((SMALL && (!ANY || RT_ANY_STACK16)) ? 2 : 4) + (SMALL ? (8 * RT_SMALL_NODES + 10 * RT_SMALL_TRIS) * 4 : 32));
   unsigned waves = 8;
-  if (SMALL && threaded) { lds = (unsigned)((8 * RT_SMALL_NODES + 10 * RT_SMALL_TRIS) * 4 + (ANY ? 1 : 8) * RT_SMALL_NODES * 2); waves = ANY ? RT_LDS_ANY_WAVES : RT_LDS_TRACE_WAVES; }
+  if (SMALL && threaded) { lds = (unsigned)((8 * RT_SMALL_NODES + 10 * RT_SMALL_TRIS) * 4 + (ANY ? 1 : 8) * RT_SMALL_NODES * (RT_LDS_LINKS ? 4 : 2) + 32); waves = ANY ? RT_LDS_ANY_WAVES : RT_LDS_TRACE_WAVES; }
   unsigned per_cu = (160u * 1024u) / lds; if (per_cu * BLOCK > waves * 256u) per_cu = waves * 256u / BLOCK; if (per_cu < 1) per_cu = 1;
   return (unsigned)s->n_cu * per_cu;
 }

@@ -971,6 +971,94 @@ RT_DEV bool closest_small(const float* __restrict__ s_nodes, const float* __rest
   return found;
 }
 
+// ---- Round 5: the stackless walks over LINKS, and over fewer nodes. closest_small / occluded_small find the next node from the node's record (split axis, second child)
+// and the skip table; here one word per (octant, node) says both - where the walk goes when the node's box passes (interior nodes), where it carries on after the node's subtree -
+// so the node step is the box test and one select. And the tables need not name every node: a node's box CONTAINS its children's boxes (bvh/mod.rs:279-287: an interior node's
+// bounds are the union), so for a finite ray an interior node's test fails only if both children's tests fail too (minima / maxima are monotone in the box, slab_test_finite) -
+// the test of an interior node decides nothing, it only saves work when it fails. rt_scene_create measures, on synthetic path-like rays, which interior nodes' tests save less
+// than they cost and leaves those out of link8 (S1: 8 of 19 interior nodes stay; 18.5 -> 12.3 node tests per ray); the walk visits the same leaves in the same order with the same
+// t_max - every leaf is still tested against its own box at its own time, which is all BVH::intersect's result depends on. Rays with a zero direction component keep every node
+// (link8_full, read from HBM by the few hundred waves that hold one): the literal node test's NaN rules are not the minima / maxima the argument needs.
+#ifndef RT_LDS_LINKS
+#define RT_LDS_LINKS 1
+#endif
+template <int N, int T, bool FINITE>
+RT_DEV bool occluded_small_links(const float* __restrict__ s_nodes, const float* __restrict__ s_tris, const unsigned* __restrict__ link /* octant 0's row; [8 * n_nodes]: its start */, const int n_nodes, const int start, const Ray ray) {
+  const f3 inv_dir = mk3(1.0f / ray.d.x, 1.0f / ray.d.y, 1.0f / ray.d.z);
+  const RayPre rp = ray_pre(ray);
+  const float* const tpx = s_tris + rp.kx * T; const float* const tpy = s_tris + rp.ky * T; const float* const tpz = s_tris + rp.kz * T;
+  const f3 op = permute(ray.o, rp.kx, rp.ky, rp.kz);
+  bool found = false;
+  int cur = start;  // n_nodes: done
+  for (;;) {
+    if (cur < n_nodes) {
+      const float* nd = s_nodes + cur;
+      const float4 n0 = make_float4(nd[0], nd[2 * N], nd[4 * N], nd[N]), n1 = make_float4(nd[3 * N], nd[5 * N], 0.0f, 0.0f);
+      const unsigned lk = link[cur];
+      const bool hit = slab_test_t<FINITE>(n0, n1, ray, inv_dir, inv_dir.x < 0.0f, inv_dir.y < 0.0f, inv_dir.z < 0.0f);
+      int next = (int)(lk & 0xffffu);
+      if (hit) {
+        const int n_prims = (int)(__float_as_uint(nd[7 * N]) & 0xffffu);
+        if (n_prims != 0) {
+          const int off = __float_as_int(nd[6 * N]);
+          for (int i = 0; i < n_prims; ++i) {
+            const int t = off + i;
+            const f3 p0t = mk3(tpx[t] - op.x, tpy[t] - op.y, tpz[t] - op.z), p1t = mk3(tpx[3 * T + t] - op.x, tpy[3 * T + t] - op.y, tpz[3 * T + t] - op.z),
+                     p2t = mk3(tpx[6 * T + t] - op.x, tpy[6 * T + t] - op.y, tpz[6 * T + t] - op.z);
+            TriHit h;
+            if (tri_test_permuted<RT_ANY_EARLY_SIGN != 0>(p0t, p1t, p2t, rp.sx, rp.sy, rp.sz, ray.t_max, h)) { found = true; next = n_nodes; break; }
+          }
+        } else next = (int)(lk >> 16);
+      }
+      cur = next;
+    }
+    if (__ballot(cur < n_nodes) == 0ull) break;
+  }
+  return found;
+}
+template <int N, int T, bool FINITE, int LEAF_MIN>
+RT_DEV bool closest_small_links(const float* __restrict__ s_nodes, const float* __restrict__ s_tris, const unsigned* __restrict__ link8 /* rows N (LDS) or n_nodes (HBM) apart */, const int row, const int n_nodes, Ray ray, int& prim_out, TriHit& hit_out) {
+  const f3 inv_dir = mk3(1.0f / ray.d.x, 1.0f / ray.d.y, 1.0f / ray.d.z);
+  const int neg_x = inv_dir.x < 0.0f, neg_y = inv_dir.y < 0.0f, neg_z = inv_dir.z < 0.0f;
+  const unsigned oct = (neg_x ? 1u : 0u) | (neg_y ? 2u : 0u) | (neg_z ? 4u : 0u);
+  const unsigned* const link = link8 + oct * row;
+  const RayPre rp = ray_pre(ray);
+  const float* const tpx = s_tris + rp.kx * T; const float* const tpy = s_tris + rp.ky * T; const float* const tpz = s_tris + rp.kz * T;
+  const f3 op = permute(ray.o, rp.kx, rp.ky, rp.kz);
+  bool found = false;
+  int cur = (int)link8[8 * row + oct], leaf_off = 0, leaf_n = 0;  // the octant's first tested node
+  for (;;) {
+    unsigned long long holders = 0ull;
+    for (;;) {
+      if (leaf_n == 0 && cur < n_nodes) {
+        const float* nd = s_nodes + cur;
+        const float4 n0 = make_float4(nd[0], nd[2 * N], nd[4 * N], nd[N]), n1 = make_float4(nd[3 * N], nd[5 * N], 0.0f, 0.0f);
+        const unsigned lk = link[cur];
+        int next = (int)(lk & 0xffffu);
+        if (slab_test_t<FINITE>(n0, n1, ray, inv_dir, neg_x, neg_y, neg_z)) {
+          const int n_prims = (int)(__float_as_uint(nd[7 * N]) & 0xffffu);
+          if (n_prims != 0) { leaf_off = __float_as_int(nd[6 * N]); leaf_n = n_prims; }
+          else next = (int)(lk >> 16);
+        }
+        cur = next;
+      }
+      holders = __ballot(leaf_n > 0);
+      if (__ballot(leaf_n == 0 && cur < n_nodes) == 0ull) break;
+      if (__builtin_popcount((unsigned)holders) + __builtin_popcount((unsigned)(holders >> 32)) >= LEAF_MIN) break;
+    }
+    if (holders == 0ull) break;
+    if (leaf_n > 0) {
+      const int t = leaf_off;
+      const f3 p0t = mk3(tpx[t] - op.x, tpy[t] - op.y, tpz[t] - op.z), p1t = mk3(tpx[3 * T + t] - op.x, tpy[3 * T + t] - op.y, tpz[3 * T + t] - op.z),
+               p2t = mk3(tpx[6 * T + t] - op.x, tpy[6 * T + t] - op.y, tpz[6 * T + t] - op.z);
+      TriHit h;
+      if (tri_test_permuted(p0t, p1t, p2t, rp.sx, rp.sy, rp.sz, ray.t_max, h)) { found = true; ray.t_max = h.t; prim_out = t; hit_out = h; }
+      leaf_off += 1; leaf_n -= 1;
+    }
+  }
+  return found;
+}
+
 // Round 5: the closest-hit walk of an LDS-resident scene in which NOBODY WAITS. In closest_small a lane that reaches a leaf holds it until
 // LEAF_MIN lanes hold one - 48.6 % of the lanes step in a node round, 29.2 % test in a leaf phase (probe build, S1). It has to wait because what follows the leaf
 // is tested against the t_max the leaf leaves behind. Here the lane notes the leaf (FIFO of up to six node ids in one 64-bit register) and WALKS ON with the t_max
@@ -1091,10 +1179,17 @@ __global__ void __launch_bounds__(BLOCK, (SMALL && GENERAL == 0 && !COUNT) ? ((A
   QView qv; if (queue) qv.init(io.queue_is_slots ? nullptr : queue, shard_counts, shard_cap);
   const unsigned count = queue ? qv.total() : count_static;
   if (blockIdx.x * BLOCK >= count) return;  // short queues (MIS rays, late bounces): most blocks of the persistent grid have nothing to stage for
-  __shared__ unsigned short s_skip[STACKLESS ? (ANY ? 1 : 8) * NN : 1];  // the links of the walk order(s): DScene::skip8, rows NN apart
+  constexpr bool LINKS = STACKLESS && RT_LDS_LINKS && RT_LDS_ANY_DEFER_MIN == 0 && RT_LDS_CLOSEST_DEFER_MIN == 0;  // the link-table walks (the deferred experiments keep the skip tables)
+  __shared__ unsigned short s_skip[(STACKLESS && !LINKS) ? (ANY ? 1 : 8) * NN : 1];  // the links of the walk order(s): DScene::skip8, rows NN apart
+  __shared__ unsigned s_link[LINKS ? (ANY ? 1 : 8) * NN + 8 : 1];  // DScene::link8 (the tested nodes' links), rows NN apart, then the 8 start nodes
   if (SMALL) { stage_small_scene<BLOCK, NN, NT>(sc, s_nodes, s_tris); __syncthreads(); }
-  if (STACKLESS) {
+  if (STACKLESS && !LINKS) {
     for (unsigned i = threadIdx.x; i < (ANY ? 1u : 8u) * sc.n_nodes; i += BLOCK) { const unsigned o = i / sc.n_nodes, k = i - o * sc.n_nodes; s_skip[o * NN + k] = sc.skip8[i]; }
+    __syncthreads();
+  }
+  if (LINKS) {
+    for (unsigned i = threadIdx.x; i < (ANY ? 1u : 8u) * sc.n_nodes; i += BLOCK) { const unsigned o = i / sc.n_nodes, k = i - o * sc.n_nodes; s_link[o * NN + k] = sc.link8[i]; }
+    if (threadIdx.x < 8u) s_link[(ANY ? 1 : 8) * NN + threadIdx.x] = sc.link8[8u * sc.n_nodes + threadIdx.x];
     __syncthreads();
   }
   const unsigned stride = gridDim.x * BLOCK;
@@ -1112,13 +1207,20 @@ __global__ void __launch_bounds__(BLOCK, (SMALL && GENERAL == 0 && !COUNT) ? ((A
     const bool fin = FIN_FORMS && __ballot(!inv_dir_finite(mk3(1.0f / ray.d.x, 1.0f / ray.d.y, 1.0f / ray.d.z))) == 0ull;
     if (SMALL && LM > 1 && LM < 64 && !COUNT) {
       LdsS src{s_nodes, s_tris};
-      if (STACKLESS && !ANY && RT_LDS_CLOSEST_DEFER_MIN > 0) found = fin ? closest_small_deferred<NN, NT, true, RT_LDS_CLOSEST_DEFER_MIN>(s_nodes, s_tris, s_skip, (int)sc.n_nodes, ray, prim, h) : closest_small_deferred<NN, NT, false, RT_LDS_CLOSEST_DEFER_MIN>(s_nodes, s_tris, s_skip, (int)sc.n_nodes, ray, prim, h);
+      if (LINKS && !ANY) {
+        if (fin) {  // (s_link: 8 rows NN apart, the starts behind them - closest_small_links reads link8[8 * row + oct])
+          found = closest_small_links<NN, NT, true, LM>(s_nodes, s_tris, s_link, NN, (int)sc.n_nodes, ray, prim, h);
+        } else found = closest_small_links<NN, NT, false, LM>(s_nodes, s_tris, sc.link8_full, (int)sc.n_nodes, (int)sc.n_nodes, ray, prim, h);
+      }
+      else if (STACKLESS && !ANY && RT_LDS_CLOSEST_DEFER_MIN > 0) found = fin ? closest_small_deferred<NN, NT, true, RT_LDS_CLOSEST_DEFER_MIN>(s_nodes, s_tris, s_skip, (int)sc.n_nodes, ray, prim, h) : closest_small_deferred<NN, NT, false, RT_LDS_CLOSEST_DEFER_MIN>(s_nodes, s_tris, s_skip, (int)sc.n_nodes, ray, prim, h);
       else if (STACKLESS && !ANY) found = fin ? closest_small<NN, NT, true, LM>(s_nodes, s_tris, s_skip, (int)sc.n_nodes, ray, prim, h) : closest_small<NN, NT, false, LM>(s_nodes, s_tris, s_skip, (int)sc.n_nodes, ray, prim, h);
       else found = traverse_rounds<ANY, COUNT, LM, LdsS, StackT, GENERAL>(src, ray, stack + threadIdx.x, BLOCK, prim, h, n_nodes, n_tris, gen);
     }
     else if (SMALL) {
       LdsS src{s_nodes, s_tris};
-      if (STACKLESS && RT_LDS_ANY_DEFER_MIN > 0) found = fin ? occluded_small_deferred<NN, NT, true, RT_LDS_ANY_DEFER_MIN>(s_nodes, s_tris, s_skip, (int)sc.n_nodes, ray) : occluded_small_deferred<NN, NT, false, RT_LDS_ANY_DEFER_MIN>(s_nodes, s_tris, s_skip, (int)sc.n_nodes, ray);
+      if (LINKS) found = fin ? occluded_small_links<NN, NT, true>(s_nodes, s_tris, s_link, (int)sc.n_nodes, (int)s_link[NN], ray)
+                             : occluded_small_links<NN, NT, false>(s_nodes, s_tris, sc.link8_full, (int)sc.n_nodes, (int)sc.link8_full[8u * sc.n_nodes], ray);
+      else if (STACKLESS && RT_LDS_ANY_DEFER_MIN > 0) found = fin ? occluded_small_deferred<NN, NT, true, RT_LDS_ANY_DEFER_MIN>(s_nodes, s_tris, s_skip, (int)sc.n_nodes, ray) : occluded_small_deferred<NN, NT, false, RT_LDS_ANY_DEFER_MIN>(s_nodes, s_tris, s_skip, (int)sc.n_nodes, ray);
       else if (STACKLESS) found = fin ? occluded_small<NN, NT, true>(s_nodes, s_tris, s_skip, (int)sc.n_nodes, ray) : occluded_small<NN, NT, false>(s_nodes, s_tris, s_skip, (int)sc.n_nodes, ray);
       else found = traverse<ANY, COUNT, LdsS, StackT, GENERAL>(src, ray, stack + threadIdx.x, BLOCK, prim, h, n_nodes, n_tris, gen);
     }

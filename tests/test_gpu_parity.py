@@ -115,6 +115,49 @@ def test_rays_with_zero_direction_components_take_the_reference_selects(gpu_host
     assert np.array_equal(o.trace(rays, True)["occluded"], h.trace(rays, True, count=False)["occluded"])
 
 
+@pytest.mark.parametrize("scene", ["cornell", "soup-128", "soup-40-degenerate"])
+def test_untested_interior_nodes_change_no_hit_record(gpu_host, orc, scene, monkeypatch):
+    """Round 5: the stackless walks of an LDS-resident scene pass over interior nodes whose box test rarely fails (rt_scene_create picks them on synthetic rays; a box contains
+    its children's boxes, so an interior node's test decides nothing). Hit records and occlusion answers must be the oracle's bit for bit with and without that - on rays
+    inside and outside the scene, axis-parallel rays and rays with zero components (which walk every node) among them."""
+    from rustracer_amd.scenes import cornell_box, random_soup
+    if scene == "cornell":
+        d = cornell_box(32, 32, 1)
+        lo, hi = np.float32([-50, -50, -850]), np.float32([600, 600, 600])
+    elif scene == "soup-128":
+        d = random_soup(126, seed=5, max_prims=4)            # (+ the emitter quad: 128 primitives, the LDS kernels' limit)
+        lo, hi = np.float32([-20] * 3), np.float32([120] * 3)
+    else:
+        d = random_soup(40, seed=9, max_prims=1, degenerate=True)   # coincident centroids, a flat half: the leaf fall-backs of the build
+        lo, hi = np.float32([-20] * 3), np.float32([120] * 3)
+    n = 60000
+    rays = random_rays(n, lo, hi, seed=17)
+    k = np.arange(n)
+    rays[k % 11 == 0, 4] = 0.0                     # zero direction components: those waves take the full tables
+    rays[k % 13 == 0, 5] = -0.0
+    rays[k % 17 == 0, 4:7] = np.float32([0, 0, 1])  # axis-parallel
+    o = orc.OracleScene(d)
+    ro = o.trace(rays)
+    rays_any = rays.copy(); rays_any[:, 3] = np.random.default_rng(3).uniform(0.1, 700 if scene == "cornell" else 150, n).astype(np.float32)
+    ra = o.trace(rays_any, True)
+    tested = {}
+    for prune in ("1", "0"):
+        monkeypatch.setenv("RTX_LDS_PRUNE", prune)
+        h = gpu_host.HostScene(d); h.upload(0)
+        assert h.lds_resident()
+        tested[prune] = gpu_host.lib().rtxh_scene_query(h.h, 1)
+        rh = h.trace(rays, count=False)
+        assert np.array_equal(ro["prim"], rh["prim"]), prune
+        for f in ("t", "b0", "b1"):
+            assert np.array_equal(bits(ro[f]), bits(rh[f])), (prune, f)
+        assert np.array_equal(ra["occluded"], h.trace(rays_any, True, count=False)["occluded"]), prune
+    nn = gpu_host.HostScene(d).bvh_sizes()[0]
+    assert tested["0"] == nn and tested["1"] <= nn
+    if scene == "cornell":
+        assert tested["1"] < nn   # the Cornell box's walls fill their parents' boxes: some interior tests never pay
+    assert (ro["prim"] >= 0).mean() > 0.02
+
+
 def test_offset_ray_origin_steps_ulps_like_the_reference(gpu_host, orc):
     """offset_ray_origin (geometry/mod.rs:203-220): the device steps a coordinate up or down with ONE fused sequence (next_float_toward, round 5); the reference has
     next_float_up / next_float_down (lib.rs:227-262). Bit-equal on ordinary points and on every special value: zeros of both signs, denormals, the largest floats,
