@@ -615,7 +615,8 @@ extern "C" int rt_scene_create(const rt_scene_desc* desc, int device, rt_scene**
     // A box contains its children's boxes, so an interior node's test decides nothing - it saves its subtree's tests when it fails and costs one test when it does not. Which
     // interior nodes earn their test is measured here on synthetic rays of the kind a path tracer casts (origins on the surfaces, cosine-distributed directions): a greedy pass
     // drops a node when the walk without it tests fewer nodes. Leaves always stay (a leaf's own test is what decides whether its primitives are tested). The choice only moves time.
-    std::vector<char> kept(nn, 1);
+    // kept[o]: the nodes the closest-hit walk of octant o tests; kept[8]: the nodes the occlusion walk (octant 0's order for every ray) tests
+    std::vector<std::vector<char>> kept(9, std::vector<char>(nn, 1));
     bool nested = !s->general_prims && nn >= 3;
     for (uint32_t i = 0; i < nn && nested; ++i) {
       const rt_bvh_node& n = desc->nodes[i];
@@ -626,9 +627,9 @@ extern "C" int rt_scene_create(const rt_scene_desc* desc, int device, rt_scene**
     const char* prune_env = getenv("RTX_LDS_PRUNE");  // measurement / test knob, read per scene: 0 = every node is tested
     s->lds_nodes_tested = nn;
     if (nested && !(prune_env && prune_env[0] == '0')) {
-      const uint32_t K = nn <= 64 ? 2048u : 512u;  // (the greedy pass costs interior nodes x rays x visits: milliseconds for S1's 39 nodes, under a tenth of a second for 255)
-      struct CalRay { double o[3], d[3]; };
-      std::vector<CalRay> rays; rays.reserve(K);
+      const uint32_t K = nn <= 64 ? 8192u : 2048u;  // (a greedy pass costs interior nodes x rays x visits: milliseconds for S1's 39 nodes, ~0.1 s for 255)
+      struct CalRay { double o[3], d[3], t_max; };
+      std::vector<CalRay> rays[9];  // closest-hit rays by octant; [8]: occlusion segments
       std::vector<double> cum(desc->n_tris + 1, 0.0);
       auto P = [&](uint32_t t, int v, int k) { return (double)desc->tri_p[9 * (size_t)t + 3 * v + k]; };
       for (uint32_t t = 0; t < desc->n_tris; ++t) {
@@ -636,16 +637,18 @@ extern "C" int rt_scene_create(const rt_scene_desc* desc, int device, rt_scene**
         const double cx = e1[1] * e2[2] - e1[2] * e2[1], cy = e1[2] * e2[0] - e1[0] * e2[2], cz = e1[0] * e2[1] - e1[1] * e2[0];
         cum[t + 1] = cum[t] + 0.5 * std::sqrt(cx * cx + cy * cy + cz * cz);
       }
+      std::vector<uint32_t> emitters;  // emitting triangles: where shadow rays go
+      for (uint32_t i = 0; i < desc->n_lights; ++i) if (desc->lights[i].kind == RT_LIGHT_DIFFUSE_AREA && desc->lights[i].prim >= 0 && (uint32_t)desc->lights[i].prim < desc->n_tris) emitters.push_back((uint32_t)desc->lights[i].prim);
       unsigned long long rs = 0x9e3779b97f4a7c15ull;  // splitmix64: a fixed stream, the same tables for the same scene
       auto rnd = [&]() { rs += 0x9e3779b97f4a7c15ull; unsigned long long z = rs; z = (z ^ (z >> 30)) * 0xbf58476d1ce4e5b9ull; z = (z ^ (z >> 27)) * 0x94d049bb133111ebull; z ^= z >> 31; return (double)(z >> 11) * (1.0 / 9007199254740992.0); };
       const rt_bvh_node& root = desc->nodes[0];
       const double ctr[3] = {0.5 * ((double)root.bmin[0] + root.bmax[0]), 0.5 * ((double)root.bmin[1] + root.bmax[1]), 0.5 * ((double)root.bmin[2] + root.bmax[2])};
+      auto surface_point = [&](uint32_t t, double* p) { const double su = std::sqrt(rnd()), b0 = 1.0 - su, b1 = rnd() * su, b2 = 1.0 - b0 - b1; for (int k = 0; k < 3; ++k) p[k] = b0 * P(t, 0, k) + b1 * P(t, 1, k) + b2 * P(t, 2, k); };
+      auto pick_tri = [&]() { const double x = rnd() * cum[desc->n_tris]; return (uint32_t)std::min<size_t>(desc->n_tris - 1, (size_t)(std::upper_bound(cum.begin(), cum.end(), x) - cum.begin()) - 1); };
       for (uint32_t r = 0; r < K && cum[desc->n_tris] > 0.0; ++r) {
-        const double x = rnd() * cum[desc->n_tris];
-        const uint32_t t = (uint32_t)std::min<size_t>(desc->n_tris - 1, (size_t)(std::upper_bound(cum.begin(), cum.end(), x) - cum.begin()) - 1);
-        const double su = std::sqrt(rnd()), b0 = 1.0 - su, b1 = rnd() * su, b2 = 1.0 - b0 - b1;
-        CalRay cr;
-        for (int k = 0; k < 3; ++k) cr.o[k] = b0 * P(t, 0, k) + b1 * P(t, 1, k) + b2 * P(t, 2, k);
+        const uint32_t t = pick_tri();
+        CalRay cr; cr.t_max = 1e300;
+        surface_point(t, cr.o);
         const double e1[3] = {P(t, 1, 0) - P(t, 0, 0), P(t, 1, 1) - P(t, 0, 1), P(t, 1, 2) - P(t, 0, 2)}, e2[3] = {P(t, 2, 0) - P(t, 0, 0), P(t, 2, 1) - P(t, 0, 1), P(t, 2, 2) - P(t, 0, 2)};
         double n[3] = {e1[1] * e2[2] - e1[2] * e2[1], e1[2] * e2[0] - e1[0] * e2[2], e1[0] * e2[1] - e1[1] * e2[0]};
         const double nl = std::sqrt(n[0] * n[0] + n[1] * n[1] + n[2] * n[2]);
@@ -654,35 +657,45 @@ extern "C" int rt_scene_create(const rt_scene_desc* desc, int device, rt_scene**
         // three of four rays leave towards the middle of the scene (where a path's next vertex usually lies), one the other way
         const double side = ((ctr[0] - cr.o[0]) * n[0] + (ctr[1] - cr.o[1]) * n[1] + (ctr[2] - cr.o[2]) * n[2]) < 0.0 ? -1.0 : 1.0;
         const double flip = (rnd() < 0.25 ? -1.0 : 1.0) * side;
-        for (int k = 0; k < 3; ++k) n[k] *= flip;
+        for (int k = 0; k < 3; ++k) { n[k] *= flip; cr.o[k] += n[k] * 1e-6 * (std::fabs(cr.o[k]) + 1.0); }
+        if ((r & 3u) == 3u) {  // every fourth ray: a shadow segment towards a point on an emitter (any surface point where nothing emits)
+          double q[3]; surface_point(emitters.empty() ? pick_tri() : emitters[(size_t)(rnd() * emitters.size()) % emitters.size()], q);
+          for (int k = 0; k < 3; ++k) cr.d[k] = q[k] - cr.o[k];
+          cr.t_max = 1.0 - 1e-4;
+          if (cr.d[0] == 0.0 || cr.d[1] == 0.0 || cr.d[2] == 0.0) continue;
+          rays[8].push_back(cr);
+          continue;
+        }
         const double a[3] = {std::fabs(n[0]) > 0.9 ? 0.0 : 1.0, std::fabs(n[0]) > 0.9 ? 1.0 : 0.0, 0.0};
         double tx[3] = {n[1] * a[2] - n[2] * a[1], n[2] * a[0] - n[0] * a[2], n[0] * a[1] - n[1] * a[0]};
         const double tl = std::sqrt(tx[0] * tx[0] + tx[1] * tx[1] + tx[2] * tx[2]);
         for (int k = 0; k < 3; ++k) tx[k] /= tl;
         const double ty[3] = {n[1] * tx[2] - n[2] * tx[1], n[2] * tx[0] - n[0] * tx[2], n[0] * tx[1] - n[1] * tx[0]};
         const double r1 = rnd(), ph = 6.283185307179586 * rnd(), rr = std::sqrt(r1), cz = std::sqrt(1.0 - r1);
-        for (int k = 0; k < 3; ++k) { cr.d[k] = tx[k] * rr * std::cos(ph) + ty[k] * rr * std::sin(ph) + n[k] * cz; cr.o[k] += 1e-4 * nl * 0.0 + n[k] * 1e-6 * (std::fabs(cr.o[k]) + 1.0); }
+        for (int k = 0; k < 3; ++k) cr.d[k] = tx[k] * rr * std::cos(ph) + ty[k] * rr * std::sin(ph) + n[k] * cz;
         if (cr.d[0] == 0.0 || cr.d[1] == 0.0 || cr.d[2] == 0.0) continue;
-        rays.push_back(cr);
+        rays[(cr.d[0] < 0.0 ? 1 : 0) | (cr.d[1] < 0.0 ? 2 : 0) | (cr.d[2] < 0.0 ? 4 : 0)].push_back(cr);
       }
-      // node tests of BVH::intersect's walk over the rays when only `kept` nodes are tested (a node that is not tested counts as passed)
-      auto cost = [&]() {
+      // node tests of the walk over the rays of set `w` when only kept[w] nodes are tested (a node that is not tested counts as passed). w < 8: BVH::intersect's order and its
+      // shrinking t_max; w == 8: the occlusion walk - first child first at every node, over at the first primitive hit
+      auto cost = [&](int w) {
         unsigned long long tests = 0;
         std::vector<uint32_t> stk; stk.reserve(64);
-        for (const CalRay& cr : rays) {
+        const std::vector<char>& kp = kept[w];
+        for (const CalRay& cr : rays[w]) {
           const double inv[3] = {1.0 / cr.d[0], 1.0 / cr.d[1], 1.0 / cr.d[2]};
-          double t_max = 1e300; stk.clear(); uint32_t cur = 0;
-          for (;;) {
+          double t_max = cr.t_max; stk.clear(); uint32_t cur = 0; bool done = false;
+          while (!done) {
             const rt_bvh_node& n = desc->nodes[cur];
             bool hit = true;
-            if (kept[cur]) {
+            if (kp[cur]) {
               tests += 1;
               double tn = -1e300, tf = 1e300;
               for (int k = 0; k < 3; ++k) { double a0 = ((double)n.bmin[k] - cr.o[k]) * inv[k], a1 = ((double)n.bmax[k] - cr.o[k]) * inv[k]; if (a0 > a1) std::swap(a0, a1); tn = std::max(tn, a0); tf = std::min(tf, a1); }
               hit = tn <= tf && tf > 0.0 && tn < t_max;
             }
             if (hit && n.n_prims != 0) {
-              for (uint32_t t = n.offset; t < n.offset + n.n_prims; ++t) {  // Moeller-Trumbore in double: the t_max a hit leaves behind
+              for (uint32_t t = n.offset; t < n.offset + n.n_prims && !done; ++t) {  // Moeller-Trumbore in double: the t_max a hit leaves behind
                 const double e1[3] = {P(t, 1, 0) - P(t, 0, 0), P(t, 1, 1) - P(t, 0, 1), P(t, 1, 2) - P(t, 0, 2)}, e2[3] = {P(t, 2, 0) - P(t, 0, 0), P(t, 2, 1) - P(t, 0, 1), P(t, 2, 2) - P(t, 0, 2)};
                 const double pv[3] = {cr.d[1] * e2[2] - cr.d[2] * e2[1], cr.d[2] * e2[0] - cr.d[0] * e2[2], cr.d[0] * e2[1] - cr.d[1] * e2[0]};
                 const double det = pv[0] * e1[0] + pv[1] * e1[1] + pv[2] * e1[2];
@@ -694,38 +707,47 @@ extern "C" int rt_scene_create(const rt_scene_desc* desc, int device, rt_scene**
                 const double v = (cr.d[0] * qv[0] + cr.d[1] * qv[1] + cr.d[2] * qv[2]) / det;
                 if (v < 0.0 || u + v > 1.0) continue;
                 const double tt = (e2[0] * qv[0] + e2[1] * qv[1] + e2[2] * qv[2]) / det;
-                if (tt > 1e-9 && tt < t_max) t_max = tt;
+                if (tt > 1e-9 && tt < t_max) { if (w == 8) done = true; else t_max = tt; }
               }
             }
+            if (done) break;
             if (hit && n.n_prims == 0) {
-              const bool neg = inv[n.axis < 2 ? n.axis : 2] < 0.0;
+              const bool neg = w < 8 && inv[n.axis < 2 ? n.axis : 2] < 0.0;
               if (neg) { stk.push_back(cur + 1); cur = n.offset; } else { stk.push_back(n.offset); cur = cur + 1; }
             } else { if (stk.empty()) break; cur = stk.back(); stk.pop_back(); }
           }
         }
         return tests;
       };
-      if (rays.size() >= K / 2) {
-        unsigned long long best = cost();
-        for (int pass = 0; pass < 3; ++pass) {
-          bool changed = false;
-          for (uint32_t i = 0; i < nn; ++i) {
-            if (desc->nodes[i].n_prims != 0 || !kept[i]) continue;
-            kept[i] = 0;
-            const unsigned long long c = cost();
-            if (c < best) { best = c; changed = true; } else kept[i] = 1;
+      uint32_t nt = 0;
+      for (int w = 0; w < 9; ++w) {
+        if (rays[w].size() >= 64) {
+          unsigned long long best = cost(w);
+          for (int pass = 0; pass < 3; ++pass) {
+            bool changed = false;
+            for (uint32_t i = 0; i < nn; ++i) {
+              if (desc->nodes[i].n_prims != 0 || !kept[w][i]) continue;
+              kept[w][i] = 0;
+              const unsigned long long c = cost(w);
+              if (c < best) { best = c; changed = true; } else kept[w][i] = 1;
+            }
+            if (!changed) break;
           }
-          if (!changed) break;
         }
+        if (w < 8) for (uint32_t i = 0; i < nn; ++i) nt += kept[w][i] ? 1u : 0u;
       }
-      uint32_t nt = 0; for (uint32_t i = 0; i < nn; ++i) nt += kept[i] ? 1u : 0u;
-      s->lds_nodes_tested = nt;
+      s->lds_nodes_tested = (nt + 4u) / 8u;  // (the closest-hit walks' average over the octants)
     }
     {
-      // the octant's order over ALL nodes (pos), each node's subtree as a range of it; then per node: the first TESTED node inside its subtree (enter) and the first after it (skip)
-      std::vector<uint32_t> link_full((size_t)8 * nn + 8, 0u), link_kept((size_t)8 * nn + 8, 0u);
+      // the octant's order over ALL nodes (pos), each node's subtree as a range of it; then per node: the first TESTED node inside its subtree (enter) and the first after it (skip).
+      // Layout: rows 0 - 7 (closest hit, one per octant), their 8 start nodes, row 8 (occlusion rays: octant 0's order, their own set of tested nodes), its start node.
+      const size_t tab = (size_t)9 * nn + 9;
+      std::vector<uint32_t> link_full(tab, 0u), link_kept(tab, 0u);
       std::vector<uint32_t> order; std::vector<uint32_t> pos(nn), end_(nn);
-      for (uint32_t o = 0; o < 8; ++o) {
+      std::vector<uint32_t> size(nn, 1u);
+      for (uint32_t i = nn; i-- > 0;) if (desc->nodes[i].n_prims == 0) size[i] = 1u + size[i + 1] + size[desc->nodes[i].offset];
+      for (uint32_t row = 0; row < 9; ++row) {
+        const uint32_t o = row < 8 ? row : 0u;
         order.clear(); st.clear();
         uint32_t cur = 0;
         for (;;) {
@@ -736,21 +758,19 @@ extern "C" int rt_scene_create(const rt_scene_desc* desc, int device, rt_scene**
             if (neg) { st.push_back(cur + 1); cur = n.offset; } else { st.push_back(n.offset); cur = cur + 1; }
           } else { if (st.empty()) break; cur = st.back(); st.pop_back(); }
         }
-        // subtree end in the octant's order: a node's subtree is contiguous in any depth-first order; its length is its node count
-        std::vector<uint32_t> size(nn, 1u);
-        for (uint32_t i = nn; i-- > 0;) if (desc->nodes[i].n_prims == 0) size[i] = 1u + size[i + 1] + size[desc->nodes[i].offset];
-        for (uint32_t i = 0; i < nn; ++i) end_[i] = pos[i] + size[i];
+        for (uint32_t i = 0; i < nn; ++i) end_[i] = pos[i] + size[i];  // (a node's subtree is contiguous in any depth-first order)
+        const size_t base = row < 8 ? (size_t)row * nn : (size_t)8 * nn + 8, start_at = row < 8 ? (size_t)8 * nn + row : (size_t)9 * nn + 8;
         for (int which = 0; which < 2; ++which) {
           std::vector<uint32_t>& L = which == 0 ? link_full : link_kept;
-          auto tested = [&](uint32_t i) { return which == 0 || kept[i] != 0; };
+          auto tested = [&](uint32_t i) { return which == 0 || kept[row][i] != 0; };
           std::vector<uint32_t> next_tested(nn + 1, nn);  // by position: the first tested node at or after it
           for (uint32_t p_ = nn; p_-- > 0;) next_tested[p_] = tested(order[p_]) ? order[p_] : next_tested[p_ + 1];
           for (uint32_t i = 0; i < nn; ++i) {
             const uint32_t enter = pos[i] + 1 < end_[i] ? next_tested[pos[i] + 1] : nn;  // (inside the subtree a tested node always exists: its leaves)
             const uint32_t skp = end_[i] < nn ? next_tested[end_[i]] : nn;
-            L[(size_t)o * nn + i] = (enter << 16) | skp;
+            L[base + i] = (enter << 16) | skp;
           }
-          L[(size_t)8 * nn + o] = next_tested[0];
+          L[start_at] = next_tested[0];
         }
       }
       int rcl = upload(s->link8_full, link_full.data(), link_full.size() * 4);

@@ -1188,8 +1188,12 @@ __global__ void __launch_bounds__(BLOCK, (SMALL && GENERAL == 0 && !COUNT) ? ((A
     __syncthreads();
   }
   if (LINKS) {
-    for (unsigned i = threadIdx.x; i < (ANY ? 1u : 8u) * sc.n_nodes; i += BLOCK) { const unsigned o = i / sc.n_nodes, k = i - o * sc.n_nodes; s_link[o * NN + k] = sc.link8[i]; }
-    if (threadIdx.x < 8u) s_link[(ANY ? 1 : 8) * NN + threadIdx.x] = sc.link8[8u * sc.n_nodes + threadIdx.x];
+    // DScene::link8: rows 0 - 7 (closest hit, by octant), their 8 starts, row 8 (occlusion rays), its start
+    if (ANY) { for (unsigned k = threadIdx.x; k < sc.n_nodes; k += BLOCK) s_link[k] = sc.link8[8u * sc.n_nodes + 8u + k]; if (threadIdx.x == 0u) s_link[NN] = sc.link8[9u * sc.n_nodes + 8u]; }
+    else {
+      for (unsigned i = threadIdx.x; i < 8u * sc.n_nodes; i += BLOCK) { const unsigned o = i / sc.n_nodes, k = i - o * sc.n_nodes; s_link[o * NN + k] = sc.link8[i]; }
+      if (threadIdx.x < 8u) s_link[8 * NN + threadIdx.x] = sc.link8[8u * sc.n_nodes + threadIdx.x];
+    }
     __syncthreads();
   }
   const unsigned stride = gridDim.x * BLOCK;
@@ -1219,7 +1223,7 @@ __global__ void __launch_bounds__(BLOCK, (SMALL && GENERAL == 0 && !COUNT) ? ((A
     else if (SMALL) {
       LdsS src{s_nodes, s_tris};
       if (LINKS) found = fin ? occluded_small_links<NN, NT, true>(s_nodes, s_tris, s_link, (int)sc.n_nodes, (int)s_link[NN], ray)
-                             : occluded_small_links<NN, NT, false>(s_nodes, s_tris, sc.link8_full, (int)sc.n_nodes, (int)sc.link8_full[8u * sc.n_nodes], ray);
+                             : occluded_small_links<NN, NT, false>(s_nodes, s_tris, sc.link8_full + 8u * sc.n_nodes + 8u, (int)sc.n_nodes, (int)sc.link8_full[9u * sc.n_nodes + 8u], ray);
       else if (STACKLESS && RT_LDS_ANY_DEFER_MIN > 0) found = fin ? occluded_small_deferred<NN, NT, true, RT_LDS_ANY_DEFER_MIN>(s_nodes, s_tris, s_skip, (int)sc.n_nodes, ray) : occluded_small_deferred<NN, NT, false, RT_LDS_ANY_DEFER_MIN>(s_nodes, s_tris, s_skip, (int)sc.n_nodes, ray);
       else if (STACKLESS) found = fin ? occluded_small<NN, NT, true>(s_nodes, s_tris, s_skip, (int)sc.n_nodes, ray) : occluded_small<NN, NT, false>(s_nodes, s_tris, s_skip, (int)sc.n_nodes, ray);
       else found = traverse<ANY, COUNT, LdsS, StackT, GENERAL>(src, ray, stack + threadIdx.x, BLOCK, prim, h, n_nodes, n_tris, gen);
