@@ -768,7 +768,8 @@ extern "C" int rt_scene_create(const rt_scene_desc* desc, int device, rt_scene**
           for (uint32_t i = 0; i < nn; ++i) {
             const uint32_t enter = pos[i] + 1 < end_[i] ? next_tested[pos[i] + 1] : nn;  // (inside the subtree a tested node always exists: its leaves)
             const uint32_t skp = end_[i] < nn ? next_tested[end_[i]] : nn;
-            L[base + i] = (enter << 16) | skp;
+            const rt_bvh_node& nd = desc->nodes[i];
+            L[base + i] = nd.n_prims != 0 && RT_LINK_LEAF ? (0x80000000u | ((uint32_t)nd.n_prims << 23) | ((uint32_t)nd.offset << 16) | skp) : ((enter << 16) | skp);
           }
           L[start_at] = next_tested[0];
         }

@@ -982,6 +982,9 @@ RT_DEV bool closest_small(const float* __restrict__ s_nodes, const float* __rest
 #ifndef RT_LDS_LINKS
 #define RT_LDS_LINKS 1
 #endif
+#ifndef RT_LINK_LEAF
+#define RT_LINK_LEAF 1  // a leaf's link word carries its primitives in the half an interior node's uses for "enter": bit 31, count << 23, first << 16 (<= 128 primitives)
+#endif
 template <int N, int T, bool FINITE>
 RT_DEV bool occluded_small_links(const float* __restrict__ s_nodes, const float* __restrict__ s_tris, const unsigned* __restrict__ link /* octant 0's row; [8 * n_nodes]: its start */, const int n_nodes, const int start, const Ray ray) {
   const f3 inv_dir = mk3(1.0f / ray.d.x, 1.0f / ray.d.y, 1.0f / ray.d.z);
@@ -998,9 +1001,15 @@ RT_DEV bool occluded_small_links(const float* __restrict__ s_nodes, const float*
       const bool hit = slab_test_t<FINITE>(n0, n1, ray, inv_dir, inv_dir.x < 0.0f, inv_dir.y < 0.0f, inv_dir.z < 0.0f);
       int next = (int)(lk & 0xffffu);
       if (hit) {
+#if RT_LINK_LEAF
+        const int n_prims = (int)(lk >> 31) * (int)((lk >> 23) & 0xffu);
+        if (n_prims != 0) {
+          const int off = (int)((lk >> 16) & 0x7fu);
+#else
         const int n_prims = (int)(__float_as_uint(nd[7 * N]) & 0xffffu);
         if (n_prims != 0) {
           const int off = __float_as_int(nd[6 * N]);
+#endif
           for (int i = 0; i < n_prims; ++i) {
             const int t = off + i;
             const f3 p0t = mk3(tpx[t] - op.x, tpy[t] - op.y, tpz[t] - op.z), p1t = mk3(tpx[3 * T + t] - op.x, tpy[3 * T + t] - op.y, tpz[3 * T + t] - op.z),
@@ -1036,9 +1045,14 @@ RT_DEV bool closest_small_links(const float* __restrict__ s_nodes, const float* 
         const unsigned lk = link[cur];
         int next = (int)(lk & 0xffffu);
         if (slab_test_t<FINITE>(n0, n1, ray, inv_dir, neg_x, neg_y, neg_z)) {
+#if RT_LINK_LEAF
+          if ((int)lk < 0) { leaf_off = (int)((lk >> 16) & 0x7fu); leaf_n = (int)((lk >> 23) & 0xffu); }
+          else next = (int)(lk >> 16);
+#else
           const int n_prims = (int)(__float_as_uint(nd[7 * N]) & 0xffffu);
           if (n_prims != 0) { leaf_off = __float_as_int(nd[6 * N]); leaf_n = n_prims; }
           else next = (int)(lk >> 16);
+#endif
         }
         cur = next;
       }
@@ -1054,6 +1068,52 @@ RT_DEV bool closest_small_links(const float* __restrict__ s_nodes, const float* 
       TriHit h;
       if (tri_test_permuted(p0t, p1t, p2t, rp.sx, rp.sy, rp.sz, ray.t_max, h)) { found = true; ray.t_max = h.t; prim_out = t; hit_out = h; }
       leaf_off += 1; leaf_n -= 1;
+    }
+  }
+  return found;
+}
+// occluded_small_links in rounds (RT_LDS_LEAF_MIN_ANY > 1): a lane that reaches a leaf holds it until LEAF_MIN lanes hold one, then every holder tests one primitive
+template <int N, int T, bool FINITE, int LEAF_MIN>
+RT_DEV bool occluded_small_links_rounds(const float* __restrict__ s_nodes, const float* __restrict__ s_tris, const unsigned* __restrict__ link, const int n_nodes, const int start, const Ray ray) {
+  const f3 inv_dir = mk3(1.0f / ray.d.x, 1.0f / ray.d.y, 1.0f / ray.d.z);
+  const int neg_x = inv_dir.x < 0.0f, neg_y = inv_dir.y < 0.0f, neg_z = inv_dir.z < 0.0f;
+  const RayPre rp = ray_pre(ray);
+  const float* const tpx = s_tris + rp.kx * T; const float* const tpy = s_tris + rp.ky * T; const float* const tpz = s_tris + rp.kz * T;
+  const f3 op = permute(ray.o, rp.kx, rp.ky, rp.kz);
+  bool found = false;
+  int cur = start, leaf_off = 0, leaf_n = 0;
+  for (;;) {
+    unsigned long long holders = 0ull;
+    for (;;) {
+      if (leaf_n == 0 && cur < n_nodes) {
+        const float* nd = s_nodes + cur;
+        const float4 n0 = make_float4(nd[0], nd[2 * N], nd[4 * N], nd[N]), n1 = make_float4(nd[3 * N], nd[5 * N], 0.0f, 0.0f);
+        const unsigned lk = link[cur];
+        int next = (int)(lk & 0xffffu);
+        if (slab_test_t<FINITE>(n0, n1, ray, inv_dir, neg_x, neg_y, neg_z)) {
+#if RT_LINK_LEAF
+          if ((int)lk < 0) { leaf_off = (int)((lk >> 16) & 0x7fu); leaf_n = (int)((lk >> 23) & 0xffu); }
+          else next = (int)(lk >> 16);
+#else
+          const int n_prims = (int)(__float_as_uint(nd[7 * N]) & 0xffffu);
+          if (n_prims != 0) { leaf_off = __float_as_int(nd[6 * N]); leaf_n = n_prims; }
+          else next = (int)(lk >> 16);
+#endif
+        }
+        cur = next;
+      }
+      holders = __ballot(leaf_n > 0);
+      if (__ballot(leaf_n == 0 && cur < n_nodes) == 0ull) break;
+      if (__builtin_popcount((unsigned)holders) + __builtin_popcount((unsigned)(holders >> 32)) >= LEAF_MIN) break;
+    }
+    if (holders == 0ull) break;
+    if (leaf_n > 0) {
+      const int t = leaf_off;
+      const f3 p0t = mk3(tpx[t] - op.x, tpy[t] - op.y, tpz[t] - op.z), p1t = mk3(tpx[3 * T + t] - op.x, tpy[3 * T + t] - op.y, tpz[3 * T + t] - op.z),
+               p2t = mk3(tpx[6 * T + t] - op.x, tpy[6 * T + t] - op.y, tpz[6 * T + t] - op.z);
+      TriHit h;
+      leaf_off += 1; leaf_n -= 1;
+      if (tri_test_permuted<RT_ANY_EARLY_SIGN != 0>(p0t, p1t, p2t, rp.sx, rp.sy, rp.sz, ray.t_max, h)) { found = true; cur = n_nodes; leaf_n = 0; }
     }
   }
   return found;
@@ -1211,7 +1271,9 @@ __global__ void __launch_bounds__(BLOCK, (SMALL && GENERAL == 0 && !COUNT) ? ((A
     const bool fin = FIN_FORMS && __ballot(!inv_dir_finite(mk3(1.0f / ray.d.x, 1.0f / ray.d.y, 1.0f / ray.d.z))) == 0ull;
     if (SMALL && LM > 1 && LM < 64 && !COUNT) {
       LdsS src{s_nodes, s_tris};
-      if (LINKS && !ANY) {
+      if (LINKS && ANY) found = fin ? occluded_small_links_rounds<NN, NT, true, LM>(s_nodes, s_tris, s_link, (int)sc.n_nodes, (int)s_link[NN], ray)
+                                    : occluded_small_links_rounds<NN, NT, false, LM>(s_nodes, s_tris, sc.link8_full + 8u * sc.n_nodes + 8u, (int)sc.n_nodes, (int)sc.link8_full[9u * sc.n_nodes + 8u], ray);
+      else if (LINKS && !ANY) {
         if (fin) {  // (s_link: 8 rows NN apart, the starts behind them - closest_small_links reads link8[8 * row + oct])
           found = closest_small_links<NN, NT, true, LM>(s_nodes, s_tris, s_link, NN, (int)sc.n_nodes, ray, prim, h);
         } else found = closest_small_links<NN, NT, false, LM>(s_nodes, s_tris, sc.link8_full, (int)sc.n_nodes, (int)sc.n_nodes, ray, prim, h);
