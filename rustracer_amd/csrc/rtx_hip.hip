@@ -8,6 +8,8 @@
 #include <cstring>
 #include <string>
 #include <vector>
+#include <limits>
+#include <algorithm>
 #include <functional>
 #include <map>
 #include <atomic>
@@ -617,7 +619,7 @@ extern "C" int rt_scene_create(const rt_scene_desc* desc, int device, rt_scene**
     // drops a node when the walk without it tests fewer nodes. Leaves always stay (a leaf's own test is what decides whether its primitives are tested). The choice only moves time.
     // kept[o]: the nodes the closest-hit walk of octant o tests; kept[8]: the nodes the occlusion walk (octant 0's order for every ray) tests
     std::vector<std::vector<char>> kept(9, std::vector<char>(nn, 1));
-    bool nested = !s->general_prims && nn >= 3;
+    bool nested = nn >= 3;  // (s->small: no object instances; quadrics and masked triangles walk the same tables, k_trace's LINKS_G)
     for (uint32_t i = 0; i < nn && nested; ++i) {
       const rt_bvh_node& n = desc->nodes[i];
       if (n.n_prims != 0) continue;
@@ -632,10 +634,25 @@ extern "C" int rt_scene_create(const rt_scene_desc* desc, int device, rt_scene**
       std::vector<CalRay> rays[9];  // closest-hit rays by octant; [8]: occlusion segments
       std::vector<double> cum(desc->n_tris + 1, 0.0);
       auto P = [&](uint32_t t, int v, int k) { return (double)desc->tri_p[9 * (size_t)t + 3 * v + k]; };
+      // a quadric slot: whole spheres are calibrated as the spheres they are (centre and radius in world space, a uniform scale assumed); any other quadric starts no ray
+      // and stops none, a masked triangle counts as opaque - the calibration is a cost model, every set of nodes it may choose leaves the hit records as they are
+      auto quadric = [&](uint32_t t, double* c, double* rad) {
+        if (!(desc->tri_meta[t].flags & RT_PRIM_SPHERE)) return 0;
+        uint32_t k; memcpy(&k, desc->tri_p + 9 * (size_t)t + 6, 4);
+        const rt_sphere& q = desc->spheres[k];
+        if (q.kind != 0 || q.z_min > -q.radius || q.z_max < q.radius || q.phi_max < 6.28f) return 2;
+        for (int a = 0; a < 3; ++a) c[a] = q.o2w[4 * a + 3];
+        *rad = (double)q.radius * std::sqrt((double)q.o2w[0] * q.o2w[0] + (double)q.o2w[4] * q.o2w[4] + (double)q.o2w[8] * q.o2w[8]);
+        return 1;
+      };
       for (uint32_t t = 0; t < desc->n_tris; ++t) {
+        double c[3], rad;
+        const int qk = quadric(t, c, &rad);
+        if (qk) { cum[t + 1] = cum[t] + (qk == 1 ? 12.566370614359172 * rad * rad : 0.0); continue; }
         const double e1[3] = {P(t, 1, 0) - P(t, 0, 0), P(t, 1, 1) - P(t, 0, 1), P(t, 1, 2) - P(t, 0, 2)}, e2[3] = {P(t, 2, 0) - P(t, 0, 0), P(t, 2, 1) - P(t, 0, 1), P(t, 2, 2) - P(t, 0, 2)};
         const double cx = e1[1] * e2[2] - e1[2] * e2[1], cy = e1[2] * e2[0] - e1[0] * e2[2], cz = e1[0] * e2[1] - e1[1] * e2[0];
-        cum[t + 1] = cum[t] + 0.5 * std::sqrt(cx * cx + cy * cy + cz * cz);
+        const double ar = 0.5 * std::sqrt(cx * cx + cy * cy + cz * cz);
+        cum[t + 1] = cum[t] + (ar < 1e300 ? ar : 0.0);  // (NaN / inf areas: none)
       }
       std::vector<uint32_t> emitters;  // emitting triangles: where shadow rays go
       for (uint32_t i = 0; i < desc->n_lights; ++i) if (desc->lights[i].kind == RT_LIGHT_DIFFUSE_AREA && desc->lights[i].prim >= 0 && (uint32_t)desc->lights[i].prim < desc->n_tris) emitters.push_back((uint32_t)desc->lights[i].prim);
@@ -643,23 +660,39 @@ extern "C" int rt_scene_create(const rt_scene_desc* desc, int device, rt_scene**
       auto rnd = [&]() { rs += 0x9e3779b97f4a7c15ull; unsigned long long z = rs; z = (z ^ (z >> 30)) * 0xbf58476d1ce4e5b9ull; z = (z ^ (z >> 27)) * 0x94d049bb133111ebull; z ^= z >> 31; return (double)(z >> 11) * (1.0 / 9007199254740992.0); };
       const rt_bvh_node& root = desc->nodes[0];
       const double ctr[3] = {0.5 * ((double)root.bmin[0] + root.bmax[0]), 0.5 * ((double)root.bmin[1] + root.bmax[1]), 0.5 * ((double)root.bmin[2] + root.bmax[2])};
-      auto surface_point = [&](uint32_t t, double* p) { const double su = std::sqrt(rnd()), b0 = 1.0 - su, b1 = rnd() * su, b2 = 1.0 - b0 - b1; for (int k = 0; k < 3; ++k) p[k] = b0 * P(t, 0, k) + b1 * P(t, 1, k) + b2 * P(t, 2, k); };
+      // a point of primitive t and the normal there (false: a primitive the calibration has no points on)
+      auto surface_point = [&](uint32_t t, double* p, double* n) {
+        double c[3], rad;
+        const int qk = quadric(t, c, &rad);
+        if (qk == 2) return false;
+        if (qk == 1) {
+          const double z = 1.0 - 2.0 * rnd(), rr = std::sqrt(std::max(0.0, 1.0 - z * z)), ph = 6.283185307179586 * rnd();
+          n[0] = rr * std::cos(ph); n[1] = rr * std::sin(ph); n[2] = z;
+          for (int k = 0; k < 3; ++k) p[k] = c[k] + rad * n[k];
+          return true;
+        }
+        const double su = std::sqrt(rnd()), b0 = 1.0 - su, b1 = rnd() * su, b2 = 1.0 - b0 - b1;
+        for (int k = 0; k < 3; ++k) p[k] = b0 * P(t, 0, k) + b1 * P(t, 1, k) + b2 * P(t, 2, k);
+        const double e1[3] = {P(t, 1, 0) - P(t, 0, 0), P(t, 1, 1) - P(t, 0, 1), P(t, 1, 2) - P(t, 0, 2)}, e2[3] = {P(t, 2, 0) - P(t, 0, 0), P(t, 2, 1) - P(t, 0, 1), P(t, 2, 2) - P(t, 0, 2)};
+        n[0] = e1[1] * e2[2] - e1[2] * e2[1]; n[1] = e1[2] * e2[0] - e1[0] * e2[2]; n[2] = e1[0] * e2[1] - e1[1] * e2[0];
+        const double nl = std::sqrt(n[0] * n[0] + n[1] * n[1] + n[2] * n[2]);
+        if (!(nl > 0.0)) return false;
+        for (int k = 0; k < 3; ++k) n[k] /= nl;
+        return true;
+      };
       auto pick_tri = [&]() { const double x = rnd() * cum[desc->n_tris]; return (uint32_t)std::min<size_t>(desc->n_tris - 1, (size_t)(std::upper_bound(cum.begin(), cum.end(), x) - cum.begin()) - 1); };
       for (uint32_t r = 0; r < K && cum[desc->n_tris] > 0.0; ++r) {
         const uint32_t t = pick_tri();
         CalRay cr; cr.t_max = 1e300;
-        surface_point(t, cr.o);
-        const double e1[3] = {P(t, 1, 0) - P(t, 0, 0), P(t, 1, 1) - P(t, 0, 1), P(t, 1, 2) - P(t, 0, 2)}, e2[3] = {P(t, 2, 0) - P(t, 0, 0), P(t, 2, 1) - P(t, 0, 1), P(t, 2, 2) - P(t, 0, 2)};
-        double n[3] = {e1[1] * e2[2] - e1[2] * e2[1], e1[2] * e2[0] - e1[0] * e2[2], e1[0] * e2[1] - e1[1] * e2[0]};
-        const double nl = std::sqrt(n[0] * n[0] + n[1] * n[1] + n[2] * n[2]);
-        if (!(nl > 0.0)) continue;
-        for (int k = 0; k < 3; ++k) n[k] /= nl;
+        double n[3];
+        if (!surface_point(t, cr.o, n)) continue;
         // three of four rays leave towards the middle of the scene (where a path's next vertex usually lies), one the other way
         const double side = ((ctr[0] - cr.o[0]) * n[0] + (ctr[1] - cr.o[1]) * n[1] + (ctr[2] - cr.o[2]) * n[2]) < 0.0 ? -1.0 : 1.0;
         const double flip = (rnd() < 0.25 ? -1.0 : 1.0) * side;
         for (int k = 0; k < 3; ++k) { n[k] *= flip; cr.o[k] += n[k] * 1e-6 * (std::fabs(cr.o[k]) + 1.0); }
         if ((r & 3u) == 3u) {  // every fourth ray: a shadow segment towards a point on an emitter (any surface point where nothing emits)
-          double q[3]; surface_point(emitters.empty() ? pick_tri() : emitters[(size_t)(rnd() * emitters.size()) % emitters.size()], q);
+          double q[3], qn[3];
+          if (!surface_point(emitters.empty() ? pick_tri() : emitters[(size_t)(rnd() * emitters.size()) % emitters.size()], q, qn)) continue;
           for (int k = 0; k < 3; ++k) cr.d[k] = q[k] - cr.o[k];
           cr.t_max = 1.0 - 1e-4;
           if (cr.d[0] == 0.0 || cr.d[1] == 0.0 || cr.d[2] == 0.0) continue;
@@ -676,43 +709,72 @@ extern "C" int rt_scene_create(const rt_scene_desc* desc, int device, rt_scene**
         if (cr.d[0] == 0.0 || cr.d[1] == 0.0 || cr.d[2] == 0.0) continue;
         rays[(cr.d[0] < 0.0 ? 1 : 0) | (cr.d[1] < 0.0 ? 2 : 0) | (cr.d[2] < 0.0 ? 4 : 0)].push_back(cr);
       }
+      // What a ray's walk meets does not depend on which nodes are tested: per set, ray and node the parameter at which the ray enters the node's box (+inf: it misses the
+      // box), per ray and primitive the parameter of its hit (+inf: none; Moeller-Trumbore in double) - computed once, so that a candidate set of nodes costs table lookups.
+      const double kNone = std::numeric_limits<double>::infinity();
+      std::vector<double> t_node[9], t_prim[9];
+      for (int w = 0; w < 9; ++w) {
+        t_node[w].resize(rays[w].size() * nn); t_prim[w].resize(rays[w].size() * (size_t)desc->n_tris);
+        for (size_t r = 0; r < rays[w].size(); ++r) {
+          const CalRay& cr = rays[w][r];
+          const double inv[3] = {1.0 / cr.d[0], 1.0 / cr.d[1], 1.0 / cr.d[2]};
+          for (uint32_t i = 0; i < nn; ++i) {
+            const rt_bvh_node& n = desc->nodes[i];
+            double tn = -1e300, tf = 1e300;
+            for (int k = 0; k < 3; ++k) { double a0 = ((double)n.bmin[k] - cr.o[k]) * inv[k], a1 = ((double)n.bmax[k] - cr.o[k]) * inv[k]; if (a0 > a1) std::swap(a0, a1); tn = std::max(tn, a0); tf = std::min(tf, a1); }
+            t_node[w][r * nn + i] = (tn <= tf && tf > 0.0) ? tn : kNone;
+          }
+          for (uint32_t t = 0; t < desc->n_tris; ++t) {
+            double& out = t_prim[w][r * (size_t)desc->n_tris + t]; out = kNone;
+            double sc_[3], srad;
+            const int qk = quadric(t, sc_, &srad);
+            if (qk == 2) continue;
+            if (qk == 1) {
+              const double oc[3] = {cr.o[0] - sc_[0], cr.o[1] - sc_[1], cr.o[2] - sc_[2]};
+              const double A = cr.d[0] * cr.d[0] + cr.d[1] * cr.d[1] + cr.d[2] * cr.d[2], B = 2.0 * (oc[0] * cr.d[0] + oc[1] * cr.d[1] + oc[2] * cr.d[2]), Cq = oc[0] * oc[0] + oc[1] * oc[1] + oc[2] * oc[2] - srad * srad;
+              const double disc = B * B - 4.0 * A * Cq;
+              if (disc < 0.0) continue;
+              const double sq = std::sqrt(disc), t0 = (-B - sq) / (2.0 * A), t1 = (-B + sq) / (2.0 * A), eps = 1e-6 * srad / std::sqrt(A);
+              const double tt = t0 > eps ? t0 : t1;
+              if (tt > eps) out = tt;
+              continue;
+            }
+            const double e1[3] = {P(t, 1, 0) - P(t, 0, 0), P(t, 1, 1) - P(t, 0, 1), P(t, 1, 2) - P(t, 0, 2)}, e2[3] = {P(t, 2, 0) - P(t, 0, 0), P(t, 2, 1) - P(t, 0, 1), P(t, 2, 2) - P(t, 0, 2)};
+            const double pv[3] = {cr.d[1] * e2[2] - cr.d[2] * e2[1], cr.d[2] * e2[0] - cr.d[0] * e2[2], cr.d[0] * e2[1] - cr.d[1] * e2[0]};
+            const double det = pv[0] * e1[0] + pv[1] * e1[1] + pv[2] * e1[2];
+            if (det == 0.0) continue;
+            const double tv[3] = {cr.o[0] - P(t, 0, 0), cr.o[1] - P(t, 0, 1), cr.o[2] - P(t, 0, 2)};
+            const double u = (tv[0] * pv[0] + tv[1] * pv[1] + tv[2] * pv[2]) / det;
+            if (u < 0.0 || u > 1.0) continue;
+            const double qv[3] = {tv[1] * e1[2] - tv[2] * e1[1], tv[2] * e1[0] - tv[0] * e1[2], tv[0] * e1[1] - tv[1] * e1[0]};
+            const double v = (cr.d[0] * qv[0] + cr.d[1] * qv[1] + cr.d[2] * qv[2]) / det;
+            if (v < 0.0 || u + v > 1.0) continue;
+            const double tt = (e2[0] * qv[0] + e2[1] * qv[1] + e2[2] * qv[2]) / det;
+            if (tt > 1e-9) out = tt;
+          }
+        }
+      }
       // node tests of the walk over the rays of set `w` when only kept[w] nodes are tested (a node that is not tested counts as passed). w < 8: BVH::intersect's order and its
       // shrinking t_max; w == 8: the occlusion walk - first child first at every node, over at the first primitive hit
       auto cost = [&](int w) {
         unsigned long long tests = 0;
         std::vector<uint32_t> stk; stk.reserve(64);
         const std::vector<char>& kp = kept[w];
-        for (const CalRay& cr : rays[w]) {
-          const double inv[3] = {1.0 / cr.d[0], 1.0 / cr.d[1], 1.0 / cr.d[2]};
-          double t_max = cr.t_max; stk.clear(); uint32_t cur = 0; bool done = false;
+        const unsigned oct = w < 8 ? (unsigned)w : 0u;  // (every ray of set w < 8 lies in octant w)
+        for (size_t r = 0; r < rays[w].size(); ++r) {
+          const double* tnode = t_node[w].data() + r * nn; const double* tprim = t_prim[w].data() + r * (size_t)desc->n_tris;
+          double t_max = rays[w][r].t_max; stk.clear(); uint32_t cur = 0; bool done = false;
           while (!done) {
             const rt_bvh_node& n = desc->nodes[cur];
             bool hit = true;
-            if (kp[cur]) {
-              tests += 1;
-              double tn = -1e300, tf = 1e300;
-              for (int k = 0; k < 3; ++k) { double a0 = ((double)n.bmin[k] - cr.o[k]) * inv[k], a1 = ((double)n.bmax[k] - cr.o[k]) * inv[k]; if (a0 > a1) std::swap(a0, a1); tn = std::max(tn, a0); tf = std::min(tf, a1); }
-              hit = tn <= tf && tf > 0.0 && tn < t_max;
-            }
+            if (kp[cur]) { tests += 1; hit = tnode[cur] < t_max; }
             if (hit && n.n_prims != 0) {
-              for (uint32_t t = n.offset; t < n.offset + n.n_prims && !done; ++t) {  // Moeller-Trumbore in double: the t_max a hit leaves behind
-                const double e1[3] = {P(t, 1, 0) - P(t, 0, 0), P(t, 1, 1) - P(t, 0, 1), P(t, 1, 2) - P(t, 0, 2)}, e2[3] = {P(t, 2, 0) - P(t, 0, 0), P(t, 2, 1) - P(t, 0, 1), P(t, 2, 2) - P(t, 0, 2)};
-                const double pv[3] = {cr.d[1] * e2[2] - cr.d[2] * e2[1], cr.d[2] * e2[0] - cr.d[0] * e2[2], cr.d[0] * e2[1] - cr.d[1] * e2[0]};
-                const double det = pv[0] * e1[0] + pv[1] * e1[1] + pv[2] * e1[2];
-                if (det == 0.0) continue;
-                const double tv[3] = {cr.o[0] - P(t, 0, 0), cr.o[1] - P(t, 0, 1), cr.o[2] - P(t, 0, 2)};
-                const double u = (tv[0] * pv[0] + tv[1] * pv[1] + tv[2] * pv[2]) / det;
-                if (u < 0.0 || u > 1.0) continue;
-                const double qv[3] = {tv[1] * e1[2] - tv[2] * e1[1], tv[2] * e1[0] - tv[0] * e1[2], tv[0] * e1[1] - tv[1] * e1[0]};
-                const double v = (cr.d[0] * qv[0] + cr.d[1] * qv[1] + cr.d[2] * qv[2]) / det;
-                if (v < 0.0 || u + v > 1.0) continue;
-                const double tt = (e2[0] * qv[0] + e2[1] * qv[1] + e2[2] * qv[2]) / det;
-                if (tt > 1e-9 && tt < t_max) { if (w == 8) done = true; else t_max = tt; }
-              }
+              for (uint32_t t = n.offset; t < n.offset + n.n_prims; ++t)
+                if (tprim[t] < t_max) { if (w == 8) { done = true; break; } t_max = tprim[t]; }
             }
             if (done) break;
             if (hit && n.n_prims == 0) {
-              const bool neg = w < 8 && inv[n.axis < 2 ? n.axis : 2] < 0.0;
+              const bool neg = w < 8 && ((oct >> (n.axis < 2 ? n.axis : 2)) & 1u) != 0u;
               if (neg) { stk.push_back(cur + 1); cur = n.offset; } else { stk.push_back(n.offset); cur = cur + 1; }
             } else { if (stk.empty()) break; cur = stk.back(); stk.pop_back(); }
           }
@@ -1211,7 +1273,12 @@ static void launch_trace_c(rt_scene* s, const TraceIO& io, const unsigned* queue
 #define RT_GEN_LAUNCH3(KERNEL_ALL, KERNEL_NOMASK, KERNEL_INST, GRID, BLK, ...) do { if (!all && !s->has_spheres) hipLaunchKernelGGL(KERNEL_INST, dim3(GRID), dim3(BLK), 0, stream, __VA_ARGS__); \
                                                                                    else RT_GEN_LAUNCH(KERNEL_ALL, KERNEL_NOMASK, GRID, BLK, __VA_ARGS__); } while (0)
       if (!big_only && s->small) {
-        if (s->stack_depth <= 16) RT_GEN_LAUNCH((k_trace<ANY, false, true, 256, 16, RT_GEN_ALL>), (k_trace<ANY, false, true, 256, 16, RT_GEN_NO_MASKS>), (trace_grid<ANY, true, 256, 16>(s)), 256, s->d, io, queue, count_ptr, shard_cap, count_static, stats, st_rays, st_nodes, st_tris);
+        if (RT_LDS_THREADED && RT_LDS_LINKS && RT_LDS_LINKS_GENERAL) {  // no stack: one instantiation whatever the tree's depth; grid = what fits a CU (LDS: scene + link rows; registers: RT_GEN_MIN_WAVES)
+          const unsigned lds = (unsigned)((8 * RT_SMALL_NODES + 10 * RT_SMALL_TRIS) * 4 + ((ANY ? 1 : 8) * RT_SMALL_NODES + 8) * 4 + 64);
+          unsigned per_cu = (160u * 1024u) / lds; const unsigned by_regs = all ? 2u : 4u; if (per_cu > by_regs) per_cu = by_regs;
+          RT_GEN_LAUNCH((k_trace<ANY, false, true, 256, 16, RT_GEN_ALL>), (k_trace<ANY, false, true, 256, 16, RT_GEN_NO_MASKS>), ((unsigned)s->n_cu * per_cu), 256, s->d, io, queue, count_ptr, shard_cap, count_static, stats, st_rays, st_nodes, st_tris);
+        }
+        else if (s->stack_depth <= 16) RT_GEN_LAUNCH((k_trace<ANY, false, true, 256, 16, RT_GEN_ALL>), (k_trace<ANY, false, true, 256, 16, RT_GEN_NO_MASKS>), (trace_grid<ANY, true, 256, 16>(s)), 256, s->d, io, queue, count_ptr, shard_cap, count_static, stats, st_rays, st_nodes, st_tris);
         else if (s->stack_depth <= 32) RT_GEN_LAUNCH((k_trace<ANY, false, true, 256, 32, RT_GEN_ALL>), (k_trace<ANY, false, true, 256, 32, RT_GEN_NO_MASKS>), (trace_grid<ANY, true, 256, 32>(s)), 256, s->d, io, queue, count_ptr, shard_cap, count_static, stats, st_rays, st_nodes, st_tris);
         else RT_GEN_LAUNCH((k_trace<ANY, false, true, 128, 64, RT_GEN_ALL>), (k_trace<ANY, false, true, 128, 64, RT_GEN_NO_MASKS>), (trace_grid<ANY, true, 128, 64>(s)), 128, s->d, io, queue, count_ptr, shard_cap, count_static, stats, st_rays, st_nodes, st_tris);
         return;

@@ -982,11 +982,15 @@ RT_DEV bool closest_small(const float* __restrict__ s_nodes, const float* __rest
 #ifndef RT_LDS_LINKS
 #define RT_LDS_LINKS 1
 #endif
+#ifndef RT_LDS_LINKS_GENERAL
+#define RT_LDS_LINKS_GENERAL 1  // LDS-resident scenes with quadrics / masked triangles walk the link tables too (0: the stack walk, traverse_rounds / traverse)
+#endif
 #ifndef RT_LINK_LEAF
 #define RT_LINK_LEAF 1  // a leaf's link word carries its primitives in the half an interior node's uses for "enter": bit 31, count << 23, first << 16 (<= 128 primitives)
 #endif
-template <int N, int T, bool FINITE>
-RT_DEV bool occluded_small_links(const float* __restrict__ s_nodes, const float* __restrict__ s_tris, const unsigned* __restrict__ link /* octant 0's row; [8 * n_nodes]: its start */, const int n_nodes, const int start, const Ray ray) {
+// GENERAL != 0 (round 5): leaves may hold quadrics and masked triangles (leaf_prim_test; a plain triangle of such a scene takes tri_test_pre as in the stack walk it replaces)
+template <int N, int T, bool FINITE, int GENERAL = 0>
+RT_DEV bool occluded_small_links(const float* __restrict__ s_nodes, const float* __restrict__ s_tris, const unsigned* __restrict__ link /* the occlusion walk's row */, const int n_nodes, const int start, const Ray ray, const GeneralCtx gen = GeneralCtx{nullptr, false}) {
   const f3 inv_dir = mk3(1.0f / ray.d.x, 1.0f / ray.d.y, 1.0f / ray.d.z);
   const RayPre rp = ray_pre(ray);
   const float* const tpx = s_tris + rp.kx * T; const float* const tpy = s_tris + rp.ky * T; const float* const tpz = s_tris + rp.kz * T;
@@ -1015,7 +1019,8 @@ RT_DEV bool occluded_small_links(const float* __restrict__ s_nodes, const float*
             const f3 p0t = mk3(tpx[t] - op.x, tpy[t] - op.y, tpz[t] - op.z), p1t = mk3(tpx[3 * T + t] - op.x, tpy[3 * T + t] - op.y, tpz[3 * T + t] - op.z),
                      p2t = mk3(tpx[6 * T + t] - op.x, tpy[6 * T + t] - op.y, tpz[6 * T + t] - op.z);
             TriHit h;
-            if (tri_test_permuted<RT_ANY_EARLY_SIGN != 0>(p0t, p1t, p2t, rp.sx, rp.sy, rp.sz, ray.t_max, h)) { found = true; next = n_nodes; break; }
+            if (GENERAL) { if (leaf_prim_test<GENERAL>(LdsSrcT<N, T>{s_nodes, s_tris}, gen, t, ray, rp, h)) { found = true; next = n_nodes; break; } }
+            else if (tri_test_permuted<RT_ANY_EARLY_SIGN != 0>(p0t, p1t, p2t, rp.sx, rp.sy, rp.sz, ray.t_max, h)) { found = true; next = n_nodes; break; }
           }
         } else next = (int)(lk >> 16);
       }
@@ -1025,8 +1030,8 @@ RT_DEV bool occluded_small_links(const float* __restrict__ s_nodes, const float*
   }
   return found;
 }
-template <int N, int T, bool FINITE, int LEAF_MIN>
-RT_DEV bool closest_small_links(const float* __restrict__ s_nodes, const float* __restrict__ s_tris, const unsigned* __restrict__ link8 /* rows N (LDS) or n_nodes (HBM) apart */, const int row, const int n_nodes, Ray ray, int& prim_out, TriHit& hit_out) {
+template <int N, int T, bool FINITE, int LEAF_MIN, int GENERAL = 0>
+RT_DEV bool closest_small_links(const float* __restrict__ s_nodes, const float* __restrict__ s_tris, const unsigned* __restrict__ link8 /* rows N (LDS) or n_nodes (HBM) apart */, const int row, const int n_nodes, Ray ray, int& prim_out, TriHit& hit_out, const GeneralCtx gen = GeneralCtx{nullptr, false}) {
   const f3 inv_dir = mk3(1.0f / ray.d.x, 1.0f / ray.d.y, 1.0f / ray.d.z);
   const int neg_x = inv_dir.x < 0.0f, neg_y = inv_dir.y < 0.0f, neg_z = inv_dir.z < 0.0f;
   const unsigned oct = (neg_x ? 1u : 0u) | (neg_y ? 2u : 0u) | (neg_z ? 4u : 0u);
@@ -1066,7 +1071,8 @@ RT_DEV bool closest_small_links(const float* __restrict__ s_nodes, const float* 
       const f3 p0t = mk3(tpx[t] - op.x, tpy[t] - op.y, tpz[t] - op.z), p1t = mk3(tpx[3 * T + t] - op.x, tpy[3 * T + t] - op.y, tpz[3 * T + t] - op.z),
                p2t = mk3(tpx[6 * T + t] - op.x, tpy[6 * T + t] - op.y, tpz[6 * T + t] - op.z);
       TriHit h;
-      if (tri_test_permuted(p0t, p1t, p2t, rp.sx, rp.sy, rp.sz, ray.t_max, h)) { found = true; ray.t_max = h.t; prim_out = t; hit_out = h; }
+      if (GENERAL) { if (leaf_prim_test<GENERAL>(LdsSrcT<N, T>{s_nodes, s_tris}, gen, t, ray, rp, h)) { found = true; ray.t_max = h.t; prim_out = t; hit_out = h; } }
+      else if (tri_test_permuted(p0t, p1t, p2t, rp.sx, rp.sy, rp.sz, ray.t_max, h)) { found = true; ray.t_max = h.t; prim_out = t; hit_out = h; }
       leaf_off += 1; leaf_n -= 1;
     }
   }
@@ -1231,7 +1237,8 @@ __global__ void __launch_bounds__(BLOCK, (SMALL && GENERAL == 0 && !COUNT) ? ((A
 #endif
   typedef typename std::conditional<SMALL && (!ANY || RT_ANY_STACK16), unsigned short, int>::type StackT;
   constexpr bool STACKLESS = RT_LDS_THREADED && SMALL && !COUNT && GENERAL == 0;  // closest_small / occluded_small: no to-visit stack at all
-  __shared__ StackT stack[STACKLESS ? 1 : DEPTH * BLOCK];
+  constexpr bool LINKS_G_ = RT_LDS_THREADED && SMALL && !COUNT && GENERAL != 0 && RT_LDS_LINKS && RT_LDS_LINKS_GENERAL;  // (= LINKS_G below)
+  __shared__ StackT stack[(STACKLESS || LINKS_G_) ? 1 : DEPTH * BLOCK];
   constexpr int NN = RT_SMALL_NODES, NT = RT_SMALL_TRIS;
   typedef LdsSrcT<NN, NT> LdsS;
   __shared__ float s_nodes[SMALL ? 8 * NN : 1];
@@ -1239,7 +1246,9 @@ __global__ void __launch_bounds__(BLOCK, (SMALL && GENERAL == 0 && !COUNT) ? ((A
   QView qv; if (queue) qv.init(io.queue_is_slots ? nullptr : queue, shard_counts, shard_cap);
   const unsigned count = queue ? qv.total() : count_static;
   if (blockIdx.x * BLOCK >= count) return;  // short queues (MIS rays, late bounces): most blocks of the persistent grid have nothing to stage for
-  constexpr bool LINKS = STACKLESS && RT_LDS_LINKS && RT_LDS_ANY_DEFER_MIN == 0 && RT_LDS_CLOSEST_DEFER_MIN == 0;  // the link-table walks (the deferred experiments keep the skip tables)
+  // the link-table walks (the deferred experiments keep the skip tables); round 5: the GENERAL kernels of an LDS-resident scene too (LINKS_G: no stack either)
+  constexpr bool LINKS_G = RT_LDS_THREADED && SMALL && !COUNT && GENERAL != 0 && RT_LDS_LINKS && RT_LDS_LINKS_GENERAL;
+  constexpr bool LINKS = (STACKLESS && RT_LDS_LINKS && RT_LDS_ANY_DEFER_MIN == 0 && RT_LDS_CLOSEST_DEFER_MIN == 0) || LINKS_G;
   __shared__ unsigned short s_skip[(STACKLESS && !LINKS) ? (ANY ? 1 : 8) * NN : 1];  // the links of the walk order(s): DScene::skip8, rows NN apart
   __shared__ unsigned s_link[LINKS ? (ANY ? 1 : 8) * NN + 8 : 1];  // DScene::link8 (the tested nodes' links), rows NN apart, then the 8 start nodes
   if (SMALL) { stage_small_scene<BLOCK, NN, NT>(sc, s_nodes, s_tris); __syncthreads(); }
@@ -1267,16 +1276,16 @@ __global__ void __launch_bounds__(BLOCK, (SMALL && GENERAL == 0 && !COUNT) ? ((A
     const GeneralCtx gen{sc.self, ANY && io.shadow_masks != 0};
     // Plain-triangle launches that do not count visits take the min / max node test (slab_test_finite) when every ray of the wave has a finite reciprocal
     // direction - all but a few hundred waves of a frame; a wave that holds one ray with a zero direction component walks with the reference's selects.
-    constexpr bool FIN_FORMS = !COUNT && GENERAL == 0;
+    constexpr bool FIN_FORMS = !COUNT && (GENERAL == 0 || LINKS_G);
     const bool fin = FIN_FORMS && __ballot(!inv_dir_finite(mk3(1.0f / ray.d.x, 1.0f / ray.d.y, 1.0f / ray.d.z))) == 0ull;
     if (SMALL && LM > 1 && LM < 64 && !COUNT) {
       LdsS src{s_nodes, s_tris};
-      if (LINKS && ANY) found = fin ? occluded_small_links_rounds<NN, NT, true, LM>(s_nodes, s_tris, s_link, (int)sc.n_nodes, (int)s_link[NN], ray)
+      if (LINKS && ANY && GENERAL == 0) found = fin ? occluded_small_links_rounds<NN, NT, true, LM>(s_nodes, s_tris, s_link, (int)sc.n_nodes, (int)s_link[NN], ray)
                                     : occluded_small_links_rounds<NN, NT, false, LM>(s_nodes, s_tris, sc.link8_full + 8u * sc.n_nodes + 8u, (int)sc.n_nodes, (int)sc.link8_full[9u * sc.n_nodes + 8u], ray);
       else if (LINKS && !ANY) {
         if (fin) {  // (s_link: 8 rows NN apart, the starts behind them - closest_small_links reads link8[8 * row + oct])
-          found = closest_small_links<NN, NT, true, LM>(s_nodes, s_tris, s_link, NN, (int)sc.n_nodes, ray, prim, h);
-        } else found = closest_small_links<NN, NT, false, LM>(s_nodes, s_tris, sc.link8_full, (int)sc.n_nodes, (int)sc.n_nodes, ray, prim, h);
+          found = closest_small_links<NN, NT, true, LM, GENERAL>(s_nodes, s_tris, s_link, NN, (int)sc.n_nodes, ray, prim, h, gen);
+        } else found = closest_small_links<NN, NT, false, LM, GENERAL>(s_nodes, s_tris, sc.link8_full, (int)sc.n_nodes, (int)sc.n_nodes, ray, prim, h, gen);
       }
       else if (STACKLESS && !ANY && RT_LDS_CLOSEST_DEFER_MIN > 0) found = fin ? closest_small_deferred<NN, NT, true, RT_LDS_CLOSEST_DEFER_MIN>(s_nodes, s_tris, s_skip, (int)sc.n_nodes, ray, prim, h) : closest_small_deferred<NN, NT, false, RT_LDS_CLOSEST_DEFER_MIN>(s_nodes, s_tris, s_skip, (int)sc.n_nodes, ray, prim, h);
       else if (STACKLESS && !ANY) found = fin ? closest_small<NN, NT, true, LM>(s_nodes, s_tris, s_skip, (int)sc.n_nodes, ray, prim, h) : closest_small<NN, NT, false, LM>(s_nodes, s_tris, s_skip, (int)sc.n_nodes, ray, prim, h);
@@ -1284,8 +1293,8 @@ __global__ void __launch_bounds__(BLOCK, (SMALL && GENERAL == 0 && !COUNT) ? ((A
     }
     else if (SMALL) {
       LdsS src{s_nodes, s_tris};
-      if (LINKS) found = fin ? occluded_small_links<NN, NT, true>(s_nodes, s_tris, s_link, (int)sc.n_nodes, (int)s_link[NN], ray)
-                             : occluded_small_links<NN, NT, false>(s_nodes, s_tris, sc.link8_full + 8u * sc.n_nodes + 8u, (int)sc.n_nodes, (int)sc.link8_full[9u * sc.n_nodes + 8u], ray);
+      if (LINKS) found = fin ? occluded_small_links<NN, NT, true, GENERAL>(s_nodes, s_tris, s_link, (int)sc.n_nodes, (int)s_link[NN], ray, gen)
+                             : occluded_small_links<NN, NT, false, GENERAL>(s_nodes, s_tris, sc.link8_full + 8u * sc.n_nodes + 8u, (int)sc.n_nodes, (int)sc.link8_full[9u * sc.n_nodes + 8u], ray, gen);
       else if (STACKLESS && RT_LDS_ANY_DEFER_MIN > 0) found = fin ? occluded_small_deferred<NN, NT, true, RT_LDS_ANY_DEFER_MIN>(s_nodes, s_tris, s_skip, (int)sc.n_nodes, ray) : occluded_small_deferred<NN, NT, false, RT_LDS_ANY_DEFER_MIN>(s_nodes, s_tris, s_skip, (int)sc.n_nodes, ray);
       else if (STACKLESS) found = fin ? occluded_small<NN, NT, true>(s_nodes, s_tris, s_skip, (int)sc.n_nodes, ray) : occluded_small<NN, NT, false>(s_nodes, s_tris, s_skip, (int)sc.n_nodes, ray);
       else found = traverse<ANY, COUNT, LdsS, StackT, GENERAL>(src, ray, stack + threadIdx.x, BLOCK, prim, h, n_nodes, n_tris, gen);

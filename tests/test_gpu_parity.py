@@ -115,7 +115,7 @@ def test_rays_with_zero_direction_components_take_the_reference_selects(gpu_host
     assert np.array_equal(o.trace(rays, True)["occluded"], h.trace(rays, True, count=False)["occluded"])
 
 
-@pytest.mark.parametrize("scene", ["cornell", "soup-128", "soup-40-degenerate"])
+@pytest.mark.parametrize("scene", ["cornell", "soup-128", "soup-40-degenerate", "sphere-zoo", "cutout"])
 def test_untested_interior_nodes_change_no_hit_record(gpu_host, orc, scene, monkeypatch):
     """Round 5: the stackless walks of an LDS-resident scene pass over interior nodes whose box test rarely fails (rt_scene_create picks them on synthetic rays; a box contains
     its children's boxes, so an interior node's test decides nothing). Hit records and occlusion answers must be the oracle's bit for bit with and without that - on rays
@@ -127,6 +127,11 @@ def test_untested_interior_nodes_change_no_hit_record(gpu_host, orc, scene, monk
     elif scene == "soup-128":
         d = random_soup(126, seed=5, max_prims=4)            # (+ the emitter quad: 128 primitives, the LDS kernels' limit)
         lo, hi = np.float32([-20] * 3), np.float32([120] * 3)
+    elif scene in ("sphere-zoo", "cutout"):                   # quadrics of every kind / alpha and shadow-alpha masks: the GENERAL kernels walk the same tables
+        from test_gpu_sphere import _sphere_zoo
+        from test_gpu_alpha import _cutout_scene
+        d = _sphere_zoo(8, 1) if scene == "sphere-zoo" else _cutout_scene(8, 1)
+        lo, hi = np.float32([-50, -50, -850]), np.float32([600, 600, 600])
     else:
         d = random_soup(40, seed=9, max_prims=1, degenerate=True)   # coincident centroids, a flat half: the leaf fall-backs of the build
         lo, hi = np.float32([-20] * 3), np.float32([120] * 3)
@@ -138,7 +143,7 @@ def test_untested_interior_nodes_change_no_hit_record(gpu_host, orc, scene, monk
     rays[k % 17 == 0, 4:7] = np.float32([0, 0, 1])  # axis-parallel
     o = orc.OracleScene(d)
     ro = o.trace(rays)
-    rays_any = rays.copy(); rays_any[:, 3] = np.random.default_rng(3).uniform(0.1, 700 if scene == "cornell" else 150, n).astype(np.float32)
+    rays_any = rays.copy(); rays_any[:, 3] = np.random.default_rng(3).uniform(0.1, 150 if scene.startswith("soup") else 700, n).astype(np.float32)
     ra = o.trace(rays_any, True)
     tested = {}
     for prune in ("1", "0"):
@@ -148,12 +153,12 @@ def test_untested_interior_nodes_change_no_hit_record(gpu_host, orc, scene, monk
         tested[prune] = gpu_host.lib().rtxh_scene_query(h.h, 1)
         rh = h.trace(rays, count=False)
         assert np.array_equal(ro["prim"], rh["prim"]), prune
-        for f in ("t", "b0", "b1"):
+        for f in ("t",) if scene == "sphere-zoo" else ("t", "b0", "b1"):   # (a quadric's hit record carries t and the primitive, test_gpu_sphere.py)
             assert np.array_equal(bits(ro[f]), bits(rh[f])), (prune, f)
         assert np.array_equal(ra["occluded"], h.trace(rays_any, True, count=False)["occluded"]), prune
     nn = gpu_host.HostScene(d).bvh_sizes()[0]
     assert tested["0"] == nn and tested["1"] <= nn
-    if scene == "cornell":
+    if scene in ("cornell", "sphere-zoo", "cutout"):
         assert tested["1"] < nn   # the Cornell box's walls fill their parents' boxes: some interior tests never pay
     assert (ro["prim"] >= 0).mean() > 0.02
 
