@@ -79,6 +79,7 @@ struct rt_scene {
   bool has_spheres = false;
   bool has_instances = false;  // object instances: two-level traversal in k_trace_big<.., GENERAL>, every vertex shaded by k_shade<0, true>
   DevBuf instances;
+  bool mid = false;  // plain scene of <= RT_MID_NODES / RT_MID_TRIS: occlusion rays through k_trace<.., MID>
   bool general_prims = false;  // alpha-masked triangles, quadrics, object instances: the GENERAL instantiations of the trace kernels
   bool has_masks = false;      // some triangle carries an alpha / shadow-alpha mask (RT_GEN_ALL; without: RT_GEN_NO_MASKS, 134 instead of 179 VGPRs)
   bool masked_emitters = false;  // ... and some of them emit: every vertex is shaded by k_shade<0, true> (Shape::pdf_wi evaluates the mask)
@@ -589,7 +590,10 @@ extern "C" int rt_scene_create(const rt_scene_desc* desc, int device, rt_scene**
     s->deep_column = s->stack_depth > 64;
   }
   d.pairs = nullptr; d.quads = nullptr; d.obj_pairs = 0; d.skip8 = nullptr; d.link8 = nullptr; d.link8_full = nullptr;
-  if (s->small) {
+  // mid-size scenes (round 5): too large for the 256-node LDS kernels, small enough for one workgroup's 160 KB - occlusion rays walk link tables in LDS (k_trace<.., MID>)
+  s->mid = !s->small && !s->general_prims && !s->has_instances && desc->n_nodes <= RT_MID_NODES && desc->n_tris <= RT_MID_TRIS && !(getenv("RTX_MID") && getenv("RTX_MID")[0] == '0');
+  for (uint32_t i = 0; i < desc->n_nodes && s->mid; ++i) if (desc->nodes[i].n_prims > 15) s->mid = false;  // (the link word's count field)
+  if (s->small || s->mid) {
     // The order in which BVH::intersect (bvh/mod.rs:381-425) reaches the nodes depends on the ray only through the signs of its direction (at an interior node
     // the child on the ray's side of the split axis first, the other one pushed): one fixed order per octant. skip[o][i] = the entry on top of the to-visit stack
     // when that walk reaches node i = where it carries on once i's subtree is done; n_nodes when nothing is pending.
@@ -619,7 +623,7 @@ extern "C" int rt_scene_create(const rt_scene_desc* desc, int device, rt_scene**
     // drops a node when the walk without it tests fewer nodes. Leaves always stay (a leaf's own test is what decides whether its primitives are tested). The choice only moves time.
     // kept[o]: the nodes the closest-hit walk of octant o tests; kept[8]: the nodes the occlusion walk (octant 0's order for every ray) tests
     std::vector<std::vector<char>> kept(9, std::vector<char>(nn, 1));
-    bool nested = nn >= 3;  // (s->small: no object instances; quadrics and masked triangles walk the same tables, k_trace's LINKS_G)
+    bool nested = nn >= 3;  // (s->small / s->mid: no object instances; quadrics and masked triangles walk the same tables, k_trace's LINKS_G)
     for (uint32_t i = 0; i < nn && nested; ++i) {
       const rt_bvh_node& n = desc->nodes[i];
       if (n.n_prims != 0) continue;
@@ -629,7 +633,7 @@ extern "C" int rt_scene_create(const rt_scene_desc* desc, int device, rt_scene**
     const char* prune_env = getenv("RTX_LDS_PRUNE");  // measurement / test knob, read per scene: 0 = every node is tested
     s->lds_nodes_tested = nn;
     if (nested && !(prune_env && prune_env[0] == '0')) {
-      const uint32_t K = nn <= 64 ? 8192u : 2048u;  // (a greedy pass costs interior nodes x rays x visits: milliseconds for S1's 39 nodes, ~0.1 s for 255)
+      const uint32_t K = nn <= 64 ? 8192u : (nn <= RT_SMALL_NODES ? 4096u : 2048u);  // (the tables below: rays x (nodes + primitives) doubles)
       struct CalRay { double o[3], d[3], t_max; };
       std::vector<CalRay> rays[9];  // closest-hit rays by octant; [8]: occlusion segments
       std::vector<double> cum(desc->n_tris + 1, 0.0);
@@ -690,7 +694,7 @@ extern "C" int rt_scene_create(const rt_scene_desc* desc, int device, rt_scene**
         const double side = ((ctr[0] - cr.o[0]) * n[0] + (ctr[1] - cr.o[1]) * n[1] + (ctr[2] - cr.o[2]) * n[2]) < 0.0 ? -1.0 : 1.0;
         const double flip = (rnd() < 0.25 ? -1.0 : 1.0) * side;
         for (int k = 0; k < 3; ++k) { n[k] *= flip; cr.o[k] += n[k] * 1e-6 * (std::fabs(cr.o[k]) + 1.0); }
-        if ((r & 3u) == 3u) {  // every fourth ray: a shadow segment towards a point on an emitter (any surface point where nothing emits)
+        if ((r & 3u) == 3u || (s->mid && (r & 1u))) {  // every fourth ray (mid-size scenes, whose closest-hit rays take other kernels: every other one): a shadow segment towards a point on an emitter (any surface point where nothing emits)
           double q[3], qn[3];
           if (!surface_point(emitters.empty() ? pick_tri() : emitters[(size_t)(rnd() * emitters.size()) % emitters.size()], q, qn)) continue;
           for (int k = 0; k < 3; ++k) cr.d[k] = q[k] - cr.o[k];
@@ -713,7 +717,7 @@ extern "C" int rt_scene_create(const rt_scene_desc* desc, int device, rt_scene**
       // box), per ray and primitive the parameter of its hit (+inf: none; Moeller-Trumbore in double) - computed once, so that a candidate set of nodes costs table lookups.
       const double kNone = std::numeric_limits<double>::infinity();
       std::vector<double> t_node[9], t_prim[9];
-      for (int w = 0; w < 9; ++w) {
+      for (int w = s->mid ? 8 : 0; w < 9; ++w) {
         t_node[w].resize(rays[w].size() * nn); t_prim[w].resize(rays[w].size() * (size_t)desc->n_tris);
         for (size_t r = 0; r < rays[w].size(); ++r) {
           const CalRay& cr = rays[w][r];
@@ -754,10 +758,12 @@ extern "C" int rt_scene_create(const rt_scene_desc* desc, int device, rt_scene**
           }
         }
       }
-      // node tests of the walk over the rays of set `w` when only kept[w] nodes are tested (a node that is not tested counts as passed). w < 8: BVH::intersect's order and its
-      // shrinking t_max; w == 8: the occlusion walk - first child first at every node, over at the first primitive hit
-      auto cost = [&](int w) {
+      // The walk over the rays of set `w` when only kept[w] nodes are tested (a node that is not tested counts as passed). w < 8: BVH::intersect's order and its shrinking
+      // t_max; w == 8: the occlusion walk - first child first at every node, over at the first primitive hit. Returns the node tests; n_pass / n_fail: per node, the rays
+      // that reach it and would pass / fail its test (whether it is tested or not).
+      auto simulate = [&](int w, std::vector<uint32_t>& n_pass, std::vector<uint32_t>& n_fail) {
         unsigned long long tests = 0;
+        std::fill(n_pass.begin(), n_pass.end(), 0u); std::fill(n_fail.begin(), n_fail.end(), 0u);
         std::vector<uint32_t> stk; stk.reserve(64);
         const std::vector<char>& kp = kept[w];
         const unsigned oct = w < 8 ? (unsigned)w : 0u;  // (every ray of set w < 8 lies in octant w)
@@ -766,8 +772,10 @@ extern "C" int rt_scene_create(const rt_scene_desc* desc, int device, rt_scene**
           double t_max = rays[w][r].t_max; stk.clear(); uint32_t cur = 0; bool done = false;
           while (!done) {
             const rt_bvh_node& n = desc->nodes[cur];
+            const bool would = tnode[cur] < t_max;
+            (would ? n_pass : n_fail)[cur] += 1u;
             bool hit = true;
-            if (kp[cur]) { tests += 1; hit = tnode[cur] < t_max; }
+            if (kp[cur]) { tests += 1; hit = would; }
             if (hit && n.n_prims != 0) {
               for (uint32_t t = n.offset; t < n.offset + n.n_prims; ++t)
                 if (tprim[t] < t_max) { if (w == 8) { done = true; break; } t_max = tprim[t]; }
@@ -781,22 +789,39 @@ extern "C" int rt_scene_create(const rt_scene_desc* desc, int device, rt_scene**
         }
         return tests;
       };
+      // Which interior nodes to test. A ray that fails node i's box fails every box below it (nested boxes, ordered products, no hit in between to move t_max), so without
+      // i's test it runs into exactly the TESTED nodes nearest below i - frontier(i) of them, whatever the ray - and fails each; a ray that passes saves the one test. Dropping
+      // i therefore changes the count by fail_i x (frontier(i) - 1) - pass_i over the rays that reach i: decided bottom-up (children first: their decisions are frontier(i)),
+      // from the counts of one simulated walk; which rays reach i depends on the nodes above it, so the sweep is repeated on the new set until nothing changes (<= 6 times).
       uint32_t nt = 0;
-      for (int w = 0; w < 9; ++w) {
+      std::vector<uint32_t> n_pass(nn), n_fail(nn), frontier(nn);
+      for (int w = s->mid ? 8 : 0; w < 9; ++w) {
         if (rays[w].size() >= 64) {
-          unsigned long long best = cost(w);
-          for (int pass = 0; pass < 3; ++pass) {
+          for (int sweep = 0; sweep < 6; ++sweep) {
+            (void)simulate(w, n_pass, n_fail);
             bool changed = false;
-            for (uint32_t i = 0; i < nn; ++i) {
-              if (desc->nodes[i].n_prims != 0 || !kept[w][i]) continue;
-              kept[w][i] = 0;
-              const unsigned long long c = cost(w);
-              if (c < best) { best = c; changed = true; } else kept[w][i] = 1;
+            for (uint32_t i = nn; i-- > 0;) {
+              const rt_bvh_node& n = desc->nodes[i];
+              if (n.n_prims != 0) { frontier[i] = 1u; continue; }
+              const uint32_t a = i + 1, b2 = n.offset;
+              frontier[i] = (kept[w][a] ? 1u : frontier[a]) + (kept[w][b2] ? 1u : frontier[b2]);
+              const char keep = (unsigned long long)n_fail[i] * (frontier[i] - 1u) > (unsigned long long)n_pass[i] ? 1 : 0;
+              if (keep != kept[w][i]) { kept[w][i] = keep; changed = true; }
             }
             if (!changed) break;
           }
         }
         if (w < 8) for (uint32_t i = 0; i < nn; ++i) nt += kept[w][i] ? 1u : 0u;
+      }
+      if (s->mid) { nt = 0; for (uint32_t i = 0; i < nn; ++i) nt += kept[8][i] ? 8u : 0u; }  // (mid-size scenes: only the occlusion walk uses the tables)
+      if (getenv("RTX_PRUNE_REPORT")) {  // measurement knob: simulated node tests per calibration ray, all nodes against the chosen ones
+        for (int w = s->mid ? 8 : 0; w < 9; ++w) if (rays[w].size() >= 64) {
+          std::vector<char> sel = kept[w]; kept[w].assign(nn, 1);
+          const unsigned long long full = simulate(w, n_pass, n_fail); kept[w] = sel;
+          const unsigned long long now = simulate(w, n_pass, n_fail);
+          uint32_t k = 0; for (uint32_t i = 0; i < nn; ++i) k += sel[i] ? 1u : 0u;
+          fprintf(stderr, "[rtx] prune set %d: %zu rays, %.2f -> %.2f node tests per ray, %u of %u nodes tested\n", w, rays[w].size(), (double)full / rays[w].size(), (double)now / rays[w].size(), k, nn);
+        }
       }
       s->lds_nodes_tested = (nt + 4u) / 8u;  // (the closest-hit walks' average over the octants)
     }
@@ -831,7 +856,8 @@ extern "C" int rt_scene_create(const rt_scene_desc* desc, int device, rt_scene**
             const uint32_t enter = pos[i] + 1 < end_[i] ? next_tested[pos[i] + 1] : nn;  // (inside the subtree a tested node always exists: its leaves)
             const uint32_t skp = end_[i] < nn ? next_tested[end_[i]] : nn;
             const rt_bvh_node& nd = desc->nodes[i];
-            L[base + i] = nd.n_prims != 0 && RT_LINK_LEAF ? (0x80000000u | ((uint32_t)nd.n_prims << 23) | ((uint32_t)nd.offset << 16) | skp) : ((enter << 16) | skp);
+            const int off_bits = s->mid ? RT_LINK_OFF_BITS(RT_MID_NODES) : RT_LINK_OFF_BITS(RT_SMALL_NODES);
+            L[base + i] = nd.n_prims != 0 && RT_LINK_LEAF ? (0x80000000u | ((uint32_t)nd.n_prims << (16 + off_bits)) | ((uint32_t)nd.offset << 16) | skp) : ((enter << 16) | skp);
           }
           L[start_at] = next_tested[0];
         }
@@ -1034,7 +1060,8 @@ extern "C" int rt_offset_ray_origin(const float* p, const float* p_error, const 
 extern "C" int rt_scene_query(rt_scene* s, int32_t what) {
   if (!s) return fail(RT_ERR_INVALID, "null scene");
   if (what == RT_QUERY_LDS_RESIDENT) return s->small ? 1 : 0;
-  if (what == RT_QUERY_LDS_NODES_TESTED) return s->small ? (int)s->lds_nodes_tested : 0;
+  if (what == RT_QUERY_LDS_NODES_TESTED) return (s->small || s->mid) ? (int)s->lds_nodes_tested : 0;
+  if (what == RT_QUERY_LDS_OCCLUSION) return s->mid ? 1 : 0;
   return fail(RT_ERR_INVALID, "unknown rt_scene_query item");
 }
 
@@ -1316,6 +1343,12 @@ static void launch_trace_c(rt_scene* s, const TraceIO& io, const unsigned* queue
     else if (s->stack_depth <= 32) hipLaunchKernelGGL((k_trace_big<ANY, COUNT, 128, 32, true>), dim3(trace_grid<ANY, false, 128, 32>(s)), dim3(128), 0, stream, s->d, io, queue, count_ptr, shard_cap, count_static, stats, st_rays, st_nodes, st_tris);
     else hipLaunchKernelGGL((k_trace_big<ANY, COUNT, 128, 64, true>), dim3(trace_grid<ANY, false, 128, 64>(s)), dim3(128), 0, stream, s->d, io, queue, count_ptr, shard_cap, count_static, stats, st_rays, st_nodes, st_tris);
     return;
+  }
+  if constexpr (ANY && !COUNT) {
+    if (s->mid) {
+      hipLaunchKernelGGL((k_trace<true, false, true, 1024, 16, 0, 1>), dim3((unsigned)s->n_cu), dim3(1024), 0, stream, s->d, io, queue, count_ptr, shard_cap, count_static, stats, st_rays, st_nodes, st_tris);
+      return;
+    }
   }
   if (s->small) {
     if (s->stack_depth <= 16) launch_trace_v<ANY, COUNT, true, 256, 16>(RT_ARGS);

@@ -985,6 +985,10 @@ RT_DEV bool closest_small(const float* __restrict__ s_nodes, const float* __rest
 #ifndef RT_LDS_LINKS_GENERAL
 #define RT_LDS_LINKS_GENERAL 1  // LDS-resident scenes with quadrics / masked triangles walk the link tables too (0: the stack walk, traverse_rounds / traverse)
 #endif
+// a leaf's primitives in its link word: first primitive from bit 16 up (7 bits for the 128-primitive LDS scenes, 11 for the mid-size ones), the count above it
+#define RT_LINK_OFF_BITS(N) ((N) > 256 ? 11 : 7)
+#define RT_LINK_LEAF_OFF(lk, N) ((int)(((lk) >> 16) & ((1u << RT_LINK_OFF_BITS(N)) - 1u)))
+#define RT_LINK_LEAF_N(lk, N) ((int)(((lk) & 0x7fffffffu) >> (16 + RT_LINK_OFF_BITS(N))))
 #ifndef RT_LINK_LEAF
 #define RT_LINK_LEAF 1  // a leaf's link word carries its primitives in the half an interior node's uses for "enter": bit 31, count << 23, first << 16 (<= 128 primitives)
 #endif
@@ -1006,9 +1010,9 @@ RT_DEV bool occluded_small_links(const float* __restrict__ s_nodes, const float*
       int next = (int)(lk & 0xffffu);
       if (hit) {
 #if RT_LINK_LEAF
-        const int n_prims = (int)(lk >> 31) * (int)((lk >> 23) & 0xffu);
+        const int n_prims = (int)(lk >> 31) * RT_LINK_LEAF_N(lk, N);
         if (n_prims != 0) {
-          const int off = (int)((lk >> 16) & 0x7fu);
+          const int off = RT_LINK_LEAF_OFF(lk, N);
 #else
         const int n_prims = (int)(__float_as_uint(nd[7 * N]) & 0xffffu);
         if (n_prims != 0) {
@@ -1051,7 +1055,7 @@ RT_DEV bool closest_small_links(const float* __restrict__ s_nodes, const float* 
         int next = (int)(lk & 0xffffu);
         if (slab_test_t<FINITE>(n0, n1, ray, inv_dir, neg_x, neg_y, neg_z)) {
 #if RT_LINK_LEAF
-          if ((int)lk < 0) { leaf_off = (int)((lk >> 16) & 0x7fu); leaf_n = (int)((lk >> 23) & 0xffu); }
+          if ((int)lk < 0) { leaf_off = RT_LINK_LEAF_OFF(lk, N); leaf_n = RT_LINK_LEAF_N(lk, N); }
           else next = (int)(lk >> 16);
 #else
           const int n_prims = (int)(__float_as_uint(nd[7 * N]) & 0xffffu);
@@ -1098,7 +1102,7 @@ RT_DEV bool occluded_small_links_rounds(const float* __restrict__ s_nodes, const
         int next = (int)(lk & 0xffffu);
         if (slab_test_t<FINITE>(n0, n1, ray, inv_dir, neg_x, neg_y, neg_z)) {
 #if RT_LINK_LEAF
-          if ((int)lk < 0) { leaf_off = (int)((lk >> 16) & 0x7fu); leaf_n = (int)((lk >> 23) & 0xffu); }
+          if ((int)lk < 0) { leaf_off = RT_LINK_LEAF_OFF(lk, N); leaf_n = RT_LINK_LEAF_N(lk, N); }
           else next = (int)(lk >> 16);
 #else
           const int n_prims = (int)(__float_as_uint(nd[7 * N]) & 0xffffu);
@@ -1223,8 +1227,19 @@ RT_DEV void trace_write_any(float4* __restrict__ lacc, size_t ls, const float4* 
 #ifndef RT_LDS_ANY_WAVES      // ... the occlusion kernel, 13.9 KB of LDS per 256 lanes, is bound by its registers
 #define RT_LDS_ANY_WAVES 8
 #endif
-template <bool ANY, bool COUNT, bool SMALL, int BLOCK, int DEPTH, int GENERAL = 0>  // GENERAL: quadrics / alpha-masked triangles in the leaves (no object instances)
-__global__ void __launch_bounds__(BLOCK, (SMALL && GENERAL == 0 && !COUNT) ? ((ANY && RT_LDS_THREADED) ? RT_LDS_ANY_WAVES : RT_LDS_TRACE_WAVES) : RT_GEN_MIN_WAVES(GENERAL)) k_trace(DScene sc, TraceIO io, const unsigned* __restrict__ queue, const unsigned* __restrict__ shard_counts, unsigned shard_cap,
+// MID (round 5): a scene of <= RT_MID_NODES nodes and <= RT_MID_TRIS triangles (S3: 2461 / 1294) in the LDS of ONE 1024-lane workgroup per CU (157 KB): occlusion rays only -
+// closest hit needs eight link rows. The walk is the 256-node kernel's (occluded_small_links_rounds over the occlusion row, pruned by the same calibration); leaf phases at 8
+// waiting lanes. S3 occlusion rays: k_trace_quad 100.7 ms -> 82.4 (all nodes) -> 76.1 (pruned: 35.4 -> 26.2 node tests per calibration ray) -> 65.4 (leaf phases at 8; 16: 66.7,
+// 32: 72.0). Measured and not kept: the same walk as persistent waves with refill (idle lanes take the wave's next rays at 8 / 16 / 24 / 32 idle, leaf phases at 8 / 12 / 16):
+// 104.4 / 96.0 / 94.5 / 98.5 ms - 74 registers cost nothing here (LDS bounds the CU at four waves per SIMD), but set-up at a quarter of the lanes and the longer round do, as
+// in k_trace_pool; SQ of the kept kernel before leaf batching: 18.2 lanes per VALU instruction, waits 35 %, LDS bank conflicts 32 % of its LDS cycles, no LDS waits to speak of.
+#ifndef RT_MID_LEAF_MIN_ANY
+#define RT_MID_LEAF_MIN_ANY 8  // (> 1: the occlusion walk in rounds, occluded_small_links_rounds)
+#endif
+#define RT_MID_NODES 2816
+#define RT_MID_TRIS 1408
+template <bool ANY, bool COUNT, bool SMALL, int BLOCK, int DEPTH, int GENERAL = 0, int MID = 0>  // GENERAL: quadrics / alpha-masked triangles in the leaves (no object instances)
+__global__ void __launch_bounds__(BLOCK, MID ? 4 : ((SMALL && GENERAL == 0 && !COUNT) ? ((ANY && RT_LDS_THREADED) ? RT_LDS_ANY_WAVES : RT_LDS_TRACE_WAVES) : RT_GEN_MIN_WAVES(GENERAL))) k_trace(DScene sc, TraceIO io, const unsigned* __restrict__ queue, const unsigned* __restrict__ shard_counts, unsigned shard_cap,
                                                  unsigned count_static, unsigned long long* stats, int st_rays, int st_nodes, int st_tris) {
   const float4* __restrict__ ray_o = io.ray_o; const float4* __restrict__ ray_d = io.ray_d; const size_t rs = io.ray_stride;
   float4* __restrict__ hits = io.hits; const size_t hs = io.hit_stride; const bool hit_b2 = io.hit_b2 != 0;
@@ -1239,7 +1254,8 @@ __global__ void __launch_bounds__(BLOCK, (SMALL && GENERAL == 0 && !COUNT) ? ((A
   constexpr bool STACKLESS = RT_LDS_THREADED && SMALL && !COUNT && GENERAL == 0;  // closest_small / occluded_small: no to-visit stack at all
   constexpr bool LINKS_G_ = RT_LDS_THREADED && SMALL && !COUNT && GENERAL != 0 && RT_LDS_LINKS && RT_LDS_LINKS_GENERAL;  // (= LINKS_G below)
   __shared__ StackT stack[(STACKLESS || LINKS_G_) ? 1 : DEPTH * BLOCK];
-  constexpr int NN = RT_SMALL_NODES, NT = RT_SMALL_TRIS;
+  constexpr int NN = MID ? RT_MID_NODES : RT_SMALL_NODES, NT = MID ? RT_MID_TRIS : RT_SMALL_TRIS;
+  static_assert(!MID || (ANY && SMALL && !COUNT && GENERAL == 0), "mid-size LDS scenes: plain occlusion rays only");
   typedef LdsSrcT<NN, NT> LdsS;
   __shared__ float s_nodes[SMALL ? 8 * NN : 1];
   __shared__ float s_tris[SMALL ? 10 * NT : 1];
@@ -1272,7 +1288,7 @@ __global__ void __launch_bounds__(BLOCK, (SMALL && GENERAL == 0 && !COUNT) ? ((A
     Ray ray; ray.o = mk3(o4.x, o4.y, o4.z); ray.d = mk3(d4.x, d4.y, d4.z); ray.t_max = o4.w;
     int prim = -1; TriHit h; h.t = kInf; h.b0 = h.b1 = h.b2 = 0.0f;
     bool found;
-    constexpr int LM = ANY ? RT_LDS_LEAF_MIN_ANY : RT_LDS_LEAF_MIN_CLOSEST;
+    constexpr int LM = ANY ? (MID ? RT_MID_LEAF_MIN_ANY : RT_LDS_LEAF_MIN_ANY) : RT_LDS_LEAF_MIN_CLOSEST;
     const GeneralCtx gen{sc.self, ANY && io.shadow_masks != 0};
     // Plain-triangle launches that do not count visits take the min / max node test (slab_test_finite) when every ray of the wave has a finite reciprocal
     // direction - all but a few hundred waves of a frame; a wave that holds one ray with a zero direction component walks with the reference's selects.

@@ -10,3 +10,9 @@ for name, d in [('cornell', cornell_box(32, 32, 1)), ('soup-126', random_soup(12
         h = host.HostScene(d)
         t0 = time.perf_counter(); h.upload(0); t1 = time.perf_counter()
         print(name, 'prune', prune, 'upload %.1f ms' % ((t1 - t0) * 1e3), 'nodes', h.bvh_sizes()[0], 'tested', host.lib().rtxh_scene_query(h.h, 1))
+os.environ['RTX_LDS_PRUNE'] = '1'
+os.environ['RTX_PRUNE_REPORT'] = '1'
+h = host.HostScene(cornell_box(32, 32, 1)); h.upload(0)
+d = mis_plates(spp=1); h = host.HostScene(d)
+t0 = time.perf_counter(); h.upload(0); t1 = time.perf_counter()
+print('mis-plates upload %.1f ms' % ((t1 - t0) * 1e3), 'nodes', h.bvh_sizes()[0], 'tested', host.lib().rtxh_scene_query(h.h, 1))

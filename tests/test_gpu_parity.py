@@ -115,7 +115,7 @@ def test_rays_with_zero_direction_components_take_the_reference_selects(gpu_host
     assert np.array_equal(o.trace(rays, True)["occluded"], h.trace(rays, True, count=False)["occluded"])
 
 
-@pytest.mark.parametrize("scene", ["cornell", "soup-128", "soup-40-degenerate", "sphere-zoo", "cutout"])
+@pytest.mark.parametrize("scene", ["cornell", "soup-128", "soup-40-degenerate", "sphere-zoo", "cutout", "mis-plates"])
 def test_untested_interior_nodes_change_no_hit_record(gpu_host, orc, scene, monkeypatch):
     """Round 5: the stackless walks of an LDS-resident scene pass over interior nodes whose box test rarely fails (rt_scene_create picks them on synthetic rays; a box contains
     its children's boxes, so an interior node's test decides nothing). Hit records and occlusion answers must be the oracle's bit for bit with and without that - on rays
@@ -127,6 +127,11 @@ def test_untested_interior_nodes_change_no_hit_record(gpu_host, orc, scene, monk
     elif scene == "soup-128":
         d = random_soup(126, seed=5, max_prims=4)            # (+ the emitter quad: 128 primitives, the LDS kernels' limit)
         lo, hi = np.float32([-20] * 3), np.float32([120] * 3)
+    elif scene == "mis-plates":                              # S3: 2461 nodes - too many for the LDS kernels' tables, few enough for its OCCLUSION rays to walk an LDS copy (k_trace<.., MID>)
+        from rustracer_amd.scenes import mis_plates
+        d = mis_plates(spp=1)
+        bb = np.asarray(d.arrays()[0], np.float32)
+        lo, hi = bb.min(0) - np.float32(0.5), bb.max(0) + np.float32(0.5)
     elif scene in ("sphere-zoo", "cutout"):                   # quadrics of every kind / alpha and shadow-alpha masks: the GENERAL kernels walk the same tables
         from test_gpu_sphere import _sphere_zoo
         from test_gpu_alpha import _cutout_scene
@@ -143,13 +148,13 @@ def test_untested_interior_nodes_change_no_hit_record(gpu_host, orc, scene, monk
     rays[k % 17 == 0, 4:7] = np.float32([0, 0, 1])  # axis-parallel
     o = orc.OracleScene(d)
     ro = o.trace(rays)
-    rays_any = rays.copy(); rays_any[:, 3] = np.random.default_rng(3).uniform(0.1, 150 if scene.startswith("soup") else 700, n).astype(np.float32)
+    rays_any = rays.copy(); rays_any[:, 3] = np.random.default_rng(3).uniform(0.1, 150 if scene.startswith("soup") else (float(np.linalg.norm(hi - lo)) if scene == "mis-plates" else 700), n).astype(np.float32)
     ra = o.trace(rays_any, True)
     tested = {}
     for prune in ("1", "0"):
         monkeypatch.setenv("RTX_LDS_PRUNE", prune)
         h = gpu_host.HostScene(d); h.upload(0)
-        assert h.lds_resident()
+        assert h.lds_resident() if scene != "mis-plates" else (not h.lds_resident() and gpu_host.lib().rtxh_scene_query(h.h, 2) == 1)
         tested[prune] = gpu_host.lib().rtxh_scene_query(h.h, 1)
         rh = h.trace(rays, count=False)
         assert np.array_equal(ro["prim"], rh["prim"]), prune
@@ -158,7 +163,7 @@ def test_untested_interior_nodes_change_no_hit_record(gpu_host, orc, scene, monk
         assert np.array_equal(ra["occluded"], h.trace(rays_any, True, count=False)["occluded"]), prune
     nn = gpu_host.HostScene(d).bvh_sizes()[0]
     assert tested["0"] == nn and tested["1"] <= nn
-    if scene in ("cornell", "sphere-zoo", "cutout"):
+    if scene in ("cornell", "sphere-zoo", "cutout", "mis-plates"):
         assert tested["1"] < nn   # the Cornell box's walls fill their parents' boxes: some interior tests never pay
     assert (ro["prim"] >= 0).mean() > 0.02
 
