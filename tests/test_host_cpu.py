@@ -243,7 +243,7 @@ def test_kernel_register_and_scratch_budgets(host):
     spec.loader.exec_module(kb)
     res = kb.kernel_resources(host.HIP_LIB)
     # (round 5: k_shade has a sixth template argument, LDSREC; the forms with LDSREC = 0 keep their names below)
-    res = {(re.sub(r", 0>$", ">", k) if k.startswith("rtx::k_shade<") else k): v for k, v in res.items()}
+    res = {(re.sub(r", 0>$", ">", k) if k.startswith(("rtx::k_shade<", "rtx::k_trace<")) else k): v for k, v in res.items()}  # (trailing defaults: LDSREC = 0, MID = 0)
     budget = {  # kernel prefix -> (max VGPRs, max scratch bytes)
         "rtx::k_shade<1, false, false, false, false>": (128, 32),       # FOUR waves per SIMD (round 4), no out-of-line call; round 5: the two registers of a voxel's 32-byte distribution record cost five spilled dwords
         # the textured front-ends bound to three waves (round 4): a few dozen spilled dwords buy the third wave (S4 shade 3027 -> 2801 ms)
@@ -253,6 +253,7 @@ def test_kernel_register_and_scratch_budgets(host):
         "rtx::k_shade<0, false, false, false, false>": (256, 2048),     # 257 (one accumulation register added by a callee) is ONE wave per SIMD
         "rtx::k_trace<false, false, true, 256, 16, 0>": (72, 0),    # the LDS-resident closest-hit kernel of the headline: 7 waves
         "rtx::k_trace<true, false, true, 256, 16, 0>": (64, 0),     # ... and its shadow-ray twin: 8 waves
+        "rtx::k_trace<true, false, true, 1024, 16, 0, 1>": (64, 0), # a mid-size scene's occlusion rays: one 1024-lane workgroup per CU around 157 KB of LDS
         "rtx::k_trace_pair<false, false, 128, 32, 0>": (80, 0),     # HBM scenes: 6 waves; no scratch (an indexed load per node visit once hid here)
         "rtx::k_trace_quad<true, 128, 32, 0>": (72, 0),   # (its 16 KB stack column per 128 lanes holds it to five waves per SIMD; 66 registers with the two node tests)
         "rtx::k_trace_top<false, 512, 0>": (80, 0), "rtx::k_trace_top<true, 512, 0>": (80, 0),   # 512 lanes per workgroup: 6 waves
