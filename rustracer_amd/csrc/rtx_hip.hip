@@ -623,6 +623,7 @@ extern "C" int rt_scene_create(const rt_scene_desc* desc, int device, rt_scene**
     // drops a node when the walk without it tests fewer nodes. Leaves always stay (a leaf's own test is what decides whether its primitives are tested). The choice only moves time.
     // kept[o]: the nodes the closest-hit walk of octant o tests; kept[8]: the nodes the occlusion walk (octant 0's order for every ray) tests
     std::vector<std::vector<char>> kept(9, std::vector<char>(nn, 1));
+    std::vector<char> any_swap(nn, 0);  // the occlusion walk's own order: second child first at these nodes (any order gives intersect_p's answer)
     bool nested = nn >= 3;  // (s->small / s->mid: no object instances; quadrics and masked triangles walk the same tables, k_trace's LINKS_G)
     for (uint32_t i = 0; i < nn && nested; ++i) {
       const rt_bvh_node& n = desc->nodes[i];
@@ -782,7 +783,7 @@ extern "C" int rt_scene_create(const rt_scene_desc* desc, int device, rt_scene**
             }
             if (done) break;
             if (hit && n.n_prims == 0) {
-              const bool neg = w < 8 && ((oct >> (n.axis < 2 ? n.axis : 2)) & 1u) != 0u;
+              const bool neg = w < 8 ? ((oct >> (n.axis < 2 ? n.axis : 2)) & 1u) != 0u : any_swap[cur] != 0;
               if (neg) { stk.push_back(cur + 1); cur = n.offset; } else { stk.push_back(n.offset); cur = cur + 1; }
             } else { if (stk.empty()) break; cur = stk.back(); stk.pop_back(); }
           }
@@ -793,6 +794,33 @@ extern "C" int rt_scene_create(const rt_scene_desc* desc, int device, rt_scene**
       // i's test it runs into exactly the TESTED nodes nearest below i - frontier(i) of them, whatever the ray - and fails each; a ray that passes saves the one test. Dropping
       // i therefore changes the count by fail_i x (frontier(i) - 1) - pass_i over the rays that reach i: decided bottom-up (children first: their decisions are frontier(i)),
       // from the counts of one simulated walk; which rays reach i depends on the nodes above it, so the sweep is repeated on the new set until nothing changes (<= 6 times).
+      // The occlusion walk's ORDER. intersect_p's answer does not depend on it, the work does: an occluded ray stops at its first hit. Per interior node and child X: p_X =
+      // the share of the rays through the node that have an occluder below X, c_X = the node tests below X of a ray that looks through all of it (every node tested: the
+      // order is chosen before the pruning); searching X first costs c_X + (1 - p_X) c_Y, so the child with the larger p / c goes first (array order on ties).
+      static const char* order_env = getenv("RTX_LDS_ANY_ORDER");  // measurement knob: 0 = array order
+      if (rays[8].size() >= 64 && !(order_env && order_env[0] == '0')) {
+        std::vector<double> sum_tests(nn, 0.0); std::vector<uint32_t> occ(nn, 0u);
+        struct Res { uint32_t tests; bool occ; };
+        for (size_t r = 0; r < rays[8].size(); ++r) {
+          const double* tnode = t_node[8].data() + r * nn; const double* tprim = t_prim[8].data() + r * (size_t)desc->n_tris;
+          const double t_max = rays[8][r].t_max;
+          std::function<Res(uint32_t)> explore = [&](uint32_t i) -> Res {
+            Res res{1u, false};
+            if (!(tnode[i] < t_max)) return res;
+            const rt_bvh_node& n = desc->nodes[i];
+            if (n.n_prims != 0) { for (uint32_t t = n.offset; t < n.offset + n.n_prims; ++t) if (tprim[t] < t_max) res.occ = true; return res; }
+            const Res a = explore(i + 1), b = explore(n.offset);
+            sum_tests[i + 1] += a.tests; sum_tests[n.offset] += b.tests; occ[i + 1] += a.occ ? 1u : 0u; occ[n.offset] += b.occ ? 1u : 0u;
+            res.tests += a.tests + b.tests; res.occ = a.occ || b.occ;
+            return res;
+          };
+          (void)explore(0);
+        }
+        for (uint32_t i = 0; i < nn; ++i) {
+          const rt_bvh_node& n = desc->nodes[i];
+          if (n.n_prims == 0) any_swap[i] = (double)occ[n.offset] * sum_tests[i + 1] > (double)occ[i + 1] * sum_tests[n.offset] ? 1 : 0;
+        }
+      }
       uint32_t nt = 0;
       std::vector<uint32_t> n_pass(nn), n_fail(nn), frontier(nn);
       for (int w = s->mid ? 8 : 0; w < 9; ++w) {
@@ -841,7 +869,7 @@ extern "C" int rt_scene_create(const rt_scene_desc* desc, int device, rt_scene**
           pos[cur] = (uint32_t)order.size(); order.push_back(cur);
           const rt_bvh_node& n = desc->nodes[cur];
           if (n.n_prims == 0) {
-            const bool neg = ((o >> (n.axis < 2 ? n.axis : 2)) & 1u) != 0u;
+            const bool neg = row < 8 ? ((o >> (n.axis < 2 ? n.axis : 2)) & 1u) != 0u : any_swap[cur] != 0;
             if (neg) { st.push_back(cur + 1); cur = n.offset; } else { st.push_back(n.offset); cur = cur + 1; }
           } else { if (st.empty()) break; cur = st.back(); st.pop_back(); }
         }
