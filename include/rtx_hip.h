@@ -338,7 +338,7 @@ int rt_light_distribution(rt_scene* scene, int32_t n_voxels[3], float* func, flo
 /* What rt_scene_create decided about a scene (measurement / tests): RT_QUERY_LDS_RESIDENT - 1 if the traversal kernels keep the whole tree and its
  * primitives in LDS (k_trace; the roofline of such a scene's traversal is VALU issue, its HBM bytes are ray records only), else 0. < 0: bad argument. */
 enum { RT_QUERY_LDS_RESIDENT = 0, RT_QUERY_LDS_NODES_TESTED = 1 /* LDS-resident scenes: the nodes the stackless walks test (<= n_nodes: interior nodes whose test rarely fails are passed over) */,
-       RT_QUERY_LDS_OCCLUSION = 2 /* 1 if the scene is too large for RT_QUERY_LDS_RESIDENT but its OCCLUSION rays walk an LDS copy (<= 2816 nodes, <= 1408 plain triangles: one workgroup's 160 KB);
+       RT_QUERY_LDS_OCCLUSION = 2 /* 1 if the scene is too large for RT_QUERY_LDS_RESIDENT but fits ONE workgroup's 160 KB per CU (<= 2816 nodes, <= 1408 plain triangles): occlusion rays walk an LDS copy of it, closest-hit rays its bounds and link tables;
                                       RT_QUERY_LDS_NODES_TESTED then counts the occlusion walk's nodes */ };
 int rt_scene_query(rt_scene* scene, int32_t what);
 /* sizeof() of an ABI struct by its C name ("rt_stats", "rt_scene_desc", ...), or -1: lets a binding in another language check its mirror of the

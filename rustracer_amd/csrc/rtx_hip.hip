@@ -634,7 +634,7 @@ extern "C" int rt_scene_create(const rt_scene_desc* desc, int device, rt_scene**
     const char* prune_env = getenv("RTX_LDS_PRUNE");  // measurement / test knob, read per scene: 0 = every node is tested
     s->lds_nodes_tested = nn;
     if (nested && !(prune_env && prune_env[0] == '0')) {
-      const uint32_t K = nn <= 64 ? 8192u : (nn <= RT_SMALL_NODES ? 4096u : 2048u);  // (the tables below: rays x (nodes + primitives) doubles)
+      const uint32_t K = nn <= 64 ? 8192u : 4096u;  // (the tables below: rays x (nodes + primitives) floats, 62 MB at the mid-size limit)
       struct CalRay { double o[3], d[3], t_max; };
       std::vector<CalRay> rays[9];  // closest-hit rays by octant; [8]: occlusion segments
       std::vector<double> cum(desc->n_tris + 1, 0.0);
@@ -695,7 +695,7 @@ extern "C" int rt_scene_create(const rt_scene_desc* desc, int device, rt_scene**
         const double side = ((ctr[0] - cr.o[0]) * n[0] + (ctr[1] - cr.o[1]) * n[1] + (ctr[2] - cr.o[2]) * n[2]) < 0.0 ? -1.0 : 1.0;
         const double flip = (rnd() < 0.25 ? -1.0 : 1.0) * side;
         for (int k = 0; k < 3; ++k) { n[k] *= flip; cr.o[k] += n[k] * 1e-6 * (std::fabs(cr.o[k]) + 1.0); }
-        if ((r & 3u) == 3u || (s->mid && (r & 1u))) {  // every fourth ray (mid-size scenes, whose closest-hit rays take other kernels: every other one): a shadow segment towards a point on an emitter (any surface point where nothing emits)
+        if ((r & 3u) == 3u) {  // every fourth ray: a shadow segment towards a point on an emitter (any surface point where nothing emits)
           double q[3], qn[3];
           if (!surface_point(emitters.empty() ? pick_tri() : emitters[(size_t)(rnd() * emitters.size()) % emitters.size()], q, qn)) continue;
           for (int k = 0; k < 3; ++k) cr.d[k] = q[k] - cr.o[k];
@@ -715,50 +715,52 @@ extern "C" int rt_scene_create(const rt_scene_desc* desc, int device, rt_scene**
         rays[(cr.d[0] < 0.0 ? 1 : 0) | (cr.d[1] < 0.0 ? 2 : 0) | (cr.d[2] < 0.0 ? 4 : 0)].push_back(cr);
       }
       // What a ray's walk meets does not depend on which nodes are tested: per set, ray and node the parameter at which the ray enters the node's box (+inf: it misses the
-      // box), per ray and primitive the parameter of its hit (+inf: none; Moeller-Trumbore in double) - computed once, so that a candidate set of nodes costs table lookups.
-      const double kNone = std::numeric_limits<double>::infinity();
-      std::vector<double> t_node[9], t_prim[9];
-      for (int w = s->mid ? 8 : 0; w < 9; ++w) {
-        t_node[w].resize(rays[w].size() * nn); t_prim[w].resize(rays[w].size() * (size_t)desc->n_tris);
-        for (size_t r = 0; r < rays[w].size(); ++r) {
-          const CalRay& cr = rays[w][r];
-          const double inv[3] = {1.0 / cr.d[0], 1.0 / cr.d[1], 1.0 / cr.d[2]};
-          for (uint32_t i = 0; i < nn; ++i) {
-            const rt_bvh_node& n = desc->nodes[i];
-            double tn = -1e300, tf = 1e300;
-            for (int k = 0; k < 3; ++k) { double a0 = ((double)n.bmin[k] - cr.o[k]) * inv[k], a1 = ((double)n.bmax[k] - cr.o[k]) * inv[k]; if (a0 > a1) std::swap(a0, a1); tn = std::max(tn, a0); tf = std::min(tf, a1); }
-            t_node[w][r * nn + i] = (tn <= tf && tf > 0.0) ? tn : kNone;
-          }
-          for (uint32_t t = 0; t < desc->n_tris; ++t) {
-            double& out = t_prim[w][r * (size_t)desc->n_tris + t]; out = kNone;
-            double sc_[3], srad;
-            const int qk = quadric(t, sc_, &srad);
-            if (qk == 2) continue;
-            if (qk == 1) {
-              const double oc[3] = {cr.o[0] - sc_[0], cr.o[1] - sc_[1], cr.o[2] - sc_[2]};
-              const double A = cr.d[0] * cr.d[0] + cr.d[1] * cr.d[1] + cr.d[2] * cr.d[2], B = 2.0 * (oc[0] * cr.d[0] + oc[1] * cr.d[1] + oc[2] * cr.d[2]), Cq = oc[0] * oc[0] + oc[1] * oc[1] + oc[2] * oc[2] - srad * srad;
-              const double disc = B * B - 4.0 * A * Cq;
-              if (disc < 0.0) continue;
-              const double sq = std::sqrt(disc), t0 = (-B - sq) / (2.0 * A), t1 = (-B + sq) / (2.0 * A), eps = 1e-6 * srad / std::sqrt(A);
-              const double tt = t0 > eps ? t0 : t1;
-              if (tt > eps) out = tt;
-              continue;
-            }
-            const double e1[3] = {P(t, 1, 0) - P(t, 0, 0), P(t, 1, 1) - P(t, 0, 1), P(t, 1, 2) - P(t, 0, 2)}, e2[3] = {P(t, 2, 0) - P(t, 0, 0), P(t, 2, 1) - P(t, 0, 1), P(t, 2, 2) - P(t, 0, 2)};
-            const double pv[3] = {cr.d[1] * e2[2] - cr.d[2] * e2[1], cr.d[2] * e2[0] - cr.d[0] * e2[2], cr.d[0] * e2[1] - cr.d[1] * e2[0]};
-            const double det = pv[0] * e1[0] + pv[1] * e1[1] + pv[2] * e1[2];
-            if (det == 0.0) continue;
-            const double tv[3] = {cr.o[0] - P(t, 0, 0), cr.o[1] - P(t, 0, 1), cr.o[2] - P(t, 0, 2)};
-            const double u = (tv[0] * pv[0] + tv[1] * pv[1] + tv[2] * pv[2]) / det;
-            if (u < 0.0 || u > 1.0) continue;
-            const double qv[3] = {tv[1] * e1[2] - tv[2] * e1[1], tv[2] * e1[0] - tv[0] * e1[2], tv[0] * e1[1] - tv[1] * e1[0]};
-            const double v = (cr.d[0] * qv[0] + cr.d[1] * qv[1] + cr.d[2] * qv[2]) / det;
-            if (v < 0.0 || u + v > 1.0) continue;
-            const double tt = (e2[0] * qv[0] + e2[1] * qv[1] + e2[2] * qv[2]) / det;
-            if (tt > 1e-9) out = tt;
-          }
+      // box), per ray and primitive the parameter of its hit (+inf: none; Moeller-Trumbore in double) - computed when first asked for and kept (NaN: not yet), so that a
+      // candidate set of nodes costs table lookups and a ray pays only for the nodes some walk of it reaches.
+      const float kNone = std::numeric_limits<float>::infinity(), kUnknown = std::numeric_limits<float>::quiet_NaN();
+      std::vector<float> t_node[9], t_prim[9];
+      for (int w = 0; w < 9; ++w) { t_node[w].assign(rays[w].size() * nn, kUnknown); t_prim[w].assign(rays[w].size() * (size_t)desc->n_tris, kUnknown); }
+      auto node_t = [&](int w, size_t r, uint32_t i) -> float {
+        float& out = t_node[w][r * nn + i];
+        if (out == out) return out;
+        const CalRay& cr = rays[w][r];
+        const rt_bvh_node& n = desc->nodes[i];
+        double tn = -1e300, tf = 1e300;
+        for (int k = 0; k < 3; ++k) { const double iv = 1.0 / cr.d[k]; double a0 = ((double)n.bmin[k] - cr.o[k]) * iv, a1 = ((double)n.bmax[k] - cr.o[k]) * iv; if (a0 > a1) std::swap(a0, a1); tn = std::max(tn, a0); tf = std::min(tf, a1); }
+        return out = (tn <= tf && tf > 0.0) ? (float)tn : kNone;
+      };
+      auto prim_t = [&](int w, size_t r, uint32_t t) -> float {
+        float& out = t_prim[w][r * (size_t)desc->n_tris + t];
+        if (out == out) return out;
+        const CalRay& cr = rays[w][r];
+        out = kNone;
+        double sc_[3], srad;
+        const int qk = quadric(t, sc_, &srad);
+        if (qk == 2) return out;
+        if (qk == 1) {
+          const double oc[3] = {cr.o[0] - sc_[0], cr.o[1] - sc_[1], cr.o[2] - sc_[2]};
+          const double A = cr.d[0] * cr.d[0] + cr.d[1] * cr.d[1] + cr.d[2] * cr.d[2], B = 2.0 * (oc[0] * cr.d[0] + oc[1] * cr.d[1] + oc[2] * cr.d[2]), Cq = oc[0] * oc[0] + oc[1] * oc[1] + oc[2] * oc[2] - srad * srad;
+          const double disc = B * B - 4.0 * A * Cq;
+          if (disc < 0.0) return out;
+          const double sq = std::sqrt(disc), t0 = (-B - sq) / (2.0 * A), t1 = (-B + sq) / (2.0 * A), eps = 1e-6 * srad / std::sqrt(A);
+          const double tt = t0 > eps ? t0 : t1;
+          if (tt > eps) out = (float)tt;
+          return out;
         }
-      }
+        const double e1[3] = {P(t, 1, 0) - P(t, 0, 0), P(t, 1, 1) - P(t, 0, 1), P(t, 1, 2) - P(t, 0, 2)}, e2[3] = {P(t, 2, 0) - P(t, 0, 0), P(t, 2, 1) - P(t, 0, 1), P(t, 2, 2) - P(t, 0, 2)};
+        const double pv[3] = {cr.d[1] * e2[2] - cr.d[2] * e2[1], cr.d[2] * e2[0] - cr.d[0] * e2[2], cr.d[0] * e2[1] - cr.d[1] * e2[0]};
+        const double det = pv[0] * e1[0] + pv[1] * e1[1] + pv[2] * e1[2];
+        if (det == 0.0) return out;
+        const double tv[3] = {cr.o[0] - P(t, 0, 0), cr.o[1] - P(t, 0, 1), cr.o[2] - P(t, 0, 2)};
+        const double u = (tv[0] * pv[0] + tv[1] * pv[1] + tv[2] * pv[2]) / det;
+        if (u < 0.0 || u > 1.0) return out;
+        const double qv[3] = {tv[1] * e1[2] - tv[2] * e1[1], tv[2] * e1[0] - tv[0] * e1[2], tv[0] * e1[1] - tv[1] * e1[0]};
+        const double v = (cr.d[0] * qv[0] + cr.d[1] * qv[1] + cr.d[2] * qv[2]) / det;
+        if (v < 0.0 || u + v > 1.0) return out;
+        const double tt = (e2[0] * qv[0] + e2[1] * qv[1] + e2[2] * qv[2]) / det;
+        if (tt > 1e-9) out = (float)tt;
+        return out;
+      };
       // The walk over the rays of set `w` when only kept[w] nodes are tested (a node that is not tested counts as passed). w < 8: BVH::intersect's order and its shrinking
       // t_max; w == 8: the occlusion walk - first child first at every node, over at the first primitive hit. Returns the node tests; n_pass / n_fail: per node, the rays
       // that reach it and would pass / fail its test (whether it is tested or not).
@@ -769,17 +771,18 @@ extern "C" int rt_scene_create(const rt_scene_desc* desc, int device, rt_scene**
         const std::vector<char>& kp = kept[w];
         const unsigned oct = w < 8 ? (unsigned)w : 0u;  // (every ray of set w < 8 lies in octant w)
         for (size_t r = 0; r < rays[w].size(); ++r) {
-          const double* tnode = t_node[w].data() + r * nn; const double* tprim = t_prim[w].data() + r * (size_t)desc->n_tris;
-          double t_max = rays[w][r].t_max; stk.clear(); uint32_t cur = 0; bool done = false;
+          float t_max = (float)std::min(rays[w][r].t_max, 3.0e38); stk.clear(); uint32_t cur = 0; bool done = false;
           while (!done) {
             const rt_bvh_node& n = desc->nodes[cur];
-            const bool would = tnode[cur] < t_max;
+            const bool would = node_t(w, r, cur) < t_max;
             (would ? n_pass : n_fail)[cur] += 1u;
             bool hit = true;
             if (kp[cur]) { tests += 1; hit = would; }
             if (hit && n.n_prims != 0) {
-              for (uint32_t t = n.offset; t < n.offset + n.n_prims; ++t)
-                if (tprim[t] < t_max) { if (w == 8) { done = true; break; } t_max = tprim[t]; }
+              for (uint32_t t = n.offset; t < n.offset + n.n_prims; ++t) {
+                const float tp = prim_t(w, r, t);
+                if (tp < t_max) { if (w == 8) { done = true; break; } t_max = tp; }
+              }
             }
             if (done) break;
             if (hit && n.n_prims == 0) {
@@ -802,13 +805,12 @@ extern "C" int rt_scene_create(const rt_scene_desc* desc, int device, rt_scene**
         std::vector<double> sum_tests(nn, 0.0); std::vector<uint32_t> occ(nn, 0u);
         struct Res { uint32_t tests; bool occ; };
         for (size_t r = 0; r < rays[8].size(); ++r) {
-          const double* tnode = t_node[8].data() + r * nn; const double* tprim = t_prim[8].data() + r * (size_t)desc->n_tris;
-          const double t_max = rays[8][r].t_max;
+          const float t_max = (float)std::min(rays[8][r].t_max, 3.0e38);
           std::function<Res(uint32_t)> explore = [&](uint32_t i) -> Res {
             Res res{1u, false};
-            if (!(tnode[i] < t_max)) return res;
+            if (!(node_t(8, r, i) < t_max)) return res;
             const rt_bvh_node& n = desc->nodes[i];
-            if (n.n_prims != 0) { for (uint32_t t = n.offset; t < n.offset + n.n_prims; ++t) if (tprim[t] < t_max) res.occ = true; return res; }
+            if (n.n_prims != 0) { for (uint32_t t = n.offset; t < n.offset + n.n_prims; ++t) if (prim_t(8, r, t) < t_max) res.occ = true; return res; }
             const Res a = explore(i + 1), b = explore(n.offset);
             sum_tests[i + 1] += a.tests; sum_tests[n.offset] += b.tests; occ[i + 1] += a.occ ? 1u : 0u; occ[n.offset] += b.occ ? 1u : 0u;
             res.tests += a.tests + b.tests; res.occ = a.occ || b.occ;
@@ -823,7 +825,7 @@ extern "C" int rt_scene_create(const rt_scene_desc* desc, int device, rt_scene**
       }
       uint32_t nt = 0;
       std::vector<uint32_t> n_pass(nn), n_fail(nn), frontier(nn);
-      for (int w = s->mid ? 8 : 0; w < 9; ++w) {
+      for (int w = 0; w < 9; ++w) {
         if (rays[w].size() >= 64) {
           for (int sweep = 0; sweep < 6; ++sweep) {
             (void)simulate(w, n_pass, n_fail);
@@ -833,7 +835,8 @@ extern "C" int rt_scene_create(const rt_scene_desc* desc, int device, rt_scene**
               if (n.n_prims != 0) { frontier[i] = 1u; continue; }
               const uint32_t a = i + 1, b2 = n.offset;
               frontier[i] = (kept[w][a] ? 1u : frontier[a]) + (kept[w][b2] ? 1u : frontier[b2]);
-              const char keep = (unsigned long long)n_fail[i] * (frontier[i] - 1u) > (unsigned long long)n_pass[i] ? 1 : 0;
+              // (fewer than 8 rays through the node: no evidence - it stays tested, as the tree's builder meant it)
+              const char keep = (n_pass[i] + n_fail[i] < 8u || (unsigned long long)n_fail[i] * (frontier[i] - 1u) > (unsigned long long)n_pass[i]) ? 1 : 0;
               if (keep != kept[w][i]) { kept[w][i] = keep; changed = true; }
             }
             if (!changed) break;
@@ -841,9 +844,8 @@ extern "C" int rt_scene_create(const rt_scene_desc* desc, int device, rt_scene**
         }
         if (w < 8) for (uint32_t i = 0; i < nn; ++i) nt += kept[w][i] ? 1u : 0u;
       }
-      if (s->mid) { nt = 0; for (uint32_t i = 0; i < nn; ++i) nt += kept[8][i] ? 8u : 0u; }  // (mid-size scenes: only the occlusion walk uses the tables)
       if (getenv("RTX_PRUNE_REPORT")) {  // measurement knob: simulated node tests per calibration ray, all nodes against the chosen ones
-        for (int w = s->mid ? 8 : 0; w < 9; ++w) if (rays[w].size() >= 64) {
+        for (int w = 0; w < 9; ++w) if (rays[w].size() >= 64) {
           std::vector<char> sel = kept[w]; kept[w].assign(nn, 1);
           const unsigned long long full = simulate(w, n_pass, n_fail); kept[w] = sel;
           const unsigned long long now = simulate(w, n_pass, n_fail);
@@ -1372,9 +1374,10 @@ static void launch_trace_c(rt_scene* s, const TraceIO& io, const unsigned* queue
     else hipLaunchKernelGGL((k_trace_big<ANY, COUNT, 128, 64, true>), dim3(trace_grid<ANY, false, 128, 64>(s)), dim3(128), 0, stream, s->d, io, queue, count_ptr, shard_cap, count_static, stats, st_rays, st_nodes, st_tris);
     return;
   }
-  if constexpr (ANY && !COUNT) {
-    if (s->mid) {
-      hipLaunchKernelGGL((k_trace<true, false, true, 1024, 16, 0, 1>), dim3((unsigned)s->n_cu), dim3(1024), 0, stream, s->d, io, queue, count_ptr, shard_cap, count_static, stats, st_rays, st_nodes, st_tris);
+  if constexpr (!COUNT) {
+    static const bool mid_closest = !(getenv("RTX_MID_CLOSEST") && getenv("RTX_MID_CLOSEST")[0] == '0');  // measurement knob: 0 = a mid-size scene's closest-hit rays through the HBM kernels
+    if (s->mid && (ANY || mid_closest)) {
+      hipLaunchKernelGGL((k_trace<ANY, false, true, 1024, 16, 0, 1>), dim3((unsigned)s->n_cu), dim3(1024), 0, stream, s->d, io, queue, count_ptr, shard_cap, count_static, stats, st_rays, st_nodes, st_tris);
       return;
     }
   }

@@ -783,13 +783,16 @@ typedef LdsSrcT<RT_SMALL_NODES, RT_SMALL_TRIS> LdsSrc;
 // (LDS arrays sized for S1's 63 nodes / 32 triangles - 11.5 KB per workgroup, eight resident instead of seven, 62 VGPRs - were measured in round 4: closest hit
 // 328 -> 341 ms, shadow rays 155 -> 166. Seven waves per SIMD is this kernel's optimum.)
 // copies the scene's nodes and leaf-ordered triangle records into the planar LDS arrays (every thread of the workgroup; followed by a barrier at the caller)
-template <int BLOCK, int N = RT_SMALL_NODES, int T = RT_SMALL_TRIS>
+// BOUNDS_ONLY: the six bound planes and no triangles (a mid-size scene's closest-hit walk: its leaves' primitives are in the link words, its triangles stay in HBM)
+template <int BLOCK, int N = RT_SMALL_NODES, int T = RT_SMALL_TRIS, bool BOUNDS_ONLY = false>
 RT_DEV void stage_small_scene(const DScene& sc, float* s_nodes, float* s_tris) {
   for (unsigned i = threadIdx.x; i < 2u * sc.n_nodes; i += BLOCK) {
     const float4 v = sc.nodes[i]; const unsigned n = i >> 1, h = (i & 1u) * 4u;
     if (h == 0u) { s_nodes[n] = v.x; s_nodes[2 * N + n] = v.y; s_nodes[4 * N + n] = v.z; s_nodes[N + n] = v.w; }
+    else if (BOUNDS_ONLY) { s_nodes[3 * N + n] = v.x; s_nodes[5 * N + n] = v.y; }
     else { s_nodes[3 * N + n] = v.x; s_nodes[5 * N + n] = v.y; s_nodes[6 * N + n] = v.z; s_nodes[7 * N + n] = __uint_as_float(lds_node_ctl(__float_as_uint(v.w))); }
   }
+  if (BOUNDS_ONLY) return;
   for (unsigned i = threadIdx.x; i < 3u * sc.n_tris; i += BLOCK) {
     const float4 v = sc.tri_p[i]; const unsigned t = i / 3u, r = i - 3u * t;
     s_tris[(3u * r) * T + t] = v.x; s_tris[(3u * r + 1u) * T + t] = v.y; s_tris[(3u * r + 2u) * T + t] = v.z;
@@ -1034,8 +1037,9 @@ RT_DEV bool occluded_small_links(const float* __restrict__ s_nodes, const float*
   }
   return found;
 }
-template <int N, int T, bool FINITE, int LEAF_MIN, int GENERAL = 0>
-RT_DEV bool closest_small_links(const float* __restrict__ s_nodes, const float* __restrict__ s_tris, const unsigned* __restrict__ link8 /* rows N (LDS) or n_nodes (HBM) apart */, const int row, const int n_nodes, Ray ray, int& prim_out, TriHit& hit_out, const GeneralCtx gen = GeneralCtx{nullptr, false}) {
+// TRIS_GLOBAL: the triangles are read from HBM (tri_p; s_tris unused) - the mid-size scenes' closest-hit walk, whose LDS holds the bounds and eight link rows
+template <int N, int T, bool FINITE, int LEAF_MIN, int GENERAL = 0, bool TRIS_GLOBAL = false>
+RT_DEV bool closest_small_links(const float* __restrict__ s_nodes, const float* __restrict__ s_tris, const unsigned* __restrict__ link8 /* rows N (LDS) or n_nodes (HBM) apart */, const int row, const int n_nodes, Ray ray, int& prim_out, TriHit& hit_out, const GeneralCtx gen = GeneralCtx{nullptr, false}, const float4* __restrict__ tri_p = nullptr) {
   const f3 inv_dir = mk3(1.0f / ray.d.x, 1.0f / ray.d.y, 1.0f / ray.d.z);
   const int neg_x = inv_dir.x < 0.0f, neg_y = inv_dir.y < 0.0f, neg_z = inv_dir.z < 0.0f;
   const unsigned oct = (neg_x ? 1u : 0u) | (neg_y ? 2u : 0u) | (neg_z ? 4u : 0u);
@@ -1076,6 +1080,7 @@ RT_DEV bool closest_small_links(const float* __restrict__ s_nodes, const float* 
                p2t = mk3(tpx[6 * T + t] - op.x, tpy[6 * T + t] - op.y, tpz[6 * T + t] - op.z);
       TriHit h;
       if (GENERAL) { if (leaf_prim_test<GENERAL>(LdsSrcT<N, T>{s_nodes, s_tris}, gen, t, ray, rp, h)) { found = true; ray.t_max = h.t; prim_out = t; hit_out = h; } }
+      else if (TRIS_GLOBAL) { f3 q0, q1, q2; load_tri(tri_p, t, q0, q1, q2); if (tri_test_pre(q0, q1, q2, ray, rp, h)) { found = true; ray.t_max = h.t; prim_out = t; hit_out = h; } }
       else if (tri_test_permuted(p0t, p1t, p2t, rp.sx, rp.sy, rp.sz, ray.t_max, h)) { found = true; ray.t_max = h.t; prim_out = t; hit_out = h; }
       leaf_off += 1; leaf_n -= 1;
     }
@@ -1236,6 +1241,9 @@ RT_DEV void trace_write_any(float4* __restrict__ lacc, size_t ls, const float4* 
 #ifndef RT_MID_LEAF_MIN_ANY
 #define RT_MID_LEAF_MIN_ANY 8  // (> 1: the occlusion walk in rounds, occluded_small_links_rounds)
 #endif
+#ifndef RT_MID_LEAF_MIN_CLOSEST
+#define RT_MID_LEAF_MIN_CLOSEST 16
+#endif
 #define RT_MID_NODES 2816
 #define RT_MID_TRIS 1408
 template <bool ANY, bool COUNT, bool SMALL, int BLOCK, int DEPTH, int GENERAL = 0, int MID = 0>  // GENERAL: quadrics / alpha-masked triangles in the leaves (no object instances)
@@ -1255,10 +1263,11 @@ __global__ void __launch_bounds__(BLOCK, MID ? 4 : ((SMALL && GENERAL == 0 && !C
   constexpr bool LINKS_G_ = RT_LDS_THREADED && SMALL && !COUNT && GENERAL != 0 && RT_LDS_LINKS && RT_LDS_LINKS_GENERAL;  // (= LINKS_G below)
   __shared__ StackT stack[(STACKLESS || LINKS_G_) ? 1 : DEPTH * BLOCK];
   constexpr int NN = MID ? RT_MID_NODES : RT_SMALL_NODES, NT = MID ? RT_MID_TRIS : RT_SMALL_TRIS;
-  static_assert(!MID || (ANY && SMALL && !COUNT && GENERAL == 0), "mid-size LDS scenes: plain occlusion rays only");
+  static_assert(!MID || (SMALL && !COUNT && GENERAL == 0), "mid-size LDS scenes: plain triangles, no visit counts");
+  constexpr bool MIDC = MID != 0 && !ANY;  // closest hit of a mid-size scene: six bound planes + eight link rows fill the LDS, the triangles stay in HBM
   typedef LdsSrcT<NN, NT> LdsS;
-  __shared__ float s_nodes[SMALL ? 8 * NN : 1];
-  __shared__ float s_tris[SMALL ? 10 * NT : 1];
+  __shared__ float s_nodes[SMALL ? (MIDC ? 6 : 8) * NN : 1];
+  __shared__ float s_tris[(SMALL && !MIDC) ? 10 * NT : 1];
   QView qv; if (queue) qv.init(io.queue_is_slots ? nullptr : queue, shard_counts, shard_cap);
   const unsigned count = queue ? qv.total() : count_static;
   if (blockIdx.x * BLOCK >= count) return;  // short queues (MIS rays, late bounces): most blocks of the persistent grid have nothing to stage for
@@ -1267,7 +1276,7 @@ __global__ void __launch_bounds__(BLOCK, MID ? 4 : ((SMALL && GENERAL == 0 && !C
   constexpr bool LINKS = (STACKLESS && RT_LDS_LINKS && RT_LDS_ANY_DEFER_MIN == 0 && RT_LDS_CLOSEST_DEFER_MIN == 0) || LINKS_G;
   __shared__ unsigned short s_skip[(STACKLESS && !LINKS) ? (ANY ? 1 : 8) * NN : 1];  // the links of the walk order(s): DScene::skip8, rows NN apart
   __shared__ unsigned s_link[LINKS ? (ANY ? 1 : 8) * NN + 8 : 1];  // DScene::link8 (the tested nodes' links), rows NN apart, then the 8 start nodes
-  if (SMALL) { stage_small_scene<BLOCK, NN, NT>(sc, s_nodes, s_tris); __syncthreads(); }
+  if (SMALL) { stage_small_scene<BLOCK, NN, NT, MIDC>(sc, s_nodes, s_tris); __syncthreads(); }
   if (STACKLESS && !LINKS) {
     for (unsigned i = threadIdx.x; i < (ANY ? 1u : 8u) * sc.n_nodes; i += BLOCK) { const unsigned o = i / sc.n_nodes, k = i - o * sc.n_nodes; s_skip[o * NN + k] = sc.skip8[i]; }
     __syncthreads();
@@ -1288,7 +1297,7 @@ __global__ void __launch_bounds__(BLOCK, MID ? 4 : ((SMALL && GENERAL == 0 && !C
     Ray ray; ray.o = mk3(o4.x, o4.y, o4.z); ray.d = mk3(d4.x, d4.y, d4.z); ray.t_max = o4.w;
     int prim = -1; TriHit h; h.t = kInf; h.b0 = h.b1 = h.b2 = 0.0f;
     bool found;
-    constexpr int LM = ANY ? (MID ? RT_MID_LEAF_MIN_ANY : RT_LDS_LEAF_MIN_ANY) : RT_LDS_LEAF_MIN_CLOSEST;
+    constexpr int LM = ANY ? (MID ? RT_MID_LEAF_MIN_ANY : RT_LDS_LEAF_MIN_ANY) : (MID ? RT_MID_LEAF_MIN_CLOSEST : RT_LDS_LEAF_MIN_CLOSEST);
     const GeneralCtx gen{sc.self, ANY && io.shadow_masks != 0};
     // Plain-triangle launches that do not count visits take the min / max node test (slab_test_finite) when every ray of the wave has a finite reciprocal
     // direction - all but a few hundred waves of a frame; a wave that holds one ray with a zero direction component walks with the reference's selects.
@@ -1300,8 +1309,8 @@ __global__ void __launch_bounds__(BLOCK, MID ? 4 : ((SMALL && GENERAL == 0 && !C
                                     : occluded_small_links_rounds<NN, NT, false, LM>(s_nodes, s_tris, sc.link8_full + 8u * sc.n_nodes + 8u, (int)sc.n_nodes, (int)sc.link8_full[9u * sc.n_nodes + 8u], ray);
       else if (LINKS && !ANY) {
         if (fin) {  // (s_link: 8 rows NN apart, the starts behind them - closest_small_links reads link8[8 * row + oct])
-          found = closest_small_links<NN, NT, true, LM, GENERAL>(s_nodes, s_tris, s_link, NN, (int)sc.n_nodes, ray, prim, h, gen);
-        } else found = closest_small_links<NN, NT, false, LM, GENERAL>(s_nodes, s_tris, sc.link8_full, (int)sc.n_nodes, (int)sc.n_nodes, ray, prim, h, gen);
+          found = closest_small_links<NN, NT, true, LM, GENERAL, MIDC>(s_nodes, s_tris, s_link, NN, (int)sc.n_nodes, ray, prim, h, gen, sc.tri_p);
+        } else found = closest_small_links<NN, NT, false, LM, GENERAL, MIDC>(s_nodes, s_tris, sc.link8_full, (int)sc.n_nodes, (int)sc.n_nodes, ray, prim, h, gen, sc.tri_p);
       }
       else if (STACKLESS && !ANY && RT_LDS_CLOSEST_DEFER_MIN > 0) found = fin ? closest_small_deferred<NN, NT, true, RT_LDS_CLOSEST_DEFER_MIN>(s_nodes, s_tris, s_skip, (int)sc.n_nodes, ray, prim, h) : closest_small_deferred<NN, NT, false, RT_LDS_CLOSEST_DEFER_MIN>(s_nodes, s_tris, s_skip, (int)sc.n_nodes, ray, prim, h);
       else if (STACKLESS && !ANY) found = fin ? closest_small<NN, NT, true, LM>(s_nodes, s_tris, s_skip, (int)sc.n_nodes, ray, prim, h) : closest_small<NN, NT, false, LM>(s_nodes, s_tris, s_skip, (int)sc.n_nodes, ray, prim, h);

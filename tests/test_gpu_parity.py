@@ -127,7 +127,7 @@ def test_untested_interior_nodes_change_no_hit_record(gpu_host, orc, scene, monk
     elif scene == "soup-128":
         d = random_soup(126, seed=5, max_prims=4)            # (+ the emitter quad: 128 primitives, the LDS kernels' limit)
         lo, hi = np.float32([-20] * 3), np.float32([120] * 3)
-    elif scene == "mis-plates":                              # S3: 2461 nodes - too many for the LDS kernels' tables, few enough for its OCCLUSION rays to walk an LDS copy (k_trace<.., MID>)
+    elif scene == "mis-plates":                              # S3: 2461 nodes - too many for the 256-node LDS kernels, few enough for ONE workgroup's LDS per CU (k_trace<.., MID>: occlusion rays over an LDS copy of the scene, closest hit over bounds + link rows)
         from rustracer_amd.scenes import mis_plates
         d = mis_plates(spp=1)
         bb = np.asarray(d.arrays()[0], np.float32)

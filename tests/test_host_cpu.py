@@ -254,6 +254,7 @@ def test_kernel_register_and_scratch_budgets(host):
         "rtx::k_trace<false, false, true, 256, 16, 0>": (72, 0),    # the LDS-resident closest-hit kernel of the headline: 7 waves
         "rtx::k_trace<true, false, true, 256, 16, 0>": (64, 0),     # ... and its shadow-ray twin: 8 waves
         "rtx::k_trace<true, false, true, 1024, 16, 0, 1>": (64, 0), # a mid-size scene's occlusion rays: one 1024-lane workgroup per CU around 157 KB of LDS
+        "rtx::k_trace<false, false, true, 1024, 16, 0, 1>": (72, 0),  # ... and its closest-hit rays (bounds + eight link rows in LDS, triangles from HBM)
         "rtx::k_trace_pair<false, false, 128, 32, 0>": (80, 0),     # HBM scenes: 6 waves; no scratch (an indexed load per node visit once hid here)
         "rtx::k_trace_quad<true, 128, 32, 0>": (72, 0),   # (its 16 KB stack column per 128 lanes holds it to five waves per SIMD; 66 registers with the two node tests)
         "rtx::k_trace_top<false, 512, 0>": (80, 0), "rtx::k_trace_top<true, 512, 0>": (80, 0),   # 512 lanes per workgroup: 6 waves
