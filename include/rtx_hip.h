@@ -341,6 +341,12 @@ enum { RT_QUERY_LDS_RESIDENT = 0, RT_QUERY_LDS_NODES_TESTED = 1 /* LDS-resident 
        RT_QUERY_LDS_OCCLUSION = 2 /* 1 if the scene is too large for RT_QUERY_LDS_RESIDENT but fits ONE workgroup's 160 KB per CU (<= 2816 nodes, <= 1408 plain triangles): occlusion rays walk an LDS copy of it, closest-hit rays its bounds and link tables;
                                       RT_QUERY_LDS_NODES_TESTED then counts the occlusion walk's nodes */ };
 int rt_scene_query(rt_scene* scene, int32_t what);
+/* The tables rt_scene_create hands the stackless LDS walks of a small (<= 256 nodes, <= 128 primitives) or mid-size (<= 2816 / 1408) scene, computed on the host alone - no
+ * device is touched (tests, offline inspection). link_kept / link_full: 9 * n_nodes + 9 words each (rows 0 - 7: closest hit by direction octant, their 8 start nodes,
+ * row 8: occlusion rays, its start node; a word = (first tested node inside the node's subtree << 16) | first tested node after it, a leaf's word = bit 31 | its primitive
+ * range | the same low half) over the nodes the calibration kept / over all nodes. stats (27 doubles, may be NULL): per set of calibration rays 0 - 8 the number of rays, their
+ * simulated node tests with every node tested, and with the kept ones. mid != 0: the mid-size packing of a leaf's primitive range. RT_ERR_INVALID when capacity_words is short. */
+int rt_link_tables(const rt_scene_desc* desc, int32_t mid, uint32_t* link_kept, uint32_t* link_full, uint64_t capacity_words, double* stats);
 /* sizeof() of an ABI struct by its C name ("rt_stats", "rt_scene_desc", ...), or -1: lets a binding in another language check its mirror of the
  * header against the library it actually loaded (rustracer_amd/host.py does at load time; tests/test_abi_cpu.py checks every struct). */
 int rt_sizeof(const char* struct_name);

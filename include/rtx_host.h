@@ -134,6 +134,8 @@ int rtxh_trace_device(rtxh_scene*, const void* d_rays, uint64_t n, void* d_hits,
 int rtxh_light_distribution(rtxh_scene*, int32_t n_voxels[3], float* func, float* cdf, float* func_int);
 /* rt_scene_query on the uploaded scene (uploads it first if need be; rtx_hip.h: RT_QUERY_*). */
 int rtxh_scene_query(rtxh_scene*, int32_t what);
+/* rt_link_tables on the scene's description (host only: nothing is uploaded). */
+int rtxh_scene_link_tables(rtxh_scene*, int32_t mid, uint32_t* link_kept, uint32_t* link_full, uint64_t capacity_words, double* stats);
 /* sizeof() of a struct of this header or of rtx_hip.h by its C name, or -1 (a binding checks its mirrors against the library it loaded). */
 int rtxh_sizeof(const char* struct_name);
 const char* rtxh_last_error(void);

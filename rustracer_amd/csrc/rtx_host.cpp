@@ -1165,6 +1165,12 @@ int rtxh_scene_query(rtxh_scene* s, int32_t what) {
   if (!s->dev) { int rc = rtxh_scene_upload(s, -1); if (rc != RT_OK) return rc; }
   return rt_scene_query(s->dev, what);
 }
+int rtxh_scene_link_tables(rtxh_scene* s, int32_t mid, uint32_t* link_kept, uint32_t* link_full, uint64_t capacity_words, double* stats) {
+  if (!s || !s->committed) return fail(RT_ERR_INVALID, "scene not committed");
+  g_err.clear();
+  rt_scene_desc d = make_desc(s);
+  return rt_link_tables(&d, mid, link_kept, link_full, capacity_words, stats);
+}
 int rtxh_sizeof(const char* name) {
   if (!name) return -1;
 #define RTXH_SZ(T) if (!strcmp(name, #T)) return (int)sizeof(T);

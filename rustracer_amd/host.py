@@ -241,6 +241,20 @@ class HostScene:
         lib().rtxh_scene_bvh_sizes(self.h, C.byref(nn), C.byref(npr))
         return nn.value, npr.value
 
+    def link_tables(self, mid=False):
+        """The link tables rt_scene_create gives the stackless LDS walks of this scene (rt_link_tables: host only, no device), as
+        dict(kept=[9 rows x n_nodes], full=..., start_kept=[9], start_full=[9], rays=[9], tests_all=[9], tests_kept=[9])."""
+        nn = self.bvh_sizes()[0]
+        words = 9 * nn + 9
+        kept, full, stats = np.zeros(words, np.uint32), np.zeros(words, np.uint32), np.zeros(27, np.float64)
+        _check(lib().rtxh_scene_link_tables(self.h, C.c_int32(1 if mid else 0), _p(kept, C.c_uint32), _p(full, C.c_uint32), C.c_uint64(words), _p(stats, C.c_double)), "rtxh_scene_link_tables")
+
+        def split(t):
+            rows = np.concatenate([t[:8 * nn].reshape(8, nn), t[8 * nn + 8:9 * nn + 8].reshape(1, nn)])
+            return rows, np.concatenate([t[8 * nn:8 * nn + 8], t[9 * nn + 8:9 * nn + 9]])
+        (rk, sk), (rf, sf) = split(kept), split(full)
+        return dict(kept=rk, full=rf, start_kept=sk, start_full=sf, rays=stats[:9], tests_all=stats[9:18], tests_kept=stats[18:27])
+
     def lds_resident(self):
         """Does the traversal kernel keep this scene's nodes and primitives in LDS? Asked of the uploaded scene (rt_scene_query: what rt_scene_create decided,
         the RTX_SMALL knob included), not re-derived here."""
