@@ -594,6 +594,13 @@ extern "C" int rt_scene_create(const rt_scene_desc* desc, int device, rt_scene**
   // mid-size scenes (round 5): too large for the 256-node LDS kernels, small enough for one workgroup's 160 KB - occlusion rays walk link tables in LDS (k_trace<.., MID>)
   s->mid = !s->small && !s->general_prims && !s->has_instances && desc->n_nodes <= RT_MID_NODES && desc->n_tris <= RT_MID_TRIS && !(getenv("RTX_MID") && getenv("RTX_MID")[0] == '0');
   for (uint32_t i = 0; i < desc->n_nodes && s->mid; ++i) if (desc->nodes[i].n_prims > 15) s->mid = false;  // (the link word's count field)
+  if (s->mid) {  // the kernels declare 157.7 KB of LDS: were a device (or a driver's reservation) to leave a workgroup less, they could not launch - the HBM kernels then
+    int fit_any = 0, fit_closest = 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&fit_any, (const void*)(k_trace<true, false, true, 1024, 16, 0, 1>), 1024, 0) != hipSuccess) fit_any = 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&fit_closest, (const void*)(k_trace<false, false, true, 1024, 16, 0, 1>), 1024, 0) != hipSuccess) fit_closest = 0;
+    (void)hipGetLastError();
+    if (fit_any < 1 || fit_closest < 1) s->mid = false;
+  }
   if (s->small || s->mid) {
     // skip table (round 4's walks) and link tables (round 5: per octant and node where the stackless walk goes on, over all nodes and over the nodes a calibration on
     // synthetic path rays found worth testing): rtx_link_tables.h
