@@ -115,16 +115,69 @@ static void rt_build_link_tables(const rt_scene_desc* desc, bool mid, bool want_
         for (int k = 0; k < 3; ++k) n[k] /= nl;
         return true;
       };
+      // the parameter at which a calibration ray hits primitive t (Moeller-Trumbore in double; whole spheres as spheres), +inf: it does not
+      auto prim_hit = [&](const CalRay& cr, uint32_t t) -> double {
+        const double none = std::numeric_limits<double>::infinity();
+        double sc_[3], srad;
+        const int qk = quadric(t, sc_, &srad);
+        if (qk == 2) return none;
+        if (qk == 1) {
+          const double oc[3] = {cr.o[0] - sc_[0], cr.o[1] - sc_[1], cr.o[2] - sc_[2]};
+          const double A = cr.d[0] * cr.d[0] + cr.d[1] * cr.d[1] + cr.d[2] * cr.d[2], B = 2.0 * (oc[0] * cr.d[0] + oc[1] * cr.d[1] + oc[2] * cr.d[2]), Cq = oc[0] * oc[0] + oc[1] * oc[1] + oc[2] * oc[2] - srad * srad;
+          const double disc = B * B - 4.0 * A * Cq;
+          if (disc < 0.0) return none;
+          const double sq = std::sqrt(disc), t0 = (-B - sq) / (2.0 * A), t1 = (-B + sq) / (2.0 * A), eps = 1e-6 * srad / std::sqrt(A);
+          const double tt = t0 > eps ? t0 : t1;
+          return tt > eps ? tt : none;
+        }
+        const double e1[3] = {P(t, 1, 0) - P(t, 0, 0), P(t, 1, 1) - P(t, 0, 1), P(t, 1, 2) - P(t, 0, 2)}, e2[3] = {P(t, 2, 0) - P(t, 0, 0), P(t, 2, 1) - P(t, 0, 1), P(t, 2, 2) - P(t, 0, 2)};
+        const double pv[3] = {cr.d[1] * e2[2] - cr.d[2] * e2[1], cr.d[2] * e2[0] - cr.d[0] * e2[2], cr.d[0] * e2[1] - cr.d[1] * e2[0]};
+        const double det = pv[0] * e1[0] + pv[1] * e1[1] + pv[2] * e1[2];
+        if (det == 0.0) return none;
+        const double tv[3] = {cr.o[0] - P(t, 0, 0), cr.o[1] - P(t, 0, 1), cr.o[2] - P(t, 0, 2)};
+        const double u = (tv[0] * pv[0] + tv[1] * pv[1] + tv[2] * pv[2]) / det;
+        if (u < 0.0 || u > 1.0) return none;
+        const double qv[3] = {tv[1] * e1[2] - tv[2] * e1[1], tv[2] * e1[0] - tv[0] * e1[2], tv[0] * e1[1] - tv[1] * e1[0]};
+        const double v = (cr.d[0] * qv[0] + cr.d[1] * qv[1] + cr.d[2] * qv[2]) / det;
+        if (v < 0.0 || u + v > 1.0) return none;
+        const double tt = (e2[0] * qv[0] + e2[1] * qv[1] + e2[2] * qv[2]) / det;
+        return tt > 1e-9 ? tt : none;
+      };
+      // the nearest hit of a calibration ray (a plain stack walk of the tree in double): the next vertex of the random walk below. false: it leaves the scene
+      auto closest_hit = [&](const CalRay& cr, double& t_hit, uint32_t& prim) {
+        t_hit = std::numeric_limits<double>::infinity(); prim = 0;
+        std::vector<uint32_t> stk; stk.reserve(64); stk.push_back(0);
+        const double inv[3] = {1.0 / cr.d[0], 1.0 / cr.d[1], 1.0 / cr.d[2]};
+        while (!stk.empty()) {
+          const uint32_t i = stk.back(); stk.pop_back();
+          const rt_bvh_node& n = desc->nodes[i];
+          double tn = -1e300, tf = 1e300;
+          for (int k = 0; k < 3; ++k) { double a0 = ((double)n.bmin[k] - cr.o[k]) * inv[k], a1 = ((double)n.bmax[k] - cr.o[k]) * inv[k]; if (a0 > a1) std::swap(a0, a1); tn = std::max(tn, a0); tf = std::min(tf, a1); }
+          if (!(tn <= tf && tf > 0.0 && tn < t_hit)) continue;
+          if (n.n_prims != 0) { for (uint32_t t = n.offset; t < n.offset + n.n_prims; ++t) { const double tt = prim_hit(cr, t); if (tt < t_hit) { t_hit = tt; prim = t; } } }
+          else { stk.push_back(i + 1); stk.push_back(n.offset); }
+        }
+        return t_hit < 1e300;
+      };
       auto pick_tri = [&]() { const double x = rnd() * cum[desc->n_tris]; return (uint32_t)std::min<size_t>(desc->n_tris - 1, (size_t)(std::upper_bound(cum.begin(), cum.end(), x) - cum.begin()) - 1); };
+      // Where the rays start: a RANDOM WALK, as the paths they stand for - the first vertex of a chain an area-weighted surface point (three of four chains leave it
+      // towards the middle of the scene, where a path's next vertex usually lies), each further vertex where the chain's last ray hit, up to five deep or until a ray
+      // leaves the scene; surfaces are thereby weighted by how much of the scene sees them (RTX_CAL_WALK=0, measurement knob: every ray from an area-weighted point).
+      static const bool walk_on = !(getenv("RTX_CAL_WALK") && getenv("RTX_CAL_WALK")[0] == '0');
+      bool have_vertex = false; int depth = 0; double vp[3] = {0, 0, 0}, vn[3] = {0, 0, 1};
       for (uint32_t r = 0; r < K && cum[desc->n_tris] > 0.0; ++r) {
-        const uint32_t t = pick_tri();
         CalRay cr; cr.t_max = 1e300;
         double n[3];
-        if (!surface_point(t, cr.o, n)) continue;
-        // three of four rays leave towards the middle of the scene (where a path's next vertex usually lies), one the other way
-        const double side = ((ctr[0] - cr.o[0]) * n[0] + (ctr[1] - cr.o[1]) * n[1] + (ctr[2] - cr.o[2]) * n[2]) < 0.0 ? -1.0 : 1.0;
-        const double flip = (rnd() < 0.25 ? -1.0 : 1.0) * side;
-        for (int k = 0; k < 3; ++k) { n[k] *= flip; cr.o[k] += n[k] * 1e-6 * (std::fabs(cr.o[k]) + 1.0); }
+        if (walk_on && have_vertex && depth < 5) { for (int k = 0; k < 3; ++k) { n[k] = vn[k]; cr.o[k] = vp[k] + n[k] * 1e-6 * (std::fabs(vp[k]) + 1.0); } }
+        else {
+          const uint32_t t = pick_tri();
+          if (!surface_point(t, cr.o, n)) continue;
+          const double side = ((ctr[0] - cr.o[0]) * n[0] + (ctr[1] - cr.o[1]) * n[1] + (ctr[2] - cr.o[2]) * n[2]) < 0.0 ? -1.0 : 1.0;
+          const double flip = (rnd() < 0.25 ? -1.0 : 1.0) * side;
+          for (int k = 0; k < 3; ++k) { n[k] *= flip; cr.o[k] += n[k] * 1e-6 * (std::fabs(cr.o[k]) + 1.0); }
+          depth = 0; have_vertex = false;
+          if (walk_on) { for (int k = 0; k < 3; ++k) { vp[k] = cr.o[k]; vn[k] = n[k]; } have_vertex = true; }
+        }
         if ((r & 3u) == 3u) {  // every fourth ray: a shadow segment towards a point on an emitter (any surface point where nothing emits)
           double q[3], qn[3];
           if (!surface_point(emitters.empty() ? pick_tri() : emitters[(size_t)(rnd() * emitters.size()) % emitters.size()], q, qn)) continue;
@@ -143,6 +196,23 @@ static void rt_build_link_tables(const rt_scene_desc* desc, bool mid, bool want_
         for (int k = 0; k < 3; ++k) cr.d[k] = tx[k] * rr * std::cos(ph) + ty[k] * rr * std::sin(ph) + n[k] * cz;
         if (cr.d[0] == 0.0 || cr.d[1] == 0.0 || cr.d[2] == 0.0) continue;
         rays[(cr.d[0] < 0.0 ? 1 : 0) | (cr.d[1] < 0.0 ? 2 : 0) | (cr.d[2] < 0.0 ? 4 : 0)].push_back(cr);
+        if (walk_on) {  // the chain's next vertex: where this ray hits, the normal there turned against the ray
+          double th; uint32_t hp;
+          have_vertex = closest_hit(cr, th, hp);
+          if (have_vertex) {
+            double c[3], rad;
+            for (int k = 0; k < 3; ++k) vp[k] = cr.o[k] + th * cr.d[k];
+            if (quadric(hp, c, &rad) == 1) { for (int k = 0; k < 3; ++k) vn[k] = (vp[k] - c[k]) / rad; }
+            else {
+              const double e1[3] = {P(hp, 1, 0) - P(hp, 0, 0), P(hp, 1, 1) - P(hp, 0, 1), P(hp, 1, 2) - P(hp, 0, 2)}, e2[3] = {P(hp, 2, 0) - P(hp, 0, 0), P(hp, 2, 1) - P(hp, 0, 1), P(hp, 2, 2) - P(hp, 0, 2)};
+              vn[0] = e1[1] * e2[2] - e1[2] * e2[1]; vn[1] = e1[2] * e2[0] - e1[0] * e2[2]; vn[2] = e1[0] * e2[1] - e1[1] * e2[0];
+              const double nl = std::sqrt(vn[0] * vn[0] + vn[1] * vn[1] + vn[2] * vn[2]);
+              if (nl > 0.0) { for (int k = 0; k < 3; ++k) vn[k] /= nl; } else have_vertex = false;
+            }
+            if (vn[0] * cr.d[0] + vn[1] * cr.d[1] + vn[2] * cr.d[2] > 0.0) for (int k = 0; k < 3; ++k) vn[k] = -vn[k];
+            depth += 1;
+          }
+        }
       }
       // What a ray's walk meets does not depend on which nodes are tested: per set, ray and node the parameter at which the ray enters the node's box (+inf: it misses the
       // box), per ray and primitive the parameter of its hit (+inf: none; Moeller-Trumbore in double) - computed when first asked for and kept (NaN: not yet), so that a
@@ -162,34 +232,8 @@ static void rt_build_link_tables(const rt_scene_desc* desc, bool mid, bool want_
       auto prim_t = [&](int w, size_t r, uint32_t t) -> float {
         float& out = t_prim[w][r * (size_t)desc->n_tris + t];
         if (out == out) return out;
-        const CalRay& cr = rays[w][r];
-        out = kNone;
-        double sc_[3], srad;
-        const int qk = quadric(t, sc_, &srad);
-        if (qk == 2) return out;
-        if (qk == 1) {
-          const double oc[3] = {cr.o[0] - sc_[0], cr.o[1] - sc_[1], cr.o[2] - sc_[2]};
-          const double A = cr.d[0] * cr.d[0] + cr.d[1] * cr.d[1] + cr.d[2] * cr.d[2], B = 2.0 * (oc[0] * cr.d[0] + oc[1] * cr.d[1] + oc[2] * cr.d[2]), Cq = oc[0] * oc[0] + oc[1] * oc[1] + oc[2] * oc[2] - srad * srad;
-          const double disc = B * B - 4.0 * A * Cq;
-          if (disc < 0.0) return out;
-          const double sq = std::sqrt(disc), t0 = (-B - sq) / (2.0 * A), t1 = (-B + sq) / (2.0 * A), eps = 1e-6 * srad / std::sqrt(A);
-          const double tt = t0 > eps ? t0 : t1;
-          if (tt > eps) out = (float)tt;
-          return out;
-        }
-        const double e1[3] = {P(t, 1, 0) - P(t, 0, 0), P(t, 1, 1) - P(t, 0, 1), P(t, 1, 2) - P(t, 0, 2)}, e2[3] = {P(t, 2, 0) - P(t, 0, 0), P(t, 2, 1) - P(t, 0, 1), P(t, 2, 2) - P(t, 0, 2)};
-        const double pv[3] = {cr.d[1] * e2[2] - cr.d[2] * e2[1], cr.d[2] * e2[0] - cr.d[0] * e2[2], cr.d[0] * e2[1] - cr.d[1] * e2[0]};
-        const double det = pv[0] * e1[0] + pv[1] * e1[1] + pv[2] * e1[2];
-        if (det == 0.0) return out;
-        const double tv[3] = {cr.o[0] - P(t, 0, 0), cr.o[1] - P(t, 0, 1), cr.o[2] - P(t, 0, 2)};
-        const double u = (tv[0] * pv[0] + tv[1] * pv[1] + tv[2] * pv[2]) / det;
-        if (u < 0.0 || u > 1.0) return out;
-        const double qv[3] = {tv[1] * e1[2] - tv[2] * e1[1], tv[2] * e1[0] - tv[0] * e1[2], tv[0] * e1[1] - tv[1] * e1[0]};
-        const double v = (cr.d[0] * qv[0] + cr.d[1] * qv[1] + cr.d[2] * qv[2]) / det;
-        if (v < 0.0 || u + v > 1.0) return out;
-        const double tt = (e2[0] * qv[0] + e2[1] * qv[1] + e2[2] * qv[2]) / det;
-        if (tt > 1e-9) out = (float)tt;
-        return out;
+        const double tt = prim_hit(rays[w][r], t);
+        return out = tt < 3.0e38 ? (float)tt : kNone;
       };
       // The walk over the rays of set `w` when only kept[w] nodes are tested (a node that is not tested counts as passed). w < 8: BVH::intersect's order and its shrinking
       // t_max; w == 8: the occlusion walk - first child first at every node, over at the first primitive hit. Returns the node tests; n_pass / n_fail: per node, the rays
