@@ -496,3 +496,15 @@ def test_parallel_replay_of_the_shuffle_is_exact():
                        cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
     assert "passed" in r.stdout and "k_sampler_shuffle_par: 0 wave(s) re-sorted" in r.stderr + r.stdout  # the parallel kernel ran, its groups came out sorted
+
+
+def test_random_scenes_of_every_size_class_walk_like_the_oracle(gpu_host, orc, monkeypatch):
+    """scripts/fuzz_lds_walks.py, sixteen scenes of it: soups of 3 ... 1400 triangles with random leaf sizes (LDS-resident, with quadrics, mid-size; some degenerate), 40 000
+    rays each with zero / denormal components, axis-parallel rays and origins on vertices among them - closest hit bit for bit, occlusion answers equal."""
+    import importlib.util
+    import os
+    spec = importlib.util.spec_from_file_location("fuzz_lds_walks", os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "scripts", "fuzz_lds_walks.py"))
+    m = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(m)
+    monkeypatch.setattr("sys.argv", ["fuzz_lds_walks.py", "16", "5"])
+    assert m.main() == 0
