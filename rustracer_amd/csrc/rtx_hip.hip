@@ -807,6 +807,22 @@ extern "C" int rt_link_tables(const rt_scene_desc* desc, int32_t mid, uint32_t* 
   const size_t words = (size_t)9 * desc->n_nodes + 9;
   if (desc->n_nodes > (mid ? RT_MID_NODES : RT_SMALL_NODES) || desc->n_tris > (uint64_t)(mid ? RT_MID_TRIS : RT_SMALL_TRIS) || desc->n_instances != 0) return fail(RT_ERR_INVALID, "not an LDS-sized scene");
   if (capacity_words < words) return fail(RT_ERR_INVALID, "link table capacity too small");
+  {  // the tree as rt_scene_create requires it: pre-order, first child at i + 1, second child right behind the first one's subtree, leaf ranges inside the primitives
+    const uint32_t nn = desc->n_nodes;
+    std::vector<uint32_t> size(nn, 1u);
+    for (uint32_t i = nn; i-- > 0;) {
+      const rt_bvh_node& n = desc->nodes[i];
+      if (n.n_prims != 0) { if ((uint64_t)n.offset + n.n_prims > desc->n_tris) return fail(RT_ERR_INVALID, "leaf range out of bounds"); continue; }
+      if (i + 1 >= nn || n.offset != i + 1 + size[i + 1] || n.offset >= nn) return fail(RT_ERR_INVALID, "nodes are not a pre-order tree");
+      size[i] = 1u + size[i + 1] + size[n.offset];
+    }
+    if (size[0] != nn) return fail(RT_ERR_INVALID, "nodes are not one tree");
+    for (uint64_t t = 0; t < desc->n_tris; ++t)
+      if (desc->tri_meta[t].flags & RT_PRIM_SPHERE) {
+        uint32_t k; memcpy(&k, desc->tri_p + 9 * t + 6, 4);
+        if (!desc->spheres || k >= desc->n_spheres) return fail(RT_ERR_INVALID, "sphere index out of range");
+      }
+  }
   RtLinkTables lt;
   rt_build_link_tables(desc, mid != 0, stats != nullptr, lt);
   memcpy(link_kept, lt.link_kept.data(), words * 4); memcpy(link_full, lt.link_full.data(), words * 4);
