@@ -1088,8 +1088,8 @@ RT_DEV bool closest_small_links(const float* __restrict__ s_nodes, const float* 
   return found;
 }
 // occluded_small_links in rounds (RT_LDS_LEAF_MIN_ANY > 1): a lane that reaches a leaf holds it until LEAF_MIN lanes hold one, then every holder tests one primitive
-template <int N, int T, bool FINITE, int LEAF_MIN>
-RT_DEV bool occluded_small_links_rounds(const float* __restrict__ s_nodes, const float* __restrict__ s_tris, const unsigned* __restrict__ link, const int n_nodes, const int start, const Ray ray) {
+template <int N, int T, bool FINITE, int LEAF_MIN, int GENERAL = 0>
+RT_DEV bool occluded_small_links_rounds(const float* __restrict__ s_nodes, const float* __restrict__ s_tris, const unsigned* __restrict__ link, const int n_nodes, const int start, const Ray ray, const GeneralCtx gen = GeneralCtx{nullptr, false}) {
   const f3 inv_dir = mk3(1.0f / ray.d.x, 1.0f / ray.d.y, 1.0f / ray.d.z);
   const int neg_x = inv_dir.x < 0.0f, neg_y = inv_dir.y < 0.0f, neg_z = inv_dir.z < 0.0f;
   const RayPre rp = ray_pre(ray);
@@ -1128,7 +1128,8 @@ RT_DEV bool occluded_small_links_rounds(const float* __restrict__ s_nodes, const
                p2t = mk3(tpx[6 * T + t] - op.x, tpy[6 * T + t] - op.y, tpz[6 * T + t] - op.z);
       TriHit h;
       leaf_off += 1; leaf_n -= 1;
-      if (tri_test_permuted<RT_ANY_EARLY_SIGN != 0>(p0t, p1t, p2t, rp.sx, rp.sy, rp.sz, ray.t_max, h)) { found = true; cur = n_nodes; leaf_n = 0; }
+      if (GENERAL) { if (leaf_prim_test<GENERAL>(LdsSrcT<N, T>{s_nodes, s_tris}, gen, t, ray, rp, h)) { found = true; cur = n_nodes; leaf_n = 0; } }
+      else if (tri_test_permuted<RT_ANY_EARLY_SIGN != 0>(p0t, p1t, p2t, rp.sx, rp.sy, rp.sz, ray.t_max, h)) { found = true; cur = n_nodes; leaf_n = 0; }
     }
   }
   return found;
@@ -1241,6 +1242,12 @@ RT_DEV void trace_write_any(float4* __restrict__ lacc, size_t ls, const float4* 
 #ifndef RT_MID_LEAF_MIN_ANY
 #define RT_MID_LEAF_MIN_ANY 8  // (> 1: the occlusion walk in rounds, occluded_small_links_rounds)
 #endif
+#ifndef RT_LDS_LEAF_MIN_CLOSEST_GENERAL
+#define RT_LDS_LEAF_MIN_CLOSEST_GENERAL 16
+#endif
+#ifndef RT_LDS_LEAF_MIN_ANY_GENERAL
+#define RT_LDS_LEAF_MIN_ANY_GENERAL 56  // occlusion rays of an LDS-resident scene with quadrics / masks: leaf phases at this many waiting lanes (1: every lane tests its leaf at once)
+#endif
 #ifndef RT_MID_LEAF_MIN_CLOSEST
 #define RT_MID_LEAF_MIN_CLOSEST 16
 #endif
@@ -1297,7 +1304,7 @@ __global__ void __launch_bounds__(BLOCK, MID ? 4 : ((SMALL && GENERAL == 0 && !C
     Ray ray; ray.o = mk3(o4.x, o4.y, o4.z); ray.d = mk3(d4.x, d4.y, d4.z); ray.t_max = o4.w;
     int prim = -1; TriHit h; h.t = kInf; h.b0 = h.b1 = h.b2 = 0.0f;
     bool found;
-    constexpr int LM = ANY ? (MID ? RT_MID_LEAF_MIN_ANY : RT_LDS_LEAF_MIN_ANY) : (MID ? RT_MID_LEAF_MIN_CLOSEST : RT_LDS_LEAF_MIN_CLOSEST);
+    constexpr int LM = ANY ? (MID ? RT_MID_LEAF_MIN_ANY : (GENERAL ? RT_LDS_LEAF_MIN_ANY_GENERAL : RT_LDS_LEAF_MIN_ANY)) : (MID ? RT_MID_LEAF_MIN_CLOSEST : (GENERAL ? RT_LDS_LEAF_MIN_CLOSEST_GENERAL : RT_LDS_LEAF_MIN_CLOSEST));
     const GeneralCtx gen{sc.self, ANY && io.shadow_masks != 0};
     // Plain-triangle launches that do not count visits take the min / max node test (slab_test_finite) when every ray of the wave has a finite reciprocal
     // direction - all but a few hundred waves of a frame; a wave that holds one ray with a zero direction component walks with the reference's selects.
@@ -1305,8 +1312,8 @@ __global__ void __launch_bounds__(BLOCK, MID ? 4 : ((SMALL && GENERAL == 0 && !C
     const bool fin = FIN_FORMS && __ballot(!inv_dir_finite(mk3(1.0f / ray.d.x, 1.0f / ray.d.y, 1.0f / ray.d.z))) == 0ull;
     if (SMALL && LM > 1 && LM < 64 && !COUNT) {
       LdsS src{s_nodes, s_tris};
-      if (LINKS && ANY && GENERAL == 0) found = fin ? occluded_small_links_rounds<NN, NT, true, LM>(s_nodes, s_tris, s_link, (int)sc.n_nodes, (int)s_link[NN], ray)
-                                    : occluded_small_links_rounds<NN, NT, false, LM>(s_nodes, s_tris, sc.link8_full + 8u * sc.n_nodes + 8u, (int)sc.n_nodes, (int)sc.link8_full[9u * sc.n_nodes + 8u], ray);
+      if (LINKS && ANY) found = fin ? occluded_small_links_rounds<NN, NT, true, LM, GENERAL>(s_nodes, s_tris, s_link, (int)sc.n_nodes, (int)s_link[NN], ray, gen)
+                                    : occluded_small_links_rounds<NN, NT, false, LM, GENERAL>(s_nodes, s_tris, sc.link8_full + 8u * sc.n_nodes + 8u, (int)sc.n_nodes, (int)sc.link8_full[9u * sc.n_nodes + 8u], ray, gen);
       else if (LINKS && !ANY) {
         if (fin) {  // (s_link: 8 rows NN apart, the starts behind them - closest_small_links reads link8[8 * row + oct])
           found = closest_small_links<NN, NT, true, LM, GENERAL, MIDC>(s_nodes, s_tris, s_link, NN, (int)sc.n_nodes, ray, prim, h, gen, sc.tri_p);
