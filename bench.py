@@ -386,25 +386,37 @@ def run_workload(scene_name, runner, workload, steps, warmup):
     def trace_roofline():
         c = classes["path_closest"]
         if lds_scene:
-            return 48 * c["rays"], launches_path, ms_tc, "trace_closest", c["rays"], "ray"
-        return c["algorithmic_bytes"], launches_path, ms_tc, "trace_closest", c["rays"], "ray"
+            return 48 * c["rays"], launches_path, ms_tc, "trace_closest", c["rays"], "ray", 32 * c["rays"]
+        return c["algorithmic_bytes"], launches_path, ms_tc, "trace_closest", c["rays"], "ray", 32 * c["rays"]
 
     def shade_roofline():
         verts = (cst["rays_closest"] - tail_nc) / nd_div
         emitted = (cst["rays_shadow"] + cst["rays_mis"] - not_cast + (cst["rays_closest"] - tail_nc - cst["camera_rays"])) / nd_div
         # one shade STAGE per bounce and pass (= per path-ray trace launch, counted by rt_render); on a class-split queue a stage is several k_shade launches
         # (rt_stats::launches_shade, in the detail file) - `traffic` (PMC) is per stage as well
-        return 128 * verts + 32 * emitted + 48 * cst["camera_rays"] / nd_div, launches_path, ms_sh, "shade", verts, "vertex"
+        return 128 * verts + 32 * emitted + 48 * cst["camera_rays"] / nd_div, launches_path, ms_sh, "shade", verts, "vertex", 64 * verts
 
-    def roof(algo_bytes, n_launch, ms_kernel, kname, unit_n, unit):
+    # `traffic` (PMC, stored profile): FETCH_SIZE counts the L2's fabric-side read REQUESTS at 64 B each. Calibrated on known byte counts (round 6,
+    # profiles/r06_fetch_calibration.json, scripts/micro/fetch_calibrate.hip): a coalesced stream - 4 or 16 bytes per lane - is fetched as 128-byte requests, so the counter
+    # shows HALF its bytes; a gather that misses the L2 is ONE request per 64-byte sector, so the counter shows what it moved (1.00 - 1.01 of the distinct sectors of a 1 GB
+    # table); WRITE_SIZE is exact. The x2 of the hardware guide therefore applies to the STREAMED reads of a kernel only: traffic = writes + raw reads + half of the bytes the
+    # stage streams in (`stream_read`: the ray / vertex records it reads in slot order, known from the counts). `traffic_doubled` is rounds 1 - 5's figure (every read x2).
+    def roof(algo_bytes, n_launch, ms_kernel, kname, unit_n, unit, stream_read):
         achieved = algo_bytes / (ms_kernel * 1e-3) / 1e9  # GB/s per device
         e, prov = pmc_entry(scene_name, kname)
         r = {"bound": "hbm", "kernel": "k_" + kname, "achieved": round(achieved, 1), "peak": 8000.0, "unit": "GB/s",
-             "frac": round(achieved / 8000.0, 4), "traffic": e.get("hbm_bytes_per_launch"), "traffic_raw_reads": e.get("hbm_bytes_per_launch_raw"),
+             "frac": round(achieved / 8000.0, 4), "traffic": None, "traffic_raw_reads": e.get("hbm_bytes_per_launch_raw"), "traffic_doubled": e.get("hbm_bytes_per_launch"),
              "traffic_provenance": prov,
              "algorithmic_bytes_per_launch": round(algo_bytes / max(n_launch, 1)), "avg_launch_ms": round(ms_kernel / max(n_launch, 1), 4),
              "launches_per_step": int(n_launch), f"bytes_per_{unit}": round(algo_bytes / max(unit_n, 1), 1),
              "lanes": e.get("lanes_per_valu"), "valu_busy": e.get("valu_busy")}  # lanes / valu_busy: SQ counters of the stored profile (share of the SIMDs' cycles that issue a vector instruction)
+        if e.get("hbm_bytes_per_launch_raw") is not None:
+            raw = float(e["hbm_bytes_per_launch_raw"])
+            r["traffic"] = round(min(raw + 0.5 * stream_read / max(n_launch, 1), float(e.get("hbm_bytes_per_launch") or 1e30)))
+            # the L2-miss read requests of the stage per second (reads: doubled - raw = raw reads; 64 B each): the fabric sustained ~55 G requests/s in the calibration's
+            # gathers and ~44 G/s (128-byte) in its streams, whatever the table's size - a stage near that rate is bound by REQUESTS, not by bytes
+            reads_raw = float(e.get("hbm_bytes_per_launch") or raw) - raw
+            r["l2_miss_read_requests_per_s"] = round(reads_raw / 64.0 / (ms_kernel / max(n_launch, 1) * 1e-3) / 1e9, 1)  # G requests / s
         if kname == "trace_closest" and lds_scene:
             r["limiter"] = "VALU issue: the scene is LDS-resident, a ray's HBM bytes are its record in and its hit out"
         if prov and prov.get("stale"):
@@ -444,7 +456,7 @@ def run_workload(scene_name, runner, workload, steps, warmup):
 
 LINE_LIMIT = 4096  # bytes of the ONE printed line (a 78 KB line was not parsed by the driver); tests/test_bench_cpu.py holds it there
 
-ROOF_KEYS = ("bound", "kernel", "achieved", "peak", "unit", "frac", "traffic", "traffic_raw_reads", "algorithmic_bytes_per_launch", "avg_launch_ms", "launches_per_step", "lanes", "valu_busy", "limiter")
+ROOF_KEYS = ("bound", "kernel", "achieved", "peak", "unit", "frac", "traffic", "traffic_raw_reads", "traffic_doubled", "l2_miss_read_requests_per_s", "algorithmic_bytes_per_launch", "avg_launch_ms", "launches_per_step", "lanes", "valu_busy", "limiter")
 CPU_KEYS = ("value", "unit", "cores", "kind", "sample")
 TOP_KEYS = ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data", "config",
             "n_gpus_requested", "per_device_ms", "gather_ms", "imbalance_max_over_mean")

@@ -1133,6 +1133,15 @@ static void launch_trace_c(rt_scene* s, const TraceIO& io, const unsigned* queue
   }
 #undef RT_ARGS
 }
+// the frame loop's path rays go through k_trace (an LDS copy of the scene: its closest-hit walks read a link row per direction octant, and it knows dead queue entries)
+static bool path_rays_walk_lds(const rt_scene* s) {
+  static const bool mid_closest = !(getenv("RTX_MID_CLOSEST") && getenv("RTX_MID_CLOSEST")[0] == '0');
+  static const bool gen_big = getenv("RTX_TRACE_GENERAL") && getenv("RTX_TRACE_GENERAL")[0] == 'b';
+  static const bool pool = getenv("RTX_LDS_POOL") && atoi(getenv("RTX_LDS_POOL")) != 0;
+  if (pool) return false;
+  if (s->general_prims) return s->small && !gen_big && !s->has_instances;
+  return s->small || (s->mid && mid_closest);
+}
 template <bool ANY>
 static void launch_trace(rt_scene* s, bool count, const TraceIO& io, const unsigned* queue, const unsigned* count_ptr, unsigned shard_cap, unsigned count_static,
                          unsigned long long* stats, int st_rays, int st_nodes, int st_tris, hipStream_t stream) {
@@ -1504,7 +1513,15 @@ extern "C" int rt_render(rt_scene* s, const rt_camera* cam, const rt_film_desc* 
   const unsigned pgrid_q = (unsigned)s->n_cu * 8u;
   const unsigned long long table_bytes_per_pixel = 2ull * dims * spp * 2ull;
 
-  unsigned long long batch_pixels = 0, chunk_pixels = 0, cap = 0, lead_pixels = 0; unsigned pass_samples = 0, shard_cap = 0; bool multi_batch = false; size_t n_slots = 0;
+  unsigned long long batch_pixels = 0, chunk_pixels = 0, cap = 0, lead_pixels = 0; unsigned pass_samples = 0, shard_cap = 0; bool multi_batch = false; size_t n_slots = 0, n_ent = 0;
+  // Octant runs (round 6, block_push_oct): the continuing paths of scenes whose path rays walk an LDS copy of the scene (k_trace: LDS-resident and mid-size scenes) are appended in runs
+  // of one direction octant. Off on frames that count the reference's walk (a dead entry would count a node test). RTX_OCT = 0 | 64 | 128 | 256: the A/B control / the run length
+  unsigned oct_log2 = 0;
+  {
+    static const int oct_env = getenv("RTX_OCT") ? atoi(getenv("RTX_OCT")) : -1;
+    const bool count_frame = (flags & RT_FLAG_COUNT_TRAVERSAL) != 0;
+    if (path_rays_walk_lds(s) && !count_frame && oct_env != 0) oct_log2 = oct_env == 64 ? 6u : (oct_env == 128 ? 7u : 8u);
+  }
   static const char* lead_env = getenv("RTX_LEAD_BATCH");  // measurement knob (round 4), see lead_pixels below: 1 always, 0 never, unset: at 1024 spp
   const bool lead_on = lead_env ? lead_env[0] == '1' : spp == 1024u;
   for (int shrink = 0;; ++shrink) {
@@ -1530,19 +1547,21 @@ extern "C" int rt_render(rt_scene* s, const rt_camera* cam, const rt_film_desc* 
     if (cap > 0x7fffffffull) return fail(RT_ERR_INVALID, "pass too large");
     // a shard receives the appends of the blocks with blockIdx % RT_QSHARDS == shard; a grid-stride loop hands
     // each block at most ceil(n / (grid * 256)) iterations, so cap / RT_QSHARDS plus one iteration per block bounds it
-    shard_cap = (unsigned)(cap / RT_QSHARDS) + 256u * (pgrid_q / RT_QSHARDS + 1u) + 256u;
+    // (octant runs, block_push_oct: a workgroup may leave eight open runs of <= 256 slots behind instead of none)
+    shard_cap = (unsigned)(cap / RT_QSHARDS) + 256u * (pgrid_q / RT_QSHARDS + 1u) + 256u + (oct_log2 ? 8u * 256u * (pgrid_q / RT_QSHARDS + 1u) : 0u);
     const size_t szq = (size_t)shard_cap * RT_QSHARDS * 4;
     n_slots = (size_t)shard_cap * RT_QSHARDS;  // slots of a sharded queue (>= cap: bounce 0 of a fully traced pass uses slot = path id)
     multi_batch = owned_pixels > chunk_pixels || lead_pixels > 0;
+    n_ent = oct_log2 ? n_slots : (size_t)cap;  // entries a bounce's queue can hold: with octant runs the dead ones as well
     struct Want { DevBuf* buf; size_t bytes; };
     std::vector<Want> want = {
         {&s->ws[B_GEN0], n_slots * 64}, {&s->ws[B_GEN1], n_slots * 64}, {&s->ws[B_HIT], n_slots * 16}, {&s->ws[B_GENS], bin_move ? n_slots * 64 : 16}, {&s->ws[B_HITS], bin_move ? n_slots * 16 : 16}, {&s->ws[B_LACC], cap * 16}, {&s->ws[B_PFILM], cap * 8},
-        {&s->ws[B_SH], cap * 48}, {&s->ws[B_MI], cap * 100}, {&s->ws[B_OCCSH], cap}, {&s->ws[B_OCCMI], cap},
+        {&s->ws[B_SH], n_ent * 48}, {&s->ws[B_MI], n_ent * 100}, {&s->ws[B_OCCSH], n_ent}, {&s->ws[B_OCCMI], n_ent},
         {&s->ws[B_QSH], szq}, {&s->ws[B_QMI], szq}, {&s->ws[B_QMA], has_infinite ? szq : 16},
         {&s->counters, counter_words * 4}, {&s->stats, (size_t)ST_COUNT * 8}, {&s->film_acc, (size_t)cw * ch * 16}, {&s->own_acc, (size_t)chunk_pixels * 16},
         {&s->filter_table, 1024}, {&s->scrambles[0], (size_t)chunk_pixels * 3 * dims * 4}, {&s->perms[0], (size_t)(chunk_pixels * table_bytes_per_pixel)},
         {&s->sampler_plan.partners, (size_t)(chunk_pixels * table_bytes_per_pixel)}};
-    if (use_bins) { want.push_back({&s->bin_words, (size_t)(fp.max_depth + 1) * bin_stride * 4}); want.push_back({&s->bin_sorted, bin_move ? 16 : (size_t)cap * 4}); want.push_back({&s->bin_at, (size_t)cap * 2}); }
+    if (use_bins) { want.push_back({&s->bin_words, (size_t)(fp.max_depth + 1) * bin_stride * 4}); want.push_back({&s->bin_sorted, bin_move ? 16 : n_ent * 4}); want.push_back({&s->bin_at, n_ent * 2}); }
     if (multi_batch) { want.push_back({&s->scrambles[1], (size_t)chunk_pixels * 3 * dims * 4}); want.push_back({&s->perms[1], (size_t)(chunk_pixels * table_bytes_per_pixel)}); }
     if (!(flags & RT_FLAG_FILM_ON_DEVICE)) want.push_back({&s->film_out, (size_t)cw * ch * 16});
     size_t grow = 0;  // bytes the buffers have to grow by (a buffer that is too small is freed and allocated anew)
@@ -1573,12 +1592,12 @@ extern "C" int rt_render(rt_scene* s, const rt_camera* cam, const rt_film_desc* 
   auto gen_of = [&](int b) { PathGen g; char* p = (char*)s->ws[b].p; g.o = (float4*)p; g.d = (float4*)(p + n_slots * 16); g.beta = (float4*)(p + n_slots * 32); g.st = (uint4*)(p + n_slots * 48); return g; };
   const PathGen gen0 = gen_of(B_GEN0), gen1 = gen_of(B_GEN1), gen_sorted = gen_of(B_GENS);
   ps.hit = s->ws[B_HIT].as<float4>(); ps.lacc = s->ws[B_LACC].as<float4>(); ps.pfilm = s->ws[B_PFILM].as<float2>();
-  { char* p = (char*)s->ws[B_SH].p; ps.sh.o = (float4*)p; ps.sh.d = (float4*)(p + cap * 16); ps.sh.add = (float4*)(p + cap * 32);
-    char* q = (char*)s->ws[B_MI].p; ps.mi.o = (float4*)q; ps.mi.d = (float4*)(q + cap * 16); ps.mi.hit = (float4*)(q + cap * 32); ps.mi.a = (float4*)(q + cap * 48);
-    ps.mi.b = (float4*)(q + cap * 64); ps.mi.c = (float4*)(q + cap * 80); ps.mi.flags = (unsigned*)(q + cap * 96); }
+  { char* p = (char*)s->ws[B_SH].p; ps.sh.o = (float4*)p; ps.sh.d = (float4*)(p + n_ent * 16); ps.sh.add = (float4*)(p + n_ent * 32);
+    char* q = (char*)s->ws[B_MI].p; ps.mi.o = (float4*)q; ps.mi.d = (float4*)(q + n_ent * 16); ps.mi.hit = (float4*)(q + n_ent * 32); ps.mi.a = (float4*)(q + n_ent * 48);
+    ps.mi.b = (float4*)(q + n_ent * 64); ps.mi.c = (float4*)(q + n_ent * 80); ps.mi.flags = (unsigned*)(q + n_ent * 96); }
   ps.occ_sh = s->ws[B_OCCSH].as<unsigned char>(); ps.occ_mi = s->ws[B_OCCMI].as<unsigned char>();
   ps.q_shadow = s->ws[B_QSH].as<unsigned>(); ps.q_mis = s->ws[B_QMI].as<unsigned>(); ps.q_misany = s->ws[B_QMA].as<unsigned>();
-  ps.own_acc = s->own_acc.as<float4>(); ps.shard_cap = shard_cap; ps.stats = s->stats.as<unsigned long long>();
+  ps.own_acc = s->own_acc.as<float4>(); ps.shard_cap = shard_cap; ps.oct_log2 = oct_log2; ps.stats = s->stats.as<unsigned long long>();
 
   if ((rc = sampler_plan_prepare(s->sampler_plan, spp, dims)) != RT_OK) return rc;
   if ((rc = sampler_set_lds_limits(spp)) != RT_OK) return rc;
@@ -1595,8 +1614,7 @@ extern "C" int rt_render(rt_scene* s, const rt_camera* cam, const rt_film_desc* 
   const unsigned pgrid = (unsigned)s->n_cu * 8u;
   // workgroup size of the shade launches (measurement knob RTX_SHADE_BLOCK = 64 | 128 | 256): the queue appends of a workgroup meet at three barriers per
   // iteration, so its waves run in lockstep; smaller workgroups trade that for more atomics on the shard counters. Same number of lanes in the grid.
-  static const unsigned sblock = [] { const char* e = getenv("RTX_SHADE_BLOCK"); const int v = e ? atoi(e) : 256; return (unsigned)(v == 64 || v == 128 ? v : 256); }();
-  const unsigned sgrid = pgrid * (256u / sblock);
+  const unsigned sblock = 256u, sgrid = pgrid;
   unsigned long long* dstats = s->stats.as<unsigned long long>();
 
   // K0 of a batch goes to the low-priority aux stream: it is a latency-bound chain of LDS swaps that leaves the

@@ -22,12 +22,57 @@ namespace rtx {
 // the radiance sum `lacc` (added to by the any-hit epilogue, k_resolve and - for emitters seen directly - k_shade) and the film position `pfilm`.
 // Before: RayRec / VertRec / PathAcc arrays indexed by path id and queues of ids, so a consumer's loads were a gather through the id (two dependent round
 // trips, lines shared with dead paths; S1 k_shade<1> moved 1.7x its algorithmic bytes at 0.68 wait cycles per wave cycle - VERDICT r03 weak #3).
-struct PathGen { float4* o; float4* d; float4* beta; uint4* st; };  // [slot]: ray (o | t_max), (d | -), throughput (rgb | eta_scale), (packed state, path id, RNG state lo, hi)
+// ---- Cache policy of the once-through streams (round 6). SPtr<T> is T* by default. With -DRT_NT_STREAMS=1 it is a pointer whose element reads and
+// writes carry the non-temporal hint (global_load / global_store ... nt): the travelling path records, ray and hit records, ray queues and occlusion bytes are written
+// once and read once, and should not push the gathered tables (environment rows, texels, triangle records) out of L2 / Infinity Cache. Same values either way; measured in
+// MEASUREMENTS R6 (scripts/micro/fetch_calibrate.hip has the same mix in isolation).
+#ifndef RT_NT_STREAMS
+#define RT_NT_STREAMS 0
+#endif
+#if RT_NT_STREAMS
+typedef float nt_v4f __attribute__((ext_vector_type(4)));
+typedef unsigned nt_v4u __attribute__((ext_vector_type(4)));
+typedef float nt_v2f __attribute__((ext_vector_type(2)));
+RT_DEV float4 nt_ld(const float4* p) { const nt_v4f v = __builtin_nontemporal_load((const nt_v4f*)p); return make_float4(v.x, v.y, v.z, v.w); }
+RT_DEV uint4 nt_ld(const uint4* p) { const nt_v4u v = __builtin_nontemporal_load((const nt_v4u*)p); return make_uint4(v.x, v.y, v.z, v.w); }
+RT_DEV float2 nt_ld(const float2* p) { const nt_v2f v = __builtin_nontemporal_load((const nt_v2f*)p); return make_float2(v.x, v.y); }
+RT_DEV unsigned nt_ld(const unsigned* p) { return __builtin_nontemporal_load(p); }
+RT_DEV unsigned char nt_ld(const unsigned char* p) { return __builtin_nontemporal_load(p); }
+RT_DEV void nt_st(float4 a, float4* p) { nt_v4f v; v.x = a.x; v.y = a.y; v.z = a.z; v.w = a.w; __builtin_nontemporal_store(v, (nt_v4f*)p); }
+RT_DEV void nt_st(uint4 a, uint4* p) { nt_v4u v; v.x = a.x; v.y = a.y; v.z = a.z; v.w = a.w; __builtin_nontemporal_store(v, (nt_v4u*)p); }
+RT_DEV void nt_st(float2 a, float2* p) { nt_v2f v; v.x = a.x; v.y = a.y; __builtin_nontemporal_store(v, (nt_v2f*)p); }
+RT_DEV void nt_st(unsigned a, unsigned* p) { __builtin_nontemporal_store(a, p); }
+RT_DEV void nt_st(unsigned char a, unsigned char* p) { __builtin_nontemporal_store(a, p); }
+template <class T> struct NtRef {
+  T* p;
+  RT_DEV operator T() const { return nt_ld((const T*)p); }
+  RT_DEV void operator=(const T& v) const { nt_st(v, p); }
+};
+template <class T> struct NtPtr {
+  typedef typename std::remove_const<T>::type V;
+  T* p;
+  __host__ __device__ NtPtr() : p(nullptr) {}
+  __host__ __device__ NtPtr(T* q) : p(q) {}
+  template <class U> __host__ __device__ NtPtr(const NtPtr<U>& q) : p(q.p) {}  // NtPtr<T> -> NtPtr<const T>
+  RT_DEV typename std::conditional<std::is_const<T>::value, V, NtRef<V>>::type operator[](size_t i) const { if constexpr (std::is_const<T>::value) return nt_ld(p + i); else return NtRef<V>{p + i}; }
+  __host__ __device__ explicit operator bool() const { return p != nullptr; }
+  __host__ __device__ bool operator!=(std::nullptr_t) const { return p != nullptr; }
+  __host__ __device__ bool operator==(std::nullptr_t) const { return p == nullptr; }
+};
+template <class T> using SPtr = NtPtr<T>;
+#define RT_SPTR_R(T) NtPtr<T>
+template <class T> __host__ __device__ T* sraw(NtPtr<T> q) { return q.p; }
+#else
+template <class T> using SPtr = T*;
+#define RT_SPTR_R(T) T* __restrict__
+template <class T> __host__ __device__ T* sraw(T* q) { return q; }
+#endif
+struct PathGen { SPtr<float4> o; SPtr<float4> d; SPtr<float4> beta; SPtr<uint4> st; };  // [slot]: ray (o | t_max), (d | -), throughput (rgb | eta_scale), (packed state, path id, RNG state lo, hi)
 // The records of a vertex's shadow ray and BSDF-sampled MIS ray, PLANAR (round 4; 64- and 128-byte structs with 16 + 44 unused bytes before): a shade wave's
 // stores are contiguous 1 KB runs per field, the trace kernels read the two ray fields and nothing else, k_resolve reads what it needs of a vertex that
 // contributes. 48 B per shadow ray, 100 B per MIS ray.
-struct ShadowPlanes { float4* o; float4* d; float4* add; };  // (o | t_max), (d | complete-here flag << 31 | path id), beta * Ld / pick_pdf
-struct MisPlanes { float4* o; float4* d; float4* hit; float4* a; float4* b; float4* c; unsigned* flags; };  // d.w = path id; hit: of closest-hit MIS rays
+struct ShadowPlanes { SPtr<float4> o; SPtr<float4> d; SPtr<float4> add; };  // (o | t_max), (d | complete-here flag << 31 | path id), beta * Ld / pick_pdf
+struct MisPlanes { SPtr<float4> o; SPtr<float4> d; SPtr<float4> hit; SPtr<float4> a; SPtr<float4> b; SPtr<float4> c; SPtr<unsigned> flags; };  // d.w = path id; hit: of closest-hit MIS rays
 // 128 B, one line: everything k_resolve needs of a vertex with a BSDF-sampled MIS ray. hit.y = prim of the closest hit, or - for rays that only
 // need occlusion (sampled light infinite) - 1 / 0 from the any-hit kernel
 #define RT_PEND_SHADOW 1u           // MisPlanes::flags: a shadow ray is out (its result is in occ_sh)
@@ -43,9 +88,9 @@ struct PassState {
   const unsigned* scrambles;        // [pixel][3*dims]
   const unsigned short* perms;      // [pixel][2*dims][spp]
   PathGen in, out;         // records of the paths of this bounce (read) and of the next (written), by queue slot
-  float4* hit;             // [slot] closest hit of the bounce's ray: (b2, prim, b0, b1)
+  SPtr<float4> hit;        // [slot] closest hit of the bounce's ray: (b2, prim, b0, b1)
   float4* lacc;            // [path id] (L rgb | flags: RT_STATE_OUT_OF_BOUNDS)
-  float2* pfilm;           // [path id] film position of the camera sample
+  SPtr<float2> pfilm;      // [path id] film position of the camera sample
   // The records of a vertex's shadow ray and BSDF-sampled MIS ray are indexed by the vertex's POSITION IN THE SHADE LAUNCH'S QUEUE (entry i of the - possibly
   // material-sorted - queue; distinct for every vertex of a bounce), not by its path id: the 64 lanes of a shade wave then write 64 neighbouring records, the
   // ray queues (which hold these indices) list them in nearly ascending order for the trace kernels and k_resolve, and occ_sh / occ_mi below are indexed the
@@ -78,6 +123,7 @@ struct PassState {
   // frames that count the reference's walk.
   int skip_dead_tail;
   const unsigned* range;  // k_shade: shade entries [range[0], range[1]) of q_in only (NULL = all): class-wise dispatch over the binned queue
+  unsigned oct_log2;      // != 0: the continuing paths are appended in runs of 1 << oct_log2 slots per direction octant (block_push_oct); unfilled slots become dead entries
   unsigned long long* stats;  // device-side u64 counters, see ST_* below
 };
 #define RT_NQ 4  // queues a bounce fills
@@ -191,6 +237,75 @@ RT_DEV void block_push(unsigned* counters, unsigned shard_cap, const int* queue_
   for (int q = 0; q < NQ; ++q) slot[q] = s_base[q] + s_cnt[q][wave] + (unsigned)__popcll(mask[q] & ((1ull << lane) - 1ull));
   __syncthreads();
 }
+
+// ---- Round 6: the continuation queue grouped by DIRECTION OCTANT. An LDS-resident scene's closest-hit walk reads one link row per octant and meets its
+// leaves in one order per octant (BVH::intersect's visiting order is a function of the signs of the direction, rc/bvh/mod.rs:366-433), so a wave whose 64 rays share an
+// octant reads ONE row and walks more alike. Round 3 had sharded the queue by octant and lost (the queue then held path ids, and the next shade launch gathered its records
+// through them); since round 4 the records travel with their slot, so grouping costs the consumers nothing. Here a workgroup keeps one OPEN RUN of `1 << run_log2` slots per
+// octant (allocated from its shard's counter like the 256-entry runs of block_push: the shards, the counters and entry -> slot stay what they were) and appends a path at the
+// next free slot of its ray's octant's run; runs are multiples of 64 slots and the shard counts multiples of the run, so every 64-entry wave of the next bounce's consumers
+// holds one octant. What is left of a workgroup's open runs when its launch ends is filled with DEAD entries (oct_fill_dead): a ray no box test passes (t_max < 0, origin
+// 1e30 away), which the trace kernel reports as prim = -2 and every consumer skips and does not count. <= 8 * run dead entries per workgroup and launch.
+struct OctRuns { unsigned next[8], left[8]; };  // (LDS, workgroup-uniform) next free slot and free slots of each octant's open run
+#define RT_DEAD_PRIM (-2)
+template <int NQ>
+RT_DEV void block_push_oct(unsigned* counters, unsigned shard_cap, const bool* pred /* [NQ], pred[0] = the path continues */, unsigned oct, unsigned run_log2, OctRuns& runs, unsigned* slot) {
+  constexpr int NR = NQ + 7;  // rows 0 - 7: the octants of queue 0; rows 8 ...: queues 1 .. NQ - 1
+  __shared__ unsigned s_cnt[NR][16];
+  __shared__ unsigned s_base[NR], s_split[8], s_base2[8];
+  const unsigned lane = __lane_id(), wave = threadIdx.x >> 6, n_waves = (blockDim.x + 63u) >> 6;
+  const unsigned shard = blockIdx.x & (RT_QSHARDS - 1);
+  unsigned my_rank = 0;  // among the lanes of this wave that append to the same octant
+  unsigned long long mask_q[NQ];
+#pragma unroll
+  for (int r = 0; r < 8; ++r) {
+    const unsigned long long m = __ballot(pred[0] && oct == (unsigned)r);
+    if (lane == 0) s_cnt[r][wave] = (unsigned)__popcll(m);
+    const unsigned rk = __builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0u));
+    my_rank = oct == (unsigned)r ? rk : my_rank;
+  }
+#pragma unroll
+  for (int q = 1; q < NQ; ++q) { mask_q[q] = __ballot(pred[q]); if (lane == 0) s_cnt[7 + q][wave] = (unsigned)__popcll(mask_q[q]); }
+  __syncthreads();
+  if (threadIdx.x < NR) {
+    const unsigned r = threadIdx.x;
+    unsigned total = 0;
+    for (unsigned w = 0; w < n_waves; ++w) { unsigned c = s_cnt[r][w]; s_cnt[r][w] = total; total += c; }
+    if (r >= 8u) s_base[r] = shard * shard_cap + (total ? atomicAdd(&counters[((r - 7u) * RT_QSHARDS + shard) * RT_CNT_STRIDE], total) : 0u);
+    else {
+      const unsigned left = runs.left[r], next = runs.next[r];
+      s_base[r] = next;
+      if (total <= left) { s_split[r] = 0xffffffffu; runs.next[r] = next + total; runs.left[r] = left - total; }
+      else {  // the open run takes `left` of them, new runs (contiguous: one add) the rest
+        const unsigned need = total - left, n_new = (need + (1u << run_log2) - 1u) >> run_log2;
+        const unsigned nb = shard * shard_cap + atomicAdd(&counters[shard * RT_CNT_STRIDE], n_new << run_log2);
+        s_split[r] = left; s_base2[r] = nb; runs.next[r] = nb + need; runs.left[r] = (n_new << run_log2) - need;
+      }
+    }
+  }
+  __syncthreads();
+  {
+    const unsigned o = pred[0] ? oct : 0u;
+    const unsigned k = s_cnt[o][wave] + my_rank, sp = s_split[o];
+    slot[0] = k < sp ? s_base[o] + k : s_base2[o] + (k - sp);
+  }
+#pragma unroll
+  for (int q = 1; q < NQ; ++q) slot[q] = s_base[7 + q] + s_cnt[7 + q][wave] + (unsigned)__popcll(mask_q[q] & ((1ull << lane) - 1ull));
+  __syncthreads();
+}
+// the workgroup's open runs are closed at the end of its launch: their free slots become dead entries. Reached by every thread of the workgroup.
+RT_DEV void oct_fill_dead(const PathGen& out, const OctRuns& runs) {
+  __syncthreads();
+#pragma unroll 1
+  for (int r = 0; r < 8; ++r) {
+    const unsigned n = runs.left[r], b = runs.next[r];
+    for (unsigned k = threadIdx.x; k < n; k += blockDim.x) {
+      out.o[b + k] = make_float4(1e30f, 1e30f, 1e30f, -1.0f); out.d[b + k] = make_float4(1.0f, 1.0f, 1.0f, 0.0f);
+      out.beta[b + k] = make_float4(0.0f, 0.0f, 0.0f, 1.0f); out.st[b + k] = make_uint4(pack_state(1, false, 0, 0), 0u, 0u, 0u);
+    }
+  }
+}
+RT_DEV unsigned dir_octant(f3 d) { return (__float_as_uint(d.x) >> 31) | ((__float_as_uint(d.y) >> 31) << 1) | ((__float_as_uint(d.z) >> 31) << 2); }  // the signs of 1 / d, as the walks take them
 
 // owned-pixel index -> raster pixel (x, y) and keyed pixel index inside the sample bounds
 RT_DEV void owned_pixel(const FrameParams& fp, unsigned long long k, int& x, int& y, unsigned long long& pixel_index) {
@@ -1197,11 +1312,11 @@ RT_DEV bool closest_small_deferred(const float* __restrict__ s_nodes, const floa
 // Where a trace launch reads its rays and writes its results: element [pid * stride] of each pointer (strides in elements of the pointer's
 // type), so that the same kernels serve the records of a frame (RayRec / VertRec / ShadowRec / MisRec) and the planar arrays of the batch entry points.
 struct TraceIO {
-  const float4* ray_o; const float4* ray_d; unsigned ray_stride;  // (o | t_max), (d | flag)
-  float4* hits; unsigned hit_stride; int hit_b2;  // closest hit: (t, prim, b0, b1), or (b2, prim, b0, b1) inside a frame (shade needs the three barycentrics, not t)
+  SPtr<const float4> ray_o; SPtr<const float4> ray_d; unsigned ray_stride;  // (o | t_max), (d | flag)
+  SPtr<float4> hits; unsigned hit_stride; int hit_b2;  // closest hit: (t, prim, b0, b1), or (b2, prim, b0, b1) inside a frame (shade needs the three barycentrics, not t)
   unsigned* occluded; unsigned occ_stride;        // any hit: 1 / 0 (occ_stride 0: one BYTE per ray at ((unsigned char*)occluded)[pid] - the frame's dense result arrays, PassState::occ_sh / occ_mi)
   // any hit inside a frame: a shadow ray with d.w != 0 belongs to a vertex without MIS ray - its `direct_add` goes into lacc right here if unoccluded
-  float4* lacc; unsigned lacc_stride; const float4* direct_add; unsigned add_stride;
+  float4* lacc; unsigned lacc_stride; SPtr<const float4> direct_add; unsigned add_stride;
   // any hit on scenes with masked meshes: 1 = Triangle::intersect_p's test (alpha and shadowalpha, mesh.rs:534-582: shadow rays), 0 = Triangle::intersect's
   // (alpha only, mesh.rs:353-370): a BSDF-sampled MIS ray toward an infinite light is traced by scene.intersect (integrator/mod.rs:291-309) although only
   // its occlusion is read
@@ -1210,7 +1325,7 @@ struct TraceIO {
   // shard counts alone, `queue` is then only a non-NULL marker
   int queue_is_slots;
 };
-RT_DEV void trace_write_any(float4* __restrict__ lacc, size_t ls, const float4* __restrict__ direct_add, size_t as, unsigned* __restrict__ occluded, size_t os,
+RT_DEV void trace_write_any(float4* __restrict__ lacc, size_t ls, const RT_SPTR_R(const float4) direct_add, size_t as, unsigned* __restrict__ occluded, size_t os,
                             unsigned pid, float dw, bool found) {
   // Shadow rays of the frame loop carry d.w = 1 when the vertex has no MIS ray in flight: the light-sampling
   // term of estimate_direct is then complete and `L += beta * (Ld / pick_pdf)` (precomputed by k_shade into
@@ -1256,10 +1371,10 @@ RT_DEV void trace_write_any(float4* __restrict__ lacc, size_t ls, const float4* 
 template <bool ANY, bool COUNT, bool SMALL, int BLOCK, int DEPTH, int GENERAL = 0, int MID = 0>  // GENERAL: quadrics / alpha-masked triangles in the leaves (no object instances)
 __global__ void __launch_bounds__(BLOCK, MID ? 4 : ((SMALL && GENERAL == 0 && !COUNT) ? ((ANY && RT_LDS_THREADED) ? RT_LDS_ANY_WAVES : RT_LDS_TRACE_WAVES) : RT_GEN_MIN_WAVES(GENERAL))) k_trace(DScene sc, TraceIO io, const unsigned* __restrict__ queue, const unsigned* __restrict__ shard_counts, unsigned shard_cap,
                                                  unsigned count_static, unsigned long long* stats, int st_rays, int st_nodes, int st_tris) {
-  const float4* __restrict__ ray_o = io.ray_o; const float4* __restrict__ ray_d = io.ray_d; const size_t rs = io.ray_stride;
-  float4* __restrict__ hits = io.hits; const size_t hs = io.hit_stride; const bool hit_b2 = io.hit_b2 != 0;
+  const RT_SPTR_R(const float4) ray_o = io.ray_o; const RT_SPTR_R(const float4) ray_d = io.ray_d; const size_t rs = io.ray_stride;
+  RT_SPTR_R(float4) hits = io.hits; const size_t hs = io.hit_stride; const bool hit_b2 = io.hit_b2 != 0;
   unsigned* __restrict__ occluded = io.occluded; const size_t os = io.occ_stride;
-  float4* __restrict__ lacc = io.lacc; const size_t ls = io.lacc_stride; const float4* __restrict__ direct_add = io.direct_add; const size_t as = io.add_stride;
+  float4* __restrict__ lacc = io.lacc; const size_t ls = io.lacc_stride; const RT_SPTR_R(const float4) direct_add = io.direct_add; const size_t as = io.add_stride;
   // node indices of a tiny scene fit 16 bits: half the stack bytes => more resident waves per CU
 // (round 4: 16-bit stack entries for the occlusion kernel too - 30 -> 21.5 KB of LDS per workgroup, 5 -> 7 resident: S1 shadow rays 169 -> 154.5 ms)
 #ifndef RT_ANY_STACK16
@@ -1336,9 +1451,11 @@ __global__ void __launch_bounds__(BLOCK, MID ? 4 : ((SMALL && GENERAL == 0 && !C
       if (FIN_FORMS && fin) found = traverse<ANY, COUNT, GlobalSrc, StackT, GENERAL, FIN_FORMS>(src, ray, stack + threadIdx.x, BLOCK, prim, h, n_nodes, n_tris, gen);
       else found = traverse<ANY, COUNT, GlobalSrc, StackT, GENERAL>(src, ray, stack + threadIdx.x, BLOCK, prim, h, n_nodes, n_tris, gen);
     }
-    n_rays += 1;
+    // a dead entry of an octant run (block_push_oct; path rays only): t_max < 0 from 1e30 away - no box test passes; reported as RT_DEAD_PRIM, not counted
+    const bool dead = !ANY && o4.w < 0.0f;
+    n_rays += dead ? 0u : 1u;
     if (ANY) trace_write_any(lacc, ls, direct_add, as, occluded, os, pid, d4.w, found);
-    else hits[pid * hs] = make_float4(hit_b2 ? h.b2 : (found ? h.t : kInf), __int_as_float(found ? prim : -1), h.b0, h.b1);
+    else hits[pid * hs] = make_float4(hit_b2 ? h.b2 : (found ? h.t : kInf), __int_as_float(found ? prim : (dead ? RT_DEAD_PRIM : -1)), h.b0, h.b1);
   };
   for (unsigned i = blockIdx.x * BLOCK + threadIdx.x; i < count; i += stride) trace_one(queue ? qv.get(i) : i);
   if (stats) {
@@ -1365,7 +1482,7 @@ __global__ void __launch_bounds__(BLOCK, MID ? 4 : ((SMALL && GENERAL == 0 && !C
 //    reading of the 28-of-64 lanes: the lanes of a wave do not finish at very different times; they are idle INSIDE a round - the holders of a leaf while the
 //    others step nodes, the walkers while the leaf phase tests triangles, and either side of every branch of the node step (hit / miss, push / pop);
 //  * (kept) the scene planar in LDS (LdsSrc): 336 -> 329 ms; bank conflicts were real (round 3's counters) but not what the kernel waits for.
-struct TraceOut { float4* hits; size_t hs; bool hit_b2; unsigned* occluded; size_t os; float4* lacc; size_t ls; const float4* direct_add; size_t as; };
+struct TraceOut { SPtr<float4> hits; size_t hs; bool hit_b2; unsigned* occluded; size_t os; float4* lacc; size_t ls; SPtr<const float4> direct_add; size_t as; };
 RT_DEV TraceOut trace_out_of(const TraceIO& io) {
   TraceOut o; o.hits = io.hits; o.hs = io.hit_stride; o.hit_b2 = io.hit_b2 != 0; o.occluded = io.occluded; o.os = io.occ_stride;
   o.lacc = io.lacc; o.ls = io.lacc_stride; o.direct_add = io.direct_add; o.as = io.add_stride; return o;
@@ -1389,7 +1506,7 @@ template <bool ANY, int BLOCK>
 __global__ void __launch_bounds__(BLOCK, RT_POOL_WAVES) k_trace_pool(DScene sc, TraceIO io, const unsigned* __restrict__ queue, const unsigned* __restrict__ shard_counts, unsigned shard_cap,
                                                                     unsigned count_static, unsigned long long* stats, int st_rays) {
   constexpr int N = RT_SMALL_NODES, T = RT_SMALL_TRIS, LEAF_MIN = RT_LDS_LEAF_MIN_CLOSEST;
-  const float4* __restrict__ ray_o = io.ray_o; const float4* __restrict__ ray_d = io.ray_d; const size_t rs = io.ray_stride;
+  const RT_SPTR_R(const float4) ray_o = io.ray_o; const RT_SPTR_R(const float4) ray_d = io.ray_d; const size_t rs = io.ray_stride;
   __shared__ float s_nodes[8 * N];
   __shared__ float s_tris[10 * T];
   __shared__ unsigned short s_skip[(ANY ? 1 : 8) * N];
@@ -1607,10 +1724,10 @@ RT_DEV bool general_leaf_prim(const DScene& sc, const float4* __restrict__ tri_p
 template <bool ANY, bool COUNT, int BLOCK, int DEPTH, int GENERAL = 0>
 __global__ void __launch_bounds__(BLOCK) k_trace_big(DScene sc, TraceIO io, const unsigned* __restrict__ queue, const unsigned* __restrict__ shard_counts, unsigned shard_cap,
                                                      unsigned count_static, unsigned long long* stats, int st_rays, int st_nodes, int st_tris) {
-  const float4* __restrict__ ray_o = io.ray_o; const float4* __restrict__ ray_d = io.ray_d; const size_t rs = io.ray_stride;
-  float4* __restrict__ hits = io.hits; const size_t hs = io.hit_stride; const bool hit_b2 = io.hit_b2 != 0;
+  const RT_SPTR_R(const float4) ray_o = io.ray_o; const RT_SPTR_R(const float4) ray_d = io.ray_d; const size_t rs = io.ray_stride;
+  RT_SPTR_R(float4) hits = io.hits; const size_t hs = io.hit_stride; const bool hit_b2 = io.hit_b2 != 0;
   unsigned* __restrict__ occluded = io.occluded; const size_t os = io.occ_stride;
-  float4* __restrict__ lacc = io.lacc; const size_t ls = io.lacc_stride; const float4* __restrict__ direct_add = io.direct_add; const size_t as = io.add_stride;
+  float4* __restrict__ lacc = io.lacc; const size_t ls = io.lacc_stride; const RT_SPTR_R(const float4) direct_add = io.direct_add; const size_t as = io.add_stride;
   __shared__ int stack_mem[DEPTH * BLOCK];
   int* const stack = stack_mem + threadIdx.x;
   QView qv; if (queue) qv.init(io.queue_is_slots ? nullptr : queue, shard_counts, shard_cap);
@@ -1966,7 +2083,7 @@ RT_DEV void pair_leaf_step(PairLane& L, const TraceOut& o, const DScene& sc, con
 template <bool ANY, bool WW, int BLOCK, int DEPTH, int GENERAL = 0>
 __global__ void __launch_bounds__(BLOCK, (GENERAL == RT_GEN_NO_MASKS && !ANY) ? 3 : RT_GEN_MIN_WAVES(GENERAL)) k_trace_pair(DScene sc, TraceIO io, const unsigned* __restrict__ queue, const unsigned* __restrict__ shard_counts, unsigned shard_cap,
                                                       unsigned count_static, unsigned long long* stats, int st_rays, float* __restrict__ tmin_stack_mem, unsigned refill_min) {
-  const float4* __restrict__ ray_o = io.ray_o; const float4* __restrict__ ray_d = io.ray_d; const size_t rs = io.ray_stride;
+  const RT_SPTR_R(const float4) ray_o = io.ray_o; const RT_SPTR_R(const float4) ray_d = io.ray_d; const size_t rs = io.ray_stride;
   __shared__ unsigned stack_mem[DEPTH * BLOCK];
   unsigned* const stack = stack_mem + threadIdx.x;
   // the deferred tmin of each stack entry lives in HBM, [depth][lane of the grid]: a push is a fire-and-forget
@@ -2045,7 +2162,7 @@ __global__ void __launch_bounds__(BLOCK, (GENERAL == RT_GEN_NO_MASKS && !ANY) ? 
 template <bool ANY, int BLOCK, int DEPTH>
 __global__ void __launch_bounds__(BLOCK, 4) k_trace_inst(DScene sc, TraceIO io, const unsigned* __restrict__ queue, const unsigned* __restrict__ shard_counts, unsigned shard_cap,
                                                          unsigned count_static, unsigned long long* stats, int st_rays, float* __restrict__ tmin_stack_mem, unsigned refill_min) {
-  const float4* __restrict__ ray_o = io.ray_o; const float4* __restrict__ ray_d = io.ray_d; const size_t rs = io.ray_stride;
+  const RT_SPTR_R(const float4) ray_o = io.ray_o; const RT_SPTR_R(const float4) ray_d = io.ray_d; const size_t rs = io.ray_stride;
   __shared__ unsigned stack_mem[DEPTH * BLOCK];
   __shared__ float s_world[13 * BLOCK];  // the world-space ray of a lane that is inside an instance: o, d, 1 / d, the watertight test's shear
   unsigned* const stack = stack_mem + threadIdx.x;
@@ -2267,7 +2384,7 @@ __global__ void __launch_bounds__(BLOCK, GENERAL ? 4 : 6) k_trace_top(DScene sc,
                                                      unsigned refill_min) {
   __shared__ unsigned stack_mem[RT_TOP_LDS_DEPTH * BLOCK];
   __shared__ float4 s_top[4 * RT_TOP_MAX];
-  const float4* __restrict__ ray_o = io.ray_o; const float4* __restrict__ ray_d = io.ray_d; const size_t rs = io.ray_stride;
+  const RT_SPTR_R(const float4) ray_o = io.ray_o; const RT_SPTR_R(const float4) ray_d = io.ray_d; const size_t rs = io.ray_stride;
   QView qv; if (queue) qv.init(io.queue_is_slots ? nullptr : queue, shard_counts, shard_cap);
   const unsigned count = queue ? qv.total() : count_static;
   if ((unsigned long long)blockIdx.x * BLOCK >= count) return;  // (uniform per workgroup: nothing to stage the top of the tree for)
@@ -2473,7 +2590,7 @@ RT_DEV void quad_near_first_step(PairLane& L, const TraceOut& o, const float4* _
 template <bool ANY, int BLOCK, int DEPTH, int GENERAL = 0>
 __global__ void __launch_bounds__(BLOCK, RT_GEN_MIN_WAVES(GENERAL)) k_trace_quad(DScene sc, TraceIO io, const unsigned* __restrict__ queue, const unsigned* __restrict__ shard_counts, unsigned shard_cap,
                                                       unsigned count_static, unsigned long long* stats, int st_rays, float* __restrict__ tmin_stack_mem, unsigned refill_min) {
-  const float4* __restrict__ ray_o = io.ray_o; const float4* __restrict__ ray_d = io.ray_d; const size_t rs = io.ray_stride;
+  const RT_SPTR_R(const float4) ray_o = io.ray_o; const RT_SPTR_R(const float4) ray_d = io.ray_d; const size_t rs = io.ray_stride;
   __shared__ unsigned stack_mem[DEPTH * BLOCK];
   unsigned* const stack = stack_mem + threadIdx.x;
   const size_t grid_lanes = (size_t)gridDim.x * BLOCK;
@@ -2547,8 +2664,9 @@ RT_DEV int hit_primitive(const DInstance* __restrict__ instances, unsigned n_ins
   while (hi - lo > 1u) { const unsigned mid = (lo + hi) >> 1; if (instances[mid].id_base <= (unsigned)hit_id) lo = mid; else hi = mid; }
   return (int)(instances[lo].prim_base + ((unsigned)hit_id - instances[lo].id_base));
 }
-RT_DEV unsigned bin_of(const DScene& sc, const DMaterial* __restrict__ materials, const float4* __restrict__ tri_p /* the shade records */, const float4* __restrict__ hit, unsigned slot, unsigned n_bins) {
-  int prim = __float_as_int(hit[slot].y);
+RT_DEV unsigned bin_of(const DScene& sc, const DMaterial* __restrict__ materials, const float4* __restrict__ tri_p /* the shade records */, const RT_SPTR_R(const float4) hit, unsigned slot, unsigned n_bins) {
+  const float4 h4 = hit[slot];
+  int prim = __float_as_int(h4.y);
   if (prim < 0) return n_bins - 1u;
   prim = hit_primitive(sc.instances, sc.n_instances, sc.n_top_prims, prim);
   // route_quadric_hits: the bin before the miss bin collects the vertices on analytic quadrics, whatever their material - it lies in the generic range, so the
@@ -2985,6 +3103,8 @@ __global__ void __launch_bounds__(256, (MODE == 1 || LEAN || BOUNCED) ? ((LEAN |
     if (LDSREC == 3) sc.images = (const DImage*)s_imgs;
     sc.materials = (const DMaterial*)s_mats; sc.textures = (const DTexture*)s_texs;
   }
+  __shared__ OctRuns s_oct;
+  if (threadIdx.x < 8u) { s_oct.next[threadIdx.x] = 0u; s_oct.left[threadIdx.x] = 0u; }  // (the first barrier of the first append orders this)
   QView qv; if (ps.cnt_in) qv.init(ps.q_in, ps.cnt_in, ps.shard_cap);
   unsigned first = 0, count = ps.cnt_in ? qv.total() : ps.cap;  // no counts: bounce 0 of a pass whose samples are all traced (entry i = slot i = path i)
   if (MODE != 1 && ps.range) { first = ps.range[0]; count = ps.range[1]; }
@@ -3005,6 +3125,7 @@ __global__ void __launch_bounds__(256, (MODE == 1 || LEAN || BOUNCED) ? ((LEAN |
       // the vertex's records: four 16-byte loads at consecutive slots of consecutive lanes, requested together
       const float4 d4 = ps.in.d[rslot], h4 = ps.hit[rslot], b4 = ps.in.beta[rslot]; const uint4 s4 = ps.in.st[rslot];
       pid = s4.y;
+      if (__float_as_int(h4.y) == RT_DEAD_PRIM) n_shaded -= 1u;  // a dead entry of an octant run (block_push_oct): a miss that is nobody's vertex
       unsigned sl, pix; split_path_id(ps, pid, sl, pix); const unsigned s = ps.s0 + sl;
       f3 ray_d = mk3(d4.x, d4.y, d4.z);
       beta = mkc(b4.x, b4.y, b4.z); eta_scale = b4.w;
@@ -3191,7 +3312,8 @@ __global__ void __launch_bounds__(256, (MODE == 1 || LEAN || BOUNCED) ? ((LEAN |
     n_tail += (unsigned)__popcll(__ballot(tail));
     constexpr int NQ = (MODE == 1 || LEAN) ? 3 : 4;  // area lights only: every MIS ray needs its closest hit
     const int ci[4] = {0, 1, 2, 3}; const bool pr[4] = {cont, want_shadow, want_mis && !mis_occlusion_only, want_mis && mis_occlusion_only}; unsigned slot[4];
-    block_push<NQ>(ps.cnt_out, ps.shard_cap, ci, pr, slot);
+    if (ps.oct_log2) block_push_oct<NQ>(ps.cnt_out, ps.shard_cap, pr, dir_octant(nr_d), ps.oct_log2, s_oct, slot);
+    else block_push<NQ>(ps.cnt_out, ps.shard_cap, ci, pr, slot);
     if (cont) {  // the path's records for the next bounce, at its slot of that bounce's queue: a wave's stores are runs of consecutive slots
       ps.out.o[slot[0]] = make_float4(nr_o.x, nr_o.y, nr_o.z, kInf);
       ps.out.d[slot[0]] = make_float4(nr_d.x, nr_d.y, nr_d.z, 0.0f);
@@ -3224,7 +3346,9 @@ __global__ void __launch_bounds__(256, (MODE == 1 || LEAN || BOUNCED) ? ((LEAN |
       const bool lane_live = i < count;
       n_shaded += lane_live ? 1u : 0u;
       const unsigned rslot = lane_live ? (ps.cnt_in ? qv.get(i) : i) : 0u;
-      const bool hit = lane_live && __float_as_int(ps.hit[rslot].y) >= 0;
+      int hprim = -1; if (lane_live) { const float4 hh = ps.hit[rslot]; hprim = __float_as_int(hh.y); }
+      const bool hit = hprim >= 0;
+      if (hprim == RT_DEAD_PRIM) n_shaded -= 1u;
       const unsigned long long m = __ballot(hit);
       if (lane == 0u) s_wave_hits[wv] = (unsigned)__popcll(m);
       __syncthreads();
@@ -3246,6 +3370,7 @@ __global__ void __launch_bounds__(256, (MODE == 1 || LEAN || BOUNCED) ? ((LEAN |
       shade_vertex(lv, lv ? s_ring_i[pos] : 0u, lv ? s_ring_slot[pos] : 0u);
     }
   }
+  if (ps.oct_log2) oct_fill_dead(ps.out, s_oct);
   if (GENERAL || QLIGHTS) {
     for (int off = 32; off > 0; off >>= 1) n_unreached += __shfl_down(n_unreached, off);
     if ((threadIdx.x & 63u) == 0u && n_unreached) atomicAdd(&ps.stats[ST_MIS_UNREACHED], (unsigned long long)n_unreached);
@@ -3329,7 +3454,7 @@ __global__ void __launch_bounds__(256) k_resolve(DScene sc, PassState ps) {
     }
     rgb3 add = mkc(c.x, c.y, c.z) * vdiv(ld, a.w);
     if (add.r == 0.0f && add.g == 0.0f && add.b == 0.0f) continue;  // both rays blocked (most vertices of an interior): L + 0 = L, the scattered read-modify-write is skipped (a NaN is not 0)
-    const unsigned pid = __float_as_uint(ps.mi.d[rec].w);  // the path the vertex belongs to
+    const float4 md4 = ps.mi.d[rec]; const unsigned pid = __float_as_uint(md4.w);  // the path the vertex belongs to
     float4 l4 = ps.lacc[pid];
     ps.lacc[pid] = make_float4(l4.x + add.r, l4.y + add.g, l4.z + add.b, l4.w);
   }
