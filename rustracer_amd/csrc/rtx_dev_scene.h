@@ -542,56 +542,5 @@ RT_DEV bool leaf_phase_now(bool active, bool at_leaf, unsigned leaf_min) {  // c
 #ifndef RT_LDS_LEAF_MIN_ANY
 #define RT_LDS_LEAF_MIN_ANY 1
 #endif
-template <bool ANY, bool COUNT, int LEAF_MIN, class Src, class StackT, int GENERAL = 0, bool FINITE = false>
-RT_DEV bool traverse_rounds(const Src& src, Ray ray, StackT* stack, int stack_stride, int& prim_out, TriHit& hit_out, unsigned& n_nodes, unsigned& n_tris, GeneralCtx gen = GeneralCtx{nullptr, false}) {
-  bool found = false, done = false;
-  int sp = 0, cur = 0, leaf_off = 0, leaf_n = 0;
-  f3 inv_dir = mk3(1.0f / ray.d.x, 1.0f / ray.d.y, 1.0f / ray.d.z);
-  const int neg_x = inv_dir.x < 0.0f, neg_y = inv_dir.y < 0.0f, neg_z = inv_dir.z < 0.0f;
-  const RayPre rp = ray_pre(ray);
-  for (;;) {
-    unsigned long long holders, walkers;
-    for (;;) {
-      if (!done && leaf_n == 0) {
-        float4 n0, n1;
-        src.node(cur, n0, n1);
-        if (COUNT) n_nodes += 1;
-        if (slab_test_t<FINITE>(n0, n1, ray, inv_dir, neg_x, neg_y, neg_z)) {
-          const unsigned packed = __float_as_uint(n1.w);
-          const int n_prims = (int)(packed & 0xffffu);
-          const int offset = __float_as_int(n1.z);
-          if (n_prims > 0) { leaf_off = offset; leaf_n = n_prims; }
-          else {
-            const int axis = (int)((packed >> 16) & 0xffu);
-            const int neg = axis == 0 ? neg_x : (axis == 1 ? neg_y : neg_z);
-            if (neg) { stack[(sp++) * stack_stride] = (StackT)(cur + 1); cur = offset; }
-            else { stack[(sp++) * stack_stride] = (StackT)offset; cur = cur + 1; }
-          }
-        } else {
-          if (sp == 0) done = true;
-          else cur = (int)stack[(--sp) * stack_stride];
-        }
-      }
-      holders = __ballot(!done && leaf_n > 0); walkers = __ballot(!done && leaf_n == 0);
-      if (walkers == 0ull || __popcll(holders) >= LEAF_MIN) break;
-    }
-    if ((holders | walkers) == 0ull) break;
-    if (!done && leaf_n > 0) {
-      for (int i = 0; i < leaf_n; ++i) {
-        if (COUNT) n_tris += 1;
-        TriHit h;
-        if (leaf_prim_test<GENERAL>(src, gen, leaf_off + i, ray, rp, h)) {
-          found = true;
-          if (ANY) break;
-          ray.t_max = h.t; prim_out = leaf_off + i; hit_out = h;  // `.or(result)`: later accepted hits replace
-        }
-      }
-      leaf_n = 0;
-      if ((ANY && found) || sp == 0) done = true;
-      else cur = (int)stack[(--sp) * stack_stride];
-    }
-  }
-  return found;
-}
 
 }  // namespace rtx

@@ -9,7 +9,7 @@
 namespace rtx {
 
 // ---------------------------------------------------------------- MIPMap lookups (rc/mipmap.rs)
-__device__ __constant__ float kEwaLut[128];  // filled by the host at start-up: exp(-2 r2) - exp(-2) (:33-44)
+static __device__ __constant__ float kEwaLut[128];  // filled by the host at start-up: exp(-2 r2) - exp(-2) (:33-44). One copy per translation unit (rtx_hip.hip, rtx_shade.hip): rtx_fill_ewa_lut_here() in each
 
 // MIPMap::texel (:208-225). Level sizes are powers of two (MIPMap::new resamples, :75-139; checked at rt_scene_create), so the Repeat wrap
 // `modulo(s, size)` (:428-435) is the low bits of s - for negative s too, in two's complement - instead of a 64-bit signed division per texel.
@@ -99,7 +99,7 @@ RT_DEV rgb3 mip_lookup_diff(const DImage& im, f2 st, f2 dst0, f2 dst1) {  // :24
 // ---------------------------------------------------------------- textures (rc/texture/*.rs)
 // Scale/Mix operands are resolved iteratively with a tiny explicit stack (no device recursion).
 // ---- Perlin noise (rc/noise.rs)
-__device__ __constant__ const unsigned char kNoisePerm[512] = {
+static __device__ __constant__ const unsigned char kNoisePerm[512] = {
     151, 160, 137, 91, 90, 15, 131, 13, 201, 95, 96, 53, 194, 233, 7, 225, 140, 36, 103, 30, 69, 142, 8, 99, 37, 240, 21, 10, 23, 190, 6, 148,
     247, 120, 234, 75, 0, 26, 197, 62, 94, 252, 219, 203, 117, 35, 11, 32, 57, 177, 33, 88, 237, 149, 56, 87, 174, 20, 125, 136, 171, 168, 68, 175,
     74, 165, 71, 134, 139, 48, 27, 166, 77, 146, 158, 231, 83, 111, 229, 122, 60, 211, 133, 230, 220, 105, 92, 41, 55, 46, 245, 40, 244, 102, 143, 54,

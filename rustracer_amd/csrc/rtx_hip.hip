@@ -18,16 +18,20 @@
 
 #include "../../include/rtx_hip.h"
 #include "rtx_kernels.h"
+#include "rtx_shade_launch.h"
 #include "rtx_link_tables.h"
 
 using namespace rtx;
 
 static thread_local std::string g_err;
 static int fail(int code, const std::string& msg) { g_err = msg; return code; }
+// The measurement knobs that remain are the A/B controls of features that are in the product (and two test hooks): read through these two.
+static bool env_is(const char* name, char c) { const char* e = getenv(name); return e && e[0] == c; }
+static int env_int(const char* name, int dflt) { const char* e = getenv(name); return e ? atoi(e) : dflt; }
 // Guide tables (environment-map rows, light-distribution rows) bracket a CDF search: bucket k of 2^glog holds the entries whose cdf lies in [k, k+1) / 2^glog.
 // Density in quarters of an entry per bucket on average: 4 = as many buckets as entries (the search that follows is 0-2 dependent loads instead of the 4-5 of
-// round 2's 16 entries per bucket; a 2048 x 1024 map's tables grow from 0.3 to 4 MB). Measurement knob RTX_GUIDE_QUARTERS (64 = round 2).
-static long guide_quarters() { static const long q = getenv("RTX_GUIDE_QUARTERS") ? std::min(4096, std::max(1, atoi(getenv("RTX_GUIDE_QUARTERS")))) : 4; return q; }
+// round 2's 16 entries per bucket; a 2048 x 1024 map's tables grow from 0.3 to 4 MB).
+static long guide_quarters() { return 4; }
 #define HIP_TRY(expr)                                                                                        \
   do {                                                                                                       \
     hipError_t e_ = (expr);                                                                                  \
@@ -73,8 +77,7 @@ struct rt_scene {
   bool top_for_closest = false;  // closest-hit rays through k_trace_top as well (shadow rays always, when no four-wide records exist)
   bool use_pairs = false;
   bool deep_column = false;  // top level + deepest object need more than 64 stack entries in one column: k_trace_big with 128
-  DevBuf skip8;  // DScene::skip8 (LDS-resident scenes)
-  DevBuf quads; bool use_quads = false, use_quads_closest = false; int quad_stack_depth = 0;  // four-wide records of the any-hit kernel (k_trace_quad)
+  DevBuf quads; bool use_quads = false; int quad_stack_depth = 0;  // four-wide records of the any-hit kernel (k_trace_quad)
   DevBuf tri_rec;  // per-triangle shade records (k_tri_records)
   DevBuf nodes, tri_p, tri_n, tri_uv, tri_s, tri_alpha, spheres, textures, images, materials, lights, texels, dist, guides;
   bool has_spheres = false;
@@ -139,6 +142,7 @@ static void fill_ewa_lut() {
     lut[i] = expf(-alpha * r2) - expf(-alpha);
   }
   (void)hipMemcpyToSymbol(HIP_SYMBOL(kEwaLut), lut, sizeof(lut));
+  rtx_shade_set_ewa_lut(lut);  // the shade kernels' translation unit has a copy of its own
 }
 
 static size_t tmin_stack_bytes(const rt_scene* s);
@@ -512,7 +516,7 @@ extern "C" int rt_scene_create(const rt_scene_desc* desc, int device, rt_scene**
   d.ld_uniform = 1; d.nvox[0] = d.nvox[1] = d.nvox[2] = 1; d.ld_glog = -1; d.ld_guide = nullptr;
   d.needs_differentials = 0;
 #ifdef RT_ABLATE
-  d.dbg = getenv("RTX_DBG") ? atoi(getenv("RTX_DBG")) : 0;
+  d.dbg = env_int("RTX_DBG", 0);
 #endif
   for (uint32_t i = 0; i < desc->n_textures; ++i) {
     const rt_texture& t = desc->textures[i];
@@ -551,13 +555,11 @@ extern "C" int rt_scene_create(const rt_scene_desc* desc, int device, rt_scene**
     bool ok = true;
     for (uint32_t i = 0; i < desc->n_lights; ++i) if (desc->lights[i].kind != RT_LIGHT_DIFFUSE_AREA) ok = false;
     for (uint32_t i = 0; i < desc->n_textures; ++i) if (desc->textures[i].kind != RT_TEX_CONST) ok = false;
-    static const bool off = getenv("RTX_SHADE_QLIGHTS") && getenv("RTX_SHADE_QLIGHTS")[0] == '0';  // measurement knob: the GENERAL forms as in round 3
-    s->lean_qlights = ok && !off && sphere_lights_clear(desc);
+    s->lean_qlights = ok && sphere_lights_clear(desc);
   }
   if (s->masked_emitters) s->lambert_only = false;  // (the constant-matte kernel has no GENERAL form: such scenes shade through the Lambert front-end k_shade<3, true>)
   s->n_materials = desc->n_materials;
   s->small = desc->n_nodes <= RT_SMALL_NODES && desc->n_tris <= RT_SMALL_TRIS && !s->has_instances;  // quadrics and masked triangles: the GENERAL form of the LDS kernel
-  if (getenv("RTX_SMALL") && getenv("RTX_SMALL")[0] == '0') s->small = false;  // measurement knob: an LDS-sized scene through the kernels of the large ones
   int max_obj_depth = 0;
   {  // tree height bounds the number of simultaneously pending stack entries
     // one tree: nodes [base, base + nn), child offsets relative to base, leaf ranges within its np primitives
@@ -590,28 +592,27 @@ extern "C" int rt_scene_create(const rt_scene_desc* desc, int device, rt_scene**
     s->stack_depth += max_obj; max_obj_depth = max_obj;
     s->deep_column = s->stack_depth > 64;
   }
-  d.pairs = nullptr; d.quads = nullptr; d.obj_pairs = 0; d.skip8 = nullptr; d.link8 = nullptr; d.link8_full = nullptr;
+  d.pairs = nullptr; d.quads = nullptr; d.obj_pairs = 0; d.link8 = nullptr; d.link8_full = nullptr;
   // mid-size scenes (round 5): too large for the 256-node LDS kernels, small enough for one workgroup's 160 KB - occlusion rays walk link tables in LDS (k_trace<.., MID>)
-  s->mid = !s->small && !s->general_prims && !s->has_instances && desc->n_nodes <= RT_MID_NODES && desc->n_tris <= RT_MID_TRIS && !(getenv("RTX_MID") && getenv("RTX_MID")[0] == '0');
+  s->mid = !s->small && !s->general_prims && !s->has_instances && desc->n_nodes <= RT_MID_NODES && desc->n_tris <= RT_MID_TRIS;
   for (uint32_t i = 0; i < desc->n_nodes && s->mid; ++i) if (desc->nodes[i].n_prims > 15) s->mid = false;  // (the link word's count field)
   if (s->mid) {  // the kernels declare 157.7 KB of LDS: were a device (or a driver's reservation) to leave a workgroup less, they could not launch - the HBM kernels then
     int fit_any = 0, fit_closest = 0;
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&fit_any, (const void*)(k_trace<true, false, true, 1024, 16, 0, 1>), 1024, 0) != hipSuccess) fit_any = 0;
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&fit_closest, (const void*)(k_trace<false, false, true, 1024, 16, 0, 1>), 1024, 0) != hipSuccess) fit_closest = 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&fit_any, (const void*)(k_trace<true, false, 1024, 16, 0, 1>), 1024, 0) != hipSuccess) fit_any = 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&fit_closest, (const void*)(k_trace<false, false, 1024, 16, 0, 1>), 1024, 0) != hipSuccess) fit_closest = 0;
     (void)hipGetLastError();
     if (fit_any < 1 || fit_closest < 1) s->mid = false;
   }
   if (s->small || s->mid) {
-    // skip table (round 4's walks) and link tables (round 5: per octant and node where the stackless walk goes on, over all nodes and over the nodes a calibration on
+    // link tables (round 5: per octant and node where the stackless walk goes on, over all nodes and over the nodes a calibration on
     // synthetic path rays found worth testing): rtx_link_tables.h
     RtLinkTables lt;
     rt_build_link_tables(desc, s->mid, false, lt);
     s->lds_nodes_tested = lt.nodes_tested;
-    int rcl = upload(s->skip8, lt.skip8.data(), lt.skip8.size() * sizeof(uint16_t));
-    if (rcl == RT_OK) rcl = upload(s->link8_full, lt.link_full.data(), lt.link_full.size() * 4);
+    int rcl = upload(s->link8_full, lt.link_full.data(), lt.link_full.size() * 4);
     if (rcl == RT_OK) rcl = upload(s->link8, lt.link_kept.data(), lt.link_kept.size() * 4);
     if (rcl != RT_OK) { delete s; return rcl; }
-    d.skip8 = s->skip8.as<unsigned short>(); d.link8_full = s->link8_full.as<unsigned>(); d.link8 = s->link8.as<unsigned>();
+    d.link8_full = s->link8_full.as<unsigned>(); d.link8 = s->link8.as<unsigned>();
   }
   if (!s->small && !s->deep_column) {  // LDS-resident scenes keep the one-node-per-step loop: the pair form measured no faster there
     // With object instances the records cover the top-level tree (objects are walked one node per step, their child offsets are relative to the object).
@@ -673,7 +674,6 @@ extern "C" int rt_scene_create(const rt_scene_desc* desc, int device, rt_scene**
       if (rc2 != RT_OK) { delete s; return rc2; }
       d.pairs = s->pairs.as<float4>(); s->use_pairs = true;
       d.obj_pairs = obj_ok ? 1 : 0;
-      if (getenv("RTX_OBJ_PAIRS") && getenv("RTX_OBJ_PAIRS")[0] == '0') d.obj_pairs = 0;  // measurement knob: objects walked one node per step
     }
     d.top_pairs = nullptr; d.n_top = 0;
     if (ok && n_pair_nodes < (1u << 28) && desc->nodes[0].n_prims == 0 && !s->has_instances) {  // (an object's walk needs a contiguous stack column: k_trace_pair)
@@ -702,7 +702,6 @@ extern "C" int rt_scene_create(const rt_scene_desc* desc, int device, rt_scene**
       // gains is its sixth wave per SIMD, and that pays where the tree fits the 32 MB of L2 without fitting an L1.
       const size_t pair_bytes = (size_t)n_pair_nodes * 64;
       s->top_for_closest = pair_bytes <= ((size_t)64 << 20);  // measured with the gated leaf phase: S3 (0.1 MB) 81 -> 78 ms, S4 (13 MB) 1743 -> 1659 ms, S2 (67 MB) 94 -> 102 ms
-      if (getenv("RTX_TOP_CLOSEST")) s->top_for_closest = getenv("RTX_TOP_CLOSEST")[0] == '1';  // measurement knob
     }
     // four-wide records for the any-hit kernel (k_trace_quad): an interior node's grandchildren (a leaf child stands for itself), 128 B
     // per node: 24 floats = boxes of slots 0..3 (slots 0,1: first child's part, 2,3: second child's), 4 codes (0xffffffff = empty slot),
@@ -734,17 +733,11 @@ extern "C" int rt_scene_create(const rt_scene_desc* desc, int device, rt_scene**
         need[i] = deepest + n_entries - 1;
       }
       s->quad_stack_depth = need[0] + 1 + max_obj_depth;  // (+ the deepest object's walk above the pending entries)
-      // closest-hit rays through the same records (quad_near_first_step pushes at most one entry per level: the binary walk's stack need). Plain scenes only.
-      // MEASURED (round 5, one box, interleaved with the two-wide kernels): S2 closest hit 91.0 -> 95.9 ms (k_trace_pair), S4 1371 -> 1554 ms (k_trace_top), S3 71.2 = 71.2;
-      // hit records bit-equal (tests). OFF: RTX_QUAD_CLOSEST=1 turns it on. A pair record shares its 128-byte line with the record of its first child (pre-order:
-      // node i + 1), so half of the two-wide walk's steps are served by the line the step before fetched - the four-wide record has no such neighbour and spends half of
-      // its line on the far side, which a closest-hit ray mostly discards.
-      static const char* qc_env = getenv("RTX_QUAD_CLOSEST");
-      s->use_quads_closest = ok && !s->general_prims && qc_env && qc_env[0] == '1';
-      if (ok && (s->quad_stack_depth <= 32 || s->use_quads_closest)) {  // (any hit: beyond the 32-entry LDS stack the larger stack costs more residency than the wider step returns)
+      // (closest-hit rays through the same records - near side first, exact - were built in round 5 and measured slower: S2 91.0 -> 95.9 ms, S4 1371 -> 1554; MEASUREMENTS R5)
+      if (ok && s->quad_stack_depth <= 32) {  // (any hit: beyond the 32-entry LDS stack the larger stack costs more residency than the wider step returns)
         int rc2 = upload(s->quads, qr.data(), qr.size() * 4);
         if (rc2 != RT_OK) { delete s; return rc2; }
-        d.quads = s->quads.as<float4>(); s->use_quads = s->quad_stack_depth <= 32;
+        d.quads = s->quads.as<float4>(); s->use_quads = true;
       }
     }
   }
@@ -760,10 +753,10 @@ extern "C" int rt_scene_create(const rt_scene_desc* desc, int device, rt_scene**
   d.tri_rec = s->tri_rec.as<float4>();
   hipLaunchKernelGGL(k_tri_records, dim3((desc->n_tris + 255u) / 256u), dim3(256), 0, nullptr, d, s->tri_rec.as<float4>());
   d.n_lights_all = (int)n_all_lights;
-  s->lds_records = s->small && !s->has_instances && !s->has_spheres && desc->n_tris <= RT_SMALL_TRIS && n_all_lights <= RT_LDS_LIGHTS && desc->n_materials <= RT_LDS_MATERIALS && desc->n_textures <= RT_LDS_TEXTURES && !(getenv("RTX_SHADE_LDSREC") && getenv("RTX_SHADE_LDSREC")[0] == '0');  // k_shade<1, .., LDSREC> (RTX_SHADE_LDSREC=0: measurement knob)
-  s->lds_records_q = desc->n_tris <= RT_SMALL_TRIS && !s->has_instances && n_all_lights <= RT_LDS_LIGHTS && desc->n_materials <= RT_LDS_MATERIALS && desc->n_textures <= RT_LDS_TEXTURES && !(getenv("RTX_SHADE_LDSREC") && getenv("RTX_SHADE_LDSREC")[0] == '0');
-  s->lds_tables = n_all_lights <= RT_LDS_LIGHTS && desc->n_materials <= RT_LDS_MATERIALS && desc->n_textures <= RT_LDS_TEXTURES && desc->n_images <= RT_LDS_IMAGES && !(getenv("RTX_SHADE_LDSREC") && getenv("RTX_SHADE_LDSREC")[0] == '0');
-  s->lds_mats = desc->n_materials <= RT_LDS_MATERIALS && desc->n_textures <= RT_LDS_TEXTURES && !(getenv("RTX_SHADE_LDSREC") && getenv("RTX_SHADE_LDSREC")[0] == '0');  // the LEAN forms: material and texture tables in LDS
+  s->lds_records = s->small && !s->has_instances && !s->has_spheres && desc->n_tris <= RT_SMALL_TRIS && n_all_lights <= RT_LDS_LIGHTS && desc->n_materials <= RT_LDS_MATERIALS && desc->n_textures <= RT_LDS_TEXTURES && !(env_is("RTX_SHADE_LDSREC", '0'));  // k_shade<1, .., LDSREC> (RTX_SHADE_LDSREC=0: measurement knob)
+  s->lds_records_q = desc->n_tris <= RT_SMALL_TRIS && !s->has_instances && n_all_lights <= RT_LDS_LIGHTS && desc->n_materials <= RT_LDS_MATERIALS && desc->n_textures <= RT_LDS_TEXTURES && !(env_is("RTX_SHADE_LDSREC", '0'));
+  s->lds_tables = n_all_lights <= RT_LDS_LIGHTS && desc->n_materials <= RT_LDS_MATERIALS && desc->n_textures <= RT_LDS_TEXTURES && desc->n_images <= RT_LDS_IMAGES && !(env_is("RTX_SHADE_LDSREC", '0'));
+  s->lds_mats = desc->n_materials <= RT_LDS_MATERIALS && desc->n_textures <= RT_LDS_TEXTURES && !(env_is("RTX_SHADE_LDSREC", '0'));  // the LEAN forms: material and texture tables in LDS
   if (n_all_lights) hipLaunchKernelGGL(k_light_consts, dim3((n_all_lights + 255u) / 256u), dim3(256), 0, nullptr, d, s->lights.as<DLight>(), (int)n_all_lights);
   if (hipGetLastError() != hipSuccess) { delete s; return fail(RT_ERR_HIP, "constant precomputation launch failed"); }
   if (s->self.ensure(sizeof(DScene)) != hipSuccess) { delete s; return fail(RT_ERR_OOM, "scene record allocation failed"); }
@@ -812,7 +805,12 @@ extern "C" int rt_link_tables(const rt_scene_desc* desc, int32_t mid, uint32_t* 
     std::vector<uint32_t> size(nn, 1u);
     for (uint32_t i = nn; i-- > 0;) {
       const rt_bvh_node& n = desc->nodes[i];
-      if (n.n_prims != 0) { if ((uint64_t)n.offset + n.n_prims > desc->n_tris) return fail(RT_ERR_INVALID, "leaf range out of bounds"); continue; }
+      if (n.n_prims != 0) {
+        if ((uint64_t)n.offset + n.n_prims > desc->n_tris) return fail(RT_ERR_INVALID, "leaf range out of bounds");
+        // a leaf's link word holds its primitive count above the first primitive's bits (RT_LINK_LEAF_N): 4 bits in a mid-size scene's word, 8 otherwise
+        if (n.n_prims >= (1u << (15 - RT_LINK_OFF_BITS(mid ? RT_MID_NODES : RT_SMALL_NODES)))) return fail(RT_ERR_INVALID, "a leaf holds more primitives than a link word can name");
+        continue;
+      }
       if (i + 1 >= nn || n.offset != i + 1 + size[i + 1] || n.offset >= nn) return fail(RT_ERR_INVALID, "nodes are not a pre-order tree");
       size[i] = 1u + size[i + 1] + size[n.offset];
     }
@@ -911,14 +909,14 @@ static int build_light_distribution(rt_scene* s, int strategy, hipStream_t strea
   d.ld_func = s->ld_func.as<float>(); d.ld_cdf = s->ld_cdf.as<float>(); d.ld_int = s->ld_int.as<float>(); d.ld_slot = s->ld_slot.as<int>();
   d.ld_guide = glog >= 0 ? s->ld_guide.as<unsigned short>() : nullptr;
   d.ld_rows8 = nullptr; d.ld_dense8 = nullptr;
-  if (nl >= 1 && nl <= 3 && !(getenv("RTX_LD_ROWS8") && getenv("RTX_LD_ROWS8")[0] == '0')) {  // (measurement knob: 0 = the three separate tables)
+  if (nl >= 1 && nl <= 3 && !(env_is("RTX_LD_ROWS8", '0'))) {  // (measurement knob: 0 = the three separate tables)
     const size_t n_rows = ld_rows_built;
     HIP_TRY(s->ld_rows8.ensure(n_rows * 32));
     hipLaunchKernelGGL(k_lightdist_rows8, dim3((unsigned)((n_rows + 255) / 256)), dim3(256), 0, stream, s->ld_func.as<float>(), s->ld_cdf.as<float>(), s->ld_int.as<float>(), (int)nl, (unsigned)n_rows, s->ld_rows8.as<float4>());
     HIP_TRY(hipGetLastError());
     d.ld_rows8 = s->ld_rows8.as<float4>();
     const unsigned long long n_vox = (unsigned long long)d.nvox[0] * d.nvox[1] * d.nvox[2];
-    const int dense_mb = getenv("RTX_LD_DENSE_MB") ? atoi(getenv("RTX_LD_DENSE_MB")) : 16;  // (measurement knob, read per build: 0 = never)
+    const int dense_mb = env_int("RTX_LD_DENSE_MB", 16);  // (measurement knob, read per build: 0 = never)
     if (!uniform && n_vox * 32ull <= (unsigned long long)dense_mb << 20) {
       HIP_TRY(s->ld_dense8.ensure((size_t)n_vox * 32));
       hipLaunchKernelGGL(k_lightdist_dense8, dim3((unsigned)((n_vox + 255) / 256)), dim3(256), 0, stream, s->ld_rows8.as<float4>(), s->ld_slot.as<int>(), n_vox, s->ld_dense8.as<float4>());
@@ -946,22 +944,13 @@ extern "C" int rt_light_distribution(rt_scene* s, int32_t n_voxels[3], float* fu
   return RT_OK;
 }
 
-// k_trace_pool (round 5), MEASURED on S1 (one box, same run): closest hit 238.6 -> 351 ms, occlusion rays 118.1 -> 219 ms. OFF (RTX_LDS_POOL=3 turns it on). The finished
-// lanes do get new rays at a dozen LDS reads each - and the kernel still loses a third: its 13 KB of pools leave five waves per SIMD instead of seven / eight, and
-// the refill bookkeeping (three more ballots and their scalar chain) sits in every round. Together with the deferred walks (closest_small_deferred, occluded_small_deferred:
-// more lanes per instruction, same or more time) this says what these kernels wait for: not VALU issue slots - a wave's round is a chain of dependent steps (LDS read ->
-// box test -> select -> ballot -> branch) and the SIMD is busy 62 % of the time with seven such chains interleaved; anything that lengthens the chain or removes a wave costs
-// more than the lanes it fills return.
-#ifndef RT_LDS_POOL_DEFAULT
-#define RT_LDS_POOL_DEFAULT 0
-#endif
 // ---------------------------------------------------------------------------------------------- trace launches
 // LDS a workgroup of the trace kernels declares, and the persistent grid that fills every CU at that residency
 template <bool ANY, bool SMALL, int BLOCK, int DEPTH>
-static unsigned trace_grid(const rt_scene* s, bool threaded = false) {  // threaded: the plain-triangle kernels of an LDS-resident scene (closest_small / occluded_small: skip links instead of a stack)
-  unsigned lds = (unsigned)(DEPTH * BLOCK * ((SMALL && (!ANY || RT_ANY_STACK16)) ? 2 : 4) + (SMALL ? (8 * RT_SMALL_NODES + 10 * RT_SMALL_TRIS) * 4 : 32));
+static unsigned trace_grid(const rt_scene* s, bool links = false) {  // links: an LDS-resident scene's rays that count no visits (link rows instead of a stack, k_trace)
+  unsigned lds = (unsigned)(DEPTH * BLOCK * (SMALL ? 2 : 4) + (SMALL ? (8 * RT_SMALL_NODES + 10 * RT_SMALL_TRIS) * 4 : 32));
   unsigned waves = 8;
-  if (SMALL && threaded) { lds = (unsigned)((8 * RT_SMALL_NODES + 10 * RT_SMALL_TRIS) * 4 + (ANY ? 1 : 8) * RT_SMALL_NODES * (RT_LDS_LINKS ? 4 : 2) + 32); waves = ANY ? RT_LDS_ANY_WAVES : RT_LDS_TRACE_WAVES; }
+  if (SMALL && links) { lds = (unsigned)((8 * RT_SMALL_NODES + 10 * RT_SMALL_TRIS) * 4 + (ANY ? 1 : 8) * RT_SMALL_NODES * 4 + 32); waves = ANY ? RT_LDS_ANY_WAVES : RT_LDS_TRACE_WAVES; }
   unsigned per_cu = (160u * 1024u) / lds; if (per_cu * BLOCK > waves * 256u) per_cu = waves * 256u / BLOCK; if (per_cu < 1) per_cu = 1;
   return (unsigned)s->n_cu * per_cu;
 }
@@ -969,13 +958,9 @@ static unsigned trace_grid(const rt_scene* s, bool threaded = false) {  // threa
 // launch variant uses (rt_scene_create), so that no launch can fail on an allocation and leave stale hit records behind.
 #define RT_TOP_BLOCK 512
 static unsigned top_grid(const rt_scene* s, bool any = false) {
-  static const int env_top = getenv("RTX_TOP_BLOCKS_PER_CU") ? atoi(getenv("RTX_TOP_BLOCKS_PER_CU")) : 0;  // measurement knobs
-  static const int env_any = getenv("RTX_TOP_BLOCKS_ANY") ? atoi(getenv("RTX_TOP_BLOCKS_ANY")) : 0;
+  (void)any;
   const unsigned fit = (160u * 1024u) / (16384u + (unsigned)RT_TOP_LDS_DEPTH * RT_TOP_BLOCK * 4u);
-  unsigned n = 3u;
-  if (env_top > 0) n = (unsigned)env_top;
-  if (any && env_any > 0) n = (unsigned)env_any;
-  return (unsigned)s->n_cu * std::max(1u, std::min(n, fit));
+  return (unsigned)s->n_cu * std::max(1u, std::min(3u, fit));
 }  // 48 KB of LDS per workgroup: three per CU, six waves per SIMD
 static size_t tmin_stack_bytes(const rt_scene* s) {
   if (s->small || !s->use_pairs) return 0;
@@ -988,16 +973,12 @@ static size_t deep_stack_bytes(const rt_scene* s) {
   return (size_t)std::max(top_grid(s), top_grid(s, true)) * RT_TOP_BLOCK * (size_t)std::max(1, s->stack_depth - RT_TOP_LDS_DEPTH) * 4;
 }
 // the two knobs of the persistent traversal loops in one launch argument: lanes that must be idle before a wave refills (bits 0-7) and lanes that must wait at
-// a leaf before the leaf phase runs (bits 8-15; RT_LEAF_MIN, see leaf_phase_now; measurement knobs RTX_LEAF_MIN / RTX_LEAF_MIN_ANY). On an instanced scene a
+// a leaf before the leaf phase runs (bits 8-15; RT_LEAF_MIN, see leaf_phase_now). On an instanced scene a
 // leaf is a whole nested walk and gating pays even more (10 000 placements, closest hit: 310 / 227 / 166 / 140 / 125 / 122 ms at 1 / 8 / 20 / 32 / 48 / 64).
-// does the scene trace through k_trace_inst (object instances over plain triangles, objects with pair records; RTX_INST_LOOP=0: the nested walks)?
-static int inst_loop_bits() { static const int v = getenv("RTX_INST_LOOP") ? atoi(getenv("RTX_INST_LOOP")) : 3; return v; }
-static bool inst_loop_kernel(const rt_scene* s) { return inst_loop_bits() != 0 && s->has_instances && !s->has_masks && !s->has_spheres && s->use_pairs && s->d.obj_pairs; }
+// does the scene trace through k_trace_inst (object instances over plain triangles, objects with pair records)?
+static bool inst_loop_kernel(const rt_scene* s) { return s->has_instances && !s->has_masks && !s->has_spheres && s->use_pairs && s->d.obj_pairs; }
 static unsigned trace_knobs(const rt_scene* s, bool any) {
-  static const int env_refill = getenv("RTX_REFILL_MIN") ? std::min(64, std::max(1, atoi(getenv("RTX_REFILL_MIN")))) : -1;
-  static const int env_leaf = getenv("RTX_LEAF_MIN") ? std::min(64, std::max(1, atoi(getenv("RTX_LEAF_MIN")))) : -1;
-  static const int env_leaf_any = getenv("RTX_LEAF_MIN_ANY") ? std::min(64, std::max(1, atoi(getenv("RTX_LEAF_MIN_ANY")))) : -1;
-  const unsigned refill = env_refill > 0 ? (unsigned)env_refill : (unsigned)RT_REFILL_MIN;
+  const unsigned refill = (unsigned)RT_REFILL_MIN;
   // (an instance leaf of the nested form is a whole walk: the holders wait for every walker. In k_trace_inst a leaf is a leaf again: 20 / 24 / 32 / 40 / 48 / 64 lanes
   // gave 780 / 779 / 781 / 764 / 739 / 684 Msamples/s on 10 000 placements of a 1280-triangle object)
   unsigned leaf = s->has_instances ? (inst_loop_kernel(s) ? 32u : 64u) : (unsigned)RT_LEAF_MIN;
@@ -1005,142 +986,110 @@ static unsigned trace_knobs(const rt_scene* s, bool any) {
   // (S4 shadow / environment MIS rays 360 / 686 ms at 20, 335 / 637 at 28 - 32, 321 / 606 at 48), where the bounded shadow rays of area-light scenes lose
   // (S2 31 -> 45 ms, S3 101 -> 112)
   if (any && s->d.n_infinite > 0 && !s->has_instances) leaf = 48u;
-  if (env_leaf > 0) leaf = (unsigned)env_leaf;
-  if (any && env_leaf_any > 0) leaf = (unsigned)env_leaf_any;
   return refill | (leaf << 8);
 }
-template <bool ANY, bool COUNT, bool SMALL, int BLOCK, int DEPTH>
-static void launch_trace_v(rt_scene* s, const TraceIO& io, const unsigned* queue, const unsigned* count_ptr, unsigned shard_cap, unsigned count_static,
-                           unsigned long long* stats, int st_rays, int st_nodes, int st_tris, hipStream_t stream) {
-  const unsigned grid = trace_grid<ANY, SMALL, BLOCK, DEPTH>(s, RT_LDS_THREADED && SMALL && !COUNT);
-  if constexpr (!SMALL) {
-    // measurement knob RTX_TRACE: "plain" = one ray per lane per iteration, "refill" = persistent waves on the one-node-per-step
-    // loop, default = child-pair traversal (frames that count visits always use the one-node-per-step loops)
-    static const char* mode = getenv("RTX_TRACE");
-    const bool plain = mode && mode[0] == 'p', refill_only = mode && mode[0] == 'r';
-    const unsigned refill_min = trace_knobs(s, ANY);
-    if (ANY && !COUNT && !plain && !refill_only && !(mode && mode[0] == 'c') && s->use_quads && s->quad_stack_depth <= DEPTH) {  // RTX_TRACE=childpair: two-wide only
-      hipLaunchKernelGGL((k_trace_quad<ANY, BLOCK, DEPTH>), dim3(grid), dim3(BLOCK), 0, stream, s->d, io, queue, count_ptr, shard_cap, count_static, stats, st_rays, s->tmin_stack.as<float>(), refill_min);
+template <bool ANY, bool COUNT, int BLOCK, int DEPTH>
+static void launch_trace_hbm(rt_scene* s, const TraceIO& io, const unsigned* queue, const unsigned* count_ptr, unsigned shard_cap, unsigned count_static,
+                             unsigned long long* stats, int st_rays, int st_nodes, int st_tris, hipStream_t stream) {
+  // HBM scenes of plain triangles: occlusion rays four-wide (k_trace_quad) where the records exist, otherwise child-pair steps with the top of the tree in LDS (k_trace_top)
+  // or without (k_trace_pair); frames that count visits and trees without pair records walk one node per step (k_trace_big)
+  const unsigned grid = trace_grid<ANY, false, BLOCK, DEPTH>(s);
+  const unsigned refill_min = trace_knobs(s, ANY);
+  if constexpr (ANY && !COUNT) {
+    if (s->use_quads && s->quad_stack_depth <= DEPTH) {
+      hipLaunchKernelGGL((k_trace_quad<BLOCK, DEPTH>), dim3(grid), dim3(BLOCK), 0, stream, s->d, io, queue, count_ptr, shard_cap, count_static, stats, st_rays, s->tmin_stack.as<float>(), refill_min);
       return;
     }
-    if (!ANY && !COUNT && !plain && !refill_only && !(mode && mode[0] == 'c') && s->use_quads_closest && s->stack_depth <= DEPTH) {  // closest hit four-wide, near side first (round 5)
-      hipLaunchKernelGGL((k_trace_quad<ANY, BLOCK, DEPTH>), dim3(grid), dim3(BLOCK), 0, stream, s->d, io, queue, count_ptr, shard_cap, count_static, stats, st_rays, s->tmin_stack.as<float>(), refill_min);
-      return;
-    }
-    // RTX_TRACE=top0: the child-pair kernel without the LDS-resident top of the tree (measurement knob)
-    if (!COUNT && !plain && !refill_only && s->use_pairs && s->use_top && (ANY || s->top_for_closest) && !(mode && mode[0] == 't')) {
+  }
+  if constexpr (!COUNT) {
+    if (s->use_pairs && s->use_top && (ANY || s->top_for_closest)) {
       hipLaunchKernelGGL((k_trace_top<ANY, RT_TOP_BLOCK>), dim3(top_grid(s, ANY)), dim3(RT_TOP_BLOCK), 0, stream, s->d, io, queue, count_ptr, shard_cap, count_static, stats, st_rays,
                          s->tmin_stack.as<float>(), s->deep_stack.as<unsigned>(), refill_min);
       return;
     }
-    if (!COUNT && !plain && !refill_only && s->use_pairs) {
-      static const bool ww = getenv("RTX_TRACE_WW") && getenv("RTX_TRACE_WW")[0] == '1';  // measurement knob; the single loop is faster
-      if (ww) hipLaunchKernelGGL((k_trace_pair<ANY, true, BLOCK, DEPTH>), dim3(grid), dim3(BLOCK), 0, stream, s->d, io, queue, count_ptr, shard_cap, count_static, stats, st_rays, s->tmin_stack.as<float>(), refill_min);
-      else hipLaunchKernelGGL((k_trace_pair<ANY, false, BLOCK, DEPTH>), dim3(grid), dim3(BLOCK), 0, stream, s->d, io, queue, count_ptr, shard_cap, count_static, stats, st_rays, s->tmin_stack.as<float>(), refill_min);
-      return;
-    }
-    if (!plain) {
-      hipLaunchKernelGGL((k_trace_big<ANY, COUNT, BLOCK, DEPTH>), dim3(grid), dim3(BLOCK), 0, stream, s->d, io, queue, count_ptr, shard_cap, count_static, stats, st_rays, st_nodes, st_tris);
+    if (s->use_pairs) {
+      hipLaunchKernelGGL((k_trace_pair<ANY, BLOCK, DEPTH>), dim3(grid), dim3(BLOCK), 0, stream, s->d, io, queue, count_ptr, shard_cap, count_static, stats, st_rays, s->tmin_stack.as<float>(), refill_min);
       return;
     }
   }
-  if constexpr (SMALL && !COUNT && RT_LDS_THREADED) {  // the LDS-resident walks with a pool of set-up rays (k_trace_pool, round 5); RTX_LDS_POOL: bit 0 closest hit, bit 1 occlusion rays
-    static const int pool_bits = getenv("RTX_LDS_POOL") ? atoi(getenv("RTX_LDS_POOL")) : RT_LDS_POOL_DEFAULT;
-    if (pool_bits & (ANY ? 2 : 1)) {
-      const unsigned lds = (unsigned)((8 * RT_SMALL_NODES + 10 * RT_SMALL_TRIS) * 4 + (ANY ? 1 : 8) * RT_SMALL_NODES * 2 + 4 * RT_POOL_FIELDS * 64 * 4);
-      const unsigned per_cu = std::max(1u, std::min((unsigned)RT_POOL_WAVES, (160u * 1024u) / lds));
-      hipLaunchKernelGGL((k_trace_pool<ANY, 256>), dim3((unsigned)s->n_cu * per_cu), dim3(256), 0, stream, s->d, io, queue, count_ptr, shard_cap, count_static, stats, st_rays);
-      return;
-    }
-  }
-  hipLaunchKernelGGL((k_trace<ANY, COUNT, SMALL, BLOCK, DEPTH>), dim3(grid), dim3(BLOCK), 0, stream, s->d, io, queue, count_ptr, shard_cap, count_static, stats, st_rays, st_nodes, st_tris);
+  hipLaunchKernelGGL((k_trace_big<ANY, COUNT, BLOCK, DEPTH>), dim3(grid), dim3(BLOCK), 0, stream, s->d, io, queue, count_ptr, shard_cap, count_static, stats, st_rays, st_nodes, st_tris);
 }
+// does the scene's tree live in LDS for the rays of a frame (k_trace: the 256-node kernels, or one 1024-lane workgroup per CU for a mid-size scene)? RTX_MID_CLOSEST=0: the A/B
+// control of the mid-size closest-hit walk (those rays through the HBM kernels)
+static bool mid_closest_on() { static const bool on = !(env_is("RTX_MID_CLOSEST", '0')); return on; }
 template <bool ANY, bool COUNT>
 static void launch_trace_c(rt_scene* s, const TraceIO& io, const unsigned* queue, const unsigned* count_ptr, unsigned shard_cap, unsigned count_static,
                            unsigned long long* stats, int st_rays, int st_nodes, int st_tris, hipStream_t stream) {
 #define RT_ARGS s, io, queue, count_ptr, shard_cap, count_static, stats, st_rays, st_nodes, st_tris, stream
+#define RT_KARGS s->d, io, queue, count_ptr, shard_cap, count_static, stats, st_rays
   if (s->general_prims) {  // quadrics, masked triangles, object instances: the GENERAL instantiations (plain leaves of such a scene still run the bare triangle loop)
-    static const char* gmode = getenv("RTX_TRACE_GENERAL");  // measurement knob: "big" = the one-node-per-step kernel for every ray (round 2's path)
-    const bool big_only = gmode && gmode[0] == 'b';
     if constexpr (!COUNT) {
       const unsigned refill_min = trace_knobs(s, ANY);
-      static const bool masks_always = getenv("RTX_GEN_MASKS") && getenv("RTX_GEN_MASKS")[0] == '1';  // measurement knob: every general scene through the RT_GEN_ALL kernels
-      const bool all = s->has_masks || masks_always;
+      const bool all = s->has_masks;
 #define RT_GEN_LAUNCH(KERNEL_ALL, KERNEL_NOMASK, GRID, BLK, ...) do { if (all) hipLaunchKernelGGL(KERNEL_ALL, dim3(GRID), dim3(BLK), 0, stream, __VA_ARGS__); \
                                                                       else hipLaunchKernelGGL(KERNEL_NOMASK, dim3(GRID), dim3(BLK), 0, stream, __VA_ARGS__); } while (0)
       // ... and neither masks nor quadrics (instances over plain triangles): the pair / four-wide kernels without the quadric test as well
 #define RT_GEN_LAUNCH3(KERNEL_ALL, KERNEL_NOMASK, KERNEL_INST, GRID, BLK, ...) do { if (!all && !s->has_spheres) hipLaunchKernelGGL(KERNEL_INST, dim3(GRID), dim3(BLK), 0, stream, __VA_ARGS__); \
                                                                                    else RT_GEN_LAUNCH(KERNEL_ALL, KERNEL_NOMASK, GRID, BLK, __VA_ARGS__); } while (0)
-      if (!big_only && s->small) {
-        if (RT_LDS_THREADED && RT_LDS_LINKS && RT_LDS_LINKS_GENERAL) {  // no stack: one instantiation whatever the tree's depth; grid = what fits a CU (LDS: scene + link rows; registers: RT_GEN_MIN_WAVES)
-          const unsigned lds = (unsigned)((8 * RT_SMALL_NODES + 10 * RT_SMALL_TRIS) * 4 + ((ANY ? 1 : 8) * RT_SMALL_NODES + 8) * 4 + 64);
-          unsigned per_cu = (160u * 1024u) / lds; const unsigned by_regs = all ? 2u : 4u; if (per_cu > by_regs) per_cu = by_regs;
-          RT_GEN_LAUNCH((k_trace<ANY, false, true, 256, 16, RT_GEN_ALL>), (k_trace<ANY, false, true, 256, 16, RT_GEN_NO_MASKS>), ((unsigned)s->n_cu * per_cu), 256, s->d, io, queue, count_ptr, shard_cap, count_static, stats, st_rays, st_nodes, st_tris);
-        }
-        else if (s->stack_depth <= 16) RT_GEN_LAUNCH((k_trace<ANY, false, true, 256, 16, RT_GEN_ALL>), (k_trace<ANY, false, true, 256, 16, RT_GEN_NO_MASKS>), (trace_grid<ANY, true, 256, 16>(s)), 256, s->d, io, queue, count_ptr, shard_cap, count_static, stats, st_rays, st_nodes, st_tris);
-        else if (s->stack_depth <= 32) RT_GEN_LAUNCH((k_trace<ANY, false, true, 256, 32, RT_GEN_ALL>), (k_trace<ANY, false, true, 256, 32, RT_GEN_NO_MASKS>), (trace_grid<ANY, true, 256, 32>(s)), 256, s->d, io, queue, count_ptr, shard_cap, count_static, stats, st_rays, st_nodes, st_tris);
-        else RT_GEN_LAUNCH((k_trace<ANY, false, true, 128, 64, RT_GEN_ALL>), (k_trace<ANY, false, true, 128, 64, RT_GEN_NO_MASKS>), (trace_grid<ANY, true, 128, 64>(s)), 128, s->d, io, queue, count_ptr, shard_cap, count_static, stats, st_rays, st_nodes, st_tris);
+      if (s->small) {  // the link walks: no stack, one instantiation whatever the tree's depth; grid = what fits a CU (LDS: scene + link rows; registers: RT_GEN_MIN_WAVES)
+        const unsigned lds = (unsigned)((8 * RT_SMALL_NODES + 10 * RT_SMALL_TRIS) * 4 + ((ANY ? 1 : 8) * RT_SMALL_NODES + 8) * 4 + 64);
+        unsigned per_cu = (160u * 1024u) / lds; const unsigned by_regs = all ? 2u : 4u; if (per_cu > by_regs) per_cu = by_regs;
+        RT_GEN_LAUNCH((k_trace<ANY, false, 256, 16, RT_GEN_ALL>), (k_trace<ANY, false, 256, 16, RT_GEN_NO_MASKS>), ((unsigned)s->n_cu * per_cu), 256, RT_KARGS, st_nodes, st_tris);
         return;
       }
-      // object instances over plain triangles: the two-level walk as one loop (k_trace_inst). RTX_INST_LOOP (measurement knob): bit 0 closest hit, bit 1 any hit; 0 = the nested walks
-      const int inst_loop = inst_loop_bits();
-      if (!big_only && s->has_instances && !all && !s->has_spheres && s->use_pairs && s->d.obj_pairs && ((ANY ? 2 : 1) & inst_loop)) {
+      if (inst_loop_kernel(s)) {  // object instances over plain triangles: the two-level walk as one loop (k_trace_inst)
         const unsigned depth = s->stack_depth <= 32 ? 32u : 64u;
         const unsigned lds = depth * 128u * 4u + 13u * 128u * 4u;
         const unsigned grid_i = (unsigned)s->n_cu * std::max(1u, std::min(16u, (160u * 1024u) / lds));
         const unsigned grid_cap = depth == 32u ? trace_grid<ANY, false, 128, 32>(s) : trace_grid<ANY, false, 128, 64>(s);  // (the deferred-tmin array is sized for this grid)
         const unsigned g = std::min(grid_i, grid_cap);
-        if (depth == 32u) hipLaunchKernelGGL((k_trace_inst<ANY, 128, 32>), dim3(g), dim3(128), 0, stream, s->d, io, queue, count_ptr, shard_cap, count_static, stats, st_rays, s->tmin_stack.as<float>(), refill_min);
-        else hipLaunchKernelGGL((k_trace_inst<ANY, 128, 64>), dim3(g), dim3(128), 0, stream, s->d, io, queue, count_ptr, shard_cap, count_static, stats, st_rays, s->tmin_stack.as<float>(), refill_min);
+        if (depth == 32u) hipLaunchKernelGGL((k_trace_inst<ANY, 128, 32>), dim3(g), dim3(128), 0, stream, RT_KARGS, s->tmin_stack.as<float>(), refill_min);
+        else hipLaunchKernelGGL((k_trace_inst<ANY, 128, 64>), dim3(g), dim3(128), 0, stream, RT_KARGS, s->tmin_stack.as<float>(), refill_min);
         return;
       }
-      if (!big_only && ANY && s->use_quads && s->quad_stack_depth <= 32) {
-        RT_GEN_LAUNCH3((k_trace_quad<ANY, 128, 32, RT_GEN_ALL>), (k_trace_quad<ANY, 128, 32, RT_GEN_NO_MASKS>), (k_trace_quad<ANY, 128, 32, RT_GEN_INSTANCES_ONLY>), (trace_grid<ANY, false, 128, 32>(s)), 128, s->d, io, queue, count_ptr, shard_cap, count_static, stats, st_rays, s->tmin_stack.as<float>(), refill_min);
+      if constexpr (ANY) {
+        if (s->use_quads && s->quad_stack_depth <= 32) {
+          RT_GEN_LAUNCH3((k_trace_quad<128, 32, RT_GEN_ALL>), (k_trace_quad<128, 32, RT_GEN_NO_MASKS>), (k_trace_quad<128, 32, RT_GEN_INSTANCES_ONLY>), (trace_grid<ANY, false, 128, 32>(s)), 128, RT_KARGS, s->tmin_stack.as<float>(), refill_min);
+          return;
+        }
+      }
+      if (s->use_pairs && s->use_top && (ANY || s->top_for_closest)) {
+        RT_GEN_LAUNCH((k_trace_top<ANY, RT_TOP_BLOCK, RT_GEN_ALL>), (k_trace_top<ANY, RT_TOP_BLOCK, RT_GEN_NO_MASKS>), (top_grid(s, ANY)), RT_TOP_BLOCK, RT_KARGS, s->tmin_stack.as<float>(), s->deep_stack.as<unsigned>(), refill_min);
         return;
       }
-      if (!big_only && s->use_pairs && s->use_top && (ANY || s->top_for_closest)) {
-        RT_GEN_LAUNCH((k_trace_top<ANY, RT_TOP_BLOCK, RT_GEN_ALL>), (k_trace_top<ANY, RT_TOP_BLOCK, RT_GEN_NO_MASKS>), (top_grid(s, ANY)), RT_TOP_BLOCK, s->d, io, queue, count_ptr, shard_cap, count_static, stats, st_rays,
-                      s->tmin_stack.as<float>(), s->deep_stack.as<unsigned>(), refill_min);
-        return;
-      }
-      if (!big_only && s->use_pairs) {
-        if (s->stack_depth <= 32) RT_GEN_LAUNCH3((k_trace_pair<ANY, false, 128, 32, RT_GEN_ALL>), (k_trace_pair<ANY, false, 128, 32, RT_GEN_NO_MASKS>), (k_trace_pair<ANY, false, 128, 32, RT_GEN_INSTANCES_ONLY>), (trace_grid<ANY, false, 128, 32>(s)), 128, s->d, io, queue, count_ptr, shard_cap, count_static, stats, st_rays, s->tmin_stack.as<float>(), refill_min);
-        else RT_GEN_LAUNCH3((k_trace_pair<ANY, false, 128, 64, RT_GEN_ALL>), (k_trace_pair<ANY, false, 128, 64, RT_GEN_NO_MASKS>), (k_trace_pair<ANY, false, 128, 64, RT_GEN_INSTANCES_ONLY>), (trace_grid<ANY, false, 128, 64>(s)), 128, s->d, io, queue, count_ptr, shard_cap, count_static, stats, st_rays, s->tmin_stack.as<float>(), refill_min);
+      if (s->use_pairs) {
+        if (s->stack_depth <= 32) RT_GEN_LAUNCH3((k_trace_pair<ANY, 128, 32, RT_GEN_ALL>), (k_trace_pair<ANY, 128, 32, RT_GEN_NO_MASKS>), (k_trace_pair<ANY, 128, 32, RT_GEN_INSTANCES_ONLY>), (trace_grid<ANY, false, 128, 32>(s)), 128, RT_KARGS, s->tmin_stack.as<float>(), refill_min);
+        else RT_GEN_LAUNCH3((k_trace_pair<ANY, 128, 64, RT_GEN_ALL>), (k_trace_pair<ANY, 128, 64, RT_GEN_NO_MASKS>), (k_trace_pair<ANY, 128, 64, RT_GEN_INSTANCES_ONLY>), (trace_grid<ANY, false, 128, 64>(s)), 128, RT_KARGS, s->tmin_stack.as<float>(), refill_min);
         return;
       }
 #undef RT_GEN_LAUNCH3
 #undef RT_GEN_LAUNCH
     }
-    if (s->stack_depth > 64) hipLaunchKernelGGL((k_trace_big<ANY, COUNT, 64, 128, true>), dim3(trace_grid<ANY, false, 64, 128>(s)), dim3(64), 0, stream, s->d, io, queue, count_ptr, shard_cap, count_static, stats, st_rays, st_nodes, st_tris);
-    else if (s->stack_depth <= 32) hipLaunchKernelGGL((k_trace_big<ANY, COUNT, 128, 32, true>), dim3(trace_grid<ANY, false, 128, 32>(s)), dim3(128), 0, stream, s->d, io, queue, count_ptr, shard_cap, count_static, stats, st_rays, st_nodes, st_tris);
-    else hipLaunchKernelGGL((k_trace_big<ANY, COUNT, 128, 64, true>), dim3(trace_grid<ANY, false, 128, 64>(s)), dim3(128), 0, stream, s->d, io, queue, count_ptr, shard_cap, count_static, stats, st_rays, st_nodes, st_tris);
+    if (s->stack_depth > 64) hipLaunchKernelGGL((k_trace_big<ANY, COUNT, 64, 128, true>), dim3(trace_grid<ANY, false, 64, 128>(s)), dim3(64), 0, stream, RT_KARGS, st_nodes, st_tris);
+    else if (s->stack_depth <= 32) hipLaunchKernelGGL((k_trace_big<ANY, COUNT, 128, 32, true>), dim3(trace_grid<ANY, false, 128, 32>(s)), dim3(128), 0, stream, RT_KARGS, st_nodes, st_tris);
+    else hipLaunchKernelGGL((k_trace_big<ANY, COUNT, 128, 64, true>), dim3(trace_grid<ANY, false, 128, 64>(s)), dim3(128), 0, stream, RT_KARGS, st_nodes, st_tris);
     return;
   }
   if constexpr (!COUNT) {
-    static const bool mid_closest = !(getenv("RTX_MID_CLOSEST") && getenv("RTX_MID_CLOSEST")[0] == '0');  // measurement knob: 0 = a mid-size scene's closest-hit rays through the HBM kernels
-    if (s->mid && (ANY || mid_closest)) {
-      hipLaunchKernelGGL((k_trace<ANY, false, true, 1024, 16, 0, 1>), dim3((unsigned)s->n_cu), dim3(1024), 0, stream, s->d, io, queue, count_ptr, shard_cap, count_static, stats, st_rays, st_nodes, st_tris);
+    if (s->mid && (ANY || mid_closest_on())) {
+      hipLaunchKernelGGL((k_trace<ANY, false, 1024, 16, 0, 1>), dim3((unsigned)s->n_cu), dim3(1024), 0, stream, RT_KARGS, st_nodes, st_tris);
+      return;
+    }
+    if (s->small) {  // the link walks: no stack, whatever the tree's depth
+      hipLaunchKernelGGL((k_trace<ANY, false, 256, 16>), dim3(trace_grid<ANY, true, 256, 16>(s, true)), dim3(256), 0, stream, RT_KARGS, st_nodes, st_tris);
       return;
     }
   }
-  if (s->small) {
-    if (s->stack_depth <= 16) launch_trace_v<ANY, COUNT, true, 256, 16>(RT_ARGS);
-    else if (s->stack_depth <= 32) launch_trace_v<ANY, COUNT, true, 256, 32>(RT_ARGS);
-    else launch_trace_v<ANY, COUNT, true, 128, 64>(RT_ARGS);
+  if (s->small) {  // a frame that counts the reference's walk: the stack walk over the LDS copy
+    if (s->stack_depth <= 16) hipLaunchKernelGGL((k_trace<ANY, true, 256, 16>), dim3(trace_grid<ANY, true, 256, 16>(s)), dim3(256), 0, stream, RT_KARGS, st_nodes, st_tris);
+    else if (s->stack_depth <= 32) hipLaunchKernelGGL((k_trace<ANY, true, 256, 32>), dim3(trace_grid<ANY, true, 256, 32>(s)), dim3(256), 0, stream, RT_KARGS, st_nodes, st_tris);
+    else hipLaunchKernelGGL((k_trace<ANY, true, 128, 64>), dim3(trace_grid<ANY, true, 128, 64>(s)), dim3(128), 0, stream, RT_KARGS, st_nodes, st_tris);
   } else {
-    if (s->stack_depth <= 32) launch_trace_v<ANY, COUNT, false, 128, 32>(RT_ARGS);
-    else launch_trace_v<ANY, COUNT, false, 128, 64>(RT_ARGS);
+    if (s->stack_depth <= 32) launch_trace_hbm<ANY, COUNT, 128, 32>(RT_ARGS);
+    else launch_trace_hbm<ANY, COUNT, 128, 64>(RT_ARGS);
   }
+#undef RT_KARGS
 #undef RT_ARGS
-}
-// the frame loop's path rays go through k_trace (an LDS copy of the scene: its closest-hit walks read a link row per direction octant, and it knows dead queue entries)
-static bool path_rays_walk_lds(const rt_scene* s) {
-  static const bool mid_closest = !(getenv("RTX_MID_CLOSEST") && getenv("RTX_MID_CLOSEST")[0] == '0');
-  static const bool gen_big = getenv("RTX_TRACE_GENERAL") && getenv("RTX_TRACE_GENERAL")[0] == 'b';
-  static const bool pool = getenv("RTX_LDS_POOL") && atoi(getenv("RTX_LDS_POOL")) != 0;
-  if (pool) return false;
-  if (s->general_prims) return s->small && !gen_big && !s->has_instances;
-  return s->small || (s->mid && mid_closest);
 }
 template <bool ANY>
 static void launch_trace(rt_scene* s, bool count, const TraceIO& io, const unsigned* queue, const unsigned* count_ptr, unsigned shard_cap, unsigned count_static,
@@ -1299,10 +1248,10 @@ static int launch_sampler_tables(SamplerPlan& pl, const FrameParams& fp, unsigne
   // and the parallel one competes for issue slots and LDS. Measured in round 4, frame times: at 256 / 512 spp the parallel replay loses (S2 167.3 -> 169.5 ms, S3 323.5 ->
   // 324.6); at 1024 spp, with a short leading batch (lead_pixels in rt_render), it wins for EVERY batch (S1 679.5 -> 667.5 ms, S4 5280 -> 5242).
   // DEFAULT therefore: parallel replay at spp == 1024, chain kernel otherwise. RTX_K0_PARALLEL=1 forces the parallel replay (64 <= spp <= 1024), =0 the chain kernel.
-  static const bool par_on = getenv("RTX_K0_PARALLEL") && getenv("RTX_K0_PARALLEL")[0] == '1';
-  static const bool par_never = getenv("RTX_K0_PARALLEL") && getenv("RTX_K0_PARALLEL")[0] == '0';
+  static const bool par_on = env_is("RTX_K0_PARALLEL", '1');
+  static const bool par_never = env_is("RTX_K0_PARALLEL", '0');
   // RTX_K0_FORCE_RESORT=1 (test knob, read per call): the parallel replay is handed descending ranks, so every wave takes the branch that re-sorts its groups
-  const unsigned force_resort = (getenv("RTX_K0_FORCE_RESORT") && getenv("RTX_K0_FORCE_RESORT")[0] == '1') ? 1u : 0u;
+  const unsigned force_resort = (env_is("RTX_K0_FORCE_RESORT", '1')) ? 1u : 0u;
   const bool par = (par_on || (!par_never && spp == 1024u)) && spp >= 64u && spp <= 1024u;
   hipLaunchKernelGGL(k_sampler_draws, dim3((n_pixels + 255u) / 256u, pl.n_segs), dim3(256), 0, stream, fp, n_pixels, spp, dims, pl.seg_len, explicit_pixel0, use_explicit,
                      pl.segs.as<SamplerSeg>(), pl.magic.as<unsigned>(), scrambles, partners, pl.dirty.as<unsigned>(), par ? 1 : 0);
@@ -1393,38 +1342,10 @@ struct KTimer {  // HIP-event kernel timing on the render stream; events come fr
   }
 };
 
-// one shade launch of front-end MODE: the GENERAL form (quadric / instance hits, masked emitters), the LEAN form (area lights and constant textures only;
-// front-ends 3 / 5 / 6), or the plain one
+// one shade launch of front-end MODE (rtx_shade.hip: the k_shade instantiations are a translation unit of their own, compiled beside this one)
 template <int MODE>
 static void launch_shade(bool general, bool lean, bool bounced, unsigned grid, unsigned block, hipStream_t stream, const DScene& d, const FrameParams& fp, const PassState& p, bool qlights = false, int lds = 0) {
-  // sphere lights over constant textures: the front-end ranges hold triangle vertices only (quadric hits are binned into the generic range)
-  // lds (LEAN / QLIGHTS forms): 1 = the scene's records, lights, materials and textures fit the kernel's LDS, 2 = its materials and textures do (k_shade's LDSREC)
-  if constexpr (MODE != 0) {
-    if (qlights) {
-      if (lds == 1) hipLaunchKernelGGL((k_shade<MODE, false, true, false, true, 1>), dim3(grid), dim3(block), 0, stream, d, fp, p);
-      else if (lds == 2) hipLaunchKernelGGL((k_shade<MODE, false, true, false, true, 2>), dim3(grid), dim3(block), 0, stream, d, fp, p);
-      else hipLaunchKernelGGL((k_shade<MODE, false, true, false, true>), dim3(grid), dim3(block), 0, stream, d, fp, p);
-      return;
-    }
-  }
-  if (general) { hipLaunchKernelGGL((k_shade<MODE, true>), dim3(grid), dim3(block), 0, stream, d, fp, p); return; }
-  if constexpr (MODE != 0) {
-    if (lean) {
-      if (lds == 2) hipLaunchKernelGGL((k_shade<MODE, false, true, false, false, 2>), dim3(grid), dim3(block), 0, stream, d, fp, p);
-      else hipLaunchKernelGGL((k_shade<MODE, false, true>), dim3(grid), dim3(block), 0, stream, d, fp, p);
-      return;
-    }
-  }
-  // the Lambert front-end past the camera vertices: no differentials, bilinear image lookups, everything inline under a three-wave bound
-  if constexpr (MODE == 3) {
-    if (bounced) {
-      if (lds == 3) hipLaunchKernelGGL((k_shade<3, false, false, true, false, 3>), dim3(grid), dim3(block), 0, stream, d, fp, p);
-      else hipLaunchKernelGGL((k_shade<3, false, false, true>), dim3(grid), dim3(block), 0, stream, d, fp, p);
-      return;
-    }
-  }
-  if constexpr (MODE == 3 || MODE == 5 || MODE == 6) { if (lds == 3) { hipLaunchKernelGGL((k_shade<MODE, false, false, false, false, 3>), dim3(grid), dim3(block), 0, stream, d, fp, p); return; } }
-  hipLaunchKernelGGL((k_shade<MODE, false>), dim3(grid), dim3(block), 0, stream, d, fp, p);
+  rtx_launch_shade(MODE, general, lean, bounced, grid, block, stream, d, fp, p, qlights, lds);
 }
 
 extern "C" int rt_render(rt_scene* s, const rt_camera* cam, const rt_film_desc* film, const rt_sampler_desc* smp, const rt_path_desc* path,
@@ -1486,42 +1407,28 @@ extern "C" int rt_render(rt_scene* s, const rt_camera* cam, const rt_film_desc* 
   auto env_log2 = [](const char* name, int dflt) { const char* e = getenv(name); return e ? std::min(30, std::max(16, atoi(e))) : dflt; };
   static const int tp_log2 = env_log2("RTX_PASS_LOG2", 29);  // (round 4: 2^28 -> 2^29 paths per pass, 211 GB of workspace: S1 815.9 -> 808.5 ms, S4 5764 -> 5728, S2 167.4 -> 164.9)
   static const int bp_log2 = env_log2("RTX_BATCH_LOG2", 19);
-  enum { B_GEN0, B_GEN1, B_GENS, B_HIT, B_HITS, B_LACC, B_PFILM, B_SH, B_MI, B_QSH, B_QMI, B_QMA, B_OCCSH, B_OCCMI, B_COUNT };  // two generations of travelling path records + their hits (by queue slot), radiance and film position (by path id), ray records and the three ray queues
+  enum { B_GEN0, B_GEN1, B_HIT, B_LACC, B_PFILM, B_SH, B_MI, B_QSH, B_QMI, B_QMA, B_OCCSH, B_OCCMI, B_COUNT };  // two generations of travelling path records + their hits (by queue slot), radiance and film position (by path id), ray records and the three ray queues
   const bool has_infinite = s->d.n_infinite > 0;
   const size_t counter_words = (size_t)(fp.max_depth + 2) * RT_NQ * RT_QSHARDS * RT_CNT_STRIDE;  // one block of {out, shadow, mis, mis-any} shard counts per bounce + raygen's
   // material binning before the generic shade kernel: per bounce {hist, cursor}[RT_BIN_MAX + 1] + the 8 count words of the sorted queue
-  static const bool bin_off = getenv("RTX_SHADE_BINS") && getenv("RTX_SHADE_BINS")[0] == '0';  // measurement knob
-  const bool use_bins = !s->lambert_materials && s->n_code_classes > 1 && !bin_off;  // one class: every vertex runs the same code, the queue order is kept
-  // RTX_BIN_MOVE=1 (measurement knob): k_bin_scatter copies the travelling records into sorted order so that the shade launches stream them. Measured (one box,
-  // back to back): S3 shade 121.6 -> 135.5 ms, S4 3158 -> 3235, mis-spheres 224 -> 244 - a bin keeps the queue's order in rounds of 256 entries, so the gather
-  // through the sorted list already reads runs of neighbouring slots, and the copy (128-160 B per vertex) costs more than the rest of the gather. Off.
-  static const bool bin_move_on = getenv("RTX_BIN_MOVE") && getenv("RTX_BIN_MOVE")[0] == '1';
-  const bool bin_move = use_bins && bin_move_on;
+  const bool use_bins = !s->lambert_materials && s->n_code_classes > 1;  // one class: every vertex runs the same code, the queue order is kept
+  // (moving the travelling records into sorted order so that the shade launches stream them was measured in round 3: S3 shade 121.6 -> 135.5 ms, S4 3158 -> 3235 - a bin keeps
+  // the queue's order in rounds of 256 entries, so the gather through the sorted list already reads runs of neighbouring slots. Removed.)
   const bool gshade = s->masked_emitters;  // quadric / instance hits, quadric or masked emitters: the GENERAL instantiations of the shade kernels
-  static const bool lean_off = getenv("RTX_SHADE_LEAN") && getenv("RTX_SHADE_LEAN")[0] == '0';  // measurement knob
-  const bool lean_shade = s->lean_shade && !lean_off;
-  static const bool bounced_off = getenv("RTX_SHADE_BOUNCED") && getenv("RTX_SHADE_BOUNCED")[0] == '0';  // measurement knob
+  const bool lean_shade = s->lean_shade;
   const int lds_shade = (s->lds_records_q && s->d.route_quadric_hits != 0) ? 1 : ((lean_shade || gshade) ? (s->lds_mats ? 2 : 0) : (s->lds_tables ? 3 : 0));  // the LEAN / QLIGHTS forms' tables in LDS
   const bool qlights = s->d.route_quadric_hits != 0 && use_bins;  // QLIGHTS forms on the front-end ranges, quadric hits in a generic bin of their own
   const unsigned n_bins = std::min<unsigned>(s->n_code_classes, RT_BIN_MAX - 1) + 1u + (qlights ? 1u : 0u);
   const size_t bin_stride = (RT_BIN_MAX + 1) + (size_t)(RT_BIN_MAX + 1) * RT_CNT_STRIDE + (size_t)RT_QSHARDS * RT_CNT_STRIDE + 10;  // hist, cursors (spread), the sorted queue's counts (laid out as shard counters)  // + {begin, end} of the four class ranges and of the miss bin
   // RTX_SHADE_SPLIT (measurement knob): 0 = every class through the generic front-end, 1 = Lambert classes apart, default = Lambert and two-lobe classes apart
-  const int split_mode = getenv("RTX_SHADE_SPLIT") ? atoi(getenv("RTX_SHADE_SPLIT")) : 2;
+  const int split_mode = env_int("RTX_SHADE_SPLIT", 2);
   const unsigned n_first = split_mode >= 1 ? s->n_lambert_classes : 0u, n_second = split_mode >= 2 ? s->n_small_classes : 0u;
   const unsigned n_third = split_mode >= 2 ? s->n_wide_classes : 0u;
   const bool split_classes = use_bins && (n_first + n_second + n_third) > 0 && n_first + n_second + n_third < RT_BIN_MAX;
   const unsigned pgrid_q = (unsigned)s->n_cu * 8u;
   const unsigned long long table_bytes_per_pixel = 2ull * dims * spp * 2ull;
 
-  unsigned long long batch_pixels = 0, chunk_pixels = 0, cap = 0, lead_pixels = 0; unsigned pass_samples = 0, shard_cap = 0; bool multi_batch = false; size_t n_slots = 0, n_ent = 0;
-  // Octant runs (round 6, block_push_oct): the continuing paths of scenes whose path rays walk an LDS copy of the scene (k_trace: LDS-resident and mid-size scenes) are appended in runs
-  // of one direction octant. Off on frames that count the reference's walk (a dead entry would count a node test). RTX_OCT = 0 | 64 | 128 | 256: the A/B control / the run length
-  unsigned oct_log2 = 0;
-  {
-    static const int oct_env = getenv("RTX_OCT") ? atoi(getenv("RTX_OCT")) : -1;
-    const bool count_frame = (flags & RT_FLAG_COUNT_TRAVERSAL) != 0;
-    if (path_rays_walk_lds(s) && !count_frame && oct_env != 0) oct_log2 = oct_env == 64 ? 6u : (oct_env == 128 ? 7u : 8u);
-  }
+  unsigned long long batch_pixels = 0, chunk_pixels = 0, cap = 0, lead_pixels = 0; unsigned pass_samples = 0, shard_cap = 0; bool multi_batch = false; size_t n_slots = 0;
   static const char* lead_env = getenv("RTX_LEAD_BATCH");  // measurement knob (round 4), see lead_pixels below: 1 always, 0 never, unset: at 1024 spp
   const bool lead_on = lead_env ? lead_env[0] == '1' : spp == 1024u;
   for (int shrink = 0;; ++shrink) {
@@ -1547,21 +1454,19 @@ extern "C" int rt_render(rt_scene* s, const rt_camera* cam, const rt_film_desc* 
     if (cap > 0x7fffffffull) return fail(RT_ERR_INVALID, "pass too large");
     // a shard receives the appends of the blocks with blockIdx % RT_QSHARDS == shard; a grid-stride loop hands
     // each block at most ceil(n / (grid * 256)) iterations, so cap / RT_QSHARDS plus one iteration per block bounds it
-    // (octant runs, block_push_oct: a workgroup may leave eight open runs of <= 256 slots behind instead of none)
-    shard_cap = (unsigned)(cap / RT_QSHARDS) + 256u * (pgrid_q / RT_QSHARDS + 1u) + 256u + (oct_log2 ? 8u * 256u * (pgrid_q / RT_QSHARDS + 1u) : 0u);
+    shard_cap = (unsigned)(cap / RT_QSHARDS) + 256u * (pgrid_q / RT_QSHARDS + 1u) + 256u;
     const size_t szq = (size_t)shard_cap * RT_QSHARDS * 4;
     n_slots = (size_t)shard_cap * RT_QSHARDS;  // slots of a sharded queue (>= cap: bounce 0 of a fully traced pass uses slot = path id)
     multi_batch = owned_pixels > chunk_pixels || lead_pixels > 0;
-    n_ent = oct_log2 ? n_slots : (size_t)cap;  // entries a bounce's queue can hold: with octant runs the dead ones as well
     struct Want { DevBuf* buf; size_t bytes; };
     std::vector<Want> want = {
-        {&s->ws[B_GEN0], n_slots * 64}, {&s->ws[B_GEN1], n_slots * 64}, {&s->ws[B_HIT], n_slots * 16}, {&s->ws[B_GENS], bin_move ? n_slots * 64 : 16}, {&s->ws[B_HITS], bin_move ? n_slots * 16 : 16}, {&s->ws[B_LACC], cap * 16}, {&s->ws[B_PFILM], cap * 8},
-        {&s->ws[B_SH], n_ent * 48}, {&s->ws[B_MI], n_ent * 100}, {&s->ws[B_OCCSH], n_ent}, {&s->ws[B_OCCMI], n_ent},
+        {&s->ws[B_GEN0], n_slots * 64}, {&s->ws[B_GEN1], n_slots * 64}, {&s->ws[B_HIT], n_slots * 16}, {&s->ws[B_LACC], cap * 16}, {&s->ws[B_PFILM], cap * 8},
+        {&s->ws[B_SH], cap * 48}, {&s->ws[B_MI], cap * 100}, {&s->ws[B_OCCSH], cap}, {&s->ws[B_OCCMI], cap},
         {&s->ws[B_QSH], szq}, {&s->ws[B_QMI], szq}, {&s->ws[B_QMA], has_infinite ? szq : 16},
         {&s->counters, counter_words * 4}, {&s->stats, (size_t)ST_COUNT * 8}, {&s->film_acc, (size_t)cw * ch * 16}, {&s->own_acc, (size_t)chunk_pixels * 16},
         {&s->filter_table, 1024}, {&s->scrambles[0], (size_t)chunk_pixels * 3 * dims * 4}, {&s->perms[0], (size_t)(chunk_pixels * table_bytes_per_pixel)},
         {&s->sampler_plan.partners, (size_t)(chunk_pixels * table_bytes_per_pixel)}};
-    if (use_bins) { want.push_back({&s->bin_words, (size_t)(fp.max_depth + 1) * bin_stride * 4}); want.push_back({&s->bin_sorted, bin_move ? 16 : n_ent * 4}); want.push_back({&s->bin_at, n_ent * 2}); }
+    if (use_bins) { want.push_back({&s->bin_words, (size_t)(fp.max_depth + 1) * bin_stride * 4}); want.push_back({&s->bin_sorted, (size_t)cap * 4}); want.push_back({&s->bin_at, (size_t)cap * 2}); }
     if (multi_batch) { want.push_back({&s->scrambles[1], (size_t)chunk_pixels * 3 * dims * 4}); want.push_back({&s->perms[1], (size_t)(chunk_pixels * table_bytes_per_pixel)}); }
     if (!(flags & RT_FLAG_FILM_ON_DEVICE)) want.push_back({&s->film_out, (size_t)cw * ch * 16});
     size_t grow = 0;  // bytes the buffers have to grow by (a buffer that is too small is freed and allocated anew)
@@ -1590,14 +1495,15 @@ extern "C" int rt_render(rt_scene* s, const rt_camera* cam, const rt_film_desc* 
   PassState ps{};
   ps.spp = spp; ps.spp_log2 = spp_log2; ps.dims = dims;
   auto gen_of = [&](int b) { PathGen g; char* p = (char*)s->ws[b].p; g.o = (float4*)p; g.d = (float4*)(p + n_slots * 16); g.beta = (float4*)(p + n_slots * 32); g.st = (uint4*)(p + n_slots * 48); return g; };
-  const PathGen gen0 = gen_of(B_GEN0), gen1 = gen_of(B_GEN1), gen_sorted = gen_of(B_GENS);
+  const PathGen gen0 = gen_of(B_GEN0), gen1 = gen_of(B_GEN1);
   ps.hit = s->ws[B_HIT].as<float4>(); ps.lacc = s->ws[B_LACC].as<float4>(); ps.pfilm = s->ws[B_PFILM].as<float2>();
-  { char* p = (char*)s->ws[B_SH].p; ps.sh.o = (float4*)p; ps.sh.d = (float4*)(p + n_ent * 16); ps.sh.add = (float4*)(p + n_ent * 32);
-    char* q = (char*)s->ws[B_MI].p; ps.mi.o = (float4*)q; ps.mi.d = (float4*)(q + n_ent * 16); ps.mi.hit = (float4*)(q + n_ent * 32); ps.mi.a = (float4*)(q + n_ent * 48);
-    ps.mi.b = (float4*)(q + n_ent * 64); ps.mi.c = (float4*)(q + n_ent * 80); ps.mi.flags = (unsigned*)(q + n_ent * 96); }
+  { char* p = (char*)s->ws[B_SH].p; ps.sh.o = (float4*)p; ps.sh.d = (float4*)(p + cap * 16); ps.sh.add = (float4*)(p + cap * 32);
+    char* q = (char*)s->ws[B_MI].p; ps.mi.o = (float4*)q; ps.mi.d = (float4*)(q + cap * 16); ps.mi.hit = (float4*)(q + cap * 32); ps.mi.a = (float4*)(q + cap * 48);
+    ps.mi.b = (float4*)(q + cap * 64); ps.mi.c = (float4*)(q + cap * 80); ps.mi.flags = (unsigned*)(q + cap * 96); }
   ps.occ_sh = s->ws[B_OCCSH].as<unsigned char>(); ps.occ_mi = s->ws[B_OCCMI].as<unsigned char>();
   ps.q_shadow = s->ws[B_QSH].as<unsigned>(); ps.q_mis = s->ws[B_QMI].as<unsigned>(); ps.q_misany = s->ws[B_QMA].as<unsigned>();
-  ps.own_acc = s->own_acc.as<float4>(); ps.shard_cap = shard_cap; ps.oct_log2 = oct_log2; ps.stats = s->stats.as<unsigned long long>();
+  ps.own_acc = s->own_acc.as<float4>(); ps.shard_cap = shard_cap;
+  ps.stats = s->stats.as<unsigned long long>();
 
   if ((rc = sampler_plan_prepare(s->sampler_plan, spp, dims)) != RT_OK) return rc;
   if ((rc = sampler_set_lds_limits(spp)) != RT_OK) return rc;
@@ -1631,9 +1537,7 @@ extern "C" int rt_render(rt_scene* s, const rt_camera* cam, const rt_film_desc* 
     const unsigned long long npx = (first == 0 && lead_pixels) ? lead_pixels : std::min(chunk_pixels, owned_pixels - first);
     batches.push_back({first, npx}); first += npx;
   }
-  static const bool groups_off = getenv("RTX_K0_GROUPS") && getenv("RTX_K0_GROUPS")[0] == '0';  // measurement knob: every table before the batch's first kernel
-  TableGroups tgroups = groups_off ? table_groups_all(dims) : table_groups_frame(dims);
-  if (groups_off) { tgroups.n_groups = 3; }  // (groups 1 and 2 empty: their events follow group 0's at once)
+  TableGroups tgroups = table_groups_frame(dims);
   auto launch_tables = [&](size_t b, int buf) {
     FrameParams f2 = fp; f2.chunk_first = batches[b].first;
     tm.begin(&stats.ms_sampler, aux);
@@ -1665,9 +1569,9 @@ extern "C" int rt_render(rt_scene* s, const rt_camera* cam, const rt_film_desc* 
       ps.all_in_bounds = all_in_bounds ? 1 : 0;
       // a frame that counts node visits keeps the reference's closest-hit walk for every MIS ray, unless it is asked to count what a production frame walks
       ps.mis_any = (has_infinite && (!count || (flags & RT_FLAG_COUNT_AS_RENDERED))) ? 1 : 0;
-      static const bool reach_off = getenv("RTX_MIS_REACH") && getenv("RTX_MIS_REACH")[0] == '0';  // measurement knob
+      static const bool reach_off = env_is("RTX_MIS_REACH", '0');  // measurement knob
       ps.skip_unreachable_mis = (!reach_off && (!count || (flags & RT_FLAG_COUNT_AS_RENDERED))) ? 1 : 0;
-      static const bool tail_off = getenv("RTX_DEAD_TAIL") && getenv("RTX_DEAD_TAIL")[0] == '0';  // measurement knob: cast the rays nothing reads as well
+      static const bool tail_off = env_is("RTX_DEAD_TAIL", '0');  // measurement knob: cast the rays nothing reads as well
       ps.skip_dead_tail = (!tail_off && (!count || (flags & RT_FLAG_COUNT_AS_RENDERED))) ? 1 : 0;
       tm.begin(&stats.ms_raygen);
       hipLaunchKernelGGL(k_raygen, dim3(pgrid), dim3(256), 0, stream, fp, ps);
@@ -1682,12 +1586,10 @@ extern "C" int rt_render(rt_scene* s, const rt_camera* cam, const rt_film_desc* 
         launch_trace<false>(s, count, io_path, ps.cnt_in, ps.cnt_in, ps.shard_cap, ps.cap, dstats, ST_RAYS_CLOSEST, ST_NODES_CLOSEST, ST_TRIS_CLOSEST, stream);
         tm.end();
         if (bounce <= 1) HIP_TRY(hipStreamWaitEvent(stream, s->ev_tables[buf][bounce + 1], 0));  // table groups 1 / 2: first read by the shade launches of bounce 0 / 1
-#define RT_SHADE(MODE, P) stats.launches_shade += 1, launch_shade<MODE>(gshade, lean_shade, bounce >= 1 && !bounced_off, sgrid, sblock, stream, s->d, fp, P, qlights, lds_shade)
+#define RT_SHADE(MODE, P) stats.launches_shade += 1, launch_shade<MODE>(gshade, lean_shade, bounce >= 1, sgrid, sblock, stream, s->d, fp, P, qlights, lds_shade)
         if (s->lambert_only) {
           tm.begin(&stats.ms_shade_lambert_const);
-          if (s->lds_records) hipLaunchKernelGGL((k_shade<1, false, false, false, false, 1>), dim3(sgrid), dim3(sblock), 0, stream, s->d, fp, ps);
-          else if (s->lds_tables) hipLaunchKernelGGL((k_shade<1, false, false, false, false, 3>), dim3(sgrid), dim3(sblock), 0, stream, s->d, fp, ps);  // a large mesh with few lights / materials (S2)
-          else hipLaunchKernelGGL(k_shade<1>, dim3(sgrid), dim3(sblock), 0, stream, s->d, fp, ps);
+          rtx_launch_shade_const(s->lds_records ? 1 : (s->lds_tables ? 3 : 0), sgrid, sblock, stream, s->d, fp, ps);  // LDSREC 3: a large mesh with few lights / materials (S2)
           tm.end(); stats.launches_shade += 1;
         }
         else if (s->lambert_materials) { tm.begin(&stats.ms_shade_lambert); RT_SHADE(3, ps); tm.end(); }
@@ -1699,12 +1601,11 @@ extern "C" int rt_render(rt_scene* s, const rt_camera* cam, const rt_film_desc* 
           hipLaunchKernelGGL(k_bin_count, dim3(pgrid), dim3(256), 0, stream, s->d, ps, n_bins, hist, s->bin_at.as<unsigned short>());
           unsigned* ranges = sorted_cnt + (size_t)RT_QSHARDS * RT_CNT_STRIDE;
 #define RT_BIN_ARGS dim3(pgrid), dim3(256), 0, stream, s->d, ps, n_bins, hist, cursor, s->bin_sorted.as<unsigned>(), sorted_cnt, split_classes ? n_first : 0u, split_classes ? n_first + n_second : 0u, \
-                    split_classes ? n_first + n_second + n_third : 0u, ranges, s->bin_at.as<unsigned short>(), gen_sorted, s->ws[B_HITS].as<float4>(), (s->has_spheres || s->has_instances) ? 1 : 0
-          if (bin_move) hipLaunchKernelGGL(k_bin_scatter<true>, RT_BIN_ARGS); else hipLaunchKernelGGL(k_bin_scatter<false>, RT_BIN_ARGS);
+                    split_classes ? n_first + n_second + n_third : 0u, ranges, s->bin_at.as<unsigned short>()
+          hipLaunchKernelGGL(k_bin_scatter, RT_BIN_ARGS);
 #undef RT_BIN_ARGS
           tm.end();
           PassState pb = ps; pb.q_in = s->bin_sorted.as<unsigned>(); pb.cnt_in = sorted_cnt;  // all entries in shard 0: QView::get(i) = ids[i]
-          if (bin_move) { pb.q_in = nullptr; pb.in = gen_sorted; pb.hit = s->ws[B_HITS].as<float4>(); }  // the records were moved: entry i is slot i
           // classes of the register-resident front-ends, then the generic one, then the rays that left the scene
           if (split_classes && n_first) { pb.range = ranges; tm.begin(&stats.ms_shade_lambert); RT_SHADE(3, pb); tm.end(); }
           if (split_classes && n_second) { pb.range = ranges + 2; tm.begin(&stats.ms_shade_two_lobe); RT_SHADE(5, pb); tm.end(); }
@@ -1765,14 +1666,6 @@ extern "C" int rt_render(rt_scene* s, const rt_camera* cam, const rt_film_desc* 
   stats.vertices_lambert_const = h[ST_SHADED]; stats.vertices_lambert = h[ST_SHADED + 1]; stats.vertices_two_lobe = h[ST_SHADED + 2]; stats.vertices_generic = h[ST_SHADED + 3];
   if (h[ST_UNBUILT_VOXEL]) return fail(RT_ERR_INVALID, "a path looked up a light-distribution voxel that holds no surface (voxel marking bug)");
   stats.ms_total = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_begin).count();
-#ifdef RT_TRACE_PROBE
-  if (getenv("RTX_PROBE")) {
-    unsigned long long pr[16]; HIP_TRY(hipMemcpyFromSymbol(pr, HIP_SYMBOL(g_probe), sizeof(pr))); unsigned long long z[16] = {0}; HIP_TRY(hipMemcpyToSymbol(HIP_SYMBOL(g_probe), z, sizeof(z)));
-    auto f = [](unsigned long long a, unsigned long long b) { return b ? (double)a / (double)b : 0.0; };
-    fprintf(stderr, "probe: occlusion walk lanes stepping %.3f of rounds | closest: node rounds %.3f, leaf phases %.3f (node : leaf slots %.2f : 1) | tail: all lanes' steps / (64 x longest lane) %.3f\n",
-            f(pr[1], pr[0]), f(pr[3], pr[2]), f(pr[5], pr[4]), f(pr[2], pr[4]), f(pr[7], pr[6]));
-  }
-#endif
   if (stats_out) *stats_out = stats;
   return RT_OK;
 }
@@ -1878,6 +1771,7 @@ extern "C" int rt_multi_render(rt_multi* m, const rt_camera* cam, const rt_film_
   HIP_TRY(hipSetDevice(m->devices[0]));
   HIP_TRY(m->acc.ensure(frame_bytes));
   HIP_TRY(hipMemset(m->acc.p, 0, frame_bytes));
+  HIP_TRY(hipStreamSynchronize(nullptr));  // the additions run on add_stream (non-blocking: not ordered behind the null stream): the clear is complete before the first of them
   while ((int)m->staging.size() < n_chunks) m->staging.push_back(new DevBuf());
   std::vector<std::vector<std::pair<int, int>>> chunk_bands(n_chunks);
   for (int c = 0; c < n_chunks; ++c) {

@@ -22,12 +22,12 @@ namespace rtx {
 // the radiance sum `lacc` (added to by the any-hit epilogue, k_resolve and - for emitters seen directly - k_shade) and the film position `pfilm`.
 // Before: RayRec / VertRec / PathAcc arrays indexed by path id and queues of ids, so a consumer's loads were a gather through the id (two dependent round
 // trips, lines shared with dead paths; S1 k_shade<1> moved 1.7x its algorithmic bytes at 0.68 wait cycles per wave cycle - VERDICT r03 weak #3).
-// ---- Cache policy of the once-through streams (round 6). SPtr<T> is T* by default. With -DRT_NT_STREAMS=1 it is a pointer whose element reads and
+// ---- Cache policy of the once-through streams (round 6). With RT_NT_STREAMS (the default; -DRT_NT_STREAMS=0: SPtr<T> is T*) SPtr<T> is a pointer whose element reads and
 // writes carry the non-temporal hint (global_load / global_store ... nt): the travelling path records, ray and hit records, ray queues and occlusion bytes are written
 // once and read once, and should not push the gathered tables (environment rows, texels, triangle records) out of L2 / Infinity Cache. Same values either way; measured in
 // MEASUREMENTS R6 (scripts/micro/fetch_calibrate.hip has the same mix in isolation).
 #ifndef RT_NT_STREAMS
-#define RT_NT_STREAMS 0
+#define RT_NT_STREAMS 1
 #endif
 #if RT_NT_STREAMS
 typedef float nt_v4f __attribute__((ext_vector_type(4)));
@@ -62,10 +62,13 @@ template <class T> struct NtPtr {
 template <class T> using SPtr = NtPtr<T>;
 #define RT_SPTR_R(T) NtPtr<T>
 template <class T> __host__ __device__ T* sraw(NtPtr<T> q) { return q.p; }
+// sp<NT>(q): the stream pointer as a kernel wants it - with the hint (q itself) or without (the plain pointer)
+template <bool NT, class T> RT_DEV typename std::conditional<NT, NtPtr<T>, T*>::type sp(NtPtr<T> q) { if constexpr (NT) return q; else return q.p; }
 #else
 template <class T> using SPtr = T*;
 #define RT_SPTR_R(T) T* __restrict__
 template <class T> __host__ __device__ T* sraw(T* q) { return q; }
+template <bool NT, class T> RT_DEV T* sp(T* q) { return q; }
 #endif
 struct PathGen { SPtr<float4> o; SPtr<float4> d; SPtr<float4> beta; SPtr<uint4> st; };  // [slot]: ray (o | t_max), (d | -), throughput (rgb | eta_scale), (packed state, path id, RNG state lo, hi)
 // The records of a vertex's shadow ray and BSDF-sampled MIS ray, PLANAR (round 4; 64- and 128-byte structs with 16 + 44 unused bytes before): a shade wave's
@@ -123,7 +126,6 @@ struct PassState {
   // frames that count the reference's walk.
   int skip_dead_tail;
   const unsigned* range;  // k_shade: shade entries [range[0], range[1]) of q_in only (NULL = all): class-wise dispatch over the binned queue
-  unsigned oct_log2;      // != 0: the continuing paths are appended in runs of 1 << oct_log2 slots per direction octant (block_push_oct); unfilled slots become dead entries
   unsigned long long* stats;  // device-side u64 counters, see ST_* below
 };
 #define RT_NQ 4  // queues a bounce fills
@@ -211,6 +213,13 @@ struct QView {
     return ids ? ids[slot] : slot;
   }
 };
+// Round 6 measured the continuing paths GROUPED BY THE DIRECTION OCTANT of their rays (an LDS-resident scene's closest-hit walk reads one link row per octant and meets its
+// leaves in one order per octant, rc/bvh/mod.rs:366-433) - VERDICT r05 item 2, twice: as runs of ONE octant across a workgroup's iterations (commit 1c259ca: every wave of the
+// next bounce holds one octant; unfilled slots as dead entries) and as octant order inside one iteration's run of 256 slots (two or three octants per wave). S1, one box,
+// interleaved: runs - closest hit 184 -> 168 ms, occlusion rays 90 -> 114, shade 220 -> 236; order inside the run - closest hit 189 -> 184, occlusion rays 94 -> 100 - 117,
+// shade +1 - 4. What the order costs is what is still addressed by PATH ID: the any-hit epilogue's read-modify-write of lacc[path] (1.6 G per S1 frame) touches 8x / 4x the
+// lines once the paths of a wave are no longer neighbours (1.6 G x 2 x 64 B = 26 ms at 8 TB/s: the loss), and a shade wave's record stores go to eight runs. Not kept
+// (MEASUREMENTS R6); S3 / mis-spheres +0.3 / +1.6 %.
 // Block-aggregated append to up to three sharded device queues: one returning atomic per queue per
 // 256-lane iteration, on the counter word of this block's shard. Must be reached by every thread of
 // the block. Returns the absolute slot for each queue (valid where pred).
@@ -237,75 +246,6 @@ RT_DEV void block_push(unsigned* counters, unsigned shard_cap, const int* queue_
   for (int q = 0; q < NQ; ++q) slot[q] = s_base[q] + s_cnt[q][wave] + (unsigned)__popcll(mask[q] & ((1ull << lane) - 1ull));
   __syncthreads();
 }
-
-// ---- Round 6: the continuation queue grouped by DIRECTION OCTANT. An LDS-resident scene's closest-hit walk reads one link row per octant and meets its
-// leaves in one order per octant (BVH::intersect's visiting order is a function of the signs of the direction, rc/bvh/mod.rs:366-433), so a wave whose 64 rays share an
-// octant reads ONE row and walks more alike. Round 3 had sharded the queue by octant and lost (the queue then held path ids, and the next shade launch gathered its records
-// through them); since round 4 the records travel with their slot, so grouping costs the consumers nothing. Here a workgroup keeps one OPEN RUN of `1 << run_log2` slots per
-// octant (allocated from its shard's counter like the 256-entry runs of block_push: the shards, the counters and entry -> slot stay what they were) and appends a path at the
-// next free slot of its ray's octant's run; runs are multiples of 64 slots and the shard counts multiples of the run, so every 64-entry wave of the next bounce's consumers
-// holds one octant. What is left of a workgroup's open runs when its launch ends is filled with DEAD entries (oct_fill_dead): a ray no box test passes (t_max < 0, origin
-// 1e30 away), which the trace kernel reports as prim = -2 and every consumer skips and does not count. <= 8 * run dead entries per workgroup and launch.
-struct OctRuns { unsigned next[8], left[8]; };  // (LDS, workgroup-uniform) next free slot and free slots of each octant's open run
-#define RT_DEAD_PRIM (-2)
-template <int NQ>
-RT_DEV void block_push_oct(unsigned* counters, unsigned shard_cap, const bool* pred /* [NQ], pred[0] = the path continues */, unsigned oct, unsigned run_log2, OctRuns& runs, unsigned* slot) {
-  constexpr int NR = NQ + 7;  // rows 0 - 7: the octants of queue 0; rows 8 ...: queues 1 .. NQ - 1
-  __shared__ unsigned s_cnt[NR][16];
-  __shared__ unsigned s_base[NR], s_split[8], s_base2[8];
-  const unsigned lane = __lane_id(), wave = threadIdx.x >> 6, n_waves = (blockDim.x + 63u) >> 6;
-  const unsigned shard = blockIdx.x & (RT_QSHARDS - 1);
-  unsigned my_rank = 0;  // among the lanes of this wave that append to the same octant
-  unsigned long long mask_q[NQ];
-#pragma unroll
-  for (int r = 0; r < 8; ++r) {
-    const unsigned long long m = __ballot(pred[0] && oct == (unsigned)r);
-    if (lane == 0) s_cnt[r][wave] = (unsigned)__popcll(m);
-    const unsigned rk = __builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0u));
-    my_rank = oct == (unsigned)r ? rk : my_rank;
-  }
-#pragma unroll
-  for (int q = 1; q < NQ; ++q) { mask_q[q] = __ballot(pred[q]); if (lane == 0) s_cnt[7 + q][wave] = (unsigned)__popcll(mask_q[q]); }
-  __syncthreads();
-  if (threadIdx.x < NR) {
-    const unsigned r = threadIdx.x;
-    unsigned total = 0;
-    for (unsigned w = 0; w < n_waves; ++w) { unsigned c = s_cnt[r][w]; s_cnt[r][w] = total; total += c; }
-    if (r >= 8u) s_base[r] = shard * shard_cap + (total ? atomicAdd(&counters[((r - 7u) * RT_QSHARDS + shard) * RT_CNT_STRIDE], total) : 0u);
-    else {
-      const unsigned left = runs.left[r], next = runs.next[r];
-      s_base[r] = next;
-      if (total <= left) { s_split[r] = 0xffffffffu; runs.next[r] = next + total; runs.left[r] = left - total; }
-      else {  // the open run takes `left` of them, new runs (contiguous: one add) the rest
-        const unsigned need = total - left, n_new = (need + (1u << run_log2) - 1u) >> run_log2;
-        const unsigned nb = shard * shard_cap + atomicAdd(&counters[shard * RT_CNT_STRIDE], n_new << run_log2);
-        s_split[r] = left; s_base2[r] = nb; runs.next[r] = nb + need; runs.left[r] = (n_new << run_log2) - need;
-      }
-    }
-  }
-  __syncthreads();
-  {
-    const unsigned o = pred[0] ? oct : 0u;
-    const unsigned k = s_cnt[o][wave] + my_rank, sp = s_split[o];
-    slot[0] = k < sp ? s_base[o] + k : s_base2[o] + (k - sp);
-  }
-#pragma unroll
-  for (int q = 1; q < NQ; ++q) slot[q] = s_base[7 + q] + s_cnt[7 + q][wave] + (unsigned)__popcll(mask_q[q] & ((1ull << lane) - 1ull));
-  __syncthreads();
-}
-// the workgroup's open runs are closed at the end of its launch: their free slots become dead entries. Reached by every thread of the workgroup.
-RT_DEV void oct_fill_dead(const PathGen& out, const OctRuns& runs) {
-  __syncthreads();
-#pragma unroll 1
-  for (int r = 0; r < 8; ++r) {
-    const unsigned n = runs.left[r], b = runs.next[r];
-    for (unsigned k = threadIdx.x; k < n; k += blockDim.x) {
-      out.o[b + k] = make_float4(1e30f, 1e30f, 1e30f, -1.0f); out.d[b + k] = make_float4(1.0f, 1.0f, 1.0f, 0.0f);
-      out.beta[b + k] = make_float4(0.0f, 0.0f, 0.0f, 1.0f); out.st[b + k] = make_uint4(pack_state(1, false, 0, 0), 0u, 0u, 0u);
-    }
-  }
-}
-RT_DEV unsigned dir_octant(f3 d) { return (__float_as_uint(d.x) >> 31) | ((__float_as_uint(d.y) >> 31) << 1) | ((__float_as_uint(d.z) >> 31) << 2); }  // the signs of 1 / d, as the walks take them
 
 // owned-pixel index -> raster pixel (x, y) and keyed pixel index inside the sample bounds
 RT_DEV void owned_pixel(const FrameParams& fp, unsigned long long k, int& x, int& y, unsigned long long& pixel_index) {
@@ -355,7 +295,7 @@ RT_DEV void mark_dirty(unsigned* dirty, unsigned pix) {  // dirty[0] = count, di
   if (k < RT_DIRTY_CAP) dirty[1 + k] = pix;
 }
 
-__global__ void __launch_bounds__(256) k_sampler_draws(FrameParams fp, unsigned n_pixels, unsigned spp, unsigned dims, unsigned seg_len,
+static __global__ void __launch_bounds__(256) k_sampler_draws(FrameParams fp, unsigned n_pixels, unsigned spp, unsigned dims, unsigned seg_len,
                                                        unsigned long long explicit_pixel0, int use_explicit, const SamplerSeg* __restrict__ segs,
                                                        const unsigned* __restrict__ magic, unsigned* __restrict__ scrambles, unsigned short* __restrict__ partners,
                                                        unsigned* dirty, int chain_major) {
@@ -445,7 +385,7 @@ RT_DEV void unpack8(uint4 v, unsigned* o) {
 }
 // blockDim.x = L lanes (one wave at most), blockIdx.y = table
 // `tables`: the launch's tables, 4 bits each (blockIdx.y-th nibble): a frame builds its tables in the order it needs them (rt_render)
-__global__ void __launch_bounds__(64) k_sampler_shuffle(unsigned n_pixels, unsigned spp, const unsigned short* __restrict__ partners, unsigned short* __restrict__ perms, unsigned long long tables) {
+static __global__ void __launch_bounds__(64) k_sampler_shuffle(unsigned n_pixels, unsigned spp, const unsigned short* __restrict__ partners, unsigned short* __restrict__ perms, unsigned long long tables) {
   const unsigned table = (unsigned)(tables >> (4u * blockIdx.y)) & 15u;
   extern __shared__ unsigned short lds_perm[];
   const unsigned lane = threadIdx.x, L = blockDim.x;
@@ -520,11 +460,6 @@ __global__ void __launch_bounds__(64) k_sampler_shuffle(unsigned n_pixels, unsig
 // included). E = spp / 64 steps per lane: instantiated for spp 64 ... 1024; other sample counts keep k_sampler_shuffle.
 #define RT_SHUF_PIX 16
 RT_DEV void wave_sync_lds() { __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup"); __builtin_amdgcn_wave_barrier(); }
-#ifdef RT_K0_STAMP
-#define K0S(k) do { const unsigned long long t_ = clock64(); if (lane == 0u) atomicAdd(&((unsigned long long*)(n_resorted + 2))[k], t_ - t_last); t_last = clock64(); } while (0)
-#else
-#define K0S(k) do { } while (0)
-#endif
 template <int E>
 __global__ void __launch_bounds__(256) k_sampler_shuffle_par(unsigned n_pixels, const unsigned short* __restrict__ partners, unsigned short* __restrict__ perms, unsigned* __restrict__ n_resorted, unsigned long long tables, unsigned force_resort) {
   constexpr unsigned N = 64u * E, NONE = 0xffffu;
@@ -535,9 +470,6 @@ __global__ void __launch_bounds__(256) k_sampler_shuffle_par(unsigned n_pixels, 
   const unsigned lane = threadIdx.x & 63u, wv = threadIdx.x >> 6, t = (unsigned)(tables >> (4u * blockIdx.y)) & 15u, pix0 = blockIdx.x * RT_SHUF_PIX;
   unsigned short* const o = s_o[wv]; unsigned* const cnt = s_cnt[wv]; unsigned short* const wl = s_wl[wv];
   const unsigned short* const cnt16 = (const unsigned short*)cnt;
-#ifdef RT_K0_STAMP
-  unsigned long long t_last = clock64();
-#endif
   // the partners of the workgroup's 16 chains, all requested at once (one memory latency per workgroup, not one per chain): each chain's row of the tile holds
   // its partners until the chain is replayed and its permutation afterwards
   {  // 16-byte loads, all of a thread's in flight together: thread tid takes 16-byte piece tid, tid + 256, ... of the workgroup's 16 x 2 N bytes
@@ -557,7 +489,6 @@ __global__ void __launch_bounds__(256) k_sampler_shuffle_par(unsigned n_pixels, 
     }
   }
   __syncthreads();
-  K0S(0);
   for (unsigned c = wv; c < RT_SHUF_PIX; c += 4u) {
     const unsigned pix = pix0 + c;
     if (pix >= n_pixels) break;  // (wave-uniform)
@@ -581,7 +512,6 @@ __global__ void __launch_bounds__(256) k_sampler_shuffle_par(unsigned n_pixels, 
 #pragma unroll
     for (int m = 0; m < E; ++m) rk[m] = (pk[m] & 1u) ? (rk[m] >> 16) : (rk[m] & 0xffffu);
     wave_sync_lds();
-    K0S(1);
     if (force_resort) {  // test knob (RTX_K0_FORCE_RESORT=1): hand every group its ranks in DESCENDING order, what an atomic unit that served lanes the other way round would
                          // return - the check below then fails for every group of two or more writers and the wave takes the re-sort branch (that branch is
                          // "never seen" on this hardware and would otherwise never be exercised)
@@ -604,14 +534,12 @@ __global__ void __launch_bounds__(256) k_sampler_shuffle_par(unsigned n_pixels, 
       for (int m = 0; m < E; ++m) ((unsigned short*)cnt)[lane * (E + 2u) + (unsigned)m] = (unsigned short)(excl + local[m]);
     }
     wave_sync_lds();
-    K0S(2);
     unsigned bs[E];
 #pragma unroll
     for (int m = 0; m < E; ++m) bs[m] = cnt16[pk[m] + 2u * (pk[m] / (unsigned)E)];
 #pragma unroll
     for (int m = 0; m < E; ++m) wl[bs[m] + rk[m]] = (unsigned short)(64u * (unsigned)m + lane);
     wave_sync_lds();
-    K0S(3);
     unsigned pred[E];  // the writer before step i in its group (sorted: its predecessor in arrival order), NONE for the first
 #pragma unroll
     for (int m = 0; m < E; ++m) pred[m] = wl[bs[m] + (rk[m] > 0u ? rk[m] - 1u : 0u)];
@@ -647,7 +575,6 @@ __global__ void __launch_bounds__(256) k_sampler_shuffle_par(unsigned n_pixels, 
       }
     }
     wave_sync_lds();
-    K0S(4);
     // ... then by pointer jumping (in place: an entry only ever moves to an ancestor) until every entry names the start of its chain
     for (;;) {
       unsigned r[E], rr[E];
@@ -661,7 +588,6 @@ __global__ void __launch_bounds__(256) k_sampler_shuffle_par(unsigned n_pixels, 
       wave_sync_lds();
       if (__ballot(changed) == 0ull) break;
     }
-    K0S(5);
     {  // perm[i]: the target's own index for its first writer, else what the writer before it moved there
       unsigned val[E];
 #pragma unroll
@@ -670,10 +596,8 @@ __global__ void __launch_bounds__(256) k_sampler_shuffle_par(unsigned n_pixels, 
       for (int m = 0; m < E; ++m) tile[c][64u * (unsigned)m + lane] = (unsigned short)(pred[m] != NONE ? val[m] : pk[m]);
     }
     wave_sync_lds();
-    K0S(6);
   }
   __syncthreads();
-  K0S(7);
   // perms[table][sample][pixel]: a thread gathers sample i of the 16 chains (neighbouring lanes read neighbouring entries of a row) and stores 32 contiguous bytes
   unsigned short* const out = perms + (size_t)t * N * n_pixels;
   if ((n_pixels & 7u) == 0u && pix0 + RT_SHUF_PIX <= n_pixels) {
@@ -688,12 +612,11 @@ __global__ void __launch_bounds__(256) k_sampler_shuffle_par(unsigned n_pixels, 
     for (unsigned i = threadIdx.x; i < N; i += 256u)
       for (unsigned c = 0; c < RT_SHUF_PIX; ++c) if (pix0 + c < n_pixels) out[(size_t)i * n_pixels + pix0 + c] = tile[c][i];
   }
-  K0S(8);
 }
 
 // K0c: the swap partners and scrambles of the (rare) pixels whose stream holds a retry, redone from the start of
 // the stream in order, one lane per pixel, before K0b consumes them.
-__global__ void __launch_bounds__(64) k_sampler_redo(FrameParams fp, unsigned n_pixels, unsigned spp, unsigned dims,
+static __global__ void __launch_bounds__(64) k_sampler_redo(FrameParams fp, unsigned n_pixels, unsigned spp, unsigned dims,
                                                      unsigned long long explicit_pixel0, int use_explicit, unsigned* dirty,
                                                      const unsigned* __restrict__ magic, unsigned* scrambles, unsigned short* partners, int chain_major) {
   const unsigned k = blockIdx.x * blockDim.x + threadIdx.x;
@@ -724,7 +647,7 @@ __global__ void __launch_bounds__(64) k_sampler_redo(FrameParams fp, unsigned n_
 
 // The plain statement of the whole algorithm, one lane per pixel (kept as the in-tree cross-check of K0a-c:
 // rt_sampler_tables(..., RT_SAMPLER_PLAIN)).
-__global__ void k_sampler_tables(FrameParams fp, unsigned n_pixels, unsigned spp, unsigned dims,
+static __global__ void k_sampler_tables(FrameParams fp, unsigned n_pixels, unsigned spp, unsigned dims,
                                  unsigned long long explicit_pixel0, int use_explicit, unsigned* scrambles, unsigned short* perms) {
   extern __shared__ unsigned short lds_perm[];
   const unsigned lane = threadIdx.x;
@@ -822,7 +745,7 @@ RT_DEV CameraRay generate_camera_ray(const FrameParams& fp, f2 p_film, f2 p_lens
   return r;
 }
 
-__global__ void __launch_bounds__(256) k_raygen(FrameParams fp, PassState ps) {
+static __global__ void __launch_bounds__(256) k_raygen(FrameParams fp, PassState ps) {
   const unsigned stride = gridDim.x * blockDim.x;
   const Tables tb = tables_of(ps);
   unsigned n_camera = 0;
@@ -915,201 +838,29 @@ RT_DEV void stage_small_scene(const DScene& sc, float* s_nodes, float* s_tris) {
   }
 }
 
-// ---- The walks of an LDS-resident scene of plain triangles WITHOUT a stack (FINITE: the node test of a finite ray, slab_test_finite; otherwise the reference's
-// selects). The order in which BVH::intersect reaches the nodes depends on the ray only through the signs of its direction, so "the entry on top of the
-// to-visit stack when the walk reaches node i" is a constant of (octant, i): DScene::skip8, staged into LDS. A node step is then the box test and a select
-// between the near child and the link - no push, no pop, no stack memory (the closest-hit kernel: 17.5 KB of LDS per 256 lanes instead of 21.5, 13.9 for
-// occlusion rays). Per ray the sequence of node tests, primitive tests and t_max updates is the reference's: a far child is tested when the reference pops
-// it, with the t_max of that moment.
-// Occlusion rays: intersect_p's answer is a property of the tree and the ray alone - "some primitive passes its test and every box above it passes the node
-// test" (t_max never shrinks; bvh/mod.rs:443-500 returns at the first accepted primitive) - so they all walk in ONE order, octant 0's = array order, and
-// the kernel stages one row of links.
+// ---- The walks of an LDS-resident scene WITHOUT a stack, over LINK tables (FINITE: the node test of a finite ray, slab_test_finite; otherwise the reference's selects).
+// The order in which BVH::intersect reaches the nodes depends on the ray only through the signs of its direction, so "where the walk goes when node i's box passes" and
+// "where it carries on after node i and everything below it" are constants of (octant, i): one word per (octant, node), DScene::link8, staged into LDS. A node step is the box
+// test and one select - no push, no pop, no stack memory. Per ray the sequence of leaf-box tests, primitive tests and t_max updates is the reference's: a far child is tested
+// when the reference pops it, with the t_max of that moment. Rounds 4 - 5 walked over a skip table first (closest_small / occluded_small: next node from the node record's
+// split axis and second child) - replaced by the link words, which also let the tables LEAVE NODES OUT:
+// a node's box CONTAINS its children's boxes (bvh/mod.rs:279-287: an interior node's bounds are the union), so for a finite ray an interior node's test fails only if both
+// children's tests fail too (minima / maxima are monotone in the box, slab_test_finite) - the test of an interior node decides nothing, it only saves work when it fails.
+// rt_scene_create measures, on synthetic path-like rays, which interior nodes' tests save less than they cost and leaves those out of link8 (S1: 8 of 19 interior nodes stay;
+// 18.5 -> 12.3 node tests per ray); the walk visits the same leaves in the same order with the same t_max - every leaf is still tested against its own box at its own time,
+// which is all BVH::intersect's result depends on. Rays with a zero direction component keep every node (link8_full, read from HBM by the few hundred waves that hold one):
+// the literal node test's NaN rules are not the minima / maxima the argument needs.
+// Occlusion rays: intersect_p's answer is a property of the tree and the ray alone - "some primitive passes its test and every box above it passes the node test" (t_max never
+// shrinks; bvh/mod.rs:443-500 returns at the first accepted primitive) - so they all walk ONE row (row 8: an order the calibration chose) and the kernel stages one row of links.
+// Quadrics and masked triangles in the leaves (GENERAL) go through leaf_prim_test inside the same walks.
 #ifndef RT_ANY_EARLY_SIGN
 #define RT_ANY_EARLY_SIGN 1
-#endif
-// Measurement builds (EXTRA=-DRT_TRACE_PROBE): how the lanes of a wave spend the rounds of the LDS walks. g_probe[0 / 1]: occlusion walk, rounds x 64 and lanes
-// that stepped; [2 / 3]: closest-hit node rounds x 64 and lanes that stepped; [4 / 5]: its leaf phases x 64 and lanes that tested; [6 / 7]: per wave the LONGEST
-// lane's steps x 64 against all lanes' steps (the tail: what a wave that could hand finished lanes new work would save). Printed by rt_render (RTX_PROBE=1).
-#ifdef RT_TRACE_PROBE
-__device__ unsigned long long g_probe[16];
-#define RT_PROBE_ADD(k, v) do { if ((threadIdx.x & 63u) == 0u) atomicAdd(&g_probe[k], (unsigned long long)(v)); } while (0)
-#else
-#define RT_PROBE_ADD(k, v) do { } while (0)
-#endif
-template <int N, int T, bool FINITE>
-RT_DEV bool occluded_small(const float* __restrict__ s_nodes, const float* __restrict__ s_tris, const unsigned short* __restrict__ s_skip, const int n_nodes, const Ray ray) {
-  const f3 inv_dir = mk3(1.0f / ray.d.x, 1.0f / ray.d.y, 1.0f / ray.d.z);
-  const RayPre rp = ray_pre(ray);
-  const float* const tpx = s_tris + rp.kx * T; const float* const tpy = s_tris + rp.ky * T; const float* const tpz = s_tris + rp.kz * T;
-  const f3 op = permute(ray.o, rp.kx, rp.ky, rp.kz);
-  bool found = false;
-  int cur = 0;  // n_nodes: done
-#ifdef RT_TRACE_PROBE
-  unsigned pr_rounds = 0, pr_mine = 0;
-#endif
-  for (;;) {
-#ifdef RT_TRACE_PROBE
-    pr_rounds += 1; pr_mine += cur < n_nodes ? 1u : 0u;
-#endif
-    if (cur < n_nodes) {
-      const float* nd = s_nodes + cur;
-      const float4 n0 = make_float4(nd[0], nd[2 * N], nd[4 * N], nd[N]), n1 = make_float4(nd[3 * N], nd[5 * N], 0.0f, 0.0f);
-      const bool hit = slab_test_t<FINITE>(n0, n1, ray, inv_dir, inv_dir.x < 0.0f, inv_dir.y < 0.0f, inv_dir.z < 0.0f);
-      int next = hit ? cur + 1 : (int)s_skip[cur];
-      if (hit) {
-        const int n_prims = (int)(__float_as_uint(nd[7 * N]) & 0xffffu);
-        if (n_prims != 0) {
-          const int off = __float_as_int(nd[6 * N]);
-          for (int i = 0; i < n_prims; ++i) {
-            const int t = off + i;
-            const f3 p0t = mk3(tpx[t] - op.x, tpy[t] - op.y, tpz[t] - op.z), p1t = mk3(tpx[3 * T + t] - op.x, tpy[3 * T + t] - op.y, tpz[3 * T + t] - op.z),
-                     p2t = mk3(tpx[6 * T + t] - op.x, tpy[6 * T + t] - op.y, tpz[6 * T + t] - op.z);
-            TriHit h;
-            if (tri_test_permuted<RT_ANY_EARLY_SIGN != 0>(p0t, p1t, p2t, rp.sx, rp.sy, rp.sz, ray.t_max, h)) { found = true; next = n_nodes; break; }
-          }
-        }
-      }
-      cur = next;
-    }
-    if (__ballot(cur < n_nodes) == 0ull) break;
-  }
-#ifdef RT_TRACE_PROBE
-  { unsigned tot = pr_mine; for (int off = 32; off > 0; off >>= 1) tot += __shfl_down(tot, off); RT_PROBE_ADD(0, 64u * pr_rounds); RT_PROBE_ADD(1, tot); }
-#endif
-  return found;
-}
-// (Measured and not kept: holding a reached leaf until 4 / 8 / 12 / 16 lanes of the wave hold one, one primitive per phase - shadow rays 124 -> 130 / 135.5 / 140 /
-// 144 ms per S1 frame. A holder's wait costs more node rounds than the fuller triangle tests return.)
-//
-// Round 5: the occlusion walk with its primitive tests DEFERRED. occluded_small tests a leaf's primitives inside the node step, so in almost every round of the
-// wave two or three lanes run a triangle test (~100 instructions) while the others wait: 34 % of the lanes busy over the kernel, worse than the closest-hit
-// walk. But intersect_p's answer does not depend on WHEN a primitive is tested (t_max never shrinks), so a lane that reaches a leaf only notes it - up to six
-// pending leaves, ten bits each, in one 64-bit register - and walks on; nobody waits. Whenever LEAF_MIN lanes have something pending (or nobody can walk), every
-// lane with pending work tests ONE primitive: the triangle tests run at half the wave or more instead of at 3 - 5 lanes. A lane whose list is full stops
-// walking until a phase has taken an entry. Same answer: the set of (leaf box passes, primitive passes) pairs examined is a superset-until-found of the
-// reference's, and found = any of them.
-#ifndef RT_LDS_ANY_DEFER_MIN
-#define RT_LDS_ANY_DEFER_MIN 0  // measured (S1, two interleaved rounds): shadow rays 116.8 ms without, 117.6 / 115.2 / 117.7 at 16 / 32 / 48 - nothing: the occlusion kernel does not wait for its VALUs
-#endif
-template <int N, int T, bool FINITE, int LEAF_MIN>
-RT_DEV bool occluded_small_deferred(const float* __restrict__ s_nodes, const float* __restrict__ s_tris, const unsigned short* __restrict__ s_skip, const int n_nodes, const Ray ray) {
-  const f3 inv_dir = mk3(1.0f / ray.d.x, 1.0f / ray.d.y, 1.0f / ray.d.z);
-  const RayPre rp = ray_pre(ray);
-  const float* const tpx = s_tris + rp.kx * T; const float* const tpy = s_tris + rp.ky * T; const float* const tpz = s_tris + rp.kz * T;
-  const f3 op = permute(ray.o, rp.kx, rp.ky, rp.kz);
-  bool found = false;
-  int cur = 0;                     // n_nodes: nothing left to visit
-  unsigned long long pend = 0ull;  // pending leaves, (node index + 1) in ten bits each, the latest in bits 0-9
-  int leaf_off = 0, leaf_n = 0;    // the leaf being tested: leaf_n primitives from leaf_off on are still untested
-  for (;;) {
-    if (cur < n_nodes && (pend >> 50) == 0ull) {
-      const float* nd = s_nodes + cur;
-      const float4 n0 = make_float4(nd[0], nd[2 * N], nd[4 * N], nd[N]), n1 = make_float4(nd[3 * N], nd[5 * N], 0.0f, 0.0f);
-      const bool hit = slab_test_t<FINITE>(n0, n1, ray, inv_dir, inv_dir.x < 0.0f, inv_dir.y < 0.0f, inv_dir.z < 0.0f);
-      const int next = hit ? cur + 1 : (int)s_skip[cur];
-      if (hit && (__float_as_uint(nd[7 * N]) & 0xffffu) != 0u) pend = (pend << 10) | (unsigned long long)(cur + 1);
-      cur = next;
-    }
-    const bool has = (pend != 0ull) | (leaf_n > 0);
-    const unsigned long long walkers = __ballot(cur < n_nodes && (pend >> 50) == 0ull), havers = __ballot(has);
-    if ((walkers | havers) == 0ull) break;
-    if (walkers == 0ull || __builtin_popcount((unsigned)havers) + __builtin_popcount((unsigned)(havers >> 32)) >= LEAF_MIN) {
-      if (has) {
-        if (leaf_n == 0) {
-          const int node = (int)(pend & 1023ull) - 1; pend >>= 10;
-          leaf_off = __float_as_int(s_nodes[6 * N + node]); leaf_n = (int)(__float_as_uint(s_nodes[7 * N + node]) & 0xffffu);
-        }
-        const int t = leaf_off;
-        const f3 p0t = mk3(tpx[t] - op.x, tpy[t] - op.y, tpz[t] - op.z), p1t = mk3(tpx[3 * T + t] - op.x, tpy[3 * T + t] - op.y, tpz[3 * T + t] - op.z),
-                 p2t = mk3(tpx[6 * T + t] - op.x, tpy[6 * T + t] - op.y, tpz[6 * T + t] - op.z);
-        TriHit h;
-        if (tri_test_permuted<RT_ANY_EARLY_SIGN != 0>(p0t, p1t, p2t, rp.sx, rp.sy, rp.sz, ray.t_max, h)) { found = true; cur = n_nodes; pend = 0ull; leaf_n = 0; }
-        else { leaf_off += 1; leaf_n -= 1; }
-      }
-    }
-  }
-  return found;
-}
-// Closest hit: rounds (every walking lane takes one node; when LEAF_MIN lanes hold a leaf, or none walks, every holder tests ONE primitive - a holder with more
-// stays a holder; whole leaves per phase: closest hit 256 ms per S1 frame against 248).
-template <int N, int T, bool FINITE, int LEAF_MIN>
-RT_DEV bool closest_small(const float* __restrict__ s_nodes, const float* __restrict__ s_tris, const unsigned short* __restrict__ s_skip8, const int n_nodes, Ray ray, int& prim_out, TriHit& hit_out) {
-  const f3 inv_dir = mk3(1.0f / ray.d.x, 1.0f / ray.d.y, 1.0f / ray.d.z);
-  const int neg_x = inv_dir.x < 0.0f, neg_y = inv_dir.y < 0.0f, neg_z = inv_dir.z < 0.0f;
-  const unsigned oct = (neg_x ? 1u : 0u) | (neg_y ? 2u : 0u) | (neg_z ? 4u : 0u), negmask = oct << 16;
-  const unsigned short* const skip = s_skip8 + oct * N;
-  const RayPre rp = ray_pre(ray);
-  const float* const tpx = s_tris + rp.kx * T; const float* const tpy = s_tris + rp.ky * T; const float* const tpz = s_tris + rp.kz * T;
-  const f3 op = permute(ray.o, rp.kx, rp.ky, rp.kz);
-  bool found = false;
-  int cur = 0, leaf_off = 0, leaf_n = 0;  // cur == n_nodes: nothing left to visit; leaf_n > 0: the lane holds that many untested primitives from leaf_off on (cur already names what follows the leaf)
-#ifdef RT_TRACE_PROBE
-  unsigned pr_w = 0, pr_wm = 0, pr_l = 0, pr_lm = 0;
-#endif
-  for (;;) {
-    unsigned long long holders = 0ull;
-    for (;;) {
-#ifdef RT_TRACE_PROBE
-      pr_w += 1; pr_wm += (leaf_n == 0 && cur < n_nodes) ? 1u : 0u;
-#endif
-      if (leaf_n == 0 && cur < n_nodes) {
-        const float* nd = s_nodes + cur;
-        const float4 n0 = make_float4(nd[0], nd[2 * N], nd[4 * N], nd[N]), n1 = make_float4(nd[3 * N], nd[5 * N], 0.0f, 0.0f);
-        const int offset = __float_as_int(nd[6 * N]); const unsigned ctl = __float_as_uint(nd[7 * N]);
-        int next = (int)skip[cur];
-        if (slab_test_t<FINITE>(n0, n1, ray, inv_dir, neg_x, neg_y, neg_z)) {
-          const int n_prims = (int)(ctl & 0xffffu);
-          if (n_prims != 0) { leaf_off = offset; leaf_n = n_prims; }
-          else next = (ctl & negmask) != 0u ? offset : cur + 1;
-        }
-        cur = next;
-      }
-      holders = __ballot(leaf_n > 0);
-      if (__ballot(leaf_n == 0 && cur < n_nodes) == 0ull) break;
-      if (__builtin_popcount((unsigned)holders) + __builtin_popcount((unsigned)(holders >> 32)) >= LEAF_MIN) break;  // (two 32-bit counts: the 64-bit count's compare is compiled as a VECTOR compare)
-    }
-    if (holders == 0ull) break;
-#ifdef RT_TRACE_PROBE
-    pr_l += 1; pr_lm += leaf_n > 0 ? 1u : 0u;
-#endif
-    if (leaf_n > 0) {
-      const int t = leaf_off;
-      const f3 p0t = mk3(tpx[t] - op.x, tpy[t] - op.y, tpz[t] - op.z), p1t = mk3(tpx[3 * T + t] - op.x, tpy[3 * T + t] - op.y, tpz[3 * T + t] - op.z),
-               p2t = mk3(tpx[6 * T + t] - op.x, tpy[6 * T + t] - op.y, tpz[6 * T + t] - op.z);
-      TriHit h;
-      if (tri_test_permuted(p0t, p1t, p2t, rp.sx, rp.sy, rp.sz, ray.t_max, h)) { found = true; ray.t_max = h.t; prim_out = t; hit_out = h; }  // `.or(result)`: later accepted hits replace
-      leaf_off += 1; leaf_n -= 1;
-    }
-  }
-#ifdef RT_TRACE_PROBE
-  { unsigned a = pr_wm, b = pr_lm, mx = pr_wm + pr_lm, sm = pr_wm + pr_lm;
-    for (int off = 32; off > 0; off >>= 1) { a += __shfl_down(a, off); b += __shfl_down(b, off); sm += __shfl_down(sm, off); const unsigned o = __shfl_down(mx, off); mx = o > mx ? o : mx; }
-    RT_PROBE_ADD(2, 64u * pr_w); RT_PROBE_ADD(3, a); RT_PROBE_ADD(4, 64u * pr_l); RT_PROBE_ADD(5, b); RT_PROBE_ADD(6, 64u * mx); RT_PROBE_ADD(7, sm); }
-#endif
-  return found;
-}
-
-// ---- Round 5: the stackless walks over LINKS, and over fewer nodes. closest_small / occluded_small find the next node from the node's record (split axis, second child)
-// and the skip table; here one word per (octant, node) says both - where the walk goes when the node's box passes (interior nodes), where it carries on after the node's subtree -
-// so the node step is the box test and one select. And the tables need not name every node: a node's box CONTAINS its children's boxes (bvh/mod.rs:279-287: an interior node's
-// bounds are the union), so for a finite ray an interior node's test fails only if both children's tests fail too (minima / maxima are monotone in the box, slab_test_finite) -
-// the test of an interior node decides nothing, it only saves work when it fails. rt_scene_create measures, on synthetic path-like rays, which interior nodes' tests save less
-// than they cost and leaves those out of link8 (S1: 8 of 19 interior nodes stay; 18.5 -> 12.3 node tests per ray); the walk visits the same leaves in the same order with the same
-// t_max - every leaf is still tested against its own box at its own time, which is all BVH::intersect's result depends on. Rays with a zero direction component keep every node
-// (link8_full, read from HBM by the few hundred waves that hold one): the literal node test's NaN rules are not the minima / maxima the argument needs.
-#ifndef RT_LDS_LINKS
-#define RT_LDS_LINKS 1
-#endif
-#ifndef RT_LDS_LINKS_GENERAL
-#define RT_LDS_LINKS_GENERAL 1  // LDS-resident scenes with quadrics / masked triangles walk the link tables too (0: the stack walk, traverse_rounds / traverse)
 #endif
 // a leaf's primitives in its link word: first primitive from bit 16 up (7 bits for the 128-primitive LDS scenes, 11 for the mid-size ones), the count above it
 #define RT_LINK_OFF_BITS(N) ((N) > 256 ? 11 : 7)
 #define RT_LINK_LEAF_OFF(lk, N) ((int)(((lk) >> 16) & ((1u << RT_LINK_OFF_BITS(N)) - 1u)))
 #define RT_LINK_LEAF_N(lk, N) ((int)(((lk) & 0x7fffffffu) >> (16 + RT_LINK_OFF_BITS(N))))
-#ifndef RT_LINK_LEAF
-#define RT_LINK_LEAF 1  // a leaf's link word carries its primitives in the half an interior node's uses for "enter": bit 31, count << 23, first << 16 (<= 128 primitives)
-#endif
+// (a leaf's link word carries its primitives in the half an interior node's uses for "enter": bit 31, count above the first primitive's bits)
 // GENERAL != 0 (round 5): leaves may hold quadrics and masked triangles (leaf_prim_test; a plain triangle of such a scene takes tri_test_pre as in the stack walk it replaces)
 template <int N, int T, bool FINITE, int GENERAL = 0>
 RT_DEV bool occluded_small_links(const float* __restrict__ s_nodes, const float* __restrict__ s_tris, const unsigned* __restrict__ link /* the occlusion walk's row */, const int n_nodes, const int start, const Ray ray, const GeneralCtx gen = GeneralCtx{nullptr, false}) {
@@ -1127,22 +878,15 @@ RT_DEV bool occluded_small_links(const float* __restrict__ s_nodes, const float*
       const bool hit = slab_test_t<FINITE>(n0, n1, ray, inv_dir, inv_dir.x < 0.0f, inv_dir.y < 0.0f, inv_dir.z < 0.0f);
       int next = (int)(lk & 0xffffu);
       if (hit) {
-#if RT_LINK_LEAF
         const int n_prims = (int)(lk >> 31) * RT_LINK_LEAF_N(lk, N);
         if (n_prims != 0) {
           const int off = RT_LINK_LEAF_OFF(lk, N);
-#else
-        const int n_prims = (int)(__float_as_uint(nd[7 * N]) & 0xffffu);
-        if (n_prims != 0) {
-          const int off = __float_as_int(nd[6 * N]);
-#endif
           for (int i = 0; i < n_prims; ++i) {
             const int t = off + i;
-            const f3 p0t = mk3(tpx[t] - op.x, tpy[t] - op.y, tpz[t] - op.z), p1t = mk3(tpx[3 * T + t] - op.x, tpy[3 * T + t] - op.y, tpz[3 * T + t] - op.z),
-                     p2t = mk3(tpx[6 * T + t] - op.x, tpy[6 * T + t] - op.y, tpz[6 * T + t] - op.z);
             TriHit h;
             if (GENERAL) { if (leaf_prim_test<GENERAL>(LdsSrcT<N, T>{s_nodes, s_tris}, gen, t, ray, rp, h)) { found = true; next = n_nodes; break; } }
-            else if (tri_test_permuted<RT_ANY_EARLY_SIGN != 0>(p0t, p1t, p2t, rp.sx, rp.sy, rp.sz, ray.t_max, h)) { found = true; next = n_nodes; break; }
+            else { const f3 p0t = mk3(tpx[t] - op.x, tpy[t] - op.y, tpz[t] - op.z), p1t = mk3(tpx[3 * T + t] - op.x, tpy[3 * T + t] - op.y, tpz[3 * T + t] - op.z), p2t = mk3(tpx[6 * T + t] - op.x, tpy[6 * T + t] - op.y, tpz[6 * T + t] - op.z);  /* (the LDS planes of plain triangles: read where they are tested - the GENERAL and TRIS_GLOBAL instantiations never index s_tris here) */
+              if (tri_test_permuted<RT_ANY_EARLY_SIGN != 0>(p0t, p1t, p2t, rp.sx, rp.sy, rp.sz, ray.t_max, h)) { found = true; next = n_nodes; break; } }
           }
         } else next = (int)(lk >> 16);
       }
@@ -1173,14 +917,8 @@ RT_DEV bool closest_small_links(const float* __restrict__ s_nodes, const float* 
         const unsigned lk = link[cur];
         int next = (int)(lk & 0xffffu);
         if (slab_test_t<FINITE>(n0, n1, ray, inv_dir, neg_x, neg_y, neg_z)) {
-#if RT_LINK_LEAF
           if ((int)lk < 0) { leaf_off = RT_LINK_LEAF_OFF(lk, N); leaf_n = RT_LINK_LEAF_N(lk, N); }
           else next = (int)(lk >> 16);
-#else
-          const int n_prims = (int)(__float_as_uint(nd[7 * N]) & 0xffffu);
-          if (n_prims != 0) { leaf_off = __float_as_int(nd[6 * N]); leaf_n = n_prims; }
-          else next = (int)(lk >> 16);
-#endif
         }
         cur = next;
       }
@@ -1191,12 +929,11 @@ RT_DEV bool closest_small_links(const float* __restrict__ s_nodes, const float* 
     if (holders == 0ull) break;
     if (leaf_n > 0) {
       const int t = leaf_off;
-      const f3 p0t = mk3(tpx[t] - op.x, tpy[t] - op.y, tpz[t] - op.z), p1t = mk3(tpx[3 * T + t] - op.x, tpy[3 * T + t] - op.y, tpz[3 * T + t] - op.z),
-               p2t = mk3(tpx[6 * T + t] - op.x, tpy[6 * T + t] - op.y, tpz[6 * T + t] - op.z);
       TriHit h;
       if (GENERAL) { if (leaf_prim_test<GENERAL>(LdsSrcT<N, T>{s_nodes, s_tris}, gen, t, ray, rp, h)) { found = true; ray.t_max = h.t; prim_out = t; hit_out = h; } }
       else if (TRIS_GLOBAL) { f3 q0, q1, q2; load_tri(tri_p, t, q0, q1, q2); if (tri_test_pre(q0, q1, q2, ray, rp, h)) { found = true; ray.t_max = h.t; prim_out = t; hit_out = h; } }
-      else if (tri_test_permuted(p0t, p1t, p2t, rp.sx, rp.sy, rp.sz, ray.t_max, h)) { found = true; ray.t_max = h.t; prim_out = t; hit_out = h; }
+      else { const f3 p0t = mk3(tpx[t] - op.x, tpy[t] - op.y, tpz[t] - op.z), p1t = mk3(tpx[3 * T + t] - op.x, tpy[3 * T + t] - op.y, tpz[3 * T + t] - op.z), p2t = mk3(tpx[6 * T + t] - op.x, tpy[6 * T + t] - op.y, tpz[6 * T + t] - op.z);  /* (the LDS planes of plain triangles: read where they are tested - the GENERAL and TRIS_GLOBAL instantiations never index s_tris here) */
+        if (tri_test_permuted(p0t, p1t, p2t, rp.sx, rp.sy, rp.sz, ray.t_max, h)) { found = true; ray.t_max = h.t; prim_out = t; hit_out = h; } }
       leaf_off += 1; leaf_n -= 1;
     }
   }
@@ -1221,14 +958,8 @@ RT_DEV bool occluded_small_links_rounds(const float* __restrict__ s_nodes, const
         const unsigned lk = link[cur];
         int next = (int)(lk & 0xffffu);
         if (slab_test_t<FINITE>(n0, n1, ray, inv_dir, neg_x, neg_y, neg_z)) {
-#if RT_LINK_LEAF
           if ((int)lk < 0) { leaf_off = RT_LINK_LEAF_OFF(lk, N); leaf_n = RT_LINK_LEAF_N(lk, N); }
           else next = (int)(lk >> 16);
-#else
-          const int n_prims = (int)(__float_as_uint(nd[7 * N]) & 0xffffu);
-          if (n_prims != 0) { leaf_off = __float_as_int(nd[6 * N]); leaf_n = n_prims; }
-          else next = (int)(lk >> 16);
-#endif
         }
         cur = next;
       }
@@ -1239,75 +970,16 @@ RT_DEV bool occluded_small_links_rounds(const float* __restrict__ s_nodes, const
     if (holders == 0ull) break;
     if (leaf_n > 0) {
       const int t = leaf_off;
-      const f3 p0t = mk3(tpx[t] - op.x, tpy[t] - op.y, tpz[t] - op.z), p1t = mk3(tpx[3 * T + t] - op.x, tpy[3 * T + t] - op.y, tpz[3 * T + t] - op.z),
-               p2t = mk3(tpx[6 * T + t] - op.x, tpy[6 * T + t] - op.y, tpz[6 * T + t] - op.z);
       TriHit h;
       leaf_off += 1; leaf_n -= 1;
       if (GENERAL) { if (leaf_prim_test<GENERAL>(LdsSrcT<N, T>{s_nodes, s_tris}, gen, t, ray, rp, h)) { found = true; cur = n_nodes; leaf_n = 0; } }
-      else if (tri_test_permuted<RT_ANY_EARLY_SIGN != 0>(p0t, p1t, p2t, rp.sx, rp.sy, rp.sz, ray.t_max, h)) { found = true; cur = n_nodes; leaf_n = 0; }
+      else { const f3 p0t = mk3(tpx[t] - op.x, tpy[t] - op.y, tpz[t] - op.z), p1t = mk3(tpx[3 * T + t] - op.x, tpy[3 * T + t] - op.y, tpz[3 * T + t] - op.z), p2t = mk3(tpx[6 * T + t] - op.x, tpy[6 * T + t] - op.y, tpz[6 * T + t] - op.z);  /* (the LDS planes of plain triangles: read where they are tested - the GENERAL and TRIS_GLOBAL instantiations never index s_tris here) */
+        if (tri_test_permuted<RT_ANY_EARLY_SIGN != 0>(p0t, p1t, p2t, rp.sx, rp.sy, rp.sz, ray.t_max, h)) { found = true; cur = n_nodes; leaf_n = 0; } }
     }
   }
   return found;
 }
 
-// Round 5: the closest-hit walk of an LDS-resident scene in which NOBODY WAITS. In closest_small a lane that reaches a leaf holds it until
-// LEAF_MIN lanes hold one - 48.6 % of the lanes step in a node round, 29.2 % test in a leaf phase (probe build, S1). It has to wait because what follows the leaf
-// is tested against the t_max the leaf leaves behind. Here the lane notes the leaf (FIFO of up to six node ids in one 64-bit register) and WALKS ON with the t_max
-// it has - a stale, larger t_max only lets more boxes pass, so what it notes is a superset, in the reference's order, of the leaves BVH::intersect visits. When a
-// leaf phase comes the lane takes its OLDEST noted leaf and tests that leaf's box again with the t_max of the moment: that test - same ray, same box, the t_max
-// left by every earlier leaf - IS the reference's test of that node at that point of its walk, and a leaf whose ancestor the reference culled fails it (a box
-// contains its children's boxes and tmin is monotone in the box: tmin(leaf) >= tmin(ancestor) >= t_max then >= t_max now). Leaves that pass have their primitives
-// tested in order, one per phase. The sequence of primitive tests and t_max updates per ray is BVH::intersect's; hit records bit-equal.
-#ifndef RT_LDS_CLOSEST_DEFER_MIN
-#define RT_LDS_CLOSEST_DEFER_MIN 0
-#endif
-template <int N, int T, bool FINITE, int LEAF_MIN>
-RT_DEV bool closest_small_deferred(const float* __restrict__ s_nodes, const float* __restrict__ s_tris, const unsigned short* __restrict__ s_skip8, const int n_nodes, Ray ray, int& prim_out, TriHit& hit_out) {
-  const f3 inv_dir = mk3(1.0f / ray.d.x, 1.0f / ray.d.y, 1.0f / ray.d.z);
-  const int neg_x = inv_dir.x < 0.0f, neg_y = inv_dir.y < 0.0f, neg_z = inv_dir.z < 0.0f;
-  const unsigned oct = (neg_x ? 1u : 0u) | (neg_y ? 2u : 0u) | (neg_z ? 4u : 0u), negmask = oct << 16;
-  const unsigned short* const skip = s_skip8 + oct * N;
-  const RayPre rp = ray_pre(ray);
-  const float* const tpx = s_tris + rp.kx * T; const float* const tpy = s_tris + rp.ky * T; const float* const tpz = s_tris + rp.kz * T;
-  const f3 op = permute(ray.o, rp.kx, rp.ky, rp.kz);
-  bool found = false;
-  int cur = 0, leaf_off = 0, leaf_n = 0;
-  unsigned long long pend = 0ull;  // noted leaves, (node index + 1) in ten bits each: the OLDEST in the highest occupied field
-  for (;;) {
-    if (cur < n_nodes && (pend >> 50) == 0ull) {
-      const float* nd = s_nodes + cur;
-      const float4 n0 = make_float4(nd[0], nd[2 * N], nd[4 * N], nd[N]), n1 = make_float4(nd[3 * N], nd[5 * N], 0.0f, 0.0f);
-      const int offset = __float_as_int(nd[6 * N]); const unsigned ctl = __float_as_uint(nd[7 * N]);
-      int next = (int)skip[cur];
-      if (slab_test_t<FINITE>(n0, n1, ray, inv_dir, neg_x, neg_y, neg_z)) {
-        if ((ctl & 0xffffu) != 0u) pend = (pend << 10) | (unsigned long long)(cur + 1);
-        else next = (ctl & negmask) != 0u ? offset : cur + 1;
-      }
-      cur = next;
-    }
-    const bool has = (pend != 0ull) | (leaf_n > 0);
-    const unsigned long long walkers = __ballot(cur < n_nodes && (pend >> 50) == 0ull), havers = __ballot(has);
-    if ((walkers | havers) == 0ull) break;
-    if (walkers == 0ull || __builtin_popcount((unsigned)havers) + __builtin_popcount((unsigned)(havers >> 32)) >= LEAF_MIN) {
-      while (leaf_n == 0 && pend != 0ull) {  // the oldest noted leaf that still passes its node test
-        const int field = (63 - __builtin_clzll(pend)) / 10, shift = 10 * field;
-        const int node = (int)((pend >> shift) & 1023ull) - 1; pend &= (1ull << shift) - 1ull;
-        const float* nd = s_nodes + node;
-        const float4 n0 = make_float4(nd[0], nd[2 * N], nd[4 * N], nd[N]), n1 = make_float4(nd[3 * N], nd[5 * N], 0.0f, 0.0f);
-        if (slab_test_t<FINITE>(n0, n1, ray, inv_dir, neg_x, neg_y, neg_z)) { leaf_off = __float_as_int(nd[6 * N]); leaf_n = (int)(__float_as_uint(nd[7 * N]) & 0xffffu); }
-      }
-      if (leaf_n > 0) {
-        const int t = leaf_off;
-        const f3 p0t = mk3(tpx[t] - op.x, tpy[t] - op.y, tpz[t] - op.z), p1t = mk3(tpx[3 * T + t] - op.x, tpy[3 * T + t] - op.y, tpz[3 * T + t] - op.z),
-                 p2t = mk3(tpx[6 * T + t] - op.x, tpy[6 * T + t] - op.y, tpz[6 * T + t] - op.z);
-        TriHit h;
-        if (tri_test_permuted(p0t, p1t, p2t, rp.sx, rp.sy, rp.sz, ray.t_max, h)) { found = true; ray.t_max = h.t; prim_out = t; hit_out = h; }
-        leaf_off += 1; leaf_n -= 1;
-      }
-    }
-  }
-  return found;
-}
 
 // Where a trace launch reads its rays and writes its results: element [pid * stride] of each pointer (strides in elements of the pointer's
 // type), so that the same kernels serve the records of a frame (RayRec / VertRec / ShadowRec / MisRec) and the planar arrays of the batch entry points.
@@ -1325,7 +997,8 @@ struct TraceIO {
   // shard counts alone, `queue` is then only a non-NULL marker
   int queue_is_slots;
 };
-RT_DEV void trace_write_any(float4* __restrict__ lacc, size_t ls, const RT_SPTR_R(const float4) direct_add, size_t as, unsigned* __restrict__ occluded, size_t os,
+template <class AddPtr>
+RT_DEV void trace_write_any(float4* __restrict__ lacc, size_t ls, const AddPtr direct_add, size_t as, unsigned* __restrict__ occluded, size_t os,
                             unsigned pid, float dw, bool found) {
   // Shadow rays of the frame loop carry d.w = 1 when the vertex has no MIS ray in flight: the light-sampling
   // term of estimate_direct is then complete and `L += beta * (Ld / pick_pdf)` (precomputed by k_shade into
@@ -1341,9 +1014,6 @@ RT_DEV void trace_write_any(float4* __restrict__ lacc, size_t ls, const RT_SPTR_
 // smallest of 16/32/64 that covers the tree height; the reference's fixed 64 is the maximum).
 #ifndef RT_LDS_TRACE_WAVES  // the LDS-resident kernels' register bound in waves per SIMD: their LDS (21.5 KB per 256 lanes) lets seven workgroups share a CU
 #define RT_LDS_TRACE_WAVES 7
-#endif
-#ifndef RT_LDS_THREADED      // the plain-triangle kernels of an LDS-resident scene walk without a stack (closest_small, occluded_small)
-#define RT_LDS_THREADED 1
 #endif
 #ifndef RT_LDS_ANY_WAVES      // ... the occlusion kernel, 13.9 KB of LDS per 256 lanes, is bound by its registers
 #define RT_LDS_ANY_WAVES 8
@@ -1368,41 +1038,31 @@ RT_DEV void trace_write_any(float4* __restrict__ lacc, size_t ls, const RT_SPTR_
 #endif
 #define RT_MID_NODES 2816
 #define RT_MID_TRIS 1408
-template <bool ANY, bool COUNT, bool SMALL, int BLOCK, int DEPTH, int GENERAL = 0, int MID = 0>  // GENERAL: quadrics / alpha-masked triangles in the leaves (no object instances)
-__global__ void __launch_bounds__(BLOCK, MID ? 4 : ((SMALL && GENERAL == 0 && !COUNT) ? ((ANY && RT_LDS_THREADED) ? RT_LDS_ANY_WAVES : RT_LDS_TRACE_WAVES) : RT_GEN_MIN_WAVES(GENERAL))) k_trace(DScene sc, TraceIO io, const unsigned* __restrict__ queue, const unsigned* __restrict__ shard_counts, unsigned shard_cap,
+template <bool ANY, bool COUNT, int BLOCK, int DEPTH, int GENERAL = 0, int MID = 0>  // LDS-resident and mid-size scenes. GENERAL: quadrics / alpha-masked triangles in the leaves (no object instances)
+__global__ void __launch_bounds__(BLOCK, MID ? 4 : ((GENERAL == 0 && !COUNT) ? (ANY ? RT_LDS_ANY_WAVES : RT_LDS_TRACE_WAVES) : RT_GEN_MIN_WAVES(GENERAL))) k_trace(DScene sc, TraceIO io, const unsigned* __restrict__ queue, const unsigned* __restrict__ shard_counts, unsigned shard_cap,
                                                  unsigned count_static, unsigned long long* stats, int st_rays, int st_nodes, int st_tris) {
-  const RT_SPTR_R(const float4) ray_o = io.ray_o; const RT_SPTR_R(const float4) ray_d = io.ray_d; const size_t rs = io.ray_stride;
-  RT_SPTR_R(float4) hits = io.hits; const size_t hs = io.hit_stride; const bool hit_b2 = io.hit_b2 != 0;
+  // (plain loads and stores, no non-temporal hint: the scene is in LDS, the ray streams are all these launches read)
+  const float4* __restrict__ ray_o = sraw(io.ray_o); const float4* __restrict__ ray_d = sraw(io.ray_d); const size_t rs = io.ray_stride;
+  float4* __restrict__ hits = sraw(io.hits); const size_t hs = io.hit_stride; const bool hit_b2 = io.hit_b2 != 0;
   unsigned* __restrict__ occluded = io.occluded; const size_t os = io.occ_stride;
-  float4* __restrict__ lacc = io.lacc; const size_t ls = io.lacc_stride; const RT_SPTR_R(const float4) direct_add = io.direct_add; const size_t as = io.add_stride;
+  float4* __restrict__ lacc = io.lacc; const size_t ls = io.lacc_stride; const float4* __restrict__ direct_add = sraw(io.direct_add); const size_t as = io.add_stride;
   // node indices of a tiny scene fit 16 bits: half the stack bytes => more resident waves per CU
-// (round 4: 16-bit stack entries for the occlusion kernel too - 30 -> 21.5 KB of LDS per workgroup, 5 -> 7 resident: S1 shadow rays 169 -> 154.5 ms)
-#ifndef RT_ANY_STACK16
-#define RT_ANY_STACK16 1
-#endif
-  typedef typename std::conditional<SMALL && (!ANY || RT_ANY_STACK16), unsigned short, int>::type StackT;
-  constexpr bool STACKLESS = RT_LDS_THREADED && SMALL && !COUNT && GENERAL == 0;  // closest_small / occluded_small: no to-visit stack at all
-  constexpr bool LINKS_G_ = RT_LDS_THREADED && SMALL && !COUNT && GENERAL != 0 && RT_LDS_LINKS && RT_LDS_LINKS_GENERAL;  // (= LINKS_G below)
-  __shared__ StackT stack[(STACKLESS || LINKS_G_) ? 1 : DEPTH * BLOCK];
+  typedef unsigned short StackT;
+  // LINKS: an LDS-resident scene's rays that do not count visits walk WITHOUT a stack over the link tables (closest_small_links, occluded_small_links[_rounds]) -
+  // plain triangles, quadrics and masked triangles alike. Counting launches (the reference's walk, visit by visit) and HBM scenes keep the stack walk (traverse).
+  constexpr bool LINKS = !COUNT;
+  __shared__ StackT stack[LINKS ? 1 : DEPTH * BLOCK];
   constexpr int NN = MID ? RT_MID_NODES : RT_SMALL_NODES, NT = MID ? RT_MID_TRIS : RT_SMALL_TRIS;
-  static_assert(!MID || (SMALL && !COUNT && GENERAL == 0), "mid-size LDS scenes: plain triangles, no visit counts");
+  static_assert(!MID || (!COUNT && GENERAL == 0), "mid-size LDS scenes: plain triangles, no visit counts");
   constexpr bool MIDC = MID != 0 && !ANY;  // closest hit of a mid-size scene: six bound planes + eight link rows fill the LDS, the triangles stay in HBM
   typedef LdsSrcT<NN, NT> LdsS;
-  __shared__ float s_nodes[SMALL ? (MIDC ? 6 : 8) * NN : 1];
-  __shared__ float s_tris[(SMALL && !MIDC) ? 10 * NT : 1];
+  __shared__ float s_nodes[(MIDC ? 6 : 8) * NN];
+  __shared__ float s_tris[MIDC ? 1 : 10 * NT];
   QView qv; if (queue) qv.init(io.queue_is_slots ? nullptr : queue, shard_counts, shard_cap);
   const unsigned count = queue ? qv.total() : count_static;
   if (blockIdx.x * BLOCK >= count) return;  // short queues (MIS rays, late bounces): most blocks of the persistent grid have nothing to stage for
-  // the link-table walks (the deferred experiments keep the skip tables); round 5: the GENERAL kernels of an LDS-resident scene too (LINKS_G: no stack either)
-  constexpr bool LINKS_G = RT_LDS_THREADED && SMALL && !COUNT && GENERAL != 0 && RT_LDS_LINKS && RT_LDS_LINKS_GENERAL;
-  constexpr bool LINKS = (STACKLESS && RT_LDS_LINKS && RT_LDS_ANY_DEFER_MIN == 0 && RT_LDS_CLOSEST_DEFER_MIN == 0) || LINKS_G;
-  __shared__ unsigned short s_skip[(STACKLESS && !LINKS) ? (ANY ? 1 : 8) * NN : 1];  // the links of the walk order(s): DScene::skip8, rows NN apart
   __shared__ unsigned s_link[LINKS ? (ANY ? 1 : 8) * NN + 8 : 1];  // DScene::link8 (the tested nodes' links), rows NN apart, then the 8 start nodes
-  if (SMALL) { stage_small_scene<BLOCK, NN, NT, MIDC>(sc, s_nodes, s_tris); __syncthreads(); }
-  if (STACKLESS && !LINKS) {
-    for (unsigned i = threadIdx.x; i < (ANY ? 1u : 8u) * sc.n_nodes; i += BLOCK) { const unsigned o = i / sc.n_nodes, k = i - o * sc.n_nodes; s_skip[o * NN + k] = sc.skip8[i]; }
-    __syncthreads();
-  }
+  stage_small_scene<BLOCK, NN, NT, MIDC>(sc, s_nodes, s_tris); __syncthreads();
   if (LINKS) {
     // DScene::link8: rows 0 - 7 (closest hit, by octant), their 8 starts, row 8 (occlusion rays), its start
     if (ANY) { for (unsigned k = threadIdx.x; k < sc.n_nodes; k += BLOCK) s_link[k] = sc.link8[8u * sc.n_nodes + 8u + k]; if (threadIdx.x == 0u) s_link[NN] = sc.link8[9u * sc.n_nodes + 8u]; }
@@ -1423,39 +1083,28 @@ __global__ void __launch_bounds__(BLOCK, MID ? 4 : ((SMALL && GENERAL == 0 && !C
     const GeneralCtx gen{sc.self, ANY && io.shadow_masks != 0};
     // Plain-triangle launches that do not count visits take the min / max node test (slab_test_finite) when every ray of the wave has a finite reciprocal
     // direction - all but a few hundred waves of a frame; a wave that holds one ray with a zero direction component walks with the reference's selects.
-    constexpr bool FIN_FORMS = !COUNT && (GENERAL == 0 || LINKS_G);
+    constexpr bool FIN_FORMS = !COUNT;
     const bool fin = FIN_FORMS && __ballot(!inv_dir_finite(mk3(1.0f / ray.d.x, 1.0f / ray.d.y, 1.0f / ray.d.z))) == 0ull;
-    if (SMALL && LM > 1 && LM < 64 && !COUNT) {
-      LdsS src{s_nodes, s_tris};
-      if (LINKS && ANY) found = fin ? occluded_small_links_rounds<NN, NT, true, LM, GENERAL>(s_nodes, s_tris, s_link, (int)sc.n_nodes, (int)s_link[NN], ray, gen)
-                                    : occluded_small_links_rounds<NN, NT, false, LM, GENERAL>(s_nodes, s_tris, sc.link8_full + 8u * sc.n_nodes + 8u, (int)sc.n_nodes, (int)sc.link8_full[9u * sc.n_nodes + 8u], ray, gen);
-      else if (LINKS && !ANY) {
-        if (fin) {  // (s_link: 8 rows NN apart, the starts behind them - closest_small_links reads link8[8 * row + oct])
-          found = closest_small_links<NN, NT, true, LM, GENERAL, MIDC>(s_nodes, s_tris, s_link, NN, (int)sc.n_nodes, ray, prim, h, gen, sc.tri_p);
-        } else found = closest_small_links<NN, NT, false, LM, GENERAL, MIDC>(s_nodes, s_tris, sc.link8_full, (int)sc.n_nodes, (int)sc.n_nodes, ray, prim, h, gen, sc.tri_p);
+    if (LINKS) {
+      static_assert(!LINKS || ANY || (LM > 1 && LM < 64), "the closest-hit link walk tests its leaves in phases: 1 < LEAF_MIN < 64");
+      if (!ANY) {
+        if (fin) found = closest_small_links<NN, NT, true, LM, GENERAL, MIDC>(s_nodes, s_tris, s_link, NN, (int)sc.n_nodes, ray, prim, h, gen, sc.tri_p);  // (s_link: 8 rows NN apart, the starts behind them)
+        else found = closest_small_links<NN, NT, false, LM, GENERAL, MIDC>(s_nodes, s_tris, sc.link8_full, (int)sc.n_nodes, (int)sc.n_nodes, ray, prim, h, gen, sc.tri_p);
+      } else if (LM > 1 && LM < 64) {
+        found = fin ? occluded_small_links_rounds<NN, NT, true, LM, GENERAL>(s_nodes, s_tris, s_link, (int)sc.n_nodes, (int)s_link[NN], ray, gen)
+                    : occluded_small_links_rounds<NN, NT, false, LM, GENERAL>(s_nodes, s_tris, sc.link8_full + 8u * sc.n_nodes + 8u, (int)sc.n_nodes, (int)sc.link8_full[9u * sc.n_nodes + 8u], ray, gen);
+      } else {
+        found = fin ? occluded_small_links<NN, NT, true, GENERAL>(s_nodes, s_tris, s_link, (int)sc.n_nodes, (int)s_link[NN], ray, gen)
+                    : occluded_small_links<NN, NT, false, GENERAL>(s_nodes, s_tris, sc.link8_full + 8u * sc.n_nodes + 8u, (int)sc.n_nodes, (int)sc.link8_full[9u * sc.n_nodes + 8u], ray, gen);
       }
-      else if (STACKLESS && !ANY && RT_LDS_CLOSEST_DEFER_MIN > 0) found = fin ? closest_small_deferred<NN, NT, true, RT_LDS_CLOSEST_DEFER_MIN>(s_nodes, s_tris, s_skip, (int)sc.n_nodes, ray, prim, h) : closest_small_deferred<NN, NT, false, RT_LDS_CLOSEST_DEFER_MIN>(s_nodes, s_tris, s_skip, (int)sc.n_nodes, ray, prim, h);
-      else if (STACKLESS && !ANY) found = fin ? closest_small<NN, NT, true, LM>(s_nodes, s_tris, s_skip, (int)sc.n_nodes, ray, prim, h) : closest_small<NN, NT, false, LM>(s_nodes, s_tris, s_skip, (int)sc.n_nodes, ray, prim, h);
-      else found = traverse_rounds<ANY, COUNT, LM, LdsS, StackT, GENERAL>(src, ray, stack + threadIdx.x, BLOCK, prim, h, n_nodes, n_tris, gen);
     }
-    else if (SMALL) {
+    else {  // a frame that counts the reference's walk, visit by visit: the stack walk over the LDS copy
       LdsS src{s_nodes, s_tris};
-      if (LINKS) found = fin ? occluded_small_links<NN, NT, true, GENERAL>(s_nodes, s_tris, s_link, (int)sc.n_nodes, (int)s_link[NN], ray, gen)
-                             : occluded_small_links<NN, NT, false, GENERAL>(s_nodes, s_tris, sc.link8_full + 8u * sc.n_nodes + 8u, (int)sc.n_nodes, (int)sc.link8_full[9u * sc.n_nodes + 8u], ray, gen);
-      else if (STACKLESS && RT_LDS_ANY_DEFER_MIN > 0) found = fin ? occluded_small_deferred<NN, NT, true, RT_LDS_ANY_DEFER_MIN>(s_nodes, s_tris, s_skip, (int)sc.n_nodes, ray) : occluded_small_deferred<NN, NT, false, RT_LDS_ANY_DEFER_MIN>(s_nodes, s_tris, s_skip, (int)sc.n_nodes, ray);
-      else if (STACKLESS) found = fin ? occluded_small<NN, NT, true>(s_nodes, s_tris, s_skip, (int)sc.n_nodes, ray) : occluded_small<NN, NT, false>(s_nodes, s_tris, s_skip, (int)sc.n_nodes, ray);
-      else found = traverse<ANY, COUNT, LdsS, StackT, GENERAL>(src, ray, stack + threadIdx.x, BLOCK, prim, h, n_nodes, n_tris, gen);
+      found = traverse<ANY, COUNT, LdsS, StackT, GENERAL>(src, ray, stack + threadIdx.x, BLOCK, prim, h, n_nodes, n_tris, gen);
     }
-    else {
-      GlobalSrc src{sc.nodes, sc.tri_p};
-      if (FIN_FORMS && fin) found = traverse<ANY, COUNT, GlobalSrc, StackT, GENERAL, FIN_FORMS>(src, ray, stack + threadIdx.x, BLOCK, prim, h, n_nodes, n_tris, gen);
-      else found = traverse<ANY, COUNT, GlobalSrc, StackT, GENERAL>(src, ray, stack + threadIdx.x, BLOCK, prim, h, n_nodes, n_tris, gen);
-    }
-    // a dead entry of an octant run (block_push_oct; path rays only): t_max < 0 from 1e30 away - no box test passes; reported as RT_DEAD_PRIM, not counted
-    const bool dead = !ANY && o4.w < 0.0f;
-    n_rays += dead ? 0u : 1u;
+    n_rays += 1;
     if (ANY) trace_write_any(lacc, ls, direct_add, as, occluded, os, pid, d4.w, found);
-    else hits[pid * hs] = make_float4(hit_b2 ? h.b2 : (found ? h.t : kInf), __int_as_float(found ? prim : (dead ? RT_DEAD_PRIM : -1)), h.b0, h.b1);
+    else hits[pid * hs] = make_float4(hit_b2 ? h.b2 : (found ? h.t : kInf), __int_as_float(found ? prim : -1), h.b0, h.b1);
   };
   for (unsigned i = blockIdx.x * BLOCK + threadIdx.x; i < count; i += stride) trace_one(queue ? qv.get(i) : i);
   if (stats) {
@@ -1486,166 +1135,6 @@ struct TraceOut { SPtr<float4> hits; size_t hs; bool hit_b2; unsigned* occluded;
 RT_DEV TraceOut trace_out_of(const TraceIO& io) {
   TraceOut o; o.hits = io.hits; o.hs = io.hit_stride; o.hit_b2 = io.hit_b2 != 0; o.occluded = io.occluded; o.os = io.occ_stride;
   o.lacc = io.lacc; o.ls = io.lacc_stride; o.direct_add = io.direct_add; o.as = io.add_stride; return o;
-}
-// ---- Round 5: the LDS-resident walks with a POOL of set-up rays (k_trace_pool). The probe build says where the lanes of k_trace's waves go (S1): a closest-hit
-// wave steps nodes with 48.6 % of its lanes and tests primitives with 29.2 %; of that, the TAIL - lanes whose ray is done while the wave's longest ray walks on -
-// costs a third (all lanes' steps / (64 x the longest lane's) = 0.674; occlusion rays 0.645). Round 4 tried to hand finished lanes new rays (persistent waves
-// with refill: 413 / 275 ms against 329 / 168) and lost, because a ray's set-up - its record from HBM, six IEEE divisions for 1 / d and the watertight test's
-// shear - then ran for the 16 - 24 refilled lanes only. Here set-up and refill are two things: whenever the pool is empty ALL 64 lanes of the wave - walking or
-// not - set up the wave's next 64 rays (one record each, full width, the loads of the whole wave in flight together) and park them in LDS, 13 words a ray; a lane
-// whose ray is done takes the next parked ray: a dozen LDS reads, no division, no HBM. Per ray nothing changes: closest_small's / occluded_small's steps, the
-// reference's sequence of node tests, primitive tests and t_max updates; hit records bit-equal.
-#ifndef RT_POOL_REFILL_MIN
-#define RT_POOL_REFILL_MIN 8
-#endif
-#ifndef RT_POOL_WAVES  // register bound in waves per SIMD (LDS: 13.9 / 17.4 KB of scene + 13 KB of pools per 256 lanes)
-#define RT_POOL_WAVES 5
-#endif
-#define RT_POOL_FIELDS 13
-template <bool ANY, int BLOCK>
-__global__ void __launch_bounds__(BLOCK, RT_POOL_WAVES) k_trace_pool(DScene sc, TraceIO io, const unsigned* __restrict__ queue, const unsigned* __restrict__ shard_counts, unsigned shard_cap,
-                                                                    unsigned count_static, unsigned long long* stats, int st_rays) {
-  constexpr int N = RT_SMALL_NODES, T = RT_SMALL_TRIS, LEAF_MIN = RT_LDS_LEAF_MIN_CLOSEST;
-  const RT_SPTR_R(const float4) ray_o = io.ray_o; const RT_SPTR_R(const float4) ray_d = io.ray_d; const size_t rs = io.ray_stride;
-  __shared__ float s_nodes[8 * N];
-  __shared__ float s_tris[10 * T];
-  __shared__ unsigned short s_skip[(ANY ? 1 : 8) * N];
-  __shared__ float s_pool[BLOCK / 64][RT_POOL_FIELDS][64];
-  QView qv; if (queue) qv.init(io.queue_is_slots ? nullptr : queue, shard_counts, shard_cap);
-  const unsigned count = queue ? qv.total() : count_static;
-  if ((unsigned long long)blockIdx.x * BLOCK >= count) return;
-  stage_small_scene<BLOCK, N, T>(sc, s_nodes, s_tris);
-  for (unsigned i = threadIdx.x; i < (ANY ? 1u : 8u) * sc.n_nodes; i += BLOCK) { const unsigned o = i / sc.n_nodes, k = i - o * sc.n_nodes; s_skip[o * N + k] = sc.skip8[i]; }
-  __syncthreads();
-  const TraceOut out = trace_out_of(io);
-  const int n_nodes = (int)sc.n_nodes;
-  const unsigned lane = __lane_id(), wv = threadIdx.x >> 6;
-  const unsigned n_waves = gridDim.x * (BLOCK / 64), wave = blockIdx.x * (BLOCK / 64) + wv;
-  float (* const pool)[64] = s_pool[wv];
-  unsigned cursor = 0, pool_n = 0, pool_head = 0, n_rays = 0;  // (wave-uniform) rays of the wave's share that went into pools; parked rays left; the next one to hand out
-  bool exhausted = (unsigned long long)wave * 64ull >= count;
-  // the lane's ray
-  bool active = false, found = false, fin = true;
-  unsigned pid = 0; float dw = 0.0f;
-  Ray ray; ray.o = ray.d = mk3(0, 0, 0); ray.t_max = 0.0f;
-  f3 inv_dir = mk3(0, 0, 0), op = mk3(0, 0, 0); float sx = 0.0f, sy = 0.0f, sz = 0.0f;
-  unsigned ox = 0u, oy = 0u, oz = 0u, skip_off = 0u, negmask = 0u;  // (LDS offsets, not pointers: the planes of the permuted coordinates, the octant's row of links)
-  int cur = 0, leaf_off = 0, leaf_n = 0, prim = -1; TriHit h; h.t = kInf; h.b0 = h.b1 = h.b2 = 0.0f;
-  for (;;) {
-    const unsigned long long idle = __ballot(!active);
-    const unsigned n_idle = (unsigned)__popcll(idle);
-    if (n_idle >= (idle == ~0ull ? 1u : (unsigned)RT_POOL_REFILL_MIN)) {
-      if (pool_n == 0u && !exhausted) {  // every lane sets up one ray of the wave's next 64 and parks it
-        const unsigned long long e = ((unsigned long long)(cursor >> 6) * n_waves + wave) * 64ull + lane;
-        const bool valid = e < count;
-        if (valid) {
-          const unsigned p = queue ? qv.get((unsigned)e) : (unsigned)e;
-          const float4 o4 = ray_o[p * rs], d4 = ray_d[p * rs];
-          Ray r; r.o = mk3(o4.x, o4.y, o4.z); r.d = mk3(d4.x, d4.y, d4.z); r.t_max = o4.w;
-          const f3 inv = mk3(1.0f / r.d.x, 1.0f / r.d.y, 1.0f / r.d.z);
-          const RayPre rp = ray_pre(r);
-          pool[0][lane] = o4.x; pool[1][lane] = o4.y; pool[2][lane] = o4.z; pool[3][lane] = o4.w;
-          pool[4][lane] = inv.x; pool[5][lane] = inv.y; pool[6][lane] = inv.z;
-          pool[7][lane] = rp.sx; pool[8][lane] = rp.sy; pool[9][lane] = rp.sz;
-          pool[10][lane] = __int_as_float(rp.kz | (inv_dir_finite(inv) ? 0 : 4));
-          pool[11][lane] = __uint_as_float(p); pool[12][lane] = d4.w;
-        }
-        pool_n = (unsigned)__popcll(__ballot(valid)); pool_head = 0u;
-        cursor += 64u;
-        exhausted = ((unsigned long long)(cursor >> 6) * n_waves + wave) * 64ull >= count;
-        wave_sync_lds();
-      }
-      if (pool_n > 0u) {
-        const unsigned rank = (unsigned)__popcll(idle & ((1ull << lane) - 1ull));
-        if (!active && rank < pool_n) {
-          const unsigned k = pool_head + rank;
-          ray.o = mk3(pool[0][k], pool[1][k], pool[2][k]); ray.t_max = pool[3][k];
-          inv_dir = mk3(pool[4][k], pool[5][k], pool[6][k]);
-          sx = pool[7][k]; sy = pool[8][k]; sz = pool[9][k];
-          const int kzf = __float_as_int(pool[10][k]); const int kz = kzf & 3; fin = (kzf & 4) == 0;
-          int kx = kz + 1; if (kx == 3) kx = 0; int ky = kx + 1; if (ky == 3) ky = 0;
-          pid = __float_as_uint(pool[11][k]); dw = pool[12][k];
-          ox = (unsigned)(kx * T); oy = (unsigned)(ky * T); oz = (unsigned)(kz * T);
-          op = permute(ray.o, kx, ky, kz);
-          const unsigned oct = (inv_dir.x < 0.0f ? 1u : 0u) | (inv_dir.y < 0.0f ? 2u : 0u) | (inv_dir.z < 0.0f ? 4u : 0u);
-          negmask = oct << 16; skip_off = ANY ? 0u : oct * N;
-          cur = 0; leaf_off = 0; leaf_n = 0; prim = -1; found = false; h.t = kInf; h.b0 = h.b1 = h.b2 = 0.0f;
-          active = true; n_rays += 1u;
-        }
-        const unsigned taken = n_idle < pool_n ? n_idle : pool_n;
-        pool_head += taken; pool_n -= taken;
-        wave_sync_lds();  // (the parked rays are read before the next fill overwrites them)
-      }
-    }
-    if (__ballot(active) == 0ull) { if (exhausted && pool_n == 0u) break; else continue; }
-    const bool all_fin = __ballot(active && !fin) == 0ull;  // a wave that holds a ray with a zero direction component tests nodes with the reference's selects
-    const int neg_x = inv_dir.x < 0.0f, neg_y = inv_dir.y < 0.0f, neg_z = inv_dir.z < 0.0f;
-    if (ANY) {  // occluded_small's step
-      if (active) {
-        if (cur < n_nodes) {
-          const float* nd = s_nodes + cur;
-          const float4 n0 = make_float4(nd[0], nd[2 * N], nd[4 * N], nd[N]), n1 = make_float4(nd[3 * N], nd[5 * N], 0.0f, 0.0f);
-          const bool hit = all_fin ? slab_test_finite(n0, n1, ray.o, ray.t_max, inv_dir) : slab_test(n0, n1, ray, inv_dir, neg_x, neg_y, neg_z);
-          int next = hit ? cur + 1 : (int)s_skip[skip_off + cur];
-          if (hit) {
-            const int n_prims = (int)(__float_as_uint(nd[7 * N]) & 0xffffu);
-            if (n_prims != 0) {
-              const int off = __float_as_int(nd[6 * N]);
-              for (int i = 0; i < n_prims; ++i) {
-                const int t = off + i;
-                const f3 p0t = mk3(s_tris[ox + t] - op.x, s_tris[oy + t] - op.y, s_tris[oz + t] - op.z), p1t = mk3(s_tris[ox + 3 * T + t] - op.x, s_tris[oy + 3 * T + t] - op.y, s_tris[oz + 3 * T + t] - op.z),
-                         p2t = mk3(s_tris[ox + 6 * T + t] - op.x, s_tris[oy + 6 * T + t] - op.y, s_tris[oz + 6 * T + t] - op.z);
-                TriHit hh;
-                if (tri_test_permuted<RT_ANY_EARLY_SIGN != 0>(p0t, p1t, p2t, sx, sy, sz, ray.t_max, hh)) { found = true; next = n_nodes; break; }
-              }
-            }
-          }
-          cur = next;
-        }
-        if (cur >= n_nodes) { trace_write_any(out.lacc, out.ls, out.direct_add, out.as, out.occluded, out.os, pid, dw, found); active = false; }
-      }
-    } else {  // closest_small's rounds: node steps until LEAF_MIN lanes hold a leaf (or nobody walks), then one primitive per holder
-      unsigned long long holders = 0ull;
-      for (;;) {
-        if (active && leaf_n == 0 && cur < n_nodes) {
-          const float* nd = s_nodes + cur;
-          const float4 n0 = make_float4(nd[0], nd[2 * N], nd[4 * N], nd[N]), n1 = make_float4(nd[3 * N], nd[5 * N], 0.0f, 0.0f);
-          const int offset = __float_as_int(nd[6 * N]); const unsigned ctl = __float_as_uint(nd[7 * N]);
-          int next = (int)s_skip[skip_off + cur];
-          if (all_fin ? slab_test_finite(n0, n1, ray.o, ray.t_max, inv_dir) : slab_test(n0, n1, ray, inv_dir, neg_x, neg_y, neg_z)) {
-            const int n_prims = (int)(ctl & 0xffffu);
-            if (n_prims != 0) { leaf_off = offset; leaf_n = n_prims; }
-            else next = (ctl & negmask) != 0u ? offset : cur + 1;
-          }
-          cur = next;
-        }
-        holders = __ballot(active && leaf_n > 0);
-        const unsigned long long walkers = __ballot(active && leaf_n == 0 && cur < n_nodes);
-        if (walkers == 0ull) break;
-        if (__builtin_popcount((unsigned)holders) + __builtin_popcount((unsigned)(holders >> 32)) >= LEAF_MIN) break;
-        // a round after which enough lanes have run out of nodes goes back for new rays (the holders keep their leaves)
-        if ((pool_n > 0u || !exhausted) && (unsigned)__popcll(__ballot(!active || (leaf_n == 0 && cur >= n_nodes))) >= (unsigned)RT_POOL_REFILL_MIN) break;
-      }
-      const bool run_leaf = holders != 0ull && (__ballot(active && leaf_n == 0 && cur < n_nodes) == 0ull ||
-                                                __builtin_popcount((unsigned)holders) + __builtin_popcount((unsigned)(holders >> 32)) >= LEAF_MIN);  // (wave-uniform)
-      if (run_leaf && active && leaf_n > 0) {
-        const int t = leaf_off;
-        const f3 p0t = mk3(s_tris[ox + t] - op.x, s_tris[oy + t] - op.y, s_tris[oz + t] - op.z), p1t = mk3(s_tris[ox + 3 * T + t] - op.x, s_tris[oy + 3 * T + t] - op.y, s_tris[oz + 3 * T + t] - op.z),
-                 p2t = mk3(s_tris[ox + 6 * T + t] - op.x, s_tris[oy + 6 * T + t] - op.y, s_tris[oz + 6 * T + t] - op.z);
-        TriHit hh;
-        if (tri_test_permuted(p0t, p1t, p2t, sx, sy, sz, ray.t_max, hh)) { found = true; ray.t_max = hh.t; prim = t; h = hh; }
-        leaf_off += 1; leaf_n -= 1;
-      }
-      if (active && leaf_n == 0 && cur >= n_nodes) {
-        out.hits[pid * out.hs] = make_float4(out.hit_b2 ? h.b2 : (found ? h.t : kInf), __int_as_float(found ? prim : -1), h.b0, h.b1);
-        active = false;
-      }
-    }
-  }
-  if (stats) {
-    for (int off = 32; off > 0; off >>= 1) n_rays += __shfl_down(n_rays, off);
-    if (lane == 0u && n_rays) atomicAdd(&stats[st_rays], (unsigned long long)n_rays);
-  }
 }
 
 // ---- K2/K4 for scenes that live in HBM. Ray lengths then vary by an order of magnitude (a camera ray that
@@ -1926,16 +1415,6 @@ RT_DEV bool nested_pair_walk(const float4* __restrict__ pairs, const float4* __r
 #ifndef RT_TTOP
 #define RT_TTOP 1
 #endif
-// RT_PUSH_PREFETCH (round 5, measurement knob): these kernels wait for memory with a seventh of the bandwidth in use, and an entry that is pushed is usually
-// popped a few steps later from HBM. Pushing an interior entry therefore also REQUESTS one word of its record (a load whose value nothing needs: it is folded
-// into a register at the next push, when it has long arrived, and that register reaches memory only if it equals a constant it cannot equal by design of the
-// sink - the lane's own dead stack slot), so the pop finds the line in L2.
-#ifndef RT_PUSH_PREFETCH
-#define RT_PUSH_PREFETCH 0
-#endif
-#define RT_PF_PAIR(L, base, code) do { if (RT_PUSH_PREFETCH && !((code) & (RT_PAIR_LEAF | RT_PAIR_TOP))) { (L).pf_acc ^= (L).pf; (L).pf = __float_as_uint((base)[4 * (size_t)((code) & 0x0fffffffu)].x); } } while (0)
-#define RT_PF_QUAD(L, base, code) do { if (RT_PUSH_PREFETCH && (code) != 0xffffffffu && !((code) & RT_PAIR_LEAF)) { (L).pf_acc ^= (L).pf; (L).pf = __float_as_uint((base)[8 * (size_t)((code) & 0x1fffffffu)].x); } } while (0)
-#define RT_PF_SINK(L, tstack) do { if (RT_PUSH_PREFETCH && ((L).pf_acc ^ (L).pf) == 0x7fc1a5a5u && (L).sp == 0x40000000) (tstack)[0] = 0.0f; } while (0)
 struct PairLane {
   bool active, found; unsigned pid; float dw;
   // registers are the currency of this kernel (86 -> 80 VGPRs is one more wave per SIMD): the direction signs are read off inv_dir where
@@ -1954,7 +1433,6 @@ struct PairLane {
   RT_DEV RayPre rp() const { RayPre r; r.kz = kz & 3; r.kx = r.kz + 1; if (r.kx == 3) r.kx = 0; r.ky = r.kx + 1; if (r.ky == 3) r.ky = 0; r.sx = sx; r.sy = sy; r.sz = sz; return r; }
   RT_DEV void set_rp(const RayPre& r) { kz = (kz & 4) | r.kz; sx = r.sx; sy = r.sy; sz = r.sz; }
   int sp, prim; unsigned cur; TriHit hit;
-  unsigned pf, pf_acc;  // RT_PUSH_PREFETCH: the word requested from the record of the entry pushed last, folded into pf_acc at the next push (never read for its value)
   float ttop;  // closest hit: the deferred tmin of the entry on TOP of the to-visit stack (RT_TTOP), so that a pop compares a register and the load of the next entry's tmin is in flight long before the next pop
   int kz;  // (apart from inv_dir: written together as neighbours, the two become one 16-byte store to a private copy of the lane's state - 24 bytes of scratch per lane)
 };
@@ -2039,7 +1517,7 @@ RT_DEV void pair_interior_step(PairLane& L, const TraceOut& o, const float4* __r
   bool ff = ANY && r.far_first;
   if (ANY && RT_ANY_ORDER >= 3 && RT_ANY_ORDER != 8 && ((code_n ^ code_f) & RT_PAIR_LEAF) != 0u) ff = (code_f & RT_PAIR_LEAF) != 0u;  // exactly one child is a leaf: its primitives first
   const unsigned first = ff ? code_f : code_n, second = ff ? code_n : code_f;  // (closest hit: always near, far)
-  if (r.hit_n & r.keep_f) { stack[L.sp * BLOCK] = second; if (!ANY) { tstack[(size_t)L.sp * grid_lanes] = r.tmin_f; L.ttop = r.tmin_f; } ++L.sp; L.cur = first; RT_PF_PAIR(L, pairs, second); }
+  if (r.hit_n & r.keep_f) { stack[L.sp * BLOCK] = second; if (!ANY) { tstack[(size_t)L.sp * grid_lanes] = r.tmin_f; L.ttop = r.tmin_f; } ++L.sp; L.cur = first; }
   else if (r.hit_n) L.cur = code_n;
   else if (r.keep_f) L.cur = code_f;
   else pair_pop<ANY, BLOCK>(L, o, stack, tstack, grid_lanes);
@@ -2080,7 +1558,7 @@ RT_DEV void pair_leaf_step(PairLane& L, const TraceOut& o, const DScene& sc, con
 }
 
 // (closest hit with quadrics AND the nested walk: 154 VGPRs at three waves; bound to four it would spill 24 dwords)
-template <bool ANY, bool WW, int BLOCK, int DEPTH, int GENERAL = 0>
+template <bool ANY, int BLOCK, int DEPTH, int GENERAL = 0>
 __global__ void __launch_bounds__(BLOCK, (GENERAL == RT_GEN_NO_MASKS && !ANY) ? 3 : RT_GEN_MIN_WAVES(GENERAL)) k_trace_pair(DScene sc, TraceIO io, const unsigned* __restrict__ queue, const unsigned* __restrict__ shard_counts, unsigned shard_cap,
                                                       unsigned count_static, unsigned long long* stats, int st_rays, float* __restrict__ tmin_stack_mem, unsigned refill_min) {
   const RT_SPTR_R(const float4) ray_o = io.ray_o; const RT_SPTR_R(const float4) ray_d = io.ray_d; const size_t rs = io.ray_stride;
@@ -2103,7 +1581,7 @@ __global__ void __launch_bounds__(BLOCK, (GENERAL == RT_GEN_NO_MASKS && !ANY) ? 
   PairLane L;
   L.active = false; L.found = false; L.pid = 0; L.dw = 0.0f;
   L.ray.o = L.ray.d = mk3(0, 0, 0); L.ray.t_max = 0.0f; L.set_inv(mk3(0, 0, 0)); L.set_rp(ray_pre(L.ray));
-  L.sp = 0; L.prim = -1; L.cur = 0; L.ttop = 0.0f; L.pf = L.pf_acc = 0u; L.hit.t = kInf; L.hit.b0 = L.hit.b1 = L.hit.b2 = 0.0f;
+  L.sp = 0; L.prim = -1; L.cur = 0; L.ttop = 0.0f; L.hit.t = kInf; L.hit.b0 = L.hit.b1 = L.hit.b2 = 0.0f;
 
   for (;;) {
     const unsigned long long idle = __ballot(!L.active);
@@ -2130,10 +1608,7 @@ __global__ void __launch_bounds__(BLOCK, (GENERAL == RT_GEN_NO_MASKS && !ANY) ? 
     }
     if (__ballot(L.active) == 0ull) { if (exhausted) break; else continue; }
     const bool shadow_masks = ANY && io.shadow_masks != 0;
-    if (WW) {
-      while (L.active && !(L.cur & RT_PAIR_LEAF)) pair_interior_step<ANY, BLOCK>(L, out, pairs, stack, tstack, grid_lanes);
-      if (L.active) pair_leaf_step<ANY, BLOCK, GENERAL>(L, out, sc, tri_p, stack, tstack, grid_lanes, shadow_masks);
-    } else {
+    {
       const bool at_leaf = L.active && (L.cur & RT_PAIR_LEAF) != 0u;
       const bool leaves_now = leaf_phase_now(L.active, at_leaf, leaf_min);
       if (L.active) {
@@ -2142,7 +1617,6 @@ __global__ void __launch_bounds__(BLOCK, (GENERAL == RT_GEN_NO_MASKS && !ANY) ? 
       }
     }
   }
-  RT_PF_SINK(L, tstack);
   if (stats) {
     for (int off = 32; off > 0; off >>= 1) n_rays += __shfl_down(n_rays, off);
     if (lane == 0u && n_rays) atomicAdd(&stats[st_rays], (unsigned long long)n_rays);
@@ -2181,7 +1655,7 @@ __global__ void __launch_bounds__(BLOCK, 4) k_trace_inst(DScene sc, TraceIO io, 
   PairLane L;
   L.active = false; L.found = false; L.pid = 0; L.dw = 0.0f;
   L.ray.o = L.ray.d = mk3(0, 0, 0); L.ray.t_max = 0.0f; L.set_inv(mk3(0, 0, 0)); L.set_rp(ray_pre(L.ray));
-  L.sp = 0; L.prim = -1; L.cur = 0; L.ttop = 0.0f; L.pf = L.pf_acc = 0u; L.hit.t = kInf; L.hit.b0 = L.hit.b1 = L.hit.b2 = 0.0f;
+  L.sp = 0; L.prim = -1; L.cur = 0; L.ttop = 0.0f; L.hit.t = kInf; L.hit.b0 = L.hit.b1 = L.hit.b2 = 0.0f;
   unsigned inst = RT_INST_NONE, node_base = 0u, prim_base = 0u, id_base = 0u; int sp_base = -1;  // the instance the lane is inside, its records, the stack height it was entered at
 
   // next pending entry that still passes tmin < t_max; an object whose entries are used up is left first; no entry left: the ray is complete
@@ -2368,7 +1842,7 @@ RT_DEV void top_interior_step(PairLane& L, const TraceOut& o, const float4* __re
   bool ff = ANY && r.far_first;
   if (ANY && RT_ANY_ORDER >= 3 && RT_ANY_ORDER != 8 && ((code_n ^ code_f) & RT_PAIR_LEAF) != 0u) ff = (code_f & RT_PAIR_LEAF) != 0u;
   const unsigned first = ff ? code_f : code_n, second = ff ? code_n : code_f;
-  if (r.hit_n & r.keep_f) { stk.put(L.sp, second); if (!ANY) { tstack[(size_t)L.sp * grid_lanes] = r.tmin_f; L.ttop = r.tmin_f; } ++L.sp; L.cur = first; RT_PF_PAIR(L, pairs, second); }
+  if (r.hit_n & r.keep_f) { stk.put(L.sp, second); if (!ANY) { tstack[(size_t)L.sp * grid_lanes] = r.tmin_f; L.ttop = r.tmin_f; } ++L.sp; L.cur = first; }
   else if (r.hit_n) L.cur = code_n;
   else if (r.keep_f) L.cur = code_f;
   else top_pop<ANY, BLOCK>(L, o, stk, tstack, grid_lanes);
@@ -2404,7 +1878,7 @@ __global__ void __launch_bounds__(BLOCK, GENERAL ? 4 : 6) k_trace_top(DScene sc,
   PairLane L;
   L.active = false; L.found = false; L.pid = 0; L.dw = 0.0f;
   L.ray.o = L.ray.d = mk3(0, 0, 0); L.ray.t_max = 0.0f; L.set_inv(mk3(0, 0, 0)); L.set_rp(ray_pre(L.ray));
-  L.sp = 0; L.prim = -1; L.cur = 0; L.ttop = 0.0f; L.pf = L.pf_acc = 0u; L.hit.t = kInf; L.hit.b0 = L.hit.b1 = L.hit.b2 = 0.0f;
+  L.sp = 0; L.prim = -1; L.cur = 0; L.ttop = 0.0f; L.hit.t = kInf; L.hit.b0 = L.hit.b1 = L.hit.b2 = 0.0f;
   for (;;) {
     const unsigned long long idle = __ballot(!L.active);
     if (!exhausted && (unsigned)__popcll(idle) >= (idle == ~0ull ? 1u : refill_min)) {  // the refill scheme of k_trace_pair
@@ -2437,7 +1911,6 @@ __global__ void __launch_bounds__(BLOCK, GENERAL ? 4 : 6) k_trace_top(DScene sc,
       }
     }
   }
-  RT_PF_SINK(L, tstack);
   if (stats) {
     for (int off = 32; off > 0; off >>= 1) n_rays += __shfl_down(n_rays, off);
     if (lane == 0u && n_rays) atomicAdd(&stats[st_rays], (unsigned long long)n_rays);
@@ -2523,73 +1996,18 @@ RT_DEV void quad_interior_step(PairLane& L, const TraceOut& o, const float4* __r
 #pragma unroll
     for (int e = 0; e < j; ++e) earlier |= h[e];
     if (h[j]) {
-      if (earlier) { stack[L.sp * BLOCK] = c[j]; if (!ANY) { tstack[(size_t)L.sp * grid_lanes] = t[j]; L.ttop = t[j]; } ++L.sp; RT_PF_QUAD(L, quads, c[j]); }
+      if (earlier) { stack[L.sp * BLOCK] = c[j]; if (!ANY) { tstack[(size_t)L.sp * grid_lanes] = t[j]; L.ttop = t[j]; } ++L.sp; }
       else { entered = true; next = c[j]; }
     }
   }
   if (entered) L.cur = next; else pair_pop<ANY, BLOCK>(L, o, stack, tstack, grid_lanes);
 }
 
-// ---- The four-wide step of a CLOSEST-HIT ray (round 5). quad_interior_step pushes both halves of the far child and every dead pop of
-// them waited for its tmin - rounds 2 / 3 measured that as a loss and kept closest hit two-wide. This step reads the same 128-byte record and spends it
-// differently: the NEAR child N of the node (the side BVH::intersect enters first, bvh/mod.rs:411-417) is resolved two levels deep - its two children in N's
-// own order, or N itself where it is a leaf - and the FAR child F is tested AS A WHOLE: its box is the union of its children's boxes in the record (interior
-// bounds are exactly that union, bvh/mod.rs:279-287, so the products (bound - o) * inv_dir are F's own, bit for bit). Entries in the reference's order:
-// N's first, N's second, F. The first that is hit is entered, the others wait on the stack with their tmin, re-tested against the t_max of the moment they are
-// popped (pair_pop) - which is when the reference tests them. Not testing N itself changes nothing: a box contains its children's, so N fails exactly when both
-// of its children fail and passes whenever one of them does (finite rays: minima / maxima are monotone; rays with a zero direction component: the literal test
-// rejects a NaN on x and ignores one on y / z for parent and child alike - the argument k_trace_pair's far-child re-test and the any-hit quad kernel rest on).
-// Per ray the leaves visited, their order and every t_max update are BVH::intersect's; at most two entries are pushed per step (two levels), so the stack
-// need is the binary walk's. One dependent fetch per two levels on the near side, where a closest-hit ray finds its hit.
-template <int BLOCK>
-RT_DEV void quad_near_first_step(PairLane& L, const TraceOut& o, const float4* __restrict__ quads, unsigned* stack, float* tstack, size_t grid_lanes) {
-  const unsigned P = L.cur & 0x1fffffffu, axis_p = (L.cur >> 29) & 3u;
-  const float4* __restrict__ rec = quads + 8 * (size_t)P;
-  const float4 q0 = rec[0], q1 = rec[1], q2 = rec[2], q3 = rec[3], q4 = rec[4], q5 = rec[5], qc = rec[6], qx = rec[7];
-  const bool far_is_a = L.neg_axis(axis_p);  // negative along the node's split axis: the second child (slots 2, 3) is near
-  // near side's two slots (n0x: first slot of the side), far side's two slots
-  const float4 na0 = far_is_a ? q3 : q0, na1 = far_is_a ? q4 : q1, na2 = far_is_a ? q5 : q2;  // 12 floats: boxes of the near side's slots
-  const float4 fa0 = far_is_a ? q0 : q3, fa1 = far_is_a ? q1 : q4, fa2 = far_is_a ? q2 : q5;  // ... of the far side's
-  const unsigned cn0 = far_is_a ? __float_as_uint(qc.z) : __float_as_uint(qc.x), cn1 = far_is_a ? __float_as_uint(qc.w) : __float_as_uint(qc.y);
-  const unsigned cf1 = far_is_a ? __float_as_uint(qc.y) : __float_as_uint(qc.w);
-  const unsigned axes = __float_as_uint(qx.x);
-  const unsigned code_f = far_is_a ? __float_as_uint(qx.y) : __float_as_uint(qx.z);  // the far child itself (an interior node's index | axis, or its leaf code)
-  const unsigned axis_n = far_is_a ? ((axes >> 2) & 3u) : (axes & 3u);
-  // far child's box: the union of its two slots (slot 1 empty: the far child is a leaf and slot 0 is its own box)
-  const bool f_two = cf1 != 0xffffffffu;
-  const float4 fb0 = make_float4(f_two ? fminf(fa0.x, fa1.z) : fa0.x, f_two ? fminf(fa0.y, fa1.w) : fa0.y, f_two ? fminf(fa0.z, fa2.x) : fa0.z, f_two ? fmaxf(fa0.w, fa2.y) : fa0.w);
-  const float4 fb1 = make_float4(f_two ? fmaxf(fa1.x, fa2.z) : fa1.x, f_two ? fmaxf(fa1.y, fa2.w) : fa1.y, 0.0f, 0.0f);
-  // boxes as (min.xyz, max.x) (max.yz): slot 0 of a side = floats 0-5, slot 1 = floats 6-11
-  const float4 n0a = na0, n0b = na1, n1a = make_float4(na1.z, na1.w, na2.x, na2.y), n1b = make_float4(na2.z, na2.w, 0.0f, 0.0f);
-  bool h0, h1, hf; float t0, t1, tf;
-  if (__builtin_expect(L.finite(), 1)) {
-    const f3 qo = mk3(L.ray.o.x, L.ray.o.y, L.ray.o.z), qinv = mk3(L.inv_dir.x, L.inv_dir.y, L.inv_dir.z); const float qt = L.ray.t_max;
-    float m0, m1, mf;
-    slab_interval_finite_scalar(n0a, n0b, qo, qinv, t0, m0);
-    slab_interval_finite_scalar(n1a, n1b, qo, qinv, t1, m1);
-    slab_interval_finite_scalar(fb0, fb1, qo, qinv, tf, mf);
-    h0 = (t0 <= m0) & (m0 > 0.0f) & (t0 < qt);
-    h1 = (cn1 != 0xffffffffu) & (t1 <= m1) & (m1 > 0.0f) & (t1 < qt);
-    hf = (tf <= mf) & (mf > 0.0f) & (tf < qt);
-  } else {
-    const int nx = L.neg_x(), ny = L.neg_y(), nz = L.neg_z();
-    t0 = t1 = tf = 0.0f;
-    h0 = slab_geom(n0a, n0b, L.ray, L.inv_dir, nx, ny, nz, t0) && t0 < L.ray.t_max;
-    h1 = cn1 != 0xffffffffu && slab_geom(n1a, n1b, L.ray, L.inv_dir, nx, ny, nz, t1) && t1 < L.ray.t_max;
-    hf = slab_geom(fb0, fb1, L.ray, L.inv_dir, nx, ny, nz, tf) && tf < L.ray.t_max;
-  }
-  // the near child's own order: negative along ITS split axis => its second child first (a leaf near child has one slot)
-  const bool swap_n = (cn1 != 0xffffffffu) & L.neg_axis(axis_n);
-  const bool ha = swap_n ? h1 : h0, hb = swap_n ? h0 : h1; const float ta = swap_n ? t1 : t0, tb = swap_n ? t0 : t1; const unsigned ca = swap_n ? cn1 : cn0, cb = swap_n ? cn0 : cn1;
-  // entries in order: a, b, F. Push the later ones (F deepest), enter the first that is hit.
-  if (hf & (ha | hb)) { stack[L.sp * BLOCK] = code_f; tstack[(size_t)L.sp * grid_lanes] = tf; L.ttop = tf; ++L.sp; }
-  if (hb & ha) { stack[L.sp * BLOCK] = cb; tstack[(size_t)L.sp * grid_lanes] = tb; L.ttop = tb; ++L.sp; }
-  if (ha) L.cur = ca; else if (hb) L.cur = cb; else if (hf) L.cur = code_f; else pair_pop<false, BLOCK>(L, o, stack, tstack, grid_lanes);
-}
 
-template <bool ANY, int BLOCK, int DEPTH, int GENERAL = 0>
+template <int BLOCK, int DEPTH, int GENERAL = 0>  // occlusion rays only (closest hit four-wide was built in round 5, exact and slower: MEASUREMENTS R5)
 __global__ void __launch_bounds__(BLOCK, RT_GEN_MIN_WAVES(GENERAL)) k_trace_quad(DScene sc, TraceIO io, const unsigned* __restrict__ queue, const unsigned* __restrict__ shard_counts, unsigned shard_cap,
                                                       unsigned count_static, unsigned long long* stats, int st_rays, float* __restrict__ tmin_stack_mem, unsigned refill_min) {
+  constexpr bool ANY = true;
   const RT_SPTR_R(const float4) ray_o = io.ray_o; const RT_SPTR_R(const float4) ray_d = io.ray_d; const size_t rs = io.ray_stride;
   __shared__ unsigned stack_mem[DEPTH * BLOCK];
   unsigned* const stack = stack_mem + threadIdx.x;
@@ -2608,7 +2026,7 @@ __global__ void __launch_bounds__(BLOCK, RT_GEN_MIN_WAVES(GENERAL)) k_trace_quad
   PairLane L;
   L.active = false; L.found = false; L.pid = 0; L.dw = 0.0f;
   L.ray.o = L.ray.d = mk3(0, 0, 0); L.ray.t_max = 0.0f; L.set_inv(mk3(0, 0, 0)); L.set_rp(ray_pre(L.ray));
-  L.sp = 0; L.prim = -1; L.cur = 0; L.ttop = 0.0f; L.pf = L.pf_acc = 0u; L.hit.t = kInf; L.hit.b0 = L.hit.b1 = L.hit.b2 = 0.0f;
+  L.sp = 0; L.prim = -1; L.cur = 0; L.ttop = 0.0f; L.hit.t = kInf; L.hit.b0 = L.hit.b1 = L.hit.b2 = 0.0f;
   for (;;) {
     const unsigned long long idle = __ballot(!L.active);
     if (!exhausted && (unsigned)__popcll(idle) >= (idle == ~0ull ? 1u : refill_min)) {  // same refill scheme as k_trace_pair
@@ -2637,12 +2055,10 @@ __global__ void __launch_bounds__(BLOCK, RT_GEN_MIN_WAVES(GENERAL)) k_trace_quad
       const bool leaves_now = leaf_phase_now(L.active, at_leaf, leaf_min);
       if (L.active) {
         if (at_leaf) { if (leaves_now) pair_leaf_step<ANY, BLOCK, GENERAL>(L, out, sc, tri_p, stack, tstack, grid_lanes, ANY && io.shadow_masks != 0); }
-        else if constexpr (ANY) quad_interior_step<ANY, BLOCK>(L, out, quads, stack, tstack, grid_lanes);
-        else quad_near_first_step<BLOCK>(L, out, quads, stack, tstack, grid_lanes);
+        else quad_interior_step<ANY, BLOCK>(L, out, quads, stack, tstack, grid_lanes);
       }
     }
   }
-  RT_PF_SINK(L, tstack);
   if (stats) {
     for (int off = 32; off > 0; off >>= 1) n_rays += __shfl_down(n_rays, off);
     if (lane == 0u && n_rays) atomicAdd(&stats[st_rays], (unsigned long long)n_rays);
@@ -2664,7 +2080,7 @@ RT_DEV int hit_primitive(const DInstance* __restrict__ instances, unsigned n_ins
   while (hi - lo > 1u) { const unsigned mid = (lo + hi) >> 1; if (instances[mid].id_base <= (unsigned)hit_id) lo = mid; else hi = mid; }
   return (int)(instances[lo].prim_base + ((unsigned)hit_id - instances[lo].id_base));
 }
-RT_DEV unsigned bin_of(const DScene& sc, const DMaterial* __restrict__ materials, const float4* __restrict__ tri_p /* the shade records */, const RT_SPTR_R(const float4) hit, unsigned slot, unsigned n_bins) {
+RT_DEV unsigned bin_of(const DScene& sc, const DMaterial* __restrict__ materials, const float4* __restrict__ tri_p /* the shade records */, const float4* __restrict__ hit, unsigned slot, unsigned n_bins) {
   const float4 h4 = hit[slot];
   int prim = __float_as_int(h4.y);
   if (prim < 0) return n_bins - 1u;
@@ -2680,7 +2096,7 @@ RT_DEV unsigned bin_of(const DScene& sc, const DMaterial* __restrict__ materials
   return m < n_bins - 1u ? m : n_bins - 2u;
 }
 // bin_at[i]: the bin of queue entry i, kept for k_bin_scatter - finding it takes two dependent gathers (hit record -> triangle -> material) that need not be repeated
-__global__ void __launch_bounds__(256) k_bin_count(DScene sc, PassState ps, unsigned n_bins, unsigned* __restrict__ hist, unsigned short* __restrict__ bin_at) {
+static __global__ void __launch_bounds__(256) k_bin_count(DScene sc, PassState ps, unsigned n_bins, unsigned* __restrict__ hist, unsigned short* __restrict__ bin_at) {
   __shared__ unsigned lh[RT_BIN_MAX + 1];
   for (unsigned i = threadIdx.x; i <= RT_BIN_MAX; i += 256u) lh[i] = 0u;
   __syncthreads();
@@ -2688,23 +2104,18 @@ __global__ void __launch_bounds__(256) k_bin_count(DScene sc, PassState ps, unsi
   const unsigned count = ps.cnt_in ? qv.total() : ps.cap;
   for (unsigned i = blockIdx.x * 256u + threadIdx.x; i < count; i += gridDim.x * 256u) {
     const unsigned slot = ps.cnt_in ? qv.get(i) : i;
-    const unsigned b = bin_of(sc, sc.materials, sc.tri_rec, ps.hit, slot, n_bins);
+    const unsigned b = bin_of(sc, sc.materials, sc.tri_rec, sraw(ps.hit), slot, n_bins);
     bin_at[i] = (unsigned short)b;
     atomicAdd(&lh[b], 1u);
   }
   __syncthreads();
   for (unsigned i = threadIdx.x; i < n_bins; i += 256u) if (lh[i]) atomicAdd(&hist[i], lh[i]);
 }
-// The bounce's paths grouped by bin; sorted_cnt[RT_QSHARDS]: {total, 0, ...} so that the result reads as a one-shard queue. MOVE: the travelling records themselves
-// (ray direction - and origin where the scene has quadrics or instances, whose interactions need it -, hit, throughput, state) are copied to the sorted
-// position into the generation `to` / `to_hit`, so that the shade launches STREAM them (entry i = slot i) instead of gathering 4 x 16 bytes per vertex through
-// the sorted list from lines they share with vertices of other bins; the copy itself reads a stream and writes runs (a round's entries of one bin are
-// consecutive). !MOVE: `sorted` receives the slots and the shade kernels gather.
-template <bool MOVE>
-__global__ void __launch_bounds__(256) k_bin_scatter(DScene sc, PassState ps, unsigned n_bins, const unsigned* __restrict__ hist, unsigned* __restrict__ cursor,
+// The bounce's paths grouped by bin; sorted_cnt[RT_QSHARDS]: {total, 0, ...} so that the result reads as a one-shard queue. `sorted` receives the slots and the shade
+// kernels gather their records through it (a bin keeps the queue's order in rounds of 256 entries: runs of neighbouring slots).
+static __global__ void __launch_bounds__(256) k_bin_scatter(DScene sc, PassState ps, unsigned n_bins, const unsigned* __restrict__ hist, unsigned* __restrict__ cursor,
                                                      unsigned* __restrict__ sorted, unsigned* __restrict__ sorted_cnt, unsigned split_bin, unsigned split_bin2,
-                                                     unsigned split_bin3, unsigned* __restrict__ ranges, const unsigned short* __restrict__ bin_at,
-                                                     PathGen to, float4* __restrict__ to_hit, int with_origin) {
+                                                     unsigned split_bin3, unsigned* __restrict__ ranges, const unsigned short* __restrict__ bin_at) {
   __shared__ unsigned base[RT_BIN_MAX + 1], lcount[RT_BIN_MAX + 1], lbase[RT_BIN_MAX + 1];
   if (threadIdx.x == 0) {  // exclusive prefix of the histogram (<= 257 entries)
     unsigned run = 0;
@@ -2741,11 +2152,7 @@ __global__ void __launch_bounds__(256) k_bin_scatter(DScene sc, PassState ps, un
 #pragma unroll
     for (unsigned k = 0; k < E; ++k) if (live[k]) {
       const unsigned p = base[bin[k]] + lbase[bin[k]] + rank[k], from = pid[k];
-      if (MOVE) {
-        const float4 d4 = ps.in.d[from], h4 = ps.hit[from], b4 = ps.in.beta[from]; const uint4 s4 = ps.in.st[from];
-        to.d[p] = d4; to_hit[p] = h4; to.beta[p] = b4; to.st[p] = s4;
-        if (with_origin) to.o[p] = ps.in.o[from];
-      } else sorted[p] = from;
+      sorted[p] = from;
     }
     __syncthreads();
     for (unsigned b = threadIdx.x; b < n_bins; b += 256u) lcount[b] = 0u;
@@ -3103,8 +2510,14 @@ __global__ void __launch_bounds__(256, (MODE == 1 || LEAN || BOUNCED) ? ((LEAN |
     if (LDSREC == 3) sc.images = (const DImage*)s_imgs;
     sc.materials = (const DMaterial*)s_mats; sc.textures = (const DTexture*)s_texs;
   }
-  __shared__ OctRuns s_oct;
-  if (threadIdx.x < 8u) { s_oct.next[threadIdx.x] = 0u; s_oct.left[threadIdx.x] = 0u; }  // (the first barrier of the first append orders this)
+  // The kernel's once-through streams (path records in and out, shadow / MIS ray records) with or without the non-temporal hint (SPtr, RT_NT_STREAMS): with it where the launch
+  // also GATHERS from tables larger than a cache (triangle records, texels, environment rows - the hint keeps the streams from evicting them: S4 shade 2489 -> 2325 ms, S2
+  // 22.0 -> 20.6, S3 117.6 -> 114.3); without it where every table sits in LDS and the streams are all the launch reads (LDSREC == 1: S1 shade 219 -> 234 ms WITH the hint).
+  constexpr bool NTK = LDSREC != 1;
+  const auto in_o = sp<NTK>(ps.in.o), in_d = sp<NTK>(ps.in.d), in_beta = sp<NTK>(ps.in.beta); const auto in_st = sp<NTK>(ps.in.st); const auto pfilm_ = sp<NTK>(ps.pfilm);
+  const auto out_o = sp<NTK>(ps.out.o), out_d = sp<NTK>(ps.out.d), out_beta = sp<NTK>(ps.out.beta); const auto out_st = sp<NTK>(ps.out.st);
+  const auto sh_o = sp<NTK>(ps.sh.o), sh_d = sp<NTK>(ps.sh.d), sh_add = sp<NTK>(ps.sh.add);
+  const auto mi_o = sp<NTK>(ps.mi.o), mi_d = sp<NTK>(ps.mi.d), mi_a = sp<NTK>(ps.mi.a), mi_b = sp<NTK>(ps.mi.b), mi_c = sp<NTK>(ps.mi.c); const auto mi_flags = sp<NTK>(ps.mi.flags);
   QView qv; if (ps.cnt_in) qv.init(ps.q_in, ps.cnt_in, ps.shard_cap);
   unsigned first = 0, count = ps.cnt_in ? qv.total() : ps.cap;  // no counts: bounce 0 of a pass whose samples are all traced (entry i = slot i = path i)
   if (MODE != 1 && ps.range) { first = ps.range[0]; count = ps.range[1]; }
@@ -3123,9 +2536,8 @@ __global__ void __launch_bounds__(256, (MODE == 1 || LEAN || BOUNCED) ? ((LEAN |
     f3 nr_o = mk3(0, 0, 0), nr_d = mk3(0, 0, 0); rgb3 beta = mkc(0, 0, 0); float eta_scale = 1.0f; unsigned st_out = 0u, pid = 0u; unsigned long long rng_out = 0ull;
     if (lane_live) {
       // the vertex's records: four 16-byte loads at consecutive slots of consecutive lanes, requested together
-      const float4 d4 = ps.in.d[rslot], h4 = ps.hit[rslot], b4 = ps.in.beta[rslot]; const uint4 s4 = ps.in.st[rslot];
+      const float4 d4 = in_d[rslot], h4 = sraw(ps.hit)[rslot], b4 = in_beta[rslot]; const uint4 s4 = in_st[rslot];  // (hit: read twice in a launch - never with the non-temporal hint)
       pid = s4.y;
-      if (__float_as_int(h4.y) == RT_DEAD_PRIM) n_shaded -= 1u;  // a dead entry of an octant run (block_push_oct): a miss that is nobody's vertex
       unsigned sl, pix; split_path_id(ps, pid, sl, pix); const unsigned s = ps.s0 + sl;
       f3 ray_d = mk3(d4.x, d4.y, d4.z);
       beta = mkc(b4.x, b4.y, b4.z); eta_scale = b4.w;
@@ -3141,11 +2553,11 @@ __global__ void __launch_bounds__(256, (MODE == 1 || LEAN || BOUNCED) ? ((LEAN |
       SurfaceInteraction si; TriHit th; th.t = 0.0f; th.b0 = h4.z; th.b1 = h4.w; th.b2 = h4.x;
       if (found) {
         if (GENERAL && sc.n_instances != 0u && (unsigned)prim >= sc.n_top_prims) {  // a hit inside an object instance: from here on `prim` is the object's primitive
-          const float4 o4 = ps.in.o[rslot];
+          const float4 o4 = in_o[rslot];
           prim = instance_fill_interaction(gsc, (unsigned)prim, o4.x, o4.y, o4.z, ray_d.x, ray_d.y, ray_d.z, th.b0, th.b1, th.b2, si);
         }
         else if (GENERAL && (tri_flags(sc.tri_p, prim) & RT_FLAG_SPHERE)) {  // Sphere::intersect builds its interaction from the ray: origin and direction of the path's ray
-          const float4 o4 = ps.in.o[rslot];
+          const float4 o4 = in_o[rslot];
           (void)sphere_fill_interaction(sc.spheres[prim_sphere_index(sc.tri_p, prim)], mk3(o4.x, o4.y, o4.z), ray_d, si);
           si.ssb = normalize(si.sh_dpdu);
           si.prim = prim;
@@ -3170,7 +2582,7 @@ __global__ void __launch_bounds__(256, (MODE == 1 || LEAN || BOUNCED) ? ((LEAN |
       }
       if (found && bounces < fp.max_depth) {  // path.rs:139
         if ((MODE != 1 && !LEAN && !BOUNCED) && bounces == 0 && sc.needs_differentials && !RT_DBG(sc, 16)) {  // only the camera ray carries differentials (interaction.rs:245-314)
-          f2 pf; { float2 t = ps.pfilm[pid]; pf = mk2(t.x, t.y); }
+          f2 pf; { float2 t = pfilm_[pid]; pf = mk2(t.x, t.y); }
           f2 pl = table_2d(smp.tb, pix, 1, s);
           CameraRay cr = generate_camera_ray(fp, pf, pl, 1.0f / sqrtf((float)ps.spp));
           if (MODE == 0) compute_differential_call(si, cr.rx_o, cr.ry_o, cr.rx_d, cr.ry_d); else compute_differential(si, cr.rx_o, cr.ry_o, cr.rx_d, cr.ry_d);
@@ -3205,14 +2617,15 @@ __global__ void __launch_bounds__(256, (MODE == 1 || LEAN || BOUNCED) ? ((LEAN |
         if (voxel_ok && bsdf.num_nonspecular() > 0 && sc.n_lights > 0) {  // uniform_sample_one_light, integrator/mod.rs:186-220
           float su = smp.get_1d();
           int light_num; float light_pdf;
-          if (rows8) d1_sample_discrete_row8(ld_r0, ld_r1, sc.n_lights, su, light_num, light_pdf);
+          if (RT_DBG(sc, 128)) { light_num = clampi((int)(su * (float)sc.n_lights), 0, sc.n_lights - 1); light_pdf = 1.0f / (float)sc.n_lights; }  // (measurement builds: no row search)
+          else if (rows8) d1_sample_discrete_row8(ld_r0, ld_r1, sc.n_lights, su, light_num, light_pdf);
           else if (MODE != 1 && sc.ld_glog >= 0) d1_sample_discrete_guided(ld_func, ld_cdf, ld_int, sc.n_lights, su, sc.ld_guide + ld_row * ((1 << sc.ld_glog) + 1), sc.ld_glog, light_num, light_pdf);
           else d1_sample_discrete(ld_func, ld_cdf, ld_int, sc.n_lights, su, light_num, light_pdf);
           RT_STAMP(3);  // light pick: voxel row + discrete search
           if (light_pdf != 0.0f) {
             f2 u_light = smp.get_2d();
             f2 u_scattering = smp.get_2d();
-            const DLight& light = sc.lights[light_num];
+            const DLight& light = sc.lights[RT_DBG(sc, 256) ? 0 : light_num];  // (measurement builds, 256: one light's record for every lane - no gather)
             // ---- estimate_direct (integrator/mod.rs:222-318), light-sampling half
             rgb3 ld1 = mkc(0, 0, 0); f3 sh_dir = mk3(0, 0, 0);
             const bool q_light = QLIGHTS && (tri_flags(sc.tri_p, light.prim) & RT_FLAG_SPHERE) != 0u;  // the picked light sits on a sphere
@@ -3230,7 +2643,7 @@ __global__ void __launch_bounds__(256, (MODE == 1 || LEAN || BOUNCED) ? ((LEAN |
               float scattering_pdf = ((MODE != 1 && !LEAN) && light_is_delta(light)) ? 0.0f : bsdf.pdf(si.hit.wo, ls.wi, nonspec);  // read by the power heuristic only: a delta light has none
               if (!is_black(f)) {
                 Ray sr = spawn_ray_to_interaction(si.hit, ls.p1);  // VisibilityTester, light/mod.rs:52-55
-                ps.sh.o[i] = make_float4(sr.o.x, sr.o.y, sr.o.z, sr.t_max);  // (shadow and MIS records sit at the vertex's position in THIS launch's queue, see PassState::sh)
+                sh_o[i] = make_float4(sr.o.x, sr.o.y, sr.o.z, sr.t_max);  // (shadow and MIS records sit at the vertex's position in THIS launch's queue, see PassState::sh)
                 sh_dir = sr.d;
                 want_shadow = true;
                 if (light_is_delta(light)) ld1 = vdiv(f * ls.li, ls.pdf);
@@ -3248,6 +2661,7 @@ __global__ void __launch_bounds__(256, (MODE == 1 || LEAN || BOUNCED) ? ((LEAN |
                 if (!(bs.type & BSDF_SPECULAR)) {
                   float lp;
                   if (q_light) lp = sphere_cone_pdf_wi(sc.spheres[prim_sphere_index(sc.tri_p, light.prim)], q_center, si.hit);
+                  else if (RT_DBG(sc, 512)) lp = 1.0f;  // (measurement builds: no re-intersection of the emitter)
                   else lp = (MODE == 1 || LEAN) ? area_light_pdf_li<false>(sc, light, si.hit, bs.wi) : light_pdf_li<GENERAL, BOUNCED>(gsc, light, si.hit, bs.wi);
                   if (lp == 0.0f) go = false;  // `return ld`
                   else weight = power_heuristic1(bs.pdf, lp);
@@ -3258,8 +2672,8 @@ __global__ void __launch_bounds__(256, (MODE == 1 || LEAN || BOUNCED) ? ((LEAN |
                 }
                 if (go) {
                   Ray mr = spawn_ray(si.hit, bs.wi);
-                  ps.mi.o[i] = make_float4(mr.o.x, mr.o.y, mr.o.z, kInf);
-                  ps.mi.d[i] = make_float4(mr.d.x, mr.d.y, mr.d.z, __uint_as_float(pid));  // the path the record belongs to
+                  mi_o[i] = make_float4(mr.o.x, mr.o.y, mr.o.z, kInf);
+                  mi_d[i] = make_float4(mr.d.x, mr.d.y, mr.d.z, __uint_as_float(pid));  // the path the record belongs to
                   want_mis = true; f2v = f; w2 = weight; spdf2 = bs.pdf;
                   // An infinite light is never the emitter a ray hits (integrator/mod.rs:291-309): the term is `Le(ray)` if the ray leaves the
                   // scene and nothing otherwise, so occlusion is all this ray has to report.
@@ -3268,16 +2682,16 @@ __global__ void __launch_bounds__(256, (MODE == 1 || LEAN || BOUNCED) ? ((LEAN |
               }
             }
             if (want_mis) {  // both halves are combined by k_resolve once both rays are back
-              ps.mi.a[i] = make_float4(ld1.r, ld1.g, ld1.b, light_pdf);
-              ps.mi.b[i] = make_float4(f2v.r, f2v.g, f2v.b, w2);
-              ps.mi.c[i] = make_float4(beta.r, beta.g, beta.b, spdf2);
-              ps.mi.flags[i] = (want_shadow ? RT_PEND_SHADOW : 0u) | 2u | ((unsigned)light_num << 2) | (mis_occlusion_only ? RT_PEND_MIS_ANY : 0u);
+              mi_a[i] = make_float4(ld1.r, ld1.g, ld1.b, light_pdf);
+              mi_b[i] = make_float4(f2v.r, f2v.g, f2v.b, w2);
+              mi_c[i] = make_float4(beta.r, beta.g, beta.b, spdf2);
+              mi_flags[i] = (want_shadow ? RT_PEND_SHADOW : 0u) | 2u | ((unsigned)light_num << 2) | (mis_occlusion_only ? RT_PEND_MIS_ANY : 0u);
               if (!want_shadow) ps.occ_sh[i] = (unsigned char)1;  // no light-sampling term: as good as blocked (the any-hit kernel writes the byte of every other vertex)
             } else if (want_shadow) {  // L += beta * ((0 + Ld1) / pick_pdf) if unoccluded, applied by the any-hit kernel
               rgb3 add = beta * vdiv(mkc(0, 0, 0) + ld1, light_pdf);
-              ps.sh.add[i] = make_float4(add.r, add.g, add.b, 0.0f);
+              sh_add[i] = make_float4(add.r, add.g, add.b, 0.0f);
             }
-            if (want_shadow) ps.sh.d[i] = make_float4(sh_dir.x, sh_dir.y, sh_dir.z, __uint_as_float((want_mis ? 0u : 0x80000000u) | pid));  // bit 31: complete here (no MIS ray), bits 0-30: the path
+            if (want_shadow) sh_d[i] = make_float4(sh_dir.x, sh_dir.y, sh_dir.z, __uint_as_float((want_mis ? 0u : 0x80000000u) | pid));  // bit 31: complete here (no MIS ray), bits 0-30: the path
           }
         }
         RT_STAMP(5);  // BSDF-sampling half + records
@@ -3312,13 +2726,12 @@ __global__ void __launch_bounds__(256, (MODE == 1 || LEAN || BOUNCED) ? ((LEAN |
     n_tail += (unsigned)__popcll(__ballot(tail));
     constexpr int NQ = (MODE == 1 || LEAN) ? 3 : 4;  // area lights only: every MIS ray needs its closest hit
     const int ci[4] = {0, 1, 2, 3}; const bool pr[4] = {cont, want_shadow, want_mis && !mis_occlusion_only, want_mis && mis_occlusion_only}; unsigned slot[4];
-    if (ps.oct_log2) block_push_oct<NQ>(ps.cnt_out, ps.shard_cap, pr, dir_octant(nr_d), ps.oct_log2, s_oct, slot);
-    else block_push<NQ>(ps.cnt_out, ps.shard_cap, ci, pr, slot);
+    block_push<NQ>(ps.cnt_out, ps.shard_cap, ci, pr, slot);
     if (cont) {  // the path's records for the next bounce, at its slot of that bounce's queue: a wave's stores are runs of consecutive slots
-      ps.out.o[slot[0]] = make_float4(nr_o.x, nr_o.y, nr_o.z, kInf);
-      ps.out.d[slot[0]] = make_float4(nr_d.x, nr_d.y, nr_d.z, 0.0f);
-      ps.out.beta[slot[0]] = make_float4(beta.r, beta.g, beta.b, eta_scale);
-      ps.out.st[slot[0]] = make_uint4(st_out, pid, (unsigned)rng_out, (unsigned)(rng_out >> 32));
+      out_o[slot[0]] = make_float4(nr_o.x, nr_o.y, nr_o.z, kInf);
+      out_d[slot[0]] = make_float4(nr_d.x, nr_d.y, nr_d.z, 0.0f);
+      out_beta[slot[0]] = make_float4(beta.r, beta.g, beta.b, eta_scale);
+      out_st[slot[0]] = make_uint4(st_out, pid, (unsigned)rng_out, (unsigned)(rng_out >> 32));
     }
     if (want_shadow) ps.q_shadow[slot[1]] = i;  // the ray queues name RECORDS (= this launch's queue positions)
     if (pr[2]) ps.q_mis[slot[2]] = i;
@@ -3346,9 +2759,8 @@ __global__ void __launch_bounds__(256, (MODE == 1 || LEAN || BOUNCED) ? ((LEAN |
       const bool lane_live = i < count;
       n_shaded += lane_live ? 1u : 0u;
       const unsigned rslot = lane_live ? (ps.cnt_in ? qv.get(i) : i) : 0u;
-      int hprim = -1; if (lane_live) { const float4 hh = ps.hit[rslot]; hprim = __float_as_int(hh.y); }
+      const int hprim = lane_live ? __float_as_int(sraw(ps.hit)[rslot].y) : -1;
       const bool hit = hprim >= 0;
-      if (hprim == RT_DEAD_PRIM) n_shaded -= 1u;
       const unsigned long long m = __ballot(hit);
       if (lane == 0u) s_wave_hits[wv] = (unsigned)__popcll(m);
       __syncthreads();
@@ -3370,7 +2782,6 @@ __global__ void __launch_bounds__(256, (MODE == 1 || LEAN || BOUNCED) ? ((LEAN |
       shade_vertex(lv, lv ? s_ring_i[pos] : 0u, lv ? s_ring_slot[pos] : 0u);
     }
   }
-  if (ps.oct_log2) oct_fill_dead(ps.out, s_oct);
   if (GENERAL || QLIGHTS) {
     for (int off = 32; off > 0; off >>= 1) n_unreached += __shfl_down(n_unreached, off);
     if ((threadIdx.x & 63u) == 0u && n_unreached) atomicAdd(&ps.stats[ST_MIS_UNREACHED], (unsigned long long)n_unreached);
@@ -3386,7 +2797,7 @@ __global__ void __launch_bounds__(256, (MODE == 1 || LEAN || BOUNCED) ? ((LEAN |
 // The miss bin of a binned queue: a path whose ray left the scene. PathIntegrator::li adds the environment's radiance only for camera rays
 // and after specular bounces (path.rs:127-136, otherwise the light samples already account for it) and terminates the path; throughput,
 // RNG and sampler counters stay as they are. One load for most entries - instead of the generic shade kernel's whole prologue.
-__global__ void __launch_bounds__(256) k_shade_miss(DScene sc, PassState ps) {
+static __global__ void __launch_bounds__(256) k_shade_miss(DScene sc, PassState ps) {
   const unsigned first = ps.range[0], count = ps.range[1];
   const unsigned stride = gridDim.x * blockDim.x;
   for (unsigned i = first + blockIdx.x * blockDim.x + threadIdx.x; i < count; i += stride) {
@@ -3466,7 +2877,7 @@ __global__ void __launch_bounds__(256) k_resolve(DScene sc, PassState ps) {
 // therefore accumulated in exactly the reference's per-tile order and flushed once after the last pass;
 // splats onto other pixels (filter radius > 0.5, or a sample exactly on a pixel edge) go through float
 // atomics. film_acc: float4 (R, G, B sums, weight sum) per cropped pixel.
-__global__ void __launch_bounds__(256) k_film_accumulate(FrameParams fp, PassState ps, const float* __restrict__ filter_table, float4* film_acc) {
+static __global__ void __launch_bounds__(256) k_film_accumulate(FrameParams fp, PassState ps, const float* __restrict__ filter_table, float4* film_acc) {
   const unsigned stride = gridDim.x * blockDim.x;
   const int cw = fp.crop_x1 - fp.crop_x0;
   const float inv_rx = 1.0f / fp.radius_x, inv_ry = 1.0f / fp.radius_y;
@@ -3520,7 +2931,7 @@ __global__ void __launch_bounds__(256) k_film_accumulate(FrameParams fp, PassSta
   }
 }
 // merge_film_tile's RGB -> XYZ (spectrum.rs:98-106); output (X, Y, Z, filter_weight_sum)
-__global__ void k_film_finalize(const float4* film_acc, float4* film_xyzw, unsigned long long n) {
+static __global__ void k_film_finalize(const float4* film_acc, float4* film_xyzw, unsigned long long n) {
   unsigned long long i = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
   float4 a = film_acc[i];
@@ -3534,7 +2945,7 @@ __global__ void k_film_finalize(const float4* film_acc, float4* film_xyzw, unsig
 // What Triangle::intersect computes of the triangle alone (dpdu, dpdv, the geometric normal and - without per-vertex normals or tangents - the whole shading
 // frame and the first axis of Bsdf::new's frame) is evaluated once here, by the functions the per-vertex path uses (tri_geo, tri_frame: IEEE + - * / sqrt
 // without contraction give the same bits wherever they run), and kept in one 128-byte record per triangle together with the traversal record.
-__global__ void __launch_bounds__(256) k_tri_records(DScene sc, float4* __restrict__ out) {
+static __global__ void __launch_bounds__(256) k_tri_records(DScene sc, float4* __restrict__ out) {
   const unsigned t = blockIdx.x * blockDim.x + threadIdx.x;
   if (t >= sc.n_tris) return;
   const float4 a = sc.tri_p[3 * (size_t)t], b = sc.tri_p[3 * (size_t)t + 1], c = sc.tri_p[3 * (size_t)t + 2];
@@ -3555,21 +2966,21 @@ __global__ void __launch_bounds__(256) k_tri_records(DScene sc, float4* __restri
   r[6] = make_float4(g.dpdu.x, g.dpdu.y, g.dpdu.z, 0.0f); r[7] = make_float4(g.dpdv.x, g.dpdv.y, g.dpdv.z, 0.0f);
 }
 // DScene::ld_rows8: the tables of a scene with <= 3 lights repacked, one 32-byte record per built voxel
-__global__ void __launch_bounds__(256) k_lightdist_rows8(const float* __restrict__ func, const float* __restrict__ cdf, const float* __restrict__ fint, int n_lights, unsigned rows, float4* __restrict__ out) {
+static __global__ void __launch_bounds__(256) k_lightdist_rows8(const float* __restrict__ func, const float* __restrict__ cdf, const float* __restrict__ fint, int n_lights, unsigned rows, float4* __restrict__ out) {
   const unsigned r = blockIdx.x * blockDim.x + threadIdx.x;
   if (r >= rows) return;
   const float* f = func + (size_t)r * n_lights; const float* c = cdf + (size_t)r * (n_lights + 1);
   out[2 * (size_t)r] = make_float4(fint[r], f[0], n_lights > 1 ? f[1] : 0.0f, n_lights > 2 ? f[2] : 0.0f);
   out[2 * (size_t)r + 1] = make_float4(c[0], c[1], n_lights > 1 ? c[2] : 0.0f, n_lights > 2 ? c[3] : 0.0f);
 }
-__global__ void __launch_bounds__(256) k_lightdist_dense8(const float4* __restrict__ rows8, const int* __restrict__ slot_of, unsigned long long n_voxels, float4* __restrict__ out) {
+static __global__ void __launch_bounds__(256) k_lightdist_dense8(const float4* __restrict__ rows8, const int* __restrict__ slot_of, unsigned long long n_voxels, float4* __restrict__ out) {
   const unsigned long long v = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x;
   if (v >= n_voxels) return;
   const int slot = slot_of[v];
   out[2 * v] = slot >= 0 ? rows8[2 * (size_t)slot] : make_float4(-1.0f, 0.0f, 0.0f, 0.0f);
   out[2 * v + 1] = slot >= 0 ? rows8[2 * (size_t)slot + 1] : make_float4(0.0f, 0.0f, 0.0f, 0.0f);
 }
-__global__ void __launch_bounds__(256) k_light_consts(DScene sc, DLight* __restrict__ lights, int n_all /* sampled lights + unlisted emitters */) {
+static __global__ void __launch_bounds__(256) k_light_consts(DScene sc, DLight* __restrict__ lights, int n_all /* sampled lights + unlisted emitters */) {
   const int j = (int)(blockIdx.x * blockDim.x + threadIdx.x);
   if (j >= n_all) return;
   DLight& l = lights[j];
@@ -3591,7 +3002,7 @@ __global__ void __launch_bounds__(256) k_light_consts(DScene sc, DLight* __restr
 // per triangle, the voxels of its (slightly inflated) box that its plane crosses - a conservative superset; the
 // reference computes voxels lazily on first lookup (lightdistrib.rs:200-296), this is the eager equivalent.
 // Only marked voxels are built (list = compacted marks); rt_light_distribution() asks for all of them.
-__global__ void __launch_bounds__(256) k_lightdist_mark(DScene sc, unsigned char* __restrict__ mark) {
+static __global__ void __launch_bounds__(256) k_lightdist_mark(DScene sc, unsigned char* __restrict__ mark) {
   const unsigned t = blockIdx.x * blockDim.x + threadIdx.x;
   if (t >= (sc.n_instances != 0u ? sc.n_top_prims : sc.n_tris)) return;  // object-space primitives follow the top level's: they are reached through their instances
   f3 p0, p1, p2; load_tri(sc.tri_p, (int)t, p0, p1, p2);
@@ -3633,7 +3044,7 @@ __global__ void __launch_bounds__(256) k_lightdist_mark(DScene sc, unsigned char
         if (flat || fabsf(dot(n, c - p0)) <= r * 1.01f) mark[((size_t)z * sc.nvox[1] + y) * sc.nvox[0] + x] = 1;
       }
 }
-__global__ void __launch_bounds__(256) k_lightdist_compact(const unsigned char* __restrict__ mark, unsigned n_vox, int mark_all, unsigned* __restrict__ list, unsigned* __restrict__ n_list) {
+static __global__ void __launch_bounds__(256) k_lightdist_compact(const unsigned char* __restrict__ mark, unsigned n_vox, int mark_all, unsigned* __restrict__ list, unsigned* __restrict__ n_list) {
   const unsigned v = blockIdx.x * blockDim.x + threadIdx.x;
   const bool take = v < n_vox && (mark_all || mark[v]);
   const unsigned slot = wave_push(n_list, take);
@@ -3705,7 +3116,7 @@ __global__ void __launch_bounds__(128) k_lightdist_contrib(DScene sc, const unsi
   }
   func[(size_t)li * sc.n_lights + j] = contrib;
 }
-__global__ void __launch_bounds__(128) k_lightdist_finish(DScene sc, const unsigned* __restrict__ list, const unsigned* __restrict__ n_list, float* func, float* cdf, float* fint, int* slot_of,
+static __global__ void __launch_bounds__(128) k_lightdist_finish(DScene sc, const unsigned* __restrict__ list, const unsigned* __restrict__ n_list, float* func, float* cdf, float* fint, int* slot_of,
                                                           unsigned short* guide, int glog) {
   const unsigned li = blockIdx.x * blockDim.x + threadIdx.x;
   if (li >= *n_list) return;
@@ -3729,7 +3140,7 @@ __global__ void __launch_bounds__(128) k_lightdist_finish(DScene sc, const unsig
     for (int k = 0; k <= G; ++k) { const float x = (float)k / (float)G; while (i <= nl && cv[i] <= x) ++i; gv[k] = (unsigned short)i; }
   }
 }
-__global__ void k_lightdist_iota(unsigned n, unsigned* __restrict__ list, unsigned* __restrict__ n_list) {  // every voxel, in order: slot == voxel
+static __global__ void k_lightdist_iota(unsigned n, unsigned* __restrict__ list, unsigned* __restrict__ n_list) {  // every voxel, in order: slot == voxel
   const unsigned v = blockIdx.x * blockDim.x + threadIdx.x;
   if (v < n) list[v] = v;
   if (v == 0) *n_list = n;

@@ -12,7 +12,7 @@
 #include <limits>
 #include <vector>
 #include "../../include/rtx_hip.h"
-// (after rtx_kernels.h: RT_LINK_LEAF, RT_LINK_OFF_BITS, RT_MID_NODES, RT_SMALL_NODES)
+// (after rtx_kernels.h: RT_LINK_OFF_BITS, RT_MID_NODES, RT_SMALL_NODES)
 
 struct RtLinkTables {
   std::vector<uint16_t> skip8;                 // 8 x n_nodes
@@ -163,7 +163,7 @@ static void rt_build_link_tables(const rt_scene_desc* desc, bool mid, bool want_
       // Where the rays start: a RANDOM WALK, as the paths they stand for - the first vertex of a chain an area-weighted surface point (three of four chains leave it
       // towards the middle of the scene, where a path's next vertex usually lies), each further vertex where the chain's last ray hit, up to five deep or until a ray
       // leaves the scene; surfaces are thereby weighted by how much of the scene sees them (RTX_CAL_WALK=0, measurement knob: every ray from an area-weighted point).
-      static const bool walk_on = !(getenv("RTX_CAL_WALK") && getenv("RTX_CAL_WALK")[0] == '0');
+      static const char* walk_env = getenv("RTX_CAL_WALK"); static const bool walk_on = !(walk_env && walk_env[0] == '0');
       bool have_vertex = false; int depth = 0; double vp[3] = {0, 0, 0}, vn[3] = {0, 0, 1};
       for (uint32_t r = 0; r < K && cum[desc->n_tris] > 0.0; ++r) {
         CalRay cr; cr.t_max = 1e300;
@@ -318,14 +318,15 @@ static void rt_build_link_tables(const rt_scene_desc* desc, bool mid, bool want_
         }
         if (w < 8) for (uint32_t i = 0; i < nn; ++i) nt += kept[w][i] ? 1u : 0u;
       }
-      if (getenv("RTX_PRUNE_REPORT") || want_stats) {  // measurement knob / rt_link_tables: simulated node tests per calibration ray, all nodes against the chosen ones
+      static const bool prune_report = getenv("RTX_PRUNE_REPORT") != nullptr;
+      if (prune_report || want_stats) {  // measurement knob / rt_link_tables: simulated node tests per calibration ray, all nodes against the chosen ones
         for (int w = 0; w < 9; ++w) if (rays[w].size() >= 64) {
           std::vector<char> sel = kept[w]; kept[w].assign(nn, 1);
           const unsigned long long full = simulate(w, n_pass, n_fail); kept[w] = sel;
           const unsigned long long now = simulate(w, n_pass, n_fail);
           uint32_t k = 0; for (uint32_t i = 0; i < nn; ++i) k += sel[i] ? 1u : 0u;
           out.n_rays[w] = rays[w].size(); out.tests_all[w] = (double)full; out.tests_kept[w] = (double)now;
-          if (getenv("RTX_PRUNE_REPORT")) fprintf(stderr, "[rtx] prune set %d: %zu rays, %.2f -> %.2f node tests per ray, %u of %u nodes tested\n", w, rays[w].size(), (double)full / rays[w].size(), (double)now / rays[w].size(), k, nn);
+          if (prune_report) fprintf(stderr, "[rtx] prune set %d: %zu rays, %.2f -> %.2f node tests per ray, %u of %u nodes tested\n", w, rays[w].size(), (double)full / rays[w].size(), (double)now / rays[w].size(), k, nn);
         }
       }
       out.nodes_tested = (nt + 4u) / 8u;  // (the closest-hit walks' average over the octants)
@@ -362,7 +363,7 @@ static void rt_build_link_tables(const rt_scene_desc* desc, bool mid, bool want_
             const uint32_t skp = end_[i] < nn ? next_tested[end_[i]] : nn;
             const rt_bvh_node& nd = desc->nodes[i];
             const int off_bits = mid ? RT_LINK_OFF_BITS(RT_MID_NODES) : RT_LINK_OFF_BITS(RT_SMALL_NODES);
-            L[base + i] = nd.n_prims != 0 && RT_LINK_LEAF ? (0x80000000u | ((uint32_t)nd.n_prims << (16 + off_bits)) | ((uint32_t)nd.offset << 16) | skp) : ((enter << 16) | skp);
+            L[base + i] = nd.n_prims != 0 ? (0x80000000u | ((uint32_t)nd.n_prims << (16 + off_bits)) | ((uint32_t)nd.offset << 16) | skp) : ((enter << 16) | skp);
           }
           L[start_at] = next_tested[0];
         }

@@ -29,16 +29,30 @@ class BackendError(RuntimeError):
     pass
 
 
+STAMP = os.path.join(_BUILD, "source.sha")
+
+
+def source_sha() -> str:
+    """sha256 over everything the two libraries are built from (csrc/*.{h,hip,cpp,inl}, the Makefile, include/*.h)."""
+    import hashlib
+    h = hashlib.sha256()
+    files = [os.path.join(_CSRC, f) for f in sorted(os.listdir(_CSRC)) if f.endswith((".h", ".hip", ".cpp", ".inl")) or f == "Makefile"]
+    files += [os.path.join(_HERE, "..", "include", f) for f in ("rtx_hip.h", "rtx_host.h")]
+    for f in files:
+        h.update(os.path.basename(f).encode() + b"\0")
+        h.update(open(f, "rb").read())
+    return h.hexdigest()
+
+
 def build(force: bool = False) -> None:
-    """Compile both libraries for gfx950 (hipcc cross-compiles without a GPU)."""
-    srcs = [os.path.join(_CSRC, f) for f in os.listdir(_CSRC) if f.endswith((".h", ".hip", ".cpp", ".inl")) or f == "Makefile"]
-    srcs += [os.path.join(_HERE, "..", "include", f) for f in ("rtx_hip.h", "rtx_host.h")]
-    stale = force or not (os.path.exists(HOST_LIB) and os.path.exists(HIP_LIB))
-    if not stale:
-        newest = max(os.path.getmtime(s) for s in srcs)
-        stale = newest > min(os.path.getmtime(HOST_LIB), os.path.getmtime(HIP_LIB))
-    if stale:
-        subprocess.check_call(["make", "-C", _CSRC, "-s"])
+    """Compile both libraries for gfx950 (hipcc cross-compiles without a GPU). Whether the built libraries are current is decided by CONTENT: the sha256 of the
+    sources is stamped beside them (csrc/_build/source.sha) - the libraries are untracked and travel to the GPU box by snapshot, where file times mean nothing."""
+    sha = source_sha()
+    stamped = open(STAMP).read().strip() if os.path.exists(STAMP) else None
+    if force or stamped != sha or not (os.path.exists(HOST_LIB) and os.path.exists(HIP_LIB)):
+        subprocess.check_call(["make", "-C", _CSRC, "-s"] + (["-B"] if force or (stamped is not None and stamped != sha) else []))
+        with open(STAMP, "w") as f:
+            f.write(sha + "\n")
 
 
 class RenderParams(C.Structure):

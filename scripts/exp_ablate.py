@@ -1,12 +1,14 @@
 """Measurement build only (make -C rustracer_amd/csrc ABLATE=1): per-kernel-stage times and per-front-end vertex counts of a scene with parts of the
-shade kernel switched off through RTX_DBG (1 textures, 2 env CDF search, 4 env map lookup, 8 BSDF-sampled MIS half, 16 differentials). Images are wrong."""
+shade kernel switched off through RTX_DBG (1 textures, 2 env CDF search, 4 env map lookup, 8 BSDF-sampled MIS half, 16 differentials, 32 per-triangle uv gather, 64 half triangle record,
+128 light pick without the row search, 256 every lane the first light's record, 512 light pdf without re-intersecting the emitter). Images are wrong.
+Usage (GPU box, after `make -C rustracer_amd/csrc ABLATE=1`): python scripts/exp_ablate.py <scene> <spp> [dbg ...]"""
 import os, subprocess, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 scene, spp = (sys.argv[1] if len(sys.argv) > 1 else "room"), int(sys.argv[2]) if len(sys.argv) > 2 else 256
 if len(sys.argv) > 3 and sys.argv[3] == "child":
     from rustracer_amd import host
     from rustracer_amd.scenes import blob_scene, cornell_box, mis_plates, room_env
-    d = {"room": room_env, "mis": mis_plates, "blob": blob_scene}[scene](spp=spp) if scene != "cornell" else cornell_box(1024, 1024, spp)
+    d = {"room": room_env, "mis": mis_plates, "blob": blob_scene, "mis-spheres": (lambda spp: mis_plates(spp=spp, analytic_spheres=True))}[scene](spp=spp) if scene != "cornell" else cornell_box(1024, 1024, spp)
     h = host.HostScene(d); h.upload(); h.render(time_kernels=True)
     _, st = h.render(time_kernels=True)
     v = [st[k] for k in ("vertices_lambert_const", "vertices_lambert", "vertices_two_lobe", "vertices_generic")]

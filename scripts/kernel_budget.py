@@ -16,24 +16,26 @@ READELF = "/opt/rocm/lib/llvm/bin/llvm-readelf"
 def kernel_resources(lib=LIB):
     """{demangled kernel name: dict(vgpr, agpr, sgpr, scratch, lds, vgpr_spills)}"""
     b = open(lib, "rb").read()
-    i = b.find(b"__CLANG_OFFLOAD_BUNDLE__")
-    if i < 0:
-        raise RuntimeError("no offload bundle in " + lib)
-    n = struct.unpack_from("<Q", b, i + 24)[0]
-    p, code = i + 32, None
-    for _ in range(n):
-        off, size, tl = struct.unpack_from("<QQQ", b, p)
-        p += 24
-        triple = b[p:p + tl]
-        p += tl
-        if b"gfx950" in triple:
-            code = b[i + off:i + off + size]
-    if code is None:
+    codes, i = [], b.find(b"__CLANG_OFFLOAD_BUNDLE__")
+    while i >= 0:  # one bundle per translation unit (rtx_hip.hip, rtx_shade.hip)
+        n = struct.unpack_from("<Q", b, i + 24)[0]
+        p = i + 32
+        for _ in range(n):
+            off, size, tl = struct.unpack_from("<QQQ", b, p)
+            p += 24
+            triple = b[p:p + tl]
+            p += tl
+            if b"gfx950" in triple:
+                codes.append(b[i + off:i + off + size])
+        i = b.find(b"__CLANG_OFFLOAD_BUNDLE__", i + 24)
+    if not codes:
         raise RuntimeError("no gfx950 code object in " + lib)
-    with tempfile.NamedTemporaryFile(suffix=".co") as f:
-        f.write(code)
-        f.flush()
-        notes = subprocess.run([READELF, "--notes", f.name], capture_output=True, text=True, check=True).stdout
+    notes = ""
+    for code in codes:
+        with tempfile.NamedTemporaryFile(suffix=".co") as f:
+            f.write(code)
+            f.flush()
+            notes += subprocess.run([READELF, "--notes", f.name], capture_output=True, text=True, check=True).stdout
     out = {}
     for blk in re.split(r"\n  - \.agpr_count:", notes)[1:]:
         g = lambda k: int(re.search(r"\." + k + r":\s+(\d+)", blk).group(1))
