@@ -27,6 +27,11 @@ struct DLight {
   // guide tables of the CDF searches (rt_scene_create): guide[row][k] = the number of entries of the row's CDF that are <= k / 2^glog, k = 0 .. 2^glog - so
   // the bisection for u starts inside [guide[k], guide[k + 1]], k = floor(u 2^glog), ~16 entries instead of 2049 (same answer: the CDF is non-decreasing)
   const unsigned short* guide; const unsigned short* mguide; int glog, mglog;
+  // round 6: the conditional rows' brackets as BUCKET RECORDS (rt_scene_create): bk[(v << glog) + k] = 32 bytes for the u in [k, k + 1) / 2^glog of row v -
+  // {g0 | len << 16, cdf[g0 - 1 .. g0 + 2], func[g0 - 1 .. g0 + 1]}, g0 = guide[v][k], len = min(guide[v][k + 1] - g0, 3). With len <= 2 (what a sample almost always meets: u is
+  // uniform over the buckets, and the buckets crowded with entries are the dark texels' few) the record holds everything Distribution1D::sample_continuous reads of the row -
+  // ONE 32-byte gather instead of a guide entry and then a bracket of pairs (two dependent round trips, two L2-miss requests); len == 3: the guided search. NULL: not built
+  const float4* bk;
   // constants of a triangle emitter, evaluated once on the device (k_light_consts) by the expressions DiffuseAreaLight::sample_li's call chain uses per sample:
   // normalize(cross(p1 - p0, p2 - p0)) (Triangle::sample, mesh.rs:617, before orientation) and 1 / area (shapes/mod.rs:45)
   float nrm[3]; float inv_area;

@@ -79,7 +79,7 @@ struct rt_scene {
   bool deep_column = false;  // top level + deepest object need more than 64 stack entries in one column: k_trace_big with 128
   DevBuf quads; bool use_quads = false; int quad_stack_depth = 0;  // four-wide records of the any-hit kernel (k_trace_quad)
   DevBuf tri_rec;  // per-triangle shade records (k_tri_records)
-  DevBuf nodes, tri_p, tri_n, tri_uv, tri_s, tri_alpha, spheres, textures, images, materials, lights, texels, dist, guides;
+  DevBuf nodes, tri_p, tri_n, tri_uv, tri_s, tri_alpha, spheres, textures, images, materials, lights, texels, dist, guides, buckets;
   bool has_spheres = false;
   bool has_instances = false;  // object instances: two-level traversal in k_trace_big<.., GENERAL>, every vertex shaded by k_shade<0, true>
   DevBuf instances;
@@ -489,6 +489,27 @@ extern "C" int rt_scene_create(const rt_scene_desc* desc, int device, rt_scene**
         const size_t gw = ((size_t)1 << d.glog) + 1;
         d.guide = s->guides.as<unsigned short>() + gbase;
         for (int r = 0; r < l.dist_nv; ++r) guide_row(l.dist_cdf + (size_t)r * (l.dist_nu + 1), l.dist_nu, d.glog, &gblob[gbase + (size_t)r * gw]);
+        // the rows' bucket records (DLight::bk, round 6): per (row, bucket) what a sample of that bucket reads of the row, 32 bytes
+        d.bk = nullptr;
+        const size_t n_rec = (size_t)l.dist_nv << d.glog;
+        if (n_inf == 1 && n_rec * 32 <= ((size_t)256 << 20) && !env_is("RTX_ENV_BUCKETS", '0')) {  // (one environment light; RTX_ENV_BUCKETS=0: the A/B control)
+          std::vector<float> rec(n_rec * 8);
+          const int n = l.dist_nu, G = 1 << d.glog;
+          for (int r = 0; r < l.dist_nv; ++r) {
+            const float* cdf = l.dist_cdf + (size_t)r * (n + 1); const float* fn = l.dist_func + (size_t)r * n;
+            const unsigned short* g = &gblob[gbase + (size_t)r * gw];
+            for (int k = 0; k < G; ++k) {
+              float* o = &rec[(((size_t)r << d.glog) + (size_t)k) * 8];
+              const int g0 = g[k], len = std::min((int)g[k + 1] - g0, 3);
+              const uint32_t w = (uint32_t)g0 | ((uint32_t)len << 16); memcpy(o, &w, 4);
+              auto c = [&](int i) { return cdf[std::min(std::max(i, 0), n)]; };  // (the search clamps its probes to the last entry: find_interval_le_from_pairs)
+              auto f = [&](int i) { return (i >= 0 && i < n) ? fn[i] : 0.0f; };
+              o[1] = c(g0 - 1); o[2] = c(g0); o[3] = c(g0 + 1); o[4] = c(g0 + 2); o[5] = f(g0 - 1); o[6] = f(g0); o[7] = f(g0 + 1);
+            }
+          }
+          if (upload(s->buckets, rec.data(), rec.size() * 4) != RT_OK) { delete s; return fail(RT_ERR_OOM, "environment bucket records"); }
+          d.bk = s->buckets.as<float4>();
+        }
         gbase += (size_t)l.dist_nv * gw;
         d.mguide = s->guides.as<unsigned short>() + gbase;
         guide_row(l.marg_cdf, l.dist_nv, d.mglog, &gblob[gbase]);
@@ -1225,10 +1246,13 @@ static TableGroups table_groups_all(unsigned dims) {
   for (unsigned t = 0; t < 2u * dims; ++t) { g.packed[0] |= (unsigned long long)t << (4u * g.n[0]); g.n[0] += 1; }
   return g;
 }
-static TableGroups table_groups_frame(unsigned dims) {
+static TableGroups table_groups_frame(unsigned dims, bool pinhole) {
   TableGroups g{}; g.n_groups = 3;
   auto add = [&](int k, unsigned t) { g.packed[k] |= (unsigned long long)t << (4u * g.n[k]); g.n[k] += 1; };
-  add(0, dims); add(0, dims + 1u);                                   // 2-D tables 0, 1: the camera sample
+  add(0, dims);                                                      // 2-D table 0: the camera sample's film position
+  // 2-D table 1 is the lens sample: get_camera_sample consumes it (camera/mod.rs), a pinhole camera never looks at it (perspective.rs: lens_radius > 0) - like 1-D table 0,
+  // the time sample nothing reads, its shuffle is not replayed inside a frame (round 6: a seventh of K0's replays; the draws still advance the pixel's RNG stream)
+  if (!pinhole) add(0, dims + 1u);
   if (dims > 1u) add(1, 1u);                                         // 1-D table 1: bounce 0's light pick
   for (unsigned d = 2; d < dims; ++d) add(1, dims + d);              // 2-D tables 2 ...: bounce 0's light point and scattering direction
   for (unsigned d = 2; d < dims; ++d) add(2, d);                     // 1-D tables 2 ...: the light picks of bounces 1, 2, ...
@@ -1537,7 +1561,7 @@ extern "C" int rt_render(rt_scene* s, const rt_camera* cam, const rt_film_desc* 
     const unsigned long long npx = (first == 0 && lead_pixels) ? lead_pixels : std::min(chunk_pixels, owned_pixels - first);
     batches.push_back({first, npx}); first += npx;
   }
-  TableGroups tgroups = table_groups_frame(dims);
+  TableGroups tgroups = table_groups_frame(dims, !(fp.lens_radius > 0.0f));
   auto launch_tables = [&](size_t b, int buf) {
     FrameParams f2 = fp; f2.chunk_first = batches[b].first;
     tm.begin(&stats.ms_sampler, aux);

@@ -1,7 +1,7 @@
 // rtx_shade.hip - the k_shade instantiations (K3, rtx_kernels.h) and their launches: a translation unit of its own, compiled beside rtx_hip.hip.
 #include <hip/hip_runtime.h>
 #include "../../include/rtx_hip.h"
-#include "rtx_kernels.h"
+#include "rtx_shade_kernels.h"
 #include "rtx_shade_launch.h"
 
 namespace rtx {
