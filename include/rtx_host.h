@@ -75,6 +75,13 @@ int rtxh_scene_add_object(rtxh_scene*, const float* P, int32_t nv, const int32_t
 /* ObjectInstance (rc/api.rs:1053-1090): a TransformedPrimitive over `object` with primitive_to_world = o2w (and its inverse w2o, row-major 4x4). The
  * object's tree is traversed in object space (rc/primitive.rs:90-101) - nothing is copied. Returns the instance's index. */
 int rtxh_scene_add_instance(rtxh_scene*, int32_t object, const float* o2w16, const float* w2o16);
+/* What else an object definition may hold (round 6; rc/api.rs:1019-1051 collects EVERY primitive between ObjectBegin and ObjectEnd, and rc/primitive.rs:79-118 wraps
+ * whatever that is): a quadric in object space - o2w / w2o = the CTM inside the definition; emitter = -1 or an unlisted emitter (rtxh_scene_add_emitter); returns its
+ * primitive id inside the object, after the object's triangles - and alpha / shadowalpha masks on the object's triangles ({alpha, shadowalpha} float-texture ids or -1
+ * per triangle; NULL removes them). rtxh_scene_add_object with nt == 0 creates an object that holds quadrics only. */
+int rtxh_object_add_quadric(rtxh_scene*, int32_t object, int32_t kind, const float* o2w16, const float* w2o16, float radius, float z_min, float z_max, float phi_max,
+                            int32_t reverse_orientation, int32_t material, int32_t emitter);
+int rtxh_object_set_alpha(rtxh_scene*, int32_t object, const int32_t* tri_alpha2);
 /* Alpha masks of the meshes, after rtxh_scene_set_mesh: per triangle {alpha, shadowalpha} float-texture ids or -1 (TriangleMesh::create,
  * rc/shapes/mesh.rs:134-156: a named float texture, or the constant 0 when the float parameter is 0). NULL removes all masks. */
 int rtxh_scene_set_alpha(rtxh_scene*, const int32_t* tri_alpha2);
@@ -113,7 +120,8 @@ enum { RTXH_TABLE_TEXTURES = 0, RTXH_TABLE_MATERIALS, RTXH_TABLE_LIGHTS, RTXH_TA
        RTXH_TABLE_EMITTERS,          /* rtxh_emitter_info per emitter that is in no light list (rtxh_scene_add_emitter) */
        RTXH_TABLE_QUADRICS,          /* per quadric (rtxh_scene_add_quadric): rt_sphere, then int32 material, int32 light (>= 0 a listed light, -2 - k unlisted emitter k, -1 none) */
        RTXH_TABLE_OBJECT_BASE = 1000 /* + 8 * object + {0 P, 1 N, 2 UV, 3 S, 4 indices, 5 tri material, 6 tri flags, 7 tri emitter (k or -1; empty when no
-                                        triangle of the object emits)}: the object-space soup of one object */ };
+                                        triangle of the object emits)}: the object-space soup of one object */,
+       RTXH_TABLE_OBJECT_EXTRA_BASE = 100000 /* + 2 * object + {0 the object's quadrics (as RTXH_TABLE_QUADRICS; light: -1 or -2 - k), 1 {alpha, shadowalpha} per triangle (empty: none)} */ };
 typedef struct rtxh_emitter_info { float rgb[3]; int32_t two_sided; } rtxh_emitter_info;
 typedef struct rtxh_instance_info { int32_t object; float o2w[16], w2o[16]; } rtxh_instance_info;
 typedef struct rtxh_light_info { int32_t kind, tri; float rgb[3]; int32_t two_sided; float vec[3]; int32_t mip; float l2w[12], w2l[12]; } rtxh_light_info;

@@ -55,9 +55,11 @@ def lib():
         _lib = C.CDLL(_LIB_PATH)
         L = _lib
         L.orc_scene_new.restype = C.c_void_p
+        L.orc_scene_object_handle.restype = C.c_void_p
+        L.orc_scene_object_handle.argtypes = [C.c_void_p, C.c_int]
         L.orc_scene_free.argtypes = [C.c_void_p]
         for name in ("orc_scene_set_mesh", "orc_scene_add_mipmap", "orc_scene_add_texture", "orc_scene_add_material",
-                     "orc_scene_add_light", "orc_scene_add_object", "orc_scene_object_emitter", "orc_scene_add_instance", "orc_scene_commit", "orc_scene_bvh_sizes", "orc_scene_bvh_get", "orc_trace",
+                     "orc_scene_add_light", "orc_scene_add_object", "orc_scene_object_emitter", "orc_scene_object_quadric_emitter", "orc_scene_add_instance", "orc_scene_commit", "orc_scene_bvh_sizes", "orc_scene_bvh_get", "orc_trace",
                      "orc_render", "orc_light_distrib", "orc_li_keyed", "orc_camera_film_setup"):
             getattr(L, name).restype = C.c_int
         L.orc_radical_inverse.restype = C.c_float
@@ -158,6 +160,19 @@ class OracleScene:
                     if o.emit[t] >= 0:
                         rgb, two_sided = desc.emitters[int(o.emit[t])]
                         assert L.orc_scene_object_emitter(self.h, k, t, _p(np.float32(rgb)), int(two_sided)) >= 0
+            oh = None
+            for q in getattr(o, "quadrics", None) or []:  # quadrics of the object definition (object space), emitters among them in no light list
+                oh = oh or C.c_void_p(L.orc_scene_object_handle(self.h, k))
+                light = -1
+                if q.light <= -2:
+                    rgb, two_sided = desc.emitters[-2 - q.light]
+                    light = L.orc_scene_object_quadric_emitter(self.h, k, _p(np.float32(rgb)), int(two_sided))
+                    assert light >= 0
+                assert L.orc_scene_add_sphere(oh, _p(q.o2w), _p(q.w2o), C.c_float(q.radius), C.c_float(q.z_min), C.c_float(q.z_max), C.c_float(q.phi_max),
+                                              int(q.reverse_orientation), q.material, light, int(q.kind)) >= 0
+            if getattr(o, "alpha", None) is not None:
+                oh = oh or C.c_void_p(L.orc_scene_object_handle(self.h, k))
+                assert L.orc_scene_set_alpha(oh, _p(o.alpha, C.c_int32)) == 0
         for i in getattr(desc, "instances", []):
             assert L.orc_scene_add_instance(self.h, i.obj, _p(i.o2w), _p(i.w2o)) >= 0
         for l in desc.lights:

@@ -205,7 +205,7 @@ int orc_scene_add_object(void* h, const float* P, int nv, const int32_t* idx, in
   Scene* s = (Scene*)h;
   auto o = std::make_shared<Scene>();
   std::vector<int32_t> no_light((size_t)nt, -1);
-  if (nt <= 0 || orc_scene_set_mesh(o.get(), P, nv, idx, nt, N, UV, S, tri_material, no_light.data(), tri_flags) != 0) return -1;
+  if (nt < 0 || (nt > 0 && orc_scene_set_mesh(o.get(), P, nv, idx, nt, N, UV, S, tri_material, no_light.data(), tri_flags) != 0)) return -1;  // (nt == 0: an object of quadrics only)
   s->objects.push_back(o);
   return (int)s->objects.size() - 1;
 }
@@ -220,6 +220,22 @@ int orc_scene_object_emitter(void* h, int object, int tri, const float* rgbv, in
   o.lights.push_back(l);
   o.tri_light[(size_t)tri] = (int32_t)o.lights.size() - 1;
   return 0;
+}
+// The object definition as a scene of its own: what else ObjectBegin ... ObjectEnd collected (api.rs:1019-1051 pushes EVERY primitive) is added to it through the calls
+// a top-level scene takes - orc_scene_add_sphere (a quadric under the CTM inside the definition; light: -1, or the index orc_scene_object_quadric_emitter returns),
+// orc_scene_set_alpha (masks on its triangles; the texture ids name the TOP-LEVEL scene's textures: orc_scene_commit hands the tables on).
+void* orc_scene_object_handle(void* h, int object) {
+  Scene* s = (Scene*)h;
+  return (object < 0 || (size_t)object >= s->objects.size()) ? nullptr : (void*)s->objects[(size_t)object].get();
+}
+// an unlisted emitter for a quadric of an object (before orc_scene_add_sphere names it as the quadric's light): returns its index in the OBJECT's light table
+int orc_scene_object_quadric_emitter(void* h, int object, const float* rgbv, int two_sided) {
+  Scene* s = (Scene*)h;
+  if (object < 0 || (size_t)object >= s->objects.size()) return -1;
+  Scene& o = *s->objects[(size_t)object];
+  Light l{}; l.kind = LIGHT_DIFFUSE_AREA; l.l_emit = rgb(rgbv[0], rgbv[1], rgbv[2]); l.two_sided = two_sided != 0; l.tri = (int)o.n_prims();  // (the quadric added next)
+  o.lights.push_back(l);
+  return (int)o.lights.size() - 1;
 }
 // ObjectInstance (api.rs:1053-1090): TransformedPrimitive{object, primitive_to_world = the CTM}. Returns the primitive id. After every sphere.
 int orc_scene_add_instance(void* h, int object, const float* o2w16, const float* w2o16) {
@@ -307,6 +323,7 @@ int orc_scene_add_light(void* h, int kind, int tri, const float* rgbv, int two_s
 int orc_scene_commit(void* h, int max_prims_per_node) {
   Scene* s = (Scene*)h;
   s->max_prims_per_node = max_prims_per_node > 255 ? 255 : max_prims_per_node;
+  for (auto& o : s->objects) if (!o->tri_alpha.empty()) { o->textures = s->textures; o->mips = s->mips; }  // an object's alpha masks are float textures of the scene
   s->build_bvh();
   s->preprocess_lights();
   return 0;

@@ -27,11 +27,6 @@ struct DLight {
   // guide tables of the CDF searches (rt_scene_create): guide[row][k] = the number of entries of the row's CDF that are <= k / 2^glog, k = 0 .. 2^glog - so
   // the bisection for u starts inside [guide[k], guide[k + 1]], k = floor(u 2^glog), ~16 entries instead of 2049 (same answer: the CDF is non-decreasing)
   const unsigned short* guide; const unsigned short* mguide; int glog, mglog;
-  // round 6: the conditional rows' brackets as BUCKET RECORDS (rt_scene_create): bk[(v << glog) + k] = 32 bytes for the u in [k, k + 1) / 2^glog of row v -
-  // {g0 | len << 16, cdf[g0 - 1 .. g0 + 2], func[g0 - 1 .. g0 + 1]}, g0 = guide[v][k], len = min(guide[v][k + 1] - g0, 3). With len <= 2 (what a sample almost always meets: u is
-  // uniform over the buckets, and the buckets crowded with entries are the dark texels' few) the record holds everything Distribution1D::sample_continuous reads of the row -
-  // ONE 32-byte gather instead of a guide entry and then a bracket of pairs (two dependent round trips, two L2-miss requests); len == 3: the guided search. NULL: not built
-  const float4* bk;
   // constants of a triangle emitter, evaluated once on the device (k_light_consts) by the expressions DiffuseAreaLight::sample_li's call chain uses per sample:
   // normalize(cross(p1 - p0, p2 - p0)) (Triangle::sample, mesh.rs:617, before orientation) and 1 / area (shapes/mod.rs:45)
   float nrm[3]; float inv_area;
@@ -44,6 +39,7 @@ struct DScene {
   const float4* nodes; unsigned n_nodes;
   const float4* pairs;  // n_nodes x 64 B child-pair records of the interior nodes (NULL for LDS-resident scenes), see k_trace_pair
   int obj_pairs;        // ... the objects' trees have records too (behind the top level's, child codes local to the object): nested_pair_walk
+  int obj_general;      // some instanced object holds a quadric or a masked triangle: objects are walked by the general one-node-per-step walk (instance_intersect)
   const float4* top_pairs; unsigned n_top;  // pair records of the first levels of the tree, child codes re-pointed at LDS slots (k_trace_top); n_top <= RT_TOP_MAX
   const float4* quads;  // n_nodes x 128 B grandchild records of the interior nodes (NULL when not built), see k_trace_quad
   // LDS-resident scenes of plain triangles: [8][n_nodes] u16 - for each sign octant of a ray's direction (bit 0 / 1 / 2: d.x / d.y / d.z negative) the node the
@@ -436,13 +432,13 @@ template <bool MASKS, bool QUADRICS> RT_DEV bool general_prim_test(const DScene&
 
 // GENERAL: leaves may hold quadrics and alpha-masked triangles (gen = the scene record in device memory and whether shadowalpha masks apply); the plain
 // instantiation is the code it was.
-struct GeneralCtx { const DScene* self; bool shadow_masks; };
+struct GeneralCtx { const DScene* self; bool shadow_masks; int prim_base = 0; };  // prim_base: the walk's primitive 0 in the scene's arrays (an instanced object's walk)
 template <int GENERAL, class Src>
 RT_DEV bool leaf_prim_test(const Src& src, const GeneralCtx& gen, int prim, const Ray& ray, const RayPre& rp, TriHit& h) {
   f3 p0, p1, p2;
   if (GENERAL) {
     unsigned flags; src.tri_flags(prim, p0, p1, p2, flags);
-    if (flags & (RT_FLAG_SPHERE | RT_FLAG_GENERAL_TRI)) return general_prim_test<GENERAL == RT_GEN_ALL, GENERAL != RT_GEN_INSTANCES_ONLY>(*gen.self, prim, p0, p1, p2, flags, ray, rp, gen.shadow_masks, h);
+    if (flags & (RT_FLAG_SPHERE | RT_FLAG_GENERAL_TRI)) return general_prim_test<GENERAL == RT_GEN_ALL, GENERAL != RT_GEN_INSTANCES_ONLY>(*gen.self, gen.prim_base + prim, p0, p1, p2, flags, ray, rp, gen.shadow_masks, h);
     return tri_test_pre(p0, p1, p2, ray, rp, h);
   }
   src.tri(prim, p0, p1, p2);

@@ -565,25 +565,10 @@ RT_DEV void d1_sample_continuous_pairs(const float* cf, float func_int, int n, f
   x = ((float)offset + du) / (float)n;
   off = offset;
 }
-// ... over a row's BUCKET RECORD (DLight::bk): the same offset, the same quotient, from one 32-byte gather. r0 = {g0 | len << 16, cdf[g0 - 1], cdf[g0], cdf[g0 + 1]},
-// r1 = {cdf[g0 + 2], func[g0 - 1], func[g0], func[g0 + 1]}: the partition point of the non-decreasing row is g0 + #{i in [g0, g0 + len) : cdf[i] <= u} (find_interval_le_from_pairs'
-// three-entry form), so offset = that - 1 clamped to [0, n - 1] is g0 - 1, g0 or g0 + 1 and cdf[offset], cdf[offset + 1], func[offset] are in the record. Returns false when the
-// bucket holds more entries than the record (len == 3): the caller searches the row.
-template <bool EXACT = false>
-RT_DEV bool d1_sample_continuous_bucket(float4 r0, float4 r1, float func_int, int n, float u, float& x, float& pdf) {
-  const unsigned w = __float_as_uint(r0.x);
-  const int g0 = (int)(w & 0xffffu), len = (int)(w >> 16);
-  if (len > 2) return false;
-  const int first = g0 + ((len > 0 && r0.z <= u) ? 1 : 0) + ((len > 1 && r0.w <= u) ? 1 : 0);
-  const int offset = clampi(first - 1, 0, n - 1);
-  const int j = offset - (g0 - 1);  // 0, 1 or 2 (a clamped offset stays inside: g0 >= 1, and first - 1 > n - 1 only where cdf[n] <= u, i.e. g0 + len > n)
-  const float c0 = j <= 0 ? r0.y : (j == 1 ? r0.z : r0.w), c1 = j <= 0 ? r0.z : (j == 1 ? r0.w : r1.x), f0 = j <= 0 ? r1.y : (j == 1 ? r1.z : r1.w);
-  float du = u - c0;
-  if (c1 - c0 > 0.0f) du /= c1 - c0;
-  pdf = func_int > 0.0f ? vdiv_e<EXACT>(f0, func_int) : 0.0f;
-  x = ((float)offset + du) / (float)n;
-  return true;
-}
+// (Round 6 measured the row's bracket as ONE 32-byte bucket record per (row, guide bucket) - {first index | count, four cdf entries, three func entries}: everything
+// sample_continuous reads of the row in one gather instead of a guide entry and then a bracket of pairs. Exact, and slower: S4 shade 2331 -> 2371 ms. The 4 MB of guide entries
+// mostly hit L2 and the 17 MB of pairs the Infinity Cache; 64 MB of records do neither better, and the stage is bound by its L2-miss REQUESTS, of which the record saves none.
+// Commit ec235f5; MEASUREMENTS R6.)
 RT_DEV void d1_sample_discrete_guided(const float* func, const float* cdf, float func_int, int n, float u, const unsigned short* guide, int glog, int& off, float& pdf) {
   const int G = 1 << glog;
   const int k = clampi((int)(u * (float)G), 0, G - 1);
@@ -702,14 +687,7 @@ RT_DEV LiSample light_sample_li_inl(const DScene& sc, const DLight& l, Interacti
       float d1, pdf1, d0, pdf0; int v, dummy;
       if (RT_DBG(sc, 2)) { d1 = u.y; d0 = u.x; pdf0 = pdf1 = 1.0f; } else {
       d1_sample_continuous_guided<EXACT>(l.mfunc, l.mcdf, l.mfunc_int, l.nv, u.y, l.mguide, l.mglog, d1, pdf1, v);  // Distribution2D::sample_continuous
-      bool done = false;
-      if (l.bk != nullptr) {  // the row's bucket record: one gather (DLight::bk)
-        const int G = 1 << l.glog, k = clampi((int)(u.x * (float)G), 0, G - 1);
-        const float4* rec = l.bk + 2 * (((size_t)v << l.glog) + (size_t)k);
-        const float4 r0 = rec[0], r1 = rec[1];
-        done = d1_sample_continuous_bucket<EXACT>(r0, r1, l.func_int[v], l.nu, u.x, d0, pdf0);
-      }
-      if (!done) d1_sample_continuous_pairs<EXACT>(l.cf + (size_t)v * (l.nu + 1) * 2, l.func_int[v], l.nu, u.x, l.guide + ((size_t)v << l.glog) + (size_t)v, l.glog, d0, pdf0, dummy);
+      d1_sample_continuous_pairs<EXACT>(l.cf + (size_t)v * (l.nu + 1) * 2, l.func_int[v], l.nu, u.x, l.guide + ((size_t)v << l.glog) + (size_t)v, l.glog, d0, pdf0, dummy);
       }
       float map_pdf = pdf0 * pdf1;
       s.p1.p_error = mk3(0, 0, 0); s.p1.n = mk3(0, 0, 0);

@@ -79,12 +79,13 @@ struct rt_scene {
   bool deep_column = false;  // top level + deepest object need more than 64 stack entries in one column: k_trace_big with 128
   DevBuf quads; bool use_quads = false; int quad_stack_depth = 0;  // four-wide records of the any-hit kernel (k_trace_quad)
   DevBuf tri_rec;  // per-triangle shade records (k_tri_records)
-  DevBuf nodes, tri_p, tri_n, tri_uv, tri_s, tri_alpha, spheres, textures, images, materials, lights, texels, dist, guides, buckets;
+  DevBuf nodes, tri_p, tri_n, tri_uv, tri_s, tri_alpha, spheres, textures, images, materials, lights, texels, dist, guides;
   bool has_spheres = false;
   bool has_instances = false;  // object instances: two-level traversal in k_trace_big<.., GENERAL>, every vertex shaded by k_shade<0, true>
   DevBuf instances;
   bool mid = false;  // plain scene of <= RT_MID_NODES / RT_MID_TRIS: occlusion rays through k_trace<.., MID>
   bool general_prims = false;  // alpha-masked triangles, quadrics, object instances: the GENERAL instantiations of the trace kernels
+  bool obj_general = false;    // some instanced object holds a quadric or a masked triangle: the objects are walked by the general one-node-per-step walk (instance_intersect)
   bool has_masks = false;      // some triangle carries an alpha / shadow-alpha mask (RT_GEN_ALL; without: RT_GEN_NO_MASKS, 134 instead of 179 VGPRs)
   bool masked_emitters = false;  // ... and some of them emit: every vertex is shaded by k_shade<0, true> (Shape::pdf_wi evaluates the mask)
   std::vector<DLight> h_lights;
@@ -251,11 +252,15 @@ extern "C" int rt_scene_create(const rt_scene_desc* desc, int device, rt_scene**
       const rt_instance& in = desc->instances[k];
       if (in.n_prims == 0 || (uint64_t)in.prim_base + in.n_prims > desc->n_tris || in.prim_base < n_top_prims || (in.n_nodes == 0 && in.n_prims != 1) ||
           (in.n_nodes != 0 && ((uint64_t)in.node_base + in.n_nodes > desc->n_nodes || in.node_base < n_top_nodes))) { delete s; return fail(RT_ERR_INVALID, "instance ranges out of bounds"); }
-      for (uint32_t t = in.prim_base; t < in.prim_base + in.n_prims; ++t)
-        if (desc->tri_meta[t].flags & (RT_PRIM_SPHERE | RT_PRIM_INSTANCE | RT_TRI_HAS_ALPHA | RT_TRI_HAS_SHADOW_ALPHA) ||
-            (desc->tri_meta[t].light >= 0 && (uint32_t)desc->tri_meta[t].light < desc->n_lights)) {  // (an emitter inside an object is never a listed light, api.rs:954-964)
-          delete s; return fail(RT_ERR_UNSUPPORTED, "an instanced object holds triangles without masks only, and no light of the scene's list");
+      // An object holds triangles (masked or not) and quadrics (round 6: TransformedPrimitive wraps whatever the object definition collected, primitive.rs:79-118) - not
+      // another instance (the reference's ObjectInstance inside an object definition is an error, api.rs:1056-1059), and no light of the scene's list (an emitter inside
+      // an object is never a listed light, api.rs:954-964)
+      for (uint32_t t = in.prim_base; t < in.prim_base + in.n_prims; ++t) {
+        if ((desc->tri_meta[t].flags & RT_PRIM_INSTANCE) || (desc->tri_meta[t].light >= 0 && (uint32_t)desc->tri_meta[t].light < desc->n_lights)) {
+          delete s; return fail(RT_ERR_UNSUPPORTED, "an instanced object holds triangles and quadrics only, and no light of the scene's list");
         }
+        if (desc->tri_meta[t].flags & (RT_PRIM_SPHERE | RT_TRI_HAS_ALPHA | RT_TRI_HAS_SHADOW_ALPHA)) s->obj_general = true;
+      }
       memcpy(di[k].o2w, in.o2w, 64); memcpy(di[k].w2o, in.w2o, 64);
       di[k].node_base = in.node_base; di[k].n_nodes = in.n_nodes; di[k].prim_base = in.prim_base; di[k].n_prims = in.n_prims; di[k].id_base = (unsigned)id;
       id += in.n_prims;
@@ -489,27 +494,6 @@ extern "C" int rt_scene_create(const rt_scene_desc* desc, int device, rt_scene**
         const size_t gw = ((size_t)1 << d.glog) + 1;
         d.guide = s->guides.as<unsigned short>() + gbase;
         for (int r = 0; r < l.dist_nv; ++r) guide_row(l.dist_cdf + (size_t)r * (l.dist_nu + 1), l.dist_nu, d.glog, &gblob[gbase + (size_t)r * gw]);
-        // the rows' bucket records (DLight::bk, round 6): per (row, bucket) what a sample of that bucket reads of the row, 32 bytes
-        d.bk = nullptr;
-        const size_t n_rec = (size_t)l.dist_nv << d.glog;
-        if (n_inf == 1 && n_rec * 32 <= ((size_t)256 << 20) && !env_is("RTX_ENV_BUCKETS", '0')) {  // (one environment light; RTX_ENV_BUCKETS=0: the A/B control)
-          std::vector<float> rec(n_rec * 8);
-          const int n = l.dist_nu, G = 1 << d.glog;
-          for (int r = 0; r < l.dist_nv; ++r) {
-            const float* cdf = l.dist_cdf + (size_t)r * (n + 1); const float* fn = l.dist_func + (size_t)r * n;
-            const unsigned short* g = &gblob[gbase + (size_t)r * gw];
-            for (int k = 0; k < G; ++k) {
-              float* o = &rec[(((size_t)r << d.glog) + (size_t)k) * 8];
-              const int g0 = g[k], len = std::min((int)g[k + 1] - g0, 3);
-              const uint32_t w = (uint32_t)g0 | ((uint32_t)len << 16); memcpy(o, &w, 4);
-              auto c = [&](int i) { return cdf[std::min(std::max(i, 0), n)]; };  // (the search clamps its probes to the last entry: find_interval_le_from_pairs)
-              auto f = [&](int i) { return (i >= 0 && i < n) ? fn[i] : 0.0f; };
-              o[1] = c(g0 - 1); o[2] = c(g0); o[3] = c(g0 + 1); o[4] = c(g0 + 2); o[5] = f(g0 - 1); o[6] = f(g0); o[7] = f(g0 + 1);
-            }
-          }
-          if (upload(s->buckets, rec.data(), rec.size() * 4) != RT_OK) { delete s; return fail(RT_ERR_OOM, "environment bucket records"); }
-          d.bk = s->buckets.as<float4>();
-        }
         gbase += (size_t)l.dist_nv * gw;
         d.mguide = s->guides.as<unsigned short>() + gbase;
         guide_row(l.marg_cdf, l.dist_nv, d.mglog, &gblob[gbase]);
@@ -613,7 +597,7 @@ extern "C" int rt_scene_create(const rt_scene_desc* desc, int device, rt_scene**
     s->stack_depth += max_obj; max_obj_depth = max_obj;
     s->deep_column = s->stack_depth > 64;
   }
-  d.pairs = nullptr; d.quads = nullptr; d.obj_pairs = 0; d.link8 = nullptr; d.link8_full = nullptr;
+  d.pairs = nullptr; d.quads = nullptr; d.obj_pairs = 0; d.obj_general = s->obj_general ? 1 : 0; d.link8 = nullptr; d.link8_full = nullptr;
   // mid-size scenes (round 5): too large for the 256-node LDS kernels, small enough for one workgroup's 160 KB - occlusion rays walk link tables in LDS (k_trace<.., MID>)
   s->mid = !s->small && !s->general_prims && !s->has_instances && desc->n_nodes <= RT_MID_NODES && desc->n_tris <= RT_MID_TRIS;
   for (uint32_t i = 0; i < desc->n_nodes && s->mid; ++i) if (desc->nodes[i].n_prims > 15) s->mid = false;  // (the link word's count field)
@@ -694,7 +678,7 @@ extern "C" int rt_scene_create(const rt_scene_desc* desc, int device, rt_scene**
       int rc2 = upload(s->pairs, pr.data(), pr.size() * 4);
       if (rc2 != RT_OK) { delete s; return rc2; }
       d.pairs = s->pairs.as<float4>(); s->use_pairs = true;
-      d.obj_pairs = obj_ok ? 1 : 0;
+      d.obj_pairs = (obj_ok && !s->obj_general) ? 1 : 0;  // (nested_pair_walk tests plain triangles only)
     }
     d.top_pairs = nullptr; d.n_top = 0;
     if (ok && n_pair_nodes < (1u << 28) && desc->nodes[0].n_prims == 0 && !s->has_instances) {  // (an object's walk needs a contiguous stack column: k_trace_pair)
@@ -1044,7 +1028,8 @@ static void launch_trace_c(rt_scene* s, const TraceIO& io, const unsigned* queue
 #define RT_ARGS s, io, queue, count_ptr, shard_cap, count_static, stats, st_rays, st_nodes, st_tris, stream
 #define RT_KARGS s->d, io, queue, count_ptr, shard_cap, count_static, stats, st_rays
   if (s->general_prims) {  // quadrics, masked triangles, object instances: the GENERAL instantiations (plain leaves of such a scene still run the bare triangle loop)
-    if constexpr (!COUNT) {
+    // (objects that hold quadrics or masked triangles - obj_general - are walked by the one-node-per-step kernel below: the only one whose object walk takes them)
+    if (!COUNT && !s->obj_general) {
       const unsigned refill_min = trace_knobs(s, ANY);
       const bool all = s->has_masks;
 #define RT_GEN_LAUNCH(KERNEL_ALL, KERNEL_NOMASK, GRID, BLK, ...) do { if (all) hipLaunchKernelGGL(KERNEL_ALL, dim3(GRID), dim3(BLK), 0, stream, __VA_ARGS__); \

@@ -205,8 +205,14 @@ struct rtxh_scene {
   struct HostObject {
     std::vector<float> P, N, UV, S; std::vector<int32_t> idx, tri_mat; std::vector<uint8_t> tri_flags;
     std::vector<int32_t> tri_emit;  // per triangle: an unlisted emitter (rtxh_scene_add_emitter) or -1; empty = none
+    // round 6: an object holds whatever the reference's object definition holds (api.rs:1019-1051 pushes any Primitive): quadrics in OBJECT space (their own
+    // object_to_world = the CTM inside the definition; light = -1 or -2 - k: unlisted emitter k) and alpha / shadowalpha masks on its triangles. Primitive ids inside the
+    // object: the triangles, then the quadrics.
+    std::vector<HostSphere> spheres;
+    std::vector<int32_t> tri_alpha;  // 2 per triangle or empty
     std::vector<rt_bvh_node> nodes; std::vector<int32_t> ordered;
     size_t n_tris() const { return idx.size() / 3; }
+    size_t n_prims() const { return n_tris() + spheres.size(); }
   };
   struct HostInstance { int32_t object; float o2w[16], w2o[16]; };
   std::vector<HostObject> objects; std::vector<HostInstance> instances; std::vector<rt_instance> f_instances;
@@ -413,7 +419,7 @@ static Box triangle_box(const std::vector<float>& P, const std::vector<int32_t>&
 // TransformedPrimitive::world_bounds (primitive.rs:86-88): Transform * Bounds3f - the 8 corners of the object's bounds (transform.rs:342-378)
 static Box instance_world_box(const rtxh_scene::HostObject& o, const float* o2w) {
   Box ob;
-  if (o.n_tris() == 1) ob = triangle_box(o.P, o.idx, 0);  // a single primitive is wrapped as it is (api.rs:1073-1082)
+  if (o.n_prims() == 1) ob = o.n_tris() == 1 ? triangle_box(o.P, o.idx, 0) : sphere_world_box(o.spheres[0].s);  // a single primitive is wrapped as it is (api.rs:1073-1082)
   else { for (int k = 0; k < 3; ++k) { ob.lo[k] = o.nodes[0].bmin[k]; ob.hi[k] = o.nodes[0].bmax[k]; } }
   const int order[8][3] = {{0, 0, 0}, {1, 0, 0}, {0, 1, 0}, {0, 0, 1}, {0, 1, 1}, {1, 1, 0}, {1, 0, 1}, {1, 1, 1}};
   Box bb;
@@ -434,9 +440,10 @@ int commit_scene(rtxh_scene* s, int max_prims_per_node) {
   const size_t nt = s->n_prims();  // every primitive: the triangles, then the spheres, then the object instances
   if (nt == 0) return fail(RT_ERR_INVALID, "no triangles");
   for (auto& o : s->objects) {  // make_accelerator over the object's primitives, with the scene's accelerator parameters (api.rs:1073-1080)
-    const size_t on = o.n_tris();
+    const size_t on = o.n_prims(), otri = o.n_tris();
+    if (on == 0) return fail(RT_ERR_INVALID, "an object without primitives");
     std::vector<Box> ob(on);
-    for (size_t t = 0; t < on; ++t) ob[t] = triangle_box(o.P, o.idx, t);
+    for (size_t t = 0; t < on; ++t) ob[t] = t < otri ? triangle_box(o.P, o.idx, t) : sphere_world_box(o.spheres[t - otri].s);  // (a quadric's box under its own object_to_world: the object's space)
     build_tree(on, ob, max_prims_per_node, o.nodes, o.ordered);
   }
   std::vector<Box> boxes(nt);
@@ -481,12 +488,14 @@ int finish_commit(rtxh_scene* s) {
   const size_t n_geom = n_triangles + s->spheres.size();
   // object primitives follow the top level's in the same arrays: every INSTANCED object once, in the order of its first instance
   std::vector<int64_t> obj_prim_base(s->objects.size(), -1), obj_node_base(s->objects.size(), -1);
-  size_t n_all = nt, n_all_nodes = s->nodes.size();
+  std::vector<size_t> obj_sphere_base(s->objects.size(), 0);  // where an instanced object's quadrics sit behind the top level's in the scene's quadric table
+  size_t n_all = nt, n_all_nodes = s->nodes.size(), n_obj_spheres = 0; bool any_obj_alpha = false;
   for (const auto& in : s->instances) {
     const size_t o = (size_t)in.object;
     if (obj_prim_base[o] >= 0) continue;
     obj_prim_base[o] = (int64_t)n_all; obj_node_base[o] = (int64_t)n_all_nodes;
-    n_all += s->objects[o].n_tris(); n_all_nodes += s->objects[o].nodes.size();
+    obj_sphere_base[o] = n_obj_spheres; n_obj_spheres += s->objects[o].spheres.size(); any_obj_alpha = any_obj_alpha || !s->objects[o].tri_alpha.empty();
+    n_all += s->objects[o].n_prims(); n_all_nodes += s->objects[o].nodes.size();
     any_n = any_n || !s->objects[o].N.empty(); any_uv = any_uv || !s->objects[o].UV.empty(); any_s = any_s || !s->objects[o].S.empty();
   }
   s->n_top_prims = nt;
@@ -502,8 +511,24 @@ int finish_commit(rtxh_scene* s) {
       const auto& ob = s->objects[o];
       std::copy(ob.nodes.begin(), ob.nodes.end(), s->f_nodes.begin() + obj_node_base[o]);
       const bool on = !ob.N.empty(), ouv = !ob.UV.empty(), os = !ob.S.empty();
-      for (size_t i = 0; i < ob.n_tris(); ++i) {
+      for (size_t i = 0; i < ob.n_prims(); ++i) {
         const size_t g = (size_t)obj_prim_base[o] + i; const int32_t t = ob.ordered[i];
+        if ((size_t)t >= ob.n_tris()) {  // a quadric of the object: its box (object space) in p0 / p1, its index in the scene's quadric table as the bits of p2.x
+          const auto& hs = ob.spheres[(size_t)t - ob.n_tris()];
+          const Box bb = sphere_world_box(hs.s);
+          for (int k = 0; k < 3; ++k) { s->f_p[9 * g + k] = bb.lo[k]; s->f_p[9 * g + 3 + k] = bb.hi[k]; }
+          const uint32_t si = (uint32_t)(s->spheres.size() + obj_sphere_base[o] + ((size_t)t - ob.n_tris())); memcpy(&s->f_p[9 * g + 6], &si, 4);
+          const uint32_t flip = (hs.s.reverse_orientation != 0) != (hs.s.swaps_handedness != 0) ? RT_TRI_FLIP : 0u;
+          int32_t sl = -1;
+          if (hs.light <= -2) {
+            const size_t k = (size_t)(-2 - (int64_t)hs.light);
+            if (k >= s->emitters.size()) return fail(RT_ERR_INVALID, "emitter index out of range");
+            sl = (int32_t)(s->lights.size() + k);
+            if (emitter_prim[k] < 0) emitter_prim[k] = (int64_t)g;
+          }
+          s->f_meta[g] = rt_tri_meta{hs.material, sl, RT_PRIM_SPHERE | flip, (uint32_t)t};
+          continue;
+        }
         for (int v = 0; v < 3; ++v) {
           const int32_t vi = ob.idx[3 * t + v];
           for (int k = 0; k < 3; ++k) s->f_p[9 * g + 3 * v + k] = ob.P[3 * vi + k];
@@ -520,13 +545,14 @@ int finish_commit(rtxh_scene* s) {
       const auto& ob = s->objects[(size_t)in.object];
       rt_instance ri{};
       memcpy(ri.o2w, in.o2w, 64); memcpy(ri.w2o, in.w2o, 64);
-      ri.node_base = (uint32_t)obj_node_base[(size_t)in.object]; ri.n_nodes = ob.n_tris() == 1 ? 0u : (uint32_t)ob.nodes.size();
-      ri.prim_base = (uint32_t)obj_prim_base[(size_t)in.object]; ri.n_prims = (uint32_t)ob.n_tris();
+      ri.node_base = (uint32_t)obj_node_base[(size_t)in.object]; ri.n_nodes = ob.n_prims() == 1 ? 0u : (uint32_t)ob.nodes.size();
+      ri.prim_base = (uint32_t)obj_prim_base[(size_t)in.object]; ri.n_prims = (uint32_t)ob.n_prims();
       s->f_instances.push_back(ri);
     }
   }
   s->f_spheres.clear();
   for (const auto& hs : s->spheres) s->f_spheres.push_back(hs.s);
+  for (size_t o = 0; o < s->objects.size(); ++o) if (obj_prim_base[o] >= 0) for (const auto& hs : s->objects[o].spheres) s->f_spheres.push_back(hs.s);  // (in the order of obj_sphere_base)
   for (size_t i = 0; i < nt; ++i) {
     const int32_t t = s->ordered[i];
     if ((size_t)t >= n_geom) {  // an object instance: world box in p0 / p1, its index as the bits of p2.x
@@ -570,9 +596,22 @@ int finish_commit(rtxh_scene* s) {
     s->f_meta[i] = rt_tri_meta{s->tri_mat[t], tl, (uint32_t)s->tri_flags[t], (uint32_t)t};
   }
   s->f_alpha.clear();
-  if (!s->tri_alpha.empty()) {
+  if (!s->tri_alpha.empty() || any_obj_alpha) {
     s->f_alpha.assign(n_all * 2, -1);
-    for (size_t i = 0; i < nt; ++i) {
+    for (size_t o = 0; o < s->objects.size(); ++o) {  // masks on the triangles of instanced objects
+      if (obj_prim_base[o] < 0 || s->objects[o].tri_alpha.empty()) continue;
+      const auto& ob = s->objects[o];
+      for (size_t i = 0; i < ob.n_prims(); ++i) {
+        const int32_t t = ob.ordered[i];
+        if ((size_t)t >= ob.n_tris()) continue;
+        for (int k = 0; k < 2; ++k) {
+          const int32_t id = ob.tri_alpha[2 * (size_t)t + k];
+          if (id >= (int32_t)s->textures.size()) return fail(RT_ERR_INVALID, "alpha texture out of range");
+          if (id >= 0) { s->f_alpha[2 * ((size_t)obj_prim_base[o] + i) + k] = id; s->f_meta[(size_t)obj_prim_base[o] + i].flags |= (k == 0 ? RT_TRI_HAS_ALPHA : RT_TRI_HAS_SHADOW_ALPHA); }
+        }
+      }
+    }
+    for (size_t i = 0; i < nt && !s->tri_alpha.empty(); ++i) {
       const int32_t t = s->ordered[i];
       if ((size_t)t >= n_triangles) continue;  // spheres and instances carry no mask
       for (int k = 0; k < 2; ++k) {
@@ -720,11 +759,12 @@ int rtxh_scene_add_sphere(rtxh_scene* s, const float* o2w16, const float* w2o16,
                           int32_t material, int32_t light) {
   return rtxh_scene_add_quadric(s, 0, o2w16, w2o16, radius, z_min, z_max, phi_max, reverse_orientation, material, light);
 }
-int rtxh_scene_add_quadric(rtxh_scene* s, int32_t kind, const float* o2w16, const float* w2o16, float radius, float z_min, float z_max, float phi_max,
-                           int32_t reverse_orientation, int32_t material, int32_t light) {
+// the record of a quadric (Sphere::new sphere.rs:29-51, Disk::new disk.rs:25-46, Cylinder::create cylinder.rs:26-46) under its object_to_world
+static int make_quadric(int32_t kind, const float* o2w16, const float* w2o16, float radius, float z_min, float z_max, float phi_max, int32_t reverse_orientation,
+                        int32_t material, int32_t light, rtxh_scene::HostSphere& hs) {
   if (kind < 0 || kind > 2) return fail(RT_ERR_INVALID, "unknown quadric kind");
-  if (!s || !o2w16 || !w2o16) return fail(RT_ERR_INVALID, "bad sphere arguments");
-  rtxh_scene::HostSphere hs{}; rt_sphere& sp = hs.s;
+  if (!o2w16 || !w2o16) return fail(RT_ERR_INVALID, "bad sphere arguments");
+  hs = rtxh_scene::HostSphere{}; rt_sphere& sp = hs.s;
   memcpy(sp.o2w, o2w16, 64); memcpy(sp.w2o, w2o16, 64);
   auto clampf = [](float v, float lo, float hi) { return v < lo ? lo : (v > hi ? hi : v); };  // lib.rs:264-275
   sp.radius = radius; sp.kind = kind;
@@ -741,15 +781,46 @@ int rtxh_scene_add_quadric(rtxh_scene* s, int32_t kind, const float* o2w16, cons
   const float det = m[0] * (m[5] * m[10] - m[6] * m[9]) - m[1] * (m[4] * m[10] - m[6] * m[8]) + m[2] * (m[4] * m[9] - m[5] * m[8]);
   sp.swaps_handedness = det < 0.0f ? 1 : 0;
   hs.material = material; hs.light = light;
+  return RT_OK;
+}
+int rtxh_scene_add_quadric(rtxh_scene* s, int32_t kind, const float* o2w16, const float* w2o16, float radius, float z_min, float z_max, float phi_max,
+                           int32_t reverse_orientation, int32_t material, int32_t light) {
+  if (!s) return fail(RT_ERR_INVALID, "bad sphere arguments");
+  rtxh_scene::HostSphere hs;
+  const int rc = make_quadric(kind, o2w16, w2o16, radius, z_min, z_max, phi_max, reverse_orientation, material, light, hs);
+  if (rc != RT_OK) return rc;
   s->spheres.push_back(hs);
   s->committed = false;
   return (int)s->spheres.size() - 1;
 }
+// A quadric INSIDE an object definition (api.rs:1019-1051: ObjectBegin collects every primitive): o2w / w2o = the CTM inside the definition (object space). emitter: -1, or
+// the index of an unlisted emitter (rtxh_scene_add_emitter: a shape under an AreaLightSource inside an object definition is in no light list, api.rs:954-964).
+// Returns the quadric's primitive id inside the object (after the object's triangles).
+int rtxh_object_add_quadric(rtxh_scene* s, int32_t object, int32_t kind, const float* o2w16, const float* w2o16, float radius, float z_min, float z_max, float phi_max,
+                            int32_t reverse_orientation, int32_t material, int32_t emitter) {
+  if (!s || object < 0 || (size_t)object >= s->objects.size()) return fail(RT_ERR_INVALID, "bad object");
+  if (emitter >= (int32_t)s->emitters.size()) return fail(RT_ERR_INVALID, "emitter index out of range");
+  rtxh_scene::HostSphere hs;
+  const int rc = make_quadric(kind, o2w16, w2o16, radius, z_min, z_max, phi_max, reverse_orientation, material, emitter >= 0 ? -2 - emitter : -1, hs);
+  if (rc != RT_OK) return rc;
+  auto& o = s->objects[(size_t)object];
+  o.spheres.push_back(hs); s->committed = false;
+  return (int)(o.n_prims() - 1);
+}
+// alpha / shadowalpha float textures of an object's triangles (2 per triangle, -1 = none; NULL clears)
+int rtxh_object_set_alpha(rtxh_scene* s, int32_t object, const int32_t* tri_alpha2) {
+  if (!s || object < 0 || (size_t)object >= s->objects.size()) return fail(RT_ERR_INVALID, "bad object");
+  auto& o = s->objects[(size_t)object];
+  if (!tri_alpha2) o.tri_alpha.clear(); else o.tri_alpha.assign(tri_alpha2, tri_alpha2 + 2 * o.n_tris());
+  s->committed = false;
+  return RT_OK;
+}
 
 int rtxh_scene_add_object(rtxh_scene* s, const float* P, int32_t nv, const int32_t* idx, int32_t nt, const float* N, const float* UV, const float* S,
                           const int32_t* tri_material, const uint8_t* tri_flags) {
-  if (!s || !P || !idx || !tri_material || !tri_flags || nv <= 0 || nt <= 0) return fail(RT_ERR_INVALID, "bad object mesh");
+  if (!s || nv < 0 || nt < 0 || (nt > 0 && (!P || !idx || !tri_material || !tri_flags || nv <= 0))) return fail(RT_ERR_INVALID, "bad object mesh");
   rtxh_scene::HostObject o;
+  if (nt == 0) { s->objects.push_back(std::move(o)); s->committed = false; return (int)s->objects.size() - 1; }  // (an object of quadrics only: rtxh_object_add_quadric)
   o.P.assign(P, P + 3 * (size_t)nv); o.idx.assign(idx, idx + 3 * (size_t)nt);
   if (N) o.N.assign(N, N + 3 * (size_t)nv); if (UV) o.UV.assign(UV, UV + 2 * (size_t)nv); if (S) o.S.assign(S, S + 3 * (size_t)nv);
   o.tri_mat.assign(tri_material, tri_material + nt); o.tri_flags.assign(tri_flags, tri_flags + nt);
@@ -1024,6 +1095,16 @@ int rtxh_scene_inspect(rtxh_scene* s, int32_t table, void* out, uint64_t capacit
   if (!s || !n_items) return fail(RT_ERR_INVALID, "null argument");
   const void* src = nullptr; size_t item = 0, n = 0;
   std::vector<rtxh_light_info> li; std::vector<rtxh_instance_info> ii;
+  if (table >= RTXH_TABLE_OBJECT_EXTRA_BASE) {
+    const size_t k = (size_t)(table - RTXH_TABLE_OBJECT_EXTRA_BASE) / 2; const int j = (table - RTXH_TABLE_OBJECT_EXTRA_BASE) % 2;
+    if (k >= s->objects.size()) return fail(RT_ERR_INVALID, "unknown object table");
+    const auto& o = s->objects[k];
+    if (j == 0) { src = o.spheres.data(); item = sizeof(rtxh_scene::HostSphere); n = o.spheres.size(); }
+    else { src = o.tri_alpha.data(); item = 8; n = o.tri_alpha.size() / 2; }
+    *n_items = n;
+    if (out) { if (capacity_bytes < n * item) return fail(RT_ERR_INVALID, "buffer too small"); if (n) memcpy(out, src, n * item); }
+    return RT_OK;
+  }
   if (table >= RTXH_TABLE_OBJECT_BASE) {
     const size_t k = (size_t)(table - RTXH_TABLE_OBJECT_BASE) / 8; const int j = (table - RTXH_TABLE_OBJECT_BASE) % 8;
     if (k >= s->objects.size() || j > 7) return fail(RT_ERR_INVALID, "unknown object table");

@@ -1161,18 +1161,45 @@ struct NestedCtx { const float4* pairs; float* tstack; size_t grid_lanes; };
 template <bool ANY, class StackT>
 RT_DEV bool nested_pair_walk(const float4* __restrict__ pairs, const float4* __restrict__ nodes, const float4* __restrict__ tri_p, Ray& r, StackT* stack, int stack_stride,
                              float* tstack, size_t grid_lanes, int& prim_out, TriHit& hit_out);
-template <bool ANY, bool COUNT, class StackT>
+// The walk of an object that holds quadrics or masked triangles, OUT OF LINE: it is the rare path of the general kernels, and inlined into their leaf steps it cost the
+// common paths registers (k_trace_top<.., NO_MASKS> 19 -> 112 spilled dwords). Scalars in, eight dwords out (the call ABI's register budget, MEASUREMENTS R2).
+struct ObjWalkOut { int found, prim; float t, b0, b1, b2; unsigned n_nodes, n_tris; };
+template <bool ANY, bool COUNT, class StackT, int G>
+RT_DEVN ObjWalkOut object_walk_general(const DScene* self, unsigned node_base, unsigned prim_base, float ox, float oy, float oz, float dx, float dy, float dz, float t_max,
+                                       StackT* stack, int stack_stride, bool shadow_masks) {
+  const DScene& sc = *self;
+  Ray r; r.o = mk3(ox, oy, oz); r.d = mk3(dx, dy, dz); r.t_max = t_max;
+  const GlobalSrc src{sc.nodes + 2 * (size_t)node_base, sc.tri_p + 3 * (size_t)prim_base};
+  const GeneralCtx gen{self, shadow_masks, (int)prim_base};
+  ObjWalkOut o{}; TriHit h; h.t = kInf; h.b0 = h.b1 = h.b2 = 0.0f;
+  o.found = traverse<ANY, COUNT, GlobalSrc, StackT, G>(src, r, stack, stack_stride, o.prim, h, o.n_nodes, o.n_tris, gen) ? 1 : 0;
+  o.t = h.t; o.b0 = h.b0; o.b1 = h.b1; o.b2 = h.b2;
+  return o;
+}
+// MASKS / QUADRICS (round 6): the object may hold masked triangles / quadrics (TransformedPrimitive wraps whatever the definition collected, primitive.rs:79-118): its
+// primitives are tested in OBJECT space by the general tests - a quadric's own object_to_world is the CTM inside the definition, so the ray is transformed twice, once
+// per Transform * Ray, as in the reference (not by one product matrix).
+template <bool ANY, bool COUNT, class StackT, bool MASKS = false, bool QUADRICS = false>
 RT_DEV bool instance_intersect(const DScene& sc, unsigned inst, f3 o, f3 d, float& t_max, int& prim_out, TriHit& hit_out, unsigned& n_nodes, unsigned& n_tris,
-                               StackT* stack, int stack_stride, NestedCtx nc = NestedCtx{nullptr, nullptr, 0}) {
+                               StackT* stack, int stack_stride, NestedCtx nc = NestedCtx{nullptr, nullptr, 0}, bool shadow_masks = false) {
   const DInstance& in = sc.instances[inst];
   Ray r; r.o = xf34_point(in.w2o, o); r.d = xf34_vector(in.w2o, d); r.t_max = t_max;
   bool found;
+  constexpr int OBJ_GENERAL = MASKS ? RT_GEN_ALL : (QUADRICS ? RT_GEN_NO_MASKS : 0);
   if (in.n_nodes == 0u) {  // an object of one primitive is wrapped as it is (api.rs:1073-1082): no node test
-    f3 p0, p1, p2; load_tri(sc.tri_p, (int)in.prim_base, p0, p1, p2);
+    const float4 pa = sc.tri_p[3 * (size_t)in.prim_base], pb = sc.tri_p[3 * (size_t)in.prim_base + 1], pc = sc.tri_p[3 * (size_t)in.prim_base + 2];
+    const f3 p0 = mk3(pa.x, pa.y, pa.z), p1 = mk3(pb.x, pb.y, pb.z), p2 = mk3(pc.x, pc.y, pc.z);
+    const unsigned flags = __float_as_uint(pc.w);
     if (COUNT) n_tris += 1;
     TriHit h;
-    found = tri_test(p0, p1, p2, r, h);
+    if (OBJ_GENERAL != 0 && (flags & (RT_FLAG_SPHERE | RT_FLAG_GENERAL_TRI))) found = general_prim_test<MASKS, QUADRICS>(*sc.self, (int)in.prim_base, p0, p1, p2, flags, r, ray_pre(r), shadow_masks, h);
+    else found = tri_test(p0, p1, p2, r, h);
     if (found) { prim_out = 0; hit_out = h; r.t_max = h.t; }
+  } else if (OBJ_GENERAL != 0 && sc.obj_general) {  // (scenes whose objects hold such primitives carry no pair records for them: DScene::obj_pairs == 0)
+    const ObjWalkOut w = object_walk_general<ANY, COUNT, StackT, OBJ_GENERAL>(sc.self, in.node_base, in.prim_base, r.o.x, r.o.y, r.o.z, r.d.x, r.d.y, r.d.z, r.t_max, stack, stack_stride, shadow_masks);
+    found = w.found != 0;
+    if (COUNT) { n_nodes += w.n_nodes; n_tris += w.n_tris; }
+    if (found) { prim_out = w.prim; hit_out.t = w.t; hit_out.b0 = w.b0; hit_out.b1 = w.b1; hit_out.b2 = w.b2; if (!ANY) r.t_max = w.t; }
   } else {
     // the object's walk takes the entries of this lane's stack column above the caller's pending ones (rt_scene_create sizes the column for the
     // deepest top-level path plus the deepest object)
@@ -1190,16 +1217,18 @@ RT_DEV bool instance_intersect(const DScene& sc, unsigned inst, f3 o, f3 d, floa
 }
 // One primitive of a leaf of a GENERAL scene, for the persistent kernels: an object instance (the hit id then names (instance, the object's primitive)), a
 // quadric, a masked triangle or a plain one. Returns whether the ray hits; for a closest-hit ray prim / hit / t_max are updated by the caller's rule.
-template <bool ANY, bool COUNT, class StackT, bool MASKS = true, bool QUADRICS = true>
+// INSTANCES = false: the caller's scenes hold none (k_trace_top). OBJ_GENERAL: the instanced objects may hold quadrics / masked triangles (k_trace_big only: rt_scene_create
+// sends every ray of such a scene there - the pair / four-wide kernels keep the plain object walk and their registers)
+template <bool ANY, bool COUNT, class StackT, bool MASKS = true, bool QUADRICS = true, bool INSTANCES = true, bool OBJ_GENERAL = false>
 RT_DEV bool general_leaf_prim(const DScene& sc, const float4* __restrict__ tri_p, int prim, const Ray& ray, const RayPre& rp, bool shadow_masks, StackT* nested_stack, int stack_stride,
                               TriHit& h, int& hit_prim, float& t_hit, unsigned& n_nodes, unsigned& n_tris, NestedCtx nc = NestedCtx{nullptr, nullptr, 0}) {
   const float4 a = tri_p[3 * prim], b = tri_p[3 * prim + 1], c = tri_p[3 * prim + 2];
   const f3 p0 = mk3(a.x, a.y, a.z), p1 = mk3(b.x, b.y, b.z), p2 = mk3(c.x, c.y, c.z);
   const unsigned flags = __float_as_uint(c.w);
-  if (flags & RT_FLAG_INSTANCE) {
+  if (INSTANCES && (flags & RT_FLAG_INSTANCE)) {
     const unsigned k = __float_as_uint(c.x);
     int oprim = 0; float tm = ray.t_max;
-    if (!instance_intersect<ANY, COUNT, StackT>(sc, k, ray.o, ray.d, tm, oprim, h, n_nodes, n_tris, nested_stack, stack_stride, nc)) return false;
+    if (!instance_intersect<ANY, COUNT, StackT, MASKS && OBJ_GENERAL, QUADRICS && OBJ_GENERAL>(sc, k, ray.o, ray.d, tm, oprim, h, n_nodes, n_tris, nested_stack, stack_stride, nc, shadow_masks)) return false;
     hit_prim = (int)(sc.instances[k].id_base + (unsigned)oprim); t_hit = tm;
     return true;
   }
@@ -1287,7 +1316,7 @@ __global__ void __launch_bounds__(BLOCK) k_trace_big(DScene sc, TraceIO io, cons
         TriHit h;
         if (GENERAL) {
           int hp = 0; float th = 0.0f; unsigned nn = 0, ntt = 0;
-          const bool hitp = general_leaf_prim<ANY, COUNT, int>(sc, sc.tri_p, leaf_off + i, ray, rp, ANY && io.shadow_masks != 0, stack + sp * BLOCK, BLOCK, h, hp, th, nn, ntt);
+          const bool hitp = general_leaf_prim<ANY, COUNT, int, true, true, true, true>(sc, sc.tri_p, leaf_off + i, ray, rp, ANY && io.shadow_masks != 0, stack + sp * BLOCK, BLOCK, h, hp, th, nn, ntt);
           if (COUNT) { n_nodes += nn; n_tris += ntt; }
           if (!hitp) continue;
           found = true;
@@ -1525,13 +1554,13 @@ RT_DEV void pair_interior_step(PairLane& L, const TraceOut& o, const float4* __r
 // GENERAL scenes: a leaf that holds anything but plain triangles carries RT_PAIR_GENERAL in its code (first primitive then in bits 0-24) and walks its
 // primitives through general_leaf_prim; every other leaf of such a scene, and every leaf of a plain scene, runs the bare triangle loop.
 #define RT_PAIR_GENERAL 0x02000000u
-template <bool ANY, int GENERAL>
+template <bool ANY, int GENERAL, bool INSTANCES = true>
 RT_DEV bool pair_leaf_prims(PairLane& L, const DScene& sc, const float4* __restrict__ tri_p, bool shadow_masks, unsigned* nested_stack, int stack_stride, NestedCtx nc = NestedCtx{nullptr, nullptr, 0}) {
   const int off = (int)(L.cur & (GENERAL ? 0x01ffffffu : 0x03ffffffu)), n = (int)((L.cur >> 26) & 31u) + 1;
   if (GENERAL && (L.cur & RT_PAIR_GENERAL)) {
     for (int i = 0; i < n; ++i) {
       TriHit h; int hp = 0; float th = 0.0f; unsigned nn = 0, ntt = 0;
-      if (!general_leaf_prim<ANY, false, unsigned, GENERAL == RT_GEN_ALL, GENERAL != RT_GEN_INSTANCES_ONLY>(sc, tri_p, off + i, L.ray, L.rp(), shadow_masks, nested_stack, stack_stride, h, hp, th, nn, ntt, nc)) continue;
+      if (!general_leaf_prim<ANY, false, unsigned, GENERAL == RT_GEN_ALL, GENERAL != RT_GEN_INSTANCES_ONLY, INSTANCES>(sc, tri_p, off + i, L.ray, L.rp(), shadow_masks, nested_stack, stack_stride, h, hp, th, nn, ntt, nc)) continue;
       L.found = true;
       if (ANY) break;
       L.ray.t_max = th; L.prim = hp; L.hit = h;
@@ -1849,7 +1878,7 @@ RT_DEV void top_interior_step(PairLane& L, const TraceOut& o, const float4* __re
 }
 template <bool ANY, int BLOCK, int GENERAL = 0>  // GENERAL here: quadrics and masked triangles (an instanced scene needs a contiguous stack column: k_trace_pair)
 RT_DEV void top_leaf_step(PairLane& L, const TraceOut& o, const DScene& sc, const float4* __restrict__ tri_p, const SplitStack<BLOCK>& stk, const float* tstack, size_t grid_lanes, bool shadow_masks) {
-  (void)pair_leaf_prims<ANY, GENERAL>(L, sc, tri_p, shadow_masks, nullptr, 0);
+  (void)pair_leaf_prims<ANY, GENERAL, false>(L, sc, tri_p, shadow_masks, nullptr, 0);  // (an instanced scene needs a contiguous stack column: k_trace_pair)
   if (ANY && L.found) pair_finish<ANY>(L, o); else top_pop<ANY, BLOCK>(L, o, stk, tstack, grid_lanes);
 }
 template <bool ANY, int BLOCK, int GENERAL = 0>
@@ -2178,9 +2207,6 @@ RT_DEV bool ray_may_reach_box(f3 lo, f3 hi, f3 o, f3 d) {
 #define RT_LDS_MATERIALS 16
 #define RT_LDS_TEXTURES 64
 #define RT_LDS_IMAGES 8
-#ifndef RT_LDS_MARGINAL
-#define RT_LDS_MARGINAL 1024  // rows of ONE environment light's marginal distribution (the plain forms, LDSREC = 3); 0: the A/B control
-#endif
 // ================================================================================ K3 shade: rtx_shade_kernels.h (the k_shade front-ends and kernel, compiled by rtx_shade.hip); the miss bin's kernel:
 // The miss bin of a binned queue: a path whose ray left the scene. PathIntegrator::li adds the environment's radiance only for camera rays
 // and after specular bounces (path.rs:127-136, otherwise the light samples already account for it) and terminates the path; throughput,

@@ -458,23 +458,23 @@ struct PbrtLoader {
     auto it = instances.find(name);
     if (it == instances.end()) return fail_("Unable to find instance named " + name);
     const PbrtSoup& o = it->second;
-    for (const PbrtObjQuadric& q : o.quadrics) {  // the object's quadrics under instance_to_world * object_to_world
-      const Xf w = xf_mul(ctm, q.xf);
-      if (rtxh_scene_add_quadric(scene, q.kind, &w.m.a[0][0], &w.inv.a[0][0], q.radius, q.zmin, q.zmax, q.phimax, q.reverse, q.mat, q.emitter >= 0 ? -2 - q.emitter : -1) < 0) return fail_(rtxh_last_error());
-      n_spheres++;
-    }
-    if (o.idx.empty()) return true;
-    // The reference's form (the default): one tree per object, a TransformedPrimitive per instance - rtxh_scene_add_object once, rtxh_scene_add_instance
-    // per use, nothing copied, traversed in object space by the general kernels. Objects whose meshes carry alpha masks are written out (below), and so
-    // is everything when the caller asked for it (rtxh_set_flatten_instances: every ray then stays in the single-level kernels).
-    bool plain = !g_flatten_instances;
-    for (int32_t a : o.tri_alpha) if (a >= 0) plain = false;
-    if (plain) {
+    if (o.idx.empty() && o.quadrics.empty()) return true;
+    // The reference's form (the default): one tree per object, a TransformedPrimitive per instance (primitive.rs:79-118) over WHATEVER the definition collected -
+    // triangles, masked or not, and quadrics (round 6: rtxh_object_add_quadric / rtxh_object_set_alpha; a quadric keeps its own object_to_world = the CTM inside
+    // the definition, so a ray meets two Transform * Ray roundings, as in the reference) - rtxh_scene_add_object once, rtxh_scene_add_instance per use, nothing
+    // copied. Everything is written out instead when the caller asked for it (rtxh_set_flatten_instances: every ray then stays in the single-level kernels; a quadric
+    // then goes under the PRODUCT instance_to_world * object_to_world - one rounding, not the reference's two).
+    if (!g_flatten_instances) {
       auto id = object_ids.find(name);
       if (id == object_ids.end()) {
         const int k = rtxh_scene_add_object(scene, o.P.data(), (int32_t)o.n_verts(), o.idx.data(), (int32_t)(o.idx.size() / 3), o.any_n ? o.N.data() : nullptr,
                                             o.any_uv ? o.UV.data() : nullptr, o.any_s ? o.S.data() : nullptr, o.tri_mat.data(), o.tri_flags.data());
         if (k < 0) return fail_(rtxh_last_error());
+        for (const PbrtObjQuadric& q : o.quadrics)
+          if (rtxh_object_add_quadric(scene, k, q.kind, &q.xf.m.a[0][0], &q.xf.inv.a[0][0], q.radius, q.zmin, q.zmax, q.phimax, q.reverse, q.mat, q.emitter) < 0) return fail_(rtxh_last_error());
+        bool masked = false;
+        for (int32_t a : o.tri_alpha) masked = masked || a >= 0;
+        if (masked && rtxh_object_set_alpha(scene, k, o.tri_alpha.data()) != RT_OK) return fail_(rtxh_last_error());
         bool emits = false;
         for (int32_t l : o.tri_light) emits = emits || l <= -2;
         if (emits) {
@@ -488,6 +488,12 @@ struct PbrtLoader {
       n_instances += 1;
       return true;
     }
+    for (const PbrtObjQuadric& q : o.quadrics) {  // written out: the object's quadrics under instance_to_world * object_to_world
+      const Xf w = xf_mul(ctm, q.xf);
+      if (rtxh_scene_add_quadric(scene, q.kind, &w.m.a[0][0], &w.inv.a[0][0], q.radius, q.zmin, q.zmax, q.phimax, q.reverse, q.mat, q.emitter >= 0 ? -2 - q.emitter : -1) < 0) return fail_(rtxh_last_error());
+      n_spheres++;
+    }
+    if (o.idx.empty()) return true;
     // Written-out instances cost memory in proportion to instances x mesh size, where the reference's TransformedPrimitive shares one BVH. A scene
     // that instantiates its way past the budget is refused with a message instead of exhausting the host (RTX_INSTANCE_TRIANGLE_BUDGET, default 2^28
     // triangles ~ 40 GB of device geometry and BVH - a fraction of the 288 GB the design counts on).

@@ -240,10 +240,11 @@ RT_DEVN int instance_fill_interaction(const DScene& sc, unsigned hit_id, float o
   const DInstance& in = sc.instances[lo];
   const int gprim = (int)(in.prim_base + (hit_id - in.id_base));
   const f3 d_obj = xf34_vector(in.w2o, mk3(dx, dy, dz));  // Transform * Ray: the direction as a vector (the origin does not enter a triangle's interaction)
-  (void)ox; (void)oy; (void)oz;
   TriHit th; th.t = 0.0f; th.b0 = b0; th.b1 = b1; th.b2 = b2;
   SurfaceInteraction s;
-  tri_fill_interaction_inl(sc, gprim, d_obj, th, s);
+  if (tri_flags(sc.tri_p, gprim) & RT_FLAG_SPHERE) {  // a quadric of the object (round 6): Sphere::intersect builds its interaction from the OBJECT-space ray, then SurfaceInteraction::transform
+    (void)sphere_fill_interaction(sc.spheres[prim_sphere_index(sc.tri_p, gprim)], xf34_point(in.w2o, mk3(ox, oy, oz)), d_obj, s);
+  } else tri_fill_interaction_inl(sc, gprim, d_obj, th, s);
   f3 perr;
   si.hit.p = xf34_point_with_error(in.o2w, s.hit.p, s.hit.p_error, perr); si.hit.p_error = perr;
   si.hit.wo = normalize(xf34_vector(in.o2w, s.hit.wo));
@@ -319,9 +320,7 @@ __global__ void __launch_bounds__(256, (MODE == 1 || LEAN || BOUNCED) ? ((LEAN |
   __shared__ unsigned s_imgs[LDSREC == 3 ? RT_LDS_IMAGES * (sizeof(DImage) / 4) : 1];
   __shared__ unsigned s_mats[LDSREC ? RT_LDS_MATERIALS * (sizeof(DMaterial) / 4) : 1];
   __shared__ unsigned s_texs[LDSREC ? RT_LDS_TEXTURES * (sizeof(DTexture) / 4) : 1];
-  constexpr bool LDS_MARG = LDSREC == 3 && !LEAN && MODE != 1;  // the forms that can meet an environment light, with their tables in LDS
-  __shared__ float s_mcdf[LDS_MARG ? RT_LDS_MARGINAL + 1 : 1], s_mfunc[LDS_MARG ? RT_LDS_MARGINAL + 1 : 1];
-  __shared__ unsigned short s_mguide[LDS_MARG ? RT_LDS_MARGINAL + 2 : 1];
+  // (round 6 also kept ONE environment light's marginal distribution - cdf, func, guide: 10 KB - in LDS for the plain forms: S4 shade 2368 -> 2378 ms, not kept; commit ec235f5)
   if (LDSREC) {
     if (LDSREC == 1) {
       for (unsigned k = threadIdx.x; k < 8u * sc.n_tris; k += blockDim.x) s_rec[k] = sc.tri_rec[k];
@@ -337,23 +336,6 @@ __global__ void __launch_bounds__(256, (MODE == 1 || LEAN || BOUNCED) ? ((LEAN |
     __syncthreads();
     if (LDSREC == 1) { sc.tri_rec = (const float4*)s_rec; sc.tri_p = (const float4*)s_trip; }
     if (LDSREC == 1 || LDSREC == 3) sc.lights = (const DLight*)s_lights;
-    if (LDS_MARG) {
-      // round 6: ONE environment light's MARGINAL distribution (Distribution2D::p_marginal: nv <= 1024 entries - cdf, func and the search's guide, 10 KB) in LDS as well: a
-      // sample walks guide -> cdf bracket -> func, three dependent gathers of tables that never miss L2 and still cost a round trip each. The LDS copy of the light record
-      // is re-pointed at them (generic pointers: the out-of-line light evaluators read through whatever they are given).
-      DLight* const L = (DLight*)s_lights + (sc.n_infinite == 1 ? sc.infinite_ids[0] : 0);
-      const bool fits = sc.n_infinite == 1 && L->nv <= RT_LDS_MARGINAL && (1 << L->mglog) <= RT_LDS_MARGINAL;  // (workgroup-uniform)
-      if (fits) {
-        const float* const g_cdf = L->mcdf; const float* const g_func = L->mfunc; const unsigned short* const g_guide = L->mguide; const int nv = L->nv, ng = (1 << L->mglog) + 1;
-        for (int k = threadIdx.x; k <= nv; k += blockDim.x) s_mcdf[k] = g_cdf[k];
-        for (int k = threadIdx.x; k < nv; k += blockDim.x) s_mfunc[k] = g_func[k];
-        for (int k = threadIdx.x; k < ng; k += blockDim.x) s_mguide[k] = g_guide[k];
-        __syncthreads();
-        if (threadIdx.x == 0u) { L->mcdf = s_mcdf; L->mfunc = s_mfunc; L->mguide = s_mguide; }
-        __syncthreads();
-      }
-    }
-    if (LDSREC == 3) sc.images = (const DImage*)s_imgs;
     sc.materials = (const DMaterial*)s_mats; sc.textures = (const DTexture*)s_texs;
   }
   // The kernel's once-through streams (path records in and out, shadow / MIS ray records) with or without the non-temporal hint (SPtr, RT_NT_STREAMS): with it where the launch

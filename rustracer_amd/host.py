@@ -216,6 +216,11 @@ class HostScene:
                                            _p(o.mat, C.c_int32), _p(o.flags, C.c_uint8)), "add_object")
             if getattr(o, "emit", None) is not None:
                 _check(L.rtxh_scene_object_emitters(self.h, k, _p(o.emit, C.c_int32)), "object_emitters")
+            for q in getattr(o, "quadrics", None) or []:  # quadrics of the object definition, in object space; light -2 - k: unlisted emitter k
+                _check(L.rtxh_object_add_quadric(self.h, k, int(q.kind), _p(q.o2w), _p(q.w2o), C.c_float(q.radius), C.c_float(q.z_min), C.c_float(q.z_max), C.c_float(q.phi_max),
+                                                 int(q.reverse_orientation), q.material, (-2 - q.light) if q.light <= -2 else -1), "object_add_quadric")
+            if getattr(o, "alpha", None) is not None:
+                _check(L.rtxh_object_set_alpha(self.h, k, _p(o.alpha, C.c_int32)), "object_set_alpha")
         for i in getattr(desc, "instances", []):
             _check(L.rtxh_scene_add_instance(self.h, i.obj, _p(i.o2w), _p(i.w2o)), "add_instance")
         for l in desc.lights:
@@ -430,7 +435,9 @@ _OBJECT_TABLES = {"P": (0, np.dtype(("<f4", 3))), "N": (1, np.dtype(("<f4", 3)))
 
 def scene_table(handle, name):
     """Copy of one unflattened table of an rtxh_scene (rtxh_scene_inspect)."""
-    if isinstance(name, tuple):  # (object index, table): the object-space soup of one ObjectBegin block
+    if isinstance(name, tuple) and name[1] in ("quadrics", "tri_alpha"):  # what else the object definition holds: RTXH_TABLE_OBJECT_EXTRA_BASE + 2 * object + {0, 1}
+        which, dt = 100000 + 2 * int(name[0]) + (0 if name[1] == "quadrics" else 1), (_TABLES["quadrics"][1] if name[1] == "quadrics" else np.dtype(("<i4", 2)))
+    elif isinstance(name, tuple):  # (object index, table): the object-space soup of one ObjectBegin block
         j, dt = _OBJECT_TABLES[name[1]]
         which = 1000 + 8 * int(name[0]) + j
     else:

@@ -141,6 +141,10 @@ class ObjectDef:
     mat: np.ndarray
     flags: np.ndarray
     emit: Optional[np.ndarray] = None  # per triangle: index into SceneDesc.emitters or -1 (None: no triangle of the object emits)
+    # what else the definition holds (rc/api.rs:1019-1051 collects every primitive): quadrics in OBJECT space (SphereShape; light = -1 or -2 - k: emitter k of
+    # SceneDesc.emitters, in no light list) - primitive ids inside the object after its triangles - and {alpha, shadowalpha} texture ids per triangle
+    quadrics: Optional[list] = None
+    alpha: Optional[np.ndarray] = None
 
 
 @dataclass
@@ -364,13 +368,14 @@ class SceneDesc:
         """Shape "cylinder" (rc/shapes/cylinder.rs): the open cylinder of `radius` around the object-space z axis between z_min and z_max."""
         return self._add_quadric(2, o2w, radius, z_min, z_max, phi_max, material, reverse_orientation, emission, two_sided)
 
-    def add_object(self, meshes) -> int:
+    def add_object(self, meshes, quadrics=None) -> int:
         """ObjectBegin ... ObjectEnd (rc/api.rs:1019-1051): triangle meshes in OBJECT space - an iterable of dicts with the keys of `add_mesh`
-        (P, idx, material, N, UV, S, reverse_orientation, emission, two_sided; no alpha masks). A mesh with `emission` is a shape under an AreaLightSource
+        (P, idx, material, N, UV, S, reverse_orientation, emission, two_sided, alpha, shadow_alpha) - and `quadrics`: dicts with kind (0 sphere, 1 disk, 2 cylinder),
+        o2w (the CTM inside the definition), radius, z_min, z_max (disk: height, inner radius), phi_max, material, reverse_orientation, emission, two_sided. A mesh with `emission` is a shape under an AreaLightSource
         inside the object definition: it keeps its DiffuseAreaLight (it glows when a camera ray or a specular bounce reaches it) but the light never enters
         the scene's list (rc/api.rs:954-964) - an entry of `self.emitters`, not of `self.lights`. Returns the object's index; nothing is rendered until
         `add_instance` places it."""
-        Ps, Is, Ns, UVs, Ss, mats, flags, emits, nv0 = [], [], [], [], [], [], [], [], 0
+        Ps, Is, Ns, UVs, Ss, mats, flags, emits, alphas, nv0 = [], [], [], [], [], [], [], [], [], 0
         for m in meshes:
             P = np.ascontiguousarray(m["P"], dtype=np.float32).reshape(-1, 3)
             idx = np.ascontiguousarray(m["idx"], dtype=np.int32).reshape(-1, 3)
@@ -395,7 +400,25 @@ class SceneDesc:
                 self.emitters.append((tuple(float(x) for x in m["emission"]), bool(m.get("two_sided", False))))
                 em = len(self.emitters) - 1
             emits.append(np.full(nt, em, dtype=np.int32))
+            am = [(-1 if a is None else (int(a) if isinstance(a, (int, np.integer)) and not isinstance(a, bool) else (self.const_tex(0.0) if float(a) == 0.0 else -1)))
+                  for a in (m.get("alpha"), m.get("shadow_alpha"))]
+            alphas.append(np.tile(np.int32(am), (nt, 1)))
             nv0 += nv
+        qs = []
+        for q in quadrics or []:
+            o2w = np.ascontiguousarray(q["o2w"], np.float32).reshape(4, 4)
+            w2o = np.ascontiguousarray(np.linalg.inv(o2w.astype(np.float64)), np.float32)
+            light = -1
+            if q.get("emission") is not None:
+                self.emitters.append((tuple(float(x) for x in q["emission"]), bool(q.get("two_sided", False))))
+                light = -2 - (len(self.emitters) - 1)
+            r = float(q.get("radius", 1.0)); kind = int(q.get("kind", 0))
+            qs.append(SphereShape(o2w, w2o, r, float(q.get("z_min", -r if kind == 0 else 0.0)), float(q.get("z_max", r if kind == 0 else 0.0)), float(q.get("phi_max", 360.0)),
+                                  bool(q.get("reverse_orientation", False)), int(q["material"]), light, kind))
+        if not Ps:  # an object of quadrics only
+            assert qs, "an object without primitives"
+            self.objects.append(ObjectDef(np.zeros((0, 3), np.float32), np.zeros((0, 3), np.int32), None, None, None, np.zeros(0, np.int32), np.zeros(0, np.uint8), None, qs, None))
+            return len(self.objects) - 1
         fl = np.ascontiguousarray(np.concatenate(flags), dtype=np.uint8)
         self.objects.append(ObjectDef(
             np.ascontiguousarray(np.concatenate(Ps)), np.ascontiguousarray(np.concatenate(Is)),
@@ -403,7 +426,8 @@ class SceneDesc:
             np.ascontiguousarray(np.concatenate(UVs)) if (fl & TRI_HAS_UV).any() else None,
             np.ascontiguousarray(np.concatenate(Ss)) if (fl & TRI_HAS_S).any() else None,
             np.ascontiguousarray(np.concatenate(mats)), fl,
-            np.ascontiguousarray(np.concatenate(emits)) if any((e >= 0).any() for e in emits) else None))
+            np.ascontiguousarray(np.concatenate(emits)) if any((e >= 0).any() for e in emits) else None,
+            qs or None, np.ascontiguousarray(np.concatenate(alphas), dtype=np.int32) if any((a >= 0).any() for a in alphas) else None))
         return len(self.objects) - 1
 
     def add_instance(self, obj: int, o2w) -> int:

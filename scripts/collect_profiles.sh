@@ -1,6 +1,6 @@
 #!/bin/bash
 # After `bash scripts/round_profiles.sh <tag>` ran on the GPU box and gpurun merged gpurun_out/ back: copy what the judge reads into profiles/ (tracked). Usage: bash scripts/collect_profiles.sh r05
-TAG=${1:-r05}
+TAG=${1:-r06}
 cd "$(dirname "$0")/.." || exit 1
 cp gpurun_out/final/profiles/${TAG}_* gpurun_out/final/profiles/pmc_*.json profiles/ || exit 1
 cp gpurun_out/final/bench_default.json profiles/${TAG}_bench_default.json

@@ -106,9 +106,10 @@ def test_object_instances_render_like_the_written_out_scene(gpu_host, orc):
 
 
 def test_quadrics_inside_objects_are_placed_by_their_instances(gpu_host, orc):
-    """ObjectBegin .. Shape "sphere" .. ObjectEnd + ObjectInstance: the reference's TransformedPrimitive over a sphere (rc/api.rs:1053-1090, primitive.rs:79-118)
-    is the sphere under instance_to_world * object_to_world. Against the oracle on the scene with the spheres placed by hand; and an emitting sphere of an object
-    glows at L where the camera sees it and lights nothing (api.rs:954-964)."""
+    """ObjectBegin .. Shape "sphere" .. ObjectEnd + ObjectInstance: the reference's TransformedPrimitive over a sphere (rc/api.rs:1053-1090, primitive.rs:79-118).
+    Round 6: the object HOLDS the spheres (object space) and is placed by its instances - against the oracle's TransformedPrimitive over the same object, built by
+    calls; written out (flatten_instances) it is the sphere under instance_to_world * object_to_world - against the oracle on the scene with the spheres placed by
+    hand. And an emitting sphere of an object glows at L where the camera sees it and lights nothing (api.rs:954-964)."""
     from rustracer_amd.scene_desc import SceneDesc
     from test_pbrt_cpu import _mm, _scale, _translate
     head = ('LookAt 0 3 -9  0 1 0  0 1 0\nCamera "perspective" "float fov" [45]\nSampler "02sequence" "integer pixelsamples" [16]\n'
@@ -119,21 +120,42 @@ def test_quadrics_inside_objects_are_placed_by_their_instances(gpu_host, orc):
     obj = ('ObjectBegin "ball"\nMaterial "plastic" "rgb Kd" [0.2 0.4 0.7] "float roughness" [0.2]\nTranslate 0 1 0\nShape "sphere" "float radius" 0.8\n'
            'Translate 0 1.2 0\nShape "sphere" "float radius" 0.4 "float zmax" 0.2\nObjectEnd\n')
     places = ('AttributeBegin\nTranslate -2.5 0 0\nObjectInstance "ball"\nAttributeEnd\nAttributeBegin\nTranslate 2 0 1\nScale 1 1.5 1\nObjectInstance "ball"\nAttributeEnd\n')
-    p = gpu_host.PbrtScene(text=head + lamp + obj + places + 'WorldEnd\n')
-    assert len(p.table("quadrics")) == 4 and len(p.table("instances")) == 0
-    d = SceneDesc()
-    grey, blue = d.matte((0.7, 0.7, 0.7)), d.plastic((0.2, 0.4, 0.7), (0.25, 0.25, 0.25), 0.2)
-    d.add_quad((-6, 0, -6), (-6, 0, 6), (6, 0, 6), (6, 0, -6), grey)
-    d.add_quad((-1, 5.9, -1), (1, 5.9, -1), (1, 5.9, 1), (-1, 5.9, 1), grey, emission=(20.0, 18.0, 15.0))
+    text = head + lamp + obj + places + 'WorldEnd\n'
+
+    def base():
+        d = SceneDesc()
+        grey, blue = d.matte((0.7, 0.7, 0.7)), d.plastic((0.2, 0.4, 0.7), (0.25, 0.25, 0.25), 0.2)
+        d.add_quad((-6, 0, -6), (-6, 0, 6), (6, 0, 6), (6, 0, -6), grey)
+        d.add_quad((-1, 5.9, -1), (1, 5.9, -1), (1, 5.9, 1), (-1, 5.9, 1), grey, emission=(20.0, 18.0, 15.0))
+        d.camera.pos, d.camera.look, d.camera.fov = (0.0, 3.0, -9.0), (0.0, 1.0, 0.0), 45.0
+        d.film.xres, d.film.yres = 96, 64
+        d.sampler.spp = 16
+        return d, blue
+    # two-level (the default): the object holds its two spheres
+    p = gpu_host.PbrtScene(text=text)
+    assert len(p.table("quadrics")) == 0 and len(p.table("instances")) == 2 and len(p.table((0, "quadrics"))) == 2
+    d, blue = base()
+    o = d.add_object([], quadrics=[dict(kind=0, o2w=_translate(0, 1, 0).astype(np.float32), radius=0.8, material=blue),
+                                   dict(kind=0, o2w=_translate(0, 2.2, 0).astype(np.float32), radius=0.4, z_max=0.2, material=blue)])
     for inst in (_translate(-2.5, 0, 0), _mm(_translate(2, 0, 1), _scale(1, 1.5, 1))):
-        d.add_sphere(radius=0.8, material=blue, o2w=_mm(inst, _translate(0, 1, 0)).astype(np.float32))
-        d.add_sphere(radius=0.4, material=blue, o2w=_mm(inst, _translate(0, 2.2, 0)).astype(np.float32), z_max=0.2)
-    d.camera.pos, d.camera.look, d.camera.fov = (0.0, 3.0, -9.0), (0.0, 1.0, 0.0), 45.0
-    d.film.xres, d.film.yres = 96, 64
-    d.sampler.spp = 16
+        d.add_instance(o, inst.astype(np.float32))
+    h = gpu_host.HostScene(d)
+    for k in ("o2w", "w2o", "radius", "z_min", "z_max", "phi_max", "material", "light", "kind"):
+        assert np.array_equal(p.table((0, "quadrics"))[k], h.table((0, "quadrics"))[k]), k
     fo, _ = orc.OracleScene(d).render(mode=1)
     fp, _ = p.render()
     assert np.array_equal(fo[..., 3], fp[..., 3]) and rel_l2(gpu_host.film_to_rgb(fp), orc.film_to_rgb(fo)) < 1e-3
+    # written out: the spheres at the top level under the composed transforms
+    pf = gpu_host.PbrtScene(text=text, flatten_instances=True)
+    assert len(pf.table("quadrics")) == 4 and len(pf.table("instances")) == 0
+    d, blue = base()
+    for inst in (_translate(-2.5, 0, 0), _mm(_translate(2, 0, 1), _scale(1, 1.5, 1))):
+        d.add_sphere(radius=0.8, material=blue, o2w=_mm(inst, _translate(0, 1, 0)).astype(np.float32))
+        d.add_sphere(radius=0.4, material=blue, o2w=_mm(inst, _translate(0, 2.2, 0)).astype(np.float32), z_max=0.2)
+    fo, _ = orc.OracleScene(d).render(mode=1)
+    ff, _ = pf.render()
+    assert np.array_equal(fo[..., 3], ff[..., 3]) and rel_l2(gpu_host.film_to_rgb(ff), orc.film_to_rgb(fo)) < 1e-3
+    assert rel_l2(gpu_host.film_to_rgb(ff), gpu_host.film_to_rgb(fp)) < 5e-3   # two roundings of one scene
     # an emitting sphere inside an object, the only emitter of the scene: L where it is seen, black everywhere else
     glow = ('ObjectBegin "glow"\nAreaLightSource "diffuse" "rgb L" [5 4 3]\nTranslate 0 2 0\nShape "sphere" "float radius" 1.5\nObjectEnd\nObjectInstance "glow"\n')
     g = gpu_host.PbrtScene(text=head + glow + 'WorldEnd\n')

@@ -283,8 +283,8 @@ def test_kernel_register_and_scratch_budgets(host):
     # bounds of the forms they replace, a handful of spilled dwords in the four-wave kernels, and LDS that leaves the waves the bound promises (4 x 33 KB, 3 x 10 KB)
     lds_budget = {  # name -> (max VGPRs, max scratch bytes, max spilled dwords, max LDS bytes)
         "rtx::k_shade<1, false, false, false, false, 1>": (128, 32, 8, 36864), "rtx::k_shade<1, false, false, false, false, 3>": (128, 32, 8, 16384),
-        "rtx::k_shade<3, false, false, false, false, 3>": (168, 64, 72, 24576), "rtx::k_shade<3, false, false, true, false, 3>": (168, 32, 64, 24576),  # (round 6: + 10 KB, an environment light's marginal distribution)
-        "rtx::k_shade<5, false, false, false, false, 3>": (168, 160, 72, 24576), "rtx::k_shade<6, false, false, false, false, 3>": (168, 224, 72, 24576),
+        "rtx::k_shade<3, false, false, false, false, 3>": (168, 64, 72, 16384), "rtx::k_shade<3, false, false, true, false, 3>": (168, 32, 64, 16384),
+        "rtx::k_shade<5, false, false, false, false, 3>": (168, 160, 72, 16384), "rtx::k_shade<6, false, false, false, false, 3>": (168, 224, 72, 16384),
         "rtx::k_shade<3, false, true, false, false, 2>": (168, 0, 0, 6144), "rtx::k_shade<5, false, true, false, false, 2>": (168, 32, 64, 6144), "rtx::k_shade<6, false, true, false, false, 2>": (168, 64, 64, 6144),
         "rtx::k_shade<3, false, true, false, true, 1>": (168, 0, 0, 32768), "rtx::k_shade<5, false, true, false, true, 1>": (168, 32, 64, 32768), "rtx::k_shade<6, false, true, false, true, 1>": (168, 64, 64, 32768),
     }

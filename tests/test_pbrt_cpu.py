@@ -550,9 +550,10 @@ def test_area_lights_inside_object_definitions_stay_out_of_the_light_list():
 
 
 def test_quadrics_inside_object_definitions_are_placed_by_every_instance():
-    """The reference wraps whatever an object holds in a TransformedPrimitive (rc/api.rs:1053-1090). A quadric has an object-to-world transform of its own, so
-    an instance of it is the same quadric under instance_to_world * object_to_world: the same tables as the scene with the quadrics written at the top level
-    under the composed transforms; an area light on it stays out of the light list (api.rs:954-964)."""
+    """The reference wraps whatever an object holds in a TransformedPrimitive (rc/api.rs:1053-1090, primitive.rs:79-118). Round 6: so does the host - a quadric of an
+    object definition stays IN the object, in object space (its own object_to_world = the CTM inside the definition), and every ObjectInstance places the object.
+    Written out (flatten_instances) an instance of it is the same quadric under instance_to_world * object_to_world: the same tables as the scene with the quadrics
+    written at the top level under the composed transforms. An area light on it stays out of the light list (api.rs:954-964) either way."""
     obj = ('ObjectBegin "o"\n' + TRI + 'AttributeBegin\nTranslate 0 1 0\nScale 1 2 1\nShape "sphere" "float radius" 0.5 "float zmax" 0.25\nAttributeEnd\n'
            'Rotate 30 0 0 1\nShape "cylinder" "float radius" 0.2\nObjectEnd\n')
     text = HEADER + 'WorldBegin\nLightSource "point" "rgb I" [1 1 1]\n' + TRI + obj + 'Translate 3 0 0\nObjectInstance "o"\nRotate 45 0 1 0\nTranslate 0 0 2\nObjectInstance "o"\nWorldEnd\n'
@@ -562,9 +563,18 @@ def test_quadrics_inside_object_definitions_are_placed_by_every_instance():
             'AttributeBegin\nTranslate 3 0 0\nRotate 45 0 1 0\nTranslate 0 0 2\nAttributeBegin\nTranslate 0 1 0\nScale 1 2 1\nShape "sphere" "float radius" 0.5 "float zmax" 0.25\nAttributeEnd\n'
             'Rotate 30 0 0 1\nShape "cylinder" "float radius" 0.2\nAttributeEnd\nWorldEnd\n')
     p, q = _parse(text), _parse(flat)
-    assert len(p.table("instances")) == 2 and len(p.table((0, "indices"))) == 1   # the object's triangle stays two-level
-    sp, sq = p.table("quadrics"), q.table("quadrics")
-    assert len(sp) == 4 and list(sp["kind"]) == [0, 2, 0, 2]
+    # two-level (the default): the object holds its triangle AND its two quadrics, in object space; nothing at the top level
+    assert len(p.table("instances")) == 2 and len(p.table((0, "indices"))) == 1 and len(p.table("quadrics")) == 0
+    oq = p.table((0, "quadrics"))
+    assert len(oq) == 2 and list(oq["kind"]) == [0, 2] and list(oq["light"]) == [-1, -1]
+    one = _parse(HEADER + 'WorldBegin\n' + TRI + 'AttributeBegin\nTranslate 0 1 0\nScale 1 2 1\nShape "sphere" "float radius" 0.5 "float zmax" 0.25\nAttributeEnd\n'
+                 'Rotate 30 0 0 1\nShape "cylinder" "float radius" 0.2\nWorldEnd\n').table("quadrics")   # the same statements at the top level of an identity CTM
+    for k in oq.dtype.names:
+        assert np.array_equal(oq[k], one[k]), k
+    # written out: the quadrics at the top level under the composed transforms
+    f = host.PbrtScene(text=text, flatten_instances=True)
+    sp, sq = f.table("quadrics"), q.table("quadrics")
+    assert len(sp) == 4 and list(sp["kind"]) == [0, 2, 0, 2] and len(f.table("instances")) == 0
     for k in sp.dtype.names:
         if k in ("o2w", "w2o"):
             assert np.allclose(sp[k], sq[k], rtol=0, atol=1e-6), k   # (the file spells the product out statement by statement: the same matrices up to the order of the roundings)
@@ -574,7 +584,9 @@ def test_quadrics_inside_object_definitions_are_placed_by_every_instance():
     text_e = text.replace('Shape "sphere"', 'AreaLightSource "diffuse" "rgb L" [5 4 3]\nShape "sphere"')
     e = _parse(text_e)
     assert e.n_lights() == 1 and len(e.table("emitters")) == 1 and np.array_equal(e.table("emitters")["rgb"][0], F32([5, 4, 3]))
-    assert list(e.table("quadrics")["light"]) == [-2, -1, -2, -1]  # -2 - k: unlisted emitter k; the cylinders emit nothing
+    assert list(e.table((0, "quadrics"))["light"]) == [-2, -1]  # -2 - k: unlisted emitter k; the cylinder emits nothing
+    ef = host.PbrtScene(text=text_e, flatten_instances=True)
+    assert list(ef.table("quadrics")["light"]) == [-2, -1, -2, -1]
 
 
 def test_a_redefined_object_is_what_later_instances_place():
