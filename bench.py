@@ -3,7 +3,7 @@
 
 A "step" is one full frame of the hot path: the synthetic Cornell box (S1) at 1024x1024, PathIntegrator maxdepth=5,
 1024 spp, scene already resident in HBM. With N > 1 (one process per GPU under torch.distributed) the film is sharded by interleaved
-16-row tile rows (8-row bands where the tile rows do not divide over the ranks: RT_SHARD_ROWS), no collective on the data path, and gathered at the end of the frame: every rank sends the rows it touched to rank 0
+4-row bands (RT_SHARD_ROWS), no collective on the data path, and gathered at the end of the frame: every rank sends the rows it touched to rank 0
 over RCCL point-to-point sends, inside the timed region.
 
 Prints ONE JSON line (rank 0). `roofline` is for the dominant kernel stage of the workload: algorithmic bytes (a ray cast =

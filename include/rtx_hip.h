@@ -197,12 +197,12 @@ typedef struct rt_path_desc {     /* PathIntegrator (rc/integrator/path.rs:25-31
   int32_t pixel_bounds[4];        /* x0 y0 x1 y1                                    */
 } rt_path_desc;
 /* Film sharding for multi-GPU: this call renders the bands r of the sample rows with r % world_size == rank; pixels of
- * other rows stay zero in the output. A band is RT_SHARD_ROWS(H, world_size) rows high, H = the sample bounds' height: the reference's 16-row tile
- * rows - or 8 rows when the number of 16-row bands is not a multiple of world_size (1080 rows on 8 devices: 68 bands would be 9 for four devices and
- * 8 for the others, 1.059 of the mean by construction; 135 bands of 8 rows are 17 at most against 16.9). Which samples a device renders changes nothing
- * in the film: every pixel's sampler is keyed by the pixel (pixel-keyed mode). */
+ * other rows stay zero in the output. A band is RT_SHARD_ROWS(H, world_size) rows high: 4 rows on a sharded frame (round 6; rounds 4 - 5 cut the reference's 16-row
+ * tile rows, or 8 rows where those did not divide over the ranks). What a rank's rows cost depends on what they show, and the slowest rank sets the frame time: on the
+ * headline scene the 8-way split's slowest rank took 1.037 of the mean with 16-row bands, 1.022 with 8, 1.013 with 4 (profiles/r06_shard_band_sweep.txt), and 1080 rows
+ * are 270 bands - 34 or 33 per rank of 8. Which samples a device renders changes nothing in the film: every pixel's sampler is keyed by the pixel (pixel-keyed mode). */
 typedef struct rt_shard { int32_t rank, world_size; } rt_shard;
-#define RT_SHARD_ROWS(H, world_size) (((world_size) > 1 && ((((H) + 15) / 16) % (world_size)) != 0) ? 8 : 16)
+#define RT_SHARD_ROWS(H, world_size) ((world_size) > 1 ? 4 : 16)
 
 typedef struct rt_stats {
   uint64_t camera_rays;
@@ -292,7 +292,7 @@ int rt_render(rt_scene* scene, const rt_camera* camera, const rt_film_desc* film
 /* Several GPUs of one node from one process (north_star: "partition the film across the 8 GPUs of one node"). The reference's
  * render loop hands 16 x 16 tiles to worker threads from a shared queue and merges finished tiles into the film (rc/renderer.rs:47-71,
  * rc/film.rs:177-194); here the workers are GPUs. rt_multi_create replicates the scene on every listed device (a device may be listed more than
- * once). rt_multi_render cuts the frame into n_devices * chunks_per_device chunks of interleaved 16-row tile rows, lets one host thread per
+ * once). rt_multi_render cuts the frame into n_devices * chunks_per_device chunks of interleaved bands of RT_SHARD_ROWS rows, lets one host thread per
  * device pull chunks from a shared counter (chunks_per_device = 1: the static split; > 1: the dynamic queue for frames whose rows differ in
  * cost), and sends only the film rows a chunk can have touched to devices[0] over xGMI (hipMemcpyPeerAsync), where they are summed in chunk
  * order - the gather that replaces Film::merge_film_tile. No collective while paths are traced. film_xyzw: host memory, or memory of

@@ -1386,8 +1386,8 @@ extern "C" int rt_render(rt_scene* s, const rt_camera* cam, const rt_film_desc* 
   fp.max_depth = (int)(uint8_t)path->max_depth; fp.rr_threshold = path->rr_threshold;
   fp.pb_x0 = path->pixel_bounds[0]; fp.pb_y0 = path->pixel_bounds[1]; fp.pb_x1 = path->pixel_bounds[2]; fp.pb_y1 = path->pixel_bounds[3];
   fp.rank = rank; fp.world = world;
-  const int band = RT_SHARD_ROWS(H, world);  // rows per shard band: 16, or 8 where the 16-row bands do not divide over the ranks
-  fp.shard_log2 = band == 16 ? 4 : 3;
+  const int band = RT_SHARD_ROWS(H, world);  // rows per shard band (a power of two: 4 on a sharded frame)
+  fp.shard_log2 = 0; while ((1 << fp.shard_log2) < band) fp.shard_log2 += 1;
   fp.w_recip = W > 1 ? (unsigned)((1ull << 32) / (unsigned long long)W) : 0u;
 
   // owned sample rows (tile rows of 16, interleaved over ranks)
@@ -1681,7 +1681,7 @@ extern "C" int rt_render(rt_scene* s, const rt_camera* cam, const rt_film_desc* 
 
 // ---------------------------------------------------------------------------------------------- several GPUs, one process
 // renderer::render hands tiles to worker threads from a shared queue and merges each finished tile into the film (rc/renderer.rs:47-71,
-// rc/film.rs:177-194). Here the workers are GPUs: the scene is replicated, the frame is cut into chunks of interleaved 16-row tile rows
+// rc/film.rs:177-194). Here the workers are GPUs: the scene is replicated, the frame is cut into chunks of interleaved bands of RT_SHARD_ROWS rows
 // (rt_shard), one host thread per device takes chunks from a shared counter, renders each with rt_render into a film on its own device and sends
 // the rows that chunk can have touched - its tile rows plus the filter's reach - to the first device over xGMI (hipMemcpyPeerAsync), where they are
 // added into the frame in chunk order. Only those rows cross the links; nothing is exchanged while paths are traced.

@@ -21,9 +21,9 @@ TILE = 16  # block_size passed by rc/api.rs:1009
 
 
 def shard_rows(n_sample_rows: int, world: int) -> int:
-    """Rows per shard band - RT_SHARD_ROWS of include/rtx_hip.h: the reference's 16-row tile rows, or 8 rows when the number of 16-row bands is not a
-    multiple of `world` (1080 rows on 8 devices: 68 bands = 9 for four devices and 8 for the others; 135 bands of 8 rows = 17 at most against 16.9)."""
-    return 8 if world > 1 and ((n_sample_rows + 15) // 16) % world != 0 else 16
+    """Rows per shard band - RT_SHARD_ROWS of include/rtx_hip.h: 4 rows on a sharded frame (thin bands even out what the ranks' rows show: the slowest rank sets
+    the frame time), the reference's 16-row tile rows on a single device."""
+    return 4 if world > 1 else 16
 
 
 def owned_sample_rows(sample_y0: int, sample_y1: int, rank: int, world: int) -> np.ndarray:

@@ -13,14 +13,14 @@ def test_owned_rows_partition_the_frame():
             rows = [owned_sample_rows(y0, y1, r, world) for r in range(world)]
             allr = np.sort(np.concatenate(rows))
             assert np.array_equal(allr, np.arange(y0, y1))  # every row owned exactly once
-            band = shard_rows(y1 - y0, world)  # RT_SHARD_ROWS: 16-row tile rows, or 8 rows where those do not divide over the ranks
-            assert band == (8 if world > 1 and ((y1 - y0 + 15) // 16) % world else 16)
+            band = shard_rows(y1 - y0, world)  # RT_SHARD_ROWS: 4-row bands on a sharded frame
+            assert band == (4 if world > 1 else 16)
             for r in range(world):
                 assert np.all(((rows[r] - y0) // band) % world == r)
-    # what the rule is for: 1080 rows on 8 devices - 68 tile rows would be 9 for four devices and 8 for the others (1.059 of the mean), 135 bands of 8 rows are 17 at most
+    # what thin bands are for: 1080 rows on 8 devices - 68 tile rows of 16 would be 9 for four devices and 8 for the others (1.059 of the mean); 270 bands of 4 rows are 34 at most
     n = [len(owned_sample_rows(0, 1080, r, 8)) for r in range(8)]
-    assert shard_rows(1080, 8) == 8 and max(n) / (1080 / 8) < 1.01
-    assert shard_rows(1024, 8) == 16 and len({len(owned_sample_rows(0, 1024, r, 8)) for r in range(8)}) == 1
+    assert shard_rows(1080, 8) == 4 and max(n) / (1080 / 8) < 1.01
+    assert shard_rows(1024, 8) == 4 and len({len(owned_sample_rows(0, 1024, r, 8)) for r in range(8)}) == 1
     m = [owned_pixel_mask((0, 0, 40, 70), (0, 0, 40, 70), r, 2) for r in range(2)]
     assert np.all(m[0] ^ m[1])
 
@@ -54,7 +54,7 @@ CASES = {
     # name: (cropped x0 y0 x1 y1, sample bounds x0 y0 x1 y1, filter radius y)
     "box-70-rows": ((0, 0, 40, 70), (0, 0, 40, 70), 0.5),          # 5 tile rows: bands of 8 rows for every world that does not divide 5
     "wide-filter-cropped": ((3, 10, 43, 90), (1, 8, 45, 92), 2.0),  # Film::get_sample_bounds grows the cropped window by the radius (film.rs:249-257): rows nobody owns inside the film
-    "triangle-1080": ((0, 0, 8, 1080), (0, -1, 8, 1081), 1.5),      # C5's height: 68 tile rows -> 8-row bands on 8 ranks (RT_SHARD_ROWS)
+    "triangle-1080": ((0, 0, 8, 1080), (0, -1, 8, 1081), 1.5),      # C5's height: 270 bands of 4 rows on 8 ranks (RT_SHARD_ROWS)
 }
 
 
@@ -111,7 +111,7 @@ def _worker(rank, world, port, q, case):
 @pytest.mark.parametrize("world, case", [(2, "box-70-rows"), (3, "box-70-rows"), (8, "box-70-rows"), (2, "wide-filter-cropped"), (3, "wide-filter-cropped"),
                                          (8, "wide-filter-cropped"), (8, "triangle-1080")])
 def test_film_merge_over_gloo_gathers_the_touched_rows(world, case):
-    """The N > 1 data path on CPU (gloo): worlds 2, 3 and 8 - a world that divides the tile rows and ones that do not (8-row bands) -, the box filter, a wide
+    """The N > 1 data path on CPU (gloo): worlds 2, 3 and 8 - 4-row bands (RT_SHARD_ROWS) -, the box filter, a wide
     filter on a cropped film, C5's 1080 rows on 8 ranks. Rank 0's merged film equals the rank films summed in rank order bit for bit, and the whole frame
     rendered by one rank up to the order of additions."""
     import torch.multiprocessing as mp
