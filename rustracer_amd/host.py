@@ -276,7 +276,7 @@ class HostScene:
 
     def lds_resident(self):
         """Does the traversal kernel keep this scene's nodes and primitives in LDS? Asked of the uploaded scene (rt_scene_query: what rt_scene_create decided,
-        the RTX_SMALL knob included), not re-derived here."""
+        not re-derived here)."""
         return bool(_check(lib().rtxh_scene_query(self.h, 0), "scene_query"))
 
     def _render_params(self, **kw):

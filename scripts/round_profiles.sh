@@ -14,6 +14,9 @@ done
 # the 8-way static split of C5 and of the headline replayed on this one GPU: per-rank ms / mean (what the 8-GPU target will be measured on)
 timeout 600 python scripts/shard_replay.py room 8 profiles/${TAG}_shard_replay_room_8.json > gpurun_out/final/shard_room.log 2>&1
 timeout 300 python scripts/shard_replay.py cornell 8 profiles/${TAG}_shard_replay_cornell_8.json > gpurun_out/final/shard_cornell.log 2>&1
+# film parity of the production kernels against the oracle on medium-size versions of the six workloads, and the STRICT build through the parity tests
+timeout 900 python scripts/parity_report.py $TAG > gpurun_out/final/parity.log 2>&1; cp gpurun_out/${TAG}_parity.json profiles/${TAG}_parity.json 2>/dev/null
+[ -f rustracer_amd/csrc/_build/strict/librtx_hip.so ] && timeout 900 bash scripts/strict_check.sh > profiles/${TAG}_strict_build_tests.txt 2>&1
 mkdir -p gpurun_out/final/profiles && cp profiles/${TAG}_* profiles/pmc_*.json gpurun_out/final/profiles/ 2>/dev/null
 ls gpurun_out/final gpurun_out/final/profiles
 tail -c 600 gpurun_out/final/bench_default.json
