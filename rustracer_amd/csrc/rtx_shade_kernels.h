@@ -233,6 +233,9 @@ struct SmallBsdfT {
 
 // The SurfaceInteraction of a hit inside an object instance: the object-space interaction of the object's primitive, then SurfaceInteraction::transform
 // (primitive_to_world), rc/interaction.rs:156-190. Returns the primitive's index in the scene's arrays (material, flags).
+// OBJ_GENERAL: the object may hold quadrics (DScene::obj_general) - an instantiation of its own, so that scenes of plain objects keep the function they had (instances-10k:
+// one function with both branches cost the generic shade launches 80 B of call frame and 12 %)
+template <bool OBJ_GENERAL>
 RT_DEVN int instance_fill_interaction(const DScene& sc, unsigned hit_id, float ox, float oy, float oz, float dx, float dy, float dz, float b0, float b1, float b2,
                                       SurfaceInteraction& si) {
   unsigned lo = 0, hi = sc.n_instances;  // the last instance whose id_base <= hit_id
@@ -242,7 +245,7 @@ RT_DEVN int instance_fill_interaction(const DScene& sc, unsigned hit_id, float o
   const f3 d_obj = xf34_vector(in.w2o, mk3(dx, dy, dz));  // Transform * Ray: the direction as a vector (the origin does not enter a triangle's interaction)
   TriHit th; th.t = 0.0f; th.b0 = b0; th.b1 = b1; th.b2 = b2;
   SurfaceInteraction s;
-  if (tri_flags(sc.tri_p, gprim) & RT_FLAG_SPHERE) {  // a quadric of the object (round 6): Sphere::intersect builds its interaction from the OBJECT-space ray, then SurfaceInteraction::transform
+  if (OBJ_GENERAL && (tri_flags(sc.tri_p, gprim) & RT_FLAG_SPHERE)) {  // a quadric of the object (round 6): Sphere::intersect builds its interaction from the OBJECT-space ray, then SurfaceInteraction::transform
     (void)sphere_fill_interaction(sc.spheres[prim_sphere_index(sc.tri_p, gprim)], xf34_point(in.w2o, mk3(ox, oy, oz)), d_obj, s);
   } else tri_fill_interaction_inl(sc, gprim, d_obj, th, s);
   f3 perr;
@@ -382,7 +385,8 @@ __global__ void __launch_bounds__(256, (MODE == 1 || LEAN || BOUNCED) ? ((LEAN |
       if (found) {
         if (GENERAL && sc.n_instances != 0u && (unsigned)prim >= sc.n_top_prims) {  // a hit inside an object instance: from here on `prim` is the object's primitive
           const float4 o4 = in_o[rslot];
-          prim = instance_fill_interaction(gsc, (unsigned)prim, o4.x, o4.y, o4.z, ray_d.x, ray_d.y, ray_d.z, th.b0, th.b1, th.b2, si);
+          prim = sc.obj_general ? instance_fill_interaction<true>(gsc, (unsigned)prim, o4.x, o4.y, o4.z, ray_d.x, ray_d.y, ray_d.z, th.b0, th.b1, th.b2, si)
+                                : instance_fill_interaction<false>(gsc, (unsigned)prim, o4.x, o4.y, o4.z, ray_d.x, ray_d.y, ray_d.z, th.b0, th.b1, th.b2, si);
         }
         else if (GENERAL && (tri_flags(sc.tri_p, prim) & RT_FLAG_SPHERE)) {  // Sphere::intersect builds its interaction from the ray: origin and direction of the path's ray
           const float4 o4 = in_o[rslot];
