@@ -50,6 +50,7 @@ struct DScene {
   // everything below it), then 8 start nodes. link8: over the nodes the walks TEST (interior nodes whose test rarely fails are passed over, rt_scene_create); link8_full: over all nodes
   const unsigned* link8; const unsigned* link8_full;
   const float4* tri_p; unsigned n_tris;
+  const unsigned short* prim_class;  // [n_tris] the code class of the primitive's material (DMaterial::code_class), bit 15: a quadric - the key of the vertex queue's binning
   const float4* tri_rec;  // per-triangle shade records (8 x float4, see tri_fill_interaction_inl), built on the device at rt_scene_create
   const float* tri_n; const float* tri_uv; const float* tri_s;
   const int2* tri_alpha;  // {alpha, shadowalpha} texture ids of the triangles whose flags carry bit 4 / bit 5 (NULL: no mask in the scene)

@@ -79,7 +79,7 @@ struct rt_scene {
   bool deep_column = false;  // top level + deepest object need more than 64 stack entries in one column: k_trace_big with 128
   DevBuf quads; bool use_quads = false; int quad_stack_depth = 0;  // four-wide records of the any-hit kernel (k_trace_quad)
   DevBuf tri_rec;  // per-triangle shade records (k_tri_records)
-  DevBuf nodes, tri_p, tri_n, tri_uv, tri_s, tri_alpha, spheres, textures, images, materials, lights, texels, dist, guides;
+  DevBuf nodes, tri_p, tri_n, tri_uv, tri_s, tri_alpha, spheres, textures, images, materials, lights, texels, dist, guides, prim_class;
   bool has_spheres = false;
   bool has_instances = false;  // object instances: two-level traversal in k_trace_big<.., GENERAL>, every vertex shaded by k_shade<0, true>
   DevBuf instances;
@@ -436,6 +436,17 @@ extern "C" int rt_scene_create(const rt_scene_desc* desc, int device, rt_scene**
     for (uint32_t i = 0; i < desc->n_materials; ++i) hmat[i].code_class = remap[hmat[i].code_class];
   }
   TRY_RC(upload(s->materials, hmat.data(), hmat.size() * sizeof(DMaterial)));
+  {  // per primitive: the code class of its material (bit 15: a quadric) - what the vertex queue is binned by (k_bin_count), ONE two-byte gather instead of the primitive's
+     // 128-byte shade record and then its material (round 6)
+    std::vector<uint16_t> pc(desc->n_tris, 0);
+    for (size_t i = 0; i < desc->n_tris; ++i) {
+      const rt_tri_meta& m = desc->tri_meta[i];
+      if (m.flags & RT_PRIM_INSTANCE) continue;
+      const int c = (m.material >= 0 && (uint32_t)m.material < desc->n_materials) ? hmat[m.material].code_class : 0;
+      pc[i] = (uint16_t)(std::min(c, 0x7ffe) | ((m.flags & RT_PRIM_SPHERE) ? 0x8000 : 0));
+    }
+    TRY_RC(upload(s->prim_class, pc.data(), pc.size() * 2));
+  }
   // lights (+ env distributions in one blob)
   const uint32_t n_all_lights = desc->n_lights + desc->n_unlisted_lights;  // sampled lights, then the emitters no light list holds
   s->h_lights.resize(n_all_lights);
@@ -765,6 +776,7 @@ extern "C" int rt_scene_create(const rt_scene_desc* desc, int device, rt_scene**
   if (n_all_lights) hipLaunchKernelGGL(k_light_consts, dim3((n_all_lights + 255u) / 256u), dim3(256), 0, nullptr, d, s->lights.as<DLight>(), (int)n_all_lights);
   if (hipGetLastError() != hipSuccess) { delete s; return fail(RT_ERR_HIP, "constant precomputation launch failed"); }
   if (s->self.ensure(sizeof(DScene)) != hipSuccess) { delete s; return fail(RT_ERR_OOM, "scene record allocation failed"); }
+  d.prim_class = s->prim_class.as<unsigned short>();
   d.route_quadric_hits = (s->lean_qlights && s->n_code_classes > 1 && !s->lambert_materials) ? 1 : 0;  // (the condition of rt_render's use_bins)
   d.self = s->self.as<DScene>();
   HIP_TRY(hipMemcpy(s->self.p, &d, sizeof(DScene), hipMemcpyHostToDevice));

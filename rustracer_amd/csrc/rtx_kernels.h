@@ -2102,6 +2102,7 @@ __global__ void __launch_bounds__(BLOCK, RT_GEN_MIN_WAVES(GENERAL)) k_trace_quad
 // class; misses last), so that most waves run one code path. Order within a bin is arbitrary: paths are
 // independent and the film sums each pixel's samples in sample order. hist/cursor: RT_BIN_MAX + 1 zeroed words each.
 #define RT_BIN_MAX 256
+#define RT_BIN_LDS_PRIMS 8192
 // hit id -> index of the primitive in the scene's arrays (an id past the top level's primitives names (instance, the object's primitive))
 RT_DEV int hit_primitive(const DInstance* __restrict__ instances, unsigned n_instances, unsigned n_top_prims, int hit_id) {
   if (n_instances == 0u || (unsigned)hit_id < n_top_prims) return hit_id;
@@ -2109,31 +2110,33 @@ RT_DEV int hit_primitive(const DInstance* __restrict__ instances, unsigned n_ins
   while (hi - lo > 1u) { const unsigned mid = (lo + hi) >> 1; if (instances[mid].id_base <= (unsigned)hit_id) lo = mid; else hi = mid; }
   return (int)(instances[lo].prim_base + ((unsigned)hit_id - instances[lo].id_base));
 }
-RT_DEV unsigned bin_of(const DScene& sc, const DMaterial* __restrict__ materials, const float4* __restrict__ tri_p /* the shade records */, const float4* __restrict__ hit, unsigned slot, unsigned n_bins) {
-  const float4 h4 = hit[slot];
-  int prim = __float_as_int(h4.y);
+RT_DEV unsigned bin_of(const DScene& sc, const unsigned short* __restrict__ prim_class /* DScene::prim_class, or the workgroup's LDS copy */, const float4* __restrict__ hit, unsigned slot, unsigned n_bins) {
+  int prim = __float_as_int(hit[slot].y);
   if (prim < 0) return n_bins - 1u;
   prim = hit_primitive(sc.instances, sc.n_instances, sc.n_top_prims, prim);
+  const unsigned pc = prim_class[prim], m = pc & 0x7fffu;
   // route_quadric_hits: the bin before the miss bin collects the vertices on analytic quadrics, whatever their material - it lies in the generic range, so the
   // register-resident front-ends of such a scene (QLIGHTS forms) see triangles only and need no Sphere::intersect to rebuild an interaction
   if (sc.route_quadric_hits) {
-    if (rec_flags(tri_p, prim) & RT_FLAG_SPHERE) return n_bins - 2u;
-    const unsigned m = (unsigned)materials[rec_material(tri_p, prim)].code_class;
+    if (pc & 0x8000u) return n_bins - 2u;
     return m < n_bins - 2u ? m : n_bins - 3u;
   }
-  const unsigned m = (unsigned)materials[rec_material(tri_p, prim)].code_class;
   return m < n_bins - 1u ? m : n_bins - 2u;
 }
 // bin_at[i]: the bin of queue entry i, kept for k_bin_scatter - finding it takes two dependent gathers (hit record -> triangle -> material) that need not be repeated
 static __global__ void __launch_bounds__(256) k_bin_count(DScene sc, PassState ps, unsigned n_bins, unsigned* __restrict__ hist, unsigned short* __restrict__ bin_at) {
   __shared__ unsigned lh[RT_BIN_MAX + 1];
+  __shared__ unsigned short s_pc[RT_BIN_LDS_PRIMS];  // the primitives' classes of a scene of few primitives (S3: 1294) in LDS
   for (unsigned i = threadIdx.x; i <= RT_BIN_MAX; i += 256u) lh[i] = 0u;
+  const bool pc_lds = sc.n_tris <= RT_BIN_LDS_PRIMS;
+  if (pc_lds) for (unsigned i = threadIdx.x; i < sc.n_tris; i += 256u) s_pc[i] = sc.prim_class[i];
+  const unsigned short* const pcls = pc_lds ? (const unsigned short*)s_pc : sc.prim_class;
   __syncthreads();
   QView qv; if (ps.cnt_in) qv.init(ps.q_in, ps.cnt_in, ps.shard_cap);
   const unsigned count = ps.cnt_in ? qv.total() : ps.cap;
   for (unsigned i = blockIdx.x * 256u + threadIdx.x; i < count; i += gridDim.x * 256u) {
     const unsigned slot = ps.cnt_in ? qv.get(i) : i;
-    const unsigned b = bin_of(sc, sc.materials, sc.tri_rec, sraw(ps.hit), slot, n_bins);
+    const unsigned b = bin_of(sc, pcls, sraw(ps.hit), slot, n_bins);
     bin_at[i] = (unsigned short)b;
     atomicAdd(&lh[b], 1u);
   }
