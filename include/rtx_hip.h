@@ -249,6 +249,10 @@ typedef struct rt_stats {
 #define RT_FLAG_COUNT_AS_RENDERED 8u /* with RT_FLAG_COUNT_TRAVERSAL: count the walks an uncounted frame runs (occlusion-only MIS rays walk as
                                         intersect_p does) instead of the reference's (every MIS ray a closest-hit walk): what a roofline figure divides by
                                         the time of */
+#define RT_FLAG_REF_STREAM 16u /* round 6: the frame with the REFERENCE'S sampler stream - one PCG32 stream per 16 x 16 tile, consumed by the tile's pixels and samples in order
+                                (rc/renderer.rs:83-84) - instead of the pixel-keyed one: one lane per tile walks the reference's loop (slow by construction; for the configuration
+                                the reference itself runs). The film then equals the oracle's SAMPLER_REF mode sample for sample: weights exact, radiance inside the image gate.
+                                Single device, plain-triangle scenes; stats: camera_rays and the three ray counts. */
 
 typedef struct rt_scene rt_scene;
 

@@ -19,6 +19,7 @@
 #include "../../include/rtx_hip.h"
 #include "rtx_kernels.h"
 #include "rtx_shade_launch.h"
+#include "rtx_ref_launch.h"
 #include "rtx_link_tables.h"
 
 using namespace rtx;
@@ -96,7 +97,7 @@ struct rt_scene {
   std::mutex render_mutex;  // rt_render shares the workspace below: concurrent calls on one rt_scene take turns
   // per-render workspace
   DevBuf ws[32];
-  DevBuf film_acc, own_acc, film_out, counters, stats, filter_table;
+  DevBuf film_acc, own_acc, film_out, counters, stats, filter_table, ref_samples, ref_stack;
   DevBuf bin_words, bin_sorted, bin_at;  // material binning of the shade queue (generic shade path); bin_at: u16 per queue entry
   unsigned n_materials = 0, n_code_classes = 0, n_lambert_classes = 0, n_small_classes = 0, n_wide_classes = 0;
   // sampler tables are double-buffered: K0 of batch b+1 runs on aux_stream under the path kernels of batch b
@@ -144,6 +145,7 @@ static void fill_ewa_lut() {
   }
   (void)hipMemcpyToSymbol(HIP_SYMBOL(kEwaLut), lut, sizeof(lut));
   rtx_shade_set_ewa_lut(lut);  // the shade kernels' translation unit has a copy of its own
+  rtx_ref_set_ewa_lut(lut);    // ... and the reference-stream kernel's
 }
 
 static size_t tmin_stack_bytes(const rt_scene* s);
@@ -1416,6 +1418,36 @@ extern "C" int rt_render(rt_scene* s, const rt_camera* cam, const rt_film_desc* 
   if (rc != RT_OK) return rc;
   tm.end();
 
+  if (flags & RT_FLAG_REF_STREAM) {  // the reference's own sampler stream: one lane per 16 x 16 tile (rtx_ref.hip)
+    if (world != 1) return fail(RT_ERR_UNSUPPORTED, "the reference-stream frame renders on one device");
+    if (s->general_prims) return fail(RT_ERR_UNSUPPORTED, "the reference-stream frame takes scenes of plain triangles");
+    if (s->stack_depth > 64) return fail(RT_ERR_UNSUPPORTED, "BVH deeper than the reference's 64-entry stack");
+    RefParams rp{};
+    rp.spp = spp; rp.dims = dims; rp.tile = 16; rp.ntx = (W + 15) / 16; rp.nty = (H + 15) / 16;
+    const size_t n_tiles = (size_t)rp.ntx * rp.nty;
+    HIP_TRY(s->ref_samples.ensure(n_tiles * 3 * dims * spp * 4)); HIP_TRY(s->ref_stack.ensure(n_tiles * 64 * 4));
+    HIP_TRY(s->film_acc.ensure((size_t)cw * ch * 16)); HIP_TRY(s->filter_table.ensure(1024)); HIP_TRY(s->stats.ensure((size_t)ST_COUNT * 8));
+    if (!(flags & RT_FLAG_FILM_ON_DEVICE)) HIP_TRY(s->film_out.ensure((size_t)cw * ch * 16));
+    float4* const d_out = (flags & RT_FLAG_FILM_ON_DEVICE) ? (float4*)film_xyzw : s->film_out.as<float4>();
+    HIP_TRY(hipMemcpyAsync(s->filter_table.p, film->filter_table, 1024, hipMemcpyHostToDevice, stream));
+    HIP_TRY(hipMemsetAsync(s->film_acc.p, 0, (size_t)cw * ch * 16, stream));
+    HIP_TRY(hipMemsetAsync(s->stats.p, 0, ST_COUNT * 8, stream));
+    rp.samples = s->ref_samples.as<float>(); rp.stack = s->ref_stack.as<int>(); rp.film_acc = s->film_acc.as<float4>();
+    rp.filter_table = s->filter_table.as<float>(); rp.stats = s->stats.as<unsigned long long>();
+    rtx_launch_render_ref(s->d, fp, rp, stream);
+    const unsigned long long n = (unsigned long long)cw * ch;
+    hipLaunchKernelGGL(k_film_finalize, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, s->film_acc.as<float4>(), d_out, n);
+    HIP_TRY(hipGetLastError());
+    if (!(flags & RT_FLAG_FILM_ON_DEVICE)) HIP_TRY(hipMemcpyAsync(film_xyzw, d_out, (size_t)cw * ch * 16, hipMemcpyDeviceToHost, stream));
+    HIP_TRY(hipStreamSynchronize(stream));
+    unsigned long long h5[5];
+    HIP_TRY(hipMemcpy(h5, s->stats.p, sizeof(h5), hipMemcpyDeviceToHost));
+    stats.camera_rays = h5[0]; stats.rays_closest = h5[1]; stats.rays_shadow = h5[2]; stats.rays_mis = h5[3]; stats.paths_scrubbed = h5[4];
+    stats.n_passes = 1;
+    stats.ms_total = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_begin).count();
+    if (stats_out) *stats_out = stats;
+    return RT_OK;
+  }
   // pixel_bounds (path.rs:30) that do not crop the sample bounds: every generated sample is traced
   const bool all_in_bounds = path->pixel_bounds[0] <= film->sample_bounds[0] && path->pixel_bounds[2] >= film->sample_bounds[2] &&
                              path->pixel_bounds[1] <= film->sample_bounds[1] && path->pixel_bounds[3] >= film->sample_bounds[3];

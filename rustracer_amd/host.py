@@ -23,6 +23,7 @@ RT_FLAG_COUNT_TRAVERSAL = 1
 RT_FLAG_FILM_ON_DEVICE = 2
 RT_FLAG_TIME_KERNELS = 4
 RT_FLAG_COUNT_AS_RENDERED = 8
+RT_FLAG_REF_STREAM = 16
 
 
 class BackendError(RuntimeError):
@@ -314,11 +315,12 @@ class HostScene:
     def upload(self, device=-1):
         _check(lib().rtxh_scene_upload(self.h, device), "upload")
 
-    def render(self, rank=0, world_size=1, count_traversal=False, time_kernels=False, device_out=None, stream=0, count_as_rendered=False):
+    def render(self, rank=0, world_size=1, count_traversal=False, time_kernels=False, device_out=None, stream=0, count_as_rendered=False, ref_stream=False):
         """renderer::render on the GPU. Returns (film_xyzw (H,W,4) over the cropped bounds, stats dict).
-        `device_out`: optional torch CUDA tensor (H,W,4) float32 that receives the film in HBM."""
+        `device_out`: optional torch CUDA tensor (H,W,4) float32 that receives the film in HBM. `ref_stream`: the reference's own sampler stream - one RNG stream per
+        16 x 16 tile, one lane per tile (RT_FLAG_REF_STREAM; slow by construction) - instead of the pixel-keyed one."""
         flags = ((RT_FLAG_COUNT_TRAVERSAL if count_traversal else 0) | (RT_FLAG_TIME_KERNELS if time_kernels else 0) |
-                 (RT_FLAG_COUNT_AS_RENDERED if count_as_rendered else 0))
+                 (RT_FLAG_COUNT_AS_RENDERED if count_as_rendered else 0) | (RT_FLAG_REF_STREAM if ref_stream else 0))
         st = self.setup(rank=rank, world_size=world_size)
         cr = st["cropped"]
         w, h = int(cr[2] - cr[0]), int(cr[3] - cr[1])
