@@ -5,6 +5,10 @@ the HIP path by tests/test_gpu_invariants.py.
   furnace_scene      a convex Lambertian body of albedo rho inside a constant environment of radiance 1: a ray leaving the body never
                      returns, so the one vertex of every path collects exactly rho (the cosine-weighted integral of the environment) and a
                      camera ray that hits the body sees L = rho at ANY max_depth >= 1, whatever the sampling and the MIS weights.
+  furnace_instances_scene  the same furnace with a convex body placed by a TWO-LEVEL instance (rc/primitive.rs:79-118): an object that holds one sphere under a stretch
+                     of its own, or an object that holds a closed box of triangles, placed by a rotated, non-uniformly scaled, mirrored instance - affine images of
+                     convex bodies are convex, so every body pixel is rho still. A wrong normal transform (inverse transpose, the mirror's flip), a wrong
+                     hit point after the two Transform * Ray or a leak at an object's boundary shows as L != rho.
   furnace_box_scene  the camera inside a closed box whose walls emit L_e and reflect rho: every point sees emitters over its whole hemisphere,
                      so each further bounce adds rho times the previous order and L = L_e (1 + rho + ... + rho^max_depth) in every pixel
                      (emission at the first hit, direct light at every vertex with bounces < max_depth, rc/integrator/path.rs:127-165; Russian
@@ -36,6 +40,36 @@ def furnace_scene(rho=0.5, max_depth=5, res=48, spp=64):
     env = s.add_mip(np.ones((4, 8, 3), np.float32), trilinear=False, max_aniso=8.0)
     s.infinite_light(env)
     s.camera.pos, s.camera.look, s.camera.up, s.camera.fov = (1.9, 1.4, 1.1), (0.0, 0.0, 0.0), (0.0, 0.0, 1.0), 40.0
+    s.film.xres = s.film.yres = res
+    s.sampler.spp = spp
+    s.integrator.max_depth = max_depth
+    return s
+
+
+def furnace_instances_scene(kind="ball", rho=0.5, max_depth=5, res=64, spp=64):
+    s = SceneDesc()
+    s.name = f"furnace of an instanced {kind} rho={rho} depth={max_depth}"
+    m = s.matte((rho, rho, rho))
+
+    def place(angle, axis, scale, at):
+        a = np.float64(axis) / np.linalg.norm(axis); K = np.array([[0, -a[2], a[1]], [a[2], 0, -a[0]], [-a[1], a[0], 0]])
+        R = np.eye(3) + np.sin(angle) * K + (1 - np.cos(angle)) * K @ K
+        M = np.eye(4); M[:3, :3] = R @ np.diag(scale); M[:3, 3] = at
+        return M.astype(np.float32)
+    if kind == "ball":
+        stretch = np.eye(4, dtype=np.float32); stretch[1, 1] = 1.5; stretch[:3, 3] = (0.1, -0.05, 0.2)  # the transform inside the object's definition
+        o = s.add_object([], quadrics=[dict(kind=0, o2w=stretch, radius=0.3, material=m)])
+        s.add_instance(o, place(0.7, (1, 2, 0.5), (1.6, 1.0, -2.0), (0.2, 0.0, 0.1)))                # rotated, non-uniformly scaled, mirrored
+    else:
+        lo, hi = np.float32((-0.3, -0.25, -0.2)), np.float32((0.3, 0.25, 0.2))
+        c = np.float32([(lo[0] if i & 1 == 0 else hi[0], lo[1] if i & 2 == 0 else hi[1], lo[2] if i & 4 == 0 else hi[2]) for i in range(8)])
+        quads = [(0, 2, 3, 1), (4, 5, 7, 6), (0, 1, 5, 4), (2, 6, 7, 3), (0, 4, 6, 2), (1, 3, 7, 5)]
+        o = s.add_object([dict(P=c, idx=[t for q in quads for t in ((q[0], q[1], q[2]), (q[0], q[2], q[3]))], material=m)])
+        s.add_instance(o, place(-1.1, (0.3, 1, 1), (-1.7, 1.2, 1.5), (0.0, 0.1, 0.0)))
+    env = s.add_mip(np.ones((4, 8, 3), np.float32), trilinear=False, max_aniso=8.0)
+    s.infinite_light(env)
+    s.add_quad((40, 40, 40), (40.01, 40, 40), (40.01, 40.01, 40), (40, 40.01, 40), s.matte((0.0,) * 3))  # (the top level must hold a triangle: a speck, far away)
+    s.camera.pos, s.camera.look, s.camera.up, s.camera.fov = (1.9, -2.4, 1.1), (0.0, 0.0, 0.0), (0.0, 0.0, 1.0), 36.0
     s.film.xres = s.film.yres = res
     s.sampler.spp = spp
     s.integrator.max_depth = max_depth

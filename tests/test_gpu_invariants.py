@@ -26,6 +26,20 @@ def test_white_furnace_convex_body_under_constant_environment(gpu_host, rho, dep
     assert len(sky) > 200 and (np.abs(sky - 1.0).max(axis=-1) < 5e-6).mean() > 0.9
 
 
+@pytest.mark.parametrize("kind", ["ball", "box"])
+@pytest.mark.parametrize("rho,depth", [(0.5, 1), (0.8, 4)])
+def test_white_furnace_of_a_two_level_instance(gpu_host, kind, rho, depth):
+    """The furnace's body placed by a rotated, non-uniformly scaled, mirrored INSTANCE of an object that holds one stretched sphere (object_walk_general, the
+    quadric's interaction built in object space and transformed, rtx_shade_kernels.h instance_fill_interaction<true>) or a closed box of triangles
+    (k_trace_inst): still convex, still L = rho in every body pixel."""
+    d = inv.furnace_instances_scene(kind, rho, depth, res=96, spp=64)
+    img = _rgb(gpu_host, d)
+    body = inv.furnace_body_mask(img, rho, depth)
+    assert body.sum() > 800
+    assert np.allclose(img[body].mean(axis=0), rho, rtol=0.004), (img[body].mean(axis=0), rho)
+    assert np.abs(img[body] / rho - 1).max() < 0.15
+
+
 @pytest.mark.parametrize("rho,depth", [(0.5, 0), (0.5, 1), (0.5, 2), (0.5, 5), (0.8, 5), (0.25, 8)])
 def test_closed_emissive_box_geometric_series(gpu_host, rho, depth):
     d = inv.furnace_box_scene(rho, depth, res=64, spp=64)

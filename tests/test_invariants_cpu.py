@@ -27,6 +27,18 @@ def test_white_furnace_convex_body_under_constant_environment(orc, rho, depth):
     assert len(sky) > 50 and exact.mean() > 0.9
 
 
+@pytest.mark.parametrize("kind", ["ball", "box"])
+def test_white_furnace_of_a_two_level_instance(orc, kind):
+    """The body placed by a rotated, non-uniformly scaled, mirrored instance of an object holding one stretched sphere / a closed box of triangles
+    (TransformedPrimitive, rc/primitive.rs:79-118): an affine image of a convex body is convex, L = rho still."""
+    rho, depth = 0.8, 4
+    img = _rgb(orc, inv.furnace_instances_scene(kind, rho, depth))
+    body = inv.furnace_body_mask(img, rho, depth)
+    assert body.sum() > 300
+    assert np.allclose(img[body].mean(axis=0), rho, rtol=0.005), (img[body].mean(axis=0), rho)
+    assert np.abs(img[body] / rho - 1).max() < 0.15
+
+
 @pytest.mark.parametrize("rho,depth", [(0.5, 0), (0.5, 1), (0.5, 2), (0.5, 5), (0.8, 5), (0.25, 8)])
 def test_closed_emissive_box_geometric_series(orc, rho, depth):
     d = inv.furnace_box_scene(rho, depth)
