@@ -489,10 +489,12 @@ int finish_commit(rtxh_scene* s) {
   // object primitives follow the top level's in the same arrays: every INSTANCED object once, in the order of its first instance
   std::vector<int64_t> obj_prim_base(s->objects.size(), -1), obj_node_base(s->objects.size(), -1);
   std::vector<size_t> obj_sphere_base(s->objects.size(), 0);  // where an instanced object's quadrics sit behind the top level's in the scene's quadric table
+  std::vector<size_t> instanced;  // the instanced objects in that order
   size_t n_all = nt, n_all_nodes = s->nodes.size(), n_obj_spheres = 0; bool any_obj_alpha = false;
   for (const auto& in : s->instances) {
     const size_t o = (size_t)in.object;
     if (obj_prim_base[o] >= 0) continue;
+    instanced.push_back(o);
     obj_prim_base[o] = (int64_t)n_all; obj_node_base[o] = (int64_t)n_all_nodes;
     obj_sphere_base[o] = n_obj_spheres; n_obj_spheres += s->objects[o].spheres.size(); any_obj_alpha = any_obj_alpha || !s->objects[o].tri_alpha.empty();
     n_all += s->objects[o].n_prims(); n_all_nodes += s->objects[o].nodes.size();
@@ -552,7 +554,7 @@ int finish_commit(rtxh_scene* s) {
   }
   s->f_spheres.clear();
   for (const auto& hs : s->spheres) s->f_spheres.push_back(hs.s);
-  for (size_t o = 0; o < s->objects.size(); ++o) if (obj_prim_base[o] >= 0) for (const auto& hs : s->objects[o].spheres) s->f_spheres.push_back(hs.s);  // (in the order of obj_sphere_base)
+  for (const size_t o : instanced) for (const auto& hs : s->objects[o].spheres) s->f_spheres.push_back(hs.s);  // (the order of obj_sphere_base: of the objects' FIRST INSTANCES, not of their definitions)
   for (size_t i = 0; i < nt; ++i) {
     const int32_t t = s->ordered[i];
     if ((size_t)t >= n_geom) {  // an object instance: world box in p0 / p1, its index as the bits of p2.x

@@ -22,6 +22,9 @@ def bits(a):
     return np.ascontiguousarray(a, np.float32).view(np.uint32)
 
 
+OFF = set(os.environ.get("FUZZ_OFF", "").split(","))   # bisecting switches: inst_mirror, inst_scale, q_mirror, q_xform, partial, kind0, kind1, kind2, masks
+
+
 def rotation(rng):
     q = rng.normal(size=4); q /= np.linalg.norm(q)
     w, x, y, z = q
@@ -30,12 +33,12 @@ def rotation(rng):
                      [2 * (x * z - y * w), 2 * (y * z + x * w), 1 - 2 * (x * x + y * y)]])
 
 
-def affine(rng, spread, scale=(0.4, 1.8), mirror=0.25):
+def affine(rng, spread, scale=(0.4, 1.8), mirror=0.25, who="inst"):
     m = np.eye(4)
     s = rng.uniform(scale[0], scale[1], 3)
-    if rng.random() < 0.3:
+    if rng.random() < 0.3 or who + "_scale" in OFF:
         s[:] = s[0]                                        # a similarity now and then
-    if rng.random() < mirror:
+    if rng.random() < mirror and who + "_mirror" not in OFF:
         s[int(rng.integers(0, 3))] *= -1.0
     m[:3, :3] = rotation(rng) @ np.diag(s)
     m[:3, 3] = rng.uniform(-spread, spread, 3)
@@ -50,8 +53,10 @@ def soup(rng, n, extent):
 
 def quadric(rng, mats, extent):
     kind = int(rng.integers(0, 3))
-    o2w = affine(rng, extent, scale=(0.6, 1.5), mirror=0.15)
-    if rng.random() < 0.25:
+    while f"kind{kind}" in OFF:
+        kind = (kind + 1) % 3
+    o2w = affine(rng, extent, scale=(0.6, 1.5), mirror=0.15, who="q")
+    if rng.random() < 0.25 or "q_xform" in OFF:
         o2w = np.eye(4, dtype=np.float32); o2w[:3, 3] = rng.uniform(-extent, extent, 3)
     r = float(rng.uniform(0.1, 0.5) * extent)
     q = dict(kind=kind, o2w=o2w, radius=r, material=mats[int(rng.integers(0, len(mats)))])
@@ -68,6 +73,11 @@ def quadric(rng, mats, extent):
         q.update(z_min=float(rng.uniform(-0.5, 0.5) * extent), z_max=float(r * rng.uniform(0.0, 0.6)) if rng.random() < 0.5 else 0.0)
         if rng.random() < 0.4:
             q.update(phi_max=float(rng.uniform(60.0, 330.0)))
+    if "partial" in OFF:
+        for k in ("phi_max",) + (("z_min", "z_max") if kind == 0 else ()):
+            q.pop(k, None)
+        if kind == 1:
+            q["z_max"] = 0.0
     return q
 
 
@@ -80,7 +90,10 @@ def make_scene(rng):
     n_obj = int(rng.integers(1, 5))
     objects = []
     for _ in range(n_obj):
-        form = int(rng.integers(0, 5))   # 0 plain triangles, 1 + quadrics, 2 + masked mesh, 3 both, 4 one quadric alone
+        form = int(rng.integers(0, 5))
+        if "masks" in OFF and form in (2, 3):
+            form -= 2
+        # 0 plain triangles, 1 + quadrics, 2 + masked mesh, 3 both, 4 one quadric alone
         meshes, quads = [], None
         if form != 4:
             P, F = soup(rng, int(rng.choice([1, 2, 7, 40, 300])), 1.0)
@@ -149,11 +162,19 @@ def main():
             if count:
                 bad += int(ro["nodes"] != rh["nodes"]) + int(ro["tris"] != rh["tris"])
         rays[:, 3] = rng.uniform(0.05, 1.5, len(rays)).astype(np.float32) * np.float32(2.0 * spread)
+        rays_o = rays.copy()
         ao = o.trace(rays, True)["occluded"]
         for count in (True, False):
             bad += int((ao != h.trace(rays, True, count=count)["occluded"]).sum())
         bad_total += bad
         n_top = len(bo["ordered"])
+        if bad and os.environ.get("FUZZ_VERBOSE"):
+            rays[:, 3] = np.inf
+            rh = h.trace(rays, count=False)
+            dp = ro["prim"] != rh["prim"]; dt = (bits(ro["t"]) != bits(rh["t"])) & ~dp; db = ((bits(ro["b0"]) != bits(rh["b0"])) | (bits(ro["b1"]) != bits(rh["b1"]))) & ~dp & ~dt
+            print(f"    closest: prim differs {int(dp.sum())}, t only {int(dt.sum())}, b only {int(db.sum())}; occlusion differs {int((ao != h.trace(rays_o, True, count=False)['occluded']).sum())}")
+            for i in np.flatnonzero(dp | dt | db)[:4]:
+                print(f"    ray {i}: o {rays[i, :3]} d {rays[i, 4:7]} oracle prim {ro['prim'][i]} t {ro['t'][i]:.9g} b {ro['b0'][i]:.6g} {ro['b1'][i]:.6g} | device prim {rh['prim'][i]} t {rh['t'][i]:.9g} b {rh['b0'][i]:.6g} {rh['b1'][i]:.6g}")
         print(f"scene {k:3d}: objects {what:4s} x {n_inst:3d} instances, top level {top}, {n_top:4d} top-level primitives, hits {float((ro['prim'] >= 0).mean()):.2f} "
               f"(inside objects {float((ro['prim'] >= n_top).mean()):.2f}), occluded {float(ao.mean()):.2f}: {bad} mismatches", flush=True)
     print(f"{n_scenes} scenes, {bad_total} mismatching values, {time.time() - t0:.0f} s")

@@ -287,6 +287,38 @@ def test_objects_that_hold_quadrics_or_masked_meshes(gpu_host, orc, kind):
         assert abs(int(sh[k]) - int(so[k])) <= 2e-3 * int(so[k]) + 16, (k, sh[k], so[k])
 
 
+def test_objects_first_instanced_in_another_order_than_defined(gpu_host, orc):
+    """Found by scripts/fuzz_objects.py: the scene's quadric table held the objects' quadrics in the order of their DEFINITIONS while the object primitives named them in the order
+    of the objects' FIRST INSTANCES (rtx_host.cpp commit: obj_sphere_base) - every scene that instanced its second quadric-holding object first met the wrong quadrics."""
+    from rustracer_amd.scene_desc import SceneDesc
+    s = SceneDesc()
+    m = s.matte((0.5, 0.5, 0.5))
+    s.add_quad((-5, 0, -5), (-5, 0, 5), (5, 0, 5), (5, 0, -5), m)
+    a_in = np.eye(4, dtype=np.float32); a_in[:3, 3] = (0.0, 0.5, 0.0)
+    b_in = (np.eye(4) @ _rot_y(0.7)).astype(np.float32); b_in[:3, 3] = (0.2, 0.3, 0.0)
+    tri = dict(P=np.float32([[-0.4, 0, 0], [0.4, 0, 0], [0, 0.6, 0.2]]), idx=[[0, 1, 2]], material=m)
+    a = s.add_object([tri], quadrics=[dict(kind=0, o2w=a_in, radius=0.4, material=m), dict(kind=2, o2w=a_in, radius=0.15, z_min=-0.5, z_max=0.5, material=m)])
+    b = s.add_object([tri], quadrics=[dict(kind=1, o2w=b_in, radius=0.6, z_min=0.1, z_max=0.2, material=m), dict(kind=0, o2w=b_in, radius=0.25, phi_max=200.0, material=m)])
+    c = s.add_object([], quadrics=[dict(kind=0, o2w=a_in, radius=0.3, material=m)])
+    for k, (o, at) in enumerate([(c, (2.0, 0.5, 1.0)), (b, (-1.5, 0.4, 0.0)), (a, (0.5, 0.3, -1.0)), (b, (1.0, 1.0, 2.0)), (c, (-2.0, 0.8, -2.0))]):  # first instances: c, b, a
+        mtx = (np.eye(4) @ _rot_y(0.5 * k)).astype(np.float32); mtx[:3, 3] = at; mtx[1, 1] = 1.0 + 0.2 * k
+        s.add_instance(o, mtx)
+    s.camera.pos, s.camera.look, s.camera.fov = (0.0, 2.5, -7.0), (0.0, 0.8, 0.0), 50.0
+    s.film.xres, s.film.yres = 32, 24
+    s.sampler.spp = 4
+    o, h = orc.OracleScene(s), gpu_host.HostScene(s)
+    rays = random_rays(40000, np.float32([-3, 0, -3]), np.float32([3, 2.5, 3]), 5)
+    ro = o.trace(rays)
+    assert (ro["prim"] >= len(o.bvh()["ordered"])).sum() > 2000
+    for count in (True, False):
+        rh = h.trace(rays, count=count)
+        assert np.array_equal(ro["prim"], rh["prim"]) and all(np.array_equal(bits(ro[k]), bits(rh[k])) for k in ("t", "b0", "b1")), count
+    rays[:, 3] = np.random.default_rng(8).uniform(0.3, 6.0, len(rays)).astype(np.float32)
+    assert np.array_equal(o.trace(rays, True)["occluded"], h.trace(rays, True, count=False)["occluded"])
+    fo, fh = o.render(mode=1)[0], h.render()[0]
+    assert np.array_equal(fo[..., 3], fh[..., 3]) and rel_l2(gpu_host.film_to_rgb(fh), orc.film_to_rgb(fo)) < 1e-3
+
+
 def _chain_mesh(n, material, base=13.0):
     """n triangles at x = 13^k, each as large as its x: of the SAH's 12 buckets the last holds the largest triangle alone and the first all the others
     (13^(n-1) / 13^n < 1 / 12), so every split peels one triangle off and the tree is a chain n - 1 deep."""
