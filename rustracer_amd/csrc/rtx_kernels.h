@@ -2438,19 +2438,29 @@ static __global__ void __launch_bounds__(256) k_lightdist_mark(DScene sc, unsign
   f3 p0, p1, p2; load_tri(sc.tri_p, (int)t, p0, p1, p2);
   // a quadric or an object instance: every voxel of its box is kept (the instance's slot holds its world box in p0 / p1: min and max below are that box)
   const bool is_instance = (tri_flags(sc.tri_p, (int)t) & RT_FLAG_INSTANCE) != 0u;
+  const unsigned slot_index = __float_as_uint(p2.x);  // (a quadric's index in the quadric table / an instance's in the instance table)
   if (is_instance) p2 = p0;
   const bool is_sphere = (tri_flags(sc.tri_p, (int)t) & RT_FLAG_SPHERE) != 0u;
   f3 mn = mk3(fminf(p0.x, fminf(p1.x, p2.x)), fminf(p0.y, fminf(p1.y, p2.y)), fminf(p0.z, fminf(p1.z, p2.z)));
   f3 mx = mk3(fmaxf(p0.x, fmaxf(p1.x, p2.x)), fmaxf(p0.y, fmaxf(p1.y, p2.y)), fmaxf(p0.z, fmaxf(p1.z, p2.z)));
-  if (is_sphere) {
-    // The box in the slot is the one the reference's BVH uses, and Disk::world_bounds is wrong under a rotation (disk.rs:127-134): surface points of a
-    // disk can lie outside it. Marking needs a box that truly holds the surface: the 8 mapped corners of the object-space box.
-    const DSphere& q = sc.spheres[__float_as_uint(p2.x)];
+  // The box in a quadric's slot is the one the reference's BVH uses, and Disk::world_bounds is wrong under a rotation (disk.rs:127-134): surface points of a
+  // disk can lie outside it. Marking needs a box that truly holds the surface: the 8 mapped corners of the object-space box.
+  auto true_box = [&](const DSphere& q, const float* outer) {
     const float zlo = q.kind == 1 ? q.height : fminf(q.z_min, q.z_max), zhi = q.kind == 1 ? q.height : fmaxf(q.z_min, q.z_max);
-    mn = mk3(kInf, kInf, kInf); mx = mk3(-kInf, -kInf, -kInf);
     for (int c = 0; c < 8; ++c) {
-      const f3 w = xf34_point(q.o2w, mk3(c & 1 ? q.radius : -q.radius, c & 2 ? q.radius : -q.radius, c & 4 ? zhi : zlo));
+      f3 w = xf34_point(q.o2w, mk3(c & 1 ? q.radius : -q.radius, c & 2 ? q.radius : -q.radius, c & 4 ? zhi : zlo));
+      if (outer) w = xf34_point(outer, w);
       mn = mk3(fminf(mn.x, w.x), fminf(mn.y, w.y), fminf(mn.z, w.z)); mx = mk3(fmaxf(mx.x, w.x), fmaxf(mx.y, w.y), fmaxf(mx.z, w.z));
+    }
+  };
+  if (is_sphere) { mn = mk3(kInf, kInf, kInf); mx = mk3(-kInf, -kInf, -kInf); true_box(sc.spheres[slot_index], nullptr); }
+  // ... and an instance's world box is the image of its object's root box, which holds the quadrics' boxes of the same kind (found by scripts/fuzz_objects.py: a rotated
+  // disk inside an object): widened by the true boxes of the object's quadrics under the instance's transform (objects that hold quadrics are few and small)
+  if (is_instance && sc.obj_general) {
+    const DInstance& in = sc.instances[slot_index];
+    for (unsigned j = 0; j < in.n_prims; ++j) {
+      const int g = (int)(in.prim_base + j);
+      if (tri_flags(sc.tri_p, g) & RT_FLAG_SPHERE) true_box(sc.spheres[__float_as_uint(sc.tri_p[3 * (size_t)g + 2].x)], in.o2w);
     }
   }
   const f3 o0 = bounds_offset(sc.wb_min, sc.wb_max, mn), o1 = bounds_offset(sc.wb_min, sc.wb_max, mx);

