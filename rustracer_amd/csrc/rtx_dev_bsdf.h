@@ -220,6 +220,19 @@ RT_DEV float disney_smith_g_ggx(float cos_theta, float alpha) {  // disney.rs:51
 }
 RT_DEV float default_pdf(f3 wo, f3 wi) { return same_hemisphere(wo, wi) ? abs_cos_theta(wi) * kInvPi : 0.0f; }  // bxdf.rs:38-44
 
+// A microfacet lobe evaluates D at the half vector through sin^2 = 1 - cos^2 of wh.z: with alpha ~ 1e-3 the lobe lives where sin^2 ~ alpha^2 = 1e-6, and ONE ulp in the
+// length of wh (2e-7 in cos^2) is a fifth of that - the reference's own value is this ill-conditioned, so parity needs its wh bit for bit: below this alpha the half vector is
+// normalised by the correctly rounded sqrt and quotients instead of v_rsq_f32 (found by scripts/fuzz_shading.py: un-remapped roughness 0.001 put films 3e-3 ... 1.6e-2 from
+// the oracle's; at alpha 0.02 the same ulp is 5e-4 of one sample's D, random in sign). Remapped roughnesses never come near (roughness_to_alpha(0.001) = 0.054).
+#define RT_SHARP_ALPHA 0.02f
+RT_DEV bool sharp_lobe(const Lobe& l) {
+#ifdef RT_STRICT_SHADE
+  return true;
+#else
+  return fminf(l.ax, l.ay) < RT_SHARP_ALPHA;
+#endif
+}
+
 RT_DEV rgb3 lobe_f_inner(const Lobe& l, f3 wo, f3 wi) {
   switch (l.kind) {
     case LB_LAMBERT_R: case LB_LAMBERT_T: return l.r * kInvPi;
@@ -251,7 +264,7 @@ RT_DEV rgb3 lobe_f_inner(const Lobe& l, f3 wo, f3 wi) {
       f3 wh = wi + wo;
       if (cos_theta_o == 0.0f || cos_theta_i == 0.0f) return mkc(0, 0, 0);
       if (wh.x == 0.0f && wh.y == 0.0f && wh.z == 0.0f) return mkc(0, 0, 0);
-      wh = vnormalize(wh);
+      wh = sharp_lobe(l) ? normalize(wh) : vnormalize(wh);
       rgb3 fr = fresnel_eval(l, dot(wi, wh));
       return vdiv(l.r * tr_d(l.ax, l.ay, wh) * lobe_g(l, wo, wi) * fr, 4.0f * cos_theta_i * cos_theta_o);
     }
@@ -308,7 +321,7 @@ RT_DEV float lobe_pdf_inner(const Lobe& l, f3 wo, f3 wi) {
     }
     case LB_MICRO_R: {  // microfacet.rs:86-93
       if (!same_hemisphere(wo, wi)) return 0.0f;
-      f3 wh = vnormalize(wo + wi);
+      f3 wh = sharp_lobe(l) ? normalize(wo + wi) : vnormalize(wo + wi);
       return vdiv(tr_pdf(l.ax, l.ay, wo, wh), 4.0f * dot(wo, wh));
     }
     case LB_MICRO_T: {  // microfacet.rs:210-226
