@@ -1,11 +1,11 @@
 """Randomised FILM parity against the oracle: random scenes over every size class of the trace kernels (a few dozen triangles in LDS, a mid-size tree, a mesh that lives in
 HBM), every material of rc/material/* with constant, image (trilinear and EWA, three wrap modes), checkerboard, uv, fbm, scale and mix textures in its slots, bump maps, mix
 materials, alpha masks, per-vertex normals / uv, analytic quadrics, and light sets drawn from emitting quads (one- and two-sided), emitting spheres and disks, point, distant
-and environment lights (constant or image); random depth, light strategy, pixel filter, lens. One small frame (48 x 36 x 8 spp) per scene: filter weights equal, film inside
+and environment lights (constant or image); random depth, light strategy, pixel filter, lens, crop window / pixel bounds / screen window. One small frame (48 x 36 x 8 spp) per scene: filter weights equal, film inside
 1e-3 (a scene above it is judged again at 64 and at 512 spp: one path that ends a bounce early - the radiance-only reciprocals, DESIGN §2 - or one firefly of a mirror-sharp lobe
 can be 1e-3 of so small a frame, and weighs 1 / spp; one still above it is compared with what the ORACLE's frame does when the camera moves by one ulp: a scene whose own frame moves as
 much is chaotic, not wrong), ray
-counts inside 2e-3. GPU box, repo root:
+counts inside 2e-3; every fourth scene is also rendered as three film shards whose sum has to be the whole frame. GPU box, repo root:
     python scripts/fuzz_shading.py [n_scenes=60] [seed=1]
 The oracle is the checker here, as in tests/."""
 import os
@@ -173,6 +173,13 @@ def make_scene(rng):
     if rng.random() < 0.5:
         s.film.filter_kind = int(rng.integers(0, 4))
         s.film.filter_params = {0: (0.5, 0.5, 0, 0), 1: (1.5, 1.5, 0, 0), 2: (1.5, 1.5, 2.0, 0), 3: (2.0, 2.0, 1 / 3, 1 / 3)}[s.film.filter_kind]
+    if rng.random() < 0.15:     # a crop window (film.rs:48-64) / the integrator's pixel bounds (path.rs:53, renderer.rs:103) / a screen window
+        x0, y0 = float(rng.uniform(0.0, 0.4)), float(rng.uniform(0.0, 0.4))
+        s.film.crop = (x0, x0 + float(rng.uniform(0.3, 0.6)), y0, y0 + float(rng.uniform(0.3, 0.6)))
+    elif rng.random() < 0.1:
+        s.integrator.pixel_bounds = (int(rng.integers(0, 20)), int(rng.integers(24, 48)), int(rng.integers(0, 12)), int(rng.integers(16, 36)))
+    elif rng.random() < 0.1:
+        s.camera.screen_window = (-1.2, 0.9, -0.7, 0.8)
     s.sampler.spp = 8
     s.integrator.max_depth = int(rng.choice([1, 2, 3, 5, 5, 8]))
     s.integrator.light_strategy = str(rng.choice(["spatial", "spatial", "uniform", "power"]))
@@ -216,6 +223,14 @@ def main():
                       "scrubbed": abs(int(sh["paths_scrubbed"]) - int(so["scrubbed"])) > 2}
             for f in ("rays_closest", "rays_shadow", "rays_mis"):
                 checks[f] = abs(int(sh[f]) - int(so[f])) > 2e-3 * int(so[f]) + 16
+            # the frame in film shards (one process per GPU in production: rt_shard's 4-row bands) sums to the whole frame - bit for bit under the box filter, in another
+            # order of the splats under a wider one
+            if k % 4 == 0:
+                d.sampler.spp = 8
+                hs = host.HostScene(d); full = hs.render()[0]; acc = np.zeros_like(full)
+                for r in range(3):
+                    acc += hs.render(rank=r, world_size=3)[0]
+                checks["shards"] = not (np.array_equal(acc, full) if box else np.allclose(acc, full, rtol=2e-5, atol=1e-5))
             bad = sum(int(v) for v in checks.values())
             if bad:
                 kinds = sorted({m.kind for m in d.materials})
