@@ -197,7 +197,8 @@ void rtxh_copper(float eta_rgb[3], float k_rgb[3]);
  * Errors like the reference's (unknown Film / Filter / Sampler / Camera, options inside the world block, ...) and
  * every directive or class this backend does not implement (non-triangle shapes, object instancing, integrators
  * other than "path", spectral parameter types, alpha masks) fail with a message; nothing is skipped silently.
- * n_warnings counts the conditions the reference only logs (missing named texture, unknown material -> matte, ...). */
+ * n_warnings counts the conditions the reference only logs (missing named texture, unknown material -> matte, ...); after a successful load with
+ * n_warnings > 0 rtxh_last_error() holds the text of the first one. */
 typedef struct rtxh_pbrt_result {
   rtxh_scene* scene;            /* owned by the caller: rtxh_scene_free */
   rtxh_render_params params;

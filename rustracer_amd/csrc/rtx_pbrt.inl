@@ -90,7 +90,8 @@ struct PbrtLoader {
   int n_lights = 0, n_spheres = 0; size_t instanced_triangles = 0;
 
   bool fail_(const std::string& m) { if (err.empty()) err = m; return false; }
-  void warn(const std::string&) { warnings += 1; }
+  std::string first_warning;  // what the reference logs and carries on from (warn!): counted; the first one's text is left in rtxh_last_error() after a successful load
+  void warn(const std::string& m) { if (warnings == 0) first_warning = m; warnings += 1; }
 
   // ------------------------------------------------------------------ tokens (rc/pbrt/lexer.rs)
   struct Tok { int kind; std::string s; };  // 0 word / number, 1 quoted string, 2 '[', 3 ']'
@@ -741,6 +742,7 @@ int pbrt_load_text(const std::string& text, const std::string& base_dir, rtxh_pb
   if (!ok) { std::string m = L.err.empty() ? std::string("pbrt: parse error") : "pbrt: " + L.err; return fail(RT_ERR_INVALID, m); }
   out->scene = L.scene; L.scene_handed_over = true; out->max_prims_per_node = L.max_prims; out->n_warnings = L.warnings;
   snprintf(out->film_filename, sizeof out->film_filename, "%s", L.film_filename.c_str());
+  if (L.warnings > 0) g_err = "pbrt warning: " + L.first_warning; else g_err.clear();
   return RT_OK;
 }
 

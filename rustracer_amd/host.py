@@ -476,6 +476,7 @@ class PbrtScene(HostScene):
         self.params = RenderParams.from_buffer_copy(res.params)
         self.max_prims_per_node = res.max_prims_per_node
         self.n_warnings = res.n_warnings
+        self.first_warning = (L.rtxh_last_error() or b"").decode(errors="replace") if res.n_warnings else ""  # (the loader leaves the first warning's text there)
         self.film_filename = res.film_filename.decode(errors='replace')
 
     def _render_params(self, rank=0, world_size=1, flags=0):

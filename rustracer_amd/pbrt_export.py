@@ -137,6 +137,16 @@ class _Writer:
         return name
 
     # ---- lights ---------------------------------------------------------------------------------------------------
+    @staticmethod
+    def quadric_shape(sp) -> str:
+        kind = getattr(sp, "kind", 0)
+        if kind == 0:
+            return f'Shape "sphere" "float radius" [{_n(sp.radius)}] "float zmin" [{_n(sp.z_min)}] "float zmax" [{_n(sp.z_max)}] "float phimax" [{_n(sp.phi_max)}]'
+        if kind == 1:
+            return f'Shape "disk" "float radius" [{_n(sp.radius)}] "float height" [{_n(sp.z_min)}] "float innerradius" [{_n(sp.z_max)}] "float phimax" [{_n(sp.phi_max)}]'
+        # the reference's Cylinder::create reads z_min / z_max / phi_max (cylinder.rs:31-34)
+        return f'Shape "cylinder" "float radius" [{_n(sp.radius)}] "float z_min" [{_n(sp.z_min)}] "float z_max" [{_n(sp.z_max)}] "float phi_max" [{_n(sp.phi_max)}]'
+
     def light(self, l: sd.Light):
         if l.kind == sd.LIGHT_POINT:
             self.out.append(f'LightSource "point" "rgb I" [{_nums(l.rgb)}] "point from" [{_nums(l.vec)}]')
@@ -228,25 +238,27 @@ class _Writer:
             if sp.light >= 0:
                 l = d.lights[sp.light]
                 o.append(f'  AreaLightSource "diffuse" "rgb L" [{_nums(l.rgb)}] "bool twosided" "{"true" if l.two_sided else "false"}"')
-            kind = getattr(sp, "kind", 0)
-            if kind == 0:
-                o.append(f'  Shape "sphere" "float radius" [{_n(sp.radius)}] "float zmin" [{_n(sp.z_min)}] "float zmax" [{_n(sp.z_max)}] "float phimax" [{_n(sp.phi_max)}]')
-            elif kind == 1:
-                o.append(f'  Shape "disk" "float radius" [{_n(sp.radius)}] "float height" [{_n(sp.z_min)}] "float innerradius" [{_n(sp.z_max)}] "float phimax" [{_n(sp.phi_max)}]')
-            else:  # the reference's Cylinder::create reads z_min / z_max / phi_max (cylinder.rs:31-34)
-                o.append(f'  Shape "cylinder" "float radius" [{_n(sp.radius)}] "float z_min" [{_n(sp.z_min)}] "float z_max" [{_n(sp.z_max)}] "float phi_max" [{_n(sp.phi_max)}]')
+            o.append("  " + self.quadric_shape(sp))
             o.append("AttributeEnd")
         # ObjectBegin .. ObjectEnd per object (one Shape per run of triangles that share material and flags: the meshes add_object was given), then
         # one ObjectInstance per placement under its primitive-to-world matrix
         for k, ob in enumerate(getattr(d, "objects", [])):
+            # named materials and textures live in the graphics state, which ObjectEnd / AttributeEnd pop (api.rs:1019-1051): whatever the definition names is made
+            # before it (a material first used inside a definition and again after it came back as "no such named material, using matte": scripts/fuzz_pbrt.py)
+            for mid in sorted({int(x) for x in ob.mat} | {int(q.material) for q in (getattr(ob, "quadrics", None) or [])}):
+                self.material(mid)
+            if getattr(ob, "alpha", None) is not None:
+                for tid in sorted({int(x) for x in np.asarray(ob.alpha).reshape(-1) if x >= 0}):
+                    self.param("alpha", tid, _F)
             o.append(f'ObjectBegin "object{k}"')
             nt = ob.idx.shape[0]
             t0 = 0
             while t0 < nt:
                 t1 = t0
                 emit = getattr(ob, "emit", None)
+                alpha = getattr(ob, "alpha", None)
                 while (t1 + 1 < nt and ob.mat[t1 + 1] == ob.mat[t0] and ob.flags[t1 + 1] == ob.flags[t0] and ob.idx[t1 + 1].min() >= ob.idx[t0:t1 + 1].min()
-                       and (emit is None or emit[t1 + 1] == emit[t0])):
+                       and (emit is None or emit[t1 + 1] == emit[t0]) and (alpha is None or tuple(alpha[t1 + 1]) == tuple(alpha[t0]))):
                     t1 += 1
                 tri = ob.idx[t0:t1 + 1]
                 v0, v1 = int(tri.min()), int(tri.max()) + 1
@@ -265,9 +277,24 @@ class _Writer:
                     shape += f' "float uv" [{_nums(ob.UV[v0:v1])}]'
                 if flags & sd.TRI_HAS_S:
                     shape += f' "vector S" [{_nums(ob.S[v0:v1])}]'
+                if alpha is not None:  # "alpha" / "shadowalpha" of a mesh inside the definition
+                    for pname, tid in zip(("alpha", "shadowalpha"), (int(x) for x in alpha[t0])):
+                        if tid >= 0:
+                            shape += " " + self.param(pname, tid, _F)
                 o.append(shape)
                 o.append("  AttributeEnd")
                 t0 = t1 + 1
+            for sp in (getattr(ob, "quadrics", None) or []):  # the definition's quadrics, each under the CTM it was given inside ObjectBegin .. ObjectEnd
+                o.append("  AttributeBegin")
+                o.append(f'    NamedMaterial "{self.material(sp.material)}"')
+                o.append(f"    ConcatTransform [{_nums(np.asarray(sp.o2w, np.float32).T)}]")
+                if sp.reverse_orientation:
+                    o.append("    ReverseOrientation")
+                if sp.light <= -2:
+                    rgb, two_sided = d.emitters[-2 - int(sp.light)]
+                    o.append(f'    AreaLightSource "diffuse" "rgb L" [{_nums(rgb)}] "bool twosided" "{"true" if two_sided else "false"}"')
+                o.append("    " + self.quadric_shape(sp))
+                o.append("  AttributeEnd")
             o.append("ObjectEnd")
         for i in getattr(d, "instances", []):
             o.append("AttributeBegin")

@@ -135,7 +135,11 @@ def make_scene(rng):
             P, F, N, UV = displaced_sphere(96, 64, c, float(rng.uniform(0.5, 1.0)), 0.25, int(rng.integers(1 << 20)))
             s.add_mesh(P, F, pick(), N=N if rng.random() < 0.6 else None, UV=UV)
     if rng.random() < 0.3:      # a masked card
-        tex = s.checker_tex(1.0, 0.0, 4.0, 4.0, aa="none")
+        if rng.random() < 0.5:
+            tex = s.checker_tex(1.0, 0.0, 4.0, 4.0, aa="none")   # (a float checkerboard: the reference's file format has none, api.rs:1201-1216; its Texture trait has)
+        else:
+            holes = (rng.random((8, 8, 1)) < 0.6).astype(np.float32).repeat(3, axis=2)
+            tex = s.image_tex(s.add_mip(holes, trilinear=True, wrap=int(rng.integers(0, 3))), float(rng.uniform(1.0, 4.0)), float(rng.uniform(1.0, 4.0)))
         c = rng.uniform(-2, 2, 3); c[1] = abs(c[1]) + 0.5
         s.add_mesh(np.float32([c + (-0.8, -0.5, 0), c + (0.8, -0.5, 0), c + (0.8, 0.5, 0.3), c + (-0.8, 0.5, 0.3)]), [[0, 1, 2], [0, 2, 3]], pick(), UV=np.float32(quv), alpha=tex,
                    shadow_alpha=tex if rng.random() < 0.6 else None)
