@@ -5,7 +5,8 @@ and environment lights (constant or image); random depth, light strategy, pixel 
 1e-3 (a scene above it is judged again at 64 and at 512 spp: one path that ends a bounce early - the radiance-only reciprocals, DESIGN §2 - or one firefly of a mirror-sharp lobe
 can be 1e-3 of so small a frame, and weighs 1 / spp; one still above it is compared with what the ORACLE's frame does when the camera moves by one ulp: a scene whose own frame moves as
 much is chaotic, not wrong), ray
-counts inside 2e-3; every fourth scene is also rendered as three film shards whose sum has to be the whole frame. GPU box, repo root:
+counts inside 2e-3; every fourth scene is also rendered as three film shards whose sum has to be the whole frame, and of
+every fourth 20 000 random rays' hit records, occlusion answers and the light-distribution tables are compared bit for bit. GPU box, repo root:
     python scripts/fuzz_shading.py [n_scenes=60] [seed=1]
 The oracle is the checker here, as in tests/."""
 import os
@@ -229,6 +230,35 @@ def main():
                 checks[f] = abs(int(sh[f]) - int(so[f])) > 2e-3 * int(so[f]) + 16
             # the frame in film shards (one process per GPU in production: rt_shard's 4-row bands) sums to the whole frame - bit for bit under the box filter, in another
             # order of the splats under a wider one
+            if k % 4 == 1:   # hit records of random rays (primitive, the bits of t / b0 / b1, visit counts) and occlusion answers; the light-distribution tables bit for bit
+                rays = np.zeros((20000, 8), np.float32)
+                rays[:, :3] = rng.uniform((-4, 0, -4), (4, 8, 4), (20000, 3)); dd_ = rng.normal(size=(20000, 3)); rays[:, 4:7] = dd_ / np.linalg.norm(dd_, axis=1, keepdims=True); rays[:, 3] = np.inf
+                ro = o.trace(rays)
+                for count in (True, False):
+                    rh = h.trace(rays, count=count)
+                    checks[f"hits{int(count)}"] = not (np.array_equal(ro["prim"], rh["prim"]) and all(np.array_equal(ro[f].view(np.uint32), rh[f].view(np.uint32)) for f in (("t",) if d.spheres else ("t", "b0", "b1")))
+                                                       and (not count or (ro["nodes"], ro["tris"]) == (rh["nodes"], rh["tris"])))
+                rays[:, 3] = rng.uniform(0.2, 9.0, 20000).astype(np.float32)
+                ao = o.trace(rays, True)["occluded"]
+                checks["occlusion"] = not (np.array_equal(ao, h.trace(rays, True)["occluded"]) and np.array_equal(ao, h.trace(rays, True, count=False)["occluded"]))
+                if d.integrator.light_strategy == "spatial" and len(d.lights) > 1:
+                    lo, lh = o.light_distrib(max_voxels=400), h.light_distribution()
+                    kk = lo["func"].shape[0]
+                    # Bit for bit where the contribution of a light is arithmetic alone (triangle emitters, point and distant lights, a constant environment); a light that is
+                    # sampled through sin / cos - an emitting sphere or disk (cone / concentric-disk sampling), an image-mapped environment (sin(theta) of its pdf) - carries the last-bit
+                    # difference of the device's sine and cosine against glibc's (rtx_dev_bsdf.h:11-15) into its column: those within 4 ulp
+                    if lo["n_voxels"].tolist() != lh["n_voxels"].tolist():
+                        note += f" [voxels {lo['n_voxels'].tolist()} / {lh['n_voxels'].tolist()}]"; checks["light tables"] = True
+                    else:
+                        trig = np.array([(l.kind == sd.LIGHT_INFINITE and d.mipmaps[l.mip].data.std() > 0) or getattr(l, "sphere", -1) >= 0 for l in d.lights])
+                        fa, fb = lo["func"], lh["func"][:kk]
+                        exact = np.array_equal(fa[:, ~trig].view(np.uint32), fb[:, ~trig].view(np.uint32))
+                        near = np.allclose(fa[:, trig], fb[:, trig], rtol=5e-7, atol=0.0)
+                        cdf_ok = np.array_equal(lo["cdf"].view(np.uint32), lh["cdf"][:kk].view(np.uint32)) if not trig.any() else np.allclose(lo["cdf"], lh["cdf"][:kk], rtol=0.0, atol=5e-7)
+                        checks["light tables"] = not (exact and near and cdf_ok)
+                        if checks["light tables"]:
+                            cols = np.flatnonzero((fa.view(np.uint32) != fb.view(np.uint32)).any(axis=0))
+                            note += f" [light columns that differ {cols.tolist()}: kinds {[d.lights[int(c)].kind for c in cols]}, through sin / cos {trig[cols].tolist()}; exact part {exact}, near part {near}, cdf {cdf_ok}]"
             if k % 4 == 0:
                 d.sampler.spp = 8
                 hs = host.HostScene(d); full = hs.render()[0]; acc = np.zeros_like(full)
