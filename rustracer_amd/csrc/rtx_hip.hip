@@ -1620,6 +1620,8 @@ extern "C" int rt_render(rt_scene* s, const rt_camera* cam, const rt_film_desc* 
       unsigned* const cb = s->counters.as<unsigned>();
       ps.cnt_in = nullptr; ps.cnt_out = cb;  // raygen appends to block 0's `out` queue
       ps.all_in_bounds = all_in_bounds ? 1 : 0;
+      const int fresh_planes = all_in_bounds ? ((s->lambert_only && s->lds_records) ? RT_FRESH_RECORDS_LDS : RT_FRESH_RECORDS) : 0;  // which records k_raygen leaves out (PassState::fresh)
+      ps.fresh = fresh_planes;
       // a frame that counts node visits keeps the reference's closest-hit walk for every MIS ray, unless it is asked to count what a production frame walks
       ps.mis_any = (has_infinite && (!count || (flags & RT_FLAG_COUNT_AS_RENDERED))) ? 1 : 0;
       static const bool reach_off = env_is("RTX_MIS_REACH", '0');  // measurement knob
@@ -1633,6 +1635,7 @@ extern "C" int rt_render(rt_scene* s, const rt_camera* cam, const rt_film_desc* 
         ps.cnt_in = cb + (size_t)bounce * RT_NQ * RT_QSHARDS * RT_CNT_STRIDE; ps.cnt_out = cb + (size_t)(bounce + 1) * RT_NQ * RT_QSHARDS * RT_CNT_STRIDE;
         std::swap(ps.in, ps.out);  // what the previous stage appended is this bounce's input
         if (bounce == 0 && all_in_bounds) ps.cnt_in = nullptr;  // identity: entry i is slot i is path i
+        ps.fresh = bounce == 0 ? fresh_planes : 0;                // ... whose throughput / state records are rebuilt, not read
         io_path.ray_o = ps.in.o; io_path.ray_d = ps.in.d;
         tm.begin(&stats.ms_trace_closest);
         // the rays of the bounce sit at their queue slots: the kernels walk the entries by the shard counts alone (a non-NULL `queue` only says "sharded")

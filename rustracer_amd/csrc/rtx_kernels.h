@@ -114,6 +114,20 @@ struct PassState {
   const unsigned* q_in; unsigned* q_shadow; unsigned* q_mis; unsigned* q_misany;
   const unsigned* cnt_in; unsigned* cnt_out; unsigned shard_cap;
   int all_in_bounds;  // every sample of the pass is traced (no crop by pixel_bounds): bounce 0 needs no queue, path i is entry i
+  // ... and then bounce 0's throughput and state records are known without being stored: beta = (1, 1, 1 | eta_scale 1), st = (pack_state(0, false, 1, 2), path id = slot,
+  // the keyed RNG stream's first state). fresh: bit 0 - k_raygen does not write the throughput record and the launches of bounce 0 do not read it, bit 1 - the same for the
+  // state record (16 + 16 of the 72 bytes a camera sample wrote and of the 80 its first vertex read; round 6, end). During k_raygen it names what the frame leaves out;
+  // in the bounce loop it is zero from bounce 1 on.
+  int fresh;
+#ifndef RT_FRESH_RECORDS
+#define RT_FRESH_RECORDS 3      // which of the two records a frame leaves out (0: the A/B control - every record written and read)
+#endif
+#ifndef RT_FRESH_RECORDS_LDS
+#define RT_FRESH_RECORDS_LDS 2  // ... a frame of k_shade<1, .., LDSREC = 1> (S1): the state record only. One box, interleaved, three rounds (profiles/r06_ab_fresh_records.txt):
+#endif                          // S1 0 / 1 / 2 / 3 = 2003 / 1978 / 2020 / 1977 Msamples/s (a constant throughput costs that kernel 12 ms of shade); the other forms
+                                // 0 / 1 / 2 / 3: S2 1509 / 1533 / 1523 / 1556, S3 1816 / 1825 / 1828 / 1842, S4 447.0 / 445.3 / 448.2 / 446.6
+#define RT_FRESH_BETA(ps) (((ps).fresh & 1) != 0)
+#define RT_FRESH_ST(ps) (((ps).fresh & 2) != 0)
   int mis_any;        // BSDF-sampled MIS rays toward an infinite light go to q_misany (off on frames that count node visits: reference walk)
   // Sphere::pdf_wi answers with the cone's uniform density for ANY direction (sphere.rs:310-334 never tests wi against the cone), so estimate_direct casts the
   // BSDF-sampled ray of every vertex whose picked light is a sphere - 150x the MIS rays of the tessellated S3 - and drops all that do not end on the sphere. A ray
@@ -778,8 +792,8 @@ static __global__ void __launch_bounds__(256) k_raygen(FrameParams fp, PassState
     if (in_bounds) {  // the path's travelling records, at its slot of bounce 0's queue
       ps.out.o[slot] = make_float4(cr.o.x, cr.o.y, cr.o.z, kInf);
       ps.out.d[slot] = make_float4(cr.d.x, cr.d.y, cr.d.z, 0.0f);
-      ps.out.beta[slot] = make_float4(1.0f, 1.0f, 1.0f, 1.0f);
-      ps.out.st[slot] = make_uint4(pack_state(0, false, 1, 2), pid, (unsigned)rng_state, (unsigned)(rng_state >> 32));
+      if (!RT_FRESH_BETA(ps)) ps.out.beta[slot] = make_float4(1.0f, 1.0f, 1.0f, 1.0f);  // (left out: bounce 0 rebuilds the record from the slot, PassState::fresh)
+      if (!RT_FRESH_ST(ps)) ps.out.st[slot] = make_uint4(pack_state(0, false, 1, 2), pid, (unsigned)rng_state, (unsigned)(rng_state >> 32));
     }
   }
   // camera samples actually generated: calls of PathIntegrator::li (samples outside pixel_bounds are skipped, renderer.rs:103)
@@ -2219,11 +2233,14 @@ static __global__ void __launch_bounds__(256) k_shade_miss(DScene sc, PassState 
   const unsigned stride = gridDim.x * blockDim.x;
   for (unsigned i = first + blockIdx.x * blockDim.x + threadIdx.x; i < count; i += stride) {
     const unsigned slot = ps.q_in ? ps.q_in[i] : i;  // (a binned queue: the sorted list of slots, or the moved records themselves)
-    const uint4 s4 = ps.in.st[slot];
+    uint4 s4 = make_uint4(pack_state(0, false, 1, 2), slot, 0u, 0u);  // bounce 0 of a pass whose samples are all traced: PassState::fresh
+    if (!RT_FRESH_ST(ps)) s4 = ps.in.st[slot];
     const unsigned st = s4.x, pid = s4.y;
     const int bounces = (int)(st & 0xffu); const bool specular_bounce = (st >> 8) & 1u;
     if (!(bounces == 0 || specular_bounce) || sc.n_infinite == 0) continue;
-    const float4 d4 = ps.in.d[slot], b4 = ps.in.beta[slot], l4 = ps.lacc[pid];
+    float4 b4 = make_float4(1.0f, 1.0f, 1.0f, 1.0f);
+    if (!RT_FRESH_BETA(ps)) b4 = ps.in.beta[slot];
+    const float4 d4 = ps.in.d[slot], l4 = ps.lacc[pid];
     const f3 ray_d = mk3(d4.x, d4.y, d4.z);
     const rgb3 beta = mkc(b4.x, b4.y, b4.z);
     rgb3 L = mkc(l4.x, l4.y, l4.z);

@@ -367,7 +367,12 @@ __global__ void __launch_bounds__(256, (MODE == 1 || LEAN || BOUNCED) ? ((LEAN |
     f3 nr_o = mk3(0, 0, 0), nr_d = mk3(0, 0, 0); rgb3 beta = mkc(0, 0, 0); float eta_scale = 1.0f; unsigned st_out = 0u, pid = 0u; unsigned long long rng_out = 0ull;
     if (lane_live) {
       // the vertex's records: four 16-byte loads at consecutive slots of consecutive lanes, requested together
-      const float4 d4 = in_d[rslot], h4 = sraw(ps.hit)[rslot], b4 = in_beta[rslot]; const uint4 s4 = in_st[rslot];  // (hit: read twice in a launch - never with the non-temporal hint)
+      const float4 d4 = in_d[rslot], h4 = sraw(ps.hit)[rslot];  // (hit: read twice in a launch - never with the non-temporal hint)
+      float4 b4 = make_float4(1.0f, 1.0f, 1.0f, 1.0f); uint4 s4 = make_uint4(pack_state(0, false, 1, 2), rslot, 0u, 0u);
+      // (fresh: bounce 0 of a pass whose samples are all traced - k_raygen left the record out, PassState::fresh; compiled out of the forms whose frames keep both)
+      constexpr int FRESH = LDSREC == 1 ? RT_FRESH_RECORDS_LDS : RT_FRESH_RECORDS;
+      if (!((FRESH & 1) && RT_FRESH_BETA(ps))) b4 = in_beta[rslot];
+      if (!((FRESH & 2) && RT_FRESH_ST(ps))) s4 = in_st[rslot];
       pid = s4.y;
       unsigned sl, pix; split_path_id(ps, pid, sl, pix); const unsigned s = ps.s0 + sl;
       f3 ray_d = mk3(d4.x, d4.y, d4.z);
@@ -376,8 +381,9 @@ __global__ void __launch_bounds__(256, (MODE == 1 || LEAN || BOUNCED) ? ((LEAN |
       int bounces = (int)(st & 0xffu); bool specular_bounce = (st >> 8) & 1u;
       PathSampler smp; smp.tb = tables_of(ps); smp.pix = pix; smp.s = s; smp.c1 = (int)((st >> 9) & 15u); smp.c2 = (int)((st >> 13) & 15u);
       int x, y; unsigned long long pixel_index; owned_pixel(fp, fp.chunk_first + pix, x, y, pixel_index);
-      smp.rng.state = (unsigned long long)s4.z | ((unsigned long long)s4.w << 32);
       smp.rng.inc = ((pixel_index * (unsigned long long)ps.spp + s + (1ull << 32)) << 1u) | 1ull;
+      smp.rng.state = (unsigned long long)s4.z | ((unsigned long long)s4.w << 32);
+      if ((FRESH & 2) && RT_FRESH_ST(ps)) smp.rng.state = (smp.rng.inc + 0x853c49e6748fea9bULL) * 0x5851f42d4c957f2dULL + smp.rng.inc;  // Pcg32::set_sequence (rng.rs:46-52) of the sample's keyed stream, as k_raygen leaves it
       int prim = __float_as_int(h4.y);
       const bool found = prim >= 0;
       // the frame loop's hit record is (b2, prim, b0, b1): the three barycentrics of the accepted test

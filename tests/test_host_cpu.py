@@ -277,7 +277,7 @@ def test_kernel_register_and_scratch_budgets(host):
     }
     for name, (vg, sc) in budget.items():
         r = res[name]
-        spills_allowed = 32 if name.startswith("rtx::k_shade<0") else (72 if name.startswith("rtx::k_shade<") and name[13] in "356" and name.endswith("false, false, false, false>") else 64 if name.startswith("rtx::k_shade<") and (name.endswith("true, false, false, false>") or name.endswith("false, true, false, false>") or name.endswith("false, false, true>")) else ((8 if name.startswith("rtx::k_trace<") else 2) if name.endswith(", 2>") else (8 if name.startswith("rtx::k_shade<1,") or name.endswith(", 3>") else 0)))  # the generic kernel fills its 256 registers: a few spilled values, never a second wave lost
+        spills_allowed = 32 if name.startswith("rtx::k_shade<0") else (80 if name.startswith("rtx::k_shade<") and name[13] in "356" and name.endswith("false, false, false, false>") else 64 if name.startswith("rtx::k_shade<") and (name.endswith("true, false, false, false>") or name.endswith("false, true, false, false>") or name.endswith("false, false, true>")) else ((8 if name.startswith("rtx::k_trace<") else 2) if name.endswith(", 2>") else (8 if name.startswith("rtx::k_shade<1,") or name.endswith(", 3>") else 0)))  # the generic kernel fills its 256 registers: a few spilled values, never a second wave lost
         assert r["vgpr"] <= vg and r["scratch"] <= sc and r["vgpr_spills"] <= spills_allowed, (name, r)
     # round 5: the forms that keep the scene's small tables in LDS (LDSREC: 1 everything, 2 materials + textures, 3 lights + materials + textures + image headers): the register
     # bounds of the forms they replace, a handful of spilled dwords in the four-wave kernels, and LDS that leaves the waves the bound promises (4 x 33 KB, 3 x 10 KB)
