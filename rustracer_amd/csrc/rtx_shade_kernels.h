@@ -370,7 +370,7 @@ __global__ void __launch_bounds__(256, (MODE == 1 || LEAN || BOUNCED) ? ((LEAN |
       const float4 d4 = in_d[rslot], h4 = sraw(ps.hit)[rslot];  // (hit: read twice in a launch - never with the non-temporal hint)
       float4 b4 = make_float4(1.0f, 1.0f, 1.0f, 1.0f); uint4 s4 = make_uint4(pack_state(0, false, 1, 2), rslot, 0u, 0u);
       // (fresh: bounce 0 of a pass whose samples are all traced - k_raygen left the record out, PassState::fresh; compiled out of the forms whose frames keep both)
-      constexpr int FRESH = LDSREC == 1 ? RT_FRESH_RECORDS_LDS : RT_FRESH_RECORDS;
+      constexpr int FRESH = (MODE == 1 && LDSREC == 1) ? RT_FRESH_RECORDS_LDS : RT_FRESH_RECORDS;  // (rt_render: fresh_planes - the frames of exactly this kernel)
       if (!((FRESH & 1) && RT_FRESH_BETA(ps))) b4 = in_beta[rslot];
       if (!((FRESH & 2) && RT_FRESH_ST(ps))) s4 = in_st[rslot];
       pid = s4.y;
