@@ -37,7 +37,8 @@ def main():
             for x0 in range(0, W, 16):
                 ta, tb = a[y0:y0 + 16, x0:x0 + 16], b[y0:y0 + 16, x0:x0 + 16]
                 inside.append(np.linalg.norm(ta - tb) <= 1e-3 * max(np.linalg.norm(tb), 1e-30))
-        bad_weights += int(not w_ok and all(inside)); tiles_in   # (under a wide filter a tile whose stream went another way has other film positions, so other weights) += sum(inside); tiles_all += len(inside); whole += int(all(inside))
+        # (under a wide filter a tile whose stream went another way has other film positions, so other weights)
+        bad_weights += int(not w_ok and all(inside)); tiles_in += sum(inside); tiles_all += len(inside); whole += int(all(inside))
         print(f"scene {k:3d}: weights {'equal' if w_ok else 'DIFFER'}, {sum(inside)} of {len(inside)} tiles inside 1e-3, film rel-L2 {F.rel_l2(a, b):.1e}, rays {sh['rays_closest']} / {so['rays_closest']}", flush=True)
     print(f"{n} scenes, {refused} with quadrics or masks (not taken by this mode): weights differ in {bad_weights}; {tiles_in} of {tiles_all} tiles inside 1e-3; {whole} scenes with every tile inside")
     return 1 if bad_weights else 0
