@@ -2,7 +2,7 @@
 over call by call - geometry, per-triangle tables, the BVH node for node, camera / film / sampler / integrator parameters, every material and texture a triangle names, the
 light list in order, object definitions and instances (tests/test_pbrt_cpu.py assert_same_scene). The scenes are those of scripts/fuzz_shading.py (rooms over every material,
 texture and light class) and scripts/fuzz_objects.py (two-level scenes whose objects hold quadrics and masked meshes).
-    python scripts/fuzz_pbrt.py [n_scenes=60] [seed=1]
+    python scripts/fuzz_pbrt.py [n_scenes=60] [seed=1]          (FUZZ_DEVICE_INGEST=1 on the GPU box: the loader's device ingest path, meshes over 2000 triangles as PLY)
 Scenes the reference's file format cannot say are counted apart (a float checkerboard: api.rs:1201-1216 has none)."""
 import os
 import sys
@@ -20,6 +20,9 @@ import fuzz_shading  # noqa: E402
 import test_pbrt_cpu as T  # noqa: E402
 
 
+DEVICE_INGEST = bool(os.environ.get("FUZZ_DEVICE_INGEST"))   # (GPU box: PLY / PFM decoding, MIP pyramids and the environment's distribution built on the device)
+
+
 def main():
     n = int(sys.argv[1]) if len(sys.argv) > 1 else 60
     seed = int(sys.argv[2]) if len(sys.argv) > 2 else 1
@@ -33,8 +36,8 @@ def main():
             d.name = f"{name}{k}"
             try:
                 path = os.path.join(tmp, f"{d.name}.pbrt")
-                write_pbrt(d, path)
-                p = host.PbrtScene(path)
+                write_pbrt(d, path, ply_over=2000 if DEVICE_INGEST else 20000)
+                p = host.PbrtScene(path, device_ingest=DEVICE_INGEST)
                 assert p.n_warnings == 0, p.first_warning
                 T.assert_same_scene(p, host.HostScene(d))
                 if d.objects:   # the definitions themselves; the loader numbers an object when it is first instanced, the SceneDesc when it is defined
