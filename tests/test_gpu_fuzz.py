@@ -1,0 +1,18 @@
+"""The randomised checks of scripts/fuzz_*.py on a few scenes each (the seeds the round's full runs used: profiles/r06_fuzz_*.txt), so that they run with the suite:
+hit records, occlusion, light tables and films of random rooms; two-level scenes whose objects hold quadrics and masked meshes; the linear BVH builder; the
+reference-stream mode. Each script exits non-zero on a mismatch and prints the scene."""
+import os
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.mark.parametrize("script,args", [("fuzz_shading.py", ("24", "1")), ("fuzz_objects.py", ("24", "1")), ("fuzz_lds_walks.py", ("24", "21")), ("fuzz_device_bvh.py", ("24", "1")),
+                                         ("fuzz_ref_stream.py", ("24", "1"))])
+def test_random_scenes(gpu_host, script, args):
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "scripts", script), *args], capture_output=True, text=True, timeout=1200, cwd=ROOT)
+    assert r.returncode == 0, (r.stdout[-3000:], r.stderr[-2000:])
