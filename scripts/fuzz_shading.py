@@ -2,7 +2,7 @@
 HBM), every material of rc/material/* with constant, image (trilinear and EWA, three wrap modes), checkerboard, uv, fbm, scale and mix textures in its slots, bump maps, mix
 materials, alpha masks, per-vertex normals / uv, analytic quadrics, and light sets drawn from emitting quads (one- and two-sided), emitting spheres and disks, point, distant
 and environment lights (constant or image); random depth, light strategy, pixel filter, lens, crop window / pixel bounds / screen window. One small frame (48 x 36 x 8 spp) per scene: filter weights equal, film inside
-1e-3 (a scene above it is judged again at 64 and at 512 spp: one path that ends a bounce early - the radiance-only reciprocals, DESIGN §2 - or one firefly of a mirror-sharp lobe
+1e-3 (a scene above it is judged again at 64, 512 and 4096 spp: one path that ends a bounce early - the radiance-only reciprocals, DESIGN §2 - or one firefly of a mirror-sharp lobe
 can be 1e-3 of so small a frame, and weighs 1 / spp; one still above it is compared with what the ORACLE's frame does when the camera moves by one ulp: a scene whose own frame moves as
 much is chaotic, not wrong), ray
 counts inside 2e-3; every fourth scene is also rendered as three film shards whose sum has to be the whole frame, and of
@@ -196,6 +196,7 @@ def main():
     orc.build()
     n_scenes = int(sys.argv[1]) if len(sys.argv) > 1 else 60
     rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 1)
+    rng_rays = np.random.default_rng(10 ** 6 + (int(sys.argv[2]) if len(sys.argv) > 2 else 1))   # (the scenes are a function of the seed alone: `bisect` replays them)
     bad_total, worst, t0 = 0, 0.0, time.time()
     for k in range(n_scenes):
         d, size, closed, n_l = make_scene(rng)
@@ -205,7 +206,7 @@ def main():
             fo, so = o.render(mode=1)
             fh, sh = h.render()
             err = rel_l2(host.film_to_rgb(fh), orc.film_to_rgb(fo))
-            for spp in (64, 512):   # a frame above the gate is judged again with more samples: what one early-ended path or one firefly weighs falls as 1 / spp, what a wrong value weighs does not
+            for spp in (64, 512, 4096):   # a frame above the gate is judged again with more samples: what one early-ended path or one firefly weighs falls as 1 / spp, what a wrong value weighs does not
                 if err > 1e-3:
                     d.sampler.spp = spp
                     fo, so = orc.OracleScene(d).render(mode=1); fh, sh = host.HostScene(d).render()
@@ -232,13 +233,13 @@ def main():
             # order of the splats under a wider one
             if k % 4 == 1:   # hit records of random rays (primitive, the bits of t / b0 / b1, visit counts) and occlusion answers; the light-distribution tables bit for bit
                 rays = np.zeros((20000, 8), np.float32)
-                rays[:, :3] = rng.uniform((-4, 0, -4), (4, 8, 4), (20000, 3)); dd_ = rng.normal(size=(20000, 3)); rays[:, 4:7] = dd_ / np.linalg.norm(dd_, axis=1, keepdims=True); rays[:, 3] = np.inf
+                rays[:, :3] = rng_rays.uniform((-4, 0, -4), (4, 8, 4), (20000, 3)); dd_ = rng_rays.normal(size=(20000, 3)); rays[:, 4:7] = dd_ / np.linalg.norm(dd_, axis=1, keepdims=True); rays[:, 3] = np.inf
                 ro = o.trace(rays)
                 for count in (True, False):
                     rh = h.trace(rays, count=count)
                     checks[f"hits{int(count)}"] = not (np.array_equal(ro["prim"], rh["prim"]) and all(np.array_equal(ro[f].view(np.uint32), rh[f].view(np.uint32)) for f in (("t",) if d.spheres else ("t", "b0", "b1")))
                                                        and (not count or (ro["nodes"], ro["tris"]) == (rh["nodes"], rh["tris"])))
-                rays[:, 3] = rng.uniform(0.2, 9.0, 20000).astype(np.float32)
+                rays[:, 3] = rng_rays.uniform(0.2, 9.0, 20000).astype(np.float32)
                 ao = o.trace(rays, True)["occluded"]
                 checks["occlusion"] = not (np.array_equal(ao, h.trace(rays, True)["occluded"]) and np.array_equal(ao, h.trace(rays, True, count=False)["occluded"]))
                 if d.integrator.light_strategy == "spatial" and len(d.lights) > 1:
