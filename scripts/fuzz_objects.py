@@ -4,7 +4,7 @@ cylinders, disks under transforms of their own; objects of one quadric only), ra
 top-level quadrics and a masked top-level mesh beside them. Closest hit (primitive id and the bits of t, b0, b1; node / primitive visit counts of the counting kernels) and
 occlusion, production and counting kernels; a small frame of every scene (40 x 30 x 4 spp under an emitting quad, half of them inside a constant environment): filter weights
 equal, film inside 1e-3, ray counts inside 2e-3. GPU box, repo root:
-    python scripts/fuzz_objects.py [n_scenes=40] [seed=1]
+    python scripts/fuzz_objects.py [n_scenes=40] [seed=1]          (FUZZ_RICH=1: the objects wear the material zoo of scripts/fuzz_shading.py)
 Prints one line per scene and the number of mismatching values in all (expected: 0). The oracle is the checker here, as in tests/."""
 import os
 import sys
@@ -12,7 +12,7 @@ import time
 
 import numpy as np
 
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__)))); sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 
 from rustracer_amd import host  # noqa: E402
 from rustracer_amd.scene_desc import SceneDesc  # noqa: E402
@@ -85,6 +85,10 @@ def quadric(rng, mats, extent):
 def make_scene(rng):
     s = SceneDesc()
     mats = [s.matte((0.6, 0.5, 0.4)), s.plastic((0.2, 0.3, 0.6), (0.3, 0.3, 0.3), 0.1), s.glass(index=1.5)]
+    if os.environ.get("FUZZ_RICH"):   # the material zoo of scripts/fuzz_shading.py (every material, texture class, bump maps) on the objects' surfaces: three of them beside the matte one
+        import fuzz_shading
+        mips = [s.add_mip(rng.uniform(0.02, 1.0, (16, 16, 3)).astype(np.float32) ** 2, trilinear=bool(rng.random() < 0.5), wrap=int(rng.integers(0, 3)))]
+        mats = [mats[0]] + [fuzz_shading.material(s, rng, mips) for _ in range(2)]
     img = np.zeros((8, 8, 3), np.float32); img[::2, ::2] = 1.0; img[1::2, 1::2] = 1.0
     mask = s.image_tex(s.add_mip(img, trilinear=True), su=float(rng.uniform(1.0, 5.0)), sv=float(rng.uniform(1.0, 5.0)))
     what = []

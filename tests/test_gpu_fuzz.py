@@ -16,3 +16,10 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 def test_random_scenes(gpu_host, script, args):
     r = subprocess.run([sys.executable, os.path.join(ROOT, "scripts", script), *args], capture_output=True, text=True, timeout=1200, cwd=ROOT)
     assert r.returncode == 0, (r.stdout[-3000:], r.stderr[-2000:])
+
+
+def test_random_two_level_scenes_in_the_material_zoo(gpu_host):
+    """scripts/fuzz_objects.py with FUZZ_RICH=1: the instanced objects' triangles and quadrics wear every material / texture class / bump maps of scripts/fuzz_shading.py
+    (the interaction of a hit inside a rotated, scaled, mirrored instance carries dpdu / dpdv / the shading frame through the instance's transform into them)."""
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "scripts", "fuzz_objects.py"), "24", "2"], capture_output=True, text=True, timeout=1200, cwd=ROOT, env=dict(os.environ, FUZZ_RICH="1"))
+    assert r.returncode == 0, (r.stdout[-3000:], r.stderr[-2000:])
