@@ -5,7 +5,7 @@ and environment lights (constant or image); random depth, light strategy, pixel 
 1e-3 (a scene above it is judged again at 64, 512 and 4096 spp: one path that ends a bounce early - the radiance-only reciprocals, DESIGN §2 - or one firefly of a mirror-sharp lobe
 can be 1e-3 of so small a frame, and weighs 1 / spp; one still above it is compared with what the ORACLE's frame does when the camera moves by one ulp: a scene whose own frame moves as
 much is chaotic, not wrong), ray
-counts inside 2e-3; every fourth scene is also rendered as three film shards whose sum has to be the whole frame, and of
+counts inside 2e-3; every fourth scene is also rendered as three film shards whose sum has to be the whole frame (every eighth by two threads of rt_multi_render too), and of
 every fourth 20 000 random rays' hit records, occlusion answers and the light-distribution tables are compared bit for bit. GPU box, repo root:
     python scripts/fuzz_shading.py [n_scenes=60] [seed=1]
 The oracle is the checker here, as in tests/."""
@@ -266,6 +266,9 @@ def main():
                 for r in range(3):
                     acc += hs.render(rank=r, world_size=3)[0]
                 checks["shards"] = not (np.array_equal(acc, full) if box else np.allclose(acc, full, rtol=2e-5, atol=1e-5))
+                if k % 8 == 0:   # ... and by two host threads of this process on chunks of tile rows (rt_multi_render; both on device 0 here)
+                    multi = hs.render_multi([0, 0], chunks_per_device=int(rng_rays.integers(1, 4)))[0]
+                    checks["multi"] = not (np.array_equal(multi, full) if box else np.allclose(multi, full, rtol=2e-5, atol=1e-5))
             bad = sum(int(v) for v in checks.values())
             if bad:
                 kinds = sorted({m.kind for m in d.materials})
