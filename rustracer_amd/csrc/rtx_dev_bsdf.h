@@ -224,7 +224,9 @@ RT_DEV float default_pdf(f3 wo, f3 wi) { return same_hemisphere(wo, wi) ? abs_co
 // length of wh (2e-7 in cos^2) is a fifth of that - the reference's own value is this ill-conditioned, so parity needs its wh bit for bit: below this alpha the half vector is
 // normalised by the correctly rounded sqrt and quotients instead of v_rsq_f32 (found by scripts/fuzz_shading.py: un-remapped roughness 0.001 put films 3e-3 ... 1.6e-2 from
 // the oracle's; at alpha 0.02 the same ulp is 5e-4 of one sample's D, random in sign). Remapped roughnesses never come near (roughness_to_alpha(0.001) = 0.054).
+#ifndef RT_SHARP_ALPHA
 #define RT_SHARP_ALPHA 0.02f
+#endif
 RT_DEV bool sharp_lobe(const Lobe& l) {
 #ifdef RT_STRICT_SHADE
   return true;

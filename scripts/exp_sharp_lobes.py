@@ -56,11 +56,16 @@ def compare(d):
     return float(np.linalg.norm((a - b).ravel()) / np.linalg.norm(b.ravel())), off
 
 
-for mat in ("plastic", "metal", "substrate", "matte"):  # (prints one line per case; depth 5 adds two more walls of the material)
-    for bump in ("none", "fbm", "image_tri", "image_ewa", "checker", "uv"):
-        for rough, remap in ((0.001, False), (0.02, False), (0.1, True)):
-            if mat == "matte" and rough != 0.1:
-                continue
-            for depth in (1, 5):
-                e, off = compare(scene(mat, bump, rough, remap, depth=depth))
-                print(f"{mat:9s} bump {bump:9s} roughness {rough} remap {remap} depth {depth}: rel-L2 {e:.1e}, pixels off {off:.3f}", flush=True)
+def main():
+    for mat in ("plastic", "metal", "substrate", "matte"):  # (prints one line per case; depth 5 adds two more walls of the material)
+        for bump in ("none", "fbm", "image_tri", "image_ewa", "checker", "uv"):
+            for rough, remap in ((0.001, False), (0.02, False), (0.1, True)):
+                if mat == "matte" and rough != 0.1:
+                    continue
+                for depth in (1, 5):
+                    e, off = compare(scene(mat, bump, rough, remap, depth=depth))
+                    print(f"{mat:9s} bump {bump:9s} roughness {rough} remap {remap} depth {depth}: rel-L2 {e:.1e}, pixels off {off:.3f}", flush=True)
+
+
+if __name__ == "__main__":
+    main()

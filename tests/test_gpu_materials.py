@@ -222,3 +222,19 @@ def test_sharded_render_of_a_class_dispatched_scene_sums_to_the_full_frame(gpu_h
             assert np.all(part[~m] == 0)
             acc += part
         assert np.array_equal(bits(acc), bits(full))
+
+
+@pytest.mark.parametrize("material", ["plastic", "metal"])
+def test_a_mirror_sharp_lobe_agrees_at_its_first_vertex(gpu_host, orc, material):
+    """Found by scripts/fuzz_shading.py: roughness 0.001 taken as alpha itself (remaproughness false) is a lobe 1e-3 rad wide whose D reads 1 - cos^2 of the half vector where
+    that is ~1e-6; with the half vector normalised through v_rsq_f32 (one ulp in its length) direct-light frames were 3e-3 ... 1.6e-2 from the oracle's. Below alpha 0.02 the
+    lobe takes the correctly rounded normalisation (rtx_dev_bsdf.h sharp_lobe; checked to fail with -DRT_SHARP_ALPHA=0.0f)."""
+    import os
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "scripts"))
+    import exp_sharp_lobes as E
+    d = E.scene(material, "none", 0.001, False, spp=64, depth=1)
+    fo, _ = orc.OracleScene(d).render(mode=1)
+    fh, _ = gpu_host.HostScene(d).render()
+    assert np.array_equal(fo[..., 3], fh[..., 3]) and rel_l2(gpu_host.film_to_rgb(fh), orc.film_to_rgb(fo)) < 1e-4
+
